@@ -1,0 +1,617 @@
+#!/usr/bin/env python3
+"""
+Golden-vector generator.  RUNS ONLY IN THE BUILD CONTAINER (needs /root/reference, which does not travel).
+
+Imports the reference (cvlab-kaist/3DGAN-Inversion) on CPU -- its pure-PyTorch `_ref` op path -- feeds it
+seeded inputs with injected randomness, records inputs + the REFERENCE's outputs/gradients as small .npz
+fixtures, and asserts that oracle/eg3d_oracle.py reproduces every one of them (the oracle "pin").
+
+    python tests/golden/make_golden.py            # regenerates tests/golden/*.npz + MANIFEST.json
+
+Nothing under tests/ other than this script reads /root/reference.
+"""
+import contextlib
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+torch.Tensor.cuda = lambda self, *a, **k: self      # ray_sampler.py:38 calls .cuda() on an unused tensor
+
+from torch_utils.ops import bias_act as ref_bias_act            # noqa: E402
+from torch_utils.ops import upfirdn2d as ref_upfirdn2d          # noqa: E402
+from torch_utils.ops import conv2d_resample as ref_c2r          # noqa: E402
+from training import networks_stylegan2 as ref_sg2              # noqa: E402
+from training.triplane import TriPlaneGenerator, OSGDecoder     # noqa: E402
+from training.volumetric_rendering.renderer import ImportanceRenderer, sample_from_planes, generate_planes  # noqa: E402
+from training.volumetric_rendering.ray_sampler import RaySampler  # noqa: E402
+from training.volumetric_rendering.ray_marcher import MipRayMarcher2  # noqa: E402
+from training.volumetric_rendering import math_utils as ref_math  # noqa: E402
+
+from oracle import eg3d_oracle as O                              # noqa: E402
+
+torch.manual_seed(0)
+MANIFEST = {}
+
+
+def T(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+def save(name, tol, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **{k: T(v) for k, v in arrays.items()})
+    MANIFEST[name] = dict(tol=tol, keys=sorted(arrays.keys()), bytes=os.path.getsize(path))
+    print(f'  wrote {name}.npz  ({os.path.getsize(path)/1024:.1f} KiB)')
+
+
+def check(a, b, tol, what):
+    a, b = torch.as_tensor(T(a)), torch.as_tensor(T(b))
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    scale = max(1.0, b.abs().max().item()) if b.numel() else 1.0
+    assert err <= tol * scale, f'ORACLE != REFERENCE for {what}: err {err:.3e} (scale {scale:.3e}, tol {tol})'
+    return err
+
+
+@contextlib.contextmanager
+def inject(rand_like=None, rand=None, randn=None):
+    """Replay recorded tensors in place of torch.rand_like / torch.rand / torch.randn inside the reference."""
+    o_rl, o_r, o_rn = torch.rand_like, torch.rand, torch.randn
+    q_rl, q_r, q_rn = list(rand_like or []), list(rand or []), list(randn or [])
+    if rand_like is not None:
+        torch.rand_like = lambda x, **k: q_rl.pop(0).reshape(x.shape)
+    if rand is not None:
+        torch.rand = lambda *s, **k: q_r.pop(0)
+    if randn is not None:
+        torch.randn = lambda *s, **k: q_rn.pop(0)
+    try:
+        yield
+    finally:
+        torch.rand_like, torch.rand, torch.randn = o_rl, o_r, o_rn
+
+
+# ---------------------------------------------------------------------------------------------------
+def gen_bias_act():
+    print('bias_act')
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    case = 0
+    for act in O.ACTIVATIONS:
+        for clamp in (None, 0.7):
+            for shape, dim in (((2, 5, 4, 3), 1), ((3, 6), 1), ((2, 4, 3, 5), 3)):
+                x = (torch.randn(shape, generator=g) * 2).requires_grad_(True)
+                b = torch.randn(shape[dim], generator=g).requires_grad_(True)
+                dy = torch.randn(shape, generator=g)
+                gain = None if case % 3 else 1.3
+                alpha = None if case % 2 else 0.1
+                y = ref_bias_act.bias_act(x, b, dim=dim, act=act, alpha=alpha, gain=gain, clamp=clamp, impl='ref')
+                dx, db = torch.autograd.grad(y, [x, b], dy)
+                yo = O.bias_act(x, b, dim=dim, act=act, alpha=alpha, gain=gain, clamp=clamp)
+                check(yo, y, 1e-6, f'bias_act {act}')
+                k = f'c{case}'
+                out.update({f'{k}_x': x, f'{k}_b': b, f'{k}_dy': dy, f'{k}_y': y, f'{k}_dx': dx, f'{k}_db': db})
+                out[f'{k}_meta'] = np.array([dim, -1 if clamp is None else clamp, -1 if gain is None else gain,
+                                             -1 if alpha is None else alpha], dtype=np.float64)
+                out[f'{k}_act'] = np.array(act)
+                case += 1
+    out['ncases'] = np.array(case)
+    save('bias_act', 1e-6, **out)
+
+
+def gen_upfirdn2d():
+    print('upfirdn2d')
+    g = torch.Generator().manual_seed(12)
+    f44 = ref_upfirdn2d.setup_filter([1, 3, 3, 1])
+    check(O.setup_filter([1, 3, 3, 1]), f44, 1e-7, 'setup_filter')
+    f_sep = ref_upfirdn2d.setup_filter([1, 2, 3, 4, 4, 3, 2, 1])          # separable (>= 8 taps)
+    check(O.setup_filter([1, 2, 3, 4, 4, 3, 2, 1]), f_sep, 1e-7, 'setup_filter sep')
+    f_asym = torch.tensor([[1., 2., 0.5], [0., -1., 3.], [0.25, 1., 1.5], [2., 0.1, -0.3]])   # 4x3 asymmetric
+    f_gain = ref_upfirdn2d.setup_filter([1, 3, 3, 1], gain=4)
+    check(O.setup_filter([1, 3, 3, 1], gain=4), f_gain, 1e-7, 'setup_filter gain')
+    cases = [
+        # (shape, filter, up, down, padding, flip, gain)   -- first three are the on-path configs
+        ((2, 6, 9, 9), f44, 1, 1, [1, 1, 1, 1], False, 4.0),          # FIR after up-2 transposed conv
+        ((2, 6, 8, 8), f44, 2, 1, [2, 1, 2, 1], False, 4.0),          # skip-image upsample2d
+        ((1, 3, 8, 8), f44, 1, 1, [2, 2, 2, 2], True, 4.0),           # backward of the first
+        ((1, 3, 10, 12), f44, 1, 2, [1, 1, 1, 1], False, 1.0),        # downsample
+        ((1, 4, 7, 5), f_sep, 2, 1, [4, 3, 4, 3], False, 4.0),        # separable
+        ((2, 3, 9, 8), f_asym, 1, 1, [1, 1, 2, 1], False, 1.0),       # asymmetric non-flipped
+        ((2, 3, 9, 8), f_asym, 1, 1, [1, 1, 2, 1], True, 1.0),        # asymmetric flipped
+        ((1, 2, 12, 12), f44, 1, 1, [-1, -2, 0, -1], False, 1.0),     # negative padding (crop)
+        ((1, 2, 6, 7), f_asym, (2, 1), (1, 2), [2, 1, 3, 2], False, 2.0),   # anisotropic up/down
+        ((1, 2, 6, 6), None, 1, 1, 0, False, 1.0),                    # identity
+        ((1, 2, 5, 5), f44, 4, 1, [3, 3, 3, 3], False, 16.0),         # up 4
+    ]
+    out = {}
+    for i, (shape, f, up, down, pad, flip, gain) in enumerate(cases):
+        x = torch.randn(shape, generator=g).requires_grad_(True)
+        y = ref_upfirdn2d.upfirdn2d(x, f, up=up, down=down, padding=pad, flip_filter=flip, gain=gain, impl='ref')
+        dy = torch.randn(y.shape, generator=g)
+        dx, = torch.autograd.grad(y, x, dy)
+        check(O.upfirdn2d(x, f, up=up, down=down, padding=pad, flip_filter=flip, gain=gain), y, 1e-6, f'upfirdn2d {i}')
+        k = f'c{i}'
+        upx, upy = O._xy(up)
+        dnx, dny = O._xy(down)
+        out.update({f'{k}_x': x, f'{k}_y': y, f'{k}_dy': dy, f'{k}_dx': dx,
+                    f'{k}_f': (f if f is not None else np.zeros((0,), np.float32)),
+                    f'{k}_meta': np.array([upx, upy, dnx, dny, *O._pad4(pad), int(flip), gain], dtype=np.float64)})
+    # wrappers
+    x = torch.randn(1, 3, 6, 6, generator=g)
+    for nm, fn_r, fn_o in (('upsample2d', ref_upfirdn2d.upsample2d, O.upsample2d),
+                           ('downsample2d', ref_upfirdn2d.downsample2d, O.downsample2d),
+                           ('filter2d', ref_upfirdn2d.filter2d, O.filter2d)):
+        y = fn_r(x, f44, impl='ref')
+        check(fn_o(x, f44), y, 1e-6, nm)
+        out[f'w_{nm}_y'] = y
+    out['w_x'] = x
+    out['f44'] = f44
+    out['ncases'] = np.array(len(cases))
+    save('upfirdn2d', 1e-6, **out)
+
+
+def gen_conv2d_resample():
+    print('conv2d_resample / modulated_conv2d / fc')
+    g = torch.Generator().manual_seed(13)
+    f44 = ref_upfirdn2d.setup_filter([1, 3, 3, 1])
+    out = {}
+    cases = [
+        # (xshape, wshape, up, down, padding, groups, flip_weight)
+        ((2, 4, 8, 8), (6, 4, 3, 3), 1, 1, 1, 1, True),      # plain 3x3          (:134)
+        ((2, 4, 8, 8), (6, 4, 1, 1), 1, 1, 0, 1, True),      # 1x1                (:134)
+        ((2, 4, 8, 8), (6, 4, 3, 3), 2, 1, 1, 1, False),     # up-2 transposed    (:114)
+        ((1, 4, 8, 8), (6, 2, 3, 3), 2, 1, 1, 2, False),     # up-2 grouped
+        ((1, 4, 8, 8), (6, 4, 3, 3), 1, 2, 1, 1, True),      # down-2 strided     (:108)
+        ((1, 4, 8, 8), (6, 4, 1, 1), 1, 2, 0, 1, True),      # 1x1 + down         (:96)
+        ((1, 4, 8, 8), (6, 4, 1, 1), 2, 1, 0, 1, True),      # 1x1 + up           (:102)
+        ((1, 4, 8, 8), (6, 4, 3, 3), 1, 1, [1, 2, 0, 1], 1, True),   # asymmetric pad -> fallback (:139)
+        ((1, 4, 8, 8), (6, 4, 3, 3), 2, 1, 1, 1, True),      # up-2 with flip_weight=True
+    ]
+    for i, (xs, wsh, up, down, pad, groups, flipw) in enumerate(cases):
+        x = torch.randn(xs, generator=g).requires_grad_(True)
+        w = torch.randn(wsh, generator=g).requires_grad_(True)
+        y = ref_c2r.conv2d_resample(x, w, f=f44, up=up, down=down, padding=pad, groups=groups, flip_weight=flipw)
+        dy = torch.randn(y.shape, generator=g)
+        dx, dw = torch.autograd.grad(y, [x, w], dy)
+        check(O.conv2d_resample(x, w, f=f44, up=up, down=down, padding=pad, groups=groups, flip_weight=flipw), y, 1e-5, f'c2r {i}')
+        k = f'c{i}'
+        out.update({f'{k}_x': x, f'{k}_w': w, f'{k}_y': y, f'{k}_dy': dy, f'{k}_dx': dx, f'{k}_dw': dw,
+                    f'{k}_meta': np.array([up, down, *O._pad4(pad), groups, int(flipw)], dtype=np.int64)})
+    out['f44'] = f44
+    out['ncases'] = np.array(len(cases))
+    save('conv2d_resample', 1e-5, **out)
+
+    # modulated_conv2d
+    out = {}
+    i = 0
+    for up in (1, 2):
+        for demod in (True, False):
+            for fused in (True, False):
+                for with_noise in (True, False):
+                    k = 3
+                    x = torch.randn(2, 5, 8, 8, generator=g).requires_grad_(True)
+                    w = torch.randn(7, 5, k, k, generator=g).requires_grad_(True)
+                    s = (torch.randn(2, 5, generator=g) + 1).requires_grad_(True)
+                    res = 8 * up
+                    nz = torch.randn(res, res, generator=g) * 0.3 if with_noise else None
+                    y = ref_sg2.modulated_conv2d(x, w, s, noise=nz, up=up, padding=1, resample_filter=f44, demodulate=demod,
+                                                 flip_weight=(up == 1), fused_modconv=fused)
+                    dy = torch.randn(y.shape, generator=g)
+                    dx, dw, ds = torch.autograd.grad(y, [x, w, s], dy)
+                    yo = O.modulated_conv2d(x, w, s, noise=nz, up=up, padding=1, resample_filter=f44, demodulate=demod,
+                                            flip_weight=(up == 1), fused_modconv=fused)
+                    check(yo, y, 1e-5, f'modconv {i}')
+                    kk = f'c{i}'
+                    out.update({f'{kk}_x': x, f'{kk}_w': w, f'{kk}_s': s, f'{kk}_y': y, f'{kk}_dy': dy, f'{kk}_dx': dx,
+                                f'{kk}_dw': dw, f'{kk}_ds': ds,
+                                f'{kk}_noise': nz if nz is not None else np.zeros((0,), np.float32),
+                                f'{kk}_meta': np.array([up, int(demod), int(fused)], dtype=np.int64)})
+                    i += 1
+    # 1x1 torgb-style
+    x = torch.randn(2, 5, 8, 8, generator=g).requires_grad_(True)
+    w = torch.randn(3, 5, 1, 1, generator=g).requires_grad_(True)
+    s = (torch.randn(2, 5, generator=g) + 1).requires_grad_(True)
+    y = ref_sg2.modulated_conv2d(x, w, s, demodulate=False, fused_modconv=True)
+    dy = torch.randn(y.shape, generator=g)
+    dx, dw, ds = torch.autograd.grad(y, [x, w, s], dy)
+    check(O.modulated_conv2d(x, w, s, demodulate=False), y, 1e-5, 'modconv 1x1')
+    out.update(dict(t_x=x, t_w=w, t_s=s, t_y=y, t_dy=dy, t_dx=dx, t_dw=dw, t_ds=ds))
+    out['f44'] = f44
+    out['ncases'] = np.array(i)
+    save('modulated_conv2d', 1e-5, **out)
+
+    # FullyConnectedLayer
+    out = {}
+    for i, (act, lr, binit) in enumerate((('linear', 1.0, 1.0), ('lrelu', 0.01, 0.0), ('linear', 0.5, 0.3))):
+        fc = ref_sg2.FullyConnectedLayer(12, 9, activation=act, lr_multiplier=lr, bias_init=binit)
+        x = torch.randn(4, 12, generator=g)
+        y = fc(x)
+        check(O.fully_connected(x, fc.weight, fc.bias, lr, act), y, 1e-6, f'fc {i}')
+        out.update({f'c{i}_x': x, f'c{i}_w': fc.weight, f'c{i}_b': fc.bias, f'c{i}_y': y,
+                    f'c{i}_lr': np.array(lr), f'c{i}_act': np.array(act)})
+    out['ncases'] = np.array(3)
+    save('fully_connected', 1e-6, **out)
+
+
+# ---------------------------------------------------------------------------------------------------
+def ref_decoder_from(P, lr_mul=1.0):
+    dec = OSGDecoder(32, {'decoder_lr_mul': lr_mul, 'decoder_output_dim': 32})
+    sd = {k[len('decoder.'):]: v for k, v in P.items() if k.startswith('decoder.')}
+    dec.load_state_dict(sd)
+    return dec
+
+
+def gen_renderer():
+    print('renderer pieces')
+    g = torch.Generator().manual_seed(14)
+    cfg = O.small_config()
+    P = O.synth_params(cfg, seed=5)
+    opts = dict(cfg.rendering)
+    out = {}
+
+    # ray sampler: 3 cameras incl. skew != 0
+    c = O.synth_cameras(3, seed=7)
+    c2w = c[:, :16].reshape(3, 4, 4).clone().requires_grad_(True)
+    K = c[:, 16:].reshape(3, 3, 3).clone()
+    K[1, 0, 1] = 0.05
+    K[2, 0, 0], K[2, 1, 1], K[2, 0, 2], K[2, 1, 2] = 3.1, 3.7, 0.45, 0.52
+    K = K.requires_grad_(True)
+    rs = RaySampler()
+    ro, rd = rs(c2w, K, 8)
+    go, gd = torch.randn(ro.shape, generator=g), torch.randn(rd.shape, generator=g)
+    dc2w, dK = torch.autograd.grad([ro, rd], [c2w, K], [go, gd])
+    oo, od = O.ray_sampler(c2w, K, 8)
+    check(oo, ro, 1e-6, 'ray origins'); check(od, rd, 1e-6, 'ray dirs')
+    out.update(dict(rs_c2w=c2w, rs_K=K, rs_o=ro, rs_d=rd, rs_go=go, rs_gd=gd, rs_dc2w=dc2w, rs_dK=dK))
+    depth = torch.rand(1, 1, 8, 8, generator=g) + 2
+    xyz = rs.calculate_xyz_of_depth(ro[:1], rd[:1], depth[0])
+    check(O.calculate_xyz_of_depth(oo[:1], od[:1], depth[0]), xyz, 1e-6, 'xyz_of_depth')
+    out.update(dict(rs_depth=depth, rs_xyz=xyz))
+
+    # sample_from_planes: in- and out-of-range coords
+    planes = torch.randn(2, 3, 4, 16, 16, generator=g).requires_grad_(True)
+    coords = ((torch.rand(2, 50, 3, generator=g) - 0.5) * 1.3).requires_grad_(True)
+    feats = sample_from_planes(generate_planes(), planes, coords, padding_mode='zeros', box_warp=1.0)
+    gf = torch.randn(feats.shape, generator=g)
+    dpl, dco = torch.autograd.grad(feats, [planes, coords], gf)
+    check(O.sample_from_planes(planes, coords, 1.0), feats, 1e-6, 'sample_from_planes')
+    out.update(dict(sp_planes=planes, sp_coords=coords, sp_feats=feats, sp_gf=gf, sp_dplanes=dpl, sp_dcoords=dco))
+
+    # decoder
+    dec = ref_decoder_from(P)
+    f_in = torch.randn(2, 3, 40, 32, generator=g).requires_grad_(True)
+    o = dec(f_in, None)
+    g_rgb, g_sig = torch.randn(o['rgb'].shape, generator=g), torch.randn(o['sigma'].shape, generator=g)
+    params = list(dec.parameters())
+    grads = torch.autograd.grad([o['rgb'], o['sigma']], [f_in] + params, [g_rgb, g_sig])
+    orgb, osig = O.osg_decoder(P, f_in)
+    check(orgb, o['rgb'], 1e-6, 'decoder rgb'); check(osig, o['sigma'], 1e-6, 'decoder sigma')
+    out.update(dict(dec_in=f_in, dec_rgb=o['rgb'], dec_sigma=o['sigma'], dec_grgb=g_rgb, dec_gsig=g_sig, dec_din=grads[0],
+                    dec_dw0=grads[1], dec_db0=grads[2], dec_dw1=grads[3], dec_db1=grads[4],
+                    dec_w0=P['decoder.net.0.weight'], dec_b0=P['decoder.net.0.bias'],
+                    dec_w1=P['decoder.net.2.weight'], dec_b1=P['decoder.net.2.bias']))
+
+    # ray marcher incl. a zero-density ray (NaN -> inf -> clamp) and white_back
+    rm = MipRayMarcher2()
+    S = 10
+    colors = torch.rand(1, 6, S, 32, generator=g).requires_grad_(True)
+    dens = (torch.randn(1, 6, S, 1, generator=g) * 3).detach()
+    dens[0, 2] = -80.0                                    # zero-density ray
+    dens = dens.requires_grad_(True)
+    depths = torch.sort(torch.rand(1, 6, S, 1, generator=g) * 1.05 + 2.25, dim=2)[0]
+    depths[0, 4, 3] = depths[0, 4, 4]                     # a tie
+    for wb in (False, True):
+        o_ = dict(opts, white_back=wb)
+        rgb, dep, w = rm(colors, dens, depths, o_)
+        orgb, odep, ow = O.ray_march(colors, dens, depths, o_)
+        check(orgb, rgb, 1e-6, 'march rgb'); check(odep, dep, 1e-6, 'march depth'); check(ow, w, 1e-6, 'march w')
+        out.update({f'rm{int(wb)}_rgb': rgb, f'rm{int(wb)}_depth': dep, f'rm{int(wb)}_w': w})
+    g1, g2 = torch.randn(1, 6, 32, generator=g), torch.randn(1, 6, 1, generator=g)
+    g2[0, 2] = 0
+    rgb, dep, w = rm(colors, dens, depths, opts)
+    dcol, dden = torch.autograd.grad([rgb, dep], [colors, dens], [g1, g2])
+    out.update(dict(rm_colors=colors, rm_dens=dens, rm_depths=depths, rm_grgb=g1, rm_gdepth=g2, rm_dcolors=dcol, rm_ddens=dden))
+
+    # stratified sampling: fixed / disparity / per-ray tensor limits
+    R = ImportanceRenderer()
+    ro1 = ro[:2].detach()
+    u1 = torch.rand(2, 64, 12, 1, generator=g)
+    with inject(rand_like=[u1]):
+        d_fix = R.sample_stratified(ro1, 2.25, 3.3, 12, False)
+    check(O.sample_stratified(2, 64, 2.25, 3.3, 12, False, u1), d_fix, 1e-6, 'stratified fixed')
+    with inject(rand_like=[u1]):
+        d_disp = R.sample_stratified(ro1, 2.25, 3.3, 12, True)
+    check(O.sample_stratified(2, 64, 2.25, 3.3, 12, True, u1), d_disp, 1e-6, 'stratified disparity')
+    rs_t = torch.rand(2, 64, 1, generator=g) * 0.2 + 2.2
+    re_t = rs_t + 0.5 + torch.rand(2, 64, 1, generator=g)
+    with inject(rand_like=[u1]):
+        d_ten = R.sample_stratified(ro1, rs_t, re_t, 12, False)
+    check(O.sample_stratified(2, 64, rs_t, re_t, 12, False, u1), d_ten, 1e-6, 'stratified tensor')
+    out.update(dict(ss_u1=u1, ss_fixed=d_fix, ss_disp=d_disp, ss_rs=rs_t, ss_re=re_t, ss_tensor=d_ten))
+    # the full-size 48-sample linspace (kernel must reproduce torch.linspace rounding)
+    u48 = torch.zeros(1, 1, 48, 1)
+    with inject(rand_like=[u48]):
+        out['ss_lin48'] = R.sample_stratified(ro1[:1, :1], 2.25, 3.3, 48, False)
+    check(O.sample_stratified(1, 1, 2.25, 3.3, 48, False, u48), out['ss_lin48'], 0, 'linspace48')
+
+    # importance sampling (+ det), weights with exact zeros and spikes
+    z = d_fix
+    w = torch.rand(2, 64, 11, 1, generator=g) ** 4
+    w[0, :8] = 0.0
+    w[1, 3, 5] = 50.0
+    u2 = torch.rand(128, 12, generator=g)
+    u2[0, 0] = 0.0
+    u2[1, 1] = 0.99999994
+    with inject(rand=[u2]):
+        zi = R.sample_importance(z, w, 12)
+    check(O.sample_importance(z, w, 12, u2), zi, 1e-6, 'sample_importance')
+    out.update(dict(si_z=z, si_w=w, si_u2=u2, si_out=zi))
+    bins = 0.5 * (z.reshape(128, 12)[:, :-1] + z.reshape(128, 12)[:, 1:])
+    wts = w.reshape(128, 11)[:, 1:-1]
+    pdf_det = R.sample_pdf(bins, wts, 12, det=True)
+    check(O.sample_pdf(bins, wts, 12, torch.linspace(0, 1, 12).expand(128, 12)), pdf_det, 1e-6, 'sample_pdf det')
+    out['si_det'] = pdf_det
+
+    # unify_samples (with ties)
+    d1 = d_fix[:1, :4]
+    d2 = zi[:1, :4].clone()
+    d2[0, 0, 0] = d1[0, 0, 3]
+    c1, c2 = torch.rand(1, 4, 12, 32, generator=g), torch.rand(1, 4, 12, 32, generator=g)
+    s1, s2 = torch.randn(1, 4, 12, 1, generator=g), torch.randn(1, 4, 12, 1, generator=g)
+    ud, uc, us = R.unify_samples(d1, c1, s1, d2, c2, s2)
+    od_, oc_, os_ = O.unify_samples(d1, c1, s1, d2, c2, s2)
+    check(od_, ud, 0, 'unify depths')
+    out.update(dict(us_d1=d1, us_d2=d2, us_c1=c1, us_c2=c2, us_s1=s1, us_s2=s2, us_d=ud, us_c=uc, us_s=us))
+
+    # box limits incl. misses
+    ob = torch.tensor([[0., 0., 2.7], [0., 0., 2.7], [2.7, 0., 0.], [0., 3., 0.]])[None]
+    db = torch.nn.functional.normalize(torch.tensor([[0., 0.05, -1.], [0., 0.6, -1.], [-1., 0.1, 0.1], [0.2, -1., 0.1]]), dim=1)[None]
+    t0, t1 = ref_math.get_ray_limits_box(ob, db, box_side_length=1.0)
+    q0, q1 = O.get_ray_limits_box(ob, db, 1.0)
+    check(q0, t0, 1e-6, 'box tmin'); check(q1, t1, 1e-6, 'box tmax')
+    out.update(dict(box_o=ob, box_d=db, box_tmin=t0, box_tmax=t1))
+
+    # full ImportanceRenderer.forward on small planes, with gradients
+    planes = (torch.randn(2, 3, 32, 16, 16, generator=g) * 0.7).requires_grad_(True)
+    cam = O.synth_cameras(2, seed=9)
+    c2w = cam[:, :16].reshape(2, 4, 4).clone().requires_grad_(True)
+    K = cam[:, 16:].reshape(2, 3, 3)
+    ro, rd = rs(c2w, K, 6)
+    u1 = torch.rand(2, 36, 12, 1, generator=g)
+    u2 = torch.rand(72, 12, generator=g)
+    with inject(rand_like=[u1], rand=[u2]):
+        rgb, dep, wsum = R(planes, dec, ro, rd, opts)
+    g_rgb, g_dep = torch.randn(rgb.shape, generator=g), torch.randn(dep.shape, generator=g)
+    grads = torch.autograd.grad([rgb, dep], [planes, c2w] + params, [g_rgb, g_dep])
+    oro, ord_ = O.ray_sampler(c2w, K, 6)
+    orgb, odep, owsum = O.render(P, planes, oro, ord_, opts, u1, u2)
+    e1 = check(orgb, rgb, 2e-6, 'render rgb'); e2 = check(odep, dep, 2e-6, 'render depth'); check(owsum, wsum, 2e-6, 'render wsum')
+    og = torch.autograd.grad([orgb, odep], [planes, c2w], [g_rgb, g_dep])
+    check(og[0], grads[0], 1e-5, 'render dplanes'); check(og[1], grads[1], 1e-5, 'render dc2w')
+    print(f'    render err rgb {e1:.2e} depth {e2:.2e}')
+    out.update(dict(rn_planes=planes, rn_c2w=c2w, rn_K=K, rn_u1=u1, rn_u2=u2, rn_rgb=rgb, rn_depth=dep, rn_wsum=wsum,
+                    rn_grgb=g_rgb, rn_gdepth=g_dep, rn_dplanes=grads[0], rn_dc2w=grads[1], rn_dw0=grads[2], rn_db0=grads[3],
+                    rn_dw1=grads[4], rn_db1=grads[5]))
+    # 'auto' ray limits branch (forward only)
+    o_auto = dict(opts, ray_start='auto', ray_end='auto')
+    with inject(rand_like=[u1], rand=[u2]):
+        rgb_a, dep_a, _ = R(planes, dec, ro, rd, o_auto)
+    orgb_a, odep_a, _ = O.render(P, planes, oro, ord_, o_auto, u1, u2)
+    check(orgb_a, rgb_a, 2e-6, 'render auto rgb'); check(odep_a, dep_a, 2e-6, 'render auto depth')
+    out.update(dict(rn_auto_rgb=rgb_a, rn_auto_depth=dep_a))
+    save('renderer', 2e-6, **out)
+
+
+# ---------------------------------------------------------------------------------------------------
+class RefComposite(torch.nn.Module):
+    """The reference's own classes composed exactly as TriPlaneGenerator does (triplane.py:36-45,53-90), but with
+    free plane / SR sizes (the reference class hard-codes 256 / 512)."""
+
+    def __init__(self, cfg, P):
+        super().__init__()
+        self.cfg = cfg
+        self.backbone = ref_sg2.Generator(cfg.z_dim, cfg.c_dim, cfg.w_dim, img_resolution=cfg.plane_res,
+                                          img_channels=cfg.plane_channels, mapping_kwargs={'num_layers': cfg.mapping_layers},
+                                          channel_base=cfg.channel_base, channel_max=cfg.channel_max,
+                                          fused_modconv_default='inference_only', num_fp16_res=0, conv_clamp=None)
+        c0, c1 = cfg.sr_channels
+        self.block0 = ref_sg2.SynthesisBlock(32, c0, w_dim=cfg.w_dim, resolution=cfg.sr_in_res * 2, img_channels=3, is_last=False,
+                                             use_fp16=True, conv_clamp=256, fused_modconv_default='inference_only')
+        self.block1 = ref_sg2.SynthesisBlock(c0, c1, w_dim=cfg.w_dim, resolution=cfg.sr_in_res * 4, img_channels=3, is_last=True,
+                                             use_fp16=True, conv_clamp=256, fused_modconv_default='inference_only')
+        self.decoder = ref_decoder_from(P)
+        self.renderer = ImportanceRenderer()
+        self.ray_sampler = RaySampler()
+        sd = {}
+        for k, v in P.items():
+            if k.startswith('backbone.'):
+                sd[k] = v
+            elif k.startswith('superresolution.'):
+                sd[k[len('superresolution.'):]] = v
+        missing, unexpected = self.load_state_dict(sd, strict=False)
+        assert not unexpected, unexpected
+        assert all(m.startswith('decoder.') for m in missing), missing
+        self.eval().float()
+
+    def synthesis(self, ws, c, u1, u2, noise_mode='const', randn=None, fused_modconv=None):
+        cfg = self.cfg
+        c2w = c[:, :16].view(-1, 4, 4)
+        K = c[:, 16:25].view(-1, 3, 3)
+        ro, rd = self.ray_sampler(c2w, K, cfg.nrr)
+        with inject(randn=randn):
+            planes = self.backbone.synthesis(ws, noise_mode=noise_mode, force_fp32=True, fused_modconv=fused_modconv)
+        pl = planes.view(len(planes), 3, 32, planes.shape[-2], planes.shape[-1])
+        with inject(rand_like=[u1], rand=[u2]):
+            feat, depth, _ = self.renderer(pl, self.decoder, ro, rd, cfg.rendering)
+        n = ws.shape[0]
+        feat_img = feat.permute(0, 2, 1).reshape(n, 32, cfg.nrr, cfg.nrr).contiguous()
+        depth_img = depth.permute(0, 2, 1).reshape(n, 1, cfg.nrr, cfg.nrr)
+        rgb = feat_img[:, :3]
+        ws3 = ws[:, -1:, :].repeat(1, 3, 1)                                  # superresolution.py:280
+        x, img = self.block0(feat_img, rgb, ws3, noise_mode='none', force_fp32=True, fused_modconv=fused_modconv)
+        x, img = self.block1(x, img, ws3, noise_mode='none', force_fp32=True, fused_modconv=fused_modconv)
+        return {'image': img, 'image_raw': rgb, 'image_depth': depth_img, 'planes': planes}
+
+
+def gen_graph_small():
+    print('small generator graph')
+    cfg = O.small_config()
+    P = O.synth_params(cfg, seed=0)
+    G = RefComposite(cfg, P)
+    n = 2
+    ws = O.synth_ws(cfg, n, seed=1, wplus=True).requires_grad_(True)
+    c = O.synth_cameras(n, seed=2).requires_grad_(True)
+    u1, u2 = O.make_uniforms(cfg, n, seed=4)
+    out = {}
+    # mapping network
+    z = O._randn('z', 3, (n, cfg.z_dim))
+    wmap = G.backbone.mapping(z, c.detach() * 1.0, truncation_psi=0.7, truncation_cutoff=5)
+    check(O.mapping(P, cfg, z, c.detach(), 0.7, 5), wmap, 1e-5, 'mapping')
+    out.update(dict(map_z=z, map_out=wmap))
+
+    for mode in ('const', 'random'):
+        randn = None
+        noises = None
+        if mode == 'random':
+            # one randn per backbone SynthesisLayer, in call order (networks_stylegan2.py:318-319)
+            noises, randn = {}, []
+            for r in cfg.block_resolutions:
+                for conv in (['conv1'] if r == 4 else ['conv0', 'conv1']):
+                    nm = f'backbone.synthesis.b{r}.{conv}'
+                    t = O._randn('noise.' + nm, 6, (n, 1, r, r))
+                    noises[nm] = t
+                    randn.append(t)
+        tr_params = [G.backbone.synthesis.b8.conv0.weight, G.backbone.synthesis.b16.torgb.weight, G.block1.conv1.weight,
+                     G.decoder.net[0].weight, G.backbone.synthesis.b32.conv1.noise_strength, G.backbone.synthesis.b16.conv0.bias,
+                     G.block0.conv0.affine.weight]
+        tr_names = ['backbone.synthesis.b8.conv0.weight', 'backbone.synthesis.b16.torgb.weight',
+                    'superresolution.block1.conv1.weight', 'decoder.net.0.weight',
+                    'backbone.synthesis.b32.conv1.noise_strength', 'backbone.synthesis.b16.conv0.bias',
+                    'superresolution.block0.conv0.affine.weight']
+        o = G.synthesis(ws, c, u1, u2, noise_mode=mode, randn=randn)
+        g_img = O._randn('g_img', 8, o['image'].shape)
+        g_raw = O._randn('g_raw', 8, o['image_raw'].shape)
+        g_dep = O._randn('g_dep', 8, o['image_depth'].shape)
+        grads = torch.autograd.grad([o['image'], o['image_raw'], o['image_depth']], [ws, c] + tr_params, [g_img, g_raw, g_dep])
+        Pg = {k: (v.clone().requires_grad_(True) if k in tr_names else v) for k, v in P.items()}
+        oo = O.synthesis(Pg, cfg, ws, c, u1, u2, noise_mode=mode, noises=noises)
+        for k in ('image', 'image_raw', 'image_depth', 'planes'):
+            e = check(oo[k], o[k], 2e-5, f'graph[{mode}] {k}')
+            print(f'    [{mode}] {k}: max err {e:.2e}')
+        ograds = torch.autograd.grad([oo['image'], oo['image_raw'], oo['image_depth']], [ws, c] + [Pg[k] for k in tr_names],
+                                     [g_img, g_raw, g_dep])
+        for nm, a, b in zip(['ws', 'c'] + tr_names, ograds, grads):
+            e = check(a, b, 2e-4, f'graph[{mode}] grad {nm}')
+        # non-fused formulation is interchangeable
+        onf = O.synthesis(P, cfg, ws, c, u1, u2, noise_mode=mode, noises=noises, fused_modconv=False)
+        check(onf['image'], o['image'], 1e-4, 'non-fused image')
+        m = mode[0]
+        out.update({f'{m}_image': o['image'], f'{m}_raw': o['image_raw'], f'{m}_depth': o['image_depth'],
+                    f'{m}_planes': o['planes'], f'{m}_dws': grads[0], f'{m}_dc': grads[1]})
+        for nm, gval in zip(tr_names, grads[2:]):
+            out[f'{m}_d.{nm}'] = gval
+    out.update(dict(ws=ws, c=c, g_img=g_img, g_raw=g_raw, g_dep=g_dep))
+    # noise_const gradient (Phase A optimises them): w.r.t. one buffer
+    save('graph_small', 2e-5, **out)
+
+
+def gen_graph_full():
+    """Full-size ffhqrebalanced512-128-shaped generator: the reference's own TriPlaneGenerator class.
+    Only probe samples + statistics are stored (weights come from the deterministic generator)."""
+    print('full-size generator (reference TriPlaneGenerator) -- takes a minute')
+    cfg = O.full_config()
+    P = O.synth_params(cfg, seed=0)
+    rk = dict(cfg.rendering, superresolution_module='training.superresolution.SuperresolutionHybrid8XDC')
+    G = TriPlaneGenerator(z_dim=512, c_dim=25, w_dim=512, img_resolution=512, img_channels=3, mapping_kwargs={'num_layers': 2},
+                          rendering_kwargs=rk, channel_base=32768, channel_max=512, fused_modconv_default='inference_only',
+                          num_fp16_res=0, sr_num_fp16_res=4,
+                          sr_kwargs={'channel_base': 32768, 'channel_max': 512, 'fused_modconv_default': 'inference_only'},
+                          conv_clamp=None)
+    G.neural_rendering_resolution = 128
+    missing, unexpected = G.load_state_dict(P, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    G.eval().float()
+    ws = O.synth_ws(cfg, 1, seed=1).requires_grad_(True)
+    c = O.synth_cameras(1, seed=2).requires_grad_(True)
+    u1, u2 = O.make_uniforms(cfg, 1, seed=4)
+    with inject(rand_like=[u1], rand=[u2]):
+        o = G.synthesis(ws, c, noise_mode='const', force_fp32=True)
+    probe = torch.Generator().manual_seed(99)
+    idx_img = torch.randint(0, 3 * 512 * 512, (4096,), generator=probe)
+    idx_raw = torch.randint(0, 3 * 128 * 128, (2048,), generator=probe)
+    idx_dep = torch.randint(0, 128 * 128, (2048,), generator=probe)
+    g_img = O._randn('gf_img', 8, o['image'].shape) / (3 * 512 * 512)
+    g_dep = O._randn('gf_dep', 8, o['image_depth'].shape) / (128 * 128)
+    dws, dc = torch.autograd.grad([o['image'], o['image_depth']], [ws, c], [g_img, g_dep])
+    with torch.no_grad():
+        oo = O.synthesis(P, cfg, ws.detach(), c.detach(), u1, u2, noise_mode='const')
+    for k in ('image', 'image_raw', 'image_depth'):
+        e = check(oo[k], o[k], 1e-4, f'full {k}')
+        mse = torch.mean((oo[k] - o[k]) ** 2).item()
+        print(f'    {k}: max err {e:.2e}, psnr vs ref {(-10*math.log10(max(mse,1e-30)/4.0)):.1f} dB')
+    stats = lambda t: np.array([t.mean().item(), t.abs().mean().item(), t.min().item(), t.max().item()])
+    save('graph_full', 1e-4, ws=ws, c=c, idx_img=idx_img, idx_raw=idx_raw, idx_dep=idx_dep,
+         img_probe=o['image'].flatten()[idx_img], raw_probe=o['image_raw'].flatten()[idx_raw],
+         dep_probe=o['image_depth'].flatten()[idx_dep], img_stats=stats(o['image']), raw_stats=stats(o['image_raw']),
+         dep_stats=stats(o['image_depth']), dws=dws, dc=dc)
+
+
+def gen_loss_glue():
+    print('loss glue')
+    g = torch.Generator().manual_seed(15)
+    out = {}
+    # quaternion -> rotation
+    from utils import camera_utils as ref_cam
+    q = torch.randn(3, 4, generator=g)
+    Rm = ref_cam.compute_rotation_matrix_from_quaternion(q)
+    check(O.quaternion_to_rotmat(q), Rm, 1e-6, 'quat->R')
+    out.update(dict(q=q, R=Rm))
+    # lookat
+    origin = torch.tensor([[0.3, 0.5, 2.6]])
+    fwd = ref_math.normalize_vecs(-origin)
+    m = ref_cam.create_cam2world_matrix(fwd, origin)
+    check(O.lookat_cam2world(origin[0], torch.zeros(3)), m[0], 1e-6, 'lookat')
+    out.update(dict(lookat_origin=origin, lookat=m))
+    # noise regulariser: restated from w_projector.py:221-237 (file not importable: needs wandb/lpips)
+    bufs = [torch.randn(r, r, generator=g) for r in (4, 8, 16, 32)]
+    reg = 0.0
+    for v in bufs:
+        noise = v[None, None]
+        while True:
+            reg = reg + (noise * torch.roll(noise, shifts=1, dims=3)).mean() ** 2
+            reg = reg + (noise * torch.roll(noise, shifts=1, dims=2)).mean() ** 2
+            if noise.shape[2] <= 8:
+                break
+            noise = torch.nn.functional.avg_pool2d(noise, kernel_size=2)
+    check(O.noise_regularizer(bufs), reg, 1e-6, 'noise reg')
+    # tv norm: restated from base_coach.py:294-305 (file not importable)
+    d = torch.rand(1, 16, 16, generator=g)
+    v00, v01, v10 = d[:, :-1, :-1], d[:, :-1, 1:], d[:, 1:, :-1]
+    tv = torch.mean(torch.mean((v00 - v01) ** 2 + (v00 - v10) ** 2))
+    check(O.compute_tv_norm(d), tv, 1e-7, 'tv')
+    out.update(dict(tv_in=d, tv=tv, reg=reg, **{f'reg_buf{i}': b for i, b in enumerate(bufs)}))
+    save('loss_glue', 1e-6, **out)
+
+
+if __name__ == '__main__':
+    only = sys.argv[1:]
+    gens = dict(bias_act=gen_bias_act, upfirdn2d=gen_upfirdn2d, conv=gen_conv2d_resample, renderer=gen_renderer,
+                graph_small=gen_graph_small, graph_full=gen_graph_full, loss=gen_loss_glue)
+    mpath = os.path.join(HERE, 'MANIFEST.json')
+    if only and os.path.exists(mpath):
+        MANIFEST.update(json.load(open(mpath)).get('fixtures', {}))
+    for k, fn in gens.items():
+        if not only or k in only:
+            fn()
+    json.dump(dict(generator='tests/golden/make_golden.py', reference='cvlab-kaist/3DGAN-Inversion @ /root/reference (CPU, *_ref op path)',
+                   torch=torch.__version__, dtype='float32', fixtures=MANIFEST), open(mpath, 'w'), indent=1, sort_keys=True)
+    print('ORACLE PINNED against the reference on all generated cases.')
