@@ -1,0 +1,102 @@
+// Shared helpers for the gfx950 kernels of libeg3d_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <math.h>
+#include "../../include/eg3d_hip.h"
+
+#define EG3D_LAUNCH_CHECK()                          \
+    do {                                             \
+        hipError_t _e = hipGetLastError();           \
+        if (_e != hipSuccess) return (int)_e;        \
+    } while (0)
+
+static inline int eg3d_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- activations (semantics of bias_act: forward, first and second derivative keyed on the output) ----------
+__device__ __forceinline__ float eg3d_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float eg3d_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+#define EG3D_SELU_S 1.0507009873554804934193349852946f
+#define EG3D_SELU_A 1.6732632423543772848170429916717f
+
+__device__ __forceinline__ float m_exp(float x) { return expf(x); }
+__device__ __forceinline__ double m_exp(double x) { return exp(x); }
+__device__ __forceinline__ float m_expm1(float x) { return expm1f(x); }
+__device__ __forceinline__ double m_expm1(double x) { return expm1(x); }
+__device__ __forceinline__ float m_log1p(float x) { return log1pf(x); }
+__device__ __forceinline__ double m_log1p(double x) { return log1p(x); }
+__device__ __forceinline__ float m_tanh(float x) { return tanhf(x); }
+__device__ __forceinline__ double m_tanh(double x) { return tanh(x); }
+
+template <typename F>
+__device__ __forceinline__ F eg3d_act_fwd(F x, int act, F alpha) {
+    switch (act) {
+        default:
+        case EG3D_ACT_LINEAR: return x;
+        case EG3D_ACT_RELU: return x > 0 ? x : (F)0;
+        case EG3D_ACT_LRELU: return x > 0 ? x : x * alpha;
+        case EG3D_ACT_TANH: return m_tanh(x);
+        case EG3D_ACT_SIGMOID: return (F)1 / ((F)1 + m_exp(-x));
+        case EG3D_ACT_ELU: return x >= 0 ? x : m_expm1(x);
+        case EG3D_ACT_SELU: return x >= 0 ? x * (F)EG3D_SELU_S : (F)(EG3D_SELU_S * EG3D_SELU_A) * m_expm1(x);
+        case EG3D_ACT_SOFTPLUS: return x > 20 ? x : m_log1p(m_exp(x));
+        case EG3D_ACT_SWISH: return x / ((F)1 + m_exp(-x));
+    }
+}
+
+// first derivative of act, expressed with the un-gained output yy = y/gain (x only for swish)
+template <typename F>
+__device__ __forceinline__ F eg3d_act_d1(F yy, F x, int act, F alpha) {
+    switch (act) {
+        default:
+        case EG3D_ACT_LINEAR: return (F)1;
+        case EG3D_ACT_RELU: return yy > 0 ? (F)1 : (F)0;
+        case EG3D_ACT_LRELU: return yy > 0 ? (F)1 : alpha;
+        case EG3D_ACT_TANH: return (F)1 - yy * yy;
+        case EG3D_ACT_SIGMOID: return yy * ((F)1 - yy);
+        case EG3D_ACT_ELU: return yy >= 0 ? (F)1 : yy + (F)1;
+        case EG3D_ACT_SELU: return yy >= 0 ? (F)EG3D_SELU_S : yy + (F)(EG3D_SELU_S * EG3D_SELU_A);
+        case EG3D_ACT_SOFTPLUS: return (F)1 - m_exp(-yy);
+        case EG3D_ACT_SWISH: {
+            if (x > 40) return (F)1;
+            if (x < -80) return (F)0;
+            F e = m_exp(x);
+            F d = e + (F)1;
+            return e * (x + d) / (d * d);
+        }
+    }
+}
+
+// second derivative of act
+template <typename F>
+__device__ __forceinline__ F eg3d_act_d2(F yy, F x, int act, F alpha) {
+    switch (act) {
+        default: return (F)0;
+        case EG3D_ACT_TANH: return (F)-2 * yy * ((F)1 - yy * yy);
+        case EG3D_ACT_SIGMOID: return yy * ((F)1 - yy) * ((F)1 - (F)2 * yy);
+        case EG3D_ACT_ELU: return yy >= 0 ? (F)0 : yy + (F)1;
+        case EG3D_ACT_SELU: return yy >= 0 ? (F)0 : yy + (F)(EG3D_SELU_S * EG3D_SELU_A);
+        case EG3D_ACT_SOFTPLUS: {
+            F c = m_exp(-yy);
+            return c * ((F)1 - c);
+        }
+        case EG3D_ACT_SWISH: {
+            if (x > 40 || x < -80) return (F)0;
+            F e = m_exp(x);
+            F d = e + (F)1;
+            return e * ((F)2 * d + x * ((F)1 - e)) / (d * d * d);
+        }
+    }
+}
+
+// XCD-aware block-id remap (bijective for any grid size): hardware places block b on XCD b % 8; give each XCD a
+// contiguous chunk of logical tiles so that tiles sharing operands share an L2.
+__device__ __forceinline__ int eg3d_xcd_remap(int bid, int nblocks) {
+    const int NX = 8;
+    int q = nblocks / NX, r = nblocks % NX;
+    int xcd = bid % NX, idx = bid / NX;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

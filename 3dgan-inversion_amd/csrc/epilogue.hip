@@ -1,0 +1,280 @@
+// Layer epilogues and style/demodulation helpers for gfx950 (NHWC fp32, 16-byte accesses over channels).
+//
+//  * modconv_epilogue_fwd : [4x4 FIR of the up-2 path] * demod + noise + bias -> activation -> gain -> clamp in ONE pass
+//    (the reference runs upfirdn2d, add_, bias_act as three kernels: conv2d_resample.py:129,
+//     networks_stylegan2.py:89-90,327-329).
+//  * modconv_epilogue_bwd : bias_act gradient (output-keyed, bias_act.cu semantics) + every per-layer reduction the
+//    inversion loop needs (bias, demod coefficient, noise_const, noise_strength) in ONE pass over (dout, out).
+//  * weight_sqsum / demod_fwd / demod_bwd : the demodulation coefficient d[n,o] = rsqrt(sum (w*s)^2 + 1e-8)
+//    (networks_stylegan2.py:62-66) factored as sum_k s^2 * (sum_taps w^2), so that the conv can share weights
+//    across the batch (activation-scaled formulation, numerically interchangeable: SURVEY.md section 7).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+__device__ __forceinline__ float act1(float v, int act, float alpha, float gain, float clamp) {
+    v = eg3d_act_fwd<float>(v, act, alpha) * gain;
+    if (clamp >= 0.f) v = fminf(fmaxf(v, -clamp), clamp);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) epilogue_fwd_kernel(const float* __restrict__ z, float* __restrict__ out, int N, int H, int W, int C4,
+                                                           int Hz, int Wz, const float* __restrict__ fir, int fh, int fw, int pad0,
+                                                           float fir_gain, const float* __restrict__ d, const float* __restrict__ noise,
+                                                           int64_t noise_nstride, const float* __restrict__ noise_strength,
+                                                           const float* __restrict__ bias, int act, float alpha, float gain, float clamp) {
+    __shared__ float fs[64];
+    if (fir != nullptr && threadIdx.x < fh * fw) {
+        int ky = threadIdx.x / fw, kx = threadIdx.x % fw;
+        fs[threadIdx.x] = fir[(fh - 1 - ky) * fw + (fw - 1 - kx)] * fir_gain;      // true convolution (flip_filter=False)
+    }
+    __syncthreads();
+    const float strength = noise ? *noise_strength : 0.f;
+    const int C = C4 * 4;
+    const int64_t total = (int64_t)N * H * W * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        int64_t r = i / C4;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const int n = (int)(r / H);
+        float4 v;
+        if (fir != nullptr) {
+            v = make_float4(0, 0, 0, 0);
+            for (int ky = 0; ky < fh; ++ky) {
+                int iy = y + ky - pad0;
+                if ((unsigned)iy >= (unsigned)Hz) continue;
+                for (int kx = 0; kx < fw; ++kx) {
+                    int ix = x + kx - pad0;
+                    if ((unsigned)ix >= (unsigned)Wz) continue;
+                    float wgt = fs[ky * fw + kx];
+                    float4 t = ld4(z + ((int64_t)(n * Hz + iy) * Wz + ix) * C + c);
+                    v.x += wgt * t.x; v.y += wgt * t.y; v.z += wgt * t.z; v.w += wgt * t.w;
+                }
+            }
+        } else {
+            v = ld4(z + i * 4);
+        }
+        if (d != nullptr) {
+            float4 dv = ld4(d + (int64_t)n * C + c);
+            v.x *= dv.x; v.y *= dv.y; v.z *= dv.z; v.w *= dv.w;
+        }
+        if (noise != nullptr) {
+            float nz = noise[(int64_t)n * noise_nstride + (int64_t)y * W + x] * strength;
+            v.x += nz; v.y += nz; v.z += nz; v.w += nz;
+        }
+        if (bias != nullptr) {
+            float4 b = ld4(bias + c);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        v.x = act1(v.x, act, alpha, gain, clamp); v.y = act1(v.y, act, alpha, gain, clamp);
+        v.z = act1(v.z, act, alpha, gain, clamp); v.w = act1(v.w, act, alpha, gain, clamp);
+        st4(out + i * 4, v);
+    }
+}
+
+// derivative factor and recovered pre-activation for one element
+__device__ __forceinline__ void bwd1(float dout, float o, int act, float alpha, float gain, float clamp, float& dy, float& pre) {
+    float yy = o / gain;
+    float g = dout * gain * eg3d_act_d1<float>(yy, 0.f, act, alpha);
+    if (clamp >= 0.f && (o >= clamp || o <= -clamp)) g = 0.f;
+    dy = g;
+    pre = (act == EG3D_ACT_LRELU) ? (yy > 0.f ? yy : yy / alpha) : yy;     // linear / lrelu are invertible
+}
+
+// grid = (blocks_x, N).  Block: 256 threads = PPB pixels x C4 channel-quads.
+__global__ void __launch_bounds__(256) epilogue_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ outv, float* __restrict__ dz,
+                                                           int H, int W, int C4, const float* __restrict__ d, const float* __restrict__ noise,
+                                                           int64_t noise_nstride, const float* __restrict__ noise_strength,
+                                                           const float* __restrict__ bias, int act, float alpha, float gain, float clamp,
+                                                           float* __restrict__ dbias, float* __restrict__ dd, float* __restrict__ dnoise,
+                                                           int64_t dnoise_nstride, float* __restrict__ dstrength) {
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [PPB][C4][8] floats + 1
+    const int n = blockIdx.y;
+    const int C = C4 * 4;
+    const int ppb = 256 / C4 > 0 ? 256 / C4 : 1;
+    const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
+    const bool active = pl < ppb;
+    const int HW = H * W;
+    const float strength = noise ? *noise_strength : 0.f;
+    const int c = c4 * 4;
+    float4 dv = make_float4(1, 1, 1, 1), bv = make_float4(0, 0, 0, 0);
+    if (active && d) dv = ld4(d + (int64_t)n * C + c);
+    if (active && bias) bv = ld4(bias + c);
+    float4 accb = make_float4(0, 0, 0, 0), accd = make_float4(0, 0, 0, 0);
+    float accs = 0.f;
+    // lanes of one pixel are contiguous; groups of min(C4,64) lanes can be shuffle-reduced when C4 is a power of two
+    const bool pow2 = (C4 & (C4 - 1)) == 0;
+    const int grp = C4 < 64 ? C4 : 64;
+    if (active) {
+        for (int pix = blockIdx.x * ppb + pl; pix < HW; pix += gridDim.x * ppb) {
+            const int64_t off = ((int64_t)n * HW + pix) * C + c;
+            float4 g = ld4(dout + off), o = ld4(outv + off);
+            float4 dy, pre;
+            bwd1(g.x, o.x, act, alpha, gain, clamp, dy.x, pre.x); bwd1(g.y, o.y, act, alpha, gain, clamp, dy.y, pre.y);
+            bwd1(g.z, o.z, act, alpha, gain, clamp, dy.z, pre.z); bwd1(g.w, o.w, act, alpha, gain, clamp, dy.w, pre.w);
+            st4(dz + off, make_float4(dy.x * dv.x, dy.y * dv.y, dy.z * dv.z, dy.w * dv.w));
+            accb.x += dy.x; accb.y += dy.y; accb.z += dy.z; accb.w += dy.w;
+            float nz = 0.f, nraw = 0.f;
+            if (noise) { nraw = noise[(int64_t)n * noise_nstride + pix]; nz = nraw * strength; }
+            if (dd) {
+                accd.x += dy.x * (pre.x - bv.x - nz); accd.y += dy.y * (pre.y - bv.y - nz);
+                accd.z += dy.z * (pre.z - bv.z - nz); accd.w += dy.w * (pre.w - bv.w - nz);
+            }
+            if (dnoise || dstrength) {
+                float s = (dy.x + dy.y) + (dy.z + dy.w);
+                if (pow2) {
+                    for (int m = grp >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+                    if ((threadIdx.x & (grp - 1)) == 0) {
+                        if (dnoise) unsafeAtomicAdd(dnoise + (int64_t)n * dnoise_nstride + pix, s * strength);
+                        accs += s * nraw;
+                    }
+                } else {
+                    if (dnoise) unsafeAtomicAdd(dnoise + (int64_t)n * dnoise_nstride + pix, s * strength);
+                    accs += s * nraw;
+                }
+            }
+        }
+    }
+    // block reduction over the PPB pixel lanes
+    float* rb = red;                         // [ppb][C4][4]
+    float* rd = red + ppb * C4 * 4;          // [ppb][C4][4]
+    float* rs = rd + ppb * C4 * 4;           // [1]
+    if (threadIdx.x == 0) rs[0] = 0.f;
+    if (active) { st4(rb + (pl * C4 + c4) * 4, accb); st4(rd + (pl * C4 + c4) * 4, accd); }
+    __syncthreads();
+    if (dstrength && accs != 0.f) atomicAdd(rs, accs);
+    if (threadIdx.x < C4) {
+        float4 sb = make_float4(0, 0, 0, 0), sd = make_float4(0, 0, 0, 0);
+        for (int q = 0; q < ppb; ++q) {
+            float4 t = ld4(rb + (q * C4 + c4) * 4), u = ld4(rd + (q * C4 + c4) * 4);
+            sb.x += t.x; sb.y += t.y; sb.z += t.z; sb.w += t.w;
+            sd.x += u.x; sd.y += u.y; sd.z += u.z; sd.w += u.w;
+        }
+        if (dbias) {
+            unsafeAtomicAdd(dbias + c + 0, sb.x); unsafeAtomicAdd(dbias + c + 1, sb.y);
+            unsafeAtomicAdd(dbias + c + 2, sb.z); unsafeAtomicAdd(dbias + c + 3, sb.w);
+        }
+        if (dd) {     // dL/dd = sum dy * z,  z = (pre - bias - noise) / d
+            float* q = dd + (int64_t)n * C + c;
+            unsafeAtomicAdd(q + 0, sd.x / dv.x); unsafeAtomicAdd(q + 1, sd.y / dv.y);
+            unsafeAtomicAdd(q + 2, sd.z / dv.z); unsafeAtomicAdd(q + 3, sd.w / dv.w);
+        }
+    }
+    __syncthreads();
+    if (dstrength && threadIdx.x == 0 && rs[0] != 0.f) unsafeAtomicAdd(dstrength, rs[0]);
+}
+
+__global__ void weight_sqsum_kernel(const float* __restrict__ w, float* __restrict__ wsq, int Co, int ntaps, int Ck) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Co * Ck) return;
+    int o = i / Ck, k = i - o * Ck;
+    float s = 0.f;
+    for (int t = 0; t < ntaps; ++t) { float v = w[((int64_t)o * ntaps + t) * Ck + k]; s += v * v; }
+    wsq[i] = s;
+}
+
+// one wave per (n,o)
+__global__ void __launch_bounds__(256) demod_fwd_kernel(const float* __restrict__ s, const float* __restrict__ wsq, float* __restrict__ d, int N, int Co, int Ck) {
+    int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wid >= N * Co) return;
+    int n = wid / Co, o = wid - n * Co;
+    float acc = 0.f;
+    for (int k = lane; k < Ck; k += 64) { float sv = s[(int64_t)n * Ck + k]; acc += sv * sv * wsq[(int64_t)o * Ck + k]; }
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+    if (lane == 0) d[wid] = 1.0f / sqrtf(acc + 1e-8f);
+}
+
+// thread per (n,k): ds[n,k] += -s[n,k] * sum_o dd[n,o] d[n,o]^3 wsq[o,k]
+__global__ void __launch_bounds__(256) demod_bwd_kernel(const float* __restrict__ s, const float* __restrict__ wsq, const float* __restrict__ d,
+                                                        const float* __restrict__ dd, float* __restrict__ ds, int N, int Co, int Ck) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * Ck) return;
+    int n = i / Ck, k = i - n * Ck;
+    float acc = 0.f;
+    for (int o = 0; o < Co; ++o) {
+        float dv = d[(int64_t)n * Co + o];
+        acc += dd[(int64_t)n * Co + o] * dv * dv * dv * wsq[(int64_t)o * Ck + k];
+    }
+    ds[i] += -s[i] * acc;
+}
+
+// thread per (o,k): dwsq[o,k] += sum_n dd[n,o] * (-0.5 d^3 s[n,k]^2)
+__global__ void __launch_bounds__(256) demod_bwd_wsq_kernel(const float* __restrict__ s, const float* __restrict__ d, const float* __restrict__ dd,
+                                                            float* __restrict__ dwsq, int N, int Co, int Ck) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Co * Ck) return;
+    int o = i / Ck, k = i - o * Ck;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) {
+        float dv = d[(int64_t)n * Co + o], sv = s[(int64_t)n * Ck + k];
+        acc += dd[(int64_t)n * Co + o] * (-0.5f) * dv * dv * dv * sv * sv;
+    }
+    dwsq[i] += acc;
+}
+
+}  // namespace
+
+extern "C" int eg3d_modconv_epilogue_fwd(const float* z, float* out, int N, int H, int W, int C, int Hz, int Wz, const float* fir, int fh,
+                                         int fw, int pad0, float fir_gain, const float* d, const float* noise, int64_t noise_nstride,
+                                         const float* noise_strength, const float* bias, int act, float alpha, float gain, float clamp,
+                                         void* stream) {
+    if (!z || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0) return EG3D_ERR_INVALID;
+    if (C % 4) return EG3D_ERR_UNSUPPORTED;
+    if (fir && (fh < 1 || fw < 1 || fh * fw > 64)) return EG3D_ERR_UNSUPPORTED;
+    if (fir && (H != Hz + 2 * pad0 - fh + 1 || W != Wz + 2 * pad0 - fw + 1)) return EG3D_ERR_INVALID;
+    if (!fir && (Hz != H || Wz != W)) return EG3D_ERR_INVALID;
+    if (noise && !noise_strength) return EG3D_ERR_INVALID;
+    const int64_t total = (int64_t)N * H * W * (C / 4);
+    int blocks = (int)std::min<int64_t>(eg3d_cdiv(total, 256), 256 * 16);
+    hipLaunchKernelGGL(epilogue_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, out, N, H, W, C / 4, Hz, Wz, fir, fh, fw, pad0,
+                       fir_gain, d, noise, noise_nstride, noise_strength, bias, act, alpha, gain, clamp);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_modconv_epilogue_bwd(const float* dout, const float* out, float* dz, int N, int H, int W, int C, const float* d,
+                                         const float* noise, int64_t noise_nstride, const float* noise_strength, const float* bias, int act,
+                                         float alpha, float gain, float clamp, float* dbias, float* dd, float* dnoise, int64_t dnoise_nstride,
+                                         float* dstrength, void* stream) {
+    if (!dout || !out || !dz || N <= 0 || H <= 0 || W <= 0 || C <= 0) return EG3D_ERR_INVALID;
+    if (C % 4 || C / 4 > 256) return EG3D_ERR_UNSUPPORTED;
+    if (dd && act != EG3D_ACT_LINEAR && act != EG3D_ACT_LRELU) return EG3D_ERR_UNSUPPORTED;   // needs an invertible activation
+    if (dd && !d) return EG3D_ERR_INVALID;
+    if ((noise || dnoise || dstrength) && !noise_strength) return EG3D_ERR_INVALID;
+    if ((dnoise || dstrength) && !noise) return EG3D_ERR_INVALID;
+    const int C4 = C / 4;
+    const int ppb = std::max(256 / C4, 1);
+    int bx = std::min(eg3d_cdiv((int64_t)H * W, ppb), std::max(1, 2048 / N));
+    size_t smem = (size_t)(ppb * C4 * 8 + 4) * sizeof(float);
+    hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(bx, N), dim3(256), smem, (hipStream_t)stream, dout, out, dz, H, W, C4, d, noise, noise_nstride,
+                       noise_strength, bias, act, alpha, gain, clamp, dbias, dd, dnoise, dnoise_nstride, dstrength);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_weight_sqsum(const float* w, float* wsq, int Co, int ntaps, int Ck, void* stream) {
+    if (!w || !wsq || Co <= 0 || ntaps <= 0 || Ck <= 0) return EG3D_ERR_INVALID;
+    hipLaunchKernelGGL(weight_sqsum_kernel, dim3(eg3d_cdiv((int64_t)Co * Ck, 256)), dim3(256), 0, (hipStream_t)stream, w, wsq, Co, ntaps, Ck);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_demod_fwd(const float* s, const float* wsq, float* d, int N, int Co, int Ck, void* stream) {
+    if (!s || !wsq || !d || N <= 0 || Co <= 0 || Ck <= 0) return EG3D_ERR_INVALID;
+    hipLaunchKernelGGL(demod_fwd_kernel, dim3(eg3d_cdiv((int64_t)N * Co * 64, 256)), dim3(256), 0, (hipStream_t)stream, s, wsq, d, N, Co, Ck);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_demod_bwd(const float* s, const float* wsq, const float* d, const float* dd, float* ds, float* dwsq, int N, int Co, int Ck,
+                              void* stream) {
+    if (!s || !wsq || !d || !dd || N <= 0 || Co <= 0 || Ck <= 0) return EG3D_ERR_INVALID;
+    if (ds) hipLaunchKernelGGL(demod_bwd_kernel, dim3(eg3d_cdiv((int64_t)N * Ck, 256)), dim3(256), 0, (hipStream_t)stream, s, wsq, d, dd, ds, N, Co, Ck);
+    if (dwsq) hipLaunchKernelGGL(demod_bwd_wsq_kernel, dim3(eg3d_cdiv((int64_t)Co * Ck, 256)), dim3(256), 0, (hipStream_t)stream, s, d, dd, dwsq, N, Co, Ck);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}

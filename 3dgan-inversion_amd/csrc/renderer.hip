@@ -1,0 +1,707 @@
+// Fused tri-plane volume renderer for gfx950 (forward + backward), one (ray, sample) pair per thread.
+//
+// Replaces, per ray and without materialising anything but the per-ray outputs (the reference writes ~5 GB of
+// intermediates per pass):
+//   RaySampler.forward                       training/volumetric_rendering/ray_sampler.py:24-73
+//   ImportanceRenderer.forward               renderer.py:143-195   (fixed / per-ray limits)
+//     sample_stratified :224-247, sample_from_planes + F.grid_sample(bilinear, zeros, align_corners=False) :39-66,
+//     OSGDecoder.forward triplane.py:124-136, MipRayMarcher2 ray_marcher.py:25-57,
+//     sample_importance/sample_pdf :249-308, unify_samples :212-222
+//
+// Thread mapping: a block holds RPB rays x D threads (D = max(coarse, fine) samples, 48 at the FFHQ config -> 4 rays
+// per 192-thread block).  Thread (r,s) evaluates coarse sample s and fine sample s of ray r: 12 texel gathers of 128 B
+// (planes are NHWC so the 32 features of a texel are one cache line) + the 32->64->33 MLP in registers; decoder weights
+// are wave-uniform and come through the scalar cache as SGPR operands of v_fmac (fp32 VALU rate == fp32 MFMA rate on
+// gfx950, so the MLP stays on the vector pipe).  Everything that couples the samples of a ray (transmittance scan,
+// importance CDF, merge of the sorted coarse list with the unsorted fine list, compositing) goes through a few hundred
+// bytes of LDS per ray.  The composite colour uses  sum_i w_i (c_i + c_{i+1})/2 = sum_j c_j (w_{j-1} + w_j)/2  so the
+// 2 x 32 colours of a thread never leave its registers.
+#include "common.h"
+
+namespace {
+
+constexpr int FC = 32;     // features per plane
+constexpr int HD = 64;     // decoder hidden width
+constexpr int CO = 32;     // decoder colour outputs
+constexpr int MAXT = 192;  // threads per block
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+struct PlaneUV { float u, v; };
+
+__device__ __forceinline__ void plane_uv(int pl, float x, float y, float z, float& u, float& v) {
+    // renderer.py:23-53: plane 0 -> (x,y), plane 1 -> (x,z), plane 2 -> (z,x)
+    if (pl == 0) { u = x; v = y; } else if (pl == 1) { u = x; v = z; } else { u = z; v = x; }
+}
+
+// bilinear gather of the 3 planes at one point, mean over planes.  pn = planes + n*Hp*Wp*ldp.
+__device__ __forceinline__ void gather_feats(const float* __restrict__ pn, int Hp, int Wp, int ldp, float cs, float x, float y, float z,
+                                             float (&f)[FC]) {
+#pragma unroll
+    for (int c = 0; c < FC; ++c) f[c] = 0.f;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        float u, v;
+        plane_uv(pl, x * cs, y * cs, z * cs, u, v);
+        float ix = ((u + 1.f) * Wp - 1.f) * 0.5f, iy = ((v + 1.f) * Hp - 1.f) * 0.5f;
+        float fx0 = floorf(ix), fy0 = floorf(iy);
+        int x0 = (int)fx0, y0 = (int)fy0;
+        float wx1 = ix - fx0, wx0 = (fx0 + 1.f) - ix, wy1 = iy - fy0, wy0 = (fy0 + 1.f) - iy;
+        const float wts[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int xx = x0 + (q & 1), yy = y0 + (q >> 1);
+            if ((unsigned)xx < (unsigned)Wp && (unsigned)yy < (unsigned)Hp) {
+                const float4* t = reinterpret_cast<const float4*>(pn + ((int64_t)yy * Wp + xx) * ldp + pl * FC);
+                float w = wts[q];
+#pragma unroll
+                for (int c4 = 0; c4 < FC / 4; ++c4) {
+                    float4 tv = t[c4];
+                    f[c4 * 4 + 0] = fmaf(w, tv.x, f[c4 * 4 + 0]); f[c4 * 4 + 1] = fmaf(w, tv.y, f[c4 * 4 + 1]);
+                    f[c4 * 4 + 2] = fmaf(w, tv.z, f[c4 * 4 + 2]); f[c4 * 4 + 3] = fmaf(w, tv.w, f[c4 * 4 + 3]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < FC; ++c) f[c] = f[c] / 3.f;
+}
+
+// 32 -> 64 (softplus) -> 33; w1t is [HD][1+CO] (transposed so that a hidden unit's fan-out is contiguous)
+__device__ __forceinline__ void mlp_fwd(const float* __restrict__ w0, const float* __restrict__ b0, const float* __restrict__ w1t,
+                                        const float* __restrict__ b1, const float (&f)[FC], float (&out)[1 + CO]) {
+#pragma unroll
+    for (int k = 0; k < 1 + CO; ++k) out[k] = b1[k];
+#pragma unroll 2
+    for (int j = 0; j < HD; ++j) {
+        const float* wj = w0 + j * FC;
+        float pre = b0[j];
+#pragma unroll
+        for (int c = 0; c < FC; ++c) pre = fmaf(wj[c], f[c], pre);
+        float h = softplusf_(pre);
+        const float* vj = w1t + j * (1 + CO);
+#pragma unroll
+        for (int k = 0; k < 1 + CO; ++k) out[k] = fmaf(vj[k], h, out[k]);
+    }
+}
+
+__device__ __forceinline__ float lin_depth(int i, int D, float start, float end) {
+    // torch.linspace: symmetric evaluation from both ends
+    float step = (end - start) / (float)(D - 1);
+    return i < D / 2 ? start + step * (float)i : end - step * (float)(D - 1 - i);
+}
+
+__device__ __forceinline__ float coarse_depth(const eg3d_render_params& p, int64_t ray, int s, float u) {
+    const int D = p.Dc;
+    if (p.ray_limits != nullptr) {        // per-ray limits: math_utils.linspace (start + i/(D-1) * (end-start))
+        float rs = p.ray_limits[ray * 2], re = p.ray_limits[ray * 2 + 1];
+        float t = rs + ((float)s / (float)(D - 1)) * (re - rs);
+        return t + u * ((re - rs) / (float)(D - 1));
+    }
+    if (p.disparity) {
+        float t = lin_depth(s, D, 0.f, 1.f) + u * (1.f / (float)(D - 1));
+        return 1.f / (1.f / p.ray_start * (1.f - t) + 1.f / p.ray_end * t);
+    }
+    return lin_depth(s, D, p.ray_start, p.ray_end) + u * ((p.ray_end - p.ray_start) / (float)(D - 1));
+}
+
+struct RayLds {          // per-ray LDS scratch (floats), laid out by the kernels below
+    float* dc; float* sc; float* df; float* sf;   // coarse / fine depths and densities          [D] each
+    float* sd; float* ss;                          // merged, depth-sorted depths and densities   [2D]
+    float* w;                                      // interval weights                            [2D]
+    float* q;                                      // 1 - alpha + 1e-10                           [2D]
+    float* t;                                      // scratch                                     [2D]
+    float* misc;                                   // [8]
+};
+constexpr int RAY_LDS_FLOATS(int D) { return 4 * D + 5 * 2 * D + 8; }
+
+__device__ __forceinline__ RayLds ray_lds(float* base, int r, int D) {
+    float* b = base + r * RAY_LDS_FLOATS(D);
+    RayLds L;
+    L.dc = b; L.sc = b + D; L.df = b + 2 * D; L.sf = b + 3 * D;
+    L.sd = b + 4 * D; L.ss = b + 6 * D; L.w = b + 8 * D; L.q = b + 10 * D; L.t = b + 12 * D; L.misc = b + 14 * D;
+    return L;
+}
+
+// weights of nS sorted samples (depths d, densities sg): alpha_i -> q_i -> T_i -> w_i, serial scan by one thread per ray
+__device__ __forceinline__ void march_alpha(const float* d, const float* sg, int i, float& alpha, float& delta, float& dens_mid) {
+    delta = d[i + 1] - d[i];
+    dens_mid = (sg[i] + sg[i + 1]) * 0.5f;
+    float sp = softplusf_(dens_mid - 1.f);
+    alpha = 1.f - expf(-(sp * delta));
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_params bp) {
+    const eg3d_render_params& p = bp.fwd;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int D = p.Dc > p.Df ? p.Dc : p.Df;
+    const int RPB = MAXT / D;                    // rays per block
+    const int nthreads = RPB * D;
+    const int tid = threadIdx.x;
+    const int r = tid / D, s = tid - r * D;
+    const int64_t nrays = (int64_t)p.N * p.R;
+    const int nblocks = (int)((nrays + RPB - 1) / RPB);
+    const int bid = eg3d_xcd_remap(blockIdx.x, nblocks);
+    const int64_t ray = (int64_t)bid * RPB + r;
+    const bool live = tid < nthreads && ray < nrays;
+    const int64_t rr = live ? ray : 0;
+    const int n = (int)(rr / p.R);
+    RayLds L = ray_lds(lds, r < RPB ? r : 0, D);
+    float* red = lds + RPB * RAY_LDS_FLOATS(D);   // [nthreads][33] reduction scratch
+
+    const float ox = p.origins[rr * 3 + 0], oy = p.origins[rr * 3 + 1], oz = p.origins[rr * 3 + 2];
+    const float dx = p.dirs[rr * 3 + 0], dy = p.dirs[rr * 3 + 1], dz = p.dirs[rr * 3 + 2];
+    const float cs = 2.f / p.box_warp;
+    const float* pn = p.planes + (int64_t)n * p.Hp * p.Wp * p.ldp;
+    const int Dc = p.Dc, Df = p.Df;
+    const bool has_c = live && s < Dc, has_f = live && s < Df;
+
+    // ---------------- coarse sample ----------------
+    float depth_c = 0.f, sig_c = 0.f, rgb_c[CO];
+    {
+        float f[FC], out[1 + CO];
+        if (has_c) {
+            depth_c = coarse_depth(p, rr, s, p.u1[rr * Dc + s]);
+            gather_feats(pn, p.Hp, p.Wp, p.ldp, cs, fmaf(depth_c, dx, ox), fmaf(depth_c, dy, oy), fmaf(depth_c, dz, oz), f);
+            mlp_fwd(p.w0, p.b0, p.w1, p.b1, f, out);
+            sig_c = out[0];
+#pragma unroll
+            for (int k = 0; k < CO; ++k) rgb_c[k] = sigmoidf_(out[1 + k]) * 1.002f - 0.001f;
+            L.dc[s] = depth_c; L.sc[s] = sig_c;
+        } else {
+#pragma unroll
+            for (int k = 0; k < CO; ++k) rgb_c[k] = 0.f;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- importance sampling (forward only; backward re-reads the saved fine depths) ----------------
+    float depth_f = 0.f;
+    if (Df > 0) {
+        if (!BWD) {
+            // coarse march -> weights (Dc-1 intervals)
+            if (live && s < Dc - 1) {
+                float a, de, dm;
+                march_alpha(L.dc, L.sc, s, a, de, dm);
+                L.t[s] = a; L.q[s] = 1.f - a + 1e-10f;
+            }
+            __syncthreads();
+            if (live && s == 0) {
+                float T = 1.f;
+                for (int i = 0; i < Dc - 1; ++i) { L.w[i] = L.t[i] * T; T *= L.q[i]; }
+            }
+            __syncthreads();
+            // smoothing: max_pool1d(2,1,pad 1) -> avg_pool1d(2,1) -> + 0.01      (renderer.py:260-262)
+            const int nw = Dc - 1;
+            float sm = 0.f;
+            if (live && s < nw) {
+                float wl = s > 0 ? L.w[s - 1] : -INFINITY, wc = L.w[s], wr = s + 1 < nw ? L.w[s + 1] : -INFINITY;
+                sm = 0.5f * (fmaxf(wl, wc) + fmaxf(wc, wr)) + 0.01f;
+            }
+            __syncthreads();
+            if (live && s < nw) L.t[s] = sm;
+            __syncthreads();
+            if (has_f) {
+                // sample_pdf on bins = mids[0..nw-1], weights = sm[1..nw-2]   (renderer.py:264-266,281-307)
+                const int ns = nw - 2;
+                const float eps = 1e-5f;
+                float tot = 0.f;
+                for (int k = 0; k < ns; ++k) tot += L.t[1 + k] + eps;
+                const float u = p.u2[rr * Df + s];
+                float c = 0.f, c_below = 0.f, c_above = 0.f;
+                int inds = ns + 1;
+                for (int k = 1; k <= ns; ++k) {
+                    float cn = c + (L.t[k] + eps) / tot;
+                    if (cn > u) { inds = k; c_below = c; c_above = cn; c = cn; break; }
+                    c = cn;
+                }
+                int below, above;
+                if (inds > ns) { below = ns; above = ns; c_below = c; c_above = c; }
+                else { below = inds - 1; above = inds; }
+                float bb = 0.5f * (L.dc[below] + L.dc[below + 1]), ba = 0.5f * (L.dc[above] + L.dc[above + 1]);
+                float denom = c_above - c_below;
+                if (denom < eps) denom = 1.f;
+                depth_f = bb + (u - c_below) / denom * (ba - bb);
+                if (p.fine_depths) p.fine_depths[rr * Df + s] = depth_f;
+            }
+        } else {
+            if (has_f) depth_f = p.fine_depths[rr * Df + s];
+        }
+    }
+
+    // ---------------- fine sample ----------------
+    float sig_f = 0.f, rgb_f[CO];
+    {
+        float f[FC], out[1 + CO];
+        if (has_f) {
+            gather_feats(pn, p.Hp, p.Wp, p.ldp, cs, fmaf(depth_f, dx, ox), fmaf(depth_f, dy, oy), fmaf(depth_f, dz, oz), f);
+            mlp_fwd(p.w0, p.b0, p.w1, p.b1, f, out);
+            sig_f = out[0];
+#pragma unroll
+            for (int k = 0; k < CO; ++k) rgb_f[k] = sigmoidf_(out[1 + k]) * 1.002f - 0.001f;
+            L.df[s] = depth_f; L.sf[s] = sig_f;
+        } else {
+#pragma unroll
+            for (int k = 0; k < CO; ++k) rgb_f[k] = 0.f;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- merge (stable: coarse precedes fine at ties) ----------------
+    const int nS = Dc + Df;
+    int rank_c = s, rank_f = 0;
+    if (has_c) {
+        int cnt = 0;
+        for (int j = 0; j < Df; ++j) cnt += L.df[j] < depth_c ? 1 : 0;
+        rank_c = s + cnt;
+        L.sd[rank_c] = depth_c; L.ss[rank_c] = sig_c;
+    }
+    if (has_f) {
+        int cnt = 0;
+        for (int i = 0; i < Dc; ++i) cnt += L.dc[i] <= depth_f ? 1 : 0;
+        for (int j = 0; j < Df; ++j) { float o = L.df[j]; cnt += (o < depth_f || (o == depth_f && j < s)) ? 1 : 0; }
+        rank_f = cnt;
+        L.sd[rank_f] = depth_f; L.ss[rank_f] = sig_f;
+    }
+    __syncthreads();
+
+    // ---------------- final march over nS-1 intervals ----------------
+    const int nI = nS - 1;
+    if (live) {
+        for (int i = s; i < nI; i += D) {
+            float a, de, dm;
+            march_alpha(L.sd, L.ss, i, a, de, dm);
+            L.t[i] = a; L.q[i] = 1.f - a + 1e-10f;
+        }
+    }
+    __syncthreads();
+    if (live && s == 0) {
+        float T = 1.f, wsum = 0.f, dnum = 0.f;
+        for (int i = 0; i < nI; ++i) {
+            float w = L.t[i] * T;
+            L.w[i] = w;
+            if (BWD) L.t[i] = T;                     // keep T_i for the gradient
+            T *= L.q[i];
+            wsum += w;
+            dnum += w * (0.5f * (L.sd[i] + L.sd[i + 1]));
+        }
+        L.misc[0] = wsum; L.misc[1] = dnum; L.misc[2] = L.sd[0]; L.misc[3] = L.sd[nS - 1];
+    }
+    __syncthreads();
+
+    if (!BWD) {
+        // composite colour: each thread contributes a_c * rgb_c + a_f * rgb_f, reduced over the ray's D threads via LDS
+        float a_c = 0.f, a_f = 0.f;
+        if (has_c) a_c = 0.5f * ((rank_c > 0 ? L.w[rank_c - 1] : 0.f) + (rank_c < nI ? L.w[rank_c] : 0.f));
+        if (has_f) a_f = 0.5f * ((rank_f > 0 ? L.w[rank_f - 1] : 0.f) + (rank_f < nI ? L.w[rank_f] : 0.f));
+        if (tid < nthreads) {
+            float* my = red + tid * (CO + 1);
+#pragma unroll
+            for (int k = 0; k < CO; ++k) my[k] = a_c * rgb_c[k] + a_f * rgb_f[k];
+        }
+        __syncthreads();
+        if (live) {
+            for (int k = s; k < CO; k += D) {
+                float acc = 0.f;
+                const float* col = red + (r * D) * (CO + 1) + k;
+                for (int j = 0; j < D; ++j) acc += col[j * (CO + 1)];
+                float wsum = L.misc[0];
+                if (p.white_back) acc = acc + 1.f - wsum;
+                p.rgb[rr * CO + k] = acc * 2.f - 1.f;
+            }
+        }
+        if (live && s == 0) {
+            float wsum = L.misc[0];
+            p.depth[rr] = L.misc[1] / wsum;          // NaN when wsum == 0; finalize handles it
+            p.wsum[rr] = wsum;
+        }
+        // global depth range (ray_marcher.py:50 clamps to min/max over ALL samples of ALL rays)
+        __syncthreads();
+        if (tid == 0) {
+            float mn = INFINITY, mx = -INFINITY;
+            for (int q = 0; q < RPB; ++q) {
+                if ((int64_t)bid * RPB + q < nrays) {
+                    RayLds Lq = ray_lds(lds, q, D);
+                    mn = fminf(mn, Lq.misc[2]); mx = fmaxf(mx, Lq.misc[3]);
+                }
+            }
+            atomicMin(p.depth_minmax, mn);
+            atomicMax(p.depth_minmax + 1, mx);
+        }
+        return;
+    }
+
+    // =====================================================================================================
+    // backward
+    // =====================================================================================================
+    // per-ray incoming gradients
+    float g_rgb[CO];
+    {
+#pragma unroll
+        for (int k = 0; k < CO; ++k) g_rgb[k] = live ? bp.d_rgb[rr * CO + k] : 0.f;
+    }
+    // e_j = <g_rgb, c_j> at the sorted position of each sample
+    if (has_c) { float e = 0.f;
+#pragma unroll
+        for (int k = 0; k < CO; ++k) e = fmaf(g_rgb[k], rgb_c[k], e);
+        red[(r * 2 * D) + rank_c] = e; }
+    if (has_f) { float e = 0.f;
+#pragma unroll
+        for (int k = 0; k < CO; ++k) e = fmaf(g_rgb[k], rgb_f[k], e);
+        red[(r * 2 * D) + rank_f] = e; }
+    __syncthreads();
+    float* E = red + r * 2 * D;                  // [nS]
+    float* GA = red + RPB * 2 * D + r * 2 * D;   // dL/dm_i per interval [nI]
+    if (live && s == 0) {
+        const float wsum = L.misc[0], dnum = L.misc[1];
+        const float depth_raw = dnum / wsum;
+        const float dmin = p.depth_minmax[0], dmax = p.depth_minmax[1];
+        float gd = bp.d_depth ? bp.d_depth[rr] : 0.f;
+        if (!(depth_raw >= dmin && depth_raw <= dmax)) gd = 0.f;        // NaN / clamped: no gradient
+        const float gws = bp.d_wsum ? bp.d_wsum[rr] : 0.f;
+        float grgb_sum = 0.f;
+        if (p.white_back) {
+#pragma unroll
+            for (int k = 0; k < CO; ++k) grgb_sum += g_rgb[k];
+        }
+        // dL/dw_i, then dL/dalpha_i with a reverse suffix scan
+        float S = 0.f;
+        for (int i = nI - 1; i >= 0; --i) {
+            float dmid = 0.5f * (L.sd[i] + L.sd[i + 1]);
+            float gw = (E[i] + E[i + 1]) + gd * (dmid - depth_raw) / wsum + gws - 2.f * grgb_sum;
+            float T = L.t[i], q = L.q[i], w = L.w[i];
+            float galpha = gw * T - S / q;
+            S += gw * w;
+            // alpha = 1 - exp(-sp*delta);  sp = softplus(m - 1)
+            float delta = L.sd[i + 1] - L.sd[i];
+            float m = 0.5f * (L.ss[i] + L.ss[i + 1]) - 1.f;
+            float one_minus_alpha = q - 1e-10f;
+            float gsp = galpha * delta * one_minus_alpha;
+            float gm = gsp * (m > 20.f ? 1.f : sigmoidf_(m));
+            GA[i] = gm;
+        }
+    }
+    __syncthreads();
+
+    // ---- per-sample backward: colours/density -> MLP -> features -> planes / coordinates -----------------------
+    float gcoord[3] = {0.f, 0.f, 0.f};       // dL/d(o + t*dir) summed over this thread's samples
+    float gdir[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool has = pass == 0 ? has_c : has_f;
+        if (!has) continue;
+        const int rank = pass == 0 ? rank_c : rank_f;
+        const float depth = pass == 0 ? depth_c : depth_f;
+        const float a = 0.5f * ((rank > 0 ? L.w[rank - 1] : 0.f) + (rank < nI ? L.w[rank] : 0.f));
+        const float gsig = 0.5f * ((rank > 0 ? GA[rank - 1] : 0.f) + (rank < nI ? GA[rank] : 0.f));
+        const float px = fmaf(depth, dx, ox), py = fmaf(depth, dy, oy), pz = fmaf(depth, dz, oz);
+        float f[FC], out[1 + CO];
+        gather_feats(pn, p.Hp, p.Wp, p.ldp, cs, px, py, pz, f);
+        mlp_fwd(p.w0, p.b0, p.w1, p.b1, f, out);
+        // d_out
+        float dout[1 + CO];
+        dout[0] = gsig;
+#pragma unroll
+        for (int k = 0; k < CO; ++k) {
+            float sg = sigmoidf_(out[1 + k]);
+            dout[1 + k] = (2.f * a * g_rgb[k]) * 1.002f * sg * (1.f - sg);
+        }
+        const int64_t sample_id = (rr * 2 + pass) * D + s;       // row in the optional decoder-gradient dumps
+        if (bp.dump_dout) {
+            float* o = bp.dump_dout + sample_id * (1 + CO);      // [S, 33]
+#pragma unroll
+            for (int k = 0; k < 1 + CO; ++k) o[k] = dout[k];
+        }
+        if (bp.dump_feat) {
+            float* o = bp.dump_feat + sample_id * FC;            // [S, 32]
+#pragma unroll
+            for (int c = 0; c < FC; ++c) o[c] = f[c];
+        }
+        float df[FC];
+#pragma unroll
+        for (int c = 0; c < FC; ++c) df[c] = 0.f;
+#pragma unroll 2
+        for (int j = 0; j < HD; ++j) {
+            const float* wj = p.w0 + j * FC;
+            float pre = p.b0[j];
+#pragma unroll
+            for (int c = 0; c < FC; ++c) pre = fmaf(wj[c], f[c], pre);
+            const float* vj = p.w1 + j * (1 + CO);
+            float dh = 0.f;
+#pragma unroll
+            for (int k = 0; k < 1 + CO; ++k) dh = fmaf(vj[k], dout[k], dh);
+            float dpre = dh * (pre > 20.f ? 1.f : sigmoidf_(pre));
+            if (bp.dump_dpre) bp.dump_dpre[sample_id * HD + j] = dpre;          // [S, 64]
+            if (bp.dump_h) bp.dump_h[sample_id * HD + j] = softplusf_(pre);     // [S, 64]
+#pragma unroll
+            for (int c = 0; c < FC; ++c) df[c] = fmaf(wj[c], dpre, df[c]);
+        }
+        // features -> planes (scatter) and -> coordinates
+#pragma unroll
+        for (int c = 0; c < FC; ++c) df[c] = df[c] / 3.f;
+        float* gpn = bp.d_planes ? bp.d_planes + (int64_t)n * p.Hp * p.Wp * p.ldp : nullptr;
+        const bool want_coord = bp.d_origins != nullptr || bp.d_dirs != nullptr;
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            float u, v;
+            plane_uv(pl, px * cs, py * cs, pz * cs, u, v);
+            float ix = ((u + 1.f) * p.Wp - 1.f) * 0.5f, iy = ((v + 1.f) * p.Hp - 1.f) * 0.5f;
+            float fx0 = floorf(ix), fy0 = floorf(iy);
+            int x0 = (int)fx0, y0 = (int)fy0;
+            float wx1 = ix - fx0, wx0 = (fx0 + 1.f) - ix, wy1 = iy - fy0, wy0 = (fy0 + 1.f) - iy;
+            const float wts[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+            float gix = 0.f, giy = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int xx = x0 + (q & 1), yy = y0 + (q >> 1);
+                if ((unsigned)xx < (unsigned)p.Wp && (unsigned)yy < (unsigned)p.Hp) {
+                    const int64_t toff = ((int64_t)yy * p.Wp + xx) * p.ldp + pl * FC;
+                    if (gpn) {
+                        float w = wts[q];
+#pragma unroll
+                        for (int c = 0; c < FC; ++c) unsafeAtomicAdd(gpn + toff + c, w * df[c]);
+                    }
+                    if (want_coord) {
+                        const float4* t = reinterpret_cast<const float4*>(pn + toff);
+                        float dot = 0.f;
+#pragma unroll
+                        for (int c4 = 0; c4 < FC / 4; ++c4) {
+                            float4 tv = t[c4];
+                            dot = fmaf(tv.x, df[c4 * 4 + 0], dot); dot = fmaf(tv.y, df[c4 * 4 + 1], dot);
+                            dot = fmaf(tv.z, df[c4 * 4 + 2], dot); dot = fmaf(tv.w, df[c4 * 4 + 3], dot);
+                        }
+                        // d(weight)/d(ix), d(weight)/d(iy) of corner q
+                        float sx = (q & 1) ? 1.f : -1.f, sy = (q >> 1) ? 1.f : -1.f;
+                        gix += dot * sx * ((q >> 1) ? wy1 : wy0);
+                        giy += dot * sy * ((q & 1) ? wx1 : wx0);
+                    }
+                }
+            }
+            if (want_coord) {
+                float gu = gix * (0.5f * p.Wp) * cs, gv = giy * (0.5f * p.Hp) * cs;
+                if (pl == 0) { gx += gu; gy += gv; } else if (pl == 1) { gx += gu; gz += gv; } else { gz += gu; gx += gv; }
+            }
+        }
+        gcoord[0] += gx; gcoord[1] += gy; gcoord[2] += gz;
+        gdir[0] += gx * depth; gdir[1] += gy * depth; gdir[2] += gz * depth;
+    }
+    if (bp.d_origins != nullptr || bp.d_dirs != nullptr) {
+        __syncthreads();
+        float* my = red + 2 * RPB * 2 * D + tid * 7;
+        if (tid < nthreads) {
+            my[0] = gcoord[0]; my[1] = gcoord[1]; my[2] = gcoord[2]; my[3] = gdir[0]; my[4] = gdir[1]; my[5] = gdir[2];
+        }
+        __syncthreads();
+        if (live && s < 6) {          // D >= 6 (host-checked)
+            float acc = 0.f;
+            const float* col = red + 2 * RPB * 2 * D + (r * D) * 7 + s;
+            for (int j = 0; j < D; ++j) acc += col[j * 7];
+            if (s < 3) { if (bp.d_origins) bp.d_origins[rr * 3 + s] = acc; }
+            else if (bp.d_dirs) bp.d_dirs[rr * 3 + (s - 3)] = acc;
+        }
+    }
+}
+
+__global__ void render_finalize_kernel(float* depth, const float* mm, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = depth[i];
+    if (isnan(v)) v = INFINITY;            // nan_to_num(nan=inf)
+    if (isinf(v)) v = v > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;   // posinf/neginf -> finite max (only original infs)
+    depth[i] = fminf(fmaxf(v, mm[0]), mm[1]);
+}
+
+// ---- ray generation -----------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ray_gen_fwd_kernel(const float* __restrict__ c2w, const float* __restrict__ K, float* __restrict__ origins,
+                                                          float* __restrict__ dirs, int N, int res) {
+    const int64_t total = (int64_t)N * res * res;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int n = (int)(i / (res * res));
+    const int pix = (int)(i - (int64_t)n * res * res);
+    const int row = pix / res, col = pix - row * res;
+    const float* M = c2w + n * 16;
+    const float* Kn = K + n * 9;
+    const float fx = Kn[0], sk = Kn[1], cx = Kn[2], fy = Kn[4], cy = Kn[5];
+    const float inv = (float)(1.0 / res), half = (float)(0.5 / res);
+    const float xc = (float)col * inv + half, yc = (float)row * inv + half;
+    const float xl = (xc - cx + cy * sk / fy - sk * yc / fy) / fx;
+    const float yl = (yc - cy) / fy;
+    float v[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float w = M[a * 4 + 0] * xl + M[a * 4 + 1] * yl + M[a * 4 + 2] + M[a * 4 + 3];
+        v[a] = w - M[a * 4 + 3];
+        origins[i * 3 + a] = M[a * 4 + 3];
+    }
+    float nrm = fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
+    dirs[i * 3 + 0] = v[0] / nrm; dirs[i * 3 + 1] = v[1] / nrm; dirs[i * 3 + 2] = v[2] / nrm;
+}
+
+// grid = (blocks, N); accumulates with atomics into pre-zeroed d_c2w [N,16], d_K [N,9]
+__global__ void __launch_bounds__(256) ray_gen_bwd_kernel(const float* __restrict__ c2w, const float* __restrict__ K, const float* __restrict__ g_o,
+                                                          const float* __restrict__ g_d, float* __restrict__ d_c2w, float* __restrict__ d_K, int res) {
+    __shared__ float red[4][17];
+    const int n = blockIdx.y;
+    const float* M = c2w + n * 16;
+    const float* Kn = K + n * 9;
+    const float fx = Kn[0], sk = Kn[1], cx = Kn[2], fy = Kn[4], cy = Kn[5];
+    const float inv = (float)(1.0 / res), half = (float)(0.5 / res);
+    float acc[17];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) acc[k] = 0.f;
+    for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < res * res; pix += gridDim.x * blockDim.x) {
+        const int row = pix / res, col = pix - row * res;
+        const int64_t i = (int64_t)n * res * res + pix;
+        const float xc = (float)col * inv + half, yc = (float)row * inv + half;
+        const float xl = (xc - cx + cy * sk / fy - sk * yc / fy) / fx;
+        const float yl = (yc - cy) / fy;
+        float v[3], g[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            v[a] = M[a * 4 + 0] * xl + M[a * 4 + 1] * yl + M[a * 4 + 2];
+            g[a] = g_d ? g_d[i * 3 + a] : 0.f;
+        }
+        float nrm = fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
+        float dn[3] = {v[0] / nrm, v[1] / nrm, v[2] / nrm};
+        float dot = dn[0] * g[0] + dn[1] * g[1] + dn[2] * g[2];
+        float dxl = 0.f, dyl = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float dv = (g[a] - dn[a] * dot) / nrm;
+            acc[a * 4 + 0] += dv * xl; acc[a * 4 + 1] += dv * yl; acc[a * 4 + 2] += dv;
+            acc[a * 4 + 3] += g_o ? g_o[i * 3 + a] : 0.f;
+            dxl += dv * M[a * 4 + 0]; dyl += dv * M[a * 4 + 1];
+        }
+        // intrinsics: order fx, sk, cx, fy, cy -> acc[12..16]
+        acc[12] += -xl / fx * dxl;
+        acc[13] += (cy / fy - yc / fy) / fx * dxl;
+        acc[14] += -dxl / fx;
+        acc[15] += dxl * (-cy * sk / (fy * fy) + sk * yc / (fy * fy)) / fx - (yc - cy) / (fy * fy) * dyl;
+        acc[16] += (sk / fy) / fx * dxl - dyl / fy;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 17; ++k) {
+        float t = acc[k];
+        for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m);
+        if (lane == 0) red[wv][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 17) {
+        float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        int k = threadIdx.x;
+        if (k < 12) unsafeAtomicAdd(d_c2w + n * 16 + k, t);
+        else if (d_K) {
+            const int map[5] = {0, 1, 2, 4, 5};
+            unsafeAtomicAdd(d_K + n * 9 + map[k - 12], t);
+        }
+    }
+}
+
+// run_model on arbitrary points
+__global__ void __launch_bounds__(256) sample_decode_kernel(const eg3d_render_params p, const float* __restrict__ coords, int64_t M,
+                                                            float* __restrict__ rgb, float* __restrict__ sigma) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)p.N * M) return;
+    const int n = (int)(i / M);
+    const float* pn = p.planes + (int64_t)n * p.Hp * p.Wp * p.ldp;
+    float f[FC], out[1 + CO];
+    gather_feats(pn, p.Hp, p.Wp, p.ldp, 2.f / p.box_warp, coords[i * 3], coords[i * 3 + 1], coords[i * 3 + 2], f);
+    mlp_fwd(p.w0, p.b0, p.w1, p.b1, f, out);
+    sigma[i] = out[0];
+#pragma unroll
+    for (int k = 0; k < CO; ++k) rgb[i * CO + k] = sigmoidf_(out[1 + k]) * 1.002f - 0.001f;
+}
+
+int check_render(const eg3d_render_params& p) {
+    if (!p.planes || !p.origins || !p.dirs || !p.u1 || !p.w0 || !p.b0 || !p.w1 || !p.b1) return EG3D_ERR_INVALID;
+    if (p.N <= 0 || p.R <= 0 || p.Hp <= 0 || p.Wp <= 0 || p.Dc < 2 || p.Df < 0) return EG3D_ERR_INVALID;
+    if (p.C != FC || p.Hdim != HD || p.Cout != CO) return EG3D_ERR_UNSUPPORTED;
+    if (p.ldp < 3 * FC || (p.ldp & 3) || (reinterpret_cast<uintptr_t>(p.planes) & 15)) return EG3D_ERR_UNSUPPORTED;
+    const int D = p.Dc > p.Df ? p.Dc : p.Df;
+    if (D > MAXT || D < 6) return EG3D_ERR_UNSUPPORTED;
+    if (p.Df > 0 && (!p.u2 || !p.fine_depths || p.Dc < 4)) return EG3D_ERR_INVALID;
+    return EG3D_OK;
+}
+
+size_t render_smem(const eg3d_render_params& p) {
+    const int D = p.Dc > p.Df ? p.Dc : p.Df;
+    const int RPB = MAXT / D;
+    size_t red = std::max<size_t>((size_t)RPB * D * (CO + 1), (size_t)2 * RPB * 2 * D + (size_t)RPB * D * 7);
+    return ((size_t)RPB * RAY_LDS_FLOATS(D) + red) * sizeof(float);
+}
+
+}  // namespace
+
+extern "C" int eg3d_render_fwd(const eg3d_render_params* pp, void* stream) {
+    if (!pp) return EG3D_ERR_INVALID;
+    int rc = check_render(*pp);
+    if (rc) return rc;
+    if (!pp->rgb || !pp->depth || !pp->wsum || !pp->depth_minmax) return EG3D_ERR_INVALID;
+    const int D = pp->Dc > pp->Df ? pp->Dc : pp->Df;
+    const int RPB = MAXT / D;
+    eg3d_render_bwd_params bp = {};
+    bp.fwd = *pp;
+    const int64_t nrays = (int64_t)pp->N * pp->R;
+    hipLaunchKernelGGL(render_kernel<false>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(*pp), (hipStream_t)stream, bp);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_render_finalize(float* depth, const float* depth_minmax, int64_t n, void* stream) {
+    if (!depth || !depth_minmax || n < 0) return EG3D_ERR_INVALID;
+    if (n == 0) return EG3D_OK;
+    hipLaunchKernelGGL(render_finalize_kernel, dim3(eg3d_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, depth, depth_minmax, n);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_render_bwd(const eg3d_render_bwd_params* bp, void* stream) {
+    if (!bp) return EG3D_ERR_INVALID;
+    int rc = check_render(bp->fwd);
+    if (rc) return rc;
+    if (!bp->d_rgb || !bp->fwd.depth_minmax) return EG3D_ERR_INVALID;
+    const eg3d_render_params& p = bp->fwd;
+    const int D = p.Dc > p.Df ? p.Dc : p.Df;
+    const int RPB = MAXT / D;
+    const int64_t nrays = (int64_t)p.N * p.R;
+    hipLaunchKernelGGL(render_kernel<true>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(p), (hipStream_t)stream, *bp);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_sample_decode(const eg3d_render_params* pp, const float* coords, int64_t M, float* rgb, float* sigma, void* stream) {
+    if (!pp || !coords || !rgb || !sigma || M < 0) return EG3D_ERR_INVALID;
+    const eg3d_render_params& p = *pp;
+    if (!p.planes || !p.w0 || !p.b0 || !p.w1 || !p.b1 || p.N <= 0) return EG3D_ERR_INVALID;
+    if (p.C != FC || p.Hdim != HD || p.Cout != CO || p.ldp < 3 * FC || (p.ldp & 3)) return EG3D_ERR_UNSUPPORTED;
+    if (M == 0) return EG3D_OK;
+    hipLaunchKernelGGL(sample_decode_kernel, dim3(eg3d_cdiv((int64_t)p.N * M, 256)), dim3(256), 0, (hipStream_t)stream, p, coords, M, rgb, sigma);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_ray_gen_fwd(const float* cam2world, const float* intrinsics, float* origins, float* dirs, int N, int res, void* stream) {
+    if (!cam2world || !intrinsics || !origins || !dirs || N <= 0 || res <= 0) return EG3D_ERR_INVALID;
+    hipLaunchKernelGGL(ray_gen_fwd_kernel, dim3(eg3d_cdiv((int64_t)N * res * res, 256)), dim3(256), 0, (hipStream_t)stream, cam2world, intrinsics,
+                       origins, dirs, N, res);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_ray_gen_bwd(const float* cam2world, const float* intrinsics, const float* d_origins, const float* d_dirs, float* d_cam2world,
+                                float* d_intrinsics, int N, int res, void* stream) {
+    if (!cam2world || !intrinsics || !d_cam2world || N <= 0 || res <= 0) return EG3D_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(d_cam2world, 0, sizeof(float) * 16 * N, st);
+    if (e != hipSuccess) return (int)e;
+    if (d_intrinsics) { e = hipMemsetAsync(d_intrinsics, 0, sizeof(float) * 9 * N, st); if (e != hipSuccess) return (int)e; }
+    int bx = std::min(eg3d_cdiv((int64_t)res * res, 256), 64);
+    hipLaunchKernelGGL(ray_gen_bwd_kernel, dim3(bx, N), dim3(256), 0, st, cam2world, intrinsics, d_origins, d_dirs, d_cam2world, d_intrinsics, res);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}

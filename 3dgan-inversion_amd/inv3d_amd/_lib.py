@@ -1,0 +1,140 @@
+"""ctypes binding of libeg3d_hip.so (the C-ABI declared in include/eg3d_hip.h).
+
+The library is built in-tree by `make -C 3dgan-inversion_amd` (or `__graft_entry__.build()`).  There is NO fallback:
+if the shared object is missing, or a kernel returns a non-zero status, this module raises -- the product path never
+silently drops to PyTorch / CPU code.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libeg3d_hip.so')
+
+F32, F16, F64 = 0, 1, 2
+EPI_STORE, EPI_ATOMIC, EPI_FWD, EPI_BWD = 0, 1, 2, 3
+ACT_IDS = dict(linear=1, relu=2, lrelu=3, tanh=4, sigmoid=5, elu=6, selu=7, softplus=8, swish=9)
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class ConvClass(C.Structure):
+    _fields_ = [('Ha', C.c_int32), ('Wa', C.c_int32), ('out_py', C.c_int32), ('out_px', C.c_int32), ('ntaps', C.c_int32),
+                ('dy', C.c_int32 * 9), ('dx', C.c_int32 * 9), ('wtap', C.c_int32 * 9)]
+
+
+class ConvParams(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('w', C.c_void_p), ('out', C.c_void_p),
+                ('N', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32), ('Ck', C.c_int32), ('ldx', C.c_int32),
+                ('Nc', C.c_int32), ('w_row', C.c_int32),
+                ('Ho', C.c_int32), ('Wo', C.c_int32), ('ldo', C.c_int32),
+                ('in_stride', C.c_int32), ('out_stride', C.c_int32),
+                ('ncls', C.c_int32), ('cls', ConvClass * 4),
+                ('in_scale', C.c_void_p), ('epi', C.c_int32), ('ksplit', C.c_int32),
+                ('out_scale', C.c_void_p), ('bias', C.c_void_p), ('noise', C.c_void_p), ('noise_nstride', C.c_int64),
+                ('noise_strength', C.c_void_p), ('act', C.c_int32), ('alpha', C.c_float), ('gain', C.c_float),
+                ('clamp', C.c_float), ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p)]
+
+
+class WgradParams(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('g', C.c_void_p), ('dw', C.c_void_p),
+                ('N', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32), ('Ck', C.c_int32), ('ldx', C.c_int32),
+                ('Nc', C.c_int32), ('w_row', C.c_int32),
+                ('Ho', C.c_int32), ('Wo', C.c_int32), ('ldg', C.c_int32),
+                ('in_stride', C.c_int32), ('out_stride', C.c_int32),
+                ('ncls', C.c_int32), ('cls', ConvClass * 4),
+                ('in_scale', C.c_void_p), ('psplit', C.c_int32)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [('planes', C.c_void_p), ('N', C.c_int32), ('Hp', C.c_int32), ('Wp', C.c_int32), ('ldp', C.c_int32),
+                ('C', C.c_int32), ('origins', C.c_void_p), ('dirs', C.c_void_p), ('R', C.c_int32), ('u1', C.c_void_p),
+                ('u2', C.c_void_p), ('Dc', C.c_int32), ('Df', C.c_int32), ('ray_start', C.c_float), ('ray_end', C.c_float),
+                ('ray_limits', C.c_void_p), ('disparity', C.c_int32), ('box_warp', C.c_float), ('white_back', C.c_int32),
+                ('w0', C.c_void_p), ('b0', C.c_void_p), ('w1', C.c_void_p), ('b1', C.c_void_p), ('Hdim', C.c_int32),
+                ('Cout', C.c_int32), ('rgb', C.c_void_p), ('depth', C.c_void_p), ('wsum', C.c_void_p),
+                ('depth_minmax', C.c_void_p), ('fine_depths', C.c_void_p)]
+
+
+class RenderBwdParams(C.Structure):
+    _fields_ = [('fwd', RenderParams), ('depth_out', C.c_void_p), ('d_rgb', C.c_void_p), ('d_depth', C.c_void_p),
+                ('d_wsum', C.c_void_p), ('d_planes', C.c_void_p), ('d_origins', C.c_void_p), ('d_dirs', C.c_void_p),
+                ('dump_dpre', C.c_void_p), ('dump_h', C.c_void_p), ('dump_dout', C.c_void_p), ('dump_feat', C.c_void_p)]
+
+
+_SIGS = {
+    'eg3d_abi_version': (C.c_int, []),
+    'eg3d_status_string': (C.c_char_p, [C.c_int]),
+    'eg3d_bias_act': (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                C.c_float, C.c_void_p]),
+    'eg3d_upfirdn2d': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p]),
+    'eg3d_conv2d_igemm_f32': (C.c_int, [C.POINTER(ConvParams), C.c_void_p]),
+    'eg3d_conv2d_wgrad_f32': (C.c_int, [C.POINTER(WgradParams), C.c_void_p]),
+    'eg3d_modconv_epilogue_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int64,
+                                            C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    'eg3d_modconv_epilogue_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                            C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                            C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'eg3d_upfirdn2d_nhwc': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 14 + [C.c_float, C.c_int, C.c_int,
+                                                                                             C.c_int, C.c_void_p]),
+    'eg3d_weight_sqsum': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'eg3d_demod_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'eg3d_demod_bwd': (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'eg3d_ray_gen_fwd': (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]),
+    'eg3d_ray_gen_bwd': (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
+    'eg3d_render_fwd': (C.c_int, [C.POINTER(RenderParams), C.c_void_p]),
+    'eg3d_render_finalize': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'eg3d_render_bwd': (C.c_int, [C.POINTER(RenderBwdParams), C.c_void_p]),
+    'eg3d_sample_decode': (C.c_int, [C.POINTER(RenderParams), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+_lib = None
+
+
+class Eg3dHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Eg3dHipError(f'{LIB_PATH} not found: build it with `make -C 3dgan-inversion_amd` '
+                               f'(or python -c "import __graft_entry__ as g; g.build()"). There is no fallback path.')
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(h, name)          # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(status, what=''):
+    if status != 0:
+        msg = lib().eg3d_status_string(int(status)).decode()
+        raise Eg3dHipError(f'{what or "eg3d kernel"} failed: status {status} ({msg})')
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise Eg3dHipError('eg3d HIP path needs tensors on an AMD GPU (cuda device); there is no CPU fallback. '
+                               'Use oracle/eg3d_oracle.py only as a test checker.')

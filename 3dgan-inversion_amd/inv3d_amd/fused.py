@@ -1,0 +1,321 @@
+"""Autograd-level fused operators of the MI355X path (each forward/backward = a handful of HIP launches).
+
+These are what the generator modules call instead of the reference's chains of ATen ops:
+  ModConvLayerFn  <- SynthesisLayer.forward  (training/networks_stylegan2.py:311-330): style-modulated 3x3 conv (up 1|2) +
+                     demod + noise + bias + lrelu + gain + clamp, backward into x, styles, noise_const / strength, bias, weight.
+  ToRGBFn         <- ToRGBLayer.forward (:353-357) fused with the skip-image accumulation of SynthesisBlock (:455-457).
+  UpsampleImgFn   <- upfirdn2d.upsample2d on the skip image (:453).
+  RayGenFn / RenderFn <- RaySampler.forward / ImportanceRenderer.forward.
+Formulation: activations are scaled by the styles inside the conv's operand load and the demodulation coefficient is
+applied in the epilogue (the reference's non-fused branch, :70-79), so weights are shared by the whole batch and the
+style gradient is a reduction fused into the data-gradient conv (no per-sample weight gradient).
+"""
+import math
+
+import torch
+
+from . import _lib as L
+from . import hipops as H
+
+_F44 = {}
+
+
+def fir44(device):
+    """outer([1,3,3,1])/64 on `device` (upfirdn2d.setup_filter([1,3,3,1]))."""
+    key = str(device)
+    if key not in _F44:
+        f = torch.tensor([1., 3., 3., 1.], dtype=torch.float32, device=device)
+        f = torch.outer(f, f)
+        _F44[key] = (f / f.sum()).contiguous()
+    return _F44[key]
+
+
+class WeightCache:
+    """Packed / derived weight images, rebuilt only when the parameter changes (key: data_ptr + in-place version)."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, w: torch.Tensor):
+        key = (w.data_ptr(), w._version, tuple(w.shape))
+        hit = self._c.get('k')
+        if hit != key:
+            with torch.no_grad():
+                wd = w.detach()
+                o, i, kh, kw = wd.shape
+                wf = H.pack_weight_fwd(wd)
+                wa = H.pack_weight_adj(wd)
+                wsq = H.weight_sqsum(wf, o, kh * kw, i)
+            self._c = {'k': key, 'wf': wf, 'wa': wa, 'wsq': wsq}
+        return self._c['wf'], self._c['wa'], self._c['wsq']
+
+
+def _auto_ksplit(n_cells, Nc, steps):
+    """Split-K factor for layers too small to fill 256 CUs (low-resolution 512-channel layers)."""
+    tiles = max(1, (n_cells + 31) // 32) * max(1, (Nc + 127) // 128)
+    if tiles >= 256:
+        return 1
+    return max(1, min(steps, 512 // tiles))
+
+
+class ModConvLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, styles, noise, noise_strength, bias, up, act_gain, clamp, cache, want_wgrad):
+        # x: CL [N,Ci,H,W]; weight [Co,Ci,3,3]; styles [N,Ci]; noise None | [res,res] | [N,1,res,res]; noise_strength 0-d
+        L.require_cuda(x, weight, styles)
+        x = H.to_cl(x.float())
+        styles = styles.contiguous().float()
+        N, Ci, Hi, Wi = x.shape
+        Co, _, kh, kw = weight.shape
+        wf, wa, wsq = cache.get(weight)
+        d = H.demod_fwd(styles, wsq)
+        Ho, Wo = Hi * up, Wi * up
+        nz = nstride = None
+        if noise is not None:
+            nz = noise.contiguous().float()
+            nstride = 0 if nz.dim() == 2 else Ho * Wo
+        clampv = -1.0 if clamp is None else float(clamp)
+        out = H.empty_cl(N, Co, Ho, Wo, x.device)
+        b = bias.contiguous().float() if bias is not None else None
+        steps = ((Ci + 31) // 32) * kh * kw
+        if up == 1:
+            cls = H.classes_corr(Ho, Wo, kh, kw, kh // 2)
+            ks = _auto_ksplit(N * Ho * Wo, Co, steps)
+            if ks == 1:
+                H.conv_igemm(x, wf, Ci, Co, out, cls, in_scale=styles, epi=L.EPI_FWD, out_scale=d, bias=b, noise=nz,
+                             noise_nstride=nstride or 0, noise_strength=noise_strength, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv)
+            else:
+                z = H.zeros_cl(N, Co, Ho, Wo, x.device)
+                H.conv_igemm(x, wf, Ci, Co, z, cls, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks)
+                H.epilogue_fwd(z, out, d=d, noise=nz, noise_nstride=nstride or 0, noise_strength=noise_strength, bias=b, act='lrelu',
+                               alpha=0.2, gain=act_gain, clamp=clampv)
+        else:
+            cls, Hz, Wz = H.classes_convT(Hi, Wi, kh, kw, up)
+            ks = _auto_ksplit(N * (Hi + 1) * (Wi + 1), Co, ((Ci + 31) // 32) * 4)
+            if ks == 1:
+                z = H.empty_cl(N, Co, Hz, Wz, x.device)
+                H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_STORE)
+            else:
+                z = H.zeros_cl(N, Co, Hz, Wz, x.device)
+                H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks)
+            H.epilogue_fwd(z, out, fir=fir44(x.device), pad0=1, fir_gain=float(up * up), d=d, noise=nz, noise_nstride=nstride or 0,
+                           noise_strength=noise_strength, bias=b, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv)
+        ctx.save_for_backward(x, weight, styles, d, out, nz, noise_strength, b)
+        ctx.cfg = (up, act_gain, clampv, nstride, cache, want_wgrad, noise is not None and noise.dim() == 4)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, styles, d, out, nz, noise_strength, b = ctx.saved_tensors
+        up, act_gain, clampv, nstride, cache, want_wgrad, noise4d = ctx.cfg
+        need_x, need_w, need_s, need_nz, need_ns, need_b = ctx.needs_input_grad[:6]
+        need_w = need_w and want_wgrad
+        dout = H.to_cl(dout.float())
+        N, Ci, Hi, Wi = x.shape
+        Co, _, kh, kw = weight.shape
+        Ho, Wo = Hi * up, Wi * up
+        dev = x.device
+        wf, wa, wsq = cache.get(weight)
+        dz = H.empty_cl(N, Co, Ho, Wo, dev)
+        dbias = torch.zeros(Co, device=dev) if need_b else None
+        dd = torch.zeros((N, Co), device=dev) if (need_s or need_w) else None
+        dnoise = None
+        if need_nz and nz is not None:
+            dnoise = torch.zeros_like(nz)
+        dstrength = torch.zeros((), device=dev) if (need_ns and nz is not None) else None
+        H.epilogue_bwd(dout, out, dz, d=d, noise=nz, noise_nstride=nstride or 0, noise_strength=noise_strength if nz is not None else None,
+                       bias=b, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv, dbias=dbias, dd=dd, dnoise=dnoise,
+                       dnoise_nstride=nstride or 0, dstrength=dstrength)
+        if up == 1:
+            g = dz
+            cls_adj = H.classes_corr_adjoint(Hi, Wi, kh, kw, kh // 2)
+            in_stride = 1
+            cls_w, out_stride_w = H.classes_corr(Ho, Wo, kh, kw, kh // 2), 1
+        else:
+            g = H.upfirdn2d_nhwc(dz, fir44(dev), pad=(2, 2, 2, 2), flip=True, gain=float(up * up))     # adjoint of the FIR
+            cls_adj = H.classes_convT_adjoint(Hi, Wi, kh, kw, up)
+            in_stride = up
+            cls_w, out_stride_w = H.classes_convT(Hi, Wi, kh, kw, up)[0], up
+        dx = ds = None
+        if need_x or need_s:
+            dx = H.empty_cl(N, Ci, Hi, Wi, dev)
+            ds = torch.zeros((N, Ci), device=dev)
+            H.conv_igemm(g, wa, Co, Ci, dx, cls_adj, in_stride=in_stride, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds)
+        dwsq = torch.zeros_like(wsq) if need_w else None
+        if dd is not None and (need_s or need_w):
+            if ds is None:
+                ds = torch.zeros((N, Ci), device=dev)
+            H.demod_bwd(styles, wsq, d, dd, ds=ds if need_s else None, dwsq=dwsq)
+        dweight = None
+        if need_w:
+            dwp = torch.zeros_like(wf)
+            H.conv_wgrad(x, g, Ci, Co, dwp, cls_w, in_stride=1, out_stride=out_stride_w, in_scale=styles)
+            dweight = dwp.view(Co, kh, kw, Ci).permute(0, 3, 1, 2) + 2.0 * weight * dwsq[:, :, None, None]
+        if dnoise is not None and noise4d:
+            dnoise = dnoise.view(N, 1, Ho, Wo)
+        return (dx if need_x else None, dweight, ds if need_s else None, dnoise, dstrength, dbias, None, None, None, None, None)
+
+
+class ToRGBFn(torch.autograd.Function):
+    """y = clamp(conv1x1(x * styles, W) + bias);  out = skip + y (skip optional).  Small channel counts are padded to 4."""
+
+    @staticmethod
+    def forward(ctx, x, weight, styles, bias, skip, clamp, cache, want_wgrad):
+        L.require_cuda(x, weight, styles)
+        x = H.to_cl(x.float())
+        styles = styles.contiguous().float()
+        N, Ci, Hh, Ww = x.shape
+        Co = weight.shape[0]
+        Cp = (Co + 3) // 4 * 4
+        wf, wa, _ = cache.get(weight)
+        clampv = -1.0 if clamp is None else float(clamp)
+        b = bias.contiguous().float() if bias is not None else None
+        cls = H.classes_corr(Hh, Ww, 1, 1, 0)
+        y = None
+        if skip is not None:
+            skip = H.to_cl(skip.float())
+            assert skip.shape[1] == Cp
+        if clampv < 0 and skip is not None:
+            out = H.empty_cl(N, Cp, Hh, Ww, x.device) if Cp == Co else H.zeros_cl(N, Cp, Hh, Ww, x.device)
+            H.conv_igemm(x, wf, Ci, Co, out, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=-1.0, addend=skip)
+            if Cp != Co:
+                out[:, Co:] = skip[:, Co:]
+        else:
+            y = H.zeros_cl(N, Cp, Hh, Ww, x.device) if Cp != Co else H.empty_cl(N, Cp, Hh, Ww, x.device)
+            H.conv_igemm(x, wf, Ci, Co, y, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=clampv)
+            out = y + skip if skip is not None else y
+        ctx.save_for_backward(x, weight, styles, y if clampv >= 0 else None)
+        ctx.cfg = (clampv, cache, want_wgrad, Cp, skip is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, styles, y = ctx.saved_tensors
+        clampv, cache, want_wgrad, Cp, has_skip = ctx.cfg
+        need_x, need_w, need_s, need_b, need_skip = ctx.needs_input_grad[:5]
+        need_w = need_w and want_wgrad
+        dout = H.to_cl(dout.float())
+        N, Ci, Hh, Ww = x.shape
+        Co = weight.shape[0]
+        dev = x.device
+        wf, wa, _ = cache.get(weight)
+        dy = dout
+        dbias = None
+        if clampv >= 0 or need_b:
+            dbias_p = torch.zeros(Cp, device=dev) if need_b else None
+            dy = H.empty_cl(N, Cp, Hh, Ww, dev)
+            H.epilogue_bwd(dout, y if y is not None else dout, dy, act='linear', gain=1.0, clamp=clampv, dbias=dbias_p)
+            dbias = dbias_p[:Co] if need_b else None
+        dx = ds = None
+        if need_x or need_s:
+            wa_p = wa
+            if Cp != Co:       # pad the contraction dim (output channels) with zeros to a multiple of 4
+                wa_p = torch.zeros((Ci, Cp), device=dev)
+                wa_p[:, :Co] = wa
+            dx = H.empty_cl(N, Ci, Hh, Ww, dev)
+            ds = torch.zeros((N, Ci), device=dev)
+            H.conv_igemm(dy, wa_p, Cp, Ci, dx, H.classes_corr_adjoint(Hh, Ww, 1, 1, 0), epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds)
+        dweight = None
+        if need_w:
+            dwp = torch.zeros((Co, Ci), device=dev)
+            H.conv_wgrad(x, dy, Ci, Co, dwp, H.classes_corr(Hh, Ww, 1, 1, 0), in_scale=styles)
+            dweight = dwp.view(Co, Ci, 1, 1)
+        return (dx if need_x else None, dweight, ds if need_s else None, dbias, dout if (need_skip and has_skip) else None, None, None, None)
+
+
+class UpsampleImgFn(torch.autograd.Function):
+    """upfirdn2d.upsample2d(img, [1,3,3,1]) on a channels_last image (C % 4 == 0)."""
+
+    @staticmethod
+    def forward(ctx, img):
+        img = H.to_cl(img.float())
+        return H.upfirdn2d_nhwc(img, fir44(img.device), up=2, pad=(2, 1, 2, 1), gain=4.0)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = H.to_cl(g.float())
+        return H.upfirdn2d_nhwc(g, fir44(g.device), down=2, pad=(1, 1, 1, 1), flip=True, gain=4.0)
+
+
+class RayGenFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, c2w, K, res):
+        L.require_cuda(c2w, K)
+        c2w = c2w.contiguous().float()
+        K = K.contiguous().float()
+        o, d = H.ray_gen_fwd(c2w, K, res)
+        ctx.save_for_backward(c2w, K)
+        ctx.res = res
+        return o, d
+
+    @staticmethod
+    def backward(ctx, g_o, g_d):
+        c2w, K = ctx.saved_tensors
+        g_o = g_o.contiguous().float() if g_o is not None else None
+        g_d = g_d.contiguous().float() if g_d is not None else None
+        d_c2w, d_K = H.ray_gen_bwd(c2w, K, g_o, g_d, ctx.res, want_K=ctx.needs_input_grad[1])
+        return d_c2w, d_K, None
+
+
+class RenderFn(torch.autograd.Function):
+    """ImportanceRenderer.forward fused.  planes: CL [N,96,Hp,Wp]; returns rgb [N,R,32], depth [N,R,1], wsum [N,R,1]."""
+
+    @staticmethod
+    def forward(ctx, planes, origins, dirs, w0, b0, w1, b1, u1, u2, opts, lr_mul, ray_limits):
+        L.require_cuda(planes, origins, dirs, w0)
+        planes = H.to_cl(planes.float())
+        origins = origins.contiguous().float()
+        dirs = dirs.contiguous().float()
+        N, R = origins.shape[0], origins.shape[1]
+        dev = planes.device
+        Dc, Df = int(opts['depth_resolution']), int(opts['depth_resolution_importance'])
+        hid, cin = w0.shape
+        g0, g1 = lr_mul / math.sqrt(cin), lr_mul / math.sqrt(hid)
+        w0g = (w0.detach().float() * g0).contiguous()
+        b0g = (b0.detach().float() * lr_mul).contiguous()
+        w1t = (w1.detach().float() * g1).t().contiguous()
+        b1g = (b1.detach().float() * lr_mul).contiguous()
+        u1 = u1.contiguous().float()
+        u2 = u2.contiguous().float() if u2 is not None else None
+        rgb = torch.empty((N, R, w1.shape[0] - 1), device=dev)
+        depth = torch.empty((N, R, 1), device=dev)
+        wsum = torch.empty((N, R, 1), device=dev)
+        minmax = torch.tensor([float('inf'), float('-inf')], device=dev)
+        fine = torch.empty((N, R, max(Df, 1)), device=dev)
+        rl = ray_limits.contiguous().float() if ray_limits is not None else None
+        p = H.make_render_params(planes, origins, dirs, u1, u2, opts, w0g, b0g, w1t, b1g, rgb, depth, wsum, minmax, fine, rl)
+        H.render_fwd(p)
+        H.render_finalize(depth, minmax)
+        ctx.save_for_backward(planes, origins, dirs, w0g, b0g, w1t, b1g, u1, u2, minmax, fine, rl)
+        ctx.cfg = (dict(opts), g0, g1, lr_mul)
+        return rgb, depth, wsum
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_wsum):
+        planes, origins, dirs, w0g, b0g, w1t, b1g, u1, u2, minmax, fine, rl = ctx.saved_tensors
+        opts, g0, g1, lr_mul = ctx.cfg
+        need = ctx.needs_input_grad
+        dev = planes.device
+        N, R = origins.shape[0], origins.shape[1]
+        g_rgb = g_rgb.contiguous().float() if g_rgb is not None else torch.zeros((N, R, w1t.shape[1] - 1), device=dev)
+        g_depth = g_depth.contiguous().float() if g_depth is not None else None
+        g_wsum = g_wsum.contiguous().float() if g_wsum is not None else None
+        p = H.make_render_params(planes, origins, dirs, u1, u2, opts, w0g, b0g, w1t, b1g, None, None, None, minmax, fine, rl)
+        d_planes = torch.zeros_like(planes) if need[0] else None
+        d_o = torch.empty_like(origins) if (need[1] or need[2]) else None
+        d_d = torch.empty_like(dirs) if (need[1] or need[2]) else None
+        dumps = None
+        if any(need[3:7]):
+            D = max(p.Dc, p.Df)
+            S = N * R * 2 * D
+            dumps = [torch.zeros((S, 64), device=dev), torch.zeros((S, 64), device=dev), torch.zeros((S, 33), device=dev),
+                     torch.zeros((S, 32), device=dev)]
+        H.render_bwd(p, g_rgb, g_depth, g_wsum, d_planes, d_o, d_d, dumps)
+        dw0 = db0 = dw1 = db1 = None
+        if dumps is not None:
+            dpre, hid, dout, feat = dumps
+            dw0 = (dpre.t() @ feat) * g0
+            db0 = dpre.sum(0) * lr_mul
+            dw1 = (dout.t() @ hid) * g1
+            db1 = dout.sum(0) * lr_mul
+        return (d_planes, d_o if need[1] else None, d_d if need[2] else None, dw0, db0, dw1, db1, None, None, None, None, None)

@@ -1,0 +1,332 @@
+"""Thin, allocation-aware wrappers over the C-ABI kernels (one Python function per entry point).
+
+Tensors handed to the fused path are fp32 "NHWC": logical shape [N,C,H,W] with channels_last strides (so the
+reference-facing API keeps NCHW shapes while memory is channel-contiguous, which is what the MFMA implicit GEMM,
+the float4 epilogues and the 128-byte tri-plane gathers want).
+"""
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+CL = torch.channels_last
+
+
+def is_cl(t: torch.Tensor) -> bool:
+    return t.dim() == 4 and t.is_cuda and t.dtype == torch.float32 and (t.stride(1) == 1 or t.shape[1] == 1) and \
+        t.is_contiguous(memory_format=CL)
+
+
+def to_cl(t: torch.Tensor) -> torch.Tensor:
+    return t.contiguous(memory_format=CL)
+
+
+def empty_cl(n, c, h, w, device) -> torch.Tensor:
+    return torch.empty((n, c, h, w), dtype=torch.float32, device=device, memory_format=CL)
+
+
+def zeros_cl(n, c, h, w, device) -> torch.Tensor:
+    return torch.zeros((n, c, h, w), dtype=torch.float32, device=device).contiguous(memory_format=CL)
+
+
+def _dtype_code(t):
+    try:
+        return {torch.float32: L.F32, torch.float16: L.F16, torch.float64: L.F64}[t.dtype]
+    except KeyError:
+        raise L.Eg3dHipError(f'unsupported dtype {t.dtype}')
+
+
+# ------------------------------------------------------------------------------------------------- bias_act
+def bias_act_raw(x, b, xref, yref, dy, grad, dim, act_id, alpha, gain, clamp):
+    """y = eg3d_bias_act(...); x dense (any layout); output has x's layout."""
+    L.require_cuda(x, b, xref, yref, dy)
+    y = torch.empty_like(x)
+    if x.numel() == 0:
+        return y
+    size_b = b.numel() if b is not None else 0
+    step_b = x.stride(dim) if b is not None else 1
+    L.check(L.lib().eg3d_bias_act(L.ptr(x), L.ptr(b), L.ptr(xref), L.ptr(yref), L.ptr(dy), L.ptr(y), _dtype_code(x), x.numel(),
+                                  size_b, step_b, grad, act_id, float(alpha), float(gain), float(clamp), L.stream_ptr()), 'bias_act')
+    return y
+
+
+# ------------------------------------------------------------------------------------------------- upfirdn2d
+def upfirdn2d_raw(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain):
+    L.require_cuda(x, f2d)
+    n, c, h, w = x.shape
+    fh, fw = f2d.shape
+    ow = (w * upx + padx0 + padx1 - fw + downx) // downx
+    oh = (h * upy + pady0 + pady1 - fh + downy) // downy
+    if ow < 1 or oh < 1:
+        raise L.Eg3dHipError('upfirdn2d: output must be at least 1x1')
+    mf = CL if (x.stride(1) == 1 and c > 1) else torch.contiguous_format
+    y = torch.empty((n, c, oh, ow), dtype=x.dtype, device=x.device, memory_format=mf)
+    xs = (C.c_int64 * 4)(*x.stride())
+    ys = (C.c_int64 * 4)(*y.stride())
+    f2d = f2d.contiguous().float()
+    L.check(L.lib().eg3d_upfirdn2d(L.ptr(x), L.ptr(f2d), L.ptr(y), _dtype_code(x), n, c, h, w, xs, fh, fw, upx, upy, downx, downy,
+                                   padx0, padx1, pady0, pady1, int(bool(flip)), float(gain), oh, ow, ys, L.stream_ptr()), 'upfirdn2d')
+    return y
+
+
+def upfirdn2d_nhwc(x, f2d, up=1, down=1, pad=(0, 0, 0, 0), flip=False, gain=1.0, out=None, accumulate=False):
+    assert is_cl(x), 'upfirdn2d_nhwc expects an fp32 channels_last CUDA tensor'
+    n, c, h, w = x.shape
+    fh, fw = f2d.shape
+    px0, px1, py0, py1 = pad
+    ow = (w * up + px0 + px1 - fw + down) // down
+    oh = (h * up + py0 + py1 - fh + down) // down
+    if out is None:
+        out = empty_cl(n, c, oh, ow, x.device)
+        accumulate = False
+    L.check(L.lib().eg3d_upfirdn2d_nhwc(L.ptr(x), L.ptr(f2d), L.ptr(out), n, c, h, w, fh, fw, up, down, px0, px1, py0, py1,
+                                        int(bool(flip)), float(gain), oh, ow, int(bool(accumulate)), L.stream_ptr()), 'upfirdn2d_nhwc')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- conv tap lists
+def _mk_class(Ha, Wa, py, px, taps):
+    c = L.ConvClass()
+    c.Ha, c.Wa, c.out_py, c.out_px, c.ntaps = Ha, Wa, py, px, len(taps)
+    assert 1 <= len(taps) <= 9
+    for i, (dy, dx, wt) in enumerate(taps):
+        c.dy[i], c.dx[i], c.wtap[i] = dy, dx, wt
+    return c
+
+
+def classes_corr(Ho, Wo, kh, kw, pad, flip_taps=False):
+    """stride-1 correlation: out[y,x] = sum_k w[ky,kx] * in[y+ky-pad, x+kx-pad]  (flip_taps: true convolution)."""
+    taps = []
+    for ky in range(kh):
+        for kx in range(kw):
+            wt = ((kh - 1 - ky) * kw + (kw - 1 - kx)) if flip_taps else (ky * kw + kx)
+            taps.append((ky - pad, kx - pad, wt))
+    return [_mk_class(Ho, Wo, 0, 0, taps)]
+
+
+def classes_corr_adjoint(Hi, Wi, kh, kw, pad, flip_taps=False):
+    """data-gradient of classes_corr: dx[y,x] = sum_k w[ky,kx] * g[y-ky+pad, x-kx+pad]."""
+    taps = []
+    for ky in range(kh):
+        for kx in range(kw):
+            wt = ((kh - 1 - ky) * kw + (kw - 1 - kx)) if flip_taps else (ky * kw + kx)
+            taps.append((pad - ky, pad - kx, wt))
+    return [_mk_class(Hi, Wi, 0, 0, taps)]
+
+
+def classes_convT(Hi, Wi, kh, kw, up, flip_taps=False):
+    """stride-`up` transposed conv, no padding: out[up*a+ky, up*b+kx] += in[a,b]*w[ky,kx]; out = (Hi-1)*up + kh.
+    One class per output phase (py,px); taps ky == py (mod up) read in[a - (ky-py)/up]."""
+    Ho, Wo = (Hi - 1) * up + kh, (Wi - 1) * up + kw
+    cls = []
+    for py in range(up):
+        for px in range(up):
+            taps = []
+            for ky in range(py, kh, up):
+                for kx in range(px, kw, up):
+                    wt = ((kh - 1 - ky) * kw + (kw - 1 - kx)) if flip_taps else (ky * kw + kx)
+                    taps.append((-(ky - py) // up, -(kx - px) // up, wt))
+            Ha = (Ho - py + up - 1) // up
+            Wa = (Wo - px + up - 1) // up
+            if taps and Ha > 0 and Wa > 0:
+                cls.append(_mk_class(Ha, Wa, py, px, taps))
+    return cls, Ho, Wo
+
+
+def classes_convT_adjoint(Hi, Wi, kh, kw, up, flip_taps=False):
+    """data-gradient of classes_convT: dx[a,b] = sum_k g[up*a+ky, up*b+kx] * w[ky,kx]  (in_stride = up)."""
+    taps = []
+    for ky in range(kh):
+        for kx in range(kw):
+            wt = ((kh - 1 - ky) * kw + (kw - 1 - kx)) if flip_taps else (ky * kw + kx)
+            taps.append((ky, kx, wt))
+    return [_mk_class(Hi, Wi, 0, 0, taps)]
+
+
+def pack_weight_fwd(w):
+    """[O,I,kh,kw] -> [O, kh*kw*I]  (row o: taps major, input channel minor)."""
+    o, i, kh, kw = w.shape
+    return w.permute(0, 2, 3, 1).reshape(o, kh * kw * i).contiguous()
+
+
+def pack_weight_adj(w):
+    """[O,I,kh,kw] -> [I, kh*kw*O]  (for data gradients: roles of I and O swapped)."""
+    o, i, kh, kw = w.shape
+    return w.permute(1, 2, 3, 0).reshape(i, kh * kw * o).contiguous()
+
+
+def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=None, epi=L.EPI_STORE, ksplit=1,
+               out_scale=None, bias=None, noise=None, noise_nstride=0, noise_strength=None, act='linear', alpha=0.0, gain=1.0,
+               clamp=-1.0, addend=None, xin=None, ds=None):
+    """Launch eg3d_conv2d_igemm_f32.  x/out/addend/xin: channels_last fp32 [N,C,H,W]; wp: packed weights [Nc, taps*Ck]."""
+    assert is_cl(x) and is_cl(out), 'conv_igemm expects fp32 channels_last CUDA tensors'
+    p = L.ConvParams()
+    n, cx, hi, wi = x.shape
+    _, co, ho, wo = out.shape
+    p.x, p.w, p.out = x.data_ptr(), wp.data_ptr(), out.data_ptr()
+    p.N, p.Hi, p.Wi, p.Ck, p.ldx = n, hi, wi, Ck, cx
+    p.Nc, p.w_row = Nc, wp.stride(0)
+    p.Ho, p.Wo, p.ldo = ho, wo, co
+    p.in_stride, p.out_stride = in_stride, out_stride
+    p.ncls = len(classes)
+    for i, c in enumerate(classes):
+        p.cls[i] = c
+    p.in_scale = in_scale.data_ptr() if in_scale is not None else None
+    p.epi, p.ksplit = epi, ksplit
+    p.out_scale = out_scale.data_ptr() if out_scale is not None else None
+    p.bias = bias.data_ptr() if bias is not None else None
+    p.noise = noise.data_ptr() if noise is not None else None
+    p.noise_nstride = noise_nstride
+    p.noise_strength = noise_strength.data_ptr() if noise_strength is not None else None
+    p.act, p.alpha, p.gain, p.clamp = L.ACT_IDS[act], float(alpha), float(gain), float(clamp)
+    p.addend = addend.data_ptr() if addend is not None else None
+    p.xin = xin.data_ptr() if xin is not None else None
+    p.ds = ds.data_ptr() if ds is not None else None
+    L.check(L.lib().eg3d_conv2d_igemm_f32(C.byref(p), L.stream_ptr()), 'conv2d_igemm_f32')
+    return out
+
+
+def conv_wgrad(x, g, Ck, Nc, dwp, classes, in_stride=1, out_stride=1, in_scale=None, psplit=0):
+    """dwp[Nc, taps*Ck] += grad of the packed weights (dwp pre-zeroed)."""
+    assert is_cl(x) and is_cl(g)
+    p = L.WgradParams()
+    n, cx, hi, wi = x.shape
+    _, cg, ho, wo = g.shape
+    p.x, p.g, p.dw = x.data_ptr(), g.data_ptr(), dwp.data_ptr()
+    p.N, p.Hi, p.Wi, p.Ck, p.ldx = n, hi, wi, Ck, cx
+    p.Nc, p.w_row = Nc, dwp.stride(0)
+    p.Ho, p.Wo, p.ldg = ho, wo, cg
+    p.in_stride, p.out_stride = in_stride, out_stride
+    p.ncls = len(classes)
+    for i, c in enumerate(classes):
+        p.cls[i] = c
+    p.in_scale = in_scale.data_ptr() if in_scale is not None else None
+    p.psplit = psplit
+    L.check(L.lib().eg3d_conv2d_wgrad_f32(C.byref(p), L.stream_ptr()), 'conv2d_wgrad_f32')
+    return dwp
+
+
+# ------------------------------------------------------------------------------------------------- epilogues
+def epilogue_fwd(z, out, fir=None, pad0=0, fir_gain=1.0, d=None, noise=None, noise_nstride=0, noise_strength=None, bias=None,
+                 act='linear', alpha=0.0, gain=1.0, clamp=-1.0):
+    assert is_cl(z) and is_cl(out)
+    n, c, h, w = out.shape
+    _, _, hz, wz = z.shape
+    fh, fw = (fir.shape if fir is not None else (0, 0))
+    L.check(L.lib().eg3d_modconv_epilogue_fwd(L.ptr(z), L.ptr(out), n, h, w, c, hz, wz, L.ptr(fir), fh, fw, pad0, float(fir_gain),
+                                              L.ptr(d), L.ptr(noise), noise_nstride, L.ptr(noise_strength), L.ptr(bias),
+                                              L.ACT_IDS[act], float(alpha), float(gain), float(clamp), L.stream_ptr()),
+            'modconv_epilogue_fwd')
+    return out
+
+
+def epilogue_bwd(dout, out, dz, d=None, noise=None, noise_nstride=0, noise_strength=None, bias=None, act='linear', alpha=0.0, gain=1.0,
+                 clamp=-1.0, dbias=None, dd=None, dnoise=None, dnoise_nstride=0, dstrength=None):
+    assert is_cl(dout) and is_cl(out) and is_cl(dz)
+    n, c, h, w = out.shape
+    L.check(L.lib().eg3d_modconv_epilogue_bwd(L.ptr(dout), L.ptr(out), L.ptr(dz), n, h, w, c, L.ptr(d), L.ptr(noise), noise_nstride,
+                                              L.ptr(noise_strength), L.ptr(bias), L.ACT_IDS[act], float(alpha), float(gain),
+                                              float(clamp), L.ptr(dbias), L.ptr(dd), L.ptr(dnoise), dnoise_nstride, L.ptr(dstrength),
+                                              L.stream_ptr()), 'modconv_epilogue_bwd')
+    return dz
+
+
+def weight_sqsum(wp, Co, ntaps, Ck):
+    wsq = torch.empty((Co, Ck), dtype=torch.float32, device=wp.device)
+    L.check(L.lib().eg3d_weight_sqsum(L.ptr(wp), L.ptr(wsq), Co, ntaps, Ck, L.stream_ptr()), 'weight_sqsum')
+    return wsq
+
+
+def demod_fwd(s, wsq):
+    n, ck = s.shape
+    co = wsq.shape[0]
+    d = torch.empty((n, co), dtype=torch.float32, device=s.device)
+    L.check(L.lib().eg3d_demod_fwd(L.ptr(s), L.ptr(wsq), L.ptr(d), n, co, ck, L.stream_ptr()), 'demod_fwd')
+    return d
+
+
+def demod_bwd(s, wsq, d, dd, ds=None, dwsq=None):
+    n, ck = s.shape
+    co = wsq.shape[0]
+    L.check(L.lib().eg3d_demod_bwd(L.ptr(s), L.ptr(wsq), L.ptr(d), L.ptr(dd), L.ptr(ds), L.ptr(dwsq), n, co, ck, L.stream_ptr()),
+            'demod_bwd')
+
+
+# ------------------------------------------------------------------------------------------------- renderer
+def ray_gen_fwd(c2w, K, res):
+    n = c2w.shape[0]
+    o = torch.empty((n, res * res, 3), dtype=torch.float32, device=c2w.device)
+    d = torch.empty_like(o)
+    L.check(L.lib().eg3d_ray_gen_fwd(L.ptr(c2w), L.ptr(K), L.ptr(o), L.ptr(d), n, res, L.stream_ptr()), 'ray_gen_fwd')
+    return o, d
+
+
+def ray_gen_bwd(c2w, K, g_o, g_d, res, want_K=True):
+    n = c2w.shape[0]
+    d_c2w = torch.empty((n, 4, 4), dtype=torch.float32, device=c2w.device)
+    d_K = torch.empty((n, 3, 3), dtype=torch.float32, device=c2w.device) if want_K else None
+    L.check(L.lib().eg3d_ray_gen_bwd(L.ptr(c2w), L.ptr(K), L.ptr(g_o), L.ptr(g_d), L.ptr(d_c2w), L.ptr(d_K), n, res, L.stream_ptr()),
+            'ray_gen_bwd')
+    return d_c2w, d_K
+
+
+def make_render_params(planes, origins, dirs, u1, u2, opts, w0, b0, w1t, b1, rgb, depth, wsum, minmax, fine, ray_limits=None):
+    """planes: channels_last [N, 3*C, Hp, Wp]; decoder weights with gains folded (w1t transposed [H, 1+Cout])."""
+    assert is_cl(planes)
+    p = L.RenderParams()
+    n, c3, hp, wp = planes.shape
+    p.planes, p.N, p.Hp, p.Wp, p.ldp, p.C = planes.data_ptr(), n, hp, wp, c3, c3 // 3
+    p.origins, p.dirs, p.R = origins.data_ptr(), dirs.data_ptr(), origins.shape[1]
+    p.u1 = u1.data_ptr()
+    p.u2 = u2.data_ptr() if u2 is not None else None
+    p.Dc, p.Df = int(opts['depth_resolution']), int(opts['depth_resolution_importance'])
+    if ray_limits is not None:
+        p.ray_limits = ray_limits.data_ptr()
+        p.ray_start = p.ray_end = 0.0
+    else:
+        p.ray_limits = None
+        p.ray_start, p.ray_end = float(opts['ray_start']), float(opts['ray_end'])
+    p.disparity = int(bool(opts.get('disparity_space_sampling', False)))
+    p.box_warp = float(opts['box_warp'])
+    p.white_back = int(bool(opts.get('white_back', False)))
+    p.w0, p.b0, p.w1, p.b1 = w0.data_ptr(), b0.data_ptr(), w1t.data_ptr(), b1.data_ptr()
+    p.Hdim, p.Cout = w0.shape[0], w1t.shape[1] - 1
+    p.rgb = rgb.data_ptr() if rgb is not None else None
+    p.depth = depth.data_ptr() if depth is not None else None
+    p.wsum = wsum.data_ptr() if wsum is not None else None
+    p.depth_minmax = minmax.data_ptr() if minmax is not None else None
+    p.fine_depths = fine.data_ptr() if fine is not None else None
+    return p
+
+
+def render_fwd(p):
+    L.check(L.lib().eg3d_render_fwd(C.byref(p), L.stream_ptr()), 'render_fwd')
+
+
+def render_finalize(depth, minmax):
+    L.check(L.lib().eg3d_render_finalize(L.ptr(depth), L.ptr(minmax), depth.numel(), L.stream_ptr()), 'render_finalize')
+
+
+def render_bwd(p, d_rgb, d_depth, d_wsum, d_planes, d_origins, d_dirs, dumps=None):
+    bp = L.RenderBwdParams()
+    bp.fwd = p
+    bp.depth_out = None
+    bp.d_rgb = d_rgb.data_ptr()
+    bp.d_depth = d_depth.data_ptr() if d_depth is not None else None
+    bp.d_wsum = d_wsum.data_ptr() if d_wsum is not None else None
+    bp.d_planes = d_planes.data_ptr() if d_planes is not None else None
+    bp.d_origins = d_origins.data_ptr() if d_origins is not None else None
+    bp.d_dirs = d_dirs.data_ptr() if d_dirs is not None else None
+    if dumps is not None:
+        bp.dump_dpre, bp.dump_h, bp.dump_dout, bp.dump_feat = [t.data_ptr() for t in dumps]
+    L.check(L.lib().eg3d_render_bwd(C.byref(bp), L.stream_ptr()), 'render_bwd')
+
+
+def sample_decode(p, coords, M):
+    n = p.N
+    rgb = torch.empty((n, M, p.Cout), dtype=torch.float32, device=coords.device)
+    sigma = torch.empty((n, M, 1), dtype=torch.float32, device=coords.device)
+    L.check(L.lib().eg3d_sample_decode(C.byref(p), L.ptr(coords), M, L.ptr(rgb), L.ptr(sigma), L.stream_ptr()), 'sample_decode')
+    return rgb, sigma

@@ -1,0 +1,193 @@
+"""conv2d / conv_transpose2d with the reference's conv2d_gradfix surface (torch_utils/ops/conv2d_gradfix.py:23-45,
+flags `enabled`, `weight_gradients_disabled`, context manager `no_weight_gradients`), executed by the fp32-MFMA implicit
+GEMM of libeg3d_hip.so.  Forward, data gradient (the opposite-transpose op, :139-143) and weight gradient (:166-173) are
+three launches of the same family; gradients of gradients re-enter these Functions.
+
+Supported: fp32, groups == 1, dilation == 1, kernel <= 3x3, conv2d stride 1 with symmetric padding,
+conv_transpose2d stride 1|2 with symmetric padding (cropping), channel counts that are multiples of 4 on the contraction
+side.  Anything else raises NotImplementedError -- there is no silent fallback."""
+import contextlib
+
+import torch
+
+from ... import _lib as L
+from ... import hipops as H
+
+enabled = False                      # kept for API parity; this implementation is always the one used on GPU tensors
+weight_gradients_disabled = False
+
+
+@contextlib.contextmanager
+def no_weight_gradients(disable=True):
+    global weight_gradients_disabled
+    old = weight_gradients_disabled
+    if disable:
+        weight_gradients_disabled = True
+    yield
+    weight_gradients_disabled = old
+
+
+def _pair(v):
+    return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+def _pad_c4(t):
+    """Pad the channel dim of an NCHW-shaped tensor with zeros to a multiple of 4 (16-byte pixels)."""
+    c = t.shape[1]
+    if c % 4 == 0:
+        return t
+    return torch.cat([t, t.new_zeros(t.shape[0], 4 - c % 4, *t.shape[2:])], 1)
+
+
+class _ConvFn(torch.autograd.Function):
+    """mode 'corr': y = correlate(x, w) stride 1, padding p.   mode 'convT': y = conv_transpose(x, w^T-layout [I,O,kh,kw]) stride up."""
+
+    @staticmethod
+    def forward(ctx, x, w, mode, up, pad, flip_taps):
+        L.require_cuda(x, w)
+        if x.dtype != torch.float32:
+            raise NotImplementedError('eg3d conv kernels are fp32')
+        xin = H.to_cl(_pad_c4(x))
+        N, Cip, Hi, Wi = xin.shape
+        if mode == 'corr':
+            Co, Ci, kh, kw = w.shape
+            wfull = w
+        else:
+            Ci, Co, kh, kw = w.shape
+            wfull = w.transpose(0, 1)                  # [O,I,kh,kw] view: out[o, up*a+ky] += x[i,a] * w[i,o,ky]
+        if Cip != Ci:
+            wfull = torch.cat([wfull, wfull.new_zeros(Co, Cip - Ci, kh, kw)], 1)
+        wf = H.pack_weight_fwd(wfull)
+        Cop = (Co + 3) // 4 * 4
+        if mode == 'corr':
+            Ho, Wo = Hi + 2 * pad[0] - kh + 1, Wi + 2 * pad[1] - kw + 1
+            if pad[0] != pad[1]:
+                raise NotImplementedError('asymmetric conv padding')
+            cls = H.classes_corr(Ho, Wo, kh, kw, pad[0], flip_taps)
+            out = (H.zeros_cl if Cop != Co else H.empty_cl)(N, Cop, Ho, Wo, x.device)
+            H.conv_igemm(xin, wf, Cip, Co, out, cls, epi=L.EPI_STORE)
+        else:
+            cls, Ho, Wo = H.classes_convT(Hi, Wi, kh, kw, up, flip_taps)
+            out = H.zeros_cl(N, Cop, Ho, Wo, x.device)       # phases without taps (k < up) stay zero
+            H.conv_igemm(xin, wf, Cip, Co, out, cls, out_stride=up, epi=L.EPI_STORE)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (mode, up, pad, flip_taps, Co, Ci)
+        y = out[:, :Co] if Cop != Co else out
+        if mode == 'convT' and (pad[0] or pad[1]):
+            y = y[:, :, pad[0]: y.shape[2] - pad[0], pad[1]: y.shape[3] - pad[1]]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        mode, up, pad, flip_taps, Co, Ci = ctx.cfg
+        dx = dw = None
+        if mode == 'convT' and (pad[0] or pad[1]):
+            dy = torch.nn.functional.pad(dy, [pad[1], pad[1], pad[0], pad[0]])
+        if ctx.needs_input_grad[0]:
+            dx = _ConvDataGradFn.apply(dy, w, mode, up, pad, flip_taps, x.shape)
+        if ctx.needs_input_grad[1] and not weight_gradients_disabled:
+            dw = _ConvWeightGradFn.apply(dy, x, mode, up, pad, flip_taps, w.shape)
+        return dx, dw, None, None, None, None
+
+
+class _ConvDataGradFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, w, mode, up, pad, flip_taps, x_shape):
+        g = H.to_cl(_pad_c4(dy.float()))
+        N, Cgp, Hg, Wg = g.shape
+        _, Ci, Hi, Wi = x_shape
+        if mode == 'corr':
+            Co, _, kh, kw = w.shape
+            wfull = w
+        else:
+            _, Co, kh, kw = w.shape
+            wfull = w.transpose(0, 1)
+        if Cgp != Co:
+            wfull = torch.cat([wfull, wfull.new_zeros(Cgp - Co, Ci, kh, kw)], 0)
+        wa = H.pack_weight_adj(wfull)                   # [Ci, taps*Cgp]
+        Cip = (Ci + 3) // 4 * 4
+        dx = (H.zeros_cl if Cip != Ci else H.empty_cl)(N, Cip, Hi, Wi, dy.device)
+        if mode == 'corr':
+            cls = H.classes_corr_adjoint(Hi, Wi, kh, kw, pad[0], flip_taps)
+            H.conv_igemm(g, wa, Cgp, Ci, dx, cls, epi=L.EPI_STORE)
+        else:
+            cls = H.classes_convT_adjoint(Hi, Wi, kh, kw, up, flip_taps)
+            H.conv_igemm(g, wa, Cgp, Ci, dx, cls, in_stride=up, epi=L.EPI_STORE)
+        ctx.save_for_backward(dy, w)
+        ctx.cfg = (mode, up, pad, flip_taps, x_shape)
+        return dx[:, :Ci] if Cip != Ci else dx
+
+    @staticmethod
+    def backward(ctx, d_dx):
+        dy, w = ctx.saved_tensors
+        mode, up, pad, flip_taps, x_shape = ctx.cfg
+        d_dy = d_w = None
+        if ctx.needs_input_grad[0]:
+            y = _ConvFn.apply(d_dx, w, mode, up, (0, 0) if mode == 'convT' else pad, flip_taps)
+            d_dy = y
+        if ctx.needs_input_grad[1] and not weight_gradients_disabled:
+            d_w = _ConvWeightGradFn.apply(dy, d_dx, mode, up, pad, flip_taps, w.shape)
+        return d_dy, d_w, None, None, None, None, None
+
+
+class _ConvWeightGradFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, x, mode, up, pad, flip_taps, w_shape):
+        g = H.to_cl(_pad_c4(dy.float()))
+        xin = H.to_cl(_pad_c4(x.float()))
+        N, Cip, Hi, Wi = xin.shape
+        if mode == 'corr':
+            Co, Ci, kh, kw = w_shape
+            cls = H.classes_corr(g.shape[2], g.shape[3], kh, kw, pad[0], flip_taps)
+            out_stride = 1
+        else:
+            Ci, Co, kh, kw = w_shape
+            cls = H.classes_convT(Hi, Wi, kh, kw, up, flip_taps)[0]
+            out_stride = up
+        dwp = torch.zeros((Co, kh * kw * Cip), device=dy.device)
+        H.conv_wgrad(xin, g, Cip, Co, dwp, cls, in_stride=1, out_stride=out_stride)
+        dw = dwp.view(Co, kh, kw, Cip)[..., :Ci].permute(0, 3, 1, 2)          # [O,I,kh,kw]
+        if mode == 'convT':
+            dw = dw.transpose(0, 1)
+        ctx.save_for_backward(dy, x)
+        ctx.cfg = (mode, up, pad, flip_taps, w_shape)
+        return dw.contiguous()
+
+    @staticmethod
+    def backward(ctx, d_dw):
+        dy, x = ctx.saved_tensors
+        mode, up, pad, flip_taps, w_shape = ctx.cfg
+        d_dy = d_x = None
+        if ctx.needs_input_grad[0]:
+            y = _ConvFn.apply(x, d_dw, mode, up, (0, 0) if mode == 'convT' else pad, flip_taps)
+            d_dy = y
+        if ctx.needs_input_grad[1]:
+            d_x = _ConvDataGradFn.apply(dy, d_dw, mode, up, pad, flip_taps, x.shape)
+        return d_dy, d_x, None, None, None, None, None
+
+
+def _check(weight, stride, dilation, groups):
+    if groups != 1:
+        raise NotImplementedError('grouped convolution: the MI355X path shares weights across the batch instead (see fused.ModConvLayerFn)')
+    if _pair(dilation) != (1, 1):
+        raise NotImplementedError('dilated convolution')
+    if weight.shape[2] * weight.shape[3] > 9:
+        raise NotImplementedError('kernels larger than 9 taps')
+
+
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, _flip_taps=False):
+    _check(weight, stride, dilation, groups)
+    if _pair(stride) != (1, 1):
+        raise NotImplementedError('strided conv2d (only used by the discriminator / down-sampling path)')
+    y = _ConvFn.apply(input, weight, 'corr', 1, _pair(padding), _flip_taps)
+    return y if bias is None else y + bias.reshape(1, -1, 1, 1)
+
+
+def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1, _flip_taps=False):
+    _check(weight, stride, dilation, groups)
+    s = _pair(stride)
+    if s[0] != s[1] or _pair(output_padding) != (0, 0):
+        raise NotImplementedError('anisotropic stride / output_padding')
+    y = _ConvFn.apply(input, weight, 'convT', s[0], _pair(padding), _flip_taps)
+    return y if bias is None else y + bias.reshape(1, -1, 1, 1)

@@ -1,0 +1,35 @@
+"""Super-resolution head (reference: training/superresolution.py:262-290, SuperresolutionHybrid8XDC).
+Two SynthesisBlocks 32->256 @256^2 and 256->128 @512^2 on the fused gfx950 ops; the 3-channel image is carried padded
+to 4 channels (16-byte pixels) and sliced at the end."""
+import torch
+
+from .. import hipops as H
+from .networks_stylegan2 import SynthesisBlock
+
+
+class SuperresolutionHybrid8XDC(torch.nn.Module):
+    def __init__(self, channels, img_resolution, sr_num_fp16_res, sr_antialias, num_fp16_res=4, conv_clamp=None, channel_base=None,
+                 channel_max=None, sr_widths=(256, 128), input_resolution=128, **block_kwargs):
+        super().__init__()
+        assert img_resolution == input_resolution * 4
+        use_fp16 = sr_num_fp16_res > 0
+        self.input_resolution = input_resolution
+        self.sr_antialias = sr_antialias
+        clamp = 256 if use_fp16 else None
+        c0, c1 = sr_widths
+        self.block0 = SynthesisBlock(channels, c0, w_dim=block_kwargs.pop('w_dim', 512), resolution=input_resolution * 2, img_channels=3,
+                                     is_last=False, use_fp16=use_fp16, conv_clamp=clamp, **block_kwargs)
+        self.block1 = SynthesisBlock(c0, c1, w_dim=self.block0.w_dim, resolution=input_resolution * 4, img_channels=3, is_last=True,
+                                     use_fp16=use_fp16, conv_clamp=clamp, **block_kwargs)
+
+    def forward(self, rgb, x, ws, noise_inject=None, **block_kwargs):
+        ws = ws[:, -1:, :].repeat(1, 3, 1)
+        if x.shape[-1] != self.input_resolution:
+            size = (self.input_resolution, self.input_resolution)
+            x = torch.nn.functional.interpolate(x, size=size, mode='bilinear', align_corners=False, antialias=self.sr_antialias)
+            rgb = torch.nn.functional.interpolate(rgb, size=size, mode='bilinear', align_corners=False, antialias=self.sr_antialias)
+        n, _, h, w = rgb.shape
+        rgb4 = torch.cat([rgb, rgb.new_zeros(n, 1, h, w)], 1).contiguous(memory_format=torch.channels_last)
+        x, rgb4 = self.block0(x, rgb4, ws, noise_inject=noise_inject, _name='superresolution.block0', **block_kwargs)
+        x, rgb4 = self.block1(x, rgb4, ws, noise_inject=noise_inject, _name='superresolution.block1', **block_kwargs)
+        return rgb4[:, :3].contiguous()

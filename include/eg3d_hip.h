@@ -1,0 +1,262 @@
+/*
+ * eg3d_hip.h -- C-ABI of libeg3d_hip.so: the MI355X (gfx950) native hot path of EG3D inversion
+ * (TriPlaneGenerator.synthesis forward + backward).  Drop-in boundary for the reference's three JIT-built
+ * pybind11 CUDA plugins and for the ATen/cuDNN kernels under G.synthesis.
+ *
+ * Conventions:
+ *   - extern "C", plain device pointers + sizes; no torch / C++ types cross the boundary.
+ *   - every entry takes the hipStream_t to launch on (as void*), allocates nothing (the caller owns all
+ *     buffers, including workspaces), keeps no global mutable state (re-entrant, multi-stream safe).
+ *   - return value: 0 = ok, <0 = invalid argument / unsupported configuration (EG3D_ERR_*),
+ *     >0 = hipError_t of a failed launch.  No exceptions.
+ *   - tensors are fp32 unless a `dtype` argument says otherwise (EG3D_F32 / EG3D_F16 / EG3D_F64).
+ *   - activations on the fused path are NHWC ("channels_last"): element (n,y,x,c) at ((n*H+y)*W+x)*ld + c.
+ *
+ * Each group cites the reference interface it replaces (paths relative to the reference repo root).
+ */
+#ifndef EG3D_HIP_H
+#define EG3D_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EG3D_OK 0
+#define EG3D_ERR_INVALID (-1)      /* bad argument (null pointer, negative size, ...) */
+#define EG3D_ERR_UNSUPPORTED (-2)  /* valid request this build has no kernel for        */
+#define EG3D_ERR_TOO_LARGE (-3)    /* exceeds int32 indexing, as the reference checks   */
+
+#define EG3D_F32 0
+#define EG3D_F16 1
+#define EG3D_F64 2
+
+/* activation ids == the reference's cuda_idx (torch_utils/ops/bias_act.py:23-33) */
+#define EG3D_ACT_LINEAR 1
+#define EG3D_ACT_RELU 2
+#define EG3D_ACT_LRELU 3
+#define EG3D_ACT_TANH 4
+#define EG3D_ACT_SIGMOID 5
+#define EG3D_ACT_ELU 6
+#define EG3D_ACT_SELU 7
+#define EG3D_ACT_SOFTPLUS 8
+#define EG3D_ACT_SWISH 9
+
+int eg3d_abi_version(void);
+const char* eg3d_status_string(int status);
+
+/* ------------------------------------------------------------------------------------------------
+ * bias_act -- replaces bias_act_plugin.bias_act(x,b,xref,yref,dy,grad,dim,act,alpha,gain,clamp)
+ *   torch_utils/ops/bias_act.cpp:36-94 (host), bias_act.cu:27-151 (kernel), bound at bias_act.cpp:100.
+ *   grad=0: y = clamp(act(x + b[(i/step_b) % size_b]) * gain)
+ *   grad=1: x := incoming dy; y = dx  (uses yref, or xref+b for swish); zero where |yref| >= clamp
+ *   grad=2: x := incoming d_dx; `dy` = first-order dy; y = d_x (2nd-order term)
+ *   Any dense layout: flat index, bias index from step_b = x.stride(dim)  (bias_act.cpp:77).
+ *   Null pointers stand for the reference's empty tensors.  clamp < 0 disables clamping.
+ */
+int eg3d_bias_act(const void* x, const void* b, const void* xref, const void* yref, const void* dy, void* y,
+                  int dtype, int64_t numel, int size_b, int step_b, int grad, int act, float alpha, float gain,
+                  float clamp, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * upfirdn2d -- replaces upfirdn2d_plugin.upfirdn2d(x,f,upx,upy,downx,downy,padx0,padx1,pady0,pady1,flip,gain)
+ *   torch_utils/ops/upfirdn2d.cpp:20-102 (host), upfirdn2d.cu:33-204 (kernels), bound at upfirdn2d.cpp:108.
+ *   x: [N,C,inH,inW] with arbitrary element strides xs[4] (NCHW or channels_last); f: fp32 [fH,fW] contiguous;
+ *   y: [N,C,outH,outW] with strides ys[4];  outW = (inW*upx + padx0 + padx1 - fW + downx) / downx.
+ *   Backward w.r.t. x is the same entry with up<->down, !flip and the padding of upfirdn2d.py:258-268.
+ */
+int eg3d_upfirdn2d(const void* x, const float* f, void* y, int dtype, int N, int C, int inH, int inW,
+                   const int64_t xs[4], int fH, int fW, int upx, int upy, int downx, int downy, int padx0,
+                   int padx1, int pady0, int pady1, int flip, float gain, int outH, int outW,
+                   const int64_t ys[4], void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32) -- replaces the ATen/cuDNN calls made by
+ * conv2d_resample / modulated_conv2d (torch_utils/ops/conv2d_resample.py:31-43,114-136;
+ * training/networks_stylegan2.py:34-91) and their autograd backward (the dX contract of
+ * torch_utils/ops/conv2d_gradfix.py:139-143).  One launch computes, for every output-grid cell (n,ay,ax):
+ *     acc[n,ay,ax,o] = sum_t sum_k  in_scale[n,k] * x[n, ay*in_stride+dy[t], ax*in_stride+dx[t], k] * w[o, wtap[t], k]
+ * and applies one of the epilogues below at out[n, ay*out_stride+out_py, ax*out_stride+out_px, o].
+ * The tap list expresses: 3x3 / 1x1 correlation (forward), the four parity classes of a stride-2 transposed
+ * conv (forward of up=2 layers), the stride-2 correlation (their data gradient) and the flipped 3x3 (data gradient
+ * of plain layers).  Up to 4 classes (tap lists + output grids) run in one launch.
+ */
+#define EG3D_EPI_STORE 0   /* out = acc                                                                  */
+#define EG3D_EPI_ATOMIC 1  /* out += acc  (split-K; out must be pre-zeroed)                               */
+#define EG3D_EPI_FWD 2     /* out = clamp(act(acc*out_scale[n,o] + noise[n,y,x]*strength + bias[o])*gain) (+ addend) */
+#define EG3D_EPI_BWD 3     /* ds[n,o] += sum_px acc*xin ; out = acc*out_scale[n,o] (+ addend)             */
+
+typedef struct eg3d_conv_class {
+    int32_t Ha, Wa;            /* output grid of this class                              */
+    int32_t out_py, out_px;    /* output pixel = (ay*out_stride + out_py, ax*out_stride + out_px) */
+    int32_t ntaps;
+    int32_t dy[9], dx[9];      /* input pixel  = (ay*in_stride + dy[t], ax*in_stride + dx[t]); OOB reads are zero */
+    int32_t wtap[9];           /* weight tap index of tap t                              */
+} eg3d_conv_class;
+
+typedef struct eg3d_conv_params {
+    const float* x;            /* [N,Hi,Wi,ldx] NHWC, Ck used channels                   */
+    const float* w;            /* w[o*w_row + tap*Ck + k]                                */
+    float* out;                /* [N,Ho,Wo,ldo] NHWC, Nc used channels                   */
+    int32_t N, Hi, Wi, Ck, ldx;
+    int32_t Nc, w_row;
+    int32_t Ho, Wo, ldo;
+    int32_t in_stride, out_stride;
+    int32_t ncls;
+    eg3d_conv_class cls[4];
+    const float* in_scale;     /* [N,Ck] or null                                         */
+    int32_t epi;
+    int32_t ksplit;            /* >=1; >1 only with EG3D_EPI_ATOMIC                      */
+    const float* out_scale;    /* [N,Nc] or null                                         */
+    const float* bias;         /* [Nc] or null                                           */
+    const float* noise;        /* [*,Ho,Wo] or null; batch stride noise_nstride (0 = shared) */
+    int64_t noise_nstride;
+    const float* noise_strength; /* device scalar (may be null when noise is null)       */
+    int32_t act;
+    float alpha, gain, clamp;
+    const float* addend;       /* [N,Ho,Wo,ldo] or null; may alias out                   */
+    const float* xin;          /* EPI_BWD: [N,Ho,Wo,ldo] layer input for the style-gradient reduction, or null */
+    float* ds;                 /* EPI_BWD: [N,Nc] accumulated with atomics (pre-zeroed), or null */
+} eg3d_conv_params;
+
+int eg3d_conv2d_igemm_f32(const eg3d_conv_params* p, void* stream);
+
+/* Weight-gradient GEMM (PTI phase: grads into generator weights, training/coaches/base_coach.py:96-99):
+ *   dw[o, wtap[t], k] += sum_{n,ay,ax} g[n, ay*out_stride+out_py, ax*out_stride+out_px, o]
+ *                                       * in_scale[n,k] * x[n, ay*in_stride+dy[t], ax*in_stride+dx[t], k]
+ * Same class/tap description as the forward; dw must be pre-zeroed (split over pixels with atomics). */
+typedef struct eg3d_wgrad_params {
+    const float* x;  const float* g;  float* dw;
+    int32_t N, Hi, Wi, Ck, ldx;
+    int32_t Nc, w_row;
+    int32_t Ho, Wo, ldg;
+    int32_t in_stride, out_stride;
+    int32_t ncls;
+    eg3d_conv_class cls[4];
+    const float* in_scale;     /* [N,Ck] or null */
+    int32_t psplit;            /* number of pixel slices */
+} eg3d_wgrad_params;
+
+int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Layer epilogues (NHWC fp32) -- the fused replacement of upfirdn2d + noise add + bias_act after a modulated
+ * conv (training/networks_stylegan2.py:87-90,327-329; conv2d_resample.py:129) and of its backward.
+ *
+ * fwd: out[n,y,x,c] = clamp(act( FIR(z)[n,y,x,c] * d[n,c] + noise[n,y,x]*strength + bias[c] ) * gain)
+ *      FIR: fir==null -> identity (z is [N,H,W,C]); else a (fh x fw) filter applied with padding pad0 (top/left) on
+ *      z [N,Hz,Wz,C] and multiplied by fir_gain (the on-path case: 4x4, pad 1, gain 4, Hz = H+1).
+ */
+int eg3d_modconv_epilogue_fwd(const float* z, float* out, int N, int H, int W, int C, int Hz, int Wz,
+                              const float* fir, int fh, int fw, int pad0, float fir_gain, const float* d,
+                              const float* noise, int64_t noise_nstride, const float* noise_strength,
+                              const float* bias, int act, float alpha, float gain, float clamp, void* stream);
+
+/* bwd: given dout and the saved layer output `out`:
+ *      dy = dout * act'(out) * gain   (0 where |out| >= clamp; derivative keyed on the OUTPUT as bias_act.cu:76,145)
+ *      dz[n,y,x,c] = dy * d[n,c]                    (written; d==null -> dy)
+ *      dbias[c]   += sum dy                         (if dbias)
+ *      dd[n,c]    += sum_px dy * (pre_act - bias[c] - noise*strength)   (if dd; pre_act recovered from out)
+ *      dnoise[n?,y,x] += strength * sum_c dy        (if dnoise; batch stride dnoise_nstride, 0 = shared buffer)
+ *      dstrength  += sum dy * noise                 (if dstrength)
+ *   All reduction targets must be pre-zeroed; they are accumulated with atomics. */
+int eg3d_modconv_epilogue_bwd(const float* dout, const float* out, float* dz, int N, int H, int W, int C,
+                              const float* d, const float* noise, int64_t noise_nstride,
+                              const float* noise_strength, const float* bias, int act, float alpha, float gain,
+                              float clamp, float* dbias, float* dd, float* dnoise, int64_t dnoise_nstride,
+                              float* dstrength, void* stream);
+
+/* NHWC FIR resampler used on the fused path (skip-image 2x upsample and its adjoint, FIR adjoint of up=2 layers):
+ *   same arithmetic as eg3d_upfirdn2d on a channels-last fp32 tensor, float4 over channels (C % 4 == 0),
+ *   optional accumulate into y (y += result). */
+int eg3d_upfirdn2d_nhwc(const float* x, const float* f, float* y, int N, int C, int inH, int inW, int fH, int fW,
+                        int up, int down, int padx0, int padx1, int pady0, int pady1, int flip, float gain,
+                        int outH, int outW, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Style / demodulation helpers (training/networks_stylegan2.py:62-67,303,315,354):
+ *   wsq[o,k]   = sum_taps w[o,tap,k]^2                               (once per weight update)
+ *   demod fwd:  d[n,o] = rsqrt( sum_k s[n,k]^2 * wsq[o,k] + 1e-8 )
+ *   demod bwd:  ds[n,k] += sum_o dd[n,o] * ( -d[n,o]^3 * s[n,k] * wsq[o,k] )
+ *               dwsq[o,k] += sum_n dd[n,o] * ( -0.5 * d[n,o]^3 * s[n,k]^2 )       (if dwsq)
+ */
+int eg3d_weight_sqsum(const float* w, float* wsq, int Co, int ntaps, int Ck, void* stream);
+int eg3d_demod_fwd(const float* s, const float* wsq, float* d, int N, int Co, int Ck, void* stream);
+int eg3d_demod_bwd(const float* s, const float* wsq, const float* d, const float* dd, float* ds, float* dwsq,
+                   int N, int Co, int Ck, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Volume renderer -- replaces RaySampler.forward (training/volumetric_rendering/ray_sampler.py:24-73) and
+ * ImportanceRenderer.forward (renderer.py:143-195: sample_stratified, sample_from_planes/grid_sample, OSGDecoder
+ * triplane.py:124-136, MipRayMarcher2 ray_marcher.py:25-57, sample_importance/sample_pdf, unify_samples), fused
+ * per ray; nothing but the final per-ray outputs is materialised.
+ */
+int eg3d_ray_gen_fwd(const float* cam2world, const float* intrinsics, float* origins, float* dirs, int N, int res,
+                     void* stream);
+/* d_cam2world [N,16], d_intrinsics [N,9] (may be null) are overwritten. */
+int eg3d_ray_gen_bwd(const float* cam2world, const float* intrinsics, const float* d_origins, const float* d_dirs,
+                     float* d_cam2world, float* d_intrinsics, int N, int res, void* stream);
+
+typedef struct eg3d_render_params {
+    const float* planes;       /* [N,Hp,Wp,ldp] NHWC; plane p = channels [p*C, (p+1)*C)    */
+    int32_t N, Hp, Wp, ldp, C; /* C = 32 features per plane                                */
+    const float* origins;      /* [N,R,3]                                                  */
+    const float* dirs;         /* [N,R,3]                                                  */
+    int32_t R;                 /* rays per image                                           */
+    const float* u1;           /* [N,R,Dc] stratified jitter in [0,1)                      */
+    const float* u2;           /* [N*R,Df] importance uniforms                             */
+    int32_t Dc, Df;            /* coarse / fine samples per ray (Df may be 0)              */
+    float ray_start, ray_end;  /* used when ray_limits == null                             */
+    const float* ray_limits;   /* [N,R,2] per-ray (start,end) for the 'auto' mode, or null */
+    int32_t disparity;         /* disparity_space_sampling                                 */
+    float box_warp;
+    int32_t white_back;
+    /* decoder (OSGDecoder): runtime gains already folded in by the caller */
+    const float* w0;           /* [H,C]   = net.0.weight * lr_mul/sqrt(C)                  */
+    const float* b0;           /* [H]     = net.0.bias * lr_mul                            */
+    const float* w1;           /* [H,1+Cout] = (net.2.weight * lr_mul/sqrt(H))^T  (transposed) */
+    const float* b1;           /* [1+Cout]                                                 */
+    int32_t Hdim, Cout;        /* 64, 32                                                   */
+    /* outputs */
+    float* rgb;                /* [N,R,Cout]                                               */
+    float* depth;              /* [N,R]  (unclamped; NaN kept -- finalize clamps)          */
+    float* wsum;               /* [N,R]                                                    */
+    float* depth_minmax;       /* [2] running global (min,max) of all sample depths; init (+inf,-inf) */
+    float* fine_depths;        /* [N,R,Df] workspace: importance depths (re-used by backward)*/
+} eg3d_render_params;
+
+int eg3d_render_fwd(const eg3d_render_params* p, void* stream);
+/* depth <- clamp(nan_to_num(depth, inf), min, max) with the global min/max (ray_marcher.py:49-50). */
+int eg3d_render_finalize(float* depth, const float* depth_minmax, int64_t n, void* stream);
+
+typedef struct eg3d_render_bwd_params {
+    eg3d_render_params fwd;    /* same inputs as the forward (fine_depths filled by it)     */
+    const float* depth_out;    /* [N,R] finalized depth (to know which rays were clamped)   */
+    const float* d_rgb;        /* [N,R,Cout]                                               */
+    const float* d_depth;      /* [N,R] or null                                            */
+    const float* d_wsum;       /* [N,R] or null                                            */
+    float* d_planes;           /* [N,Hp,Wp,ldp] pre-zeroed, accumulated with atomics, or null */
+    float* d_origins;          /* [N,R,3] overwritten, or null                             */
+    float* d_dirs;             /* [N,R,3] overwritten, or null                             */
+    /* Decoder-weight gradients (PTI phase): when non-null the kernel dumps, for sample row
+     * ((n*R + ray)*2 + pass)*D + s  (pass 0 = coarse, 1 = fine, D = max(Dc,Df); rows of absent samples untouched, so
+     * pre-zero the buffers), the four GEMM operands; the caller contracts them with a library GEMM:
+     *   d_w0 = dump_dpre^T @ dump_feat,  d_b0 = colsum(dump_dpre),  d_w1t = dump_h^T @ dump_dout,  d_b1 = colsum(dump_dout) */
+    float* dump_dpre;          /* [S,64]  */
+    float* dump_h;             /* [S,64]  */
+    float* dump_dout;          /* [S,33]  */
+    float* dump_feat;          /* [S,32]  */
+} eg3d_render_bwd_params;
+
+int eg3d_render_bwd(const eg3d_render_bwd_params* p, void* stream);
+
+/* Decoder-only query (ImportanceRenderer.run_model, renderer.py:197-203; used for density grids):
+ *   coords [N,M,3] -> rgb [N,M,Cout], sigma [N,M]. */
+int eg3d_sample_decode(const eg3d_render_params* p, const float* coords, int64_t M, float* rgb, float* sigma,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EG3D_HIP_H */

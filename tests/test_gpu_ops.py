@@ -1,0 +1,399 @@
+"""GPU parity tests (run with `-m gpu` on the MI355X box): every HIP entry point, through the C-ABI, against
+(a) the golden vectors recorded from the imported reference and (b) the CPU oracle on seeded inputs.
+Tolerances: fp32 op level 1e-5; reductions over many elements get a looser relative bound."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import eg3d_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def t(a, dev=DEV):
+    return torch.from_numpy(np.asarray(a)).to(dev)
+
+
+def close(a, b, tol, what=''):
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert torch.isfinite(a).all(), f'{what}: non-finite values'
+    scale = max(1.0, float(b.abs().max())) if b.numel() else 1.0
+    err = float((a - b).abs().max()) if a.numel() else 0.0
+    assert err <= tol * scale, f'{what}: err {err:.3e} > {tol} * {scale:.3e}'
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from inv3d_amd.torch_utils.ops import bias_act, upfirdn2d, conv2d_resample
+    return dict(bias_act=bias_act, upfirdn2d=upfirdn2d, conv2d_resample=conv2d_resample)
+
+
+# ------------------------------------------------------------------------------------------------- bias_act
+def test_bias_act_golden(golden, ops):
+    d = golden('bias_act')
+    ba = ops['bias_act']
+    for i in range(int(d['ncases'])):
+        k = f'c{i}'
+        dim, clamp, gain, alpha = d[f'{k}_meta']
+        act = str(d[f'{k}_act'])
+        kw = dict(dim=int(dim), act=act, alpha=None if alpha < 0 else float(alpha), gain=None if gain < 0 else float(gain),
+                  clamp=None if clamp < 0 else float(clamp))
+        x = t(d[f'{k}_x']).requires_grad_(True)
+        b = t(d[f'{k}_b']).requires_grad_(True)
+        y = ba.bias_act(x, b, **kw)
+        close(y, d[f'{k}_y'], 1e-5, f'bias_act {act} fwd')
+        dx, db = torch.autograd.grad(y, [x, b], t(d[f'{k}_dy']))
+        close(dx, d[f'{k}_dx'], 1e-5, f'bias_act {act} dx')
+        close(db, d[f'{k}_db'], 1e-4, f'bias_act {act} db')
+
+
+@pytest.mark.parametrize('act', ['tanh', 'sigmoid', 'elu', 'selu', 'softplus', 'swish', 'lrelu'])
+def test_bias_act_second_order(ops, act):
+    """grad=2 kernel vs double-backward of the oracle."""
+    ba = ops['bias_act']
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8, 5, 5, generator=g)
+    b = torch.randn(8, generator=g)
+    dy = torch.randn(2, 8, 5, 5, generator=g)
+    v = torch.randn(2, 8, 5, 5, generator=g)
+
+    def run(fn, dev):
+        xx, bb = x.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        dyy = dy.to(dev).requires_grad_(True)
+        y = fn(xx, bb)
+        dx, = torch.autograd.grad(y, xx, dyy, create_graph=True)
+        gx, gdy = torch.autograd.grad(dx, [xx, dyy], v.to(dev), allow_unused=True)
+        return dx, (gx if gx is not None else torch.zeros_like(xx)), gdy
+    ref = run(lambda a, c: O.bias_act(a, c, act=act, gain=1.3), 'cpu')
+    got = run(lambda a, c: ba.bias_act(a, c, act=act, gain=1.3), DEV)
+    for r, h, nm in zip(ref, got, ('dx', 'd2x', 'd_dy')):
+        close(h, r, 2e-5, f'{act} {nm}')
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.float64])
+@pytest.mark.parametrize('cl', [False, True])
+def test_bias_act_dtypes_layouts(ops, dtype, cl):
+    ba = ops['bias_act']
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 6, 7, 5, generator=g)
+    b = torch.randn(6, generator=g)
+    ref = O.bias_act(x.double(), b.double(), act='lrelu', clamp=1.5)
+    xg = x.to(DEV, dtype)
+    if cl:
+        xg = xg.contiguous(memory_format=torch.channels_last)
+    y = ba.bias_act(xg, b.to(DEV, dtype), act='lrelu', clamp=1.5)
+    assert y.dtype == dtype and y.stride() == xg.stride()
+    close(y.double(), ref, 2e-3 if dtype == torch.float16 else 1e-12, 'bias_act dtype')
+
+
+def test_bias_act_large_vectorised(ops):
+    ba = ops['bias_act']
+    x = torch.randn(1, 128, 96, 96, device=DEV)
+    b = torch.randn(128, device=DEV)
+    for xx in (x, x.contiguous(memory_format=torch.channels_last)):
+        y = ba.bias_act(xx, b, act='lrelu', clamp=256)
+        ref = O.bias_act(xx.cpu(), b.cpu(), act='lrelu', clamp=256)
+        close(y, ref, 1e-6, 'bias_act large')
+
+
+# ------------------------------------------------------------------------------------------------- upfirdn2d
+def test_upfirdn2d_golden(golden, ops):
+    d = golden('upfirdn2d')
+    up = ops['upfirdn2d']
+    for i in range(int(d['ncases'])):
+        k = f'c{i}'
+        m = d[f'{k}_meta']
+        f = t(d[f'{k}_f'])
+        f = None if f.numel() == 0 else f
+        for cl in (False, True):
+            x = t(d[f'{k}_x'])
+            if cl:
+                x = x.contiguous(memory_format=torch.channels_last)
+            x = x.requires_grad_(True)
+            y = up.upfirdn2d(x, f, up=[int(m[0]), int(m[1])], down=[int(m[2]), int(m[3])], padding=[int(v) for v in m[4:8]],
+                             flip_filter=bool(m[8]), gain=float(m[9]))
+            close(y, d[f'{k}_y'], 1e-5, f'upfirdn2d case {i} cl={cl}')
+            dx, = torch.autograd.grad(y, x, t(d[f'{k}_dy']))
+            close(dx, d[f'{k}_dx'], 1e-5, f'upfirdn2d case {i} dx')
+    x, f44 = t(d['w_x']), t(d['f44'])
+    close(up.upsample2d(x, f44), d['w_upsample2d_y'], 1e-5)
+    close(up.downsample2d(x, f44), d['w_downsample2d_y'], 1e-5)
+    close(up.filter2d(x, f44), d['w_filter2d_y'], 1e-5)
+    close(up.setup_filter([1, 3, 3, 1]), d['f44'], 1e-7)
+
+
+def test_upfirdn2d_nhwc_fused(golden):
+    """The channels-last float4 resampler used on the fused path vs the oracle (skip upsample, its adjoint, FIR adjoint)."""
+    from inv3d_amd import hipops as H
+    g = torch.Generator().manual_seed(5)
+    f = O.setup_filter([1, 3, 3, 1])
+    x = torch.randn(2, 8, 9, 7, generator=g)
+    xc = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    close(H.upfirdn2d_nhwc(xc, f.to(DEV), up=2, pad=(2, 1, 2, 1), gain=4.0), O.upfirdn2d(x, f, up=2, padding=[2, 1, 2, 1], gain=4.0), 1e-5)
+    close(H.upfirdn2d_nhwc(xc, f.to(DEV), down=2, pad=(1, 1, 1, 1), flip=True, gain=4.0),
+          O.upfirdn2d(x, f, down=2, padding=[1, 1, 1, 1], flip_filter=True, gain=4.0), 1e-5)
+    close(H.upfirdn2d_nhwc(xc, f.to(DEV), pad=(2, 2, 2, 2), flip=True, gain=4.0), O.upfirdn2d(x, f, padding=[2, 2, 2, 2], flip_filter=True, gain=4.0), 1e-5)
+
+
+# ------------------------------------------------------------------------------------------------- conv
+def test_conv2d_resample_golden(golden, ops):
+    d = golden('conv2d_resample')
+    c2r = ops['conv2d_resample']
+    f44 = t(d['f44'])
+    ran = 0
+    for i in range(int(d['ncases'])):
+        k = f'c{i}'
+        m = [int(v) for v in d[f'{k}_meta']]
+        x = t(d[f'{k}_x']).requires_grad_(True)
+        w = t(d[f'{k}_w']).requires_grad_(True)
+        kw = dict(f=f44, up=m[0], down=m[1], padding=m[2:6], groups=m[6], flip_weight=bool(m[7]))
+        try:
+            y = c2r.conv2d_resample(x, w, **kw)
+        except NotImplementedError:
+            assert m[6] > 1 or (m[1] > 1 and w.shape[-1] > 1), f'case {i} must be supported'
+            continue
+        ran += 1
+        close(y, d[f'{k}_y'], 1e-5, f'conv2d_resample case {i}')
+        dx, dw = torch.autograd.grad(y, [x, w], t(d[f'{k}_dy']))
+        close(dx, d[f'{k}_dx'], 1e-5, f'conv2d_resample case {i} dx')
+        close(dw, d[f'{k}_dw'], 1e-5, f'conv2d_resample case {i} dw')
+    assert ran >= 6
+
+
+@pytest.mark.parametrize('shape', [(1, 32, 16, 16, 64, 1), (2, 64, 8, 8, 160, 1), (1, 128, 24, 24, 128, 3), (3, 16, 5, 7, 12, 3),
+                                   (1, 512, 4, 4, 512, 3), (1, 256, 40, 40, 256, 3)])
+def test_conv_igemm_vs_torch(shape):
+    """All tile configurations / split-K of the implicit GEMM vs the oracle's F.conv2d (fp32)."""
+    from inv3d_amd import hipops as H, _lib as L
+    n, ci, h, w, co, k = shape
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, k, k, generator=g) / math.sqrt(ci * k * k)
+    ref = torch.nn.functional.conv2d(x, wt, padding=k // 2)
+    xc = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    wf = H.pack_weight_fwd(wt.to(DEV))
+    cop = (co + 3) // 4 * 4
+    for ks in (1, 3):
+        out = H.zeros_cl(n, cop, h, w, DEV)
+        H.conv_igemm(xc, wf, ci, co, out, H.classes_corr(h, w, k, k, k // 2), epi=L.EPI_ATOMIC if ks > 1 else L.EPI_STORE, ksplit=ks)
+        close(out[:, :co], ref, 2e-5, f'conv_igemm {shape} ksplit {ks}')
+
+
+def _layer_case(n, ci, co, res, up, seed, noise_kind='const', clamp=None):
+    g = torch.Generator().manual_seed(seed)
+    hin = res // up
+    P = {
+        'L.weight': torch.randn(co, ci, 3, 3, generator=g),
+        'L.bias': torch.randn(co, generator=g) * 0.1,
+        'L.affine.weight': torch.randn(ci, 32, generator=g),
+        'L.affine.bias': torch.ones(ci),
+        'L.noise_strength': torch.tensor(0.07),
+        'L.noise_const': torch.randn(res, res, generator=g),
+        'L.resample_filter': O.setup_filter([1, 3, 3, 1]),
+    }
+    x = torch.randn(n, ci, hin, hin, generator=g)
+    w = torch.randn(n, 32, generator=g)
+    dy = torch.randn(n, co, res, res, generator=g)
+    noise = torch.randn(n, 1, res, res, generator=g) if noise_kind == 'random' else None
+    return P, x, w, dy, noise
+
+
+@pytest.mark.parametrize('cfg', [(2, 16, 24, 8, 1, 'const', None), (2, 16, 24, 16, 2, 'const', None), (1, 32, 16, 16, 2, 'random', 0.9),
+                                 (1, 64, 128, 32, 1, 'none', 256.0), (1, 128, 128, 64, 2, 'const', 256.0), (3, 8, 8, 4, 1, 'const', None),
+                                 (1, 512, 512, 8, 2, 'const', None)])
+def test_synthesis_layer_fwd_bwd(cfg):
+    """Fused SynthesisLayer (conv + demod + noise + bias + lrelu + clamp) vs the oracle, all gradients."""
+    from inv3d_amd.training.networks_stylegan2 import SynthesisLayer
+    n, ci, co, res, up, noise_kind, clamp = cfg
+    P, x, w, dy, noise = _layer_case(n, ci, co, res, up, seed=(n * 131 + ci * 17 + co * 7 + res * 3 + up), noise_kind=noise_kind, clamp=clamp)
+    # oracle
+    names = ['L.weight', 'L.bias', 'L.affine.weight', 'L.affine.bias', 'L.noise_strength', 'L.noise_const']
+    Pg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in P.items()}
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = O.synthesis_layer(Pg, 'L', xr, wr, up, noise_kind, noise, clamp)
+    gr = torch.autograd.grad(yr, [xr, wr] + [Pg[k] for k in names], dy, allow_unused=True)
+    # hip
+    layer = SynthesisLayer(ci, co, w_dim=32, resolution=res, up=up, conv_clamp=clamp).to(DEV)
+    layer.load_state_dict({k[2:]: v for k, v in P.items()})
+    layer.noise_const.requires_grad_(True)
+    xg = x.to(DEV).requires_grad_(True)
+    wg = w.to(DEV).requires_grad_(True)
+    yg = layer(xg, wg, noise_mode=noise_kind, noise_inject=noise.to(DEV) if noise is not None else None)
+    close(yg, yr, 2e-5, f'layer fwd {cfg}')
+    params = [layer.weight, layer.bias, layer.affine.weight, layer.affine.bias, layer.noise_strength, layer.noise_const]
+    gg = torch.autograd.grad(yg, [xg, wg] + params, dy.to(DEV), allow_unused=True)
+    for nm, a, b in zip(['x', 'w'] + names, gg, gr):
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0, nm
+            continue
+        close(a, b, 1e-4, f'layer grad {nm} {cfg}')
+
+
+@pytest.mark.parametrize('cfg', [(2, 16, 96, 8, None, True), (1, 32, 3, 16, 256.0, True), (2, 8, 3, 4, 0.5, False)])
+def test_torgb_fwd_bwd(cfg):
+    from inv3d_amd.training.networks_stylegan2 import ToRGBLayer
+    n, ci, co, res, clamp, with_skip = cfg
+    g = torch.Generator().manual_seed(9)
+    P = {'T.weight': torch.randn(co, ci, 1, 1, generator=g), 'T.bias': torch.randn(co, generator=g) * 0.1,
+         'T.affine.weight': torch.randn(ci, 32, generator=g), 'T.affine.bias': torch.ones(ci)}
+    x = torch.randn(n, ci, res, res, generator=g)
+    w = torch.randn(n, 32, generator=g)
+    cp = (co + 3) // 4 * 4
+    skip = torch.randn(n, cp, res, res, generator=g) if with_skip else None
+    if skip is not None and cp != co:
+        skip[:, co:] = 0
+    dy = torch.randn(n, cp, res, res, generator=g)
+    names = list(P)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = O.torgb_layer(Pg, 'T', xr, wr, clamp)
+    if skip is not None:
+        sr = skip.clone().requires_grad_(True)
+        yr = yr + sr[:, :co]
+    gr = torch.autograd.grad(yr, [xr, wr] + [Pg[k] for k in names], dy[:, :co])
+    layer = ToRGBLayer(ci, co, w_dim=32, conv_clamp=clamp).to(DEV)
+    layer.load_state_dict({k[2:]: v for k, v in P.items()})
+    xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    sg = skip.to(DEV).requires_grad_(True) if skip is not None else None
+    yg = layer(xg, wg, skip=sg)
+    close(yg[:, :co], yr, 2e-5, f'torgb fwd {cfg}')
+    dyg = dy.to(DEV).clone()
+    dyg[:, co:] = 0
+    gg = torch.autograd.grad(yg, [xg, wg, layer.weight, layer.bias, layer.affine.weight, layer.affine.bias] + ([sg] if sg is not None else []), dyg)
+    for nm, a, b in zip(['x', 'w'] + names, gg, gr):
+        close(a, b, 1e-4, f'torgb grad {nm} {cfg}')
+    if sg is not None:
+        close(gg[-1][:, :co], dy[:, :co], 0, 'torgb dskip')
+
+
+# ------------------------------------------------------------------------------------------------- renderer
+def test_ray_gen_golden(golden):
+    from inv3d_amd.training.volumetric_rendering.ray_sampler import RaySampler
+    d = golden('renderer')
+    c2w = t(d['rs_c2w']).requires_grad_(True)
+    K = t(d['rs_K']).requires_grad_(True)
+    rs = RaySampler()
+    o, dr = rs(c2w, K, 8)
+    close(o, d['rs_o'], 1e-6, 'ray origins'); close(dr, d['rs_d'], 1e-6, 'ray dirs')
+    g = torch.autograd.grad([o, dr], [c2w, K], [t(d['rs_go']), t(d['rs_gd'])])
+    close(g[0], d['rs_dc2w'], 1e-5, 'd cam2world'); close(g[1], d['rs_dK'], 1e-5, 'd intrinsics')
+    close(rs.calculate_xyz_of_depth(o[:1], dr[:1], t(d['rs_depth'])[0]), d['rs_xyz'], 1e-6, 'xyz of depth')
+
+
+def _decoder(P):
+    from inv3d_amd.training.triplane import OSGDecoder
+    dec = OSGDecoder(32, {'decoder_lr_mul': 1.0, 'decoder_output_dim': 32}).to(DEV)
+    dec.load_state_dict({k[len('decoder.'):]: v for k, v in P.items() if k.startswith('decoder.')})
+    return dec
+
+
+def test_render_golden(golden):
+    """ImportanceRenderer.forward (D = 12+12) vs the reference's outputs and gradients (planes, cam2world, decoder)."""
+    from inv3d_amd.training.volumetric_rendering.renderer import ImportanceRenderer
+    from inv3d_amd.training.volumetric_rendering.ray_sampler import RaySampler
+    d = golden('renderer')
+    cfg = O.small_config()
+    P = O.synth_params(cfg, seed=5)
+    dec = _decoder(P)
+    planes = t(d['rn_planes']).requires_grad_(True)
+    c2w = t(d['rn_c2w']).requires_grad_(True)
+    o, dr = RaySampler()(c2w, t(d['rn_K']), 6)
+    R = ImportanceRenderer()
+    R.set_uniforms(t(d['rn_u1']), t(d['rn_u2']))
+    rgb, dep, ws = R(planes, dec, o, dr, cfg.rendering)
+    close(rgb, d['rn_rgb'], 1e-5, 'render rgb'); close(dep, d['rn_depth'], 1e-5, 'render depth'); close(ws, d['rn_wsum'], 1e-5, 'render wsum')
+    params = [dec.net[0].weight, dec.net[0].bias, dec.net[2].weight, dec.net[2].bias]
+    g = torch.autograd.grad([rgb, dep], [planes, c2w] + params, [t(d['rn_grgb']), t(d['rn_gdepth'])])
+    close(g[0], d['rn_dplanes'], 5e-5, 'd planes'); close(g[1], d['rn_dc2w'], 1e-4, 'd cam2world')
+    for a, k in zip(g[2:], ('rn_dw0', 'rn_db0', 'rn_dw1', 'rn_db1')):
+        close(a, d[k], 1e-4, k)
+    # 'auto' ray limits
+    R.set_uniforms(t(d['rn_u1']), t(d['rn_u2']))
+    rgb, dep, _ = R(planes, dec, o, dr, dict(cfg.rendering, ray_start='auto', ray_end='auto'))
+    close(rgb, d['rn_auto_rgb'], 1e-5, 'render auto rgb'); close(dep, d['rn_auto_depth'], 1e-5, 'render auto depth')
+
+
+@pytest.mark.parametrize('variant', ['ffhq48', 'white_back', 'disparity', 'coarse_only', 'uneven'])
+def test_render_vs_oracle(variant):
+    """48+48-sample configuration (and variants) on random planes vs the oracle, forward and gradients."""
+    from inv3d_amd.training.volumetric_rendering.renderer import ImportanceRenderer
+    cfg = O.full_config()
+    opts = dict(cfg.rendering)
+    res, n = 10, 2
+    if variant == 'white_back':
+        opts['white_back'] = True
+    if variant == 'disparity':
+        opts['disparity_space_sampling'] = True
+    if variant == 'coarse_only':
+        opts['depth_resolution_importance'] = 0
+    if variant == 'uneven':
+        opts['depth_resolution'], opts['depth_resolution_importance'] = 40, 24
+    P = O.synth_params(O.small_config(), seed=7)
+    g = torch.Generator().manual_seed(21)
+    planes = (torch.randn(n, 3, 32, 64, 64, generator=g) * 0.8)
+    cam = O.synth_cameras(n, seed=11)
+    c2w, K = cam[:, :16].reshape(n, 4, 4), cam[:, 16:].reshape(n, 3, 3)
+    o, dr = O.ray_sampler(c2w, K, res)
+    dc, df = opts['depth_resolution'], opts['depth_resolution_importance']
+    u1 = torch.rand(n, res * res, dc, 1, generator=g)
+    u2 = torch.rand(n * res * res, df, generator=g) if df else None
+    g_rgb = torch.randn(n, res * res, 32, generator=g)
+    g_dep = torch.randn(n, res * res, 1, generator=g)
+    pr, orr, drr = planes.clone().requires_grad_(True), o.clone().requires_grad_(True), dr.clone().requires_grad_(True)
+    rgb_r, dep_r, ws_r = O.render(P, pr, orr, drr, opts, u1, u2)
+    gr = torch.autograd.grad([rgb_r, dep_r], [pr, orr, drr], [g_rgb, g_dep])
+    dec = _decoder(P)
+    R = ImportanceRenderer()
+    R.set_uniforms(u1.to(DEV), u2.to(DEV) if u2 is not None else None)
+    pg = planes.to(DEV).requires_grad_(True)
+    og, dg = o.to(DEV).requires_grad_(True), dr.to(DEV).requires_grad_(True)
+    rgb, dep, ws = R(pg, dec, og, dg, opts)
+    close(rgb, rgb_r, 1e-5, f'{variant} rgb'); close(dep, dep_r, 1e-5, f'{variant} depth'); close(ws, ws_r, 1e-5, f'{variant} wsum')
+    gg = torch.autograd.grad([rgb, dep], [pg, og, dg], [g_rgb.to(DEV), g_dep.to(DEV)])
+    close(gg[0], gr[0], 1e-4, f'{variant} d planes'); close(gg[1], gr[1], 1e-4, f'{variant} d origins'); close(gg[2], gr[2], 1e-4, f'{variant} d dirs')
+
+
+def test_render_zero_density_ray():
+    """A ray with no density anywhere: depth must take the NaN -> +inf -> clamp-to-global-max path (ray_marcher.py:49-50)."""
+    from inv3d_amd import hipops as H
+    from inv3d_amd import fused
+    cfg = O.small_config()
+    opts = dict(cfg.rendering)
+    P = O.synth_params(cfg, seed=5)
+    P = dict(P)
+    P['decoder.net.2.bias'] = P['decoder.net.2.bias'].clone()
+    P['decoder.net.2.weight'] = P['decoder.net.2.weight'].clone()
+    P['decoder.net.2.weight'][0] = 0
+    P['decoder.net.2.bias'][0] = -90.0            # sigma = -90 everywhere
+    g = torch.Generator().manual_seed(2)
+    planes = torch.randn(1, 3, 32, 16, 16, generator=g)
+    cam = O.synth_cameras(1, seed=3)
+    o, dr = O.ray_sampler(cam[:, :16].reshape(1, 4, 4), cam[:, 16:].reshape(1, 3, 3), 4)
+    u1 = torch.rand(1, 16, 12, 1, generator=g); u2 = torch.rand(16, 12, generator=g)
+    rgb_r, dep_r, ws_r = O.render(P, planes, o, dr, opts, u1, u2)
+    dec = _decoder(P)
+    from inv3d_amd.training.volumetric_rendering.renderer import ImportanceRenderer
+    R = ImportanceRenderer()
+    R.set_uniforms(u1.to(DEV), u2.to(DEV))
+    pg = planes.to(DEV).requires_grad_(True)
+    rgb, dep, ws = R(pg, dec, o.to(DEV), dr.to(DEV), opts)
+    close(dep, dep_r, 1e-5, 'zero-density depth'); close(rgb, rgb_r, 1e-5, 'zero-density rgb')
+    gp, = torch.autograd.grad([rgb, dep], [pg], [torch.ones_like(rgb), torch.ones_like(dep)])
+    assert torch.isfinite(gp).all()
+
+
+def test_run_model_vs_oracle():
+    from inv3d_amd.training.volumetric_rendering.renderer import ImportanceRenderer
+    cfg = O.small_config()
+    P = O.synth_params(cfg, seed=5)
+    g = torch.Generator().manual_seed(8)
+    planes = torch.randn(2, 3, 32, 16, 16, generator=g)
+    coords = (torch.rand(2, 300, 3, generator=g) - 0.5) * 1.2
+    rgb_r, sig_r = O.run_model(P, planes, coords, cfg.rendering)
+    out = ImportanceRenderer().run_model(planes.to(DEV), _decoder(P), coords.to(DEV), None, cfg.rendering)
+    close(out['rgb'], rgb_r, 1e-5, 'run_model rgb'); close(out['sigma'], sig_r, 1e-5, 'run_model sigma')

@@ -1,0 +1,88 @@
+"""CPU-side checks (no GPU needed): the C-ABI library loads and exports every symbol include/eg3d_hip.h declares, the
+product refuses CPU tensors instead of falling back, host-side tap-list / packing logic, state-dict schema, and the
+product's synthetic-input generator matches the oracle's."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from inv3d_amd import _lib as L
+    hdr = open(os.path.join(ROOT, 'include', 'eg3d_hip.h')).read()
+    declared = set(re.findall(r'\b(eg3d_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, 'no declarations parsed'
+    lib = L.lib()
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/eg3d_hip.h but not exported by libeg3d_hip.so'
+    assert declared == set(L.EXPORTED_SYMBOLS), declared ^ set(L.EXPORTED_SYMBOLS)
+    assert lib.eg3d_abi_version() == 1
+    assert lib.eg3d_status_string(-2) == b'unsupported configuration'
+
+
+def test_no_cpu_fallback():
+    from inv3d_amd._lib import Eg3dHipError
+    from inv3d_amd.torch_utils.ops import bias_act, upfirdn2d, conv2d_resample
+    x = torch.randn(1, 4, 8, 8)
+    with pytest.raises(Eg3dHipError):
+        bias_act.bias_act(x, torch.randn(4))
+    with pytest.raises(Eg3dHipError):
+        upfirdn2d.upfirdn2d(x, upfirdn2d.setup_filter([1, 3, 3, 1]))
+    with pytest.raises(Eg3dHipError):
+        conv2d_resample.conv2d_resample(x, torch.randn(4, 4, 3, 3), padding=1)
+    with pytest.raises(NotImplementedError):
+        bias_act.bias_act(x, impl='ref')
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, '3dgan-inversion_amd', 'inv3d_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f'{f} imports the oracle'
+                assert '/root/reference' not in src
+
+
+def test_tap_lists():
+    from inv3d_amd import hipops as H
+    c, = H.classes_corr(8, 8, 3, 3, 1)
+    assert c.ntaps == 9 and (c.dy[0], c.dx[0], c.wtap[0]) == (-1, -1, 0) and (c.dy[8], c.dx[8], c.wtap[8]) == (1, 1, 8)
+    cls, ho, wo = H.classes_convT(4, 4, 3, 3, 2)
+    assert (ho, wo) == (9, 9) and len(cls) == 4
+    assert sorted(k.ntaps for k in cls) == [1, 2, 2, 4]
+    assert sum(k.Ha * k.Wa for k in cls) == 81                       # the phases tile the (2H+1)^2 output exactly
+    ee = [k for k in cls if k.out_py == 0 and k.out_px == 0][0]
+    assert (ee.Ha, ee.Wa) == (5, 5) and sorted((ee.dy[i], ee.dx[i]) for i in range(4)) == [(-1, -1), (-1, 0), (0, -1), (0, 0)]
+    a, = H.classes_convT_adjoint(4, 4, 3, 3, 2)
+    assert a.ntaps == 9 and max(a.dy[i] for i in range(9)) == 2
+    f, = H.classes_corr(8, 8, 3, 3, 1, flip_taps=True)
+    assert f.wtap[0] == 8 and f.wtap[8] == 0
+    w = torch.arange(2 * 4 * 3 * 3, dtype=torch.float32).reshape(2, 4, 3, 3)
+    wf, wa = H.pack_weight_fwd(w), H.pack_weight_adj(w)
+    assert wf.shape == (2, 36) and wa.shape == (4, 18)
+    assert wf[1, (1 * 3 + 2) * 4 + 3] == w[1, 3, 1, 2] and wa[3, (1 * 3 + 2) * 2 + 1] == w[1, 3, 1, 2]
+
+
+def test_schema_and_synthetic_inputs_match_oracle():
+    from inv3d_amd import synthetic as S
+    from oracle import eg3d_oracle as O
+    cfg = O.small_config()
+    G = S.make_generator(w_dim=32, z_dim=32, plane_res=32, channel_base=256, channel_max=16, nrr=16, sr_in_res=16, sr_widths=(16, 8),
+                         rendering_kwargs=cfg.rendering, device='cpu')
+    W = S.load_synthetic_weights(G, 0)
+    P = O.synth_params(cfg, 0)
+    assert set(W) == set(P)
+    assert all(torch.equal(W[k], P[k]) for k in P)
+    assert torch.equal(S.synth_cameras(3), O.synth_cameras(3))
+    assert torch.equal(S.synth_ws(cfg.num_ws, 32, 2, wplus=True), O.synth_ws(cfg, 2, wplus=True))
+    u1, u2 = S.make_uniforms(2, 256, 12, 12)
+    v1, v2 = O.make_uniforms(cfg, 2)
+    assert torch.equal(u1, v1) and torch.equal(u2, v2)
+    full = S.make_generator(device='cpu')
+    assert set(full.state_dict()) == set(O.param_shapes(O.full_config()))
+    assert sum(p.numel() for p in full.parameters()) == 30662136
+    assert full.backbone.num_ws == 14
