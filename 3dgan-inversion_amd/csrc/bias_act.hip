@@ -82,7 +82,7 @@ extern "C" int eg3d_bias_act(const void* x, const void* b, const void* xref, con
     if (!x || !y || numel < 0 || grad < 0 || grad > 2 || act < EG3D_ACT_LINEAR || act > EG3D_ACT_SWISH) return EG3D_ERR_INVALID;
     if (numel > INT32_MAX) return EG3D_ERR_TOO_LARGE;      // bias_act.cpp:44
     if (b && (size_b <= 0 || step_b <= 0)) return EG3D_ERR_INVALID;
-    if (grad >= 1 && !yref && !xref) return EG3D_ERR_INVALID;
+    /* grad >= 1 with neither xref nor yref is legal (linear: the reference saves nothing, bias_act.py:153-156; refs read as 0) */
     if (grad == 2 && !dy) return EG3D_ERR_INVALID;
     if (numel == 0) return EG3D_OK;
     hipStream_t st_ = (hipStream_t)stream;

@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
         float f[FC], out[1 + CO];
         if (has_c) {
             depth_c = coarse_depth(p, rr, s, p.u1[rr * Dc + s]);
-            gather_feats(pn, p.Hp, p.Wp, p.ldp, cs, fmaf(depth_c, dx, ox), fmaf(depth_c, dy, oy), fmaf(depth_c, dz, oz), f);
+            gather_feats(pn, p.Hp, p.Wp, p.ldp, cs, ox + depth_c * dx, oy + depth_c * dy, oz + depth_c * dz, f);   // mul+add like the reference (no fma)
             mlp_fwd(p.w0, p.b0, p.w1, p.b1, f, out);
             sig_c = out[0];
 #pragma unroll
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
     {
         float f[FC], out[1 + CO];
         if (has_f) {
-            gather_feats(pn, p.Hp, p.Wp, p.ldp, cs, fmaf(depth_f, dx, ox), fmaf(depth_f, dy, oy), fmaf(depth_f, dz, oz), f);
+            gather_feats(pn, p.Hp, p.Wp, p.ldp, cs, ox + depth_f * dx, oy + depth_f * dy, oz + depth_f * dz, f);
             mlp_fwd(p.w0, p.b0, p.w1, p.b1, f, out);
             sig_f = out[0];
 #pragma unroll
@@ -370,7 +370,8 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
         float S = 0.f;
         for (int i = nI - 1; i >= 0; --i) {
             float dmid = 0.5f * (L.sd[i] + L.sd[i + 1]);
-            float gw = (E[i] + E[i + 1]) + gd * (dmid - depth_raw) / wsum + gws - 2.f * grgb_sum;
+            float gw = (E[i] + E[i + 1]) + gws - 2.f * grgb_sum;
+            if (gd != 0.f) gw += gd * (dmid - depth_raw) / wsum;
             float T = L.t[i], q = L.q[i], w = L.w[i];
             float galpha = gw * T - S / q;
             S += gw * w;
@@ -396,7 +397,7 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
         const float depth = pass == 0 ? depth_c : depth_f;
         const float a = 0.5f * ((rank > 0 ? L.w[rank - 1] : 0.f) + (rank < nI ? L.w[rank] : 0.f));
         const float gsig = 0.5f * ((rank > 0 ? GA[rank - 1] : 0.f) + (rank < nI ? GA[rank] : 0.f));
-        const float px = fmaf(depth, dx, ox), py = fmaf(depth, dy, oy), pz = fmaf(depth, dz, oz);
+        const float px = ox + depth * dx, py = oy + depth * dy, pz = oz + depth * dz;
         float f[FC], out[1 + CO];
         gather_feats(pn, p.Hp, p.Wp, p.ldp, cs, px, py, pz, f);
         mlp_fwd(p.w0, p.b0, p.w1, p.b1, f, out);

@@ -60,7 +60,7 @@ class _BiasAct(torch.autograd.Function):
 class _BiasActGrad(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dy, x, b, y, dim, spec, alpha, gain, clamp):
-        ref = y if y is not None else x
+        ref = y if y is not None else (x if x is not None else dy)
         dy = dy.contiguous(memory_format=torch.channels_last) if (ref.dim() == 4 and ref.stride(1) == 1 and ref.shape[1] > 1) else dy.contiguous()
         dx = H.bias_act_raw(dy, b, x, y, None, 1, dim, spec.cuda_idx, alpha, gain, clamp)
         ctx.save_for_backward(dy if spec.has_2nd_grad else None, x, b, y)
