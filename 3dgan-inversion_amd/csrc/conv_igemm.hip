@@ -269,6 +269,19 @@ int launch_conv(const eg3d_conv_params& p, hipStream_t st) {
     return EG3D_OK;
 }
 
+// tile configuration: 0 = 128x128 (dominant), 1 = 64x128, 2 = 32x128 (tiny spatial extent), 3 = 128x32 (few output channels)
+int pick_config(const eg3d_conv_params& p) {
+    int64_t maxM = 0;
+    for (int c = 0; c < p.ncls; ++c) maxM = std::max<int64_t>(maxM, (int64_t)p.N * p.cls[c].Ha * p.cls[c].Wa);
+    if (p.Nc <= 32) return 3;
+    if (maxM <= 32) return 2;
+    // enough 128x128 tiles to fill the chip (2 blocks/CU)?  otherwise shrink the M tile
+    int64_t big_tiles = (int64_t)eg3d_cdiv(maxM, 128) * eg3d_cdiv(p.Nc, 128) * p.ncls * p.ksplit;
+    if (big_tiles >= 384) return 0;
+    if (maxM <= 64 * 8) return 2;
+    return 1;
+}
+
 }  // namespace
 
 extern "C" int eg3d_conv2d_igemm_f32(const eg3d_conv_params* pp, void* stream) {
@@ -293,11 +306,15 @@ extern "C" int eg3d_conv2d_igemm_f32(const eg3d_conv_params* pp, void* stream) {
     }
     if ((int64_t)p.N * p.Hi * p.Wi * p.ldx > INT32_MAX || (int64_t)p.N * p.Ho * p.Wo * p.ldo > INT32_MAX) return EG3D_ERR_TOO_LARGE;
     hipStream_t st = (hipStream_t)stream;
-    if (p.Nc <= 32) return launch_conv<128, 32, 4, 1>(p, st);
-    if (maxM <= 32) return launch_conv<32, 128, 1, 4>(p, st);
-    // enough 128x128 tiles to fill the chip (2 blocks/CU)?  otherwise halve the M tile
-    int64_t big_tiles = (int64_t)eg3d_cdiv(maxM, 128) * eg3d_cdiv(p.Nc, 128) * p.ncls * p.ksplit;
-    if (big_tiles >= 384) return launch_conv<128, 128, 2, 2>(p, st);
-    if (maxM <= 64 * 8) return launch_conv<32, 128, 1, 4>(p, st);
-    return launch_conv<64, 128, 2, 2>(p, st);
+    switch (pick_config(p)) {
+        case 0: return launch_conv<128, 128, 2, 2>(p, st);
+        case 1: return launch_conv<64, 128, 2, 2>(p, st);
+        case 2: return launch_conv<32, 128, 1, 4>(p, st);
+        default: return launch_conv<128, 32, 4, 1>(p, st);
+    }
+}
+
+extern "C" int eg3d_conv2d_igemm_config(const eg3d_conv_params* pp) {
+    if (!pp || pp->ncls < 1 || pp->ncls > 4) return EG3D_ERR_INVALID;
+    return pick_config(*pp);
 }

@@ -78,15 +78,17 @@ class ModConvLayerFn(torch.autograd.Function):
         out = H.empty_cl(N, Co, Ho, Wo, x.device)
         b = bias.contiguous().float() if bias is not None else None
         steps = ((Ci + 31) // 32) * kh * kw
+        aflops = 2.0 * N * Hi * Wi * (1 if up == 2 else 1) * kh * kw * Ci * Co     # MACs of the (transposed) conv
         if up == 1:
             cls = H.classes_corr(Ho, Wo, kh, kw, kh // 2)
             ks = _auto_ksplit(N * Ho * Wo, Co, steps)
             if ks == 1:
                 H.conv_igemm(x, wf, Ci, Co, out, cls, in_scale=styles, epi=L.EPI_FWD, out_scale=d, bias=b, noise=nz,
-                             noise_nstride=nstride or 0, noise_strength=noise_strength, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv)
+                             noise_nstride=nstride or 0, noise_strength=noise_strength, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv,
+                             algo_flops=aflops)
             else:
                 z = H.zeros_cl(N, Co, Ho, Wo, x.device)
-                H.conv_igemm(x, wf, Ci, Co, z, cls, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks)
+                H.conv_igemm(x, wf, Ci, Co, z, cls, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops)
                 H.epilogue_fwd(z, out, d=d, noise=nz, noise_nstride=nstride or 0, noise_strength=noise_strength, bias=b, act='lrelu',
                                alpha=0.2, gain=act_gain, clamp=clampv)
         else:
@@ -94,10 +96,10 @@ class ModConvLayerFn(torch.autograd.Function):
             ks = _auto_ksplit(N * (Hi + 1) * (Wi + 1), Co, ((Ci + 31) // 32) * 4)
             if ks == 1:
                 z = H.empty_cl(N, Co, Hz, Wz, x.device)
-                H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_STORE)
+                H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_STORE, algo_flops=aflops)
             else:
                 z = H.zeros_cl(N, Co, Hz, Wz, x.device)
-                H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks)
+                H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops)
             H.epilogue_fwd(z, out, fir=fir44(x.device), pad0=1, fir_gain=float(up * up), d=d, noise=nz, noise_nstride=nstride or 0,
                            noise_strength=noise_strength, bias=b, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv)
         ctx.save_for_backward(x, weight, styles, d, out, nz, noise_strength, b)
@@ -140,7 +142,8 @@ class ModConvLayerFn(torch.autograd.Function):
         if need_x or need_s:
             dx = H.empty_cl(N, Ci, Hi, Wi, dev)
             ds = torch.zeros((N, Ci), device=dev)
-            H.conv_igemm(g, wa, Co, Ci, dx, cls_adj, in_stride=in_stride, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds)
+            H.conv_igemm(g, wa, Co, Ci, dx, cls_adj, in_stride=in_stride, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds,
+                         algo_flops=2.0 * N * Hi * Wi * kh * kw * Ci * Co)
         dwsq = torch.zeros_like(wsq) if need_w else None
         if dd is not None and (need_s or need_w):
             if ds is None:

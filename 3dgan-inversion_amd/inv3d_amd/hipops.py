@@ -14,6 +14,27 @@ from . import _lib as L
 CL = torch.channels_last
 
 
+class LaunchProfiler:
+    """Optional per-launch timing of the implicit-GEMM conv (bench.py roofline): HIP events recorded on the launch stream
+    around every eg3d_conv2d_igemm_f32 call, with the launch's algorithmic FLOPs and tile configuration."""
+
+    def __init__(self):
+        self.records = []          # (config_id, algo_flops, start_event, end_event)
+
+    def summary(self):
+        out = {}
+        for cfg, fl, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            d = out.setdefault(cfg, dict(launches=0, flops=0.0, ms=0.0))
+            d['launches'] += 1
+            d['flops'] += fl
+            d['ms'] += ms
+        return out
+
+
+PROFILER = None
+
+
 def is_cl(t: torch.Tensor) -> bool:
     return t.dim() == 4 and t.is_cuda and t.dtype == torch.float32 and (t.stride(1) == 1 or t.shape[1] == 1) and \
         t.is_contiguous(memory_format=CL)
@@ -159,7 +180,7 @@ def pack_weight_adj(w):
 
 def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=None, epi=L.EPI_STORE, ksplit=1,
                out_scale=None, bias=None, noise=None, noise_nstride=0, noise_strength=None, act='linear', alpha=0.0, gain=1.0,
-               clamp=-1.0, addend=None, xin=None, ds=None):
+               clamp=-1.0, addend=None, xin=None, ds=None, algo_flops=None):
     """Launch eg3d_conv2d_igemm_f32.  x/out/addend/xin: channels_last fp32 [N,C,H,W]; wp: packed weights [Nc, taps*Ck]."""
     assert is_cl(x) and is_cl(out), 'conv_igemm expects fp32 channels_last CUDA tensors'
     p = L.ConvParams()
@@ -184,7 +205,17 @@ def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=
     p.addend = addend.data_ptr() if addend is not None else None
     p.xin = xin.data_ptr() if xin is not None else None
     p.ds = ds.data_ptr() if ds is not None else None
+    prof = PROFILER
+    if prof is not None:
+        if algo_flops is None:
+            algo_flops = 2.0 * Ck * Nc * sum(n * c.Ha * c.Wa * c.ntaps for c in classes)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cfg = L.lib().eg3d_conv2d_igemm_config(C.byref(p))
+        e0.record()
     L.check(L.lib().eg3d_conv2d_igemm_f32(C.byref(p), L.stream_ptr()), 'conv2d_igemm_f32')
+    if prof is not None:
+        e1.record()
+        prof.records.append((cfg, float(algo_flops), e0, e1))
     return out
 
 

@@ -1,0 +1,295 @@
+"""Inversion inner loops on the MI355X path -- the callers of G.synthesis.
+
+  LatentProjector  <- training/projectors/w_projector.py:28-280 (Phase A: latent w [+ camera pose + translation] + noise
+                      buffers, LPIPS-feature distance + noise regulariser [+ depth-reprojection warping loss])
+  PivotalTuner     <- training/coaches/{base_coach.py:96-126, single_id_coach.py:64-77} (Phase B: all generator weights, Adam 3e-4,
+                      MSE(512^2)+MSE(128^2)+LPIPS(512^2)+LPIPS(128^2)+TV(depth), early exit on the LPIPS threshold)
+
+The perceptual networks are third-party weights that are not available offline (VGG16-LPIPS,
+torchvision VGG16, LPIPS-AlexNet).  They enter through `feature_net` callables; the default `StubFeatureNet` is a small
+fixed-random conv pyramid running on this package's own conv kernels, so the loss has the same structure (feature-space
+squared distance) and the same gradient path into the image.  Hyper-parameters default to configs/hyperparameters.py.
+All schedule arithmetic stays on the host; there is no per-step device->host sync unless `early_stop` is requested.
+"""
+import math
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .torch_utils.ops import bias_act, conv2d_gradfix
+
+
+class StubFeatureNet(torch.nn.Module):
+    """Stand-in for the LPIPS / VGG feature extractors: 3 x (3x3 conv -> lrelu -> 2x2 avg-pool), fixed random weights,
+    unit-normalised channel features at 3 scales, concatenated.  Runs on the gfx950 conv + bias_act kernels."""
+
+    def __init__(self, widths=(16, 32, 64), seed=1234):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        cin = 4                                  # rgb padded to 4 channels (16-byte pixels)
+        self.ws = torch.nn.ParameterList()
+        for w in widths:
+            self.ws.append(torch.nn.Parameter(torch.randn(w, cin, 3, 3, generator=g) / math.sqrt(cin * 9), requires_grad=False))
+            cin = w
+
+    def forward(self, img):
+        n, c, h, w = img.shape
+        x = torch.cat([img, img.new_zeros(n, 4 - c, h, w)], 1) if c < 4 else img
+        feats = []
+        for wt in self.ws:
+            x = conv2d_gradfix.conv2d(x, wt, padding=1)
+            x = bias_act.bias_act(x, None, act='lrelu')
+            x = F.avg_pool2d(x, 2)
+            f = x * torch.rsqrt(x.square().sum(1, keepdim=True) + 1e-10)
+            feats.append(f.flatten(1) / math.sqrt(f.shape[2] * f.shape[3]))
+        return torch.cat(feats, 1)
+
+
+def noise_regularizer(noise_bufs) -> torch.Tensor:
+    """Multi-scale shifted auto-correlation penalty on the noise maps (w_projector.py:221-237)."""
+    reg = 0.0
+    for v in noise_bufs:
+        noise = v[None, None]
+        while True:
+            reg = reg + (noise * torch.roll(noise, shifts=1, dims=3)).mean() ** 2
+            reg = reg + (noise * torch.roll(noise, shifts=1, dims=2)).mean() ** 2
+            if noise.shape[2] <= 8:
+                break
+            noise = F.avg_pool2d(noise, kernel_size=2)
+    return reg
+
+
+def compute_tv_norm(values: torch.Tensor) -> torch.Tensor:
+    """Squared forward-difference total variation of a [*,H,W] map (base_coach.py:294-305)."""
+    v00, v01, v10 = values[:, :-1, :-1], values[:, :-1, 1:], values[:, 1:, :-1]
+    return ((v00 - v01) ** 2 + (v00 - v10) ** 2).mean()
+
+
+def quaternion_to_rotmat(q: torch.Tensor) -> torch.Tensor:
+    """[B,4] (w,x,y,z) -> [B,3,3] (utils/camera_utils.py:201-228)."""
+    q = q / torch.sqrt(torch.clamp((q * q).sum(1, keepdim=True), min=1e-8))
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    r = torch.stack([1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * z * w, 2 * x * z + 2 * y * w,
+                     2 * x * y + 2 * z * w, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * x * w,
+                     2 * x * z - 2 * y * w, 2 * y * z + 2 * x * w, 1 - 2 * x * x - 2 * y * y], 1)
+    return r.view(-1, 3, 3)
+
+
+def pose_to_cam(rotmat: torch.Tensor, translation_opt: torch.Tensor, intrinsic: torch.Tensor, radius: float = 2.7):
+    """Rotation + optimisable translation -> extrinsic [B,4,4] and c [B,25] (w_projector.py:160-172)."""
+    b = rotmat.shape[0]
+    pred_translation = -radius * rotmat[:, :3, 2]
+    t_world = -torch.bmm(rotmat, translation_opt.unsqueeze(-1)).squeeze(-1) * radius
+    t = t_world + pred_translation
+    t = t / torch.norm(t, dim=-1, keepdim=True) * radius
+    ext = torch.eye(4, device=rotmat.device).unsqueeze(0).repeat(b, 1, 1)
+    ext = torch.cat([torch.cat([rotmat, t.unsqueeze(-1)], 2), ext[:, 3:]], 1)
+    return ext, torch.cat([ext.reshape(b, 16), intrinsic.reshape(1, 9).expand(b, 9)], 1)
+
+
+def line_plane_intersection(plane_normal, plane_point, ray_dir, ray_point, eps=1e-6):
+    """training/warping_loss.py:58-72."""
+    ndotu = (plane_normal * ray_dir).sum(-1, keepdim=True)
+    w_vec = ray_point - plane_point
+    si = -(plane_normal * w_vec).sum(-1, keepdim=True) / ndotu
+    return w_vec + si * ray_dir + plane_point
+
+
+def warping_loss(G, ws, canonical_cam, extrinsic, init_ext, intrinsic, depth, target_feat, feat_fn, synth_kwargs=None):
+    """Depth-reprojection loss (training/warping_loss.py:6-56): render the canonical view without gradient, lift the predicted
+    depth to 3-D with the predicted extrinsic, project into the canonical image, sample canonical features there and compare
+    with the target's features under a foreground mask.  The target's feature map is passed in (the reference recomputes it
+    every step, :35)."""
+    synth_kwargs = synth_kwargs or {}
+    with torch.no_grad():
+        can = G.synthesis(ws.detach(), canonical_cam.detach(), noise_mode='const', force_fp32=True, **synth_kwargs)['image']
+        if can.shape[2] > 256:
+            can = F.interpolate(can, size=(256, 256), mode='area')
+        can_feat = feat_fn(can)
+    mask = (depth < depth.mean()).float()
+    res = depth.shape[-1]
+    o, d = G.ray_sampler(extrinsic, intrinsic.reshape(1, 3, 3), res)
+    xyz = (o + d * depth.reshape(1, -1, 1))[0]                                   # [res*res,3]; grad -> extrinsic, depth
+    init_t = init_ext[:, :3, 3]
+    cam_o = init_t.expand(xyz.shape[0], 3)
+    plane_pt = torch.bmm(init_ext.reshape(-1, 4, 4), torch.tensor([[0., 0., 1., 1.]], device=xyz.device).unsqueeze(-1)).squeeze(-1)[:, :3]
+    hit = line_plane_intersection(-cam_o, plane_pt.expand_as(cam_o), xyz - cam_o, cam_o)
+    hit1 = torch.cat([hit, torch.ones(hit.shape[0], 1, device=hit.device)], -1).t()
+    uv = (torch.linalg.inv(init_ext.reshape(4, 4)) @ hit1)[:3].t()
+    uv = uv / uv[:, 2:]
+    uv = (intrinsic.reshape(3, 3) @ uv.t())[:2].t()
+    uv = (uv - 0.5) * 2
+    fr = target_feat.shape[-1]
+    uv_f = F.interpolate(uv.reshape(1, res, res, 2).permute(0, 3, 1, 2), size=(fr, fr), mode='bilinear').permute(0, 2, 3, 1)
+    warped = F.grid_sample(can_feat, uv_f, mode='bilinear', align_corners=False)
+    m = F.interpolate(mask, size=(fr, fr), mode='bilinear')
+    return ((warped - target_feat) * m).abs().mean()
+
+
+class LatentProjector:
+    """Phase A.  One `step()` = pose chain (optional) -> G.synthesis with grad -> [canonical no-grad forward + warping loss] ->
+    feature distance + 1e5 * noise regulariser -> backward -> Adam steps -> noise renormalisation."""
+
+    def __init__(self, G, target: torch.Tensor, *, num_steps=400, w_avg: Optional[torch.Tensor] = None, w_std: float = 1.0,
+                 start_w: Optional[torch.Tensor] = None, cam: Optional[torch.Tensor] = None, optimize_pose: bool = False,
+                 feature_net: Optional[Callable] = None, warp_feature_net: Optional[Callable] = None, use_warping_loss: bool = False,
+                 first_inv_lr=8e-3, cam_lr=6e-7, translation_lr=2e-4, cam_preheat_steps=50, initial_noise_factor=0.05,
+                 noise_ramp_length=0.75, lr_rampdown_length=0.25, lr_rampup_length=0.05, regularize_noise_weight=1e5,
+                 initial_learning_rate=0.01, radius=2.7, wplus=False, synth_kwargs: Optional[dict] = None, seed: int = 0):
+        dev = target.device
+        self.G = G.eval().requires_grad_(False)
+        self.dev = dev
+        self.num_steps, self.preheat = num_steps, (cam_preheat_steps if optimize_pose else 0)
+        self.w_std, self.noise_factor, self.noise_ramp = w_std, initial_noise_factor, noise_ramp_length
+        self.lr_down, self.lr_up, self.lr0, self.reg_w = lr_rampdown_length, lr_rampup_length, initial_learning_rate, regularize_noise_weight
+        self.radius, self.optimize_pose, self.use_warp = radius, optimize_pose, use_warping_loss
+        self.synth_kwargs = dict(synth_kwargs or {})
+        self.num_ws = G.backbone.num_ws
+        self.feature_net = feature_net if feature_net is not None else StubFeatureNet().to(dev)
+        self.warp_net = warp_feature_net if warp_feature_net is not None else self.feature_net_map
+        self.gen = torch.Generator(device=dev).manual_seed(seed)
+        # target: [1,3,H,W] in [-1,1]  ->  [0,255] at 256^2 (w_projector.py:106-110)
+        self.target = target
+        t255 = (target + 1) * (255 / 2)
+        if t255.shape[2] > 256:
+            t255 = F.interpolate(t255, size=(256, 256), mode='area')
+        with torch.no_grad():
+            self.target_features = self.feature_net(t255)
+            self.target_warp_feat = self.warp_net(target) if use_warping_loss else None
+        w_avg = torch.zeros(1, 1, G.w_dim, device=dev) if w_avg is None else w_avg.to(dev).reshape(1, 1, -1)
+        start = torch.zeros_like(w_avg) if start_w is None else start_w.to(dev).reshape(1, -1, G.w_dim)
+        w0 = (w_avg + start)
+        if wplus and w0.shape[1] == 1:
+            w0 = w0.repeat(1, self.num_ws, 1)
+        self.w_opt = w0.clone().float().requires_grad_(True)
+        self.noise_bufs = {n: b for n, b in G.backbone.synthesis.named_buffers() if 'noise_const' in n}
+        self.noise_bufs2 = {n: b for n, b in G.superresolution.named_buffers() if 'noise_const' in n}
+        with torch.no_grad():
+            for b in list(self.noise_bufs.values()) + list(self.noise_bufs2.values()):
+                b.copy_(torch.randn(b.shape, device=dev, generator=self.gen))
+                b.requires_grad = True
+        self.optimizer = torch.optim.Adam([self.w_opt] + list(self.noise_bufs.values()) + list(self.noise_bufs2.values()),
+                                          betas=(0.9, 0.999), lr=first_inv_lr)
+        self.intrinsic = torch.tensor([4.2647, 0, 0.5, 0, 4.2647, 0.5, 0, 0, 1], device=dev).unsqueeze(0)
+        self.init_ext = torch.tensor([1, 0, 0, 0, 0, -1, 0, 0, 0, 0, -1, 2.7, 0, 0, 0, 1.], device=dev).reshape(1, 4, 4)
+        self.canonical_cam = torch.cat([self.init_ext.reshape(1, 16), self.intrinsic], -1)
+        self.cam = cam.to(dev) if cam is not None else self.canonical_cam.clone()
+        if optimize_pose:
+            # the reference predicts the quaternion with a ResNet34 (scripts/resnet) fine-tuned per image; here the
+            # quaternion itself is the optimisable state ("ResNet34 optional stub")
+            self.quat = torch.tensor([[0., 1., 0., 0.]], device=dev).requires_grad_(True)     # = init_ext rotation
+            self.translation_opt = torch.zeros(1, 3, device=dev, requires_grad=True)
+            self.cam_optimizer = torch.optim.Adam([self.quat], lr=cam_lr, betas=(0.9, 0.999))
+            self.translation_optimizer = torch.optim.Adam([self.translation_opt], lr=translation_lr)
+        self.step_idx = 0
+        self.last = {}
+
+    def feature_net_map(self, img):
+        """Spatial feature map for the warping loss from the stub net's first two stages ([N,C,h,w])."""
+        net = self.feature_net
+        n, c, h, w = img.shape
+        x = torch.cat([img, img.new_zeros(n, 4 - c, h, w)], 1) if c < 4 else img
+        for wt in list(net.ws)[:2]:
+            x = F.avg_pool2d(bias_act.bias_act(conv2d_gradfix.conv2d(x, wt, padding=1), None, act='lrelu'), 2)
+        return x
+
+    def _schedule(self, step):
+        t = (step - self.preheat) / max(1, (self.num_steps - self.preheat))
+        w_noise_scale = self.w_std * self.noise_factor * max(0.0, 1.0 - t / self.noise_ramp) ** 2
+        lr_ramp = min(1.0, (1.0 - t) / self.lr_down)
+        lr_ramp = 0.5 - 0.5 * np.cos(lr_ramp * np.pi)
+        lr_ramp = lr_ramp * min(1.0, t / self.lr_up)
+        return w_noise_scale, self.lr0 * lr_ramp
+
+    def step(self) -> Dict[str, torch.Tensor]:
+        step = self.step_idx
+        G = self.G
+        w_noise_scale, lr = self._schedule(step)
+        for g in self.optimizer.param_groups:
+            g['lr'] = lr
+        if self.optimize_pose:
+            rot = quaternion_to_rotmat(self.quat)
+            pred_ext, pred_cam = pose_to_cam(rot, self.translation_opt, self.intrinsic, self.radius)
+        else:
+            pred_ext, pred_cam = None, self.cam
+        w = self.w_opt
+        if step >= self.preheat:
+            w = w + torch.randn(w.shape, device=self.dev, generator=self.gen) * w_noise_scale
+        ws = w.repeat(1, self.num_ws, 1) if w.shape[1] == 1 else w
+        out = G.synthesis(ws, pred_cam, noise_mode='const', force_fp32=True, **self.synth_kwargs)
+        img = out['image'] * 127.5 + 128
+        if img.shape[2] > 256:
+            img = F.interpolate(img, size=(256, 256), mode='area')
+        dist = (self.target_features - self.feature_net(img)).square().sum()
+        reg = noise_regularizer(list(self.noise_bufs.values()) + list(self.noise_bufs2.values()))
+        loss = dist + reg * self.reg_w
+        warp = None
+        if self.use_warp and self.optimize_pose:
+            warp = warping_loss(G, ws, self.canonical_cam, pred_ext, self.init_ext, self.intrinsic, out['image_depth'],
+                                self.target_warp_feat, self.warp_net, self.synth_kwargs)
+            loss = loss + warp
+        self.optimizer.zero_grad(set_to_none=True)
+        if self.optimize_pose:
+            self.cam_optimizer.zero_grad(set_to_none=True)
+            self.translation_optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.optimize_pose:
+            self.cam_optimizer.step()
+            self.translation_optimizer.step()
+        if step >= self.preheat:
+            self.optimizer.step()
+        with torch.no_grad():
+            for b in list(self.noise_bufs.values()) + list(self.noise_bufs2.values()):
+                b -= b.mean()
+                b *= b.square().mean().rsqrt()
+        self.step_idx += 1
+        self.last = dict(loss=loss.detach(), dist=dist.detach(), reg=reg.detach() if torch.is_tensor(reg) else reg, image=out['image'].detach(),
+                         cam=pred_cam.detach(), ws=ws.detach())
+        if warp is not None:
+            self.last['warp'] = warp.detach()
+        return self.last
+
+
+class PivotalTuner:
+    """Phase B.  One `step()` = G.synthesis(w_pivot, cam) with default kwargs (noise_mode='random') -> L2 + LPIPS at 512^2 and
+    128^2 + depth TV -> backward into all generator weights -> Adam."""
+
+    def __init__(self, G, target: torch.Tensor, w_pivot: torch.Tensor, cam: torch.Tensor, *, lr=3e-4, l2_lambda=1.0, lpips_lambda=1.0,
+                 lpips_threshold=0.06, feature_net: Optional[Callable] = None, synth_kwargs: Optional[dict] = None):
+        self.G = G
+        G.requires_grad_(True)
+        self.target = target
+        self.target_128 = F.interpolate(target, size=(G.neural_rendering_resolution,) * 2, mode='area')
+        self.w_pivot, self.cam = w_pivot.detach(), cam.detach()
+        self.l2_lambda, self.lpips_lambda, self.thr = l2_lambda, lpips_lambda, lpips_threshold
+        self.feature_net = feature_net if feature_net is not None else StubFeatureNet().to(target.device)
+        with torch.no_grad():
+            self.tf = self.feature_net(target)
+            self.tf128 = self.feature_net(self.target_128)
+        self.optimizer = torch.optim.Adam(G.parameters(), lr=lr)
+        self.synth_kwargs = dict(synth_kwargs or {})
+        self.last = {}
+
+    def step(self, early_stop: bool = False) -> Dict[str, torch.Tensor]:
+        G = self.G
+        out = G.synthesis(self.w_pivot[:, :G.backbone.num_ws], self.cam[:, :25], **self.synth_kwargs)
+        l2 = F.mse_loss(out['image'], self.target) + F.mse_loss(out['image_raw'], self.target_128)
+        lp = (self.feature_net(out['image']) - self.tf).square().sum() + (self.feature_net(out['image_raw']) - self.tf128).square().sum()
+        tv = compute_tv_norm(out['image_depth'].squeeze(0))
+        loss = l2 * self.l2_lambda + lp * self.lpips_lambda + tv
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        self.optimizer.step()
+        self.last = dict(loss=loss.detach(), l2=l2.detach(), lpips=lp.detach(), tv=tv.detach(), image=out['image'].detach())
+        if early_stop:
+            self.last['done'] = bool(lp.item() <= self.thr)       # the reference's per-step host sync (single_id_coach.py:69)
+        return self.last
+
+
+def psnr_01(img: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """PSNR = -10 log10(MSE) on [0,1]-scaled images (single_id_coach.py:90-94 scaling)."""
+    a = (img.clamp(-1, 1) + 1) / 2
+    b = (target.clamp(-1, 1) + 1) / 2
+    return -10.0 * torch.log10(F.mse_loss(a, b))

@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- inversion-steps/sec of the MI355X-native EG3D inversion inner loop (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one Phase-A latent-inversion step of config C2 (BASELINE.json configs[1], "FFHQ 512^2
+single-image w+ inversion, 1 x MI355X"): G.synthesis forward with grad on the full-size ffhqrebalanced512-128-shaped generator
+(30.66 M params, 128^2 x (48+48)-sample neural rendering, 512^2 output), feature-space distance + noise regulariser, backward
+into the latent and the 13+4 noise buffers, Adam step, noise renormalisation.  Weights/latents/cameras are synthetic
+(deterministic per-tensor generator); the perceptual net is the stub feature pyramid of inv3d_amd.inversion.
+N GPUs = N independent images (weak scaling), one packed stat all-reduce per step over RCCL.
+
+The JSON line also carries
+  roofline      : the dominant kernel conv_igemm_kernel<128,128,2,2> (fp32 MFMA implicit GEMM): algorithmic FLOPs of its launches
+                  (2 x MACs of the convolution) / their HIP-event durations measured on the launch stream
+                  inside the timed region, against the 157.3 TFLOP/s fp32 matrix peak of gfx950.
+  cpu_baseline  : the CPU oracle (oracle/eg3d_oracle.py, a port of the reference's pure-PyTorch `_ref` path, pinned against
+                  the reference) running the same C2 step on the host cores, bounded sample, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, '3dgan-inversion_amd')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+DOMINANT = 0                        # tile configuration id of conv_igemm_kernel<128,128,2,2>
+
+
+def cpu_baseline_c2(seconds_budget=30.0):
+    """Time the oracle's C2 step (same generator shape, same loss structure) on the host cores."""
+    import torch.nn.functional as F
+    from oracle import eg3d_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = O.full_config()
+    P = O.synth_params(cfg, seed=0)
+    nb = [k for k in P if k.endswith('noise_const')]
+    for k in nb:
+        P[k] = P[k].clone().requires_grad_(True)
+    w_opt = O.synth_ws(cfg, 1, seed=1)[:, :1].clone().requires_grad_(True)
+    c = O.synth_cameras(1, seed=2)
+    u1, u2 = O.make_uniforms(cfg, 1, seed=4)
+    g = torch.Generator().manual_seed(3)
+    target = torch.rand(1, 3, 256, 256, generator=g) * 255
+    opt = torch.optim.Adam([w_opt] + [P[k] for k in nb], lr=8e-3)
+
+    def feat(img):                       # same structure as StubFeatureNet, plain torch on CPU
+        gw = torch.Generator().manual_seed(1234)
+        x, cin, out = torch.cat([img, img.new_zeros(1, 1, *img.shape[2:])], 1), 4, []
+        for wd in (16, 32, 64):
+            wt = torch.randn(wd, cin, 3, 3, generator=gw) / (cin * 9) ** 0.5
+            x = F.avg_pool2d(F.leaky_relu(F.conv2d(x, wt, padding=1), 0.2) * 2 ** 0.5, 2)
+            f = x * torch.rsqrt(x.square().sum(1, keepdim=True) + 1e-10)
+            out.append(f.flatten(1) / (f.shape[2] * f.shape[3]) ** 0.5)
+            cin = wd
+        return torch.cat(out, 1)
+    tf = feat(target)
+
+    def step():
+        ws = w_opt.repeat(1, cfg.num_ws, 1)
+        o = O.synthesis(P, cfg, ws, c, u1, u2, noise_mode='const')
+        img = F.interpolate(o['image'] * 127.5 + 128, size=(256, 256), mode='area')
+        loss = (tf - feat(img)).square().sum() + 1e5 * O.noise_regularizer([P[k] for k in nb])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    t0 = time.time()
+    step()                                # warm-up
+    warm = time.time() - t0
+    times = []
+    while len(times) < 3 and (time.time() - t0) < seconds_budget:
+        t1 = time.time()
+        step()
+        times.append(time.time() - t1)
+    if not times:
+        times = [warm]
+    times.sort()
+    med = times[len(times) // 2]
+    return dict(value=1.0 / med, unit='steps/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'oracle C2 step, full-size generator, N=1: 1 warm-up + {len(times)} timed steps (median {med:.2f} s/step)')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--wplus', action='store_true')
+    args = ap.parse_args()
+
+    from inv3d_amd import dist as D
+    rank, world, local = D.init_from_env('nccl')
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback in the product path)'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    from inv3d_amd import synthetic as S, hipops as H
+    from inv3d_amd.inversion import LatentProjector, psnr_01
+
+    G = S.make_generator(device=dev)
+    S.load_synthetic_weights(G, seed=0)
+    # per-rank independent image: target = render of a different latent by the same generator (so PSNR is meaningful)
+    cam = S.synth_cameras(world, seed=2)[rank:rank + 1].to(dev)
+    with torch.no_grad():
+        ws_t = S.synth_ws(14, 512, world, seed=3)[rank:rank + 1].to(dev)
+        target = G.synthesis(ws_t, cam, noise_mode='const', force_fp32=True)['image'].clamp(-1, 1)
+    proj = LatentProjector(G, target, num_steps=400, cam=cam, wplus=args.wplus, seed=100 + rank)
+    proj.preheat = 0
+
+    def one_step():
+        out = proj.step()
+        st = D.allreduce_stats(dict(loss=0.0, n_active=1.0, steps=1.0), dev) if world > 1 else None   # stat sync (latency only)
+        return out
+
+    for _ in range(args.warmup):
+        one_step()
+    prof = None
+    if not args.no_roofline:
+        prof = H.LaunchProfiler()
+        H.PROFILER = prof
+    torch.cuda.synchronize()
+    D.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = time.perf_counter() - t0
+    H.PROFILER = None
+    elapsed = D.max_over_ranks(elapsed, dev)
+
+    roof = None
+    if prof is not None:
+        summ = prof.summary()
+        dom = summ.get(DOMINANT)
+        if dom and dom['ms'] > 0:
+            ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+            roof = dict(bound='mfma', kernel='conv_igemm_kernel<128,128,2,2> (fp32 v_mfma_f32_32x32x2_f32)', achieved=round(ach, 2),
+                        peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        launches_per_step=dom['launches'] / args.steps, gflop_per_launch=round(dom['flops'] / dom['launches'] / 1e9, 3),
+                        avg_launch_ms=round(dom['ms'] / dom['launches'], 4),
+                        all_conv_ms_per_step=round(sum(v['ms'] for v in summ.values()) / args.steps, 3),
+                        all_conv_gflop_per_step=round(sum(v['flops'] for v in summ.values()) / args.steps / 1e9, 1))
+    final_psnr = float(psnr_01(proj.last['image'], target))
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_c2()
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        line = dict(metric='inversion-steps/sec (G fwd+bwd, 512^2 FFHQ EG3D) at 1/2/4/8 GPUs; final PSNR', value=round(world * args.steps / elapsed, 3),
+                    unit='steps/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True,
+                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                    config=dict(workload='C2: FFHQ 512^2 single-image latent inversion step (Phase A, w%s + 17 noise buffers; G.synthesis fwd+bwd, '
+                                         '128^2 x 96-sample rendering, stub-LPIPS feature distance + noise regulariser, Adam)' % ('+' if args.wplus else ''),
+                                images_per_gpu=1, generator='ffhqrebalanced512-128-shaped, 30.66 M params, random-init (synthetic weights)',
+                                parallelism=f'{world} independent images, 1 per GPU; stat all-reduce only',
+                                psnr_after_timed_steps_db=round(final_psnr, 3)),
+                    roofline=roof, cpu_baseline=cpu)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

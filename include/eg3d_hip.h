@@ -121,6 +121,9 @@ typedef struct eg3d_conv_params {
 } eg3d_conv_params;
 
 int eg3d_conv2d_igemm_f32(const eg3d_conv_params* p, void* stream);
+/* Which tile configuration eg3d_conv2d_igemm_f32 will launch for p: 0 = 128x128x32 (the dominant kernel), 1 = 64x128,
+ * 2 = 32x128, 3 = 128x32.  Pure host function (used by bench.py to attribute launch times to kernels). */
+int eg3d_conv2d_igemm_config(const eg3d_conv_params* p);
 
 /* Weight-gradient GEMM (PTI phase: grads into generator weights, training/coaches/base_coach.py:96-99):
  *   dw[o, wtap[t], k] += sum_{n,ay,ax} g[n, ay*out_stride+out_py, ax*out_stride+out_px, o]
