@@ -59,7 +59,7 @@ class RenderParams(C.Structure):
 
 class RenderBwdParams(C.Structure):
     _fields_ = [('fwd', RenderParams), ('depth_out', C.c_void_p), ('d_rgb', C.c_void_p), ('d_depth', C.c_void_p),
-                ('d_wsum', C.c_void_p), ('d_planes', C.c_void_p), ('d_origins', C.c_void_p), ('d_dirs', C.c_void_p),
+                ('d_wsum', C.c_void_p), ('df_rows', C.c_void_p), ('df_pos', C.c_void_p), ('d_origins', C.c_void_p), ('d_dirs', C.c_void_p),
                 ('dump_dpre', C.c_void_p), ('dump_h', C.c_void_p), ('dump_dout', C.c_void_p), ('dump_feat', C.c_void_p)]
 
 
@@ -90,6 +90,9 @@ _SIGS = {
     'eg3d_render_fwd': (C.c_int, [C.POINTER(RenderParams), C.c_void_p]),
     'eg3d_render_finalize': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'eg3d_render_bwd': (C.c_int, [C.POINTER(RenderBwdParams), C.c_void_p]),
+    'eg3d_triplane_scatter_workspace_ints': (C.c_int64, [C.c_int64, C.c_int, C.c_int, C.c_int]),
+    'eg3d_triplane_scatter': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                        C.c_void_p, C.c_void_p]),
     'eg3d_sample_decode': (C.c_int, [C.POINTER(RenderParams), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 

@@ -341,18 +341,30 @@ def render_finalize(depth, minmax):
 
 
 def render_bwd(p, d_rgb, d_depth, d_wsum, d_planes, d_origins, d_dirs, dumps=None):
+    """d_planes (pre-zeroed, channels_last [N,3C,Hp,Wp]) is filled by the tile-binned scatter of the dumped rows."""
     bp = L.RenderBwdParams()
     bp.fwd = p
     bp.depth_out = None
     bp.d_rgb = d_rgb.data_ptr()
     bp.d_depth = d_depth.data_ptr() if d_depth is not None else None
     bp.d_wsum = d_wsum.data_ptr() if d_wsum is not None else None
-    bp.d_planes = d_planes.data_ptr() if d_planes is not None else None
+    rows = pos = None
+    if d_planes is not None:
+        D = max(p.Dc, p.Df)
+        S = p.N * p.R * 2 * D
+        rows = torch.empty((S, 32), dtype=torch.float32, device=d_planes.device)
+        pos = torch.empty((S, 4), dtype=torch.float32, device=d_planes.device)
+        bp.df_rows, bp.df_pos = rows.data_ptr(), pos.data_ptr()
     bp.d_origins = d_origins.data_ptr() if d_origins is not None else None
     bp.d_dirs = d_dirs.data_ptr() if d_dirs is not None else None
     if dumps is not None:
         bp.dump_dpre, bp.dump_h, bp.dump_dout, bp.dump_feat = [t.data_ptr() for t in dumps]
     L.check(L.lib().eg3d_render_bwd(C.byref(bp), L.stream_ptr()), 'render_bwd')
+    if d_planes is not None:
+        nints = L.lib().eg3d_triplane_scatter_workspace_ints(S, p.N, p.Hp, p.Wp)
+        ws = torch.empty(nints, dtype=torch.int32, device=d_planes.device)
+        L.check(L.lib().eg3d_triplane_scatter(L.ptr(rows), L.ptr(pos), S, p.R * 2 * D, L.ptr(d_planes), p.N, p.Hp, p.Wp, p.ldp,
+                                              p.box_warp, L.ptr(ws), L.stream_ptr()), 'triplane_scatter')
 
 
 def sample_decode(p, coords, M):

@@ -239,7 +239,11 @@ typedef struct eg3d_render_bwd_params {
     const float* d_rgb;        /* [N,R,Cout]                                               */
     const float* d_depth;      /* [N,R] or null                                            */
     const float* d_wsum;       /* [N,R] or null                                            */
-    float* d_planes;           /* [N,Hp,Wp,ldp] pre-zeroed, accumulated with atomics, or null */
+    /* Plane gradient: the kernel dumps one row per (ray, pass, s) -- row ((n*R + ray)*2 + pass)*D + s, D = max(Dc,Df) --
+     * holding dL/d(mean feature)/3 and the sample position; eg3d_triplane_scatter then bins the rows by texel tile and
+     * accumulates them in LDS (a direct scatter would be 384 float atomics per sample).  Both null = no plane gradient. */
+    float* df_rows;            /* [S,32]                                                   */
+    float* df_pos;             /* [S,4] (x,y,z,-); x = NaN marks an absent sample          */
     float* d_origins;          /* [N,R,3] overwritten, or null                             */
     float* d_dirs;             /* [N,R,3] overwritten, or null                             */
     /* Decoder-weight gradients (PTI phase): when non-null the kernel dumps, for sample row
@@ -253,6 +257,12 @@ typedef struct eg3d_render_bwd_params {
 } eg3d_render_bwd_params;
 
 int eg3d_render_bwd(const eg3d_render_bwd_params* p, void* stream);
+
+/* d_planes[N,Hp,Wp,ldp] (pre-zeroed) += bilinear-adjoint scatter of the S dumped rows (grid_sample backward w.r.t. the
+ * planes, renderer.py:64 under autograd).  rows_per_image = R*2*D.  workspace: eg3d_triplane_scatter_workspace_ints() int32. */
+int64_t eg3d_triplane_scatter_workspace_ints(int64_t S, int N, int Hp, int Wp);
+int eg3d_triplane_scatter(const float* df_rows, const float* df_pos, int64_t S, int64_t rows_per_image, float* d_planes, int N,
+                          int Hp, int Wp, int ldp, float box_warp, int32_t* workspace, void* stream);
 
 /* Decoder-only query (ImportanceRenderer.run_model, renderer.py:197-203; used for density grids):
  *   coords [N,M,3] -> rgb [N,M,Cout], sigma [N,M]. */

@@ -1,0 +1,31 @@
+import sys, torch, time
+sys.path.insert(0,'.'); sys.path.insert(0,'3dgan-inversion_amd')
+from inv3d_amd import synthetic as S
+from inv3d_amd.training.volumetric_rendering.renderer import ImportanceRenderer
+from inv3d_amd.training.volumetric_rendering.ray_sampler import RaySampler
+from inv3d_amd.training.triplane import OSGDecoder
+dev='cuda'
+torch.manual_seed(0)
+N=int(sys.argv[1]) if len(sys.argv)>1 else 1
+planes = (torch.randn(N,96,256,256,device=dev)*0.5).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+dec = OSGDecoder(32, {'decoder_lr_mul':1.0,'decoder_output_dim':32}).to(dev)
+for p in dec.parameters(): p.requires_grad_(False)
+cam = S.synth_cameras(N).to(dev)
+c2w = cam[:,:16].reshape(N,4,4).clone().requires_grad_(True); K = cam[:,16:].reshape(N,3,3)
+opts = S.default_rendering_kwargs()
+R = ImportanceRenderer(); rs = RaySampler()
+def run(bwd=True, coord=True):
+    o,d = rs(c2w if coord else c2w.detach(), K, 128)
+    rgb, dep, ws = R(planes, dec, o, d, opts)
+    if bwd:
+        (rgb.sum()+dep.sum()).backward()
+for coord in (True, False):
+    for _ in range(3): run(coord=coord)
+    torch.cuda.synchronize(); t=time.perf_counter()
+    for _ in range(10): run(coord=coord)
+    torch.cuda.synchronize(); print(f'N={N} coord={coord} fwd+bwd ms', (time.perf_counter()-t)*100)
+for _ in range(3): run(False)
+torch.cuda.synchronize(); t=time.perf_counter()
+for _ in range(10):
+    with torch.no_grad(): run(False)
+torch.cuda.synchronize(); print('fwd only ms', (time.perf_counter()-t)*100)
