@@ -188,18 +188,28 @@ __global__ void __launch_bounds__(256) demod_fwd_kernel(const float* __restrict_
     if (lane == 0) d[wid] = 1.0f / sqrtf(acc + 1e-8f);
 }
 
-// thread per (n,k): ds[n,k] += -s[n,k] * sum_o dd[n,o] d[n,o]^3 wsq[o,k]
+// ds[n,k] += -s[n,k] * sum_o dd[n,o] d[n,o]^3 wsq[o,k].  Block = 64 k-columns x 4 o-slices (coalesced rows of wsq), grid.y = n,
+// grid.z splits o further; partial sums meet in LDS, one atomic per (block, k).
 __global__ void __launch_bounds__(256) demod_bwd_kernel(const float* __restrict__ s, const float* __restrict__ wsq, const float* __restrict__ d,
-                                                        const float* __restrict__ dd, float* __restrict__ ds, int N, int Co, int Ck) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * Ck) return;
-    int n = i / Ck, k = i - n * Ck;
+                                                        const float* __restrict__ dd, float* __restrict__ ds, int N, int Co, int Ck, int osplit) {
+    __shared__ float part[4][64];
+    const int n = blockIdx.y;
+    const int k = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    const int per = (Co + osplit - 1) / osplit;
+    const int o_beg = blockIdx.z * per, o_end = min(Co, o_beg + per);
     float acc = 0.f;
-    for (int o = 0; o < Co; ++o) {
-        float dv = d[(int64_t)n * Co + o];
-        acc += dd[(int64_t)n * Co + o] * dv * dv * dv * wsq[(int64_t)o * Ck + k];
+    if (k < Ck) {
+        for (int o = o_beg + sl; o < o_end; o += 4) {
+            float dv = d[(int64_t)n * Co + o];
+            acc = fmaf(dd[(int64_t)n * Co + o] * dv * dv * dv, wsq[(int64_t)o * Ck + k], acc);
+        }
     }
-    ds[i] += -s[i] * acc;
+    part[sl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (sl == 0 && k < Ck) {
+        float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        unsafeAtomicAdd(ds + (int64_t)n * Ck + k, -s[(int64_t)n * Ck + k] * t);
+    }
 }
 
 // thread per (o,k): dwsq[o,k] += sum_n dd[n,o] * (-0.5 d^3 s[n,k]^2)
@@ -273,7 +283,10 @@ extern "C" int eg3d_demod_fwd(const float* s, const float* wsq, float* d, int N,
 extern "C" int eg3d_demod_bwd(const float* s, const float* wsq, const float* d, const float* dd, float* ds, float* dwsq, int N, int Co, int Ck,
                               void* stream) {
     if (!s || !wsq || !d || !dd || N <= 0 || Co <= 0 || Ck <= 0) return EG3D_ERR_INVALID;
-    if (ds) hipLaunchKernelGGL(demod_bwd_kernel, dim3(eg3d_cdiv((int64_t)N * Ck, 256)), dim3(256), 0, (hipStream_t)stream, s, wsq, d, dd, ds, N, Co, Ck);
+    if (ds) {
+        const int osplit = std::max(1, std::min(Co / 16, 16));
+        hipLaunchKernelGGL(demod_bwd_kernel, dim3(eg3d_cdiv(Ck, 64), N, osplit), dim3(256), 0, (hipStream_t)stream, s, wsq, d, dd, ds, N, Co, Ck, osplit);
+    }
     if (dwsq) hipLaunchKernelGGL(demod_bwd_wsq_kernel, dim3(eg3d_cdiv((int64_t)Co * Ck, 256)), dim3(256), 0, (hipStream_t)stream, s, d, dd, dwsq, N, Co, Ck);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;

@@ -85,6 +85,10 @@ _SIGS = {
     'eg3d_weight_sqsum': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'eg3d_demod_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'eg3d_demod_bwd': (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'eg3d_noise_reg_workspace_floats': (C.c_int64, [C.POINTER(C.c_int32), C.c_int]),
+    'eg3d_noise_regularizer': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_float, C.c_void_p]),
+    'eg3d_noise_normalize': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
     'eg3d_ray_gen_fwd': (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]),
     'eg3d_ray_gen_bwd': (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
     'eg3d_render_fwd': (C.c_int, [C.POINTER(RenderParams), C.c_void_p]),

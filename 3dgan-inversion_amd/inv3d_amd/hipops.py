@@ -373,3 +373,31 @@ def sample_decode(p, coords, M):
     sigma = torch.empty((n, M, 1), dtype=torch.float32, device=coords.device)
     L.check(L.lib().eg3d_sample_decode(C.byref(p), L.ptr(coords), M, L.ptr(rgb), L.ptr(sigma), L.stream_ptr()), 'sample_decode')
     return rgb, sigma
+
+
+# ------------------------------------------------------------------------------------------------- noise buffers
+def _buf_arrays(bufs):
+    n = len(bufs)
+    xs = (C.c_void_p * n)(*[b.data_ptr() for b in bufs])
+    res = (C.c_int32 * n)(*[int(b.shape[-1]) for b in bufs])
+    return n, xs, res
+
+
+def noise_regularizer(bufs, scale=1.0, want_grad=True):
+    """Returns (reg [0-d tensor] = scale * regulariser, grads list or None) for square fp32 noise buffers, one launch."""
+    for b in bufs:
+        L.require_cuda(b)
+        assert b.dim() == 2 and b.shape[0] == b.shape[1] and b.is_contiguous() and b.dtype == torch.float32
+    n, xs, res = _buf_arrays(bufs)
+    dev = bufs[0].device
+    grads = [torch.empty_like(b) for b in bufs] if want_grad else None
+    gs = (C.c_void_p * n)(*[g.data_ptr() for g in grads]) if want_grad else (C.c_void_p * n)()
+    ws = torch.empty(int(L.lib().eg3d_noise_reg_workspace_floats(res, n)), dtype=torch.float32, device=dev)
+    reg = torch.empty((), dtype=torch.float32, device=dev)
+    L.check(L.lib().eg3d_noise_regularizer(xs, gs, res, n, L.ptr(ws), L.ptr(reg), float(scale), L.stream_ptr()), 'noise_regularizer')
+    return reg, grads
+
+
+def noise_normalize_(bufs):
+    n, xs, res = _buf_arrays(bufs)
+    L.check(L.lib().eg3d_noise_normalize(xs, res, n, L.stream_ptr()), 'noise_normalize')

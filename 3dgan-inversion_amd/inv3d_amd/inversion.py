@@ -18,6 +18,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import hipops
 from .torch_utils.ops import bias_act, conv2d_gradfix
 
 
@@ -47,18 +48,23 @@ class StubFeatureNet(torch.nn.Module):
         return torch.cat(feats, 1)
 
 
-def noise_regularizer(noise_bufs) -> torch.Tensor:
-    """Multi-scale shifted auto-correlation penalty on the noise maps (w_projector.py:221-237)."""
-    reg = 0.0
-    for v in noise_bufs:
-        noise = v[None, None]
-        while True:
-            reg = reg + (noise * torch.roll(noise, shifts=1, dims=3)).mean() ** 2
-            reg = reg + (noise * torch.roll(noise, shifts=1, dims=2)).mean() ** 2
-            if noise.shape[2] <= 8:
-                break
-            noise = F.avg_pool2d(noise, kernel_size=2)
-    return reg
+class _NoiseRegFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scale, *bufs):
+        reg, grads = hipops.noise_regularizer([b.detach() for b in bufs], scale=scale, want_grad=True)
+        ctx.save_for_backward(*grads)
+        return reg
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = ctx.saved_tensors
+        return (None,) + tuple(torch._foreach_mul(list(grads), g))
+
+
+def noise_regularizer(noise_bufs, weight: float = 1.0) -> torch.Tensor:
+    """weight * multi-scale shifted auto-correlation penalty on the noise maps (w_projector.py:221-237); value and gradient of
+    all buffers come from ONE fused launch (csrc/noise_ops.hip)."""
+    return _NoiseRegFn.apply(float(weight), *noise_bufs)
 
 
 def compute_tv_norm(values: torch.Tensor) -> torch.Tensor:
@@ -170,8 +176,8 @@ class LatentProjector:
             for b in list(self.noise_bufs.values()) + list(self.noise_bufs2.values()):
                 b.copy_(torch.randn(b.shape, device=dev, generator=self.gen))
                 b.requires_grad = True
-        self.optimizer = torch.optim.Adam([self.w_opt] + list(self.noise_bufs.values()) + list(self.noise_bufs2.values()),
-                                          betas=(0.9, 0.999), lr=first_inv_lr)
+        self._all_bufs = list(self.noise_bufs.values()) + list(self.noise_bufs2.values())
+        self.optimizer = torch.optim.Adam([self.w_opt] + self._all_bufs, betas=(0.9, 0.999), lr=first_inv_lr, fused=True)
         self.intrinsic = torch.tensor([4.2647, 0, 0.5, 0, 4.2647, 0.5, 0, 0, 1], device=dev).unsqueeze(0)
         self.init_ext = torch.tensor([1, 0, 0, 0, 0, -1, 0, 0, 0, 0, -1, 2.7, 0, 0, 0, 1.], device=dev).reshape(1, 4, 4)
         self.canonical_cam = torch.cat([self.init_ext.reshape(1, 16), self.intrinsic], -1)
@@ -223,8 +229,8 @@ class LatentProjector:
         if img.shape[2] > 256:
             img = F.interpolate(img, size=(256, 256), mode='area')
         dist = (self.target_features - self.feature_net(img)).square().sum()
-        reg = noise_regularizer(list(self.noise_bufs.values()) + list(self.noise_bufs2.values()))
-        loss = dist + reg * self.reg_w
+        reg = noise_regularizer(self._all_bufs, self.reg_w)           # already weighted
+        loss = dist + reg
         warp = None
         if self.use_warp and self.optimize_pose:
             warp = warping_loss(G, ws, self.canonical_cam, pred_ext, self.init_ext, self.intrinsic, out['image_depth'],
@@ -240,10 +246,7 @@ class LatentProjector:
             self.translation_optimizer.step()
         if step >= self.preheat:
             self.optimizer.step()
-        with torch.no_grad():
-            for b in list(self.noise_bufs.values()) + list(self.noise_bufs2.values()):
-                b -= b.mean()
-                b *= b.square().mean().rsqrt()
+        hipops.noise_normalize_(self._all_bufs)        # buf -= mean; buf *= rsqrt(mean(buf^2))   (w_projector.py:264-270)
         self.step_idx += 1
         self.last = dict(loss=loss.detach(), dist=dist.detach(), reg=reg.detach() if torch.is_tensor(reg) else reg, image=out['image'].detach(),
                          cam=pred_cam.detach(), ws=ws.detach())

@@ -39,7 +39,9 @@ class _BiasAct(torch.autograd.Function):
         trivial = spec.cuda_idx == 1 and gain == 1 and clamp < 0 and bb is None
         y = x if trivial else H.bias_act_raw(x, bb, None, None, None, 0, dim, spec.cuda_idx, alpha, gain, clamp)
         keep_x = 'x' in spec.ref or spec.has_2nd_grad
-        ctx.save_for_backward(x if keep_x else None, bb if keep_x else None, y if 'y' in spec.ref else None)
+        # y is also kept whenever a clamp is active: the reference's native path drops it for 'linear'/'swish' and thereby ignores
+        # the clamp in the gradient (bias_act.py:153-156 + bias_act.cu:145); the `_ref` path -- the parity anchor -- honours it.
+        ctx.save_for_backward(x if keep_x else None, bb if keep_x else None, y if ('y' in spec.ref or clamp >= 0) else None)
         ctx.cfg = (dim, spec, alpha, gain, clamp, bb is not None, x.dim())
         return y
 

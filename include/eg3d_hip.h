@@ -190,6 +190,19 @@ int eg3d_demod_bwd(const float* s, const float* wsq, const float* d, const float
                    int N, int Co, int Ck, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Noise-buffer maintenance of the latent projector (training/projectors/w_projector.py:221-237 noise regulariser and its
+ * autograd backward; :264-270 renormalisation), all buffers in one launch each.  x[i]: [res[i],res[i]] fp32 device
+ * buffers (res a power of two), nbufs <= 32.
+ *   regularizer: *reg_out = scale * sum_buffers sum_levels (mean(x*roll(x,1,W))^2 + mean(x*roll(x,1,H))^2) over the avg-pool
+ *                pyramid res, res/2, ... (last level <= 8); grad[i] (may be null / contain nulls) = d(*reg_out)/d x[i].
+ *   normalize:   x <- (x - mean(x)) * rsqrt(mean((x - mean)^2))   in place.
+ */
+int64_t eg3d_noise_reg_workspace_floats(const int32_t* res, int nbufs);
+int eg3d_noise_regularizer(float* const* x, float* const* grad, const int32_t* res, int nbufs, float* workspace,
+                           float* reg_out, float scale, void* stream);
+int eg3d_noise_normalize(float* const* x, const int32_t* res, int nbufs, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Volume renderer -- replaces RaySampler.forward (training/volumetric_rendering/ray_sampler.py:24-73) and
  * ImportanceRenderer.forward (renderer.py:143-195: sample_stratified, sample_from_planes/grid_sample, OSGDecoder
  * triplane.py:124-136, MipRayMarcher2 ray_marcher.py:25-57, sample_importance/sample_pdf, unify_samples), fused

@@ -410,3 +410,26 @@ def test_run_model_vs_oracle():
     rgb_r, sig_r = O.run_model(P, planes, coords, cfg.rendering)
     out = ImportanceRenderer().run_model(planes.to(DEV), _decoder(P), coords.to(DEV), None, cfg.rendering)
     close(out['rgb'], rgb_r, 1e-5, 'run_model rgb'); close(out['sigma'], sig_r, 1e-5, 'run_model sigma')
+
+
+# ------------------------------------------------------------------------------------------------- noise buffers
+def test_noise_regularizer_and_normalize():
+    from inv3d_amd import hipops as H
+    from inv3d_amd.inversion import noise_regularizer
+    g = torch.Generator().manual_seed(31)
+    bufs = [torch.randn(r, r, generator=g) for r in (4, 8, 16, 64, 128, 512)]
+    ref_in = [b.clone().requires_grad_(True) for b in bufs]
+    reg_r = O.noise_regularizer(ref_in) * 1e5
+    gr = torch.autograd.grad(reg_r, ref_in)
+    dev_in = [b.to(DEV).requires_grad_(True) for b in bufs]
+    reg = noise_regularizer(dev_in, 1e5)
+    close(reg, reg_r, 1e-4, 'noise reg value')
+    gg = torch.autograd.grad(reg * 2.0, dev_in)
+    for a, b in zip(gg, gr):
+        close(a, b * 2.0, 1e-4, 'noise reg grad')
+    dn = [b.to(DEV).clone() for b in bufs]
+    H.noise_normalize_(dn)
+    for a, b in zip(dn, bufs):
+        e = b - b.mean()
+        e = e * e.square().mean().rsqrt()
+        close(a, e, 1e-5, 'noise normalize')
