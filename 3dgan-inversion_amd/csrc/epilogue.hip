@@ -168,6 +168,38 @@ __global__ void __launch_bounds__(256) epilogue_bwd_kernel(const float* __restri
     if (dstrength && threadIdx.x == 0 && rs[0] != 0.f) unsafeAtomicAdd(dstrength, rs[0]);
 }
 
+// finish of a split-K data-gradient: dx = z * s[n,c] (+ addend);  ds[n,c] += sum_px z * x      (grid = (blocks, N))
+__global__ void __launch_bounds__(256) dgrad_finish_kernel(const float* __restrict__ z, const float* __restrict__ x, const float* __restrict__ s,
+                                                           const float* __restrict__ addend, float* __restrict__ dx, float* __restrict__ ds, int HW, int C4) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const int n = blockIdx.y, C = C4 * 4;
+    const int ppb = 256 / C4 > 0 ? 256 / C4 : 1;
+    const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
+    const bool active = pl < ppb;
+    const int c = c4 * 4;
+    float4 sv = make_float4(1, 1, 1, 1), acc = make_float4(0, 0, 0, 0);
+    if (active && s) sv = ld4(s + (int64_t)n * C + c);
+    if (active) {
+        for (int pix = blockIdx.x * ppb + pl; pix < HW; pix += gridDim.x * ppb) {
+            const int64_t off = ((int64_t)n * HW + pix) * C + c;
+            float4 zv = ld4(z + off);
+            if (ds) { float4 xv = ld4(x + off); acc.x += zv.x * xv.x; acc.y += zv.y * xv.y; acc.z += zv.z * xv.z; acc.w += zv.w * xv.w; }
+            float4 o = make_float4(zv.x * sv.x, zv.y * sv.y, zv.z * sv.z, zv.w * sv.w);
+            if (addend) { float4 a = ld4(addend + off); o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+            st4(dx + off, o);
+        }
+    }
+    if (ds == nullptr) return;
+    if (active) st4(red + (pl * C4 + c4) * 4, acc);
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        float4 t = make_float4(0, 0, 0, 0);
+        for (int q = 0; q < ppb; ++q) { float4 u = ld4(red + (q * C4 + c4) * 4); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        float* q = ds + (int64_t)n * C + c;
+        unsafeAtomicAdd(q + 0, t.x); unsafeAtomicAdd(q + 1, t.y); unsafeAtomicAdd(q + 2, t.z); unsafeAtomicAdd(q + 3, t.w);
+    }
+}
+
 __global__ void weight_sqsum_kernel(const float* __restrict__ w, float* __restrict__ wsq, int Co, int ntaps, int Ck) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Co * Ck) return;
@@ -258,10 +290,23 @@ extern "C" int eg3d_modconv_epilogue_bwd(const float* dout, const float* out, fl
     if ((dnoise || dstrength) && !noise) return EG3D_ERR_INVALID;
     const int C4 = C / 4;
     const int ppb = std::max(256 / C4, 1);
-    int bx = std::min(eg3d_cdiv((int64_t)H * W, ppb), std::max(1, 2048 / N));
+    // one atomic per (block, channel) lands on the same N*C addresses: keep the block count near the CU count
+    int bx = std::min(eg3d_cdiv((int64_t)H * W, ppb), std::max(1, 512 / N));
     size_t smem = (size_t)(ppb * C4 * 8 + 4) * sizeof(float);
     hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(bx, N), dim3(256), smem, (hipStream_t)stream, dout, out, dz, H, W, C4, d, noise, noise_nstride,
                        noise_strength, bias, act, alpha, gain, clamp, dbias, dd, dnoise, dnoise_nstride, dstrength);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_dgrad_finish(const float* z, const float* x, const float* s, const float* addend, float* dx, float* ds, int N, int H, int W, int C,
+                                 void* stream) {
+    if (!z || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (ds && !x)) return EG3D_ERR_INVALID;
+    if (C % 4 || C / 4 > 256) return EG3D_ERR_UNSUPPORTED;
+    const int C4 = C / 4, ppb = std::max(256 / C4, 1);
+    int bx = std::min(eg3d_cdiv((int64_t)H * W, ppb), std::max(1, 512 / N));
+    hipLaunchKernelGGL(dgrad_finish_kernel, dim3(bx, N), dim3(256), (size_t)ppb * C4 * 4 * sizeof(float), (hipStream_t)stream, z, x, s, addend, dx, ds,
+                       H * W, C4);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -142,8 +142,14 @@ class ModConvLayerFn(torch.autograd.Function):
         if need_x or need_s:
             dx = H.empty_cl(N, Ci, Hi, Wi, dev)
             ds = torch.zeros((N, Ci), device=dev)
-            H.conv_igemm(g, wa, Co, Ci, dx, cls_adj, in_stride=in_stride, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds,
-                         algo_flops=2.0 * N * Hi * Wi * kh * kw * Ci * Co)
+            aflops = 2.0 * N * Hi * Wi * kh * kw * Ci * Co
+            ks = _auto_ksplit(N * Hi * Wi, Ci, ((Co + 31) // 32) * kh * kw)
+            if ks == 1:
+                H.conv_igemm(g, wa, Co, Ci, dx, cls_adj, in_stride=in_stride, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, algo_flops=aflops)
+            else:                                  # low resolution: split K over blocks, then scale / reduce in a finishing pass
+                z = H.zeros_cl(N, Ci, Hi, Wi, dev)
+                H.conv_igemm(g, wa, Co, Ci, z, cls_adj, in_stride=in_stride, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops)
+                H.dgrad_finish(z, x, styles, dx, ds=ds)
         dwsq = torch.zeros_like(wsq) if need_w else None
         if dd is not None and (need_s or need_w):
             if ds is None:

@@ -264,6 +264,12 @@ def epilogue_bwd(dout, out, dz, d=None, noise=None, noise_nstride=0, noise_stren
     return dz
 
 
+def dgrad_finish(z, x, s, dx, ds=None, addend=None):
+    n, c, h, w = z.shape
+    L.check(L.lib().eg3d_dgrad_finish(L.ptr(z), L.ptr(x), L.ptr(s), L.ptr(addend), L.ptr(dx), L.ptr(ds), n, h, w, c, L.stream_ptr()), 'dgrad_finish')
+    return dx
+
+
 def weight_sqsum(wp, Co, ntaps, Ck):
     wsq = torch.empty((Co, Ck), dtype=torch.float32, device=wp.device)
     L.check(L.lib().eg3d_weight_sqsum(L.ptr(wp), L.ptr(wsq), Co, ntaps, Ck, L.stream_ptr()), 'weight_sqsum')

@@ -170,6 +170,11 @@ int eg3d_modconv_epilogue_bwd(const float* dout, const float* out, float* dz, in
                               float clamp, float* dbias, float* dd, float* dnoise, int64_t dnoise_nstride,
                               float* dstrength, void* stream);
 
+/* Finish of a split-K data gradient (low-resolution layers, where one launch cannot fill 256 CUs without splitting K):
+ *   z = conv data-gradient accumulated with EG3D_EPI_ATOMIC;  dx = z * s[n,c] (+ addend);  ds[n,c] += sum_px z * x  (if ds). */
+int eg3d_dgrad_finish(const float* z, const float* x, const float* s, const float* addend, float* dx, float* ds, int N, int H,
+                      int W, int C, void* stream);
+
 /* NHWC FIR resampler used on the fused path (skip-image 2x upsample and its adjoint, FIR adjoint of up=2 layers):
  *   same arithmetic as eg3d_upfirdn2d on a channels-last fp32 tensor, float4 over channels (C % 4 == 0),
  *   optional accumulate into y (y += result). */
