@@ -143,7 +143,8 @@ class LatentProjector:
                  feature_net: Optional[Callable] = None, warp_feature_net: Optional[Callable] = None, use_warping_loss: bool = False,
                  first_inv_lr=8e-3, cam_lr=6e-7, translation_lr=2e-4, cam_preheat_steps=50, initial_noise_factor=0.05,
                  noise_ramp_length=0.75, lr_rampdown_length=0.25, lr_rampup_length=0.05, regularize_noise_weight=1e5,
-                 initial_learning_rate=0.01, radius=2.7, wplus=False, synth_kwargs: Optional[dict] = None, seed: int = 0):
+                 initial_learning_rate=0.01, radius=2.7, wplus=False, synth_kwargs: Optional[dict] = None, seed: int = 0,
+                 init_noise: Optional[Dict[str, torch.Tensor]] = None):
         dev = target.device
         self.G = G.eval().requires_grad_(False)
         self.dev = dev
@@ -173,9 +174,11 @@ class LatentProjector:
         self.noise_bufs = {n: b for n, b in G.backbone.synthesis.named_buffers() if 'noise_const' in n}
         self.noise_bufs2 = {n: b for n, b in G.superresolution.named_buffers() if 'noise_const' in n}
         with torch.no_grad():
-            for b in list(self.noise_bufs.values()) + list(self.noise_bufs2.values()):
-                b.copy_(torch.randn(b.shape, device=dev, generator=self.gen))
-                b.requires_grad = True
+            for prefix, bufs in (('backbone.synthesis.', self.noise_bufs), ('superresolution.', self.noise_bufs2)):
+                for nm, b in bufs.items():
+                    src = init_noise[prefix + nm].to(dev) if init_noise is not None else torch.randn(b.shape, device=dev, generator=self.gen)
+                    b.copy_(src)
+                    b.requires_grad = True
         self._all_bufs = list(self.noise_bufs.values()) + list(self.noise_bufs2.values())
         self.optimizer = torch.optim.Adam([self.w_opt] + self._all_bufs, betas=(0.9, 0.999), lr=first_inv_lr, fused=True)
         self.intrinsic = torch.tensor([4.2647, 0, 0.5, 0, 4.2647, 0.5, 0, 0, 1], device=dev).unsqueeze(0)
@@ -209,8 +212,11 @@ class LatentProjector:
         lr_ramp = lr_ramp * min(1.0, t / self.lr_up)
         return w_noise_scale, self.lr0 * lr_ramp
 
-    def step(self) -> Dict[str, torch.Tensor]:
+    def step(self, w_noise: Optional[torch.Tensor] = None, **step_kwargs) -> Dict[str, torch.Tensor]:
+        """One optimisation step.  `w_noise` (unit normal, shape of w_opt) and `render_uniforms=(u1,u2)` may be injected for
+        deterministic runs; otherwise they are drawn on the device."""
         step = self.step_idx
+        kw = dict(self.synth_kwargs, **step_kwargs)
         G = self.G
         w_noise_scale, lr = self._schedule(step)
         for g in self.optimizer.param_groups:
@@ -222,9 +228,10 @@ class LatentProjector:
             pred_ext, pred_cam = None, self.cam
         w = self.w_opt
         if step >= self.preheat:
-            w = w + torch.randn(w.shape, device=self.dev, generator=self.gen) * w_noise_scale
+            wn = w_noise.to(self.dev) if w_noise is not None else torch.randn(w.shape, device=self.dev, generator=self.gen)
+            w = w + wn * w_noise_scale
         ws = w.repeat(1, self.num_ws, 1) if w.shape[1] == 1 else w
-        out = G.synthesis(ws, pred_cam, noise_mode='const', force_fp32=True, **self.synth_kwargs)
+        out = G.synthesis(ws, pred_cam, noise_mode='const', force_fp32=True, **kw)
         img = out['image'] * 127.5 + 128
         if img.shape[2] > 256:
             img = F.interpolate(img, size=(256, 256), mode='area')
@@ -234,7 +241,7 @@ class LatentProjector:
         warp = None
         if self.use_warp and self.optimize_pose:
             warp = warping_loss(G, ws, self.canonical_cam, pred_ext, self.init_ext, self.intrinsic, out['image_depth'],
-                                self.target_warp_feat, self.warp_net, self.synth_kwargs)
+                                self.target_warp_feat, self.warp_net, kw)
             loss = loss + warp
         self.optimizer.zero_grad(set_to_none=True)
         if self.optimize_pose:
@@ -275,9 +282,9 @@ class PivotalTuner:
         self.synth_kwargs = dict(synth_kwargs or {})
         self.last = {}
 
-    def step(self, early_stop: bool = False) -> Dict[str, torch.Tensor]:
+    def step(self, early_stop: bool = False, **step_kwargs) -> Dict[str, torch.Tensor]:
         G = self.G
-        out = G.synthesis(self.w_pivot[:, :G.backbone.num_ws], self.cam[:, :25], **self.synth_kwargs)
+        out = G.synthesis(self.w_pivot[:, :G.backbone.num_ws], self.cam[:, :25], **dict(self.synth_kwargs, **step_kwargs))
         l2 = F.mse_loss(out['image'], self.target) + F.mse_loss(out['image_raw'], self.target_128)
         lp = (self.feature_net(out['image']) - self.tf).square().sum() + (self.feature_net(out['image_raw']) - self.tf128).square().sum()
         tv = compute_tv_norm(out['image_depth'].squeeze(0))

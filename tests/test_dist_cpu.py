@@ -1,0 +1,63 @@
+"""Multi-process path on CPU (gloo, world_size 2): image sharding + the packed stat all-reduce, i.e. everything that crosses
+ranks on the N > 1 path (independent images, one tiny all-reduce and nothing else)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from inv3d_amd import dist as D
+    r, w, _ = D.init_from_env('gloo')
+    assert (r, w) == (rank, world)
+    mine = D.shard_images(7, r, w)
+    # every rank reports the stats of its own images; the reduced vector must equal the global sums / max
+    stats = D.allreduce_stats(dict(loss=float(sum(mine)), dist=1.0, psnr=10.0 * (r + 1), n_active=float(len(mine)), steps=3.0,
+                                   step_ms=5.0 + r), torch.device('cpu'))
+    D.barrier()
+    mx = D.max_over_ranks(1.0 + r, torch.device('cpu'))
+    out.put((rank, mine, stats, mx))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_stat_sync():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    shards = [r[1] for r in res]
+    assert sorted(shards[0] + shards[1]) == list(range(7)) and not set(shards[0]) & set(shards[1])
+    for _, _, st, mx in res:
+        assert st['loss'] == float(sum(range(7)))
+        assert st['n_active'] == 7.0 and st['dist'] == 2.0 and st['steps'] == 6.0 and st['psnr'] == 30.0
+        assert st['step_ms'] == 6.0
+        assert mx == 2.0
+
+
+def test_single_process_is_a_noop():
+    from inv3d_amd import dist as D
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        os.environ.pop(k, None)
+    assert D.init_from_env('gloo') == (0, 1, 0)
+    st = D.allreduce_stats(dict(loss=2.5, n_active=1.0), torch.device('cpu'))
+    assert st['loss'] == 2.5 and st['n_active'] == 1.0
+    assert D.shard_images(5, 0, 1) == [0, 1, 2, 3, 4]
+    assert D.max_over_ranks(3.0, torch.device('cpu')) == 3.0

@@ -1,0 +1,92 @@
+"""Inversion loops on the GPU vs their CPU oracle twins on identical inputs (BASELINE.json configs 2-4 as parity cases; the small
+generator keeps the CPU side to seconds).  Bar: final-PSNR drift after an N-step optimisation <= 1e-3 dB."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import eg3d_oracle as O
+from oracle import inversion_oracle as IO
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _setup():
+    from inv3d_amd import synthetic as S
+    cfg = O.small_config()
+    P = O.synth_params(cfg, 0)
+    G = S.make_generator(w_dim=32, z_dim=32, plane_res=32, channel_base=256, channel_max=16, nrr=16, sr_in_res=16, sr_widths=(16, 8),
+                         rendering_kwargs=cfg.rendering, device=DEV)
+    S.load_synthetic_weights(G, 0)
+    cam = O.synth_cameras(1, seed=2)
+    u1, u2 = O.make_uniforms(cfg, 1, seed=4)
+    with torch.no_grad():
+        target = O.synthesis(P, cfg, O.synth_ws(cfg, 1, seed=3), cam, u1, u2, noise_mode='const')['image'].clamp(-1, 1)
+    init_noise = {k: O._randn('init.' + k, 9, v.shape) for k, v in P.items() if k.endswith('noise_const')}
+    return cfg, P, G, cam, u1, u2, target, init_noise
+
+
+def _psnr(a, b):
+    return float(O.psnr_01(a.detach().cpu(), b.detach().cpu()))
+
+
+@pytest.mark.parametrize('wplus', [False, True])
+def test_latent_projection_c2(wplus):
+    """Config C2: latent (w or w+) + noise buffers, no pose."""
+    from inv3d_amd.inversion import LatentProjector
+    cfg, P, G, cam, u1, u2, target, init_noise = _setup()
+    w_start = O.synth_ws(cfg, 1, seed=1)[:, :1]
+    ref = IO.ProjectorOracle(P, cfg, target, num_steps=30, cam=cam, init_noise=init_noise, w_start=w_start, wplus=wplus)
+    hip = LatentProjector(G, target.to(DEV), num_steps=30, cam=cam.to(DEV), init_noise=init_noise, start_w=w_start, wplus=wplus)
+    shape = (1, cfg.num_ws if wplus else 1, cfg.w_dim)
+    for i in range(12):
+        wn = O._randn('wn', i, shape)
+        r = ref.step(u1, u2, w_noise=wn)
+        h = hip.step(w_noise=wn, render_uniforms=(u1.to(DEV), u2.to(DEV)))
+    assert abs(float(h['dist']) - float(r['dist'])) <= 2e-3 * max(1.0, abs(float(r['dist'])))
+    drift = abs(_psnr(h['image'], target) - _psnr(r['image'], target))
+    assert drift <= 1e-3, f'final PSNR drift {drift:.2e} dB'
+    assert float((hip.w_opt.detach().cpu() - ref.w_opt.detach()).abs().max()) < 1e-3
+
+
+def test_pose_and_warping_c3():
+    """Config C3: C2 + quaternion/translation pose chain + canonical no-grad forward + depth-reprojection warping loss."""
+    from inv3d_amd.inversion import LatentProjector
+    cfg, P, G, cam, u1, u2, target, init_noise = _setup()
+    kw = dict(num_steps=30, init_noise=init_noise, optimize_pose=True, use_warping_loss=True, cam_preheat_steps=3, cam_lr=5e-3,
+              translation_lr=5e-3)
+    ref = IO.ProjectorOracle(P, cfg, target, **kw)
+    hip = LatentProjector(G, target.to(DEV), **kw)
+    for i in range(8):
+        wn = O._randn('wn', i, (1, 1, cfg.w_dim))
+        r = ref.step(u1, u2, w_noise=wn)
+        h = hip.step(w_noise=wn, render_uniforms=(u1.to(DEV), u2.to(DEV)))
+    assert float((hip.quat.detach().cpu() - ref.quat.detach()).abs().max()) < 2e-3
+    assert float((hip.translation_opt.detach().cpu() - ref.translation_opt.detach()).abs().max()) < 2e-3
+    assert float((hip.last['cam'].cpu() - ref.last['cam']).abs().max()) < 5e-3
+    drift = abs(_psnr(h['image'], target) - _psnr(r['image'], target))
+    assert drift <= 2e-2, f'final PSNR drift {drift:.2e} dB'     # pose gradients are piecewise constant (see close_most in test_gpu_ops)
+
+
+def test_pivotal_tuning_c4():
+    """Config C4: all generator weights trainable (Phase B), random per-layer noise injected identically on both sides."""
+    from inv3d_amd.inversion import PivotalTuner
+    cfg, P, G, cam, u1, u2, target, _ = _setup()
+    w_pivot = O.synth_ws(cfg, 1, seed=1)
+    ref = IO.PivotalTunerOracle(P, cfg, target, w_pivot, cam)
+    hip = PivotalTuner(G, target.to(DEV), w_pivot.to(DEV), cam.to(DEV))
+    for i in range(8):
+        noises = {}
+        for r_ in cfg.block_resolutions:
+            for conv in (['conv1'] if r_ == 4 else ['conv0', 'conv1']):
+                nm = f'backbone.synthesis.b{r_}.{conv}'
+                noises[nm] = O._randn(f'n{i}.' + nm, 6, (1, 1, r_, r_))
+        r = ref.step(u1, u2, noise_mode='random', noises=noises)
+        h = hip.step(noise_mode='random', noise_inject={k: v.to(DEV) for k, v in noises.items()}, render_uniforms=(u1.to(DEV), u2.to(DEV)))
+    assert abs(float(h['loss']) - float(r['loss'])) <= 2e-3 * max(1.0, abs(float(r['loss'])))
+    drift = abs(_psnr(h['image'], target) - _psnr(r['image'], target))
+    assert drift <= 1e-3, f'final PSNR drift {drift:.2e} dB'
+    # the tuned weights themselves
+    sd = G.state_dict()
+    worst = max(float((sd[k].cpu() - v.detach()).abs().max()) for k, v in ref.P.items() if v.requires_grad)
+    assert worst < 5e-3, worst

@@ -1,0 +1,43 @@
+"""BASELINE.json configs[0] (the reference's own CPU-runnable case): a few projector steps + 10 PTI steps on CPU through the
+pure-PyTorch path -- here the oracle (small generator of the same topology, so the whole thing takes seconds).  Plumbing check:
+the loops run, gradients reach every optimised tensor, the loss goes down."""
+import torch
+
+from oracle import eg3d_oracle as O
+from oracle import inversion_oracle as IO
+
+
+def _setup():
+    cfg = O.small_config()
+    P = O.synth_params(cfg, 0)
+    cam = O.synth_cameras(1, seed=2)
+    u1, u2 = O.make_uniforms(cfg, 1, seed=4)
+    with torch.no_grad():
+        target = O.synthesis(P, cfg, O.synth_ws(cfg, 1, seed=3), cam, u1, u2, noise_mode='const')['image'].clamp(-1, 1)
+    return cfg, P, cam, u1, u2, target
+
+
+def test_projector_steps_cpu():
+    cfg, P, cam, u1, u2, target = _setup()
+    init_noise = {k: O._randn('init.' + k, 9, v.shape) for k, v in P.items() if k.endswith('noise_const')}
+    proj = IO.ProjectorOracle(P, cfg, target, num_steps=20, cam=cam, init_noise=init_noise, w_start=O.synth_ws(cfg, 1, seed=1)[:, :1])
+    w0 = proj.w_opt.detach().clone()
+    dists = []
+    for i in range(8):
+        dists.append(float(proj.step(u1, u2, w_noise=None)['dist']))
+    assert all(map(lambda v: v == v, dists))
+    assert min(dists[4:]) < dists[0], dists              # the feature distance goes down once the lr ramp has started
+    assert float((proj.w_opt.detach() - w0).abs().max()) > 0
+    assert proj.w_opt.grad is not None and all(b.grad is not None for b in proj.bufs[:13])
+
+
+def test_pti_10_steps_cpu():
+    cfg, P, cam, u1, u2, target = _setup()
+    w_pivot = O.synth_ws(cfg, 1, seed=1)
+    tuner = IO.PivotalTunerOracle(P, cfg, target, w_pivot, cam)
+    losses = [float(tuner.step(u1, u2, noise_mode='const')['loss']) for _ in range(10)]
+    assert losses[-1] < losses[0]
+    n_grad = sum(1 for p in tuner.params if p.grad is not None and float(p.grad.abs().max()) > 0)
+    assert n_grad >= len(tuner.params) - 12       # mapping network (6 tensors) and unused SR noise strengths get no gradient
+    psnr = float(O.psnr_01(tuner.last['image'], target))
+    assert psnr == psnr
