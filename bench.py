@@ -35,56 +35,32 @@ DOMINANT = 0                        # tile configuration id of conv_igemm_kernel
 
 
 def cpu_baseline_c2(seconds_budget=30.0):
-    """Time the oracle's C2 step (same generator shape, same loss structure) on the host cores."""
-    import torch.nn.functional as F
+    """Time the oracle's C2 step (same generator shape, same loss structure: oracle/inversion_oracle.ProjectorOracle) on the host."""
     from oracle import eg3d_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    from oracle import inversion_oracle as IO
+    threads = min(os.cpu_count() or 1, 32)        # more threads than this only adds contention for these op sizes
+    torch.set_num_threads(threads)
     cfg = O.full_config()
     P = O.synth_params(cfg, seed=0)
-    nb = [k for k in P if k.endswith('noise_const')]
-    for k in nb:
-        P[k] = P[k].clone().requires_grad_(True)
-    w_opt = O.synth_ws(cfg, 1, seed=1)[:, :1].clone().requires_grad_(True)
     c = O.synth_cameras(1, seed=2)
     u1, u2 = O.make_uniforms(cfg, 1, seed=4)
     g = torch.Generator().manual_seed(3)
-    target = torch.rand(1, 3, 256, 256, generator=g) * 255
-    opt = torch.optim.Adam([w_opt] + [P[k] for k in nb], lr=8e-3)
-
-    def feat(img):                       # same structure as StubFeatureNet, plain torch on CPU
-        gw = torch.Generator().manual_seed(1234)
-        x, cin, out = torch.cat([img, img.new_zeros(1, 1, *img.shape[2:])], 1), 4, []
-        for wd in (16, 32, 64):
-            wt = torch.randn(wd, cin, 3, 3, generator=gw) / (cin * 9) ** 0.5
-            x = F.avg_pool2d(F.leaky_relu(F.conv2d(x, wt, padding=1), 0.2) * 2 ** 0.5, 2)
-            f = x * torch.rsqrt(x.square().sum(1, keepdim=True) + 1e-10)
-            out.append(f.flatten(1) / (f.shape[2] * f.shape[3]) ** 0.5)
-            cin = wd
-        return torch.cat(out, 1)
-    tf = feat(target)
-
-    def step():
-        ws = w_opt.repeat(1, cfg.num_ws, 1)
-        o = O.synthesis(P, cfg, ws, c, u1, u2, noise_mode='const')
-        img = F.interpolate(o['image'] * 127.5 + 128, size=(256, 256), mode='area')
-        loss = (tf - feat(img)).square().sum() + 1e5 * O.noise_regularizer([P[k] for k in nb])
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
+    target = torch.rand(1, 3, 512, 512, generator=g) * 2 - 1
+    proj = IO.ProjectorOracle(P, cfg, target, num_steps=400, cam=c, w_start=O.synth_ws(cfg, 1, seed=1)[:, :1])
     t0 = time.time()
-    step()                                # warm-up
+    proj.step(u1, u2)                       # warm-up
     warm = time.time() - t0
     times = []
     while len(times) < 3 and (time.time() - t0) < seconds_budget:
         t1 = time.time()
-        step()
+        proj.step(u1, u2)
         times.append(time.time() - t1)
     if not times:
         times = [warm]
     times.sort()
     med = times[len(times) // 2]
-    return dict(value=1.0 / med, unit='steps/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'oracle C2 step, full-size generator, N=1: 1 warm-up + {len(times)} timed steps (median {med:.2f} s/step)')
+    return dict(value=round(1.0 / med, 4), unit='steps/s', cores=threads, kind='port',
+                sample=f'oracle C2 step (ProjectorOracle), full-size generator, N=1: 1 warm-up + {len(times)} timed steps, median {med:.2f} s/step')
 
 
 def main():
