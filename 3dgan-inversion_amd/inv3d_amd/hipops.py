@@ -18,8 +18,9 @@ class LaunchProfiler:
     """Optional per-launch timing of the implicit-GEMM conv (bench.py roofline): HIP events recorded on the launch stream
     around every eg3d_conv2d_igemm_f32 call, with the launch's algorithmic FLOPs and tile configuration."""
 
-    def __init__(self):
+    def __init__(self, only_config=None):
         self.records = []          # (config_id, algo_flops, start_event, end_event)
+        self.only_config = only_config      # time only launches of this tile configuration (keeps the event overhead small)
 
     def summary(self):
         out = {}
@@ -207,10 +208,13 @@ def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=
     p.ds = ds.data_ptr() if ds is not None else None
     prof = PROFILER
     if prof is not None:
+        cfg = L.lib().eg3d_conv2d_igemm_config(C.byref(p))
+        if prof.only_config is not None and cfg != prof.only_config:
+            prof = None
+    if prof is not None:
         if algo_flops is None:
             algo_flops = 2.0 * Ck * Nc * sum(n * c.Ha * c.Wa * c.ntaps for c in classes)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        cfg = L.lib().eg3d_conv2d_igemm_config(C.byref(p))
         e0.record()
     L.check(L.lib().eg3d_conv2d_igemm_f32(C.byref(p), L.stream_ptr()), 'conv2d_igemm_f32')
     if prof is not None:
