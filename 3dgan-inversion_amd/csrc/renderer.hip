@@ -73,6 +73,39 @@ __device__ __forceinline__ void gather_feats(const float* __restrict__ pn, int H
     for (int c = 0; c < FC; ++c) f[c] = f[c] / 3.f;
 }
 
+// same arithmetic, but plane/corner loops kept rolled: at most 8 texel loads in flight, for kernels that trade in-flight loads
+// for occupancy (the sample-level backward)
+__device__ __forceinline__ void gather_feats_rolled(const float* __restrict__ pn, int Hp, int Wp, int ldp, float cs, float x, float y, float z,
+                                                    float (&f)[FC]) {
+#pragma unroll
+    for (int c = 0; c < FC; ++c) f[c] = 0.f;
+#pragma unroll 1
+    for (int pl = 0; pl < 3; ++pl) {
+        float u, v;
+        plane_uv(pl, x * cs, y * cs, z * cs, u, v);
+        float ix = ((u + 1.f) * Wp - 1.f) * 0.5f, iy = ((v + 1.f) * Hp - 1.f) * 0.5f;
+        float fx0 = floorf(ix), fy0 = floorf(iy);
+        int x0 = (int)fx0, y0 = (int)fy0;
+        float wx1 = ix - fx0, wx0 = (fx0 + 1.f) - ix, wy1 = iy - fy0, wy0 = (fy0 + 1.f) - iy;
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+            int xx = x0 + (q & 1), yy = y0 + (q >> 1);
+            if ((unsigned)xx < (unsigned)Wp && (unsigned)yy < (unsigned)Hp) {
+                const float4* t = reinterpret_cast<const float4*>(pn + ((int64_t)yy * Wp + xx) * ldp + pl * FC);
+                float w = ((q & 1) ? wx1 : wx0) * ((q >> 1) ? wy1 : wy0);
+#pragma unroll
+                for (int c4 = 0; c4 < FC / 4; ++c4) {
+                    float4 tv = t[c4];
+                    f[c4 * 4 + 0] = fmaf(w, tv.x, f[c4 * 4 + 0]); f[c4 * 4 + 1] = fmaf(w, tv.y, f[c4 * 4 + 1]);
+                    f[c4 * 4 + 2] = fmaf(w, tv.z, f[c4 * 4 + 2]); f[c4 * 4 + 3] = fmaf(w, tv.w, f[c4 * 4 + 3]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < FC; ++c) f[c] = f[c] / 3.f;
+}
+
 // 32 -> 64 (softplus) -> 33; w1t is [HD][1+CO] (transposed so that a hidden unit's fan-out is contiguous)
 __device__ __forceinline__ void mlp_fwd(const float* __restrict__ w0, const float* __restrict__ b0, const float* __restrict__ w1t,
                                         const float* __restrict__ b1, const float (&f)[FC], float (&out)[1 + CO]) {
@@ -181,16 +214,33 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
     float depth_c = 0.f, sig_c = 0.f, rgb_c[NKEEP], e_c = 0.f;
 #pragma unroll
     for (int k = 0; k < NKEEP; ++k) rgb_c[k] = 0.f;
-    if (has_c) {
+    if constexpr (BWD) if (has_c) {      // ray-level backward: (sigma, colour) come from the forward's save buffers
+        depth_c = coarse_depth(p, rr, s, p.u1[rr * Dc + s]);
+        const int64_t row = (rr * 2 + 0) * D + s;
+        sig_c = p.save_sigma[row];
+        const float4* c4p = reinterpret_cast<const float4*>(p.save_rgb + row * CO);
+#pragma unroll
+        for (int c4 = 0; c4 < CO / 4; ++c4) {
+            float4 v = c4p[c4];
+            e_c = fmaf(grgb[c4 * 4], v.x, e_c); e_c = fmaf(grgb[c4 * 4 + 1], v.y, e_c);
+            e_c = fmaf(grgb[c4 * 4 + 2], v.z, e_c); e_c = fmaf(grgb[c4 * 4 + 3], v.w, e_c);
+        }
+        L.dc[s] = depth_c; L.sc[s] = sig_c;
+    }
+    if constexpr (!BWD) if (has_c) {
         float f[FC], out[1 + CO];
         depth_c = coarse_depth(p, rr, s, p.u1[rr * Dc + s]);
         gather_feats(pn, p.Hp, p.Wp, p.ldp, cs, ox + depth_c * dx, oy + depth_c * dy, oz + depth_c * dz, f);   // mul+add like the reference (no fma)
         mlp_fwd(p.w0, p.b0, p.w1, p.b1, f, out);
         sig_c = out[0];
 #pragma unroll
-        for (int k = 0; k < CO; ++k) {
-            float c = sigmoidf_(out[1 + k]) * 1.002f - 0.001f;
-            if (BWD) e_c = fmaf(grgb[k], c, e_c); else rgb_c[k] = c;
+        for (int k = 0; k < CO; ++k) rgb_c[k] = sigmoidf_(out[1 + k]) * 1.002f - 0.001f;
+        if (p.save_sigma) {                 // training mode: keep (sigma, colour) per sample for the backward
+            const int64_t row = (rr * 2 + 0) * D + s;
+            p.save_sigma[row] = sig_c;
+            float4* o = reinterpret_cast<float4*>(p.save_rgb + row * CO);
+#pragma unroll
+            for (int c4 = 0; c4 < CO / 4; ++c4) o[c4] = make_float4(rgb_c[c4 * 4], rgb_c[c4 * 4 + 1], rgb_c[c4 * 4 + 2], rgb_c[c4 * 4 + 3]);
         }
         L.dc[s] = depth_c; L.sc[s] = sig_c;
     }
@@ -254,15 +304,31 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
     float sig_f = 0.f, rgb_f[NKEEP], e_f = 0.f;
 #pragma unroll
     for (int k = 0; k < NKEEP; ++k) rgb_f[k] = 0.f;
-    if (has_f) {
+    if constexpr (BWD) if (has_f) {
+        const int64_t row = (rr * 2 + 1) * D + s;
+        sig_f = p.save_sigma[row];
+        const float4* c4p = reinterpret_cast<const float4*>(p.save_rgb + row * CO);
+#pragma unroll
+        for (int c4 = 0; c4 < CO / 4; ++c4) {
+            float4 v = c4p[c4];
+            e_f = fmaf(grgb[c4 * 4], v.x, e_f); e_f = fmaf(grgb[c4 * 4 + 1], v.y, e_f);
+            e_f = fmaf(grgb[c4 * 4 + 2], v.z, e_f); e_f = fmaf(grgb[c4 * 4 + 3], v.w, e_f);
+        }
+        L.df[s] = depth_f; L.sf[s] = sig_f;
+    }
+    if constexpr (!BWD) if (has_f) {
         float f[FC], out[1 + CO];
         gather_feats(pn, p.Hp, p.Wp, p.ldp, cs, ox + depth_f * dx, oy + depth_f * dy, oz + depth_f * dz, f);
         mlp_fwd(p.w0, p.b0, p.w1, p.b1, f, out);
         sig_f = out[0];
 #pragma unroll
-        for (int k = 0; k < CO; ++k) {
-            float c = sigmoidf_(out[1 + k]) * 1.002f - 0.001f;
-            if (BWD) e_f = fmaf(grgb[k], c, e_f); else rgb_f[k] = c;
+        for (int k = 0; k < CO; ++k) rgb_f[k] = sigmoidf_(out[1 + k]) * 1.002f - 0.001f;
+        if (p.save_sigma) {
+            const int64_t row = (rr * 2 + 1) * D + s;
+            p.save_sigma[row] = sig_f;
+            float4* o = reinterpret_cast<float4*>(p.save_rgb + row * CO);
+#pragma unroll
+            for (int c4 = 0; c4 < CO / 4; ++c4) o[c4] = make_float4(rgb_f[c4 * 4], rgb_f[c4 * 4 + 1], rgb_f[c4 * 4 + 2], rgb_f[c4 * 4 + 3]);
         }
         L.df[s] = depth_f; L.sf[s] = sig_f;
     }
@@ -388,26 +454,51 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
     }
     __syncthreads();
 
-    // ---- per-sample backward: colours/density -> MLP -> features; features -> planes is done by the tile-binned scatter
-    //      (eg3d_triplane_scatter) from the dumped (d_feature, position) rows; features -> coordinates here -------------
-    float gcoord[3] = {0.f, 0.f, 0.f};       // dL/d(o + t*dir) summed over this thread's samples
-    float gdir[3] = {0.f, 0.f, 0.f};
-    const bool want_coord = bp.d_origins != nullptr || bp.d_dirs != nullptr;
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-        const bool has = pass == 0 ? has_c : has_f;
-        const int64_t sample_id = (rr * 2 + pass) * D + s;       // row in the dump buffers
-        if (!has) {
-            if (live && bp.df_pos) bp.df_pos[sample_id * 4] = NAN;    // absent sample: skipped by the scatter
-            continue;
-        }
-        const int rank = pass == 0 ? rank_c : rank_f;
-        const float depth = pass == 0 ? depth_c : depth_f;
-        const float a = 0.5f * ((rank > 0 ? L.w[rank - 1] : 0.f) + (rank < nI ? L.w[rank] : 0.f));
-        const float gsig = 0.5f * ((rank > 0 ? GA[rank - 1] : 0.f) + (rank < nI ? GA[rank] : 0.f));
+    // per-sample results of the ray-level pass: a = colour weight (dL/d colour = 2 a d_rgb), gsig = dL/d sigma
+    if (has_c) {
+        const float a = 0.5f * ((rank_c > 0 ? L.w[rank_c - 1] : 0.f) + (rank_c < nI ? L.w[rank_c] : 0.f));
+        const float gs = 0.5f * ((rank_c > 0 ? GA[rank_c - 1] : 0.f) + (rank_c < nI ? GA[rank_c] : 0.f));
+        reinterpret_cast<float2*>(bp.ag_rows)[(rr * 2 + 0) * D + s] = make_float2(a, gs);
+    }
+    if (has_f) {
+        const float a = 0.5f * ((rank_f > 0 ? L.w[rank_f - 1] : 0.f) + (rank_f < nI ? L.w[rank_f] : 0.f));
+        const float gs = 0.5f * ((rank_f > 0 ? GA[rank_f - 1] : 0.f) + (rank_f < nI ? GA[rank_f] : 0.f));
+        reinterpret_cast<float2*>(bp.ag_rows)[(rr * 2 + 1) * D + s] = make_float2(a, gs);
+    }
+}
+
+// ---- sample-level backward: one thread per (ray, pass, s) row; no coupling between threads -----------------------------------
+// colours/density -> MLP -> features; features -> planes goes through the tile-binned scatter below (rows of dL/d feature +
+// position); features -> coordinates is written per row and summed per ray by render_coord_reduce_kernel.
+__global__ void __launch_bounds__(256) render_sample_bwd_kernel(const eg3d_render_bwd_params bp) {
+    const eg3d_render_params& p = bp.fwd;
+    const int D = p.Dc > p.Df ? p.Dc : p.Df;
+    const int64_t S = (int64_t)p.N * p.R * 2 * D;
+    const int64_t sample_id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sample_id >= S) return;
+    const int64_t rr = sample_id / (2 * D);
+    const int rem = (int)(sample_id - rr * 2 * D);
+    const int pass = rem / D, s = rem - pass * D;
+    const bool has = s < (pass == 0 ? p.Dc : p.Df);
+    const bool want_coord = bp.gc_rows != nullptr;
+    if (!has) {
+        if (bp.df_pos) bp.df_pos[sample_id * 4] = NAN;          // absent sample: skipped by the scatter
+        if (want_coord) reinterpret_cast<float4*>(bp.gc_rows)[sample_id] = make_float4(0, 0, 0, 0);
+        return;
+    }
+    const int n = (int)(rr / p.R);
+    const float* pn = p.planes + (int64_t)n * p.Hp * p.Wp * p.ldp;
+    const float cs = 2.f / p.box_warp;
+    const float ox = p.origins[rr * 3 + 0], oy = p.origins[rr * 3 + 1], oz = p.origins[rr * 3 + 2];
+    const float dx = p.dirs[rr * 3 + 0], dy = p.dirs[rr * 3 + 1], dz = p.dirs[rr * 3 + 2];
+    const float depth = pass == 0 ? coarse_depth(p, rr, s, p.u1[rr * p.Dc + s]) : p.fine_depths[rr * p.Df + s];
+    const float2 ag = reinterpret_cast<const float2*>(bp.ag_rows)[sample_id];
+    const float a = ag.x, gsig = ag.y;
+    const float* grgb = bp.d_rgb + rr * CO;
+    {
         const float px = ox + depth * dx, py = oy + depth * dy, pz = oz + depth * dz;
         float f[FC], dout[1 + CO];
-        gather_feats(pn, p.Hp, p.Wp, p.ldp, cs, px, py, pz, f);
+        gather_feats_rolled(pn, p.Hp, p.Wp, p.ldp, cs, px, py, pz, f);
         mlp_fwd(p.w0, p.b0, p.w1, p.b1, f, dout);
         dout[0] = gsig;
 #pragma unroll
@@ -428,7 +519,7 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
         float df[FC];
 #pragma unroll
         for (int c = 0; c < FC; ++c) df[c] = 0.f;
-#pragma unroll 2
+#pragma unroll 1
         for (int j = 0; j < HD; ++j) {
             const float* wj = p.w0 + j * FC;
             float pre = p.b0[j];
@@ -454,7 +545,7 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
         }
         if (want_coord) {
             float gx = 0.f, gy = 0.f, gz = 0.f;
-#pragma unroll
+#pragma unroll 1
             for (int pl = 0; pl < 3; ++pl) {
                 float u, v;
                 plane_uv(pl, px * cs, py * cs, pz * cs, u, v);
@@ -463,7 +554,7 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
                 int x0 = (int)fx0, y0 = (int)fy0;
                 float wx1 = ix - fx0, wx0 = (fx0 + 1.f) - ix, wy1 = iy - fy0, wy0 = (fy0 + 1.f) - iy;
                 float gix = 0.f, giy = 0.f;
-#pragma unroll
+#pragma unroll 1
                 for (int q = 0; q < 4; ++q) {
                     int xx = x0 + (q & 1), yy = y0 + (q >> 1);
                     if ((unsigned)xx < (unsigned)p.Wp && (unsigned)yy < (unsigned)p.Hp) {
@@ -484,25 +575,25 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
                 float gu = gix * (0.5f * p.Wp) * cs, gv = giy * (0.5f * p.Hp) * cs;
                 if (pl == 0) { gx += gu; gy += gv; } else if (pl == 1) { gx += gu; gz += gv; } else { gz += gu; gx += gv; }
             }
-            gcoord[0] += gx; gcoord[1] += gy; gcoord[2] += gz;
-            gdir[0] += gx * depth; gdir[1] += gy * depth; gdir[2] += gz * depth;
+            reinterpret_cast<float4*>(bp.gc_rows)[sample_id] = make_float4(gx, gy, gz, depth);
         }
     }
-    if (want_coord) {
-        __syncthreads();
-        float* my = red + 2 * RPB * 2 * D + tid * 7;
-        if (tid < nthreads) {
-            my[0] = gcoord[0]; my[1] = gcoord[1]; my[2] = gcoord[2]; my[3] = gdir[0]; my[4] = gdir[1]; my[5] = gdir[2];
-        }
-        __syncthreads();
-        if (live && s < 6) {          // D >= 6 (host-checked)
-            float acc = 0.f;
-            const float* col = red + 2 * RPB * 2 * D + (r * D) * 7 + s;
-            for (int j = 0; j < D; ++j) acc += col[j * 7];
-            if (s < 3) { if (bp.d_origins) bp.d_origins[rr * 3 + s] = acc; }
-            else if (bp.d_dirs) bp.d_dirs[rr * 3 + (s - 3)] = acc;
-        }
+}
+
+// d_origins[ray] = sum_rows g;  d_dirs[ray] = sum_rows depth * g
+__global__ void __launch_bounds__(256) render_coord_reduce_kernel(const float4* __restrict__ gc, float* __restrict__ d_o, float* __restrict__ d_d,
+                                                                  int64_t nrays, int rows_per_ray) {
+    const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= nrays) return;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    const float4* g = gc + ray * rows_per_ray;
+    for (int i = 0; i < rows_per_ray; ++i) {
+        const float4 v = g[i];
+        o0 += v.x; o1 += v.y; o2 += v.z;
+        d0 += v.x * v.w; d1 += v.y * v.w; d2 += v.z * v.w;
     }
+    if (d_o) { d_o[ray * 3] = o0; d_o[ray * 3 + 1] = o1; d_o[ray * 3 + 2] = o2; }
+    if (d_d) { d_d[ray * 3] = d0; d_d[ray * 3 + 1] = d1; d_d[ray * 3 + 2] = d2; }
 }
 
 // =========================================================================================================
@@ -834,12 +925,20 @@ extern "C" int eg3d_render_bwd(const eg3d_render_bwd_params* bp, void* stream) {
     if (!bp) return EG3D_ERR_INVALID;
     int rc = check_render(bp->fwd);
     if (rc) return rc;
-    if (!bp->d_rgb || !bp->fwd.depth_minmax) return EG3D_ERR_INVALID;
     const eg3d_render_params& p = bp->fwd;
+    if (!bp->d_rgb || !p.depth_minmax || !p.save_sigma || !p.save_rgb || !bp->ag_rows) return EG3D_ERR_INVALID;
+    if ((bp->d_origins || bp->d_dirs) && !bp->gc_rows) return EG3D_ERR_INVALID;
+    if ((bp->df_rows != nullptr) != (bp->df_pos != nullptr)) return EG3D_ERR_INVALID;
     const int D = p.Dc > p.Df ? p.Dc : p.Df;
     const int RPB = MAXT / D;
     const int64_t nrays = (int64_t)p.N * p.R;
-    hipLaunchKernelGGL(render_kernel<true>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(p), (hipStream_t)stream, *bp);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(render_kernel<true>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(p), st, *bp);
+    const int64_t S = nrays * 2 * D;
+    hipLaunchKernelGGL(render_sample_bwd_kernel, dim3(eg3d_cdiv(S, 256)), dim3(256), 0, st, *bp);
+    if (bp->d_origins || bp->d_dirs)
+        hipLaunchKernelGGL(render_coord_reduce_kernel, dim3(eg3d_cdiv(nrays, 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(bp->gc_rows),
+                           bp->d_origins, bp->d_dirs, nrays, 2 * D);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -54,12 +54,13 @@ class RenderParams(C.Structure):
                 ('ray_limits', C.c_void_p), ('disparity', C.c_int32), ('box_warp', C.c_float), ('white_back', C.c_int32),
                 ('w0', C.c_void_p), ('b0', C.c_void_p), ('w1', C.c_void_p), ('b1', C.c_void_p), ('Hdim', C.c_int32),
                 ('Cout', C.c_int32), ('rgb', C.c_void_p), ('depth', C.c_void_p), ('wsum', C.c_void_p),
-                ('depth_minmax', C.c_void_p), ('fine_depths', C.c_void_p)]
+                ('depth_minmax', C.c_void_p), ('fine_depths', C.c_void_p), ('save_sigma', C.c_void_p), ('save_rgb', C.c_void_p)]
 
 
 class RenderBwdParams(C.Structure):
     _fields_ = [('fwd', RenderParams), ('depth_out', C.c_void_p), ('d_rgb', C.c_void_p), ('d_depth', C.c_void_p),
-                ('d_wsum', C.c_void_p), ('df_rows', C.c_void_p), ('df_pos', C.c_void_p), ('d_origins', C.c_void_p), ('d_dirs', C.c_void_p),
+                ('d_wsum', C.c_void_p), ('df_rows', C.c_void_p), ('df_pos', C.c_void_p), ('ag_rows', C.c_void_p), ('gc_rows', C.c_void_p), ('d_origins', C.c_void_p),
+                ('d_dirs', C.c_void_p),
                 ('dump_dpre', C.c_void_p), ('dump_h', C.c_void_p), ('dump_dout', C.c_void_p), ('dump_feat', C.c_void_p)]
 
 

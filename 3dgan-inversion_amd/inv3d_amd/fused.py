@@ -292,16 +292,21 @@ class RenderFn(torch.autograd.Function):
         minmax = torch.tensor([float('inf'), float('-inf')], device=dev)
         fine = torch.empty((N, R, max(Df, 1)), device=dev)
         rl = ray_limits.contiguous().float() if ray_limits is not None else None
-        p = H.make_render_params(planes, origins, dirs, u1, u2, opts, w0g, b0g, w1t, b1g, rgb, depth, wsum, minmax, fine, rl)
+        save = None
+        if any(ctx.needs_input_grad[:7]):          # training mode: keep (sigma, colour) per sample (207 MB at the FFHQ config)
+            S = N * R * 2 * max(Dc, Df)
+            save = (torch.empty((S,), device=dev), torch.empty((S, w1.shape[0] - 1), device=dev))
+        p = H.make_render_params(planes, origins, dirs, u1, u2, opts, w0g, b0g, w1t, b1g, rgb, depth, wsum, minmax, fine, rl, save)
         H.render_fwd(p)
         H.render_finalize(depth, minmax)
-        ctx.save_for_backward(planes, origins, dirs, w0g, b0g, w1t, b1g, u1, u2, minmax, fine, rl)
+        ctx.save_for_backward(planes, origins, dirs, w0g, b0g, w1t, b1g, u1, u2, minmax, fine, rl, *(save or ()))
         ctx.cfg = (dict(opts), g0, g1, lr_mul)
         return rgb, depth, wsum
 
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_wsum):
-        planes, origins, dirs, w0g, b0g, w1t, b1g, u1, u2, minmax, fine, rl = ctx.saved_tensors
+        planes, origins, dirs, w0g, b0g, w1t, b1g, u1, u2, minmax, fine, rl = ctx.saved_tensors[:12]
+        save = ctx.saved_tensors[12:14]
         opts, g0, g1, lr_mul = ctx.cfg
         need = ctx.needs_input_grad
         dev = planes.device
@@ -309,7 +314,7 @@ class RenderFn(torch.autograd.Function):
         g_rgb = g_rgb.contiguous().float() if g_rgb is not None else torch.zeros((N, R, w1t.shape[1] - 1), device=dev)
         g_depth = g_depth.contiguous().float() if g_depth is not None else None
         g_wsum = g_wsum.contiguous().float() if g_wsum is not None else None
-        p = H.make_render_params(planes, origins, dirs, u1, u2, opts, w0g, b0g, w1t, b1g, None, None, None, minmax, fine, rl)
+        p = H.make_render_params(planes, origins, dirs, u1, u2, opts, w0g, b0g, w1t, b1g, None, None, None, minmax, fine, rl, save)
         d_planes = torch.zeros_like(planes) if need[0] else None
         d_o = torch.empty_like(origins) if (need[1] or need[2]) else None
         d_d = torch.empty_like(dirs) if (need[1] or need[2]) else None

@@ -313,7 +313,7 @@ def ray_gen_bwd(c2w, K, g_o, g_d, res, want_K=True):
     return d_c2w, d_K
 
 
-def make_render_params(planes, origins, dirs, u1, u2, opts, w0, b0, w1t, b1, rgb, depth, wsum, minmax, fine, ray_limits=None):
+def make_render_params(planes, origins, dirs, u1, u2, opts, w0, b0, w1t, b1, rgb, depth, wsum, minmax, fine, ray_limits=None, save=None):
     """planes: channels_last [N, 3*C, Hp, Wp]; decoder weights with gains folded (w1t transposed [H, 1+Cout])."""
     assert is_cl(planes)
     p = L.RenderParams()
@@ -339,6 +339,8 @@ def make_render_params(planes, origins, dirs, u1, u2, opts, w0, b0, w1t, b1, rgb
     p.wsum = wsum.data_ptr() if wsum is not None else None
     p.depth_minmax = minmax.data_ptr() if minmax is not None else None
     p.fine_depths = fine.data_ptr() if fine is not None else None
+    if save is not None:
+        p.save_sigma, p.save_rgb = save[0].data_ptr(), save[1].data_ptr()
     return p
 
 
@@ -359,11 +361,17 @@ def render_bwd(p, d_rgb, d_depth, d_wsum, d_planes, d_origins, d_dirs, dumps=Non
     bp.d_depth = d_depth.data_ptr() if d_depth is not None else None
     bp.d_wsum = d_wsum.data_ptr() if d_wsum is not None else None
     rows = pos = None
+    D = max(p.Dc, p.Df)
+    S = p.N * p.R * 2 * D
+    dev = d_rgb.device
+    ag = torch.empty((S, 2), dtype=torch.float32, device=dev)
+    bp.ag_rows = ag.data_ptr()
+    if d_origins is not None or d_dirs is not None:
+        gc = torch.empty((S, 4), dtype=torch.float32, device=dev)
+        bp.gc_rows = gc.data_ptr()
     if d_planes is not None:
-        D = max(p.Dc, p.Df)
-        S = p.N * p.R * 2 * D
-        rows = torch.empty((S, 32), dtype=torch.float32, device=d_planes.device)
-        pos = torch.empty((S, 4), dtype=torch.float32, device=d_planes.device)
+        rows = torch.empty((S, 32), dtype=torch.float32, device=dev)
+        pos = torch.empty((S, 4), dtype=torch.float32, device=dev)
         bp.df_rows, bp.df_pos = rows.data_ptr(), pos.data_ptr()
     bp.d_origins = d_origins.data_ptr() if d_origins is not None else None
     bp.d_dirs = d_dirs.data_ptr() if d_dirs is not None else None

@@ -245,6 +245,10 @@ typedef struct eg3d_render_params {
     float* wsum;               /* [N,R]                                                    */
     float* depth_minmax;       /* [2] running global (min,max) of all sample depths; init (+inf,-inf) */
     float* fine_depths;        /* [N,R,Df] workspace: importance depths (re-used by backward)*/
+    /* training mode (both or neither): the forward keeps (sigma, colour) of every sample for the backward.
+     * Row ((n*R + ray)*2 + pass)*D + s, pass 0 = coarse / 1 = fine, D = max(Dc,Df).                                  */
+    float* save_sigma;         /* [S]                                                      */
+    float* save_rgb;           /* [S,Cout]                                                 */
 } eg3d_render_params;
 
 int eg3d_render_fwd(const eg3d_render_params* p, void* stream);
@@ -262,6 +266,8 @@ typedef struct eg3d_render_bwd_params {
      * accumulates them in LDS (a direct scatter would be 384 float atomics per sample).  Both null = no plane gradient. */
     float* df_rows;            /* [S,32]                                                   */
     float* df_pos;             /* [S,4] (x,y,z,-); x = NaN marks an absent sample          */
+    float* ag_rows;            /* [S,2] workspace: per-sample (colour weight, dL/d sigma) from the ray-level pass */
+    float* gc_rows;            /* [S,4] workspace: per-sample (dL/d position, depth); required with d_origins/d_dirs */
     float* d_origins;          /* [N,R,3] overwritten, or null                             */
     float* d_dirs;             /* [N,R,3] overwritten, or null                             */
     /* Decoder-weight gradients (PTI phase): when non-null the kernel dumps, for sample row
@@ -276,7 +282,10 @@ typedef struct eg3d_render_bwd_params {
 
 int eg3d_render_bwd(const eg3d_render_bwd_params* p, void* stream);
 
-/* d_planes[N,Hp,Wp,ldp] (pre-zeroed) += bilinear-adjoint scatter of the S dumped rows (grid_sample backward w.r.t. the
+/* eg3d_render_bwd = a ray-level kernel (merge, march, reverse scan -> ag_rows) + a sample-level kernel (gather, decoder
+ * forward/backward -> df_rows/df_pos, gc_rows, optional decoder dumps) + a per-ray reduction of gc_rows.
+ *
+ * d_planes[N,Hp,Wp,ldp] (pre-zeroed) += bilinear-adjoint scatter of the S dumped rows (grid_sample backward w.r.t. the
  * planes, renderer.py:64 under autograd).  rows_per_image = R*2*D.  workspace: eg3d_triplane_scatter_workspace_ints() int32. */
 int64_t eg3d_triplane_scatter_workspace_ints(int64_t S, int N, int Hp, int Wp);
 int eg3d_triplane_scatter(const float* df_rows, const float* df_pos, int64_t S, int64_t rows_per_image, float* d_planes, int N,
