@@ -17,6 +17,7 @@
 // bytes of LDS per ray.  The composite colour uses  sum_i w_i (c_i + c_{i+1})/2 = sum_j c_j (w_{j-1} + w_j)/2  so the
 // 2 x 32 colours of a thread never leave its registers.
 #include "common.h"
+#include "render_common.h"
 
 namespace {
 
@@ -454,6 +455,12 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
     }
     __syncthreads();
 
+    // position rows (x, y, z, depth) of this thread's two samples: input of the sample-level kernel and of the plane scatter
+    if (live && s < D) {
+        float4* pr = reinterpret_cast<float4*>(bp.df_pos);
+        pr[(rr * 2 + 0) * D + s] = has_c ? make_float4(ox + depth_c * dx, oy + depth_c * dy, oz + depth_c * dz, depth_c) : make_float4(NAN, 0, 0, 0);
+        pr[(rr * 2 + 1) * D + s] = has_f ? make_float4(ox + depth_f * dx, oy + depth_f * dy, oz + depth_f * dz, depth_f) : make_float4(NAN, 0, 0, 0);
+    }
     // per-sample results of the ray-level pass: a = colour weight (dL/d colour = 2 a d_rgb), gsig = dL/d sigma
     if (has_c) {
         const float a = 0.5f * ((rank_c > 0 ? L.w[rank_c - 1] : 0.f) + (rank_c < nI ? L.w[rank_c] : 0.f));
@@ -963,14 +970,15 @@ extern "C" int eg3d_render_bwd(const eg3d_render_bwd_params* bp, void* stream) {
     const eg3d_render_params& p = bp->fwd;
     if (!bp->d_rgb || !p.depth_minmax || !p.save_sigma || !p.save_rgb || !bp->ag_rows) return EG3D_ERR_INVALID;
     if ((bp->d_origins || bp->d_dirs) && !bp->gc_rows) return EG3D_ERR_INVALID;
-    if ((bp->df_rows != nullptr) != (bp->df_pos != nullptr)) return EG3D_ERR_INVALID;
+    if (!bp->df_pos) return EG3D_ERR_INVALID;
     const int D = p.Dc > p.Df ? p.Dc : p.Df;
     const int RPB = MAXT / D;
     const int64_t nrays = (int64_t)p.N * p.R;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(render_kernel<true>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(p), st, *bp);
     const int64_t S = nrays * 2 * D;
-    hipLaunchKernelGGL(render_sample_bwd_kernel, dim3(eg3d_cdiv(S, 256)), dim3(256), 0, st, *bp);
+    if (getenv("EG3D_VALU_DECODE")) hipLaunchKernelGGL(render_sample_bwd_kernel, dim3(eg3d_cdiv(S, 256)), dim3(256), 0, st, *bp);
+    else { int rc2 = eg3d_decode_rows_bwd(*bp, bp->df_pos, 0, S, (int64_t)p.R * 2 * D, 2 * D, stream); if (rc2) return rc2; }
     if (bp->d_origins || bp->d_dirs)
         hipLaunchKernelGGL(render_coord_reduce_kernel, dim3(eg3d_cdiv(nrays, 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(bp->gc_rows),
                            bp->d_origins, bp->d_dirs, nrays, 2 * D);
@@ -1019,6 +1027,7 @@ extern "C" int eg3d_sample_decode(const eg3d_render_params* pp, const float* coo
     if (!p.planes || !p.w0 || !p.b0 || !p.w1 || !p.b1 || p.N <= 0) return EG3D_ERR_INVALID;
     if (p.C != FC || p.Hdim != HD || p.Cout != CO || p.ldp < 3 * FC || (p.ldp & 3)) return EG3D_ERR_UNSUPPORTED;
     if (M == 0) return EG3D_OK;
+    if (!getenv("EG3D_VALU_DECODE")) return eg3d_decode_rows_fwd(p, coords, 3, (int64_t)p.N * M, M, sigma, rgb, stream);
     hipLaunchKernelGGL(sample_decode_kernel, dim3(eg3d_cdiv((int64_t)p.N * M, 256)), dim3(256), 0, (hipStream_t)stream, p, coords, M, rgb, sigma);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;

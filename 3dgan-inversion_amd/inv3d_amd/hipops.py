@@ -369,10 +369,11 @@ def render_bwd(p, d_rgb, d_depth, d_wsum, d_planes, d_origins, d_dirs, dumps=Non
     if d_origins is not None or d_dirs is not None:
         gc = torch.empty((S, 4), dtype=torch.float32, device=dev)
         bp.gc_rows = gc.data_ptr()
+    pos = torch.empty((S, 4), dtype=torch.float32, device=dev)          # (x, y, z, depth) per sample row, NaN = absent
+    bp.df_pos = pos.data_ptr()
     if d_planes is not None:
         rows = torch.empty((S, 32), dtype=torch.float32, device=dev)
-        pos = torch.empty((S, 4), dtype=torch.float32, device=dev)
-        bp.df_rows, bp.df_pos = rows.data_ptr(), pos.data_ptr()
+        bp.df_rows = rows.data_ptr()
     bp.d_origins = d_origins.data_ptr() if d_origins is not None else None
     bp.d_dirs = d_dirs.data_ptr() if d_dirs is not None else None
     if dumps is not None:
