@@ -19,27 +19,62 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int BK = 32;
+constexpr int BK = 32;                    // K per step, fp32 path
 constexpr int LDK = BK + 4;
+// split-bf16 paths: K per step is 16 (one v_mfma_f32_32x32x16_bf16 deep) for the 128x128 tile, 32 for the smaller tiles.
+// LDS image of one operand tile of R rows: [piece][k-octet = 2*chunk + h][row][8 bf16]; a wave's fragment read (lane = row, h)
+// is two contiguous 512-byte runs -> conflict-free ds_read_b128.  The 128-byte pad staggers the banks of the two halves.
+__host__ __device__ constexpr int split_plane_bytes(int rows) { return rows * 16 + 128; }
+__host__ __device__ constexpr int split_tile_bytes(int rows, int np, int kb) { return np * (kb / 8) * split_plane_bytes(rows); }
+
+// Split-bf16 operand pieces (precision 1/2): an fp32 value is cut into bf16 terms by truncation,
+//   x = b0 + b1 + b2 + e,  |e| < 2^-24 |x|   (every subtraction below is exact; the pieces are the operands of
+//   v_mfma_f32_32x32x16_bf16, whose products are exact and accumulated in fp32).
+// loader-side split of four consecutive-k values into NP bf16 pieces (4 bf16 = 8 bytes per piece)
+template <int NP>
+__device__ __forceinline__ void split4(const float4 v, uint2* out) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned w[3][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const unsigned u0 = __float_as_uint(x[2 * q]), u1 = __float_as_uint(x[2 * q + 1]);
+        w[0][q] = __builtin_amdgcn_perm(u1, u0, 0x07060302);
+        const float r0 = x[2 * q] - __uint_as_float(u0 & 0xffff0000u), r1 = x[2 * q + 1] - __uint_as_float(u1 & 0xffff0000u);
+        const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+        w[1][q] = __builtin_amdgcn_perm(v1, v0, 0x07060302);
+        const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+        w[2][q] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302);
+    }
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) out[pc] = make_uint2(w[pc][0], w[pc][1]);
+}
 
 __device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 
-template <int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const eg3d_conv_params p) {
+template <int BM, int BN, int WM, int WN, int PREC>
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? (PREC ? 3 : 2) : 1) conv_igemm_kernel(const eg3d_conv_params p) {
     constexpr int NT = WM * WN * 64;                        // 4 or 8 waves
-    constexpr int RPP = NT / 8;                             // tile rows covered by one pass of the loader (8 float4 per row)
+    constexpr int NP = PREC == 1 ? 3 : 2;                   // bf16 pieces per operand (split paths)
+    constexpr int KB = PREC ? (BM * BN >= 128 * 128 ? 16 : 32) : BK;      // K per step
+    constexpr int TPR = KB / 4;                             // loader threads per tile row (one float4 each)
+    constexpr int RPP = NT / TPR;                           // tile rows covered by one pass of the loader
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int A_LD = BM / RPP, B_LD = BN / RPP;         // float4 per thread per tile
-    static_assert(BM % RPP == 0 && BN % RPP == 0, "loader");
+    constexpr int A_LD = BM >= RPP ? BM / RPP : 1, B_LD = BN >= RPP ? BN / RPP : 1;         // float4 per thread per tile
+    static_assert((BM >= RPP ? BM % RPP : RPP % BM) == 0 && (BN >= RPP ? BN % RPP : RPP % BN) == 0, "loader");
     static_assert(TM >= 1 && TN >= 1, "tile");
+    constexpr int A_STAGE = PREC ? split_tile_bytes(BM, NP, KB) : BM * LDK * 4;      // bytes per pipeline stage
+    constexpr int B_STAGE = PREC ? split_tile_bytes(BN, NP, KB) : BN * LDK * 4;
+    constexpr int A_PIECE = (KB / 8) * split_plane_bytes(BM), B_PIECE = (KB / 8) * split_plane_bytes(BN);
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                         // [2][BM][LDK]
-    float* Bs = smem + 2 * BM * LDK;          // [2][BN][LDK]
-    int* rowpix = reinterpret_cast<int*>(Bs + 2 * BN * LDK);   // [BM] output pixel index (n*Ho+oy)*Wo+ox, -1 = none
+    char* const As_b = reinterpret_cast<char*>(smem);               // [2] stages
+    char* const Bs_b = As_b + 2 * A_STAGE;
+    float* As = smem;
+    int* rowpix = reinterpret_cast<int*>(Bs_b + 2 * B_STAGE);   // [BM] output pixel index (n*Ho+oy)*Wo+ox, -1 = none
     int* rown = rowpix + BM;                  // [BM] batch index
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -76,7 +111,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const eg3d_con
     // mask are computed once; per step the address is base + (wave-uniform tap/chunk offset), and an out-of-image tap (or
     // a row / channel past the end) is redirected to an out-of-range buffer offset, which the hardware returns as zeros.  No
     // divergent control flow in the K loop, so the loads interleave with the MFMAs of the previous step.
-    const int lrow = tid >> 3, col4 = tid & 7;
+    const int lrow = tid / TPR, col4 = tid % TPR;
     constexpr unsigned OOB = 0x7ffffff0u;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((int64_t)p.N * p.Hi * p.Wi * p.ldx * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)(((int64_t)(p.Nc - 1) * p.w_row + (int64_t)9 * p.Ck) * 4 > 0x7fffffe0 ? 0x7fffffe0 : ((int64_t)(p.Nc - 1) * p.w_row + (int64_t)9 * p.Ck) * 4), 0x00020000);
@@ -85,7 +120,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const eg3d_con
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
         int m = m0 + lrow + RPP * j;
-        const bool ok = m < Mc;
+        const bool ok = m < Mc && lrow + RPP * j < BM;
         int mm = ok ? m : 0;
         int n = mm / HWa;
         int rem = mm - n * HWa;
@@ -104,10 +139,10 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const eg3d_con
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
         int row = n0 + lrow + RPP * j;
-        b_base[j] = row < p.Nc ? (unsigned)(((int64_t)row * p.w_row + col4 * 4) * 4) : OOB;
+        b_base[j] = (row < p.Nc && lrow + RPP * j < BN) ? (unsigned)(((int64_t)row * p.w_row + col4 * 4) * 4) : OOB;
     }
 
-    const int nchunks = (p.Ck + BK - 1) / BK;
+    const int nchunks = (p.Ck + KB - 1) / KB;
     const int S = nchunks * ntaps;
     const int s_begin = (int)((int64_t)kslice * S / p.ksplit);
     const int s_end = (int)((int64_t)(kslice + 1) * S / p.ksplit);
@@ -118,15 +153,15 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const eg3d_con
 
     auto load_tiles = [&]() {
         const int chunk = nx_chunk, tap = nx_tap;
-        const bool kok = chunk * BK + col4 * 4 < p.Ck;
+        const bool kok = chunk * KB + col4 * 4 < p.Ck;
         if (p.in_scale != nullptr && chunk != cur_chunk) {
 #pragma unroll
             for (int j = 0; j < A_LD; ++j)
-                sc[j] = kok ? *reinterpret_cast<const float4*>(p.in_scale + (int64_t)a_n[j] * p.Ck + chunk * BK + col4 * 4) : make_float4(0, 0, 0, 0);
+                sc[j] = kok ? *reinterpret_cast<const float4*>(p.in_scale + (int64_t)a_n[j] * p.Ck + chunk * KB + col4 * 4) : make_float4(0, 0, 0, 0);
             cur_chunk = chunk;
         }
-        const unsigned aoff = (unsigned)(((cl.dy[tap] * p.Wi + cl.dx[tap]) * p.ldx + chunk * BK) * 4);       // wave-uniform
-        const unsigned boff = (unsigned)((cl.wtap[tap] * p.Ck + chunk * BK) * 4);
+        const unsigned aoff = (unsigned)(((cl.dy[tap] * p.Wi + cl.dx[tap]) * p.ldx + chunk * KB) * 4);       // wave-uniform
+        const unsigned boff = (unsigned)((cl.wtap[tap] * p.Ck + chunk * KB) * 4);
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
             const bool ok = kok && ((a_mask[j] >> tap) & 1u);
@@ -141,16 +176,43 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const eg3d_con
         if (++nx_tap == ntaps) { nx_tap = 0; ++nx_chunk; }
     };
     auto store_tiles = [&](int buf) {
-        float* a = As + buf * BM * LDK;
-        float* b = Bs + buf * BN * LDK;
+        if constexpr (PREC == 0) {
+            float* a = reinterpret_cast<float*>(As_b + buf * A_STAGE);
+            float* b = reinterpret_cast<float*>(Bs_b + buf * B_STAGE);
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j) {
-            float4 v = ra[j];
-            if (p.in_scale != nullptr) v = f4mul(v, sc[j]);
-            *reinterpret_cast<float4*>(a + (lrow + RPP * j) * LDK + col4 * 4) = v;
+            for (int j = 0; j < A_LD; ++j) {
+                float4 v = ra[j];
+                if (p.in_scale != nullptr) v = f4mul(v, sc[j]);
+                if (BM >= RPP || lrow < BM) *reinterpret_cast<float4*>(a + (lrow + RPP * j) * LDK + col4 * 4) = v;
+            }
+#pragma unroll
+            for (int j = 0; j < B_LD; ++j)
+                if (BN >= RPP || lrow < BN) *reinterpret_cast<float4*>(b + (lrow + RPP * j) * LDK + col4 * 4) = rb[j];
+        } else {
+            // thread (row, col4) owns k = 4*col4 .. +3  ->  k-octet col4>>1, 8-byte slot (col4&1) of the row's 16-byte group
+            char* a = As_b + buf * A_STAGE + (col4 >> 1) * split_plane_bytes(BM) + (col4 & 1) * 8;
+            char* b = Bs_b + buf * B_STAGE + (col4 >> 1) * split_plane_bytes(BN) + (col4 & 1) * 8;
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                float4 v = ra[j];
+                if (p.in_scale != nullptr) v = f4mul(v, sc[j]);
+                uint2 pc[NP];
+                split4<NP>(v, pc);
+                if (BM >= RPP || lrow < BM) {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(a + q * A_PIECE + (lrow + RPP * j) * 16) = pc[q];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < B_LD; ++j) {
+                uint2 pc[NP];
+                split4<NP>(rb[j], pc);
+                if (BN >= RPP || lrow < BN) {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(b + q * B_PIECE + (lrow + RPP * j) * 16) = pc[q];
+                }
+            }
         }
-#pragma unroll
-        for (int j = 0; j < B_LD; ++j) *reinterpret_cast<float4*>(b + (lrow + RPP * j) * LDK + col4 * 4) = rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -175,8 +237,9 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const eg3d_con
         const int buf = (step - s_begin) & 1;
         const bool more = step + 1 < s_end;
         if (more) load_tiles();
-        const float* a = As + buf * BM * LDK;
-        const float* b = Bs + buf * BN * LDK;
+        if constexpr (PREC == 0) {
+        const float* a = reinterpret_cast<const float*>(As_b + buf * A_STAGE);
+        const float* b = reinterpret_cast<const float*>(Bs_b + buf * B_STAGE);
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
             float4 af[TM], bf[TN];
@@ -194,6 +257,33 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const eg3d_con
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                 }
         }
+        } else {
+            // split-bf16: PREC 1 = six products (b0b0, b0b1, b1b0, b1b1, b0b2, b2b0; dropped terms < 2^-23), PREC 2 = three
+            // (b0b0, b0b1, b1b0; dropped terms < 2^-15).  Small terms are accumulated first.
+            const char* a = As_b + buf * A_STAGE + (lane >> 5) * split_plane_bytes(BM) + arow * 16;
+            const char* b = Bs_b + buf * B_STAGE + (lane >> 5) * split_plane_bytes(BN) + brow * 16;
+#pragma unroll
+            for (int kc = 0; kc < KB / 16; ++kc) {
+                bf16x8 af[NP][TM], bf[NP][TN];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[q][i] = *reinterpret_cast<const bf16x8*>(a + q * A_PIECE + kc * 2 * split_plane_bytes(BM) + i * 32 * 16);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[q][j] = *reinterpret_cast<const bf16x8*>(b + q * B_PIECE + kc * 2 * split_plane_bytes(BN) + j * 32 * 16);
+                }
+                // product-major order: the TM*TN accumulators are independent, so consecutive MFMAs never wait on each other
+                constexpr int NPROD = PREC == 1 ? 6 : 3;
+                constexpr int PA[6] = {0, 1, 0, 1, 2, 0}, PB[6] = {0, 0, 1, 1, 0, 2};      // issued from the back: small terms first
+#pragma unroll
+                for (int t = NPROD - 1; t >= 0; --t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t]][i], bf[PB[t]][j], acc[i][j], 0, 0, 0);
+            }
+        }
         if (more) store_tiles(buf ^ 1);
         __syncthreads();
     }
@@ -205,6 +295,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const eg3d_con
     const bool single_n = (m_last / HWa) == n_first;
     float* ds_lds = As;                     // BN floats, reused after the final barrier
     const bool do_ds = (epi == EG3D_EPI_BWD) && p.ds != nullptr && p.xin != nullptr;
+    float* const ds_out = p.ds_replicas > 1 ? p.ds + (size_t)(blockIdx.x % p.ds_replicas) * p.N * p.Nc : p.ds;
     if (do_ds && single_n) {
         if (tid < BN) ds_lds[tid] = 0.f;
         __syncthreads();
@@ -220,36 +311,56 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const eg3d_con
         const float bias = (epi == EG3D_EPI_FWD && p.bias != nullptr && cok) ? p.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            // Two phases per half tile (8 rows per lane): every side input (style scale, noise, skip addend, layer input for the
+            // style gradient) is requested first, the arithmetic and the stores follow.  Interleaving them per element makes
+            // each load wait for the previous store (the compiler must assume out / addend / xin alias).
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int pix = rowpix[rl];
-                if (pix < 0 || !cok) continue;
-                const int64_t off = (int64_t)pix * p.ldo + col;
-                float v = acc[i][j][r];
-                if (epi == EG3D_EPI_STORE) {
-                    p.out[off] = v;
-                } else if (epi == EG3D_EPI_ATOMIC) {
-                    unsafeAtomicAdd(p.out + off, v);
-                } else if (epi == EG3D_EPI_FWD) {
-                    const int n = rown[rl];
-                    if (p.out_scale != nullptr) v *= p.out_scale[(int64_t)n * p.Nc + col];
-                    if (p.noise != nullptr) v += p.noise[(int64_t)n * p.noise_nstride + (pix - n * HWo)] * strength;
-                    v += bias;
-                    v = eg3d_act_fwd<float>(v, p.act, p.alpha) * p.gain;
-                    if (p.clamp >= 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
-                    if (p.addend != nullptr) v += p.addend[off];
-                    p.out[off] = v;
-                } else {   // EG3D_EPI_BWD
-                    const int n = rown[rl];
-                    if (do_ds) {
-                        float t = v * p.xin[off];
-                        if (single_n) dsum += t;
-                        else unsafeAtomicAdd(p.ds + (int64_t)n * p.Nc + col, t);
+            for (int rh = 0; rh < 16; rh += 8) {
+                int offs[8];
+                float scl[8], sidea[8], sideb[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = rh + q;
+                    const int rl = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int pix = rowpix[rl];
+                    const bool ok = pix >= 0 && cok;
+                    const int off = ok ? pix * p.ldo + col : -1;
+                    offs[q] = off;
+                    scl[q] = 1.f; sidea[q] = 0.f; sideb[q] = 0.f;
+                    if (epi == EG3D_EPI_FWD || epi == EG3D_EPI_BWD) {
+                        const int n = rown[rl];
+                        if (ok && p.out_scale != nullptr) scl[q] = p.out_scale[(int64_t)n * p.Nc + col];
+                        if (ok && p.addend != nullptr) sidea[q] = p.addend[off];
+                        if (epi == EG3D_EPI_FWD) {
+                            if (ok && p.noise != nullptr) sideb[q] = p.noise[(int64_t)n * p.noise_nstride + (pix - n * HWo)];
+                        } else if (ok && do_ds) {
+                            sideb[q] = p.xin[off];
+                        }
                     }
-                    if (p.out_scale != nullptr) v *= p.out_scale[(int64_t)n * p.Nc + col];
-                    if (p.addend != nullptr) v += p.addend[off];
-                    p.out[off] = v;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = rh + q;
+                    const int off = offs[q];
+                    if (off < 0) continue;
+                    float v = acc[i][j][r];
+                    if (epi == EG3D_EPI_STORE) {
+                        p.out[off] = v;
+                    } else if (epi == EG3D_EPI_ATOMIC) {
+                        unsafeAtomicAdd(p.out + off, v);
+                    } else if (epi == EG3D_EPI_FWD) {
+                        v = v * scl[q] + sideb[q] * strength + bias;
+                        v = eg3d_act_fwd<float>(v, p.act, p.alpha) * p.gain;
+                        if (p.clamp >= 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
+                        p.out[off] = v + sidea[q];
+                    } else {   // EG3D_EPI_BWD
+                        if (do_ds) {
+                            const float t = v * sideb[q];
+                            if (single_n) dsum += t;
+                            else unsafeAtomicAdd(ds_out + (int64_t)rown[wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] * p.Nc + col, t);
+                        }
+                        p.out[off] = v * scl[q] + sidea[q];
+                    }
                 }
             }
         }
@@ -260,15 +371,17 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const eg3d_con
     }
     if (do_ds && single_n) {
         __syncthreads();
-        if (tid < BN && n0 + tid < p.Nc) unsafeAtomicAdd(p.ds + (int64_t)n_first * p.Nc + n0 + tid, ds_lds[tid]);
+        if (tid < BN && n0 + tid < p.Nc) unsafeAtomicAdd(ds_out + (int64_t)n_first * p.Nc + n0 + tid, ds_lds[tid]);
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch_conv(const eg3d_conv_params& p, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int PREC>
+int launch_conv_p(const eg3d_conv_params& p, hipStream_t st) {
     static bool attr_done = false;
-    const size_t smem = (size_t)(2 * (BM + BN) * LDK) * sizeof(float) + 2 * BM * sizeof(int);
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN>;
+    constexpr int NP = PREC == 1 ? 3 : 2;
+    constexpr int KB = BM * BN >= 128 * 128 ? 16 : 32;
+    const size_t smem = (PREC ? (size_t)2 * (split_tile_bytes(BM, NP, KB) + split_tile_bytes(BN, NP, KB)) : (size_t)(2 * (BM + BN) * LDK) * sizeof(float)) + 2 * BM * sizeof(int);
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, PREC>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
@@ -287,11 +400,22 @@ int launch_conv(const eg3d_conv_params& p, hipStream_t st) {
     return EG3D_OK;
 }
 
-// tile configuration: 0 = 128x128 (dominant), 1 = 64x128, 2 = 32x128 (tiny spatial extent), 3 = 128x32 (few output channels)
+template <int BM, int BN, int WM, int WN>
+int launch_conv(const eg3d_conv_params& p, hipStream_t st) {
+    switch (p.precision) {
+        case 1: return launch_conv_p<BM, BN, WM, WN, 1>(p, st);
+        case 2: return launch_conv_p<BM, BN, WM, WN, 2>(p, st);
+        default: return launch_conv_p<BM, BN, WM, WN, 0>(p, st);
+    }
+}
+
+// tile configuration: 0 = 128x128 (dominant), 1 = 64x128, 2 = 32x128 (tiny spatial extent), 3 = 128x32 (few output channels),
+// 4 = 256x64 (the 64-channel 512^2 layers of the super-resolution head)
 int pick_config(const eg3d_conv_params& p) {
     int64_t maxM = 0;
     for (int c = 0; c < p.ncls; ++c) maxM = std::max<int64_t>(maxM, (int64_t)p.N * p.cls[c].Ha * p.cls[c].Wa);
     if (p.Nc <= 32) return 3;
+    if (p.Nc <= 64 && maxM * p.ncls * p.ksplit >= 256 * 256 && !getenv("EG3D_NO_CFG4")) return 4;
     if (maxM <= 32) return 2;
     // enough 128x128 tiles to fill the chip (2 blocks/CU)?  otherwise shrink the M tile
     int64_t big_tiles = (int64_t)eg3d_cdiv(maxM, 128) * eg3d_cdiv(p.Nc, 128) * p.ncls * p.ksplit;
@@ -310,6 +434,7 @@ extern "C" int eg3d_conv2d_igemm_f32(const eg3d_conv_params* pp, void* stream) {
     if (p.ncls < 1 || p.ncls > 4 || p.ksplit < 1 || p.in_stride < 1 || p.out_stride < 1) return EG3D_ERR_INVALID;
     if (p.ksplit > 1 && p.epi != EG3D_EPI_ATOMIC) return EG3D_ERR_INVALID;
     if (p.epi < EG3D_EPI_STORE || p.epi > EG3D_EPI_BWD) return EG3D_ERR_INVALID;
+    if (p.precision < 0 || p.precision > 2 || p.ds_replicas < 0) return EG3D_ERR_INVALID;
     if (p.epi == EG3D_EPI_FWD && p.noise && !p.noise_strength) return EG3D_ERR_INVALID;
     if ((p.Ck & 3) || (p.ldx & 3) || (p.w_row & 3)) return EG3D_ERR_UNSUPPORTED;   // 16-byte operand loads
     if ((reinterpret_cast<uintptr_t>(p.x) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15)) return EG3D_ERR_UNSUPPORTED;
@@ -329,6 +454,7 @@ extern "C" int eg3d_conv2d_igemm_f32(const eg3d_conv_params* pp, void* stream) {
         case 0: return (getenv("EG3D_CONV8") ? launch_conv<128, 128, 2, 4>(p, st) : launch_conv<128, 128, 2, 2>(p, st));
         case 1: return launch_conv<64, 128, 2, 2>(p, st);
         case 2: return launch_conv<32, 128, 1, 4>(p, st);
+        case 4: return launch_conv<256, 64, 4, 1>(p, st);
         default: return launch_conv<128, 32, 4, 1>(p, st);
     }
 }

@@ -27,6 +27,17 @@ __device__ __forceinline__ void plane_uv(int pl, float x, float y, float z, floa
 // (k-pairs (e, e+4)) without any cross-lane traffic.
 __device__ __forceinline__ constexpr int split_idx(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// Work-slot -> ray permutation (eg3d_render_params::ray_tile_width).  Slots are handed to XCDs in contiguous runs, so a run of
+// 32*H slots covers a 32-pixel-wide column strip of the image instead of full-width rows: the tri-plane texels a run touches
+// then span 1/4 of x (128-wide image) on all three planes, which is what lets them stay in the XCD's 4 MB L2.
+__device__ __forceinline__ int64_t ray_of_slot(int64_t slot, int R, int W) {
+    if (W <= 0 || (W & 31) || R % W) return slot;
+    const int64_t n = slot / R;
+    const int i = (int)(slot - n * R), H = R / W;
+    const int strip = i / (32 * H), within = i - strip * 32 * H;
+    return n * R + (int64_t)(within >> 5) * W + strip * 32 + (within & 31);
+}
+
 }  // namespace eg3d_render
 
 // sample-level kernels (decoder_mfma.hip), called by the entry points in renderer.hip

@@ -188,8 +188,9 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
     const int64_t nrays = (int64_t)p.N * p.R;
     const int nblocks = (int)((nrays + RPB - 1) / RPB);
     const int bid = eg3d_xcd_remap(blockIdx.x, nblocks);
-    const int64_t ray = (int64_t)bid * RPB + r;
-    const bool live = tid < nthreads && ray < nrays;
+    const int64_t slot = (int64_t)bid * RPB + r;
+    const bool live = tid < nthreads && slot < nrays;
+    const int64_t ray = live ? eg3d_render::ray_of_slot(slot, p.R, p.ray_tile_width) : slot;
     const int64_t rr = live ? ray : 0;
     const int n = (int)(rr / p.R);
     RayLds L = ray_lds(lds, r < RPB ? r : 0, D);

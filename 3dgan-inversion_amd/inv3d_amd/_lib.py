@@ -34,7 +34,7 @@ class ConvParams(C.Structure):
                 ('in_scale', C.c_void_p), ('epi', C.c_int32), ('ksplit', C.c_int32),
                 ('out_scale', C.c_void_p), ('bias', C.c_void_p), ('noise', C.c_void_p), ('noise_nstride', C.c_int64),
                 ('noise_strength', C.c_void_p), ('act', C.c_int32), ('alpha', C.c_float), ('gain', C.c_float),
-                ('clamp', C.c_float), ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p)]
+                ('clamp', C.c_float), ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p), ('precision', C.c_int32), ('ds_replicas', C.c_int32)]
 
 
 class WgradParams(C.Structure):
@@ -54,7 +54,8 @@ class RenderParams(C.Structure):
                 ('ray_limits', C.c_void_p), ('disparity', C.c_int32), ('box_warp', C.c_float), ('white_back', C.c_int32),
                 ('w0', C.c_void_p), ('b0', C.c_void_p), ('w1', C.c_void_p), ('b1', C.c_void_p), ('Hdim', C.c_int32),
                 ('Cout', C.c_int32), ('rgb', C.c_void_p), ('depth', C.c_void_p), ('wsum', C.c_void_p),
-                ('depth_minmax', C.c_void_p), ('fine_depths', C.c_void_p), ('save_sigma', C.c_void_p), ('save_rgb', C.c_void_p)]
+                ('depth_minmax', C.c_void_p), ('fine_depths', C.c_void_p), ('save_sigma', C.c_void_p), ('save_rgb', C.c_void_p),
+                ('ray_tile_width', C.c_int32)]
 
 
 class RenderBwdParams(C.Structure):

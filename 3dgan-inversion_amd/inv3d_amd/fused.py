@@ -12,12 +12,23 @@ style gradient is a reduction fused into the data-gradient conv (no per-sample w
 """
 import math
 
+import os
 import torch
 
 from . import _lib as L
 from . import hipops as H
 
 _F44 = {}
+
+
+_MINMAX = {}
+
+
+def _minmax_init(device):
+    key = str(device)
+    if key not in _MINMAX:
+        _MINMAX[key] = torch.tensor([float('inf'), float('-inf')], device=device)
+    return _MINMAX[key]
 
 
 def fir44(device):
@@ -50,12 +61,15 @@ class WeightCache:
         return self._c['wf'], self._c['wa'], self._c['wsq']
 
 
-def _auto_ksplit(n_cells, Nc, steps):
-    """Split-K factor for layers too small to fill 256 CUs (low-resolution 512-channel layers)."""
-    tiles = max(1, (n_cells + 31) // 32) * max(1, (Nc + 127) // 128)
-    if tiles >= 256:
+def _auto_ksplit(classes, N, Nc, Ck):
+    """Split-K factor of an implicit GEMM whose output grid is too small to keep 256 CUs busy (the 4^2..64^2 layers): with few
+    128x128 tiles each workgroup walks a long K = taps x channels chain on its own and the launch is latency-bound (64^2 x 512
+    channels: 91 TF unsplit, 148 TF split 4 ways).  Slices accumulate with fp32 atomics into a zeroed buffer."""
+    blocks = sum((N * c.Ha * c.Wa + 127) // 128 for c in classes) * ((Nc + 127) // 128)
+    if blocks >= int(os.environ.get('EG3D_KS_BLOCKS', '200')):
         return 1
-    return max(1, min(steps, 512 // tiles))
+    steps = ((Ck + 15) // 16) * min(c.ntaps for c in classes)
+    return max(1, min(-(-512 // blocks), steps // 8))
 
 
 class ModConvLayerFn(torch.autograd.Function):
@@ -77,11 +91,10 @@ class ModConvLayerFn(torch.autograd.Function):
         clampv = -1.0 if clamp is None else float(clamp)
         out = H.empty_cl(N, Co, Ho, Wo, x.device)
         b = bias.contiguous().float() if bias is not None else None
-        steps = ((Ci + 31) // 32) * kh * kw
         aflops = 2.0 * N * Hi * Wi * (1 if up == 2 else 1) * kh * kw * Ci * Co     # MACs of the (transposed) conv
         if up == 1:
             cls = H.classes_corr(Ho, Wo, kh, kw, kh // 2)
-            ks = _auto_ksplit(N * Ho * Wo, Co, steps)
+            ks = _auto_ksplit(cls, N, Co, Ci)
             if ks == 1:
                 H.conv_igemm(x, wf, Ci, Co, out, cls, in_scale=styles, epi=L.EPI_FWD, out_scale=d, bias=b, noise=nz,
                              noise_nstride=nstride or 0, noise_strength=noise_strength, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv,
@@ -93,7 +106,7 @@ class ModConvLayerFn(torch.autograd.Function):
                                alpha=0.2, gain=act_gain, clamp=clampv)
         else:
             cls, Hz, Wz = H.classes_convT(Hi, Wi, kh, kw, up)
-            ks = _auto_ksplit(N * (Hi + 1) * (Wi + 1), Co, ((Ci + 31) // 32) * 4)
+            ks = _auto_ksplit(cls, N, Co, Ci)
             if ks == 1:
                 z = H.empty_cl(N, Co, Hz, Wz, x.device)
                 H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_STORE, algo_flops=aflops)
@@ -141,12 +154,17 @@ class ModConvLayerFn(torch.autograd.Function):
         dx = ds = None
         if need_x or need_s:
             dx = H.empty_cl(N, Ci, Hi, Wi, dev)
-            ds = torch.zeros((N, Ci), device=dev)
             aflops = 2.0 * N * Hi * Wi * kh * kw * Ci * Co
-            ks = _auto_ksplit(N * Hi * Wi, Ci, ((Co + 31) // 32) * kh * kw)
+            ks = _auto_ksplit(cls_adj, N, Ci, Co)
             if ks == 1:
+                # thousands of tiles reduce into the same N*Ci style-gradient addresses: spread them over replicas, sum afterwards
+                rep = 32 if N * Hi * Wi >= 128 * 512 else 1
+                ds = torch.zeros((rep, N, Ci) if rep > 1 else (N, Ci), device=dev)
                 H.conv_igemm(g, wa, Co, Ci, dx, cls_adj, in_stride=in_stride, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, algo_flops=aflops)
+                if rep > 1:
+                    ds = ds.sum(0)
             else:                                  # low resolution: split K over blocks, then scale / reduce in a finishing pass
+                ds = torch.zeros((N, Ci), device=dev)
                 z = H.zeros_cl(N, Ci, Hi, Wi, dev)
                 H.conv_igemm(g, wa, Co, Ci, z, cls_adj, in_stride=in_stride, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops)
                 H.dgrad_finish(z, x, styles, dx, ds=ds)
@@ -289,7 +307,7 @@ class RenderFn(torch.autograd.Function):
         rgb = torch.empty((N, R, w1.shape[0] - 1), device=dev)
         depth = torch.empty((N, R, 1), device=dev)
         wsum = torch.empty((N, R, 1), device=dev)
-        minmax = torch.tensor([float('inf'), float('-inf')], device=dev)
+        minmax = _minmax_init(dev).clone()          # device-side copy: no host transfer on the step path (HIP-graph capturable)
         fine = torch.empty((N, R, max(Df, 1)), device=dev)
         rl = ray_limits.contiguous().float() if ray_limits is not None else None
         save = None

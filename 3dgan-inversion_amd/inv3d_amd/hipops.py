@@ -4,6 +4,7 @@ Tensors handed to the fused path are fp32 "NHWC": logical shape [N,C,H,W] with c
 reference-facing API keeps NCHW shapes while memory is channel-contiguous, which is what the MFMA implicit GEMM,
 the float4 epilogues and the 128-byte tri-plane gathers want).
 """
+import os
 import ctypes as C
 from typing import List, Optional, Sequence
 
@@ -179,9 +180,22 @@ def pack_weight_adj(w):
     return w.permute(1, 2, 3, 0).reshape(i, kh * kw * o).contiguous()
 
 
+# Matrix-core arithmetic of the implicit GEMMs (include/eg3d_hip.h EG3D_PREC_*).  Operands, accumulators and results are fp32 in
+# every mode: 'bf16x6' (default) forms each fp32 product from six exact bf16 products (error < 2^-23, i.e. fp32-equivalent, at
+# ~1.4x the rate of the fp32 MFMA), 'f32' uses v_mfma_f32_32x32x2_f32, 'bf16x3' three products (~2^-15, opt-in only).
+# Set with set_conv_precision() or the EG3D_CONV_PRECISION environment variable.
+PRECISIONS = {'f32': 0, 'bf16x6': 1, 'bf16x3': 2}
+CONV_PRECISION = PRECISIONS[os.environ.get('EG3D_CONV_PRECISION', 'bf16x6')]
+
+
+def set_conv_precision(name):
+    global CONV_PRECISION
+    CONV_PRECISION = PRECISIONS[name]
+
+
 def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=None, epi=L.EPI_STORE, ksplit=1,
                out_scale=None, bias=None, noise=None, noise_nstride=0, noise_strength=None, act='linear', alpha=0.0, gain=1.0,
-               clamp=-1.0, addend=None, xin=None, ds=None, algo_flops=None):
+               clamp=-1.0, addend=None, xin=None, ds=None, algo_flops=None, precision=None):
     """Launch eg3d_conv2d_igemm_f32.  x/out/addend/xin: channels_last fp32 [N,C,H,W]; wp: packed weights [Nc, taps*Ck]."""
     assert is_cl(x) and is_cl(out), 'conv_igemm expects fp32 channels_last CUDA tensors'
     p = L.ConvParams()
@@ -206,6 +220,8 @@ def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=
     p.addend = addend.data_ptr() if addend is not None else None
     p.xin = xin.data_ptr() if xin is not None else None
     p.ds = ds.data_ptr() if ds is not None else None
+    p.precision = CONV_PRECISION if precision is None else PRECISIONS[precision]
+    p.ds_replicas = ds.shape[0] if (ds is not None and ds.dim() == 3) else 1
     prof = PROFILER
     if prof is not None:
         cfg = L.lib().eg3d_conv2d_igemm_config(C.byref(p))
@@ -313,7 +329,7 @@ def ray_gen_bwd(c2w, K, g_o, g_d, res, want_K=True):
     return d_c2w, d_K
 
 
-def make_render_params(planes, origins, dirs, u1, u2, opts, w0, b0, w1t, b1, rgb, depth, wsum, minmax, fine, ray_limits=None, save=None):
+def make_render_params(planes, origins, dirs, u1, u2, opts, w0, b0, w1t, b1, rgb, depth, wsum, minmax, fine, ray_limits=None, save=None, ray_tile_width=None):
     """planes: channels_last [N, 3*C, Hp, Wp]; decoder weights with gains folded (w1t transposed [H, 1+Cout])."""
     assert is_cl(planes)
     p = L.RenderParams()
@@ -341,6 +357,10 @@ def make_render_params(planes, origins, dirs, u1, u2, opts, w0, b0, w1t, b1, rgb
     p.fine_depths = fine.data_ptr() if fine is not None else None
     if save is not None:
         p.save_sigma, p.save_rgb = save[0].data_ptr(), save[1].data_ptr()
+    if ray_tile_width is None:          # RaySampler emits the pixels of a square image in row-major order (ray_sampler.py:43-48)
+        side = int(round(p.R ** 0.5))
+        ray_tile_width = side if side * side == p.R and side % 32 == 0 else 0
+    p.ray_tile_width = int(ray_tile_width)
     return p
 
 

@@ -144,8 +144,11 @@ class LatentProjector:
                  first_inv_lr=8e-3, cam_lr=6e-7, translation_lr=2e-4, cam_preheat_steps=50, initial_noise_factor=0.05,
                  noise_ramp_length=0.75, lr_rampdown_length=0.25, lr_rampup_length=0.05, regularize_noise_weight=1e5,
                  initial_learning_rate=0.01, radius=2.7, wplus=False, synth_kwargs: Optional[dict] = None, seed: int = 0,
-                 init_noise: Optional[Dict[str, torch.Tensor]] = None):
+                 init_noise: Optional[Dict[str, torch.Tensor]] = None, use_graph: bool = False, graph_warmup: int = 2):
         dev = target.device
+        if use_graph and optimize_pose:
+            raise ValueError('use_graph: the pose chain skips optimiser steps during the preheat (data-dependent control flow on the host)')
+        self.use_graph, self._graph, self._graph_warmup = use_graph, None, graph_warmup
         self.G = G.eval().requires_grad_(False)
         self.dev = dev
         self.num_steps, self.preheat = num_steps, (cam_preheat_steps if optimize_pose else 0)
@@ -180,7 +183,13 @@ class LatentProjector:
                     b.copy_(src)
                     b.requires_grad = True
         self._all_bufs = list(self.noise_bufs.values()) + list(self.noise_bufs2.values())
-        self.optimizer = torch.optim.Adam([self.w_opt] + self._all_bufs, betas=(0.9, 0.999), lr=first_inv_lr, fused=True)
+        if use_graph:       # the schedule values live on the device so that one captured step can be replayed for every step index
+            self._scale_t = torch.zeros((), device=dev)
+            self._wn = torch.zeros_like(self.w_opt)
+            self.optimizer = torch.optim.Adam([self.w_opt] + self._all_bufs, betas=(0.9, 0.999), lr=torch.tensor(float(first_inv_lr), device=dev),
+                                              fused=True, capturable=True)
+        else:
+            self.optimizer = torch.optim.Adam([self.w_opt] + self._all_bufs, betas=(0.9, 0.999), lr=first_inv_lr, fused=True)
         self.intrinsic = torch.tensor([4.2647, 0, 0.5, 0, 4.2647, 0.5, 0, 0, 1], device=dev).unsqueeze(0)
         self.init_ext = torch.tensor([1, 0, 0, 0, 0, -1, 0, 0, 0, 0, -1, 2.7, 0, 0, 0, 1.], device=dev).reshape(1, 4, 4)
         self.canonical_cam = torch.cat([self.init_ext.reshape(1, 16), self.intrinsic], -1)
@@ -214,21 +223,60 @@ class LatentProjector:
 
     def step(self, w_noise: Optional[torch.Tensor] = None, **step_kwargs) -> Dict[str, torch.Tensor]:
         """One optimisation step.  `w_noise` (unit normal, shape of w_opt) and `render_uniforms=(u1,u2)` may be injected for
-        deterministic runs; otherwise they are drawn on the device."""
+        deterministic runs; otherwise they are drawn on the device.
+
+        With `use_graph=True` the whole step (~640 kernel launches: synthesis forward and backward, loss, fused Adam, noise
+        renormalisation) is captured once into a HIP graph after `graph_warmup` eager steps and replayed afterwards; the per-step
+        schedule values (latent-noise scale, learning rate) and the latent noise are device tensors refreshed before each replay.
+        The host then issues one graph launch per step instead of ~640 launches (~20 us of Python/ctypes each, which is about the
+        GPU time of the step itself)."""
         step = self.step_idx
-        kw = dict(self.synth_kwargs, **step_kwargs)
-        G = self.G
         w_noise_scale, lr = self._schedule(step)
+        if self.use_graph:
+            if step_kwargs:
+                raise ValueError('use_graph: per-step synthesis kwargs cannot change between replays; pass them as synth_kwargs')
+            self._scale_t.fill_(float(w_noise_scale))
+            self.optimizer.param_groups[0]['lr'].fill_(float(lr))
+            if w_noise is not None:
+                self._wn.copy_(w_noise)
+            else:
+                self._wn.normal_(generator=self.gen)
+            if self._graph is not None:
+                self._graph.replay()
+            elif step < self._graph_warmup:           # eager warm-up on a side stream (allocator / autograd state, lazy kernel attributes)
+                side = torch.cuda.Stream(device=self.dev)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self.last = self._step_body(self._scale_t, self._wn, self.synth_kwargs, True)
+                torch.cuda.current_stream().wait_stream(side)
+            else:
+                torch.cuda.synchronize()
+                self.optimizer.zero_grad(set_to_none=True)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self.last = self._step_body(self._scale_t, self._wn, self.synth_kwargs, True)
+                self._graph = graph
+                graph.replay()                        # capture records without executing
+            self.step_idx += 1
+            return self.last
         for g in self.optimizer.param_groups:
             g['lr'] = lr
+        wn = None
+        if step >= self.preheat:
+            wn = w_noise.to(self.dev) if w_noise is not None else torch.randn(self.w_opt.shape, device=self.dev, generator=self.gen)
+        self.last = self._step_body(w_noise_scale, wn, dict(self.synth_kwargs, **step_kwargs), step >= self.preheat)
+        self.step_idx += 1
+        return self.last
+
+    def _step_body(self, w_noise_scale, wn, kw, do_step):
+        G = self.G
         if self.optimize_pose:
             rot = quaternion_to_rotmat(self.quat)
             pred_ext, pred_cam = pose_to_cam(rot, self.translation_opt, self.intrinsic, self.radius)
         else:
             pred_ext, pred_cam = None, self.cam
         w = self.w_opt
-        if step >= self.preheat:
-            wn = w_noise.to(self.dev) if w_noise is not None else torch.randn(w.shape, device=self.dev, generator=self.gen)
+        if wn is not None:
             w = w + wn * w_noise_scale
         ws = w.repeat(1, self.num_ws, 1) if w.shape[1] == 1 else w
         out = G.synthesis(ws, pred_cam, noise_mode='const', force_fp32=True, **kw)
@@ -251,15 +299,14 @@ class LatentProjector:
         if self.optimize_pose:
             self.cam_optimizer.step()
             self.translation_optimizer.step()
-        if step >= self.preheat:
+        if do_step:
             self.optimizer.step()
         hipops.noise_normalize_(self._all_bufs)        # buf -= mean; buf *= rsqrt(mean(buf^2))   (w_projector.py:264-270)
-        self.step_idx += 1
-        self.last = dict(loss=loss.detach(), dist=dist.detach(), reg=reg.detach() if torch.is_tensor(reg) else reg, image=out['image'].detach(),
-                         cam=pred_cam.detach(), ws=ws.detach())
+        last = dict(loss=loss.detach(), dist=dist.detach(), reg=reg.detach() if torch.is_tensor(reg) else reg, image=out['image'].detach(),
+                    cam=pred_cam.detach(), ws=ws.detach())
         if warp is not None:
-            self.last['warp'] = warp.detach()
-        return self.last
+            last['warp'] = warp.detach()
+        return last
 
 
 class PivotalTuner:

@@ -11,9 +11,12 @@ into the latent and the 13+4 noise buffers, Adam step, noise renormalisation.  W
 N GPUs = N independent images (weak scaling), one packed stat all-reduce per step over RCCL.
 
 The JSON line also carries
-  roofline      : the dominant kernel conv_igemm_kernel<128,128,2,2> (fp32 MFMA implicit GEMM): algorithmic FLOPs of its launches
-                  (2 x MACs of the convolution) / their HIP-event durations measured on the launch stream
-                  inside the timed region, against the 157.3 TFLOP/s fp32 matrix peak of gfx950.
+  roofline      : the dominant kernel conv_igemm_kernel<128,128,2,2,PREC> (implicit GEMM on the matrix cores): algorithmic FLOPs of
+                  its launches (2 x MACs of the convolution) / their HIP-event durations measured on the
+                  launch stream inside the timed region.  `peak` is the matrix peak for the arithmetic the kernel executes:
+                  157.3 TFLOP/s for --precision f32 (v_mfma_f32_32x32x2_f32); for the default bf16x6 (fp32 operands and results,
+                  every fp32 product formed from six exact bf16 MFMA products, error < 2^-23) it is the dense bf16 peak / 6 =
+                  416.7 fp32-equivalent TFLOP/s.  `frac_of_fp32_mfma_peak` and `mfma_executed_tflops` are given beside it.
   cpu_baseline  : the CPU oracle (oracle/eg3d_oracle.py, a port of the reference's pure-PyTorch `_ref` path, pinned against
                   the reference) running the same C2 step on the host cores, bounded sample, rank 0 at N=1 only.
 """
@@ -31,6 +34,9 @@ for _p in (ROOT, os.path.join(ROOT, '3dgan-inversion_amd')):
 import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide, dense bf16 (never the 2:1-sparsity figure)
+PRODUCTS = {'f32': 1, 'bf16x6': 6, 'bf16x3': 3}      # MFMA products executed per algorithmic fp32 product
+CONV_TRAFFIC_BYTES = None           # HBM bytes per launch of the dominant kernel from rocprofv3 --pmc (profiles/); filled from a committed measurement
 DOMINANT = 0                        # tile configuration id of conv_igemm_kernel<128,128,2,2>
 
 
@@ -70,6 +76,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel from the host instead of replaying the captured step')
+    ap.add_argument('--precision', default=None, choices=sorted(PRODUCTS), help='matrix-core arithmetic of the implicit GEMMs (default: library default, bf16x6)')
     ap.add_argument('--wplus', action='store_true')
     args = ap.parse_args()
 
@@ -80,6 +88,9 @@ def main():
     dev = torch.device('cuda', local)
 
     from inv3d_amd import synthetic as S, hipops as H
+    if args.precision is not None:
+        H.set_conv_precision(args.precision)
+    prec_name = {v: k for k, v in H.PRECISIONS.items()}[H.CONV_PRECISION]
     from inv3d_amd.inversion import LatentProjector, psnr_01
 
     G = S.make_generator(device=dev)
@@ -89,18 +100,22 @@ def main():
     with torch.no_grad():
         ws_t = S.synth_ws(14, 512, world, seed=3)[rank:rank + 1].to(dev)
         target = G.synthesis(ws_t, cam, noise_mode='const', force_fp32=True)['image'].clamp(-1, 1)
-    proj = LatentProjector(G, target, num_steps=400, cam=cam, wplus=args.wplus, seed=100 + rank)
+    use_graph = not args.no_graph
+    proj = LatentProjector(G, target, num_steps=400, cam=cam, wplus=args.wplus, seed=100 + rank, use_graph=use_graph)
     proj.preheat = 0
 
-    def one_step():
-        out = proj.step()
+    def one_step(pr=proj):
+        out = pr.step()
         st = D.allreduce_stats(dict(loss=0.0, n_active=1.0, steps=1.0), dev) if world > 1 else None   # stat sync (latency only)
         return out
 
+    if use_graph:                       # set-up, not a step of the benchmark: eager passes + the capture of the step into a HIP graph
+        for _ in range(proj._graph_warmup + 1):
+            one_step()
     for _ in range(args.warmup):
         one_step()
     prof = None
-    if not args.no_roofline:
+    if not args.no_roofline and not use_graph:
         prof = H.LaunchProfiler(only_config=DOMINANT)
         H.PROFILER = prof
     torch.cuda.synchronize()
@@ -113,6 +128,21 @@ def main():
     elapsed = time.perf_counter() - t0
     H.PROFILER = None
     elapsed = D.max_over_ranks(elapsed, dev)
+    final_psnr = float(psnr_01(proj.last['image'], target))
+    roofline_pass = 'HIP events around every launch of the kernel inside the timed region'
+    if not args.no_roofline and use_graph:
+        # HIP events cannot bracket a kernel inside a captured graph: the per-launch durations of the dominant kernel come from an
+        # instrumented EAGER pass over the same K steps (same generator, same shapes), run right after the timed region.
+        roofline_pass = 'HIP events around every launch of the kernel in an eager re-run of the same %d steps right after the timed (graph-replay) region' % args.steps
+        eager = LatentProjector(G, target, num_steps=400, cam=cam, wplus=args.wplus, seed=100 + rank, use_graph=False)
+        eager.preheat = 0
+        one_step(eager)
+        prof = H.LaunchProfiler(only_config=DOMINANT)
+        H.PROFILER = prof
+        for _ in range(args.steps):
+            one_step(eager)
+        torch.cuda.synchronize()
+        H.PROFILER = None
 
     roof = None
     if prof is not None:
@@ -120,11 +150,16 @@ def main():
         dom = summ.get(DOMINANT)
         if dom and dom['ms'] > 0:
             ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-            roof = dict(bound='mfma', kernel='conv_igemm_kernel<128,128,2,2> (fp32 v_mfma_f32_32x32x2_f32)', achieved=round(ach, 2),
-                        peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+            nprod = PRODUCTS[prec_name]
+            peak = FP32_MFMA_PEAK_TFLOPS if prec_name == 'f32' else BF16_MFMA_PEAK_TFLOPS / nprod
+            kern = ('conv_igemm_kernel<128,128,2,2,0> (v_mfma_f32_32x32x2_f32)' if prec_name == 'f32' else
+                    'conv_igemm_kernel<128,128,2,2,%d> (fp32 in/out, %d x v_mfma_f32_32x32x16_bf16 per fp32 product)' % (H.PRECISIONS[prec_name], nprod))
+            roof = dict(bound='mfma', kernel=kern, achieved=round(ach, 2),
+                        peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4), traffic=CONV_TRAFFIC_BYTES,
+                        peak_basis=('fp32 matrix peak' if prec_name == 'f32' else 'dense bf16 matrix peak 2500 / %d products' % nprod),
+                        frac_of_fp32_mfma_peak=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), mfma_executed_tflops=round(ach * nprod, 1),
                         launches_per_step=dom['launches'] / args.steps, gflop_per_launch=round(dom['flops'] / dom['launches'] / 1e9, 3),
-                        avg_launch_ms=round(dom['ms'] / dom['launches'], 4))
-    final_psnr = float(psnr_01(proj.last['image'], target))
+                        avg_launch_ms=round(dom['ms'] / dom['launches'], 4), timing=roofline_pass)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_c2()
@@ -132,11 +167,12 @@ def main():
         ms = elapsed / args.steps * 1e3
         line = dict(metric='inversion-steps/sec (G fwd+bwd, 512^2 FFHQ EG3D) at 1/2/4/8 GPUs; final PSNR', value=round(world * args.steps / elapsed, 3),
                     unit='steps/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True,
-                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                    scaling='weak', vs_baseline=None, dtype='f32' if prec_name == 'f32' else 'f32 (%s split products, fp32-equivalent)' % prec_name if prec_name == 'bf16x6' else 'f32 storage, bf16x3 products (~2^-15)', data='synthetic',
                     config=dict(workload='C2: FFHQ 512^2 single-image latent inversion step (Phase A, w%s + 17 noise buffers; G.synthesis fwd+bwd, '
                                          '128^2 x 96-sample rendering, stub-LPIPS feature distance + noise regulariser, Adam)' % ('+' if args.wplus else ''),
                                 images_per_gpu=1, generator='ffhqrebalanced512-128-shaped, 30.66 M params, random-init (synthetic weights)',
                                 parallelism=f'{world} independent images, 1 per GPU; stat all-reduce only',
+                                launch='one HIP graph replay per step' if use_graph else 'eager (one launch per kernel)',
                                 psnr_after_timed_steps_db=round(final_psnr, 3)),
                     roofline=roof, cpu_baseline=cpu)
         print(json.dumps(line), flush=True)

@@ -95,6 +95,13 @@ typedef struct eg3d_conv_class {
     int32_t wtap[9];           /* weight tap index of tap t                              */
 } eg3d_conv_class;
 
+/* Arithmetic of the implicit GEMM.  Operands, accumulators and results are fp32 in every mode.
+ *   F32     v_mfma_f32_32x32x2_f32, exact fp32 products.
+ *   BF16X6  each operand cut into 3 bf16 terms (x = b0+b1+b2, exact to 2^-24), six bf16 MFMA products accumulated in fp32;
+ *           the dropped cross terms are < 2^-23 relative per product, i.e. fp32-equivalent (below fp32 accumulation error).
+ *   BF16X3  three products (b0b0+b0b1+b1b0), relative error < 2^-15 per product (between TF32 and fp32). */
+enum { EG3D_PREC_F32 = 0, EG3D_PREC_BF16X6 = 1, EG3D_PREC_BF16X3 = 2 };
+
 typedef struct eg3d_conv_params {
     const float* x;            /* [N,Hi,Wi,ldx] NHWC, Ck used channels                   */
     const float* w;            /* w[o*w_row + tap*Ck + k]                                */
@@ -118,6 +125,10 @@ typedef struct eg3d_conv_params {
     const float* addend;       /* [N,Ho,Wo,ldo] or null; may alias out                   */
     const float* xin;          /* EPI_BWD: [N,Ho,Wo,ldo] layer input for the style-gradient reduction, or null */
     float* ds;                 /* EPI_BWD: [N,Nc] accumulated with atomics (pre-zeroed), or null */
+    int32_t precision;         /* EG3D_PREC_*: how the fp32 products are formed on the matrix cores */
+    int32_t ds_replicas;       /* EPI_BWD: ds is [ds_replicas][N,Nc]; workgroup b accumulates into replica b % ds_replicas so that
+                                * thousands of tiles do not serialise on the same N*Nc addresses; the caller sums the replicas.
+                                * 0 or 1 = a single [N,Nc] buffer. */
 } eg3d_conv_params;
 
 int eg3d_conv2d_igemm_f32(const eg3d_conv_params* p, void* stream);
@@ -249,6 +260,10 @@ typedef struct eg3d_render_params {
      * Row ((n*R + ray)*2 + pass)*D + s, pass 0 = coarse / 1 = fine, D = max(Dc,Df).                                  */
     float* save_sigma;         /* [S]                                                      */
     float* save_rgb;           /* [S,Cout]                                                 */
+    int32_t ray_tile_width;    /* locality hint only (any value gives identical results): when the R rays of an image are the
+                                * row-major pixels of an image ray_tile_width wide (a multiple of 32), workgroups are assigned
+                                * to rays in 32-pixel-wide column strips so that each XCD's L2 sees a compact screen tile and
+                                * hence a small tri-plane footprint.  0 = rays in no particular order. */
 } eg3d_render_params;
 
 int eg3d_render_fwd(const eg3d_render_params* p, void* stream);

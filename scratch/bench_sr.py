@@ -1,0 +1,28 @@
+import sys, torch, time, math
+sys.path.insert(0,'.'); sys.path.insert(0,'3dgan-inversion_amd')
+from inv3d_amd import hipops as H, _lib as L
+dev='cuda'
+def run(n, ci, co, h, k=3, iters=30, convT=False):
+    torch.manual_seed(0)
+    x = torch.randn(n, ci, h, h, device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(co, ci, k, k, device=dev) / math.sqrt(ci*k*k)
+    wf = H.pack_weight_fwd(w)
+    s = torch.rand(n, ci, device=dev) + 0.5
+    if convT:
+        cls, ho, wo = H.classes_convT(h, h, k, k, 2); kw = dict(out_stride=2)
+    else:
+        cls = H.classes_corr(h, h, k, k, k//2); ho = wo = h; kw = {}
+    flops = 2.0*n*h*h*k*k*ci*co
+    out = H.empty_cl(n, co, ho, wo, dev)
+    ref = torch.nn.functional.conv2d((x*s[:,:,None,None]), w, padding=k//2) if not convT else None
+    f = lambda: H.conv_igemm(x, wf, ci, co, out, cls, in_scale=s, **kw)
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    err = float((out-ref).abs().max()) if ref is not None else -1
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): f()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)/iters
+    print(f'N={n} {ci:4d}->{co:4d} @{h:4d}^2 k={k} convT={convT}: {ms:7.3f} ms {flops/ms/1e9:6.1f} TF err {err:.2e}')
+run(1,64,64,512); run(1,128,64,256,convT=True); run(1,64,128,512); run(1,128,128,512)

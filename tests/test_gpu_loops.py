@@ -49,6 +49,28 @@ def test_latent_projection_c2(wplus):
     assert float((hip.w_opt.detach().cpu() - ref.w_opt.detach()).abs().max()) < 1e-3
 
 
+def test_latent_projection_graph_replay_matches_eager():
+    """The step captured into a HIP graph (LatentProjector(use_graph=True): eager warm-up, capture, replays) follows the same
+    trajectory as the eager loop when latent noise and renderer uniforms are pinned."""
+    from inv3d_amd.inversion import LatentProjector
+    cfg, P, G, cam, u1, u2, target, init_noise = _setup()
+    w_start = O.synth_ws(cfg, 1, seed=1)[:, :1]
+    uni = (u1.to(DEV), u2.to(DEV))
+    runs = {}
+    for mode in (False, True):
+        pr = LatentProjector(G, target.to(DEV), num_steps=30, cam=cam.to(DEV), init_noise=init_noise, start_w=w_start, use_graph=mode,
+                             synth_kwargs=dict(render_uniforms=uni))
+        for i in range(8):
+            out = pr.step(w_noise=O._randn('wn', i, (1, 1, cfg.w_dim)))
+        assert (pr._graph is not None) == mode
+        runs[mode] = (pr.w_opt.detach().clone(), out['image'].clone(), float(out['dist']), [b.detach().clone() for b in pr._all_bufs])
+    assert float((runs[True][0] - runs[False][0]).abs().max()) < 1e-5
+    assert abs(runs[True][2] - runs[False][2]) <= 1e-4 * max(1.0, abs(runs[False][2]))
+    assert float((runs[True][1] - runs[False][1]).abs().max()) < 1e-4
+    for a, b in zip(runs[True][3], runs[False][3]):
+        assert float((a - b).abs().max()) < 1e-4
+
+
 def test_pose_and_warping_c3():
     """Config C3: C2 + quaternion/translation pose chain + canonical no-grad forward + depth-reprojection warping loss.
     (i) one step: the pose gradients themselves; (ii) a short trajectory.  Pose gradients are sums of piecewise-constant

@@ -180,21 +180,44 @@ def test_conv2d_resample_golden(golden, ops):
 
 @pytest.mark.parametrize('shape', [(1, 32, 16, 16, 64, 1), (2, 64, 8, 8, 160, 1), (1, 128, 24, 24, 128, 3), (3, 16, 5, 7, 12, 3),
                                    (1, 512, 4, 4, 512, 3), (1, 256, 40, 40, 256, 3)])
-def test_conv_igemm_vs_torch(shape):
-    """All tile configurations / split-K of the implicit GEMM vs the oracle's F.conv2d (fp32)."""
+@pytest.mark.parametrize('prec,tol', [('f32', 2e-5), ('bf16x6', 2e-5), ('bf16x3', 3e-4)])
+def test_conv_igemm_vs_torch(shape, prec, tol):
+    """All tile configurations / split-K / matrix-core arithmetic modes of the implicit GEMM vs F.conv2d evaluated in fp64.
+    'bf16x6' (the default: six bf16 products per fp32 product) must meet the SAME bound as the exact-fp32 MFMA path."""
     from inv3d_amd import hipops as H, _lib as L
     n, ci, h, w, co, k = shape
     g = torch.Generator().manual_seed(6)
     x = torch.randn(n, ci, h, w, generator=g)
     wt = torch.randn(co, ci, k, k, generator=g) / math.sqrt(ci * k * k)
-    ref = torch.nn.functional.conv2d(x, wt, padding=k // 2)
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), padding=k // 2).float()
     xc = x.to(DEV).contiguous(memory_format=torch.channels_last)
     wf = H.pack_weight_fwd(wt.to(DEV))
     cop = (co + 3) // 4 * 4
     for ks in (1, 3):
         out = H.zeros_cl(n, cop, h, w, DEV)
-        H.conv_igemm(xc, wf, ci, co, out, H.classes_corr(h, w, k, k, k // 2), epi=L.EPI_ATOMIC if ks > 1 else L.EPI_STORE, ksplit=ks)
-        close(out[:, :co], ref, 2e-5, f'conv_igemm {shape} ksplit {ks}')
+        H.conv_igemm(xc, wf, ci, co, out, H.classes_corr(h, w, k, k, k // 2), epi=L.EPI_ATOMIC if ks > 1 else L.EPI_STORE, ksplit=ks,
+                     precision=prec)
+        close(out[:, :co], ref, tol, f'conv_igemm {shape} ksplit {ks} {prec}')
+
+
+def test_conv_igemm_split_bf16_is_fp32_equivalent():
+    """The default arithmetic (bf16x6) is as close to the fp64 result as the exact-fp32 MFMA path on a long reduction with badly
+    scaled operands (values spread over 12 orders of magnitude), where a reduced-precision product would show."""
+    from inv3d_amd import hipops as H
+    g = torch.Generator().manual_seed(8)
+    n, ci, h, co = 1, 512, 16, 128
+    x = torch.randn(n, ci, h, h, generator=g) * torch.exp(torch.randn(n, ci, 1, 1, generator=g) * 4)
+    wt = torch.randn(co, ci, 3, 3, generator=g) * torch.exp(torch.randn(1, ci, 1, 1, generator=g) * 4) / 70
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), padding=1)
+    xc = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    wf = H.pack_weight_fwd(wt.to(DEV))
+    err = {}
+    for prec in ('f32', 'bf16x6', 'bf16x3'):
+        out = H.zeros_cl(n, co, h, h, DEV)
+        H.conv_igemm(xc, wf, ci, co, out, H.classes_corr(h, h, 3, 3, 1), precision=prec)
+        err[prec] = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err['bf16x6'] <= 2.0 * err['f32'] + 1e-7, err
+    assert err['f32'] < 1e-5 and err['bf16x3'] < 1e-3, err
 
 
 def _layer_case(n, ci, co, res, up, seed, noise_kind='const', clamp=None):
