@@ -1,0 +1,120 @@
+// All style affines of a synthesis network in one launch.
+//
+// Every modulated layer owns a FullyConnectedLayer(w_dim -> in_channels, bias_init=1) that maps the layer's latent row to its
+// styles (training/networks_stylegan2.py:98-108 conv layers, :129-137 toRGB with its extra weight_gain).  Per layer that is a
+// [N,512]x[512,C] GEMM plus two scalings -- ~5 launches forward+backward for 26 layers, each far below a microsecond of work.
+// Here the bank of layers is one memory-bound pass over the ~18 MB of affine weights:
+//   fwd:  styles_l[n, j] = ( sum_k ws[n, wrow_l, k] * (W_l[j,k] * wgain_l) + b_l[j] * bgain_l ) * post_l
+//   bwd:  dws[n, wrow_l, k] += sum_j dstyles_l[n, j] * post_l * (W_l[j,k] * wgain_l)
+// (weights frozen: the latent-inversion phase; with trainable affines the host uses the per-layer path.)
+#include "common.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK_FWD = 4;     // one wave per output row
+constexpr int ROWS_PER_BLOCK_BWD = 32;
+
+__device__ __forceinline__ int find_layer(const eg3d_style_bank& b, int tile, const int rows_per_block, int& row0) {
+    int l = 0, t0 = 0;
+    for (; l < b.nlayers; ++l) {
+        const int nt = (b.layers[l].C + rows_per_block - 1) / rows_per_block;
+        if (tile < t0 + nt) break;
+        t0 += nt;
+    }
+    row0 = (tile - t0) * rows_per_block;
+    return l;
+}
+
+__global__ void __launch_bounds__(256) style_affine_fwd_kernel(const eg3d_style_bank b) {
+    int row0;
+    const int l = find_layer(b, blockIdx.x, ROWS_PER_BLOCK_FWD, row0);
+    if (l >= b.nlayers) return;
+    const eg3d_style_layer& ly = b.layers[l];
+    const int lane = threadIdx.x & 63, j = row0 + (threadIdx.x >> 6);
+    if (j >= ly.C) return;
+    const float* wrow = ly.weight + (int64_t)j * b.D;
+    const float bias = ly.bias ? ly.bias[j] * ly.bgain : 0.f;
+    for (int n = 0; n < b.N; ++n) {
+        const float* x = b.ws + ((int64_t)n * b.L + ly.wrow) * b.D;
+        float acc = 0.f;
+        for (int k = lane * 4; k < b.D; k += 256) {
+            const float4 w = *reinterpret_cast<const float4*>(wrow + k);
+            const float4 v = *reinterpret_cast<const float4*>(x + k);
+            acc += v.x * (w.x * ly.wgain);
+            acc += v.y * (w.y * ly.wgain);
+            acc += v.z * (w.z * ly.wgain);
+            acc += v.w * (w.w * ly.wgain);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) ly.out[(int64_t)n * ly.C + j] = (acc + bias) * ly.post;
+    }
+}
+
+__global__ void __launch_bounds__(128) style_affine_bwd_kernel(const eg3d_style_bank b) {
+    int row0;
+    const int l = find_layer(b, blockIdx.x, ROWS_PER_BLOCK_BWD, row0);
+    if (l >= b.nlayers) return;
+    const eg3d_style_layer& ly = b.layers[l];
+    if (ly.dout == nullptr) return;
+    const int rows = min(ROWS_PER_BLOCK_BWD, ly.C - row0);
+    __shared__ float coef[ROWS_PER_BLOCK_BWD];
+    for (int n = 0; n < b.N; ++n) {
+        __syncthreads();
+        if (threadIdx.x < rows) coef[threadIdx.x] = ly.dout[(int64_t)n * ly.C + row0 + threadIdx.x] * ly.post;
+        __syncthreads();
+        float* dst = b.dws + ((int64_t)n * b.L + ly.wrow) * b.D;
+        for (int k = threadIdx.x * 4; k < b.D; k += 512) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r = 0; r < rows; ++r) {
+                const float4 w = *reinterpret_cast<const float4*>(ly.weight + (int64_t)(row0 + r) * b.D + k);
+                const float c = coef[r];
+                acc.x += c * (w.x * ly.wgain);
+                acc.y += c * (w.y * ly.wgain);
+                acc.z += c * (w.z * ly.wgain);
+                acc.w += c * (w.w * ly.wgain);
+            }
+            unsafeAtomicAdd(dst + k + 0, acc.x);
+            unsafeAtomicAdd(dst + k + 1, acc.y);
+            unsafeAtomicAdd(dst + k + 2, acc.z);
+            unsafeAtomicAdd(dst + k + 3, acc.w);
+        }
+    }
+}
+
+int check_bank(const eg3d_style_bank* pb, bool bwd) {
+    if (!pb) return EG3D_ERR_INVALID;
+    const eg3d_style_bank& b = *pb;
+    if (b.nlayers < 1 || b.nlayers > EG3D_STYLE_BANK_MAX || b.N < 1 || b.L < 1 || b.D < 4 || (b.D & 3)) return EG3D_ERR_INVALID;
+    if (!b.ws || (bwd && !b.dws)) return EG3D_ERR_INVALID;
+    if ((reinterpret_cast<uintptr_t>(b.ws) & 15) || (bwd && (reinterpret_cast<uintptr_t>(b.dws) & 15))) return EG3D_ERR_UNSUPPORTED;
+    for (int l = 0; l < b.nlayers; ++l) {
+        const eg3d_style_layer& ly = b.layers[l];
+        if (!ly.weight || ly.C < 1 || ly.wrow < 0 || ly.wrow >= b.L) return EG3D_ERR_INVALID;
+        if (!bwd && !ly.out) return EG3D_ERR_INVALID;
+        if (reinterpret_cast<uintptr_t>(ly.weight) & 15) return EG3D_ERR_UNSUPPORTED;
+    }
+    return EG3D_OK;
+}
+
+int total_tiles(const eg3d_style_bank& b, int rows_per_block) {
+    int t = 0;
+    for (int l = 0; l < b.nlayers; ++l) t += eg3d_cdiv(b.layers[l].C, rows_per_block);
+    return t;
+}
+
+}  // namespace
+
+extern "C" int eg3d_style_affine_fwd(const eg3d_style_bank* pb, void* stream) {
+    if (int rc = check_bank(pb, false)) return rc;
+    hipLaunchKernelGGL(style_affine_fwd_kernel, dim3(total_tiles(*pb, ROWS_PER_BLOCK_FWD)), dim3(256), 0, (hipStream_t)stream, *pb);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_style_affine_bwd(const eg3d_style_bank* pb, void* stream) {
+    if (int rc = check_bank(pb, true)) return rc;
+    hipLaunchKernelGGL(style_affine_bwd_kernel, dim3(total_tiles(*pb, ROWS_PER_BLOCK_BWD)), dim3(128), 0, (hipStream_t)stream, *pb);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}

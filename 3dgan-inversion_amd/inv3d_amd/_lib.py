@@ -65,6 +65,19 @@ class RenderBwdParams(C.Structure):
                 ('dump_dpre', C.c_void_p), ('dump_h', C.c_void_p), ('dump_dout', C.c_void_p), ('dump_feat', C.c_void_p)]
 
 
+class StyleLayer(C.Structure):
+    _fields_ = [('weight', C.c_void_p), ('bias', C.c_void_p), ('out', C.c_void_p), ('dout', C.c_void_p), ('C', C.c_int32), ('wrow', C.c_int32),
+                ('wgain', C.c_float), ('bgain', C.c_float), ('post', C.c_float), ('reserved', C.c_int32)]
+
+
+STYLE_BANK_MAX = 32
+
+
+class StyleBank(C.Structure):
+    _fields_ = [('ws', C.c_void_p), ('dws', C.c_void_p), ('N', C.c_int32), ('L', C.c_int32), ('D', C.c_int32), ('nlayers', C.c_int32),
+                ('layers', StyleLayer * STYLE_BANK_MAX)]
+
+
 _SIGS = {
     'eg3d_abi_version': (C.c_int, []),
     'eg3d_status_string': (C.c_char_p, [C.c_int]),
@@ -92,6 +105,8 @@ _SIGS = {
     'eg3d_noise_regularizer': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_float, C.c_void_p]),
     'eg3d_noise_normalize': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
+    'eg3d_style_affine_fwd': (C.c_int, [C.POINTER(StyleBank), C.c_void_p]),
+    'eg3d_style_affine_bwd': (C.c_int, [C.POINTER(StyleBank), C.c_void_p]),
     'eg3d_ray_gen_fwd': (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]),
     'eg3d_ray_gen_bwd': (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
     'eg3d_render_fwd': (C.c_int, [C.POINTER(RenderParams), C.c_void_p]),

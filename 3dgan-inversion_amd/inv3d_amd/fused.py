@@ -183,6 +183,53 @@ class ModConvLayerFn(torch.autograd.Function):
         return (dx if need_x else None, dweight, ds if need_s else None, dnoise, dstrength, dbias, None, None, None, None, None)
 
 
+class StyleBankFn(torch.autograd.Function):
+    """styles of all modulated layers of a network from one launch (eg3d_style_affine_fwd/_bwd).  apply(ws, plan, *weights_and_biases)
+    -> tuple of [N, C_l] tensors; plan = tuple of (wrow, wgain, bgain, post, has_bias) per layer.  Gradients flow to ws only (the
+    affines are frozen on this path: the callers fall back to the per-layer modules when an affine parameter requires grad)."""
+
+    @staticmethod
+    def forward(ctx, ws, plan, *params):
+        L.require_cuda(ws)
+        ws = ws.contiguous().float()
+        N = ws.shape[0]
+        layers, pi = [], 0
+        for wrow, wgain, bgain, post, has_bias in plan:
+            w = params[pi].detach().contiguous().float()
+            b = params[pi + 1].detach().contiguous().float() if has_bias else None
+            pi += 2 if has_bias else 1
+            layers.append((w, b, wrow, wgain, bgain, post))
+        outs = tuple(torch.empty((N, ly[0].shape[0]), device=ws.device) for ly in layers)
+        H.style_affine(ws, layers, outs=outs)
+        ctx.layers, ctx.ws = layers, ws
+        return outs
+
+    @staticmethod
+    def backward(ctx, *douts):
+        dws = None
+        if ctx.needs_input_grad[0]:
+            dws = torch.zeros_like(ctx.ws)
+            douts = [d.contiguous().float() if d is not None else None for d in douts]
+            H.style_affine(ctx.ws, ctx.layers, douts=douts, dws=dws)
+        return (dws, None) + (None,) * sum(2 if ly[1] is not None else 1 for ly in ctx.layers)
+
+
+def style_bank(ws, entries):
+    """entries: list of (FullyConnectedLayer affine, ws row index, post scale).  Returns the list of styles, or None when the bank
+    does not apply (an affine parameter requires grad, non-linear activation, too many layers)."""
+    if len(entries) > L.STYLE_BANK_MAX or not ws.is_cuda:
+        return None
+    plan, params = [], []
+    for fc, wrow, post in entries:
+        if fc.activation != 'linear' or fc.weight.requires_grad or (fc.bias is not None and fc.bias.requires_grad):
+            return None
+        plan.append((int(wrow), float(fc.weight_gain), float(fc.bias_gain), float(post), fc.bias is not None))
+        params.append(fc.weight)
+        if fc.bias is not None:
+            params.append(fc.bias)
+    return list(StyleBankFn.apply(ws, tuple(plan), *params))
+
+
 class ToRGBFn(torch.autograd.Function):
     """y = clamp(conv1x1(x * styles, W) + bias);  out = skip + y (skip optional).  Small channel counts are padded to 4."""
 

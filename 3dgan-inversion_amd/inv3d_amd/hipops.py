@@ -290,6 +290,24 @@ def dgrad_finish(z, x, s, dx, ds=None, addend=None):
     return dx
 
 
+def style_affine(ws, layers, outs=None, douts=None, dws=None):
+    """eg3d_style_affine_fwd (outs given) / _bwd (douts + dws given).  ws: [N,L,D] contiguous fp32;
+    layers: sequence of (weight [C,D], bias [C] | None, wrow, wgain, bgain, post)."""
+    assert ws.is_contiguous() and ws.dtype == torch.float32 and len(layers) <= L.STYLE_BANK_MAX
+    b = L.StyleBank()
+    b.ws, b.N, b.L, b.D, b.nlayers = ws.data_ptr(), ws.shape[0], ws.shape[1], ws.shape[2], len(layers)
+    b.dws = dws.data_ptr() if dws is not None else None
+    for i, (w, bias, wrow, wgain, bgain, post) in enumerate(layers):
+        ly = b.layers[i]
+        assert w.is_contiguous() and w.dtype == torch.float32 and w.shape[1] == b.D
+        ly.weight, ly.bias = w.data_ptr(), (bias.data_ptr() if bias is not None else None)
+        ly.C, ly.wrow, ly.wgain, ly.bgain, ly.post = w.shape[0], int(wrow), float(wgain), float(bgain), float(post)
+        ly.out = outs[i].data_ptr() if outs is not None else None
+        ly.dout = douts[i].data_ptr() if (douts is not None and douts[i] is not None) else None
+    fn = L.lib().eg3d_style_affine_fwd if outs is not None else L.lib().eg3d_style_affine_bwd
+    L.check(fn(C.byref(b), L.stream_ptr()), 'style_affine')
+
+
 def weight_sqsum(wp, Co, ntaps, Ck):
     wsq = torch.empty((Co, Ck), dtype=torch.float32, device=wp.device)
     L.check(L.lib().eg3d_weight_sqsum(L.ptr(wp), L.ptr(wsq), Co, ntaps, Ck, L.stream_ptr()), 'weight_sqsum')

@@ -103,9 +103,11 @@ class SynthesisLayer(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
         self._cache = fused.WeightCache()
 
-    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, noise_inject=None):
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, noise_inject=None, styles=None):
+        """`styles`: this layer's affine(w) when the enclosing network already evaluated all affines in one launch."""
         assert noise_mode in ['random', 'const', 'none']
-        styles = self.affine(w)
+        if styles is None:
+            styles = self.affine(w)
         noise = None
         if self.use_noise and noise_mode == 'random':
             noise = noise_inject if noise_inject is not None else \
@@ -132,9 +134,11 @@ class ToRGBLayer(torch.nn.Module):
         self.weight_gain = 1 / math.sqrt(in_channels * (kernel_size ** 2))
         self._cache = fused.WeightCache()
 
-    def forward(self, x, w, fused_modconv=True, skip=None):
-        """Returns skip + torgb(x) on a channel count padded to a multiple of 4 (padding channels stay as in `skip`/zero)."""
-        styles = self.affine(w) * self.weight_gain
+    def forward(self, x, w, fused_modconv=True, skip=None, styles=None):
+        """Returns skip + torgb(x) on a channel count padded to a multiple of 4 (padding channels stay as in `skip`/zero).
+        `styles`: affine(w) * weight_gain when precomputed by the enclosing network."""
+        if styles is None:
+            styles = self.affine(w) * self.weight_gain
         return fused.ToRGBFn.apply(x, self.weight, styles, self.bias, skip, self.conv_clamp, self._cache, self.weight.requires_grad)
 
 
@@ -164,20 +168,31 @@ class SynthesisBlock(torch.nn.Module):
         self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp)
         self.num_torgb += 1
 
-    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, noise_inject=None, _name='', **layer_kwargs):
+    def affine_entries(self, w_idx):
+        """(affine module, ws row, post scale) of this block's modulated layers in evaluation order (for fused.style_bank)."""
+        ent = []
+        if self.in_channels != 0:
+            ent.append((self.conv0.affine, w_idx + len(ent), 1.0))
+        ent.append((self.conv1.affine, w_idx + len(ent), 1.0))
+        ent.append((self.torgb.affine, w_idx + len(ent), self.torgb.weight_gain))
+        return ent
+
+    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, noise_inject=None, _name='', styles=None,
+                **layer_kwargs):
         """x: [N,Cin,r/2,r/2] (any layout) or None; img: skip image with channels padded to a multiple of 4, or None.
-        Returns (x, img) as channels_last fp32."""
+        `styles`: this block's precomputed styles in the order of affine_entries(), or None.  Returns (x, img) as channels_last fp32."""
         w_iter = iter(ws.unbind(dim=1))
+        s_iter = iter(styles) if styles is not None else iter(lambda: None, 0)
         ni = noise_inject or {}
         if self.in_channels == 0:
             x = self.const.unsqueeze(0).expand(ws.shape[0], -1, -1, -1)
-            x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), **layer_kwargs)
+            x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), styles=next(s_iter), **layer_kwargs)
         else:
-            x = self.conv0(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv0'), **layer_kwargs)
-            x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), **layer_kwargs)
+            x = self.conv0(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv0'), styles=next(s_iter), **layer_kwargs)
+            x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), styles=next(s_iter), **layer_kwargs)
         if img is not None:
             img = fused.UpsampleImgFn.apply(img)
-        img = self.torgb(x, next(w_iter), skip=img)
+        img = self.torgb(x, next(w_iter), skip=img, styles=next(s_iter))
         return x, img
 
 
@@ -202,12 +217,23 @@ class SynthesisNetwork(torch.nn.Module):
     def forward(self, ws, noise_inject=None, _prefix='backbone.synthesis', **block_kwargs):
         ws = ws.to(torch.float32)
         x = img = None
-        w_idx = 0
+        # all 20 style affines of the backbone in one launch (None: some affine is trainable -> per-layer path)
+        entries, counts, w_idx = [], [], 0
         for res in self.block_resolutions:
+            block = getattr(self, f'b{res}')
+            ent = block.affine_entries(w_idx)
+            entries += ent
+            counts.append(len(ent))
+            w_idx += block.num_conv
+        bank = fused.style_bank(ws, entries)
+        w_idx = s_idx = 0
+        for res, cnt in zip(self.block_resolutions, counts):
             block = getattr(self, f'b{res}')
             cur = ws.narrow(1, w_idx, block.num_conv + block.num_torgb)
             w_idx += block.num_conv
-            x, img = block(x, img, cur, noise_inject=noise_inject, _name=f'{_prefix}.b{res}', **block_kwargs)
+            st = bank[s_idx:s_idx + cnt] if bank is not None else None
+            s_idx += cnt
+            x, img = block(x, img, cur, noise_inject=noise_inject, _name=f'{_prefix}.b{res}', styles=st, **block_kwargs)
         return img if img.shape[1] == self.img_channels else img[:, :self.img_channels]
 
 

@@ -155,6 +155,27 @@ typedef struct eg3d_wgrad_params {
 int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Style affines of a whole synthesis network in one launch (the per-layer FullyConnectedLayer(w_dim -> in_channels) of
+ * training/networks_stylegan2.py:98-108 and :129-137, ~26 tiny GEMMs + scalings per forward in the reference):
+ *   fwd:  out_l[n,j] = ( sum_k ws[n,wrow_l,k] * (weight_l[j,k]*wgain_l) + bias_l[j]*bgain_l ) * post_l
+ *   bwd:  dws[n,wrow_l,k] += sum_j dout_l[n,j] * post_l * (weight_l[j,k]*wgain_l)       (dws pre-zeroed; dout_l null = skip)
+ * ws/dws: [N,L,D] fp32, D a multiple of 4; weight_l: [C_l,D] row-major. */
+#define EG3D_STYLE_BANK_MAX 32
+typedef struct eg3d_style_layer {
+    const float* weight;  const float* bias;  float* out;  const float* dout;
+    int32_t C, wrow;
+    float wgain, bgain, post;
+    int32_t reserved;
+} eg3d_style_layer;
+typedef struct eg3d_style_bank {
+    const float* ws;  float* dws;
+    int32_t N, L, D, nlayers;
+    eg3d_style_layer layers[EG3D_STYLE_BANK_MAX];
+} eg3d_style_bank;
+int eg3d_style_affine_fwd(const eg3d_style_bank* bank, void* stream);
+int eg3d_style_affine_bwd(const eg3d_style_bank* bank, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Layer epilogues (NHWC fp32) -- the fused replacement of upfirdn2d + noise add + bias_act after a modulated
  * conv (training/networks_stylegan2.py:87-90,327-329; conv2d_resample.py:129) and of its backward.
  *
