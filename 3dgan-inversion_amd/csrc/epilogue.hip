@@ -42,7 +42,22 @@ __global__ void __launch_bounds__(256) epilogue_fwd_kernel(const float* __restri
         const int y = (int)(r % H);
         const int n = (int)(r / H);
         float4 v;
-        if (fir != nullptr) {
+        if (fir != nullptr && fh == 4 && fw == 4) {
+            // the on-path case (4x4 FIR after the transposed conv): 16 unconditional loads (clamped address, zero weight outside)
+            // so that all of them are in flight together
+            float4 t[16];
+            float wgt[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int iy = y + (k >> 2) - pad0, ix = x + (k & 3) - pad0;
+                const bool ok = (unsigned)iy < (unsigned)Hz && (unsigned)ix < (unsigned)Wz;
+                wgt[k] = ok ? fs[k] : 0.f;
+                t[k] = ld4(z + ((int64_t)(n * Hz + (ok ? iy : 0)) * Wz + (ok ? ix : 0)) * C + c);
+            }
+            v = make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { v.x += wgt[k] * t[k].x; v.y += wgt[k] * t[k].y; v.z += wgt[k] * t[k].z; v.w += wgt[k] * t[k].w; }
+        } else if (fir != nullptr) {
             v = make_float4(0, 0, 0, 0);
             for (int ky = 0; ky < fh; ++ky) {
                 int iy = y + ky - pad0;
@@ -85,8 +100,11 @@ __device__ __forceinline__ void bwd1(float dout, float o, int act, float alpha, 
     pre = (act == EG3D_ACT_LRELU) ? (yy > 0.f ? yy : yy / alpha) : yy;     // linear / lrelu are invertible
 }
 
-// grid = (blocks_x, N).  Block: 256 threads = PPB pixels x C4 channel-quads.
-__global__ void __launch_bounds__(256) epilogue_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ outv, float* __restrict__ dz,
+// grid = (blocks_x, N).  Block: EPI_BWD_THREADS threads = PPB pixels x C4 channel-quads.  Big blocks on purpose: every block ends with
+// 2*C atomics onto the same dbias / dd addresses (measured: launch time grows linearly with the block count), so the
+// parallelism comes from 16 waves per block rather than from many blocks.
+constexpr int EPI_BWD_THREADS = 1024;
+__global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ outv, float* __restrict__ dz,
                                                            int H, int W, int C4, const float* __restrict__ d, const float* __restrict__ noise,
                                                            int64_t noise_nstride, const float* __restrict__ noise_strength,
                                                            const float* __restrict__ bias, int act, float alpha, float gain, float clamp,
@@ -95,7 +113,7 @@ __global__ void __launch_bounds__(256) epilogue_bwd_kernel(const float* __restri
     extern __shared__ __attribute__((aligned(16))) float red[];      // [PPB][C4][8] floats + 1
     const int n = blockIdx.y;
     const int C = C4 * 4;
-    const int ppb = 256 / C4 > 0 ? 256 / C4 : 1;
+    const int ppb = EPI_BWD_THREADS / C4 > 0 ? EPI_BWD_THREADS / C4 : 1;
     const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
     const bool active = pl < ppb;
     const int HW = H * W;
@@ -110,31 +128,49 @@ __global__ void __launch_bounds__(256) epilogue_bwd_kernel(const float* __restri
     const bool pow2 = (C4 & (C4 - 1)) == 0;
     const int grp = C4 < 64 ? C4 : 64;
     if (active) {
-        for (int pix = blockIdx.x * ppb + pl; pix < HW; pix += gridDim.x * ppb) {
-            const int64_t off = ((int64_t)n * HW + pix) * C + c;
-            float4 g = ld4(dout + off), o = ld4(outv + off);
-            float4 dy, pre;
-            bwd1(g.x, o.x, act, alpha, gain, clamp, dy.x, pre.x); bwd1(g.y, o.y, act, alpha, gain, clamp, dy.y, pre.y);
-            bwd1(g.z, o.z, act, alpha, gain, clamp, dy.z, pre.z); bwd1(g.w, o.w, act, alpha, gain, clamp, dy.w, pre.w);
-            st4(dz + off, make_float4(dy.x * dv.x, dy.y * dv.y, dy.z * dv.z, dy.w * dv.w));
-            accb.x += dy.x; accb.y += dy.y; accb.z += dy.z; accb.w += dy.w;
-            float nz = 0.f, nraw = 0.f;
-            if (noise) { nraw = noise[(int64_t)n * noise_nstride + pix]; nz = nraw * strength; }
-            if (dd) {
-                accd.x += dy.x * (pre.x - bv.x - nz); accd.y += dy.y * (pre.y - bv.y - nz);
-                accd.z += dy.z * (pre.z - bv.z - nz); accd.w += dy.w * (pre.w - bv.w - nz);
+        // U pixels per trip: all 2*U 16-byte loads are in flight before the first dependent instruction (the kernel is a pure
+        // stream over dout/out/dz; with one pixel per trip each wave had two loads outstanding and 8 waves/CU could not cover
+        // the HBM latency).
+        constexpr int U = 4;
+        const int stride = gridDim.x * ppb;
+        for (int pix0 = blockIdx.x * ppb + pl; pix0 < HW; pix0 += U * stride) {
+            float4 g[U], o[U];
+            float nraw[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pix = pix0 + u * stride;
+                const bool ok = pix < HW;
+                const int64_t off = ((int64_t)n * HW + (ok ? pix : pix0)) * C + c;
+                g[u] = ld4(dout + off); o[u] = ld4(outv + off);
+                nraw[u] = (noise && ok) ? noise[(int64_t)n * noise_nstride + pix] : 0.f;
             }
-            if (dnoise || dstrength) {
-                float s = (dy.x + dy.y) + (dy.z + dy.w);
-                if (pow2) {
-                    for (int m = grp >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-                    if ((threadIdx.x & (grp - 1)) == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pix = pix0 + u * stride;
+                if (pix >= HW) break;
+                const int64_t off = ((int64_t)n * HW + pix) * C + c;
+                float4 dy, pre;
+                bwd1(g[u].x, o[u].x, act, alpha, gain, clamp, dy.x, pre.x); bwd1(g[u].y, o[u].y, act, alpha, gain, clamp, dy.y, pre.y);
+                bwd1(g[u].z, o[u].z, act, alpha, gain, clamp, dy.z, pre.z); bwd1(g[u].w, o[u].w, act, alpha, gain, clamp, dy.w, pre.w);
+                st4(dz + off, make_float4(dy.x * dv.x, dy.y * dv.y, dy.z * dv.z, dy.w * dv.w));
+                accb.x += dy.x; accb.y += dy.y; accb.z += dy.z; accb.w += dy.w;
+                const float nz = nraw[u] * strength;
+                if (dd) {
+                    accd.x += dy.x * (pre.x - bv.x - nz); accd.y += dy.y * (pre.y - bv.y - nz);
+                    accd.z += dy.z * (pre.z - bv.z - nz); accd.w += dy.w * (pre.w - bv.w - nz);
+                }
+                if (dnoise || dstrength) {
+                    float s = (dy.x + dy.y) + (dy.z + dy.w);
+                    if (pow2) {
+                        for (int m = grp >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+                        if ((threadIdx.x & (grp - 1)) == 0) {
+                            if (dnoise) unsafeAtomicAdd(dnoise + (int64_t)n * dnoise_nstride + pix, s * strength);
+                            accs += s * nraw[u];
+                        }
+                    } else {
                         if (dnoise) unsafeAtomicAdd(dnoise + (int64_t)n * dnoise_nstride + pix, s * strength);
-                        accs += s * nraw;
+                        accs += s * nraw[u];
                     }
-                } else {
-                    if (dnoise) unsafeAtomicAdd(dnoise + (int64_t)n * dnoise_nstride + pix, s * strength);
-                    accs += s * nraw;
                 }
             }
         }
@@ -169,24 +205,37 @@ __global__ void __launch_bounds__(256) epilogue_bwd_kernel(const float* __restri
 }
 
 // finish of a split-K data-gradient: dx = z * s[n,c] (+ addend);  ds[n,c] += sum_px z * x      (grid = (blocks, N))
-__global__ void __launch_bounds__(256) dgrad_finish_kernel(const float* __restrict__ z, const float* __restrict__ x, const float* __restrict__ s,
+__global__ void __launch_bounds__(EPI_BWD_THREADS) dgrad_finish_kernel(const float* __restrict__ z, const float* __restrict__ x, const float* __restrict__ s,
                                                            const float* __restrict__ addend, float* __restrict__ dx, float* __restrict__ ds, int HW, int C4) {
     extern __shared__ __attribute__((aligned(16))) float red[];
     const int n = blockIdx.y, C = C4 * 4;
-    const int ppb = 256 / C4 > 0 ? 256 / C4 : 1;
+    const int ppb = EPI_BWD_THREADS / C4 > 0 ? EPI_BWD_THREADS / C4 : 1;
     const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
     const bool active = pl < ppb;
     const int c = c4 * 4;
     float4 sv = make_float4(1, 1, 1, 1), acc = make_float4(0, 0, 0, 0);
     if (active && s) sv = ld4(s + (int64_t)n * C + c);
     if (active) {
-        for (int pix = blockIdx.x * ppb + pl; pix < HW; pix += gridDim.x * ppb) {
-            const int64_t off = ((int64_t)n * HW + pix) * C + c;
-            float4 zv = ld4(z + off);
-            if (ds) { float4 xv = ld4(x + off); acc.x += zv.x * xv.x; acc.y += zv.y * xv.y; acc.z += zv.z * xv.z; acc.w += zv.w * xv.w; }
-            float4 o = make_float4(zv.x * sv.x, zv.y * sv.y, zv.z * sv.z, zv.w * sv.w);
-            if (addend) { float4 a = ld4(addend + off); o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
-            st4(dx + off, o);
+        constexpr int U = 4;                      // loads of U pixels in flight per trip (see epilogue_bwd_kernel)
+        const int stride = gridDim.x * ppb;
+        for (int pix0 = blockIdx.x * ppb + pl; pix0 < HW; pix0 += U * stride) {
+            float4 zv[U], xv[U], av[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pix = pix0 + u * stride;
+                const int64_t off = ((int64_t)n * HW + (pix < HW ? pix : pix0)) * C + c;
+                zv[u] = ld4(z + off);
+                xv[u] = ds ? ld4(x + off) : make_float4(0, 0, 0, 0);
+                av[u] = addend ? ld4(addend + off) : make_float4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pix = pix0 + u * stride;
+                if (pix >= HW) break;
+                const int64_t off = ((int64_t)n * HW + pix) * C + c;
+                acc.x += zv[u].x * xv[u].x; acc.y += zv[u].y * xv[u].y; acc.z += zv[u].z * xv[u].z; acc.w += zv[u].w * xv[u].w;
+                st4(dx + off, make_float4(zv[u].x * sv.x + av[u].x, zv[u].y * sv.y + av[u].y, zv[u].z * sv.z + av[u].z, zv[u].w * sv.w + av[u].w));
+            }
         }
     }
     if (ds == nullptr) return;
@@ -289,11 +338,13 @@ extern "C" int eg3d_modconv_epilogue_bwd(const float* dout, const float* out, fl
     if ((noise || dnoise || dstrength) && !noise_strength) return EG3D_ERR_INVALID;
     if ((dnoise || dstrength) && !noise) return EG3D_ERR_INVALID;
     const int C4 = C / 4;
-    const int ppb = std::max(256 / C4, 1);
+    const int ppb = std::max(EPI_BWD_THREADS / C4, 1);
     // one atomic per (block, channel) lands on the same N*C addresses: keep the block count near the CU count
-    int bx = std::min(eg3d_cdiv((int64_t)H * W, ppb), std::max(1, 512 / N));
+    // >= 8 pixels per thread (two unrolled trips) so that the per-block channel atomics stay a small fraction of the work
+    const int cap = 256;
+    int bx = std::max(1, std::min(eg3d_cdiv((int64_t)H * W, ppb * 8), std::max(1, cap / N)));
     size_t smem = (size_t)(ppb * C4 * 8 + 4) * sizeof(float);
-    hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(bx, N), dim3(256), smem, (hipStream_t)stream, dout, out, dz, H, W, C4, d, noise, noise_nstride,
+    hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(bx, N), dim3(EPI_BWD_THREADS), smem, (hipStream_t)stream, dout, out, dz, H, W, C4, d, noise, noise_nstride,
                        noise_strength, bias, act, alpha, gain, clamp, dbias, dd, dnoise, dnoise_nstride, dstrength);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
@@ -303,9 +354,9 @@ extern "C" int eg3d_dgrad_finish(const float* z, const float* x, const float* s,
                                  void* stream) {
     if (!z || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (ds && !x)) return EG3D_ERR_INVALID;
     if (C % 4 || C / 4 > 256) return EG3D_ERR_UNSUPPORTED;
-    const int C4 = C / 4, ppb = std::max(256 / C4, 1);
-    int bx = std::min(eg3d_cdiv((int64_t)H * W, ppb), std::max(1, 512 / N));
-    hipLaunchKernelGGL(dgrad_finish_kernel, dim3(bx, N), dim3(256), (size_t)ppb * C4 * 4 * sizeof(float), (hipStream_t)stream, z, x, s, addend, dx, ds,
+    const int C4 = C / 4, ppb = std::max(EPI_BWD_THREADS / C4, 1);
+    int bx = std::max(1, std::min(eg3d_cdiv((int64_t)H * W, ppb * 8), std::max(1, 256 / N)));
+    hipLaunchKernelGGL(dgrad_finish_kernel, dim3(bx, N), dim3(EPI_BWD_THREADS), (size_t)ppb * C4 * 4 * sizeof(float), (hipStream_t)stream, z, x, s, addend, dx, ds,
                        H * W, C4);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;

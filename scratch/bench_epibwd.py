@@ -1,0 +1,21 @@
+import sys, torch
+sys.path.insert(0,'.'); sys.path.insert(0,'3dgan-inversion_amd')
+from inv3d_amd import hipops as H, _lib as L
+dev='cuda'
+def timeit(f, iters=20):
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1)/iters
+for (c,h) in ((128,512),(64,512),(256,256),(512,128),(512,64)):
+    dout = torch.randn(1,c,h,h,device=dev).contiguous(memory_format=torch.channels_last)
+    out = torch.randn(1,c,h,h,device=dev).contiguous(memory_format=torch.channels_last)
+    dz = torch.empty_like(out)
+    d = torch.rand(1,c,device=dev)+0.5; nz = torch.randn(h,h,device=dev); ns = torch.tensor(0.1,device=dev); b = torch.randn(c,device=dev)
+    dbias=torch.zeros(c,device=dev); dd=torch.zeros(1,c,device=dev); dn=torch.zeros(h,h,device=dev); dst=torch.zeros((),device=dev)
+    t = timeit(lambda: H.epilogue_bwd(dout,out,dz,d=d,noise=nz,noise_nstride=0,noise_strength=ns,bias=b,act='lrelu',alpha=0.2,gain=1.414,clamp=256.0,dbias=dbias,dd=dd,dnoise=dn,dnoise_nstride=0,dstrength=dst))
+    gb = 3*c*h*h*4/1e9
+    print(f'C={c} {h}^2: {t*1e3:7.1f} us  {gb/t:6.2f} TB/s')
