@@ -74,6 +74,20 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc4(const float* __restrict__
         const int by = oy * down - pady0, bx = ox * down - padx0;
         const int ky0 = pos_mod(-by, up), kx0 = pos_mod(-bx, up);
         float4 acc = make_float4(0, 0, 0, 0);
+        if (up == 1 && fH == 4 && fW == 4) {
+            // plain 4x4 FIR (the adjoint filter pass of every up-sampling layer's backward): 16 unconditional loads in flight
+            float4 t[16];
+            float wg[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int iy = by + (k >> 2), ix = bx + (k & 3);
+                const bool ok = (unsigned)iy < (unsigned)inH && (unsigned)ix < (unsigned)inW;
+                wg[k] = ok ? fs[k] : 0.f;
+                t[k] = x4[((int64_t)(n * inH + (ok ? iy : 0)) * inW + (ok ? ix : 0)) * C4 + c];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { acc.x += wg[k] * t[k].x; acc.y += wg[k] * t[k].y; acc.z += wg[k] * t[k].z; acc.w += wg[k] * t[k].w; }
+        } else
         for (int ky = ky0; ky < fH; ky += up) {
             int iy = (by + ky) / up;
             if (by + ky < 0 || iy >= inH) continue;
