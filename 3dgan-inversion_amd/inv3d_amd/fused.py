@@ -60,6 +60,28 @@ class WeightCache:
             self._c = {'k': key, 'wf': wf, 'wa': wa, 'wsq': wsq}
         return self._c['wf'], self._c['wa'], self._c['wsq']
 
+    def adjoint_padded(self, w: torch.Tensor, cp: int):
+        """[Ci, cp] adjoint image of a 1x1 weight with the contraction dim (output channels) zero-padded to cp (toRGB: 3 -> 4)."""
+        _, wa, _ = self.get(w)
+        hit = self._c.get('wa_p')
+        if hit is None or hit.shape[1] != cp:
+            hit = torch.zeros((wa.shape[0], cp), device=wa.device)
+            hit[:, :wa.shape[1]] = wa
+            self._c['wa_p'] = hit
+        return hit
+
+
+def _zeros_views(device, *shapes):
+    """Several small zero-initialised accumulators (targets of atomics) from ONE allocation and ONE fill launch.  A shape of
+    None yields None.  Every view starts on a 16-byte boundary."""
+    sizes = [0 if s is None else -(-int(torch.Size(s).numel()) // 4) * 4 for s in shapes]
+    flat = torch.zeros(max(sum(sizes), 1), dtype=torch.float32, device=device)
+    out, o = [], 0
+    for s, n in zip(shapes, sizes):
+        out.append(None if s is None else flat[o:o + torch.Size(s).numel()].view(s))
+        o += n
+    return out
+
 
 def _auto_ksplit(classes, N, Nc, Ck):
     """Split-K factor of an implicit GEMM whose output grid is too small to keep 256 CUs busy (the 4^2..64^2 layers): with few
@@ -132,12 +154,17 @@ class ModConvLayerFn(torch.autograd.Function):
         dev = x.device
         wf, wa, wsq = cache.get(weight)
         dz = H.empty_cl(N, Co, Ho, Wo, dev)
-        dbias = torch.zeros(Co, device=dev) if need_b else None
-        dd = torch.zeros((N, Co), device=dev) if (need_s or need_w) else None
-        dnoise = None
-        if need_nz and nz is not None:
-            dnoise = torch.zeros_like(nz)
-        dstrength = torch.zeros((), device=dev) if (need_ns and nz is not None) else None
+        ks_adj = rep = None
+        if need_x or need_s:
+            cls_probe = H.classes_corr_adjoint(Hi, Wi, kh, kw, kh // 2) if up == 1 else H.classes_convT_adjoint(Hi, Wi, kh, kw, up)
+            ks_adj = _auto_ksplit(cls_probe, N, Ci, Co)
+            # thousands of tiles reduce into the same N*Ci style-gradient addresses: spread them over replicas, sum afterwards
+            rep = 32 if (ks_adj == 1 and N * Hi * Wi >= 128 * 512) else 1
+        # all small atomically-accumulated outputs of this backward from one zero fill
+        dbias, dd, dnoise, dstrength, ds = _zeros_views(
+            dev, (Co,) if need_b else None, (N, Co) if (need_s or need_w) else None,
+            tuple(nz.shape) if (need_nz and nz is not None) else None, () if (need_ns and nz is not None) else None,
+            None if ks_adj is None else ((rep, N, Ci) if rep > 1 else (N, Ci)))
         H.epilogue_bwd(dout, out, dz, d=d, noise=nz, noise_nstride=nstride or 0, noise_strength=noise_strength if nz is not None else None,
                        bias=b, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv, dbias=dbias, dd=dd, dnoise=dnoise,
                        dnoise_nstride=nstride or 0, dstrength=dstrength)
@@ -151,20 +178,16 @@ class ModConvLayerFn(torch.autograd.Function):
             cls_adj = H.classes_convT_adjoint(Hi, Wi, kh, kw, up)
             in_stride = up
             cls_w, out_stride_w = H.classes_convT(Hi, Wi, kh, kw, up)[0], up
-        dx = ds = None
+        dx = None
         if need_x or need_s:
             dx = H.empty_cl(N, Ci, Hi, Wi, dev)
             aflops = 2.0 * N * Hi * Wi * kh * kw * Ci * Co
-            ks = _auto_ksplit(cls_adj, N, Ci, Co)
+            ks = ks_adj
             if ks == 1:
-                # thousands of tiles reduce into the same N*Ci style-gradient addresses: spread them over replicas, sum afterwards
-                rep = 32 if N * Hi * Wi >= 128 * 512 else 1
-                ds = torch.zeros((rep, N, Ci) if rep > 1 else (N, Ci), device=dev)
                 H.conv_igemm(g, wa, Co, Ci, dx, cls_adj, in_stride=in_stride, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, algo_flops=aflops)
                 if rep > 1:
                     ds = ds.sum(0)
             else:                                  # low resolution: split K over blocks, then scale / reduce in a finishing pass
-                ds = torch.zeros((N, Ci), device=dev)
                 z = H.zeros_cl(N, Ci, Hi, Wi, dev)
                 H.conv_igemm(g, wa, Co, Ci, z, cls_adj, in_stride=in_stride, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops)
                 H.dgrad_finish(z, x, styles, dx, ds=ds)
@@ -282,10 +305,7 @@ class ToRGBFn(torch.autograd.Function):
             dbias = dbias_p[:Co] if need_b else None
         dx = ds = None
         if need_x or need_s:
-            wa_p = wa
-            if Cp != Co:       # pad the contraction dim (output channels) with zeros to a multiple of 4
-                wa_p = torch.zeros((Ci, Cp), device=dev)
-                wa_p[:, :Co] = wa
+            wa_p = wa if Cp == Co else cache.adjoint_padded(weight, Cp)    # contraction dim (output channels) padded to 4
             dx = H.empty_cl(N, Ci, Hh, Ww, dev)
             ds = torch.zeros((N, Ci), device=dev)
             H.conv_igemm(dy, wa_p, Cp, Ci, dx, H.classes_corr_adjoint(Hh, Ww, 1, 1, 0), epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds)

@@ -51,7 +51,7 @@ def empty_cl(n, c, h, w, device) -> torch.Tensor:
 
 
 def zeros_cl(n, c, h, w, device) -> torch.Tensor:
-    return torch.zeros((n, c, h, w), dtype=torch.float32, device=device).contiguous(memory_format=CL)
+    return torch.empty((n, c, h, w), dtype=torch.float32, device=device, memory_format=CL).zero_()
 
 
 def _dtype_code(t):
