@@ -55,8 +55,16 @@ __device__ __forceinline__ void split4(const float4 v, uint2* out) {
 
 __device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 
+// waves per SIMD the register allocation is held to: 3 for the 4-wave split-bf16 tiles whose two loader register sets are small
+// (<= 168 VGPRs, 3 x 49 KB of LDS per CU), 2 where the sets are larger, unconstrained for the 8-wave / fp32 256-row variants
+__host__ __device__ constexpr int conv_min_waves(int bm, int bn, int waves, int prec) {
+    const int kb = prec ? (bm * bn >= 128 * 128 ? 16 : 32) : 32;
+    const int per_thread = (bm + bn) * (kb / 4) / (waves * 64);          // float4 per thread and register set
+    return waves != 4 ? 1 : (prec ? (per_thread <= 4 ? 3 : 2) : (per_thread <= 8 ? 2 : 1));
+}
+
 template <int BM, int BN, int WM, int WN, int PREC>
-__global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? (PREC ? 3 : 2) : 1) conv_igemm_kernel(const eg3d_conv_params p) {
+__global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, PREC)) conv_igemm_kernel(const eg3d_conv_params p) {
     constexpr int NT = WM * WN * 64;                        // 4 or 8 waves
     constexpr int NP = PREC == 1 ? 3 : 2;                   // bf16 pieces per operand (split paths)
     constexpr int KB = PREC ? (BM * BN >= 128 * 128 ? 16 : 32) : BK;      // K per step
@@ -147,18 +155,22 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? (PREC ? 3 : 2) 
     const int s_begin = (int)((int64_t)kslice * S / p.ksplit);
     const int s_end = (int)((int64_t)(kslice + 1) * S / p.ksplit);
 
-    float4 ra[A_LD], rb[B_LD], sc[A_LD];
-    int cur_chunk = -1;
+    // Two register sets: the global loads of step s+2 / s+3 are in flight while step s is multiplied and step s+1 is split and
+    // written to LDS, so the split arithmetic never waits on memory and can be interleaved with the MFMAs of the same wave.
+    struct Regs { float4 ra[A_LD], rb[B_LD], sc[A_LD]; int chunk; };
+    Regs R0, R1;
+    R0.chunk = R1.chunk = -1;
     int nx_chunk = s_begin / ntaps, nx_tap = s_begin - nx_chunk * ntaps;      // (chunk, tap) of the next step to load
 
-    auto load_tiles = [&]() {
+    auto load_tiles = [&](Regs& R) {
+        float4 (&ra)[A_LD] = R.ra; float4 (&rb)[B_LD] = R.rb; float4 (&sc)[A_LD] = R.sc;
         const int chunk = nx_chunk, tap = nx_tap;
         const bool kok = chunk * KB + col4 * 4 < p.Ck;
-        if (p.in_scale != nullptr && chunk != cur_chunk) {
+        if (p.in_scale != nullptr && chunk != R.chunk) {
 #pragma unroll
             for (int j = 0; j < A_LD; ++j)
                 sc[j] = kok ? *reinterpret_cast<const float4*>(p.in_scale + (int64_t)a_n[j] * p.Ck + chunk * KB + col4 * 4) : make_float4(0, 0, 0, 0);
-            cur_chunk = chunk;
+            R.chunk = chunk;
         }
         const unsigned aoff = (unsigned)(((cl.dy[tap] * p.Wi + cl.dx[tap]) * p.ldx + chunk * KB) * 4);       // wave-uniform
         const unsigned boff = (unsigned)((cl.wtap[tap] * p.Ck + chunk * KB) * 4);
@@ -175,7 +187,8 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? (PREC ? 3 : 2) 
         }
         if (++nx_tap == ntaps) { nx_tap = 0; ++nx_chunk; }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](Regs& R, int buf) {
+        float4 (&ra)[A_LD] = R.ra; float4 (&rb)[B_LD] = R.rb; float4 (&sc)[A_LD] = R.sc;
         if constexpr (PREC == 0) {
             float* a = reinterpret_cast<float*>(As_b + buf * A_STAGE);
             float* b = reinterpret_cast<float*>(Bs_b + buf * B_STAGE);
@@ -224,19 +237,18 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? (PREC ? 3 : 2) 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (s_begin < s_end) {
-        load_tiles();
-        store_tiles(0);
+        load_tiles(R0);
+        store_tiles(R0, 0);
     }
+    if (s_begin + 1 < s_end) load_tiles(R1);
+    if (s_begin + 2 < s_end) load_tiles(R0);
     __syncthreads();
 
     const int arow = wm * (TM * 32) + (lane & 31);
     const int brow = wn * (TN * 32) + (lane & 31);
     const int khalf = (lane >> 5) * 4;
 
-    for (int step = s_begin; step < s_end; ++step) {
-        const int buf = (step - s_begin) & 1;
-        const bool more = step + 1 < s_end;
-        if (more) load_tiles();
+    auto compute = [&](const int buf) {
         if constexpr (PREC == 0) {
         const float* a = reinterpret_cast<const float*>(As_b + buf * A_STAGE);
         const float* b = reinterpret_cast<const float*>(Bs_b + buf * B_STAGE);
@@ -284,7 +296,42 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? (PREC ? 3 : 2) 
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t]][i], bf[PB[t]][j], acc[i][j], 0, 0, 0);
             }
         }
-        if (more) store_tiles(buf ^ 1);
+    };
+    // In-order issue: a wave that emits its 24 MFMAs back to back and only then the ~110 VALU of the next tile's split keeps the
+    // matrix pipe idle during the second phase, and the co-resident waves run in lockstep, so they do not fill it either (counters:
+    // 50 % MFMA busy).  The steady-state step is one straight-line block and the scheduler is told to weave the two streams.
+    auto weave = [&]() {
+        if constexpr (PREC != 0) {
+            constexpr int NMFMA = TM * TN * (PREC == 1 ? 6 : 3) * (KB / 16);
+            constexpr int NVALU = (A_LD + B_LD) * (PREC == 1 ? 22 : 12) + A_LD * 4;
+            constexpr int PER = (NVALU + NMFMA - 1) / NMFMA;
+            __builtin_amdgcn_sched_group_barrier(0x100, (TM + TN) * NP * (KB / 16), 0);      // fragment reads
+#pragma unroll
+            for (int i = 0; i < NMFMA; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                           // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, PER, 0);                         // a slice of the split arithmetic
+            }
+            __builtin_amdgcn_sched_group_barrier(0x200, (A_LD + B_LD) * NP, 0);              // LDS writes of the next tile
+            __builtin_amdgcn_sched_group_barrier(0x020, A_LD + B_LD, 0);                     // global loads two steps ahead
+        }
+    };
+
+    int step = s_begin;
+    for (; step + 4 < s_end; step += 2) {          // steady state: every load / store below is unconditional
+        compute(0); store_tiles(R1, 1); load_tiles(R1); weave();
+        __syncthreads();
+        compute(1); store_tiles(R0, 0); load_tiles(R0); weave();
+        __syncthreads();
+    }
+    for (; step < s_end; step += 2) {              // drain
+        compute(0);
+        if (step + 1 < s_end) store_tiles(R1, 1);
+        if (step + 3 < s_end) load_tiles(R1);
+        __syncthreads();
+        if (step + 1 >= s_end) break;
+        compute(1);
+        if (step + 2 < s_end) store_tiles(R0, 0);
+        if (step + 4 < s_end) load_tiles(R0);
         __syncthreads();
     }
 

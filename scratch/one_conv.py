@@ -1,0 +1,11 @@
+import sys, torch, math
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/3dgan-inversion_amd')
+from inv3d_amd import hipops as H, _lib as L
+dev='cuda'
+n,ci,co,h,k=1,128,128,512,3
+x = torch.randn(n, ci, h, h, device=dev).contiguous(memory_format=torch.channels_last)
+w = torch.randn(co, ci, k, k, device=dev) / math.sqrt(ci*k*k)
+wf = H.pack_weight_fwd(w); s = torch.rand(n, ci, device=dev) + 0.5
+cls = H.classes_corr(h, h, k, k, k//2); out = H.empty_cl(n, co, h, h, dev)
+for _ in range(10): H.conv_igemm(x, wf, ci, co, out, cls, in_scale=s)
+torch.cuda.synchronize()
