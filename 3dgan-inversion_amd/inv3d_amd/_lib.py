@@ -65,6 +65,16 @@ class RenderBwdParams(C.Structure):
                 ('dump_dpre', C.c_void_p), ('dump_h', C.c_void_p), ('dump_dout', C.c_void_p), ('dump_feat', C.c_void_p)]
 
 
+class FlreluParams(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('b', C.c_void_p), ('y', C.c_void_p), ('fu', C.c_void_p), ('fd', C.c_void_p), ('mask', C.c_void_p),
+                ('dtype', C.c_int32), ('N', C.c_int32), ('C', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('fuh', C.c_int32), ('fuw', C.c_int32), ('fdh', C.c_int32), ('fdw', C.c_int32), ('up', C.c_int32), ('down', C.c_int32),
+                ('px0', C.c_int32), ('px1', C.c_int32), ('py0', C.c_int32), ('py1', C.c_int32),
+                ('qx0', C.c_int32), ('qx1', C.c_int32), ('qy0', C.c_int32), ('qy1', C.c_int32), ('Ho', C.c_int32), ('Wo', C.c_int32),
+                ('flip_fu', C.c_int32), ('flip_fd', C.c_int32), ('mode', C.c_int32), ('gain1', C.c_float), ('gain2', C.c_float),
+                ('gain', C.c_float), ('slope', C.c_float), ('clamp', C.c_float)]
+
+
 class StyleLayer(C.Structure):
     _fields_ = [('weight', C.c_void_p), ('bias', C.c_void_p), ('out', C.c_void_p), ('dout', C.c_void_p), ('C', C.c_int32), ('wrow', C.c_int32),
                 ('wgain', C.c_float), ('bgain', C.c_float), ('post', C.c_float), ('reserved', C.c_int32)]
@@ -105,6 +115,7 @@ _SIGS = {
     'eg3d_noise_regularizer': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_float, C.c_void_p]),
     'eg3d_noise_normalize': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
+    'eg3d_filtered_lrelu': (C.c_int, [C.POINTER(FlreluParams), C.c_void_p]),
     'eg3d_style_affine_fwd': (C.c_int, [C.POINTER(StyleBank), C.c_void_p]),
     'eg3d_style_affine_bwd': (C.c_int, [C.POINTER(StyleBank), C.c_void_p]),
     'eg3d_ray_gen_fwd': (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]),

@@ -155,6 +155,30 @@ typedef struct eg3d_wgrad_params {
 int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * filtered_lrelu -- replaces filtered_lrelu_plugin.filtered_lrelu / filtered_lrelu_act_ (torch_utils/ops/filtered_lrelu.cpp:20,217;
+ * Python wrapper filtered_lrelu.py:161-274; slow reference :123-155).  Contiguous NCHW, fp32 or fp16 (float accumulation).
+ *   t = gain1 * FIR_fu( zero_insert_up(x + b[c]) padded by (px0,px1,py0,py1) )                 size Hm x Wm
+ *   a = mode 0: clamp(lrelu(t, slope) * gain)   [mask := da/dt written when mask != null]      mode 1: t * mask
+ *   y = gain2 * decimate_down( FIR_fd( a padded/cropped by (qx0,qx1,qy0,qy1) ) )               size Ho x Wo (checked)
+ * Filters are dense 2-D fp32 ([fh][fw], null = identity), flip_* as upfirdn2d's flip_filter.  Forward: q = 0, gain1 = up^2,
+ * gain2 = 1; gradients: mode 1 with the stages transposed (see inv3d_amd/torch_utils/ops/filtered_lrelu.py). */
+typedef struct eg3d_flrelu_params {
+    const void* x;  const void* b;  void* y;
+    const float* fu;  const float* fd;
+    float* mask;               /* [N,C,Hm,Wm] fp32 */
+    int32_t dtype, N, C, H, W;
+    int32_t fuh, fuw, fdh, fdw;
+    int32_t up, down;
+    int32_t px0, px1, py0, py1;
+    int32_t qx0, qx1, qy0, qy1;
+    int32_t Ho, Wo;
+    int32_t flip_fu, flip_fd, mode;
+    float gain1, gain2;
+    float gain, slope, clamp;  /* mode 0 only; clamp < 0 = none */
+} eg3d_flrelu_params;
+int eg3d_filtered_lrelu(const eg3d_flrelu_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Style affines of a whole synthesis network in one launch (the per-layer FullyConnectedLayer(w_dim -> in_channels) of
  * training/networks_stylegan2.py:98-108 and :129-137, ~26 tiny GEMMs + scalings per forward in the reference):
  *   fwd:  out_l[n,j] = ( sum_k ws[n,wrow_l,k] * (weight_l[j,k]*wgain_l) + bias_l[j]*bgain_l ) * post_l

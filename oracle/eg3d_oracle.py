@@ -318,6 +318,16 @@ def upfirdn2d(x: Tensor, f: Optional[Tensor], up=1, down=1, padding=0, flip_filt
     return z[:, :, ::dny, ::dnx]
 
 
+def filtered_lrelu(x: Tensor, fu: Optional[Tensor] = None, fd: Optional[Tensor] = None, b: Optional[Tensor] = None, up: int = 1, down: int = 1,
+                   padding=0, gain: float = math.sqrt(2), slope: float = 0.2, clamp=None, flip_filter: bool = False) -> Tensor:
+    """bias -> upsample FIR (gain up^2, all of the padding) -> leaky ReLU * gain, clamp -> downsample FIR.
+    torch_utils/ops/filtered_lrelu.py:123-155 (_filtered_lrelu_ref)."""
+    x = bias_act(x, b)
+    x = upfirdn2d(x, fu, up=up, padding=_pad4(padding), gain=float(up) ** 2, flip_filter=flip_filter)
+    x = bias_act(x, None, act='lrelu', alpha=slope, gain=gain, clamp=clamp)
+    return upfirdn2d(x, fd, down=down, flip_filter=flip_filter)
+
+
 def upsample2d(x, f, up=2, padding=0, flip_filter=False, gain=1.0):
     """torch_utils/ops/upfirdn2d.py:315-350."""
     upx, upy = _xy(up)

@@ -30,6 +30,7 @@ torch.Tensor.cuda = lambda self, *a, **k: self      # ray_sampler.py:38 calls .c
 from torch_utils.ops import bias_act as ref_bias_act            # noqa: E402
 from torch_utils.ops import upfirdn2d as ref_upfirdn2d          # noqa: E402
 from torch_utils.ops import conv2d_resample as ref_c2r          # noqa: E402
+from torch_utils.ops import filtered_lrelu as ref_flrelu        # noqa: E402
 from training import networks_stylegan2 as ref_sg2              # noqa: E402
 from training.triplane import TriPlaneGenerator, OSGDecoder     # noqa: E402
 from training.volumetric_rendering.renderer import ImportanceRenderer, sample_from_planes, generate_planes  # noqa: E402
@@ -157,6 +158,47 @@ def gen_upfirdn2d():
     out['f44'] = f44
     out['ncases'] = np.array(len(cases))
     save('upfirdn2d', 1e-6, **out)
+
+
+def gen_filtered_lrelu():
+    """filtered_lrelu (torch_utils/ops/filtered_lrelu.py): the reference's `_filtered_lrelu_ref` composition, forward and gradients."""
+    print('filtered_lrelu')
+    g = torch.Generator().manual_seed(31)
+    f12 = ref_upfirdn2d.setup_filter([1, 4, 9, 16, 22, 26, 26, 22, 16, 9, 4, 1][:12], normalize=True)     # 12x12 (outer product)
+    f6_1d = torch.tensor([1., 3., 5., 5., 3., 1.]) / 18.0                                                   # separable, 1-D
+    f_asym = torch.tensor([[1., 2., 0.5, 0.2], [0., -1., 3., 0.4], [0.25, 1., 1.5, -0.6], [2., 0.1, -0.3, 0.7]]) / 4
+    f44 = ref_upfirdn2d.setup_filter([1, 3, 3, 1])
+    cases = [
+        # (shape, fu, fd, up, down, padding, gain, slope, clamp, flip, bias)
+        ((2, 3, 8, 8), f12, f12, 2, 2, [5, 5, 5, 5], math.sqrt(2), 0.2, None, False, True),     # StyleGAN3-like up2/down2, 12 taps
+        ((1, 4, 6, 7), f6_1d, f6_1d, 2, 1, [3, 2, 3, 2], math.sqrt(2), 0.2, 0.7, False, True),  # separable filters, clamp active
+        ((2, 2, 9, 8), f_asym, f44, 1, 2, [2, 1, 1, 2], 1.0, 0.1, None, True, False),           # asymmetric 2-D up filter, flipped, no bias
+        ((1, 3, 5, 5), f44, None, 4, 1, [3, 3, 3, 3], 2.0, 0.0, 1.5, False, True),              # up 4, no down filter, relu (slope 0)
+        ((1, 2, 10, 10), None, f44, 1, 2, [1, 1, 1, 1], math.sqrt(2), 0.2, None, False, True),  # no up filter
+        ((2, 3, 7, 6), None, None, 1, 1, 0, math.sqrt(2), 0.2, 0.5, False, True),               # plain bias + lrelu + clamp
+        ((1, 2, 12, 12), f12, f12, 4, 2, [8, 9, 9, 8], math.sqrt(2), 0.2, 256.0, False, True),  # up 4 / down 2, uneven padding
+    ]
+    out = {}
+    for i, (shape, fu, fd, up, down, pad, gain, slope, clamp, flip, has_b) in enumerate(cases):
+        x = torch.randn(shape, generator=g).requires_grad_(True)
+        b = (torch.randn(shape[1], generator=g) * 0.5).requires_grad_(True) if has_b else None
+        y = ref_flrelu.filtered_lrelu(x, fu=fu, fd=fd, b=b, up=up, down=down, padding=pad, gain=gain, slope=slope, clamp=clamp,
+                                      flip_filter=flip, impl='ref')
+        dy = torch.randn(y.shape, generator=g)
+        grads = torch.autograd.grad(y, [x] + ([b] if has_b else []), dy)
+        yo = O.filtered_lrelu(x, fu=fu, fd=fd, b=b, up=up, down=down, padding=pad, gain=gain, slope=slope, clamp=clamp, flip_filter=flip)
+        check(yo, y, 1e-6, f'filtered_lrelu {i}')
+        go = torch.autograd.grad(yo, [x] + ([b] if has_b else []), dy)
+        for a_, b_ in zip(go, grads):
+            check(a_, b_, 1e-5, f'filtered_lrelu {i} grad')
+        k = f'c{i}'
+        out.update({f'{k}_x': x, f'{k}_y': y, f'{k}_dy': dy, f'{k}_dx': grads[0],
+                    f'{k}_b': (b if has_b else np.zeros((0,), np.float32)), f'{k}_db': (grads[1] if has_b else np.zeros((0,), np.float32)),
+                    f'{k}_fu': (fu if fu is not None else np.zeros((0,), np.float32)),
+                    f'{k}_fd': (fd if fd is not None else np.zeros((0,), np.float32)),
+                    f'{k}_meta': np.array([up, down, *O._pad4(pad), gain, slope, -1.0 if clamp is None else clamp, int(flip)], dtype=np.float64)})
+    out['ncases'] = np.array(len(cases))
+    save('filtered_lrelu', 1e-6, **out)
 
 
 def gen_conv2d_resample():
@@ -604,7 +646,7 @@ def gen_loss_glue():
 
 if __name__ == '__main__':
     only = sys.argv[1:]
-    gens = dict(bias_act=gen_bias_act, upfirdn2d=gen_upfirdn2d, conv=gen_conv2d_resample, renderer=gen_renderer,
+    gens = dict(bias_act=gen_bias_act, upfirdn2d=gen_upfirdn2d, filtered_lrelu=gen_filtered_lrelu, conv=gen_conv2d_resample, renderer=gen_renderer,
                 graph_small=gen_graph_small, graph_full=gen_graph_full, loss=gen_loss_glue)
     mpath = os.path.join(HERE, 'MANIFEST.json')
     if only and os.path.exists(mpath):

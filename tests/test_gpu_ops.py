@@ -140,6 +140,49 @@ def test_upfirdn2d_golden(golden, ops):
     close(up.setup_filter([1, 3, 3, 1]), d['f44'], 1e-7)
 
 
+def test_filtered_lrelu_golden(golden):
+    """eg3d_filtered_lrelu (one fused launch) vs the reference's _filtered_lrelu_ref fixtures: forward, dx, db, fp16, and a
+    second-order check (gradient of the gradient is the same masked-FIR operator, transposed twice)."""
+    from inv3d_amd.torch_utils.ops import filtered_lrelu as FL
+    d = golden('filtered_lrelu')
+    for i in range(int(d['ncases'])):
+        k = f'c{i}'
+        m = d[f'{k}_meta']
+        opt = lambda a: None if a.size == 0 else t(a)
+        kw = dict(fu=opt(d[f'{k}_fu']), fd=opt(d[f'{k}_fd']), up=int(m[0]), down=int(m[1]), padding=[int(v) for v in m[2:6]], gain=float(m[6]),
+                  slope=float(m[7]), clamp=None if m[8] < 0 else float(m[8]), flip_filter=bool(m[9]))
+        x = t(d[f'{k}_x']).requires_grad_(True)
+        b = opt(d[f'{k}_b'])
+        if b is not None:
+            b = b.requires_grad_(True)
+        y = FL.filtered_lrelu(x, b=b, **kw)
+        close(y, d[f'{k}_y'], 1e-5, f'filtered_lrelu case {i}')
+        dy = t(d[f'{k}_dy'])
+        g = torch.autograd.grad(y, [x] + ([b] if b is not None else []), dy, create_graph=True)
+        close(g[0], d[f'{k}_dx'], 2e-5, f'filtered_lrelu case {i} dx')
+        if b is not None:
+            close(g[1], d[f'{k}_db'], 5e-5, f'filtered_lrelu case {i} db')
+        # second order: d/d(dy) <dx, v> must equal the forward linearisation applied to v  (oracle autograd as the checker)
+        v = torch.randn_like(x)
+        xo = t(d[f'{k}_x']).cpu().requires_grad_(True)
+        kwo = {a: (b_.cpu() if torch.is_tensor(b_) else b_) for a, b_ in kw.items()}
+        yo = O.filtered_lrelu(xo, b=None if b is None else b.detach().cpu(), **kwo)
+        dyo = dy.cpu().requires_grad_(True)
+        gxo, = torch.autograd.grad(yo, xo, dyo, create_graph=True)
+        ggo, = torch.autograd.grad(gxo, dyo, v.cpu())
+        dyg = dy.clone().requires_grad_(True)
+        y2 = FL.filtered_lrelu(x, b=b, **kw)
+        gx, = torch.autograd.grad(y2, x, dyg, create_graph=True)
+        gg, = torch.autograd.grad(gx, dyg, v)
+        close(gg, ggo, 5e-5, f'filtered_lrelu case {i} second order')
+        # fp16 storage
+        yh = FL.filtered_lrelu(x.detach().half(), b=None if b is None else b.detach().half(), **kw)
+        assert yh.dtype == torch.float16
+        close(yh.float(), d[f'{k}_y'], 2e-2, f'filtered_lrelu case {i} fp16')
+    with pytest.raises(NotImplementedError):
+        FL.filtered_lrelu(torch.zeros(1, 1, 4, 4, device=DEV), impl='ref')
+
+
 def test_upfirdn2d_nhwc_fused(golden):
     """The channels-last float4 resampler used on the fused path vs the oracle (skip upsample, its adjoint, FIR adjoint)."""
     from inv3d_amd import hipops as H

@@ -53,6 +53,31 @@ def test_upfirdn2d(golden):
     close(O.filter2d(x, f44), t(d['w_filter2d_y']), 1e-6)
 
 
+def _flrelu_case(d, i):
+    k = f'c{i}'
+    m = d[f'{k}_meta']
+    opt = lambda a: None if a.size == 0 else t(a)
+    kw = dict(fu=opt(d[f'{k}_fu']), fd=opt(d[f'{k}_fd']), up=int(m[0]), down=int(m[1]), padding=[int(v) for v in m[2:6]], gain=float(m[6]),
+              slope=float(m[7]), clamp=None if m[8] < 0 else float(m[8]), flip_filter=bool(m[9]))
+    return k, kw, opt(d[f'{k}_b'])
+
+
+def test_filtered_lrelu(golden):
+    """oracle.filtered_lrelu vs the reference's _filtered_lrelu_ref outputs and gradients (fixtures from make_golden.py)."""
+    d = golden('filtered_lrelu')
+    for i in range(int(d['ncases'])):
+        k, kw, b = _flrelu_case(d, i)
+        x = t(d[f'{k}_x']).requires_grad_(True)
+        if b is not None:
+            b = b.requires_grad_(True)
+        y = O.filtered_lrelu(x, b=b, **kw)
+        close(y, t(d[f'{k}_y']), 1e-6)
+        g = torch.autograd.grad(y, [x] + ([b] if b is not None else []), t(d[f'{k}_dy']))
+        close(g[0], t(d[f'{k}_dx']), 1e-5)
+        if b is not None:
+            close(g[1], t(d[f'{k}_db']), 1e-5)
+
+
 def test_conv2d_resample(golden):
     d = golden('conv2d_resample')
     f44 = t(d['f44'])
