@@ -57,6 +57,15 @@ def allreduce_stats(values: Dict[str, float], device) -> Dict[str, float]:
     return {k: out[i] for i, k in enumerate(keys)}
 
 
+def allreduce_stats_device(t: torch.Tensor) -> torch.Tensor:
+    """Per-step variant for the optimisation loop: sum a packed fp32 stat vector that already lives on the device over all ranks,
+    in place, with ONE collective and no host read-back (the host keeps queueing the next step; read the tensor at a logging
+    interval).  No-op for a single process."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -104,9 +104,14 @@ def main():
     proj = LatentProjector(G, target, num_steps=400, cam=cam, wplus=args.wplus, seed=100 + rank, use_graph=use_graph)
     proj.preheat = 0
 
+    stats = torch.zeros(4, device=dev)
+    ones = torch.ones(1, device=dev)
+
     def one_step(pr=proj):
         out = pr.step()
-        st = D.allreduce_stats(dict(loss=0.0, n_active=1.0, steps=1.0), dev) if world > 1 else None   # stat sync (latency only)
+        if world > 1:       # the path's only collective: packed per-step stats, summed on the device, never read inside the timed region
+            stats.copy_(torch.stack([out['loss'], out['dist'], ones[0], ones[0]]))
+            D.allreduce_stats_device(stats)
         return out
 
     if use_graph:                       # set-up, not a step of the benchmark: eager passes + the capture of the step into a HIP graph

@@ -27,6 +27,8 @@ def _worker(rank, world, port, out):
                                    step_ms=5.0 + r), torch.device('cpu'))
     D.barrier()
     mx = D.max_over_ranks(1.0 + r, torch.device('cpu'))
+    dev_stats = D.allreduce_stats_device(torch.tensor([1.0 + r, 10.0, float(len(mine))]))       # per-step in-place variant
+    stats['dev'] = dev_stats.tolist()
     out.put((rank, mine, stats, mx))
     dist.destroy_process_group()
 
@@ -49,6 +51,7 @@ def test_two_rank_gloo_stat_sync():
         assert st['loss'] == float(sum(range(7)))
         assert st['n_active'] == 7.0 and st['dist'] == 2.0 and st['steps'] == 6.0 and st['psnr'] == 30.0
         assert st['step_ms'] == 6.0
+        assert st['dev'] == [3.0, 20.0, 7.0]
         assert mx == 2.0
 
 
@@ -59,5 +62,6 @@ def test_single_process_is_a_noop():
     assert D.init_from_env('gloo') == (0, 1, 0)
     st = D.allreduce_stats(dict(loss=2.5, n_active=1.0), torch.device('cpu'))
     assert st['loss'] == 2.5 and st['n_active'] == 1.0
+    assert D.allreduce_stats_device(torch.tensor([4.0])).item() == 4.0
     assert D.shard_images(5, 0, 1) == [0, 1, 2, 3, 4]
     assert D.max_over_ranks(3.0, torch.device('cpu')) == 3.0
