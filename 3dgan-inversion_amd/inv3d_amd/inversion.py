@@ -148,7 +148,7 @@ class LatentProjector:
         dev = target.device
         if use_graph and optimize_pose:
             raise ValueError('use_graph: the pose chain skips optimiser steps during the preheat (data-dependent control flow on the host)')
-        self.use_graph, self._graph, self._graph_warmup = use_graph, None, graph_warmup
+        self.use_graph, self._graph, self._graph_warmup, self.graph_capture_error = use_graph, None, graph_warmup, None
         self.G = G.eval().requires_grad_(False)
         self.dev = dev
         self.num_steps, self.preheat = num_steps, (cam_preheat_steps if optimize_pose else 0)
@@ -244,7 +244,8 @@ class LatentProjector:
                 self._wn.normal_(generator=self.gen)
             if self._graph is not None:
                 self._graph.replay()
-            elif step < self._graph_warmup:           # eager warm-up on a side stream (allocator / autograd state, lazy kernel attributes)
+            elif step < self._graph_warmup or self.graph_capture_error is not None:
+                # eager: warm-up on a side stream (allocator / autograd state, lazy kernel attributes), or capture was refused
                 side = torch.cuda.Stream(device=self.dev)
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
@@ -254,10 +255,18 @@ class LatentProjector:
                 torch.cuda.synchronize()
                 self.optimizer.zero_grad(set_to_none=True)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                try:
+                    with torch.cuda.graph(graph, capture_error_mode='thread_local'):   # other threads (RCCL watchdog) may touch the runtime
+                        self.last = self._step_body(self._scale_t, self._wn, self.synth_kwargs, True)
+                    self._graph = graph
+                    graph.replay()                    # capture records without executing
+                except RuntimeError as e:             # the runtime refused the capture: keep optimising eagerly (same kernels), say so
+                    import warnings
+                    self.graph_capture_error = e
+                    warnings.warn(f'LatentProjector: HIP graph capture failed ({e}); continuing with eager launches')
+                    torch.cuda.synchronize()
+                    self.optimizer.zero_grad(set_to_none=True)
                     self.last = self._step_body(self._scale_t, self._wn, self.synth_kwargs, True)
-                self._graph = graph
-                graph.replay()                        # capture records without executing
             self.step_idx += 1
             return self.last
         for g in self.optimizer.param_groups:

@@ -177,7 +177,7 @@ def main():
                                          '128^2 x 96-sample rendering, stub-LPIPS feature distance + noise regulariser, Adam)' % ('+' if args.wplus else ''),
                                 images_per_gpu=1, generator='ffhqrebalanced512-128-shaped, 30.66 M params, random-init (synthetic weights)',
                                 parallelism=f'{world} independent images, 1 per GPU; stat all-reduce only',
-                                launch='one HIP graph replay per step' if use_graph else 'eager (one launch per kernel)',
+                                launch='one HIP graph replay per step' if (use_graph and proj._graph is not None) else 'eager (one launch per kernel)',
                                 psnr_after_timed_steps_db=round(final_psnr, 3)),
                     roofline=roof, cpu_baseline=cpu)
         print(json.dumps(line), flush=True)
