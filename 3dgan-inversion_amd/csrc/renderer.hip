@@ -672,7 +672,7 @@ __global__ void __launch_bounds__(256) scatter_bin_kernel(const float4* __restri
     }
 }
 
-constexpr int CHUNK = 8192;             // pairs per accumulate block
+constexpr int CHUNK = 4096;             // pairs per accumulate block
 
 // single block: exclusive scan of `n` counts -> offsets[n+1], and of ceil(count/CHUNK) -> chunk_offsets[n+1]
 __global__ void __launch_bounds__(1024) scatter_scan_kernel(const int* __restrict__ counts, int* __restrict__ offsets, int* __restrict__ chunk_offsets, int n) {
