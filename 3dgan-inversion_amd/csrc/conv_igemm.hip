@@ -462,7 +462,7 @@ int pick_config(const eg3d_conv_params& p) {
     int64_t maxM = 0;
     for (int c = 0; c < p.ncls; ++c) maxM = std::max<int64_t>(maxM, (int64_t)p.N * p.cls[c].Ha * p.cls[c].Wa);
     if (p.Nc <= 32) return 3;
-    if (p.Nc <= 64 && maxM * p.ncls * p.ksplit >= 256 * 256 && !getenv("EG3D_NO_CFG4")) return 4;
+    if (p.Nc <= 64 && maxM * p.ncls * p.ksplit >= 256 * 256) return 4;
     if (maxM <= 32) return 2;
     // enough 128x128 tiles to fill the chip (2 blocks/CU)?  otherwise shrink the M tile
     int64_t big_tiles = (int64_t)eg3d_cdiv(maxM, 128) * eg3d_cdiv(p.Nc, 128) * p.ncls * p.ksplit;
@@ -498,7 +498,7 @@ extern "C" int eg3d_conv2d_igemm_f32(const eg3d_conv_params* pp, void* stream) {
     if ((int64_t)p.Nc * p.w_row * 4 > 0x7fffffe0ll) return EG3D_ERR_TOO_LARGE;       // 31-bit buffer offsets
     hipStream_t st = (hipStream_t)stream;
     switch (pick_config(p)) {
-        case 0: return (getenv("EG3D_CONV8") ? launch_conv<128, 128, 2, 4>(p, st) : launch_conv<128, 128, 2, 2>(p, st));
+        case 0: return launch_conv<128, 128, 2, 2>(p, st);
         case 1: return launch_conv<64, 128, 2, 2>(p, st);
         case 2: return launch_conv<32, 128, 1, 4>(p, st);
         case 4: return launch_conv<256, 64, 4, 1>(p, st);

@@ -74,39 +74,6 @@ __device__ __forceinline__ void gather_feats(const float* __restrict__ pn, int H
     for (int c = 0; c < FC; ++c) f[c] = f[c] / 3.f;
 }
 
-// same arithmetic, but plane/corner loops kept rolled: at most 8 texel loads in flight, for kernels that trade in-flight loads
-// for occupancy (the sample-level backward)
-__device__ __forceinline__ void gather_feats_rolled(const float* __restrict__ pn, int Hp, int Wp, int ldp, float cs, float x, float y, float z,
-                                                    float (&f)[FC]) {
-#pragma unroll
-    for (int c = 0; c < FC; ++c) f[c] = 0.f;
-#pragma unroll 1
-    for (int pl = 0; pl < 3; ++pl) {
-        float u, v;
-        plane_uv(pl, x * cs, y * cs, z * cs, u, v);
-        float ix = ((u + 1.f) * Wp - 1.f) * 0.5f, iy = ((v + 1.f) * Hp - 1.f) * 0.5f;
-        float fx0 = floorf(ix), fy0 = floorf(iy);
-        int x0 = (int)fx0, y0 = (int)fy0;
-        float wx1 = ix - fx0, wx0 = (fx0 + 1.f) - ix, wy1 = iy - fy0, wy0 = (fy0 + 1.f) - iy;
-#pragma unroll 1
-        for (int q = 0; q < 4; ++q) {
-            int xx = x0 + (q & 1), yy = y0 + (q >> 1);
-            if ((unsigned)xx < (unsigned)Wp && (unsigned)yy < (unsigned)Hp) {
-                const float4* t = reinterpret_cast<const float4*>(pn + ((int64_t)yy * Wp + xx) * ldp + pl * FC);
-                float w = ((q & 1) ? wx1 : wx0) * ((q >> 1) ? wy1 : wy0);
-#pragma unroll
-                for (int c4 = 0; c4 < FC / 4; ++c4) {
-                    float4 tv = t[c4];
-                    f[c4 * 4 + 0] = fmaf(w, tv.x, f[c4 * 4 + 0]); f[c4 * 4 + 1] = fmaf(w, tv.y, f[c4 * 4 + 1]);
-                    f[c4 * 4 + 2] = fmaf(w, tv.z, f[c4 * 4 + 2]); f[c4 * 4 + 3] = fmaf(w, tv.w, f[c4 * 4 + 3]);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < FC; ++c) f[c] = f[c] / 3.f;
-}
-
 // 32 -> 64 (softplus) -> 33; w1t is [HD][1+CO] (transposed so that a hidden unit's fan-out is contiguous)
 __device__ __forceinline__ void mlp_fwd(const float* __restrict__ w0, const float* __restrict__ b0, const float* __restrict__ w1t,
                                         const float* __restrict__ b1, const float (&f)[FC], float (&out)[1 + CO]) {
@@ -475,119 +442,6 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
     }
 }
 
-// ---- sample-level backward: one thread per (ray, pass, s) row; no coupling between threads -----------------------------------
-// colours/density -> MLP -> features; features -> planes goes through the tile-binned scatter below (rows of dL/d feature +
-// position); features -> coordinates is written per row and summed per ray by render_coord_reduce_kernel.
-__global__ void __launch_bounds__(256) render_sample_bwd_kernel(const eg3d_render_bwd_params bp) {
-    const eg3d_render_params& p = bp.fwd;
-    const int D = p.Dc > p.Df ? p.Dc : p.Df;
-    const int64_t S = (int64_t)p.N * p.R * 2 * D;
-    const int64_t sample_id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (sample_id >= S) return;
-    const int64_t rr = sample_id / (2 * D);
-    const int rem = (int)(sample_id - rr * 2 * D);
-    const int pass = rem / D, s = rem - pass * D;
-    const bool has = s < (pass == 0 ? p.Dc : p.Df);
-    const bool want_coord = bp.gc_rows != nullptr;
-    if (!has) {
-        if (bp.df_pos) bp.df_pos[sample_id * 4] = NAN;          // absent sample: skipped by the scatter
-        if (want_coord) reinterpret_cast<float4*>(bp.gc_rows)[sample_id] = make_float4(0, 0, 0, 0);
-        return;
-    }
-    const int n = (int)(rr / p.R);
-    const float* pn = p.planes + (int64_t)n * p.Hp * p.Wp * p.ldp;
-    const float cs = 2.f / p.box_warp;
-    const float ox = p.origins[rr * 3 + 0], oy = p.origins[rr * 3 + 1], oz = p.origins[rr * 3 + 2];
-    const float dx = p.dirs[rr * 3 + 0], dy = p.dirs[rr * 3 + 1], dz = p.dirs[rr * 3 + 2];
-    const float depth = pass == 0 ? coarse_depth(p, rr, s, p.u1[rr * p.Dc + s]) : p.fine_depths[rr * p.Df + s];
-    const float2 ag = reinterpret_cast<const float2*>(bp.ag_rows)[sample_id];
-    const float a = ag.x, gsig = ag.y;
-    const float* grgb = bp.d_rgb + rr * CO;
-    {
-        const float px = ox + depth * dx, py = oy + depth * dy, pz = oz + depth * dz;
-        float f[FC], dout[1 + CO];
-        gather_feats_rolled(pn, p.Hp, p.Wp, p.ldp, cs, px, py, pz, f);
-        mlp_fwd(p.w0, p.b0, p.w1, p.b1, f, dout);
-        dout[0] = gsig;
-#pragma unroll
-        for (int k = 0; k < CO; ++k) {
-            float sg = sigmoidf_(dout[1 + k]);
-            dout[1 + k] = (2.f * a * grgb[k]) * 1.002f * sg * (1.f - sg);
-        }
-        if (bp.dump_dout) {
-            float* o = bp.dump_dout + sample_id * (1 + CO);      // [S, 33]
-#pragma unroll
-            for (int k = 0; k < 1 + CO; ++k) o[k] = dout[k];
-        }
-        if (bp.dump_feat) {
-            float* o = bp.dump_feat + sample_id * FC;            // [S, 32]
-#pragma unroll
-            for (int c = 0; c < FC; ++c) o[c] = f[c];
-        }
-        float df[FC];
-#pragma unroll
-        for (int c = 0; c < FC; ++c) df[c] = 0.f;
-#pragma unroll 1
-        for (int j = 0; j < HD; ++j) {
-            const float* wj = p.w0 + j * FC;
-            float pre = p.b0[j];
-#pragma unroll
-            for (int c = 0; c < FC; ++c) pre = fmaf(wj[c], f[c], pre);
-            const float* vj = p.w1 + j * (1 + CO);
-            float dh = 0.f;
-#pragma unroll
-            for (int k = 0; k < 1 + CO; ++k) dh = fmaf(vj[k], dout[k], dh);
-            float dpre = dh * (pre > 20.f ? 1.f : sigmoidf_(pre));
-            if (bp.dump_dpre) bp.dump_dpre[sample_id * HD + j] = dpre;          // [S, 64]
-            if (bp.dump_h) bp.dump_h[sample_id * HD + j] = softplusf_(pre);     // [S, 64]
-#pragma unroll
-            for (int c = 0; c < FC; ++c) df[c] = fmaf(wj[c], dpre, df[c]);
-        }
-#pragma unroll
-        for (int c = 0; c < FC; ++c) df[c] = df[c] / 3.f;          // mean over the three planes
-        if (bp.df_rows) {
-            float4* o = reinterpret_cast<float4*>(bp.df_rows + sample_id * FC);
-#pragma unroll
-            for (int c4 = 0; c4 < FC / 4; ++c4) o[c4] = make_float4(df[c4 * 4], df[c4 * 4 + 1], df[c4 * 4 + 2], df[c4 * 4 + 3]);
-            *reinterpret_cast<float4*>(bp.df_pos + sample_id * 4) = make_float4(px, py, pz, 0.f);
-        }
-        if (want_coord) {
-            float gx = 0.f, gy = 0.f, gz = 0.f;
-#pragma unroll 1
-            for (int pl = 0; pl < 3; ++pl) {
-                float u, v;
-                plane_uv(pl, px * cs, py * cs, pz * cs, u, v);
-                float ix = ((u + 1.f) * p.Wp - 1.f) * 0.5f, iy = ((v + 1.f) * p.Hp - 1.f) * 0.5f;
-                float fx0 = floorf(ix), fy0 = floorf(iy);
-                int x0 = (int)fx0, y0 = (int)fy0;
-                float wx1 = ix - fx0, wx0 = (fx0 + 1.f) - ix, wy1 = iy - fy0, wy0 = (fy0 + 1.f) - iy;
-                float gix = 0.f, giy = 0.f;
-#pragma unroll 1
-                for (int q = 0; q < 4; ++q) {
-                    int xx = x0 + (q & 1), yy = y0 + (q >> 1);
-                    if ((unsigned)xx < (unsigned)p.Wp && (unsigned)yy < (unsigned)p.Hp) {
-                        const float4* t = reinterpret_cast<const float4*>(pn + ((int64_t)yy * p.Wp + xx) * p.ldp + pl * FC);
-                        float dot = 0.f;
-#pragma unroll
-                        for (int c4 = 0; c4 < FC / 4; ++c4) {
-                            float4 tv = t[c4];
-                            dot = fmaf(tv.x, df[c4 * 4 + 0], dot); dot = fmaf(tv.y, df[c4 * 4 + 1], dot);
-                            dot = fmaf(tv.z, df[c4 * 4 + 2], dot); dot = fmaf(tv.w, df[c4 * 4 + 3], dot);
-                        }
-                        // d(weight)/d(ix), d(weight)/d(iy) of corner q
-                        float sx = (q & 1) ? 1.f : -1.f, sy = (q >> 1) ? 1.f : -1.f;
-                        gix += dot * sx * ((q >> 1) ? wy1 : wy0);
-                        giy += dot * sy * ((q & 1) ? wx1 : wx0);
-                    }
-                }
-                float gu = gix * (0.5f * p.Wp) * cs, gv = giy * (0.5f * p.Hp) * cs;
-                if (pl == 0) { gx += gu; gy += gv; } else if (pl == 1) { gx += gu; gz += gv; } else { gz += gu; gx += gv; }
-            }
-            reinterpret_cast<float4*>(bp.gc_rows)[sample_id] = make_float4(gx, gy, gz, depth);
-        }
-    }
-}
-
 // d_origins[ray] = sum_rows g;  d_dirs[ray] = sum_rows depth * g
 __global__ void __launch_bounds__(256) render_coord_reduce_kernel(const float4* __restrict__ gc, float* __restrict__ d_o, float* __restrict__ d_d,
                                                                   int64_t nrays, int rows_per_ray) {
@@ -907,21 +761,6 @@ __global__ void __launch_bounds__(256) ray_gen_bwd_kernel(const float* __restric
     }
 }
 
-// run_model on arbitrary points
-__global__ void __launch_bounds__(256) sample_decode_kernel(const eg3d_render_params p, const float* __restrict__ coords, int64_t M,
-                                                            float* __restrict__ rgb, float* __restrict__ sigma) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)p.N * M) return;
-    const int n = (int)(i / M);
-    const float* pn = p.planes + (int64_t)n * p.Hp * p.Wp * p.ldp;
-    float f[FC], out[1 + CO];
-    gather_feats(pn, p.Hp, p.Wp, p.ldp, 2.f / p.box_warp, coords[i * 3], coords[i * 3 + 1], coords[i * 3 + 2], f);
-    mlp_fwd(p.w0, p.b0, p.w1, p.b1, f, out);
-    sigma[i] = out[0];
-#pragma unroll
-    for (int k = 0; k < CO; ++k) rgb[i * CO + k] = sigmoidf_(out[1 + k]) * 1.002f - 0.001f;
-}
-
 int check_render(const eg3d_render_params& p) {
     if (!p.planes || !p.origins || !p.dirs || !p.u1 || !p.w0 || !p.b0 || !p.w1 || !p.b1) return EG3D_ERR_INVALID;
     if (p.N <= 0 || p.R <= 0 || p.Hp <= 0 || p.Wp <= 0 || p.Dc < 2 || p.Df < 0) return EG3D_ERR_INVALID;
@@ -978,8 +817,7 @@ extern "C" int eg3d_render_bwd(const eg3d_render_bwd_params* bp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(render_kernel<true>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(p), st, *bp);
     const int64_t S = nrays * 2 * D;
-    if (getenv("EG3D_VALU_DECODE")) hipLaunchKernelGGL(render_sample_bwd_kernel, dim3(eg3d_cdiv(S, 256)), dim3(256), 0, st, *bp);
-    else { int rc2 = eg3d_decode_rows_bwd(*bp, bp->df_pos, 0, S, (int64_t)p.R * 2 * D, 2 * D, stream); if (rc2) return rc2; }
+    if (int rc2 = eg3d_decode_rows_bwd(*bp, bp->df_pos, 0, S, (int64_t)p.R * 2 * D, 2 * D, stream)) return rc2;
     if (bp->d_origins || bp->d_dirs)
         hipLaunchKernelGGL(render_coord_reduce_kernel, dim3(eg3d_cdiv(nrays, 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(bp->gc_rows),
                            bp->d_origins, bp->d_dirs, nrays, 2 * D);
@@ -1028,10 +866,7 @@ extern "C" int eg3d_sample_decode(const eg3d_render_params* pp, const float* coo
     if (!p.planes || !p.w0 || !p.b0 || !p.w1 || !p.b1 || p.N <= 0) return EG3D_ERR_INVALID;
     if (p.C != FC || p.Hdim != HD || p.Cout != CO || p.ldp < 3 * FC || (p.ldp & 3)) return EG3D_ERR_UNSUPPORTED;
     if (M == 0) return EG3D_OK;
-    if (!getenv("EG3D_VALU_DECODE")) return eg3d_decode_rows_fwd(p, coords, 3, (int64_t)p.N * M, M, sigma, rgb, stream);
-    hipLaunchKernelGGL(sample_decode_kernel, dim3(eg3d_cdiv((int64_t)p.N * M, 256)), dim3(256), 0, (hipStream_t)stream, p, coords, M, rgb, sigma);
-    EG3D_LAUNCH_CHECK();
-    return EG3D_OK;
+    return eg3d_decode_rows_fwd(p, coords, 3, (int64_t)p.N * M, M, sigma, rgb, stream);
 }
 
 extern "C" int eg3d_ray_gen_fwd(const float* cam2world, const float* intrinsics, float* origins, float* dirs, int N, int res, void* stream) {

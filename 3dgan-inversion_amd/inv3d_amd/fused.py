@@ -88,7 +88,7 @@ def _auto_ksplit(classes, N, Nc, Ck):
     128x128 tiles each workgroup walks a long K = taps x channels chain on its own and the launch is latency-bound (64^2 x 512
     channels: 91 TF unsplit, 148 TF split 4 ways).  Slices accumulate with fp32 atomics into a zeroed buffer."""
     blocks = sum((N * c.Ha * c.Wa + 127) // 128 for c in classes) * ((Nc + 127) // 128)
-    if blocks >= int(os.environ.get('EG3D_KS_BLOCKS', '200')):
+    if blocks >= 200:           # measured: splitting layers with 256 tiles (128^2 x 256 ch) costs more in zero-fill + finish passes than it gains
         return 1
     steps = ((Ck + 15) // 16) * min(c.ntaps for c in classes)
     return max(1, min(-(-512 // blocks), steps // 8))

@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0,'.'); sys.path.insert(0,'3dgan-inversion_amd')
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/3dgan-inversion_amd')
 from inv3d_amd import hipops as H, _lib as L
 dev='cuda'
 def timeit(f, iters=20):

@@ -1,5 +1,5 @@
 import sys, torch, time
-sys.path.insert(0,'.'); sys.path.insert(0,'3dgan-inversion_amd')
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/3dgan-inversion_amd')
 from inv3d_amd import synthetic as S
 from inv3d_amd.training.volumetric_rendering.renderer import ImportanceRenderer
 from inv3d_amd.training.volumetric_rendering.ray_sampler import RaySampler
