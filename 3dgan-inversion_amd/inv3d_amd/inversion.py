@@ -112,7 +112,7 @@ def warping_loss(G, ws, canonical_cam, extrinsic, init_ext, intrinsic, depth, ta
     with torch.no_grad():
         can = G.synthesis(ws.detach(), canonical_cam.detach(), noise_mode='const', force_fp32=True, **synth_kwargs)['image']
         if can.shape[2] > 256:
-            can = F.interpolate(can, size=(256, 256), mode='area')
+            can = _area_resize(can, 256)
         can_feat = feat_fn(can)
     mask = (depth < depth.mean()).float()
     res = depth.shape[-1]
@@ -132,6 +132,15 @@ def warping_loss(G, ws, canonical_cam, extrinsic, init_ext, intrinsic, depth, ta
     warped = F.grid_sample(can_feat, uv_f, mode='bilinear', align_corners=False)
     m = F.interpolate(mask, size=(fr, fr), mode='bilinear')
     return ((warped - target_feat) * m).abs().mean()
+
+
+def _area_resize(img: torch.Tensor, size: int) -> torch.Tensor:
+    """F.interpolate(img, size=(size, size), mode='area') (w_projector.py:106-110,198-200).  For an integer factor that is a plain
+    k x k average: avg_pool2d runs in ~5 us forward/backward where the generic adaptive-pool kernels take 65 + 42 us at 512^2."""
+    h, w = img.shape[-2:]
+    if h % size == 0 and w % size == 0 and h // size == w // size:
+        return F.avg_pool2d(img, h // size)
+    return F.interpolate(img, size=(size, size), mode='area')
 
 
 class LatentProjector:
@@ -164,7 +173,7 @@ class LatentProjector:
         self.target = target
         t255 = (target + 1) * (255 / 2)
         if t255.shape[2] > 256:
-            t255 = F.interpolate(t255, size=(256, 256), mode='area')
+            t255 = _area_resize(t255, 256)
         with torch.no_grad():
             self.target_features = self.feature_net(t255)
             self.target_warp_feat = self.warp_net(target) if use_warping_loss else None
@@ -300,7 +309,7 @@ class LatentProjector:
         out = G.synthesis(ws, pred_cam, noise_mode='const', force_fp32=True, **kw)
         img = out['image'] * 127.5 + 128
         if img.shape[2] > 256:
-            img = F.interpolate(img, size=(256, 256), mode='area')
+            img = _area_resize(img, 256)
         dist = (self.target_features - self.feature_net(img)).square().sum()
         cur.wait_stream(self._reg_stream)
         loss = dist + reg
@@ -336,7 +345,7 @@ class PivotalTuner:
         self.G = G
         G.requires_grad_(True)
         self.target = target
-        self.target_128 = F.interpolate(target, size=(G.neural_rendering_resolution,) * 2, mode='area')
+        self.target_128 = _area_resize(target, G.neural_rendering_resolution)
         self.w_pivot, self.cam = w_pivot.detach(), cam.detach()
         self.l2_lambda, self.lpips_lambda, self.thr = l2_lambda, lpips_lambda, lpips_threshold
         self.feature_net = feature_net if feature_net is not None else StubFeatureNet().to(target.device)
