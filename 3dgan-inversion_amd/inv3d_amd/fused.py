@@ -407,14 +407,14 @@ class RenderFn(torch.autograd.Function):
         if any(need[3:7]):
             D = max(p.Dc, p.Df)
             S = N * R * 2 * D
-            dumps = [torch.zeros((S, 64), device=dev), torch.zeros((S, 64), device=dev), torch.zeros((S, 33), device=dev),
-                     torch.zeros((S, 32), device=dev)]
+            # with equal coarse / fine counts every row is a live sample and is written by the sample-level kernel
+            mk = torch.empty if p.Dc == p.Df else torch.zeros
+            dumps = [mk((S, 64), device=dev), mk((S, 64), device=dev), mk((S, 33), device=dev), mk((S, 32), device=dev)]
         H.render_bwd(p, g_rgb, g_depth, g_wsum, d_planes, d_o, d_d, dumps)
         dw0 = db0 = dw1 = db1 = None
         if dumps is not None:
             dpre, hid, dout, feat = dumps
-            dw0 = (dpre.t() @ feat) * g0
-            db0 = dpre.sum(0) * lr_mul
-            dw1 = (dout.t() @ hid) * g1
-            db1 = dout.sum(0) * lr_mul
+            dw0, db0 = H.rows_gram(dpre, feat)          # [64,32] = dpre^T feat and its column sums over 1.57 M samples
+            dw1, db1 = H.rows_gram(dout, hid)           # [33,64]
+            dw0, db0, dw1, db1 = dw0 * g0, db0 * lr_mul, dw1 * g1, db1 * lr_mul
         return (d_planes, d_o if need[1] else None, d_d if need[2] else None, dw0, db0, dw1, db1, None, None, None, None, None)

@@ -290,6 +290,15 @@ def dgrad_finish(z, x, s, dx, ds=None, addend=None):
     return dx
 
 
+def rows_gram(a, b):
+    """(a^T b [Ka,Kb], column sums of a [Ka]) for row matrices a [S,Ka], b [S,Kb] with Ka, Kb <= 64 (eg3d_rows_gram)."""
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0] and a.is_contiguous() and b.is_contiguous()
+    z = torch.zeros(a.shape[1] * b.shape[1] + a.shape[1], dtype=torch.float32, device=a.device)
+    out, cs = z[:a.shape[1] * b.shape[1]].view(a.shape[1], b.shape[1]), z[a.shape[1] * b.shape[1]:]
+    L.check(L.lib().eg3d_rows_gram(L.ptr(a), L.ptr(b), a.shape[0], a.shape[1], b.shape[1], L.ptr(out), L.ptr(cs), L.stream_ptr()), 'rows_gram')
+    return out, cs
+
+
 def style_affine(ws, layers, outs=None, douts=None, dws=None):
     """eg3d_style_affine_fwd (outs given) / _bwd (douts + dws given).  ws: [N,L,D] contiguous fp32;
     layers: sequence of (weight [C,D], bias [C] | None, wrow, wgain, bgain, post)."""

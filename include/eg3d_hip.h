@@ -155,6 +155,12 @@ typedef struct eg3d_wgrad_params {
 int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Tall-skinny Gram product for the decoder-weight gradients of pivotal tuning (training/triplane.py:116-136 under
+ * base_coach.py:96-99):  out[i][j] += sum_s a[s][i]*b[s][j]  (Ka, Kb <= 64, row-major a [S,Ka], b [S,Kb]),
+ * colsum[i] += sum_s a[s][i] (or null).  out / colsum must be pre-zeroed (accumulated with atomics).  Exact fp32 MFMA. */
+int eg3d_rows_gram(const float* a, const float* b, int64_t S, int Ka, int Kb, float* out, float* colsum, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * filtered_lrelu -- replaces filtered_lrelu_plugin.filtered_lrelu / filtered_lrelu_act_ (torch_utils/ops/filtered_lrelu.cpp:20,217;
  * Python wrapper filtered_lrelu.py:161-274; slow reference :123-155).  Contiguous NCHW, fp32 or fp16 (float accumulation).
  *   t = gain1 * FIR_fu( zero_insert_up(x + b[c]) padded by (px0,px1,py0,py1) )                 size Hm x Wm

@@ -479,6 +479,19 @@ def test_run_model_vs_oracle():
 
 
 # ------------------------------------------------------------------------------------------------- noise buffers
+@pytest.mark.parametrize('shape', [(100003, 64, 32), (4097, 33, 64), (17, 5, 7), (2, 64, 64)])
+def test_rows_gram(shape):
+    """a^T b and column sums of tall-skinny row matrices (decoder-weight gradients of pivotal tuning) vs fp64."""
+    from inv3d_amd import hipops as H
+    s, ka, kb = shape
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.randn(s, ka, generator=g), torch.randn(s, kb, generator=g)
+    out, cs = H.rows_gram(a.to(DEV), b.to(DEV))
+    ref, refs = a.double().t() @ b.double(), a.double().sum(0)
+    close(out, ref, 2e-6 * math.sqrt(s), f'rows_gram {shape}')
+    close(cs, refs, 2e-6 * math.sqrt(s), f'rows_gram colsum {shape}')
+
+
 def test_noise_regularizer_and_normalize():
     from inv3d_amd import hipops as H
     from inv3d_amd.inversion import noise_regularizer
