@@ -45,44 +45,54 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const eg3d_wgrad_params
     const int s_end = (int)((int64_t)(blockIdx.z + 1) * nsteps_total / p.psplit);
     if (s_begin >= s_end) return;
 
-    // loader mapping: 32 rows x 32 float4 columns = 1024 float4 per tile, 4 per thread
+    // ---- loaders: branch-free raw buffer loads (as in conv_igemm.hip) -------------------------------------------------------
+    // 32 cells x 32 float4 columns per operand and step = 4 + 4 sixteen-byte loads per thread.  A cell outside the range, a tap
+    // outside the image or a channel past the end is redirected to an out-of-range buffer offset, which the hardware returns as
+    // zeros: no divergent control flow, so the loads and the index arithmetic can be woven between the MFMAs.
     const int lcol = tid & 31, lrow0 = tid >> 5;          // rows lrow0 + 8*j
-    float4 rg[4], rx[4];
+    constexpr unsigned OOB = 0x7ffffff0u;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((int64_t)p.N * p.Hi * p.Wi * p.ldx * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, (int)((int64_t)p.N * p.Ho * p.Wo * p.ldg * 4), 0x00020000);
+    const bool ocok = o0 + lcol * 4 < p.Nc, kcok = k0 + lcol * 4 < p.Ck;
+    struct Regs { float4 rg[4], rx[4]; };
+    Regs R0, R1;
+    float4 sv = make_float4(1.f, 1.f, 1.f, 1.f);
+    int sv_n = -1;
 
-    auto load = [&](int step) {
+    auto load = [&](Regs& R, int step) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = step * BC + lrow0 + 8 * j;
-            float4 gv = make_float4(0, 0, 0, 0), xv = make_float4(0, 0, 0, 0);
-            if (m < Mc) {
-                const int n = m / HWa;
-                const int rem = m - n * HWa;
-                const int ay = rem / Wa, ax = rem - ay * Wa;
-                const int oc = o0 + lcol * 4;
-                if (oc < p.Nc) {
-                    const int64_t gp = ((int64_t)(n * p.Ho + ay * p.out_stride + cl.out_py) * p.Wo + ax * p.out_stride + cl.out_px) * p.ldg + oc;
-                    gv = *reinterpret_cast<const float4*>(p.g + gp);
-                }
-                const int iy = ay * p.in_stride + dy, ix = ax * p.in_stride + dx;
-                const int kc = k0 + lcol * 4;
-                if (kc < p.Ck && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) {
-                    xv = *reinterpret_cast<const float4*>(p.x + ((int64_t)(n * p.Hi + iy) * p.Wi + ix) * p.ldx + kc);
-                    if (p.in_scale != nullptr) {
-                        float4 sv = *reinterpret_cast<const float4*>(p.in_scale + (int64_t)n * p.Ck + kc);
-                        xv.x *= sv.x; xv.y *= sv.y; xv.z *= sv.z; xv.w *= sv.w;
-                    }
-                }
+            const bool ok = m < Mc;
+            const int mm = ok ? m : 0;
+            const int n = mm / HWa;
+            const int rem = mm - n * HWa;
+            const int ay = rem / Wa, ax = rem - ay * Wa;
+            const unsigned goff = (unsigned)((((int64_t)(n * p.Ho + ay * p.out_stride + cl.out_py) * p.Wo + ax * p.out_stride + cl.out_px) * p.ldg + o0 + lcol * 4) * 4);
+            const int iy = ay * p.in_stride + dy, ix = ax * p.in_stride + dx;
+            const bool xin = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const unsigned xoff = (unsigned)((((int64_t)(n * p.Hi + iy) * p.Wi + ix) * p.ldx + k0 + lcol * 4) * 4);
+            auto gv = __builtin_amdgcn_raw_buffer_load_b128(grs, (ok && ocok) ? goff : OOB, 0, 0);
+            auto xv = __builtin_amdgcn_raw_buffer_load_b128(xrs, (ok && kcok && xin) ? xoff : OOB, 0, 0);
+            __builtin_memcpy(&R.rg[j], &gv, 16);
+            __builtin_memcpy(&R.rx[j], &xv, 16);
+            if (p.in_scale != nullptr && p.N > 1 && ok) {      // batch > 1: the style row follows the cell's sample
+                const float4 s4 = kcok ? *reinterpret_cast<const float4*>(p.in_scale + (int64_t)n * p.Ck + k0 + lcol * 4) : make_float4(0, 0, 0, 0);
+                R.rx[j].x *= s4.x; R.rx[j].y *= s4.y; R.rx[j].z *= s4.z; R.rx[j].w *= s4.w;
             }
-            rg[j] = gv; rx[j] = xv;
         }
     };
-    auto store = [&](int buf) {
+    if (p.in_scale != nullptr && p.N == 1 && kcok) sv = *reinterpret_cast<const float4*>(p.in_scale + k0 + lcol * 4);
+    (void)sv_n;
+    auto store = [&](Regs& R, int buf) {
         float* g = Gs + buf * BC * LDO;
         float* x = Xs + buf * BC * LDI;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            *reinterpret_cast<float4*>(g + (lrow0 + 8 * j) * LDO + lcol * 4) = rg[j];
-            *reinterpret_cast<float4*>(x + (lrow0 + 8 * j) * LDI + lcol * 4) = rx[j];
+            *reinterpret_cast<float4*>(g + (lrow0 + 8 * j) * LDO + lcol * 4) = R.rg[j];
+            float4 v = R.rx[j];
+            if (p.N == 1) { v.x *= sv.x; v.y *= sv.y; v.z *= sv.z; v.w *= sv.w; }
+            *reinterpret_cast<float4*>(x + (lrow0 + 8 * j) * LDI + lcol * 4) = v;
         }
     };
 
@@ -94,14 +104,14 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const eg3d_wgrad_params
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load(s_begin);
-    store(0);
+    // two register sets: loads of steps s+2 / s+3 in flight while step s is multiplied and s+1 goes to LDS
+    load(R0, s_begin);
+    store(R0, 0);
+    if (s_begin + 1 < s_end) load(R1, s_begin + 1);
+    if (s_begin + 2 < s_end) load(R0, s_begin + 2);
     __syncthreads();
     const int l31 = lane & 31, kh = lane >> 5;
-    for (int step = s_begin; step < s_end; ++step) {
-        const int buf = (step - s_begin) & 1;
-        const bool more = step + 1 < s_end;
-        if (more) load(step + 1);
+    auto compute = [&](const int buf) {
         const float* g = Gs + buf * BC * LDO + wm * 64 + l31;
         const float* x = Xs + buf * BC * LDI + wn * 64 + l31;
 #pragma unroll
@@ -114,7 +124,34 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const eg3d_wgrad_params
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (more) store(buf ^ 1);
+    };
+    // the steady-state step is one straight-line block: weave LDS reads, index arithmetic, global loads and LDS writes between MFMAs
+    auto weave = [&]() {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read (64 per step)
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // a slice of the loader arithmetic
+            if ((i & 7) == 7) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // 8 global loads per step
+            if ((i & 7) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // 8 LDS writes per step
+        }
+    };
+    int step = s_begin;
+    for (; step + 4 < s_end; step += 2) {
+        compute(0); store(R1, 1); load(R1, step + 3); weave();
+        __syncthreads();
+        compute(1); store(R0, 0); load(R0, step + 4); weave();
+        __syncthreads();
+    }
+    for (; step < s_end; step += 2) {
+        compute(0);
+        if (step + 1 < s_end) store(R1, 1);
+        if (step + 3 < s_end) load(R1, step + 3);
+        __syncthreads();
+        if (step + 1 >= s_end) break;
+        compute(1);
+        if (step + 2 < s_end) store(R0, 0);
+        if (step + 4 < s_end) load(R0, step + 4);
         __syncthreads();
     }
 
@@ -140,6 +177,7 @@ extern "C" int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* pp, void* stream) 
     if (!p.x || !p.g || !p.dw) return EG3D_ERR_INVALID;
     if (p.N <= 0 || p.Hi <= 0 || p.Wi <= 0 || p.Ck <= 0 || p.Nc <= 0 || p.Ho <= 0 || p.Wo <= 0) return EG3D_ERR_INVALID;
     if (p.ncls < 1 || p.ncls > 4 || p.in_stride < 1 || p.out_stride < 1) return EG3D_ERR_INVALID;
+    if ((int64_t)p.N * p.Hi * p.Wi * p.ldx * 4 > 0x7fffffe0ll || (int64_t)p.N * p.Ho * p.Wo * p.ldg * 4 > 0x7fffffe0ll) return EG3D_ERR_TOO_LARGE;   // 31-bit buffer offsets
     if ((p.Ck & 3) || (p.ldx & 3) || (p.ldg & 3) || p.ldg < ((p.Nc + 3) & ~3)) return EG3D_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(p.x) & 15) || (reinterpret_cast<uintptr_t>(p.g) & 15)) return EG3D_ERR_UNSUPPORTED;
     int ntap_total = 0;
@@ -151,10 +189,10 @@ extern "C" int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* pp, void* stream) 
         maxM = std::max<int64_t>(maxM, (int64_t)p.N * k.Ha * k.Wa);
     }
     const int tiles_o = eg3d_cdiv(p.Nc, BO), tiles_i = eg3d_cdiv(p.Ck, BI);
-    if (p.psplit <= 0) {      // auto: aim for >= ~1024 blocks, at least 8 K-steps per block
+    if (p.psplit <= 0) {      // auto: aim for >= ~2048 blocks (measured: 128ch@512^2 81 TF at 1026 blocks, 95 at 1152, flat beyond), at least 8 K-steps per block
         int64_t base = (int64_t)tiles_o * tiles_i * ntap_total;
         int64_t steps = (maxM + BC - 1) / BC;
-        int64_t want = (1024 + base - 1) / base;
+        int64_t want = (2048 + base - 1) / base;
         p.psplit = (int)std::max<int64_t>(1, std::min<int64_t>(want, std::max<int64_t>(1, steps / 8)));
     }
     static bool attr_done = false;
