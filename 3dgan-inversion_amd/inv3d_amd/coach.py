@@ -1,0 +1,118 @@
+"""Per-image inversion driver: the caller of the hot path.
+
+Counterpart of the reference's image loop (training/coaches/single_id_coach.py:27-84 on top of base_coach.py:52-99 and
+training/projectors/w_projector.py:55-283), reduced to what touches the generator:
+
+    for every image of this rank's shard:
+        restore the pristine generator                        (restart_training: a fresh G per image, base_coach.py:52-61)
+        Phase A  first_inv_steps of LatentProjector.step()    -> pivot latent (+ optimised camera)
+        restore the generator's noise buffers                 (the reference projects on a deep copy of G, w_projector.py:68)
+        Phase B  <= max_pti_steps of PivotalTuner.step(), early stop on the perceptual threshold (single_id_coach.py:69)
+        metrics: MSE / PSNR of the pivot and of the tuned reconstruction
+    one packed-stat all-reduce over the ranks at the end     (inv3d_amd.dist)
+
+Images are independent optimisations, so N GPUs = N shards with no data-path communication (weak scaling).  File I/O, logging,
+video / mesh export and the third-party encoders (e4e, ResNet pose head, ArcFace) of the reference loop are outside this package.
+"""
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import dist as D
+from .inversion import LatentProjector, PivotalTuner, psnr_01
+
+
+@dataclass
+class InversionResult:
+    name: str
+    w_pivot: torch.Tensor                 # [1, num_ws, w_dim]
+    cam: torch.Tensor                     # [1, 25]
+    psnr_pivot: float
+    psnr_tuned: float
+    mse_tuned: float
+    steps_a: int
+    steps_b: int
+    tuned_state: Optional[Dict[str, torch.Tensor]] = field(default=None, repr=False)    # generator weights after Phase B (opt-in)
+
+
+class InversionCoach:
+    def __init__(self, G, *, first_inv_steps: int = 400, max_pti_steps: int = 400, lpips_threshold: float = 0.06, first_inv_lr: float = 8e-3,
+                 pti_lr: float = 3e-4, optimize_pose: bool = False, use_warping_loss: bool = False, wplus: bool = False,
+                 feature_net: Optional[Callable] = None, early_stop_interval: int = 1, use_graph: bool = False, keep_tuned_state: bool = False,
+                 synth_kwargs: Optional[dict] = None, seed: int = 0):
+        """Hyper-parameter names and defaults follow configs/hyperparameters.py.  `early_stop_interval` = how often Phase B reads the
+        perceptual loss back to the host for the early-stop test (1 = every step like the reference; larger values keep the host from
+        stalling the GPU queue every step)."""
+        self.G = G
+        self.first_inv_steps, self.max_pti_steps, self.thr = first_inv_steps, max_pti_steps, lpips_threshold
+        self.first_inv_lr, self.pti_lr = first_inv_lr, pti_lr
+        self.optimize_pose, self.use_warp, self.wplus = optimize_pose, use_warping_loss, wplus
+        self.feature_net, self.interval, self.use_graph, self.keep = feature_net, max(1, early_stop_interval), use_graph, keep_tuned_state
+        self.synth_kwargs, self.seed = dict(synth_kwargs or {}), seed
+        # pristine copy of every parameter and buffer: what "re-loading the generator" means without a pickle on disk
+        self._pristine = {k: v.detach().clone() for k, v in G.state_dict().items()}
+
+    def restore_generator(self, only_buffers: bool = False):
+        with torch.no_grad():
+            bufs = {k for k, _ in self.G.named_buffers()}
+            for k, v in self.G.state_dict().items():
+                if only_buffers and k not in bufs:
+                    continue
+                v.copy_(self._pristine[k])
+        for b in self.G.buffers():
+            b.requires_grad = False
+            b.grad = None
+
+    def invert(self, name: str, target: torch.Tensor, cam: Optional[torch.Tensor] = None) -> InversionResult:
+        G = self.G
+        self.restore_generator()
+        # ---- Phase A: latent (+ pose) with frozen weights ----------------------------------------------------------------------
+        G.requires_grad_(False)
+        proj = LatentProjector(G, target, num_steps=self.first_inv_steps, cam=cam, optimize_pose=self.optimize_pose,
+                               use_warping_loss=self.use_warp, first_inv_lr=self.first_inv_lr, wplus=self.wplus,
+                               feature_net=self.feature_net, synth_kwargs=self.synth_kwargs, seed=self.seed,
+                               use_graph=self.use_graph and not self.optimize_pose)
+        out = {}
+        for _ in range(self.first_inv_steps):
+            out = proj.step()
+        w = proj.w_opt.detach()
+        w_pivot = (w.repeat(1, G.backbone.num_ws, 1) if w.shape[1] == 1 else w).clone()
+        cam_pivot = out['cam'].detach().clone() if out else proj.cam.detach().clone()
+        self.restore_generator(only_buffers=True)
+        with torch.no_grad():
+            img = G.synthesis(w_pivot, cam_pivot, noise_mode='const', force_fp32=True, **self.synth_kwargs)['image']
+            psnr_pivot = float(psnr_01(img, target))
+        # ---- Phase B: generator weights around the pivot ------------------------------------------------------------------------
+        tuner = PivotalTuner(G, target, w_pivot, cam_pivot, lr=self.pti_lr, lpips_threshold=self.thr, feature_net=self.feature_net,
+                             synth_kwargs=self.synth_kwargs)
+        steps_b = 0
+        for i in range(self.max_pti_steps):
+            check = (i % self.interval) == self.interval - 1
+            res = tuner.step(early_stop=check)
+            steps_b += 1
+            if check and res.get('done'):
+                break
+        with torch.no_grad():
+            img = G.synthesis(w_pivot, cam_pivot, noise_mode='const', force_fp32=True, **self.synth_kwargs)['image']
+            psnr_tuned = float(psnr_01(img, target))
+            mse = float(((img.clamp(-1, 1) - target) ** 2).mean() / 4.0)
+        state = {k: v.detach().clone() for k, v in G.state_dict().items()} if self.keep else None
+        G.requires_grad_(False)
+        return InversionResult(name, w_pivot, cam_pivot, psnr_pivot, psnr_tuned, mse, self.first_inv_steps, steps_b, state)
+
+    def run(self, images: Sequence[Tuple[str, torch.Tensor, Optional[torch.Tensor]]]) -> Tuple[List[InversionResult], Dict[str, float]]:
+        """Invert this rank's shard of `images` = [(name, target [1,3,H,W] in [-1,1], cam [1,25] | None), ...] (every rank passes the
+        same full list).  Returns (results of this rank, stats summed / maxed over all ranks)."""
+        rank, world, _ = D.init_from_env()
+        results = []
+        for i in D.shard_images(len(images), rank, world):
+            name, target, cam = images[i]
+            results.append(self.invert(name, target, cam))
+        dev = images[0][1].device if len(images) else torch.device('cpu')
+        stats = D.allreduce_stats(dict(psnr=sum(r.psnr_tuned for r in results), mse=sum(r.mse_tuned for r in results),
+                                       n_done=float(len(results)), steps=float(sum(r.steps_a + r.steps_b for r in results))), dev)
+        if stats['n_done'] > 0:
+            stats['mean_psnr'] = stats['psnr'] / stats['n_done']
+        self.restore_generator()
+        return results, stats

@@ -299,6 +299,9 @@ class LatentProjector:
         cur = torch.cuda.current_stream()
         if self._reg_stream is None:
             self._reg_stream = torch.cuda.Stream(device=self.dev)
+            _quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+            if _quiet is not None:      # the noise buffers' gradients are accumulated from two streams on purpose
+                _quiet(False)
         self._reg_stream.wait_stream(cur)
         with torch.cuda.stream(self._reg_stream):
             reg = noise_regularizer(self._all_bufs, self.reg_w)           # already weighted

@@ -126,3 +126,31 @@ def test_pivotal_tuning_c4():
     sd = G.state_dict()
     worst = max(float((sd[k].cpu() - v.detach()).abs().max()) for k, v in ref.P.items() if v.requires_grad)
     assert worst < 5e-3, worst
+
+
+def test_coach_phase_a_then_b_per_image():
+    """InversionCoach (the image loop of single_id_coach.py): per image a pristine generator, Phase A then Phase B, metrics; the
+    generator is restored between images and at the end, and tuning improves on the pivot."""
+    from inv3d_amd.coach import InversionCoach
+    cfg, P, G, cam, u1, u2, target, init_noise = _setup()
+    pristine = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    tgt = target.to(DEV)
+    with torch.no_grad():
+        target2 = G.synthesis(O.synth_ws(cfg, 1, seed=7).to(DEV), cam.to(DEV), noise_mode='const', force_fp32=True)['image'].clamp(-1, 1)
+    coach = InversionCoach(G, first_inv_steps=6, max_pti_steps=5, lpips_threshold=0.0, early_stop_interval=2, seed=3)
+    seen = []
+    orig_invert = coach.invert
+
+    def spy(name, t, c=None):
+        coach.restore_generator()
+        seen.append(all(torch.equal(v, pristine[k]) for k, v in G.state_dict().items()))
+        return orig_invert(name, t, c)
+    coach.invert = spy
+    results, stats = coach.run([('a', tgt, cam.to(DEV)), ('b', target2, cam.to(DEV))])
+    assert [r.name for r in results] == ['a', 'b'] and all(seen)
+    for r in results:
+        assert r.steps_a == 6 and r.steps_b == 5 and r.w_pivot.shape == (1, cfg.num_ws, cfg.w_dim)
+        assert r.psnr_tuned > r.psnr_pivot, (r.psnr_pivot, r.psnr_tuned)        # 5 tuning steps already lower the reconstruction error
+    assert stats['n_done'] == 2.0 and stats['steps'] == 22.0 and abs(stats['mean_psnr'] - sum(r.psnr_tuned for r in results) / 2) < 1e-4
+    assert all(torch.equal(v, pristine[k]) for k, v in G.state_dict().items())           # restored at the end
+    assert not any(p.requires_grad for p in G.parameters())
