@@ -63,7 +63,7 @@ __host__ __device__ constexpr int conv_min_waves(int bm, int bn, int waves, int 
     return waves != 4 ? 1 : (prec ? (per_thread <= 4 ? 3 : 2) : (per_thread <= 8 ? 2 : 1));
 }
 
-template <int BM, int BN, int WM, int WN, int PREC>
+template <int BM, int BN, int WM, int WN, int PREC, bool VEC>
 __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, PREC)) conv_igemm_kernel(const eg3d_conv_params p) {
     constexpr int NT = WM * WN * 64;                        // 4 or 8 waves
     constexpr int NP = PREC == 1 ? 3 : 2;                   // bf16 pieces per operand (split paths)
@@ -350,6 +350,86 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
     const float strength = (epi == EG3D_EPI_FWD && p.noise != nullptr) ? *p.noise_strength : 0.f;
     const int HWo = p.Ho * p.Wo;
 
+    // ---- vector epilogue: the tile goes through LDS once so that global traffic is 16 bytes per lane and row-contiguous ----------
+    // (the accumulator layout gives every lane one float of 16 different rows; written directly that is 64 four-byte accesses per
+    //  thread for the output and again for every side input).  Wave-rows are staged 32 rows at a time: WM x 32 x (BN+4) floats.
+    // VEC kernels are launched only when conv_vector_epilogue_ok() holds (host side): no split-K atomics, tiles within one image,
+    // 16-byte aligned rows and channel counts that are multiples of 4.
+    if constexpr (VEC) {
+        constexpr int LDS_N = BN + 4;
+        constexpr int UPR = BN / 4;                         // float4 units per row
+        constexpr int UNITS = WM * 32 * UPR;
+        constexpr int UPT = UNITS / NT;                     // units per thread and pass
+        static_assert(UNITS % NT == 0 && NT % UPR == 0, "epilogue mapping");
+        float* stage = smem + BN;                           // after the ds_lds row
+        const int c4 = tid % UPR;                           // this thread's column group is the same in every unit it handles
+        const int col = n0 + c4 * 4;
+        const bool cok = col < p.Nc;
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), scl4 = make_float4(1.f, 1.f, 1.f, 1.f), dsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cok && epi == EG3D_EPI_FWD && p.bias != nullptr) bias4 = *reinterpret_cast<const float4*>(p.bias + col);
+        if (cok && (epi == EG3D_EPI_FWD || epi == EG3D_EPI_BWD) && p.out_scale != nullptr)
+            scl4 = *reinterpret_cast<const float4*>(p.out_scale + (int64_t)n_first * p.Nc + col);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            __syncthreads();                                // previous pass fully consumed (and the main loop's LDS reads are done)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDS_N + wn * (TN * 32) + j * 32 + (lane & 31)] = acc[i][j][r];
+            __syncthreads();
+            constexpr int UG = UPT > 4 ? 4 : UPT;            // units in flight per thread (register budget)
+#pragma unroll
+            for (int ug = 0; ug < UPT; ug += UG) {
+            int offs[UG];
+            float4 va[UG], sa[UG], sb[UG];
+            float nz[UG];
+#pragma unroll
+            for (int uu = 0; uu < UG; ++uu) {               // phase 1: all loads
+                const int u = uu;
+                const int row = (tid + (ug + uu) * NT) / UPR;       // 0 .. WM*32-1  (wave-row = row / 32)
+                const int rl = (row >> 5) * (TM * 32) + i * 32 + (row & 31);
+                const int pix = rowpix[rl];
+                const bool ok = pix >= 0 && cok;
+                offs[u] = ok ? pix * p.ldo + col : -1;
+                va[u] = *reinterpret_cast<const float4*>(stage + row * LDS_N + c4 * 4);
+                sa[u] = make_float4(0.f, 0.f, 0.f, 0.f); sb[u] = sa[u]; nz[u] = 0.f;
+                if (ok && (epi == EG3D_EPI_FWD || epi == EG3D_EPI_BWD) && p.addend != nullptr) sa[u] = *reinterpret_cast<const float4*>(p.addend + offs[u]);
+                if (ok && epi == EG3D_EPI_FWD && p.noise != nullptr) nz[u] = p.noise[(int64_t)n_first * p.noise_nstride + (pix - n_first * HWo)];
+                if (ok && do_ds) sb[u] = *reinterpret_cast<const float4*>(p.xin + offs[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < UG; ++u) {                  // phase 2: arithmetic + stores
+                if (offs[u] < 0) continue;
+                float4 v = va[u];
+                if (epi == EG3D_EPI_FWD) {
+                    const float nzs = nz[u] * strength;
+                    float e[4] = {v.x * scl4.x + nzs + bias4.x, v.y * scl4.y + nzs + bias4.y, v.z * scl4.z + nzs + bias4.z, v.w * scl4.w + nzs + bias4.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        e[q] = eg3d_act_fwd<float>(e[q], p.act, p.alpha) * p.gain;
+                        if (p.clamp >= 0.f) e[q] = fminf(fmaxf(e[q], -p.clamp), p.clamp);
+                    }
+                    v = make_float4(e[0] + sa[u].x, e[1] + sa[u].y, e[2] + sa[u].z, e[3] + sa[u].w);
+                } else if (epi == EG3D_EPI_BWD) {
+                    if (do_ds) { dsum4.x += v.x * sb[u].x; dsum4.y += v.y * sb[u].y; dsum4.z += v.z * sb[u].z; dsum4.w += v.w * sb[u].w; }
+                    v = make_float4(v.x * scl4.x + sa[u].x, v.y * scl4.y + sa[u].y, v.z * scl4.z + sa[u].z, v.w * scl4.w + sa[u].w);
+                }
+                *reinterpret_cast<float4*>(p.out + offs[u]) = v;
+            }
+            }
+        }
+        if (do_ds) {                                        // block-level column sums, then one atomic per column
+            if (cok) {
+                atomicAdd(&ds_lds[c4 * 4 + 0], dsum4.x); atomicAdd(&ds_lds[c4 * 4 + 1], dsum4.y);
+                atomicAdd(&ds_lds[c4 * 4 + 2], dsum4.z); atomicAdd(&ds_lds[c4 * 4 + 3], dsum4.w);
+            }
+            __syncthreads();
+            if (tid < BN && n0 + tid < p.Nc) unsafeAtomicAdd(ds_out + (int64_t)n_first * p.Nc + n0 + tid, ds_lds[tid]);
+        }
+    } else {
+    // ---- scalar epilogue (split-K atomics, tiles spanning several images, unaligned or odd channel counts) -----------------------
+
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
@@ -420,15 +500,29 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
         __syncthreads();
         if (tid < BN && n0 + tid < p.Nc) unsafeAtomicAdd(ds_out + (int64_t)n_first * p.Nc + n0 + tid, ds_lds[tid]);
     }
+    }
 }
 
-template <int BM, int BN, int WM, int WN, int PREC>
-int launch_conv_p(const eg3d_conv_params& p, hipStream_t st) {
+// host-side test for the vector epilogue (see the kernel): everything the kernel would otherwise have to branch on
+template <int BM>
+bool conv_vector_epilogue_ok(const eg3d_conv_params& p) {
+    if (p.epi == EG3D_EPI_ATOMIC || (p.ldo & 3) || (p.Nc & 3)) return false;
+    const void* ptrs[] = {p.out, p.addend, p.xin, p.out_scale, p.bias};
+    for (const void* q : ptrs)
+        if (q != nullptr && (reinterpret_cast<uintptr_t>(q) & 15)) return false;
+    if (p.N > 1)                          // every tile must lie within one image (per-image scale / style-gradient rows)
+        for (int c = 0; c < p.ncls; ++c)
+            if ((p.cls[c].Ha * p.cls[c].Wa) % BM) return false;
+    return true;
+}
+
+template <int BM, int BN, int WM, int WN, int PREC, bool VEC>
+int launch_conv_pv(const eg3d_conv_params& p, hipStream_t st) {
     static bool attr_done = false;
     constexpr int NP = PREC == 1 ? 3 : 2;
     constexpr int KB = BM * BN >= 128 * 128 ? 16 : 32;
     const size_t smem = (PREC ? (size_t)2 * (split_tile_bytes(BM, NP, KB) + split_tile_bytes(BN, NP, KB)) : (size_t)(2 * (BM + BN) * LDK) * sizeof(float)) + 2 * BM * sizeof(int);
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, PREC>;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, PREC, VEC>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
@@ -445,6 +539,11 @@ int launch_conv_p(const eg3d_conv_params& p, hipStream_t st) {
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, st, p);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int PREC>
+int launch_conv_p(const eg3d_conv_params& p, hipStream_t st) {
+    return conv_vector_epilogue_ok<BM>(p) ? launch_conv_pv<BM, BN, WM, WN, PREC, true>(p, st) : launch_conv_pv<BM, BN, WM, WN, PREC, false>(p, st);
 }
 
 template <int BM, int BN, int WM, int WN>
