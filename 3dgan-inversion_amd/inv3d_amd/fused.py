@@ -60,6 +60,17 @@ class WeightCache:
             self._c = {'k': key, 'wf': wf, 'wa': wa, 'wsq': wsq}
         return self._c['wf'], self._c['wa'], self._c['wsq']
 
+    def forward_padded(self, w: torch.Tensor, cp: int):
+        """[cp, taps*Ci] forward image with zero rows appended (toRGB 3 -> 4 outputs: the padded output channel is 0 + skip, and
+        the launch takes the 16-byte vector epilogue)."""
+        wf, _, _ = self.get(w)
+        hit = self._c.get('wf_p')
+        if hit is None or hit.shape[0] != cp:
+            hit = torch.zeros((cp, wf.shape[1]), device=wf.device)
+            hit[:wf.shape[0]] = wf
+            self._c['wf_p'] = hit
+        return hit
+
     def adjoint_padded(self, w: torch.Tensor, cp: int):
         """[Ci, cp] adjoint image of a 1x1 weight with the contraction dim (output channels) zero-padded to cp (toRGB: 3 -> 4)."""
         _, wa, _ = self.get(w)
@@ -267,19 +278,21 @@ class ToRGBFn(torch.autograd.Function):
         wf, wa, _ = cache.get(weight)
         clampv = -1.0 if clamp is None else float(clamp)
         b = bias.contiguous().float() if bias is not None else None
+        if Cp != Co:              # compute all Cp channels: zero weight rows / bias give 0 (+ skip) in the padding channels
+            wf = cache.forward_padded(weight, Cp)
+            if b is not None:
+                b = torch.nn.functional.pad(b, (0, Cp - Co))
         cls = H.classes_corr(Hh, Ww, 1, 1, 0)
         y = None
         if skip is not None:
             skip = H.to_cl(skip.float())
             assert skip.shape[1] == Cp
         if clampv < 0 and skip is not None:
-            out = H.empty_cl(N, Cp, Hh, Ww, x.device) if Cp == Co else H.zeros_cl(N, Cp, Hh, Ww, x.device)
-            H.conv_igemm(x, wf, Ci, Co, out, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=-1.0, addend=skip)
-            if Cp != Co:
-                out[:, Co:] = skip[:, Co:]
+            out = H.empty_cl(N, Cp, Hh, Ww, x.device)
+            H.conv_igemm(x, wf, Ci, Cp, out, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=-1.0, addend=skip)
         else:
-            y = H.zeros_cl(N, Cp, Hh, Ww, x.device) if Cp != Co else H.empty_cl(N, Cp, Hh, Ww, x.device)
-            H.conv_igemm(x, wf, Ci, Co, y, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=clampv)
+            y = H.empty_cl(N, Cp, Hh, Ww, x.device)
+            H.conv_igemm(x, wf, Ci, Cp, y, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=clampv)
             out = y + skip if skip is not None else y
         ctx.save_for_backward(x, weight, styles, y if clampv >= 0 else None)
         ctx.cfg = (clampv, cache, want_wgrad, Cp, skip is not None)
