@@ -36,7 +36,7 @@ import torch  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide, dense bf16 (never the 2:1-sparsity figure)
 PRODUCTS = {'f32': 1, 'bf16x6': 6, 'bf16x3': 3}      # MFMA products executed per algorithmic fp32 product
-CONV_TRAFFIC_BYTES = 195.6e6       # HBM bytes per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/r01_bench_c2_summary.md
+CONV_TRAFFIC_BYTES = 196.4e6       # HBM bytes per launch of the dominant kernel (both epilogue instantiations, launch-weighted): rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/r01_bench_c2_summary.md
 DOMINANT = 0                        # tile configuration id of conv_igemm_kernel<128,128,2,2>
 
 
@@ -157,8 +157,8 @@ def main():
             ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
             nprod = PRODUCTS[prec_name]
             peak = FP32_MFMA_PEAK_TFLOPS if prec_name == 'f32' else BF16_MFMA_PEAK_TFLOPS / nprod
-            kern = ('conv_igemm_kernel<128,128,2,2,0> (v_mfma_f32_32x32x2_f32)' if prec_name == 'f32' else
-                    'conv_igemm_kernel<128,128,2,2,%d> (fp32 in/out, %d x v_mfma_f32_32x32x16_bf16 per fp32 product)' % (H.PRECISIONS[prec_name], nprod))
+            kern = ('conv_igemm_kernel<128,128,2,2,0,*> (v_mfma_f32_32x32x2_f32)' if prec_name == 'f32' else
+                    'conv_igemm_kernel<128,128,2,2,%d,*> (fp32 in/out, %d x v_mfma_f32_32x32x16_bf16 per fp32 product)' % (H.PRECISIONS[prec_name], nprod))
             roof = dict(bound='mfma', kernel=kern, achieved=round(ach, 2),
                         peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4), traffic=CONV_TRAFFIC_BYTES,
                         peak_basis=('fp32 matrix peak' if prec_name == 'f32' else 'dense bf16 matrix peak 2500 / %d products' % nprod),
