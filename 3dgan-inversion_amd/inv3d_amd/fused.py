@@ -86,7 +86,7 @@ def _zeros_views(device, *shapes):
     """Several small zero-initialised accumulators (targets of atomics) from ONE allocation and ONE fill launch.  A shape of
     None yields None.  Every view starts on a 16-byte boundary."""
     sizes = [0 if s is None else -(-int(torch.Size(s).numel()) // 4) * 4 for s in shapes]
-    flat = torch.zeros(max(sum(sizes), 1), dtype=torch.float32, device=device)
+    flat = H.zeros((max(sum(sizes), 1),), device)
     out, o = [], 0
     for s, n in zip(shapes, sizes):
         out.append(None if s is None else flat[o:o + torch.Size(s).numel()].view(s))
@@ -205,7 +205,7 @@ class ModConvLayerFn(torch.autograd.Function):
         dwsq = torch.zeros_like(wsq) if need_w else None
         if dd is not None and (need_s or need_w):
             if ds is None:
-                ds = torch.zeros((N, Ci), device=dev)
+                ds = H.zeros((N, Ci), dev)
             H.demod_bwd(styles, wsq, d, dd, ds=ds if need_s else None, dwsq=dwsq)
         dweight = None
         if need_w:
@@ -242,7 +242,7 @@ class StyleBankFn(torch.autograd.Function):
     def backward(ctx, *douts):
         dws = None
         if ctx.needs_input_grad[0]:
-            dws = torch.zeros_like(ctx.ws)
+            dws = H.zeros(ctx.ws.shape, ctx.ws.device)
             douts = [d.contiguous().float() if d is not None else None for d in douts]
             H.style_affine(ctx.ws, ctx.layers, douts=douts, dws=dws)
         return (dws, None) + (None,) * sum(2 if ly[1] is not None else 1 for ly in ctx.layers)
@@ -312,7 +312,7 @@ class ToRGBFn(torch.autograd.Function):
         dy = dout
         dbias = None
         if clampv >= 0 or need_b:
-            dbias_p = torch.zeros(Cp, device=dev) if need_b else None
+            dbias_p = H.zeros((Cp,), dev) if need_b else None
             dy = H.empty_cl(N, Cp, Hh, Ww, dev)
             H.epilogue_bwd(dout, y if y is not None else dout, dy, act='linear', gain=1.0, clamp=clampv, dbias=dbias_p)
             dbias = dbias_p[:Co] if need_b else None
@@ -320,7 +320,7 @@ class ToRGBFn(torch.autograd.Function):
         if need_x or need_s:
             wa_p = wa if Cp == Co else cache.adjoint_padded(weight, Cp)    # contraction dim (output channels) padded to 4
             dx = H.empty_cl(N, Ci, Hh, Ww, dev)
-            ds = torch.zeros((N, Ci), device=dev)
+            ds = H.zeros((N, Ci), dev)
             H.conv_igemm(dy, wa_p, Cp, Ci, dx, H.classes_corr_adjoint(Hh, Ww, 1, 1, 0), epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds)
         dweight = None
         if need_w:
@@ -413,7 +413,7 @@ class RenderFn(torch.autograd.Function):
         g_depth = g_depth.contiguous().float() if g_depth is not None else None
         g_wsum = g_wsum.contiguous().float() if g_wsum is not None else None
         p = H.make_render_params(planes, origins, dirs, u1, u2, opts, w0g, b0g, w1t, b1g, None, None, None, minmax, fine, rl, save)
-        d_planes = torch.zeros_like(planes) if need[0] else None
+        d_planes = H.zeros_cl(*planes.shape, dev) if need[0] else None
         d_o = torch.empty_like(origins) if (need[1] or need[2]) else None
         d_d = torch.empty_like(dirs) if (need[1] or need[2]) else None
         dumps = None

@@ -50,7 +50,78 @@ def empty_cl(n, c, h, w, device) -> torch.Tensor:
     return torch.empty((n, c, h, w), dtype=torch.float32, device=device, memory_format=CL)
 
 
+class ZeroArena:
+    """One zero-fill launch per optimisation step instead of ~60.
+
+    Split-K partial-sum buffers and the small atomically accumulated outputs (style / noise / bias gradients ...) all have to start
+    at zero, and inside a replayed graph every fill is a ~5 us kernel.  The arena hands out slices of ONE buffer that is cleared once
+    at the start of the step; the demand of the previous step sizes it (shapes are static from step to step; anything that does not
+    fit falls back to torch.zeros and enlarges the arena for the next step).  Slices are only valid until the next begin(): use it
+    for temporaries and for gradients that are consumed within the step (inversion.LatentProjector does)."""
+
+    def __init__(self, device):
+        self.device, self.buf, self.off, self.limit, self.demand, self.prev_demand = device, None, 0, 0, 0, 0
+
+    def begin(self):
+        need = self.prev_demand
+        if need and (self.buf is None or self.buf.numel() < need):
+            self.buf = torch.empty(need, dtype=torch.float32, device=self.device)
+        self.limit = need if self.buf is not None else 0
+        if self.limit:
+            self.buf[:self.limit].zero_()
+        self.off = self.demand = 0
+
+    def take(self, numel: int):
+        n = -(-numel // 64) * 64                        # 256-byte granules
+        self.demand += n
+        if self.off + n > self.limit:
+            return None
+        v = self.buf[self.off:self.off + numel]
+        self.off += n
+        return v
+
+    def end(self):
+        self.prev_demand = max(self.prev_demand, self.demand)
+
+
+ARENA: Optional[ZeroArena] = None
+
+
+class zero_arena:
+    """Context manager: route hipops.zeros / zeros_cl through `arena` for the duration of one step."""
+
+    def __init__(self, arena: Optional[ZeroArena]):
+        self.arena = arena
+
+    def __enter__(self):
+        global ARENA
+        self.prev, ARENA = ARENA, self.arena
+        if self.arena is not None:
+            self.arena.begin()
+        return self.arena
+
+    def __exit__(self, *exc):
+        global ARENA
+        if self.arena is not None:
+            self.arena.end()
+        ARENA = self.prev
+        return False
+
+
+def zeros(shape, device) -> torch.Tensor:
+    """fp32 zeros; from the step's ZeroArena when one is active."""
+    shape = tuple(shape)
+    numel = 1
+    for d in shape:
+        numel *= int(d)
+    a = ARENA.take(numel) if (ARENA is not None and torch.device(device) == ARENA.device and numel > 0) else None
+    return a.view(shape) if a is not None else torch.zeros(shape, dtype=torch.float32, device=device)
+
+
 def zeros_cl(n, c, h, w, device) -> torch.Tensor:
+    a = ARENA.take(n * c * h * w) if (ARENA is not None and torch.device(device) == ARENA.device) else None
+    if a is not None:
+        return a.view(n, h, w, c).permute(0, 3, 1, 2)           # NHWC memory, NCHW shape = channels_last
     return torch.empty((n, c, h, w), dtype=torch.float32, device=device, memory_format=CL).zero_()
 
 
@@ -293,7 +364,7 @@ def dgrad_finish(z, x, s, dx, ds=None, addend=None):
 def rows_gram(a, b):
     """(a^T b [Ka,Kb], column sums of a [Ka]) for row matrices a [S,Ka], b [S,Kb] with Ka, Kb <= 64 (eg3d_rows_gram)."""
     assert a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0] and a.is_contiguous() and b.is_contiguous()
-    z = torch.zeros(a.shape[1] * b.shape[1] + a.shape[1], dtype=torch.float32, device=a.device)
+    z = zeros((a.shape[1] * b.shape[1] + a.shape[1],), a.device)
     out, cs = z[:a.shape[1] * b.shape[1]].view(a.shape[1], b.shape[1]), z[a.shape[1] * b.shape[1]:]
     L.check(L.lib().eg3d_rows_gram(L.ptr(a), L.ptr(b), a.shape[0], a.shape[1], b.shape[1], L.ptr(out), L.ptr(cs), L.stream_ptr()), 'rows_gram')
     return out, cs

@@ -213,6 +213,7 @@ class LatentProjector:
         self.step_idx = 0
         self.last = {}
         self._reg_stream = None
+        self._arena = None
 
     def feature_net_map(self, img):
         """Spatial feature map for the warping loss from the stub net's first two stages ([N,C,h,w])."""
@@ -288,6 +289,12 @@ class LatentProjector:
         return self.last
 
     def _step_body(self, w_noise_scale, wn, kw, do_step):
+        if self._arena is None:
+            self._arena = hipops.ZeroArena(torch.device(self.dev))
+        with hipops.zero_arena(self._arena):
+            return self._step_body_inner(w_noise_scale, wn, kw, do_step)
+
+    def _step_body_inner(self, w_noise_scale, wn, kw, do_step):
         G = self.G
         if self.optimize_pose:
             rot = quaternion_to_rotmat(self.quat)
