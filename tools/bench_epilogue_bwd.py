@@ -10,7 +10,7 @@ def timeit(f, iters=20):
     for _ in range(iters): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1)/iters
-for (c,h) in ((128,512),(64,512),(256,256),(512,128),(512,64)):
+for (c,h) in ((128,512),(256,256),(512,128),(512,64),(512,32),(512,16),(512,8)):
     dout = torch.randn(1,c,h,h,device=dev).contiguous(memory_format=torch.channels_last)
     out = torch.randn(1,c,h,h,device=dev).contiguous(memory_format=torch.channels_last)
     dz = torch.empty_like(out)
