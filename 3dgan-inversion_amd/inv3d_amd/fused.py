@@ -170,7 +170,7 @@ class ModConvLayerFn(torch.autograd.Function):
             cls_probe = H.classes_corr_adjoint(Hi, Wi, kh, kw, kh // 2) if up == 1 else H.classes_convT_adjoint(Hi, Wi, kh, kw, up)
             ks_adj = _auto_ksplit(cls_probe, N, Ci, Co)
             # thousands of tiles reduce into the same N*Ci style-gradient addresses: spread them over replicas, sum afterwards
-            rep = 32 if (ks_adj == 1 and N * Hi * Wi >= 128 * 512) else 1
+            rep = 1          # replicas of the style-gradient accumulator (eg3d_conv_params::ds_replicas) measured no gain on MI355X
         # all small atomically-accumulated outputs of this backward from one zero fill
         dbias, dd, dnoise, dstrength, ds = _zeros_views(
             dev, (Co,) if need_b else None, (N, Co) if (need_s or need_w) else None,

@@ -311,7 +311,9 @@ class LatentProjector:
                 _quiet(False)
         self._reg_stream.wait_stream(cur)
         with torch.cuda.stream(self._reg_stream):
-            reg = noise_regularizer(self._all_bufs, self.reg_w)           # already weighted
+            # value AND gradient of the regulariser for all 17 buffers from one launch; the gradient is added to the buffers' .grad
+            # after backward with one fused multi-tensor add (through autograd it would be 17 AccumulateGrad add launches)
+            reg, reg_grads = hipops.noise_regularizer([b.detach() for b in self._all_bufs], scale=float(self.reg_w), want_grad=True)
         w = self.w_opt
         if wn is not None:
             w = w + wn * w_noise_scale
@@ -322,7 +324,7 @@ class LatentProjector:
             img = _area_resize(img, 256)
         dist = (self.target_features - self.feature_net(img)).square().sum()
         cur.wait_stream(self._reg_stream)
-        loss = dist + reg
+        loss = dist + reg                         # reported value; only `dist` (and the warping term) goes through autograd
         warp = None
         if self.use_warp and self.optimize_pose:
             warp = warping_loss(G, ws, self.canonical_cam, pred_ext, self.init_ext, self.intrinsic, out['image_depth'],
@@ -332,7 +334,13 @@ class LatentProjector:
         if self.optimize_pose:
             self.cam_optimizer.zero_grad(set_to_none=True)
             self.translation_optimizer.zero_grad(set_to_none=True)
-        loss.backward()
+        (dist if warp is None else dist + warp).backward()
+        have = [(b.grad, g) for b, g in zip(self._all_bufs, reg_grads) if b.grad is not None]
+        for b, g in zip(self._all_bufs, reg_grads):
+            if b.grad is None:                 # buffers the synthesis does not read (SR noise with noise_mode='none'): regulariser only
+                b.grad = g
+        if have:
+            torch._foreach_add_([a for a, _ in have], [g for _, g in have])
         if self.optimize_pose:
             self.cam_optimizer.step()
             self.translation_optimizer.step()
