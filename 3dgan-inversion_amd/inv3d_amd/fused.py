@@ -268,7 +268,10 @@ class ToRGBFn(torch.autograd.Function):
     """y = clamp(conv1x1(x * styles, W) + bias);  out = skip + y (skip optional).  Small channel counts are padded to 4."""
 
     @staticmethod
-    def forward(ctx, x, weight, styles, bias, skip, clamp, cache, want_wgrad):
+    def forward(ctx, x, weight, styles, bias, skip, clamp, cache, want_wgrad, passthrough=False):
+        """passthrough=True additionally returns x itself: the consumer of that output (the next block's conv0) then sends its
+        gradient through THIS backward, where it is added inside the data-gradient epilogue instead of by a separate autograd add
+        (3 x tensor bytes per block, 67 MB tensors in the SR head)."""
         L.require_cuda(x, weight, styles)
         x = H.to_cl(x.float())
         styles = styles.contiguous().float()
@@ -296,10 +299,10 @@ class ToRGBFn(torch.autograd.Function):
             out = y + skip if skip is not None else y
         ctx.save_for_backward(x, weight, styles, y if clampv >= 0 else None)
         ctx.cfg = (clampv, cache, want_wgrad, Cp, skip is not None)
-        return out
+        return (out, x.view_as(x)) if passthrough else out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dx_pass=None):
         x, weight, styles, y = ctx.saved_tensors
         clampv, cache, want_wgrad, Cp, has_skip = ctx.cfg
         need_x, need_w, need_s, need_b, need_skip = ctx.needs_input_grad[:5]
@@ -321,13 +324,16 @@ class ToRGBFn(torch.autograd.Function):
             wa_p = wa if Cp == Co else cache.adjoint_padded(weight, Cp)    # contraction dim (output channels) padded to 4
             dx = H.empty_cl(N, Ci, Hh, Ww, dev)
             ds = H.zeros((N, Ci), dev)
-            H.conv_igemm(dy, wa_p, Cp, Ci, dx, H.classes_corr_adjoint(Hh, Ww, 1, 1, 0), epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds)
+            add = H.to_cl(dx_pass.float()) if dx_pass is not None else None
+            H.conv_igemm(dy, wa_p, Cp, Ci, dx, H.classes_corr_adjoint(Hh, Ww, 1, 1, 0), epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, addend=add)
+        elif dx_pass is not None:
+            dx = dx_pass
         dweight = None
         if need_w:
             dwp = torch.zeros((Co, Ci), device=dev)
             H.conv_wgrad(x, dy, Ci, Co, dwp, H.classes_corr(Hh, Ww, 1, 1, 0), in_scale=styles)
             dweight = dwp.view(Co, Ci, 1, 1)
-        return (dx if need_x else None, dweight, ds if need_s else None, dbias, dout if (need_skip and has_skip) else None, None, None, None)
+        return (dx if need_x else None, dweight, ds if need_s else None, dbias, dout if (need_skip and has_skip) else None, None, None, None, None)
 
 
 class UpsampleImgFn(torch.autograd.Function):

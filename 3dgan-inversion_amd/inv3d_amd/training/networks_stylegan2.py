@@ -134,12 +134,13 @@ class ToRGBLayer(torch.nn.Module):
         self.weight_gain = 1 / math.sqrt(in_channels * (kernel_size ** 2))
         self._cache = fused.WeightCache()
 
-    def forward(self, x, w, fused_modconv=True, skip=None, styles=None):
+    def forward(self, x, w, fused_modconv=True, skip=None, styles=None, passthrough=False):
         """Returns skip + torgb(x) on a channel count padded to a multiple of 4 (padding channels stay as in `skip`/zero).
-        `styles`: affine(w) * weight_gain when precomputed by the enclosing network."""
+        `styles`: affine(w) * weight_gain when precomputed by the enclosing network.  passthrough=True: returns (img, x) where the
+        second output is x routed through this op's autograd node (see fused.ToRGBFn)."""
         if styles is None:
             styles = self.affine(w) * self.weight_gain
-        return fused.ToRGBFn.apply(x, self.weight, styles, self.bias, skip, self.conv_clamp, self._cache, self.weight.requires_grad)
+        return fused.ToRGBFn.apply(x, self.weight, styles, self.bias, skip, self.conv_clamp, self._cache, self.weight.requires_grad, passthrough)
 
 
 def _pad4(c):
@@ -192,7 +193,10 @@ class SynthesisBlock(torch.nn.Module):
             x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), styles=next(s_iter), **layer_kwargs)
         if img is not None:
             img = fused.UpsampleImgFn.apply(img)
-        img = self.torgb(x, next(w_iter), skip=img, styles=next(s_iter))
+        if self.is_last:
+            img = self.torgb(x, next(w_iter), skip=img, styles=next(s_iter))
+        else:       # x goes on to the next block: route it through the toRGB node so the two gradients are summed in its epilogue
+            img, x = self.torgb(x, next(w_iter), skip=img, styles=next(s_iter), passthrough=True)
         return x, img
 
 
