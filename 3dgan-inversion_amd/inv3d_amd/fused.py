@@ -284,7 +284,7 @@ class ToRGBFn(torch.autograd.Function):
         if Cp != Co:              # compute all Cp channels: zero weight rows / bias give 0 (+ skip) in the padding channels
             wf = cache.forward_padded(weight, Cp)
             if b is not None:
-                b = torch.nn.functional.pad(b, (0, Cp - Co))
+                b = H.memo(('torgb_bias_pad', Cp), [bias], lambda: torch.nn.functional.pad(bias.detach().float(), (0, Cp - Co)))
         cls = H.classes_corr(Hh, Ww, 1, 1, 0)
         y = None
         if skip is not None:
@@ -384,10 +384,9 @@ class RenderFn(torch.autograd.Function):
         Dc, Df = int(opts['depth_resolution']), int(opts['depth_resolution_importance'])
         hid, cin = w0.shape
         g0, g1 = lr_mul / math.sqrt(cin), lr_mul / math.sqrt(hid)
-        w0g = (w0.detach().float() * g0).contiguous()
-        b0g = (b0.detach().float() * lr_mul).contiguous()
-        w1t = (w1.detach().float() * g1).t().contiguous()
-        b1g = (b1.detach().float() * lr_mul).contiguous()
+        w0g, b0g, w1t, b1g = H.memo(('decoder', lr_mul), [w0, b0, w1, b1], lambda: (
+            (w0.detach().float() * g0).contiguous(), (b0.detach().float() * lr_mul).contiguous(),
+            (w1.detach().float() * g1).t().contiguous(), (b1.detach().float() * lr_mul).contiguous()))
         u1 = u1.contiguous().float()
         u2 = u2.contiguous().float() if u2 is not None else None
         rgb = torch.empty((N, R, w1.shape[0] - 1), device=dev)

@@ -5,6 +5,7 @@ reference-facing API keeps NCHW shapes while memory is channel-contiguous, which
 the float4 epilogues and the 128-byte tri-plane gathers want).
 """
 import os
+import weakref
 import ctypes as C
 from typing import List, Optional, Sequence
 
@@ -237,6 +238,25 @@ def classes_convT_adjoint(Hi, Wi, kh, kw, up, flip_taps=False):
             wt = ((kh - 1 - ky) * kw + (kw - 1 - kx)) if flip_taps else (ky * kw + kx)
             taps.append((ky, kx, wt))
     return [_mk_class(Hi, Wi, 0, 0, taps)]
+
+
+_MEMO = {}
+
+
+def memo(tag, tensors, fn):
+    """Derived images of parameters (packed / padded / pre-scaled weights), recomputed only when a source tensor changes (storage
+    pointer or in-place version).  One entry per (tag, storage): frozen weights cost nothing per step, trained ones are rebuilt."""
+    key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+    slot = (tag, tensors[0].data_ptr())
+    hit = _MEMO.get(slot)
+    # the entry is only valid for the very same tensor objects (a freed temporary's address can be reused by another tensor)
+    if hit is None or hit[0] != key or any(r() is not t for r, t in zip(hit[2], tensors)):
+        if len(_MEMO) > 512:
+            _MEMO.clear()
+        with torch.no_grad():
+            hit = (key, fn(), tuple(weakref.ref(t) for t in tensors))
+        _MEMO[slot] = hit
+    return hit[1]
 
 
 def pack_weight_fwd(w):

@@ -55,9 +55,10 @@ class _ConvFn(torch.autograd.Function):
         else:
             Ci, Co, kh, kw = w.shape
             wfull = w.transpose(0, 1)                  # [O,I,kh,kw] view: out[o, up*a+ky] += x[i,a] * w[i,o,ky]
-        if Cip != Ci:
-            wfull = torch.cat([wfull, wfull.new_zeros(Co, Cip - Ci, kh, kw)], 1)
-        wf = H.pack_weight_fwd(wfull)
+        def _pack(wfull=wfull):
+            wp = torch.cat([wfull, wfull.new_zeros(Co, Cip - Ci, kh, kw)], 1) if Cip != Ci else wfull
+            return H.pack_weight_fwd(wp.detach())
+        wf = H.memo(('gradfix_fwd', mode, Cip), [w], _pack)
         Cop = (Co + 3) // 4 * 4
         if mode == 'corr':
             Ho, Wo = Hi + 2 * pad[0] - kh + 1, Wi + 2 * pad[1] - kw + 1
@@ -103,9 +104,10 @@ class _ConvDataGradFn(torch.autograd.Function):
         else:
             _, Co, kh, kw = w.shape
             wfull = w.transpose(0, 1)
-        if Cgp != Co:
-            wfull = torch.cat([wfull, wfull.new_zeros(Cgp - Co, Ci, kh, kw)], 0)
-        wa = H.pack_weight_adj(wfull)                   # [Ci, taps*Cgp]
+        def _pack(wfull=wfull):
+            wp = torch.cat([wfull, wfull.new_zeros(Cgp - Co, Ci, kh, kw)], 0) if Cgp != Co else wfull
+            return H.pack_weight_adj(wp.detach())
+        wa = H.memo(('gradfix_adj', mode, Cgp), [w], _pack)                   # [Ci, taps*Cgp]
         Cip = (Ci + 3) // 4 * 4
         dx = (H.zeros_cl if Cip != Ci else H.empty_cl)(N, Cip, Hi, Wi, dy.device)
         if mode == 'corr':
