@@ -20,6 +20,9 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -53,18 +56,39 @@ __device__ __forceinline__ void split4(const float4 v, uint2* out) {
     for (int pc = 0; pc < NP; ++pc) out[pc] = make_uint2(w[pc][0], w[pc][1]);
 }
 
+// Two-piece fp16 split (precision 3): x = h + l,  h = fp16(x) rounded toward zero,  l = fp16(x - h) rounded to nearest.  x - h is exact in
+// fp32, |l| < 2^-10 |x|, and the residual |x - h - l| <= max(2^-22 |x|, 2^-25) (the second term where l is a subnormal fp16, i.e. for
+// |x| < 2^-4).  l is clamped to the fp16 range so that an out-of-range x saturates instead of producing inf - inf.
+__device__ __forceinline__ void split4h(const float4 v, uint2* out) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned hw[2], lw[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const fp16x2_t h = __builtin_amdgcn_cvt_pkrtz(x[2 * q], x[2 * q + 1]);
+        const float r0 = __builtin_amdgcn_fmed3f(x[2 * q] - (float)h[0], -65504.f, 65504.f);
+        const float r1 = __builtin_amdgcn_fmed3f(x[2 * q + 1] - (float)h[1], -65504.f, 65504.f);
+        const f16x2_t l = {(_Float16)r0, (_Float16)r1};
+        __builtin_memcpy(&hw[q], &h, 4);
+        __builtin_memcpy(&lw[q], &l, 4);
+    }
+    out[0] = make_uint2(hw[0], hw[1]);
+    out[1] = make_uint2(lw[0], lw[1]);
+}
+
 __device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 
 // waves per SIMD the register allocation is held to: 3 for the 4-wave split-bf16 tiles whose two loader register sets are small
 // (<= 168 VGPRs, 3 x 49 KB of LDS per CU), 2 where the sets are larger, unconstrained for the 8-wave / fp32 256-row variants
-__host__ __device__ constexpr int conv_min_waves(int bm, int bn, int waves, int prec) {
+__host__ __device__ constexpr int conv_min_waves(int bm, int bn, int waves, int prec, bool vec) {
     const int kb = prec ? (bm * bn >= 128 * 128 ? 16 : 32) : 32;
     const int per_thread = (bm + bn) * (kb / 4) / (waves * 64);          // float4 per thread and register set
-    return waves != 4 ? 1 : (prec ? (per_thread <= 4 ? 3 : 2) : (per_thread <= 8 ? 2 : 1));
+    // the scalar-epilogue instantiation (split-K launches: few blocks, latency-bound) keeps 16 rows x 4 side inputs in flight per lane and
+    // spills badly at 168 registers: it is held to 2 waves per SIMD instead
+    return waves != 4 ? 1 : (prec ? (per_thread <= 4 && vec ? 3 : 2) : (per_thread <= 8 ? 2 : 1));
 }
 
 template <int BM, int BN, int WM, int WN, int PREC, bool VEC>
-__global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, PREC)) conv_igemm_kernel(const eg3d_conv_params p) {
+__global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, PREC, VEC)) conv_igemm_kernel(const eg3d_conv_params p) {
     constexpr int NT = WM * WN * 64;                        // 4 or 8 waves
     constexpr int NP = PREC == 1 ? 3 : 2;                   // bf16 pieces per operand (split paths)
     constexpr int KB = PREC ? (BM * BN >= 128 * 128 ? 16 : 32) : BK;      // K per step
@@ -113,6 +137,21 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
         }
         rowpix[tid] = pix;
         rown[tid] = n;
+    }
+    // ---- F16X3 operand range: bring the A operand to ~2^13..2^14 at its maximum with an exact power of two (p.a_amax: device scalar
+    // holding max|A|, e.g. written by the producer of a gradient tensor); the accumulators are rescaled in the epilogue.
+    float a_mul = 1.f, a_inv = 1.f;
+    if constexpr (PREC == 3) {
+        if (p.a_amax != nullptr) {
+            const float am = *p.a_amax * p.a_amax_mul;
+            if (am > 0.f && am < 3.0e38f) {
+                int e;
+                (void)frexpf(am, &e);                       // am = m * 2^e, m in [0.5, 1)
+                e = e > 110 ? 110 : (e < -110 ? -110 : e);
+                a_mul = ldexpf(1.f, 14 - e);
+                a_inv = ldexpf(1.f, e - 14);
+            }
+        }
     }
     // ---- operand loaders: branch-free raw buffer loads ----------------------------------------------------------------
     // Every thread fetches A_LD + B_LD 16-byte pieces per K-step.  The per-row part of the address and a 9-bit "tap in bounds"
@@ -209,8 +248,9 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
             for (int j = 0; j < A_LD; ++j) {
                 float4 v = ra[j];
                 if (p.in_scale != nullptr) v = f4mul(v, sc[j]);
+                if constexpr (PREC == 3) { v.x *= a_mul; v.y *= a_mul; v.z *= a_mul; v.w *= a_mul; }
                 uint2 pc[NP];
-                split4<NP>(v, pc);
+                if constexpr (PREC == 3) split4h(v, pc); else split4<NP>(v, pc);
                 if (BM >= RPP || lrow < BM) {
 #pragma unroll
                     for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(a + q * A_PIECE + (lrow + RPP * j) * 16) = pc[q];
@@ -219,7 +259,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
 #pragma unroll
             for (int j = 0; j < B_LD; ++j) {
                 uint2 pc[NP];
-                split4<NP>(rb[j], pc);
+                if constexpr (PREC == 3) split4h(rb[j], pc); else split4<NP>(rb[j], pc);
                 if (BN >= RPP || lrow < BN) {
 #pragma unroll
                     for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(b + q * B_PIECE + (lrow + RPP * j) * 16) = pc[q];
@@ -292,8 +332,16 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t]][i], bf[PB[t]][j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j) {
+                            if constexpr (PREC == 3) {      // the same bits as two fp16 pieces: h*h + h*l + l*h
+                                f16x8 ah, bh;
+                                __builtin_memcpy(&ah, &af[PA[t]][i], 16);
+                                __builtin_memcpy(&bh, &bf[PB[t]][j], 16);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
+                            } else {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t]][i], bf[PB[t]][j], acc[i][j], 0, 0, 0);
+                            }
+                        }
             }
         }
     };
@@ -303,7 +351,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
     auto weave = [&]() {
         if constexpr (PREC != 0) {
             constexpr int NMFMA = TM * TN * (PREC == 1 ? 6 : 3) * (KB / 16);
-            constexpr int NVALU = (A_LD + B_LD) * (PREC == 1 ? 22 : 12) + A_LD * 4;
+            constexpr int NVALU = (A_LD + B_LD) * (PREC == 1 ? 22 : (PREC == 2 ? 12 : 14)) + A_LD * 4;
             constexpr int PER = (NVALU + NMFMA - 1) / NMFMA;
             __builtin_amdgcn_sched_group_barrier(0x100, (TM + TN) * NP * (KB / 16), 0);      // fragment reads
 #pragma unroll
@@ -376,7 +424,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    stage[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDS_N + wn * (TN * 32) + j * 32 + (lane & 31)] = acc[i][j][r];
+                    stage[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDS_N + wn * (TN * 32) + j * 32 + (lane & 31)] = acc[i][j][r] * a_inv;
             __syncthreads();
             constexpr int UG = UPT > 4 ? 4 : UPT;            // units in flight per thread (register budget)
 #pragma unroll
@@ -428,6 +476,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
             if (tid < BN && n0 + tid < p.Nc) unsafeAtomicAdd(ds_out + (int64_t)n_first * p.Nc + n0 + tid, ds_lds[tid]);
         }
     } else {
+    constexpr int RC = 8;                     // rows per lane whose side inputs are in flight together
     // ---- scalar epilogue (split-K atomics, tiles spanning several images, unaligned or odd channel counts) -----------------------
 
 #pragma unroll
@@ -438,15 +487,15 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
         const float bias = (epi == EG3D_EPI_FWD && p.bias != nullptr && cok) ? p.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            // Two phases per half tile (8 rows per lane): every side input (style scale, noise, skip addend, layer input for the
+            // Two phases per quarter tile (RC rows per lane): every side input (style scale, noise, skip addend, layer input for the
             // style gradient) is requested first, the arithmetic and the stores follow.  Interleaving them per element makes
             // each load wait for the previous store (the compiler must assume out / addend / xin alias).
 #pragma unroll
-            for (int rh = 0; rh < 16; rh += 8) {
-                int offs[8];
-                float scl[8], sidea[8], sideb[8];
+            for (int rh = 0; rh < 16; rh += RC) {
+                int offs[RC];
+                float scl[RC], sidea[RC], sideb[RC];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < RC; ++q) {
                     const int r = rh + q;
                     const int rl = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const int pix = rowpix[rl];
@@ -466,11 +515,11 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < RC; ++q) {
                     const int r = rh + q;
                     const int off = offs[q];
                     if (off < 0) continue;
-                    float v = acc[i][j][r];
+                    float v = acc[i][j][r] * a_inv;
                     if (epi == EG3D_EPI_STORE) {
                         p.out[off] = v;
                     } else if (epi == EG3D_EPI_ATOMIC) {
@@ -506,7 +555,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
 // host-side test for the vector epilogue (see the kernel): everything the kernel would otherwise have to branch on
 template <int BM>
 bool conv_vector_epilogue_ok(const eg3d_conv_params& p) {
-    if (p.epi == EG3D_EPI_ATOMIC || (p.ldo & 3) || (p.Nc & 3)) return false;
+    if (p.epi == EG3D_EPI_ATOMIC || (p.ldo & 3) || (p.Nc & 3)) return false;     // atomics stay lane-per-column (coalesced per row)
     const void* ptrs[] = {p.out, p.addend, p.xin, p.out_scale, p.bias};
     for (const void* q : ptrs)
         if (q != nullptr && (reinterpret_cast<uintptr_t>(q) & 15)) return false;
@@ -551,6 +600,7 @@ int launch_conv(const eg3d_conv_params& p, hipStream_t st) {
     switch (p.precision) {
         case 1: return launch_conv_p<BM, BN, WM, WN, 1>(p, st);
         case 2: return launch_conv_p<BM, BN, WM, WN, 2>(p, st);
+        case 3: return launch_conv_p<BM, BN, WM, WN, 3>(p, st);
         default: return launch_conv_p<BM, BN, WM, WN, 0>(p, st);
     }
 }
@@ -580,7 +630,7 @@ extern "C" int eg3d_conv2d_igemm_f32(const eg3d_conv_params* pp, void* stream) {
     if (p.ncls < 1 || p.ncls > 4 || p.ksplit < 1 || p.in_stride < 1 || p.out_stride < 1) return EG3D_ERR_INVALID;
     if (p.ksplit > 1 && p.epi != EG3D_EPI_ATOMIC) return EG3D_ERR_INVALID;
     if (p.epi < EG3D_EPI_STORE || p.epi > EG3D_EPI_BWD) return EG3D_ERR_INVALID;
-    if (p.precision < 0 || p.precision > 2 || p.ds_replicas < 0) return EG3D_ERR_INVALID;
+    if (p.precision < 0 || p.precision > 3 || p.ds_replicas < 0) return EG3D_ERR_INVALID;
     if (p.epi == EG3D_EPI_FWD && p.noise && !p.noise_strength) return EG3D_ERR_INVALID;
     if ((p.Ck & 3) || (p.ldx & 3) || (p.w_row & 3)) return EG3D_ERR_UNSUPPORTED;   // 16-byte operand loads
     if ((reinterpret_cast<uintptr_t>(p.x) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15)) return EG3D_ERR_UNSUPPORTED;

@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const flo
                                                            int64_t noise_nstride, const float* __restrict__ noise_strength,
                                                            const float* __restrict__ bias, int act, float alpha, float gain, float clamp,
                                                            float* __restrict__ dbias, float* __restrict__ dd, float* __restrict__ dnoise,
-                                                           int64_t dnoise_nstride, float* __restrict__ dstrength) {
+                                                           int64_t dnoise_nstride, float* __restrict__ dstrength, float* __restrict__ dz_amax) {
     extern __shared__ __attribute__((aligned(16))) float red[];      // [PPB][C4][8] floats + 1
     const int n = blockIdx.y;
     const int C = C4 * 4;
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const flo
     if (active && d) dv = ld4(d + (int64_t)n * C + c);
     if (active && bias) bv = ld4(bias + c);
     float4 accb = make_float4(0, 0, 0, 0), accd = make_float4(0, 0, 0, 0);
-    float accs = 0.f;
+    float accs = 0.f, amax = 0.f;
     // lanes of one pixel are contiguous; groups of min(C4,64) lanes can be shuffle-reduced when C4 is a power of two
     const bool pow2 = (C4 & (C4 - 1)) == 0;
     const int grp = C4 < 64 ? C4 : 64;
@@ -152,7 +152,9 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const flo
                 float4 dy, pre;
                 bwd1(g[u].x, o[u].x, act, alpha, gain, clamp, dy.x, pre.x); bwd1(g[u].y, o[u].y, act, alpha, gain, clamp, dy.y, pre.y);
                 bwd1(g[u].z, o[u].z, act, alpha, gain, clamp, dy.z, pre.z); bwd1(g[u].w, o[u].w, act, alpha, gain, clamp, dy.w, pre.w);
-                st4(dz + off, make_float4(dy.x * dv.x, dy.y * dv.y, dy.z * dv.z, dy.w * dv.w));
+                const float4 zz = make_float4(dy.x * dv.x, dy.y * dv.y, dy.z * dv.z, dy.w * dv.w);
+                st4(dz + off, zz);
+                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(zz.x), fabsf(zz.y)), fmaxf(fabsf(zz.z), fabsf(zz.w))));
                 accb.x += dy.x; accb.y += dy.y; accb.z += dy.z; accb.w += dy.w;
                 const float nz = nraw[u] * strength;
                 if (dd) {
@@ -202,6 +204,17 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const flo
     }
     __syncthreads();
     if (dstrength && threadIdx.x == 0 && rs[0] != 0.f) unsafeAtomicAdd(dstrength, rs[0]);
+    if (dz_amax != nullptr) {                 // max|dz|: non-negative floats order like their bit patterns; one global atomic per block
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        unsigned* wmax = reinterpret_cast<unsigned*>(red);                 // the reduction scratch is free again
+        __syncthreads();
+        if (threadIdx.x == 0) wmax[0] = 0u;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0 && amax < 3.0e38f) atomicMax(wmax, __float_as_uint(amax));
+        __syncthreads();
+        if (threadIdx.x == 0 && wmax[0] != 0u) atomicMax(reinterpret_cast<unsigned*>(dz_amax), wmax[0]);
+    }
 }
 
 // finish of a split-K data-gradient: dx = z * s[n,c] (+ addend);  ds[n,c] += sum_px z * x      (grid = (blocks, N))
@@ -330,7 +343,7 @@ extern "C" int eg3d_modconv_epilogue_fwd(const float* z, float* out, int N, int 
 extern "C" int eg3d_modconv_epilogue_bwd(const float* dout, const float* out, float* dz, int N, int H, int W, int C, const float* d,
                                          const float* noise, int64_t noise_nstride, const float* noise_strength, const float* bias, int act,
                                          float alpha, float gain, float clamp, float* dbias, float* dd, float* dnoise, int64_t dnoise_nstride,
-                                         float* dstrength, void* stream) {
+                                         float* dstrength, float* dz_amax, void* stream) {
     if (!dout || !out || !dz || N <= 0 || H <= 0 || W <= 0 || C <= 0) return EG3D_ERR_INVALID;
     if (C % 4 || C / 4 > 256) return EG3D_ERR_UNSUPPORTED;
     if (dd && act != EG3D_ACT_LINEAR && act != EG3D_ACT_LRELU) return EG3D_ERR_UNSUPPORTED;   // needs an invertible activation
@@ -345,7 +358,7 @@ extern "C" int eg3d_modconv_epilogue_bwd(const float* dout, const float* out, fl
     int bx = std::max(1, std::min(eg3d_cdiv((int64_t)H * W, ppb * 4), std::max(1, cap / N)));
     size_t smem = (size_t)(ppb * C4 * 8 + 4) * sizeof(float);
     hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(bx, N), dim3(EPI_BWD_THREADS), smem, (hipStream_t)stream, dout, out, dz, H, W, C4, d, noise, noise_nstride,
-                       noise_strength, bias, act, alpha, gain, clamp, dbias, dd, dnoise, dnoise_nstride, dstrength);
+                       noise_strength, bias, act, alpha, gain, clamp, dbias, dd, dnoise, dnoise_nstride, dstrength, dz_amax);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

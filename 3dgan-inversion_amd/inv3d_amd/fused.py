@@ -125,16 +125,17 @@ class ModConvLayerFn(torch.autograd.Function):
         out = H.empty_cl(N, Co, Ho, Wo, x.device)
         b = bias.contiguous().float() if bias is not None else None
         aflops = 2.0 * N * Hi * Wi * (1 if up == 2 else 1) * kh * kw * Ci * Co     # MACs of the (transposed) conv
+        prec = H.modconv_precision()
         if up == 1:
             cls = H.classes_corr(Ho, Wo, kh, kw, kh // 2)
             ks = _auto_ksplit(cls, N, Co, Ci)
             if ks == 1:
                 H.conv_igemm(x, wf, Ci, Co, out, cls, in_scale=styles, epi=L.EPI_FWD, out_scale=d, bias=b, noise=nz,
                              noise_nstride=nstride or 0, noise_strength=noise_strength, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv,
-                             algo_flops=aflops)
+                             algo_flops=aflops, precision=prec)
             else:
                 z = H.zeros_cl(N, Co, Ho, Wo, x.device)
-                H.conv_igemm(x, wf, Ci, Co, z, cls, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops)
+                H.conv_igemm(x, wf, Ci, Co, z, cls, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=prec)
                 H.epilogue_fwd(z, out, d=d, noise=nz, noise_nstride=nstride or 0, noise_strength=noise_strength, bias=b, act='lrelu',
                                alpha=0.2, gain=act_gain, clamp=clampv)
         else:
@@ -142,10 +143,10 @@ class ModConvLayerFn(torch.autograd.Function):
             ks = _auto_ksplit(cls, N, Co, Ci)
             if ks == 1:
                 z = H.empty_cl(N, Co, Hz, Wz, x.device)
-                H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_STORE, algo_flops=aflops)
+                H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_STORE, algo_flops=aflops, precision=prec)
             else:
                 z = H.zeros_cl(N, Co, Hz, Wz, x.device)
-                H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops)
+                H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=prec)
             H.epilogue_fwd(z, out, fir=fir44(x.device), pad0=1, fir_gain=float(up * up), d=d, noise=nz, noise_nstride=nstride or 0,
                            noise_strength=noise_strength, bias=b, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv)
         ctx.save_for_backward(x, weight, styles, d, out, nz, noise_strength, b)
@@ -172,13 +173,16 @@ class ModConvLayerFn(torch.autograd.Function):
             # thousands of tiles reduce into the same N*Ci style-gradient addresses: spread them over replicas, sum afterwards
             rep = 1          # replicas of the style-gradient accumulator (eg3d_conv_params::ds_replicas) measured no gain on MI355X
         # all small atomically-accumulated outputs of this backward from one zero fill
-        dbias, dd, dnoise, dstrength, ds = _zeros_views(
+        prec = H.modconv_precision()
+        dbias, dd, dnoise, dstrength, ds, amax = _zeros_views(
             dev, (Co,) if need_b else None, (N, Co) if (need_s or need_w) else None,
             tuple(nz.shape) if (need_nz and nz is not None) else None, () if (need_ns and nz is not None) else None,
-            None if ks_adj is None else ((rep, N, Ci) if rep > 1 else (N, Ci)))
+            None if ks_adj is None else ((rep, N, Ci) if rep > 1 else (N, Ci)),
+            (1,) if (prec == 'f16x3' and ks_adj is not None) else None)          # max|dz|: operand range of the f16x3 data gradient
         H.epilogue_bwd(dout, out, dz, d=d, noise=nz, noise_nstride=nstride or 0, noise_strength=noise_strength if nz is not None else None,
                        bias=b, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv, dbias=dbias, dd=dd, dnoise=dnoise,
-                       dnoise_nstride=nstride or 0, dstrength=dstrength)
+                       dnoise_nstride=nstride or 0, dstrength=dstrength, dz_amax=amax)
+        amul = 1.0 if up == 1 else float(up * up)       # g = FIR(dz) * up^2 with a non-negative unit-sum filter: |g| <= up^2 max|dz|
         if up == 1:
             g = dz
             cls_adj = H.classes_corr_adjoint(Hi, Wi, kh, kw, kh // 2)
@@ -195,12 +199,14 @@ class ModConvLayerFn(torch.autograd.Function):
             aflops = 2.0 * N * Hi * Wi * kh * kw * Ci * Co
             ks = ks_adj
             if ks == 1:
-                H.conv_igemm(g, wa, Co, Ci, dx, cls_adj, in_stride=in_stride, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, algo_flops=aflops)
+                H.conv_igemm(g, wa, Co, Ci, dx, cls_adj, in_stride=in_stride, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, algo_flops=aflops,
+                             precision=prec, a_amax=amax, a_amax_mul=amul)
                 if rep > 1:
                     ds = ds.sum(0)
             else:                                  # low resolution: split K over blocks, then scale / reduce in a finishing pass
                 z = H.zeros_cl(N, Ci, Hi, Wi, dev)
-                H.conv_igemm(g, wa, Co, Ci, z, cls_adj, in_stride=in_stride, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops)
+                H.conv_igemm(g, wa, Co, Ci, z, cls_adj, in_stride=in_stride, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=prec, a_amax=amax,
+                             a_amax_mul=amul)
                 H.dgrad_finish(z, x, styles, dx, ds=ds)
         dwsq = torch.zeros_like(wsq) if need_w else None
         if dd is not None and (need_s or need_w):

@@ -272,21 +272,35 @@ def pack_weight_adj(w):
 
 
 # Matrix-core arithmetic of the implicit GEMMs (include/eg3d_hip.h EG3D_PREC_*).  Operands, accumulators and results are fp32 in
-# every mode: 'bf16x6' (default) forms each fp32 product from six exact bf16 products (error < 2^-23, i.e. fp32-equivalent, at
-# ~1.4x the rate of the fp32 MFMA), 'f32' uses v_mfma_f32_32x32x2_f32, 'bf16x3' three products (~2^-15, opt-in only).
+# every mode; the modes differ in how an fp32 product is formed on the matrix cores:
+#   'f16x3'   two fp16 pieces per operand, three products; error vs fp64 as small as the fp32 MFMA path for operands of ordinary
+#             magnitude (|x| ~ 2^-4 .. 2^16), 1.45x the rate of bf16x6.  Needs the operand range: used where it is known.
+#   'bf16x6'  three bf16 pieces, six products; fp32-equivalent for any operand range.
+#   'f32'     v_mfma_f32_32x32x2_f32.       'bf16x3'  three bf16 products (~2^-15), opt-in only.
+# Mode 'auto' (default): the style-modulated convolutions run 'f16x3' -- their forward operands are demodulated O(1) activations and
+# unit-variance weights, and the data gradient is range-normalised with the max|dz| its producer (epilogue_bwd) reports -- everything
+# else (toRGB, the generic conv2d of conv2d_gradfix) runs 'bf16x6'.  Any other value forces that mode everywhere.
 # Set with set_conv_precision() or the EG3D_CONV_PRECISION environment variable.
-PRECISIONS = {'f32': 0, 'bf16x6': 1, 'bf16x3': 2}
-CONV_PRECISION = PRECISIONS[os.environ.get('EG3D_CONV_PRECISION', 'bf16x6')]
+PRECISIONS = {'f32': 0, 'bf16x6': 1, 'bf16x3': 2, 'f16x3': 3}
+CONV_MODE = os.environ.get('EG3D_CONV_PRECISION', 'auto')
+CONV_PRECISION = PRECISIONS['bf16x6' if CONV_MODE == 'auto' else CONV_MODE]
 
 
 def set_conv_precision(name):
-    global CONV_PRECISION
-    CONV_PRECISION = PRECISIONS[name]
+    global CONV_MODE, CONV_PRECISION
+    assert name == 'auto' or name in PRECISIONS
+    CONV_MODE = name
+    CONV_PRECISION = PRECISIONS['bf16x6' if name == 'auto' else name]
+
+
+def modconv_precision() -> str:
+    """Arithmetic of the style-modulated convolutions (the dominant kernels) under the current mode."""
+    return 'f16x3' if CONV_MODE == 'auto' else CONV_MODE
 
 
 def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=None, epi=L.EPI_STORE, ksplit=1,
                out_scale=None, bias=None, noise=None, noise_nstride=0, noise_strength=None, act='linear', alpha=0.0, gain=1.0,
-               clamp=-1.0, addend=None, xin=None, ds=None, algo_flops=None, precision=None):
+               clamp=-1.0, addend=None, xin=None, ds=None, algo_flops=None, precision=None, a_amax=None, a_amax_mul=1.0):
     """Launch eg3d_conv2d_igemm_f32.  x/out/addend/xin: channels_last fp32 [N,C,H,W]; wp: packed weights [Nc, taps*Ck]."""
     assert is_cl(x) and is_cl(out), 'conv_igemm expects fp32 channels_last CUDA tensors'
     p = L.ConvParams()
@@ -312,6 +326,8 @@ def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=
     p.xin = xin.data_ptr() if xin is not None else None
     p.ds = ds.data_ptr() if ds is not None else None
     p.precision = CONV_PRECISION if precision is None else PRECISIONS[precision]
+    p.a_amax = a_amax.data_ptr() if a_amax is not None else None
+    p.a_amax_mul = float(a_amax_mul)
     p.ds_replicas = ds.shape[0] if (ds is not None and ds.dim() == 3) else 1
     prof = PROFILER
     if prof is not None:
@@ -365,13 +381,13 @@ def epilogue_fwd(z, out, fir=None, pad0=0, fir_gain=1.0, d=None, noise=None, noi
 
 
 def epilogue_bwd(dout, out, dz, d=None, noise=None, noise_nstride=0, noise_strength=None, bias=None, act='linear', alpha=0.0, gain=1.0,
-                 clamp=-1.0, dbias=None, dd=None, dnoise=None, dnoise_nstride=0, dstrength=None):
+                 clamp=-1.0, dbias=None, dd=None, dnoise=None, dnoise_nstride=0, dstrength=None, dz_amax=None):
     assert is_cl(dout) and is_cl(out) and is_cl(dz)
     n, c, h, w = out.shape
     L.check(L.lib().eg3d_modconv_epilogue_bwd(L.ptr(dout), L.ptr(out), L.ptr(dz), n, h, w, c, L.ptr(d), L.ptr(noise), noise_nstride,
                                               L.ptr(noise_strength), L.ptr(bias), L.ACT_IDS[act], float(alpha), float(gain),
                                               float(clamp), L.ptr(dbias), L.ptr(dd), L.ptr(dnoise), dnoise_nstride, L.ptr(dstrength),
-                                              L.stream_ptr()), 'modconv_epilogue_bwd')
+                                              L.ptr(dz_amax), L.stream_ptr()), 'modconv_epilogue_bwd')
     return dz
 
 

@@ -14,9 +14,10 @@ The JSON line also carries
   roofline      : the dominant kernel conv_igemm_kernel<128,128,2,2,PREC> (implicit GEMM on the matrix cores): algorithmic FLOPs of
                   its launches (2 x MACs of the convolution) / their HIP-event durations measured on the
                   launch stream inside the timed region.  `peak` is the matrix peak for the arithmetic the kernel executes:
-                  157.3 TFLOP/s for --precision f32 (v_mfma_f32_32x32x2_f32); for the default bf16x6 (fp32 operands and results,
-                  every fp32 product formed from six exact bf16 MFMA products, error < 2^-23) it is the dense bf16 peak / 6 =
-                  416.7 fp32-equivalent TFLOP/s.  `frac_of_fp32_mfma_peak` and `mfma_executed_tflops` are given beside it.
+                  157.3 TFLOP/s for --precision f32 (v_mfma_f32_32x32x2_f32); for the split modes (fp32 operands and results, every
+                  fp32 product formed from exact 16-bit MFMA products: 3 fp16 products in the default mode, 6 bf16 products with
+                  --precision bf16x6) it is the dense 16-bit peak / products = 833.3 resp. 416.7 fp32-equivalent TFLOP/s.
+                  `frac_of_fp32_mfma_peak` and `mfma_executed_tflops` are given beside it.
   cpu_baseline  : the CPU oracle (oracle/eg3d_oracle.py, a port of the reference's pure-PyTorch `_ref` path, pinned against
                   the reference) running the same C2 step on the host cores, bounded sample, rank 0 at N=1 only.
 """
@@ -35,7 +36,7 @@ import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide, dense bf16 (never the 2:1-sparsity figure)
-PRODUCTS = {'f32': 1, 'bf16x6': 6, 'bf16x3': 3}      # MFMA products executed per algorithmic fp32 product
+PRODUCTS = {'f32': 1, 'bf16x6': 6, 'bf16x3': 3, 'f16x3': 3}      # MFMA products executed per algorithmic fp32 product
 CONV_TRAFFIC_BYTES = 196.4e6       # HBM bytes per launch of the dominant kernel (both epilogue instantiations, launch-weighted): rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/r01_bench_c2_summary.md
 DOMINANT = 0                        # tile configuration id of conv_igemm_kernel<128,128,2,2>
 
@@ -77,7 +78,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel from the host instead of replaying the captured step')
-    ap.add_argument('--precision', default=None, choices=sorted(PRODUCTS), help='matrix-core arithmetic of the implicit GEMMs (default: library default, bf16x6)')
+    ap.add_argument('--precision', default=None, choices=sorted(PRODUCTS) + ['auto'],
+                    help="matrix-core arithmetic of the implicit GEMMs (default 'auto': f16x3 for the modulated convs, bf16x6 elsewhere)")
     ap.add_argument('--wplus', action='store_true')
     args = ap.parse_args()
 
@@ -90,7 +92,7 @@ def main():
     from inv3d_amd import synthetic as S, hipops as H
     if args.precision is not None:
         H.set_conv_precision(args.precision)
-    prec_name = {v: k for k, v in H.PRECISIONS.items()}[H.CONV_PRECISION]
+    prec_name = H.modconv_precision()          # arithmetic of the dominant kernel's launches
     from inv3d_amd.inversion import LatentProjector, psnr_01
 
     G = S.make_generator(device=dev)
@@ -158,10 +160,11 @@ def main():
             nprod = PRODUCTS[prec_name]
             peak = FP32_MFMA_PEAK_TFLOPS if prec_name == 'f32' else BF16_MFMA_PEAK_TFLOPS / nprod
             kern = ('conv_igemm_kernel<128,128,2,2,0,*> (v_mfma_f32_32x32x2_f32)' if prec_name == 'f32' else
-                    'conv_igemm_kernel<128,128,2,2,%d,*> (fp32 in/out, %d x v_mfma_f32_32x32x16_bf16 per fp32 product)' % (H.PRECISIONS[prec_name], nprod))
+                    'conv_igemm_kernel<128,128,2,2,%d,*> (fp32 in/out, %d x v_mfma_f32_32x32x16_%s per fp32 product)' % (
+                        H.PRECISIONS[prec_name], nprod, 'f16' if prec_name == 'f16x3' else 'bf16'))
             roof = dict(bound='mfma', kernel=kern, achieved=round(ach, 2),
                         peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4), traffic=CONV_TRAFFIC_BYTES,
-                        peak_basis=('fp32 matrix peak' if prec_name == 'f32' else 'dense bf16 matrix peak 2500 / %d products' % nprod),
+                        peak_basis=('fp32 matrix peak' if prec_name == 'f32' else 'dense 16-bit matrix peak 2500 / %d products' % nprod),
                         frac_of_fp32_mfma_peak=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), mfma_executed_tflops=round(ach * nprod, 1),
                         launches_per_step=dom['launches'] / args.steps, gflop_per_launch=round(dom['flops'] / dom['launches'] / 1e9, 3),
                         avg_launch_ms=round(dom['ms'] / dom['launches'], 4), timing=roofline_pass)
@@ -172,7 +175,9 @@ def main():
         ms = elapsed / args.steps * 1e3
         line = dict(metric='inversion-steps/sec (G fwd+bwd, 512^2 FFHQ EG3D) at 1/2/4/8 GPUs; final PSNR', value=round(world * args.steps / elapsed, 3),
                     unit='steps/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True,
-                    scaling='weak', vs_baseline=None, dtype='f32' if prec_name == 'f32' else 'f32 (%s split products, fp32-equivalent)' % prec_name if prec_name == 'bf16x6' else 'f32 storage, bf16x3 products (~2^-15)', data='synthetic',
+                    scaling='weak', vs_baseline=None, dtype={'f32': 'f32', 'bf16x6': 'f32 (bf16x6 split products, fp32-equivalent)',
+                           'f16x3': 'f32 (modulated convs: two-piece fp16 split, 3 products, range-normalised; other GEMMs bf16x6; fp32-equivalent)',
+                           'bf16x3': 'f32 storage, bf16x3 products (~2^-15)'}[prec_name], data='synthetic',
                     config=dict(workload='C2: FFHQ 512^2 single-image latent inversion step (Phase A, w%s + 17 noise buffers; G.synthesis fwd+bwd, '
                                          '128^2 x 96-sample rendering, stub-LPIPS feature distance + noise regulariser, Adam)' % ('+' if args.wplus else ''),
                                 images_per_gpu=1, generator='ffhqrebalanced512-128-shaped, 30.66 M params, random-init (synthetic weights)',

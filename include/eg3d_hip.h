@@ -99,8 +99,11 @@ typedef struct eg3d_conv_class {
  *   F32     v_mfma_f32_32x32x2_f32, exact fp32 products.
  *   BF16X6  each operand cut into 3 bf16 terms (x = b0+b1+b2, exact to 2^-24), six bf16 MFMA products accumulated in fp32;
  *           the dropped cross terms are < 2^-23 relative per product, i.e. fp32-equivalent (below fp32 accumulation error).
- *   BF16X3  three products (b0b0+b0b1+b1b0), relative error < 2^-15 per product (between TF32 and fp32). */
-enum { EG3D_PREC_F32 = 0, EG3D_PREC_BF16X6 = 1, EG3D_PREC_BF16X3 = 2 };
+ *   BF16X3  three products (b0b0+b0b1+b1b0), relative error < 2^-15 per product (between TF32 and fp32).
+ *   F16X3   each operand cut into 2 fp16 terms (x = h+l; residual <= max(2^-22 |x|, 2^-25)), three fp16 MFMA products (hh+hl+lh)
+ *           accumulated in fp32: fp32-like for operands of magnitude ~2^-4 .. 2^16; operands outside that range must be brought
+ *           into it by the caller with a power-of-two `a_scale` (the result is rescaled exactly). */
+enum { EG3D_PREC_F32 = 0, EG3D_PREC_BF16X6 = 1, EG3D_PREC_BF16X3 = 2, EG3D_PREC_F16X3 = 3 };
 
 typedef struct eg3d_conv_params {
     const float* x;            /* [N,Hi,Wi,ldx] NHWC, Ck used channels                   */
@@ -126,6 +129,9 @@ typedef struct eg3d_conv_params {
     const float* xin;          /* EPI_BWD: [N,Ho,Wo,ldo] layer input for the style-gradient reduction, or null */
     float* ds;                 /* EPI_BWD: [N,Nc] accumulated with atomics (pre-zeroed), or null */
     int32_t precision;         /* EG3D_PREC_*: how the fp32 products are formed on the matrix cores */
+    const float* a_amax;       /* F16X3 only, optional: device scalar max|x| of the A operand; the kernel multiplies A by the power of
+                                * two that brings a_amax * a_amax_mul to ~2^14 and divides the result by it (exact).  null = none. */
+    float a_amax_mul;
     int32_t ds_replicas;       /* EPI_BWD: ds is [ds_replicas][N,Nc]; workgroup b accumulates into replica b % ds_replicas so that
                                 * thousands of tiles do not serialise on the same N*Nc addresses; the caller sums the replicas.
                                 * 0 or 1 = a single [N,Nc] buffer. */
@@ -230,7 +236,8 @@ int eg3d_modconv_epilogue_bwd(const float* dout, const float* out, float* dz, in
                               const float* d, const float* noise, int64_t noise_nstride,
                               const float* noise_strength, const float* bias, int act, float alpha, float gain,
                               float clamp, float* dbias, float* dd, float* dnoise, int64_t dnoise_nstride,
-                              float* dstrength, void* stream);
+                              float* dstrength, float* dz_amax, void* stream);
+/* dz_amax (optional, pre-zeroed device scalar): receives max|dz| (atomic max) -- the operand range an F16X3 data-gradient conv needs. */
 
 /* Finish of a split-K data gradient (low-resolution layers, where one launch cannot fill 256 CUs without splitting K):
  *   z = conv data-gradient accumulated with EG3D_EPI_ATOMIC;  dx = z * s[n,c] (+ addend);  ds[n,c] += sum_px z * x  (if ds). */

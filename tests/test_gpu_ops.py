@@ -223,7 +223,7 @@ def test_conv2d_resample_golden(golden, ops):
 
 @pytest.mark.parametrize('shape', [(1, 32, 16, 16, 64, 1), (2, 64, 8, 8, 160, 1), (1, 128, 24, 24, 128, 3), (3, 16, 5, 7, 12, 3),
                                    (1, 512, 4, 4, 512, 3), (1, 256, 40, 40, 256, 3)])
-@pytest.mark.parametrize('prec,tol', [('f32', 2e-5), ('bf16x6', 2e-5), ('bf16x3', 3e-4)])
+@pytest.mark.parametrize('prec,tol', [('f32', 2e-5), ('bf16x6', 2e-5), ('f16x3', 2e-5), ('bf16x3', 3e-4)])
 def test_conv_igemm_vs_torch(shape, prec, tol):
     """All tile configurations / split-K / matrix-core arithmetic modes of the implicit GEMM vs F.conv2d evaluated in fp64.
     'bf16x6' (the default: six bf16 products per fp32 product) must meet the SAME bound as the exact-fp32 MFMA path."""
@@ -241,6 +241,35 @@ def test_conv_igemm_vs_torch(shape, prec, tol):
         H.conv_igemm(xc, wf, ci, co, out, H.classes_corr(h, w, k, k, k // 2), epi=L.EPI_ATOMIC if ks > 1 else L.EPI_STORE, ksplit=ks,
                      precision=prec)
         close(out[:, :co], ref, tol, f'conv_igemm {shape} ksplit {ks} {prec}')
+
+
+def test_conv_igemm_f16x3_range_normalisation():
+    """'f16x3' forms fp32 products from two fp16 pieces per operand: as accurate as the fp32 MFMA path for operands of ordinary
+    magnitude, and -- given max|A| (what epilogue_bwd reports for a gradient tensor) -- for tiny / huge operands as well."""
+    from inv3d_amd import hipops as H
+    g = torch.Generator().manual_seed(9)
+    n, ci, h, co = 1, 256, 16, 128
+    w = (torch.randn(co, ci, 3, 3, generator=g) / 48).to(DEV)
+    wf = H.pack_weight_fwd(w)
+    cls = H.classes_corr(h, h, 3, 3, 1)
+    for scale in (1.0, 3e-7, 2.5e6):
+        x = (torch.randn(n, ci, h, h, generator=g) * scale)
+        ref = torch.nn.functional.conv2d(x.double(), w.double().cpu(), padding=1)
+        xc = x.to(DEV).contiguous(memory_format=torch.channels_last)
+        amax = xc.abs().max().reshape(1)
+        err = {}
+        for name, kw in (('f32', dict(precision='f32')), ('f16x3', dict(precision='f16x3', a_amax=amax)),
+                         ('f16x3 with a 4x loose bound', dict(precision='f16x3', a_amax=amax / 4, a_amax_mul=16.0))):
+            out = H.zeros_cl(n, co, h, h, DEV)
+            H.conv_igemm(xc, wf, ci, co, out, cls, **kw)
+            err[name] = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
+        assert err['f16x3'] <= 2.0 * err['f32'] + 1e-7 and err['f16x3 with a 4x loose bound'] <= 4.0 * err['f32'] + 1e-7, (scale, err)
+    # the producer side: epilogue_bwd reports max|dz|
+    dout = torch.randn(1, 32, 8, 8, generator=g).to(DEV).contiguous(memory_format=torch.channels_last) * 1e-5
+    outv = torch.randn(1, 32, 8, 8, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    dz, am = torch.empty_like(dout), torch.zeros(1, device=DEV)
+    H.epilogue_bwd(dout, outv, dz, act='lrelu', alpha=0.2, gain=1.4, clamp=-1.0, dz_amax=am)
+    assert float(am) == float(dz.abs().max()) > 0
 
 
 def test_conv_igemm_split_bf16_is_fp32_equivalent():

@@ -17,7 +17,7 @@ def run(n, ci, co, h, k=3, iters=20, convT=False, check=False):
     if check and not convT:
         ref = torch.nn.functional.conv2d((x*s[:,:,None,None]).double(), w.double(), padding=k//2)
     line = f'N={n} {ci:4d}->{co:4d} @{h:4d}^2 k={k} convT={convT}:'
-    for prec in ('f32', 'bf16x6', 'bf16x3'):
+    for prec in ('f32', 'bf16x6', 'f16x3', 'bf16x3'):
         out = H.empty_cl(n, co, ho, wo, dev)
         f = lambda: H.conv_igemm(x, wf, ci, co, out, cls, in_scale=s, precision=prec, **kw)
         for _ in range(3): f()
