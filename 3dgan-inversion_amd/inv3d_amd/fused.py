@@ -298,10 +298,12 @@ class ToRGBFn(torch.autograd.Function):
             assert skip.shape[1] == Cp
         if clampv < 0 and skip is not None:
             out = H.empty_cl(N, Cp, Hh, Ww, x.device)
-            H.conv_igemm(x, wf, Ci, Cp, out, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=-1.0, addend=skip)
+            H.conv_igemm(x, wf, Ci, Cp, out, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=-1.0, addend=skip,
+                         precision=H.modconv_precision())
         else:
             y = H.empty_cl(N, Cp, Hh, Ww, x.device)
-            H.conv_igemm(x, wf, Ci, Cp, y, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=clampv)
+            H.conv_igemm(x, wf, Ci, Cp, y, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=clampv,
+                         precision=H.modconv_precision())
             out = y + skip if skip is not None else y
         ctx.save_for_backward(x, weight, styles, y if clampv >= 0 else None)
         ctx.cfg = (clampv, cache, want_wgrad, Cp, skip is not None)
