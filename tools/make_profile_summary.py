@@ -52,7 +52,7 @@ o = ['# rocprofv3 summary of `bench.py` (C2, N=1, default bf16x6 arithmetic, HIP
      '| kernel (one replayed step) | launches | ms | avg µs |\n|---|---:|---:|---:|']
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:26]:
     o.append(f'| `{k[:100]}` | {v[0]} | {v[1]/1e6:.3f} | {v[1]/v[0]/1e3:.1f} |')
-dom = next(r for r in rows if 'conv_igemm_kernel<128, 128, 2, 2, 1, true>' in r['Name'])
+dom = next(r for r in rows if 'conv_igemm_kernel<128, 128, 2, 2,' in r['Name'] and 'true>' in r['Name'])
 o.append(f'\nWhole-run `--stats` table ({ncalls} launches incl. set-up, warm-up and the eager roofline pass): `{prefix.split("/")[-1]}_kernel_stats.csv`. '
          f'Dominant kernel there: `{dom["Name"][:90]}` {dom["Calls"]} calls, average {float(dom["AverageNs"])/1e3:.1f} µs '
          f'(bench.py HIP events, un-profiled: {bench["roofline"]["avg_launch_ms"]*1e3:.1f} µs).\n')
@@ -66,7 +66,7 @@ for k in sorted(f, key=lambda k: -f[k][1])[:10]:
     o.append(f'| `{k[:90]}` | {f[k][0]} | {fr:.2f} | {2*fr:.2f} | {wr:.2f} | {2*fr+wr:.2f} |')
 open(prefix + '_summary.md', 'w').write('\n'.join(o) + '\n')
 shutil.copy(glob.glob(stats_dir + '/*_kernel_stats.csv')[0], prefix + '_kernel_stats.csv')
-dk = [k for k in f if 'conv_igemm_kernel<128, 128, 2, 2, 1, true>' in k]
+dk = [k for k in f if 'conv_igemm_kernel<128, 128, 2, 2, 3, true>' in k]
 if dk:
     k = dk[0]
     print('dominant kernel traffic MB/launch:', 2 * f[k][1] / f[k][0] / 1024 + w[k][1] / max(w[k][0], 1) / 1024)
