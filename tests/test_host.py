@@ -86,3 +86,43 @@ def test_schema_and_synthetic_inputs_match_oracle():
     assert set(full.state_dict()) == set(O.param_shapes(O.full_config()))
     assert sum(p.numel() for p in full.parameters()) == 30662136
     assert full.backbone.num_ws == 14
+
+
+def test_zero_arena_and_memo_host_logic():
+    """Host-side helpers of the step: ZeroArena (one zero-fill per step, sized by the previous step's demand, fallback when it does not
+    fit) and memo() (derived weight images keyed on storage + in-place version + object identity).  Pure host logic, CPU tensors."""
+    import torch
+    from inv3d_amd import hipops as H
+    arena = H.ZeroArena(torch.device('cpu'))
+    shapes = [(3, 5), (1, 8, 4, 4), (70,)]
+    for step in range(3):
+        with H.zero_arena(arena):
+            outs = [H.zeros(shapes[0], 'cpu'), H.zeros_cl(*shapes[1], 'cpu'), H.zeros(shapes[2], 'cpu')]
+            for t, sh in zip(outs, shapes):
+                assert tuple(t.shape) == sh and float(t.abs().sum()) == 0.0
+                t += 1.0                                           # dirty it: the next step must see zeros again
+            assert outs[1].is_contiguous(memory_format=torch.channels_last)
+            if step == 0:
+                assert arena.buf is None                           # nothing known yet: plain torch.zeros
+            else:
+                base = arena.buf.data_ptr()
+                assert all(base <= t.data_ptr() < base + arena.buf.numel() * 4 for t in outs)
+                assert outs[0].data_ptr() % 256 == outs[2].data_ptr() % 256 == base % 256      # 256-byte granules
+        assert arena.prev_demand == 64 + 128 + 128
+    assert H.ARENA is None
+    with H.zero_arena(arena):
+        big = H.zeros((4096,), 'cpu')                              # does not fit: falls back, arena grows for the next step
+        assert arena.buf is None or not (arena.buf.data_ptr() <= big.data_ptr() < arena.buf.data_ptr() + arena.buf.numel() * 4)
+    assert arena.prev_demand >= 4096
+
+    calls = []
+    w = torch.arange(6.).reshape(2, 3)
+    f = lambda: (calls.append(1), w * 2)[1]
+    a = H.memo('t', [w], f); b = H.memo('t', [w], f)
+    assert a is b and len(calls) == 1
+    w.add_(1.0)                                                    # in-place update bumps the version -> recompute
+    c = H.memo('t', [w], f)
+    assert len(calls) == 2 and torch.equal(c, w * 2)
+    w2 = w.clone()
+    H.memo('t', [w2], lambda: (calls.append(1), w2 * 2)[1])
+    assert len(calls) == 3                                         # a different tensor object never hits another one's entry
