@@ -91,6 +91,63 @@ __global__ void __launch_bounds__(256) epilogue_fwd_kernel(const float* __restri
     }
 }
 
+// 4x4 FIR + demod + noise + bias + activation with a 2x2 output block per thread: the four outputs share a 5x5 input patch, i.e. 25
+// sixteen-byte loads instead of 64 (the one-output kernel above is bound by the texture/L1 path: 16 loads per 16 bytes of output).
+__global__ void __launch_bounds__(256) epilogue_fwd_fir44_kernel(const float* __restrict__ z, float* __restrict__ out, int N, int H, int W, int C4,
+                                                                 int Hz, int Wz, const float* __restrict__ fir, int pad0, float fir_gain,
+                                                                 const float* __restrict__ d, const float* __restrict__ noise, int64_t noise_nstride,
+                                                                 const float* __restrict__ noise_strength, const float* __restrict__ bias, int act,
+                                                                 float alpha, float gain, float clamp) {
+    __shared__ float fs[16];
+    if (threadIdx.x < 16) fs[threadIdx.x] = fir[(3 - threadIdx.x / 4) * 4 + (3 - threadIdx.x % 4)] * fir_gain;      // true convolution
+    __syncthreads();
+    const float strength = noise ? *noise_strength : 0.f;
+    const int C = C4 * 4, H2 = H / 2, W2 = W / 2;
+    const int64_t total = (int64_t)N * H2 * W2 * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        int64_t r = i / C4;
+        const int x0 = (int)(r % W2) * 2; r /= W2;
+        const int y0 = (int)(r % H2) * 2;
+        const int n = (int)(r / H2);
+        float4 t[25];
+#pragma unroll
+        for (int k = 0; k < 25; ++k) {
+            const int iy = y0 - pad0 + k / 5, ix = x0 - pad0 + k % 5;
+            const bool ok = (unsigned)iy < (unsigned)Hz && (unsigned)ix < (unsigned)Wz;
+            t[k] = ld4(z + ((int64_t)(n * Hz + (ok ? iy : 0)) * Wz + (ok ? ix : 0)) * C + c);
+            if (!ok) t[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 dv = make_float4(1.f, 1.f, 1.f, 1.f), bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d != nullptr) dv = ld4(d + (int64_t)n * C + c);
+        if (bias != nullptr) bv = ld4(bias + c);
+#pragma unroll
+        for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+            for (int ox = 0; ox < 2; ++ox) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) {
+                        const float wgt = fs[ky * 4 + kx];
+                        const float4 q = t[(oy + ky) * 5 + ox + kx];
+                        v.x += wgt * q.x; v.y += wgt * q.y; v.z += wgt * q.z; v.w += wgt * q.w;
+                    }
+                const int y = y0 + oy, x = x0 + ox;
+                v.x *= dv.x; v.y *= dv.y; v.z *= dv.z; v.w *= dv.w;
+                if (noise != nullptr) {
+                    const float nz = noise[(int64_t)n * noise_nstride + (int64_t)y * W + x] * strength;
+                    v.x += nz; v.y += nz; v.z += nz; v.w += nz;
+                }
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                v.x = act1(v.x, act, alpha, gain, clamp); v.y = act1(v.y, act, alpha, gain, clamp);
+                v.z = act1(v.z, act, alpha, gain, clamp); v.w = act1(v.w, act, alpha, gain, clamp);
+                st4(out + (((int64_t)n * H + y) * W + x) * C + c, v);
+            }
+    }
+}
+
 // derivative factor and recovered pre-activation for one element
 __device__ __forceinline__ void bwd1(float dout, float o, int act, float alpha, float gain, float clamp, float& dy, float& pre) {
     float yy = o / gain;
@@ -332,6 +389,14 @@ extern "C" int eg3d_modconv_epilogue_fwd(const float* z, float* out, int N, int 
     if (fir && (H != Hz + 2 * pad0 - fh + 1 || W != Wz + 2 * pad0 - fw + 1)) return EG3D_ERR_INVALID;
     if (!fir && (Hz != H || Wz != W)) return EG3D_ERR_INVALID;
     if (noise && !noise_strength) return EG3D_ERR_INVALID;
+    if (fir != nullptr && fh == 4 && fw == 4 && !(H & 1) && !(W & 1)) {
+        const int64_t total4 = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
+        const int blocks4 = (int)std::min<int64_t>(eg3d_cdiv(total4, 256), 256 * 16);
+        hipLaunchKernelGGL(epilogue_fwd_fir44_kernel, dim3(blocks4), dim3(256), 0, (hipStream_t)stream, z, out, N, H, W, C / 4, Hz, Wz, fir, pad0,
+                           fir_gain, d, noise, noise_nstride, noise_strength, bias, act, alpha, gain, clamp);
+        EG3D_LAUNCH_CHECK();
+        return EG3D_OK;
+    }
     const int64_t total = (int64_t)N * H * W * (C / 4);
     int blocks = (int)std::min<int64_t>(eg3d_cdiv(total, 256), 256 * 16);
     hipLaunchKernelGGL(epilogue_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, out, N, H, W, C / 4, Hz, Wz, fir, fh, fw, pad0,

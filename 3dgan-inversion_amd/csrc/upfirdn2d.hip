@@ -104,6 +104,56 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc4(const float* __restrict__
     }
 }
 
+// plain 4x4 FIR (up = down = 1), 2x2 outputs per thread sharing a 5x5 input patch: 25 sixteen-byte loads per 4 outputs instead of 64
+__global__ void __launch_bounds__(256) upfirdn2d_nhwc4_fir44(const float* __restrict__ x, const float* __restrict__ f, float* __restrict__ y, int N, int C4,
+                                                             int inH, int inW, int outH, int outW, int padx0, int pady0, int flip, float gain,
+                                                             int accumulate) {
+    __shared__ float fs[16];
+    if (threadIdx.x < 16) {
+        const int ky = threadIdx.x / 4, kx = threadIdx.x % 4;
+        fs[threadIdx.x] = f[(flip ? ky : 3 - ky) * 4 + (flip ? kx : 3 - kx)] * gain;
+    }
+    __syncthreads();
+    const int H2 = (outH + 1) / 2, W2 = (outW + 1) / 2;
+    const int64_t total = (int64_t)N * H2 * W2 * C4;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    float4* y4 = reinterpret_cast<float4*>(y);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        int64_t r = i / C4;
+        const int ox0 = (int)(r % W2) * 2; r /= W2;
+        const int oy0 = (int)(r % H2) * 2;
+        const int n = (int)(r / H2);
+        float4 t[25];
+#pragma unroll
+        for (int k = 0; k < 25; ++k) {
+            const int iy = oy0 - pady0 + k / 5, ix = ox0 - padx0 + k % 5;
+            const bool ok = (unsigned)iy < (unsigned)inH && (unsigned)ix < (unsigned)inW;
+            t[k] = x4[((int64_t)(n * inH + (ok ? iy : 0)) * inW + (ok ? ix : 0)) * C4 + c];
+            if (!ok) t[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int oy = oy0 + dy, ox = ox0 + dx;
+                if (oy >= outH || ox >= outW) continue;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) {
+                        const float w = fs[ky * 4 + kx];
+                        const float4 v = t[(dy + ky) * 5 + dx + kx];
+                        acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+                    }
+                const int64_t o = (((int64_t)n * outH + oy) * outW + ox) * C4 + c;
+                if (accumulate) { const float4 p = y4[o]; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
+                y4[o] = acc;
+            }
+    }
+}
+
 }  // namespace
 
 extern "C" int eg3d_upfirdn2d(const void* x, const float* f, void* y, int dtype, int N, int C, int inH, int inW, const int64_t xs[4],
@@ -146,6 +196,14 @@ extern "C" int eg3d_upfirdn2d_nhwc(const float* x, const float* f, float* y, int
     if (C % 4 != 0 || fH * fW > 64) return EG3D_ERR_UNSUPPORTED;
     if (outW != (inW * up + padx0 + padx1 - fW + down) / down || outH != (inH * up + pady0 + pady1 - fH + down) / down)
         return EG3D_ERR_INVALID;
+    if (up == 1 && down == 1 && fH == 4 && fW == 4) {
+        const int64_t total4 = (int64_t)N * ((outH + 1) / 2) * ((outW + 1) / 2) * (C / 4);
+        const int blocks4 = (int)std::min<int64_t>(eg3d_cdiv(total4, 256), 256 * 16);
+        hipLaunchKernelGGL(upfirdn2d_nhwc4_fir44, dim3(blocks4), dim3(256), 0, (hipStream_t)stream, x, f, y, N, C / 4, inH, inW, outH, outW, padx0,
+                           pady0, flip, gain, accumulate);
+        EG3D_LAUNCH_CHECK();
+        return EG3D_OK;
+    }
     const int64_t total = (int64_t)N * outH * outW * (C / 4);
     int blocks = (int)std::min<int64_t>(eg3d_cdiv(total, 256), 256 * 16);
     hipLaunchKernelGGL(upfirdn2d_nhwc4, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, f, y, N, C / 4, inH, inW, outH, outW, fH,
