@@ -121,6 +121,43 @@ __global__ void __launch_bounds__(NT) noise_normalize_kernel(const NoiseBufs B) 
     for (int i = threadIdx.x; i < n; i += NT) x[i] = (x[i] - mean) * inv;
 }
 
+// Multi-block form of the renormalisation (the 256^2 / 512^2 buffers of the SR head make the one-block-per-buffer kernel above a
+// 110 us serial tail of every step): pass 1 accumulates sum(x) and sum(x^2) per buffer with one atomic pair per block, pass 2 applies
+// (x - mean) * rsqrt(E[x^2] - mean^2)  ==  the reference's  buf -= mean; buf *= rsqrt(mean(buf^2))  (w_projector.py:264-270).
+constexpr int NORM_CHUNK = NT * 8;            // elements per block
+
+__device__ __forceinline__ bool norm_locate(const NoiseBufs& B, int blk, int& buf, int& start, int& n) {
+    int b0 = 0;
+    for (buf = 0; buf < B.n; ++buf) {
+        n = B.res[buf] * B.res[buf];
+        const int nb = (n + NORM_CHUNK - 1) / NORM_CHUNK;
+        if (blk < b0 + nb) { start = (blk - b0) * NORM_CHUNK; return true; }
+        b0 += nb;
+    }
+    return false;
+}
+
+__global__ void __launch_bounds__(NT) noise_moments_kernel(const NoiseBufs B, float* __restrict__ ws) {
+    __shared__ float red[32];
+    int buf, start, n;
+    if (!norm_locate(B, blockIdx.x, buf, start, n)) return;
+    const float* x = B.x[buf];
+    float s = 0.f, q = 0.f;
+    for (int i = start + threadIdx.x; i < min(n, start + NORM_CHUNK); i += NT) { const float v = x[i]; s += v; q += v * v; }
+    s = block_sum(s, red);
+    q = block_sum(q, red);
+    if (threadIdx.x == 0) { unsafeAtomicAdd(ws + 2 * buf, s); unsafeAtomicAdd(ws + 2 * buf + 1, q); }
+}
+
+__global__ void __launch_bounds__(NT) noise_apply_norm_kernel(const NoiseBufs B, const float* __restrict__ ws) {
+    int buf, start, n;
+    if (!norm_locate(B, blockIdx.x, buf, start, n)) return;
+    float* x = B.x[buf];
+    const float mean = ws[2 * buf] / (float)n;
+    const float inv = 1.0f / sqrtf(ws[2 * buf + 1] / (float)n - mean * mean);
+    for (int i = start + threadIdx.x; i < min(n, start + NORM_CHUNK); i += NT) x[i] = (x[i] - mean) * inv;
+}
+
 int fill(NoiseBufs& B, float* const* x, float* const* g, const int32_t* res, int nbufs) {
     if (!x || !res || nbufs < 1 || nbufs > MAXB) return EG3D_ERR_INVALID;
     B.n = nbufs;
@@ -158,11 +195,18 @@ extern "C" int eg3d_noise_regularizer(float* const* x, float* const* grad, const
     return EG3D_OK;
 }
 
-extern "C" int eg3d_noise_normalize(float* const* x, const int32_t* res, int nbufs, void* stream) {
+extern "C" int eg3d_noise_normalize(float* const* x, const int32_t* res, int nbufs, float* workspace, void* stream) {
     NoiseBufs B;
     int rc = fill(B, x, nullptr, res, nbufs);
     if (rc) return rc;
-    hipLaunchKernelGGL(noise_normalize_kernel, dim3(nbufs), dim3(NT), 0, (hipStream_t)stream, B);
+    if (workspace == nullptr) {               // one block per buffer, no scratch
+        hipLaunchKernelGGL(noise_normalize_kernel, dim3(nbufs), dim3(NT), 0, (hipStream_t)stream, B);
+    } else {                                  // workspace: 2 * nbufs floats, zeroed by the caller
+        int blocks = 0;
+        for (int i = 0; i < nbufs; ++i) blocks += eg3d_cdiv((int64_t)res[i] * res[i], NORM_CHUNK);
+        hipLaunchKernelGGL(noise_moments_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, B, workspace);
+        hipLaunchKernelGGL(noise_apply_norm_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, B, workspace);
+    }
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -114,7 +114,7 @@ _SIGS = {
     'eg3d_noise_reg_workspace_floats': (C.c_int64, [C.POINTER(C.c_int32), C.c_int]),
     'eg3d_noise_regularizer': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_float, C.c_void_p]),
-    'eg3d_noise_normalize': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
+    'eg3d_noise_normalize': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_void_p]),
     'eg3d_rows_gram': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'eg3d_filtered_lrelu': (C.c_int, [C.POINTER(FlreluParams), C.c_void_p]),
     'eg3d_style_affine_fwd': (C.c_int, [C.POINTER(StyleBank), C.c_void_p]),

@@ -573,4 +573,5 @@ def noise_regularizer(bufs, scale=1.0, want_grad=True):
 
 def noise_normalize_(bufs):
     n, xs, res = _buf_arrays(bufs)
-    L.check(L.lib().eg3d_noise_normalize(xs, res, n, L.stream_ptr()), 'noise_normalize')
+    ws = zeros((2 * n,), bufs[0].device)          # per-buffer (sum, sum of squares): multi-block path
+    L.check(L.lib().eg3d_noise_normalize(xs, res, n, L.ptr(ws), L.stream_ptr()), 'noise_normalize')

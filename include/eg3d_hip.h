@@ -269,12 +269,13 @@ int eg3d_demod_bwd(const float* s, const float* wsq, const float* d, const float
  * buffers (res a power of two), nbufs <= 32.
  *   regularizer: *reg_out = scale * sum_buffers sum_levels (mean(x*roll(x,1,W))^2 + mean(x*roll(x,1,H))^2) over the avg-pool
  *                pyramid res, res/2, ... (last level <= 8); grad[i] (may be null / contain nulls) = d(*reg_out)/d x[i].
- *   normalize:   x <- (x - mean(x)) * rsqrt(mean((x - mean)^2))   in place.
+ *   normalize:   x <- (x - mean(x)) * rsqrt(mean((x - mean)^2))   in place.  workspace: 2*nbufs zeroed floats -> two multi-block
+ *                launches (moments, apply); null -> one block per buffer in a single launch.
  */
 int64_t eg3d_noise_reg_workspace_floats(const int32_t* res, int nbufs);
 int eg3d_noise_regularizer(float* const* x, float* const* grad, const int32_t* res, int nbufs, float* workspace,
                            float* reg_out, float scale, void* stream);
-int eg3d_noise_normalize(float* const* x, const int32_t* res, int nbufs, void* stream);
+int eg3d_noise_normalize(float* const* x, const int32_t* res, int nbufs, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Volume renderer -- replaces RaySampler.forward (training/volumetric_rendering/ray_sampler.py:24-73) and
