@@ -51,17 +51,77 @@ __global__ void __launch_bounds__(256) style_affine_fwd_kernel(const eg3d_style_
     }
 }
 
+// demodulation coefficients of every conv layer of the bank: one wave per (layer, n, o)
+__global__ void __launch_bounds__(256) style_demod_fwd_kernel(const eg3d_style_bank b) {
+    int blk = blockIdx.x, l = 0;
+    for (; l < b.nlayers; ++l) {
+        const int nb = b.layers[l].wsq ? (b.N * b.layers[l].Co + 3) / 4 : 0;
+        if (blk < nb) break;
+        blk -= nb;
+    }
+    if (l >= b.nlayers) return;
+    const eg3d_style_layer& ly = b.layers[l];
+    const int wid = blk * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wid >= b.N * ly.Co) return;
+    const int n = wid / ly.Co, o = wid - n * ly.Co;
+    const float* s = ly.out + (int64_t)n * ly.C;
+    const float* wq = ly.wsq + (int64_t)o * ly.C;
+    float acc = 0.f;
+    for (int k = lane; k < ly.C; k += 64) { const float sv = s[k]; acc += sv * sv * wq[k]; }
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+    if (lane == 0) ly.d[wid] = 1.0f / sqrtf(acc + 1e-8f);
+}
+
+// dout_extra[n,k] += -s[n,k] * sum_o dd[n,o] d[n,o]^3 wsq[o,k]:  block = 64 k-columns x 4 o-slices, (k-chunk, n, o-split) per layer
+__global__ void __launch_bounds__(256) style_demod_bwd_kernel(const eg3d_style_bank b) {
+    __shared__ float part[4][64];
+    int blk = blockIdx.x, l = 0, osplit = 1, kchunks = 1;
+    for (; l < b.nlayers; ++l) {
+        const eg3d_style_layer& q = b.layers[l];
+        int nb = 0;
+        if (q.dd != nullptr && q.wsq != nullptr) {
+            osplit = max(1, min(q.Co / 16, 16));
+            kchunks = (q.C + 63) / 64;
+            nb = kchunks * b.N * osplit;
+        }
+        if (blk < nb) break;
+        blk -= nb;
+    }
+    if (l >= b.nlayers) return;
+    const eg3d_style_layer& ly = b.layers[l];
+    const int kc = blk % kchunks, n = (blk / kchunks) % b.N, oz = blk / (kchunks * b.N);
+    const int k = kc * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    const int per = (ly.Co + osplit - 1) / osplit;
+    const int o_beg = oz * per, o_end = min(ly.Co, o_beg + per);
+    float acc = 0.f;
+    if (k < ly.C) {
+        for (int o = o_beg + sl; o < o_end; o += 4) {
+            const float dv = ly.d[(int64_t)n * ly.Co + o];
+            acc = fmaf(ly.dd[(int64_t)n * ly.Co + o] * dv * dv * dv, ly.wsq[(int64_t)o * ly.C + k], acc);
+        }
+    }
+    part[sl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (sl == 0 && k < ly.C) {
+        const float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        unsafeAtomicAdd(ly.dout_extra + (int64_t)n * ly.C + k, -ly.out[(int64_t)n * ly.C + k] * t);
+    }
+}
+
 __global__ void __launch_bounds__(128) style_affine_bwd_kernel(const eg3d_style_bank b) {
     int row0;
     const int l = find_layer(b, blockIdx.x, ROWS_PER_BLOCK_BWD, row0);
     if (l >= b.nlayers) return;
     const eg3d_style_layer& ly = b.layers[l];
-    if (ly.dout == nullptr) return;
+    if (ly.dout == nullptr && ly.dout_extra == nullptr) return;
     const int rows = min(ROWS_PER_BLOCK_BWD, ly.C - row0);
     __shared__ float coef[ROWS_PER_BLOCK_BWD];
     for (int n = 0; n < b.N; ++n) {
         __syncthreads();
-        if (threadIdx.x < rows) coef[threadIdx.x] = ly.dout[(int64_t)n * ly.C + row0 + threadIdx.x] * ly.post;
+        if (threadIdx.x < rows) {
+            const int64_t j = (int64_t)n * ly.C + row0 + threadIdx.x;
+            coef[threadIdx.x] = ((ly.dout ? ly.dout[j] : 0.f) + (ly.dout_extra ? ly.dout_extra[j] : 0.f)) * ly.post;
+        }
         __syncthreads();
         float* dst = b.dws + ((int64_t)n * b.L + ly.wrow) * b.D;
         for (int k = threadIdx.x * 4; k < b.D; k += 512) {
@@ -108,12 +168,30 @@ int total_tiles(const eg3d_style_bank& b, int rows_per_block) {
 extern "C" int eg3d_style_affine_fwd(const eg3d_style_bank* pb, void* stream) {
     if (int rc = check_bank(pb, false)) return rc;
     hipLaunchKernelGGL(style_affine_fwd_kernel, dim3(total_tiles(*pb, ROWS_PER_BLOCK_FWD)), dim3(256), 0, (hipStream_t)stream, *pb);
+    int dblocks = 0;
+    for (int l = 0; l < pb->nlayers; ++l) {
+        const eg3d_style_layer& ly = pb->layers[l];
+        if (ly.wsq != nullptr) {
+            if (ly.Co < 1 || ly.d == nullptr) return EG3D_ERR_INVALID;
+            dblocks += (pb->N * ly.Co + 3) / 4;
+        }
+    }
+    if (dblocks > 0) hipLaunchKernelGGL(style_demod_fwd_kernel, dim3(dblocks), dim3(256), 0, (hipStream_t)stream, *pb);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }
 
 extern "C" int eg3d_style_affine_bwd(const eg3d_style_bank* pb, void* stream) {
     if (int rc = check_bank(pb, true)) return rc;
+    int dblocks = 0;
+    for (int l = 0; l < pb->nlayers; ++l) {
+        const eg3d_style_layer& ly = pb->layers[l];
+        if (ly.dd != nullptr && ly.wsq != nullptr) {
+            if (ly.Co < 1 || ly.d == nullptr || ly.dout_extra == nullptr || ly.out == nullptr) return EG3D_ERR_INVALID;
+            dblocks += ((ly.C + 63) / 64) * pb->N * std::max(1, std::min(ly.Co / 16, 16));
+        }
+    }
+    if (dblocks > 0) hipLaunchKernelGGL(style_demod_bwd_kernel, dim3(dblocks), dim3(256), 0, (hipStream_t)stream, *pb);
     hipLaunchKernelGGL(style_affine_bwd_kernel, dim3(total_tiles(*pb, ROWS_PER_BLOCK_BWD)), dim3(128), 0, (hipStream_t)stream, *pb);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;

@@ -107,15 +107,16 @@ def _auto_ksplit(classes, N, Nc, Ck):
 
 class ModConvLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, styles, noise, noise_strength, bias, up, act_gain, clamp, cache, want_wgrad):
+    def forward(ctx, x, weight, styles, noise, noise_strength, bias, up, act_gain, clamp, cache, want_wgrad, d_in=None):
         # x: CL [N,Ci,H,W]; weight [Co,Ci,3,3]; styles [N,Ci]; noise None | [res,res] | [N,1,res,res]; noise_strength 0-d
+        # d_in: the demodulation coefficients [N,Co] when the style bank already computed them (their gradient is then returned)
         L.require_cuda(x, weight, styles)
         x = H.to_cl(x.float())
         styles = styles.contiguous().float()
         N, Ci, Hi, Wi = x.shape
         Co, _, kh, kw = weight.shape
         wf, wa, wsq = cache.get(weight)
-        d = H.demod_fwd(styles, wsq)
+        d = d_in.contiguous().float() if d_in is not None else H.demod_fwd(styles, wsq)
         Ho, Wo = Hi * up, Wi * up
         nz = nstride = None
         if noise is not None:
@@ -150,13 +151,13 @@ class ModConvLayerFn(torch.autograd.Function):
             H.epilogue_fwd(z, out, fir=fir44(x.device), pad0=1, fir_gain=float(up * up), d=d, noise=nz, noise_nstride=nstride or 0,
                            noise_strength=noise_strength, bias=b, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv)
         ctx.save_for_backward(x, weight, styles, d, out, nz, noise_strength, b)
-        ctx.cfg = (up, act_gain, clampv, nstride, cache, want_wgrad, noise is not None and noise.dim() == 4)
+        ctx.cfg = (up, act_gain, clampv, nstride, cache, want_wgrad, noise is not None and noise.dim() == 4, d_in is not None)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, weight, styles, d, out, nz, noise_strength, b = ctx.saved_tensors
-        up, act_gain, clampv, nstride, cache, want_wgrad, noise4d = ctx.cfg
+        up, act_gain, clampv, nstride, cache, want_wgrad, noise4d, d_given = ctx.cfg
         need_x, need_w, need_s, need_nz, need_ns, need_b = ctx.needs_input_grad[:6]
         need_w = need_w and want_wgrad
         dout = H.to_cl(dout.float())
@@ -209,7 +210,7 @@ class ModConvLayerFn(torch.autograd.Function):
                              a_amax_mul=amul)
                 H.dgrad_finish(z, x, styles, dx, ds=ds)
         dwsq = torch.zeros_like(wsq) if need_w else None
-        if dd is not None and (need_s or need_w):
+        if dd is not None and (need_s or need_w) and not d_given:       # with d from the style bank, dd is returned and handled there
             if ds is None:
                 ds = H.zeros((N, Ci), dev)
             H.demod_bwd(styles, wsq, d, dd, ds=ds if need_s else None, dwsq=dwsq)
@@ -220,54 +221,88 @@ class ModConvLayerFn(torch.autograd.Function):
             dweight = dwp.view(Co, kh, kw, Ci).permute(0, 3, 1, 2) + 2.0 * weight * dwsq[:, :, None, None]
         if dnoise is not None and noise4d:
             dnoise = dnoise.view(N, 1, Ho, Wo)
-        return (dx if need_x else None, dweight, ds if need_s else None, dnoise, dstrength, dbias, None, None, None, None, None)
+        return (dx if need_x else None, dweight, ds if need_s else None, dnoise, dstrength, dbias, None, None, None, None, None,
+                dd if d_given else None)
 
 
 class StyleBankFn(torch.autograd.Function):
-    """styles of all modulated layers of a network from one launch (eg3d_style_affine_fwd/_bwd).  apply(ws, plan, *weights_and_biases)
-    -> tuple of [N, C_l] tensors; plan = tuple of (wrow, wgain, bgain, post, has_bias) per layer.  Gradients flow to ws only (the
-    affines are frozen on this path: the callers fall back to the per-layer modules when an affine parameter requires grad)."""
+    """Styles -- and, for the conv layers, demodulation coefficients -- of all modulated layers of a network from two launches
+    (eg3d_style_affine_fwd/_bwd).  apply(ws, plan, *weights_and_biases) -> tuple: the L styles [N, C_l], then one d [N, Co_l] per
+    layer whose plan entry carries wsq.  plan = tuple of (wrow, wgain, bgain, post, has_bias, wsq | None) per layer.  Gradients flow
+    to ws only (the affines and conv weights are frozen on this path: callers fall back to the per-layer modules otherwise)."""
 
     @staticmethod
     def forward(ctx, ws, plan, *params):
         L.require_cuda(ws)
         ws = ws.contiguous().float()
         N = ws.shape[0]
-        layers, pi = [], 0
-        for wrow, wgain, bgain, post, has_bias in plan:
+        layers, wsqs, pi = [], [], 0
+        for wrow, wgain, bgain, post, has_bias, wsq in plan:
             w = params[pi].detach().contiguous().float()
             b = params[pi + 1].detach().contiguous().float() if has_bias else None
             pi += 2 if has_bias else 1
             layers.append((w, b, wrow, wgain, bgain, post))
+            wsqs.append(wsq)
         outs = tuple(torch.empty((N, ly[0].shape[0]), device=ws.device) for ly in layers)
-        H.style_affine(ws, layers, outs=outs)
-        ctx.layers, ctx.ws = layers, ws
-        return outs
+        ds = [torch.empty((N, q.shape[0]), device=ws.device) if q is not None else None for q in wsqs]
+        H.style_affine(ws, layers, outs=outs, demod=[(q, d, None, None) if q is not None else None for q, d in zip(wsqs, ds)])
+        ctx.layers, ctx.ws, ctx.wsqs = layers, ws, wsqs
+        ctx.save_for_backward(*outs, *[d for d in ds if d is not None])
+        return outs + tuple(d for d in ds if d is not None)
 
     @staticmethod
-    def backward(ctx, *douts):
+    def backward(ctx, *grads):
+        nl = len(ctx.layers)
+        saved = ctx.saved_tensors
+        outs, dsaved = saved[:nl], list(saved[nl:])
         dws = None
         if ctx.needs_input_grad[0]:
-            dws = H.zeros(ctx.ws.shape, ctx.ws.device)
-            douts = [d.contiguous().float() if d is not None else None for d in douts]
-            H.style_affine(ctx.ws, ctx.layers, douts=douts, dws=dws)
+            dev = ctx.ws.device
+            dws = H.zeros(ctx.ws.shape, dev)
+            douts = [g.contiguous().float() if g is not None else None for g in grads[:nl]]
+            dds = [g.contiguous().float() if g is not None else None for g in grads[nl:]]
+            demod, di = [], 0
+            extra_shapes = [tuple(o.shape) if q is not None else None for o, q in zip(outs, ctx.wsqs)]
+            extras = _zeros_views(dev, *extra_shapes)
+            for q, ex in zip(ctx.wsqs, extras):
+                if q is None:
+                    demod.append(None)
+                else:
+                    demod.append((q, dsaved[di], dds[di], ex))
+                    di += 1
+            H.style_affine(ctx.ws, ctx.layers, outs=outs, douts=douts, dws=dws, demod=demod, backward=True)
         return (dws, None) + (None,) * sum(2 if ly[1] is not None else 1 for ly in ctx.layers)
 
 
 def style_bank(ws, entries):
-    """entries: list of (FullyConnectedLayer affine, ws row index, post scale).  Returns the list of styles, or None when the bank
-    does not apply (an affine parameter requires grad, non-linear activation, too many layers)."""
+    """entries: list of (FullyConnectedLayer affine, ws row index, post scale, conv layer | None).  Returns (styles, demods) -- two
+    lists aligned with `entries` (demods[i] is None for layers without demodulation) -- or None when the bank does not apply (an
+    affine or conv weight requires grad, non-linear activation, too many layers)."""
     if len(entries) > L.STYLE_BANK_MAX or not ws.is_cuda:
         return None
     plan, params = [], []
-    for fc, wrow, post in entries:
+    for fc, wrow, post, conv in entries:
         if fc.activation != 'linear' or fc.weight.requires_grad or (fc.bias is not None and fc.bias.requires_grad):
             return None
-        plan.append((int(wrow), float(fc.weight_gain), float(fc.bias_gain), float(post), fc.bias is not None))
+        wsq = None
+        if conv is not None:
+            if conv.weight.requires_grad:
+                return None
+            wsq = conv._cache.get(conv.weight)[2]
+        plan.append((int(wrow), float(fc.weight_gain), float(fc.bias_gain), float(post), fc.bias is not None, wsq))
         params.append(fc.weight)
         if fc.bias is not None:
             params.append(fc.bias)
-    return list(StyleBankFn.apply(ws, tuple(plan), *params))
+    res = list(StyleBankFn.apply(ws, tuple(plan), *params))
+    styles, rest = res[:len(entries)], res[len(entries):]
+    demods, di = [], 0
+    for e in entries:
+        if e[3] is not None:
+            demods.append(rest[di])
+            di += 1
+        else:
+            demods.append(None)
+    return styles, demods
 
 
 class ToRGBFn(torch.autograd.Function):

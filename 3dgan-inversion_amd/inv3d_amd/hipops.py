@@ -406,9 +406,10 @@ def rows_gram(a, b):
     return out, cs
 
 
-def style_affine(ws, layers, outs=None, douts=None, dws=None):
-    """eg3d_style_affine_fwd (outs given) / _bwd (douts + dws given).  ws: [N,L,D] contiguous fp32;
-    layers: sequence of (weight [C,D], bias [C] | None, wrow, wgain, bgain, post)."""
+def style_affine(ws, layers, outs=None, douts=None, dws=None, demod=None, backward=False):
+    """eg3d_style_affine_fwd / _bwd.  ws: [N,L,D] contiguous fp32; layers: sequence of (weight [C,D], bias [C] | None, wrow, wgain,
+    bgain, post); outs: per-layer [N,C] styles (written by fwd, read by bwd); demod: per layer None or (wsq [Co,C], d [N,Co],
+    dd [N,Co] | None, dout_extra [N,C] | None) -- the demodulation coefficients of the layer's conv and their backward."""
     assert ws.is_contiguous() and ws.dtype == torch.float32 and len(layers) <= L.STYLE_BANK_MAX
     b = L.StyleBank()
     b.ws, b.N, b.L, b.D, b.nlayers = ws.data_ptr(), ws.shape[0], ws.shape[1], ws.shape[2], len(layers)
@@ -420,7 +421,14 @@ def style_affine(ws, layers, outs=None, douts=None, dws=None):
         ly.C, ly.wrow, ly.wgain, ly.bgain, ly.post = w.shape[0], int(wrow), float(wgain), float(bgain), float(post)
         ly.out = outs[i].data_ptr() if outs is not None else None
         ly.dout = douts[i].data_ptr() if (douts is not None and douts[i] is not None) else None
-    fn = L.lib().eg3d_style_affine_fwd if outs is not None else L.lib().eg3d_style_affine_bwd
+        dm = demod[i] if demod is not None else None
+        if dm is not None:
+            wsq, d, dd, extra = dm
+            assert wsq.is_contiguous() and wsq.shape[1] == w.shape[0]
+            ly.Co, ly.wsq, ly.d = wsq.shape[0], wsq.data_ptr(), d.data_ptr()
+            ly.dd = dd.data_ptr() if dd is not None else None
+            ly.dout_extra = extra.data_ptr() if extra is not None else None
+    fn = L.lib().eg3d_style_affine_bwd if backward else L.lib().eg3d_style_affine_fwd
     L.check(fn(C.byref(b), L.stream_ptr()), 'style_affine')
 
 

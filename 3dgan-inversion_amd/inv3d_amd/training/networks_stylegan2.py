@@ -103,8 +103,9 @@ class SynthesisLayer(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
         self._cache = fused.WeightCache()
 
-    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, noise_inject=None, styles=None):
-        """`styles`: this layer's affine(w) when the enclosing network already evaluated all affines in one launch."""
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, noise_inject=None, styles=None, demod=None):
+        """`styles` / `demod`: this layer's affine(w) and demodulation coefficients when the enclosing network already evaluated them
+        for all layers in one launch (fused.style_bank)."""
         assert noise_mode in ['random', 'const', 'none']
         if styles is None:
             styles = self.affine(w)
@@ -116,7 +117,7 @@ class SynthesisLayer(torch.nn.Module):
             noise = self.noise_const
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return fused.ModConvLayerFn.apply(x, self.weight, styles, noise, self.noise_strength if noise is not None else None, self.bias,
-                                          self.up, self.act_gain * gain, clamp, self._cache, self.weight.requires_grad)
+                                          self.up, self.act_gain * gain, clamp, self._cache, self.weight.requires_grad, demod)
 
     def extra_repr(self):
         return f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}, w_dim={self.w_dim:d}, ' \
@@ -173,24 +174,25 @@ class SynthesisBlock(torch.nn.Module):
         """(affine module, ws row, post scale) of this block's modulated layers in evaluation order (for fused.style_bank)."""
         ent = []
         if self.in_channels != 0:
-            ent.append((self.conv0.affine, w_idx + len(ent), 1.0))
-        ent.append((self.conv1.affine, w_idx + len(ent), 1.0))
-        ent.append((self.torgb.affine, w_idx + len(ent), self.torgb.weight_gain))
+            ent.append((self.conv0.affine, w_idx + len(ent), 1.0, self.conv0))
+        ent.append((self.conv1.affine, w_idx + len(ent), 1.0, self.conv1))
+        ent.append((self.torgb.affine, w_idx + len(ent), self.torgb.weight_gain, None))
         return ent
 
     def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, noise_inject=None, _name='', styles=None,
                 **layer_kwargs):
         """x: [N,Cin,r/2,r/2] (any layout) or None; img: skip image with channels padded to a multiple of 4, or None.
-        `styles`: this block's precomputed styles in the order of affine_entries(), or None.  Returns (x, img) as channels_last fp32."""
+        `styles`: (styles, demods) of this block's layers in the order of affine_entries(), or None.  Returns (x, img) as channels_last fp32."""
         w_iter = iter(ws.unbind(dim=1))
-        s_iter = iter(styles) if styles is not None else iter(lambda: None, 0)
+        s_iter = iter(styles[0]) if styles is not None else iter(lambda: None, 0)
+        d_iter = iter(styles[1]) if styles is not None else iter(lambda: None, 0)
         ni = noise_inject or {}
         if self.in_channels == 0:
             x = self.const.unsqueeze(0).expand(ws.shape[0], -1, -1, -1)
-            x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), styles=next(s_iter), **layer_kwargs)
+            x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), styles=next(s_iter), demod=next(d_iter), **layer_kwargs)
         else:
-            x = self.conv0(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv0'), styles=next(s_iter), **layer_kwargs)
-            x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), styles=next(s_iter), **layer_kwargs)
+            x = self.conv0(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv0'), styles=next(s_iter), demod=next(d_iter), **layer_kwargs)
+            x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), styles=next(s_iter), demod=next(d_iter), **layer_kwargs)
         if img is not None:
             img = fused.UpsampleImgFn.apply(img)
         if self.is_last:
@@ -235,7 +237,7 @@ class SynthesisNetwork(torch.nn.Module):
             block = getattr(self, f'b{res}')
             cur = ws.narrow(1, w_idx, block.num_conv + block.num_torgb)
             w_idx += block.num_conv
-            st = bank[s_idx:s_idx + cnt] if bank is not None else None
+            st = (bank[0][s_idx:s_idx + cnt], bank[1][s_idx:s_idx + cnt]) if bank is not None else None
             s_idx += cnt
             x, img = block(x, img, cur, noise_inject=noise_inject, _name=f'{_prefix}.b{res}', styles=st, **block_kwargs)
         return img if img.shape[1] == self.img_channels else img[:, :self.img_channels]

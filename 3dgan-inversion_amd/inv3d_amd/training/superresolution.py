@@ -33,7 +33,7 @@ class SuperresolutionHybrid8XDC(torch.nn.Module):
         rgb4 = torch.cat([rgb, rgb.new_zeros(n, 1, h, w)], 1).contiguous(memory_format=torch.channels_last)
         e0, e1 = self.block0.affine_entries(0), self.block1.affine_entries(0)        # both blocks read ws rows 0..2 (superresolution.py:63-64)
         bank = fused.style_bank(ws.float(), e0 + e1)
-        s0, s1 = (bank[:len(e0)], bank[len(e0):]) if bank is not None else (None, None)
+        s0, s1 = ((bank[0][:len(e0)], bank[1][:len(e0)]), (bank[0][len(e0):], bank[1][len(e0):])) if bank is not None else (None, None)
         x, rgb4 = self.block0(x, rgb4, ws, noise_inject=noise_inject, _name='superresolution.block0', styles=s0, **block_kwargs)
         x, rgb4 = self.block1(x, rgb4, ws, noise_inject=noise_inject, _name='superresolution.block1', styles=s1, **block_kwargs)
         return rgb4[:, :3].contiguous()

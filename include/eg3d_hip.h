@@ -194,14 +194,20 @@ int eg3d_filtered_lrelu(const eg3d_flrelu_params* p, void* stream);
  * Style affines of a whole synthesis network in one launch (the per-layer FullyConnectedLayer(w_dim -> in_channels) of
  * training/networks_stylegan2.py:98-108 and :129-137, ~26 tiny GEMMs + scalings per forward in the reference):
  *   fwd:  out_l[n,j] = ( sum_k ws[n,wrow_l,k] * (weight_l[j,k]*wgain_l) + bias_l[j]*bgain_l ) * post_l
- *   bwd:  dws[n,wrow_l,k] += sum_j dout_l[n,j] * post_l * (weight_l[j,k]*wgain_l)       (dws pre-zeroed; dout_l null = skip)
+ *         d_l[n,o]   = rsqrt( sum_j out_l[n,j]^2 wsq_l[o,j] + 1e-8 )                      (layers with wsq: second launch)
+ *   bwd:  dout_extra_l[n,j] += -out_l[n,j] * sum_o dd_l[n,o] d_l[n,o]^3 wsq_l[o,j]        (layers with dd: first launch)
+ *         dws[n,wrow_l,k] += sum_j (dout_l[n,j] + dout_extra_l[n,j]) * post_l * (weight_l[j,k]*wgain_l)   (dws pre-zeroed)
  * ws/dws: [N,L,D] fp32, D a multiple of 4; weight_l: [C_l,D] row-major. */
 #define EG3D_STYLE_BANK_MAX 32
 typedef struct eg3d_style_layer {
     const float* weight;  const float* bias;  float* out;  const float* dout;
     int32_t C, wrow;
     float wgain, bgain, post;
-    int32_t reserved;
+    int32_t Co;                /* demodulation (conv layers; 0 = none): number of output channels of the layer's conv          */
+    const float* wsq;          /* [Co, C] sum over taps of w^2 (networks_stylegan2.py:62-65), or null                             */
+    float* d;                  /* fwd out: [N, Co] demodulation coefficients rsqrt(sum_k out[n,k]^2 wsq[o,k] + 1e-8)               */
+    const float* dd;           /* bwd in : [N, Co] gradient w.r.t. d, or null                                                     */
+    float* dout_extra;         /* bwd scratch: [N, C] zeroed; receives the style gradient that flows through d; added to dout    */
 } eg3d_style_layer;
 typedef struct eg3d_style_bank {
     const float* ws;  float* dws;
