@@ -435,7 +435,8 @@ class RenderFn(torch.autograd.Function):
         rgb = torch.empty((N, R, w1.shape[0] - 1), device=dev)
         depth = torch.empty((N, R, 1), device=dev)
         wsum = torch.empty((N, R, 1), device=dev)
-        minmax = _minmax_init(dev).clone()          # device-side copy: no host transfer on the step path (HIP-graph capturable)
+        minmax = _minmax_init(dev) + 0.0            # device-side copy by an elementwise kernel: no host transfer (graph-capturable) and no
+                                                    # memcpy node (those split a captured graph into separately submitted segments)
         fine = torch.empty((N, R, max(Df, 1)), device=dev)
         rl = ray_limits.contiguous().float() if ray_limits is not None else None
         save = None
