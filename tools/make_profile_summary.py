@@ -19,7 +19,7 @@ rows = list(csv.DictReader(open(glob.glob(stats_dir + '/*_kernel_stats.csv')[0])
 ncalls = sum(int(r['Calls']) for r in rows)
 tr = list(csv.DictReader(open(glob.glob(stats_dir + '/*_kernel_trace.csv')[0])))
 tr.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(tr) if 'noise_normalize_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(tr) if 'noise_apply_norm_kernel' in r['Kernel_Name']]
 a, b = idx[8], idx[9]                       # a graph-replayed step of the timed region (3 set-up + 2 warm-up steps precede it)
 seg = tr[a + 1:b + 1]
 agg = collections.defaultdict(lambda: [0, 0])
