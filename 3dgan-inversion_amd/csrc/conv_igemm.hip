@@ -161,7 +161,10 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
     const int lrow = tid / TPR, col4 = tid % TPR;
     constexpr unsigned OOB = 0x7ffffff0u;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((int64_t)p.N * p.Hi * p.Wi * p.ldx * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)(((int64_t)(p.Nc - 1) * p.w_row + (int64_t)9 * p.Ck) * 4 > 0x7fffffe0 ? 0x7fffffe0 : ((int64_t)(p.Nc - 1) * p.w_row + (int64_t)9 * p.Ck) * 4), 0x00020000);
+    int wt_hi = 9;                                // weight taps addressed by this class (kernels larger than 3x3 come as several classes)
+    for (int t = 0; t < ntaps; ++t) wt_hi = max(wt_hi, cl.wtap[t] + 1);
+    const int64_t w_bytes = ((int64_t)(p.Nc - 1) * p.w_row + (int64_t)wt_hi * p.Ck) * 4;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)(w_bytes > 0x7fffffe0 ? 0x7fffffe0 : w_bytes), 0x00020000);
     unsigned a_base[A_LD], a_mask[A_LD];
     int a_n[A_LD];
 #pragma unroll
@@ -640,6 +643,8 @@ extern "C" int eg3d_conv2d_igemm_f32(const eg3d_conv_params* pp, void* stream) {
     for (int c = 0; c < p.ncls; ++c) {
         const eg3d_conv_class& k = p.cls[c];
         if (k.Ha <= 0 || k.Wa <= 0 || k.ntaps < 1 || k.ntaps > 9) return EG3D_ERR_INVALID;
+        for (int t = 0; t < k.ntaps; ++t)
+            if (k.wtap[t] < 0 || (int64_t)(k.wtap[t] + 1) * p.Ck > p.w_row) return EG3D_ERR_INVALID;   // tap outside the weight row
         if ((k.Ha - 1) * p.out_stride + k.out_py >= p.Ho || (k.Wa - 1) * p.out_stride + k.out_px >= p.Wo) return EG3D_ERR_INVALID;
         maxM = std::max<int64_t>(maxM, (int64_t)p.N * k.Ha * k.Wa);
     }

@@ -1,0 +1,195 @@
+// Building blocks of the perceptual-loss networks that score every inversion step:
+//   * the VGG16-LPIPS feature distance of the latent projector   (training/projectors/w_projector.py:50-52,112,215-219),
+//   * the VGG16 conv3_3 features of the depth-reprojection loss   (training/warping_loss.py:31-37),
+//   * LPIPS-AlexNet of the pivotal-tuning loss                    (training/coaches/base_coach.py:48,111-112).
+// Their convolutions run on the implicit-GEMM kernel of conv_igemm.hip (bias + ReLU fused in its epilogue); this file holds the two
+// memory-bound pieces in between, NHWC fp32, four channels (16 bytes) per thread:
+//   max pooling (2x2/2 of VGG, 3x3/2 of AlexNet) with the arg-max kept as one byte per element for a gather-form backward, and
+//   the LPIPS feature head:  f[c] = scale[c] * x[c] / (||x||_2 + eps) * mul   per pixel (unit-normalise over channels, multiply by
+//   the square root of the learned 1x1 "lin" weight and by 1/sqrt(H*W), so that the plain squared distance of two such vectors is
+//   the LPIPS distance), written straight into a slice of the flat feature vector.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__global__ void __launch_bounds__(NT) maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx, int N, int H,
+                                                         int W, int C4, int ld4, int k, int s, int Ho, int Wo) {
+    const int64_t total = (int64_t)N * Ho * Wo * C4;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int c = (int)(i % C4);
+        int64_t r = i / C4;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        uchar4 a = make_uchar4(0, 0, 0, 0);
+        for (int ky = 0; ky < k; ++ky) {
+            const int yy = oy * s + ky;
+            if (yy >= H) break;
+            for (int kx = 0; kx < k; ++kx) {
+                const int xx = ox * s + kx;
+                if (xx >= W) break;
+                const float4 v = reinterpret_cast<const float4*>(x)[((int64_t)(n * H + yy) * W + xx) * ld4 + c];
+                const uint8_t t = (uint8_t)(ky * k + kx);
+                // first maximum in scan order wins (the tie rule of torch.nn.functional.max_pool2d); NaN propagates
+                if (v.x > m.x || v.x != v.x) { m.x = v.x; a.x = t; }
+                if (v.y > m.y || v.y != v.y) { m.y = v.y; a.y = t; }
+                if (v.z > m.z || v.z != v.z) { m.z = v.z; a.z = t; }
+                if (v.w > m.w || v.w != v.w) { m.w = v.w; a.w = t; }
+            }
+        }
+        reinterpret_cast<float4*>(y)[i] = m;
+        if (idx) reinterpret_cast<uchar4*>(idx)[i] = a;
+    }
+}
+
+// dx[n,y,x,c] = sum over the (at most ceil(k/s)^2) windows covering (y,x) whose arg-max is this pixel.  No atomics.
+__global__ void __launch_bounds__(NT) maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx, float* __restrict__ dx, int N,
+                                                         int H, int W, int C4, int ld4, int k, int s, int Ho, int Wo) {
+    const int64_t total = (int64_t)N * H * W * C4;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int c = (int)(i % C4);
+        int64_t r = i / C4;
+        const int xx = (int)(r % W); r /= W;
+        const int yy = (int)(r % H);
+        const int n = (int)(r / H);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int oy0 = max(0, (yy - k + s) / s), oy1 = min(Ho - 1, yy / s);
+        const int ox0 = max(0, (xx - k + s) / s), ox1 = min(Wo - 1, xx / s);
+        for (int oy = oy0; oy <= oy1; ++oy)
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                const uint8_t t = (uint8_t)((yy - oy * s) * k + (xx - ox * s));
+                const int64_t o = ((int64_t)(n * Ho + oy) * Wo + ox) * C4 + c;
+                const uchar4 a = reinterpret_cast<const uchar4*>(idx)[o];
+                const float4 v = reinterpret_cast<const float4*>(dy)[o];
+                if (a.x == t) g.x += v.x;
+                if (a.y == t) g.y += v.y;
+                if (a.z == t) g.z += v.z;
+                if (a.w == t) g.w += v.w;
+            }
+        reinterpret_cast<float4*>(dx)[((int64_t)(n * H + yy) * W + xx) * ld4 + c] = g;
+    }
+}
+
+// One pixel per group of G = min(64, C/4 rounded up to a power of two) lanes; each lane walks the pixel's channels four at a time.
+template <bool BWD>
+__global__ void __launch_bounds__(NT) unit_normalize_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ dout,
+                                                            float* __restrict__ out, int64_t npix, int HW, int C4, int ld4, float mul, float eps,
+                                                            int64_t o_nstride, int G) {
+    const int lane = threadIdx.x % G;
+    const int64_t gid = ((int64_t)blockIdx.x * NT + threadIdx.x) / G;
+    const int64_t ngroups = (int64_t)gridDim.x * NT / G;
+    for (int64_t pix = gid; pix < npix; pix += ngroups) {
+        const float4* xp = reinterpret_cast<const float4*>(x) + pix * ld4;
+        const int64_t n = pix / HW, q = pix - n * HW;
+        // dout / features live in a flat [N, F] vector: this layer's slice starts at the pointer passed in, batch stride o_nstride
+        const int64_t fo = n * o_nstride + q * (int64_t)C4 * 4;
+        float ss = 0.f, dot = 0.f;
+        for (int c = lane; c < C4; c += G) {
+            const float4 v = xp[c];
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            if (BWD) {
+                const float4 g = *reinterpret_cast<const float4*>(dout + fo + 4 * c);
+                const float4 s = scale ? reinterpret_cast<const float4*>(scale)[c] : make_float4(1.f, 1.f, 1.f, 1.f);
+                dot += v.x * g.x * s.x + v.y * g.y * s.y + v.z * g.z * s.z + v.w * g.w * s.w;
+            }
+        }
+        for (int m = G >> 1; m >= 1; m >>= 1) {
+            ss += __shfl_xor(ss, m);
+            if (BWD) dot += __shfl_xor(dot, m);
+        }
+        const float r = sqrtf(ss);
+        // n = x/(r+eps):  dx = g/(r+eps) - x (x.g) / (r (r+eps)^2).  An all-zero pixel (r = 0) gets gradient 0: autograd of the reference
+        // expression yields NaN there (0 * inf through sqrt), the limit g/eps is 1e10 * g -- neither is useful to an optimiser.
+        const float inv = (BWD && r == 0.f) ? 0.f : mul / (r + eps);
+        const float back = (BWD && r > 0.f) ? dot * mul / (r * (r + eps) * (r + eps)) : 0.f;
+        for (int c = lane; c < C4; c += G) {
+            const float4 v = xp[c];
+            const float4 s = scale ? reinterpret_cast<const float4*>(scale)[c] : make_float4(1.f, 1.f, 1.f, 1.f);
+            float4 o;
+            if (!BWD) {
+                o = make_float4(v.x * s.x * inv, v.y * s.y * inv, v.z * s.z * inv, v.w * s.w * inv);
+                *reinterpret_cast<float4*>(out + fo + 4 * c) = o;
+            } else {
+                const float4 g = *reinterpret_cast<const float4*>(dout + fo + 4 * c);
+                o = make_float4(g.x * s.x * inv - v.x * back, g.y * s.y * inv - v.y * back, g.z * s.z * inv - v.z * back,
+                                g.w * s.w * inv - v.w * back);
+                reinterpret_cast<float4*>(out)[pix * ld4 + c] = o;
+            }
+        }
+    }
+}
+
+int grid_blocks(int64_t threads) {
+    const int64_t b = (threads + NT - 1) / NT;
+    return (int)(b < 8192 ? b : 8192);
+}
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+int pool_check(const void* a, const void* b, int N, int H, int W, int C, int ld, int k, int s) {
+    if (!a || !b || N < 1 || H < 1 || W < 1 || C < 4 || (C & 3) || ld < C || (ld & 3) || k < 1 || k > 15 || s < 1 || H < k || W < k) return EG3D_ERR_INVALID;
+    if (!aligned16(a) || !aligned16(b)) return EG3D_ERR_INVALID;
+    return EG3D_OK;
+}
+
+int group_width(int C4) {
+    int g = 1;
+    while (g < C4 && g < 64) g <<= 1;
+    return g;
+}
+
+}  // namespace
+
+extern "C" int eg3d_maxpool2d_fwd(const float* x, float* y, uint8_t* argmax, int N, int H, int W, int C, int ldx, int k, int s, void* stream) {
+    int rc = pool_check(x, y, N, H, W, C, ldx, k, s);
+    if (rc) return rc;
+    const int Ho = (H - k) / s + 1, Wo = (W - k) / s + 1;
+    const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
+    const int blocks = grid_blocks(total);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, x, y, argmax, N, H, W, C / 4, ldx / 4, k, s, Ho, Wo);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_maxpool2d_bwd(const float* dy, const uint8_t* argmax, float* dx, int N, int H, int W, int C, int ldx, int k, int s, void* stream) {
+    int rc = pool_check(dy, dx, N, H, W, C, ldx, k, s);
+    if (rc) return rc;
+    if (!argmax) return EG3D_ERR_INVALID;
+    const int Ho = (H - k) / s + 1, Wo = (W - k) / s + 1;
+    const int64_t total = (int64_t)N * H * W * (C / 4);
+    const int blocks = grid_blocks(total);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, dy, argmax, dx, N, H, W, C / 4, ldx / 4, k, s, Ho, Wo);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_unit_normalize_fwd(const float* x, const float* scale, float* feat, int N, int HW, int C, int ldx, float mul, float eps,
+                                       int64_t feat_nstride, void* stream) {
+    if (!x || !feat || N < 1 || HW < 1 || C < 4 || (C & 3) || ldx < C || (ldx & 3) || !aligned16(x) || !aligned16(feat) || (feat_nstride & 3) ||
+        (scale && !aligned16(scale)))
+        return EG3D_ERR_INVALID;
+    const int G = group_width(C / 4);
+    const int64_t npix = (int64_t)N * HW;
+    const int blocks = grid_blocks(npix * G);
+    hipLaunchKernelGGL(unit_normalize_kernel<false>, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, x, scale, (const float*)nullptr, feat, npix, HW,
+                       C / 4, ldx / 4, mul, eps, feat_nstride, G);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_unit_normalize_bwd(const float* x, const float* scale, const float* dfeat, float* dx, int N, int HW, int C, int ldx, float mul,
+                                       float eps, int64_t feat_nstride, void* stream) {
+    if (!x || !dfeat || !dx || N < 1 || HW < 1 || C < 4 || (C & 3) || ldx < C || (ldx & 3) || !aligned16(x) || !aligned16(dfeat) || !aligned16(dx) ||
+        (feat_nstride & 3) || (scale && !aligned16(scale)))
+        return EG3D_ERR_INVALID;
+    const int G = group_width(C / 4);
+    const int64_t npix = (int64_t)N * HW;
+    const int blocks = grid_blocks(npix * G);
+    hipLaunchKernelGGL(unit_normalize_kernel<true>, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, x, scale, dfeat, dx, npix, HW, C / 4, ldx / 4, mul,
+                       eps, feat_nstride, G);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}

@@ -1,0 +1,387 @@
+"""Perceptual-loss networks of the inversion loops on the gfx950 kernels.
+
+The reference scores every step with third-party networks whose code and weights live outside its tree:
+
+  VGG16LPIPS      <- the torchscript `vgg16.pt` of stylegan2-ada-pytorch, called as vgg16(img_0_255, resize_images=False,
+                     return_lpips=True) (training/projectors/w_projector.py:50-52,112,215-219): LPIPS-VGG features as one flat vector
+                     per image whose squared distance is the LPIPS distance.
+  VGG16Features   <- torchvision.models.vgg16().features, children 0..14 = conv3_3 without its ReLU
+                     (training/projectors/w_projector.py:55-58, training/warping_loss.py:74-105 with layers='14').
+  LPIPSAlex       <- lpips.LPIPS(net='alex') (training/coaches/base_coach.py:48,111-112).
+
+None of the three packages / checkpoints exists offline, so the networks are restated here from their published definitions
+(Simonyan & Zisserman 2015 configuration D; Krizhevsky 2014 as shipped by torchvision; Zhang et al. 2018, lpips v0.1:
+ScalingLayer, normalize_tensor with eps 1e-10, non-negative 1x1 `lin` layers, spatial mean, sum over layers) with the state-dict
+keys of the original modules, so real checkpoints load with `load_state_dict`; without them the weights are seeded random
+(constructor argument `seed`).  The CPU restatement used by the tests is oracle/loss_nets_oracle.py; parity against the third-party packages
+themselves is unpinned.
+
+All convolutions run on the implicit-GEMM kernel with bias + ReLU fused in its epilogue (frozen weights: forward and data gradient
+only), pooling and the LPIPS head on csrc/loss_ops.hip.  Activations are fp32 channels-last; the 3-channel image is carried padded
+to 4 channels.  There is no fallback: tensors must live on the GPU."""
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from . import hipops as H
+from .fused import _auto_ksplit
+from .torch_utils.ops import bias_act
+
+LOSS_NET_PRECISION = 'bf16x6'        # fp32-equivalent for any operand range (pixel values up to 255 enter these networks)
+
+
+# ----------------------------------------------------------------------------------------------------------- tap lists
+def _chunks(taps, n=9):
+    return [taps[i:i + n] for i in range(0, len(taps), n)]
+
+
+def _classes_strided(Ho, Wo, kh, kw, pad):
+    """out[y,x] = sum_k w[ky,kx] * in[y*s + ky - pad, x*s + kx - pad]; kernels with more than 9 taps become several classes that
+    accumulate into the same output grid."""
+    taps = [(ky - pad, kx - pad, ky * kw + kx) for ky in range(kh) for kx in range(kw)]
+    return [H._mk_class(Ho, Wo, 0, 0, c) for c in _chunks(taps)]
+
+
+def _classes_strided_adjoint(Hi, Wi, kh, kw, s, pad):
+    """Data gradient of _classes_strided: dx[a*s+py, b*s+px] = sum over taps with ky = py+pad (mod s) of g[a + (py+pad-ky)/s, ...] *
+    w[ky,kx]: one class per output phase (py,px), chunked to 9 taps.  Returns (classes, overlapping)."""
+    cls, overlapping = [], False
+    for py in range(s):
+        for px in range(s):
+            taps = []
+            for ky in range(kh):
+                if (py + pad - ky) % s:
+                    continue
+                for kx in range(kw):
+                    if (px + pad - kx) % s:
+                        continue
+                    taps.append(((py + pad - ky) // s, (px + pad - kx) // s, ky * kw + kx))
+            Ha, Wa = (Hi - py + s - 1) // s, (Wi - px + s - 1) // s
+            if not taps or Ha <= 0 or Wa <= 0:
+                overlapping = True          # a phase nobody writes: the caller must start from zeros
+                continue
+            ch = _chunks(taps)
+            overlapping |= len(ch) > 1
+            cls += [H._mk_class(Ha, Wa, py, px, c) for c in ch]
+    return cls, overlapping
+
+
+def _launch_groups(x, wp, Ck, Nc, out, classes, accumulate, **kw):
+    """At most 4 classes per launch.  accumulate: several classes add into the same pixels (out pre-zeroed, atomics)."""
+    for i in range(0, len(classes), 4):
+        H.conv_igemm(x, wp, Ck, Nc, out, classes[i:i + 4], epi=L.EPI_ATOMIC if accumulate else L.EPI_STORE, precision=LOSS_NET_PRECISION, **kw)
+
+
+class _ConvActFn(torch.autograd.Function):
+    """y = act(conv2d(x, w, stride, pad) + b) with frozen w, b.  x, y: fp32 channels-last, channel counts multiples of 4."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, act):
+        L.require_cuda(x, weight, bias)
+        assert H.is_cl(x) and x.dtype == torch.float32
+        N, Cip, Hi, Wi = x.shape
+        Co, Ci, kh, kw = weight.shape
+        assert Ci <= Cip and Cip % 4 == 0 and Co % 4 == 0, (weight.shape, x.shape)
+
+        def _pack():
+            wp = torch.cat([weight, weight.new_zeros(Co, Cip - Ci, kh, kw)], 1) if Cip != Ci else weight
+            return H.pack_weight_fwd(wp.detach().float())
+        wf = H.memo(('lossnet_fwd', Cip), [weight], _pack)
+        Ho, Wo = (Hi + 2 * pad - kh) // stride + 1, (Wi + 2 * pad - kw) // stride + 1
+        cls = _classes_strided(Ho, Wo, kh, kw, pad)
+        ks = _auto_ksplit(cls, N, Co, Cip) if len(cls) == 1 else 1
+        if len(cls) == 1 and ks == 1:
+            y = H.empty_cl(N, Co, Ho, Wo, x.device)
+            H.conv_igemm(x, wf, Cip, Co, y, cls, in_stride=stride, epi=L.EPI_FWD, bias=bias, act=act, gain=1.0, precision=LOSS_NET_PRECISION)
+        else:           # several tap classes per pixel, or a grid too small to fill the chip (split-K): accumulate, then bias + act
+            z = H.zeros_cl(N, Co, Ho, Wo, x.device)
+            _launch_groups(x, wf, Cip, Co, z, cls, True, in_stride=stride, ksplit=ks)
+            y = H.bias_act_raw(z, bias, None, None, None, 0, 1, L.ACT_IDS[act], 0.0, 1.0, -1.0)
+        ctx.save_for_backward(y, weight)
+        ctx.cfg = (stride, pad, act, x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, weight = ctx.saved_tensors
+        stride, pad, act, (N, Cip, Hi, Wi) = ctx.cfg
+        Co, Ci, kh, kw = weight.shape
+        if not ctx.needs_input_grad[0]:
+            return (None,) * 6
+        dy = H.to_cl(dy.float())
+        dz = dy if act == 'linear' else H.bias_act_raw(dy, None, None, y, None, 1, 1, L.ACT_IDS[act], 0.0, 1.0, -1.0)
+
+        def _pack():
+            wp = torch.cat([weight, weight.new_zeros(Co, Cip - Ci, kh, kw)], 1) if Cip != Ci else weight
+            return H.pack_weight_adj(wp.detach().float())                 # [Cip, taps*Co]
+        wa = H.memo(('lossnet_adj', Cip), [weight], _pack)
+        cls, overlapping = _classes_strided_adjoint(Hi, Wi, kh, kw, stride, pad)
+        ks = _auto_ksplit(cls, N, Cip, Co) if len(cls) == 1 else 1
+        overlapping |= ks > 1
+        dx = (H.zeros_cl if overlapping else H.empty_cl)(N, Cip, Hi, Wi, dy.device)
+        _launch_groups(dz, wa, Co, Cip, dx, cls, overlapping, out_stride=stride, ksplit=ks)
+        return dx, None, None, None, None, None
+
+
+def conv_act(x, weight, bias, stride=1, pad=0, act='relu'):
+    return _ConvActFn.apply(x, weight, bias, stride, pad, act)
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, s):
+        L.require_cuda(x)
+        assert H.is_cl(x) and x.dtype == torch.float32
+        N, C, Hi, Wi = x.shape
+        Ho, Wo = (Hi - k) // s + 1, (Wi - k) // s + 1
+        y = H.empty_cl(N, C, Ho, Wo, x.device)
+        idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device) if ctx.needs_input_grad[0] else None
+        L.check(L.lib().eg3d_maxpool2d_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr() if idx is not None else None, N, Hi, Wi, C, C, k, s,
+                                           L.stream_ptr()), 'maxpool2d_fwd')
+        ctx.idx, ctx.cfg = idx, (k, s, x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        k, s, (N, C, Hi, Wi) = ctx.cfg
+        dy = H.to_cl(dy.float())
+        dx = H.empty_cl(N, C, Hi, Wi, dy.device)
+        L.check(L.lib().eg3d_maxpool2d_bwd(dy.data_ptr(), ctx.idx.data_ptr(), dx.data_ptr(), N, Hi, Wi, C, C, k, s, L.stream_ptr()), 'maxpool2d_bwd')
+        return dx, None, None
+
+
+def max_pool(x, k, s):
+    return _MaxPoolFn.apply(x, k, s)
+
+
+class _LpipsHeadFn(torch.autograd.Function):
+    """feat[n, off : off + H*W*C] = sqrt_lin[c] * x / (||x|| + eps) / sqrt(H*W)  for every tap of the trunk, one flat vector per image
+    (pixel-major, channel-minor inside a layer's slice)."""
+
+    @staticmethod
+    def forward(ctx, eps, nscales, *args):
+        xs, scales = args[:nscales], args[nscales:]
+        N = xs[0].shape[0]
+        sizes = [x.shape[1] * x.shape[2] * x.shape[3] for x in xs]
+        F = sum(sizes)
+        feat = torch.empty((N, F), device=xs[0].device, dtype=torch.float32)
+        off = 0
+        for x, sc, n in zip(xs, scales, sizes):
+            assert H.is_cl(x) and x.dtype == torch.float32
+            _, C, Hh, Ww = x.shape
+            L.check(L.lib().eg3d_unit_normalize_fwd(x.data_ptr(), sc.data_ptr(), feat.data_ptr() + 4 * off, N, Hh * Ww, C, C,
+                                                    1.0 / math.sqrt(Hh * Ww), eps, F, L.stream_ptr()), 'unit_normalize_fwd')
+            off += n
+        ctx.save_for_backward(*xs, *scales)
+        ctx.cfg = (eps, nscales, sizes, F)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        eps, nscales, sizes, F = ctx.cfg
+        xs, scales = ctx.saved_tensors[:nscales], ctx.saved_tensors[nscales:]
+        dfeat = dfeat.contiguous().float()
+        grads, off = [], 0
+        for i, (x, sc, n) in enumerate(zip(xs, scales, sizes)):
+            if ctx.needs_input_grad[2 + i]:
+                N, C, Hh, Ww = x.shape
+                dx = H.empty_cl(N, C, Hh, Ww, x.device)
+                L.check(L.lib().eg3d_unit_normalize_bwd(x.data_ptr(), sc.data_ptr(), dfeat.data_ptr() + 4 * off, dx.data_ptr(), N, Hh * Ww, C, C,
+                                                        1.0 / math.sqrt(Hh * Ww), eps, F, L.stream_ptr()), 'unit_normalize_bwd')
+                grads.append(dx)
+            else:
+                grads.append(None)
+            off += n
+        return (None, None, *grads, *([None] * nscales))
+
+
+def lpips_features(xs: Sequence[torch.Tensor], sqrt_lins: Sequence[torch.Tensor], eps: float = 1e-10) -> torch.Tensor:
+    return _LpipsHeadFn.apply(eps, len(xs), *xs, *sqrt_lins)
+
+
+def _image_cl4(img: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, pre_mul: float, pre_add: float) -> torch.Tensor:
+    """[N,3,H,W] -> channels-last [N,4,H,W]: ((img*pre_mul + pre_add) - shift) / scale in the first three channels, zero in the fourth."""
+    n, c, h, w = img.shape
+    assert c == 3, 'loss networks take RGB images'
+    a = (pre_mul / scale).view(1, 3, 1, 1)
+    b = ((pre_add - shift) / scale).view(1, 3, 1, 1)
+    y = img.float() * a + b
+    return torch.cat([y, y.new_zeros(n, 1, h, w)], 1).contiguous(memory_format=torch.channels_last)
+
+
+# ----------------------------------------------------------------------------------------------------------- trunks
+VGG16_CFG = (64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M')      # torchvision cfg 'D'
+
+
+class _VGG16Trunk(torch.nn.Module):
+    """torchvision.models.vgg16().features with its module indices (conv k -> `<k>.weight`, `<k>.bias`); ReLU and pooling layers hold
+    no parameters.  `run(x, upto, taps)` evaluates children 0..upto and returns the outputs of the children listed in `taps`."""
+
+    def __init__(self):
+        super().__init__()
+        self.kinds = []
+        cin = 3
+        for v in VGG16_CFG:
+            if v == 'M':
+                self.kinds.append(('pool',))
+            else:
+                idx = len(self.kinds)
+                conv = torch.nn.Conv2d(cin, v, 3, padding=1)
+                conv.requires_grad_(False)
+                self.add_module(str(idx), conv)
+                self.kinds += [('conv', idx), ('relu',)]
+                cin = v
+
+    def run(self, x, upto, taps):
+        outs = {}
+        i = 0
+        while i <= upto:
+            kind = self.kinds[i]
+            if kind[0] == 'conv':
+                conv = getattr(self, str(i))
+                fuse_relu = i + 1 <= upto and i not in taps
+                x = conv_act(x, conv.weight, conv.bias, 1, 1, 'relu' if fuse_relu else 'linear')
+                if i in taps:
+                    outs[i] = x
+                if fuse_relu:
+                    i += 1                                   # the ReLU child has been applied in the conv epilogue
+                    if i in taps:
+                        outs[i] = x
+            elif kind[0] == 'relu':                          # only reached when the conv output itself was tapped
+                x = bias_act.bias_act(x, None, act='relu')
+                if i in taps:
+                    outs[i] = x
+            else:
+                x = max_pool(x, 2, 2)
+                if i in taps:
+                    outs[i] = x
+            i += 1
+        return x, outs
+
+
+def _he_init_(module: torch.nn.Module, seed: int):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if p.dim() == 4 and 'lin' not in name:
+                fan_in = p.shape[1] * p.shape[2] * p.shape[3]
+                p.copy_(torch.randn(p.shape, generator=g) * math.sqrt(2.0 / fan_in))
+            elif p.dim() == 4:                               # LPIPS lin layers: non-negative channel weights
+                p.copy_(torch.rand(p.shape, generator=g) * (2.0 / p.shape[1]))
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+
+
+class _Lin(torch.nn.Module):
+    """lpips.NetLinLayer: Dropout + Conv2d(C, 1, 1, bias=False); key `model.1.weight`."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.model = torch.nn.Sequential(torch.nn.Identity(), torch.nn.Conv2d(c, 1, 1, bias=False))
+        self.model.requires_grad_(False)
+
+    def sqrt_weight(self):
+        w = self.model[1].weight
+        return H.memo(('lpips_sqrt_lin',), [w], lambda: w.detach().float().clamp_min(0).sqrt().reshape(-1).contiguous())
+
+
+LPIPS_SHIFT = (-.030, -.088, -.188)          # lpips.ScalingLayer
+LPIPS_SCALE = (.458, .448, .450)
+
+
+class _LpipsBase(torch.nn.Module):
+    def __init__(self, chns, input_range):
+        super().__init__()
+        self.chns = chns
+        self.input_range = input_range       # '255': images in [0,255] (the projector's convention); 'pm1': images in [-1,1] (lpips)
+        self.register_buffer('shift', torch.tensor(LPIPS_SHIFT))
+        self.register_buffer('scale', torch.tensor(LPIPS_SCALE))
+        for i, c in enumerate(chns):
+            self.add_module(f'lin{i}', _Lin(c))
+
+    def _input(self, img):
+        if self.input_range == '255':
+            return _image_cl4(img, self.shift, self.scale, 2.0 / 255.0, -1.0)
+        return _image_cl4(img, self.shift, self.scale, 1.0, 0.0)
+
+    def _head(self, taps):
+        return lpips_features(taps, [getattr(self, f'lin{i}').sqrt_weight() for i in range(len(self.chns))])
+
+    def distance(self, a, b):
+        """LPIPS distance per image, [N]."""
+        return (self(a) - self(b)).square().sum(1)
+
+
+class VGG16LPIPS(_LpipsBase):
+    """LPIPS-VGG as a feature extractor: forward(img) -> [N, F] with  sum((f(a)-f(b))^2) == LPIPS_vgg(a, b).  Taps: relu1_2, relu2_2,
+    relu3_3, relu4_3, relu5_3 (torchvision children 3, 8, 15, 22, 29).  The projector feeds 256^2 images in [0,255]."""
+    TAPS = (3, 8, 15, 22, 29)
+
+    def __init__(self, input_range='255', seed: Optional[int] = 11):
+        super().__init__((64, 128, 256, 512, 512), input_range)
+        self.net = _VGG16Trunk()
+        if seed is not None:
+            _he_init_(self, seed)
+
+    def forward(self, img):
+        _, outs = self.net.run(self._input(img), self.TAPS[-1], self.TAPS)
+        return self._head([outs[t] for t in self.TAPS])
+
+
+class VGG16Features(torch.nn.Module):
+    """torchvision vgg16().features children 0..upto as a spatial feature map [N,C,h,w] (upto=14: conv3_3 before its ReLU, the
+    reference's layers='14').  Takes the image as the reference passes it (no extra normalisation, warping_loss.py:35-36)."""
+
+    def __init__(self, upto=14, seed: Optional[int] = 12):
+        super().__init__()
+        self.upto = upto
+        self.features = _VGG16Trunk()
+        if seed is not None:
+            _he_init_(self, seed)
+
+    def forward(self, img):
+        n, c, h, w = img.shape
+        x = torch.cat([img.float(), img.new_zeros(n, 1, h, w, dtype=torch.float32)], 1).contiguous(memory_format=torch.channels_last)
+        y, _ = self.features.run(x, self.upto, ())
+        return y
+
+
+class _AlexTrunk(torch.nn.Module):
+    """torchvision.models.alexnet().features children 0..11 split as lpips.pretrained_networks.alexnet does
+    (slice1 = 0-1, slice2 = 2-4, slice3 = 5-7, slice4 = 8-9, slice5 = 10-11); parameter keys `slice<k>.<child>.weight`."""
+    SPEC = ((1, 0, 3, 64, 11, 4, 2, False), (2, 3, 64, 192, 5, 1, 2, True), (3, 6, 192, 384, 3, 1, 1, True), (4, 8, 384, 256, 3, 1, 1, False),
+            (5, 10, 256, 256, 3, 1, 1, False))          # (slice, child index, cin, cout, k, stride, pad, max-pool 3/2 first)
+
+    def __init__(self):
+        super().__init__()
+        for sl, idx, cin, cout, k, s, p, _ in self.SPEC:
+            m = torch.nn.Module()
+            conv = torch.nn.Conv2d(cin, cout, k, stride=s, padding=p)
+            conv.requires_grad_(False)
+            m.add_module(str(idx), conv)
+            self.add_module(f'slice{sl}', m)
+
+    def run(self, x):
+        outs = []
+        for sl, idx, cin, cout, k, s, p, pool in self.SPEC:
+            conv = getattr(getattr(self, f'slice{sl}'), str(idx))
+            if pool:
+                x = max_pool(x, 3, 2)
+            x = conv_act(x, conv.weight, conv.bias, s, p, 'relu')
+            outs.append(x)
+        return outs
+
+
+class LPIPSAlex(_LpipsBase):
+    """lpips.LPIPS(net='alex') as a feature extractor (images in [-1,1]): sum((f(a)-f(b))^2) == lpips(a, b)."""
+
+    def __init__(self, input_range='pm1', seed: Optional[int] = 13):
+        super().__init__((64, 192, 384, 256, 256), input_range)
+        self.net = _AlexTrunk()
+        if seed is not None:
+            _he_init_(self, seed)
+
+    def forward(self, img):
+        return self._head(self.net.run(self._input(img)))

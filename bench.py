@@ -81,6 +81,9 @@ def main():
     ap.add_argument('--precision', default=None, choices=sorted(PRODUCTS) + ['auto'],
                     help="matrix-core arithmetic of the implicit GEMMs (default 'auto': f16x3 for the modulated convs, bf16x6 elsewhere)")
     ap.add_argument('--wplus', action='store_true')
+    ap.add_argument('--loss-net', default='stub', choices=['stub', 'vgg16'],
+                    help="feature network of the LPIPS term: 'stub' = the small fixed conv pyramid the C2 workload is defined with (SURVEY.md "
+                         "section 8d); 'vgg16' = the full VGG16-LPIPS architecture (random weights) on the same kernels")
     args = ap.parse_args()
 
     from inv3d_amd import dist as D
@@ -103,7 +106,11 @@ def main():
         ws_t = S.synth_ws(14, 512, world, seed=3)[rank:rank + 1].to(dev)
         target = G.synthesis(ws_t, cam, noise_mode='const', force_fp32=True)['image'].clamp(-1, 1)
     use_graph = not args.no_graph
-    proj = LatentProjector(G, target, num_steps=400, cam=cam, wplus=args.wplus, seed=100 + rank, use_graph=use_graph)
+    feature_net = None
+    if args.loss_net == 'vgg16':
+        from inv3d_amd.loss_nets import VGG16LPIPS
+        feature_net = VGG16LPIPS().to(dev)
+    proj = LatentProjector(G, target, num_steps=400, cam=cam, wplus=args.wplus, seed=100 + rank, use_graph=use_graph, feature_net=feature_net)
     proj.preheat = 0
 
     stats = torch.zeros(4, device=dev)
@@ -141,7 +148,7 @@ def main():
         # HIP events cannot bracket a kernel inside a captured graph: the per-launch durations of the dominant kernel come from an
         # instrumented EAGER pass over the same K steps (same generator, same shapes), run right after the timed region.
         roofline_pass = 'HIP events around every launch of the kernel in an eager re-run of the same %d steps right after the timed (graph-replay) region' % args.steps
-        eager = LatentProjector(G, target, num_steps=400, cam=cam, wplus=args.wplus, seed=100 + rank, use_graph=False)
+        eager = LatentProjector(G, target, num_steps=400, cam=cam, wplus=args.wplus, seed=100 + rank, use_graph=False, feature_net=feature_net)
         eager.preheat = 0
         one_step(eager)
         prof = H.LaunchProfiler(only_config=DOMINANT)
@@ -179,7 +186,7 @@ def main():
                            'f16x3': 'f32 (modulated convs: two-piece fp16 split, 3 products, range-normalised; other GEMMs bf16x6; fp32-equivalent)',
                            'bf16x3': 'f32 storage, bf16x3 products (~2^-15)'}[prec_name], data='synthetic',
                     config=dict(workload='C2: FFHQ 512^2 single-image latent inversion step (Phase A, w%s + 17 noise buffers; G.synthesis fwd+bwd, '
-                                         '128^2 x 96-sample rendering, stub-LPIPS feature distance + noise regulariser, Adam)' % ('+' if args.wplus else ''),
+                                         '128^2 x 96-sample rendering, %s feature distance + noise regulariser, Adam)' % ('+' if args.wplus else '', 'stub-LPIPS' if args.loss_net == 'stub' else 'VGG16-LPIPS (256^2, random weights)'),
                                 images_per_gpu=1, generator='ffhqrebalanced512-128-shaped, 30.66 M params, random-init (synthetic weights)',
                                 parallelism=f'{world} independent images, 1 per GPU; stat all-reduce only',
                                 launch='one HIP graph replay per step' if (use_graph and proj._graph is not None) else 'eager (one launch per kernel)',

@@ -376,6 +376,28 @@ int eg3d_triplane_scatter(const float* df_rows, const float* df_pos, int64_t S, 
 int eg3d_sample_decode(const eg3d_render_params* p, const float* coords, int64_t M, float* rgb, float* sigma,
                        void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Perceptual-loss network pieces.  The reference evaluates three third-party networks per step:
+ * VGG16-LPIPS features (training/projectors/w_projector.py:50-52,112,215-219), torchvision VGG16 features[:15]
+ * (training/warping_loss.py:31-37) and lpips.LPIPS(net='alex') (training/coaches/base_coach.py:48,111-112).  Their convolutions
+ * go through eg3d_conv2d_igemm_f32 (bias + ReLU in the epilogue); these entry points are the layers in between.  NHWC fp32,
+ * C and ldx multiples of 4, 16-byte aligned pointers.
+ *
+ * Max pooling without padding (torch.nn.MaxPool2d(k, s), floor mode): y[N,Ho,Wo,C] dense, Ho = (H-k)/s+1.  argmax (optional in
+ * forward) holds ky*k+kx of the winning tap, one byte per output element; the first maximum in scan order wins. */
+int eg3d_maxpool2d_fwd(const float* x, float* y, uint8_t* argmax, int N, int H, int W, int C, int ldx, int k, int s, void* stream);
+/* dx[N,H,W,ldx] (every used channel overwritten) from dy[N,Ho,Wo,C] and the forward's argmax; gather form, no atomics. */
+int eg3d_maxpool2d_bwd(const float* dy, const uint8_t* argmax, float* dx, int N, int H, int W, int C, int ldx, int k, int s, void* stream);
+/* LPIPS feature head (lpips.normalize_tensor + the square root of the 1x1 "lin" layer + spatial mean folded into the features):
+ *   feat[n*feat_nstride + (pix*C + c)] = scale[c] * x[n,pix,c] / (sqrt(sum_c x^2) + eps) * mul
+ * so that sum((feat_a - feat_b)^2) is the layer's LPIPS term when scale = sqrt(lin weight), mul = 1/sqrt(H*W).  scale may be null (1).
+ * feat points at this layer's slice of a flat [N, F] feature vector (feat_nstride = F). */
+int eg3d_unit_normalize_fwd(const float* x, const float* scale, float* feat, int N, int HW, int C, int ldx, float mul, float eps,
+                            int64_t feat_nstride, void* stream);
+/* dx[N,HW,ldx] = d feat / d x applied to dfeat (same slice addressing as the forward). */
+int eg3d_unit_normalize_bwd(const float* x, const float* scale, const float* dfeat, float* dx, int N, int HW, int C, int ldx, float mul,
+                            float eps, int64_t feat_nstride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,177 @@
+"""GPU parity tests of the perceptual-loss networks against oracle/loss_nets_oracle.py: the layers
+(conv + bias + ReLU epilogue incl. strided / >9-tap kernels, max pooling, LPIPS head) and the three networks, forward and image
+gradient.  fp32 tolerances: layers 1e-5 relative to the output scale; whole networks 1e-4 (up to 13 stacked convolutions)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import loss_nets_oracle as LO
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def close(a, b, tol, what=''):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert torch.isfinite(a).all(), what
+    scale = max(1e-30, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f'{what}: err {err:.3e} > {tol} * {scale:.3e}'
+
+
+def close_most(a, b, tol, what='', frac=0.2, loose=0.3):
+    """Whole-network image gradients are piecewise smooth: max pooling routes the gradient to the arg-max, and two activations that
+    agree to ~1e-7 can swap rank between the CPU and GPU arithmetic (observed: 2 of 131072 elements of relu2_2 at 64^2), which changes
+    the gradient inside that window's receptive field (5 % of a 64^2 image for one flip at relu2_2).  Layer-level tests are exact;
+    here all but `frac` of the elements must meet `tol` (an arithmetic error in any layer would move every element) and the rest a
+    loose bound."""
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape and torch.isfinite(a).all(), what
+    scale = max(1e-30, float(b.abs().max()))
+    err = (a - b).abs().flatten()
+    bad = int((err > tol * scale).sum())
+    assert bad <= frac * err.numel(), f'{what}: {bad}/{err.numel()} elements above {tol}'
+    assert float(err.max()) <= loose * scale, f'{what}: worst element {float(err.max()):.3e} vs scale {scale:.3e}'
+
+
+def cl(x):
+    return x.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize('k,s,h,w', [(2, 2, 16, 16), (2, 2, 9, 7), (3, 2, 15, 15), (3, 2, 12, 9), (3, 1, 6, 5)])
+def test_maxpool(k, s, h, w):
+    from inv3d_amd import loss_nets as LN
+    g = torch.Generator().manual_seed(k * 100 + h)
+    x = torch.randn(2, 8, h, w, generator=g)
+    x[0, :, 2:4, 2:4] = 1.5                                   # ties: the first maximum in scan order takes the gradient
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, k, s)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    xg = cl(x).requires_grad_(True)
+    y = LN.max_pool(xg, k, s)
+    y.backward(cl(dy))
+    close(y, yr, 0, 'maxpool fwd')
+    close(xg.grad, xr.grad, 1e-6, 'maxpool bwd')
+
+
+@pytest.mark.parametrize('cin,cout,k,s,p,h,w,act', [(8, 16, 3, 1, 1, 12, 10, 'relu'), (4, 64, 11, 4, 2, 67, 64, 'relu'), (16, 24, 5, 1, 2, 9, 11, 'relu'),
+                                                     (8, 8, 3, 2, 1, 10, 10, 'linear'), (8, 12, 1, 1, 0, 5, 5, 'relu'), (512, 512, 3, 1, 1, 4, 4, 'relu'),
+                                                     (256, 512, 3, 1, 1, 8, 8, 'relu'), (128, 128, 3, 1, 1, 32, 32, 'relu')])
+def test_conv_act(cin, cout, k, s, p, h, w, act):
+    from inv3d_amd import loss_nets as LN
+    g = torch.Generator().manual_seed(cin * 7 + k)
+    x = torch.randn(1 if cin >= 128 else 2, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin if cin > 4 else 3, k, k, generator=g) / (k * cin ** 0.5)
+    if cin == 4:
+        x[:, 3] = 0
+    b = torch.randn(cout, generator=g) * 0.1
+    xr = x[:, :wt.shape[1]].clone().requires_grad_(True)
+    yr = F.conv2d(xr, wt, b, stride=s, padding=p)
+    yr = F.relu(yr) if act == 'relu' else yr
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    xg = cl(x).requires_grad_(True)
+    y = LN.conv_act(xg, wt.to(DEV), b.to(DEV), s, p, act)
+    y.backward(cl(dy))
+    close(y, yr, 1e-5, 'conv_act fwd')
+    close(xg.grad[:, :wt.shape[1]], xr.grad, 1e-5, 'conv_act dgrad')
+
+
+def test_lpips_head():
+    from inv3d_amd import loss_nets as LN
+    g = torch.Generator().manual_seed(5)
+    shapes = [(2, 8, 6, 5), (2, 64, 4, 4), (2, 512, 3, 2), (2, 192, 2, 2)]
+    xs = [torch.randn(s, generator=g) for s in shapes]
+    xs[0][0, :, 0, 0] = 0                                    # an all-zero pixel: features 0, gradient 0 * inf must not appear
+    lins = [torch.rand(1, s[1], 1, 1, generator=g) for s in shapes]
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    fr = LO._lpips_head(xr, lins)
+    df = torch.randn(fr.shape, generator=g)
+    fr.backward(df)
+    xg = [cl(x).requires_grad_(True) for x in xs]
+    f = LN.lpips_features(xg, [l.reshape(-1).sqrt().to(DEV) for l in lins])
+    f.backward(df.to(DEV))
+    close(f, fr, 1e-6, 'lpips head fwd')
+    for a, b in zip(xg, xr):
+        gb = torch.nan_to_num(b.grad)                        # autograd of sqrt at 0 gives NaN for the all-zero pixel; the kernel defines it as 0
+        close(a.grad, gb, 1e-5, 'lpips head bwd')
+
+
+def _net_check(net, oracle_fn, img, tol, **kw):
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    ir = img.clone().requires_grad_(True)
+    fr = oracle_fn(sd, ir, **kw)
+    g = torch.Generator().manual_seed(99)
+    df = torch.randn(fr.shape, generator=g) / fr.numel() ** 0.5
+    (fr * df).sum().backward()
+    ig = img.to(DEV).requires_grad_(True)
+    f = net(ig)
+    (f * df.to(DEV)).sum().backward()
+    close(f, fr, tol, 'features')
+    close_most(ig.grad, ir.grad, 10 * tol, 'image gradient')
+    return f
+
+
+def test_vgg16_lpips_matches_oracle():
+    from inv3d_amd import loss_nets as LN
+    net = LN.VGG16LPIPS().to(DEV)
+    img = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(1)) * 255
+    _net_check(net, LO.vgg16_lpips_features, img, 1e-4, input_range='255')
+
+
+def test_vgg16_features_matches_oracle():
+    from inv3d_amd import loss_nets as LN
+    net = LN.VGG16Features(14).to(DEV)
+    img = torch.rand(2, 3, 40, 48, generator=torch.Generator().manual_seed(2)) * 2 - 1
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    ir = img.clone().requires_grad_(True)
+    fr = LO.vgg16_features(sd, ir, 14)
+    fr.square().sum().backward()
+    ig = img.to(DEV).requires_grad_(True)
+    f = net(ig)
+    f.square().sum().backward()
+    assert f.shape == (2, 256, 10, 12)
+    close(f, fr, 1e-4, 'vgg features[:15]')
+    close_most(ig.grad, ir.grad, 1e-3, 'vgg features[:15] image gradient')
+
+
+def test_lpips_alex_matches_oracle_and_direct_form():
+    from inv3d_amd import loss_nets as LN
+    net = LN.LPIPSAlex().to(DEV)
+    g = torch.Generator().manual_seed(3)
+    a = torch.rand(2, 3, 128, 128, generator=g) * 2 - 1
+    b = (a + 0.2 * torch.randn(a.shape, generator=g)).clamp(-1, 1)
+    fa = _net_check(net, LO.lpips_alex_features, a, 1e-4)
+    d = (fa - net(b.to(DEV))).square().sum(1)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    close(d, LO.lpips_distance_direct(sd, a, b, 'alex'), 1e-4, 'lpips distance')
+    close(net.distance(a.to(DEV), b.to(DEV)), d, 1e-6, 'distance()')
+
+
+def test_projector_with_vgg16_lpips_graph_matches_eager():
+    """The latent projector with the real-architecture LPIPS network as `feature_net`: graph replay == eager, loss decreases."""
+    from inv3d_amd import inversion as INV, loss_nets as LN, synthetic as S
+    from oracle import eg3d_oracle as O
+    cfg = O.small_config()
+
+    def run(use_graph):
+        torch.manual_seed(0)
+        G = S.make_generator(w_dim=32, z_dim=32, plane_res=32, channel_base=256, channel_max=16, nrr=16, sr_in_res=16, sr_widths=(16, 8),
+                             rendering_kwargs=cfg.rendering, device=DEV)
+        S.load_synthetic_weights(G, 0)
+        target = torch.tanh(torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(7))).to(DEV)
+        u1, u2 = O.make_uniforms(cfg, 1, seed=4)
+        P = INV.LatentProjector(G, target, num_steps=6, feature_net=LN.VGG16LPIPS().to(DEV), use_graph=use_graph, graph_warmup=2,
+                                synth_kwargs=dict(render_uniforms=(u1.to(DEV), u2.to(DEV))), seed=3)
+        wn = [torch.randn(1, 1, 32, generator=torch.Generator().manual_seed(100 + i)).to(DEV) for i in range(6)]
+        losses = [float(P.step(w_noise=wn[i])['dist']) for i in range(6)]
+        return losses, P
+
+    le, _ = run(False)
+    lg, P = run(True)
+    assert P.graph_capture_error is None, P.graph_capture_error
+    assert np.allclose(le, lg, rtol=2e-3), (le, lg)
+    assert le[-1] < le[0]
