@@ -644,10 +644,79 @@ def gen_loss_glue():
     save('loss_glue', 1e-6, **out)
 
 
+def gen_inference():
+    """Inference consumers: orbit cameras, grid samples, density grid, mean-latent statistics."""
+    print('inference consumers')
+    import ast
+    from utils import camera_utils as ref_cam
+    from oracle import inference_oracle as IO
+    out = {}
+    # LookAtPoseSampler (utils/camera_utils.py:87-105)
+    hv = [(3.14 / 2, 3.14 / 2), (3.14 / 2 + 0.35, 3.14 / 2 - 0.05), (1.0, 2.0), (2.2, 0.7)]
+    poses = torch.cat([ref_cam.LookAtPoseSampler.sample(h, v, torch.tensor([0., 0, 0]), radius=2.7) for h, v in hv])
+    for (h, v), m in zip(hv, poses):
+        check(IO.lookat_pose(h, v, (0., 0., 0.), 2.7), m, 1e-6, 'lookat pose')
+    out.update(dict(hv=torch.tensor(hv), poses=poses))
+    # orbit of gen_interp_video (gen_videos.py:105-117; the file itself needs imageio, so the loop is restated around the reference sampler)
+    F_ = 8
+    K = torch.tensor([[4.2647, 0, 0.5], [0, 4.2647, 0.5], [0, 0, 1]])
+    cams = []
+    for frame_idx in range(F_):
+        m = ref_cam.LookAtPoseSampler.sample(3.14 / 2 + 0.35 * np.sin(2 * 3.14 * frame_idx / F_), 3.14 / 2 - 0.05 + 0.25 * np.cos(2 * 3.14 * frame_idx / F_),
+                                             torch.tensor([0., 0, 0]), radius=2.7)
+        cams.append(torch.cat([m.reshape(-1, 16), K.reshape(-1, 9)], 1))
+    cams = torch.cat(cams)
+    check(IO.orbit_cameras(F_), cams, 1e-6, 'orbit cameras')
+    out['orbit8'] = cams
+    # create_samples: the function's own source, lifted out of single_id_coach.py (the module imports wandb/lpips/mrcfile)
+    src = open(os.path.join(REF, 'training/coaches/single_id_coach.py')).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == 'create_samples'][0]
+    ns = dict(np=np, torch=torch)
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), 'create_samples', 'exec'), ns)
+    for N, L_ in ((6, 1.0), (20, 1.0), (37, 2.0)):
+        ref_s, _, _ = ns['create_samples'](N=N, voxel_origin=[0, 0, 0], cube_length=L_)
+        check(IO.create_samples(N, L_), ref_s, 1e-6, f'create_samples {N}')
+    out['samples20'] = ns['create_samples'](N=20, voxel_origin=[0, 0, 0], cube_length=1.0)[0]
+    # density grid: create_geometry's evaluation (single_id_coach.py:120-157) on the small reference generator
+    cfg = O.small_config()
+    P = O.synth_params(cfg, seed=0)
+    G = RefComposite(cfg, P)
+    ws = O.synth_ws(cfg, 1, seed=1, wplus=True)
+    res = 12
+    with torch.no_grad():
+        samples, _, _ = ns['create_samples'](N=res, voxel_origin=[0, 0, 0], cube_length=cfg.rendering['box_warp'] * 1)
+        planes = G.backbone.synthesis(ws, update_emas=False, noise_mode='const', force_fp32=True)
+        planes = planes.view(len(planes), 3, 32, planes.shape[-2], planes.shape[-1])
+        dirs = torch.zeros((1, samples.shape[1], 3)); dirs[..., -1] = -1
+        sigma = G.renderer.run_model(planes, G.decoder, samples, dirs, cfg.rendering)['sigma']
+    sigmas = np.flip(sigma.reshape((res, res, res)).numpy(), 0).copy()
+    pad = int(30 * res / 256)
+    for sl in ((slice(None, pad),), (slice(-pad, None),), (slice(None), slice(None, pad)), (slice(None), slice(-pad, None)),
+               (slice(None), slice(None), slice(None, pad)), (slice(None), slice(None), slice(-pad, None))):
+        sigmas[sl] = -1000
+    check(IO.density_grid(P, cfg, ws, res), sigmas, 2e-5, 'density grid')
+    out.update(dict(grid_ws=ws, grid12=sigmas))
+    # mean latent (w_projector.py:88-97) on the small mapping network
+    n = 64
+    ext = ref_cam.euler2rot(torch.tensor([math.pi / 2]), torch.tensor([math.pi / 2]), torch.zeros(1, 1), batch_size=1)
+    cam_init = torch.cat([ext.reshape(1, 16), torch.tensor([[4.2647, 0, 0.5, 0, 4.2647, 0.5, 0, 0, 1]])], -1)
+    z = np.random.RandomState(123).randn(n, cfg.z_dim)
+    with torch.no_grad():
+        w = G.backbone.mapping(torch.from_numpy(z).float(), cam_init.repeat(n, 1), truncation_cutoff=14, truncation_psi=0.7)
+    w = w[:, :1, :].numpy().astype(np.float32)
+    w_avg = np.mean(w, axis=0, keepdims=True)
+    w_std = (np.sum((w - w_avg) ** 2) / n) ** 0.5
+    oa, os_ = IO.w_stats(P, cfg, n)
+    check(oa, w_avg, 1e-5, 'w_avg')
+    assert abs(os_ - w_std) <= 1e-5 * max(1.0, w_std), (os_, w_std)
+    out.update(dict(w_avg64=w_avg, w_std64=np.float32(w_std)))
+    save('inference', 2e-5, **out)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
     gens = dict(bias_act=gen_bias_act, upfirdn2d=gen_upfirdn2d, filtered_lrelu=gen_filtered_lrelu, conv=gen_conv2d_resample, renderer=gen_renderer,
-                graph_small=gen_graph_small, graph_full=gen_graph_full, loss=gen_loss_glue)
+                graph_small=gen_graph_small, graph_full=gen_graph_full, loss=gen_loss_glue, inference=gen_inference)
     mpath = os.path.join(HERE, 'MANIFEST.json')
     if only and os.path.exists(mpath):
         MANIFEST.update(json.load(open(mpath)).get('fixtures', {}))

@@ -154,3 +154,28 @@ def test_coach_phase_a_then_b_per_image():
     assert stats['n_done'] == 2.0 and stats['steps'] == 22.0 and abs(stats['mean_psnr'] - sum(r.psnr_tuned for r in results) / 2) < 1e-4
     assert all(torch.equal(v, pristine[k]) for k, v in G.state_dict().items())           # restored at the end
     assert not any(p.requires_grad for p in G.parameters())
+
+
+def test_inference_consumers_match_oracle():
+    """Row f3: density grid (create_geometry), mean-latent statistics and the orbit renderer on the GPU vs their CPU oracle twins."""
+    from inv3d_amd import inference as INF
+    from oracle import inference_oracle as FO
+    cfg, P, G, cam, u1, u2, target, init_noise = _setup()
+    ws = O.synth_ws(cfg, 1, seed=1, wplus=True)
+    grid = INF.density_grid(G, ws.to(DEV), res=12, max_batch=500)            # ragged chunks
+    ref = FO.density_grid(P, cfg, ws, 12)
+    assert float((grid.cpu() - ref).abs().max()) <= 2e-4 * max(1.0, float(ref[ref > -999].abs().max()))
+    w_avg, w_std = INF.estimate_w_stats(G, num_samples=96, batch=40)
+    ra, rs = FO.w_stats(P, cfg, 96)
+    assert float((w_avg.cpu() - ra).abs().max()) < 1e-5 and abs(w_std - rs) < 1e-5 * max(1.0, rs)
+    # orbit: the cached-backbone frames equal a fresh synthesis at the same camera
+    cams = INF.orbit_cameras(3, device=DEV)
+    uni = (u1.to(DEV), u2.to(DEV))
+    frames = list(INF.render_orbit(G, ws.to(DEV), cameras=cams, render_uniforms=uni))
+    assert len(frames) == 3 and frames[0].shape == (3, 64, 64)
+    with torch.no_grad():
+        for i in range(3):
+            direct = G.synthesis(ws.to(DEV), cams[i:i + 1], noise_mode='const', render_uniforms=uni)['image'][0]
+            assert float((frames[i] - direct).abs().max()) < 1e-5
+        o_ref = O.synthesis(P, cfg, ws, cams[1:2].cpu(), u1, u2, noise_mode='const')['image'][0]
+    assert float((frames[1].cpu() - o_ref).abs().max()) < 1e-4

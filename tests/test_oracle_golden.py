@@ -216,3 +216,25 @@ def test_param_schema_counts():
     total = sum(int(np.prod(sh[k])) for k in params)
     assert abs(total - 30.66e6) < 0.02e6, total
     assert cfg.num_ws == 14
+
+
+def test_inference_consumers(golden):
+    """oracle/inference_oracle.py and the host-side camera / grid helpers of inv3d_amd/inference.py vs the reference's
+    LookAtPoseSampler, create_samples, create_geometry evaluation and mean-latent statistics (fixture `inference`)."""
+    from oracle import inference_oracle as IO
+    from inv3d_amd import inference as INF
+    d = golden('inference')
+    for (h, v), m in zip(d['hv'], d['poses']):
+        close(IO.lookat_pose(float(h), float(v), (0., 0., 0.), 2.7), t(m), 1e-6)
+        close(INF.lookat_pose(float(h), float(v), (0., 0., 0.), 2.7), t(m), 1e-6)
+    close(IO.orbit_cameras(8), t(d['orbit8']), 1e-6)
+    close(INF.orbit_cameras(8), t(d['orbit8']), 1e-6)
+    close(IO.create_samples(20, 1.0), t(d['samples20']), 1e-6)
+    close(INF._grid_points(20, 1.0, 0, 8000, 'cpu').unsqueeze(0), t(d['samples20']), 1e-6)
+    close(INF._grid_points(20, 1.0, 777, 4001, 'cpu'), t(d['samples20'])[0, 777:4001], 1e-6)
+    cfg = O.small_config()
+    P = O.synth_params(cfg, seed=0)
+    close(IO.density_grid(P, cfg, t(d['grid_ws']), 12), t(d['grid12']), 2e-5)
+    w_avg, w_std = IO.w_stats(P, cfg, 64)
+    close(w_avg, t(d['w_avg64']), 1e-5)
+    assert abs(w_std - float(d['w_std64'])) <= 1e-5 * max(1.0, float(d['w_std64']))
