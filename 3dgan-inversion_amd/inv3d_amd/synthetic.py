@@ -25,7 +25,7 @@ def make_generator(w_dim=512, z_dim=512, c_dim=25, plane_res=256, channel_base=3
     G = TriPlaneGenerator(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, img_resolution=sr_in_res * 4, img_channels=3, sr_num_fp16_res=4,
                           mapping_kwargs={'num_layers': mapping_layers}, rendering_kwargs=rk,
                           sr_kwargs={'channel_base': channel_base, 'channel_max': channel_max, 'fused_modconv_default': 'inference_only',
-                                     'sr_widths': tuple(sr_widths), 'input_resolution': sr_in_res},
+                                     'sr_widths': tuple(sr_widths), 'input_resolution': sr_in_res, 'w_dim': w_dim},
                           plane_resolution=plane_res, channel_base=channel_base, channel_max=channel_max,
                           fused_modconv_default='inference_only', conv_clamp=None)
     G.neural_rendering_resolution = nrr

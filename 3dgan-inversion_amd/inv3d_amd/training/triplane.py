@@ -44,8 +44,7 @@ class TriPlaneGenerator(torch.nn.Module):
         sr_cls = _SR_MODULES.get(rendering_kwargs.get('superresolution_module', 'training.superresolution.SuperresolutionHybrid8XDC'))
         if sr_cls is None:
             raise NotImplementedError(f"superresolution module {rendering_kwargs.get('superresolution_module')} (only the 512^2 head is on the inversion path)")
-        sr_kwargs = dict(sr_kwargs)
-        sr_kwargs.setdefault('w_dim', w_dim)
+        sr_kwargs = dict(sr_kwargs)          # the SR blocks take 512-d latents unless told otherwise (superresolution.py:268-275 hard-codes w_dim=512)
         self.superresolution = sr_cls(channels=32, img_resolution=img_resolution, sr_num_fp16_res=sr_num_fp16_res,
                                       sr_antialias=rendering_kwargs.get('sr_antialias', True), **sr_kwargs)
         self.decoder = OSGDecoder(32, {'decoder_lr_mul': rendering_kwargs.get('decoder_lr_mul', 1), 'decoder_output_dim': 32})
