@@ -6,7 +6,8 @@
 // Here the bank of layers is one memory-bound pass over the ~18 MB of affine weights:
 //   fwd:  styles_l[n, j] = ( sum_k ws[n, wrow_l, k] * (W_l[j,k] * wgain_l) + b_l[j] * bgain_l ) * post_l
 //   bwd:  dws[n, wrow_l, k] += sum_j dstyles_l[n, j] * post_l * (W_l[j,k] * wgain_l)
-// (weights frozen: the latent-inversion phase; with trainable affines the host uses the per-layer path.)
+//         dW_l[j,k] = sum_n dstyles_l[n,j] * post_l * wgain_l * ws[n,wrow_l,k],  db_l[j] = sum_n dstyles_l[n,j] * post_l * bgain_l
+//         (trainable affines: the pivotal-tuning phase)
 #include "common.h"
 
 namespace {
@@ -123,6 +124,7 @@ __global__ void __launch_bounds__(128) style_affine_bwd_kernel(const eg3d_style_
             coef[threadIdx.x] = ((ly.dout ? ly.dout[j] : 0.f) + (ly.dout_extra ? ly.dout_extra[j] : 0.f)) * ly.post;
         }
         __syncthreads();
+        if (b.dws == nullptr) continue;              // latent frozen (pivotal tuning): only the weight gradients below are wanted
         float* dst = b.dws + ((int64_t)n * b.L + ly.wrow) * b.D;
         for (int k = threadIdx.x * 4; k < b.D; k += 512) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -142,17 +144,50 @@ __global__ void __launch_bounds__(128) style_affine_bwd_kernel(const eg3d_style_
     }
 }
 
+// Gradients of trainable affines: the block owns rows [row0, row0+32) of its layer, so plain stores.
+__global__ void __launch_bounds__(128) style_affine_wgrad_kernel(const eg3d_style_bank b) {
+    int row0;
+    const int l = find_layer(b, blockIdx.x, ROWS_PER_BLOCK_BWD, row0);
+    if (l >= b.nlayers) return;
+    const eg3d_style_layer& ly = b.layers[l];
+    if ((ly.dweight == nullptr && ly.dbias == nullptr) || (ly.dout == nullptr && ly.dout_extra == nullptr)) return;
+    const int rows = min(ROWS_PER_BLOCK_BWD, ly.C - row0);
+    auto coef = [&](int n, int r) {
+        const int64_t j = (int64_t)n * ly.C + row0 + r;
+        return ((ly.dout ? ly.dout[j] : 0.f) + (ly.dout_extra ? ly.dout_extra[j] : 0.f)) * ly.post;
+    };
+    if (ly.dbias != nullptr && threadIdx.x < rows) {
+        float s = 0.f;
+        for (int n = 0; n < b.N; ++n) s += coef(n, threadIdx.x);
+        ly.dbias[row0 + threadIdx.x] = s * ly.bgain;
+    }
+    if (ly.dweight == nullptr) return;
+    for (int k = threadIdx.x * 4; k < b.D; k += 512) {
+        for (int r = 0; r < rows; ++r) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int n = 0; n < b.N; ++n) {
+                const float4 x = *reinterpret_cast<const float4*>(b.ws + ((int64_t)n * b.L + ly.wrow) * b.D + k);
+                const float c = coef(n, r) * ly.wgain;
+                acc.x += c * x.x; acc.y += c * x.y; acc.z += c * x.z; acc.w += c * x.w;
+            }
+            *reinterpret_cast<float4*>(ly.dweight + (int64_t)(row0 + r) * b.D + k) = acc;
+        }
+    }
+}
+
 int check_bank(const eg3d_style_bank* pb, bool bwd) {
     if (!pb) return EG3D_ERR_INVALID;
     const eg3d_style_bank& b = *pb;
     if (b.nlayers < 1 || b.nlayers > EG3D_STYLE_BANK_MAX || b.N < 1 || b.L < 1 || b.D < 4 || (b.D & 3)) return EG3D_ERR_INVALID;
-    if (!b.ws || (bwd && !b.dws)) return EG3D_ERR_INVALID;
+    bool wants_wgrad = false;
+    for (int l = 0; l < b.nlayers && l < EG3D_STYLE_BANK_MAX; ++l) wants_wgrad |= b.layers[l].dweight != nullptr || b.layers[l].dbias != nullptr;
+    if (!b.ws || (bwd && !b.dws && !wants_wgrad)) return EG3D_ERR_INVALID;
     if ((reinterpret_cast<uintptr_t>(b.ws) & 15) || (bwd && (reinterpret_cast<uintptr_t>(b.dws) & 15))) return EG3D_ERR_UNSUPPORTED;
     for (int l = 0; l < b.nlayers; ++l) {
         const eg3d_style_layer& ly = b.layers[l];
         if (!ly.weight || ly.C < 1 || ly.wrow < 0 || ly.wrow >= b.L) return EG3D_ERR_INVALID;
         if (!bwd && !ly.out) return EG3D_ERR_INVALID;
-        if (reinterpret_cast<uintptr_t>(ly.weight) & 15) return EG3D_ERR_UNSUPPORTED;
+        if ((reinterpret_cast<uintptr_t>(ly.weight) & 15) || (reinterpret_cast<uintptr_t>(ly.dweight) & 15)) return EG3D_ERR_UNSUPPORTED;
     }
     return EG3D_OK;
 }
@@ -192,7 +227,10 @@ extern "C" int eg3d_style_affine_bwd(const eg3d_style_bank* pb, void* stream) {
         }
     }
     if (dblocks > 0) hipLaunchKernelGGL(style_demod_bwd_kernel, dim3(dblocks), dim3(256), 0, (hipStream_t)stream, *pb);
-    hipLaunchKernelGGL(style_affine_bwd_kernel, dim3(total_tiles(*pb, ROWS_PER_BLOCK_BWD)), dim3(128), 0, (hipStream_t)stream, *pb);
+    if (pb->dws != nullptr) hipLaunchKernelGGL(style_affine_bwd_kernel, dim3(total_tiles(*pb, ROWS_PER_BLOCK_BWD)), dim3(128), 0, (hipStream_t)stream, *pb);
+    bool wants_wgrad = false;
+    for (int l = 0; l < pb->nlayers; ++l) wants_wgrad |= pb->layers[l].dweight != nullptr || pb->layers[l].dbias != nullptr;
+    if (wants_wgrad) hipLaunchKernelGGL(style_affine_wgrad_kernel, dim3(total_tiles(*pb, ROWS_PER_BLOCK_BWD)), dim3(128), 0, (hipStream_t)stream, *pb);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -78,7 +78,7 @@ class FlreluParams(C.Structure):
 class StyleLayer(C.Structure):
     _fields_ = [('weight', C.c_void_p), ('bias', C.c_void_p), ('out', C.c_void_p), ('dout', C.c_void_p), ('C', C.c_int32), ('wrow', C.c_int32),
                 ('wgain', C.c_float), ('bgain', C.c_float), ('post', C.c_float), ('Co', C.c_int32),
-                ('wsq', C.c_void_p), ('d', C.c_void_p), ('dd', C.c_void_p), ('dout_extra', C.c_void_p)]
+                ('wsq', C.c_void_p), ('d', C.c_void_p), ('dd', C.c_void_p), ('dout_extra', C.c_void_p), ('dweight', C.c_void_p), ('dbias', C.c_void_p)]
 
 
 STYLE_BANK_MAX = 32

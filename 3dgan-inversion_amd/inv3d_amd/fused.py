@@ -229,7 +229,7 @@ class StyleBankFn(torch.autograd.Function):
     """Styles -- and, for the conv layers, demodulation coefficients -- of all modulated layers of a network from two launches
     (eg3d_style_affine_fwd/_bwd).  apply(ws, plan, *weights_and_biases) -> tuple: the L styles [N, C_l], then one d [N, Co_l] per
     layer whose plan entry carries wsq.  plan = tuple of (wrow, wgain, bgain, post, has_bias, wsq | None) per layer.  Gradients flow
-    to ws only (the affines and conv weights are frozen on this path: callers fall back to the per-layer modules otherwise)."""
+    to ws and to the affine weights / biases that require them; the demodulation part is only used with frozen conv weights."""
 
     @staticmethod
     def forward(ctx, ws, plan, *params):
@@ -255,39 +255,55 @@ class StyleBankFn(torch.autograd.Function):
         nl = len(ctx.layers)
         saved = ctx.saved_tensors
         outs, dsaved = saved[:nl], list(saved[nl:])
+        dev = ctx.ws.device
+        # which affine parameters want a gradient (pivotal tuning): needs_input_grad is aligned with (ws, plan, *params)
+        want, pi = [], 2
+        for ly in ctx.layers:
+            ww = ctx.needs_input_grad[pi]
+            wb = ly[1] is not None and ctx.needs_input_grad[pi + 1]
+            want.append((ww, wb))
+            pi += 2 if ly[1] is not None else 1
+        any_w = any(a or b for a, b in want)
         dws = None
+        if not (ctx.needs_input_grad[0] or any_w):
+            return (None, None) + (None,) * (pi - 2)
         if ctx.needs_input_grad[0]:
-            dev = ctx.ws.device
             dws = H.zeros(ctx.ws.shape, dev)
-            douts = [g.contiguous().float() if g is not None else None for g in grads[:nl]]
-            dds = [g.contiguous().float() if g is not None else None for g in grads[nl:]]
-            demod, di = [], 0
-            extra_shapes = [tuple(o.shape) if q is not None else None for o, q in zip(outs, ctx.wsqs)]
-            extras = _zeros_views(dev, *extra_shapes)
-            for q, ex in zip(ctx.wsqs, extras):
-                if q is None:
-                    demod.append(None)
-                else:
-                    demod.append((q, dsaved[di], dds[di], ex))
-                    di += 1
-            H.style_affine(ctx.ws, ctx.layers, outs=outs, douts=douts, dws=dws, demod=demod, backward=True)
-        return (dws, None) + (None,) * sum(2 if ly[1] is not None else 1 for ly in ctx.layers)
+        douts = [g.contiguous().float() if g is not None else None for g in grads[:nl]]
+        dds = [g.contiguous().float() if g is not None else None for g in grads[nl:]]
+        demod, di = [], 0
+        extra_shapes = [tuple(o.shape) if q is not None else None for o, q in zip(outs, ctx.wsqs)]
+        extras = _zeros_views(dev, *extra_shapes)
+        for q, ex in zip(ctx.wsqs, extras):
+            if q is None:
+                demod.append(None)
+            else:
+                demod.append((q, dsaved[di], dds[di], ex))
+                di += 1
+        dW = [torch.empty_like(ly[0]) if (w_ and g is not None) else None for ly, (w_, _), g in zip(ctx.layers, want, douts)]
+        dB = [torch.empty_like(ly[1]) if (b_ and g is not None) else None for ly, (_, b_), g in zip(ctx.layers, want, douts)]
+        H.style_affine(ctx.ws, ctx.layers, outs=outs, douts=douts, dws=dws, demod=demod, backward=True, dweights=dW if any_w else None,
+                       dbiases=dB if any_w else None)
+        pg = []
+        for ly, w_, b_ in zip(ctx.layers, dW, dB):
+            pg.append(w_)
+            if ly[1] is not None:
+                pg.append(b_)
+        return (dws, None) + tuple(pg)
 
 
 def style_bank(ws, entries):
     """entries: list of (FullyConnectedLayer affine, ws row index, post scale, conv layer | None).  Returns (styles, demods) -- two
-    lists aligned with `entries` (demods[i] is None for layers without demodulation) -- or None when the bank does not apply (an
-    affine or conv weight requires grad, non-linear activation, too many layers)."""
+    lists aligned with `entries` (demods[i] is None for layers without demodulation or with trainable conv weights) -- or None when
+    the bank does not apply (non-linear activation, too many layers)."""
     if len(entries) > L.STYLE_BANK_MAX or not ws.is_cuda:
         return None
     plan, params = [], []
     for fc, wrow, post, conv in entries:
-        if fc.activation != 'linear' or fc.weight.requires_grad or (fc.bias is not None and fc.bias.requires_grad):
+        if fc.activation != 'linear' or fc.weight.dtype != torch.float32:
             return None
         wsq = None
-        if conv is not None:
-            if conv.weight.requires_grad:
-                return None
+        if conv is not None and not conv.weight.requires_grad:     # trainable conv weights: the layer computes (and differentiates) its own demodulation
             wsq = conv._cache.get(conv.weight)[2]
         plan.append((int(wrow), float(fc.weight_gain), float(fc.bias_gain), float(post), fc.bias is not None, wsq))
         params.append(fc.weight)
@@ -296,8 +312,8 @@ def style_bank(ws, entries):
     res = list(StyleBankFn.apply(ws, tuple(plan), *params))
     styles, rest = res[:len(entries)], res[len(entries):]
     demods, di = [], 0
-    for e in entries:
-        if e[3] is not None:
+    for e, pl in zip(entries, plan):
+        if pl[5] is not None:
             demods.append(rest[di])
             di += 1
         else:

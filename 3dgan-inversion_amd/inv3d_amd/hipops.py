@@ -407,10 +407,11 @@ def rows_gram(a, b):
     return out, cs
 
 
-def style_affine(ws, layers, outs=None, douts=None, dws=None, demod=None, backward=False):
+def style_affine(ws, layers, outs=None, douts=None, dws=None, demod=None, backward=False, dweights=None, dbiases=None):
     """eg3d_style_affine_fwd / _bwd.  ws: [N,L,D] contiguous fp32; layers: sequence of (weight [C,D], bias [C] | None, wrow, wgain,
     bgain, post); outs: per-layer [N,C] styles (written by fwd, read by bwd); demod: per layer None or (wsq [Co,C], d [N,Co],
-    dd [N,Co] | None, dout_extra [N,C] | None) -- the demodulation coefficients of the layer's conv and their backward."""
+    dd [N,Co] | None, dout_extra [N,C] | None) -- the demodulation coefficients of the layer's conv and their backward;
+    dweights / dbiases: per layer None or the tensor that receives the gradient of that layer's affine weight / bias (backward)."""
     assert ws.is_contiguous() and ws.dtype == torch.float32 and len(layers) <= L.STYLE_BANK_MAX
     b = L.StyleBank()
     b.ws, b.N, b.L, b.D, b.nlayers = ws.data_ptr(), ws.shape[0], ws.shape[1], ws.shape[2], len(layers)
@@ -422,6 +423,11 @@ def style_affine(ws, layers, outs=None, douts=None, dws=None, demod=None, backwa
         ly.C, ly.wrow, ly.wgain, ly.bgain, ly.post = w.shape[0], int(wrow), float(wgain), float(bgain), float(post)
         ly.out = outs[i].data_ptr() if outs is not None else None
         ly.dout = douts[i].data_ptr() if (douts is not None and douts[i] is not None) else None
+        if dweights is not None and dweights[i] is not None:
+            assert dweights[i].is_contiguous() and dweights[i].shape == w.shape
+            ly.dweight = dweights[i].data_ptr()
+        if dbiases is not None and dbiases[i] is not None:
+            ly.dbias = dbiases[i].data_ptr()
         dm = demod[i] if demod is not None else None
         if dm is not None:
             wsq, d, dd, extra = dm

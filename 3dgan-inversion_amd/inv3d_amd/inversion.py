@@ -373,8 +373,17 @@ class PivotalTuner:
         self.optimizer = torch.optim.Adam(G.parameters(), lr=lr)
         self.synth_kwargs = dict(synth_kwargs or {})
         self.last = {}
+        self._arena = None
 
     def step(self, early_stop: bool = False, **step_kwargs) -> Dict[str, torch.Tensor]:
+        # every zero-initialised accumulator of the step (split-K outputs, gradient sums) comes out of one arena cleared by one launch;
+        # nothing allocated from it outlives the step (gradients are consumed by optimizer.step() below)
+        if self._arena is None:
+            self._arena = hipops.ZeroArena(self.target.device)
+        with hipops.zero_arena(self._arena):
+            return self._step(early_stop, **step_kwargs)
+
+    def _step(self, early_stop: bool = False, **step_kwargs) -> Dict[str, torch.Tensor]:
         G = self.G
         out = G.synthesis(self.w_pivot[:, :G.backbone.num_ws], self.cam[:, :25], **dict(self.synth_kwargs, **step_kwargs))
         l2 = F.mse_loss(out['image'], self.target) + F.mse_loss(out['image_raw'], self.target_128)

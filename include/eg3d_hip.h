@@ -196,7 +196,9 @@ int eg3d_filtered_lrelu(const eg3d_flrelu_params* p, void* stream);
  *   fwd:  out_l[n,j] = ( sum_k ws[n,wrow_l,k] * (weight_l[j,k]*wgain_l) + bias_l[j]*bgain_l ) * post_l
  *         d_l[n,o]   = rsqrt( sum_j out_l[n,j]^2 wsq_l[o,j] + 1e-8 )                      (layers with wsq: second launch)
  *   bwd:  dout_extra_l[n,j] += -out_l[n,j] * sum_o dd_l[n,o] d_l[n,o]^3 wsq_l[o,j]        (layers with dd: first launch)
- *         dws[n,wrow_l,k] += sum_j (dout_l[n,j] + dout_extra_l[n,j]) * post_l * (weight_l[j,k]*wgain_l)   (dws pre-zeroed)
+ *         dws[n,wrow_l,k] += sum_j (dout_l[n,j] + dout_extra_l[n,j]) * post_l * (weight_l[j,k]*wgain_l)   (dws pre-zeroed; null = skip)
+ *         dweight_l[j,k]   = sum_n (dout_l[n,j] + dout_extra_l[n,j]) * post_l * wgain_l * ws[n,wrow_l,k]  (trainable affines: the
+ *         dbias_l[j]       = sum_n (dout_l[n,j] + dout_extra_l[n,j]) * post_l * bgain_l                     pivotal-tuning phase)
  * ws/dws: [N,L,D] fp32, D a multiple of 4; weight_l: [C_l,D] row-major. */
 #define EG3D_STYLE_BANK_MAX 32
 typedef struct eg3d_style_layer {
@@ -208,6 +210,8 @@ typedef struct eg3d_style_layer {
     float* d;                  /* fwd out: [N, Co] demodulation coefficients rsqrt(sum_k out[n,k]^2 wsq[o,k] + 1e-8)               */
     const float* dd;           /* bwd in : [N, Co] gradient w.r.t. d, or null                                                     */
     float* dout_extra;         /* bwd scratch: [N, C] zeroed; receives the style gradient that flows through d; added to dout    */
+    float* dweight;            /* bwd out: [C, D] gradient of `weight` (overwritten), or null                                    */
+    float* dbias;              /* bwd out: [C] gradient of `bias` (overwritten), or null                                         */
 } eg3d_style_layer;
 typedef struct eg3d_style_bank {
     const float* ws;  float* dws;
