@@ -209,14 +209,14 @@ class ModConvLayerFn(torch.autograd.Function):
                 H.conv_igemm(g, wa, Co, Ci, z, cls_adj, in_stride=in_stride, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=prec, a_amax=amax,
                              a_amax_mul=amul)
                 H.dgrad_finish(z, x, styles, dx, ds=ds)
-        dwsq = torch.zeros_like(wsq) if need_w else None
+        dwsq = H.zeros(wsq.shape, dev) if need_w else None
         if dd is not None and (need_s or need_w) and not d_given:       # with d from the style bank, dd is returned and handled there
             if ds is None:
                 ds = H.zeros((N, Ci), dev)
             H.demod_bwd(styles, wsq, d, dd, ds=ds if need_s else None, dwsq=dwsq)
         dweight = None
         if need_w:
-            dwp = torch.zeros_like(wf)
+            dwp = H.zeros(wf.shape, dev)
             H.conv_wgrad(x, g, Ci, Co, dwp, cls_w, in_stride=1, out_stride=out_stride_w, in_scale=styles)
             dweight = dwp.view(Co, kh, kw, Ci).permute(0, 3, 1, 2) + 2.0 * weight * dwsq[:, :, None, None]
         if dnoise is not None and noise4d:
@@ -389,7 +389,7 @@ class ToRGBFn(torch.autograd.Function):
             dx = dx_pass
         dweight = None
         if need_w:
-            dwp = torch.zeros((Co, Ci), device=dev)
+            dwp = H.zeros((Co, Ci), dev)
             H.conv_wgrad(x, dy, Ci, Co, dwp, H.classes_corr(Hh, Ww, 1, 1, 0), in_scale=styles)
             dweight = dwp.view(Co, Ci, 1, 1)
         return (dx if need_x else None, dweight, ds if need_s else None, dbias, dout if (need_skip and has_skip) else None, None, None, None, None)
