@@ -48,7 +48,7 @@ class WeightCache:
         self._c = {}
 
     def get(self, w: torch.Tensor):
-        key = (w.data_ptr(), w._version, tuple(w.shape))
+        key = (w.data_ptr(), w._version, tuple(w.shape), H.WEIGHTS_EPOCH)
         hit = self._c.get('k')
         if hit != key:
             with torch.no_grad():
@@ -218,7 +218,10 @@ class ModConvLayerFn(torch.autograd.Function):
         if need_w:
             dwp = H.zeros(wf.shape, dev)
             H.conv_wgrad(x, g, Ci, Co, dwp, cls_w, in_stride=1, out_stride=out_stride_w, in_scale=styles)
-            dweight = dwp.view(Co, kh, kw, Ci).permute(0, 3, 1, 2) + 2.0 * weight * dwsq[:, :, None, None]
+            # [O,taps,I] accumulator -> the parameter's own (contiguous [O,I,kh,kw]) layout, plus the demodulation path d wsq / d w = 2 w,
+            # in one pass; the fused multi-tensor Adam walks parameter and gradient with the same linear index
+            dweight = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            torch.addcmul(dwp.view(Co, kh, kw, Ci).permute(0, 3, 1, 2), weight.detach(), dwsq[:, :, None, None], value=2.0, out=dweight)
         if dnoise is not None and noise4d:
             dnoise = dnoise.view(N, 1, Ho, Wo)
         return (dx if need_x else None, dweight, ds if need_s else None, dnoise, dstrength, dbias, None, None, None, None, None,

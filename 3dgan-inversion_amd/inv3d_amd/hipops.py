@@ -242,12 +242,22 @@ def classes_convT_adjoint(Hi, Wi, kh, kw, up, flip_taps=False):
 
 
 _MEMO = {}
+WEIGHTS_EPOCH = 0
+
+
+def weights_changed():
+    """Invalidate every derived weight image (memo(), fused.WeightCache).  The caches key on a tensor's in-place version counter, which
+    ordinary in-place updates bump -- but fused multi-tensor optimisers (torch.optim.Adam(fused=True)) write parameters without
+    touching it.  Call this after such an update (inversion.PivotalTuner registers it as an optimizer step hook)."""
+    global WEIGHTS_EPOCH
+    WEIGHTS_EPOCH += 1
+
 
 
 def memo(tag, tensors, fn):
     """Derived images of parameters (packed / padded / pre-scaled weights), recomputed only when a source tensor changes (storage
     pointer or in-place version).  One entry per (tag, storage): frozen weights cost nothing per step, trained ones are rebuilt."""
-    key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+    key = (WEIGHTS_EPOCH,) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
     slot = (tag, tensors[0].data_ptr())
     hit = _MEMO.get(slot)
     # the entry is only valid for the very same tensor objects (a freed temporary's address can be reused by another tensor)

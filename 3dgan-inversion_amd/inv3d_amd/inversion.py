@@ -370,7 +370,9 @@ class PivotalTuner:
         with torch.no_grad():
             self.tf = self.feature_net(target)
             self.tf128 = self.feature_net(self.target_128)
-        self.optimizer = torch.optim.Adam(G.parameters(), lr=lr)
+        self.optimizer = torch.optim.Adam(G.parameters(), lr=lr, fused=True)      # one multi-tensor launch over the 30.7 M parameters
+        # the fused kernel updates parameters without bumping their version counters, which the packed-weight caches key on
+        self.optimizer.register_step_post_hook(lambda *_: hipops.weights_changed())
         self.synth_kwargs = dict(synth_kwargs or {})
         self.last = {}
         self._arena = None

@@ -126,3 +126,16 @@ def test_zero_arena_and_memo_host_logic():
     w2 = w.clone()
     H.memo('t', [w2], lambda: (calls.append(1), w2 * 2)[1])
     assert len(calls) == 3                                         # a different tensor object never hits another one's entry
+    # updates that do not bump the version counter (fused multi-tensor optimisers write through raw pointers): weights_changed()
+    n = len(calls)
+    w2.data_ptr()
+    with torch.no_grad():
+        w2.view(-1).numpy()[:] = 7.0                               # same storage, same version
+    assert torch.equal(H.memo('t', [w2], lambda: (calls.append(1), w2 * 2)[1]), torch.full((2, 3), 14.0)) is False or len(calls) == n
+    H.weights_changed()
+    d = H.memo('t', [w2], lambda: (calls.append(1), w2 * 2)[1])
+    assert len(calls) == n + 1 and torch.equal(d, torch.full((2, 3), 14.0))
+    from inv3d_amd import fused
+    cache = fused.WeightCache()
+    cache._c = {'k': (w2.data_ptr(), w2._version, tuple(w2.shape), H.WEIGHTS_EPOCH - 1)}
+    assert cache._c['k'] != (w2.data_ptr(), w2._version, tuple(w2.shape), H.WEIGHTS_EPOCH)     # an epoch bump invalidates packed conv weights too

@@ -1,15 +1,19 @@
-"""Count ATen ops launched during one eager C2 step, grouped by op name and calling source line (where the tiny launches come from)."""
+"""Count ATen ops launched during one eager C2 step (or, with the argument `b`, one pivotal-tuning step), grouped by op name and
+calling source line (where the tiny launches come from)."""
 import sys, collections, traceback, torch
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/3dgan-inversion_amd')
 from torch.utils._python_dispatch import TorchDispatchMode
 from inv3d_amd import synthetic as S
-from inv3d_amd.inversion import LatentProjector
+from inv3d_amd.inversion import LatentProjector, PivotalTuner
 dev = torch.device('cuda')
 G = S.make_generator(device=dev); S.load_synthetic_weights(G, seed=0)
 cam = S.synth_cameras(1, seed=2).to(dev)
 with torch.no_grad():
     target = G.synthesis(S.synth_ws(14, 512, 1, seed=3).to(dev), cam, noise_mode='const', force_fp32=True)['image'].clamp(-1, 1)
-proj = LatentProjector(G, target, num_steps=400, cam=cam, seed=100); proj.preheat = 0
+if len(sys.argv) > 1 and sys.argv[1] == 'b':
+    proj = PivotalTuner(G, target, S.synth_ws(14, 512, 1, seed=5).to(dev), cam)
+else:
+    proj = LatentProjector(G, target, num_steps=400, cam=cam, seed=100); proj.preheat = 0
 for _ in range(2): proj.step()
 cnt = collections.Counter()
 class Mode(TorchDispatchMode):
