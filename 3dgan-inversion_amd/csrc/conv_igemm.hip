@@ -106,7 +106,10 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
     char* const As_b = reinterpret_cast<char*>(smem);               // [2] stages
     char* const Bs_b = As_b + 2 * A_STAGE;
     float* As = smem;
-    int* rowpix = reinterpret_cast<int*>(Bs_b + 2 * B_STAGE);   // [BM] output pixel index (n*Ho+oy)*Wo+ox, -1 = none
+    // the row bookkeeping sits behind whichever is larger: the operand stages or the vector epilogue's staging area (which reuses them)
+    constexpr int OPER_BYTES = 2 * (A_STAGE + B_STAGE);
+    constexpr int EPI_STAGE_BYTES = VEC ? (BN + WM * 32 * (BN + 4)) * 4 : 0;
+    int* rowpix = reinterpret_cast<int*>(As_b + (OPER_BYTES > EPI_STAGE_BYTES ? OPER_BYTES : EPI_STAGE_BYTES));   // [BM] output pixel index (n*Ho+oy)*Wo+ox, -1 = none
     int* rown = rowpix + BM;                  // [BM] batch index
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -573,7 +576,9 @@ int launch_conv_pv(const eg3d_conv_params& p, hipStream_t st) {
     static bool attr_done = false;
     constexpr int NP = PREC == 1 ? 3 : 2;
     constexpr int KB = BM * BN >= 128 * 128 ? 16 : 32;
-    const size_t smem = (PREC ? (size_t)2 * (split_tile_bytes(BM, NP, KB) + split_tile_bytes(BN, NP, KB)) : (size_t)(2 * (BM + BN) * LDK) * sizeof(float)) + 2 * BM * sizeof(int);
+    const size_t loop_bytes = PREC ? (size_t)2 * (split_tile_bytes(BM, NP, KB) + split_tile_bytes(BN, NP, KB)) : (size_t)(2 * (BM + BN) * LDK) * sizeof(float);
+    const size_t stage_bytes = VEC ? (size_t)(BN + WM * 32 * (BN + 4)) * sizeof(float) : 0;        // epilogue staging reuses the operand buffers
+    const size_t smem = (loop_bytes > stage_bytes ? loop_bytes : stage_bytes) + 2 * BM * sizeof(int);
     auto kern = conv_igemm_kernel<BM, BN, WM, WN, PREC, VEC>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -618,7 +623,7 @@ int pick_config(const eg3d_conv_params& p) {
     if (maxM <= 32) return 2;
     // enough 128x128 tiles to fill the chip (2 blocks/CU)?  otherwise shrink the M tile
     int64_t big_tiles = (int64_t)eg3d_cdiv(maxM, 128) * eg3d_cdiv(p.Nc, 128) * p.ncls * p.ksplit;
-    if (big_tiles >= 384) return 0;
+    if (big_tiles >= 384) return 0;       // (a 256x128 tile with 8 waves was measured slower on every 512^2 / 256^2 layer: 192-227 vs 228-254 TFLOP/s)
     if (maxM <= 64 * 8) return 2;
     return 1;
 }

@@ -20,9 +20,10 @@ class LaunchProfiler:
     """Optional per-launch timing of the implicit-GEMM conv (bench.py roofline): HIP events recorded on the launch stream
     around every eg3d_conv2d_igemm_f32 call, with the launch's algorithmic FLOPs and tile configuration."""
 
-    def __init__(self, only_config=None):
+    def __init__(self, only_config=None, keep_meta=False):
         self.records = []          # (config_id, algo_flops, start_event, end_event)
         self.only_config = only_config      # time only launches of this tile configuration (keeps the event overhead small)
+        self.meta = [] if keep_meta else None      # per record: launch geometry (tools/conv_launch_table.py)
 
     def summary(self):
         out = {}
@@ -354,6 +355,9 @@ def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=
     if prof is not None:
         e1.record()
         prof.records.append((cfg, float(algo_flops), e0, e1))
+        if prof.meta is not None:
+            prof.meta.append(dict(N=n, Hi=hi, Wi=wi, Ck=Ck, Nc=Nc, Ho=ho, Wo=wo, taps=[c.ntaps for c in classes], epi=epi, ksplit=ksplit,
+                                  in_stride=in_stride, out_stride=out_stride, prec=p.precision))
     return out
 
 
