@@ -40,7 +40,7 @@ class InversionCoach:
     def __init__(self, G, *, first_inv_steps: int = 400, max_pti_steps: int = 400, lpips_threshold: float = 0.06, first_inv_lr: float = 8e-3,
                  pti_lr: float = 3e-4, optimize_pose: bool = False, use_warping_loss: bool = False, wplus: bool = False,
                  feature_net: Optional[Callable] = None, early_stop_interval: int = 1, use_graph: bool = False, keep_tuned_state: bool = False,
-                 synth_kwargs: Optional[dict] = None, seed: int = 0):
+                 synth_kwargs: Optional[dict] = None, seed: int = 0, pose_net_factory: Optional[Callable] = None):
         """Hyper-parameter names and defaults follow configs/hyperparameters.py.  `early_stop_interval` = how often Phase B reads the
         perceptual loss back to the host for the early-stop test (1 = every step like the reference; larger values keep the host from
         stalling the GPU queue every step)."""
@@ -50,6 +50,7 @@ class InversionCoach:
         self.optimize_pose, self.use_warp, self.wplus = optimize_pose, use_warping_loss, wplus
         self.feature_net, self.interval, self.use_graph, self.keep = feature_net, max(1, early_stop_interval), use_graph, keep_tuned_state
         self.synth_kwargs, self.seed = dict(synth_kwargs or {}), seed
+        self.pose_net_factory = pose_net_factory      # () -> a fresh pose estimator per image (the reference deep-copies its encoder, w_projector.py:62)
         # pristine copy of every parameter and buffer: what "re-loading the generator" means without a pickle on disk
         self._pristine = {k: v.detach().clone() for k, v in G.state_dict().items()}
 
@@ -72,7 +73,8 @@ class InversionCoach:
         proj = LatentProjector(G, target, num_steps=self.first_inv_steps, cam=cam, optimize_pose=self.optimize_pose,
                                use_warping_loss=self.use_warp, first_inv_lr=self.first_inv_lr, wplus=self.wplus,
                                feature_net=self.feature_net, synth_kwargs=self.synth_kwargs, seed=self.seed,
-                               use_graph=self.use_graph and not self.optimize_pose)
+                               use_graph=self.use_graph and not self.optimize_pose,
+                               pose_net=self.pose_net_factory() if (self.pose_net_factory is not None and self.optimize_pose) else None)
         out = {}
         for _ in range(self.first_inv_steps):
             out = proj.step()

@@ -153,13 +153,15 @@ class LatentProjector:
                  first_inv_lr=8e-3, cam_lr=6e-7, translation_lr=2e-4, cam_preheat_steps=50, initial_noise_factor=0.05,
                  noise_ramp_length=0.75, lr_rampdown_length=0.25, lr_rampup_length=0.05, regularize_noise_weight=1e5,
                  initial_learning_rate=0.01, radius=2.7, wplus=False, synth_kwargs: Optional[dict] = None, seed: int = 0,
-                 init_noise: Optional[Dict[str, torch.Tensor]] = None, use_graph: bool = False, graph_warmup: int = 2):
+                 init_noise: Optional[Dict[str, torch.Tensor]] = None, use_graph: bool = False, graph_warmup: int = 2,
+                 pose_net: Optional[torch.nn.Module] = None):
         dev = target.device
         if use_graph and optimize_pose:
             raise ValueError('use_graph: the pose chain skips optimiser steps during the preheat (data-dependent control flow on the host)')
         self.use_graph, self._graph, self._graph_warmup, self.graph_capture_error = use_graph, None, graph_warmup, None
         self.G = G.eval().requires_grad_(False)
         self.dev = dev
+        self.pose_net = None
         self.num_steps, self.preheat = num_steps, (cam_preheat_steps if optimize_pose else 0)
         self.w_std, self.noise_factor, self.noise_ramp = w_std, initial_noise_factor, noise_ramp_length
         self.lr_down, self.lr_up, self.lr0, self.reg_w = lr_rampdown_length, lr_rampup_length, initial_learning_rate, regularize_noise_weight
@@ -208,7 +210,12 @@ class LatentProjector:
             # quaternion itself is the optimisable state ("ResNet34 optional stub")
             self.quat = torch.tensor([[0., 1., 0., 0.]], device=dev).requires_grad_(True)     # = init_ext rotation
             self.translation_opt = torch.zeros(1, 3, device=dev, requires_grad=True)
-            self.cam_optimizer = torch.optim.Adam([self.quat], lr=cam_lr, betas=(0.9, 0.999))
+            # pose_net (pose_net.ResNetPose or any module image -> quaternion): the reference's per-image fine-tuned estimator,
+            # cam_predictor(target_images) every step with Adam over all its parameters (w_projector.py:62,122,148-150)
+            self.pose_net = pose_net
+            if pose_net is not None:
+                pose_net.requires_grad_(True)
+            self.cam_optimizer = torch.optim.Adam(list(pose_net.parameters()) if pose_net is not None else [self.quat], lr=cam_lr, betas=(0.9, 0.999))
             self.translation_optimizer = torch.optim.Adam([self.translation_opt], lr=translation_lr)
         self.step_idx = 0
         self.last = {}
@@ -297,7 +304,7 @@ class LatentProjector:
     def _step_body_inner(self, w_noise_scale, wn, kw, do_step):
         G = self.G
         if self.optimize_pose:
-            rot = quaternion_to_rotmat(self.quat)
+            rot = quaternion_to_rotmat(self.pose_net(self.target) if self.pose_net is not None else self.quat)
             pred_ext, pred_cam = pose_to_cam(rot, self.translation_opt, self.intrinsic, self.radius)
         else:
             pred_ext, pred_cam = None, self.cam

@@ -75,7 +75,9 @@ def _launch_groups(x, wp, Ck, Nc, out, classes, accumulate, **kw):
 
 
 class _ConvActFn(torch.autograd.Function):
-    """y = act(conv2d(x, w, stride, pad) + b) with frozen w, b.  x, y: fp32 channels-last, channel counts multiples of 4."""
+    """y = act(conv2d(x, w, stride, pad) + b).  x, y: fp32 channels-last, channel counts multiples of 4.  The loss networks call it
+    with frozen w, b (forward + data gradient); with trainable w / b (the pose estimator, pose_net.py) the weight gradient comes from
+    eg3d_conv2d_wgrad_f32 over the same tap classes and the bias gradient is the pixel sum of the pre-activation gradient."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, act):
@@ -84,11 +86,12 @@ class _ConvActFn(torch.autograd.Function):
         N, Cip, Hi, Wi = x.shape
         Co, Ci, kh, kw = weight.shape
         assert Ci <= Cip and Cip % 4 == 0 and Co % 4 == 0, (weight.shape, x.shape)
+        trainable = ctx.needs_input_grad[1]
 
         def _pack():
             wp = torch.cat([weight, weight.new_zeros(Co, Cip - Ci, kh, kw)], 1) if Cip != Ci else weight
             return H.pack_weight_fwd(wp.detach().float())
-        wf = H.memo(('lossnet_fwd', Cip), [weight], _pack)
+        wf = _pack() if trainable else H.memo(('lossnet_fwd', Cip), [weight], _pack)      # trainable weights are new tensors every step
         Ho, Wo = (Hi + 2 * pad - kh) // stride + 1, (Wi + 2 * pad - kw) // stride + 1
         cls = _classes_strided(Ho, Wo, kh, kw, pad)
         ks = _auto_ksplit(cls, N, Co, Cip) if len(cls) == 1 else 1
@@ -99,30 +102,40 @@ class _ConvActFn(torch.autograd.Function):
             z = H.zeros_cl(N, Co, Ho, Wo, x.device)
             _launch_groups(x, wf, Cip, Co, z, cls, True, in_stride=stride, ksplit=ks)
             y = H.bias_act_raw(z, bias, None, None, None, 0, 1, L.ACT_IDS[act], 0.0, 1.0, -1.0)
-        ctx.save_for_backward(y, weight)
-        ctx.cfg = (stride, pad, act, x.shape)
+        ctx.save_for_backward(y, weight, x if trainable else None)
+        ctx.cfg = (stride, pad, act, x.shape, (Ho, Wo))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        y, weight = ctx.saved_tensors
-        stride, pad, act, (N, Cip, Hi, Wi) = ctx.cfg
+        y, weight, x = ctx.saved_tensors
+        stride, pad, act, (N, Cip, Hi, Wi), (Ho, Wo) = ctx.cfg
         Co, Ci, kh, kw = weight.shape
-        if not ctx.needs_input_grad[0]:
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        if not (need_x or need_w or need_b):
             return (None,) * 6
         dy = H.to_cl(dy.float())
         dz = dy if act == 'linear' else H.bias_act_raw(dy, None, None, y, None, 1, 1, L.ACT_IDS[act], 0.0, 1.0, -1.0)
-
-        def _pack():
-            wp = torch.cat([weight, weight.new_zeros(Co, Cip - Ci, kh, kw)], 1) if Cip != Ci else weight
-            return H.pack_weight_adj(wp.detach().float())                 # [Cip, taps*Co]
-        wa = H.memo(('lossnet_adj', Cip), [weight], _pack)
-        cls, overlapping = _classes_strided_adjoint(Hi, Wi, kh, kw, stride, pad)
-        ks = _auto_ksplit(cls, N, Cip, Co) if len(cls) == 1 else 1
-        overlapping |= ks > 1
-        dx = (H.zeros_cl if overlapping else H.empty_cl)(N, Cip, Hi, Wi, dy.device)
-        _launch_groups(dz, wa, Co, Cip, dx, cls, overlapping, out_stride=stride, ksplit=ks)
-        return dx, None, None, None, None, None
+        dx = dw = db = None
+        if need_x:
+            def _pack():
+                wp = torch.cat([weight, weight.new_zeros(Co, Cip - Ci, kh, kw)], 1) if Cip != Ci else weight
+                return H.pack_weight_adj(wp.detach().float())                 # [Cip, taps*Co]
+            wa = _pack() if need_w else H.memo(('lossnet_adj', Cip), [weight], _pack)
+            cls, overlapping = _classes_strided_adjoint(Hi, Wi, kh, kw, stride, pad)
+            ks = _auto_ksplit(cls, N, Cip, Co) if len(cls) == 1 else 1
+            overlapping |= ks > 1
+            dx = (H.zeros_cl if overlapping else H.empty_cl)(N, Cip, Hi, Wi, dy.device)
+            _launch_groups(dz, wa, Co, Cip, dx, cls, overlapping, out_stride=stride, ksplit=ks)
+        if need_w:
+            dwp = H.zeros((Co, kh * kw * Cip), dy.device)
+            cls = _classes_strided(Ho, Wo, kh, kw, pad)
+            for i in range(0, len(cls), 4):
+                H.conv_wgrad(x, dz, Cip, Co, dwp, cls[i:i + 4], in_stride=stride, out_stride=1)
+            dw = dwp.view(Co, kh, kw, Cip)[..., :Ci].permute(0, 3, 1, 2).contiguous()
+        if need_b:
+            db = dz.sum((0, 2, 3))
+        return dx, dw, db, None, None, None
 
 
 def conv_act(x, weight, bias, stride=1, pad=0, act='relu'):
@@ -250,7 +263,7 @@ class _VGG16Trunk(torch.nn.Module):
                     if i in taps:
                         outs[i] = x
             elif kind[0] == 'relu':                          # only reached when the conv output itself was tapped
-                x = bias_act.bias_act(x, None, act='relu')
+                x = bias_act.bias_act(x, None, act='relu', gain=1)
                 if i in taps:
                     outs[i] = x
             else:

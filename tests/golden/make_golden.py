@@ -713,10 +713,45 @@ def gen_inference():
     save('inference', 2e-5, **out)
 
 
+GRAD_KEYS_POSE = ('conv1.weight', 'bn1.weight', 'bn1.bias', 'layer1.0.conv2.weight', 'layer2.0.downsample.0.weight', 'layer2.0.downsample.1.weight',
+                  'layer3.2.bn1.bias', 'layer4.2.conv1.weight', 'fc.weight', 'fc3.bias')
+
+
+def gen_pose_net():
+    """In-loop pose estimator: the reference's own ResNet class (scripts/resnet/resnet.py) in eval mode."""
+    print('pose estimator (ResNet-34)')
+    sys.path.insert(0, os.path.join(REF, 'scripts'))
+    from resnet import resnet as ref_resnet
+    from oracle import pose_net_oracle as PO
+    out = {}
+    for dims in (4, 6):
+        net = ref_resnet.resnet34(output_dims=dims).eval()
+        sd = PO.synth_state(seed=3, output_dims=dims)
+        net.load_state_dict(sd, strict=True)
+        img = O._randn('pose_img', dims, (2, 3, 64, 64)).clamp(-1, 1)
+        y = net(img)
+        gy = O._randn('pose_gy', dims, y.shape)
+        params = dict(net.named_parameters())
+        grads = torch.autograd.grad(y, [params[k] for k in GRAD_KEYS_POSE], gy)
+        sdo = {k: (v.clone().requires_grad_(True) if k in GRAD_KEYS_POSE else v) for k, v in sd.items()}
+        yo = PO.forward(sdo, img)
+        check(yo, y, 1e-6, f'pose net output d={dims}')
+        go = torch.autograd.grad(yo, [sdo[k] for k in GRAD_KEYS_POSE], gy)
+        for k, a, b in zip(GRAD_KEYS_POSE, go, grads):
+            check(a, b, 1e-5, f'pose net grad {k}')
+        out.update({f'd{dims}_img': img, f'd{dims}_y': y, f'd{dims}_gy': gy})
+        for k, g in zip(GRAD_KEYS_POSE, grads):
+            if g.numel() <= 40000:
+                out[f'd{dims}_g.{k}'] = g
+            else:                           # large tensors: a strided sample
+                out[f'd{dims}_gs.{k}'] = g.flatten()[::97].clone()
+    save('pose_net', 1e-5, **out)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
     gens = dict(bias_act=gen_bias_act, upfirdn2d=gen_upfirdn2d, filtered_lrelu=gen_filtered_lrelu, conv=gen_conv2d_resample, renderer=gen_renderer,
-                graph_small=gen_graph_small, graph_full=gen_graph_full, loss=gen_loss_glue, inference=gen_inference)
+                graph_small=gen_graph_small, graph_full=gen_graph_full, loss=gen_loss_glue, inference=gen_inference, pose_net=gen_pose_net)
     mpath = os.path.join(HERE, 'MANIFEST.json')
     if only and os.path.exists(mpath):
         MANIFEST.update(json.load(open(mpath)).get('fixtures', {}))

@@ -238,3 +238,21 @@ def test_inference_consumers(golden):
     w_avg, w_std = IO.w_stats(P, cfg, 64)
     close(w_avg, t(d['w_avg64']), 1e-5)
     assert abs(w_std - float(d['w_std64'])) <= 1e-5 * max(1.0, float(d['w_std64']))
+
+
+def test_pose_net_oracle(golden):
+    """oracle/pose_net_oracle.py vs the reference's ResNet-34 pose estimator (outputs and parameter gradients, fixture `pose_net`)."""
+    from oracle import pose_net_oracle as PO
+    d = golden('pose_net')
+    keys = [k[len('d4_g.'):] for k in d.files if k.startswith('d4_g.')] + [k[len('d4_gs.'):] for k in d.files if k.startswith('d4_gs.')]
+    for dims in (4, 6):
+        sd = PO.synth_state(seed=3, output_dims=dims)
+        sd = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in sd.items()}
+        y = PO.forward(sd, t(d[f'd{dims}_img']))
+        close(y, t(d[f'd{dims}_y']), 1e-6)
+        grads = torch.autograd.grad(y, [sd[k] for k in keys], t(d[f'd{dims}_gy']))
+        for k, g in zip(keys, grads):
+            if f'd{dims}_g.{k}' in d.files:
+                close(g, t(d[f'd{dims}_g.{k}']), 1e-5)
+            else:
+                close(g.flatten()[::97], t(d[f'd{dims}_gs.{k}']), 1e-5)
