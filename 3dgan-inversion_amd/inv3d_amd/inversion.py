@@ -215,7 +215,10 @@ class LatentProjector:
             self.pose_net = pose_net
             if pose_net is not None:
                 pose_net.requires_grad_(True)
-            self.cam_optimizer = torch.optim.Adam(list(pose_net.parameters()) if pose_net is not None else [self.quat], lr=cam_lr, betas=(0.9, 0.999))
+            if pose_net is not None:       # 222 tensors: one multi-tensor launch (trainable conv weights are re-packed every step, no version-keyed cache involved)
+                self.cam_optimizer = torch.optim.Adam(list(pose_net.parameters()), lr=cam_lr, betas=(0.9, 0.999), fused=True)
+            else:
+                self.cam_optimizer = torch.optim.Adam([self.quat], lr=cam_lr, betas=(0.9, 0.999))
             self.translation_optimizer = torch.optim.Adam([self.translation_opt], lr=translation_lr)
         self.step_idx = 0
         self.last = {}
