@@ -73,7 +73,7 @@ class InversionCoach:
         proj = LatentProjector(G, target, num_steps=self.first_inv_steps, cam=cam, optimize_pose=self.optimize_pose,
                                use_warping_loss=self.use_warp, first_inv_lr=self.first_inv_lr, wplus=self.wplus,
                                feature_net=self.feature_net, synth_kwargs=self.synth_kwargs, seed=self.seed,
-                               use_graph=self.use_graph and not self.optimize_pose,
+                               use_graph=self.use_graph,
                                pose_net=self.pose_net_factory() if (self.pose_net_factory is not None and self.optimize_pose) else None)
         out = {}
         for _ in range(self.first_inv_steps):

@@ -103,6 +103,24 @@ def line_plane_intersection(plane_normal, plane_point, ray_dir, ray_point, eps=1
     return w_vec + si * ray_dir + plane_point
 
 
+_WARP_CONST = {}
+
+
+def _warp_constants(init_ext):
+    """(a point on the canonical image plane, world->canonical-camera matrix): functions of the constant canonical extrinsic only,
+    computed once (a host->device constant and a matrix inverse would otherwise sit inside every step and break graph capture)."""
+    key = (init_ext.data_ptr(), init_ext._version)
+    hit = _WARP_CONST.get(key)
+    if hit is None:
+        with torch.no_grad():
+            pt = torch.bmm(init_ext.reshape(-1, 4, 4), torch.tensor([[0., 0., 1., 1.]], device=init_ext.device).unsqueeze(-1)).squeeze(-1)[:, :3]
+            hit = (pt.clone(), torch.linalg.inv(init_ext.reshape(4, 4)).clone(), init_ext)
+        if len(_WARP_CONST) > 64:
+            _WARP_CONST.clear()
+        _WARP_CONST[key] = hit
+    return hit[0], hit[1]
+
+
 def warping_loss(G, ws, canonical_cam, extrinsic, init_ext, intrinsic, depth, target_feat, feat_fn, synth_kwargs=None):
     """Depth-reprojection loss (training/warping_loss.py:6-56): render the canonical view without gradient, lift the predicted
     depth to 3-D with the predicted extrinsic, project into the canonical image, sample canonical features there and compare
@@ -120,10 +138,10 @@ def warping_loss(G, ws, canonical_cam, extrinsic, init_ext, intrinsic, depth, ta
     xyz = (o + d * depth.reshape(1, -1, 1))[0]                                   # [res*res,3]; grad -> extrinsic, depth
     init_t = init_ext[:, :3, 3]
     cam_o = init_t.expand(xyz.shape[0], 3)
-    plane_pt = torch.bmm(init_ext.reshape(-1, 4, 4), torch.tensor([[0., 0., 1., 1.]], device=xyz.device).unsqueeze(-1)).squeeze(-1)[:, :3]
+    plane_pt, w2c = _warp_constants(init_ext)
     hit = line_plane_intersection(-cam_o, plane_pt.expand_as(cam_o), xyz - cam_o, cam_o)
     hit1 = torch.cat([hit, torch.ones(hit.shape[0], 1, device=hit.device)], -1).t()
-    uv = (torch.linalg.inv(init_ext.reshape(4, 4)) @ hit1)[:3].t()
+    uv = (w2c @ hit1)[:3].t()
     uv = uv / uv[:, 2:]
     uv = (intrinsic.reshape(3, 3) @ uv.t())[:2].t()
     uv = (uv - 0.5) * 2
@@ -156,8 +174,6 @@ class LatentProjector:
                  init_noise: Optional[Dict[str, torch.Tensor]] = None, use_graph: bool = False, graph_warmup: int = 2,
                  pose_net: Optional[torch.nn.Module] = None):
         dev = target.device
-        if use_graph and optimize_pose:
-            raise ValueError('use_graph: the pose chain skips optimiser steps during the preheat (data-dependent control flow on the host)')
         self.use_graph, self._graph, self._graph_warmup, self.graph_capture_error = use_graph, None, graph_warmup, None
         self.G = G.eval().requires_grad_(False)
         self.dev = dev
@@ -216,10 +232,10 @@ class LatentProjector:
             if pose_net is not None:
                 pose_net.requires_grad_(True)
             if pose_net is not None:       # 222 tensors: one multi-tensor launch (trainable conv weights are re-packed every step, no version-keyed cache involved)
-                self.cam_optimizer = torch.optim.Adam(list(pose_net.parameters()), lr=cam_lr, betas=(0.9, 0.999), fused=True)
+                self.cam_optimizer = torch.optim.Adam(list(pose_net.parameters()), lr=cam_lr, betas=(0.9, 0.999), fused=True, capturable=use_graph)
             else:
-                self.cam_optimizer = torch.optim.Adam([self.quat], lr=cam_lr, betas=(0.9, 0.999))
-            self.translation_optimizer = torch.optim.Adam([self.translation_opt], lr=translation_lr)
+                self.cam_optimizer = torch.optim.Adam([self.quat], lr=cam_lr, betas=(0.9, 0.999), capturable=use_graph)
+            self.translation_optimizer = torch.optim.Adam([self.translation_opt], lr=translation_lr, capturable=use_graph)
         self.step_idx = 0
         self.last = {}
         self._reg_stream = None
@@ -264,7 +280,11 @@ class LatentProjector:
                 self._wn.normal_(generator=self.gen)
             if self._graph is not None:
                 self._graph.replay()
-            elif step < self._graph_warmup or self.graph_capture_error is not None:
+            elif step < self.preheat:
+                # camera preheat (pose chain): the latent is frozen and un-noised for these steps (w_projector.py:249-253) -- different
+                # control flow, run eagerly; the steady-state step is captured afterwards
+                self.last = self._step_body(self._scale_t, None, self.synth_kwargs, False)
+            elif step < self.preheat + self._graph_warmup or self.graph_capture_error is not None:
                 # eager: warm-up on a side stream (allocator / autograd state, lazy kernel attributes), or capture was refused
                 side = torch.cuda.Stream(device=self.dev)
                 side.wait_stream(torch.cuda.current_stream())
@@ -274,6 +294,9 @@ class LatentProjector:
             else:
                 torch.cuda.synchronize()
                 self.optimizer.zero_grad(set_to_none=True)
+                if self.optimize_pose:
+                    self.cam_optimizer.zero_grad(set_to_none=True)
+                    self.translation_optimizer.zero_grad(set_to_none=True)
                 graph = torch.cuda.CUDAGraph()
                 try:
                     with torch.cuda.graph(graph, capture_error_mode='thread_local'):   # other threads (RCCL watchdog) may touch the runtime

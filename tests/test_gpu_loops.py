@@ -179,3 +179,25 @@ def test_inference_consumers_match_oracle():
             assert float((frames[i] - direct).abs().max()) < 1e-5
         o_ref = O.synthesis(P, cfg, ws, cams[1:2].cpu(), u1, u2, noise_mode='const')['image'][0]
     assert float((frames[1].cpu() - o_ref).abs().max()) < 1e-4
+
+
+def test_pose_chain_graph_replay_matches_eager():
+    """Config C3 captured: preheat steps run eagerly, the steady-state step (pose chain, canonical no-grad forward, warping loss, three
+    optimisers) is captured and replayed; same trajectory as the eager loop."""
+    from inv3d_amd.inversion import LatentProjector
+    cfg, P, G, cam, u1, u2, target, init_noise = _setup()
+    uni = (u1.to(DEV), u2.to(DEV))
+    runs = {}
+    for mode in (False, True):
+        pr = LatentProjector(G, target.to(DEV), num_steps=30, init_noise=init_noise, optimize_pose=True, use_warping_loss=True, cam_preheat_steps=2,
+                             cam_lr=1e-3, translation_lr=1e-3, use_graph=mode, synth_kwargs=dict(render_uniforms=uni))
+        for i in range(9):
+            out = pr.step(w_noise=O._randn('wn', i, (1, 1, cfg.w_dim)))
+        if mode:
+            assert pr.graph_capture_error is None, pr.graph_capture_error
+            assert pr._graph is not None
+        runs[mode] = (pr.w_opt.detach().clone(), pr.quat.detach().clone(), pr.translation_opt.detach().clone(), float(out['loss']))
+    assert float((runs[True][0] - runs[False][0]).abs().max()) < 1e-4
+    assert float((runs[True][1] - runs[False][1]).abs().max()) < 1e-4
+    assert float((runs[True][2] - runs[False][2]).abs().max()) < 1e-4
+    assert abs(runs[True][3] - runs[False][3]) <= 1e-3 * max(1.0, abs(runs[False][3]))
