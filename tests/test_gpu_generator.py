@@ -163,3 +163,40 @@ def test_cpu_tensors_fail_loudly():
     from inv3d_amd._lib import Eg3dHipError
     with pytest.raises(Eg3dHipError):
         bias_act.bias_act(torch.randn(4, 4), torch.randn(4))
+
+
+def test_forward_sample_and_fma_entry_points(golden):
+    """The remaining public entry points of the reference's generator API: G(z, c) = synthesis(mapping(z, c), c) (triplane.py:112-115),
+    G.sample_mixed / G.sample (density queries, :92-110) and torch_utils.ops.fma (fma.py:17-60, un-broadcast gradients)."""
+    from inv3d_amd.torch_utils.ops import fma
+    d = golden('graph_small')
+    cfg, G = small_G()
+    c = t(d['c'])
+    z = t(d['map_z'])
+    u1, u2 = O.make_uniforms(cfg, 2, seed=4)
+    uni = (u1.to(DEV), u2.to(DEV))
+    with torch.no_grad():
+        ws = G.mapping(z, c, truncation_psi=0.7, truncation_cutoff=5)
+        a = G(z, c, truncation_psi=0.7, truncation_cutoff=5, noise_mode='const', render_uniforms=uni)
+        b = G.synthesis(ws, c, noise_mode='const', render_uniforms=uni)
+        close(a['image'], b['image'], 0, 'G(z,c)')
+        pts = (torch.rand(2, 777, 3, device=DEV) - 0.5) * cfg.rendering['box_warp']
+        dirs = torch.zeros_like(pts)
+        s1 = G.sample_mixed(pts, dirs, ws, noise_mode='const')
+        s2 = G.sample(pts, dirs, z, c, truncation_psi=0.7, truncation_cutoff=5, noise_mode='const')
+        planes = G.backbone.synthesis(ws, noise_mode='const')
+        s3 = G.renderer.run_model(planes.view(2, 3, 32, planes.shape[-2], planes.shape[-1]), G.decoder, pts, dirs, G.rendering_kwargs)
+        close(s1['sigma'], s3['sigma'], 0, 'sample_mixed'); close(s2['rgb'], s3['rgb'], 0, 'sample')
+        P = O.synth_params(cfg, 0)
+        pl_ref = O.backbone_synthesis(P, cfg, ws.cpu(), noise_mode='const')
+        rgb_ref, sig_ref = O.run_model(P, pl_ref.view(2, 3, 32, pl_ref.shape[-2], pl_ref.shape[-1]), pts.cpu(), cfg.rendering)
+        close(s1['sigma'], sig_ref, 1e-4, 'sample_mixed vs oracle'); close(s1['rgb'], rgb_ref, 1e-4, 'sample_mixed rgb vs oracle')
+    g = torch.Generator().manual_seed(0)
+    av, bv, cv = torch.randn(2, 3, 4, generator=g), torch.randn(1, 3, 1, generator=g), torch.randn(4, generator=g)
+    ar, br, cr = [v.clone().requires_grad_(True) for v in (av, bv, cv)]
+    ag, bg, cg = [v.to(DEV).requires_grad_(True) for v in (av, bv, cv)]
+    (ar * br + cr).square().sum().backward()
+    fma.fma(ag, bg, cg).square().sum().backward()
+    for x, y in ((ag, ar), (bg, br), (cg, cr)):
+        assert x.grad.shape == y.grad.shape
+        close(x.grad, y.grad, 1e-5, 'fma grad')
