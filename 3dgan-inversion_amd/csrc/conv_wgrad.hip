@@ -169,6 +169,191 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const eg3d_wgrad_params
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Split-arithmetic variant (precision EG3D_PREC_F16X3): the same GEMM on v_mfma_f32_32x32x16_f16 with every fp32 operand cut into
+// two fp16 pieces (x = h + l, products hh + hl + lh accumulated in fp32; see conv_igemm.hip), 24 MFMAs of 32 cycles per 32 cells
+// instead of 64 MFMAs of 64 cycles.  The 16-bit MFMA wants 8 consecutive reduction indices (cells) per lane, but a cell is a ROW of
+// the NHWC operands: a thread therefore loads the same four channels of FOUR CONSECUTIVE cells, transposes them in registers, splits,
+// and writes one 8-byte run of four cells per channel and piece into an LDS image laid out [piece][cell octet][channel slot][8 cells]
+// -- the fragment layout of conv_igemm.hip.  Channel c of the tile lives in slot (c % 4) * 32 + c / 4, so the 32 lanes that hold the
+// same sub-channel write consecutive 16-byte slots (no bank conflicts) and an MFMA tile is 32 slots = channels {4 i + t}.
+// g is brought to ~2^13 at its maximum with an exact power of two from the device scalar g_amax (the producer of dz reports it) and
+// the accumulators are scaled back; x (activations times styles) is of ordinary magnitude.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int H_PLANE = 128 * 16 + 128;           // one cell octet of 128 channel slots (+ pad staggering the two halves of a wave)
+constexpr int H_PIECE = 4 * H_PLANE;              // 32 cells = 4 octets
+constexpr int H_OPER = 2 * H_PIECE;               // two pieces
+constexpr int H_STAGE = 2 * H_OPER;               // g and x
+
+__device__ __forceinline__ void split4h_w(const float a, const float b, const float c, const float d, uint2& hi, uint2& lo) {
+    const fp16x2_t h0 = __builtin_amdgcn_cvt_pkrtz(a, b), h1 = __builtin_amdgcn_cvt_pkrtz(c, d);
+    const f16x2_t l0 = {(_Float16)__builtin_amdgcn_fmed3f(a - (float)h0[0], -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(b - (float)h0[1], -65504.f, 65504.f)};
+    const f16x2_t l1 = {(_Float16)__builtin_amdgcn_fmed3f(c - (float)h1[0], -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(d - (float)h1[1], -65504.f, 65504.f)};
+    __builtin_memcpy(&hi.x, &h0, 4); __builtin_memcpy(&hi.y, &h1, 4);
+    __builtin_memcpy(&lo.x, &l0, 4); __builtin_memcpy(&lo.y, &l1, 4);
+}
+
+__global__ void __launch_bounds__(256, 2) conv_wgrad_f16x3_kernel(const eg3d_wgrad_params p, int tiles_o, int tiles_i, int ntap_total) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);          // [2 stages][g | x][piece][octet][slot][16 B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int to = blockIdx.x / tiles_i, ti = blockIdx.x % tiles_i;
+    int cls_id = 0, tap = blockIdx.y;
+    while (cls_id < p.ncls && tap >= p.cls[cls_id].ntaps) { tap -= p.cls[cls_id].ntaps; ++cls_id; }
+    if (cls_id >= p.ncls) return;
+    const eg3d_conv_class& cl = p.cls[cls_id];
+    const int Ha = cl.Ha, Wa = cl.Wa, HWa = Ha * Wa;
+    const int Mc = p.N * HWa;
+    const int dy = cl.dy[tap], dx = cl.dx[tap], wt = cl.wtap[tap];
+    const int o0 = to * BO, k0 = ti * BI;
+    const int nsteps_total = (Mc + BC - 1) / BC;
+    const int s_begin = (int)((int64_t)blockIdx.z * nsteps_total / p.psplit);
+    const int s_end = (int)((int64_t)(blockIdx.z + 1) * nsteps_total / p.psplit);
+    if (s_begin >= s_end) return;
+
+    float g_mul = 1.f, g_inv = 1.f;
+    if (p.g_amax != nullptr) {
+        const float am = *p.g_amax * p.g_amax_mul;
+        if (am > 0.f && am < 3.0e38f) {
+            int e;
+            (void)frexpf(am, &e);
+            e = e > 110 ? 110 : (e < -110 ? -110 : e);
+            g_mul = ldexpf(1.f, 13 - e);
+            g_inv = ldexpf(1.f, e - 13);
+        }
+    }
+
+    const int lcol = tid & 31, lq = tid >> 5;               // channels 4*lcol..+3, cells 4*lq..+3 of the step
+    constexpr unsigned OOB = 0x7ffffff0u;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((int64_t)p.N * p.Hi * p.Wi * p.ldx * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, (int)((int64_t)p.N * p.Ho * p.Wo * p.ldg * 4), 0x00020000);
+    const bool ocok = o0 + lcol * 4 < p.Nc, kcok = k0 + lcol * 4 < p.Ck;
+    struct Regs { float4 rg[4], rx[4]; };
+    Regs R0, R1;
+    float4 sv = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (p.in_scale != nullptr && p.N == 1 && kcok) sv = *reinterpret_cast<const float4*>(p.in_scale + k0 + lcol * 4);
+
+    auto load = [&](Regs& R, int step) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = step * BC + 4 * lq + j;
+            const bool ok = m < Mc;
+            const int mm = ok ? m : 0;
+            const int n = mm / HWa;
+            const int rem = mm - n * HWa;
+            const int ay = rem / Wa, ax = rem - ay * Wa;
+            const unsigned goff = (unsigned)((((int64_t)(n * p.Ho + ay * p.out_stride + cl.out_py) * p.Wo + ax * p.out_stride + cl.out_px) * p.ldg + o0 + lcol * 4) * 4);
+            const int iy = ay * p.in_stride + dy, ix = ax * p.in_stride + dx;
+            const bool xin = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const unsigned xoff = (unsigned)((((int64_t)(n * p.Hi + iy) * p.Wi + ix) * p.ldx + k0 + lcol * 4) * 4);
+            auto gv = __builtin_amdgcn_raw_buffer_load_b128(grs, (ok && ocok) ? goff : OOB, 0, 0);
+            auto xv = __builtin_amdgcn_raw_buffer_load_b128(xrs, (ok && kcok && xin) ? xoff : OOB, 0, 0);
+            __builtin_memcpy(&R.rg[j], &gv, 16);
+            __builtin_memcpy(&R.rx[j], &xv, 16);
+            if (p.in_scale != nullptr && p.N > 1 && ok) {
+                const float4 s4 = kcok ? *reinterpret_cast<const float4*>(p.in_scale + (int64_t)n * p.Ck + k0 + lcol * 4) : make_float4(0, 0, 0, 0);
+                R.rx[j].x *= s4.x; R.rx[j].y *= s4.y; R.rx[j].z *= s4.z; R.rx[j].w *= s4.w;
+            }
+        }
+    };
+    // write: piece planes of the stage; this thread's run = octet lq>>1, bytes (lq&1)*8 of slot (c*32 + lcol)
+    auto store = [&](Regs& R, int buf) {
+        char* gb = lds + buf * H_STAGE + (lq >> 1) * H_PLANE + lcol * 16 + (lq & 1) * 8;
+        char* xb = gb + H_OPER;
+        const float gq[4][4] = {{R.rg[0].x, R.rg[1].x, R.rg[2].x, R.rg[3].x}, {R.rg[0].y, R.rg[1].y, R.rg[2].y, R.rg[3].y},
+                                {R.rg[0].z, R.rg[1].z, R.rg[2].z, R.rg[3].z}, {R.rg[0].w, R.rg[1].w, R.rg[2].w, R.rg[3].w}};
+        const float xq[4][4] = {{R.rx[0].x, R.rx[1].x, R.rx[2].x, R.rx[3].x}, {R.rx[0].y, R.rx[1].y, R.rx[2].y, R.rx[3].y},
+                                {R.rx[0].z, R.rx[1].z, R.rx[2].z, R.rx[3].z}, {R.rx[0].w, R.rx[1].w, R.rx[2].w, R.rx[3].w}};
+        const float svq[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint2 hi, lo;
+            split4h_w(gq[c][0] * g_mul, gq[c][1] * g_mul, gq[c][2] * g_mul, gq[c][3] * g_mul, hi, lo);
+            *reinterpret_cast<uint2*>(gb + c * 32 * 16) = hi;
+            *reinterpret_cast<uint2*>(gb + H_PIECE + c * 32 * 16) = lo;
+            const float m = p.N == 1 ? svq[c] : 1.f;
+            split4h_w(xq[c][0] * m, xq[c][1] * m, xq[c][2] * m, xq[c][3] * m, hi, lo);
+            *reinterpret_cast<uint2*>(xb + c * 32 * 16) = hi;
+            *reinterpret_cast<uint2*>(xb + H_PIECE + c * 32 * 16) = lo;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load(R0, s_begin);
+    store(R0, 0);
+    if (s_begin + 1 < s_end) load(R1, s_begin + 1);
+    if (s_begin + 2 < s_end) load(R0, s_begin + 2);
+    __syncthreads();
+    const int l31 = lane & 31, kh = lane >> 5;
+    auto compute = [&](const int buf) {
+        const char* g = lds + buf * H_STAGE + kh * H_PLANE + (wm * 64 + l31) * 16;
+        const char* x = lds + buf * H_STAGE + H_OPER + kh * H_PLANE + (wn * 64 + l31) * 16;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {                      // two 16-cell MFMA steps per 32-cell stage
+            f16x8 a[2][2], b[2][2];                           // [piece][tile]
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    a[q][t] = *reinterpret_cast<const f16x8*>(g + q * H_PIECE + kc * 2 * H_PLANE + t * 32 * 16);
+                    b[q][t] = *reinterpret_cast<const f16x8*>(x + q * H_PIECE + kc * 2 * H_PLANE + t * 32 * 16);
+                }
+#pragma unroll
+            for (int pr = 2; pr >= 0; --pr) {                 // l*h, h*l, then h*h
+                const int qa = pr == 2 ? 1 : 0, qb = pr == 1 ? 1 : 0;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[qa][i], b[qb][j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+    int step = s_begin;
+    for (; step < s_end; step += 2) {
+        compute(0);
+        if (step + 1 < s_end) store(R1, 1);
+        if (step + 3 < s_end) load(R1, step + 3);
+        __syncthreads();
+        if (step + 1 >= s_end) break;
+        compute(1);
+        if (step + 2 < s_end) store(R0, 0);
+        if (step + 4 < s_end) load(R0, step + 4);
+        __syncthreads();
+    }
+
+    // tile (wm, i) of g holds channels 4*row + (2*wm + i); tile (wn, j) of x holds channels 4*l31 + (2*wn + j).  The 128 x 128 result
+    // is put back into natural order through LDS so that the atomics of a wave go to 64 consecutive addresses of one dw row.
+    __syncthreads();                                          // all fragment reads of the last stage are done
+    float* stage = smem;                                      // [128 o][128 + 4 k] fp32 = 67.6 KB <= 2 * H_STAGE
+    constexpr int LDS_K = 128 + 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stage[(4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + 2 * wm + i) * LDS_K + 4 * l31 + 2 * wn + j] = acc[i][j][r] * g_inv;
+    __syncthreads();
+    const int kl = tid & 127, k = k0 + kl;
+    if (k < p.Ck) {
+        float* dst = p.dw + (int64_t)wt * p.Ck + k;
+        for (int ol = tid >> 7; ol < 128; ol += 2)
+            if (o0 + ol < p.Nc) unsafeAtomicAdd(dst + (int64_t)(o0 + ol) * p.w_row, stage[ol * LDS_K + kl]);
+    }
+}
+
 }  // namespace
 
 extern "C" int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* pp, void* stream) {
@@ -189,11 +374,31 @@ extern "C" int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* pp, void* stream) 
         maxM = std::max<int64_t>(maxM, (int64_t)p.N * k.Ha * k.Wa);
     }
     const int tiles_o = eg3d_cdiv(p.Nc, BO), tiles_i = eg3d_cdiv(p.Ck, BI);
+    if (p.psplit <= 0 && p.precision == EG3D_PREC_F16X3) {      // the shorter main loop makes the atomic epilogue weigh more: ~1024 blocks, >= 16 K-steps each
+        int64_t base = (int64_t)tiles_o * tiles_i * ntap_total;
+        int64_t steps = (maxM + BC - 1) / BC;
+        int64_t want = (1024 + base - 1) / base;
+        p.psplit = (int)std::max<int64_t>(1, std::min<int64_t>(want, std::max<int64_t>(1, steps / 16)));
+    }
     if (p.psplit <= 0) {      // auto: aim for >= ~2048 blocks (measured: 128ch@512^2 81 TF at 1026 blocks, 95 at 1152, flat beyond), at least 8 K-steps per block
         int64_t base = (int64_t)tiles_o * tiles_i * ntap_total;
         int64_t steps = (maxM + BC - 1) / BC;
         int64_t want = (2048 + base - 1) / base;
         p.psplit = (int)std::max<int64_t>(1, std::min<int64_t>(want, std::max<int64_t>(1, steps / 8)));
+    }
+    if (p.precision != EG3D_PREC_F32 && p.precision != EG3D_PREC_F16X3) return EG3D_ERR_UNSUPPORTED;
+    if (p.precision == EG3D_PREC_F16X3) {
+        static bool attr16 = false;
+        const size_t smem16 = (size_t)2 * H_STAGE;
+        if (!attr16) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16);
+            if (e != hipSuccess) return (int)e;
+            attr16 = true;
+        }
+        dim3 grid16(tiles_o * tiles_i, ntap_total, p.psplit);
+        hipLaunchKernelGGL(conv_wgrad_f16x3_kernel, grid16, dim3(256), smem16, (hipStream_t)stream, p, tiles_o, tiles_i, ntap_total);
+        EG3D_LAUNCH_CHECK();
+        return EG3D_OK;
     }
     static bool attr_done = false;
     const size_t smem = (size_t)(2 * BC * (LDO + LDI)) * sizeof(float);

@@ -44,7 +44,7 @@ class WgradParams(C.Structure):
                 ('Ho', C.c_int32), ('Wo', C.c_int32), ('ldg', C.c_int32),
                 ('in_stride', C.c_int32), ('out_stride', C.c_int32),
                 ('ncls', C.c_int32), ('cls', ConvClass * 4),
-                ('in_scale', C.c_void_p), ('psplit', C.c_int32)]
+                ('in_scale', C.c_void_p), ('psplit', C.c_int32), ('precision', C.c_int32), ('g_amax', C.c_void_p), ('g_amax_mul', C.c_float)]
 
 
 class RenderParams(C.Structure):

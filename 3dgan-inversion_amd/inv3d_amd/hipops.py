@@ -361,8 +361,9 @@ def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=
     return out
 
 
-def conv_wgrad(x, g, Ck, Nc, dwp, classes, in_stride=1, out_stride=1, in_scale=None, psplit=0):
-    """dwp[Nc, taps*Ck] += grad of the packed weights (dwp pre-zeroed)."""
+def conv_wgrad(x, g, Ck, Nc, dwp, classes, in_stride=1, out_stride=1, in_scale=None, psplit=0, precision='f32', g_amax=None, g_amax_mul=1.0):
+    """dwp[Nc, taps*Ck] += grad of the packed weights (dwp pre-zeroed).  precision 'f32' | 'f16x3' (g_amax: device scalar max|g|
+    for the range normalisation of the gradient operand, see include/eg3d_hip.h)."""
     assert is_cl(x) and is_cl(g)
     p = L.WgradParams()
     n, cx, hi, wi = x.shape
@@ -377,6 +378,9 @@ def conv_wgrad(x, g, Ck, Nc, dwp, classes, in_stride=1, out_stride=1, in_scale=N
         p.cls[i] = c
     p.in_scale = in_scale.data_ptr() if in_scale is not None else None
     p.psplit = psplit
+    p.precision = PRECISIONS[precision]
+    p.g_amax = g_amax.data_ptr() if g_amax is not None else None
+    p.g_amax_mul = float(g_amax_mul)
     L.check(L.lib().eg3d_conv2d_wgrad_f32(C.byref(p), L.stream_ptr()), 'conv2d_wgrad_f32')
     return dwp
 

@@ -156,6 +156,9 @@ typedef struct eg3d_wgrad_params {
     eg3d_conv_class cls[4];
     const float* in_scale;     /* [N,Ck] or null */
     int32_t psplit;            /* number of pixel slices */
+    int32_t precision;         /* EG3D_PREC_F32 (v_mfma_f32_32x32x2_f32) or EG3D_PREC_F16X3 (two fp16 pieces per operand, three products) */
+    const float* g_amax;       /* F16X3: optional device scalar max|g|; g is scaled by the power of two that brings g_amax * g_amax_mul */
+    float g_amax_mul;          /*        to ~2^13 and the result is scaled back (exact).  null = g is used as it is.                   */
 } eg3d_wgrad_params;
 
 int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* p, void* stream);

@@ -6,6 +6,7 @@ import math
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import eg3d_oracle as O
 
@@ -541,3 +542,38 @@ def test_noise_regularizer_and_normalize():
         e = b - b.mean()
         e = e * e.square().mean().rsqrt()
         close(a, e, 1e-5, 'noise normalize')
+
+
+@pytest.mark.parametrize('shape', [(1, 32, 64, 16, 16, 1), (2, 160, 96, 12, 9, 1), (1, 128, 128, 8, 8, 2), (1, 4, 16, 10, 10, 1)])
+@pytest.mark.parametrize('prec,tol', [('f32', 2e-5), ('f16x3', 2e-5)])
+def test_conv_wgrad_vs_torch(shape, prec, tol):
+    """eg3d_conv2d_wgrad_f32 in both arithmetic modes vs autograd of F.conv2d / F.conv_transpose2d in float64: style-modulated input,
+    ragged channel counts, batch > 1, the four parity classes of an up-sampling layer, and (f16x3) a gradient operand of magnitude
+    1e-6 brought into range by g_amax."""
+    from inv3d_amd import hipops as H
+    n, ci, co, h, w, up = shape
+    g_ = torch.Generator().manual_seed(ci * 31 + co)
+    x = torch.randn(n, ci, h, w, generator=g_)
+    s = torch.rand(n, ci, generator=g_) + 0.5
+    wt = (torch.randn(co, ci, 3, 3, generator=g_) / (3 * ci ** 0.5)).double().requires_grad_(True)
+    xs = (x * s[:, :, None, None]).double()
+    if up == 1:
+        y = F.conv2d(xs, wt, padding=1)
+        cls, out_stride = H.classes_corr(h, w, 3, 3, 1), 1
+    else:
+        y = F.conv_transpose2d(xs, wt.transpose(0, 1), stride=2)
+        cls, out_stride = H.classes_convT(h, w, 3, 3, 2)[0], 2
+    dy = torch.randn(y.shape, generator=g_) * 1e-6
+    y.backward(dy.double())
+    cop = (co + 3) // 4 * 4
+    gq = torch.zeros(n, cop, *y.shape[2:])
+    gq[:, :co] = dy
+    xq, gq = x.to(DEV).contiguous(memory_format=torch.channels_last), gq.to(DEV).contiguous(memory_format=torch.channels_last)
+    dwp = torch.zeros(co, 9 * ci, device=DEV)
+    amax = gq.abs().max().reshape(1)
+    H.conv_wgrad(xq, gq, ci, co, dwp, cls, in_stride=1, out_stride=out_stride, in_scale=s.to(DEV).contiguous(), precision=prec,
+                 g_amax=amax if prec == 'f16x3' else None)
+    dw = dwp.view(co, 3, 3, ci).permute(0, 3, 1, 2)
+    ref = wt.grad
+    err = float((dw.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err <= tol, err

@@ -19,7 +19,9 @@ for (ci, co, h) in ((128, 128, 512), (256, 256, 256), (512, 512, 64), (512, 512,
     cls = H.classes_corr(h, h, 3, 3, 1)
     fl = 2.0 * h * h * 9 * ci * co
     line = f'{ci}->{co} @{h}^2:'
-    for ps in (0, 128, 192, 256, 384):
-        t = timeit(lambda: H.conv_wgrad(x, g, ci, co, dw, cls, in_scale=s, psplit=ps))
-        line += f'  psplit={ps}: {t*1e3:7.1f} us {fl/t/1e9:6.1f} TF'
+    amax = g.abs().max().reshape(1)
+    for prec in ('f32', 'f16x3'):
+        for ps in (0, 128, 256):
+            t = timeit(lambda: H.conv_wgrad(x, g, ci, co, dw, cls, in_scale=s, psplit=ps, precision=prec, g_amax=amax if prec == 'f16x3' else None))
+            line += f'  {prec} psplit={ps}: {t*1e3:7.1f} us {fl/t/1e9:6.1f} TF'
     print(line)
