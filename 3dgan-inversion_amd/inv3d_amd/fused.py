@@ -220,7 +220,10 @@ class ModConvLayerFn(torch.autograd.Function):
         dweight = None
         if need_w:
             dwp = H.zeros(wf.shape, dev)
-            H.conv_wgrad(x, g, Ci, Co, dwp, cls_w, in_stride=1, out_stride=out_stride_w, in_scale=styles)
+            # same arithmetic as the data gradient: two-piece fp16 split with the gradient operand range-normalised by max|dz|
+            wprec = 'f16x3' if (prec == 'f16x3' and amax is not None) else 'f32'
+            H.conv_wgrad(x, g, Ci, Co, dwp, cls_w, in_stride=1, out_stride=out_stride_w, in_scale=styles, precision=wprec,
+                         g_amax=amax if wprec == 'f16x3' else None, g_amax_mul=amul)
             # [O,taps,I] accumulator -> the parameter's own (contiguous [O,I,kh,kw]) layout, plus the demodulation path d wsq / d w = 2 w,
             # in one pass; the fused multi-tensor Adam walks parameter and gradient with the same linear index
             dweight = torch.empty_like(weight, memory_format=torch.contiguous_format)
