@@ -374,10 +374,10 @@ extern "C" int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* pp, void* stream) 
         maxM = std::max<int64_t>(maxM, (int64_t)p.N * k.Ha * k.Wa);
     }
     const int tiles_o = eg3d_cdiv(p.Nc, BO), tiles_i = eg3d_cdiv(p.Ck, BI);
-    if (p.psplit <= 0 && p.precision == EG3D_PREC_F16X3) {      // the shorter main loop makes the atomic epilogue weigh more: ~1024 blocks, >= 16 K-steps each
+    if (p.psplit <= 0 && p.precision == EG3D_PREC_F16X3) {      // ~2048 blocks like the fp32 path, but >= 16 K-steps each (the shorter main loop makes the atomic epilogue weigh more)
         int64_t base = (int64_t)tiles_o * tiles_i * ntap_total;
         int64_t steps = (maxM + BC - 1) / BC;
-        int64_t want = (1024 + base - 1) / base;
+        int64_t want = (2048 + base - 1) / base;
         p.psplit = (int)std::max<int64_t>(1, std::min<int64_t>(want, std::max<int64_t>(1, steps / 16)));
     }
     if (p.psplit <= 0) {      // auto: aim for >= ~2048 blocks (measured: 128ch@512^2 81 TF at 1026 blocks, 95 at 1152, flat beyond), at least 8 K-steps per block
