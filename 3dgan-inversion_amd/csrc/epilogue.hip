@@ -328,6 +328,42 @@ __global__ void weight_sqsum_kernel(const float* __restrict__ w, float* __restri
     wsq[i] = s;
 }
 
+// One pass over a conv weight [O,I,T] (T = kh*kw taps) producing the three images the path keeps per layer: the forward operand
+// wf[o][t*I + i], the data-gradient operand wa[i][t*O + o] and wsq[o][i] = sum_t w^2 (demodulation).  A block handles 32 x 32 (o,i)
+// pairs through LDS so that all three are written in runs of 32 consecutive floats.  Replaces two permute-copies and a reduction per
+// layer and step of the pivotal-tuning phase (weights change every step there).
+constexpr int PK = 32;
+__global__ void __launch_bounds__(256) pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wa,
+                                                               float* __restrict__ wsq, int O, int I, int T) {
+    extern __shared__ float sm[];                       // [PK][PK*T + 1]
+    const int ld = PK * T + 1;
+    const int o0 = blockIdx.y * PK, i0 = blockIdx.x * PK;
+    const int no = min(PK, O - o0), ni = min(PK, I - i0);
+    const int tid = threadIdx.x, run = ni * T;
+    for (int idx = tid; idx < no * run; idx += 256) {   // rows of w are contiguous in (i, t)
+        const int ol = idx / run, r = idx - ol * run;
+        sm[ol * ld + r] = w[((int64_t)(o0 + ol) * I + i0) * T + r];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < no * T * PK; idx += 256) {
+        const int il = idx % PK, t = (idx / PK) % T, ol = idx / (PK * T);
+        if (il < ni) wf[((int64_t)(o0 + ol) * T + t) * I + i0 + il] = sm[ol * ld + il * T + t];
+    }
+    for (int idx = tid; idx < ni * T * PK; idx += 256) {
+        const int ol = idx % PK, t = (idx / PK) % T, il = idx / (PK * T);
+        if (ol < no) wa[((int64_t)(i0 + il) * T + t) * O + o0 + ol] = sm[ol * ld + il * T + t];
+    }
+    if (wsq != nullptr)
+        for (int idx = tid; idx < no * PK; idx += 256) {
+            const int il = idx % PK, ol = idx / PK;
+            if (il < ni) {
+                float a = 0.f;
+                for (int t = 0; t < T; ++t) { const float v = sm[ol * ld + il * T + t]; a += v * v; }
+                wsq[(int64_t)(o0 + ol) * I + i0 + il] = a;
+            }
+        }
+}
+
 // one wave per (n,o)
 __global__ void __launch_bounds__(256) demod_fwd_kernel(const float* __restrict__ s, const float* __restrict__ wsq, float* __restrict__ d, int N, int Co, int Ck) {
     int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
@@ -443,6 +479,21 @@ extern "C" int eg3d_dgrad_finish(const float* z, const float* x, const float* s,
 extern "C" int eg3d_weight_sqsum(const float* w, float* wsq, int Co, int ntaps, int Ck, void* stream) {
     if (!w || !wsq || Co <= 0 || ntaps <= 0 || Ck <= 0) return EG3D_ERR_INVALID;
     hipLaunchKernelGGL(weight_sqsum_kernel, dim3(eg3d_cdiv((int64_t)Co * Ck, 256)), dim3(256), 0, (hipStream_t)stream, w, wsq, Co, ntaps, Ck);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_pack_conv_weight(const float* w, float* wf, float* wa, float* wsq, int O, int I, int T, void* stream) {
+    if (!w || !wf || !wa || O <= 0 || I <= 0 || T <= 0 || T > 64) return EG3D_ERR_INVALID;
+    const size_t smem = (size_t)PK * (PK * T + 1) * sizeof(float);
+    if (smem > 64 * 1024) return EG3D_ERR_UNSUPPORTED;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pack_conv_weight_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(eg3d_cdiv(I, PK), eg3d_cdiv(O, PK)), dim3(256), smem, (hipStream_t)stream, w, wf, wa, wsq, O, I, T);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -52,11 +52,7 @@ class WeightCache:
         hit = self._c.get('k')
         if hit != key:
             with torch.no_grad():
-                wd = w.detach()
-                o, i, kh, kw = wd.shape
-                wf = H.pack_weight_fwd(wd)
-                wa = H.pack_weight_adj(wd)
-                wsq = H.weight_sqsum(wf, o, kh * kw, i)
+                wf, wa, wsq = H.pack_conv_weight(w)
             self._c = {'k': key, 'wf': wf, 'wa': wa, 'wsq': wsq}
         return self._c['wf'], self._c['wa'], self._c['wsq']
 

@@ -457,6 +457,18 @@ def style_affine(ws, layers, outs=None, douts=None, dws=None, demod=None, backwa
     L.check(fn(C.byref(b), L.stream_ptr()), 'style_affine')
 
 
+def pack_conv_weight(w):
+    """[O,I,kh,kw] fp32 contiguous -> (wf [O, taps*I], wa [I, taps*O], wsq [O,I]) in one launch (eg3d_pack_conv_weight)."""
+    L.require_cuda(w)
+    w = w.detach().contiguous().float()
+    o, i, kh, kw = w.shape
+    wf = torch.empty((o, kh * kw * i), device=w.device)
+    wa = torch.empty((i, kh * kw * o), device=w.device)
+    wsq = torch.empty((o, i), device=w.device)
+    L.check(L.lib().eg3d_pack_conv_weight(w.data_ptr(), wf.data_ptr(), wa.data_ptr(), wsq.data_ptr(), o, i, kh * kw, L.stream_ptr()), 'pack_conv_weight')
+    return wf, wa, wsq
+
+
 def weight_sqsum(wp, Co, ntaps, Ck):
     wsq = torch.empty((Co, Ck), dtype=torch.float32, device=wp.device)
     L.check(L.lib().eg3d_weight_sqsum(L.ptr(wp), L.ptr(wsq), Co, ntaps, Ck, L.stream_ptr()), 'weight_sqsum')

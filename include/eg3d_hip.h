@@ -272,6 +272,9 @@ int eg3d_upfirdn2d_nhwc(const float* x, const float* f, float* y, int N, int C, 
  *               dwsq[o,k] += sum_n dd[n,o] * ( -0.5 * d[n,o]^3 * s[n,k]^2 )       (if dwsq)
  */
 int eg3d_weight_sqsum(const float* w, float* wsq, int Co, int ntaps, int Ck, void* stream);
+/* One pass over a dense conv weight w[O][I][T] (T = kh*kw): wf[o][t*I+i] (forward operand), wa[i][t*O+o] (data-gradient operand),
+ * wsq[o][i] = sum_t w^2 (or null).  Used where weights change every step (pivotal tuning). */
+int eg3d_pack_conv_weight(const float* w, float* wf, float* wa, float* wsq, int O, int I, int T, void* stream);
 int eg3d_demod_fwd(const float* s, const float* wsq, float* d, int N, int Co, int Ck, void* stream);
 int eg3d_demod_bwd(const float* s, const float* wsq, const float* d, const float* dd, float* ds, float* dwsq,
                    int N, int Co, int Ck, void* stream);

@@ -577,3 +577,14 @@ def test_conv_wgrad_vs_torch(shape, prec, tol):
     ref = wt.grad
     err = float((dw.double().cpu() - ref).abs().max() / ref.abs().max())
     assert err <= tol, err
+
+
+@pytest.mark.parametrize('shape', [(512, 512, 3), (96, 256, 1), (3, 128, 1), (40, 33, 3), (16, 8, 3)])
+def test_pack_conv_weight(shape):
+    """eg3d_pack_conv_weight == the two permute-copies + sum of squares it replaces (bit-exact copies)."""
+    from inv3d_amd import hipops as H
+    o, i, k = shape
+    w = torch.randn(o, i, k, k, generator=torch.Generator().manual_seed(o + i)).to(DEV)
+    wf, wa, wsq = H.pack_conv_weight(w)
+    assert torch.equal(wf, H.pack_weight_fwd(w)) and torch.equal(wa, H.pack_weight_adj(w))
+    close(wsq, w.square().sum((2, 3)), 1e-6, 'wsq')
