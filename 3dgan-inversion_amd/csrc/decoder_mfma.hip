@@ -28,6 +28,7 @@ struct DecodeArgs {
     int64_t rows_per_image;     // image index of row i = i / rows_per_image
     float* sigma;               // [M]
     float* rgb;                 // [M,CO]
+    int seg_len, seg_stride, seg_off;   // forward outputs: logical row i is written at (i / seg_len) * seg_stride + seg_off + i % seg_len (seg_len 0 = identity)
     // backward only
     const float2* ag;           // [M] (colour weight a, dL/d sigma)
     const float* d_rgb;         // [rays,CO] incoming per-ray colour gradient
@@ -169,8 +170,9 @@ __global__ void __launch_bounds__(256) decode_rows_kernel(const DecodeArgs a) {
 
         if (!BWD) {
             if (valid) {
-                if (h == 0) a.sigma[row] = sig;
-                float* o = a.rgb + row * CO + 4 * h;
+                const int64_t orow = a.seg_len ? (row / a.seg_len) * a.seg_stride + a.seg_off + row % a.seg_len : row;
+                if (h == 0) a.sigma[orow] = sig;
+                float* o = a.rgb + orow * CO + 4 * h;
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     *reinterpret_cast<float4*>(o + 8 * g) = make_float4(sigmoid_fast(out[4 * g]) * 1.002f - 0.001f, sigmoid_fast(out[4 * g + 1]) * 1.002f - 0.001f,
@@ -301,11 +303,12 @@ int launch_decode(const DecodeArgs& a, bool bwd, hipStream_t st) {
 
 // ---- internal entry points used by renderer.hip (same shared object) -----------------------------------------------------
 int eg3d_decode_rows_fwd(const eg3d_render_params& p, const float* pos, int pos_stride, int64_t M, int64_t rows_per_image, float* sigma, float* rgb,
-                         void* stream) {
+                         void* stream, int seg_len, int seg_stride, int seg_off) {
     DecodeArgs a = {};
     a.planes = p.planes; a.N = p.N; a.Hp = p.Hp; a.Wp = p.Wp; a.ldp = p.ldp; a.cs = 2.f / p.box_warp;
     a.w0 = p.w0; a.b0 = p.b0; a.w1t = p.w1; a.b1 = p.b1;
     a.pos = pos; a.pos_stride = pos_stride; a.M = M; a.rows_per_image = rows_per_image; a.sigma = sigma; a.rgb = rgb;
+    a.seg_len = seg_len; a.seg_stride = seg_stride; a.seg_off = seg_off;
     return launch_decode(a, false, (hipStream_t)stream);
 }
 

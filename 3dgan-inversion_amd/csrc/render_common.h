@@ -42,6 +42,6 @@ __device__ __forceinline__ int64_t ray_of_slot(int64_t slot, int R, int W) {
 
 // sample-level kernels (decoder_mfma.hip), called by the entry points in renderer.hip
 int eg3d_decode_rows_fwd(const eg3d_render_params& p, const float* pos, int pos_stride, int64_t M, int64_t rows_per_image, float* sigma, float* rgb,
-                         void* stream);
+                         void* stream, int seg_len = 0, int seg_stride = 0, int seg_off = 0);
 int eg3d_decode_rows_bwd(const eg3d_render_bwd_params& bp, const float* pos, int64_t row0, int64_t M, int64_t rows_per_image, int64_t samples_per_ray_row,
                          void* stream);

@@ -143,8 +143,12 @@ __host__ __device__ constexpr int render_red_floats(int RPB, int D) {
     return fwd > bwd ? fwd : bwd;
 }
 
-template <bool BWD>
+// MODE 0: fused forward (decoder on the vector ALUs inside the ray kernel).  MODE 1: ray-level backward.  MODE 2 / 3: the two ray-level
+// stages of the pipelined forward -- 2 = importance sampling from the saved coarse densities (writes fine depths and fine sample
+// positions), 3 = merge + march + compositing from the saved (sigma, colour) rows of both passes.
+template <int MODE>
 __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_params bp) {
+    constexpr bool BWD = MODE == 1;
     const eg3d_render_params& p = bp.fwd;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int D = p.Dc > p.Df ? p.Dc : p.Df;
@@ -179,7 +183,7 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
     // ---------------- coarse sample ----------------
     // forward keeps the 32 colours of both samples in registers until the weights are known; backward only needs
     // e = <d_rgb, colour> per sample at this point (the MLP is re-run in the per-sample gradient pass).
-    constexpr int NKEEP = BWD ? 1 : CO;
+    constexpr int NKEEP = (BWD || MODE == 2) ? 1 : CO;
     float depth_c = 0.f, sig_c = 0.f, rgb_c[NKEEP], e_c = 0.f;
 #pragma unroll
     for (int k = 0; k < NKEEP; ++k) rgb_c[k] = 0.f;
@@ -196,7 +200,21 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
         }
         L.dc[s] = depth_c; L.sc[s] = sig_c;
     }
-    if constexpr (!BWD) if (has_c) {
+    if constexpr (MODE >= 2) if (has_c) {      // pipelined forward: the sample-level kernel already decoded the coarse rows
+        depth_c = coarse_depth(p, rr, s, p.u1[rr * Dc + s]);
+        const int64_t row = (rr * 2 + 0) * D + s;
+        sig_c = p.save_sigma[row];
+        if constexpr (MODE == 3) {
+            const float4* c4p = reinterpret_cast<const float4*>(p.save_rgb + row * CO);
+#pragma unroll
+            for (int c4 = 0; c4 < CO / 4; ++c4) {
+                float4 v = c4p[c4];
+                rgb_c[c4 * 4] = v.x; rgb_c[c4 * 4 + 1] = v.y; rgb_c[c4 * 4 + 2] = v.z; rgb_c[c4 * 4 + 3] = v.w;
+            }
+        }
+        L.dc[s] = depth_c; L.sc[s] = sig_c;
+    }
+    if constexpr (MODE == 0) if (has_c) {
         float f[FC], out[1 + CO];
         depth_c = coarse_depth(p, rr, s, p.u1[rr * Dc + s]);
         gather_feats(pn, p.Hp, p.Wp, p.ldp, cs, ox + depth_c * dx, oy + depth_c * dy, oz + depth_c * dz, f);   // mul+add like the reference (no fma)
@@ -218,7 +236,7 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
     // ---------------- importance sampling (forward only; backward re-reads the saved fine depths) ----------------
     float depth_f = 0.f;
     if (Df > 0) {
-        if (!BWD) {
+        if (MODE == 0 || MODE == 2) {
             // coarse march -> weights (Dc-1 intervals)
             if (live && s < Dc - 1) {
                 float a, de, dm;
@@ -268,6 +286,14 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
             if (has_f) depth_f = p.fine_depths[rr * Df + s];
         }
     }
+    if constexpr (MODE == 2) {          // hand the fine sample positions to the sample-level kernel and stop here
+        if (live) {
+            float4 ps = make_float4(NAN, 0.f, 0.f, 0.f);
+            if (has_f) ps = make_float4(ox + depth_f * dx, oy + depth_f * dy, oz + depth_f * dz, depth_f);
+            reinterpret_cast<float4*>(p.pos_rows)[((int64_t)nrays + rr) * D + s] = ps;
+        }
+        return;
+    }
 
     // ---------------- fine sample ----------------
     float sig_f = 0.f, rgb_f[NKEEP], e_f = 0.f;
@@ -285,7 +311,18 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
         }
         L.df[s] = depth_f; L.sf[s] = sig_f;
     }
-    if constexpr (!BWD) if (has_f) {
+    if constexpr (MODE == 3) if (has_f) {
+        const int64_t row = (rr * 2 + 1) * D + s;
+        sig_f = p.save_sigma[row];
+        const float4* c4p = reinterpret_cast<const float4*>(p.save_rgb + row * CO);
+#pragma unroll
+        for (int c4 = 0; c4 < CO / 4; ++c4) {
+            float4 v = c4p[c4];
+            rgb_f[c4 * 4] = v.x; rgb_f[c4 * 4 + 1] = v.y; rgb_f[c4 * 4 + 2] = v.z; rgb_f[c4 * 4 + 3] = v.w;
+        }
+        L.df[s] = depth_f; L.sf[s] = sig_f;
+    }
+    if constexpr (MODE == 0) if (has_f) {
         float f[FC], out[1 + CO];
         gather_feats(pn, p.Hp, p.Wp, p.ldp, cs, ox + depth_f * dx, oy + depth_f * dy, oz + depth_f * dz, f);
         mlp_fwd(p.w0, p.b0, p.w1, p.b1, f, out);
@@ -345,7 +382,7 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
     }
     __syncthreads();
 
-    if (!BWD) {
+    if constexpr (MODE == 0 || MODE == 3) {
         // composite colour: each thread contributes a_c * rgb_c + a_f * rgb_f, reduced over the ray's D threads via LDS
         float a_c = 0.f, a_f = 0.f;
         if (has_c) a_c = 0.5f * ((rank_c > 0 ? L.w[rank_c - 1] : 0.f) + (rank_c < nI ? L.w[rank_c] : 0.f));
@@ -772,6 +809,22 @@ int check_render(const eg3d_render_params& p) {
     return EG3D_OK;
 }
 
+// positions of the coarse samples for the sample-level kernel: pos_rows[0][ray][s] = (o + t d, t); x = NaN marks an absent sample
+__global__ void __launch_bounds__(256) coarse_pos_kernel(const eg3d_render_params p, int D) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t nrays = (int64_t)p.N * p.R;
+    if (i >= nrays * D) return;
+    const int64_t ray = i / D;
+    const int s = (int)(i - ray * D);
+    float4 ps = make_float4(NAN, 0.f, 0.f, 0.f);
+    if (s < p.Dc) {
+        const float t = coarse_depth(p, ray, s, p.u1[ray * p.Dc + s]);
+        ps = make_float4(p.origins[ray * 3] + t * p.dirs[ray * 3], p.origins[ray * 3 + 1] + t * p.dirs[ray * 3 + 1],
+                         p.origins[ray * 3 + 2] + t * p.dirs[ray * 3 + 2], t);
+    }
+    reinterpret_cast<float4*>(p.pos_rows)[i] = ps;
+}
+
 size_t render_smem(const eg3d_render_params& p) {
     const int D = p.Dc > p.Df ? p.Dc : p.Df;
     const int RPB = MAXT / D;
@@ -790,7 +843,21 @@ extern "C" int eg3d_render_fwd(const eg3d_render_params* pp, void* stream) {
     eg3d_render_bwd_params bp = {};
     bp.fwd = *pp;
     const int64_t nrays = (int64_t)pp->N * pp->R;
-    hipLaunchKernelGGL(render_kernel<false>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(*pp), (hipStream_t)stream, bp);
+    hipStream_t st = (hipStream_t)stream;
+    if (pp->pos_rows != nullptr && pp->save_sigma != nullptr && pp->save_rgb != nullptr && pp->fine_depths != nullptr && pp->Df > 0) {
+        // pipelined forward: positions -> decode (matrix cores) -> importance sampling -> decode -> compositing
+        const int64_t M = nrays * D;
+        hipLaunchKernelGGL(coarse_pos_kernel, dim3(eg3d_cdiv(M, 256)), dim3(256), 0, st, *pp, D);
+        rc = eg3d_decode_rows_fwd(*pp, pp->pos_rows, 4, M, (int64_t)pp->R * D, pp->save_sigma, pp->save_rgb, stream, D, 2 * D, 0);
+        if (rc) return rc;
+        hipLaunchKernelGGL(render_kernel<2>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(*pp), st, bp);
+        rc = eg3d_decode_rows_fwd(*pp, pp->pos_rows + M * 4, 4, M, (int64_t)pp->R * D, pp->save_sigma, pp->save_rgb, stream, D, 2 * D, D);
+        if (rc) return rc;
+        hipLaunchKernelGGL(render_kernel<3>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(*pp), st, bp);
+        EG3D_LAUNCH_CHECK();
+        return EG3D_OK;
+    }
+    hipLaunchKernelGGL(render_kernel<0>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(*pp), st, bp);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }
@@ -815,7 +882,7 @@ extern "C" int eg3d_render_bwd(const eg3d_render_bwd_params* bp, void* stream) {
     const int RPB = MAXT / D;
     const int64_t nrays = (int64_t)p.N * p.R;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(render_kernel<true>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(p), st, *bp);
+    hipLaunchKernelGGL(render_kernel<1>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(p), st, *bp);
     const int64_t S = nrays * 2 * D;
     if (int rc2 = eg3d_decode_rows_bwd(*bp, bp->df_pos, 0, S, (int64_t)p.R * 2 * D, 2 * D, stream)) return rc2;
     if (bp->d_origins || bp->d_dirs)

@@ -90,6 +90,7 @@ def _zeros_views(device, *shapes):
     return out
 
 
+RENDER_PIPELINE = os.environ.get('EG3D_RENDER_PIPELINE', '1') != '0'     # forward renderer as positions -> MFMA decode -> importance -> decode -> composite
 KS_TARGET = int(os.environ.get('EG3D_KS_TARGET', '256'))       # blocks a split launch aims for (one per CU; 512 measured 0.7 % slower per step)
 
 
@@ -464,7 +465,10 @@ class RenderFn(torch.autograd.Function):
         if any(ctx.needs_input_grad[:7]):          # training mode: keep (sigma, colour) per sample (207 MB at the FFHQ config)
             S = N * R * 2 * max(Dc, Df)
             save = (torch.empty((S,), device=dev), torch.empty((S, w1.shape[0] - 1), device=dev))
-        p = H.make_render_params(planes, origins, dirs, u1, u2, opts, w0g, b0g, w1t, b1g, rgb, depth, wsum, minmax, fine, rl, save)
+        pos = None
+        if save is not None and Df > 0 and RENDER_PIPELINE:      # training mode: sample-level decode on the matrix cores between ray-level stages
+            pos = torch.empty((2, N * R, max(Dc, Df), 4), device=dev)
+        p = H.make_render_params(planes, origins, dirs, u1, u2, opts, w0g, b0g, w1t, b1g, rgb, depth, wsum, minmax, fine, rl, save, pos_rows=pos)
         H.render_fwd(p)
         H.render_finalize(depth, minmax)
         ctx.save_for_backward(planes, origins, dirs, w0g, b0g, w1t, b1g, u1, u2, minmax, fine, rl, *(save or ()))

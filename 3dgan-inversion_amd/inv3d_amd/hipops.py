@@ -508,7 +508,7 @@ def ray_gen_bwd(c2w, K, g_o, g_d, res, want_K=True):
     return d_c2w, d_K
 
 
-def make_render_params(planes, origins, dirs, u1, u2, opts, w0, b0, w1t, b1, rgb, depth, wsum, minmax, fine, ray_limits=None, save=None, ray_tile_width=None):
+def make_render_params(planes, origins, dirs, u1, u2, opts, w0, b0, w1t, b1, rgb, depth, wsum, minmax, fine, ray_limits=None, save=None, ray_tile_width=None, pos_rows=None):
     """planes: channels_last [N, 3*C, Hp, Wp]; decoder weights with gains folded (w1t transposed [H, 1+Cout])."""
     assert is_cl(planes)
     p = L.RenderParams()
@@ -540,6 +540,7 @@ def make_render_params(planes, origins, dirs, u1, u2, opts, w0, b0, w1t, b1, rgb
         side = int(round(p.R ** 0.5))
         ray_tile_width = side if side * side == p.R and side % 32 == 0 else 0
     p.ray_tile_width = int(ray_tile_width)
+    p.pos_rows = pos_rows.data_ptr() if pos_rows is not None else None       # workspace [2, N*R, D, 4]: selects the pipelined forward
     return p
 
 

@@ -339,6 +339,10 @@ typedef struct eg3d_render_params {
                                 * row-major pixels of an image ray_tile_width wide (a multiple of 32), workgroups are assigned
                                 * to rays in 32-pixel-wide column strips so that each XCD's L2 sees a compact screen tile and
                                 * hence a small tri-plane footprint.  0 = rays in no particular order. */
+    float* pos_rows;           /* optional workspace [2, N*R, D, 4] (D = max(Dc,Df)).  With it (and save_sigma / save_rgb / fine_depths) the
+                                * forward runs as a pipeline -- sample positions -> tri-plane gather + decoder on the matrix cores
+                                * (the sample-level kernel of the backward) -> importance sampling -> decoder -> compositing from the
+                                * saved rows -- instead of one fused per-ray kernel with the decoder on the vector ALUs.  null = fused. */
 } eg3d_render_params;
 
 int eg3d_render_fwd(const eg3d_render_params* p, void* stream);
