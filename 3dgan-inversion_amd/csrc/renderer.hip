@@ -130,6 +130,20 @@ __device__ __forceinline__ RayLds ray_lds(float* base, int r, int D) {
     return L;
 }
 
+// float min / max as native integer atomics on the value's bit pattern (atomicMin / atomicMax on float compile to compare-and-swap
+// loops, and 4096 workgroups looping on the same two addresses cost ~0.3 ms per launch): non-negative floats order like signed ints,
+// negative ones like reversed unsigned ints.  The cell holds an ordinary float throughout (initialised to +inf / -inf by the caller).
+__device__ __forceinline__ void atomic_min_float(float* a, float v) {
+    v += 0.0f;                                        // -0 -> +0
+    if (v >= 0.f) atomicMin(reinterpret_cast<int*>(a), __float_as_int(v));
+    else if (v < 0.f) atomicMax(reinterpret_cast<unsigned*>(a), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_max_float(float* a, float v) {
+    v += 0.0f;
+    if (v >= 0.f) atomicMax(reinterpret_cast<int*>(a), __float_as_int(v));
+    else if (v < 0.f) atomicMin(reinterpret_cast<unsigned*>(a), __float_as_uint(v));
+}
+
 // weights of nS sorted samples (depths d, densities sg): alpha_i -> q_i -> T_i -> w_i, serial scan by one thread per ray
 __device__ __forceinline__ void march_alpha(const float* d, const float* sg, int i, float& alpha, float& delta, float& dens_mid) {
     delta = d[i + 1] - d[i];
@@ -138,9 +152,11 @@ __device__ __forceinline__ void march_alpha(const float* d, const float* sg, int
     alpha = 1.f - expf(-(sp * delta));
 }
 
-__host__ __device__ constexpr int render_red_floats(int RPB, int D) {
-    int fwd = RPB * D * (CO + 1), bwd = 2 * RPB * 2 * D + RPB * D * 7;
-    return fwd > bwd ? fwd : bwd;
+// The colour reduction of the compositing stage goes through LDS CCH channels at a time: a full [threads][33] buffer (25 KB) holds a
+// block to 3 waves per SIMD; [threads][9] leaves room for 6 (the stage streams 200 MB of saved rows and is latency-bound).
+constexpr int CCH = 8;
+__host__ __device__ constexpr int render_red_floats(int RPB, int D, int mode) {
+    return mode == 1 ? 2 * RPB * 2 * D + RPB * D * 7 : (mode == 2 ? 0 : RPB * D * (CCH + 1));
 }
 
 // MODE 0: fused forward (decoder on the vector ALUs inside the ray kernel).  MODE 1: ray-level backward.  MODE 2 / 3: the two ray-level
@@ -166,7 +182,7 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
     const int n = (int)(rr / p.R);
     RayLds L = ray_lds(lds, r < RPB ? r : 0, D);
     float* red = lds + RPB * RAY_LDS_FLOATS(D);   // forward: [nthreads][33] colour reduction; backward: E / GA / coordinate sums
-    float* grgb = red + render_red_floats(RPB, D) + (r < RPB ? r : 0) * CO;   // backward: this ray's incoming d_rgb [32]
+    float* grgb = red + render_red_floats(RPB, D, MODE) + (r < RPB ? r : 0) * CO;   // backward: this ray's incoming d_rgb [32]
 
     const float ox = p.origins[rr * 3 + 0], oy = p.origins[rr * 3 + 1], oz = p.origins[rr * 3 + 2];
     const float dx = p.dirs[rr * 3 + 0], dy = p.dirs[rr * 3 + 1], dz = p.dirs[rr * 3 + 2];
@@ -387,21 +403,25 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
         float a_c = 0.f, a_f = 0.f;
         if (has_c) a_c = 0.5f * ((rank_c > 0 ? L.w[rank_c - 1] : 0.f) + (rank_c < nI ? L.w[rank_c] : 0.f));
         if (has_f) a_f = 0.5f * ((rank_f > 0 ? L.w[rank_f - 1] : 0.f) + (rank_f < nI ? L.w[rank_f] : 0.f));
-        if (tid < nthreads) {
-            float* my = red + tid * (CO + 1);
 #pragma unroll
-            for (int k = 0; k < NKEEP; ++k) my[k] = a_c * rgb_c[k] + a_f * rgb_f[k];
-        }
-        __syncthreads();
-        if (live) {
-            for (int k = s; k < CO; k += D) {
-                float acc = 0.f;
-                const float* col = red + (r * D) * (CO + 1) + k;
-                for (int j = 0; j < D; ++j) acc += col[j * (CO + 1)];
-                float wsum = L.misc[0];
-                if (p.white_back) acc = acc + 1.f - wsum;
-                p.rgb[rr * CO + k] = acc * 2.f - 1.f;
+        for (int c0 = 0; c0 < NKEEP; c0 += CCH) {
+            if (tid < nthreads) {
+                float* my = red + tid * (CCH + 1);
+#pragma unroll
+                for (int k = 0; k < CCH; ++k) my[k] = a_c * rgb_c[c0 + k] + a_f * rgb_f[c0 + k];
             }
+            __syncthreads();
+            if (live) {
+                for (int k = s; k < CCH; k += D) {
+                    float acc = 0.f;
+                    const float* col = red + (r * D) * (CCH + 1) + k;
+                    for (int j = 0; j < D; ++j) acc += col[j * (CCH + 1)];
+                    float wsum = L.misc[0];
+                    if (p.white_back) acc = acc + 1.f - wsum;
+                    p.rgb[rr * CO + c0 + k] = acc * 2.f - 1.f;
+                }
+            }
+            __syncthreads();
         }
         if (live && s == 0) {
             float wsum = L.misc[0];
@@ -418,8 +438,8 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
                     mn = fminf(mn, Lq.misc[2]); mx = fmaxf(mx, Lq.misc[3]);
                 }
             }
-            atomicMin(p.depth_minmax, mn);
-            atomicMax(p.depth_minmax + 1, mx);
+            atomic_min_float(p.depth_minmax, mn);
+            atomic_max_float(p.depth_minmax + 1, mx);
         }
         return;
     }
@@ -825,10 +845,10 @@ __global__ void __launch_bounds__(256) coarse_pos_kernel(const eg3d_render_param
     reinterpret_cast<float4*>(p.pos_rows)[i] = ps;
 }
 
-size_t render_smem(const eg3d_render_params& p) {
+size_t render_smem(const eg3d_render_params& p, int mode) {
     const int D = p.Dc > p.Df ? p.Dc : p.Df;
     const int RPB = MAXT / D;
-    return ((size_t)RPB * RAY_LDS_FLOATS(D) + render_red_floats(RPB, D) + (size_t)RPB * CO) * sizeof(float);
+    return ((size_t)RPB * RAY_LDS_FLOATS(D) + render_red_floats(RPB, D, mode) + (size_t)RPB * CO) * sizeof(float);
 }
 
 }  // namespace
@@ -850,14 +870,14 @@ extern "C" int eg3d_render_fwd(const eg3d_render_params* pp, void* stream) {
         hipLaunchKernelGGL(coarse_pos_kernel, dim3(eg3d_cdiv(M, 256)), dim3(256), 0, st, *pp, D);
         rc = eg3d_decode_rows_fwd(*pp, pp->pos_rows, 4, M, (int64_t)pp->R * D, pp->save_sigma, pp->save_rgb, stream, D, 2 * D, 0);
         if (rc) return rc;
-        hipLaunchKernelGGL(render_kernel<2>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(*pp), st, bp);
+        hipLaunchKernelGGL(render_kernel<2>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(*pp, 2), st, bp);
         rc = eg3d_decode_rows_fwd(*pp, pp->pos_rows + M * 4, 4, M, (int64_t)pp->R * D, pp->save_sigma, pp->save_rgb, stream, D, 2 * D, D);
         if (rc) return rc;
-        hipLaunchKernelGGL(render_kernel<3>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(*pp), st, bp);
+        hipLaunchKernelGGL(render_kernel<3>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(*pp, 3), st, bp);
         EG3D_LAUNCH_CHECK();
         return EG3D_OK;
     }
-    hipLaunchKernelGGL(render_kernel<0>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(*pp), st, bp);
+    hipLaunchKernelGGL(render_kernel<0>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(*pp, 0), st, bp);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }
@@ -882,7 +902,7 @@ extern "C" int eg3d_render_bwd(const eg3d_render_bwd_params* bp, void* stream) {
     const int RPB = MAXT / D;
     const int64_t nrays = (int64_t)p.N * p.R;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(render_kernel<1>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(p), st, *bp);
+    hipLaunchKernelGGL(render_kernel<1>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(p, 1), st, *bp);
     const int64_t S = nrays * 2 * D;
     if (int rc2 = eg3d_decode_rows_bwd(*bp, bp->df_pos, 0, S, (int64_t)p.R * 2 * D, 2 * D, stream)) return rc2;
     if (bp->d_origins || bp->d_dirs)
