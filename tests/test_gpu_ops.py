@@ -427,7 +427,7 @@ def test_render_golden(golden):
     close(rgb, d['rn_auto_rgb'], 1e-5, 'render auto rgb'); close(dep, d['rn_auto_depth'], 1e-5, 'render auto depth')
 
 
-@pytest.mark.parametrize('variant', ['ffhq48', 'white_back', 'disparity', 'coarse_only', 'uneven'])
+@pytest.mark.parametrize('variant', ['ffhq48', 'white_back', 'disparity', 'coarse_only', 'uneven', 'negative_depths', 'no_grad_fused'])
 def test_render_vs_oracle(variant):
     """48+48-sample configuration (and variants) on random planes vs the oracle, forward and gradients."""
     from inv3d_amd.training.volumetric_rendering.renderer import ImportanceRenderer
@@ -442,6 +442,8 @@ def test_render_vs_oracle(variant):
         opts['depth_resolution_importance'] = 0
     if variant == 'uneven':
         opts['depth_resolution'], opts['depth_resolution_importance'] = 40, 24
+    if variant == 'negative_depths':         # sample depths of both signs: the global depth range goes through both branches of the integer atomics
+        opts['ray_start'], opts['ray_end'] = -0.4, 0.7
     P = O.synth_params(O.small_config(), seed=7)
     g = torch.Generator().manual_seed(21)
     planes = (torch.randn(n, 3, 32, 64, 64, generator=g) * 0.8)
@@ -461,6 +463,11 @@ def test_render_vs_oracle(variant):
     R.set_uniforms(u1.to(DEV), u2.to(DEV) if u2 is not None else None)
     pg = planes.to(DEV).requires_grad_(True)
     og, dg = o.to(DEV).requires_grad_(True), dr.to(DEV).requires_grad_(True)
+    if variant == 'no_grad_fused':           # inference form: one fused ray kernel (training mode runs the pipelined stages)
+        with torch.no_grad():
+            rgb, dep, ws = R(pg, dec, og, dg, opts)
+        close(rgb, rgb_r, 1e-5, f'{variant} rgb'); close(dep, dep_r, 1e-5, f'{variant} depth'); close(ws, ws_r, 1e-5, f'{variant} wsum')
+        return
     rgb, dep, ws = R(pg, dec, og, dg, opts)
     close(rgb, rgb_r, 1e-5, f'{variant} rgb'); close(dep, dep_r, 1e-5, f'{variant} depth'); close(ws, ws_r, 1e-5, f'{variant} wsum')
     gg = torch.autograd.grad([rgb, dep], [pg, og, dg], [g_rgb.to(DEV), g_dep.to(DEV)])
