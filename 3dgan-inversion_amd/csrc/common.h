@@ -46,6 +46,14 @@ __device__ __forceinline__ F eg3d_act_fwd(F x, int act, F alpha) {
     }
 }
 
+// The three piecewise-linear activations (linear, relu, lrelu -- the only ones on the generator path) as one branch-free form:
+// y = x > 0 ? x : slope * x with slope 1 / 0 / alpha; derivative (keyed on the output) y > 0 ? 1 : slope.  Kernels whose fused epilogue
+// only ever sees these use it instead of the nine-way switch (which, inlined per element, made e.g. the FIR epilogue 7000 instructions).
+__host__ __device__ __forceinline__ bool eg3d_act_is_pwl(int act) { return act == EG3D_ACT_LINEAR || act == EG3D_ACT_RELU || act == EG3D_ACT_LRELU; }
+__host__ __device__ __forceinline__ float eg3d_act_pwl_slope(int act, float alpha) { return act == EG3D_ACT_LINEAR ? 1.f : (act == EG3D_ACT_LRELU ? alpha : 0.f); }
+__device__ __forceinline__ float eg3d_pwl_fwd(float x, float slope) { return x > 0.f ? x : (slope == 0.f ? 0.f : x * slope); }
+__device__ __forceinline__ float eg3d_pwl_d1(float yy, float slope) { return yy > 0.f ? 1.f : slope; }
+
 // first derivative of act, expressed with the un-gained output yy = y/gain (x only for swish)
 template <typename F>
 __device__ __forceinline__ F eg3d_act_d1(F yy, F x, int act, F alpha) {

@@ -402,6 +402,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
         __syncthreads();
     }
     const float strength = (epi == EG3D_EPI_FWD && p.noise != nullptr) ? *p.noise_strength : 0.f;
+    const float act_slope = eg3d_act_pwl_slope(p.act, p.alpha);       // the fused epilogue takes linear / relu / lrelu only (checked on the host)
     const int HWo = p.Ho * p.Wo;
 
     // ---- vector epilogue: the tile goes through LDS once so that global traffic is 16 bytes per lane and row-contiguous ----------
@@ -461,7 +462,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
                     float e[4] = {v.x * scl4.x + nzs + bias4.x, v.y * scl4.y + nzs + bias4.y, v.z * scl4.z + nzs + bias4.z, v.w * scl4.w + nzs + bias4.w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        e[q] = eg3d_act_fwd<float>(e[q], p.act, p.alpha) * p.gain;
+                        e[q] = eg3d_pwl_fwd(e[q], act_slope) * p.gain;
                         if (p.clamp >= 0.f) e[q] = fminf(fmaxf(e[q], -p.clamp), p.clamp);
                     }
                     v = make_float4(e[0] + sa[u].x, e[1] + sa[u].y, e[2] + sa[u].z, e[3] + sa[u].w);
@@ -532,7 +533,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
                         unsafeAtomicAdd(p.out + off, v);
                     } else if (epi == EG3D_EPI_FWD) {
                         v = v * scl[q] + sideb[q] * strength + bias;
-                        v = eg3d_act_fwd<float>(v, p.act, p.alpha) * p.gain;
+                        v = eg3d_pwl_fwd(v, act_slope) * p.gain;
                         if (p.clamp >= 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
                         p.out[off] = v + sidea[q];
                     } else {   // EG3D_EPI_BWD
@@ -640,6 +641,7 @@ extern "C" int eg3d_conv2d_igemm_f32(const eg3d_conv_params* pp, void* stream) {
     if (p.epi < EG3D_EPI_STORE || p.epi > EG3D_EPI_BWD) return EG3D_ERR_INVALID;
     if (p.precision < 0 || p.precision > 3 || p.ds_replicas < 0) return EG3D_ERR_INVALID;
     if (p.epi == EG3D_EPI_FWD && p.noise && !p.noise_strength) return EG3D_ERR_INVALID;
+    if (p.epi == EG3D_EPI_FWD && !eg3d_act_is_pwl(p.act)) return EG3D_ERR_UNSUPPORTED;      // other activations: EPI_STORE + eg3d_bias_act
     if ((p.Ck & 3) || (p.ldx & 3) || (p.w_row & 3)) return EG3D_ERR_UNSUPPORTED;   // 16-byte operand loads
     if ((reinterpret_cast<uintptr_t>(p.x) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15)) return EG3D_ERR_UNSUPPORTED;
     if (p.in_scale && (reinterpret_cast<uintptr_t>(p.in_scale) & 15)) return EG3D_ERR_UNSUPPORTED;

@@ -15,12 +15,15 @@ namespace {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// PWL: the launch's activation is linear / relu / lrelu (host dispatch): `alpha` then carries the slope and no switch is compiled in
+template <bool PWL>
 __device__ __forceinline__ float act1(float v, int act, float alpha, float gain, float clamp) {
-    v = eg3d_act_fwd<float>(v, act, alpha) * gain;
+    v = (PWL ? eg3d_pwl_fwd(v, alpha) : eg3d_act_fwd<float>(v, act, alpha)) * gain;
     if (clamp >= 0.f) v = fminf(fmaxf(v, -clamp), clamp);
     return v;
 }
 
+template <bool PWL>
 __global__ void __launch_bounds__(256) epilogue_fwd_kernel(const float* __restrict__ z, float* __restrict__ out, int N, int H, int W, int C4,
                                                            int Hz, int Wz, const float* __restrict__ fir, int fh, int fw, int pad0,
                                                            float fir_gain, const float* __restrict__ d, const float* __restrict__ noise,
@@ -85,14 +88,15 @@ __global__ void __launch_bounds__(256) epilogue_fwd_kernel(const float* __restri
             float4 b = ld4(bias + c);
             v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
         }
-        v.x = act1(v.x, act, alpha, gain, clamp); v.y = act1(v.y, act, alpha, gain, clamp);
-        v.z = act1(v.z, act, alpha, gain, clamp); v.w = act1(v.w, act, alpha, gain, clamp);
+        v.x = act1<PWL>(v.x, act, alpha, gain, clamp); v.y = act1<PWL>(v.y, act, alpha, gain, clamp);
+        v.z = act1<PWL>(v.z, act, alpha, gain, clamp); v.w = act1<PWL>(v.w, act, alpha, gain, clamp);
         st4(out + i * 4, v);
     }
 }
 
 // 4x4 FIR + demod + noise + bias + activation with a 2x2 output block per thread: the four outputs share a 5x5 input patch, i.e. 25
 // sixteen-byte loads instead of 64 (the one-output kernel above is bound by the texture/L1 path: 16 loads per 16 bytes of output).
+template <bool PWL>
 __global__ void __launch_bounds__(256) epilogue_fwd_fir44_kernel(const float* __restrict__ z, float* __restrict__ out, int N, int H, int W, int C4,
                                                                  int Hz, int Wz, const float* __restrict__ fir, int pad0, float fir_gain,
                                                                  const float* __restrict__ d, const float* __restrict__ noise, int64_t noise_nstride,
@@ -132,7 +136,7 @@ __global__ void __launch_bounds__(256) epilogue_fwd_fir44_kernel(const float* __
                     for (int kx = 0; kx < 4; ++kx) {
                         const float wgt = fs[ky * 4 + kx];
                         const float4 q = t[(oy + ky) * 5 + ox + kx];
-                        v.x += wgt * q.x; v.y += wgt * q.y; v.z += wgt * q.z; v.w += wgt * q.w;
+                        v.x = fmaf(wgt, q.x, v.x); v.y = fmaf(wgt, q.y, v.y); v.z = fmaf(wgt, q.z, v.z); v.w = fmaf(wgt, q.w, v.w);   // as the reference's CUDA kernel (nvcc contracts v += w * x)
                     }
                 const int y = y0 + oy, x = x0 + ox;
                 v.x *= dv.x; v.y *= dv.y; v.z *= dv.z; v.w *= dv.w;
@@ -141,26 +145,29 @@ __global__ void __launch_bounds__(256) epilogue_fwd_fir44_kernel(const float* __
                     v.x += nz; v.y += nz; v.z += nz; v.w += nz;
                 }
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                v.x = act1(v.x, act, alpha, gain, clamp); v.y = act1(v.y, act, alpha, gain, clamp);
-                v.z = act1(v.z, act, alpha, gain, clamp); v.w = act1(v.w, act, alpha, gain, clamp);
+                v.x = act1<PWL>(v.x, act, alpha, gain, clamp); v.y = act1<PWL>(v.y, act, alpha, gain, clamp);
+                v.z = act1<PWL>(v.z, act, alpha, gain, clamp); v.w = act1<PWL>(v.w, act, alpha, gain, clamp);
                 st4(out + (((int64_t)n * H + y) * W + x) * C + c, v);
             }
     }
 }
 
 // derivative factor and recovered pre-activation for one element
+template <bool PWL>
 __device__ __forceinline__ void bwd1(float dout, float o, int act, float alpha, float gain, float clamp, float& dy, float& pre) {
     float yy = o / gain;
-    float g = dout * gain * eg3d_act_d1<float>(yy, 0.f, act, alpha);
+    float g = dout * gain * (PWL ? eg3d_pwl_d1(yy, alpha) : eg3d_act_d1<float>(yy, 0.f, act, alpha));
     if (clamp >= 0.f && (o >= clamp || o <= -clamp)) g = 0.f;
     dy = g;
-    pre = (act == EG3D_ACT_LRELU) ? (yy > 0.f ? yy : yy / alpha) : yy;     // linear / lrelu are invertible
+    if (PWL) pre = (yy > 0.f || alpha == 0.f) ? yy : yy / alpha;            // alpha = slope: 1 (linear), alpha (lrelu); relu is not invertible
+    else pre = (act == EG3D_ACT_LRELU) ? (yy > 0.f ? yy : yy / alpha) : yy;     // linear / lrelu are invertible
 }
 
 // grid = (blocks_x, N).  Block: EPI_BWD_THREADS threads = PPB pixels x C4 channel-quads.  Big blocks on purpose: every block ends with
 // 2*C atomics onto the same dbias / dd addresses (measured: launch time grows linearly with the block count), so the
 // parallelism comes from 16 waves per block rather than from many blocks.
 constexpr int EPI_BWD_THREADS = 1024;
+template <bool PWL>
 __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ outv, float* __restrict__ dz,
                                                            int H, int W, int C4, const float* __restrict__ d, const float* __restrict__ noise,
                                                            int64_t noise_nstride, const float* __restrict__ noise_strength,
@@ -207,8 +214,8 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const flo
                 if (pix >= HW) break;
                 const int64_t off = ((int64_t)n * HW + pix) * C + c;
                 float4 dy, pre;
-                bwd1(g[u].x, o[u].x, act, alpha, gain, clamp, dy.x, pre.x); bwd1(g[u].y, o[u].y, act, alpha, gain, clamp, dy.y, pre.y);
-                bwd1(g[u].z, o[u].z, act, alpha, gain, clamp, dy.z, pre.z); bwd1(g[u].w, o[u].w, act, alpha, gain, clamp, dy.w, pre.w);
+                bwd1<PWL>(g[u].x, o[u].x, act, alpha, gain, clamp, dy.x, pre.x); bwd1<PWL>(g[u].y, o[u].y, act, alpha, gain, clamp, dy.y, pre.y);
+                bwd1<PWL>(g[u].z, o[u].z, act, alpha, gain, clamp, dy.z, pre.z); bwd1<PWL>(g[u].w, o[u].w, act, alpha, gain, clamp, dy.w, pre.w);
                 const float4 zz = make_float4(dy.x * dv.x, dy.y * dv.y, dy.z * dv.z, dy.w * dv.w);
                 st4(dz + off, zz);
                 amax = fmaxf(amax, fmaxf(fmaxf(fabsf(zz.x), fabsf(zz.y)), fmaxf(fabsf(zz.z), fabsf(zz.w))));
@@ -425,18 +432,24 @@ extern "C" int eg3d_modconv_epilogue_fwd(const float* z, float* out, int N, int 
     if (fir && (H != Hz + 2 * pad0 - fh + 1 || W != Wz + 2 * pad0 - fw + 1)) return EG3D_ERR_INVALID;
     if (!fir && (Hz != H || Wz != W)) return EG3D_ERR_INVALID;
     if (noise && !noise_strength) return EG3D_ERR_INVALID;
+    const bool pwl = eg3d_act_is_pwl(act);
+    const float slope = eg3d_act_pwl_slope(act, alpha);
     if (fir != nullptr && fh == 4 && fw == 4 && !(H & 1) && !(W & 1)) {
         const int64_t total4 = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
         const int blocks4 = (int)std::min<int64_t>(eg3d_cdiv(total4, 256), 256 * 16);
-        hipLaunchKernelGGL(epilogue_fwd_fir44_kernel, dim3(blocks4), dim3(256), 0, (hipStream_t)stream, z, out, N, H, W, C / 4, Hz, Wz, fir, pad0,
-                           fir_gain, d, noise, noise_nstride, noise_strength, bias, act, alpha, gain, clamp);
+        if (pwl) hipLaunchKernelGGL(epilogue_fwd_fir44_kernel<true>, dim3(blocks4), dim3(256), 0, (hipStream_t)stream, z, out, N, H, W, C / 4, Hz, Wz, fir, pad0,
+                                    fir_gain, d, noise, noise_nstride, noise_strength, bias, act, slope, gain, clamp);
+        else hipLaunchKernelGGL(epilogue_fwd_fir44_kernel<false>, dim3(blocks4), dim3(256), 0, (hipStream_t)stream, z, out, N, H, W, C / 4, Hz, Wz, fir, pad0,
+                                fir_gain, d, noise, noise_nstride, noise_strength, bias, act, alpha, gain, clamp);
         EG3D_LAUNCH_CHECK();
         return EG3D_OK;
     }
     const int64_t total = (int64_t)N * H * W * (C / 4);
     int blocks = (int)std::min<int64_t>(eg3d_cdiv(total, 256), 256 * 16);
-    hipLaunchKernelGGL(epilogue_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, out, N, H, W, C / 4, Hz, Wz, fir, fh, fw, pad0,
-                       fir_gain, d, noise, noise_nstride, noise_strength, bias, act, alpha, gain, clamp);
+    if (pwl) hipLaunchKernelGGL(epilogue_fwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, out, N, H, W, C / 4, Hz, Wz, fir, fh, fw, pad0,
+                                fir_gain, d, noise, noise_nstride, noise_strength, bias, act, slope, gain, clamp);
+    else hipLaunchKernelGGL(epilogue_fwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, out, N, H, W, C / 4, Hz, Wz, fir, fh, fw, pad0,
+                            fir_gain, d, noise, noise_nstride, noise_strength, bias, act, alpha, gain, clamp);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }
@@ -458,8 +471,12 @@ extern "C" int eg3d_modconv_epilogue_bwd(const float* dout, const float* out, fl
     const int cap = 256;
     int bx = std::max(1, std::min(eg3d_cdiv((int64_t)H * W, ppb * 4), std::max(1, cap / N)));
     size_t smem = (size_t)(ppb * C4 * 8 + 4) * sizeof(float);
-    hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(bx, N), dim3(EPI_BWD_THREADS), smem, (hipStream_t)stream, dout, out, dz, H, W, C4, d, noise, noise_nstride,
-                       noise_strength, bias, act, alpha, gain, clamp, dbias, dd, dnoise, dnoise_nstride, dstrength, dz_amax);
+    if (eg3d_act_is_pwl(act))
+        hipLaunchKernelGGL(epilogue_bwd_kernel<true>, dim3(bx, N), dim3(EPI_BWD_THREADS), smem, (hipStream_t)stream, dout, out, dz, H, W, C4, d, noise, noise_nstride,
+                           noise_strength, bias, act, eg3d_act_pwl_slope(act, alpha), gain, clamp, dbias, dd, dnoise, dnoise_nstride, dstrength, dz_amax);
+    else
+        hipLaunchKernelGGL(epilogue_bwd_kernel<false>, dim3(bx, N), dim3(EPI_BWD_THREADS), smem, (hipStream_t)stream, dout, out, dz, H, W, C4, d, noise, noise_nstride,
+                           noise_strength, bias, act, alpha, gain, clamp, dbias, dd, dnoise, dnoise_nstride, dstrength, dz_amax);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc4_fir44(const float* __rest
                     for (int kx = 0; kx < 4; ++kx) {
                         const float w = fs[ky * 4 + kx];
                         const float4 v = t[(dy + ky) * 5 + dx + kx];
-                        acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+                        acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
                     }
                 const int64_t o = (((int64_t)n * outH + oy) * outW + ox) * C4 + c;
                 if (accumulate) { const float4 p = y4[o]; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }

@@ -84,7 +84,7 @@ int eg3d_upfirdn2d(const void* x, const float* f, void* y, int dtype, int N, int
  */
 #define EG3D_EPI_STORE 0   /* out = acc                                                                  */
 #define EG3D_EPI_ATOMIC 1  /* out += acc  (split-K; out must be pre-zeroed)                               */
-#define EG3D_EPI_FWD 2     /* out = clamp(act(acc*out_scale[n,o] + noise[n,y,x]*strength + bias[o])*gain) (+ addend) */
+#define EG3D_EPI_FWD 2     /* out = clamp(act(acc*out_scale[n,o] + noise[n,y,x]*strength + bias[o])*gain) (+ addend); act: linear | relu | lrelu */
 #define EG3D_EPI_BWD 3     /* ds[n,o] += sum_px acc*xin ; out = acc*out_scale[n,o] (+ addend)             */
 
 typedef struct eg3d_conv_class {
