@@ -37,7 +37,7 @@ import torch  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide, dense bf16 (never the 2:1-sparsity figure)
 PRODUCTS = {'f32': 1, 'bf16x6': 6, 'bf16x3': 3, 'f16x3': 3}      # MFMA products executed per algorithmic fp32 product
-CONV_TRAFFIC_BYTES = 222.1e6       # HBM bytes per launch of the dominant kernel (both epilogue instantiations, launch-weighted): rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/r01_bench_c2_summary.md
+CONV_TRAFFIC_BYTES = 209.9e6       # HBM bytes per launch of the dominant kernel (both epilogue instantiations, launch-weighted): rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/r01_bench_c2_summary.md
 DOMINANT = 0                        # tile configuration id of conv_igemm_kernel<128,128,2,2>
 
 
