@@ -15,6 +15,9 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    import torch
+    if not torch.cuda.is_available():      # CPU suite: small problems; a modest fixed thread count is faster than one thread per core on a shared host
+        torch.set_num_threads(min(8, os.cpu_count() or 1))
 
 
 def pytest_collection_modifyitems(config, items):
