@@ -17,6 +17,7 @@ def _free_port():
 
 
 def _worker(rank, world, port, out):
+    torch.set_num_threads(2)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     from inv3d_amd import dist as D
     r, w, _ = D.init_from_env('gloo')
