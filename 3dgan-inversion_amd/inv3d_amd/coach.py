@@ -20,6 +20,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import dist as D
+from .inference import estimate_w_stats
 from .inversion import LatentProjector, PivotalTuner, psnr_01
 
 
@@ -40,10 +41,14 @@ class InversionCoach:
     def __init__(self, G, *, first_inv_steps: int = 400, max_pti_steps: int = 400, lpips_threshold: float = 0.06, first_inv_lr: float = 8e-3,
                  pti_lr: float = 3e-4, optimize_pose: bool = False, use_warping_loss: bool = False, wplus: bool = False,
                  feature_net: Optional[Callable] = None, early_stop_interval: int = 1, use_graph: bool = False, keep_tuned_state: bool = False,
-                 synth_kwargs: Optional[dict] = None, seed: int = 0, pose_net_factory: Optional[Callable] = None):
+                 synth_kwargs: Optional[dict] = None, seed: int = 0, pose_net_factory: Optional[Callable] = None, pose_mode: str = 'quat',
+                 w_avg_samples: int = 10000, w_stats: Optional[Tuple[torch.Tensor, float]] = None,
+                 start_w_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
         """Hyper-parameter names and defaults follow configs/hyperparameters.py.  `early_stop_interval` = how often Phase B reads the
         perceptual loss back to the host for the early-stop test (1 = every step like the reference; larger values keep the host from
-        stalling the GPU queue every step)."""
+        stalling the GPU queue every step).  Phase A starts where the reference starts (w_projector.py:88-97,100,118): at the mean latent
+        of `w_avg_samples` mapped z (plus `start_w_fn(target_255_256)`, the e4e encoder's offset, when given) with the latent-noise scale
+        tied to their standard deviation; `w_stats=(w_avg, w_std)` overrides the estimate, `w_avg_samples=0` starts at w = 0, std 1."""
         self.G = G
         self.first_inv_steps, self.max_pti_steps, self.thr = first_inv_steps, max_pti_steps, lpips_threshold
         self.first_inv_lr, self.pti_lr = first_inv_lr, pti_lr
@@ -51,6 +56,13 @@ class InversionCoach:
         self.feature_net, self.interval, self.use_graph, self.keep = feature_net, max(1, early_stop_interval), use_graph, keep_tuned_state
         self.synth_kwargs, self.seed = dict(synth_kwargs or {}), seed
         self.pose_net_factory = pose_net_factory      # () -> a fresh pose estimator per image (the reference deep-copies its encoder, w_projector.py:62)
+        self.pose_mode, self.start_w_fn = pose_mode, start_w_fn
+        if w_stats is not None:
+            self.w_avg, self.w_std = w_stats[0], float(w_stats[1])
+        elif w_avg_samples > 0:
+            self.w_avg, self.w_std = estimate_w_stats(G, num_samples=w_avg_samples)     # once per generator: the weights are restored per image
+        else:
+            self.w_avg, self.w_std = None, 1.0
         # pristine copy of every parameter and buffer: what "re-loading the generator" means without a pickle on disk
         self._pristine = {k: v.detach().clone() for k, v in G.state_dict().items()}
 
@@ -70,10 +82,17 @@ class InversionCoach:
         self.restore_generator()
         # ---- Phase A: latent (+ pose) with frozen weights ----------------------------------------------------------------------
         G.requires_grad_(False)
+        start_w = None
+        if self.start_w_fn is not None:
+            with torch.no_grad():
+                t255 = (target + 1) * (255 / 2)
+                if t255.shape[2] > 256:
+                    t255 = torch.nn.functional.interpolate(t255, size=(256, 256), mode='area')
+                start_w = self.start_w_fn(t255)                       # e4e_enc(target_e4e).unsqueeze(1)  (w_projector.py:71-74,100)
         proj = LatentProjector(G, target, num_steps=self.first_inv_steps, cam=cam, optimize_pose=self.optimize_pose,
                                use_warping_loss=self.use_warp, first_inv_lr=self.first_inv_lr, wplus=self.wplus,
                                feature_net=self.feature_net, synth_kwargs=self.synth_kwargs, seed=self.seed,
-                               use_graph=self.use_graph,
+                               use_graph=self.use_graph, w_avg=self.w_avg, w_std=self.w_std, start_w=start_w, pose_mode=self.pose_mode,
                                pose_net=self.pose_net_factory() if (self.pose_net_factory is not None and self.optimize_pose) else None)
         out = {}
         for _ in range(self.first_inv_steps):
@@ -92,9 +111,9 @@ class InversionCoach:
         for i in range(self.max_pti_steps):
             check = (i % self.interval) == self.interval - 1
             res = tuner.step(early_stop=check)
-            steps_b += 1
-            if check and res.get('done'):
+            if check and res.get('done'):         # the reference leaves before the update (single_id_coach.py:68-71)
                 break
+            steps_b += 1
         with torch.no_grad():
             img = G.synthesis(w_pivot, cam_pivot, noise_mode='const', force_fp32=True, **self.synth_kwargs)['image']
             psnr_tuned = float(psnr_01(img, target))

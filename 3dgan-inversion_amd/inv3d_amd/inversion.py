@@ -83,6 +83,48 @@ def quaternion_to_rotmat(q: torch.Tensor) -> torch.Tensor:
     return r.view(-1, 3, 3)
 
 
+def rot6d_to_rotmat(x: torch.Tensor) -> torch.Tensor:
+    """[B,6] -> [B,3,3]: the continuous 6-D rotation representation of the AFHQ pose head (utils/camera_utils.py:259-273; every
+    component is offset by 1e-4 first, as there).  Columns = orthonormalised first vector, second vector, their cross product."""
+    v = x.reshape(-1, 2, 3) + 1e-4
+    e1 = F.normalize(v[:, 0], dim=-1)
+    e2 = F.normalize(v[:, 1] - (e1 * v[:, 1]).sum(-1, keepdim=True) * e1, dim=-1)
+    return torch.stack((e1, e2, torch.linalg.cross(e1, e2, dim=-1)), dim=-1)
+
+
+def euler_to_rotmat(theta: torch.Tensor, phi: torch.Tensor, roll: Optional[torch.Tensor] = None, radius: float = 2.7) -> torch.Tensor:
+    """Azimuth / polar angle (+ roll) -> [B,3,3]: rotation of a camera on the sphere looking at the origin, y up -- the rotation
+    block of euler2rot -> create_cam2world_matrix_roll (utils/camera_utils.py:241-257, 158-188)."""
+    theta, phi = theta.reshape(-1, 1), phi.reshape(-1, 1)
+    sp = torch.sin(phi)
+    origin = radius * torch.cat([sp * torch.cos(math.pi - theta), torch.cos(phi), sp * torch.sin(math.pi - theta)], 1)
+    fwd = F.normalize(-origin, dim=-1, eps=0.0)
+    right = -F.normalize(torch.linalg.cross(torch.tensor([0., 1., 0.], device=fwd.device).expand_as(fwd), fwd, dim=-1), dim=-1, eps=0.0)
+    up = F.normalize(torch.linalg.cross(fwd, right, dim=-1), dim=-1, eps=0.0)
+    rot = torch.stack((right, up, fwd), dim=-1)
+    if roll is not None:
+        r = roll.reshape(-1, 1).to(rot.device)
+        c, s_, z, o = torch.cos(r), torch.sin(r), torch.zeros_like(r), torch.ones_like(r)
+        rot = torch.bmm(torch.stack([torch.cat([c, -s_, z], 1), torch.cat([s_, c, z], 1), torch.cat([z, z, o], 1)], 1), rot)
+    return rot
+
+
+POSE_DIMS = {'quat': 4, '6d': 6, 'euler': 2}
+POSE_INIT = {'quat': [0., 1., 0., 0.], '6d': [1., 0., 0., 0., -1., 0.], 'euler': [0., 0.]}     # each = the canonical extrinsic's rotation
+
+
+def pose_to_rotmat(pred: torch.Tensor, mode: str) -> torch.Tensor:
+    """The pose-head dispatch of w_projector.py:147-158 / scripts/run_pti.py:36-45: 'quat' (FFHQ, global_config.use_quaternions),
+    '6d' (AFHQ, use_6d), 'euler' (two angles added to pi/2, no roll)."""
+    if mode == 'quat':
+        return quaternion_to_rotmat(pred)
+    if mode == '6d':
+        return rot6d_to_rotmat(pred)
+    if mode == 'euler':
+        return euler_to_rotmat(math.pi / 2 + pred[:, 0], math.pi / 2 + pred[:, 1])
+    raise ValueError(f'pose_mode must be one of {sorted(POSE_DIMS)}, got {mode!r}')
+
+
 def pose_to_cam(rotmat: torch.Tensor, translation_opt: torch.Tensor, intrinsic: torch.Tensor, radius: float = 2.7):
     """Rotation + optimisable translation -> extrinsic [B,4,4] and c [B,25] (w_projector.py:160-172)."""
     b = rotmat.shape[0]
@@ -172,7 +214,10 @@ class LatentProjector:
                  noise_ramp_length=0.75, lr_rampdown_length=0.25, lr_rampup_length=0.05, regularize_noise_weight=1e5,
                  initial_learning_rate=0.01, radius=2.7, wplus=False, synth_kwargs: Optional[dict] = None, seed: int = 0,
                  init_noise: Optional[Dict[str, torch.Tensor]] = None, use_graph: bool = False, graph_warmup: int = 2,
-                 pose_net: Optional[torch.nn.Module] = None):
+                 pose_net: Optional[torch.nn.Module] = None, pose_mode: str = 'quat', translation_start=None):
+        if pose_mode not in POSE_DIMS:
+            raise ValueError(f'pose_mode must be one of {sorted(POSE_DIMS)}, got {pose_mode!r}')
+        self.pose_mode = pose_mode
         dev = target.device
         self.use_graph, self._graph, self._graph_warmup, self.graph_capture_error = use_graph, None, graph_warmup, None
         self.G = G.eval().requires_grad_(False)
@@ -192,6 +237,7 @@ class LatentProjector:
         t255 = (target + 1) * (255 / 2)
         if t255.shape[2] > 256:
             t255 = _area_resize(t255, 256)
+        self.t255 = t255                   # also the pose estimator's input, every step (w_projector.py:106-110,148)
         with torch.no_grad():
             self.target_features = self.feature_net(t255)
             self.target_warp_feat = self.warp_net(target) if use_warping_loss else None
@@ -208,38 +254,46 @@ class LatentProjector:
                 for nm, b in bufs.items():
                     src = init_noise[prefix + nm].to(dev) if init_noise is not None else torch.randn(b.shape, device=dev, generator=self.gen)
                     b.copy_(src)
-                    b.requires_grad = True
-        self._all_bufs = list(self.noise_bufs.values()) + list(self.noise_bufs2.values())
+                    # only the backbone's buffers become leaves (w_projector.py:126-128); the SR head's are re-drawn (:129-131) but never
+                    # receive a gradient: they enter the regulariser's value and are renormalised, nothing else
+                    b.requires_grad = prefix == 'backbone.synthesis.'
+        self._opt_bufs = list(self.noise_bufs.values())
+        self._all_bufs = self._opt_bufs + list(self.noise_bufs2.values())
         if use_graph:       # the schedule values live on the device so that one captured step can be replayed for every step index
             self._scale_t = torch.zeros((), device=dev)
             self._wn = torch.zeros_like(self.w_opt)
-            self.optimizer = torch.optim.Adam([self.w_opt] + self._all_bufs, betas=(0.9, 0.999), lr=torch.tensor(float(first_inv_lr), device=dev),
+            self.optimizer = torch.optim.Adam([self.w_opt] + self._opt_bufs, betas=(0.9, 0.999), lr=torch.tensor(float(first_inv_lr), device=dev),
                                               fused=True, capturable=True)
         else:
-            self.optimizer = torch.optim.Adam([self.w_opt] + self._all_bufs, betas=(0.9, 0.999), lr=first_inv_lr, fused=True)
+            self.optimizer = torch.optim.Adam([self.w_opt] + self._opt_bufs, betas=(0.9, 0.999), lr=first_inv_lr, fused=True)
         self.intrinsic = torch.tensor([4.2647, 0, 0.5, 0, 4.2647, 0.5, 0, 0, 1], device=dev).unsqueeze(0)
         self.init_ext = torch.tensor([1, 0, 0, 0, 0, -1, 0, 0, 0, 0, -1, 2.7, 0, 0, 0, 1.], device=dev).reshape(1, 4, 4)
         self.canonical_cam = torch.cat([self.init_ext.reshape(1, 16), self.intrinsic], -1)
         self.cam = cam.to(dev) if cam is not None else self.canonical_cam.clone()
         if optimize_pose:
-            # the reference predicts the quaternion with a ResNet34 (scripts/resnet) fine-tuned per image; here the
-            # quaternion itself is the optimisable state ("ResNet34 optional stub")
-            self.quat = torch.tensor([[0., 1., 0., 0.]], device=dev).requires_grad_(True)     # = init_ext rotation
-            self.translation_opt = torch.zeros(1, 3, device=dev, requires_grad=True)
-            # pose_net (pose_net.ResNetPose or any module image -> quaternion): the reference's per-image fine-tuned estimator,
-            # cam_predictor(target_images) every step with Adam over all its parameters (w_projector.py:62,122,148-150)
+            # the reference predicts the pose vector (quaternion / 6-D / two angles) with a ResNet34 (scripts/resnet) fine-tuned per
+            # image; without a pose_net the vector itself is the optimisable state ("ResNet34 optional stub")
+            self.pose_vec = torch.tensor([POSE_INIT[pose_mode]], device=dev).requires_grad_(True)     # = init_ext rotation
+            self.translation_opt = (torch.zeros(1, 3, device=dev) if translation_start is None else
+                                    torch.as_tensor(translation_start, dtype=torch.float32, device=dev).reshape(1, 3).clone()).requires_grad_(True)
+            # pose_net (pose_net.ResNetPose or any module image -> pose vector): the reference's per-image fine-tuned estimator,
+            # cam_predictor(target_images) every step with Adam over all its parameters (w_projector.py:62,122,148-158)
             self.pose_net = pose_net
             if pose_net is not None:
                 pose_net.requires_grad_(True)
             if pose_net is not None:       # 222 tensors: one multi-tensor launch (trainable conv weights are re-packed every step, no version-keyed cache involved)
                 self.cam_optimizer = torch.optim.Adam(list(pose_net.parameters()), lr=cam_lr, betas=(0.9, 0.999), fused=True, capturable=use_graph)
             else:
-                self.cam_optimizer = torch.optim.Adam([self.quat], lr=cam_lr, betas=(0.9, 0.999), capturable=use_graph)
+                self.cam_optimizer = torch.optim.Adam([self.pose_vec], lr=cam_lr, betas=(0.9, 0.999), capturable=use_graph)
             self.translation_optimizer = torch.optim.Adam([self.translation_opt], lr=translation_lr, capturable=use_graph)
         self.step_idx = 0
         self.last = {}
         self._reg_stream = None
         self._arena = None
+
+    @property
+    def quat(self):
+        return self.pose_vec
 
     def feature_net_map(self, img):
         """Spatial feature map for the warping loss from the stub net's first two stages ([N,C,h,w])."""
@@ -330,7 +384,7 @@ class LatentProjector:
     def _step_body_inner(self, w_noise_scale, wn, kw, do_step):
         G = self.G
         if self.optimize_pose:
-            rot = quaternion_to_rotmat(self.pose_net(self.target) if self.pose_net is not None else self.quat)
+            rot = pose_to_rotmat(self.pose_net(self.t255) if self.pose_net is not None else self.pose_vec, self.pose_mode)
             pred_ext, pred_cam = pose_to_cam(rot, self.translation_opt, self.intrinsic, self.radius)
         else:
             pred_ext, pred_cam = None, self.cam
@@ -368,17 +422,18 @@ class LatentProjector:
             self.cam_optimizer.zero_grad(set_to_none=True)
             self.translation_optimizer.zero_grad(set_to_none=True)
         (dist if warp is None else dist + warp).backward()
-        have = [(b.grad, g) for b, g in zip(self._all_bufs, reg_grads) if b.grad is not None]
-        for b, g in zip(self._all_bufs, reg_grads):
-            if b.grad is None:                 # buffers the synthesis does not read (SR noise with noise_mode='none'): regulariser only
+        have = [(b.grad, g) for b, g in zip(self._opt_bufs, reg_grads) if b.grad is not None]
+        for b, g in zip(self._opt_bufs, reg_grads):
+            if b.grad is None:                 # a backbone buffer the synthesis did not read (noise_mode overridden): regulariser only
                 b.grad = g
         if have:
             torch._foreach_add_([a for a, _ in have], [g for _, g in have])
-        if self.optimize_pose:
+        if self.optimize_pose:                 # order of w_projector.py:249-261
             self.cam_optimizer.step()
-            self.translation_optimizer.step()
         if do_step:
             self.optimizer.step()
+        if self.optimize_pose:
+            self.translation_optimizer.step()
         hipops.noise_normalize_(self._all_bufs)        # buf -= mean; buf *= rsqrt(mean(buf^2))   (w_projector.py:264-270)
         last = dict(loss=loss.detach(), dist=dist.detach(), reg=reg.detach() if torch.is_tensor(reg) else reg, image=out['image'].detach(),
                     cam=pred_cam.detach(), ws=ws.detach())
@@ -425,12 +480,13 @@ class PivotalTuner:
         lp = (self.feature_net(out['image']) - self.tf).square().sum() + (self.feature_net(out['image_raw']) - self.tf128).square().sum()
         tv = compute_tv_norm(out['image_depth'].squeeze(0))
         loss = l2 * self.l2_lambda + lp * self.lpips_lambda + tv
+        self.last = dict(loss=loss.detach(), l2=l2.detach(), lpips=lp.detach(), tv=tv.detach(), image=out['image'].detach(), done=False)
         self.optimizer.zero_grad(set_to_none=True)
+        if early_stop and bool(lp.item() <= self.thr):            # the reference's per-step host sync; it leaves BEFORE the update
+            self.last['done'] = True                              # (single_id_coach.py:68-71)
+            return self.last
         loss.backward()
         self.optimizer.step()
-        self.last = dict(loss=loss.detach(), l2=l2.detach(), lpips=lp.detach(), tv=tv.detach(), image=out['image'].detach())
-        if early_stop:
-            self.last['done'] = bool(lp.item() <= self.thr)       # the reference's per-step host sync (single_id_coach.py:69)
         return self.last
 
 

@@ -824,6 +824,49 @@ def quaternion_to_rotmat(q):
     return torch.stack((r0, r1, r2), 1)
 
 
+def rot6d_to_rotmat(x):
+    """utils/camera_utils.py:259-273 (Zhou et al. 6-D rotation; the reference offsets every component by 1e-4 first):
+    Gram-Schmidt of the two 3-vectors, third axis by cross product, the three axes are the COLUMNS of the result."""
+    v = x.reshape(-1, 2, 3) + 1e-4
+    e1 = F.normalize(v[:, 0])
+    e2 = F.normalize(v[:, 1] - (e1 * v[:, 1]).sum(-1, keepdim=True) * e1)
+    e3 = torch.linalg.cross(e1, e2)
+    return torch.stack((e1, e2, e3), dim=-1)
+
+
+def euler_to_rotmat(theta, phi, roll=None, radius: float = 2.7):
+    """Rotation block of utils/camera_utils.py:241-257 euler2rot -> :158-188 create_cam2world_matrix_roll: camera on the sphere at
+    azimuth theta / polar angle phi looking at the origin (y up), then an in-plane roll.  theta, phi: [B] or [B,1]; returns [B,3,3]."""
+    theta, phi = theta.reshape(-1, 1), phi.reshape(-1, 1)
+    origin = torch.cat([radius * torch.sin(phi) * torch.cos(math.pi - theta), radius * torch.cos(phi),
+                        radius * torch.sin(phi) * torch.sin(math.pi - theta)], 1)
+    fwd = -origin / torch.norm(-origin, dim=-1, keepdim=True)
+    fwd = fwd / torch.norm(fwd, dim=-1, keepdim=True)
+    up0 = torch.tensor([0., 1., 0.]).expand_as(fwd)
+    right = torch.linalg.cross(up0, fwd)
+    right = -(right / torch.norm(right, dim=-1, keepdim=True))
+    up = torch.linalg.cross(fwd, right)
+    up = up / torch.norm(up, dim=-1, keepdim=True)
+    R0 = torch.stack((right, up, fwd), dim=-1)
+    if roll is None:
+        return R0
+    r = roll.reshape(-1, 1)
+    z, o = torch.zeros_like(r), torch.ones_like(r)
+    Rz = torch.stack([torch.cat([torch.cos(r), -torch.sin(r), z], 1), torch.cat([torch.sin(r), torch.cos(r), z], 1), torch.cat([z, z, o], 1)], 1)
+    return torch.bmm(Rz, R0)
+
+
+def pose_to_rotmat(pred, mode: str):
+    """Dispatch of training/projectors/w_projector.py:147-158: 'quat' (FFHQ default), '6d' (AFHQ), 'euler' (two angles around pi/2)."""
+    if mode == 'quat':
+        return quaternion_to_rotmat(pred)
+    if mode == '6d':
+        return rot6d_to_rotmat(pred)
+    if mode == 'euler':
+        return euler_to_rotmat(math.pi / 2 + pred[:, 0], math.pi / 2 + pred[:, 1], torch.zeros(1, 1))
+    raise ValueError(mode)
+
+
 def l2_loss(a, b):
     """criteria/l2_loss.py:6-8."""
     return F.mse_loss(a, b, reduction='mean')

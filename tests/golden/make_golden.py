@@ -64,6 +64,19 @@ def check(a, b, tol, what):
     return err
 
 
+def check_adam(a, b, tol, step_bound, what, frac=0.995):
+    """Adam-updated state after a few steps: an element whose gradient is at rounding-noise level moves by lr * g / (|g| + eps) -- a
+    full step in a direction the reference's own arithmetic does not determine -- so a handful of elements of the 256^2 buffers
+    legitimately differ by up to the accumulated step size.  Required: >= frac of the elements within tol, all within step_bound."""
+    a, b = torch.as_tensor(T(a)), torch.as_tensor(T(b))
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    scale = max(1.0, b.abs().max().item())
+    ok = (err <= tol * scale).float().mean().item()
+    assert ok >= frac and err.max().item() <= step_bound, f'ORACLE != REFERENCE for {what}: {100 * ok:.2f} % within {tol}, max {err.max().item():.3e}'
+    return err.max().item()
+
+
 @contextlib.contextmanager
 def inject(rand_like=None, rand=None, randn=None):
     """Replay recorded tensors in place of torch.rand_like / torch.rand / torch.randn inside the reference."""
@@ -607,41 +620,338 @@ def gen_graph_full():
          dep_stats=stats(o['image_depth']), dws=dws, dc=dc)
 
 
+# ---------------------------------------------------------------------------------------------------
+# Loop-level pins.  training/projectors/w_projector.py, training/coaches/*.py import wandb / lpips / torchvision / mrcfile
+# (absent here), so their loop bodies are lifted out of the source by AST and executed UNMODIFIED in a namespace that holds the
+# reference's own generator classes / RaySampler / calc_warping_loss / camera utilities plus stub perceptual networks.
+# ---------------------------------------------------------------------------------------------------
+import ast          # noqa: E402
+import types        # noqa: E402
+
+
+def _parse(rel):
+    return ast.parse(open(os.path.join(REF, rel)).read())
+
+
+def _func(tree, name, cls=None):
+    body = tree.body
+    if cls is not None:
+        body = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls][0].body
+    return [n for n in body if isinstance(n, ast.FunctionDef) and n.name == name][0]
+
+
+def _exec_nodes(nodes, ns, tag):
+    mod = ast.Module(body=list(nodes), type_ignores=[])
+    ast.fix_missing_locations(mod)
+    exec(compile(mod, f'<lifted {tag}>', 'exec'), ns)
+    return ns
+
+
+def _lifted_loop(for_node, n_iter_expr, trace_src):
+    """The reference `for` statement with its iterable replaced by range(<n_iter_expr>) and one trace statement appended."""
+    node = ast.parse(ast.unparse(for_node)).body[0]
+    node.iter = ast.parse(f'range({n_iter_expr})').body[0].value
+    node.body = node.body + ast.parse(trace_src).body
+    return node
+
+
+class _Lambda(torch.nn.Module):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+    def forward(self, x):
+        return self.fn(x)
+
+
+def _stub_torch_vgg(fw):
+    """22 children like torchvision vgg16().features[:22] as get_features (warping_loss.py:74-110) walks them; children 0-5 are the
+    oracle's two-stage stub feature map, the rest identities, so layers='14' returns that map."""
+    mods = []
+    pad4 = lambda x: torch.cat([x, x.new_zeros(*x.shape[:-3], 4 - x.shape[-3], *x.shape[-2:])], -3) if x.shape[-3] < 4 else x     # noqa: E731
+    for wt in fw[:2]:
+        mods += [_Lambda(lambda x, wt=wt: torch.nn.functional.conv2d(pad4(x), wt, padding=1)), _Lambda(lambda x: O.bias_act(x, None, act='lrelu')),
+                 torch.nn.AvgPool2d(2)]
+    mods += [torch.nn.Identity() for _ in range(22 - len(mods))]
+    return torch.nn.Sequential(*mods)
+
+
+class _GSteps:
+    """G as the lifted loops see it: .synthesis(ws, c, **kw) of the reference classes with the step's recorded uniforms replayed
+    (calls_per_step consecutive calls share one (u1, u2): the optimised view and the canonical view of calc_warping_loss)."""
+
+    def __init__(self, ref_composite, uniforms, calls_per_step, randn=None):
+        self.R, self.uniforms, self.cps, self.calls, self.randn = ref_composite, uniforms, calls_per_step, 0, randn
+        self.backbone = ref_composite.backbone
+
+    def synthesis(self, ws, c, noise_mode='random', force_fp32=False, **kw):
+        k = self.calls // self.cps
+        self.calls += 1
+        u1, u2 = self.uniforms[k]
+        return self.R.synthesis(ws, c, u1, u2, noise_mode=noise_mode, randn=None if self.randn is None else self.randn[k])
+
+    def parameters(self):
+        return self.R.parameters()
+
+
+def _pad3(img):
+    return torch.cat([img, img.new_zeros(img.shape[0], 1, *img.shape[2:])], 1) if img.dim() == 4 else \
+        torch.cat([img, img.new_zeros(1, *img.shape[1:])], 0)
+
+
 def gen_loss_glue():
-    print('loss glue')
+    print('loss glue (reference functions; restatement-free)')
+    from utils import camera_utils as ref_cam
+    from training.warping_loss import LinePlaneCollision
+    from training.explainability_network.loss_functions import photometric_reconstruction_loss
+    from oracle import inversion_oracle as IO
     g = torch.Generator().manual_seed(15)
     out = {}
-    # quaternion -> rotation
-    from utils import camera_utils as ref_cam
+    # rotation parametrisations (utils/camera_utils.py:201-228, 259-273, 241-257)
     q = torch.randn(3, 4, generator=g)
-    Rm = ref_cam.compute_rotation_matrix_from_quaternion(q)
-    check(O.quaternion_to_rotmat(q), Rm, 1e-6, 'quat->R')
-    out.update(dict(q=q, R=Rm))
+    Rq = ref_cam.compute_rotation_matrix_from_quaternion(q)
+    check(O.quaternion_to_rotmat(q), Rq, 1e-6, 'quat->R')
+    x6 = torch.randn(4, 6, generator=g)          # (not 3: the reference's dim-less torch.cross would pick the batch axis)
+    R6 = ref_cam.rot6d_to_rotmat(x6)
+    check(O.rot6d_to_rotmat(x6), R6, 1e-6, '6d->R')
+    ang = torch.randn(3, 2, generator=g) * 0.3
+    Re = torch.cat([ref_cam.euler2rot(math.pi / 2 + a[0:1], math.pi / 2 + a[1:2], torch.zeros(1, 1), batch_size=1).reshape(-1, 4, 4)[:, :3, :3]
+                    for a in ang])
+    check(torch.cat([O.pose_to_rotmat(a[None], 'euler') for a in ang]), Re, 1e-6, 'euler->R')
+    roll = torch.tensor([[0.3]])
+    Rr = ref_cam.euler2rot(torch.tensor([1.2]), torch.tensor([1.9]), roll, batch_size=1).reshape(-1, 4, 4)
+    check(O.euler_to_rotmat(torch.tensor([1.2]), torch.tensor([1.9]), roll), Rr[:, :3, :3], 1e-6, 'euler+roll->R')
+    out.update(dict(q=q, R=Rq, x6=x6, R6=R6, ang=ang, Re=Re, roll_R=Rr[:, :3, :3]))
     # lookat
     origin = torch.tensor([[0.3, 0.5, 2.6]])
     fwd = ref_math.normalize_vecs(-origin)
     m = ref_cam.create_cam2world_matrix(fwd, origin)
     check(O.lookat_cam2world(origin[0], torch.zeros(3)), m[0], 1e-6, 'lookat')
     out.update(dict(lookat_origin=origin, lookat=m))
-    # noise regulariser: restated from w_projector.py:221-237 (file not importable: needs wandb/lpips)
+    # pose -> extrinsic / camera block and the noise regulariser: the reference's own statements out of the body of the optimisation
+    # loop (w_projector.py:147-172 and :221-237)
+    proj = _func(_parse('training/projectors/w_projector.py'), 'project')
+    loop = [n for n in proj.body if isinstance(n, ast.For)][-1]
+    first_reg = [i for i, n in enumerate(loop.body) if isinstance(n, ast.Assign) and ast.unparse(n.targets[0]) == 'reg_loss'][0]
+    reg_nodes = loop.body[first_reg:first_reg + 3]
+    assert [type(n).__name__ for n in reg_nodes] == ['Assign', 'For', 'For'], reg_nodes
+    last_pose = [i for i, n in enumerate(loop.body) if isinstance(n, ast.Assign) and ast.unparse(n.targets[0]) == 'pred_cam'][0]
+    pose_nodes = loop.body[:last_pose + 1]
+    from configs import global_config as gc
+    intrinsic = torch.tensor([4.2647, 0, 0.5, 0, 4.2647, 0.5, 0, 0, 1]).unsqueeze(0)
+    saved = (gc.use_quaternions, gc.use_6d)
+    try:
+        for mode, pred in (('quat', torch.randn(1, 4, generator=g)), ('6d', torch.randn(1, 6, generator=g)), ('euler', torch.randn(1, 2, generator=g) * 0.3)):
+            gc.use_quaternions, gc.use_6d = mode == 'quat', mode == '6d'
+            tr = (torch.randn(1, 3, generator=g) * 0.1).requires_grad_(True)
+            pr = pred.clone().requires_grad_(True)
+            ns = dict(torch=torch, math=math, global_config=gc, cam_predictor=lambda x: pr, target_images=None, radius=2.7,
+                      compute_rotation_matrix_from_quaternion=ref_cam.compute_rotation_matrix_from_quaternion,
+                      rot6d_to_rotmat=ref_cam.rot6d_to_rotmat, euler2rot=ref_cam.euler2rot, translation_opt=tr, intrinsic=intrinsic)
+            _exec_nodes(pose_nodes, ns, 'pose block')
+            gcam = torch.randn(1, 25, generator=g)
+            d_pr, d_tr = torch.autograd.grad(ns['pred_cam'], [pr, tr], gcam)
+            pr2, tr2 = pred.clone().requires_grad_(True), tr.detach().clone().requires_grad_(True)
+            ext, cam = IO.pose_to_cam(O.pose_to_rotmat(pr2, mode), tr2, intrinsic, 2.7)
+            check(ext, ns['pred_ext'], 1e-6, f'pose->ext {mode}')
+            check(cam, ns['pred_cam'], 1e-6, f'pose->cam {mode}')
+            e_pr, e_tr = torch.autograd.grad(cam, [pr2, tr2], gcam)
+            check(e_pr, d_pr, 2e-5, f'd cam / d pose {mode}')
+            check(e_tr, d_tr, 2e-5, f'd cam / d translation {mode}')
+            out.update({f'pose_{mode}_pred': pred, f'pose_{mode}_tr': tr, f'pose_{mode}_cam': ns['pred_cam'], f'pose_{mode}_gcam': gcam,
+                        f'pose_{mode}_dpred': d_pr, f'pose_{mode}_dtr': d_tr})
+    finally:
+        gc.use_quaternions, gc.use_6d = saved
     bufs = [torch.randn(r, r, generator=g) for r in (4, 8, 16, 32)]
-    reg = 0.0
-    for v in bufs:
-        noise = v[None, None]
-        while True:
-            reg = reg + (noise * torch.roll(noise, shifts=1, dims=3)).mean() ** 2
-            reg = reg + (noise * torch.roll(noise, shifts=1, dims=2)).mean() ** 2
-            if noise.shape[2] <= 8:
-                break
-            noise = torch.nn.functional.avg_pool2d(noise, kernel_size=2)
-    check(O.noise_regularizer(bufs), reg, 1e-6, 'noise reg')
-    # tv norm: restated from base_coach.py:294-305 (file not importable)
+    bufs2 = [torch.randn(r, r, generator=g) for r in (16, 64)]
+    ns = dict(torch=torch, F=torch.nn.functional, noise_bufs={str(i): b for i, b in enumerate(bufs)}, noise_bufs2={str(i): b for i, b in enumerate(bufs2)})
+    _exec_nodes(reg_nodes, ns, 'noise regulariser')
+    reg = ns['reg_loss']
+    check(O.noise_regularizer(bufs + bufs2), reg, 1e-6, 'noise reg')
+    # depth TV: the reference function itself (base_coach.py:294-305), lifted out of its un-importable module
+    ns = _exec_nodes([_func(_parse('training/coaches/base_coach.py'), 'compute_tv_norm')], dict(torch=torch), 'compute_tv_norm')
     d = torch.rand(1, 16, 16, generator=g)
-    v00, v01, v10 = d[:, :-1, :-1], d[:, :-1, 1:], d[:, 1:, :-1]
-    tv = torch.mean(torch.mean((v00 - v01) ** 2 + (v00 - v10) ** 2))
+    tv = ns['compute_tv_norm'](d)
     check(O.compute_tv_norm(d), tv, 1e-7, 'tv')
-    out.update(dict(tv_in=d, tv=tv, reg=reg, **{f'reg_buf{i}': b for i, b in enumerate(bufs)}))
+    out.update(dict(tv_in=d, tv=tv, reg=reg, **{f'reg_buf{i}': b for i, b in enumerate(bufs + bufs2)}))
+    # line-plane intersection + masked photometric loss (warping_loss.py:58-72, loss_functions.py:9-19)
+    n_ = 50
+    pn, pp, rd, rp = (torch.randn(n_, 3, generator=g) for _ in range(4))
+    psi = LinePlaneCollision(pn, pp, rd, rp)
+    check(IO.line_plane_collision(pn, pp, rd, rp), psi, 1e-5, 'LinePlaneCollision')
+    a, b_, mk = torch.randn(1, 5, 6, 6, generator=g), torch.randn(5, 6, 6, generator=g), torch.rand(1, 1, 6, 6, generator=g)
+    ph = photometric_reconstruction_loss(a, b_, mk)
+    check(((a - b_) * mk).abs().mean(), ph, 1e-7, 'photometric')
+    out.update(dict(lpc_n=pn, lpc_p=pp, lpc_d=rd, lpc_o=rp, lpc_out=psi))
     save('loss_glue', 1e-6, **out)
+
+
+def gen_projector_loop():
+    """Phase A: the reference's optimisation-loop body (w_projector.py:145-270) executed as is -- pose chain, synthesis, calc_warping_loss
+    (the reference's own function, imported), LPIPS-feature distance, noise regulariser, optimiser order, noise renormalisation -- for the
+    quaternion / 6-D / Euler pose modes; ProjectorOracle must reproduce every recorded step."""
+    print('projector loop (reference loop body, lifted)')
+    from utils import camera_utils as ref_cam
+    from training.warping_loss import calc_warping_loss
+    from configs import global_config as gc, hyperparameters as hp
+    from oracle import inversion_oracle as IO
+    cfg = IO.pin_config()
+    P = O.synth_params(cfg, seed=0)
+    target = IO.pin_target(cfg, P)                          # [3,H,W] in [-1,1]  (w_projector.project's `target`)
+    PROJ_STEPS, PROJ_PREHEAT = IO.PIN_PROJ_STEPS, IO.PIN_PROJ_PREHEAT
+    fw = IO.stub_feature_weights()
+    loop = [n for n in _func(_parse('training/projectors/w_projector.py'), 'project').body if isinstance(n, ast.For)][-1]
+    node = _lifted_loop(loop, 'num_steps', "_trace.append((float(loss), float(dist), float(reg_loss), float(warp_loss), _psnr(pred_dict['image']))); _gtrace.append((translation_opt.grad.clone(), cam_predictor.base.grad.clone()))")
+    out = dict(target_probe=target.flatten()[::37].clone())       # the target itself is regenerated by the tests (oracle render, seed 31)
+    saved = (gc.use_quaternions, gc.use_6d, gc.visualize_opt_process, gc.visualize_warp_process, hp.cam_preheat_steps)
+    o_randn_like = torch.randn_like
+    try:
+        gc.visualize_opt_process = gc.visualize_warp_process = False
+        hp.cam_preheat_steps = PROJ_PREHEAT
+        for mode in ('quat', '6d', 'euler'):
+            gc.use_quaternions, gc.use_6d = mode == 'quat', mode == '6d'
+            G = RefComposite(cfg, P).requires_grad_(False)
+            pin = IO.pin_projector_inputs(cfg, P, mode)
+            uniforms, wns, init_noise, w0, base = pin['uniforms'], pin['wns'], pin['init_noise'], pin['w0'], pin['pose_base']
+            cam_predictor = IO.StubPoseNet(base, seed=7)
+            Gs = _GSteps(G, uniforms, calls_per_step=2)
+            noise_bufs = {n: b for n, b in G.backbone.synthesis.named_buffers() if 'noise_const' in n}
+            noise_bufs2 = {f'{blk}.{n}': b for blk in ('block0', 'block1') for n, b in getattr(G, blk).named_buffers() if 'noise_const' in n}
+            with torch.no_grad():
+                for n_, b in noise_bufs.items():
+                    b[:] = init_noise['backbone.synthesis.' + n_]
+                    b.requires_grad = True                                      # w_projector.py:126-128
+                for n_, b in noise_bufs2.items():
+                    b[:] = init_noise['superresolution.' + n_]                  # :129-131 (no requires_grad)
+            w_opt = w0.clone().requires_grad_(True)
+            # (a non-zero start: at exactly zero the gradient along the viewing axis vanishes and Adam's first step follows rounding noise)
+            translation_opt = torch.tensor([IO.PIN_TRANSLATION_START], requires_grad=True)
+            t255 = (((target + 1) / 2) * 255).unsqueeze(0)
+            if t255.shape[2] > 256:
+                t255 = torch.nn.functional.interpolate(t255, size=(256, 256), mode='area')
+            vgg16 = lambda img, resize_images=False, return_lpips=True: IO.stub_features(img, fw)      # noqa: E731
+            init_ext = torch.Tensor([1, 0, 0, 0, 0, -1, 0, 0, 0, 0, -1, 2.7, 0, 0, 0, 1]).reshape(-1, 4, 4)
+            intrinsic = torch.tensor([4.2647, 0, 0.5, 0, 4.2647, 0.5, 0, 0, 1]).unsqueeze(0)
+            cam_lr = dict(quat=hp.cam_lr_quat, euler=hp.cam_lr_2d)
+            cam_lr['6d'] = hp.cam_lr_6d
+            ns = dict(torch=torch, F=torch.nn.functional, np=np, math=math, os=os, PIL=None, tqdm=lambda x: x, global_config=gc, hyperparameters=hp,
+                      compute_rotation_matrix_from_quaternion=ref_cam.compute_rotation_matrix_from_quaternion, rot6d_to_rotmat=ref_cam.rot6d_to_rotmat,
+                      euler2rot=ref_cam.euler2rot, calc_warping_loss=calc_warping_loss, ray_generator=RaySampler(), G=Gs, vgg16=vgg16,
+                      torch_vgg=_stub_torch_vgg(fw), layers='14', cam_predictor=cam_predictor, target_images=t255, target_images_contiguous=target.contiguous(),
+                      target_features=vgg16(t255), init_ext=init_ext, intrinsic=intrinsic, canonical_cam=torch.cat([init_ext.reshape(-1, 16), intrinsic], -1),
+                      radius=2.7, w_opt=w_opt, translation_opt=translation_opt, noise_bufs=noise_bufs, noise_bufs2=noise_bufs2,
+                      optimizer=torch.optim.Adam([w_opt] + list(noise_bufs.values()) + list(noise_bufs2.values()), betas=(0.9, 0.999), lr=hp.first_inv_lr),
+                      cam_optimizer=torch.optim.Adam(cam_predictor.parameters(), lr=cam_lr[mode], betas=(0.9, 0.999)),
+                      translation_optimizer=torch.optim.Adam([translation_opt], lr=hp.translation_lr),
+                      num_steps=PROJ_STEPS, w_std=IO.PIN_W_STD, initial_learning_rate=0.01, lr_rampdown_length=0.25, initial_noise_factor=0.05,
+                      noise_ramp_length=0.75, lr_rampup_length=0.05, regularize_noise_weight=1e5, outdir=None, w_name='pin', _trace=[], _gtrace=[],
+                      _psnr=lambda im: float(O.psnr_01(im.detach(), target[None])))
+            q = list(wns[PROJ_PREHEAT:])
+            torch.randn_like = lambda x, **k: q.pop(0).reshape(x.shape)          # w_noise = torch.randn_like(w_opt) (:183)
+            try:
+                _exec_nodes([node], ns, 'w_projector.project loop')
+            finally:
+                torch.randn_like = o_randn_like
+            trace = torch.tensor(ns['_trace'])
+            # ---- the oracle must reproduce it ------------------------------------------------------------------------------------
+            po = IO.ProjectorOracle(P, cfg, target[None], num_steps=PROJ_STEPS, optimize_pose=True, use_warping_loss=True, init_noise=init_noise,
+                                    w_start=w0, cam_preheat_steps=PROJ_PREHEAT, pose_mode=mode, pose_net=IO.StubPoseNet(base, seed=7), w_std=IO.PIN_W_STD, translation_start=IO.PIN_TRANSLATION_START,
+                                    cam_lr=cam_lr[mode])
+            otrace = []
+            for k in range(PROJ_STEPS):
+                r = po.step(*uniforms[k], w_noise=wns[k])
+                otrace.append((float(r['loss']), float(r['dist']), float(r['reg']), float(r['warp']), float(O.psnr_01(r['image'], target[None]))))
+            otrace = torch.tensor(otrace)
+            e = [check(otrace[:, j], trace[:, j], 2e-5, f'projector loop {mode}: {nm}') for j, nm in enumerate(('loss', 'dist', 'reg', 'warp', 'psnr'))]
+            check(po.w_opt, w_opt, 1e-5, f'projector loop {mode}: w_opt')
+            check(po.translation_opt, translation_opt, 1e-5, f'projector loop {mode}: translation')
+            check(po.pose_net.base, cam_predictor.base, 1e-6, f'projector loop {mode}: pose base')
+            check(po.pose_net.A, cam_predictor.A, 1e-6, f'projector loop {mode}: pose A')
+            dpose = (cam_predictor.base.detach() - base).abs().max().item()
+            assert dpose > 0 and (translation_opt.detach().abs().max().item() > 0), 'pose chain received no gradient'
+            for k_, b in noise_bufs.items():
+                check_adam(po.P['backbone.synthesis.' + k_], b, 1e-5, PROJ_STEPS * 0.01, f'projector loop {mode}: {k_}')
+            for k_, b in noise_bufs2.items():
+                check(po.P['superresolution.' + k_], b, 1e-5, f'projector loop {mode}: SR {k_}')
+            print(f'    {mode}: trace errs {["%.1e" % x for x in e]}, |d pose| {dpose:.2e}, final loss {trace[-1, 0]:.4f}')
+            out.update({f'{mode}_trace': trace, f'{mode}_w_opt': w_opt, f'{mode}_translation': translation_opt, f'{mode}_pose_base0': base,
+                        f'{mode}_pose_base': cam_predictor.base, f'{mode}_pose_A': cam_predictor.A,
+                        f'{mode}_buf_last': list(noise_bufs.values())[-1], f'{mode}_srbuf_last': list(noise_bufs2.values())[-1]})
+    finally:
+        gc.use_quaternions, gc.use_6d, gc.visualize_opt_process, gc.visualize_warp_process, hp.cam_preheat_steps = saved
+    out['w0'] = w0
+    save('projector_loop', 2e-5, **out)
+
+
+TUNER_KEYS = ('backbone.synthesis.b8.conv0.weight', 'backbone.synthesis.b16.torgb.bias', 'backbone.synthesis.b32.conv1.noise_strength',
+              'backbone.synthesis.b16.conv1.affine.weight', 'superresolution.block1.conv1.weight', 'superresolution.block0.torgb.weight',
+              'decoder.net.0.weight', 'decoder.net.2.bias')
+
+
+def gen_tuner_loop():
+    """Phase B: SingleIDCoach.train's inner loop (single_id_coach.py:64-77) with BaseCoach.calc_loss / forward (base_coach.py:101-126,
+    162-164) and compute_tv_norm (:294-305), all lifted and executed as is; PivotalTunerOracle must reproduce losses and weights."""
+    print('pivotal-tuning loop (reference loop body, lifted)')
+    from configs import global_config as gc, hyperparameters as hp
+    from criteria import l2_loss
+    from oracle import inversion_oracle as IO
+    cfg = IO.pin_config(tuner=True)                        # calc_loss hard-codes the 128^2 raw image (base_coach.py:103)
+    P = O.synth_params(cfg, seed=0)
+    target = IO.pin_target(cfg, P)[None]
+    TUNER_STEPS = IO.PIN_TUNER_STEPS
+    fw = IO.stub_feature_weights()
+    base = _parse('training/coaches/base_coach.py')
+    ns_c = dict(torch=torch, F=torch.nn.functional, hyperparameters=hp, global_config=gc, l2_loss=l2_loss, wandb=None)
+    _exec_nodes([_func(base, 'compute_tv_norm'), _func(base, 'calc_loss', 'BaseCoach'), _func(base, 'forward', 'BaseCoach')], ns_c, 'BaseCoach')
+    train = _func(_parse('training/coaches/single_id_coach.py'), 'train', 'SingleIDCoach')
+    loops = [n for n in ast.walk(train) if isinstance(n, ast.For) and 'max_pti_steps' in ast.unparse(n.iter)]
+    assert len(loops) == 1
+    node = _lifted_loop(loops[0], 'hyperparameters.max_pti_steps', "_trace.append((float(loss), float(l2_loss_val), float(loss_lpips), _psnr(generated_images['image'])))")
+    pin = IO.pin_tuner_inputs(cfg)
+    w_pivot, cam, noise_names, uniforms, noises = pin['w_pivot'], pin['cam'], pin['noise_names'], pin['uniforms'], pin['noises']
+    out = dict(target_probe=target.flatten()[::997].clone(), w_pivot=w_pivot, cam=cam)
+    saved = (hp.max_pti_steps, hp.LPIPS_value_threshold, gc.training_step)
+    try:
+        for tag, thr in (('full', -1.0), ('stop', None)):
+            if thr is None:         # a threshold that trips in the middle of the run: between the recorded LPIPS values of steps 2 and 3
+                lp = out['full_trace'][:, 2]
+                assert lp[3] < lp[2], lp
+                thr = float((lp[2] + lp[3]) / 2)
+            hp.max_pti_steps, hp.LPIPS_value_threshold = TUNER_STEPS, thr
+            G = RefComposite(cfg, P).requires_grad_(True)
+            Gs = _GSteps(G, uniforms, calls_per_step=1, randn=[[nz[nm] for nm in noise_names] for nz in noises])
+            coach = types.SimpleNamespace(G=Gs, use_wandb=False, space_regulizer=None,
+                                          lpips_loss=lambda a, b: (IO.stub_features(a, fw) - IO.stub_features(b, fw)).square().sum())
+            coach.calc_loss = types.MethodType(ns_c['calc_loss'], coach)
+            coach.forward = types.MethodType(ns_c['forward'], coach)
+            coach.optimizer = torch.optim.Adam(G.parameters(), lr=hp.pti_learning_rate)               # base_coach.py:96-99
+            ns = dict(self=coach, tqdm=lambda x: x, hyperparameters=hp, global_config=gc, w_pivot=w_pivot, freezed_cam=cam, real_images_batch=target,
+                      image_name='pin', use_ball_holder=True, log_images_counter=0, _trace=[],
+                      _psnr=lambda im: float(O.psnr_01(im.detach(), target)))
+            _exec_nodes([node], ns, 'SingleIDCoach.train loop')
+            trace = torch.tensor(ns['_trace'])
+            # the early exit `break`s before the trace statement: the number of recorded rows is the number of completed updates
+            to = IO.PivotalTunerOracle(P, cfg, target, w_pivot, cam, lr=hp.pti_learning_rate, lpips_threshold=thr)
+            otrace = []
+            for k in range(TUNER_STEPS):
+                r = to.step(*uniforms[k], noise_mode='random', noises=noises[k], early_stop=True)
+                if r['done']:
+                    break
+                otrace.append((float(r['loss']), float(r['l2']), float(r['lpips']), float(O.psnr_01(r['image'], target))))
+            otrace = torch.tensor(otrace)
+            assert otrace.shape == trace.shape, (tag, otrace.shape, trace.shape)
+            e = [check(otrace[:, j], trace[:, j], 2e-5, f'tuner loop {tag}: {nm}') for j, nm in enumerate(('loss', 'l2', 'lpips', 'psnr'))]
+            sd = dict(G.named_parameters())
+            for k_ in TUNER_KEYS:
+                rk = k_[len('superresolution.'):] if k_.startswith('superresolution.') else k_
+                check(to.P[k_], sd[rk], 1e-5, f'tuner loop {tag}: {k_}')
+                out[f'{tag}_p.{k_}'] = sd[rk]
+            print(f'    {tag}: {trace.shape[0]} updates, trace errs {["%.1e" % x for x in e]}, loss {trace[0, 0]:.4f} -> {trace[-1, 0]:.4f}')
+            out[f'{tag}_trace'] = trace
+            out[f'{tag}_thr'] = np.float64(thr)
+    finally:
+        hp.max_pti_steps, hp.LPIPS_value_threshold, gc.training_step = saved
+    save('tuner_loop', 2e-5, **out)
 
 
 def gen_inference():
@@ -751,7 +1061,8 @@ def gen_pose_net():
 if __name__ == '__main__':
     only = sys.argv[1:]
     gens = dict(bias_act=gen_bias_act, upfirdn2d=gen_upfirdn2d, filtered_lrelu=gen_filtered_lrelu, conv=gen_conv2d_resample, renderer=gen_renderer,
-                graph_small=gen_graph_small, graph_full=gen_graph_full, loss=gen_loss_glue, inference=gen_inference, pose_net=gen_pose_net)
+                graph_small=gen_graph_small, graph_full=gen_graph_full, loss=gen_loss_glue, projector_loop=gen_projector_loop, tuner_loop=gen_tuner_loop,
+                inference=gen_inference, pose_net=gen_pose_net)
     mpath = os.path.join(HERE, 'MANIFEST.json')
     if only and os.path.exists(mpath):
         MANIFEST.update(json.load(open(mpath)).get('fixtures', {}))

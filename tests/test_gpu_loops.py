@@ -1,5 +1,8 @@
-"""Inversion loops on the GPU vs their CPU oracle twins on identical inputs (BASELINE.json configs 2-4 as parity cases; the small
-generator keeps the CPU side to seconds).  Bar: final-PSNR drift after an N-step optimisation <= 1e-3 dB."""
+"""Inversion loops on the GPU vs (i) the trajectories the REFERENCE's own loop bodies produced (fixtures projector_loop / tuner_loop:
+w_projector.py:145-270 and single_id_coach.py:64-77 lifted and run by tests/golden/make_golden.py, no oracle in between) and (ii) their
+CPU oracle twins on identical inputs (BASELINE.json configs 2-4 as parity cases; the small generator keeps the CPU side to seconds).
+Bar: final-PSNR drift after an N-step optimisation <= 1e-3 dB."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -204,3 +207,94 @@ def test_pose_chain_graph_replay_matches_eager():
     assert float((runs[True][1] - runs[False][1]).abs().max()) < 1e-4
     assert float((runs[True][2] - runs[False][2]).abs().max()) < 1e-4
     assert abs(runs[True][3] - runs[False][3]) <= 1e-3 * max(1.0, abs(runs[False][3]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# HIP path vs the REFERENCE's recorded loop trajectories (no oracle arithmetic on the expected side)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _pin_generator(cfg):
+    from inv3d_amd import synthetic as S
+    G = S.make_generator(w_dim=cfg.w_dim, z_dim=cfg.z_dim, plane_res=cfg.plane_res, channel_base=cfg.channel_base, channel_max=cfg.channel_max,
+                         nrr=cfg.nrr, sr_in_res=cfg.sr_in_res, sr_widths=tuple(cfg.sr_channels), rendering_kwargs=cfg.rendering, device=DEV)
+    S.load_synthetic_weights(G, 0)
+    return G
+
+
+def _adam_close(a, b, tol, step_bound, frac=0.99):
+    err = (a - b).abs()
+    scale = max(1.0, float(b.abs().max()))
+    assert float((err <= tol * scale).float().mean()) >= frac and float(err.max()) <= step_bound, (float(err.max()), float((err <= tol * scale).float().mean()))
+
+
+@pytest.mark.parametrize('mode', ['quat', '6d', 'euler'])
+def test_projector_loop_vs_reference(golden, mode):
+    """Config C3 against the reference itself: 2 camera-preheat + 4 full steps of w_projector.project's loop body (pose estimator on the
+    [0,255] 256^2 target -> quaternion / 6-D / Euler rotation -> translation -> camera; synthesis; the reference's calc_warping_loss;
+    LPIPS-stub distance; noise regulariser over backbone + SR buffers; three Adam optimisers in the reference's order; renormalisation).
+    Per-step loss terms, final PSNR (<= 1e-3 dB), latent, pose-estimator weights, translation, noise buffers."""
+    from inv3d_amd.inversion import LatentProjector
+    d = golden('projector_loop')
+    cfg = IO.pin_config()
+    P = O.synth_params(cfg, seed=0)
+    target = IO.pin_target(cfg, P)[None]
+    pin = IO.pin_projector_inputs(cfg, P, mode)
+    G = _pin_generator(cfg)
+    lr = dict(quat=6e-7, euler=6e-6)
+    lr['6d'] = 6e-6
+    net = IO.StubPoseNet(pin['pose_base'], seed=7).to(DEV)
+    hip = LatentProjector(G, target.to(DEV), num_steps=IO.PIN_PROJ_STEPS, optimize_pose=True, use_warping_loss=True, init_noise=pin['init_noise'],
+                          start_w=pin['w0'], cam_preheat_steps=IO.PIN_PROJ_PREHEAT, pose_mode=mode, pose_net=net, w_std=IO.PIN_W_STD,
+                          translation_start=IO.PIN_TRANSLATION_START, cam_lr=lr[mode])
+    ref = torch.from_numpy(np.asarray(d[f'{mode}_trace'])).double()
+    for k in range(IO.PIN_PROJ_STEPS):
+        u1, u2 = pin['uniforms'][k]
+        h = hip.step(w_noise=pin['wns'][k], render_uniforms=(u1.to(DEV), u2.to(DEV)))
+        got = [float(h['loss']), float(h['dist']), float(h['reg']) / 1e5, float(h['warp']), _psnr(h['image'], target)]
+        for j, (nm, tol) in enumerate((('loss', 1e-4), ('dist', 1e-3), ('reg', 1e-4), ('warp', 2e-3))):
+            assert abs(got[j] - float(ref[k, j])) <= tol * max(1.0, abs(float(ref[k, j]))), (mode, k, nm, got[j], float(ref[k, j]))
+        assert abs(got[4] - float(ref[k, 4])) <= 1e-3, f'{mode} step {k}: PSNR drift {abs(got[4] - float(ref[k, 4])):.2e} dB vs the reference'
+    g = lambda k: torch.from_numpy(np.asarray(d[f'{mode}_{k}']))           # noqa: E731
+    assert float((hip.w_opt.detach().cpu() - g('w_opt')).abs().max()) < 2e-4
+    # pose parameters move by lr * (a few steps) = 4e-6 ... 4e-5: compare the MOVEMENT, relative to its own size
+    for got, key in ((net.base, 'pose_base'), (net.A, 'pose_A')):
+        mv_ref = g(key) - (pin['pose_base'].reshape(1, -1) if key == 'pose_base' else IO.StubPoseNet(pin['pose_base'], seed=7).A.detach())
+        mv_hip = got.detach().cpu() - (pin['pose_base'].reshape(1, -1) if key == 'pose_base' else IO.StubPoseNet(pin['pose_base'], seed=7).A.detach())
+        assert float((mv_hip - mv_ref).abs().max()) <= 0.05 * float(mv_ref.abs().max()) + 1e-9, (mode, key)
+    mv_ref = g('translation') - torch.tensor([IO.PIN_TRANSLATION_START])
+    mv_hip = hip.translation_opt.detach().cpu() - torch.tensor([IO.PIN_TRANSLATION_START])
+    assert float((mv_hip - mv_ref).abs().max()) <= 0.05 * float(mv_ref.abs().max()), (mode, mv_hip, mv_ref)
+    _adam_close(list(hip.noise_bufs.values())[-1].detach().cpu(), g('buf_last'), 1e-4, IO.PIN_PROJ_STEPS * 0.01)
+    assert float((list(hip.noise_bufs2.values())[-1].detach().cpu() - g('srbuf_last')).abs().max()) < 1e-5
+
+
+def test_tuner_loop_vs_reference(golden):
+    """Config C4 against the reference itself: SingleIDCoach.train's loop (BaseCoach.calc_loss: MSE 512^2 + MSE 128^2 + LPIPS-stub at both
+    sizes + depth TV; Adam 3e-4 over every generator weight; noise_mode='random') at 128^2 -> 512^2 rendering, and its LPIPS-threshold
+    exit, which leaves before the update."""
+    from inv3d_amd.inversion import PivotalTuner
+    d = golden('tuner_loop')
+    cfg = IO.pin_config(tuner=True)
+    P = O.synth_params(cfg, seed=0)
+    target = IO.pin_target(cfg, P)[None]
+    pin = IO.pin_tuner_inputs(cfg)
+    for tag in ('full', 'stop'):
+        G = _pin_generator(cfg)
+        hip = PivotalTuner(G, target.to(DEV), pin['w_pivot'].to(DEV), pin['cam'].to(DEV), lr=3e-4, lpips_threshold=float(d[f'{tag}_thr']))
+        ref = torch.from_numpy(np.asarray(d[f'{tag}_trace'])).double()
+        n = 0
+        for k in range(IO.PIN_TUNER_STEPS):
+            u1, u2 = pin['uniforms'][k]
+            h = hip.step(early_stop=True, noise_mode='random', noise_inject={a: b.to(DEV) for a, b in pin['noises'][k].items()},
+                         render_uniforms=(u1.to(DEV), u2.to(DEV)))
+            if h['done']:
+                break
+            got = [float(h['loss']), float(h['l2']), float(h['lpips']), _psnr(h['image'], target)]
+            for j in range(3):
+                assert abs(got[j] - float(ref[k, j])) <= 1e-3 * max(1.0, abs(float(ref[k, j]))), (tag, k, j, got[j], float(ref[k, j]))
+            assert abs(got[3] - float(ref[k, 3])) <= 1e-3, f'{tag} step {k}: PSNR drift {abs(got[3] - float(ref[k, 3])):.2e} dB vs the reference'
+            n += 1
+        assert n == ref.shape[0] == (IO.PIN_TUNER_STEPS if tag == 'full' else 3), (tag, n)
+        sd = G.state_dict()
+        for key in [k[len(tag) + 3:] for k in d.files if k.startswith(tag + '_p.')]:
+            e = float((sd[key].detach().cpu() - torch.from_numpy(np.asarray(d[f'{tag}_p.{key}']))).abs().max())
+            assert e <= 0.1 * 3e-4 * n + 1e-6, (tag, key, e)          # a tenth of the accumulated Adam step

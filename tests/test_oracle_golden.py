@@ -199,11 +199,103 @@ def test_mapping_and_glue(golden):
     cfg = O.small_config()
     P = O.synth_params(cfg, seed=0)
     close(O.mapping(P, cfg, t(d['map_z']), t(d['c']), 0.7, 5), t(d['map_out']), 1e-5)
+
+
+def test_loss_glue(golden):
+    """Rotation parametrisations, pose -> camera block, noise regulariser, depth TV, line-plane intersection: fixture `loss_glue` holds the
+    outputs of the reference's own functions / lifted statements (utils/camera_utils.py, w_projector.py:147-172,221-237,
+    base_coach.py:294-305, warping_loss.py:58-72).  Checked: the oracle AND the product's host-side restatements (pure torch, CPU)."""
+    from oracle import inversion_oracle as IO
+    from inv3d_amd import inversion as INV
     g = golden('loss_glue')
-    close(O.quaternion_to_rotmat(t(g['q'])), t(g['R']), 1e-6)
-    close(O.compute_tv_norm(t(g['tv_in'])), t(g['tv']), 1e-7)
-    close(O.noise_regularizer([t(g[f'reg_buf{i}']) for i in range(4)]), t(g['reg']), 1e-6)
+    for mod in (O, INV):
+        close(mod.quaternion_to_rotmat(t(g['q'])), t(g['R']), 1e-6)
+        close(mod.rot6d_to_rotmat(t(g['x6'])), t(g['R6']), 1e-6)
+        close(torch.cat([mod.pose_to_rotmat(a[None], 'euler') for a in t(g['ang'])]), t(g['Re']), 1e-6)
+        close(mod.euler_to_rotmat(torch.tensor([1.2]), torch.tensor([1.9]), torch.tensor([[0.3]])), t(g['roll_R']), 1e-6)
+        close(mod.compute_tv_norm(t(g['tv_in'])), t(g['tv']), 1e-7)
+    close(O.noise_regularizer([t(g[f'reg_buf{i}']) for i in range(6)]), t(g['reg']), 1e-6)
     close(O.lookat_cam2world(t(g['lookat_origin'])[0], torch.zeros(3)), t(g['lookat'])[0], 1e-6)
+    intr = torch.tensor([4.2647, 0, 0.5, 0, 4.2647, 0.5, 0, 0, 1]).unsqueeze(0)
+    for mode in ('quat', '6d', 'euler'):
+        for mod, p2c in ((O, IO.pose_to_cam), (INV, INV.pose_to_cam)):
+            pr, tr = t(g[f'pose_{mode}_pred']).requires_grad_(True), t(g[f'pose_{mode}_tr']).requires_grad_(True)
+            _, cam = p2c(mod.pose_to_rotmat(pr, mode), tr, intr, 2.7)
+            close(cam, t(g[f'pose_{mode}_cam']), 1e-6)
+            d_pr, d_tr = torch.autograd.grad(cam, [pr, tr], t(g[f'pose_{mode}_gcam']))
+            close(d_pr, t(g[f'pose_{mode}_dpred']), 2e-5)
+            close(d_tr, t(g[f'pose_{mode}_dtr']), 2e-5)
+    args = [t(g[k]) for k in ('lpc_n', 'lpc_p', 'lpc_d', 'lpc_o')]
+    close(IO.line_plane_collision(*args), t(g['lpc_out']), 1e-5)
+    close(INV.line_plane_intersection(*args), t(g['lpc_out']), 1e-5)
+
+
+def adam_close(a, b, tol, step_bound, frac=0.995):
+    """State after a few Adam steps (see make_golden.check_adam): an element whose gradient is rounding noise takes a full step in an
+    undetermined direction, so >= frac of the elements must agree to tol and every element to the accumulated step size."""
+    err = (torch.as_tensor(a) - torch.as_tensor(b)).abs()
+    scale = max(1.0, float(torch.as_tensor(b).abs().max()))
+    assert float((err <= tol * scale).float().mean()) >= frac and float(err.max()) <= step_bound, float(err.max())
+
+
+@pytest.mark.parametrize('mode', ['quat', '6d', 'euler'])
+def test_projector_loop_pin(golden, mode):
+    """ProjectorOracle vs the reference's own Phase-A loop body (w_projector.py:145-270, lifted and run by make_golden.py with the
+    reference's calc_warping_loss / RaySampler / generator classes): loss, feature distance, regulariser and warping loss of every
+    step (2 camera-preheat + 4 full steps), final latent, pose-estimator parameters, translation and noise buffers."""
+    from oracle import inversion_oracle as IO
+    d = golden('projector_loop')
+    cfg = IO.pin_config()
+    P = O.synth_params(cfg, seed=0)
+    target = IO.pin_target(cfg, P)
+    close(target.flatten()[::37], t(d['target_probe']), 1e-6)
+    pin = IO.pin_projector_inputs(cfg, P, mode)
+    lr = dict(quat=6e-7, euler=6e-6)
+    lr['6d'] = 6e-6                                                        # configs/hyperparameters.py cam_lr_{quat,2d,6d}
+    po = IO.ProjectorOracle(P, cfg, target[None], num_steps=IO.PIN_PROJ_STEPS, optimize_pose=True, use_warping_loss=True, init_noise=pin['init_noise'],
+                            w_start=pin['w0'], cam_preheat_steps=IO.PIN_PROJ_PREHEAT, pose_mode=mode, pose_net=IO.StubPoseNet(pin['pose_base'], seed=7),
+                            w_std=IO.PIN_W_STD, translation_start=IO.PIN_TRANSLATION_START, cam_lr=lr[mode])
+    trace = []
+    for k in range(IO.PIN_PROJ_STEPS):
+        r = po.step(*pin['uniforms'][k], w_noise=pin['wns'][k])
+        trace.append((float(r['loss']), float(r['dist']), float(r['reg']), float(r['warp']), float(O.psnr_01(r['image'], target[None]))))
+    ref = t(d[f'{mode}_trace'])
+    assert abs(trace[-1][4] - float(ref[-1, 4])) <= 1e-3              # SURVEY section 8c: final-PSNR drift <= 1e-3 dB
+    for j in range(5):
+        close(torch.tensor(trace)[:, j], ref[:, j].float(), 2e-5)
+    close(po.w_opt.detach(), t(d[f'{mode}_w_opt']), 1e-5)
+    close(po.translation_opt.detach(), t(d[f'{mode}_translation']), 1e-5)
+    close(po.pose_net.base.detach(), t(d[f'{mode}_pose_base']), 1e-6)
+    close(po.pose_net.A.detach(), t(d[f'{mode}_pose_A']), 1e-6)
+    adam_close(po.bufs[-1].detach(), t(d[f'{mode}_buf_last']), 1e-5, IO.PIN_PROJ_STEPS * 0.01)
+    close(po.bufs2[-1], t(d[f'{mode}_srbuf_last']), 1e-5)
+
+
+def test_tuner_loop_pin(golden):
+    """PivotalTunerOracle vs the reference's own Phase-B loop (single_id_coach.py:64-77 with BaseCoach.calc_loss / forward and
+    compute_tv_norm, lifted): per-step loss / MSE / LPIPS-stub, tuned weights, and the LPIPS-threshold exit before the update."""
+    from oracle import inversion_oracle as IO
+    d = golden('tuner_loop')
+    cfg = IO.pin_config(tuner=True)
+    P = O.synth_params(cfg, seed=0)
+    target = IO.pin_target(cfg, P)[None]
+    close(target.flatten()[::997], t(d['target_probe']), 1e-6)
+    pin = IO.pin_tuner_inputs(cfg)
+    for tag in ('full', 'stop'):
+        to = IO.PivotalTunerOracle(P, cfg, target, pin['w_pivot'], pin['cam'], lr=3e-4, lpips_threshold=float(d[f'{tag}_thr']))
+        trace = []
+        for k in range(IO.PIN_TUNER_STEPS):
+            r = to.step(*pin['uniforms'][k], noise_mode='random', noises=pin['noises'][k], early_stop=True)
+            if r['done']:
+                break
+            trace.append((float(r['loss']), float(r['l2']), float(r['lpips']), float(O.psnr_01(r['image'], target))))
+        ref = t(d[f'{tag}_trace']).float()
+        assert len(trace) == ref.shape[0] == (5 if tag == 'full' else 3)
+        close(torch.tensor(trace), ref, 2e-5)
+        for key in [k[len(tag) + 3:] for k in d.files if k.startswith(tag + '_p.')]:
+            close(to.P[key].detach(), t(d[f'{tag}_p.{key}']), 1e-5)
+        if tag == 'stop':
+            break
 
 
 def test_param_schema_counts():

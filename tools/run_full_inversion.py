@@ -31,7 +31,7 @@ if args.loss_net == 'real':
 
 
 coach = InversionCoach(G, first_inv_steps=args.steps_a, max_pti_steps=args.steps_b, lpips_threshold=0.0, use_graph=True, early_stop_interval=50,
-                       feature_net=fa)
+                       feature_net=fa, w_avg_samples=0)      # synthetic weights: the latent distribution is centred on 0 by construction
 if fb is not None:
     import inv3d_amd.coach as C
     _PT = C.PivotalTuner
