@@ -8,47 +8,54 @@ from ... import _lib as L
 from ... import hipops as H
 
 
+def _pair(v, what):
+    x, y = (v, v) if isinstance(v, int) else v
+    if int(x) < 1 or int(y) < 1:
+        raise ValueError(f'{what} factors must be >= 1')
+    return int(x), int(y)
+
+
 def _scaling(s):
-    if isinstance(s, int):
-        s = [s, s]
-    sx, sy = s
-    assert sx >= 1 and sy >= 1
-    return int(sx), int(sy)
+    return _pair(s, 'up / down')
 
 
 def _padding(p):
-    if isinstance(p, int):
-        p = [p, p]
-    p = [int(v) for v in p]
-    if len(p) == 2:
-        p = [p[0], p[0], p[1], p[1]]
-    return tuple(p)
+    """int | [px, py] | [px0, px1, py0, py1]  ->  (px0, px1, py0, py1)."""
+    vals = [int(p)] * 4 if isinstance(p, int) else [int(v) for v in p]
+    if len(vals) == 2:
+        vals = [vals[0], vals[0], vals[1], vals[1]]
+    if len(vals) != 4:
+        raise ValueError('padding must have 1, 2 or 4 entries')
+    return tuple(vals)
 
 
 def _filter_size(f):
+    """(width, height) of a FIR filter; None is the identity (1 tap)."""
     if f is None:
         return 1, 1
-    assert isinstance(f, torch.Tensor) and f.ndim in (1, 2)
+    if not (isinstance(f, torch.Tensor) and f.ndim in (1, 2)):
+        raise TypeError('filter must be a 1-D or 2-D tensor')
     return int(f.shape[-1]), int(f.shape[0])
 
 
 def setup_filter(f, device=torch.device('cpu'), normalize=True, flip_filter=False, gain=1, separable=None):
-    """FIR setup: 1-D filters with < 8 taps become their outer product; unit DC gain; optional flip / gain."""
-    f = torch.as_tensor(1 if f is None else f, dtype=torch.float32)
-    assert f.ndim in (0, 1, 2) and f.numel() > 0
-    if f.ndim == 0:
-        f = f[np.newaxis]
-    if separable is None:
-        separable = (f.ndim == 1 and f.numel() >= 8)
-    if f.ndim == 1 and not separable:
-        f = torch.outer(f, f)
-    assert f.ndim == (1 if separable else 2)
+    """Filter taps -> the float32 tensor the FIR ops take (reference contract: upfirdn2d.py:72-116).  A 1-D filter with fewer than 8
+    taps is expanded to its outer product unless `separable` says otherwise (longer ones stay 1-D and run as two passes); `normalize`
+    scales to unit DC gain; `gain` is split evenly over the dimensions of a separable filter (gain^(ndim/2))."""
+    taps = torch.as_tensor(1 if f is None else f, dtype=torch.float32)
+    if taps.ndim > 2 or taps.numel() == 0:
+        raise ValueError('filter must be a scalar, 1-D or 2-D and non-empty')
+    taps = taps.reshape(1) if taps.ndim == 0 else taps
+    keep_1d = (taps.ndim == 1 and taps.numel() >= 8) if separable is None else bool(separable)
+    if taps.ndim == 1 and not keep_1d:
+        taps = taps[:, None] * taps[None, :]
+    if taps.ndim != (1 if keep_1d else 2):
+        raise ValueError('separable=True needs a 1-D filter')
     if normalize:
-        f = f / f.sum()
+        taps = taps / taps.sum()
     if flip_filter:
-        f = f.flip(list(range(f.ndim)))
-    f = f * (gain ** (f.ndim / 2))
-    return f.to(device=device)
+        taps = taps.flip(tuple(range(taps.ndim)))
+    return (taps * (gain ** (taps.ndim / 2))).to(device=device)
 
 
 class _Upfirdn2d(torch.autograd.Function):
@@ -95,24 +102,28 @@ def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cu
     return _Upfirdn2d.apply(x, f, _scaling(up), _scaling(down), _padding(padding), bool(flip_filter), float(gain))
 
 
-def filter2d(x, f, padding=0, flip_filter=False, gain=1, impl='cuda'):
+def _centred(f, padding, lo_fn, hi_fn):
+    """User padding + the margins that keep the output grid centred: lo_fn / hi_fn map (taps, axis) to the low / high margin."""
     px0, px1, py0, py1 = _padding(padding)
     fw, fh = _filter_size(f)
-    p = [px0 + fw // 2, px1 + (fw - 1) // 2, py0 + fh // 2, py1 + (fh - 1) // 2]
+    return [px0 + lo_fn(fw, 0), px1 + hi_fn(fw, 0), py0 + lo_fn(fh, 1), py1 + hi_fn(fh, 1)]
+
+
+def filter2d(x, f, padding=0, flip_filter=False, gain=1, impl='cuda'):
+    """FIR-filter at the same resolution ('same' output size for padding=0; reference: upfirdn2d.py:279-311)."""
+    p = _centred(f, padding, lambda t, a: t // 2, lambda t, a: (t - 1) // 2)
     return upfirdn2d(x, f, padding=p, flip_filter=flip_filter, gain=gain, impl=impl)
 
 
 def upsample2d(x, f, up=2, padding=0, flip_filter=False, gain=1, impl='cuda'):
-    upx, upy = _scaling(up)
-    px0, px1, py0, py1 = _padding(padding)
-    fw, fh = _filter_size(f)
-    p = [px0 + (fw + upx - 1) // 2, px1 + (fw - upx) // 2, py0 + (fh + upy - 1) // 2, py1 + (fh - upy) // 2]
-    return upfirdn2d(x, f, up=up, padding=p, flip_filter=flip_filter, gain=gain * upx * upy, impl=impl)
+    """Zero-insert by `up` and FIR-filter; the gain is multiplied by up_x * up_y so that magnitudes are preserved (:315-350)."""
+    u = _scaling(up)
+    p = _centred(f, padding, lambda t, a: (t + u[a] - 1) // 2, lambda t, a: (t - u[a]) // 2)
+    return upfirdn2d(x, f, up=up, padding=p, flip_filter=flip_filter, gain=gain * u[0] * u[1], impl=impl)
 
 
 def downsample2d(x, f, down=2, padding=0, flip_filter=False, gain=1, impl='cuda'):
-    dx, dy = _scaling(down)
-    px0, px1, py0, py1 = _padding(padding)
-    fw, fh = _filter_size(f)
-    p = [px0 + (fw - dx + 1) // 2, px1 + (fw - dx) // 2, py0 + (fh - dy + 1) // 2, py1 + (fh - dy) // 2]
+    """FIR-filter and keep every `down`-th sample (:354-389)."""
+    d = _scaling(down)
+    p = _centred(f, padding, lambda t, a: (t - d[a] + 1) // 2, lambda t, a: (t - d[a]) // 2)
     return upfirdn2d(x, f, down=down, padding=p, flip_filter=flip_filter, gain=gain, impl=impl)

@@ -15,92 +15,99 @@ import torch
 
 from .. import fused
 from .. import hipops as H
+from ..reference_binding import ReferenceStateMixin
 from ..torch_utils.ops import bias_act, upfirdn2d
 
 
 def normalize_2nd_moment(x, dim=1, eps=1e-8):
-    return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
+    """x / rms(x) along `dim` (the latent / embedding normalisation in front of the mapping MLP)."""
+    return x * torch.rsqrt(torch.mean(x * x, dim=dim, keepdim=True) + eps)
 
 
-class FullyConnectedLayer(torch.nn.Module):
+class FullyConnectedLayer(ReferenceStateMixin, torch.nn.Module):
+    """y = act(x @ (W * g_w)^T + b * g_b) with the equalised-learning-rate gains g_w = lr_mul / sqrt(in), g_b = lr_mul
+    (reference: networks_stylegan2.py:95-127; state-dict keys `weight` [out,in], `bias` [out])."""
+
     def __init__(self, in_features, out_features, bias=True, activation='linear', lr_multiplier=1, bias_init=0):
         super().__init__()
-        self.in_features, self.out_features, self.activation = in_features, out_features, activation
-        self.weight = torch.nn.Parameter(torch.randn([out_features, in_features]) / lr_multiplier)
-        self.bias = torch.nn.Parameter(torch.full([out_features], np.float32(bias_init))) if bias else None
-        self.weight_gain = lr_multiplier / math.sqrt(in_features)
-        self.bias_gain = lr_multiplier
+        self.in_features, self.out_features, self.activation = int(in_features), int(out_features), activation
+        self.weight_gain, self.bias_gain = lr_multiplier / math.sqrt(in_features), lr_multiplier
+        self.weight = torch.nn.Parameter(torch.randn(out_features, in_features) * (1.0 / lr_multiplier))
+        self.bias = torch.nn.Parameter(torch.full((out_features,), float(bias_init), dtype=torch.float32)) if bias else None
 
     def forward(self, x):
-        w = self.weight.to(x.dtype) * self.weight_gain
-        b = self.bias
-        if b is not None:
-            b = b.to(x.dtype)
-            if self.bias_gain != 1:
-                b = b * self.bias_gain
-        if self.activation == 'linear' and b is not None:
-            return torch.addmm(b.unsqueeze(0), x, w.t())          # tiny library GEMM ([N,512] x [512,C])
-        return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
+        # off the per-layer hot path (the 26 style affines and the decoder run inside fused kernels): one small library GEMM
+        bias = None if self.bias is None else self.bias.to(x.dtype) * self.bias_gain
+        y = torch.nn.functional.linear(x, self.weight.to(x.dtype) * self.weight_gain, bias)
+        return y if self.activation == 'linear' else bias_act.bias_act(y, None, act=self.activation)
 
     def extra_repr(self):
         return f'in_features={self.in_features:d}, out_features={self.out_features:d}, activation={self.activation:s}'
 
 
-class MappingNetwork(torch.nn.Module):
+class MappingNetwork(ReferenceStateMixin, torch.nn.Module):
+    """z (+ embedded c) -> w, broadcast to num_ws rows, truncated towards the running mean `w_avg`
+    (reference: networks_stylegan2.py:190-268; children `embed`, `fc0..fc{L-1}`, buffer `w_avg`)."""
+
     def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=8, embed_features=None, layer_features=None, activation='lrelu',
                  lr_multiplier=0.01, w_avg_beta=0.998):
         super().__init__()
         self.z_dim, self.c_dim, self.w_dim, self.num_ws, self.num_layers, self.w_avg_beta = z_dim, c_dim, w_dim, num_ws, num_layers, w_avg_beta
-        embed_features = w_dim if embed_features is None else embed_features
-        if c_dim == 0:
-            embed_features = 0
-        layer_features = w_dim if layer_features is None else layer_features
-        feats = [z_dim + embed_features] + [layer_features] * (num_layers - 1) + [w_dim]
+        embed = 0 if c_dim == 0 else (embed_features if embed_features is not None else w_dim)
+        hidden = layer_features if layer_features is not None else w_dim
         if c_dim > 0:
-            self.embed = FullyConnectedLayer(c_dim, embed_features)
-        for i in range(num_layers):
-            setattr(self, f'fc{i}', FullyConnectedLayer(feats[i], feats[i + 1], activation=activation, lr_multiplier=lr_multiplier))
+            self.embed = FullyConnectedLayer(c_dim, embed)
+        widths = [z_dim + embed] + [hidden] * (num_layers - 1) + [w_dim]
+        for i, (fan_in, fan_out) in enumerate(zip(widths[:-1], widths[1:])):
+            self.add_module(f'fc{i}', FullyConnectedLayer(fan_in, fan_out, activation=activation, lr_multiplier=lr_multiplier))
         if num_ws is not None and w_avg_beta is not None:
-            self.register_buffer('w_avg', torch.zeros([w_dim]))
+            self.register_buffer('w_avg', torch.zeros(w_dim))
+
+    def _truncate(self, w, psi):
+        return self.w_avg + (w - self.w_avg) * psi                      # lerp(w_avg, w, psi)
 
     def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False):
-        x = None
+        parts = []
         if self.z_dim > 0:
-            x = normalize_2nd_moment(z.to(torch.float32))
+            parts.append(normalize_2nd_moment(z.float()))
         if self.c_dim > 0:
-            y = normalize_2nd_moment(self.embed(c.to(torch.float32)))
-            x = torch.cat([x, y], dim=1) if x is not None else y
+            parts.append(normalize_2nd_moment(self.embed(c.float())))
+        w = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
         for i in range(self.num_layers):
-            x = getattr(self, f'fc{i}')(x)
-        if update_emas and self.w_avg_beta is not None:
-            self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+            w = self._modules[f'fc{i}'](w)
+        if update_emas and self.w_avg_beta is not None:                  # exponential moving average of the batch mean
+            self.w_avg.copy_(self.w_avg * self.w_avg_beta + w.detach().mean(0) * (1 - self.w_avg_beta))
         if self.num_ws is not None:
-            x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
-        if truncation_psi != 1:
-            if self.num_ws is None or truncation_cutoff is None:
-                x = self.w_avg.lerp(x, truncation_psi)
-            else:
-                x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
-        return x
+            w = w[:, None, :].expand(-1, self.num_ws, -1).contiguous()
+        if truncation_psi == 1:
+            return w
+        if self.num_ws is None or truncation_cutoff is None:
+            return self._truncate(w, truncation_psi)
+        head = self._truncate(w[:, :truncation_cutoff], truncation_psi)
+        return torch.cat([head, w[:, truncation_cutoff:]], dim=1)
 
 
-class SynthesisLayer(torch.nn.Module):
+class SynthesisLayer(ReferenceStateMixin, torch.nn.Module):
+    """Modulated 3x3 conv (optionally up-2) + noise + bias + lrelu as ONE fused op (reference: networks_stylegan2.py:272-335).
+    State: weight [O,I,3,3], bias [O], affine.{weight,bias} (bias initialised to 1), noise_strength [], buffers noise_const [r,r] and
+    resample_filter [4,4]."""
+
     def __init__(self, in_channels, out_channels, w_dim, resolution, kernel_size=3, up=1, use_noise=True, activation='lrelu',
                  resample_filter=[1, 3, 3, 1], conv_clamp=None, channels_last=False):
         super().__init__()
-        assert activation == 'lrelu' and kernel_size == 3 and up in (1, 2), 'fused layer op covers the EG3D generator configuration'
-        assert list(resample_filter) == [1, 3, 3, 1]
-        self.in_channels, self.out_channels, self.w_dim, self.resolution, self.up = in_channels, out_channels, w_dim, resolution, up
-        self.use_noise, self.activation, self.conv_clamp = use_noise, activation, conv_clamp
-        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
-        self.padding = kernel_size // 2
+        if activation != 'lrelu' or kernel_size != 3 or up not in (1, 2) or list(resample_filter) != [1, 3, 3, 1]:
+            raise NotImplementedError('the fused layer op covers the EG3D generator configuration: 3x3, lrelu, up in {1,2}, [1,3,3,1] FIR')
+        self.in_channels, self.out_channels, self.w_dim, self.resolution = in_channels, out_channels, w_dim, resolution
+        self.up, self.use_noise, self.activation, self.conv_clamp = up, use_noise, activation, conv_clamp
+        self.padding = 1
         self.act_gain = bias_act.activation_funcs[activation].def_gain
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
         self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
-        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]))
+        self.weight = torch.nn.Parameter(torch.randn(out_channels, in_channels, 3, 3))
+        self.bias = torch.nn.Parameter(torch.zeros(out_channels))
         if use_noise:
-            self.register_buffer('noise_const', torch.randn([resolution, resolution]))
-            self.noise_strength = torch.nn.Parameter(torch.zeros([]))
-        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+            self.noise_strength = torch.nn.Parameter(torch.zeros(()))
+            self.register_buffer('noise_const', torch.randn(resolution, resolution))
         self._cache = fused.WeightCache()
 
     def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, noise_inject=None, styles=None, demod=None):
@@ -124,15 +131,18 @@ class SynthesisLayer(torch.nn.Module):
                f'resolution={self.resolution:d}, up={self.up}, activation={self.activation:s}'
 
 
-class ToRGBLayer(torch.nn.Module):
+class ToRGBLayer(ReferenceStateMixin, torch.nn.Module):
+    """Modulated 1x1 conv without demodulation + bias, accumulated onto the skip image (reference: networks_stylegan2.py:338-359)."""
+
     def __init__(self, in_channels, out_channels, w_dim, kernel_size=1, conv_clamp=None, channels_last=False):
         super().__init__()
-        assert kernel_size == 1
+        if kernel_size != 1:
+            raise NotImplementedError('toRGB layers are 1x1')
         self.in_channels, self.out_channels, self.w_dim, self.conv_clamp = in_channels, out_channels, w_dim, conv_clamp
+        self.weight_gain = in_channels ** -0.5                 # folded into the styles (networks_stylegan2.py:354)
         self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
-        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]))
-        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
-        self.weight_gain = 1 / math.sqrt(in_channels * (kernel_size ** 2))
+        self.weight = torch.nn.Parameter(torch.randn(out_channels, in_channels, 1, 1))
+        self.bias = torch.nn.Parameter(torch.zeros(out_channels))
         self._cache = fused.WeightCache()
 
     def forward(self, x, w, fused_modconv=True, skip=None, styles=None, passthrough=False):
@@ -148,27 +158,28 @@ def _pad4(c):
     return (c + 3) // 4 * 4
 
 
-class SynthesisBlock(torch.nn.Module):
+class SynthesisBlock(ReferenceStateMixin, torch.nn.Module):
+    """One resolution of the 'skip' architecture: [conv0 (up-2)] -> conv1 -> toRGB accumulated onto the up-sampled skip image; the 4^2
+    block starts from the learned constant (reference: networks_stylegan2.py:362-465)."""
+
     def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, is_last, architecture='skip',
                  resample_filter=[1, 3, 3, 1], conv_clamp=256, use_fp16=False, fp16_channels_last=False, fused_modconv_default=True,
                  **layer_kwargs):
-        assert architecture == 'skip', "EG3D generators use the 'skip' architecture"
+        if architecture != 'skip':
+            raise NotImplementedError("EG3D generators use the 'skip' architecture")
         super().__init__()
         self.in_channels, self.w_dim, self.resolution, self.img_channels, self.is_last = in_channels, w_dim, resolution, img_channels, is_last
         self.architecture, self.use_fp16, self.fused_modconv_default = architecture, use_fp16, fused_modconv_default
         self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
-        self.num_conv = 0
-        self.num_torgb = 0
-        if in_channels == 0:
-            self.const = torch.nn.Parameter(torch.randn([out_channels, resolution, resolution]))
-        if in_channels != 0:
-            self.conv0 = SynthesisLayer(in_channels, out_channels, w_dim=w_dim, resolution=resolution, up=2,
-                                        resample_filter=resample_filter, conv_clamp=conv_clamp, **layer_kwargs)
-            self.num_conv += 1
-        self.conv1 = SynthesisLayer(out_channels, out_channels, w_dim=w_dim, resolution=resolution, conv_clamp=conv_clamp, **layer_kwargs)
-        self.num_conv += 1
+        first = in_channels == 0
+        common = dict(w_dim=w_dim, resolution=resolution, conv_clamp=conv_clamp, **layer_kwargs)
+        if first:
+            self.const = torch.nn.Parameter(torch.randn(out_channels, resolution, resolution))
+        else:
+            self.conv0 = SynthesisLayer(in_channels, out_channels, up=2, resample_filter=resample_filter, **common)
+        self.conv1 = SynthesisLayer(out_channels, out_channels, **common)
         self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp)
-        self.num_torgb += 1
+        self.num_conv, self.num_torgb = (1 if first else 2), 1
 
     def affine_entries(self, w_idx):
         """(affine module, ws row, post scale) of this block's modulated layers in evaluation order (for fused.style_bank)."""
@@ -202,23 +213,25 @@ class SynthesisBlock(torch.nn.Module):
         return x, img
 
 
-class SynthesisNetwork(torch.nn.Module):
+class SynthesisNetwork(ReferenceStateMixin, torch.nn.Module):
+    """Blocks b4 ... b{img_resolution}; width(res) = min(channel_base / res, channel_max); num_ws = number of conv layers + the last
+    block's toRGB (reference: networks_stylegan2.py:468-522)."""
+
     def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512, num_fp16_res=4, **block_kwargs):
-        assert img_resolution >= 4 and img_resolution & (img_resolution - 1) == 0
+        if img_resolution < 4 or img_resolution & (img_resolution - 1):
+            raise ValueError('img_resolution must be a power of two >= 4')
         super().__init__()
         self.w_dim, self.img_resolution, self.img_channels, self.num_fp16_res = w_dim, img_resolution, img_channels, num_fp16_res
-        self.img_resolution_log2 = int(np.log2(img_resolution))
-        self.block_resolutions = [2 ** i for i in range(2, self.img_resolution_log2 + 1)]
-        channels = {res: min(channel_base // res, channel_max) for res in self.block_resolutions}
+        self.img_resolution_log2 = img_resolution.bit_length() - 1
+        self.block_resolutions = [4 << i for i in range(self.img_resolution_log2 - 1)]
+        width = lambda r: min(channel_base // r, channel_max)               # noqa: E731
         self.num_ws = 0
         for res in self.block_resolutions:
-            cin = channels[res // 2] if res > 4 else 0
-            block = SynthesisBlock(cin, channels[res], w_dim=w_dim, resolution=res, img_channels=img_channels,
-                                   is_last=(res == img_resolution), use_fp16=False, **block_kwargs)
-            self.num_ws += block.num_conv
-            if res == img_resolution:
-                self.num_ws += block.num_torgb
-            setattr(self, f'b{res}', block)
+            last = res == img_resolution
+            block = SynthesisBlock(0 if res == 4 else width(res // 2), width(res), w_dim=w_dim, resolution=res, img_channels=img_channels,
+                                   is_last=last, use_fp16=False, **block_kwargs)
+            self.add_module(f'b{res}', block)
+            self.num_ws += block.num_conv + (block.num_torgb if last else 0)
 
     def forward(self, ws, noise_inject=None, _prefix='backbone.synthesis', **block_kwargs):
         ws = ws.to(torch.float32)
@@ -243,7 +256,9 @@ class SynthesisNetwork(torch.nn.Module):
         return img if img.shape[1] == self.img_channels else img[:, :self.img_channels]
 
 
-class Generator(torch.nn.Module):
+class Generator(ReferenceStateMixin, torch.nn.Module):
+    """mapping + synthesis (reference: networks_stylegan2.py:525-553); EG3D uses it as the tri-plane backbone."""
+
     def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs={}, **synthesis_kwargs):
         super().__init__()
         self.z_dim, self.c_dim, self.w_dim, self.img_resolution, self.img_channels = z_dim, c_dim, w_dim, img_resolution, img_channels

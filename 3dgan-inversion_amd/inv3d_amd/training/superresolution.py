@@ -5,10 +5,11 @@ import torch
 
 from .. import fused
 from .. import hipops as H
+from ..reference_binding import ReferenceStateMixin
 from .networks_stylegan2 import SynthesisBlock
 
 
-class SuperresolutionHybrid8XDC(torch.nn.Module):
+class SuperresolutionHybrid8XDC(ReferenceStateMixin, torch.nn.Module):
     def __init__(self, channels, img_resolution, sr_num_fp16_res, sr_antialias, num_fp16_res=4, conv_clamp=None, channel_base=None,
                  channel_max=None, sr_widths=(256, 128), input_resolution=128, **block_kwargs):
         super().__init__()

@@ -7,6 +7,7 @@ scripts/run_pti.py-style callers, the projector and the coaches can use it uncha
 deterministic runs: render_uniforms=(u1,u2), noise_inject={layer-name: [N,1,res,res]}."""
 import torch
 
+from ..reference_binding import ReferenceStateMixin
 from .networks_stylegan2 import Generator as StyleGAN2Backbone, FullyConnectedLayer
 from .superresolution import SuperresolutionHybrid8XDC
 from .volumetric_rendering.ray_sampler import RaySampler
@@ -15,90 +16,100 @@ from .volumetric_rendering.renderer import ImportanceRenderer
 _SR_MODULES = {'training.superresolution.SuperresolutionHybrid8XDC': SuperresolutionHybrid8XDC}
 
 
-class OSGDecoder(torch.nn.Module):
+class OSGDecoder(ReferenceStateMixin, torch.nn.Module):
+    """Tri-plane feature decoder 32 -> 64 -(softplus)-> 1 + 32 (reference: training/triplane.py:116-136; state `net.0`, `net.2`).
+    On the hot path these four tensors are consumed inside the render kernels; forward() is the stand-alone form."""
+
     def __init__(self, n_features, options):
         super().__init__()
         self.hidden_dim = 64
-        lr = options['decoder_lr_mul']
-        self.net = torch.nn.Sequential(FullyConnectedLayer(n_features, self.hidden_dim, lr_multiplier=lr), torch.nn.Softplus(),
-                                       FullyConnectedLayer(self.hidden_dim, 1 + options['decoder_output_dim'], lr_multiplier=lr))
+        fc = lambda i, o: FullyConnectedLayer(i, o, lr_multiplier=options['decoder_lr_mul'])        # noqa: E731
+        self.net = torch.nn.Sequential(fc(n_features, self.hidden_dim), torch.nn.Softplus(), fc(self.hidden_dim, 1 + options['decoder_output_dim']))
 
     def forward(self, sampled_features, ray_directions):
-        """Stand-alone decode of pre-sampled features [N,3,M,C] (API parity; the hot path decodes inside the render kernel)."""
-        x = sampled_features.mean(1)
-        N, M, C = x.shape
-        x = self.net(x.reshape(N * M, C)).view(N, M, -1)
-        return {'rgb': torch.sigmoid(x[..., 1:]) * (1 + 2 * 0.001) - 0.001, 'sigma': x[..., 0:1]}
+        """[N,3,M,C] plane features -> {'rgb' [N,M,32] in (-0.001, 1.001), 'sigma' [N,M,1]} (mean over the three planes first)."""
+        feats = sampled_features.mean(dim=1)
+        out = self.net(feats.flatten(0, 1)).unflatten(0, feats.shape[:2])
+        sigma, colour = out[..., :1], out[..., 1:]
+        return {'rgb': torch.sigmoid(colour) * 1.002 - 0.001, 'sigma': sigma}
 
 
-class TriPlaneGenerator(torch.nn.Module):
+class TriPlaneGenerator(ReferenceStateMixin, torch.nn.Module):
+    """backbone (StyleGAN2 -> 3 x 32 x 256^2 planes) -> renderer (ray sampling + two-pass volume rendering with the OSG decoder) ->
+    super-resolution head.  Constructor arguments, children and state-dict keys as the reference class (training/triplane.py:18-46)."""
+
     def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, sr_num_fp16_res=0, mapping_kwargs={}, rendering_kwargs={},
                  sr_kwargs={}, plane_resolution=256, **synthesis_kwargs):
         super().__init__()
         self.z_dim, self.c_dim, self.w_dim, self.img_resolution, self.img_channels = z_dim, c_dim, w_dim, img_resolution, img_channels
+        self.rendering_kwargs = rendering_kwargs
+        self.neural_rendering_resolution = 64
+        self._last_planes = None
+        sr_name = rendering_kwargs.get('superresolution_module', 'training.superresolution.SuperresolutionHybrid8XDC')
+        if sr_name not in _SR_MODULES:
+            raise NotImplementedError(f'superresolution module {sr_name} (only the 512^2 head is on the inversion path)')
+        synthesis_kwargs = {k: v for k, v in synthesis_kwargs.items() if k != 'num_fp16_res'}          # the backbone runs in fp32 (:40)
         self.renderer = ImportanceRenderer()
         self.ray_sampler = RaySampler()
-        synthesis_kwargs.pop('num_fp16_res', None)
-        self.backbone = StyleGAN2Backbone(z_dim, c_dim, w_dim, img_resolution=plane_resolution, img_channels=32 * 3,
-                                          mapping_kwargs=mapping_kwargs, num_fp16_res=0, **synthesis_kwargs)
-        sr_cls = _SR_MODULES.get(rendering_kwargs.get('superresolution_module', 'training.superresolution.SuperresolutionHybrid8XDC'))
-        if sr_cls is None:
-            raise NotImplementedError(f"superresolution module {rendering_kwargs.get('superresolution_module')} (only the 512^2 head is on the inversion path)")
-        sr_kwargs = dict(sr_kwargs)          # the SR blocks take 512-d latents unless told otherwise (superresolution.py:268-275 hard-codes w_dim=512)
-        self.superresolution = sr_cls(channels=32, img_resolution=img_resolution, sr_num_fp16_res=sr_num_fp16_res,
-                                      sr_antialias=rendering_kwargs.get('sr_antialias', True), **sr_kwargs)
+        self.backbone = StyleGAN2Backbone(z_dim, c_dim, w_dim, img_resolution=plane_resolution, img_channels=96, mapping_kwargs=mapping_kwargs,
+                                          num_fp16_res=0, **synthesis_kwargs)
+        self.superresolution = _SR_MODULES[sr_name](channels=32, img_resolution=img_resolution, sr_num_fp16_res=sr_num_fp16_res,
+                                                    sr_antialias=rendering_kwargs.get('sr_antialias', True), **dict(sr_kwargs))
         self.decoder = OSGDecoder(32, {'decoder_lr_mul': rendering_kwargs.get('decoder_lr_mul', 1), 'decoder_output_dim': 32})
-        self.neural_rendering_resolution = 64
-        self.rendering_kwargs = rendering_kwargs
-        self._last_planes = None
 
+    # ---- latent side ---------------------------------------------------------------------------------------------------------
     def mapping(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False):
-        if self.rendering_kwargs['c_gen_conditioning_zero']:
-            c = torch.zeros_like(c)
-        return self.backbone.mapping(z, c * self.rendering_kwargs.get('c_scale', 0), truncation_psi=truncation_psi,
-                                     truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        """Camera-conditioned mapping: c is scaled by rendering_kwargs['c_scale'] (zeroed with c_gen_conditioning_zero) (triplane.py:48-51)."""
+        rk = self.rendering_kwargs
+        cond = torch.zeros_like(c) if rk['c_gen_conditioning_zero'] else c
+        return self.backbone.mapping(z, cond * rk.get('c_scale', 0), truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff,
+                                     update_emas=update_emas)
 
-    def synthesis(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False, use_cached_backbone=False,
-                  render_uniforms=None, noise_inject=None, **synthesis_kwargs):
-        cam2world = c[:, :16].view(-1, 4, 4)
-        intrinsics = c[:, 16:25].view(-1, 3, 3)
-        if neural_rendering_resolution is None:
-            neural_rendering_resolution = self.neural_rendering_resolution
-        else:
-            self.neural_rendering_resolution = neural_rendering_resolution
-        synthesis_kwargs.pop('force_fp32', None)          # always fp32 here
-        ray_origins, ray_directions = self.ray_sampler(cam2world, intrinsics, neural_rendering_resolution)
-        N = ray_origins.shape[0]
-        if use_cached_backbone and self._last_planes is not None:
+    def _planes(self, ws, use_cached, cache, update_emas, noise_inject, kwargs):
+        if use_cached and self._last_planes is not None:
             planes = self._last_planes
         else:
-            planes = self.backbone.synthesis(ws, update_emas=update_emas, noise_inject=noise_inject, **synthesis_kwargs)
-        if cache_backbone:
+            planes = self.backbone.synthesis(ws, update_emas=update_emas, noise_inject=noise_inject, **kwargs)
+        if cache:
             self._last_planes = planes
+        return planes
+
+    # ---- image side ----------------------------------------------------------------------------------------------------------
+    def synthesis(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False, use_cached_backbone=False,
+                  render_uniforms=None, noise_inject=None, **synthesis_kwargs):
+        """ws [N,num_ws,w_dim], c [N,25] = (cam2world 4x4, intrinsics 3x3) -> {'image','image_raw','image_depth'} (triplane.py:53-90).
+        `force_fp32` is accepted and ignored (everything is fp32-equivalent here); `render_uniforms=(u1,u2)` / `noise_inject` pin the
+        stratified-sampling / per-layer noise draws for deterministic runs."""
+        if neural_rendering_resolution is not None:
+            self.neural_rendering_resolution = neural_rendering_resolution                           # sticky, as in the reference (:58-61)
+        res = self.neural_rendering_resolution
+        kwargs = {k: v for k, v in synthesis_kwargs.items() if k != 'force_fp32'}
+        origins, directions = self.ray_sampler(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), res)
+        planes = self._planes(ws, use_cached_backbone, cache_backbone, update_emas, noise_inject, kwargs)
         if render_uniforms is not None:
             self.renderer.set_uniforms(*render_uniforms)
-        feat, depth, _ = self.renderer(planes, self.decoder, ray_origins, ray_directions, self.rendering_kwargs)
-        Hh = Ww = self.neural_rendering_resolution
-        # [N, H*W, 32] is already the channels_last image of [N,32,H,W]
-        feature_image = feat.view(N, Hh, Ww, feat.shape[-1]).permute(0, 3, 1, 2)
-        depth_image = depth.permute(0, 2, 1).reshape(N, 1, Hh, Ww)
-        rgb_image = feature_image[:, :3].contiguous()
-        sr_kwargs = {k: v for k, v in synthesis_kwargs.items() if k != 'noise_mode'}
-        sr_image = self.superresolution(rgb_image, feature_image, ws, noise_mode=self.rendering_kwargs['superresolution_noise_mode'],
-                                        noise_inject=noise_inject, **sr_kwargs)
-        return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image}
-
-    def sample(self, coordinates, directions, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
-        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
-        return self.sample_mixed(coordinates, directions, ws, update_emas=update_emas, **synthesis_kwargs)
+        feat, depth, _ = self.renderer(planes, self.decoder, origins, directions, self.rendering_kwargs)
+        n = origins.shape[0]
+        features = feat.view(n, res, res, feat.shape[-1]).permute(0, 3, 1, 2)          # [N, H*W, 32] IS the channels_last image: zero-copy
+        rgb = features[:, :3].contiguous()
+        image = self.superresolution(rgb, features, ws, noise_mode=self.rendering_kwargs['superresolution_noise_mode'], noise_inject=noise_inject,
+                                     **{k: v for k, v in kwargs.items() if k != 'noise_mode'})
+        return {'image': image, 'image_raw': rgb, 'image_depth': depth.transpose(1, 2).reshape(n, 1, res, res)}
 
     def sample_mixed(self, coordinates, directions, ws, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
-        synthesis_kwargs.pop('force_fp32', None)
-        planes = self.backbone.synthesis(ws, update_emas=update_emas, **synthesis_kwargs)
+        """{'rgb','sigma'} of the field at arbitrary points for given ws (triplane.py:99-103; density-grid extraction)."""
+        kwargs = {k: v for k, v in synthesis_kwargs.items() if k != 'force_fp32'}
+        planes = self._planes(ws, False, False, update_emas, None, kwargs)
         return self.renderer.run_model(planes, self.decoder, coordinates, directions, self.rendering_kwargs)
+
+    def sample(self, coordinates, directions, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
+        """sample_mixed on mapped latents (triplane.py:92-97)."""
+        return self.sample_mixed(coordinates, directions, self.mapping(z, c, truncation_psi, truncation_cutoff, update_emas),
+                                 update_emas=update_emas, **synthesis_kwargs)
 
     def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, neural_rendering_resolution=None, update_emas=False,
                 cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
-        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
-        return self.synthesis(ws, c, update_emas=update_emas, neural_rendering_resolution=neural_rendering_resolution,
-                              cache_backbone=cache_backbone, use_cached_backbone=use_cached_backbone, **synthesis_kwargs)
+        """synthesis on mapped latents (triplane.py:105-108)."""
+        return self.synthesis(self.mapping(z, c, truncation_psi, truncation_cutoff, update_emas), c, update_emas=update_emas,
+                              neural_rendering_resolution=neural_rendering_resolution, cache_backbone=cache_backbone,
+                              use_cached_backbone=use_cached_backbone, **synthesis_kwargs)

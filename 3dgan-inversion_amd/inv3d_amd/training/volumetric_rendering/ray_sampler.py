@@ -12,12 +12,9 @@ class RaySampler(torch.nn.Module):
         return fused.RayGenFn.apply(cam2world_matrix, intrinsics, int(resolution))
 
     def calculate_xyz_of_depth(self, ray_origin, ray_dirs, depth):
-        """xyz1 [4, res*res] of the surface points o + d * depth (batch 1)."""
+        """Surface points of one view, homogeneous: origins / directions [1,res^2,3] (or [3,res,res]) and depth [1,1,res,res] ->
+        [4, res^2] = (o + d * depth ; 1), pixel-major (reference: ray_sampler.py:75-93; the warping loss's caller, warping_loss.py:20)."""
         res = depth.shape[-1]
-        if ray_origin.shape[0] == 1 and ray_origin.shape[1] == res ** 2:
-            ray_origin = ray_origin.squeeze(0).reshape(res, res, 3).permute(2, 0, 1)
-        if ray_dirs.shape[0] == 1 and ray_dirs.shape[1] == res ** 2:
-            ray_dirs = ray_dirs.squeeze(0).reshape(res, res, 3).permute(2, 0, 1)
-        xyz = ray_origin + ray_dirs * depth.squeeze(0)
-        ones = torch.ones(1, res, res, device=xyz.device)
-        return torch.cat([xyz, ones], dim=0).reshape(4, res * res)
+        flat = lambda v: v.reshape(res * res, 3) if v.shape[-1] == 3 else v.reshape(3, res * res).t()       # noqa: E731
+        xyz = flat(ray_origin) + flat(ray_dirs) * depth.reshape(res * res, 1)
+        return torch.cat([xyz, xyz.new_ones(res * res, 1)], dim=1).t()

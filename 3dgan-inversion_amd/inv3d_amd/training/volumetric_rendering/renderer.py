@@ -2,6 +2,8 @@
 fused per-ray gfx950 kernel: forward(planes, decoder, ray_origins, ray_directions, rendering_options) ->
 (rgb [N,M,32], depth [N,M,1], weights_sum [N,M,1]);  run_model(planes, decoder, coords, dirs, options) -> {'rgb','sigma'}.
 
+Ray marching (reference ray_marcher.py:25-57, MipRayMarcher2) happens inside the render kernels; there is no stand-alone marcher module.
+
 Randomness: the stratified jitter / importance uniforms are drawn with torch.rand on the device unless the caller
 injects them (`set_uniforms`, used by parity tests and by deterministic optimisation runs)."""
 import torch
@@ -9,7 +11,6 @@ import torch
 from ... import fused
 from ... import hipops as H
 from . import math_utils
-from .ray_marcher import MipRayMarcher2
 
 
 def generate_planes():
@@ -29,7 +30,6 @@ def _planes_cl(planes):
 class ImportanceRenderer(torch.nn.Module):
     def __init__(self):
         super().__init__()
-        self.ray_marcher = MipRayMarcher2()
         self.plane_axes = generate_planes()
         self._u = None
 

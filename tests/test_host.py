@@ -139,3 +139,59 @@ def test_zero_arena_and_memo_host_logic():
     cache = fused.WeightCache()
     cache._c = {'k': (w2.data_ptr(), w2._version, tuple(w2.shape), H.WEIGHTS_EPOCH - 1)}
     assert cache._c['k'] != (w2.data_ptr(), w2._version, tuple(w2.shape), H.WEIGHTS_EPOCH)     # an epoch bump invalidates packed conv weights too
+
+
+def test_reference_binding_against_checkout():
+    """INTEGRATION.md section 1 executed against the real checkout (build container only): tools/check_reference_binding.py binds the
+    L1 / L2 modules, runs the reference's own calc_warping_loss into this package's G.synthesis, resolves every attribute chain the
+    reference's callers apply to a generator, and unpickles a reference-class generator (embedded NVIDIA source) into this package's
+    classes through the reference's persistence.import_hook."""
+    import subprocess
+    import sys
+    if not os.path.isdir('/root/reference/training'):
+        pytest.skip('needs the reference checkout (/root/reference), which does not travel')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_reference_binding.py')], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'REFERENCE BINDING OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_install_as_reference_modules_on_a_stand_in_checkout(tmp_path):
+    """The binding mechanism itself, runnable anywhere: a directory with the checkout's package skeleton (training/, torch_utils/ops/,
+    training/volumetric_rendering/, a persistence module with import_hook, one caller module) is put on sys.path; after
+    install_as_reference_modules() the hot-path names are this package's module OBJECTS, the caller module stays the checkout's, and
+    putting .../inv3d_amd itself on sys.path (the broken recipe of round 1) is refused with a clear message."""
+    import subprocess
+    import sys
+    for d in ('training/volumetric_rendering', 'training/coaches', 'torch_utils/ops'):
+        (tmp_path / d).mkdir(parents=True)
+    for d in ('training', 'training/volumetric_rendering', 'training/coaches', 'torch_utils', 'torch_utils/ops'):
+        (tmp_path / d / '__init__.py').write_text('')
+    (tmp_path / 'torch_utils' / 'persistence.py').write_text('_hooks = []\ndef import_hook(h):\n    _hooks.append(h)\n')
+    (tmp_path / 'training' / 'coaches' / 'base_coach.py').write_text(
+        'from training.triplane import TriPlaneGenerator\nfrom torch_utils.ops import bias_act, conv2d_gradfix\nWHO = "checkout"\n')
+    code = f"""
+import sys
+sys.path.insert(0, {str(tmp_path)!r}); sys.path.insert(0, {os.path.join(ROOT, '3dgan-inversion_amd')!r})
+import inv3d_amd
+inv3d_amd.install_as_reference_modules()
+import training.coaches.base_coach as bc, training, torch_utils.ops, torch_utils.persistence as P
+import inv3d_amd.training.triplane as T, inv3d_amd.torch_utils.ops.conv2d_gradfix as CG
+assert bc.WHO == 'checkout' and bc.__file__.startswith({str(tmp_path)!r})
+assert bc.TriPlaneGenerator is T.TriPlaneGenerator and training.triplane is T and sys.modules['training.triplane'] is T
+assert bc.conv2d_gradfix is CG and torch_utils.ops.conv2d_gradfix is CG
+assert len(P._hooks) == 1
+inv3d_amd.install_as_reference_modules(); assert len(P._hooks) == 1      # idempotent
+print('BOUND')
+"""
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'BOUND' in r.stdout, r.stdout + r.stderr[-3000:]
+    bad = f"""
+import sys
+sys.path.insert(0, {os.path.join(ROOT, '3dgan-inversion_amd')!r}); sys.path.insert(0, {os.path.join(ROOT, '3dgan-inversion_amd', 'inv3d_amd')!r})
+import inv3d_amd
+try:
+    inv3d_amd.install_as_reference_modules()
+except ImportError as e:
+    print('REFUSED', e)
+"""
+    r = subprocess.run([sys.executable, '-c', bad], capture_output=True, text=True, timeout=300)
+    assert 'REFUSED' in r.stdout, r.stdout + r.stderr[-3000:]
