@@ -14,6 +14,24 @@
 
 static inline int eg3d_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+#ifdef __cplusplus
+#include <atomic>
+// Opt a kernel into more than 64 KB of dynamic LDS.  The attribute is a property of the (function, device) pair, so the "already
+// done" memo is one bit per device ordinal: correct with several devices in one process and from several host threads (a lost race
+// only repeats the idempotent call).  Returns 0 or a HIP error code.
+static inline int eg3d_ensure_dynamic_lds(const void* fn, int bytes, std::atomic<uint64_t>& done_mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (dev < 64 && (done_mask.load(std::memory_order_acquire) & bit)) return 0;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 64) done_mask.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
+#endif
+
 // ---- activations (semantics of bias_act: forward, first and second derivative keyed on the output) ----------
 __device__ __forceinline__ float eg3d_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float eg3d_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }

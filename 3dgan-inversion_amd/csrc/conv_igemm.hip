@@ -574,18 +574,14 @@ bool conv_vector_epilogue_ok(const eg3d_conv_params& p) {
 
 template <int BM, int BN, int WM, int WN, int PREC, bool VEC>
 int launch_conv_pv(const eg3d_conv_params& p, hipStream_t st) {
-    static bool attr_done = false;
+    static std::atomic<uint64_t> attr_done{0};               // one bit per device ordinal
     constexpr int NP = PREC == 1 ? 3 : 2;
     constexpr int KB = BM * BN >= 128 * 128 ? 16 : 32;
     const size_t loop_bytes = PREC ? (size_t)2 * (split_tile_bytes(BM, NP, KB) + split_tile_bytes(BN, NP, KB)) : (size_t)(2 * (BM + BN) * LDK) * sizeof(float);
     const size_t stage_bytes = VEC ? (size_t)(BN + WM * 32 * (BN + 4)) * sizeof(float) : 0;        // epilogue staging reuses the operand buffers
     const size_t smem = (loop_bytes > stage_bytes ? loop_bytes : stage_bytes) + 2 * BM * sizeof(int);
     auto kern = conv_igemm_kernel<BM, BN, WM, WN, PREC, VEC>;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)smem, attr_done)) return e;
     int max_tiles = 0;
     for (int c = 0; c < p.ncls; ++c) {
         int64_t Mc = (int64_t)p.N * p.cls[c].Ha * p.cls[c].Wa;

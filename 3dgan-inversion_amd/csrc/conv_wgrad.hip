@@ -388,25 +388,17 @@ extern "C" int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* pp, void* stream) 
     }
     if (p.precision != EG3D_PREC_F32 && p.precision != EG3D_PREC_F16X3) return EG3D_ERR_UNSUPPORTED;
     if (p.precision == EG3D_PREC_F16X3) {
-        static bool attr16 = false;
+        static std::atomic<uint64_t> attr16{0};
         const size_t smem16 = (size_t)2 * H_STAGE;
-        if (!attr16) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16);
-            if (e != hipSuccess) return (int)e;
-            attr16 = true;
-        }
+        if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_wgrad_f16x3_kernel), (int)smem16, attr16)) return e;
         dim3 grid16(tiles_o * tiles_i, ntap_total, p.psplit);
         hipLaunchKernelGGL(conv_wgrad_f16x3_kernel, grid16, dim3(256), smem16, (hipStream_t)stream, p, tiles_o, tiles_i, ntap_total);
         EG3D_LAUNCH_CHECK();
         return EG3D_OK;
     }
-    static bool attr_done = false;
+    static std::atomic<uint64_t> attr_done{0};
     const size_t smem = (size_t)(2 * BC * (LDO + LDI)) * sizeof(float);
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_wgrad_kernel), (int)smem, attr_done)) return e;
     dim3 grid(tiles_o * tiles_i, ntap_total, p.psplit);
     hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), smem, (hipStream_t)stream, p, tiles_o, tiles_i, ntap_total);
     EG3D_LAUNCH_CHECK();

@@ -504,12 +504,8 @@ extern "C" int eg3d_pack_conv_weight(const float* w, float* wf, float* wa, float
     if (!w || !wf || !wa || O <= 0 || I <= 0 || T <= 0 || T > 64) return EG3D_ERR_INVALID;
     const size_t smem = (size_t)PK * (PK * T + 1) * sizeof(float);
     if (smem > 64 * 1024) return EG3D_ERR_UNSUPPORTED;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pack_conv_weight_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(pack_conv_weight_kernel), 64 * 1024, attr_done)) return e;
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(eg3d_cdiv(I, PK), eg3d_cdiv(O, PK)), dim3(256), smem, (hipStream_t)stream, w, wf, wa, wsq, O, I, T);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;

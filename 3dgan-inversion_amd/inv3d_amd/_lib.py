@@ -37,6 +37,16 @@ class ConvParams(C.Structure):
                 ('clamp', C.c_float), ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p), ('precision', C.c_int32), ('a_amax', C.c_void_p), ('a_amax_mul', C.c_float), ('ds_replicas', C.c_int32)]
 
 
+class ConvV2Params(C.Structure):
+    _fields_ = [('a', C.c_void_p), ('w', C.c_void_p), ('a_scale', C.c_void_p), ('w_scale', C.c_void_p), ('out', C.c_void_p),
+                ('N', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32), ('Ck', C.c_int32), ('Nc', C.c_int32), ('wtaps', C.c_int32),
+                ('Ho', C.c_int32), ('Wo', C.c_int32), ('ldo', C.c_int32), ('in_stride', C.c_int32), ('out_stride', C.c_int32),
+                ('ncls', C.c_int32), ('cls', ConvClass * 4), ('epi', C.c_int32),
+                ('out_scale', C.c_void_p), ('bias', C.c_void_p), ('noise', C.c_void_p), ('noise_nstride', C.c_int64),
+                ('noise_strength', C.c_void_p), ('act', C.c_int32), ('alpha', C.c_float), ('gain', C.c_float), ('clamp', C.c_float),
+                ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p), ('out_amax', C.c_void_p)]
+
+
 class WgradParams(C.Structure):
     _fields_ = [('x', C.c_void_p), ('g', C.c_void_p), ('dw', C.c_void_p),
                 ('N', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32), ('Ck', C.c_int32), ('ldx', C.c_int32),
@@ -100,6 +110,12 @@ _SIGS = {
     'eg3d_conv2d_igemm_f32': (C.c_int, [C.POINTER(ConvParams), C.c_void_p]),
     'eg3d_conv2d_igemm_config': (C.c_int, [C.POINTER(ConvParams)]),
     'eg3d_conv2d_wgrad_f32': (C.c_int, [C.POINTER(WgradParams), C.c_void_p]),
+    'eg3d_conv2d_v2_supported': (C.c_int, [C.POINTER(ConvV2Params)]),
+    'eg3d_conv2d_v2': (C.c_int, [C.POINTER(ConvV2Params), C.c_void_p]),
+    'eg3d_split_activation_bytes': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'eg3d_split_activation': (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]),
+    'eg3d_split_weight': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
+    'eg3d_absmax': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'eg3d_modconv_epilogue_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int64,
                                             C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),

@@ -361,6 +361,116 @@ def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=
     return out
 
 
+# ------------------------------------------------------------------------------------------------- pre-split convolution (csrc/conv_v2.hip)
+def absmax(x, out=None):
+    """Device scalar max|x| (eg3d_absmax); `out`: a pre-zeroed 1-element tensor to accumulate into."""
+    if out is None:
+        out = zeros((1,), x.device)
+    L.check(L.lib().eg3d_absmax(L.ptr(x), x.numel(), L.ptr(out), L.stream_ptr()), 'absmax')
+    return out
+
+
+class SplitImage:
+    """Two-piece fp16 image of an operand + the power-of-two scale it was written with (device scalar)."""
+    __slots__ = ('data', 'scale', 'shape')
+
+    def __init__(self, data, scale, shape):
+        self.data, self.scale, self.shape = data, scale, shape
+
+
+def split_activation(x, x_amax, in_scale=None, s_amax=None, C=None):
+    """fp32 channels_last [N,C,H,W] (times in_scale[n,c]) -> SplitImage [N][2][C/8][H][W][8] fp16, range-normalised with the device scalars
+    x_amax = max|x| and s_amax = max|in_scale|."""
+    assert is_cl(x)
+    n, cx, h, w = x.shape
+    C_ = cx if C is None else C
+    img = torch.empty((n * h * w * C_ * 2,), dtype=torch.float16, device=x.device)
+    scale = torch.empty((1,), dtype=torch.float32, device=x.device)
+    L.check(L.lib().eg3d_split_activation(L.ptr(x), L.ptr(in_scale), L.ptr(x_amax), L.ptr(s_amax), L.ptr(img), L.ptr(scale), n, h, w, C_, cx,
+                                          L.stream_ptr()), 'split_activation')
+    return SplitImage(img, scale, (n, C_, h, w))
+
+
+def split_weight(wp, O, I, T):
+    """Packed fp32 weights [O, T*I] (forward or adjoint image) -> SplitImage [T][I/16][2][2][O][8] fp16 (unscaled low piece)."""
+    amax = absmax(wp)
+    img = torch.empty((O * T * I * 2,), dtype=torch.float16, device=wp.device)
+    scale = torch.empty((1,), dtype=torch.float32, device=wp.device)
+    L.check(L.lib().eg3d_split_weight(L.ptr(wp), L.ptr(amax), L.ptr(img), L.ptr(scale), O, I, T, wp.stride(0), L.stream_ptr()), 'split_weight')
+    return SplitImage(img, scale, (O, I, T))
+
+
+def _conv_v2_params(a, w, out, classes, out_stride, epi, out_scale, bias, noise, noise_nstride, noise_strength, act, alpha, gain, clamp,
+                    addend, xin, ds, out_amax):
+    p = L.ConvV2Params()
+    n, ck, hi, wi = a.shape
+    nc, _, wtaps = w.shape
+    _, co, ho, wo = out.shape
+    p.a, p.w, p.a_scale, p.w_scale, p.out = a.data.data_ptr(), w.data.data_ptr(), a.scale.data_ptr(), w.scale.data_ptr(), out.data_ptr()
+    p.N, p.Hi, p.Wi, p.Ck, p.Nc, p.wtaps = n, hi, wi, ck, nc, wtaps
+    p.Ho, p.Wo, p.ldo, p.in_stride, p.out_stride = ho, wo, co, 1, out_stride
+    p.ncls = len(classes)
+    for i, c in enumerate(classes):
+        p.cls[i] = c
+    p.epi = epi
+    p.out_scale = out_scale.data_ptr() if out_scale is not None else None
+    p.bias = bias.data_ptr() if bias is not None else None
+    p.noise = noise.data_ptr() if noise is not None else None
+    p.noise_nstride = noise_nstride
+    p.noise_strength = noise_strength.data_ptr() if noise_strength is not None else None
+    p.act, p.alpha, p.gain, p.clamp = L.ACT_IDS[act], float(alpha), float(gain), float(clamp)
+    p.addend = addend.data_ptr() if addend is not None else None
+    p.xin = xin.data_ptr() if xin is not None else None
+    p.ds = ds.data_ptr() if ds is not None else None
+    p.out_amax = out_amax.data_ptr() if out_amax is not None else None
+    return p
+
+
+def conv_v2_supported(Ck, Nc, classes, N=1):
+    """Geometry the pre-split kernel takes (see eg3d_conv2d_v2_supported) AND enough 256 x 128 tiles to fill the chip."""
+    if Ck % 16 or Nc % 128 or CONV_MODE != 'auto':
+        return False
+    for c in classes:
+        if c.ntaps not in (9, 4, 2, 1):
+            return False
+        dys, dxs = [c.dy[t] for t in range(c.ntaps)], [c.dx[t] for t in range(c.ntaps)]
+        if max(dys) - min(dys) > 2 or max(dxs) - min(dxs) > 2:
+            return False
+    tiles = sum(N * -(-c.Ha // 8) * -(-c.Wa // 32) for c in classes) * (Nc // 128)
+    return tiles >= V2_MIN_TILES
+
+
+V2_MIN_TILES = int(os.environ.get('EG3D_V2_MIN_TILES', '256'))
+USE_V2 = os.environ.get('EG3D_CONV_V2', '1') != '0'
+
+
+def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_STORE, out_scale=None, bias=None, noise=None, noise_nstride=0,
+            noise_strength=None, act='linear', alpha=0.0, gain=1.0, clamp=-1.0, addend=None, xin=None, ds=None, out_amax=None, algo_flops=None):
+    """Launch eg3d_conv2d_v2 (operands prepared by split_activation / split_weight)."""
+    assert is_cl(out)
+    p = _conv_v2_params(a, w, out, classes, out_stride, epi, out_scale, bias, noise, noise_nstride, noise_strength, act, alpha, gain, clamp,
+                        addend, xin, ds, out_amax)
+    prof = PROFILER
+    if prof is not None and prof.only_config is not None and prof.only_config != V2_CONFIG:
+        prof = None
+    if prof is not None:
+        if algo_flops is None:
+            algo_flops = 2.0 * p.Ck * p.Nc * sum(p.N * c.Ha * c.Wa * c.ntaps for c in classes)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    L.check(L.lib().eg3d_conv2d_v2(C.byref(p), L.stream_ptr()), 'conv2d_v2')
+    if prof is not None:
+        e1.record()
+        prof.records.append((V2_CONFIG, float(algo_flops), e0, e1))
+        if prof.meta is not None:
+            prof.meta.append(dict(N=p.N, Hi=p.Hi, Wi=p.Wi, Ck=p.Ck, Nc=p.Nc, Ho=p.Ho, Wo=p.Wo, taps=[c.ntaps for c in classes], epi=epi, ksplit=1,
+                                  in_stride=1, out_stride=out_stride, prec=3, v2=True))
+    return out
+
+
+V2_CONFIG = 5        # "tile configuration" id of the pre-split kernel in profiler records (eg3d_conv2d_igemm_config returns 0..4)
+
+
 def conv_wgrad(x, g, Ck, Nc, dwp, classes, in_stride=1, out_stride=1, in_scale=None, psplit=0, precision='f32', g_amax=None, g_amax_mul=1.0):
     """dwp[Nc, taps*Ck] += grad of the packed weights (dwp pre-zeroed).  precision 'f32' | 'f16x3' (g_amax: device scalar max|g|
     for the range normalisation of the gradient operand, see include/eg3d_hip.h)."""

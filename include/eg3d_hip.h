@@ -142,6 +142,52 @@ int eg3d_conv2d_igemm_f32(const eg3d_conv_params* p, void* stream);
  * 2 = 32x128, 3 = 128x32.  Pure host function (used by bench.py to attribute launch times to kernels). */
 int eg3d_conv2d_igemm_config(const eg3d_conv_params* p);
 
+/* ------------------------------------------------------------------------------------------------
+ * Pre-split implicit-GEMM convolution (csrc/conv_v2.hip): same contract as eg3d_conv2d_igemm_f32 in F16X3 arithmetic -- one launch
+ * computes, for every cell of every class grid,
+ *     acc[n,ay,ax,o] = sum_t sum_k  A[n, ay+dy[t], ax+dx[t], k] * W[o, wtap[t], k]            (in_stride 1; OOB reads are zero)
+ * and applies epilogue STORE / FWD / BWD (as above) at out[n, ay*out_stride+out_py, ax*out_stride+out_px, o] -- but both operands are
+ * "split images" prepared once by eg3d_split_activation / eg3d_split_weight (two fp16 pieces per value, see conv_v2.hip), so the
+ * style modulation, the range normalisation and the fp32 -> 2 x fp16 split are NOT repeated per tile and per tap:
+ *   A image [N][2][Ck/8][Hi][Wi][8] fp16 = split( x * in_scale[n,k] * a_scale ),  a_scale = the power of two that brings
+ *           max|x| * max|in_scale| to [2^13, 2^14)  (device scalar written by eg3d_split_activation);
+ *   W image [wtaps][Ck/16][2][2][Nc][8] fp16 = split( w[o, tap, k] * w_scale )    (eg3d_split_weight; cached per weight version).
+ * The result is divided by a_scale * w_scale in the epilogue (exact).  out_amax (optional, pre-zeroed device scalar) receives
+ * max|out| (atomic max): the operand range of the next layer's split.
+ * Restrictions (eg3d_conv2d_v2_supported): Ck % 16 == 0, Nc % 128 == 0, in_stride 1, classes of 9 / 4 / 2 / 1 taps whose offsets span
+ * at most 3 x 3, 16-byte aligned rows; everything else stays on eg3d_conv2d_igemm_f32. */
+typedef struct eg3d_conv_v2_params {
+    const void* a;  const void* w;
+    const float* a_scale;  const float* w_scale;
+    float* out;
+    int32_t N, Hi, Wi, Ck;
+    int32_t Nc, wtaps;
+    int32_t Ho, Wo, ldo;
+    int32_t in_stride, out_stride;
+    int32_t ncls;
+    eg3d_conv_class cls[4];
+    int32_t epi;
+    const float* out_scale;  const float* bias;  const float* noise;
+    int64_t noise_nstride;
+    const float* noise_strength;
+    int32_t act;
+    float alpha, gain, clamp;
+    const float* addend;  const float* xin;
+    float* ds;
+    float* out_amax;
+} eg3d_conv_v2_params;
+int eg3d_conv2d_v2_supported(const eg3d_conv_v2_params* p);
+int eg3d_conv2d_v2(const eg3d_conv_v2_params* p, void* stream);
+/* Operand preparation.  x: NHWC fp32 [N,H,W,ldx] (C used channels, C % 8 == 0); in_scale [N,C] or null; x_amax / s_amax: device scalars
+ * holding max|x| and max|in_scale| (s_amax null = 1); image: eg3d_split_activation_bytes() bytes; scale_out: device scalar. */
+int64_t eg3d_split_activation_bytes(int N, int H, int W, int C);
+int eg3d_split_activation(const float* x, const float* in_scale, const float* x_amax, const float* s_amax, void* image, float* scale_out,
+                          int N, int H, int W, int C, int ldx, void* stream);
+/* w: packed [O][T][I] fp32 with row stride w_row (the forward or adjoint image of eg3d_pack_conv_weight); image: O*T*I*4 bytes. */
+int eg3d_split_weight(const float* w, const float* w_amax, void* image, float* scale_out, int O, int I, int T, int w_row, void* stream);
+/* out (pre-zeroed device scalar) = max(out, max|x|) over n floats. */
+int eg3d_absmax(const float* x, int64_t n, float* out, void* stream);
+
 /* Weight-gradient GEMM (PTI phase: grads into generator weights, training/coaches/base_coach.py:96-99):
  *   dw[o, wtap[t], k] += sum_{n,ay,ax} g[n, ay*out_stride+out_py, ax*out_stride+out_px, o]
  *                                       * in_scale[n,k] * x[n, ay*in_stride+dy[t], ax*in_stride+dx[t], k]
