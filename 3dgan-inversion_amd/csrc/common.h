@@ -117,6 +117,19 @@ __device__ __forceinline__ F eg3d_act_d2(F yy, F x, int act, F alpha) {
     }
 }
 
+// max|v| reporting: wave-level reduce, then ONE conditional atomic per wave -- thousands of unconditional atomics on one address
+// serialise at ~12 ns each (measured: a 25 us pass became 77 us), so a wave first looks at the current value (monotone: a stale read
+// only costs a redundant atomic) and almost every wave skips.  Non-negative floats order like their bit patterns.
+__device__ __forceinline__ void eg3d_commit_amax(float m, float* out) {
+    if (out == nullptr) return;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f && m < 3.0e38f) {
+        const float cur = __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (m > cur) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+    }
+}
+
 // XCD-aware block-id remap (bijective for any grid size): hardware places block b on XCD b % 8; give each XCD a
 // contiguous chunk of logical tiles so that tiles sharing operands share an L2.
 __device__ __forceinline__ int eg3d_xcd_remap(int bid, int nblocks) {

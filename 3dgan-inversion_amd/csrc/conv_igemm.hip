@@ -421,6 +421,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
         const int col = n0 + c4 * 4;
         const bool cok = col < p.Nc;
         float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), scl4 = make_float4(1.f, 1.f, 1.f, 1.f), dsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float omax = 0.f;
         if (cok && epi == EG3D_EPI_FWD && p.bias != nullptr) bias4 = *reinterpret_cast<const float4*>(p.bias + col);
         if (cok && (epi == EG3D_EPI_FWD || epi == EG3D_EPI_BWD) && p.out_scale != nullptr)
             scl4 = *reinterpret_cast<const float4*>(p.out_scale + (int64_t)n_first * p.Nc + col);
@@ -470,10 +471,12 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
                     if (do_ds) { dsum4.x += v.x * sb[u].x; dsum4.y += v.y * sb[u].y; dsum4.z += v.z * sb[u].z; dsum4.w += v.w * sb[u].w; }
                     v = make_float4(v.x * scl4.x + sa[u].x, v.y * scl4.y + sa[u].y, v.z * scl4.z + sa[u].z, v.w * scl4.w + sa[u].w);
                 }
+                omax = fmaxf(omax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
                 *reinterpret_cast<float4*>(p.out + offs[u]) = v;
             }
             }
         }
+        eg3d_commit_amax(omax, p.out_amax);                 // max|out| for the consumer's operand range
         if (do_ds) {                                        // block-level column sums, then one atomic per column
             if (cok) {
                 atomicAdd(&ds_lds[c4 * 4 + 0], dsum4.x); atomicAdd(&ds_lds[c4 * 4 + 1], dsum4.y);
@@ -484,6 +487,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
         }
     } else {
     constexpr int RC = 8;                     // rows per lane whose side inputs are in flight together
+    float omax = 0.f;
     // ---- scalar epilogue (split-K atomics, tiles spanning several images, unaligned or odd channel counts) -----------------------
 
 #pragma unroll
@@ -528,6 +532,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
                     if (off < 0) continue;
                     float v = acc[i][j][r] * a_inv;
                     if (epi == EG3D_EPI_STORE) {
+                        omax = fmaxf(omax, fabsf(v));
                         p.out[off] = v;
                     } else if (epi == EG3D_EPI_ATOMIC) {
                         unsafeAtomicAdd(p.out + off, v);
@@ -535,6 +540,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
                         v = v * scl[q] + sideb[q] * strength + bias;
                         v = eg3d_pwl_fwd(v, act_slope) * p.gain;
                         if (p.clamp >= 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
+                        omax = fmaxf(omax, fabsf(v + sidea[q]));
                         p.out[off] = v + sidea[q];
                     } else {   // EG3D_EPI_BWD
                         if (do_ds) {
@@ -542,6 +548,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
                             if (single_n) dsum += t;
                             else unsafeAtomicAdd(ds_out + (int64_t)rown[wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] * p.Nc + col, t);
                         }
+                        omax = fmaxf(omax, fabsf(v * scl[q] + sidea[q]));
                         p.out[off] = v * scl[q] + sidea[q];
                     }
                 }
@@ -556,6 +563,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
         __syncthreads();
         if (tid < BN && n0 + tid < p.Nc) unsafeAtomicAdd(ds_out + (int64_t)n_first * p.Nc + n0 + tid, ds_lds[tid]);
     }
+    if (epi != EG3D_EPI_ATOMIC) eg3d_commit_amax(omax, p.out_amax);
     }
 }
 

@@ -266,11 +266,7 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
         __syncthreads();
         if (tid < BN) unsafeAtomicAdd(p.ds + (int64_t)n * p.Nc + n0 + tid, ds_lds[tid]);
     }
-    if (p.out_amax != nullptr) {                       // max|out| for the consumer's operand range (non-negative floats order like ints)
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-        if (lane == 0 && amax > 0.f) atomicMax(reinterpret_cast<int*>(p.out_amax), __float_as_int(amax));
-    }
+    eg3d_commit_amax(amax, p.out_amax);          // max|out|: the consumer's operand range
 }
 
 // ---- operand preparation -------------------------------------------------------------------------------------------------------------
@@ -298,7 +294,20 @@ __device__ __forceinline__ float range_mul(float amax) {
 // thread = pixel; loop over the channel octets of its NHWC row; writes are 16 bytes per lane, contiguous over the wave
 __global__ void __launch_bounds__(256) split_act_kernel(const float* __restrict__ x, const float* __restrict__ s, const float* x_amax, const float* s_amax,
                                                         f16x8* __restrict__ out, float* scale_out, int N, int HW, int C, int ldx) {
-    const float mul = range_mul(*x_amax * (s_amax ? *s_amax : 1.f));
+    float smax = 1.f;
+    if (s_amax != nullptr) {
+        smax = *s_amax;
+    } else if (s != nullptr) {            // max|in_scale| over [N,C] (a few KB): every block derives the same value itself
+        __shared__ float red[4];
+        float m = 0.f;
+        for (int i = threadIdx.x; i < N * C; i += 256) m = fmaxf(m, fabsf(s[i]));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        smax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    }
+    const float mul = range_mul(*x_amax * smax);
     if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = mul;
     const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (pix >= (int64_t)N * HW) return;
@@ -325,9 +334,7 @@ __global__ void __launch_bounds__(256) split_act_kernel(const float* __restrict_
 __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, int64_t n, float* out) {
     float m = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<int*>(out), __float_as_int(m));
+    eg3d_commit_amax(m, out);
 }
 
 // w: packed [O][T][I] fp32 -> [T][I/16][piece][koct][O] x 8 fp16, unscaled low piece

@@ -23,13 +23,17 @@ __device__ __forceinline__ float act1(float v, int act, float alpha, float gain,
     return v;
 }
 
+__device__ __forceinline__ void commit_amax(float m, float* out) { eg3d_commit_amax(m, out); }
+__device__ __forceinline__ float amax4(float m, const float4 v) { return fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))); }
+
 template <bool PWL>
 __global__ void __launch_bounds__(256) epilogue_fwd_kernel(const float* __restrict__ z, float* __restrict__ out, int N, int H, int W, int C4,
                                                            int Hz, int Wz, const float* __restrict__ fir, int fh, int fw, int pad0,
                                                            float fir_gain, const float* __restrict__ d, const float* __restrict__ noise,
                                                            int64_t noise_nstride, const float* __restrict__ noise_strength,
-                                                           const float* __restrict__ bias, int act, float alpha, float gain, float clamp) {
+                                                           const float* __restrict__ bias, int act, float alpha, float gain, float clamp, float* out_amax) {
     __shared__ float fs[64];
+    float am = 0.f;
     if (fir != nullptr && threadIdx.x < fh * fw) {
         int ky = threadIdx.x / fw, kx = threadIdx.x % fw;
         fs[threadIdx.x] = fir[(fh - 1 - ky) * fw + (fw - 1 - kx)] * fir_gain;      // true convolution (flip_filter=False)
@@ -90,8 +94,10 @@ __global__ void __launch_bounds__(256) epilogue_fwd_kernel(const float* __restri
         }
         v.x = act1<PWL>(v.x, act, alpha, gain, clamp); v.y = act1<PWL>(v.y, act, alpha, gain, clamp);
         v.z = act1<PWL>(v.z, act, alpha, gain, clamp); v.w = act1<PWL>(v.w, act, alpha, gain, clamp);
+        am = amax4(am, v);
         st4(out + i * 4, v);
     }
+    commit_amax(am, out_amax);
 }
 
 // 4x4 FIR + demod + noise + bias + activation with a 2x2 output block per thread: the four outputs share a 5x5 input patch, i.e. 25
@@ -101,8 +107,9 @@ __global__ void __launch_bounds__(256) epilogue_fwd_fir44_kernel(const float* __
                                                                  int Hz, int Wz, const float* __restrict__ fir, int pad0, float fir_gain,
                                                                  const float* __restrict__ d, const float* __restrict__ noise, int64_t noise_nstride,
                                                                  const float* __restrict__ noise_strength, const float* __restrict__ bias, int act,
-                                                                 float alpha, float gain, float clamp) {
+                                                                 float alpha, float gain, float clamp, float* out_amax) {
     __shared__ float fs[16];
+    float am = 0.f;
     if (threadIdx.x < 16) fs[threadIdx.x] = fir[(3 - threadIdx.x / 4) * 4 + (3 - threadIdx.x % 4)] * fir_gain;      // true convolution
     __syncthreads();
     const float strength = noise ? *noise_strength : 0.f;
@@ -147,9 +154,11 @@ __global__ void __launch_bounds__(256) epilogue_fwd_fir44_kernel(const float* __
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                 v.x = act1<PWL>(v.x, act, alpha, gain, clamp); v.y = act1<PWL>(v.y, act, alpha, gain, clamp);
                 v.z = act1<PWL>(v.z, act, alpha, gain, clamp); v.w = act1<PWL>(v.w, act, alpha, gain, clamp);
+                am = amax4(am, v);
                 st4(out + (((int64_t)n * H + y) * W + x) * C + c, v);
             }
     }
+    commit_amax(am, out_amax);
 }
 
 // derivative factor and recovered pre-activation for one element
@@ -425,7 +434,7 @@ __global__ void __launch_bounds__(256) demod_bwd_wsq_kernel(const float* __restr
 extern "C" int eg3d_modconv_epilogue_fwd(const float* z, float* out, int N, int H, int W, int C, int Hz, int Wz, const float* fir, int fh,
                                          int fw, int pad0, float fir_gain, const float* d, const float* noise, int64_t noise_nstride,
                                          const float* noise_strength, const float* bias, int act, float alpha, float gain, float clamp,
-                                         void* stream) {
+                                         float* out_amax, void* stream) {
     if (!z || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0) return EG3D_ERR_INVALID;
     if (C % 4) return EG3D_ERR_UNSUPPORTED;
     if (fir && (fh < 1 || fw < 1 || fh * fw > 64)) return EG3D_ERR_UNSUPPORTED;
@@ -438,18 +447,18 @@ extern "C" int eg3d_modconv_epilogue_fwd(const float* z, float* out, int N, int 
         const int64_t total4 = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
         const int blocks4 = (int)std::min<int64_t>(eg3d_cdiv(total4, 256), 256 * 16);
         if (pwl) hipLaunchKernelGGL(epilogue_fwd_fir44_kernel<true>, dim3(blocks4), dim3(256), 0, (hipStream_t)stream, z, out, N, H, W, C / 4, Hz, Wz, fir, pad0,
-                                    fir_gain, d, noise, noise_nstride, noise_strength, bias, act, slope, gain, clamp);
+                                    fir_gain, d, noise, noise_nstride, noise_strength, bias, act, slope, gain, clamp, out_amax);
         else hipLaunchKernelGGL(epilogue_fwd_fir44_kernel<false>, dim3(blocks4), dim3(256), 0, (hipStream_t)stream, z, out, N, H, W, C / 4, Hz, Wz, fir, pad0,
-                                fir_gain, d, noise, noise_nstride, noise_strength, bias, act, alpha, gain, clamp);
+                                fir_gain, d, noise, noise_nstride, noise_strength, bias, act, alpha, gain, clamp, out_amax);
         EG3D_LAUNCH_CHECK();
         return EG3D_OK;
     }
     const int64_t total = (int64_t)N * H * W * (C / 4);
     int blocks = (int)std::min<int64_t>(eg3d_cdiv(total, 256), 256 * 16);
     if (pwl) hipLaunchKernelGGL(epilogue_fwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, out, N, H, W, C / 4, Hz, Wz, fir, fh, fw, pad0,
-                                fir_gain, d, noise, noise_nstride, noise_strength, bias, act, slope, gain, clamp);
+                                fir_gain, d, noise, noise_nstride, noise_strength, bias, act, slope, gain, clamp, out_amax);
     else hipLaunchKernelGGL(epilogue_fwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, out, N, H, W, C / 4, Hz, Wz, fir, fh, fw, pad0,
-                            fir_gain, d, noise, noise_nstride, noise_strength, bias, act, alpha, gain, clamp);
+                            fir_gain, d, noise, noise_nstride, noise_strength, bias, act, alpha, gain, clamp, out_amax);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

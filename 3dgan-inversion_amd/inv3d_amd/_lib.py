@@ -34,7 +34,7 @@ class ConvParams(C.Structure):
                 ('in_scale', C.c_void_p), ('epi', C.c_int32), ('ksplit', C.c_int32),
                 ('out_scale', C.c_void_p), ('bias', C.c_void_p), ('noise', C.c_void_p), ('noise_nstride', C.c_int64),
                 ('noise_strength', C.c_void_p), ('act', C.c_int32), ('alpha', C.c_float), ('gain', C.c_float),
-                ('clamp', C.c_float), ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p), ('precision', C.c_int32), ('a_amax', C.c_void_p), ('a_amax_mul', C.c_float), ('ds_replicas', C.c_int32)]
+                ('clamp', C.c_float), ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p), ('precision', C.c_int32), ('a_amax', C.c_void_p), ('a_amax_mul', C.c_float), ('ds_replicas', C.c_int32), ('out_amax', C.c_void_p)]
 
 
 class ConvV2Params(C.Structure):
@@ -118,7 +118,7 @@ _SIGS = {
     'eg3d_absmax': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'eg3d_modconv_epilogue_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int64,
-                                            C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+                                            C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     'eg3d_modconv_epilogue_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                             C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                             C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),

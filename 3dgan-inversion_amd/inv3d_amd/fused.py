@@ -56,6 +56,17 @@ class WeightCache:
             self._c = {'k': key, 'wf': wf, 'wa': wa, 'wsq': wsq}
         return self._c['wf'], self._c['wa'], self._c['wsq']
 
+    def get_split(self, w: torch.Tensor):
+        """(forward, adjoint) split images of the packed weights for the pre-split conv kernel (csrc/conv_v2.hip), rebuilt with them."""
+        wf, wa, _ = self.get(w)
+        hit = self._c.get('split')
+        if hit is None:
+            o, i, kh, kw = w.shape
+            with torch.no_grad():
+                hit = (H.split_weight(wf, o, i, kh * kw), H.split_weight(wa, i, o, kh * kw))
+            self._c['split'] = hit
+        return hit
+
     def forward_padded(self, w: torch.Tensor, cp: int):
         """[cp, taps*Ci] forward image with zero rows appended (toRGB 3 -> 4 outputs: the padded output channel is 0 + skip, and
         the launch takes the 16-byte vector epilogue)."""
@@ -129,29 +140,38 @@ class ModConvLayerFn(torch.autograd.Function):
         b = bias.contiguous().float() if bias is not None else None
         aflops = 2.0 * N * Hi * Wi * (1 if up == 2 else 1) * kh * kw * Ci * Co     # MACs of the (transposed) conv
         prec = H.modconv_precision()
+        amax_out = H.zeros((1,), x.device)            # max|out|, reported by whichever kernel writes `out`: the next layer's operand range
+        cls, Hz, Wz = (H.classes_corr(Ho, Wo, kh, kw, kh // 2), Ho, Wo) if up == 1 else H.classes_convT(Hi, Wi, kh, kw, up)
+        ks = _auto_ksplit(cls, N, Co, Ci)
+        # (transposed-conv classes run on it too, but measured slower than the loader-split kernel: three launches of 4 / 2 / 1-tap
+        #  classes on ragged 257-wide grids -- 196 vs 174 us on 256^2 x 256 -> 513^2 x 128, 116 vs 67 us on 128^2 x 256; opt-in)
+        v2 = H.USE_V2 and prec == 'f16x3' and ks == 1 and (up == 1 or H.V2_CONVT) and H.conv_v2_supported(Ci, Co, cls, N)
+        epi_kw = dict(noise=nz, noise_nstride=nstride or 0, noise_strength=noise_strength, bias=b, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv)
+        if v2:          # pre-split operands: modulation, range normalisation and the fp16 split happen once, not per tile and tap
+            aimg = H.split_activation(x, H.amax_of(x), in_scale=styles)
+            wimg = cache.get_split(weight)[0]
         if up == 1:
-            cls = H.classes_corr(Ho, Wo, kh, kw, kh // 2)
-            ks = _auto_ksplit(cls, N, Co, Ci)
-            if ks == 1:
-                H.conv_igemm(x, wf, Ci, Co, out, cls, in_scale=styles, epi=L.EPI_FWD, out_scale=d, bias=b, noise=nz,
-                             noise_nstride=nstride or 0, noise_strength=noise_strength, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv,
-                             algo_flops=aflops, precision=prec)
+            if v2:
+                H.conv_v2(aimg, wimg, out, cls, epi=L.EPI_FWD, out_scale=d, out_amax=amax_out, algo_flops=aflops, **epi_kw)
+            elif ks == 1:
+                H.conv_igemm(x, wf, Ci, Co, out, cls, in_scale=styles, epi=L.EPI_FWD, out_scale=d, algo_flops=aflops, precision=prec, out_amax=amax_out,
+                             **epi_kw)
             else:
                 z = H.zeros_cl(N, Co, Ho, Wo, x.device)
                 H.conv_igemm(x, wf, Ci, Co, z, cls, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=prec)
-                H.epilogue_fwd(z, out, d=d, noise=nz, noise_nstride=nstride or 0, noise_strength=noise_strength, bias=b, act='lrelu',
-                               alpha=0.2, gain=act_gain, clamp=clampv)
+                H.epilogue_fwd(z, out, d=d, out_amax=amax_out, **epi_kw)
         else:
-            cls, Hz, Wz = H.classes_convT(Hi, Wi, kh, kw, up)
-            ks = _auto_ksplit(cls, N, Co, Ci)
-            if ks == 1:
+            if v2:
+                z = H.empty_cl(N, Co, Hz, Wz, x.device)
+                H.conv_v2(aimg, wimg, z, cls, out_stride=up, epi=L.EPI_STORE, algo_flops=aflops)
+            elif ks == 1:
                 z = H.empty_cl(N, Co, Hz, Wz, x.device)
                 H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_STORE, algo_flops=aflops, precision=prec)
             else:
                 z = H.zeros_cl(N, Co, Hz, Wz, x.device)
                 H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=prec)
-            H.epilogue_fwd(z, out, fir=fir44(x.device), pad0=1, fir_gain=float(up * up), d=d, noise=nz, noise_nstride=nstride or 0,
-                           noise_strength=noise_strength, bias=b, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv)
+            H.epilogue_fwd(z, out, fir=fir44(x.device), pad0=1, fir_gain=float(up * up), d=d, out_amax=amax_out, **epi_kw)
+        H.tag_amax(out, amax_out)
         ctx.save_for_backward(x, weight, styles, d, out, nz, noise_strength, b)
         ctx.cfg = (up, act_gain, clampv, nstride, cache, want_wgrad, noise is not None and noise.dim() == 4, d_in is not None)
         return out
@@ -201,7 +221,10 @@ class ModConvLayerFn(torch.autograd.Function):
             dx = H.empty_cl(N, Ci, Hi, Wi, dev)
             aflops = 2.0 * N * Hi * Wi * kh * kw * Ci * Co
             ks = ks_adj
-            if ks == 1:
+            if H.USE_V2 and up == 1 and ks == 1 and prec == 'f16x3' and H.conv_v2_supported(Co, Ci, cls_adj, N):
+                H.conv_v2(H.split_activation(g, amax), cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds,
+                          algo_flops=aflops)
+            elif ks == 1:
                 H.conv_igemm(g, wa, Co, Ci, dx, cls_adj, in_stride=in_stride, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, algo_flops=aflops,
                              precision=prec, a_amax=amax, a_amax_mul=amul)
                 if rep > 1:
@@ -366,7 +389,12 @@ class ToRGBFn(torch.autograd.Function):
             out = y + skip if skip is not None else y
         ctx.save_for_backward(x, weight, styles, y if clampv >= 0 else None)
         ctx.cfg = (clampv, cache, want_wgrad, Cp, skip is not None)
-        return (out, x.view_as(x)) if passthrough else out
+        if not passthrough:
+            return out
+        xv = x.view_as(x)
+        if getattr(x, '_eg3d_amax', None) is not None:
+            H.tag_amax(xv, x._eg3d_amax)
+        return out, xv
 
     @staticmethod
     def backward(ctx, dout, dx_pass=None):

@@ -312,7 +312,7 @@ def modconv_precision() -> str:
 
 def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=None, epi=L.EPI_STORE, ksplit=1,
                out_scale=None, bias=None, noise=None, noise_nstride=0, noise_strength=None, act='linear', alpha=0.0, gain=1.0,
-               clamp=-1.0, addend=None, xin=None, ds=None, algo_flops=None, precision=None, a_amax=None, a_amax_mul=1.0):
+               clamp=-1.0, addend=None, xin=None, ds=None, algo_flops=None, precision=None, a_amax=None, a_amax_mul=1.0, out_amax=None):
     """Launch eg3d_conv2d_igemm_f32.  x/out/addend/xin: channels_last fp32 [N,C,H,W]; wp: packed weights [Nc, taps*Ck]."""
     assert is_cl(x) and is_cl(out), 'conv_igemm expects fp32 channels_last CUDA tensors'
     p = L.ConvParams()
@@ -341,6 +341,7 @@ def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=
     p.a_amax = a_amax.data_ptr() if a_amax is not None else None
     p.a_amax_mul = float(a_amax_mul)
     p.ds_replicas = ds.shape[0] if (ds is not None and ds.dim() == 3) else 1
+    p.out_amax = out_amax.data_ptr() if out_amax is not None else None
     prof = PROFILER
     if prof is not None:
         cfg = L.lib().eg3d_conv2d_igemm_config(C.byref(p))
@@ -368,6 +369,18 @@ def absmax(x, out=None):
         out = zeros((1,), x.device)
     L.check(L.lib().eg3d_absmax(L.ptr(x), x.numel(), L.ptr(out), L.stream_ptr()), 'absmax')
     return out
+
+
+def tag_amax(t, amax):
+    """Attach the device scalar max|t| its producer kernel reported to a tensor (read back by amax_of)."""
+    t._eg3d_amax = amax
+    return t
+
+
+def amax_of(t):
+    """Device scalar max|t|: the producer's report when the tensor carries one, else one reduction pass (eg3d_absmax)."""
+    a = getattr(t, '_eg3d_amax', None)
+    return a if a is not None else absmax(t)
 
 
 class SplitImage:
@@ -442,6 +455,7 @@ def conv_v2_supported(Ck, Nc, classes, N=1):
 
 V2_MIN_TILES = int(os.environ.get('EG3D_V2_MIN_TILES', '256'))
 USE_V2 = os.environ.get('EG3D_CONV_V2', '1') != '0'
+V2_CONVT = os.environ.get('EG3D_V2_CONVT', '0') == '1'
 
 
 def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_STORE, out_scale=None, bias=None, noise=None, noise_nstride=0,
@@ -497,14 +511,14 @@ def conv_wgrad(x, g, Ck, Nc, dwp, classes, in_stride=1, out_stride=1, in_scale=N
 
 # ------------------------------------------------------------------------------------------------- epilogues
 def epilogue_fwd(z, out, fir=None, pad0=0, fir_gain=1.0, d=None, noise=None, noise_nstride=0, noise_strength=None, bias=None,
-                 act='linear', alpha=0.0, gain=1.0, clamp=-1.0):
+                 act='linear', alpha=0.0, gain=1.0, clamp=-1.0, out_amax=None):
     assert is_cl(z) and is_cl(out)
     n, c, h, w = out.shape
     _, _, hz, wz = z.shape
     fh, fw = (fir.shape if fir is not None else (0, 0))
     L.check(L.lib().eg3d_modconv_epilogue_fwd(L.ptr(z), L.ptr(out), n, h, w, c, hz, wz, L.ptr(fir), fh, fw, pad0, float(fir_gain),
                                               L.ptr(d), L.ptr(noise), noise_nstride, L.ptr(noise_strength), L.ptr(bias),
-                                              L.ACT_IDS[act], float(alpha), float(gain), float(clamp), L.stream_ptr()),
+                                              L.ACT_IDS[act], float(alpha), float(gain), float(clamp), L.ptr(out_amax), L.stream_ptr()),
             'modconv_epilogue_fwd')
     return out
 

@@ -209,7 +209,10 @@ class SynthesisBlock(ReferenceStateMixin, torch.nn.Module):
         if self.is_last:
             img = self.torgb(x, next(w_iter), skip=img, styles=next(s_iter))
         else:       # x goes on to the next block: route it through the toRGB node so the two gradients are summed in its epilogue
+            amax = getattr(x, '_eg3d_amax', None)
             img, x = self.torgb(x, next(w_iter), skip=img, styles=next(s_iter), passthrough=True)
+            if amax is not None:        # the pass-through output is the same values: keep the producer's max|x| report with it
+                H.tag_amax(x, amax)
         return x, img
 
 

@@ -135,6 +135,8 @@ typedef struct eg3d_conv_params {
     int32_t ds_replicas;       /* EPI_BWD: ds is [ds_replicas][N,Nc]; workgroup b accumulates into replica b % ds_replicas so that
                                 * thousands of tiles do not serialise on the same N*Nc addresses; the caller sums the replicas.
                                 * 0 or 1 = a single [N,Nc] buffer. */
+    float* out_amax;           /* optional, pre-zeroed device scalar: receives max|out| (atomic max; EPI_STORE / FWD / BWD) -- the operand
+                                * range a consumer needs to range-normalise its two-piece fp16 split */
 } eg3d_conv_params;
 
 int eg3d_conv2d_igemm_f32(const eg3d_conv_params* p, void* stream);
@@ -179,7 +181,7 @@ typedef struct eg3d_conv_v2_params {
 int eg3d_conv2d_v2_supported(const eg3d_conv_v2_params* p);
 int eg3d_conv2d_v2(const eg3d_conv_v2_params* p, void* stream);
 /* Operand preparation.  x: NHWC fp32 [N,H,W,ldx] (C used channels, C % 8 == 0); in_scale [N,C] or null; x_amax / s_amax: device scalars
- * holding max|x| and max|in_scale| (s_amax null = 1); image: eg3d_split_activation_bytes() bytes; scale_out: device scalar. */
+ * holding max|x| and max|in_scale| (s_amax null: computed from in_scale by the kernel); image: eg3d_split_activation_bytes() bytes; scale_out: device scalar. */
 int64_t eg3d_split_activation_bytes(int N, int H, int W, int C);
 int eg3d_split_activation(const float* x, const float* in_scale, const float* x_amax, const float* s_amax, void* image, float* scale_out,
                           int N, int H, int W, int C, int ldx, void* stream);
@@ -277,11 +279,12 @@ int eg3d_style_affine_bwd(const eg3d_style_bank* bank, void* stream);
  * fwd: out[n,y,x,c] = clamp(act( FIR(z)[n,y,x,c] * d[n,c] + noise[n,y,x]*strength + bias[c] ) * gain)
  *      FIR: fir==null -> identity (z is [N,H,W,C]); else a (fh x fw) filter applied with padding pad0 (top/left) on
  *      z [N,Hz,Wz,C] and multiplied by fir_gain (the on-path case: 4x4, pad 1, gain 4, Hz = H+1).
+ *      out_amax (optional, pre-zeroed device scalar) receives max|out| (atomic max): the operand range of the next layer's split image.
  */
 int eg3d_modconv_epilogue_fwd(const float* z, float* out, int N, int H, int W, int C, int Hz, int Wz,
                               const float* fir, int fh, int fw, int pad0, float fir_gain, const float* d,
                               const float* noise, int64_t noise_nstride, const float* noise_strength,
-                              const float* bias, int act, float alpha, float gain, float clamp, void* stream);
+                              const float* bias, int act, float alpha, float gain, float clamp, float* out_amax, void* stream);
 
 /* bwd: given dout and the saved layer output `out`:
  *      dy = dout * act'(out) * gain   (0 where |out| >= clamp; derivative keyed on the OUTPUT as bias_act.cu:76,145)
