@@ -499,8 +499,9 @@ class RenderFn(torch.autograd.Function):
         if save is not None and Df > 0 and RENDER_PIPELINE:      # training mode: sample-level decode on the matrix cores between ray-level stages
             pos = torch.empty((2, N * R, max(Dc, Df), 4), device=dev)
         p = H.make_render_params(planes, origins, dirs, u1, u2, opts, w0g, b0g, w1t, b1g, rgb, depth, wsum, minmax, fine, rl, save, pos_rows=pos)
-        H.render_fwd(p)
-        H.render_finalize(depth, minmax)
+        with H._Span('render_fwd'):
+            H.render_fwd(p)
+            H.render_finalize(depth, minmax)
         ctx.save_for_backward(planes, origins, dirs, w0g, b0g, w1t, b1g, u1, u2, minmax, fine, rl, *(save or ()))
         ctx.cfg = (dict(opts), g0, g1, lr_mul)
         return rgb, depth, wsum
@@ -527,7 +528,8 @@ class RenderFn(torch.autograd.Function):
             # with equal coarse / fine counts every row is a live sample and is written by the sample-level kernel
             mk = torch.empty if p.Dc == p.Df else torch.zeros
             dumps = [mk((S, 64), device=dev), mk((S, 64), device=dev), mk((S, 33), device=dev), mk((S, 32), device=dev)]
-        H.render_bwd(p, g_rgb, g_depth, g_wsum, d_planes, d_o, d_d, dumps)
+        with H._Span('render_bwd'):
+            H.render_bwd(p, g_rgb, g_depth, g_wsum, d_planes, d_o, d_d, dumps)
         dw0 = db0 = dw1 = db1 = None
         if dumps is not None:
             dpre, hid, dout, feat = dumps

@@ -17,12 +17,14 @@ CL = torch.channels_last
 
 
 class LaunchProfiler:
-    """Optional per-launch timing of the implicit-GEMM conv (bench.py roofline): HIP events recorded on the launch stream
-    around every eg3d_conv2d_igemm_f32 call, with the launch's algorithmic FLOPs and tile configuration."""
+    """Optional per-launch timing (bench.py roofline): HIP events recorded on the launch stream around every implicit-GEMM conv launch,
+    with the launch's algorithmic FLOPs and kernel id (tile configuration 0..4 of eg3d_conv2d_igemm_f32, V2_CONFIG for the pre-split
+    kernel), and around named spans (the renderer's forward / backward)."""
 
     def __init__(self, only_config=None, keep_meta=False):
         self.records = []          # (config_id, algo_flops, start_event, end_event)
-        self.only_config = only_config      # time only launches of this tile configuration (keeps the event overhead small)
+        self.spans = []            # (name, start_event, end_event)
+        self.only_config = only_config      # time only launches of this kernel id (keeps the event overhead small)
         self.meta = [] if keep_meta else None      # per record: launch geometry (tools/conv_launch_table.py)
 
     def summary(self):
@@ -34,6 +36,33 @@ class LaunchProfiler:
             d['flops'] += fl
             d['ms'] += ms
         return out
+
+    def span_summary(self):
+        out = {}
+        for name, e0, e1 in self.spans:
+            d = out.setdefault(name, dict(count=0, ms=0.0))
+            d['count'] += 1
+            d['ms'] += e0.elapsed_time(e1)
+        return out
+
+
+class _Span:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.prof = PROFILER
+        if self.prof is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.prof is not None:
+            self.e1.record()
+            self.prof.spans.append((self.name, self.e0, self.e1))
+
+
+TILE_NAMES = {0: '128,128,2,2', 1: '64,128,2,2', 2: '32,128,1,4', 3: '128,32,4,1', 4: '256,64,4,1'}
 
 
 PROFILER = None
@@ -726,22 +755,32 @@ def _buf_arrays(bufs):
     return n, xs, res
 
 
-def noise_regularizer(bufs, scale=1.0, want_grad=True):
-    """Returns (reg [0-d tensor] = scale * regulariser, grads list or None) for square fp32 noise buffers, one launch."""
+NOISE_BANK_MAX = 32          # buffers per launch of the noise kernels (include/eg3d_hip.h)
+
+
+def noise_regularizer(bufs, scale=1.0, want_grad=True, grads=None):
+    """Returns (reg [0-d tensor] = scale * regulariser summed over all buffers, grads list or None) for square fp32 noise buffers;
+    one launch per 32 buffers (a batch of images brings 17 per image).  `grads`: optional pre-allocated gradient tensors (views allowed)."""
     for b in bufs:
         L.require_cuda(b)
         assert b.dim() == 2 and b.shape[0] == b.shape[1] and b.is_contiguous() and b.dtype == torch.float32
-    n, xs, res = _buf_arrays(bufs)
     dev = bufs[0].device
-    grads = [torch.empty_like(b) for b in bufs] if want_grad else None
-    gs = (C.c_void_p * n)(*[g.data_ptr() for g in grads]) if want_grad else (C.c_void_p * n)()
-    ws = torch.empty(int(L.lib().eg3d_noise_reg_workspace_floats(res, n)), dtype=torch.float32, device=dev)
-    reg = torch.empty((), dtype=torch.float32, device=dev)
-    L.check(L.lib().eg3d_noise_regularizer(xs, gs, res, n, L.ptr(ws), L.ptr(reg), float(scale), L.stream_ptr()), 'noise_regularizer')
-    return reg, grads
+    if want_grad and grads is None:
+        grads = [torch.empty_like(b) for b in bufs]
+    total = None
+    for lo in range(0, len(bufs), NOISE_BANK_MAX):
+        part = bufs[lo:lo + NOISE_BANK_MAX]
+        n, xs, res = _buf_arrays(part)
+        gs = (C.c_void_p * n)(*[g.data_ptr() for g in grads[lo:lo + NOISE_BANK_MAX]]) if want_grad else (C.c_void_p * n)()
+        ws = torch.empty(int(L.lib().eg3d_noise_reg_workspace_floats(res, n)), dtype=torch.float32, device=dev)
+        reg = torch.empty((), dtype=torch.float32, device=dev)
+        L.check(L.lib().eg3d_noise_regularizer(xs, gs, res, n, L.ptr(ws), L.ptr(reg), float(scale), L.stream_ptr()), 'noise_regularizer')
+        total = reg if total is None else total + reg
+    return total, (grads if want_grad else None)
 
 
 def noise_normalize_(bufs):
-    n, xs, res = _buf_arrays(bufs)
-    ws = zeros((2 * n,), bufs[0].device)          # per-buffer (sum, sum of squares): multi-block path
-    L.check(L.lib().eg3d_noise_normalize(xs, res, n, L.ptr(ws), L.stream_ptr()), 'noise_normalize')
+    for lo in range(0, len(bufs), NOISE_BANK_MAX):
+        n, xs, res = _buf_arrays(bufs[lo:lo + NOISE_BANK_MAX])
+        ws = zeros((2 * n,), bufs[0].device)          # per-buffer (sum, sum of squares): multi-block path
+        L.check(L.lib().eg3d_noise_normalize(xs, res, n, L.ptr(ws), L.stream_ptr()), 'noise_normalize')

@@ -205,7 +205,13 @@ def _area_resize(img: torch.Tensor, size: int) -> torch.Tensor:
 
 class LatentProjector:
     """Phase A.  One `step()` = pose chain (optional) -> G.synthesis with grad -> [canonical no-grad forward + warping loss] ->
-    feature distance + 1e5 * noise regulariser -> backward -> Adam steps -> noise renormalisation."""
+    feature distance + 1e5 * noise regulariser -> backward -> Adam steps -> noise renormalisation.
+
+    `target` [N,3,H,W]: N > 1 runs N INDEPENDENT inversions as one batch (config C5: 8 images per GPU) -- per-image latent, camera,
+    noise maps and Adam state, the frozen generator weights shared; per-sample modulation makes this exactly N separate trajectories
+    (networks_stylegan2.py:85-88), while the 4^2 ... 64^2 layers stop being latency-bound.  With N == 1 the noise
+    maps are the generator's own `noise_const` buffers, as in the reference; with N > 1 they are per-image tensors [N,1,r,r] owned by
+    the projector (`noise_maps`) and fed to the layers as per-sample noise."""
 
     def __init__(self, G, target: torch.Tensor, *, num_steps=400, w_avg: Optional[torch.Tensor] = None, w_std: float = 1.0,
                  start_w: Optional[torch.Tensor] = None, cam: Optional[torch.Tensor] = None, optimize_pose: bool = False,
@@ -219,6 +225,9 @@ class LatentProjector:
             raise ValueError(f'pose_mode must be one of {sorted(POSE_DIMS)}, got {pose_mode!r}')
         self.pose_mode = pose_mode
         dev = target.device
+        N = self.N = int(target.shape[0])
+        if N > 1 and optimize_pose:
+            raise NotImplementedError('batched projection optimises latents and noise maps; the pose chain / warping loss are per image (N = 1)')
         self.use_graph, self._graph, self._graph_warmup, self.graph_capture_error = use_graph, None, graph_warmup, None
         self.G = G.eval().requires_grad_(False)
         self.dev = dev
@@ -242,23 +251,39 @@ class LatentProjector:
             self.target_features = self.feature_net(t255)
             self.target_warp_feat = self.warp_net(target) if use_warping_loss else None
         w_avg = torch.zeros(1, 1, G.w_dim, device=dev) if w_avg is None else w_avg.to(dev).reshape(1, 1, -1)
-        start = torch.zeros_like(w_avg) if start_w is None else start_w.to(dev).reshape(1, -1, G.w_dim)
+        start = torch.zeros_like(w_avg) if start_w is None else (start_w.to(dev) if start_w.dim() == 3 else start_w.to(dev).reshape(1, -1, G.w_dim))
         w0 = (w_avg + start)
         if wplus and w0.shape[1] == 1:
             w0 = w0.repeat(1, self.num_ws, 1)
+        if w0.shape[0] == 1 and N > 1:
+            w0 = w0.repeat(N, 1, 1)
         self.w_opt = w0.clone().float().requires_grad_(True)
         self.noise_bufs = {n: b for n, b in G.backbone.synthesis.named_buffers() if 'noise_const' in n}
         self.noise_bufs2 = {n: b for n, b in G.superresolution.named_buffers() if 'noise_const' in n}
+        self.noise_maps, self._noise_inject = {}, None
         with torch.no_grad():
             for prefix, bufs in (('backbone.synthesis.', self.noise_bufs), ('superresolution.', self.noise_bufs2)):
                 for nm, b in bufs.items():
-                    src = init_noise[prefix + nm].to(dev) if init_noise is not None else torch.randn(b.shape, device=dev, generator=self.gen)
-                    b.copy_(src)
-                    # only the backbone's buffers become leaves (w_projector.py:126-128); the SR head's are re-drawn (:129-131) but never
+                    shape = tuple(b.shape) if N == 1 else (N, 1) + tuple(b.shape)
+                    src = init_noise[prefix + nm].to(dev) if init_noise is not None else torch.randn(shape, device=dev, generator=self.gen)
+                    # only the backbone's maps become leaves (w_projector.py:126-128); the SR head's are re-drawn (:129-131) but never
                     # receive a gradient: they enter the regulariser's value and are renormalised, nothing else
-                    b.requires_grad = prefix == 'backbone.synthesis.'
-        self._opt_bufs = list(self.noise_bufs.values())
-        self._all_bufs = self._opt_bufs + list(self.noise_bufs2.values())
+                    if N == 1:
+                        b.copy_(src)
+                        b.requires_grad = prefix == 'backbone.synthesis.'
+                    else:
+                        t = src.expand(shape).contiguous().clone()
+                        t.requires_grad = prefix == 'backbone.synthesis.'
+                        self.noise_maps[prefix + nm] = t
+        if N == 1:
+            self._opt_bufs = list(self.noise_bufs.values())
+            self._all_bufs = self._opt_bufs + list(self.noise_bufs2.values())
+            self._buf_views = None
+        else:
+            self._opt_bufs = [t for k, t in self.noise_maps.items() if k.startswith('backbone.')]
+            self._all_bufs = self._opt_bufs + [t for k, t in self.noise_maps.items() if not k.startswith('backbone.')]
+            self._noise_inject = {k[:-len('.noise_const')]: t for k, t in self.noise_maps.items() if k.startswith('backbone.')}
+            self._buf_views = [t.detach()[i, 0] for t in self._all_bufs for i in range(N)]       # [r,r] views, image-major per map
         if use_graph:       # the schedule values live on the device so that one captured step can be replayed for every step index
             self._scale_t = torch.zeros((), device=dev)
             self._wn = torch.zeros_like(self.w_opt)
@@ -270,6 +295,8 @@ class LatentProjector:
         self.init_ext = torch.tensor([1, 0, 0, 0, 0, -1, 0, 0, 0, 0, -1, 2.7, 0, 0, 0, 1.], device=dev).reshape(1, 4, 4)
         self.canonical_cam = torch.cat([self.init_ext.reshape(1, 16), self.intrinsic], -1)
         self.cam = cam.to(dev) if cam is not None else self.canonical_cam.clone()
+        if self.cam.shape[0] == 1 and N > 1:
+            self.cam = self.cam.repeat(N, 1)
         if optimize_pose:
             # the reference predicts the pose vector (quaternion / 6-D / two angles) with a ResNet34 (scripts/resnet) fine-tuned per
             # image; without a pose_net the vector itself is the optimisable state ("ResNet34 optional stub")
@@ -400,16 +427,24 @@ class LatentProjector:
         with torch.cuda.stream(self._reg_stream):
             # value AND gradient of the regulariser for all 17 buffers from one launch; the gradient is added to the buffers' .grad
             # after backward with one fused multi-tensor add (through autograd it would be 17 AccumulateGrad add launches)
-            reg, reg_grads = hipops.noise_regularizer([b.detach() for b in self._all_bufs], scale=float(self.reg_w), want_grad=True)
+            if self._buf_views is None:
+                reg, reg_grads = hipops.noise_regularizer([b.detach() for b in self._all_bufs], scale=float(self.reg_w), want_grad=True)
+            else:       # batched: the same kernel over the N x 17 per-image maps, gradients assembled per map tensor
+                reg_grads = [torch.empty_like(t) for t in self._all_bufs]
+                reg, _ = hipops.noise_regularizer(self._buf_views, scale=float(self.reg_w), want_grad=True,
+                                                  grads=[g[i, 0] for g in reg_grads for i in range(self.N)])
         w = self.w_opt
         if wn is not None:
             w = w + wn * w_noise_scale
         ws = w.repeat(1, self.num_ws, 1) if w.shape[1] == 1 else w
+        if self._noise_inject is not None:
+            kw = dict(kw, noise_inject=self._noise_inject)
         out = G.synthesis(ws, pred_cam, noise_mode='const', force_fp32=True, **kw)
         img = out['image'] * 127.5 + 128
         if img.shape[2] > 256:
             img = _area_resize(img, 256)
-        dist = (self.target_features - self.feature_net(img)).square().sum()
+        dist_i = (self.target_features - self.feature_net(img)).square().sum(1)      # per image; independent trajectories: the sum's
+        dist = dist_i.sum()                                                           # gradient is each image's own gradient
         cur.wait_stream(self._reg_stream)
         loss = dist + reg                         # reported value; only `dist` (and the warping term) goes through autograd
         warp = None
@@ -434,8 +469,8 @@ class LatentProjector:
             self.optimizer.step()
         if self.optimize_pose:
             self.translation_optimizer.step()
-        hipops.noise_normalize_(self._all_bufs)        # buf -= mean; buf *= rsqrt(mean(buf^2))   (w_projector.py:264-270)
-        last = dict(loss=loss.detach(), dist=dist.detach(), reg=reg.detach() if torch.is_tensor(reg) else reg, image=out['image'].detach(),
+        hipops.noise_normalize_(self._all_bufs if self._buf_views is None else self._buf_views)   # buf -= mean; buf *= rsqrt(mean(buf^2)) (w_projector.py:264-270)
+        last = dict(loss=loss.detach(), dist=dist.detach(), dist_per_image=dist_i.detach(), reg=reg.detach() if torch.is_tensor(reg) else reg, image=out['image'].detach(),
                     cam=pred_cam.detach(), ws=ws.detach())
         if warp is not None:
             last['warp'] = warp.detach()

@@ -117,10 +117,11 @@ class SynthesisLayer(ReferenceStateMixin, torch.nn.Module):
         if styles is None:
             styles = self.affine(w)
         noise = None
-        if self.use_noise and noise_mode == 'random':
-            noise = noise_inject if noise_inject is not None else \
-                torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device)
-        if self.use_noise and noise_mode == 'const':
+        if self.use_noise and noise_mode != 'none' and noise_inject is not None:
+            noise = noise_inject             # per-sample noise [N,1,res,res] supplied by the caller: recorded draws ('random') or the
+        elif self.use_noise and noise_mode == 'random':      # per-image optimised noise maps of a batched latent projection ('const')
+            noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device)
+        elif self.use_noise and noise_mode == 'const':
             noise = self.noise_const
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return fused.ModConvLayerFn.apply(x, self.weight, styles, noise, self.noise_strength if noise is not None else None, self.bias,

@@ -37,8 +37,7 @@ import torch  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide, dense bf16 (never the 2:1-sparsity figure)
 PRODUCTS = {'f32': 1, 'bf16x6': 6, 'bf16x3': 3, 'f16x3': 3}      # MFMA products executed per algorithmic fp32 product
-CONV_TRAFFIC_BYTES = 209.9e6       # HBM bytes per launch of the dominant kernel (both epilogue instantiations, launch-weighted): rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/r01_bench_c2_summary.md
-DOMINANT = 0                        # tile configuration id of conv_igemm_kernel<128,128,2,2>
+TRAFFIC_TABLE = os.path.join(ROOT, 'profiles', 'traffic_table.json')     # per-kernel HBM bytes per launch from the committed rocprofv3 PMC passes
 
 
 def cpu_baseline_c2(seconds_budget=30.0):
@@ -81,14 +80,29 @@ def main():
     ap.add_argument('--precision', default=None, choices=sorted(PRODUCTS) + ['auto'],
                     help="matrix-core arithmetic of the implicit GEMMs (default 'auto': f16x3 for the modulated convs, bf16x6 elsewhere)")
     ap.add_argument('--wplus', action='store_true')
+    ap.add_argument('--images-per-gpu', type=int, default=1,
+                    help='images inverted as one batch on every GPU (1 = config C2; 8 = the per-GPU share of config C5: 64 images on 8 GPUs)')
+    ap.add_argument('--no-final-psnr', action='store_true', help='skip the full-budget (400 + 400 steps) inversion that reports the final PSNR')
     ap.add_argument('--loss-net', default='stub', choices=['stub', 'vgg16'],
                     help="feature network of the LPIPS term: 'stub' = the small fixed conv pyramid the C2 workload is defined with (SURVEY.md "
                          "section 8d); 'vgg16' = the full VGG16-LPIPS architecture (random weights) on the same kernels")
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # not under torch.distributed.run: launch the ranks ourselves (one process per GPU, RCCL rendezvous on the loopback address)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     from inv3d_amd import dist as D
     rank, world, local = D.init_from_env('nccl')
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback in the product path)'
+    assert world == args.gpus, f'--gpus {args.gpus} but the launcher started {world} rank(s)'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
@@ -100,11 +114,12 @@ def main():
 
     G = S.make_generator(device=dev)
     S.load_synthetic_weights(G, seed=0)
-    # per-rank independent image: target = render of a different latent by the same generator (so PSNR is meaningful)
-    cam = S.synth_cameras(world, seed=2)[rank:rank + 1].to(dev)
+    # per-rank independent images: targets = renders of different latents by the same generator (so PSNR is meaningful)
+    M = args.images_per_gpu
+    cam = S.synth_cameras(world * M, seed=2)[rank * M:(rank + 1) * M].to(dev)
     with torch.no_grad():
-        ws_t = S.synth_ws(14, 512, world, seed=3)[rank:rank + 1].to(dev)
-        target = G.synthesis(ws_t, cam, noise_mode='const', force_fp32=True)['image'].clamp(-1, 1)
+        ws_t = S.synth_ws(14, 512, world * M, seed=3)[rank * M:(rank + 1) * M].to(dev)
+        target = torch.cat([G.synthesis(ws_t[i:i + 1], cam[i:i + 1], noise_mode='const', force_fp32=True)['image'].clamp(-1, 1) for i in range(M)])
     use_graph = not args.no_graph
     feature_net = None
     if args.loss_net == 'vgg16':
@@ -126,11 +141,16 @@ def main():
     if use_graph:                       # set-up, not a step of the benchmark: eager passes + the capture of the step into a HIP graph
         for _ in range(proj._graph_warmup + 1):
             one_step()
+        if proj._graph is None:         # a number measured on the eager fallback must not pass for the captured step
+            raise RuntimeError(f'HIP graph capture of the step failed: {proj.graph_capture_error}')
     for _ in range(args.warmup):
         one_step()
+    def profiler():
+        return H.LaunchProfiler()           # every implicit-GEMM launch (grouped by kernel afterwards) + the renderer's forward / backward spans
+
     prof = None
     if not args.no_roofline and not use_graph:
-        prof = H.LaunchProfiler(only_config=DOMINANT)
+        prof = profiler()
         H.PROFILER = prof
     torch.cuda.synchronize()
     D.barrier()
@@ -142,7 +162,7 @@ def main():
     elapsed = time.perf_counter() - t0
     H.PROFILER = None
     elapsed = D.max_over_ranks(elapsed, dev)
-    final_psnr = float(psnr_01(proj.last['image'], target))
+    psnr_now = float(psnr_01(proj.last['image'], target))
     roofline_pass = 'HIP events around every launch of the kernel inside the timed region'
     if not args.no_roofline and use_graph:
         # HIP events cannot bracket a kernel inside a captured graph: the per-launch durations of the dominant kernel come from an
@@ -151,47 +171,91 @@ def main():
         eager = LatentProjector(G, target, num_steps=400, cam=cam, wplus=args.wplus, seed=100 + rank, use_graph=False, feature_net=feature_net)
         eager.preheat = 0
         one_step(eager)
-        prof = H.LaunchProfiler(only_config=DOMINANT)
+        prof = profiler()
         H.PROFILER = prof
         for _ in range(args.steps):
             one_step(eager)
         torch.cuda.synchronize()
         H.PROFILER = None
+        del eager
 
-    roof = None
+    roof = roof_r = None
     if prof is not None:
+        traffic = json.load(open(TRAFFIC_TABLE)) if os.path.exists(TRAFFIC_TABLE) else {}
         summ = prof.summary()
-        dom = summ.get(DOMINANT)
+        dom_id = max(summ, key=lambda k: summ[k]['ms']) if summ else None      # the kernel with the largest share of the step
+        dom = summ.get(dom_id)
         if dom and dom['ms'] > 0:
             ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+            is_v2 = dom_id == H.V2_CONFIG
             nprod = PRODUCTS[prec_name]
             peak = FP32_MFMA_PEAK_TFLOPS if prec_name == 'f32' else BF16_MFMA_PEAK_TFLOPS / nprod
-            kern = ('conv_igemm_kernel<128,128,2,2,0,*> (v_mfma_f32_32x32x2_f32)' if prec_name == 'f32' else
-                    'conv_igemm_kernel<128,128,2,2,%d,*> (fp32 in/out, %d x v_mfma_f32_32x32x16_%s per fp32 product)' % (
-                        H.PRECISIONS[prec_name], nprod, 'f16' if prec_name == 'f16x3' else 'bf16'))
+            if is_v2:
+                kern, tkey = 'conv_v2_kernel<9> (pre-split fp16 pieces, LDS-DMA staged halo; fp32 in/out, 3 x v_mfma_f32_32x32x16_f16 per fp32 product)', 'conv_v2_kernel<9>'
+            else:
+                kern = 'conv_igemm_kernel<%s,%d,*> (fp32 in/out, %d x MFMA per fp32 product)' % (H.TILE_NAMES.get(dom_id, '?'), H.PRECISIONS[prec_name], nprod)
+                tkey = 'conv_igemm_kernel<%s>' % H.TILE_NAMES.get(dom_id, '?')
+            tr = traffic.get(tkey, {})
+            per_launch_ref = tr.get('gflop_per_launch')
+            tbytes = tr.get('bytes_per_launch')
+            if tbytes is not None and per_launch_ref:           # the PMC pass ran the same kernel: scale by the work of this run's launches
+                tbytes = tbytes * (dom['flops'] / dom['launches'] / 1e9) / per_launch_ref
+            all_ms = sum(v['ms'] for v in summ.values())
+            all_fl = sum(v['flops'] for v in summ.values())
             roof = dict(bound='mfma', kernel=kern, achieved=round(ach, 2),
-                        peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4), traffic=CONV_TRAFFIC_BYTES,
+                        peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4), traffic=tbytes, traffic_source=tr.get('source'),
                         peak_basis=('fp32 matrix peak' if prec_name == 'f32' else 'dense 16-bit matrix peak 2500 / %d products' % nprod),
+                        measured_mfma_ceiling_tflops=round(1550.0 / nprod, 1) if prec_name != 'f32' else None,
+                        ceiling_note='a register-only v_mfma_f32_32x32x16_f16 loop sustains 1.5-1.6 PFLOP/s on random data on this chip (clock throttling; 2.0-2.3 on zeros): tools/proto/mfma_peak.hip',
                         frac_of_fp32_mfma_peak=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), mfma_executed_tflops=round(ach * nprod, 1),
                         launches_per_step=dom['launches'] / args.steps, gflop_per_launch=round(dom['flops'] / dom['launches'] / 1e9, 3),
-                        avg_launch_ms=round(dom['ms'] / dom['launches'], 4), timing=roofline_pass)
+                        avg_launch_ms=round(dom['ms'] / dom['launches'], 4), share_of_conv_time=round(dom['ms'] / all_ms, 3),
+                        all_conv_tflops=round(all_fl / (all_ms * 1e-3) / 1e12, 1), all_conv_ms_per_step=round(all_ms / args.steps, 3),
+                        all_conv_frac=round(all_fl / (all_ms * 1e-3) / 1e12 / peak, 4), timing=roofline_pass)
+        sp = prof.span_summary()
+        if 'render_fwd' in sp and 'render_bwd' in sp:
+            # fused renderer forward 34.1 MB per image (planes 25.17 + rays 0.39 + uniforms 6.29 + outputs 2.23), backward
+            # adds the 25.17 MB plane-gradient write and re-reads the forward's inputs
+            alg = (34.1e6 + 34.1e6 + 25.17e6) * M
+            t = (sp['render_fwd']['ms'] + sp['render_bwd']['ms']) / args.steps * 1e-3
+            rt = traffic.get('renderer', {})
+            roof_r = dict(bound='hbm', kernel='volume renderer: coarse_pos + decode_rows x2 + render<2>,<3> (forward); render<1> + decode_rows<true> + scatter_* (backward)',
+                          achieved=round(alg / t / 1e9, 1), peak=8000.0, unit='GB/s', frac=round(alg / t / 1e9 / 8000.0, 4),
+                          algorithmic_bytes_per_step=alg, fwd_ms=round(sp['render_fwd']['ms'] / args.steps, 3), bwd_ms=round(sp['render_bwd']['ms'] / args.steps, 3),
+                          traffic=rt.get('bytes_per_step'), traffic_source=rt.get('source'), timing=roofline_pass)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_c2()
+    final = None
+    if rank == 0 and world == 1 and not args.no_final_psnr:
+        # second half of the metric: one image through the whole budget of configs/hyperparameters.py (400 latent + 400 pivotal-tuning steps)
+        from inv3d_amd.coach import InversionCoach
+        del proj
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        coach = InversionCoach(G, first_inv_steps=400, max_pti_steps=400, lpips_threshold=0.0, use_graph=True, early_stop_interval=50, w_avg_samples=0,
+                               feature_net=feature_net)
+        res = coach.invert('bench', target[:1], cam[:1])
+        torch.cuda.synchronize()
+        final = dict(final_psnr_db=round(res.psnr_tuned, 3), pivot_psnr_db=round(res.psnr_pivot, 3), steps=res.steps_a + res.steps_b,
+                     wall_s=round(time.perf_counter() - t1, 2), note='400 latent steps (graph-replayed) + 400 pivotal-tuning steps, stub feature pyramid, synthetic target')
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        line = dict(metric='inversion-steps/sec (G fwd+bwd, 512^2 FFHQ EG3D) at 1/2/4/8 GPUs; final PSNR', value=round(world * args.steps / elapsed, 3),
+        wl = ('C2: FFHQ 512^2 single-image latent inversion step' if M == 1 else
+              f'C5 per-GPU share: {M} FFHQ 512^2 latent inversions as one batch (independent trajectories)')
+        line = dict(metric='inversion-steps/sec (G fwd+bwd, 512^2 FFHQ EG3D) at 1/2/4/8 GPUs; final PSNR', value=round(world * M * args.steps / elapsed, 3),
                     unit='steps/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True,
                     scaling='weak', vs_baseline=None, dtype={'f32': 'f32', 'bf16x6': 'f32 (bf16x6 split products, fp32-equivalent)',
                            'f16x3': 'f32 (modulated convs: two-piece fp16 split, 3 products, range-normalised; other GEMMs bf16x6; fp32-equivalent)',
                            'bf16x3': 'f32 storage, bf16x3 products (~2^-15)'}[prec_name], data='synthetic',
-                    config=dict(workload='C2: FFHQ 512^2 single-image latent inversion step (Phase A, w%s + 17 noise buffers; G.synthesis fwd+bwd, '
-                                         '128^2 x 96-sample rendering, %s feature distance + noise regulariser, Adam)' % ('+' if args.wplus else '', 'stub-LPIPS' if args.loss_net == 'stub' else 'VGG16-LPIPS (256^2, random weights)'),
-                                images_per_gpu=1, generator='ffhqrebalanced512-128-shaped, 30.66 M params, random-init (synthetic weights)',
-                                parallelism=f'{world} independent images, 1 per GPU; stat all-reduce only',
-                                launch='one HIP graph replay per step' if (use_graph and proj._graph is not None) else 'eager (one launch per kernel)',
-                                psnr_after_timed_steps_db=round(final_psnr, 3)),
-                    roofline=roof, cpu_baseline=cpu)
+                    config=dict(workload=wl + ' (Phase A, w%s + 17 noise maps per image; G.synthesis fwd+bwd, 128^2 x 96-sample rendering, %s feature '
+                                              'distance + noise regulariser, Adam)' % ('+' if args.wplus else '', 'stub-LPIPS' if args.loss_net == 'stub' else 'VGG16-LPIPS (256^2, random weights)'),
+                                images_per_gpu=M, image_steps_per_timed_step=M, world_size=world,
+                                generator='ffhqrebalanced512-128-shaped, 30.66 M params, random-init (synthetic weights)',
+                                parallelism=f'{world * M} independent images, {M} per GPU; stat all-reduce only',
+                                launch='one HIP graph replay per step' if use_graph else 'eager (one launch per kernel)',
+                                psnr_after_timed_steps_db=round(psnr_now, 3)),
+                    roofline=roof, roofline_renderer=roof_r, cpu_baseline=cpu, final_psnr=final)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

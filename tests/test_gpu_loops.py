@@ -298,3 +298,36 @@ def test_tuner_loop_vs_reference(golden):
         for key in [k[len(tag) + 3:] for k in d.files if k.startswith(tag + '_p.')]:
             e = float((sd[key].detach().cpu() - torch.from_numpy(np.asarray(d[f'{tag}_p.{key}']))).abs().max())
             assert e <= 0.1 * 3e-4 * n + 1e-6, (tag, key, e)          # a tenth of the accumulated Adam step
+
+
+def test_batched_projection_equals_sequential_c5():
+    """Config C5 (per GPU): N images inverted as ONE batch (per-image latent, camera, noise maps, Adam state; shared frozen weights) follow
+    the same trajectories as N separate N = 1 projections -- per-sample modulation makes the batch N independent problems."""
+    from inv3d_amd.inversion import LatentProjector
+    from inv3d_amd import synthetic as S
+    cfg, P, G, cam, u1, u2, target, init_noise1 = _setup()
+    N, steps = 3, 8
+    cams = O.synth_cameras(N, seed=5)
+    with torch.no_grad():
+        targets = torch.cat([O.synthesis(P, cfg, O.synth_ws(cfg, 1, seed=30 + i), cams[i:i + 1], u1, u2, noise_mode='const')['image'].clamp(-1, 1) for i in range(N)])
+    w0 = 0.3 * O._randn('w0b', 1, (N, 1, cfg.w_dim))
+    noise = {k: O._randn('initb.' + k, 2, (N, 1) + tuple(v.shape)) for k, v in P.items() if k.endswith('noise_const')}
+    U1, U2 = O.make_uniforms(cfg, N, seed=9)
+    R = U1.shape[1]
+    wns = [O._randn(f'wnb{k}', 3, (N, 1, cfg.w_dim)) for k in range(steps)]
+    batched = LatentProjector(G, targets.to(DEV), num_steps=30, cam=cams.to(DEV), init_noise=noise, start_w=w0)
+    for k in range(steps):
+        hb = batched.step(w_noise=wns[k], render_uniforms=(U1.to(DEV), U2.to(DEV)))
+    assert hb['image'].shape[0] == N and hb['dist_per_image'].shape == (N,)
+    for i in range(N):
+        single = LatentProjector(G, targets[i:i + 1].to(DEV), num_steps=30, cam=cams[i:i + 1].to(DEV), init_noise={k: v[i, 0] for k, v in noise.items()},
+                                 start_w=w0[i:i + 1])
+        for k in range(steps):
+            hs = single.step(w_noise=wns[k][i:i + 1], render_uniforms=(U1[i:i + 1].to(DEV), U2[i * R:(i + 1) * R].to(DEV)))
+        assert float((batched.w_opt[i:i + 1] - single.w_opt).abs().max()) < 2e-4, i
+        assert abs(float(hb['dist_per_image'][i]) - float(hs['dist'])) <= 2e-3 * max(1.0, abs(float(hs['dist'])))
+        drift = abs(_psnr(hb['image'][i:i + 1], targets[i:i + 1]) - _psnr(hs['image'], targets[i:i + 1]))
+        assert drift <= 1e-3, f'image {i}: final PSNR drift {drift:.2e} dB between the batched and the sequential run'
+        key = 'backbone.synthesis.b32.conv1.noise_const'
+        err = (batched.noise_maps[key][i, 0] - single.noise_bufs['b32.conv1.noise_const']).abs()
+        assert float((err <= 1e-4).float().mean()) >= 0.99 and float(err.max()) <= 0.1
