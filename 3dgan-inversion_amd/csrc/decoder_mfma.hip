@@ -86,7 +86,9 @@ __device__ __forceinline__ void gather_split(const float* __restrict__ pn, int H
                                              float (&f)[16]) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) f[r] = 0.f;
-#pragma unroll
+    // one plane at a time (16 sixteen-byte loads in flight per lane): fully unrolled, the scheduler hoists all 48 loads and their
+    // 192 destination registers, which pins the backward kernel at ONE wave per SIMD and leaves the gather latency fully exposed
+#pragma unroll 1
     for (int pl = 0; pl < 3; ++pl) {
         float u, v;
         plane_uv(pl, x * cs, y * cs, z * cs, u, v);
@@ -113,8 +115,14 @@ __device__ __forceinline__ void gather_split(const float* __restrict__ pn, int H
     for (int r = 0; r < 16; ++r) f[r] = f[r] / 3.f;
 }
 
+#ifndef DEC_OCC_BWD
+#define DEC_OCC_BWD 1
+#endif
+#ifndef DEC_OCC_FWD
+#define DEC_OCC_FWD 1
+#endif
 template <bool BWD>
-__global__ void __launch_bounds__(256) decode_rows_kernel(const DecodeArgs a) {
+__global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_rows_kernel(const DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const Frags F = setup_frags<BWD>(lds, a);
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
@@ -254,7 +262,7 @@ __global__ void __launch_bounds__(256) decode_rows_kernel(const DecodeArgs a) {
         }
         if (a.gc_rows) {
             float gx = 0.f, gy = 0.f, gz = 0.f;
-#pragma unroll
+#pragma unroll 1
             for (int pl = 0; pl < 3; ++pl) {
                 float u, v;
                 plane_uv(pl, px * a.cs, py * a.cs, pz * a.cs, u, v);

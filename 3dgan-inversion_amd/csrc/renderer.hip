@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(256) render_coord_reduce_kernel(const float4* 
 //   accumulates its pairs into a 17x17x32 LDS tile with conflict-free ds_add_f32 (lane = channel) and flushes the tile
 //   once.  Global atomics drop to ~9 K per tile.
 // =========================================================================================================
-constexpr int TS = 16;
+constexpr int TS = 15;          // interior texels per tile side; a tile's accumulator covers TS + 1 = 16 rows / columns (the last one is shared with the neighbour)
 
 __device__ __forceinline__ bool plane_cell(const float4 pos, int pl, float cs, int Hp, int Wp, int& x0, int& y0, float& wx1, float& wy1) {
     float u, v;
@@ -608,28 +608,39 @@ __global__ void __launch_bounds__(1024) scatter_scan_kernel(const int* __restric
     if (t == 1023) { offsets[n] = part[1023]; chunk_offsets[n] = partc[1023]; }
 }
 
-// One block per (bin, chunk of <= CHUNK pairs).  Row-owner accumulation, no atomics in the loop and all lanes busy:
-//   * the 17x17x32 tile lives in LDS; tile row r is owned by exactly one half-wave (32 lanes = the 32 channels),
-//   * the chunk is streamed in batches: gradient rows + per-pair (cell, weights) records are staged in LDS and the pairs are
-//     bucketed by their tile row (17+1 short lists, integer LDS counters),
-//   * the owner of row r walks the pairs whose upper corners (list r) or lower corners (list r-1) lie in its row and does plain
-//     read-modify-write on its row (in-order LDS ops of one wave; no other wave touches the row).
-// Measured alternatives for this scatter on MI355X: global float atomics 30 ms, LDS float atomics 4.0 ms (~0.3 lane-op/clk/CU),
-// one-thread-per-cell owner-computes 1.7 ms (2-4 active lanes per hit).
-constexpr int ACC_THREADS = 512;
-constexpr int ACC_BATCH = 128;
+// One block per (bin, chunk of <= CHUNK pairs): the accumulation of a tile-row pair is a small GEMM on the fp32 matrix cores.
+//   * wave w owns the pairs whose upper texel row is tile row w - 1 (list w; each pair is in exactly one list; list 0 = the pairs above
+//     the first row, image border only).  A pair adds  wy_half * wx_x * g[c]  to (half, column x, channel c) for half in {upper, lower}
+//     and x in {lx, lx+1}:  Acc[(half,x)][c] += sum_e C[(half,x)][e] * G[e][c]  with a 32 x E coefficient matrix (two rows x 16 columns)
+//     that has four non-zeros per pair.  v_mfma_f32_32x32x2_f32 takes two pairs per instruction: lane (m, k) builds C[m][e_k] from the
+//     pair record, lane (c, k) supplies g[e_k][c]; exact fp32 products and accumulation.  No read-modify-write chain, no atomics, no
+//     dynamically indexed registers in the loop: per two pairs three LDS reads, ~10 VALU and one MFMA.
+//   * the chunk is streamed in batches of 256 pairs: gradient rows + (cell, weights) records staged in LDS, bucketed by tile row;
+//   * at the end the 16 row pairs are combined in the LDS tile (every tile row has exactly one "lower" and one "upper" owner) and the
+//     16 x 16 x 32 tile is flushed with one atomic per touched cell channel.
+// History of this scatter on MI355X (1.57 M samples x 3 planes x 4 corners x 32 channels): global float atomics 30 ms, LDS float
+// atomics 4.0 ms (~0.3 lane-op/clk/CU), one-thread-per-cell owner-computes 1.7 ms, half-wave row owner with LDS read-modify-write
+// 0.82 ms (a chain of ~5 dependent LDS round trips per pair and row), register accumulators selected by a scalar switch 0.48 ms /
+// by indexed-VGPR moves 0.40 ms (0.14 ms of it the row gather), this form: see DESIGN.md.
+constexpr int ACC_THREADS = 1024;
+constexpr int ACC_BATCH = 256;
 constexpr int TROWS = TS + 1;
+static_assert(TROWS == 16 && ACC_THREADS == 64 * TROWS, "one wave per list, two rows x 16 columns = the 32 rows of the MFMA tile");
+typedef float acc16_t __attribute__((ext_vector_type(16)));
 
 __global__ void __launch_bounds__(ACC_THREADS) scatter_accum_kernel(const float* __restrict__ df, const float4* __restrict__ pos,
                                                                     const int* __restrict__ offsets, const int* __restrict__ chunk_offsets,
                                                                     const int* __restrict__ ids, float* __restrict__ d_planes, float cs, int Hp, int Wp,
                                                                     int ldp, int ntx, int nty, int nb) {
-    __shared__ __attribute__((aligned(16))) float tile[TROWS * TROWS * FC];
-    __shared__ __attribute__((aligned(16))) float dfb[ACC_BATCH * FC];
-    __shared__ __attribute__((aligned(16))) float4 meta[ACC_BATCH];      // (lx, ly) as int bits, wx1, wy1
-    __shared__ int cnt[TROWS + 1];                                       // list k holds the pairs with ly == k - 1
-    __shared__ unsigned short lists[(TROWS + 1) * ACC_BATCH];
+    constexpr int STAGE_FLOATS = ACC_BATCH * FC + ACC_BATCH * 4;          // gradient rows + pair records
+    constexpr int TILE_FLOATS = TROWS * TROWS * FC;
+    __shared__ __attribute__((aligned(16))) float sbuf[STAGE_FLOATS > TILE_FLOATS ? STAGE_FLOATS : TILE_FLOATS];
+    __shared__ int cnt[TROWS];                                           // list k holds the pairs with ly == k - 1
+    __shared__ unsigned short lists[TROWS * ACC_BATCH];
     __shared__ int sbin;
+    float* dfb = sbuf;
+    float4* meta = reinterpret_cast<float4*>(sbuf + ACC_BATCH * FC);     // (lx, ly) as int bits, wx1, wy1
+    float* tile = sbuf;                                                  // after the last batch
     const int tid = threadIdx.x;
     if (tid == 0) {
         int lo = 0, hi = nb;
@@ -638,8 +649,7 @@ __global__ void __launch_bounds__(ACC_THREADS) scatter_accum_kernel(const float*
         else while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (chunk_offsets[mid] <= me) lo = mid; else hi = mid; }
         sbin = lo;
     }
-    if (tid <= TROWS) cnt[tid] = 0;
-    for (int i = tid; i < TROWS * TROWS * FC; i += ACC_THREADS) tile[i] = 0.f;
+    if (tid < TROWS) cnt[tid] = 0;
     __syncthreads();
     const int bin = sbin;
     if (bin < 0) return;
@@ -651,27 +661,37 @@ __global__ void __launch_bounds__(ACC_THREADS) scatter_accum_kernel(const float*
     const int pl = (bin / ntile) % 3;
     const int t = bin % ntile;
     const int ty0 = (t / ntx) * TS, tx0 = (t % ntx) * TS;
-    const int c = tid & 31, hw = tid >> 5;                 // channel, half-wave id (16 half-waves)
+    const int wave = tid >> 6, lane = tid & 63, c = lane & 31, kk = lane >> 5;
+    const int mx = c & 15, mhalf = c >> 4;                               // this lane's row of the coefficient matrix: (half, column)
+
+    acc16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
     // software pipeline: the (id -> position, id -> gradient row) loads of batch b+1 are in flight while batch b is accumulated
     static_assert(ACC_BATCH * (FC / 4) == 2 * ACC_THREADS, "two float4 of the gradient rows per thread");
     float4 r_meta = make_float4(0, 0, 0, 0), r_df0, r_df1;
     int r_ly = 0;
+    // (batches are 256 CONSECUTIVE pairs of the chunk: taking every nbat-th pair instead, or placing the pairs of a bin in a pseudo-random
+    //  order, evens out the 16 lists further -- the largest list of a batch holds ~30 of 256 pairs as it is -- but was measured slower,
+    //  426 / 608 vs 389 us: the gather of the 128-byte gradient rows loses its locality)
+    auto pair_at = [&](int b0, int i) { return b0 + i; };
+    auto count_of = [&](int b0) { return min(ACC_BATCH, end - b0); };
     auto fetch = [&](int b0) {
-        const int nbatch = min(ACC_BATCH, end - b0);
+        const int nbatch = count_of(b0);
         if (tid < nbatch) {
-            const int row = ids[b0 + tid] >> 2;
+            const int row = ids[pair_at(b0, tid)] >> 2;
             int x0, y0; float wx1, wy1;
             plane_cell(pos[row], pl, cs, Hp, Wp, x0, y0, wx1, wy1);
             r_ly = y0 - ty0;                                             // in [-1, TS-1]
             r_meta = make_float4(__int_as_float(x0 - tx0), __int_as_float(r_ly), wx1, wy1);
         }
-        const int j0 = tid >> 3, q = tid & 7;                           // rows j0 and j0 + 64
-        r_df0 = j0 < nbatch ? reinterpret_cast<const float4*>(df + (int64_t)(ids[b0 + j0] >> 2) * FC)[q] : make_float4(0, 0, 0, 0);
-        r_df1 = j0 + 64 < nbatch ? reinterpret_cast<const float4*>(df + (int64_t)(ids[b0 + j0 + 64] >> 2) * FC)[q] : make_float4(0, 0, 0, 0);
+        const int j0 = tid >> 3, q = tid & 7;                           // rows j0 and j0 + 128
+        r_df0 = j0 < nbatch ? reinterpret_cast<const float4*>(df + (int64_t)(ids[pair_at(b0, j0)] >> 2) * FC)[q] : make_float4(0, 0, 0, 0);
+        r_df1 = j0 + 128 < nbatch ? reinterpret_cast<const float4*>(df + (int64_t)(ids[pair_at(b0, j0 + 128)] >> 2) * FC)[q] : make_float4(0, 0, 0, 0);
     };
     auto commit = [&](int b0) {
-        const int nbatch = min(ACC_BATCH, end - b0);
+        const int nbatch = count_of(b0);
         if (tid < nbatch) {
             meta[tid] = r_meta;
             const int k = r_ly + 1;
@@ -685,33 +705,54 @@ __global__ void __launch_bounds__(ACC_THREADS) scatter_accum_kernel(const float*
     for (int b0 = beg; b0 < end; b0 += ACC_BATCH) {
         const bool more = b0 + ACC_BATCH < end;
         if (more) fetch(b0 + ACC_BATCH);
-        for (int r = hw; r < TROWS; r += ACC_THREADS / 32) {
-            float* trow = tile + r * TROWS * FC + c;
+        {
+            const int m = cnt[wave];
+            const unsigned short* lst = lists + wave * ACC_BATCH;
+            // lanes 0-31 take pair e, lanes 32-63 pair e + 1; four MFMA steps per trip with all of their LDS reads issued up front (the
+            // list is a pointer chase: entry -> record -> gradient row; unpipelined it costs ~5x the MFMA time when one wave holds a
+            // whole batch, which happens: consecutive samples of a ray fall into the same texel row)
+            for (int e = 0; e < m; e += 8) {
+                int j[4];
+                float4 mt[4];
+                float g[4];
 #pragma unroll
-            for (int part = 0; part < 2; ++part) {                        // part 0: upper corners (ly == r), part 1: lower corners (ly == r-1)
-                const int k = part == 0 ? r + 1 : r;
-                if (part == 0 && r == TS) continue;                       // ly == TS never occurs
-                const int m = cnt[k];
-                const unsigned short* lst = lists + k * ACC_BATCH;
-                for (int e = 0; e < m; ++e) {
-                    const int j = lst[e];
-                    const float4 mt = meta[j];
-                    const float g = dfb[j * FC + c];
-                    const int lx = __float_as_int(mt.x);
-                    const float wy = part == 0 ? 1.f - mt.w : mt.w;
-                    if (lx >= 0) trow[lx * FC] += (1.f - mt.z) * wy * g;
-                    if (lx + 1 <= TS) trow[(lx + 1) * FC] += mt.z * wy * g;
+                for (int q = 0; q < 4; ++q) j[q] = lst[min(e + 2 * q + kk, ACC_BATCH - 1)] & (ACC_BATCH - 1);      // stale entries past m: masked below
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { mt[q] = meta[j[q]]; g[q] = dfb[j[q] * FC + c]; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool live = e + 2 * q + kk < m;
+                    const int lx = __float_as_int(mt[q].x);
+                    const float wx = mx == lx ? 1.f - mt[q].z : (mx == lx + 1 ? mt[q].z : 0.f);
+                    const float wy = mhalf ? mt[q].w : 1.f - mt[q].w;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(live ? wx * wy : 0.f, live ? g[q] : 0.f, acc, 0, 0, 0);
                 }
             }
         }
         __syncthreads();
-        if (tid <= TROWS) cnt[tid] = 0;
+        if (tid < TROWS) cnt[tid] = 0;
         __syncthreads();
         if (more) commit(b0 + ACC_BATCH);
         __syncthreads();
     }
+    // Combine the row pairs in the LDS tile.  Accumulator element r of a lane is coefficient row m = (r&3) + 8 (r>>2) + 4 (lane>>5), i.e.
+    // (half, column) = (m >> 4, m & 15), for channel lane & 31.  List `wave` covers tile rows wave - 1 (upper) and wave (lower).
+    // Lower halves first (rows 0..15, one owner each: plain stores), then the upper halves (rows 0..14: one read-modify-write owner each).
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (m >= 16) tile[(wave * TROWS + (m & 15)) * FC + c] = acc[r];
+    }
     __syncthreads();
-    for (int i = tid; i < TROWS * TROWS * FC; i += ACC_THREADS) {
+    if (wave >= 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * kk;
+            if (m < 16) tile[((wave - 1) * TROWS + m) * FC + c] += acc[r];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < TILE_FLOATS; i += ACC_THREADS) {
         const float v = tile[i];
         if (v != 0.f) {
             const int cell = i / FC, ch = i - cell * FC;
