@@ -1058,11 +1058,40 @@ def gen_pose_net():
     save('pose_net', 1e-5, **out)
 
 
+def gen_e4e():
+    """One-shot latent encoder: the reference's own Encoder4Editing(50, 'ir_se') in eval mode.  Its module
+    imports models.e4e.stylegan2.model, whose `op` sub-package JIT-compiles CUDA extensions at import; the encoder uses none of them
+    (EqualLinear without activation), so the sub-package is replaced by an empty stand-in for the import."""
+    print('e4e encoder (IR-SE-50 + 18 style heads)')
+    import types as _types
+    from oracle import e4e_oracle as EO
+    stub = _types.ModuleType('models.e4e.stylegan2.op')
+    for nm in ('fused_act', 'upfirdn2d'):
+        sub = _types.ModuleType(f'models.e4e.stylegan2.op.{nm}')
+        sub.FusedLeakyReLU = sub.fused_leaky_relu = sub.upfirdn2d = None
+        sys.modules[f'models.e4e.stylegan2.op.{nm}'] = sub
+        setattr(stub, nm, sub)
+    stub.FusedLeakyReLU = stub.fused_leaky_relu = stub.upfirdn2d = None
+    stub.__path__ = []
+    sys.modules['models.e4e.stylegan2.op'] = stub
+    from models.e4e.encoders.psp_encoders import Encoder4Editing
+    net = Encoder4Editing(50, 'ir_se').eval()
+    sd = EO.synth_state(seed=5)
+    missing, unexpected = net.load_state_dict(sd, strict=True)
+    img = O._randn('e4e_img', 5, (2, 3, 64, 64)).clamp(-1, 1) * 127.5 + 127.5          # the projector feeds the [0,255] image (w_projector.py:71-74,100)
+    with torch.no_grad():
+        y = net(img)
+        yo = EO.forward(sd, img)
+    check(yo, y, 2e-5, 'e4e codes')
+    assert float(y[:, 0].abs().max()) > 1e-3 and float((y[:, 3] - y[:, 0]).abs().max()) > 1e-3
+    save('e4e', 2e-5, img=img, codes=y)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
     gens = dict(bias_act=gen_bias_act, upfirdn2d=gen_upfirdn2d, filtered_lrelu=gen_filtered_lrelu, conv=gen_conv2d_resample, renderer=gen_renderer,
                 graph_small=gen_graph_small, graph_full=gen_graph_full, loss=gen_loss_glue, projector_loop=gen_projector_loop, tuner_loop=gen_tuner_loop,
-                inference=gen_inference, pose_net=gen_pose_net)
+                inference=gen_inference, pose_net=gen_pose_net, e4e=gen_e4e)
     mpath = os.path.join(HERE, 'MANIFEST.json')
     if only and os.path.exists(mpath):
         MANIFEST.update(json.load(open(mpath)).get('fixtures', {}))

@@ -80,3 +80,26 @@ def test_projector_fine_tunes_the_pose_net():
         Q.quat.copy_(q0)
     o = Q.step()
     assert abs(float(o['loss']) - float(outs[0]['loss'])) <= 1e-4 * abs(float(o['loss']))
+
+
+def test_e4e_encoder_vs_reference(golden):
+    """The one-shot latent initialiser (row f2): inv3d_amd.e4e.Encoder4Editing loads the reference's state dict (same keys) and reproduces
+    the reference class's 18 codes on the fixture input; PSPEncoder returns code 0 -- what w_projector.py:100 adds to w_avg."""
+    import numpy as np
+    from inv3d_amd.e4e import Encoder4Editing, PSPEncoder
+    from oracle import e4e_oracle as EO
+    d = golden('e4e')
+    sd = EO.synth_state(seed=5)
+    net = Encoder4Editing(50, 'ir_se')
+    assert set(net.state_dict()) == set(sd)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV)
+    img = torch.from_numpy(np.asarray(d['img'])).to(DEV)
+    ref = torch.from_numpy(np.asarray(d['codes']))
+    y = net(img).cpu()
+    scale = float(ref.abs().max())
+    assert float((y - ref).abs().max()) <= 2e-4 * scale, float((y - ref).abs().max()) / scale
+    psp = PSPEncoder()
+    psp.encoder.load_state_dict(sd)
+    w0 = psp.to(DEV)(img).cpu()
+    assert w0.shape == (2, 512) and float((w0 - ref[:, 0]).abs().max()) <= 2e-4 * scale

@@ -348,3 +348,13 @@ def test_pose_net_oracle(golden):
                 close(g, t(d[f'd{dims}_g.{k}']), 1e-5)
             else:
                 close(g.flatten()[::97], t(d[f'd{dims}_gs.{k}']), 1e-5)
+
+
+def test_e4e_oracle(golden):
+    """oracle/e4e_oracle.py vs the reference's Encoder4Editing(50, 'ir_se') (fixture `e4e`: [0,255] input, all 18 codes)."""
+    from oracle import e4e_oracle as EO
+    d = golden('e4e')
+    sd = EO.synth_state(seed=5)
+    with torch.no_grad():
+        y = EO.forward(sd, t(d['img']))
+    close(y, t(d['codes']), 2e-5)
