@@ -331,10 +331,27 @@ __global__ void __launch_bounds__(256) split_act_kernel(const float* __restrict_
     }
 }
 
+__device__ __forceinline__ float finite_abs(float v) { const float a = fabsf(v); return a < 3.0e38f ? a : 0.f; }     // NaN / inf -> 0
+
 __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, int64_t n, float* out) {
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
-    eg3d_commit_amax(m, out);
+    const int64_t n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = x4[i];
+        m = fmaxf(m, fmaxf(fmaxf(finite_abs(v.x), finite_abs(v.y)), fmaxf(finite_abs(v.z), finite_abs(v.w))));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, finite_abs(x[(n4 << 2) + threadIdx.x]));
+    // one atomic per block: with one per wave a 150 K-element weight tensor spent 28 us queueing on a single address
+    __shared__ float red[4];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m > 0.f && m < 3.0e38f) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+    }
 }
 
 // w: packed [O][T][I] fp32 -> [T][I/16][piece][koct][O] x 8 fp16, unscaled low piece
@@ -438,7 +455,8 @@ extern "C" int eg3d_split_activation(const float* x, const float* in_scale, cons
 
 extern "C" int eg3d_absmax(const float* x, int64_t n, float* out, void* stream) {
     if (!x || !out || n <= 0) return EG3D_ERR_INVALID;
-    const int blocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
+    if (reinterpret_cast<uintptr_t>(x) & 15) return EG3D_ERR_UNSUPPORTED;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(512, n / (256 * 4 * 4)));       // >= 16 elements per thread
     hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, out);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;

@@ -115,11 +115,22 @@ __device__ __forceinline__ void gather_split(const float* __restrict__ pn, int H
     for (int r = 0; r < 16; ++r) f[r] = f[r] / 3.f;
 }
 
+// Compiler-level fence between the phases of a tile.  Without it the scheduler hoists the LDS fragment reads and the gather of later
+// phases above the MFMA chains of earlier ones: 256 VGPRs + 92 AGPRs for the backward kernel (one wave per SIMD, every latency exposed).
+// With it: 137 VGPRs, no spills.
+__device__ __forceinline__ void phase_fence() { asm volatile("" ::: "memory"); }
+
 #ifndef DEC_OCC_BWD
-#define DEC_OCC_BWD 1
+#define DEC_OCC_BWD 3
 #endif
 #ifndef DEC_OCC_FWD
-#define DEC_OCC_FWD 1
+#define DEC_OCC_FWD 4
+#endif
+#ifndef DEC_GRID_BWD
+#define DEC_GRID_BWD 3
+#endif
+#ifndef DEC_GRID_FWD
+#define DEC_GRID_FWD 6
 #endif
 template <bool BWD>
 __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_rows_kernel(const DecodeArgs a) {
@@ -145,6 +156,7 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
         float f[16];
         gather_split(pn, a.Hp, a.Wp, a.ldp, a.cs, px, py, pz, h, f);
 
+        phase_fence();
         // ---- layer 1: PRE^T = W0 F^T + b0 ;  H = softplus(PRE) -----------------------------------------------------------
         f32x16 hid[2];
 #pragma unroll
@@ -161,6 +173,7 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
 #pragma unroll
             for (int r = 0; r < 16; ++r) hid[ht][r] = softplus_fast(hid[ht][r]);
 
+        phase_fence();
         // ---- layer 2: OUT^T = W1c H^T + b1c ; sigma = w1s . H + b1[0] ----------------------------------------------------
         f32x16 out;
         float sig = 0.f;
@@ -189,6 +202,7 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
             continue;
         }
 
+        phase_fence();
         // =========================== backward ===========================
         float2 ag = make_float2(0.f, 0.f);
         if (valid) ag = a.ag[row];
@@ -224,6 +238,7 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a.dump_h[row * HD + 32 * ht + split_idx(r, h)] = hid[ht][r];
         }
+        phase_fence();
         // ---- dH^T = W1c^T dOUT^T + w1s dsigma ;  dPRE = dH * sigmoid(PRE) = dH * (1 - exp(-H)) ---------------------------
         f32x16 dh[2];
 #pragma unroll
@@ -245,6 +260,7 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a.dump_dpre[row * HD + 32 * ht + split_idx(r, h)] = dh[ht][r];
         }
+        phase_fence();
         // ---- dF^T = W0^T dPRE^T -------------------------------------------------------------------------------------------
         f32x16 df;
 #pragma unroll
@@ -300,7 +316,7 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
 int launch_decode(const DecodeArgs& a, bool bwd, hipStream_t st) {
     if (a.M <= 0) return EG3D_OK;
     const int64_t ntiles = (a.M + 31) / 32;
-    const int blocks = (int)std::min<int64_t>((ntiles + 3) / 4, 256 * 4);
+    const int blocks = (int)std::min<int64_t>((ntiles + 3) / 4, 256 * (bwd ? DEC_GRID_BWD : DEC_GRID_FWD));     // persistent: resident blocks per CU x 256 CUs
     if (bwd) hipLaunchKernelGGL(decode_rows_kernel<true>, dim3(blocks), dim3(256), FRAG_FLOATS_BWD * sizeof(float), st, a);
     else hipLaunchKernelGGL(decode_rows_kernel<false>, dim3(blocks), dim3(256), FRAG_FLOATS_FWD * sizeof(float), st, a);
     EG3D_LAUNCH_CHECK();

@@ -348,7 +348,7 @@ __global__ void weight_sqsum_kernel(const float* __restrict__ w, float* __restri
 // wf[o][t*I + i], the data-gradient operand wa[i][t*O + o] and wsq[o][i] = sum_t w^2 (demodulation).  A block handles 32 x 32 (o,i)
 // pairs through LDS so that all three are written in runs of 32 consecutive floats.  Replaces two permute-copies and a reduction per
 // layer and step of the pivotal-tuning phase (weights change every step there).
-constexpr int PK = 32;
+constexpr int PK = 16;      // 16 x 16 (o, i) pairs per block: 1024 blocks for a 512 x 512 layer (32 x 32 left most CUs with a single, serial block)
 __global__ void __launch_bounds__(256) pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wa,
                                                                float* __restrict__ wsq, int O, int I, int T) {
     extern __shared__ float sm[];                       // [PK][PK*T + 1]

@@ -953,6 +953,18 @@ extern "C" int eg3d_render_bwd(const eg3d_render_bwd_params* bp, void* stream) {
     return EG3D_OK;
 }
 
+extern "C" int eg3d_render_query_sizes(const eg3d_render_params* p, eg3d_render_sizes* out) {
+    if (!p || !out || p->N <= 0 || p->R <= 0 || p->Dc <= 0 || p->Df < 0 || p->Cout <= 0) return EG3D_ERR_INVALID;
+    const int64_t NR = (int64_t)p->N * p->R, D = p->Dc > p->Df ? p->Dc : p->Df, S = NR * 2 * D;
+    out->S = S;
+    out->rgb = NR * p->Cout;  out->depth = NR;  out->wsum = NR;  out->depth_minmax = 2;
+    out->fine_depths = NR * p->Df;
+    out->save_sigma = S;  out->save_rgb = S * p->Cout;  out->pos_rows = p->Df > 0 ? 2 * NR * D * 4 : 0;
+    out->df_rows = S * FC;  out->df_pos = S * 4;  out->ag_rows = S * 2;  out->gc_rows = S * 4;
+    out->dump_dpre = S * 64;  out->dump_h = S * 64;  out->dump_dout = S * (1 + p->Cout);  out->dump_feat = S * FC;
+    return EG3D_OK;
+}
+
 extern "C" int64_t eg3d_triplane_scatter_workspace_ints(int64_t S, int N, int Hp, int Wp) {
     const int64_t nb = (int64_t)N * 3 * ((Hp + TS - 1) / TS) * ((Wp + TS - 1) / TS);
     return 4 * nb + 2 + 3 * S;                 // counts, fill, offsets (+1), chunk_offsets (+1), ids

@@ -75,6 +75,11 @@ class RenderBwdParams(C.Structure):
                 ('dump_dpre', C.c_void_p), ('dump_h', C.c_void_p), ('dump_dout', C.c_void_p), ('dump_feat', C.c_void_p)]
 
 
+class RenderSizes(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ('S', 'rgb', 'depth', 'wsum', 'depth_minmax', 'fine_depths', 'save_sigma', 'save_rgb', 'pos_rows',
+                                         'df_rows', 'df_pos', 'ag_rows', 'gc_rows', 'dump_dpre', 'dump_h', 'dump_dout', 'dump_feat')]
+
+
 class FlreluParams(C.Structure):
     _fields_ = [('x', C.c_void_p), ('b', C.c_void_p), ('y', C.c_void_p), ('fu', C.c_void_p), ('fd', C.c_void_p), ('mask', C.c_void_p),
                 ('dtype', C.c_int32), ('N', C.c_int32), ('C', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
@@ -146,6 +151,7 @@ _SIGS = {
     'eg3d_render_fwd': (C.c_int, [C.POINTER(RenderParams), C.c_void_p]),
     'eg3d_render_finalize': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'eg3d_render_bwd': (C.c_int, [C.POINTER(RenderBwdParams), C.c_void_p]),
+    'eg3d_render_query_sizes': (C.c_int, [C.c_void_p, C.c_void_p]),
     'eg3d_triplane_scatter_workspace_ints': (C.c_int64, [C.c_int64, C.c_int, C.c_int, C.c_int]),
     'eg3d_triplane_scatter': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                         C.c_void_p, C.c_void_p]),

@@ -697,6 +697,13 @@ def make_render_params(planes, origins, dirs, u1, u2, opts, w0, b0, w1t, b1, rgb
     return p
 
 
+def render_sizes(p):
+    """Element counts of every caller-owned renderer buffer (eg3d_render_query_sizes): the host allocates from the library's own answer."""
+    z = L.RenderSizes()
+    L.check(L.lib().eg3d_render_query_sizes(C.byref(p), C.byref(z)), 'render_query_sizes')
+    return z
+
+
 def render_fwd(p):
     L.check(L.lib().eg3d_render_fwd(C.byref(p), L.stream_ptr()), 'render_fwd')
 
@@ -715,17 +722,18 @@ def render_bwd(p, d_rgb, d_depth, d_wsum, d_planes, d_origins, d_dirs, dumps=Non
     bp.d_wsum = d_wsum.data_ptr() if d_wsum is not None else None
     rows = pos = None
     D = max(p.Dc, p.Df)
-    S = p.N * p.R * 2 * D
+    z = render_sizes(p)
+    S = z.S
     dev = d_rgb.device
-    ag = torch.empty((S, 2), dtype=torch.float32, device=dev)
+    ag = torch.empty(z.ag_rows, dtype=torch.float32, device=dev)
     bp.ag_rows = ag.data_ptr()
     if d_origins is not None or d_dirs is not None:
-        gc = torch.empty((S, 4), dtype=torch.float32, device=dev)
+        gc = torch.empty(z.gc_rows, dtype=torch.float32, device=dev)
         bp.gc_rows = gc.data_ptr()
-    pos = torch.empty((S, 4), dtype=torch.float32, device=dev)          # (x, y, z, depth) per sample row, NaN = absent
+    pos = torch.empty(z.df_pos, dtype=torch.float32, device=dev)        # (x, y, z, depth) per sample row, NaN = absent
     bp.df_pos = pos.data_ptr()
     if d_planes is not None:
-        rows = torch.empty((S, 32), dtype=torch.float32, device=dev)
+        rows = torch.empty(z.df_rows, dtype=torch.float32, device=dev)
         bp.df_rows = rows.data_ptr()
     bp.d_origins = d_origins.data_ptr() if d_origins is not None else None
     bp.d_dirs = d_dirs.data_ptr() if d_dirs is not None else None

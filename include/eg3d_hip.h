@@ -395,6 +395,18 @@ typedef struct eg3d_render_params {
 } eg3d_render_params;
 
 int eg3d_render_fwd(const eg3d_render_params* p, void* stream);
+
+/* Element counts (floats) of every caller-owned buffer of the renderer entries for a given problem -- the contract a binding in another
+ * language sizes its allocations from (the reference's plugins allocate inside ATen; this library never allocates).  Only N, R, Dc, Df and
+ * Cout of `p` are read.  S = N*R*2*max(Dc,Df) sample rows.  A count of 0 = that buffer does not exist for this problem. */
+typedef struct eg3d_render_sizes {
+    int64_t S;                 /* sample rows                                                            */
+    int64_t rgb, depth, wsum, depth_minmax, fine_depths;      /* eg3d_render_fwd outputs                  */
+    int64_t save_sigma, save_rgb, pos_rows;                   /* training-mode forward (pos_rows optional) */
+    int64_t df_rows, df_pos, ag_rows, gc_rows;                /* eg3d_render_bwd                          */
+    int64_t dump_dpre, dump_h, dump_dout, dump_feat;          /* decoder-weight gradient operands         */
+} eg3d_render_sizes;
+int eg3d_render_query_sizes(const eg3d_render_params* p, eg3d_render_sizes* out);
 /* depth <- clamp(nan_to_num(depth, inf), min, max) with the global min/max (ray_marcher.py:49-50). */
 int eg3d_render_finalize(float* depth, const float* depth_minmax, int64_t n, void* stream);
 

@@ -331,3 +331,61 @@ def test_batched_projection_equals_sequential_c5():
         key = 'backbone.synthesis.b32.conv1.noise_const'
         err = (batched.noise_maps[key][i, 0] - single.noise_bufs['b32.conv1.noise_const']).abs()
         assert float((err <= 1e-4).float().mean()) >= 0.99 and float(err.max()) <= 0.1
+
+
+def test_archive_loads_on_device_and_renders_identically_f4(tmp_path):
+    """Row f4: a generator written to the source-free archive and read back with weights.load_generator(device='cuda') renders the same
+    image (bit for bit: same kernels, same weights) and still agrees with the oracle."""
+    from inv3d_amd import weights as W
+    cfg, P, G, cam, u1, u2, target, _ = _setup()
+    kw = dict(z_dim=32, c_dim=25, w_dim=32, img_resolution=64, img_channels=3, sr_num_fp16_res=4, mapping_kwargs={'num_layers': 2},
+              rendering_kwargs=G.rendering_kwargs, sr_kwargs={'channel_base': 256, 'channel_max': 16, 'fused_modconv_default': 'inference_only',
+                                                              'sr_widths': (16, 8), 'input_resolution': 16, 'w_dim': 32},
+              plane_resolution=32, channel_base=256, channel_max=16, fused_modconv_default='inference_only', conv_clamp=None)
+    p = str(tmp_path / 'g.safetensors')
+    W.save_generator_archive(p, {k: v.cpu() for k, v in G.state_dict().items()}, kw, 16)
+    G2 = W.load_generator(p, device=DEV)
+    assert all(t.is_cuda for t in G2.state_dict().values())
+    ws = O.synth_ws(cfg, 1, seed=3).float().to(DEV)
+    c = cam.float().to(DEV)
+    with torch.no_grad():
+        kwargs = dict(noise_mode='const', force_fp32=True, render_uniforms=(u1.float().to(DEV), u2.float().to(DEV)))
+        a = G.synthesis(ws, c, **kwargs)
+        b = G2.synthesis(ws, c, **kwargs)
+    for k in ('image', 'image_raw', 'image_depth'):
+        assert torch.equal(a[k], b[k]), k
+    assert _psnr(b['image'].clamp(-1, 1).double().cpu(), target) > 45
+
+
+def test_coach_starts_from_the_encoder_latent():
+    """w_projector.py:71-74,100: with the e4e encoder present Phase A starts at w_avg + e4e(target_256).  InversionCoach(start_w_fn=PSPEncoder)
+    does that (checked on the projector's first latent) and then runs both phases."""
+    from inv3d_amd import synthetic as S
+    from inv3d_amd.coach import InversionCoach
+    from inv3d_amd.e4e import PSPEncoder
+    from inv3d_amd import inversion as INV
+    from oracle import e4e_oracle as EO
+    G = S.make_generator(w_dim=512, z_dim=32, plane_res=32, channel_base=256, channel_max=16, nrr=16, sr_in_res=16, sr_widths=(16, 8), device=DEV)
+    S.load_synthetic_weights(G, 0)
+    enc = PSPEncoder()
+    enc.encoder.load_state_dict(EO.synth_state(seed=5))
+    enc = enc.to(DEV)
+    g = torch.Generator().manual_seed(1)
+    target = (torch.rand(1, 3, 256, 256, generator=g) * 2 - 1).to(DEV)
+    cam = O.synth_cameras(1, seed=2).float().to(DEV)
+    coach = InversionCoach(G, first_inv_steps=3, max_pti_steps=2, lpips_threshold=0.0, seed=3, w_avg_samples=64, start_w_fn=enc)
+    seen = {}
+    orig = INV.LatentProjector.__init__
+
+    def spy(self, *a, **k):
+        orig(self, *a, **k)
+        seen['w0'] = self.w_opt.detach().clone()
+    INV.LatentProjector.__init__ = spy
+    try:
+        res = coach.invert('x', torch.nn.functional.interpolate(target, size=(64, 64), mode='area'), cam)
+    finally:
+        INV.LatentProjector.__init__ = orig
+    t255 = (torch.nn.functional.interpolate(target, size=(64, 64), mode='area') + 1) * 127.5
+    want = coach.w_avg.reshape(1, 1, -1).to(DEV) + enc(t255).reshape(1, 1, -1)
+    assert torch.allclose(seen['w0'], want, rtol=0, atol=1e-5 * float(want.abs().max()))
+    assert res.steps_a == 3 and res.w_pivot.shape == (1, G.backbone.num_ws, 512)

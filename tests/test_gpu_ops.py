@@ -703,3 +703,18 @@ def test_conv_v2_heavy_tailed_operands():
     scale = float(ref.abs().max())
     e_v2, e_32 = float((out.double().cpu() - ref).abs().max()) / scale, float((out32.double().cpu() - ref).abs().max()) / scale
     assert e_v2 <= 2.0 * e_32 + 1e-7, (e_v2, e_32)
+
+
+@pytest.mark.parametrize('n', [1, 3, 4, 1023, 147456, 1 << 20, (1 << 20) + 3])
+def test_absmax_any_length(n):
+    """eg3d_absmax: max|x| of a dense fp32 array (operand range of the split images), any length, non-finite entries ignored."""
+    from inv3d_amd import hipops as H
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g)
+    x[n // 2] = -7.5
+    got = H.absmax(x.to(DEV))
+    assert float(got) == 7.5
+    if n > 8:
+        x[1] = float('inf')
+        x[n - 1] = 9.25
+        assert float(H.absmax(x.to(DEV))) == 9.25

@@ -23,6 +23,21 @@ def test_library_exports_every_declared_symbol():
     assert lib.eg3d_status_string(-2) == b'unsupported configuration'
 
 
+def test_render_size_query_is_host_only():
+    """eg3d_render_query_sizes: the buffer-size contract of the renderer entries, answerable without a GPU."""
+    import ctypes as C
+    from inv3d_amd import _lib as L
+    p = L.RenderParams()
+    p.N, p.R, p.Dc, p.Df, p.Cout = 2, 128 * 128, 48, 48, 32
+    z = L.RenderSizes()
+    assert L.lib().eg3d_render_query_sizes(C.byref(p), C.byref(z)) == 0
+    S = 2 * 128 * 128 * 2 * 48
+    assert (z.S, z.rgb, z.depth, z.fine_depths, z.save_rgb, z.pos_rows) == (S, 2 * 16384 * 32, 2 * 16384, 2 * 16384 * 48, S * 32, S * 4)
+    assert (z.df_rows, z.df_pos, z.ag_rows, z.gc_rows, z.dump_dout) == (S * 32, S * 4, S * 2, S * 4, S * 33)
+    p.Dc = 0
+    assert L.lib().eg3d_render_query_sizes(C.byref(p), C.byref(z)) != 0
+
+
 def test_no_cpu_fallback():
     from inv3d_amd._lib import Eg3dHipError
     from inv3d_amd.torch_utils.ops import bias_act, upfirdn2d, conv2d_resample
