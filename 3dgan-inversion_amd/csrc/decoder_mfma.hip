@@ -1,5 +1,6 @@
 // Sample-level kernels of the volume renderer: tri-plane gather + OSG decoder (32 -> 64 softplus -> 1+32), forward and
-// backward, with the decoder on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+// backward, with the decoder on the 16-bit matrix cores at fp32-equivalent precision (three v_mfma_f32_32x32x16_f16 per product
+// block on two-piece fp16 operands, the arithmetic of conv_v2.hip; fp32 accumulation).
 //
 // Replaces sample_from_planes/F.grid_sample (training/volumetric_rendering/renderer.py:55-66) + OSGDecoder.forward
 // (training/triplane.py:124-136) and their autograd backward, for arbitrary sample positions ("rows").
@@ -9,10 +10,14 @@
 // samples), so the MFMA result layout of one layer *is* the B-operand layout of the next one:
 //     PRE^T[64 x 32s] = W0 F^T          H = softplus(PRE)          OUT^T[32 x 32s] = W1c H^T       sigma = w1s . H  (VALU + 1 shuffle)
 //     dH^T = W1c^T dOUT^T + w1s dsigma  dPRE = dH (1 - exp(-H))    dF^T [32 x 32s] = W0^T dPRE^T
-// The weight-side (A) operands are per-lane constants; they are staged once per block in LDS in fragment order and fetched with one
-// conflict-free ds_read_b32 per MFMA (a 64-cycle instruction), so they cost no registers.  128 MFMAs per 32 samples for the
-// backward kernel, 64 for the forward one.  The gather is done in the same split layout: the two lanes of a sample read the two
-// 64-byte halves of each 128-byte texel.
+// A k-step of the 16-bit MFMA takes 8 consecutive registers of the split layout per lane (K index = split_idx(8 s + j, lane >> 5)),
+// the weight-side (A) operands are staged once per block in LDS in that same K order as three fp16 planes (high piece, low piece,
+// high piece x 2^-11), one conflict-free ds_read_b128 each.  The activation-side operands are split in registers:
+//     x = h + l 2^-11,  h = rtz16(x),  l = rne16((x - h) 2^11);      w 2^e = hw + lw;      x w 2^e = h hw + h lw + l (hw 2^-11)
+// Gradient operands (dOUT, dPRE) span many decades from sample to sample, so each sample (= GEMM column) is brought into fp16 range
+// by its own power of two, undone exactly on the result column.  48 MFMAs (32 cycles each) per 32 samples for the backward kernel
+// instead of 128 fp32 ones (64 cycles each); 24 instead of 64 for the forward one.  The gather is done in the same split layout: the
+// two lanes of a sample read the two 64-byte halves of each 128-byte texel.
 #include "render_common.h"
 
 using namespace eg3d_render;
@@ -39,45 +44,114 @@ struct DecodeArgs {
     float* dump_dpre; float* dump_h; float* dump_dout; float* dump_feat;   // decoder-weight gradient operands (or null)
 };
 
-// LDS fragment images of the weights.  frag(ht, r)[lane] is the A operand of the k-step whose B operand is register r of the
-// ht-th 16-register group.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+
+// LDS fragment images of the weights: per (output block, k-step) three planes (hw, lw, hw 2^-11) of 64 lanes x 8 halfs.
+// K index of slot j of lane l in k-step s: kidx(s, l >> 5, j) = split_idx(8 s + j, l >> 5).
 struct Frags {
-    float* a1;    // [2][16][64]  W0[32ht + (l&31)][idx(r,h)]                       (layer 1:  i = hidden, k = feature)
-    float* a2;    // [2][16][64]  W1[1 + (l&31)][32ht + idx(r,h)]                   (layer 2:  i = colour, k = hidden)
-    float* a3;    // [2][16][64]  W1[1 + idx(r,h)][32ht + (l&31)]                   (dH:       i = hidden, k = colour)
-    float* a4;    // [2][16][64]  W0[32ht + idx(r,h)][(l&31)]                       (dF:       i = feature, k = hidden)
-    float* ws;    // [2][16][2]   W1[0][32ht + idx(r,h)]                            (sigma row)
-    float* bi0;   // [2][16][2]   b0[32ht + idx(r,h)]
-    float* bi1;   // [16][2]      b1[1 + idx(r,h)]
+    const f16x8* a1;   // [2 ht][2 s][3][64]   W0[32 ht + (l&31)][kidx]                         (layer 1:  i = hidden, k = feature)
+    const f16x8* a2;   // [4 ks][3][64]        W1[1 + (l&31)][32 (ks>>1) + kidx(ks&1)]          (layer 2:  i = colour, k = hidden)
+    const f16x8* a3;   // [2 ht][2 s][3][64]   W1[1 + kidx][32 ht + (l&31)]                     (dH:       i = hidden, k = colour)
+    const f16x8* a4;   // [4 ks][3][64]        W0[32 (ks>>1) + kidx(ks&1)][(l&31)]              (dF:       i = feature, k = hidden)
+    const float* ws;   // [2][16][2]   W1[0][32ht + idx(r,h)]                                   (sigma row, fp32)
+    const float* bi0;  // [2][16][2]   b0[32ht + idx(r,h)]
+    const float* bi1;  // [16][2]      b1[1 + idx(r,h)]
+    float inv0, inv1;  // 1 / (power-of-two range multiplier of W0, W1)
 };
-constexpr int FRAG_FLOATS_FWD = 2 * 2048 + 64 + 64 + 32;
-constexpr int FRAG_FLOATS_BWD = 4 * 2048 + 64 + 64 + 32;
+constexpr int FRAG_PLANES = 4 * 3 * 64;                 // f16x8 units of one GEMM's fragment image
+constexpr int FRAG_BYTES_FWD = 2 * FRAG_PLANES * 16 + (64 + 64 + 32 + 8) * 4;
+constexpr int FRAG_BYTES_BWD = 4 * FRAG_PLANES * 16 + (64 + 64 + 32 + 8) * 4;
+
+// multiplier that brings `amax` to [2^11, 2^12): an exact power of two (1 for zero / non-finite input)
+__device__ __forceinline__ float pow2_range_mul(float amax, int target_exp) {
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+    int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127;          // floor(log2 amax) (subnormals: -127)
+    e = max(-100, min(100, e));
+    return __uint_as_float((unsigned)(127 + target_exp - e) << 23);
+}
+
+__device__ __forceinline__ void split_pieces8(const float (&v)[8], float lo_mul, f16x8& h, f16x8& l) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a = v[2 * q], b = v[2 * q + 1];
+        const fp16x2_t hh = __builtin_amdgcn_cvt_pkrtz(a, b);
+        const float ra = __builtin_amdgcn_fmed3f((a - (float)hh[0]) * lo_mul, -65504.f, 65504.f);
+        const float rb = __builtin_amdgcn_fmed3f((b - (float)hh[1]) * lo_mul, -65504.f, 65504.f);
+        h[2 * q] = (_Float16)hh[0]; h[2 * q + 1] = (_Float16)hh[1];
+        l[2 * q] = (_Float16)ra; l[2 * q + 1] = (_Float16)rb;
+    }
+}
+
+// B-operand fragments (high piece, low piece scaled by 2^11) of k-step s of a 16-register split-layout vector, times `mul`
+__device__ __forceinline__ void act_frag(const f32x16& v, int s, float mul, f16x8& h, f16x8& l) {
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = v[8 * s + j] * mul;
+    split_pieces8(t, 2048.f, h, l);
+}
+
+// acc += W-fragment (3 planes at `a`) x activation fragment (bh, bl): small terms first
+__device__ __forceinline__ void mfma3(f32x16& acc, const f16x8* a, int lane, const f16x8& bh, const f16x8& bl) {
+    const f16x8 ah = a[lane], al = a[64 + lane], ag = a[128 + lane];
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ag, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+}
 
 template <bool BWD>
-__device__ __forceinline__ Frags setup_frags(float* lds, const DecodeArgs& a) {
+__device__ __forceinline__ Frags setup_frags(char* lds, const DecodeArgs& a) {
     Frags F;
-    F.a1 = lds; F.a2 = lds + 2048;
-    float* p = lds + 4096;
-    if (BWD) { F.a3 = p; F.a4 = p + 2048; p += 4096; } else { F.a3 = F.a4 = nullptr; }
-    F.ws = p; F.bi0 = p + 64; F.bi1 = p + 128;
-    for (int i = threadIdx.x; i < 2048; i += blockDim.x) {
-        const int lane = i & 63, r = (i >> 6) & 15, ht = i >> 10;
-        const int li = lane & 31, e = split_idx(r, lane >> 5);
-        F.a1[i] = a.w0[(32 * ht + li) * FC + e];
-        F.a2[i] = a.w1t[(32 * ht + e) * (1 + CO) + 1 + li];
-        if (BWD) {
-            F.a3[i] = a.w1t[(32 * ht + li) * (1 + CO) + 1 + e];
-            F.a4[i] = a.w0[(32 * ht + e) * FC + li];
+    f16x8* q = reinterpret_cast<f16x8*>(lds);
+    f16x8* a1 = q; f16x8* a2 = q + FRAG_PLANES; f16x8* a3 = nullptr; f16x8* a4 = nullptr;
+    q += 2 * FRAG_PLANES;
+    if (BWD) { a3 = q; a4 = q + FRAG_PLANES; q += 2 * FRAG_PLANES; }
+    float* fl = reinterpret_cast<float*>(q);
+    float* ws = fl; float* bi0 = fl + 64; float* bi1 = fl + 128; float* red = fl + 160;
+    // range multipliers of the two weight matrices (every block derives the same values itself: 4 K floats)
+    float m0 = 0.f, m1 = 0.f;
+    for (int i = threadIdx.x; i < HD * FC; i += blockDim.x) m0 = fmaxf(m0, fabsf(a.w0[i]));
+    for (int i = threadIdx.x; i < HD * (1 + CO); i += blockDim.x) m1 = fmaxf(m1, fabsf(a.w1t[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { m0 = fmaxf(m0, __shfl_xor(m0, o)); m1 = fmaxf(m1, __shfl_xor(m1, o)); }
+    if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = m0; red[(threadIdx.x >> 6) * 2 + 1] = m1; }
+    __syncthreads();
+    m0 = fmaxf(fmaxf(red[0], red[2]), fmaxf(red[4], red[6]));
+    m1 = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+    const float s0 = pow2_range_mul(m0, 11), s1 = pow2_range_mul(m1, 11);
+    F.inv0 = 1.f / s0; F.inv1 = 1.f / s1;
+    // one (block/k-step, lane) fragment per thread iteration: 4 x 64 per GEMM
+    for (int i = threadIdx.x; i < 4 * 64; i += blockDim.x) {
+        const int lane = i & 63, bs = i >> 6;                 // bs = 2 ht + s  (layer 1 / dH)   or   ks  (layer 2 / dF)
+        const int li = lane & 31, g = lane >> 5, hi = bs >> 1, s = bs & 1;
+        float v1[8], v2[8], v3[8], v4[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = split_idx(8 * s + j, g);
+            v1[j] = a.w0[(32 * hi + li) * FC + k] * s0;
+            v2[j] = a.w1t[(32 * hi + k) * (1 + CO) + 1 + li] * s1;
+            v3[j] = a.w1t[(32 * hi + li) * (1 + CO) + 1 + k] * s1;
+            v4[j] = a.w0[(32 * hi + k) * FC + li] * s0;
         }
+        auto put = [&](f16x8* dst, const float (&v)[8]) {
+            f16x8 h, l, gg;
+            split_pieces8(v, 1.f, h, l);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gg[j] = h[j] * (_Float16)0.00048828125f;
+            dst[(bs * 3 + 0) * 64 + lane] = h; dst[(bs * 3 + 1) * 64 + lane] = l; dst[(bs * 3 + 2) * 64 + lane] = gg;
+        };
+        put(a1, v1); put(a2, v2);
+        if (BWD) { put(a3, v3); put(a4, v4); }
     }
     for (int i = threadIdx.x; i < 64; i += blockDim.x) {
         const int h = i & 1, r = (i >> 1) & 15, ht = i >> 5;
         const int e = 32 * ht + split_idx(r, h);
-        F.ws[i] = a.w1t[e * (1 + CO)];
-        F.bi0[i] = a.b0[e];
-        if (ht == 0) F.bi1[i] = a.b1[1 + split_idx(r, h)];
+        ws[i] = a.w1t[e * (1 + CO)];
+        bi0[i] = a.b0[e];
+        if (ht == 0) bi1[i] = a.b1[1 + split_idx(r, h)];
     }
     __syncthreads();
+    F.a1 = a1; F.a2 = a2; F.a3 = a3; F.a4 = a4; F.ws = ws; F.bi0 = bi0; F.bi1 = bi1;
     return F;
 }
 
@@ -130,11 +204,11 @@ __device__ __forceinline__ void phase_fence() { asm volatile("" ::: "memory"); }
 #define DEC_GRID_BWD 3
 #endif
 #ifndef DEC_GRID_FWD
-#define DEC_GRID_FWD 6
+#define DEC_GRID_FWD 5
 #endif
 template <bool BWD>
 __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_rows_kernel(const DecodeArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) char lds[];
     const Frags F = setup_frags<BWD>(lds, a);
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     const int64_t ntiles = (a.M + 31) / 32;
@@ -153,39 +227,52 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
         const int n = valid ? (int)(row / a.rows_per_image) : 0;
         const float* pn = a.planes + (int64_t)n * a.Hp * a.Wp * a.ldp;
 
-        float f[16];
-        gather_split(pn, a.Hp, a.Wp, a.ldp, a.cs, px, py, pz, h, f);
+        f32x16 f;
+        {
+            float fr[16];
+            gather_split(pn, a.Hp, a.Wp, a.ldp, a.cs, px, py, pz, h, fr);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) f[r] = fr[r];
+        }
 
         phase_fence();
         // ---- layer 1: PRE^T = W0 F^T + b0 ;  H = softplus(PRE) -----------------------------------------------------------
         f32x16 hid[2];
+        {
+            f16x8 bh[2], bl[2];
+            act_frag(f, 0, 1.f, bh[0], bl[0]);
+            act_frag(f, 1, 1.f, bh[1], bl[1]);
 #pragma unroll
-        for (int ht = 0; ht < 2; ++ht)
+            for (int ht = 0; ht < 2; ++ht) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hid[ht][r] = F.bi0[(ht * 16 + r) * 2 + h];
+                for (int r = 0; r < 16; ++r) hid[ht][r] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            hid[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a1[(0 * 16 + r) * 64 + lane], f[r], hid[0], 0, 0, 0);
-            hid[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a1[(1 * 16 + r) * 64 + lane], f[r], hid[1], 0, 0, 0);
+                for (int s = 0; s < 2; ++s) mfma3(hid[ht], F.a1 + (2 * ht + s) * 192, lane, bh[s], bl[s]);
+            }
         }
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hid[ht][r] = softplus_fast(hid[ht][r]);
+            for (int r = 0; r < 16; ++r) hid[ht][r] = softplus_fast(fmaf(hid[ht][r], F.inv0, F.bi0[(ht * 16 + r) * 2 + h]));
 
         phase_fence();
         // ---- layer 2: OUT^T = W1c H^T + b1c ; sigma = w1s . H + b1[0] ----------------------------------------------------
         f32x16 out;
         float sig = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[r] = F.bi1[r * 2 + h];
+        for (int r = 0; r < 16; ++r) out[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            f16x8 bh, bl;
+            act_frag(hid[ks >> 1], ks & 1, 1.f, bh, bl);
+            mfma3(out, F.a2 + ks * 192, lane, bh, bl);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[r] = fmaf(out[r], F.inv1, F.bi1[r * 2 + h]);
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                out = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a2[(ht * 16 + r) * 64 + lane], hid[ht][r], out, 0, 0, 0);
-                sig = fmaf(F.ws[(ht * 16 + r) * 2 + h], hid[ht][r], sig);
-            }
+            for (int r = 0; r < 16; ++r) sig = fmaf(F.ws[(ht * 16 + r) * 2 + h], hid[ht][r], sig);
         sig += __shfl_xor(sig, 32);
         sig += a.b1[0];
 
@@ -240,20 +327,28 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
         }
         phase_fence();
         // ---- dH^T = W1c^T dOUT^T + w1s dsigma ;  dPRE = dH * sigmoid(PRE) = dH * (1 - exp(-H)) ---------------------------
+        // the sample's gradient column is brought to [2^6, 2^7) by its own power of two and the result column scaled back
         f32x16 dh[2];
+        {
+            float m = 0.f;
 #pragma unroll
-        for (int ht = 0; ht < 2; ++ht)
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(dout[r]));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            const float sc = pow2_range_mul(m, 6), isc = F.inv1 / sc;
+            f16x8 bh[2], bl[2];
+            act_frag(dout, 0, sc, bh[0], bl[0]);
+            act_frag(dout, 1, sc, bh[1], bl[1]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dh[ht][r] = F.ws[(ht * 16 + r) * 2 + h] * dsig;
+            for (int ht = 0; ht < 2; ++ht) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            dh[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a3[(0 * 16 + r) * 64 + lane], dout[r], dh[0], 0, 0, 0);
-            dh[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a3[(1 * 16 + r) * 64 + lane], dout[r], dh[1], 0, 0, 0);
+                for (int r = 0; r < 16; ++r) dh[ht][r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) mfma3(dh[ht], F.a3 + (2 * ht + s) * 192, lane, bh[s], bl[s]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    dh[ht][r] = fmaf(dh[ht][r], isc, F.ws[(ht * 16 + r) * 2 + h] * dsig) * (1.f - __expf(-hid[ht][r]));
+            }
         }
-#pragma unroll
-        for (int ht = 0; ht < 2; ++ht)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dh[ht][r] = dh[ht][r] * (1.f - __expf(-hid[ht][r]));
         if (a.dump_dpre && valid) {
 #pragma unroll
             for (int ht = 0; ht < 2; ++ht)
@@ -263,14 +358,25 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
         phase_fence();
         // ---- dF^T = W0^T dPRE^T -------------------------------------------------------------------------------------------
         f32x16 df;
+        {
+            float m = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) df[r] = 0.f;
+            for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
-        for (int ht = 0; ht < 2; ++ht)
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(dh[ht][r]));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            const float sc = pow2_range_mul(m, 6), isc = F.inv0 / sc * (1.f / 3.f);     // / 3: mean over the three planes
 #pragma unroll
-            for (int r = 0; r < 16; ++r) df = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a4[(ht * 16 + r) * 64 + lane], dh[ht][r], df, 0, 0, 0);
+            for (int r = 0; r < 16; ++r) df[r] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) df[r] = df[r] / 3.f;                 // mean over the three planes
+            for (int ks = 0; ks < 4; ++ks) {
+                f16x8 bh, bl;
+                act_frag(dh[ks >> 1], ks & 1, sc, bh, bl);
+                mfma3(df, F.a4 + ks * 192, lane, bh, bl);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) df[r] = df[r] * isc;
+        }
         if (a.df_rows && valid) {
             float* o = a.df_rows + row * FC + 4 * h;
 #pragma unroll
@@ -317,8 +423,8 @@ int launch_decode(const DecodeArgs& a, bool bwd, hipStream_t st) {
     if (a.M <= 0) return EG3D_OK;
     const int64_t ntiles = (a.M + 31) / 32;
     const int blocks = (int)std::min<int64_t>((ntiles + 3) / 4, 256 * (bwd ? DEC_GRID_BWD : DEC_GRID_FWD));     // persistent: resident blocks per CU x 256 CUs
-    if (bwd) hipLaunchKernelGGL(decode_rows_kernel<true>, dim3(blocks), dim3(256), FRAG_FLOATS_BWD * sizeof(float), st, a);
-    else hipLaunchKernelGGL(decode_rows_kernel<false>, dim3(blocks), dim3(256), FRAG_FLOATS_FWD * sizeof(float), st, a);
+    if (bwd) hipLaunchKernelGGL(decode_rows_kernel<true>, dim3(blocks), dim3(256), FRAG_BYTES_BWD, st, a);
+    else hipLaunchKernelGGL(decode_rows_kernel<false>, dim3(blocks), dim3(256), FRAG_BYTES_FWD, st, a);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

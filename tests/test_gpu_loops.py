@@ -335,7 +335,7 @@ def test_batched_projection_equals_sequential_c5():
 
 def test_archive_loads_on_device_and_renders_identically_f4(tmp_path):
     """Row f4: a generator written to the source-free archive and read back with weights.load_generator(device='cuda') renders the same
-    image (bit for bit: same kernels, same weights) and still agrees with the oracle."""
+    image (same kernels, same weights: equal up to the summation order of the split-K atomics) and still agrees with the oracle."""
     from inv3d_amd import weights as W
     cfg, P, G, cam, u1, u2, target, _ = _setup()
     kw = dict(z_dim=32, c_dim=25, w_dim=32, img_resolution=64, img_channels=3, sr_num_fp16_res=4, mapping_kwargs={'num_layers': 2},
@@ -353,7 +353,7 @@ def test_archive_loads_on_device_and_renders_identically_f4(tmp_path):
         a = G.synthesis(ws, c, **kwargs)
         b = G2.synthesis(ws, c, **kwargs)
     for k in ('image', 'image_raw', 'image_depth'):
-        assert torch.equal(a[k], b[k]), k
+        assert float((a[k] - b[k]).abs().max()) <= 2e-6 * float(a[k].abs().max()), k
     assert _psnr(b['image'].clamp(-1, 1).double().cpu(), target) > 45
 
 
