@@ -186,7 +186,7 @@ __device__ __forceinline__ void gather_split(const float* __restrict__ pn, int H
         }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) f[r] = f[r] / 3.f;
+    for (int r = 0; r < 16; ++r) f[r] = f[r] * (1.f / 3.f);      // mean over the planes (a multiplication: the IEEE division sequence is ~10 instructions per value)
 }
 
 // Compiler-level fence between the phases of a tile.  Without it the scheduler hoists the LDS fragment reads and the gather of later
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
         }
         const bool valid = !isnan(ps.x);
         const float px = valid ? ps.x : 0.f, py = valid ? ps.y : 0.f, pz = valid ? ps.z : 0.f;
-        const int n = valid ? (int)(row / a.rows_per_image) : 0;
+        const int n = valid ? (int)((unsigned)row / (unsigned)a.rows_per_image) : 0;          // rows fit 31 bits (launch_decode): 32-bit divides
         const float* pn = a.planes + (int64_t)n * a.Hp * a.Wp * a.ldp;
 
         f32x16 f;
@@ -278,7 +278,8 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
 
         if (!BWD) {
             if (valid) {
-                const int64_t orow = a.seg_len ? (row / a.seg_len) * a.seg_stride + a.seg_off + row % a.seg_len : row;
+                const unsigned seg = a.seg_len ? (unsigned)row / (unsigned)a.seg_len : 0u;
+                const int64_t orow = a.seg_len ? (int64_t)seg * a.seg_stride + a.seg_off + ((unsigned)row - seg * (unsigned)a.seg_len) : row;
                 if (h == 0) a.sigma[orow] = sig;
                 float* o = a.rgb + orow * CO + 4 * h;
 #pragma unroll
@@ -293,7 +294,7 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
         // =========================== backward ===========================
         float2 ag = make_float2(0.f, 0.f);
         if (valid) ag = a.ag[row];
-        const int64_t ray = a.ray0 + (valid ? row / a.samples_per_ray_row : 0);
+        const int64_t ray = a.ray0 + (valid ? (int64_t)((unsigned)row / (unsigned)a.samples_per_ray_row) : 0);
         const float* grgb = a.d_rgb + ray * CO + 4 * h;
         // dOUT (colours): d rgb / d out = 1.002 * s (1 - s);  dL/d rgb = 2 a d_rgb
         f32x16 dout;
@@ -334,7 +335,7 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
 #pragma unroll
             for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(dout[r]));
             m = fmaxf(m, __shfl_xor(m, 32));
-            const float sc = pow2_range_mul(m, 6), isc = F.inv1 / sc;
+            const float sc = pow2_range_mul(m, 6), isc = F.inv1 * __frcp_rn(sc);      // exact: sc is a power of two
             f16x8 bh[2], bl[2];
             act_frag(dout, 0, sc, bh[0], bl[0]);
             act_frag(dout, 1, sc, bh[1], bl[1]);
@@ -365,7 +366,7 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
 #pragma unroll
                 for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(dh[ht][r]));
             m = fmaxf(m, __shfl_xor(m, 32));
-            const float sc = pow2_range_mul(m, 6), isc = F.inv0 / sc * (1.f / 3.f);     // / 3: mean over the three planes
+            const float sc = pow2_range_mul(m, 6), isc = F.inv0 * __frcp_rn(sc) * (1.f / 3.f);     // / 3: mean over the three planes
 #pragma unroll
             for (int r = 0; r < 16; ++r) df[r] = 0.f;
 #pragma unroll
@@ -421,6 +422,7 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
 
 int launch_decode(const DecodeArgs& a, bool bwd, hipStream_t st) {
     if (a.M <= 0) return EG3D_OK;
+    if (a.M > INT32_MAX || a.rows_per_image > INT32_MAX || a.samples_per_ray_row > INT32_MAX) return EG3D_ERR_UNSUPPORTED;      // 32-bit row arithmetic in the kernels
     const int64_t ntiles = (a.M + 31) / 32;
     const int blocks = (int)std::min<int64_t>((ntiles + 3) / 4, 256 * (bwd ? DEC_GRID_BWD : DEC_GRID_FWD));     // persistent: resident blocks per CU x 256 CUs
     if (bwd) hipLaunchKernelGGL(decode_rows_kernel<true>, dim3(blocks), dim3(256), FRAG_BYTES_BWD, st, a);

@@ -14,7 +14,8 @@ constexpr int CO = 32;     // decoder colour outputs
 // hardware exp2/log2 forms are ~10 instructions, absolute error < 2e-7 on the result (softplus(x) = max(x,0) + log(1 + exp(-|x|))
 // keeps the argument of log in (1,2]).  The ray marcher keeps the libm forms.
 __device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.f + __expf(-x)); }
-__device__ __forceinline__ float softplus_fast(float x) { return fmaxf(x, 0.f) + __logf(1.f + __expf(-fabsf(x))); }
+// the log argument lies in [1, 2]: the bare v_log_f32 (log2) needs none of __logf's denormal handling
+__device__ __forceinline__ float softplus_fast(float x) { return fmaf(0.6931471805599453f, __builtin_amdgcn_logf(1.f + __expf(-fabsf(x))), fmaxf(x, 0.f)); }
 
 // renderer.py:23-53: plane 0 -> (x,y), plane 1 -> (x,z), plane 2 -> (z,x)
 __device__ __forceinline__ void plane_uv(int pl, float x, float y, float z, float& u, float& v) {

@@ -71,7 +71,7 @@ __device__ __forceinline__ void gather_feats(const float* __restrict__ pn, int H
         }
     }
 #pragma unroll
-    for (int c = 0; c < FC; ++c) f[c] = f[c] / 3.f;
+    for (int c = 0; c < FC; ++c) f[c] = f[c] * (1.f / 3.f);
 }
 
 // 32 -> 64 (softplus) -> 33; w1t is [HD][1+CO] (transposed so that a hidden unit's fan-out is contiguous)

@@ -22,7 +22,7 @@ class LaunchProfiler:
     kernel), and around named spans (the renderer's forward / backward)."""
 
     def __init__(self, only_config=None, keep_meta=False):
-        self.records = []          # (config_id, algo_flops, start_event, end_event)
+        self.records = []          # ((config_id, precision_id), algo_flops, start_event, end_event): one key per kernel family
         self.spans = []            # (name, start_event, end_event)
         self.only_config = only_config      # time only launches of this kernel id (keeps the event overhead small)
         self.meta = [] if keep_meta else None      # per record: launch geometry (tools/conv_launch_table.py)
@@ -384,7 +384,7 @@ def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=
     L.check(L.lib().eg3d_conv2d_igemm_f32(C.byref(p), L.stream_ptr()), 'conv2d_igemm_f32')
     if prof is not None:
         e1.record()
-        prof.records.append((cfg, float(algo_flops), e0, e1))
+        prof.records.append(((cfg, int(p.precision)), float(algo_flops), e0, e1))
         if prof.meta is not None:
             prof.meta.append(dict(N=n, Hi=hi, Wi=wi, Ck=Ck, Nc=Nc, Ho=ho, Wo=wo, taps=[c.ntaps for c in classes], epi=epi, ksplit=ksplit,
                                   in_stride=in_stride, out_stride=out_stride, prec=p.precision))
@@ -504,7 +504,7 @@ def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_
     L.check(L.lib().eg3d_conv2d_v2(C.byref(p), L.stream_ptr()), 'conv2d_v2')
     if prof is not None:
         e1.record()
-        prof.records.append((V2_CONFIG, float(algo_flops), e0, e1))
+        prof.records.append(((V2_CONFIG, PRECISIONS['f16x3']), float(algo_flops), e0, e1))
         if prof.meta is not None:
             prof.meta.append(dict(N=p.N, Hi=p.Hi, Wi=p.Wi, Ck=p.Ck, Nc=p.Nc, Ho=p.Ho, Wo=p.Wo, taps=[c.ntaps for c in classes], epi=epi, ksplit=1,
                                   in_stride=1, out_stride=out_stride, prec=3, v2=True))

@@ -11,13 +11,18 @@ into the latent and the 13+4 noise buffers, Adam step, noise renormalisation.  W
 N GPUs = N independent images (weak scaling), one packed stat all-reduce per step over RCCL.
 
 The JSON line also carries
-  roofline      : the dominant kernel conv_igemm_kernel<128,128,2,2,PREC> (implicit GEMM on the matrix cores): algorithmic FLOPs of
-                  its launches (2 x MACs of the convolution) / their HIP-event durations measured on the
-                  launch stream inside the timed region.  `peak` is the matrix peak for the arithmetic the kernel executes:
+  roofline      : the dominant kernel = the conv kernel family (tile configuration x arithmetic) with the largest share of the step's
+                  time: conv_v2_kernel<9> (csrc/conv_v2.hip, pre-split fp16 pieces, LDS-DMA staged halo) on the default settings.
+                  achieved = algorithmic FLOPs of its launches (2 x MACs of the convolution) / their HIP-event
+                  durations measured on the launch stream.  `peak` is the matrix peak for the arithmetic the kernel executes:
                   157.3 TFLOP/s for --precision f32 (v_mfma_f32_32x32x2_f32); for the split modes (fp32 operands and results, every
                   fp32 product formed from exact 16-bit MFMA products: 3 fp16 products in the default mode, 6 bf16 products with
                   --precision bf16x6) it is the dense 16-bit peak / products = 833.3 resp. 416.7 fp32-equivalent TFLOP/s.
-                  `frac_of_fp32_mfma_peak` and `mfma_executed_tflops` are given beside it.
+                  `frac_of_fp32_mfma_peak`, `mfma_executed_tflops`, the measured register-only MFMA ceiling and the same figures over
+                  ALL conv launches of the step (`all_conv_*`) are given beside it; `traffic` = HBM bytes per launch from the committed
+                  PMC passes (profiles/traffic_table.json).
+  roofline_renderer : the volume renderer's forward + backward against HBM (SURVEY section 8d algorithmic bytes).
+  final_psnr    : one image through the whole 400 + 400 step budget (InversionCoach): the second half of the metric.
   cpu_baseline  : the CPU oracle (oracle/eg3d_oracle.py, a port of the reference's pure-PyTorch `_ref` path, pinned against
                   the reference) running the same C2 step on the host cores, bounded sample, rank 0 at N=1 only.
 """
@@ -187,14 +192,15 @@ def main():
         dom = summ.get(dom_id)
         if dom and dom['ms'] > 0:
             ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-            is_v2 = dom_id == H.V2_CONFIG
-            nprod = PRODUCTS[prec_name]
-            peak = FP32_MFMA_PEAK_TFLOPS if prec_name == 'f32' else BF16_MFMA_PEAK_TFLOPS / nprod
+            is_v2 = dom_id[0] == H.V2_CONFIG
+            dom_prec = {v: k for k, v in H.PRECISIONS.items()}[dom_id[1]]          # arithmetic of the dominant kernel's launches
+            nprod = PRODUCTS[dom_prec]
+            peak = FP32_MFMA_PEAK_TFLOPS if dom_prec == 'f32' else BF16_MFMA_PEAK_TFLOPS / nprod
             if is_v2:
                 kern, tkey = 'conv_v2_kernel<9> (pre-split fp16 pieces, LDS-DMA staged halo; fp32 in/out, 3 x v_mfma_f32_32x32x16_f16 per fp32 product)', 'conv_v2_kernel<9>'
             else:
-                kern = 'conv_igemm_kernel<%s,%d,*> (fp32 in/out, %d x MFMA per fp32 product)' % (H.TILE_NAMES.get(dom_id, '?'), H.PRECISIONS[prec_name], nprod)
-                tkey = 'conv_igemm_kernel<%s>' % H.TILE_NAMES.get(dom_id, '?')
+                kern = 'conv_igemm_kernel<%s,%d,*> (fp32 in/out, %d x MFMA per fp32 product)' % (H.TILE_NAMES.get(dom_id[0], '?'), H.PRECISIONS[dom_prec], nprod)
+                tkey = 'conv_igemm_kernel<%s>' % H.TILE_NAMES.get(dom_id[0], '?')
             tr = traffic.get(tkey, {})
             per_launch_ref = tr.get('gflop_per_launch')
             tbytes = tr.get('bytes_per_launch')
@@ -204,8 +210,8 @@ def main():
             all_fl = sum(v['flops'] for v in summ.values())
             roof = dict(bound='mfma', kernel=kern, achieved=round(ach, 2),
                         peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4), traffic=tbytes, traffic_source=tr.get('source'),
-                        peak_basis=('fp32 matrix peak' if prec_name == 'f32' else 'dense 16-bit matrix peak 2500 / %d products' % nprod),
-                        measured_mfma_ceiling_tflops=round(1550.0 / nprod, 1) if prec_name != 'f32' else None,
+                        peak_basis=('fp32 matrix peak' if dom_prec == 'f32' else 'dense 16-bit matrix peak 2500 / %d products' % nprod),
+                        measured_mfma_ceiling_tflops=round(1550.0 / nprod, 1) if dom_prec != 'f32' else None,
                         ceiling_note='a register-only v_mfma_f32_32x32x16_f16 loop sustains 1.5-1.6 PFLOP/s on random data on this chip (clock throttling; 2.0-2.3 on zeros): tools/proto/mfma_peak.hip',
                         frac_of_fp32_mfma_peak=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), mfma_executed_tflops=round(ach * nprod, 1),
                         launches_per_step=dom['launches'] / args.steps, gflop_per_launch=round(dom['flops'] / dom['launches'] / 1e9, 3),

@@ -24,6 +24,6 @@ print(f'{"#":>3} cfg {"in":>14} {"out":>14} taps           epi    ks prec   {"GF
 for i, (rec, m) in enumerate(zip(profs[0].records, profs[0].meta)):
     us = sorted(p.records[i][2].elapsed_time(p.records[i][3]) for p in profs)[reps // 2] * 1e3
     tot += us
-    print(f'{i:3d} {rec[0]:3d} {m["Hi"]:4d}x{m["Wi"]:<4d}x{m["Ck"]:<4d} {m["Ho"]:4d}x{m["Wo"]:<4d}x{m["Nc"]:<4d} {str(m["taps"]):14s} {EPI[m["epi"]]:6s} {m["ksplit"]:2d} {PREC[m["prec"]]:6s} '
+    print(f'{i:3d} {rec[0][0]:3d} {m["Hi"]:4d}x{m["Wi"]:<4d}x{m["Ck"]:<4d} {m["Ho"]:4d}x{m["Wo"]:<4d}x{m["Nc"]:<4d} {str(m["taps"]):14s} {EPI[m["epi"]]:6s} {m["ksplit"]:2d} {PREC[m["prec"]]:6s} '
           f'{rec[1] / 1e9:7.2f} {us:7.1f} {rec[1] / us / 1e6:6.1f}')
 print(f'total {tot / 1e3:.3f} ms over {len(profs[0].records)} launches')
