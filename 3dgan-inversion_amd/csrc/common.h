@@ -130,6 +130,43 @@ __device__ __forceinline__ void eg3d_commit_amax(float m, float* out) {
     }
 }
 
+// ---- EG3D_EPI_BWD_ACT: the producing layer's activation backward inside a data-gradient epilogue (conv_igemm.hip, conv_v2.hip) --------
+// One float4 unit (4 channels of one pixel): v = that layer's dout, o = its saved output.  Returns dz = dy * d; accumulates the
+// per-channel sums (accb: dy, accd: dy * (pre - bias - noise)) and hands back the unit's channel sum of dy.
+struct eg3d_act_bwd_consts {
+    float slope, gain, inv_gain, clamp, strength;
+};
+__device__ __forceinline__ eg3d_act_bwd_consts eg3d_act_bwd_setup(const eg3d_act_bwd& ab) {
+    eg3d_act_bwd_consts c;
+    c.slope = eg3d_act_pwl_slope(ab.act, ab.alpha);
+    c.gain = ab.gain; c.inv_gain = 1.f / ab.gain; c.clamp = ab.clamp;
+    c.strength = (ab.noise != nullptr && ab.noise_strength != nullptr) ? *ab.noise_strength : 0.f;
+    return c;
+}
+__device__ __forceinline__ float4 eg3d_act_bwd_unit(const eg3d_act_bwd_consts& c, float4 v, float4 o, float4 d4, float4 b4, float nzs,
+                                                    float4& accb, float4& accd, float& chan_sum) {
+    const float vv[4] = {v.x, v.y, v.z, v.w}, oo[4] = {o.x, o.y, o.z, o.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+    float dy[4], ad[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float yy = oo[q] * c.inv_gain;
+        float g = vv[q] * c.gain * (yy > 0.f ? 1.f : c.slope);
+        if (c.clamp >= 0.f && (oo[q] >= c.clamp || oo[q] <= -c.clamp)) g = 0.f;
+        const float pre = (yy > 0.f || c.slope == 0.f) ? yy : yy / c.slope;
+        dy[q] = g;
+        ad[q] = g * (pre - bb[q] - nzs);
+    }
+    accb.x += dy[0]; accb.y += dy[1]; accb.z += dy[2]; accb.w += dy[3];
+    accd.x += ad[0]; accd.y += ad[1]; accd.z += ad[2]; accd.w += ad[3];
+    chan_sum = (dy[0] + dy[1]) + (dy[2] + dy[3]);
+    return make_float4(dy[0] * d4.x, dy[1] * d4.y, dy[2] * d4.z, dy[3] * d4.w);
+}
+// sum over the `group` (power of two <= 32) consecutive lanes that hold the channel quads of one pixel row
+__device__ __forceinline__ float eg3d_row_group_sum(float s, int group) {
+    for (int m = group >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    return s;
+}
+
 // XCD-aware block-id remap (bijective for any grid size): hardware places block b on XCD b % 8; give each XCD a
 // contiguous chunk of logical tiles so that tiles sharing operands share an L2.
 __device__ __forceinline__ int eg3d_xcd_remap(int bid, int nblocks) {

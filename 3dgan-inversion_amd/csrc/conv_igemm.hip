@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
     float* As = smem;
     // the row bookkeeping sits behind whichever is larger: the operand stages or the vector epilogue's staging area (which reuses them)
     constexpr int OPER_BYTES = 2 * (A_STAGE + B_STAGE);
-    constexpr int EPI_STAGE_BYTES = VEC ? (BN + WM * 32 * (BN + 4)) * 4 : 0;
+    constexpr int EPI_STAGE_BYTES = VEC ? (3 * BN + 4 + WM * 32 * (BN + 4)) * 4 : 0;
     int* rowpix = reinterpret_cast<int*>(As_b + (OPER_BYTES > EPI_STAGE_BYTES ? OPER_BYTES : EPI_STAGE_BYTES));   // [BM] output pixel index (n*Ho+oy)*Wo+ox, -1 = none
     int* rown = rowpix + BM;                  // [BM] batch index
 
@@ -395,7 +395,9 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
     const int m_last = (m0 + BM < Mc ? m0 + BM : Mc) - 1;
     const bool single_n = (m_last / HWa) == n_first;
     float* ds_lds = As;                     // BN floats, reused after the final barrier
-    const bool do_ds = (epi == EG3D_EPI_BWD) && p.ds != nullptr && p.xin != nullptr;
+    const bool act_on = VEC && epi == EG3D_EPI_BWD_ACT;                  // + the producing layer's activation backward (common.h); host: VEC only
+    const bool bwd_like = epi == EG3D_EPI_BWD || act_on;
+    const bool do_ds = bwd_like && p.ds != nullptr && p.xin != nullptr;
     float* const ds_out = p.ds_replicas > 1 ? p.ds + (size_t)(blockIdx.x % p.ds_replicas) * p.N * p.Nc : p.ds;
     if (do_ds && single_n) {
         if (tid < BN) ds_lds[tid] = 0.f;
@@ -416,15 +418,30 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
         constexpr int UNITS = WM * 32 * UPR;
         constexpr int UPT = UNITS / NT;                     // units per thread and pass
         static_assert(UNITS % NT == 0 && NT % UPR == 0, "epilogue mapping");
-        float* stage = smem + BN;                           // after the ds_lds row
+        float* db_lds = smem + BN;                          // column sums of the fused activation backward (dbias, dd) + a scalar
+        float* dq_lds = smem + 2 * BN;
+        float* sc_lds = smem + 3 * BN;
+        float* stage = smem + 3 * BN + 4;                   // after the column-sum rows
+        const eg3d_act_bwd& ab = p.act_bwd;
+        eg3d_act_bwd_consts abc = {};
+        if (act_on) {
+            abc = eg3d_act_bwd_setup(ab);
+            if (tid < BN) { db_lds[tid] = 0.f; dq_lds[tid] = 0.f; }
+            if (tid == 0) sc_lds[0] = 0.f;
+        }
+        const bool row_sums = act_on && (ab.dnoise != nullptr || ab.dstrength != nullptr);
         const int c4 = tid % UPR;                           // this thread's column group is the same in every unit it handles
         const int col = n0 + c4 * 4;
         const bool cok = col < p.Nc;
         float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), scl4 = make_float4(1.f, 1.f, 1.f, 1.f), dsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float omax = 0.f;
         if (cok && epi == EG3D_EPI_FWD && p.bias != nullptr) bias4 = *reinterpret_cast<const float4*>(p.bias + col);
-        if (cok && (epi == EG3D_EPI_FWD || epi == EG3D_EPI_BWD) && p.out_scale != nullptr)
+        if (cok && (epi == EG3D_EPI_FWD || bwd_like) && p.out_scale != nullptr)
             scl4 = *reinterpret_cast<const float4*>(p.out_scale + (int64_t)n_first * p.Nc + col);
+        float4 abd4 = make_float4(1.f, 1.f, 1.f, 1.f), abb4 = make_float4(0.f, 0.f, 0.f, 0.f), accb4 = abb4, accd4 = abb4;
+        float accs = 0.f;
+        if (act_on && ab.d != nullptr) abd4 = *reinterpret_cast<const float4*>(ab.d + (int64_t)n_first * p.Nc + col);
+        if (act_on && ab.bias != nullptr) abb4 = *reinterpret_cast<const float4*>(ab.bias + col);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             __syncthreads();                                // previous pass fully consumed (and the main loop's LDS reads are done)
@@ -437,7 +454,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
             constexpr int UG = UPT > 4 ? 4 : UPT;            // units in flight per thread (register budget)
 #pragma unroll
             for (int ug = 0; ug < UPT; ug += UG) {
-            int offs[UG];
+            int offs[UG], pixl[UG];
             float4 va[UG], sa[UG], sb[UG];
             float nz[UG];
 #pragma unroll
@@ -448,11 +465,13 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
                 const int pix = rowpix[rl];
                 const bool ok = pix >= 0 && cok;
                 offs[u] = ok ? pix * p.ldo + col : -1;
+                pixl[u] = pix - n_first * HWo;
                 va[u] = *reinterpret_cast<const float4*>(stage + row * LDS_N + c4 * 4);
                 sa[u] = make_float4(0.f, 0.f, 0.f, 0.f); sb[u] = sa[u]; nz[u] = 0.f;
-                if (ok && (epi == EG3D_EPI_FWD || epi == EG3D_EPI_BWD) && p.addend != nullptr) sa[u] = *reinterpret_cast<const float4*>(p.addend + offs[u]);
-                if (ok && epi == EG3D_EPI_FWD && p.noise != nullptr) nz[u] = p.noise[(int64_t)n_first * p.noise_nstride + (pix - n_first * HWo)];
-                if (ok && do_ds) sb[u] = *reinterpret_cast<const float4*>(p.xin + offs[u]);
+                if (ok && (epi == EG3D_EPI_FWD || bwd_like) && p.addend != nullptr) sa[u] = *reinterpret_cast<const float4*>(p.addend + offs[u]);
+                if (ok && epi == EG3D_EPI_FWD && p.noise != nullptr) nz[u] = p.noise[(int64_t)n_first * p.noise_nstride + pixl[u]];
+                if (ok && act_on && ab.noise != nullptr) nz[u] = ab.noise[(int64_t)n_first * ab.noise_nstride + pixl[u]];
+                if (ok && (do_ds || act_on)) sb[u] = *reinterpret_cast<const float4*>(p.xin + offs[u]);
             }
 #pragma unroll
             for (int u = 0; u < UG; ++u) {                  // phase 2: arithmetic + stores
@@ -467,9 +486,20 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
                         if (p.clamp >= 0.f) e[q] = fminf(fmaxf(e[q], -p.clamp), p.clamp);
                     }
                     v = make_float4(e[0] + sa[u].x, e[1] + sa[u].y, e[2] + sa[u].z, e[3] + sa[u].w);
-                } else if (epi == EG3D_EPI_BWD) {
+                } else if (bwd_like) {
                     if (do_ds) { dsum4.x += v.x * sb[u].x; dsum4.y += v.y * sb[u].y; dsum4.z += v.z * sb[u].z; dsum4.w += v.w * sb[u].w; }
                     v = make_float4(v.x * scl4.x + sa[u].x, v.y * scl4.y + sa[u].y, v.z * scl4.z + sa[u].z, v.w * scl4.w + sa[u].w);
+                    if (act_on) {                   // v = dout of the layer that produced xin: its activation backward, here
+                        float cs;
+                        v = eg3d_act_bwd_unit(abc, v, sb[u], abd4, abb4, nz[u] * abc.strength, accb4, accd4, cs);
+                        if (row_sums) {             // the UPR consecutive lanes of a row (host: Nc % BN == 0, so all of them are here)
+                            cs = eg3d_row_group_sum(cs, UPR);
+                            if (c4 == 0) {
+                                if (ab.dnoise != nullptr) unsafeAtomicAdd(ab.dnoise + (int64_t)n_first * ab.dnoise_nstride + pixl[u], cs * abc.strength);
+                                accs += cs * nz[u];
+                            }
+                        }
+                    }
                 }
                 omax = fmaxf(omax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
                 *reinterpret_cast<float4*>(p.out + offs[u]) = v;
@@ -477,13 +507,30 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
             }
         }
         eg3d_commit_amax(omax, p.out_amax);                 // max|out| for the consumer's operand range
-        if (do_ds) {                                        // block-level column sums, then one atomic per column
-            if (cok) {
+        if (do_ds || act_on) {                              // block-level column sums, then one atomic per column
+            if (cok && do_ds) {
                 atomicAdd(&ds_lds[c4 * 4 + 0], dsum4.x); atomicAdd(&ds_lds[c4 * 4 + 1], dsum4.y);
                 atomicAdd(&ds_lds[c4 * 4 + 2], dsum4.z); atomicAdd(&ds_lds[c4 * 4 + 3], dsum4.w);
             }
+            if (cok && act_on) {
+                if (ab.dbias != nullptr) {
+                    atomicAdd(&db_lds[c4 * 4 + 0], accb4.x); atomicAdd(&db_lds[c4 * 4 + 1], accb4.y);
+                    atomicAdd(&db_lds[c4 * 4 + 2], accb4.z); atomicAdd(&db_lds[c4 * 4 + 3], accb4.w);
+                }
+                if (ab.dd != nullptr) {
+                    atomicAdd(&dq_lds[c4 * 4 + 0], accd4.x); atomicAdd(&dq_lds[c4 * 4 + 1], accd4.y);
+                    atomicAdd(&dq_lds[c4 * 4 + 2], accd4.z); atomicAdd(&dq_lds[c4 * 4 + 3], accd4.w);
+                }
+                if (ab.dstrength != nullptr && accs != 0.f) atomicAdd(sc_lds, accs);
+            }
             __syncthreads();
-            if (tid < BN && n0 + tid < p.Nc) unsafeAtomicAdd(ds_out + (int64_t)n_first * p.Nc + n0 + tid, ds_lds[tid]);
+            if (tid < BN && n0 + tid < p.Nc) {
+                if (do_ds) unsafeAtomicAdd(ds_out + (int64_t)n_first * p.Nc + n0 + tid, ds_lds[tid]);
+                if (act_on && ab.dbias != nullptr) unsafeAtomicAdd(ab.dbias + n0 + tid, db_lds[tid]);
+                if (act_on && ab.dd != nullptr)         // dL/dd = sum dy * z,  z = (pre - bias - noise) / d
+                    unsafeAtomicAdd(ab.dd + (int64_t)n_first * p.Nc + n0 + tid, dq_lds[tid] / (ab.d != nullptr ? ab.d[(int64_t)n_first * p.Nc + n0 + tid] : 1.f));
+            }
+            if (act_on && ab.dstrength != nullptr && tid == 0 && sc_lds[0] != 0.f) unsafeAtomicAdd(ab.dstrength, sc_lds[0]);
         }
     } else {
     constexpr int RC = 8;                     // rows per lane whose side inputs are in flight together
@@ -586,7 +633,7 @@ int launch_conv_pv(const eg3d_conv_params& p, hipStream_t st) {
     constexpr int NP = PREC == 1 ? 3 : 2;
     constexpr int KB = BM * BN >= 128 * 128 ? 16 : 32;
     const size_t loop_bytes = PREC ? (size_t)2 * (split_tile_bytes(BM, NP, KB) + split_tile_bytes(BN, NP, KB)) : (size_t)(2 * (BM + BN) * LDK) * sizeof(float);
-    const size_t stage_bytes = VEC ? (size_t)(BN + WM * 32 * (BN + 4)) * sizeof(float) : 0;        // epilogue staging reuses the operand buffers
+    const size_t stage_bytes = VEC ? (size_t)(3 * BN + 4 + WM * 32 * (BN + 4)) * sizeof(float) : 0;        // epilogue staging reuses the operand buffers
     const size_t smem = (loop_bytes > stage_bytes ? loop_bytes : stage_bytes) + 2 * BM * sizeof(int);
     auto kern = conv_igemm_kernel<BM, BN, WM, WN, PREC, VEC>;
     if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)smem, attr_done)) return e;
@@ -633,7 +680,28 @@ int pick_config(const eg3d_conv_params& p) {
     return 1;
 }
 
+bool act_bwd_ok(const eg3d_conv_params& p) {
+    const eg3d_act_bwd& ab = p.act_bwd;
+    if (!p.xin || p.ksplit != 1) return false;
+    if (ab.act != EG3D_ACT_LINEAR && ab.act != EG3D_ACT_LRELU) return false;            // invertible piecewise-linear activations only
+    if (!(ab.gain > 0.f) || (ab.noise != nullptr && ab.noise_strength == nullptr)) return false;
+    if ((reinterpret_cast<uintptr_t>(ab.d) & 15) || (reinterpret_cast<uintptr_t>(ab.bias) & 15)) return false;
+    static const int BMs[5] = {128, 64, 32, 128, 256}, BNs[5] = {128, 128, 128, 32, 64};
+    const int cfg = pick_config(p);
+    if (p.Nc % BNs[cfg]) return false;                                                   // whole rows of channel quads in every tile
+    switch (BMs[cfg]) {
+        case 128: return conv_vector_epilogue_ok<128>(p);
+        case 64: return conv_vector_epilogue_ok<64>(p);
+        case 32: return conv_vector_epilogue_ok<32>(p);
+        default: return conv_vector_epilogue_ok<256>(p);
+    }
+}
+
 }  // namespace
+
+extern "C" int eg3d_conv2d_igemm_act_bwd_ok(const eg3d_conv_params* pp) {
+    return (pp != nullptr && pp->epi == EG3D_EPI_BWD_ACT && pp->ncls >= 1 && pp->ncls <= 4 && pp->ksplit >= 1 && act_bwd_ok(*pp)) ? 1 : 0;
+}
 
 extern "C" int eg3d_conv2d_igemm_f32(const eg3d_conv_params* pp, void* stream) {
     if (!pp) return EG3D_ERR_INVALID;
@@ -642,7 +710,7 @@ extern "C" int eg3d_conv2d_igemm_f32(const eg3d_conv_params* pp, void* stream) {
     if (p.N <= 0 || p.Hi <= 0 || p.Wi <= 0 || p.Ck <= 0 || p.Nc <= 0 || p.Ho <= 0 || p.Wo <= 0) return EG3D_ERR_INVALID;
     if (p.ncls < 1 || p.ncls > 4 || p.ksplit < 1 || p.in_stride < 1 || p.out_stride < 1) return EG3D_ERR_INVALID;
     if (p.ksplit > 1 && p.epi != EG3D_EPI_ATOMIC) return EG3D_ERR_INVALID;
-    if (p.epi < EG3D_EPI_STORE || p.epi > EG3D_EPI_BWD) return EG3D_ERR_INVALID;
+    if (p.epi < EG3D_EPI_STORE || p.epi > EG3D_EPI_BWD_ACT) return EG3D_ERR_INVALID;
     if (p.precision < 0 || p.precision > 3 || p.ds_replicas < 0) return EG3D_ERR_INVALID;
     if (p.epi == EG3D_EPI_FWD && p.noise && !p.noise_strength) return EG3D_ERR_INVALID;
     if (p.epi == EG3D_EPI_FWD && !eg3d_act_is_pwl(p.act)) return EG3D_ERR_UNSUPPORTED;      // other activations: EPI_STORE + eg3d_bias_act
@@ -661,6 +729,7 @@ extern "C" int eg3d_conv2d_igemm_f32(const eg3d_conv_params* pp, void* stream) {
     }
     if ((int64_t)p.N * p.Hi * p.Wi * p.ldx * 4 > 0x7fffffe0ll || (int64_t)p.N * p.Ho * p.Wo * p.ldo > INT32_MAX) return EG3D_ERR_TOO_LARGE;
     if ((int64_t)p.Nc * p.w_row * 4 > 0x7fffffe0ll) return EG3D_ERR_TOO_LARGE;       // 31-bit buffer offsets
+    if (p.epi == EG3D_EPI_BWD_ACT && !act_bwd_ok(p)) return EG3D_ERR_UNSUPPORTED;     // callers probe with eg3d_conv2d_igemm_act_bwd_ok
     hipStream_t st = (hipStream_t)stream;
     switch (pick_config(p)) {
         case 0: return launch_conv<128, 128, 2, 2>(p, st);

@@ -37,7 +37,7 @@ constexpr int ABUF = 4 * APLANE, BSLOT = 4 * BPLANE;
 constexpr int LDS_A = 0, LDS_B = 2 * ABUF;
 constexpr int LDS_MAIN = 2 * ABUF + 3 * BSLOT;  // 73728
 constexpr int LDS_N = BN + 4;                   // epilogue staging row (floats)
-constexpr int LDS_EPI = (BN + 64 * LDS_N) * 4;  // column sums + 64 staged rows
+constexpr int LDS_EPI = (3 * BN + 4 + 64 * LDS_N) * 4;  // column sums (ds, dbias, dd) + a scalar + 64 staged rows
 constexpr int LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
 
 __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rs, unsigned lds_byte, unsigned voff) {
@@ -196,11 +196,19 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
     const float out_mul = 1.f / (*p.a_scale * *p.w_scale);              // exact powers of two
     const int epi = p.epi;
     float* ds_lds = reinterpret_cast<float*>(smem);
-    float* stage = ds_lds + BN;
-    const bool do_ds = epi == EG3D_EPI_BWD && p.ds != nullptr && p.xin != nullptr;
-    if (do_ds) {
-        if (tid < BN) ds_lds[tid] = 0.f;
-    }
+    float* db_lds = ds_lds + BN;
+    float* dq_lds = ds_lds + 2 * BN;
+    float* sc_lds = ds_lds + 3 * BN;
+    float* stage = ds_lds + 3 * BN + 4;
+    const bool act_on = epi == EG3D_EPI_BWD_ACT;                         // + the producing layer's activation backward (common.h)
+    const bool bwd_like = epi == EG3D_EPI_BWD || act_on;
+    const bool do_ds = bwd_like && p.ds != nullptr && p.xin != nullptr;
+    const eg3d_act_bwd& ab = p.act_bwd;
+    eg3d_act_bwd_consts abc = {};
+    if (act_on) abc = eg3d_act_bwd_setup(ab);
+    const bool row_sums = act_on && (ab.dnoise != nullptr || ab.dstrength != nullptr);
+    if (tid < BN) { ds_lds[tid] = 0.f; db_lds[tid] = 0.f; dq_lds[tid] = 0.f; }
+    if (tid == 0) sc_lds[0] = 0.f;
     const float strength = (epi == EG3D_EPI_FWD && p.noise != nullptr) ? *p.noise_strength : 0.f;
     const float act_slope = eg3d_act_pwl_slope(p.act, p.alpha);
     const int HWo = p.Ho * p.Wo;
@@ -208,7 +216,11 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
     const int col = n0 + c4 * 4;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), scl4 = make_float4(1.f, 1.f, 1.f, 1.f), dsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (epi == EG3D_EPI_FWD && p.bias != nullptr) bias4 = *reinterpret_cast<const float4*>(p.bias + col);
-    if ((epi == EG3D_EPI_FWD || epi == EG3D_EPI_BWD) && p.out_scale != nullptr) scl4 = *reinterpret_cast<const float4*>(p.out_scale + (int64_t)n * p.Nc + col);
+    if ((epi == EG3D_EPI_FWD || bwd_like) && p.out_scale != nullptr) scl4 = *reinterpret_cast<const float4*>(p.out_scale + (int64_t)n * p.Nc + col);
+    float4 abd4 = make_float4(1.f, 1.f, 1.f, 1.f), abb4 = make_float4(0.f, 0.f, 0.f, 0.f), accb4 = abb4, accd4 = abb4;
+    float accs = 0.f;
+    if (act_on && ab.d != nullptr) abd4 = *reinterpret_cast<const float4*>(ab.d + (int64_t)n * p.Nc + col);
+    if (act_on && ab.bias != nullptr) abb4 = *reinterpret_cast<const float4*>(ab.bias + col);
     float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -222,7 +234,7 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
         // 64 rows x 32 float4 units = 2048 units, 8 per thread, in two groups of 4 (loads first, then arithmetic + stores)
 #pragma unroll
         for (int ug = 0; ug < 8; ug += 4) {
-            int offs[4];
+            int offs[4], pixl[4];
             float4 va[4], sa[4], sb[4];
             float nz[4];
 #pragma unroll
@@ -232,11 +244,13 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
                 const bool ok = ay < Ha && ax < Wa;
                 const int pix = (n * p.Ho + ay * p.out_stride + cl.out_py) * p.Wo + ax * p.out_stride + cl.out_px;
                 offs[u] = ok ? pix * p.ldo + col : -1;
+                pixl[u] = pix - n * HWo;
                 va[u] = *reinterpret_cast<const float4*>(stage + row * LDS_N + c4 * 4);
                 sa[u] = make_float4(0.f, 0.f, 0.f, 0.f); sb[u] = sa[u]; nz[u] = 0.f;
-                if (ok && (epi == EG3D_EPI_FWD || epi == EG3D_EPI_BWD) && p.addend != nullptr) sa[u] = *reinterpret_cast<const float4*>(p.addend + offs[u]);
-                if (ok && epi == EG3D_EPI_FWD && p.noise != nullptr) nz[u] = p.noise[(int64_t)n * p.noise_nstride + (pix - n * HWo)];
-                if (ok && do_ds) sb[u] = *reinterpret_cast<const float4*>(p.xin + offs[u]);
+                if (ok && (epi == EG3D_EPI_FWD || bwd_like) && p.addend != nullptr) sa[u] = *reinterpret_cast<const float4*>(p.addend + offs[u]);
+                if (ok && epi == EG3D_EPI_FWD && p.noise != nullptr) nz[u] = p.noise[(int64_t)n * p.noise_nstride + pixl[u]];
+                if (ok && act_on && ab.noise != nullptr) nz[u] = ab.noise[(int64_t)n * ab.noise_nstride + pixl[u]];
+                if (ok && (do_ds || act_on)) sb[u] = *reinterpret_cast<const float4*>(p.xin + offs[u]);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -251,20 +265,50 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
                         if (p.clamp >= 0.f) e[q] = fminf(fmaxf(e[q], -p.clamp), p.clamp);
                     }
                     v = make_float4(e[0] + sa[u].x, e[1] + sa[u].y, e[2] + sa[u].z, e[3] + sa[u].w);
-                } else if (epi == EG3D_EPI_BWD) {
+                } else if (bwd_like) {
                     if (do_ds) { dsum4.x += v.x * sb[u].x; dsum4.y += v.y * sb[u].y; dsum4.z += v.z * sb[u].z; dsum4.w += v.w * sb[u].w; }
                     v = make_float4(v.x * scl4.x + sa[u].x, v.y * scl4.y + sa[u].y, v.z * scl4.z + sa[u].z, v.w * scl4.w + sa[u].w);
+                    if (act_on) {                   // v = dout of the layer that produced xin: its activation backward, here
+                        float cs;
+                        v = eg3d_act_bwd_unit(abc, v, sb[u], abd4, abb4, nz[u] * abc.strength, accb4, accd4, cs);
+                        if (row_sums) {             // the 32 lanes of a half-wave hold the 128 channels of this pixel (rows are half-wave uniform)
+                            cs = eg3d_row_group_sum(cs, 32);
+                            if (c4 == 0) {
+                                if (ab.dnoise != nullptr) unsafeAtomicAdd(ab.dnoise + (int64_t)n * ab.dnoise_nstride + pixl[u], cs * abc.strength);
+                                accs += cs * nz[u];
+                            }
+                        }
+                    }
                 }
                 amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
                 *reinterpret_cast<float4*>(p.out + offs[u]) = v;
             }
         }
     }
-    if (do_ds) {
-        atomicAdd(&ds_lds[c4 * 4 + 0], dsum4.x); atomicAdd(&ds_lds[c4 * 4 + 1], dsum4.y);
-        atomicAdd(&ds_lds[c4 * 4 + 2], dsum4.z); atomicAdd(&ds_lds[c4 * 4 + 3], dsum4.w);
+    if (do_ds || act_on) {
+        if (do_ds) {
+            atomicAdd(&ds_lds[c4 * 4 + 0], dsum4.x); atomicAdd(&ds_lds[c4 * 4 + 1], dsum4.y);
+            atomicAdd(&ds_lds[c4 * 4 + 2], dsum4.z); atomicAdd(&ds_lds[c4 * 4 + 3], dsum4.w);
+        }
+        if (act_on) {
+            if (ab.dbias != nullptr) {
+                atomicAdd(&db_lds[c4 * 4 + 0], accb4.x); atomicAdd(&db_lds[c4 * 4 + 1], accb4.y);
+                atomicAdd(&db_lds[c4 * 4 + 2], accb4.z); atomicAdd(&db_lds[c4 * 4 + 3], accb4.w);
+            }
+            if (ab.dd != nullptr) {
+                atomicAdd(&dq_lds[c4 * 4 + 0], accd4.x); atomicAdd(&dq_lds[c4 * 4 + 1], accd4.y);
+                atomicAdd(&dq_lds[c4 * 4 + 2], accd4.z); atomicAdd(&dq_lds[c4 * 4 + 3], accd4.w);
+            }
+            if (ab.dstrength != nullptr && accs != 0.f) atomicAdd(sc_lds, accs);
+        }
         __syncthreads();
-        if (tid < BN) unsafeAtomicAdd(p.ds + (int64_t)n * p.Nc + n0 + tid, ds_lds[tid]);
+        if (tid < BN) {
+            if (do_ds) unsafeAtomicAdd(p.ds + (int64_t)n * p.Nc + n0 + tid, ds_lds[tid]);
+            if (act_on && ab.dbias != nullptr) unsafeAtomicAdd(ab.dbias + n0 + tid, db_lds[tid]);
+            if (act_on && ab.dd != nullptr)       // dL/dd = sum dy * z,  z = (pre - bias - noise) / d
+                unsafeAtomicAdd(ab.dd + (int64_t)n * p.Nc + n0 + tid, dq_lds[tid] / (ab.d != nullptr ? ab.d[(int64_t)n * p.Nc + n0 + tid] : 1.f));
+        }
+        if (act_on && ab.dstrength != nullptr && tid == 0 && sc_lds[0] != 0.f) unsafeAtomicAdd(ab.dstrength, sc_lds[0]);
     }
     eg3d_commit_amax(amax, p.out_amax);          // max|out|: the consumer's operand range
 }
@@ -392,8 +436,13 @@ extern "C" int eg3d_conv2d_v2_supported(const eg3d_conv_v2_params* pp) {
     const eg3d_conv_v2_params& p = *pp;
     if (p.N <= 0 || p.Hi <= 0 || p.Wi <= 0 || p.Ck < 16 || (p.Ck & 15) || p.Nc < BN || (p.Nc % BN) || (p.ldo & 3)) return 0;
     if (p.in_stride != 1 || p.out_stride < 1 || p.ncls < 1 || p.ncls > 4) return 0;
-    if (p.epi != EG3D_EPI_STORE && p.epi != EG3D_EPI_FWD && p.epi != EG3D_EPI_BWD) return 0;
+    if (p.epi != EG3D_EPI_STORE && p.epi != EG3D_EPI_FWD && p.epi != EG3D_EPI_BWD && p.epi != EG3D_EPI_BWD_ACT) return 0;
     if (p.epi == EG3D_EPI_FWD && !eg3d_act_is_pwl(p.act)) return 0;
+    if (p.epi == EG3D_EPI_BWD_ACT) {
+        const eg3d_act_bwd& ab = p.act_bwd;
+        if (ab.act != EG3D_ACT_LINEAR && ab.act != EG3D_ACT_LRELU) return 0;          // invertible piecewise-linear activations only
+        if (!(ab.gain > 0.f) || (ab.noise != nullptr && ab.noise_strength == nullptr)) return 0;
+    }
     for (int c = 0; c < p.ncls; ++c) {
         const eg3d_conv_class& k = p.cls[c];
         if (k.ntaps != 9 && k.ntaps != 4 && k.ntaps != 2 && k.ntaps != 1) return 0;
@@ -412,7 +461,8 @@ extern "C" int eg3d_conv2d_v2(const eg3d_conv_v2_params* pp, void* stream) {
     if (!pp || !pp->a || !pp->w || !pp->out || !pp->a_scale || !pp->w_scale) return EG3D_ERR_INVALID;
     if (!eg3d_conv2d_v2_supported(pp)) return EG3D_ERR_UNSUPPORTED;
     const eg3d_conv_v2_params& p = *pp;
-    const void* ptrs[] = {p.out, p.addend, p.xin, p.out_scale, p.bias};
+    if (p.epi == EG3D_EPI_BWD_ACT && !p.xin) return EG3D_ERR_INVALID;
+    const void* ptrs[] = {p.out, p.addend, p.xin, p.out_scale, p.bias, p.act_bwd.d, p.act_bwd.bias};
     for (const void* q : ptrs)
         if (q != nullptr && (reinterpret_cast<uintptr_t>(q) & 15)) return EG3D_ERR_UNSUPPORTED;
     if (p.epi == EG3D_EPI_FWD && p.noise && !p.noise_strength) return EG3D_ERR_INVALID;

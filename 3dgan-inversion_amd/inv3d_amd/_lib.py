@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get('EG3D_LIBNAME', 'libeg3d_hip.so'))     # EG3D_LIBNAME: A/B builds in one GPU session
 
 F32, F16, F64 = 0, 1, 2
-EPI_STORE, EPI_ATOMIC, EPI_FWD, EPI_BWD = 0, 1, 2, 3
+EPI_STORE, EPI_ATOMIC, EPI_FWD, EPI_BWD, EPI_BWD_ACT = 0, 1, 2, 3, 4
 ACT_IDS = dict(linear=1, relu=2, lrelu=3, tanh=4, sigmoid=5, elu=6, selu=7, softplus=8, swish=9)
 
 c_float_p = C.POINTER(C.c_float)
@@ -22,6 +22,13 @@ c_float_p = C.POINTER(C.c_float)
 class ConvClass(C.Structure):
     _fields_ = [('Ha', C.c_int32), ('Wa', C.c_int32), ('out_py', C.c_int32), ('out_px', C.c_int32), ('ntaps', C.c_int32),
                 ('dy', C.c_int32 * 9), ('dx', C.c_int32 * 9), ('wtap', C.c_int32 * 9)]
+
+
+class ActBwd(C.Structure):
+    """eg3d_act_bwd: the producing layer's activation backward fused into a data-gradient epilogue (EPI_BWD_ACT)."""
+    _fields_ = [('d', C.c_void_p), ('bias', C.c_void_p), ('noise', C.c_void_p), ('noise_nstride', C.c_int64), ('noise_strength', C.c_void_p),
+                ('act', C.c_int32), ('alpha', C.c_float), ('gain', C.c_float), ('clamp', C.c_float),
+                ('dbias', C.c_void_p), ('dd', C.c_void_p), ('dnoise', C.c_void_p), ('dnoise_nstride', C.c_int64), ('dstrength', C.c_void_p)]
 
 
 class ConvParams(C.Structure):
@@ -34,7 +41,7 @@ class ConvParams(C.Structure):
                 ('in_scale', C.c_void_p), ('epi', C.c_int32), ('ksplit', C.c_int32),
                 ('out_scale', C.c_void_p), ('bias', C.c_void_p), ('noise', C.c_void_p), ('noise_nstride', C.c_int64),
                 ('noise_strength', C.c_void_p), ('act', C.c_int32), ('alpha', C.c_float), ('gain', C.c_float),
-                ('clamp', C.c_float), ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p), ('precision', C.c_int32), ('a_amax', C.c_void_p), ('a_amax_mul', C.c_float), ('ds_replicas', C.c_int32), ('out_amax', C.c_void_p)]
+                ('clamp', C.c_float), ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p), ('precision', C.c_int32), ('a_amax', C.c_void_p), ('a_amax_mul', C.c_float), ('ds_replicas', C.c_int32), ('out_amax', C.c_void_p), ('act_bwd', ActBwd)]
 
 
 class ConvV2Params(C.Structure):
@@ -44,7 +51,7 @@ class ConvV2Params(C.Structure):
                 ('ncls', C.c_int32), ('cls', ConvClass * 4), ('epi', C.c_int32),
                 ('out_scale', C.c_void_p), ('bias', C.c_void_p), ('noise', C.c_void_p), ('noise_nstride', C.c_int64),
                 ('noise_strength', C.c_void_p), ('act', C.c_int32), ('alpha', C.c_float), ('gain', C.c_float), ('clamp', C.c_float),
-                ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p), ('out_amax', C.c_void_p)]
+                ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p), ('out_amax', C.c_void_p), ('act_bwd', ActBwd)]
 
 
 class WgradParams(C.Structure):
@@ -114,6 +121,7 @@ _SIGS = {
                                  C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p]),
     'eg3d_conv2d_igemm_f32': (C.c_int, [C.POINTER(ConvParams), C.c_void_p]),
     'eg3d_conv2d_igemm_config': (C.c_int, [C.POINTER(ConvParams)]),
+    'eg3d_conv2d_igemm_act_bwd_ok': (C.c_int, [C.POINTER(ConvParams)]),
     'eg3d_conv2d_wgrad_f32': (C.c_int, [C.POINTER(WgradParams), C.c_void_p]),
     'eg3d_conv2d_v2_supported': (C.c_int, [C.POINTER(ConvV2Params)]),
     'eg3d_conv2d_v2': (C.c_int, [C.POINTER(ConvV2Params), C.c_void_p]),

@@ -118,9 +118,54 @@ def _auto_ksplit(classes, N, Nc, Ck):
     return max(1, min(-(-target // blocks), steps // 8))
 
 
+# ---- cross-layer backward fusion (EG3D_EPI_BWD_ACT) ------------------------------------------------------------------------------------
+# A modulated conv layer's backward starts with an element-wise pass over (dout, out) -> dz + four reductions (eg3d_modconv_epilogue_bwd:
+# 3 x tensor bytes, 0.64 ms of a C2 step).  dout is itself the output of the CONSUMER's data-gradient conv, whose epilogue already reads
+# this layer's saved output (its `xin`, for the style gradient).  So a layer whose output has exactly one consumer leaves a record at
+# forward time; the consumer's backward finds it through its input tensor, launches its data gradient with EPI_BWD_ACT -- which applies
+# this layer's activation backward in the same epilogue -- and hands back dz in place of dout.  This layer's backward recognises the
+# buffer and skips its own pass.
+FUSE_ACT_BWD = os.environ.get('EG3D_FUSE_ACT_BWD', '1') != '0'
+
+
+class _ActProducer:
+    __slots__ = ('out', 'd', 'nz', 'nstride', 'noise_strength', 'b', 'gain', 'clamp', 'need', 'fused')
+
+
+_PRODUCER_BY_LAYER = {}       # id(layer cache) -> record (at most one per layer: replaced by the layer's next forward)
+_PRODUCER_BY_PTR = {}         # out.data_ptr() -> record (the record holds `out`, so the address cannot be recycled while it is listed)
+
+
+def _set_producer(cache, rec):
+    old = _PRODUCER_BY_LAYER.pop(id(cache), None)
+    if old is not None and _PRODUCER_BY_PTR.get(old.out.data_ptr()) is old:
+        del _PRODUCER_BY_PTR[old.out.data_ptr()]
+    if rec is not None:
+        _PRODUCER_BY_LAYER[id(cache)] = rec
+        _PRODUCER_BY_PTR[rec.out.data_ptr()] = rec
+    return old
+
+
+def _act_bwd_for(x, dev):
+    """(record, ActBwdSpec, accumulators) when `x` is the output of a layer that left a producer record, else (None, None, None)."""
+    rec = _PRODUCER_BY_PTR.get(x.data_ptr()) if FUSE_ACT_BWD else None
+    if rec is None or rec.fused is not None or rec.out.shape != x.shape:
+        return None, None, None
+    N, Co = x.shape[:2]
+    need_b, need_dd, need_nz, need_ns = rec.need
+    has_nz = rec.nz is not None
+    acc = _zeros_views(dev, (Co,) if need_b else None, (N, Co) if need_dd else None, tuple(rec.nz.shape) if (need_nz and has_nz) else None,
+                       () if (need_ns and has_nz) else None, (1,))
+    spec = H.ActBwdSpec(d=rec.d, bias=rec.b, noise=rec.nz, noise_nstride=rec.nstride or 0, noise_strength=rec.noise_strength if has_nz else None,
+                        act='lrelu', alpha=0.2, gain=rec.gain, clamp=rec.clamp, dbias=acc[0], dd=acc[1], dnoise=acc[2],
+                        dnoise_nstride=rec.nstride or 0, dstrength=acc[3])
+    return rec, spec, acc
+
+
 class ModConvLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, styles, noise, noise_strength, bias, up, act_gain, clamp, cache, want_wgrad, d_in=None):
+    def forward(ctx, x, weight, styles, noise, noise_strength, bias, up, act_gain, clamp, cache, want_wgrad, d_in=None, single_consumer=False,
+                input_is_layer_output=False):
         # x: CL [N,Ci,H,W]; weight [Co,Ci,3,3]; styles [N,Ci]; noise None | [res,res] | [N,1,res,res]; noise_strength 0-d
         # d_in: the demodulation coefficients [N,Co] when the style bank already computed them (their gradient is then returned)
         L.require_cuda(x, weight, styles)
@@ -172,8 +217,18 @@ class ModConvLayerFn(torch.autograd.Function):
                 H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=prec)
             H.epilogue_fwd(z, out, fir=fir44(x.device), pad0=1, fir_gain=float(up * up), d=d, out_amax=amax_out, **epi_kw)
         H.tag_amax(out, amax_out)
+        rec = None
+        if FUSE_ACT_BWD and single_consumer and any(ctx.needs_input_grad[:6]):      # see _ActProducer: the consumer may run this layer's activation backward
+            ng = ctx.needs_input_grad
+            rec = _ActProducer()
+            rec.out, rec.d, rec.nz, rec.nstride, rec.noise_strength, rec.b, rec.gain, rec.clamp, rec.fused = out, d, nz, nstride, noise_strength, b, act_gain, clampv, None
+            rec.need = (bool(ng[5]), bool(ng[2] or (ng[1] and want_wgrad)), bool(ng[3]), bool(ng[4]))
+        _set_producer(cache, rec)
         ctx.save_for_backward(x, weight, styles, d, out, nz, noise_strength, b)
         ctx.cfg = (up, act_gain, clampv, nstride, cache, want_wgrad, noise is not None and noise.dim() == 4, d_in is not None)
+        # both ends opt in: the producer promises a single consumer, the consumer that its x is that producer's output handed over directly
+        # (NOT the copy routed through a toRGB node: that gradient is summed inside the toRGB data gradient, which is the fusing launch then)
+        ctx.fuse_input = bool(input_is_layer_output)
         return out
 
     @staticmethod
@@ -188,7 +243,11 @@ class ModConvLayerFn(torch.autograd.Function):
         Ho, Wo = Hi * up, Wi * up
         dev = x.device
         wf, wa, wsq = cache.get(weight)
-        dz = H.empty_cl(N, Co, Ho, Wo, dev)
+        rec = _set_producer(cache, None)
+        pre = None              # (dz, dbias, dd, dnoise, dstrength, amax) when the consumer's data gradient already ran this layer's activation backward
+        if rec is not None and rec.fused is not None and rec.fused[0].data_ptr() == dout.data_ptr() and rec.fused[0].shape == dout.shape:
+            pre = rec.fused
+        dz = pre[0] if pre is not None else H.empty_cl(N, Co, Ho, Wo, dev)
         ks_adj = rep = None
         if need_x or need_s:
             cls_probe = H.classes_corr_adjoint(Hi, Wi, kh, kw, kh // 2) if up == 1 else H.classes_convT_adjoint(Hi, Wi, kh, kw, up)
@@ -197,14 +256,18 @@ class ModConvLayerFn(torch.autograd.Function):
             rep = 1          # replicas of the style-gradient accumulator (eg3d_conv_params::ds_replicas) measured no gain on MI355X
         # all small atomically-accumulated outputs of this backward from one zero fill
         prec = H.modconv_precision()
-        dbias, dd, dnoise, dstrength, ds, amax = _zeros_views(
-            dev, (Co,) if need_b else None, (N, Co) if (need_s or need_w) else None,
-            tuple(nz.shape) if (need_nz and nz is not None) else None, () if (need_ns and nz is not None) else None,
-            None if ks_adj is None else ((rep, N, Ci) if rep > 1 else (N, Ci)),
-            (1,) if (prec == 'f16x3' and ks_adj is not None) else None)          # max|dz|: operand range of the f16x3 data gradient
-        H.epilogue_bwd(dout, out, dz, d=d, noise=nz, noise_nstride=nstride or 0, noise_strength=noise_strength if nz is not None else None,
-                       bias=b, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv, dbias=dbias, dd=dd, dnoise=dnoise,
-                       dnoise_nstride=nstride or 0, dstrength=dstrength, dz_amax=amax)
+        if pre is not None:
+            _, dbias, dd, dnoise, dstrength, amax = pre
+            ds = None if ks_adj is None else H.zeros((N, Ci), dev)
+        else:
+            dbias, dd, dnoise, dstrength, ds, amax = _zeros_views(
+                dev, (Co,) if need_b else None, (N, Co) if (need_s or need_w) else None,
+                tuple(nz.shape) if (need_nz and nz is not None) else None, () if (need_ns and nz is not None) else None,
+                None if ks_adj is None else ((rep, N, Ci) if rep > 1 else (N, Ci)),
+                (1,) if (prec == 'f16x3' and ks_adj is not None) else None)          # max|dz|: operand range of the f16x3 data gradient
+            H.epilogue_bwd(dout, out, dz, d=d, noise=nz, noise_nstride=nstride or 0, noise_strength=noise_strength if nz is not None else None,
+                           bias=b, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv, dbias=dbias, dd=dd, dnoise=dnoise,
+                           dnoise_nstride=nstride or 0, dstrength=dstrength, dz_amax=amax)
         amul = 1.0 if up == 1 else float(up * up)       # g = FIR(dz) * up^2 with a non-negative unit-sum filter: |g| <= up^2 max|dz|
         if up == 1:
             g = dz
@@ -221,19 +284,25 @@ class ModConvLayerFn(torch.autograd.Function):
             dx = H.empty_cl(N, Ci, Hi, Wi, dev)
             aflops = 2.0 * N * Hi * Wi * kh * kw * Ci * Co
             ks = ks_adj
+            # x is some layer's output: if that layer left a record, this launch also runs ITS activation backward (dx then holds its dz)
+            prod, spec, pacc = _act_bwd_for(x, dev) if (ks == 1 and need_x and ctx.fuse_input) else (None, None, None)
+            fkw = dict(act_bwd=spec, out_amax=pacc[4]) if prod is not None else {}
             if H.USE_V2 and up == 1 and ks == 1 and prec == 'f16x3' and H.conv_v2_supported(Co, Ci, cls_adj, N):
-                H.conv_v2(H.split_activation(g, amax), cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds,
-                          algo_flops=aflops)
+                did = H.conv_v2(H.split_activation(g, amax), cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds,
+                                algo_flops=aflops, **fkw)
             elif ks == 1:
-                H.conv_igemm(g, wa, Co, Ci, dx, cls_adj, in_stride=in_stride, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, algo_flops=aflops,
-                             precision=prec, a_amax=amax, a_amax_mul=amul)
+                did = H.conv_igemm(g, wa, Co, Ci, dx, cls_adj, in_stride=in_stride, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, algo_flops=aflops,
+                                   precision=prec, a_amax=amax, a_amax_mul=amul, **fkw)
                 if rep > 1:
                     ds = ds.sum(0)
             else:                                  # low resolution: split K over blocks, then scale / reduce in a finishing pass
+                did = False
                 z = H.zeros_cl(N, Ci, Hi, Wi, dev)
                 H.conv_igemm(g, wa, Co, Ci, z, cls_adj, in_stride=in_stride, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=prec, a_amax=amax,
                              a_amax_mul=amul)
                 H.dgrad_finish(z, x, styles, dx, ds=ds)
+            if prod is not None and did is True:
+                prod.fused = (dx,) + tuple(pacc)
         dwsq = H.zeros(wsq.shape, dev) if need_w else None
         if dd is not None and (need_s or need_w) and not d_given:       # with d from the style bank, dd is returned and handled there
             if ds is None:
@@ -253,7 +322,7 @@ class ModConvLayerFn(torch.autograd.Function):
         if dnoise is not None and noise4d:
             dnoise = dnoise.view(N, 1, Ho, Wo)
         return (dx if need_x else None, dweight, ds if need_s else None, dnoise, dstrength, dbias, None, None, None, None, None,
-                dd if d_given else None)
+                dd if d_given else None, None, None)
 
 
 class StyleBankFn(torch.autograd.Function):
@@ -356,7 +425,7 @@ class ToRGBFn(torch.autograd.Function):
     """y = clamp(conv1x1(x * styles, W) + bias);  out = skip + y (skip optional).  Small channel counts are padded to 4."""
 
     @staticmethod
-    def forward(ctx, x, weight, styles, bias, skip, clamp, cache, want_wgrad, passthrough=False):
+    def forward(ctx, x, weight, styles, bias, skip, clamp, cache, want_wgrad, passthrough=False, input_is_layer_output=False):
         """passthrough=True additionally returns x itself: the consumer of that output (the next block's conv0) then sends its
         gradient through THIS backward, where it is added inside the data-gradient epilogue instead of by a separate autograd add
         (3 x tensor bytes per block, 67 MB tensors in the SR head)."""
@@ -389,6 +458,7 @@ class ToRGBFn(torch.autograd.Function):
             out = y + skip if skip is not None else y
         ctx.save_for_backward(x, weight, styles, y if clampv >= 0 else None)
         ctx.cfg = (clampv, cache, want_wgrad, Cp, skip is not None)
+        ctx.fuse_input = bool(input_is_layer_output)         # x is conv1's output handed over directly (see ModConvLayerFn)
         if not passthrough:
             return out
         xv = x.view_as(x)
@@ -420,7 +490,12 @@ class ToRGBFn(torch.autograd.Function):
             dx = H.empty_cl(N, Ci, Hh, Ww, dev)
             ds = H.zeros((N, Ci), dev)
             add = H.to_cl(dx_pass.float()) if dx_pass is not None else None
-            H.conv_igemm(dy, wa_p, Cp, Ci, dx, H.classes_corr_adjoint(Hh, Ww, 1, 1, 0), epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, addend=add)
+            prod, spec, pacc = _act_bwd_for(x, dev) if (need_x and ctx.fuse_input) else (None, None, None)      # x = conv1's output: run its activation backward here
+            fkw = dict(act_bwd=spec, out_amax=pacc[4]) if prod is not None else {}
+            did = H.conv_igemm(dy, wa_p, Cp, Ci, dx, H.classes_corr_adjoint(Hh, Ww, 1, 1, 0), epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, addend=add,
+                               **fkw)
+            if prod is not None and did is True:
+                prod.fused = (dx,) + tuple(pacc)
         elif dx_pass is not None:
             dx = dx_pass
         dweight = None
@@ -428,7 +503,7 @@ class ToRGBFn(torch.autograd.Function):
             dwp = H.zeros((Co, Ci), dev)
             H.conv_wgrad(x, dy, Ci, Co, dwp, H.classes_corr(Hh, Ww, 1, 1, 0), in_scale=styles)
             dweight = dwp.view(Co, Ci, 1, 1)
-        return (dx if need_x else None, dweight, ds if need_s else None, dbias, dout if (need_skip and has_skip) else None, None, None, None, None)
+        return (dx if need_x else None, dweight, ds if need_s else None, dbias, dout if (need_skip and has_skip) else None, None, None, None, None, None)
 
 
 class UpsampleImgFn(torch.autograd.Function):

@@ -339,10 +339,31 @@ def modconv_precision() -> str:
     return 'f16x3' if CONV_MODE == 'auto' else CONV_MODE
 
 
+class ActBwdSpec:
+    """What EPI_BWD_ACT needs about the layer that produced a data gradient's `xin`: that layer's epilogue constants (saved at its forward)
+    and the pre-zeroed reduction targets of its backward (filled by the fused launch)."""
+    __slots__ = ('d', 'bias', 'noise', 'noise_nstride', 'noise_strength', 'act', 'alpha', 'gain', 'clamp', 'dbias', 'dd', 'dnoise',
+                 'dnoise_nstride', 'dstrength')
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+    def fill(self, ab):
+        tp = lambda t: t.data_ptr() if t is not None else None
+        ab.d, ab.bias, ab.noise, ab.noise_strength = tp(self.d), tp(self.bias), tp(self.noise), tp(self.noise_strength)
+        ab.noise_nstride, ab.dnoise_nstride = int(self.noise_nstride or 0), int(self.dnoise_nstride or 0)
+        ab.act, ab.alpha, ab.gain, ab.clamp = L.ACT_IDS[self.act], float(self.alpha), float(self.gain), float(self.clamp)
+        ab.dbias, ab.dd, ab.dnoise, ab.dstrength = tp(self.dbias), tp(self.dd), tp(self.dnoise), tp(self.dstrength)
+
+
 def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=None, epi=L.EPI_STORE, ksplit=1,
                out_scale=None, bias=None, noise=None, noise_nstride=0, noise_strength=None, act='linear', alpha=0.0, gain=1.0,
-               clamp=-1.0, addend=None, xin=None, ds=None, algo_flops=None, precision=None, a_amax=None, a_amax_mul=1.0, out_amax=None):
-    """Launch eg3d_conv2d_igemm_f32.  x/out/addend/xin: channels_last fp32 [N,C,H,W]; wp: packed weights [Nc, taps*Ck]."""
+               clamp=-1.0, addend=None, xin=None, ds=None, algo_flops=None, precision=None, a_amax=None, a_amax_mul=1.0, out_amax=None,
+               act_bwd=None):
+    """Launch eg3d_conv2d_igemm_f32.  x/out/addend/xin: channels_last fp32 [N,C,H,W]; wp: packed weights [Nc, taps*Ck].
+    act_bwd (an ActBwdSpec, with epi=EPI_BWD): try EPI_BWD_ACT; returns True when the fused epilogue ran (out then holds the producing
+    layer's dz), False when the launch was a plain EPI_BWD."""
     assert is_cl(x) and is_cl(out), 'conv_igemm expects fp32 channels_last CUDA tensors'
     p = L.ConvParams()
     n, cx, hi, wi = x.shape
@@ -371,6 +392,14 @@ def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=
     p.a_amax_mul = float(a_amax_mul)
     p.ds_replicas = ds.shape[0] if (ds is not None and ds.dim() == 3) else 1
     p.out_amax = out_amax.data_ptr() if out_amax is not None else None
+    fused_act = False
+    if act_bwd is not None and epi == L.EPI_BWD:
+        p.epi = L.EPI_BWD_ACT
+        act_bwd.fill(p.act_bwd)
+        fused_act = bool(L.lib().eg3d_conv2d_igemm_act_bwd_ok(C.byref(p)))
+        if not fused_act:
+            p.epi = L.EPI_BWD
+            p.act_bwd = L.ActBwd()
     prof = PROFILER
     if prof is not None:
         cfg = L.lib().eg3d_conv2d_igemm_config(C.byref(p))
@@ -388,7 +417,7 @@ def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=
         if prof.meta is not None:
             prof.meta.append(dict(N=n, Hi=hi, Wi=wi, Ck=Ck, Nc=Nc, Ho=ho, Wo=wo, taps=[c.ntaps for c in classes], epi=epi, ksplit=ksplit,
                                   in_stride=in_stride, out_stride=out_stride, prec=p.precision))
-    return out
+    return fused_act if act_bwd is not None else out
 
 
 # ------------------------------------------------------------------------------------------------- pre-split convolution (csrc/conv_v2.hip)
@@ -488,11 +517,22 @@ V2_CONVT = os.environ.get('EG3D_V2_CONVT', '0') == '1'
 
 
 def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_STORE, out_scale=None, bias=None, noise=None, noise_nstride=0,
-            noise_strength=None, act='linear', alpha=0.0, gain=1.0, clamp=-1.0, addend=None, xin=None, ds=None, out_amax=None, algo_flops=None):
-    """Launch eg3d_conv2d_v2 (operands prepared by split_activation / split_weight)."""
+            noise_strength=None, act='linear', alpha=0.0, gain=1.0, clamp=-1.0, addend=None, xin=None, ds=None, out_amax=None, algo_flops=None,
+            act_bwd=None):
+    """Launch eg3d_conv2d_v2 (operands prepared by split_activation / split_weight).  act_bwd (ActBwdSpec, with epi=EPI_BWD): EPI_BWD_ACT when
+    the kernel takes it -- returns True if the fused epilogue ran, False for a plain EPI_BWD."""
     assert is_cl(out)
     p = _conv_v2_params(a, w, out, classes, out_stride, epi, out_scale, bias, noise, noise_nstride, noise_strength, act, alpha, gain, clamp,
                         addend, xin, ds, out_amax)
+    fused_act = False
+    if act_bwd is not None and epi == L.EPI_BWD and xin is not None:
+        p.epi = L.EPI_BWD_ACT
+        act_bwd.fill(p.act_bwd)
+        fused_act = bool(L.lib().eg3d_conv2d_v2_supported(C.byref(p))) and all(
+            t is None or t.data_ptr() % 16 == 0 for t in (act_bwd.d, act_bwd.bias))
+        if not fused_act:
+            p.epi = L.EPI_BWD
+            p.act_bwd = L.ActBwd()
     prof = PROFILER
     if prof is not None and prof.only_config is not None and prof.only_config != V2_CONFIG:
         prof = None
@@ -508,7 +548,7 @@ def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_
         if prof.meta is not None:
             prof.meta.append(dict(N=p.N, Hi=p.Hi, Wi=p.Wi, Ck=p.Ck, Nc=p.Nc, Ho=p.Ho, Wo=p.Wo, taps=[c.ntaps for c in classes], epi=epi, ksplit=1,
                                   in_stride=1, out_stride=out_stride, prec=3, v2=True))
-    return out
+    return fused_act if act_bwd is not None else out
 
 
 V2_CONFIG = 5        # "tile configuration" id of the pre-split kernel in profiler records (eg3d_conv2d_igemm_config returns 0..4)

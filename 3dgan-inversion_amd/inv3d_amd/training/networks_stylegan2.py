@@ -110,9 +110,12 @@ class SynthesisLayer(ReferenceStateMixin, torch.nn.Module):
             self.register_buffer('noise_const', torch.randn(resolution, resolution))
         self._cache = fused.WeightCache()
 
-    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, noise_inject=None, styles=None, demod=None):
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, noise_inject=None, styles=None, demod=None, single_consumer=False,
+                input_is_layer_output=False):
         """`styles` / `demod`: this layer's affine(w) and demodulation coefficients when the enclosing network already evaluated them
-        for all layers in one launch (fused.style_bank)."""
+        for all layers in one launch (fused.style_bank).  `single_consumer`: the caller promises that the returned tensor feeds exactly one
+        fused op (conv1 / toRGB of the same block), which lets that op's backward absorb this layer's activation backward (fused.py);
+        `input_is_layer_output`: x is such a layer's output, handed over directly."""
         assert noise_mode in ['random', 'const', 'none']
         if styles is None:
             styles = self.affine(w)
@@ -125,7 +128,8 @@ class SynthesisLayer(ReferenceStateMixin, torch.nn.Module):
             noise = self.noise_const
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return fused.ModConvLayerFn.apply(x, self.weight, styles, noise, self.noise_strength if noise is not None else None, self.bias,
-                                          self.up, self.act_gain * gain, clamp, self._cache, self.weight.requires_grad, demod)
+                                          self.up, self.act_gain * gain, clamp, self._cache, self.weight.requires_grad, demod, single_consumer,
+                                          input_is_layer_output)
 
     def extra_repr(self):
         return f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}, w_dim={self.w_dim:d}, ' \
@@ -146,13 +150,14 @@ class ToRGBLayer(ReferenceStateMixin, torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros(out_channels))
         self._cache = fused.WeightCache()
 
-    def forward(self, x, w, fused_modconv=True, skip=None, styles=None, passthrough=False):
+    def forward(self, x, w, fused_modconv=True, skip=None, styles=None, passthrough=False, input_is_layer_output=False):
         """Returns skip + torgb(x) on a channel count padded to a multiple of 4 (padding channels stay as in `skip`/zero).
         `styles`: affine(w) * weight_gain when precomputed by the enclosing network.  passthrough=True: returns (img, x) where the
         second output is x routed through this op's autograd node (see fused.ToRGBFn)."""
         if styles is None:
             styles = self.affine(w) * self.weight_gain
-        return fused.ToRGBFn.apply(x, self.weight, styles, self.bias, skip, self.conv_clamp, self._cache, self.weight.requires_grad, passthrough)
+        return fused.ToRGBFn.apply(x, self.weight, styles, self.bias, skip, self.conv_clamp, self._cache, self.weight.requires_grad, passthrough,
+                                   input_is_layer_output)
 
 
 def _pad4(c):
@@ -201,17 +206,20 @@ class SynthesisBlock(ReferenceStateMixin, torch.nn.Module):
         ni = noise_inject or {}
         if self.in_channels == 0:
             x = self.const.unsqueeze(0).expand(ws.shape[0], -1, -1, -1)
-            x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), styles=next(s_iter), demod=next(d_iter), **layer_kwargs)
-        else:
-            x = self.conv0(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv0'), styles=next(s_iter), demod=next(d_iter), **layer_kwargs)
-            x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), styles=next(s_iter), demod=next(d_iter), **layer_kwargs)
+            x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), styles=next(s_iter), demod=next(d_iter), single_consumer=True,
+                           **layer_kwargs)
+        else:       # conv0's output feeds conv1 only, conv1's the toRGB node only (which passes it on to the next block through itself)
+            x = self.conv0(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv0'), styles=next(s_iter), demod=next(d_iter), single_consumer=True,
+                           **layer_kwargs)
+            x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), styles=next(s_iter), demod=next(d_iter), single_consumer=True,
+                           input_is_layer_output=True, **layer_kwargs)
         if img is not None:
             img = fused.UpsampleImgFn.apply(img)
         if self.is_last:
-            img = self.torgb(x, next(w_iter), skip=img, styles=next(s_iter))
+            img = self.torgb(x, next(w_iter), skip=img, styles=next(s_iter), input_is_layer_output=True)
         else:       # x goes on to the next block: route it through the toRGB node so the two gradients are summed in its epilogue
             amax = getattr(x, '_eg3d_amax', None)
-            img, x = self.torgb(x, next(w_iter), skip=img, styles=next(s_iter), passthrough=True)
+            img, x = self.torgb(x, next(w_iter), skip=img, styles=next(s_iter), passthrough=True, input_is_layer_output=True)
             if amax is not None:        # the pass-through output is the same values: keep the producer's max|x| report with it
                 H.tag_amax(x, amax)
         return x, img

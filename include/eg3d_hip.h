@@ -86,6 +86,27 @@ int eg3d_upfirdn2d(const void* x, const float* f, void* y, int dtype, int N, int
 #define EG3D_EPI_ATOMIC 1  /* out += acc  (split-K; out must be pre-zeroed)                               */
 #define EG3D_EPI_FWD 2     /* out = clamp(act(acc*out_scale[n,o] + noise[n,y,x]*strength + bias[o])*gain) (+ addend); act: linear | relu | lrelu */
 #define EG3D_EPI_BWD 3     /* ds[n,o] += sum_px acc*xin ; out = acc*out_scale[n,o] (+ addend)             */
+#define EG3D_EPI_BWD_ACT 4 /* EPI_BWD followed, in the same epilogue, by the activation backward of the layer that PRODUCED xin
+                            * (eg3d_act_bwd below): the value EPI_BWD would store is that layer's dout, xin is its saved output, so
+                            *   dy = dout * act'(xin) * gain (0 where |xin| >= clamp);  out = dy * d[n,o];  + the reductions of
+                            * eg3d_modconv_epilogue_bwd.  Saves that pass: dout is never written, xin is read once.           */
+
+/* The producing layer's activation backward for EG3D_EPI_BWD_ACT (same contract as eg3d_modconv_epilogue_bwd: linear / lrelu, reduction
+ * targets pre-zeroed and accumulated with atomics; every pointer optional). */
+typedef struct eg3d_act_bwd {
+    const float* d;            /* [N,Nc] demodulation coefficients of that layer (out = dy * d), or null */
+    const float* bias;         /* [Nc] or null                                                          */
+    const float* noise;        /* [*,Ho,Wo] or null; batch stride noise_nstride (0 = shared)            */
+    int64_t noise_nstride;
+    const float* noise_strength;
+    int32_t act;
+    float alpha, gain, clamp;
+    float* dbias;              /* [Nc]   += sum dy                                                      */
+    float* dd;                 /* [N,Nc] += sum_px dy * (pre_act - bias - noise*strength) / d            */
+    float* dnoise;             /* [*,Ho,Wo] += strength * sum_c dy; batch stride dnoise_nstride          */
+    int64_t dnoise_nstride;
+    float* dstrength;          /* scalar += sum dy * noise                                              */
+} eg3d_act_bwd;
 
 typedef struct eg3d_conv_class {
     int32_t Ha, Wa;            /* output grid of this class                              */
@@ -137,7 +158,12 @@ typedef struct eg3d_conv_params {
                                 * 0 or 1 = a single [N,Nc] buffer. */
     float* out_amax;           /* optional, pre-zeroed device scalar: receives max|out| (atomic max; EPI_STORE / FWD / BWD) -- the operand
                                 * range a consumer needs to range-normalise its two-piece fp16 split */
+    eg3d_act_bwd act_bwd;      /* EG3D_EPI_BWD_ACT only (xin required; vector epilogue only: eg3d_conv2d_igemm_act_bwd_ok) */
 } eg3d_conv_params;
+
+/* 1 when this launch can run EG3D_EPI_BWD_ACT (aligned rows, channel counts that are multiples of 4, no split-K, tiles within one
+ * image); otherwise run EG3D_EPI_BWD and eg3d_modconv_epilogue_bwd separately. */
+int eg3d_conv2d_igemm_act_bwd_ok(const eg3d_conv_params* p);
 
 int eg3d_conv2d_igemm_f32(const eg3d_conv_params* p, void* stream);
 /* Which tile configuration eg3d_conv2d_igemm_f32 will launch for p: 0 = 128x128x32 (the dominant kernel), 1 = 64x128,
@@ -177,6 +203,7 @@ typedef struct eg3d_conv_v2_params {
     const float* addend;  const float* xin;
     float* ds;
     float* out_amax;
+    eg3d_act_bwd act_bwd;      /* EG3D_EPI_BWD_ACT only */
 } eg3d_conv_v2_params;
 int eg3d_conv2d_v2_supported(const eg3d_conv_v2_params* p);
 int eg3d_conv2d_v2(const eg3d_conv_v2_params* p, void* stream);

@@ -718,3 +718,86 @@ def test_absmax_any_length(n):
         x[1] = float('inf')
         x[n - 1] = 9.25
         assert float(H.absmax(x.to(DEV))) == 9.25
+
+
+@pytest.mark.parametrize('kind', ['v2_3x3', 'igemm_3x3', 'igemm_1x1', 'igemm_clamp_shared_noise'])
+def test_fused_activation_backward_equals_separate_pass(kind):
+    """EG3D_EPI_BWD_ACT: a data-gradient launch that also runs the activation backward of the layer that produced its `xin`
+    (dz, dbias, dd, dnoise, dstrength, max|dz|) against the two-pass form it replaces (EPI_BWD, then eg3d_modconv_epilogue_bwd on
+    the stored dout) -- and the two-pass form against a float64 evaluation of the same expressions."""
+    from inv3d_amd import hipops as H, _lib as L
+    CL = torch.channels_last
+
+    def close(a, b, tol, what):            # relative to the largest reference value (the operands here are gradient-sized)
+        a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+        assert a.shape == b.shape and torch.isfinite(a).all(), what
+        err, scale = float((a - b).abs().max()), float(b.abs().max())
+        assert err <= tol * scale, f'{what}: err {err:.3e} > {tol} * {scale:.3e}'
+
+    n, ci, h, w, co = (2, 128, 24, 64, 128) if kind != 'igemm_1x1' else (2, 128, 32, 32, 4)
+    k = 1 if kind == 'igemm_1x1' else 3
+    g = torch.Generator().manual_seed(31)
+    gz = torch.randn(n, co, h, w, generator=g) * 1e-3
+    wt = torch.randn(co, ci, k, k, generator=g) / math.sqrt(ci * k * k)
+    s = 1 + 0.5 * torch.randn(n, ci, generator=g)
+    xin = torch.randn(n, ci, h, w, generator=g) * 1.5                   # the producing layer's saved output (lrelu'd, gained)
+    add = torch.randn(n, ci, h, w, generator=g) * 1e-3
+    d = 0.5 + torch.rand(n, ci, generator=g)
+    bias = torch.randn(ci, generator=g) * 0.1
+    shared = kind == 'igemm_clamp_shared_noise'
+    noise = torch.randn(h, w, generator=g) if shared else torch.randn(n, 1, h, w, generator=g)
+    strength = torch.tensor(0.37)
+    gain, clamp, alpha = math.sqrt(2), (1.2 if shared else -1.0), 0.2
+    dev = lambda t: t.to(DEV).contiguous(memory_format=CL) if t.dim() == 4 and t.shape[1] > 1 else t.to(DEV).contiguous()
+    xin_d, add_d, s_d, d_d, b_d, nz_d, st_d = dev(xin), dev(add), dev(s), dev(d), dev(bias), dev(noise), strength.to(DEV)
+    nstride = 0 if shared else h * w
+    cls = H.classes_corr_adjoint(h, w, k, k, k // 2)
+
+    def launch(spec, out_amax):
+        dx, ds = H.empty_cl(n, ci, h, w, DEV), torch.zeros(n, ci, device=DEV)
+        kw = dict(epi=L.EPI_BWD, out_scale=s_d, xin=xin_d, ds=ds, addend=add_d, out_amax=out_amax)
+        if spec is not None:
+            kw['act_bwd'] = spec
+        if kind == 'v2_3x3':
+            _, aimg, wimg = _v2_operands(gz, wt, None, adjoint=True)
+            r = H.conv_v2(aimg, wimg, dx, cls, **kw)
+        else:
+            wa = wt.permute(1, 2, 3, 0).reshape(ci, k * k * co).to(DEV).contiguous()          # adjoint pack [I][tap][O]
+            r = H.conv_igemm(dev(gz), wa, co, ci, dx, cls, precision='bf16x6', **kw)
+        return dx, ds, r
+
+    def accs():
+        return dict(dbias=torch.zeros(ci, device=DEV), dd=torch.zeros(n, ci, device=DEV), dnoise=torch.zeros_like(nz_d), dstrength=torch.zeros((), device=DEV))
+
+    # two passes
+    dout, ds_a, _ = launch(None, None)
+    A = accs()
+    amax_a = torch.zeros(1, device=DEV)
+    dz_a = H.epilogue_bwd(dout, xin_d, H.empty_cl(n, ci, h, w, DEV), d=d_d, noise=nz_d, noise_nstride=nstride, noise_strength=st_d, bias=b_d, act='lrelu',
+                          alpha=alpha, gain=gain, clamp=clamp, dnoise_nstride=nstride, dz_amax=amax_a, **A)
+    # one pass
+    B = accs()
+    amax_b = torch.zeros(1, device=DEV)
+    spec = H.ActBwdSpec(d=d_d, bias=b_d, noise=nz_d, noise_nstride=nstride, noise_strength=st_d, act='lrelu', alpha=alpha, gain=gain, clamp=clamp,
+                        dnoise_nstride=nstride, **B)
+    dz_b, ds_b, fused = launch(spec, amax_b)
+    assert fused is True, 'the fused epilogue was not taken'
+    close(dz_b, dz_a, 1e-6, f'{kind} dz')
+    close(ds_b, ds_a, 1e-5, f'{kind} ds')
+    for key in A:
+        close(B[key], A[key], 2e-5, f'{kind} {key}')
+    assert abs(float(amax_b) - float(dz_a.abs().max())) <= 1e-6 * float(amax_b)
+    # float64 statement of the activation backward on the stored dout
+    o, do = xin.double(), dout.cpu().double()
+    yy = o / gain
+    dy = do * gain * torch.where(yy > 0, 1.0, alpha)
+    if clamp >= 0:
+        dy = torch.where(o.abs() >= clamp, 0.0, dy)
+    pre = torch.where(yy > 0, yy, yy / alpha)
+    nz64 = (noise.double() * float(strength)).reshape((1, 1, h, w) if shared else (n, 1, h, w))
+    close(dz_b, (dy * d.double()[:, :, None, None]).float(), 1e-5, f'{kind} dz vs f64')
+    close(B['dbias'], dy.sum((0, 2, 3)).float(), 5e-5, f'{kind} dbias vs f64')
+    close(B['dd'], ((dy * (pre - bias.double()[None, :, None, None] - nz64)).sum((2, 3)) / d.double()).float(), 5e-5, f'{kind} dd vs f64')
+    dn = dy.sum(1, keepdim=True) * float(strength)
+    close(B['dnoise'], (dn.sum(0)[0] if shared else dn).float(), 5e-5, f'{kind} dnoise vs f64')
+    close(B['dstrength'], (dy.sum(1, keepdim=True) * noise.double().reshape(nz64.shape)).sum().float(), 1e-4, f'{kind} dstrength vs f64')
