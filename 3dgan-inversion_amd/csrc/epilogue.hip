@@ -176,8 +176,11 @@ __device__ __forceinline__ void bwd1(float dout, float o, int act, float alpha, 
 // 2*C atomics onto the same dbias / dd addresses (measured: launch time grows linearly with the block count), so the
 // parallelism comes from 16 waves per block rather than from many blocks.
 constexpr int EPI_BWD_THREADS = 1024;
-template <bool PWL>
-__global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ outv, float* __restrict__ dz,
+// FIN: the incoming gradient is not read but formed on the fly as the finish of a split-K data gradient of the CONSUMER layer,
+// dout = fz * fs[n,c] (+ fadd), and that layer's style gradient fds[n,c] += sum_px fz * out rides along (eg3d_dgrad_finish_act).
+struct FinArgs { const float* z; const float* s; const float* addend; float* ds; };
+template <bool PWL, bool FIN>
+__global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const FinArgs fin, const float* __restrict__ dout, const float* __restrict__ outv, float* __restrict__ dz,
                                                            int H, int W, int C4, const float* __restrict__ d, const float* __restrict__ noise,
                                                            int64_t noise_nstride, const float* __restrict__ noise_strength,
                                                            const float* __restrict__ bias, int act, float alpha, float gain, float clamp,
@@ -195,7 +198,8 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const flo
     float4 dv = make_float4(1, 1, 1, 1), bv = make_float4(0, 0, 0, 0);
     if (active && d) dv = ld4(d + (int64_t)n * C + c);
     if (active && bias) bv = ld4(bias + c);
-    float4 accb = make_float4(0, 0, 0, 0), accd = make_float4(0, 0, 0, 0);
+    float4 accb = make_float4(0, 0, 0, 0), accd = make_float4(0, 0, 0, 0), accz = make_float4(0, 0, 0, 0), fsv = make_float4(1, 1, 1, 1);
+    if (FIN && active && fin.s) fsv = ld4(fin.s + (int64_t)n * C + c);
     float accs = 0.f, amax = 0.f;
     // lanes of one pixel are contiguous; groups of min(C4,64) lanes can be shuffle-reduced when C4 is a power of two
     const bool pow2 = (C4 & (C4 - 1)) == 0;
@@ -214,7 +218,14 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const flo
                 const int pix = pix0 + u * stride;
                 const bool ok = pix < HW;
                 const int64_t off = ((int64_t)n * HW + (ok ? pix : pix0)) * C + c;
-                g[u] = ld4(dout + off); o[u] = ld4(outv + off);
+                o[u] = ld4(outv + off);
+                if (FIN) {
+                    const float4 zz = ld4(fin.z + off), av = fin.addend ? ld4(fin.addend + off) : make_float4(0, 0, 0, 0);
+                    if (ok && fin.ds) { accz.x += zz.x * o[u].x; accz.y += zz.y * o[u].y; accz.z += zz.z * o[u].z; accz.w += zz.w * o[u].w; }
+                    g[u] = make_float4(zz.x * fsv.x + av.x, zz.y * fsv.y + av.y, zz.z * fsv.z + av.z, zz.w * fsv.w + av.w);
+                } else {
+                    g[u] = ld4(dout + off);
+                }
                 nraw[u] = (noise && ok) ? noise[(int64_t)n * noise_nstride + pix] : 0.f;
             }
 #pragma unroll
@@ -253,9 +264,11 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const flo
     // block reduction over the PPB pixel lanes
     float* rb = red;                         // [ppb][C4][4]
     float* rd = red + ppb * C4 * 4;          // [ppb][C4][4]
-    float* rs = rd + ppb * C4 * 4;           // [1]
+    float* rz = rd + ppb * C4 * 4;           // [ppb][C4][4]  (FIN only)
+    float* rs = rz + (FIN ? ppb * C4 * 4 : 0);    // [1]
     if (threadIdx.x == 0) rs[0] = 0.f;
     if (active) { st4(rb + (pl * C4 + c4) * 4, accb); st4(rd + (pl * C4 + c4) * 4, accd); }
+    if (FIN && active) st4(rz + (pl * C4 + c4) * 4, accz);
     __syncthreads();
     if (dstrength && accs != 0.f) atomicAdd(rs, accs);
     if (threadIdx.x < C4) {
@@ -273,6 +286,12 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const flo
             float* q = dd + (int64_t)n * C + c;
             unsafeAtomicAdd(q + 0, sd.x / dv.x); unsafeAtomicAdd(q + 1, sd.y / dv.y);
             unsafeAtomicAdd(q + 2, sd.z / dv.z); unsafeAtomicAdd(q + 3, sd.w / dv.w);
+        }
+        if (FIN && fin.ds) {
+            float4 sz = make_float4(0, 0, 0, 0);
+            for (int q = 0; q < ppb; ++q) { float4 t = ld4(rz + (q * C4 + c4) * 4); sz.x += t.x; sz.y += t.y; sz.z += t.z; sz.w += t.w; }
+            float* q = fin.ds + (int64_t)n * C + c;
+            unsafeAtomicAdd(q + 0, sz.x); unsafeAtomicAdd(q + 1, sz.y); unsafeAtomicAdd(q + 2, sz.z); unsafeAtomicAdd(q + 3, sz.w);
         }
     }
     __syncthreads();
@@ -480,12 +499,33 @@ extern "C" int eg3d_modconv_epilogue_bwd(const float* dout, const float* out, fl
     const int cap = 256;
     int bx = std::max(1, std::min(eg3d_cdiv((int64_t)H * W, ppb * 4), std::max(1, cap / N)));
     size_t smem = (size_t)(ppb * C4 * 8 + 4) * sizeof(float);
+    const FinArgs nofin = {nullptr, nullptr, nullptr, nullptr};
     if (eg3d_act_is_pwl(act))
-        hipLaunchKernelGGL(epilogue_bwd_kernel<true>, dim3(bx, N), dim3(EPI_BWD_THREADS), smem, (hipStream_t)stream, dout, out, dz, H, W, C4, d, noise, noise_nstride,
+        hipLaunchKernelGGL((epilogue_bwd_kernel<true, false>), dim3(bx, N), dim3(EPI_BWD_THREADS), smem, (hipStream_t)stream, nofin, dout, out, dz, H, W, C4, d, noise, noise_nstride,
                            noise_strength, bias, act, eg3d_act_pwl_slope(act, alpha), gain, clamp, dbias, dd, dnoise, dnoise_nstride, dstrength, dz_amax);
     else
-        hipLaunchKernelGGL(epilogue_bwd_kernel<false>, dim3(bx, N), dim3(EPI_BWD_THREADS), smem, (hipStream_t)stream, dout, out, dz, H, W, C4, d, noise, noise_nstride,
+        hipLaunchKernelGGL((epilogue_bwd_kernel<false, false>), dim3(bx, N), dim3(EPI_BWD_THREADS), smem, (hipStream_t)stream, nofin, dout, out, dz, H, W, C4, d, noise, noise_nstride,
                            noise_strength, bias, act, alpha, gain, clamp, dbias, dd, dnoise, dnoise_nstride, dstrength, dz_amax);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_dgrad_finish_act(const float* z, const float* x, const float* s, const float* addend, float* dz, float* ds, int N, int H, int W, int C,
+                                     const eg3d_act_bwd* ab, float* dz_amax, void* stream) {
+    if (!z || !x || !dz || !ab || N <= 0 || H <= 0 || W <= 0 || C <= 0) return EG3D_ERR_INVALID;
+    if (C % 4 || C / 4 > 256) return EG3D_ERR_UNSUPPORTED;
+    if (ab->act != EG3D_ACT_LINEAR && ab->act != EG3D_ACT_LRELU) return EG3D_ERR_UNSUPPORTED;
+    if ((ab->dd && !ab->d) || ((ab->noise || ab->dnoise || ab->dstrength) && !ab->noise_strength) || ((ab->dnoise || ab->dstrength) && !ab->noise)) return EG3D_ERR_INVALID;
+    const int C4 = C / 4, ppb = std::max(EPI_BWD_THREADS / C4, 1);
+    int bx = std::max(1, std::min(eg3d_cdiv((int64_t)H * W, ppb * 4), std::max(1, 256 / N)));
+    const size_t smem = (size_t)(ppb * C4 * 12 + 4) * sizeof(float);
+    static std::atomic<uint64_t> attr_done{0};
+    auto kern = epilogue_bwd_kernel<true, true>;
+    if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)smem, attr_done)) return e;
+    const FinArgs fin = {z, s, addend, ds};
+    hipLaunchKernelGGL(kern, dim3(bx, N), dim3(EPI_BWD_THREADS), smem, (hipStream_t)stream, fin, nullptr, x, dz, H, W, C4, ab->d, ab->noise, ab->noise_nstride,
+                       ab->noise_strength, ab->bias, ab->act, eg3d_act_pwl_slope(ab->act, ab->alpha), ab->gain, ab->clamp, ab->dbias, ab->dd, ab->dnoise,
+                       ab->dnoise_nstride, ab->dstrength, dz_amax);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

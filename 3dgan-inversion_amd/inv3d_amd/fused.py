@@ -285,7 +285,7 @@ class ModConvLayerFn(torch.autograd.Function):
             aflops = 2.0 * N * Hi * Wi * kh * kw * Ci * Co
             ks = ks_adj
             # x is some layer's output: if that layer left a record, this launch also runs ITS activation backward (dx then holds its dz)
-            prod, spec, pacc = _act_bwd_for(x, dev) if (ks == 1 and need_x and ctx.fuse_input) else (None, None, None)
+            prod, spec, pacc = _act_bwd_for(x, dev) if (need_x and ctx.fuse_input) else (None, None, None)
             fkw = dict(act_bwd=spec, out_amax=pacc[4]) if prod is not None else {}
             if H.USE_V2 and up == 1 and ks == 1 and prec == 'f16x3' and H.conv_v2_supported(Co, Ci, cls_adj, N):
                 did = H.conv_v2(H.split_activation(g, amax), cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds,
@@ -296,11 +296,14 @@ class ModConvLayerFn(torch.autograd.Function):
                 if rep > 1:
                     ds = ds.sum(0)
             else:                                  # low resolution: split K over blocks, then scale / reduce in a finishing pass
-                did = False
                 z = H.zeros_cl(N, Ci, Hi, Wi, dev)
                 H.conv_igemm(g, wa, Co, Ci, z, cls_adj, in_stride=in_stride, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=prec, a_amax=amax,
                              a_amax_mul=amul)
-                H.dgrad_finish(z, x, styles, dx, ds=ds)
+                did = prod is not None and Ci % 4 == 0 and Ci <= 1024
+                if did:
+                    H.dgrad_finish_act(z, x, styles, dx, spec, ds=ds, dz_amax=pacc[4])
+                else:
+                    H.dgrad_finish(z, x, styles, dx, ds=ds)
             if prod is not None and did is True:
                 prod.fused = (dx,) + tuple(pacc)
         dwsq = H.zeros(wsq.shape, dev) if need_w else None

@@ -609,6 +609,16 @@ def dgrad_finish(z, x, s, dx, ds=None, addend=None):
     return dx
 
 
+def dgrad_finish_act(z, x, s, dz, act_bwd, ds=None, addend=None, dz_amax=None):
+    """eg3d_dgrad_finish_act: split-K finish + the activation backward of the layer that produced x; dz receives THAT layer's dz."""
+    n, c, h, w = z.shape
+    ab = L.ActBwd()
+    act_bwd.fill(ab)
+    L.check(L.lib().eg3d_dgrad_finish_act(L.ptr(z), L.ptr(x), L.ptr(s), L.ptr(addend), L.ptr(dz), L.ptr(ds), n, h, w, c, C.byref(ab), L.ptr(dz_amax),
+                                          L.stream_ptr()), 'dgrad_finish_act')
+    return dz
+
+
 def rows_gram(a, b):
     """(a^T b [Ka,Kb], column sums of a [Ka]) for row matrices a [S,Ka], b [S,Kb] with Ka, Kb <= 64 (eg3d_rows_gram)."""
     assert a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0] and a.is_contiguous() and b.is_contiguous()

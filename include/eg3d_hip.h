@@ -332,6 +332,11 @@ int eg3d_modconv_epilogue_bwd(const float* dout, const float* out, float* dz, in
  *   z = conv data-gradient accumulated with EG3D_EPI_ATOMIC;  dx = z * s[n,c] (+ addend);  ds[n,c] += sum_px z * x  (if ds). */
 int eg3d_dgrad_finish(const float* z, const float* x, const float* s, const float* addend, float* dx, float* ds, int N, int H,
                       int W, int C, void* stream);
+/* The same finish followed, in the same pass, by the activation backward of the layer that produced x (EG3D_EPI_BWD_ACT for the split-K
+ * layers): the value eg3d_dgrad_finish would store is that layer's dout;  dz = dout * act'(x) * gain * d, reductions as in
+ * eg3d_modconv_epilogue_bwd (targets in `ab`, pre-zeroed), dz_amax optional. */
+int eg3d_dgrad_finish_act(const float* z, const float* x, const float* s, const float* addend, float* dz, float* ds, int N, int H,
+                          int W, int C, const eg3d_act_bwd* ab, float* dz_amax, void* stream);
 
 /* NHWC FIR resampler used on the fused path (skip-image 2x upsample and its adjoint, FIR adjoint of up=2 layers):
  *   same arithmetic as eg3d_upfirdn2d on a channels-last fp32 tensor, float4 over channels (C % 4 == 0),

@@ -801,3 +801,37 @@ def test_fused_activation_backward_equals_separate_pass(kind):
     dn = dy.sum(1, keepdim=True) * float(strength)
     close(B['dnoise'], (dn.sum(0)[0] if shared else dn).float(), 5e-5, f'{kind} dnoise vs f64')
     close(B['dstrength'], (dy.sum(1, keepdim=True) * noise.double().reshape(nz64.shape)).sum().float(), 1e-4, f'{kind} dstrength vs f64')
+
+
+@pytest.mark.parametrize('shape', [(1, 512, 8, 8), (2, 256, 32, 32), (1, 96, 16, 16)])
+def test_dgrad_finish_with_activation_backward_equals_two_passes(shape):
+    """eg3d_dgrad_finish_act (split-K layers) against eg3d_dgrad_finish followed by eg3d_modconv_epilogue_bwd."""
+    from inv3d_amd import hipops as H
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(41)
+    cl = lambda t: t.to(DEV).contiguous(memory_format=torch.channels_last)
+    z, x, add = cl(torch.randn(n, c, h, w, generator=g) * 1e-3), cl(torch.randn(n, c, h, w, generator=g)), cl(torch.randn(n, c, h, w, generator=g) * 1e-3)
+    s, d, bias = (1 + 0.5 * torch.randn(n, c, generator=g)).to(DEV), (0.5 + torch.rand(n, c, generator=g)).to(DEV), (torch.randn(c, generator=g) * 0.1).to(DEV)
+    noise, strength = torch.randn(h, w, generator=g).to(DEV), torch.tensor(0.4, device=DEV)
+    gain = math.sqrt(2)
+
+    def accs():
+        return dict(dbias=torch.zeros(c, device=DEV), dd=torch.zeros(n, c, device=DEV), dnoise=torch.zeros_like(noise), dstrength=torch.zeros((), device=DEV))
+    A, B = accs(), accs()
+    ds_a, ds_b = torch.zeros(n, c, device=DEV), torch.zeros(n, c, device=DEV)
+    am_a, am_b = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    dout = H.dgrad_finish(z, x, s, H.empty_cl(n, c, h, w, DEV), ds=ds_a, addend=add)
+    dz_a = H.epilogue_bwd(dout, x, H.empty_cl(n, c, h, w, DEV), d=d, noise=noise, noise_strength=strength, bias=bias, act='lrelu', alpha=0.2, gain=gain,
+                          dz_amax=am_a, **A)
+    spec = H.ActBwdSpec(d=d, bias=bias, noise=noise, noise_nstride=0, noise_strength=strength, act='lrelu', alpha=0.2, gain=gain, clamp=-1.0,
+                        dnoise_nstride=0, **B)
+    dz_b = H.dgrad_finish_act(z, x, s, H.empty_cl(n, c, h, w, DEV), spec, ds=ds_b, addend=add, dz_amax=am_b)
+
+    def rel(a, b, tol, what):
+        err, scale = float((a - b).abs().max()), float(b.abs().max())
+        assert err <= tol * scale, f'{what}: {err:.3e} > {tol} * {scale:.3e}'
+    rel(dz_b, dz_a, 1e-6, 'dz')
+    rel(ds_b, ds_a, 1e-5, 'ds')
+    for k in A:
+        rel(B[k], A[k], 2e-5, k)
+    assert float(am_b) == float(am_a)
