@@ -26,6 +26,9 @@ def one(pattern):
 
 def short(name):
     """conv_igemm_kernel<128, 128, 2, 2, 3, true>(eg3d_conv_params) -> conv_igemm_kernel<128,128,2,2,3,true>"""
+    m = re.match(r'_ZN12_GLOBAL__N_1(\d+)', name)          # a symbol rocprofv3 left mangled (vector-of-_Float16 parameters)
+    if m:
+        return name[len(m.group(0)):][:int(m.group(1))]
     name = re.sub(r'^void ', '', name).replace('(anonymous namespace)::', '')
     m = re.match(r'([A-Za-z0-9_:]+(<[^(]*>)?)', name)
     return (m.group(1) if m else name).replace(' ', '')[:110]

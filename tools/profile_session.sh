@@ -15,4 +15,4 @@ timeout 600 rocprofv3 --pmc MfmaUtil LdsUtil --kernel-trace --output-format csv 
 timeout 600 rocprofv3 --pmc LdsBankConflict SQ_INSTS_VALU_MFMA_MOPS_F16 --kernel-trace --output-format csv -d $O/pl -o l -- python $R/bench.py --steps 3 --warmup 1 $Q --no-roofline --no-graph $X > $O/pl.log 2>&1
 tail -1 $O/bench.json | cut -c1-300
 ls $O/stats/* $O/pf/* $O/pw/* $O/pm/* $O/pl/* | head -30
-tail -3 $O/pm.log $O/pl.log
+for f in pm pl; do tail -n 3 $O/$f.log; done
