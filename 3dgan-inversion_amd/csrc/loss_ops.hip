@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(NT) maxpool_bwd_kernel(const float* __restrict
 template <bool BWD>
 __global__ void __launch_bounds__(NT) unit_normalize_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ dout,
                                                             float* __restrict__ out, int64_t npix, int HW, int C4, int ld4, float mul, float eps,
-                                                            int64_t o_nstride, int G) {
+                                                            int64_t o_nstride, int G, int eps_inside) {
     const int lane = threadIdx.x % G;
     const int64_t gid = ((int64_t)blockIdx.x * NT + threadIdx.x) / G;
     const int64_t ngroups = (int64_t)gridDim.x * NT / G;
@@ -103,8 +103,13 @@ __global__ void __launch_bounds__(NT) unit_normalize_kernel(const float* __restr
         const float r = sqrtf(ss);
         // n = x/(r+eps):  dx = g/(r+eps) - x (x.g) / (r (r+eps)^2).  An all-zero pixel (r = 0) gets gradient 0: autograd of the reference
         // expression yields NaN there (0 * inf through sqrt), the limit g/eps is 1e10 * g -- neither is useful to an optimiser.
-        const float inv = (BWD && r == 0.f) ? 0.f : mul / (r + eps);
-        const float back = (BWD && r > 0.f) ? dot * mul / (r * (r + eps) * (r + eps)) : 0.f;
+        float inv = (BWD && r == 0.f) ? 0.f : mul / (r + eps);
+        float back = (BWD && r > 0.f) ? dot * mul / (r * (r + eps) * (r + eps)) : 0.f;
+        if (eps_inside) {       // n = x rsqrt(|x|^2 + eps):  dx = g q - x (x.g) q^3,  q = (|x|^2 + eps)^-1/2  (smooth at 0)
+            const float q = 1.0f / sqrtf(ss + eps);
+            inv = mul * q;
+            back = BWD ? dot * mul * q * q * q : 0.f;
+        }
         for (int c = lane; c < C4; c += G) {
             const float4 v = xp[c];
             const float4 s = scale ? reinterpret_cast<const float4*>(scale)[c] : make_float4(1.f, 1.f, 1.f, 1.f);
@@ -167,7 +172,7 @@ extern "C" int eg3d_maxpool2d_bwd(const float* dy, const uint8_t* argmax, float*
 }
 
 extern "C" int eg3d_unit_normalize_fwd(const float* x, const float* scale, float* feat, int N, int HW, int C, int ldx, float mul, float eps,
-                                       int64_t feat_nstride, void* stream) {
+                                       int64_t feat_nstride, int eps_inside, void* stream) {
     if (!x || !feat || N < 1 || HW < 1 || C < 4 || (C & 3) || ldx < C || (ldx & 3) || !aligned16(x) || !aligned16(feat) || (feat_nstride & 3) ||
         (scale && !aligned16(scale)))
         return EG3D_ERR_INVALID;
@@ -175,13 +180,13 @@ extern "C" int eg3d_unit_normalize_fwd(const float* x, const float* scale, float
     const int64_t npix = (int64_t)N * HW;
     const int blocks = grid_blocks(npix * G);
     hipLaunchKernelGGL(unit_normalize_kernel<false>, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, x, scale, (const float*)nullptr, feat, npix, HW,
-                       C / 4, ldx / 4, mul, eps, feat_nstride, G);
+                       C / 4, ldx / 4, mul, eps, feat_nstride, G, eps_inside);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }
 
 extern "C" int eg3d_unit_normalize_bwd(const float* x, const float* scale, const float* dfeat, float* dx, int N, int HW, int C, int ldx, float mul,
-                                       float eps, int64_t feat_nstride, void* stream) {
+                                       float eps, int64_t feat_nstride, int eps_inside, void* stream) {
     if (!x || !dfeat || !dx || N < 1 || HW < 1 || C < 4 || (C & 3) || ldx < C || (ldx & 3) || !aligned16(x) || !aligned16(dfeat) || !aligned16(dx) ||
         (feat_nstride & 3) || (scale && !aligned16(scale)))
         return EG3D_ERR_INVALID;
@@ -189,7 +194,7 @@ extern "C" int eg3d_unit_normalize_bwd(const float* x, const float* scale, const
     const int64_t npix = (int64_t)N * HW;
     const int blocks = grid_blocks(npix * G);
     hipLaunchKernelGGL(unit_normalize_kernel<true>, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, x, scale, dfeat, dx, npix, HW, C / 4, ldx / 4, mul,
-                       eps, feat_nstride, G);
+                       eps, feat_nstride, G, eps_inside);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -36,16 +36,25 @@ class StubFeatureNet(torch.nn.Module):
             cin = w
 
     def forward(self, img):
+        """Three launches per stage and direction: conv + lrelu (fused epilogue), the 2x2 average, the channel normalisation written
+        straight into the flat feature vector (loss_nets.unit_features).  The features are pixel-major inside a stage's slice -- the
+        projector only ever takes squared distances between two such vectors."""
+        from . import loss_nets as LN
+        x = self.stages(img)
+        return LN.unit_features(x, eps=1e-10)
+
+    def stages(self, img, upto=None):
+        """The pooled stage outputs [N,C_l,h_l,w_l] (channels_last)."""
+        from . import loss_nets as LN
         n, c, h, w = img.shape
         x = torch.cat([img, img.new_zeros(n, 4 - c, h, w)], 1) if c < 4 else img
-        feats = []
-        for wt in self.ws:
-            x = conv2d_gradfix.conv2d(x, wt, padding=1)
-            x = bias_act.bias_act(x, None, act='lrelu')
+        x = hipops.to_cl(x.float())
+        outs = []
+        for wt in list(self.ws)[:upto]:
+            x = LN.conv_act(x, wt, None, 1, 1, 'lrelu', 0.2, math.sqrt(2.0))
             x = F.avg_pool2d(x, 2)
-            f = x * torch.rsqrt(x.square().sum(1, keepdim=True) + 1e-10)
-            feats.append(f.flatten(1) / math.sqrt(f.shape[2] * f.shape[3]))
-        return torch.cat(feats, 1)
+            outs.append(x)
+        return outs
 
 
 class _NoiseRegFn(torch.autograd.Function):
@@ -324,12 +333,7 @@ class LatentProjector:
 
     def feature_net_map(self, img):
         """Spatial feature map for the warping loss from the stub net's first two stages ([N,C,h,w])."""
-        net = self.feature_net
-        n, c, h, w = img.shape
-        x = torch.cat([img, img.new_zeros(n, 4 - c, h, w)], 1) if c < 4 else img
-        for wt in list(net.ws)[:2]:
-            x = F.avg_pool2d(bias_act.bias_act(conv2d_gradfix.conv2d(x, wt, padding=1), None, act='lrelu'), 2)
-        return x
+        return self.feature_net.stages(img, upto=2)[-1]
 
     def _schedule(self, step):
         t = (step - self.preheat) / max(1, (self.num_steps - self.preheat))

@@ -80,7 +80,7 @@ class _ConvActFn(torch.autograd.Function):
     eg3d_conv2d_wgrad_f32 over the same tap classes and the bias gradient is the pixel sum of the pre-activation gradient."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act):
+    def forward(ctx, x, weight, bias, stride, pad, act, alpha=0.0, gain=1.0):
         L.require_cuda(x, weight, bias)
         assert H.is_cl(x) and x.dtype == torch.float32
         N, Cip, Hi, Wi = x.shape
@@ -97,25 +97,25 @@ class _ConvActFn(torch.autograd.Function):
         ks = _auto_ksplit(cls, N, Co, Cip) if len(cls) == 1 else 1
         if len(cls) == 1 and ks == 1:
             y = H.empty_cl(N, Co, Ho, Wo, x.device)
-            H.conv_igemm(x, wf, Cip, Co, y, cls, in_stride=stride, epi=L.EPI_FWD, bias=bias, act=act, gain=1.0, precision=LOSS_NET_PRECISION)
+            H.conv_igemm(x, wf, Cip, Co, y, cls, in_stride=stride, epi=L.EPI_FWD, bias=bias, act=act, alpha=alpha, gain=gain, precision=LOSS_NET_PRECISION)
         else:           # several tap classes per pixel, or a grid too small to fill the chip (split-K): accumulate, then bias + act
             z = H.zeros_cl(N, Co, Ho, Wo, x.device)
             _launch_groups(x, wf, Cip, Co, z, cls, True, in_stride=stride, ksplit=ks)
-            y = H.bias_act_raw(z, bias, None, None, None, 0, 1, L.ACT_IDS[act], 0.0, 1.0, -1.0)
+            y = H.bias_act_raw(z, bias, None, None, None, 0, 1, L.ACT_IDS[act], alpha, gain, -1.0)
         ctx.save_for_backward(y, weight, x if trainable else None)
-        ctx.cfg = (stride, pad, act, x.shape, (Ho, Wo))
+        ctx.cfg = (stride, pad, act, x.shape, (Ho, Wo), float(alpha), float(gain))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         y, weight, x = ctx.saved_tensors
-        stride, pad, act, (N, Cip, Hi, Wi), (Ho, Wo) = ctx.cfg
+        stride, pad, act, (N, Cip, Hi, Wi), (Ho, Wo), alpha, gain = ctx.cfg
         Co, Ci, kh, kw = weight.shape
         need_x, need_w, need_b = ctx.needs_input_grad[:3]
         if not (need_x or need_w or need_b):
-            return (None,) * 6
+            return (None,) * 8
         dy = H.to_cl(dy.float())
-        dz = dy if act == 'linear' else H.bias_act_raw(dy, None, None, y, None, 1, 1, L.ACT_IDS[act], 0.0, 1.0, -1.0)
+        dz = dy if (act == 'linear' and gain == 1.0) else H.bias_act_raw(dy, None, None, y, None, 1, 1, L.ACT_IDS[act], alpha, gain, -1.0)
         dx = dw = db = None
         if need_x:
             def _pack():
@@ -135,11 +135,12 @@ class _ConvActFn(torch.autograd.Function):
             dw = dwp.view(Co, kh, kw, Cip)[..., :Ci].permute(0, 3, 1, 2).contiguous()
         if need_b:
             db = dz.sum((0, 2, 3))
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv_act(x, weight, bias, stride=1, pad=0, act='relu'):
-    return _ConvActFn.apply(x, weight, bias, stride, pad, act)
+def conv_act(x, weight, bias, stride=1, pad=0, act='relu', alpha=0.0, gain=1.0):
+    """act(conv2d(x, weight) + bias) * gain in one launch (act: 'linear' | 'relu' | 'lrelu' with slope alpha)."""
+    return _ConvActFn.apply(x, weight, bias, stride, pad, act, alpha, gain)
 
 
 class _MaxPoolFn(torch.autograd.Function):
@@ -175,6 +176,7 @@ class _LpipsHeadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, eps, nscales, *args):
+        eps, eps_inside = (eps[0], int(eps[1])) if isinstance(eps, tuple) else (eps, 0)
         xs, scales = args[:nscales], args[nscales:]
         N = xs[0].shape[0]
         sizes = [x.shape[1] * x.shape[2] * x.shape[3] for x in xs]
@@ -184,25 +186,26 @@ class _LpipsHeadFn(torch.autograd.Function):
         for x, sc, n in zip(xs, scales, sizes):
             assert H.is_cl(x) and x.dtype == torch.float32
             _, C, Hh, Ww = x.shape
-            L.check(L.lib().eg3d_unit_normalize_fwd(x.data_ptr(), sc.data_ptr(), feat.data_ptr() + 4 * off, N, Hh * Ww, C, C,
-                                                    1.0 / math.sqrt(Hh * Ww), eps, F, L.stream_ptr()), 'unit_normalize_fwd')
+            L.check(L.lib().eg3d_unit_normalize_fwd(x.data_ptr(), sc.data_ptr() if sc is not None else None, feat.data_ptr() + 4 * off, N, Hh * Ww, C, C,
+                                                    1.0 / math.sqrt(Hh * Ww), eps, F, eps_inside, L.stream_ptr()), 'unit_normalize_fwd')
             off += n
-        ctx.save_for_backward(*xs, *scales)
-        ctx.cfg = (eps, nscales, sizes, F)
+        ctx.save_for_backward(*xs, *[s for s in scales if s is not None])
+        ctx.cfg = (eps, nscales, sizes, F, eps_inside, [s is not None for s in scales])
         return feat
 
     @staticmethod
     def backward(ctx, dfeat):
-        eps, nscales, sizes, F = ctx.cfg
-        xs, scales = ctx.saved_tensors[:nscales], ctx.saved_tensors[nscales:]
+        eps, nscales, sizes, F, eps_inside, has_scale = ctx.cfg
+        xs, rest = ctx.saved_tensors[:nscales], list(ctx.saved_tensors[nscales:])
+        scales = [rest.pop(0) if h else None for h in has_scale]
         dfeat = dfeat.contiguous().float()
         grads, off = [], 0
         for i, (x, sc, n) in enumerate(zip(xs, scales, sizes)):
             if ctx.needs_input_grad[2 + i]:
                 N, C, Hh, Ww = x.shape
                 dx = H.empty_cl(N, C, Hh, Ww, x.device)
-                L.check(L.lib().eg3d_unit_normalize_bwd(x.data_ptr(), sc.data_ptr(), dfeat.data_ptr() + 4 * off, dx.data_ptr(), N, Hh * Ww, C, C,
-                                                        1.0 / math.sqrt(Hh * Ww), eps, F, L.stream_ptr()), 'unit_normalize_bwd')
+                L.check(L.lib().eg3d_unit_normalize_bwd(x.data_ptr(), sc.data_ptr() if sc is not None else None, dfeat.data_ptr() + 4 * off, dx.data_ptr(), N, Hh * Ww, C, C,
+                                                        1.0 / math.sqrt(Hh * Ww), eps, F, eps_inside, L.stream_ptr()), 'unit_normalize_bwd')
                 grads.append(dx)
             else:
                 grads.append(None)
@@ -212,6 +215,11 @@ class _LpipsHeadFn(torch.autograd.Function):
 
 def lpips_features(xs: Sequence[torch.Tensor], sqrt_lins: Sequence[torch.Tensor], eps: float = 1e-10) -> torch.Tensor:
     return _LpipsHeadFn.apply(eps, len(xs), *xs, *sqrt_lins)
+
+
+def unit_features(xs: Sequence[torch.Tensor], eps: float = 1e-10) -> torch.Tensor:
+    """[N, sum H*W*C]: per tap x * rsqrt(sum_c x^2 + eps) / sqrt(H*W), pixel-major inside a tap's slice (one launch per tap and direction)."""
+    return _LpipsHeadFn.apply((eps, 1), len(xs), *xs, *([None] * len(xs)))
 
 
 def _image_cl4(img: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, pre_mul: float, pre_add: float) -> torch.Tensor:

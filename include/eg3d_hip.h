@@ -498,12 +498,13 @@ int eg3d_maxpool2d_bwd(const float* dy, const uint8_t* argmax, float* dx, int N,
 /* LPIPS feature head (lpips.normalize_tensor + the square root of the 1x1 "lin" layer + spatial mean folded into the features):
  *   feat[n*feat_nstride + (pix*C + c)] = scale[c] * x[n,pix,c] / (sqrt(sum_c x^2) + eps) * mul
  * so that sum((feat_a - feat_b)^2) is the layer's LPIPS term when scale = sqrt(lin weight), mul = 1/sqrt(H*W).  scale may be null (1).
- * feat points at this layer's slice of a flat [N, F] feature vector (feat_nstride = F). */
+ * feat points at this layer's slice of a flat [N, F] feature vector (feat_nstride = F).
+ * eps_inside != 0: the normaliser is rsqrt(sum_c x^2 + eps) instead (the stand-in feature pyramid of the C2 workload). */
 int eg3d_unit_normalize_fwd(const float* x, const float* scale, float* feat, int N, int HW, int C, int ldx, float mul, float eps,
-                            int64_t feat_nstride, void* stream);
+                            int64_t feat_nstride, int eps_inside, void* stream);
 /* dx[N,HW,ldx] = d feat / d x applied to dfeat (same slice addressing as the forward). */
 int eg3d_unit_normalize_bwd(const float* x, const float* scale, const float* dfeat, float* dx, int N, int HW, int C, int ldx, float mul,
-                            float eps, int64_t feat_nstride, void* stream);
+                            float eps, int64_t feat_nstride, int eps_inside, void* stream);
 
 #ifdef __cplusplus
 }
