@@ -1,11 +1,15 @@
-// Implicit-GEMM convolution for gfx950 on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32, 157 TF peak).
+// Implicit-GEMM convolution for gfx950, loader-split variant: fp32 operands and results in every arithmetic mode; an fp32 product is
+// formed on the matrix cores either exactly (EG3D_PREC_F32: v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak) or from 16-bit MFMA products of
+// operand pieces cut in the LOADER (F16X3 three fp16 products -- the default of the modulated convs --, BF16X6 six bf16 products,
+// BF16X3; include/eg3d_hip.h).  The layers whose grids fill the chip run on the pre-split kernel of conv_v2.hip instead; this kernel
+// keeps the transposed / strided classes, split-K, the small grids, 1x1 heads and every non-modulated conv (loss / pose / e4e networks).
 //
 //   GEMM view:  M = output-grid cells (n,ay,ax)   N = output channels   K = taps x input channels
 //   A[m][k]  gathered on the fly from the NHWC activation tensor (im2col never materialised), optionally scaled by the
 //            per-(n,k) style (modulation folded into the operand load -> weights are shared by the whole batch);
 //   B[n][k]  = w[o][tap][k]  (k contiguous, i.e. the channels_last image of a [O,I,kh,kw] weight).
 //
-//   Block = 256 threads = 4 waves (WM x WN); block tile BM x BN x 32; each wave owns (BM/WM) x (BN/WN) outputs as
+//   Block = 256 threads = 4 waves (WM x WN); block tile BM x BN x (32 fp32 | 16 or 32 split); each wave owns (BM/WM) x (BN/WN) outputs as
 //   32x32 MFMA tiles held in 16 accumulator registers each.  Operands go global -> registers -> LDS (k-contiguous rows
 //   padded to 36 floats: conflict-free ds_read_b128 for the 4x16-lane service groups of gfx950) and are double buffered:
 //   the global loads of step s+1 are in flight while step s is multiplied; one barrier per K-step.

@@ -72,7 +72,8 @@ int eg3d_upfirdn2d(const void* x, const float* f, void* y, int dtype, int N, int
                    const int64_t ys[4], void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32) -- replaces the ATen/cuDNN calls made by
+ * Implicit-GEMM convolution, fp32 in / fp32 out, products on the matrix cores in the arithmetic `precision` selects (exact fp32 MFMA
+ * or 16-bit MFMA products of operand pieces: EG3D_PREC_* below) -- replaces the ATen/cuDNN calls made by
  * conv2d_resample / modulated_conv2d (torch_utils/ops/conv2d_resample.py:31-43,114-136;
  * training/networks_stylegan2.py:34-91) and their autograd backward (the dX contract of
  * torch_utils/ops/conv2d_gradfix.py:139-143).  One launch computes, for every output-grid cell (n,ay,ax):
