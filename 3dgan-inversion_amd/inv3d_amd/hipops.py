@@ -287,7 +287,10 @@ def weights_changed():
 def memo(tag, tensors, fn):
     """Derived images of parameters (packed / padded / pre-scaled weights), recomputed only when a source tensor changes (storage
     pointer or in-place version).  One entry per (tag, storage): frozen weights cost nothing per step, trained ones are rebuilt."""
-    key = (WEIGHTS_EPOCH,) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+    # the optimiser epoch only concerns tensors an optimiser can write: frozen sources (the loss / pose / encoder networks during
+    # pivotal tuning) keep their images across the tuned generator's steps
+    epoch = WEIGHTS_EPOCH if any(t.requires_grad for t in tensors) else -1
+    key = (epoch,) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
     slot = (tag, tensors[0].data_ptr())
     hit = _MEMO.get(slot)
     # the entry is only valid for the very same tensor objects (a freed temporary's address can be reused by another tensor)

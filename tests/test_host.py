@@ -142,6 +142,8 @@ def test_zero_arena_and_memo_host_logic():
     H.memo('t', [w2], lambda: (calls.append(1), w2 * 2)[1])
     assert len(calls) == 3                                         # a different tensor object never hits another one's entry
     # updates that do not bump the version counter (fused multi-tensor optimisers write through raw pointers): weights_changed()
+    w2.requires_grad_(True)                                        # an optimiser's parameter (frozen tensors ignore the epoch, below)
+    H.memo('t', [w2], lambda: (calls.append(1), w2 * 2)[1])
     n = len(calls)
     w2.data_ptr()
     with torch.no_grad():
@@ -150,6 +152,12 @@ def test_zero_arena_and_memo_host_logic():
     H.weights_changed()
     d = H.memo('t', [w2], lambda: (calls.append(1), w2 * 2)[1])
     assert len(calls) == n + 1 and torch.equal(d, torch.full((2, 3), 14.0))
+    # frozen sources (loss / pose / encoder networks during pivotal tuning) keep their images across the tuned generator's steps
+    fz = torch.ones(2, 2)
+    e = H.memo('frozen', [fz], lambda: (calls.append(1), fz * 3)[1])
+    n = len(calls)
+    H.weights_changed()
+    assert H.memo('frozen', [fz], lambda: (calls.append(1), fz * 3)[1]) is e and len(calls) == n
     from inv3d_amd import fused
     cache = fused.WeightCache()
     cache._c = {'k': (w2.data_ptr(), w2._version, tuple(w2.shape), H.WEIGHTS_EPOCH - 1)}
