@@ -127,6 +127,67 @@ __global__ void __launch_bounds__(NT) unit_normalize_kernel(const float* __restr
     }
 }
 
+// Generator image -> feature-net input (w_projector.py:198-200,215: (img + 1) * 255/2, area-resized to 256^2): one pass instead of
+// slice / scale / shift / pool / pad / layout copies.  Thread = output pixel; img pixels are 16 bytes (3 used channels + padding).
+__global__ void __launch_bounds__(NT) image_prepare_fwd_kernel(const float4* __restrict__ img, float4* __restrict__ out, int N, int Ho, int Wo, int f,
+                                                               float mul, float add) {
+    const int64_t total = (int64_t)N * Ho * Wo;
+    const int W = Wo * f;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int ox = (int)(i % Wo);
+        const int64_t r = i / Wo;                  // n * Ho + oy
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int ky = 0; ky < f; ++ky)
+            for (int kx = 0; kx < f; ++kx) {
+                const float4 v = img[(r * f + ky) * W + ox * f + kx];
+                sx += v.x; sy += v.y; sz += v.z;
+            }
+        const float m = mul / (float)(f * f);
+        out[i] = make_float4(fmaf(sx, m, add), fmaf(sy, m, add), fmaf(sz, m, add), 0.f);
+    }
+}
+
+__global__ void __launch_bounds__(NT) image_prepare_bwd_kernel(const float4* __restrict__ dout, float4* __restrict__ dimg, int N, int H, int W, int f, float mul) {
+    const int64_t total = (int64_t)N * H * W;
+    const int Wo = W / f;
+    const float m = mul / (float)(f * f);
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int x = (int)(i % W);
+        const int64_t r = i / W;                   // n * H + y
+        const int64_t ro = (r / H) * (H / f) + (r % H) / f;
+        const float4 g = dout[ro * Wo + x / f];
+        dimg[i] = make_float4(g.x * m, g.y * m, g.z * m, 0.f);
+    }
+}
+
+// Squared distance of two flat feature vectors per image and its gradient (the projector's `dist`, w_projector.py:216-219).
+__global__ void __launch_bounds__(NT) sqdist_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t F) {
+    const int n = blockIdx.y;
+    const float4* a4 = reinterpret_cast<const float4*>(a + n * F);
+    const float4* b4 = reinterpret_cast<const float4*>(b + n * F);
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < F / 4; i += (int64_t)gridDim.x * NT) {
+        const float4 u = a4[i], v = b4[i];
+        const float dx = u.x - v.x, dy = u.y - v.y, dz = u.z - v.z, dw = u.w - v.w;
+        s += dx * dx + dy * dy + dz * dz + dw * dw;
+    }
+    __shared__ float red[NT / 64];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(out + n, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+__global__ void __launch_bounds__(NT) sqdist_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ g,
+                                                        float* __restrict__ da, int64_t F, int64_t total4) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total4; i += (int64_t)gridDim.x * NT) {
+        const float k = 2.f * g[(i * 4) / F];
+        const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+        reinterpret_cast<float4*>(da)[i] = make_float4(k * (u.x - v.x), k * (u.y - v.y), k * (u.z - v.z), k * (u.w - v.w));
+    }
+}
+
 int grid_blocks(int64_t threads) {
     const int64_t b = (threads + NT - 1) / NT;
     return (int)(b < 8192 ? b : 8192);
@@ -195,6 +256,39 @@ extern "C" int eg3d_unit_normalize_bwd(const float* x, const float* scale, const
     const int blocks = grid_blocks(npix * G);
     hipLaunchKernelGGL(unit_normalize_kernel<true>, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, x, scale, dfeat, dx, npix, HW, C / 4, ldx / 4, mul,
                        eps, feat_nstride, G, eps_inside);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_image_prepare_fwd(const float* img, float* out, int N, int H, int W, int factor, float mul, float add, void* stream) {
+    if (!img || !out || N < 1 || H < 1 || W < 1 || factor < 1 || H % factor || W % factor || !aligned16(img) || !aligned16(out)) return EG3D_ERR_INVALID;
+    const int Ho = H / factor, Wo = W / factor;
+    hipLaunchKernelGGL(image_prepare_fwd_kernel, dim3(grid_blocks((int64_t)N * Ho * Wo)), dim3(NT), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(img), reinterpret_cast<float4*>(out), N, Ho, Wo, factor, mul, add);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_image_prepare_bwd(const float* dout, float* dimg, int N, int H, int W, int factor, float mul, void* stream) {
+    if (!dout || !dimg || N < 1 || H < 1 || W < 1 || factor < 1 || H % factor || W % factor || !aligned16(dout) || !aligned16(dimg)) return EG3D_ERR_INVALID;
+    hipLaunchKernelGGL(image_prepare_bwd_kernel, dim3(grid_blocks((int64_t)N * H * W)), dim3(NT), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(dout), reinterpret_cast<float4*>(dimg), N, H, W, factor, mul);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_sqdist_fwd(const float* a, const float* b, float* out, int N, int64_t F, void* stream) {
+    if (!a || !b || !out || N < 1 || F < 4 || (F & 3) || !aligned16(a) || !aligned16(b)) return EG3D_ERR_INVALID;
+    const int bx = (int)std::min<int64_t>(256, (F / 4 + NT * 4 - 1) / (NT * 4));
+    hipLaunchKernelGGL(sqdist_fwd_kernel, dim3(std::max(bx, 1), N), dim3(NT), 0, (hipStream_t)stream, a, b, out, F);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_sqdist_bwd(const float* a, const float* b, const float* g, float* da, int N, int64_t F, void* stream) {
+    if (!a || !b || !g || !da || N < 1 || F < 4 || (F & 3) || !aligned16(a) || !aligned16(b) || !aligned16(da)) return EG3D_ERR_INVALID;
+    const int64_t total4 = (int64_t)N * F / 4;
+    hipLaunchKernelGGL(sqdist_bwd_kernel, dim3(grid_blocks(total4)), dim3(NT), 0, (hipStream_t)stream, a, b, g, da, F, total4);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -149,6 +149,10 @@ _SIGS = {
     'eg3d_maxpool2d_fwd': (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p]),
     'eg3d_maxpool2d_bwd': (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p]),
     'eg3d_unit_normalize_fwd': (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int64, C.c_int, C.c_void_p]),
+    'eg3d_image_prepare_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    'eg3d_image_prepare_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    'eg3d_sqdist_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    'eg3d_sqdist_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     'eg3d_unit_normalize_bwd': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int64, C.c_int, C.c_void_p]),
     'eg3d_pack_conv_weight': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     'eg3d_rows_gram': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

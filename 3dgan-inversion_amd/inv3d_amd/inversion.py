@@ -26,6 +26,8 @@ class StubFeatureNet(torch.nn.Module):
     """Stand-in for the LPIPS / VGG feature extractors: 3 x (3x3 conv -> lrelu -> 2x2 avg-pool), fixed random weights,
     unit-normalised channel features at 3 scales, concatenated.  Runs on the gfx950 conv + bias_act kernels."""
 
+    accepts_cl4 = True          # takes [N,4,H,W] channels_last input (channel 3 = 0) as well as RGB
+
     def __init__(self, widths=(16, 32, 64), seed=1234):
         super().__init__()
         g = torch.Generator().manual_seed(seed)
@@ -444,10 +446,16 @@ class LatentProjector:
         if self._noise_inject is not None:
             kw = dict(kw, noise_inject=self._noise_inject)
         out = G.synthesis(ws, pred_cam, noise_mode='const', force_fp32=True, **kw)
-        img = out['image'] * 127.5 + 128
-        if img.shape[2] > 256:
-            img = _area_resize(img, 256)
-        dist_i = (self.target_features - self.feature_net(img)).square().sum(1)      # per image; independent trajectories: the sum's
+        from . import loss_nets as LN
+        p4 = getattr(out['image'], '_eg3d_padded4', None)
+        res = out['image'].shape[2]
+        if p4 is not None and getattr(self.feature_net, 'accepts_cl4', False) and (res <= 256 or res % 256 == 0) and res == out['image'].shape[3]:
+            img = LN.image_prepare(p4, max(1, res // 256), 127.5, 128.0)              # scale, shift, area resize and 4-float pixels in one pass
+        else:
+            img = out['image'] * 127.5 + 128
+            if img.shape[2] > 256:
+                img = _area_resize(img, 256)
+        dist_i = LN.sqdist(self.feature_net(img), self.target_features)              # per image; independent trajectories: the sum's
         dist = dist_i.sum()                                                           # gradient is each image's own gradient
         cur.wait_stream(self._reg_stream)
         loss = dist + reg                         # reported value; only `dist` (and the warping term) goes through autograd

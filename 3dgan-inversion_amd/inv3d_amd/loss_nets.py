@@ -217,6 +217,62 @@ def lpips_features(xs: Sequence[torch.Tensor], sqrt_lins: Sequence[torch.Tensor]
     return _LpipsHeadFn.apply(eps, len(xs), *xs, *sqrt_lins)
 
 
+class _ImagePrepFn(torch.autograd.Function):
+    """(img4 [N,4,H,W] channels_last, 3 used channels) -> [N,4,H/f,W/f] channels_last:  mul * area-mean + add, channel 3 = 0."""
+
+    @staticmethod
+    def forward(ctx, img4, factor, mul, add):
+        L.require_cuda(img4)
+        assert H.is_cl(img4) and img4.shape[1] == 4 and img4.dtype == torch.float32
+        N, _, Hh, Ww = img4.shape
+        out = H.empty_cl(N, 4, Hh // factor, Ww // factor, img4.device)
+        L.check(L.lib().eg3d_image_prepare_fwd(img4.data_ptr(), out.data_ptr(), N, Hh, Ww, factor, float(mul), float(add), L.stream_ptr()), 'image_prepare_fwd')
+        ctx.cfg = (N, Hh, Ww, factor, float(mul))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        N, Hh, Ww, factor, mul = ctx.cfg
+        dout = H.to_cl(dout.float())
+        dimg = H.empty_cl(N, 4, Hh, Ww, dout.device)
+        L.check(L.lib().eg3d_image_prepare_bwd(dout.data_ptr(), dimg.data_ptr(), N, Hh, Ww, factor, mul, L.stream_ptr()), 'image_prepare_bwd')
+        return dimg, None, None, None
+
+
+def image_prepare(img4: torch.Tensor, factor: int, mul: float, add: float) -> torch.Tensor:
+    """The feature networks' input from the generator's 4-float-pixel image in one pass: (img + 1) * 255/2 and the area resize of
+    w_projector.py:198-200 (integer factor), channels kept padded to 4."""
+    return _ImagePrepFn.apply(img4, int(factor), mul, add)
+
+
+class _SqDistFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        L.require_cuda(a, b)
+        a, b = a.contiguous().float(), b.contiguous().float()
+        N, F = a.shape
+        out = H.zeros((N,), a.device)
+        L.check(L.lib().eg3d_sqdist_fwd(a.data_ptr(), b.data_ptr(), out.data_ptr(), N, F, L.stream_ptr()), 'sqdist_fwd')
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        N, F = a.shape
+        g = g.contiguous().float()
+        da = torch.empty_like(a)
+        L.check(L.lib().eg3d_sqdist_bwd(a.data_ptr(), b.data_ptr(), g.data_ptr(), da.data_ptr(), N, F, L.stream_ptr()), 'sqdist_bwd')
+        return (da if ctx.needs_input_grad[0] else None), (-da if ctx.needs_input_grad[1] else None)
+
+
+def sqdist(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """[N]: sum_i (a[n,i] - b[n,i])^2 of flat feature vectors [N,F] (F % 4 == 0), one launch per direction."""
+    if a.shape[1] % 4 or a.data_ptr() % 16 or b.data_ptr() % 16:
+        return (a - b).square().sum(1)
+    return _SqDistFn.apply(a, b)
+
+
 def unit_features(xs: Sequence[torch.Tensor], eps: float = 1e-10) -> torch.Tensor:
     """[N, sum H*W*C]: per tap x * rsqrt(sum_c x^2 + eps) / sqrt(H*W), pixel-major inside a tap's slice (one launch per tap and direction)."""
     return _LpipsHeadFn.apply((eps, 1), len(xs), *xs, *([None] * len(xs)))

@@ -507,6 +507,17 @@ int eg3d_unit_normalize_fwd(const float* x, const float* scale, float* feat, int
 int eg3d_unit_normalize_bwd(const float* x, const float* scale, const float* dfeat, float* dx, int N, int HW, int C, int ldx, float mul,
                             float eps, int64_t feat_nstride, int eps_inside, void* stream);
 
+/* Generator image -> feature-net input, one pass (w_projector.py:198-200,215: (img + 1) * 255/2, then F.interpolate(mode='area') to 256^2):
+ *   out[n,y,x,c] = mul * mean_{factor x factor block}(img[n,...,c]) + add  for c < 3,  0 for c = 3.
+ * img: [N,H,W,4] NHWC (the SR head's 3-channel image is carried with 4-float pixels), out: [N,H/factor,W/factor,4].
+ * bwd: dimg[n,Y,X,c] = mul / factor^2 * dout[n,Y/factor,X/factor,c] (c < 3), 0 for c = 3. */
+int eg3d_image_prepare_fwd(const float* img, float* out, int N, int H, int W, int factor, float mul, float add, void* stream);
+int eg3d_image_prepare_bwd(const float* dout, float* dimg, int N, int H, int W, int factor, float mul, void* stream);
+/* out[n] (pre-zeroed) += sum_i (a[n,i] - b[n,i])^2 over flat feature vectors [N,F] (F % 4 == 0) -- the projector's per-image distance
+ * (w_projector.py:216-219); bwd: da = 2 g[n] (a - b). */
+int eg3d_sqdist_fwd(const float* a, const float* b, float* out, int N, int64_t F, void* stream);
+int eg3d_sqdist_bwd(const float* a, const float* b, const float* g, float* da, int N, int64_t F, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -175,3 +175,31 @@ def test_projector_with_vgg16_lpips_graph_matches_eager():
     assert P.graph_capture_error is None, P.graph_capture_error
     assert np.allclose(le, lg, rtol=2e-3), (le, lg)
     assert le[-1] < le[0]
+
+
+def test_image_prepare_and_sqdist_vs_torch():
+    """The two fused loss-side passes against the ATen expressions they replace (w_projector.py:198-200,215-219)."""
+    from inv3d_amd import loss_nets as LN
+    g = torch.Generator().manual_seed(5)
+    for n, res, f in ((1, 512, 2), (2, 64, 1), (1, 1024, 4)):
+        img4 = torch.cat([torch.rand(n, 3, res, res, generator=g) * 2 - 1, torch.zeros(n, 1, res, res)], 1).to(DEV).contiguous(memory_format=torch.channels_last)
+        img4.requires_grad_(True)
+        y = LN.image_prepare(img4, f, 127.5, 128.0)
+        ref_in = img4.detach()[:, :3].clone().requires_grad_(True)
+        ref = ref_in * 127.5 + 128
+        if f > 1:
+            ref = torch.nn.functional.interpolate(ref, size=(res // f, res // f), mode='area')
+        assert y.shape == (n, 4, res // f, res // f) and float(y[:, 3].abs().max()) == 0.0
+        assert float((y[:, :3] - ref).abs().max()) <= 2e-4                      # values up to 255
+        gy = torch.randn(y.shape, generator=g).to(DEV)
+        y.backward(gy)
+        ref.backward(gy[:, :3])
+        assert float((img4.grad[:, :3] - ref_in.grad).abs().max()) <= 1e-5 * float(ref_in.grad.abs().max()) and float(img4.grad[:, 3].abs().max()) == 0.0
+    for n, F in ((1, 114688), (3, 4096), (2, 20)):
+        a, b = torch.randn(n, F, generator=g).to(DEV).requires_grad_(True), torch.randn(n, F, generator=g).to(DEV)
+        d = LN.sqdist(a, b)
+        ref = (a.detach().double() - b.double()).square().sum(1)
+        assert float((d.double() - ref).abs().max()) <= 1e-5 * float(ref.max())
+        w = torch.arange(1, n + 1, device=DEV, dtype=torch.float32)
+        (d * w).sum().backward()
+        assert torch.allclose(a.grad, 2 * (a.detach() - b) * w[:, None], rtol=1e-6, atol=1e-6)
