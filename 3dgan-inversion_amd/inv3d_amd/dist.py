@@ -66,6 +66,44 @@ def allreduce_stats_device(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+class StepStatReducer:
+    """The per-step packed-stat all-reduce without putting the ranks in lockstep.  A blocking collective per step makes every rank's
+    compute stream wait for the slowest rank of THAT step (jitter adds up over 8 ranks) plus the collective's latency.  Here each
+    step's vector is copied into a slot of a small ring and reduced with an asynchronous collective: RCCL's stream waits for the copy,
+    the compute stream waits for nothing.  A slot is waited on only when it is reused `depth` steps later (long finished by then) or in
+    `finish()`, which returns the sum over all pushed steps of the rank-summed vectors."""
+
+    def __init__(self, nfields: int, device, depth: int = 8):
+        self.ring = torch.zeros(depth, nfields, dtype=torch.float32, device=device)
+        self.total = torch.zeros(nfields, dtype=torch.float32, device=device)
+        self.works = [None] * depth
+        self.used = [False] * depth
+        self.depth, self.i = depth, 0
+        self.active = dist.is_initialized() and dist.get_world_size() > 1
+
+    def _retire(self, slot):
+        if self.works[slot] is not None:
+            self.works[slot].wait()          # nccl: the current stream waits for the collective; gloo: the host does
+            self.works[slot] = None
+        if self.used[slot]:
+            self.total += self.ring[slot]
+            self.used[slot] = False
+
+    def push(self, vec: torch.Tensor):
+        slot = self.i % self.depth
+        self._retire(slot)
+        self.ring[slot].copy_(vec)
+        self.used[slot] = True
+        if self.active:
+            self.works[slot] = dist.all_reduce(self.ring[slot], op=dist.ReduceOp.SUM, async_op=True)
+        self.i += 1
+
+    def finish(self) -> torch.Tensor:
+        for slot in range(self.depth):
+            self._retire(slot)
+        return self.total
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -133,14 +133,13 @@ def main():
     proj = LatentProjector(G, target, num_steps=400, cam=cam, wplus=args.wplus, seed=100 + rank, use_graph=use_graph, feature_net=feature_net)
     proj.preheat = 0
 
-    stats = torch.zeros(4, device=dev)
     ones = torch.ones(1, device=dev)
+    reducer = D.StepStatReducer(4, dev)      # the path's only collective: packed per-step stats, reduced asynchronously (no rank lockstep)
 
     def one_step(pr=proj):
         out = pr.step()
-        if world > 1:       # the path's only collective: packed per-step stats, summed on the device, never read inside the timed region
-            stats.copy_(torch.stack([out['loss'], out['dist'], ones[0], ones[0]]))
-            D.allreduce_stats_device(stats)
+        if world > 1:       # summed on the device, read after the timed region
+            reducer.push(torch.stack([out['loss'].reshape(()), out['dist'].reshape(()), ones[0], ones[0]]))
         return out
 
     if use_graph:                       # set-up, not a step of the benchmark: eager passes + the capture of the step into a HIP graph
@@ -167,6 +166,7 @@ def main():
     elapsed = time.perf_counter() - t0
     H.PROFILER = None
     elapsed = D.max_over_ranks(elapsed, dev)
+    step_stats = reducer.finish()              # [sum loss, sum dist, steps x ranks, .] over everything pushed (warm-up included)
     psnr_now = float(psnr_01(proj.last['image'], target))
     roofline_pass = 'HIP events around every launch of the kernel inside the timed region'
     if not args.no_roofline and use_graph:
@@ -258,7 +258,8 @@ def main():
                                               'distance + noise regulariser, Adam)' % ('+' if args.wplus else '', 'stub-LPIPS' if args.loss_net == 'stub' else 'VGG16-LPIPS (256^2, random weights)'),
                                 images_per_gpu=M, image_steps_per_timed_step=M, world_size=world,
                                 generator='ffhqrebalanced512-128-shaped, 30.66 M params, random-init (synthetic weights)',
-                                parallelism=f'{world * M} independent images, {M} per GPU; stat all-reduce only',
+                                parallelism=f'{world * M} independent images, {M} per GPU; stat all-reduce only' + (
+                                    ' (one packed vector per step, asynchronous; mean loss over ranks and steps %.5g)' % float(step_stats[0] / step_stats[2].clamp(min=1)) if world > 1 else ''),
                                 launch='one HIP graph replay per step' if use_graph else 'eager (one launch per kernel)',
                                 psnr_after_timed_steps_db=round(psnr_now, 3)),
                     roofline=roof, roofline_renderer=roof_r, cpu_baseline=cpu, final_psnr=final)

@@ -30,6 +30,11 @@ def _worker(rank, world, port, out):
     mx = D.max_over_ranks(1.0 + r, torch.device('cpu'))
     dev_stats = D.allreduce_stats_device(torch.tensor([1.0 + r, 10.0, float(len(mine))]))       # per-step in-place variant
     stats['dev'] = dev_stats.tolist()
+    # the asynchronous per-step reducer: 11 steps through a ring of 4 slots
+    red = D.StepStatReducer(3, torch.device('cpu'), depth=4)
+    for step in range(11):
+        red.push(torch.tensor([float(step) * (r + 1), 1.0, float(r)]))
+    stats['async'] = red.finish().tolist()
     out.put((rank, mine, stats, mx))
     dist.destroy_process_group()
 
@@ -53,6 +58,7 @@ def test_two_rank_gloo_stat_sync():
         assert st['n_active'] == 7.0 and st['dist'] == 2.0 and st['steps'] == 6.0 and st['psnr'] == 30.0
         assert st['step_ms'] == 6.0
         assert st['dev'] == [3.0, 20.0, 7.0]
+        assert st['async'] == [55.0 * 3, 22.0, 11.0]            # sum over steps of the rank-summed vectors
         assert mx == 2.0
 
 
@@ -64,5 +70,9 @@ def test_single_process_is_a_noop():
     st = D.allreduce_stats(dict(loss=2.5, n_active=1.0), torch.device('cpu'))
     assert st['loss'] == 2.5 and st['n_active'] == 1.0
     assert D.allreduce_stats_device(torch.tensor([4.0])).item() == 4.0
+    red = D.StepStatReducer(2, torch.device('cpu'), depth=2)
+    for i in range(5):
+        red.push(torch.tensor([1.0, float(i)]))
+    assert red.finish().tolist() == [5.0, 10.0]
     assert D.shard_images(5, 0, 1) == [0, 1, 2, 3, 4]
     assert D.max_over_ranks(3.0, torch.device('cpu')) == 3.0
