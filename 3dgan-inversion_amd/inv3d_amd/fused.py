@@ -101,6 +101,7 @@ def _zeros_views(device, *shapes):
     return out
 
 
+RENDER_PIPELINE_NOGRAD = os.environ.get('EG3D_RENDER_PIPELINE_NOGRAD', '1') != '0'   # ... also for no-grad rendering (scratch rows)
 RENDER_PIPELINE = os.environ.get('EG3D_RENDER_PIPELINE', '1') != '0'     # forward renderer as positions -> MFMA decode -> importance -> decode -> composite
 KS_TARGET = int(os.environ.get('EG3D_KS_TARGET', '256'))       # blocks a split launch aims for (one per CU; 512 measured 0.7 % slower per step)
 
@@ -223,7 +224,8 @@ class ModConvLayerFn(torch.autograd.Function):
             rec = _ActProducer()
             rec.out, rec.d, rec.nz, rec.nstride, rec.noise_strength, rec.b, rec.gain, rec.clamp, rec.fused = out, d, nz, nstride, noise_strength, b, act_gain, clampv, None
             rec.need = (bool(ng[5]), bool(ng[2] or (ng[1] and want_wgrad)), bool(ng[3]), bool(ng[4]))
-        _set_producer(cache, rec)
+        if rec is not None:             # (a no-grad forward of the same layer -- the canonical view of the warping loss -- leaves a pending record alone)
+            _set_producer(cache, rec)
         ctx.save_for_backward(x, weight, styles, d, out, nz, noise_strength, b)
         ctx.cfg = (up, act_gain, clampv, nstride, cache, want_wgrad, noise is not None and noise.dim() == 4, d_in is not None)
         # both ends opt in: the producer promises a single consumer, the consumer that its x is that producer's output handed over directly
@@ -574,9 +576,16 @@ class RenderFn(torch.autograd.Function):
             S = N * R * 2 * max(Dc, Df)
             save = (torch.empty((S,), device=dev), torch.empty((S, w1.shape[0] - 1), device=dev))
         pos = None
-        if save is not None and Df > 0 and RENDER_PIPELINE:      # training mode: sample-level decode on the matrix cores between ray-level stages
+        rows = save
+        if rows is None and Df > 0 and RENDER_PIPELINE and RENDER_PIPELINE_NOGRAD and N * R >= 4096:
+            # no-grad rendering (orbit frames, the canonical view of the warping loss, evaluation): the same pipeline with the per-sample rows
+            # as scratch -- since the decoder moved to the 16-bit matrix cores it beats the fused per-ray kernel (0.50 vs 0.84 ms at 128^2 x 96)
+            S = N * R * 2 * max(Dc, Df)
+            rows = (torch.empty((S,), device=dev), torch.empty((S, w1.shape[0] - 1), device=dev))
+        if rows is not None and Df > 0 and RENDER_PIPELINE:      # sample-level decode on the matrix cores between ray-level stages
             pos = torch.empty((2, N * R, max(Dc, Df), 4), device=dev)
-        p = H.make_render_params(planes, origins, dirs, u1, u2, opts, w0g, b0g, w1t, b1g, rgb, depth, wsum, minmax, fine, rl, save, pos_rows=pos)
+        p = H.make_render_params(planes, origins, dirs, u1, u2, opts, w0g, b0g, w1t, b1g, rgb, depth, wsum, minmax, fine, rl, rows if pos is not None else save,
+                                 pos_rows=pos)
         with H._Span('render_fwd'):
             H.render_fwd(p)
             H.render_finalize(depth, minmax)
