@@ -188,6 +188,54 @@ __global__ void __launch_bounds__(NT) sqdist_bwd_kernel(const float* __restrict_
     }
 }
 
+// Depth-reprojection geometry of the warping loss (training/warping_loss.py:18-54, LinePlaneCollision :58-72): lift a pixel with its
+// rendered depth along its ray, intersect the line from the canonical camera centre through that point with the canonical image plane,
+// project with the canonical world->camera matrix and the intrinsics, map to [-1,1].  One thread per pixel; constants [24]:
+// c[3] canonical camera centre, P0[3] point on its image plane, A[9] + b[3] rows 0..2 of the world->camera matrix, K[6] rows 0..1 of the intrinsics.
+struct WarpPix { float ux, uy, uz, ndotu, si, qx, qy, qz; };
+__device__ __forceinline__ WarpPix warp_pixel(const float* __restrict__ k, float ox, float oy, float oz, float dx, float dy, float dz, float t) {
+    WarpPix w;
+    w.ux = ox + dx * t - k[0]; w.uy = oy + dy * t - k[1]; w.uz = oz + dz * t - k[2];        // u = xyz - c
+    const float nx = -k[0], ny = -k[1], nz = -k[2];                                         // plane normal = -c
+    w.ndotu = nx * w.ux + ny * w.uy + nz * w.uz;
+    const float kk = -(nx * (k[0] - k[3]) + ny * (k[1] - k[4]) + nz * (k[2] - k[5]));       // -(n . (c - P0))
+    w.si = kk / w.ndotu;
+    const float hx = k[0] + w.si * w.ux, hy = k[1] + w.si * w.uy, hz = k[2] + w.si * w.uz;
+    w.qx = k[6] * hx + k[7] * hy + k[8] * hz + k[15];
+    w.qy = k[9] * hx + k[10] * hy + k[11] * hz + k[16];
+    w.qz = k[12] * hx + k[13] * hy + k[14] * hz + k[17];
+    return w;
+}
+
+__global__ void __launch_bounds__(NT) warp_project_fwd_kernel(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ depth,
+                                                              const float* __restrict__ k, float2* __restrict__ uv, int64_t P) {
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= P) return;
+    const WarpPix w = warp_pixel(k, o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2], depth[i]);
+    const float rx = w.qx / w.qz, ry = w.qy / w.qz;
+    uv[i] = make_float2((k[18] * rx + k[19] * ry + k[20] - 0.5f) * 2.f, (k[21] * rx + k[22] * ry + k[23] - 0.5f) * 2.f);
+}
+
+__global__ void __launch_bounds__(NT) warp_project_bwd_kernel(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ depth,
+                                                              const float* __restrict__ k, const float2* __restrict__ duv, float* __restrict__ d_o,
+                                                              float* __restrict__ d_d, float* __restrict__ d_depth, int64_t P) {
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= P) return;
+    const float dx = d[3 * i], dy = d[3 * i + 1], dz = d[3 * i + 2], t = depth[i];
+    const WarpPix w = warp_pixel(k, o[3 * i], o[3 * i + 1], o[3 * i + 2], dx, dy, dz, t);
+    const float2 g = duv[i];
+    const float drx = 2.f * (k[18] * g.x + k[21] * g.y), dry = 2.f * (k[19] * g.x + k[22] * g.y);
+    const float iz = 1.f / w.qz;
+    const float dqx = drx * iz, dqy = dry * iz, dqz = -(drx * w.qx + dry * w.qy) * iz * iz;
+    const float dhx = k[6] * dqx + k[9] * dqy + k[12] * dqz, dhy = k[7] * dqx + k[10] * dqy + k[13] * dqz, dhz = k[8] * dqx + k[11] * dqy + k[14] * dqz;
+    const float dsi = dhx * w.ux + dhy * w.uy + dhz * w.uz;
+    const float dn = -w.si / w.ndotu * dsi;                                                  // si = kk / ndotu
+    const float gx = w.si * dhx - k[0] * dn, gy = w.si * dhy - k[1] * dn, gz = w.si * dhz - k[2] * dn;     // d u = si d hit + n d ndotu,  n = -c
+    d_o[3 * i] = gx; d_o[3 * i + 1] = gy; d_o[3 * i + 2] = gz;
+    d_d[3 * i] = gx * t; d_d[3 * i + 1] = gy * t; d_d[3 * i + 2] = gz * t;
+    d_depth[i] = gx * dx + gy * dy + gz * dz;
+}
+
 int grid_blocks(int64_t threads) {
     const int64_t b = (threads + NT - 1) / NT;
     return (int)(b < 8192 ? b : 8192);
@@ -289,6 +337,23 @@ extern "C" int eg3d_sqdist_bwd(const float* a, const float* b, const float* g, f
     if (!a || !b || !g || !da || N < 1 || F < 4 || (F & 3) || !aligned16(a) || !aligned16(b) || !aligned16(da)) return EG3D_ERR_INVALID;
     const int64_t total4 = (int64_t)N * F / 4;
     hipLaunchKernelGGL(sqdist_bwd_kernel, dim3(grid_blocks(total4)), dim3(NT), 0, (hipStream_t)stream, a, b, g, da, F, total4);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_warp_project_fwd(const float* origins, const float* dirs, const float* depth, const float* consts, float* uv, int64_t P, void* stream) {
+    if (!origins || !dirs || !depth || !consts || !uv || P < 1) return EG3D_ERR_INVALID;
+    hipLaunchKernelGGL(warp_project_fwd_kernel, dim3((unsigned)((P + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, origins, dirs, depth, consts,
+                       reinterpret_cast<float2*>(uv), P);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_warp_project_bwd(const float* origins, const float* dirs, const float* depth, const float* consts, const float* duv, float* d_origins,
+                                     float* d_dirs, float* d_depth, int64_t P, void* stream) {
+    if (!origins || !dirs || !depth || !consts || !duv || !d_origins || !d_dirs || !d_depth || P < 1) return EG3D_ERR_INVALID;
+    hipLaunchKernelGGL(warp_project_bwd_kernel, dim3((unsigned)((P + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, origins, dirs, depth, consts,
+                       reinterpret_cast<const float2*>(duv), d_origins, d_dirs, d_depth, P);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -518,6 +518,15 @@ int eg3d_image_prepare_bwd(const float* dout, float* dimg, int N, int H, int W, 
 int eg3d_sqdist_fwd(const float* a, const float* b, float* out, int N, int64_t F, void* stream);
 int eg3d_sqdist_bwd(const float* a, const float* b, const float* g, float* da, int N, int64_t F, void* stream);
 
+/* Depth-reprojection geometry of the warping loss (training/warping_loss.py:18-54 + LinePlaneCollision :58-72) per pixel:
+ *   xyz = o + d * depth;  hit = intersection of the line (c, xyz - c) with the plane through P0 with normal -c;
+ *   q = A hit + b;  uv = (K (q / q_z) - 0.5) * 2.
+ * origins / dirs [P,3], depth [P], uv [P,2]; consts [24] = c[3], P0[3], A[9] (row-major), b[3], K[6] (rows 0..1 of the intrinsics).
+ * bwd: gradients w.r.t. origins, dirs and depth from d uv (overwritten). */
+int eg3d_warp_project_fwd(const float* origins, const float* dirs, const float* depth, const float* consts, float* uv, int64_t P, void* stream);
+int eg3d_warp_project_bwd(const float* origins, const float* dirs, const float* depth, const float* consts, const float* duv, float* d_origins,
+                          float* d_dirs, float* d_depth, int64_t P, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -389,3 +389,35 @@ def test_coach_starts_from_the_encoder_latent():
     want = coach.w_avg.reshape(1, 1, -1).to(DEV) + enc(t255).reshape(1, 1, -1)
     assert torch.allclose(seen['w0'], want, rtol=0, atol=1e-5 * float(want.abs().max()))
     assert res.steps_a == 3 and res.w_pivot.shape == (1, G.backbone.num_ws, 512)
+
+
+def test_warp_projection_kernel_vs_aten_chain():
+    """eg3d_warp_project_fwd/_bwd against the tensor-op statement of warping_loss.py:18-54 + LinePlaneCollision (:58-72) it replaced."""
+    from inv3d_amd import inversion as INV
+    g = torch.Generator().manual_seed(8)
+    P = 4096
+    cams = O.synth_cameras(2, seed=5).float()
+    init_ext = cams[0:1, :16].reshape(1, 4, 4).to(DEV)
+    intrinsic = cams[0, 16:25].to(DEV)
+    o = (cams[1, :16].reshape(4, 4)[:3, 3] + 0.01 * torch.randn(P, 3, generator=g)).to(DEV).requires_grad_(True)
+    d = torch.nn.functional.normalize(-cams[1, :16].reshape(4, 4)[:3, 3] + 0.25 * torch.randn(P, 3, generator=g), dim=-1).to(DEV).requires_grad_(True)
+    depth = (2.2 + torch.rand(P, generator=g)).to(DEV).requires_grad_(True)
+
+    def chain(o, d, depth):
+        xyz = o + d * depth[:, None]
+        cam_o = init_ext[:, :3, 3].expand(P, 3)
+        plane_pt, w2c = INV._warp_constants(init_ext)
+        hit = INV.line_plane_intersection(-cam_o, plane_pt.expand_as(cam_o), xyz - cam_o, cam_o)
+        hit1 = torch.cat([hit, torch.ones(P, 1, device=DEV)], -1).t()
+        uv = (w2c @ hit1)[:3].t()
+        uv = uv / uv[:, 2:]
+        uv = (intrinsic.reshape(3, 3) @ uv.t())[:2].t()
+        return (uv - 0.5) * 2
+    ref = chain(o.double(), d.double(), depth.double()) if False else chain(o, d, depth)
+    got = INV.warp_project(o, d, depth, init_ext, intrinsic)
+    assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    w = torch.randn(P, 2, generator=g).to(DEV)
+    gr = torch.autograd.grad((ref * w).sum(), [o, d, depth])
+    gg = torch.autograd.grad((got * w).sum(), [o, d, depth])
+    for a, b, name in zip(gg, gr, ('origins', 'dirs', 'depth')):
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()), name
