@@ -544,7 +544,8 @@ __device__ __forceinline__ int tile_of(int x0, int y0, int ntx, int nty) {
 // pass 0: count; pass 1: place.  One thread per (sample row, plane).  Bin counters are pre-aggregated in an LDS histogram so
 // that the global counters see one atomic per (block, touched bin) instead of one per pair (the pairs of neighbouring rows
 // fall into the same few tiles: same-address atomics would serialise).
-constexpr int BIN_ITEMS = 4;            // pairs per thread
+constexpr int BIN_ITEMS = 16;           // pairs per thread (block-strided).  4 per thread took 87 + 99 us for the two passes, 16: 36 + 41 -- the per-block flush
+                                        // (an LDS sweep + global atomics for every touched bin) is the cost, not the per-pair work; 32 / 64 are slower again
 template <int PASS>
 __global__ void __launch_bounds__(256) scatter_bin_kernel(const float4* __restrict__ pos, int64_t S, int64_t rows_per_image, float cs, int Hp, int Wp,
                                                           int ntx, int nty, int nb, int* __restrict__ counts, const int* __restrict__ offsets,
@@ -553,11 +554,11 @@ __global__ void __launch_bounds__(256) scatter_bin_kernel(const float4* __restri
     for (int i = threadIdx.x; i < nb; i += 256) hist[i] = 0;
     __syncthreads();
     int bin[BIN_ITEMS], lrank[BIN_ITEMS], rowi[BIN_ITEMS];
-    const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * BIN_ITEMS;
+    const int64_t base = (int64_t)blockIdx.x * 256 * BIN_ITEMS + threadIdx.x;          // consecutive lanes -> consecutive (row, plane) pairs
 #pragma unroll
     for (int k = 0; k < BIN_ITEMS; ++k) {
         bin[k] = -1;
-        const int64_t i = base + k;
+        const int64_t i = base + (int64_t)k * 256;
         if (i >= S * 3) continue;
         const int64_t row = i / 3;
         const int pl = (int)(i - row * 3);
