@@ -369,7 +369,7 @@ __global__ void weight_sqsum_kernel(const float* __restrict__ w, float* __restri
 // layer and step of the pivotal-tuning phase (weights change every step there).
 constexpr int PK = 16;      // 16 x 16 (o, i) pairs per block: 1024 blocks for a 512 x 512 layer (32 x 32 left most CUs with a single, serial block)
 __global__ void __launch_bounds__(256) pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wa,
-                                                               float* __restrict__ wsq, int O, int I, int T) {
+                                                               float* __restrict__ wsq, int O, int I, int T, const float* __restrict__ oscale) {
     extern __shared__ float sm[];                       // [PK][PK*T + 1]
     const int ld = PK * T + 1;
     const int o0 = blockIdx.y * PK, i0 = blockIdx.x * PK;
@@ -377,17 +377,18 @@ __global__ void __launch_bounds__(256) pack_conv_weight_kernel(const float* __re
     const int tid = threadIdx.x, run = ni * T;
     for (int idx = tid; idx < no * run; idx += 256) {   // rows of w are contiguous in (i, t)
         const int ol = idx / run, r = idx - ol * run;
-        sm[ol * ld + r] = w[((int64_t)(o0 + ol) * I + i0) * T + r];
+        sm[ol * ld + r] = w[((int64_t)(o0 + ol) * I + i0) * T + r] * (oscale ? oscale[o0 + ol] : 1.f);     // per-output-channel scale (folded BatchNorm)
     }
     __syncthreads();
     for (int idx = tid; idx < no * T * PK; idx += 256) {
         const int il = idx % PK, t = (idx / PK) % T, ol = idx / (PK * T);
         if (il < ni) wf[((int64_t)(o0 + ol) * T + t) * I + i0 + il] = sm[ol * ld + il * T + t];
     }
-    for (int idx = tid; idx < ni * T * PK; idx += 256) {
-        const int ol = idx % PK, t = (idx / PK) % T, il = idx / (PK * T);
-        if (ol < no) wa[((int64_t)(i0 + il) * T + t) * O + o0 + ol] = sm[ol * ld + il * T + t];
-    }
+    if (wa != nullptr)
+        for (int idx = tid; idx < ni * T * PK; idx += 256) {
+            const int ol = idx % PK, t = (idx / PK) % T, il = idx / (PK * T);
+            if (ol < no) wa[((int64_t)(i0 + il) * T + t) * O + o0 + ol] = sm[ol * ld + il * T + t];
+        }
     if (wsq != nullptr)
         for (int idx = tid; idx < no * PK; idx += 256) {
             const int il = idx % PK, ol = idx / PK;
@@ -397,6 +398,33 @@ __global__ void __launch_bounds__(256) pack_conv_weight_kernel(const float* __re
                 wsq[(int64_t)(o0 + ol) * I + i0 + il] = a;
             }
         }
+}
+
+// Gradient of a per-output-channel scaled weight w' = w * a[o] from the packed weight-gradient image g[o][t*Ip + i] of the conv that used
+// w':  dw[o][i][t] = g[o][t*Ip + i] * a[o]  (the parameter's own layout),  da[o] = sum_{i,t} g[o][t*Ip + i] * w[o][i][t].
+// One block per output channel; the row goes through LDS so that both global streams are contiguous.
+__global__ void __launch_bounds__(256) unpack_weight_grad_kernel(const float* __restrict__ g, const float* __restrict__ w, const float* __restrict__ a,
+                                                                 float* __restrict__ dw, float* __restrict__ da, int I, int Ip, int T) {
+    extern __shared__ float row[];                      // [T][Ip]
+    __shared__ float red[4];
+    const int o = blockIdx.x, tid = threadIdx.x;
+    const int64_t gro = (int64_t)o * T * Ip, wro = (int64_t)o * I * T;
+    for (int k = tid; k < T * Ip; k += 256) row[k] = g[gro + k];
+    __syncthreads();
+    const float ao = a ? a[o] : 1.f;
+    float s = 0.f;
+    for (int k = tid; k < I * T; k += 256) {
+        const int i = k / T, t = k - i * T;
+        const float gv = row[t * Ip + i];
+        s = fmaf(gv, w[wro + k], s);
+        dw[wro + k] = gv * ao;
+    }
+    if (da == nullptr) return;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) da[o] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // one wave per (n,o)
@@ -549,13 +577,35 @@ extern "C" int eg3d_weight_sqsum(const float* w, float* wsq, int Co, int ntaps, 
     return EG3D_OK;
 }
 
+static int pack_conv_weight_impl(const float* w, const float* oscale, float* wf, float* wa, float* wsq, int O, int I, int T, void* stream);
+
 extern "C" int eg3d_pack_conv_weight(const float* w, float* wf, float* wa, float* wsq, int O, int I, int T, void* stream) {
-    if (!w || !wf || !wa || O <= 0 || I <= 0 || T <= 0 || T > 64) return EG3D_ERR_INVALID;
+    if (!wa) return EG3D_ERR_INVALID;
+    return pack_conv_weight_impl(w, nullptr, wf, wa, wsq, O, I, T, stream);
+}
+
+extern "C" int eg3d_pack_conv_weight_scaled(const float* w, const float* oscale, float* wf, float* wa, int O, int I, int T, void* stream) {
+    return pack_conv_weight_impl(w, oscale, wf, wa, nullptr, O, I, T, stream);
+}
+
+extern "C" int eg3d_unpack_weight_grad(const float* g, const float* w, const float* oscale, float* dw, float* doscale, int O, int I, int Ip, int T, void* stream) {
+    if (!g || !w || !dw || O <= 0 || I <= 0 || Ip < I || T <= 0 || T > 64) return EG3D_ERR_INVALID;
+    const size_t smem = (size_t)T * Ip * sizeof(float);
+    if (smem > 64 * 1024) return EG3D_ERR_UNSUPPORTED;
+    static std::atomic<uint64_t> attr_done{0};
+    if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(unpack_weight_grad_kernel), 64 * 1024, attr_done)) return e;
+    hipLaunchKernelGGL(unpack_weight_grad_kernel, dim3(O), dim3(256), smem, (hipStream_t)stream, g, w, oscale, dw, doscale, I, Ip, T);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+static int pack_conv_weight_impl(const float* w, const float* oscale, float* wf, float* wa, float* wsq, int O, int I, int T, void* stream) {
+    if (!w || !wf || O <= 0 || I <= 0 || T <= 0 || T > 64) return EG3D_ERR_INVALID;
     const size_t smem = (size_t)PK * (PK * T + 1) * sizeof(float);
     if (smem > 64 * 1024) return EG3D_ERR_UNSUPPORTED;
     static std::atomic<uint64_t> attr_done{0};
     if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(pack_conv_weight_kernel), 64 * 1024, attr_done)) return e;
-    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(eg3d_cdiv(I, PK), eg3d_cdiv(O, PK)), dim3(256), smem, (hipStream_t)stream, w, wf, wa, wsq, O, I, T);
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(eg3d_cdiv(I, PK), eg3d_cdiv(O, PK)), dim3(256), smem, (hipStream_t)stream, w, wf, wa, wsq, O, I, T, oscale);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -157,6 +157,8 @@ _SIGS = {
     'eg3d_warp_project_bwd': (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_void_p]),
     'eg3d_unit_normalize_bwd': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int64, C.c_int, C.c_void_p]),
     'eg3d_pack_conv_weight': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
+    'eg3d_pack_conv_weight_scaled': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
+    'eg3d_unpack_weight_grad': (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     'eg3d_rows_gram': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'eg3d_filtered_lrelu': (C.c_int, [C.POINTER(FlreluParams), C.c_void_p]),
     'eg3d_style_affine_fwd': (C.c_int, [C.POINTER(StyleBank), C.c_void_p]),

@@ -138,6 +138,84 @@ class _ConvActFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None
 
 
+class _ConvScaleActFn(torch.autograd.Function):
+    """y = act(conv2d(x, w * a[o], stride, pad) + b) with trainable w, a, b -- a conv followed by an eval-mode BatchNorm (a = gamma /
+    sqrt(var + eps) folded into the weights, b the shifted bias) and ReLU, as the in-loop pose estimator evaluates it every step.  Per
+    layer and step: ONE kernel builds both packed images of the folded weight (eg3d_pack_conv_weight_scaled), ONE kernel turns the packed
+    weight gradient into dw (parameter layout) and da (eg3d_unpack_weight_grad), and the activation backward also sums the bias gradient
+    -- instead of ~12 weight-sized ATen passes (fold, two permute-copies, un-permute, two products, two reductions, fills)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, a, bias, stride, pad, act):
+        L.require_cuda(x, weight, a, bias)
+        assert H.is_cl(x) and x.dtype == torch.float32
+        N, Ci, Hi, Wi = x.shape
+        Co, Ciw, kh, kw = weight.shape
+        assert Ciw == Ci and Ci % 4 == 0 and Co % 4 == 0 and kh * kw <= 9, (weight.shape, x.shape)
+        w = weight.detach().contiguous().float()
+        av = a.detach().contiguous().float()
+        T = kh * kw
+        wf = torch.empty((Co, T * Ci), device=x.device)
+        wa = torch.empty((Ci, T * Co), device=x.device)
+        L.check(L.lib().eg3d_pack_conv_weight_scaled(w.data_ptr(), av.data_ptr(), wf.data_ptr(), wa.data_ptr(), Co, Ci, T, L.stream_ptr()), 'pack_conv_weight_scaled')
+        Ho, Wo = (Hi + 2 * pad - kh) // stride + 1, (Wi + 2 * pad - kw) // stride + 1
+        cls = _classes_strided(Ho, Wo, kh, kw, pad)
+        ks = _auto_ksplit(cls, N, Co, Ci)
+        b = bias.detach().contiguous().float()
+        if ks == 1:
+            y = H.empty_cl(N, Co, Ho, Wo, x.device)
+            H.conv_igemm(x, wf, Ci, Co, y, cls, in_stride=stride, epi=L.EPI_FWD, bias=b, act=act, gain=1.0, precision=LOSS_NET_PRECISION)
+        else:
+            z = H.zeros_cl(N, Co, Ho, Wo, x.device)
+            _launch_groups(x, wf, Ci, Co, z, cls, True, in_stride=stride, ksplit=ks)
+            y = H.bias_act_raw(z, b, None, None, None, 0, 1, L.ACT_IDS[act], 0.0, 1.0, -1.0)
+        ctx.save_for_backward(y, w, av, x, wa)
+        ctx.cfg = (stride, pad, act, (Ho, Wo), kh, kw)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, w, av, x, wa = ctx.saved_tensors
+        stride, pad, act, (Ho, Wo), kh, kw = ctx.cfg
+        N, Ci, Hi, Wi = x.shape
+        Co = w.shape[0]
+        need_x, need_w, need_a, need_b = ctx.needs_input_grad[:4]
+        dy = H.to_cl(dy.float())
+        db = None
+        if act == 'linear':
+            dz = dy
+            if need_b:
+                db = dy.sum((0, 2, 3))
+        else:                                  # activation backward and the bias gradient in one pass
+            db = H.zeros((Co,), dy.device) if need_b else None
+            dz = H.epilogue_bwd(dy, y, H.empty_cl(N, Co, Ho, Wo, dy.device), act=act, gain=1.0, dbias=db)
+        dx = dw = da = None
+        if need_x:
+            cls, overlapping = _classes_strided_adjoint(Hi, Wi, kh, kw, stride, pad)
+            ks = _auto_ksplit(cls, N, Ci, Co) if len(cls) == 1 else 1
+            overlapping |= ks > 1
+            dx = (H.zeros_cl if overlapping else H.empty_cl)(N, Ci, Hi, Wi, dy.device)
+            _launch_groups(dz, wa, Co, Ci, dx, cls, overlapping, out_stride=stride, ksplit=ks)
+        if need_w or need_a:
+            T = kh * kw
+            dwp = H.zeros((Co, T * Ci), dy.device)
+            H.conv_wgrad(x, dz, Ci, Co, dwp, _classes_strided(Ho, Wo, kh, kw, pad), in_stride=stride, out_stride=1)
+            dw = torch.empty_like(w)
+            da = torch.empty_like(av) if need_a else None
+            L.check(L.lib().eg3d_unpack_weight_grad(dwp.data_ptr(), w.data_ptr(), av.data_ptr(), dw.data_ptr(), da.data_ptr() if da is not None else None,
+                                                    Co, Ci, Ci, T, L.stream_ptr()), 'unpack_weight_grad')
+        return dx, (dw if need_w else None), da, db, None, None, None
+
+
+def conv_scale_act(x, weight, a, bias, stride=1, pad=0, act='relu'):
+    """act(conv2d(x, weight * a[:, None, None, None]) + bias): conv + folded eval-mode BatchNorm + activation, trainable (see _ConvScaleActFn);
+    falls back to conv_act on a separately folded weight for shapes the fused form does not take (padded input channels, > 9 taps)."""
+    Co, Ci, kh, kw = weight.shape
+    if x.shape[1] == Ci and Ci % 4 == 0 and Co % 4 == 0 and kh * kw <= 9 and act in ('linear', 'relu'):
+        return _ConvScaleActFn.apply(x, weight, a, bias, stride, pad, act)
+    return conv_act(x, weight * a.view(-1, 1, 1, 1), bias, stride, pad, act)
+
+
 def conv_act(x, weight, bias, stride=1, pad=0, act='relu', alpha=0.0, gain=1.0):
     """act(conv2d(x, weight) + bias) * gain in one launch (act: 'linear' | 'relu' | 'lrelu' with slope alpha)."""
     return _ConvActFn.apply(x, weight, bias, stride, pad, act, alpha, gain)

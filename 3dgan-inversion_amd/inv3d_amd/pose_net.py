@@ -16,18 +16,21 @@ import torch
 import torch.nn.functional as F
 
 from . import hipops as H
-from .loss_nets import conv_act, max_pool
+from .loss_nets import conv_act, conv_scale_act, max_pool
 from .torch_utils.ops import bias_act
 
 
 def _bn_affine(bn):
+    pre = getattr(bn, '_eg3d_affine', None)        # set for the duration of ResNetPose.forward: all layers' affines from four launches
+    if pre is not None:
+        return pre
     a = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
     return a, bn.bias - bn.running_mean * a
 
 
 def _conv_bn(x, conv, bn, act):
     a, b = _bn_affine(bn)
-    return conv_act(x, conv.weight * a.view(-1, 1, 1, 1), b, conv.stride[0], conv.padding[0], act)
+    return conv_scale_act(x, conv.weight, a, b, conv.stride[0], conv.padding[0], act)
 
 
 class BasicBlock(torch.nn.Module):
@@ -84,13 +87,36 @@ class ResNetPose(torch.nn.Module):
             raise NotImplementedError('ResNetPose runs with frozen BatchNorm statistics (w_projector.py:62 .eval())')
         return super().train(False)
 
+    def _bank_affines(self):
+        """(a, b) of every eval-mode BatchNorm from four launches on the concatenated statistics (per layer that is ~10 launches on
+        64...512-element tensors, forward and backward, times 36 layers); split() so that autograd joins the 36 gradients with one cat."""
+        bns = [m for m in self.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        sizes = [bn.num_features for bn in bns]
+        key = tuple((bn.running_mean.data_ptr(), bn.running_mean._version, bn.running_var._version) for bn in bns)
+        if getattr(self, '_stat_key', None) != key:
+            assert len({bn.eps for bn in bns}) == 1
+            with torch.no_grad():
+                self._stat_cat = (torch.cat([bn.running_mean for bn in bns]).float(), torch.cat([bn.running_var for bn in bns]).float())
+            self._stat_key = key
+        mean, var = self._stat_cat
+        a = torch.cat([bn.weight for bn in bns]) * torch.rsqrt(var + bns[0].eps)
+        b = torch.cat([bn.bias for bn in bns]) - mean * a
+        for bn, ai, bi in zip(bns, torch.split(a, sizes), torch.split(b, sizes)):
+            bn._eg3d_affine = (ai, bi)
+        return bns
+
     def forward(self, img):
         n, c, h, w = img.shape
         x = torch.cat([img.float(), img.new_zeros(n, 1, h, w, dtype=torch.float32)], 1).contiguous(memory_format=torch.channels_last)
-        x = _conv_bn(x, self.conv1, self.bn1, 'relu')
-        x = max_pool(H.to_cl(F.pad(x, (1, 1, 1, 1), value=float('-inf'))), 3, 2)
-        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
-            x = layer(x)
+        bns = self._bank_affines()
+        try:
+            x = _conv_bn(x, self.conv1, self.bn1, 'relu')
+            x = max_pool(H.to_cl(F.pad(x, (1, 1, 1, 1), value=float('-inf'))), 3, 2)
+            for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+                x = layer(x)
+        finally:
+            for bn in bns:
+                bn._eg3d_affine = None
         x = x.mean((2, 3))
         x = F.relu(self.fc(x))
         x = F.relu(self.fc2(x))

@@ -357,6 +357,12 @@ int eg3d_weight_sqsum(const float* w, float* wsq, int Co, int ntaps, int Ck, voi
 /* One pass over a dense conv weight w[O][I][T] (T = kh*kw): wf[o][t*I+i] (forward operand), wa[i][t*O+o] (data-gradient operand),
  * wsq[o][i] = sum_t w^2 (or null).  Used where weights change every step (pivotal tuning). */
 int eg3d_pack_conv_weight(const float* w, float* wf, float* wa, float* wsq, int O, int I, int T, void* stream);
+/* The same with a per-output-channel scale folded in, w'[o] = w[o] * oscale[o] (an eval-mode BatchNorm folded into the conv that precedes
+ * it: scripts/resnet/resnet.py + w_projector.py:62), no wsq; wa may be null (forward image only).  And the gradient of that fold from
+ * the packed weight-gradient image g[o][t*Ip + i] (eg3d_conv2d_wgrad_f32 output, Ip >= I padded input channels):
+ *   dw[o][i][t] = g[o][t*Ip + i] * oscale[o] (parameter layout),  doscale[o] = sum_{i,t} g[o][t*Ip + i] * w[o][i][t]   (oscale / doscale may be null). */
+int eg3d_pack_conv_weight_scaled(const float* w, const float* oscale, float* wf, float* wa, int O, int I, int T, void* stream);
+int eg3d_unpack_weight_grad(const float* g, const float* w, const float* oscale, float* dw, float* doscale, int O, int I, int Ip, int T, void* stream);
 int eg3d_demod_fwd(const float* s, const float* wsq, float* d, int N, int Co, int Ck, void* stream);
 int eg3d_demod_bwd(const float* s, const float* wsq, const float* d, const float* dd, float* ds, float* dwsq,
                    int N, int Co, int Ck, void* stream);
