@@ -11,6 +11,7 @@ applied in the epilogue (the reference's non-fused branch, :70-79), so weights a
 style gradient is a reduction fused into the data-gradient conv (no per-sample weight gradient).
 """
 import math
+import weakref
 
 import os
 import torch
@@ -130,7 +131,10 @@ FUSE_ACT_BWD = os.environ.get('EG3D_FUSE_ACT_BWD', '1') != '0'
 
 
 class _ActProducer:
-    __slots__ = ('out', 'd', 'nz', 'nstride', 'noise_strength', 'b', 'gain', 'clamp', 'need', 'fused')
+    """`out_ptr` / `shape` identify the layer's output (the tensor itself is NOT held: it is an output of the autograd node that owns this
+    record, and a node -> record -> output cycle breaks graph teardown); `node` is a weak reference to that node -- while it is alive its
+    saved output is, so the address cannot have been recycled."""
+    __slots__ = ('out_ptr', 'shape', 'node', 'd', 'nz', 'nstride', 'noise_strength', 'b', 'gain', 'clamp', 'need', 'fused')
 
 
 _PRODUCER_BY_LAYER = {}       # id(layer cache) -> record (at most one per layer: replaced by the layer's next forward)
@@ -139,18 +143,18 @@ _PRODUCER_BY_PTR = {}         # out.data_ptr() -> record (the record holds `out`
 
 def _set_producer(cache, rec):
     old = _PRODUCER_BY_LAYER.pop(id(cache), None)
-    if old is not None and _PRODUCER_BY_PTR.get(old.out.data_ptr()) is old:
-        del _PRODUCER_BY_PTR[old.out.data_ptr()]
+    if old is not None and _PRODUCER_BY_PTR.get(old.out_ptr) is old:
+        del _PRODUCER_BY_PTR[old.out_ptr]
     if rec is not None:
         _PRODUCER_BY_LAYER[id(cache)] = rec
-        _PRODUCER_BY_PTR[rec.out.data_ptr()] = rec
+        _PRODUCER_BY_PTR[rec.out_ptr] = rec
     return old
 
 
 def _act_bwd_for(x, dev):
     """(record, ActBwdSpec, accumulators) when `x` is the output of a layer that left a producer record, else (None, None, None)."""
     rec = _PRODUCER_BY_PTR.get(x.data_ptr()) if FUSE_ACT_BWD else None
-    if rec is None or rec.fused is not None or rec.out.shape != x.shape:
+    if rec is None or rec.fused is not None or rec.shape != tuple(x.shape) or rec.node() is None:
         return None, None, None
     N, Co = x.shape[:2]
     need_b, need_dd, need_nz, need_ns = rec.need
@@ -222,10 +226,12 @@ class ModConvLayerFn(torch.autograd.Function):
         if FUSE_ACT_BWD and single_consumer and any(ctx.needs_input_grad[:6]):      # see _ActProducer: the consumer may run this layer's activation backward
             ng = ctx.needs_input_grad
             rec = _ActProducer()
-            rec.out, rec.d, rec.nz, rec.nstride, rec.noise_strength, rec.b, rec.gain, rec.clamp, rec.fused = out, d, nz, nstride, noise_strength, b, act_gain, clampv, None
+            rec.out_ptr, rec.shape, rec.node = out.data_ptr(), tuple(out.shape), weakref.ref(ctx)
+            rec.d, rec.nz, rec.nstride, rec.noise_strength, rec.b, rec.gain, rec.clamp, rec.fused = d, nz, nstride, noise_strength, b, act_gain, clampv, None
             rec.need = (bool(ng[5]), bool(ng[2] or (ng[1] and want_wgrad)), bool(ng[3]), bool(ng[4]))
         if rec is not None:             # (a no-grad forward of the same layer -- the canonical view of the warping loss -- leaves a pending record alone)
             _set_producer(cache, rec)
+        ctx.rec = rec                   # THIS forward's record: the backward below trusts only it (two live graphs of one layer cannot mix)
         ctx.save_for_backward(x, weight, styles, d, out, nz, noise_strength, b)
         ctx.cfg = (up, act_gain, clampv, nstride, cache, want_wgrad, noise is not None and noise.dim() == 4, d_in is not None)
         # both ends opt in: the producer promises a single consumer, the consumer that its x is that producer's output handed over directly
@@ -245,7 +251,12 @@ class ModConvLayerFn(torch.autograd.Function):
         Ho, Wo = Hi * up, Wi * up
         dev = x.device
         wf, wa, wsq = cache.get(weight)
-        rec = _set_producer(cache, None)
+        rec = ctx.rec
+        if rec is not None:
+            if _PRODUCER_BY_LAYER.get(id(cache)) is rec:
+                del _PRODUCER_BY_LAYER[id(cache)]
+            if _PRODUCER_BY_PTR.get(rec.out_ptr) is rec:
+                del _PRODUCER_BY_PTR[rec.out_ptr]
         pre = None              # (dz, dbias, dd, dnoise, dstrength, amax) when the consumer's data gradient already ran this layer's activation backward
         if rec is not None and rec.fused is not None and rec.fused[0].data_ptr() == dout.data_ptr() and rec.fused[0].shape == dout.shape:
             pre = rec.fused

@@ -200,3 +200,28 @@ def test_forward_sample_and_fma_entry_points(golden):
     for x, y in ((ag, ar), (bg, br), (cg, cr)):
         assert x.grad.shape == y.grad.shape
         close(x.grad, y.grad, 1e-5, 'fma grad')
+
+
+def test_two_live_graphs_of_one_generator_backward_together():
+    """The cross-layer backward fusion keeps one producer record per forward: two forwards of the same layers whose graphs are alive
+    at the same time (loss = f(G(ws1)) + f(G(ws2)), one backward) must give the sum of the two separate gradients."""
+    from inv3d_amd import synthetic as S
+    cfg = O.small_config()
+    G = S.make_generator(w_dim=32, z_dim=32, plane_res=32, channel_base=256, channel_max=16, nrr=16, sr_in_res=16, sr_widths=(16, 8),
+                         rendering_kwargs=cfg.rendering, device=DEV)
+    S.load_synthetic_weights(G, 0)
+    G.requires_grad_(False)
+    u1, u2 = O.make_uniforms(cfg, 1, seed=4)
+    kw = dict(noise_mode='const', force_fp32=True, render_uniforms=(u1.float().to(DEV), u2.float().to(DEV)))
+    cam = O.synth_cameras(1, seed=2).float().to(DEV)
+    wa = O.synth_ws(cfg, 1, seed=3).float().to(DEV).requires_grad_(True)
+    wb = O.synth_ws(cfg, 1, seed=7).float().to(DEV).requires_grad_(True)
+    g = torch.Generator().manual_seed(0)
+    pa, pb = torch.randn(1, 3, 64, 64, generator=g).to(DEV), torch.randn(1, 3, 64, 64, generator=g).to(DEV)
+    ga, = torch.autograd.grad((G.synthesis(wa, cam, **kw)['image'] * pa).sum(), wa)
+    gb, = torch.autograd.grad((G.synthesis(wb, cam, **kw)['image'] * pb).sum(), wb)
+    la = (G.synthesis(wa, cam, **kw)['image'] * pa).sum()
+    lb = (G.synthesis(wb, cam, **kw)['image'] * pb).sum()
+    ja, jb = torch.autograd.grad(la + lb, [wa, wb])
+    for got, ref, name in ((ja, ga, 'first'), (jb, gb, 'second')):
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), name
