@@ -130,6 +130,26 @@ __device__ __forceinline__ void eg3d_commit_amax(float m, float* out) {
     }
 }
 
+// Block-level form (every thread of the block must call it): wave maxima meet in LDS, ONE conditional atomic per block.  For short
+// memory-bound kernels all waves finish within the same few microseconds, every one reads the still-stale value and the per-wave form
+// degenerates into thousands of serialised atomics on one address (a 20 us pass took 55 us).
+__device__ __forceinline__ void eg3d_commit_amax_block(float m, float* out) {
+    if (out == nullptr) return;                 // uniform across the block
+    __shared__ float s_wave_max[16];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const int nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) s_wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nw; ++w) m = fmaxf(m, s_wave_max[w]);
+        if (m > 0.f && m < 3.0e38f) {
+            const float cur = __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (m > cur) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+        }
+    }
+}
+
 // ---- EG3D_EPI_BWD_ACT: the producing layer's activation backward inside a data-gradient epilogue (conv_igemm.hip, conv_v2.hip) --------
 // One float4 unit (4 channels of one pixel): v = that layer's dout, o = its saved output.  Returns dz = dy * d; accumulates the
 // per-channel sums (accb: dy, accd: dy * (pre - bias - noise)) and hands back the unit's channel sum of dy.

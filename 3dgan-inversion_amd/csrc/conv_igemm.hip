@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
             }
             }
         }
-        eg3d_commit_amax(omax, p.out_amax);                 // max|out| for the consumer's operand range
+        eg3d_commit_amax_block(omax, p.out_amax);           // max|out| for the consumer's operand range
         if (do_ds || act_on) {                              // block-level column sums, then one atomic per column
             if (cok && do_ds) {
                 atomicAdd(&ds_lds[c4 * 4 + 0], dsum4.x); atomicAdd(&ds_lds[c4 * 4 + 1], dsum4.y);
@@ -614,7 +614,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
         __syncthreads();
         if (tid < BN && n0 + tid < p.Nc) unsafeAtomicAdd(ds_out + (int64_t)n_first * p.Nc + n0 + tid, ds_lds[tid]);
     }
-    if (epi != EG3D_EPI_ATOMIC) eg3d_commit_amax(omax, p.out_amax);
+    if (epi != EG3D_EPI_ATOMIC) eg3d_commit_amax_block(omax, p.out_amax);
     }
 }
 

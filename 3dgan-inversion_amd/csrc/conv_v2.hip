@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
         }
         if (act_on && ab.dstrength != nullptr && tid == 0 && sc_lds[0] != 0.f) unsafeAtomicAdd(ab.dstrength, sc_lds[0]);
     }
-    eg3d_commit_amax(amax, p.out_amax);          // max|out|: the consumer's operand range
+    eg3d_commit_amax_block(amax, p.out_amax);    // max|out|: the consumer's operand range (one atomic per block)
 }
 
 // ---- operand preparation -------------------------------------------------------------------------------------------------------------

@@ -23,7 +23,7 @@ __device__ __forceinline__ float act1(float v, int act, float alpha, float gain,
     return v;
 }
 
-__device__ __forceinline__ void commit_amax(float m, float* out) { eg3d_commit_amax(m, out); }
+__device__ __forceinline__ void commit_amax(float m, float* out) { eg3d_commit_amax_block(m, out); }        // called by every thread, outside divergent flow
 __device__ __forceinline__ float amax4(float m, const float4 v) { return fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))); }
 
 template <bool PWL>
