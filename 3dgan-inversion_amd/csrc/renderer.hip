@@ -438,8 +438,10 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
                     mn = fminf(mn, Lq.misc[2]); mx = fmaxf(mx, Lq.misc[3]);
                 }
             }
-            atomic_min_float(p.depth_minmax, mn);
-            atomic_max_float(p.depth_minmax + 1, mx);
+            // look first: the range is monotone, so a stale read only costs a redundant atomic -- and after the first few workgroups
+            // almost nobody improves it (4096 workgroups x 2 same-address atomics, ~30 ns apart, is what the atomic unit sustains at best)
+            if (mn < __hip_atomic_load(p.depth_minmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_min_float(p.depth_minmax, mn);
+            if (mx > __hip_atomic_load(p.depth_minmax + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_float(p.depth_minmax + 1, mx);
         }
         return;
     }
