@@ -105,7 +105,11 @@ def main():
         sys.exit(subprocess.call(cmd))
 
     from inv3d_amd import dist as D
-    rank, world, local = D.init_from_env('nccl')
+    # EG3D_BENCH_BACKEND=gloo + EG3D_BENCH_ONE_DEVICE=1: dry-run of the multi-rank control flow (async stat reducer, barriers, rank-max timing)
+    # with every rank on GPU 0 of a single-GPU box -- RCCL refuses two ranks on one device; never used for a reported number
+    if os.environ.get('EG3D_BENCH_ONE_DEVICE') == '1':
+        os.environ['LOCAL_RANK'] = '0'
+    rank, world, local = D.init_from_env(os.environ.get('EG3D_BENCH_BACKEND', 'nccl'))
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback in the product path)'
     assert world == args.gpus, f'--gpus {args.gpus} but the launcher started {world} rank(s)'
     torch.cuda.set_device(local)
