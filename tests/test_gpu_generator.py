@@ -225,3 +225,27 @@ def test_two_live_graphs_of_one_generator_backward_together():
     ja, jb = torch.autograd.grad(la + lb, [wa, wb])
     for got, ref, name in ((ja, ga, 'first'), (jb, gb, 'second')):
         assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), name
+
+
+def test_rendering_resolution_other_than_the_sr_input():
+    """SuperresolutionHybrid8XDC resizes its inputs when the neural-rendering resolution differs from its input resolution
+    (superresolution.py:282-286: bilinear, antialiased): render at 24^2 into the 16^2 SR head, against the oracle, forward and d ws."""
+    cfg, G = small_G()
+    nrr = 24
+    P = O.synth_params(cfg, 0)
+    ws = O.synth_ws(cfg, 1, seed=3)
+    cam = O.synth_cameras(1, seed=2)
+    u1, u2 = O.make_uniforms(cfg, 1, seed=4, nrr=nrr)
+    wr = ws.clone().requires_grad_(True)
+    ref = O.synthesis(P, cfg, wr, cam, u1, u2, noise_mode='const', nrr=nrr)
+    pr = torch.randn(ref['image'].shape, generator=torch.Generator().manual_seed(1), dtype=ref['image'].dtype)
+    gref, = torch.autograd.grad((ref['image'] * pr).sum(), wr)
+    wg = ws.float().to(DEV).requires_grad_(True)
+    out = G.synthesis(wg, cam.float().to(DEV), neural_rendering_resolution=nrr, noise_mode='const', force_fp32=True,
+                      render_uniforms=(u1.float().to(DEV), u2.float().to(DEV)))
+    G.neural_rendering_resolution = 16                                 # the setting is sticky, as in the reference (triplane.py:58-61)
+    assert out['image'].shape == ref['image'].shape and out['image_raw'].shape[-1] == nrr
+    close(out['image'], ref['image'], 1e-4, 'image at nrr 24')
+    close(out['image_raw'], ref['image_raw'], 5e-5, 'image_raw at nrr 24')
+    gg, = torch.autograd.grad((out['image'] * pr.float().to(DEV)).sum(), wg)
+    close(gg, gref.float(), 2e-4, 'd ws at nrr 24')
