@@ -715,7 +715,9 @@ extern "C" int eg3d_conv2d_igemm_f32(const eg3d_conv_params* pp, void* stream) {
     if (p.ncls < 1 || p.ncls > 4 || p.ksplit < 1 || p.in_stride < 1 || p.out_stride < 1) return EG3D_ERR_INVALID;
     if (p.ksplit > 1 && p.epi != EG3D_EPI_ATOMIC) return EG3D_ERR_INVALID;
     if (p.epi < EG3D_EPI_STORE || p.epi > EG3D_EPI_BWD_ACT) return EG3D_ERR_INVALID;
-    if (p.precision < 0 || p.precision > 3 || p.ds_replicas < 0) return EG3D_ERR_INVALID;
+    if (p.precision < 0 || p.precision > EG3D_PREC_F16X1 || p.ds_replicas < 0) return EG3D_ERR_INVALID;
+    if (p.precision == EG3D_PREC_F16X1) return EG3D_ERR_UNSUPPORTED;      // single-product arithmetic exists in eg3d_conv2d_v2 and the weight gradient; a runtime
+                                                                          // skip of the cross products in this kernel's woven main loop measured 4x SLOWER -- callers use F16X3 here
     if (p.epi == EG3D_EPI_FWD && p.noise && !p.noise_strength) return EG3D_ERR_INVALID;
     if (p.epi == EG3D_EPI_FWD && !eg3d_act_is_pwl(p.act)) return EG3D_ERR_UNSUPPORTED;      // other activations: EPI_STORE + eg3d_bias_act
     if ((p.Ck & 3) || (p.ldx & 3) || (p.w_row & 3)) return EG3D_ERR_UNSUPPORTED;   // 16-byte operand loads

@@ -54,7 +54,7 @@ __device__ __forceinline__ void wait_vm() {
     else static_assert(N == 0, "vmcnt immediate");
 }
 
-template <int NTAPS>
+template <int NTAPS, bool FULL = true>         // FULL: three products per fp32 product; !FULL: high pieces only (EG3D_PREC_F16X1)
 __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_params p, const int cls_base) {
     constexpr int APT = (6 + NTAPS - 1) / NTAPS;          // A parts a wave issues per step
     constexpr int NA_TAPS = 6 / APT;                      // ... during the first NA_TAPS taps of a chunk (APT divides 6)
@@ -108,14 +108,15 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
     auto issue_A = [&](int chunk, int i) {
         const int piece = a_plane[i] >> 1, koct = a_plane[i] & 1;
         const unsigned plane_off = (unsigned)((((n * 2 + piece) * (p.Ck / 8)) + chunk * 2 + koct) * planeA);
-        glds16(ars, lds0 + LDS_A + (chunk & 1) * ABUF + a_plane[i] * APLANE + a_part[i] * 1024, a_pix[i] == OOB ? OOB : a_pix[i] + plane_off);
+        // (!FULL: the low-piece planes are never read -- the DMA slot is kept for the wait accounting but fetches nothing)
+        glds16(ars, lds0 + LDS_A + (chunk & 1) * ABUF + a_plane[i] * APLANE + a_part[i] * 1024, (a_pix[i] == OOB || (!FULL && piece == 1)) ? OOB : a_pix[i] + plane_off);
     };
     auto issue_B = [&](int chunk, int tap, int slot) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int idx = wave * 2 + e, plane = idx >> 1, half = idx & 1;
             const unsigned v = (unsigned)(((((cl.wtap[tap] * nchunk + chunk) * 4 + plane) * p.Nc) + n0 + half * 64 + lane) * 16);
-            glds16(wrs, lds0 + LDS_B + slot * BSLOT + plane * BPLANE + half * 1024, v);
+            glds16(wrs, lds0 + LDS_B + slot * BSLOT + plane * BPLANE + half * 1024, (!FULL && plane >= 2) ? OOB : v);
         }
     };
 
@@ -168,21 +169,28 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 bh[j] = *reinterpret_cast<const f16x8*>(smem + bbase + j * 512);
-                bl[j] = *reinterpret_cast<const f16x8*>(smem + bbase + j * 512 + 2 * BPLANE);
-                f16x2* s2 = reinterpret_cast<f16x2*>(&bh[j]);
-                f16x2* d2 = reinterpret_cast<f16x2*>(&bg[j]);
+                if constexpr (FULL) {
+                    bl[j] = *reinterpret_cast<const f16x8*>(smem + bbase + j * 512 + 2 * BPLANE);
+                    f16x2* s2 = reinterpret_cast<f16x2*>(&bh[j]);
+                    f16x2* d2 = reinterpret_cast<f16x2*>(&bg[j]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) d2[q] = s2[q] * k2m11;
+                    for (int q = 0; q < 4; ++q) d2[q] = s2[q] * k2m11;
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const f16x8 ah = *reinterpret_cast<const f16x8*>(smem + abase + i * hw * 16);
-                const f16x8 al = *reinterpret_cast<const f16x8*>(smem + abase + i * hw * 16 + 2 * APLANE);
+                if constexpr (FULL) {
+                    const f16x8 al = *reinterpret_cast<const f16x8*>(smem + abase + i * hw * 16 + 2 * APLANE);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {       // small terms first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bg[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) {       // small terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bg[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[i][j], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[i][j], 0, 0, 0);
                 }
             }
         }
@@ -418,11 +426,11 @@ __global__ void __launch_bounds__(256) split_w_kernel(const float* __restrict__ 
     out[((((int64_t)tap * (I / 16) + chunk) * 2 + 1) * 2 + koct) * O + o] = l;
 }
 
-std::atomic<uint64_t> g_attr[4];
+std::atomic<uint64_t> g_attr[5];
 
-template <int NTAPS>
+template <int NTAPS, bool FULL = true>
 int launch_v2(const eg3d_conv_v2_params& p, int cls_base, int ncls, int max_tiles, hipStream_t st, int slot) {
-    auto kern = conv_v2_kernel<NTAPS>;
+    auto kern = conv_v2_kernel<NTAPS, FULL>;
     if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, g_attr[slot])) return e;
     hipLaunchKernelGGL(kern, dim3(max_tiles, 1, ncls), dim3(256), LDS_BYTES, st, p, cls_base);
     EG3D_LAUNCH_CHECK();
@@ -436,6 +444,9 @@ extern "C" int eg3d_conv2d_v2_supported(const eg3d_conv_v2_params* pp) {
     const eg3d_conv_v2_params& p = *pp;
     if (p.N <= 0 || p.Hi <= 0 || p.Wi <= 0 || p.Ck < 16 || (p.Ck & 15) || p.Nc < BN || (p.Nc % BN) || (p.ldo & 3)) return 0;
     if (p.in_stride != 1 || p.out_stride < 1 || p.ncls < 1 || p.ncls > 4) return 0;
+    if (p.products != 0 && p.products != 1 && p.products != 3) return 0;
+    if (p.products == 1)                                  // the single-product instantiation exists for the 3x3 classes
+        for (int c = 0; c < p.ncls; ++c) if (p.cls[c].ntaps != 9) return 0;
     if (p.epi != EG3D_EPI_STORE && p.epi != EG3D_EPI_FWD && p.epi != EG3D_EPI_BWD && p.epi != EG3D_EPI_BWD_ACT) return 0;
     if (p.epi == EG3D_EPI_FWD && !eg3d_act_is_pwl(p.act)) return 0;
     if (p.epi == EG3D_EPI_BWD_ACT) {
@@ -479,7 +490,7 @@ extern "C" int eg3d_conv2d_v2(const eg3d_conv_v2_params* pp, void* stream) {
         }
         int rc;
         switch (p.cls[c].ntaps) {
-            case 9: rc = launch_v2<9>(p, c, e - c, max_tiles, st, 0); break;
+            case 9: rc = p.products == 1 ? launch_v2<9, false>(p, c, e - c, max_tiles, st, 4) : launch_v2<9>(p, c, e - c, max_tiles, st, 0); break;
             case 4: rc = launch_v2<4>(p, c, e - c, max_tiles, st, 1); break;
             case 2: rc = launch_v2<2>(p, c, e - c, max_tiles, st, 2); break;
             default: rc = launch_v2<1>(p, c, e - c, max_tiles, st, 3); break;

@@ -202,6 +202,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_f16x3_kernel(const eg3d_wgr
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    const bool one_product = p.precision == EG3D_PREC_F16X1;
     const int to = blockIdx.x / tiles_i, ti = blockIdx.x % tiles_i;
     int cls_id = 0, tap = blockIdx.y;
     while (cls_id < p.ncls && tap >= p.cls[cls_id].ntaps) { tap -= p.cls[cls_id].ntaps; ++cls_id; }
@@ -312,6 +313,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_f16x3_kernel(const eg3d_wgr
                 }
 #pragma unroll
             for (int pr = 2; pr >= 0; --pr) {                 // l*h, h*l, then h*h
+                if (pr > 0 && one_product) continue;          // EG3D_PREC_F16X1 (uniform branch)
                 const int qa = pr == 2 ? 1 : 0, qb = pr == 1 ? 1 : 0;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -374,7 +376,8 @@ extern "C" int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* pp, void* stream) 
         maxM = std::max<int64_t>(maxM, (int64_t)p.N * k.Ha * k.Wa);
     }
     const int tiles_o = eg3d_cdiv(p.Nc, BO), tiles_i = eg3d_cdiv(p.Ck, BI);
-    if (p.psplit <= 0 && p.precision == EG3D_PREC_F16X3) {      // ~2048 blocks like the fp32 path, but >= 16 K-steps each (the shorter main loop makes the atomic epilogue weigh more)
+    const bool f16 = p.precision == EG3D_PREC_F16X3 || p.precision == EG3D_PREC_F16X1;
+    if (p.psplit <= 0 && f16) {      // ~2048 blocks like the fp32 path, but >= 16 K-steps each (the shorter main loop makes the atomic epilogue weigh more)
         int64_t base = (int64_t)tiles_o * tiles_i * ntap_total;
         int64_t steps = (maxM + BC - 1) / BC;
         int64_t want = (2048 + base - 1) / base;
@@ -386,8 +389,8 @@ extern "C" int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* pp, void* stream) 
         int64_t want = (2048 + base - 1) / base;
         p.psplit = (int)std::max<int64_t>(1, std::min<int64_t>(want, std::max<int64_t>(1, steps / 8)));
     }
-    if (p.precision != EG3D_PREC_F32 && p.precision != EG3D_PREC_F16X3) return EG3D_ERR_UNSUPPORTED;
-    if (p.precision == EG3D_PREC_F16X3) {
+    if (p.precision != EG3D_PREC_F32 && !f16) return EG3D_ERR_UNSUPPORTED;
+    if (f16) {
         static std::atomic<uint64_t> attr16{0};
         const size_t smem16 = (size_t)2 * H_STAGE;
         if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_wgrad_f16x3_kernel), (int)smem16, attr16)) return e;

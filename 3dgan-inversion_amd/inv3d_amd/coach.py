@@ -43,7 +43,7 @@ class InversionCoach:
                  feature_net: Optional[Callable] = None, early_stop_interval: int = 1, use_graph: bool = False, keep_tuned_state: bool = False,
                  synth_kwargs: Optional[dict] = None, seed: int = 0, pose_net_factory: Optional[Callable] = None, pose_mode: str = 'quat',
                  w_avg_samples: int = 10000, w_stats: Optional[Tuple[torch.Tensor, float]] = None,
-                 start_w_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
+                 start_w_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, sr_fp16: bool = True):
         """Hyper-parameter names and defaults follow configs/hyperparameters.py.  `early_stop_interval` = how often Phase B reads the
         perceptual loss back to the host for the early-stop test (1 = every step like the reference; larger values keep the host from
         stalling the GPU queue every step).  Phase A starts where the reference starts (w_projector.py:88-97,100,118): at the mean latent
@@ -57,6 +57,7 @@ class InversionCoach:
         self.synth_kwargs, self.seed = dict(synth_kwargs or {}), seed
         self.pose_net_factory = pose_net_factory      # () -> a fresh pose estimator per image (the reference deep-copies its encoder, w_projector.py:62)
         self.pose_mode, self.start_w_fn = pose_mode, start_w_fn
+        self.sr_fp16 = sr_fp16                        # Phase B runs the SR head like the reference does (PivotalTuner); Phase A is always fp32-equivalent
         if w_stats is not None:
             self.w_avg, self.w_std = w_stats[0], float(w_stats[1])
         elif w_avg_samples > 0:
@@ -106,7 +107,7 @@ class InversionCoach:
             psnr_pivot = float(psnr_01(img, target))
         # ---- Phase B: generator weights around the pivot ------------------------------------------------------------------------
         tuner = PivotalTuner(G, target, w_pivot, cam_pivot, lr=self.pti_lr, lpips_threshold=self.thr, feature_net=self.feature_net,
-                             synth_kwargs=self.synth_kwargs)
+                             synth_kwargs=self.synth_kwargs, sr_fp16=self.sr_fp16)
         steps_b = 0
         for i in range(self.max_pti_steps):
             check = (i % self.interval) == self.interval - 1

@@ -170,7 +170,9 @@ def _act_bwd_for(x, dev):
 class ModConvLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, styles, noise, noise_strength, bias, up, act_gain, clamp, cache, want_wgrad, d_in=None, single_consumer=False,
-                input_is_layer_output=False):
+                input_is_layer_output=False, precision=None):
+        # precision: None = the process-wide arithmetic of the modulated convs; 'f16x1' = the reference's fp16 layers (one product of
+        # fp16-rounded operands, fp32 accumulation; forward, data gradient and weight gradient alike)
         # x: CL [N,Ci,H,W]; weight [Co,Ci,3,3]; styles [N,Ci]; noise None | [res,res] | [N,1,res,res]; noise_strength 0-d
         # d_in: the demodulation coefficients [N,Co] when the style bank already computed them (their gradient is then returned)
         L.require_cuda(x, weight, styles)
@@ -189,26 +191,28 @@ class ModConvLayerFn(torch.autograd.Function):
         out = H.empty_cl(N, Co, Ho, Wo, x.device)
         b = bias.contiguous().float() if bias is not None else None
         aflops = 2.0 * N * Hi * Wi * (1 if up == 2 else 1) * kh * kw * Ci * Co     # MACs of the (transposed) conv
-        prec = H.modconv_precision()
+        prec = precision or H.modconv_precision()
+        ig_prec = 'f16x3' if prec == 'f16x1' else prec      # the loader-split kernel has no single-product form: it keeps the three products
         amax_out = H.zeros((1,), x.device)            # max|out|, reported by whichever kernel writes `out`: the next layer's operand range
         cls, Hz, Wz = (H.classes_corr(Ho, Wo, kh, kw, kh // 2), Ho, Wo) if up == 1 else H.classes_convT(Hi, Wi, kh, kw, up)
         ks = _auto_ksplit(cls, N, Co, Ci)
         # (transposed-conv classes run on it too, but measured slower than the loader-split kernel: three launches of 4 / 2 / 1-tap
         #  classes on ragged 257-wide grids -- 196 vs 174 us on 256^2 x 256 -> 513^2 x 128, 116 vs 67 us on 128^2 x 256; opt-in)
-        v2 = H.USE_V2 and prec == 'f16x3' and ks == 1 and (up == 1 or H.V2_CONVT) and H.conv_v2_supported(Ci, Co, cls, N)
+        v2 = H.USE_V2 and prec in ('f16x3', 'f16x1') and ks == 1 and (up == 1 or (H.V2_CONVT and prec == 'f16x3')) and H.conv_v2_supported(Ci, Co, cls, N)
+        nprod = 1 if prec == 'f16x1' else 3
         epi_kw = dict(noise=nz, noise_nstride=nstride or 0, noise_strength=noise_strength, bias=b, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv)
         if v2:          # pre-split operands: modulation, range normalisation and the fp16 split happen once, not per tile and tap
             aimg = H.split_activation(x, H.amax_of(x), in_scale=styles)
             wimg = cache.get_split(weight)[0]
         if up == 1:
             if v2:
-                H.conv_v2(aimg, wimg, out, cls, epi=L.EPI_FWD, out_scale=d, out_amax=amax_out, algo_flops=aflops, **epi_kw)
+                H.conv_v2(aimg, wimg, out, cls, epi=L.EPI_FWD, out_scale=d, out_amax=amax_out, algo_flops=aflops, products=nprod, **epi_kw)
             elif ks == 1:
-                H.conv_igemm(x, wf, Ci, Co, out, cls, in_scale=styles, epi=L.EPI_FWD, out_scale=d, algo_flops=aflops, precision=prec, out_amax=amax_out,
+                H.conv_igemm(x, wf, Ci, Co, out, cls, in_scale=styles, epi=L.EPI_FWD, out_scale=d, algo_flops=aflops, precision=ig_prec, out_amax=amax_out,
                              **epi_kw)
             else:
                 z = H.zeros_cl(N, Co, Ho, Wo, x.device)
-                H.conv_igemm(x, wf, Ci, Co, z, cls, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=prec)
+                H.conv_igemm(x, wf, Ci, Co, z, cls, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=ig_prec)
                 H.epilogue_fwd(z, out, d=d, out_amax=amax_out, **epi_kw)
         else:
             if v2:
@@ -216,10 +220,10 @@ class ModConvLayerFn(torch.autograd.Function):
                 H.conv_v2(aimg, wimg, z, cls, out_stride=up, epi=L.EPI_STORE, algo_flops=aflops)
             elif ks == 1:
                 z = H.empty_cl(N, Co, Hz, Wz, x.device)
-                H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_STORE, algo_flops=aflops, precision=prec)
+                H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_STORE, algo_flops=aflops, precision=ig_prec)
             else:
                 z = H.zeros_cl(N, Co, Hz, Wz, x.device)
-                H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=prec)
+                H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=ig_prec)
             H.epilogue_fwd(z, out, fir=fir44(x.device), pad0=1, fir_gain=float(up * up), d=d, out_amax=amax_out, **epi_kw)
         H.tag_amax(out, amax_out)
         rec = None
@@ -234,6 +238,7 @@ class ModConvLayerFn(torch.autograd.Function):
         ctx.rec = rec                   # THIS forward's record: the backward below trusts only it (two live graphs of one layer cannot mix)
         ctx.save_for_backward(x, weight, styles, d, out, nz, noise_strength, b)
         ctx.cfg = (up, act_gain, clampv, nstride, cache, want_wgrad, noise is not None and noise.dim() == 4, d_in is not None)
+        ctx.prec = prec
         # both ends opt in: the producer promises a single consumer, the consumer that its x is that producer's output handed over directly
         # (NOT the copy routed through a toRGB node: that gradient is summed inside the toRGB data gradient, which is the fusing launch then)
         ctx.fuse_input = bool(input_is_layer_output)
@@ -268,7 +273,8 @@ class ModConvLayerFn(torch.autograd.Function):
             # thousands of tiles reduce into the same N*Ci style-gradient addresses: spread them over replicas, sum afterwards
             rep = 1          # replicas of the style-gradient accumulator (eg3d_conv_params::ds_replicas) measured no gain on MI355X
         # all small atomically-accumulated outputs of this backward from one zero fill
-        prec = H.modconv_precision()
+        prec = ctx.prec
+        ig_prec = 'f16x3' if prec == 'f16x1' else prec
         if pre is not None:
             _, dbias, dd, dnoise, dstrength, amax = pre
             ds = None if ks_adj is None else H.zeros((N, Ci), dev)
@@ -277,7 +283,7 @@ class ModConvLayerFn(torch.autograd.Function):
                 dev, (Co,) if need_b else None, (N, Co) if (need_s or need_w) else None,
                 tuple(nz.shape) if (need_nz and nz is not None) else None, () if (need_ns and nz is not None) else None,
                 None if ks_adj is None else ((rep, N, Ci) if rep > 1 else (N, Ci)),
-                (1,) if (prec == 'f16x3' and ks_adj is not None) else None)          # max|dz|: operand range of the f16x3 data gradient
+                (1,) if (prec in ('f16x3', 'f16x1') and ks_adj is not None) else None)          # max|dz|: operand range of the two-piece fp16 data gradient
             H.epilogue_bwd(dout, out, dz, d=d, noise=nz, noise_nstride=nstride or 0, noise_strength=noise_strength if nz is not None else None,
                            bias=b, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv, dbias=dbias, dd=dd, dnoise=dnoise,
                            dnoise_nstride=nstride or 0, dstrength=dstrength, dz_amax=amax)
@@ -300,17 +306,17 @@ class ModConvLayerFn(torch.autograd.Function):
             # x is some layer's output: if that layer left a record, this launch also runs ITS activation backward (dx then holds its dz)
             prod, spec, pacc = _act_bwd_for(x, dev) if (need_x and ctx.fuse_input) else (None, None, None)
             fkw = dict(act_bwd=spec, out_amax=pacc[4]) if prod is not None else {}
-            if H.USE_V2 and up == 1 and ks == 1 and prec == 'f16x3' and H.conv_v2_supported(Co, Ci, cls_adj, N):
+            if H.USE_V2 and up == 1 and ks == 1 and prec in ('f16x3', 'f16x1') and H.conv_v2_supported(Co, Ci, cls_adj, N):
                 did = H.conv_v2(H.split_activation(g, amax), cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds,
-                                algo_flops=aflops, **fkw)
+                                algo_flops=aflops, products=1 if prec == 'f16x1' else 3, **fkw)
             elif ks == 1:
                 did = H.conv_igemm(g, wa, Co, Ci, dx, cls_adj, in_stride=in_stride, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, algo_flops=aflops,
-                                   precision=prec, a_amax=amax, a_amax_mul=amul, **fkw)
+                                   precision=ig_prec, a_amax=amax, a_amax_mul=amul, **fkw)
                 if rep > 1:
                     ds = ds.sum(0)
             else:                                  # low resolution: split K over blocks, then scale / reduce in a finishing pass
                 z = H.zeros_cl(N, Ci, Hi, Wi, dev)
-                H.conv_igemm(g, wa, Co, Ci, z, cls_adj, in_stride=in_stride, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=prec, a_amax=amax,
+                H.conv_igemm(g, wa, Co, Ci, z, cls_adj, in_stride=in_stride, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=ig_prec, a_amax=amax,
                              a_amax_mul=amul)
                 did = prod is not None and Ci % 4 == 0 and Ci <= 1024
                 if did:
@@ -328,9 +334,9 @@ class ModConvLayerFn(torch.autograd.Function):
         if need_w:
             dwp = H.zeros(wf.shape, dev)
             # same arithmetic as the data gradient: two-piece fp16 split with the gradient operand range-normalised by max|dz|
-            wprec = 'f16x3' if (prec == 'f16x3' and amax is not None) else 'f32'
+            wprec = prec if (prec in ('f16x3', 'f16x1') and amax is not None) else 'f32'
             H.conv_wgrad(x, g, Ci, Co, dwp, cls_w, in_stride=1, out_stride=out_stride_w, in_scale=styles, precision=wprec,
-                         g_amax=amax if wprec == 'f16x3' else None, g_amax_mul=amul)
+                         g_amax=amax if wprec != 'f32' else None, g_amax_mul=amul)
             # [O,taps,I] accumulator -> the parameter's own (contiguous [O,I,kh,kw]) layout, plus the demodulation path d wsq / d w = 2 w,
             # in one pass; the fused multi-tensor Adam walks parameter and gradient with the same linear index
             dweight = torch.empty_like(weight, memory_format=torch.contiguous_format)
@@ -338,7 +344,7 @@ class ModConvLayerFn(torch.autograd.Function):
         if dnoise is not None and noise4d:
             dnoise = dnoise.view(N, 1, Ho, Wo)
         return (dx if need_x else None, dweight, ds if need_s else None, dnoise, dstrength, dbias, None, None, None, None, None,
-                dd if d_given else None, None, None)
+                dd if d_given else None, None, None, None)
 
 
 class StyleBankFn(torch.autograd.Function):

@@ -325,7 +325,7 @@ def pack_weight_adj(w):
 # unit-variance weights, and the data gradient is range-normalised with the max|dz| its producer (epilogue_bwd) reports -- everything
 # else (toRGB, the generic conv2d of conv2d_gradfix) runs 'bf16x6'.  Any other value forces that mode everywhere.
 # Set with set_conv_precision() or the EG3D_CONV_PRECISION environment variable.
-PRECISIONS = {'f32': 0, 'bf16x6': 1, 'bf16x3': 2, 'f16x3': 3}
+PRECISIONS = {'f32': 0, 'bf16x6': 1, 'bf16x3': 2, 'f16x3': 3, 'f16x1': 4}      # 'f16x1': single product of the high fp16 pieces (include/eg3d_hip.h)
 CONV_MODE = os.environ.get('EG3D_CONV_PRECISION', 'auto')
 CONV_PRECISION = PRECISIONS['bf16x6' if CONV_MODE == 'auto' else CONV_MODE]
 
@@ -521,12 +521,13 @@ V2_CONVT = os.environ.get('EG3D_V2_CONVT', '0') == '1'
 
 def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_STORE, out_scale=None, bias=None, noise=None, noise_nstride=0,
             noise_strength=None, act='linear', alpha=0.0, gain=1.0, clamp=-1.0, addend=None, xin=None, ds=None, out_amax=None, algo_flops=None,
-            act_bwd=None):
+            act_bwd=None, products=3):
     """Launch eg3d_conv2d_v2 (operands prepared by split_activation / split_weight).  act_bwd (ActBwdSpec, with epi=EPI_BWD): EPI_BWD_ACT when
     the kernel takes it -- returns True if the fused epilogue ran, False for a plain EPI_BWD."""
     assert is_cl(out)
     p = _conv_v2_params(a, w, out, classes, out_stride, epi, out_scale, bias, noise, noise_nstride, noise_strength, act, alpha, gain, clamp,
                         addend, xin, ds, out_amax)
+    p.products = int(products)
     fused_act = False
     if act_bwd is not None and epi == L.EPI_BWD and xin is not None:
         p.epi = L.EPI_BWD_ACT

@@ -533,7 +533,10 @@ class PivotalTuner:
     128^2 + depth TV -> backward into all generator weights -> Adam."""
 
     def __init__(self, G, target: torch.Tensor, w_pivot: torch.Tensor, cam: torch.Tensor, *, lr=3e-4, l2_lambda=1.0, lpips_lambda=1.0,
-                 lpips_threshold=0.06, feature_net: Optional[Callable] = None, synth_kwargs: Optional[dict] = None):
+                 lpips_threshold=0.06, feature_net: Optional[Callable] = None, synth_kwargs: Optional[dict] = None, sr_fp16: bool = True):
+        """`sr_fp16` (default, as the reference: BaseCoach.forward calls G.synthesis without force_fp32, base_coach.py:162-164): the
+        super-resolution head's convolutions -- forward, data and weight gradients -- run with one product of fp16-rounded operands instead
+        of the three-product fp32-equivalent split; pass False (or force_fp32=True in synth_kwargs) for fp32-equivalent tuning."""
         self.G = G
         G.requires_grad_(True)
         self.target = target
@@ -548,6 +551,7 @@ class PivotalTuner:
         # the fused kernel updates parameters without bumping their version counters, which the packed-weight caches key on
         self.optimizer.register_step_post_hook(lambda *_: hipops.weights_changed())
         self.synth_kwargs = dict(synth_kwargs or {})
+        self.synth_kwargs.setdefault('sr_fp16', bool(sr_fp16))
         self.last = {}
         self._arena = None
 

@@ -111,7 +111,7 @@ class SynthesisLayer(ReferenceStateMixin, torch.nn.Module):
         self._cache = fused.WeightCache()
 
     def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, noise_inject=None, styles=None, demod=None, single_consumer=False,
-                input_is_layer_output=False):
+                input_is_layer_output=False, precision=None):
         """`styles` / `demod`: this layer's affine(w) and demodulation coefficients when the enclosing network already evaluated them
         for all layers in one launch (fused.style_bank).  `single_consumer`: the caller promises that the returned tensor feeds exactly one
         fused op (conv1 / toRGB of the same block), which lets that op's backward absorb this layer's activation backward (fused.py);
@@ -129,7 +129,7 @@ class SynthesisLayer(ReferenceStateMixin, torch.nn.Module):
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return fused.ModConvLayerFn.apply(x, self.weight, styles, noise, self.noise_strength if noise is not None else None, self.bias,
                                           self.up, self.act_gain * gain, clamp, self._cache, self.weight.requires_grad, demod, single_consumer,
-                                          input_is_layer_output)
+                                          input_is_layer_output, precision)
 
     def extra_repr(self):
         return f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}, w_dim={self.w_dim:d}, ' \
@@ -204,6 +204,8 @@ class SynthesisBlock(ReferenceStateMixin, torch.nn.Module):
         s_iter = iter(styles[0]) if styles is not None else iter(lambda: None, 0)
         d_iter = iter(styles[1]) if styles is not None else iter(lambda: None, 0)
         ni = noise_inject or {}
+        if self.use_fp16 and not force_fp32:        # the reference runs this block in fp16 (networks_stylegan2.py:421-424): one product of fp16-rounded operands
+            layer_kwargs = dict(layer_kwargs, precision='f16x1')
         if self.in_channels == 0:
             x = self.const.unsqueeze(0).expand(ws.shape[0], -1, -1, -1)
             x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), styles=next(s_iter), demod=next(d_iter), single_consumer=True,

@@ -75,11 +75,18 @@ class TriPlaneGenerator(ReferenceStateMixin, torch.nn.Module):
         return planes
 
     # ---- image side ----------------------------------------------------------------------------------------------------------
+    sr_fp16_default = False      # True: G.synthesis without force_fp32 runs the fp16 blocks like the reference does on CUDA (see `sr_fp16`)
+
     def synthesis(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False, use_cached_backbone=False,
-                  render_uniforms=None, noise_inject=None, **synthesis_kwargs):
+                  render_uniforms=None, noise_inject=None, sr_fp16=None, **synthesis_kwargs):
         """ws [N,num_ws,w_dim], c [N,25] = (cam2world 4x4, intrinsics 3x3) -> {'image','image_raw','image_depth'} (triplane.py:53-90).
-        `force_fp32` is accepted and ignored (everything is fp32-equivalent here); `render_uniforms=(u1,u2)` / `noise_inject` pin the
-        stratified-sampling / per-layer noise draws for deterministic runs."""
+        Arithmetic: fp32-equivalent everywhere by default.  `sr_fp16=True` (and no `force_fp32=True`) runs the blocks the reference runs
+        in fp16 when `force_fp32` is not passed -- the super-resolution head, sr_num_fp16_res > 0, networks_stylegan2.py:421-424; what
+        BaseCoach.forward does during pivotal tuning -- with one product of fp16-rounded operands (EG3D_PREC_F16X1; accumulation and
+        storage stay fp32).  `render_uniforms=(u1,u2)` / `noise_inject` pin the stratified-sampling / per-layer noise draws."""
+        if sr_fp16 is None:
+            sr_fp16 = self.sr_fp16_default
+        block_fp32 = bool(synthesis_kwargs.get('force_fp32', False)) or not sr_fp16
         if neural_rendering_resolution is not None:
             self.neural_rendering_resolution = neural_rendering_resolution                           # sticky, as in the reference (:58-61)
         res = self.neural_rendering_resolution
@@ -93,7 +100,7 @@ class TriPlaneGenerator(ReferenceStateMixin, torch.nn.Module):
         features = feat.view(n, res, res, feat.shape[-1]).permute(0, 3, 1, 2)          # [N, H*W, 32] IS the channels_last image: zero-copy
         rgb = features[:, :3].contiguous()
         image = self.superresolution(rgb, features, ws, noise_mode=self.rendering_kwargs['superresolution_noise_mode'], noise_inject=noise_inject,
-                                     **{k: v for k, v in kwargs.items() if k != 'noise_mode'})
+                                     force_fp32=block_fp32, **{k: v for k, v in kwargs.items() if k != 'noise_mode'})
         return {'image': image, 'image_raw': rgb, 'image_depth': depth.transpose(1, 2).reshape(n, 1, res, res)}
 
     def sample_mixed(self, coordinates, directions, ws, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):

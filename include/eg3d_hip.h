@@ -125,7 +125,11 @@ typedef struct eg3d_conv_class {
  *   F16X3   each operand cut into 2 fp16 terms (x = h+l; residual <= max(2^-22 |x|, 2^-25)), three fp16 MFMA products (hh+hl+lh)
  *           accumulated in fp32: fp32-like for operands of magnitude ~2^-4 .. 2^16; operands outside that range must be brought
  *           into it by the caller with a power-of-two `a_scale` (the result is rescaled exactly). */
-enum { EG3D_PREC_F32 = 0, EG3D_PREC_BF16X6 = 1, EG3D_PREC_BF16X3 = 2, EG3D_PREC_F16X3 = 3 };
+enum { EG3D_PREC_F32 = 0, EG3D_PREC_BF16X6 = 1, EG3D_PREC_BF16X3 = 2, EG3D_PREC_F16X3 = 3,
+       /* F16X1: the high fp16 piece of each (range-normalised) operand only, ONE product, fp32 accumulation and fp32 results -- the
+        * arithmetic of the reference's own fp16 layers (SynthesisBlock with use_fp16 and force_fp32=False, networks_stylegan2.py:421-424:
+        * the super-resolution head during pivotal tuning), with operands rounded to fp16 (rel. 2^-11) but nothing stored in fp16. */
+       EG3D_PREC_F16X1 = 4 };
 
 typedef struct eg3d_conv_params {
     const float* x;            /* [N,Hi,Wi,ldx] NHWC, Ck used channels                   */
@@ -205,6 +209,7 @@ typedef struct eg3d_conv_v2_params {
     float* ds;
     float* out_amax;
     eg3d_act_bwd act_bwd;      /* EG3D_EPI_BWD_ACT only */
+    int32_t products;          /* 0 / 3: three products (fp32-equivalent);  1: high pieces only (EG3D_PREC_F16X1)            */
 } eg3d_conv_v2_params;
 int eg3d_conv2d_v2_supported(const eg3d_conv_v2_params* p);
 int eg3d_conv2d_v2(const eg3d_conv_v2_params* p, void* stream);
@@ -232,7 +237,7 @@ typedef struct eg3d_wgrad_params {
     eg3d_conv_class cls[4];
     const float* in_scale;     /* [N,Ck] or null */
     int32_t psplit;            /* number of pixel slices */
-    int32_t precision;         /* EG3D_PREC_F32 (v_mfma_f32_32x32x2_f32) or EG3D_PREC_F16X3 (two fp16 pieces per operand, three products) */
+    int32_t precision;         /* EG3D_PREC_F32 (v_mfma_f32_32x32x2_f32), EG3D_PREC_F16X3 (two fp16 pieces per operand, three products) or EG3D_PREC_F16X1 */
     const float* g_amax;       /* F16X3: optional device scalar max|g|; g is scaled by the power of two that brings g_amax * g_amax_mul */
     float g_amax_mul;          /*        to ~2^13 and the result is scaled back (exact).  null = g is used as it is.                   */
 } eg3d_wgrad_params;

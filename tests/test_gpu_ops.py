@@ -835,3 +835,34 @@ def test_dgrad_finish_with_activation_backward_equals_two_passes(shape):
     for k in A:
         rel(B[k], A[k], 2e-5, k)
     assert float(am_b) == float(am_a)
+
+
+def test_conv_single_product_fp16_arithmetic():
+    """EG3D_PREC_F16X1 (the reference's fp16 layers): one product of fp16-rounded, range-normalised operands, fp32 accumulation.  Error
+    against float64 at the level of fp16 operand rounding (2^-11 per operand), on the pre-split kernel and the weight gradient; against the exact product of the ROUNDED operands it is fp32-accumulation sized."""
+    from inv3d_amd import hipops as H, _lib as L
+    n, ci, h, w, co = 1, 128, 64, 64, 128
+    g = torch.Generator().manual_seed(51)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)
+    s = 1 + 0.3 * torch.randn(n, ci, generator=g)
+    ref = torch.nn.functional.conv2d(x.double() * s.double()[:, :, None, None], wt.double(), padding=1)
+    xc, aimg, wimg = _v2_operands(x, wt, s)
+    cls = H.classes_corr(h, w, 3, 3, 1)
+    out1, out3 = H.empty_cl(n, co, h, w, DEV), H.empty_cl(n, co, h, w, DEV)
+    H.conv_v2(aimg, wimg, out1, cls, epi=L.EPI_STORE, products=1)
+    H.conv_v2(aimg, wimg, out3, cls, epi=L.EPI_STORE, products=3)
+    scale = float(ref.abs().max())
+    e1, e3 = float((out1.cpu().double() - ref).abs().max()) / scale, float((out3.cpu().double() - ref).abs().max()) / scale
+    assert e3 < 2e-6 and 2e-5 < e1 < 2e-3, (e1, e3)
+    wf = wt.permute(0, 2, 3, 1).reshape(co, 9 * ci).to(DEV).contiguous()
+    with pytest.raises(L.Eg3dHipError):          # the loader-split kernel declines the mode (its callers keep three products)
+        H.conv_igemm(xc, wf, ci, co, H.empty_cl(n, co, h, w, DEV), cls, in_scale=s.to(DEV), epi=L.EPI_STORE, precision='f16x1')
+    gz = (torch.randn(n, co, h, w, generator=g) * 1e-3).to(DEV).contiguous(memory_format=torch.channels_last)
+    dref = torch.nn.grad.conv2d_weight((x.double() * s.double()[:, :, None, None]), wt.shape, gz.cpu().double(), padding=1)
+    for prec, lo, hi in (('f16x3', 0.0, 5e-6), ('f16x1', 1e-5, 2e-3)):
+        dwp = torch.zeros(co, 9 * ci, device=DEV)
+        H.conv_wgrad(xc, gz, ci, co, dwp, cls, in_scale=s.to(DEV), precision=prec, g_amax=H.absmax(gz))
+        got = dwp.view(co, 3, 3, ci).permute(0, 3, 1, 2).cpu().double()
+        e = float((got - dref).abs().max()) / float(dref.abs().max())
+        assert lo <= e < hi, (prec, e)
