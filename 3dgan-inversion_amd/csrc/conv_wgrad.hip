@@ -196,13 +196,13 @@ __device__ __forceinline__ void split4h_w(const float a, const float b, const fl
     __builtin_memcpy(&lo.x, &l0, 4); __builtin_memcpy(&lo.y, &l1, 4);
 }
 
+template <bool ONE>          // ONE: EG3D_PREC_F16X1 -- high pieces only: no low-piece arithmetic, LDS traffic or cross products
 __global__ void __launch_bounds__(256, 2) conv_wgrad_f16x3_kernel(const eg3d_wgrad_params p, int tiles_o, int tiles_i, int ntap_total) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);          // [2 stages][g | x][piece][octet][slot][16 B]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const bool one_product = p.precision == EG3D_PREC_F16X1;
     const int to = blockIdx.x / tiles_i, ti = blockIdx.x % tiles_i;
     int cls_id = 0, tap = blockIdx.y;
     while (cls_id < p.ncls && tap >= p.cls[cls_id].ntaps) { tap -= p.cls[cls_id].ntaps; ++cls_id; }
@@ -274,13 +274,22 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_f16x3_kernel(const eg3d_wgr
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             uint2 hi, lo;
-            split4h_w(gq[c][0] * g_mul, gq[c][1] * g_mul, gq[c][2] * g_mul, gq[c][3] * g_mul, hi, lo);
-            *reinterpret_cast<uint2*>(gb + c * 32 * 16) = hi;
-            *reinterpret_cast<uint2*>(gb + H_PIECE + c * 32 * 16) = lo;
             const float m = p.N == 1 ? svq[c] : 1.f;
-            split4h_w(xq[c][0] * m, xq[c][1] * m, xq[c][2] * m, xq[c][3] * m, hi, lo);
-            *reinterpret_cast<uint2*>(xb + c * 32 * 16) = hi;
-            *reinterpret_cast<uint2*>(xb + H_PIECE + c * 32 * 16) = lo;
+            if constexpr (ONE) {
+                const fp16x2_t g0 = __builtin_amdgcn_cvt_pkrtz(gq[c][0] * g_mul, gq[c][1] * g_mul), g1 = __builtin_amdgcn_cvt_pkrtz(gq[c][2] * g_mul, gq[c][3] * g_mul);
+                __builtin_memcpy(&hi.x, &g0, 4); __builtin_memcpy(&hi.y, &g1, 4);
+                *reinterpret_cast<uint2*>(gb + c * 32 * 16) = hi;
+                const fp16x2_t x0 = __builtin_amdgcn_cvt_pkrtz(xq[c][0] * m, xq[c][1] * m), x1 = __builtin_amdgcn_cvt_pkrtz(xq[c][2] * m, xq[c][3] * m);
+                __builtin_memcpy(&hi.x, &x0, 4); __builtin_memcpy(&hi.y, &x1, 4);
+                *reinterpret_cast<uint2*>(xb + c * 32 * 16) = hi;
+            } else {
+                split4h_w(gq[c][0] * g_mul, gq[c][1] * g_mul, gq[c][2] * g_mul, gq[c][3] * g_mul, hi, lo);
+                *reinterpret_cast<uint2*>(gb + c * 32 * 16) = hi;
+                *reinterpret_cast<uint2*>(gb + H_PIECE + c * 32 * 16) = lo;
+                split4h_w(xq[c][0] * m, xq[c][1] * m, xq[c][2] * m, xq[c][3] * m, hi, lo);
+                *reinterpret_cast<uint2*>(xb + c * 32 * 16) = hi;
+                *reinterpret_cast<uint2*>(xb + H_PIECE + c * 32 * 16) = lo;
+            }
         }
     };
 
@@ -305,15 +314,14 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_f16x3_kernel(const eg3d_wgr
         for (int kc = 0; kc < 2; ++kc) {                      // two 16-cell MFMA steps per 32-cell stage
             f16x8 a[2][2], b[2][2];                           // [piece][tile]
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+            for (int q = 0; q < (ONE ? 1 : 2); ++q)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     a[q][t] = *reinterpret_cast<const f16x8*>(g + q * H_PIECE + kc * 2 * H_PLANE + t * 32 * 16);
                     b[q][t] = *reinterpret_cast<const f16x8*>(x + q * H_PIECE + kc * 2 * H_PLANE + t * 32 * 16);
                 }
 #pragma unroll
-            for (int pr = 2; pr >= 0; --pr) {                 // l*h, h*l, then h*h
-                if (pr > 0 && one_product) continue;          // EG3D_PREC_F16X1 (uniform branch)
+            for (int pr = (ONE ? 0 : 2); pr >= 0; --pr) {     // l*h, h*l, then h*h
                 const int qa = pr == 2 ? 1 : 0, qb = pr == 1 ? 1 : 0;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -391,11 +399,13 @@ extern "C" int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* pp, void* stream) 
     }
     if (p.precision != EG3D_PREC_F32 && !f16) return EG3D_ERR_UNSUPPORTED;
     if (f16) {
-        static std::atomic<uint64_t> attr16{0};
+        static std::atomic<uint64_t> attr16{0}, attr16one{0};
         const size_t smem16 = (size_t)2 * H_STAGE;
-        if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_wgrad_f16x3_kernel), (int)smem16, attr16)) return e;
+        const bool one = p.precision == EG3D_PREC_F16X1;
+        auto kern = one ? conv_wgrad_f16x3_kernel<true> : conv_wgrad_f16x3_kernel<false>;
+        if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)smem16, one ? attr16one : attr16)) return e;
         dim3 grid16(tiles_o * tiles_i, ntap_total, p.psplit);
-        hipLaunchKernelGGL(conv_wgrad_f16x3_kernel, grid16, dim3(256), smem16, (hipStream_t)stream, p, tiles_o, tiles_i, ntap_total);
+        hipLaunchKernelGGL(kern, grid16, dim3(256), smem16, (hipStream_t)stream, p, tiles_o, tiles_i, ntap_total);
         EG3D_LAUNCH_CHECK();
         return EG3D_OK;
     }
