@@ -369,7 +369,7 @@ __global__ void weight_sqsum_kernel(const float* __restrict__ w, float* __restri
 // layer and step of the pivotal-tuning phase (weights change every step there).
 constexpr int PK = 16;      // 16 x 16 (o, i) pairs per block: 1024 blocks for a 512 x 512 layer (32 x 32 left most CUs with a single, serial block)
 __global__ void __launch_bounds__(256) pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wa,
-                                                               float* __restrict__ wsq, int O, int I, int T, const float* __restrict__ oscale) {
+                                                               float* __restrict__ wsq, int O, int I, int T, const float* __restrict__ oscale, int Old) {
     extern __shared__ float sm[];                       // [PK][PK*T + 1]
     const int ld = PK * T + 1;
     const int o0 = blockIdx.y * PK, i0 = blockIdx.x * PK;
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(256) pack_conv_weight_kernel(const float* __re
     if (wa != nullptr)
         for (int idx = tid; idx < ni * T * PK; idx += 256) {
             const int ol = idx % PK, t = (idx / PK) % T, il = idx / (PK * T);
-            if (ol < no) wa[((int64_t)(i0 + il) * T + t) * O + o0 + ol] = sm[ol * ld + il * T + t];
+            if (ol < no) wa[((int64_t)(i0 + il) * T + t) * Old + o0 + ol] = sm[ol * ld + il * T + t];       // Old >= O: rows padded by the caller
         }
     if (wsq != nullptr)
         for (int idx = tid; idx < no * PK; idx += 256) {
@@ -577,7 +577,7 @@ extern "C" int eg3d_weight_sqsum(const float* w, float* wsq, int Co, int ntaps, 
     return EG3D_OK;
 }
 
-static int pack_conv_weight_impl(const float* w, const float* oscale, float* wf, float* wa, float* wsq, int O, int I, int T, void* stream);
+static int pack_conv_weight_impl(const float* w, const float* oscale, float* wf, float* wa, float* wsq, int O, int I, int T, void* stream, int Old = 0);
 
 extern "C" int eg3d_pack_conv_weight(const float* w, float* wf, float* wa, float* wsq, int O, int I, int T, void* stream) {
     if (!wa) return EG3D_ERR_INVALID;
@@ -586,6 +586,10 @@ extern "C" int eg3d_pack_conv_weight(const float* w, float* wf, float* wa, float
 
 extern "C" int eg3d_pack_conv_weight_scaled(const float* w, const float* oscale, float* wf, float* wa, int O, int I, int T, void* stream) {
     return pack_conv_weight_impl(w, oscale, wf, wa, nullptr, O, I, T, stream);
+}
+
+extern "C" int eg3d_pack_conv_weight_padded(const float* w, float* wf, float* wa, float* wsq, int O, int I, int T, int O_pad, void* stream) {
+    return pack_conv_weight_impl(w, nullptr, wf, wa, wsq, O, I, T, stream, O_pad);
 }
 
 extern "C" int eg3d_unpack_weight_grad(const float* g, const float* w, const float* oscale, float* dw, float* doscale, int O, int I, int Ip, int T, void* stream) {
@@ -599,13 +603,14 @@ extern "C" int eg3d_unpack_weight_grad(const float* g, const float* w, const flo
     return EG3D_OK;
 }
 
-static int pack_conv_weight_impl(const float* w, const float* oscale, float* wf, float* wa, float* wsq, int O, int I, int T, void* stream) {
-    if (!w || !wf || O <= 0 || I <= 0 || T <= 0 || T > 64) return EG3D_ERR_INVALID;
+static int pack_conv_weight_impl(const float* w, const float* oscale, float* wf, float* wa, float* wsq, int O, int I, int T, void* stream, int Old) {
+    if (!w || !wf || O <= 0 || I <= 0 || T <= 0 || T > 64 || (Old != 0 && Old < O)) return EG3D_ERR_INVALID;
+    if (Old == 0) Old = O;
     const size_t smem = (size_t)PK * (PK * T + 1) * sizeof(float);
     if (smem > 64 * 1024) return EG3D_ERR_UNSUPPORTED;
     static std::atomic<uint64_t> attr_done{0};
     if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(pack_conv_weight_kernel), 64 * 1024, attr_done)) return e;
-    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(eg3d_cdiv(I, PK), eg3d_cdiv(O, PK)), dim3(256), smem, (hipStream_t)stream, w, wf, wa, wsq, O, I, T, oscale);
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(eg3d_cdiv(I, PK), eg3d_cdiv(O, PK)), dim3(256), smem, (hipStream_t)stream, w, wf, wa, wsq, O, I, T, oscale, Old);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -188,6 +188,90 @@ __global__ void __launch_bounds__(NT) sqdist_bwd_kernel(const float* __restrict_
     }
 }
 
+// The pivotal-tuning objective (base_coach.py:104-126 calc_loss: L2 + LPIPS at both resolutions, plus the depth total variation of
+// :294-305) as weighted sums of a few reductions: every term kernel adds its own value to `term` and its weighted share to `total`,
+// so the objective needs no scalar glue launches; the backward kernels take the incoming scalar gradient by pointer and the term's
+// weight by value.
+__device__ __forceinline__ void block_sum_commit(float s, float* __restrict__ term, float term_scale, float* __restrict__ total, float total_scale) {
+    __shared__ float red[NT / 64];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = (red[0] + red[1]) + (red[2] + red[3]);
+        if (term) unsafeAtomicAdd(term, v * term_scale);
+        if (total) unsafeAtomicAdd(total, v * total_scale);
+    }
+}
+
+__global__ void __launch_bounds__(NT) sqdist_sum_fwd_kernel(const float4* __restrict__ a, const float4* __restrict__ b, int64_t total4, float* __restrict__ term,
+                                                            float term_scale, float* __restrict__ total, float total_scale) {
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total4; i += (int64_t)gridDim.x * NT) {
+        const float4 u = a[i], v = b[i];
+        const float dx = u.x - v.x, dy = u.y - v.y, dz = u.z - v.z, dw = u.w - v.w;
+        s += dx * dx + dy * dy + dz * dz + dw * dw;
+    }
+    block_sum_commit(s, term, term_scale, total, total_scale);
+}
+
+__global__ void __launch_bounds__(NT) sqdist_sum_bwd_kernel(const float4* __restrict__ a, const float4* __restrict__ b, const float* __restrict__ g, float gscale,
+                                                            float4* __restrict__ da, int64_t total4) {
+    const float k = 2.f * gscale * g[0];
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total4; i += (int64_t)gridDim.x * NT) {
+        const float4 u = a[i], v = b[i];
+        da[i] = make_float4(k * (u.x - v.x), k * (u.y - v.y), k * (u.z - v.z), k * (u.w - v.w));
+    }
+}
+
+// Squared forward-difference total variation of a [B,H,W] map: sum over y < H-1, x < W-1 of (v - v_right)^2 + (v - v_below)^2.
+__global__ void __launch_bounds__(NT) tv_norm_fwd_kernel(const float* __restrict__ v, int B, int H, int W, float* __restrict__ term, float term_scale,
+                                                         float* __restrict__ total, float total_scale) {
+    const int64_t n = (int64_t)B * H * W;
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        if (x < W - 1 && y < H - 1) {
+            const float c = v[i], r = c - v[i + 1], d = c - v[i + W];
+            s += r * r + d * d;
+        }
+    }
+    block_sum_commit(s, term, term_scale, total, total_scale);
+}
+
+__global__ void __launch_bounds__(NT) tv_norm_bwd_kernel(const float* __restrict__ v, const float* __restrict__ g, float gscale, float* __restrict__ dv, int B,
+                                                         int H, int W) {
+    const int64_t n = (int64_t)B * H * W;
+    const float k = 2.f * gscale * g[0];
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const float c = v[i];
+        float a = 0.f;
+        if (x < W - 1 && y < H - 1) a += (c - v[i + 1]) + (c - v[i + W]);       // as the centre of its own pair of differences
+        if (x >= 1 && y < H - 1) a -= v[i - 1] - c;                             // as the right neighbour of (y, x-1)
+        if (y >= 1 && x < W - 1) a -= v[i - W] - c;                             // as the lower neighbour of (y-1, x)
+        dv[i] = k * a;
+    }
+}
+
+// The raw (neural-rendering resolution) RGB image with 4-float pixels from the C-channel rendered feature image (triplane.py:84-85:
+// rgb = features[:, :3]): y[p] = (x[p,0], x[p,1], x[p,2], 0); backward scatters into a zero-filled [P,C] gradient.
+__global__ void __launch_bounds__(NT) slice_rgb4_fwd_kernel(const float* __restrict__ x, float4* __restrict__ y, int64_t P, int C) {
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= P) return;
+    const float4 v = *reinterpret_cast<const float4*>(x + i * C);
+    y[i] = make_float4(v.x, v.y, v.z, 0.f);
+}
+
+__global__ void __launch_bounds__(NT) slice_rgb4_bwd_kernel(const float4* __restrict__ dy, float4* __restrict__ dx, int64_t P, int C4) {
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= P * C4) return;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i % C4 == 0) { const float4 g = dy[i / C4]; o = make_float4(g.x, g.y, g.z, 0.f); }
+    dx[i] = o;
+}
+
 // Depth-reprojection geometry of the warping loss (training/warping_loss.py:18-54, LinePlaneCollision :58-72): lift a pixel with its
 // rendered depth along its ray, intersect the line from the canonical camera centre through that point with the canonical image plane,
 // project with the canonical world->camera matrix and the intrinsics, map to [-1,1].  One thread per pixel; constants [24]:
@@ -337,6 +421,53 @@ extern "C" int eg3d_sqdist_bwd(const float* a, const float* b, const float* g, f
     if (!a || !b || !g || !da || N < 1 || F < 4 || (F & 3) || !aligned16(a) || !aligned16(b) || !aligned16(da)) return EG3D_ERR_INVALID;
     const int64_t total4 = (int64_t)N * F / 4;
     hipLaunchKernelGGL(sqdist_bwd_kernel, dim3(grid_blocks(total4)), dim3(NT), 0, (hipStream_t)stream, a, b, g, da, F, total4);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_sqdist_sum_fwd(const float* a, const float* b, int64_t n, float* term, float term_scale, float* total, float total_scale, void* stream) {
+    if (!a || !b || n < 4 || (n & 3) || !aligned16(a) || !aligned16(b) || (!term && !total)) return EG3D_ERR_INVALID;
+    const int bx = (int)std::min<int64_t>(512, (n / 4 + NT * 4 - 1) / (NT * 4));
+    hipLaunchKernelGGL(sqdist_sum_fwd_kernel, dim3(std::max(bx, 1)), dim3(NT), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(a),
+                       reinterpret_cast<const float4*>(b), n / 4, term, term_scale, total, total_scale);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_sqdist_sum_bwd(const float* a, const float* b, const float* g, float gscale, float* da, int64_t n, void* stream) {
+    if (!a || !b || !g || !da || n < 4 || (n & 3) || !aligned16(a) || !aligned16(b) || !aligned16(da)) return EG3D_ERR_INVALID;
+    hipLaunchKernelGGL(sqdist_sum_bwd_kernel, dim3(grid_blocks(n / 4)), dim3(NT), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(a),
+                       reinterpret_cast<const float4*>(b), g, gscale, reinterpret_cast<float4*>(da), n / 4);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_tv_norm_fwd(const float* v, int B, int H, int W, float* term, float term_scale, float* total, float total_scale, void* stream) {
+    if (!v || B < 1 || H < 2 || W < 2 || (!term && !total)) return EG3D_ERR_INVALID;
+    hipLaunchKernelGGL(tv_norm_fwd_kernel, dim3(grid_blocks((int64_t)B * H * W)), dim3(NT), 0, (hipStream_t)stream, v, B, H, W, term, term_scale, total,
+                       total_scale);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_tv_norm_bwd(const float* v, const float* g, float gscale, float* dv, int B, int H, int W, void* stream) {
+    if (!v || !g || !dv || B < 1 || H < 2 || W < 2) return EG3D_ERR_INVALID;
+    hipLaunchKernelGGL(tv_norm_bwd_kernel, dim3(grid_blocks((int64_t)B * H * W)), dim3(NT), 0, (hipStream_t)stream, v, g, gscale, dv, B, H, W);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_slice_rgb4_fwd(const float* x, float* y4, int64_t P, int C, void* stream) {
+    if (!x || !y4 || P < 1 || C < 4 || (C & 3) || !aligned16(x) || !aligned16(y4)) return EG3D_ERR_INVALID;
+    hipLaunchKernelGGL(slice_rgb4_fwd_kernel, dim3((unsigned)((P + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, x, reinterpret_cast<float4*>(y4), P, C);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_slice_rgb4_bwd(const float* dy4, float* dx, int64_t P, int C, void* stream) {
+    if (!dy4 || !dx || P < 1 || C < 4 || (C & 3) || !aligned16(dx) || !aligned16(dy4)) return EG3D_ERR_INVALID;
+    hipLaunchKernelGGL(slice_rgb4_bwd_kernel, dim3((unsigned)((P * (C / 4) + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(dy4), reinterpret_cast<float4*>(dx), P, C / 4);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -12,6 +12,7 @@ style gradient is a reduction fused into the data-gradient conv (no per-sample w
 """
 import math
 import weakref
+from typing import Optional
 
 import os
 import torch
@@ -47,6 +48,7 @@ class WeightCache:
 
     def __init__(self):
         self._c = {}
+        self._pad, self._pad_key = None, None
 
     def get(self, w: torch.Tensor):
         key = (w.data_ptr(), w._version, tuple(w.shape), H.WEIGHTS_EPOCH)
@@ -68,26 +70,25 @@ class WeightCache:
             self._c['split'] = hit
         return hit
 
-    def forward_padded(self, w: torch.Tensor, cp: int):
-        """[cp, taps*Ci] forward image with zero rows appended (toRGB 3 -> 4 outputs: the padded output channel is 0 + skip, and
-        the launch takes the 16-byte vector epilogue)."""
-        wf, _, _ = self.get(w)
-        hit = self._c.get('wf_p')
-        if hit is None or hit.shape[0] != cp:
-            hit = torch.zeros((cp, wf.shape[1]), device=wf.device)
-            hit[:wf.shape[0]] = wf
-            self._c['wf_p'] = hit
-        return hit
-
-    def adjoint_padded(self, w: torch.Tensor, cp: int):
-        """[Ci, cp] adjoint image of a 1x1 weight with the contraction dim (output channels) zero-padded to cp (toRGB: 3 -> 4)."""
-        _, wa, _ = self.get(w)
-        hit = self._c.get('wa_p')
-        if hit is None or hit.shape[1] != cp:
-            hit = torch.zeros((wa.shape[0], cp), device=wa.device)
-            hit[:, :wa.shape[1]] = wa
-            self._c['wa_p'] = hit
-        return hit
+    def get_padded(self, w: torch.Tensor, cp: int, bias: Optional[torch.Tensor] = None):
+        """(wf_p [cp, taps*Ci], wa_p [Ci, taps*cp], bias_p [cp] | None): the packed images with the output-channel dimension zero-padded to
+        cp (toRGB 3 -> 4: the padded output channel is 0 + skip, the launch takes the 16-byte vector epilogue, and the data gradient
+        contracts over 4 channels).  The buffers are zero-filled once and re-packed in place whenever the weights change -- one launch per
+        step of the pivotal-tuning phase instead of a fill and a copy per image."""
+        key = (w.data_ptr(), w._version, tuple(w.shape), H.WEIGHTS_EPOCH, cp, None if bias is None else (bias.data_ptr(), bias._version))
+        pad = self._pad
+        if pad is None or pad[0].shape[0] != cp or pad[0].device != w.device:
+            o, i, kh, kw = w.shape
+            pad = self._pad = (torch.zeros((cp, kh * kw * i), device=w.device), torch.zeros((i, kh * kw * cp), device=w.device),
+                               torch.zeros((cp,), device=w.device))
+            self._pad_key = None
+        if self._pad_key != key:
+            with torch.no_grad():
+                H.pack_conv_weight_padded(w, pad[0], pad[1], cp)
+                if bias is not None:
+                    pad[2][:bias.shape[0]].copy_(bias.detach().float())
+            self._pad_key = key
+        return pad[0], pad[1], (pad[2] if bias is not None else None)
 
 
 def _zeros_views(device, *shapes):
@@ -265,6 +266,8 @@ class ModConvLayerFn(torch.autograd.Function):
         pre = None              # (dz, dbias, dd, dnoise, dstrength, amax) when the consumer's data gradient already ran this layer's activation backward
         if rec is not None and rec.fused is not None and rec.fused[0].data_ptr() == dout.data_ptr() and rec.fused[0].shape == dout.shape:
             pre = rec.fused
+        if rec is not None:
+            rec.fused = None    # the accumulators become parameter gradients: AccumulateGrad adopts a gradient nobody else references, copies it otherwise
         dz = pre[0] if pre is not None else H.empty_cl(N, Co, Ho, Wo, dev)
         ks_adj = rep = None
         if need_x or need_s:
@@ -457,13 +460,12 @@ class ToRGBFn(torch.autograd.Function):
         N, Ci, Hh, Ww = x.shape
         Co = weight.shape[0]
         Cp = (Co + 3) // 4 * 4
-        wf, wa, _ = cache.get(weight)
         clampv = -1.0 if clamp is None else float(clamp)
-        b = bias.contiguous().float() if bias is not None else None
         if Cp != Co:              # compute all Cp channels: zero weight rows / bias give 0 (+ skip) in the padding channels
-            wf = cache.forward_padded(weight, Cp)
-            if b is not None:
-                b = H.memo(('torgb_bias_pad', Cp), [bias], lambda: torch.nn.functional.pad(bias.detach().float(), (0, Cp - Co)))
+            wf, _, b = cache.get_padded(weight, Cp, bias)
+        else:
+            wf, _, _ = cache.get(weight)
+            b = bias.contiguous().float() if bias is not None else None
         cls = H.classes_corr(Hh, Ww, 1, 1, 0)
         y = None
         if skip is not None:
@@ -498,7 +500,6 @@ class ToRGBFn(torch.autograd.Function):
         N, Ci, Hh, Ww = x.shape
         Co = weight.shape[0]
         dev = x.device
-        wf, wa, _ = cache.get(weight)
         dy = dout
         dbias = None
         if clampv >= 0 or need_b:
@@ -508,7 +509,7 @@ class ToRGBFn(torch.autograd.Function):
             dbias = dbias_p[:Co] if need_b else None
         dx = ds = None
         if need_x or need_s:
-            wa_p = wa if Cp == Co else cache.adjoint_padded(weight, Cp)    # contraction dim (output channels) padded to 4
+            wa_p = cache.get(weight)[1] if Cp == Co else cache.get_padded(weight, Cp)[1]    # contraction dim (output channels) padded to 4
             dx = H.empty_cl(N, Ci, Hh, Ww, dev)
             ds = H.zeros((N, Ci), dev)
             add = H.to_cl(dx_pass.float()) if dx_pass is not None else None
@@ -526,6 +527,32 @@ class ToRGBFn(torch.autograd.Function):
             H.conv_wgrad(x, dy, Ci, Co, dwp, H.classes_corr(Hh, Ww, 1, 1, 0), in_scale=styles)
             dweight = dwp.view(Co, Ci, 1, 1)
         return (dx if need_x else None, dweight, ds if need_s else None, dbias, dout if (need_skip and has_skip) else None, None, None, None, None, None)
+
+
+class _SliceRgb4Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, res):
+        L.require_cuda(feat)
+        feat = feat.contiguous().float()
+        n, r, c = feat.shape
+        y = torch.empty((n, res, res, 4), device=feat.device)
+        L.check(L.lib().eg3d_slice_rgb4_fwd(feat.data_ptr(), y.data_ptr(), n * r, c, L.stream_ptr()), 'slice_rgb4_fwd')
+        ctx.shape = (n, r, c)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        n, r, c = ctx.shape
+        g = H.to_cl(g.float())
+        dx = torch.empty((n, r, c), device=g.device)
+        L.check(L.lib().eg3d_slice_rgb4_bwd(g.data_ptr(), dx.data_ptr(), n * r, c, L.stream_ptr()), 'slice_rgb4_bwd')
+        return dx, None
+
+
+def slice_rgb4(feat: torch.Tensor, res: int) -> torch.Tensor:
+    """[N, res*res, C] rendered features -> the raw RGB image [N,4,res,res] channels_last with 4-float pixels (features[:, :3], channel 3 = 0;
+    triplane.py:84-85) in one launch per direction."""
+    return _SliceRgb4Fn.apply(feat, int(res))
 
 
 class UpsampleImgFn(torch.autograd.Function):

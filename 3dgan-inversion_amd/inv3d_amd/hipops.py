@@ -676,6 +676,16 @@ def pack_conv_weight(w):
     return wf, wa, wsq
 
 
+def pack_conv_weight_padded(w, wf_p, wa_p, o_pad):
+    """eg3d_pack_conv_weight_padded into caller-owned, zero-initialised buffers wf_p [o_pad, taps*I], wa_p [I, taps*o_pad]."""
+    L.require_cuda(w, wf_p, wa_p)
+    w = w.detach().contiguous().float()
+    o, i, kh, kw = w.shape
+    assert tuple(wf_p.shape) == (o_pad, kh * kw * i) and tuple(wa_p.shape) == (i, kh * kw * o_pad) and wf_p.is_contiguous() and wa_p.is_contiguous()
+    L.check(L.lib().eg3d_pack_conv_weight_padded(w.data_ptr(), wf_p.data_ptr(), wa_p.data_ptr(), None, o, i, kh * kw, o_pad, L.stream_ptr()),
+            'pack_conv_weight_padded')
+
+
 def weight_sqsum(wp, Co, ntaps, Ck):
     wsq = torch.empty((Co, Ck), dtype=torch.float32, device=wp.device)
     L.check(L.lib().eg3d_weight_sqsum(L.ptr(wp), L.ptr(wsq), Co, ntaps, Ck, L.stream_ptr()), 'weight_sqsum')

@@ -547,6 +547,9 @@ class PivotalTuner:
         with torch.no_grad():
             self.tf = self.feature_net(target)
             self.tf128 = self.feature_net(self.target_128)
+            # the targets with 4-float pixels (channel 3 = 0), the layout the SR head and the renderer hand their images over in
+            self.target4 = _pad_cl4(target)
+            self.target4_128 = _pad_cl4(self.target_128)
         self.optimizer = torch.optim.Adam(G.parameters(), lr=lr, fused=True)      # one multi-tensor launch over the 30.7 M parameters
         # the fused kernel updates parameters without bumping their version counters, which the packed-weight caches key on
         self.optimizer.register_step_post_hook(lambda *_: hipops.weights_changed())
@@ -554,6 +557,31 @@ class PivotalTuner:
         self.synth_kwargs.setdefault('sr_fp16', bool(sr_fp16))
         self.last = {}
         self._arena = None
+
+    def _fused_objective(self, out):
+        """The same objective as the ATen composition in `_step` from five reduction launches per direction (loss_nets.weighted_objective):
+        both L2 terms and both feature distances read the images with 4-float pixels straight from the SR head / the renderer, the depth
+        total variation is one kernel.  None when the images did not come with that layout (CPU tensors, N > 1, a resized SR input)."""
+        from . import loss_nets as LN
+        img, raw, depth = out['image'], out['image_raw'], out['image_depth']
+        p4, r4 = getattr(img, '_eg3d_padded4', None), getattr(raw, '_eg3d_padded4', None)
+        if p4 is None or r4 is None or img.shape[0] != 1 or p4.shape != self.target4.shape or r4.shape != self.target4_128.shape:
+            return None
+        cl4 = getattr(self.feature_net, 'accepts_cl4', False)
+        f1 = self.feature_net(p4 if cl4 else img)
+        f2 = self.feature_net(r4 if cl4 else raw)
+        d3 = depth.squeeze(0)                               # [1,H,W] for one image, as compute_tv_norm takes it (single_id_coach.py:81)
+        if f1.shape != self.tf.shape or f2.shape != self.tf128.shape or d3.dim() != 3:
+            return None
+        d3 = d3.contiguous()
+        B, Hh, Ww = d3.shape
+        terms = [('sq', 0, 1.0 / img.numel(), p4, self.target4), ('sq', 0, 1.0 / raw.numel(), r4, self.target4_128),
+                 ('sq', 1, 1.0, f1, self.tf), ('sq', 1, 1.0, f2, self.tf128), ('tv', 2, 1.0 / (B * (Hh - 1) * (Ww - 1)), d3)]
+        res = LN.weighted_objective(terms, (self.l2_lambda, self.lpips_lambda, 1.0))
+        if res is None:
+            return None
+        total, parts = res
+        return total, parts.unbind(0)
 
     def step(self, early_stop: bool = False, **step_kwargs) -> Dict[str, torch.Tensor]:
         # every zero-initialised accumulator of the step (split-K outputs, gradient sums) comes out of one arena cleared by one launch;
@@ -566,10 +594,14 @@ class PivotalTuner:
     def _step(self, early_stop: bool = False, **step_kwargs) -> Dict[str, torch.Tensor]:
         G = self.G
         out = G.synthesis(self.w_pivot[:, :G.backbone.num_ws], self.cam[:, :25], **dict(self.synth_kwargs, **step_kwargs))
-        l2 = F.mse_loss(out['image'], self.target) + F.mse_loss(out['image_raw'], self.target_128)
-        lp = (self.feature_net(out['image']) - self.tf).square().sum() + (self.feature_net(out['image_raw']) - self.tf128).square().sum()
-        tv = compute_tv_norm(out['image_depth'].squeeze(0))
-        loss = l2 * self.l2_lambda + lp * self.lpips_lambda + tv
+        fusedobj = self._fused_objective(out)
+        if fusedobj is not None:
+            loss, (l2, lp, tv) = fusedobj
+        else:
+            l2 = F.mse_loss(out['image'], self.target) + F.mse_loss(out['image_raw'], self.target_128)
+            lp = (self.feature_net(out['image']) - self.tf).square().sum() + (self.feature_net(out['image_raw']) - self.tf128).square().sum()
+            tv = compute_tv_norm(out['image_depth'].squeeze(0))
+            loss = l2 * self.l2_lambda + lp * self.lpips_lambda + tv
         self.last = dict(loss=loss.detach(), l2=l2.detach(), lpips=lp.detach(), tv=tv.detach(), image=out['image'].detach(), done=False)
         self.optimizer.zero_grad(set_to_none=True)
         if early_stop and bool(lp.item() <= self.thr):            # the reference's per-step host sync; it leaves BEFORE the update
@@ -578,6 +610,12 @@ class PivotalTuner:
         loss.backward()
         self.optimizer.step()
         return self.last
+
+
+def _pad_cl4(img: torch.Tensor) -> torch.Tensor:
+    """[N,3,H,W] -> [N,4,H,W] channels_last, channel 3 = 0."""
+    n, c, h, w = img.shape
+    return torch.cat([img.float(), img.new_zeros(n, 4 - c, h, w, dtype=torch.float32)], 1).contiguous(memory_format=torch.channels_last)
 
 
 def psnr_01(img: torch.Tensor, target: torch.Tensor) -> torch.Tensor:

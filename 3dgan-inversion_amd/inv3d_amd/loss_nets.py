@@ -351,6 +351,95 @@ def sqdist(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return _SqDistFn.apply(a, b)
 
 
+def _same_memory(a: torch.Tensor, b: torch.Tensor) -> bool:
+    return a.shape == b.shape and a.stride() == b.stride() and a.dtype == b.dtype == torch.float32
+
+
+def _dense(t: torch.Tensor) -> bool:
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
+class _ObjectiveFn(torch.autograd.Function):
+    """total = sum_k group_weight[group_k] * scale_k * value_k and the per-group sums, one launch per term and direction."""
+
+    @staticmethod
+    def forward(ctx, spec, group_weights, *tensors):
+        dev = tensors[0].device
+        buf = torch.zeros((4 + len(group_weights),), device=dev)     # its own allocation (not the step's zero arena): callers keep the values
+        total, parts = buf[:1], buf[4:]
+        lib, st = L.lib(), L.stream_ptr()
+        ti = 0
+        for kind, group, scale in spec:
+            part = parts.data_ptr() + 4 * group
+            gw = float(group_weights[group]) * scale
+            if kind == 'sq':
+                a, b = tensors[ti], tensors[ti + 1]
+                ti += 2
+                L.check(lib.eg3d_sqdist_sum_fwd(a.data_ptr(), b.data_ptr(), a.numel(), part, scale, total.data_ptr(), gw, st), 'sqdist_sum_fwd')
+            else:
+                v = tensors[ti]
+                ti += 1
+                B, Hh, Ww = v.shape
+                L.check(lib.eg3d_tv_norm_fwd(v.data_ptr(), B, Hh, Ww, part, scale, total.data_ptr(), gw, st), 'tv_norm_fwd')
+        ctx.spec, ctx.gw = spec, group_weights
+        ctx.save_for_backward(*tensors)
+        ctx.mark_non_differentiable(parts)
+        return total.view(()), parts
+
+    @staticmethod
+    def backward(ctx, g, _gparts):
+        tensors = ctx.saved_tensors
+        g = g.contiguous().float()
+        lib, st = L.lib(), L.stream_ptr()
+        grads, ti = [], 0
+        for kind, group, scale in ctx.spec:
+            gw = float(ctx.gw[group]) * scale
+            if kind == 'sq':
+                a, b = tensors[ti], tensors[ti + 1]
+                da = None
+                if ctx.needs_input_grad[2 + ti]:
+                    da = torch.empty_like(a)               # same strides as a (dense): the kernels walk memory linearly
+                    L.check(lib.eg3d_sqdist_sum_bwd(a.data_ptr(), b.data_ptr(), g.data_ptr(), gw, da.data_ptr(), a.numel(), st), 'sqdist_sum_bwd')
+                db = -da if (ctx.needs_input_grad[3 + ti] and da is not None) else None
+                if ctx.needs_input_grad[3 + ti] and da is None:
+                    db = torch.empty_like(b)
+                    L.check(lib.eg3d_sqdist_sum_bwd(b.data_ptr(), a.data_ptr(), g.data_ptr(), gw, db.data_ptr(), a.numel(), st), 'sqdist_sum_bwd')
+                grads += [da, db]
+                ti += 2
+            else:
+                v = tensors[ti]
+                dv = None
+                if ctx.needs_input_grad[2 + ti]:
+                    B, Hh, Ww = v.shape
+                    dv = torch.empty_like(v)
+                    L.check(lib.eg3d_tv_norm_bwd(v.data_ptr(), g.data_ptr(), gw, dv.data_ptr(), B, Hh, Ww, st), 'tv_norm_bwd')
+                grads.append(dv)
+                ti += 1
+        return (None, None) + tuple(grads)
+
+
+def weighted_objective(terms, group_weights):
+    """(total, parts): total = sum_k group_weights[g_k] * scale_k * value_k, parts[g] = sum_{k in g} scale_k * value_k (not differentiable).
+    terms: ('sq', group, scale, a, b) -- value = sum (a - b)^2 over two tensors of identical dense memory layout (numel % 4 == 0) -- or
+    ('tv', group, scale, v) -- value = squared forward-difference total variation of a contiguous [B,H,W] map.  Returns None when an
+    operand does not meet the kernels' layout requirements (the caller then composes the objective from ATen ops)."""
+    spec, tensors = [], []
+    for t in terms:
+        if t[0] == 'sq':
+            _, group, scale, a, b = t
+            if not (a.is_cuda and _same_memory(a, b) and _dense(a) and a.numel() % 4 == 0 and a.numel() >= 4
+                    and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0):
+                return None
+            tensors += [a, b]
+        else:
+            _, group, scale, v = t
+            if not (v.is_cuda and v.dim() == 3 and v.is_contiguous() and v.dtype == torch.float32 and v.shape[1] >= 2 and v.shape[2] >= 2):
+                return None
+            tensors.append(v)
+        spec.append((t[0], int(group), float(scale)))
+    return _ObjectiveFn.apply(tuple(spec), tuple(float(w) for w in group_weights), *tensors)
+
+
 def unit_features(xs: Sequence[torch.Tensor], eps: float = 1e-10) -> torch.Tensor:
     """[N, sum H*W*C]: per tap x * rsqrt(sum_c x^2 + eps) / sqrt(H*W), pixel-major inside a tap's slice (one launch per tap and direction)."""
     return _LpipsHeadFn.apply((eps, 1), len(xs), *xs, *([None] * len(xs)))

@@ -247,6 +247,24 @@ class SynthesisNetwork(ReferenceStateMixin, torch.nn.Module):
             self.add_module(f'b{res}', block)
             self.num_ws += block.num_conv + (block.num_torgb if last else 0)
 
+    def _draw_noise(self, n, device, prefix):
+        """noise_mode='random': the fresh per-layer normal draws of one forward (networks_stylegan2.py:318-319) from ONE generator launch,
+        handed to the layers as views (13 launches of a few microseconds each otherwise)."""
+        lay = []
+        for res in self.block_resolutions:
+            block = getattr(self, f'b{res}')
+            for name in (('conv1',) if block.in_channels == 0 else ('conv0', 'conv1')):
+                if getattr(block, name).use_noise:
+                    lay.append((f'{prefix}.b{res}.{name}', res))
+        if not lay:
+            return None
+        flat = torch.randn(sum(n * r * r for _, r in lay), device=device)
+        out, o = {}, 0
+        for key, r in lay:
+            out[key] = flat[o:o + n * r * r].view(n, 1, r, r)
+            o += n * r * r
+        return out
+
     def forward(self, ws, noise_inject=None, _prefix='backbone.synthesis', **block_kwargs):
         ws = ws.to(torch.float32)
         x = img = None
@@ -259,6 +277,8 @@ class SynthesisNetwork(ReferenceStateMixin, torch.nn.Module):
             counts.append(len(ent))
             w_idx += block.num_conv
         bank = fused.style_bank(ws, entries)
+        if noise_inject is None and block_kwargs.get('noise_mode', 'random') == 'random':
+            noise_inject = self._draw_noise(ws.shape[0], ws.device, _prefix)
         w_idx = s_idx = 0
         for res, cnt in zip(self.block_resolutions, counts):
             block = getattr(self, f'b{res}')

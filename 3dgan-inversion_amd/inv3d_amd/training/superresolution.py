@@ -31,7 +31,9 @@ class SuperresolutionHybrid8XDC(ReferenceStateMixin, torch.nn.Module):
             x = torch.nn.functional.interpolate(x, size=size, mode='bilinear', align_corners=False, antialias=self.sr_antialias)
             rgb = torch.nn.functional.interpolate(rgb, size=size, mode='bilinear', align_corners=False, antialias=self.sr_antialias)
         n, _, h, w = rgb.shape
-        rgb4 = torch.cat([rgb, rgb.new_zeros(n, 1, h, w)], 1).contiguous(memory_format=torch.channels_last)
+        rgb4 = getattr(rgb, '_eg3d_padded4', None)          # set by TriPlaneGenerator.synthesis: sliced and padded in one launch
+        if rgb4 is None:
+            rgb4 = torch.cat([rgb, rgb.new_zeros(n, 1, h, w)], 1).contiguous(memory_format=torch.channels_last)
         e0, e1 = self.block0.affine_entries(0), self.block1.affine_entries(0)        # both blocks read ws rows 0..2 (superresolution.py:63-64)
         bank = fused.style_bank(ws.float(), e0 + e1)
         s0, s1 = ((bank[0][:len(e0)], bank[1][:len(e0)]), (bank[0][len(e0):], bank[1][len(e0):])) if bank is not None else (None, None)

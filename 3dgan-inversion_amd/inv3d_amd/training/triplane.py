@@ -7,6 +7,7 @@ scripts/run_pti.py-style callers, the projector and the coaches can use it uncha
 deterministic runs: render_uniforms=(u1,u2), noise_inject={layer-name: [N,1,res,res]}."""
 import torch
 
+from .. import fused
 from ..reference_binding import ReferenceStateMixin
 from .networks_stylegan2 import Generator as StyleGAN2Backbone, FullyConnectedLayer
 from .superresolution import SuperresolutionHybrid8XDC
@@ -99,6 +100,8 @@ class TriPlaneGenerator(ReferenceStateMixin, torch.nn.Module):
         n = origins.shape[0]
         features = feat.view(n, res, res, feat.shape[-1]).permute(0, 3, 1, 2)          # [N, H*W, 32] IS the channels_last image: zero-copy
         rgb = features[:, :3].contiguous()
+        if feat.is_cuda and feat.shape[-1] % 4 == 0:      # the same image with 4-float pixels for the SR head's skip path and the fused loss kernels
+            rgb._eg3d_padded4 = fused.slice_rgb4(feat, res)
         image = self.superresolution(rgb, features, ws, noise_mode=self.rendering_kwargs['superresolution_noise_mode'], noise_inject=noise_inject,
                                      force_fp32=block_fp32, **{k: v for k, v in kwargs.items() if k != 'noise_mode'})
         return {'image': image, 'image_raw': rgb, 'image_depth': depth.transpose(1, 2).reshape(n, 1, res, res)}

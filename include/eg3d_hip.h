@@ -367,6 +367,10 @@ int eg3d_pack_conv_weight(const float* w, float* wf, float* wa, float* wsq, int 
  * the packed weight-gradient image g[o][t*Ip + i] (eg3d_conv2d_wgrad_f32 output, Ip >= I padded input channels):
  *   dw[o][i][t] = g[o][t*Ip + i] * oscale[o] (parameter layout),  doscale[o] = sum_{i,t} g[o][t*Ip + i] * w[o][i][t]   (oscale / doscale may be null). */
 int eg3d_pack_conv_weight_scaled(const float* w, const float* oscale, float* wf, float* wa, int O, int I, int T, void* stream);
+/* eg3d_pack_conv_weight into buffers whose output-channel dimension is padded to O_pad >= O (toRGB: 3 -> 4 channels so that the image
+ * is carried with 16-byte pixels): wf has O_pad rows, wa rows of T*O_pad floats (element (i, t, o) at (i*T + t)*O_pad + o).  Only the O real
+ * channels are written: the caller zero-fills both buffers once and reuses them while the weights train. */
+int eg3d_pack_conv_weight_padded(const float* w, float* wf, float* wa, float* wsq, int O, int I, int T, int O_pad, void* stream);
 int eg3d_unpack_weight_grad(const float* g, const float* w, const float* oscale, float* dw, float* doscale, int O, int I, int Ip, int T, void* stream);
 int eg3d_demod_fwd(const float* s, const float* wsq, float* d, int N, int Co, int Ck, void* stream);
 int eg3d_demod_bwd(const float* s, const float* wsq, const float* d, const float* dd, float* ds, float* dwsq,
@@ -528,6 +532,20 @@ int eg3d_image_prepare_bwd(const float* dout, float* dimg, int N, int H, int W, 
  * (w_projector.py:216-219); bwd: da = 2 g[n] (a - b). */
 int eg3d_sqdist_fwd(const float* a, const float* b, float* out, int N, int64_t F, void* stream);
 int eg3d_sqdist_bwd(const float* a, const float* b, const float* g, float* da, int N, int64_t F, void* stream);
+
+/* Terms of the pivotal-tuning objective (training/coaches/base_coach.py:104-126 calc_loss; depth TV :294-305) as weighted reductions:
+ * each forward adds  value * term_scale  to *term and  value * total_scale  to *total (either may be null; both pre-zeroed), each
+ * backward multiplies by the incoming scalar gradient g[0] (device) and the term's weight gscale (host).
+ *   sqdist_sum: value = sum_i (a[i] - b[i])^2 over n floats (n % 4 == 0, 16-byte aligned);   da = 2 g gscale (a - b)
+ *   tv_norm:    value = sum_{y<H-1, x<W-1} (v - v[x+1])^2 + (v - v[y+1])^2 over a [B,H,W] map;  dv = its gradient * g gscale */
+int eg3d_sqdist_sum_fwd(const float* a, const float* b, int64_t n, float* term, float term_scale, float* total, float total_scale, void* stream);
+int eg3d_sqdist_sum_bwd(const float* a, const float* b, const float* g, float gscale, float* da, int64_t n, void* stream);
+int eg3d_tv_norm_fwd(const float* v, int B, int H, int W, float* term, float term_scale, float* total, float total_scale, void* stream);
+int eg3d_tv_norm_bwd(const float* v, const float* g, float gscale, float* dv, int B, int H, int W, void* stream);
+/* image_raw with 4-float pixels from the rendered feature image (training/triplane.py:84-85, rgb = features[:, :3]):
+ * x [P,C] (C % 4 == 0) -> y4 [P,4] = (x0, x1, x2, 0);  bwd: dx [P,C] = (dy4.xyz, 0, ..., 0) (overwritten). */
+int eg3d_slice_rgb4_fwd(const float* x, float* y4, int64_t P, int C, void* stream);
+int eg3d_slice_rgb4_bwd(const float* dy4, float* dx, int64_t P, int C, void* stream);
 
 /* Depth-reprojection geometry of the warping loss (training/warping_loss.py:18-54 + LinePlaneCollision :58-72) per pixel:
  *   xyz = o + d * depth;  hit = intersection of the line (c, xyz - c) with the plane through P0 with normal -c;

@@ -459,3 +459,61 @@ def test_pivotal_tuning_with_the_references_fp16_sr_head():
     assert l16[-1] < l16[0]
     for a, b in zip(l32, l16):
         assert abs(a - b) <= 2e-2 * abs(a), (l32, l16)
+
+
+def test_pivotal_tuning_objective_from_reduction_kernels_equals_the_aten_composition():
+    """PivotalTuner composes L2 + LPIPS (both resolutions) + depth TV from five reduction launches when the images arrive with 4-float
+    pixels; with that path disabled it falls back to the ATen expressions of base_coach.py:104-126.  Both must walk the same trajectory.
+    Also: the 3 -> 4 channel padded toRGB weight images are re-packed in place every step (no stale weights)."""
+    from inv3d_amd import synthetic as S
+    from inv3d_amd.inversion import PivotalTuner
+    cfg = O.small_config()
+
+    def run(fused_objective):
+        G = S.make_generator(w_dim=32, z_dim=32, plane_res=32, channel_base=256, channel_max=16, nrr=16, sr_in_res=16, sr_widths=(16, 8),
+                             rendering_kwargs=cfg.rendering, device=DEV)
+        S.load_synthetic_weights(G, 0)
+        cam = O.synth_cameras(1, seed=2).float().to(DEV)
+        u1, u2 = O.make_uniforms(cfg, 1, seed=4)
+        kw = dict(noise_mode='const', render_uniforms=(u1.float().to(DEV), u2.float().to(DEV)))
+        with torch.no_grad():
+            target = G.synthesis(O.synth_ws(cfg, 1, seed=3).float().to(DEV), cam, **kw)['image'].clamp(-1, 1)
+        t = PivotalTuner(G, target, O.synth_ws(cfg, 1, seed=5).float().to(DEV), cam, synth_kwargs=kw, sr_fp16=False)
+        used = []
+        if not fused_objective:
+            t._fused_objective = lambda out: None
+        else:
+            orig = t._fused_objective
+            t._fused_objective = lambda out: (used.append(1), orig(out))[1]
+        hist = [t.step() for _ in range(6)]
+        assert bool(used) == fused_objective and (not fused_objective or all(r is not None for r in used))
+        return [[float(h[k]) for k in ('loss', 'l2', 'lpips', 'tv')] for h in hist], [p.detach().clone() for p in G.parameters()]
+    a, pa = run(True)
+    b, pb = run(False)
+    for ra, rb in zip(a, b):
+        for x, y in zip(ra, rb):
+            assert abs(x - y) <= 2e-4 * abs(y) + 1e-9, (a, b)
+    assert a[-1][0] < a[0][0]
+    worst = max(float((x - y).abs().max()) / (float(y.abs().max()) + 1e-12) for x, y in zip(pa, pb))
+    assert worst <= 5e-3, worst            # six Adam steps of 3e-4 from gradients equal to fp32 rounding
+
+
+def test_random_noise_mode_draws_fresh_noise_from_one_launch():
+    """noise_mode='random': SynthesisNetwork draws every layer's noise in one generator launch and hands views to the layers; two forwards
+    differ, a seeded forward reproduces, and 'const' is untouched."""
+    from inv3d_amd import synthetic as S
+    cfg = O.small_config()
+    G = S.make_generator(w_dim=32, z_dim=32, plane_res=32, channel_base=256, channel_max=16, nrr=16, sr_in_res=16, sr_widths=(16, 8),
+                         rendering_kwargs=cfg.rendering, device=DEV)
+    S.load_synthetic_weights(G, 0)
+    for m in G.backbone.synthesis.modules():
+        if hasattr(m, 'noise_strength'):
+            m.noise_strength.data.fill_(0.5)
+    ws = O.synth_ws(cfg, 2, seed=3).float().to(DEV)[:, :G.backbone.num_ws]
+    with torch.no_grad():
+        torch.manual_seed(1); p1 = G.backbone.synthesis(ws, noise_mode='random')
+        torch.manual_seed(1); p2 = G.backbone.synthesis(ws, noise_mode='random')
+        p3 = G.backbone.synthesis(ws, noise_mode='random')
+        c1, c2 = G.backbone.synthesis(ws, noise_mode='const'), G.backbone.synthesis(ws, noise_mode='const')
+    assert torch.equal(p1, p2) and not torch.equal(p1, p3) and torch.equal(c1, c2) and not torch.equal(p1, c1)
+    assert float((p1[0] - p1[1]).abs().max()) > 0            # per-sample draws

@@ -203,3 +203,43 @@ def test_image_prepare_and_sqdist_vs_torch():
         w = torch.arange(1, n + 1, device=DEV, dtype=torch.float32)
         (d * w).sum().backward()
         assert torch.allclose(a.grad, 2 * (a.detach() - b) * w[:, None], rtol=1e-6, atol=1e-6)
+
+
+def test_weighted_objective_and_rgb_slice_vs_aten():
+    """The pivotal-tuning objective from reduction kernels (base_coach.py:104-126 + the depth TV of :294-305) against the ATen composition
+    it replaces: value, per-group parts and every gradient; and the one-launch features[:, :3] -> 4-float-pixel image."""
+    from inv3d_amd import loss_nets as LN, fused
+    from inv3d_amd.inversion import compute_tv_norm
+    g = torch.Generator().manual_seed(9)
+    img = torch.cat([torch.rand(1, 3, 64, 64, generator=g), torch.zeros(1, 1, 64, 64)], 1).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    tgt = torch.cat([torch.rand(1, 3, 64, 64, generator=g), torch.zeros(1, 1, 64, 64)], 1).to(DEV).contiguous(memory_format=torch.channels_last)
+    f, tf = torch.randn(1, 4096, generator=g).to(DEV).requires_grad_(True), torch.randn(1, 4096, generator=g).to(DEV)
+    depth = (torch.rand(1, 33, 47, generator=g) + 2).to(DEV).requires_grad_(True)
+    lam = (0.7, 1.3, 1.0)
+    total, parts = LN.weighted_objective([('sq', 0, 1.0 / (3 * 64 * 64), img, tgt), ('sq', 1, 1.0, f, tf), ('tv', 2, 1.0 / (32 * 46), depth)], lam)
+    total.backward()
+    got = [t.grad.clone() for t in (img, f, depth)]
+    for t in (img, f, depth):
+        t.grad = None
+    l2 = torch.nn.functional.mse_loss(img[:, :3], tgt[:, :3])
+    lp = (f - tf).square().sum()
+    tv = compute_tv_norm(depth)
+    ref = l2 * lam[0] + lp * lam[1] + tv
+    ref.backward()
+    assert abs(float(total) - float(ref)) <= 2e-6 * abs(float(ref))
+    for a, b in zip(parts.tolist(), (float(l2), float(lp), float(tv))):
+        assert abs(a - b) <= 2e-6 * abs(b)
+    for a, t, name in zip(got, (img, f, depth), ('image', 'features', 'depth')):
+        assert float((a - t.grad).abs().max()) <= 2e-6 * float(t.grad.abs().max()), name
+    # operands the kernels cannot walk linearly: the caller is told to fall back
+    assert LN.weighted_objective([('sq', 0, 1.0, f[:, :-1], tf[:, :-1])], (1.0,)) is None
+    feat = torch.randn(2, 16 * 16, 32, generator=g).to(DEV).requires_grad_(True)
+    y = fused.slice_rgb4(feat, 16)
+    assert y.shape == (2, 4, 16, 16) and y.is_contiguous(memory_format=torch.channels_last)
+    ref = feat.detach().view(2, 16, 16, 32).permute(0, 3, 1, 2)[:, :3]
+    assert torch.equal(y[:, :3], ref) and float(y[:, 3].abs().max()) == 0.0
+    gy = torch.randn(y.shape, generator=g).to(DEV)
+    y.backward(gy)
+    want = torch.zeros_like(feat)
+    want.view(2, 16, 16, 32)[..., :3] = gy[:, :3].permute(0, 2, 3, 1)
+    assert torch.equal(feat.grad, want)
