@@ -16,6 +16,18 @@ static inline int eg3d_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b
 
 #ifdef __cplusplus
 #include <atomic>
+
+// Zero-fill of a small accumulator as a KERNEL node.  hipMemsetAsync becomes a memset node when the step is captured into a HIP graph, and
+// the ROCm 7.0 runtime's packet-captured replay of a single-branch graph stops honouring such a node after the first device-wide
+// synchronise (found with rocgdb: the tri-plane scatter's bin cursors were no longer cleared, the fill pass ran past its id buffer --
+// "write access to a read-only page"; DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 also avoids it).  No entry point of this library issues memset nodes.
+static __global__ void eg3d_zero_words_kernel(uint32_t* __restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+static inline void eg3d_zero_words(void* p, int64_t nwords, hipStream_t st) {
+    if (nwords > 0) hipLaunchKernelGGL(eg3d_zero_words_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, st, reinterpret_cast<uint32_t*>(p), nwords);
+}
 // Opt a kernel into more than 64 KB of dynamic LDS.  The attribute is a property of the (function, device) pair, so the "already
 // done" memo is one bit per device ordinal: correct with several devices in one process and from several host threads (a lost race
 // only repeats the idempotent call).  Returns 0 or a HIP error code.

@@ -188,8 +188,7 @@ extern "C" int eg3d_noise_regularizer(float* const* x, float* const* grad, const
     if (rc) return rc;
     if (!workspace || !reg_out) return EG3D_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(reg_out, 0, sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
+    eg3d_zero_words(reg_out, 1, st);
     hipLaunchKernelGGL(noise_reg_kernel, dim3(nbufs), dim3(NT), 0, st, B, workspace, reg_out, scale);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;

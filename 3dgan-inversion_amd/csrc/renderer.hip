@@ -986,8 +986,7 @@ extern "C" int eg3d_triplane_scatter(const float* df_rows, const float* df_pos, 
     int* chunk_offsets = offsets + nb + 1;
     int* ids = chunk_offsets + nb + 1;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * 2 * (size_t)nb, st);
-    if (e != hipSuccess) return (int)e;
+    eg3d_zero_words(counts, 2 * (int64_t)nb, st);          // counts + fill cursors (a kernel, not a memset node: see common.h)
     const float cs = 2.f / box_warp;
     const int blocks = eg3d_cdiv(S * 3, 256 * BIN_ITEMS);
     const float4* pos4 = reinterpret_cast<const float4*>(df_pos);
@@ -1024,9 +1023,8 @@ extern "C" int eg3d_ray_gen_bwd(const float* cam2world, const float* intrinsics,
                                 float* d_intrinsics, int N, int res, void* stream) {
     if (!cam2world || !intrinsics || !d_cam2world || N <= 0 || res <= 0) return EG3D_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(d_cam2world, 0, sizeof(float) * 16 * N, st);
-    if (e != hipSuccess) return (int)e;
-    if (d_intrinsics) { e = hipMemsetAsync(d_intrinsics, 0, sizeof(float) * 9 * N, st); if (e != hipSuccess) return (int)e; }
+    eg3d_zero_words(d_cam2world, 16 * (int64_t)N, st);
+    if (d_intrinsics) eg3d_zero_words(d_intrinsics, 9 * (int64_t)N, st);
     int bx = std::min(eg3d_cdiv((int64_t)res * res, 256), 64);
     hipLaunchKernelGGL(ray_gen_bwd_kernel, dim3(bx, N), dim3(256), 0, st, cam2world, intrinsics, d_origins, d_dirs, d_cam2world, d_intrinsics, res);
     EG3D_LAUNCH_CHECK();

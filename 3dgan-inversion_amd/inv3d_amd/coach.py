@@ -107,7 +107,7 @@ class InversionCoach:
             psnr_pivot = float(psnr_01(img, target))
         # ---- Phase B: generator weights around the pivot ------------------------------------------------------------------------
         tuner = PivotalTuner(G, target, w_pivot, cam_pivot, lr=self.pti_lr, lpips_threshold=self.thr, feature_net=self.feature_net,
-                             synth_kwargs=self.synth_kwargs, sr_fp16=self.sr_fp16)
+                             synth_kwargs=self.synth_kwargs, sr_fp16=self.sr_fp16, use_graph=self.use_graph)
         steps_b = 0
         for i in range(self.max_pti_steps):
             check = (i % self.interval) == self.interval - 1

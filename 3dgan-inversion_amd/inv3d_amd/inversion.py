@@ -533,8 +533,13 @@ class PivotalTuner:
     128^2 + depth TV -> backward into all generator weights -> Adam."""
 
     def __init__(self, G, target: torch.Tensor, w_pivot: torch.Tensor, cam: torch.Tensor, *, lr=3e-4, l2_lambda=1.0, lpips_lambda=1.0,
-                 lpips_threshold=0.06, feature_net: Optional[Callable] = None, synth_kwargs: Optional[dict] = None, sr_fp16: bool = True):
-        """`sr_fp16` (default, as the reference: BaseCoach.forward calls G.synthesis without force_fp32, base_coach.py:162-164): the
+                 lpips_threshold=0.06, feature_net: Optional[Callable] = None, synth_kwargs: Optional[dict] = None, sr_fp16: bool = True,
+                 use_graph: bool = False, graph_warmup: int = 2):
+        """`use_graph`: after `graph_warmup` eager steps the whole step (forward, objective, backward into all weights, fused Adam: ~370
+        launches) is captured into one HIP graph and replayed; steps that read the early-stop criterion (`step(early_stop=True)`, a host
+        sync before the update, single_id_coach.py:68-71) run eagerly in between, so the reference's leave-before-update order is kept.
+        The tensors in `last` are then static buffers that the next replay overwrites.
+        `sr_fp16` (default, as the reference: BaseCoach.forward calls G.synthesis without force_fp32, base_coach.py:162-164): the
         super-resolution head's convolutions -- forward, data and weight gradients -- run with one product of fp16-rounded operands instead
         of the three-product fp32-equivalent split; pass False (or force_fp32=True in synth_kwargs) for fp32-equivalent tuning."""
         self.G = G
@@ -550,7 +555,9 @@ class PivotalTuner:
             # the targets with 4-float pixels (channel 3 = 0), the layout the SR head and the renderer hand their images over in
             self.target4 = _pad_cl4(target)
             self.target4_128 = _pad_cl4(self.target_128)
-        self.optimizer = torch.optim.Adam(G.parameters(), lr=lr, fused=True)      # one multi-tensor launch over the 30.7 M parameters
+        self.use_graph, self._graph, self._graph_warmup, self.graph_capture_error, self._eager_steps = bool(use_graph), None, int(graph_warmup), None, 0
+        # one multi-tensor launch over the 30.7 M parameters; capturable: the step counters live on the device
+        self.optimizer = torch.optim.Adam(G.parameters(), lr=lr, fused=True, capturable=self.use_graph)
         # the fused kernel updates parameters without bumping their version counters, which the packed-weight caches key on
         self.optimizer.register_step_post_hook(lambda *_: hipops.weights_changed())
         self.synth_kwargs = dict(synth_kwargs or {})
@@ -588,8 +595,42 @@ class PivotalTuner:
         # nothing allocated from it outlives the step (gradients are consumed by optimizer.step() below)
         if self._arena is None:
             self._arena = hipops.ZeroArena(self.target.device)
-        with hipops.zero_arena(self._arena):
-            return self._step(early_stop, **step_kwargs)
+        if not self.use_graph or early_stop or self.graph_capture_error is not None:
+            with hipops.zero_arena(self._arena):
+                return self._step(early_stop, **step_kwargs)
+        if step_kwargs:
+            raise ValueError('use_graph: per-step synthesis kwargs cannot change between replays; pass them as synth_kwargs')
+        if self._graph is not None:
+            self._graph.replay()
+            hipops.weights_changed()              # the optimizer's post-step hook does not run under replay
+            self.last = self._graph_last
+            return self.last
+        if self._eager_steps < self._graph_warmup:             # warm-up on a side stream (allocator / autograd state, lazy kernel attributes)
+            side = torch.cuda.Stream(device=self.target.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), hipops.zero_arena(self._arena):
+                res = self._step(False)
+            torch.cuda.current_stream().wait_stream(side)
+            self._eager_steps += 1
+            return res
+        torch.cuda.synchronize()
+        self.optimizer.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'), hipops.zero_arena(self._arena):
+                self._step(False)
+            self._graph, self._graph_last = graph, self.last
+            graph.replay()                        # capture records without executing
+            hipops.weights_changed()
+        except RuntimeError as e:                 # the runtime refused the capture: keep tuning eagerly (same kernels), say so
+            import warnings
+            self.graph_capture_error = e
+            warnings.warn(f'PivotalTuner: HIP graph capture failed ({e}); continuing with eager launches')
+            torch.cuda.synchronize()
+            self.optimizer.zero_grad(set_to_none=True)
+            with hipops.zero_arena(self._arena):
+                return self._step(False)
+        return self.last
 
     def _step(self, early_stop: bool = False, **step_kwargs) -> Dict[str, torch.Tensor]:
         G = self.G

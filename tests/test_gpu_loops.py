@@ -517,3 +517,40 @@ def test_random_noise_mode_draws_fresh_noise_from_one_launch():
         c1, c2 = G.backbone.synthesis(ws, noise_mode='const'), G.backbone.synthesis(ws, noise_mode='const')
     assert torch.equal(p1, p2) and not torch.equal(p1, p3) and torch.equal(c1, c2) and not torch.equal(p1, c1)
     assert float((p1[0] - p1[1]).abs().max()) > 0            # per-sample draws
+
+
+def test_pivotal_tuning_step_replayed_from_a_hip_graph():
+    """PivotalTuner(use_graph=True): warm-up steps, capture, replays with device-wide synchronisations in between (the pattern that
+    faulted in the round-1 runtime investigation), early-stop checks served eagerly between replays -- same trajectory as the eager tuner."""
+    from inv3d_amd import synthetic as S
+    from inv3d_amd.inversion import PivotalTuner
+    cfg = O.small_config()
+
+    def run(use_graph):
+        G = S.make_generator(w_dim=32, z_dim=32, plane_res=32, channel_base=256, channel_max=16, nrr=16, sr_in_res=16, sr_widths=(16, 8),
+                             rendering_kwargs=cfg.rendering, device=DEV)
+        S.load_synthetic_weights(G, 0)
+        cam = O.synth_cameras(1, seed=2).float().to(DEV)
+        u1, u2 = O.make_uniforms(cfg, 1, seed=4)
+        kw = dict(noise_mode='const', render_uniforms=(u1.float().to(DEV), u2.float().to(DEV)))
+        with torch.no_grad():
+            target = G.synthesis(O.synth_ws(cfg, 1, seed=3).float().to(DEV), cam, **kw)['image'].clamp(-1, 1)
+        t = PivotalTuner(G, target, O.synth_ws(cfg, 1, seed=5).float().to(DEV), cam, synth_kwargs=kw, lpips_threshold=0.0, use_graph=use_graph)
+        losses = []
+        for i in range(16):
+            res = t.step(early_stop=(i % 5 == 4))
+            losses.append(float(res['loss']))
+            assert not res['done']
+            if i % 3 == 2:
+                torch.cuda.synchronize()
+        if use_graph:
+            assert t._graph is not None and t.graph_capture_error is None
+        with torch.no_grad():
+            img = G.synthesis(O.synth_ws(cfg, 1, seed=5).float().to(DEV), cam, force_fp32=True, **kw)['image']       # eager use of the tuned weights afterwards
+        return losses, img
+    le, ie = run(False)
+    lg, ig = run(True)
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 2e-3 * abs(a), (le, lg)
+    assert lg[-1] < lg[0]
+    assert float((ie - ig).abs().max()) <= 2e-2 * float(ie.abs().max())

@@ -9,10 +9,10 @@ cam = S.synth_cameras(1, seed=2).to(dev)
 with torch.no_grad():
     target = G.synthesis(S.synth_ws(14, 512, 1, seed=3).to(dev), cam, noise_mode='const', force_fp32=True)['image'].clamp(-1, 1)
 w_pivot = S.synth_ws(14, 512, 1, seed=5).to(dev)
-tuner = PivotalTuner(G, target, w_pivot, cam)
-for _ in range(3): tuner.step()
+tuner = PivotalTuner(G, target, w_pivot, cam, use_graph='graph' in sys.argv[1:])
+for _ in range(4): tuner.step()
 torch.cuda.synchronize(); t = time.perf_counter()
-n = 10
+n = 40 if tuner.use_graph else 10
 for _ in range(n): tuner.step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
-print(f'Phase B step: {dt*1e3:.2f} ms  ({1/dt:.1f} steps/s)')
+print(f'Phase B step: {dt*1e3:.2f} ms  ({1/dt:.1f} steps/s)', 'graph' if tuner._graph is not None else 'eager', tuner.graph_capture_error)
