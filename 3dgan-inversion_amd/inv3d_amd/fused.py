@@ -48,7 +48,7 @@ class WeightCache:
 
     def __init__(self):
         self._c = {}
-        self._pad, self._pad_key = None, None
+        self._pad, self._pad_key, self._pad_bias_key = None, None, None
 
     def get(self, w: torch.Tensor):
         key = (w.data_ptr(), w._version, tuple(w.shape), H.WEIGHTS_EPOCH)
@@ -75,19 +75,23 @@ class WeightCache:
         cp (toRGB 3 -> 4: the padded output channel is 0 + skip, the launch takes the 16-byte vector epilogue, and the data gradient
         contracts over 4 channels).  The buffers are zero-filled once and re-packed in place whenever the weights change -- one launch per
         step of the pivotal-tuning phase instead of a fill and a copy per image."""
-        key = (w.data_ptr(), w._version, tuple(w.shape), H.WEIGHTS_EPOCH, cp, None if bias is None else (bias.data_ptr(), bias._version))
+        key = (w.data_ptr(), w._version, tuple(w.shape), H.WEIGHTS_EPOCH, cp)
         pad = self._pad
         if pad is None or pad[0].shape[0] != cp or pad[0].device != w.device:
             o, i, kh, kw = w.shape
             pad = self._pad = (torch.zeros((cp, kh * kw * i), device=w.device), torch.zeros((i, kh * kw * cp), device=w.device),
                                torch.zeros((cp,), device=w.device))
-            self._pad_key = None
+            self._pad_key = self._pad_bias_key = None
         if self._pad_key != key:
             with torch.no_grad():
                 H.pack_conv_weight_padded(w, pad[0], pad[1], cp)
-                if bias is not None:
-                    pad[2][:bias.shape[0]].copy_(bias.detach().float())
             self._pad_key = key
+        if bias is not None:          # (the backward asks without the bias: its image keeps its own key)
+            bkey = (bias.data_ptr(), bias._version, H.WEIGHTS_EPOCH if bias.requires_grad else -1)
+            if self._pad_bias_key != bkey:
+                with torch.no_grad():
+                    pad[2][:bias.shape[0]].copy_(bias.detach().float())
+                self._pad_bias_key = bkey
         return pad[0], pad[1], (pad[2] if bias is not None else None)
 
 

@@ -25,7 +25,7 @@ class SuperresolutionHybrid8XDC(ReferenceStateMixin, torch.nn.Module):
                                      use_fp16=use_fp16, conv_clamp=clamp, **block_kwargs)
 
     def forward(self, rgb, x, ws, noise_inject=None, **block_kwargs):
-        ws = ws[:, -1:, :].repeat(1, 3, 1)
+        ws_all = ws
         if x.shape[-1] != self.input_resolution:
             size = (self.input_resolution, self.input_resolution)
             x = torch.nn.functional.interpolate(x, size=size, mode='bilinear', align_corners=False, antialias=self.sr_antialias)
@@ -34,8 +34,12 @@ class SuperresolutionHybrid8XDC(ReferenceStateMixin, torch.nn.Module):
         rgb4 = getattr(rgb, '_eg3d_padded4', None)          # set by TriPlaneGenerator.synthesis: sliced and padded in one launch
         if rgb4 is None:
             rgb4 = torch.cat([rgb, rgb.new_zeros(n, 1, h, w)], 1).contiguous(memory_format=torch.channels_last)
-        e0, e1 = self.block0.affine_entries(0), self.block1.affine_entries(0)        # both blocks read ws rows 0..2 (superresolution.py:63-64)
-        bank = fused.style_bank(ws.float(), e0 + e1)
+        # both blocks read rows 0..2 of ws[:, -1:, :].repeat(1, 3, 1) (superresolution.py:63-64), i.e. the LAST row of ws six times: the bank
+        # reads that row in place (no repeat / slice copies and their backward), the repeated tensor is only built for the per-layer path
+        e0, e1 = self.block0.affine_entries(0), self.block1.affine_entries(0)
+        last = ws_all.shape[1] - 1
+        bank = fused.style_bank(ws_all.float(), [(fc, last, post, conv) for fc, _, post, conv in e0 + e1])
+        ws = ws_all[:, -1:, :].expand(-1, 3, -1) if bank is not None else ws_all[:, -1:, :].repeat(1, 3, 1)
         s0, s1 = ((bank[0][:len(e0)], bank[1][:len(e0)]), (bank[0][len(e0):], bank[1][len(e0):])) if bank is not None else (None, None)
         x, rgb4 = self.block0(x, rgb4, ws, noise_inject=noise_inject, _name='superresolution.block0', styles=s0, **block_kwargs)
         x, rgb4 = self.block1(x, rgb4, ws, noise_inject=noise_inject, _name='superresolution.block1', styles=s1, **block_kwargs)

@@ -99,9 +99,12 @@ class TriPlaneGenerator(ReferenceStateMixin, torch.nn.Module):
         feat, depth, _ = self.renderer(planes, self.decoder, origins, directions, self.rendering_kwargs)
         n = origins.shape[0]
         features = feat.view(n, res, res, feat.shape[-1]).permute(0, 3, 1, 2)          # [N, H*W, 32] IS the channels_last image: zero-copy
-        rgb = features[:, :3].contiguous()
-        if feat.is_cuda and feat.shape[-1] % 4 == 0:      # the same image with 4-float pixels for the SR head's skip path and the fused loss kernels
-            rgb._eg3d_padded4 = fused.slice_rgb4(feat, res)
+        if feat.is_cuda and feat.shape[-1] % 4 == 0:      # 4-float pixels (channel 3 = 0) for the SR head's skip path and the fused loss kernels
+            raw4 = fused.slice_rgb4(feat, res)
+            rgb = raw4[:, :3]                             # image_raw is a view of it
+            rgb._eg3d_padded4 = raw4
+        else:
+            rgb = features[:, :3].contiguous()
         image = self.superresolution(rgb, features, ws, noise_mode=self.rendering_kwargs['superresolution_noise_mode'], noise_inject=noise_inject,
                                      force_fp32=block_fp32, **{k: v for k, v in kwargs.items() if k != 'noise_mode'})
         return {'image': image, 'image_raw': rgb, 'image_depth': depth.transpose(1, 2).reshape(n, 1, res, res)}
