@@ -427,6 +427,34 @@ __global__ void __launch_bounds__(256) unpack_weight_grad_kernel(const float* __
     if (tid == 0) da[o] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Weight gradient of a demodulated modulated conv in the parameter's own layout, both paths in one pass (block = output channel):
+//   dw[o][i][t] = g[o][t*I + i]  (the conv's packed weight-gradient image)  +  2 w[o][i][t] * dwsq[o][i],
+//   dwsq[o][i] = sum_n dd[n,o] * (-1/2) d[n,o]^3 s[n,i]^2       (d = rsqrt(sum_i s^2 wsq + eps), wsq = sum_t w^2: networks_stylegan2.py:60-63)
+// dd = gradient w.r.t. the demodulation coefficients (the activation-backward pass accumulates it); null: no demodulation term.
+__global__ void __launch_bounds__(256) weight_grad_finish_kernel(const float* __restrict__ g, const float* __restrict__ w, const float* __restrict__ s,
+                                                                 const float* __restrict__ d, const float* __restrict__ dd, float* __restrict__ dw, int N,
+                                                                 int O, int I, int T) {
+    extern __shared__ float row[];                      // [T][I + 1] packed row, then q[I] = 2 dwsq[o][.]
+    const int o = blockIdx.x, tid = threadIdx.x, ld = I + 1;
+    float* q = row + T * ld;
+    const int64_t ro = (int64_t)o * T * I;
+    for (int k = tid; k < T * I; k += 256) { const int t = k / I, i = k - t * I; row[t * ld + i] = g[ro + k]; }
+    for (int i = tid; i < I; i += 256) {
+        float acc = 0.f;
+        if (dd != nullptr)
+            for (int n = 0; n < N; ++n) {
+                const float dv = d[(int64_t)n * O + o], sv = s[(int64_t)n * I + i];
+                acc = fmaf(dd[(int64_t)n * O + o] * (-0.5f) * dv * dv * dv, sv * sv, acc);
+            }
+        q[i] = 2.f * acc;
+    }
+    __syncthreads();
+    for (int k = tid; k < I * T; k += 256) {
+        const int i = k / T, t = k - i * T;
+        dw[ro + k] = fmaf(w[ro + k], q[i], row[t * ld + i]);
+    }
+}
+
 // one wave per (n,o)
 __global__ void __launch_bounds__(256) demod_fwd_kernel(const float* __restrict__ s, const float* __restrict__ wsq, float* __restrict__ d, int N, int Co, int Ck) {
     int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
@@ -599,6 +627,18 @@ extern "C" int eg3d_unpack_weight_grad(const float* g, const float* w, const flo
     static std::atomic<uint64_t> attr_done{0};
     if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(unpack_weight_grad_kernel), 64 * 1024, attr_done)) return e;
     hipLaunchKernelGGL(unpack_weight_grad_kernel, dim3(O), dim3(256), smem, (hipStream_t)stream, g, w, oscale, dw, doscale, I, Ip, T);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_weight_grad_finish(const float* g, const float* w, const float* s, const float* d, const float* dd, float* dw, int N, int O, int I,
+                                      int T, void* stream) {
+    if (!g || !w || !dw || N <= 0 || O <= 0 || I <= 0 || T <= 0 || T > 64 || (dd && (!s || !d))) return EG3D_ERR_INVALID;
+    const size_t smem = ((size_t)T * (I + 1) + I) * sizeof(float);
+    if (smem > 64 * 1024) return EG3D_ERR_UNSUPPORTED;
+    static std::atomic<uint64_t> attr_done{0};
+    if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(weight_grad_finish_kernel), 64 * 1024, attr_done)) return e;
+    hipLaunchKernelGGL(weight_grad_finish_kernel, dim3(O), dim3(256), smem, (hipStream_t)stream, g, w, s, d, dd, dw, N, O, I, T);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -332,11 +332,11 @@ class ModConvLayerFn(torch.autograd.Function):
                     H.dgrad_finish(z, x, styles, dx, ds=ds)
             if prod is not None and did is True:
                 prod.fused = (dx,) + tuple(pacc)
-        dwsq = H.zeros(wsq.shape, dev) if need_w else None
-        if dd is not None and (need_s or need_w) and not d_given:       # with d from the style bank, dd is returned and handled there
+        # with d from the style bank, dd is returned and its d styles part handled there; the d weight part of it is in weight_grad_finish below
+        if dd is not None and need_s and not d_given:
             if ds is None:
                 ds = H.zeros((N, Ci), dev)
-            H.demod_bwd(styles, wsq, d, dd, ds=ds if need_s else None, dwsq=dwsq)
+            H.demod_bwd(styles, wsq, d, dd, ds=ds)
         dweight = None
         if need_w:
             dwp = H.zeros(wf.shape, dev)
@@ -344,10 +344,9 @@ class ModConvLayerFn(torch.autograd.Function):
             wprec = prec if (prec in ('f16x3', 'f16x1') and amax is not None) else 'f32'
             H.conv_wgrad(x, g, Ci, Co, dwp, cls_w, in_stride=1, out_stride=out_stride_w, in_scale=styles, precision=wprec,
                          g_amax=amax if wprec != 'f32' else None, g_amax_mul=amul)
-            # [O,taps,I] accumulator -> the parameter's own (contiguous [O,I,kh,kw]) layout, plus the demodulation path d wsq / d w = 2 w,
-            # in one pass; the fused multi-tensor Adam walks parameter and gradient with the same linear index
-            dweight = torch.empty_like(weight, memory_format=torch.contiguous_format)
-            torch.addcmul(dwp.view(Co, kh, kw, Ci).permute(0, 3, 1, 2), weight.detach(), dwsq[:, :, None, None], value=2.0, out=dweight)
+            # [O,taps,I] accumulator -> the parameter's own (contiguous [O,I,kh,kw]) layout, plus the demodulation path d wsq / d w = 2 w
+            # (dwsq from dd on the fly), in one pass; the fused multi-tensor Adam walks parameter and gradient with the same linear index
+            dweight = H.weight_grad_finish(dwp, weight, styles, d, dd)
         if dnoise is not None and noise4d:
             dnoise = dnoise.view(N, 1, Ho, Wo)
         return (dx if need_x else None, dweight, ds if need_s else None, dnoise, dstrength, dbias, None, None, None, None, None,
@@ -358,7 +357,8 @@ class StyleBankFn(torch.autograd.Function):
     """Styles -- and, for the conv layers, demodulation coefficients -- of all modulated layers of a network from two launches
     (eg3d_style_affine_fwd/_bwd).  apply(ws, plan, *weights_and_biases) -> tuple: the L styles [N, C_l], then one d [N, Co_l] per
     layer whose plan entry carries wsq.  plan = tuple of (wrow, wgain, bgain, post, has_bias, wsq | None) per layer.  Gradients flow
-    to ws and to the affine weights / biases that require them; the demodulation part is only used with frozen conv weights."""
+    to ws and to the affine weights / biases that require them (the demodulation part covers d d / d styles; a layer with trainable conv
+    weights adds d d / d weight itself)."""
 
     @staticmethod
     def forward(ctx, ws, plan, *params):
@@ -423,7 +423,7 @@ class StyleBankFn(torch.autograd.Function):
 
 def style_bank(ws, entries):
     """entries: list of (FullyConnectedLayer affine, ws row index, post scale, conv layer | None).  Returns (styles, demods) -- two
-    lists aligned with `entries` (demods[i] is None for layers without demodulation or with trainable conv weights) -- or None when
+    lists aligned with `entries` (demods[i] is None for layers without demodulation) -- or None when
     the bank does not apply (non-linear activation, too many layers)."""
     if len(entries) > L.STYLE_BANK_MAX or not ws.is_cuda:
         return None
@@ -431,9 +431,9 @@ def style_bank(ws, entries):
     for fc, wrow, post, conv in entries:
         if fc.activation != 'linear' or fc.weight.dtype != torch.float32:
             return None
-        wsq = None
-        if conv is not None and not conv.weight.requires_grad:     # trainable conv weights: the layer computes (and differentiates) its own demodulation
-            wsq = conv._cache.get(conv.weight)[2]
+        # demodulation coefficients of every conv layer from one launch, d d / d styles in the bank's backward; for trainable conv weights
+        # the layer adds d d / d weight itself (hipops.weight_grad_finish)
+        wsq = conv._cache.get(conv.weight)[2] if conv is not None else None
         plan.append((int(wrow), float(fc.weight_gain), float(fc.bias_gain), float(post), fc.bias is not None, wsq))
         params.append(fc.weight)
         if fc.bias is not None:

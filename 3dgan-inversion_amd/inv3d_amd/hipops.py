@@ -686,6 +686,19 @@ def pack_conv_weight_padded(w, wf_p, wa_p, o_pad):
             'pack_conv_weight_padded')
 
 
+def weight_grad_finish(dwp, weight, styles, d, dd):
+    """[O,I,kh,kw] gradient of a demodulated modulated conv weight from the packed weight-gradient image dwp [O, taps*I] and the
+    demodulation path (eg3d_weight_grad_finish); dd None: no demodulation term."""
+    L.require_cuda(dwp, weight)
+    w = weight.detach().contiguous().float()
+    o, i, kh, kw = w.shape
+    dw = torch.empty_like(w)
+    n = styles.shape[0] if styles is not None else 1
+    L.check(L.lib().eg3d_weight_grad_finish(dwp.data_ptr(), w.data_ptr(), L.ptr(styles), L.ptr(d), L.ptr(dd), dw.data_ptr(), n, o, i, kh * kw,
+                                            L.stream_ptr()), 'weight_grad_finish')
+    return dw
+
+
 def weight_sqsum(wp, Co, ntaps, Ck):
     wsq = torch.empty((Co, Ck), dtype=torch.float32, device=wp.device)
     L.check(L.lib().eg3d_weight_sqsum(L.ptr(wp), L.ptr(wsq), Co, ntaps, Ck, L.stream_ptr()), 'weight_sqsum')

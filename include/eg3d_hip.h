@@ -371,6 +371,12 @@ int eg3d_pack_conv_weight_scaled(const float* w, const float* oscale, float* wf,
  * is carried with 16-byte pixels): wf has O_pad rows, wa rows of T*O_pad floats (element (i, t, o) at (i*T + t)*O_pad + o).  Only the O real
  * channels are written: the caller zero-fills both buffers once and reuses them while the weights train. */
 int eg3d_pack_conv_weight_padded(const float* w, float* wf, float* wa, float* wsq, int O, int I, int T, int O_pad, void* stream);
+/* Weight gradient of a demodulated modulated conv, parameter layout, from the packed weight-gradient image g[o][t*I + i] of
+ * eg3d_conv2d_wgrad_f32 plus the demodulation path (networks_stylegan2.py:60-63):
+ *   dw[o][i][t] = g[o][t*I + i] + 2 w[o][i][t] * sum_n dd[n,o] (-1/2) d[n,o]^3 s[n,i]^2        (dd null: first term only)
+ * s [N,I] styles, d [N,O] demodulation coefficients, dd [N,O] their gradient; w, dw [O,I,T]. */
+int eg3d_weight_grad_finish(const float* g, const float* w, const float* s, const float* d, const float* dd, float* dw, int N, int O, int I, int T,
+                            void* stream);
 int eg3d_unpack_weight_grad(const float* g, const float* w, const float* oscale, float* dw, float* doscale, int O, int I, int Ip, int T, void* stream);
 int eg3d_demod_fwd(const float* s, const float* wsq, float* d, int N, int Co, int Ck, void* stream);
 int eg3d_demod_bwd(const float* s, const float* wsq, const float* d, const float* dd, float* ds, float* dwsq,
