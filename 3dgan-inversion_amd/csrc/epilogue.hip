@@ -368,11 +368,10 @@ __global__ void weight_sqsum_kernel(const float* __restrict__ w, float* __restri
 // pairs through LDS so that all three are written in runs of 32 consecutive floats.  Replaces two permute-copies and a reduction per
 // layer and step of the pivotal-tuning phase (weights change every step there).
 constexpr int PK = 16;      // 16 x 16 (o, i) pairs per block: 1024 blocks for a 512 x 512 layer (32 x 32 left most CUs with a single, serial block)
-__global__ void __launch_bounds__(256) pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wa,
-                                                               float* __restrict__ wsq, int O, int I, int T, const float* __restrict__ oscale, int Old) {
-    extern __shared__ float sm[];                       // [PK][PK*T + 1]
-    const int ld = PK * T + 1;
-    const int o0 = blockIdx.y * PK, i0 = blockIdx.x * PK;
+__device__ __forceinline__ void pack_conv_weight_tile(float* sm, const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wa,
+                                                      float* __restrict__ wsq, int O, int I, int T, const float* __restrict__ oscale, int Old, int bx, int by) {
+    const int ld = PK * T + 1;                          // sm: [PK][PK*T + 1]
+    const int o0 = by * PK, i0 = bx * PK;
     const int no = min(PK, O - o0), ni = min(PK, I - i0);
     const int tid = threadIdx.x, run = ni * T;
     for (int idx = tid; idx < no * run; idx += 256) {   // rows of w are contiguous in (i, t)
@@ -398,6 +397,24 @@ __global__ void __launch_bounds__(256) pack_conv_weight_kernel(const float* __re
                 wsq[(int64_t)(o0 + ol) * I + i0 + il] = a;
             }
         }
+}
+
+__global__ void __launch_bounds__(256) pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wa,
+                                                               float* __restrict__ wsq, int O, int I, int T, const float* __restrict__ oscale, int Old) {
+    extern __shared__ float sm[];
+    pack_conv_weight_tile(sm, w, wf, wa, wsq, O, I, T, oscale, Old, blockIdx.x, blockIdx.y);
+}
+
+// Every layer of a network in one launch (the weights of all layers change together, once per pivotal-tuning step): block -> (layer, tile)
+// through a prefix table held in the kernel arguments.
+struct PackBatch { eg3d_pack_item it[EG3D_PACK_BATCH_MAX]; int blk0[EG3D_PACK_BATCH_MAX + 1]; int n; };
+__global__ void __launch_bounds__(256) pack_conv_weights_batched_kernel(const PackBatch b) {
+    extern __shared__ float sm[];
+    int l = 0;
+    while (l + 1 < b.n && (int)blockIdx.x >= b.blk0[l + 1]) ++l;
+    const eg3d_pack_item& q = b.it[l];
+    const int local = blockIdx.x - b.blk0[l], tiles_i = (q.I + PK - 1) / PK;
+    pack_conv_weight_tile(sm, q.w, q.wf, q.wa, q.wsq, q.O, q.I, q.T, nullptr, q.O_pad > 0 ? q.O_pad : q.O, local % tiles_i, local / tiles_i);
 }
 
 // Gradient of a per-output-channel scaled weight w' = w * a[o] from the packed weight-gradient image g[o][t*Ip + i] of the conv that used
@@ -614,6 +631,29 @@ extern "C" int eg3d_pack_conv_weight(const float* w, float* wf, float* wa, float
 
 extern "C" int eg3d_pack_conv_weight_scaled(const float* w, const float* oscale, float* wf, float* wa, int O, int I, int T, void* stream) {
     return pack_conv_weight_impl(w, oscale, wf, wa, nullptr, O, I, T, stream);
+}
+
+extern "C" int eg3d_pack_conv_weights_batched(const eg3d_pack_item* items, int n, void* stream) {
+    if (!items || n < 1 || n > EG3D_PACK_BATCH_MAX) return EG3D_ERR_INVALID;
+    PackBatch b;
+    int maxT = 1, blocks = 0;
+    for (int l = 0; l < n; ++l) {
+        const eg3d_pack_item& q = items[l];
+        if (!q.w || !q.wf || q.O <= 0 || q.I <= 0 || q.T <= 0 || q.T > 64 || (q.O_pad != 0 && q.O_pad < q.O)) return EG3D_ERR_INVALID;
+        b.it[l] = q;
+        b.blk0[l] = blocks;
+        blocks += eg3d_cdiv(q.I, PK) * eg3d_cdiv(q.O, PK);
+        maxT = std::max(maxT, q.T);
+    }
+    b.blk0[n] = blocks;
+    b.n = n;
+    const size_t smem = (size_t)PK * (PK * maxT + 1) * sizeof(float);
+    if (smem > 64 * 1024) return EG3D_ERR_UNSUPPORTED;
+    static std::atomic<uint64_t> attr_done{0};
+    if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(pack_conv_weights_batched_kernel), 64 * 1024, attr_done)) return e;
+    hipLaunchKernelGGL(pack_conv_weights_batched_kernel, dim3(blocks), dim3(256), smem, (hipStream_t)stream, b);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
 }
 
 extern "C" int eg3d_pack_conv_weight_padded(const float* w, float* wf, float* wa, float* wsq, int O, int I, int T, int O_pad, void* stream) {

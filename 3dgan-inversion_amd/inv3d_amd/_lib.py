@@ -31,6 +31,15 @@ class ActBwd(C.Structure):
                 ('dbias', C.c_void_p), ('dd', C.c_void_p), ('dnoise', C.c_void_p), ('dnoise_nstride', C.c_int64), ('dstrength', C.c_void_p)]
 
 
+class PackItem(C.Structure):
+    """eg3d_pack_item: one layer of eg3d_pack_conv_weights_batched."""
+    _fields_ = [('w', C.c_void_p), ('wf', C.c_void_p), ('wa', C.c_void_p), ('wsq', C.c_void_p),
+                ('O', C.c_int32), ('I', C.c_int32), ('T', C.c_int32), ('O_pad', C.c_int32)]
+
+
+PACK_BATCH_MAX = 40
+
+
 class ConvParams(C.Structure):
     _fields_ = [('x', C.c_void_p), ('w', C.c_void_p), ('out', C.c_void_p),
                 ('N', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32), ('Ck', C.c_int32), ('ldx', C.c_int32),
@@ -164,6 +173,7 @@ _SIGS = {
     'eg3d_unit_normalize_bwd': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int64, C.c_int, C.c_void_p]),
     'eg3d_pack_conv_weight': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     'eg3d_weight_grad_finish': (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]),
+    'eg3d_pack_conv_weights_batched': (C.c_int, [C.POINTER(PackItem), C.c_int, C.c_void_p]),
     'eg3d_pack_conv_weight_padded': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
     'eg3d_pack_conv_weight_scaled': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     'eg3d_unpack_weight_grad': (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),

@@ -95,6 +95,45 @@ class WeightCache:
         return pad[0], pad[1], (pad[2] if bias is not None else None)
 
 
+def prepack_weights(layers):
+    """Re-pack the derived weight images of every layer whose weights changed since its last pack in ONE launch (pivotal tuning: all
+    generator weights change together, once per step -- 28 launches of a few microseconds otherwise).  `layers`: modules with `.weight`
+    [O,I,kh,kw] and `._cache` (WeightCache); an `out_pad` attribute (toRGB: 3 -> 4 channels) selects the zero-padded images.  Layers whose
+    images are current (frozen weights) cost one key comparison; the per-layer lazy paths stay valid for anything not passed here."""
+    items, installs = [], []
+    for m in layers:
+        w, cache = m.weight, m._cache
+        if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
+            continue
+        o, i, kh, kw = w.shape
+        cp = (o + 3) // 4 * 4
+        key = (w.data_ptr(), w._version, tuple(w.shape), H.WEIGHTS_EPOCH)
+        if getattr(m, 'out_pad', False) and cp != o:
+            pad = cache._pad
+            if pad is None or pad[0].shape[0] != cp or pad[0].device != w.device:
+                pad = cache._pad = (torch.zeros((cp, kh * kw * i), device=w.device), torch.zeros((i, kh * kw * cp), device=w.device),
+                                    torch.zeros((cp,), device=w.device))
+                cache._pad_key = cache._pad_bias_key = None
+            if cache._pad_key != key + (cp,):
+                items.append((w.detach(), pad[0], pad[1], None, cp))
+                installs.append((cache, 'pad', key + (cp,), None))
+        elif cache._c.get('k') != key:
+            wf = torch.empty((o, kh * kw * i), device=w.device)
+            wa = torch.empty((i, kh * kw * o), device=w.device)
+            wsq = torch.empty((o, i), device=w.device)
+            items.append((w.detach(), wf, wa, wsq, 0))
+            installs.append((cache, 'full', key, (wf, wa, wsq)))
+    if not items:
+        return 0
+    H.pack_conv_weights_batched(items)
+    for cache, kind, key, out in installs:
+        if kind == 'pad':
+            cache._pad_key = key
+        else:
+            cache._c = {'k': key, 'wf': out[0], 'wa': out[1], 'wsq': out[2]}
+    return len(items)
+
+
 def _zeros_views(device, *shapes):
     """Several small zero-initialised accumulators (targets of atomics) from ONE allocation and ONE fill launch.  A shape of
     None yields None.  Every view starts on a 16-byte boundary."""

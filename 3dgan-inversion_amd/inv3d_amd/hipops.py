@@ -686,6 +686,21 @@ def pack_conv_weight_padded(w, wf_p, wa_p, o_pad):
             'pack_conv_weight_padded')
 
 
+def pack_conv_weights_batched(items):
+    """items: list of (w [O,I,kh,kw], wf, wa | None, wsq | None, o_pad) with caller-allocated outputs (eg3d_pack_conv_weights_batched);
+    one launch per L.PACK_BATCH_MAX layers."""
+    for a in range(0, len(items), L.PACK_BATCH_MAX):
+        chunk = items[a:a + L.PACK_BATCH_MAX]
+        arr = (L.PackItem * len(chunk))()
+        for q, (w, wf, wa, wsq, o_pad) in zip(arr, chunk):
+            L.require_cuda(w, wf)
+            assert w.is_contiguous() and w.dtype == torch.float32
+            o, i, kh, kw = w.shape
+            q.w, q.wf, q.wa, q.wsq = w.data_ptr(), wf.data_ptr(), L.ptr(wa), L.ptr(wsq)
+            q.O, q.I, q.T, q.O_pad = o, i, kh * kw, int(o_pad)
+        L.check(L.lib().eg3d_pack_conv_weights_batched(arr, len(chunk), L.stream_ptr()), 'pack_conv_weights_batched')
+
+
 def weight_grad_finish(dwp, weight, styles, d, dd):
     """[O,I,kh,kw] gradient of a demodulated modulated conv weight from the packed weight-gradient image dwp [O, taps*I] and the
     demodulation path (eg3d_weight_grad_finish); dd None: no demodulation term."""

@@ -139,6 +139,8 @@ class SynthesisLayer(ReferenceStateMixin, torch.nn.Module):
 class ToRGBLayer(ReferenceStateMixin, torch.nn.Module):
     """Modulated 1x1 conv without demodulation + bias, accumulated onto the skip image (reference: networks_stylegan2.py:338-359)."""
 
+    out_pad = True          # fused.ToRGBFn computes ceil(out_channels / 4) * 4 channels: zero-padded weight images (fused.prepack_weights)
+
     def __init__(self, in_channels, out_channels, w_dim, kernel_size=1, conv_clamp=None, channels_last=False):
         super().__init__()
         if kernel_size != 1:
@@ -186,6 +188,10 @@ class SynthesisBlock(ReferenceStateMixin, torch.nn.Module):
         self.conv1 = SynthesisLayer(out_channels, out_channels, **common)
         self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp)
         self.num_conv, self.num_torgb = (1 if first else 2), 1
+
+    def packed_layers(self):
+        """The layers of this block that keep packed weight images (for fused.prepack_weights)."""
+        return ([] if self.in_channels == 0 else [self.conv0]) + [self.conv1, self.torgb]
 
     def affine_entries(self, w_idx):
         """(affine module, ws row, post scale) of this block's modulated layers in evaluation order (for fused.style_bank)."""
@@ -276,6 +282,8 @@ class SynthesisNetwork(ReferenceStateMixin, torch.nn.Module):
             entries += ent
             counts.append(len(ent))
             w_idx += block.num_conv
+        if ws.is_cuda and self.b4.conv1.weight.requires_grad:       # pivotal tuning: every weight image is stale once per step -> one launch for all
+            fused.prepack_weights([m for res in self.block_resolutions for m in getattr(self, f'b{res}').packed_layers()])
         bank = fused.style_bank(ws, entries)
         if noise_inject is None and block_kwargs.get('noise_mode', 'random') == 'random':
             noise_inject = self._draw_noise(ws.shape[0], ws.device, _prefix)

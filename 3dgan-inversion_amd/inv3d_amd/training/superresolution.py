@@ -36,6 +36,8 @@ class SuperresolutionHybrid8XDC(ReferenceStateMixin, torch.nn.Module):
             rgb4 = torch.cat([rgb, rgb.new_zeros(n, 1, h, w)], 1).contiguous(memory_format=torch.channels_last)
         # both blocks read rows 0..2 of ws[:, -1:, :].repeat(1, 3, 1) (superresolution.py:63-64), i.e. the LAST row of ws six times: the bank
         # reads that row in place (no repeat / slice copies and their backward), the repeated tensor is only built for the per-layer path
+        if ws_all.is_cuda and self.block0.conv1.weight.requires_grad:
+            fused.prepack_weights(self.block0.packed_layers() + self.block1.packed_layers())
         e0, e1 = self.block0.affine_entries(0), self.block1.affine_entries(0)
         last = ws_all.shape[1] - 1
         bank = fused.style_bank(ws_all.float(), [(fc, last, post, conv) for fc, _, post, conv in e0 + e1])

@@ -377,6 +377,14 @@ int eg3d_pack_conv_weight_padded(const float* w, float* wf, float* wa, float* ws
  * s [N,I] styles, d [N,O] demodulation coefficients, dd [N,O] their gradient; w, dw [O,I,T]. */
 int eg3d_weight_grad_finish(const float* g, const float* w, const float* s, const float* d, const float* dd, float* dw, int N, int O, int I, int T,
                             void* stream);
+/* eg3d_pack_conv_weight (O_pad = 0) / eg3d_pack_conv_weight_padded of up to EG3D_PACK_BATCH_MAX layers in ONE launch: during pivotal tuning
+ * all generator weights change together once per step.  wa / wsq may be null per item. */
+#define EG3D_PACK_BATCH_MAX 40
+typedef struct eg3d_pack_item {
+    const float* w; float* wf; float* wa; float* wsq;
+    int32_t O, I, T, O_pad;
+} eg3d_pack_item;
+int eg3d_pack_conv_weights_batched(const eg3d_pack_item* items, int n, void* stream);
 int eg3d_unpack_weight_grad(const float* g, const float* w, const float* oscale, float* dw, float* doscale, int O, int I, int Ip, int T, void* stream);
 int eg3d_demod_fwd(const float* s, const float* wsq, float* d, int N, int Co, int Ck, void* stream);
 int eg3d_demod_bwd(const float* s, const float* wsq, const float* d, const float* dd, float* ds, float* dwsq,

@@ -866,3 +866,40 @@ def test_conv_single_product_fp16_arithmetic():
         got = dwp.view(co, 3, 3, ci).permute(0, 3, 1, 2).cpu().double()
         e = float((got - dref).abs().max()) / float(dref.abs().max())
         assert lo <= e < hi, (prec, e)
+
+
+def test_batched_weight_pack_equals_per_layer_pack():
+    """eg3d_pack_conv_weights_batched (all layers of a network, one launch) writes the same images as the per-layer packs, including the
+    zero-padded 3 -> 4 channel toRGB images; eg3d_weight_grad_finish = packed gradient image -> parameter layout + demodulation term."""
+    from inv3d_amd import hipops as H
+    g = torch.Generator().manual_seed(3)
+    shapes = [(32, 16, 3, 3), (16, 32, 3, 3), (3, 16, 1, 1), (96, 24, 1, 1), (40, 8, 3, 3)]
+    ws = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+    items, outs = [], []
+    for w in ws:
+        o, i, kh, kw = w.shape
+        pad = (o + 3) // 4 * 4 if o % 4 else 0
+        wf = torch.zeros((pad or o, kh * kw * i), device=DEV)
+        wa = torch.zeros((i, kh * kw * (pad or o)), device=DEV)
+        wsq = torch.zeros((o, i), device=DEV)
+        items.append((w, wf, wa, wsq, pad))
+        outs.append((wf, wa, wsq))
+    H.pack_conv_weights_batched(items)
+    for w, (wf, wa, wsq) in zip(ws, outs):
+        o, i, kh, kw = w.shape
+        rf, ra, rq = H.pack_conv_weight(w)
+        assert torch.equal(wf[:o], rf) and float(wf[o:].abs().sum()) == 0.0
+        ra_p = wa.view(i, kh * kw, -1)
+        assert torch.equal(ra_p[:, :, :o].reshape(i, -1), ra) and float(ra_p[:, :, o:].abs().sum()) == 0.0
+        assert torch.equal(wsq, rq)
+    # gradient finishing pass
+    w = ws[0]
+    o, i, kh, kw = w.shape
+    n = 2
+    dwp = torch.randn(o, kh * kw * i, generator=g).to(DEV)
+    s, d, dd = torch.randn(n, i, generator=g).to(DEV), torch.rand(n, o, generator=g).to(DEV) + 0.5, torch.randn(n, o, generator=g).to(DEV)
+    got = H.weight_grad_finish(dwp, w, s, d, dd)
+    dwsq = torch.einsum('no,ni->oi', dd * (-0.5) * d ** 3, s * s)
+    ref = dwp.view(o, kh, kw, i).permute(0, 3, 1, 2) + 2 * w * dwsq[:, :, None, None]
+    close(got, ref, 1e-5, 'weight_grad_finish')
+    close(H.weight_grad_finish(dwp, w, None, None, None), dwp.view(o, kh, kw, i).permute(0, 3, 1, 2), 1e-7, 'weight_grad_finish (no demodulation)')
