@@ -248,7 +248,7 @@ def main():
         res = coach.invert('bench', target[:1], cam[:1])
         torch.cuda.synchronize()
         final = dict(final_psnr_db=round(res.psnr_tuned, 3), pivot_psnr_db=round(res.psnr_pivot, 3), steps=res.steps_a + res.steps_b,
-                     wall_s=round(time.perf_counter() - t1, 2), note='400 latent steps (graph-replayed, fp32-equivalent) + 400 pivotal-tuning steps (SR head in the reference\'s fp16-operand arithmetic, as BaseCoach.forward), stub feature pyramid, synthetic target')
+                     wall_s=round(time.perf_counter() - t1, 2), note='400 latent steps (fp32-equivalent) + 400 pivotal-tuning steps (SR head in the reference\'s fp16-operand arithmetic, as BaseCoach.forward), both phases replayed from HIP graphs (the early-stop reads every 50 steps run eagerly), stub feature pyramid, synthetic target')
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         wl = ('C2: FFHQ 512^2 single-image latent inversion step' if M == 1 else

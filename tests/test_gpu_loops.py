@@ -2,6 +2,7 @@
 w_projector.py:145-270 and single_id_coach.py:64-77 lifted and run by tests/golden/make_golden.py, no oracle in between) and (ii) their
 CPU oracle twins on identical inputs (BASELINE.json configs 2-4 as parity cases; the small generator keeps the CPU side to seconds).
 Bar: final-PSNR drift after an N-step optimisation <= 1e-3 dB."""
+import math
 import numpy as np
 import pytest
 import torch
@@ -554,3 +555,28 @@ def test_pivotal_tuning_step_replayed_from_a_hip_graph():
         assert abs(a - b) <= 2e-3 * abs(a), (le, lg)
     assert lg[-1] < lg[0]
     assert float((ie - ig).abs().max()) <= 2e-2 * float(ie.abs().max())
+
+
+def test_config_c4_at_full_size_replays_from_a_graph():
+    """Config C4 on the full-size (30.7 M parameter) generator: the pivotal-tuning step captured into a HIP graph and replayed across
+    device-wide synchronisations, SR head in the reference's fp16-operand arithmetic, noise_mode='random' as BaseCoach.forward.  Asserts
+    that the capture succeeded (no silent eager fallback), the objective falls and stays finite, and that an eager early-stop check between
+    replays sees the same state."""
+    from inv3d_amd import synthetic as S
+    from inv3d_amd.inversion import PivotalTuner
+    G = S.make_generator(device=DEV)
+    S.load_synthetic_weights(G, seed=0)
+    cam = S.synth_cameras(1, seed=2).to(DEV)
+    with torch.no_grad():
+        target = G.synthesis(S.synth_ws(14, 512, 1, seed=3).to(DEV), cam, noise_mode='const', force_fp32=True)['image'].clamp(-1, 1)
+    t = PivotalTuner(G, target, S.synth_ws(14, 512, 1, seed=5).to(DEV), cam, lpips_threshold=0.0, use_graph=True)
+    losses = []
+    for i in range(14):
+        res = t.step(early_stop=(i == 9))
+        losses.append(float(res['loss']))
+        if i % 4 == 3:
+            torch.cuda.synchronize()
+    assert t._graph is not None and t.graph_capture_error is None
+    assert all(math.isfinite(v) for v in losses)
+    assert losses[-1] < 0.8 * losses[0], losses
+    assert max(losses[3:]) <= losses[2] * 1.05, losses          # no blow-up at the eager -> replay -> eager transitions
