@@ -366,6 +366,7 @@ class LatentProjector:
         self.step_idx = 0
         self.last = {}
         self._reg_stream = None
+        self._one = None
         self._arena = None
 
     @property
@@ -495,7 +496,7 @@ class LatentProjector:
             if img.shape[2] > 256:
                 img = _area_resize(img, 256)
         dist_i = LN.sqdist(self.feature_net(img), self.target_features)              # per image; independent trajectories: the sum's
-        dist = dist_i.sum()                                                           # gradient is each image's own gradient
+        dist = dist_i.sum() if dist_i.numel() > 1 else dist_i.reshape(())            # gradient is each image's own gradient (one image: a view)
         cur.wait_stream(self._reg_stream)
         loss = dist + reg                         # reported value; only `dist` (and the warping term) goes through autograd
         warp = None
@@ -507,7 +508,9 @@ class LatentProjector:
         if self.optimize_pose:
             self.cam_optimizer.zero_grad(set_to_none=True)
             self.translation_optimizer.zero_grad(set_to_none=True)
-        (dist if warp is None else dist + warp).backward()
+        if self._one is None:
+            self._one = torch.ones((), device=dist.device)          # the seed gradient, allocated once (backward() would fill a new one per step)
+        (dist if warp is None else dist + warp).backward(gradient=self._one)
         have = [(b.grad, g) for b, g in zip(self._opt_bufs, reg_grads) if b.grad is not None]
         for b, g in zip(self._opt_bufs, reg_grads):
             if b.grad is None:                 # a backbone buffer the synthesis did not read (noise_mode overridden): regulariser only

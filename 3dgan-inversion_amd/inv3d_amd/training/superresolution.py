@@ -45,6 +45,6 @@ class SuperresolutionHybrid8XDC(ReferenceStateMixin, torch.nn.Module):
         s0, s1 = ((bank[0][:len(e0)], bank[1][:len(e0)]), (bank[0][len(e0):], bank[1][len(e0):])) if bank is not None else (None, None)
         x, rgb4 = self.block0(x, rgb4, ws, noise_inject=noise_inject, _name='superresolution.block0', styles=s0, **block_kwargs)
         x, rgb4 = self.block1(x, rgb4, ws, noise_inject=noise_inject, _name='superresolution.block1', styles=s1, **block_kwargs)
-        img = rgb4[:, :3].contiguous()
-        img._eg3d_padded4 = rgb4          # the same image with 4-float pixels (channel 3 = 0): what the fused loss-side kernels read (inversion.py)
+        img = rgb4[:, :3]                 # a view of the image with 4-float pixels (channel 3 = 0), which the fused loss-side kernels read (inversion.py)
+        img._eg3d_padded4 = rgb4
         return img
