@@ -115,6 +115,9 @@ class InversionCoach:
             if check and res.get('done'):         # the reference leaves before the update (single_id_coach.py:68-71)
                 break
             steps_b += 1
+        # how the two phases were actually issued (a refused capture falls back to eager launches with a warning: callers that quote timings check this)
+        self.last_launch_modes = dict(phase_a='graph' if getattr(proj, '_graph', None) is not None else 'eager',
+                                      phase_b='graph' if getattr(tuner, '_graph', None) is not None else 'eager')
         with torch.no_grad():
             img = G.synthesis(w_pivot, cam_pivot, noise_mode='const', force_fp32=True, **self.synth_kwargs)['image']
             psnr_tuned = float(psnr_01(img, target))
