@@ -12,7 +12,7 @@ N GPUs = N independent images (weak scaling), one packed stat all-reduce per ste
 
 The JSON line also carries
   roofline      : the dominant kernel = the conv kernel family (tile configuration x arithmetic) with the largest share of the step's
-                  time: conv_v2_kernel<9> (csrc/conv_v2.hip, pre-split fp16 pieces, LDS-DMA staged halo) on the default settings.
+                  time: conv_v2_kernel<9,true> (csrc/conv_v2.hip, pre-split fp16 pieces, LDS-DMA staged halo) on the default settings.
                   achieved = algorithmic FLOPs of its launches (2 x MACs of the convolution) / their HIP-event
                   durations measured on the launch stream.  `peak` is the matrix peak for the arithmetic the kernel executes:
                   157.3 TFLOP/s for --precision f32 (v_mfma_f32_32x32x2_f32); for the split modes (fp32 operands and results, every
@@ -201,11 +201,11 @@ def main():
             nprod = PRODUCTS[dom_prec]
             peak = FP32_MFMA_PEAK_TFLOPS if dom_prec == 'f32' else BF16_MFMA_PEAK_TFLOPS / nprod
             if is_v2:
-                kern, tkey = 'conv_v2_kernel<9> (pre-split fp16 pieces, LDS-DMA staged halo; fp32 in/out, 3 x v_mfma_f32_32x32x16_f16 per fp32 product)', 'conv_v2_kernel<9>'
+                kern, tkey = 'conv_v2_kernel<9,true> (pre-split fp16 pieces, LDS-DMA staged halo; fp32 in/out, 3 x v_mfma_f32_32x32x16_f16 per fp32 product)', 'conv_v2_kernel<9,true>'
             else:
                 kern = 'conv_igemm_kernel<%s,%d,*> (fp32 in/out, %d x MFMA per fp32 product)' % (H.TILE_NAMES.get(dom_id[0], '?'), H.PRECISIONS[dom_prec], nprod)
                 tkey = 'conv_igemm_kernel<%s>' % H.TILE_NAMES.get(dom_id[0], '?')
-            tr = traffic.get(tkey, {})
+            tr = traffic.get(tkey) or traffic.get(tkey.replace(',true>', '>'), {})
             per_launch_ref = tr.get('gflop_per_launch')
             tbytes = tr.get('bytes_per_launch')
             if tbytes is not None and per_launch_ref:           # the PMC pass ran the same kernel: scale by the work of this run's launches
