@@ -11,15 +11,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int GRAM_BLOCKS = 512;
+constexpr int GRAM_BLOCKS = 1024;
 constexpr int UNROLL = 8;            // row pairs in flight per wave and trip
 
+// A_HI / B_HI: columns 32..63 of a / b go through the matrix cores as well; A_EX (only without A_HI): a has 32 + A_EX columns (A_EX <= 8),
+// the extra ones are multiplied on the VALU (a row's extra value is one broadcast load).  The two products of the decoder gradients are
+// (64 x 32) and (33 x 64): two MFMAs per row pair each instead of four.
+template <bool A_HI, bool B_HI, int A_EX>
 __global__ void __launch_bounds__(256) rows_gram_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t S, int Ka, int Kb,
                                                         float* __restrict__ out, float* __restrict__ colsum) {
     __shared__ float red[64 * 64 + 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane & 31, h = lane >> 5;
     const int64_t nw = (int64_t)gridDim.x * 4, w = (int64_t)blockIdx.x * 4 + wave;
-    const bool a0 = l < Ka, a1 = 32 + l < Ka, b0 = l < Kb, b1 = 32 + l < Kb;
+    const bool a0 = l < Ka, a1 = A_HI && 32 + l < Ka, b0 = l < Kb, b1 = B_HI && 32 + l < Kb;
+    constexpr int NEX = A_EX > 0 ? A_EX : 1;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -27,9 +32,11 @@ __global__ void __launch_bounds__(256) rows_gram_kernel(const float* __restrict_
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float cs0 = 0.f, cs1 = 0.f;
+    float cs0 = 0.f, cs1 = 0.f, ex[NEX][2], exs[NEX];
+#pragma unroll
+    for (int c = 0; c < NEX; ++c) { ex[c][0] = ex[c][1] = 0.f; exs[c] = 0.f; }
     for (int64_t r0 = 2 * UNROLL * w; r0 < S; r0 += 2 * UNROLL * nw) {
-        float av[UNROLL][2], bv[UNROLL][2];
+        float av[UNROLL][2], bv[UNROLL][2], xv[UNROLL][NEX];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int64_t row = r0 + 2 * u + h;
@@ -40,24 +47,34 @@ __global__ void __launch_bounds__(256) rows_gram_kernel(const float* __restrict_
             av[u][1] = (ok && a1) ? ar[32 + l] : 0.f;
             bv[u][0] = (ok && b0) ? br[l] : 0.f;
             bv[u][1] = (ok && b1) ? br[32 + l] : 0.f;
+#pragma unroll
+            for (int c = 0; c < NEX; ++c) xv[u][c] = (A_EX > 0 && ok && 32 + c < Ka) ? ar[32 + c] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][0], bv[u][0], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][0], bv[u][1], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][1], bv[u][0], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][1], bv[u][1], acc[1][1], 0, 0, 0);
+            if (B_HI) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][0], bv[u][1], acc[0][1], 0, 0, 0);
+            if (A_HI) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][1], bv[u][0], acc[1][0], 0, 0, 0);
+            if (A_HI && B_HI) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][1], bv[u][1], acc[1][1], 0, 0, 0);
             cs0 += av[u][0];
             cs1 += av[u][1];
+            if (A_EX > 0) {
+#pragma unroll
+                for (int c = 0; c < NEX; ++c) {
+                    ex[c][0] = fmaf(xv[u][c], bv[u][0], ex[c][0]);
+                    ex[c][1] = fmaf(xv[u][c], bv[u][1], ex[c][1]);
+                    exs[c] += xv[u][c];
+                }
+            }
         }
     }
     // block reduction in LDS, then one global atomic per element
     for (int i = threadIdx.x; i < 64 * 64 + 64; i += 256) red[i] = 0.f;
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < (A_HI ? 2 : 1); ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < (B_HI ? 2 : 1); ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, col = j * 32 + l;
@@ -65,7 +82,15 @@ __global__ void __launch_bounds__(256) rows_gram_kernel(const float* __restrict_
             }
     cs0 += __shfl_xor(cs0, 32);
     cs1 += __shfl_xor(cs1, 32);
-    if (h == 0) { atomicAdd(&red[64 * 64 + l], cs0); atomicAdd(&red[64 * 64 + 32 + l], cs1); }
+    if (h == 0) { atomicAdd(&red[64 * 64 + l], cs0); if (A_HI) atomicAdd(&red[64 * 64 + 32 + l], cs1); }
+    if (A_EX > 0) {
+#pragma unroll
+        for (int c = 0; c < NEX; ++c) {
+            atomicAdd(&red[(32 + c) * 64 + l], ex[c][0]);                 // both half-waves add their rows' share
+            if (B_HI) atomicAdd(&red[(32 + c) * 64 + 32 + l], ex[c][1]);
+            if (l == 0) atomicAdd(&red[64 * 64 + 32 + c], exs[c]);        // every lane of a half-wave holds the same sum: one of them
+        }
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         const int row = i >> 6, col = i & 63;
@@ -81,7 +106,14 @@ extern "C" int eg3d_rows_gram(const float* a, const float* b, int64_t S, int Ka,
     if (Ka > 64 || Kb > 64) return EG3D_ERR_UNSUPPORTED;
     if (S == 0) return EG3D_OK;
     const int blocks = (int)std::min<int64_t>(GRAM_BLOCKS, eg3d_cdiv(S, 2 * UNROLL * 4));
-    hipLaunchKernelGGL(rows_gram_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, S, Ka, Kb, out, colsum);
+    const bool bhi = Kb > 32;
+    const int aex = (Ka > 32 && Ka <= 40) ? Ka - 32 : 0;
+    auto kern = rows_gram_kernel<true, true, 0>;
+    if (aex == 1) kern = bhi ? rows_gram_kernel<false, true, 1> : rows_gram_kernel<false, false, 1>;
+    else if (aex > 1) kern = bhi ? rows_gram_kernel<false, true, 8> : rows_gram_kernel<false, false, 8>;
+    else if (Ka > 32) kern = bhi ? rows_gram_kernel<true, true, 0> : rows_gram_kernel<true, false, 0>;
+    else kern = bhi ? rows_gram_kernel<false, true, 0> : rows_gram_kernel<false, false, 0>;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, S, Ka, Kb, out, colsum);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

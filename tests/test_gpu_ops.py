@@ -516,7 +516,7 @@ def test_run_model_vs_oracle():
 
 
 # ------------------------------------------------------------------------------------------------- noise buffers
-@pytest.mark.parametrize('shape', [(100003, 64, 32), (4097, 33, 64), (17, 5, 7), (2, 64, 64)])
+@pytest.mark.parametrize('shape', [(100003, 64, 32), (4097, 33, 64), (17, 5, 7), (2, 64, 64), (1001, 36, 40), (513, 33, 20), (129, 40, 64), (77, 41, 33)])
 def test_rows_gram(shape):
     """a^T b and column sums of tall-skinny row matrices (decoder-weight gradients of pivotal tuning) vs fp64."""
     from inv3d_amd import hipops as H
