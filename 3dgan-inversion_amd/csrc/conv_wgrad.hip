@@ -29,9 +29,15 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const eg3d_wgrad_params
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // blockIdx.x -> (tile_o, tile_i); blockIdx.y -> global tap index (class, tap); blockIdx.z -> cell slice
-    const int to = blockIdx.x / tiles_i, ti = blockIdx.x % tiles_i;
-    int cls_id = 0, tap = blockIdx.y;
+    // logical block id -> (tile_o, tile_i) fastest, then the global tap index (class, tap), then the cell slice.  The hardware deals
+    // consecutive workgroups to the 8 XCDs in turn; the remap hands every XCD a contiguous run of logical ids instead, so that all tiles
+    // and taps of one cell slice -- which read the same cells of x and g -- run on one XCD and share its L2 (un-mapped, the nine taps of a
+    // slice sit on eight different L2s and every one of them fetches its operands from HBM: 2.4 GB for a 128-channel 512^2 layer).
+    const int nblk_xy = gridDim.x * gridDim.y;
+    const int lid = eg3d_xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nblk_xy * gridDim.z);
+    const int bz = lid / nblk_xy, bxy = lid - bz * nblk_xy, by = bxy / gridDim.x, bx = bxy - by * gridDim.x;
+    const int to = bx / tiles_i, ti = bx % tiles_i;
+    int cls_id = 0, tap = by;
     while (cls_id < p.ncls && tap >= p.cls[cls_id].ntaps) { tap -= p.cls[cls_id].ntaps; ++cls_id; }
     if (cls_id >= p.ncls) return;
     const eg3d_conv_class& cl = p.cls[cls_id];
@@ -41,8 +47,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const eg3d_wgrad_params
     const int o0 = to * BO, k0 = ti * BI;
 
     const int nsteps_total = (Mc + BC - 1) / BC;
-    const int s_begin = (int)((int64_t)blockIdx.z * nsteps_total / p.psplit);
-    const int s_end = (int)((int64_t)(blockIdx.z + 1) * nsteps_total / p.psplit);
+    const int s_begin = (int)((int64_t)bz * nsteps_total / p.psplit);
+    const int s_end = (int)((int64_t)(bz + 1) * nsteps_total / p.psplit);
     if (s_begin >= s_end) return;
 
     // ---- loaders: branch-free raw buffer loads (as in conv_igemm.hip) -------------------------------------------------------
@@ -203,8 +209,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_f16x3_kernel(const eg3d_wgr
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int to = blockIdx.x / tiles_i, ti = blockIdx.x % tiles_i;
-    int cls_id = 0, tap = blockIdx.y;
+    const int nblk_xy = gridDim.x * gridDim.y;          // XCD-aware logical block id, as in conv_wgrad_kernel
+    const int lid = eg3d_xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nblk_xy * gridDim.z);
+    const int bz = lid / nblk_xy, bxy = lid - bz * nblk_xy, by = bxy / gridDim.x, bx = bxy - by * gridDim.x;
+    const int to = bx / tiles_i, ti = bx % tiles_i;
+    int cls_id = 0, tap = by;
     while (cls_id < p.ncls && tap >= p.cls[cls_id].ntaps) { tap -= p.cls[cls_id].ntaps; ++cls_id; }
     if (cls_id >= p.ncls) return;
     const eg3d_conv_class& cl = p.cls[cls_id];
@@ -213,8 +222,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_f16x3_kernel(const eg3d_wgr
     const int dy = cl.dy[tap], dx = cl.dx[tap], wt = cl.wtap[tap];
     const int o0 = to * BO, k0 = ti * BI;
     const int nsteps_total = (Mc + BC - 1) / BC;
-    const int s_begin = (int)((int64_t)blockIdx.z * nsteps_total / p.psplit);
-    const int s_end = (int)((int64_t)(blockIdx.z + 1) * nsteps_total / p.psplit);
+    const int s_begin = (int)((int64_t)bz * nsteps_total / p.psplit);
+    const int s_end = (int)((int64_t)(bz + 1) * nsteps_total / p.psplit);
     if (s_begin >= s_end) return;
 
     float g_mul = 1.f, g_inv = 1.f;
@@ -239,7 +248,45 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_f16x3_kernel(const eg3d_wgr
     float4 sv = make_float4(1.f, 1.f, 1.f, 1.f);
     if (p.in_scale != nullptr && p.N == 1 && kcok) sv = *reinterpret_cast<const float4*>(p.in_scale + k0 + lcol * 4);
 
+    // Cell -> (image, row, column): the steps of a block are loaded strictly in order (s_begin, s_begin + 1, ...), each 32 cells further on.
+    // With rows of >= 32 cells and a multiple of four (every layer from 32^2 up) a thread's four cells share a row and the coordinates are
+    // advanced incrementally -- the eight integer divisions per step this replaces were several times the MFMA time of the single-product
+    // variant.  Other geometries divide as before.
+    const bool rows_fast = (Wa % 4 == 0) && Wa >= BC && (HWa % 4 == 0);
+    int cn = 0, cay = 0, cax = 0;
+    {
+        const int m0 = s_begin * BC + 4 * lq;
+        cn = m0 / HWa;
+        const int rem = m0 - cn * HWa;
+        cay = rem / Wa; cax = rem - cay * Wa;
+    }
+    const unsigned gcol = (unsigned)(p.out_stride * p.ldg), gch = (unsigned)(o0 + lcol * 4), xch = (unsigned)(k0 + lcol * 4);
     auto load = [&](Regs& R, int step) {
+        if (rows_fast) {
+            // one row base per thread and step, 32-bit element offsets (the launch checks that both tensors stay below 2^31 bytes)
+            const int n0 = cn, ay0 = cay, ax0 = cax;
+            cax += BC;
+            if (cax >= Wa) { cax -= Wa; if (++cay >= Ha) { cay = 0; ++cn; } }
+            const bool ok = step * BC + 4 * lq < Mc;                  // Mc is a multiple of four here: the four cells go together
+            const int iy = ay0 * p.in_stride + dy;
+            const bool yin = ok && kcok && (unsigned)iy < (unsigned)p.Hi;
+            const unsigned grow = ((unsigned)(n0 * p.Ho + ay0 * p.out_stride + cl.out_py) * (unsigned)p.Wo + (unsigned)cl.out_px) * (unsigned)p.ldg + gch;
+            const unsigned xrow = (unsigned)(n0 * p.Hi + iy) * (unsigned)p.Wi * (unsigned)p.ldx + xch;
+            float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (p.in_scale != nullptr && p.N > 1 && ok && kcok) s4 = *reinterpret_cast<const float4*>(p.in_scale + (int64_t)n0 * p.Ck + k0 + lcol * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ax = ax0 + j, ix = ax * p.in_stride + dx;
+                const unsigned goff = (grow + (unsigned)ax * gcol) * 4u;
+                const unsigned xoff = (xrow + (unsigned)ix * (unsigned)p.ldx) * 4u;
+                auto gv = __builtin_amdgcn_raw_buffer_load_b128(grs, (ok && ocok) ? goff : OOB, 0, 0);
+                auto xv = __builtin_amdgcn_raw_buffer_load_b128(xrs, (yin && (unsigned)ix < (unsigned)p.Wi) ? xoff : OOB, 0, 0);
+                __builtin_memcpy(&R.rg[j], &gv, 16);
+                __builtin_memcpy(&R.rx[j], &xv, 16);
+                if (p.in_scale != nullptr && p.N > 1) { R.rx[j].x *= s4.x; R.rx[j].y *= s4.y; R.rx[j].z *= s4.z; R.rx[j].w *= s4.w; }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = step * BC + 4 * lq + j;
