@@ -170,20 +170,27 @@ __device__ __forceinline__ void gather_split(const float* __restrict__ pn, int H
         float fx0 = floorf(ix), fy0 = floorf(iy);
         int x0 = (int)fx0, y0 = (int)fy0;
         float wx1 = ix - fx0, wx0 = (fx0 + 1.f) - ix, wy1 = iy - fy0, wy0 = (fy0 + 1.f) - iy;
+        // Branch-free: a corner outside the plane reads the clamped texel with weight 0 (zeros padding).  With the loads under a per-corner
+        // branch every corner was its own basic block -- issue four loads, wait, multiply -- i.e. twelve exposed memory round trips per tile.
+        float4 tv[4][4];
+        float wq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            int xx = x0 + (q & 1), yy = y0 + (q >> 1);
-            if ((unsigned)xx < (unsigned)Wp && (unsigned)yy < (unsigned)Hp) {
-                const float* t = pn + ((int64_t)yy * Wp + xx) * ldp + pl * FC + 4 * h;
-                const float w = ((q & 1) ? wx1 : wx0) * ((q >> 1) ? wy1 : wy0);
+            const int xx = x0 + (q & 1), yy = y0 + (q >> 1);
+            const bool inb = (unsigned)xx < (unsigned)Wp && (unsigned)yy < (unsigned)Hp;
+            const int xc = min(max(xx, 0), Wp - 1), yc = min(max(yy, 0), Hp - 1);
+            const float* t = pn + (yc * Wp + xc) * ldp + pl * FC + 4 * h;
+            wq[q] = inb ? ((q & 1) ? wx1 : wx0) * ((q >> 1) ? wy1 : wy0) : 0.f;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 tv = *reinterpret_cast<const float4*>(t + 8 * g);
-                    f[4 * g + 0] = fmaf(w, tv.x, f[4 * g + 0]); f[4 * g + 1] = fmaf(w, tv.y, f[4 * g + 1]);
-                    f[4 * g + 2] = fmaf(w, tv.z, f[4 * g + 2]); f[4 * g + 3] = fmaf(w, tv.w, f[4 * g + 3]);
-                }
-            }
+            for (int g = 0; g < 4; ++g) tv[q][g] = *reinterpret_cast<const float4*>(t + 8 * g);
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f[4 * g + 0] = fmaf(wq[q], tv[q][g].x, f[4 * g + 0]); f[4 * g + 1] = fmaf(wq[q], tv[q][g].y, f[4 * g + 1]);
+                f[4 * g + 2] = fmaf(wq[q], tv[q][g].z, f[4 * g + 2]); f[4 * g + 3] = fmaf(wq[q], tv[q][g].w, f[4 * g + 3]);
+            }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) f[r] = f[r] * (1.f / 3.f);      // mean over the planes (a multiplication: the IEEE division sequence is ~10 instructions per value)
@@ -394,22 +401,29 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
                 int x0 = (int)fx0, y0 = (int)fy0;
                 float wx1 = ix - fx0, wx0 = (fx0 + 1.f) - ix, wy1 = iy - fy0, wy0 = (fy0 + 1.f) - iy;
                 float gix = 0.f, giy = 0.f;
+                float4 tv[4][4];                   // branch-free as in gather_split: clamped texel, zero contribution outside the plane
+                float mk[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    int xx = x0 + (q & 1), yy = y0 + (q >> 1);
-                    if ((unsigned)xx < (unsigned)a.Wp && (unsigned)yy < (unsigned)a.Hp) {
-                        const float* t = pn + ((int64_t)yy * a.Wp + xx) * a.ldp + pl * FC + 4 * h;
-                        float dot = 0.f;
+                    const int xx = x0 + (q & 1), yy = y0 + (q >> 1);
+                    mk[q] = ((unsigned)xx < (unsigned)a.Wp && (unsigned)yy < (unsigned)a.Hp) ? 1.f : 0.f;
+                    const int xc = min(max(xx, 0), a.Wp - 1), yc = min(max(yy, 0), a.Hp - 1);
+                    const float* t = pn + (yc * a.Wp + xc) * a.ldp + pl * FC + 4 * h;
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const float4 tv = *reinterpret_cast<const float4*>(t + 8 * g);
-                            dot = fmaf(tv.x, df[4 * g], dot); dot = fmaf(tv.y, df[4 * g + 1], dot);
-                            dot = fmaf(tv.z, df[4 * g + 2], dot); dot = fmaf(tv.w, df[4 * g + 3], dot);
-                        }
-                        const float sx = (q & 1) ? 1.f : -1.f, sy = (q >> 1) ? 1.f : -1.f;
-                        gix += dot * sx * ((q >> 1) ? wy1 : wy0);
-                        giy += dot * sy * ((q & 1) ? wx1 : wx0);
+                    for (int g = 0; g < 4; ++g) tv[q][g] = *reinterpret_cast<const float4*>(t + 8 * g);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float dot = 0.f;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        dot = fmaf(tv[q][g].x, df[4 * g], dot); dot = fmaf(tv[q][g].y, df[4 * g + 1], dot);
+                        dot = fmaf(tv[q][g].z, df[4 * g + 2], dot); dot = fmaf(tv[q][g].w, df[4 * g + 3], dot);
                     }
+                    dot *= mk[q];
+                    const float sx = (q & 1) ? 1.f : -1.f, sy = (q >> 1) ? 1.f : -1.f;
+                    gix += dot * sx * ((q >> 1) ? wy1 : wy0);
+                    giy += dot * sy * ((q & 1) ? wx1 : wx0);
                 }
                 const float gu = gix * (0.5f * a.Wp) * a.cs, gv = giy * (0.5f * a.Hp) * a.cs;
                 if (pl == 0) { gx += gu; gy += gv; } else if (pl == 1) { gx += gu; gz += gv; } else { gz += gu; gx += gv; }
@@ -422,7 +436,8 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
 
 int launch_decode(const DecodeArgs& a, bool bwd, hipStream_t st) {
     if (a.M <= 0) return EG3D_OK;
-    if (a.M > INT32_MAX || a.rows_per_image > INT32_MAX || a.samples_per_ray_row > INT32_MAX) return EG3D_ERR_UNSUPPORTED;      // 32-bit row arithmetic in the kernels
+    if (a.M > INT32_MAX || a.rows_per_image > INT32_MAX || a.samples_per_ray_row > INT32_MAX || (int64_t)a.Hp * a.Wp * a.ldp > INT32_MAX)
+        return EG3D_ERR_UNSUPPORTED;      // 32-bit row and texel-offset arithmetic in the kernels
     const int64_t ntiles = (a.M + 31) / 32;
     const int blocks = (int)std::min<int64_t>((ntiles + 3) / 4, 256 * (bwd ? DEC_GRID_BWD : DEC_GRID_FWD));     // persistent: resident blocks per CU x 256 CUs
     if (bwd) hipLaunchKernelGGL(decode_rows_kernel<true>, dim3(blocks), dim3(256), FRAG_BYTES_BWD, st, a);
