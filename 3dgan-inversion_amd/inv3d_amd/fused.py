@@ -545,10 +545,13 @@ class ToRGBFn(torch.autograd.Function):
         dev = x.device
         dy = dout
         dbias = None
+        dy_amax = None
         if clampv >= 0 or need_b:
             dbias_p = H.zeros((Cp,), dev) if need_b else None
             dy = H.empty_cl(N, Cp, Hh, Ww, dev)
-            H.epilogue_bwd(dout, y if y is not None else dout, dy, act='linear', gain=1.0, clamp=clampv, dbias=dbias_p)
+            if need_w and H.modconv_precision() == 'f16x3':
+                dy_amax = H.zeros((1,), dev)          # max|dy| from the same pass: the weight gradient can then run in the two-piece fp16 arithmetic
+            H.epilogue_bwd(dout, y if y is not None else dout, dy, act='linear', gain=1.0, clamp=clampv, dbias=dbias_p, dz_amax=dy_amax)
             dbias = dbias_p[:Co] if need_b else None
         dx = ds = None
         if need_x or need_s:
@@ -567,7 +570,12 @@ class ToRGBFn(torch.autograd.Function):
         dweight = None
         if need_w:
             dwp = H.zeros((Co, Ci), dev)
-            H.conv_wgrad(x, dy, Ci, Co, dwp, H.classes_corr(Hh, Ww, 1, 1, 0), in_scale=styles)
+            # a 1x1 conv with 3..96 outputs: on the fp32 matrix path the 128 x 128 tile costs 64 MFMAs of 64 cycles per 32 cells whatever the
+            # channel count; the split-fp16 kernel needs 24 of 32 (same fp32-equivalent arithmetic as the 3x3 layers)
+            if dy_amax is not None:
+                H.conv_wgrad(x, dy, Ci, Co, dwp, H.classes_corr(Hh, Ww, 1, 1, 0), in_scale=styles, precision='f16x3', g_amax=dy_amax)
+            else:
+                H.conv_wgrad(x, dy, Ci, Co, dwp, H.classes_corr(Hh, Ww, 1, 1, 0), in_scale=styles)
             dweight = dwp.view(Co, Ci, 1, 1)
         return (dx if need_x else None, dweight, ds if need_s else None, dbias, dout if (need_skip and has_skip) else None, None, None, None, None, None)
 
