@@ -436,7 +436,9 @@ extern "C" int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* pp, void* stream) 
         int64_t base = (int64_t)tiles_o * tiles_i * ntap_total;
         int64_t steps = (maxM + BC - 1) / BC;
         int64_t want = (2048 + base - 1) / base;
-        p.psplit = (int)std::max<int64_t>(1, std::min<int64_t>(want, std::max<int64_t>(1, steps / 16)));
+        // (1x1 layers -- a single tap, few tiles -- are memory-bound streams of x: shorter slices so that every CU gets a block)
+        p.psplit = (int)std::max<int64_t>(1, std::min<int64_t>(want, std::max<int64_t>(1, steps / (base >= 9 ? 16 : 8))));
+        if (base < 9) p.psplit = (int)std::min<int64_t>(p.psplit, std::max<int64_t>(1, 512 / base));
     }
     if (p.psplit <= 0) {      // auto: aim for >= ~2048 blocks (measured: 128ch@512^2 81 TF at 1026 blocks, 95 at 1152, flat beyond), at least 8 K-steps per block
         int64_t base = (int64_t)tiles_o * tiles_i * ntap_total;
