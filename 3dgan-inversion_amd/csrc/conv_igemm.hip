@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
     // ---- F16X3 operand range: bring the A operand to ~2^13..2^14 at its maximum with an exact power of two (p.a_amax: device scalar
     // holding max|A|, e.g. written by the producer of a gradient tensor); the accumulators are rescaled in the epilogue.
     float a_mul = 1.f, a_inv = 1.f;
-    if constexpr (PREC == 3) {
+    if constexpr (PREC == 3 || PREC == 5) {
         if (p.a_amax != nullptr) {
             const float am = *p.a_amax * p.a_amax_mul;
             if (am > 0.f && am < 3.0e38f) {
@@ -258,9 +258,9 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
             for (int j = 0; j < A_LD; ++j) {
                 float4 v = ra[j];
                 if (p.in_scale != nullptr) v = f4mul(v, sc[j]);
-                if constexpr (PREC == 3) { v.x *= a_mul; v.y *= a_mul; v.z *= a_mul; v.w *= a_mul; }
+                if constexpr (PREC == 3 || PREC == 5) { v.x *= a_mul; v.y *= a_mul; v.z *= a_mul; v.w *= a_mul; }
                 uint2 pc[NP];
-                if constexpr (PREC == 3) split4h(v, pc); else split4<NP>(v, pc);
+                if constexpr (PREC == 3 || PREC == 5) split4h(v, pc); else split4<NP>(v, pc);
                 if (BM >= RPP || lrow < BM) {
 #pragma unroll
                     for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(a + q * A_PIECE + (lrow + RPP * j) * 16) = pc[q];
@@ -269,7 +269,10 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
 #pragma unroll
             for (int j = 0; j < B_LD; ++j) {
                 uint2 pc[NP];
-                if constexpr (PREC == 3) split4h(rb[j], pc); else split4<NP>(rb[j], pc);
+                if constexpr (PREC == 5) {             // pre-split weights (eg3d_split_weight_pieces): the 16 bytes ARE the two pieces
+                    __builtin_memcpy(&pc[0], &rb[j].x, 8);
+                    __builtin_memcpy(&pc[1], &rb[j].z, 8);
+                } else if constexpr (PREC == 3) split4h(rb[j], pc); else split4<NP>(rb[j], pc);
                 if (BN >= RPP || lrow < BN) {
 #pragma unroll
                     for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(b + q * B_PIECE + (lrow + RPP * j) * 16) = pc[q];
@@ -343,7 +346,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {
-                            if constexpr (PREC == 3) {      // the same bits as two fp16 pieces: h*h + h*l + l*h
+                            if constexpr (PREC == 3 || PREC == 5) {      // the same bits as two fp16 pieces: h*h + h*l + l*h
                                 f16x8 ah, bh;
                                 __builtin_memcpy(&ah, &af[PA[t]][i], 16);
                                 __builtin_memcpy(&bh, &bf[PB[t]][j], 16);
@@ -361,7 +364,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
     auto weave = [&]() {
         if constexpr (PREC != 0) {
             constexpr int NMFMA = TM * TN * (PREC == 1 ? 6 : 3) * (KB / 16);
-            constexpr int NVALU = (A_LD + B_LD) * (PREC == 1 ? 22 : (PREC == 2 ? 12 : 14)) + A_LD * 4;
+            constexpr int NVALU = (A_LD + (PREC == 5 ? 0 : B_LD)) * (PREC == 1 ? 22 : (PREC == 2 ? 12 : 14)) + A_LD * 4;
             constexpr int PER = (NVALU + NMFMA - 1) / NMFMA;
             __builtin_amdgcn_sched_group_barrier(0x100, (TM + TN) * NP * (KB / 16), 0);      // fragment reads
 #pragma unroll
@@ -664,7 +667,7 @@ int launch_conv(const eg3d_conv_params& p, hipStream_t st) {
     switch (p.precision) {
         case 1: return launch_conv_p<BM, BN, WM, WN, 1>(p, st);
         case 2: return launch_conv_p<BM, BN, WM, WN, 2>(p, st);
-        case 3: return launch_conv_p<BM, BN, WM, WN, 3>(p, st);
+        case 3: return p.w_presplit ? launch_conv_p<BM, BN, WM, WN, 5>(p, st) : launch_conv_p<BM, BN, WM, WN, 3>(p, st);
         default: return launch_conv_p<BM, BN, WM, WN, 0>(p, st);
     }
 }
@@ -701,7 +704,25 @@ bool act_bwd_ok(const eg3d_conv_params& p) {
     }
 }
 
+// Every four consecutive floats of a packed weight matrix -> 16 bytes: their four high fp16 pieces, then the four low pieces -- the
+// loader's split4h applied once per weight instead of once per workgroup and K-step (the same bits: results are unchanged).
+__global__ void __launch_bounds__(256) split_weight_pieces_kernel(const float4* __restrict__ w, uint4* __restrict__ image, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    uint2 pc[2];
+    split4h(w[i], pc);
+    image[i] = make_uint4(pc[0].x, pc[0].y, pc[1].x, pc[1].y);
+}
+
 }  // namespace
+
+extern "C" int eg3d_split_weight_pieces(const float* w, void* image, int64_t n, void* stream) {
+    if (!w || !image || n < 4 || (n & 3) || (reinterpret_cast<uintptr_t>(w) & 15) || (reinterpret_cast<uintptr_t>(image) & 15)) return EG3D_ERR_INVALID;
+    hipLaunchKernelGGL(split_weight_pieces_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(w), reinterpret_cast<uint4*>(image), n / 4);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
 
 extern "C" int eg3d_conv2d_igemm_act_bwd_ok(const eg3d_conv_params* pp) {
     return (pp != nullptr && pp->epi == EG3D_EPI_BWD_ACT && pp->ncls >= 1 && pp->ncls <= 4 && pp->ksplit >= 1 && act_bwd_ok(*pp)) ? 1 : 0;
@@ -716,6 +737,7 @@ extern "C" int eg3d_conv2d_igemm_f32(const eg3d_conv_params* pp, void* stream) {
     if (p.ksplit > 1 && p.epi != EG3D_EPI_ATOMIC) return EG3D_ERR_INVALID;
     if (p.epi < EG3D_EPI_STORE || p.epi > EG3D_EPI_BWD_ACT) return EG3D_ERR_INVALID;
     if (p.precision < 0 || p.precision > EG3D_PREC_F16X1 || p.ds_replicas < 0) return EG3D_ERR_INVALID;
+    if (p.w_presplit && (p.precision != EG3D_PREC_F16X3 || (p.w_row & 3) || (p.Ck & 3))) return EG3D_ERR_INVALID;
     if (p.precision == EG3D_PREC_F16X1) return EG3D_ERR_UNSUPPORTED;      // single-product arithmetic exists in eg3d_conv2d_v2 and the weight gradient; a runtime
                                                                           // skip of the cross products in this kernel's woven main loop measured 4x SLOWER -- callers use F16X3 here
     if (p.epi == EG3D_EPI_FWD && p.noise && !p.noise_strength) return EG3D_ERR_INVALID;

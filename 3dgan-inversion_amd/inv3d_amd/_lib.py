@@ -50,7 +50,7 @@ class ConvParams(C.Structure):
                 ('in_scale', C.c_void_p), ('epi', C.c_int32), ('ksplit', C.c_int32),
                 ('out_scale', C.c_void_p), ('bias', C.c_void_p), ('noise', C.c_void_p), ('noise_nstride', C.c_int64),
                 ('noise_strength', C.c_void_p), ('act', C.c_int32), ('alpha', C.c_float), ('gain', C.c_float),
-                ('clamp', C.c_float), ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p), ('precision', C.c_int32), ('a_amax', C.c_void_p), ('a_amax_mul', C.c_float), ('ds_replicas', C.c_int32), ('out_amax', C.c_void_p), ('act_bwd', ActBwd)]
+                ('clamp', C.c_float), ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p), ('precision', C.c_int32), ('a_amax', C.c_void_p), ('a_amax_mul', C.c_float), ('ds_replicas', C.c_int32), ('out_amax', C.c_void_p), ('act_bwd', ActBwd), ('w_presplit', C.c_int32)]
 
 
 class ConvV2Params(C.Structure):
@@ -129,6 +129,7 @@ _SIGS = {
                                  C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p]),
     'eg3d_conv2d_igemm_f32': (C.c_int, [C.POINTER(ConvParams), C.c_void_p]),
+    'eg3d_split_weight_pieces': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'eg3d_conv2d_igemm_config': (C.c_int, [C.POINTER(ConvParams)]),
     'eg3d_conv2d_igemm_act_bwd_ok': (C.c_int, [C.POINTER(ConvParams)]),
     'eg3d_conv2d_wgrad_f32': (C.c_int, [C.POINTER(WgradParams), C.c_void_p]),

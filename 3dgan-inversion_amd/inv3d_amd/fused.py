@@ -70,6 +70,19 @@ class WeightCache:
             self._c['split'] = hit
         return hit
 
+    def get_pieces(self, w: torch.Tensor):
+        """(forward, adjoint) pre-split images of the packed weights for the loader-split conv kernel (hipops.split_weight_pieces): the
+        weight-side half of its split arithmetic done once per weight instead of once per workgroup and K-step.  None when a packed
+        matrix is not a multiple of four floats."""
+        wf, wa, _ = self.get(w)
+        hit = self._c.get('pieces')
+        if hit is None:
+            with torch.no_grad():
+                ok = wf.shape[1] % 4 == 0 and wa.shape[1] % 4 == 0
+                hit = (H.split_weight_pieces(wf), H.split_weight_pieces(wa)) if ok else (None, None)
+            self._c['pieces'] = hit
+        return hit
+
     def get_padded(self, w: torch.Tensor, cp: int, bias: Optional[torch.Tensor] = None):
         """(wf_p [cp, taps*Ci], wa_p [Ci, taps*cp], bias_p [cp] | None): the packed images with the output-channel dimension zero-padded to
         cp (toRGB 3 -> 4: the padded output channel is 0 + skip, the launch takes the 16-byte vector epilogue, and the data gradient
@@ -146,6 +159,7 @@ def _zeros_views(device, *shapes):
     return out
 
 
+USE_PIECES = os.environ.get('EG3D_WEIGHT_PIECES', '1') != '0'      # loader-split conv kernel reads pre-split weight images (WeightCache.get_pieces)
 RENDER_PIPELINE_NOGRAD = os.environ.get('EG3D_RENDER_PIPELINE_NOGRAD', '1') != '0'   # ... also for no-grad rendering (scratch rows)
 RENDER_PIPELINE = os.environ.get('EG3D_RENDER_PIPELINE', '1') != '0'     # forward renderer as positions -> MFMA decode -> importance -> decode -> composite
 KS_TARGET = int(os.environ.get('EG3D_KS_TARGET', '256'))       # blocks a split launch aims for (one per CU; 512 measured 0.7 % slower per step)
@@ -237,6 +251,8 @@ class ModConvLayerFn(torch.autograd.Function):
         aflops = 2.0 * N * Hi * Wi * (1 if up == 2 else 1) * kh * kw * Ci * Co     # MACs of the (transposed) conv
         prec = precision or H.modconv_precision()
         ig_prec = 'f16x3' if prec == 'f16x1' else prec      # the loader-split kernel has no single-product form: it keeps the three products
+        # pre-split weight image for the loader-split kernel; frozen weights only (a trained weight would need the pass every step: +34 launches for ~1 %)
+        wfp = cache.get_pieces(weight)[0] if (ig_prec == 'f16x3' and USE_PIECES and not weight.requires_grad) else None
         amax_out = H.zeros((1,), x.device)            # max|out|, reported by whichever kernel writes `out`: the next layer's operand range
         cls, Hz, Wz = (H.classes_corr(Ho, Wo, kh, kw, kh // 2), Ho, Wo) if up == 1 else H.classes_convT(Hi, Wi, kh, kw, up)
         ks = _auto_ksplit(cls, N, Co, Ci)
@@ -252,11 +268,11 @@ class ModConvLayerFn(torch.autograd.Function):
             if v2:
                 H.conv_v2(aimg, wimg, out, cls, epi=L.EPI_FWD, out_scale=d, out_amax=amax_out, algo_flops=aflops, products=nprod, **epi_kw)
             elif ks == 1:
-                H.conv_igemm(x, wf, Ci, Co, out, cls, in_scale=styles, epi=L.EPI_FWD, out_scale=d, algo_flops=aflops, precision=ig_prec, out_amax=amax_out,
+                H.conv_igemm(x, wf, Ci, Co, out, cls, in_scale=styles, epi=L.EPI_FWD, out_scale=d, algo_flops=aflops, precision=ig_prec, out_amax=amax_out, w_pieces=wfp,
                              **epi_kw)
             else:
                 z = H.zeros_cl(N, Co, Ho, Wo, x.device)
-                H.conv_igemm(x, wf, Ci, Co, z, cls, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=ig_prec)
+                H.conv_igemm(x, wf, Ci, Co, z, cls, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=ig_prec, w_pieces=wfp)
                 H.epilogue_fwd(z, out, d=d, out_amax=amax_out, **epi_kw)
         else:
             if v2:
@@ -264,10 +280,10 @@ class ModConvLayerFn(torch.autograd.Function):
                 H.conv_v2(aimg, wimg, z, cls, out_stride=up, epi=L.EPI_STORE, algo_flops=aflops)
             elif ks == 1:
                 z = H.empty_cl(N, Co, Hz, Wz, x.device)
-                H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_STORE, algo_flops=aflops, precision=ig_prec)
+                H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_STORE, algo_flops=aflops, precision=ig_prec, w_pieces=wfp)
             else:
                 z = H.zeros_cl(N, Co, Hz, Wz, x.device)
-                H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=ig_prec)
+                H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=ig_prec, w_pieces=wfp)
             H.epilogue_fwd(z, out, fir=fir44(x.device), pad0=1, fir_gain=float(up * up), d=d, out_amax=amax_out, **epi_kw)
         H.tag_amax(out, amax_out)
         rec = None
@@ -321,6 +337,7 @@ class ModConvLayerFn(torch.autograd.Function):
         # all small atomically-accumulated outputs of this backward from one zero fill
         prec = ctx.prec
         ig_prec = 'f16x3' if prec == 'f16x1' else prec
+        wap = cache.get_pieces(weight)[1] if (ig_prec == 'f16x3' and USE_PIECES and not weight.requires_grad) else None
         if pre is not None:
             _, dbias, dd, dnoise, dstrength, amax = pre
             ds = None if ks_adj is None else H.zeros((N, Ci), dev)
@@ -356,13 +373,13 @@ class ModConvLayerFn(torch.autograd.Function):
                 did = H.conv_v2(H.split_activation(g, amax), cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds,
                                 algo_flops=aflops, products=1 if prec == 'f16x1' else 3, **fkw)
             elif ks == 1:
-                did = H.conv_igemm(g, wa, Co, Ci, dx, cls_adj, in_stride=in_stride, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, algo_flops=aflops,
+                did = H.conv_igemm(g, wa, Co, Ci, dx, cls_adj, in_stride=in_stride, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, algo_flops=aflops, w_pieces=wap,
                                    precision=ig_prec, a_amax=amax, a_amax_mul=amul, **fkw)
                 if rep > 1:
                     ds = ds.sum(0)
             else:                                  # low resolution: split K over blocks, then scale / reduce in a finishing pass
                 z = H.zeros_cl(N, Ci, Hi, Wi, dev)
-                H.conv_igemm(g, wa, Co, Ci, z, cls_adj, in_stride=in_stride, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=ig_prec, a_amax=amax,
+                H.conv_igemm(g, wa, Co, Ci, z, cls_adj, in_stride=in_stride, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=ig_prec, a_amax=amax, w_pieces=wap,
                              a_amax_mul=amul)
                 did = prod is not None and Ci % 4 == 0 and Ci <= 1024
                 if did:

@@ -363,7 +363,7 @@ class ActBwdSpec:
 def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=None, epi=L.EPI_STORE, ksplit=1,
                out_scale=None, bias=None, noise=None, noise_nstride=0, noise_strength=None, act='linear', alpha=0.0, gain=1.0,
                clamp=-1.0, addend=None, xin=None, ds=None, algo_flops=None, precision=None, a_amax=None, a_amax_mul=1.0, out_amax=None,
-               act_bwd=None):
+               act_bwd=None, w_pieces=None):
     """Launch eg3d_conv2d_igemm_f32.  x/out/addend/xin: channels_last fp32 [N,C,H,W]; wp: packed weights [Nc, taps*Ck].
     act_bwd (an ActBwdSpec, with epi=EPI_BWD): try EPI_BWD_ACT; returns True when the fused epilogue ran (out then holds the producing
     layer's dz), False when the launch was a plain EPI_BWD."""
@@ -395,6 +395,9 @@ def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=
     p.a_amax_mul = float(a_amax_mul)
     p.ds_replicas = ds.shape[0] if (ds is not None and ds.dim() == 3) else 1
     p.out_amax = out_amax.data_ptr() if out_amax is not None else None
+    if w_pieces is not None and p.precision == PRECISIONS['f16x3']:      # the packed weights' pre-split image (split_weight_pieces): same indexing
+        assert w_pieces.shape == wp.shape and w_pieces.stride() == wp.stride()
+        p.w, p.w_presplit = w_pieces.data_ptr(), 1
     fused_act = False
     if act_bwd is not None and epi == L.EPI_BWD:
         p.epi = L.EPI_BWD_ACT
@@ -684,6 +687,16 @@ def pack_conv_weight_padded(w, wf_p, wa_p, o_pad):
     assert tuple(wf_p.shape) == (o_pad, kh * kw * i) and tuple(wa_p.shape) == (i, kh * kw * o_pad) and wf_p.is_contiguous() and wa_p.is_contiguous()
     L.check(L.lib().eg3d_pack_conv_weight_padded(w.data_ptr(), wf_p.data_ptr(), wa_p.data_ptr(), None, o, i, kh * kw, o_pad, L.stream_ptr()),
             'pack_conv_weight_padded')
+
+
+def split_weight_pieces(wp):
+    """The two-piece fp16 image of a packed weight matrix for conv_igemm(..., w_pieces=): element group [4j..4j+3] -> 4 high + 4 low fp16
+    pieces in the same 16 bytes (eg3d_split_weight_pieces).  Returned as a float32-typed tensor of wp's shape (it holds fp16 bit patterns)."""
+    L.require_cuda(wp)
+    assert wp.is_contiguous() and wp.dtype == torch.float32 and wp.numel() % 4 == 0
+    img = torch.empty_like(wp)
+    L.check(L.lib().eg3d_split_weight_pieces(wp.data_ptr(), img.data_ptr(), wp.numel(), L.stream_ptr()), 'split_weight_pieces')
+    return img
 
 
 def pack_conv_weights_batched(items):

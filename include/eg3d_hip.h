@@ -164,6 +164,10 @@ typedef struct eg3d_conv_params {
     float* out_amax;           /* optional, pre-zeroed device scalar: receives max|out| (atomic max; EPI_STORE / FWD / BWD) -- the operand
                                 * range a consumer needs to range-normalise its two-piece fp16 split */
     eg3d_act_bwd act_bwd;      /* EG3D_EPI_BWD_ACT only (xin required; vector epilogue only: eg3d_conv2d_igemm_act_bwd_ok) */
+    int32_t w_presplit;        /* F16X3 only: w is the image written by eg3d_split_weight_pieces (same indexing as the fp32 matrix; w_row and
+                                * Ck multiples of 4): the loader copies the two fp16 pieces instead of forming them -- the weight-side half of
+                                * the split arithmetic, which this kernel is bound by, is then done once per weight instead of once per
+                                * workgroup and K-step.  Same bits, same results. */
 } eg3d_conv_params;
 
 /* 1 when this launch can run EG3D_EPI_BWD_ACT (aligned rows, channel counts that are multiples of 4, no split-K, tiles within one
@@ -171,6 +175,9 @@ typedef struct eg3d_conv_params {
 int eg3d_conv2d_igemm_act_bwd_ok(const eg3d_conv_params* p);
 
 int eg3d_conv2d_igemm_f32(const eg3d_conv_params* p, void* stream);
+/* image[4j .. 4j+3] (16 bytes) = the four high fp16 pieces of w[4j .. 4j+3] followed by their four low pieces (h = rtz16(w),
+ * l = rne16(w - h)): the operand image eg3d_conv_params::w_presplit expects.  n floats, n % 4 == 0, both pointers 16-byte aligned. */
+int eg3d_split_weight_pieces(const float* w, void* image, int64_t n, void* stream);
 /* Which tile configuration eg3d_conv2d_igemm_f32 will launch for p: 0 = 128x128x32 (the dominant kernel), 1 = 64x128,
  * 2 = 32x128, 3 = 128x32.  Pure host function (used by bench.py to attribute launch times to kernels). */
 int eg3d_conv2d_igemm_config(const eg3d_conv_params* p);

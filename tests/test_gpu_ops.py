@@ -903,3 +903,29 @@ def test_batched_weight_pack_equals_per_layer_pack():
     ref = dwp.view(o, kh, kw, i).permute(0, 3, 1, 2) + 2 * w * dwsq[:, :, None, None]
     close(got, ref, 1e-5, 'weight_grad_finish')
     close(H.weight_grad_finish(dwp, w, None, None, None), dwp.view(o, kh, kw, i).permute(0, 3, 1, 2), 1e-7, 'weight_grad_finish (no demodulation)')
+
+
+def test_conv_igemm_presplit_weights_bit_identical():
+    """eg3d_conv_params::w_presplit: the loader copies the weight pieces written by eg3d_split_weight_pieces instead of forming them --
+    the same bits, so the result must be IDENTICAL to the in-loader split (forward and a strided data-gradient geometry)."""
+    from inv3d_amd import hipops as H, _lib as L
+    g = torch.Generator().manual_seed(11)
+    for (ci, co, h, up) in ((32, 64, 24, 1), (16, 128, 16, 2)):
+        x = torch.randn(2, ci, h, h, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+        w = torch.randn(co, ci, 3, 3, generator=g).to(DEV)
+        wf, wa, _ = H.pack_conv_weight(w)
+        cls = H.classes_corr(h, h, 3, 3, 1) if up == 1 else H.classes_convT(h, h, 3, 3, up)[0]
+        ho = h if up == 1 else cls_out_size(h, up)
+        outs = []
+        for pieces in (None, H.split_weight_pieces(wf)):
+            out = H.zeros_cl(2, co, ho, ho, DEV)
+            H.conv_igemm(x, wf, ci, co, out, cls, out_stride=up, epi=L.EPI_STORE, precision='f16x3', w_pieces=pieces)
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1])
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1) if up == 1 else None
+        if ref is not None:
+            close(outs[1], ref, 2e-6 * math.sqrt(ci * 9), 'conv_igemm with pre-split weights')
+
+
+def cls_out_size(h, up):
+    return h * up + 1
