@@ -271,13 +271,28 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const Fin
     if (FIN && active) st4(rz + (pl * C4 + c4) * 4, accz);
     __syncthreads();
     if (dstrength && accs != 0.f) atomicAdd(rs, accs);
-    if (threadIdx.x < C4) {
-        float4 sb = make_float4(0, 0, 0, 0), sd = make_float4(0, 0, 0, 0);
-        for (int q = 0; q < ppb; ++q) {
-            float4 t = ld4(rb + (q * C4 + c4) * 4), u = ld4(rd + (q * C4 + c4) * 4);
-            sb.x += t.x; sb.y += t.y; sb.z += t.z; sb.w += t.w;
-            sd.x += u.x; sd.y += u.y; sd.z += u.z; sd.w += u.w;
+    // pixel lanes -> one sum per channel: a tree over the pixel index (with 4 channels there are 1024 pixel lanes per block: summed by one
+    // thread this tail took longer than the pass itself), skipped when no per-channel sum is asked for (a clamp-only pass)
+    const bool want_cs = dbias != nullptr || dd != nullptr || (FIN && fin.ds != nullptr);
+    if (want_cs) {
+        for (int st = 1; st < ppb; st <<= 1) {
+            if (active && (pl & (2 * st - 1)) == 0 && pl + st < ppb) {
+                float* a0 = rb + (pl * C4 + c4) * 4;
+                float* a1 = rd + (pl * C4 + c4) * 4;
+                const float4 t = ld4(a0 + st * C4 * 4), u = ld4(a1 + st * C4 * 4), t0 = ld4(a0), u0 = ld4(a1);
+                st4(a0, make_float4(t0.x + t.x, t0.y + t.y, t0.z + t.z, t0.w + t.w));
+                st4(a1, make_float4(u0.x + u.x, u0.y + u.y, u0.z + u.z, u0.w + u.w));
+                if (FIN) {
+                    float* a2 = rz + (pl * C4 + c4) * 4;
+                    const float4 v = ld4(a2 + st * C4 * 4), v0 = ld4(a2);
+                    st4(a2, make_float4(v0.x + v.x, v0.y + v.y, v0.z + v.z, v0.w + v.w));
+                }
+            }
+            __syncthreads();
         }
+    }
+    if (want_cs && threadIdx.x < C4) {
+        const float4 sb = ld4(rb + c4 * 4), sd = ld4(rd + c4 * 4);
         if (dbias) {
             unsafeAtomicAdd(dbias + c + 0, sb.x); unsafeAtomicAdd(dbias + c + 1, sb.y);
             unsafeAtomicAdd(dbias + c + 2, sb.z); unsafeAtomicAdd(dbias + c + 3, sb.w);
@@ -288,8 +303,7 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const Fin
             unsafeAtomicAdd(q + 2, sd.z / dv.z); unsafeAtomicAdd(q + 3, sd.w / dv.w);
         }
         if (FIN && fin.ds) {
-            float4 sz = make_float4(0, 0, 0, 0);
-            for (int q = 0; q < ppb; ++q) { float4 t = ld4(rz + (q * C4 + c4) * 4); sz.x += t.x; sz.y += t.y; sz.z += t.z; sz.w += t.w; }
+            const float4 sz = ld4(rz + c4 * 4);
             float* q = fin.ds + (int64_t)n * C + c;
             unsafeAtomicAdd(q + 0, sz.x); unsafeAtomicAdd(q + 1, sz.y); unsafeAtomicAdd(q + 2, sz.z); unsafeAtomicAdd(q + 3, sz.w);
         }
