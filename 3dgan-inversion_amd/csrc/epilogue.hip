@@ -178,7 +178,10 @@ __device__ __forceinline__ void bwd1(float dout, float o, int act, float alpha, 
 constexpr int EPI_BWD_THREADS = 1024;
 // FIN: the incoming gradient is not read but formed on the fly as the finish of a split-K data gradient of the CONSUMER layer,
 // dout = fz * fs[n,c] (+ fadd), and that layer's style gradient fds[n,c] += sum_px fz * out rides along (eg3d_dgrad_finish_act).
-struct FinArgs { const float* z; const float* s; const float* addend; float* ds; };
+struct FinArgs { const float* z; const float* s; const float* addend; float* ds; const float* dy4; const float* wa4; };
+// (dy4 / wa4, with z null: the consumer is a 1x1 layer with four (padded) outputs -- toRGB of the super-resolution head -- whose data gradient
+//  z[c] = sum_o dy[px][o] wa[c][o] is four multiply-adds per element: formed here instead of by a GEMM launch with a 4-deep contraction,
+//  eg3d_torgb_dgrad_act)
 template <bool PWL, bool FIN>
 __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const FinArgs fin, const float* __restrict__ dout, const float* __restrict__ outv, float* __restrict__ dz,
                                                            int H, int W, int C4, const float* __restrict__ d, const float* __restrict__ noise,
@@ -200,6 +203,8 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const Fin
     if (active && bias) bv = ld4(bias + c);
     float4 accb = make_float4(0, 0, 0, 0), accd = make_float4(0, 0, 0, 0), accz = make_float4(0, 0, 0, 0), fsv = make_float4(1, 1, 1, 1);
     if (FIN && active && fin.s) fsv = ld4(fin.s + (int64_t)n * C + c);
+    float4 w40 = make_float4(0, 0, 0, 0), w41 = w40, w42 = w40, w43 = w40;
+    if (FIN && active && fin.dy4) { w40 = ld4(fin.wa4 + (c + 0) * 4); w41 = ld4(fin.wa4 + (c + 1) * 4); w42 = ld4(fin.wa4 + (c + 2) * 4); w43 = ld4(fin.wa4 + (c + 3) * 4); }
     float accs = 0.f, amax = 0.f;
     // lanes of one pixel are contiguous; groups of min(C4,64) lanes can be shuffle-reduced when C4 is a power of two
     const bool pow2 = (C4 & (C4 - 1)) == 0;
@@ -220,7 +225,15 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const Fin
                 const int64_t off = ((int64_t)n * HW + (ok ? pix : pix0)) * C + c;
                 o[u] = ld4(outv + off);
                 if (FIN) {
-                    const float4 zz = ld4(fin.z + off), av = fin.addend ? ld4(fin.addend + off) : make_float4(0, 0, 0, 0);
+                    float4 zz;
+                    if (fin.dy4) {
+                        const float4 g4 = ld4(fin.dy4 + ((int64_t)n * HW + (ok ? pix : pix0)) * 4);
+                        zz.x = fmaf(g4.w, w40.w, fmaf(g4.z, w40.z, fmaf(g4.y, w40.y, g4.x * w40.x)));
+                        zz.y = fmaf(g4.w, w41.w, fmaf(g4.z, w41.z, fmaf(g4.y, w41.y, g4.x * w41.x)));
+                        zz.z = fmaf(g4.w, w42.w, fmaf(g4.z, w42.z, fmaf(g4.y, w42.y, g4.x * w42.x)));
+                        zz.w = fmaf(g4.w, w43.w, fmaf(g4.z, w43.z, fmaf(g4.y, w43.y, g4.x * w43.x)));
+                    } else zz = ld4(fin.z + off);
+                    const float4 av = fin.addend ? ld4(fin.addend + off) : make_float4(0, 0, 0, 0);
                     if (ok && fin.ds) { accz.x += zz.x * o[u].x; accz.y += zz.y * o[u].y; accz.z += zz.z * o[u].z; accz.w += zz.w * o[u].w; }
                     g[u] = make_float4(zz.x * fsv.x + av.x, zz.y * fsv.y + av.y, zz.z * fsv.z + av.z, zz.w * fsv.w + av.w);
                 } else {
@@ -586,7 +599,7 @@ extern "C" int eg3d_modconv_epilogue_bwd(const float* dout, const float* out, fl
     const int cap = 256;
     int bx = std::max(1, std::min(eg3d_cdiv((int64_t)H * W, ppb * 4), std::max(1, cap / N)));
     size_t smem = (size_t)(ppb * C4 * 8 + 4) * sizeof(float);
-    const FinArgs nofin = {nullptr, nullptr, nullptr, nullptr};
+    const FinArgs nofin = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (eg3d_act_is_pwl(act))
         hipLaunchKernelGGL((epilogue_bwd_kernel<true, false>), dim3(bx, N), dim3(EPI_BWD_THREADS), smem, (hipStream_t)stream, nofin, dout, out, dz, H, W, C4, d, noise, noise_nstride,
                            noise_strength, bias, act, eg3d_act_pwl_slope(act, alpha), gain, clamp, dbias, dd, dnoise, dnoise_nstride, dstrength, dz_amax);
@@ -609,7 +622,27 @@ extern "C" int eg3d_dgrad_finish_act(const float* z, const float* x, const float
     static std::atomic<uint64_t> attr_done{0};
     auto kern = epilogue_bwd_kernel<true, true>;
     if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)smem, attr_done)) return e;
-    const FinArgs fin = {z, s, addend, ds};
+    const FinArgs fin = {z, s, addend, ds, nullptr, nullptr};
+    hipLaunchKernelGGL(kern, dim3(bx, N), dim3(EPI_BWD_THREADS), smem, (hipStream_t)stream, fin, nullptr, x, dz, H, W, C4, ab->d, ab->noise, ab->noise_nstride,
+                       ab->noise_strength, ab->bias, ab->act, eg3d_act_pwl_slope(ab->act, ab->alpha), ab->gain, ab->clamp, ab->dbias, ab->dd, ab->dnoise,
+                       ab->dnoise_nstride, ab->dstrength, dz_amax);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_torgb_dgrad_act(const float* dy4, const float* wa4, const float* x, const float* s, const float* addend, float* dz, float* ds, int N, int H,
+                                    int W, int C, const eg3d_act_bwd* ab, float* dz_amax, void* stream) {
+    if (!dy4 || !wa4 || !x || !dz || !ab || N <= 0 || H <= 0 || W <= 0 || C <= 0) return EG3D_ERR_INVALID;
+    if (C % 4 || C / 4 > 256 || (reinterpret_cast<uintptr_t>(dy4) & 15) || (reinterpret_cast<uintptr_t>(wa4) & 15)) return EG3D_ERR_UNSUPPORTED;
+    if (ab->act != EG3D_ACT_LINEAR && ab->act != EG3D_ACT_LRELU) return EG3D_ERR_UNSUPPORTED;
+    if ((ab->dd && !ab->d) || ((ab->noise || ab->dnoise || ab->dstrength) && !ab->noise_strength) || ((ab->dnoise || ab->dstrength) && !ab->noise)) return EG3D_ERR_INVALID;
+    const int C4 = C / 4, ppb = std::max(EPI_BWD_THREADS / C4, 1);
+    int bx = std::max(1, std::min(eg3d_cdiv((int64_t)H * W, ppb * 4), std::max(1, 256 / N)));
+    const size_t smem = (size_t)(ppb * C4 * 12 + 4) * sizeof(float);
+    static std::atomic<uint64_t> attr_done{0};
+    auto kern = epilogue_bwd_kernel<true, true>;
+    if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)smem, attr_done)) return e;
+    const FinArgs fin = {nullptr, s, addend, ds, dy4, wa4};
     hipLaunchKernelGGL(kern, dim3(bx, N), dim3(EPI_BWD_THREADS), smem, (hipStream_t)stream, fin, nullptr, x, dz, H, W, C4, ab->d, ab->noise, ab->noise_nstride,
                        ab->noise_strength, ab->bias, ab->act, eg3d_act_pwl_slope(ab->act, ab->alpha), ab->gain, ab->clamp, ab->dbias, ab->dd, ab->dnoise,
                        ab->dnoise_nstride, ab->dstrength, dz_amax);

@@ -626,6 +626,18 @@ def dgrad_finish_act(z, x, s, dz, act_bwd, ds=None, addend=None, dz_amax=None):
     return dz
 
 
+def torgb_dgrad_act(dy4, wa4, x, s, dz, act_bwd, ds=None, addend=None, dz_amax=None):
+    """eg3d_torgb_dgrad_act: data gradient of a 1x1 layer with four (padded) outputs + the activation backward of the layer that produced x,
+    one element-wise pass.  dy4 [N,4,H,W] channels_last, wa4 [C,4] contiguous; dz receives the producing layer's dz."""
+    n, c, h, w = x.shape
+    assert is_cl(dy4) and dy4.shape[1] == 4 and tuple(wa4.shape) == (c, 4) and wa4.is_contiguous()
+    ab = L.ActBwd()
+    act_bwd.fill(ab)
+    L.check(L.lib().eg3d_torgb_dgrad_act(L.ptr(dy4), L.ptr(wa4), L.ptr(x), L.ptr(s), L.ptr(addend), L.ptr(dz), L.ptr(ds), n, h, w, c, C.byref(ab), L.ptr(dz_amax),
+                                         L.stream_ptr()), 'torgb_dgrad_act')
+    return dz
+
+
 def rows_gram(a, b):
     """(a^T b [Ka,Kb], column sums of a [Ka]) for row matrices a [S,Ka], b [S,Kb] with Ka, Kb <= 64 (eg3d_rows_gram)."""
     assert a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0] and a.is_contiguous() and b.is_contiguous()

@@ -350,6 +350,12 @@ int eg3d_dgrad_finish(const float* z, const float* x, const float* s, const floa
  * eg3d_modconv_epilogue_bwd (targets in `ab`, pre-zeroed), dz_amax optional. */
 int eg3d_dgrad_finish_act(const float* z, const float* x, const float* s, const float* addend, float* dz, float* ds, int N, int H,
                           int W, int C, const eg3d_act_bwd* ab, float* dz_amax, void* stream);
+/* Data gradient of a 1x1 layer with FOUR (padded) outputs -- toRGB of the super-resolution head, networks_stylegan2.py:338-359 -- fused
+ * with the activation backward of the layer that produced x, as one element-wise pass (eg3d_conv2d_igemm_f32 with EG3D_EPI_BWD_ACT does the
+ * same through a GEMM with a 4-deep contraction):  z[px,c] = sum_o dy4[px,o] * wa4[c,o];  dout = z * s[n,c] (+ addend);  ds[n,c] += sum_px z * x;
+ * then dz / dbias / dd / dnoise / dstrength / max|dz| exactly as eg3d_dgrad_finish_act.  dy4 [N,H,W,4], wa4 [C,4], x / addend / dz [N,H,W,C]. */
+int eg3d_torgb_dgrad_act(const float* dy4, const float* wa4, const float* x, const float* s, const float* addend, float* dz, float* ds, int N, int H,
+                         int W, int C, const eg3d_act_bwd* act_bwd, float* dz_amax, void* stream);
 
 /* NHWC FIR resampler used on the fused path (skip-image 2x upsample and its adjoint, FIR adjoint of up=2 layers):
  *   same arithmetic as eg3d_upfirdn2d on a channels-last fp32 tensor, float4 over channels (C % 4 == 0),

@@ -720,7 +720,7 @@ def test_absmax_any_length(n):
         assert float(H.absmax(x.to(DEV))) == 9.25
 
 
-@pytest.mark.parametrize('kind', ['v2_3x3', 'igemm_3x3', 'igemm_1x1', 'igemm_clamp_shared_noise'])
+@pytest.mark.parametrize('kind', ['v2_3x3', 'igemm_3x3', 'igemm_1x1', 'igemm_clamp_shared_noise', 'torgb4_elementwise'])
 def test_fused_activation_backward_equals_separate_pass(kind):
     """EG3D_EPI_BWD_ACT: a data-gradient launch that also runs the activation backward of the layer that produced its `xin`
     (dz, dbias, dd, dnoise, dstrength, max|dz|) against the two-pass form it replaces (EPI_BWD, then eg3d_modconv_epilogue_bwd on
@@ -734,8 +734,9 @@ def test_fused_activation_backward_equals_separate_pass(kind):
         err, scale = float((a - b).abs().max()), float(b.abs().max())
         assert err <= tol * scale, f'{what}: err {err:.3e} > {tol} * {scale:.3e}'
 
-    n, ci, h, w, co = (2, 128, 24, 64, 128) if kind != 'igemm_1x1' else (2, 128, 32, 32, 4)
-    k = 1 if kind == 'igemm_1x1' else 3
+    one = kind in ('igemm_1x1', 'torgb4_elementwise')
+    n, ci, h, w, co = (2, 128, 24, 64, 128) if not one else (2, 128, 32, 32, 4)
+    k = 1 if one else 3
     g = torch.Generator().manual_seed(31)
     gz = torch.randn(n, co, h, w, generator=g) * 1e-3
     wt = torch.randn(co, ci, k, k, generator=g) / math.sqrt(ci * k * k)
@@ -763,6 +764,9 @@ def test_fused_activation_backward_equals_separate_pass(kind):
             r = H.conv_v2(aimg, wimg, dx, cls, **kw)
         else:
             wa = wt.permute(1, 2, 3, 0).reshape(ci, k * k * co).to(DEV).contiguous()          # adjoint pack [I][tap][O]
+            if kind == 'torgb4_elementwise' and spec is not None:          # the element-wise form of the same launch (eg3d_torgb_dgrad_act)
+                H.torgb_dgrad_act(dev(gz), wa, xin_d, s_d, dx, spec, ds=ds, addend=add_d, dz_amax=out_amax)
+                return dx, ds, True
             r = H.conv_igemm(dev(gz), wa, co, ci, dx, cls, precision='bf16x6', **kw)
         return dx, ds, r
 
