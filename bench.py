@@ -247,10 +247,9 @@ def main():
                                feature_net=feature_net)
         res = coach.invert('bench', target[:1], cam[:1])
         torch.cuda.synchronize()
-        if use_graph and coach.last_launch_modes != dict(phase_a='graph', phase_b='graph'):          # the wall time below must not pass for graph replay if a capture was refused
-            raise RuntimeError(f'HIP graph capture failed in the full-inversion run: {coach.last_launch_modes}')
+        modes = coach.last_launch_modes                 # how the two phases were actually issued: stated in the note (a refused capture falls back to eager launches)
         final = dict(final_psnr_db=round(res.psnr_tuned, 3), pivot_psnr_db=round(res.psnr_pivot, 3), steps=res.steps_a + res.steps_b,
-                     wall_s=round(time.perf_counter() - t1, 2), note='400 latent steps (fp32-equivalent) + 400 pivotal-tuning steps (SR head in the reference\'s fp16-operand arithmetic, as BaseCoach.forward), %s, stub feature pyramid, synthetic target' % ('both phases replayed from HIP graphs (the early-stop reads every 50 steps run eagerly)' if use_graph else 'eager launches'))
+                     wall_s=round(time.perf_counter() - t1, 2), note='400 latent steps (fp32-equivalent) + 400 pivotal-tuning steps (SR head in the reference\'s fp16-operand arithmetic, as BaseCoach.forward), %s, stub feature pyramid, synthetic target' % ('both phases replayed from HIP graphs (the early-stop reads every 50 steps run eagerly)' if modes == dict(phase_a='graph', phase_b='graph') else 'launch modes: %s' % modes))
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         wl = ('C2: FFHQ 512^2 single-image latent inversion step' if M == 1 else
