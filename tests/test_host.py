@@ -218,3 +218,39 @@ except ImportError as e:
 """
     r = subprocess.run([sys.executable, '-c', bad], capture_output=True, text=True, timeout=300)
     assert 'REFUSED' in r.stdout, r.stdout + r.stderr[-3000:]
+
+
+def test_round2_entry_points_reject_bad_arguments_before_touching_the_gpu():
+    """Argument validation of the entry points added in round 2 returns EG3D_ERR_INVALID / _UNSUPPORTED (negative status, never a launch):
+    null pointers, sizes that are not multiples of four floats, misaligned pointers, more layers than a pack batch holds."""
+    import ctypes as C
+    from inv3d_amd import _lib as L
+    lib = L.lib()
+    a = 0x10000                                            # a non-null, 16-byte aligned fake address (never dereferenced: validation fails first)
+    assert lib.eg3d_sqdist_sum_fwd(None, a, 64, a, 1.0, a, 1.0, None) < 0
+    assert lib.eg3d_sqdist_sum_fwd(a, a, 62, a, 1.0, a, 1.0, None) < 0               # n % 4
+    assert lib.eg3d_sqdist_sum_fwd(a, a + 4, 64, a, 1.0, a, 1.0, None) < 0           # misaligned
+    assert lib.eg3d_sqdist_sum_fwd(a, a, 64, None, 1.0, None, 1.0, None) < 0         # nowhere to write
+    assert lib.eg3d_sqdist_sum_bwd(a, a, None, 1.0, a, 64, None) < 0
+    assert lib.eg3d_tv_norm_fwd(a, 1, 1, 8, a, 1.0, a, 1.0, None) < 0                # H < 2
+    assert lib.eg3d_tv_norm_bwd(a, a, 1.0, None, 1, 8, 8, None) < 0
+    assert lib.eg3d_slice_rgb4_fwd(a, a, 16, 30, None) < 0                           # C % 4
+    assert lib.eg3d_slice_rgb4_bwd(None, a, 16, 32, None) < 0
+    assert lib.eg3d_split_weight_pieces(a, a, 6, None) < 0
+    assert lib.eg3d_split_weight_pieces(a, a + 8, 16, None) < 0
+    assert lib.eg3d_weight_grad_finish(None, a, a, a, a, a, 1, 8, 8, 9, None) < 0
+    assert lib.eg3d_weight_grad_finish(a, a, None, None, a, a, 1, 8, 8, 9, None) < 0  # dd without styles / d
+    items = (L.PackItem * 1)()
+    assert lib.eg3d_pack_conv_weights_batched(items, 0, None) < 0
+    assert lib.eg3d_pack_conv_weights_batched(items, L.PACK_BATCH_MAX + 1, None) < 0
+    assert lib.eg3d_pack_conv_weights_batched(items, 1, None) < 0                     # null weight pointer in the item
+    assert lib.eg3d_pack_conv_weight_padded(a, a, a, None, 8, 8, 9, 4, None) < 0      # O_pad < O
+    ab = L.ActBwd()
+    assert lib.eg3d_torgb_dgrad_act(None, a, a, a, None, a, None, 1, 8, 8, 16, C.byref(ab), None, None) < 0
+    assert lib.eg3d_torgb_dgrad_act(a, a, a, a, None, a, None, 1, 8, 8, 18, C.byref(ab), None, None) < 0   # C % 4
+    p = L.ConvParams()
+    p.x = p.w = p.out = a
+    p.N, p.Hi, p.Wi, p.Ck, p.ldx, p.Nc, p.w_row, p.Ho, p.Wo, p.ldo = 1, 8, 8, 16, 16, 16, 16, 8, 8, 16
+    p.in_stride = p.out_stride = p.ncls = p.ksplit = 1
+    p.epi, p.precision, p.w_presplit = L.EPI_STORE, 1, 1                             # pre-split weights only exist for the fp16 split
+    assert lib.eg3d_conv2d_igemm_f32(C.byref(p), None) < 0
