@@ -316,22 +316,24 @@ class LatentProjector:
                 for nm, b in bufs.items():
                     shape = tuple(b.shape) if N == 1 else (N, 1) + tuple(b.shape)
                     src = init_noise[prefix + nm].to(dev) if init_noise is not None else torch.randn(shape, device=dev, generator=self.gen)
-                    # only the backbone's maps become leaves (w_projector.py:126-128); the SR head's are re-drawn (:129-131) but never
-                    # receive a gradient: they enter the regulariser's value and are renormalised, nothing else
+                    # the backbone's AND the SR head's maps are re-drawn, become leaves and sit in the latent optimiser
+                    # (w_projector.py:120,126-131).  With superresolution_noise_mode='none' the SR maps get no gradient from the
+                    # synthesis: theirs is the regulariser's alone (:230-237), and Adam moves them with it every step.
                     if N == 1:
                         b.copy_(src)
-                        b.requires_grad = prefix == 'backbone.synthesis.'
+                        b.requires_grad = True
                     else:
                         t = src.expand(shape).contiguous().clone()
-                        t.requires_grad = prefix == 'backbone.synthesis.'
+                        t.requires_grad = True
                         self.noise_maps[prefix + nm] = t
         if N == 1:
-            self._opt_bufs = list(self.noise_bufs.values())
-            self._all_bufs = self._opt_bufs + list(self.noise_bufs2.values())
+            self._all_bufs = list(self.noise_bufs.values()) + list(self.noise_bufs2.values())
             self._buf_views = None
         else:
-            self._opt_bufs = [t for k, t in self.noise_maps.items() if k.startswith('backbone.')]
-            self._all_bufs = self._opt_bufs + [t for k, t in self.noise_maps.items() if not k.startswith('backbone.')]
+            self._all_bufs = [t for k, t in self.noise_maps.items() if k.startswith('backbone.')] + \
+                             [t for k, t in self.noise_maps.items() if not k.startswith('backbone.')]
+        self._opt_bufs = list(self._all_bufs)          # every map is optimised (reg_grads below is aligned with _all_bufs)
+        if N > 1:
             self._noise_inject = {k[:-len('.noise_const')]: t for k, t in self.noise_maps.items() if k.startswith('backbone.')}
             self._buf_views = [t.detach()[i, 0] for t in self._all_bufs for i in range(N)]       # [r,r] views, image-major per map
         if use_graph:       # the schedule values live on the device so that one captured step can be replayed for every step index
@@ -524,6 +526,11 @@ class LatentProjector:
         if self.optimize_pose:
             self.translation_optimizer.step()
         hipops.noise_normalize_(self._all_bufs if self._buf_views is None else self._buf_views)   # buf -= mean; buf *= rsqrt(mean(buf^2)) (w_projector.py:264-270)
+        if not torch.cuda.is_current_stream_capturing():
+            # the feature distance is accumulated into a slice of the step's ZeroArena, which the next step clears: callers that collect
+            # per-step values lazily must get their own copy (under graph replay `last` is documented as static buffers)
+            dist_i = dist_i.detach().clone()
+            dist = dist_i.sum() if dist_i.numel() > 1 else dist_i.reshape(())
         last = dict(loss=loss.detach(), dist=dist.detach(), dist_per_image=dist_i.detach(), reg=reg.detach() if torch.is_tensor(reg) else reg, image=out['image'].detach(),
                     cam=pred_cam.detach(), ws=ws.detach())
         if warp is not None:

@@ -159,16 +159,17 @@ class ProjectorOracle:
         if wplus and w0.shape[1] == 1:
             w0 = w0.repeat(1, cfg.num_ws, 1)
         self.w_opt = w0.float().requires_grad_(True)
-        # backbone noise buffers are leaves that require grad (w_projector.py:126-128); the SR buffers are re-drawn but NOT made to require
-        # grad (:129-131): they sit in the optimiser without ever receiving a gradient, enter the regulariser's VALUE and are renormalised
+        # the backbone's AND the SR head's noise buffers are re-drawn, made leaves that require grad (w_projector.py:126-131) and handed to
+        # the latent optimiser (:120).  The SR head runs with noise_mode 'none', so its buffers only ever receive the regulariser's
+        # gradient (:230-237) -- which Adam applies every step before the renormalisation (:264-270).
         self.buf_names = [k for k in P if k.endswith('noise_const') and k.startswith('backbone.')]
         self.buf_names2 = [k for k in P if k.endswith('noise_const') and not k.startswith('backbone.')]
         for k in self.buf_names + self.buf_names2:
             v = init_noise[k].clone() if init_noise is not None else torch.randn_like(P[k])
-            self.P[k] = v.requires_grad_(True) if k in self.buf_names else v
+            self.P[k] = v.requires_grad_(True)
         self.bufs = [self.P[k] for k in self.buf_names]
         self.bufs2 = [self.P[k] for k in self.buf_names2]
-        self.optimizer = torch.optim.Adam([self.w_opt] + self.bufs, betas=(0.9, 0.999), lr=first_inv_lr)
+        self.optimizer = torch.optim.Adam([self.w_opt] + self.bufs + self.bufs2, betas=(0.9, 0.999), lr=first_inv_lr)
         self.intrinsic = torch.tensor([4.2647, 0, 0.5, 0, 4.2647, 0.5, 0, 0, 1]).unsqueeze(0)
         self.init_ext = torch.tensor([1, 0, 0, 0, 0, -1, 0, 0, 0, 0, -1, 2.7, 0, 0, 0, 1.]).reshape(1, 4, 4)
         self.canonical_cam = torch.cat([self.init_ext.reshape(1, 16), self.intrinsic], -1)

@@ -579,6 +579,17 @@ def gen_graph_small():
     save('graph_small', 2e-5, **out)
 
 
+FULL_WGRAD_KEYS = ['backbone.synthesis.b4.conv1.weight', 'backbone.synthesis.b32.conv1.weight', 'backbone.synthesis.b64.conv0.weight',
+                   'backbone.synthesis.b128.conv0.weight', 'backbone.synthesis.b128.conv1.weight', 'backbone.synthesis.b256.conv0.weight',
+                   'backbone.synthesis.b256.conv1.weight', 'backbone.synthesis.b256.torgb.weight', 'backbone.synthesis.b64.torgb.bias',
+                   'backbone.synthesis.b64.conv1.noise_strength', 'backbone.synthesis.b256.conv1.noise_strength',
+                   'backbone.synthesis.b128.conv1.bias', 'backbone.synthesis.b64.conv1.affine.weight', 'backbone.synthesis.b256.conv0.affine.bias',
+                   'superresolution.block0.conv0.weight', 'superresolution.block0.conv1.weight', 'superresolution.block1.conv0.weight',
+                   'superresolution.block1.conv1.weight', 'superresolution.block1.torgb.weight', 'superresolution.block1.conv1.affine.weight',
+                   'decoder.net.0.weight', 'decoder.net.0.bias', 'decoder.net.2.weight', 'decoder.net.2.bias']
+FULL_NOISE_KEYS = ['backbone.synthesis.b256.conv1.noise_const', 'backbone.synthesis.b32.conv0.noise_const']
+
+
 def gen_graph_full():
     """Full-size ffhqrebalanced512-128-shaped generator: the reference's own TriPlaneGenerator class.
     Only probe samples + statistics are stored (weights come from the deterministic generator)."""
@@ -598,6 +609,7 @@ def gen_graph_full():
     ws = O.synth_ws(cfg, 1, seed=1).requires_grad_(True)
     c = O.synth_cameras(1, seed=2).requires_grad_(True)
     u1, u2 = O.make_uniforms(cfg, 1, seed=4)
+    nbufs = [dict(G.named_buffers())[k].requires_grad_(True) for k in FULL_NOISE_KEYS]
     with inject(rand_like=[u1], rand=[u2]):
         o = G.synthesis(ws, c, noise_mode='const', force_fp32=True)
     probe = torch.Generator().manual_seed(99)
@@ -606,7 +618,20 @@ def gen_graph_full():
     idx_dep = torch.randint(0, 128 * 128, (2048,), generator=probe)
     g_img = O._randn('gf_img', 8, o['image'].shape) / (3 * 512 * 512)
     g_dep = O._randn('gf_dep', 8, o['image_depth'].shape) / (128 * 128)
-    dws, dc = torch.autograd.grad([o['image'], o['image_depth']], [ws, c], [g_img, g_dep])
+    # Phase B at full size (base_coach.py:96-99: Adam over every generator weight): weight-gradient probes from the reference class
+    # itself -- 256 fixed indices + L2 norm + max|g| per tensor -- plus the gradient of two noise_const buffers (Phase A leaves)
+    named = dict(G.named_parameters())
+    wg = [named[k] for k in FULL_WGRAD_KEYS]
+    grads = torch.autograd.grad([o['image'], o['image_depth']], [ws, c] + wg + nbufs, [g_img, g_dep])
+    dws, dc = grads[:2]
+    wprobe = {}
+    for k, gval in zip(FULL_WGRAD_KEYS + FULL_NOISE_KEYS, grads[2:]):
+        flat = gval.detach().flatten()
+        idx = torch.randint(0, flat.numel(), (min(256, flat.numel()),), generator=probe)
+        wprobe['wg_idx.' + k] = idx
+        wprobe['wg_val.' + k] = flat[idx]
+        wprobe['wg_stat.' + k] = np.array([flat.norm().item(), flat.abs().max().item()])
+        print(f'    d {k}: norm {flat.norm().item():.3e}  max {flat.abs().max().item():.3e}')
     with torch.no_grad():
         oo = O.synthesis(P, cfg, ws.detach(), c.detach(), u1, u2, noise_mode='const')
     for k in ('image', 'image_raw', 'image_depth'):
@@ -617,7 +642,7 @@ def gen_graph_full():
     save('graph_full', 1e-4, ws=ws, c=c, idx_img=idx_img, idx_raw=idx_raw, idx_dep=idx_dep,
          img_probe=o['image'].flatten()[idx_img], raw_probe=o['image_raw'].flatten()[idx_raw],
          dep_probe=o['image_depth'].flatten()[idx_dep], img_stats=stats(o['image']), raw_stats=stats(o['image_raw']),
-         dep_stats=stats(o['image_depth']), dws=dws, dc=dc)
+         dep_stats=stats(o['image_depth']), dws=dws, dc=dc, **wprobe)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -822,7 +847,8 @@ def gen_projector_loop():
                     b[:] = init_noise['backbone.synthesis.' + n_]
                     b.requires_grad = True                                      # w_projector.py:126-128
                 for n_, b in noise_bufs2.items():
-                    b[:] = init_noise['superresolution.' + n_]                  # :129-131 (no requires_grad)
+                    b[:] = init_noise['superresolution.' + n_]
+                    b.requires_grad = True                                      # :129-131
             w_opt = w0.clone().requires_grad_(True)
             # (a non-zero start: at exactly zero the gradient along the viewing axis vanishes and Adam's first step follows rounding noise)
             translation_opt = torch.tensor([IO.PIN_TRANSLATION_START], requires_grad=True)
@@ -872,7 +898,7 @@ def gen_projector_loop():
             for k_, b in noise_bufs.items():
                 check_adam(po.P['backbone.synthesis.' + k_], b, 1e-5, PROJ_STEPS * 0.01, f'projector loop {mode}: {k_}')
             for k_, b in noise_bufs2.items():
-                check(po.P['superresolution.' + k_], b, 1e-5, f'projector loop {mode}: SR {k_}')
+                check_adam(po.P['superresolution.' + k_], b, 1e-5, PROJ_STEPS * 0.01, f'projector loop {mode}: SR {k_}')
             print(f'    {mode}: trace errs {["%.1e" % x for x in e]}, |d pose| {dpose:.2e}, final loss {trace[-1, 0]:.4f}')
             out.update({f'{mode}_trace': trace, f'{mode}_w_opt': w_opt, f'{mode}_translation': translation_opt, f'{mode}_pose_base0': base,
                         f'{mode}_pose_base': cam_predictor.base, f'{mode}_pose_A': cam_predictor.A,

@@ -158,6 +158,55 @@ def test_graph_full_golden(golden):
     close(dc, d['dc'], 1e-2, 'full d c')
 
 
+@pytest.mark.parametrize('arith', ['f16x3', 'sr_f16x1'])
+def test_graph_full_weight_grads_golden(golden, arith):
+    """Phase B at full size (base_coach.py:96-99: Adam over every weight): weight, bias, affine, noise-strength, decoder and noise_const
+    gradients of the ffhqrebalanced512-128-shaped generator against probes recorded from the reference's own TriPlaneGenerator
+    (tests/golden/make_golden.py::gen_graph_full) -- the weight-gradient GEMMs, the decoder Gram kernels and the style bank at the
+    geometries they were tuned for (512^2 x 128, 256^2 x 256, XCD-remapped cell slices).  'f16x3': the fp32-equivalent default, bound
+    1e-3 of each tensor's max|g| (fp32 summation order over up to 262144 cells); 'sr_f16x1': the SR head in the reference's fp16-operand
+    arithmetic (one product, what PivotalTuner runs by default) -- a looser, stated bound."""
+    from inv3d_amd import synthetic as S
+    d = golden('graph_full')
+    cfg = O.full_config()
+    G = S.make_generator(device=DEV)
+    S.load_synthetic_weights(G, 0)
+    G.requires_grad_(True)
+    wkeys = [k[len('wg_idx.'):] for k in d.files if k.startswith('wg_idx.')]
+    assert len(wkeys) >= 20
+    named = dict(G.named_parameters())
+    bufs = dict(G.named_buffers())
+    leaves = []
+    for k in wkeys:
+        if k in named:
+            leaves.append(named[k])
+        else:
+            leaves.append(bufs[k].requires_grad_(True))
+    ws, c = t(d['ws']).requires_grad_(True), t(d['c']).requires_grad_(True)
+    u1, u2 = O.make_uniforms(cfg, 1, seed=4)
+    kw = dict(force_fp32=True) if arith == 'f16x3' else dict(sr_fp16=True)
+    o = G.synthesis(ws, c, noise_mode='const', render_uniforms=(u1.to(DEV), u2.to(DEV)), **kw)
+    g_img = O._randn('gf_img', 8, o['image'].shape) / (3 * 512 * 512)
+    g_dep = O._randn('gf_dep', 8, o['image_depth'].shape) / (128 * 128)
+    grads = torch.autograd.grad([o['image'], o['image_depth']], [ws, c] + leaves, [g_img.to(DEV), g_dep.to(DEV)])
+    close(grads[0], d['dws'], 2e-3 if arith == 'f16x3' else 2e-2, 'full d ws (all weights trainable)')
+    worst = {}
+    for k, gv in zip(wkeys, grads[2:]):
+        ref_norm, ref_max = [float(v) for v in d['wg_stat.' + k]]
+        flat = gv.detach().flatten()
+        assert torch.isfinite(flat).all(), k
+        got = flat[t(d['wg_idx.' + k])].double().cpu()
+        ref = torch.from_numpy(d['wg_val.' + k]).double()
+        sr = k.startswith('superresolution.')
+        tol = 1e-3 if arith == 'f16x3' else (3e-2 if sr else 1e-2)
+        err = float((got - ref).abs().max())
+        worst[k] = err / ref_max
+        assert err <= tol * ref_max, f'd {k}: probe err {err:.3e} > {tol} * max|g| {ref_max:.3e}'
+        nrm = float(flat.double().norm())
+        assert abs(nrm - ref_norm) <= 2 * tol * ref_norm, f'd {k}: norm {nrm:.6e} vs {ref_norm:.6e}'
+    print({k: f'{v:.1e}' for k, v in worst.items()})
+
+
 def test_cpu_tensors_fail_loudly():
     from inv3d_amd.torch_utils.ops import bias_act
     from inv3d_amd._lib import Eg3dHipError

@@ -265,7 +265,8 @@ def test_projector_loop_vs_reference(golden, mode):
     mv_hip = hip.translation_opt.detach().cpu() - torch.tensor([IO.PIN_TRANSLATION_START])
     assert float((mv_hip - mv_ref).abs().max()) <= 0.05 * float(mv_ref.abs().max()), (mode, mv_hip, mv_ref)
     _adam_close(list(hip.noise_bufs.values())[-1].detach().cpu(), g('buf_last'), 1e-4, IO.PIN_PROJ_STEPS * 0.01)
-    assert float((list(hip.noise_bufs2.values())[-1].detach().cpu() - g('srbuf_last')).abs().max()) < 1e-5
+    # the SR head's maps are Adam-updated leaves too (w_projector.py:120,129-131): the regulariser's gradient only
+    _adam_close(list(hip.noise_bufs2.values())[-1].detach().cpu(), g('srbuf_last'), 1e-4, IO.PIN_PROJ_STEPS * 0.01)
 
 
 def test_tuner_loop_vs_reference(golden):

@@ -268,7 +268,7 @@ def test_projector_loop_pin(golden, mode):
     close(po.pose_net.base.detach(), t(d[f'{mode}_pose_base']), 1e-6)
     close(po.pose_net.A.detach(), t(d[f'{mode}_pose_A']), 1e-6)
     adam_close(po.bufs[-1].detach(), t(d[f'{mode}_buf_last']), 1e-5, IO.PIN_PROJ_STEPS * 0.01)
-    close(po.bufs2[-1], t(d[f'{mode}_srbuf_last']), 1e-5)
+    adam_close(po.bufs2[-1].detach(), t(d[f'{mode}_srbuf_last']), 1e-5, IO.PIN_PROJ_STEPS * 0.01)
 
 
 def test_tuner_loop_pin(golden):
