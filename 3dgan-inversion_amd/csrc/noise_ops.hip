@@ -2,9 +2,8 @@
 //
 // The reference runs, per optimisation step and per noise buffer (13 backbone + 4 SR maps, 4^2 .. 512^2), a pyramid of
 // roll / mul / mean / square / avg_pool2d ops, their autograd backward, and a mean/rsqrt renormalisation: ~2500 tiny launches
-// per step, which is what bounds the step once the generator is fast.  Here: ONE launch computes the regulariser of all buffers
-// AND its gradient (one 1024-thread block per buffer walks the pyramid; levels live in a small scratch), ONE launch renormalises
-// all buffers.
+// per step, which is what bounds the step once the generator is fast.  Here: three multi-block launches compute the regulariser of all
+// buffers AND its gradient (pyramid -> moments -> gradient, below), two renormalise all buffers.
 //   reg = sum_buffers sum_levels ( mean(x * roll(x,1,W)) ^2 + mean(x * roll(x,1,H)) ^2 ),  levels: res, res/2, ... while res > 8
 #include "common.h"
 
@@ -37,76 +36,135 @@ __device__ float block_sum(float v, float* red) {
     return red[16];
 }
 
-__global__ void __launch_bounds__(NT) noise_reg_kernel(const NoiseBufs B, float* __restrict__ ws, float* __restrict__ reg_out, float scale) {
-    __shared__ float red[32];
-    __shared__ float mx[12], my[12];
-    const int b = blockIdx.x;
-    const int res0 = B.res[b];
-    const float* x0 = B.x[b];
-    float* scratch = ws + B.ws_off[b];
-    // level pointers: level 0 = input; level l >= 1 at lev_off(l); gradient pyramid after the value pyramid
-    int nl = 1;
-    for (int r = res0; r > 8; r >>= 1) ++nl;
-    float reg = 0.f;
-    const float* cur = x0;
-    int r = res0;
-    int64_t off = 0;
-    for (int l = 0; l < nl; ++l) {
-        float sx = 0.f, sy = 0.f;
-        const int n = r * r;
-        const int sh = (r & (r - 1)) == 0 ? __ffs(r) - 1 : -1;          // every StyleGAN resolution is a power of two: shifts instead of a division per element
-        for (int i = threadIdx.x; i < n; i += NT) {
-            const int y = sh >= 0 ? i >> sh : i / r, xx = i - y * r;
-            const float v = cur[i];
-            sx += v * cur[y * r + (xx == 0 ? r - 1 : xx - 1)];
-            sy += v * cur[(y == 0 ? r - 1 : y - 1) * r + xx];
-        }
-        sx = block_sum(sx, red) / (float)n;
-        sy = block_sum(sy, red) / (float)n;
-        if (threadIdx.x == 0) { mx[l] = sx; my[l] = sy; }
-        reg += sx * sx + sy * sy;
-        if (l + 1 < nl) {
-            const int h = r >> 1;
-            float* nxt = scratch + off;
-            for (int i = threadIdx.x; i < h * h; i += NT) {
-                const int y = sh >= 1 ? i >> (sh - 1) : i / h, xx = i - y * h;
-                const float* p = cur + (2 * y) * r + 2 * xx;
-                nxt[i] = ((p[0] + p[1]) + (p[r] + p[r + 1])) * 0.25f;
-            }
-            __threadfence_block();
-            __syncthreads();
-            cur = nxt;
-            off += (int64_t)h * h;
-            r = h;
-        }
+// ---- regulariser: three multi-block passes ---------------------------------------------------------------------------------------
+// Round 2 ran ONE 1024-thread block per buffer over the whole pyramid: the 512^2 map of the SR head made it a 440-465 us kernel on 17 of
+// 256 CUs (3.3 MB of data: ~1 us at HBM speed).  Now
+//   pass 1 (pyramid):  block = (buffer, band of 64 rows): the 2x2-average pyramid of its band, all levels (bands are aligned to 2^6 rows,
+//                      so pooling never crosses a band), written to the scratch;
+//   pass 2 (moments):  block = (buffer, level, chunk): sum v * roll_x(v), sum v * roll_y(v) -> one atomic pair per block;
+//   pass 3 (gradient): block = (buffer, chunk of level 0): with m_l = the level's two means, the chain rule through the average pools is
+//                      g[i] = scale * sum_l 4^-l * 2/n_l * ( mx_l (left + right) + my_l (up + down) ) at the level-l ancestor of i
+//                      -- every element independent -- and the buffer's regulariser value from the moments.
+constexpr int BAND = 64;                 // rows of level 0 per pyramid block (>= 2^(levels-1) for res <= 512; larger maps: see noise_levels)
+constexpr int CHUNK = NT * 4;            // elements per block in passes 2 and 3
+constexpr int MAXL = 12;
+
+__host__ __device__ inline int noise_levels(int res) { int nl = 1; for (int r = res; r > 8; r >>= 1) ++nl; return nl; }
+// rows of level 0 a pyramid block owns: the whole coarsest level (8 rows) must split evenly over the bands
+__host__ __device__ inline int noise_band(int res) { const int b = res / 8; return b < 1 ? res : (b < BAND ? (res < BAND ? res : BAND) : b); }
+__host__ __device__ inline int64_t lev_off(int res, int l) {        // offset of level l >= 1 inside a buffer's scratch
+    int64_t o = 0;
+    for (int k = 1; k < l; ++k) { const int r = res >> k; o += (int64_t)r * r; }
+    return o;
+}
+
+__global__ void __launch_bounds__(NT) noise_pyramid_kernel(const NoiseBufs B, float* __restrict__ ws, float* __restrict__ sums, float* __restrict__ reg_out) {
+    int blk = blockIdx.x, b = 0, band = 0;
+    for (; b < B.n; ++b) {
+        const int nb = B.res[b] / noise_band(B.res[b]);
+        if (blk < nb) { band = blk; break; }
+        blk -= nb;
     }
-    if (threadIdx.x == 0) unsafeAtomicAdd(reg_out, reg * scale);
-    float* gout = B.g[b];
-    if (gout == nullptr) return;
-    __syncthreads();
-    // gradient, coarse -> fine.  value level l >= 1 sits at voff[l]; gradient level l >= 1 at vtot + voff[l]
-    int64_t voff[12];
-    int64_t vtot = 0;
-    voff[0] = 0;
-    for (int l = 1; l < nl; ++l) { voff[l] = vtot; const int rr = res0 >> l; vtot += (int64_t)rr * rr; }
-    for (int l = nl - 1; l >= 0; --l) {
-        const int rl = res0 >> l;
-        const float* xl = l == 0 ? x0 : scratch + voff[l];
-        float* gl = l == 0 ? gout : scratch + vtot + voff[l];
-        const float* gup = (l + 1 < nl) ? scratch + vtot + voff[l + 1] : nullptr;
-        const float n = (float)(rl * rl);
-        const float cxm = 2.f * mx[l] / n * scale, cym = 2.f * my[l] / n * scale;
-        const int h = rl >> 1;
-        const int shl = (rl & (rl - 1)) == 0 ? __ffs(rl) - 1 : -1;
-        for (int i = threadIdx.x; i < rl * rl; i += NT) {
-            const int y = shl >= 0 ? i >> shl : i / rl, xx = i - y * rl;
-            float g = cxm * (xl[y * rl + (xx == 0 ? rl - 1 : xx - 1)] + xl[y * rl + (xx == rl - 1 ? 0 : xx + 1)]) +
-                      cym * (xl[(y == 0 ? rl - 1 : y - 1) * rl + xx] + xl[(y == rl - 1 ? 0 : y + 1) * rl + xx]);
-            if (gup) g += gup[(y >> 1) * h + (xx >> 1)] * 0.25f;
-            gl[i] = g;
+    if (b >= B.n) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *reg_out = 0.f;
+    if (band == 0 && threadIdx.x < 2 * MAXL) sums[b * 2 * MAXL + threadIdx.x] = 0.f;
+    const int res = B.res[b], nl = noise_levels(res), R = noise_band(res);
+    float* scratch = ws + B.ws_off[b];
+    const float* cur = B.x[b];
+    int r = res, rows = R, y0 = band * R;            // current level: width r, this band's rows [y0, y0 + rows)
+    for (int l = 1; l < nl; ++l) {
+        const int h = r >> 1, hrows = rows >> 1, hy0 = y0 >> 1;
+        float* nxt = scratch + lev_off(res, l);
+        const int sh = __ffs(h) - 1;
+        for (int i = threadIdx.x; i < hrows * h; i += NT) {
+            const int yy = i >> sh, xx = i - (yy << sh);
+            const float2 p0 = *reinterpret_cast<const float2*>(cur + (int64_t)(y0 + 2 * yy) * r + 2 * xx);
+            const float2 p1 = *reinterpret_cast<const float2*>(cur + (int64_t)(y0 + 2 * yy + 1) * r + 2 * xx);
+            nxt[(int64_t)(hy0 + yy) * h + xx] = ((p0.x + p0.y) + (p1.x + p1.y)) * 0.25f;
         }
         __threadfence_block();
         __syncthreads();
+        cur = nxt; r = h; rows = hrows; y0 = hy0;
+    }
+}
+
+// block -> (buffer, level, chunk) for pass 2; level < 0: not a block of this launch
+__device__ __forceinline__ void moments_locate(const NoiseBufs& B, int blk, int& buf, int& lev, int& start) {
+    for (buf = 0; buf < B.n; ++buf) {
+        const int nl = noise_levels(B.res[buf]);
+        for (lev = 0; lev < nl; ++lev) {
+            const int r = B.res[buf] >> lev;
+            const int nb = (r * r + CHUNK - 1) / CHUNK;
+            if (blk < nb) { start = blk * CHUNK; return; }
+            blk -= nb;
+        }
+    }
+    lev = -1;
+}
+
+__global__ void __launch_bounds__(NT) noise_moments2_kernel(const NoiseBufs B, const float* __restrict__ ws, float* __restrict__ sums) {
+    __shared__ float red[32];
+    int b, l, start;
+    moments_locate(B, blockIdx.x, b, l, start);
+    if (l < 0) return;
+    const int res = B.res[b], r = res >> l, n = r * r, sh = __ffs(r) - 1;
+    const float* v = l == 0 ? B.x[b] : ws + B.ws_off[b] + lev_off(res, l);
+    float sx = 0.f, sy = 0.f;
+    for (int i = start + threadIdx.x; i < min(n, start + CHUNK); i += NT) {
+        const int y = i >> sh, xx = i - (y << sh);
+        const float c = v[i];
+        sx += c * v[(y << sh) + ((xx - 1) & (r - 1))];
+        sy += c * v[(((y - 1) & (r - 1)) << sh) + xx];
+    }
+    sx = block_sum(sx, red);
+    sy = block_sum(sy, red);
+    if (threadIdx.x == 0) { unsafeAtomicAdd(sums + (b * MAXL + l) * 2, sx); unsafeAtomicAdd(sums + (b * MAXL + l) * 2 + 1, sy); }
+}
+
+__global__ void __launch_bounds__(NT) noise_grad_kernel(const NoiseBufs B, const float* __restrict__ ws, const float* __restrict__ sums, float* __restrict__ reg_out,
+                                                        float scale) {
+    int blk = blockIdx.x, b = 0;
+    for (; b < B.n; ++b) {
+        const int nb = (B.res[b] * B.res[b] + CHUNK - 1) / CHUNK;
+        if (blk < nb) break;
+        blk -= nb;
+    }
+    if (b >= B.n) return;
+    const int res = B.res[b], nl = noise_levels(res);
+    __shared__ float cx[MAXL], cy[MAXL];
+    if (threadIdx.x < 16) {                            // lanes 0 .. nl-1 of wave 0 hold one level each
+        float part = 0.f;
+        if (threadIdx.x < nl) {
+            const int r = res >> threadIdx.x;
+            const float n = (float)(r * r);
+            const float mx = sums[(b * MAXL + threadIdx.x) * 2] / n, my = sums[(b * MAXL + threadIdx.x) * 2 + 1] / n;
+            const float w = 2.f / n * scale / (float)(1 << (2 * threadIdx.x));    // 2 m / n_l  x  4^-l (one average pool per level)
+            cx[threadIdx.x] = mx * w;
+            cy[threadIdx.x] = my * w;
+            part = mx * mx + my * my;
+        }
+        for (int m = 8; m >= 1; m >>= 1) part += __shfl_xor(part, m, 16);
+        if (blk == 0 && threadIdx.x == 0) unsafeAtomicAdd(reg_out, part * scale);          // this buffer's part of the value
+    }
+    float* gout = B.g[b];
+    if (gout == nullptr) return;
+    __syncthreads();
+    const float* x0 = B.x[b];
+    const float* scratch = ws + B.ws_off[b];
+    const int sh0 = __ffs(res) - 1, n0 = res * res;
+    for (int i = blk * CHUNK + threadIdx.x; i < min(n0, (blk + 1) * CHUNK); i += NT) {
+        const int y = i >> sh0, xx = i - (y << sh0);
+        float g = 0.f;
+        const float* v = x0;
+        int64_t off = 0;
+        for (int l = 0; l < nl; ++l) {
+            const int r = res >> l, sh = sh0 - l, yl = y >> l, xl = xx >> l;
+            g += cx[l] * (v[(yl << sh) + ((xl - 1) & (r - 1))] + v[(yl << sh) + ((xl + 1) & (r - 1))]) +
+                 cy[l] * (v[(((yl - 1) & (r - 1)) << sh) + xl] + v[(((yl + 1) & (r - 1)) << sh) + xl]);
+            v = scratch + off;                         // level l + 1
+            off += (int64_t)(r >> 1) * (r >> 1);
+        }
+        gout[i] = g;
     }
 }
 
@@ -179,8 +237,8 @@ int fill(NoiseBufs& B, float* const* x, float* const* g, const int32_t* res, int
 
 extern "C" int64_t eg3d_noise_reg_workspace_floats(const int32_t* res, int nbufs) {
     int64_t t = 0;
-    for (int i = 0; i < nbufs; ++i) t += (int64_t)res[i] * res[i];
-    return t;
+    for (int i = 0; i < nbufs; ++i) t += (int64_t)res[i] * res[i];      // per buffer: its pyramid (< res^2 / 3), 16-byte aligned slots
+    return t + 2 * MAXL * MAXB;                                        // + the per-(buffer, level) moment pairs
 }
 
 extern "C" int eg3d_noise_regularizer(float* const* x, float* const* grad, const int32_t* res, int nbufs, float* workspace, float* reg_out, float scale,
@@ -190,8 +248,18 @@ extern "C" int eg3d_noise_regularizer(float* const* x, float* const* grad, const
     if (rc) return rc;
     if (!workspace || !reg_out) return EG3D_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    eg3d_zero_words(reg_out, 1, st);
-    hipLaunchKernelGGL(noise_reg_kernel, dim3(nbufs), dim3(NT), 0, st, B, workspace, reg_out, scale);
+    int64_t pyr = 0;
+    int nb1 = 0, nb2 = 0, nb3 = 0;
+    for (int i = 0; i < nbufs; ++i) {
+        pyr += (int64_t)res[i] * res[i];
+        nb1 += res[i] / noise_band(res[i]);
+        for (int l = 0; l < noise_levels(res[i]); ++l) nb2 += eg3d_cdiv((int64_t)(res[i] >> l) * (res[i] >> l), CHUNK);
+        nb3 += eg3d_cdiv((int64_t)res[i] * res[i], CHUNK);
+    }
+    float* sums = workspace + pyr;
+    hipLaunchKernelGGL(noise_pyramid_kernel, dim3(nb1), dim3(NT), 0, st, B, workspace, sums, reg_out);     // also zeroes the moments and reg_out
+    hipLaunchKernelGGL(noise_moments2_kernel, dim3(nb2), dim3(NT), 0, st, B, workspace, sums);
+    hipLaunchKernelGGL(noise_grad_kernel, dim3(nb3), dim3(NT), 0, st, B, workspace, sums, reg_out, scale);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

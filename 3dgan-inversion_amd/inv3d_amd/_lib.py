@@ -139,6 +139,7 @@ _SIGS = {
     'eg3d_split_activation': (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]),
     'eg3d_split_weight': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
     'eg3d_absmax': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'eg3d_probe_mfma_f16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'eg3d_modconv_epilogue_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int64,
                                             C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),

@@ -573,7 +573,7 @@ class PivotalTuner:
         self.synth_kwargs = dict(synth_kwargs or {})
         self.synth_kwargs.setdefault('sr_fp16', bool(sr_fp16))
         self.last = {}
-        self._arena = None
+        self._arena = self._arena_eager = None
 
     def _fused_objective(self, out):
         """The same objective as the ATen composition in `_step` from five reduction launches per direction (loss_nets.weighted_objective):
@@ -606,7 +606,15 @@ class PivotalTuner:
         if self._arena is None:
             self._arena = hipops.ZeroArena(self.target.device)
         if not self.use_graph or early_stop or self.graph_capture_error is not None:
-            with hipops.zero_arena(self._arena):
+            # the captured graph holds raw pointers into self._arena.buf, which begin() re-allocates when the demand grows (an eager step
+            # with other shapes or a fallback path): once a graph exists, eager steps take their accumulators from an arena of their own
+            if self._graph is not None:
+                if self._arena_eager is None:
+                    self._arena_eager = hipops.ZeroArena(self.target.device)
+                arena = self._arena_eager
+            else:
+                arena = self._arena
+            with hipops.zero_arena(arena):
                 return self._step(early_stop, **step_kwargs)
         if step_kwargs:
             raise ValueError('use_graph: per-step synthesis kwargs cannot change between replays; pass them as synth_kwargs')

@@ -8,6 +8,7 @@ deterministic runs: render_uniforms=(u1,u2), noise_inject={layer-name: [N,1,res,
 import torch
 
 from .. import fused
+from .. import graphed
 from ..reference_binding import ReferenceStateMixin
 from .networks_stylegan2 import Generator as StyleGAN2Backbone, FullyConnectedLayer
 from .superresolution import SuperresolutionHybrid8XDC
@@ -78,13 +79,28 @@ class TriPlaneGenerator(ReferenceStateMixin, torch.nn.Module):
     # ---- image side ----------------------------------------------------------------------------------------------------------
     sr_fp16_default = False      # True: G.synthesis without force_fp32 runs the fp16 blocks like the reference does on CUDA (see `sr_fp16`)
 
+    graph_eager = True           # plain calls whose signature repeats are replayed from HIP graphs (inv3d_amd/graphed.py); False: always per-launch
+
     def synthesis(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False, use_cached_backbone=False,
                   render_uniforms=None, noise_inject=None, sr_fp16=None, **synthesis_kwargs):
         """ws [N,num_ws,w_dim], c [N,25] = (cam2world 4x4, intrinsics 3x3) -> {'image','image_raw','image_depth'} (triplane.py:53-90).
         Arithmetic: fp32-equivalent everywhere by default.  `sr_fp16=True` (and no `force_fp32=True`) runs the blocks the reference runs
         in fp16 when `force_fp32` is not passed -- the super-resolution head, sr_num_fp16_res > 0, networks_stylegan2.py:421-424; what
         BaseCoach.forward does during pivotal tuning -- with one product of fp16-rounded operands (EG3D_PREC_F16X1; accumulation and
-        storage stay fp32).  `render_uniforms=(u1,u2)` / `noise_inject` pin the stratified-sampling / per-layer noise draws."""
+        storage stay fp32).  `render_uniforms=(u1,u2)` / `noise_inject` pin the stratified-sampling / per-layer noise draws.
+        A call signature that repeats (an optimisation loop) is captured into HIP graphs and replayed -- same kernels, same results, one
+        launch per direction instead of ~190 (inv3d_amd/graphed.py; `graph_eager`)."""
+        kw = dict(synthesis_kwargs)
+        for name, val, default in (('neural_rendering_resolution', neural_rendering_resolution, None), ('update_emas', update_emas, False),
+                                   ('cache_backbone', cache_backbone, False), ('use_cached_backbone', use_cached_backbone, False),
+                                   ('noise_inject', noise_inject, None), ('sr_fp16', sr_fp16 if sr_fp16 is not None else self.sr_fp16_default, False)):
+            if val is not default and val != default:
+                kw[name] = val
+        return graphed.synthesis(self, self._synthesis_impl, ws, c, render_uniforms=render_uniforms, **kw)
+
+    def _synthesis_impl(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False, use_cached_backbone=False,
+                        render_uniforms=None, noise_inject=None, sr_fp16=None, **synthesis_kwargs):
+        """The per-launch synthesis (what `synthesis` captures)."""
         if sr_fp16 is None:
             sr_fp16 = self.sr_fp16_default
         block_fp32 = bool(synthesis_kwargs.get('force_fp32', False)) or not sr_fp16

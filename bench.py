@@ -25,6 +25,9 @@ The JSON line also carries
   final_psnr    : one image through the whole 400 + 400 step budget (InversionCoach): the second half of the metric.
   cpu_baseline  : the CPU oracle (oracle/eg3d_oracle.py, a port of the reference's pure-PyTorch `_ref` path, pinned against
                   the reference) running the same C2 step on the host cores, bounded sample, rank 0 at N=1 only.
+  cpu_baseline_c1 : the oracle's pivotal-tuning step at full size on the same cores (BASELINE.json configs[0]: 10 PTI steps on CPU).
+  side_configs  : w+ latent, VGG16-LPIPS architecture, 8 images per GPU (config C5's per-GPU share), the pivotal-tuning step (config C4)
+                  and the plain `G.synthesis` loop of a drop-in caller, each timed for a few steps in the same run (never the headline).
 """
 import argparse
 import json
@@ -74,6 +77,174 @@ def cpu_baseline_c2(seconds_budget=30.0):
                 sample=f'oracle C2 step (ProjectorOracle), full-size generator, N=1: 1 warm-up + {len(times)} timed steps, median {med:.2f} s/step')
 
 
+def self_launch_command(gpus, argv, port=None):
+    """The command `bench.py --gpus N` re-launches itself with when it was not started by a launcher: the driver's own form
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>)."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={int(gpus)}', '--master-addr', '127.0.0.1',
+            '--master-port', str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def cpu_baseline_c1(seconds_budget=40.0):
+    """BASELINE.json configs[0] ("1 image, 10 PTI steps on CPU via the pure-Python fallback"): the pivotal-tuning step of the oracle
+    (PivotalTunerOracle: forward, objective, backward into all 30.7 M weights, Adam) on the full-size generator, bounded sample."""
+    from oracle import eg3d_oracle as O
+    from oracle import inversion_oracle as IO
+    threads = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
+    cfg = O.full_config()
+    P = O.synth_params(cfg, seed=0)
+    c = O.synth_cameras(1, seed=2)
+    u1, u2 = O.make_uniforms(cfg, 1, seed=4)
+    g = torch.Generator().manual_seed(3)
+    target = torch.rand(1, 3, 512, 512, generator=g) * 2 - 1
+    tuner = IO.PivotalTunerOracle(P, cfg, target, O.synth_ws(cfg, 1, seed=1), c)
+    t0 = time.time()
+    tuner.step(u1, u2, noise_mode='const')          # warm-up
+    times = []
+    while len(times) < 2 and (time.time() - t0) < seconds_budget:
+        t1 = time.time()
+        tuner.step(u1, u2, noise_mode='const')
+        times.append(time.time() - t1)
+    if not times:
+        times = [time.time() - t0]
+    med = sorted(times)[len(times) // 2]
+    return dict(value=round(1.0 / med, 4), unit='steps/s', cores=threads, kind='port', ten_pti_steps_s=round(10 * med, 1),
+                sample=f'oracle pivotal-tuning step (PivotalTunerOracle), full-size generator, N=1: 1 warm-up + {len(times)} timed steps, median {med:.2f} s/step; '
+                       'config C1 (10 PTI steps) = 10 x that')
+
+
+def measure_mfma_probe(dev):
+    """TFLOP/s a register-only v_mfma_f32_32x32x16_f16 loop sustains on random data, measured now (eg3d_probe_mfma_f16, HIP events)."""
+    from inv3d_amd import _lib as L
+    data = (torch.rand(4096 * 8, device=dev) * 2 - 1).mul_(1000.0).half()
+    blocks, iters = 1024, 2000
+    out = torch.empty(blocks * 256, device=dev)
+    call = lambda: L.check(L.lib().eg3d_probe_mfma_f16(data.data_ptr(), out.data_ptr(), blocks, iters, L.stream_ptr()), 'probe_mfma_f16')   # noqa: E731
+    call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    return blocks * 4 * iters * 24 * 32768.0 / (ms * 1e-3) / 1e12
+
+
+def _time_steps(fn, n, warm):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def side_configs(G, target, cam, dev, use_graph, steps=10):
+    """The other configurations of BASELINE.json / SURVEY section 8d, measured in the same run as side figures (never the headline):
+    w+ latent, the VGG16-LPIPS architecture in the loop, 8 images per GPU (the per-GPU share of config C5), the pivotal-tuning step
+    (config C4) and the PLAIN `G.synthesis` loop a drop-in caller runs (no projector object: inv3d_amd/graphed.py)."""
+    from inv3d_amd import synthetic as S
+    from inv3d_amd.inversion import LatentProjector, PivotalTuner
+    out = {}
+
+    def guarded(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:           # a side figure must never cost the benchmark line
+            out[name] = dict(error='%s: %s' % (type(e).__name__, e))
+        torch.cuda.synchronize()
+
+    def projector(**kw):
+        def run():
+            pr = LatentProjector(G, kw.pop('target', target), num_steps=400, cam=kw.pop('cam', cam), seed=100, use_graph=use_graph, **kw)
+            pr.preheat = 0
+            m = pr.N
+            ms = _time_steps(pr.step, steps, pr._graph_warmup + 2)
+            if use_graph and pr._graph is None:
+                raise RuntimeError(f'capture failed: {pr.graph_capture_error}')
+            return dict(ms_per_step=round(ms, 3), image_steps_per_s=round(m * 1e3 / ms, 2))
+        return run
+
+    guarded('wplus', projector(wplus=True))
+
+    def vgg():
+        from inv3d_amd.loss_nets import VGG16LPIPS
+        return projector(feature_net=VGG16LPIPS().to(dev))()
+    guarded('loss_net_vgg16', vgg)
+
+    def c5():
+        m = 8
+        cams = S.synth_cameras(m, seed=2).to(dev)
+        with torch.no_grad():
+            ws_t = S.synth_ws(14, 512, m, seed=3).to(dev)
+            tg = torch.cat([G.synthesis(ws_t[i:i + 1], cams[i:i + 1], noise_mode='const', force_fp32=True)['image'].clamp(-1, 1) for i in range(m)])
+        r = projector(target=tg, cam=cams)()
+        r['note'] = '8 independent inversions as one batch on this GPU = the per-GPU share of config C5 (64 images on 8 GPUs)'
+        return r
+    guarded('images_per_gpu_8', c5)
+
+    def plain_loop():
+        # the shape of training/projectors/w_projector.py:189-261 with no object of this package around the call
+        import torch.nn.functional as F
+        G.requires_grad_(False)
+        bufs = [b for n, b in G.backbone.synthesis.named_buffers() if 'noise_const' in n]
+        for b in bufs:
+            b.requires_grad = True
+        saved = [b.detach().clone() for b in bufs]
+        w_opt = S.synth_ws(14, 512, 1, seed=1)[:, :1].to(dev).clone().requires_grad_(True)
+        opt = torch.optim.Adam([w_opt] + bufs, lr=0.01, fused=True)
+        t256 = F.avg_pool2d(target[:1], 2)
+
+        def step():
+            ws = (w_opt + 0.01 * torch.randn_like(w_opt)).repeat(1, 14, 1)
+            o = G.synthesis(ws, cam[:1], noise_mode='const', force_fp32=True)
+            loss = (F.avg_pool2d(o['image'], 2) - t256).square().sum()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+        try:
+            res = {}
+            for flag, key in ((True, 'ms_per_step'), (False, 'ms_per_step_per_launch_path')):
+                G.graph_eager = flag
+                res[key] = round(_time_steps(step, steps, 4), 3)
+            res['note'] = 'plain `out = G.synthesis(ws, c, noise_mode="const", force_fp32=True); loss.backward(); opt.step()` loop, L2 loss at 256^2: forward and backward replayed from HIP graphs inside G.synthesis vs one launch per kernel'
+            return res
+        finally:
+            G.graph_eager = True
+            with torch.no_grad():
+                for b, v in zip(bufs, saved):
+                    b.requires_grad = False
+                    b.copy_(v)
+    guarded('plain_g_synthesis_loop', plain_loop)
+
+    def phase_b():
+        import copy
+        state = copy.deepcopy(G.state_dict())
+        try:
+            w_pivot = S.synth_ws(14, 512, 1, seed=5).to(dev)
+            tuner = PivotalTuner(G, target[:1], w_pivot, cam[:1], use_graph=use_graph)
+            ms = _time_steps(tuner.step, steps, 4)
+            if use_graph and tuner._graph is None:
+                raise RuntimeError(f'capture failed: {tuner.graph_capture_error}')
+            return dict(ms_per_step=round(ms, 3), steps_per_s=round(1e3 / ms, 2),
+                        note='config C4: pivotal-tuning step, all 30.7 M weights trainable (forward + data and weight gradients + fused Adam), SR head in the reference\'s fp16-operand arithmetic')
+        finally:
+            G.load_state_dict(state)
+            G.requires_grad_(False)
+            from inv3d_amd import hipops as H
+            H.weights_changed()
+    guarded('phase_b_c4', phase_b)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -88,6 +259,7 @@ def main():
     ap.add_argument('--images-per-gpu', type=int, default=1,
                     help='images inverted as one batch on every GPU (1 = config C2; 8 = the per-GPU share of config C5: 64 images on 8 GPUs)')
     ap.add_argument('--no-final-psnr', action='store_true', help='skip the full-budget (400 + 400 steps) inversion that reports the final PSNR')
+    ap.add_argument('--no-side-configs', action='store_true', help='skip the side figures (w+, VGG16-LPIPS, 8 images per GPU, pivotal tuning, plain G.synthesis loop)')
     ap.add_argument('--loss-net', default='stub', choices=['stub', 'vgg16'],
                     help="feature network of the LPIPS term: 'stub' = the small fixed conv pyramid the C2 workload is defined with (SURVEY.md "
                          "section 8d); 'vgg16' = the full VGG16-LPIPS architecture (random weights) on the same kernels")
@@ -95,14 +267,8 @@ def main():
 
     if args.gpus > 1 and 'RANK' not in os.environ:
         # not under torch.distributed.run: launch the ranks ourselves (one process per GPU, RCCL rendezvous on the loopback address)
-        import socket
         import subprocess
-        with socket.socket() as sk:
-            sk.bind(('127.0.0.1', 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
-               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.call(cmd))
+        sys.exit(subprocess.call(self_launch_command(args.gpus, sys.argv[1:])))
 
     from inv3d_amd import dist as D
     # EG3D_BENCH_BACKEND=gloo + EG3D_BENCH_ONE_DEVICE=1: dry-run of the multi-rank control flow (async stat reducer, barriers, rank-max timing)
@@ -189,7 +355,12 @@ def main():
         del eager
 
     roof = roof_r = None
+    probe_tf = None
     if prof is not None:
+        try:
+            probe_tf = measure_mfma_probe(dev)
+        except Exception:
+            probe_tf = None
         traffic = json.load(open(TRAFFIC_TABLE)) if os.path.exists(TRAFFIC_TABLE) else {}
         summ = prof.summary()
         dom_id = max(summ, key=lambda k: summ[k]['ms']) if summ else None      # the kernel with the largest share of the step
@@ -215,8 +386,9 @@ def main():
             roof = dict(bound='mfma', kernel=kern, achieved=round(ach, 2),
                         peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4), traffic=tbytes, traffic_source=tr.get('source'),
                         peak_basis=('fp32 matrix peak' if dom_prec == 'f32' else 'dense 16-bit matrix peak 2500 / %d products' % nprod),
-                        measured_mfma_ceiling_tflops=round(1550.0 / nprod, 1) if dom_prec != 'f32' else None,
-                        ceiling_note='a register-only v_mfma_f32_32x32x16_f16 loop sustains 1.5-1.6 PFLOP/s on random data on this chip (clock throttling; 2.0-2.3 on zeros): tools/proto/mfma_peak.hip',
+                        frac_of_fp16_dense_algorithmic=round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
+                        mfma_register_loop_tflops_measured=round(probe_tf, 1) if probe_tf is not None else None,
+                        mfma_register_loop_note='eg3d_probe_mfma_f16 (register-only v_mfma_f32_32x32x16_f16 loop on random fp16 data, 1024 blocks) timed with HIP events in THIS run, right after the timed region; executed (not algorithmic) TFLOP/s -- compare with mfma_executed_tflops',
                         frac_of_fp32_mfma_peak=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), mfma_executed_tflops=round(ach * nprod, 1),
                         launches_per_step=dom['launches'] / args.steps, gflop_per_launch=round(dom['flops'] / dom['launches'] / 1e9, 3),
                         avg_launch_ms=round(dom['ms'] / dom['launches'], 4), share_of_conv_time=round(dom['ms'] / all_ms, 3),
@@ -236,6 +408,12 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_c2()
+    cpu_c1 = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_c1 = cpu_baseline_c1()
+    side = None
+    if rank == 0 and world == 1 and not args.no_side_configs and M == 1 and args.loss_net == 'stub' and not args.wplus:
+        side = side_configs(G, target, cam, dev, use_graph)
     final = None
     if rank == 0 and world == 1 and not args.no_final_psnr:
         # second half of the metric: one image through the whole budget of configs/hyperparameters.py (400 latent + 400 pivotal-tuning steps)
@@ -270,7 +448,7 @@ def main():
                                     ' (one packed vector per step, asynchronous; mean loss over ranks and steps %.5g)' % float(step_stats[0] / step_stats[2].clamp(min=1)) if world > 1 else ''),
                                 launch='one HIP graph replay per step' if use_graph else 'eager (one launch per kernel)',
                                 psnr_after_timed_steps_db=round(psnr_now, 3)),
-                    roofline=roof, roofline_renderer=roof_r, cpu_baseline=cpu, final_psnr=final)
+                    roofline=roof, roofline_renderer=roof_r, cpu_baseline=cpu, cpu_baseline_c1=cpu_c1, side_configs=side, final_psnr=final)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

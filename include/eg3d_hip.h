@@ -583,6 +583,11 @@ int eg3d_warp_project_fwd(const float* origins, const float* dirs, const float* 
 int eg3d_warp_project_bwd(const float* origins, const float* dirs, const float* depth, const float* consts, const float* duv, float* d_origins,
                           float* d_dirs, float* d_depth, int64_t P, void* stream);
 
+/* Measurement aid (bench.py): a register-only v_mfma_f32_32x32x16_f16 loop on caller-supplied fp16 data -- what the matrix pipe sustains on
+ * this chip at its current power / clock state, timed inside the benchmark run.  in: 4096 x 8 fp16 (64 KiB); out: blocks x 256 floats;
+ * executes blocks x 4 waves x iters x 24 MFMAs of 32 x 32 x 16.  No reference counterpart. */
+int eg3d_probe_mfma_f16(const void* in, float* out, int blocks, int iters, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,3 +76,23 @@ def test_single_process_is_a_noop():
     assert red.finish().tolist() == [5.0, 10.0]
     assert D.shard_images(5, 0, 1) == [0, 1, 2, 3, 4]
     assert D.max_over_ranks(3.0, torch.device('cpu')) == 3.0
+
+
+def test_bench_self_launch_plumbing():
+    """`python bench.py --gpus N` outside a launcher re-launches itself in the driver's own form (torch.distributed.run, one rank per GPU,
+    loopback rendezvous) with its arguments passed through unchanged."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    argv = ['--gpus', '4', '--steps', '7', '--warmup', '2', '--images-per-gpu', '8']
+    cmd = bench.self_launch_command(4, argv, port=23456)
+    assert cmd[0] == sys.executable and cmd[1:3] == ['-m', 'torch.distributed.run']
+    assert '--nnodes=1' in cmd and '--nproc-per-node=4' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[cmd.index('--master-port') + 1] == '23456'
+    k = cmd.index(os.path.join(root, 'bench.py'))
+    assert cmd[k + 1:] == argv
+    auto = bench.self_launch_command(2, [])
+    assert 1024 < int(auto[auto.index('--master-port') + 1]) < 65536
