@@ -111,7 +111,7 @@ class _GraphedFn(torch.autograd.Function):
             gi += 1
         # a parameter whose .grad still aliases our static buffer (zero_grad(set_to_none=False)) must not be accumulated onto itself
         for t, s in zip(e.grad_targets, e.s_gin):
-            if s is not None and t.grad is not None and t.grad.data_ptr() == s.data_ptr():
+            if s is not None and t.is_leaf and t.grad is not None and t.grad.data_ptr() == s.data_ptr():
                 t.grad = t.grad.clone()
         e.bwd.replay()
         e.done = True
@@ -125,6 +125,40 @@ class _GraphedFn(torch.autograd.Function):
             k += 1
         res += [s.detach() if s is not None else None for s in e.s_gin[k:]]
         return tuple(res)
+
+
+class _aliased_leaves:
+    """For the duration of a capture, every leaf of the generator that requires grad (trainable parameters, the noise_const buffers of a
+    latent projection) is replaced inside its module by a fresh leaf sharing the same storage.  The captured autograd graph is then
+    entirely private: it never touches the caller's tensors' gradient accumulators -- those were created on whatever stream the caller's
+    earlier (per-launch) iterations ran on, usually the default stream, and autograd synchronises a backward with its accumulators'
+    streams: a cross-stream wait on a non-capturing stream inside hipStreamBeginCapture ... EndCapture (observed: a segfault in
+    capture_end).  `aliases` is aligned with `leaves`."""
+
+    def __init__(self, G, leaves):
+        self.G, self.leaves = G, leaves
+        self.aliases, self.undo = [], []
+
+    def __enter__(self):
+        by_id = {}
+        for t in self.leaves:
+            a = t.detach()
+            a = torch.nn.Parameter(a, requires_grad=True) if isinstance(t, torch.nn.Parameter) else a.requires_grad_(True)
+            by_id[id(t)] = a
+            self.aliases.append(a)
+        if by_id:
+            for m in self.G.modules():
+                for store in (m._parameters, m._buffers):
+                    for name, t in store.items():
+                        if t is not None and id(t) in by_id:
+                            self.undo.append((store, name, t))
+                            store[name] = by_id[id(t)]
+        return self.aliases
+
+    def __exit__(self, *exc):
+        for store, name, t in self.undo:
+            store[name] = t
+        return False
 
 
 def _capture(G, impl, ws, c, uni, kw, leaves, need_grad):
@@ -147,20 +181,22 @@ def _capture(G, impl, ws, c, uni, kw, leaves, need_grad):
         if leaves and keep:
             H.weights_changed()
         fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(fwd, capture_error_mode='thread_local'), H.zero_arena(e.arena_f):
-            with torch.set_grad_enabled(need_grad):
-                out = impl(e.s_ws, e.s_c, render_uniforms=s_uni, **kw)
+        with _aliased_leaves(G, leaves) as aliases:
+            with torch.cuda.graph(fwd, capture_error_mode='thread_local'), H.zero_arena(e.arena_f):
+                with torch.set_grad_enabled(need_grad):
+                    out = impl(e.s_ws, e.s_c, render_uniforms=s_uni, **kw)
         img, raw = out['image'], out['image_raw']
         img4, raw4 = getattr(img, '_eg3d_padded4', None), getattr(raw, '_eg3d_padded4', None)
         outs = [img4 if img4 is not None else img, raw4 if raw4 is not None else raw, out['image_depth']]
         req = [bool(need_grad and o.requires_grad) for o in outs]
         bwd = gins = gouts = None
-        targets = ([e.s_ws] if e.ws_req else []) + ([e.s_c] if e.c_req else []) + list(leaves)
+        targets = ([e.s_ws] if e.ws_req else []) + ([e.s_c] if e.c_req else []) + list(aliases)
         if any(req):
             gouts = [torch.zeros_like(o) for o, r in zip(outs, req) if r]
             bwd = torch.cuda.CUDAGraph()
             with torch.cuda.graph(bwd, pool=fwd.pool(), capture_error_mode='thread_local'), H.zero_arena(e.arena_b):
                 gins = torch.autograd.grad([o for o, r in zip(outs, req) if r], targets, gouts, allow_unused=True)
+        del aliases, targets
         if keep:
             e.fwd, e.bwd = fwd, bwd
             e.s_out = [o.detach() for o in outs]
