@@ -18,43 +18,10 @@
 //
 // Replaces, like conv_igemm.hip, the F.conv2d / F.conv_transpose2d calls under modulated_conv2d (training/networks_stylegan2.py:34-91,
 // torch_utils/ops/conv2d_resample.py:31-43,114-136) and their data gradient, for the layers whose grids fill the chip.
-#include "common.h"
-#include <type_traits>
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+#include "conv_v2_common.h"
 
 namespace {
-
-constexpr int PH = 8, PW = 32;                  // output patch of a block
-constexpr int BN = 128;                         // output channels of a block
-constexpr int A_PARTS = 6;                      // 64-slot wave-instructions per A plane (halo <= 10 x 34 = 340 <= 384 slots)
-constexpr int APLANE = A_PARTS * 64 * 16;       // 6144 bytes
-constexpr int BPLANE = BN * 16;                 // 2048
-constexpr int ABUF = 4 * APLANE, BSLOT = 4 * BPLANE;
-constexpr int LDS_A = 0, LDS_B = 2 * ABUF;
-constexpr int LDS_MAIN = 2 * ABUF + 3 * BSLOT;  // 73728
-constexpr int LDS_N = BN + 4;                   // epilogue staging row (floats)
-constexpr int LDS_EPI = (3 * BN + 4 + 64 * LDS_N) * 4;  // column sums (ds, dbias, dd) + a scalar + 64 staged rows
-constexpr int LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
-
-__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rs, unsigned lds_byte, unsigned voff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(uintptr_t)lds_byte, 16, voff, 0, 0, 0);
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else static_assert(N == 0, "vmcnt immediate");
-}
-
-template <int NTAPS, bool FULL = true>         // FULL: three products per fp32 product; !FULL: high pieces only (EG3D_PREC_F16X1)
+template <int NTAPS, bool FULL = true, bool ATOMIC = false>   // FULL: three products per fp32 product; !FULL: high pieces only (EG3D_PREC_F16X1); ATOMIC: split-K
 __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_params p, const int cls_base) {
     constexpr int APT = (6 + NTAPS - 1) / NTAPS;          // A parts a wave issues per step
     constexpr int NA_TAPS = 6 / APT;                      // ... during the first NA_TAPS taps of a chunk (APT divides 6)
@@ -75,6 +42,9 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
     const int ty = bid % tiles_y; const int n = bid / tiles_y;
     const int y0 = ty * PH, x0 = tx * PW, n0 = n_t * BN;
     const int nchunk = p.Ck / 16;
+    // split-K (EG3D_EPI_ATOMIC): blockIdx.y owns the 16-channel chunks [c0, c1) of the contraction and adds its partial tile to `out`
+    const int ks = p.ksplit > 1 ? p.ksplit : 1;
+    const int c0 = (int)((int64_t)blockIdx.y * nchunk / ks), c1 = (int)((int64_t)(blockIdx.y + 1) * nchunk / ks);
     const int planeA = p.Hi * p.Wi * 16;                   // bytes of one (piece, k-octet) plane of the A image
     // tap extent of this class -> halo geometry
     int dymin = cl.dy[0], dymax = cl.dy[0], dxmin = cl.dx[0], dxmax = cl.dx[0];
@@ -132,13 +102,13 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
     const unsigned b_lane = (unsigned)((wn * 64 + (lane & 31)) * 16 + (lane >> 5) * BPLANE);
     const f16x2 k2m11 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
 
-    // ---- prologue: A(0), B(step 0), B(step 1) --------------------------------------------------------------------------------------------
-    const int S = nchunk * NTAPS;
+    // ---- prologue: A(c0), B(step 0), B(step 1) -------------------------------------------------------------------------------------------
+    const int S = (c1 - c0) * NTAPS;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) issue_A(0, i);
-    issue_B(0, 0, 0);
-    if (S > 1) issue_B(NTAPS > 1 ? 0 : 1, NTAPS > 1 ? 1 : 0, 1);
-    else { issue_B(0, 0, 1); }                       // keeps the wait accounting uniform (never read)
+    for (int i = 0; i < 6; ++i) issue_A(c0, i);
+    issue_B(c0, 0, 0);
+    if (S > 1) issue_B(NTAPS > 1 ? c0 : c0 + 1, NTAPS > 1 ? 1 : 0, 1);
+    else { issue_B(c0, 0, 1); }                      // keeps the wait accounting uniform (never read)
 
     int step = 0;
     auto run_chunk = [&](const int chunk, auto last_tag) {
@@ -161,7 +131,7 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
             {
                 int t2 = tap + 2, c2 = chunk;
                 while (t2 >= NTAPS) { t2 -= NTAPS; c2 += 1; }
-                if (NTAPS == 1 ? c2 < nchunk : (!LAST || c2 == chunk)) issue_B(c2, t2, (step + 2) % 3);
+                if (NTAPS == 1 ? c2 < c1 : (!LAST || c2 == chunk)) issue_B(c2, t2, (step + 2) % 3);
             }
             const unsigned abase = LDS_A + (chunk & 1) * ABUF + a_lane + (unsigned)((cl.dy[tap] * hw + cl.dx[tap]) * 16);
             const unsigned bbase = LDS_B + (step % 3) * BSLOT + b_lane;
@@ -195,154 +165,15 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
             }
         }
     };
-    for (int chunk = 0; chunk + 1 < nchunk; ++chunk) run_chunk(chunk, std::false_type{});
-    run_chunk(nchunk - 1, std::true_type{});
+    for (int chunk = c0; chunk + 1 < c1; ++chunk) run_chunk(chunk, std::false_type{});
+    run_chunk(c1 - 1, std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // ---- epilogue: the tile goes through LDS once (64 rows at a time) so that every global access is 16 bytes per lane ----------------
-    const float out_mul = 1.f / (*p.a_scale * *p.w_scale);              // exact powers of two
-    const int epi = p.epi;
-    float* ds_lds = reinterpret_cast<float*>(smem);
-    float* db_lds = ds_lds + BN;
-    float* dq_lds = ds_lds + 2 * BN;
-    float* sc_lds = ds_lds + 3 * BN;
-    float* stage = ds_lds + 3 * BN + 4;
-    const bool act_on = epi == EG3D_EPI_BWD_ACT;                         // + the producing layer's activation backward (common.h)
-    const bool bwd_like = epi == EG3D_EPI_BWD || act_on;
-    const bool do_ds = bwd_like && p.ds != nullptr && p.xin != nullptr;
-    const eg3d_act_bwd& ab = p.act_bwd;
-    eg3d_act_bwd_consts abc = {};
-    if (act_on) abc = eg3d_act_bwd_setup(ab);
-    const bool row_sums = act_on && (ab.dnoise != nullptr || ab.dstrength != nullptr);
-    if (tid < BN) { ds_lds[tid] = 0.f; db_lds[tid] = 0.f; dq_lds[tid] = 0.f; }
-    if (tid == 0) sc_lds[0] = 0.f;
-    const float strength = (epi == EG3D_EPI_FWD && p.noise != nullptr) ? *p.noise_strength : 0.f;
-    const float act_slope = eg3d_act_pwl_slope(p.act, p.alpha);
-    const int HWo = p.Ho * p.Wo;
-    const int c4 = tid & 31;                            // this thread's float4 column group in every unit it handles
-    const int col = n0 + c4 * 4;
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), scl4 = make_float4(1.f, 1.f, 1.f, 1.f), dsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (epi == EG3D_EPI_FWD && p.bias != nullptr) bias4 = *reinterpret_cast<const float4*>(p.bias + col);
-    if ((epi == EG3D_EPI_FWD || bwd_like) && p.out_scale != nullptr) scl4 = *reinterpret_cast<const float4*>(p.out_scale + (int64_t)n * p.Nc + col);
-    float4 abd4 = make_float4(1.f, 1.f, 1.f, 1.f), abb4 = make_float4(0.f, 0.f, 0.f, 0.f), accb4 = abb4, accd4 = abb4;
-    float accs = 0.f;
-    if (act_on && ab.d != nullptr) abd4 = *reinterpret_cast<const float4*>(ab.d + (int64_t)n * p.Nc + col);
-    if (act_on && ab.bias != nullptr) abb4 = *reinterpret_cast<const float4*>(ab.bias + col);
-    float amax = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                stage[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDS_N + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r] * out_mul;
-        __syncthreads();
-        // 64 rows x 32 float4 units = 2048 units, 8 per thread, in two groups of 4 (loads first, then arithmetic + stores)
-#pragma unroll
-        for (int ug = 0; ug < 8; ug += 4) {
-            int offs[4], pixl[4];
-            float4 va[4], sa[4], sb[4];
-            float nz[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int row = (tid + (ug + u) * 256) >> 5;             // 0..63: wave-row row >> 5, patch column row & 31
-                const int ay = y0 + (row >> 5) * 4 + i, ax = x0 + (row & 31);
-                const bool ok = ay < Ha && ax < Wa;
-                const int pix = (n * p.Ho + ay * p.out_stride + cl.out_py) * p.Wo + ax * p.out_stride + cl.out_px;
-                offs[u] = ok ? pix * p.ldo + col : -1;
-                pixl[u] = pix - n * HWo;
-                va[u] = *reinterpret_cast<const float4*>(stage + row * LDS_N + c4 * 4);
-                sa[u] = make_float4(0.f, 0.f, 0.f, 0.f); sb[u] = sa[u]; nz[u] = 0.f;
-                if (ok && (epi == EG3D_EPI_FWD || bwd_like) && p.addend != nullptr) sa[u] = *reinterpret_cast<const float4*>(p.addend + offs[u]);
-                if (ok && epi == EG3D_EPI_FWD && p.noise != nullptr) nz[u] = p.noise[(int64_t)n * p.noise_nstride + pixl[u]];
-                if (ok && act_on && ab.noise != nullptr) nz[u] = ab.noise[(int64_t)n * ab.noise_nstride + pixl[u]];
-                if (ok && (do_ds || act_on)) sb[u] = *reinterpret_cast<const float4*>(p.xin + offs[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (offs[u] < 0) continue;
-                float4 v = va[u];
-                if (epi == EG3D_EPI_FWD) {
-                    const float nzs = nz[u] * strength;
-                    float e[4] = {v.x * scl4.x + nzs + bias4.x, v.y * scl4.y + nzs + bias4.y, v.z * scl4.z + nzs + bias4.z, v.w * scl4.w + nzs + bias4.w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        e[q] = eg3d_pwl_fwd(e[q], act_slope) * p.gain;
-                        if (p.clamp >= 0.f) e[q] = fminf(fmaxf(e[q], -p.clamp), p.clamp);
-                    }
-                    v = make_float4(e[0] + sa[u].x, e[1] + sa[u].y, e[2] + sa[u].z, e[3] + sa[u].w);
-                } else if (bwd_like) {
-                    if (do_ds) { dsum4.x += v.x * sb[u].x; dsum4.y += v.y * sb[u].y; dsum4.z += v.z * sb[u].z; dsum4.w += v.w * sb[u].w; }
-                    v = make_float4(v.x * scl4.x + sa[u].x, v.y * scl4.y + sa[u].y, v.z * scl4.z + sa[u].z, v.w * scl4.w + sa[u].w);
-                    if (act_on) {                   // v = dout of the layer that produced xin: its activation backward, here
-                        float cs;
-                        v = eg3d_act_bwd_unit(abc, v, sb[u], abd4, abb4, nz[u] * abc.strength, accb4, accd4, cs);
-                        if (row_sums) {             // the 32 lanes of a half-wave hold the 128 channels of this pixel (rows are half-wave uniform)
-                            cs = eg3d_row_group_sum(cs, 32);
-                            if (c4 == 0) {
-                                if (ab.dnoise != nullptr) unsafeAtomicAdd(ab.dnoise + (int64_t)n * ab.dnoise_nstride + pixl[u], cs * abc.strength);
-                                accs += cs * nz[u];
-                            }
-                        }
-                    }
-                }
-                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-                *reinterpret_cast<float4*>(p.out + offs[u]) = v;
-            }
-        }
-    }
-    if (do_ds || act_on) {
-        if (do_ds) {
-            atomicAdd(&ds_lds[c4 * 4 + 0], dsum4.x); atomicAdd(&ds_lds[c4 * 4 + 1], dsum4.y);
-            atomicAdd(&ds_lds[c4 * 4 + 2], dsum4.z); atomicAdd(&ds_lds[c4 * 4 + 3], dsum4.w);
-        }
-        if (act_on) {
-            if (ab.dbias != nullptr) {
-                atomicAdd(&db_lds[c4 * 4 + 0], accb4.x); atomicAdd(&db_lds[c4 * 4 + 1], accb4.y);
-                atomicAdd(&db_lds[c4 * 4 + 2], accb4.z); atomicAdd(&db_lds[c4 * 4 + 3], accb4.w);
-            }
-            if (ab.dd != nullptr) {
-                atomicAdd(&dq_lds[c4 * 4 + 0], accd4.x); atomicAdd(&dq_lds[c4 * 4 + 1], accd4.y);
-                atomicAdd(&dq_lds[c4 * 4 + 2], accd4.z); atomicAdd(&dq_lds[c4 * 4 + 3], accd4.w);
-            }
-            if (ab.dstrength != nullptr && accs != 0.f) atomicAdd(sc_lds, accs);
-        }
-        __syncthreads();
-        if (tid < BN) {
-            if (do_ds) unsafeAtomicAdd(p.ds + (int64_t)n * p.Nc + n0 + tid, ds_lds[tid]);
-            if (act_on && ab.dbias != nullptr) unsafeAtomicAdd(ab.dbias + n0 + tid, db_lds[tid]);
-            if (act_on && ab.dd != nullptr)       // dL/dd = sum dy * z,  z = (pre - bias - noise) / d
-                unsafeAtomicAdd(ab.dd + (int64_t)n * p.Nc + n0 + tid, dq_lds[tid] / (ab.d != nullptr ? ab.d[(int64_t)n * p.Nc + n0 + tid] : 1.f));
-        }
-        if (act_on && ab.dstrength != nullptr && tid == 0 && sc_lds[0] != 0.f) unsafeAtomicAdd(ab.dstrength, sc_lds[0]);
-    }
-    eg3d_commit_amax_block(amax, p.out_amax);    // max|out|: the consumer's operand range (one atomic per block)
+    v2_epilogue<ATOMIC>(p, acc, Ha, Wa, cl.out_py, cl.out_px, n, y0, x0, n0, smem);
 }
 
-// ---- operand preparation -------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void split8(const float* x, float mul, f16x8& h, f16x8& l, float lo_mul) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float a = x[2 * q] * mul, b = x[2 * q + 1] * mul;
-        const fp16x2_t hh = __builtin_amdgcn_cvt_pkrtz(a, b);
-        const float ra = __builtin_amdgcn_fmed3f((a - (float)hh[0]) * lo_mul, -65504.f, 65504.f);
-        const float rb = __builtin_amdgcn_fmed3f((b - (float)hh[1]) * lo_mul, -65504.f, 65504.f);
-        h[2 * q] = (_Float16)hh[0]; h[2 * q + 1] = (_Float16)hh[1];
-        l[2 * q] = (_Float16)ra; l[2 * q + 1] = (_Float16)rb;
-    }
-}
-
-// multiplier that brings `amax` to [2^13, 2^14): an exact power of two
-__device__ __forceinline__ float range_mul(float amax) {
-    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
-    int e;
-    (void)frexpf(amax, &e);                   // amax = m 2^e, m in [0.5, 1)
-    e = e > 100 ? 100 : (e < -100 ? -100 : e);
-    return ldexpf(1.f, 14 - e);
-}
-
+// ---- operand preparation (split8 / range_mul: conv_v2_common.h) ------------------------------------------------------------
 // thread = pixel; loop over the channel octets of its NHWC row; writes are 16 bytes per lane, contiguous over the wave
 __global__ void __launch_bounds__(256) split_act_kernel(const float* __restrict__ x, const float* __restrict__ s, const float* x_amax, const float* s_amax,
                                                         f16x8* __restrict__ out, float* scale_out, int N, int HW, int C, int ldx) {
@@ -368,7 +199,10 @@ __global__ void __launch_bounds__(256) split_act_kernel(const float* __restrict_
     const int noct = C / 8;
     const float* xr = x + pix * ldx;
     const float* sr = s ? s + (int64_t)n * C : nullptr;
-    for (int ko = 0; ko < noct; ++ko) {
+    // blockIdx.y owns a group of channel octets: small images (128^2 and below: 64 blocks of pixels) would otherwise leave most CUs idle
+    const int og = (noct + gridDim.y - 1) / gridDim.y;
+    const int ko_end = min(noct, (int)(blockIdx.y + 1) * og);
+    for (int ko = blockIdx.y * og; ko < ko_end; ++ko) {
         float v[8];
         const float4 v0 = *reinterpret_cast<const float4*>(xr + ko * 8), v1 = *reinterpret_cast<const float4*>(xr + ko * 8 + 4);
         v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
@@ -378,6 +212,66 @@ __global__ void __launch_bounds__(256) split_act_kernel(const float* __restrict_
         }
         f16x8 h, l;
         split8(v, mul, h, l, 2048.f);
+        out[((int64_t)(n * 2 + 0) * noct + ko) * HW + pp] = h;
+        out[((int64_t)(n * 2 + 1) * noct + ko) * HW + pp] = l;
+    }
+}
+
+// Same pass through LDS: the loads run along the channel axis (a wave-instruction = whole 512-byte pixel rows), the stores along the
+// pixel axis (1 KB runs of one (piece, octet) plane).  Block = 64 pixels x CH channels.  The thread-per-pixel form above reads 32 bytes
+// per lane from 64 different rows per instruction: 3.6 TB/s at 512^2 x 128; and one block per 256 pixels leaves a 64^2 image on 16 CUs.
+template <int CH>
+__global__ void __launch_bounds__(256) split_act_lds_kernel(const float* __restrict__ x, const float* __restrict__ s, const float* x_amax, const float* s_amax,
+                                                            f16x8* __restrict__ out, float* scale_out, int N, int HW, int C, int ldx) {
+    constexpr int TP = 64, PITCH = CH + 4, F4 = CH / 4, PPP = 256 / F4;          // pixels per load pass
+    __shared__ __attribute__((aligned(16))) float tile[TP * PITCH];
+    __shared__ float red[4];
+    float smax = 1.f;
+    if (s_amax != nullptr) {
+        smax = *s_amax;
+    } else if (s != nullptr) {
+        float m = 0.f;
+        for (int i = threadIdx.x; i < N * C; i += 256) m = fmaxf(m, fabsf(s[i]));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        smax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    }
+    const float mul = range_mul(*x_amax * smax);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *scale_out = mul;
+    const int64_t npix = (int64_t)N * HW;
+    const int64_t pix0 = (int64_t)blockIdx.x * TP;
+    const int c0 = blockIdx.y * CH;
+    const int f4 = threadIdx.x % F4, pl = threadIdx.x / F4;
+#pragma unroll
+    for (int pass = 0; pass < TP / PPP; ++pass) {
+        const int p = pl + pass * PPP;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pix0 + p < npix) v = *reinterpret_cast<const float4*>(x + (pix0 + p) * ldx + c0 + f4 * 4);
+        *reinterpret_cast<float4*>(tile + p * PITCH + f4 * 4) = v;
+    }
+    __syncthreads();
+    const int p = threadIdx.x & 63, og = threadIdx.x >> 6;                        // pixel, group of CH / 32 octets
+    const int64_t pix = pix0 + p;
+    if (pix >= npix) return;
+    const int n = (int)(pix / HW);
+    const int64_t pp = pix - (int64_t)n * HW;
+    const int noct = C / 8;
+    const float* sr = s ? s + (int64_t)n * C + c0 : nullptr;
+#pragma unroll
+    for (int k = 0; k < CH / 32; ++k) {
+        const int kl = og * (CH / 32) + k;                                        // octet inside the chunk
+        float v[8];
+        const float4 v0 = *reinterpret_cast<const float4*>(tile + p * PITCH + kl * 8), v1 = *reinterpret_cast<const float4*>(tile + p * PITCH + kl * 8 + 4);
+        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+        if (sr) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] *= sr[kl * 8 + q];
+        }
+        f16x8 h, l;
+        split8(v, mul, h, l, 2048.f);
+        const int ko = c0 / 8 + kl;
         out[((int64_t)(n * 2 + 0) * noct + ko) * HW + pp] = h;
         out[((int64_t)(n * 2 + 1) * noct + ko) * HW + pp] = l;
     }
@@ -426,13 +320,13 @@ __global__ void __launch_bounds__(256) split_w_kernel(const float* __restrict__ 
     out[((((int64_t)tap * (I / 16) + chunk) * 2 + 1) * 2 + koct) * O + o] = l;
 }
 
-std::atomic<uint64_t> g_attr[5];
+std::atomic<uint64_t> g_attr[7];
 
-template <int NTAPS, bool FULL = true>
+template <int NTAPS, bool FULL = true, bool ATOMIC = false>
 int launch_v2(const eg3d_conv_v2_params& p, int cls_base, int ncls, int max_tiles, hipStream_t st, int slot) {
-    auto kern = conv_v2_kernel<NTAPS, FULL>;
+    auto kern = conv_v2_kernel<NTAPS, FULL, ATOMIC>;
     if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, g_attr[slot])) return e;
-    hipLaunchKernelGGL(kern, dim3(max_tiles, 1, ncls), dim3(256), LDS_BYTES, st, p, cls_base);
+    hipLaunchKernelGGL(kern, dim3(max_tiles, p.ksplit > 1 ? p.ksplit : 1, ncls), dim3(256), LDS_BYTES, st, p, cls_base);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }
@@ -447,7 +341,10 @@ extern "C" int eg3d_conv2d_v2_supported(const eg3d_conv_v2_params* pp) {
     if (p.products != 0 && p.products != 1 && p.products != 3) return 0;
     if (p.products == 1)                                  // the single-product instantiation exists for the 3x3 classes
         for (int c = 0; c < p.ncls; ++c) if (p.cls[c].ntaps != 9) return 0;
-    if (p.epi != EG3D_EPI_STORE && p.epi != EG3D_EPI_FWD && p.epi != EG3D_EPI_BWD && p.epi != EG3D_EPI_BWD_ACT) return 0;
+    if (p.epi != EG3D_EPI_STORE && p.epi != EG3D_EPI_FWD && p.epi != EG3D_EPI_BWD && p.epi != EG3D_EPI_BWD_ACT && p.epi != EG3D_EPI_ATOMIC) return 0;
+    if (p.epi == EG3D_EPI_ATOMIC)                         // the split-K instantiations exist for the 3x3 classes
+        for (int c = 0; c < p.ncls; ++c) if (p.cls[c].ntaps != 9) return 0;
+    if (p.ksplit > 1 && (p.epi != EG3D_EPI_ATOMIC || p.ksplit > p.Ck / 16 || p.ksplit > 65535)) return 0;     // every slice owns >= 1 chunk
     if (p.epi == EG3D_EPI_FWD && !eg3d_act_is_pwl(p.act)) return 0;
     if (p.epi == EG3D_EPI_BWD_ACT) {
         const eg3d_act_bwd& ab = p.act_bwd;
@@ -490,7 +387,10 @@ extern "C" int eg3d_conv2d_v2(const eg3d_conv_v2_params* pp, void* stream) {
         }
         int rc;
         switch (p.cls[c].ntaps) {
-            case 9: rc = p.products == 1 ? launch_v2<9, false>(p, c, e - c, max_tiles, st, 4) : launch_v2<9>(p, c, e - c, max_tiles, st, 0); break;
+            case 9:
+                if (p.epi == EG3D_EPI_ATOMIC) rc = p.products == 1 ? launch_v2<9, false, true>(p, c, e - c, max_tiles, st, 6) : launch_v2<9, true, true>(p, c, e - c, max_tiles, st, 5);
+                else rc = p.products == 1 ? launch_v2<9, false>(p, c, e - c, max_tiles, st, 4) : launch_v2<9>(p, c, e - c, max_tiles, st, 0);
+                break;
             case 4: rc = launch_v2<4>(p, c, e - c, max_tiles, st, 1); break;
             case 2: rc = launch_v2<2>(p, c, e - c, max_tiles, st, 2); break;
             default: rc = launch_v2<1>(p, c, e - c, max_tiles, st, 3); break;
@@ -508,7 +408,19 @@ extern "C" int eg3d_split_activation(const float* x, const float* in_scale, cons
     if (!x || !x_amax || !image || !scale_out || N <= 0 || H <= 0 || W <= 0 || C < 8 || (C & 7) || (ldx & 3) || ldx < C) return EG3D_ERR_INVALID;
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(image) & 15)) return EG3D_ERR_UNSUPPORTED;
     const int64_t pix = (int64_t)N * H * W;
-    hipLaunchKernelGGL(split_act_kernel, dim3((unsigned)((pix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, in_scale, x_amax, s_amax,
+    if (C % 128 == 0 || C == 64) {                  // through LDS: channel-major loads, pixel-major stores
+        const dim3 grid((unsigned)((pix + 63) / 64), C % 128 == 0 ? C / 128 : 1);
+        if (C % 128 == 0)
+            hipLaunchKernelGGL(split_act_lds_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, x, in_scale, x_amax, s_amax, reinterpret_cast<f16x8*>(image), scale_out, N, H * W, C, ldx);
+        else
+            hipLaunchKernelGGL(split_act_lds_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, x, in_scale, x_amax, s_amax, reinterpret_cast<f16x8*>(image), scale_out, N, H * W, C, ldx);
+        EG3D_LAUNCH_CHECK();
+        return EG3D_OK;
+    }
+    const int pb = (int)((pix + 255) / 256), noct = C / 8;
+    int gy = 1;                                     // octet groups: >= 4 octets (one 128-byte line of the pixel's row) per thread, ~2048 blocks
+    while (gy * 2 <= noct / 4 && pb * gy < 2048) gy *= 2;
+    hipLaunchKernelGGL(split_act_kernel, dim3((unsigned)pb, gy), dim3(256), 0, (hipStream_t)stream, x, in_scale, x_amax, s_amax,
                        reinterpret_cast<f16x8*>(image), scale_out, N, H * W, C, ldx);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;

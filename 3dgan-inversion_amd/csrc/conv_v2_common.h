@@ -1,0 +1,213 @@
+// Shared pieces of the pre-split convolution kernels (conv_v2.hip: stride-1 tap classes; conv_v2_s2adj.hip: the stride-2 adjoint of the
+// up-sampling layers): LDS geometry of the 8 x 32 patch x 128 channel tile, the LDS-DMA helper, counted vmcnt waits and the fused epilogue.
+#pragma once
+#include "common.h"
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int PH = 8, PW = 32;                  // output patch of a block
+constexpr int BN = 128;                         // output channels of a block
+constexpr int A_PARTS = 6;                      // 64-slot wave-instructions per A plane (halo <= 10 x 34 = 340 <= 384 slots)
+constexpr int APLANE = A_PARTS * 64 * 16;       // 6144 bytes
+constexpr int BPLANE = BN * 16;                 // 2048
+constexpr int ABUF = 4 * APLANE, BSLOT = 4 * BPLANE;
+constexpr int LDS_A = 0, LDS_B = 2 * ABUF;
+constexpr int LDS_MAIN = 2 * ABUF + 3 * BSLOT;  // 73728
+constexpr int LDS_N = BN + 4;                   // epilogue staging row (floats)
+constexpr int LDS_EPI = (3 * BN + 4 + 64 * LDS_N) * 4;  // column sums (ds, dbias, dd) + a scalar + 64 staged rows
+constexpr int LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rs, unsigned lds_byte, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(uintptr_t)lds_byte, 16, voff, 0, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else static_assert(N == 0, "vmcnt immediate");
+}
+
+
+// ---- operand preparation -------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split8(const float* x, float mul, f16x8& h, f16x8& l, float lo_mul) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a = x[2 * q] * mul, b = x[2 * q + 1] * mul;
+        const fp16x2_t hh = __builtin_amdgcn_cvt_pkrtz(a, b);
+        const float ra = __builtin_amdgcn_fmed3f((a - (float)hh[0]) * lo_mul, -65504.f, 65504.f);
+        const float rb = __builtin_amdgcn_fmed3f((b - (float)hh[1]) * lo_mul, -65504.f, 65504.f);
+        h[2 * q] = (_Float16)hh[0]; h[2 * q + 1] = (_Float16)hh[1];
+        l[2 * q] = (_Float16)ra; l[2 * q + 1] = (_Float16)rb;
+    }
+}
+
+// multiplier that brings `amax` to [2^13, 2^14): an exact power of two
+__device__ __forceinline__ float range_mul(float amax) {
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+    int e;
+    (void)frexpf(amax, &e);                   // amax = m 2^e, m in [0.5, 1)
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    return ldexpf(1.f, 14 - e);
+}
+
+
+// ---- epilogue of a 256-cell x 128-channel tile held as acc[4][2] (wave (wm, wn): patch rows 4 wm .. 4 wm + 3, channels 64 wn .. + 63) ---
+// Output cell (ay, ax) of the class grid Ha x Wa goes to pixel (ay * out_stride + out_py, ax * out_stride + out_px).  Must be entered by
+// the whole block after the last LDS read of the main loop (it re-uses the dynamic LDS).
+template <bool ATOMIC>        // compile-time: the split-K form must not cost the fused epilogues a register (the two paths together spilled 30 VGPRs)
+__device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16 (&acc)[4][2], const int Ha, const int Wa, const int out_py, const int out_px,
+                                            const int n, const int y0, const int x0, const int n0, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    struct { int out_py, out_px; } cl = {out_py, out_px};
+    // ---- epilogue: the tile goes through LDS once (64 rows at a time) so that every global access is 16 bytes per lane ----------------
+    const float out_mul = 1.f / (*p.a_scale * *p.w_scale);              // exact powers of two
+    const int epi = p.epi;
+    if constexpr (ATOMIC) {
+        // split-K partial tile: atomics straight from the accumulator layout, one lane per channel -- a wave-instruction covers two runs of
+        // 32 consecutive floats.  (Through the staged float4 path each lane would own 4 consecutive channels: four instructions that each
+        // touch sixteen 64-byte lines -- measured 2.3x SLOWER than the loader-split kernel on the 128^2 x 256 layer.)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ay = y0 + wm * 4 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ax = x0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (ay >= Ha || ax >= Wa) continue;
+                float* o = p.out + ((int64_t)(n * p.Ho + ay * p.out_stride + cl.out_py) * p.Wo + ax * p.out_stride + cl.out_px) * p.ldo + n0 + wn * 64 + (lane & 31);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) unsafeAtomicAdd(o + j * 32, acc[i][j][r] * out_mul);
+            }
+        }
+    } else {
+    float* ds_lds = reinterpret_cast<float*>(smem);
+    float* db_lds = ds_lds + BN;
+    float* dq_lds = ds_lds + 2 * BN;
+    float* sc_lds = ds_lds + 3 * BN;
+    float* stage = ds_lds + 3 * BN + 4;
+    const bool act_on = epi == EG3D_EPI_BWD_ACT;                         // + the producing layer's activation backward (common.h)
+    const bool bwd_like = epi == EG3D_EPI_BWD || act_on;
+    const bool do_ds = bwd_like && p.ds != nullptr && p.xin != nullptr;
+    const eg3d_act_bwd& ab = p.act_bwd;
+    eg3d_act_bwd_consts abc = {};
+    if (act_on) abc = eg3d_act_bwd_setup(ab);
+    const bool row_sums = act_on && (ab.dnoise != nullptr || ab.dstrength != nullptr);
+    if (tid < BN) { ds_lds[tid] = 0.f; db_lds[tid] = 0.f; dq_lds[tid] = 0.f; }
+    if (tid == 0) sc_lds[0] = 0.f;
+    const float strength = (epi == EG3D_EPI_FWD && p.noise != nullptr) ? *p.noise_strength : 0.f;
+    const float act_slope = eg3d_act_pwl_slope(p.act, p.alpha);
+    const int HWo = p.Ho * p.Wo;
+    const int c4 = tid & 31;                            // this thread's float4 column group in every unit it handles
+    const int col = n0 + c4 * 4;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), scl4 = make_float4(1.f, 1.f, 1.f, 1.f), dsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (epi == EG3D_EPI_FWD && p.bias != nullptr) bias4 = *reinterpret_cast<const float4*>(p.bias + col);
+    if ((epi == EG3D_EPI_FWD || bwd_like) && p.out_scale != nullptr) scl4 = *reinterpret_cast<const float4*>(p.out_scale + (int64_t)n * p.Nc + col);
+    float4 abd4 = make_float4(1.f, 1.f, 1.f, 1.f), abb4 = make_float4(0.f, 0.f, 0.f, 0.f), accb4 = abb4, accd4 = abb4;
+    float accs = 0.f;
+    if (act_on && ab.d != nullptr) abd4 = *reinterpret_cast<const float4*>(ab.d + (int64_t)n * p.Nc + col);
+    if (act_on && ab.bias != nullptr) abb4 = *reinterpret_cast<const float4*>(ab.bias + col);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stage[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDS_N + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r] * out_mul;
+        __syncthreads();
+        // 64 rows x 32 float4 units = 2048 units, 8 per thread, in two groups of 4 (loads first, then arithmetic + stores)
+#pragma unroll
+        for (int ug = 0; ug < 8; ug += 4) {
+            int offs[4], pixl[4];
+            float4 va[4], sa[4], sb[4];
+            float nz[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = (tid + (ug + u) * 256) >> 5;             // 0..63: wave-row row >> 5, patch column row & 31
+                const int ay = y0 + (row >> 5) * 4 + i, ax = x0 + (row & 31);
+                const bool ok = ay < Ha && ax < Wa;
+                const int pix = (n * p.Ho + ay * p.out_stride + cl.out_py) * p.Wo + ax * p.out_stride + cl.out_px;
+                offs[u] = ok ? pix * p.ldo + col : -1;
+                pixl[u] = pix - n * HWo;
+                va[u] = *reinterpret_cast<const float4*>(stage + row * LDS_N + c4 * 4);
+                sa[u] = make_float4(0.f, 0.f, 0.f, 0.f); sb[u] = sa[u]; nz[u] = 0.f;
+                if (ok && (epi == EG3D_EPI_FWD || bwd_like) && p.addend != nullptr) sa[u] = *reinterpret_cast<const float4*>(p.addend + offs[u]);
+                if (ok && epi == EG3D_EPI_FWD && p.noise != nullptr) nz[u] = p.noise[(int64_t)n * p.noise_nstride + pixl[u]];
+                if (ok && act_on && ab.noise != nullptr) nz[u] = ab.noise[(int64_t)n * ab.noise_nstride + pixl[u]];
+                if (ok && (do_ds || act_on)) sb[u] = *reinterpret_cast<const float4*>(p.xin + offs[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (offs[u] < 0) continue;
+                float4 v = va[u];
+                if (epi == EG3D_EPI_FWD) {
+                    const float nzs = nz[u] * strength;
+                    float e[4] = {v.x * scl4.x + nzs + bias4.x, v.y * scl4.y + nzs + bias4.y, v.z * scl4.z + nzs + bias4.z, v.w * scl4.w + nzs + bias4.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        e[q] = eg3d_pwl_fwd(e[q], act_slope) * p.gain;
+                        if (p.clamp >= 0.f) e[q] = fminf(fmaxf(e[q], -p.clamp), p.clamp);
+                    }
+                    v = make_float4(e[0] + sa[u].x, e[1] + sa[u].y, e[2] + sa[u].z, e[3] + sa[u].w);
+                } else if (bwd_like) {
+                    if (do_ds) { dsum4.x += v.x * sb[u].x; dsum4.y += v.y * sb[u].y; dsum4.z += v.z * sb[u].z; dsum4.w += v.w * sb[u].w; }
+                    v = make_float4(v.x * scl4.x + sa[u].x, v.y * scl4.y + sa[u].y, v.z * scl4.z + sa[u].z, v.w * scl4.w + sa[u].w);
+                    if (act_on) {                   // v = dout of the layer that produced xin: its activation backward, here
+                        float cs;
+                        v = eg3d_act_bwd_unit(abc, v, sb[u], abd4, abb4, nz[u] * abc.strength, accb4, accd4, cs);
+                        if (row_sums) {             // the 32 lanes of a half-wave hold the 128 channels of this pixel (rows are half-wave uniform)
+                            cs = eg3d_row_group_sum(cs, 32);
+                            if (c4 == 0) {
+                                if (ab.dnoise != nullptr) unsafeAtomicAdd(ab.dnoise + (int64_t)n * ab.dnoise_nstride + pixl[u], cs * abc.strength);
+                                accs += cs * nz[u];
+                            }
+                        }
+                    }
+                }
+                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+                *reinterpret_cast<float4*>(p.out + offs[u]) = v;
+            }
+        }
+    }
+    if (do_ds || act_on) {
+        if (do_ds) {
+            atomicAdd(&ds_lds[c4 * 4 + 0], dsum4.x); atomicAdd(&ds_lds[c4 * 4 + 1], dsum4.y);
+            atomicAdd(&ds_lds[c4 * 4 + 2], dsum4.z); atomicAdd(&ds_lds[c4 * 4 + 3], dsum4.w);
+        }
+        if (act_on) {
+            if (ab.dbias != nullptr) {
+                atomicAdd(&db_lds[c4 * 4 + 0], accb4.x); atomicAdd(&db_lds[c4 * 4 + 1], accb4.y);
+                atomicAdd(&db_lds[c4 * 4 + 2], accb4.z); atomicAdd(&db_lds[c4 * 4 + 3], accb4.w);
+            }
+            if (ab.dd != nullptr) {
+                atomicAdd(&dq_lds[c4 * 4 + 0], accd4.x); atomicAdd(&dq_lds[c4 * 4 + 1], accd4.y);
+                atomicAdd(&dq_lds[c4 * 4 + 2], accd4.z); atomicAdd(&dq_lds[c4 * 4 + 3], accd4.w);
+            }
+            if (ab.dstrength != nullptr && accs != 0.f) atomicAdd(sc_lds, accs);
+        }
+        __syncthreads();
+        if (tid < BN) {
+            if (do_ds) unsafeAtomicAdd(p.ds + (int64_t)n * p.Nc + n0 + tid, ds_lds[tid]);
+            if (act_on && ab.dbias != nullptr) unsafeAtomicAdd(ab.dbias + n0 + tid, db_lds[tid]);
+            if (act_on && ab.dd != nullptr)       // dL/dd = sum dy * z,  z = (pre - bias - noise) / d
+                unsafeAtomicAdd(ab.dd + (int64_t)n * p.Nc + n0 + tid, dq_lds[tid] / (ab.d != nullptr ? ab.d[(int64_t)n * p.Nc + n0 + tid] : 1.f));
+        }
+        if (act_on && ab.dstrength != nullptr && tid == 0 && sc_lds[0] != 0.f) unsafeAtomicAdd(ab.dstrength, sc_lds[0]);
+    }
+    eg3d_commit_amax_block(amax, p.out_amax);    // max|out|: the consumer's operand range (one atomic per block)
+    }
+}
+
+}  // namespace

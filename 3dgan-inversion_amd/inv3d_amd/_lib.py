@@ -60,7 +60,14 @@ class ConvV2Params(C.Structure):
                 ('ncls', C.c_int32), ('cls', ConvClass * 4), ('epi', C.c_int32),
                 ('out_scale', C.c_void_p), ('bias', C.c_void_p), ('noise', C.c_void_p), ('noise_nstride', C.c_int64),
                 ('noise_strength', C.c_void_p), ('act', C.c_int32), ('alpha', C.c_float), ('gain', C.c_float), ('clamp', C.c_float),
-                ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p), ('out_amax', C.c_void_p), ('act_bwd', ActBwd), ('products', C.c_int32)]
+                ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p), ('out_amax', C.c_void_p), ('act_bwd', ActBwd), ('products', C.c_int32), ('ksplit', C.c_int32)]
+
+
+class ConvUp2Params(C.Structure):
+    _fields_ = [('a', C.c_void_p), ('w', C.c_void_p), ('a_scale', C.c_void_p), ('w_scale', C.c_void_p), ('out', C.c_void_p),
+                ('N', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32), ('Ck', C.c_int32), ('Nc', C.c_int32),
+                ('Hc', C.c_int32), ('Wc', C.c_int32), ('Ho', C.c_int32), ('Wo', C.c_int32), ('ldo', C.c_int32),
+                ('wtap', C.c_int32 * 9), ('epi', C.c_int32), ('products', C.c_int32), ('ksplit', C.c_int32)]
 
 
 class WgradParams(C.Structure):
@@ -139,6 +146,12 @@ _SIGS = {
     'eg3d_split_activation': (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]),
     'eg3d_split_weight': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
     'eg3d_absmax': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'eg3d_conv2d_v2_s2adj_supported': (C.c_int, [C.POINTER(ConvV2Params)]),
+    'eg3d_conv2d_v2_s2adj': (C.c_int, [C.POINTER(ConvV2Params), C.c_void_p]),
+    'eg3d_fir44_adjoint_split_bytes': (C.c_int64, [C.c_int] * 4),
+    'eg3d_fir44_adjoint_split': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_float, C.c_void_p]),
+    'eg3d_conv2d_up2_supported': (C.c_int, [C.POINTER(ConvUp2Params)]),
+    'eg3d_conv2d_up2': (C.c_int, [C.POINTER(ConvUp2Params), C.c_void_p]),
     'eg3d_probe_mfma_f16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'eg3d_modconv_epilogue_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int64,

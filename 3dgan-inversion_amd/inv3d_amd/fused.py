@@ -147,6 +147,18 @@ def prepack_weights(layers):
     return len(items)
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """One auxiliary stream per device for small launches that are independent of the kernel issued next (forked and joined around it)."""
+    key = str(device)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def _zeros_views(device, *shapes):
     """Several small zero-initialised accumulators (targets of atomics) from ONE allocation and ONE fill launch.  A shape of
     None yields None.  Every view starts on a 16-byte boundary."""
@@ -261,13 +273,22 @@ class ModConvLayerFn(torch.autograd.Function):
         #  classes on ragged 257-wide grids -- 196 vs 174 us on 256^2 x 256 -> 513^2 x 128, 116 vs 67 us on 128^2 x 256; opt-in)
         v2 = H.USE_V2 and prec in ('f16x3', 'f16x1') and ks == 1 and (up == 1 or (H.V2_CONVT and prec == 'f16x3')) and H.conv_v2_supported(Ci, Co, cls, N)
         nprod = 1 if prec == 'f16x1' else 3
+        # 3x3 layers whose grids cannot fill the chip (128^2 x 256, 64^2 x 512, 32^2 x 512): the pre-split kernel with the contraction
+        # split over workgroups (atomic partial tiles) + the finishing epilogue pass
+        ks2 = H.conv_v2_ksplit(Ci, Co, cls, N) if (up == 1 and not v2 and prec in ('f16x3', 'f16x1')) else 0
+        # up-sampling layers: the four output parities of the transposed conv from one workgroup per input patch (csrc/conv_v2_up.hip)
+        ksu = H.conv_up2_plan(Ci, Co, Hi, Wi, N) if (up == 2 and not v2 and kh == 3 and kw == 3 and prec in ('f16x3', 'f16x1')) else None
         epi_kw = dict(noise=nz, noise_nstride=nstride or 0, noise_strength=noise_strength, bias=b, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv)
-        if v2:          # pre-split operands: modulation, range normalisation and the fp16 split happen once, not per tile and tap
+        if v2 or ks2 or ksu:   # pre-split operands: modulation, range normalisation and the fp16 split happen once, not per tile and tap
             aimg = H.split_activation(x, H.amax_of(x), in_scale=styles)
             wimg = cache.get_split(weight)[0]
         if up == 1:
             if v2:
                 H.conv_v2(aimg, wimg, out, cls, epi=L.EPI_FWD, out_scale=d, out_amax=amax_out, algo_flops=aflops, products=nprod, **epi_kw)
+            elif ks2:
+                z = H.zeros_cl(N, Co, Ho, Wo, x.device)
+                H.conv_v2(aimg, wimg, z, cls, epi=L.EPI_ATOMIC, ksplit=ks2, algo_flops=aflops, products=nprod)
+                H.epilogue_fwd(z, out, d=d, out_amax=amax_out, **epi_kw)
             elif ks == 1:
                 H.conv_igemm(x, wf, Ci, Co, out, cls, in_scale=styles, epi=L.EPI_FWD, out_scale=d, algo_flops=aflops, precision=ig_prec, out_amax=amax_out, w_pieces=wfp,
                              **epi_kw)
@@ -276,7 +297,24 @@ class ModConvLayerFn(torch.autograd.Function):
                 H.conv_igemm(x, wf, Ci, Co, z, cls, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=ig_prec, w_pieces=wfp)
                 H.epilogue_fwd(z, out, d=d, out_amax=amax_out, **epi_kw)
         else:
-            if v2:
+            if ksu:
+                ksplit, ragged = ksu
+                z = H.zeros_cl(N, Co, Hz, Wz, x.device) if ksplit > 1 else H.empty_cl(N, Co, Hz, Wz, x.device)
+                if ragged:      # the full (Hi + 1) x (Wi + 1) cell grid still fits one round of workgroups
+                    H.conv_up2(aimg, wimg, z, epi=L.EPI_ATOMIC if ksplit > 1 else L.EPI_STORE, ksplit=ksplit, products=nprod, algo_flops=aflops)
+                else:
+                    # main grid (Hi x Wi cells, perfectly tiled) on the fused-parity kernel; the last output row / column (1-D problems: 25 us
+                    # of latency for 0.1 GFLOP) as four small tap classes of the loader-split kernel on a forked stream (a parallel branch of
+                    # a captured graph): it writes pixels the main launch does not touch
+                    cur = torch.cuda.current_stream()
+                    side = _side_stream(x.device)
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        H.conv_igemm(x, wf, Ci, Co, z, H.up2_border_classes(Hi, Wi), out_stride=up, in_scale=styles, epi=L.EPI_STORE, algo_flops=0.0,
+                                     precision=ig_prec, w_pieces=wfp)
+                    H.conv_up2(aimg, wimg, z, Hc=Hi, Wc=Wi, epi=L.EPI_ATOMIC if ksplit > 1 else L.EPI_STORE, ksplit=ksplit, products=nprod, algo_flops=aflops)
+                    cur.wait_stream(side)
+            elif v2:
                 z = H.empty_cl(N, Co, Hz, Wz, x.device)
                 H.conv_v2(aimg, wimg, z, cls, out_stride=up, epi=L.EPI_STORE, algo_flops=aflops)
             elif ks == 1:
@@ -352,11 +390,21 @@ class ModConvLayerFn(torch.autograd.Function):
                            bias=b, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv, dbias=dbias, dd=dd, dnoise=dnoise,
                            dnoise_nstride=nstride or 0, dstrength=dstrength, dz_amax=amax)
         amul = 1.0 if up == 1 else float(up * up)       # g = FIR(dz) * up^2 with a non-negative unit-sum filter: |g| <= up^2 max|dz|
+        gimg = None
         if up == 1:
             g = dz
             cls_adj = H.classes_corr_adjoint(Hi, Wi, kh, kw, kh // 2)
             in_stride = 1
             cls_w, out_stride_w = H.classes_corr(Ho, Wo, kh, kw, kh // 2), 1
+        elif (not need_w and (need_x or need_s) and up == 2 and kh == 3 and kw == 3 and prec in ('f16x3', 'f16x1') and amax is not None
+              and H.conv_s2adj_ok(Co, Ci, Hi, Wi, N)):
+            # frozen weights (latent projection): the FIR adjoint writes the data gradient's operand directly as parity-split fp16 images
+            # (range bound up^2 max|dz|) -- no fp32 g, no strided gathers in the conv loader
+            g = None
+            gimg = H.fir44_adjoint_split(dz, amax, gain=float(up * up))
+            cls_adj = H.classes_convT_adjoint(Hi, Wi, kh, kw, up)
+            in_stride = up
+            cls_w, out_stride_w = None, up
         else:
             g = H.upfirdn2d_nhwc(dz, fir44(dev), pad=(2, 2, 2, 2), flip=True, gain=float(up * up))     # adjoint of the FIR
             cls_adj = H.classes_convT_adjoint(Hi, Wi, kh, kw, up)
@@ -370,9 +418,22 @@ class ModConvLayerFn(torch.autograd.Function):
             # x is some layer's output: if that layer left a record, this launch also runs ITS activation backward (dx then holds its dz)
             prod, spec, pacc = _act_bwd_for(x, dev) if (need_x and ctx.fuse_input) else (None, None, None)
             fkw = dict(act_bwd=spec, out_amax=pacc[4]) if prod is not None else {}
-            if H.USE_V2 and up == 1 and ks == 1 and prec in ('f16x3', 'f16x1') and H.conv_v2_supported(Co, Ci, cls_adj, N):
+            ks2 = H.conv_v2_ksplit(Co, Ci, cls_adj, N) if (up == 1 and prec in ('f16x3', 'f16x1') and amax is not None) else 0
+            if gimg is not None:
+                did = H.conv_v2_s2adj(gimg, cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, algo_flops=aflops,
+                                      products=1 if prec == 'f16x1' else 3, **fkw)
+            elif H.USE_V2 and up == 1 and ks == 1 and prec in ('f16x3', 'f16x1') and H.conv_v2_supported(Co, Ci, cls_adj, N):
                 did = H.conv_v2(H.split_activation(g, amax), cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds,
                                 algo_flops=aflops, products=1 if prec == 'f16x1' else 3, **fkw)
+            elif ks2:                              # under-filled 3x3 grid: split-K launch of the pre-split kernel, then the finishing pass
+                z = H.zeros_cl(N, Ci, Hi, Wi, dev)
+                H.conv_v2(H.split_activation(g, amax), cache.get_split(weight)[1], z, cls_adj, epi=L.EPI_ATOMIC, ksplit=ks2, algo_flops=aflops,
+                          products=1 if prec == 'f16x1' else 3)
+                did = prod is not None and Ci % 4 == 0 and Ci <= 1024
+                if did:
+                    H.dgrad_finish_act(z, x, styles, dx, spec, ds=ds, dz_amax=pacc[4])
+                else:
+                    H.dgrad_finish(z, x, styles, dx, ds=ds)
             elif ks == 1:
                 did = H.conv_igemm(g, wa, Co, Ci, dx, cls_adj, in_stride=in_stride, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, algo_flops=aflops, w_pieces=wap,
                                    precision=ig_prec, a_amax=amax, a_amax_mul=amul, **fkw)

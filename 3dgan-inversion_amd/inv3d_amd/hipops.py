@@ -503,8 +503,12 @@ def _conv_v2_params(a, w, out, classes, out_stride, epi, out_scale, bias, noise,
     return p
 
 
-def conv_v2_supported(Ck, Nc, classes, N=1):
-    """Geometry the pre-split kernel takes (see eg3d_conv2d_v2_supported) AND enough 256 x 128 tiles to fill the chip."""
+def conv_v2_tiles(Nc, classes, N=1):
+    """256-cell x 128-channel tiles of a launch of the pre-split kernel."""
+    return sum(N * -(-c.Ha // 8) * -(-c.Wa // 32) for c in classes) * (Nc // 128)
+
+
+def conv_v2_geometry_ok(Ck, Nc, classes):
     if Ck % 16 or Nc % 128 or CONV_MODE != 'auto':
         return False
     for c in classes:
@@ -513,24 +517,49 @@ def conv_v2_supported(Ck, Nc, classes, N=1):
         dys, dxs = [c.dy[t] for t in range(c.ntaps)], [c.dx[t] for t in range(c.ntaps)]
         if max(dys) - min(dys) > 2 or max(dxs) - min(dxs) > 2:
             return False
-    tiles = sum(N * -(-c.Ha // 8) * -(-c.Wa // 32) for c in classes) * (Nc // 128)
-    return tiles >= V2_MIN_TILES
+    return True
+
+
+def conv_v2_supported(Ck, Nc, classes, N=1):
+    """Geometry the pre-split kernel takes (see eg3d_conv2d_v2_supported) AND enough 256 x 128 tiles to fill the chip."""
+    return conv_v2_geometry_ok(Ck, Nc, classes) and conv_v2_tiles(Nc, classes, N) >= V2_MIN_TILES
+
+
+def conv_v2_ksplit(Ck, Nc, classes, N=1):
+    """Split-K factor for a 3x3 layer whose grid cannot fill the chip with 256 x 128 tiles (128^2 x 256: 128 tiles, 64^2 x 512: 64):
+    slices of >= V2_KS_MIN_CHUNKS 16-channel chunks, aiming at two workgroups per CU.  0 = leave the layer to the loader-split kernel."""
+    if not (USE_V2 and V2_SPLITK) or len(classes) != 1 or classes[0].ntaps != 9 or not conv_v2_geometry_ok(Ck, Nc, classes):
+        return 0
+    tiles = conv_v2_tiles(Nc, classes, N)
+    if tiles >= V2_MIN_TILES or tiles < V2_KS_MIN_TILES:
+        return 0
+    ks = min(-(-V2_KS_TARGET // tiles), (Ck // 16) // V2_KS_MIN_CHUNKS)
+    return ks if ks >= 2 else 0
 
 
 V2_MIN_TILES = int(os.environ.get('EG3D_V2_MIN_TILES', '256'))
 USE_V2 = os.environ.get('EG3D_CONV_V2', '1') != '0'
 V2_CONVT = os.environ.get('EG3D_V2_CONVT', '0') == '1'
+# split-K launches of the pre-split kernel for under-filled 3x3 grids: OFF by default.  Measured at N = 1 (MI355X): 128^2 x 256 118 -> 81 us,
+# 64^2 x 512 103 -> 82 us per launch, but the operand split pass (7 us), the zero fill and the finishing pass (2 x 10 us; the loader-split
+# kernel's fused epilogue needs neither on the 128^2 layer) eat it: -1.2 % per step.  Batched runs do not need it (the grids fill).
+V2_SPLITK = os.environ.get('EG3D_V2_SPLITK', '0') != '0'
+V2_KS_TARGET = int(os.environ.get('EG3D_V2_KS_TARGET', '512'))        # workgroups a split launch aims for (2 per CU)
+V2_KS_MIN_TILES = int(os.environ.get('EG3D_V2_KS_MIN_TILES', '32'))      # 32^2 x 512 (16 tiles): no gain over the loader-split kernel (46.8 vs 46.4 us)
+V2_KS_MIN_CHUNKS = int(os.environ.get('EG3D_V2_KS_MIN_CHUNKS', '2'))
 
 
 def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_STORE, out_scale=None, bias=None, noise=None, noise_nstride=0,
             noise_strength=None, act='linear', alpha=0.0, gain=1.0, clamp=-1.0, addend=None, xin=None, ds=None, out_amax=None, algo_flops=None,
-            act_bwd=None, products=3):
+            act_bwd=None, products=3, ksplit=1):
     """Launch eg3d_conv2d_v2 (operands prepared by split_activation / split_weight).  act_bwd (ActBwdSpec, with epi=EPI_BWD): EPI_BWD_ACT when
     the kernel takes it -- returns True if the fused epilogue ran, False for a plain EPI_BWD."""
     assert is_cl(out)
     p = _conv_v2_params(a, w, out, classes, out_stride, epi, out_scale, bias, noise, noise_nstride, noise_strength, act, alpha, gain, clamp,
                         addend, xin, ds, out_amax)
     p.products = int(products)
+    p.ksplit = int(ksplit)
+    assert ksplit <= 1 or epi == L.EPI_ATOMIC
     fused_act = False
     if act_bwd is not None and epi == L.EPI_BWD and xin is not None:
         p.epi = L.EPI_BWD_ACT
@@ -553,12 +582,135 @@ def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_
         e1.record()
         prof.records.append(((V2_CONFIG, PRECISIONS['f16x3']), float(algo_flops), e0, e1))
         if prof.meta is not None:
-            prof.meta.append(dict(N=p.N, Hi=p.Hi, Wi=p.Wi, Ck=p.Ck, Nc=p.Nc, Ho=p.Ho, Wo=p.Wo, taps=[c.ntaps for c in classes], epi=epi, ksplit=1,
+            prof.meta.append(dict(N=p.N, Hi=p.Hi, Wi=p.Wi, Ck=p.Ck, Nc=p.Nc, Ho=p.Ho, Wo=p.Wo, taps=[c.ntaps for c in classes], epi=epi, ksplit=int(ksplit),
                                   in_stride=1, out_stride=out_stride, prec=3, v2=True))
     return fused_act if act_bwd is not None else out
 
 
+def fir44_adjoint_split(dz, dz_amax, gain=4.0):
+    """FIR adjoint of an up layer + operand split in one pass (eg3d_fir44_adjoint_split): dz [N,C,2Hi,2Wi] channels_last ->
+    SplitImage of the four parity images of G = upfirdn2d(dz, [1,3,3,1]^2 / 64, pad 2, gain), shape (N, C, Hi + 1, Wi + 1) per parity."""
+    assert is_cl(dz)
+    n, c, ho, wo = dz.shape
+    assert ho % 2 == 0 and wo % 2 == 0 and c % 8 == 0
+    hi, wi = ho // 2, wo // 2
+    img = torch.empty((int(L.lib().eg3d_fir44_adjoint_split_bytes(n, hi, wi, c)) // 2,), dtype=torch.float16, device=dz.device)
+    scale = torch.empty((1,), dtype=torch.float32, device=dz.device)
+    L.check(L.lib().eg3d_fir44_adjoint_split(L.ptr(dz), L.ptr(dz_amax), L.ptr(img), L.ptr(scale), n, hi, wi, c, c, float(gain), L.stream_ptr()), 'fir44_adjoint_split')
+    return SplitImage(img, scale, (n, c, hi + 1, wi + 1))
+
+
+V2_S2ADJ = os.environ.get('EG3D_V2_S2ADJ', '1') != '0'
+S2ADJ_MIN_TILES = int(os.environ.get('EG3D_S2ADJ_MIN_TILES', '256'))     # 128 tiles (257^2 x 128 -> 128^2 x 256): 79 us vs 65-70 on the loader-split kernel
+S2ADJ_CONFIG = 7
+
+
+def conv_s2adj_ok(Ck, Nc, Hi, Wi, N=1):
+    """The up layers' data gradient on the parity-split kernel (csrc/conv_v2_s2adj.hip): geometry + enough 256 x 128 tiles."""
+    if not (USE_V2 and V2_S2ADJ) or CONV_MODE != 'auto' or Ck % 64 or Nc % 128:
+        return False
+    return N * -(-Hi // 8) * -(-Wi // 32) * (Nc // 128) >= S2ADJ_MIN_TILES
+
+
+def conv_v2_s2adj(a: SplitImage, w: SplitImage, out, classes, epi=L.EPI_STORE, out_scale=None, addend=None, xin=None, ds=None, out_amax=None, algo_flops=None,
+                  act_bwd=None, products=3, ksplit=1):
+    """Launch eg3d_conv2d_v2_s2adj: `a` = parity-split image of G (fir44_adjoint_split), `classes` = classes_convT_adjoint(...).  Returns like conv_v2."""
+    assert is_cl(out) and len(classes) == 1
+    p = _conv_v2_params(a, w, out, classes, 1, epi, out_scale, None, None, 0, None, 'linear', 0.0, 1.0, -1.0, addend, xin, ds, out_amax)
+    p.in_stride = 2
+    p.products, p.ksplit = int(products), int(ksplit)
+    fused_act = False
+    if act_bwd is not None and epi == L.EPI_BWD and xin is not None:
+        p.epi = L.EPI_BWD_ACT
+        act_bwd.fill(p.act_bwd)
+        fused_act = bool(L.lib().eg3d_conv2d_v2_s2adj_supported(C.byref(p))) and all(t is None or t.data_ptr() % 16 == 0 for t in (act_bwd.d, act_bwd.bias))
+        if not fused_act:
+            p.epi = L.EPI_BWD
+            p.act_bwd = L.ActBwd()
+    prof = PROFILER
+    if prof is not None and prof.only_config is not None and prof.only_config != S2ADJ_CONFIG:
+        prof = None
+    if prof is not None:
+        if algo_flops is None:
+            algo_flops = 2.0 * p.Ck * p.Nc * p.N * classes[0].Ha * classes[0].Wa * 9
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    L.check(L.lib().eg3d_conv2d_v2_s2adj(C.byref(p), L.stream_ptr()), 'conv2d_v2_s2adj')
+    if prof is not None:
+        e1.record()
+        prof.records.append(((S2ADJ_CONFIG, PRECISIONS['f16x3']), float(algo_flops), e0, e1))
+        if prof.meta is not None:
+            prof.meta.append(dict(N=p.N, Hi=2 * p.Hi - 1, Wi=2 * p.Wi - 1, Ck=p.Ck, Nc=p.Nc, Ho=p.Ho, Wo=p.Wo, taps=[9], epi=epi, ksplit=int(ksplit), in_stride=2,
+                                  out_stride=1, prec=3, v2=True))
+    return fused_act if act_bwd is not None else out
+
+
 V2_CONFIG = 5        # "tile configuration" id of the pre-split kernel in profiler records (eg3d_conv2d_igemm_config returns 0..4)
+UP2_CONFIG = 6       # ... of the fused-parity transposed-conv kernel (csrc/conv_v2_up.hip)
+V2_UP2 = os.environ.get('EG3D_V2_UP2', '1') != '0'
+UP2_MIN_TILES = int(os.environ.get('EG3D_UP2_MIN_TILES', '256'))      # workgroups (512 threads, 115 KB of LDS: one per CU) below which the layer stays on the loader-split kernel
+UP2_MIN_CK = int(os.environ.get('EG3D_UP2_MIN_CK', '64'))
+
+
+def conv_up2_plan(Ck, Nc, Hi, Wi, N=1):
+    """(ksplit, ragged) for the fused-parity transposed-conv kernel on an Hi x Wi -> (2 Hi + 1) x (2 Wi + 1) layer, or None when the layer
+    stays on the loader-split kernel.  Measured on MI355X (N = 1): 256^2 x 256 -> 513^2 x 128 172 -> 115 us, 128^2 x 256 -> 257^2 x 128
+    64 -> 50 us; the 64^2 / 32^2 layers (64 / 32 workgroups) gain nothing, with or without split-K (fp32 atomics on an output four
+    times the size of the input cost what they save), and would pay for the operand split pass on top.
+    ragged: the launch covers the full (Hi + 1) x (Wi + 1) cell grid -- chosen when that still fits one round of workgroups (one per
+    CU); otherwise the main Hi x Wi grid (perfectly tiled) + the last output row / column as border classes of the loader-split kernel."""
+    if not (USE_V2 and V2_UP2) or CONV_MODE != 'auto' or Ck % 16 or Nc % 64 or Ck < UP2_MIN_CK or Hi < 8 or Wi < 32:
+        return None
+    tiles = N * -(-Hi // 8) * -(-Wi // 32) * (Nc // 64)
+    if tiles < UP2_MIN_TILES:
+        return None
+    ragged = N * -(-(Hi + 1) // 8) * -(-(Wi + 1) // 32) * (Nc // 64) <= 256
+    return 1, ragged
+
+
+def up2_border_classes(Hi, Wi, kh=3, kw=3):
+    """The last output row (y = 2 Hi) and column (x = 2 Wi) of the stride-2 transposed 3x3 conv as four tap classes of
+    eg3d_conv2d_igemm_f32 (out_stride 2, in_stride 1): cells a = Hi resp. b = Wi, which the 8 x 32-patch grid of conv_up2 leaves out."""
+    assert kh == 3 and kw == 3
+    wt = lambda ky, kx: ky * 3 + kx                                       # noqa: E731
+    return [_mk_class(1, Wi + 1, 2 * Hi, 0, [(Hi - 1, 0, wt(2, 0)), (Hi - 1, -1, wt(2, 2))]),
+            _mk_class(1, Wi, 2 * Hi, 1, [(Hi - 1, 0, wt(2, 1))]),
+            _mk_class(Hi, 1, 0, 2 * Wi, [(0, Wi - 1, wt(0, 2)), (-1, Wi - 1, wt(2, 2))]),
+            _mk_class(Hi, 1, 1, 2 * Wi, [(0, Wi - 1, wt(1, 2))])]
+
+
+def conv_up2(a: SplitImage, w: SplitImage, out, Hc=None, Wc=None, epi=L.EPI_STORE, ksplit=1, products=3, algo_flops=None):
+    """Launch eg3d_conv2d_up2: out [N,Co,2Hi+1,2Wi+1] channels_last (+)= transposed 3x3 stride-2 conv of the split image `a` with the
+    forward weight image `w`, for the cells a < Hc, b < Wc (default: the full (Hi + 1) x (Wi + 1) grid)."""
+    assert is_cl(out)
+    p = L.ConvUp2Params()
+    n, ck, hi, wi = a.shape
+    nc, _, wtaps = w.shape
+    assert wtaps == 9
+    _, co, ho, wo = out.shape
+    p.a, p.w, p.a_scale, p.w_scale, p.out = a.data.data_ptr(), w.data.data_ptr(), a.scale.data_ptr(), w.scale.data_ptr(), out.data_ptr()
+    p.N, p.Hi, p.Wi, p.Ck, p.Nc = n, hi, wi, ck, nc
+    p.Hc, p.Wc = (hi + 1 if Hc is None else Hc), (wi + 1 if Wc is None else Wc)
+    p.Ho, p.Wo, p.ldo = ho, wo, co
+    for t in range(9):
+        p.wtap[t] = t
+    p.epi, p.products, p.ksplit = epi, int(products), int(ksplit)
+    prof = PROFILER
+    if prof is not None and prof.only_config is not None and prof.only_config != UP2_CONFIG:
+        prof = None
+    if prof is not None:
+        if algo_flops is None:
+            algo_flops = 2.0 * ck * nc * n * hi * wi * 9
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    L.check(L.lib().eg3d_conv2d_up2(C.byref(p), L.stream_ptr()), 'conv2d_up2')
+    if prof is not None:
+        e1.record()
+        prof.records.append(((UP2_CONFIG, PRECISIONS['f16x3']), float(algo_flops), e0, e1))
+        if prof.meta is not None:
+            prof.meta.append(dict(N=n, Hi=hi, Wi=wi, Ck=ck, Nc=nc, Ho=ho, Wo=wo, taps=[4, 2, 2, 1], epi=epi, ksplit=int(ksplit), in_stride=1, out_stride=2,
+                                  prec=3, v2=True, up2=True))
+    return out
 
 
 def conv_wgrad(x, g, Ck, Nc, dwp, classes, in_stride=1, out_stride=1, in_scale=None, psplit=0, precision='f32', g_amax=None, g_amax_mul=1.0):

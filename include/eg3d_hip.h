@@ -186,7 +186,7 @@ int eg3d_conv2d_igemm_config(const eg3d_conv_params* p);
  * Pre-split implicit-GEMM convolution (csrc/conv_v2.hip): same contract as eg3d_conv2d_igemm_f32 in F16X3 arithmetic -- one launch
  * computes, for every cell of every class grid,
  *     acc[n,ay,ax,o] = sum_t sum_k  A[n, ay+dy[t], ax+dx[t], k] * W[o, wtap[t], k]            (in_stride 1; OOB reads are zero)
- * and applies epilogue STORE / FWD / BWD (as above) at out[n, ay*out_stride+out_py, ax*out_stride+out_px, o] -- but both operands are
+ * and applies epilogue STORE / ATOMIC / FWD / BWD (as above) at out[n, ay*out_stride+out_py, ax*out_stride+out_px, o] -- but both operands are
  * "split images" prepared once by eg3d_split_activation / eg3d_split_weight (two fp16 pieces per value, see conv_v2.hip), so the
  * style modulation, the range normalisation and the fp32 -> 2 x fp16 split are NOT repeated per tile and per tap:
  *   A image [N][2][Ck/8][Hi][Wi][8] fp16 = split( x * in_scale[n,k] * a_scale ),  a_scale = the power of two that brings
@@ -217,9 +217,47 @@ typedef struct eg3d_conv_v2_params {
     float* out_amax;
     eg3d_act_bwd act_bwd;      /* EG3D_EPI_BWD_ACT only */
     int32_t products;          /* 0 / 3: three products (fp32-equivalent);  1: high pieces only (EG3D_PREC_F16X1)            */
+    int32_t ksplit;            /* 0 / 1: none.  > 1 (EG3D_EPI_ATOMIC only, `out` pre-zeroed): the contraction's 16-channel chunks are split over
+                                * ksplit workgroups per tile which add their partial tiles with fp32 atomics -- the layers whose grids
+                                * cannot fill the chip (128^2 x 256: 128 tiles; 64^2 x 512: 64) */
 } eg3d_conv_v2_params;
 int eg3d_conv2d_v2_supported(const eg3d_conv_v2_params* p);
 int eg3d_conv2d_v2(const eg3d_conv_v2_params* p, void* stream);
+/* Data gradient of that transposed convolution (a stride-2 3x3 correlation; csrc/conv_v2_s2adj.hip) with the contract, epilogues and
+ * weight image of eg3d_conv2d_v2, for ONE class of nine taps (dy, dx) = (t / 3, t % 3):
+ *     acc[n,a,b,o] = sum_t sum_k  G[n, 2a + dy[t], 2b + dx[t], k] * W[o, wtap[t], k]
+ * where the A operand is the PARITY-split image of G written by eg3d_fir44_adjoint_split: [N][2][Ck/8][4][Hi][Wi][8] fp16 with
+ * parity image (py, px)[a', b'] = G[2a' + py, 2b' + px] (p->Hi, p->Wi = dimensions of one parity image, >= Ha + 1, Wa + 1). */
+int eg3d_conv2d_v2_s2adj_supported(const eg3d_conv_v2_params* p);
+int eg3d_conv2d_v2_s2adj(const eg3d_conv_v2_params* p, void* stream);
+/* FIR adjoint of an up-sampling layer fused with the operand split: G = upfirdn2d(dz, outer([1,3,3,1]) / 64, padding 2, gain) of
+ * dz [N, 2 Hi, 2 Wi, ldz] NHWC fp32 (C used channels, C % 8 == 0) -- the (2 Hi + 1) x (2 Wi + 1) input of the data gradient above
+ * (torch_utils/ops/upfirdn2d.py:258-268 applied to conv2d_resample.py:129) -- written as the four parity images [.][Hi + 1][Wi + 1] in the
+ * split layout, range-normalised by the bound max|G| <= gain * max|dz| (dz_amax: device scalar max|dz|).  image:
+ * eg3d_fir44_adjoint_split_bytes() bytes; scale_out: device scalar (the image's power-of-two scale). */
+int64_t eg3d_fir44_adjoint_split_bytes(int N, int Hi, int Wi, int C);
+int eg3d_fir44_adjoint_split(const float* dz, const float* dz_amax, void* image, float* scale_out, int N, int Hi, int Wi, int C, int ldz, float gain,
+                             void* stream);
+/* Stride-2 3x3 TRANSPOSED convolution on the same split images, all four output parities per workgroup (csrc/conv_v2_up.hip) -- the
+ * F.conv_transpose2d of the up-sampling layers (torch_utils/ops/conv2d_resample.py:114-136):
+ *     out[n, 2a + py, 2b + px, o] (+)= sum over taps t = 3 ky + kx with ky % 2 == py, kx % 2 == px of
+ *                                     A[n, a - ky/2, b - kx/2, k] * W[o, wtap[t], k]                 (OOB reads are zero)
+ * for the cells a < Hc, b < Wc (Hc <= Hi + 1, Wc <= Wi + 1) and the output pixels inside Ho x Wo (<= 2 Hi + 1, 2 Wi + 1).  With
+ * Hc = Hi, Wc = Wi the launch covers rows / columns 0 .. 2 Hi - 1 / 2 Wi - 1 on perfectly tiled grids; the last output row and column
+ * (a = Hi resp. b = Wi: 1-D problems) are then four small tap classes of eg3d_conv2d_igemm_f32.  epi: EG3D_EPI_STORE, or EG3D_EPI_ATOMIC
+ * with ksplit workgroups per tile (out pre-zeroed).  Nc % 64 == 0, Ck % 16 == 0; W image with 9 taps. */
+typedef struct eg3d_conv_up2_params {
+    const void* a;  const void* w;
+    const float* a_scale;  const float* w_scale;
+    float* out;
+    int32_t N, Hi, Wi, Ck, Nc;
+    int32_t Hc, Wc;
+    int32_t Ho, Wo, ldo;
+    int32_t wtap[9];           /* weight tap index of (ky, kx) = (t / 3, t % 3)                                               */
+    int32_t epi, products, ksplit;
+} eg3d_conv_up2_params;
+int eg3d_conv2d_up2_supported(const eg3d_conv_up2_params* p);
+int eg3d_conv2d_up2(const eg3d_conv_up2_params* p, void* stream);
 /* Operand preparation.  x: NHWC fp32 [N,H,W,ldx] (C used channels, C % 8 == 0); in_scale [N,C] or null; x_amax / s_amax: device scalars
  * holding max|x| and max|in_scale| (s_amax null: computed from in_scale by the kernel); image: eg3d_split_activation_bytes() bytes; scale_out: device scalar. */
 int64_t eg3d_split_activation_bytes(int N, int H, int W, int C);

@@ -655,6 +655,28 @@ def test_conv_v2_data_gradient_epilogue_vs_torch():
     close(ds, ref_ds.float(), 5e-5, 'conv_v2 dgrad ds')
 
 
+@pytest.mark.parametrize('shape,ks', [((1, 64, 16, 32, 128), 2), ((1, 256, 24, 40, 256), 4), ((2, 128, 9, 33, 128), 8), ((1, 48, 8, 32, 128), 3)])
+@pytest.mark.parametrize('products', [3, 1])
+def test_conv_v2_split_k_vs_torch(shape, ks, products):
+    """Split-K launch of the pre-split kernel (EG3D_EPI_ATOMIC: the 16-channel chunks of the contraction divided over `ks` workgroups per
+    tile, partial tiles added with fp32 atomics into a zeroed buffer) -- the 128^2 x 256 / 64^2 x 512 layers, whose grids cannot fill
+    the chip -- vs torch fp64, incl. a chunk count that does not divide evenly and the single-product arithmetic."""
+    from inv3d_amd import hipops as H, _lib as L
+    n, ci, h, w, co = shape
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)
+    s = 1 + 0.5 * torch.randn(n, ci, generator=g)
+    ref = torch.nn.functional.conv2d(x.double() * s.double()[:, :, None, None], wt.double(), padding=1)
+    xc, aimg, wimg = _v2_operands(x, wt, s)
+    z = torch.zeros((n, co, h, w), device=DEV).contiguous(memory_format=torch.channels_last)
+    H.conv_v2(aimg, wimg, z, H.classes_corr(h, w, 3, 3, 1), epi=L.EPI_ATOMIC, ksplit=ks, products=products)
+    close(z, ref.float(), 2e-5 if products == 3 else 3e-3, f'conv_v2 split-K {shape} x{ks}')
+    one = H.empty_cl(n, co, h, w, DEV)
+    H.conv_v2(aimg, wimg, one, H.classes_corr(h, w, 3, 3, 1), epi=L.EPI_STORE, products=products)
+    close(z, one, 2e-6, 'split-K vs one workgroup per tile (same products, different summation order)')
+
+
 @pytest.mark.parametrize('shape', [(1, 32, 16, 32, 128), (2, 64, 20, 33, 128)])
 def test_conv_v2_transposed_classes_vs_torch(shape):
     """Stride-2 transposed conv as four parity classes (4 / 2 / 2 / 1 taps, three launches) with the plain-store epilogue."""
@@ -671,6 +693,72 @@ def test_conv_v2_transposed_classes_vs_torch(shape):
     z = H.empty_cl(n, co, hz, wz, DEV)
     H.conv_v2(aimg, wimg, z, cls, out_stride=2, epi=L.EPI_STORE)
     close(z, ref.float(), 2e-5, f'conv_v2 convT {shape}')
+
+
+@pytest.mark.parametrize('shape,ks', [((1, 64, 16, 32, 64), 1), ((2, 32, 20, 33, 128), 1), ((1, 128, 8, 64, 64), 4), ((1, 48, 19, 40, 192), 3)])
+@pytest.mark.parametrize('products', [3, 1])
+def test_conv_up2_fused_parity_vs_torch(shape, ks, products):
+    """The fused-parity transposed-conv kernel (csrc/conv_v2_up.hip): all four output parities of the stride-2 3x3 transposed conv from
+    one workgroup per 8 x 32 input patch, (i) on the full ragged (Hi + 1) x (Wi + 1) cell grid and (ii) as the model runs it: main grid
+    Hi x Wi + the last output row / column as four tap classes of the loader-split kernel; with and without split-K, both arithmetics."""
+    from inv3d_amd import hipops as H, _lib as L
+    n, ci, h, w, co = shape
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)
+    s = 1 + 0.5 * torch.randn(n, ci, generator=g)
+    ref = torch.nn.functional.conv_transpose2d(x.double() * s.double()[:, :, None, None], wt.double().transpose(0, 1), stride=2)
+    xc, aimg, wimg = _v2_operands(x, wt, s)
+    hz, wz = 2 * h + 1, 2 * w + 1
+    tol = 2e-5 if products == 3 else 3e-3
+    epi = L.EPI_ATOMIC if ks > 1 else L.EPI_STORE
+    mk = (lambda: torch.zeros((n, co, hz, wz), device=DEV).contiguous(memory_format=torch.channels_last)) if ks > 1 else (lambda: H.empty_cl(n, co, hz, wz, DEV))
+    z = mk()
+    H.conv_up2(aimg, wimg, z, epi=epi, ksplit=ks, products=products)
+    close(z, ref.float(), tol, f'conv_up2 full grid {shape} x{ks}')
+    z2 = mk()
+    if ks == 1:
+        z2.fill_(float('nan'))             # every output pixel must be written by exactly one of the two launches
+    H.conv_up2(aimg, wimg, z2, Hc=h, Wc=w, epi=epi, ksplit=ks, products=products)
+    H.conv_igemm(xc, H.pack_weight_fwd(wt.to(DEV)), ci, co, z2, H.up2_border_classes(h, w), out_stride=2, in_scale=s.to(DEV), epi=L.EPI_STORE, precision='f16x3')
+    close(z2, ref.float(), tol, f'conv_up2 main grid + border classes {shape} x{ks}')
+
+
+@pytest.mark.parametrize('shape', [(1, 128, 16, 32, 64), (2, 256, 9, 33, 128), (1, 128, 24, 40, 192)])
+@pytest.mark.parametrize('products', [3, 1])
+def test_conv_v2_stride2_adjoint_vs_torch(shape, products):
+    """Data gradient of an up-sampling layer on the parity-split kernel (csrc/conv_v2_s2adj.hip): FIR adjoint + operand split in one pass
+    (eg3d_fir44_adjoint_split), then dx = (stride-2 correlation of G with the layer's weights) * styles, ds = sum_px acc * x -- vs torch
+    fp64, on ragged grids (Hi, Wi not multiples of the 8 x 32 patch), batch 2, two 128-channel tiles."""
+    from inv3d_amd import hipops as H, _lib as L
+    n, ci, h, w, co = shape                       # layer: ci -> co, input h x w, output 2h x 2w
+    g_ = torch.Generator().manual_seed(51)
+    dz = torch.randn(n, co, 2 * h, 2 * w, generator=g_) * 1e-3
+    wt = torch.randn(co, ci, 3, 3, generator=g_) / math.sqrt(ci * 9)
+    s, xin = 1 + 0.5 * torch.randn(n, ci, generator=g_), torch.randn(n, ci, h, w, generator=g_)
+    f1 = torch.tensor([1., 3., 3., 1.], dtype=torch.float64) / 8
+    f2 = torch.outer(f1, f1)[None, None].repeat(co, 1, 1, 1)
+    G = torch.nn.functional.conv2d(torch.nn.functional.pad(dz.double(), (2, 2, 2, 2)), f2, groups=co) * 4.0              # (2h + 1) x (2w + 1)
+    acc = torch.nn.functional.conv2d(G, wt.double().transpose(0, 1), stride=2)
+    assert acc.shape == (n, ci, h, w)
+    ref_dx, ref_ds = acc * s.double()[:, :, None, None], (acc * xin.double()).sum((2, 3))
+    dzc = dz.to(DEV).contiguous(memory_format=torch.channels_last)
+    gimg = H.fir44_adjoint_split(dzc, H.absmax(dzc), gain=4.0)
+    wimg = H.split_weight(H.pack_weight_adj(wt.to(DEV)), ci, co, 9)
+    dx, ds = H.empty_cl(n, ci, h, w, DEV), torch.zeros(n, ci, device=DEV)
+    H.conv_v2_s2adj(gimg, wimg, dx, H.classes_convT_adjoint(h, w, 3, 3, 2), epi=L.EPI_BWD, out_scale=s.to(DEV),
+                    xin=xin.to(DEV).contiguous(memory_format=torch.channels_last), ds=ds, products=products)
+    tol = 2e-5 if products == 3 else 3e-3
+    scale = float(ref_dx.abs().max())
+    assert float((dx.double().cpu() - ref_dx).abs().max()) <= tol * scale
+    assert float((ds.double().cpu() - ref_ds).abs().max()) <= 3 * tol * float(ref_ds.abs().max())
+    # the same operand through the loader-split kernel (fp32 G from the stand-alone FIR adjoint): the path this one replaces
+    Gf = H.upfirdn2d_nhwc(dzc, torch.outer(f1, f1).float().to(DEV).contiguous(), pad=(2, 2, 2, 2), flip=True, gain=4.0)
+    dx2 = H.empty_cl(n, ci, h, w, DEV)
+    H.conv_igemm(Gf, H.pack_weight_adj(wt.to(DEV)), co, ci, dx2, H.classes_convT_adjoint(h, w, 3, 3, 2), in_stride=2, epi=L.EPI_BWD, out_scale=s.to(DEV),
+                 precision='f16x3', a_amax=H.absmax(dzc), a_amax_mul=4.0)
+    if products == 3:
+        assert float((dx - dx2).abs().max()) <= 2e-5 * scale
 
 
 def test_conv_v2_heavy_tailed_operands():
