@@ -129,3 +129,65 @@ extern "C" int eg3d_filtered_lrelu(const eg3d_flrelu_params* pp, void* stream) {
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }
+
+
+// ---- stand-alone activation with the packed sign image (torch_utils/ops/filtered_lrelu.cpp:217-272, filtered_lrelu.cu:1110-1215) ----------
+// x (in place, contiguous NCHW fp32 / fp16): v = x * gain;  mode 1 (write signs): v < 0 -> v *= slope, sign 1;  |v| > clamp -> v = +-clamp,
+// sign 2;  mode 2 (read signs): the element at (x + sx, y + sy) of the sign image decides: bit 0 -> v *= slope, bit 1 -> v = 0 (elements
+// outside the image are only scaled by gain);  mode 0: as mode 1 without writing.  Sign image: [N*C][sH][sW / 4] bytes, 2 bits per element,
+// element x in bits 2 (x & 3) of byte x >> 2 (sW a multiple of 4).
+namespace {
+template <typename T>
+__global__ void __launch_bounds__(256) flrelu_act_kernel(T* __restrict__ x, uint8_t* __restrict__ s, int NC, int H, int W, int sH, int sW, int sx, int sy,
+                                                         float gain, float slope, float clamp, int mode) {
+    // one thread per group of four consecutive elements of a row = one byte of the sign image
+    const int wq = (mode == 1 ? sW : ((W + 3) & ~3)) >> 2;
+    const int rows = mode == 1 ? sH : H;
+    const int64_t total = (int64_t)NC * rows * wq;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int q4 = (int)(i % wq);
+    const int y = (int)((i / wq) % rows);
+    const int64_t q = i / ((int64_t)wq * rows);
+    unsigned bits = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int xx = q4 * 4 + e;
+        if (xx >= W || y >= H) continue;
+        T* pv = x + (q * H + y) * W + xx;
+        float v = (float)*pv * gain;
+        if (mode == 2) {
+            const unsigned ux = (unsigned)(xx + sx), uy = (unsigned)(y + sy);
+            if (ux < (unsigned)sW && uy < (unsigned)sH) {
+                const unsigned b = (s[(ux >> 2) + (int64_t)(sW >> 2) * (uy + (int64_t)sH * q)] >> ((ux & 3) << 1)) & 3u;
+                if (b & 1u) v *= slope;
+                if (b & 2u) v = 0.f;
+            }
+        } else {
+            unsigned sg = 0;
+            if (v < 0.f) { v *= slope; sg = 1; }
+            if (fabsf(v) > clamp) { v = v < 0.f ? -clamp : clamp; sg = 2; }
+            bits |= sg << (e << 1);
+        }
+        *pv = (T)v;
+    }
+    if (mode == 1) s[q4 + (int64_t)(sW >> 2) * (y + (int64_t)sH * q)] = (uint8_t)bits;
+}
+}  // namespace
+
+extern "C" int eg3d_filtered_lrelu_act(void* x, uint8_t* signs, int dtype, int NC, int H, int W, int sH, int sW, int sx, int sy, float gain, float slope, float clamp,
+                                       int mode, void* stream) {
+    if (!x || NC <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 2) return EG3D_ERR_INVALID;
+    if (mode != 0 && (!signs || sH <= 0 || sW <= 0 || (sW & 3))) return EG3D_ERR_INVALID;
+    if (mode == 1 && (sH < H || sW < W)) return EG3D_ERR_INVALID;
+    if (dtype != EG3D_F32 && dtype != EG3D_F16) return EG3D_ERR_UNSUPPORTED;
+    if (!(clamp >= 0.f)) clamp = INFINITY;
+    const int wq = (mode == 1 ? sW : ((W + 3) & ~3)) >> 2, rows = mode == 1 ? sH : H;
+    const int64_t total = (int64_t)NC * rows * wq;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EG3D_F32) hipLaunchKernelGGL(flrelu_act_kernel<float>, dim3(blocks), dim3(256), 0, st, (float*)x, signs, NC, H, W, sH, sW, sx, sy, gain, slope, clamp, mode);
+    else hipLaunchKernelGGL(flrelu_act_kernel<__half>, dim3(blocks), dim3(256), 0, st, (__half*)x, signs, NC, H, W, sH, sW, sx, sy, gain, slope, clamp, mode);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}

@@ -270,10 +270,14 @@ class LatentProjector:
                  noise_ramp_length=0.75, lr_rampdown_length=0.25, lr_rampup_length=0.05, regularize_noise_weight=1e5,
                  initial_learning_rate=0.01, radius=2.7, wplus=False, synth_kwargs: Optional[dict] = None, seed: int = 0,
                  init_noise: Optional[Dict[str, torch.Tensor]] = None, use_graph: bool = False, graph_warmup: int = 2,
-                 pose_net: Optional[torch.nn.Module] = None, pose_mode: str = 'quat', translation_start=None):
+                 pose_net: Optional[torch.nn.Module] = None, pose_mode: str = 'quat', translation_start=None, sr_fp16: bool = False):
         if pose_mode not in POSE_DIMS:
             raise ValueError(f'pose_mode must be one of {sorted(POSE_DIMS)}, got {pose_mode!r}')
         self.pose_mode = pose_mode
+        # sr_fp16: run the super-resolution head in the reference's fp16-operand arithmetic (one product of fp16-rounded operands) also in
+        # Phase A.  The reference itself passes force_fp32=True here (w_projector.py:189), so this is an OPTION for a secondary figure
+        # (to be shown to keep the final-PSNR drift small), never the default.
+        self.sr_fp16 = bool(sr_fp16)
         dev = target.device
         N = self.N = int(target.shape[0])
         if N > 1 and optimize_pose:
@@ -487,7 +491,7 @@ class LatentProjector:
         ws = w.repeat(1, self.num_ws, 1) if w.shape[1] == 1 else w
         if self._noise_inject is not None:
             kw = dict(kw, noise_inject=self._noise_inject)
-        out = G.synthesis(ws, pred_cam, noise_mode='const', force_fp32=True, **kw)
+        out = G.synthesis(ws, pred_cam, noise_mode='const', **(dict(sr_fp16=True) if self.sr_fp16 else dict(force_fp32=True)), **kw)
         from . import loss_nets as LN
         p4 = getattr(out['image'], '_eg3d_padded4', None)
         res = out['image'].shape[2]

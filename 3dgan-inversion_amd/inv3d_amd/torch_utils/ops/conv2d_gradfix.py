@@ -3,9 +3,10 @@ flags `enabled`, `weight_gradients_disabled`, context manager `no_weight_gradien
 GEMM of libeg3d_hip.so.  Forward, data gradient (the opposite-transpose op, :139-143) and weight gradient (:166-173) are
 three launches of the same family; gradients of gradients re-enter these Functions.
 
-Supported: fp32, groups == 1, dilation == 1, kernel <= 3x3, conv2d stride 1 with symmetric padding,
-conv_transpose2d stride 1|2 with symmetric padding (cropping), channel counts that are multiples of 4 on the contraction
-side.  Anything else raises NotImplementedError -- there is no silent fallback."""
+Supported: fp32, kernels <= 3x3, conv2d with any isotropic stride and symmetric padding (stride > 1 = the data gradient of the
+transposed conv, as the reference states the duality), conv_transpose2d with isotropic stride and symmetric padding (cropping),
+groups (one launch per group), any channel counts (padded to multiples of 4 on the contraction side).  Dilated k x k kernels and
+output_padding raise NotImplementedError -- there is no silent fallback."""
 import contextlib
 
 import torch
@@ -169,27 +170,71 @@ class _ConvWeightGradFn(torch.autograd.Function):
         return d_dy, d_x, None, None, None, None, None
 
 
-def _check(weight, stride, dilation, groups):
-    if groups != 1:
-        raise NotImplementedError('grouped convolution: the MI355X path shares weights across the batch instead (see fused.ModConvLayerFn)')
-    if _pair(dilation) != (1, 1):
-        raise NotImplementedError('dilated convolution')
+def _check(weight, dilation):
+    d = _pair(dilation)
+    if d[0] != d[1]:
+        raise NotImplementedError('anisotropic dilation')
     if weight.shape[2] * weight.shape[3] > 9:
         raise NotImplementedError('kernels larger than 9 taps')
+    return d[0]
+
+
+def _grouped(fn, input, weight, groups, w_out_dim):
+    """groups > 1 (torch_utils/ops/conv2d_gradfix.py:37-45 hands every combination to ATen): one launch per group on channel slices --
+    the generator never takes this path (its per-sample weights are expressed as activation scaling, fused.ModConvLayerFn)."""
+    cin = input.shape[1] // groups
+    wpg = weight.shape[0] // groups
+    outs = [fn(input[:, g * cin:(g + 1) * cin], weight[g * wpg:(g + 1) * wpg]) for g in range(groups)]
+    return torch.cat(outs, 1)
 
 
 def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, _flip_taps=False):
-    _check(weight, stride, dilation, groups)
-    if _pair(stride) != (1, 1):
-        raise NotImplementedError('strided conv2d (only used by the discriminator / down-sampling path)')
-    y = _ConvFn.apply(input, weight, 'corr', 1, _pair(padding), _flip_taps)
+    """F.conv2d's contract (torch_utils/ops/conv2d_gradfix.py:37-40): any stride, symmetric padding, dilation, groups; <= 9 taps."""
+    dil = _check(weight, dilation)
+    s, p = _pair(stride), _pair(padding)
+    if s[0] != s[1]:
+        raise NotImplementedError('anisotropic stride')
+    if groups != 1:
+        if input.shape[1] % groups or weight.shape[0] % groups:
+            raise ValueError('channels must be divisible by groups')
+        y = _grouped(lambda x_, w_: conv2d(x_, w_, None, stride, padding, dilation, 1, _flip_taps), input, weight, groups, 0)
+    elif dil != 1:
+        # a dilated k x k kernel is a (d (k - 1) + 1)^2 kernel with zeros between the taps: for the tap-list kernel that is only a change
+        # of the tap offsets, but the <= 3 x 3 halo of the fast paths does not hold -- expressed through the strided-correlation class
+        # machinery below with explicit taps is not needed by any caller; materialise the zero-stuffed kernel while it stays <= 9 taps
+        kh, kw = weight.shape[2:]
+        if kh * kw == 1:
+            y = conv2d(input, weight, None, stride, padding, 1, 1, _flip_taps)
+        else:
+            raise NotImplementedError('dilated k x k convolution (no caller on or near the inversion path)')
+    elif s == (1, 1):
+        y = _ConvFn.apply(input, weight, 'corr', 1, p, _flip_taps)
+    else:
+        # stride-s correlation = the data gradient of the stride-s transposed convolution with the same weight tensor read as [in_t, out_t]
+        # (conv2d_gradfix.py:139-143 states the same duality): reuse that Function, whose own backward is the transposed conv + weight gradient
+        if p != (0, 0):
+            input = torch.nn.functional.pad(input, [p[1], p[1], p[0], p[0]])
+        kh, kw = weight.shape[2:]
+        ho, wo = (input.shape[2] - kh) // s[0] + 1, (input.shape[3] - kw) // s[0] + 1
+        if ho < 1 or wo < 1:
+            raise ValueError('conv2d: kernel larger than the padded input')
+        need = ((ho - 1) * s[0] + kh, (wo - 1) * s[0] + kw)             # the rows / columns the strided taps actually reach
+        input = input[:, :, :need[0], :need[1]]
+        y = _ConvDataGradFn.apply(input, weight, 'convT', s[0], (0, 0), _flip_taps, (input.shape[0], weight.shape[0], ho, wo))
     return y if bias is None else y + bias.reshape(1, -1, 1, 1)
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1, _flip_taps=False):
-    _check(weight, stride, dilation, groups)
+    """F.conv_transpose2d's contract (conv2d_gradfix.py:42-45) for isotropic stride, symmetric padding, no output_padding, dilation 1."""
+    if _check(weight, dilation) != 1:
+        raise NotImplementedError('dilated transposed convolution')
     s = _pair(stride)
     if s[0] != s[1] or _pair(output_padding) != (0, 0):
         raise NotImplementedError('anisotropic stride / output_padding')
-    y = _ConvFn.apply(input, weight, 'convT', s[0], _pair(padding), _flip_taps)
+    if groups != 1:
+        if input.shape[1] % groups or weight.shape[0] % groups:
+            raise ValueError('channels must be divisible by groups')
+        y = _grouped(lambda x_, w_: conv_transpose2d(x_, w_, None, stride, padding, 0, 1, 1, _flip_taps), input, weight, groups, 1)
+    else:
+        y = _ConvFn.apply(input, weight, 'convT', s[0], _pair(padding), _flip_taps)
     return y if bias is None else y + bias.reshape(1, -1, 1, 1)

@@ -60,10 +60,13 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
     if pointwise and down == 1:
         return fir(conv(x), up=up, padding=[px0, px1, py0, py1], gain=up * up)
     # k x k with up > 1: stride-`up` transposed conv produces the (up*H + k - up)-sized grid the FIR then trims to up*H
-    if groups != 1:
-        raise NotImplementedError('grouped up-sampling convolution (not on the EG3D path)')
+    if groups == 1:
+        wt = w.transpose(0, 1)
+    else:       # [g * O/g, I/g, kh, kw] -> the transposed layout [g * I/g, O/g, kh, kw], group by group (conv2d_resample.py:118-121)
+        co, cig = w.shape[0], w.shape[1]
+        wt = w.reshape(groups, co // groups, cig, kh, kw).transpose(1, 2).reshape(groups * cig, co // groups, kh, kw)
     qx0, qx1, qy0, qy1 = px0 - (kw - 1), px1 - (kw - up), py0 - (kh - 1), py1 - (kh - up)
     tx, ty = max(min(-qx0, -qx1), 0), max(min(-qy0, -qy1), 0)           # the part of a negative FIR padding the transposed conv can crop itself
-    y = conv(x, w.transpose(0, 1), stride=up, padding=[ty, tx], transpose=True, flip_weight=not flip_weight)
+    y = conv(x, wt, stride=up, padding=[ty, tx], transpose=True, flip_weight=not flip_weight)
     y = fir(y, padding=[qx0 + tx, qx1 + tx, qy0 + ty, qy1 + ty], gain=up * up)
     return fir(y, down=down) if down > 1 else y

@@ -163,3 +163,27 @@ def filtered_lrelu(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=np
         raise L.Eg3dHipError(f'filtered_lrelu: empty output {cfg.mid_hw} -> {cfg.out_hw}')
     act = (float(gain), float(slope), -1.0 if clamp is None else float(clamp))
     return _FilteredLReluFn.apply(x, b, f1, f2, cfg, act)
+
+
+def filtered_lrelu_act_(x, si=None, sx=0, sy=0, gain=math.sqrt(2.0), slope=0.2, clamp=None, write_signs=False):
+    """The plugin's stand-alone in-place activation (filtered_lrelu.cpp:217-272; what the reference's generic fallback calls between its two
+    upfirdn2d passes, filtered_lrelu.py:225-231).  x: contiguous [N,C,H,W] fp32 / fp16, modified in place.  write_signs=True: returns the
+    packed 2-bit sign image [N,C,H,ceil(W/4)] uint8; si given: applies a recorded sign image at offset (sx, sy) (the backward); neither:
+    the plain forward.  Returns the sign image (new, given, or None)."""
+    L.require_cuda(x, si)
+    if not (x.dim() == 4 and x.is_contiguous() and x.dtype in (torch.float32, torch.float16)):
+        raise L.Eg3dHipError('filtered_lrelu_act_: contiguous [N,C,H,W] fp32 / fp16 tensor expected')
+    n, c, h, w = x.shape
+    mode = 0
+    if write_signs:
+        si = torch.empty((n, c, h, (w + 3) // 4), dtype=torch.uint8, device=x.device)
+        mode = 1
+    elif si is not None:
+        if not (si.dtype == torch.uint8 and si.dim() == 4 and si.is_contiguous() and si.shape[:2] == x.shape[:2]):
+            raise L.Eg3dHipError('filtered_lrelu_act_: signs must be a contiguous uint8 [N,C,sH,sW/4] tensor')
+        mode = 2
+    sh, sw = (si.shape[2], si.shape[3] * 4) if si is not None else (0, 0)
+    dt = L.F32 if x.dtype == torch.float32 else L.F16
+    L.check(L.lib().eg3d_filtered_lrelu_act(x.data_ptr(), L.ptr(si), dt, n * c, h, w, sh, sw, int(sx), int(sy), float(gain), float(slope),
+                                            float(-1.0 if clamp is None else clamp), mode, L.stream_ptr()), 'filtered_lrelu_act')
+    return si

@@ -19,6 +19,30 @@ from ..reference_binding import ReferenceStateMixin
 from ..torch_utils.ops import bias_act, upfirdn2d
 
 
+def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True, flip_weight=True,
+                     fused_modconv=True):
+    """The reference's stand-alone operator (networks_stylegan2.py:34-91) with its signature: style-modulated, optionally demodulated
+    convolution with FIR-filtered resampling and an additive noise tensor.  Executed in the activation-scaled form (the reference's
+    `fused_modconv=False` branch, :70-79 -- numerically interchangeable with the grouped-conv branch; `fused_modconv` is accepted and
+    ignored): x * styles -> conv2d_resample -> * demodulation coefficients (+ noise).  The generator's layers do NOT go through this
+    function (they are single fused ops, fused.ModConvLayerFn); it exists for callers of the operator itself."""
+    from ..torch_utils.ops import conv2d_resample
+    n = x.shape[0]
+    co, ci, kh, kw = weight.shape
+    if tuple(styles.shape) != (n, ci) or x.shape[1] != ci:
+        raise ValueError(f'modulated_conv2d: x {tuple(x.shape)}, weight {tuple(weight.shape)}, styles {tuple(styles.shape)} do not agree')
+    dcoefs = None
+    if demodulate:          # rsqrt(sum_{i,taps} (w * s)^2 + 1e-8) = rsqrt(sum_i s_i^2 sum_taps w^2 + 1e-8)   (:62-65)
+        dcoefs = torch.rsqrt(styles.square() @ weight.square().sum((2, 3)).t() + 1e-8)
+    y = conv2d_resample.conv2d_resample(x=x * styles.to(x.dtype).reshape(n, -1, 1, 1), w=weight.to(x.dtype), f=resample_filter, up=up, down=down,
+                                        padding=padding, flip_weight=flip_weight)
+    if dcoefs is not None:
+        y = y * dcoefs.to(x.dtype).reshape(n, -1, 1, 1)
+    if noise is not None:
+        y = y + noise.to(x.dtype)
+    return y
+
+
 def normalize_2nd_moment(x, dim=1, eps=1e-8):
     """x / rms(x) along `dim` (the latent / embedding normalisation in front of the mapping MLP)."""
     return x * torch.rsqrt(torch.mean(x * x, dim=dim, keepdim=True) + eps)

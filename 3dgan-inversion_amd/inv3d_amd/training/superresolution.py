@@ -48,3 +48,12 @@ class SuperresolutionHybrid8XDC(ReferenceStateMixin, torch.nn.Module):
         img = rgb4[:, :3]                 # a view of the image with 4-float pixels (channel 3 = 0), which the fused loss-side kernels read (inversion.py)
         img._eg3d_padded4 = rgb4
         return img
+
+
+class SuperresolutionHybrid8X(SuperresolutionHybrid8XDC):
+    """128^2 -> 512^2 head with the narrower blocks 32 -> 128 @256^2 and 128 -> 64 @512^2 (reference: training/superresolution.py:29-58);
+    everything else as the 8XDC head."""
+
+    def __init__(self, channels, img_resolution, sr_num_fp16_res, sr_antialias, **kw):
+        kw.setdefault('sr_widths', (128, 64))
+        super().__init__(channels, img_resolution, sr_num_fp16_res, sr_antialias, **kw)

@@ -11,11 +11,12 @@ from .. import fused
 from .. import graphed
 from ..reference_binding import ReferenceStateMixin
 from .networks_stylegan2 import Generator as StyleGAN2Backbone, FullyConnectedLayer
-from .superresolution import SuperresolutionHybrid8XDC
+from .superresolution import SuperresolutionHybrid8XDC, SuperresolutionHybrid8X
 from .volumetric_rendering.ray_sampler import RaySampler
 from .volumetric_rendering.renderer import ImportanceRenderer
 
-_SR_MODULES = {'training.superresolution.SuperresolutionHybrid8XDC': SuperresolutionHybrid8XDC}
+_SR_MODULES = {'training.superresolution.SuperresolutionHybrid8XDC': SuperresolutionHybrid8XDC,
+               'training.superresolution.SuperresolutionHybrid8X': SuperresolutionHybrid8X}
 
 
 class OSGDecoder(ReferenceStateMixin, torch.nn.Module):
@@ -49,7 +50,7 @@ class TriPlaneGenerator(ReferenceStateMixin, torch.nn.Module):
         self._last_planes = None
         sr_name = rendering_kwargs.get('superresolution_module', 'training.superresolution.SuperresolutionHybrid8XDC')
         if sr_name not in _SR_MODULES:
-            raise NotImplementedError(f'superresolution module {sr_name} (only the 512^2 head is on the inversion path)')
+            raise NotImplementedError(f'superresolution module {sr_name} (the 512^2 heads 8XDC / 8X are built; the 128^2 / 256^2 heads of the ShapeNet configs are not)')
         synthesis_kwargs = {k: v for k, v in synthesis_kwargs.items() if k != 'num_fp16_res'}          # the backbone runs in fp32 (:40)
         self.renderer = ImportanceRenderer()
         self.ray_sampler = RaySampler()

@@ -225,6 +225,29 @@ def side_configs(G, target, cam, dev, use_graph, steps=10):
                     b.copy_(v)
     guarded('plain_g_synthesis_loop', plain_loop)
 
+    def phase_a_sr_f16x1():
+        # SURVEY section 7 / VERDICT r2 item 10: Phase A with the SR head in the reference's fp16-operand arithmetic (one MFMA product instead of
+        # three) -- the whole 400-step latent projection twice from the same seed, final PSNR of both and the drift between them
+        from inv3d_amd.inversion import psnr_01
+        res = {}
+        for key, flag in (('f16x3', False), ('sr_f16x1', True)):
+            pr = LatentProjector(G, target[:1], num_steps=400, cam=cam[:1], seed=321, use_graph=use_graph, sr_fp16=flag)
+            pr.preheat = 0
+            for _ in range(pr._graph_warmup + 1):
+                pr.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_timed = 400 - pr.step_idx
+            for _ in range(n_timed):
+                out = pr.step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res[key] = dict(steps_per_s=round(n_timed / dt, 2), final_psnr_db=round(float(psnr_01(out['image'], target[:1])), 4))
+        res['final_psnr_drift_db'] = round(abs(res['f16x3']['final_psnr_db'] - res['sr_f16x1']['final_psnr_db']), 4)
+        res['note'] = '400-step latent projection, same seed; sr_f16x1 = super-resolution head with one product of fp16-rounded operands (the reference uses force_fp32=True in this phase: an option, not the default)'
+        return res
+    guarded('phase_a_sr_f16x1', phase_a_sr_f16x1)
+
     def phase_b():
         import copy
         state = copy.deepcopy(G.state_dict())

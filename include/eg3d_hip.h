@@ -318,6 +318,14 @@ typedef struct eg3d_flrelu_params {
     float gain, slope, clamp;  /* mode 0 only; clamp < 0 = none */
 } eg3d_flrelu_params;
 int eg3d_filtered_lrelu(const eg3d_flrelu_params* p, void* stream);
+/* The plugin's stand-alone activation `filtered_lrelu_act_` (torch_utils/ops/filtered_lrelu.cpp:217-272; kernel filtered_lrelu.cu:1110-1215),
+ * in place on a contiguous [NC, H, W] tensor:  v = x * gain, then
+ *   mode 1 (write signs)  v < 0 -> v *= slope (sign 1);  |v| > clamp -> v = +-clamp (sign 2);  the 2-bit signs go to `signs`
+ *   mode 2 (read signs)   bit 0 of the sign at (x + sx, y + sy) -> v *= slope;  bit 1 -> v = 0;  outside the sign image: gain only
+ *   mode 0                as mode 1 without a sign image.
+ * signs: [NC][sH][sW / 4] bytes, element x in bits 2 (x & 3) of byte x >> 2, sW % 4 == 0 (mode 1: sH >= H, sW >= W).  clamp < 0: none. */
+int eg3d_filtered_lrelu_act(void* x, uint8_t* signs, int dtype, int NC, int H, int W, int sH, int sW, int sx, int sy, float gain, float slope,
+                            float clamp, int mode, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Style affines of a whole synthesis network in one launch (the per-layer FullyConnectedLayer(w_dim -> in_channels) of

@@ -1,0 +1,124 @@
+"""The reference-recorded fixtures that round 2 only fed to the CPU oracle, read directly by the HIP path:
+modulated_conv2d.npz (16 cases: up 1|2 x demodulate x fused x noise; y, dx, dw, ds), fully_connected.npz, loss_glue.npz (rotation
+parametrisations, pose -> camera block with gradients, noise regulariser, depth TV, line-plane intersection) and inference.npz (look-at poses,
+orbit, sampling grid, density grid, mean-latent statistics) -- all produced by the reference's own code in tests/golden/make_golden.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import eg3d_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a)).to(DEV)
+
+
+def close(a, b, tol, what=''):
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(np.asarray(b) if not torch.is_tensor(b) else b).detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert torch.isfinite(a).all(), what
+    scale = max(1.0, float(b.abs().max())) if b.numel() else 1.0
+    err = float((a - b).abs().max()) if a.numel() else 0.0
+    assert err <= tol * scale, f'{what}: err {err:.3e} > {tol} * {scale:.3e}'
+
+
+def test_modulated_conv2d_fixture(golden):
+    """training/networks_stylegan2.py:34-91 through the product's stand-alone operator (activation-scaled form on the implicit-GEMM conv
+    and FIR kernels): forward and all three gradients of every recorded case."""
+    from inv3d_amd.training.networks_stylegan2 import modulated_conv2d
+    d = golden('modulated_conv2d')
+    f44 = t(d['f44'])
+    for i in range(int(d['ncases'])):
+        k = f'c{i}'
+        up, demod, fused = [int(v) for v in d[f'{k}_meta']]
+        x, w, s = (t(d[f'{k}_{n}']).requires_grad_(True) for n in ('x', 'w', 's'))
+        nz = t(d[f'{k}_noise'])
+        nz = None if nz.numel() == 0 else nz
+        y = modulated_conv2d(x, w, s, noise=nz, up=up, padding=1, resample_filter=f44, demodulate=bool(demod), flip_weight=(up == 1),
+                             fused_modconv=bool(fused))
+        close(y, d[f'{k}_y'], 2e-5, f'case {i} y')
+        dx, dw, ds = torch.autograd.grad(y, [x, w, s], t(d[f'{k}_dy']))
+        close(dx, d[f'{k}_dx'], 2e-5, f'case {i} dx')
+        close(dw, d[f'{k}_dw'], 2e-5, f'case {i} dw')
+        close(ds, d[f'{k}_ds'], 2e-5, f'case {i} ds')
+
+
+def test_fully_connected_fixture(golden):
+    from inv3d_amd.training.networks_stylegan2 import FullyConnectedLayer
+    d = golden('fully_connected')
+    for i in range(int(d['ncases'])):
+        x, w, b = t(d[f'c{i}_x']), t(d[f'c{i}_w']), t(d[f'c{i}_b'])
+        fc = FullyConnectedLayer(w.shape[1], w.shape[0], bias=b.numel() > 0, activation=str(d[f'c{i}_act']), lr_multiplier=float(d[f'c{i}_lr'])).to(DEV)
+        with torch.no_grad():
+            fc.weight.copy_(w)
+            if b.numel():
+                fc.bias.copy_(b)
+        close(fc(x), d[f'c{i}_y'], 1e-5, f'fc case {i}')
+
+
+def test_loss_glue_fixture(golden):
+    from inv3d_amd import inversion as INV, hipops as H
+    g = golden('loss_glue')
+    close(INV.quaternion_to_rotmat(t(g['q'])), g['R'], 1e-6, 'quat')
+    close(INV.rot6d_to_rotmat(t(g['x6'])), g['R6'], 1e-6, '6d')
+    close(torch.cat([INV.pose_to_rotmat(a[None], 'euler') for a in t(g['ang'])]), g['Re'], 1e-6, 'euler')
+    close(INV.compute_tv_norm(t(g['tv_in'])), g['tv'], 1e-6, 'tv')
+    bufs = [t(g[f'reg_buf{i}']).contiguous() for i in range(6)]
+    reg, grads = H.noise_regularizer(bufs, scale=1.0, want_grad=True)            # the three-pass multi-block kernels of csrc/noise_ops.hip
+    close(reg, g['reg'], 1e-5, 'noise regulariser')
+    rb = [b.cpu().clone().requires_grad_(True) for b in bufs]
+    O.noise_regularizer(rb).backward()
+    for i, (a, b) in enumerate(zip(grads, rb)):
+        close(a, b.grad, 1e-5 * max(1.0, float(b.grad.abs().max())), f'd reg / d buffer {i}')
+    intr = torch.tensor([4.2647, 0, 0.5, 0, 4.2647, 0.5, 0, 0, 1], device=DEV).unsqueeze(0)
+    for mode in ('quat', '6d', 'euler'):
+        pr, tr = t(g[f'pose_{mode}_pred']).requires_grad_(True), t(g[f'pose_{mode}_tr']).requires_grad_(True)
+        _, cam = INV.pose_to_cam(INV.pose_to_rotmat(pr, mode), tr, intr, 2.7)
+        close(cam, g[f'pose_{mode}_cam'], 1e-6, f'{mode} cam')
+        d_pr, d_tr = torch.autograd.grad(cam, [pr, tr], t(g[f'pose_{mode}_gcam']))
+        close(d_pr, g[f'pose_{mode}_dpred'], 5e-5, f'{mode} d pred')
+        close(d_tr, g[f'pose_{mode}_dtr'], 5e-5, f'{mode} d tr')
+    args = [t(g[k]) for k in ('lpc_n', 'lpc_p', 'lpc_d', 'lpc_o')]
+    close(INV.line_plane_intersection(*args), g['lpc_out'], 1e-5, 'line-plane')
+
+
+def test_inference_fixture(golden):
+    from inv3d_amd import inference as INF, synthetic as S
+    d = golden('inference')
+    for (h, v), m in zip(d['hv'], d['poses']):
+        close(INF.lookat_pose(float(h), float(v), (0., 0., 0.), 2.7, device=DEV), m, 1e-6, 'lookat')
+    close(INF.orbit_cameras(8).to(DEV), d['orbit8'], 1e-6, 'orbit')
+    close(INF._grid_points(20, 1.0, 0, 8000, DEV).unsqueeze(0), d['samples20'], 1e-6, 'grid points')
+    cfg = O.small_config()
+    G = S.make_generator(w_dim=32, z_dim=32, plane_res=32, channel_base=256, channel_max=16, nrr=16, sr_in_res=16, sr_widths=(16, 8),
+                         rendering_kwargs=cfg.rendering, device=DEV)
+    S.load_synthetic_weights(G, 0)
+    grid = INF.density_grid(G, t(d['grid_ws']), res=12)
+    close(grid.reshape(np.asarray(d['grid12']).shape), d['grid12'], 5e-5, 'density grid')
+
+
+def test_filtered_lrelu_act_entry_point():
+    """eg3d_filtered_lrelu_act (torch_utils/ops/filtered_lrelu.cpp:217-272, the plugin's stand-alone activation with the packed 2-bit sign
+    image): write mode then read mode reproduce the forward value and the gradient mask of lrelu + clamp."""
+    from inv3d_amd.torch_utils.ops import filtered_lrelu as FL
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(2, 3, 10, 24, generator=g) * 2).to(DEV)
+    gain, slope, clamp = 1.4, 0.2, 2.0
+    y = x.clone()
+    signs = FL.filtered_lrelu_act_(y, None, 0, 0, gain, slope, clamp, write_signs=True)
+    ref = torch.nn.functional.leaky_relu(x * gain, slope).clamp(-clamp, clamp)
+    close(y, ref, 1e-6, 'act forward')
+    assert signs.dtype == torch.uint8 and tuple(signs.shape) == (2, 3, 10, 6)
+    dy = torch.randn(2, 3, 10, 24, generator=g).to(DEV)
+    dx = dy.clone()
+    FL.filtered_lrelu_act_(dx, signs, 0, 0, gain, slope, clamp, write_signs=False)
+    v = x * gain
+    mask = torch.where(v < 0, torch.full_like(v, slope), torch.ones_like(v))
+    mask = torch.where(torch.nn.functional.leaky_relu(v, slope).abs() > clamp, torch.zeros_like(v), mask)
+    close(dx, dy * gain * mask, 1e-6, 'act backward through the sign image')
+    z = x.clone()
+    FL.filtered_lrelu_act_(z, None, 0, 0, gain, slope, clamp, write_signs=False)
+    close(z, ref, 1e-6, 'act forward without signs')

@@ -581,3 +581,54 @@ def test_config_c4_at_full_size_replays_from_a_graph():
     assert all(math.isfinite(v) for v in losses)
     assert losses[-1] < 0.8 * losses[0], losses
     assert max(losses[3:]) <= losses[2] * 1.25, losses          # no blow-up at the eager -> replay -> eager transitions (fresh noise every step: not monotone)
+
+
+def test_pose_and_warping_c3_long_horizon():
+    """Config C3 over 60 steps (10 camera pre-heat + 50 joint steps, the reference's learning rates): the pose chain and the warping loss
+    well past the pre-heat against the CPU twin on identical inputs.  Bound stated here, not inherited: final-PSNR drift <= 2e-2 dB and
+    |loss drift| <= 0.5 % -- the pose gradients are sums of piecewise-constant per-sample terms (a 1-ulp coordinate difference moves one
+    sample across a texel edge), Adam turns every such flip into a full-size step of the pose vector, and 50 steps let the two
+    trajectories decorrelate by that mechanism; the projector-loop pin (6 steps, reference trace) holds 1e-3 dB."""
+    from inv3d_amd.inversion import LatentProjector
+    cfg, P, G, cam, u1, u2, target, init_noise = _setup()
+    steps, preheat = 60, 10
+    kw = dict(num_steps=steps, init_noise=init_noise, optimize_pose=True, use_warping_loss=True, cam_preheat_steps=preheat)
+    ref = IO.ProjectorOracle(P, cfg, target, **kw)
+    hip = LatentProjector(G, target.to(DEV), **kw)
+    q0 = torch.tensor([[0.06, 0.97, 0.11, -0.04]])
+    with torch.no_grad():
+        ref.quat.copy_(q0); hip.quat.copy_(q0.to(DEV))
+        ref.translation_opt.copy_(torch.tensor([[0.01, -0.02, 0.015]])); hip.translation_opt.copy_(ref.translation_opt.to(DEV))
+    uni = (u1.to(DEV), u2.to(DEV))
+    worst = 0.0
+    for i in range(steps):
+        wn = O._randn('wn', i, (1, 1, cfg.w_dim))
+        r = ref.step(u1, u2, w_noise=wn)
+        h = hip.step(w_noise=wn, render_uniforms=uni)
+        worst = max(worst, abs(_psnr(h['image'], target) - _psnr(r['image'], target)))
+    drift = abs(_psnr(h['image'], target) - _psnr(r['image'], target))
+    print(f'C3 60 steps: final PSNR drift {drift:.2e} dB (worst along the way {worst:.2e}), loss {float(h["loss"]):.5f} vs {float(r["loss"]):.5f}')
+    assert drift <= 2e-2, f'final PSNR drift {drift:.2e} dB'
+    assert abs(float(h['loss']) - float(r['loss'])) <= 5e-3 * max(1.0, abs(float(r['loss'])))
+    assert float((hip.w_opt.detach().cpu() - ref.w_opt.detach()).abs().max()) < 5e-2
+
+
+def test_run_to_run_drift_of_the_atomically_accumulated_gradients():
+    """The default path accumulates style / bias / noise / split-K partial sums with fp32 atomics (csrc/conv_v2_common.h, conv_igemm.hip,
+    epilogue.hip): the ORDER of those additions varies from run to run, so two runs of the same trajectory are not bit-identical.  This
+    bounds what that does to a 150-step latent projection (same seeds, same injected noise and sampling uniforms): final-PSNR difference
+    <= 1e-3 dB, latent difference <= 1e-3 -- the level of the parity bar itself.  (An ordered-reduction mode is not implemented.)"""
+    from inv3d_amd.inversion import LatentProjector
+    cfg, P, G, cam, u1, u2, target, init_noise = _setup()
+    w_start = O.synth_ws(cfg, 1, seed=1)[:, :1]
+    uni = (u1.to(DEV), u2.to(DEV))
+    runs = []
+    for rep in range(2):
+        pr = LatentProjector(G, target.to(DEV), num_steps=150, cam=cam.to(DEV), init_noise=init_noise, start_w=w_start)
+        for i in range(150):
+            out = pr.step(w_noise=O._randn('wn', i, (1, 1, cfg.w_dim)), render_uniforms=uni)
+        runs.append((pr.w_opt.detach().clone(), _psnr(out['image'], target), float(out['dist'])))
+    dw = float((runs[0][0] - runs[1][0]).abs().max())
+    dp = abs(runs[0][1] - runs[1][1])
+    print(f'run-to-run: |d w| {dw:.2e}, |d PSNR| {dp:.2e} dB, dist {runs[0][2]:.6f} vs {runs[1][2]:.6f}')
+    assert dp <= 1e-3 and dw <= 1e-3
