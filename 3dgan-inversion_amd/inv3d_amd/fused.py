@@ -147,18 +147,6 @@ def prepack_weights(layers):
     return len(items)
 
 
-_SIDE_STREAMS = {}
-
-
-def _side_stream(device):
-    """One auxiliary stream per device for small launches that are independent of the kernel issued next (forked and joined around it)."""
-    key = str(device)
-    st = _SIDE_STREAMS.get(key)
-    if st is None:
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return st
-
-
 def _zeros_views(device, *shapes):
     """Several small zero-initialised accumulators (targets of atomics) from ONE allocation and ONE fill launch.  A shape of
     None yields None.  Every view starts on a 16-byte boundary."""
@@ -303,17 +291,13 @@ class ModConvLayerFn(torch.autograd.Function):
                 if ragged:      # the full (Hi + 1) x (Wi + 1) cell grid still fits one round of workgroups
                     H.conv_up2(aimg, wimg, z, epi=L.EPI_ATOMIC if ksplit > 1 else L.EPI_STORE, ksplit=ksplit, products=nprod, algo_flops=aflops)
                 else:
-                    # main grid (Hi x Wi cells, perfectly tiled) on the fused-parity kernel; the last output row / column (1-D problems: 25 us
-                    # of latency for 0.1 GFLOP) as four small tap classes of the loader-split kernel on a forked stream (a parallel branch of
-                    # a captured graph): it writes pixels the main launch does not touch
-                    cur = torch.cuda.current_stream()
-                    side = _side_stream(x.device)
-                    side.wait_stream(cur)
-                    with torch.cuda.stream(side):
-                        H.conv_igemm(x, wf, Ci, Co, z, H.up2_border_classes(Hi, Wi), out_stride=up, in_scale=styles, epi=L.EPI_STORE, algo_flops=0.0,
-                                     precision=ig_prec, w_pieces=wfp)
+                    # main grid (Hi x Wi cells, perfectly tiled) on the fused-parity kernel; the last output row / column (1-D problems, ~20 us
+                    # of latency for 0.1 GFLOP) as four small tap classes of the loader-split kernel.  (Forking that launch onto a second
+                    # stream hides it at N = 1 -- but two processes sharing one device then replayed the two-branch graph at 1.2 s per step:
+                    # not worth the risk on an 8-rank node.)
                     H.conv_up2(aimg, wimg, z, Hc=Hi, Wc=Wi, epi=L.EPI_ATOMIC if ksplit > 1 else L.EPI_STORE, ksplit=ksplit, products=nprod, algo_flops=aflops)
-                    cur.wait_stream(side)
+                    H.conv_igemm(x, wf, Ci, Co, z, H.up2_border_classes(Hi, Wi), out_stride=up, in_scale=styles, epi=L.EPI_STORE, algo_flops=0.0,
+                                 precision=ig_prec, w_pieces=wfp)
             elif v2:
                 z = H.empty_cl(N, Co, Hz, Wz, x.device)
                 H.conv_v2(aimg, wimg, z, cls, out_stride=up, epi=L.EPI_STORE, algo_flops=aflops)
