@@ -9,6 +9,9 @@
 //    (networks_stylegan2.py:62-66) factored as sum_k s^2 * (sum_taps w^2), so that the conv can share weights
 //    across the batch (activation-scaled formulation, numerically interchangeable: SURVEY.md section 7).
 #include "common.h"
+#include <cstdlib>
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef __fp16 ue_fp16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -161,6 +164,139 @@ __global__ void __launch_bounds__(256) epilogue_fwd_fir44_kernel(const float* __
     commit_amax(am, out_amax);
 }
 
+// ---- the up layers' epilogue through LDS, optionally writing the consumer's split operand image ---------------------------------------------
+// Same arithmetic as epilogue_fwd_fir44_kernel for a SEPARABLE 4-tap FIR (outer(k, k), the [1,3,3,1] filter of every up layer):
+//   phase 1 (lanes along channels, 256-byte runs of a pixel): each thread walks the TH + 3 input rows of its (column, channel quad) once and
+//           leaves the TH vertical sums in LDS -- every z element is loaded (TH + 3) / TH x (TW + 3) / TW = 1.6 times instead of 25 / 4 = 6.25;
+//   phase 2 (lanes along channels): horizontal sums, demodulation, noise, bias, activation, gain, clamp; 16-byte stores; max|out|;
+//   phase 3 (SPLIT only; lanes along pixels): the activated tile, kept in LDS, is multiplied by the CONSUMER's styles and written as that
+//           layer's two-piece fp16 operand image (conv_v2.hip layout) -- the separate split pass (read 4 B + write 4 B per element) of the
+//           consumer disappears.  The image needs its range before the tile exists, so this form requires clamp >= 0 (the super-resolution
+//           head, conv_clamp = 256): |out| <= clamp is the bound; scale = the power of two that brings clamp * max|styles| to [2^13, 2^14).
+// Measured on MI355X, 513^2 x 128 -> 512^2 x 128: 94 us (2.9 TB/s) for the 25-load form.
+constexpr int UE_TH = 8, UE_TW = 16, UE_CH = 64, UE_PITCH = UE_CH + 4, UE_COLS = UE_TW + 3;
+
+__device__ __forceinline__ float ue_range_mul(float amax) {
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+    int e;
+    (void)frexpf(amax, &e);
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    return ldexpf(1.f, 14 - e);
+}
+
+template <bool SPLIT>
+__global__ void __launch_bounds__(256) upconv_epilogue_kernel(const float* __restrict__ z, float* __restrict__ out, int N, int H, int W, int C, int Hz, int Wz,
+                                                             float k0, float k1, float k2, float k3, int pad0, float fir_gain, const float* __restrict__ d,
+                                                             const float* __restrict__ noise, int64_t noise_nstride, const float* __restrict__ noise_strength,
+                                                             const float* __restrict__ bias, float slope, float gain, float clamp, float* out_amax,
+                                                             const float* __restrict__ sp_scale_in, _Float16* __restrict__ sp_image, float* sp_scale_out) {
+    __shared__ __attribute__((aligned(16))) float V[UE_TH * UE_COLS * UE_PITCH];                       // vertical sums [row][column][channel]
+    __shared__ __attribute__((aligned(16))) float O[SPLIT ? UE_TH * UE_TW * UE_PITCH : 4];              // activated tile (SPLIT)
+    __shared__ float red[4];
+    const int tiles_x = (W + UE_TW - 1) / UE_TW, tiles_y = (H + UE_TH - 1) / UE_TH;
+    const int n = blockIdx.x / (tiles_x * tiles_y);
+    const int t = blockIdx.x - n * tiles_x * tiles_y;
+    const int y0 = (t / tiles_x) * UE_TH, x0 = (t % tiles_x) * UE_TW;
+    const int c0 = blockIdx.y * UE_CH;
+    const float kk[4] = {k3, k2, k1, k0};                    // true convolution: tap i of the window meets filter element 3 - i
+    float sp_mul = 1.f;
+    if (SPLIT) {
+        float m = 0.f;
+        for (int i = threadIdx.x; i < N * C; i += 256) m = fmaxf(m, fabsf(sp_scale_in[i]));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        sp_mul = ue_range_mul(clamp * fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *sp_scale_out = sp_mul;
+    }
+    // ---- phase 1
+    for (int it = threadIdx.x; it < UE_COLS * (UE_CH / 4); it += 256) {
+        const int col = it / (UE_CH / 4), c4 = it - col * (UE_CH / 4);
+        const int x = x0 - pad0 + col;
+        float4 r[UE_TH + 3];
+#pragma unroll
+        for (int q = 0; q < UE_TH + 3; ++q) {
+            const int y = y0 - pad0 + q;
+            r[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)y < (unsigned)Hz && (unsigned)x < (unsigned)Wz) r[q] = ld4(z + ((int64_t)(n * Hz + y) * Wz + x) * C + c0 + c4 * 4);
+        }
+#pragma unroll
+        for (int oy = 0; oy < UE_TH; ++oy) {
+            float4 v;
+            v.x = (r[oy].x * kk[0] + r[oy + 1].x * kk[1]) + (r[oy + 2].x * kk[2] + r[oy + 3].x * kk[3]);
+            v.y = (r[oy].y * kk[0] + r[oy + 1].y * kk[1]) + (r[oy + 2].y * kk[2] + r[oy + 3].y * kk[3]);
+            v.z = (r[oy].z * kk[0] + r[oy + 1].z * kk[1]) + (r[oy + 2].z * kk[2] + r[oy + 3].z * kk[3]);
+            v.w = (r[oy].w * kk[0] + r[oy + 1].w * kk[1]) + (r[oy + 2].w * kk[2] + r[oy + 3].w * kk[3]);
+            *reinterpret_cast<float4*>(V + (oy * UE_COLS + col) * UE_PITCH + c4 * 4) = v;
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: item = (row, column, channel quad); a thread keeps its channel quad
+    const float strength = noise ? *noise_strength : 0.f;
+    const int c4 = threadIdx.x & 15, c = c0 + c4 * 4;
+    float4 dv = make_float4(1.f, 1.f, 1.f, 1.f), bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d != nullptr) dv = ld4(d + (int64_t)n * C + c);
+    if (bias != nullptr) bv = ld4(bias + c);
+    float am = 0.f;
+#pragma unroll
+    for (int k = 0; k < UE_TH * UE_TW * (UE_CH / 4) / 256; ++k) {
+        const int pix = (threadIdx.x >> 4) + k * 16;                                  // 0 .. 127
+        const int oy = pix / UE_TW, ox = pix - oy * UE_TW;
+        const int y = y0 + oy, x = x0 + ox;
+        const float* vp = V + (oy * UE_COLS + ox) * UE_PITCH + c4 * 4;
+        const float4 a0 = *reinterpret_cast<const float4*>(vp), a1 = *reinterpret_cast<const float4*>(vp + UE_PITCH),
+                     a2 = *reinterpret_cast<const float4*>(vp + 2 * UE_PITCH), a3 = *reinterpret_cast<const float4*>(vp + 3 * UE_PITCH);
+        float4 v;
+        v.x = ((a0.x * kk[0] + a1.x * kk[1]) + (a2.x * kk[2] + a3.x * kk[3])) * fir_gain;
+        v.y = ((a0.y * kk[0] + a1.y * kk[1]) + (a2.y * kk[2] + a3.y * kk[3])) * fir_gain;
+        v.z = ((a0.z * kk[0] + a1.z * kk[1]) + (a2.z * kk[2] + a3.z * kk[3])) * fir_gain;
+        v.w = ((a0.w * kk[0] + a1.w * kk[1]) + (a2.w * kk[2] + a3.w * kk[3])) * fir_gain;
+        const bool ok = y < H && x < W;
+        float nz = 0.f;
+        if (ok && noise != nullptr) nz = noise[(int64_t)n * noise_nstride + (int64_t)y * W + x] * strength;
+        v.x = act1<true>(v.x * dv.x + nz + bv.x, 0, slope, gain, clamp); v.y = act1<true>(v.y * dv.y + nz + bv.y, 0, slope, gain, clamp);
+        v.z = act1<true>(v.z * dv.z + nz + bv.z, 0, slope, gain, clamp); v.w = act1<true>(v.w * dv.w + nz + bv.w, 0, slope, gain, clamp);
+        if (ok) {
+            am = amax4(am, v);
+            st4(out + (((int64_t)n * H + y) * W + x) * C + c, v);
+        }
+        if (SPLIT) *reinterpret_cast<float4*>(O + pix * UE_PITCH + c4 * 4) = v;
+    }
+    if (SPLIT) {
+        // ---- phase 3: item = (octet, pixel), lanes along the pixels of a tile row (16 x 16 bytes contiguous in a plane's row)
+        __syncthreads();
+        const int noct = C / 8;
+        const int64_t HW = (int64_t)H * W;
+        f16x8_t* img = reinterpret_cast<f16x8_t*>(sp_image);
+#pragma unroll
+        for (int k = 0; k < UE_TH * UE_TW * (UE_CH / 8) / 256; ++k) {
+            const int item = threadIdx.x + k * 256;
+            const int pix = item & (UE_TH * UE_TW - 1), kl = item >> 7;
+            const int oy = pix / UE_TW, ox = pix - oy * UE_TW;
+            const int y = y0 + oy, x = x0 + ox;
+            if (y >= H || x >= W) continue;
+            const float4 lo = *reinterpret_cast<const float4*>(O + pix * UE_PITCH + kl * 8), hi = *reinterpret_cast<const float4*>(O + pix * UE_PITCH + kl * 8 + 4);
+            const float* sr = sp_scale_in + (int64_t)n * C + c0 + kl * 8;
+            const float v[8] = {lo.x * sr[0], lo.y * sr[1], lo.z * sr[2], lo.w * sr[3], hi.x * sr[4], hi.y * sr[5], hi.z * sr[6], hi.w * sr[7]};
+            f16x8_t h, l;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float a = v[2 * q] * sp_mul, b = v[2 * q + 1] * sp_mul;
+                const ue_fp16x2 hh = __builtin_amdgcn_cvt_pkrtz(a, b);
+                const float ra = __builtin_amdgcn_fmed3f((a - (float)hh[0]) * 2048.f, -65504.f, 65504.f);
+                const float rb = __builtin_amdgcn_fmed3f((b - (float)hh[1]) * 2048.f, -65504.f, 65504.f);
+                h[2 * q] = (_Float16)hh[0]; h[2 * q + 1] = (_Float16)hh[1];
+                l[2 * q] = (_Float16)ra; l[2 * q + 1] = (_Float16)rb;
+            }
+            const int ko = c0 / 8 + kl;
+            img[((int64_t)(n * 2 + 0) * noct + ko) * HW + (int64_t)y * W + x] = h;
+            img[((int64_t)(n * 2 + 1) * noct + ko) * HW + (int64_t)y * W + x] = l;
+        }
+    }
+    commit_amax(am, out_amax);
+}
+
 // derivative factor and recovered pre-activation for one element
 template <bool PWL>
 __device__ __forceinline__ void bwd1(float dout, float o, int act, float alpha, float gain, float clamp, float& dy, float& pre) {
@@ -176,6 +312,11 @@ __device__ __forceinline__ void bwd1(float dout, float o, int act, float alpha, 
 // 2*C atomics onto the same dbias / dd addresses (measured: launch time grows linearly with the block count), so the
 // parallelism comes from 16 waves per block rather than from many blocks.
 constexpr int EPI_BWD_THREADS = 1024;
+// blocks of the activation-backward / finishing passes (one block of 16 waves per CU by default; EG3D_EPI_BWD_CAP overrides, for tuning)
+static int epi_bwd_cap() {
+    static const int v = [] { const char* e = getenv("EG3D_EPI_BWD_CAP"); const int c = e ? atoi(e) : 256; return c > 0 ? c : 256; }();
+    return v;
+}
 // FIN: the incoming gradient is not read but formed on the fly as the finish of a split-K data gradient of the CONSUMER layer,
 // dout = fz * fs[n,c] (+ fadd), and that layer's style gradient fds[n,c] += sum_px fz * out rides along (eg3d_dgrad_finish_act).
 struct FinArgs { const float* z; const float* s; const float* addend; float* ds; const float* dy4; const float* wa4; };
@@ -596,7 +737,7 @@ extern "C" int eg3d_modconv_epilogue_bwd(const float* dout, const float* out, fl
     const int ppb = std::max(EPI_BWD_THREADS / C4, 1);
     // one atomic per (block, channel) lands on the same N*C addresses: keep the block count near the CU count
     // >= 4 pixels per thread (one unrolled trip; 8 was 5 us slower on the 8^2..32^2 layers, equal above) so that the per-block channel atomics stay a small fraction of the work
-    const int cap = 256;
+    const int cap = epi_bwd_cap();
     int bx = std::max(1, std::min(eg3d_cdiv((int64_t)H * W, ppb * 4), std::max(1, cap / N)));
     size_t smem = (size_t)(ppb * C4 * 8 + 4) * sizeof(float);
     const FinArgs nofin = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -617,7 +758,7 @@ extern "C" int eg3d_dgrad_finish_act(const float* z, const float* x, const float
     if (ab->act != EG3D_ACT_LINEAR && ab->act != EG3D_ACT_LRELU) return EG3D_ERR_UNSUPPORTED;
     if ((ab->dd && !ab->d) || ((ab->noise || ab->dnoise || ab->dstrength) && !ab->noise_strength) || ((ab->dnoise || ab->dstrength) && !ab->noise)) return EG3D_ERR_INVALID;
     const int C4 = C / 4, ppb = std::max(EPI_BWD_THREADS / C4, 1);
-    int bx = std::max(1, std::min(eg3d_cdiv((int64_t)H * W, ppb * 4), std::max(1, 256 / N)));
+    int bx = std::max(1, std::min(eg3d_cdiv((int64_t)H * W, ppb * 4), std::max(1, epi_bwd_cap() / N)));
     const size_t smem = (size_t)(ppb * C4 * 12 + 4) * sizeof(float);
     static std::atomic<uint64_t> attr_done{0};
     auto kern = epilogue_bwd_kernel<true, true>;
@@ -637,7 +778,7 @@ extern "C" int eg3d_torgb_dgrad_act(const float* dy4, const float* wa4, const fl
     if (ab->act != EG3D_ACT_LINEAR && ab->act != EG3D_ACT_LRELU) return EG3D_ERR_UNSUPPORTED;
     if ((ab->dd && !ab->d) || ((ab->noise || ab->dnoise || ab->dstrength) && !ab->noise_strength) || ((ab->dnoise || ab->dstrength) && !ab->noise)) return EG3D_ERR_INVALID;
     const int C4 = C / 4, ppb = std::max(EPI_BWD_THREADS / C4, 1);
-    int bx = std::max(1, std::min(eg3d_cdiv((int64_t)H * W, ppb * 4), std::max(1, 256 / N)));
+    int bx = std::max(1, std::min(eg3d_cdiv((int64_t)H * W, ppb * 4), std::max(1, epi_bwd_cap() / N)));
     const size_t smem = (size_t)(ppb * C4 * 12 + 4) * sizeof(float);
     static std::atomic<uint64_t> attr_done{0};
     auto kern = epilogue_bwd_kernel<true, true>;
@@ -655,7 +796,7 @@ extern "C" int eg3d_dgrad_finish(const float* z, const float* x, const float* s,
     if (!z || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (ds && !x)) return EG3D_ERR_INVALID;
     if (C % 4 || C / 4 > 256) return EG3D_ERR_UNSUPPORTED;
     const int C4 = C / 4, ppb = std::max(EPI_BWD_THREADS / C4, 1);
-    int bx = std::max(1, std::min(eg3d_cdiv((int64_t)H * W, ppb * 8), std::max(1, 256 / N)));
+    int bx = std::max(1, std::min(eg3d_cdiv((int64_t)H * W, ppb * 8), std::max(1, epi_bwd_cap() / N)));
     hipLaunchKernelGGL(dgrad_finish_kernel, dim3(bx, N), dim3(EPI_BWD_THREADS), (size_t)ppb * C4 * 4 * sizeof(float), (hipStream_t)stream, z, x, s, addend, dx, ds,
                        H * W, C4);
     EG3D_LAUNCH_CHECK();
@@ -757,6 +898,33 @@ extern "C" int eg3d_demod_bwd(const float* s, const float* wsq, const float* d, 
         hipLaunchKernelGGL(demod_bwd_kernel, dim3(eg3d_cdiv(Ck, 64), N, osplit), dim3(256), 0, (hipStream_t)stream, s, wsq, d, dd, ds, N, Co, Ck, osplit);
     }
     if (dwsq) hipLaunchKernelGGL(demod_bwd_wsq_kernel, dim3(eg3d_cdiv((int64_t)Co * Ck, 256)), dim3(256), 0, (hipStream_t)stream, s, d, dd, dwsq, N, Co, Ck);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+
+// The up layers' epilogue for a separable 4-tap FIR (host taps k[4]; 2-D filter = outer(k, k)), C % 64 == 0, piecewise-linear activation.
+// split_image / split_in_scale / split_scale_out (all or none; clamp >= 0 required): also write the consumer layer's operand image
+// split(out * split_in_scale[n,c]) in the layout of eg3d_split_activation (eg3d_split_activation_bytes(N, H, W, C) bytes).
+extern "C" int eg3d_upconv_epilogue_fwd(const float* z, float* out, int N, int H, int W, int C, int Hz, int Wz, const float* k4, int pad0, float fir_gain,
+                                        const float* d, const float* noise, int64_t noise_nstride, const float* noise_strength, const float* bias, int act,
+                                        float alpha, float gain, float clamp, float* out_amax, const float* split_in_scale, void* split_image,
+                                        float* split_scale_out, void* stream) {
+    if (!z || !out || !k4 || N <= 0 || H <= 0 || W <= 0 || C <= 0 || Hz <= 0 || Wz <= 0) return EG3D_ERR_INVALID;
+    if (C % UE_CH || !eg3d_act_is_pwl(act)) return EG3D_ERR_UNSUPPORTED;
+    if (noise && !noise_strength) return EG3D_ERR_INVALID;
+    const bool split = split_image != nullptr;
+    if (split && (!split_in_scale || !split_scale_out || !(clamp >= 0.f))) return EG3D_ERR_INVALID;
+    if ((reinterpret_cast<uintptr_t>(z) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) || (split && (reinterpret_cast<uintptr_t>(split_image) & 15))) return EG3D_ERR_UNSUPPORTED;
+    const dim3 grid(N * eg3d_cdiv(H, UE_TH) * eg3d_cdiv(W, UE_TW), C / UE_CH);
+    const float slope = eg3d_act_pwl_slope(act, alpha);
+    hipStream_t st = (hipStream_t)stream;
+    if (split)
+        hipLaunchKernelGGL(upconv_epilogue_kernel<true>, grid, dim3(256), 0, st, z, out, N, H, W, C, Hz, Wz, k4[0], k4[1], k4[2], k4[3], pad0, fir_gain, d, noise,
+                           noise_nstride, noise_strength, bias, slope, gain, clamp, out_amax, split_in_scale, reinterpret_cast<_Float16*>(split_image), split_scale_out);
+    else
+        hipLaunchKernelGGL(upconv_epilogue_kernel<false>, grid, dim3(256), 0, st, z, out, N, H, W, C, Hz, Wz, k4[0], k4[1], k4[2], k4[3], pad0, fir_gain, d, noise,
+                           noise_nstride, noise_strength, bias, slope, gain, clamp, out_amax, nullptr, nullptr, nullptr);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

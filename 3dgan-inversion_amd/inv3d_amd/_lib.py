@@ -146,6 +146,8 @@ _SIGS = {
     'eg3d_split_activation': (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]),
     'eg3d_split_weight': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
     'eg3d_absmax': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'eg3d_upconv_epilogue_fwd': (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int64,
+                                           C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'eg3d_filtered_lrelu_act': (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_float] * 3 + [C.c_int, C.c_void_p]),
     'eg3d_conv2d_v2_s2adj_supported': (C.c_int, [C.POINTER(ConvV2Params)]),
     'eg3d_conv2d_v2_s2adj': (C.c_int, [C.POINTER(ConvV2Params), C.c_void_p]),

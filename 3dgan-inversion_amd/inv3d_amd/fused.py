@@ -229,7 +229,7 @@ def _act_bwd_for(x, dev):
 class ModConvLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, styles, noise, noise_strength, bias, up, act_gain, clamp, cache, want_wgrad, d_in=None, single_consumer=False,
-                input_is_layer_output=False, precision=None):
+                input_is_layer_output=False, precision=None, next_styles=None):
         # precision: None = the process-wide arithmetic of the modulated convs; 'f16x1' = the reference's fp16 layers (one product of
         # fp16-rounded operands, fp32 accumulation; forward, data gradient and weight gradient alike)
         # x: CL [N,Ci,H,W]; weight [Co,Ci,3,3]; styles [N,Ci]; noise None | [res,res] | [N,1,res,res]; noise_strength 0-d
@@ -268,7 +268,11 @@ class ModConvLayerFn(torch.autograd.Function):
         ksu = H.conv_up2_plan(Ci, Co, Hi, Wi, N) if (up == 2 and not v2 and kh == 3 and kw == 3 and prec in ('f16x3', 'f16x1')) else None
         epi_kw = dict(noise=nz, noise_nstride=nstride or 0, noise_strength=noise_strength, bias=b, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv)
         if v2 or ks2 or ksu:   # pre-split operands: modulation, range normalisation and the fp16 split happen once, not per tile and tap
-            aimg = H.split_activation(x, H.amax_of(x), in_scale=styles)
+            pre_img = getattr(x, '_eg3d_split', None)           # (SplitImage, styles ptr, styles version) left by the producing layer's epilogue
+            if pre_img is not None and pre_img[1] == styles.data_ptr() and pre_img[2] == styles._version and pre_img[0].shape == tuple(x.shape):
+                aimg = pre_img[0]
+            else:
+                aimg = H.split_activation(x, H.amax_of(x), in_scale=styles)
             wimg = cache.get_split(weight)[0]
         if up == 1:
             if v2:
@@ -307,7 +311,18 @@ class ModConvLayerFn(torch.autograd.Function):
             else:
                 z = H.zeros_cl(N, Co, Hz, Wz, x.device)
                 H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=ig_prec, w_pieces=wfp)
-            H.epilogue_fwd(z, out, fir=fir44(x.device), pad0=1, fir_gain=float(up * up), d=d, out_amax=amax_out, **epi_kw)
+            simg = None
+            if H.UPCONV_EPI and Co % 64 == 0 and up == 2:
+                # consumer = a 3x3 layer on the pre-split kernel (same channel count, output resolution): its operand image comes out of this
+                # epilogue when the range is known beforehand (conv_clamp: the super-resolution head)
+                want_split = (H.UPCONV_EPI_SPLIT and next_styles is not None and clampv >= 0 and prec in ('f16x3', 'f16x1') and H.USE_V2
+                              and tuple(next_styles.shape) == (N, Co) and H.conv_v2_supported(Co, Co, H.classes_corr(Ho, Wo, 3, 3, 1), N))
+                ns = next_styles.contiguous().float() if want_split else None
+                simg = H.upconv_epilogue_fwd(z, out, pad0=1, fir_gain=float(up * up), d=d, out_amax=amax_out, split_in_scale=ns, **epi_kw)
+                if simg is not None:
+                    out._eg3d_split = (simg, ns.data_ptr(), ns._version)
+            else:
+                H.epilogue_fwd(z, out, fir=fir44(x.device), pad0=1, fir_gain=float(up * up), d=d, out_amax=amax_out, **epi_kw)
         H.tag_amax(out, amax_out)
         rec = None
         if FUSE_ACT_BWD and single_consumer and any(ctx.needs_input_grad[:6]):      # see _ActProducer: the consumer may run this layer's activation backward
@@ -452,7 +467,7 @@ class ModConvLayerFn(torch.autograd.Function):
         if dnoise is not None and noise4d:
             dnoise = dnoise.view(N, 1, Ho, Wo)
         return (dx if need_x else None, dweight, ds if need_s else None, dnoise, dstrength, dbias, None, None, None, None, None,
-                dd if d_given else None, None, None, None)
+                dd if d_given else None, None, None, None, None)
 
 
 class StyleBankFn(torch.autograd.Function):

@@ -751,6 +751,28 @@ def epilogue_fwd(z, out, fir=None, pad0=0, fir_gain=1.0, d=None, noise=None, noi
     return out
 
 
+UPCONV_EPI = os.environ.get('EG3D_UPCONV_EPI', '1') != '0'       # LDS-staged separable FIR epilogue for the up layers (eg3d_upconv_epilogue_fwd)
+UPCONV_EPI_SPLIT = os.environ.get('EG3D_UPCONV_EPI_SPLIT', '1') != '0'   # ... that also writes the consumer's split operand image (clamp-bounded layers)
+_K4 = (C.c_float * 4)(0.125, 0.375, 0.375, 0.125)
+
+
+def upconv_epilogue_fwd(z, out, pad0=1, fir_gain=4.0, d=None, noise=None, noise_nstride=0, noise_strength=None, bias=None, act='linear', alpha=0.0, gain=1.0,
+                        clamp=-1.0, out_amax=None, split_in_scale=None):
+    """eg3d_upconv_epilogue_fwd with the [1,3,3,1] / 8 taps.  split_in_scale (the consumer layer's styles [N,C]; needs clamp >= 0): also returns
+    that layer's SplitImage of `out`."""
+    assert is_cl(z) and is_cl(out)
+    n, c, h, w = out.shape
+    _, _, hz, wz = z.shape
+    img = scale = None
+    if split_in_scale is not None:
+        img = torch.empty((n * h * w * c * 2,), dtype=torch.float16, device=out.device)
+        scale = torch.empty((1,), dtype=torch.float32, device=out.device)
+    L.check(L.lib().eg3d_upconv_epilogue_fwd(L.ptr(z), L.ptr(out), n, h, w, c, hz, wz, _K4, pad0, float(fir_gain), L.ptr(d), L.ptr(noise), noise_nstride,
+                                             L.ptr(noise_strength), L.ptr(bias), L.ACT_IDS[act], float(alpha), float(gain), float(clamp), L.ptr(out_amax),
+                                             L.ptr(split_in_scale), L.ptr(img), L.ptr(scale), L.stream_ptr()), 'upconv_epilogue_fwd')
+    return SplitImage(img, scale, (n, c, h, w)) if img is not None else None
+
+
 def epilogue_bwd(dout, out, dz, d=None, noise=None, noise_nstride=0, noise_strength=None, bias=None, act='linear', alpha=0.0, gain=1.0,
                  clamp=-1.0, dbias=None, dd=None, dnoise=None, dnoise_nstride=0, dstrength=None, dz_amax=None):
     assert is_cl(dout) and is_cl(out) and is_cl(dz)

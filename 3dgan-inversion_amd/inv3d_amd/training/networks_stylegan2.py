@@ -135,7 +135,7 @@ class SynthesisLayer(ReferenceStateMixin, torch.nn.Module):
         self._cache = fused.WeightCache()
 
     def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, noise_inject=None, styles=None, demod=None, single_consumer=False,
-                input_is_layer_output=False, precision=None):
+                input_is_layer_output=False, precision=None, next_styles=None):
         """`styles` / `demod`: this layer's affine(w) and demodulation coefficients when the enclosing network already evaluated them
         for all layers in one launch (fused.style_bank).  `single_consumer`: the caller promises that the returned tensor feeds exactly one
         fused op (conv1 / toRGB of the same block), which lets that op's backward absorb this layer's activation backward (fused.py);
@@ -153,7 +153,7 @@ class SynthesisLayer(ReferenceStateMixin, torch.nn.Module):
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return fused.ModConvLayerFn.apply(x, self.weight, styles, noise, self.noise_strength if noise is not None else None, self.bias,
                                           self.up, self.act_gain * gain, clamp, self._cache, self.weight.requires_grad, demod, single_consumer,
-                                          input_is_layer_output, precision)
+                                          input_is_layer_output, precision, next_styles)
 
     def extra_repr(self):
         return f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}, w_dim={self.w_dim:d}, ' \
@@ -241,9 +241,10 @@ class SynthesisBlock(ReferenceStateMixin, torch.nn.Module):
             x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), styles=next(s_iter), demod=next(d_iter), single_consumer=True,
                            **layer_kwargs)
         else:       # conv0's output feeds conv1 only, conv1's the toRGB node only (which passes it on to the next block through itself)
-            x = self.conv0(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv0'), styles=next(s_iter), demod=next(d_iter), single_consumer=True,
-                           **layer_kwargs)
-            x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), styles=next(s_iter), demod=next(d_iter), single_consumer=True,
+            s0, s1 = next(s_iter), next(s_iter)          # conv1's styles are known before conv0 runs: its epilogue can write conv1's operand image
+            x = self.conv0(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv0'), styles=s0, demod=next(d_iter), single_consumer=True,
+                           next_styles=s1, **layer_kwargs)
+            x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), styles=s1, demod=next(d_iter), single_consumer=True,
                            input_is_layer_output=True, **layer_kwargs)
         if img is not None:
             img = fused.UpsampleImgFn.apply(img)

@@ -371,6 +371,15 @@ int eg3d_modconv_epilogue_fwd(const float* z, float* out, int N, int H, int W, i
                               const float* fir, int fh, int fw, int pad0, float fir_gain, const float* d,
                               const float* noise, int64_t noise_nstride, const float* noise_strength,
                               const float* bias, int act, float alpha, float gain, float clamp, float* out_amax, void* stream);
+/* The same epilogue for a SEPARABLE 4-tap FIR given by its host-side taps k4 (2-D filter = outer(k4, k4); the [1,3,3,1] / 8 filter of every
+ * up-sampling layer), C % 64 == 0, act in {linear, relu, lrelu}: staged through LDS (csrc/epilogue.hip: upconv_epilogue_kernel).  With
+ * split_image (+ split_in_scale [N,C] = the CONSUMER layer's styles, split_scale_out = device scalar; clamp >= 0 required, it is the range
+ * bound) the launch also writes that layer's operand image split(out * split_in_scale) exactly as eg3d_split_activation would
+ * (eg3d_split_activation_bytes(N, H, W, C) bytes), so the consumer needs no split pass of its own. */
+int eg3d_upconv_epilogue_fwd(const float* z, float* out, int N, int H, int W, int C, int Hz, int Wz, const float* k4, int pad0, float fir_gain,
+                             const float* d, const float* noise, int64_t noise_nstride, const float* noise_strength, const float* bias, int act,
+                             float alpha, float gain, float clamp, float* out_amax, const float* split_in_scale, void* split_image,
+                             float* split_scale_out, void* stream);
 
 /* bwd: given dout and the saved layer output `out`:
  *      dy = dout * act'(out) * gain   (0 where |out| >= clamp; derivative keyed on the OUTPUT as bias_act.cu:76,145)

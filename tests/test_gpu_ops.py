@@ -757,6 +757,41 @@ def test_conv_v2_stride2_adjoint_vs_torch(shape, products):
         assert float((dx - dx2).abs().max()) <= 2e-5 * scale
 
 
+@pytest.mark.parametrize('shape', [(1, 64, 16, 32), (2, 128, 9, 20), (1, 192, 33, 17)])
+def test_upconv_epilogue_lds_and_fused_split(shape):
+    """The LDS-staged separable FIR epilogue of the up layers (eg3d_upconv_epilogue_fwd) vs the 25-load kernel it replaces, on ragged tiles;
+    and its fused operand split: the image it writes for the consumer (range bound = conv_clamp, styles folded in) drives the pre-split
+    conv to the same result as the stand-alone split pass."""
+    from inv3d_amd import hipops as H, _lib as L
+    from inv3d_amd.fused import fir44
+    n, c, h, w = shape                                  # output h x w, z (h + 1) x (w + 1)
+    g = torch.Generator().manual_seed(61)
+    z = H.to_cl((torch.randn(n, c, h + 1, w + 1, generator=g) * 3).to(DEV))
+    d = (0.5 + torch.rand(n, c, generator=g)).to(DEV)
+    noise, strength = torch.randn(h, w, generator=g).to(DEV), torch.tensor(0.3, device=DEV)
+    bias = (0.1 * torch.randn(c, generator=g)).to(DEV)
+    kw = dict(d=d, noise=noise, noise_nstride=0, noise_strength=strength, bias=bias, act='lrelu', alpha=0.2, gain=math.sqrt(2.0))
+    for clamp in (-1.0, 4.0):
+        ref, out = H.empty_cl(n, c, h, w, DEV), H.empty_cl(n, c, h, w, DEV)
+        a0, a1 = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+        H.epilogue_fwd(z, ref, fir=fir44(DEV), pad0=1, fir_gain=4.0, clamp=clamp, out_amax=a0, **kw)
+        assert H.upconv_epilogue_fwd(z, out, pad0=1, fir_gain=4.0, clamp=clamp, out_amax=a1, **kw) is None
+        close(out, ref, 2e-6, f'upconv epilogue {shape} clamp {clamp}')
+        assert abs(float(a0) - float(a1)) <= 2e-6 * float(a0)
+    if c % 128 == 0:
+        s = (1 + 0.5 * torch.randn(n, c, generator=g)).to(DEV)
+        out = H.empty_cl(n, c, h, w, DEV)
+        simg = H.upconv_epilogue_fwd(z, out, pad0=1, fir_gain=4.0, clamp=4.0, split_in_scale=s, **kw)
+        wt = (torch.randn(128, c, 3, 3, generator=g) / math.sqrt(c * 9)).to(DEV)
+        wimg = H.split_weight(H.pack_weight_fwd(wt), 128, c, 9)
+        y1, y2 = H.empty_cl(n, 128, h, w, DEV), H.empty_cl(n, 128, h, w, DEV)
+        H.conv_v2(simg, wimg, y1, H.classes_corr(h, w, 3, 3, 1), epi=L.EPI_STORE)
+        H.conv_v2(H.split_activation(out, H.absmax(out), in_scale=s), wimg, y2, H.classes_corr(h, w, 3, 3, 1), epi=L.EPI_STORE)
+        refy = torch.nn.functional.conv2d(out.double().cpu() * s.double().cpu()[:, :, None, None], wt.double().cpu(), padding=1)
+        close(y1, refy.float(), 2e-5, 'conv on the image written by the epilogue')
+        close(y1, y2, 1e-5, 'fused split vs stand-alone split pass')
+
+
 def test_conv_v2_heavy_tailed_operands():
     """Operand ranges of a trained network nobody has loaded here: per-channel weight scales e^{N(0,3)}, activations with
     outliers up to 1e6 (beyond the fp16 range: 65 504), styles up to 50.  The split image is range-normalised by max|x| * max|s|, so
