@@ -188,6 +188,25 @@ def side_configs(G, target, cam, dev, use_graph, steps=10):
             tg = torch.cat([G.synthesis(ws_t[i:i + 1], cams[i:i + 1], noise_mode='const', force_fp32=True)['image'].clamp(-1, 1) for i in range(m)])
         r = projector(target=tg, cam=cams)()
         r['note'] = '8 independent inversions as one batch on this GPU = the per-GPU share of config C5 (64 images on 8 GPUs)'
+        # the conv kernels with the chip filled (at one image the 4^2 .. 128^2 layers are latency-bound): same accounting as `roofline`
+        from inv3d_amd import hipops as H
+        eager = LatentProjector(G, tg, num_steps=400, cam=cams, seed=100, use_graph=False)
+        eager.preheat = 0
+        eager.step()
+        prof = H.LaunchProfiler()
+        H.PROFILER = prof
+        try:
+            for _ in range(2):
+                eager.step()
+            torch.cuda.synchronize()
+        finally:
+            H.PROFILER = None
+        summ = prof.summary()
+        ms, fl = sum(v['ms'] for v in summ.values()), sum(v['flops'] for v in summ.values())
+        if ms > 0:
+            r['all_conv_tflops'] = round(fl / (ms * 1e-3) / 1e12, 1)
+            r['all_conv_frac_of_833'] = round(fl / (ms * 1e-3) / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 3), 4)
+            r['all_conv_ms_per_step'] = round(ms / 2, 3)
         return r
     guarded('images_per_gpu_8', c5)
 
@@ -395,11 +414,11 @@ def main():
             nprod = PRODUCTS[dom_prec]
             peak = FP32_MFMA_PEAK_TFLOPS if dom_prec == 'f32' else BF16_MFMA_PEAK_TFLOPS / nprod
             if is_v2:
-                kern, tkey = 'conv_v2_kernel<9,true> (pre-split fp16 pieces, LDS-DMA staged halo; fp32 in/out, 3 x v_mfma_f32_32x32x16_f16 per fp32 product)', 'conv_v2_kernel<9,true>'
+                kern, tkey = 'conv_v2_kernel<9,true,false> (pre-split fp16 pieces, LDS-DMA staged halo; fp32 in/out, 3 x v_mfma_f32_32x32x16_f16 per fp32 product)', 'conv_v2_kernel<9,true,false>'
             else:
                 kern = 'conv_igemm_kernel<%s,%d,*> (fp32 in/out, %d x MFMA per fp32 product)' % (H.TILE_NAMES.get(dom_id[0], '?'), H.PRECISIONS[dom_prec], nprod)
                 tkey = 'conv_igemm_kernel<%s>' % H.TILE_NAMES.get(dom_id[0], '?')
-            tr = traffic.get(tkey) or traffic.get(tkey.replace(',true>', '>'), {})
+            tr = traffic.get(tkey) or traffic.get(tkey.replace(',false>', '>')) or traffic.get(tkey.replace(',true>', '>'), {})
             per_launch_ref = tr.get('gflop_per_launch')
             tbytes = tr.get('bytes_per_launch')
             if tbytes is not None and per_launch_ref:           # the PMC pass ran the same kernel: scale by the work of this run's launches
