@@ -21,18 +21,23 @@
 #include "conv_v2_common.h"
 
 namespace {
-template <int NTAPS, bool FULL = true, bool ATOMIC = false>   // FULL: three products per fp32 product; !FULL: high pieces only (EG3D_PREC_F16X1); ATOMIC: split-K
+// FULL: three products per fp32 product; !FULL: high pieces only (EG3D_PREC_F16X1); ATOMIC: split-K; RPW: patch rows per wave -- 4 = the 8 x 32
+// patch (256 cells), 2 = a 4 x 32 patch (128 cells x 128 channels per workgroup, 12 MFMAs per wave and step): twice the workgroups for the
+// layers whose 8-row grids leave CUs idle (128^2 x 256: 128 -> 256), with the fused epilogues intact (split-K needs a zero fill + a finishing pass)
+template <int NTAPS, bool FULL = true, bool ATOMIC = false, int RPW = 4>
 __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_params p, const int cls_base) {
-    constexpr int APT = (6 + NTAPS - 1) / NTAPS;          // A parts a wave issues per step
-    constexpr int NA_TAPS = 6 / APT;                      // ... during the first NA_TAPS taps of a chunk (APT divides 6)
-    static_assert(6 % APT == 0, "A parts per step");
+    constexpr int PHK = 2 * RPW;                          // patch rows of this instantiation
+    constexpr int NPARTS = RPW == 4 ? 6 : 4;              // 64-slot wave-instructions per A plane: halo <= (PHK + 2) x 34 slots
+    constexpr int APT = (NPARTS + NTAPS - 1) / NTAPS;     // A parts a wave issues per step
+    constexpr int NA_TAPS = NPARTS / APT;                 // ... during the first NA_TAPS taps of a chunk (APT divides NPARTS)
+    static_assert(NPARTS % APT == 0, "A parts per step");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const eg3d_conv_class& cl = p.cls[cls_base + blockIdx.z];
     const int Ha = cl.Ha, Wa = cl.Wa;
-    const int tiles_x = (Wa + PW - 1) / PW, tiles_y = (Ha + PH - 1) / PH, ntile_n = p.Nc / BN;
+    const int tiles_x = (Wa + PW - 1) / PW, tiles_y = (Ha + PHK - 1) / PHK, ntile_n = p.Nc / BN;
     const int ntile = p.N * tiles_y * tiles_x * ntile_n;
     int bid = blockIdx.x;
     if (bid >= ntile) return;
@@ -40,7 +45,7 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
     const int n_t = bid % ntile_n; bid /= ntile_n;
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y; const int n = bid / tiles_y;
-    const int y0 = ty * PH, x0 = tx * PW, n0 = n_t * BN;
+    const int y0 = ty * PHK, x0 = tx * PW, n0 = n_t * BN;
     const int nchunk = p.Ck / 16;
     // split-K (EG3D_EPI_ATOMIC): blockIdx.y owns the 16-channel chunks [c0, c1) of the contraction and adds its partial tile to `out`
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
@@ -54,7 +59,7 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
         dxmin = min(dxmin, cl.dx[t]); dxmax = max(dxmax, cl.dx[t]);
     }
     constexpr int hw = PW + 2;                                        // LDS row pitch of the halo: always 34 pixels (columns past the
-    const int hh = PH + dymax - dymin;                                // tap extent are loaded but never read); <= 10 rows (host check)
+    const int hh = PHK + dymax - dymin;                               // tap extent are loaded but never read); <= PHK + 2 rows (host check)
     const int hslots = hw * hh;
     const unsigned lds0 = (unsigned)(uintptr_t)smem;                  // LDS byte address of the dynamic array
 
@@ -63,12 +68,12 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
     constexpr unsigned OOB = 0x7ffffff0u;
 
     // ---- A loader: wave w issues the wave-instructions j = w + 4 i (i = 0..5) of a chunk: plane j / 6, 64-slot part j % 6 ------------
-    unsigned a_pix[6];
-    int a_plane[6], a_part[6];
+    unsigned a_pix[NPARTS];
+    int a_plane[NPARTS], a_part[NPARTS];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < NPARTS; ++i) {
         const int j = wave + 4 * i;
-        a_plane[i] = j / A_PARTS; a_part[i] = j % A_PARTS;
+        a_plane[i] = j / NPARTS; a_part[i] = j % NPARTS;
         const int slot = a_part[i] * 64 + lane;
         const int hy = slot / hw, hx = slot - hy * hw;
         const int y = y0 + dymin + hy, x = x0 + dxmin + hx;
@@ -90,22 +95,22 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
         }
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[RPW][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RPW; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const unsigned a_lane = (unsigned)(((wm * 4 - dymin) * hw + (lane & 31) - dxmin) * 16 + (lane >> 5) * APLANE);
+    const unsigned a_lane = (unsigned)(((wm * RPW - dymin) * hw + (lane & 31) - dxmin) * 16 + (lane >> 5) * APLANE);
     const unsigned b_lane = (unsigned)((wn * 64 + (lane & 31)) * 16 + (lane >> 5) * BPLANE);
     const f16x2 k2m11 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
 
     // ---- prologue: A(c0), B(step 0), B(step 1) -------------------------------------------------------------------------------------------
     const int S = (c1 - c0) * NTAPS;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) issue_A(c0, i);
+    for (int i = 0; i < NPARTS; ++i) issue_A(c0, i);
     issue_B(c0, 0, 0);
     if (S > 1) issue_B(NTAPS > 1 ? c0 : c0 + 1, NTAPS > 1 ? 1 : 0, 1);
     else { issue_B(c0, 0, 1); }                      // keeps the wait accounting uniform (never read)
@@ -148,7 +153,7 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < RPW; ++i) {
                 const f16x8 ah = *reinterpret_cast<const f16x8*>(smem + abase + i * hw * 16);
                 if constexpr (FULL) {
                     const f16x8 al = *reinterpret_cast<const f16x8*>(smem + abase + i * hw * 16 + 2 * APLANE);
@@ -170,7 +175,7 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    v2_epilogue<ATOMIC>(p, acc, Ha, Wa, cl.out_py, cl.out_px, n, y0, x0, n0, smem);
+    v2_epilogue<ATOMIC, RPW>(p, acc, Ha, Wa, cl.out_py, cl.out_px, n, y0, x0, n0, smem);
 }
 
 // ---- operand preparation (split8 / range_mul: conv_v2_common.h) ------------------------------------------------------------
@@ -320,11 +325,11 @@ __global__ void __launch_bounds__(256) split_w_kernel(const float* __restrict__ 
     out[((((int64_t)tap * (I / 16) + chunk) * 2 + 1) * 2 + koct) * O + o] = l;
 }
 
-std::atomic<uint64_t> g_attr[7];
+std::atomic<uint64_t> g_attr[9];
 
-template <int NTAPS, bool FULL = true, bool ATOMIC = false>
+template <int NTAPS, bool FULL = true, bool ATOMIC = false, int RPW = 4>
 int launch_v2(const eg3d_conv_v2_params& p, int cls_base, int ncls, int max_tiles, hipStream_t st, int slot) {
-    auto kern = conv_v2_kernel<NTAPS, FULL, ATOMIC>;
+    auto kern = conv_v2_kernel<NTAPS, FULL, ATOMIC, RPW>;
     if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, g_attr[slot])) return e;
     hipLaunchKernelGGL(kern, dim3(max_tiles, p.ksplit > 1 ? p.ksplit : 1, ncls), dim3(256), LDS_BYTES, st, p, cls_base);
     EG3D_LAUNCH_CHECK();
@@ -345,6 +350,11 @@ extern "C" int eg3d_conv2d_v2_supported(const eg3d_conv_v2_params* pp) {
     if (p.epi == EG3D_EPI_ATOMIC)                         // the split-K instantiations exist for the 3x3 classes
         for (int c = 0; c < p.ncls; ++c) if (p.cls[c].ntaps != 9) return 0;
     if (p.ksplit > 1 && (p.epi != EG3D_EPI_ATOMIC || p.ksplit > p.Ck / 16 || p.ksplit > 65535)) return 0;     // every slice owns >= 1 chunk
+    if (p.patch_rows != 0 && p.patch_rows != 8 && p.patch_rows != 4) return 0;
+    if (p.patch_rows == 4) {                              // the half-height patch is instantiated for the fused 3x3 launches
+        if (p.epi == EG3D_EPI_ATOMIC) return 0;
+        for (int c = 0; c < p.ncls; ++c) if (p.cls[c].ntaps != 9) return 0;
+    }
     if (p.epi == EG3D_EPI_FWD && !eg3d_act_is_pwl(p.act)) return 0;
     if (p.epi == EG3D_EPI_BWD_ACT) {
         const eg3d_act_bwd& ab = p.act_bwd;
@@ -381,14 +391,15 @@ extern "C" int eg3d_conv2d_v2(const eg3d_conv_v2_params* pp, void* stream) {
         int e = c;
         int max_tiles = 0;
         while (e < p.ncls && p.cls[e].ntaps == p.cls[c].ntaps) {
-            const int t = p.N * eg3d_cdiv(p.cls[e].Ha, PH) * eg3d_cdiv(p.cls[e].Wa, PW) * (p.Nc / BN);
+            const int t = p.N * eg3d_cdiv(p.cls[e].Ha, p.patch_rows == 4 ? 4 : PH) * eg3d_cdiv(p.cls[e].Wa, PW) * (p.Nc / BN);
             max_tiles = std::max(max_tiles, t);
             ++e;
         }
         int rc;
         switch (p.cls[c].ntaps) {
             case 9:
-                if (p.epi == EG3D_EPI_ATOMIC) rc = p.products == 1 ? launch_v2<9, false, true>(p, c, e - c, max_tiles, st, 6) : launch_v2<9, true, true>(p, c, e - c, max_tiles, st, 5);
+                if (p.patch_rows == 4) rc = p.products == 1 ? launch_v2<9, false, false, 2>(p, c, e - c, max_tiles, st, 8) : launch_v2<9, true, false, 2>(p, c, e - c, max_tiles, st, 7);
+                else if (p.epi == EG3D_EPI_ATOMIC) rc = p.products == 1 ? launch_v2<9, false, true>(p, c, e - c, max_tiles, st, 6) : launch_v2<9, true, true>(p, c, e - c, max_tiles, st, 5);
                 else rc = p.products == 1 ? launch_v2<9, false>(p, c, e - c, max_tiles, st, 4) : launch_v2<9>(p, c, e - c, max_tiles, st, 0);
                 break;
             case 4: rc = launch_v2<4>(p, c, e - c, max_tiles, st, 1); break;

@@ -64,8 +64,9 @@ __device__ __forceinline__ float range_mul(float amax) {
 // ---- epilogue of a 256-cell x 128-channel tile held as acc[4][2] (wave (wm, wn): patch rows 4 wm .. 4 wm + 3, channels 64 wn .. + 63) ---
 // Output cell (ay, ax) of the class grid Ha x Wa goes to pixel (ay * out_stride + out_py, ax * out_stride + out_px).  Must be entered by
 // the whole block after the last LDS read of the main loop (it re-uses the dynamic LDS).
-template <bool ATOMIC>        // compile-time: the split-K form must not cost the fused epilogues a register (the two paths together spilled 30 VGPRs)
-__device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16 (&acc)[4][2], const int Ha, const int Wa, const int out_py, const int out_px,
+template <bool ATOMIC, int RPW = 4>   // ATOMIC at compile time: the split-K form must not cost the fused epilogues a register (together they spilled 30 VGPRs);
+                                      // RPW = patch rows per wave (4: 8 x 32 patch, 2: 4 x 32)
+__device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16 (&acc)[RPW][2], const int Ha, const int Wa, const int out_py, const int out_px,
                                             const int n, const int y0, const int x0, const int n0, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,8 +80,8 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
         // 32 consecutive floats.  (Through the staged float4 path each lane would own 4 consecutive channels: four instructions that each
         // touch sixteen 64-byte lines -- measured 2.3x SLOWER than the loader-split kernel on the 128^2 x 256 layer.)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ay = y0 + wm * 4 + i;
+        for (int i = 0; i < RPW; ++i) {
+            const int ay = y0 + wm * RPW + i;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ax = x0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -119,7 +120,7 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
     if (act_on && ab.bias != nullptr) abb4 = *reinterpret_cast<const float4*>(ab.bias + col);
     float amax = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RPW; ++i) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -136,7 +137,7 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int row = (tid + (ug + u) * 256) >> 5;             // 0..63: wave-row row >> 5, patch column row & 31
-                const int ay = y0 + (row >> 5) * 4 + i, ax = x0 + (row & 31);
+                const int ay = y0 + (row >> 5) * RPW + i, ax = x0 + (row & 31);
                 const bool ok = ay < Ha && ax < Wa;
                 const int pix = (n * p.Ho + ay * p.out_stride + cl.out_py) * p.Wo + ax * p.out_stride + cl.out_px;
                 offs[u] = ok ? pix * p.ldo + col : -1;

@@ -520,9 +520,23 @@ def conv_v2_geometry_ok(Ck, Nc, classes):
     return True
 
 
+def conv_v2_rows(Ck, Nc, classes, N=1):
+    """Patch rows (8 | 4) the pre-split kernel should run this launch with, 0 = not a launch for it.  8 x 32-cell patches when they fill the
+    chip (>= V2_MIN_TILES workgroups); nine-tap classes whose 8-row grid does not but whose 4-row grid does (128^2 x 256: 128 -> 256
+    workgroups) take the half-height patch -- fused epilogues intact, no split-K."""
+    if not conv_v2_geometry_ok(Ck, Nc, classes):
+        return 0
+    tiles8 = conv_v2_tiles(Nc, classes, N)
+    half_ok = V2_HALF and all(c.ntaps == 9 for c in classes)
+    tiles4 = sum(N * -(-c.Ha // 4) * -(-c.Wa // 32) for c in classes) * (Nc // 128)
+    if half_ok and tiles8 < V2_HALF_BELOW and tiles4 >= V2_MIN_TILES:
+        return 4
+    return 8 if tiles8 >= V2_MIN_TILES else 0
+
+
 def conv_v2_supported(Ck, Nc, classes, N=1):
-    """Geometry the pre-split kernel takes (see eg3d_conv2d_v2_supported) AND enough 256 x 128 tiles to fill the chip."""
-    return conv_v2_geometry_ok(Ck, Nc, classes) and conv_v2_tiles(Nc, classes, N) >= V2_MIN_TILES
+    """Geometry the pre-split kernel takes (see eg3d_conv2d_v2_supported) AND enough tiles to fill the chip (conv_v2_rows)."""
+    return conv_v2_rows(Ck, Nc, classes, N) != 0
 
 
 def conv_v2_ksplit(Ck, Nc, classes, N=1):
@@ -540,6 +554,8 @@ def conv_v2_ksplit(Ck, Nc, classes, N=1):
 V2_MIN_TILES = int(os.environ.get('EG3D_V2_MIN_TILES', '256'))
 USE_V2 = os.environ.get('EG3D_CONV_V2', '1') != '0'
 V2_CONVT = os.environ.get('EG3D_V2_CONVT', '0') == '1'
+V2_HALF = os.environ.get('EG3D_V2_HALF', '1') != '0'                  # 4 x 32-cell patches for under-filled 3x3 grids (conv_v2_rows)
+V2_HALF_BELOW = int(os.environ.get('EG3D_V2_HALF_BELOW', '512'))      # ... when the 8-row grid has fewer workgroups than this (256^2 x 128: 84 -> 67 us, 128^2 x 256: 107 -> 91 us)
 # split-K launches of the pre-split kernel for under-filled 3x3 grids: OFF by default.  Measured at N = 1 (MI355X): 128^2 x 256 118 -> 81 us,
 # 64^2 x 512 103 -> 82 us per launch, but the operand split pass (7 us), the zero fill and the finishing pass (2 x 10 us; the loader-split
 # kernel's fused epilogue needs neither on the 128^2 layer) eat it: -1.2 % per step.  Batched runs do not need it (the grids fill).
@@ -551,7 +567,7 @@ V2_KS_MIN_CHUNKS = int(os.environ.get('EG3D_V2_KS_MIN_CHUNKS', '2'))
 
 def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_STORE, out_scale=None, bias=None, noise=None, noise_nstride=0,
             noise_strength=None, act='linear', alpha=0.0, gain=1.0, clamp=-1.0, addend=None, xin=None, ds=None, out_amax=None, algo_flops=None,
-            act_bwd=None, products=3, ksplit=1):
+            act_bwd=None, products=3, ksplit=1, patch_rows=None):
     """Launch eg3d_conv2d_v2 (operands prepared by split_activation / split_weight).  act_bwd (ActBwdSpec, with epi=EPI_BWD): EPI_BWD_ACT when
     the kernel takes it -- returns True if the fused epilogue ran, False for a plain EPI_BWD."""
     assert is_cl(out)
@@ -560,6 +576,9 @@ def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_
     p.products = int(products)
     p.ksplit = int(ksplit)
     assert ksplit <= 1 or epi == L.EPI_ATOMIC
+    if patch_rows is None:          # the caller did not plan: 4-row patches where they fill the chip and 8-row ones do not
+        patch_rows = conv_v2_rows(p.Ck, p.Nc, classes, p.N) if epi != L.EPI_ATOMIC else 8
+    p.patch_rows = 4 if patch_rows == 4 else 8
     fused_act = False
     if act_bwd is not None and epi == L.EPI_BWD and xin is not None:
         p.epi = L.EPI_BWD_ACT

@@ -220,6 +220,8 @@ typedef struct eg3d_conv_v2_params {
     int32_t ksplit;            /* 0 / 1: none.  > 1 (EG3D_EPI_ATOMIC only, `out` pre-zeroed): the contraction's 16-channel chunks are split over
                                 * ksplit workgroups per tile which add their partial tiles with fp32 atomics -- the layers whose grids
                                 * cannot fill the chip (128^2 x 256: 128 tiles; 64^2 x 512: 64) */
+    int32_t patch_rows;        /* 0 / 8: workgroup tile = 8 x 32 cells x 128 channels.  4: 4 x 32 cells -- twice the workgroups for 3x3 layers whose
+                                * 8-row grid leaves CUs idle, fused epilogues intact (nine-tap classes, not with EG3D_EPI_ATOMIC) */
 } eg3d_conv_v2_params;
 int eg3d_conv2d_v2_supported(const eg3d_conv_v2_params* p);
 int eg3d_conv2d_v2(const eg3d_conv_v2_params* p, void* stream);

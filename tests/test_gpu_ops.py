@@ -607,8 +607,9 @@ def _v2_operands(x, wt, styles, adjoint=False):
     return xc, aimg, wimg
 
 
+@pytest.mark.parametrize('rows', [8, 4])
 @pytest.mark.parametrize('shape', [(1, 32, 16, 64, 128), (2, 64, 40, 72, 128), (1, 128, 33, 37, 256), (1, 16, 8, 32, 128)])
-def test_conv_v2_forward_epilogue_vs_torch(shape):
+def test_conv_v2_forward_epilogue_vs_torch(shape, rows):
     """3x3 correlation with the fused forward epilogue (style-modulated input, demodulation, noise, bias, lrelu, gain, skip addend) on
     ragged grids (sizes that are not multiples of the 8 x 32 patch), batch 2 and two 128-channel tiles; max|out| reported."""
     from inv3d_amd import hipops as H, _lib as L
@@ -627,12 +628,13 @@ def test_conv_v2_forward_epilogue_vs_torch(shape):
     amax = torch.zeros(1, device=DEV)
     H.conv_v2(aimg, wimg, out, H.classes_corr(h, w, 3, 3, 1), epi=L.EPI_FWD, out_scale=d.to(DEV), bias=bias.to(DEV), noise=noise.to(DEV).contiguous(),
               noise_nstride=h * w, noise_strength=strength.to(DEV), act='lrelu', alpha=0.2, gain=1.4, clamp=-1.0,
-              addend=add.to(DEV).contiguous(memory_format=torch.channels_last), out_amax=amax)
+              addend=add.to(DEV).contiguous(memory_format=torch.channels_last), out_amax=amax, patch_rows=rows)       # 8 x 32 and 4 x 32-cell patches
     close(out, ref.float(), 2e-5, f'conv_v2 fwd {shape}')
     assert abs(float(amax) - float(out.abs().max())) == 0.0
 
 
-def test_conv_v2_data_gradient_epilogue_vs_torch():
+@pytest.mark.parametrize('rows', [8, 4])
+def test_conv_v2_data_gradient_epilogue_vs_torch(rows):
     """Data gradient of a 3x3 layer: adjoint taps on the adjoint weight image, dx = acc * styles + addend, ds = sum_px acc * x."""
     from inv3d_amd import hipops as H, _lib as L
     n, ci, h, w, co = 2, 128, 24, 40, 64
@@ -646,7 +648,7 @@ def test_conv_v2_data_gradient_epilogue_vs_torch():
     gc, aimg, wimg = _v2_operands(gz, wt, None, adjoint=True)
     dx, ds = H.empty_cl(n, ci, h, w, DEV), torch.zeros(n, ci, device=DEV)
     H.conv_v2(aimg, wimg, dx, H.classes_corr_adjoint(h, w, 3, 3, 1), epi=L.EPI_BWD, out_scale=s.to(DEV), xin=xin.to(DEV).contiguous(memory_format=torch.channels_last),
-              ds=ds, addend=add.to(DEV).contiguous(memory_format=torch.channels_last))
+              ds=ds, addend=add.to(DEV).contiguous(memory_format=torch.channels_last), patch_rows=rows)
     close(dx, ref_dx.float(), 2e-5, 'conv_v2 dgrad dx')
     close(ds, ref_ds.float(), 5e-5, 'conv_v2 dgrad ds')
 
