@@ -119,6 +119,19 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
     if (act_on && ab.d != nullptr) abd4 = *reinterpret_cast<const float4*>(ab.d + (int64_t)n * p.Nc + col);
     if (act_on && ab.bias != nullptr) abb4 = *reinterpret_cast<const float4*>(ab.bias + col);
     float amax = 0.f;
+    // the patch's noise values (forward: this layer's; EPI_BWD_ACT: the producing layer's), one per cell, read from LDS by the 32 lanes that
+    // hold a cell's channels
+    __shared__ float nzl[2 * 4 * 32];
+    {
+        const float* nsrc = (epi == EG3D_EPI_FWD && p.noise != nullptr) ? p.noise + (int64_t)n * p.noise_nstride
+                          : ((act_on && ab.noise != nullptr) ? ab.noise + (int64_t)n * ab.noise_nstride : nullptr);
+        if (tid < 2 * RPW * 32) {
+            const int ay = y0 + (tid >> 5), ax = x0 + (tid & 31);
+            float v = 0.f;
+            if (nsrc != nullptr && ay < Ha && ax < Wa) v = nsrc[(ay * p.out_stride + cl.out_py) * p.Wo + ax * p.out_stride + cl.out_px];
+            nzl[tid] = v;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         __syncthreads();
@@ -145,8 +158,7 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
                 va[u] = *reinterpret_cast<const float4*>(stage + row * LDS_N + c4 * 4);
                 sa[u] = make_float4(0.f, 0.f, 0.f, 0.f); sb[u] = sa[u]; nz[u] = 0.f;
                 if (ok && (epi == EG3D_EPI_FWD || bwd_like) && p.addend != nullptr) sa[u] = *reinterpret_cast<const float4*>(p.addend + offs[u]);
-                if (ok && epi == EG3D_EPI_FWD && p.noise != nullptr) nz[u] = p.noise[(int64_t)n * p.noise_nstride + pixl[u]];
-                if (ok && act_on && ab.noise != nullptr) nz[u] = ab.noise[(int64_t)n * ab.noise_nstride + pixl[u]];
+                nz[u] = nzl[((row >> 5) * RPW + i) * 32 + (row & 31)];
                 if (ok && (do_ds || act_on)) sb[u] = *reinterpret_cast<const float4*>(p.xin + offs[u]);
             }
 #pragma unroll

@@ -607,7 +607,7 @@ def _v2_operands(x, wt, styles, adjoint=False):
     return xc, aimg, wimg
 
 
-@pytest.mark.parametrize('rows', [8, 4])
+@pytest.mark.parametrize('rows', [8])        # (4: the experimental half-height patch, off by default -- hipops.V2_HALF)
 @pytest.mark.parametrize('shape', [(1, 32, 16, 64, 128), (2, 64, 40, 72, 128), (1, 128, 33, 37, 256), (1, 16, 8, 32, 128)])
 def test_conv_v2_forward_epilogue_vs_torch(shape, rows):
     """3x3 correlation with the fused forward epilogue (style-modulated input, demodulation, noise, bias, lrelu, gain, skip addend) on
@@ -633,7 +633,7 @@ def test_conv_v2_forward_epilogue_vs_torch(shape, rows):
     assert abs(float(amax) - float(out.abs().max())) == 0.0
 
 
-@pytest.mark.parametrize('rows', [8, 4])
+@pytest.mark.parametrize('rows', [8])
 def test_conv_v2_data_gradient_epilogue_vs_torch(rows):
     """Data gradient of a 3x3 layer: adjoint taps on the adjoint weight image, dx = acc * styles + addend, ds = sum_px acc * x."""
     from inv3d_amd import hipops as H, _lib as L
