@@ -418,7 +418,9 @@ def main():
             else:
                 kern = 'conv_igemm_kernel<%s,%d,*> (fp32 in/out, %d x MFMA per fp32 product)' % (H.TILE_NAMES.get(dom_id[0], '?'), H.PRECISIONS[dom_prec], nprod)
                 tkey = 'conv_igemm_kernel<%s>' % H.TILE_NAMES.get(dom_id[0], '?')
-            tr = traffic.get(tkey) or traffic.get(tkey.replace(',false>', '>')) or traffic.get(tkey.replace(',true>', '>'), {})
+            tr = (traffic.get(tkey) or traffic.get(tkey.replace(',false>', '>'))
+                  or next((v for k, v in sorted(traffic.items()) if k.startswith(tkey[:-1] + ',')), None)   # trailing template args (rows per wave)
+                  or traffic.get(tkey.replace(',true>', '>'), {}))
             per_launch_ref = tr.get('gflop_per_launch')
             tbytes = tr.get('bytes_per_launch')
             if tbytes is not None and per_launch_ref:           # the PMC pass ran the same kernel: scale by the work of this run's launches
