@@ -95,6 +95,7 @@ class _GraphedFn(torch.autograd.Function):
         return outs
 
     @staticmethod
+    @torch.autograd.function.once_differentiable       # a replayed backward has no graph of its own: double backward raises
     def backward(ctx, *gouts):
         e = ctx.entry
         if ctx.gen != e.gen:
