@@ -574,7 +574,7 @@ __global__ void __launch_bounds__(256) scatter_bin_kernel(const float4* __restri
         lrank[k] = atomicAdd(&hist[bin[k]], 1);
     }
     __syncthreads();
-    if (PASS == 0) {
+    if constexpr (PASS == 0) {
         for (int i = threadIdx.x; i < nb; i += 256) { int c = hist[i]; if (c) atomicAdd(counts + i, c); }
     } else {
         int* basep = hist + nb;
@@ -582,7 +582,18 @@ __global__ void __launch_bounds__(256) scatter_bin_kernel(const float4* __restri
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < BIN_ITEMS; ++k)
-            if (bin[k] >= 0) ids[basep[bin[k]] + lrank[k]] = rowi[k] << 2;       // row id (the plane is implied by the bin)
+            if (bin[k] >= 0) {
+                if (PASS == 1) {
+                    ids[basep[bin[k]] + lrank[k]] = rowi[k] << 2;       // row id (the plane is implied by the bin)
+                } else {            // PASS 2: the whole pair record, so that the accumulate pass streams it (no id -> position gather there)
+                    const int ntile = ntx * nty, t = bin[k] % ntile, pl = (bin[k] / ntile) % 3;
+                    int x0, y0; float wx1, wy1;
+                    plane_cell(pos[rowi[k]], pl, cs, Hp, Wp, x0, y0, wx1, wy1);
+                    const int lx = x0 - (t % ntx) * TS, ly = y0 - (t / ntx) * TS;                  // in [-1, TS-1]
+                    reinterpret_cast<float4*>(ids)[basep[bin[k]] + lrank[k]] =
+                        make_float4(__int_as_float(rowi[k]), __int_as_float(((ly + 1) << 16) | (lx + 1)), wx1, wy1);
+                }
+            }
     }
 }
 
@@ -606,9 +617,9 @@ __global__ void __launch_bounds__(1024) scatter_scan_kernel(const int* __restric
     int run = part[t] - sum, runc = partc[t] - sumc;
     for (int k = 0; k < per; ++k) {
         int idx = t * per + k;
-        if (idx < n) { int c = counts[idx]; offsets[idx] = run; chunk_offsets[idx] = runc; run += c; runc += (c + CHUNK - 1) / CHUNK; }
+        if (idx < n) { int c = counts[idx]; offsets[idx] = run; if (chunk_offsets) chunk_offsets[idx] = runc; run += c; runc += (c + CHUNK - 1) / CHUNK; }
     }
-    if (t == 1023) { offsets[n] = part[1023]; chunk_offsets[n] = partc[1023]; }
+    if (t == 1023) { offsets[n] = part[1023]; if (chunk_offsets) chunk_offsets[n] = partc[1023]; }
 }
 
 // One block per (bin, chunk of <= CHUNK pairs): the accumulation of a tile-row pair is a small GEMM on the fp32 matrix cores.
@@ -761,6 +772,363 @@ __global__ void __launch_bounds__(ACC_THREADS) scatter_accum_kernel(const float*
             const int cell = i / FC, ch = i - cell * FC;
             const int yy = ty0 + cell / TROWS, xx = tx0 + cell % TROWS;
             if (yy < Hp && xx < Wp) unsafeAtomicAdd(d_planes + (int64_t)n * Hp * Wp * ldp + ((int64_t)yy * Wp + xx) * ldp + pl * FC + ch, v);
+        }
+    }
+}
+
+// ---- the same accumulation with every global -> LDS movement done by LDS-DMA, two batches ahead ---------------------------------------
+// scatter_accum_kernel above has ONE batch of gradient rows in flight per block (in registers) behind a dependent chain
+// ids -> (position, gradient row): 70 VGPRs x 16 waves = one block per CU, MfmaUtil 18 %, 2.3 TB/s of 128-byte row gathers.  Here
+//   * the binning pass writes 16-byte pair records (row, cell, weights) in list order: the record stream of a chunk is contiguous and
+//     goes to LDS with one dword-DMA instruction per wave and batch, three batches ahead (M);
+//   * the gradient rows of batch b+2 are gathered by two 16-byte-DMA instructions per wave (eight lanes per 128-byte row, row ids read
+//     from the records of batch b+2 in LDS) while batch b is accumulated (R): two batches of rows in flight per block, no registers;
+//   * issue order per iteration is M(b+3), R(b+2), so `s_waitcnt vmcnt(2)` at the top of iteration b = "R(b) and M(b+2) have landed";
+//   * WAVES x 64 threads, 16 / WAVES texel-row lists per wave; with 8 waves and 128-pair batches 2 blocks share a CU.
+__device__ __forceinline__ void glds_b32(__amdgpu_buffer_rsrc_t rs, unsigned lds_byte, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(uintptr_t)lds_byte, 4, voff, 0, 0, 0);
+}
+__device__ __forceinline__ void glds_b128(__amdgpu_buffer_rsrc_t rs, unsigned lds_byte, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(uintptr_t)lds_byte, 16, voff, 0, 0, 0);
+}
+
+// workgroup barrier without the fence of __syncthreads() (that fence waits for every outstanding LDS-DMA: vmcnt(0)); LDS writes of this
+// wave are complete (lgkmcnt) before it arrives
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// LDS atomic add by address (the compiler orders atomicAdd() on __shared__ behind pending LDS-DMA with vmcnt(0))
+__device__ __forceinline__ int lds_add_rtn(unsigned lds_byte, int v) {
+    int old;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(lds_byte), "v"(v) : "memory");
+    return old;
+}
+
+template <int WAVES, int BATCH>
+__global__ void __launch_bounds__(WAVES * 64) scatter_accum2_kernel(const float* __restrict__ df, int64_t S, const int* __restrict__ offsets,
+                                                                     const int* __restrict__ chunk_offsets, const float4* __restrict__ recs, int64_t nrec,
+                                                                     float* __restrict__ d_planes, int Hp, int Wp, int ldp, int ntx, int nty, int nb) {
+    constexpr int NT = WAVES * 64;
+    constexpr int LPW = TROWS / WAVES;                    // lists (upper texel rows) per wave
+    constexpr int NRB = 3, NMB = 4;                       // row / record buffers in flight
+    constexpr int ROWB = BATCH * FC * 4, RECB = BATCH * 16;
+    static_assert(TROWS % WAVES == 0 && BATCH * 16 == NT * 4 && BATCH * FC * 4 == NT * 2 * 16, "one record dword and two row quads per thread and batch");
+    constexpr int TILE_FLOATS = TROWS * TROWS * FC;
+    static_assert(NRB * ROWB >= TILE_FLOATS * 4, "the flush tile reuses the row buffers");
+    __shared__ __attribute__((aligned(16))) char sm[NRB * ROWB + NMB * RECB];
+    __shared__ int cnt[2][TROWS];
+    __shared__ unsigned short lists[TROWS * BATCH];
+    __shared__ int sbin;
+    float* tile = reinterpret_cast<float*>(sm);
+    const unsigned lds0 = (unsigned)(uintptr_t)sm;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int lo = 0, hi = nb;
+        const int me = blockIdx.x;
+        if (me >= chunk_offsets[nb]) lo = -1;
+        else while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (chunk_offsets[mid] <= me) lo = mid; else hi = mid; }
+        sbin = lo;
+    }
+    if (tid < 2 * TROWS) (&cnt[0][0])[tid] = 0;
+    __syncthreads();
+    const int bin = sbin;
+    if (bin < 0) return;
+    const int chunk = blockIdx.x - chunk_offsets[bin];
+    const int beg = offsets[bin] + chunk * CHUNK;
+    const int end = min(offsets[bin + 1], beg + CHUNK);
+    const int ntile = ntx * nty;
+    const int n = bin / (3 * ntile);
+    const int pl = (bin / ntile) % 3;
+    const int t = bin % ntile;
+    const int ty0 = (t / ntx) * TS, tx0 = (t % ntx) * TS;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 31, kk = lane >> 5;
+    const int mx = c & 15, mhalf = c >> 4;                               // this lane's row of the coefficient matrix: (half, column)
+    const int nbat = (end - beg + BATCH - 1) / BATCH;
+
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(recs), 0, (int)(nrec * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(df), 0, (int)(S * FC * 4), 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+    // M(b): thread tid moves dword tid of the batch's record stream; R(b): quad q of rows j0 and j0 + BATCH / 2
+    auto issue_M = [&](int b) {
+        const int i = beg + b * BATCH + (tid >> 2);
+        glds_b32(rrs, lds0 + NRB * ROWB + (b % NMB) * RECB + wave * 256, (b < nbat && i < end) ? (unsigned)(i * 16 + (tid & 3) * 4) : OOB);
+    };
+    auto issue_R = [&](int b) {
+        const float4* mb = reinterpret_cast<const float4*>(sm + NRB * ROWB + (b % NMB) * RECB);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = h * (BATCH / 2) + (tid >> 3);
+            const bool ok = b < nbat && beg + b * BATCH + j < end;
+            const unsigned row = (unsigned)__float_as_int(mb[j].x);
+            glds_b128(drs, lds0 + (b % NRB) * ROWB + h * (ROWB / 2) + wave * 1024, ok ? row * (FC * 4) + (tid & 7) * 16 : OOB);
+        }
+    };
+
+    acc16_t acc[LPW];
+#pragma unroll
+    for (int l = 0; l < LPW; ++l)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[l][i] = 0.f;
+
+    // prologue -> outstanding at the top of iteration 0: M(2), R(1) x 2 (everything older has landed)
+    issue_M(0); issue_M(1);
+    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    lds_barrier();
+    issue_R(0); issue_M(2);
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    lds_barrier();
+    issue_R(1);
+    // (order is now R(0) x 2, M(2), R(1) x 2: vmcnt(2) below = R(0) and M(2) done)
+    for (int b = 0; b < nbat; ++b) {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        lds_barrier();
+        issue_M(b + 3);
+        issue_R(b + 2);
+        const float4* meta = reinterpret_cast<const float4*>(sm + NRB * ROWB + (b % NMB) * RECB);
+        const float* dfb = reinterpret_cast<const float*>(sm + (b % NRB) * ROWB);
+        int* cn = cnt[b & 1];
+        if (tid < TROWS) cnt[(b + 1) & 1][tid] = 0;
+        if (tid < BATCH && beg + b * BATCH + tid < end) {
+            const int k = __float_as_int(meta[tid].y) >> 16;              // ly + 1
+            lists[k * BATCH + lds_add_rtn((unsigned)(uintptr_t)&cn[k], 1)] = (unsigned short)tid;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int l = 0; l < LPW; ++l) {
+            const int li = wave * LPW + l;
+            const int m = cn[li];
+            const unsigned short* lst = lists + li * BATCH;
+            for (int e = 0; e < m; e += 8) {
+                int j[4];
+                float4 mt[4];
+                float g[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) j[q] = lst[min(e + 2 * q + kk, BATCH - 1)] & (BATCH - 1);      // stale entries past m: masked below
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { mt[q] = meta[j[q]]; g[q] = dfb[j[q] * FC + c]; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool live = e + 2 * q + kk < m;
+                    const int lx = (__float_as_int(mt[q].y) & 0xffff) - 1;
+                    const float wx = mx == lx ? 1.f - mt[q].z : (mx == lx + 1 ? mt[q].z : 0.f);
+                    const float wy = mhalf ? mt[q].w : 1.f - mt[q].w;
+                    acc[l] = __builtin_amdgcn_mfma_f32_32x32x2f32(live ? wx * wy : 0.f, live ? g[q] : 0.f, acc[l], 0, 0, 0);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the masked tail DMAs still write zeros: drain before the buffers become the tile
+    __syncthreads();
+    // combine the row pairs (see scatter_accum_kernel): lower halves first, then the upper halves
+#pragma unroll
+    for (int l = 0; l < LPW; ++l) {
+        const int li = wave * LPW + l;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * kk;
+            if (m >= 16) tile[(li * TROWS + (m & 15)) * FC + c] = acc[l][r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < LPW; ++l) {
+        const int li = wave * LPW + l;
+        if (li >= 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (m < 16) tile[((li - 1) * TROWS + m) * FC + c] += acc[l][r];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < TILE_FLOATS; i += NT) {
+        const float v = tile[i];
+        if (v != 0.f) {
+            const int cell = i / FC, ch = i - cell * FC;
+            const int yy = ty0 + cell / TROWS, xx = tx0 + cell % TROWS;
+            if (yy < Hp && xx < Wp) unsafeAtomicAdd(d_planes + (int64_t)n * Hp * Wp * ldp + ((int64_t)yy * Wp + xx) * ldp + pl * FC + ch, v);
+        }
+    }
+}
+
+// ---- row-keyed variant (default): the pairs are sorted by (tile, upper texel row); every (tile, row) list is streamed by ONE wave ---------
+// The batch lists above are rebuilt per 256 consecutive pairs of a tile, and consecutive pairs come from neighbouring rays: on the plane
+// the camera faces, a ray's 96 samples fall into one texel and a strip of rays into one texel ROW -- one or two of the 16 waves do the work
+// of a batch while the others wait at its barriers (MfmaUtil 18 %, 384 us; with the DMA pipeline above 311 us).  Sorting by (tile, row) in
+// the binning passes gives contiguous record lists that need no batches, no per-batch lists and no barriers:
+//   * binning (scatter_bin16_kernel): same two passes, 16 x the bins (3 x 18 x 18 x 16 = 15.5 K for one image: 62 KB of LDS histogram),
+//     flushed sparsely -- the first arrival of a bin in a block owns its global atomic -- instead of by a sweep over all bins;
+//   * accumulate (scatter_accum16p_kernel): see there.
+// Measured per launch (1.57 M samples, 4.5 M pairs): zero 5 + count 32 + scan 9 + place 72 + accumulate 138 = 256 us against 470 us for
+// the round-2 chain (zero 5 + 36 + 5 + 44 + 384).
+// (the 62 KB histogram allows two blocks per CU: 1024-thread blocks keep the CU's wave slots full)
+// What the two passes cost is the GLOBAL atomics of the flush (one per bin a block touched): a block of consecutive rows = ~57 whole rays
+// crosses every depth tile of the two side planes, ~2 K bins per block, 0.6 M atomics per pass (77 us against 24 us with the flush
+// disabled).  With the ray structure known (rows_per_ray, rays per image row) a block takes a BRICK instead -- 16 x 16 rays x SL
+// consecutive rows of each -- whose footprint on all three planes is compact: ~4 x fewer bins touched.  Any bijection item -> row is
+// correct; without the hint the blocks fall back to consecutive rows.
+constexpr int BIN16_THREADS = 1024;
+constexpr int BIN16_ITEMS = 18;         // (sample, plane) pairs per thread: 256 rays x 24 rows x 3 planes = 1024 x 18
+
+template <int PASS, int SL>             // SL: rows per ray and brick (0 = consecutive rows)
+__global__ void __launch_bounds__(BIN16_THREADS) scatter_bin16_kernel(const float4* __restrict__ pos, int64_t S, float cs, int Hp, int Wp, int ntx, int nty,
+                                                            int nb16, int* __restrict__ counts, const int* __restrict__ offsets, int* __restrict__ fill,
+                                                            float4* __restrict__ recs, int ray_w, int rpr) {
+    extern __shared__ int hist[];       // [nb16] local counts; pass 1: replaced by the reserved base once the bin's owner has it
+    for (int i = threadIdx.x; i < nb16; i += BIN16_THREADS) hist[i] = 0;
+    __syncthreads();
+    int bin[BIN16_ITEMS], lrank[BIN16_ITEMS], rowi[BIN16_ITEMS];
+    const int ntile = ntx * nty;
+    int brick_row0 = 0;                 // SL > 0: row of (patch ray 0, first row of the slab)
+    if (SL > 0) {
+        const int nslab = rpr / SL, slab = blockIdx.x % nslab, pb = blockIdx.x / nslab, ppr = ray_w / 16;
+        brick_row0 = ((pb / ppr) * 16 * ray_w + (pb % ppr) * 16) * rpr + slab * SL;
+    }
+#pragma unroll
+    for (int k = 0; k < BIN16_ITEMS; ++k) {
+        bin[k] = -1;
+        int64_t row; int pl;
+        if (SL > 0) {
+            const int u = threadIdx.x + k * BIN16_THREADS;
+            if (u >= 256 * SL * 3) continue;
+            pl = u % 3;
+            const int v = u / 3, sidx = v % SL, r = v / SL;
+            row = brick_row0 + ((r >> 4) * ray_w + (r & 15)) * rpr + sidx;
+        } else {
+            const int64_t i = ((int64_t)blockIdx.x * BIN16_ITEMS + k) * BIN16_THREADS + threadIdx.x;
+            if (i >= S * 3) continue;
+            row = i / 3; pl = (int)(i - row * 3);
+        }
+        const float4 ps = pos[row];
+        if (isnan(ps.x)) continue;
+        int x0, y0; float wx1, wy1;
+        if (!plane_cell(ps, pl, cs, Hp, Wp, x0, y0, wx1, wy1)) continue;
+        const int t = tile_of(x0, y0, ntx, nty);
+        bin[k] = (pl * ntile + t) * TROWS + (y0 - (t / ntx) * TS + 1);
+        rowi[k] = (int)row;
+        lrank[k] = atomicAdd(&hist[bin[k]], 1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BIN16_ITEMS; ++k)
+        if (bin[k] >= 0 && lrank[k] == 0) {
+            const int c = hist[bin[k]];
+            if (PASS == 0) atomicAdd(counts + bin[k], c);
+            else hist[bin[k]] = offsets[bin[k]] + atomicAdd(fill + bin[k], c);
+        }
+    if (PASS == 0) return;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BIN16_ITEMS; ++k)
+        if (bin[k] >= 0) {
+            const int t = (bin[k] / TROWS) % ntile, pl = bin[k] / (TROWS * ntile);
+            int x0, y0; float wx1, wy1;
+            plane_cell(pos[rowi[k]], pl, cs, Hp, Wp, x0, y0, wx1, wy1);
+            const int lx = x0 - (t % ntx) * TS;                                      // in [-1, TS-1]
+            recs[hist[bin[k]] + lrank[k]] = make_float4(__int_as_float(rowi[k] | ((lx + 1) << 27)), wx1, wy1, 0.f);
+        }
+}
+
+// single block: exclusive scan of n <= 16384 counts -> offsets[n + 1]; the counts pass through LDS so that global accesses stay coalesced
+__global__ void __launch_bounds__(1024) scatter_scan16_kernel(const int* __restrict__ counts, int* __restrict__ offsets, int n) {
+    __shared__ int v[16384 + 512];
+    __shared__ int wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i = t; i < n; i += 1024) v[i + (i >> 5)] = counts[i];
+    __syncthreads();
+    const int per = (n + 1023) / 1024;
+    int sum = 0;
+    for (int k = 0; k < per; ++k) { const int i = t * per + k; if (i < n) sum += v[i + (i >> 5)]; }
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int run = inc - sum;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    for (int k = 0; k < per; ++k) { const int i = t * per + k; if (i < n) { const int c = v[i + (i >> 5)]; v[i + (i >> 5)] = run; run += c; } }
+    if (t == 1023) offsets[n] = run;
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) offsets[i] = v[i + (i >> 5)];
+}
+
+// ---- accumulate: persistent waves, one (tile, row) list at a time -------------------------------------------------------------------
+//   * A super-step = 64 pairs: lane i loads record i (coalesced 16 bytes).  The gradient row of a pair goes straight from global memory
+//     into the B register of its MFMA (two 128-byte rows per load instruction; row ids by `ds_bpermute` from the record registers).
+//     Register g[q] is reloaded for the next super-step right after MFMA q consumed it: 32 loads = 8 KB in flight per wave behind the
+//     in-order vmcnt, no LDS staging of the rows.
+//   * The 32 x 2 coefficient matrix of an MFMA has eight non-zeros (two pairs x four corners).  Computed lane by lane it costs ~12 VALU
+//     instructions per MFMA for 64 values of which 56 are zero (191 us as one block per tile, issue-bound).  Instead the non-zeros of
+//     EIGHT MFMAs (16 pairs x 4 corners = 64 values) come from one instruction sequence with lane = (pair, corner), are scattered into a
+//     wave-private, otherwise-zero LDS image of the eight A operands, read back densely (one ds_read per MFMA) and cleared again by a
+//     second masked store.  LDS operations of a wave complete in order: no barrier anywhere in the kernel.  (150 us per tile-block.)
+//   * Scheduling: a block per tile lasts as long as its longest list (1.2 x the mean) and 639 busy tiles on 256 CUs are 2.5 -> 3 rounds.
+//     Here wave w of the grid takes lists w, w + 4096, ... -- one list of each plane -- and adds its 2 x 16 x 32 sums straight to the plane
+//     with 16 coalesced float atomics per lane (a texel row receives the lower half of one list and the upper half of the next): 138 us.
+//     Handing lists out dynamically from a global counter was slower (261 us one list per grab: the same-address atomic; 270 / 532 us
+//     with 4 / 16 lists per grab: ~9.6 K busy lists are only 2.3 per wave, larger units leave waves idle).  The matrix pipe needs 59 us
+//     for the 2.25 M v_mfma_f32_32x32x2_f32; variants that read one row for every pair, use two accumulators or skip the flush run within
+//     2 % of the same time -- what is left is the imbalance of 2.3 lists per wave.
+constexpr int ACCP_WAVES = 4;
+__global__ void __launch_bounds__(ACCP_WAVES * 64) scatter_accum16p_kernel(const float* __restrict__ df, int64_t S, const int* __restrict__ offsets,
+                                                                            const float4* __restrict__ recs, float* __restrict__ d_planes, int Hp, int Wp,
+                                                                            int ldp, int ntx, int nty) {
+    __shared__ float amat[ACCP_WAVES * 8 * 64];       // per wave: the A operands of eight MFMAs
+    const int tid = threadIdx.x;
+    const int ntile = ntx * nty, nlist = 3 * ntile * TROWS;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 31, kk = lane >> 5;
+    float* abuf = amat + wave * (8 * 64);
+    for (int i = lane; i < 8 * 64; i += 64) abuf[i] = 0.f;
+    const int pj = lane >> 2, half = (lane >> 1) & 1, dx = lane & 1;          // this lane's (pair, corner) of a 16-pair group
+    const int a_slot = (pj >> 1) * 64 + (pj & 1) * 32 + half * 16;          // + column
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(df), 0, (int)(S * FC * 4), 0x00020000);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto pick = [&](int v, int src_lane_reg, int imm) { return __builtin_amdgcn_ds_bpermute(src_lane_reg + imm, v); };
+    const int nwave = gridDim.x * ACCP_WAVES;
+    for (int li = blockIdx.x * ACCP_WAVES + wave; li < nlist; li += nwave) {
+        const int beg = __builtin_amdgcn_readfirstlane(offsets[li]), end = __builtin_amdgcn_readfirstlane(offsets[li + 1]);
+        if (beg >= end) continue;
+        acc16_t acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        auto load_recs = [&](int p0) { return p0 + lane < end ? recs[p0 + lane] : zero4; };      // an all-zero record has coefficient 0 everywhere
+        unsigned g[32];
+        float4 Rc = load_recs(beg), Rn = load_recs(beg + 64), Rnn = zero4;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) g[q] = __builtin_amdgcn_raw_buffer_load_b32(drs, (pick(__float_as_int(Rc.x), kk * 4, 8 * q) & 0x7ffffff) * (FC * 4) + c * 4, 0, 0);
+        for (int p0 = beg; p0 < end; p0 += 64) {
+            Rnn = load_recs(p0 + 128);
+            const int npair = min(64, end - p0);
+            const bool more = p0 + 64 < end;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                if (gq * 16 >= npair && !more) break;
+                const int key = pick(__float_as_int(Rc.x), pj * 4, 64 * gq);
+                const float wx1 = __int_as_float(pick(__float_as_int(Rc.y), pj * 4, 64 * gq)), wy1 = __int_as_float(pick(__float_as_int(Rc.z), pj * 4, 64 * gq));
+                const int col = (int)((unsigned)key >> 27) - 1 + dx;                 // -1: the corner left of the tile (no owner here)
+                const float val = (dx ? wx1 : 1.f - wx1) * (half ? wy1 : 1.f - wy1);
+                int nk[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) nk[q] = pick(__float_as_int(Rn.x), kk * 4, 8 * (gq * 8 + q));
+                if (col >= 0) abuf[a_slot + col] = val;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int Q = gq * 8 + q;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(abuf[q * 64 + lane], __uint_as_float(g[Q]), acc, 0, 0, 0);
+                    g[Q] = __builtin_amdgcn_raw_buffer_load_b32(drs, (nk[q] & 0x7ffffff) * (FC * 4) + c * 4, 0, 0);
+                }
+                if (col >= 0) abuf[a_slot + col] = 0.f;
+            }
+            Rc = Rn; Rn = Rnn;
+        }
+        // accumulator element r of a lane = (half, column) (m >> 4, m & 15), m = (r&3) + 8 (r>>2) + 4 kk, channel c
+        const int lrow = li % TROWS, t = (li / TROWS) % ntile, pl = li / (TROWS * ntile);
+        const int yy0 = (t / ntx) * TS + lrow - 1, tx0 = (t % ntx) * TS;
+        float* base = d_planes + pl * FC + c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const int yy = yy0 + (m >> 4), xx = tx0 + (m & 15);
+            if (yy >= 0 && yy < Hp && xx < Wp && acc[r] != 0.f) unsafeAtomicAdd(base + ((int64_t)yy * Wp + xx) * ldp, acc[r]);
         }
     }
 }
@@ -970,11 +1338,12 @@ extern "C" int eg3d_render_query_sizes(const eg3d_render_params* p, eg3d_render_
 
 extern "C" int64_t eg3d_triplane_scatter_workspace_ints(int64_t S, int N, int Hp, int Wp) {
     const int64_t nb = (int64_t)N * 3 * ((Hp + TS - 1) / TS) * ((Wp + TS - 1) / TS);
-    return 4 * nb + 2 + 3 * S;                 // counts, fill, offsets (+1), chunk_offsets (+1), ids
+    const int64_t nb16 = 3 * ((Hp + TS - 1) / TS) * ((Wp + TS - 1) / TS) * (TS + 1);        // row-keyed bins of one image (3 arrays)
+    return (4 * nb + 2 > 3 * nb16 + 2 ? 4 * nb + 2 : 3 * nb16 + 2) + 3 + 12 * S;            // counts, fill, offsets (+1), chunk_offsets (+1), [pad to 16 bytes] pair records (16 bytes per (sample, plane))
 }
 
 extern "C" int eg3d_triplane_scatter(const float* df_rows, const float* df_pos, int64_t S, int64_t rows_per_image, float* d_planes, int N, int Hp,
-                                     int Wp, int ldp, float box_warp, int32_t* workspace, void* stream) {
+                                     int Wp, int ldp, float box_warp, int32_t* workspace, int ray_w, int rows_per_ray, void* stream) {
     if (!df_rows || !df_pos || !d_planes || !workspace || S <= 0 || N <= 0 || rows_per_image <= 0) return EG3D_ERR_INVALID;
     if (ldp < 3 * FC || 3 * S > INT32_MAX / 4) return EG3D_ERR_UNSUPPORTED;
     const int ntx = (Wp + TS - 1) / TS, nty = (Hp + TS - 1) / TS;
@@ -985,19 +1354,65 @@ extern "C" int eg3d_triplane_scatter(const float* df_rows, const float* df_pos, 
     int* offsets = fill + nb;
     int* chunk_offsets = offsets + nb + 1;
     int* ids = chunk_offsets + nb + 1;
+    ids += (4 - ((ids - workspace) & 3)) & 3;          // the records are float4 (the workspace itself is at least 16-byte aligned)
     hipStream_t st = (hipStream_t)stream;
-    eg3d_zero_words(counts, 2 * (int64_t)nb, st);          // counts + fill cursors (a kernel, not a memset node: see common.h)
     const float cs = 2.f / box_warp;
     const int blocks = eg3d_cdiv(S * 3, 256 * BIN_ITEMS);
     const float4* pos4 = reinterpret_cast<const float4*>(df_pos);
+    static const int variant0 = [] { const char* e = getenv("EG3D_SCATTER"); return e ? atoi(e) : 4; }();
+    const int nb16_img = 3 * ntx * nty * TROWS;                 // row-keyed bins of ONE image
+    if (variant0 == 4 && nb16_img <= 16384 && S % N == 0 && rows_per_image == S / N && rows_per_image * FC * 4 < ((int64_t)1 << 32)
+        && rows_per_image < (1 << 27)) {
+        // row-keyed sort + wave-streamed accumulation, image by image (bins, records and row ids are per image)
+        int* counts16 = workspace;
+        int* fill16 = counts16 + nb16_img;
+        int* offsets16 = fill16 + nb16_img;
+        int* recs_i = offsets16 + nb16_img + 1;
+        recs_i += (4 - ((recs_i - workspace) & 3)) & 3;
+        float4* recs = reinterpret_cast<float4*>(recs_i);
+        const int64_t Si = rows_per_image;
+        // brick mode: 16 x 16 rays x SL rows per block
+        int SL = 0;
+        if (ray_w > 0 && rows_per_ray > 0 && ray_w % 16 == 0 && Si % ((int64_t)rows_per_ray * ray_w) == 0 && (Si / ((int64_t)rows_per_ray * ray_w)) % 16 == 0)
+            SL = rows_per_ray % 24 == 0 ? 24 : (rows_per_ray % 16 == 0 ? 16 : 0);
+        const int blocks_i = SL ? (int)(Si / rows_per_ray / 256 * (rows_per_ray / SL)) : eg3d_cdiv(Si * 3, BIN16_THREADS * BIN16_ITEMS);
+        auto bin_pass = [&](int pass, const float4* pos_n) {
+#define EG3D_BIN16(P, L) hipLaunchKernelGGL((scatter_bin16_kernel<P, L>), dim3(blocks_i), dim3(BIN16_THREADS), sizeof(int) * nb16_img, st, pos_n, Si, cs, Hp, \
+                                            Wp, ntx, nty, nb16_img, counts16, offsets16, fill16, recs, ray_w, rows_per_ray)
+            if (pass == 0) { if (SL == 24) EG3D_BIN16(0, 24); else if (SL == 16) EG3D_BIN16(0, 16); else EG3D_BIN16(0, 0); }
+            else           { if (SL == 24) EG3D_BIN16(1, 24); else if (SL == 16) EG3D_BIN16(1, 16); else EG3D_BIN16(1, 0); }
+#undef EG3D_BIN16
+        };
+        for (int n = 0; n < N; ++n) {
+            const float4* pos_n = pos4 + (int64_t)n * Si;
+            eg3d_zero_words(counts16, 2 * (int64_t)nb16_img, st);
+            bin_pass(0, pos_n);
+            hipLaunchKernelGGL(scatter_scan16_kernel, dim3(1), dim3(1024), 0, st, counts16, offsets16, nb16_img);
+            bin_pass(1, pos_n);
+            hipLaunchKernelGGL(scatter_accum16p_kernel, dim3(1024), dim3(ACCP_WAVES * 64), 0, st, df_rows + (int64_t)n * Si * FC, Si, offsets16, recs,
+                               d_planes + (int64_t)n * Hp * Wp * ldp, Hp, Wp, ldp, ntx, nty);
+        }
+        EG3D_LAUNCH_CHECK();
+        return EG3D_OK;
+    }
+    eg3d_zero_words(counts, 2 * (int64_t)nb, st);          // counts + fill cursors (a kernel, not a memset node: see common.h)
     hipLaunchKernelGGL(scatter_bin_kernel<0>, dim3(blocks), dim3(256), sizeof(int) * nb, st, pos4, S, rows_per_image, cs, Hp, Wp, ntx, nty, nb, counts,
                        offsets, fill, ids);
     hipLaunchKernelGGL(scatter_scan_kernel, dim3(1), dim3(1024), 0, st, counts, offsets, chunk_offsets, nb);
-    hipLaunchKernelGGL(scatter_bin_kernel<1>, dim3(blocks), dim3(256), sizeof(int) * 2 * nb, st, pos4, S, rows_per_image, cs, Hp, Wp, ntx, nty, nb, counts,
-                       offsets, fill, ids);
     const int max_chunks = (int)((3 * S + CHUNK - 1) / CHUNK) + nb;
-    hipLaunchKernelGGL(scatter_accum_kernel, dim3(max_chunks), dim3(ACC_THREADS), 0, st, df_rows, pos4, offsets, chunk_offsets, ids, d_planes, cs, Hp, Wp, ldp,
-                       ntx, nty, nb);
+    const int variant = variant0 == 4 ? 3 : variant0;      // 1: round-2 kernel; 2 / 3: DMA-pipelined batches (8 / 16 waves); 4 (default, above): row-keyed
+    if (variant == 1 || S * FC * 4 >= ((int64_t)1 << 32) || 3 * S * 16 >= ((int64_t)1 << 32)) {
+        hipLaunchKernelGGL(scatter_bin_kernel<1>, dim3(blocks), dim3(256), sizeof(int) * 2 * nb, st, pos4, S, rows_per_image, cs, Hp, Wp, ntx, nty, nb, counts,
+                           offsets, fill, ids);
+        hipLaunchKernelGGL(scatter_accum_kernel, dim3(max_chunks), dim3(ACC_THREADS), 0, st, df_rows, pos4, offsets, chunk_offsets, ids, d_planes, cs, Hp, Wp, ldp,
+                           ntx, nty, nb);
+    } else {
+        hipLaunchKernelGGL(scatter_bin_kernel<2>, dim3(blocks), dim3(256), sizeof(int) * 2 * nb, st, pos4, S, rows_per_image, cs, Hp, Wp, ntx, nty, nb, counts,
+                           offsets, fill, ids);
+        const float4* recs = reinterpret_cast<const float4*>(ids);
+        hipLaunchKernelGGL((scatter_accum2_kernel<16, 256>), dim3(max_chunks), dim3(1024), 0, st, df_rows, S, offsets, chunk_offsets, recs, 3 * S, d_planes, Hp, Wp,
+                           ldp, ntx, nty, nb);
+    }
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

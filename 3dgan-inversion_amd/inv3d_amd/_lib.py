@@ -208,7 +208,7 @@ _SIGS = {
     'eg3d_render_query_sizes': (C.c_int, [C.c_void_p, C.c_void_p]),
     'eg3d_triplane_scatter_workspace_ints': (C.c_int64, [C.c_int64, C.c_int, C.c_int, C.c_int]),
     'eg3d_triplane_scatter': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
-                                        C.c_void_p, C.c_void_p]),
+                                        C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'eg3d_sample_decode': (C.c_int, [C.POINTER(RenderParams), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 

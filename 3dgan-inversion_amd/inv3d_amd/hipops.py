@@ -4,6 +4,7 @@ Tensors handed to the fused path are fp32 "NHWC": logical shape [N,C,H,W] with c
 reference-facing API keeps NCHW shapes while memory is channel-contiguous, which is what the MFMA implicit GEMM,
 the float4 epilogues and the 128-byte tri-plane gathers want).
 """
+import math
 import os
 import weakref
 import ctypes as C
@@ -1057,8 +1058,9 @@ def render_bwd(p, d_rgb, d_depth, d_wsum, d_planes, d_origins, d_dirs, dumps=Non
     if d_planes is not None:
         nints = L.lib().eg3d_triplane_scatter_workspace_ints(S, p.N, p.Hp, p.Wp)
         ws = torch.empty(nints, dtype=torch.int32, device=d_planes.device)
+        rw = math.isqrt(p.R)            # rays are generated row by row over a square image (ray_sampler.py:41-50): a hint for the binning order only
         L.check(L.lib().eg3d_triplane_scatter(L.ptr(rows), L.ptr(pos), S, p.R * 2 * D, L.ptr(d_planes), p.N, p.Hp, p.Wp, p.ldp,
-                                              p.box_warp, L.ptr(ws), L.stream_ptr()), 'triplane_scatter')
+                                              p.box_warp, L.ptr(ws), rw if rw * rw == p.R else 0, 2 * D, L.stream_ptr()), 'triplane_scatter')
 
 
 def sample_decode(p, coords, M):

@@ -575,8 +575,10 @@ int eg3d_render_bwd(const eg3d_render_bwd_params* p, void* stream);
  * d_planes[N,Hp,Wp,ldp] (pre-zeroed) += bilinear-adjoint scatter of the S dumped rows (grid_sample backward w.r.t. the
  * planes, renderer.py:64 under autograd).  rows_per_image = R*2*D.  workspace: eg3d_triplane_scatter_workspace_ints() int32. */
 int64_t eg3d_triplane_scatter_workspace_ints(int64_t S, int N, int Hp, int Wp);
+/* ray_w, rows_per_ray: optional hint (0, 0 = unknown) -- rays per image row and dumped rows per ray (2 D) of the row layout above; the
+ * binning passes then walk the rows in bricks of 16 x 16 rays (fewer bins per block); the result does not depend on it. */
 int eg3d_triplane_scatter(const float* df_rows, const float* df_pos, int64_t S, int64_t rows_per_image, float* d_planes, int N,
-                          int Hp, int Wp, int ldp, float box_warp, int32_t* workspace, void* stream);
+                          int Hp, int Wp, int ldp, float box_warp, int32_t* workspace, int ray_w, int rows_per_ray, void* stream);
 
 /* Decoder-only query (ImportanceRenderer.run_model, renderer.py:197-203; used for density grids):
  *   coords [N,M,3] -> rgb [N,M,Cout], sigma [N,M]. */
