@@ -1071,44 +1071,64 @@ __global__ void __launch_bounds__(1024) scatter_scan16_kernel(const int* __restr
 constexpr int ACCP_WAVES = 4;
 __global__ void __launch_bounds__(ACCP_WAVES * 64) scatter_accum16p_kernel(const float* __restrict__ df, int64_t S, const int* __restrict__ offsets,
                                                                             const float4* __restrict__ recs, float* __restrict__ d_planes, int Hp, int Wp,
-                                                                            int ldp, int ntx, int nty) {
+                                                                            int ldp, int ntx, int nty, int split) {
     __shared__ float amat[ACCP_WAVES * 8 * 64];       // per wave: the A operands of eight MFMAs
+    __shared__ __attribute__((aligned(16))) float4 recm[ACCP_WAVES * 128];      // per wave: the records of two super-steps
+    __shared__ __attribute__((aligned(16))) int keym[ACCP_WAVES * 128];         // ... and their row ids, [group][lane half][MFMA]
     const int tid = threadIdx.x;
     const int ntile = ntx * nty, nlist = 3 * ntile * TROWS;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 31, kk = lane >> 5;
     float* abuf = amat + wave * (8 * 64);
+    float4* recl = recm + wave * 128;
+    int* keyl = keym + wave * 128;
     for (int i = lane; i < 8 * 64; i += 64) abuf[i] = 0.f;
     const int pj = lane >> 2, half = (lane >> 1) & 1, dx = lane & 1;          // this lane's (pair, corner) of a 16-pair group
     const int a_slot = (pj >> 1) * 64 + (pj & 1) * 32 + half * 16;          // + column
     const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(df), 0, (int)(S * FC * 4), 0x00020000);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto pick = [&](int v, int src_lane_reg, int imm) { return __builtin_amdgcn_ds_bpermute(src_lane_reg + imm, v); };
     const int nwave = gridDim.x * ACCP_WAVES;
-    for (int li = blockIdx.x * ACCP_WAVES + wave; li < nlist; li += nwave) {
-        const int beg = __builtin_amdgcn_readfirstlane(offsets[li]), end = __builtin_amdgcn_readfirstlane(offsets[li + 1]);
+    for (int ui = blockIdx.x * ACCP_WAVES + wave; ui < nlist * split; ui += nwave) {
+        const int li = ui / split, part = ui - li * split;
+        const int lbeg = __builtin_amdgcn_readfirstlane(offsets[li]), llen = __builtin_amdgcn_readfirstlane(offsets[li + 1]) - lbeg;
+        const int beg = lbeg + (int)((int64_t)llen * part / split), end = lbeg + (int)((int64_t)llen * (part + 1) / split);
         if (beg >= end) continue;
         acc16_t acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         auto load_recs = [&](int p0) { return p0 + lane < end ? recs[p0 + lane] : zero4; };      // an all-zero record has coefficient 0 everywhere
+        // records of a super-step live in LDS (wave-private, two parities): lane (pair, corner) re-reads its pair's record as one
+        // broadcast ds_read_b128, and the row ids are stored de-interleaved so that the eight ids a lane needs for a group of MFMAs
+        // are two ds_read_b128 -- the cross-lane reads were 11 ds_bpermute per group before
+        auto stash = [&](const float4& R, int par) {
+            recl[par * 64 + lane] = R;
+            keyl[par * 64 + (lane & 48) + (lane & 1) * 8 + ((lane & 15) >> 1)] = __float_as_int(R.x);
+        };
         unsigned g[32];
-        float4 Rc = load_recs(beg), Rn = load_recs(beg + 64), Rnn = zero4;
+        {
+            const float4 R0 = load_recs(beg), R1 = load_recs(beg + 64);
+            stash(R0, 0); stash(R1, 1);
+        }
 #pragma unroll
-        for (int q = 0; q < 32; ++q) g[q] = __builtin_amdgcn_raw_buffer_load_b32(drs, (pick(__float_as_int(Rc.x), kk * 4, 8 * q) & 0x7ffffff) * (FC * 4) + c * 4, 0, 0);
-        for (int p0 = beg; p0 < end; p0 += 64) {
-            Rnn = load_recs(p0 + 128);
+        for (int gq = 0; gq < 4; ++gq) {
+            const int4 k0 = *reinterpret_cast<const int4*>(keyl + gq * 16 + kk * 8), k1 = *reinterpret_cast<const int4*>(keyl + gq * 16 + kk * 8 + 4);
+            const int nk[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) g[gq * 8 + q] = __builtin_amdgcn_raw_buffer_load_b32(drs, (nk[q] & 0x7ffffff) * (FC * 4) + c * 4, 0, 0);
+        }
+        int par = 0;
+        for (int p0 = beg; p0 < end; p0 += 64, par ^= 1) {
+            const float4 Rnn = load_recs(p0 + 128);
             const int npair = min(64, end - p0);
             const bool more = p0 + 64 < end;
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 if (gq * 16 >= npair && !more) break;
-                const int key = pick(__float_as_int(Rc.x), pj * 4, 64 * gq);
-                const float wx1 = __int_as_float(pick(__float_as_int(Rc.y), pj * 4, 64 * gq)), wy1 = __int_as_float(pick(__float_as_int(Rc.z), pj * 4, 64 * gq));
-                const int col = (int)((unsigned)key >> 27) - 1 + dx;                 // -1: the corner left of the tile (no owner here)
-                const float val = (dx ? wx1 : 1.f - wx1) * (half ? wy1 : 1.f - wy1);
-                int nk[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) nk[q] = pick(__float_as_int(Rn.x), kk * 4, 8 * (gq * 8 + q));
+                const float4 R = recl[par * 64 + gq * 16 + pj];
+                const int* kp = keyl + (par ^ 1) * 64 + gq * 16 + kk * 8;
+                const int4 k0 = *reinterpret_cast<const int4*>(kp), k1 = *reinterpret_cast<const int4*>(kp + 4);
+                const int nk[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+                const int col = (int)((unsigned)__float_as_int(R.x) >> 27) - 1 + dx;     // -1: the corner left of the tile (no owner here)
+                const float val = (dx ? R.y : 1.f - R.y) * (half ? R.z : 1.f - R.z);
                 if (col >= 0) abuf[a_slot + col] = val;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -1118,7 +1138,7 @@ __global__ void __launch_bounds__(ACCP_WAVES * 64) scatter_accum16p_kernel(const
                 }
                 if (col >= 0) abuf[a_slot + col] = 0.f;
             }
-            Rc = Rn; Rn = Rnn;
+            stash(Rnn, par);                     // super-step p0 + 128 reuses the parity that just finished
         }
         // accumulator element r of a lane = (half, column) (m >> 4, m & 15), m = (r&3) + 8 (r>>2) + 4 kk, channel c
         const int lrow = li % TROWS, t = (li / TROWS) % ntile, pl = li / (TROWS * ntile);
@@ -1389,8 +1409,9 @@ extern "C" int eg3d_triplane_scatter(const float* df_rows, const float* df_pos, 
             bin_pass(0, pos_n);
             hipLaunchKernelGGL(scatter_scan16_kernel, dim3(1), dim3(1024), 0, st, counts16, offsets16, nb16_img);
             bin_pass(1, pos_n);
+            static const int split = [] { const char* e = getenv("EG3D_SCATTER_SPLIT"); return e ? atoi(e) : 1; }();
             hipLaunchKernelGGL(scatter_accum16p_kernel, dim3(1024), dim3(ACCP_WAVES * 64), 0, st, df_rows + (int64_t)n * Si * FC, Si, offsets16, recs,
-                               d_planes + (int64_t)n * Hp * Wp * ldp, Hp, Wp, ldp, ntx, nty);
+                               d_planes + (int64_t)n * Hp * Wp * ldp, Hp, Wp, ldp, ntx, nty, split);
         }
         EG3D_LAUNCH_CHECK();
         return EG3D_OK;
