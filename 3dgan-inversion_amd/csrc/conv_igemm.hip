@@ -34,8 +34,13 @@ constexpr int BK = 32;                    // K per step, fp32 path
 constexpr int LDK = BK + 4;
 // split-bf16 paths: K per step is 16 (one v_mfma_f32_32x32x16_bf16 deep) for the 128x128 tile, 32 for the smaller tiles.
 // LDS image of one operand tile of R rows: [piece][k-octet = 2*chunk + h][row][8 bf16]; a wave's fragment read (lane = row, h)
-// is two contiguous 512-byte runs -> conflict-free ds_read_b128.  The 128-byte pad staggers the banks of the two halves.
-__host__ __device__ constexpr int split_plane_bytes(int rows) { return rows * 16 + 128; }
+// is two contiguous 512-byte runs -> conflict-free ds_read_b128.  The pad staggers the planes for the loader's 8-byte writes (a wave
+// writes 8 rows x 16 bytes into each of four planes at KB = 32): measured over all loader-split launches of a C2 step, pad 0: 2239 us,
+// 16: 2126, 32: 2097-2111, 48: 2128, 64: 2165, 96: 2120, 128 (rounds 1-2): 2197-2203, 160: 2149, 192: 2128, 224: 2170.
+#ifndef EG3D_SPLIT_PAD
+#define EG3D_SPLIT_PAD 32
+#endif
+__host__ __device__ constexpr int split_plane_bytes(int rows) { return rows * 16 + EG3D_SPLIT_PAD; }
 __host__ __device__ constexpr int split_tile_bytes(int rows, int np, int kb) { return np * (kb / 8) * split_plane_bytes(rows); }
 
 // Split-bf16 operand pieces (precision 1/2): an fp32 value is cut into bf16 terms by truncation,
