@@ -42,6 +42,7 @@ struct DecodeArgs {
     float* df_rows;             // [M,FC] dL/d(mean feature) / 3        (or null)
     float4* gc_rows;            // [M] (dL/d position, depth)            (or null)
     float* dump_dpre; float* dump_h; float* dump_dout; float* dump_feat;   // decoder-weight gradient operands (or null)
+    float* feat;                // FEAT instantiations: [rows, FC] interpolated features in OUTPUT row order (written by gather_rows_kernel)
 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -213,7 +214,47 @@ __device__ __forceinline__ void phase_fence() { asm volatile("" ::: "memory"); }
 #ifndef DEC_GRID_FWD
 #define DEC_GRID_FWD 5
 #endif
-template <bool BWD>
+// ---- the gather as a pass of its own ---------------------------------------------------------------------------------------------------
+// thread = (row, channel quad): twelve independent 16-byte texel loads, ~40 registers, every wave slot of the CU in use.  53 us for the
+// 0.79 M rows of one pass (22 TB/s of texel reads out of L1 / L2) -- inside the decoder kernels the same loads cost ~95 us of a 160 us
+// launch, because those hold ~140 registers (3-5 waves per SIMD) and each wave can keep only one plane's 16 loads in flight.
+__global__ void __launch_bounds__(256) gather_rows_kernel(const DecodeArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = i >> 3;
+    const int q = (int)(i & 7);
+    if (row >= a.M) return;
+    const float* pp = a.pos + row * a.pos_stride;
+    const float px = pp[0], py = pp[1], pz = pp[2];
+    const unsigned seg = a.seg_len ? (unsigned)row / (unsigned)a.seg_len : 0u;
+    const int64_t orow = a.seg_len ? (int64_t)seg * a.seg_stride + a.seg_off + ((unsigned)row - seg * (unsigned)a.seg_len) : row;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!isnan(px)) {
+        const int n = (int)((unsigned)row / (unsigned)a.rows_per_image);
+        const float* pn = a.planes + (int64_t)n * a.Hp * a.Wp * a.ldp + 4 * q;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            float u, v;
+            plane_uv(pl, px * a.cs, py * a.cs, pz * a.cs, u, v);
+            const float ix = ((u + 1.f) * a.Wp - 1.f) * 0.5f, iy = ((v + 1.f) * a.Hp - 1.f) * 0.5f;
+            const float fx0 = floorf(ix), fy0 = floorf(iy);
+            const int x0 = (int)fx0, y0 = (int)fy0;
+            const float wx1 = ix - fx0, wx0 = (fx0 + 1.f) - ix, wy1 = iy - fy0, wy0 = (fy0 + 1.f) - iy;      // the weights of gather_split
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int xx = x0 + (c & 1), yy = y0 + (c >> 1);
+                const bool inb = (unsigned)xx < (unsigned)a.Wp && (unsigned)yy < (unsigned)a.Hp;
+                const int xc = min(max(xx, 0), a.Wp - 1), yc = min(max(yy, 0), a.Hp - 1);
+                const float w = inb ? ((c & 1) ? wx1 : wx0) * ((c >> 1) ? wy1 : wy0) : 0.f;
+                const float4 t = *reinterpret_cast<const float4*>(pn + (yc * a.Wp + xc) * a.ldp + pl * FC);
+                acc.x = fmaf(w, t.x, acc.x); acc.y = fmaf(w, t.y, acc.y); acc.z = fmaf(w, t.z, acc.z); acc.w = fmaf(w, t.w, acc.w);
+            }
+        }
+        acc.x *= 1.f / 3.f; acc.y *= 1.f / 3.f; acc.z *= 1.f / 3.f; acc.w *= 1.f / 3.f;
+    }
+    reinterpret_cast<float4*>(a.feat + orow * FC)[q] = acc;
+}
+
+template <bool BWD, bool FEAT>
 __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_rows_kernel(const DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const Frags F = setup_frags<BWD>(lds, a);
@@ -234,8 +275,18 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
         const int n = valid ? (int)((unsigned)row / (unsigned)a.rows_per_image) : 0;          // rows fit 31 bits (launch_decode): 32-bit divides
         const float* pn = a.planes + (int64_t)n * a.Hp * a.Wp * a.ldp;
 
+        // output row of this sample (forward: the (pass, ray, s) -> (ray, pass, s) interleave of the save buffers)
+        const unsigned seg = a.seg_len ? (unsigned)row / (unsigned)a.seg_len : 0u;
+        const int64_t orow = a.seg_len ? (int64_t)seg * a.seg_stride + a.seg_off + ((unsigned)row - seg * (unsigned)a.seg_len) : row;
         f32x16 f;
-        {
+        if constexpr (FEAT) {            // the gather ran as its own pass (gather_rows_kernel): this lane's 16 features are four float4 of the row
+            const float* fr = a.feat + (row < a.M ? orow : 0) * FC + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 v = *reinterpret_cast<const float4*>(fr + 8 * g);
+                f[4 * g] = v.x; f[4 * g + 1] = v.y; f[4 * g + 2] = v.z; f[4 * g + 3] = v.w;
+            }
+        } else {
             float fr[16];
             gather_split(pn, a.Hp, a.Wp, a.ldp, a.cs, px, py, pz, h, fr);
 #pragma unroll
@@ -285,8 +336,6 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
 
         if (!BWD) {
             if (valid) {
-                const unsigned seg = a.seg_len ? (unsigned)row / (unsigned)a.seg_len : 0u;
-                const int64_t orow = a.seg_len ? (int64_t)seg * a.seg_stride + a.seg_off + ((unsigned)row - seg * (unsigned)a.seg_len) : row;
                 if (h == 0) a.sigma[orow] = sig;
                 float* o = a.rgb + orow * CO + 4 * h;
 #pragma unroll
@@ -440,8 +489,12 @@ int launch_decode(const DecodeArgs& a, bool bwd, hipStream_t st) {
         return EG3D_ERR_UNSUPPORTED;      // 32-bit row and texel-offset arithmetic in the kernels
     const int64_t ntiles = (a.M + 31) / 32;
     const int blocks = (int)std::min<int64_t>((ntiles + 3) / 4, 256 * (bwd ? DEC_GRID_BWD : DEC_GRID_FWD));     // persistent: resident blocks per CU x 256 CUs
-    if (bwd) hipLaunchKernelGGL(decode_rows_kernel<true>, dim3(blocks), dim3(256), FRAG_BYTES_BWD, st, a);
-    else hipLaunchKernelGGL(decode_rows_kernel<false>, dim3(blocks), dim3(256), FRAG_BYTES_FWD, st, a);
+    if (a.feat != nullptr) {
+        if (!bwd) hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((a.M * 8 + 255) / 256)), dim3(256), 0, st, a);
+        if (bwd) hipLaunchKernelGGL((decode_rows_kernel<true, true>), dim3(blocks), dim3(256), FRAG_BYTES_BWD, st, a);
+        else hipLaunchKernelGGL((decode_rows_kernel<false, true>), dim3(blocks), dim3(256), FRAG_BYTES_FWD, st, a);
+    } else if (bwd) hipLaunchKernelGGL((decode_rows_kernel<true, false>), dim3(blocks), dim3(256), FRAG_BYTES_BWD, st, a);
+    else hipLaunchKernelGGL((decode_rows_kernel<false, false>), dim3(blocks), dim3(256), FRAG_BYTES_FWD, st, a);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }
@@ -456,6 +509,7 @@ int eg3d_decode_rows_fwd(const eg3d_render_params& p, const float* pos, int pos_
     a.w0 = p.w0; a.b0 = p.b0; a.w1t = p.w1; a.b1 = p.b1;
     a.pos = pos; a.pos_stride = pos_stride; a.M = M; a.rows_per_image = rows_per_image; a.sigma = sigma; a.rgb = rgb;
     a.seg_len = seg_len; a.seg_stride = seg_stride; a.seg_off = seg_off;
+    a.feat = p.feat_rows;
     return launch_decode(a, false, (hipStream_t)stream);
 }
 
@@ -473,5 +527,6 @@ int eg3d_decode_rows_bwd(const eg3d_render_bwd_params& bp, const float* pos, int
     a.dump_h = bp.dump_h ? bp.dump_h + row0 * HD : nullptr;
     a.dump_dout = bp.dump_dout ? bp.dump_dout + row0 * (1 + CO) : nullptr;
     a.dump_feat = bp.dump_feat ? bp.dump_feat + row0 * FC : nullptr;
+    a.feat = p.feat_rows ? p.feat_rows + row0 * FC : nullptr;
     return launch_decode(a, true, (hipStream_t)stream);
 }

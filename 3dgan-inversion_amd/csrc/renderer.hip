@@ -1353,6 +1353,7 @@ extern "C" int eg3d_render_query_sizes(const eg3d_render_params* p, eg3d_render_
     out->save_sigma = S;  out->save_rgb = S * p->Cout;  out->pos_rows = p->Df > 0 ? 2 * NR * D * 4 : 0;
     out->df_rows = S * FC;  out->df_pos = S * 4;  out->ag_rows = S * 2;  out->gc_rows = S * 4;
     out->dump_dpre = S * 64;  out->dump_h = S * 64;  out->dump_dout = S * (1 + p->Cout);  out->dump_feat = S * FC;
+    out->feat_rows = p->Df > 0 ? S * FC : 0;
     return EG3D_OK;
 }
 
@@ -1444,7 +1445,9 @@ extern "C" int eg3d_sample_decode(const eg3d_render_params* pp, const float* coo
     if (!p.planes || !p.w0 || !p.b0 || !p.w1 || !p.b1 || p.N <= 0) return EG3D_ERR_INVALID;
     if (p.C != FC || p.Hdim != HD || p.Cout != CO || p.ldp < 3 * FC || (p.ldp & 3)) return EG3D_ERR_UNSUPPORTED;
     if (M == 0) return EG3D_OK;
-    return eg3d_decode_rows_fwd(p, coords, 3, (int64_t)p.N * M, M, sigma, rgb, stream);
+    eg3d_render_params q = p;
+    q.feat_rows = nullptr;               // (a buffer of the ray renderer's row count: not for free-standing points)
+    return eg3d_decode_rows_fwd(q, coords, 3, (int64_t)p.N * M, M, sigma, rgb, stream);
 }
 
 extern "C" int eg3d_ray_gen_fwd(const float* cam2world, const float* intrinsics, float* origins, float* dirs, int N, int res, void* stream) {

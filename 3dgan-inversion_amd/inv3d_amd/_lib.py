@@ -88,7 +88,7 @@ class RenderParams(C.Structure):
                 ('w0', C.c_void_p), ('b0', C.c_void_p), ('w1', C.c_void_p), ('b1', C.c_void_p), ('Hdim', C.c_int32),
                 ('Cout', C.c_int32), ('rgb', C.c_void_p), ('depth', C.c_void_p), ('wsum', C.c_void_p),
                 ('depth_minmax', C.c_void_p), ('fine_depths', C.c_void_p), ('save_sigma', C.c_void_p), ('save_rgb', C.c_void_p),
-                ('ray_tile_width', C.c_int32), ('pos_rows', C.c_void_p)]
+                ('ray_tile_width', C.c_int32), ('pos_rows', C.c_void_p), ('feat_rows', C.c_void_p)]
 
 
 class RenderBwdParams(C.Structure):
@@ -100,7 +100,7 @@ class RenderBwdParams(C.Structure):
 
 class RenderSizes(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ('S', 'rgb', 'depth', 'wsum', 'depth_minmax', 'fine_depths', 'save_sigma', 'save_rgb', 'pos_rows',
-                                         'df_rows', 'df_pos', 'ag_rows', 'gc_rows', 'dump_dpre', 'dump_h', 'dump_dout', 'dump_feat')]
+                                         'df_rows', 'df_pos', 'ag_rows', 'gc_rows', 'dump_dpre', 'dump_h', 'dump_dout', 'dump_feat', 'feat_rows')]
 
 
 class FlreluParams(C.Structure):

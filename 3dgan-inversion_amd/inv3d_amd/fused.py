@@ -162,6 +162,7 @@ def _zeros_views(device, *shapes):
 TORGB4_ELEMENTWISE = os.environ.get('EG3D_TORGB4_ELEMENTWISE', '1') != '0'   # 4-output toRGB data gradient as an element-wise pass (hipops.torgb_dgrad_act)
 USE_PIECES = os.environ.get('EG3D_WEIGHT_PIECES', '1') != '0'      # loader-split conv kernel reads pre-split weight images (WeightCache.get_pieces)
 RENDER_PIPELINE_NOGRAD = os.environ.get('EG3D_RENDER_PIPELINE_NOGRAD', '1') != '0'   # ... also for no-grad rendering (scratch rows)
+RENDER_FEAT_ROWS = os.environ.get('EG3D_RENDER_FEAT_ROWS', '1') != '0'   # gather pass + feature rows (eg3d_render_params.feat_rows) in the pipelined renderer
 RENDER_PIPELINE = os.environ.get('EG3D_RENDER_PIPELINE', '1') != '0'     # forward renderer as positions -> MFMA decode -> importance -> decode -> composite
 KS_TARGET = int(os.environ.get('EG3D_KS_TARGET', '256'))       # blocks a split launch aims for (one per CU; 512 measured 0.7 % slower per step)
 
@@ -761,14 +762,18 @@ class RenderFn(torch.autograd.Function):
             # as scratch -- since the decoder moved to the 16-bit matrix cores it beats the fused per-ray kernel (0.50 vs 0.84 ms at 128^2 x 96)
             S = N * R * 2 * max(Dc, Df)
             rows = (torch.empty((S,), device=dev), torch.empty((S, w1.shape[0] - 1), device=dev))
+        feat = None
         if rows is not None and Df > 0 and RENDER_PIPELINE:      # sample-level decode on the matrix cores between ray-level stages
             pos = torch.empty((2, N * R, max(Dc, Df), 4), device=dev)
+            if RENDER_FEAT_ROWS:        # the tri-plane gather as its own pass; the backward re-reads the rows instead of gathering again
+                feat = torch.empty((N * R * 2 * max(Dc, Df), 32), device=dev)
         p = H.make_render_params(planes, origins, dirs, u1, u2, opts, w0g, b0g, w1t, b1g, rgb, depth, wsum, minmax, fine, rl, rows if pos is not None else save,
-                                 pos_rows=pos)
+                                 pos_rows=pos, feat_rows=feat)
         with H._Span('render_fwd'):
             H.render_fwd(p)
             H.render_finalize(depth, minmax)
-        ctx.save_for_backward(planes, origins, dirs, w0g, b0g, w1t, b1g, u1, u2, minmax, fine, rl, *(save or ()))
+        ctx.has_feat = feat is not None and save is not None
+        ctx.save_for_backward(planes, origins, dirs, w0g, b0g, w1t, b1g, u1, u2, minmax, fine, rl, *(save or ()), *((feat,) if ctx.has_feat else ()))
         ctx.cfg = (dict(opts), g0, g1, lr_mul)
         return rgb, depth, wsum
 
@@ -776,6 +781,7 @@ class RenderFn(torch.autograd.Function):
     def backward(ctx, g_rgb, g_depth, g_wsum):
         planes, origins, dirs, w0g, b0g, w1t, b1g, u1, u2, minmax, fine, rl = ctx.saved_tensors[:12]
         save = ctx.saved_tensors[12:14]
+        feat_rows = ctx.saved_tensors[14] if ctx.has_feat else None
         opts, g0, g1, lr_mul = ctx.cfg
         need = ctx.needs_input_grad
         dev = planes.device
@@ -783,7 +789,7 @@ class RenderFn(torch.autograd.Function):
         g_rgb = g_rgb.contiguous().float() if g_rgb is not None else torch.zeros((N, R, w1t.shape[1] - 1), device=dev)
         g_depth = g_depth.contiguous().float() if g_depth is not None else None
         g_wsum = g_wsum.contiguous().float() if g_wsum is not None else None
-        p = H.make_render_params(planes, origins, dirs, u1, u2, opts, w0g, b0g, w1t, b1g, None, None, None, minmax, fine, rl, save)
+        p = H.make_render_params(planes, origins, dirs, u1, u2, opts, w0g, b0g, w1t, b1g, None, None, None, minmax, fine, rl, save, feat_rows=feat_rows)
         d_planes = H.zeros_cl(*planes.shape, dev) if need[0] else None
         d_o = torch.empty_like(origins) if (need[1] or need[2]) else None
         d_d = torch.empty_like(dirs) if (need[1] or need[2]) else None
@@ -793,7 +799,9 @@ class RenderFn(torch.autograd.Function):
             S = N * R * 2 * D
             # with equal coarse / fine counts every row is a live sample and is written by the sample-level kernel
             mk = torch.empty if p.Dc == p.Df else torch.zeros
-            dumps = [mk((S, 64), device=dev), mk((S, 64), device=dev), mk((S, 33), device=dev), mk((S, 32), device=dev)]
+            # (the feature operand of the decoder-weight Gram product is the saved feature rows themselves when the forward kept them; rows of
+            #  absent samples hold zeros there as well)
+            dumps = [mk((S, 64), device=dev), mk((S, 64), device=dev), mk((S, 33), device=dev), feat_rows if feat_rows is not None else mk((S, 32), device=dev)]
         with H._Span('render_bwd'):
             H.render_bwd(p, g_rgb, g_depth, g_wsum, d_planes, d_o, d_d, dumps)
         dw0 = db0 = dw1 = db1 = None

@@ -976,7 +976,8 @@ def ray_gen_bwd(c2w, K, g_o, g_d, res, want_K=True):
     return d_c2w, d_K
 
 
-def make_render_params(planes, origins, dirs, u1, u2, opts, w0, b0, w1t, b1, rgb, depth, wsum, minmax, fine, ray_limits=None, save=None, ray_tile_width=None, pos_rows=None):
+def make_render_params(planes, origins, dirs, u1, u2, opts, w0, b0, w1t, b1, rgb, depth, wsum, minmax, fine, ray_limits=None, save=None, ray_tile_width=None, pos_rows=None,
+                       feat_rows=None):
     """planes: channels_last [N, 3*C, Hp, Wp]; decoder weights with gains folded (w1t transposed [H, 1+Cout])."""
     assert is_cl(planes)
     p = L.RenderParams()
@@ -1009,6 +1010,7 @@ def make_render_params(planes, origins, dirs, u1, u2, opts, w0, b0, w1t, b1, rgb
         ray_tile_width = side if side * side == p.R and side % 32 == 0 else 0
     p.ray_tile_width = int(ray_tile_width)
     p.pos_rows = pos_rows.data_ptr() if pos_rows is not None else None       # workspace [2, N*R, D, 4]: selects the pipelined forward
+    p.feat_rows = feat_rows.data_ptr() if feat_rows is not None else None    # [S, 32]: gather as its own pass, rows re-read by the decoder kernels
     return p
 
 
@@ -1054,6 +1056,8 @@ def render_bwd(p, d_rgb, d_depth, d_wsum, d_planes, d_origins, d_dirs, dumps=Non
     bp.d_dirs = d_dirs.data_ptr() if d_dirs is not None else None
     if dumps is not None:
         bp.dump_dpre, bp.dump_h, bp.dump_dout, bp.dump_feat = [t.data_ptr() for t in dumps]
+        if p.feat_rows and bp.dump_feat == p.feat_rows:         # the caller uses the saved feature rows as that operand: nothing to dump
+            bp.dump_feat = None
     L.check(L.lib().eg3d_render_bwd(C.byref(bp), L.stream_ptr()), 'render_bwd')
     if d_planes is not None:
         nints = L.lib().eg3d_triplane_scatter_workspace_ints(S, p.N, p.Hp, p.Wp)

@@ -524,6 +524,11 @@ typedef struct eg3d_render_params {
                                 * forward runs as a pipeline -- sample positions -> tri-plane gather + decoder on the matrix cores
                                 * (the sample-level kernel of the backward) -> importance sampling -> decoder -> compositing from the
                                 * saved rows -- instead of one fused per-ray kernel with the decoder on the vector ALUs.  null = fused. */
+    float* feat_rows;          /* optional [S,32] (row order of save_rgb), pipelined forward only: the interpolated tri-plane feature of every
+                                * sample.  With it the gather runs as its own high-occupancy pass (the fused gather + decoder kernels hold
+                                * ~140 registers and wait on the scattered texel loads most of the time) and the decoder kernels -- forward
+                                * and, given the same buffer in eg3d_render_bwd_params.fwd, backward -- read the rows back coalesced.
+                                * Same values either way.  null = gather inside the decoder kernels. */
 } eg3d_render_params;
 
 int eg3d_render_fwd(const eg3d_render_params* p, void* stream);
@@ -537,6 +542,7 @@ typedef struct eg3d_render_sizes {
     int64_t save_sigma, save_rgb, pos_rows;                   /* training-mode forward (pos_rows optional) */
     int64_t df_rows, df_pos, ag_rows, gc_rows;                /* eg3d_render_bwd                          */
     int64_t dump_dpre, dump_h, dump_dout, dump_feat;          /* decoder-weight gradient operands         */
+    int64_t feat_rows;                                        /* optional feature rows (pipelined forward) */
 } eg3d_render_sizes;
 int eg3d_render_query_sizes(const eg3d_render_params* p, eg3d_render_sizes* out);
 /* depth <- clamp(nan_to_num(depth, inf), min, max) with the global min/max (ray_marcher.py:49-50). */
