@@ -555,11 +555,10 @@ def conv_v2_ksplit(Ck, Nc, classes, N=1):
 V2_MIN_TILES = int(os.environ.get('EG3D_V2_MIN_TILES', '256'))
 USE_V2 = os.environ.get('EG3D_CONV_V2', '1') != '0'
 V2_CONVT = os.environ.get('EG3D_V2_CONVT', '0') == '1'
-# 4 x 32-cell patches for under-filled 3x3 grids (conv_v2_rows): EXPERIMENTAL, OFF by default.  The instantiation is bit-exact with the plain-store
-# epilogue (30 / 30 runs at 256^2 x 128 and 128^2 x 256) and gains +0.7 % per step (128^2 x 256: 107 -> 91 us, 256^2 x 128: 84 -> 67 us), but
-# with the fused forward / data-gradient epilogues a few hundred of 8 M output elements per launch come out wrong on full-size layers
-# (sporadic, timing dependent; not reproduced at the small test shapes; tools/debug_half.py).  Not shipped in the default path until found.
-V2_HALF = os.environ.get('EG3D_V2_HALF', '0') != '0'
+# 4 x 32-cell patches for under-filled 3x3 grids (conv_v2_rows): 128^2 x 256: 107 -> 91 us, 256^2 x 128: 84 -> 67 us per launch.  (Off in the
+# first half of round 3: with the fused epilogues a few hundred of 8 M output elements per launch came out wrong on full-size layers --
+# a miscompile of the scalar epilogue arithmetic by the SLP vectoriser, see the Makefile; tests/test_gpu_ops.py::test_conv_v2_half_patch_full_size.)
+V2_HALF = os.environ.get('EG3D_V2_HALF', '1') != '0'             # half-height (4 x 32) patches for nine-tap launches ...
 V2_HALF_BELOW = int(os.environ.get('EG3D_V2_HALF_BELOW', '512'))      # ... when the 8-row grid has fewer workgroups than this (256^2 x 128: 84 -> 67 us, 128^2 x 256: 107 -> 91 us)
 # split-K launches of the pre-split kernel for under-filled 3x3 grids: OFF by default.  Measured at N = 1 (MI355X): 128^2 x 256 118 -> 81 us,
 # 64^2 x 512 103 -> 82 us per launch, but the operand split pass (7 us), the zero fill and the finishing pass (2 x 10 us; the loader-split

@@ -607,7 +607,7 @@ def _v2_operands(x, wt, styles, adjoint=False):
     return xc, aimg, wimg
 
 
-@pytest.mark.parametrize('rows', [8])        # (4: the experimental half-height patch, off by default -- hipops.V2_HALF)
+@pytest.mark.parametrize('rows', [8, 4])        # 4: the half-height patch (hipops.V2_HALF)
 @pytest.mark.parametrize('shape', [(1, 32, 16, 64, 128), (2, 64, 40, 72, 128), (1, 128, 33, 37, 256), (1, 16, 8, 32, 128)])
 def test_conv_v2_forward_epilogue_vs_torch(shape, rows):
     """3x3 correlation with the fused forward epilogue (style-modulated input, demodulation, noise, bias, lrelu, gain, skip addend) on
@@ -633,7 +633,35 @@ def test_conv_v2_forward_epilogue_vs_torch(shape, rows):
     assert abs(float(amax) - float(out.abs().max())) == 0.0
 
 
-@pytest.mark.parametrize('rows', [8])
+def test_conv_v2_half_patch_full_size():
+    """The 4 x 32-cell patch with the fused forward epilogue at a full-size layer (256^2 x 128 -> 128), three launches: the shapes of the test
+    above never showed the fault this guards against (sporadic wrong elements from an SLP-vectorised epilogue: 3dgan-inversion_amd/Makefile)."""
+    from inv3d_amd import hipops as H, _lib as L
+    n, ci, h, w, co = 1, 128, 256, 256, 128
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, ci, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)).to(DEV)
+    s = (1 + 0.5 * torch.randn(n, ci, generator=g)).to(DEV)
+    d = (0.5 + torch.rand(n, co, generator=g)).to(DEV)
+    noise, strength = torch.randn(h, w, generator=g).to(DEV), torch.tensor(0.3, device=DEV)
+    bias = (0.1 * torch.randn(co, generator=g)).to(DEV)
+    aimg = H.split_activation(x, H.absmax(x), in_scale=s)
+    wimg = H.split_weight(H.pack_weight_fwd(wt), co, ci, 9)
+    z = torch.nn.functional.conv2d(x.double() * s.double()[:, :, None, None], wt.double(), padding=1) * d.double()[:, :, None, None]
+    ref = (torch.nn.functional.leaky_relu(z + noise.double() * 0.3 + bias.double()[None, :, None, None], 0.2) * 1.4).float()
+    outs = []
+    for rows in (8, 4, 4, 4):
+        out = H.empty_cl(n, co, h, w, DEV)
+        H.conv_v2(aimg, wimg, out, H.classes_corr(h, w, 3, 3, 1), epi=L.EPI_FWD, out_scale=d, bias=bias, noise=noise, noise_nstride=0, noise_strength=strength,
+                  act='lrelu', alpha=0.2, gain=1.4, clamp=-1.0, out_amax=torch.zeros(1, device=DEV), patch_rows=rows)
+        torch.cuda.synchronize()
+        close(out, ref, 5e-5, f'conv_v2 full size rows {rows}')
+        outs.append(out)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), 'the 4-row and 8-row patches accumulate in the same order: bit-identical results'
+
+
+@pytest.mark.parametrize('rows', [8, 4])
 def test_conv_v2_data_gradient_epilogue_vs_torch(rows):
     """Data gradient of a 3x3 layer: adjoint taps on the adjoint weight image, dx = acc * styles + addend, ds = sum_px acc * x."""
     from inv3d_amd import hipops as H, _lib as L
