@@ -181,6 +181,10 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
     const int64_t rr = live ? ray : 0;
     const int n = (int)(rr / p.R);
     RayLds L = ray_lds(lds, r < RPB ? r : 0, D);
+    // the serial scans of the block's RPB rays run on lanes 0 .. RPB-1 of wave 0 (one lane per ray at thread s == 0 put them into three
+    // different waves, each of which then issued the whole loop for one or two active lanes)
+    const bool scan_lane = tid < RPB && (int64_t)bid * RPB + tid < nrays;
+    const RayLds Ls = ray_lds(lds, scan_lane ? tid : 0, D);
     float* red = lds + RPB * RAY_LDS_FLOATS(D);   // forward: [nthreads][33] colour reduction; backward: E / GA / coordinate sums
     float* grgb = red + render_red_floats(RPB, D, MODE) + (r < RPB ? r : 0) * CO;   // backward: this ray's incoming d_rgb [32]
 
@@ -260,9 +264,9 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
                 L.t[s] = a; L.q[s] = 1.f - a + 1e-10f;
             }
             __syncthreads();
-            if (live && s == 0) {
+            if (scan_lane) {
                 float T = 1.f;
-                for (int i = 0; i < Dc - 1; ++i) { L.w[i] = L.t[i] * T; T *= L.q[i]; }
+                for (int i = 0; i < Dc - 1; ++i) { Ls.w[i] = Ls.t[i] * T; T *= Ls.q[i]; }
             }
             __syncthreads();
             // smoothing: max_pool1d(2,1,pad 1) -> avg_pool1d(2,1) -> + 0.01      (renderer.py:260-262)
@@ -384,17 +388,17 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
         }
     }
     __syncthreads();
-    if (live && s == 0) {
+    if (scan_lane) {
         float T = 1.f, wsum = 0.f, dnum = 0.f;
         for (int i = 0; i < nI; ++i) {
-            float w = L.t[i] * T;
-            L.w[i] = w;
-            if (BWD) L.t[i] = T;                     // keep T_i for the gradient
-            T *= L.q[i];
+            float w = Ls.t[i] * T;
+            Ls.w[i] = w;
+            if (BWD) Ls.t[i] = T;                     // keep T_i for the gradient
+            T *= Ls.q[i];
             wsum += w;
-            dnum += w * (0.5f * (L.sd[i] + L.sd[i + 1]));
+            dnum += w * (0.5f * (Ls.sd[i] + Ls.sd[i + 1]));
         }
-        L.misc[0] = wsum; L.misc[1] = dnum; L.misc[2] = L.sd[0]; L.misc[3] = L.sd[nS - 1];
+        Ls.misc[0] = wsum; Ls.misc[1] = dnum; Ls.misc[2] = Ls.sd[0]; Ls.misc[3] = Ls.sd[nS - 1];
     }
     __syncthreads();
 
@@ -451,10 +455,16 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
     // =====================================================================================================
     float* E = red + r * 2 * D;                  // [nS] <d_rgb, colour> at the sorted position of each sample
     float* GA = red + RPB * 2 * D + r * 2 * D;   // [nI] dL/d(mid density) per interval
+    float* GWT = red + 2 * RPB * 2 * D + r * 4 * D;      // [nI] gw_i T_i     (scratch behind E / GA: render_red_floats keeps 7 D floats per ray there)
+    float* DL = GWT + 2 * D;                     // [nI] delta_i
     if (has_c) E[rank_c] = e_c;
     if (has_f) E[rank_f] = e_f;
     __syncthreads();
-    if (live && s == 0) {
+    // Everything of an interval that does not depend on the suffix sum is formed by the ray's D threads, two intervals each.  The serial scan
+    // below used to do all of it -- sigmoid, divisions, five LDS reads per interval -- on ONE lane per ray: 112 M wave-level VALU instructions
+    // per launch (9 K per wave), i.e. the kernel was bound by arithmetic that 63 of 64 lanes sat out.
+    float xw[2] = {0.f, 0.f};
+    if (live) {
         const float wsum = L.misc[0], dnum = L.misc[1];
         const float depth_raw = dnum / wsum;
         const float dmin = p.depth_minmax[0], dmax = p.depth_minmax[1];
@@ -463,21 +473,39 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
         const float gws = bp.d_wsum ? bp.d_wsum[rr] : 0.f;
         float grgb_sum = 0.f;
         if (p.white_back) for (int k = 0; k < CO; ++k) grgb_sum += grgb[k];
-        // dL/dw_i, then dL/dalpha_i with a reverse suffix scan
-        float S = 0.f;
-        for (int i = nI - 1; i >= 0; --i) {
-            float dmid = 0.5f * (L.sd[i] + L.sd[i + 1]);
+        int k = 0;
+        for (int i = s; i < nI; i += D, ++k) {
+            const float dmid = 0.5f * (L.sd[i] + L.sd[i + 1]);
             float gw = (E[i] + E[i + 1]) + gws - 2.f * grgb_sum;
             if (gd != 0.f) gw += gd * (dmid - depth_raw) / wsum;
-            float T = L.t[i], q = L.q[i], w = L.w[i];
-            float galpha = gw * T - S / q;
-            S += gw * w;
             // alpha = 1 - exp(-sp*delta);  sp = softplus(m - 1)
-            float delta = L.sd[i + 1] - L.sd[i];
-            float m = 0.5f * (L.ss[i] + L.ss[i + 1]) - 1.f;
-            float one_minus_alpha = q - 1e-10f;
-            float gsp = galpha * delta * one_minus_alpha;
-            GA[i] = gsp * (m > 20.f ? 1.f : sigmoid_acc(m));
+            const float m = 0.5f * (L.ss[i] + L.ss[i + 1]) - 1.f;
+            GWT[i] = gw * L.t[i];
+            DL[i] = L.sd[i + 1] - L.sd[i];
+            GA[i] = m > 20.f ? 1.f : sigmoid_acc(m);         // replaced by the interval's gradient in the scan
+            xw[k] = gw * L.w[i];
+        }
+    }
+    __syncthreads();                 // every E[i], E[i + 1] has been read: E becomes the scan's addend gw_i w_i
+    if (live) {
+        int k = 0;
+        for (int i = s; i < nI; i += D, ++k) E[i] = xw[k];
+    }
+    __syncthreads();
+    if (scan_lane) {
+        // dL/dalpha_i = gw_i T_i - S_i / q_i with the reverse suffix sum S_i = sum_{j > i} gw_j w_j
+        const float* Es = red + tid * 2 * D;
+        float* GAs = red + RPB * 2 * D + tid * 2 * D;
+        const float* GWTs = red + 2 * RPB * 2 * D + tid * 4 * D;
+        const float* DLs = GWTs + 2 * D;
+        float S = 0.f;
+        for (int i = nI - 1; i >= 0; --i) {
+            const float q = Ls.q[i];
+            const float galpha = GWTs[i] - S / q;
+            S += Es[i];
+            const float one_minus_alpha = q - 1e-10f;
+            const float gsp = galpha * DLs[i] * one_minus_alpha;
+            GAs[i] = gsp * GAs[i];
         }
     }
     __syncthreads();
