@@ -593,7 +593,8 @@ def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_
             p.epi = L.EPI_BWD
             p.act_bwd = L.ActBwd()
     prof = PROFILER
-    if prof is not None and prof.only_config is not None and prof.only_config != V2_CONFIG:
+    cfg_id = V2_CONFIG if p.patch_rows == 8 else V2H_CONFIG       # the two patch heights are different instantiations: separate profiler records
+    if prof is not None and prof.only_config is not None and prof.only_config != cfg_id:
         prof = None
     if prof is not None:
         if algo_flops is None:
@@ -603,10 +604,10 @@ def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_
     L.check(L.lib().eg3d_conv2d_v2(C.byref(p), L.stream_ptr()), 'conv2d_v2')
     if prof is not None:
         e1.record()
-        prof.records.append(((V2_CONFIG, PRECISIONS['f16x3']), float(algo_flops), e0, e1))
+        prof.records.append(((cfg_id, PRECISIONS['f16x3']), float(algo_flops), e0, e1))
         if prof.meta is not None:
             prof.meta.append(dict(N=p.N, Hi=p.Hi, Wi=p.Wi, Ck=p.Ck, Nc=p.Nc, Ho=p.Ho, Wo=p.Wo, taps=[c.ntaps for c in classes], epi=epi, ksplit=int(ksplit),
-                                  in_stride=1, out_stride=out_stride, prec=3, v2=True))
+                                  in_stride=1, out_stride=out_stride, prec=3, v2=True, patch_rows=int(p.patch_rows)))
     return fused_act if act_bwd is not None else out
 
 
@@ -670,6 +671,7 @@ def conv_v2_s2adj(a: SplitImage, w: SplitImage, out, classes, epi=L.EPI_STORE, o
 
 V2_CONFIG = 5        # "tile configuration" id of the pre-split kernel in profiler records (eg3d_conv2d_igemm_config returns 0..4)
 UP2_CONFIG = 6       # ... of the fused-parity transposed-conv kernel (csrc/conv_v2_up.hip)
+V2H_CONFIG = 8       # ... of the pre-split kernel's half-height (4 x 32) patch instantiation
 V2_UP2 = os.environ.get('EG3D_V2_UP2', '1') != '0'
 UP2_MIN_TILES = int(os.environ.get('EG3D_UP2_MIN_TILES', '256'))      # workgroups (512 threads, 115 KB of LDS: one per CU) below which the layer stays on the loader-split kernel
 UP2_MIN_CK = int(os.environ.get('EG3D_UP2_MIN_CK', '64'))

@@ -409,18 +409,18 @@ def main():
         dom = summ.get(dom_id)
         if dom and dom['ms'] > 0:
             ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-            is_v2 = dom_id[0] == H.V2_CONFIG
+            is_v2 = dom_id[0] in (H.V2_CONFIG, H.V2H_CONFIG)
+            v2_rpw = 4 if dom_id[0] == H.V2_CONFIG else 2          # patch rows per wave: template argument of the instantiation
             dom_prec = {v: k for k, v in H.PRECISIONS.items()}[dom_id[1]]          # arithmetic of the dominant kernel's launches
             nprod = PRODUCTS[dom_prec]
             peak = FP32_MFMA_PEAK_TFLOPS if dom_prec == 'f32' else BF16_MFMA_PEAK_TFLOPS / nprod
             if is_v2:
-                kern, tkey = 'conv_v2_kernel<9,true,false> (pre-split fp16 pieces, LDS-DMA staged halo; fp32 in/out, 3 x v_mfma_f32_32x32x16_f16 per fp32 product)', 'conv_v2_kernel<9,true,false>'
+                tkey = 'conv_v2_kernel<9,true,false,%d>' % v2_rpw
+                kern = tkey + ' (pre-split fp16 pieces, LDS-DMA staged halo; fp32 in/out, 3 x v_mfma_f32_32x32x16_f16 per fp32 product)'
             else:
                 kern = 'conv_igemm_kernel<%s,%d,*> (fp32 in/out, %d x MFMA per fp32 product)' % (H.TILE_NAMES.get(dom_id[0], '?'), H.PRECISIONS[dom_prec], nprod)
                 tkey = 'conv_igemm_kernel<%s>' % H.TILE_NAMES.get(dom_id[0], '?')
-            tr = (traffic.get(tkey) or traffic.get(tkey.replace(',false>', '>'))
-                  or next((v for k, v in sorted(traffic.items()) if k.startswith(tkey[:-1] + ',')), None)   # trailing template args (rows per wave)
-                  or traffic.get(tkey.replace(',true>', '>'), {}))
+            tr = traffic.get(tkey) or traffic.get(tkey.replace(',true>', '>'), {})
             per_launch_ref = tr.get('gflop_per_launch')
             tbytes = tr.get('bytes_per_launch')
             if tbytes is not None and per_launch_ref:           # the PMC pass ran the same kernel: scale by the work of this run's launches
@@ -445,7 +445,7 @@ def main():
             alg = (34.1e6 + 34.1e6 + 25.17e6) * M
             t = (sp['render_fwd']['ms'] + sp['render_bwd']['ms']) / args.steps * 1e-3
             rt = traffic.get('renderer', {})
-            roof_r = dict(bound='hbm', kernel='volume renderer: coarse_pos + decode_rows x2 + render<2>,<3> (forward); render<1> + decode_rows<true> + scatter_* (backward)',
+            roof_r = dict(bound='hbm', kernel='volume renderer: coarse_pos + (gather_rows + decode_rows) x2 + render<2>,<3> (forward); render<1> + decode_rows<true> + scatter_* (backward)',
                           achieved=round(alg / t / 1e9, 1), peak=8000.0, unit='GB/s', frac=round(alg / t / 1e9 / 8000.0, 4),
                           algorithmic_bytes_per_step=alg, fwd_ms=round(sp['render_fwd']['ms'] / args.steps, 3), bwd_ms=round(sp['render_bwd']['ms'] / args.steps, 3),
                           traffic=rt.get('bytes_per_step'), traffic_source=rt.get('source'), timing=roofline_pass)

@@ -114,7 +114,7 @@ if pf and pw:
     dk = table_key(dom_short)
     if dk in table and roof.get('gflop_per_launch'):
         table[dk]['gflop_per_launch'] = roof['gflop_per_launch']
-    ren = [k for k in agg if re.match(r'(render_kernel|decode_rows_kernel|coarse_pos_kernel|scatter_)', k)]
+    ren = [k for k in agg if re.match(r'(render_kernel|decode_rows_kernel|gather_rows_kernel|coarse_pos_kernel|scatter_)', k)]
     rb = sum(agg[k][0] * per_launch[k][3] for k in ren if k in per_launch)
     table['renderer'] = dict(bytes_per_step=rb, kernels=sorted(ren), source=src)
     o.append(f'\nRenderer kernels of one step ({", ".join("`%s`" % k for k in sorted(ren))}): **{rb/1e6:.1f} MB** of HBM traffic per step.\n')
