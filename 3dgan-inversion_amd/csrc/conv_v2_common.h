@@ -121,11 +121,7 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
     float amax = 0.f;
     // the patch's noise values (forward: this layer's; EPI_BWD_ACT: the producing layer's), one per cell, read from LDS by the 32 lanes that
     // hold a cell's channels
-#ifdef EG3D_DBG_DYNNZ
-    float* nzl = stage + 64 * LDS_N;
-#else
     __shared__ float nzl[2 * 4 * 32];
-#endif
     {
         const float* nsrc = (epi == EG3D_EPI_FWD && p.noise != nullptr) ? p.noise + (int64_t)n * p.noise_nstride
                           : ((act_on && ab.noise != nullptr) ? ab.noise + (int64_t)n * ab.noise_nstride : nullptr);
@@ -146,11 +142,7 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
                 stage[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDS_N + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r] * out_mul;
         __syncthreads();
         // 64 rows x 32 float4 units = 2048 units, 8 per thread, in two groups of 4 (loads first, then arithmetic + stores)
-#ifdef EG3D_DBG_UNROLL1
-#pragma unroll 1
-#else
 #pragma unroll
-#endif
         for (int ug = 0; ug < 8; ug += 4) {
             int offs[4], pixl[4];
             float4 va[4], sa[4], sb[4];
@@ -169,9 +161,6 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
                 nz[u] = nzl[((row >> 5) * RPW + i) * 32 + (row & 31)];
                 if (ok && (do_ds || act_on)) sb[u] = *reinterpret_cast<const float4*>(p.xin + offs[u]);
             }
-#ifdef EG3D_DBG_WAIT
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (offs[u] < 0) continue;

@@ -42,6 +42,7 @@ struct DecodeArgs {
     float* df_rows;             // [M,FC] dL/d(mean feature) / 3        (or null)
     float4* gc_rows;            // [M] (dL/d position, depth)            (or null)
     float* dump_dpre; float* dump_h; float* dump_dout; float* dump_feat;   // decoder-weight gradient operands (or null)
+    float* df_amax;             // backward: max|df_rows| over the launch (one atomic per block), or null
     float* feat;                // FEAT instantiations: [rows, FC] interpolated features in OUTPUT row order (written by gather_rows_kernel)
 };
 
@@ -263,6 +264,7 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
 
+    float df_max = 0.f;
     for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
         const int64_t row = tile * 32 + li;
         float4 ps = make_float4(NAN, 0, 0, 0);
@@ -435,6 +437,8 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
             for (int r = 0; r < 16; ++r) df[r] = df[r] * isc;
         }
         if (a.df_rows && valid) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) df_max = fmaxf(df_max, fabsf(df[r]));
             float* o = a.df_rows + row * FC + 4 * h;
 #pragma unroll
             for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(o + 8 * g) = make_float4(df[4 * g], df[4 * g + 1], df[4 * g + 2], df[4 * g + 3]);
@@ -479,6 +483,13 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
             }
             gx += __shfl_xor(gx, 32); gy += __shfl_xor(gy, 32); gz += __shfl_xor(gz, 32);     // the two feature halves of the sample
             if (h == 0 && row < a.M) a.gc_rows[row] = valid ? make_float4(gx, gy, gz, ps.w) : make_float4(0, 0, 0, 0);
+        }
+    }
+    if constexpr (BWD) {
+        if (a.df_amax != nullptr) {       // non-negative floats order like their bit patterns
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) df_max = fmaxf(df_max, __shfl_xor(df_max, o));
+            if (lane == 0 && df_max < 3.0e38f) atomicMax(reinterpret_cast<unsigned*>(a.df_amax), __float_as_uint(df_max));
         }
     }
 }
@@ -528,5 +539,6 @@ int eg3d_decode_rows_bwd(const eg3d_render_bwd_params& bp, const float* pos, int
     a.dump_dout = bp.dump_dout ? bp.dump_dout + row0 * (1 + CO) : nullptr;
     a.dump_feat = bp.dump_feat ? bp.dump_feat + row0 * FC : nullptr;
     a.feat = p.feat_rows ? p.feat_rows + row0 * FC : nullptr;
+    a.df_amax = bp.df_amax;
     return launch_decode(a, true, (hipStream_t)stream);
 }

@@ -510,6 +510,7 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
     }
     __syncthreads();
 
+    if (bp.df_amax != nullptr && blockIdx.x == 0 && tid == 0) *bp.df_amax = 0.f;      // the sample-level kernel (next launch) accumulates max|df_rows| here
     // position rows (x, y, z, depth) of this thread's two samples: input of the sample-level kernel and of the plane scatter
     if (live && s < D) {
         float4* pr = reinterpret_cast<float4*>(bp.df_pos);
@@ -1181,6 +1182,123 @@ __global__ void __launch_bounds__(ACCP_WAVES * 64) scatter_accum16p_kernel(const
     }
 }
 
+// ---- the same accumulation on the 16-bit matrix cores (opt-in: eg3d_render_bwd_params.df_amax; EG3D_SCATTER_F16=1 in the host package) -------
+// Written on the assumption that scatter_accum16p_kernel is bound by the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: two pairs per 64-cycle
+// instruction).  It is not, or not only: 128 -> 112 us.  With the gradient rows coming from eight cached rows this kernel takes 93 us, with
+// no row loads at all 77 us, without its MFMAs 116 us -- the random 128-byte row reads (0.6 GB per launch) and the per-pair instruction
+// stream share the time.  16 us do not pay for a second arithmetic in the renderer's backward, so the exact fp32 form stays the default.
+// In the arithmetic of the convolutions -- every fp32 product as three exact fp16 products of two-piece
+// operands, fp32 accumulation -- v_mfma_f32_32x32x16_f16 takes SIXTEEN pairs per 32-cycle instruction: 6 instead of 32 pipe cycles per pair.
+//   B (gradient rows):  g S = h + l 2^-11,  h = rtz16, l = rne16;  S = the power of two that brings max|df_rows| of the whole launch to
+//                       [2^13, 2^14) (eg3d_render_bwd_params.df_amax, one atomic per block of the sample-level kernel) -- the per-tensor
+//                       scaling of the convolutions' operand images; values 2^-27 below the tensor's maximum lose relative precision
+//   A (coefficients):   1024 w = hw + lw, plus the plane hw 2^-11;   w S 1024 g = hw h + lw h + (hw 2^-11) l
+// A group = 16 pairs = one MFMA per product: the 64 non-zero coefficients are written by lane = (pair, corner) into three otherwise-zero
+// [32 rows][16 pairs] fp16 images (one ds_read_b128 per lane and plane), the lane's eight gradient values of the group -- pairs
+// 8 (lane >> 5) + j -- are split in registers.
+typedef _Float16 sc_f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 sc_fp16x2 __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(ACCP_WAVES * 64) scatter_accum16h_kernel(const float* __restrict__ df, int64_t S, const int* __restrict__ offsets,
+                                                                            const float4* __restrict__ recs, float* __restrict__ d_planes, int Hp, int Wp,
+                                                                            int ldp, int ntx, int nty, const float* __restrict__ df_amax) {
+    __shared__ __attribute__((aligned(16))) _Float16 aimg[ACCP_WAVES * 3 * 512];        // per wave: three [32][16] coefficient planes
+    __shared__ __attribute__((aligned(16))) float4 recm[ACCP_WAVES * 128];              // per wave: the records of two super-steps
+    __shared__ __attribute__((aligned(16))) int keym[ACCP_WAVES * 128];                 // ... and their row ids
+    const int tid = threadIdx.x;
+    const int ntile = ntx * nty, nlist = 3 * ntile * TROWS;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 31, kk = lane >> 5;
+    _Float16* ai = aimg + wave * (3 * 512);
+    float4* recl = recm + wave * 128;
+    int* keyl = keym + wave * 128;
+    for (int i = lane; i < 3 * 512; i += 64) ai[i] = (_Float16)0.f;
+    const int pj = lane >> 2, half = (lane >> 1) & 1, dx = lane & 1;          // this lane's (pair, corner) of a 16-pair group
+    const int a_slot = half * 16 * 16 + pj;                                  // + 16 * column   (element [row = half * 16 + column][pair])
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(df), 0, (int)(S * FC * 4), 0x00020000);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // operand scale: max|g| -> [2^13, 2^14) (1 for a zero / non-finite maximum)
+    float sc = 1.f;
+    {
+        const float am = *df_amax;
+        if (am > 0.f && am < 3.0e38f) {
+            int e = (int)((__float_as_uint(am) >> 23) & 0xff) - 127;
+            e = max(-100, min(100, e));
+            sc = __uint_as_float((unsigned)(127 + 13 - e) << 23);
+        }
+    }
+    const float out_mul = 1.f / (sc * 1024.f);                 // exact: powers of two
+    const int nwave = gridDim.x * ACCP_WAVES;
+    for (int li = blockIdx.x * ACCP_WAVES + wave; li < nlist; li += nwave) {
+        const int beg = __builtin_amdgcn_readfirstlane(offsets[li]), end = __builtin_amdgcn_readfirstlane(offsets[li + 1]);
+        if (beg >= end) continue;
+        acc16_t acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        auto load_recs = [&](int p0) { return p0 + lane < end ? recs[p0 + lane] : zero4; };      // an all-zero record has coefficient 0 everywhere
+        auto stash = [&](const float4& R, int par) { recl[par * 64 + lane] = R; keyl[par * 64 + lane] = __float_as_int(R.x); };
+        // the lane's gradient value of pair 8 kk + j of group gq of the super-step whose records sit in parity `par`
+        auto issue_rows = [&](unsigned (&gr)[32], int gq, int par) {
+            const int* kp = keyl + par * 64 + gq * 16 + kk * 8;
+            const int4 k0 = *reinterpret_cast<const int4*>(kp), k1 = *reinterpret_cast<const int4*>(kp + 4);
+            const int nk[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gr[gq * 8 + j] = __builtin_amdgcn_raw_buffer_load_b32(drs, (nk[j] & 0x7ffffff) * (FC * 4) + c * 4, 0, 0);
+        };
+        unsigned g[32];
+        {
+            const float4 R0 = load_recs(beg), R1 = load_recs(beg + 64);
+            stash(R0, 0); stash(R1, 1);
+        }
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) issue_rows(g, gq, 0);
+        int par = 0;
+        for (int p0 = beg; p0 < end; p0 += 64, par ^= 1) {
+            const float4 Rnn = load_recs(p0 + 128);
+            const int npair = min(64, end - p0);
+            const bool more = p0 + 64 < end;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                if (gq * 16 >= npair && !more) break;
+                // coefficients of the group's 16 pairs x 4 corners
+                const float4 R = recl[par * 64 + gq * 16 + pj];
+                const int col = (int)((unsigned)__float_as_int(R.x) >> 27) - 1 + dx;     // -1: the corner left of the tile (no owner here)
+                const float w = (dx ? R.y : 1.f - R.y) * (half ? R.z : 1.f - R.z) * 1024.f;
+                const sc_fp16x2 hw2 = __builtin_amdgcn_cvt_pkrtz(w, 0.f);
+                const _Float16 hw = (_Float16)hw2[0], lw = (_Float16)(w - (float)hw2[0]), gw = hw * (_Float16)0.00048828125f;
+                if (col >= 0) { ai[a_slot + col * 16] = hw; ai[512 + a_slot + col * 16] = lw; ai[1024 + a_slot + col * 16] = gw; }
+                // gradient values: split, then the registers are free for the next super-step's rows
+                sc_f16x8 bh, bl;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float a0 = __uint_as_float(g[gq * 8 + 2 * q]) * sc, a1 = __uint_as_float(g[gq * 8 + 2 * q + 1]) * sc;
+                    const sc_fp16x2 hh = __builtin_amdgcn_cvt_pkrtz(a0, a1);
+                    bh[2 * q] = (_Float16)hh[0]; bh[2 * q + 1] = (_Float16)hh[1];
+                    bl[2 * q] = (_Float16)__builtin_amdgcn_fmed3f((a0 - (float)hh[0]) * 2048.f, -65504.f, 65504.f);
+                    bl[2 * q + 1] = (_Float16)__builtin_amdgcn_fmed3f((a1 - (float)hh[1]) * 2048.f, -65504.f, 65504.f);
+                }
+                issue_rows(g, gq, par ^ 1);
+                const sc_f16x8* ap = reinterpret_cast<const sc_f16x8*>(ai) + (lane & 31) * 2 + kk;       // row (lane & 31), pairs 8 kk .. 8 kk + 7
+                const sc_f16x8 ah = ap[0], al = ap[64], ag = ap[128];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ag, bl, acc, 0, 0, 0);                        // small terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+                if (col >= 0) { ai[a_slot + col * 16] = (_Float16)0.f; ai[512 + a_slot + col * 16] = (_Float16)0.f; ai[1024 + a_slot + col * 16] = (_Float16)0.f; }
+            }
+            stash(Rnn, par);                     // super-step p0 + 128 reuses the parity that just finished
+        }
+        // accumulator element r of a lane = (half, column) (m >> 4, m & 15), m = (r&3) + 8 (r>>2) + 4 kk, channel c
+        const int lrow = li % TROWS, t = (li / TROWS) % ntile, pl = li / (TROWS * ntile);
+        const int yy0 = (t / ntx) * TS + lrow - 1, tx0 = (t % ntx) * TS;
+        float* base = d_planes + pl * FC + c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const int yy = yy0 + (m >> 4), xx = tx0 + (m & 15);
+            const float v = acc[r] * out_mul;
+            if (yy >= 0 && yy < Hp && xx < Wp && v != 0.f) unsafeAtomicAdd(base + ((int64_t)yy * Wp + xx) * ldp, v);
+        }
+    }
+}
+
 __global__ void render_finalize_kernel(float* depth, const float* mm, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1392,7 +1510,7 @@ extern "C" int64_t eg3d_triplane_scatter_workspace_ints(int64_t S, int N, int Hp
 }
 
 extern "C" int eg3d_triplane_scatter(const float* df_rows, const float* df_pos, int64_t S, int64_t rows_per_image, float* d_planes, int N, int Hp,
-                                     int Wp, int ldp, float box_warp, int32_t* workspace, int ray_w, int rows_per_ray, void* stream) {
+                                     int Wp, int ldp, float box_warp, int32_t* workspace, int ray_w, int rows_per_ray, const float* df_amax, void* stream) {
     if (!df_rows || !df_pos || !d_planes || !workspace || S <= 0 || N <= 0 || rows_per_image <= 0) return EG3D_ERR_INVALID;
     if (ldp < 3 * FC || 3 * S > INT32_MAX / 4) return EG3D_ERR_UNSUPPORTED;
     const int ntx = (Wp + TS - 1) / TS, nty = (Hp + TS - 1) / TS;
@@ -1439,7 +1557,16 @@ extern "C" int eg3d_triplane_scatter(const float* df_rows, const float* df_pos, 
             hipLaunchKernelGGL(scatter_scan16_kernel, dim3(1), dim3(1024), 0, st, counts16, offsets16, nb16_img);
             bin_pass(1, pos_n);
             static const int split = [] { const char* e = getenv("EG3D_SCATTER_SPLIT"); return e ? atoi(e) : 1; }();
-            hipLaunchKernelGGL(scatter_accum16p_kernel, dim3(1024), dim3(ACCP_WAVES * 64), 0, st, df_rows + (int64_t)n * Si * FC, Si, offsets16, recs,
+            // one block of four waves per four lists: the hardware's block dispatch does the load balancing (lists differ 0 .. 990 pairs); with
+            // 1024 persistent blocks taking lists w, w + 4096, ... the launch lasted as long as its unluckiest wave (fp32: 142 -> 128 us)
+            static const int accb_env = [] { const char* e = getenv("EG3D_SCATTER_BLOCKS"); return e ? atoi(e) : 0; }();
+            const int accb = accb_env > 0 ? accb_env : (nb16_img + ACCP_WAVES - 1) / ACCP_WAVES;
+            if (df_amax != nullptr) {
+                hipLaunchKernelGGL(scatter_accum16h_kernel, dim3(accb), dim3(ACCP_WAVES * 64), 0, st, df_rows + (int64_t)n * Si * FC, Si, offsets16, recs,
+                                   d_planes + (int64_t)n * Hp * Wp * ldp, Hp, Wp, ldp, ntx, nty, df_amax);
+                continue;
+            }
+            hipLaunchKernelGGL(scatter_accum16p_kernel, dim3(accb), dim3(ACCP_WAVES * 64), 0, st, df_rows + (int64_t)n * Si * FC, Si, offsets16, recs,
                                d_planes + (int64_t)n * Hp * Wp * ldp, Hp, Wp, ldp, ntx, nty, split);
         }
         EG3D_LAUNCH_CHECK();

@@ -95,7 +95,7 @@ class RenderBwdParams(C.Structure):
     _fields_ = [('fwd', RenderParams), ('depth_out', C.c_void_p), ('d_rgb', C.c_void_p), ('d_depth', C.c_void_p),
                 ('d_wsum', C.c_void_p), ('df_rows', C.c_void_p), ('df_pos', C.c_void_p), ('ag_rows', C.c_void_p), ('gc_rows', C.c_void_p), ('d_origins', C.c_void_p),
                 ('d_dirs', C.c_void_p),
-                ('dump_dpre', C.c_void_p), ('dump_h', C.c_void_p), ('dump_dout', C.c_void_p), ('dump_feat', C.c_void_p)]
+                ('dump_dpre', C.c_void_p), ('dump_h', C.c_void_p), ('dump_dout', C.c_void_p), ('dump_feat', C.c_void_p), ('df_amax', C.c_void_p)]
 
 
 class RenderSizes(C.Structure):
@@ -208,7 +208,7 @@ _SIGS = {
     'eg3d_render_query_sizes': (C.c_int, [C.c_void_p, C.c_void_p]),
     'eg3d_triplane_scatter_workspace_ints': (C.c_int64, [C.c_int64, C.c_int, C.c_int, C.c_int]),
     'eg3d_triplane_scatter': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
-                                        C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+                                        C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'eg3d_sample_decode': (C.c_int, [C.POINTER(RenderParams), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 

@@ -977,6 +977,9 @@ def ray_gen_bwd(c2w, K, g_o, g_d, res, want_K=True):
     return d_c2w, d_K
 
 
+SCATTER_F16 = os.environ.get('EG3D_SCATTER_F16', '0') != '0'     # tri-plane gradient accumulation with three fp16 products per fp32 product: 128 -> 112 us, off (exact fp32 products)
+
+
 def make_render_params(planes, origins, dirs, u1, u2, opts, w0, b0, w1t, b1, rgb, depth, wsum, minmax, fine, ray_limits=None, save=None, ray_tile_width=None, pos_rows=None,
                        feat_rows=None):
     """planes: channels_last [N, 3*C, Hp, Wp]; decoder weights with gains folded (w1t transposed [H, 1+Cout])."""
@@ -1059,13 +1062,18 @@ def render_bwd(p, d_rgb, d_depth, d_wsum, d_planes, d_origins, d_dirs, dumps=Non
         bp.dump_dpre, bp.dump_h, bp.dump_dout, bp.dump_feat = [t.data_ptr() for t in dumps]
         if p.feat_rows and bp.dump_feat == p.feat_rows:         # the caller uses the saved feature rows as that operand: nothing to dump
             bp.dump_feat = None
+    amax = None
+    if d_planes is not None and SCATTER_F16:        # plane-gradient accumulation on the 16-bit matrix cores: needs max|df_rows| (written by the call)
+        amax = torch.empty(1, dtype=torch.float32, device=dev)
+        bp.df_amax = amax.data_ptr()
     L.check(L.lib().eg3d_render_bwd(C.byref(bp), L.stream_ptr()), 'render_bwd')
     if d_planes is not None:
         nints = L.lib().eg3d_triplane_scatter_workspace_ints(S, p.N, p.Hp, p.Wp)
         ws = torch.empty(nints, dtype=torch.int32, device=d_planes.device)
         rw = math.isqrt(p.R)            # rays are generated row by row over a square image (ray_sampler.py:41-50): a hint for the binning order only
         L.check(L.lib().eg3d_triplane_scatter(L.ptr(rows), L.ptr(pos), S, p.R * 2 * D, L.ptr(d_planes), p.N, p.Hp, p.Wp, p.ldp,
-                                              p.box_warp, L.ptr(ws), rw if rw * rw == p.R else 0, 2 * D, L.stream_ptr()), 'triplane_scatter')
+                                              p.box_warp, L.ptr(ws), rw if rw * rw == p.R else 0, 2 * D, L.ptr(amax) if amax is not None else None,
+                                              L.stream_ptr()), 'triplane_scatter')
 
 
 def sample_decode(p, coords, M):

@@ -571,6 +571,9 @@ typedef struct eg3d_render_bwd_params {
     float* dump_h;             /* [S,64]  */
     float* dump_dout;          /* [S,33]  */
     float* dump_feat;          /* [S,32]  */
+    float* df_amax;            /* optional [1]: max|df_rows| of this call (reset by the call itself).  Hand it to eg3d_triplane_scatter and the
+                                * accumulation runs on the 16-bit matrix cores (three products of two-piece operands, the arithmetic of the
+                                * convolutions, operands scaled by this maximum); null = exact fp32 products on the fp32 matrix cores */
 } eg3d_render_bwd_params;
 
 int eg3d_render_bwd(const eg3d_render_bwd_params* p, void* stream);
@@ -582,9 +585,10 @@ int eg3d_render_bwd(const eg3d_render_bwd_params* p, void* stream);
  * planes, renderer.py:64 under autograd).  rows_per_image = R*2*D.  workspace: eg3d_triplane_scatter_workspace_ints() int32. */
 int64_t eg3d_triplane_scatter_workspace_ints(int64_t S, int N, int Hp, int Wp);
 /* ray_w, rows_per_ray: optional hint (0, 0 = unknown) -- rays per image row and dumped rows per ray (2 D) of the row layout above; the
- * binning passes then walk the rows in bricks of 16 x 16 rays (fewer bins per block); the result does not depend on it. */
+ * binning passes then walk the rows in bricks of 16 x 16 rays (fewer bins per block); the result does not depend on it.
+ * df_amax: eg3d_render_bwd_params.df_amax of the call that produced df_rows, or null (see there). */
 int eg3d_triplane_scatter(const float* df_rows, const float* df_pos, int64_t S, int64_t rows_per_image, float* d_planes, int N,
-                          int Hp, int Wp, int ldp, float box_warp, int32_t* workspace, int ray_w, int rows_per_ray, void* stream);
+                          int Hp, int Wp, int ldp, float box_warp, int32_t* workspace, int ray_w, int rows_per_ray, const float* df_amax, void* stream);
 
 /* Decoder-only query (ImportanceRenderer.run_model, renderer.py:197-203; used for density grids):
  *   coords [N,M,3] -> rgb [N,M,Cout], sigma [N,M]. */
