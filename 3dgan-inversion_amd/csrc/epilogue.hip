@@ -319,11 +319,17 @@ static int epi_bwd_cap() {
 }
 // FIN: the incoming gradient is not read but formed on the fly as the finish of a split-K data gradient of the CONSUMER layer,
 // dout = fz * fs[n,c] (+ fadd), and that layer's style gradient fds[n,c] += sum_px fz * out rides along (eg3d_dgrad_finish_act).
-struct FinArgs { const float* z; const float* s; const float* addend; float* ds; const float* dy4; const float* wa4; };
+struct FinArgs { const float* z; const float* s; const float* addend; float* ds; const float* dy4; const float* wa4;
+                 // SPLIT: dz also (or only: dz null) leaves as the two-piece fp16 operand image of the data gradient that consumes it
+                 uint2* simg; const float* dy_amax; const float* add_amax; float* sp_scale; };
 // (dy4 / wa4, with z null: the consumer is a 1x1 layer with four (padded) outputs -- toRGB of the super-resolution head -- whose data gradient
 //  z[c] = sum_o dy[px][o] wa[c][o] is four multiply-adds per element: formed here instead of by a GEMM launch with a 4-deep contraction,
 //  eg3d_torgb_dgrad_act)
-template <bool PWL, bool FIN>
+// SPLIT (with FIN + dy4): the split pass that used to follow needs max|dz| before it can write a single piece.  A BOUND does as well -- the
+// pieces are floating point, a scale that is a few octaves too cautious costs range at the bottom, not precision: |dz| <= gain * (max|dy| *
+// max_{n,c}(sum_o |wa[c][o]|) |s[n,c]| |d[n,c]|) + max|addend| * max |d|) since |act'| <= 1.  Every block derives it from the same few
+// hundred numbers.  512^2 x 128: 85 + 52 us (this pass + split pass) -> 61 us, and no fp32 dz at all when nobody else reads it.
+template <bool PWL, bool FIN, bool SPLIT = false>
 __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const FinArgs fin, const float* __restrict__ dout, const float* __restrict__ outv, float* __restrict__ dz,
                                                            int H, int W, int C4, const float* __restrict__ d, const float* __restrict__ noise,
                                                            int64_t noise_nstride, const float* __restrict__ noise_strength,
@@ -347,6 +353,27 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const Fin
     float4 w40 = make_float4(0, 0, 0, 0), w41 = w40, w42 = w40, w43 = w40;
     if (FIN && active && fin.dy4) { w40 = ld4(fin.wa4 + (c + 0) * 4); w41 = ld4(fin.wa4 + (c + 1) * 4); w42 = ld4(fin.wa4 + (c + 2) * 4); w43 = ld4(fin.wa4 + (c + 3) * 4); }
     float accs = 0.f, amax = 0.f;
+    float sp_mul = 1.f;
+    if constexpr (SPLIT) {
+        float m1 = 0.f, m2 = 0.f;
+        for (int i = threadIdx.x; i < (int)gridDim.y * C; i += EPI_BWD_THREADS) {
+            const int cc = i % C;
+            const float4 wr = ld4(fin.wa4 + cc * 4);
+            const float dval = d ? fabsf(d[i]) : 1.f;
+            m1 = fmaxf(m1, (fabsf(wr.x) + fabsf(wr.y) + fabsf(wr.z) + fabsf(wr.w)) * (fin.s ? fabsf(fin.s[i]) : 1.f) * dval);
+            m2 = fmaxf(m2, dval);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { m1 = fmaxf(m1, __shfl_xor(m1, o)); m2 = fmaxf(m2, __shfl_xor(m2, o)); }
+        if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = m1; red[(threadIdx.x >> 6) * 2 + 1] = m2; }
+        __syncthreads();
+        m1 = 0.f; m2 = 0.f;
+        for (int w = 0; w < EPI_BWD_THREADS / 64; ++w) { m1 = fmaxf(m1, red[w * 2]); m2 = fmaxf(m2, red[w * 2 + 1]); }
+        __syncthreads();
+        const float bound = gain * (*fin.dy_amax * m1 + (fin.add_amax != nullptr ? *fin.add_amax * m2 : 0.f));
+        sp_mul = ue_range_mul(bound);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *fin.sp_scale = sp_mul;
+    }
     // lanes of one pixel are contiguous; groups of min(C4,64) lanes can be shuffle-reduced when C4 is a power of two
     const bool pow2 = (C4 & (C4 - 1)) == 0;
     const int grp = C4 < 64 ? C4 : 64;
@@ -356,19 +383,21 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const Fin
         // the HBM latency).
         constexpr int U = 4;
         const int stride = gridDim.x * ppb;
-        for (int pix0 = blockIdx.x * ppb + pl; pix0 < HW; pix0 += U * stride) {
+        // (the trip count is block-uniform -- `base` -- because the SPLIT form has barriers inside the loop)
+        for (int base = blockIdx.x * ppb; base < HW; base += U * stride) {
+            const int pix0 = base + pl;
             float4 g[U], o[U];
             float nraw[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int pix = pix0 + u * stride;
                 const bool ok = pix < HW;
-                const int64_t off = ((int64_t)n * HW + (ok ? pix : pix0)) * C + c;
+                const int64_t off = ((int64_t)n * HW + (ok ? pix : base)) * C + c;
                 o[u] = ld4(outv + off);
                 if (FIN) {
                     float4 zz;
                     if (fin.dy4) {
-                        const float4 g4 = ld4(fin.dy4 + ((int64_t)n * HW + (ok ? pix : pix0)) * 4);
+                        const float4 g4 = ld4(fin.dy4 + ((int64_t)n * HW + (ok ? pix : base)) * 4);
                         zz.x = fmaf(g4.w, w40.w, fmaf(g4.z, w40.z, fmaf(g4.y, w40.y, g4.x * w40.x)));
                         zz.y = fmaf(g4.w, w41.w, fmaf(g4.z, w41.z, fmaf(g4.y, w41.y, g4.x * w41.x)));
                         zz.z = fmaf(g4.w, w42.w, fmaf(g4.z, w42.z, fmaf(g4.y, w42.y, g4.x * w42.x)));
@@ -391,7 +420,29 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const Fin
                 bwd1<PWL>(g[u].x, o[u].x, act, alpha, gain, clamp, dy.x, pre.x); bwd1<PWL>(g[u].y, o[u].y, act, alpha, gain, clamp, dy.y, pre.y);
                 bwd1<PWL>(g[u].z, o[u].z, act, alpha, gain, clamp, dy.z, pre.z); bwd1<PWL>(g[u].w, o[u].w, act, alpha, gain, clamp, dy.w, pre.w);
                 const float4 zz = make_float4(dy.x * dv.x, dy.y * dv.y, dy.z * dv.z, dy.w * dv.w);
-                st4(dz + off, zz);
+                if constexpr (SPLIT) {
+                    // image [N][piece][C/8][HW][8 halves]: this thread's four channels are half an octet entry (8 bytes per piece); the block's
+                    // pixel lanes are consecutive pixels, so a plane receives runs of ppb x 16 bytes
+                    const float a0 = zz.x * sp_mul, a1 = zz.y * sp_mul, a2 = zz.z * sp_mul, a3 = zz.w * sp_mul;
+                    const ue_fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(a0, a1), h23 = __builtin_amdgcn_cvt_pkrtz(a2, a3);
+                    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                    const h2_t l01 = {(_Float16)__builtin_amdgcn_fmed3f((a0 - (float)h01[0]) * 2048.f, -65504.f, 65504.f),
+                                      (_Float16)__builtin_amdgcn_fmed3f((a1 - (float)h01[1]) * 2048.f, -65504.f, 65504.f)};
+                    const h2_t l23 = {(_Float16)__builtin_amdgcn_fmed3f((a2 - (float)h23[0]) * 2048.f, -65504.f, 65504.f),
+                                      (_Float16)__builtin_amdgcn_fmed3f((a3 - (float)h23[1]) * 2048.f, -65504.f, 65504.f)};
+                    uint2 hv, lv;
+                    __builtin_memcpy(&hv.x, &h01, 4); __builtin_memcpy(&hv.y, &h23, 4);
+                    __builtin_memcpy(&lv.x, &l01, 4); __builtin_memcpy(&lv.y, &l23, 4);
+                    // staged [u][plane = piece * C/8 + octet][pixel lane] (16-byte entries, one pad entry per plane): written straight to the image
+                    // a wave would touch 2 pixels x 16 bytes in each of 32 planes (2.6 TB/s); from LDS every thread stores one whole entry and 32
+                    // (16) consecutive lanes one 512 (256)-byte run of a plane
+                    char* sp = reinterpret_cast<char*>(red) + ((u * C4 + (c4 >> 1)) * (ppb + 1) + pl) * 16 + (c4 & 1) * 8;
+                    *reinterpret_cast<uint2*>(sp) = hv;
+                    *reinterpret_cast<uint2*>(sp + (C4 / 2) * (ppb + 1) * 16) = lv;
+                    if (dz != nullptr) st4(dz + off, zz);
+                } else {
+                    st4(dz + off, zz);
+                }
                 amax = fmaxf(amax, fmaxf(fmaxf(fabsf(zz.x), fabsf(zz.y)), fmaxf(fabsf(zz.z), fabsf(zz.w))));
                 accb.x += dy.x; accb.y += dy.y; accb.z += dy.z; accb.w += dy.w;
                 const float nz = nraw[u] * strength;
@@ -412,6 +463,21 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const Fin
                         accs += s * nraw[u];
                     }
                 }
+            }
+            if constexpr (SPLIT) {
+                __syncthreads();
+                // item = (plane, pixel lane): EPI_BWD_THREADS = C4 * ppb of them per u
+                const int plane = threadIdx.x / ppb, px = threadIdx.x - plane * ppb;
+                const int piece = plane / (C4 / 2), ko = plane - piece * (C4 / 2);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int pix = pix0 - pl + px + u * stride;
+                    if (pix < HW) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(red) + ((u * C4 + plane) * (ppb + 1) + px) * 16);
+                        reinterpret_cast<uint4*>(fin.simg)[((int64_t)(n * 2 + piece) * (C / 8) + ko) * HW + pix] = v;
+                    }
+                }
+                __syncthreads();
             }
         }
     }
@@ -783,10 +849,35 @@ extern "C" int eg3d_torgb_dgrad_act(const float* dy4, const float* wa4, const fl
     static std::atomic<uint64_t> attr_done{0};
     auto kern = epilogue_bwd_kernel<true, true>;
     if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)smem, attr_done)) return e;
-    const FinArgs fin = {nullptr, s, addend, ds, dy4, wa4};
+    const FinArgs fin = {nullptr, s, addend, ds, dy4, wa4, nullptr, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(kern, dim3(bx, N), dim3(EPI_BWD_THREADS), smem, (hipStream_t)stream, fin, nullptr, x, dz, H, W, C4, ab->d, ab->noise, ab->noise_nstride,
                        ab->noise_strength, ab->bias, ab->act, eg3d_act_pwl_slope(ab->act, ab->alpha), ab->gain, ab->clamp, ab->dbias, ab->dd, ab->dnoise,
                        ab->dnoise_nstride, ab->dstrength, dz_amax);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_torgb_dgrad_act_split(const float* dy4, const float* wa4, const float* x, const float* s, const float* addend, float* dz, float* ds, int N,
+                                          int H, int W, int C, const eg3d_act_bwd* ab, const float* dy_amax, const float* addend_amax, void* split_image,
+                                          float* split_scale_out, void* stream) {
+    if (!dy4 || !wa4 || !x || !ab || !dy_amax || !split_image || !split_scale_out || (addend && !addend_amax) || N <= 0 || H <= 0 || W <= 0 || C <= 0)
+        return EG3D_ERR_INVALID;
+    if (C % 8 || C / 4 > 256 || (reinterpret_cast<uintptr_t>(dy4) & 15) || (reinterpret_cast<uintptr_t>(wa4) & 15) || (reinterpret_cast<uintptr_t>(split_image) & 15))
+        return EG3D_ERR_UNSUPPORTED;
+    if (ab->act != EG3D_ACT_LINEAR && ab->act != EG3D_ACT_LRELU) return EG3D_ERR_UNSUPPORTED;
+    if ((ab->dd && !ab->d) || ((ab->noise || ab->dnoise || ab->dstrength) && !ab->noise_strength) || ((ab->dnoise || ab->dstrength) && !ab->noise)) return EG3D_ERR_INVALID;
+    if ((int64_t)N * C > (1 << 20)) return EG3D_ERR_TOO_LARGE;
+    const int C4 = C / 4, ppb = std::max(EPI_BWD_THREADS / C4, 1);
+    int bx = std::max(1, std::min(eg3d_cdiv((int64_t)H * W, ppb * 4), std::max(1, epi_bwd_cap() / N)));
+    if (EPI_BWD_THREADS % C4) return EG3D_ERR_UNSUPPORTED;                  // every thread takes part in the staging barriers
+    const size_t smem = std::max((size_t)(ppb * C4 * 12 + 4) * sizeof(float), (size_t)4 * C4 * (ppb + 1) * 16);      // reductions | staged pieces of 4 pixels per thread
+    static std::atomic<uint64_t> attr_done{0};
+    auto kern = epilogue_bwd_kernel<true, true, true>;
+    if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)smem, attr_done)) return e;
+    const FinArgs fin = {nullptr, s, addend, ds, dy4, wa4, reinterpret_cast<uint2*>(split_image), dy_amax, addend ? addend_amax : nullptr, split_scale_out};
+    hipLaunchKernelGGL(kern, dim3(bx, N), dim3(EPI_BWD_THREADS), smem, (hipStream_t)stream, fin, nullptr, x, dz, H, W, C4, ab->d, ab->noise, ab->noise_nstride,
+                       ab->noise_strength, ab->bias, ab->act, eg3d_act_pwl_slope(ab->act, ab->alpha), ab->gain, ab->clamp, ab->dbias, ab->dd, ab->dnoise,
+                       ab->dnoise_nstride, ab->dstrength, nullptr);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

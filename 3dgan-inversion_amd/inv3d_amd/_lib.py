@@ -165,6 +165,7 @@ _SIGS = {
     'eg3d_dgrad_finish': (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'eg3d_dgrad_finish_act': (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.POINTER(ActBwd), C.c_void_p, C.c_void_p]),
     'eg3d_torgb_dgrad_act': (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.POINTER(ActBwd), C.c_void_p, C.c_void_p]),
+    'eg3d_torgb_dgrad_act_split': (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.POINTER(ActBwd)] + [C.c_void_p] * 5),
     'eg3d_upfirdn2d_nhwc': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 13 + [C.c_float, C.c_int, C.c_int,
                                                                                              C.c_int, C.c_void_p]),
     'eg3d_weight_sqsum': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -188,13 +188,23 @@ def _auto_ksplit(classes, N, Nc, Ck):
 # this layer's activation backward in the same epilogue -- and hands back dz in place of dout.  This layer's backward recognises the
 # buffer and skips its own pass.
 FUSE_ACT_BWD = os.environ.get('EG3D_FUSE_ACT_BWD', '1') != '0'
+SPLIT_DZ = os.environ.get('EG3D_SPLIT_DZ', '1') != '0'         # ... and write dz as the data gradient's fp16 operand image where it can (torgb_dgrad_act_split)
+_DX_AMAX = {}                 # dx.data_ptr() -> device scalar max|dx| reported by the data-gradient kernel that wrote it (read once by a toRGB backward)
+_DZ_TOKEN = {}                # device -> 1-element tensor: expanded, it stands in for a dz that only exists as an operand image
+
+
+def _dz_token(shape, dev):
+    t = _DZ_TOKEN.get(dev)
+    if t is None:
+        t = _DZ_TOKEN[dev] = torch.zeros(1, device=dev)
+    return t.expand(shape)
 
 
 class _ActProducer:
     """`out_ptr` / `shape` identify the layer's output (the tensor itself is NOT held: it is an output of the autograd node that owns this
     record, and a node -> record -> output cycle breaks graph teardown); `node` is a weak reference to that node -- while it is alive its
     saved output is, so the address cannot have been recycled."""
-    __slots__ = ('out_ptr', 'shape', 'node', 'd', 'nz', 'nstride', 'noise_strength', 'b', 'gain', 'clamp', 'need', 'fused')
+    __slots__ = ('out_ptr', 'shape', 'node', 'd', 'nz', 'nstride', 'noise_strength', 'b', 'gain', 'clamp', 'need', 'fused', 'split_ok')
 
 
 _PRODUCER_BY_LAYER = {}       # id(layer cache) -> record (at most one per layer: replaced by the layer's next forward)
@@ -332,6 +342,12 @@ class ModConvLayerFn(torch.autograd.Function):
             rec.out_ptr, rec.shape, rec.node = out.data_ptr(), tuple(out.shape), weakref.ref(ctx)
             rec.d, rec.nz, rec.nstride, rec.noise_strength, rec.b, rec.gain, rec.clamp, rec.fused = d, nz, nstride, noise_strength, b, act_gain, clampv, None
             rec.need = (bool(ng[5]), bool(ng[2] or (ng[1] and want_wgrad)), bool(ng[3]), bool(ng[4]))
+            # this layer's backward will feed dz to the pre-split data-gradient kernel and to nothing else (frozen weights): a consumer that
+            # runs the activation backward may then hand dz over as that kernel's operand image instead of an fp32 tensor (SPLIT_DZ)
+            rec.split_ok = False
+            if SPLIT_DZ and up == 1 and not (ng[1] and want_wgrad) and prec in ('f16x3', 'f16x1') and H.USE_V2 and Co % 8 == 0 and (ng[0] or ng[2]):
+                cls_adj0 = H.classes_corr_adjoint(Hi, Wi, kh, kw, kh // 2)
+                rec.split_ok = bool(_auto_ksplit(cls_adj0, N, Ci, Co) == 1 and H.conv_v2_supported(Co, Ci, cls_adj0, N))
         if rec is not None:             # (a no-grad forward of the same layer -- the canonical view of the warping loss -- leaves a pending record alone)
             _set_producer(cache, rec)
         ctx.rec = rec                   # THIS forward's record: the backward below trusts only it (two live graphs of one layer cannot mix)
@@ -349,13 +365,16 @@ class ModConvLayerFn(torch.autograd.Function):
         up, act_gain, clampv, nstride, cache, want_wgrad, noise4d, d_given = ctx.cfg
         need_x, need_w, need_s, need_nz, need_ns, need_b = ctx.needs_input_grad[:6]
         need_w = need_w and want_wgrad
-        dout = H.to_cl(dout.float())
+        rec = ctx.rec
+        is_token = (rec is not None and rec.fused is not None and len(rec.fused) > 6 and rec.fused[0].data_ptr() == dout.data_ptr()
+                    and rec.fused[0].shape == dout.shape)          # dz exists only as an operand image (see _dz_token): nothing to make contiguous
+        if not is_token:
+            dout = H.to_cl(dout.float())
         N, Ci, Hi, Wi = x.shape
         Co, _, kh, kw = weight.shape
         Ho, Wo = Hi * up, Wi * up
         dev = x.device
         wf, wa, wsq = cache.get(weight)
-        rec = ctx.rec
         if rec is not None:
             if _PRODUCER_BY_LAYER.get(id(cache)) is rec:
                 del _PRODUCER_BY_LAYER[id(cache)]
@@ -377,8 +396,10 @@ class ModConvLayerFn(torch.autograd.Function):
         prec = ctx.prec
         ig_prec = 'f16x3' if prec == 'f16x1' else prec
         wap = cache.get_pieces(weight)[1] if (ig_prec == 'f16x3' and USE_PIECES and not weight.requires_grad) else None
+        dz_img = None
         if pre is not None:
-            _, dbias, dd, dnoise, dstrength, amax = pre
+            _, dbias, dd, dnoise, dstrength, amax = pre[:6]
+            dz_img = pre[6] if len(pre) > 6 else None
             ds = None if ks_adj is None else H.zeros((N, Ci), dev)
         else:
             dbias, dd, dnoise, dstrength, ds, amax = _zeros_views(
@@ -420,11 +441,16 @@ class ModConvLayerFn(torch.autograd.Function):
             fkw = dict(act_bwd=spec, out_amax=pacc[4]) if prod is not None else {}
             ks2 = H.conv_v2_ksplit(Co, Ci, cls_adj, N) if (up == 1 and prec in ('f16x3', 'f16x1') and amax is not None) else 0
             if gimg is not None:
+                if not fkw and SPLIT_DZ:          # dx goes on to a toRGB node as its pass-through gradient: that pass wants max|dx| (torgb_dgrad_act_split)
+                    dx_amax = H.zeros((1,), dev)
+                    fkw = dict(out_amax=dx_amax)
+                    _DX_AMAX[dx.data_ptr()] = dx_amax
                 did = H.conv_v2_s2adj(gimg, cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, algo_flops=aflops,
                                       products=1 if prec == 'f16x1' else 3, **fkw)
             elif H.USE_V2 and up == 1 and ks == 1 and prec in ('f16x3', 'f16x1') and H.conv_v2_supported(Co, Ci, cls_adj, N):
-                did = H.conv_v2(H.split_activation(g, amax), cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds,
-                                algo_flops=aflops, products=1 if prec == 'f16x1' else 3, **fkw)
+                did = H.conv_v2(dz_img if dz_img is not None else H.split_activation(g, amax), cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD,
+                                out_scale=styles, xin=x, ds=ds, algo_flops=aflops, products=1 if prec == 'f16x1' else 3, **fkw)
+                dz_img = None
             elif ks2:                              # under-filled 3x3 grid: split-K launch of the pre-split kernel, then the finishing pass
                 z = H.zeros_cl(N, Ci, Hi, Wi, dev)
                 H.conv_v2(H.split_activation(g, amax), cache.get_split(weight)[1], z, cls_adj, epi=L.EPI_ATOMIC, ksplit=ks2, algo_flops=aflops,
@@ -450,6 +476,9 @@ class ModConvLayerFn(torch.autograd.Function):
                     H.dgrad_finish(z, x, styles, dx, ds=ds)
             if prod is not None and did is True:
                 prod.fused = (dx,) + tuple(pacc)
+        if dz_img is not None or (is_token and need_w):
+            raise RuntimeError('ModConvLayerFn.backward: dz was handed over as an operand image but this backward needs the fp32 tensor '
+                               '(set EG3D_SPLIT_DZ=0 and report the configuration)')
         # with d from the style bank, dd is returned and its d styles part handled there; the d weight part of it is in weight_grad_finish below
         if dd is not None and need_s and not d_given:
             if ds is None:
@@ -628,8 +657,9 @@ class ToRGBFn(torch.autograd.Function):
         if clampv >= 0 or need_b:
             dbias_p = H.zeros((Cp,), dev) if need_b else None
             dy = H.empty_cl(N, Cp, Hh, Ww, dev)
-            if need_w and H.modconv_precision() == 'f16x3':
+            if (need_w and H.modconv_precision() == 'f16x3') or (SPLIT_DZ and Cp == 4):
                 dy_amax = H.zeros((1,), dev)          # max|dy| from the same pass: the weight gradient can then run in the two-piece fp16 arithmetic
+                                                      # (and the fused split of the producing layer's dz takes its range bound from it)
             H.epilogue_bwd(dout, y if y is not None else dout, dy, act='linear', gain=1.0, clamp=clampv, dbias=dbias_p, dz_amax=dy_amax)
             dbias = dbias_p[:Co] if need_b else None
         dx = ds = None
@@ -643,8 +673,17 @@ class ToRGBFn(torch.autograd.Function):
             if prod is not None and Cp == 4 and Ci % 4 == 0 and Ci <= 1024 and TORGB4_ELEMENTWISE:
                 # four outputs (the SR head's toRGB): the data gradient is four multiply-adds per element -- one element-wise pass with the
                 # producing layer's activation backward instead of a GEMM launch with a 4-deep contraction (105 -> 60 us at 512^2 x 128)
-                H.torgb_dgrad_act(dy, wa_p, x, styles, dx, spec, ds=ds, addend=add, dz_amax=pacc[4])
-                did = True
+                add_amax = _DX_AMAX.pop(add.data_ptr(), None) if add is not None else None
+                if getattr(prod, 'split_ok', False) and dy_amax is not None and (add is None or add_amax is not None) and Ci % 8 == 0:
+                    # the producing layer's backward only feeds dz to the pre-split data gradient: write its operand image here (no split pass,
+                    # no fp32 dz -- a stride-0 token stands in for the gradient tensor autograd passes on)
+                    simg = H.torgb_dgrad_act_split(dy, wa_p, x, styles, spec, dy_amax, ds=ds, addend=add, addend_amax=add_amax)
+                    dx = _dz_token(x.shape, dev)
+                    prod.fused = (dx,) + tuple(pacc) + (simg,)
+                    did = None
+                else:
+                    H.torgb_dgrad_act(dy, wa_p, x, styles, dx, spec, ds=ds, addend=add, dz_amax=pacc[4])
+                    did = True
             else:
                 did = H.conv_igemm(dy, wa_p, Cp, Ci, dx, H.classes_corr_adjoint(Hh, Ww, 1, 1, 0), epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, addend=add,
                                    **fkw)

@@ -837,6 +837,20 @@ def torgb_dgrad_act(dy4, wa4, x, s, dz, act_bwd, ds=None, addend=None, dz_amax=N
     return dz
 
 
+def torgb_dgrad_act_split(dy4, wa4, x, s, act_bwd, dy_amax, ds=None, addend=None, addend_amax=None, dz=None):
+    """eg3d_torgb_dgrad_act_split: torgb_dgrad_act whose dz leaves as the SplitImage the consuming data gradient reads (no split pass, and no
+    fp32 dz unless `dz` is given).  dy_amax / addend_amax: device scalars max|dy4| / max|addend|."""
+    n, c, h, w = x.shape
+    assert is_cl(dy4) and dy4.shape[1] == 4 and tuple(wa4.shape) == (c, 4) and wa4.is_contiguous() and c % 8 == 0
+    ab = L.ActBwd()
+    act_bwd.fill(ab)
+    img = torch.empty((n * h * w * c * 2,), dtype=torch.float16, device=x.device)
+    scale = torch.empty((1,), dtype=torch.float32, device=x.device)
+    L.check(L.lib().eg3d_torgb_dgrad_act_split(L.ptr(dy4), L.ptr(wa4), L.ptr(x), L.ptr(s), L.ptr(addend), L.ptr(dz), L.ptr(ds), n, h, w, c, C.byref(ab),
+                                               L.ptr(dy_amax), L.ptr(addend_amax), L.ptr(img), L.ptr(scale), L.stream_ptr()), 'torgb_dgrad_act_split')
+    return SplitImage(img, scale, (n, c, h, w))
+
+
 def rows_gram(a, b):
     """(a^T b [Ka,Kb], column sums of a [Ka]) for row matrices a [S,Ka], b [S,Kb] with Ka, Kb <= 64 (eg3d_rows_gram)."""
     assert a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0] and a.is_contiguous() and b.is_contiguous()

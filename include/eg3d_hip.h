@@ -413,6 +413,13 @@ int eg3d_dgrad_finish_act(const float* z, const float* x, const float* s, const 
  * then dz / dbias / dd / dnoise / dstrength / max|dz| exactly as eg3d_dgrad_finish_act.  dy4 [N,H,W,4], wa4 [C,4], x / addend / dz [N,H,W,C]. */
 int eg3d_torgb_dgrad_act(const float* dy4, const float* wa4, const float* x, const float* s, const float* addend, float* dz, float* ds, int N, int H,
                          int W, int C, const eg3d_act_bwd* act_bwd, float* dz_amax, void* stream);
+/* The same pass writing dz as the two-piece fp16 operand image of the data gradient that consumes it (layout and scale of
+ * eg3d_split_activation; replaces that pass): the range comes from a bound formed inside the kernel from dy_amax = max|dy4| and
+ * addend_amax = max|addend| (device scalars written by the producers of those tensors; addend_amax is required with addend).  dz may be
+ * null when nothing else reads the fp32 gradient.  C % 8 == 0. */
+int eg3d_torgb_dgrad_act_split(const float* dy4, const float* wa4, const float* x, const float* s, const float* addend, float* dz, float* ds,
+                               int N, int H, int W, int C, const eg3d_act_bwd* ab, const float* dy_amax, const float* addend_amax,
+                               void* split_image, float* split_scale_out, void* stream);
 
 /* NHWC FIR resampler used on the fused path (skip-image 2x upsample and its adjoint, FIR adjoint of up=2 layers):
  *   same arithmetic as eg3d_upfirdn2d on a channels-last fp32 tensor, float4 over channels (C % 4 == 0),

@@ -956,6 +956,56 @@ def test_fused_activation_backward_equals_separate_pass(kind):
     close(B['dstrength'], (dy.sum(1, keepdim=True) * noise.double().reshape(nz64.shape)).sum().float(), 1e-4, f'{kind} dstrength vs f64')
 
 
+@pytest.mark.parametrize('with_addend', [False, True])
+def test_torgb_dgrad_act_split_image_decodes_to_dz(with_addend):
+    """eg3d_torgb_dgrad_act_split: the same pass as eg3d_torgb_dgrad_act, dz written as the two-piece fp16 operand image (range from a bound
+    on max|dz|, no split pass).  The image decodes to the fp32 dz within the two-piece resolution, the scale covers max|dz| with a bound at
+    most 2^8 loose, the reductions are those of the fp32 form, and the data gradient run on the image equals the one run on the split of dz."""
+    from inv3d_amd import hipops as H, _lib as L
+    CL = torch.channels_last
+    n, c, h, w = 2, 128, 40, 48
+    g = torch.Generator().manual_seed(77)
+    dy4 = (torch.randn(n, 4, h, w, generator=g) * 1e-3).to(DEV).contiguous(memory_format=CL)
+    wa = (torch.randn(c, 4, generator=g) / 2).to(DEV).contiguous()
+    s = (1 + 0.5 * torch.randn(n, c, generator=g)).to(DEV)
+    x = (torch.randn(n, c, h, w, generator=g) * 1.5).to(DEV).contiguous(memory_format=CL)
+    add = (torch.randn(n, c, h, w, generator=g) * 2e-3).to(DEV).contiguous(memory_format=CL) if with_addend else None
+    d = (0.5 + torch.rand(n, c, generator=g)).to(DEV)
+    bias = (torch.randn(c, generator=g) * 0.1).to(DEV)
+    noise = torch.randn(n, 1, h, w, generator=g).to(DEV)
+    st = torch.tensor(0.37, device=DEV)
+
+    def spec_and_accs():
+        A = dict(dbias=torch.zeros(c, device=DEV), dd=torch.zeros(n, c, device=DEV), dnoise=torch.zeros_like(noise), dstrength=torch.zeros((), device=DEV))
+        return H.ActBwdSpec(d=d, bias=bias, noise=noise, noise_nstride=h * w, noise_strength=st, act='lrelu', alpha=0.2, gain=math.sqrt(2), clamp=256.0,
+                            dnoise_nstride=h * w, **A), A
+    spec_a, A = spec_and_accs()
+    ds_a, amax_a = torch.zeros(n, c, device=DEV), torch.zeros(1, device=DEV)
+    dz = H.torgb_dgrad_act(dy4, wa, x, s, H.empty_cl(n, c, h, w, DEV), spec_a, ds=ds_a, addend=add, dz_amax=amax_a)
+    spec_b, B = spec_and_accs()
+    ds_b = torch.zeros(n, c, device=DEV)
+    simg = H.torgb_dgrad_act_split(dy4, wa, x, s, spec_b, H.absmax(dy4), ds=ds_b, addend=add, addend_amax=H.absmax(add) if add is not None else None)
+    torch.cuda.synchronize()
+    scale = float(simg.scale)
+    assert scale > 0 and math.log2(scale) == int(math.log2(scale))
+    top = float(amax_a) * scale
+    assert 2.0 ** 5 <= top < 2.0 ** 14, f'max|dz| * scale = {top}: the bound is wrong or useless'
+    img = simg.data.view(n, 2, c // 8, h, w, 8).float()
+    dec = ((img[:, 0] + img[:, 1] / 2048.0) / scale).permute(0, 1, 4, 2, 3).reshape(n, c, h, w)       # [n][octet][8][h][w] -> channels
+    err = float((dec - dz).abs().max())
+    assert err <= 2.0 ** -21 * float(amax_a) * 2.0 ** (14 - math.floor(math.log2(top))) + 1e-30, err
+    for key in A:
+        close(B[key], A[key], 1e-6, key)
+    close(ds_b, ds_a, 1e-6, 'ds')
+    # the consumer: a 3x3 data gradient on the image vs on the split of the fp32 dz
+    wt = torch.randn(c, c, 3, 3, generator=g) / math.sqrt(c * 9)
+    wimg = H.split_weight(H.pack_weight_fwd(wt.to(DEV)), c, c, 9)
+    o1, o2 = H.empty_cl(n, c, h, w, DEV), H.empty_cl(n, c, h, w, DEV)
+    H.conv_v2(simg, wimg, o1, H.classes_corr(h, w, 3, 3, 1))
+    H.conv_v2(H.split_activation(dz, amax_a), wimg, o2, H.classes_corr(h, w, 3, 3, 1))
+    close(o1, o2, 2e-6, 'conv on the fused image vs on the split pass')
+
+
 @pytest.mark.parametrize('shape', [(1, 512, 8, 8), (2, 256, 32, 32), (1, 96, 16, 16)])
 def test_dgrad_finish_with_activation_backward_equals_two_passes(shape):
     """eg3d_dgrad_finish_act (split-K layers) against eg3d_dgrad_finish followed by eg3d_modconv_epilogue_bwd."""

@@ -248,6 +248,9 @@ def test_round2_entry_points_reject_bad_arguments_before_touching_the_gpu():
     ab = L.ActBwd()
     assert lib.eg3d_torgb_dgrad_act(None, a, a, a, None, a, None, 1, 8, 8, 16, C.byref(ab), None, None) < 0
     assert lib.eg3d_torgb_dgrad_act(a, a, a, a, None, a, None, 1, 8, 8, 18, C.byref(ab), None, None) < 0   # C % 4
+    assert lib.eg3d_torgb_dgrad_act_split(a, a, a, a, None, None, None, 1, 8, 8, 16, C.byref(ab), None, None, a, a, None) < 0      # no max|dy|
+    assert lib.eg3d_torgb_dgrad_act_split(a, a, a, a, a, None, None, 1, 8, 8, 16, C.byref(ab), a, None, a, a, None) < 0            # addend without its maximum
+    assert lib.eg3d_torgb_dgrad_act_split(a, a, a, a, None, None, None, 1, 8, 8, 20, C.byref(ab), a, None, a, a, None) < 0         # C % 8
     p = L.ConvParams()
     p.x = p.w = p.out = a
     p.N, p.Hi, p.Wi, p.Ck, p.ldx, p.Nc, p.w_row, p.Ho, p.Wo, p.ldo = 1, 8, 8, 16, 16, 16, 16, 8, 8, 16
