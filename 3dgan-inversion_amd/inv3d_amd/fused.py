@@ -189,7 +189,7 @@ def _auto_ksplit(classes, N, Nc, Ck):
 # buffer and skips its own pass.
 FUSE_ACT_BWD = os.environ.get('EG3D_FUSE_ACT_BWD', '1') != '0'
 SPLIT_DZ = os.environ.get('EG3D_SPLIT_DZ', '1') != '0'         # ... and write dz as the data gradient's fp16 operand image where it can (torgb_dgrad_act_split)
-_DX_AMAX = {}                 # dx.data_ptr() -> device scalar max|dx| reported by the data-gradient kernel that wrote it (read once by a toRGB backward)
+_DX_AMAX = {}                 # dx.data_ptr() -> (device scalar max|dx| reported by the data-gradient kernel that wrote it, weak ref to dx); read once by a toRGB backward
 _DZ_TOKEN = {}                # device -> 1-element tensor: expanded, it stands in for a dz that only exists as an operand image
 
 
@@ -444,7 +444,7 @@ class ModConvLayerFn(torch.autograd.Function):
                 if not fkw and SPLIT_DZ:          # dx goes on to a toRGB node as its pass-through gradient: that pass wants max|dx| (torgb_dgrad_act_split)
                     dx_amax = H.zeros((1,), dev)
                     fkw = dict(out_amax=dx_amax)
-                    _DX_AMAX[dx.data_ptr()] = dx_amax
+                    _DX_AMAX[dx.data_ptr()] = (dx_amax, weakref.ref(dx))
                 did = H.conv_v2_s2adj(gimg, cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, algo_flops=aflops,
                                       products=1 if prec == 'f16x1' else 3, **fkw)
             elif H.USE_V2 and up == 1 and ks == 1 and prec in ('f16x3', 'f16x1') and H.conv_v2_supported(Co, Ci, cls_adj, N):
@@ -673,7 +673,11 @@ class ToRGBFn(torch.autograd.Function):
             if prod is not None and Cp == 4 and Ci % 4 == 0 and Ci <= 1024 and TORGB4_ELEMENTWISE:
                 # four outputs (the SR head's toRGB): the data gradient is four multiply-adds per element -- one element-wise pass with the
                 # producing layer's activation backward instead of a GEMM launch with a 4-deep contraction (105 -> 60 us at 512^2 x 128)
-                add_amax = _DX_AMAX.pop(add.data_ptr(), None) if add is not None else None
+                add_amax = None
+                if add is not None:       # the report belongs to THIS tensor object (an address can be recycled; a copy made by autograd has no report)
+                    ent = _DX_AMAX.pop(add.data_ptr(), None)
+                    if ent is not None and (ent[1]() is add or ent[1]() is dx_pass):
+                        add_amax = ent[0]
                 if getattr(prod, 'split_ok', False) and dy_amax is not None and (add is None or add_amax is not None) and Ci % 8 == 0:
                     # the producing layer's backward only feeds dz to the pre-split data gradient: write its operand image here (no split pass,
                     # no fp32 dz -- a stride-0 token stands in for the gradient tensor autograd passes on)
