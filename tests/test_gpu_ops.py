@@ -423,6 +423,50 @@ def test_render_golden(golden):
     close(rgb, d['rn_auto_rgb'], 1e-5, 'render auto rgb'); close(dep, d['rn_auto_depth'], 1e-5, 'render auto depth')
 
 
+@pytest.mark.parametrize('variant', ['ffhq48', 'uneven'])
+def test_render_feature_row_path_equals_gather_in_decoder(variant):
+    """eg3d_render_params.feat_rows (the tri-plane gather as its own pass, rows re-read by the decoder kernels in forward and backward)
+    against the same renderer with the gather inside the decoder kernels: the interpolation is the same instruction sequence, so the
+    forward is bit-identical; the gradients differ only by the summation order of atomically accumulated sums.  Also the opt-in
+    three-product fp16 accumulation of the plane gradient (EG3D_SCATTER_F16) against the exact fp32 one."""
+    from inv3d_amd.training.volumetric_rendering.renderer import ImportanceRenderer
+    from inv3d_amd import fused, hipops as H
+    cfg = O.full_config()
+    opts = dict(cfg.rendering)
+    if variant == 'uneven':
+        opts['depth_resolution'], opts['depth_resolution_importance'] = 40, 24
+    res, n = 32, 2
+    P = O.synth_params(O.small_config(), seed=7)
+    g = torch.Generator().manual_seed(5)
+    planes = (torch.randn(n, 3, 32, 64, 64, generator=g) * 0.8)
+    cam = O.synth_cameras(n, seed=11)
+    o, dr = O.ray_sampler(cam[:, :16].reshape(n, 4, 4), cam[:, 16:].reshape(n, 3, 3), res)
+    dc, df = opts['depth_resolution'], opts['depth_resolution_importance']
+    u1, u2 = torch.rand(n, res * res, dc, 1, generator=g), torch.rand(n * res * res, df, generator=g)
+    g_rgb, g_dep = torch.randn(n, res * res, 32, generator=g).to(DEV), torch.randn(n, res * res, 1, generator=g).to(DEV)
+    dec = _decoder(P)
+
+    def run(feat, f16):
+        old = fused.RENDER_FEAT_ROWS, H.SCATTER_F16
+        fused.RENDER_FEAT_ROWS, H.SCATTER_F16 = feat, f16
+        try:
+            R = ImportanceRenderer()
+            R.set_uniforms(u1.to(DEV), u2.to(DEV))
+            pg = planes.to(DEV).requires_grad_(True)
+            og, dg = o.to(DEV).requires_grad_(True), dr.to(DEV).requires_grad_(True)
+            rgb, dep, ws = R(pg, dec, og, dg, opts)
+            gg = torch.autograd.grad([rgb, dep], [pg, og, dg], [g_rgb, g_dep])
+            torch.cuda.synchronize()
+            return (rgb, dep, ws) + tuple(gg)
+        finally:
+            fused.RENDER_FEAT_ROWS, H.SCATTER_F16 = old
+    a, b, c = run(False, False), run(True, False), run(True, True)
+    for k in range(3):
+        assert torch.equal(a[k], b[k]), f'forward output {k} differs between the gather paths'
+    close(b[3], a[3], 2e-6, 'd planes'); close_most(b[4], a[4], 1e-5, 'd origins'); close_most(b[5], a[5], 1e-5, 'd dirs')
+    close(c[3], b[3], 2e-6, 'd planes, fp16 three-product accumulation vs fp32')
+
+
 @pytest.mark.parametrize('variant', ['ffhq48', 'white_back', 'disparity', 'coarse_only', 'uneven', 'negative_depths', 'no_grad_fused'])
 def test_render_vs_oracle(variant):
     """48+48-sample configuration (and variants) on random planes vs the oracle, forward and gradients."""
