@@ -325,6 +325,48 @@ __global__ void __launch_bounds__(256) split_w_kernel(const float* __restrict__ 
     out[((((int64_t)tap * (I / 16) + chunk) * 2 + 1) * 2 + koct) * O + o] = l;
 }
 
+// batched forms of the two kernels above for the pivotal-tuning phase, where every weight image is stale once per step (20 launches of ~5 us)
+__global__ void __launch_bounds__(256) absmax_batched_kernel(const eg3d_split_w_batch b) {
+    const eg3d_split_w_item& it = b.items[blockIdx.y];
+    const int64_t n = (int64_t)it.O * it.w_row;                  // dense packed matrix (w_row = T * I)
+    float m = 0.f;
+    const float4* x4 = reinterpret_cast<const float4*>(it.w);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n >> 2); i += (int64_t)gridDim.x * 256) {
+        const float4 v = x4[i];
+        m = fmaxf(m, fmaxf(fmaxf(finite_abs(v.x), finite_abs(v.y)), fmaxf(finite_abs(v.z), finite_abs(v.w))));
+    }
+    __shared__ float red[4];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m > 0.f && m < 3.0e38f) atomicMax(reinterpret_cast<unsigned*>(it.amax), __float_as_uint(m));
+    }
+}
+__global__ void __launch_bounds__(256) split_w_batched_kernel(const eg3d_split_w_batch b) {
+    const eg3d_split_w_item& it = b.items[blockIdx.y];
+    const float mul = range_mul(*it.amax);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *it.scale_out = mul;
+    const int O = it.O, I = it.I, noct = I / 8;
+    f16x8* out = reinterpret_cast<f16x8*>(it.image);
+    const int64_t tot = (int64_t)O * it.T * noct;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < tot; t += (int64_t)gridDim.x * 256) {
+        const int o = (int)(t % O);
+        const int64_t r = t / O;
+        const int ko = (int)(r % noct), tap = (int)(r / noct);
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = it.w[(int64_t)o * it.w_row + (int64_t)tap * I + ko * 8 + q];
+        f16x8 h, l;
+        split8(v, mul, h, l, 1.f);
+        const int chunk = ko >> 1, koct = ko & 1;
+        out[((((int64_t)tap * (I / 16) + chunk) * 2 + 0) * 2 + koct) * O + o] = h;
+        out[((((int64_t)tap * (I / 16) + chunk) * 2 + 1) * 2 + koct) * O + o] = l;
+    }
+}
+
 std::atomic<uint64_t> g_attr[9];
 
 template <int NTAPS, bool FULL = true, bool ATOMIC = false, int RPW = 4>
@@ -442,6 +484,22 @@ extern "C" int eg3d_absmax(const float* x, int64_t n, float* out, void* stream) 
     if (reinterpret_cast<uintptr_t>(x) & 15) return EG3D_ERR_UNSUPPORTED;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(512, n / (256 * 4 * 4)));       // >= 16 elements per thread
     hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_split_weights_batched(const eg3d_split_w_batch* b, void* stream) {
+    if (!b || b->n <= 0 || b->n > EG3D_SPLIT_W_BATCH_MAX) return EG3D_ERR_INVALID;
+    int64_t big = 0;
+    for (int i = 0; i < b->n; ++i) {
+        const eg3d_split_w_item& it = b->items[i];
+        if (!it.w || !it.amax || !it.image || !it.scale_out || it.O <= 0 || it.I < 16 || (it.I & 15) || it.T <= 0 || it.w_row != it.T * it.I) return EG3D_ERR_INVALID;
+        if ((reinterpret_cast<uintptr_t>(it.w) & 15) || (((int64_t)it.O * it.w_row) & 3)) return EG3D_ERR_UNSUPPORTED;
+        big = std::max<int64_t>(big, (int64_t)it.O * it.T * (it.I / 8));
+    }
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(256, (big + 1023) / 1024));
+    hipLaunchKernelGGL(absmax_batched_kernel, dim3(blocks, b->n), dim3(256), 0, (hipStream_t)stream, *b);
+    hipLaunchKernelGGL(split_w_batched_kernel, dim3(blocks, b->n), dim3(256), 0, (hipStream_t)stream, *b);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -19,7 +19,7 @@ constexpr int UNROLL = 8;            // row pairs in flight per wave and trip
 // (64 x 32) and (33 x 64): two MFMAs per row pair each instead of four.
 template <bool A_HI, bool B_HI, int A_EX>
 __global__ void __launch_bounds__(256) rows_gram_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t S, int Ka, int Kb,
-                                                        float* __restrict__ out, float* __restrict__ colsum) {
+                                                        float* __restrict__ out, float* __restrict__ colsum, float out_scale, float cs_scale) {
     __shared__ float red[64 * 64 + 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane & 31, h = lane >> 5;
     const int64_t nw = (int64_t)gridDim.x * 4, w = (int64_t)blockIdx.x * 4 + wave;
@@ -94,14 +94,21 @@ __global__ void __launch_bounds__(256) rows_gram_kernel(const float* __restrict_
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         const int row = i >> 6, col = i & 63;
-        if (row < Ka && col < Kb) unsafeAtomicAdd(out + row * Kb + col, red[i]);
+        if (row < Ka && col < Kb) unsafeAtomicAdd(out + row * Kb + col, red[i] * out_scale);
     }
-    if (colsum != nullptr && threadIdx.x < Ka) unsafeAtomicAdd(colsum + threadIdx.x, red[64 * 64 + threadIdx.x]);
+    if (colsum != nullptr && threadIdx.x < Ka) unsafeAtomicAdd(colsum + threadIdx.x, red[64 * 64 + threadIdx.x] * cs_scale);
 }
 
 }  // namespace
 
+extern "C" int eg3d_rows_gram_scaled(const float* a, const float* b, int64_t S, int Ka, int Kb, float* out, float* colsum, float out_scale, float colsum_scale,
+                                     void* stream);
 extern "C" int eg3d_rows_gram(const float* a, const float* b, int64_t S, int Ka, int Kb, float* out, float* colsum, void* stream) {
+    return eg3d_rows_gram_scaled(a, b, S, Ka, Kb, out, colsum, 1.f, 1.f, stream);
+}
+
+extern "C" int eg3d_rows_gram_scaled(const float* a, const float* b, int64_t S, int Ka, int Kb, float* out, float* colsum, float out_scale, float colsum_scale,
+                                     void* stream) {
     if (!a || !b || !out || S < 0 || Ka < 1 || Kb < 1) return EG3D_ERR_INVALID;
     if (Ka > 64 || Kb > 64) return EG3D_ERR_UNSUPPORTED;
     if (S == 0) return EG3D_OK;
@@ -113,7 +120,7 @@ extern "C" int eg3d_rows_gram(const float* a, const float* b, int64_t S, int Ka,
     else if (aex > 1) kern = bhi ? rows_gram_kernel<false, true, 8> : rows_gram_kernel<false, false, 8>;
     else if (Ka > 32) kern = bhi ? rows_gram_kernel<true, true, 0> : rows_gram_kernel<true, false, 0>;
     else kern = bhi ? rows_gram_kernel<false, true, 0> : rows_gram_kernel<false, false, 0>;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, S, Ka, Kb, out, colsum);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, S, Ka, Kb, out, colsum, out_scale, colsum_scale);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -103,6 +103,18 @@ class RenderSizes(C.Structure):
                                          'df_rows', 'df_pos', 'ag_rows', 'gc_rows', 'dump_dpre', 'dump_h', 'dump_dout', 'dump_feat', 'feat_rows')]
 
 
+SPLIT_W_BATCH_MAX = 24
+
+
+class SplitWItem(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('image', C.c_void_p), ('scale_out', C.c_void_p), ('amax', C.c_void_p), ('O', C.c_int32), ('I', C.c_int32), ('T', C.c_int32),
+                ('w_row', C.c_int32)]
+
+
+class SplitWBatch(C.Structure):
+    _fields_ = [('n', C.c_int32), ('pad_', C.c_int32), ('items', SplitWItem * SPLIT_W_BATCH_MAX)]
+
+
 class FlreluParams(C.Structure):
     _fields_ = [('x', C.c_void_p), ('b', C.c_void_p), ('y', C.c_void_p), ('fu', C.c_void_p), ('fd', C.c_void_p), ('mask', C.c_void_p),
                 ('dtype', C.c_int32), ('N', C.c_int32), ('C', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
@@ -145,6 +157,7 @@ _SIGS = {
     'eg3d_split_activation_bytes': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'eg3d_split_activation': (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]),
     'eg3d_split_weight': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
+    'eg3d_split_weights_batched': (C.c_int, [C.POINTER(SplitWBatch), C.c_void_p]),
     'eg3d_absmax': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'eg3d_upconv_epilogue_fwd': (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int64,
                                            C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -198,6 +211,7 @@ _SIGS = {
     'eg3d_pack_conv_weight_scaled': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     'eg3d_unpack_weight_grad': (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     'eg3d_rows_gram': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'eg3d_rows_gram_scaled': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
     'eg3d_filtered_lrelu': (C.c_int, [C.POINTER(FlreluParams), C.c_void_p]),
     'eg3d_style_affine_fwd': (C.c_int, [C.POINTER(StyleBank), C.c_void_p]),
     'eg3d_style_affine_bwd': (C.c_int, [C.POINTER(StyleBank), C.c_void_p]),

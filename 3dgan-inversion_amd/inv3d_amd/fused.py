@@ -129,21 +129,31 @@ def prepack_weights(layers):
                 cache._pad_key = cache._pad_bias_key = None
             if cache._pad_key != key + (cp,):
                 items.append((w.detach(), pad[0], pad[1], None, cp))
-                installs.append((cache, 'pad', key + (cp,), None))
+                installs.append((cache, 'pad', key + (cp,), None, False, None))
         elif cache._c.get('k') != key:
             wf = torch.empty((o, kh * kw * i), device=w.device)
             wa = torch.empty((i, kh * kw * o), device=w.device)
             wsq = torch.empty((o, i), device=w.device)
             items.append((w.detach(), wf, wa, wsq, 0))
-            installs.append((cache, 'full', key, (wf, wa, wsq)))
+            installs.append((cache, 'full', key, (wf, wa, wsq), 'split' in cache._c, (o, i, kh * kw)))
     if not items:
         return 0
     H.pack_conv_weights_batched(items)
-    for cache, kind, key, out in installs:
+    resplit = []
+    for cache, kind, key, out, had_split, oit in installs:
         if kind == 'pad':
             cache._pad_key = key
         else:
             cache._c = {'k': key, 'wf': out[0], 'wa': out[1], 'wsq': out[2]}
+            if had_split:           # the layer ran on the pre-split kernel with its previous weights: its two operand images, batched with the others'
+                resplit.append((cache, out, oit))
+    if resplit:
+        mats = []
+        for cache, (wf, wa, _), (o, i, t) in resplit:
+            mats += [(wf, o, i, t), (wa, i, o, t)]
+        imgs = H.split_weights_batched(mats)
+        for k, (cache, _, _) in enumerate(resplit):
+            cache._c['split'] = (imgs[2 * k], imgs[2 * k + 1])
     return len(items)
 
 
@@ -850,7 +860,6 @@ class RenderFn(torch.autograd.Function):
         dw0 = db0 = dw1 = db1 = None
         if dumps is not None:
             dpre, hid, dout, feat = dumps
-            dw0, db0 = H.rows_gram(dpre, feat)          # [64,32] = dpre^T feat and its column sums over 1.57 M samples
-            dw1, db1 = H.rows_gram(dout, hid)           # [33,64]
-            dw0, db0, dw1, db1 = dw0 * g0, db0 * lr_mul, dw1 * g1, db1 * lr_mul
+            dw0, db0 = H.rows_gram(dpre, feat, g0, lr_mul)          # [64,32] = g0 dpre^T feat and lr_mul x its column sums over 1.57 M samples
+            dw1, db1 = H.rows_gram(dout, hid, g1, lr_mul)           # [33,64]  (the runtime gains applied to the partial sums: no scaling passes)
         return (d_planes, d_o if need[1] else None, d_d if need[2] else None, dw0, db0, dw1, db1, None, None, None, None, None)

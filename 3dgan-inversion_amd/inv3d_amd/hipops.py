@@ -478,6 +478,27 @@ def split_weight(wp, O, I, T):
     return SplitImage(img, scale, (O, I, T))
 
 
+def split_weights_batched(mats):
+    """[(packed fp32 matrix [O, T*I], O, I, T), ...] -> [SplitImage, ...] from two launches per batch of SPLIT_W_BATCH_MAX (eg3d_split_weights_batched)."""
+    outs = []
+    for b0 in range(0, len(mats), L.SPLIT_W_BATCH_MAX):
+        grp = mats[b0:b0 + L.SPLIT_W_BATCH_MAX]
+        dev = grp[0][0].device
+        amax = zeros((len(grp),), dev)
+        scales = torch.empty((len(grp),), dtype=torch.float32, device=dev)
+        b = L.SplitWBatch()
+        b.n = len(grp)
+        for k, (wp, O, I, T) in enumerate(grp):
+            assert wp.is_contiguous() and wp.shape == (O, T * I)
+            img = torch.empty((O * T * I * 2,), dtype=torch.float16, device=dev)
+            it = b.items[k]
+            it.w, it.image, it.scale_out, it.amax = wp.data_ptr(), img.data_ptr(), scales[k:k + 1].data_ptr(), amax[k:k + 1].data_ptr()
+            it.O, it.I, it.T, it.w_row = O, I, T, T * I
+            outs.append(SplitImage(img, scales[k:k + 1], (O, I, T)))
+        L.check(L.lib().eg3d_split_weights_batched(C.byref(b), L.stream_ptr()), 'split_weights_batched')
+    return outs
+
+
 def _conv_v2_params(a, w, out, classes, out_stride, epi, out_scale, bias, noise, noise_nstride, noise_strength, act, alpha, gain, clamp,
                     addend, xin, ds, out_amax):
     p = L.ConvV2Params()
@@ -851,12 +872,13 @@ def torgb_dgrad_act_split(dy4, wa4, x, s, act_bwd, dy_amax, ds=None, addend=None
     return SplitImage(img, scale, (n, c, h, w))
 
 
-def rows_gram(a, b):
-    """(a^T b [Ka,Kb], column sums of a [Ka]) for row matrices a [S,Ka], b [S,Kb] with Ka, Kb <= 64 (eg3d_rows_gram)."""
+def rows_gram(a, b, out_scale=1.0, colsum_scale=1.0):
+    """(out_scale * a^T b [Ka,Kb], colsum_scale * column sums of a [Ka]) for row matrices a [S,Ka], b [S,Kb] with Ka, Kb <= 64 (eg3d_rows_gram_scaled)."""
     assert a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0] and a.is_contiguous() and b.is_contiguous()
     z = zeros((a.shape[1] * b.shape[1] + a.shape[1],), a.device)
     out, cs = z[:a.shape[1] * b.shape[1]].view(a.shape[1], b.shape[1]), z[a.shape[1] * b.shape[1]:]
-    L.check(L.lib().eg3d_rows_gram(L.ptr(a), L.ptr(b), a.shape[0], a.shape[1], b.shape[1], L.ptr(out), L.ptr(cs), L.stream_ptr()), 'rows_gram')
+    L.check(L.lib().eg3d_rows_gram_scaled(L.ptr(a), L.ptr(b), a.shape[0], a.shape[1], b.shape[1], L.ptr(out), L.ptr(cs), float(out_scale), float(colsum_scale),
+                                          L.stream_ptr()), 'rows_gram')
     return out, cs
 
 

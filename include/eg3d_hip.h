@@ -267,6 +267,12 @@ int eg3d_split_activation(const float* x, const float* in_scale, const float* x_
                           int N, int H, int W, int C, int ldx, void* stream);
 /* w: packed [O][T][I] fp32 with row stride w_row (the forward or adjoint image of eg3d_pack_conv_weight); image: O*T*I*4 bytes. */
 int eg3d_split_weight(const float* w, const float* w_amax, void* image, float* scale_out, int O, int I, int T, int w_row, void* stream);
+/* Up to EG3D_SPLIT_W_BATCH_MAX dense packed weight matrices (w_row = T * I) in two launches: max|w| into the pre-zeroed `amax` scalars, then
+ * the images (pivotal tuning re-splits every weight once per step). */
+#define EG3D_SPLIT_W_BATCH_MAX 24
+typedef struct eg3d_split_w_item { const float* w; void* image; float* scale_out; float* amax; int32_t O, I, T, w_row; } eg3d_split_w_item;
+typedef struct eg3d_split_w_batch { int32_t n; int32_t pad_; eg3d_split_w_item items[EG3D_SPLIT_W_BATCH_MAX]; } eg3d_split_w_batch;
+int eg3d_split_weights_batched(const eg3d_split_w_batch* b, void* stream);
 /* out (pre-zeroed device scalar) = max(out, max|x|) over n floats. */
 int eg3d_absmax(const float* x, int64_t n, float* out, void* stream);
 
@@ -296,6 +302,10 @@ int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* p, void* stream);
  * base_coach.py:96-99):  out[i][j] += sum_s a[s][i]*b[s][j]  (Ka, Kb <= 64, row-major a [S,Ka], b [S,Kb]),
  * colsum[i] += sum_s a[s][i] (or null).  out / colsum must be pre-zeroed (accumulated with atomics).  Exact fp32 MFMA. */
 int eg3d_rows_gram(const float* a, const float* b, int64_t S, int Ka, int Kb, float* out, float* colsum, void* stream);
+/* ... with every partial sum multiplied by out_scale / colsum_scale before it is accumulated (the decoder's runtime weight gains: one launch
+ * instead of the product + two scaling passes). */
+int eg3d_rows_gram_scaled(const float* a, const float* b, int64_t S, int Ka, int Kb, float* out, float* colsum, float out_scale, float colsum_scale,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * filtered_lrelu -- replaces filtered_lrelu_plugin.filtered_lrelu / filtered_lrelu_act_ (torch_utils/ops/filtered_lrelu.cpp:20,217;

@@ -567,6 +567,9 @@ def test_rows_gram(shape):
     ref, refs = a.double().t() @ b.double(), a.double().sum(0)
     close(out, ref, 2e-6 * math.sqrt(s), f'rows_gram {shape}')
     close(cs, refs, 2e-6 * math.sqrt(s), f'rows_gram colsum {shape}')
+    out2, cs2 = H.rows_gram(a.to(DEV), b.to(DEV), 0.125, 3.0)               # the scaled form (eg3d_rows_gram_scaled): gains applied to the partial sums
+    close(out2, ref * 0.125, 2e-6 * math.sqrt(s), f'rows_gram scaled {shape}')
+    close(cs2, refs * 3.0, 2e-6 * math.sqrt(s), f'rows_gram scaled colsum {shape}')
 
 
 def test_noise_regularizer_and_normalize():
