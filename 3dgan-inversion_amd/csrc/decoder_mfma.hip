@@ -374,15 +374,16 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
             for (int r = 0; r < 16; ++r) o[1 + split_idx(r, h)] = dout[r];
         }
         if (a.dump_feat && valid) {
-            float* o = a.dump_feat + row * FC;
+            float* o = a.dump_feat + row * FC + 4 * h;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[split_idx(r, h)] = f[r];
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(o + 8 * g) = make_float4(f[4 * g], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
         }
-        if (a.dump_h && valid) {
+        if (a.dump_h && valid) {          // registers 4 g .. 4 g + 3 of a split-layout vector are four consecutive elements 8 g + 4 h ..: 16-byte stores
 #pragma unroll
             for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) a.dump_h[row * HD + 32 * ht + split_idx(r, h)] = hid[ht][r];
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(a.dump_h + row * HD + 32 * ht + 8 * g + 4 * h) = make_float4(hid[ht][4 * g], hid[ht][4 * g + 1], hid[ht][4 * g + 2], hid[ht][4 * g + 3]);
         }
         phase_fence();
         // ---- dH^T = W1c^T dOUT^T + w1s dsigma ;  dPRE = dH * sigmoid(PRE) = dH * (1 - exp(-H)) ---------------------------
@@ -412,7 +413,8 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
 #pragma unroll
             for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) a.dump_dpre[row * HD + 32 * ht + split_idx(r, h)] = dh[ht][r];
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(a.dump_dpre + row * HD + 32 * ht + 8 * g + 4 * h) = make_float4(dh[ht][4 * g], dh[ht][4 * g + 1], dh[ht][4 * g + 2], dh[ht][4 * g + 3]);
         }
         phase_fence();
         // ---- dF^T = W0^T dPRE^T -------------------------------------------------------------------------------------------
