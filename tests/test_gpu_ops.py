@@ -594,7 +594,8 @@ def test_noise_regularizer_and_normalize():
         close(a, e, 1e-5, 'noise normalize')
 
 
-@pytest.mark.parametrize('shape', [(1, 32, 64, 16, 16, 1), (2, 160, 96, 12, 9, 1), (1, 128, 128, 8, 8, 2), (1, 4, 16, 10, 10, 1)])
+@pytest.mark.parametrize('shape', [(1, 32, 64, 16, 16, 1), (2, 160, 96, 12, 9, 1), (1, 128, 128, 8, 8, 2), (1, 4, 16, 10, 10, 1), (1, 128, 256, 32, 40, 1),
+                                   (2, 72, 136, 12, 24, 1), (1, 256, 128, 4, 8, 1)])
 @pytest.mark.parametrize('prec,tol', [('f32', 2e-5), ('f16x3', 2e-5)])
 def test_conv_wgrad_vs_torch(shape, prec, tol):
     """eg3d_conv2d_wgrad_f32 in both arithmetic modes vs autograd of F.conv2d / F.conv_transpose2d in float64: style-modulated input,
