@@ -343,9 +343,20 @@ class LatentProjector:
         if use_graph:       # the schedule values live on the device so that one captured step can be replayed for every step index
             self._scale_t = torch.zeros((), device=dev)
             self._wn = torch.zeros_like(self.w_opt)
+            # the renderer's stratified / importance uniforms of a step from ONE draw in front of the replay: random draws inside a captured
+            # graph cost two generator-state fills per replay on top of the two draws themselves
+            self._uni = None
+            rk = getattr(G, 'rendering_kwargs', None) or {}
+            Dc, Df = int(rk.get('depth_resolution', 0)), int(rk.get('depth_resolution_importance', 0))
+            res = int(getattr(G, 'neural_rendering_resolution', 0) or 0)
+            if Dc > 0 and Df > 0 and res > 0 and 'neural_rendering_resolution' not in self.synth_kwargs:
+                R = res * res
+                self._uni = torch.empty(N * R * (Dc + Df), device=dev)
+                self._uni_views = (self._uni[:N * R * Dc].view(N, R, Dc, 1), self._uni[N * R * Dc:].view(N * R, Df))
             self.optimizer = torch.optim.Adam([self.w_opt] + self._opt_bufs, betas=(0.9, 0.999), lr=torch.tensor(float(first_inv_lr), device=dev),
                                               fused=True, capturable=True)
         else:
+            self._uni = None
             self.optimizer = torch.optim.Adam([self.w_opt] + self._opt_bufs, betas=(0.9, 0.999), lr=first_inv_lr, fused=True)
         self.intrinsic = torch.tensor([4.2647, 0, 0.5, 0, 4.2647, 0.5, 0, 0, 1], device=dev).unsqueeze(0)
         self.init_ext = torch.tensor([1, 0, 0, 0, 0, -1, 0, 0, 0, 0, -1, 2.7, 0, 0, 0, 1.], device=dev).reshape(1, 4, 4)
@@ -411,6 +422,8 @@ class LatentProjector:
                 self._wn.copy_(w_noise)
             else:
                 self._wn.normal_(generator=self.gen)
+            if self._uni is not None and step >= self.preheat:
+                self._uni.uniform_(generator=self.gen)
             if self._graph is not None:
                 self._graph.replay()
             elif step < self.preheat:
@@ -491,6 +504,8 @@ class LatentProjector:
         ws = w.repeat(1, self.num_ws, 1) if w.shape[1] == 1 else w
         if self._noise_inject is not None:
             kw = dict(kw, noise_inject=self._noise_inject)
+        if self.use_graph and self._uni is not None and 'render_uniforms' not in kw:
+            kw = dict(kw, render_uniforms=self._uni_views)          # drawn in front of the step (see __init__)
         out = G.synthesis(ws, pred_cam, noise_mode='const', **(dict(sr_fp16=True) if self.sr_fp16 else dict(force_fp32=True)), **kw)
         from . import loss_nets as LN
         p4 = getattr(out['image'], '_eg3d_padded4', None)
