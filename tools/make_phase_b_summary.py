@@ -5,7 +5,7 @@ src, out = sys.argv[1], sys.argv[2]
 line = sys.argv[3] if len(sys.argv) > 3 else ''
 tr = list(csv.DictReader(open(glob.glob(src + '/*kernel_trace.csv')[0])))
 tr.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(tr) if 'scatter_accum_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(tr) if 'scatter_accum' in r['Kernel_Name']]           # (scatter_accum_kernel | scatter_accum16p_kernel | ...)
 seg = tr[idx[-2] + 1:idx[-1] + 1]                     # one step = from after a tri-plane scatter to the next one (inclusive)
 dur = lambda r: int(r['End_Timestamp']) - int(r['Start_Timestamp'])
 busy, span = sum(map(dur, seg)), int(seg[-1]['End_Timestamp']) - int(seg[0]['Start_Timestamp'])
