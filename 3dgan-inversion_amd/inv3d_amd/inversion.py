@@ -12,6 +12,7 @@ squared distance) and the same gradient path into the image.  Hyper-parameters d
 All schedule arithmetic stays on the host; there is no per-step device->host sync unless `early_stop` is requested.
 """
 import math
+import os
 from typing import Callable, Dict, List, Optional
 
 import numpy as np
@@ -480,16 +481,20 @@ class LatentProjector:
             pred_ext, pred_cam = pose_to_cam(rot, self.translation_opt, self.intrinsic, self.radius)
         else:
             pred_ext, pred_cam = None, self.cam
-        # The noise regulariser only reads the noise buffers and its kernel occupies 17 CUs for ~0.4 ms: fork it onto a second stream
-        # (a parallel branch of the captured graph) and join where the loss is formed.
+        # The noise regulariser only reads the noise buffers.  While its kernel occupied 17 CUs for ~0.4 ms (rounds 1-2) it ran on a second
+        # stream -- a parallel branch of the captured graph, joined where the loss is formed.  Since it is three multi-block passes of
+        # ~50 us together the fork / join of the replayed graph costs more than it hides: in line by default (+1.5 % per step), the branch
+        # stays available as EG3D_REG_BRANCH=1.
         cur = torch.cuda.current_stream()
-        if self._reg_stream is None:
+        reg_branch = os.environ.get('EG3D_REG_BRANCH', '0') != '0'
+        if reg_branch and self._reg_stream is None:
             self._reg_stream = torch.cuda.Stream(device=self.dev)
             _quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
             if _quiet is not None:      # the noise buffers' gradients are accumulated from two streams on purpose
                 _quiet(False)
-        self._reg_stream.wait_stream(cur)
-        with torch.cuda.stream(self._reg_stream):
+        if reg_branch:
+            self._reg_stream.wait_stream(cur)
+        with torch.cuda.stream(self._reg_stream if reg_branch else cur):
             # value AND gradient of the regulariser for all 17 buffers from one launch; the gradient is added to the buffers' .grad
             # after backward with one fused multi-tensor add (through autograd it would be 17 AccumulateGrad add launches)
             if self._buf_views is None:
@@ -518,7 +523,8 @@ class LatentProjector:
                 img = _area_resize(img, 256)
         dist_i = LN.sqdist(self.feature_net(img), self.target_features)              # per image; independent trajectories: the sum's
         dist = dist_i.sum() if dist_i.numel() > 1 else dist_i.reshape(())            # gradient is each image's own gradient (one image: a view)
-        cur.wait_stream(self._reg_stream)
+        if reg_branch:
+            cur.wait_stream(self._reg_stream)
         loss = dist + reg                         # reported value; only `dist` (and the warping term) goes through autograd
         warp = None
         if self.use_warp and self.optimize_pose:
