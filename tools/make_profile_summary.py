@@ -80,7 +80,7 @@ o = [f'# rocprofv3 summary of `bench.py` ({title})\n',
      f'`roofline`: `{json.dumps(roof)}`\n', f'`roofline_renderer`: `{json.dumps(bench.get("roofline_renderer"))}`\n',
      f'`cpu_baseline`: `{json.dumps(bench.get("cpu_baseline"))}`\n',
      f'One graph-replayed step in the kernel trace: {len(seg)} kernels, GPU-busy {busy/1e6:.2f} ms, first-start to last-end {span/1e6:.2f} ms '
-     '(profiler attached; the noise regulariser overlaps the backbone on a graph branch).\n',
+     '(profiler attached).\n',
      '| kernel (one replayed step) | launches | ms | avg µs |\n|---|---:|---:|---:|']
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
     o.append(f'| `{k}` | {v[0]} | {v[1]/1e6:.3f} | {v[1]/v[0]/1e3:.1f} |')
