@@ -73,11 +73,13 @@ __global__ void __launch_bounds__(NT) maxpool_bwd_kernel(const float* __restrict
     }
 }
 
+__host__ __device__ int group_width(int C4);
+
 // One pixel per group of G = min(64, C/4 rounded up to a power of two) lanes; each lane walks the pixel's channels four at a time.
 template <bool BWD>
-__global__ void __launch_bounds__(NT) unit_normalize_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ dout,
-                                                            float* __restrict__ out, int64_t npix, int HW, int C4, int ld4, float mul, float eps,
-                                                            int64_t o_nstride, int G, int eps_inside) {
+__device__ __forceinline__ void unit_normalize_body(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ dout,
+                                                    float* __restrict__ out, int64_t npix, int HW, int C4, int ld4, float mul, float eps,
+                                                    int64_t o_nstride, int G, int eps_inside) {
     const int lane = threadIdx.x % G;
     const int64_t gid = ((int64_t)blockIdx.x * NT + threadIdx.x) / G;
     const int64_t ngroups = (int64_t)gridDim.x * NT / G;
@@ -125,6 +127,21 @@ __global__ void __launch_bounds__(NT) unit_normalize_kernel(const float* __restr
             }
         }
     }
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(NT) unit_normalize_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ dout,
+                                                            float* __restrict__ out, int64_t npix, int HW, int C4, int ld4, float mul, float eps,
+                                                            int64_t o_nstride, int G, int eps_inside) {
+    unit_normalize_body<BWD>(x, scale, dout, out, npix, HW, C4, ld4, mul, eps, o_nstride, G, eps_inside);
+}
+
+// Every tap of the feature pyramid in one launch: blockIdx.y = level (the grid-stride loop inside absorbs the different pixel counts).
+template <bool BWD>
+__global__ void __launch_bounds__(NT) unit_normalize_levels_kernel(const eg3d_unit_levels b) {
+    const eg3d_unit_level& l = b.levels[blockIdx.y];
+    unit_normalize_body<BWD>(l.x, l.scale, BWD ? l.feat : nullptr, BWD ? l.dx : const_cast<float*>(l.feat), (int64_t)b.N * l.HW, l.HW, l.C / 4,
+                             l.ldx / 4, l.mul, b.eps, b.feat_nstride, group_width(l.C / 4), b.eps_inside);
 }
 
 // Generator image -> feature-net input (w_projector.py:198-200,215: (img + 1) * 255/2, area-resized to 256^2): one pass instead of
@@ -333,7 +350,7 @@ int pool_check(const void* a, const void* b, int N, int H, int W, int C, int ld,
     return EG3D_OK;
 }
 
-int group_width(int C4) {
+__host__ __device__ int group_width(int C4) {
     int g = 1;
     while (g < C4 && g < 64) g <<= 1;
     return g;
@@ -388,6 +405,23 @@ extern "C" int eg3d_unit_normalize_bwd(const float* x, const float* scale, const
     const int blocks = grid_blocks(npix * G);
     hipLaunchKernelGGL(unit_normalize_kernel<true>, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, x, scale, dfeat, dx, npix, HW, C / 4, ldx / 4, mul,
                        eps, feat_nstride, G, eps_inside);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_unit_normalize_levels(const eg3d_unit_levels* batch, int bwd, void* stream) {
+    if (!batch || batch->n < 1 || batch->n > EG3D_UNIT_LEVELS_MAX || batch->N < 1 || (batch->feat_nstride & 3)) return EG3D_ERR_INVALID;
+    int64_t most = 0;
+    for (int i = 0; i < batch->n; ++i) {
+        const eg3d_unit_level& l = batch->levels[i];
+        if (!l.x || !l.feat || (bwd && !l.dx) || l.HW < 1 || l.C < 4 || (l.C & 3) || l.ldx < l.C || (l.ldx & 3) || !aligned16(l.x) ||
+            !aligned16(l.feat) || (bwd && !aligned16(l.dx)) || (l.scale && !aligned16(l.scale)))
+            return EG3D_ERR_INVALID;
+        most = std::max<int64_t>(most, (int64_t)batch->N * l.HW * group_width(l.C / 4));
+    }
+    const dim3 grid(grid_blocks(most), batch->n);
+    if (bwd) hipLaunchKernelGGL(unit_normalize_levels_kernel<true>, grid, dim3(NT), 0, (hipStream_t)stream, *batch);
+    else hipLaunchKernelGGL(unit_normalize_levels_kernel<false>, grid, dim3(NT), 0, (hipStream_t)stream, *batch);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -115,6 +115,19 @@ class SplitWBatch(C.Structure):
     _fields_ = [('n', C.c_int32), ('pad_', C.c_int32), ('items', SplitWItem * SPLIT_W_BATCH_MAX)]
 
 
+UNIT_LEVELS_MAX = 8
+
+
+class UnitLevel(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('scale', C.c_void_p), ('feat', C.c_void_p), ('dx', C.c_void_p), ('HW', C.c_int32), ('C', C.c_int32), ('ldx', C.c_int32),
+                ('mul', C.c_float)]
+
+
+class UnitLevels(C.Structure):
+    _fields_ = [('n', C.c_int32), ('N', C.c_int32), ('eps_inside', C.c_int32), ('eps', C.c_float), ('feat_nstride', C.c_int64),
+                ('levels', UnitLevel * UNIT_LEVELS_MAX)]
+
+
 class FlreluParams(C.Structure):
     _fields_ = [('x', C.c_void_p), ('b', C.c_void_p), ('y', C.c_void_p), ('fu', C.c_void_p), ('fd', C.c_void_p), ('mask', C.c_void_p),
                 ('dtype', C.c_int32), ('N', C.c_int32), ('C', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
@@ -203,6 +216,7 @@ _SIGS = {
     'eg3d_slice_rgb4_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     'eg3d_warp_project_fwd': (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]),
     'eg3d_warp_project_bwd': (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_void_p]),
+    'eg3d_unit_normalize_levels': (C.c_int, [C.POINTER(UnitLevels), C.c_int, C.c_void_p]),
     'eg3d_unit_normalize_bwd': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int64, C.c_int, C.c_void_p]),
     'eg3d_pack_conv_weight': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     'eg3d_weight_grad_finish': (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]),

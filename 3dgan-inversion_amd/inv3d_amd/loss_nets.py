@@ -20,6 +20,7 @@ All convolutions run on the implicit-GEMM kernel with bias + ReLU fused in its e
 only), pooling and the LPIPS head on csrc/loss_ops.hip.  Activations are fp32 channels-last; the 3-channel image is carried padded
 to 4 channels.  There is no fallback: tensors must live on the GPU."""
 import math
+from ctypes import byref as C_byref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -260,13 +261,16 @@ class _LpipsHeadFn(torch.autograd.Function):
         sizes = [x.shape[1] * x.shape[2] * x.shape[3] for x in xs]
         F = sum(sizes)
         feat = torch.empty((N, F), device=xs[0].device, dtype=torch.float32)
+        batch = L.UnitLevels(n=len(xs), N=N, eps_inside=eps_inside, eps=eps, feat_nstride=F)
+        assert len(xs) <= L.UNIT_LEVELS_MAX
         off = 0
-        for x, sc, n in zip(xs, scales, sizes):
-            assert H.is_cl(x) and x.dtype == torch.float32
+        for i, (x, sc, n) in enumerate(zip(xs, scales, sizes)):
+            assert H.is_cl(x) and x.dtype == torch.float32 and x.shape[0] == N
             _, C, Hh, Ww = x.shape
-            L.check(L.lib().eg3d_unit_normalize_fwd(x.data_ptr(), sc.data_ptr() if sc is not None else None, feat.data_ptr() + 4 * off, N, Hh * Ww, C, C,
-                                                    1.0 / math.sqrt(Hh * Ww), eps, F, eps_inside, L.stream_ptr()), 'unit_normalize_fwd')
+            batch.levels[i] = L.UnitLevel(x=x.data_ptr(), scale=sc.data_ptr() if sc is not None else None, feat=feat.data_ptr() + 4 * off, dx=None,
+                                          HW=Hh * Ww, C=C, ldx=C, mul=1.0 / math.sqrt(Hh * Ww))
             off += n
+        L.check(L.lib().eg3d_unit_normalize_levels(C_byref(batch), 0, L.stream_ptr()), 'unit_normalize_levels')
         ctx.save_for_backward(*xs, *[s for s in scales if s is not None])
         ctx.cfg = (eps, nscales, sizes, F, eps_inside, [s is not None for s in scales])
         return feat
@@ -277,17 +281,22 @@ class _LpipsHeadFn(torch.autograd.Function):
         xs, rest = ctx.saved_tensors[:nscales], list(ctx.saved_tensors[nscales:])
         scales = [rest.pop(0) if h else None for h in has_scale]
         dfeat = dfeat.contiguous().float()
-        grads, off = [], 0
+        grads, off, k = [], 0, 0
+        batch = L.UnitLevels(N=xs[0].shape[0], eps_inside=eps_inside, eps=eps, feat_nstride=F)
         for i, (x, sc, n) in enumerate(zip(xs, scales, sizes)):
             if ctx.needs_input_grad[2 + i]:
                 N, C, Hh, Ww = x.shape
                 dx = H.empty_cl(N, C, Hh, Ww, x.device)
-                L.check(L.lib().eg3d_unit_normalize_bwd(x.data_ptr(), sc.data_ptr() if sc is not None else None, dfeat.data_ptr() + 4 * off, dx.data_ptr(), N, Hh * Ww, C, C,
-                                                        1.0 / math.sqrt(Hh * Ww), eps, F, eps_inside, L.stream_ptr()), 'unit_normalize_bwd')
+                batch.levels[k] = L.UnitLevel(x=x.data_ptr(), scale=sc.data_ptr() if sc is not None else None, feat=dfeat.data_ptr() + 4 * off,
+                                              dx=dx.data_ptr(), HW=Hh * Ww, C=C, ldx=C, mul=1.0 / math.sqrt(Hh * Ww))
+                k += 1
                 grads.append(dx)
             else:
                 grads.append(None)
             off += n
+        if k:
+            batch.n = k
+            L.check(L.lib().eg3d_unit_normalize_levels(C_byref(batch), 1, L.stream_ptr()), 'unit_normalize_levels')
         return (None, None, *grads, *([None] * nscales))
 
 

@@ -635,6 +635,25 @@ int eg3d_unit_normalize_fwd(const float* x, const float* scale, float* feat, int
 int eg3d_unit_normalize_bwd(const float* x, const float* scale, const float* dfeat, float* dx, int N, int HW, int C, int ldx, float mul,
                             float eps, int64_t feat_nstride, int eps_inside, void* stream);
 
+/* All taps of the feature pyramid in one launch (grid.y = level).  Per level: x [N,HW,ldx], scale (or null), feat = this level's slice of
+ * the flat [N, F] vector (written by the forward, read as dfeat by the backward), dx [N,HW,ldx] (backward only). */
+#define EG3D_UNIT_LEVELS_MAX 8
+typedef struct {
+    const float* x;
+    const float* scale;
+    const float* feat;      /* forward: output slice (written); backward: dfeat slice */
+    float* dx;
+    int HW, C, ldx;
+    float mul;
+} eg3d_unit_level;
+typedef struct {
+    int n, N, eps_inside;
+    float eps;
+    int64_t feat_nstride;
+    eg3d_unit_level levels[EG3D_UNIT_LEVELS_MAX];
+} eg3d_unit_levels;
+int eg3d_unit_normalize_levels(const eg3d_unit_levels* batch, int bwd, void* stream);
+
 /* Generator image -> feature-net input, one pass (w_projector.py:198-200,215: (img + 1) * 255/2, then F.interpolate(mode='area') to 256^2):
  *   out[n,y,x,c] = mul * mean_{factor x factor block}(img[n,...,c]) + add  for c < 3,  0 for c = 3.
  * img: [N,H,W,4] NHWC (the SR head's 3-channel image is carried with 4-float pixels), out: [N,H/factor,W/factor,4].

@@ -251,6 +251,13 @@ def test_round2_entry_points_reject_bad_arguments_before_touching_the_gpu():
     assert lib.eg3d_torgb_dgrad_act_split(a, a, a, a, None, None, None, 1, 8, 8, 16, C.byref(ab), None, None, a, a, None) < 0      # no max|dy|
     assert lib.eg3d_torgb_dgrad_act_split(a, a, a, a, a, None, None, 1, 8, 8, 16, C.byref(ab), a, None, a, a, None) < 0            # addend without its maximum
     assert lib.eg3d_torgb_dgrad_act_split(a, a, a, a, None, None, None, 1, 8, 8, 20, C.byref(ab), a, None, a, a, None) < 0         # C % 8
+    ul = L.UnitLevels(n=1, N=1, eps=1e-10, feat_nstride=64)
+    ul.levels[0] = L.UnitLevel(x=a, scale=None, feat=a, dx=None, HW=4, C=16, ldx=16, mul=1.0)
+    assert lib.eg3d_unit_normalize_levels(C.byref(ul), 1, None) < 0                  # backward without dx
+    ul.n = L.UNIT_LEVELS_MAX + 1
+    assert lib.eg3d_unit_normalize_levels(C.byref(ul), 0, None) < 0
+    ul.n, ul.levels[0].C = 1, 18
+    assert lib.eg3d_unit_normalize_levels(C.byref(ul), 0, None) < 0                  # C % 4
     p = L.ConvParams()
     p.x = p.w = p.out = a
     p.N, p.Hi, p.Wi, p.Ck, p.ldx, p.Nc, p.w_row, p.Ho, p.Wo, p.ldo = 1, 8, 8, 16, 16, 16, 16, 8, 8, 16

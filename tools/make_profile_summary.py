@@ -84,6 +84,13 @@ o = [f'# rocprofv3 summary of `bench.py` ({title})\n',
      '| kernel (one replayed step) | launches | ms | avg µs |\n|---|---:|---:|---:|']
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
     o.append(f'| `{k}` | {v[0]} | {v[1]/1e6:.3f} | {v[1]/v[0]/1e3:.1f} |')
+with open(prefix + '_step_kernels.csv', 'w') as fh:          # every launch of that step, in order (what a replay actually issues)
+    fh.write('index,start_us,duration_us,grid,kernel\n')
+    t0 = int(seg[0]['Start_Timestamp'])
+    for i, r in enumerate(seg):
+        fh.write('%d,%.1f,%.1f,%s,"%s"\n' % (i, (int(r['Start_Timestamp']) - t0) / 1e3, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3,
+                                             r.get('Grid_Size', ''), short(r['Kernel_Name'])))
+o.append(f'\nAll {len(seg)} launches of that step in issue order: `{os.path.basename(prefix)}_step_kernels.csv`.\n')
 dom_short = max((k for k in agg if k.startswith('conv_')), key=lambda k: agg[k][1])
 dom = next(r for r in rows if short(r['Name']) == dom_short)
 o.append(f'\nWhole-run `--stats` table ({ncalls} launches incl. set-up, warm-up and the eager roofline pass): `{os.path.basename(prefix)}_kernel_stats.csv`. '
