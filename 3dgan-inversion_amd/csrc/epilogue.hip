@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(256) upconv_epilogue_kernel(const float* __res
                                                              const float* __restrict__ bias, float slope, float gain, float clamp, float* out_amax,
                                                              const float* __restrict__ sp_scale_in, _Float16* __restrict__ sp_image, float* sp_scale_out) {
     __shared__ __attribute__((aligned(16))) float V[UE_TH * UE_COLS * UE_PITCH];                       // vertical sums [row][column][channel]
-    __shared__ __attribute__((aligned(16))) float O[SPLIT ? UE_TH * UE_TW * UE_PITCH : 4];              // activated tile (SPLIT)
+    float* const O = V;                  // activated tile (SPLIT): takes V's place once phase 2 has read it (41 KB of LDS: three blocks per CU, not two)
     __shared__ float red[4];
     const int tiles_x = (W + UE_TW - 1) / UE_TW, tiles_y = (H + UE_TH - 1) / UE_TH;
     const int n = blockIdx.x / (tiles_x * tiles_y);
@@ -239,6 +239,7 @@ __global__ void __launch_bounds__(256) upconv_epilogue_kernel(const float* __res
     if (d != nullptr) dv = ld4(d + (int64_t)n * C + c);
     if (bias != nullptr) bv = ld4(bias + c);
     float am = 0.f;
+    float4 keep[SPLIT ? UE_TH * UE_TW * (UE_CH / 4) / 256 : 1];
 #pragma unroll
     for (int k = 0; k < UE_TH * UE_TW * (UE_CH / 4) / 256; ++k) {
         const int pix = (threadIdx.x >> 4) + k * 16;                                  // 0 .. 127
@@ -261,9 +262,13 @@ __global__ void __launch_bounds__(256) upconv_epilogue_kernel(const float* __res
             am = amax4(am, v);
             st4(out + (((int64_t)n * H + y) * W + x) * C + c, v);
         }
-        if (SPLIT) *reinterpret_cast<float4*>(O + pix * UE_PITCH + c4 * 4) = v;
+        if (SPLIT) keep[k] = v;
     }
     if (SPLIT) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < UE_TH * UE_TW * (UE_CH / 4) / 256; ++k)
+            *reinterpret_cast<float4*>(O + ((threadIdx.x >> 4) + k * 16) * UE_PITCH + c4 * 4) = keep[k];
         // ---- phase 3: item = (octet, pixel), lanes along the pixels of a tile row (16 x 16 bytes contiguous in a plane's row)
         __syncthreads();
         const int noct = C / 8;

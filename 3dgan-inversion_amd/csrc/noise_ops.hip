@@ -218,6 +218,76 @@ __global__ void __launch_bounds__(NT) noise_apply_norm_kernel(const NoiseBufs B,
     for (int i = start + threadIdx.x; i < min(n, start + NORM_CHUNK); i += NT) x[i] = (x[i] - mean) * inv;
 }
 
+// ---- Adam over the projector's leaves (w_projector.py:107-118, 256-270), one launch --------------------------------------------------
+// torch's multi-tensor Adam walks 64 K-element chunks with 512-thread blocks: ~20 blocks for the 3.3 MB of noise maps, 45 us, after a
+// 19 us multi-tensor add of the regulariser's gradient, and before a moments pass over the same maps.  Here: block = (leaf, 4096
+// elements); the gradient is g + g2 (either may be absent), the update is torch.optim.Adam's (no weight decay, no amsgrad), and leaves
+// flagged `normalize` leave sum / sum of squares of their NEW values behind for the renormalisation that follows.  The step count lives
+// on the device (graph replay): every block reads it on entry, the last block to retire writes it back incremented.
+constexpr int ADAM_CHUNK = NT * 4;
+
+__device__ __forceinline__ bool adam_locate(const eg3d_adam_list& A, int blk, int& item, int64_t& start) {
+    int b0 = 0;
+    for (item = 0; item < A.n; ++item) {
+        const int nb = (int)((A.items[item].n + ADAM_CHUNK - 1) / ADAM_CHUNK);
+        if (blk < b0 + nb) { start = (int64_t)(blk - b0) * ADAM_CHUNK; return true; }
+        b0 += nb;
+    }
+    return false;
+}
+
+__global__ void __launch_bounds__(NT) adam_step_kernel(const eg3d_adam_list A, float* __restrict__ ws) {
+    __shared__ float red[32];
+    const float t = *A.step + 1.0f;
+    int item;
+    int64_t start;
+    if (adam_locate(A, blockIdx.x, item, start)) {
+        const eg3d_adam_item& it = A.items[item];
+        const float lr = *A.lr;
+        const float bc1 = 1.0f - powf(A.beta1, t), bc2s = sqrtf(1.0f - powf(A.beta2, t));
+        const float step_size = lr / bc1;
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int u = 0; u < ADAM_CHUNK / NT; ++u) {
+            const int64_t i = start + threadIdx.x + u * NT;
+            if (i < it.n) {
+                float g = it.g ? it.g[i] : 0.f;
+                if (it.g2) g += it.g2[i];
+                const float m = it.m[i] + (g - it.m[i]) * (1.0f - A.beta1);
+                const float v = it.v[i] * A.beta2 + (1.0f - A.beta2) * g * g;
+                const float x = it.p[i] - step_size * m / (sqrtf(v) / bc2s + A.eps);
+                it.m[i] = m; it.v[i] = v; it.p[i] = x;
+                s += x; q += x * x;
+            }
+        }
+        if (it.normalize) {                  // (block-uniform)
+            s = block_sum(s, red);
+            q = block_sum(q, red);
+            if (threadIdx.x == 0) { unsafeAtomicAdd(ws + 2 * item, s); unsafeAtomicAdd(ws + 2 * item + 1, q); }
+        }
+    }
+    if (A.bump_step && threadIdx.x == 0) {
+        __threadfence();
+        unsigned* tick = reinterpret_cast<unsigned*>(ws + 2 * A.n);
+        if (atomicAdd(tick, 1u) == gridDim.x - 1) { *A.step = t; *tick = 0u; }
+    }
+}
+
+__global__ void __launch_bounds__(NT) adam_apply_norm_kernel(const eg3d_adam_list A, const float* __restrict__ ws) {
+    int item;
+    int64_t start;
+    if (!adam_locate(A, blockIdx.x, item, start)) return;
+    const eg3d_adam_item& it = A.items[item];
+    if (!it.normalize) return;
+    const float mean = ws[2 * item] / (float)it.n;
+    const float inv = 1.0f / sqrtf(ws[2 * item + 1] / (float)it.n - mean * mean);
+#pragma unroll
+    for (int u = 0; u < ADAM_CHUNK / NT; ++u) {
+        const int64_t i = start + threadIdx.x + u * NT;
+        if (i < it.n) it.p[i] = (it.p[i] - mean) * inv;
+    }
+}
+
 int fill(NoiseBufs& B, float* const* x, float* const* g, const int32_t* res, int nbufs) {
     if (!x || !res || nbufs < 1 || nbufs > MAXB) return EG3D_ERR_INVALID;
     B.n = nbufs;
@@ -276,6 +346,21 @@ extern "C" int eg3d_noise_normalize(float* const* x, const int32_t* res, int nbu
         hipLaunchKernelGGL(noise_moments_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, B, workspace);
         hipLaunchKernelGGL(noise_apply_norm_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, B, workspace);
     }
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_adam_step(const eg3d_adam_list* list, float* workspace, void* stream) {
+    if (!list || !workspace || list->n < 1 || list->n > EG3D_ADAM_ITEMS_MAX || !list->lr || !list->step) return EG3D_ERR_INVALID;
+    int blocks = 0, norm = 0;
+    for (int i = 0; i < list->n; ++i) {
+        const eg3d_adam_item& it = list->items[i];
+        if (!it.p || !it.m || !it.v || (!it.g && !it.g2) || it.n < 1 || it.n > (int64_t)1 << 30) return EG3D_ERR_INVALID;
+        blocks += (int)eg3d_cdiv(it.n, ADAM_CHUNK);
+        norm |= it.normalize;
+    }
+    hipLaunchKernelGGL(adam_step_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, *list, workspace);
+    if (norm) hipLaunchKernelGGL(adam_apply_norm_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, *list, workspace);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

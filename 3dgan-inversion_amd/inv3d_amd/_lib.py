@@ -115,6 +115,19 @@ class SplitWBatch(C.Structure):
     _fields_ = [('n', C.c_int32), ('pad_', C.c_int32), ('items', SplitWItem * SPLIT_W_BATCH_MAX)]
 
 
+ADAM_ITEMS_MAX = 32
+
+
+class AdamItem(C.Structure):
+    _fields_ = [('p', C.c_void_p), ('g', C.c_void_p), ('g2', C.c_void_p), ('m', C.c_void_p), ('v', C.c_void_p), ('n', C.c_int64), ('normalize', C.c_int32),
+                ('pad_', C.c_int32)]
+
+
+class AdamList(C.Structure):
+    _fields_ = [('n', C.c_int32), ('bump_step', C.c_int32), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float), ('pad_', C.c_float),
+                ('lr', C.c_void_p), ('step', C.c_void_p), ('items', AdamItem * ADAM_ITEMS_MAX)]
+
+
 UNIT_LEVELS_MAX = 8
 
 
@@ -216,6 +229,7 @@ _SIGS = {
     'eg3d_slice_rgb4_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     'eg3d_warp_project_fwd': (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]),
     'eg3d_warp_project_bwd': (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_void_p]),
+    'eg3d_adam_step': (C.c_int, [C.POINTER(AdamList), C.c_void_p, C.c_void_p]),
     'eg3d_unit_normalize_levels': (C.c_int, [C.POINTER(UnitLevels), C.c_int, C.c_void_p]),
     'eg3d_unit_normalize_bwd': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int64, C.c_int, C.c_void_p]),
     'eg3d_pack_conv_weight': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),

@@ -1152,6 +1152,70 @@ def noise_regularizer(bufs, scale=1.0, want_grad=True, grads=None):
     return total, (grads if want_grad else None)
 
 
+
+class HipAdam:
+    """torch.optim.Adam(params, lr, betas, eps) for fp32 leaves in one launch per 32 leaves (`eg3d_adam_step`), with two extras the latent
+    projector's step wants folded in: a second gradient per leaf (the noise regulariser's, which does not go through autograd) and the
+    renormalisation of the noise maps after the update (w_projector.py:264-270).  The learning rate and the step count are device scalars, so
+    a captured step can be replayed for every step index.  Same surface as the torch optimiser where the projector touches it
+    (`param_groups[0]['lr']` -- a float or a device scalar --, `zero_grad`, `step`, `state`)."""
+
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.params = list(params)
+        dev = self.params[0].device
+        self._lr_t = lr if torch.is_tensor(lr) else torch.tensor(float(lr), device=dev)
+        self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps)]
+        self.step_t = torch.zeros((), device=dev)
+        self.state = {p: dict(exp_avg=torch.zeros_like(p, memory_format=torch.contiguous_format),
+                              exp_avg_sq=torch.zeros_like(p, memory_format=torch.contiguous_format), step=self.step_t) for p in self.params}
+        for p in self.params:
+            assert p.dtype == torch.float32 and p.is_contiguous() and p.is_cuda
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
+
+    def step(self, extra_grads=None, normalize=None):
+        """extra_grads: {param: tensor} added to the gradient; normalize: {param: number of equal slices renormalised separately} (a noise
+        map [N,1,r,r] of N independent images: N)."""
+        g = self.param_groups[0]
+        lr = g['lr']
+        if torch.is_tensor(lr):
+            self._lr_t = lr
+        else:
+            self._lr_t.fill_(float(lr))
+        items = []
+        for p in self.params:
+            e = extra_grads.get(p) if extra_grads else None
+            if p.grad is None and e is None:
+                continue
+            gr = p.grad
+            assert gr is None or (gr.dtype == torch.float32 and gr.is_contiguous()), 'HipAdam: fp32 contiguous gradients'
+            assert e is None or (e.dtype == torch.float32 and e.is_contiguous() and e.shape == p.shape)
+            st = self.state[p]
+            k = int(normalize.get(p, 0)) if normalize else 0
+            parts = max(k, 1)
+            n = p.numel() // parts
+            assert n * parts == p.numel()
+            for i in range(parts):
+                o = 4 * n * i
+                items.append((p.data_ptr() + o, gr.data_ptr() + o if gr is not None else None, e.data_ptr() + o if e is not None else None,
+                              st['exp_avg'].data_ptr() + o, st['exp_avg_sq'].data_ptr() + o, n, 1 if k else 0))
+        dev = self.params[0].device
+        for lo in range(0, len(items), L.ADAM_ITEMS_MAX):
+            bank = items[lo:lo + L.ADAM_ITEMS_MAX]
+            a = L.AdamList(n=len(bank), bump_step=int(lo + L.ADAM_ITEMS_MAX >= len(items)), beta1=g['betas'][0], beta2=g['betas'][1], eps=g['eps'],
+                           lr=self._lr_t.data_ptr(), step=self.step_t.data_ptr())
+            for j, it in enumerate(bank):
+                a.items[j] = L.AdamItem(*it)
+            ws = zeros((2 * len(bank) + 1,), dev)
+            L.check(L.lib().eg3d_adam_step(C.byref(a), L.ptr(ws), L.stream_ptr()), 'adam_step')
+
+
 def noise_normalize_(bufs):
     for lo in range(0, len(bufs), NOISE_BANK_MAX):
         n, xs, res = _buf_arrays(bufs[lo:lo + NOISE_BANK_MAX])

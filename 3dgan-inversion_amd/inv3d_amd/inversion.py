@@ -12,6 +12,7 @@ squared distance) and the same gradient path into the image.  Hyper-parameters d
 All schedule arithmetic stays on the host; there is no per-step device->host sync unless `early_stop` is requested.
 """
 import math
+import functools
 import os
 from typing import Callable, Dict, List, Optional
 
@@ -341,6 +342,9 @@ class LatentProjector:
         if N > 1:
             self._noise_inject = {k[:-len('.noise_const')]: t for k, t in self.noise_maps.items() if k.startswith('backbone.')}
             self._buf_views = [t.detach()[i, 0] for t in self._all_bufs for i in range(N)]       # [r,r] views, image-major per map
+        # Adam over the latent and the noise maps: one launch of our own (regulariser gradient, update, moments for the renormalisation)
+        # instead of torch's multi-tensor add + multi-tensor Adam (64 us for 3.3 MB: ~20 blocks) + a moments pass; EG3D_HIP_ADAM=0 -> torch's
+        hip_adam = os.environ.get('EG3D_HIP_ADAM', '1') != '0' and torch.device(dev).type == 'cuda'
         if use_graph:       # the schedule values live on the device so that one captured step can be replayed for every step index
             self._scale_t = torch.zeros((), device=dev)
             self._wn = torch.zeros_like(self.w_opt)
@@ -354,11 +358,12 @@ class LatentProjector:
                 R = res * res
                 self._uni = torch.empty(N * R * (Dc + Df), device=dev)
                 self._uni_views = (self._uni[:N * R * Dc].view(N, R, Dc, 1), self._uni[N * R * Dc:].view(N * R, Df))
-            self.optimizer = torch.optim.Adam([self.w_opt] + self._opt_bufs, betas=(0.9, 0.999), lr=torch.tensor(float(first_inv_lr), device=dev),
-                                              fused=True, capturable=True)
+            self.optimizer = (hipops.HipAdam if hip_adam else functools.partial(torch.optim.Adam, fused=True, capturable=True))(
+                [self.w_opt] + self._opt_bufs, betas=(0.9, 0.999), lr=torch.tensor(float(first_inv_lr), device=dev))
         else:
             self._uni = None
-            self.optimizer = torch.optim.Adam([self.w_opt] + self._opt_bufs, betas=(0.9, 0.999), lr=first_inv_lr, fused=True)
+            self.optimizer = (hipops.HipAdam if hip_adam else functools.partial(torch.optim.Adam, fused=True))(
+                [self.w_opt] + self._opt_bufs, betas=(0.9, 0.999), lr=first_inv_lr)
         self.intrinsic = torch.tensor([4.2647, 0, 0.5, 0, 4.2647, 0.5, 0, 0, 1], device=dev).unsqueeze(0)
         self.init_ext = torch.tensor([1, 0, 0, 0, 0, -1, 0, 0, 0, 0, -1, 2.7, 0, 0, 0, 1.], device=dev).reshape(1, 4, 4)
         self.canonical_cam = torch.cat([self.init_ext.reshape(1, 16), self.intrinsic], -1)
@@ -538,19 +543,24 @@ class LatentProjector:
         if self._one is None:
             self._one = torch.ones((), device=dist.device)          # the seed gradient, allocated once (backward() would fill a new one per step)
         (dist if warp is None else dist + warp).backward(gradient=self._one)
-        have = [(b.grad, g) for b, g in zip(self._opt_bufs, reg_grads) if b.grad is not None]
-        for b, g in zip(self._opt_bufs, reg_grads):
-            if b.grad is None:                 # a backbone buffer the synthesis did not read (noise_mode overridden): regulariser only
-                b.grad = g
-        if have:
-            torch._foreach_add_([a for a, _ in have], [g for _, g in have])
+        fused_adam = isinstance(self.optimizer, hipops.HipAdam) and do_step
+        if not fused_adam:
+            have = [(b.grad, g) for b, g in zip(self._opt_bufs, reg_grads) if b.grad is not None]
+            for b, g in zip(self._opt_bufs, reg_grads):
+                if b.grad is None:                 # a backbone buffer the synthesis did not read (noise_mode overridden): regulariser only
+                    b.grad = g
+            if have:
+                torch._foreach_add_([a for a, _ in have], [g for _, g in have])
         if self.optimize_pose:                 # order of w_projector.py:249-261
             self.cam_optimizer.step()
-        if do_step:
+        if fused_adam:                         # regulariser gradient, update and renormalisation of the maps in two launches
+            self.optimizer.step(extra_grads=dict(zip(self._opt_bufs, reg_grads)), normalize={b: self.N for b in self._all_bufs})
+        elif do_step:
             self.optimizer.step()
         if self.optimize_pose:
             self.translation_optimizer.step()
-        hipops.noise_normalize_(self._all_bufs if self._buf_views is None else self._buf_views)   # buf -= mean; buf *= rsqrt(mean(buf^2)) (w_projector.py:264-270)
+        if not fused_adam:
+            hipops.noise_normalize_(self._all_bufs if self._buf_views is None else self._buf_views)   # buf -= mean; buf *= rsqrt(mean(buf^2)) (w_projector.py:264-270)
         if not torch.cuda.is_current_stream_capturing():
             # the feature distance is accumulated into a slice of the step's ZeroArena, which the next step clears: callers that collect
             # per-step values lazily must get their own copy (under graph replay `last` is documented as static buffers)

@@ -491,6 +491,31 @@ int eg3d_noise_regularizer(float* const* x, float* const* grad, const int32_t* r
                            float* reg_out, float scale, void* stream);
 int eg3d_noise_normalize(float* const* x, const int32_t* res, int nbufs, float* workspace, void* stream);
 
+/* torch.optim.Adam(betas, eps; no weight decay, no amsgrad) over up to EG3D_ADAM_ITEMS_MAX leaves in one launch (the projector's
+ * optimiser, w_projector.py:107-118,256): p, m (exp_avg), v (exp_avg_sq) updated in place from the gradient g + g2 (one of them may be
+ * null).  lr and step are DEVICE scalars (a captured graph is replayed for every step index): step holds the number of updates already
+ * made as a float and is incremented by the launch when bump_step != 0 (several launches of one optimiser step: set it on the last).
+ * normalize != 0: the leaf is then renormalised in place, p <- (p - mean(p)) * rsqrt(var(p)) (w_projector.py:264-270), by a second launch.
+ * workspace: 2*n + 1 ZEROED floats (moments of the flagged leaves, retirement counter; left zeroed-counter on exit). */
+#define EG3D_ADAM_ITEMS_MAX 32
+typedef struct {
+    float* p;
+    const float* g;
+    const float* g2;
+    float* m;
+    float* v;
+    int64_t n;
+    int32_t normalize, pad_;
+} eg3d_adam_item;
+typedef struct {
+    int32_t n, bump_step;
+    float beta1, beta2, eps, pad_;
+    const float* lr;
+    float* step;
+    eg3d_adam_item items[EG3D_ADAM_ITEMS_MAX];
+} eg3d_adam_list;
+int eg3d_adam_step(const eg3d_adam_list* list, float* workspace, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Volume renderer -- replaces RaySampler.forward (training/volumetric_rendering/ray_sampler.py:24-73) and
  * ImportanceRenderer.forward (renderer.py:143-195: sample_stratified, sample_from_planes/grid_sample, OSGDecoder

@@ -594,6 +594,44 @@ def test_noise_regularizer_and_normalize():
         close(a, e, 1e-5, 'noise normalize')
 
 
+def test_hip_adam_matches_torch_adam_with_regulariser_gradient_and_renormalisation():
+    """eg3d_adam_step against torch.optim.Adam on the same leaves (w_projector.py:107-118,256-270): gradient = autograd's + a second list,
+    maps renormalised after the update, learning rate changed between steps, 40 leaves (two banks), one leaf without any gradient."""
+    from inv3d_amd import hipops as H
+    g = torch.Generator().manual_seed(77)
+    shapes = [(1, 1, 512)] + [(2, 1, r, r) for r in (4, 8, 16, 32, 64, 128)] * 6 + [(2, 1, 512, 512), (3, 5), (7,)]
+    init = [torch.randn(s, generator=g) for s in shapes]
+    ref = [t.clone().to(DEV).requires_grad_(True) for t in init]
+    mine = [t.clone().to(DEV).requires_grad_(True) for t in init]
+    maps_r, maps_m = ref[1:-2], mine[1:-2]
+    o_ref = torch.optim.Adam(ref, lr=0.1, betas=(0.9, 0.999))
+    o_mine = H.HipAdam(mine, lr=torch.tensor(0.1, device=DEV), betas=(0.9, 0.999))
+    for step in range(6):
+        lr = 0.1 * (1.0 - 0.12 * step)
+        grads = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+        extra = [torch.randn(t.shape, generator=g).to(DEV) * 0.3 for t in init[1:-2]]
+        for p, q, gr in zip(ref, mine, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        ref[-1].grad = mine[-1].grad = None                     # never receives a gradient: untouched, as in torch
+        if step % 2:
+            maps_r[3].grad = None                               # regulariser gradient only
+            maps_m[3].grad = None
+        for p, e in zip(maps_r, extra):
+            p.grad = e.clone() if p.grad is None else p.grad + e
+        o_ref.param_groups[0]['lr'] = lr
+        o_ref.step()
+        with torch.no_grad():
+            for p in maps_r:                                    # per image of the batch
+                p -= p.mean(dim=(1, 2, 3), keepdim=True)
+                p *= p.square().mean(dim=(1, 2, 3), keepdim=True).rsqrt()
+        o_mine.param_groups[0]['lr'].fill_(lr)
+        o_mine.step(extra_grads=dict(zip(maps_m, extra)), normalize={p: 2 for p in maps_m})
+        for i, (p, q) in enumerate(zip(ref, mine)):
+            close(q.detach(), p.detach(), 2e-5, f'adam leaf {i} step {step}')
+    assert float(o_mine.step_t) == 6.0
+    assert torch.equal(mine[-1].detach().cpu(), init[-1])
+
+
 @pytest.mark.parametrize('shape', [(1, 32, 64, 16, 16, 1), (2, 160, 96, 12, 9, 1), (1, 128, 128, 8, 8, 2), (1, 4, 16, 10, 10, 1), (1, 128, 256, 32, 40, 1),
                                    (2, 72, 136, 12, 24, 1), (1, 256, 128, 4, 8, 1)])
 @pytest.mark.parametrize('prec,tol', [('f32', 2e-5), ('f16x3', 2e-5)])

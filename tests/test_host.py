@@ -251,6 +251,13 @@ def test_round2_entry_points_reject_bad_arguments_before_touching_the_gpu():
     assert lib.eg3d_torgb_dgrad_act_split(a, a, a, a, None, None, None, 1, 8, 8, 16, C.byref(ab), None, None, a, a, None) < 0      # no max|dy|
     assert lib.eg3d_torgb_dgrad_act_split(a, a, a, a, a, None, None, 1, 8, 8, 16, C.byref(ab), a, None, a, a, None) < 0            # addend without its maximum
     assert lib.eg3d_torgb_dgrad_act_split(a, a, a, a, None, None, None, 1, 8, 8, 20, C.byref(ab), a, None, a, a, None) < 0         # C % 8
+    ad = L.AdamList(n=1, bump_step=1, beta1=0.9, beta2=0.999, eps=1e-8, lr=a, step=a)
+    ad.items[0] = L.AdamItem(a, None, None, a, a, 16, 0)
+    assert lib.eg3d_adam_step(C.byref(ad), a, None) < 0                              # no gradient at all
+    ad.items[0] = L.AdamItem(a, a, None, a, a, 16, 0)
+    assert lib.eg3d_adam_step(C.byref(ad), None, None) < 0                           # no workspace
+    ad.n = L.ADAM_ITEMS_MAX + 1
+    assert lib.eg3d_adam_step(C.byref(ad), a, None) < 0
     ul = L.UnitLevels(n=1, N=1, eps=1e-10, feat_nstride=64)
     ul.levels[0] = L.UnitLevel(x=a, scale=None, feat=a, dx=None, HW=4, C=16, ldx=16, mul=1.0)
     assert lib.eg3d_unit_normalize_levels(C.byref(ul), 1, None) < 0                  # backward without dx
