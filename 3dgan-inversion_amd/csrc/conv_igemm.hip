@@ -96,6 +96,22 @@ __host__ __device__ constexpr int conv_min_waves(int bm, int bn, int waves, int 
     return waves != 4 ? 1 : (prec ? (per_thread <= 4 && vec ? 3 : 2) : (per_thread <= 8 ? 2 : 1));
 }
 
+// upfirdn2d.upsample2d at one output pixel for a separable 4-tap filter t (true convolution, padding (2, 1), zero outside):
+//   out[2i] = t[3] x[i-1] + t[1] x[i],   out[2i+1] = t[2] x[i] + t[0] x[i+1]   along each axis.  low -> this lane's four channels of pixel (0, 0).
+__device__ __forceinline__ float4 fir_up2_at(const float* __restrict__ low, int ld, int Hl, int Wl, int y, int x, const float* t) {
+    const int oy = y & 1, ox = x & 1;
+    const int r0 = (y >> 1) - 1 + oy, c0 = (x >> 1) - 1 + ox;
+    const float wy0 = oy ? t[2] : t[3], wy1 = oy ? t[0] : t[1], wx0 = ox ? t[2] : t[3], wx1 = ox ? t[0] : t[1];
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool ra = r0 >= 0, rb = r0 + 1 < Hl, ca = c0 >= 0, cb = c0 + 1 < Wl;
+    const float* q = low + ((int64_t)r0 * Wl + c0) * ld;
+    const float4 A = (ra && ca) ? *reinterpret_cast<const float4*>(q) : z, B = (ra && cb) ? *reinterpret_cast<const float4*>(q + ld) : z;
+    const float4 Cc = (rb && ca) ? *reinterpret_cast<const float4*>(q + (int64_t)Wl * ld) : z;
+    const float4 D = (rb && cb) ? *reinterpret_cast<const float4*>(q + (int64_t)Wl * ld + ld) : z;
+    return make_float4(wy0 * (wx0 * A.x + wx1 * B.x) + wy1 * (wx0 * Cc.x + wx1 * D.x), wy0 * (wx0 * A.y + wx1 * B.y) + wy1 * (wx0 * Cc.y + wx1 * D.y),
+                       wy0 * (wx0 * A.z + wx1 * B.z) + wy1 * (wx0 * Cc.z + wx1 * D.z), wy0 * (wx0 * A.w + wx1 * B.w) + wy1 * (wx0 * Cc.w + wx1 * D.w));
+}
+
 template <int BM, int BN, int WM, int WN, int PREC, bool VEC>
 __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, PREC, VEC)) conv_igemm_kernel(const eg3d_conv_params p) {
     constexpr int NT = WM * WN * 64;                        // 4 or 8 waves
@@ -480,7 +496,14 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
                 pixl[u] = pix - n_first * HWo;
                 va[u] = *reinterpret_cast<const float4*>(stage + row * LDS_N + c4 * 4);
                 sa[u] = make_float4(0.f, 0.f, 0.f, 0.f); sb[u] = sa[u]; nz[u] = 0.f;
-                if (ok && (epi == EG3D_EPI_FWD || bwd_like) && p.addend != nullptr) sa[u] = *reinterpret_cast<const float4*>(p.addend + offs[u]);
+                if (ok && (epi == EG3D_EPI_FWD || bwd_like) && p.addend != nullptr) {
+                    if (epi == EG3D_EPI_FWD && p.addend_up2) {      // the skip image lives at half resolution: 2 x 2 taps of the separable FIR
+                        const int yy = pixl[u] / p.Wo, xx = pixl[u] - yy * p.Wo;
+                        sa[u] = fir_up2_at(p.addend + (int64_t)n_first * (HWo >> 2) * p.ldo + col, p.ldo, p.Ho >> 1, p.Wo >> 1, yy, xx, p.addend_taps);
+                    } else {
+                        sa[u] = *reinterpret_cast<const float4*>(p.addend + offs[u]);
+                    }
+                }
                 if (ok && epi == EG3D_EPI_FWD && p.noise != nullptr) nz[u] = p.noise[(int64_t)n_first * p.noise_nstride + pixl[u]];
                 if (ok && act_on && ab.noise != nullptr) nz[u] = ab.noise[(int64_t)n_first * ab.noise_nstride + pixl[u]];
                 if (ok && (do_ds || act_on)) sb[u] = *reinterpret_cast<const float4*>(p.xin + offs[u]);
@@ -664,7 +687,11 @@ int launch_conv_pv(const eg3d_conv_params& p, hipStream_t st) {
 
 template <int BM, int BN, int WM, int WN, int PREC>
 int launch_conv_p(const eg3d_conv_params& p, hipStream_t st) {
-    return conv_vector_epilogue_ok<BM>(p) ? launch_conv_pv<BM, BN, WM, WN, PREC, true>(p, st) : launch_conv_pv<BM, BN, WM, WN, PREC, false>(p, st);
+    const bool vec = conv_vector_epilogue_ok<BM>(p);
+    if (p.addend_up2 && !(vec && p.epi == EG3D_EPI_FWD && p.addend && p.ncls == 1 && p.out_stride == 1 && !(p.Ho & 1) && !(p.Wo & 1) &&
+                          p.cls[0].Ha == p.Ho && p.cls[0].Wa == p.Wo))
+        return EG3D_ERR_UNSUPPORTED;
+    return vec ? launch_conv_pv<BM, BN, WM, WN, PREC, true>(p, st) : launch_conv_pv<BM, BN, WM, WN, PREC, false>(p, st);
 }
 
 template <int BM, int BN, int WM, int WN>

@@ -23,11 +23,12 @@
 namespace {
 // FULL: three products per fp32 product; !FULL: high pieces only (EG3D_PREC_F16X1); ATOMIC: split-K; RPW: patch rows per wave -- 4 = the 8 x 32
 // patch (256 cells), 2 = a 4 x 32 patch (128 cells x 128 channels per workgroup, 12 MFMAs per wave and step): twice the workgroups for the
-// layers whose 8-row grids leave CUs idle (128^2 x 256: 128 -> 256), with the fused epilogues intact (split-K needs a zero fill + a finishing pass)
+// layers whose 8-row grids leave CUs idle (128^2 x 256: 128 -> 256), with the fused epilogues intact (split-K needs a zero fill + a finishing pass);
+// 1 = a 2 x 32 patch (64 cells: 64^2 x 512 -> 256 workgroups)
 template <int NTAPS, bool FULL = true, bool ATOMIC = false, int RPW = 4>
 __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_params p, const int cls_base) {
     constexpr int PHK = 2 * RPW;                          // patch rows of this instantiation
-    constexpr int NPARTS = RPW == 4 ? 6 : 4;              // 64-slot wave-instructions per A plane: halo <= (PHK + 2) x 34 slots
+    constexpr int NPARTS = ((PHK + 2) * (PW + 2) + 63) / 64;      // 64-slot wave-instructions per A plane: halo <= (PHK + 2) x 34 slots (6 | 4 | 3)
     constexpr int APT = (NPARTS + NTAPS - 1) / NTAPS;     // A parts a wave issues per step
     constexpr int NA_TAPS = NPARTS / APT;                 // ... during the first NA_TAPS taps of a chunk (APT divides NPARTS)
     static_assert(NPARTS % APT == 0, "A parts per step");
@@ -367,7 +368,7 @@ __global__ void __launch_bounds__(256) split_w_batched_kernel(const eg3d_split_w
     }
 }
 
-std::atomic<uint64_t> g_attr[9];
+std::atomic<uint64_t> g_attr[11];
 
 template <int NTAPS, bool FULL = true, bool ATOMIC = false, int RPW = 4>
 int launch_v2(const eg3d_conv_v2_params& p, int cls_base, int ncls, int max_tiles, hipStream_t st, int slot) {
@@ -392,8 +393,8 @@ extern "C" int eg3d_conv2d_v2_supported(const eg3d_conv_v2_params* pp) {
     if (p.epi == EG3D_EPI_ATOMIC)                         // the split-K instantiations exist for the 3x3 classes
         for (int c = 0; c < p.ncls; ++c) if (p.cls[c].ntaps != 9) return 0;
     if (p.ksplit > 1 && (p.epi != EG3D_EPI_ATOMIC || p.ksplit > p.Ck / 16 || p.ksplit > 65535)) return 0;     // every slice owns >= 1 chunk
-    if (p.patch_rows != 0 && p.patch_rows != 8 && p.patch_rows != 4) return 0;
-    if (p.patch_rows == 4) {                              // the half-height patch is instantiated for the fused 3x3 launches
+    if (p.patch_rows != 0 && p.patch_rows != 8 && p.patch_rows != 4 && p.patch_rows != 2) return 0;
+    if (p.patch_rows == 4 || p.patch_rows == 2) {         // the half / quarter-height patches are instantiated for the fused 3x3 launches
         if (p.epi == EG3D_EPI_ATOMIC) return 0;
         for (int c = 0; c < p.ncls; ++c) if (p.cls[c].ntaps != 9) return 0;
     }
@@ -433,14 +434,15 @@ extern "C" int eg3d_conv2d_v2(const eg3d_conv_v2_params* pp, void* stream) {
         int e = c;
         int max_tiles = 0;
         while (e < p.ncls && p.cls[e].ntaps == p.cls[c].ntaps) {
-            const int t = p.N * eg3d_cdiv(p.cls[e].Ha, p.patch_rows == 4 ? 4 : PH) * eg3d_cdiv(p.cls[e].Wa, PW) * (p.Nc / BN);
+            const int t = p.N * eg3d_cdiv(p.cls[e].Ha, p.patch_rows == 4 || p.patch_rows == 2 ? p.patch_rows : PH) * eg3d_cdiv(p.cls[e].Wa, PW) * (p.Nc / BN);
             max_tiles = std::max(max_tiles, t);
             ++e;
         }
         int rc;
         switch (p.cls[c].ntaps) {
             case 9:
-                if (p.patch_rows == 4) rc = p.products == 1 ? launch_v2<9, false, false, 2>(p, c, e - c, max_tiles, st, 8) : launch_v2<9, true, false, 2>(p, c, e - c, max_tiles, st, 7);
+                if (p.patch_rows == 2) rc = p.products == 1 ? launch_v2<9, false, false, 1>(p, c, e - c, max_tiles, st, 10) : launch_v2<9, true, false, 1>(p, c, e - c, max_tiles, st, 9);
+                else if (p.patch_rows == 4) rc = p.products == 1 ? launch_v2<9, false, false, 2>(p, c, e - c, max_tiles, st, 8) : launch_v2<9, true, false, 2>(p, c, e - c, max_tiles, st, 7);
                 else if (p.epi == EG3D_EPI_ATOMIC) rc = p.products == 1 ? launch_v2<9, false, true>(p, c, e - c, max_tiles, st, 6) : launch_v2<9, true, true>(p, c, e - c, max_tiles, st, 5);
                 else rc = p.products == 1 ? launch_v2<9, false>(p, c, e - c, max_tiles, st, 4) : launch_v2<9>(p, c, e - c, max_tiles, st, 0);
                 break;

@@ -50,7 +50,8 @@ class ConvParams(C.Structure):
                 ('in_scale', C.c_void_p), ('epi', C.c_int32), ('ksplit', C.c_int32),
                 ('out_scale', C.c_void_p), ('bias', C.c_void_p), ('noise', C.c_void_p), ('noise_nstride', C.c_int64),
                 ('noise_strength', C.c_void_p), ('act', C.c_int32), ('alpha', C.c_float), ('gain', C.c_float),
-                ('clamp', C.c_float), ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p), ('precision', C.c_int32), ('a_amax', C.c_void_p), ('a_amax_mul', C.c_float), ('ds_replicas', C.c_int32), ('out_amax', C.c_void_p), ('act_bwd', ActBwd), ('w_presplit', C.c_int32)]
+                ('clamp', C.c_float), ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p), ('precision', C.c_int32), ('a_amax', C.c_void_p), ('a_amax_mul', C.c_float), ('ds_replicas', C.c_int32), ('out_amax', C.c_void_p), ('act_bwd', ActBwd), ('w_presplit', C.c_int32),
+                ('addend_up2', C.c_int32), ('addend_taps', C.c_float * 4)]
 
 
 class ConvV2Params(C.Structure):

@@ -198,6 +198,7 @@ def _auto_ksplit(classes, N, Nc, Ck):
 # this layer's activation backward in the same epilogue -- and hands back dz in place of dout.  This layer's backward recognises the
 # buffer and skips its own pass.
 FUSE_ACT_BWD = os.environ.get('EG3D_FUSE_ACT_BWD', '1') != '0'
+FUSE_SKIP_UP = os.environ.get('EG3D_FUSE_SKIP_UP', '1') != '0'   # skip image up-sampled inside the toRGB conv's epilogue (eg3d_conv_params::addend_up2)
 SPLIT_DZ = os.environ.get('EG3D_SPLIT_DZ', '1') != '0'         # ... and write dz as the data gradient's fp16 operand image where it can (torgb_dgrad_act_split)
 _DX_AMAX = {}                 # dx.data_ptr() -> (device scalar max|dx| reported by the data-gradient kernel that wrote it, weak ref to dx); read once by a toRGB backward
 _DZ_TOKEN = {}                # device -> 1-element tensor: expanded, it stands in for a dz that only exists as an operand image
@@ -280,7 +281,11 @@ class ModConvLayerFn(torch.autograd.Function):
         ks = _auto_ksplit(cls, N, Co, Ci)
         # (transposed-conv classes run on it too, but measured slower than the loader-split kernel: three launches of 4 / 2 / 1-tap
         #  classes on ragged 257-wide grids -- 196 vs 174 us on 256^2 x 256 -> 513^2 x 128, 116 vs 67 us on 128^2 x 256; opt-in)
-        v2 = H.USE_V2 and prec in ('f16x3', 'f16x1') and ks == 1 and (up == 1 or (H.V2_CONVT and prec == 'f16x3')) and H.conv_v2_supported(Ci, Co, cls, N)
+        # (a grid the pre-split kernel fills with its 2-row patches -- 64^2 x 512 -- goes there un-split rather than to a split-K launch)
+        v2 = H.USE_V2 and prec in ('f16x3', 'f16x1') and (up == 1 or (H.V2_CONVT and prec == 'f16x3')) and H.conv_v2_supported(Ci, Co, cls, N)
+        v2 = v2 and (ks == 1 or (up == 1 and H.conv_v2_rows(Ci, Co, cls, N) == 2))
+        if v2:
+            ks = 1
         nprod = 1 if prec == 'f16x1' else 3
         # 3x3 layers whose grids cannot fill the chip (128^2 x 256, 64^2 x 512, 32^2 x 512): the pre-split kernel with the contraction
         # split over workgroups (atomic partial tiles) + the finishing epilogue pass
@@ -357,7 +362,7 @@ class ModConvLayerFn(torch.autograd.Function):
             rec.split_ok = False
             if SPLIT_DZ and up == 1 and not (ng[1] and want_wgrad) and prec in ('f16x3', 'f16x1') and H.USE_V2 and Co % 8 == 0 and (ng[0] or ng[2]):
                 cls_adj0 = H.classes_corr_adjoint(Hi, Wi, kh, kw, kh // 2)
-                rec.split_ok = bool(_auto_ksplit(cls_adj0, N, Ci, Co) == 1 and H.conv_v2_supported(Co, Ci, cls_adj0, N))
+                rec.split_ok = bool((_auto_ksplit(cls_adj0, N, Ci, Co) == 1 or H.conv_v2_rows(Co, Ci, cls_adj0, N) == 2) and H.conv_v2_supported(Co, Ci, cls_adj0, N))
         if rec is not None:             # (a no-grad forward of the same layer -- the canonical view of the warping loss -- leaves a pending record alone)
             _set_producer(cache, rec)
         ctx.rec = rec                   # THIS forward's record: the backward below trusts only it (two live graphs of one layer cannot mix)
@@ -457,7 +462,7 @@ class ModConvLayerFn(torch.autograd.Function):
                     _DX_AMAX[dx.data_ptr()] = (dx_amax, weakref.ref(dx))
                 did = H.conv_v2_s2adj(gimg, cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, algo_flops=aflops,
                                       products=1 if prec == 'f16x1' else 3, **fkw)
-            elif H.USE_V2 and up == 1 and ks == 1 and prec in ('f16x3', 'f16x1') and H.conv_v2_supported(Co, Ci, cls_adj, N):
+            elif H.USE_V2 and up == 1 and (ks == 1 or H.conv_v2_rows(Co, Ci, cls_adj, N) == 2) and prec in ('f16x3', 'f16x1') and H.conv_v2_supported(Co, Ci, cls_adj, N):
                 did = H.conv_v2(dz_img if dz_img is not None else H.split_activation(g, amax), cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD,
                                 out_scale=styles, xin=x, ds=ds, algo_flops=aflops, products=1 if prec == 'f16x1' else 3, **fkw)
                 dz_img = None
@@ -611,8 +616,10 @@ class ToRGBFn(torch.autograd.Function):
     """y = clamp(conv1x1(x * styles, W) + bias);  out = skip + y (skip optional).  Small channel counts are padded to 4."""
 
     @staticmethod
-    def forward(ctx, x, weight, styles, bias, skip, clamp, cache, want_wgrad, passthrough=False, input_is_layer_output=False):
-        """passthrough=True additionally returns x itself: the consumer of that output (the next block's conv0) then sends its
+    def forward(ctx, x, weight, styles, bias, skip, clamp, cache, want_wgrad, passthrough=False, input_is_layer_output=False, skip_up=False):
+        """skip_up=True: `skip` is the HALF-resolution skip image; what is added is upsample2d(skip, [1,3,3,1]) -- inside the conv's epilogue
+        where that is possible (no clamp, even size), by UpsampleImgFn's kernel otherwise.
+        passthrough=True additionally returns x itself: the consumer of that output (the next block's conv0) then sends its
         gradient through THIS backward, where it is added inside the data-gradient epilogue instead of by a separate autograd add
         (3 x tensor bytes per block, 67 MB tensors in the SR head)."""
         L.require_cuda(x, weight, styles)
@@ -629,20 +636,34 @@ class ToRGBFn(torch.autograd.Function):
             b = bias.contiguous().float() if bias is not None else None
         cls = H.classes_corr(Hh, Ww, 1, 1, 0)
         y = None
+        up_taps = None
         if skip is not None:
             skip = H.to_cl(skip.float())
             assert skip.shape[1] == Cp
+            if skip_up:
+                if FUSE_SKIP_UP and clampv < 0 and Hh % 2 == 0 and Ww % 2 == 0 and tuple(skip.shape[2:]) == (Hh // 2, Ww // 2) and (N == 1 or (Hh * Ww) % 128 == 0):
+                    up_taps = (0.25, 0.75, 0.75, 0.25)          # [1,3,3,1] / 8, times the per-axis gain 2
+                else:
+                    skip = H.upfirdn2d_nhwc(skip, fir44(skip.device), up=2, pad=(2, 1, 2, 1), gain=4.0)
         if clampv < 0 and skip is not None:
             out = H.empty_cl(N, Cp, Hh, Ww, x.device)
-            H.conv_igemm(x, wf, Ci, Cp, out, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=-1.0, addend=skip,
-                         precision=H.modconv_precision())
+            try:
+                H.conv_igemm(x, wf, Ci, Cp, out, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=-1.0, addend=skip,
+                             precision=H.modconv_precision(), addend_up2_taps=up_taps)
+            except RuntimeError:
+                if up_taps is None:
+                    raise
+                # the launch could not take the half-resolution image (tile / alignment conditions of the vector epilogue): up-sample first
+                skip = H.upfirdn2d_nhwc(skip, fir44(skip.device), up=2, pad=(2, 1, 2, 1), gain=4.0)
+                H.conv_igemm(x, wf, Ci, Cp, out, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=-1.0, addend=skip,
+                             precision=H.modconv_precision())
         else:
             y = H.empty_cl(N, Cp, Hh, Ww, x.device)
             H.conv_igemm(x, wf, Ci, Cp, y, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=clampv,
                          precision=H.modconv_precision())
             out = y + skip if skip is not None else y
         ctx.save_for_backward(x, weight, styles, y if clampv >= 0 else None)
-        ctx.cfg = (clampv, cache, want_wgrad, Cp, skip is not None)
+        ctx.cfg = (clampv, cache, want_wgrad, Cp, skip is not None, bool(skip_up))
         ctx.fuse_input = bool(input_is_layer_output)         # x is conv1's output handed over directly (see ModConvLayerFn)
         if not passthrough:
             return out
@@ -654,7 +675,7 @@ class ToRGBFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, dx_pass=None):
         x, weight, styles, y = ctx.saved_tensors
-        clampv, cache, want_wgrad, Cp, has_skip = ctx.cfg
+        clampv, cache, want_wgrad, Cp, has_skip, skip_up = ctx.cfg
         need_x, need_w, need_s, need_b, need_skip = ctx.needs_input_grad[:5]
         need_w = need_w and want_wgrad
         dout = H.to_cl(dout.float())
@@ -715,7 +736,10 @@ class ToRGBFn(torch.autograd.Function):
             else:
                 H.conv_wgrad(x, dy, Ci, Co, dwp, H.classes_corr(Hh, Ww, 1, 1, 0), in_scale=styles)
             dweight = dwp.view(Co, Ci, 1, 1)
-        return (dx if need_x else None, dweight, ds if need_s else None, dbias, dout if (need_skip and has_skip) else None, None, None, None, None, None)
+        dskip = None
+        if need_skip and has_skip:        # the adjoint of the up-sampling when the node took the half-resolution image
+            dskip = H.upfirdn2d_nhwc(dout, fir44(dev), down=2, pad=(1, 1, 1, 1), flip=True, gain=4.0) if skip_up else dout
+        return (dx if need_x else None, dweight, ds if need_s else None, dbias, dskip, None, None, None, None, None, None)
 
 
 class _SliceRgb4Fn(torch.autograd.Function):

@@ -364,7 +364,7 @@ class ActBwdSpec:
 def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=None, epi=L.EPI_STORE, ksplit=1,
                out_scale=None, bias=None, noise=None, noise_nstride=0, noise_strength=None, act='linear', alpha=0.0, gain=1.0,
                clamp=-1.0, addend=None, xin=None, ds=None, algo_flops=None, precision=None, a_amax=None, a_amax_mul=1.0, out_amax=None,
-               act_bwd=None, w_pieces=None):
+               act_bwd=None, w_pieces=None, addend_up2_taps=None):
     """Launch eg3d_conv2d_igemm_f32.  x/out/addend/xin: channels_last fp32 [N,C,H,W]; wp: packed weights [Nc, taps*Ck].
     act_bwd (an ActBwdSpec, with epi=EPI_BWD): try EPI_BWD_ACT; returns True when the fused epilogue ran (out then holds the producing
     layer's dz), False when the launch was a plain EPI_BWD."""
@@ -389,6 +389,9 @@ def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=
     p.noise_strength = noise_strength.data_ptr() if noise_strength is not None else None
     p.act, p.alpha, p.gain, p.clamp = L.ACT_IDS[act], float(alpha), float(gain), float(clamp)
     p.addend = addend.data_ptr() if addend is not None else None
+    if addend_up2_taps is not None:             # addend is the half-resolution skip image, up-sampled inside the epilogue
+        p.addend_up2 = 1
+        p.addend_taps[:] = [float(t) for t in addend_up2_taps]
     p.xin = xin.data_ptr() if xin is not None else None
     p.ds = ds.data_ptr() if ds is not None else None
     p.precision = CONV_PRECISION if precision is None else PRECISIONS[precision]
@@ -543,7 +546,7 @@ def conv_v2_geometry_ok(Ck, Nc, classes):
 
 
 def conv_v2_rows(Ck, Nc, classes, N=1):
-    """Patch rows (8 | 4) the pre-split kernel should run this launch with, 0 = not a launch for it.  8 x 32-cell patches when they fill the
+    """Patch rows (8 | 4 | 2) the pre-split kernel should run this launch with, 0 = not a launch for it.  8 x 32-cell patches when they fill the
     chip (>= V2_MIN_TILES workgroups); nine-tap classes whose 8-row grid does not but whose 4-row grid does (128^2 x 256: 128 -> 256
     workgroups) take the half-height patch -- fused epilogues intact, no split-K."""
     if not conv_v2_geometry_ok(Ck, Nc, classes):
@@ -553,7 +556,11 @@ def conv_v2_rows(Ck, Nc, classes, N=1):
     tiles4 = sum(N * -(-c.Ha // 4) * -(-c.Wa // 32) for c in classes) * (Nc // 128)
     if half_ok and tiles8 < V2_HALF_BELOW and tiles4 >= V2_MIN_TILES:
         return 4
-    return 8 if tiles8 >= V2_MIN_TILES else 0
+    if tiles8 >= V2_MIN_TILES:
+        return 8
+    # 64^2 x 512 (64 workgroups of 8 rows): 2 x 32-cell patches give 256 (opt-in: V2_QUARTER)
+    tiles2 = sum(N * -(-c.Ha // 2) * -(-c.Wa // 32) for c in classes) * (Nc // 128)
+    return 2 if (half_ok and V2_QUARTER and tiles2 >= V2_MIN_TILES) else 0
 
 
 def conv_v2_supported(Ck, Nc, classes, N=1):
@@ -580,6 +587,10 @@ V2_CONVT = os.environ.get('EG3D_V2_CONVT', '0') == '1'
 # first half of round 3: with the fused epilogues a few hundred of 8 M output elements per launch came out wrong on full-size layers --
 # a miscompile of the scalar epilogue arithmetic by the SLP vectoriser, see the Makefile; tests/test_gpu_ops.py::test_conv_v2_half_patch_full_size.)
 V2_HALF = os.environ.get('EG3D_V2_HALF', '1') != '0'             # half-height (4 x 32) patches for nine-tap launches ...
+# quarter-height (2 x 32) patches where not even the 4-row grid fills the chip (64^2 x 512: 64 -> 256 workgroups): OFF by default.  Stand-alone
+# (weights warm in L2) 74 us against 99 + 23 (4-way split-K launch of the loader-split kernel + its finishing pass); inside the step, where every
+# workgroup streams its 2.4 MB weight slice from HBM / MALL, 109 us + the 12 us operand split: no gain (194.3 vs 194.3 steps/s, A/B in one session)
+V2_QUARTER = os.environ.get('EG3D_V2_QUARTER', '0') != '0'
 V2_HALF_BELOW = int(os.environ.get('EG3D_V2_HALF_BELOW', '512'))      # ... when the 8-row grid has fewer workgroups than this (256^2 x 128: 84 -> 67 us, 128^2 x 256: 107 -> 91 us)
 # split-K launches of the pre-split kernel for under-filled 3x3 grids: OFF by default.  Measured at N = 1 (MI355X): 128^2 x 256 118 -> 81 us,
 # 64^2 x 512 103 -> 82 us per launch, but the operand split pass (7 us), the zero fill and the finishing pass (2 x 10 us; the loader-split
@@ -603,7 +614,7 @@ def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_
     assert ksplit <= 1 or epi == L.EPI_ATOMIC
     if patch_rows is None:          # the caller did not plan: 4-row patches where they fill the chip and 8-row ones do not
         patch_rows = conv_v2_rows(p.Ck, p.Nc, classes, p.N) if epi != L.EPI_ATOMIC else 8
-    p.patch_rows = 4 if patch_rows == 4 else 8
+    p.patch_rows = patch_rows if patch_rows in (4, 2) else 8
     fused_act = False
     if act_bwd is not None and epi == L.EPI_BWD and xin is not None:
         p.epi = L.EPI_BWD_ACT
@@ -614,7 +625,7 @@ def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_
             p.epi = L.EPI_BWD
             p.act_bwd = L.ActBwd()
     prof = PROFILER
-    cfg_id = V2_CONFIG if p.patch_rows == 8 else V2H_CONFIG       # the two patch heights are different instantiations: separate profiler records
+    cfg_id = {8: V2_CONFIG, 4: V2H_CONFIG, 2: V2Q_CONFIG}[int(p.patch_rows)]   # the patch heights are different instantiations: separate profiler records
     if prof is not None and prof.only_config is not None and prof.only_config != cfg_id:
         prof = None
     if prof is not None:
@@ -693,6 +704,7 @@ def conv_v2_s2adj(a: SplitImage, w: SplitImage, out, classes, epi=L.EPI_STORE, o
 V2_CONFIG = 5        # "tile configuration" id of the pre-split kernel in profiler records (eg3d_conv2d_igemm_config returns 0..4)
 UP2_CONFIG = 6       # ... of the fused-parity transposed-conv kernel (csrc/conv_v2_up.hip)
 V2H_CONFIG = 8       # ... of the pre-split kernel's half-height (4 x 32) patch instantiation
+V2Q_CONFIG = 9       # ... of its quarter-height (2 x 32) patch instantiation
 V2_UP2 = os.environ.get('EG3D_V2_UP2', '1') != '0'
 UP2_MIN_TILES = int(os.environ.get('EG3D_UP2_MIN_TILES', '256'))      # workgroups (512 threads, 115 KB of LDS: one per CU) below which the layer stays on the loader-split kernel
 UP2_MIN_CK = int(os.environ.get('EG3D_UP2_MIN_CK', '64'))
@@ -1206,6 +1218,13 @@ class HipAdam:
                 items.append((p.data_ptr() + o, gr.data_ptr() + o if gr is not None else None, e.data_ptr() + o if e is not None else None,
                               st['exp_avg'].data_ptr() + o, st['exp_avg_sq'].data_ptr() + o, n, 1 if k else 0))
         dev = self.params[0].device
+        # the kernel writes through raw pointers: tell autograd / memo() that the leaves changed (no launch involved)
+        touched = [p for p in self.params if p.grad is not None or (extra_grads and extra_grads.get(p) is not None)]
+        bump = getattr(torch._C._autograd, '_unsafe_set_version_counter', None)
+        if bump is not None and touched:
+            bump(touched, [p._version + 1 for p in touched])
+        else:
+            weights_changed()
         for lo in range(0, len(items), L.ADAM_ITEMS_MAX):
             bank = items[lo:lo + L.ADAM_ITEMS_MAX]
             a = L.AdamList(n=len(bank), bump_step=int(lo + L.ADAM_ITEMS_MAX >= len(items)), beta1=g['betas'][0], beta2=g['betas'][1], eps=g['eps'],

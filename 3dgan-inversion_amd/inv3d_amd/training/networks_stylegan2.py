@@ -176,14 +176,14 @@ class ToRGBLayer(ReferenceStateMixin, torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros(out_channels))
         self._cache = fused.WeightCache()
 
-    def forward(self, x, w, fused_modconv=True, skip=None, styles=None, passthrough=False, input_is_layer_output=False):
+    def forward(self, x, w, fused_modconv=True, skip=None, styles=None, passthrough=False, input_is_layer_output=False, skip_up=False):
         """Returns skip + torgb(x) on a channel count padded to a multiple of 4 (padding channels stay as in `skip`/zero).
         `styles`: affine(w) * weight_gain when precomputed by the enclosing network.  passthrough=True: returns (img, x) where the
         second output is x routed through this op's autograd node (see fused.ToRGBFn)."""
         if styles is None:
             styles = self.affine(w) * self.weight_gain
         return fused.ToRGBFn.apply(x, self.weight, styles, self.bias, skip, self.conv_clamp, self._cache, self.weight.requires_grad, passthrough,
-                                   input_is_layer_output)
+                                   input_is_layer_output, skip_up)
 
 
 def _pad4(c):
@@ -246,13 +246,13 @@ class SynthesisBlock(ReferenceStateMixin, torch.nn.Module):
                            next_styles=s1, **layer_kwargs)
             x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), styles=s1, demod=next(d_iter), single_consumer=True,
                            input_is_layer_output=True, **layer_kwargs)
-        if img is not None:
-            img = fused.UpsampleImgFn.apply(img)
+        # the skip image is handed over at half resolution: the toRGB node up-samples it (inside its conv's epilogue where it can)
+        skip_up = img is not None
         if self.is_last:
-            img = self.torgb(x, next(w_iter), skip=img, styles=next(s_iter), input_is_layer_output=True)
+            img = self.torgb(x, next(w_iter), skip=img, styles=next(s_iter), input_is_layer_output=True, skip_up=skip_up)
         else:       # x goes on to the next block: route it through the toRGB node so the two gradients are summed in its epilogue
             amax = getattr(x, '_eg3d_amax', None)
-            img, x = self.torgb(x, next(w_iter), skip=img, styles=next(s_iter), passthrough=True, input_is_layer_output=True)
+            img, x = self.torgb(x, next(w_iter), skip=img, styles=next(s_iter), passthrough=True, input_is_layer_output=True, skip_up=skip_up)
             if amax is not None:        # the pass-through output is the same values: keep the producer's max|x| report with it
                 H.tag_amax(x, amax)
         return x, img

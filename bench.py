@@ -409,8 +409,8 @@ def main():
         dom = summ.get(dom_id)
         if dom and dom['ms'] > 0:
             ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-            is_v2 = dom_id[0] in (H.V2_CONFIG, H.V2H_CONFIG)
-            v2_rpw = 4 if dom_id[0] == H.V2_CONFIG else 2          # patch rows per wave: template argument of the instantiation
+            is_v2 = dom_id[0] in (H.V2_CONFIG, H.V2H_CONFIG, H.V2Q_CONFIG)
+            v2_rpw = {H.V2_CONFIG: 4, H.V2H_CONFIG: 2, H.V2Q_CONFIG: 1}.get(dom_id[0], 4)          # patch rows per wave: template argument of the instantiation
             dom_prec = {v: k for k, v in H.PRECISIONS.items()}[dom_id[1]]          # arithmetic of the dominant kernel's launches
             nprod = PRODUCTS[dom_prec]
             peak = FP32_MFMA_PEAK_TFLOPS if dom_prec == 'f32' else BF16_MFMA_PEAK_TFLOPS / nprod

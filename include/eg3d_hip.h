@@ -168,6 +168,12 @@ typedef struct eg3d_conv_params {
                                 * Ck multiples of 4): the loader copies the two fp16 pieces instead of forming them -- the weight-side half of
                                 * the split arithmetic, which this kernel is bound by, is then done once per weight instead of once per
                                 * workgroup and K-step.  Same bits, same results. */
+    int32_t addend_up2;        /* EPI_FWD, vector epilogue, one class, even Ho / Wo: `addend` is the HALF-resolution image [N,Ho/2,Wo/2,ldo] and
+                                * what is added is upfirdn2d.upsample2d(addend) with the separable 4-tap filter addend_taps (taps already
+                                * normalised and multiplied by the per-axis gain 2): the skip image of the 'skip' architecture
+                                * (networks_stylegan2.py:433-436) is up-sampled inside the toRGB launch instead of by its own pass.
+                                * EG3D_ERR_UNSUPPORTED when the conditions do not hold. */
+    float addend_taps[4];
 } eg3d_conv_params;
 
 /* 1 when this launch can run EG3D_EPI_BWD_ACT (aligned rows, channel counts that are multiples of 4, no split-K, tiles within one

@@ -376,6 +376,38 @@ def test_torgb_fwd_bwd(cfg):
         close(gg[-1][:, :co], dy[:, :co], 0, 'torgb dskip')
 
 
+@pytest.mark.parametrize('cfg', [(1, 16, 96, 8, None), (2, 32, 96, 16, None), (1, 16, 3, 32, None), (2, 16, 96, 6, None), (1, 16, 3, 16, 256.0)])
+def test_torgb_takes_the_skip_image_at_half_resolution(cfg):
+    """skip + toRGB of a 'skip' block (networks_stylegan2.py:433-436: img = upsample2d(img); img = img.add_(y)) with the up-sampling done
+    inside the conv's epilogue (eg3d_conv_params::addend_up2): against the oracle's upfirdn2d on the CPU, values and every gradient.  The
+    6 x 6, N = 2 case and the clamped case cannot take the fused form (tiles across images / clamp mask): they must fall back, same results."""
+    from inv3d_amd.training.networks_stylegan2 import ToRGBLayer
+    n, ci, co, res, clamp = cfg
+    g = torch.Generator().manual_seed(19)
+    P = {'T.weight': torch.randn(co, ci, 1, 1, generator=g), 'T.bias': torch.randn(co, generator=g) * 0.1,
+         'T.affine.weight': torch.randn(ci, 32, generator=g), 'T.affine.bias': torch.ones(ci)}
+    x = torch.randn(n, ci, res, res, generator=g)
+    w = torch.randn(n, 32, generator=g)
+    cp = (co + 3) // 4 * 4
+    low = torch.randn(n, cp, res // 2, res // 2, generator=g)
+    low[:, co:] = 0
+    dy = torch.randn(n, cp, res, res, generator=g)
+    dy[:, co:] = 0
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xr, wr, lr_ = x.clone().requires_grad_(True), w.clone().requires_grad_(True), low.clone().requires_grad_(True)
+    f = O.setup_filter([1, 3, 3, 1])
+    yr = O.torgb_layer(Pg, 'T', xr, wr, clamp) + O.upfirdn2d(lr_, f, up=2, padding=[2, 1, 2, 1], gain=4.0)[:, :co]
+    gr = torch.autograd.grad(yr, [xr, wr, lr_], dy[:, :co])
+    layer = ToRGBLayer(ci, co, w_dim=32, conv_clamp=clamp).to(DEV)
+    layer.load_state_dict({k[2:]: v for k, v in P.items()})
+    xg, wg, lg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True), low.to(DEV).requires_grad_(True)
+    yg = layer(xg, wg, skip=lg, skip_up=True)
+    close(yg[:, :co], yr, 2e-5, f'torgb + up-sampled skip fwd {cfg}')
+    gg = torch.autograd.grad(yg, [xg, wg, lg], dy.to(DEV))
+    for nm, a, b in zip(['x', 'w', 'skip'], gg, gr):
+        close(a[:, :co] if nm == 'skip' else a, b[:, :co] if nm == 'skip' else b, 1e-4, f'torgb + up-sampled skip grad {nm} {cfg}')
+
+
 # ------------------------------------------------------------------------------------------------- renderer
 def test_ray_gen_golden(golden):
     from inv3d_amd.training.volumetric_rendering.ray_sampler import RaySampler
@@ -629,6 +661,7 @@ def test_hip_adam_matches_torch_adam_with_regulariser_gradient_and_renormalisati
         for i, (p, q) in enumerate(zip(ref, mine)):
             close(q.detach(), p.detach(), 2e-5, f'adam leaf {i} step {step}')
     assert float(o_mine.step_t) == 6.0
+    assert mine[0]._version >= 6 and mine[-1]._version == 0          # raw-pointer writes are reported to autograd / memo()
     assert torch.equal(mine[-1].detach().cpu(), init[-1])
 
 
@@ -736,7 +769,7 @@ def test_conv_v2_half_patch_full_size():
     z = torch.nn.functional.conv2d(x.double() * s.double()[:, :, None, None], wt.double(), padding=1) * d.double()[:, :, None, None]
     ref = (torch.nn.functional.leaky_relu(z + noise.double() * 0.3 + bias.double()[None, :, None, None], 0.2) * 1.4).float()
     outs = []
-    for rows in (8, 4, 4, 4):
+    for rows in (8, 4, 4, 4, 2, 2):
         out = H.empty_cl(n, co, h, w, DEV)
         H.conv_v2(aimg, wimg, out, H.classes_corr(h, w, 3, 3, 1), epi=L.EPI_FWD, out_scale=d, bias=bias, noise=noise, noise_nstride=0, noise_strength=strength,
                   act='lrelu', alpha=0.2, gain=1.4, clamp=-1.0, out_amax=torch.zeros(1, device=DEV), patch_rows=rows)
@@ -744,10 +777,10 @@ def test_conv_v2_half_patch_full_size():
         close(out, ref, 5e-5, f'conv_v2 full size rows {rows}')
         outs.append(out)
     for o in outs[1:]:
-        assert torch.equal(o, outs[0]), 'the 4-row and 8-row patches accumulate in the same order: bit-identical results'
+        assert torch.equal(o, outs[0]), 'the 2-, 4- and 8-row patches accumulate in the same order: bit-identical results'
 
 
-@pytest.mark.parametrize('rows', [8, 4])
+@pytest.mark.parametrize('rows', [8, 4, 2])
 def test_conv_v2_data_gradient_epilogue_vs_torch(rows):
     """Data gradient of a 3x3 layer: adjoint taps on the adjoint weight image, dx = acc * styles + addend, ds = sum_px acc * x."""
     from inv3d_amd import hipops as H, _lib as L
