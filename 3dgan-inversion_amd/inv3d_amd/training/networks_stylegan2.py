@@ -296,7 +296,10 @@ class SynthesisNetwork(ReferenceStateMixin, torch.nn.Module):
             o += n * r * r
         return out
 
-    def forward(self, ws, noise_inject=None, _prefix='backbone.synthesis', **block_kwargs):
+    def forward(self, ws, noise_inject=None, _prefix='backbone.synthesis', _extra_entries=None, _bank_out=None, _extra_pack=None, **block_kwargs):
+        """_extra_entries / _bank_out: style-bank entries of a network that runs later on the same ws (the super-resolution head) ride along in
+        this network's bank launch -- and in its backward launches; their (styles, demods) are left in _bank_out['extra'].  _extra_pack: that
+        network's weight-carrying layers, re-packed in this network's batched launch when the weights train (their demodulation sums are bank inputs)."""
         ws = ws.to(torch.float32)
         x = img = None
         # all 20 style affines of the backbone in one launch (None: some affine is trainable -> per-layer path)
@@ -308,8 +311,15 @@ class SynthesisNetwork(ReferenceStateMixin, torch.nn.Module):
             counts.append(len(ent))
             w_idx += block.num_conv
         if ws.is_cuda and self.b4.conv1.weight.requires_grad:       # pivotal tuning: every weight image is stale once per step -> one launch for all
-            fused.prepack_weights([m for res in self.block_resolutions for m in getattr(self, f'b{res}').packed_layers()])
-        bank = fused.style_bank(ws, entries)
+            fused.prepack_weights([m for res in self.block_resolutions for m in getattr(self, f'b{res}').packed_layers()] + list(_extra_pack or []))
+        n_own = len(entries)
+        extra = list(_extra_entries) if (_extra_entries and _bank_out is not None and n_own + len(_extra_entries) <= fused.L.STYLE_BANK_MAX) else []
+        bank = fused.style_bank(ws, entries + extra)
+        if bank is not None and extra:
+            _bank_out['extra'] = (bank[0][n_own:], bank[1][n_own:])
+            bank = (bank[0][:n_own], bank[1][:n_own])
+        elif bank is None and extra:          # the joint bank does not apply (a non-linear affine somewhere): each network on its own
+            bank = fused.style_bank(ws, entries)
         if noise_inject is None and block_kwargs.get('noise_mode', 'random') == 'random':
             noise_inject = self._draw_noise(ws.shape[0], ws.device, _prefix)
         w_idx = s_idx = 0

@@ -24,7 +24,12 @@ class SuperresolutionHybrid8XDC(ReferenceStateMixin, torch.nn.Module):
         self.block1 = SynthesisBlock(c0, c1, w_dim=self.block0.w_dim, resolution=input_resolution * 4, img_channels=3, is_last=True,
                                      use_fp16=use_fp16, conv_clamp=clamp, **block_kwargs)
 
-    def forward(self, rgb, x, ws, noise_inject=None, **block_kwargs):
+    def bank_entries(self, ws):
+        """Style-bank entries of the two blocks (all read the LAST row of ws): lets the backbone's bank launch compute them too."""
+        last = ws.shape[1] - 1
+        return [(fc, last, post, conv) for fc, _, post, conv in self.block0.affine_entries(0) + self.block1.affine_entries(0)]
+
+    def forward(self, rgb, x, ws, noise_inject=None, _bank=None, **block_kwargs):
         ws_all = ws
         if x.shape[-1] != self.input_resolution:
             size = (self.input_resolution, self.input_resolution)
@@ -40,7 +45,7 @@ class SuperresolutionHybrid8XDC(ReferenceStateMixin, torch.nn.Module):
             fused.prepack_weights(self.block0.packed_layers() + self.block1.packed_layers())
         e0, e1 = self.block0.affine_entries(0), self.block1.affine_entries(0)
         last = ws_all.shape[1] - 1
-        bank = fused.style_bank(ws_all.float(), [(fc, last, post, conv) for fc, _, post, conv in e0 + e1])
+        bank = _bank if _bank is not None else fused.style_bank(ws_all.float(), [(fc, last, post, conv) for fc, _, post, conv in e0 + e1])
         ws = ws_all[:, -1:, :].expand(-1, 3, -1) if bank is not None else ws_all[:, -1:, :].repeat(1, 3, 1)
         s0, s1 = ((bank[0][:len(e0)], bank[1][:len(e0)]), (bank[0][len(e0):], bank[1][len(e0):])) if bank is not None else (None, None)
         x, rgb4 = self.block0(x, rgb4, ws, noise_inject=noise_inject, _name='superresolution.block0', styles=s0, **block_kwargs)

@@ -5,6 +5,8 @@
 Same attribute tree / state-dict keys (backbone.{synthesis,mapping}, superresolution.block{0,1}, decoder.net.{0,2}), so
 scripts/run_pti.py-style callers, the projector and the coaches can use it unchanged.  Extra, optional synthesis kwargs for
 deterministic runs: render_uniforms=(u1,u2), noise_inject={layer-name: [N,1,res,res]}."""
+import os
+
 import torch
 
 from .. import fused
@@ -14,6 +16,8 @@ from .networks_stylegan2 import Generator as StyleGAN2Backbone, FullyConnectedLa
 from .superresolution import SuperresolutionHybrid8XDC, SuperresolutionHybrid8X
 from .volumetric_rendering.ray_sampler import RaySampler
 from .volumetric_rendering.renderer import ImportanceRenderer
+
+JOINT_STYLE_BANK = os.environ.get('EG3D_JOINT_STYLE_BANK', '1') != '0'   # SR head's style affines computed by the backbone's bank launch
 
 _SR_MODULES = {'training.superresolution.SuperresolutionHybrid8XDC': SuperresolutionHybrid8XDC,
                'training.superresolution.SuperresolutionHybrid8X': SuperresolutionHybrid8X}
@@ -110,7 +114,12 @@ class TriPlaneGenerator(ReferenceStateMixin, torch.nn.Module):
         res = self.neural_rendering_resolution
         kwargs = {k: v for k, v in synthesis_kwargs.items() if k != 'force_fp32'}
         origins, directions = self.ray_sampler(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), res)
-        planes = self._planes(ws, use_cached_backbone, cache_backbone, update_emas, noise_inject, kwargs)
+        # the SR head's six style affines ride along in the backbone's bank launch (and its two backward launches) when the backbone runs
+        bank_out, bkw = {}, kwargs
+        sr_entries = getattr(self.superresolution, 'bank_entries', None)
+        if JOINT_STYLE_BANK and sr_entries is not None and ws.is_cuda and ws.dtype == torch.float32 and not (use_cached_backbone and self._last_planes is not None):
+            bkw = dict(kwargs, _extra_entries=sr_entries(ws), _bank_out=bank_out, _extra_pack=self.superresolution.block0.packed_layers() + self.superresolution.block1.packed_layers())
+        planes = self._planes(ws, use_cached_backbone, cache_backbone, update_emas, noise_inject, bkw)
         if render_uniforms is not None:
             self.renderer.set_uniforms(*render_uniforms)
         feat, depth, _ = self.renderer(planes, self.decoder, origins, directions, self.rendering_kwargs)
@@ -123,7 +132,8 @@ class TriPlaneGenerator(ReferenceStateMixin, torch.nn.Module):
         else:
             rgb = features[:, :3].contiguous()
         image = self.superresolution(rgb, features, ws, noise_mode=self.rendering_kwargs['superresolution_noise_mode'], noise_inject=noise_inject,
-                                     force_fp32=block_fp32, **{k: v for k, v in kwargs.items() if k != 'noise_mode'})
+                                     force_fp32=block_fp32, **({'_bank': bank_out['extra']} if 'extra' in bank_out else {}),
+                                     **{k: v for k, v in kwargs.items() if k != 'noise_mode'})
         return {'image': image, 'image_raw': rgb, 'image_depth': depth.transpose(1, 2).reshape(n, 1, res, res)}
 
     def sample_mixed(self, coordinates, directions, ws, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
