@@ -303,14 +303,16 @@ __global__ void __launch_bounds__(256) upconv_epilogue_kernel(const float* __res
 }
 
 // derivative factor and recovered pre-activation for one element
+// (inv_gain = 1 / gain, inv_alpha = 1 / alpha, formed once per thread: two IEEE divisions per element -- ~20 instructions -- were half of
+//  the arithmetic of these passes; the products differ from the quotients by at most one ulp, in `pre` only -- signs decide everything else)
 template <bool PWL>
-__device__ __forceinline__ void bwd1(float dout, float o, int act, float alpha, float gain, float clamp, float& dy, float& pre) {
-    float yy = o / gain;
+__device__ __forceinline__ void bwd1(float dout, float o, int act, float alpha, float gain, float clamp, float inv_gain, float inv_alpha, float& dy, float& pre) {
+    float yy = o * inv_gain;
     float g = dout * gain * (PWL ? eg3d_pwl_d1(yy, alpha) : eg3d_act_d1<float>(yy, 0.f, act, alpha));
     if (clamp >= 0.f && (o >= clamp || o <= -clamp)) g = 0.f;
     dy = g;
-    if (PWL) pre = (yy > 0.f || alpha == 0.f) ? yy : yy / alpha;            // alpha = slope: 1 (linear), alpha (lrelu); relu is not invertible
-    else pre = (act == EG3D_ACT_LRELU) ? (yy > 0.f ? yy : yy / alpha) : yy;     // linear / lrelu are invertible
+    if (PWL) pre = (yy > 0.f || alpha == 0.f) ? yy : yy * inv_alpha;        // alpha = slope: 1 (linear), alpha (lrelu); relu is not invertible
+    else pre = (act == EG3D_ACT_LRELU) ? (yy > 0.f ? yy : yy * inv_alpha) : yy;     // linear / lrelu are invertible
 }
 
 // grid = (blocks_x, N).  Block: EPI_BWD_THREADS threads = PPB pixels x C4 channel-quads.  Big blocks on purpose: every block ends with
@@ -334,6 +336,9 @@ struct FinArgs { const float* z; const float* s; const float* addend; float* ds;
 // pieces are floating point, a scale that is a few octaves too cautious costs range at the bottom, not precision: |dz| <= gain * (max|dy| *
 // max_{n,c}(sum_o |wa[c][o]|) |s[n,c]| |d[n,c]|) + max|addend| * max |d|) since |act'| <= 1.  Every block derives it from the same few
 // hundred numbers.  512^2 x 128: 85 + 52 us (this pass + split pass) -> 61 us, and no fp32 dz at all when nobody else reads it.
+// barrier that orders LDS traffic only (__syncthreads also drains the vector-memory counter: it would wait for prefetched global loads)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <bool PWL, bool FIN, bool SPLIT = false>
 __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const FinArgs fin, const float* __restrict__ dout, const float* __restrict__ outv, float* __restrict__ dz,
                                                            int H, int W, int C4, const float* __restrict__ d, const float* __restrict__ noise,
@@ -349,6 +354,7 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const Fin
     const bool active = pl < ppb;
     const int HW = H * W;
     const float strength = noise ? *noise_strength : 0.f;
+    const float inv_gain = 1.0f / gain, inv_alpha = alpha != 0.f ? 1.0f / alpha : 0.f;
     const int c = c4 * 4;
     float4 dv = make_float4(1, 1, 1, 1), bv = make_float4(0, 0, 0, 0);
     if (active && d) dv = ld4(d + (int64_t)n * C + c);
@@ -386,35 +392,61 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const Fin
         // U pixels per trip: all 2*U 16-byte loads are in flight before the first dependent instruction (the kernel is a pure
         // stream over dout/out/dz; with one pixel per trip each wave had two loads outstanding and 8 waves/CU could not cover
         // the HBM latency).
-        constexpr int U = 4;
+        constexpr int U = SPLIT ? 2 : 4;          // (SPLIT holds two trips in registers: the one being processed and the prefetched one)
         const int stride = gridDim.x * ppb;
         // (the trip count is block-uniform -- `base` -- because the SPLIT form has barriers inside the loop)
-        for (int base = blockIdx.x * ppb; base < HW; base += U * stride) {
+        // SPLIT: the next trip's loads are issued before this trip's arithmetic / staging / stores (the two barriers of the staging would
+        // otherwise leave every wave of the block without a load in flight twice per trip; they wait on LDS only -- lds_barrier -- so the
+        // prefetch stays outstanding across them)
+        struct Raw { float4 o[U], g[U], av[U]; float nraw[U]; };      // g: dout | the split-K sum z | the four toRGB gradients of the pixel
+        auto load_raw = [&](const int base, Raw& r) {
             const int pix0 = base + pl;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pix = pix0 + u * stride;
+                const bool ok = pix < HW;
+                const int64_t off = ((int64_t)n * HW + (ok ? pix : base)) * C + c;
+                r.o[u] = ld4(outv + off);
+                if (FIN) {
+                    r.g[u] = fin.dy4 ? ld4(fin.dy4 + ((int64_t)n * HW + (ok ? pix : base)) * 4) : ld4(fin.z + off);
+                    r.av[u] = fin.addend ? ld4(fin.addend + off) : make_float4(0, 0, 0, 0);
+                } else {
+                    r.g[u] = ld4(dout + off);
+                }
+                r.nraw[u] = (noise && ok) ? noise[(int64_t)n * noise_nstride + pix] : 0.f;
+            }
+        };
+        Raw cur;
+        const int first = blockIdx.x * ppb;
+        if (SPLIT && first < HW) load_raw(first, cur);
+        for (int base = first; base < HW; base += U * stride) {
+            const int pix0 = base + pl;
+            Raw nxt;
+            if constexpr (SPLIT) { if (base + U * stride < HW) load_raw(base + U * stride, nxt); }
+            else load_raw(base, cur);
             float4 g[U], o[U];
             float nraw[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int pix = pix0 + u * stride;
                 const bool ok = pix < HW;
-                const int64_t off = ((int64_t)n * HW + (ok ? pix : base)) * C + c;
-                o[u] = ld4(outv + off);
+                o[u] = cur.o[u];
                 if (FIN) {
-                    float4 zz;
+                    float4 zz = cur.g[u];
                     if (fin.dy4) {
-                        const float4 g4 = ld4(fin.dy4 + ((int64_t)n * HW + (ok ? pix : base)) * 4);
+                        const float4 g4 = cur.g[u];
                         zz.x = fmaf(g4.w, w40.w, fmaf(g4.z, w40.z, fmaf(g4.y, w40.y, g4.x * w40.x)));
                         zz.y = fmaf(g4.w, w41.w, fmaf(g4.z, w41.z, fmaf(g4.y, w41.y, g4.x * w41.x)));
                         zz.z = fmaf(g4.w, w42.w, fmaf(g4.z, w42.z, fmaf(g4.y, w42.y, g4.x * w42.x)));
                         zz.w = fmaf(g4.w, w43.w, fmaf(g4.z, w43.z, fmaf(g4.y, w43.y, g4.x * w43.x)));
-                    } else zz = ld4(fin.z + off);
-                    const float4 av = fin.addend ? ld4(fin.addend + off) : make_float4(0, 0, 0, 0);
+                    }
+                    const float4 av = cur.av[u];
                     if (ok && fin.ds) { accz.x += zz.x * o[u].x; accz.y += zz.y * o[u].y; accz.z += zz.z * o[u].z; accz.w += zz.w * o[u].w; }
                     g[u] = make_float4(zz.x * fsv.x + av.x, zz.y * fsv.y + av.y, zz.z * fsv.z + av.z, zz.w * fsv.w + av.w);
                 } else {
-                    g[u] = ld4(dout + off);
+                    g[u] = cur.g[u];
                 }
-                nraw[u] = (noise && ok) ? noise[(int64_t)n * noise_nstride + pix] : 0.f;
+                nraw[u] = cur.nraw[u];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -422,8 +454,8 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const Fin
                 if (pix >= HW) break;
                 const int64_t off = ((int64_t)n * HW + pix) * C + c;
                 float4 dy, pre;
-                bwd1<PWL>(g[u].x, o[u].x, act, alpha, gain, clamp, dy.x, pre.x); bwd1<PWL>(g[u].y, o[u].y, act, alpha, gain, clamp, dy.y, pre.y);
-                bwd1<PWL>(g[u].z, o[u].z, act, alpha, gain, clamp, dy.z, pre.z); bwd1<PWL>(g[u].w, o[u].w, act, alpha, gain, clamp, dy.w, pre.w);
+                bwd1<PWL>(g[u].x, o[u].x, act, alpha, gain, clamp, inv_gain, inv_alpha, dy.x, pre.x); bwd1<PWL>(g[u].y, o[u].y, act, alpha, gain, clamp, inv_gain, inv_alpha, dy.y, pre.y);
+                bwd1<PWL>(g[u].z, o[u].z, act, alpha, gain, clamp, inv_gain, inv_alpha, dy.z, pre.z); bwd1<PWL>(g[u].w, o[u].w, act, alpha, gain, clamp, inv_gain, inv_alpha, dy.w, pre.w);
                 const float4 zz = make_float4(dy.x * dv.x, dy.y * dv.y, dy.z * dv.z, dy.w * dv.w);
                 if constexpr (SPLIT) {
                     // image [N][piece][C/8][HW][8 halves]: this thread's four channels are half an octet entry (8 bytes per piece); the block's
@@ -470,7 +502,7 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const Fin
                 }
             }
             if constexpr (SPLIT) {
-                __syncthreads();
+                lds_barrier();
                 // item = (plane, pixel lane): EPI_BWD_THREADS = C4 * ppb of them per u
                 const int plane = threadIdx.x / ppb, px = threadIdx.x - plane * ppb;
                 const int piece = plane / (C4 / 2), ko = plane - piece * (C4 / 2);
@@ -482,7 +514,8 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const Fin
                         reinterpret_cast<uint4*>(fin.simg)[((int64_t)(n * 2 + piece) * (C / 8) + ko) * HW + pix] = v;
                     }
                 }
-                __syncthreads();
+                lds_barrier();
+                cur = nxt;
             }
         }
     }
