@@ -194,9 +194,20 @@ __device__ __forceinline__ float4 eg3d_act_bwd_unit(const eg3d_act_bwd_consts& c
     chan_sum = (dy[0] + dy[1]) + (dy[2] + dy[3]);
     return make_float4(dy[0] * d4.x, dy[1] * d4.y, dy[2] * d4.z, dy[3] * d4.w);
 }
-// sum over the `group` (power of two <= 32) consecutive lanes that hold the channel quads of one pixel row
+// sum over the `group` (power of two <= 64) consecutive lanes that hold the channel quads of one pixel row
+// (valid in every lane of the group).  Within a row of 16 lanes the exchange is four DPP modifiers on the adds -- quad_perm xor 1, xor 2,
+// row_half_mirror, row_mirror -- instead of four ds_bpermute round trips through the LDS crossbar; only the 16 / 32 strides still shuffle.
+template <int CTRL>
+__device__ __forceinline__ float eg3d_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float eg3d_row_group_sum(float s, int group) {
-    for (int m = group >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if (group >= 2) s += eg3d_dpp<0xB1>(s);          // quad_perm [1,0,3,2]
+    if (group >= 4) s += eg3d_dpp<0x4E>(s);          // quad_perm [2,3,0,1]
+    if (group >= 8) s += eg3d_dpp<0x141>(s);         // row_half_mirror: lane i <-> 7 - i
+    if (group >= 16) s += eg3d_dpp<0x140>(s);        // row_mirror: lane i <-> 15 - i
+    if (group >= 32) s += __shfl_xor(s, 16);
+    if (group >= 64) s += __shfl_xor(s, 32);
     return s;
 }
 

@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const Fin
                 if (dnoise || dstrength) {
                     float s = (dy.x + dy.y) + (dy.z + dy.w);
                     if (pow2) {
-                        for (int m = grp >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+                        s = eg3d_row_group_sum(s, grp);
                         if ((threadIdx.x & (grp - 1)) == 0) {
                             if (dnoise) unsafeAtomicAdd(dnoise + (int64_t)n * dnoise_nstride + pix, s * strength);
                             accs += s * nraw[u];
