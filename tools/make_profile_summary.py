@@ -45,7 +45,7 @@ rows = list(csv.DictReader(open(one(sess + '/stats/*_kernel_stats.csv'))))
 ncalls = sum(int(r['Calls']) for r in rows)
 tr = list(csv.DictReader(open(one(sess + '/stats/*_kernel_trace.csv'))))
 tr.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(tr) if 'noise_apply_norm_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(tr) if 'adam_apply_norm_kernel' in r['Kernel_Name'] or 'noise_apply_norm_kernel' in r['Kernel_Name']]      # last launch of a step
 a, b = idx[8], idx[9]                       # a graph-replayed step of the timed region (3 set-up + 2 warm-up steps precede it)
 seg = tr[a + 1:b + 1]
 agg = collections.defaultdict(lambda: [0, 0])
