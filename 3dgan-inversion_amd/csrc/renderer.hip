@@ -1411,6 +1411,7 @@ int check_render(const eg3d_render_params& p) {
 __global__ void __launch_bounds__(256) coarse_pos_kernel(const eg3d_render_params p, int D) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t nrays = (int64_t)p.N * p.R;
+    if (i == 0) { p.depth_minmax[0] = INFINITY; p.depth_minmax[1] = -INFINITY; }     // first launch of the pipelined forward: the caller need not initialise it
     if (i >= nrays * D) return;
     const int64_t ray = i / D;
     const int s = (int)(i - ray * D);

@@ -824,8 +824,6 @@ class RenderFn(torch.autograd.Function):
         rgb = torch.empty((N, R, w1.shape[0] - 1), device=dev)
         depth = torch.empty((N, R, 1), device=dev)
         wsum = torch.empty((N, R, 1), device=dev)
-        minmax = _minmax_init(dev) + 0.0            # device-side copy by an elementwise kernel: no host transfer (graph-capturable) and no
-                                                    # memcpy node (those split a captured graph into separately submitted segments)
         fine = torch.empty((N, R, max(Df, 1)), device=dev)
         rl = ray_limits.contiguous().float() if ray_limits is not None else None
         save = None
@@ -844,6 +842,11 @@ class RenderFn(torch.autograd.Function):
             pos = torch.empty((2, N * R, max(Dc, Df), 4), device=dev)
             if RENDER_FEAT_ROWS:        # the tri-plane gather as its own pass; the backward re-reads the rows instead of gathering again
                 feat = torch.empty((N * R * 2 * max(Dc, Df), 32), device=dev)
+        if pos is not None:
+            minmax = torch.empty((2,), device=dev)      # the pipelined forward's first launch writes (+inf, -inf) itself
+        else:
+            minmax = _minmax_init(dev) + 0.0            # device-side copy by an elementwise kernel: no host transfer (graph-capturable) and no
+                                                        # memcpy node (those split a captured graph into separately submitted segments)
         p = H.make_render_params(planes, origins, dirs, u1, u2, opts, w0g, b0g, w1t, b1g, rgb, depth, wsum, minmax, fine, rl, rows if pos is not None else save,
                                  pos_rows=pos, feat_rows=feat)
         with H._Span('render_fwd'):

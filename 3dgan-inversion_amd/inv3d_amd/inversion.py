@@ -509,8 +509,8 @@ class LatentProjector:
                 reg, _ = hipops.noise_regularizer(self._buf_views, scale=float(self.reg_w), want_grad=True,
                                                   grads=[g[i, 0] for g in reg_grads for i in range(self.N)])
         w = self.w_opt
-        if wn is not None:
-            w = w + wn * w_noise_scale
+        if wn is not None:          # w + wn * scale in one launch (scale: a device scalar under graph replay)
+            w = torch.addcmul(w, wn, w_noise_scale) if torch.is_tensor(w_noise_scale) else torch.add(w, wn, alpha=float(w_noise_scale))
         ws = w.repeat(1, self.num_ws, 1) if w.shape[1] == 1 else w
         if self._noise_inject is not None:
             kw = dict(kw, noise_inject=self._noise_inject)

@@ -237,7 +237,11 @@ class SynthesisBlock(ReferenceStateMixin, torch.nn.Module):
         if self.use_fp16 and not force_fp32:        # the reference runs this block in fp16 (networks_stylegan2.py:421-424): one product of fp16-rounded operands
             layer_kwargs = dict(layer_kwargs, precision='f16x1')
         if self.in_channels == 0:
-            x = self.const.unsqueeze(0).expand(ws.shape[0], -1, -1, -1)
+            if self.const.is_cuda and not self.const.requires_grad:      # frozen (latent projection): the broadcast channels_last copy is made once
+                nb = int(ws.shape[0])
+                x = H.memo(('const_cl', nb), [self.const], lambda: H.to_cl(self.const.detach().float().unsqueeze(0).expand(nb, -1, -1, -1)))
+            else:
+                x = self.const.unsqueeze(0).expand(ws.shape[0], -1, -1, -1)
             x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), styles=next(s_iter), demod=next(d_iter), single_consumer=True,
                            **layer_kwargs)
         else:       # conv0's output feeds conv1 only, conv1's the toRGB node only (which passes it on to the next block through itself)

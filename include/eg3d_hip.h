@@ -558,7 +558,8 @@ typedef struct eg3d_render_params {
     float* rgb;                /* [N,R,Cout]                                               */
     float* depth;              /* [N,R]  (unclamped; NaN kept -- finalize clamps)          */
     float* wsum;               /* [N,R]                                                    */
-    float* depth_minmax;       /* [2] running global (min,max) of all sample depths; init (+inf,-inf) */
+    float* depth_minmax;       /* [2] running global (min,max) of all sample depths; init (+inf,-inf) by the caller -- the pipelined forward
+                                * (pos_rows + save_* given) initialises it itself */
     float* fine_depths;        /* [N,R,Df] workspace: importance depths (re-used by backward)*/
     /* training mode (both or neither): the forward keeps (sigma, colour) of every sample for the backward.
      * Row ((n*R + ray)*2 + pass)*D + s, pass 0 = coarse / 1 = fine, D = max(Dc,Df).                                  */
