@@ -853,6 +853,7 @@ class RenderFn(torch.autograd.Function):
             H.render_fwd(p)
             H.render_finalize(depth, minmax)
         ctx.has_feat = feat is not None and save is not None
+        ctx.set_materialize_grads(False)       # an unused output (depth, weight sum) arrives as None in backward instead of a freshly filled zero tensor
         ctx.save_for_backward(planes, origins, dirs, w0g, b0g, w1t, b1g, u1, u2, minmax, fine, rl, *(save or ()), *((feat,) if ctx.has_feat else ()))
         ctx.cfg = (dict(opts), g0, g1, lr_mul)
         return rgb, depth, wsum
