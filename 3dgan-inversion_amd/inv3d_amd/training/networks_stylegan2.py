@@ -196,19 +196,20 @@ class SynthesisBlock(ReferenceStateMixin, torch.nn.Module):
 
     def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, is_last, architecture='skip',
                  resample_filter=[1, 3, 3, 1], conv_clamp=256, use_fp16=False, fp16_channels_last=False, fused_modconv_default=True,
-                 **layer_kwargs):
+                 conv0_up=2, **layer_kwargs):
         if architecture != 'skip':
             raise NotImplementedError("EG3D generators use the 'skip' architecture")
         super().__init__()
         self.in_channels, self.w_dim, self.resolution, self.img_channels, self.is_last = in_channels, w_dim, resolution, img_channels, is_last
         self.architecture, self.use_fp16, self.fused_modconv_default = architecture, use_fp16, fused_modconv_default
+        self.conv0_up = int(conv0_up)           # 1: SynthesisBlockNoUp (training/superresolution.py:155-262) -- conv0 keeps the resolution, the skip image is added as it is
         self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
         first = in_channels == 0
         common = dict(w_dim=w_dim, resolution=resolution, conv_clamp=conv_clamp, **layer_kwargs)
         if first:
             self.const = torch.nn.Parameter(torch.randn(out_channels, resolution, resolution))
         else:
-            self.conv0 = SynthesisLayer(in_channels, out_channels, up=2, resample_filter=resample_filter, **common)
+            self.conv0 = SynthesisLayer(in_channels, out_channels, up=self.conv0_up, resample_filter=resample_filter, **common)
         self.conv1 = SynthesisLayer(out_channels, out_channels, **common)
         self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp)
         self.num_conv, self.num_torgb = (1 if first else 2), 1
@@ -251,7 +252,7 @@ class SynthesisBlock(ReferenceStateMixin, torch.nn.Module):
             x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), styles=s1, demod=next(d_iter), single_consumer=True,
                            input_is_layer_output=True, **layer_kwargs)
         # the skip image is handed over at half resolution: the toRGB node up-samples it (inside its conv's epilogue where it can)
-        skip_up = img is not None
+        skip_up = img is not None and self.conv0_up == 2
         if self.is_last:
             img = self.torgb(x, next(w_iter), skip=img, styles=next(s_iter), input_is_layer_output=True, skip_up=skip_up)
         else:       # x goes on to the next block: route it through the toRGB node so the two gradients are summed in its epilogue
@@ -260,6 +261,15 @@ class SynthesisBlock(ReferenceStateMixin, torch.nn.Module):
             if amax is not None:        # the pass-through output is the same values: keep the producer's max|x| report with it
                 H.tag_amax(x, amax)
         return x, img
+
+
+class SynthesisBlockNoUp(SynthesisBlock):
+    """The first block of the 128^2 / 256^2 super-resolution heads (reference: training/superresolution.py:155-262): conv0 at the block's own
+    resolution, skip image added without up-sampling."""
+
+    def __init__(self, *args, **kw):
+        kw['conv0_up'] = 1
+        super().__init__(*args, **kw)
 
 
 class SynthesisNetwork(ReferenceStateMixin, torch.nn.Module):

@@ -6,23 +6,32 @@ import torch
 from .. import fused
 from .. import hipops as H
 from ..reference_binding import ReferenceStateMixin
-from .networks_stylegan2 import SynthesisBlock
+from .networks_stylegan2 import SynthesisBlock, SynthesisBlockNoUp
 
 
 class SuperresolutionHybrid8XDC(ReferenceStateMixin, torch.nn.Module):
-    def __init__(self, channels, img_resolution, sr_num_fp16_res, sr_antialias, num_fp16_res=4, conv_clamp=None, channel_base=None,
+    # what the five heads of the reference differ in (training/superresolution.py:29-152, 262-290); the subclasses below override these
+    block0_up = 2               # 1: the head starts with a SynthesisBlockNoUp
+    resize_when = 'ne'          # inputs are resized to input_resolution when their size differs from it ('ne') / is smaller ('lt')
+    has_filter_buffer = False   # the head registers a `resample_filter` buffer of its own (state-dict key)
+
+    def __init__(self, channels, img_resolution, sr_num_fp16_res, sr_antialias=True, num_fp16_res=4, conv_clamp=None, channel_base=None,
                  channel_max=None, sr_widths=(256, 128), input_resolution=128, **block_kwargs):
         super().__init__()
-        assert img_resolution == input_resolution * 4
+        assert img_resolution == input_resolution * self.block0_up * 2
         use_fp16 = sr_num_fp16_res > 0
         self.input_resolution = input_resolution
         self.sr_antialias = sr_antialias
         clamp = 256 if use_fp16 else None
         c0, c1 = sr_widths
-        self.block0 = SynthesisBlock(channels, c0, w_dim=block_kwargs.pop('w_dim', 512), resolution=input_resolution * 2, img_channels=3,
-                                     is_last=False, use_fp16=use_fp16, conv_clamp=clamp, **block_kwargs)
-        self.block1 = SynthesisBlock(c0, c1, w_dim=self.block0.w_dim, resolution=input_resolution * 4, img_channels=3, is_last=True,
+        self.block0 = (SynthesisBlock if self.block0_up == 2 else SynthesisBlockNoUp)(
+            channels, c0, w_dim=block_kwargs.pop('w_dim', 512), resolution=input_resolution * self.block0_up, img_channels=3, is_last=False,
+            use_fp16=use_fp16, conv_clamp=clamp, **block_kwargs)
+        self.block1 = SynthesisBlock(c0, c1, w_dim=self.block0.w_dim, resolution=img_resolution, img_channels=3, is_last=True,
                                      use_fp16=use_fp16, conv_clamp=clamp, **block_kwargs)
+        if self.has_filter_buffer:
+            from ..torch_utils.ops import upfirdn2d
+            self.register_buffer('resample_filter', upfirdn2d.setup_filter([1, 3, 3, 1]))
 
     def bank_entries(self, ws):
         """Style-bank entries of the two blocks (all read the LAST row of ws): lets the backbone's bank launch compute them too."""
@@ -31,7 +40,7 @@ class SuperresolutionHybrid8XDC(ReferenceStateMixin, torch.nn.Module):
 
     def forward(self, rgb, x, ws, noise_inject=None, _bank=None, **block_kwargs):
         ws_all = ws
-        if x.shape[-1] != self.input_resolution:
+        if (x.shape[-1] != self.input_resolution) if self.resize_when == 'ne' else (x.shape[-1] < self.input_resolution):
             size = (self.input_resolution, self.input_resolution)
             x = torch.nn.functional.interpolate(x, size=size, mode='bilinear', align_corners=False, antialias=self.sr_antialias)
             rgb = torch.nn.functional.interpolate(rgb, size=size, mode='bilinear', align_corners=False, antialias=self.sr_antialias)
@@ -58,7 +67,36 @@ class SuperresolutionHybrid8XDC(ReferenceStateMixin, torch.nn.Module):
 class SuperresolutionHybrid8X(SuperresolutionHybrid8XDC):
     """128^2 -> 512^2 head with the narrower blocks 32 -> 128 @256^2 and 128 -> 64 @512^2 (reference: training/superresolution.py:29-58);
     everything else as the 8XDC head."""
+    has_filter_buffer = True
 
     def __init__(self, channels, img_resolution, sr_num_fp16_res, sr_antialias, **kw):
         kw.setdefault('sr_widths', (128, 64))
         super().__init__(channels, img_resolution, sr_num_fp16_res, sr_antialias, **kw)
+
+
+class SuperresolutionHybrid4X(SuperresolutionHybrid8XDC):
+    """128^2 -> 256^2: SynthesisBlockNoUp 32 -> 128 @128^2, SynthesisBlock 128 -> 64 @256^2; smaller inputs are resized up to 128^2, larger ones
+    pass as they are (reference: training/superresolution.py:62-90)."""
+    block0_up, resize_when, has_filter_buffer = 1, 'lt', True
+
+    def __init__(self, channels, img_resolution, sr_num_fp16_res, sr_antialias, **kw):
+        kw.setdefault('sr_widths', (128, 64))
+        kw.setdefault('input_resolution', 128)
+        super().__init__(channels, img_resolution, sr_num_fp16_res, sr_antialias, **kw)
+
+
+class SuperresolutionHybrid2X(SuperresolutionHybrid8XDC):
+    """64^2 -> 128^2: SynthesisBlockNoUp 32 -> 128 @64^2, SynthesisBlock 128 -> 64 @128^2 (reference: training/superresolution.py:94-122)."""
+    block0_up, resize_when, has_filter_buffer = 1, 'ne', True
+
+    def __init__(self, channels, img_resolution, sr_num_fp16_res, sr_antialias, **kw):
+        kw.setdefault('sr_widths', (128, 64))
+        kw.setdefault('input_resolution', 64)
+        super().__init__(channels, img_resolution, sr_num_fp16_res, sr_antialias, **kw)
+
+
+class SuperresolutionHybridDeepfp32(SuperresolutionHybrid4X):
+    """The 4X head of old 256^2 pickles: no `sr_antialias` argument, its resize never anti-aliases (reference: training/superresolution.py:126-152)."""
+
+    def __init__(self, channels, img_resolution, sr_num_fp16_res, sr_antialias=False, **kw):
+        super().__init__(channels, img_resolution, sr_num_fp16_res, False, **kw)

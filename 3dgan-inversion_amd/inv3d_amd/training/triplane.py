@@ -13,14 +13,18 @@ from .. import fused
 from .. import graphed
 from ..reference_binding import ReferenceStateMixin
 from .networks_stylegan2 import Generator as StyleGAN2Backbone, FullyConnectedLayer
-from .superresolution import SuperresolutionHybrid8XDC, SuperresolutionHybrid8X
+from .superresolution import (SuperresolutionHybrid8XDC, SuperresolutionHybrid8X, SuperresolutionHybrid4X, SuperresolutionHybrid2X,
+                              SuperresolutionHybridDeepfp32)
 from .volumetric_rendering.ray_sampler import RaySampler
 from .volumetric_rendering.renderer import ImportanceRenderer
 
 JOINT_STYLE_BANK = os.environ.get('EG3D_JOINT_STYLE_BANK', '1') != '0'   # SR head's style affines computed by the backbone's bank launch
 
 _SR_MODULES = {'training.superresolution.SuperresolutionHybrid8XDC': SuperresolutionHybrid8XDC,
-               'training.superresolution.SuperresolutionHybrid8X': SuperresolutionHybrid8X}
+               'training.superresolution.SuperresolutionHybrid8X': SuperresolutionHybrid8X,
+               'training.superresolution.SuperresolutionHybrid4X': SuperresolutionHybrid4X,
+               'training.superresolution.SuperresolutionHybrid2X': SuperresolutionHybrid2X,
+               'training.superresolution.SuperresolutionHybridDeepfp32': SuperresolutionHybridDeepfp32}
 
 
 class OSGDecoder(ReferenceStateMixin, torch.nn.Module):
@@ -54,7 +58,7 @@ class TriPlaneGenerator(ReferenceStateMixin, torch.nn.Module):
         self._last_planes = None
         sr_name = rendering_kwargs.get('superresolution_module', 'training.superresolution.SuperresolutionHybrid8XDC')
         if sr_name not in _SR_MODULES:
-            raise NotImplementedError(f'superresolution module {sr_name} (the 512^2 heads 8XDC / 8X are built; the 128^2 / 256^2 heads of the ShapeNet configs are not)')
+            raise NotImplementedError(f'superresolution module {sr_name}: not one of the reference\'s five heads (training/superresolution.py)')
         synthesis_kwargs = {k: v for k, v in synthesis_kwargs.items() if k != 'num_fp16_res'}          # the backbone runs in fp32 (:40)
         self.renderer = ImportanceRenderer()
         self.ray_sampler = RaySampler()

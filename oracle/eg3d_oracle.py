@@ -507,18 +507,19 @@ def torgb_layer(P, pre, x, w, conv_clamp=None, fused_modconv=True):
     return bias_act(x, P[f'{pre}.bias'], clamp=conv_clamp)
 
 
-def synthesis_block(P, pre, x, img, ws, has_conv0, noise_mode, noises=None, conv_clamp=None, fused_modconv=True):
+def synthesis_block(P, pre, x, img, ws, has_conv0, noise_mode, noises=None, conv_clamp=None, fused_modconv=True, up0=2):
     """SynthesisBlock.forward ('skip' architecture), training/networks_stylegan2.py:417-461.
-    ws: [N, num_conv+1, w_dim].  noises: dict layer-prefix -> [N,1,res,res] for noise_mode='random'."""
+    ws: [N, num_conv+1, w_dim].  noises: dict layer-prefix -> [N,1,res,res] for noise_mode='random'.
+    up0=1: SynthesisBlockNoUp.forward (training/superresolution.py:210-253): conv0 without up-sampling, the skip image added as it is."""
     nz = noises or {}
     i = 0
     if not has_conv0:
         x = P[f'{pre}.const'].unsqueeze(0).repeat(ws.shape[0], 1, 1, 1)
         x = synthesis_layer(P, f'{pre}.conv1', x, ws[:, i], 1, noise_mode, nz.get(f'{pre}.conv1'), conv_clamp, fused_modconv); i += 1
     else:
-        x = synthesis_layer(P, f'{pre}.conv0', x, ws[:, i], 2, noise_mode, nz.get(f'{pre}.conv0'), conv_clamp, fused_modconv); i += 1
+        x = synthesis_layer(P, f'{pre}.conv0', x, ws[:, i], up0, noise_mode, nz.get(f'{pre}.conv0'), conv_clamp, fused_modconv); i += 1
         x = synthesis_layer(P, f'{pre}.conv1', x, ws[:, i], 1, noise_mode, nz.get(f'{pre}.conv1'), conv_clamp, fused_modconv); i += 1
-    if img is not None:
+    if img is not None and up0 == 2:
         img = upsample2d(img, P[f'{pre}.resample_filter'])
     y = torgb_layer(P, f'{pre}.torgb', x, ws[:, i], conv_clamp, fused_modconv)
     img = img + y if img is not None else y
@@ -547,6 +548,66 @@ def superresolution(P, cfg: GenConfig, rgb, x, ws, noise_mode='none', noises=Non
         rgb = F.interpolate(rgb, size=(cfg.sr_in_res, cfg.sr_in_res), mode='bilinear', align_corners=False, antialias=aa)
     x, rgb = synthesis_block(P, 'superresolution.block0', x, rgb, ws3, True, noise_mode, noises, cfg.sr_clamp, fused_modconv)
     x, rgb = synthesis_block(P, 'superresolution.block1', x, rgb, ws3, True, noise_mode, noises, cfg.sr_clamp, fused_modconv)
+    return rgb
+
+
+# The reference's five super-resolution heads (training/superresolution.py:29-58, 62-90, 94-122, 126-152, 262-290), stand-alone.
+#   kind: (input resolution, (block0, block1) widths, up factor of block0.conv0, output resolution, when the inputs are resized, antialias follows sr_antialias)
+SR_HEADS = {'8XDC': (128, (256, 128), 2, 512, 'ne', True), '8X': (128, (128, 64), 2, 512, 'ne', True), '4X': (128, (128, 64), 1, 256, 'lt', True),
+            '2X': (64, (128, 64), 1, 128, 'ne', True), 'Deepfp32': (128, (128, 64), 1, 256, 'lt', False)}
+
+
+def sr_head_param_shapes(kind: str, w_dim: int = 512, channels: int = 32) -> Dict[str, Tuple[int, ...]]:
+    in_res, (c0, c1), up0, out_res, _, _ = SR_HEADS[kind]
+    sh: Dict[str, Tuple[int, ...]] = {}
+    for pre, cin, cout, res in (('superresolution.block0', channels, c0, in_res * up0), ('superresolution.block1', c0, c1, out_res)):
+        for ly, ci, co, k in (('conv0', cin, cout, 3), ('conv1', cout, cout, 3), ('torgb', cout, 3, 1)):
+            sh[f'{pre}.{ly}.weight'] = (co, ci, k, k)
+            sh[f'{pre}.{ly}.bias'] = (co,)
+            sh[f'{pre}.{ly}.affine.weight'] = (ci, w_dim)
+            sh[f'{pre}.{ly}.affine.bias'] = (ci,)
+            if ly != 'torgb':
+                sh[f'{pre}.{ly}.noise_strength'] = ()
+                sh[f'{pre}.{ly}.noise_const'] = (res, res)
+                sh[f'{pre}.{ly}.resample_filter'] = (4, 4)
+        sh[f'{pre}.resample_filter'] = (4, 4)
+    if kind != '8XDC':
+        sh['superresolution.resample_filter'] = (4, 4)          # registered by the 8X / 4X / 2X / Deepfp32 heads themselves (:43, :75, :108, :140)
+    return sh
+
+
+def sr_head_params(kind: str, seed: int = 0, w_dim: int = 512, channels: int = 32, weight_scale: float = 1.0) -> Dict[str, Tensor]:
+    """Deterministic weights of one head, same conventions as synth_params."""
+    f1 = torch.tensor([1., 3., 3., 1.])
+    fir = torch.outer(f1, f1)
+    fir = fir / fir.sum()
+    out = {}
+    for name, shape in sr_head_param_shapes(kind, w_dim, channels).items():
+        key = f'sr{kind}.{name}'
+        if name.endswith('resample_filter'):
+            t = fir.clone()
+        elif name.endswith('affine.bias'):
+            t = torch.ones(shape)
+        elif name.endswith('noise_strength'):
+            t = _rand(key, seed, shape) * 0.1
+        elif name.endswith('.bias'):
+            t = _randn(key, seed, shape) * 0.1
+        else:
+            t = _randn(key, seed, shape) * (weight_scale if name.endswith('.weight') and 'affine' not in name else 1.0)
+        out[name] = t
+    return out
+
+
+def sr_head(P, kind: str, rgb, x, ws, sr_antialias: bool = True, conv_clamp: Optional[float] = 256.0, noise_mode='none', noises=None, fused_modconv=True):
+    """forward() of the head `kind` on (rgb [N,3,r,r], x [N,32,r,r], ws [N,L,w_dim])."""
+    in_res, _, up0, _, rule, follows = SR_HEADS[kind]
+    ws3 = ws[:, -1:, :].repeat(1, 3, 1)
+    if (x.shape[-1] != in_res) if rule == 'ne' else (x.shape[-1] < in_res):
+        aa = bool(sr_antialias) if follows else False
+        x = F.interpolate(x, size=(in_res, in_res), mode='bilinear', align_corners=False, antialias=aa)
+        rgb = F.interpolate(rgb, size=(in_res, in_res), mode='bilinear', align_corners=False, antialias=aa)
+    x, rgb = synthesis_block(P, 'superresolution.block0', x, rgb, ws3, True, noise_mode, noises, conv_clamp, fused_modconv, up0=up0)
+    x, rgb = synthesis_block(P, 'superresolution.block1', x, rgb, ws3, True, noise_mode, noises, conv_clamp, fused_modconv)
     return rgb
 
 

@@ -1113,11 +1113,63 @@ def gen_e4e():
     save('e4e', 2e-5, img=img, codes=y)
 
 
+def gen_sr_heads():
+    """The super-resolution heads other than 8XDC (training/superresolution.py:29-152): SuperresolutionHybrid8X / 4X / 2X / Deepfp32, each
+    instantiated from the reference's own class with the oracle's deterministic weights, forward + gradients on seeded inputs.  The 4X / 2X /
+    Deepfp32 heads start with a SynthesisBlockNoUp (:155-262).  Stored: the inputs' seeds are implicit (O._randn keys), probes of the output and
+    of every gradient."""
+    from training import superresolution as ref_sr
+    classes = {'8X': ref_sr.SuperresolutionHybrid8X, '4X': ref_sr.SuperresolutionHybrid4X, '2X': ref_sr.SuperresolutionHybrid2X,
+               'Deepfp32': ref_sr.SuperresolutionHybridDeepfp32}
+    probe = torch.Generator().manual_seed(123)
+    arrays = {}
+    for kind, cls in classes.items():
+        in_res, widths, up0, out_res, rule, follows = O.SR_HEADS[kind]
+        kw = dict(channels=32, img_resolution=out_res, sr_num_fp16_res=4, channel_base=32768, channel_max=512, fused_modconv_default='inference_only')
+        if kind != 'Deepfp32':
+            kw['sr_antialias'] = True
+        head = cls(**kw).eval().float()
+        P = O.sr_head_params(kind, seed=3)
+        sd = {k[len('superresolution.'):]: v for k, v in P.items()}
+        missing, unexpected = head.load_state_dict(sd, strict=False)
+        assert not missing and not unexpected, (kind, missing, unexpected)
+        # two input sizes per head: its own input resolution, and a smaller one that goes through the bilinear resize (antialias where the head passes it)
+        for tag, r in (('own', in_res), ('small', in_res // 2)):
+            x = O._randn(f'srx.{kind}.{tag}', 5, (1, 32, r, r)).requires_grad_(True)
+            rgb = O._randn(f'srrgb.{kind}.{tag}', 5, (1, 3, r, r)).requires_grad_(True)
+            ws = O._randn(f'srws.{kind}', 5, (1, 14, 512)).requires_grad_(True)
+            leaves = [head.block0.conv0.weight, head.block0.conv1.noise_strength, head.block1.conv0.weight, head.block1.torgb.weight, head.block1.torgb.bias]
+            names = ['block0.conv0.weight', 'block0.conv1.noise_strength', 'block1.conv0.weight', 'block1.torgb.weight', 'block1.torgb.bias']
+            img = head(rgb * 1.0, x, ws, noise_mode='const', force_fp32=True)       # (the no-up block adds onto its image argument in place: not a leaf)
+            assert tuple(img.shape) == (1, 3, out_res, out_res)
+            g = O._randn(f'srg.{kind}', 5, img.shape) / img.numel() ** 0.5
+            grads = torch.autograd.grad(img, [x, rgb, ws] + leaves, g)
+            Pg = {k: v.clone().requires_grad_(k[len('superresolution.'):] in names) for k, v in P.items()}
+            xo, ro, wo = x.detach().clone().requires_grad_(True), rgb.detach().clone().requires_grad_(True), ws.detach().clone().requires_grad_(True)
+            io = O.sr_head(Pg, kind, ro, xo, wo, sr_antialias=True, conv_clamp=256.0, noise_mode='const')
+            go = torch.autograd.grad(io, [xo, ro, wo] + [Pg['superresolution.' + n] for n in names], g)
+            e = check(io, img, 1e-5, f'sr head {kind} {tag} image')
+            for nm, a, b in zip(['x', 'rgb', 'ws'] + names, go, grads):
+                check(a, b, 2e-5, f'sr head {kind} {tag} d {nm}')
+            print(f'    {kind:8s} {tag:5s} {r}^2 -> {out_res}^2: image err {e:.2e}')
+            idx = torch.randint(0, img.numel(), (2048,), generator=probe)
+            arrays[f'{kind}.{tag}.idx'] = idx
+            arrays[f'{kind}.{tag}.img'] = img.flatten()[idx]
+            arrays[f'{kind}.{tag}.img_stats'] = np.array([img.mean().item(), img.abs().mean().item(), img.min().item(), img.max().item()])
+            for nm, gv in zip(['x', 'rgb', 'ws'] + names, grads):
+                flat = gv.detach().flatten()
+                gi = torch.randint(0, flat.numel(), (min(512, flat.numel()),), generator=probe)
+                arrays[f'{kind}.{tag}.gidx.{nm}'] = gi
+                arrays[f'{kind}.{tag}.gval.{nm}'] = flat[gi]
+                arrays[f'{kind}.{tag}.gstat.{nm}'] = np.array([flat.norm().item(), flat.abs().max().item()])
+    save('sr_heads', 2e-5, **arrays)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
     gens = dict(bias_act=gen_bias_act, upfirdn2d=gen_upfirdn2d, filtered_lrelu=gen_filtered_lrelu, conv=gen_conv2d_resample, renderer=gen_renderer,
                 graph_small=gen_graph_small, graph_full=gen_graph_full, loss=gen_loss_glue, projector_loop=gen_projector_loop, tuner_loop=gen_tuner_loop,
-                inference=gen_inference, pose_net=gen_pose_net, e4e=gen_e4e)
+                inference=gen_inference, pose_net=gen_pose_net, e4e=gen_e4e, sr_heads=gen_sr_heads)
     mpath = os.path.join(HERE, 'MANIFEST.json')
     if only and os.path.exists(mpath):
         MANIFEST.update(json.load(open(mpath)).get('fixtures', {}))

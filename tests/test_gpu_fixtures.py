@@ -122,3 +122,46 @@ def test_filtered_lrelu_act_entry_point():
     z = x.clone()
     FL.filtered_lrelu_act_(z, None, 0, 0, gain, slope, clamp, write_signs=False)
     close(z, ref, 1e-6, 'act forward without signs')
+
+
+SR_KINDS = ('8X', '4X', '2X', 'Deepfp32')
+SR_LEAVES = ['block0.conv0.weight', 'block0.conv1.noise_strength', 'block1.conv0.weight', 'block1.torgb.weight', 'block1.torgb.bias']
+
+
+def _sr_inputs(kind, tag):
+    in_res = O.SR_HEADS[kind][0]
+    r = in_res if tag == 'own' else in_res // 2
+    x = O._randn(f'srx.{kind}.{tag}', 5, (1, 32, r, r))
+    rgb = O._randn(f'srrgb.{kind}.{tag}', 5, (1, 3, r, r))
+    ws = O._randn(f'srws.{kind}', 5, (1, 14, 512))
+    out_res = O.SR_HEADS[kind][3]
+    g = O._randn(f'srg.{kind}', 5, (1, 3, out_res, out_res)) / (3 * out_res * out_res) ** 0.5
+    return x, rgb, ws, g
+
+
+@pytest.mark.parametrize('kind', SR_KINDS)
+def test_sr_heads_fixture(golden, kind):
+    """SuperresolutionHybrid8X / 4X / 2X / Deepfp32 of the product (the last three start with a SynthesisBlockNoUp) against the probes recorded from
+    the reference's classes (training/superresolution.py:29-152): image, input gradients, weight gradients; own input size and the resized path."""
+    from inv3d_amd.training import superresolution as SR
+    cls = {'8X': SR.SuperresolutionHybrid8X, '4X': SR.SuperresolutionHybrid4X, '2X': SR.SuperresolutionHybrid2X, 'Deepfp32': SR.SuperresolutionHybridDeepfp32}[kind]
+    d = golden('sr_heads')
+    out_res = O.SR_HEADS[kind][3]
+    head = cls(channels=32, img_resolution=out_res, sr_num_fp16_res=4, sr_antialias=True).to(DEV)
+    P = O.sr_head_params(kind, seed=3)
+    missing, unexpected = head.load_state_dict({k[len('superresolution.'):]: v for k, v in P.items()}, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    leaves = [dict(head.named_parameters())[n] for n in SR_LEAVES]
+    for tag in ('own', 'small'):
+        x, rgb, ws, g = (v.to(DEV) for v in _sr_inputs(kind, tag))
+        x, rgb, ws = x.requires_grad_(True), rgb.requires_grad_(True), ws.requires_grad_(True)
+        img = head(rgb, x, ws, noise_mode='const', force_fp32=True)
+        assert tuple(img.shape) == (1, 3, out_res, out_res)
+        close(img.flatten()[t(d[f'{kind}.{tag}.idx'])], d[f'{kind}.{tag}.img'], 2e-5, f'{kind} {tag} image')
+        grads = torch.autograd.grad(img, [x, rgb, ws] + leaves, g.to(DEV))
+        for nm, gv in zip(['x', 'rgb', 'ws'] + SR_LEAVES, grads):
+            # (d noise_strength is ONE number: a sum of 8 M signed products, |sum| ~ 1 against sum |terms| ~ 1e3 -- fp32 summation order shows at 1e-4)
+            tol = 2e-3 if nm.endswith('noise_strength') else (3e-4 if nm == 'ws' else 1e-4)        # (d ws: every element a reduction over all pixels and channels of six layers)
+            close(gv.flatten()[t(d[f'{kind}.{tag}.gidx.{nm}'])], d[f'{kind}.{tag}.gval.{nm}'], tol, f'{kind} {tag} d {nm}')
+            stat = d[f'{kind}.{tag}.gstat.{nm}']
+            assert abs(float(gv.norm()) - stat[0]) <= max(tol, 1e-3) * max(stat[0], 1e-12), (kind, tag, nm, float(gv.norm()), stat[0])

@@ -301,3 +301,38 @@ def test_rendering_resolution_other_than_the_sr_input():
     close(out['image_raw'], ref['image_raw'], 5e-5, 'image_raw at nrr 24')
     gg, = torch.autograd.grad((out['image'] * pr.float().to(DEV)).sum(), wg)
     close(gg, gref.float(), 2e-4, 'd ws at nrr 24')
+
+def test_generator_with_the_128px_head():
+    """A whole TriPlaneGenerator built around SuperresolutionHybrid2X (the reference's 128^2 configs: training/superresolution.py:94-122; neural
+    rendering at 64^2): G.synthesis through the product's graph-replaying entry point, image / raw image against the oracle assembled from its
+    pinned pieces (backbone + renderer, then the stand-alone 2X head), and the gradient into ws."""
+    from inv3d_amd.training.triplane import TriPlaneGenerator
+    cfg = O.small_config(nrr=64)
+    rk = dict(cfg.rendering, superresolution_module='training.superresolution.SuperresolutionHybrid2X')
+    G = TriPlaneGenerator(z_dim=cfg.z_dim, c_dim=25, w_dim=cfg.w_dim, img_resolution=128, img_channels=3, sr_num_fp16_res=4, mapping_kwargs={'num_layers': 2},
+                          rendering_kwargs=rk, sr_kwargs={'fused_modconv_default': 'inference_only', 'w_dim': cfg.w_dim}, plane_resolution=cfg.plane_res,
+                          channel_base=cfg.channel_base, channel_max=cfg.channel_max, fused_modconv_default='inference_only', conv_clamp=None).eval().float()
+    G.neural_rendering_resolution = 64
+    P = {k: v for k, v in O.synth_params(cfg, seed=0).items() if not k.startswith('superresolution.')}
+    P.update(O.sr_head_params('2X', seed=3, w_dim=cfg.w_dim))
+    missing, unexpected = G.load_state_dict(P, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    G = G.to(DEV)
+    ws = O.synth_ws(cfg, 1, seed=1)
+    c = O.synth_cameras(1, seed=2)
+    u1, u2 = O.make_uniforms(cfg, 1, seed=4, nrr=64)
+    wr = ws.clone().requires_grad_(True)
+    planes = O.backbone_synthesis(P, cfg, wr, noise_mode='const')
+    ro, rd = O.ray_sampler(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), 64)
+    feat, depth, _ = O.render(P, planes.view(1, 3, cfg.plane_channels // 3, planes.shape[-2], planes.shape[-1]), ro, rd, cfg.rendering, u1, u2)
+    fimg = feat.permute(0, 2, 1).reshape(1, feat.shape[-1], 64, 64).contiguous()
+    img_r = O.sr_head(P, '2X', fimg[:, :3], fimg, wr, sr_antialias=True, conv_clamp=256.0, noise_mode='none')
+    g = O._randn('g2x', 1, img_r.shape) / img_r.numel() ** 0.5
+    dws_r, = torch.autograd.grad(img_r, wr, g)
+    wg = ws.to(DEV).requires_grad_(True)
+    out = G.synthesis(wg, c.to(DEV), noise_mode='const', force_fp32=True, render_uniforms=(u1.to(DEV), u2.to(DEV)))
+    assert tuple(out['image'].shape) == (1, 3, 128, 128) and tuple(out['image_raw'].shape) == (1, 3, 64, 64)
+    close(out['image'], img_r, 2e-4, '2X generator image')
+    close(out['image_raw'], fimg[:, :3], 2e-4, '2X generator raw image')
+    dws, = torch.autograd.grad(out['image'], wg, g.to(DEV))
+    close(dws, dws_r, 2e-3, '2X generator d ws')

@@ -358,3 +358,36 @@ def test_e4e_oracle(golden):
     with torch.no_grad():
         y = EO.forward(sd, t(d['img']))
     close(y, t(d['codes']), 2e-5)
+
+
+SR_KINDS = ('8X', '4X', '2X', 'Deepfp32')
+SR_LEAVES = ['block0.conv0.weight', 'block0.conv1.noise_strength', 'block1.conv0.weight', 'block1.torgb.weight', 'block1.torgb.bias']
+
+
+def _sr_inputs(kind, tag):
+    in_res = O.SR_HEADS[kind][0]
+    r = in_res if tag == 'own' else in_res // 2
+    x = O._randn(f'srx.{kind}.{tag}', 5, (1, 32, r, r))
+    rgb = O._randn(f'srrgb.{kind}.{tag}', 5, (1, 3, r, r))
+    ws = O._randn(f'srws.{kind}', 5, (1, 14, 512))
+    out_res = O.SR_HEADS[kind][3]
+    g = O._randn(f'srg.{kind}', 5, (1, 3, out_res, out_res)) / (3 * out_res * out_res) ** 0.5
+    return x, rgb, ws, g
+
+
+@pytest.mark.parametrize('kind', SR_KINDS)
+def test_sr_heads_pin(golden, kind):
+    """The reference's other super-resolution heads (training/superresolution.py:29-152; 4X / 2X / Deepfp32 start with a SynthesisBlockNoUp,
+    :155-262): the oracle against probes recorded from the reference classes, image and every gradient, at the head's own input size and
+    through its bilinear resize."""
+    d = golden('sr_heads')
+    P = O.sr_head_params(kind, seed=3)
+    for tag in ('own', 'small'):
+        x, rgb, ws, g = _sr_inputs(kind, tag)
+        Pg = {k: v.clone().requires_grad_(k[len('superresolution.'):] in SR_LEAVES) for k, v in P.items()}
+        x, rgb, ws = x.requires_grad_(True), rgb.requires_grad_(True), ws.requires_grad_(True)
+        img = O.sr_head(Pg, kind, rgb, x, ws, sr_antialias=True, conv_clamp=256.0, noise_mode='const')
+        close(img.flatten()[torch.from_numpy(d[f'{kind}.{tag}.idx'])], t(d[f'{kind}.{tag}.img']), 1e-5)
+        grads = torch.autograd.grad(img, [x, rgb, ws] + [Pg['superresolution.' + n] for n in SR_LEAVES], g)
+        for nm, gv in zip(['x', 'rgb', 'ws'] + SR_LEAVES, grads):
+            close(gv.flatten()[torch.from_numpy(d[f'{kind}.{tag}.gidx.{nm}'])], t(d[f'{kind}.{tag}.gval.{nm}']), 2e-5)
