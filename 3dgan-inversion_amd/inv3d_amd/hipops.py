@@ -223,23 +223,23 @@ def _mk_class(Ha, Wa, py, px, taps):
     return c
 
 
-def classes_corr(Ho, Wo, kh, kw, pad, flip_taps=False):
-    """stride-1 correlation: out[y,x] = sum_k w[ky,kx] * in[y+ky-pad, x+kx-pad]  (flip_taps: true convolution)."""
+def classes_corr(Ho, Wo, kh, kw, pad, flip_taps=False, dil=1):
+    """stride-1 correlation: out[y,x] = sum_k w[ky,kx] * in[y+dil*ky-pad, x+dil*kx-pad]  (flip_taps: true convolution; dil: dilation)."""
     taps = []
     for ky in range(kh):
         for kx in range(kw):
             wt = ((kh - 1 - ky) * kw + (kw - 1 - kx)) if flip_taps else (ky * kw + kx)
-            taps.append((ky - pad, kx - pad, wt))
+            taps.append((dil * ky - pad, dil * kx - pad, wt))
     return [_mk_class(Ho, Wo, 0, 0, taps)]
 
 
-def classes_corr_adjoint(Hi, Wi, kh, kw, pad, flip_taps=False):
-    """data-gradient of classes_corr: dx[y,x] = sum_k w[ky,kx] * g[y-ky+pad, x-kx+pad]."""
+def classes_corr_adjoint(Hi, Wi, kh, kw, pad, flip_taps=False, dil=1):
+    """data-gradient of classes_corr: dx[y,x] = sum_k w[ky,kx] * g[y-dil*ky+pad, x-dil*kx+pad]."""
     taps = []
     for ky in range(kh):
         for kx in range(kw):
             wt = ((kh - 1 - ky) * kw + (kw - 1 - kx)) if flip_taps else (ky * kw + kx)
-            taps.append((pad - ky, pad - kx, wt))
+            taps.append((pad - dil * ky, pad - dil * kx, wt))
     return [_mk_class(Hi, Wi, 0, 0, taps)]
 
 
@@ -369,6 +369,13 @@ def conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=
     act_bwd (an ActBwdSpec, with epi=EPI_BWD): try EPI_BWD_ACT; returns True when the fused epilogue ran (out then holds the producing
     layer's dz), False when the launch was a plain EPI_BWD."""
     assert is_cl(x) and is_cl(out), 'conv_igemm expects fp32 channels_last CUDA tensors'
+    if len(classes) > 4:        # (a stride-3 transposed conv has nine output phases) the classes of a store / atomic launch are independent: four per launch
+        assert epi in (L.EPI_STORE, L.EPI_ATOMIC) and ds is None and out_amax is None and act_bwd is None, 'more than four tap classes: plain store launches only'
+        for i in range(0, len(classes), 4):
+            conv_igemm(x, wp, Ck, Nc, out, classes[i:i + 4], in_stride=in_stride, out_stride=out_stride, in_scale=in_scale, epi=epi, ksplit=ksplit,
+                       out_scale=out_scale, algo_flops=None if algo_flops is None else algo_flops * min(4, len(classes) - i) / len(classes),
+                       precision=precision, a_amax=a_amax, a_amax_mul=a_amax_mul, w_pieces=w_pieces)
+        return False
     p = L.ConvParams()
     n, cx, hi, wi = x.shape
     _, co, ho, wo = out.shape
@@ -775,6 +782,10 @@ def conv_wgrad(x, g, Ck, Nc, dwp, classes, in_stride=1, out_stride=1, in_scale=N
     """dwp[Nc, taps*Ck] += grad of the packed weights (dwp pre-zeroed).  precision 'f32' | 'f16x3' (g_amax: device scalar max|g|
     for the range normalisation of the gradient operand, see include/eg3d_hip.h)."""
     assert is_cl(x) and is_cl(g)
+    if len(classes) > 4:        # the launch accumulates into dwp: four classes at a time
+        for i in range(0, len(classes), 4):
+            conv_wgrad(x, g, Ck, Nc, dwp, classes[i:i + 4], in_stride, out_stride, in_scale, psplit, precision, g_amax, g_amax_mul)
+        return dwp
     p = L.WgradParams()
     n, cx, hi, wi = x.shape
     _, cg, ho, wo = g.shape

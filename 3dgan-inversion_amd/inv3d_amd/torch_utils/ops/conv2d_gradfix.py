@@ -5,8 +5,9 @@ three launches of the same family; gradients of gradients re-enter these Functio
 
 Supported: fp32, kernels <= 3x3, conv2d with any isotropic stride and symmetric padding (stride > 1 = the data gradient of the
 transposed conv, as the reference states the duality), conv_transpose2d with isotropic stride and symmetric padding (cropping),
-groups (one launch per group), any channel counts (padded to multiples of 4 on the contraction side).  Dilated k x k kernels and
-output_padding raise NotImplementedError -- there is no silent fallback."""
+output_padding < stride, groups (one launch per group), dilated stride-1 k x k kernels (other tap offsets for the tap-list kernel), any channel
+counts (padded to multiples of 4 on the contraction side).  Dilated AND strided kernels, dilated transposed convs and anisotropic strides raise
+NotImplementedError -- there is no silent fallback."""
 import contextlib
 
 import torch
@@ -62,10 +63,12 @@ class _ConvFn(torch.autograd.Function):
         wf = H.memo(('gradfix_fwd', mode, Cip), [w], _pack)
         Cop = (Co + 3) // 4 * 4
         if mode == 'corr':
-            Ho, Wo = Hi + 2 * pad[0] - kh + 1, Wi + 2 * pad[1] - kw + 1
+            Ho, Wo = Hi + 2 * pad[0] - up * (kh - 1), Wi + 2 * pad[1] - up * (kw - 1)         # mode 'corr': `up` carries the dilation
             if pad[0] != pad[1]:
                 raise NotImplementedError('asymmetric conv padding')
-            cls = H.classes_corr(Ho, Wo, kh, kw, pad[0], flip_taps)
+            if Ho < 1 or Wo < 1:
+                raise ValueError('conv2d: kernel larger than the padded input')
+            cls = H.classes_corr(Ho, Wo, kh, kw, pad[0], flip_taps, dil=up)
             out = (H.zeros_cl if Cop != Co else H.empty_cl)(N, Cop, Ho, Wo, x.device)
             H.conv_igemm(xin, wf, Cip, Co, out, cls, epi=L.EPI_STORE)
         else:
@@ -112,7 +115,7 @@ class _ConvDataGradFn(torch.autograd.Function):
         Cip = (Ci + 3) // 4 * 4
         dx = (H.zeros_cl if Cip != Ci else H.empty_cl)(N, Cip, Hi, Wi, dy.device)
         if mode == 'corr':
-            cls = H.classes_corr_adjoint(Hi, Wi, kh, kw, pad[0], flip_taps)
+            cls = H.classes_corr_adjoint(Hi, Wi, kh, kw, pad[0], flip_taps, dil=up)
             H.conv_igemm(g, wa, Cgp, Ci, dx, cls, epi=L.EPI_STORE)
         else:
             cls = H.classes_convT_adjoint(Hi, Wi, kh, kw, up, flip_taps)
@@ -142,7 +145,7 @@ class _ConvWeightGradFn(torch.autograd.Function):
         N, Cip, Hi, Wi = xin.shape
         if mode == 'corr':
             Co, Ci, kh, kw = w_shape
-            cls = H.classes_corr(g.shape[2], g.shape[3], kh, kw, pad[0], flip_taps)
+            cls = H.classes_corr(g.shape[2], g.shape[3], kh, kw, pad[0], flip_taps, dil=up)
             out_stride = 1
         else:
             Ci, Co, kh, kw = w_shape
@@ -200,13 +203,14 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, 
         y = _grouped(lambda x_, w_: conv2d(x_, w_, None, stride, padding, dilation, 1, _flip_taps), input, weight, groups, 0)
     elif dil != 1:
         # a dilated k x k kernel is a (d (k - 1) + 1)^2 kernel with zeros between the taps: for the tap-list kernel that is only a change
-        # of the tap offsets, but the <= 3 x 3 halo of the fast paths does not hold -- expressed through the strided-correlation class
-        # machinery below with explicit taps is not needed by any caller; materialise the zero-stuffed kernel while it stays <= 9 taps
+        # of the tap offsets (loader-split kernel: any offset, reads outside the image are zero)
         kh, kw = weight.shape[2:]
         if kh * kw == 1:
             y = conv2d(input, weight, None, stride, padding, 1, 1, _flip_taps)
+        elif s == (1, 1):        # the tap-list kernel only sees other tap offsets (the Function's `up` slot carries the dilation in 'corr' mode)
+            y = _ConvFn.apply(input, weight, 'corr', dil, p, _flip_taps)
         else:
-            raise NotImplementedError('dilated k x k convolution (no caller on or near the inversion path)')
+            raise NotImplementedError('dilated AND strided k x k convolution (no caller on or near the inversion path)')
     elif s == (1, 1):
         y = _ConvFn.apply(input, weight, 'corr', 1, p, _flip_taps)
     else:
@@ -225,16 +229,27 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, 
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1, _flip_taps=False):
-    """F.conv_transpose2d's contract (conv2d_gradfix.py:42-45) for isotropic stride, symmetric padding, no output_padding, dilation 1."""
+    """F.conv_transpose2d's contract (conv2d_gradfix.py:42-45) for isotropic stride, symmetric padding, dilation 1; output_padding < stride."""
     if _check(weight, dilation) != 1:
         raise NotImplementedError('dilated transposed convolution')
-    s = _pair(stride)
-    if s[0] != s[1] or _pair(output_padding) != (0, 0):
-        raise NotImplementedError('anisotropic stride / output_padding')
+    s, op, p = _pair(stride), _pair(output_padding), _pair(padding)
+    if s[0] != s[1]:
+        raise NotImplementedError('anisotropic stride')
+    if op[0] >= max(s[0], 1) or op[1] >= max(s[1], 1) or min(op) < 0:
+        raise ValueError('output_padding must be smaller than the stride')
     if groups != 1:
         if input.shape[1] % groups or weight.shape[0] % groups:
             raise ValueError('channels must be divisible by groups')
-        y = _grouped(lambda x_, w_: conv_transpose2d(x_, w_, None, stride, padding, 0, 1, 1, _flip_taps), input, weight, groups, 1)
+        y = _grouped(lambda x_, w_: conv_transpose2d(x_, w_, None, stride, padding, output_padding, 1, 1, _flip_taps), input, weight, groups, 1)
+    elif op == (0, 0):
+        y = _ConvFn.apply(input, weight, 'convT', s[0], p, _flip_taps)
     else:
-        y = _ConvFn.apply(input, weight, 'convT', s[0], _pair(padding), _flip_taps)
+        # output_padding only changes WHICH rows / columns of the un-cropped result are kept: `padding` fewer at the top / left,
+        # `padding - output_padding` fewer at the bottom / right (rows no tap reaches are zero)
+        full = _ConvFn.apply(input, weight, 'convT', s[0], (0, 0), _flip_taps)
+        grow = [max(op[1] - p[1], 0), max(op[0] - p[0], 0)]
+        if grow[0] or grow[1]:
+            full = torch.nn.functional.pad(full, [0, grow[0], 0, grow[1]])
+        Hf, Wf = full.shape[2], full.shape[3]
+        y = full[:, :, p[0]: Hf - max(p[0] - op[0], 0), p[1]: Wf - max(p[1] - op[1], 0)]
     return y if bias is None else y + bias.reshape(1, -1, 1, 1)

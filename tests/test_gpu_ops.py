@@ -408,6 +408,37 @@ def test_torgb_takes_the_skip_image_at_half_resolution(cfg):
         close(a[:, :co] if nm == 'skip' else a, b[:, :co] if nm == 'skip' else b, 1e-4, f'torgb + up-sampled skip grad {nm} {cfg}')
 
 
+@pytest.mark.parametrize('case', [('conv', 2, 2, 1), ('conv', 3, 3, 2), ('conv', 2, 0, 4), ('convT', 2, 1, 1), ('convT', 3, 1, 2), ('convT', 2, 0, 1), ('convT', 3, 0, 2)])
+def test_conv2d_gradfix_dilation_and_output_padding(case):
+    """The two corners of F.conv2d / F.conv_transpose2d that conv2d_gradfix hands to ATen unchanged (torch_utils/ops/conv2d_gradfix.py:37-45)
+    and that raised until round 3: dilated stride-1 k x k kernels, and output_padding of a transposed conv -- values and both gradients
+    against torch in float64, with groups."""
+    from inv3d_amd.torch_utils.ops import conv2d_gradfix
+    kind, a, b, groups = case
+    g = torch.Generator().manual_seed(21)
+    ci, co, k = 8, 12, 3
+    x = torch.randn(2, ci, 11, 9, generator=g)
+    dyn = None
+    if kind == 'conv':                     # a = dilation, b = padding
+        w = torch.randn(co, ci // groups, k, k, generator=g) / 5
+        ref = lambda xx, ww: torch.nn.functional.conv2d(xx, ww, None, 1, b, a, groups)
+        mine = lambda xx, ww: conv2d_gradfix.conv2d(xx, ww, None, 1, b, a, groups)
+    else:                                  # a = stride, b = padding, output_padding = a - 1
+        w = torch.randn(ci, co // groups, k, k, generator=g) / 5
+        ref = lambda xx, ww: torch.nn.functional.conv_transpose2d(xx, ww, None, a, b, a - 1, groups)
+        mine = lambda xx, ww: conv2d_gradfix.conv_transpose2d(xx, ww, None, a, b, a - 1, groups)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = ref(xr, wr)
+    dy = torch.randn(yr.shape, generator=g).double()
+    gxr, gwr = torch.autograd.grad(yr, [xr, wr], dy)
+    xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    yg = mine(xg, wg)
+    close(yg, yr, 2e-5, f'{case} forward')
+    gx, gw = torch.autograd.grad(yg, [xg, wg], dy.float().to(DEV))
+    close(gx, gxr, 2e-5, f'{case} dx')
+    close(gw, gwr, 5e-5, f'{case} dw')
+
+
 # ------------------------------------------------------------------------------------------------- renderer
 def test_ray_gen_golden(golden):
     from inv3d_amd.training.volumetric_rendering.ray_sampler import RaySampler
