@@ -183,7 +183,7 @@ def _capture(G, impl, ws, c, uni, kw, leaves, need_grad):
             H.weights_changed()
         fwd = torch.cuda.CUDAGraph()
         with _aliased_leaves(G, leaves) as aliases:
-            with torch.cuda.graph(fwd, capture_error_mode='thread_local'), H.zero_arena(e.arena_f):
+            with H.capture_guard(), torch.cuda.graph(fwd, capture_error_mode='thread_local'), H.zero_arena(e.arena_f):
                 with torch.set_grad_enabled(need_grad):
                     out = impl(e.s_ws, e.s_c, render_uniforms=s_uni, **kw)
         img, raw = out['image'], out['image_raw']
@@ -195,7 +195,7 @@ def _capture(G, impl, ws, c, uni, kw, leaves, need_grad):
         if any(req):
             gouts = [torch.zeros_like(o) for o, r in zip(outs, req) if r]
             bwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(bwd, pool=fwd.pool(), capture_error_mode='thread_local'), H.zero_arena(e.arena_b):
+            with H.capture_guard(), torch.cuda.graph(bwd, pool=fwd.pool(), capture_error_mode='thread_local'), H.zero_arena(e.arena_b):
                 gins = torch.autograd.grad([o for o, r in zip(outs, req) if r], targets, gouts, allow_unused=True)
         del aliases, targets
         if keep:

@@ -4,6 +4,8 @@ Tensors handed to the fused path are fp32 "NHWC": logical shape [N,C,H,W] with c
 reference-facing API keeps NCHW shapes while memory is channel-contiguous, which is what the MFMA implicit GEMM,
 the float4 epilogues and the 128-byte tri-plane gathers want).
 """
+import contextlib
+import gc
 import math
 import os
 import weakref
@@ -72,6 +74,21 @@ PROFILER = None
 def is_cl(t: torch.Tensor) -> bool:
     return t.dim() == 4 and t.is_cuda and t.dtype == torch.float32 and (t.stride(1) == 1 or t.shape[1] == 1) and \
         t.is_contiguous(memory_format=CL)
+
+
+@contextlib.contextmanager
+def capture_guard():
+    """Wrap a HIP-graph capture: the cyclic garbage collector must not run inside it.  Collecting the remains of an EARLIER capture (a
+    CUDAGraph, tensors of its pool) frees device memory, which the runtime refuses while a stream is capturing -- the process aborts
+    ("Fatal Python error: Aborted ... Garbage-collecting", seen once in four runs of the GPU suite).  Collect before, hold during."""
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 def to_cl(t: torch.Tensor) -> torch.Tensor:

@@ -451,7 +451,7 @@ class LatentProjector:
                     self.translation_optimizer.zero_grad(set_to_none=True)
                 graph = torch.cuda.CUDAGraph()
                 try:
-                    with torch.cuda.graph(graph, capture_error_mode='thread_local'):   # other threads (RCCL watchdog) may touch the runtime
+                    with hipops.capture_guard(), torch.cuda.graph(graph, capture_error_mode='thread_local'):   # other threads (RCCL watchdog) may touch the runtime
                         self.last = self._step_body(self._scale_t, self._wn, self.synth_kwargs, True)
                     self._graph = graph
                     graph.replay()                    # capture records without executing
@@ -670,7 +670,7 @@ class PivotalTuner:
         self.optimizer.zero_grad(set_to_none=True)
         graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(graph, capture_error_mode='thread_local'), hipops.zero_arena(self._arena):
+            with hipops.capture_guard(), torch.cuda.graph(graph, capture_error_mode='thread_local'), hipops.zero_arena(self._arena):
                 self._step(False)
             self._graph, self._graph_last = graph, self.last
             graph.replay()                        # capture records without executing
