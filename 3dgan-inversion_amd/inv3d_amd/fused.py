@@ -645,7 +645,24 @@ class ToRGBFn(torch.autograd.Function):
                     up_taps = (0.25, 0.75, 0.75, 0.25)          # [1,3,3,1] / 8, times the per-axis gain 2
                 else:
                     skip = H.upfirdn2d_nhwc(skip, fir44(skip.device), up=2, pad=(2, 1, 2, 1), gain=4.0)
-        if clampv < 0 and skip is not None:
+        # small pixel counts (the 4^2 .. 64^2 blocks): the implicit GEMM's 32-step contraction is all latency there (~21 us for 64 pixels);
+        # csrc/torgb_small.hip does the same arithmetic (exact fp32 products) in one short launch
+        small = (H.TORGB_SMALL and N * Hh * Ww <= H.TORGB_SMALL_MAX_PIX and Ci % 8 == 0 and Cp % 32 == 0 and wf.stride(1) == 1
+                 and (skip is None or up_taps is not None or tuple(skip.shape) == (N, Cp, Hh, Ww)))
+        if small and clampv < 0 and skip is not None:
+            out = H.empty_cl(N, Cp, Hh, Ww, x.device)
+            small = H.torgb_small(x, wf, styles, out, bias=b, clamp=-1.0, addend=skip, addend_up2_taps=up_taps)
+        elif small:
+            y = H.empty_cl(N, Cp, Hh, Ww, x.device)
+            if up_taps is not None:          # clamped layer: its backward needs y itself, the skip image is added by a pass of its own
+                skip = H.upfirdn2d_nhwc(skip, fir44(skip.device), up=2, pad=(2, 1, 2, 1), gain=4.0)
+                up_taps = None
+            small = H.torgb_small(x, wf, styles, y, bias=b, clamp=clampv)
+            if small:
+                out = y + skip if skip is not None else y
+        if small:
+            pass
+        elif clampv < 0 and skip is not None:
             out = H.empty_cl(N, Cp, Hh, Ww, x.device)
             try:
                 H.conv_igemm(x, wf, Ci, Cp, out, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=-1.0, addend=skip,

@@ -1193,6 +1193,26 @@ def noise_regularizer(bufs, scale=1.0, want_grad=True, grads=None):
 
 
 
+TORGB_SMALL = os.environ.get('EG3D_TORGB_SMALL', '1') != '0'            # low-latency toRGB launch for small pixel counts (csrc/torgb_small.hip)
+TORGB_SMALL_MAX_PIX = int(os.environ.get('EG3D_TORGB_SMALL_MAX_PIX', '4096'))
+
+
+def torgb_small(x, wf, styles, out, bias=None, clamp=-1.0, addend=None, addend_up2_taps=None):
+    """eg3d_torgb_small_fwd: out = clamp(conv1x1(x * styles, wf) + bias) + addend.  x / out / addend channels_last fp32; wf [Cp, C] packed rows.
+    Returns False (nothing launched) when the geometry is not the kernel's."""
+    assert is_cl(x) and is_cl(out)
+    n, c, h, w = x.shape
+    p = L.TorgbSmallParams(x=x.data_ptr(), w=wf.data_ptr(), s=styles.data_ptr(), bias=bias.data_ptr() if bias is not None else None,
+                           addend=addend.data_ptr() if addend is not None else None, out=out.data_ptr(), N=n, H=h, W=w, C=c, Cp=out.shape[1],
+                           ldx=c, ldo=out.shape[1], w_row=wf.stride(0), addend_up2=1 if addend_up2_taps is not None else 0, clamp=float(clamp))
+    if addend_up2_taps is not None:
+        p.addend_taps[:] = [float(t) for t in addend_up2_taps]
+    if not L.lib().eg3d_torgb_small_supported(C.byref(p)):
+        return False
+    L.check(L.lib().eg3d_torgb_small_fwd(C.byref(p), L.stream_ptr()), 'torgb_small_fwd')
+    return True
+
+
 class HipAdam:
     """torch.optim.Adam(params, lr, betas, eps) for fp32 leaves in one launch per 32 leaves (`eg3d_adam_step`), with two extras the latent
     projector's step wants folded in: a second gradient per leaf (the noise regulariser's, which does not go through autograd) and the

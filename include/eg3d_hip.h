@@ -497,6 +497,29 @@ int eg3d_noise_regularizer(float* const* x, float* const* grad, const int32_t* r
                            float* reg_out, float scale, void* stream);
 int eg3d_noise_normalize(float* const* x, const int32_t* res, int nbufs, float* workspace, void* stream);
 
+/* Low-latency toRGB for small pixel counts (the 4^2 .. 64^2 blocks of the backbone) -- replaces ToRGBLayer.forward
+ * (training/networks_stylegan2.py:338-359) + the skip accumulation of SynthesisBlock.forward (:433-436) where eg3d_conv2d_igemm_f32's
+ * 32-step contraction loop is all latency:
+ *   out[n,p,o] = clamp( sum_c x[n,p,c] s[n,c] w[o,c] + bias[o] ) + addend[n,p,o]
+ * with exact fp32 products (v_mfma_f32_32x32x2_f32).  x [N,H*W,ldx] NHWC (C used, C % 8 == 0), w [Cp][w_row] (row per output, Cp % 32 == 0:
+ * padded rows are zero), s [N,C], bias [Cp] or null, clamp < 0 = none; addend null | [N,H,W,ldo] | (addend_up2) the half-resolution image
+ * [N,H/2,W/2,ldo] added through upsample2d with the separable 4-tap filter addend_taps (as eg3d_conv_params::addend_up2).  out [N,H,W,ldo]. */
+typedef struct eg3d_torgb_small_params {
+    const float* x;
+    const float* w;
+    const float* s;
+    const float* bias;
+    const float* addend;
+    float* out;
+    int32_t N, H, W, C, Cp;
+    int32_t ldx, ldo, w_row;
+    int32_t addend_up2;
+    float clamp;
+    float addend_taps[4];
+} eg3d_torgb_small_params;
+int eg3d_torgb_small_supported(const eg3d_torgb_small_params* p);
+int eg3d_torgb_small_fwd(const eg3d_torgb_small_params* p, void* stream);
+
 /* torch.optim.Adam(betas, eps; no weight decay, no amsgrad) over up to EG3D_ADAM_ITEMS_MAX leaves in one launch (the projector's
  * optimiser, w_projector.py:107-118,256): p, m (exp_avg), v (exp_avg_sq) updated in place from the gradient g + g2 (one of them may be
  * null).  lr and step are DEVICE scalars (a captured graph is replayed for every step index): step holds the number of updates already
