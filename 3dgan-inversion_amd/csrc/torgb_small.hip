@@ -101,6 +101,111 @@ __global__ void __launch_bounds__(256) torgb_small_kernel(const eg3d_torgb_small
     *reinterpret_cast<float4*>(p.out + ((int64_t)n * HW + ep) * p.ldo + eo) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// ---- data gradient of the same layer: dx[n,p,c] = (sum_o dy[n,p,o] w[o,c]) s[n,c] (+ addend), ds[n,c] += sum_p (sum_o ...) x[n,p,c], and --
+// with act_on -- the activation backward of the layer that produced x (EG3D_EPI_BWD_ACT of the conv kernels: dx then holds THAT layer's dz;
+// dbias / dd / dnoise / dstrength accumulated).  Same tiling with the roles swapped: tile = 32 pixels x 32 INPUT channels, contraction over the
+// Cp outputs (96: twelve 8-groups, three per wave).
+__global__ void __launch_bounds__(256) torgb_small_bwd_kernel(const eg3d_torgb_small_bwd_params p) {
+    __shared__ float red[4][TS_PIX][TS_OUT + 1];
+    __shared__ float ds_lds[TS_OUT], db_lds[TS_OUT], dq_lds[TS_OUT], sc_lds[1];
+    const int HW = p.H * p.W;
+    const int tiles = (HW + TS_PIX - 1) / TS_PIX;
+    const int n = blockIdx.x / tiles, p0 = (blockIdx.x - n * tiles) * TS_PIX, c0 = blockIdx.y * TS_OUT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane & 31, h = lane >> 5;
+    const int pix = p0 + row;
+    const bool pok = pix < HW;
+    const int groups = p.Cp / 8;
+    const int g0 = (int)((int64_t)groups * wave / 4), g1 = (int)((int64_t)groups * (wave + 1) / 4);
+    const float* gr = p.dy + ((int64_t)n * HW + (pok ? pix : 0)) * p.ldg + 4 * h;
+    const float* wr = p.wa + (int64_t)(c0 + row) * p.wa_row + 4 * h;
+    if (threadIdx.x < TS_OUT) { ds_lds[threadIdx.x] = 0.f; db_lds[threadIdx.x] = 0.f; dq_lds[threadIdx.x] = 0.f; }
+    if (threadIdx.x == 0) sc_lds[0] = 0.f;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int g = g0; g < g1; g += TS_BATCH) {
+        float4 ga[TS_BATCH], wb[TS_BATCH];
+#pragma unroll
+        for (int j = 0; j < TS_BATCH; ++j) {
+            const bool ok = g + j < g1;
+            const int kb = (ok ? g + j : g0) * 8;
+            ga[j] = (ok && pok) ? *reinterpret_cast<const float4*>(gr + kb) : make_float4(0.f, 0.f, 0.f, 0.f);
+            wb[j] = ok ? *reinterpret_cast<const float4*>(wr + kb) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < TS_BATCH; ++j) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[j].x, wb[j].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[j].y, wb[j].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[j].z, wb[j].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[j].w, wb[j].w, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][row] = acc[r];
+    __syncthreads();
+    const int er = threadIdx.x >> 3, eq = threadIdx.x & 7;
+    const int ep = p0 + er, eo = c0 + eq * 4;
+    const bool ok = ep < HW;
+    const bool act_on = p.act_on != 0;
+    const eg3d_act_bwd& ab = p.act_bwd;
+    eg3d_act_bwd_consts abc = {};
+    if (act_on) abc = eg3d_act_bwd_setup(ab);
+    float omax = 0.f;
+    if (ok) {
+        float4 v;
+        v.x = (red[0][er][eq * 4 + 0] + red[1][er][eq * 4 + 0]) + (red[2][er][eq * 4 + 0] + red[3][er][eq * 4 + 0]);
+        v.y = (red[0][er][eq * 4 + 1] + red[1][er][eq * 4 + 1]) + (red[2][er][eq * 4 + 1] + red[3][er][eq * 4 + 1]);
+        v.z = (red[0][er][eq * 4 + 2] + red[1][er][eq * 4 + 2]) + (red[2][er][eq * 4 + 2] + red[3][er][eq * 4 + 2]);
+        v.w = (red[0][er][eq * 4 + 3] + red[1][er][eq * 4 + 3]) + (red[2][er][eq * 4 + 3] + red[3][er][eq * 4 + 3]);
+        const int64_t off = ((int64_t)n * HW + ep) * p.ldx + eo;
+        float4 xin4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.xin != nullptr) xin4 = *reinterpret_cast<const float4*>(p.xin + off);
+        if (p.ds != nullptr) {
+            atomicAdd(&ds_lds[eq * 4 + 0], v.x * xin4.x); atomicAdd(&ds_lds[eq * 4 + 1], v.y * xin4.y);
+            atomicAdd(&ds_lds[eq * 4 + 2], v.z * xin4.z); atomicAdd(&ds_lds[eq * 4 + 3], v.w * xin4.w);
+        }
+        const float4 s4 = *reinterpret_cast<const float4*>(p.s + (int64_t)n * p.C + eo);
+        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.addend != nullptr) a4 = *reinterpret_cast<const float4*>(p.addend + off);
+        v = make_float4(v.x * s4.x + a4.x, v.y * s4.y + a4.y, v.z * s4.z + a4.z, v.w * s4.w + a4.w);
+        if (act_on) {
+            float4 abd4 = make_float4(1.f, 1.f, 1.f, 1.f), abb4 = make_float4(0.f, 0.f, 0.f, 0.f), accb4 = abb4, accd4 = abb4;
+            if (ab.d != nullptr) abd4 = *reinterpret_cast<const float4*>(ab.d + (int64_t)n * p.C + eo);
+            if (ab.bias != nullptr) abb4 = *reinterpret_cast<const float4*>(ab.bias + eo);
+            const float nz = ab.noise != nullptr ? ab.noise[(int64_t)n * ab.noise_nstride + ep] : 0.f;
+            float cs;
+            v = eg3d_act_bwd_unit(abc, v, xin4, abd4, abb4, nz * abc.strength, accb4, accd4, cs);
+            if (ab.dbias != nullptr) {
+                atomicAdd(&db_lds[eq * 4 + 0], accb4.x); atomicAdd(&db_lds[eq * 4 + 1], accb4.y);
+                atomicAdd(&db_lds[eq * 4 + 2], accb4.z); atomicAdd(&db_lds[eq * 4 + 3], accb4.w);
+            }
+            if (ab.dd != nullptr) {
+                atomicAdd(&dq_lds[eq * 4 + 0], accd4.x); atomicAdd(&dq_lds[eq * 4 + 1], accd4.y);
+                atomicAdd(&dq_lds[eq * 4 + 2], accd4.z); atomicAdd(&dq_lds[eq * 4 + 3], accd4.w);
+            }
+            if (ab.dnoise != nullptr || ab.dstrength != nullptr) {      // the 8 lanes of a pixel row hold this tile's 32 channels
+                cs = eg3d_row_group_sum(cs, 8);
+                if (eq == 0) {
+                    if (ab.dnoise != nullptr) unsafeAtomicAdd(ab.dnoise + (int64_t)n * ab.dnoise_nstride + ep, cs * abc.strength);
+                    if (ab.dstrength != nullptr && cs * nz != 0.f) atomicAdd(sc_lds, cs * nz);
+                }
+            }
+        }
+        omax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        *reinterpret_cast<float4*>(p.dx + off) = v;
+    }
+    eg3d_commit_amax_block(omax, p.out_amax);
+    __syncthreads();
+    if (threadIdx.x < TS_OUT) {
+        const int c = c0 + threadIdx.x;
+        if (p.ds != nullptr) unsafeAtomicAdd(p.ds + (int64_t)n * p.C + c, ds_lds[threadIdx.x]);
+        if (act_on && ab.dbias != nullptr) unsafeAtomicAdd(ab.dbias + c, db_lds[threadIdx.x]);
+        if (act_on && ab.dd != nullptr) unsafeAtomicAdd(ab.dd + (int64_t)n * p.C + c, dq_lds[threadIdx.x] / (ab.d != nullptr ? ab.d[(int64_t)n * p.C + c] : 1.f));
+    }
+    if (act_on && ab.dstrength != nullptr && threadIdx.x == 0 && sc_lds[0] != 0.f) unsafeAtomicAdd(ab.dstrength, sc_lds[0]);
+}
+
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 }  // namespace
@@ -120,6 +225,31 @@ extern "C" int eg3d_torgb_small_fwd(const eg3d_torgb_small_params* p, void* stre
     if (!eg3d_torgb_small_supported(p)) return EG3D_ERR_UNSUPPORTED;
     const dim3 grid(p->N * eg3d_cdiv((int64_t)p->H * p->W, TS_PIX), p->Cp / TS_OUT);
     hipLaunchKernelGGL(torgb_small_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_torgb_small_bwd_supported(const eg3d_torgb_small_bwd_params* p) {
+    if (!p || !p->dy || !p->wa || !p->s || !p->dx) return 0;
+    if (p->N < 1 || p->H < 1 || p->W < 1 || p->Cp < 8 || (p->Cp & 7) || p->C < TS_OUT || (p->C % TS_OUT)) return 0;
+    if ((p->ldg & 3) || p->ldg < p->Cp || (p->ldx & 3) || p->ldx < p->C || (p->wa_row & 3) || p->wa_row < p->Cp) return 0;
+    if (!al16(p->dy) || !al16(p->wa) || !al16(p->s) || !al16(p->dx) || (p->xin && !al16(p->xin)) || (p->addend && !al16(p->addend))) return 0;
+    if ((p->ds || p->act_on) && !p->xin) return 0;
+    if (p->act_on) {
+        const eg3d_act_bwd& ab = p->act_bwd;
+        if (ab.act != EG3D_ACT_LINEAR && ab.act != EG3D_ACT_LRELU) return 0;          // invertible piecewise-linear activations only
+        if (!(ab.gain > 0.f) || (ab.noise != nullptr && ab.noise_strength == nullptr)) return 0;
+        if ((ab.d && !al16(ab.d)) || (ab.bias && !al16(ab.bias))) return 0;
+    }
+    if ((int64_t)p->N * eg3d_cdiv((int64_t)p->H * p->W, TS_PIX) > 0x7fffffff) return 0;
+    return 1;
+}
+
+extern "C" int eg3d_torgb_small_bwd(const eg3d_torgb_small_bwd_params* p, void* stream) {
+    if (!p || !p->dy || !p->wa || !p->s || !p->dx) return EG3D_ERR_INVALID;
+    if (!eg3d_torgb_small_bwd_supported(p)) return EG3D_ERR_UNSUPPORTED;
+    const dim3 grid(p->N * eg3d_cdiv((int64_t)p->H * p->W, TS_PIX), p->C / TS_OUT);
+    hipLaunchKernelGGL(torgb_small_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

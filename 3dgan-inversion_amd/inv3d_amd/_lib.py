@@ -122,6 +122,12 @@ class TorgbSmallParams(C.Structure):
                 ('w_row', C.c_int32), ('addend_up2', C.c_int32), ('clamp', C.c_float), ('addend_taps', C.c_float * 4)]
 
 
+class TorgbSmallBwdParams(C.Structure):
+    _fields_ = [('dy', C.c_void_p), ('wa', C.c_void_p), ('s', C.c_void_p), ('xin', C.c_void_p), ('addend', C.c_void_p), ('dx', C.c_void_p), ('ds', C.c_void_p),
+                ('out_amax', C.c_void_p), ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('C', C.c_int32), ('Cp', C.c_int32), ('ldg', C.c_int32),
+                ('ldx', C.c_int32), ('wa_row', C.c_int32), ('act_on', C.c_int32), ('pad_', C.c_int32), ('act_bwd', ActBwd)]
+
+
 ADAM_ITEMS_MAX = 32
 
 
@@ -238,6 +244,8 @@ _SIGS = {
     'eg3d_warp_project_bwd': (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_void_p]),
     'eg3d_torgb_small_supported': (C.c_int, [C.POINTER(TorgbSmallParams)]),
     'eg3d_torgb_small_fwd': (C.c_int, [C.POINTER(TorgbSmallParams), C.c_void_p]),
+    'eg3d_torgb_small_bwd_supported': (C.c_int, [C.POINTER(TorgbSmallBwdParams)]),
+    'eg3d_torgb_small_bwd': (C.c_int, [C.POINTER(TorgbSmallBwdParams), C.c_void_p]),
     'eg3d_adam_step': (C.c_int, [C.POINTER(AdamList), C.c_void_p, C.c_void_p]),
     'eg3d_unit_normalize_levels': (C.c_int, [C.POINTER(UnitLevels), C.c_int, C.c_void_p]),
     'eg3d_unit_normalize_bwd': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int64, C.c_int, C.c_void_p]),

@@ -737,8 +737,13 @@ class ToRGBFn(torch.autograd.Function):
                     H.torgb_dgrad_act(dy, wa_p, x, styles, dx, spec, ds=ds, addend=add, dz_amax=pacc[4])
                     did = True
             else:
-                did = H.conv_igemm(dy, wa_p, Cp, Ci, dx, H.classes_corr_adjoint(Hh, Ww, 1, 1, 0), epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, addend=add,
-                                   **fkw)
+                did = None
+                if H.TORGB_SMALL and N * Hh * Ww <= H.TORGB_SMALL_MAX_PIX and Ci % 32 == 0 and Cp % 8 == 0 and wa_p.stride(1) == 1:
+                    # small pixel counts: the low-latency launch (csrc/torgb_small.hip), same epilogue as the implicit GEMM's
+                    did = H.torgb_small_bwd(dy, wa_p, styles, x, dx, ds=ds, addend=add, **fkw)
+                if did is None:
+                    did = H.conv_igemm(dy, wa_p, Cp, Ci, dx, H.classes_corr_adjoint(Hh, Ww, 1, 1, 0), epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, addend=add,
+                                       **fkw)
             if prod is not None and did is True:
                 prod.fused = (dx,) + tuple(pacc)
         elif dx_pass is not None:

@@ -1213,6 +1213,30 @@ def torgb_small(x, wf, styles, out, bias=None, clamp=-1.0, addend=None, addend_u
     return True
 
 
+def torgb_small_bwd(dy, wa, styles, x, dx, ds=None, addend=None, act_bwd=None, out_amax=None):
+    """eg3d_torgb_small_bwd: the toRGB data gradient for small pixel counts (+ the producing layer's activation backward when act_bwd is an
+    ActBwdSpec the kernel takes).  Returns None when nothing was launched (geometry not the kernel's), else True / False = the activation
+    backward was / was not fused (as conv_igemm)."""
+    assert is_cl(dy) and is_cl(x) and is_cl(dx)
+    n, c, h, w = x.shape
+    p = L.TorgbSmallBwdParams(dy=dy.data_ptr(), wa=wa.data_ptr(), s=styles.data_ptr(), xin=x.data_ptr(), addend=addend.data_ptr() if addend is not None else None,
+                              dx=dx.data_ptr(), ds=ds.data_ptr() if ds is not None else None, out_amax=out_amax.data_ptr() if out_amax is not None else None,
+                              N=n, H=h, W=w, C=c, Cp=dy.shape[1], ldg=dy.shape[1], ldx=c, wa_row=wa.stride(0), act_on=0)
+    fused = False
+    if act_bwd is not None:
+        p.act_on = 1
+        act_bwd.fill(p.act_bwd)
+        fused = bool(L.lib().eg3d_torgb_small_bwd_supported(C.byref(p)))
+        if not fused:
+            p.act_on = 0
+            p.act_bwd = L.ActBwd()
+            p.out_amax = None
+    if not fused and not L.lib().eg3d_torgb_small_bwd_supported(C.byref(p)):
+        return None
+    L.check(L.lib().eg3d_torgb_small_bwd(C.byref(p), L.stream_ptr()), 'torgb_small_bwd')
+    return fused
+
+
 class HipAdam:
     """torch.optim.Adam(params, lr, betas, eps) for fp32 leaves in one launch per 32 leaves (`eg3d_adam_step`), with two extras the latent
     projector's step wants folded in: a second gradient per leaf (the noise regulariser's, which does not go through autograd) and the

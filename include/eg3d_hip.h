@@ -520,6 +520,27 @@ typedef struct eg3d_torgb_small_params {
 int eg3d_torgb_small_supported(const eg3d_torgb_small_params* p);
 int eg3d_torgb_small_fwd(const eg3d_torgb_small_params* p, void* stream);
 
+/* Data gradient of that layer for small pixel counts: dx[n,p,c] = (sum_o dy[n,p,o] wa[c,o]) s[n,c] + addend[n,p,c]; ds[n,c] += the un-scaled
+ * sum times xin[n,p,c] (pre-zeroed, optional).  act_on != 0: additionally the activation backward of the layer that produced xin, exactly as
+ * EG3D_EPI_BWD_ACT of eg3d_conv2d_igemm_f32 (dx receives that layer's dz; act_bwd's accumulators are filled).  dy [N,H*W,ldg] (Cp used, Cp % 8
+ * == 0), wa [C][wa_row] (row per INPUT channel), C % 32 == 0, xin / addend / dx [N,H*W,ldx].  out_amax: optional pre-zeroed max|dx|. */
+typedef struct eg3d_torgb_small_bwd_params {
+    const float* dy;
+    const float* wa;
+    const float* s;
+    const float* xin;
+    const float* addend;
+    float* dx;
+    float* ds;
+    float* out_amax;
+    int32_t N, H, W, C, Cp;
+    int32_t ldg, ldx, wa_row;
+    int32_t act_on, pad_;
+    eg3d_act_bwd act_bwd;
+} eg3d_torgb_small_bwd_params;
+int eg3d_torgb_small_bwd_supported(const eg3d_torgb_small_bwd_params* p);
+int eg3d_torgb_small_bwd(const eg3d_torgb_small_bwd_params* p, void* stream);
+
 /* torch.optim.Adam(betas, eps; no weight decay, no amsgrad) over up to EG3D_ADAM_ITEMS_MAX leaves in one launch (the projector's
  * optimiser, w_projector.py:107-118,256): p, m (exp_avg), v (exp_avg_sq) updated in place from the gradient g + g2 (one of them may be
  * null).  lr and step are DEVICE scalars (a captured graph is replayed for every step index): step holds the number of updates already

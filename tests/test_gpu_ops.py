@@ -1022,7 +1022,7 @@ def test_absmax_any_length(n):
         assert float(H.absmax(x.to(DEV))) == 9.25
 
 
-@pytest.mark.parametrize('kind', ['v2_3x3', 'igemm_3x3', 'igemm_1x1', 'igemm_clamp_shared_noise', 'torgb4_elementwise'])
+@pytest.mark.parametrize('kind', ['v2_3x3', 'igemm_3x3', 'igemm_1x1', 'igemm_clamp_shared_noise', 'torgb4_elementwise', 'torgb_small', 'torgb_small_clamp_shared_noise'])
 def test_fused_activation_backward_equals_separate_pass(kind):
     """EG3D_EPI_BWD_ACT: a data-gradient launch that also runs the activation backward of the layer that produced its `xin`
     (dz, dbias, dd, dnoise, dstrength, max|dz|) against the two-pass form it replaces (EPI_BWD, then eg3d_modconv_epilogue_bwd on
@@ -1036,8 +1036,9 @@ def test_fused_activation_backward_equals_separate_pass(kind):
         err, scale = float((a - b).abs().max()), float(b.abs().max())
         assert err <= tol * scale, f'{what}: err {err:.3e} > {tol} * {scale:.3e}'
 
-    one = kind in ('igemm_1x1', 'torgb4_elementwise')
-    n, ci, h, w, co = (2, 128, 24, 64, 128) if not one else (2, 128, 32, 32, 4)
+    small = kind.startswith('torgb_small')               # csrc/torgb_small.hip: 96 outputs, 63 pixels per image (a ragged last tile)
+    one = kind in ('igemm_1x1', 'torgb4_elementwise') or small
+    n, ci, h, w, co = (2, 128, 24, 64, 128) if not one else ((2, 128, 32, 32, 4) if not small else (2, 160, 9, 7, 96))
     k = 1 if one else 3
     g = torch.Generator().manual_seed(31)
     gz = torch.randn(n, co, h, w, generator=g) * 1e-3
@@ -1047,7 +1048,7 @@ def test_fused_activation_backward_equals_separate_pass(kind):
     add = torch.randn(n, ci, h, w, generator=g) * 1e-3
     d = 0.5 + torch.rand(n, ci, generator=g)
     bias = torch.randn(ci, generator=g) * 0.1
-    shared = kind == 'igemm_clamp_shared_noise'
+    shared = kind.endswith('clamp_shared_noise')
     noise = torch.randn(h, w, generator=g) if shared else torch.randn(n, 1, h, w, generator=g)
     strength = torch.tensor(0.37)
     gain, clamp, alpha = math.sqrt(2), (1.2 if shared else -1.0), 0.2
@@ -1069,6 +1070,10 @@ def test_fused_activation_backward_equals_separate_pass(kind):
             if kind == 'torgb4_elementwise' and spec is not None:          # the element-wise form of the same launch (eg3d_torgb_dgrad_act)
                 H.torgb_dgrad_act(dev(gz), wa, xin_d, s_d, dx, spec, ds=ds, addend=add_d, dz_amax=out_amax)
                 return dx, ds, True
+            if small:
+                r = H.torgb_small_bwd(dev(gz), wa, s_d, xin_d, dx, ds=ds, addend=add_d, act_bwd=spec, out_amax=out_amax)
+                assert r is not None, 'the small launch refused its own geometry'
+                return dx, ds, r
             r = H.conv_igemm(dev(gz), wa, co, ci, dx, cls, precision='bf16x6', **kw)
         return dx, ds, r
 

@@ -251,6 +251,14 @@ def test_round2_entry_points_reject_bad_arguments_before_touching_the_gpu():
     assert lib.eg3d_torgb_dgrad_act_split(a, a, a, a, None, None, None, 1, 8, 8, 16, C.byref(ab), None, None, a, a, None) < 0      # no max|dy|
     assert lib.eg3d_torgb_dgrad_act_split(a, a, a, a, a, None, None, 1, 8, 8, 16, C.byref(ab), a, None, a, a, None) < 0            # addend without its maximum
     assert lib.eg3d_torgb_dgrad_act_split(a, a, a, a, None, None, None, 1, 8, 8, 20, C.byref(ab), a, None, a, a, None) < 0         # C % 8
+    ts = L.TorgbSmallParams(x=a, w=a, s=a, out=a, N=1, H=4, W=4, C=64, Cp=96, ldx=64, ldo=96, w_row=64, clamp=-1.0)
+    assert lib.eg3d_torgb_small_supported(C.byref(ts)) == 1
+    ts.Cp = 4                                                                        # outputs not a multiple of 32: the implicit GEMM's case
+    assert lib.eg3d_torgb_small_supported(C.byref(ts)) == 0 and lib.eg3d_torgb_small_fwd(C.byref(ts), None) < 0
+    tb = L.TorgbSmallBwdParams(dy=a, wa=a, s=a, dx=a, ds=a, N=1, H=4, W=4, C=64, Cp=96, ldg=96, ldx=64, wa_row=96)
+    assert lib.eg3d_torgb_small_bwd_supported(C.byref(tb)) == 0                      # a style gradient without the layer input
+    tb.xin = a
+    assert lib.eg3d_torgb_small_bwd_supported(C.byref(tb)) == 1
     ad = L.AdamList(n=1, bump_step=1, beta1=0.9, beta2=0.999, eps=1e-8, lr=a, step=a)
     ad.items[0] = L.AdamItem(a, None, None, a, a, 16, 0)
     assert lib.eg3d_adam_step(C.byref(ad), a, None) < 0                              # no gradient at all
