@@ -242,6 +242,8 @@ _SIGS = {
     'eg3d_slice_rgb4_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     'eg3d_warp_project_fwd': (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]),
     'eg3d_warp_project_bwd': (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_void_p]),
+    'eg3d_conv2d_small_supported': (C.c_int, [C.POINTER(ConvParams)]),
+    'eg3d_conv2d_small_atomic': (C.c_int, [C.POINTER(ConvParams), C.c_void_p]),
     'eg3d_torgb_small_supported': (C.c_int, [C.POINTER(TorgbSmallParams)]),
     'eg3d_torgb_small_fwd': (C.c_int, [C.POINTER(TorgbSmallParams), C.c_void_p]),
     'eg3d_torgb_small_bwd_supported': (C.c_int, [C.POINTER(TorgbSmallBwdParams)]),

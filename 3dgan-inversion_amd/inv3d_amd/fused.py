@@ -312,7 +312,7 @@ class ModConvLayerFn(torch.autograd.Function):
                              **epi_kw)
             else:
                 z = H.zeros_cl(N, Co, Ho, Wo, x.device)
-                H.conv_igemm(x, wf, Ci, Co, z, cls, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=ig_prec, w_pieces=wfp)
+                H.conv_atomic(x, wf, Ci, Co, z, cls, in_scale=styles, ksplit=ks, algo_flops=aflops, precision=ig_prec, w_pieces=wfp)
                 H.epilogue_fwd(z, out, d=d, out_amax=amax_out, **epi_kw)
         else:
             if ksu:
@@ -336,7 +336,7 @@ class ModConvLayerFn(torch.autograd.Function):
                 H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_STORE, algo_flops=aflops, precision=ig_prec, w_pieces=wfp)
             else:
                 z = H.zeros_cl(N, Co, Hz, Wz, x.device)
-                H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=ig_prec, w_pieces=wfp)
+                H.conv_atomic(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, ksplit=ks, algo_flops=aflops, precision=ig_prec, w_pieces=wfp)
             simg = None
             if H.UPCONV_EPI and Co % 64 == 0 and up == 2:
                 # consumer = a 3x3 layer on the pre-split kernel (same channel count, output resolution): its operand image comes out of this
@@ -482,8 +482,8 @@ class ModConvLayerFn(torch.autograd.Function):
                     ds = ds.sum(0)
             else:                                  # low resolution: split K over blocks, then scale / reduce in a finishing pass
                 z = H.zeros_cl(N, Ci, Hi, Wi, dev)
-                H.conv_igemm(g, wa, Co, Ci, z, cls_adj, in_stride=in_stride, epi=L.EPI_ATOMIC, ksplit=ks, algo_flops=aflops, precision=ig_prec, a_amax=amax, w_pieces=wap,
-                             a_amax_mul=amul)
+                H.conv_atomic(g, wa, Co, Ci, z, cls_adj, in_stride=in_stride, ksplit=ks, algo_flops=aflops, precision=ig_prec, a_amax=amax, w_pieces=wap,
+                              a_amax_mul=amul)
                 did = prod is not None and Ci % 4 == 0 and Ci <= 1024
                 if did:
                     H.dgrad_finish_act(z, x, styles, dx, spec, ds=ds, dz_amax=pacc[4])

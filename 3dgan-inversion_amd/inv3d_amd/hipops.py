@@ -1237,6 +1237,49 @@ def torgb_small_bwd(dy, wa, styles, x, dx, ds=None, addend=None, act_bwd=None, o
     return fused
 
 
+# The same recipe for the split 3x3 / up-sampling launches of the 4^2 .. 32^2 layers (csrc/conv_small.hip): OFF by default.  It is parity-green
+# (tests/test_gpu_ops.py::test_conv_small_equals_the_split_implicit_gemm) but slower where it matters: 4608-deep contractions are arithmetic, not
+# latency, on the fp32 matrix pipe (157 TFLOP/s: 7.7 us for a 16^2 x 512 x 512 layer before anything else) -- steps/s 206.5 -> 206.1 (<= 256 cells),
+# 197 (<= 1024), 173 (<= 4096); even at <= 100 cells -0.5 %.  toRGB (K = 512, 0.4 GFLOP at most) is where the recipe pays.
+CONV_SMALL = os.environ.get('EG3D_CONV_SMALL', '0') != '0'
+CONV_SMALL_MAX_CELLS = int(os.environ.get('EG3D_CONV_SMALL_MAX_CELLS', '256'))
+
+
+def conv_small_atomic(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=None):
+    """eg3d_conv2d_small_atomic: out (pre-zeroed) += conv(x * in_scale, wp) over the tap classes; False when the geometry is not the kernel's
+    (nothing launched)."""
+    assert is_cl(x) and is_cl(out)
+    if len(classes) > 4:
+        return False
+    p = L.ConvParams()
+    n, cx, hi, wi = x.shape
+    _, co, ho, wo = out.shape
+    p.x, p.w, p.out = x.data_ptr(), wp.data_ptr(), out.data_ptr()
+    p.N, p.Hi, p.Wi, p.Ck, p.ldx = n, hi, wi, Ck, cx
+    p.Nc, p.w_row = Nc, wp.stride(0)
+    p.Ho, p.Wo, p.ldo = ho, wo, co
+    p.in_stride, p.out_stride = in_stride, out_stride
+    p.ncls = len(classes)
+    for i, c in enumerate(classes):
+        p.cls[i] = c
+    p.in_scale = in_scale.data_ptr() if in_scale is not None else None
+    p.epi, p.ksplit = L.EPI_ATOMIC, 1
+    if not L.lib().eg3d_conv2d_small_supported(C.byref(p)):
+        return False
+    L.check(L.lib().eg3d_conv2d_small_atomic(C.byref(p), L.stream_ptr()), 'conv2d_small_atomic')
+    return True
+
+
+def conv_atomic(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=None, ksplit=1, **igemm_kw):
+    """A split (EPI_ATOMIC) conv launch into the pre-zeroed `out`: the low-latency kernel when the layer has few output cells, else the implicit
+    GEMM with `ksplit` slices."""
+    cells = x.shape[0] * max(c.Ha * c.Wa for c in classes)
+    if CONV_SMALL and cells <= CONV_SMALL_MAX_CELLS and Ck % 8 == 0 and Ck >= 32 and Nc % 32 == 0 and wp.dtype == torch.float32 and wp.stride(1) == 1:
+        if conv_small_atomic(x, wp, Ck, Nc, out, classes, in_stride, out_stride, in_scale):
+            return
+    conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=in_stride, out_stride=out_stride, in_scale=in_scale, epi=L.EPI_ATOMIC, ksplit=ksplit, **igemm_kw)
+
+
 class HipAdam:
     """torch.optim.Adam(params, lr, betas, eps) for fp32 leaves in one launch per 32 leaves (`eg3d_adam_step`), with two extras the latent
     projector's step wants folded in: a second gradient per leaf (the noise regulariser's, which does not go through autograd) and the

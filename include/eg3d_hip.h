@@ -497,6 +497,14 @@ int eg3d_noise_regularizer(float* const* x, float* const* grad, const int32_t* r
                            float* reg_out, float scale, void* stream);
 int eg3d_noise_normalize(float* const* x, const int32_t* res, int nbufs, float* workspace, void* stream);
 
+/* The EG3D_EPI_ATOMIC launch of eg3d_conv2d_igemm_f32 for FEW output cells (the 4^2 .. 32^2 layers of the backbone: modulated 3x3 convs,
+ * up-sampling transposed convs and their data gradients -- training/networks_stylegan2.py:62-90, torch_utils/ops/conv2d_resample.py:114-136):
+ * out (pre-zeroed) += conv(x * in_scale, w) over the tap classes of p, exact fp32 products; all other epilogue fields of p are ignored
+ * (ksplit too: the taps are the split).  Ck % 8 == 0, Ck >= 32, Nc % 32 == 0.  Where the 16-channel step loop of the implicit GEMM is all
+ * latency (10 - 30 us for < 1.2 GFLOP) this one takes two memory latencies per workgroup. */
+int eg3d_conv2d_small_supported(const eg3d_conv_params* p);
+int eg3d_conv2d_small_atomic(const eg3d_conv_params* p, void* stream);
+
 /* Low-latency toRGB for small pixel counts (the 4^2 .. 64^2 blocks of the backbone) -- replaces ToRGBLayer.forward
  * (training/networks_stylegan2.py:338-359) + the skip accumulation of SynthesisBlock.forward (:433-436) where eg3d_conv2d_igemm_f32's
  * 32-step contraction loop is all latency:

@@ -442,6 +442,50 @@ def test_conv2d_gradfix_dilation_and_output_padding(case):
     close(gw, gwr, 5e-5, f'{case} dw')
 
 
+@pytest.mark.parametrize('kind', ['corr3', 'corr3_batch', 'corr1', 'convT', 'convT_adjoint', 'corr_adjoint'])
+def test_conv_small_equals_the_split_implicit_gemm(kind):
+    """eg3d_conv2d_small_atomic (csrc/conv_small.hip: the low-latency launch for the 4^2 .. 32^2 layers) against the EPI_ATOMIC launch of the
+    implicit GEMM in exact-fp32 arithmetic and against torch in float64: stride-1 3x3 / 1x1 classes with zero padding, the four parity classes of
+    the up-sampling transposed conv (strided writes), its stride-2 adjoint (strided reads), ragged cell counts, per-image input scales."""
+    from inv3d_amd import hipops as H, _lib as L
+    g = torch.Generator().manual_seed(5)
+    n, ci, co, h, w = (2, 64, 96, 5, 7) if kind == 'corr3_batch' else (1, 96, 64, 6, 5)
+    k = 1 if kind == 'corr1' else 3
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, k, k, generator=g) / math.sqrt(ci * k * k)
+    s = 1 + 0.5 * torch.randn(n, ci, generator=g)
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    if kind in ('corr3', 'corr3_batch', 'corr1'):
+        wp, cls, ho, wo, kw = H.pack_weight_fwd(wt.to(DEV)), H.classes_corr(h, w, k, k, k // 2), h, w, dict(in_scale=s.to(DEV))
+        ref = torch.nn.functional.conv2d(x.double() * s.double()[:, :, None, None], wt.double(), padding=k // 2)
+        ck, nc = ci, co
+    elif kind == 'convT':
+        cls, ho, wo = H.classes_convT(h, w, 3, 3, 2)
+        wp, kw = H.pack_weight_fwd(wt.to(DEV)), dict(in_scale=s.to(DEV), out_stride=2)
+        ref = torch.nn.functional.conv_transpose2d(x.double() * s.double()[:, :, None, None], wt.double().transpose(0, 1), stride=2)
+        ck, nc = ci, co
+    elif kind == 'convT_adjoint':         # data gradient of the transposed conv: input = gradient at (2h + 1) x (2w + 1), output at h x w
+        gz = torch.randn(n, co, 2 * h + 1, 2 * w + 1, generator=g)
+        xd = gz.to(DEV).contiguous(memory_format=torch.channels_last)
+        cls, ho, wo = H.classes_convT_adjoint(h, w, 3, 3, 2), h, w
+        wp, kw = H.pack_weight_adj(wt.to(DEV)), dict(in_stride=2)
+        ref = torch.nn.functional.conv2d(gz.double(), wt.double().transpose(0, 1), stride=2)
+        ck, nc = co, ci
+    else:                                  # data gradient of the stride-1 conv
+        gz = torch.randn(n, co, h, w, generator=g)
+        xd = gz.to(DEV).contiguous(memory_format=torch.channels_last)
+        cls, ho, wo = H.classes_corr_adjoint(h, w, 3, 3, 1), h, w
+        wp, kw = H.pack_weight_adj(wt.to(DEV)), {}
+        ref = torch.nn.functional.conv_transpose2d(gz.double(), wt.double(), padding=1)
+        ck, nc = co, ci
+    a = H.zeros_cl(n, nc, ho, wo, DEV)
+    assert H.conv_small_atomic(xd, wp, ck, nc, a, cls, **kw) is True
+    b = H.zeros_cl(n, nc, ho, wo, DEV)
+    H.conv_igemm(xd, wp, ck, nc, b, cls, epi=L.EPI_ATOMIC, ksplit=2, precision='f32', **kw)
+    close(a, ref, 2e-5, f'conv_small {kind} vs float64')
+    close(a, b, 2e-5, f'conv_small {kind} vs the implicit GEMM')
+
+
 # ------------------------------------------------------------------------------------------------- renderer
 def test_ray_gen_golden(golden):
     from inv3d_amd.training.volumetric_rendering.ray_sampler import RaySampler
