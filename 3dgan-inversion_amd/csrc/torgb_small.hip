@@ -47,6 +47,20 @@ __global__ void __launch_bounds__(256) torgb_small_kernel(const eg3d_torgb_small
     const float* xr = p.x + ((int64_t)n * HW + (pok ? pix : 0)) * p.ldx + 4 * h;
     const float* wr = p.w + (int64_t)(o0 + row) * p.w_row + 4 * h;           // B operand: lane = (output column, k half)
     const float* sr = p.s + (int64_t)n * p.C + 4 * h;
+    // the epilogue's side inputs do not depend on the products: issued here, they travel with the operand loads instead of after the matrix phase
+    const int er = threadIdx.x >> 3, eq = threadIdx.x & 7;
+    const int ep = p0 + er, eo = o0 + eq * 4;
+    const bool eok = ep < HW;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), add4 = bias4;
+    if (p.bias != nullptr) bias4 = *reinterpret_cast<const float4*>(p.bias + eo);
+    if (eok && p.addend != nullptr) {
+        if (p.addend_up2) {
+            const int yy = ep / p.W, xx = ep - yy * p.W;
+            add4 = up2_at(p.addend + (int64_t)n * (HW >> 2) * p.ldo + eo, p.ldo, p.H >> 1, p.W >> 1, yy, xx, p.addend_taps);
+        } else {
+            add4 = *reinterpret_cast<const float4*>(p.addend + ((int64_t)n * HW + ep) * p.ldo + eo);
+        }
+    }
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -74,31 +88,16 @@ __global__ void __launch_bounds__(256) torgb_small_kernel(const eg3d_torgb_small
     for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][row] = acc[r];
     __syncthreads();
     // epilogue: thread = (pixel row, quad of outputs)
-    const int er = threadIdx.x >> 3, eq = threadIdx.x & 7;
-    const int ep = p0 + er, eo = o0 + eq * 4;
-    if (ep >= HW) return;
+    if (!eok) return;
     float v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = (red[0][er][eq * 4 + q] + red[1][er][eq * 4 + q]) + (red[2][er][eq * 4 + q] + red[3][er][eq * 4 + q]);
-    if (p.bias != nullptr) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + eo);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-    }
+    v[0] += bias4.x; v[1] += bias4.y; v[2] += bias4.z; v[3] += bias4.w;
     if (p.clamp >= 0.f) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = fminf(fmaxf(v[q], -p.clamp), p.clamp);
     }
-    if (p.addend != nullptr) {
-        float4 a;
-        if (p.addend_up2) {
-            const int yy = ep / p.W, xx = ep - yy * p.W;
-            a = up2_at(p.addend + (int64_t)n * (HW >> 2) * p.ldo + eo, p.ldo, p.H >> 1, p.W >> 1, yy, xx, p.addend_taps);
-        } else {
-            a = *reinterpret_cast<const float4*>(p.addend + ((int64_t)n * HW + ep) * p.ldo + eo);
-        }
-        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
-    }
-    *reinterpret_cast<float4*>(p.out + ((int64_t)n * HW + ep) * p.ldo + eo) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p.out + ((int64_t)n * HW + ep) * p.ldo + eo) = make_float4(v[0] + add4.x, v[1] + add4.y, v[2] + add4.z, v[3] + add4.w);
 }
 
 // ---- data gradient of the same layer: dx[n,p,c] = (sum_o dy[n,p,o] w[o,c]) s[n,c] (+ addend), ds[n,c] += sum_p (sum_o ...) x[n,p,c], and --
@@ -107,7 +106,8 @@ __global__ void __launch_bounds__(256) torgb_small_kernel(const eg3d_torgb_small
 // Cp outputs (96: twelve 8-groups, three per wave).
 __global__ void __launch_bounds__(256) torgb_small_bwd_kernel(const eg3d_torgb_small_bwd_params p) {
     __shared__ float red[4][TS_PIX][TS_OUT + 1];
-    __shared__ float ds_lds[TS_OUT], db_lds[TS_OUT], dq_lds[TS_OUT], sc_lds[1];
+    __shared__ float col[3][TS_PIX][TS_OUT + 1];          // per-cell terms of the column sums (ds, dbias, dd): summed by 96 threads, no LDS atomics
+    __shared__ float sc_lds[1];
     const int HW = p.H * p.W;
     const int tiles = (HW + TS_PIX - 1) / TS_PIX;
     const int n = blockIdx.x / tiles, p0 = (blockIdx.x - n * tiles) * TS_PIX, c0 = blockIdx.y * TS_OUT;
@@ -119,8 +119,24 @@ __global__ void __launch_bounds__(256) torgb_small_bwd_kernel(const eg3d_torgb_s
     const int g0 = (int)((int64_t)groups * wave / 4), g1 = (int)((int64_t)groups * (wave + 1) / 4);
     const float* gr = p.dy + ((int64_t)n * HW + (pok ? pix : 0)) * p.ldg + 4 * h;
     const float* wr = p.wa + (int64_t)(c0 + row) * p.wa_row + 4 * h;
-    if (threadIdx.x < TS_OUT) { ds_lds[threadIdx.x] = 0.f; db_lds[threadIdx.x] = 0.f; dq_lds[threadIdx.x] = 0.f; }
     if (threadIdx.x == 0) sc_lds[0] = 0.f;
+    // the epilogue's side inputs (layer input, styles, pass-through gradient, the producing layer's d / bias / noise) are issued with the operands
+    const int er = threadIdx.x >> 3, eq = threadIdx.x & 7;
+    const int ep = p0 + er, eo = c0 + eq * 4;
+    const bool ok = ep < HW;
+    const bool act_on = p.act_on != 0;
+    const eg3d_act_bwd& ab = p.act_bwd;
+    const int64_t off = ((int64_t)n * HW + (ok ? ep : 0)) * p.ldx + eo;
+    float4 xin4 = make_float4(0.f, 0.f, 0.f, 0.f), a4 = xin4, abd4 = make_float4(1.f, 1.f, 1.f, 1.f), abb4 = xin4;
+    float nz = 0.f;
+    const float4 s4 = *reinterpret_cast<const float4*>(p.s + (int64_t)n * p.C + eo);
+    if (ok && p.xin != nullptr) xin4 = *reinterpret_cast<const float4*>(p.xin + off);
+    if (ok && p.addend != nullptr) a4 = *reinterpret_cast<const float4*>(p.addend + off);
+    if (act_on) {
+        if (ab.d != nullptr) abd4 = *reinterpret_cast<const float4*>(ab.d + (int64_t)n * p.C + eo);
+        if (ab.bias != nullptr) abb4 = *reinterpret_cast<const float4*>(ab.bias + eo);
+        if (ok && ab.noise != nullptr) nz = ab.noise[(int64_t)n * ab.noise_nstride + ep];
+    }
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -144,46 +160,23 @@ __global__ void __launch_bounds__(256) torgb_small_bwd_kernel(const eg3d_torgb_s
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][row] = acc[r];
     __syncthreads();
-    const int er = threadIdx.x >> 3, eq = threadIdx.x & 7;
-    const int ep = p0 + er, eo = c0 + eq * 4;
-    const bool ok = ep < HW;
-    const bool act_on = p.act_on != 0;
-    const eg3d_act_bwd& ab = p.act_bwd;
     eg3d_act_bwd_consts abc = {};
     if (act_on) abc = eg3d_act_bwd_setup(ab);
     float omax = 0.f;
+    float4 t_ds = make_float4(0.f, 0.f, 0.f, 0.f), t_db = t_ds, t_dq = t_ds;
     if (ok) {
         float4 v;
         v.x = (red[0][er][eq * 4 + 0] + red[1][er][eq * 4 + 0]) + (red[2][er][eq * 4 + 0] + red[3][er][eq * 4 + 0]);
         v.y = (red[0][er][eq * 4 + 1] + red[1][er][eq * 4 + 1]) + (red[2][er][eq * 4 + 1] + red[3][er][eq * 4 + 1]);
         v.z = (red[0][er][eq * 4 + 2] + red[1][er][eq * 4 + 2]) + (red[2][er][eq * 4 + 2] + red[3][er][eq * 4 + 2]);
         v.w = (red[0][er][eq * 4 + 3] + red[1][er][eq * 4 + 3]) + (red[2][er][eq * 4 + 3] + red[3][er][eq * 4 + 3]);
-        const int64_t off = ((int64_t)n * HW + ep) * p.ldx + eo;
-        float4 xin4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.xin != nullptr) xin4 = *reinterpret_cast<const float4*>(p.xin + off);
-        if (p.ds != nullptr) {
-            atomicAdd(&ds_lds[eq * 4 + 0], v.x * xin4.x); atomicAdd(&ds_lds[eq * 4 + 1], v.y * xin4.y);
-            atomicAdd(&ds_lds[eq * 4 + 2], v.z * xin4.z); atomicAdd(&ds_lds[eq * 4 + 3], v.w * xin4.w);
-        }
-        const float4 s4 = *reinterpret_cast<const float4*>(p.s + (int64_t)n * p.C + eo);
-        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.addend != nullptr) a4 = *reinterpret_cast<const float4*>(p.addend + off);
+        if (p.ds != nullptr) t_ds = make_float4(v.x * xin4.x, v.y * xin4.y, v.z * xin4.z, v.w * xin4.w);
         v = make_float4(v.x * s4.x + a4.x, v.y * s4.y + a4.y, v.z * s4.z + a4.z, v.w * s4.w + a4.w);
         if (act_on) {
-            float4 abd4 = make_float4(1.f, 1.f, 1.f, 1.f), abb4 = make_float4(0.f, 0.f, 0.f, 0.f), accb4 = abb4, accd4 = abb4;
-            if (ab.d != nullptr) abd4 = *reinterpret_cast<const float4*>(ab.d + (int64_t)n * p.C + eo);
-            if (ab.bias != nullptr) abb4 = *reinterpret_cast<const float4*>(ab.bias + eo);
-            const float nz = ab.noise != nullptr ? ab.noise[(int64_t)n * ab.noise_nstride + ep] : 0.f;
+            float4 accb4 = make_float4(0.f, 0.f, 0.f, 0.f), accd4 = accb4;
             float cs;
             v = eg3d_act_bwd_unit(abc, v, xin4, abd4, abb4, nz * abc.strength, accb4, accd4, cs);
-            if (ab.dbias != nullptr) {
-                atomicAdd(&db_lds[eq * 4 + 0], accb4.x); atomicAdd(&db_lds[eq * 4 + 1], accb4.y);
-                atomicAdd(&db_lds[eq * 4 + 2], accb4.z); atomicAdd(&db_lds[eq * 4 + 3], accb4.w);
-            }
-            if (ab.dd != nullptr) {
-                atomicAdd(&dq_lds[eq * 4 + 0], accd4.x); atomicAdd(&dq_lds[eq * 4 + 1], accd4.y);
-                atomicAdd(&dq_lds[eq * 4 + 2], accd4.z); atomicAdd(&dq_lds[eq * 4 + 3], accd4.w);
-            }
+            t_db = accb4; t_dq = accd4;
             if (ab.dnoise != nullptr || ab.dstrength != nullptr) {      // the 8 lanes of a pixel row hold this tile's 32 channels
                 cs = eg3d_row_group_sum(cs, 8);
                 if (eq == 0) {
@@ -196,12 +189,21 @@ __global__ void __launch_bounds__(256) torgb_small_bwd_kernel(const eg3d_torgb_s
         *reinterpret_cast<float4*>(p.dx + off) = v;
     }
     eg3d_commit_amax_block(omax, p.out_amax);
+    col[0][er][eq * 4 + 0] = t_ds.x; col[0][er][eq * 4 + 1] = t_ds.y; col[0][er][eq * 4 + 2] = t_ds.z; col[0][er][eq * 4 + 3] = t_ds.w;
+    col[1][er][eq * 4 + 0] = t_db.x; col[1][er][eq * 4 + 1] = t_db.y; col[1][er][eq * 4 + 2] = t_db.z; col[1][er][eq * 4 + 3] = t_db.w;
+    col[2][er][eq * 4 + 0] = t_dq.x; col[2][er][eq * 4 + 1] = t_dq.y; col[2][er][eq * 4 + 2] = t_dq.z; col[2][er][eq * 4 + 3] = t_dq.w;
     __syncthreads();
-    if (threadIdx.x < TS_OUT) {
-        const int c = c0 + threadIdx.x;
-        if (p.ds != nullptr) unsafeAtomicAdd(p.ds + (int64_t)n * p.C + c, ds_lds[threadIdx.x]);
-        if (act_on && ab.dbias != nullptr) unsafeAtomicAdd(ab.dbias + c, db_lds[threadIdx.x]);
-        if (act_on && ab.dd != nullptr) unsafeAtomicAdd(ab.dd + (int64_t)n * p.C + c, dq_lds[threadIdx.x] / (ab.d != nullptr ? ab.d[(int64_t)n * p.C + c] : 1.f));
+    if (threadIdx.x < 3 * TS_OUT) {          // thread = (which sum, column): 32 conflict-free LDS reads, then one global atomic
+        const int a = threadIdx.x / TS_OUT, cc = threadIdx.x - a * TS_OUT, c = c0 + cc;
+        const bool want = a == 0 ? p.ds != nullptr : (act_on && (a == 1 ? ab.dbias != nullptr : ab.dd != nullptr));
+        if (want) {
+            float sum = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < TS_PIX; ++r) sum += col[a][r][cc];
+            if (a == 0) unsafeAtomicAdd(p.ds + (int64_t)n * p.C + c, sum);
+            else if (a == 1) unsafeAtomicAdd(ab.dbias + c, sum);
+            else unsafeAtomicAdd(ab.dd + (int64_t)n * p.C + c, sum / (ab.d != nullptr ? ab.d[(int64_t)n * p.C + c] : 1.f));      // dL/dd = sum dy * z,  z = (pre - bias - noise) / d
+        }
     }
     if (act_on && ab.dstrength != nullptr && threadIdx.x == 0 && sc_lds[0] != 0.f) unsafeAtomicAdd(ab.dstrength, sc_lds[0]);
 }
