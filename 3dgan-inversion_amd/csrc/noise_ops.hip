@@ -110,12 +110,18 @@ __global__ void __launch_bounds__(NT) noise_moments2_kernel(const NoiseBufs B, c
     const int res = B.res[b], r = res >> l, n = r * r, sh = __ffs(r) - 1;
     const float* v = l == 0 ? B.x[b] : ws + B.ws_off[b] + lev_off(res, l);
     float sx = 0.f, sy = 0.f;
-    for (int i = start + threadIdx.x; i < min(n, start + CHUNK); i += NT) {
+    float c[CHUNK / NT], lx[CHUNK / NT], uy[CHUNK / NT];       // all twelve loads of the block's chunk in flight (a rolled loop waited for each triple)
+#pragma unroll
+    for (int u = 0; u < CHUNK / NT; ++u) {
+        const int i = min(start + threadIdx.x + u * NT, n - 1);
         const int y = i >> sh, xx = i - (y << sh);
-        const float c = v[i];
-        sx += c * v[(y << sh) + ((xx - 1) & (r - 1))];
-        sy += c * v[(((y - 1) & (r - 1)) << sh) + xx];
+        c[u] = v[i];
+        lx[u] = v[(y << sh) + ((xx - 1) & (r - 1))];
+        uy[u] = v[(((y - 1) & (r - 1)) << sh) + xx];
     }
+#pragma unroll
+    for (int u = 0; u < CHUNK / NT; ++u)
+        if (start + threadIdx.x + u * NT < n) { sx += c[u] * lx[u]; sy += c[u] * uy[u]; }
     sx = block_sum(sx, red);
     sy = block_sum(sy, red);
     if (threadIdx.x == 0) { unsafeAtomicAdd(sums + (b * MAXL + l) * 2, sx); unsafeAtomicAdd(sums + (b * MAXL + l) * 2 + 1, sy); }
@@ -152,6 +158,7 @@ __global__ void __launch_bounds__(NT) noise_grad_kernel(const NoiseBufs B, const
     const float* x0 = B.x[b];
     const float* scratch = ws + B.ws_off[b];
     const int sh0 = __ffs(res) - 1, n0 = res * res;
+#pragma unroll 2
     for (int i = blk * CHUNK + threadIdx.x; i < min(n0, (blk + 1) * CHUNK); i += NT) {
         const int y = i >> sh0, xx = i - (y << sh0);
         float g = 0.f;
