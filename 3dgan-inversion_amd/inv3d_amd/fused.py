@@ -738,7 +738,7 @@ class ToRGBFn(torch.autograd.Function):
                     did = True
             else:
                 did = None
-                if H.TORGB_SMALL and N * Hh * Ww <= H.TORGB_SMALL_MAX_PIX and Ci % 32 == 0 and Cp % 8 == 0 and wa_p.stride(1) == 1:
+                if H.TORGB_SMALL and N * Hh * Ww <= H.TORGB_SMALL_BWD_MAX_PIX and Ci % 32 == 0 and Cp % 8 == 0 and wa_p.stride(1) == 1:
                     # small pixel counts: the low-latency launch (csrc/torgb_small.hip), same epilogue as the implicit GEMM's
                     did = H.torgb_small_bwd(dy, wa_p, styles, x, dx, ds=ds, addend=add, **fkw)
                 if did is None:
