@@ -437,7 +437,9 @@ def main():
                         launches_per_step=dom['launches'] / args.steps, gflop_per_launch=round(dom['flops'] / dom['launches'] / 1e9, 3),
                         avg_launch_ms=round(dom['ms'] / dom['launches'], 4), share_of_conv_time=round(dom['ms'] / all_ms, 3),
                         all_conv_tflops=round(all_fl / (all_ms * 1e-3) / 1e12, 1), all_conv_ms_per_step=round(all_ms / args.steps, 3),
-                        all_conv_frac=round(all_fl / (all_ms * 1e-3) / 1e12 / peak, 4), timing=roofline_pass)
+                        all_conv_frac=round(all_fl / (all_ms * 1e-3) / 1e12 / peak, 4),
+                        all_conv_scope=('launches of the implicit-GEMM family (conv_igemm / conv_v2 / up2 / s2adj); the low-latency toRGB launches of the '
+                                        '4^2 .. 64^2 blocks (fp32 matrix pipe, 0.5 of 579 GFLOP per step) are not in it'), timing=roofline_pass)
         sp = prof.span_summary()
         if 'render_fwd' in sp and 'render_bwd' in sp:
             # fused renderer forward 34.1 MB per image (planes 25.17 + rays 0.39 + uniforms 6.29 + outputs 2.23), backward
