@@ -486,6 +486,63 @@ def test_conv_small_equals_the_split_implicit_gemm(kind):
     close(a, b, 2e-5, f'conv_small {kind} vs the implicit GEMM')
 
 
+@pytest.mark.parametrize('n,trainable', [(1, False), (3, False), (2, True)])
+def test_style_bank_matches_torch(n, trainable):
+    """fused.StyleBankFn (eg3d_style_affine_fwd / _bwd: the per-layer affines `styles = affine(w) * gain` of networks_stylegan2.py:98-108,129-137 and
+    the demodulation coefficients d = rsqrt(sum_i (w_oi s_i)^2 + 1e-8) of :62-67, all layers in one launch per direction) against the same
+    expressions in float64 autograd: styles, d, d ws and -- with trainable affines -- their weight / bias gradients.  Layers of different widths,
+    ws rows and post scales, with and without bias / demodulation."""
+    from inv3d_amd import fused
+    g = torch.Generator().manual_seed(13)
+    D, Lw = 64, 5
+    specs = [(96, 0, 1.0, True, 40), (33, 2, 0.37, True, None), (512, 4, 1.0, False, 16), (8, 4, 2.0, True, 24), (130, 1, 1.0, True, 7)]    # (C, ws row, post, bias, Co | None)
+    ws = torch.randn(n, Lw, D, generator=g)
+    Ws = [torch.randn(c, D, generator=g) for c, *_ in specs]
+    Bs = [torch.randn(c, generator=g) if hb else None for c, _, _, hb, _ in specs]
+    Wq = [torch.rand(co, c, generator=g) + 0.05 if co else None for c, _, _, _, co in specs]          # wsq = sum over taps of w^2 >= 0
+    wgain, bgain = 1.0 / math.sqrt(D), 1.0
+    # float64 reference
+    wr = ws.double().requires_grad_(True)
+    Wr = [w.double().requires_grad_(True) for w in Ws]
+    Br = [b.double().requires_grad_(True) if b is not None else None for b in Bs]
+    outs_r, ds_r = [], []
+    for (c, row, post, hb, co), w, b, q in zip(specs, Wr, Br, Wq):
+        st = (wr[:, row] @ (w * wgain).t() + (b * bgain if b is not None else 0.0)) * post
+        outs_r.append(st)
+        ds_r.append(torch.rsqrt((st.square().unsqueeze(1) * q.double().unsqueeze(0)).sum(2) + 1e-8) if q is not None else None)
+    gs = [torch.randn(o.shape, generator=g).double() for o in outs_r]
+    gd = [torch.randn(d.shape, generator=g).double() if d is not None else None for d in ds_r]
+    loss = sum((o * a).sum() for o, a in zip(outs_r, gs)) + sum((d * a).sum() for d, a in zip(ds_r, gd) if d is not None)
+    leaves = [wr] + (Wr + [b for b in Br if b is not None] if trainable else [])
+    grads_r = torch.autograd.grad(loss, leaves)
+    # product
+    wg = ws.to(DEV).requires_grad_(True)
+    Wg = [w.to(DEV).requires_grad_(trainable) for w in Ws]
+    Bg = [b.to(DEV).requires_grad_(trainable) if b is not None else None for b in Bs]
+    plan, params = [], []
+    for (c, row, post, hb, co), w, b, q in zip(specs, Wg, Bg, Wq):
+        plan.append((row, wgain, bgain, post, hb, q.to(DEV).contiguous() if q is not None else None))
+        params.append(w)
+        if hb:
+            params.append(b)
+    res = fused.StyleBankFn.apply(wg, tuple(plan), *params)
+    outs, rest = res[:len(specs)], list(res[len(specs):])
+    loss_g, di = 0.0, 0
+    for i, (o, ref) in enumerate(zip(outs, outs_r)):
+        close(o, ref.float(), 2e-5, f'styles of layer {i}')
+        loss_g = loss_g + (o * gs[i].float().to(DEV)).sum()
+    for i, ref in enumerate(ds_r):
+        if ref is not None:
+            close(rest[di], ref.float(), 2e-5, f'demodulation of layer {i}')
+            loss_g = loss_g + (rest[di] * gd[i].float().to(DEV)).sum()
+            di += 1
+    leaves_g = [wg] + (Wg + [b for b in Bg if b is not None] if trainable else [])
+    grads = torch.autograd.grad(loss_g, leaves_g)
+    names = ['ws'] + ([f'W{i}' for i in range(len(Wg))] + [f'b{i}' for i, b in enumerate(Bg) if b is not None] if trainable else [])
+    for nm, a, b in zip(names, grads, grads_r):
+        close(a, b.float(), 5e-5, f'style bank d {nm}')
+
+
 # ------------------------------------------------------------------------------------------------- renderer
 def test_ray_gen_golden(golden):
     from inv3d_amd.training.volumetric_rendering.ray_sampler import RaySampler
