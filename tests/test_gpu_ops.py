@@ -341,7 +341,9 @@ def test_synthesis_layer_fwd_bwd(cfg):
 
 @pytest.mark.parametrize('cfg', [(2, 16, 96, 8, None, True), (1, 32, 3, 16, 256.0, True), (2, 8, 3, 4, 0.5, False),
                                  # the low-latency launch of csrc/torgb_small.hip (>= 32 input channels, outputs a multiple of 32, few pixels):
-                                 (2, 64, 96, 8, None, True), (1, 512, 96, 4, None, False), (1, 64, 96, 16, 0.5, True), (3, 136, 32, 7, None, True)])
+                                 (2, 64, 96, 8, None, True), (1, 512, 96, 4, None, False), (1, 64, 96, 16, 0.5, True), (3, 136, 32, 7, None, True),
+                                 # four outputs, > 4096 pixels: the stream kernel of the SR head's toRGB (eg3d_torgb4_fwd)
+                                 (1, 64, 3, 72, 2.0, True), (2, 128, 3, 48, None, False), (1, 256, 3, 68, 256.0, True), (1, 32, 4, 80, 0.7, False)])
 def test_torgb_fwd_bwd(cfg):
     from inv3d_amd.training.networks_stylegan2 import ToRGBLayer
     n, ci, co, res, clamp, with_skip = cfg
@@ -379,7 +381,8 @@ def test_torgb_fwd_bwd(cfg):
 
 
 @pytest.mark.parametrize('cfg', [(1, 16, 96, 8, None), (2, 32, 96, 16, None), (1, 16, 3, 32, None), (2, 16, 96, 6, None), (1, 16, 3, 16, 256.0),
-                                 (1, 512, 96, 8, None), (2, 64, 96, 6, None), (1, 64, 96, 8, 2.0), (1, 256, 96, 64, None)])
+                                 (1, 512, 96, 8, None), (2, 64, 96, 6, None), (1, 64, 96, 8, 2.0), (1, 256, 96, 64, None),
+                                 (1, 64, 3, 72, 1.5), (2, 128, 3, 66, None), (1, 256, 3, 70, 256.0)])
 def test_torgb_takes_the_skip_image_at_half_resolution(cfg):
     """skip + toRGB of a 'skip' block (networks_stylegan2.py:433-436: img = upsample2d(img); img = img.add_(y)) with the up-sampling done
     inside the conv's epilogue (eg3d_conv_params::addend_up2): against the oracle's upfirdn2d on the CPU, values and every gradient.  The
