@@ -198,6 +198,7 @@ def _auto_ksplit(classes, N, Nc, Ck):
 # this layer's activation backward in the same epilogue -- and hands back dz in place of dout.  This layer's backward recognises the
 # buffer and skips its own pass.
 FUSE_ACT_BWD = os.environ.get('EG3D_FUSE_ACT_BWD', '1') != '0'
+FIR_ADJ_LDS = int(os.environ.get('EG3D_FIR_ADJ_LDS', '4096'))       # pixels from which the FIR adjoint of an up layer's backward runs on the LDS-tiled separable kernel (0 = never)
 FUSE_SKIP_UP = os.environ.get('EG3D_FUSE_SKIP_UP', '1') != '0'   # skip image up-sampled inside the toRGB conv's epilogue (eg3d_conv_params::addend_up2)
 SPLIT_DZ = os.environ.get('EG3D_SPLIT_DZ', '1') != '0'         # ... and write dz as the data gradient's fp16 operand image where it can (torgb_dgrad_act_split)
 _DX_AMAX = {}                 # dx.data_ptr() -> (device scalar max|dx| reported by the data-gradient kernel that wrote it, weak ref to dx); read once by a toRGB backward
@@ -442,7 +443,12 @@ class ModConvLayerFn(torch.autograd.Function):
             in_stride = up
             cls_w, out_stride_w = None, up
         else:
-            g = H.upfirdn2d_nhwc(dz, fir44(dev), pad=(2, 2, 2, 2), flip=True, gain=float(up * up))     # adjoint of the FIR
+            if FIR_ADJ_LDS and Co % 64 == 0 and dz.shape[2] * dz.shape[3] >= FIR_ADJ_LDS:
+                # the separable, LDS-tiled FIR pass of the forward (1.6 loads per output instead of 6.25): the [1,3,3,1] filter is its own flip
+                g = H.empty_cl(N, Co, dz.shape[2] + 1, dz.shape[3] + 1, dev)
+                H.upconv_epilogue_fwd(dz, g, pad0=2, fir_gain=float(up * up))
+            else:
+                g = H.upfirdn2d_nhwc(dz, fir44(dev), pad=(2, 2, 2, 2), flip=True, gain=float(up * up))     # adjoint of the FIR
             cls_adj = H.classes_convT_adjoint(Hi, Wi, kh, kw, up)
             in_stride = up
             cls_w, out_stride_w = H.classes_convT(Hi, Wi, kh, kw, up)[0], up
