@@ -346,7 +346,11 @@ class LatentProjector:
         # instead of torch's multi-tensor add + multi-tensor Adam (64 us for 3.3 MB: ~20 blocks) + a moments pass; EG3D_HIP_ADAM=0 -> torch's
         hip_adam = os.environ.get('EG3D_HIP_ADAM', '1') != '0' and torch.device(dev).type == 'cuda'
         if use_graph:       # the schedule values live on the device so that one captured step can be replayed for every step index
-            self._scale_t = torch.zeros((), device=dev)
+            # (latent-noise scale, learning rate) of a step: two views of one 2-float tensor, set before each replay by ONE copy from the
+            # schedule table built below (two fill launches otherwise)
+            self._sched = torch.zeros(2, device=dev)
+            self._scale_t, self._lr_t = self._sched[0], self._sched[1]
+            self._sched_table = None
             self._wn = torch.zeros_like(self.w_opt)
             # the renderer's stratified / importance uniforms of a step from ONE draw in front of the replay: random draws inside a captured
             # graph cost two generator-state fills per replay on top of the two draws themselves
@@ -359,7 +363,7 @@ class LatentProjector:
                 self._uni = torch.empty(N * R * (Dc + Df), device=dev)
                 self._uni_views = (self._uni[:N * R * Dc].view(N, R, Dc, 1), self._uni[N * R * Dc:].view(N * R, Df))
             self.optimizer = (hipops.HipAdam if hip_adam else functools.partial(torch.optim.Adam, fused=True, capturable=True))(
-                [self.w_opt] + self._opt_bufs, betas=(0.9, 0.999), lr=torch.tensor(float(first_inv_lr), device=dev))
+                [self.w_opt] + self._opt_bufs, betas=(0.9, 0.999), lr=self._lr_t)
         else:
             self._uni = None
             self.optimizer = (hipops.HipAdam if hip_adam else functools.partial(torch.optim.Adam, fused=True))(
@@ -422,8 +426,16 @@ class LatentProjector:
         if self.use_graph:
             if step_kwargs:
                 raise ValueError('use_graph: per-step synthesis kwargs cannot change between replays; pass them as synth_kwargs')
-            self._scale_t.fill_(float(w_noise_scale))
-            self.optimizer.param_groups[0]['lr'].fill_(float(lr))
+            row = (float(w_noise_scale), float(lr))
+            if self._sched_table is None or (step < len(self._sched_host) and self._sched_host[step] != row):
+                # the whole schedule on the device (it only depends on the step index; rebuilt if num_steps / preheat / ramps were changed since)
+                self._sched_host = [tuple(float(v) for v in self._schedule(i)) for i in range(max(self.num_steps, 1) + 64)]
+                self._sched_table = torch.tensor(self._sched_host, dtype=torch.float32, device=self.dev)
+            if step < len(self._sched_host) and self.optimizer.param_groups[0]['lr'] is self._lr_t:
+                self._sched.copy_(self._sched_table[step])
+            else:
+                self._scale_t.fill_(float(w_noise_scale))
+                self.optimizer.param_groups[0]['lr'].fill_(float(lr))
             if w_noise is not None:
                 self._wn.copy_(w_noise)
             else:
