@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    v2_epilogue<ATOMIC, RPW>(p, acc, Ha, Wa, cl.out_py, cl.out_px, n, y0, x0, n0, smem);
+    v2_epilogue<ATOMIC, RPW>(p, acc, Ha, Wa, cl.out_py, cl.out_px, n, y0, x0, n0, smem, 1.f / (*p.a_scale * *p.w_scale));
 }
 
 // ---- operand preparation (split8 / range_mul: conv_v2_common.h) ------------------------------------------------------------

@@ -64,16 +64,18 @@ __device__ __forceinline__ float range_mul(float amax) {
 // ---- epilogue of a 256-cell x 128-channel tile held as acc[4][2] (wave (wm, wn): patch rows 4 wm .. 4 wm + 3, channels 64 wn .. + 63) ---
 // Output cell (ay, ax) of the class grid Ha x Wa goes to pixel (ay * out_stride + out_py, ax * out_stride + out_px).  Must be entered by
 // the whole block after the last LDS read of the main loop (it re-uses the dynamic LDS).
-template <bool ATOMIC, int RPW = 4>   // ATOMIC at compile time: the split-K form must not cost the fused epilogues a register (together they spilled 30 VGPRs);
+// GENW (conv_lr.hip): the workgroup's cells are a (64 RPW >> logw) x (1 << logw) patch (narrow images: 16 / 8 / 4 columns) instead of rows of 32:
+// cell c of MFMA tile mt is patch position lin = 32 mt + c -> row lin >> logw, column lin & ((1 << logw) - 1).  out_mul: 1 / (a_scale * w_scale).
+template <bool ATOMIC, int RPW = 4, bool GENW = false>   // ATOMIC at compile time: the split-K form must not cost the fused epilogues a register (together they spilled 30 VGPRs);
                                       // RPW = patch rows per wave (4: 8 x 32 patch, 2: 4 x 32)
 __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16 (&acc)[RPW][2], const int Ha, const int Wa, const int out_py, const int out_px,
-                                            const int n, const int y0, const int x0, const int n0, char* smem) {
+                                            const int n, const int y0, const int x0, const int n0, char* smem, const float out_mul, const int logw = 5) {
+    const int wmask = (1 << logw) - 1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     struct { int out_py, out_px; } cl = {out_py, out_px};
     // ---- epilogue: the tile goes through LDS once (64 rows at a time) so that every global access is 16 bytes per lane ----------------
-    const float out_mul = 1.f / (*p.a_scale * *p.w_scale);              // exact powers of two
     const int epi = p.epi;
     if constexpr (ATOMIC) {
         // split-K partial tile: atomics straight from the accumulator layout, one lane per channel -- a wave-instruction covers two runs of
@@ -81,10 +83,11 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
         // touch sixteen 64-byte lines -- measured 2.3x SLOWER than the loader-split kernel on the 128^2 x 256 layer.)
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
-            const int ay = y0 + wm * RPW + i;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ax = x0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int cc = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int ay = GENW ? y0 + (((wm * RPW + i) * 32 + cc) >> logw) : y0 + wm * RPW + i;
+                const int ax = GENW ? x0 + (cc & wmask) : x0 + cc;
                 if (ay >= Ha || ax >= Wa) continue;
                 float* o = p.out + ((int64_t)(n * p.Ho + ay * p.out_stride + cl.out_py) * p.Wo + ax * p.out_stride + cl.out_px) * p.ldo + n0 + wn * 64 + (lane & 31);
 #pragma unroll
@@ -126,7 +129,7 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
         const float* nsrc = (epi == EG3D_EPI_FWD && p.noise != nullptr) ? p.noise + (int64_t)n * p.noise_nstride
                           : ((act_on && ab.noise != nullptr) ? ab.noise + (int64_t)n * ab.noise_nstride : nullptr);
         if (tid < 2 * RPW * 32) {
-            const int ay = y0 + (tid >> 5), ax = x0 + (tid & 31);
+            const int ay = GENW ? y0 + (tid >> logw) : y0 + (tid >> 5), ax = GENW ? x0 + (tid & wmask) : x0 + (tid & 31);
             float v = 0.f;
             if (nsrc != nullptr && ay < Ha && ax < Wa) v = nsrc[(ay * p.out_stride + cl.out_py) * p.Wo + ax * p.out_stride + cl.out_px];
             nzl[tid] = v;
@@ -150,7 +153,8 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int row = (tid + (ug + u) * 256) >> 5;             // 0..63: wave-row row >> 5, patch column row & 31
-                const int ay = y0 + (row >> 5) * RPW + i, ax = x0 + (row & 31);
+                const int ay = GENW ? y0 + ((((row >> 5) * RPW + i) * 32 + (row & 31)) >> logw) : y0 + (row >> 5) * RPW + i;
+                const int ax = GENW ? x0 + (row & wmask) : x0 + (row & 31);
                 const bool ok = ay < Ha && ax < Wa;
                 const int pix = (n * p.Ho + ay * p.out_stride + cl.out_py) * p.Wo + ax * p.out_stride + cl.out_px;
                 offs[u] = ok ? pix * p.ldo + col : -1;

@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256, 2) conv_v2_s2adj_kernel(const eg3d_conv_v
     run_chunk(c1 - 1, std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    v2_epilogue<ATOMIC, 4>(p, acc, Ha, Wa, cl.out_py, cl.out_px, n, y0, x0, n0, smem);
+    v2_epilogue<ATOMIC, 4>(p, acc, Ha, Wa, cl.out_py, cl.out_px, n, y0, x0, n0, smem, 1.f / (*p.a_scale * *p.w_scale));
 }
 
 // ---- FIR adjoint of an up layer + parity split --------------------------------------------------------------------------------------------

@@ -64,6 +64,11 @@ class ConvV2Params(C.Structure):
                 ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p), ('out_amax', C.c_void_p), ('act_bwd', ActBwd), ('products', C.c_int32), ('ksplit', C.c_int32), ('patch_rows', C.c_int32)]
 
 
+class ConvLrParams(C.Structure):
+    _fields_ = [('v', ConvV2Params), ('in_scale', C.c_void_p), ('x_amax', C.c_void_p), ('amax_mul', C.c_float), ('ldx', C.c_int32),
+                ('logw', C.c_int32), ('slabs', C.c_void_p), ('tickets', C.c_void_p), ('rotate', C.c_int32)]
+
+
 class ConvUp2Params(C.Structure):
     _fields_ = [('a', C.c_void_p), ('w', C.c_void_p), ('a_scale', C.c_void_p), ('w_scale', C.c_void_p), ('out', C.c_void_p),
                 ('N', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32), ('Ck', C.c_int32), ('Nc', C.c_int32),
@@ -193,6 +198,9 @@ _SIGS = {
     'eg3d_conv2d_wgrad_f32': (C.c_int, [C.POINTER(WgradParams), C.c_void_p]),
     'eg3d_conv2d_v2_supported': (C.c_int, [C.POINTER(ConvV2Params)]),
     'eg3d_conv2d_v2': (C.c_int, [C.POINTER(ConvV2Params), C.c_void_p]),
+    'eg3d_conv2d_lr_supported': (C.c_int, [C.POINTER(ConvLrParams)]),
+    'eg3d_conv2d_lr_workspace': (C.c_int, [C.POINTER(ConvLrParams), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    'eg3d_conv2d_lr': (C.c_int, [C.POINTER(ConvLrParams), C.c_void_p]),
     'eg3d_split_activation_bytes': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'eg3d_split_activation': (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]),
     'eg3d_split_weight': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),

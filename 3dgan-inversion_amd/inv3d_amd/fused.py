@@ -294,6 +294,11 @@ class ModConvLayerFn(torch.autograd.Function):
         # up-sampling layers: the four output parities of the transposed conv from one workgroup per input patch (csrc/conv_v2_up.hip)
         ksu = H.conv_up2_plan(Ci, Co, Hi, Wi, N) if (up == 2 and not v2 and kh == 3 and kw == 3 and prec in ('f16x3', 'f16x1')) else None
         epi_kw = dict(noise=nz, noise_nstride=nstride or 0, noise_strength=noise_strength, bias=b, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv)
+        # the 4^2 .. 64^2 layers at one image per GPU: the low-resolution kernel (csrc/conv_lr.hip) -- fp32 activation in, weight pieces streamed
+        # through a deep LDS ring, split-K summed in slice order by the last workgroup, fused epilogue; no zero fill, no finishing pass
+        lrp = H.conv_lr_plan(Ci, Co, cls, N) if (up == 1 and not v2 and not ks2 and prec in ('f16x3', 'f16x1')) else None
+        if lrp:
+            wimg = cache.get_split(weight)[0]
         if v2 or ks2 or ksu:   # pre-split operands: modulation, range normalisation and the fp16 split happen once, not per tile and tap
             pre_img = getattr(x, '_eg3d_split', None)           # (SplitImage, styles ptr, styles version) left by the producing layer's epilogue
             if pre_img is not None and pre_img[1] == styles.data_ptr() and pre_img[2] == styles._version and pre_img[0].shape == tuple(x.shape):
@@ -304,6 +309,9 @@ class ModConvLayerFn(torch.autograd.Function):
         if up == 1:
             if v2:
                 H.conv_v2(aimg, wimg, out, cls, epi=L.EPI_FWD, out_scale=d, out_amax=amax_out, algo_flops=aflops, products=nprod, **epi_kw)
+            elif lrp:
+                H.conv_lr(x, H.amax_of(x), wimg, out, cls, lrp, in_scale=styles, epi=L.EPI_FWD, out_scale=d, out_amax=amax_out, algo_flops=aflops,
+                          products=nprod, **epi_kw)
             elif ks2:
                 z = H.zeros_cl(N, Co, Ho, Wo, x.device)
                 H.conv_v2(aimg, wimg, z, cls, epi=L.EPI_ATOMIC, ksplit=ks2, algo_flops=aflops, products=nprod)
@@ -472,6 +480,10 @@ class ModConvLayerFn(torch.autograd.Function):
                 did = H.conv_v2(dz_img if dz_img is not None else H.split_activation(g, amax), cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD,
                                 out_scale=styles, xin=x, ds=ds, algo_flops=aflops, products=1 if prec == 'f16x1' else 3, **fkw)
                 dz_img = None
+            elif up == 1 and prec in ('f16x3', 'f16x1') and amax is not None and not ks2 and H.conv_lr_plan(Co, Ci, cls_adj, N):
+                # low-resolution layer: data gradient, style gradient and the producer's activation backward from one launch (csrc/conv_lr.hip)
+                did = H.conv_lr(g, amax, cache.get_split(weight)[1], dx, cls_adj, H.conv_lr_plan(Co, Ci, cls_adj, N), epi=L.EPI_BWD, out_scale=styles,
+                                xin=x, ds=ds, algo_flops=aflops, products=1 if prec == 'f16x1' else 3, **fkw)
             elif ks2:                              # under-filled 3x3 grid: split-K launch of the pre-split kernel, then the finishing pass
                 z = H.zeros_cl(N, Ci, Hi, Wi, dev)
                 H.conv_v2(H.split_activation(g, amax), cache.get_split(weight)[1], z, cls_adj, epi=L.EPI_ATOMIC, ksplit=ks2, algo_flops=aflops,

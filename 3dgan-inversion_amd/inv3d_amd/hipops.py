@@ -795,6 +795,99 @@ def conv_up2(a: SplitImage, w: SplitImage, out, Hc=None, Wc=None, epi=L.EPI_STOR
     return out
 
 
+# ------------------------------------------------------------------------------------------------- low-resolution convolution (csrc/conv_lr.hip)
+LR_CONFIG = 10       # profiler id of conv_lr_kernel
+USE_LR = os.environ.get('EG3D_CONV_LR', '0') != '0'
+LR_MAX_CELLS = int(os.environ.get('EG3D_LR_MAX_CELLS', '4096'))        # class grids up to this many cells per image (64^2)
+LR_KS_TARGET = int(os.environ.get('EG3D_LR_KS_TARGET', '256'))         # workgroups a launch aims for
+LR_ROTATE = int(os.environ.get('EG3D_LR_ROTATE', '1'))                 # tile-dependent start of the chunk walk (eg3d_conv_lr_params::rotate)
+LR_KS_MAX = int(os.environ.get('EG3D_LR_KS_MAX', '8'))                 # K slices per tile (the last arriver reads that many 32 KB slabs)
+
+
+def conv_lr_plan(Ck, Nc, classes, N=1, in_stride=1):
+    """(logw, ksplit) for eg3d_conv2d_lr, or None when the launch is not one for it: stride-1 tap classes of 9 / 4 / 2 / 1 taps on grids of at
+    most LR_MAX_CELLS cells whose 256-cell tiles cannot fill the chip.  logw: tile width 32 / 16 / 8 / 4 cells, the narrowest power of two
+    that covers the widest class grid; ksplit: K slices per 64-cell x 128-channel tile so that the launch has ~LR_KS_TARGET workgroups, each
+    with at least two 16-channel chunks, at most LR_KS_MAX."""
+    if not USE_LR or CONV_MODE != 'auto' or in_stride != 1 or Ck % 16 or Nc % 128 or Ck > 1024 or not (1 <= len(classes) <= 4):
+        return None
+    wmax = max(c.Wa for c in classes)
+    if max(c.Ha * c.Wa for c in classes) > LR_MAX_CELLS:
+        return None
+    for c in classes:
+        if c.ntaps not in (9, 4, 2, 1):
+            return None
+        dys, dxs = [c.dy[t] for t in range(c.ntaps)], [c.dx[t] for t in range(c.ntaps)]
+        if max(dys) - min(dys) > 2 or max(dxs) - min(dxs) > 2:
+            return None
+    logw = 5 if wmax > 16 else (4 if wmax > 8 else (3 if wmax > 4 else 2))
+    tw, tr = 1 << logw, 64 >> logw
+    tiles = sum(N * -(-c.Ha // tr) * -(-c.Wa // tw) for c in classes) * (Nc // 128)
+    ks = max(1, min(LR_KS_MAX, -(-LR_KS_TARGET // tiles), (Ck // 16) // 2))
+    return logw, ks
+
+
+def conv_lr(x, x_amax, w: SplitImage, out, classes, plan, in_scale=None, amax_mul=1.0, out_stride=1, epi=L.EPI_STORE, out_scale=None, bias=None,
+            noise=None, noise_nstride=0, noise_strength=None, act='linear', alpha=0.0, gain=1.0, clamp=-1.0, addend=None, xin=None, ds=None,
+            out_amax=None, algo_flops=None, act_bwd=None, products=3, rotate=None):
+    """Launch eg3d_conv2d_lr: fp32 channels_last x (times in_scale[n,k]) against the split weight image `w`, epilogues of conv_v2.  plan =
+    conv_lr_plan(...).  act_bwd (ActBwdSpec, with epi=EPI_BWD): EPI_BWD_ACT when the launch takes it -- returns True if the fused epilogue
+    ran, False for a plain EPI_BWD."""
+    assert is_cl(x) and is_cl(out)
+    logw, ks = plan
+    n, cx, hi, wi = x.shape
+    nc, ck, wtaps = w.shape
+    _, co, ho, wo = out.shape
+
+    class _A:          # what _conv_v2_params reads of an operand image
+        pass
+    a = _A()
+    a.shape, a.data, a.scale = (n, ck, hi, wi), x, x_amax
+    P = L.ConvLrParams()
+    v = _conv_v2_params(a, w, out, classes, out_stride, epi, out_scale, bias, noise, noise_nstride, noise_strength, act, alpha, gain, clamp,
+                        addend, xin, ds, out_amax)
+    v.products, v.ksplit, v.patch_rows = int(products), int(ks), 0
+    fused_act = False
+    if act_bwd is not None and epi == L.EPI_BWD and xin is not None:
+        v.epi = L.EPI_BWD_ACT
+        act_bwd.fill(v.act_bwd)
+        fused_act = all(t is None or t.data_ptr() % 16 == 0 for t in (act_bwd.d, act_bwd.bias))
+        if not fused_act:
+            v.epi = L.EPI_BWD
+            v.act_bwd = L.ActBwd()
+    P.v = v
+    P.in_scale = in_scale.data_ptr() if in_scale is not None else None
+    P.x_amax, P.amax_mul, P.ldx, P.logw = x_amax.data_ptr(), float(amax_mul), cx, int(logw)
+    P.rotate = int(LR_ROTATE if rotate is None else rotate)
+    if fused_act and not L.lib().eg3d_conv2d_lr_supported(C.byref(P)):
+        fused_act = False
+        P.v.epi = L.EPI_BWD
+        P.v.act_bwd = L.ActBwd()
+    slabs = tickets = None
+    if ks > 1:
+        sb, tw = C.c_int64(0), C.c_int64(0)
+        L.check(L.lib().eg3d_conv2d_lr_workspace(C.byref(P), C.byref(sb), C.byref(tw)), 'conv2d_lr_workspace')
+        slabs = torch.empty((sb.value // 4,), dtype=torch.float32, device=x.device)
+        tickets = zeros((tw.value,), x.device)             # zero words (the kernel leaves them zero)
+        P.slabs, P.tickets = slabs.data_ptr(), tickets.data_ptr()
+    prof = PROFILER
+    if prof is not None and prof.only_config is not None and prof.only_config != LR_CONFIG:
+        prof = None
+    if prof is not None:
+        if algo_flops is None:
+            algo_flops = 2.0 * ck * nc * sum(n * c.Ha * c.Wa * c.ntaps for c in classes)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    L.check(L.lib().eg3d_conv2d_lr(C.byref(P), L.stream_ptr()), 'conv2d_lr')
+    if prof is not None:
+        e1.record()
+        prof.records.append(((LR_CONFIG, PRECISIONS['f16x3']), float(algo_flops), e0, e1))
+        if prof.meta is not None:
+            prof.meta.append(dict(N=n, Hi=hi, Wi=wi, Ck=ck, Nc=nc, Ho=ho, Wo=wo, taps=[c.ntaps for c in classes], epi=epi, ksplit=int(ks),
+                                  in_stride=1, out_stride=out_stride, prec=3, lr=True, logw=int(logw)))
+    return fused_act if act_bwd is not None else out
+
+
 def conv_wgrad(x, g, Ck, Nc, dwp, classes, in_stride=1, out_stride=1, in_scale=None, psplit=0, precision='f32', g_amax=None, g_amax_mul=1.0):
     """dwp[Nc, taps*Ck] += grad of the packed weights (dwp pre-zeroed).  precision 'f32' | 'f16x3' (g_amax: device scalar max|g|
     for the range normalisation of the gradient operand, see include/eg3d_hip.h)."""

@@ -918,6 +918,99 @@ def test_conv_v2_half_patch_full_size():
         assert torch.equal(o, outs[0]), 'the 2-, 4- and 8-row patches accumulate in the same order: bit-identical results'
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# Low-resolution convolution (csrc/conv_lr.hip): fp32 activation in, in-kernel split, deep weight ring, ordered split-K
+# ---------------------------------------------------------------------------------------------------------------------------
+def _lr_plan(H, ci, co, cls, n, ks):
+    plan = H.conv_lr_plan(ci, co, cls, n)
+    assert plan is not None
+    return (plan[0], ks if ks else plan[1])
+
+
+@pytest.mark.parametrize('ks', [0, 1, 2, 8])      # 0: the planner's choice
+@pytest.mark.parametrize('shape', [(1, 512, 4, 4, 512), (1, 64, 8, 8, 128), (2, 128, 16, 16, 256), (1, 32, 32, 32, 128), (1, 64, 64, 64, 128),
+                                   (1, 48, 5, 9, 128), (2, 32, 17, 33, 128)])
+def test_conv_lr_forward_epilogue_vs_torch(shape, ks):
+    """3x3 correlation with the fused forward epilogue on the backbone's low resolutions (4^2 .. 64^2) and ragged grids, tile widths 4 / 8 /
+    16 / 32, with and without the ordered split-K; max|out| reported."""
+    from inv3d_amd import hipops as H, _lib as L
+    n, ci, h, w, co = shape
+    if ks > ci // 16:
+        pytest.skip('more K slices than 16-channel chunks')
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)
+    s = 1 + 0.5 * torch.randn(n, ci, generator=g)
+    d = 0.5 + torch.rand(n, co, generator=g)
+    noise, strength = torch.randn(n, 1, h, w, generator=g), torch.tensor(0.3)
+    bias, add = 0.1 * torch.randn(co, generator=g), torch.randn(n, co, h, w, generator=g)
+    z = torch.nn.functional.conv2d(x.double() * s.double()[:, :, None, None], wt.double(), padding=1) * d.double()[:, :, None, None]
+    ref = torch.nn.functional.leaky_relu(z + noise.double() * 0.3 + bias.double()[None, :, None, None], 0.2) * 1.4 + add.double()
+    xc = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    wimg = H.split_weight(H.pack_weight_fwd(wt.to(DEV)), co, ci, 9)
+    cls = H.classes_corr(h, w, 3, 3, 1)
+    out = H.empty_cl(n, co, h, w, DEV)
+    amax = torch.zeros(1, device=DEV)
+    H.conv_lr(xc, H.absmax(xc), wimg, out, cls, _lr_plan(H, ci, co, cls, n, ks), in_scale=s.to(DEV), epi=L.EPI_FWD, out_scale=d.to(DEV), bias=bias.to(DEV),
+              noise=noise.to(DEV).contiguous(), noise_nstride=h * w, noise_strength=strength.to(DEV), act='lrelu', alpha=0.2, gain=1.4, clamp=-1.0,
+              addend=add.to(DEV).contiguous(memory_format=torch.channels_last), out_amax=amax)
+    close(out, ref.float(), 2e-5, f'conv_lr fwd {shape} ks {ks}')
+    assert abs(float(amax) - float(out.abs().max())) == 0.0
+
+
+@pytest.mark.parametrize('ks', [1, 4])
+@pytest.mark.parametrize('shape', [(2, 128, 16, 16, 128), (1, 256, 8, 8, 128), (1, 128, 24, 40, 64)])
+def test_conv_lr_data_gradient_epilogue_vs_torch(shape, ks):
+    """Data gradient of a 3x3 layer on the low-resolution kernel: adjoint taps on the adjoint weight image, gradient-sized operand
+    (range-normalised by its max), dx = acc * styles + addend, ds = sum_px acc * x."""
+    from inv3d_amd import hipops as H, _lib as L
+    n, ci, h, w, co = shape
+    g = torch.Generator().manual_seed(32)
+    gz = torch.randn(n, co, h, w, generator=g) * 1e-4
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)
+    s, xin, add = 1 + 0.5 * torch.randn(n, ci, generator=g), torch.randn(n, ci, h, w, generator=g), torch.randn(n, ci, h, w, generator=g) * 1e-4
+    acc = torch.nn.functional.conv_transpose2d(gz.double(), wt.double(), padding=1)
+    ref_dx = acc * s.double()[:, :, None, None] + add.double()
+    ref_ds = (acc * xin.double()).sum((2, 3))
+    gc = gz.to(DEV).contiguous(memory_format=torch.channels_last)
+    wimg = H.split_weight(H.pack_weight_adj(wt.to(DEV)), ci, co, 9)
+    cls = H.classes_corr_adjoint(h, w, 3, 3, 1)
+    if co % 16 or ci % 128:
+        pytest.skip('geometry outside the kernel')
+    dx, ds = H.empty_cl(n, ci, h, w, DEV), torch.zeros(n, ci, device=DEV)
+    H.conv_lr(gc, H.absmax(gc), wimg, dx, cls, _lr_plan(H, co, ci, cls, n, ks), epi=L.EPI_BWD, out_scale=s.to(DEV),
+              xin=xin.to(DEV).contiguous(memory_format=torch.channels_last), ds=ds, addend=add.to(DEV).contiguous(memory_format=torch.channels_last))
+    close(dx * 1e4, ref_dx.float() * 1e4, 2e-5, 'conv_lr dgrad dx')
+    close(ds * 1e4, ref_ds.float() * 1e4, 5e-5, 'conv_lr dgrad ds')
+
+
+def test_conv_lr_split_k_is_deterministic_and_tickets_reset():
+    """The ordered split-K: repeated launches are bit-identical (the slabs are summed in slice order whatever the arrival order), equal to
+    the un-split launch up to fp32 summation order, and the ticket words are zero again after every launch."""
+    from inv3d_amd import hipops as H, _lib as L
+    n, ci, h, w, co = 1, 512, 16, 16, 512
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(n, ci, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)).to(DEV)
+    s = (1 + 0.5 * torch.randn(n, ci, generator=g)).to(DEV)
+    wimg = H.split_weight(H.pack_weight_fwd(wt), co, ci, 9)
+    cls = H.classes_corr(h, w, 3, 3, 1)
+    ax = H.absmax(x)
+    outs = []
+    for rep in range(6):
+        out = H.empty_cl(n, co, h, w, DEV)
+        H.conv_lr(x, ax, wimg, out, cls, (4, 8), in_scale=s, epi=L.EPI_STORE)
+        outs.append(out)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    one = H.empty_cl(n, co, h, w, DEV)
+    H.conv_lr(x, ax, wimg, one, cls, (4, 1), in_scale=s, epi=L.EPI_STORE)
+    ref = torch.nn.functional.conv2d(x.double() * s.double()[:, :, None, None], wt.double(), padding=1).float()
+    close(outs[0], ref, 2e-5, 'conv_lr split-K vs fp64')
+    close(one, ref, 2e-5, 'conv_lr un-split vs fp64')
+
+
 @pytest.mark.parametrize('rows', [8, 4, 2])
 def test_conv_v2_data_gradient_epilogue_vs_torch(rows):
     """Data gradient of a 3x3 layer: adjoint taps on the adjoint weight image, dx = acc * styles + addend, ds = sum_px acc * x."""

@@ -3,7 +3,7 @@ import csv, glob, re, sys, collections
 d = sys.argv[1]; mn = float(sys.argv[2]) if len(sys.argv) > 2 else 12.0
 rows = list(csv.DictReader(open(glob.glob(d + '/**/*_kernel_trace.csv', recursive=True)[0])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'noise_apply_norm_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'adam_apply_norm_kernel' in r['Kernel_Name'] or 'noise_apply_norm_kernel' in r['Kernel_Name']]
 a, b = idx[-6], idx[-5]
 seg = rows[a + 1:b + 1]
 t0 = int(seg[0]['Start_Timestamp'])

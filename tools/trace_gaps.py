@@ -3,7 +3,7 @@ noise renormalisation kernel); lists the largest idle gaps and which kernel foll
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'noise_apply_norm_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'adam_apply_norm_kernel' in r['Kernel_Name'] or 'noise_apply_norm_kernel' in r['Kernel_Name']]
 for a, b in list(zip(idx[:-1], idx[1:]))[-4:-1]:
     seg = rows[a + 1:b + 1]
     iv = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in seg)
