@@ -50,13 +50,20 @@ class WeightCache:
         self._c = {}
         self._pad, self._pad_key, self._pad_bias_key = None, None, None
 
+    @staticmethod
+    def key_of(w: torch.Tensor):
+        # the optimiser epoch only concerns weights an optimiser can write (as hipops.memo): the images of frozen weights survive other
+        # generators' steps and captures -- graphs that baked their addresses stay valid
+        return (w.data_ptr(), w._version, tuple(w.shape), H.WEIGHTS_EPOCH if w.requires_grad else -1)
+
     def get(self, w: torch.Tensor):
-        key = (w.data_ptr(), w._version, tuple(w.shape), H.WEIGHTS_EPOCH)
+        key = self.key_of(w)
         hit = self._c.get('k')
         if hit != key:
             with torch.no_grad():
                 wf, wa, wsq = H.pack_conv_weight(w)
             self._c = {'k': key, 'wf': wf, 'wa': wa, 'wsq': wsq}
+        H.keep_for_capture(self._c['wf'], self._c['wa'], self._c['wsq'])
         return self._c['wf'], self._c['wa'], self._c['wsq']
 
     def get_split(self, w: torch.Tensor):
@@ -68,6 +75,7 @@ class WeightCache:
             with torch.no_grad():
                 hit = (H.split_weight(wf, o, i, kh * kw), H.split_weight(wa, i, o, kh * kw))
             self._c['split'] = hit
+        H.keep_for_capture(hit[0].data, hit[0].scale, hit[1].data, hit[1].scale)
         return hit
 
     def get_pieces(self, w: torch.Tensor):
@@ -81,6 +89,7 @@ class WeightCache:
                 ok = wf.shape[1] % 4 == 0 and wa.shape[1] % 4 == 0
                 hit = (H.split_weight_pieces(wf), H.split_weight_pieces(wa)) if ok else (None, None)
             self._c['pieces'] = hit
+        H.keep_for_capture(*hit)
         return hit
 
     def get_padded(self, w: torch.Tensor, cp: int, bias: Optional[torch.Tensor] = None):
@@ -88,7 +97,7 @@ class WeightCache:
         cp (toRGB 3 -> 4: the padded output channel is 0 + skip, the launch takes the 16-byte vector epilogue, and the data gradient
         contracts over 4 channels).  The buffers are zero-filled once and re-packed in place whenever the weights change -- one launch per
         step of the pivotal-tuning phase instead of a fill and a copy per image."""
-        key = (w.data_ptr(), w._version, tuple(w.shape), H.WEIGHTS_EPOCH, cp)
+        key = self.key_of(w) + (cp,)
         pad = self._pad
         if pad is None or pad[0].shape[0] != cp or pad[0].device != w.device:
             o, i, kh, kw = w.shape
@@ -105,6 +114,7 @@ class WeightCache:
                 with torch.no_grad():
                     pad[2][:bias.shape[0]].copy_(bias.detach().float())
                 self._pad_bias_key = bkey
+        H.keep_for_capture(*pad)
         return pad[0], pad[1], (pad[2] if bias is not None else None)
 
 
@@ -120,7 +130,7 @@ def prepack_weights(layers):
             continue
         o, i, kh, kw = w.shape
         cp = (o + 3) // 4 * 4
-        key = (w.data_ptr(), w._version, tuple(w.shape), H.WEIGHTS_EPOCH)
+        key = WeightCache.key_of(w)
         if getattr(m, 'out_pad', False) and cp != o:
             pad = cache._pad
             if pad is None or pad[0].shape[0] != cp or pad[0].device != w.device:

@@ -47,19 +47,38 @@ class _Entry:
 
 
 def _leaves(G):
-    """(leaf tensors that require grad, signature of everything frozen).  Parameters and buffers in module order."""
-    leaves, sig = [], 0
+    """(leaf tensors that require grad, signature of everything frozen, signature of the trainable PARAMETERS).  Parameters and buffers in
+    module order.  Frozen tensors enter with (pointer, in-place version): `load_state_dict` / in-place edits re-capture (a raw `.data`
+    write bumps no version: call `graphed.reset(G)` after one).  Trainable ones enter with their identity and pointer only -- optimiser
+    steps between calls must NOT re-capture; their derived images are rebuilt inside every replay instead (`pack_inside`)."""
+    leaves, frozen, trainable = [], [], []
     for t in G.parameters():
         if t.requires_grad:
             leaves.append(t)
+            trainable.append((id(t), t.data_ptr()))
         else:
-            sig += t._version + (t.data_ptr() & 0xffff)
+            frozen.append((t.data_ptr(), t._version))
     for t in G.buffers():
         if t.requires_grad:
             leaves.append(t)
         else:
-            sig += t._version + (t.data_ptr() & 0xffff)
-    return leaves, sig
+            frozen.append((t.data_ptr(), t._version))
+    return leaves, hash(tuple(frozen)), tuple(trainable)
+
+
+def _render_key(G):
+    """Hashable snapshot of G.rendering_kwargs (depth resolutions, ray range, box_warp, white_back ... are baked into a captured graph; the
+    reference's viewers mutate them between calls: viz/renderer.py, gen_videos.py).  None = not hashable: no replay for this call."""
+    rk = getattr(G, 'rendering_kwargs', None) or {}
+    out = []
+    for k in sorted(rk):
+        v = rk[k]
+        if isinstance(v, (list, tuple)) and all(isinstance(x, (bool, int, float, str, type(None))) for x in v):
+            v = tuple(v)
+        elif not isinstance(v, (bool, int, float, str, type(None))):
+            return None
+        out.append((k, v))
+    return tuple(out)
 
 
 def _kw_key(kw):
@@ -162,7 +181,7 @@ class _aliased_leaves:
         return False
 
 
-def _capture(G, impl, ws, c, uni, kw, leaves, need_grad):
+def _capture(G, impl, ws, c, uni, kw, leaves, need_grad, pack_inside):
     """Capture forward (and backward) for this signature; returns the entry.  Two passes: the first sizes the zero arenas (every
     zero-initialised accumulator of the step comes out of one buffer cleared by one launch, hipops.ZeroArena), the second is kept."""
     dev = ws.device
@@ -174,41 +193,52 @@ def _capture(G, impl, ws, c, uni, kw, leaves, need_grad):
     e.s_u2 = uni[1].detach().clone() if (uni is not None and uni[1] is not None) else None
     e.arena_f, e.arena_b = H.ZeroArena(dev), H.ZeroArena(dev)
     e.gen, e.pending, e.done = 0, None, True
-    if leaves:
-        H.weights_changed()            # trainable weights: every derived image must be rebuilt INSIDE the captured forward
+    # trainable weights (whether or not THIS call differentiates: a no-grad preview between optimiser steps replays too): every derived
+    # image must be rebuilt INSIDE the captured forward -- a new optimiser epoch makes the caches of trainable weights miss (frozen ones keep
+    # their images: fused.WeightCache.key_of, hipops.memo)
     s_uni = (e.s_u1, e.s_u2) if e.s_u1 is not None else None
     for attempt in range(2):
         keep = attempt == 1
-        if leaves and keep:
+        if pack_inside:
             H.weights_changed()
-        fwd = torch.cuda.CUDAGraph()
-        with _aliased_leaves(G, leaves) as aliases:
-            with H.capture_guard(), torch.cuda.graph(fwd, capture_error_mode='thread_local'), H.zero_arena(e.arena_f):
-                with torch.set_grad_enabled(need_grad):
-                    out = impl(e.s_ws, e.s_c, render_uniforms=s_uni, **kw)
-        img, raw = out['image'], out['image_raw']
-        img4, raw4 = getattr(img, '_eg3d_padded4', None), getattr(raw, '_eg3d_padded4', None)
-        outs = [img4 if img4 is not None else img, raw4 if raw4 is not None else raw, out['image_depth']]
-        req = [bool(need_grad and o.requires_grad) for o in outs]
-        bwd = gins = gouts = None
-        targets = ([e.s_ws] if e.ws_req else []) + ([e.s_c] if e.c_req else []) + list(aliases)
-        if any(req):
-            gouts = [torch.zeros_like(o) for o, r in zip(outs, req) if r]
-            bwd = torch.cuda.CUDAGraph()
-            with H.capture_guard(), torch.cuda.graph(bwd, pool=fwd.pool(), capture_error_mode='thread_local'), H.zero_arena(e.arena_b):
-                gins = torch.autograd.grad([o for o, r in zip(outs, req) if r], targets, gouts, allow_unused=True)
-        del aliases, targets
+        refs = H.CAPTURE_REFS = []     # every derived tensor the launches of this capture were handed (they hold raw pointers to them)
+        try:
+            e_fwd_bwd = _capture_once(G, impl, e, kw, leaves, need_grad, s_uni)
+        finally:
+            H.CAPTURE_REFS = None
+        fwd, bwd, outs, req, gouts, gins, padded = e_fwd_bwd
         if keep:
             e.fwd, e.bwd = fwd, bwd
             e.s_out = [o.detach() for o in outs]
-            e.out_req, e.padded = req, (img4 is not None, raw4 is not None)
+            e.out_req, e.padded = req, padded
             e.s_gout = gouts
             e.s_gin = list(gins) if gins is not None else []
             e.grad_targets = ([ws] if e.ws_req else []) + ([c] if e.c_req else []) + list(leaves)      # .grad holders (the user's tensors)
-        else:
-            del fwd, bwd, out, outs, gins, gouts, img, raw, img4, raw4
+            e.refs = refs
+        del e_fwd_bwd, fwd, bwd, outs, gouts, gins
     STATS['captured'] += 1
     return e
+
+
+def _capture_once(G, impl, e, kw, leaves, need_grad, s_uni):
+    fwd = torch.cuda.CUDAGraph()
+    with _aliased_leaves(G, leaves) as aliases:
+        with H.capture_guard(), torch.cuda.graph(fwd, capture_error_mode='thread_local'), H.zero_arena(e.arena_f):
+            with torch.set_grad_enabled(need_grad):
+                out = impl(e.s_ws, e.s_c, render_uniforms=s_uni, **kw)
+    img, raw = out['image'], out['image_raw']
+    img4, raw4 = getattr(img, '_eg3d_padded4', None), getattr(raw, '_eg3d_padded4', None)
+    outs = [img4 if img4 is not None else img, raw4 if raw4 is not None else raw, out['image_depth']]
+    req = [bool(need_grad and o.requires_grad) for o in outs]
+    bwd = gins = gouts = None
+    targets = ([e.s_ws] if e.ws_req else []) + ([e.s_c] if e.c_req else []) + list(aliases)
+    if any(req):
+        gouts = [torch.zeros_like(o) for o, r in zip(outs, req) if r]
+        bwd = torch.cuda.CUDAGraph()
+        with H.capture_guard(), torch.cuda.graph(bwd, pool=fwd.pool(), capture_error_mode='thread_local'), H.zero_arena(e.arena_b):
+            gins = torch.autograd.grad([o for o, r in zip(outs, req) if r], targets, gouts, allow_unused=True)
+    del aliases, targets
+    return fwd, bwd, outs, req, gouts, gins, (img4 is not None, raw4 is not None)
 
 
 def _wrap(e, outs):
@@ -233,15 +263,19 @@ def synthesis(G, impl, ws, c, render_uniforms=None, **kw):
     if kk is None or kw.get('cache_backbone') or kw.get('use_cached_backbone') or kw.get('update_emas') or kw.get('noise_inject') is not None:
         STATS['eager'] += 1
         return impl(ws, c, render_uniforms=render_uniforms, **kw)
-    leaves, frozen_sig = _leaves(G)
+    rkey = _render_key(G)
+    if rkey is None:
+        STATS['eager'] += 1
+        return impl(ws, c, render_uniforms=render_uniforms, **kw)
+    leaves, frozen_sig, trainable = _leaves(G)
     grad_on = torch.is_grad_enabled()
     need_grad = bool(grad_on and (ws.requires_grad or c.requires_grad or leaves))
     if not need_grad:
         leaves = []
+    pack_inside = bool(trainable)
     uni_key = None if render_uniforms is None else tuple(None if u is None else tuple(u.shape) for u in render_uniforms)
     key = (tuple(ws.shape), tuple(c.shape), ws.dtype, c.dtype, need_grad, bool(ws.requires_grad and need_grad), bool(c.requires_grad and need_grad), kk, uni_key,
-           tuple(id(t) for t in leaves), frozen_sig, H.CONV_MODE, G.neural_rendering_resolution, ws.device.index, G.training,
-           str(G.rendering_kwargs.get('superresolution_noise_mode')))
+           tuple(id(t) for t in leaves), frozen_sig, trainable, H.CONV_MODE, G.neural_rendering_resolution, ws.device.index, G.training, rkey)
     st = _STATE.get(G)
     if st is None:
         st = _STATE[G] = _PerG()
@@ -255,7 +289,7 @@ def synthesis(G, impl, ws, c, render_uniforms=None, **kw):
             STATS['eager'] += 1
             return impl(ws, c, render_uniforms=render_uniforms, **kw)
         try:
-            e = _capture(G, impl, ws, c, render_uniforms, kw, leaves, need_grad)
+            e = _capture(G, impl, ws, c, render_uniforms, kw, leaves, need_grad, pack_inside)
         except RuntimeError as err:          # the runtime refused the capture: keep launching kernel by kernel (same kernels), say so once
             import warnings
             st.failed.add(key)

@@ -65,6 +65,27 @@ class _Span:
             self.prof.spans.append((self.name, self.e0, self.e1))
 
 
+def span_between_grads(name, t_start, t_end):
+    """Profiler span over a stretch of the BACKWARD pass: opened when the gradient of `t_start` arrives, closed when that of `t_end` does
+    (bench.py: the backbone's backward = from d planes to d ws).  No-op without an active profiler."""
+    prof = PROFILER
+    if prof is None or not (torch.is_tensor(t_start) and torch.is_tensor(t_end) and t_start.requires_grad and t_end.requires_grad):
+        return
+    st = {}
+
+    def opened(g):
+        st['e0'] = torch.cuda.Event(enable_timing=True)
+        st['e0'].record()
+
+    def closed(g):
+        if 'e0' in st:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            prof.spans.append((name, st.pop('e0'), e1))
+    t_start.register_hook(opened)
+    t_end.register_hook(closed)
+
+
 TILE_NAMES = {0: '128,128,2,2', 1: '64,128,2,2', 2: '32,128,1,4', 3: '128,32,4,1', 4: '256,64,4,1'}
 
 
@@ -302,6 +323,15 @@ def weights_changed():
 
 
 
+CAPTURE_REFS = None           # a list while graphed._capture runs: every derived tensor handed out (memo / WeightCache) is appended, so that the
+                              # captured graph's entry can keep alive what its kernels hold raw pointers to
+
+
+def keep_for_capture(*objs):
+    if CAPTURE_REFS is not None:
+        CAPTURE_REFS.extend(o for o in objs if o is not None)
+
+
 def memo(tag, tensors, fn):
     """Derived images of parameters (packed / padded / pre-scaled weights), recomputed only when a source tensor changes (storage
     pointer or in-place version).  One entry per (tag, storage): frozen weights cost nothing per step, trained ones are rebuilt."""
@@ -318,6 +348,7 @@ def memo(tag, tensors, fn):
         with torch.no_grad():
             hit = (key, fn(), tuple(weakref.ref(t) for t in tensors))
         _MEMO[slot] = hit
+    keep_for_capture(hit[1])
     return hit[1]
 
 
@@ -804,12 +835,12 @@ LR_ROTATE = int(os.environ.get('EG3D_LR_ROTATE', '1'))                 # tile-de
 LR_KS_MAX = int(os.environ.get('EG3D_LR_KS_MAX', '8'))                 # K slices per tile (the last arriver reads that many 32 KB slabs)
 
 
-def conv_lr_plan(Ck, Nc, classes, N=1, in_stride=1):
+def conv_lr_plan(Ck, Nc, classes, N=1, in_stride=1, force=False):
     """(logw, ksplit) for eg3d_conv2d_lr, or None when the launch is not one for it: stride-1 tap classes of 9 / 4 / 2 / 1 taps on grids of at
     most LR_MAX_CELLS cells whose 256-cell tiles cannot fill the chip.  logw: tile width 32 / 16 / 8 / 4 cells, the narrowest power of two
     that covers the widest class grid; ksplit: K slices per 64-cell x 128-channel tile so that the launch has ~LR_KS_TARGET workgroups, each
     with at least two 16-channel chunks, at most LR_KS_MAX."""
-    if not USE_LR or CONV_MODE != 'auto' or in_stride != 1 or Ck % 16 or Nc % 128 or Ck > 1024 or not (1 <= len(classes) <= 4):
+    if not (USE_LR or force) or CONV_MODE != 'auto' or in_stride != 1 or Ck % 16 or Nc % 128 or Ck > 1024 or not (1 <= len(classes) <= 4):
         return None
     wmax = max(c.Wa for c in classes)
     if max(c.Ha * c.Wa for c in classes) > LR_MAX_CELLS:

@@ -440,7 +440,7 @@ class LatentProjector:
                 self._wn.copy_(w_noise)
             else:
                 self._wn.normal_(generator=self.gen)
-            if self._uni is not None and step >= self.preheat:
+            if self._uni is not None:         # every step, the eager camera-preheat ones included: they render from the same buffer
                 self._uni.uniform_(generator=self.gen)
             if self._graph is not None:
                 self._graph.replay()

@@ -10,6 +10,7 @@ import os
 import torch
 
 from .. import fused
+from .. import hipops as H
 from .. import graphed
 from ..reference_binding import ReferenceStateMixin
 from .networks_stylegan2 import Generator as StyleGAN2Backbone, FullyConnectedLayer
@@ -80,7 +81,9 @@ class TriPlaneGenerator(ReferenceStateMixin, torch.nn.Module):
         if use_cached and self._last_planes is not None:
             planes = self._last_planes
         else:
-            planes = self.backbone.synthesis(ws, update_emas=update_emas, noise_inject=noise_inject, **kwargs)
+            with H._Span('backbone_fwd'):
+                planes = self.backbone.synthesis(ws, update_emas=update_emas, noise_inject=noise_inject, **kwargs)
+            H.span_between_grads('backbone_bwd', planes, ws)
         if cache:
             self._last_planes = planes
         return planes

@@ -120,6 +120,66 @@ def test_no_grad_calls_replay_and_match():
     assert graphed.STATS['replayed'] >= n0 + 3
 
 
+def test_no_grad_preview_between_optimiser_steps_sees_the_new_weights():
+    """single_id_coach's pattern: a no-grad preview render (hot after three calls -> captured), then optimiser steps on the
+    generator's weights, then the same preview call again.  The replay must render with the UPDATED weights: trainable weights are
+    re-packed inside the captured forward whether or not the call differentiates."""
+    from inv3d_amd import graphed
+    cfg, Ga = _small()
+    _, Gb = _small()
+    u1, u2 = O.make_uniforms(cfg, 1, seed=4)
+    uni = (u1.to(DEV), u2.to(DEV))
+    cam = O.synth_cameras(1, seed=2).to(DEV)
+    ws = O.synth_ws(cfg, 1, seed=1).to(DEV)
+    target = O._randn('tgt', 5, (1, 3, 64, 64)).to(DEV).clamp(-1, 1)
+    res = []
+    for G, flag in ((Ga, True), (Gb, False)):
+        G.graph_eager = flag
+        G.requires_grad_(True)
+        opt = torch.optim.Adam(G.parameters(), lr=3e-3)
+        n0 = graphed.STATS['replayed']
+        with torch.no_grad():
+            for _ in range(5):
+                before = G.synthesis(ws, cam, noise_mode='const', render_uniforms=uni)['image'].clone()
+        if flag:
+            assert graphed.STATS['replayed'] >= n0 + 2
+        for i in range(4):
+            gen = G.synthesis(ws, cam, noise_mode='const', render_uniforms=uni)
+            loss = F.mse_loss(gen['image'], target)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        with torch.no_grad():
+            after = G.synthesis(ws, cam, noise_mode='const', render_uniforms=uni)['image'].clone()
+        res.append((before, after))
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-5
+    moved = float((res[1][1] - res[1][0]).abs().max())
+    assert moved > 1e-3, 'the optimiser steps must change the render for this test to mean anything'
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-3 * max(1.0, moved), 'replayed preview rendered with stale weights'
+
+
+def test_rendering_kwargs_are_part_of_the_signature():
+    """viz/renderer.py and gen_videos.py rewrite G.rendering_kwargs between calls (depth resolutions, ray range): a captured graph must not
+    be replayed for other values."""
+    cfg, Ga = _small()
+    _, Gb = _small()
+    Ga.graph_eager, Gb.graph_eager = True, False
+    ws = O.synth_ws(cfg, 1, seed=1).to(DEV)
+    cam = O.synth_cameras(1, seed=2).to(DEV)
+    with torch.no_grad():
+        for _ in range(4):
+            Ga.synthesis(ws, cam, noise_mode='const')
+        for G in (Ga, Gb):
+            G.rendering_kwargs['ray_start'] = float(G.rendering_kwargs['ray_start']) + 0.15
+            G.rendering_kwargs['white_back'] = True
+        torch.manual_seed(5)
+        a = Ga.synthesis(ws, cam, noise_mode='const')
+        torch.manual_seed(5)
+        b = Gb.synthesis(ws, cam, noise_mode='const')
+    for k in ('image_raw', 'image_depth'):
+        assert float((a[k] - b[k]).abs().max()) <= 1e-4, k
+
+
 def test_second_forward_before_the_first_backward_falls_back():
     """Two live graphs of one signature: the second forward must not overwrite the first one's captured activations."""
     from inv3d_amd import graphed

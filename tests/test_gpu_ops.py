@@ -922,7 +922,7 @@ def test_conv_v2_half_patch_full_size():
 # Low-resolution convolution (csrc/conv_lr.hip): fp32 activation in, in-kernel split, deep weight ring, ordered split-K
 # ---------------------------------------------------------------------------------------------------------------------------
 def _lr_plan(H, ci, co, cls, n, ks):
-    plan = H.conv_lr_plan(ci, co, cls, n)
+    plan = H.conv_lr_plan(ci, co, cls, n, force=True)         # (the kernel is opt-in: EG3D_CONV_LR)
     assert plan is not None
     return (plan[0], ks if ks else plan[1])
 

@@ -60,7 +60,7 @@ for res in ress:
             H.conv_igemm(x, wfs[k], ci, co, out, cls, in_scale=s, epi=L.EPI_FWD, out_scale=d, precision='f16x3', out_amax=amax, w_pieces=wps[k], **epi)
     t_old = timed(old)
     print(f'res {res:3d}: igemm split-K {ks_old:2d} + fill + finishing pass {t_old:7.1f} us', flush=True)
-    plan0 = H.conv_lr_plan(ci, co, cls, 1)
+    plan0 = H.conv_lr_plan(ci, co, cls, 1, force=True)
     for ks in sorted({1, 2, 4, 8, 16, plan0[1]}):
         if ks > 16:
             continue

@@ -11,7 +11,7 @@ wimg = H.split_weight(H.pack_weight_fwd(w), co, ci, 9)
 s = (1 + 0.5 * torch.randn(1, ci, generator=g)).to(dev)
 x = torch.randn(1, ci, res, res, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
 ax = H.absmax(x); cls = H.classes_corr(res, res, 3, 3, 1); out = H.empty_cl(1, co, res, res, dev)
-logw = H.conv_lr_plan(ci, co, cls, 1)[0]
+logw = H.conv_lr_plan(ci, co, cls, 1, force=True)[0]
 def t(ks, n=20):
     for _ in range(3): H.conv_lr(x, ax, wimg, out, cls, (logw, ks), in_scale=s, epi=L.EPI_STORE)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
