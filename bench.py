@@ -329,6 +329,28 @@ def side_configs(G, target, cam, dev, use_graph, steps=10):
             from inv3d_amd import hipops as H
             H.weights_changed()
     guarded('phase_b_c4', phase_b)
+
+    def c3(real_nets):
+        # BASELINE.json configs[2]: C2 + pose optimisation (free quaternion | the ResNet-34 pose estimator fine-tuned in the loop) + translation
+        # + a second, no-grad forward at the canonical camera + the depth-reprojection warping loss (w_projector.py:145-270, warping_loss.py:6-72)
+        def run():
+            kw = {}
+            if real_nets:
+                from inv3d_amd.loss_nets import VGG16LPIPS, VGG16Features
+                from inv3d_amd.pose_net import resnet34_pose
+                kw = dict(pose_net=resnet34_pose(4).to(dev), feature_net=VGG16LPIPS().to(dev), warp_feature_net=VGG16Features().to(dev))
+            pr = LatentProjector(G, target, num_steps=400, optimize_pose=True, use_warping_loss=True, cam_preheat_steps=2, seed=1, use_graph=use_graph, **kw)
+            ms = _time_steps(pr.step, steps, pr._graph_warmup + 4)          # the two camera-preheat steps run eagerly, the steady-state step is captured
+            if use_graph and pr._graph is None:
+                raise RuntimeError(f'capture failed: {pr.graph_capture_error}')
+            return dict(ms_per_step=round(ms, 3), steps_per_s=round(1e3 / ms, 2),
+                        gflop_algorithmic=917.4, tflops=round(917.4e9 / (ms * 1e-3) / 1e12, 1),
+                        note=('config C3: latent + pose (%s) + translation, canonical-view forward, warping loss; %s; three optimisers in the step'
+                              % (('ResNet-34 pose estimator fine-tuned in the loop', 'VGG16-LPIPS + VGG16 features[:15] architectures (random weights)') if real_nets
+                                 else ('free quaternion', 'stub feature nets'))))
+        return run
+    guarded('c3_pose_warp', c3(False))
+    guarded('c3_pose_warp_real_nets', c3(True))
     return out
 
 

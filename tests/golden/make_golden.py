@@ -909,6 +909,101 @@ def gen_projector_loop():
     save('projector_loop', 2e-5, **out)
 
 
+C3_FULL_STEPS, C3_FULL_PREHEAT = 2, 1
+
+
+def gen_c3_full():
+    """Config C3 at FULL size (BASELINE.json configs[2]): one camera-preheat step + one full step of the reference's optimisation-loop body
+    (w_projector.py:145-270, executed as is) on the ffhqrebalanced512-128-shaped generator built from the reference's own classes --
+    quaternion pose chain, 512^2 synthesis, the reference's calc_warping_loss (second, canonical-view forward; depth re-projection), LPIPS-
+    stub distance, noise regulariser, the three Adam optimisers.  Recorded: the loss terms of both steps, the gradients that reach the
+    translation, the pose parameters and (probes of) the latent, and where the optimisers put them."""
+    print('config C3 at full size (reference loop body, lifted) -- takes a few minutes')
+    from utils import camera_utils as ref_cam
+    from training.warping_loss import calc_warping_loss
+    from configs import global_config as gc, hyperparameters as hp
+    from oracle import inversion_oracle as IO
+    cfg = O.full_config()
+    P = O.synth_params(cfg, seed=0)
+    target = IO.pin_target(cfg, P)
+    fw = IO.stub_feature_weights()
+    loop = [n for n in _func(_parse('training/projectors/w_projector.py'), 'project').body if isinstance(n, ast.For)][-1]
+    node = _lifted_loop(loop, 'num_steps', "_trace.append((float(loss), float(dist), float(reg_loss), float(warp_loss), _psnr(pred_dict['image']))); "
+                        "_gtrace.append((translation_opt.grad.clone(), cam_predictor.base.grad.clone(), None if w_opt.grad is None else w_opt.grad.clone()))")
+    saved = (gc.use_quaternions, gc.use_6d, gc.visualize_opt_process, gc.visualize_warp_process, hp.cam_preheat_steps)
+    o_randn_like = torch.randn_like
+    mode = 'quat'
+    try:
+        gc.visualize_opt_process = gc.visualize_warp_process = False
+        hp.cam_preheat_steps = C3_FULL_PREHEAT
+        gc.use_quaternions, gc.use_6d = True, False
+        G = RefComposite(cfg, P).requires_grad_(False)
+        pin = IO.pin_projector_inputs(cfg, P, mode)
+        uniforms, wns, init_noise, w0, base = pin['uniforms'], pin['wns'], pin['init_noise'], pin['w0'], pin['pose_base']
+        cam_predictor = IO.StubPoseNet(base, seed=7)
+        Gs = _GSteps(G, uniforms, calls_per_step=2)
+        noise_bufs = {n: b for n, b in G.backbone.synthesis.named_buffers() if 'noise_const' in n}
+        noise_bufs2 = {f'{blk}.{n}': b for blk in ('block0', 'block1') for n, b in getattr(G, blk).named_buffers() if 'noise_const' in n}
+        with torch.no_grad():
+            for n_, b in noise_bufs.items():
+                b[:] = init_noise['backbone.synthesis.' + n_]
+                b.requires_grad = True
+            for n_, b in noise_bufs2.items():
+                b[:] = init_noise['superresolution.' + n_]
+                b.requires_grad = True
+        w_opt = w0.clone().requires_grad_(True)
+        translation_opt = torch.tensor([IO.PIN_TRANSLATION_START], requires_grad=True)
+        t255 = (((target + 1) / 2) * 255).unsqueeze(0)
+        if t255.shape[2] > 256:
+            t255 = torch.nn.functional.interpolate(t255, size=(256, 256), mode='area')
+        vgg16 = lambda img, resize_images=False, return_lpips=True: IO.stub_features(img, fw)      # noqa: E731
+        init_ext = torch.Tensor([1, 0, 0, 0, 0, -1, 0, 0, 0, 0, -1, 2.7, 0, 0, 0, 1]).reshape(-1, 4, 4)
+        intrinsic = torch.tensor([4.2647, 0, 0.5, 0, 4.2647, 0.5, 0, 0, 1]).unsqueeze(0)
+        ns = dict(torch=torch, F=torch.nn.functional, np=np, math=math, os=os, PIL=None, tqdm=lambda x: x, global_config=gc, hyperparameters=hp,
+                  compute_rotation_matrix_from_quaternion=ref_cam.compute_rotation_matrix_from_quaternion, rot6d_to_rotmat=ref_cam.rot6d_to_rotmat,
+                  euler2rot=ref_cam.euler2rot, calc_warping_loss=calc_warping_loss, ray_generator=RaySampler(), G=Gs, vgg16=vgg16,
+                  torch_vgg=_stub_torch_vgg(fw), layers='14', cam_predictor=cam_predictor, target_images=t255, target_images_contiguous=target.contiguous(),
+                  target_features=vgg16(t255), init_ext=init_ext, intrinsic=intrinsic, canonical_cam=torch.cat([init_ext.reshape(-1, 16), intrinsic], -1),
+                  radius=2.7, w_opt=w_opt, translation_opt=translation_opt, noise_bufs=noise_bufs, noise_bufs2=noise_bufs2,
+                  optimizer=torch.optim.Adam([w_opt] + list(noise_bufs.values()) + list(noise_bufs2.values()), betas=(0.9, 0.999), lr=hp.first_inv_lr),
+                  cam_optimizer=torch.optim.Adam(cam_predictor.parameters(), lr=hp.cam_lr_quat, betas=(0.9, 0.999)),
+                  translation_optimizer=torch.optim.Adam([translation_opt], lr=hp.translation_lr),
+                  num_steps=C3_FULL_STEPS, w_std=IO.PIN_W_STD, initial_learning_rate=0.01, lr_rampdown_length=0.25, initial_noise_factor=0.05,
+                  noise_ramp_length=0.75, lr_rampup_length=0.05, regularize_noise_weight=1e5, outdir=None, w_name='pin', _trace=[], _gtrace=[],
+                  _psnr=lambda im: float(O.psnr_01(im.detach(), target[None])))
+        q = list(wns[C3_FULL_PREHEAT:])
+        torch.randn_like = lambda x, **k: q.pop(0).reshape(x.shape)
+        try:
+            _exec_nodes([node], ns, 'w_projector.project loop, full size')
+        finally:
+            torch.randn_like = o_randn_like
+        trace = torch.tensor(ns['_trace'])
+        gtr = ns['_gtrace']
+        print('    reference trace (loss, dist, reg, warp, psnr):', trace.tolist())
+        # ---- the oracle must reproduce it ----------------------------------------------------------------------------------------
+        po = IO.ProjectorOracle(P, cfg, target[None], num_steps=C3_FULL_STEPS, optimize_pose=True, use_warping_loss=True, init_noise=init_noise,
+                                w_start=w0, cam_preheat_steps=C3_FULL_PREHEAT, pose_mode=mode, pose_net=IO.StubPoseNet(base, seed=7), w_std=IO.PIN_W_STD,
+                                translation_start=IO.PIN_TRANSLATION_START, cam_lr=hp.cam_lr_quat)
+        otrace = []
+        for k in range(C3_FULL_STEPS):
+            r = po.step(*uniforms[k], w_noise=wns[k])
+            otrace.append((float(r['loss']), float(r['dist']), float(r['reg']), float(r['warp']), float(O.psnr_01(r['image'], target[None]))))
+        otrace = torch.tensor(otrace)
+        e = [check(otrace[:, j], trace[:, j], 5e-5, f'C3 full: {nm}') for j, nm in enumerate(('loss', 'dist', 'reg', 'warp', 'psnr'))]
+        check(po.w_opt, w_opt, 1e-5, 'C3 full: w_opt')
+        check(po.translation_opt, translation_opt, 1e-5, 'C3 full: translation')
+        check(po.pose_net.base, cam_predictor.base, 1e-6, 'C3 full: pose base')
+        print(f'    trace errs {["%.1e" % x for x in e]}')
+        dw = gtr[-1][2].flatten()
+        probe = torch.Generator().manual_seed(77)
+        idx = torch.randint(0, dw.numel(), (256,), generator=probe)
+        save('c3_full', 5e-5, trace=trace, d_translation=torch.stack([g[0] for g in gtr]), d_pose_base=torch.stack([g[1] for g in gtr]),
+             dw_idx=idx, dw_val=dw[idx], dw_stat=np.array([dw.norm().item(), dw.abs().max().item()]), w_opt=w_opt, translation=translation_opt,
+             pose_base0=base, pose_base=cam_predictor.base, pose_A=cam_predictor.A, target_probe=target.flatten()[::4099].clone())
+    finally:
+        gc.use_quaternions, gc.use_6d, gc.visualize_opt_process, gc.visualize_warp_process, hp.cam_preheat_steps = saved
+
+
 TUNER_KEYS = ('backbone.synthesis.b8.conv0.weight', 'backbone.synthesis.b16.torgb.bias', 'backbone.synthesis.b32.conv1.noise_strength',
               'backbone.synthesis.b16.conv1.affine.weight', 'superresolution.block1.conv1.weight', 'superresolution.block0.torgb.weight',
               'decoder.net.0.weight', 'decoder.net.2.bias')
@@ -1169,7 +1264,7 @@ if __name__ == '__main__':
     only = sys.argv[1:]
     gens = dict(bias_act=gen_bias_act, upfirdn2d=gen_upfirdn2d, filtered_lrelu=gen_filtered_lrelu, conv=gen_conv2d_resample, renderer=gen_renderer,
                 graph_small=gen_graph_small, graph_full=gen_graph_full, loss=gen_loss_glue, projector_loop=gen_projector_loop, tuner_loop=gen_tuner_loop,
-                inference=gen_inference, pose_net=gen_pose_net, e4e=gen_e4e, sr_heads=gen_sr_heads)
+                inference=gen_inference, pose_net=gen_pose_net, e4e=gen_e4e, sr_heads=gen_sr_heads, c3_full=gen_c3_full)
     mpath = os.path.join(HERE, 'MANIFEST.json')
     if only and os.path.exists(mpath):
         MANIFEST.update(json.load(open(mpath)).get('fixtures', {}))

@@ -269,6 +269,52 @@ def test_projector_loop_vs_reference(golden, mode):
     _adam_close(list(hip.noise_bufs2.values())[-1].detach().cpu(), g('srbuf_last'), 1e-4, IO.PIN_PROJ_STEPS * 0.01)
 
 
+def test_config_c3_at_full_size(golden):
+    """BASELINE.json configs[2] at FULL size against the reference itself (tests/golden/make_golden.py::gen_c3_full: w_projector.project's
+    loop body on the 512^2 / 128^2 generator built from the reference's classes, with its calc_warping_loss): one camera-preheat step and one
+    full step -- loss, feature distance, regulariser, warping loss and PSNR of both, the gradients that reach the translation, the pose
+    parameters and the latent, and where the three Adam optimisers put them."""
+    from inv3d_amd import synthetic as S
+    from inv3d_amd.inversion import LatentProjector
+    d = golden('c3_full')
+    cfg = O.full_config()
+    P = O.synth_params(cfg, seed=0)
+    G = S.make_generator(device=DEV)
+    S.load_synthetic_weights(G, 0)
+    pin = IO.pin_projector_inputs(cfg, P, 'quat')
+    target = IO.pin_target(cfg, P)[None]           # the pin's target: one 512^2 render by the CPU oracle (~10 s)
+    assert float((target[0].flatten()[::4099] - torch.from_numpy(np.asarray(d['target_probe']))).abs().max()) <= 2e-5      # (CPU oracle: thread count changes summation order)
+    target = target.to(DEV)
+    net = IO.StubPoseNet(pin['pose_base'], seed=7).to(DEV)
+    hip = LatentProjector(G, target, num_steps=2, optimize_pose=True, use_warping_loss=True, init_noise=pin['init_noise'], start_w=pin['w0'],
+                          cam_preheat_steps=1, pose_mode='quat', pose_net=net, w_std=IO.PIN_W_STD, translation_start=IO.PIN_TRANSLATION_START, cam_lr=6e-7)
+    ref = torch.from_numpy(np.asarray(d['trace'])).double()
+    g = lambda k: torch.from_numpy(np.asarray(d[k]))           # noqa: E731
+    for k in range(2):
+        u1, u2 = pin['uniforms'][k]
+        h = hip.step(w_noise=pin['wns'][k], render_uniforms=(u1.to(DEV), u2.to(DEV)))
+        got = [float(h['loss']), float(h['dist']), float(h['reg']) / 1e5, float(h['warp']), _psnr(h['image'], target.cpu())]
+        for j, (nm, tol) in enumerate((('loss', 2e-4), ('dist', 2e-3), ('reg', 1e-4), ('warp', 5e-3))):
+            assert abs(got[j] - float(ref[k, j])) <= tol * max(1.0, abs(float(ref[k, j]))), (k, nm, got[j], float(ref[k, j]))
+        assert abs(got[4] - float(ref[k, 4])) <= 1e-3, f'step {k}: PSNR drift {abs(got[4] - float(ref[k, 4])):.2e} dB vs the reference'
+        # gradients of this step (they stay in .grad until the next step clears them)
+        dt, dp = hip.translation_opt.grad.detach().cpu(), net.base.grad.detach().cpu()
+        rt, rp = g('d_translation')[k], g('d_pose_base')[k]
+        assert float((dt - rt).abs().max()) <= 0.03 * float(rt.abs().max()) + 1e-7, (k, dt, rt)
+        assert float((dp - rp).abs().max()) <= 0.03 * float(rp.abs().max()) + 1e-7, (k, dp, rp)
+    dw = hip.w_opt.grad.detach().cpu().flatten()
+    ref_dw, stat = g('dw_val'), np.asarray(d['dw_stat'])
+    assert float((dw[g('dw_idx')] - ref_dw).abs().max()) <= 5e-3 * float(stat[1]), 'd latent (probes) vs the reference'
+    assert abs(float(dw.norm()) - float(stat[0])) <= 5e-3 * float(stat[0])
+    assert float((hip.w_opt.detach().cpu() - g('w_opt')).abs().max()) < 2e-4
+    mv_ref = g('translation') - torch.tensor([IO.PIN_TRANSLATION_START])
+    mv_hip = hip.translation_opt.detach().cpu() - torch.tensor([IO.PIN_TRANSLATION_START])
+    assert float((mv_hip - mv_ref).abs().max()) <= 0.05 * float(mv_ref.abs().max()), (mv_hip, mv_ref)
+    mv_ref = g('pose_base') - pin['pose_base'].reshape(1, -1)
+    mv_hip = net.base.detach().cpu() - pin['pose_base'].reshape(1, -1)
+    assert float((mv_hip - mv_ref).abs().max()) <= 0.05 * float(mv_ref.abs().max()) + 1e-9
+
+
 def test_tuner_loop_vs_reference(golden):
     """Config C4 against the reference itself: SingleIDCoach.train's loop (BaseCoach.calc_loss: MSE 512^2 + MSE 128^2 + LPIPS-stub at both
     sizes + depth TV; Adam 3e-4 over every generator weight; noise_mode='random') at 128^2 -> 512^2 rendering, and its LPIPS-threshold

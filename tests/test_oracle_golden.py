@@ -271,6 +271,25 @@ def test_projector_loop_pin(golden, mode):
     adam_close(po.bufs2[-1].detach(), t(d[f'{mode}_srbuf_last']), 1e-5, IO.PIN_PROJ_STEPS * 0.01)
 
 
+def test_c3_full_pin_first_step(golden):
+    """Config C3 at full size: the oracle's camera-preheat step against the reference's loop body on the full-size generator
+    (make_golden.py::gen_c3_full checks both recorded steps; here the first, to keep the CPU suite short)."""
+    from oracle import inversion_oracle as IO
+    d = golden('c3_full')
+    cfg = O.full_config()
+    P = O.synth_params(cfg, seed=0)
+    target = IO.pin_target(cfg, P)
+    close(target.flatten()[::4099], t(d['target_probe']), 1e-6)
+    pin = IO.pin_projector_inputs(cfg, P, 'quat')
+    po = IO.ProjectorOracle(P, cfg, target[None], num_steps=2, optimize_pose=True, use_warping_loss=True, init_noise=pin['init_noise'],
+                            w_start=pin['w0'], cam_preheat_steps=1, pose_mode='quat', pose_net=IO.StubPoseNet(pin['pose_base'], seed=7),
+                            w_std=IO.PIN_W_STD, translation_start=IO.PIN_TRANSLATION_START, cam_lr=6e-7)
+    r = po.step(*pin['uniforms'][0], w_noise=pin['wns'][0])
+    got = torch.tensor([float(r['loss']), float(r['dist']), float(r['reg']), float(r['warp']), float(O.psnr_01(r['image'], target[None]))])
+    close(got, t(d['trace'])[0].float(), 5e-5)
+    close(po.translation_opt.grad, t(d['d_translation'])[0], 1e-4)
+
+
 def test_tuner_loop_pin(golden):
     """PivotalTunerOracle vs the reference's own Phase-B loop (single_id_coach.py:64-77 with BaseCoach.calc_loss / forward and
     compute_tv_norm, lifted): per-step loss / MSE / LPIPS-stub, tuned weights, and the LPIPS-threshold exit before the update."""
