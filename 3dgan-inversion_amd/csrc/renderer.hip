@@ -301,6 +301,11 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
                 if (denom < eps) denom = 1.f;
                 depth_f = bb + (u - c_below) / denom * (ba - bb);
                 if (p.fine_depths) p.fine_depths[rr * Df + s] = depth_f;
+                if (p.dbg_inds) { int32_t* q = p.dbg_inds + (rr * Df + s) * 3; q[0] = inds; q[1] = below; q[2] = above; }
+                if (p.dbg_cdf && s == 0) {
+                    float cc = 0.f;
+                    for (int k = 1; k <= ns; ++k) { cc = cc + (L.t[k] + eps) / tot; p.dbg_cdf[rr * ns + k - 1] = cc; }
+                }
             }
         } else {
             if (has_f) depth_f = p.fine_depths[rr * Df + s];
@@ -364,9 +369,12 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
     const int nS = Dc + Df;
     int rank_c = s, rank_f = 0;
     if (has_c) {
+        // position in torch.sort(cat(coarse, fine), stable=True) (renderer.py:212-222).  The stratified depths t_i + u_i * delta are increasing
+        // in exact arithmetic only: u = 1 - 2^-24 next to u = 0 can round the wrong way round, so the coarse list is ranked too, not assumed sorted
         int cnt = 0;
+        for (int i = 0; i < Dc; ++i) { float o = L.dc[i]; cnt += (o < depth_c || (o == depth_c && i < s)) ? 1 : 0; }
         for (int j = 0; j < Df; ++j) cnt += L.df[j] < depth_c ? 1 : 0;
-        rank_c = s + cnt;
+        rank_c = cnt;
         L.sd[rank_c] = depth_c; L.ss[rank_c] = sig_c;
     }
     if (has_f) {
@@ -375,6 +383,10 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
         for (int j = 0; j < Df; ++j) { float o = L.df[j]; cnt += (o < depth_f || (o == depth_f && j < s)) ? 1 : 0; }
         rank_f = cnt;
         L.sd[rank_f] = depth_f; L.ss[rank_f] = sig_f;
+    }
+    if (p.dbg_ranks) {
+        if (has_c) p.dbg_ranks[rr * nS + s] = rank_c;
+        if (has_f) p.dbg_ranks[rr * nS + Dc + s] = rank_f;
     }
     __syncthreads();
 

@@ -94,7 +94,7 @@ class RenderParams(C.Structure):
                 ('w0', C.c_void_p), ('b0', C.c_void_p), ('w1', C.c_void_p), ('b1', C.c_void_p), ('Hdim', C.c_int32),
                 ('Cout', C.c_int32), ('rgb', C.c_void_p), ('depth', C.c_void_p), ('wsum', C.c_void_p),
                 ('depth_minmax', C.c_void_p), ('fine_depths', C.c_void_p), ('save_sigma', C.c_void_p), ('save_rgb', C.c_void_p),
-                ('ray_tile_width', C.c_int32), ('pos_rows', C.c_void_p), ('feat_rows', C.c_void_p)]
+                ('ray_tile_width', C.c_int32), ('pos_rows', C.c_void_p), ('feat_rows', C.c_void_p), ('dbg_inds', C.c_void_p), ('dbg_ranks', C.c_void_p), ('dbg_cdf', C.c_void_p)]
 
 
 class RenderBwdParams(C.Structure):

@@ -852,6 +852,9 @@ class RayGenFn(torch.autograd.Function):
         return d_c2w, d_K, None
 
 
+SAMPLER_DEBUG = None          # a dict while a parity test wants the sampler's indices (tests/test_gpu_ops.py::test_sampler_indices_exact)
+
+
 class RenderFn(torch.autograd.Function):
     """ImportanceRenderer.forward fused.  planes: CL [N,96,Hp,Wp]; returns rgb [N,R,32], depth [N,R,1], wsum [N,R,1]."""
 
@@ -897,8 +900,13 @@ class RenderFn(torch.autograd.Function):
         else:
             minmax = _minmax_init(dev) + 0.0            # device-side copy by an elementwise kernel: no host transfer (graph-capturable) and no
                                                         # memcpy node (those split a captured graph into separately submitted segments)
+        dbg = None
+        if SAMPLER_DEBUG is not None and Df > 0:         # parity tests: the integer side of the sampler (eg3d_render_params::dbg_*)
+            dbg = (torch.full((N * R, Df, 3), -1, dtype=torch.int32, device=dev), torch.full((N * R, Dc + Df), -1, dtype=torch.int32, device=dev),
+                   torch.zeros((N * R, max(Dc - 3, 1)), device=dev))
+            SAMPLER_DEBUG.update(inds=dbg[0], ranks=dbg[1], cdf=dbg[2], fine=fine, rows=rows if pos is not None else save, pos=pos)
         p = H.make_render_params(planes, origins, dirs, u1, u2, opts, w0g, b0g, w1t, b1g, rgb, depth, wsum, minmax, fine, rl, rows if pos is not None else save,
-                                 pos_rows=pos, feat_rows=feat)
+                                 pos_rows=pos, feat_rows=feat, dbg=dbg)
         with H._Span('render_fwd'):
             H.render_fwd(p)
             H.render_finalize(depth, minmax)

@@ -1181,7 +1181,7 @@ SCATTER_F16 = os.environ.get('EG3D_SCATTER_F16', '0') != '0'     # tri-plane gra
 
 
 def make_render_params(planes, origins, dirs, u1, u2, opts, w0, b0, w1t, b1, rgb, depth, wsum, minmax, fine, ray_limits=None, save=None, ray_tile_width=None, pos_rows=None,
-                       feat_rows=None):
+                       feat_rows=None, dbg=None):
     """planes: channels_last [N, 3*C, Hp, Wp]; decoder weights with gains folded (w1t transposed [H, 1+Cout])."""
     assert is_cl(planes)
     p = L.RenderParams()
@@ -1215,6 +1215,9 @@ def make_render_params(planes, origins, dirs, u1, u2, opts, w0, b0, w1t, b1, rgb
     p.ray_tile_width = int(ray_tile_width)
     p.pos_rows = pos_rows.data_ptr() if pos_rows is not None else None       # workspace [2, N*R, D, 4]: selects the pipelined forward
     p.feat_rows = feat_rows.data_ptr() if feat_rows is not None else None    # [S, 32]: gather as its own pass, rows re-read by the decoder kernels
+    if dbg is not None:                  # (int32 [N*R, Df, 3], int32 [N*R, Dc + Df]): the sampler's integer side (include/eg3d_hip.h)
+        p.dbg_inds, p.dbg_ranks = dbg[0].data_ptr(), dbg[1].data_ptr()
+        p.dbg_cdf = dbg[2].data_ptr() if len(dbg) > 2 and dbg[2] is not None else None
     return p
 
 

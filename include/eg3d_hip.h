@@ -662,6 +662,12 @@ typedef struct eg3d_render_params {
                                 * ~140 registers and wait on the scattered texel loads most of the time) and the decoder kernels -- forward
                                 * and, given the same buffer in eg3d_render_bwd_params.fwd, backward -- read the rows back coalesced.
                                 * Same values either way.  null = gather inside the decoder kernels. */
+    int32_t* dbg_inds;         /* optional [N*R, Df, 3] (pipelined and fused forward): per fine sample the bin index torch.searchsorted(cdf, u,
+                                * right=True) would return, and the `below` / `above` indices after the clamps (renderer.py:292-295) -- the
+                                * integer side of sample_pdf, for index-exact parity tests.  null = not written. */
+    int32_t* dbg_ranks;        /* optional [N*R, Dc + Df]: position of coarse sample s (entry s) and fine sample s (entry Dc + s) in the depth-sorted
+                                * list of unify_samples (the inverse of the permutation torch.sort(stable) returns, renderer.py:212-222).  */
+    float* dbg_cdf;            /* optional [N*R, ns = Dc - 3]: the ray's CDF edges cdf[1 .. ns] (cdf[0] = 0) exactly as the bin search accumulates them  */
 } eg3d_render_params;
 
 int eg3d_render_fwd(const eg3d_render_params* p, void* stream);

@@ -716,8 +716,8 @@ def sample_stratified(n, m, ray_start, ray_end, depth_resolution, disparity, u1:
     return t + u1 * ((ray_end - ray_start) / (d - 1))
 
 
-def sample_pdf(bins, weights, n_importance, u: Tensor, eps=1e-5):
-    """ImportanceRenderer.sample_pdf, renderer.py:269-308 (u injected; det=True is u=linspace(0,1,N))."""
+def sample_pdf(bins, weights, n_importance, u: Tensor, eps=1e-5, debug: Optional[dict] = None):
+    """ImportanceRenderer.sample_pdf, renderer.py:269-308 (u injected; det=True is u=linspace(0,1,N)).  debug: receives cdf, inds, below, above."""
     n_rays, ns = weights.shape
     weights = weights + eps
     pdf = weights / torch.sum(weights, -1, keepdim=True)
@@ -727,6 +727,8 @@ def sample_pdf(bins, weights, n_importance, u: Tensor, eps=1e-5):
     inds = torch.searchsorted(cdf, u, right=True)
     below = torch.clamp_min(inds - 1, 0)
     above = torch.clamp_max(inds, ns)
+    if debug is not None:
+        debug.update(cdf=cdf, inds=inds, below=below, above=above)
     idx = torch.stack([below, above], -1).view(n_rays, 2 * n_importance)
     cdf_g = torch.gather(cdf, 1, idx).view(n_rays, n_importance, 2)
     bins_g = torch.gather(bins, 1, idx).view(n_rays, n_importance, 2)
@@ -735,7 +737,7 @@ def sample_pdf(bins, weights, n_importance, u: Tensor, eps=1e-5):
     return bins_g[..., 0] + (u - cdf_g[..., 0]) / denom * (bins_g[..., 1] - bins_g[..., 0])
 
 
-def sample_importance(z_vals, weights, n_importance, u2: Tensor):
+def sample_importance(z_vals, weights, n_importance, u2: Tensor, debug: Optional[dict] = None):
     """ImportanceRenderer.sample_importance, renderer.py:249-267 (runs under no_grad there)."""
     with torch.no_grad():
         b, r, s, _ = z_vals.shape
@@ -745,7 +747,7 @@ def sample_importance(z_vals, weights, n_importance, u2: Tensor):
         w = F.avg_pool1d(w, 2, 1).squeeze(1)
         w = w + 0.01
         z_mid = 0.5 * (z[:, :-1] + z[:, 1:])
-        return sample_pdf(z_mid, w[:, 1:-1], n_importance, u2).detach().reshape(b, r, n_importance, 1)
+        return sample_pdf(z_mid, w[:, 1:-1], n_importance, u2, debug=debug).detach().reshape(b, r, n_importance, 1)
 
 
 def unify_samples(d1, c1, s1, d2, c2, s2):

@@ -684,6 +684,100 @@ def test_render_vs_oracle(variant):
     close(gg[0], gr[0], 1e-4, f'{variant} d planes'); close_most(gg[1], gr[1], 1e-4, f'{variant} d origins'); close_most(gg[2], gr[2], 1e-4, f'{variant} d dirs')
 
 
+@pytest.mark.parametrize('variant', ['random', 'det', 'ties', 'no_grad_fused'])
+def test_sampler_indices_exact(variant):
+    """The integer side of the sampler at 110 592 rays x (48 + 48) samples (renderer.py:281-307 sample_pdf: searchsorted(right=True), the
+    below / above clamps; :212-222 unify_samples: the stable sort's permutation), compared as INTEGERS:
+      (a) against torch.searchsorted on the kernel's own CDF edges and against torch.sort(stable=True) on the kernel's own depths: bit-exact,
+          every ray -- the index logic itself;
+      (b) against the CPU oracle run from the kernel's coarse (depth, sigma): mismatches are COUNTED; each must be a sample whose uniform
+          lies within float rounding of a CDF edge (the oracle's CDF comes out of torch's vectorised sum / cumsum, the kernel's out of a
+          sequential scan), and there must be few.
+    Variants: random uniforms; `det=True` of the reference (u = linspace(0, 1, 48), the end points included); tied depths (duplicated
+    importance uniforms -> equal fine depths; jitter 0 next to jitter 1 - 2^-24 -> coarse neighbours that round together)."""
+    from inv3d_amd.training.volumetric_rendering.renderer import ImportanceRenderer
+    from inv3d_amd import fused
+    cfg = O.full_config()
+    opts = dict(cfg.rendering)
+    n, res = 3, 192                                   # 110 592 rays
+    P = O.synth_params(O.small_config(), seed=7)
+    g = torch.Generator().manual_seed(23)
+    planes = torch.randn(n, 3, 32, 64, 64, generator=g) * 0.8
+    cam = O.synth_cameras(n, seed=11)
+    o, dr = O.ray_sampler(cam[:, :16].reshape(n, 4, 4), cam[:, 16:].reshape(n, 3, 3), res)
+    dc, df = opts['depth_resolution'], opts['depth_resolution_importance']
+    R_ = res * res
+    u1 = torch.rand(n, R_, dc, 1, generator=g)
+    u2 = torch.rand(n * R_, df, generator=g)
+    if variant == 'det':
+        u2 = torch.linspace(0, 1, df).expand(n * R_, df).contiguous()                         # renderer.py:286-288
+    if variant == 'ties':
+        u2[:, 1::4] = u2[:, 0::4]                                                               # equal fine depths within a ray
+        u2[:, 7] = u2[:, 40]
+        u1[:, :, 10::8] = 0.0                                                                   # sample i+1 at the start of its stratum ...
+        u1[:, :, 9::8] = 1.0 - 2.0 ** -24                                                        # ... sample i at the very end of its own
+    dbg = fused.SAMPLER_DEBUG = {}
+    try:
+        Rm = ImportanceRenderer()
+        Rm.set_uniforms(u1.to(DEV), u2.to(DEV))
+        pg = planes.to(DEV).requires_grad_(variant != 'no_grad_fused')
+        with torch.set_grad_enabled(variant != 'no_grad_fused'), (torch.no_grad() if variant == 'no_grad_fused' else torch.enable_grad()):
+            if variant == 'no_grad_fused':
+                old, fused.RENDER_PIPELINE_NOGRAD = fused.RENDER_PIPELINE_NOGRAD, False            # the one-kernel form (render_kernel<0>)
+            try:
+                Rm(pg, _decoder(P), o.to(DEV), dr.to(DEV), opts)
+            finally:
+                if variant == 'no_grad_fused':
+                    fused.RENDER_PIPELINE_NOGRAD = old
+        torch.cuda.synchronize()
+    finally:
+        fused.SAMPLER_DEBUG = None
+    inds, ranks, cdf = dbg['inds'].cpu().long(), dbg['ranks'].cpu().long(), dbg['cdf'].cpu()
+    fine = dbg['fine'].reshape(n * R_, df).cpu()
+    ns = dc - 3
+    assert int((inds < 0).sum()) == 0 and int((ranks < 0).sum()) == 0, 'every sample must have been written'
+    # ---- (a) index logic on the kernel's own numbers: exact --------------------------------------------------------------------------
+    edges = torch.cat([torch.zeros(n * R_, 1), cdf[:, :ns]], 1)
+    want = torch.searchsorted(edges, u2.contiguous(), right=True)
+    assert torch.equal(inds[..., 0], want), f'searchsorted(right=True): {int((inds[..., 0] != want).sum())} of {want.numel()} indices differ'
+    assert torch.equal(inds[..., 1], torch.clamp_min(want - 1, 0)) and torch.equal(inds[..., 2], torch.clamp_max(want, ns))
+    depths_c = O.sample_stratified(n, R_, opts['ray_start'], opts['ray_end'], dc, opts['disparity_space_sampling'], u1).reshape(n * R_, dc)
+    if dbg.get('pos') is not None:                    # pipelined forward: the kernel's own coarse depths (4th component of the position rows)
+        dcg = dbg['pos'][0].reshape(n * R_, -1, 4)[:, :dc, 3].cpu()
+        assert float((dcg - depths_c).abs().max()) <= 2e-6
+        depths_c = dcg
+    allz = torch.cat([depths_c, fine], 1)
+    _, perm = torch.sort(allz, dim=1, stable=True)
+    inv = torch.empty_like(perm)
+    inv.scatter_(1, perm, torch.arange(dc + df).expand_as(perm))
+    assert torch.equal(ranks, inv), f'unify_samples permutation: {int((ranks != inv).any(1).sum())} of {n * R_} rays differ'
+    if variant == 'ties':
+        tied = (allz.sort(1).values.diff(dim=1) == 0).any(1)
+        assert int(tied.sum()) >= 0.9 * n * R_, 'the tie variant must actually tie'
+    # ---- (b) against the oracle from the kernel's coarse pass -------------------------------------------------------------------------
+    if dbg.get('rows') is None:
+        return
+    sig = dbg['rows'][0].reshape(n * R_, 2, max(dc, df))[:, 0, :dc].cpu()
+    od = {}
+    zc = depths_c.reshape(n, R_, dc, 1)
+    _, _, w = O.ray_march(torch.zeros(n, R_, dc, 1), sig.reshape(n, R_, dc, 1), zc, opts)
+    O.sample_importance(zc, w, df, u2, debug=od)
+    bad = od['inds'] != inds[..., 0]
+    nbad = int(bad.sum())
+    # (det=True puts its last uniform exactly ON the last edge, u = 1.0 = cdf[ns] up to rounding: which side it falls on is the rounding of a
+    #  48-term sum -- a third of the rays differ there, and only there)
+    at_end = (u2 >= 1.0).expand_as(bad)
+    assert int((bad & ~at_end).sum()) <= 2e-4 * bad.numel(), f'{int((bad & ~at_end).sum())} of {bad.numel()} bin indices differ from the oracle'
+    if nbad:
+        # every mismatch: u within rounding of the edge the two sides disagree about
+        r_i, s_i = bad.nonzero(as_tuple=True)
+        lo = torch.minimum(od['inds'][r_i, s_i], inds[r_i, s_i, 0])
+        e_o, e_k = od['cdf'][r_i, lo.clamp(max=ns)], edges[r_i, lo.clamp(max=ns)]
+        assert float((u2[r_i, s_i] - e_o).abs().max()) <= 4e-6 and float((e_o - e_k).abs().max()) <= 4e-6, 'an index mismatch that rounding of the CDF does not explain'
+        assert int((od['inds'][r_i, s_i] - inds[r_i, s_i, 0]).abs().max()) <= 2
+    print(f'sampler indices [{variant}]: {bad.numel()} bin indices, {nbad} differ from the CPU oracle (rounding of the CDF), permutation of {n * R_} rays exact')
+
+
 def test_render_zero_density_ray():
     """A ray with no density anywhere: depth must take the NaN -> +inf -> clamp-to-global-max path (ray_marcher.py:49-50)."""
     from inv3d_amd import hipops as H
