@@ -243,8 +243,13 @@ __device__ __forceinline__ bool adam_locate(const eg3d_adam_list& A, int blk, in
     return false;
 }
 
+__global__ void early_stop_flag_kernel(const float* __restrict__ value, float thr, float* __restrict__ done) {
+    if (*value <= thr) *done = 1.0f;
+}
+
 __global__ void __launch_bounds__(NT) adam_step_kernel(const eg3d_adam_list A, float* __restrict__ ws) {
     __shared__ float red[32];
+    if (A.skip != nullptr && *A.skip != 0.f) return;          // (uniform over the grid: nothing is touched, the step count stays)
     const float t = *A.step + 1.0f;
     int item;
     int64_t start;
@@ -283,6 +288,7 @@ __global__ void __launch_bounds__(NT) adam_step_kernel(const eg3d_adam_list A, f
 __global__ void __launch_bounds__(NT) adam_apply_norm_kernel(const eg3d_adam_list A, const float* __restrict__ ws) {
     int item;
     int64_t start;
+    if (A.skip != nullptr && *A.skip != 0.f) return;
     if (!adam_locate(A, blockIdx.x, item, start)) return;
     const eg3d_adam_item& it = A.items[item];
     if (!it.normalize) return;
@@ -368,6 +374,13 @@ extern "C" int eg3d_adam_step(const eg3d_adam_list* list, float* workspace, void
     }
     hipLaunchKernelGGL(adam_step_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, *list, workspace);
     if (norm) hipLaunchKernelGGL(adam_apply_norm_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, *list, workspace);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_early_stop_flag(const float* value, float threshold, float* done, void* stream) {
+    if (!value || !done) return EG3D_ERR_INVALID;
+    hipLaunchKernelGGL(early_stop_flag_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, value, threshold, done);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

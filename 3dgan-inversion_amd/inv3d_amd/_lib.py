@@ -143,7 +143,7 @@ class AdamItem(C.Structure):
 
 class AdamList(C.Structure):
     _fields_ = [('n', C.c_int32), ('bump_step', C.c_int32), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float), ('pad_', C.c_float),
-                ('lr', C.c_void_p), ('step', C.c_void_p), ('items', AdamItem * ADAM_ITEMS_MAX)]
+                ('lr', C.c_void_p), ('step', C.c_void_p), ('items', AdamItem * ADAM_ITEMS_MAX), ('skip', C.c_void_p)]
 
 
 UNIT_LEVELS_MAX = 8
@@ -257,6 +257,7 @@ _SIGS = {
     'eg3d_torgb_small_bwd_supported': (C.c_int, [C.POINTER(TorgbSmallBwdParams)]),
     'eg3d_torgb_small_bwd': (C.c_int, [C.POINTER(TorgbSmallBwdParams), C.c_void_p]),
     'eg3d_adam_step': (C.c_int, [C.POINTER(AdamList), C.c_void_p, C.c_void_p]),
+    'eg3d_early_stop_flag': (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     'eg3d_unit_normalize_levels': (C.c_int, [C.POINTER(UnitLevels), C.c_int, C.c_void_p]),
     'eg3d_unit_normalize_bwd': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int64, C.c_int, C.c_void_p]),
     'eg3d_pack_conv_weight': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),

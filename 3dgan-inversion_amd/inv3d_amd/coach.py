@@ -45,8 +45,9 @@ class InversionCoach:
                  w_avg_samples: int = 10000, w_stats: Optional[Tuple[torch.Tensor, float]] = None,
                  start_w_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, sr_fp16: bool = True):
         """Hyper-parameter names and defaults follow configs/hyperparameters.py.  `early_stop_interval` = how often Phase B reads the
-        perceptual loss back to the host for the early-stop test (1 = every step like the reference; larger values keep the host from
-        stalling the GPU queue every step).  Phase A starts where the reference starts (w_projector.py:88-97,100,118): at the mean latent
+        early-stop state back to the host (1 = every step like the reference).  With the library's Adam the TEST itself runs on the device
+        in every step whatever the interval (PivotalTuner.device_stop): the interval then only bounds how many masked no-op steps are
+        issued after the stop, not when tuning stops.  Phase A starts where the reference starts (w_projector.py:88-97,100,118): at the mean latent
         of `w_avg_samples` mapped z (plus `start_w_fn(target_255_256)`, the e4e encoder's offset, when given) with the latent-noise scale
         tied to their standard deviation; `w_stats=(w_avg, w_std)` overrides the estimate, `w_avg_samples=0` starts at w = 0, std 1."""
         self.G = G
@@ -109,12 +110,23 @@ class InversionCoach:
         tuner = PivotalTuner(G, target, w_pivot, cam_pivot, lr=self.pti_lr, lpips_threshold=self.thr, feature_net=self.feature_net,
                              synth_kwargs=self.synth_kwargs, sr_fp16=self.sr_fp16, use_graph=self.use_graph)
         steps_b = 0
-        for i in range(self.max_pti_steps):
-            check = (i % self.interval) == self.interval - 1
-            res = tuner.step(early_stop=check)
-            if check and res.get('done'):         # the reference leaves before the update (single_id_coach.py:68-71)
-                break
-            steps_b += 1
+        if tuner.hip_adam and tuner.device_stop:
+            # the criterion is evaluated ON THE DEVICE in every step (a sticky flag that masks the update from the step at which it is met:
+            # the reference's every-step `break` before the update, single_id_coach.py:68-71) -- every step can be a graph replay, and the
+            # host only polls the flag (every `early_stop_interval` steps) to stop issuing work.  The number of updates made is the
+            # optimiser's own device-side step count.
+            for i in range(self.max_pti_steps):
+                tuner.step()
+                if (i % self.interval) == self.interval - 1 and tuner.stopped():
+                    break
+            steps_b = int(round(float(tuner.optimizer.step_t.item())))
+        else:
+            for i in range(self.max_pti_steps):
+                check = (i % self.interval) == self.interval - 1
+                res = tuner.step(early_stop=check)
+                if check and res.get('done'):         # the reference leaves before the update (single_id_coach.py:68-71)
+                    break
+                steps_b += 1
         # how the two phases were actually issued (a refused capture falls back to eager launches with a warning: callers that quote timings check this)
         self.last_launch_modes = dict(phase_a='graph' if getattr(proj, '_graph', None) is not None else 'eager',
                                       phase_b='graph' if getattr(tuner, '_graph', None) is not None else 'eager')

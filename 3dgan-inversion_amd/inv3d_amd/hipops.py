@@ -1435,9 +1435,9 @@ class HipAdam:
                 else:
                     p.grad.zero_()
 
-    def step(self, extra_grads=None, normalize=None):
+    def step(self, extra_grads=None, normalize=None, skip=None):
         """extra_grads: {param: tensor} added to the gradient; normalize: {param: number of equal slices renormalised separately} (a noise
-        map [N,1,r,r] of N independent images: N)."""
+        map [N,1,r,r] of N independent images: N); skip: device scalar, != 0 -> this step changes nothing (eg3d_adam_list::skip)."""
         g = self.param_groups[0]
         lr = g['lr']
         if torch.is_tensor(lr):
@@ -1472,11 +1472,17 @@ class HipAdam:
         for lo in range(0, len(items), L.ADAM_ITEMS_MAX):
             bank = items[lo:lo + L.ADAM_ITEMS_MAX]
             a = L.AdamList(n=len(bank), bump_step=int(lo + L.ADAM_ITEMS_MAX >= len(items)), beta1=g['betas'][0], beta2=g['betas'][1], eps=g['eps'],
-                           lr=self._lr_t.data_ptr(), step=self.step_t.data_ptr())
+                           lr=self._lr_t.data_ptr(), step=self.step_t.data_ptr(), skip=skip.data_ptr() if skip is not None else None)
             for j, it in enumerate(bank):
                 a.items[j] = L.AdamItem(*it)
             ws = zeros((2 * len(bank) + 1,), dev)
             L.check(L.lib().eg3d_adam_step(C.byref(a), L.ptr(ws), L.stream_ptr()), 'adam_step')
+
+
+def early_stop_flag(value, threshold, done):
+    """done <- 1 where value <= threshold (sticky device flag; eg3d_early_stop_flag)."""
+    L.check(L.lib().eg3d_early_stop_flag(L.ptr(value), float(threshold), L.ptr(done), L.stream_ptr()), 'early_stop_flag')
+    return done
 
 
 def noise_normalize_(bufs):

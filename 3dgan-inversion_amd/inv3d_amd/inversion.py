@@ -591,11 +591,14 @@ class PivotalTuner:
 
     def __init__(self, G, target: torch.Tensor, w_pivot: torch.Tensor, cam: torch.Tensor, *, lr=3e-4, l2_lambda=1.0, lpips_lambda=1.0,
                  lpips_threshold=0.06, feature_net: Optional[Callable] = None, synth_kwargs: Optional[dict] = None, sr_fp16: bool = True,
-                 use_graph: bool = False, graph_warmup: int = 2):
+                 use_graph: bool = False, graph_warmup: int = 2, device_stop: bool = True):
         """`use_graph`: after `graph_warmup` eager steps the whole step (forward, objective, backward into all weights, fused Adam: ~370
         launches) is captured into one HIP graph and replayed; steps that read the early-stop criterion (`step(early_stop=True)`, a host
         sync before the update, single_id_coach.py:68-71) run eagerly in between, so the reference's leave-before-update order is kept.
         The tensors in `last` are then static buffers that the next replay overwrites.
+        `device_stop` (with the library's Adam): the criterion is ALSO evaluated on the device in every step, captured or not -- a sticky flag
+        that masks the update from the step at which it is first met (`stopped()` reads it): the reference's every-step check without leaving
+        the replayed graph.
         `sr_fp16` (default, as the reference: BaseCoach.forward calls G.synthesis without force_fp32, base_coach.py:162-164): the
         super-resolution head's convolutions -- forward, data and weight gradients -- run with one product of fp16-rounded operands instead
         of the three-product fp32-equivalent split; pass False (or force_fp32=True in synth_kwargs) for fp32-equivalent tuning."""
@@ -605,6 +608,7 @@ class PivotalTuner:
         self.target_128 = _area_resize(target, G.neural_rendering_resolution)
         self.w_pivot, self.cam = w_pivot.detach(), cam.detach()
         self.l2_lambda, self.lpips_lambda, self.thr = l2_lambda, lpips_lambda, lpips_threshold
+        self.device_stop = bool(device_stop)
         self.feature_net = feature_net if feature_net is not None else StubFeatureNet().to(target.device)
         with torch.no_grad():
             self.tf = self.feature_net(target)
@@ -613,10 +617,20 @@ class PivotalTuner:
             self.target4 = _pad_cl4(target)
             self.target4_128 = _pad_cl4(self.target_128)
         self.use_graph, self._graph, self._graph_warmup, self.graph_capture_error, self._eager_steps = bool(use_graph), None, int(graph_warmup), None, 0
-        # one multi-tensor launch over the 30.7 M parameters; capturable: the step counters live on the device
-        self.optimizer = torch.optim.Adam(G.parameters(), lr=lr, fused=True, capturable=self.use_graph)
-        # the fused kernel updates parameters without bumping their version counters, which the packed-weight caches key on
-        self.optimizer.register_step_post_hook(lambda *_: hipops.weights_changed())
+        # Adam over the 30.7 M parameters.  The library's own kernel (eg3d_adam_step, hipops.HipAdam; EG3D_HIP_ADAM=0 -> torch's fused
+        # multi-tensor Adam): device-side learning rate / step count AND a device-side skip flag -- the early stop of the reference's loop
+        # (`if loss_lpips <= threshold: break` BEFORE the update, single_id_coach.py:68-71) then needs no host sync: the captured step
+        # compares every step, sets a sticky `done` flag on the device and the update is masked from that step on (`device_stop`)
+        params = [p for p in G.parameters()]
+        self.hip_adam = (os.environ.get('EG3D_HIP_ADAM', '1') != '0' and target.is_cuda
+                         and all(p.dtype == torch.float32 and p.is_contiguous() for p in params))
+        self.done_t = torch.zeros((), device=target.device)
+        if self.hip_adam:
+            self.optimizer = hipops.HipAdam(params, lr=lr)
+        else:
+            self.optimizer = torch.optim.Adam(params, lr=lr, fused=True, capturable=self.use_graph)
+            # the fused kernel updates parameters without bumping their version counters, which the packed-weight caches key on
+            self.optimizer.register_step_post_hook(lambda *_: hipops.weights_changed())
         self.synth_kwargs = dict(synth_kwargs or {})
         self.synth_kwargs.setdefault('sr_fp16', bool(sr_fp16))
         self.last = {}
@@ -712,10 +726,23 @@ class PivotalTuner:
         self.optimizer.zero_grad(set_to_none=True)
         if early_stop and bool(lp.item() <= self.thr):            # the reference's per-step host sync; it leaves BEFORE the update
             self.last['done'] = True                              # (single_id_coach.py:68-71)
+            self.done_t.fill_(1.0)
             return self.last
+        if self.hip_adam and self.device_stop:
+            # the same decision on the device, every step, replayable: done |= (lpips <= threshold); the update below is skipped once set
+            hipops.early_stop_flag(lp.detach().reshape(()), self.thr, self.done_t)
+            self.last['done_flag'] = self.done_t
         loss.backward()
-        self.optimizer.step()
+        if self.hip_adam:
+            self.optimizer.step(skip=self.done_t if self.device_stop else None)
+        else:
+            self.optimizer.step()
         return self.last
+
+    def stopped(self) -> bool:
+        """Host read of the device-side stop flag (one synchronising copy of 4 bytes): call it every step or every k steps -- the weights are
+        those of the step at which the criterion was first met either way (the update has been masked since)."""
+        return bool(self.done_t.item() != 0)
 
 
 def _pad_cl4(img: torch.Tensor) -> torch.Tensor:

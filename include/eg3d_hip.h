@@ -587,6 +587,7 @@ int eg3d_torgb_small_bwd(const eg3d_torgb_small_bwd_params* p, void* stream);
  * made as a float and is incremented by the launch when bump_step != 0 (several launches of one optimiser step: set it on the last).
  * normalize != 0: the leaf is then renormalised in place, p <- (p - mean(p)) * rsqrt(var(p)) (w_projector.py:264-270), by a second launch.
  * workspace: 2*n + 1 ZEROED floats (moments of the flagged leaves, retirement counter; left zeroed-counter on exit). */
+/* eg3d_early_stop_flag: done = max(done, value <= threshold ? 1 : 0) on the device (sticky; `value` e.g. the LPIPS term of the step). */
 #define EG3D_ADAM_ITEMS_MAX 32
 typedef struct {
     float* p;
@@ -603,8 +604,12 @@ typedef struct {
     const float* lr;
     float* step;
     eg3d_adam_item items[EG3D_ADAM_ITEMS_MAX];
+    const float* skip;         /* optional device scalar: != 0 -> the launch changes nothing (no update, no step count): the early stop of the
+                                * pivotal-tuning loop, which leaves BEFORE the update (training/coaches/single_id_coach.py:68-71), as a device-side
+                                * flag, so that a captured step can be replayed while the criterion is checked every step */
 } eg3d_adam_list;
 int eg3d_adam_step(const eg3d_adam_list* list, float* workspace, void* stream);
+int eg3d_early_stop_flag(const float* value, float threshold, float* done, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Volume renderer -- replaces RaySampler.forward (training/volumetric_rendering/ray_sampler.py:24-73) and

@@ -604,6 +604,54 @@ def test_pivotal_tuning_step_replayed_from_a_hip_graph():
     assert float((ie - ig).abs().max()) <= 2e-2 * float(ie.abs().max())
 
 
+def test_device_side_early_stop_equals_the_every_step_host_check():
+    """The reference compares LPIPS with the threshold in EVERY step and leaves before the update (single_id_coach.py:64-77).  Reference
+    order, eagerly: `step(early_stop=True)` each step (a host sync).  Replayed: the captured step sets a sticky device flag when the criterion
+    is met and the library's Adam skips the update from then on -- the host may poll the flag late (here every 7 steps).  Both must stop
+    after the same number of updates with the same weights."""
+    from inv3d_amd import synthetic as S
+    from inv3d_amd.inversion import PivotalTuner
+    cfg = O.small_config()
+
+    def setup(use_graph, thr):
+        G = S.make_generator(w_dim=32, z_dim=32, plane_res=32, channel_base=256, channel_max=16, nrr=16, sr_in_res=16, sr_widths=(16, 8),
+                             rendering_kwargs=cfg.rendering, device=DEV)
+        S.load_synthetic_weights(G, 0)
+        cam = O.synth_cameras(1, seed=2).float().to(DEV)
+        u1, u2 = O.make_uniforms(cfg, 1, seed=4)
+        kw = dict(noise_mode='const', render_uniforms=(u1.float().to(DEV), u2.float().to(DEV)))
+        with torch.no_grad():
+            target = G.synthesis(O.synth_ws(cfg, 1, seed=3).float().to(DEV), cam, **kw)['image'].clamp(-1, 1)
+        return G, PivotalTuner(G, target, O.synth_ws(cfg, 1, seed=5).float().to(DEV), cam, synth_kwargs=kw, lpips_threshold=thr, use_graph=use_graph)
+
+    # a threshold the run crosses after a handful of updates: the LPIPS term of a probe run at its 9th step
+    _, probe = setup(False, 0.0)
+    lps = [float(probe.step()['lpips']) for _ in range(12)]
+    assert lps[9] < lps[0]
+    thr = 0.5 * (lps[8] + lps[9])
+    Ge, te = setup(False, thr)
+    n_e = 0
+    for i in range(40):
+        if te.step(early_stop=True)['done']:
+            break
+        n_e += 1
+    Gg, tg = setup(True, thr)
+    assert tg.hip_adam and tg.device_stop
+    issued = 0
+    for i in range(40):
+        tg.step()
+        issued += 1
+        if i % 7 == 6 and tg.stopped():
+            break
+    assert tg._graph is not None and tg.graph_capture_error is None
+    n_g = int(round(float(tg.optimizer.step_t)))
+    assert issued > n_g, 'the host noticed late on purpose: some replays after the stop must have been masked'
+    assert n_g == n_e == 9, (n_g, n_e, lps)
+    for (k, a), (_, b) in zip(Ge.named_parameters(), Gg.named_parameters()):
+        d = float((a - b).abs().max())
+        assert d <= 0.1 * 3e-4 * n_e + 1e-6, (k, d)
+
+
 def test_config_c4_at_full_size_replays_from_a_graph():
     """Config C4 on the full-size (30.7 M parameter) generator: the pivotal-tuning step captured into a HIP graph and replayed across
     device-wide synchronisations, SR head in the reference's fp16-operand arithmetic, noise_mode='random' as BaseCoach.forward.  Asserts
