@@ -17,6 +17,8 @@ video / mesh export and the third-party encoders (e4e, ResNet pose head, ArcFace
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from . import dist as D
@@ -141,7 +143,10 @@ class InversionCoach:
     def run(self, images: Sequence[Tuple[str, torch.Tensor, Optional[torch.Tensor]]]) -> Tuple[List[InversionResult], Dict[str, float]]:
         """Invert this rank's shard of `images` = [(name, target [1,3,H,W] in [-1,1], cam [1,25] | None), ...] (every rank passes the
         same full list).  Returns (results of this rank, stats summed / maxed over all ranks)."""
-        rank, world, _ = D.init_from_env()
+        rank, world, local = D.init_from_env()
+        if world > 1 and len(images):
+            D.pin_to_numa(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
+            D.warm_up(images[0][1].device)          # the communicator exists before any step is captured
         results = []
         for i in D.shard_images(len(images), rank, world):
             name, target, cam = images[i]

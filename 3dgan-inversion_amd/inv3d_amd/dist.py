@@ -33,6 +33,88 @@ def init_from_env(backend: str = None):
     return rank, world, local
 
 
+COMM_READY = False       # set by warm_up(): the communicator exists (RCCL creates it lazily, at the first collective)
+
+
+def warm_up(device) -> None:
+    """Run one all-reduce + barrier NOW, on `device`.  RCCL builds its communicator (device allocations, IPC handle exchange, its own
+    streams) inside the first collective; that must not happen while a stream is capturing a HIP graph or between a capture's warm-up
+    and its replay.  bench.py / InversionCoach.run call this right after init_from_env, before any generator work."""
+    global COMM_READY
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.ones(1, dtype=torch.float32, device=device)
+        dist.all_reduce(t)
+        dist.barrier()
+        if torch.device(device).type == 'cuda':
+            torch.cuda.synchronize(device)
+        assert int(t.item()) == dist.get_world_size(), 'warm-up all-reduce returned a wrong sum'
+    COMM_READY = True
+
+
+def assert_comm_ready():
+    """Called in front of a graph capture in a multi-rank job: the first collective must already have run (warm_up)."""
+    if dist.is_initialized() and dist.get_world_size() > 1 and not COMM_READY:
+        raise RuntimeError('multi-rank job: call inv3d_amd.dist.warm_up(device) after init_from_env and before capturing HIP graphs '
+                           '(RCCL creates its communicator inside the first collective)')
+
+
+def _parse_cpulist(text: str) -> List[int]:
+    out = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        a, _, b = part.partition('-')
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def numa_cpus_for_rank(local_rank: int, local_world: int, allowed: Sequence[int], node_cpus: Dict[int, List[int]], gpu_node: Dict[int, int]) -> List[int]:
+    """CPUs rank `local_rank` should run on: the allowed CPUs of its GPU's NUMA node, divided evenly among the ranks whose GPUs sit on the
+    same node (each rank queues ~200 launches + one graph launch per step: eight ranks on one socket's cores throttle each other);
+    without topology information an even contiguous split of the allowed CPUs.  Pure function (tested on CPU)."""
+    allowed = sorted(set(allowed))
+    node = gpu_node.get(local_rank, -1)
+    if node >= 0 and node in node_cpus:
+        mine = [c for c in node_cpus[node] if c in set(allowed)]
+        peers = sorted(r for r in range(local_world) if gpu_node.get(r, -1) == node)
+        if mine and local_rank in peers:
+            k, n = peers.index(local_rank), len(peers)
+            per = max(1, len(mine) // n)
+            return mine[k * per:(k + 1) * per] if k < n - 1 else mine[k * per:] or mine
+    per = max(1, len(allowed) // max(1, local_world))
+    chunk = allowed[local_rank * per:(local_rank + 1) * per]
+    return chunk or allowed
+
+
+def pin_to_numa(local_rank: int, local_world: int) -> List[int]:
+    """sched_setaffinity of this process to numa_cpus_for_rank(...) (EG3D_PIN=0: leave the affinity alone).  Returns the CPU list in effect."""
+    if os.environ.get('EG3D_PIN', '1') == '0' or local_world <= 1 or not hasattr(os, 'sched_setaffinity'):
+        return sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else []
+    node_cpus, gpu_node = {}, {}
+    try:
+        base = '/sys/devices/system/node'
+        for d in os.listdir(base):
+            if d.startswith('node') and d[4:].isdigit():
+                node_cpus[int(d[4:])] = _parse_cpulist(open(os.path.join(base, d, 'cpulist')).read())
+        if torch.cuda.is_available():
+            for r in range(min(local_world, torch.cuda.device_count())):
+                bdf = getattr(torch.cuda.get_device_properties(r), 'pci_bus_id', None)
+                dom = getattr(torch.cuda.get_device_properties(r), 'pci_domain_id', 0)
+                dv = getattr(torch.cuda.get_device_properties(r), 'pci_device_id', 0)
+                if bdf is not None:
+                    path = '/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node' % (dom, bdf, dv)
+                    if os.path.exists(path):
+                        gpu_node[r] = int(open(path).read().strip())
+    except (OSError, ValueError):
+        pass
+    cpus = numa_cpus_for_rank(local_rank, local_world, sorted(os.sched_getaffinity(0)), node_cpus, gpu_node)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        pass
+    return sorted(os.sched_getaffinity(0))
+
+
 def shard_images(num_images: int, rank: int, world: int) -> List[int]:
     """Image i -> rank (i mod world): every rank gets floor/ceil(num_images/world) independent inversions."""
     return list(range(rank, num_images, world))

@@ -461,6 +461,8 @@ class LatentProjector:
                 if self.optimize_pose:
                     self.cam_optimizer.zero_grad(set_to_none=True)
                     self.translation_optimizer.zero_grad(set_to_none=True)
+                from . import dist as _D
+                _D.assert_comm_ready()                # multi-rank: RCCL's communicator must exist before anything is captured
                 graph = torch.cuda.CUDAGraph()
                 try:
                     with hipops.capture_guard(), torch.cuda.graph(graph, capture_error_mode='thread_local'):   # other threads (RCCL watchdog) may touch the runtime
@@ -694,6 +696,8 @@ class PivotalTuner:
             return res
         torch.cuda.synchronize()
         self.optimizer.zero_grad(set_to_none=True)
+        from . import dist as _D
+        _D.assert_comm_ready()
         graph = torch.cuda.CUDAGraph()
         try:
             with hipops.capture_guard(), torch.cuda.graph(graph, capture_error_mode='thread_local'), hipops.zero_arena(self._arena):

@@ -389,6 +389,8 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but the launcher started {world} rank(s)'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    cpus = D.pin_to_numa(int(os.environ.get('LOCAL_RANK', local)) if os.environ.get('EG3D_BENCH_ONE_DEVICE') != '1' else rank, world)   # each rank on its GPU's NUMA cores
+    D.warm_up(dev)              # RCCL builds its communicator inside the first collective: before any capture (dist.assert_comm_ready)
 
     from inv3d_amd import synthetic as S, hipops as H
     if args.precision is not None:
@@ -422,6 +424,7 @@ def main():
         return out
 
     if use_graph:                       # set-up, not a step of the benchmark: eager passes + the capture of the step into a HIP graph
+        D.assert_comm_ready()
         for _ in range(proj._graph_warmup + 1):
             one_step()
         if proj._graph is None:         # a number measured on the eager fallback must not pass for the captured step
@@ -595,7 +598,7 @@ def main():
                            'bf16x3': 'f32 storage, bf16x3 products (~2^-15)'}[prec_name], data='synthetic',
                     config=dict(workload=wl + ' (Phase A, w%s + 17 noise maps per image; G.synthesis fwd+bwd, 128^2 x 96-sample rendering, %s feature '
                                               'distance + noise regulariser, Adam)' % ('+' if args.wplus else '', 'stub-LPIPS' if args.loss_net == 'stub' else 'VGG16-LPIPS (256^2, random weights)'),
-                                images_per_gpu=M, image_steps_per_timed_step=M, world_size=world,
+                                images_per_gpu=M, image_steps_per_timed_step=M, world_size=world, host_cpus_of_rank0=len(cpus),
                                 generator='ffhqrebalanced512-128-shaped, 30.66 M params, random-init (synthetic weights)',
                                 parallelism=f'{world * M} independent images, {M} per GPU; stat all-reduce only' + (
                                     ' (one packed vector per step, asynchronous; mean loss over ranks and steps %.5g)' % float(step_stats[0] / step_stats[2].clamp(min=1)) if world > 1 else ''),

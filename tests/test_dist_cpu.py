@@ -96,3 +96,28 @@ def test_bench_self_launch_plumbing():
     assert cmd[k + 1:] == argv
     auto = bench.self_launch_command(2, [])
     assert 1024 < int(auto[auto.index('--master-port') + 1]) < 65536
+
+
+def test_numa_cpu_split_is_a_partition():
+    """dist.numa_cpus_for_rank: ranks of one NUMA node share its allowed CPUs without overlap; without topology an even split."""
+    from inv3d_amd import dist as D
+    node_cpus = {0: list(range(0, 48)) + list(range(96, 144)), 1: list(range(48, 96)) + list(range(144, 192))}
+    gpu_node = {0: 0, 1: 0, 2: 0, 3: 0, 4: 1, 5: 1, 6: 1, 7: 1}
+    allowed = list(range(192))
+    got = [D.numa_cpus_for_rank(r, 8, allowed, node_cpus, gpu_node) for r in range(8)]
+    assert all(len(g) == 24 for g in got)
+    assert sorted(c for g in got for c in g) == allowed
+    for r in range(8):
+        assert set(got[r]) <= set(node_cpus[gpu_node[r]])
+    even = [D.numa_cpus_for_rank(r, 8, list(range(16)), {}, {}) for r in range(8)]
+    assert even == [[2 * r, 2 * r + 1] for r in range(8)]
+    assert D.numa_cpus_for_rank(3, 8, [5], {}, {}) == [5]          # fewer CPUs than ranks: never an empty set
+    assert D._parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11]
+
+
+def test_capture_guard_for_the_communicator():
+    from inv3d_amd import dist as D
+    D.COMM_READY = False
+    D.assert_comm_ready()          # single process: nothing to wait for
+    D.warm_up('cpu')
+    assert D.COMM_READY

@@ -38,3 +38,15 @@ def test_two_ranks_one_device_dry_run():
     ratio = two['value'] / one['value']
     assert 0.5 <= ratio <= 1.35, (two['value'], one['value'])
     assert abs(two['ms_per_step'] * two['value'] / 2 - 1e3) < 1.0                      # value = world x steps / max-over-ranks time
+
+
+def test_eight_ranks_one_device_dry_run():
+    """config C5's launch shape -- eight ranks -- on one device: the communicator warm-up in front of the captures, per-rank CPU pinning,
+    eight concurrent graph captures / replays, the asynchronous reducer with eight contributors, one JSON line from rank 0."""
+    common = ['--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-final-psnr', '--no-roofline', '--no-side-configs']
+    r = _run(['--gpus', '8'] + common, dict(EG3D_BENCH_BACKEND='gloo', EG3D_BENCH_ONE_DEVICE='1'))
+    assert r['n_gpus'] == 8 and r['config']['world_size'] == 8 and r['steps'] == 4 and r['scaling'] == 'weak'
+    assert r['config']['launch'] == 'one HIP graph replay per step'
+    assert 'mean loss over ranks and steps' in r['config']['parallelism']
+    assert abs(r['ms_per_step'] * r['value'] / 8 - 1e3) < 1.0
+    assert r['config']['host_cpus_of_rank0'] >= 1
