@@ -722,12 +722,17 @@ __global__ void __launch_bounds__(256) unpack_weight_grad_kernel(const float* __
 // dd = gradient w.r.t. the demodulation coefficients (the activation-backward pass accumulates it); null: no demodulation term.
 __global__ void __launch_bounds__(256) weight_grad_finish_kernel(const float* __restrict__ g, const float* __restrict__ w, const float* __restrict__ s,
                                                                  const float* __restrict__ d, const float* __restrict__ dd, float* __restrict__ dw, int N,
-                                                                 int O, int I, int T) {
+                                                                 int O, int I, int T, int nslab, int64_t slab_stride) {
     extern __shared__ float row[];                      // [T][I + 1] packed row, then q[I] = 2 dwsq[o][.]
     const int o = blockIdx.x, tid = threadIdx.x, ld = I + 1;
     float* q = row + T * ld;
     const int64_t ro = (int64_t)o * T * I;
-    for (int k = tid; k < T * I; k += 256) { const int t = k / I, i = k - t * I; row[t * ld + i] = g[ro + k]; }
+    for (int k = tid; k < T * I; k += 256) {
+        const int t = k / I, i = k - t * I;
+        float v = g[ro + k];
+        for (int sl = 1; sl < nslab; ++sl) v += g[(int64_t)sl * slab_stride + ro + k];          // partial images, always in slab order
+        row[t * ld + i] = v;
+    }
     for (int i = tid; i < I; i += 256) {
         float acc = 0.f;
         if (dd != nullptr)
@@ -990,12 +995,17 @@ extern "C" int eg3d_unpack_weight_grad(const float* g, const float* w, const flo
 
 extern "C" int eg3d_weight_grad_finish(const float* g, const float* w, const float* s, const float* d, const float* dd, float* dw, int N, int O, int I,
                                       int T, void* stream) {
-    if (!g || !w || !dw || N <= 0 || O <= 0 || I <= 0 || T <= 0 || T > 64 || (dd && (!s || !d))) return EG3D_ERR_INVALID;
+    return eg3d_weight_grad_finish_slabs(g, 1, 0, w, s, d, dd, dw, N, O, I, T, stream);
+}
+
+extern "C" int eg3d_weight_grad_finish_slabs(const float* g, int nslab, int64_t slab_stride, const float* w, const float* s, const float* d, const float* dd,
+                                            float* dw, int N, int O, int I, int T, void* stream) {
+    if (!g || !w || !dw || N <= 0 || O <= 0 || I <= 0 || T <= 0 || T > 64 || (dd && (!s || !d)) || nslab < 1 || (nslab > 1 && slab_stride < (int64_t)O * T * I)) return EG3D_ERR_INVALID;
     const size_t smem = ((size_t)T * (I + 1) + I) * sizeof(float);
     if (smem > 64 * 1024) return EG3D_ERR_UNSUPPORTED;
     static std::atomic<uint64_t> attr_done{0};
     if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(weight_grad_finish_kernel), 64 * 1024, attr_done)) return e;
-    hipLaunchKernelGGL(weight_grad_finish_kernel, dim3(O), dim3(256), smem, (hipStream_t)stream, g, w, s, d, dd, dw, N, O, I, T);
+    hipLaunchKernelGGL(weight_grad_finish_kernel, dim3(O), dim3(256), smem, (hipStream_t)stream, g, w, s, d, dd, dw, N, O, I, T, nslab, slab_stride);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

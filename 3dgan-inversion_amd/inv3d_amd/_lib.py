@@ -86,6 +86,13 @@ class WgradParams(C.Structure):
                 ('in_scale', C.c_void_p), ('psplit', C.c_int32), ('precision', C.c_int32), ('g_amax', C.c_void_p), ('g_amax_mul', C.c_float)]
 
 
+class WgradV2Params(C.Structure):
+    _fields_ = [('g', C.c_void_p), ('x', C.c_void_p), ('g_scale', C.c_void_p), ('x_scale', C.c_void_p), ('dw', C.c_void_p),
+                ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('Co', C.c_int32), ('Ci', C.c_int32), ('w_row', C.c_int32),
+                ('ntaps', C.c_int32), ('dy', C.c_int32 * 9), ('dx', C.c_int32 * 9), ('wtap', C.c_int32 * 9),
+                ('products', C.c_int32), ('row_groups', C.c_int32), ('slabs', C.c_int32)]
+
+
 class RenderParams(C.Structure):
     _fields_ = [('planes', C.c_void_p), ('N', C.c_int32), ('Hp', C.c_int32), ('Wp', C.c_int32), ('ldp', C.c_int32),
                 ('C', C.c_int32), ('origins', C.c_void_p), ('dirs', C.c_void_p), ('R', C.c_int32), ('u1', C.c_void_p),
@@ -198,6 +205,10 @@ _SIGS = {
     'eg3d_conv2d_wgrad_f32': (C.c_int, [C.POINTER(WgradParams), C.c_void_p]),
     'eg3d_conv2d_v2_supported': (C.c_int, [C.POINTER(ConvV2Params)]),
     'eg3d_conv2d_v2': (C.c_int, [C.POINTER(ConvV2Params), C.c_void_p]),
+    'eg3d_conv2d_wgrad_v2_supported': (C.c_int, [C.POINTER(WgradV2Params)]),
+    'eg3d_conv2d_wgrad_v2': (C.c_int, [C.POINTER(WgradV2Params), C.c_void_p]),
+    'eg3d_conv2d_wgrad_v2_slabs': (C.c_int, [C.POINTER(WgradV2Params)]),
+    'eg3d_weight_grad_finish_slabs': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'eg3d_conv2d_lr_supported': (C.c_int, [C.POINTER(ConvLrParams)]),
     'eg3d_conv2d_lr_workspace': (C.c_int, [C.POINTER(ConvLrParams), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'eg3d_conv2d_lr': (C.c_int, [C.POINTER(ConvLrParams), C.c_void_p]),

@@ -384,6 +384,8 @@ class ModConvLayerFn(torch.autograd.Function):
                 rec.split_ok = bool((_auto_ksplit(cls_adj0, N, Ci, Co) == 1 or H.conv_v2_rows(Co, Ci, cls_adj0, N) == 2) and H.conv_v2_supported(Co, Ci, cls_adj0, N))
         if rec is not None:             # (a no-grad forward of the same layer -- the canonical view of the warping loss -- leaves a pending record alone)
             _set_producer(cache, rec)
+        # pivotal tuning: the weight gradient reads the forward's operand image again (csrc/conv_wgrad_v2.hip) instead of the fp32 activation
+        ctx.aimg = aimg if (v2 and up == 1 and want_wgrad and ctx.needs_input_grad[1] and H.WGRAD_V2 and Ci % 64 == 0 and Co % 64 == 0) else None
         ctx.rec = rec                   # THIS forward's record: the backward below trusts only it (two live graphs of one layer cannot mix)
         ctx.save_for_backward(x, weight, styles, d, out, nz, noise_strength, b)
         ctx.cfg = (up, act_gain, clampv, nstride, cache, want_wgrad, noise is not None and noise.dim() == 4, d_in is not None)
@@ -487,7 +489,8 @@ class ModConvLayerFn(torch.autograd.Function):
                 did = H.conv_v2_s2adj(gimg, cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, algo_flops=aflops,
                                       products=1 if prec == 'f16x1' else 3, **fkw)
             elif H.USE_V2 and up == 1 and (ks == 1 or H.conv_v2_rows(Co, Ci, cls_adj, N) == 2) and prec in ('f16x3', 'f16x1') and H.conv_v2_supported(Co, Ci, cls_adj, N):
-                did = H.conv_v2(dz_img if dz_img is not None else H.split_activation(g, amax), cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD,
+                gimg = dz_img if dz_img is not None else H.split_activation(g, amax)           # (kept: the weight gradient below reads it too)
+                did = H.conv_v2(gimg, cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD,
                                 out_scale=styles, xin=x, ds=ds, algo_flops=aflops, products=1 if prec == 'f16x1' else 3, **fkw)
                 dz_img = None
             elif up == 1 and prec in ('f16x3', 'f16x1') and amax is not None and not ks2 and H.conv_lr_plan(Co, Ci, cls_adj, N):
@@ -529,11 +532,25 @@ class ModConvLayerFn(torch.autograd.Function):
             H.demod_bwd(styles, wsq, d, dd, ds=ds)
         dweight = None
         if need_w:
-            dwp = H.zeros(wf.shape, dev)
+            dwp = None
             # same arithmetic as the data gradient: two-piece fp16 split with the gradient operand range-normalised by max|dz|
             wprec = prec if (prec in ('f16x3', 'f16x1') and amax is not None) else 'f32'
-            H.conv_wgrad(x, g, Ci, Co, dwp, cls_w, in_stride=1, out_stride=out_stride_w, in_scale=styles, precision=wprec,
-                         g_amax=amax if wprec != 'f32' else None, g_amax_mul=amul)
+            ximg = getattr(ctx, 'aimg', None)
+            if up == 1 and ximg is not None and wprec != 'f32' and amax is not None:
+                if gimg is None:
+                    gimg = H.split_activation(g, amax)
+                use_v2w = H.conv_wgrad_v2_ok(gimg, ximg, cls_w)
+            else:
+                use_v2w = False
+            if use_v2w:       # both operands as the split images the forward / data gradient consumed: LDS-DMA + transposing LDS reads, no VALU loader
+                if H.WGRAD_SLABS:       # partial tiles stored, summed in slab order by weight_grad_finish: no atomics, no zero fill
+                    dwp = H.conv_wgrad_v2_slabs(gimg, ximg, cls_w, products=1 if wprec == 'f16x1' else 3)
+                else:
+                    dwp = H.conv_wgrad_v2(gimg, ximg, H.zeros(wf.shape, dev), cls_w, products=1 if wprec == 'f16x1' else 3)
+            else:
+                dwp = H.zeros(wf.shape, dev)
+                H.conv_wgrad(x, g, Ci, Co, dwp, cls_w, in_stride=1, out_stride=out_stride_w, in_scale=styles, precision=wprec,
+                             g_amax=amax if wprec != 'f32' else None, g_amax_mul=amul)
             # [O,taps,I] accumulator -> the parameter's own (contiguous [O,I,kh,kw]) layout, plus the demodulation path d wsq / d w = 2 w
             # (dwsq from dd on the fly), in one pass; the fused multi-tensor Adam walks parameter and gradient with the same linear index
             dweight = H.weight_grad_finish(dwp, weight, styles, d, dd)

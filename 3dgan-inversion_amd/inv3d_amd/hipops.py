@@ -947,6 +947,57 @@ def conv_wgrad(x, g, Ck, Nc, dwp, classes, in_stride=1, out_stride=1, in_scale=N
     return dwp
 
 
+WGRAD_V2 = os.environ.get('EG3D_WGRAD_V2', '1') != '0'       # weight gradients of split-image layers on csrc/conv_wgrad_v2.hip
+
+
+def conv_wgrad_v2_ok(gimg, ximg, classes):
+    """Both operands as SplitImages of equal geometry, channel counts multiples of 64, one stride-1 class of 9 (3x3) or 1 taps."""
+    if not (WGRAD_V2 and USE_V2) or gimg is None or ximg is None or len(classes) != 1 or classes[0].ntaps not in (9, 1):
+        return False
+    n, co, h, w = gimg.shape
+    n2, ci, h2, w2 = ximg.shape
+    c = classes[0]
+    return (n, h, w) == (n2, h2, w2) and co % 64 == 0 and ci % 64 == 0 and (c.Ha, c.Wa) == (h, w) and c.out_py == 0 and c.out_px == 0
+
+
+WGRAD_SLABS = os.environ.get('EG3D_WGRAD_SLABS', '0') != '0'   # partial weight-gradient tiles stored to slabs and summed in order (no atomics)
+
+
+def _wgrad_v2_params(gimg, ximg, classes, products, row_groups):
+    p = L.WgradV2Params()
+    n, co, h, w = gimg.shape
+    _, ci, _, _ = ximg.shape
+    c = classes[0]
+    p.g, p.x, p.g_scale, p.x_scale = gimg.data.data_ptr(), ximg.data.data_ptr(), gimg.scale.data_ptr(), ximg.scale.data_ptr()
+    p.N, p.H, p.W, p.Co, p.Ci, p.w_row = n, h, w, co, ci, c.ntaps * ci
+    p.ntaps = c.ntaps
+    for t in range(c.ntaps):
+        p.dy[t], p.dx[t], p.wtap[t] = c.dy[t], c.dx[t], c.wtap[t]
+    p.products, p.row_groups = int(products), int(row_groups)
+    return p
+
+
+def conv_wgrad_v2(gimg: SplitImage, ximg: SplitImage, dwp, classes, products=3, row_groups=0):
+    """dwp[Co, taps*Ci] += weight gradient from the split images of dz (gimg) and of the modulated input (ximg) (eg3d_conv2d_wgrad_v2)."""
+    p = _wgrad_v2_params(gimg, ximg, classes, products, row_groups)
+    p.dw, p.w_row, p.slabs = dwp.data_ptr(), dwp.stride(0), 0
+    L.check(L.lib().eg3d_conv2d_wgrad_v2(C.byref(p), L.stream_ptr()), 'conv2d_wgrad_v2')
+    return dwp
+
+
+def conv_wgrad_v2_slabs(gimg: SplitImage, ximg: SplitImage, classes, products=3, row_groups=0):
+    """The same without atomics: returns slabs [nslab, Co, taps*Ci] of partial gradients whose sum IN SLAB ORDER is the gradient
+    (weight_grad_finish(slabs, ...) sums them; torch.sum(0) for tests)."""
+    p = _wgrad_v2_params(gimg, ximg, classes, products, row_groups)
+    ns = int(L.lib().eg3d_conv2d_wgrad_v2_slabs(C.byref(p)))
+    if ns < 1:
+        raise L.Eg3dHipError(f'conv2d_wgrad_v2_slabs: {ns}')
+    slabs = torch.empty((ns, p.Co, p.w_row), dtype=torch.float32, device=gimg.data.device)
+    p.dw, p.slabs = slabs.data_ptr(), 1
+    L.check(L.lib().eg3d_conv2d_wgrad_v2(C.byref(p), L.stream_ptr()), 'conv2d_wgrad_v2')
+    return slabs
+
+
 # ------------------------------------------------------------------------------------------------- epilogues
 def epilogue_fwd(z, out, fir=None, pad0=0, fir_gain=1.0, d=None, noise=None, noise_nstride=0, noise_strength=None, bias=None,
                  act='linear', alpha=0.0, gain=1.0, clamp=-1.0, out_amax=None):
@@ -1133,6 +1184,11 @@ def weight_grad_finish(dwp, weight, styles, d, dd):
     o, i, kh, kw = w.shape
     dw = torch.empty_like(w)
     n = styles.shape[0] if styles is not None else 1
+    if dwp.dim() == 3:          # slabs [nslab, O, taps*I] (conv_wgrad_v2_slabs): summed in slab order by the same pass
+        assert dwp.is_contiguous() and dwp.shape[1:] == (o, kh * kw * i)
+        L.check(L.lib().eg3d_weight_grad_finish_slabs(dwp.data_ptr(), dwp.shape[0], dwp.stride(0), w.data_ptr(), L.ptr(styles), L.ptr(d), L.ptr(dd),
+                                                      dw.data_ptr(), n, o, i, kh * kw, L.stream_ptr()), 'weight_grad_finish_slabs')
+        return dw
     L.check(L.lib().eg3d_weight_grad_finish(dwp.data_ptr(), w.data_ptr(), L.ptr(styles), L.ptr(d), L.ptr(dd), dw.data_ptr(), n, o, i, kh * kw,
                                             L.stream_ptr()), 'weight_grad_finish')
     return dw

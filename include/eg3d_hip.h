@@ -335,6 +335,30 @@ typedef struct eg3d_wgrad_params {
 
 int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* p, void* stream);
 
+/* The same weight gradient for stride-1 layers whose two operands already exist as split images (csrc/conv_wgrad_v2.hip): g = the image of
+ * the gradient operand dz [N][2][Co/8][H][W][8] fp16 (what the data gradient of eg3d_conv2d_v2 consumes), x = the image of the layer input
+ * times its styles [N][2][Ci/8][H][W][8] (what its forward consumed), both written by eg3d_split_activation or a fused producer:
+ *     dw[o, wtap[t], k] += 1 / (g_scale x_scale) * sum_{n,y,x} G[n,y,x,o] * X[n, y + dy[t], x + dx[t], k]        (OOB reads are zero)
+ * for ntaps = 9 (3x3, dy / dx in -1 .. 1) or 1.  LDS-DMA staging, transposing LDS reads (ds_read_b64_tr_b16), no per-element VALU work.
+ * Co, Ci multiples of 64; dw pre-zeroed (partial tiles are accumulated with atomics).  products: 0 / 3 three products, 1 high pieces only.
+ * row_groups: 0 = chosen by the library (about two workgroups per CU). */
+typedef struct eg3d_wgrad_v2_params {
+    const void* g;  const void* x;
+    const float* g_scale;  const float* x_scale;
+    float* dw;
+    int32_t N, H, W, Co, Ci, w_row;
+    int32_t ntaps;
+    int32_t dy[9], dx[9], wtap[9];
+    int32_t products, row_groups;
+    int32_t slabs;             /* 0: partial tiles are ADDED to dw [Co][w_row] with fp32 atomics (dw pre-zeroed).  != 0: no atomics -- workgroup j of a
+                                * channel tile STORES its partial tile into slab j of dw [nslab][Co][w_row] (nslab = eg3d_conv2d_wgrad_v2_slabs(p),
+                                * every slab fully written, nothing to pre-zero) and the caller sums the slabs in order
+                                * (eg3d_weight_grad_finish_slabs): run-to-run deterministic, and cheaper than ~19 M atomics per launch */
+} eg3d_wgrad_v2_params;
+int eg3d_conv2d_wgrad_v2_supported(const eg3d_wgrad_v2_params* p);
+int eg3d_conv2d_wgrad_v2_slabs(const eg3d_wgrad_v2_params* p);      /* number of slabs (= workgroups per channel tile) the launch will write; < 0: error */
+int eg3d_conv2d_wgrad_v2(const eg3d_wgrad_v2_params* p, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Tall-skinny Gram product for the decoder-weight gradients of pivotal tuning (training/triplane.py:116-136 under
  * base_coach.py:96-99):  out[i][j] += sum_s a[s][i]*b[s][j]  (Ka, Kb <= 64, row-major a [S,Ka], b [S,Kb]),
@@ -502,6 +526,9 @@ int eg3d_pack_conv_weight_padded(const float* w, float* wf, float* wa, float* ws
  * s [N,I] styles, d [N,O] demodulation coefficients, dd [N,O] their gradient; w, dw [O,I,T]. */
 int eg3d_weight_grad_finish(const float* g, const float* w, const float* s, const float* d, const float* dd, float* dw, int N, int O, int I, int T,
                             void* stream);
+/* ... with g = the sum, in slab order, of nslab images [O][T*I] that lie slab_stride floats apart (eg3d_wgrad_v2_params::slabs). */
+int eg3d_weight_grad_finish_slabs(const float* g, int nslab, int64_t slab_stride, const float* w, const float* s, const float* d, const float* dd, float* dw,
+                                  int N, int O, int I, int T, void* stream);
 /* eg3d_pack_conv_weight (O_pad = 0) / eg3d_pack_conv_weight_padded of up to EG3D_PACK_BATCH_MAX layers in ONE launch: during pivotal tuning
  * all generator weights change together once per step.  wa / wsq may be null per item. */
 #define EG3D_PACK_BATCH_MAX 40

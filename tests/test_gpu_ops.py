@@ -933,6 +933,43 @@ def test_conv_wgrad_vs_torch(shape, prec, tol):
     assert err <= tol, err
 
 
+@pytest.mark.parametrize('products,tol', [(3, 2e-5), (1, 2e-3)])
+@pytest.mark.parametrize('shape', [(1, 64, 64, 16, 32, 0), (2, 128, 64, 24, 40, 0), (1, 64, 128, 9, 33, 3), (1, 128, 128, 64, 64, 0), (1, 256, 64, 7, 70, 2)])
+def test_conv_wgrad_v2_vs_torch(shape, products, tol):
+    """eg3d_conv2d_wgrad_v2 (split images in, LDS-DMA + transposing LDS reads) vs autograd of F.conv2d in float64: style-modulated input,
+    batch 2, widths that are not multiples of the 32-column strip, several row groups, a gradient operand of magnitude 1e-6 (range-
+    normalised by the split), three-product and single-product (fp16-operand, rel. 2^-11) arithmetic."""
+    from inv3d_amd import hipops as H
+    n, ci, co, h, w, rg = shape
+    g_ = torch.Generator().manual_seed(ci * 31 + co + h)
+    x = torch.randn(n, ci, h, w, generator=g_)
+    s = torch.rand(n, ci, generator=g_) + 0.5
+    wt = (torch.randn(co, ci, 3, 3, generator=g_) / (3 * ci ** 0.5)).double().requires_grad_(True)
+    y = F.conv2d((x * s[:, :, None, None]).double(), wt, padding=1)
+    dy = torch.randn(y.shape, generator=g_) * 1e-6
+    y.backward(dy.double())
+    xq, gq = x.to(DEV).contiguous(memory_format=torch.channels_last), dy.to(DEV).contiguous(memory_format=torch.channels_last)
+    ximg = H.split_activation(xq, H.absmax(xq), in_scale=s.to(DEV).contiguous())
+    gimg = H.split_activation(gq, H.absmax(gq))
+    cls = H.classes_corr(h, w, 3, 3, 1)
+    assert H.conv_wgrad_v2_ok(gimg, ximg, cls)
+    dwp = torch.zeros(co, 9 * ci, device=DEV)
+    H.conv_wgrad_v2(gimg, ximg, dwp, cls, products=products, row_groups=rg)
+    dw = dwp.view(co, 3, 3, ci).permute(0, 3, 1, 2)
+    ref = wt.grad
+    err = float((dw.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err <= tol, err
+    # the atomic-free form: slabs of partial tiles, summed in slab order by weight_grad_finish -- bit-identical from run to run
+    outs = []
+    for _ in range(3):
+        slabs = H.conv_wgrad_v2_slabs(gimg, ximg, cls, products=products, row_groups=rg)
+        wparam = torch.zeros(co, ci, 3, 3, device=DEV)
+        outs.append(H.weight_grad_finish(slabs, wparam, None, None, None))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    err = float((outs[0].double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err <= tol, err
+
+
 @pytest.mark.parametrize('shape', [(512, 512, 3), (96, 256, 1), (3, 128, 1), (40, 33, 3), (16, 8, 3)])
 def test_pack_conv_weight(shape):
     """eg3d_pack_conv_weight == the two permute-copies + sum of squares it replaces (bit-exact copies)."""
