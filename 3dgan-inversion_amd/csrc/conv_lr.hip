@@ -30,7 +30,7 @@ constexpr int LR_MAXCK = 1024;
 
 template <int RPW> struct lr_geom {
     static constexpr int CELLS = 64 * RPW;
-    static constexpr int MAXSLOTS = RPW == 1 ? 144 : 208;          // (TR + 2) x (TW + 2) halo pixels: 4 x 34 | 6 x 18 | 10 x 10 | 18 x 6  (RPW 2: 6 x 34 ...)
+    static constexpr int MAXSLOTS = RPW == 1 ? 144 : (RPW == 2 ? 208 : 352);   // (TR + 2) x (TW + 2) halo pixels: 4 x 34 | 6 x 18 | 10 x 10 | 18 x 6  (RPW 2: 6 x 34 ...; RPW 4: 10 x 34, 18 x 18, 34 x 10)
     static constexpr int NLD = (MAXSLOTS * 4 + 255) / 256;         // 16-byte DMA items per lane and chunk (a wave issues NLD instructions)
     static constexpr int APL = MAXSLOTS * 16;                      // one (piece, k-octet) plane of the split halo
     static constexpr int ABUF = 4 * APL;
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(256) conv_lr_kernel(const eg3d_conv_lr_params 
     v2_epilogue<false, RPW, true>(p, acc, Ha, Wa, cl.out_py, cl.out_px, n, y0, x0, n0, smem, out_mul, logw);
 }
 
-std::atomic<uint64_t> g_lr_attr[4];
+std::atomic<uint64_t> g_lr_attr[6];
 
 inline int lr_tiles_m_max(const eg3d_conv_lr_params& P, int rpw) {
     const int TW = 1 << P.logw, TR = (64 * rpw) >> P.logw;
@@ -375,14 +375,18 @@ extern "C" int eg3d_conv2d_lr_supported(const eg3d_conv_lr_params* pp) {
         if (ab.act != EG3D_ACT_LINEAR && ab.act != EG3D_ACT_LRELU) return 0;
         if (!(ab.gain > 0.f) || (ab.noise != nullptr && ab.noise_strength == nullptr)) return 0;
     }
-    const int TW = 1 << pp->logw, TR = 64 >> pp->logw;
+    const int rpw = p.patch_rows == 4 ? 4 : (p.patch_rows == 2 ? 2 : 1);
+    if (p.patch_rows != 0 && p.patch_rows != 1 && p.patch_rows != 2 && p.patch_rows != 4) return 0;
+    if (rpw == 4 && pp->logw < 3) return 0;
+    const int TW = 1 << pp->logw, TR = (64 * rpw) >> pp->logw;
+    const int maxslots = rpw == 1 ? lr_geom<1>::MAXSLOTS : (rpw == 2 ? lr_geom<2>::MAXSLOTS : lr_geom<4>::MAXSLOTS);
     for (int c = 0; c < p.ncls; ++c) {
         const eg3d_conv_class& k = p.cls[c];
         if (k.ntaps != 9 && k.ntaps != 4 && k.ntaps != 2 && k.ntaps != 1) return 0;
         int ymin = k.dy[0], ymax = k.dy[0], xmin = k.dx[0], xmax = k.dx[0];
         for (int t = 1; t < k.ntaps; ++t) { ymin = std::min(ymin, k.dy[t]); ymax = std::max(ymax, k.dy[t]); xmin = std::min(xmin, k.dx[t]); xmax = std::max(xmax, k.dx[t]); }
         if (ymax - ymin > 2 || xmax - xmin > 2) return 0;
-        if ((TR + ymax - ymin) * (TW + xmax - xmin) > lr_geom<1>::MAXSLOTS) return 0;
+        if ((TR + ymax - ymin) * (TW + xmax - xmin) > maxslots) return 0;
         for (int t = 0; t < k.ntaps; ++t) if (k.wtap[t] < 0 || k.wtap[t] >= p.wtaps) return 0;
     }
     if ((int64_t)p.N * p.Hi * p.Wi * pp->ldx * 4 > 0x7fffffe0ll) return 0;
@@ -396,8 +400,9 @@ extern "C" int eg3d_conv2d_lr_workspace(const eg3d_conv_lr_params* pp, int64_t* 
     if (!eg3d_conv2d_lr_supported(pp)) return EG3D_ERR_UNSUPPORTED;
     const int ks = pp->v.ksplit > 1 ? pp->v.ksplit : 1;
     if (ks == 1) { *slab_bytes = 0; *ticket_words = 0; return EG3D_OK; }
-    const int64_t tiles = (int64_t)lr_tiles_m_max(*pp, 1) * (pp->v.Nc / BN) * pp->v.ncls;
-    *slab_bytes = tiles * ks * 64 * BN * 4;
+    const int rpw = pp->v.patch_rows == 4 ? 4 : (pp->v.patch_rows == 2 ? 2 : 1);
+    const int64_t tiles = (int64_t)lr_tiles_m_max(*pp, rpw) * (pp->v.Nc / BN) * pp->v.ncls;
+    *slab_bytes = tiles * ks * 64 * rpw * BN * 4;
     *ticket_words = tiles;
     return EG3D_OK;
 }
@@ -413,5 +418,8 @@ extern "C" int eg3d_conv2d_lr(const eg3d_conv_lr_params* pp, void* stream) {
         if (q != nullptr && (reinterpret_cast<uintptr_t>(q) & 15)) return EG3D_ERR_UNSUPPORTED;
     if (p.epi == EG3D_EPI_FWD && p.noise && !p.noise_strength) return EG3D_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    return p.products == 1 ? launch_lr<false, 1>(*pp, st, 1) : launch_lr<true, 1>(*pp, st, 0);
+    const bool one = p.products == 1;
+    if (p.patch_rows == 4) return one ? launch_lr<false, 4>(*pp, st, 5) : launch_lr<true, 4>(*pp, st, 4);
+    if (p.patch_rows == 2) return one ? launch_lr<false, 2>(*pp, st, 3) : launch_lr<true, 2>(*pp, st, 2);
+    return one ? launch_lr<false, 1>(*pp, st, 1) : launch_lr<true, 1>(*pp, st, 0);
 }

@@ -835,7 +835,7 @@ LR_ROTATE = int(os.environ.get('EG3D_LR_ROTATE', '1'))                 # tile-de
 LR_KS_MAX = int(os.environ.get('EG3D_LR_KS_MAX', '8'))                 # K slices per tile (the last arriver reads that many 32 KB slabs)
 
 
-def conv_lr_plan(Ck, Nc, classes, N=1, in_stride=1, force=False):
+def conv_lr_plan(Ck, Nc, classes, N=1, in_stride=1, force=False, rpw=0):
     """(logw, ksplit) for eg3d_conv2d_lr, or None when the launch is not one for it: stride-1 tap classes of 9 / 4 / 2 / 1 taps on grids of at
     most LR_MAX_CELLS cells whose 256-cell tiles cannot fill the chip.  logw: tile width 32 / 16 / 8 / 4 cells, the narrowest power of two
     that covers the widest class grid; ksplit: K slices per 64-cell x 128-channel tile so that the launch has ~LR_KS_TARGET workgroups, each
@@ -852,10 +852,16 @@ def conv_lr_plan(Ck, Nc, classes, N=1, in_stride=1, force=False):
         if max(dys) - min(dys) > 2 or max(dxs) - min(dxs) > 2:
             return None
     logw = 5 if wmax > 16 else (4 if wmax > 8 else (3 if wmax > 4 else 2))
-    tw, tr = 1 << logw, 64 >> logw
+    # cells per tile: 256 (24 MFMAs per wave and step amortise the per-step latencies) when that still gives >= 64 tiles before the K split,
+    # 64 for the small images
+    cells = max(c.Ha * c.Wa for c in classes) * N
+    rpw = rpw if rpw else (4 if cells >= 4096 else (2 if cells >= 1024 else 1))
+    if rpw == 4 and logw < 3:
+        rpw = 2
+    tw, tr = 1 << logw, (64 * rpw) >> logw
     tiles = sum(N * -(-c.Ha // tr) * -(-c.Wa // tw) for c in classes) * (Nc // 128)
-    ks = max(1, min(LR_KS_MAX, -(-LR_KS_TARGET // tiles), (Ck // 16) // 2))
-    return logw, ks
+    ks = max(1, min(LR_KS_MAX if rpw == 1 else 4 * (2 if rpw == 2 else 1), -(-LR_KS_TARGET // tiles), (Ck // 16) // 2))
+    return logw, ks, rpw
 
 
 def conv_lr(x, x_amax, w: SplitImage, out, classes, plan, in_scale=None, amax_mul=1.0, out_stride=1, epi=L.EPI_STORE, out_scale=None, bias=None,
@@ -865,7 +871,8 @@ def conv_lr(x, x_amax, w: SplitImage, out, classes, plan, in_scale=None, amax_mu
     conv_lr_plan(...).  act_bwd (ActBwdSpec, with epi=EPI_BWD): EPI_BWD_ACT when the launch takes it -- returns True if the fused epilogue
     ran, False for a plain EPI_BWD."""
     assert is_cl(x) and is_cl(out)
-    logw, ks = plan
+    logw, ks = plan[:2]
+    rpw = plan[2] if len(plan) > 2 else 1
     n, cx, hi, wi = x.shape
     nc, ck, wtaps = w.shape
     _, co, ho, wo = out.shape
@@ -877,7 +884,7 @@ def conv_lr(x, x_amax, w: SplitImage, out, classes, plan, in_scale=None, amax_mu
     P = L.ConvLrParams()
     v = _conv_v2_params(a, w, out, classes, out_stride, epi, out_scale, bias, noise, noise_nstride, noise_strength, act, alpha, gain, clamp,
                         addend, xin, ds, out_amax)
-    v.products, v.ksplit, v.patch_rows = int(products), int(ks), 0
+    v.products, v.ksplit, v.patch_rows = int(products), int(ks), int(rpw)
     fused_act = False
     if act_bwd is not None and epi == L.EPI_BWD and xin is not None:
         v.epi = L.EPI_BWD_ACT

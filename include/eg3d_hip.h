@@ -237,7 +237,7 @@ int eg3d_conv2d_v2(const eg3d_conv_v2_params* p, void* stream);
  *   - the A operand is the fp32 NHWC activation itself (v.a = x [N,Hi,Wi,ldx], v.a_scale unused): a workgroup stages the halo of its tile
  *     per 16-channel chunk by LDS-DMA, multiplies by in_scale[n,k] and by the power of two that brings x_amax * amax_mul * max|in_scale| to
  *     [2^13, 2^14), and splits it into the two fp16 pieces in LDS -- no operand image, no split pass;
- *   - a workgroup tile is 64 cells x 128 channels, the cells a (64 >> logw) x (1 << logw) patch (logw = 5: 2 x 32 ... logw = 2: 16 x 4),
+ *   - a workgroup tile is 64 r cells x 128 channels (r = v.patch_rows: 1 | 2 | 4), the cells a (64 r >> logw) x (1 << logw) patch (r = 1, logw = 5: 2 x 32 ... logw = 2: 16 x 4),
  *     so narrow images do not waste matrix work on padding columns;
  *   - the weight tile of a (tap, chunk) step goes through an eight-slot LDS ring (seven steps of LDS-DMA in flight per workgroup): the
  *     4^2 .. 16^2 layers are bound by streaming 9.4 MB of weight pieces, not by arithmetic;
@@ -247,7 +247,7 @@ int eg3d_conv2d_v2(const eg3d_conv_v2_params* p, void* stream);
  *     all classes) must be zero on entry and is zero again on exit.
  * Restrictions (eg3d_conv2d_lr_supported): Ck % 16 == 0, Nc % 128 == 0, in_stride 1, tap offsets spanning at most 3 x 3, 1 <= ksplit <= 16. */
 typedef struct eg3d_conv_lr_params {
-    eg3d_conv_v2_params v;     /* v.a = fp32 activation, v.a_scale ignored, v.ksplit = K slices, v.patch_rows ignored        */
+    eg3d_conv_v2_params v;     /* v.a = fp32 activation, v.a_scale ignored, v.ksplit = K slices, v.patch_rows = 0 / 1 | 2 | 4: tile of 64 | 128 | 256 cells */
     const float* in_scale;     /* [N,Ck] or null                                                                             */
     const float* x_amax;       /* device scalar max|x| (required)                                                            */
     float amax_mul;            /* |x| <= x_amax * amax_mul                                                                   */

@@ -1052,10 +1052,10 @@ def test_conv_v2_half_patch_full_size():
 # ---------------------------------------------------------------------------------------------------------------------------
 # Low-resolution convolution (csrc/conv_lr.hip): fp32 activation in, in-kernel split, deep weight ring, ordered split-K
 # ---------------------------------------------------------------------------------------------------------------------------
-def _lr_plan(H, ci, co, cls, n, ks):
-    plan = H.conv_lr_plan(ci, co, cls, n, force=True)         # (the kernel is opt-in: EG3D_CONV_LR)
+def _lr_plan(H, ci, co, cls, n, ks, rpw=0):
+    plan = H.conv_lr_plan(ci, co, cls, n, force=True, rpw=rpw)         # (the kernel is opt-in: EG3D_CONV_LR)
     assert plan is not None
-    return (plan[0], ks if ks else plan[1])
+    return (plan[0], ks if ks else plan[1], plan[2])
 
 
 @pytest.mark.parametrize('ks', [0, 1, 2, 8])      # 0: the planner's choice
@@ -1086,6 +1086,35 @@ def test_conv_lr_forward_epilogue_vs_torch(shape, ks):
               noise=noise.to(DEV).contiguous(), noise_nstride=h * w, noise_strength=strength.to(DEV), act='lrelu', alpha=0.2, gain=1.4, clamp=-1.0,
               addend=add.to(DEV).contiguous(memory_format=torch.channels_last), out_amax=amax)
     close(out, ref.float(), 2e-5, f'conv_lr fwd {shape} ks {ks}')
+    assert abs(float(amax) - float(out.abs().max())) == 0.0
+
+
+@pytest.mark.parametrize('rpw,ks', [(2, 1), (2, 3), (4, 1), (4, 2)])
+@pytest.mark.parametrize('shape', [(1, 64, 64, 64, 128), (2, 32, 17, 33, 128), (1, 128, 16, 16, 256), (1, 64, 40, 9, 128)])
+def test_conv_lr_large_tiles_vs_torch(shape, rpw, ks):
+    """The 128- and 256-cell tiles (12 / 24 MFMAs per wave and step) with the fused forward epilogue and the ordered split-K."""
+    from inv3d_amd import hipops as H, _lib as L
+    n, ci, h, w, co = shape
+    g = torch.Generator().manual_seed(34)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)
+    s = 1 + 0.5 * torch.randn(n, ci, generator=g)
+    d = 0.5 + torch.rand(n, co, generator=g)
+    noise, strength = torch.randn(h, w, generator=g), torch.tensor(0.3)
+    bias = 0.1 * torch.randn(co, generator=g)
+    z = torch.nn.functional.conv2d(x.double() * s.double()[:, :, None, None], wt.double(), padding=1) * d.double()[:, :, None, None]
+    ref = torch.nn.functional.leaky_relu(z + noise.double() * 0.3 + bias.double()[None, :, None, None], 0.2) * 1.4
+    xc = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    wimg = H.split_weight(H.pack_weight_fwd(wt.to(DEV)), co, ci, 9)
+    cls = H.classes_corr(h, w, 3, 3, 1)
+    plan = _lr_plan(H, ci, co, cls, n, ks, rpw)
+    if plan[2] != rpw or ks > ci // 16:
+        pytest.skip('tile size not available for this width / more K slices than chunks')
+    out = H.empty_cl(n, co, h, w, DEV)
+    amax = torch.zeros(1, device=DEV)
+    H.conv_lr(xc, H.absmax(xc), wimg, out, cls, plan, in_scale=s.to(DEV), epi=L.EPI_FWD, out_scale=d.to(DEV), bias=bias.to(DEV), noise=noise.to(DEV),
+              noise_nstride=0, noise_strength=strength.to(DEV), act='lrelu', alpha=0.2, gain=1.4, clamp=-1.0, out_amax=amax)
+    close(out, ref.float(), 2e-5, f'conv_lr rpw {rpw} ks {ks} {shape}')
     assert abs(float(amax) - float(out.abs().max())) == 0.0
 
 

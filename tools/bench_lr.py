@@ -61,14 +61,14 @@ for res in ress:
     t_old = timed(old)
     print(f'res {res:3d}: igemm split-K {ks_old:2d} + fill + finishing pass {t_old:7.1f} us', flush=True)
     plan0 = H.conv_lr_plan(ci, co, cls, 1, force=True)
-    for ks in sorted({1, 2, 4, 8, 16, plan0[1]}):
-        if ks > 16:
+    for rpw in (1, 2, 4):
+        if H.conv_lr_plan(ci, co, cls, 1, force=True, rpw=rpw)[2] != rpw or rpw * 64 > 2 * res * res:
             continue
-        for rot in (0, 1):
+        for ks in (1, 2, 4, 8, 16):
             def new(k):
-                H.conv_lr(x, ax, wimgs[k], out, cls, (plan0[0], ks), in_scale=s, epi=L.EPI_FWD, out_scale=d, out_amax=amax, rotate=rot, **epi)
+                H.conv_lr(x, ax, wimgs[k], out, cls, (plan0[0], ks, rpw), in_scale=s, epi=L.EPI_FWD, out_scale=d, out_amax=amax, **epi)
             try:
                 t = timed(new)
             except Exception as e:       # noqa: BLE001
                 print('   lr ks', ks, 'failed:', str(e)[:80]); continue
-            print(f'          conv_lr logw {plan0[0]} ks {ks:2d} rotate {rot}: {t:7.1f} us' + ('   <- plan' if ks == plan0[1] else ''), flush=True)
+            print(f'          conv_lr logw {plan0[0]} cells {64 * rpw:3d} ks {ks:2d}: {t:7.1f} us' + ('   <- plan' if (ks, rpw) == plan0[1:] else ''), flush=True)
