@@ -268,6 +268,8 @@ _SIGS = {
     'eg3d_torgb_small_bwd_supported': (C.c_int, [C.POINTER(TorgbSmallBwdParams)]),
     'eg3d_torgb_small_bwd': (C.c_int, [C.POINTER(TorgbSmallBwdParams), C.c_void_p]),
     'eg3d_adam_step': (C.c_int, [C.POINTER(AdamList), C.c_void_p, C.c_void_p]),
+    'eg3d_pose_chain_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'eg3d_pose_chain_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'eg3d_early_stop_flag': (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     'eg3d_unit_normalize_levels': (C.c_int, [C.POINTER(UnitLevels), C.c_int, C.c_void_p]),
     'eg3d_unit_normalize_bwd': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int64, C.c_int, C.c_void_p]),

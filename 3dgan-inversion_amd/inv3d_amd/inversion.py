@@ -150,6 +150,53 @@ def pose_to_cam(rotmat: torch.Tensor, translation_opt: torch.Tensor, intrinsic: 
     return ext, torch.cat([ext.reshape(b, 16), intrinsic.reshape(1, 9).expand(b, 9)], 1)
 
 
+class _PoseChainFn(torch.autograd.Function):
+    """pose vector + translation -> (extrinsic [B,4,4], c [B,25]) in one launch per direction (eg3d_pose_chain_fwd / _bwd: forward-mode duals
+    give the 12 x 9 Jacobian with the values).  As PyTorch ops the chain is ~150 one-element kernels forward and as many backward."""
+
+    @staticmethod
+    def forward(ctx, pose, translation, intrinsic, radius, mode):
+        from . import _lib as L
+        pose, translation = pose.contiguous().float(), translation.contiguous().float()
+        b = pose.shape[0]
+        m = {'quat': 0, '6d': 1, 'euler': 2}[mode]
+        dev = pose.device
+        ext, cam = torch.empty((b, 4, 4), device=dev), torch.empty((b, 25), device=dev)
+        jac, out12 = torch.empty((b, 12, 9), device=dev), torch.empty((b, 12), device=dev)
+        k9 = intrinsic.reshape(-1)[:9].contiguous().float()
+        L.check(L.lib().eg3d_pose_chain_fwd(pose.data_ptr(), translation.data_ptr(), k9.data_ptr(), b, m, float(radius), ext.data_ptr(), cam.data_ptr(),
+                                            jac.data_ptr(), out12.data_ptr(), L.stream_ptr()), 'pose_chain_fwd')
+        ctx.save_for_backward(jac)
+        ctx.cfg = (b, m, pose.shape[1])
+        return ext, cam
+
+    @staticmethod
+    def backward(ctx, d_ext, d_cam):
+        from . import _lib as L
+        jac, = ctx.saved_tensors
+        b, m, npose = ctx.cfg
+        if d_ext is None and d_cam is None:
+            return None, None, None, None, None
+        d_ext = d_ext.contiguous().float() if d_ext is not None else None
+        d_cam = d_cam.contiguous().float() if d_cam is not None else None
+        d_pose = torch.empty((b, npose), device=jac.device) if ctx.needs_input_grad[0] else None
+        d_tr = torch.empty((b, 3), device=jac.device) if ctx.needs_input_grad[1] else None
+        L.check(L.lib().eg3d_pose_chain_bwd(jac.data_ptr(), L.ptr(d_ext), L.ptr(d_cam), b, m, L.ptr(d_pose), L.ptr(d_tr), L.stream_ptr()), 'pose_chain_bwd')
+        return d_pose, d_tr, None, None, None
+
+
+POSE_CHAIN_KERNEL = os.environ.get('EG3D_POSE_CHAIN', '1') != '0'
+
+
+def pose_chain(pred: torch.Tensor, translation_opt: torch.Tensor, intrinsic: torch.Tensor, radius: float, mode: str):
+    """(extrinsic [B,4,4], c [B,25]) = pose_to_cam(pose_to_rotmat(pred, mode), translation_opt, intrinsic, radius): the fused launch on the
+    GPU, the PyTorch composition elsewhere."""
+    if POSE_CHAIN_KERNEL and pred.is_cuda and pred.dtype == torch.float32 and pred.dim() == 2 and pred.shape[1] == POSE_DIMS[mode] \
+            and translation_opt.shape == (pred.shape[0], 3) and intrinsic.numel() >= 9:
+        return _PoseChainFn.apply(pred, translation_opt, intrinsic, radius, mode)
+    return pose_to_cam(pose_to_rotmat(pred, mode), translation_opt, intrinsic, radius)
+
+
 def line_plane_intersection(plane_normal, plane_point, ray_dir, ray_point, eps=1e-6):
     """training/warping_loss.py:58-72."""
     ndotu = (plane_normal * ray_dir).sum(-1, keepdim=True)
@@ -385,11 +432,17 @@ class LatentProjector:
             self.pose_net = pose_net
             if pose_net is not None:
                 pose_net.requires_grad_(True)
+            hip_small = os.environ.get('EG3D_HIP_ADAM', '1') != '0' and torch.device(dev).type == 'cuda'
             if pose_net is not None:       # 222 tensors: one multi-tensor launch (trainable conv weights are re-packed every step, no version-keyed cache involved)
                 self.cam_optimizer = torch.optim.Adam(list(pose_net.parameters()), lr=cam_lr, betas=(0.9, 0.999), fused=True, capturable=use_graph)
+            elif hip_small:                # one launch instead of torch's nine one-element kernels per optimiser (capturable Adam)
+                self.cam_optimizer = hipops.HipAdam([self.pose_vec], lr=cam_lr, betas=(0.9, 0.999))
             else:
                 self.cam_optimizer = torch.optim.Adam([self.pose_vec], lr=cam_lr, betas=(0.9, 0.999), capturable=use_graph)
-            self.translation_optimizer = torch.optim.Adam([self.translation_opt], lr=translation_lr, capturable=use_graph)
+            if hip_small:
+                self.translation_optimizer = hipops.HipAdam([self.translation_opt], lr=translation_lr)
+            else:
+                self.translation_optimizer = torch.optim.Adam([self.translation_opt], lr=translation_lr, capturable=use_graph)
         self.step_idx = 0
         self.last = {}
         self._reg_stream = None
@@ -496,8 +549,8 @@ class LatentProjector:
     def _step_body_inner(self, w_noise_scale, wn, kw, do_step):
         G = self.G
         if self.optimize_pose:
-            rot = pose_to_rotmat(self.pose_net(self.t255) if self.pose_net is not None else self.pose_vec, self.pose_mode)
-            pred_ext, pred_cam = pose_to_cam(rot, self.translation_opt, self.intrinsic, self.radius)
+            pred = self.pose_net(self.t255) if self.pose_net is not None else self.pose_vec
+            pred_ext, pred_cam = pose_chain(pred, self.translation_opt, self.intrinsic, self.radius, self.pose_mode)
         else:
             pred_ext, pred_cam = None, self.cam
         # The noise regulariser only reads the noise buffers.  While its kernel occupied 17 CUs for ~0.4 ms (rounds 1-2) it ran on a second

@@ -639,6 +639,16 @@ int eg3d_adam_step(const eg3d_adam_list* list, float* workspace, void* stream);
 int eg3d_early_stop_flag(const float* value, float threshold, float* done, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Pose chain of the latent projector (training/projectors/w_projector.py:147-172 with utils/camera_utils.py:201-228 quaternion, :259-273
+ * six-dimensional, :241-257,158-188 Euler): pose vector [B,np] (mode 0: quaternion w,x,y,z, np 4; 1: 6-D, np 6; 2: two angles added to pi/2,
+ * np 2) + optimisable translation [B,3] + intrinsics [9] -> extrinsic ext [B,16] and conditioning vector cam [B,25] = (ext, intrinsics).
+ * jac [B,12,9] (Jacobian of rotation 3x3 + translation 3 with respect to (pose, translation), forward-mode duals) and out12 [B,12] are
+ * caller-owned work buffers the backward reads: d_pose [B,np], d_translation [B,3] (either may be null) from d_ext [B,16] and / or d_cam [B,25]. */
+int eg3d_pose_chain_fwd(const float* pose, const float* translation, const float* intrinsics, int B, int mode, float radius, float* ext, float* cam,
+                        float* jac, float* out12, void* stream);
+int eg3d_pose_chain_bwd(const float* jac, const float* d_ext, const float* d_cam, int B, int mode, float* d_pose, float* d_translation, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Volume renderer -- replaces RaySampler.forward (training/volumetric_rendering/ray_sampler.py:24-73) and
  * ImportanceRenderer.forward (renderer.py:143-195: sample_stratified, sample_from_planes/grid_sample, OSGDecoder
  * triplane.py:124-136, MipRayMarcher2 ray_marcher.py:25-57, sample_importance/sample_pdf, unify_samples), fused

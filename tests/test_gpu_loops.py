@@ -269,6 +269,40 @@ def test_projector_loop_vs_reference(golden, mode):
     _adam_close(list(hip.noise_bufs2.values())[-1].detach().cpu(), g('srbuf_last'), 1e-4, IO.PIN_PROJ_STEPS * 0.01)
 
 
+@pytest.mark.parametrize('mode', ['quat', '6d', 'euler'])
+def test_pose_chain_kernel_vs_reference_fixture(golden, mode):
+    """eg3d_pose_chain_fwd / _bwd (forward-mode duals) against the reference's own pose block (w_projector.py:147-172, lifted by
+    make_golden.py::gen_loss_glue): camera vector and the gradients that reach the pose vector and the translation, for the three
+    parametrisations; and against the PyTorch composition on a batch."""
+    from inv3d_amd import inversion as INV
+    d = golden('loss_glue')
+    g = lambda k: torch.from_numpy(np.asarray(d[f'pose_{mode}_{k}'])).float()           # noqa: E731
+    intrinsic = torch.tensor([4.2647, 0, 0.5, 0, 4.2647, 0.5, 0, 0, 1], device=DEV).unsqueeze(0)
+    pred = g('pred').to(DEV).requires_grad_(True)
+    tr = g('tr').to(DEV).requires_grad_(True)
+    ext, cam = INV.pose_chain(pred, tr, intrinsic, 2.7, mode)
+    assert float((cam.detach().cpu() - g('cam')).abs().max()) <= 2e-6
+    assert float((ext.detach().cpu().reshape(1, 16) - g('cam')[:, :16]).abs().max()) <= 2e-6
+    dp, dt = torch.autograd.grad(cam, [pred, tr], g('gcam').to(DEV))
+    for got, ref in ((dp, g('dpred')), (dt, g('dtr'))):
+        assert float((got.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), (mode, got, ref)
+    # batch of 5 vs the PyTorch composition, gradient through BOTH outputs
+    gen = torch.Generator().manual_seed(5)
+    P = (torch.tensor([INV.POSE_INIT[mode]]) + 0.3 * torch.randn(5, INV.POSE_DIMS[mode], generator=gen)).to(DEV)
+    T = (0.1 * torch.randn(5, 3, generator=gen)).to(DEV)
+    ge, gc = torch.randn(5, 4, 4, generator=gen).to(DEV), torch.randn(5, 25, generator=gen).to(DEV)
+    outs = []
+    for fused in (True, False):
+        p_, t_ = P.clone().requires_grad_(True), T.clone().requires_grad_(True)
+        if fused:
+            e_, c_ = INV.pose_chain(p_, t_, intrinsic, 2.7, mode)
+        else:
+            e_, c_ = INV.pose_to_cam(INV.pose_to_rotmat(p_, mode), t_, intrinsic, 2.7)
+        outs.append((e_.detach(), c_.detach()) + torch.autograd.grad([e_, c_], [p_, t_], [ge, gc]))
+    for a, b in zip(*outs):
+        assert float((a - b).abs().max()) <= 3e-5 * max(1.0, float(b.abs().max())), mode
+
+
 def test_config_c3_at_full_size(golden):
     """BASELINE.json configs[2] at FULL size against the reference itself (tests/golden/make_golden.py::gen_c3_full: w_projector.project's
     loop body on the 512^2 / 128^2 generator built from the reference's classes, with its calc_warping_loss): one camera-preheat step and one
