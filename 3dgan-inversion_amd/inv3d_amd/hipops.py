@@ -1483,6 +1483,7 @@ class HipAdam:
         self.params = list(params)
         dev = self.params[0].device
         self._lr_t = lr if torch.is_tensor(lr) else torch.tensor(float(lr), device=dev)
+        self._lr_host = None if torch.is_tensor(lr) else float(lr)
         self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps)]
         self.step_t = torch.zeros((), device=dev)
         self.state = {p: dict(exp_avg=torch.zeros_like(p, memory_format=torch.contiguous_format),
@@ -1505,8 +1506,9 @@ class HipAdam:
         lr = g['lr']
         if torch.is_tensor(lr):
             self._lr_t = lr
-        else:
+        elif getattr(self, '_lr_host', None) != float(lr):          # (a fill launch per step only when the host value changed)
             self._lr_t.fill_(float(lr))
+            self._lr_host = float(lr)
         items = []
         for p in self.params:
             e = extra_grads.get(p) if extra_grads else None
