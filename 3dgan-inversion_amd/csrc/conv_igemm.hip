@@ -21,6 +21,7 @@
 // Reference semantics being replaced: F.conv2d / F.conv_transpose2d calls of torch_utils/ops/conv2d_resample.py:31-43,
 // 114-136 under modulated_conv2d (training/networks_stylegan2.py:34-91), and their autograd data-gradient.
 #include "common.h"
+#include "det.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -530,7 +531,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
                         if (row_sums) {             // the UPR consecutive lanes of a row (host: Nc % BN == 0, so all of them are here)
                             cs = eg3d_row_group_sum(cs, UPR);
                             if (c4 == 0) {
-                                if (ab.dnoise != nullptr) unsafeAtomicAdd(ab.dnoise + (int64_t)n_first * ab.dnoise_nstride + pixl[u], cs * abc.strength);
+                                if (ab.dnoise != nullptr) eg3d_acc(ab.dnoise + (int64_t)n_first * ab.dnoise_nstride + pixl[u], cs * abc.strength);
                                 accs += cs * nz[u];
                             }
                         }
@@ -544,28 +545,31 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
         eg3d_commit_amax_block(omax, p.out_amax);           // max|out| for the consumer's operand range
         if (do_ds || act_on) {                              // block-level column sums, then one atomic per column
             if (cok && do_ds) {
-                atomicAdd(&ds_lds[c4 * 4 + 0], dsum4.x); atomicAdd(&ds_lds[c4 * 4 + 1], dsum4.y);
-                atomicAdd(&ds_lds[c4 * 4 + 2], dsum4.z); atomicAdd(&ds_lds[c4 * 4 + 3], dsum4.w);
+                [[maybe_unused]] float* gds = ds_out + (int64_t)n_first * p.Nc + col;
+                EG3D_LDS_ACC(&ds_lds[c4 * 4 + 0], gds + 0, dsum4.x); EG3D_LDS_ACC(&ds_lds[c4 * 4 + 1], gds + 1, dsum4.y);
+                EG3D_LDS_ACC(&ds_lds[c4 * 4 + 2], gds + 2, dsum4.z); EG3D_LDS_ACC(&ds_lds[c4 * 4 + 3], gds + 3, dsum4.w);
             }
             if (cok && act_on) {
                 if (ab.dbias != nullptr) {
-                    atomicAdd(&db_lds[c4 * 4 + 0], accb4.x); atomicAdd(&db_lds[c4 * 4 + 1], accb4.y);
-                    atomicAdd(&db_lds[c4 * 4 + 2], accb4.z); atomicAdd(&db_lds[c4 * 4 + 3], accb4.w);
+                    [[maybe_unused]] float* gdb = ab.dbias + col;
+                    EG3D_LDS_ACC(&db_lds[c4 * 4 + 0], gdb + 0, accb4.x); EG3D_LDS_ACC(&db_lds[c4 * 4 + 1], gdb + 1, accb4.y);
+                    EG3D_LDS_ACC(&db_lds[c4 * 4 + 2], gdb + 2, accb4.z); EG3D_LDS_ACC(&db_lds[c4 * 4 + 3], gdb + 3, accb4.w);
                 }
                 if (ab.dd != nullptr) {
-                    atomicAdd(&dq_lds[c4 * 4 + 0], accd4.x); atomicAdd(&dq_lds[c4 * 4 + 1], accd4.y);
-                    atomicAdd(&dq_lds[c4 * 4 + 2], accd4.z); atomicAdd(&dq_lds[c4 * 4 + 3], accd4.w);
+                    [[maybe_unused]] float* gdq = ab.dd + (int64_t)n_first * p.Nc + col;
+                    EG3D_LDS_ACC(&dq_lds[c4 * 4 + 0], gdq + 0, EG3D_DET_DIV(accd4.x, abd4.x)); EG3D_LDS_ACC(&dq_lds[c4 * 4 + 1], gdq + 1, EG3D_DET_DIV(accd4.y, abd4.y));
+                    EG3D_LDS_ACC(&dq_lds[c4 * 4 + 2], gdq + 2, EG3D_DET_DIV(accd4.z, abd4.z)); EG3D_LDS_ACC(&dq_lds[c4 * 4 + 3], gdq + 3, EG3D_DET_DIV(accd4.w, abd4.w));
                 }
-                if (ab.dstrength != nullptr && accs != 0.f) atomicAdd(sc_lds, accs);
+                if (ab.dstrength != nullptr && accs != 0.f) EG3D_LDS_ACC(sc_lds, ab.dstrength, accs);
             }
             __syncthreads();
             if (tid < BN && n0 + tid < p.Nc) {
-                if (do_ds) unsafeAtomicAdd(ds_out + (int64_t)n_first * p.Nc + n0 + tid, ds_lds[tid]);
-                if (act_on && ab.dbias != nullptr) unsafeAtomicAdd(ab.dbias + n0 + tid, db_lds[tid]);
+                if (do_ds) eg3d_acc(ds_out + (int64_t)n_first * p.Nc + n0 + tid, ds_lds[tid]);
+                if (act_on && ab.dbias != nullptr) eg3d_acc(ab.dbias + n0 + tid, db_lds[tid]);
                 if (act_on && ab.dd != nullptr)         // dL/dd = sum dy * z,  z = (pre - bias - noise) / d
-                    unsafeAtomicAdd(ab.dd + (int64_t)n_first * p.Nc + n0 + tid, dq_lds[tid] / (ab.d != nullptr ? ab.d[(int64_t)n_first * p.Nc + n0 + tid] : 1.f));
+                    eg3d_acc(ab.dd + (int64_t)n_first * p.Nc + n0 + tid, dq_lds[tid] / (ab.d != nullptr ? ab.d[(int64_t)n_first * p.Nc + n0 + tid] : 1.f));
             }
-            if (act_on && ab.dstrength != nullptr && tid == 0 && sc_lds[0] != 0.f) unsafeAtomicAdd(ab.dstrength, sc_lds[0]);
+            if (act_on && ab.dstrength != nullptr && tid == 0 && sc_lds[0] != 0.f) eg3d_acc(ab.dstrength, sc_lds[0]);
         }
     } else {
     constexpr int RC = 8;                     // rows per lane whose side inputs are in flight together
@@ -617,7 +621,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
                         omax = fmaxf(omax, fabsf(v));
                         p.out[off] = v;
                     } else if (epi == EG3D_EPI_ATOMIC) {
-                        unsafeAtomicAdd(p.out + off, v);
+                        eg3d_acc(p.out + off, v);
                     } else if (epi == EG3D_EPI_FWD) {
                         v = v * scl[q] + sideb[q] * strength + bias;
                         v = eg3d_pwl_fwd(v, act_slope) * p.gain;
@@ -628,7 +632,7 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
                         if (do_ds) {
                             const float t = v * sideb[q];
                             if (single_n) dsum += t;
-                            else unsafeAtomicAdd(ds_out + (int64_t)rown[wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] * p.Nc + col, t);
+                            else eg3d_acc(ds_out + (int64_t)rown[wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] * p.Nc + col, t);
                         }
                         omax = fmaxf(omax, fabsf(v * scl[q] + sidea[q]));
                         p.out[off] = v * scl[q] + sidea[q];
@@ -638,12 +642,12 @@ __global__ void __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, 
         }
         if (do_ds && single_n) {
             dsum += __shfl_xor(dsum, 32);
-            if (lane < 32 && cok) atomicAdd(&ds_lds[wn * (TN * 32) + j * 32 + lane], dsum);
+            if (lane < 32 && cok) EG3D_LDS_ACC(&ds_lds[wn * (TN * 32) + j * 32 + lane], ds_out + (int64_t)n_first * p.Nc + n0 + wn * (TN * 32) + j * 32 + lane, dsum);
         }
     }
     if (do_ds && single_n) {
         __syncthreads();
-        if (tid < BN && n0 + tid < p.Nc) unsafeAtomicAdd(ds_out + (int64_t)n_first * p.Nc + n0 + tid, ds_lds[tid]);
+        if (tid < BN && n0 + tid < p.Nc) eg3d_acc(ds_out + (int64_t)n_first * p.Nc + n0 + tid, ds_lds[tid]);
     }
     if (epi != EG3D_EPI_ATOMIC) eg3d_commit_amax_block(omax, p.out_amax);
     }
@@ -791,13 +795,21 @@ extern "C" int eg3d_conv2d_igemm_f32(const eg3d_conv_params* pp, void* stream) {
     if ((int64_t)p.Nc * p.w_row * 4 > 0x7fffffe0ll) return EG3D_ERR_TOO_LARGE;       // 31-bit buffer offsets
     if (p.epi == EG3D_EPI_BWD_ACT && !act_bwd_ok(p)) return EG3D_ERR_UNSUPPORTED;     // callers probe with eg3d_conv2d_igemm_act_bwd_ok
     hipStream_t st = (hipStream_t)stream;
+    EG3D_DET_SCOPE(det, stream);
+    if (p.epi == EG3D_EPI_ATOMIC) { EG3D_DET_BIND(det, p.out, (int64_t)p.N * p.Ho * p.Wo * p.ldo); }
+    EG3D_DET_BIND(det, p.ds, (int64_t)(p.ds_replicas > 1 ? p.ds_replicas : 1) * p.N * p.Nc);
+    if (p.epi == EG3D_EPI_BWD_ACT) { EG3D_DET_BIND_ACT(det, p.act_bwd, p.N, p.Nc, (int64_t)p.Ho * p.Wo); }
+    EG3D_DET_COMMIT(det);
+    int rc;
     switch (pick_config(p)) {
-        case 0: return launch_conv<128, 128, 2, 2>(p, st);
-        case 1: return launch_conv<64, 128, 2, 2>(p, st);
-        case 2: return launch_conv<32, 128, 1, 4>(p, st);
-        case 4: return launch_conv<256, 64, 4, 1>(p, st);
-        default: return launch_conv<128, 32, 4, 1>(p, st);
+        case 0: rc = launch_conv<128, 128, 2, 2>(p, st); break;
+        case 1: rc = launch_conv<64, 128, 2, 2>(p, st); break;
+        case 2: rc = launch_conv<32, 128, 1, 4>(p, st); break;
+        case 4: rc = launch_conv<256, 64, 4, 1>(p, st); break;
+        default: rc = launch_conv<128, 32, 4, 1>(p, st); break;
     }
+    EG3D_DET_END(det);
+    return rc;
 }
 
 extern "C" int eg3d_conv2d_igemm_config(const eg3d_conv_params* pp) {

@@ -419,7 +419,11 @@ extern "C" int eg3d_conv2d_lr(const eg3d_conv_lr_params* pp, void* stream) {
     if (p.epi == EG3D_EPI_FWD && p.noise && !p.noise_strength) return EG3D_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     const bool one = p.products == 1;
-    if (p.patch_rows == 4) return one ? launch_lr<false, 4>(*pp, st, 5) : launch_lr<true, 4>(*pp, st, 4);
-    if (p.patch_rows == 2) return one ? launch_lr<false, 2>(*pp, st, 3) : launch_lr<true, 2>(*pp, st, 2);
-    return one ? launch_lr<false, 1>(*pp, st, 1) : launch_lr<true, 1>(*pp, st, 0);
+    EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND_V2(det, p); EG3D_DET_COMMIT(det);
+    int rc;
+    if (p.patch_rows == 4) rc = one ? launch_lr<false, 4>(*pp, st, 5) : launch_lr<true, 4>(*pp, st, 4);
+    else if (p.patch_rows == 2) rc = one ? launch_lr<false, 2>(*pp, st, 3) : launch_lr<true, 2>(*pp, st, 2);
+    else rc = one ? launch_lr<false, 1>(*pp, st, 1) : launch_lr<true, 1>(*pp, st, 0);
+    EG3D_DET_END(det);
+    return rc;
 }

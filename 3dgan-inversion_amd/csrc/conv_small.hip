@@ -9,6 +9,7 @@
 // strided reads (the stride-2 adjoint of the up layers), strided writes (their transposed form), zero padding --, so the 3x3 layers, the
 // up-sampling layers and all their data gradients use it.
 #include "common.h"
+#include "det.h"
 
 namespace {
 
@@ -67,7 +68,7 @@ __global__ void __launch_bounds__(256) conv_small_kernel(const eg3d_conv_params 
     float* o = p.out + (((int64_t)n * p.Ho + ey * p.out_stride + cl.out_py) * p.Wo + ex * p.out_stride + cl.out_px) * p.ldo + o0 + eq * 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-        unsafeAtomicAdd(o + q, (red[0][er][eq * 4 + q] + red[1][er][eq * 4 + q]) + (red[2][er][eq * 4 + q] + red[3][er][eq * 4 + q]));
+        eg3d_acc(o + q, (red[0][er][eq * 4 + q] + red[1][er][eq * 4 + q]) + (red[2][er][eq * 4 + q] + red[3][er][eq * 4 + q]));
 }
 
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -102,7 +103,9 @@ extern "C" int eg3d_conv2d_small_atomic(const eg3d_conv_params* p, void* stream)
     for (int c = 0; c < p->ncls; ++c) max_tiles = std::max(max_tiles, eg3d_cdiv((int64_t)p->cls[c].Ha * p->cls[c].Wa, CS_CELLS));
     if ((int64_t)p->N * max_tiles > 0x7fffffff) return EG3D_ERR_UNSUPPORTED;
     const dim3 grid(p->N * max_tiles, p->Nc / CS_OUT, p->ncls * 9);
+    EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND(det, p->out, (int64_t)p->N * p->Ho * p->Wo * p->ldo); EG3D_DET_COMMIT(det);
     hipLaunchKernelGGL(conv_small_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p, max_tiles);
+    EG3D_DET_END(det);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -428,6 +428,7 @@ extern "C" int eg3d_conv2d_v2(const eg3d_conv_v2_params* pp, void* stream) {
         if (q != nullptr && (reinterpret_cast<uintptr_t>(q) & 15)) return EG3D_ERR_UNSUPPORTED;
     if (p.epi == EG3D_EPI_FWD && p.noise && !p.noise_strength) return EG3D_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
+    EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND_V2(det, p); EG3D_DET_COMMIT(det);
     // classes with the same tap count go into one launch (consecutive classes only: 9 | 4,2,2,1 | 1 ...)
     int c = 0;
     while (c < p.ncls) {
@@ -453,6 +454,7 @@ extern "C" int eg3d_conv2d_v2(const eg3d_conv_v2_params* pp, void* stream) {
         if (rc != EG3D_OK) return rc;
         c = e;
     }
+    EG3D_DET_END(det);
     return EG3D_OK;
 }
 

@@ -2,6 +2,13 @@
 // up-sampling layers): LDS geometry of the 8 x 32 patch x 128 channel tile, the LDS-DMA helper, counted vmcnt waits and the fused epilogue.
 #pragma once
 #include "common.h"
+#include "det.h"
+// accumulation targets of a launch on eg3d_conv_v2_params (split-K output, style gradient, the producer's activation backward)
+#define EG3D_DET_BIND_V2(name, p) do { \
+        if ((p).epi == EG3D_EPI_ATOMIC) EG3D_DET_BIND(name, (p).out, (int64_t)(p).N * (p).Ho * (p).Wo * (p).ldo); \
+        EG3D_DET_BIND(name, (p).ds, (int64_t)(p).N * (p).Nc); \
+        if ((p).epi == EG3D_EPI_BWD_ACT) EG3D_DET_BIND_ACT(name, (p).act_bwd, (p).N, (p).Nc, (int64_t)(p).Ho * (p).Wo); \
+    } while (0)
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -91,7 +98,7 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
                 if (ay >= Ha || ax >= Wa) continue;
                 float* o = p.out + ((int64_t)(n * p.Ho + ay * p.out_stride + cl.out_py) * p.Wo + ax * p.out_stride + cl.out_px) * p.ldo + n0 + wn * 64 + (lane & 31);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) unsafeAtomicAdd(o + j * 32, acc[i][j][r] * out_mul);
+                for (int j = 0; j < 2; ++j) eg3d_acc(o + j * 32, acc[i][j][r] * out_mul);
             }
         }
     } else {
@@ -187,7 +194,7 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
                         if (row_sums) {             // the 32 lanes of a half-wave hold the 128 channels of this pixel (rows are half-wave uniform)
                             cs = eg3d_row_group_sum(cs, 32);
                             if (c4 == 0) {
-                                if (ab.dnoise != nullptr) unsafeAtomicAdd(ab.dnoise + (int64_t)n * ab.dnoise_nstride + pixl[u], cs * abc.strength);
+                                if (ab.dnoise != nullptr) eg3d_acc(ab.dnoise + (int64_t)n * ab.dnoise_nstride + pixl[u], cs * abc.strength);
                                 accs += cs * nz[u];
                             }
                         }
@@ -200,28 +207,31 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
     }
     if (do_ds || act_on) {
         if (do_ds) {
-            atomicAdd(&ds_lds[c4 * 4 + 0], dsum4.x); atomicAdd(&ds_lds[c4 * 4 + 1], dsum4.y);
-            atomicAdd(&ds_lds[c4 * 4 + 2], dsum4.z); atomicAdd(&ds_lds[c4 * 4 + 3], dsum4.w);
+            [[maybe_unused]] float* gds = p.ds + (int64_t)n * p.Nc + col;
+            EG3D_LDS_ACC(&ds_lds[c4 * 4 + 0], gds + 0, dsum4.x); EG3D_LDS_ACC(&ds_lds[c4 * 4 + 1], gds + 1, dsum4.y);
+            EG3D_LDS_ACC(&ds_lds[c4 * 4 + 2], gds + 2, dsum4.z); EG3D_LDS_ACC(&ds_lds[c4 * 4 + 3], gds + 3, dsum4.w);
         }
         if (act_on) {
             if (ab.dbias != nullptr) {
-                atomicAdd(&db_lds[c4 * 4 + 0], accb4.x); atomicAdd(&db_lds[c4 * 4 + 1], accb4.y);
-                atomicAdd(&db_lds[c4 * 4 + 2], accb4.z); atomicAdd(&db_lds[c4 * 4 + 3], accb4.w);
+                [[maybe_unused]] float* gdb = ab.dbias + col;
+                EG3D_LDS_ACC(&db_lds[c4 * 4 + 0], gdb + 0, accb4.x); EG3D_LDS_ACC(&db_lds[c4 * 4 + 1], gdb + 1, accb4.y);
+                EG3D_LDS_ACC(&db_lds[c4 * 4 + 2], gdb + 2, accb4.z); EG3D_LDS_ACC(&db_lds[c4 * 4 + 3], gdb + 3, accb4.w);
             }
             if (ab.dd != nullptr) {
-                atomicAdd(&dq_lds[c4 * 4 + 0], accd4.x); atomicAdd(&dq_lds[c4 * 4 + 1], accd4.y);
-                atomicAdd(&dq_lds[c4 * 4 + 2], accd4.z); atomicAdd(&dq_lds[c4 * 4 + 3], accd4.w);
+                [[maybe_unused]] float* gdq = ab.dd + (int64_t)n * p.Nc + col;
+                EG3D_LDS_ACC(&dq_lds[c4 * 4 + 0], gdq + 0, EG3D_DET_DIV(accd4.x, abd4.x)); EG3D_LDS_ACC(&dq_lds[c4 * 4 + 1], gdq + 1, EG3D_DET_DIV(accd4.y, abd4.y));
+                EG3D_LDS_ACC(&dq_lds[c4 * 4 + 2], gdq + 2, EG3D_DET_DIV(accd4.z, abd4.z)); EG3D_LDS_ACC(&dq_lds[c4 * 4 + 3], gdq + 3, EG3D_DET_DIV(accd4.w, abd4.w));
             }
-            if (ab.dstrength != nullptr && accs != 0.f) atomicAdd(sc_lds, accs);
+            if (ab.dstrength != nullptr && accs != 0.f) EG3D_LDS_ACC(sc_lds, ab.dstrength, accs);
         }
         __syncthreads();
         if (tid < BN) {
-            if (do_ds) unsafeAtomicAdd(p.ds + (int64_t)n * p.Nc + n0 + tid, ds_lds[tid]);
-            if (act_on && ab.dbias != nullptr) unsafeAtomicAdd(ab.dbias + n0 + tid, db_lds[tid]);
+            if (do_ds) eg3d_acc(p.ds + (int64_t)n * p.Nc + n0 + tid, ds_lds[tid]);
+            if (act_on && ab.dbias != nullptr) eg3d_acc(ab.dbias + n0 + tid, db_lds[tid]);
             if (act_on && ab.dd != nullptr)       // dL/dd = sum dy * z,  z = (pre - bias - noise) / d
-                unsafeAtomicAdd(ab.dd + (int64_t)n * p.Nc + n0 + tid, dq_lds[tid] / (ab.d != nullptr ? ab.d[(int64_t)n * p.Nc + n0 + tid] : 1.f));
+                eg3d_acc(ab.dd + (int64_t)n * p.Nc + n0 + tid, dq_lds[tid] / (ab.d != nullptr ? ab.d[(int64_t)n * p.Nc + n0 + tid] : 1.f));
         }
-        if (act_on && ab.dstrength != nullptr && tid == 0 && sc_lds[0] != 0.f) unsafeAtomicAdd(ab.dstrength, sc_lds[0]);
+        if (act_on && ab.dstrength != nullptr && tid == 0 && sc_lds[0] != 0.f) eg3d_acc(ab.dstrength, sc_lds[0]);
     }
     eg3d_commit_amax_block(amax, p.out_amax);    // max|out|: the consumer's operand range (one atomic per block)
     }

@@ -287,9 +287,11 @@ extern "C" int eg3d_conv2d_v2_s2adj(const eg3d_conv_v2_params* pp, void* stream)
     };
     const bool at = p.epi == EG3D_EPI_ATOMIC;
     int rc;
+    EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND_V2(det, p); EG3D_DET_COMMIT(det);
     if (p.products == 1) rc = at ? launch(conv_v2_s2adj_kernel<false, true>, 3) : launch(conv_v2_s2adj_kernel<false, false>, 1);
     else rc = at ? launch(conv_v2_s2adj_kernel<true, true>, 2) : launch(conv_v2_s2adj_kernel<true, false>, 0);
     if (rc) return rc;
+    EG3D_DET_END(det);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -16,6 +16,7 @@
 // Operand images as in conv_v2.hip (eg3d_split_activation / eg3d_split_weight); same arithmetic: three fp16 products per fp32 product, or
 // the high pieces only (products = 1).
 #include "common.h"
+#include "det.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -161,7 +162,7 @@ __global__ void __launch_bounds__(512, 2) conv_v2_up2_kernel(const eg3d_conv_up2
                 for (int par = 0; par < 4; ++par) {
                     const int y = 2 * a + (par >> 1), x = 2 * b + (par & 1);
                     if (y >= p.Ho || x >= p.Wo) continue;
-                    unsafeAtomicAdd(p.out + ((int64_t)(n * p.Ho + y) * p.Wo + x) * p.ldo + n0 + wn * 32 + (lane & 31), acc[i][par][r] * out_mul);
+                    eg3d_acc(p.out + ((int64_t)(n * p.Ho + y) * p.Wo + x) * p.ldo + n0 + wn * 32 + (lane & 31), acc[i][par][r] * out_mul);
                 }
             }
         }
@@ -221,6 +222,9 @@ extern "C" int eg3d_conv2d_up2(const eg3d_conv_up2_params* pp, void* stream) {
     const int tiles = p.N * eg3d_cdiv(p.Hc, PH) * eg3d_cdiv(p.Wc, PW) * (p.Nc / BN);
     const dim3 grid(tiles, p.ksplit > 1 ? p.ksplit : 1, 1);
     hipStream_t st = (hipStream_t)stream;
+    EG3D_DET_SCOPE(det, stream);
+    if (p.epi == EG3D_EPI_ATOMIC) { EG3D_DET_BIND(det, p.out, (int64_t)p.N * p.Ho * p.Wo * p.ldo); }
+    EG3D_DET_COMMIT(det);
     if (p.products == 1) {
         auto kern = conv_v2_up2_kernel<false>;
         if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, g_attr_up[1])) return e;
@@ -230,6 +234,7 @@ extern "C" int eg3d_conv2d_up2(const eg3d_conv_up2_params* pp, void* stream) {
         if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, g_attr_up[0])) return e;
         hipLaunchKernelGGL(kern, grid, dim3(512), LDS_BYTES, st, p);
     }
+    EG3D_DET_END(det);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -12,6 +12,7 @@
 // Replaces autograd's aten::convolution_backward (weight) for the PTI phase (training/coaches/base_coach.py:96-99,
 // torch_utils/ops/conv2d_gradfix.py:166-173).
 #include "common.h"
+#include "det.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -170,7 +171,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const eg3d_wgrad_params
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = o0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (o < p.Nc) unsafeAtomicAdd(p.dw + (int64_t)o * p.w_row + (int64_t)wt * p.Ck + k, acc[i][j][r]);
+                if (o < p.Nc) eg3d_acc(p.dw + (int64_t)o * p.w_row + (int64_t)wt * p.Ck + k, acc[i][j][r]);
             }
         }
 }
@@ -407,7 +408,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_f16x3_kernel(const eg3d_wgr
     if (k < p.Ck) {
         float* dst = p.dw + (int64_t)wt * p.Ck + k;
         for (int ol = tid >> 7; ol < 128; ol += 2)
-            if (o0 + ol < p.Nc) unsafeAtomicAdd(dst + (int64_t)(o0 + ol) * p.w_row, stage[ol * LDS_K + kl]);
+            if (o0 + ol < p.Nc) eg3d_acc(dst + (int64_t)(o0 + ol) * p.w_row, stage[ol * LDS_K + kl]);
     }
 }
 
@@ -447,6 +448,7 @@ extern "C" int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* pp, void* stream) 
         p.psplit = (int)std::max<int64_t>(1, std::min<int64_t>(want, std::max<int64_t>(1, steps / 8)));
     }
     if (p.precision != EG3D_PREC_F32 && !f16) return EG3D_ERR_UNSUPPORTED;
+    EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND(det, p.dw, (int64_t)p.Nc * p.w_row); EG3D_DET_COMMIT(det);
     if (f16) {
         static std::atomic<uint64_t> attr16{0}, attr16one{0};
         const size_t smem16 = (size_t)2 * H_STAGE;
@@ -455,6 +457,7 @@ extern "C" int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* pp, void* stream) 
         if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)smem16, one ? attr16one : attr16)) return e;
         dim3 grid16(tiles_o * tiles_i, ntap_total, p.psplit);
         hipLaunchKernelGGL(kern, grid16, dim3(256), smem16, (hipStream_t)stream, p, tiles_o, tiles_i, ntap_total);
+        EG3D_DET_END(det);
         EG3D_LAUNCH_CHECK();
         return EG3D_OK;
     }
@@ -463,6 +466,7 @@ extern "C" int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* pp, void* stream) 
     if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_wgrad_kernel), (int)smem, attr_done)) return e;
     dim3 grid(tiles_o * tiles_i, ntap_total, p.psplit);
     hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), smem, (hipStream_t)stream, p, tiles_o, tiles_i, ntap_total);
+    EG3D_DET_END(det);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

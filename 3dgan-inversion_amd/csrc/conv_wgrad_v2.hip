@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_v2_kernel(const eg3d_wgrad_
         for (int r = 0; r < 16; ++r) {
             const int o = to * WG_TO + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (p.slabs) dst[(int64_t)o * p.w_row] = acc[t][r] * mul;          // this workgroup's own slab: plain stores, summed in slab order later
-            else unsafeAtomicAdd(dst + (int64_t)o * p.w_row, acc[t][r] * mul);
+            else eg3d_acc(dst + (int64_t)o * p.w_row, acc[t][r] * mul);
         }
     }
 }
@@ -229,6 +229,12 @@ extern "C" int eg3d_conv2d_wgrad_v2(const eg3d_wgrad_v2_params* pp, void* stream
     const int rg = wg_row_groups(p);
     hipStream_t st = (hipStream_t)stream;
     const bool one = p.products == 1;
-    if (p.ntaps == 9) return one ? launch_wg<1, 9>(p, rg, st, 0) : launch_wg<2, 9>(p, rg, st, 1);
-    return one ? launch_wg<1, 1>(p, rg, st, 2) : launch_wg<2, 1>(p, rg, st, 3);
+    EG3D_DET_SCOPE(det, stream);
+    if (!p.slabs) { EG3D_DET_BIND(det, p.dw, (int64_t)p.Co * p.w_row); }
+    EG3D_DET_COMMIT(det);
+    int rc;
+    if (p.ntaps == 9) rc = one ? launch_wg<1, 9>(p, rg, st, 0) : launch_wg<2, 9>(p, rg, st, 1);
+    else rc = one ? launch_wg<1, 1>(p, rg, st, 2) : launch_wg<2, 1>(p, rg, st, 3);
+    EG3D_DET_END(det);
+    return rc;
 }

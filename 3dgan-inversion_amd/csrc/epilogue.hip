@@ -9,6 +9,7 @@
 //    (networks_stylegan2.py:62-66) factored as sum_k s^2 * (sum_taps w^2), so that the conv can share weights
 //    across the batch (activation-scaled formulation, numerically interchangeable: SURVEY.md section 7).
 #include "common.h"
+#include "det.h"
 #include <cstdlib>
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef __fp16 ue_fp16x2 __attribute__((ext_vector_type(2)));
@@ -492,11 +493,11 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const Fin
                     if (pow2) {
                         s = eg3d_row_group_sum(s, grp);
                         if ((threadIdx.x & (grp - 1)) == 0) {
-                            if (dnoise) unsafeAtomicAdd(dnoise + (int64_t)n * dnoise_nstride + pix, s * strength);
+                            if (dnoise) eg3d_acc(dnoise + (int64_t)n * dnoise_nstride + pix, s * strength);
                             accs += s * nraw[u];
                         }
                     } else {
-                        if (dnoise) unsafeAtomicAdd(dnoise + (int64_t)n * dnoise_nstride + pix, s * strength);
+                        if (dnoise) eg3d_acc(dnoise + (int64_t)n * dnoise_nstride + pix, s * strength);
                         accs += s * nraw[u];
                     }
                 }
@@ -528,7 +529,7 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const Fin
     if (active) { st4(rb + (pl * C4 + c4) * 4, accb); st4(rd + (pl * C4 + c4) * 4, accd); }
     if (FIN && active) st4(rz + (pl * C4 + c4) * 4, accz);
     __syncthreads();
-    if (dstrength && accs != 0.f) atomicAdd(rs, accs);
+    if (dstrength && accs != 0.f) EG3D_LDS_ACC(rs, dstrength, accs);
     // pixel lanes -> one sum per channel: a tree over the pixel index (with 4 channels there are 1024 pixel lanes per block: summed by one
     // thread this tail took longer than the pass itself), skipped when no per-channel sum is asked for (a clamp-only pass)
     const bool want_cs = dbias != nullptr || dd != nullptr || (FIN && fin.ds != nullptr);
@@ -552,22 +553,22 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) epilogue_bwd_kernel(const Fin
     if (want_cs && threadIdx.x < C4) {
         const float4 sb = ld4(rb + c4 * 4), sd = ld4(rd + c4 * 4);
         if (dbias) {
-            unsafeAtomicAdd(dbias + c + 0, sb.x); unsafeAtomicAdd(dbias + c + 1, sb.y);
-            unsafeAtomicAdd(dbias + c + 2, sb.z); unsafeAtomicAdd(dbias + c + 3, sb.w);
+            eg3d_acc(dbias + c + 0, sb.x); eg3d_acc(dbias + c + 1, sb.y);
+            eg3d_acc(dbias + c + 2, sb.z); eg3d_acc(dbias + c + 3, sb.w);
         }
         if (dd) {     // dL/dd = sum dy * z,  z = (pre - bias - noise) / d
             float* q = dd + (int64_t)n * C + c;
-            unsafeAtomicAdd(q + 0, sd.x / dv.x); unsafeAtomicAdd(q + 1, sd.y / dv.y);
-            unsafeAtomicAdd(q + 2, sd.z / dv.z); unsafeAtomicAdd(q + 3, sd.w / dv.w);
+            eg3d_acc(q + 0, sd.x / dv.x); eg3d_acc(q + 1, sd.y / dv.y);
+            eg3d_acc(q + 2, sd.z / dv.z); eg3d_acc(q + 3, sd.w / dv.w);
         }
         if (FIN && fin.ds) {
             const float4 sz = ld4(rz + c4 * 4);
             float* q = fin.ds + (int64_t)n * C + c;
-            unsafeAtomicAdd(q + 0, sz.x); unsafeAtomicAdd(q + 1, sz.y); unsafeAtomicAdd(q + 2, sz.z); unsafeAtomicAdd(q + 3, sz.w);
+            eg3d_acc(q + 0, sz.x); eg3d_acc(q + 1, sz.y); eg3d_acc(q + 2, sz.z); eg3d_acc(q + 3, sz.w);
         }
     }
     __syncthreads();
-    if (dstrength && threadIdx.x == 0 && rs[0] != 0.f) unsafeAtomicAdd(dstrength, rs[0]);
+    if (dstrength && threadIdx.x == 0 && rs[0] != 0.f) eg3d_acc(dstrength, rs[0]);
     if (dz_amax != nullptr) {                 // max|dz|: non-negative floats order like their bit patterns; one global atomic per block
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
@@ -622,7 +623,7 @@ __global__ void __launch_bounds__(EPI_BWD_THREADS) dgrad_finish_kernel(const flo
         float4 t = make_float4(0, 0, 0, 0);
         for (int q = 0; q < ppb; ++q) { float4 u = ld4(red + (q * C4 + c4) * 4); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
         float* q = ds + (int64_t)n * C + c;
-        unsafeAtomicAdd(q + 0, t.x); unsafeAtomicAdd(q + 1, t.y); unsafeAtomicAdd(q + 2, t.z); unsafeAtomicAdd(q + 3, t.w);
+        eg3d_acc(q + 0, t.x); eg3d_acc(q + 1, t.y); eg3d_acc(q + 2, t.z); eg3d_acc(q + 3, t.w);
     }
 }
 
@@ -780,7 +781,7 @@ __global__ void __launch_bounds__(256) demod_bwd_kernel(const float* __restrict_
     __syncthreads();
     if (sl == 0 && k < Ck) {
         float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-        unsafeAtomicAdd(ds + (int64_t)n * Ck + k, -s[(int64_t)n * Ck + k] * t);
+        eg3d_acc(ds + (int64_t)n * Ck + k, -s[(int64_t)n * Ck + k] * t);
     }
 }
 
@@ -850,12 +851,17 @@ extern "C" int eg3d_modconv_epilogue_bwd(const float* dout, const float* out, fl
     int bx = std::max(1, std::min(eg3d_cdiv((int64_t)H * W, ppb * 4), std::max(1, cap / N)));
     size_t smem = (size_t)(ppb * C4 * 8 + 4) * sizeof(float);
     const FinArgs nofin = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    EG3D_DET_SCOPE(det, stream);
+    EG3D_DET_BIND(det, dbias, C); EG3D_DET_BIND(det, dd, (int64_t)N * C); EG3D_DET_BIND(det, dnoise, (int64_t)(N - 1) * dnoise_nstride + (int64_t)H * W);
+    EG3D_DET_BIND(det, dstrength, 1);
+    EG3D_DET_COMMIT(det);
     if (eg3d_act_is_pwl(act))
         hipLaunchKernelGGL((epilogue_bwd_kernel<true, false>), dim3(bx, N), dim3(EPI_BWD_THREADS), smem, (hipStream_t)stream, nofin, dout, out, dz, H, W, C4, d, noise, noise_nstride,
                            noise_strength, bias, act, eg3d_act_pwl_slope(act, alpha), gain, clamp, dbias, dd, dnoise, dnoise_nstride, dstrength, dz_amax);
     else
         hipLaunchKernelGGL((epilogue_bwd_kernel<false, false>), dim3(bx, N), dim3(EPI_BWD_THREADS), smem, (hipStream_t)stream, nofin, dout, out, dz, H, W, C4, d, noise, noise_nstride,
                            noise_strength, bias, act, alpha, gain, clamp, dbias, dd, dnoise, dnoise_nstride, dstrength, dz_amax);
+    EG3D_DET_END(det);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }
@@ -873,9 +879,11 @@ extern "C" int eg3d_dgrad_finish_act(const float* z, const float* x, const float
     auto kern = epilogue_bwd_kernel<true, true>;
     if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)smem, attr_done)) return e;
     const FinArgs fin = {z, s, addend, ds, nullptr, nullptr};
+    EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND(det, ds, (int64_t)N * C); EG3D_DET_BIND_ACT(det, *ab, N, C, (int64_t)H * W); EG3D_DET_COMMIT(det);
     hipLaunchKernelGGL(kern, dim3(bx, N), dim3(EPI_BWD_THREADS), smem, (hipStream_t)stream, fin, nullptr, x, dz, H, W, C4, ab->d, ab->noise, ab->noise_nstride,
                        ab->noise_strength, ab->bias, ab->act, eg3d_act_pwl_slope(ab->act, ab->alpha), ab->gain, ab->clamp, ab->dbias, ab->dd, ab->dnoise,
                        ab->dnoise_nstride, ab->dstrength, dz_amax);
+    EG3D_DET_END(det);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }
@@ -893,9 +901,11 @@ extern "C" int eg3d_torgb_dgrad_act(const float* dy4, const float* wa4, const fl
     auto kern = epilogue_bwd_kernel<true, true>;
     if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)smem, attr_done)) return e;
     const FinArgs fin = {nullptr, s, addend, ds, dy4, wa4, nullptr, nullptr, nullptr, nullptr};
+    EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND(det, ds, (int64_t)N * C); EG3D_DET_BIND_ACT(det, *ab, N, C, (int64_t)H * W); EG3D_DET_COMMIT(det);
     hipLaunchKernelGGL(kern, dim3(bx, N), dim3(EPI_BWD_THREADS), smem, (hipStream_t)stream, fin, nullptr, x, dz, H, W, C4, ab->d, ab->noise, ab->noise_nstride,
                        ab->noise_strength, ab->bias, ab->act, eg3d_act_pwl_slope(ab->act, ab->alpha), ab->gain, ab->clamp, ab->dbias, ab->dd, ab->dnoise,
                        ab->dnoise_nstride, ab->dstrength, dz_amax);
+    EG3D_DET_END(det);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }
@@ -918,9 +928,11 @@ extern "C" int eg3d_torgb_dgrad_act_split(const float* dy4, const float* wa4, co
     auto kern = epilogue_bwd_kernel<true, true, true>;
     if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)smem, attr_done)) return e;
     const FinArgs fin = {nullptr, s, addend, ds, dy4, wa4, reinterpret_cast<uint2*>(split_image), dy_amax, addend ? addend_amax : nullptr, split_scale_out};
+    EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND(det, ds, (int64_t)N * C); EG3D_DET_BIND_ACT(det, *ab, N, C, (int64_t)H * W); EG3D_DET_COMMIT(det);
     hipLaunchKernelGGL(kern, dim3(bx, N), dim3(EPI_BWD_THREADS), smem, (hipStream_t)stream, fin, nullptr, x, dz, H, W, C4, ab->d, ab->noise, ab->noise_nstride,
                        ab->noise_strength, ab->bias, ab->act, eg3d_act_pwl_slope(ab->act, ab->alpha), ab->gain, ab->clamp, ab->dbias, ab->dd, ab->dnoise,
                        ab->dnoise_nstride, ab->dstrength, nullptr);
+    EG3D_DET_END(det);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }
@@ -931,8 +943,10 @@ extern "C" int eg3d_dgrad_finish(const float* z, const float* x, const float* s,
     if (C % 4 || C / 4 > 256) return EG3D_ERR_UNSUPPORTED;
     const int C4 = C / 4, ppb = std::max(EPI_BWD_THREADS / C4, 1);
     int bx = std::max(1, std::min(eg3d_cdiv((int64_t)H * W, ppb * 8), std::max(1, epi_bwd_cap() / N)));
+    EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND(det, ds, (int64_t)N * C); EG3D_DET_COMMIT(det);
     hipLaunchKernelGGL(dgrad_finish_kernel, dim3(bx, N), dim3(EPI_BWD_THREADS), (size_t)ppb * C4 * 4 * sizeof(float), (hipStream_t)stream, z, x, s, addend, dx, ds,
                        H * W, C4);
+    EG3D_DET_END(det);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }
@@ -1034,7 +1048,9 @@ extern "C" int eg3d_demod_bwd(const float* s, const float* wsq, const float* d, 
     if (!s || !wsq || !d || !dd || N <= 0 || Co <= 0 || Ck <= 0) return EG3D_ERR_INVALID;
     if (ds) {
         const int osplit = std::max(1, std::min(Co / 16, 16));
+        EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND(det, ds, (int64_t)N * Ck); EG3D_DET_COMMIT(det);
         hipLaunchKernelGGL(demod_bwd_kernel, dim3(eg3d_cdiv(Ck, 64), N, osplit), dim3(256), 0, (hipStream_t)stream, s, wsq, d, dd, ds, N, Co, Ck, osplit);
+        EG3D_DET_END(det);
     }
     if (dwsq) hipLaunchKernelGGL(demod_bwd_wsq_kernel, dim3(eg3d_cdiv((int64_t)Co * Ck, 256)), dim3(256), 0, (hipStream_t)stream, s, d, dd, dwsq, N, Co, Ck);
     EG3D_LAUNCH_CHECK();

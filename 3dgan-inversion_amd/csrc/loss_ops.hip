@@ -9,6 +9,7 @@
 //   the square root of the learned 1x1 "lin" weight and by 1/sqrt(H*W), so that the plain squared distance of two such vectors is
 //   the LPIPS distance), written straight into a slice of the flat feature vector.
 #include "common.h"
+#include "det.h"
 
 namespace {
 
@@ -193,7 +194,7 @@ __global__ void __launch_bounds__(NT) sqdist_fwd_kernel(const float* __restrict_
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(out + n, (red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) eg3d_acc(out + n, (red[0] + red[1]) + (red[2] + red[3]));
 }
 
 __global__ void __launch_bounds__(NT) sqdist_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ g,
@@ -217,8 +218,8 @@ __device__ __forceinline__ void block_sum_commit(float s, float* __restrict__ te
     __syncthreads();
     if (threadIdx.x == 0) {
         const float v = (red[0] + red[1]) + (red[2] + red[3]);
-        if (term) unsafeAtomicAdd(term, v * term_scale);
-        if (total) unsafeAtomicAdd(total, v * total_scale);
+        if (term) eg3d_acc(term, v * term_scale);
+        if (total) eg3d_acc(total, v * total_scale);
     }
 }
 
@@ -446,7 +447,9 @@ extern "C" int eg3d_image_prepare_bwd(const float* dout, float* dimg, int N, int
 extern "C" int eg3d_sqdist_fwd(const float* a, const float* b, float* out, int N, int64_t F, void* stream) {
     if (!a || !b || !out || N < 1 || F < 4 || (F & 3) || !aligned16(a) || !aligned16(b)) return EG3D_ERR_INVALID;
     const int bx = (int)std::min<int64_t>(256, (F / 4 + NT * 4 - 1) / (NT * 4));
+    EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND(det, out, N); EG3D_DET_COMMIT(det);
     hipLaunchKernelGGL(sqdist_fwd_kernel, dim3(std::max(bx, 1), N), dim3(NT), 0, (hipStream_t)stream, a, b, out, F);
+    EG3D_DET_END(det);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }
@@ -462,8 +465,10 @@ extern "C" int eg3d_sqdist_bwd(const float* a, const float* b, const float* g, f
 extern "C" int eg3d_sqdist_sum_fwd(const float* a, const float* b, int64_t n, float* term, float term_scale, float* total, float total_scale, void* stream) {
     if (!a || !b || n < 4 || (n & 3) || !aligned16(a) || !aligned16(b) || (!term && !total)) return EG3D_ERR_INVALID;
     const int bx = (int)std::min<int64_t>(512, (n / 4 + NT * 4 - 1) / (NT * 4));
+    EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND(det, term, 1); EG3D_DET_BIND(det, total, 1); EG3D_DET_COMMIT(det);
     hipLaunchKernelGGL(sqdist_sum_fwd_kernel, dim3(std::max(bx, 1)), dim3(NT), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(a),
                        reinterpret_cast<const float4*>(b), n / 4, term, term_scale, total, total_scale);
+    EG3D_DET_END(det);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }
@@ -478,8 +483,10 @@ extern "C" int eg3d_sqdist_sum_bwd(const float* a, const float* b, const float* 
 
 extern "C" int eg3d_tv_norm_fwd(const float* v, int B, int H, int W, float* term, float term_scale, float* total, float total_scale, void* stream) {
     if (!v || B < 1 || H < 2 || W < 2 || (!term && !total)) return EG3D_ERR_INVALID;
+    EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND(det, term, 1); EG3D_DET_BIND(det, total, 1); EG3D_DET_COMMIT(det);
     hipLaunchKernelGGL(tv_norm_fwd_kernel, dim3(grid_blocks((int64_t)B * H * W)), dim3(NT), 0, (hipStream_t)stream, v, B, H, W, term, term_scale, total,
                        total_scale);
+    EG3D_DET_END(det);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -6,6 +6,7 @@
 // buffers AND its gradient (pyramid -> moments -> gradient, below), two renormalise all buffers.
 //   reg = sum_buffers sum_levels ( mean(x * roll(x,1,W)) ^2 + mean(x * roll(x,1,H)) ^2 ),  levels: res, res/2, ... while res > 8
 #include "common.h"
+#include "det.h"
 
 namespace {
 
@@ -124,7 +125,7 @@ __global__ void __launch_bounds__(NT) noise_moments2_kernel(const NoiseBufs B, c
         if (start + threadIdx.x + u * NT < n) { sx += c[u] * lx[u]; sy += c[u] * uy[u]; }
     sx = block_sum(sx, red);
     sy = block_sum(sy, red);
-    if (threadIdx.x == 0) { unsafeAtomicAdd(sums + (b * MAXL + l) * 2, sx); unsafeAtomicAdd(sums + (b * MAXL + l) * 2 + 1, sy); }
+    if (threadIdx.x == 0) { eg3d_acc(sums + (b * MAXL + l) * 2, sx); eg3d_acc(sums + (b * MAXL + l) * 2 + 1, sy); }
 }
 
 __global__ void __launch_bounds__(NT) noise_grad_kernel(const NoiseBufs B, const float* __restrict__ ws, const float* __restrict__ sums, float* __restrict__ reg_out,
@@ -150,7 +151,7 @@ __global__ void __launch_bounds__(NT) noise_grad_kernel(const NoiseBufs B, const
             part = mx * mx + my * my;
         }
         for (int m = 8; m >= 1; m >>= 1) part += __shfl_xor(part, m, 16);
-        if (blk == 0 && threadIdx.x == 0) unsafeAtomicAdd(reg_out, part * scale);          // this buffer's part of the value
+        if (blk == 0 && threadIdx.x == 0) eg3d_acc(reg_out, part * scale);          // this buffer's part of the value
     }
     float* gout = B.g[b];
     if (gout == nullptr) return;
@@ -213,7 +214,7 @@ __global__ void __launch_bounds__(NT) noise_moments_kernel(const NoiseBufs B, fl
     for (int i = start + threadIdx.x; i < min(n, start + NORM_CHUNK); i += NT) { const float v = x[i]; s += v; q += v * v; }
     s = block_sum(s, red);
     q = block_sum(q, red);
-    if (threadIdx.x == 0) { unsafeAtomicAdd(ws + 2 * buf, s); unsafeAtomicAdd(ws + 2 * buf + 1, q); }
+    if (threadIdx.x == 0) { eg3d_acc(ws + 2 * buf, s); eg3d_acc(ws + 2 * buf + 1, q); }
 }
 
 __global__ void __launch_bounds__(NT) noise_apply_norm_kernel(const NoiseBufs B, const float* __restrict__ ws) {
@@ -275,7 +276,7 @@ __global__ void __launch_bounds__(NT) adam_step_kernel(const eg3d_adam_list A, f
         if (it.normalize) {                  // (block-uniform)
             s = block_sum(s, red);
             q = block_sum(q, red);
-            if (threadIdx.x == 0) { unsafeAtomicAdd(ws + 2 * item, s); unsafeAtomicAdd(ws + 2 * item + 1, q); }
+            if (threadIdx.x == 0) { eg3d_acc(ws + 2 * item, s); eg3d_acc(ws + 2 * item + 1, q); }
         }
     }
     if (A.bump_step && threadIdx.x == 0) {
@@ -340,9 +341,12 @@ extern "C" int eg3d_noise_regularizer(float* const* x, float* const* grad, const
         nb3 += eg3d_cdiv((int64_t)res[i] * res[i], CHUNK);
     }
     float* sums = workspace + pyr;
+    EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND(det, sums, 2 * MAXL * MAXB); EG3D_DET_BIND(det, reg_out, 1); EG3D_DET_COMMIT(det);
     hipLaunchKernelGGL(noise_pyramid_kernel, dim3(nb1), dim3(NT), 0, st, B, workspace, sums, reg_out);     // also zeroes the moments and reg_out
     hipLaunchKernelGGL(noise_moments2_kernel, dim3(nb2), dim3(NT), 0, st, B, workspace, sums);
+    EG3D_DET_FLUSH(det);
     hipLaunchKernelGGL(noise_grad_kernel, dim3(nb3), dim3(NT), 0, st, B, workspace, sums, reg_out, scale);
+    EG3D_DET_END(det);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }
@@ -356,7 +360,9 @@ extern "C" int eg3d_noise_normalize(float* const* x, const int32_t* res, int nbu
     } else {                                  // workspace: 2 * nbufs floats, zeroed by the caller
         int blocks = 0;
         for (int i = 0; i < nbufs; ++i) blocks += eg3d_cdiv((int64_t)res[i] * res[i], NORM_CHUNK);
+        EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND(det, workspace, 2 * nbufs); EG3D_DET_COMMIT(det);
         hipLaunchKernelGGL(noise_moments_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, B, workspace);
+        EG3D_DET_END(det);
         hipLaunchKernelGGL(noise_apply_norm_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, B, workspace);
     }
     EG3D_LAUNCH_CHECK();
@@ -372,7 +378,11 @@ extern "C" int eg3d_adam_step(const eg3d_adam_list* list, float* workspace, void
         blocks += (int)eg3d_cdiv(it.n, ADAM_CHUNK);
         norm |= it.normalize;
     }
+    EG3D_DET_SCOPE(det, stream);
+    if (norm) { EG3D_DET_BIND(det, workspace, 2 * list->n); }
+    EG3D_DET_COMMIT(det);
     hipLaunchKernelGGL(adam_step_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, *list, workspace);
+    EG3D_DET_END(det);
     if (norm) hipLaunchKernelGGL(adam_apply_norm_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, *list, workspace);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;

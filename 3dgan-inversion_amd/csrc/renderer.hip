@@ -17,6 +17,7 @@
 // bytes of LDS per ray.  The composite colour uses  sum_i w_i (c_i + c_{i+1})/2 = sum_j c_j (w_{j-1} + w_j)/2  so the
 // 2 x 32 colours of a thread never leave its registers.
 #include "common.h"
+#include "det.h"
 #include "render_common.h"
 
 namespace {
@@ -812,7 +813,7 @@ __global__ void __launch_bounds__(ACC_THREADS) scatter_accum_kernel(const float*
         if (v != 0.f) {
             const int cell = i / FC, ch = i - cell * FC;
             const int yy = ty0 + cell / TROWS, xx = tx0 + cell % TROWS;
-            if (yy < Hp && xx < Wp) unsafeAtomicAdd(d_planes + (int64_t)n * Hp * Wp * ldp + ((int64_t)yy * Wp + xx) * ldp + pl * FC + ch, v);
+            if (yy < Hp && xx < Wp) eg3d_acc(d_planes + (int64_t)n * Hp * Wp * ldp + ((int64_t)yy * Wp + xx) * ldp + pl * FC + ch, v);
         }
     }
 }
@@ -986,7 +987,7 @@ __global__ void __launch_bounds__(WAVES * 64) scatter_accum2_kernel(const float*
         if (v != 0.f) {
             const int cell = i / FC, ch = i - cell * FC;
             const int yy = ty0 + cell / TROWS, xx = tx0 + cell % TROWS;
-            if (yy < Hp && xx < Wp) unsafeAtomicAdd(d_planes + (int64_t)n * Hp * Wp * ldp + ((int64_t)yy * Wp + xx) * ldp + pl * FC + ch, v);
+            if (yy < Hp && xx < Wp) eg3d_acc(d_planes + (int64_t)n * Hp * Wp * ldp + ((int64_t)yy * Wp + xx) * ldp + pl * FC + ch, v);
         }
     }
 }
@@ -1092,6 +1093,43 @@ __global__ void __launch_bounds__(1024) scatter_scan16_kernel(const int* __restr
     for (int i = t; i < n; i += 1024) offsets[i] = v[i + (i >> 5)];
 }
 
+#if EG3D_DET
+// Deterministic build: the place pass above hands out list positions with atomics, so the ORDER of a list's records differs from run to run,
+// and scatter_accum16p_kernel sums a list in record order.  One block per list sorts its records by gradient row (unique within a list:
+// a (sample, plane) pair has exactly one list) -- after that the list is a function of the inputs alone.  Bitonic network in its
+// ascending-only ("flip") form, which needs no padding: a partner index beyond the list is skipped.  Lists of up to 4096 records are
+// sorted in LDS, longer ones in place in global memory.
+constexpr int SORT16_LDS = 4096;
+__global__ void __launch_bounds__(256) scatter_sort16_kernel(const int* __restrict__ offsets, float4* __restrict__ recs) {
+    __shared__ __attribute__((aligned(16))) float4 sm[SORT16_LDS];
+    const int beg = offsets[blockIdx.x], n = offsets[blockIdx.x + 1] - beg;
+    if (n < 2) return;
+    float4* g = recs + beg;
+    float4* a = n <= SORT16_LDS ? sm : g;
+    if (n <= SORT16_LDS) {
+        for (int i = threadIdx.x; i < n; i += 256) sm[i] = g[i];
+    }
+    __syncthreads();
+    auto key = [](const float4& r) { return __float_as_int(r.x) & 0x7ffffff; };
+    auto cmpx = [&](int i, int l) {
+        if (l > i && l < n) {
+            const float4 u = a[i], v = a[l];
+            if (key(v) < key(u)) { a[i] = v; a[l] = u; }
+        }
+    };
+    for (int k = 2; (k >> 1) < n; k <<= 1) {
+        for (int i = threadIdx.x; i < n; i += 256) cmpx(i, i ^ (k - 1));
+        __syncthreads();
+        for (int j = k >> 2; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += 256) cmpx(i, i ^ j);
+            __syncthreads();
+        }
+    }
+    if (n <= SORT16_LDS)
+        for (int i = threadIdx.x; i < n; i += 256) g[i] = sm[i];
+}
+#endif
+
 // ---- accumulate: persistent waves, one (tile, row) list at a time -------------------------------------------------------------------
 //   * A super-step = 64 pairs: lane i loads record i (coalesced 16 bytes).  The gradient row of a pair goes straight from global memory
 //     into the B register of its MFMA (two 128-byte rows per load instruction; row ids by `ds_bpermute` from the record registers).
@@ -1189,7 +1227,7 @@ __global__ void __launch_bounds__(ACCP_WAVES * 64) scatter_accum16p_kernel(const
         for (int r = 0; r < 16; ++r) {
             const int m = (r & 3) + 8 * (r >> 2) + 4 * kk;
             const int yy = yy0 + (m >> 4), xx = tx0 + (m & 15);
-            if (yy >= 0 && yy < Hp && xx < Wp && acc[r] != 0.f) unsafeAtomicAdd(base + ((int64_t)yy * Wp + xx) * ldp, acc[r]);
+            if (yy >= 0 && yy < Hp && xx < Wp && acc[r] != 0.f) eg3d_acc(base + ((int64_t)yy * Wp + xx) * ldp, acc[r]);
         }
     }
 }
@@ -1306,7 +1344,7 @@ __global__ void __launch_bounds__(ACCP_WAVES * 64) scatter_accum16h_kernel(const
             const int m = (r & 3) + 8 * (r >> 2) + 4 * kk;
             const int yy = yy0 + (m >> 4), xx = tx0 + (m & 15);
             const float v = acc[r] * out_mul;
-            if (yy >= 0 && yy < Hp && xx < Wp && v != 0.f) unsafeAtomicAdd(base + ((int64_t)yy * Wp + xx) * ldp, v);
+            if (yy >= 0 && yy < Hp && xx < Wp && v != 0.f) eg3d_acc(base + ((int64_t)yy * Wp + xx) * ldp, v);
         }
     }
 }
@@ -1400,10 +1438,10 @@ __global__ void __launch_bounds__(256) ray_gen_bwd_kernel(const float* __restric
     if (threadIdx.x < 17) {
         float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         int k = threadIdx.x;
-        if (k < 12) unsafeAtomicAdd(d_c2w + n * 16 + k, t);
+        if (k < 12) eg3d_acc(d_c2w + n * 16 + k, t);
         else if (d_K) {
             const int map[5] = {0, 1, 2, 4, 5};
-            unsafeAtomicAdd(d_K + n * 9 + map[k - 12], t);
+            eg3d_acc(d_K + n * 9 + map[k - 12], t);
         }
     }
 }
@@ -1537,6 +1575,7 @@ extern "C" int eg3d_triplane_scatter(const float* df_rows, const float* df_pos, 
     ids += (4 - ((ids - workspace) & 3)) & 3;          // the records are float4 (the workspace itself is at least 16-byte aligned)
     hipStream_t st = (hipStream_t)stream;
     const float cs = 2.f / box_warp;
+    EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND(det, d_planes, (int64_t)N * Hp * Wp * ldp); EG3D_DET_COMMIT(det);
     const int blocks = eg3d_cdiv(S * 3, 256 * BIN_ITEMS);
     const float4* pos4 = reinterpret_cast<const float4*>(df_pos);
     static const int variant0 = [] { const char* e = getenv("EG3D_SCATTER"); return e ? atoi(e) : 4; }();
@@ -1569,6 +1608,9 @@ extern "C" int eg3d_triplane_scatter(const float* df_rows, const float* df_pos, 
             bin_pass(0, pos_n);
             hipLaunchKernelGGL(scatter_scan16_kernel, dim3(1), dim3(1024), 0, st, counts16, offsets16, nb16_img);
             bin_pass(1, pos_n);
+#if EG3D_DET
+            hipLaunchKernelGGL(scatter_sort16_kernel, dim3(nb16_img), dim3(256), 0, st, offsets16, recs);
+#endif
             static const int split = [] { const char* e = getenv("EG3D_SCATTER_SPLIT"); return e ? atoi(e) : 1; }();
             // one block of four waves per four lists: the hardware's block dispatch does the load balancing (lists differ 0 .. 990 pairs); with
             // 1024 persistent blocks taking lists w, w + 4096, ... the launch lasted as long as its unluckiest wave (fp32: 142 -> 128 us)
@@ -1582,9 +1624,13 @@ extern "C" int eg3d_triplane_scatter(const float* df_rows, const float* df_pos, 
             hipLaunchKernelGGL(scatter_accum16p_kernel, dim3(accb), dim3(ACCP_WAVES * 64), 0, st, df_rows + (int64_t)n * Si * FC, Si, offsets16, recs,
                                d_planes + (int64_t)n * Hp * Wp * ldp, Hp, Wp, ldp, ntx, nty, split);
         }
+        EG3D_DET_END(det);
         EG3D_LAUNCH_CHECK();
         return EG3D_OK;
     }
+#if EG3D_DET
+    return EG3D_ERR_UNSUPPORTED;          // the older scatter variants sum in an order their LDS cursors decide
+#endif
     eg3d_zero_words(counts, 2 * (int64_t)nb, st);          // counts + fill cursors (a kernel, not a memset node: see common.h)
     hipLaunchKernelGGL(scatter_bin_kernel<0>, dim3(blocks), dim3(256), sizeof(int) * nb, st, pos4, S, rows_per_image, cs, Hp, Wp, ntx, nty, nb, counts,
                        offsets, fill, ids);
@@ -1633,7 +1679,9 @@ extern "C" int eg3d_ray_gen_bwd(const float* cam2world, const float* intrinsics,
     eg3d_zero_words(d_cam2world, 16 * (int64_t)N, st);
     if (d_intrinsics) eg3d_zero_words(d_intrinsics, 9 * (int64_t)N, st);
     int bx = std::min(eg3d_cdiv((int64_t)res * res, 256), 64);
+    EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND(det, d_cam2world, 16 * (int64_t)N); EG3D_DET_BIND(det, d_intrinsics, 9 * (int64_t)N); EG3D_DET_COMMIT(det);
     hipLaunchKernelGGL(ray_gen_bwd_kernel, dim3(bx, N), dim3(256), 0, st, cam2world, intrinsics, d_origins, d_dirs, d_cam2world, d_intrinsics, res);
+    EG3D_DET_END(det);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

@@ -6,6 +6,16 @@
 // wave streams row pairs straight into v_mfma_f32_32x32x2_f32 (K = 2 rows per instruction, exact fp32), keeps the whole <= 64 x 64
 // result in its accumulators, and the grid reduces once at the end (LDS per block, then one atomic per element and block).
 #include "common.h"
+#include "det.h"
+
+// a block's partial products meet in LDS (normal build) or go straight to the exact accumulators of the targets (deterministic build)
+#if EG3D_DET
+#define GRAM_ACC(r_, c_, v_) do { if ((r_) < Ka && (c_) < Kb) eg3d_acc(out + (r_) * Kb + (c_), (v_) * out_scale); } while (0)
+#define GRAM_CS(c_, v_) do { if (colsum != nullptr && (c_) < Ka) eg3d_acc(colsum + (c_), (v_) * cs_scale); } while (0)
+#else
+#define GRAM_ACC(r_, c_, v_) atomicAdd(&red[(r_) * 64 + (c_)], (v_))
+#define GRAM_CS(c_, v_) atomicAdd(&red[64 * 64 + (c_)], (v_))
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -78,25 +88,25 @@ __global__ void __launch_bounds__(256) rows_gram_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, col = j * 32 + l;
-                atomicAdd(&red[row * 64 + col], acc[i][j][r]);
+                GRAM_ACC(row, col, acc[i][j][r]);
             }
     cs0 += __shfl_xor(cs0, 32);
     cs1 += __shfl_xor(cs1, 32);
-    if (h == 0) { atomicAdd(&red[64 * 64 + l], cs0); if (A_HI) atomicAdd(&red[64 * 64 + 32 + l], cs1); }
+    if (h == 0) { GRAM_CS(l, cs0); if (A_HI) GRAM_CS(32 + l, cs1); }
     if (A_EX > 0) {
 #pragma unroll
         for (int c = 0; c < NEX; ++c) {
-            atomicAdd(&red[(32 + c) * 64 + l], ex[c][0]);                 // both half-waves add their rows' share
-            if (B_HI) atomicAdd(&red[(32 + c) * 64 + 32 + l], ex[c][1]);
-            if (l == 0) atomicAdd(&red[64 * 64 + 32 + c], exs[c]);        // every lane of a half-wave holds the same sum: one of them
+            GRAM_ACC(32 + c, l, ex[c][0]);                                // both half-waves add their rows' share
+            if (B_HI) GRAM_ACC(32 + c, 32 + l, ex[c][1]);
+            if (l == 0) GRAM_CS(32 + c, exs[c]);                          // every lane of a half-wave holds the same sum: one of them
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         const int row = i >> 6, col = i & 63;
-        if (row < Ka && col < Kb) unsafeAtomicAdd(out + row * Kb + col, red[i] * out_scale);
+        if (row < Ka && col < Kb) eg3d_acc(out + row * Kb + col, red[i] * out_scale);
     }
-    if (colsum != nullptr && threadIdx.x < Ka) unsafeAtomicAdd(colsum + threadIdx.x, red[64 * 64 + threadIdx.x] * cs_scale);
+    if (colsum != nullptr && threadIdx.x < Ka) eg3d_acc(colsum + threadIdx.x, red[64 * 64 + threadIdx.x] * cs_scale);
 }
 
 }  // namespace
@@ -120,7 +130,9 @@ extern "C" int eg3d_rows_gram_scaled(const float* a, const float* b, int64_t S, 
     else if (aex > 1) kern = bhi ? rows_gram_kernel<false, true, 8> : rows_gram_kernel<false, false, 8>;
     else if (Ka > 32) kern = bhi ? rows_gram_kernel<true, true, 0> : rows_gram_kernel<true, false, 0>;
     else kern = bhi ? rows_gram_kernel<false, true, 0> : rows_gram_kernel<false, false, 0>;
+    EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND(det, out, (int64_t)Ka * Kb); EG3D_DET_BIND(det, colsum, Ka); EG3D_DET_COMMIT(det);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, S, Ka, Kb, out, colsum, out_scale, colsum_scale);
+    EG3D_DET_END(det);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

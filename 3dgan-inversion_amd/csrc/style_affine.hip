@@ -9,6 +9,7 @@
 //         dW_l[j,k] = sum_n dstyles_l[n,j] * post_l * wgain_l * ws[n,wrow_l,k],  db_l[j] = sum_n dstyles_l[n,j] * post_l * bgain_l
 //         (trainable affines: the pivotal-tuning phase)
 #include "common.h"
+#include "det.h"
 
 namespace {
 
@@ -105,7 +106,7 @@ __global__ void __launch_bounds__(256) style_demod_bwd_kernel(const eg3d_style_b
     __syncthreads();
     if (sl == 0 && k < ly.C) {
         const float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-        unsafeAtomicAdd(ly.dout_extra + (int64_t)n * ly.C + k, -ly.out[(int64_t)n * ly.C + k] * t);
+        eg3d_acc(ly.dout_extra + (int64_t)n * ly.C + k, -ly.out[(int64_t)n * ly.C + k] * t);
     }
 }
 
@@ -142,10 +143,10 @@ __global__ void __launch_bounds__(128) style_affine_bwd_kernel(const eg3d_style_
                     acc.w += c * (w[u].w * ly.wgain);
                 }
             }
-            unsafeAtomicAdd(dst + k + 0, acc.x);
-            unsafeAtomicAdd(dst + k + 1, acc.y);
-            unsafeAtomicAdd(dst + k + 2, acc.z);
-            unsafeAtomicAdd(dst + k + 3, acc.w);
+            eg3d_acc(dst + k + 0, acc.x);
+            eg3d_acc(dst + k + 1, acc.y);
+            eg3d_acc(dst + k + 2, acc.z);
+            eg3d_acc(dst + k + 3, acc.w);
         }
     }
 }
@@ -232,8 +233,17 @@ extern "C" int eg3d_style_affine_bwd(const eg3d_style_bank* pb, void* stream) {
             dblocks += ((ly.C + 63) / 64) * pb->N * std::max(1, std::min(ly.Co / 16, 16));
         }
     }
+    EG3D_DET_SCOPE(det, stream);
+    for (int l = 0; l < pb->nlayers; ++l) {
+        const eg3d_style_layer& ly = pb->layers[l];
+        if (ly.dd != nullptr && ly.wsq != nullptr) { EG3D_DET_BIND(det, ly.dout_extra, (int64_t)pb->N * ly.C); }
+    }
+    EG3D_DET_BIND(det, pb->dws, (int64_t)pb->N * pb->L * pb->D);
+    EG3D_DET_COMMIT(det);
     if (dblocks > 0) hipLaunchKernelGGL(style_demod_bwd_kernel, dim3(dblocks), dim3(256), 0, (hipStream_t)stream, *pb);
+    EG3D_DET_FLUSH(det);          // (the affine backward reads the demodulation part it just accumulated)
     if (pb->dws != nullptr) hipLaunchKernelGGL(style_affine_bwd_kernel, dim3(total_tiles(*pb, ROWS_PER_BLOCK_BWD)), dim3(128), 0, (hipStream_t)stream, *pb);
+    EG3D_DET_END(det);
     bool wants_wgrad = false;
     for (int l = 0; l < pb->nlayers; ++l) wants_wgrad |= pb->layers[l].dweight != nullptr || pb->layers[l].dbias != nullptr;
     if (wants_wgrad) hipLaunchKernelGGL(style_affine_wgrad_kernel, dim3(total_tiles(*pb, ROWS_PER_BLOCK_BWD)), dim3(128), 0, (hipStream_t)stream, *pb);

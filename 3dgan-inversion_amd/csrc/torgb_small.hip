@@ -10,6 +10,7 @@
 // half-resolution image through the 2 x 2 taps of the separable up-sampling FIR) and stores 16 bytes per lane.
 //   block = 256 threads = 4 waves; tile = 32 pixels (of ONE image) x 32 outputs; grid = (N * ceil(HW / 32), Cp / 32).
 #include "common.h"
+#include "det.h"
 
 namespace {
 
@@ -180,8 +181,8 @@ __global__ void __launch_bounds__(256) torgb_small_bwd_kernel(const eg3d_torgb_s
             if (ab.dnoise != nullptr || ab.dstrength != nullptr) {      // the 8 lanes of a pixel row hold this tile's 32 channels
                 cs = eg3d_row_group_sum(cs, 8);
                 if (eq == 0) {
-                    if (ab.dnoise != nullptr) unsafeAtomicAdd(ab.dnoise + (int64_t)n * ab.dnoise_nstride + ep, cs * abc.strength);
-                    if (ab.dstrength != nullptr && cs * nz != 0.f) atomicAdd(sc_lds, cs * nz);
+                    if (ab.dnoise != nullptr) eg3d_acc(ab.dnoise + (int64_t)n * ab.dnoise_nstride + ep, cs * abc.strength);
+                    if (ab.dstrength != nullptr && cs * nz != 0.f) EG3D_LDS_ACC(sc_lds, ab.dstrength, cs * nz);
                 }
             }
         }
@@ -200,12 +201,12 @@ __global__ void __launch_bounds__(256) torgb_small_bwd_kernel(const eg3d_torgb_s
             float sum = 0.f;
 #pragma unroll 8
             for (int r = 0; r < TS_PIX; ++r) sum += col[a][r][cc];
-            if (a == 0) unsafeAtomicAdd(p.ds + (int64_t)n * p.C + c, sum);
-            else if (a == 1) unsafeAtomicAdd(ab.dbias + c, sum);
-            else unsafeAtomicAdd(ab.dd + (int64_t)n * p.C + c, sum / (ab.d != nullptr ? ab.d[(int64_t)n * p.C + c] : 1.f));      // dL/dd = sum dy * z,  z = (pre - bias - noise) / d
+            if (a == 0) eg3d_acc(p.ds + (int64_t)n * p.C + c, sum);
+            else if (a == 1) eg3d_acc(ab.dbias + c, sum);
+            else eg3d_acc(ab.dd + (int64_t)n * p.C + c, sum / (ab.d != nullptr ? ab.d[(int64_t)n * p.C + c] : 1.f));      // dL/dd = sum dy * z,  z = (pre - bias - noise) / d
         }
     }
-    if (act_on && ab.dstrength != nullptr && threadIdx.x == 0 && sc_lds[0] != 0.f) unsafeAtomicAdd(ab.dstrength, sc_lds[0]);
+    if (act_on && ab.dstrength != nullptr && threadIdx.x == 0 && sc_lds[0] != 0.f) eg3d_acc(ab.dstrength, sc_lds[0]);
 }
 
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -251,7 +252,12 @@ extern "C" int eg3d_torgb_small_bwd(const eg3d_torgb_small_bwd_params* p, void* 
     if (!p || !p->dy || !p->wa || !p->s || !p->dx) return EG3D_ERR_INVALID;
     if (!eg3d_torgb_small_bwd_supported(p)) return EG3D_ERR_UNSUPPORTED;
     const dim3 grid(p->N * eg3d_cdiv((int64_t)p->H * p->W, TS_PIX), p->C / TS_OUT);
+    EG3D_DET_SCOPE(det, stream);
+    EG3D_DET_BIND(det, p->ds, (int64_t)p->N * p->C);
+    if (p->act_on) { EG3D_DET_BIND_ACT(det, p->act_bwd, p->N, p->C, (int64_t)p->H * p->W); }
+    EG3D_DET_COMMIT(det);
     hipLaunchKernelGGL(torgb_small_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p);
+    EG3D_DET_END(det);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

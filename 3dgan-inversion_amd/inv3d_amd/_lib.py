@@ -10,7 +10,10 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, os.environ.get('EG3D_LIBNAME', 'libeg3d_hip.so'))     # EG3D_LIBNAME: A/B builds in one GPU session
+# EG3D_DETERMINISTIC=1: the deterministic build of the same sources (csrc/det.h: every floating-point atomic an exact fixed-point
+# accumulation -- bit-identical results from run to run); its accumulator workspace is lent on first use (det_enable below)
+DETERMINISTIC = os.environ.get('EG3D_DETERMINISTIC', '0') != '0'
+LIB_PATH = os.path.join(_HERE, os.environ.get('EG3D_LIBNAME', 'libeg3d_hip_det.so' if DETERMINISTIC else 'libeg3d_hip.so'))     # EG3D_LIBNAME: A/B builds in one GPU session
 
 F32, F16, F64 = 0, 1, 2
 EPI_STORE, EPI_ATOMIC, EPI_FWD, EPI_BWD, EPI_BWD_ACT = 0, 1, 2, 3, 4
@@ -227,6 +230,10 @@ _SIGS = {
     'eg3d_conv2d_up2_supported': (C.c_int, [C.POINTER(ConvUp2Params)]),
     'eg3d_conv2d_up2': (C.c_int, [C.POINTER(ConvUp2Params), C.c_void_p]),
     'eg3d_probe_mfma_f16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'eg3d_det_enabled': (C.c_int, []),
+    'eg3d_det_workspace_bytes': (C.c_int64, [C.c_int64]),
+    'eg3d_det_set_workspace': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    'eg3d_det_misses': (C.c_int, [C.POINTER(C.c_uint32), C.c_void_p]),
     'eg3d_modconv_epilogue_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int64,
                                             C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
@@ -317,7 +324,35 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = h
+        if h.eg3d_det_enabled() and torch.cuda.is_available():
+            det_enable()
     return _lib
+
+
+_det_ws = None
+
+
+def det_enable(max_elements: int = None, device=None):
+    """Lend the deterministic build its accumulator workspace (32 bytes per float a single library call accumulates into; the default
+    covers a 512^2 x 128 split-K output).  Called by hipops on the first GPU use when EG3D_DETERMINISTIC=1; no-op in the normal build."""
+    global _det_ws
+    h = lib()
+    if not h.eg3d_det_enabled():
+        return False
+    if _det_ws is None or (max_elements is not None and _det_ws[1] < max_elements):
+        n = int(max_elements or int(os.environ.get('EG3D_DET_ELEMENTS', str(40 * 1024 * 1024))))
+        nbytes = h.eg3d_det_workspace_bytes(n)
+        ws = torch.zeros(nbytes // 8 + 1, dtype=torch.int64, device=device or 'cuda')
+        check(h.eg3d_det_set_workspace(ws.data_ptr(), nbytes, stream_ptr()), 'det_set_workspace')
+        _det_ws = (ws, n)
+    return True
+
+
+def det_misses() -> int:
+    """Additions of the deterministic build that fell back to a float atomic (a target the call did not bind): must stay 0."""
+    out = C.c_uint32(0)
+    check(lib().eg3d_det_misses(C.byref(out), stream_ptr()), 'det_misses')
+    return int(out.value)
 
 
 def check(status, what=''):

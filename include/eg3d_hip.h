@@ -857,6 +857,20 @@ int eg3d_warp_project_bwd(const float* origins, const float* dirs, const float* 
  * executes blocks x 4 waves x iters x 24 MFMAs of 32 x 32 x 16.  No reference counterpart. */
 int eg3d_probe_mfma_f16(const void* in, float* out, int blocks, int iters, void* stream);
 
+/* ---- deterministic build (csrc/det.h; `make det` -> libeg3d_hip_det.so) ----------------------------------------------------------------
+ * Both builds export these four.  In the deterministic build every floating-point atomic of the library is an exact fixed-point
+ * accumulation (order-independent: bit-identical results from run to run), the accumulators living in a workspace the caller lends:
+ *   eg3d_det_enabled()                 1 in the deterministic build, 0 in the normal one
+ *   eg3d_det_workspace_bytes(n)        bytes for calls that accumulate into at most n float targets each (32 bytes per target + 4 KB)
+ *   eg3d_det_set_workspace(ws, bytes)  lend it (16-byte aligned; cleared here, synchronises the stream); ws = NULL returns to float atomics.
+ *                                      Calls of the library must then come from one stream at a time.
+ *   eg3d_det_misses(out)               additions that fell back to a float atomic (target not bound by the call, |v| >= 2^53); synchronises
+ * The reference has no such mode (PyTorch's backward kernels accumulate with atomicAdd the same way). */
+int eg3d_det_enabled(void);
+int64_t eg3d_det_workspace_bytes(int64_t max_elements_per_call);
+int eg3d_det_set_workspace(void* workspace, int64_t bytes, void* stream);
+int eg3d_det_misses(uint32_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
