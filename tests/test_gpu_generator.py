@@ -10,6 +10,8 @@ import torch
 from oracle import eg3d_oracle as O
 
 pytestmark = pytest.mark.gpu
+from inv3d_amd import _lib as _L
+DET = _L.DETERMINISTIC
 DEV = 'cuda'
 
 
@@ -202,6 +204,8 @@ def test_graph_full_weight_grads_golden(golden, arith):
         # samples that land one texel over) and every gradient inherits that; observed 0.5e-4 .. 9e-4 of max|g|, varying from run to run
         # with the order of the atomically accumulated sums -- bound 3e-3
         tol = 3e-3 if arith == 'f16x3' else 5e-2
+        if DET and arith == 'f16x3':      # deterministic build: exact accumulation, a third of the atomics path's bound (the sr_f16x1 bound is
+            tol /= 3.0                    # operand rounding of the fp16 head, not summation order)
         err = float((got - ref).abs().max())
         worst[k] = err / ref_max
         assert err <= tol * ref_max, f'd {k}: probe err {err:.3e} > {tol} * max|g| {ref_max:.3e}'

@@ -12,6 +12,8 @@ from oracle import eg3d_oracle as O
 from oracle import inversion_oracle as IO
 
 pytestmark = pytest.mark.gpu
+from inv3d_amd import _lib as _L
+DET = _L.DETERMINISTIC
 DEV = 'cuda'
 
 
@@ -108,7 +110,8 @@ def test_pose_and_warping_c3():
     assert float((hip.quat.detach().cpu() - ref.quat.detach()).abs().max()) < 1e-2
     assert float((hip.translation_opt.detach().cpu() - ref.translation_opt.detach()).abs().max()) < 1e-2
     drift = abs(_psnr(h['image'], target) - _psnr(r['image'], target))
-    assert drift <= 5e-2, f'final PSNR drift {drift:.2e} dB'
+    print(f'C3 7 steps: final PSNR drift {drift:.2e} dB')
+    assert drift <= (1e-3 if DET else 5e-2), f'final PSNR drift {drift:.2e} dB'
 
 
 def test_pivotal_tuning_c4():
@@ -736,16 +739,18 @@ def test_pose_and_warping_c3_long_horizon():
         worst = max(worst, abs(_psnr(h['image'], target) - _psnr(r['image'], target)))
     drift = abs(_psnr(h['image'], target) - _psnr(r['image'], target))
     print(f'C3 60 steps: final PSNR drift {drift:.2e} dB (worst along the way {worst:.2e}), loss {float(h["loss"]):.5f} vs {float(r["loss"]):.5f}')
-    assert drift <= 2e-2, f'final PSNR drift {drift:.2e} dB'
-    assert abs(float(h['loss']) - float(r['loss'])) <= 5e-3 * max(1.0, abs(float(r['loss'])))
-    assert float((hip.w_opt.detach().cpu() - ref.w_opt.detach()).abs().max()) < 5e-2
+    # deterministic build (EG3D_DETERMINISTIC=1): the sums are exact and order-free, the trajectories stay together -- the parity bar itself
+    # (observed 3e-6 dB final, 2e-5 dB worst along the way)
+    assert drift <= (1e-3 if DET else 2e-2), f'final PSNR drift {drift:.2e} dB'
+    assert abs(float(h['loss']) - float(r['loss'])) <= (1e-4 if DET else 5e-3) * max(1.0, abs(float(r['loss'])))
+    assert float((hip.w_opt.detach().cpu() - ref.w_opt.detach()).abs().max()) < (1e-3 if DET else 5e-2)
 
 
 def test_run_to_run_drift_of_the_atomically_accumulated_gradients():
     """The default path accumulates style / bias / noise / split-K partial sums with fp32 atomics (csrc/conv_v2_common.h, conv_igemm.hip,
     epilogue.hip): the ORDER of those additions varies from run to run, so two runs of the same trajectory are not bit-identical.  This
     bounds what that does to a 150-step latent projection (same seeds, same injected noise and sampling uniforms): final-PSNR difference
-    <= 1e-3 dB, latent difference <= 1e-3 -- the level of the parity bar itself.  (An ordered-reduction mode is not implemented.)"""
+    <= 1e-3 dB, latent difference <= 1e-3 -- the level of the parity bar itself.  Under the deterministic build (EG3D_DETERMINISTIC=1) the two runs are bit-identical."""
     from inv3d_amd.inversion import LatentProjector
     cfg, P, G, cam, u1, u2, target, init_noise = _setup()
     w_start = O.synth_ws(cfg, 1, seed=1)[:, :1]
@@ -760,3 +765,5 @@ def test_run_to_run_drift_of_the_atomically_accumulated_gradients():
     dp = abs(runs[0][1] - runs[1][1])
     print(f'run-to-run: |d w| {dw:.2e}, |d PSNR| {dp:.2e} dB, dist {runs[0][2]:.6f} vs {runs[1][2]:.6f}')
     assert dp <= 1e-3 and dw <= 1e-3
+    if DET:                   # deterministic build: bit-identical
+        assert dw == 0.0 and dp == 0.0 and runs[0][2] == runs[1][2]

@@ -23,6 +23,22 @@ def test_library_exports_every_declared_symbol():
     assert lib.eg3d_status_string(-2) == b'unsupported configuration'
 
 
+def test_deterministic_build_exports_the_same_symbols():
+    """`make det` -> libeg3d_hip_det.so (csrc/det.h): same C-ABI; only it reports eg3d_det_enabled() == 1."""
+    import ctypes as C
+    from inv3d_amd import _lib as L
+    path = os.path.join(os.path.dirname(L.LIB_PATH), 'libeg3d_hip_det.so')
+    assert os.path.exists(path), 'build it with `make -C 3dgan-inversion_amd` (both libraries are default targets)'
+    det = C.CDLL(path)
+    for name in L.EXPORTED_SYMBOLS:
+        assert hasattr(det, name), name
+    det.eg3d_det_enabled.restype = C.c_int
+    assert det.eg3d_det_enabled() == 1
+    if not L.DETERMINISTIC:
+        assert L.lib().eg3d_det_enabled() == 0
+        assert L.lib().eg3d_det_set_workspace(None, 0, None) == -2             # EG3D_ERR_UNSUPPORTED: the normal build has no such mode
+
+
 def test_render_size_query_is_host_only():
     """eg3d_render_query_sizes: the buffer-size contract of the renderer entries, answerable without a GPU."""
     import ctypes as C

@@ -1,7 +1,7 @@
 """Run-to-run spread of a few accumulating library calls: each is run REPS times on the same inputs and the number of distinct result bit
 patterns is printed.  Normal build: more than one for most (float atomics); deterministic build (EG3D_DETERMINISTIC=1): exactly one."""
 import sys
-sys.path.insert(0, '/root/repo/3dgan-inversion_amd')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))), '3dgan-inversion_amd'))
 import torch
 from inv3d_amd import hipops as H, _lib as L
 dev = torch.device('cuda')
