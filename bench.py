@@ -351,14 +351,31 @@ def side_configs(G, target, cam, dev, use_graph, steps=10):
         return run
     guarded('c3_pose_warp', c3(False))
     guarded('c3_pose_warp_real_nets', c3(True))
+
+    def deterministic():
+        # The deterministic build (csrc/det.h: every floating-point atomic an exact fixed-point accumulation) is chosen when the library is
+        # loaded, so its cost is timed in a fresh interpreter: the same C2 loop (graph replay), two runs compared bit for bit.
+        import subprocess
+        env = dict(os.environ, EG3D_DETERMINISTIC='1')
+        env.pop('EG3D_LIBNAME', None)
+        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'det_runs.py'), 'c2', '60', 'graph'],
+                           env=env, capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr[-400:])
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return dict(workload='C2 under EG3D_DETERMINISTIC=1 (libeg3d_hip_det.so), HIP-graph replay', ms_per_step=d['ms_per_step'],
+                    steps_per_s=round(1e3 / d['ms_per_step'], 2), two_runs_bit_identical=bool(d['equal']), float_atomic_fallbacks=d['misses'], steps=d['steps'])
+    guarded('deterministic_c2', deterministic)
     return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel from the host instead of replaying the captured step')
