@@ -250,7 +250,8 @@ def test_full_size_plain_loop_is_not_host_bound():
     ms, w_a, l_a = run(True, 24, 4)
     assert graphed.STATS['replayed'] >= n0 + 20
     print(f'plain G.synthesis loop, full size, graph-replayed: {ms:.2f} ms/step')
-    assert ms <= 8.0, f'{ms:.2f} ms per step'
+    from inv3d_amd import _lib as _L
+    assert ms <= (20.0 if _L.DETERMINISTIC else 8.0), f'{ms:.2f} ms per step'          # (the deterministic build's step is ~2.2x: DESIGN.md 3.5)
     with torch.no_grad():
         for b, s in zip(bufs, saved):
             b.copy_(s)
