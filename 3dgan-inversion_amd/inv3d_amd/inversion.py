@@ -186,6 +186,10 @@ class _PoseChainFn(torch.autograd.Function):
 
 
 POSE_CHAIN_KERNEL = os.environ.get('EG3D_POSE_CHAIN', '1') != '0'
+# C3: the canonical view of the warping loss is rendered from the planes the step's main synthesis call just computed (G.synthesis's own
+# cache_backbone / use_cached_backbone, triplane.py:55-63 of the reference) instead of running the backbone a second time on the same ws:
+# identical planes (the backbone is a function of ws and the const noise alone), one backbone forward less per step
+SHARE_BACKBONE = os.environ.get('EG3D_C3_SHARE_BACKBONE', '1') != '0'
 
 
 def pose_chain(pred: torch.Tensor, translation_opt: torch.Tensor, intrinsic: torch.Tensor, radius: float, mode: str):
@@ -583,6 +587,9 @@ class LatentProjector:
             kw = dict(kw, noise_inject=self._noise_inject)
         if self.use_graph and self._uni is not None and 'render_uniforms' not in kw:
             kw = dict(kw, render_uniforms=self._uni_views)          # drawn in front of the step (see __init__)
+        share = self.use_warp and self.optimize_pose and SHARE_BACKBONE and (self.use_graph or not getattr(G, 'graph_eager', False))      # (a plain eager call keeps its own auto-captured replay: graphed.py)
+        if share:           # the canonical view of the warping loss renders the SAME planes (same ws, const noise): keep them (see warping_loss)
+            kw = dict(kw, cache_backbone=True)
         out = G.synthesis(ws, pred_cam, noise_mode='const', **(dict(sr_fp16=True) if self.sr_fp16 else dict(force_fp32=True)), **kw)
         from . import loss_nets as LN
         p4 = getattr(out['image'], '_eg3d_padded4', None)
@@ -600,8 +607,11 @@ class LatentProjector:
         loss = dist + reg                         # reported value; only `dist` (and the warping term) goes through autograd
         warp = None
         if self.use_warp and self.optimize_pose:
+            kw_can = {k: v for k, v in kw.items() if k != 'cache_backbone'}
             warp = warping_loss(G, ws, self.canonical_cam, pred_ext, self.init_ext, self.intrinsic, out['image_depth'],
-                                self.target_warp_feat, self.warp_net, kw)
+                                self.target_warp_feat, self.warp_net, dict(kw_can, use_cached_backbone=True) if share else kw_can)
+            if share:
+                G._last_planes = None          # (nothing outside this step may render stale planes)
             loss = loss + warp
         self.optimizer.zero_grad(set_to_none=True)
         if self.optimize_pose:
