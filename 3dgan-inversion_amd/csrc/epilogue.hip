@@ -687,7 +687,7 @@ __global__ void __launch_bounds__(256) pack_conv_weights_batched_kernel(const Pa
     while (l + 1 < b.n && (int)blockIdx.x >= b.blk0[l + 1]) ++l;
     const eg3d_pack_item& q = b.it[l];
     const int local = blockIdx.x - b.blk0[l], tiles_i = (q.I + PK - 1) / PK;
-    pack_conv_weight_tile(sm, q.w, q.wf, q.wa, q.wsq, q.O, q.I, q.T, nullptr, q.O_pad > 0 ? q.O_pad : q.O, local % tiles_i, local / tiles_i);
+    pack_conv_weight_tile(sm, q.w, q.wf, q.wa, q.wsq, q.O, q.I, q.T, q.oscale, q.O_pad > 0 ? q.O_pad : q.O, local % tiles_i, local / tiles_i);
 }
 
 // Gradient of a per-output-channel scaled weight w' = w * a[o] from the packed weight-gradient image g[o][t*Ip + i] of the conv that used

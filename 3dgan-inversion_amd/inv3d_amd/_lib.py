@@ -37,7 +37,7 @@ class ActBwd(C.Structure):
 class PackItem(C.Structure):
     """eg3d_pack_item: one layer of eg3d_pack_conv_weights_batched."""
     _fields_ = [('w', C.c_void_p), ('wf', C.c_void_p), ('wa', C.c_void_p), ('wsq', C.c_void_p),
-                ('O', C.c_int32), ('I', C.c_int32), ('T', C.c_int32), ('O_pad', C.c_int32)]
+                ('O', C.c_int32), ('I', C.c_int32), ('T', C.c_int32), ('O_pad', C.c_int32), ('oscale', C.c_void_p)]
 
 
 PACK_BATCH_MAX = 40
@@ -230,6 +230,8 @@ _SIGS = {
     'eg3d_conv2d_up2_supported': (C.c_int, [C.POINTER(ConvUp2Params)]),
     'eg3d_conv2d_up2': (C.c_int, [C.POINTER(ConvUp2Params), C.c_void_p]),
     'eg3d_probe_mfma_f16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'eg3d_grid_sample_nhwc_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
+    'eg3d_grid_sample_nhwc_bwd': (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]),
     'eg3d_det_enabled': (C.c_int, []),
     'eg3d_det_workspace_bytes': (C.c_int64, [C.c_int64]),
     'eg3d_det_set_workspace': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),

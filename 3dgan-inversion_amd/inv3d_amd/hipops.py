@@ -1169,17 +1169,20 @@ def split_weight_pieces(wp):
 
 
 def pack_conv_weights_batched(items):
-    """items: list of (w [O,I,kh,kw], wf, wa | None, wsq | None, o_pad) with caller-allocated outputs (eg3d_pack_conv_weights_batched);
+    """items: list of (w [O,I,kh,kw], wf, wa | None, wsq | None, o_pad[, oscale [O] | None]) with caller-allocated outputs (eg3d_pack_conv_weights_batched);
     one launch per L.PACK_BATCH_MAX layers."""
     for a in range(0, len(items), L.PACK_BATCH_MAX):
         chunk = items[a:a + L.PACK_BATCH_MAX]
         arr = (L.PackItem * len(chunk))()
-        for q, (w, wf, wa, wsq, o_pad) in zip(arr, chunk):
+        for q, item in zip(arr, chunk):
+            w, wf, wa, wsq, o_pad = item[:5]
+            oscale = item[5] if len(item) > 5 else None          # [O]: folded into both images (eg3d_pack_item::oscale)
             L.require_cuda(w, wf)
             assert w.is_contiguous() and w.dtype == torch.float32
             o, i, kh, kw = w.shape
             q.w, q.wf, q.wa, q.wsq = w.data_ptr(), wf.data_ptr(), L.ptr(wa), L.ptr(wsq)
             q.O, q.I, q.T, q.O_pad = o, i, kh * kw, int(o_pad)
+            q.oscale = L.ptr(oscale)
         L.check(L.lib().eg3d_pack_conv_weights_batched(arr, len(chunk), L.stream_ptr()), 'pack_conv_weights_batched')
 
 

@@ -190,6 +190,7 @@ POSE_CHAIN_KERNEL = os.environ.get('EG3D_POSE_CHAIN', '1') != '0'
 # cache_backbone / use_cached_backbone, triplane.py:55-63 of the reference) instead of running the backbone a second time on the same ws:
 # identical planes (the backbone is a function of ws and the const noise alone), one backbone forward less per step
 SHARE_BACKBONE = os.environ.get('EG3D_C3_SHARE_BACKBONE', '1') != '0'
+GRID_SAMPLE_KERNEL = os.environ.get('EG3D_GRID_SAMPLE', '1') != '0'     # the feature warp of the warping loss on eg3d_grid_sample_nhwc_* (0: F.grid_sample)
 
 
 def pose_chain(pred: torch.Tensor, translation_opt: torch.Tensor, intrinsic: torch.Tensor, radius: float, mode: str):
@@ -275,6 +276,42 @@ def warp_project(o, d, depth, init_ext, intrinsic):
     return _WarpProjectFn.apply(o.reshape(-1, 3), d.reshape(-1, 3), depth.reshape(-1), _warp_consts_packed(init_ext, intrinsic))
 
 
+class _GridSampleFn(torch.autograd.Function):
+    """F.grid_sample(inp, grid, mode='bilinear', padding_mode='zeros', align_corners=False) for a channels-last fp32 map
+    (eg3d_grid_sample_nhwc_fwd / _bwd: one wave per output pixel over contiguous channel rows)."""
+
+    @staticmethod
+    def forward(ctx, inp, grid):
+        from . import _lib as L
+        N, C, Hh, Ww = inp.shape
+        _, Ho, Wo, _ = grid.shape
+        grid = grid.contiguous().float()
+        out = hipops.empty_cl(N, C, Ho, Wo, inp.device)
+        L.check(L.lib().eg3d_grid_sample_nhwc_fwd(inp.data_ptr(), grid.data_ptr(), out.data_ptr(), N, Hh, Ww, C, Ho, Wo, L.stream_ptr()), 'grid_sample_nhwc_fwd')
+        ctx.save_for_backward(inp, grid)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import _lib as L
+        inp, grid = ctx.saved_tensors
+        N, C, Hh, Ww = inp.shape
+        _, Ho, Wo, _ = grid.shape
+        dout = hipops.to_cl(dout.float())
+        dgrid = torch.empty_like(grid)
+        dinp = hipops.zeros_cl(N, C, Hh, Ww, inp.device) if ctx.needs_input_grad[0] else None
+        L.check(L.lib().eg3d_grid_sample_nhwc_bwd(inp.data_ptr(), grid.data_ptr(), dout.data_ptr(), dgrid.data_ptr(), dinp.data_ptr() if dinp is not None else None,
+                                                  N, Hh, Ww, C, Ho, Wo, L.stream_ptr()), 'grid_sample_nhwc_bwd')
+        return dinp, dgrid
+
+
+def grid_sample_bilinear(inp: torch.Tensor, grid: torch.Tensor) -> torch.Tensor:
+    """F.grid_sample(inp, grid, mode='bilinear', align_corners=False) -- on the library's kernel for fp32 CUDA maps with C % 4 == 0."""
+    if GRID_SAMPLE_KERNEL and inp.is_cuda and inp.dtype == torch.float32 and inp.shape[1] % 4 == 0 and grid.shape[0] == inp.shape[0]:
+        return _GridSampleFn.apply(hipops.to_cl(inp), grid)
+    return F.grid_sample(inp, grid, mode='bilinear', align_corners=False)
+
+
 def warping_loss(G, ws, canonical_cam, extrinsic, init_ext, intrinsic, depth, target_feat, feat_fn, synth_kwargs=None):
     """Depth-reprojection loss (training/warping_loss.py:6-56): render the canonical view without gradient, lift the predicted
     depth to 3-D with the predicted extrinsic, project into the canonical image, sample canonical features there and compare
@@ -292,7 +329,7 @@ def warping_loss(G, ws, canonical_cam, extrinsic, init_ext, intrinsic, depth, ta
     uv = warp_project(o, d, depth, init_ext, intrinsic)                            # [res*res,2]; grad -> extrinsic (through the rays), depth
     fr = target_feat.shape[-1]
     uv_f = F.interpolate(uv.reshape(1, res, res, 2).permute(0, 3, 1, 2), size=(fr, fr), mode='bilinear').permute(0, 2, 3, 1)
-    warped = F.grid_sample(can_feat, uv_f, mode='bilinear', align_corners=False)
+    warped = grid_sample_bilinear(can_feat, uv_f)
     m = F.interpolate(mask, size=(fr, fr), mode='bilinear')
     return ((warped - target_feat) * m).abs().mean()
 

@@ -23,6 +23,7 @@ import math
 from ctypes import byref as C_byref
 from typing import List, Optional, Sequence, Tuple
 
+import os
 import torch
 
 from . import _lib as L
@@ -30,6 +31,7 @@ from . import hipops as H
 from .fused import _auto_ksplit
 from .torch_utils.ops import bias_act
 
+WGRAD_PRECISION = os.environ.get('EG3D_POSE_WGRAD', 'f16x3')        # weight gradients of the in-loop pose estimator: 'f16x3' | 'f32' (v_mfma_f32_32x32x2_f32)
 LOSS_NET_PRECISION = 'bf16x6'        # fp32-equivalent for any operand range (pixel values up to 255 enter these networks)
 
 
@@ -147,7 +149,7 @@ class _ConvScaleActFn(torch.autograd.Function):
     -- instead of ~12 weight-sized ATen passes (fold, two permute-copies, un-permute, two products, two reductions, fills)."""
 
     @staticmethod
-    def forward(ctx, x, weight, a, bias, stride, pad, act):
+    def forward(ctx, x, weight, a, bias, stride, pad, act, packed=None):
         L.require_cuda(x, weight, a, bias)
         assert H.is_cl(x) and x.dtype == torch.float32
         N, Ci, Hi, Wi = x.shape
@@ -156,9 +158,12 @@ class _ConvScaleActFn(torch.autograd.Function):
         w = weight.detach().contiguous().float()
         av = a.detach().contiguous().float()
         T = kh * kw
-        wf = torch.empty((Co, T * Ci), device=x.device)
-        wa = torch.empty((Ci, T * Co), device=x.device)
-        L.check(L.lib().eg3d_pack_conv_weight_scaled(w.data_ptr(), av.data_ptr(), wf.data_ptr(), wa.data_ptr(), Co, Ci, T, L.stream_ptr()), 'pack_conv_weight_scaled')
+        if packed is not None:          # both images of w * a[o] were built with every other layer's in one launch (pose_net.ResNetPose.forward)
+            wf, wa = packed
+        else:
+            wf = torch.empty((Co, T * Ci), device=x.device)
+            wa = torch.empty((Ci, T * Co), device=x.device)
+            L.check(L.lib().eg3d_pack_conv_weight_scaled(w.data_ptr(), av.data_ptr(), wf.data_ptr(), wa.data_ptr(), Co, Ci, T, L.stream_ptr()), 'pack_conv_weight_scaled')
         Ho, Wo = (Hi + 2 * pad - kh) // stride + 1, (Wi + 2 * pad - kw) // stride + 1
         cls = _classes_strided(Ho, Wo, kh, kw, pad)
         ks = _auto_ksplit(cls, N, Co, Ci)
@@ -189,7 +194,8 @@ class _ConvScaleActFn(torch.autograd.Function):
                 db = dy.sum((0, 2, 3))
         else:                                  # activation backward and the bias gradient in one pass
             db = H.zeros((Co,), dy.device) if need_b else None
-            dz = H.epilogue_bwd(dy, y, H.empty_cl(N, Co, Ho, Wo, dy.device), act=act, gain=1.0, dbias=db)
+            amax = H.zeros((1,), dy.device) if ((need_w or need_a) and WGRAD_PRECISION != 'f32') else None      # max|dz|: range of the weight gradient's fp16 operand
+            dz = H.epilogue_bwd(dy, y, H.empty_cl(N, Co, Ho, Wo, dy.device), act=act, gain=1.0, dbias=db, dz_amax=amax)
         dx = dw = da = None
         if need_x:
             cls, overlapping = _classes_strided_adjoint(Hi, Wi, kh, kw, stride, pad)
@@ -200,20 +206,28 @@ class _ConvScaleActFn(torch.autograd.Function):
         if need_w or need_a:
             T = kh * kw
             dwp = H.zeros((Co, T * Ci), dy.device)
-            H.conv_wgrad(x, dz, Ci, Co, dwp, _classes_strided(Ho, Wo, kh, kw, pad), in_stride=stride, out_stride=1)
+            if act != 'linear' and amax is not None:        # two-piece fp16 operands, three products per fp32 product (the generator's arithmetic); dz range-normalised by max|dz|
+                H.conv_wgrad(x, dz, Ci, Co, dwp, _classes_strided(Ho, Wo, kh, kw, pad), in_stride=stride, out_stride=1, precision=WGRAD_PRECISION, g_amax=amax)
+            else:
+                H.conv_wgrad(x, dz, Ci, Co, dwp, _classes_strided(Ho, Wo, kh, kw, pad), in_stride=stride, out_stride=1)
             dw = torch.empty_like(w)
             da = torch.empty_like(av) if need_a else None
             L.check(L.lib().eg3d_unpack_weight_grad(dwp.data_ptr(), w.data_ptr(), av.data_ptr(), dw.data_ptr(), da.data_ptr() if da is not None else None,
                                                     Co, Ci, Ci, T, L.stream_ptr()), 'unpack_weight_grad')
-        return dx, (dw if need_w else None), da, db, None, None, None
+        return dx, (dw if need_w else None), da, db, None, None, None, None
 
 
-def conv_scale_act(x, weight, a, bias, stride=1, pad=0, act='relu'):
+def conv_scale_act_ok(x_channels, weight, act) -> bool:
+    Co, Ci, kh, kw = weight.shape
+    return x_channels == Ci and Ci % 4 == 0 and Co % 4 == 0 and kh * kw <= 9 and act in ('linear', 'relu')
+
+
+def conv_scale_act(x, weight, a, bias, stride=1, pad=0, act='relu', packed=None):
     """act(conv2d(x, weight * a[:, None, None, None]) + bias): conv + folded eval-mode BatchNorm + activation, trainable (see _ConvScaleActFn);
     falls back to conv_act on a separately folded weight for shapes the fused form does not take (padded input channels, > 9 taps)."""
     Co, Ci, kh, kw = weight.shape
-    if x.shape[1] == Ci and Ci % 4 == 0 and Co % 4 == 0 and kh * kw <= 9 and act in ('linear', 'relu'):
-        return _ConvScaleActFn.apply(x, weight, a, bias, stride, pad, act)
+    if conv_scale_act_ok(x.shape[1], weight, act):
+        return _ConvScaleActFn.apply(x, weight, a, bias, stride, pad, act, packed)
     return conv_act(x, weight * a.view(-1, 1, 1, 1), bias, stride, pad, act)
 
 

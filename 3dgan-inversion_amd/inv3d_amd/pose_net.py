@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from . import hipops as H
-from .loss_nets import conv_act, conv_scale_act, max_pool
+from .loss_nets import conv_act, conv_scale_act, conv_scale_act_ok, max_pool
 from .torch_utils.ops import bias_act
 
 
@@ -30,7 +30,7 @@ def _bn_affine(bn):
 
 def _conv_bn(x, conv, bn, act):
     a, b = _bn_affine(bn)
-    return conv_scale_act(x, conv.weight, a, b, conv.stride[0], conv.padding[0], act)
+    return conv_scale_act(x, conv.weight, a, b, conv.stride[0], conv.padding[0], act, packed=getattr(conv, '_eg3d_packed', None))
 
 
 class BasicBlock(torch.nn.Module):
@@ -105,10 +105,37 @@ class ResNetPose(torch.nn.Module):
             bn._eg3d_affine = (ai, bi)
         return bns
 
+    def _pack_all(self):
+        """Both packed images (forward operand, data-gradient operand) of every folded conv weight w * a[o] from ONE launch
+        (eg3d_pack_conv_weights_batched with eg3d_pack_item::oscale) instead of one 11 us launch per layer: the weights are trained, so
+        the images are rebuilt every step."""
+        pairs = [(self.conv1, self.bn1)]
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                pairs += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)]
+                if blk.downsample is not None:
+                    pairs.append((blk.downsample[0], blk.downsample[1]))
+        items, convs = [], []
+        for conv, bn in pairs:
+            w = conv.weight
+            Co, Ci, kh, kw = w.shape
+            if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and conv_scale_act_ok(Ci, w, 'relu')):
+                continue
+            a, _ = _bn_affine(bn)
+            wf = torch.empty((Co, kh * kw * Ci), device=w.device)
+            wa = torch.empty((Ci, kh * kw * Co), device=w.device)
+            items.append((w.detach(), wf, wa, None, 0, a.detach().contiguous().float()))
+            conv._eg3d_packed = (wf, wa)
+            convs.append(conv)
+        if items:
+            H.pack_conv_weights_batched(items)
+        return convs
+
     def forward(self, img):
         n, c, h, w = img.shape
         x = torch.cat([img.float(), img.new_zeros(n, 1, h, w, dtype=torch.float32)], 1).contiguous(memory_format=torch.channels_last)
         bns = self._bank_affines()
+        convs = self._pack_all()
         try:
             x = _conv_bn(x, self.conv1, self.bn1, 'relu')
             x = max_pool(H.to_cl(F.pad(x, (1, 1, 1, 1), value=float('-inf'))), 3, 2)
@@ -117,6 +144,8 @@ class ResNetPose(torch.nn.Module):
         finally:
             for bn in bns:
                 bn._eg3d_affine = None
+            for cv in convs:
+                cv._eg3d_packed = None
         x = x.mean((2, 3))
         x = F.relu(self.fc(x))
         x = F.relu(self.fc2(x))

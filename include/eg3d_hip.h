@@ -535,6 +535,7 @@ int eg3d_weight_grad_finish_slabs(const float* g, int nslab, int64_t slab_stride
 typedef struct eg3d_pack_item {
     const float* w; float* wf; float* wa; float* wsq;
     int32_t O, I, T, O_pad;
+    const float* oscale;       /* [O] per-output-channel scale folded into wf / wa (eg3d_pack_conv_weight_scaled: a folded BatchNorm), or null */
 } eg3d_pack_item;
 int eg3d_pack_conv_weights_batched(const eg3d_pack_item* items, int n, void* stream);
 int eg3d_unpack_weight_grad(const float* g, const float* w, const float* oscale, float* dw, float* doscale, int O, int I, int Ip, int T, void* stream);
@@ -851,6 +852,14 @@ int eg3d_slice_rgb4_bwd(const float* dy4, float* dx, int64_t P, int C, void* str
 int eg3d_warp_project_fwd(const float* origins, const float* dirs, const float* depth, const float* consts, float* uv, int64_t P, void* stream);
 int eg3d_warp_project_bwd(const float* origins, const float* dirs, const float* depth, const float* consts, const float* duv, float* d_origins,
                           float* d_dirs, float* d_depth, int64_t P, void* stream);
+
+/* F.grid_sample(input, grid, mode='bilinear', padding_mode='zeros', align_corners=False) for a channels-last input -- the feature warp of the
+ * depth-reprojection loss (training/warping_loss.py:50; ATen's kernel takes 152 + 218 us there, this one 6 + 8).
+ *   input [N,H,W,C] fp32, C % 4 == 0, 16-byte aligned; grid [N,Ho,Wo,2] (x, y) in [-1,1]; out / dout [N,Ho,Wo,C].
+ * bwd: dgrid [N,Ho,Wo,2] is overwritten; dinput (optional, [N,H,W,C], pre-zeroed) is accumulated with atomics. */
+int eg3d_grid_sample_nhwc_fwd(const float* input, const float* grid, float* out, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+int eg3d_grid_sample_nhwc_bwd(const float* input, const float* grid, const float* dout, float* dgrid, float* dinput, int N, int H, int W, int C, int Ho,
+                              int Wo, void* stream);
 
 /* Measurement aid (bench.py): a register-only v_mfma_f32_32x32x16_f16 loop on caller-supplied fp16 data -- what the matrix pipe sustains on
  * this chip at its current power / clock state, timed inside the benchmark run.  in: 4096 x 8 fp16 (64 KiB); out: blocks x 256 floats;

@@ -767,3 +767,23 @@ def test_run_to_run_drift_of_the_atomically_accumulated_gradients():
     assert dp <= 1e-3 and dw <= 1e-3
     if DET:                   # deterministic build: bit-identical
         assert dw == 0.0 and dp == 0.0 and runs[0][2] == runs[1][2]
+
+
+@pytest.mark.parametrize('C,Hh,Ww,Ho,Wo', [(256, 64, 64, 64, 64), (4, 33, 47, 20, 31), (68, 16, 16, 40, 40)])
+def test_grid_sample_kernel_matches_aten(C, Hh, Ww, Ho, Wo):
+    """eg3d_grid_sample_nhwc_fwd / _bwd vs F.grid_sample(bilinear, zeros, align_corners=False) (warping_loss.py:50): values, d grid, d input;
+    grid points beyond the border (zero padding, partial corner sets) included."""
+    from inv3d_amd.inversion import grid_sample_bilinear
+    g = torch.Generator(device='cpu').manual_seed(C + Ho)
+    inp = torch.randn(2, C, Hh, Ww, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    grid = (torch.rand(2, Ho, Wo, 2, generator=g) * 2.6 - 1.3).to(DEV)
+    dout = torch.randn(2, C, Ho, Wo, generator=g).to(DEV)
+    a_i, a_g = inp.clone().requires_grad_(True), grid.clone().requires_grad_(True)
+    b_i, b_g = inp.clone().double().requires_grad_(True), grid.clone().double().requires_grad_(True)
+    ya = grid_sample_bilinear(a_i, a_g)
+    yb = F.grid_sample(b_i, b_g, mode='bilinear', padding_mode='zeros', align_corners=False)
+    # (fp32 coordinate arithmetic against an fp64 reference: ix up to ~55 carries 3e-6 of rounding into the bilinear weights)
+    assert float((ya.double() - yb).abs().max()) <= 1e-5 * max(1.0, float(yb.abs().max()))
+    ya.backward(dout); yb.backward(dout.double())
+    for got, ref, nm in ((a_g.grad, b_g.grad, 'd grid'), (a_i.grad, b_i.grad, 'd input')):
+        assert float((got.double() - ref).abs().max()) <= 5e-5 * max(1.0, float(ref.abs().max())), nm
