@@ -118,8 +118,16 @@ class _ConvActFn(torch.autograd.Function):
         if not (need_x or need_w or need_b):
             return (None,) * 8
         dy = H.to_cl(dy.float())
-        dz = dy if (act == 'linear' and gain == 1.0) else H.bias_act_raw(dy, None, None, y, None, 1, 1, L.ACT_IDS[act], alpha, gain, -1.0)
         dx = dw = db = None
+        amax = None
+        if need_w and WGRAD_PRECISION != 'f32' and act in ('linear', 'relu', 'lrelu') and Co % 4 == 0 and Co <= 1024:
+            # trainable weights (the pose estimator's 7x7 stem): activation backward, bias gradient and max|dz| (the operand range of the
+            # f16x3 weight gradient) from one pass
+            db = H.zeros((Co,), dy.device) if need_b else None
+            amax = H.zeros((1,), dy.device)
+            dz = H.epilogue_bwd(dy, y, H.empty_cl(N, Co, Ho, Wo, dy.device), act=act, alpha=alpha, gain=gain, dbias=db, dz_amax=amax)
+        else:
+            dz = dy if (act == 'linear' and gain == 1.0) else H.bias_act_raw(dy, None, None, y, None, 1, 1, L.ACT_IDS[act], alpha, gain, -1.0)
         if need_x:
             def _pack():
                 wp = torch.cat([weight, weight.new_zeros(Co, Cip - Ci, kh, kw)], 1) if Cip != Ci else weight
@@ -134,9 +142,12 @@ class _ConvActFn(torch.autograd.Function):
             dwp = H.zeros((Co, kh * kw * Cip), dy.device)
             cls = _classes_strided(Ho, Wo, kh, kw, pad)
             for i in range(0, len(cls), 4):
-                H.conv_wgrad(x, dz, Cip, Co, dwp, cls[i:i + 4], in_stride=stride, out_stride=1)
+                if amax is not None:
+                    H.conv_wgrad(x, dz, Cip, Co, dwp, cls[i:i + 4], in_stride=stride, out_stride=1, precision=WGRAD_PRECISION, g_amax=amax)
+                else:
+                    H.conv_wgrad(x, dz, Cip, Co, dwp, cls[i:i + 4], in_stride=stride, out_stride=1)
             dw = dwp.view(Co, kh, kw, Cip)[..., :Ci].permute(0, 3, 1, 2).contiguous()
-        if need_b:
+        if need_b and db is None:
             db = dz.sum((0, 2, 3))
         return dx, dw, db, None, None, None, None, None
 
@@ -188,11 +199,12 @@ class _ConvScaleActFn(torch.autograd.Function):
         need_x, need_w, need_a, need_b = ctx.needs_input_grad[:4]
         dy = H.to_cl(dy.float())
         db = None
-        if act == 'linear':
+        if act == 'linear' and not ((need_w or need_a) and WGRAD_PRECISION != 'f32'):
             dz = dy
             if need_b:
                 db = dy.sum((0, 2, 3))
-        else:                                  # activation backward and the bias gradient in one pass
+            amax = None
+        else:                                  # activation backward, the bias gradient and max|dz| (the weight gradient's operand range) in one pass
             db = H.zeros((Co,), dy.device) if need_b else None
             amax = H.zeros((1,), dy.device) if ((need_w or need_a) and WGRAD_PRECISION != 'f32') else None      # max|dz|: range of the weight gradient's fp16 operand
             dz = H.epilogue_bwd(dy, y, H.empty_cl(N, Co, Ho, Wo, dy.device), act=act, gain=1.0, dbias=db, dz_amax=amax)
@@ -206,7 +218,7 @@ class _ConvScaleActFn(torch.autograd.Function):
         if need_w or need_a:
             T = kh * kw
             dwp = H.zeros((Co, T * Ci), dy.device)
-            if act != 'linear' and amax is not None:        # two-piece fp16 operands, three products per fp32 product (the generator's arithmetic); dz range-normalised by max|dz|
+            if amax is not None:        # two-piece fp16 operands, three products per fp32 product (the generator's arithmetic); dz range-normalised by max|dz|
                 H.conv_wgrad(x, dz, Ci, Co, dwp, _classes_strided(Ho, Wo, kh, kw, pad), in_stride=stride, out_stride=1, precision=WGRAD_PRECISION, g_amax=amax)
             else:
                 H.conv_wgrad(x, dz, Ci, Co, dwp, _classes_strided(Ho, Wo, kh, kw, pad), in_stride=stride, out_stride=1)
