@@ -130,6 +130,7 @@ extern "C" const char* eg3d_status_string(int status) {
         case EG3D_ERR_INVALID: return "invalid argument";
         case EG3D_ERR_UNSUPPORTED: return "unsupported configuration";
         case EG3D_ERR_TOO_LARGE: return "tensor exceeds int32 indexing";
+        case EG3D_ERR_WORKSPACE: return "deterministic build: accumulation targets of the call exceed the workspace lent with eg3d_det_set_workspace (or 40 regions)";
         default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown status";
     }
 }

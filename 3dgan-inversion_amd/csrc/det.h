@@ -10,7 +10,7 @@
 // Who owns the accumulators: the library call.  An entry point that accumulates opens a scope, binds its targets (pointer + element
 // count; any memory -- the caller's own tensors), launches its kernels, and closes the scope: the closing kernel converts each
 // accumulator to float, ADDS it to the target (targets may hold a starting value) and clears it.  The words live in a workspace the
-// caller lends once (eg3d_det_set_workspace); a call's targets must fit in it (EG3D_ERR_INVALID otherwise).  A target that was not
+// caller lends once (eg3d_det_set_workspace); a call's targets must fit in it (EG3D_ERR_WORKSPACE otherwise).  A target that was not
 // bound falls back to the float atomic and counts in eg3d_det_misses() -- the tests assert that count stays zero.
 //
 // One stream at a time: the bound-region table is a single device object updated in stream order.
@@ -120,7 +120,7 @@ struct eg3d_det_scope_t {
     }
     int commit() {
         if (!on) return EG3D_OK;
-        if (bad) return EG3D_ERR_INVALID;
+        if (bad) return EG3D_ERR_WORKSPACE;
         if (!t.n) return EG3D_OK;
         // targets carved from one allocation (neighbours, or the same pointer bound twice) become one region
         for (int i = 1; i < t.n; ++i)
@@ -140,7 +140,7 @@ struct eg3d_det_scope_t {
         unsigned long long used = 0;
         for (int i = 0; i < t.n; ++i) {
             const unsigned long long need = (unsigned long long)EG3D_DET_NW * t.r[i].count;
-            if (used + need > h->nwords) { bad = true; t.n = 0; return EG3D_ERR_INVALID; }
+            if (used + need > h->nwords) { bad = true; t.n = 0; return EG3D_ERR_WORKSPACE; }
             t.r[i].words = h->words + used;
             used += need;
         }

@@ -336,13 +336,13 @@ _det_ws = None
 
 def det_enable(max_elements: int = None, device=None):
     """Lend the deterministic build its accumulator workspace (32 bytes per float a single library call accumulates into; the default
-    covers a 512^2 x 128 split-K output).  Called by hipops on the first GPU use when EG3D_DETERMINISTIC=1; no-op in the normal build."""
+    covers a 512^2 x 128 split-K output and the plane gradients of a batch of 8; EG3D_DET_ELEMENTS overrides it).  Called by hipops on the first GPU use when EG3D_DETERMINISTIC=1; no-op in the normal build."""
     global _det_ws
     h = lib()
     if not h.eg3d_det_enabled():
         return False
     if _det_ws is None or (max_elements is not None and _det_ws[1] < max_elements):
-        n = int(max_elements or int(os.environ.get('EG3D_DET_ELEMENTS', str(40 * 1024 * 1024))))
+        n = int(max_elements or int(os.environ.get('EG3D_DET_ELEMENTS', str(96 * 1024 * 1024))))
         nbytes = h.eg3d_det_workspace_bytes(n)
         ws = torch.zeros(nbytes // 8 + 1, dtype=torch.int64, device=device or 'cuda')
         check(h.eg3d_det_set_workspace(ws.data_ptr(), nbytes, stream_ptr()), 'det_set_workspace')

@@ -27,6 +27,7 @@ extern "C" {
 #define EG3D_ERR_INVALID (-1)      /* bad argument (null pointer, negative size, ...) */
 #define EG3D_ERR_UNSUPPORTED (-2)  /* valid request this build has no kernel for        */
 #define EG3D_ERR_TOO_LARGE (-3)    /* exceeds int32 indexing, as the reference checks   */
+#define EG3D_ERR_WORKSPACE (-4)    /* deterministic build: the call's accumulation targets do not fit the lent workspace */
 
 #define EG3D_F32 0
 #define EG3D_F16 1

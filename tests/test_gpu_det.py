@@ -50,9 +50,10 @@ def test_the_normal_build_is_not_bit_identical():
 def test_library_calls_have_no_run_to_run_spread():
     r = _run(['tools/det_check.py'])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if 'differing' in l]
+    lines = [l for l in r.stdout.splitlines() if 'differing' in l and 'restoring' not in l]
     assert len(lines) >= 4 and all(l.rstrip().endswith(' 0') for l in lines), r.stdout
     assert 'deterministic build: True misses: 0' in r.stdout, r.stdout
+    assert 'workspace check: refused' in r.stdout and 'after restoring the workspace: runs differing: 0 misses: 0' in r.stdout, r.stdout
 
 
 def test_parity_bounds_tightened_under_the_deterministic_build():

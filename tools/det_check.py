@@ -47,3 +47,15 @@ from inv3d_amd import loss_nets as LN
 fa = torch.randn(1, 1 << 20, device=dev); fb = torch.randn(1, 1 << 20, device=dev)
 print('sqdist: runs differing:', distinct(lambda: LN.sqdist(fa, fb)) - 1)
 print('deterministic build:', bool(L.lib().eg3d_det_enabled()), 'misses:', L.det_misses())
+if L.lib().eg3d_det_enabled():
+    # a call whose targets exceed the lent workspace fails loudly (EG3D_ERR_WORKSPACE), it does not fall back to float atomics
+    small = torch.zeros(4096 // 8 + 64, dtype=torch.int64, device=dev)
+    L.check(L.lib().eg3d_det_set_workspace(small.data_ptr(), 4096 + 64 * 8, L.stream_ptr()), 'det_set_workspace')
+    try:
+        f_dgrad_finish()
+        print('workspace check: NOT refused')
+    except L.Eg3dHipError as e:
+        print('workspace check: refused' if 'status -4' in str(e) else f'workspace check: wrong error {e}')
+    L._det_ws = None
+    L.det_enable()
+    print('after restoring the workspace: runs differing:', distinct(f_dgrad_finish) - 1, 'misses:', L.det_misses())
