@@ -82,8 +82,7 @@ def test_latent_projection_graph_replay_matches_eager():
 
 def test_pose_and_warping_c3():
     """Config C3: C2 + quaternion/translation pose chain + canonical no-grad forward + depth-reprojection warping loss.
-    (i) one step: the pose gradients themselves; (ii) a short trajectory.  Pose gradients are sums of piecewise-constant
-    per-sample terms (see close_most in test_gpu_ops) and Adam normalises their magnitude, so the trajectory bound is loose."""
+    (i) one step: the pose gradients themselves; (ii) a short trajectory at the parity bar (final-PSNR drift <= 1e-3 dB)."""
     from inv3d_amd.inversion import LatentProjector
     cfg, P, G, cam, u1, u2, target, init_noise = _setup()
     kw = dict(num_steps=30, init_noise=init_noise, optimize_pose=True, use_warping_loss=True, cam_preheat_steps=3, cam_lr=1e-3,
@@ -111,7 +110,7 @@ def test_pose_and_warping_c3():
     assert float((hip.translation_opt.detach().cpu() - ref.translation_opt.detach()).abs().max()) < 1e-2
     drift = abs(_psnr(h['image'], target) - _psnr(r['image'], target))
     print(f'C3 7 steps: final PSNR drift {drift:.2e} dB')
-    assert drift <= (1e-3 if DET else 5e-2), f'final PSNR drift {drift:.2e} dB'
+    assert drift <= 1e-3, f'final PSNR drift {drift:.2e} dB'          # (5e-2 until the tie order of unify_samples was fixed in round 4)
 
 
 def test_pivotal_tuning_c4():
@@ -716,10 +715,8 @@ def test_config_c4_at_full_size_replays_from_a_graph():
 
 def test_pose_and_warping_c3_long_horizon():
     """Config C3 over 60 steps (10 camera pre-heat + 50 joint steps, the reference's learning rates): the pose chain and the warping loss
-    well past the pre-heat against the CPU twin on identical inputs.  Bound stated here, not inherited: final-PSNR drift <= 2e-2 dB and
-    |loss drift| <= 0.5 % -- the pose gradients are sums of piecewise-constant per-sample terms (a 1-ulp coordinate difference moves one
-    sample across a texel edge), Adam turns every such flip into a full-size step of the pose vector, and 50 steps let the two
-    trajectories decorrelate by that mechanism; the projector-loop pin (6 steps, reference trace) holds 1e-3 dB."""
+    well past the pre-heat against the CPU twin on identical inputs: final-PSNR drift (and the worst drift along the way) <= 1e-3 dB,
+    |loss drift| <= 1e-4 relative, latent within 1e-3."""
     from inv3d_amd.inversion import LatentProjector
     cfg, P, G, cam, u1, u2, target, init_noise = _setup()
     steps, preheat = 60, 10
@@ -739,11 +736,14 @@ def test_pose_and_warping_c3_long_horizon():
         worst = max(worst, abs(_psnr(h['image'], target) - _psnr(r['image'], target)))
     drift = abs(_psnr(h['image'], target) - _psnr(r['image'], target))
     print(f'C3 60 steps: final PSNR drift {drift:.2e} dB (worst along the way {worst:.2e}), loss {float(h["loss"]):.5f} vs {float(r["loss"]):.5f}')
-    # deterministic build (EG3D_DETERMINISTIC=1): the sums are exact and order-free, the trajectories stay together -- the parity bar itself
-    # (observed 3e-6 dB final, 2e-5 dB worst along the way)
-    assert drift <= (1e-3 if DET else 2e-2), f'final PSNR drift {drift:.2e} dB'
-    assert abs(float(h['loss']) - float(r['loss'])) <= (1e-4 if DET else 5e-3) * max(1.0, abs(float(r['loss'])))
-    assert float((hip.w_opt.detach().cpu() - ref.w_opt.detach()).abs().max()) < (1e-3 if DET else 5e-2)
+    # The parity bar itself, in both builds.  Rounds 2-3 held 2e-2 dB here and blamed the piecewise-constant coordinate gradient; the cause was
+    # the tie order of unify_samples (round 4, DESIGN.md 3.5 'Sampler indices'): with the coarse samples ranked like the reference's sort the
+    # trajectories stay together -- observed 3e-6 dB final, 2e-5 dB worst along the way, |d loss| 1e-6 relative (normal and deterministic build)
+    dwm = float((hip.w_opt.detach().cpu() - ref.w_opt.detach()).abs().max())
+    print(f'max |w - w_ref| {dwm:.2e}')
+    assert drift <= 1e-3 and worst <= 1e-3, f'final PSNR drift {drift:.2e} dB (worst {worst:.2e})'
+    assert abs(float(h['loss']) - float(r['loss'])) <= 1e-4 * max(1.0, abs(float(r['loss'])))
+    assert dwm < 1e-3
 
 
 def test_run_to_run_drift_of_the_atomically_accumulated_gradients():
