@@ -28,7 +28,7 @@ def close(a, b, tol, what=''):
     assert err <= tol * scale, f'{what}: err {err:.3e} > {tol} * {scale:.3e}'
 
 
-def close_most(a, b, tol, what='', frac=0.02, loose=0.05):
+def close_most(a, b, tol, what='', frac=0.002, loose=0.05):
     """Per-ray coordinate gradients are piecewise constant in the sample position (bilinear texel boundaries): a sample
     whose coordinate differs by one ulp between CPU and GPU can flip a floor() and change that ray's gradient by O(1/samples).
     Require the tight tolerance on all but `frac` of the rows and a loose bound on the rest."""

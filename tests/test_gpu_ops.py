@@ -28,10 +28,13 @@ def close(a, b, tol, what=''):
     assert err <= tol * scale, f'{what}: err {err:.3e} > {tol} * {scale:.3e}'
 
 
-def close_most(a, b, tol, what='', frac=0.02, loose=0.05):
+def close_most(a, b, tol, what='', frac=0.002, loose=0.05):
     """Per-ray coordinate gradients are piecewise constant in the sample position (bilinear texel boundaries): a sample
     whose coordinate differs by one ulp between CPU and GPU can flip a floor() and change that ray's gradient by O(1/samples).
-    Require the tight tolerance on all but `frac` of the rows and a loose bound on the rest."""
+    Require the tight tolerance on all but `frac` of the rows (at least one) and a loose bound on the rest.  Rounds 1-3 allowed 2 % of the
+    rays; since the tie order of unify_samples follows the reference's sort (round 4) every case of this suite has ZERO rows above the
+    tolerance and a worst row of 4e-6 -- the allowance is now 0.2 % (one ray of 200, four of 2048), for the 3-per-million importance
+    samples whose uniform sits within 4e-6 of a CDF edge (test_sampler_indices_exact counts those)."""
     a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
     assert a.shape == b.shape and torch.isfinite(a).all(), what
     scale = max(1.0, float(b.abs().max()))
