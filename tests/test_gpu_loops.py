@@ -99,15 +99,17 @@ def test_pose_and_warping_c3():
     h = hip.step(w_noise=None, render_uniforms=(u1.to(DEV), u2.to(DEV)))
     gq_r, gt_r = ref.quat.grad, ref.translation_opt.grad
     gq_h, gt_h = hip.quat.grad.cpu(), hip.translation_opt.grad.cpu()
-    assert float((gq_h - gq_r).abs().max()) <= 2e-2 * max(1e-6, float(gq_r.abs().max())), (gq_h, gq_r)
-    assert float((gt_h - gt_r).abs().max()) <= 2e-2 * max(1e-6, float(gt_r.abs().max())), (gt_h, gt_r)
+    print(f'pose gradients: d quat rel {float((gq_h - gq_r).abs().max()) / max(1e-6, float(gq_r.abs().max())):.2e}, d translation rel {float((gt_h - gt_r).abs().max()) / max(1e-6, float(gt_r.abs().max())):.2e}')
+    # (2e-2 in rounds 2-3; observed 2.5e-6 since the sampler's tie order follows the reference's sort)
+    assert float((gq_h - gq_r).abs().max()) <= 1e-4 * max(1e-6, float(gq_r.abs().max())), (gq_h, gq_r)
+    assert float((gt_h - gt_r).abs().max()) <= 1e-4 * max(1e-6, float(gt_r.abs().max())), (gt_h, gt_r)
     assert abs(float(h['loss']) - float(r['loss'])) <= 1e-3 * max(1.0, abs(float(r['loss'])))
     for i in range(1, 7):
         wn = O._randn('wn', i, (1, 1, cfg.w_dim))
         r = ref.step(u1, u2, w_noise=wn)
         h = hip.step(w_noise=wn, render_uniforms=(u1.to(DEV), u2.to(DEV)))
-    assert float((hip.quat.detach().cpu() - ref.quat.detach()).abs().max()) < 1e-2
-    assert float((hip.translation_opt.detach().cpu() - ref.translation_opt.detach()).abs().max()) < 1e-2
+    assert float((hip.quat.detach().cpu() - ref.quat.detach()).abs().max()) < 1e-4
+    assert float((hip.translation_opt.detach().cpu() - ref.translation_opt.detach()).abs().max()) < 1e-4
     drift = abs(_psnr(h['image'], target) - _psnr(r['image'], target))
     print(f'C3 7 steps: final PSNR drift {drift:.2e} dB')
     assert drift <= 1e-3, f'final PSNR drift {drift:.2e} dB'          # (5e-2 until the tie order of unify_samples was fixed in round 4)
