@@ -19,6 +19,7 @@
 // instead of 128 fp32 ones (64 cycles each); 24 instead of 64 for the forward one.  The gather is done in the same split layout: the
 // two lanes of a sample read the two 64-byte halves of each 128-byte texel.
 #include "render_common.h"
+#include <cstdlib>
 
 using namespace eg3d_render;
 
@@ -253,6 +254,53 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const DecodeArgs a) {
         acc.x *= 1.f / 3.f; acc.y *= 1.f / 3.f; acc.z *= 1.f / 3.f; acc.w *= 1.f / 3.f;
     }
     reinterpret_cast<float4*>(a.feat + orow * FC)[q] = acc;
+}
+
+// ---- the position gradient as a pass of its own (backward, when the camera is optimised) ---------------------------------------------
+// dL/d position = sum_planes sum_corners (df . texel) d weight / d position needs the twelve texels of a sample again.  Inside the
+// decoder's backward kernel that re-gather costs what the forward gather did there (one plane's 16 loads in flight per wave at ~140
+// registers: 214 -> 391 us for 1.57 M rows); here thread = (row, channel quad) like gather_rows_kernel: the quad of df the decoder just
+// wrote, twelve independent 16-byte texel loads, three partial sums, an 8-lane reduction.
+__global__ void __launch_bounds__(256) gather_grad_rows_kernel(const DecodeArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = i >> 3;
+    const int q = (int)(i & 7);
+    const bool in_range = row < a.M;
+    float4 ps = make_float4(NAN, 0.f, 0.f, 0.f);
+    if (in_range) ps = *reinterpret_cast<const float4*>(a.pos + row * 4);
+    const bool valid = in_range && !isnan(ps.x);
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    if (valid) {
+        const float4 dfq = *reinterpret_cast<const float4*>(a.df_rows + row * FC + 4 * q);
+        const int n = (int)((unsigned)row / (unsigned)a.rows_per_image);
+        const float* pn = a.planes + (int64_t)n * a.Hp * a.Wp * a.ldp + 4 * q;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            float u, v;
+            plane_uv(pl, ps.x * a.cs, ps.y * a.cs, ps.z * a.cs, u, v);
+            const float ix = ((u + 1.f) * a.Wp - 1.f) * 0.5f, iy = ((v + 1.f) * a.Hp - 1.f) * 0.5f;
+            const float fx0 = floorf(ix), fy0 = floorf(iy);
+            const int x0 = (int)fx0, y0 = (int)fy0;
+            const float wx1 = ix - fx0, wx0 = (fx0 + 1.f) - ix, wy1 = iy - fy0, wy0 = (fy0 + 1.f) - iy;
+            float gix = 0.f, giy = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int xx = x0 + (c & 1), yy = y0 + (c >> 1);
+                const bool inb = (unsigned)xx < (unsigned)a.Wp && (unsigned)yy < (unsigned)a.Hp;
+                const int xc = min(max(xx, 0), a.Wp - 1), yc = min(max(yy, 0), a.Hp - 1);
+                const float4 t = *reinterpret_cast<const float4*>(pn + (yc * a.Wp + xc) * a.ldp + pl * FC);
+                float dot = fmaf(t.w, dfq.w, fmaf(t.z, dfq.z, fmaf(t.y, dfq.y, t.x * dfq.x)));
+                dot = inb ? dot : 0.f;
+                gix += dot * ((c & 1) ? 1.f : -1.f) * ((c >> 1) ? wy1 : wy0);
+                giy += dot * ((c >> 1) ? 1.f : -1.f) * ((c & 1) ? wx1 : wx0);
+            }
+            const float gu = gix * (0.5f * a.Wp) * a.cs, gv = giy * (0.5f * a.Hp) * a.cs;
+            if (pl == 0) { gx += gu; gy += gv; } else if (pl == 1) { gx += gu; gz += gv; } else { gz += gu; gx += gv; }
+        }
+    }
+#pragma unroll
+    for (int o = 1; o <= 4; o <<= 1) { gx += __shfl_xor(gx, o); gy += __shfl_xor(gy, o); gz += __shfl_xor(gz, o); }
+    if (q == 0 && in_range) a.gc_rows[row] = valid ? make_float4(gx, gy, gz, ps.w) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 template <bool BWD, bool FEAT>
@@ -502,6 +550,16 @@ int launch_decode(const DecodeArgs& a, bool bwd, hipStream_t st) {
         return EG3D_ERR_UNSUPPORTED;      // 32-bit row and texel-offset arithmetic in the kernels
     const int64_t ntiles = (a.M + 31) / 32;
     const int blocks = (int)std::min<int64_t>((ntiles + 3) / 4, 256 * (bwd ? DEC_GRID_BWD : DEC_GRID_FWD));     // persistent: resident blocks per CU x 256 CUs
+    static const bool gc_split = [] { const char* e = getenv("EG3D_GC_SPLIT"); return e ? atoi(e) != 0 : true; }();
+    if (bwd && gc_split && a.gc_rows != nullptr && a.df_rows != nullptr && a.pos_stride == 4) {
+        // position gradient from the df rows this launch writes, in a high-occupancy pass of its own (gather_grad_rows_kernel)
+        DecodeArgs b = a;
+        b.gc_rows = nullptr;
+        if (int rc = launch_decode(b, true, st)) return rc;
+        hipLaunchKernelGGL(gather_grad_rows_kernel, dim3((unsigned)((a.M * 8 + 255) / 256)), dim3(256), 0, st, a);
+        EG3D_LAUNCH_CHECK();
+        return EG3D_OK;
+    }
     if (a.feat != nullptr) {
         if (!bwd) hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((a.M * 8 + 255) / 256)), dim3(256), 0, st, a);
         if (bwd) hipLaunchKernelGGL((decode_rows_kernel<true, true>), dim3(blocks), dim3(256), FRAG_BYTES_BWD, st, a);
