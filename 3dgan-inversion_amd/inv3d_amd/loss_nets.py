@@ -32,6 +32,11 @@ from .fused import _auto_ksplit
 from .torch_utils.ops import bias_act
 
 WGRAD_PRECISION = os.environ.get('EG3D_POSE_WGRAD', 'f16x3')        # weight gradients of the in-loop pose estimator: 'f16x3' | 'f32' (v_mfma_f32_32x32x2_f32)
+# Frozen loss networks (VGG16-LPIPS, VGG16 features, AlexNet-LPIPS): when the operand range is known -- the producing layer's epilogue reports
+# max|out| (a device scalar; one reduction pass for the network input and after split-K layers), the activation-backward pass reports max|dz| --
+# the convs run in the generator's arithmetic (two-piece fp16 operands range-normalised by that maximum, three MFMA products per fp32
+# product) instead of bf16x6 (six): same fp32-equivalent result, half the matrix work.  EG3D_LOSS_NET_F16X3=0: bf16x6 everywhere.
+LOSS_NET_F16X3 = os.environ.get('EG3D_LOSS_NET_F16X3', '1') != '0'
 LOSS_NET_PRECISION = 'bf16x6'        # fp32-equivalent for any operand range (pixel values up to 255 enter these networks)
 
 
@@ -74,7 +79,7 @@ def _classes_strided_adjoint(Hi, Wi, kh, kw, s, pad):
 def _launch_groups(x, wp, Ck, Nc, out, classes, accumulate, **kw):
     """At most 4 classes per launch.  accumulate: several classes add into the same pixels (out pre-zeroed, atomics)."""
     for i in range(0, len(classes), 4):
-        H.conv_igemm(x, wp, Ck, Nc, out, classes[i:i + 4], epi=L.EPI_ATOMIC if accumulate else L.EPI_STORE, precision=LOSS_NET_PRECISION, **kw)
+        H.conv_igemm(x, wp, Ck, Nc, out, classes[i:i + 4], epi=L.EPI_ATOMIC if accumulate else L.EPI_STORE, **dict(dict(precision=LOSS_NET_PRECISION), **kw))
 
 
 class _ConvActFn(torch.autograd.Function):
@@ -98,15 +103,25 @@ class _ConvActFn(torch.autograd.Function):
         Ho, Wo = (Hi + 2 * pad - kh) // stride + 1, (Wi + 2 * pad - kw) // stride + 1
         cls = _classes_strided(Ho, Wo, kh, kw, pad)
         ks = _auto_ksplit(cls, N, Co, Cip) if len(cls) == 1 else 1
+        f16 = LOSS_NET_F16X3 and not trainable and act in ('linear', 'relu', 'lrelu')
+        pk = {}
+        if f16:             # operand range: the producer's report if the tensor carries one, else one reduction pass (hipops.amax_of)
+            pk = dict(precision='f16x3', a_amax=H.amax_of(x), w_pieces=H.memo(('lossnet_fwd_pieces', Cip), [weight], lambda: H.split_weight_pieces(wf)))
+        y_amax = None
         if len(cls) == 1 and ks == 1:
             y = H.empty_cl(N, Co, Ho, Wo, x.device)
-            H.conv_igemm(x, wf, Cip, Co, y, cls, in_stride=stride, epi=L.EPI_FWD, bias=bias, act=act, alpha=alpha, gain=gain, precision=LOSS_NET_PRECISION)
+            y_amax = H.zeros((1,), x.device) if f16 else None
+            H.conv_igemm(x, wf, Cip, Co, y, cls, in_stride=stride, epi=L.EPI_FWD, bias=bias, act=act, alpha=alpha, gain=gain, out_amax=y_amax,
+                         **(pk or dict(precision=LOSS_NET_PRECISION)))
         else:           # several tap classes per pixel, or a grid too small to fill the chip (split-K): accumulate, then bias + act
             z = H.zeros_cl(N, Co, Ho, Wo, x.device)
-            _launch_groups(x, wf, Cip, Co, z, cls, True, in_stride=stride, ksplit=ks)
+            _launch_groups(x, wf, Cip, Co, z, cls, True, in_stride=stride, ksplit=ks, **pk)
             y = H.bias_act_raw(z, bias, None, None, None, 0, 1, L.ACT_IDS[act], alpha, gain, -1.0)
+        if y_amax is not None:
+            H.tag_amax(y, y_amax)          # (read by the next layer's amax_of; max pooling passes it on)
         ctx.save_for_backward(y, weight, x if trainable else None)
         ctx.cfg = (stride, pad, act, x.shape, (Ho, Wo), float(alpha), float(gain))
+        ctx.f16 = f16
         return y
 
     @staticmethod
@@ -126,6 +141,9 @@ class _ConvActFn(torch.autograd.Function):
             db = H.zeros((Co,), dy.device) if need_b else None
             amax = H.zeros((1,), dy.device)
             dz = H.epilogue_bwd(dy, y, H.empty_cl(N, Co, Ho, Wo, dy.device), act=act, alpha=alpha, gain=gain, dbias=db, dz_amax=amax)
+        elif ctx.f16 and need_x and not (act == 'linear' and gain == 1.0) and Co % 4 == 0 and Co <= 1024:
+            amax = H.zeros((1,), dy.device)       # frozen network: the activation backward also reports max|dz|, the data gradient's operand range
+            dz = H.epilogue_bwd(dy, y, H.empty_cl(N, Co, Ho, Wo, dy.device), act=act, alpha=alpha, gain=gain, dz_amax=amax)
         else:
             dz = dy if (act == 'linear' and gain == 1.0) else H.bias_act_raw(dy, None, None, y, None, 1, 1, L.ACT_IDS[act], alpha, gain, -1.0)
         if need_x:
@@ -137,7 +155,10 @@ class _ConvActFn(torch.autograd.Function):
             ks = _auto_ksplit(cls, N, Cip, Co) if len(cls) == 1 else 1
             overlapping |= ks > 1
             dx = (H.zeros_cl if overlapping else H.empty_cl)(N, Cip, Hi, Wi, dy.device)
-            _launch_groups(dz, wa, Co, Cip, dx, cls, overlapping, out_stride=stride, ksplit=ks)
+            pk = {}
+            if ctx.f16 and amax is not None and not need_w:
+                pk = dict(precision='f16x3', a_amax=amax, w_pieces=H.memo(('lossnet_adj_pieces', Cip), [weight], lambda: H.split_weight_pieces(wa)))
+            _launch_groups(dz, wa, Co, Cip, dx, cls, overlapping, out_stride=stride, ksplit=ks, **pk)
         if need_w:
             dwp = H.zeros((Co, kh * kw * Cip), dy.device)
             cls = _classes_strided(Ho, Wo, kh, kw, pad)
@@ -260,6 +281,8 @@ class _MaxPoolFn(torch.autograd.Function):
         L.check(L.lib().eg3d_maxpool2d_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr() if idx is not None else None, N, Hi, Wi, C, C, k, s,
                                            L.stream_ptr()), 'maxpool2d_fwd')
         ctx.idx, ctx.cfg = idx, (k, s, x.shape)
+        if getattr(x, '_eg3d_amax', None) is not None:
+            H.tag_amax(y, x._eg3d_amax)          # max|pool(x)| <= max|x|: an upper bound is all the range normalisation needs
         return y
 
     @staticmethod
