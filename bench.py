@@ -252,6 +252,13 @@ def side_configs(G, target, cam, dev, use_graph, steps=10):
             r['all_conv_frac'] = round(fl / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)            # algorithmic TFLOP/s / 2500 (the MFMAs issued are 16-bit)
             r['all_conv_frac_executed'] = round(3 * fl / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)
             r['all_conv_ms_per_step'] = round(ms / 2, 3)
+        try:        # SURVEY 8d's backbone-only figure with the chip filled: the north star's "MFMA on the backbone" is a batch question (at one image 0.039)
+            bf_ms, bb_ms = measure_backbone(G, dev, m)
+            tf = 93.1 * 2 * m * 1e9 / ((bf_ms + bb_ms) * 1e-3) / 1e12
+            r['roofline_backbone'] = dict(gflop_algorithmic=round(93.1 * 2 * m, 1), fwd_ms=round(bf_ms, 3), bwd_ms=round(bb_ms, 3), tflops=round(tf, 1),
+                                          peak=BF16_MFMA_PEAK_TFLOPS, frac=round(tf / BF16_MFMA_PEAK_TFLOPS, 4), frac_executed=round(3 * tf / BF16_MFMA_PEAK_TFLOPS, 4))
+        except Exception as e:
+            r['roofline_backbone'] = dict(error='%s: %s' % (type(e).__name__, e))
         return r
     guarded('images_per_gpu_8', c5)
 
