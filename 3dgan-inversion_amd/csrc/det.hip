@@ -3,6 +3,24 @@
 #include "det.h"
 #include <vector>
 
+namespace {
+// every value is added to *target by its own thread (eg3d_det_accumulate: the accumulator's property test)
+__global__ void __launch_bounds__(256) det_accumulate_kernel(const float* __restrict__ v, int64_t n, float* __restrict__ target) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) eg3d_acc(target, v[i]);
+}
+}  // namespace
+
+extern "C" int eg3d_det_accumulate(const float* values, int64_t n, float* target, void* stream) {
+    if (!values || !target || n < 0) return EG3D_ERR_INVALID;
+    if (n == 0) return EG3D_OK;
+    EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND(det, target, 1); EG3D_DET_COMMIT(det);
+    hipLaunchKernelGGL(det_accumulate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, values, n, target);
+    EG3D_DET_END(det);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
 #if EG3D_DET
 
 namespace {

@@ -236,6 +236,7 @@ _SIGS = {
     'eg3d_det_workspace_bytes': (C.c_int64, [C.c_int64]),
     'eg3d_det_set_workspace': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     'eg3d_det_misses': (C.c_int, [C.POINTER(C.c_uint32), C.c_void_p]),
+    'eg3d_det_accumulate': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'eg3d_modconv_epilogue_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int64,
                                             C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),

@@ -880,6 +880,10 @@ int eg3d_det_enabled(void);
 int64_t eg3d_det_workspace_bytes(int64_t max_elements_per_call);
 int eg3d_det_set_workspace(void* workspace, int64_t bytes, void* stream);
 int eg3d_det_misses(uint32_t* out, void* stream);
+/* *target += sum of values[0..n), every value added by its own thread through the library's accumulation primitive: float atomics in the
+ * normal build (order-dependent), the exact accumulator in the deterministic one (the sum is exact up to the final rounding whatever the
+ * values' order and range -- tests/test_gpu_det.py checks that against an exact sum). */
+int eg3d_det_accumulate(const float* values, int64_t n, float* target, void* stream);
 
 #ifdef __cplusplus
 }

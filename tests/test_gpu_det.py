@@ -53,6 +53,9 @@ def test_library_calls_have_no_run_to_run_spread():
     lines = [l for l in r.stdout.splitlines() if 'differing' in l and 'restoring' not in l]
     assert len(lines) >= 4 and all(l.rstrip().endswith(' 0') for l in lines), r.stdout
     assert 'deterministic build: True misses: 0' in r.stdout, r.stdout
+    acc = [l for l in r.stdout.splitlines() if l.startswith('accumulator:')]
+    assert acc and acc[0].startswith('accumulator: 1 distinct result(s)'), r.stdout           # order-independent ...
+    assert float(acc[0].split('exact sum ')[1].split(' ulp')[0]) <= 1.0, acc[0]              # ... and the exact sum up to the final rounding
     assert 'workspace check: refused' in r.stdout and 'after restoring the workspace: runs differing: 0 misses: 0' in r.stdout, r.stdout
 
 

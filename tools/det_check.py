@@ -59,3 +59,25 @@ if L.lib().eg3d_det_enabled():
     L._det_ws = None
     L.det_enable()
     print('after restoring the workspace: runs differing:', distinct(f_dgrad_finish) - 1, 'misses:', L.det_misses())
+
+# ---- the accumulator itself: n values of wildly different magnitude and sign, one thread each, in shuffled orders -> the exact sum -------------
+import math, random
+random.seed(7)
+vals = []
+for k in range(200000):
+    e = random.choice([-60, -40, -20, -10, -3, 0, 5, 12, 20, 30])
+    vals.append(random.uniform(-1, 1) * 2.0 ** e)
+vals += [3.0e9, -3.0e9, 1.0e-30, -7.0e-38, 1.0e-41]                      # cancellation of large terms, subnormals
+vt = torch.tensor(vals, dtype=torch.float32)
+exact = math.fsum(float(x) for x in vt.tolist())                          # exact sum of the fp32 values (Shewchuk), rounded once to double
+want = torch.tensor(exact, dtype=torch.float64).float()
+outs = []
+for rep in range(6):
+    perm = torch.randperm(vt.numel())
+    dv = vt[perm].to(dev)
+    tgt = torch.zeros(1, device=dev)
+    L.check(L.lib().eg3d_det_accumulate(dv.data_ptr(), dv.numel(), tgt.data_ptr(), L.stream_ptr()), 'det_accumulate')
+    outs.append(tgt.cpu())
+ulp = abs(float(torch.nextafter(want, torch.tensor(float('inf'))) - want))
+err_ulps = max(abs(float(o) - float(want)) / ulp for o in outs)
+print(f'accumulator: {len(set(float(o) for o in outs))} distinct result(s) over 6 shuffles, error vs the exact sum {err_ulps:.2f} ulp (exact {exact:.9e})')
