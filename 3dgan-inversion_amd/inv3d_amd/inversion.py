@@ -312,7 +312,7 @@ def grid_sample_bilinear(inp: torch.Tensor, grid: torch.Tensor) -> torch.Tensor:
     return F.grid_sample(inp, grid, mode='bilinear', align_corners=False)
 
 
-def warping_loss(G, ws, canonical_cam, extrinsic, init_ext, intrinsic, depth, target_feat, feat_fn, synth_kwargs=None):
+def warping_loss(G, ws, canonical_cam, extrinsic, init_ext, intrinsic, depth, target_feat, feat_fn, synth_kwargs=None, cl4_ok=False):
     """Depth-reprojection loss (training/warping_loss.py:6-56): render the canonical view without gradient, lift the predicted
     depth to 3-D with the predicted extrinsic, project into the canonical image, sample canonical features there and compare
     with the target's features under a foreground mask.  The target's feature map is passed in (the reference recomputes it
@@ -320,7 +320,13 @@ def warping_loss(G, ws, canonical_cam, extrinsic, init_ext, intrinsic, depth, ta
     synth_kwargs = synth_kwargs or {}
     with torch.no_grad():
         can = G.synthesis(ws.detach(), canonical_cam.detach(), noise_mode='const', force_fp32=True, **synth_kwargs)['image']
-        if can.shape[2] > 256:
+        p4 = getattr(can, '_eg3d_padded4', None)
+        res = can.shape[2]
+        if cl4_ok and p4 is not None and res == can.shape[3] and (res <= 256 or res % 256 == 0):
+            # the 4-float-pixel image the SR head wrote, area-resized in one pass (as the step's main image): no pad / cat / layout copy
+            from . import loss_nets as LN
+            can = LN.image_prepare(p4, max(1, res // 256), 1.0, 0.0)
+        elif res > 256:
             can = _area_resize(can, 256)
         can_feat = feat_fn(can)
     mask = (depth < depth.mean()).float()
@@ -384,6 +390,7 @@ class LatentProjector:
         self.num_ws = G.backbone.num_ws
         self.feature_net = feature_net if feature_net is not None else StubFeatureNet().to(dev)
         self.warp_net = warp_feature_net if warp_feature_net is not None else self.feature_net_map
+        self._warp_cl4 = os.environ.get('EG3D_C3_CL4', '1') != '0' and bool(getattr(warp_feature_net if warp_feature_net is not None else self.feature_net, 'accepts_cl4', False))    # takes [N,4,H,W] channels_last
         self.gen = torch.Generator(device=dev).manual_seed(seed)
         # target: [1,3,H,W] in [-1,1]  ->  [0,255] at 256^2 (w_projector.py:106-110)
         self.target = target
@@ -646,7 +653,8 @@ class LatentProjector:
         if self.use_warp and self.optimize_pose:
             kw_can = {k: v for k, v in kw.items() if k != 'cache_backbone'}
             warp = warping_loss(G, ws, self.canonical_cam, pred_ext, self.init_ext, self.intrinsic, out['image_depth'],
-                                self.target_warp_feat, self.warp_net, dict(kw_can, use_cached_backbone=True) if share else kw_can)
+                                self.target_warp_feat, self.warp_net, dict(kw_can, use_cached_backbone=True) if share else kw_can,
+                                cl4_ok=self._warp_cl4)
             if share:
                 G._last_planes = None          # (nothing outside this step may render stale planes)
             loss = loss + warp
