@@ -750,6 +750,39 @@ __global__ void __launch_bounds__(256) weight_grad_finish_kernel(const float* __
     }
 }
 
+// ... of every layer in one launch (pivotal tuning: 17 conv layers, block -> (layer, output channel) through a prefix table in the kernel
+// arguments): the per-layer launches are 5 - 13 us each at 128 - 512 blocks.
+struct WgfBatch { eg3d_wgf_item it[EG3D_WGF_BATCH_MAX]; int blk0[EG3D_WGF_BATCH_MAX + 1]; int n; };
+__global__ void __launch_bounds__(256) weight_grad_finish_batched_kernel(const WgfBatch b) {
+    extern __shared__ float row[];
+    int l = 0;
+    while (l + 1 < b.n && (int)blockIdx.x >= b.blk0[l + 1]) ++l;
+    const eg3d_wgf_item& q = b.it[l];
+    const int o = blockIdx.x - b.blk0[l], tid = threadIdx.x, I = q.I, T = q.T, O = q.O, ld = I + 1;
+    float* qq = row + T * ld;
+    const int64_t ro = (int64_t)o * T * I;
+    for (int k = tid; k < T * I; k += 256) {
+        const int t = k / I, i = k - t * I;
+        float v = q.g[ro + k];
+        for (int sl = 1; sl < q.nslab; ++sl) v += q.g[(int64_t)sl * q.slab_stride + ro + k];
+        row[t * ld + i] = v;
+    }
+    for (int i = tid; i < I; i += 256) {
+        float acc = 0.f;
+        if (q.dd != nullptr)
+            for (int n = 0; n < q.N; ++n) {
+                const float dv = q.d[(int64_t)n * O + o], sv = q.s[(int64_t)n * I + i];
+                acc = fmaf(q.dd[(int64_t)n * O + o] * (-0.5f) * dv * dv * dv, sv * sv, acc);
+            }
+        qq[i] = 2.f * acc;
+    }
+    __syncthreads();
+    for (int k = tid; k < I * T; k += 256) {
+        const int i = k / T, t = k - i * T;
+        q.dw[ro + k] = fmaf(q.w[ro + k], qq[i], row[t * ld + i]);
+    }
+}
+
 // one wave per (n,o)
 __global__ void __launch_bounds__(256) demod_fwd_kernel(const float* __restrict__ s, const float* __restrict__ wsq, float* __restrict__ d, int N, int Co, int Ck) {
     int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
@@ -954,6 +987,30 @@ extern "C" int eg3d_dgrad_finish(const float* z, const float* x, const float* s,
 extern "C" int eg3d_weight_sqsum(const float* w, float* wsq, int Co, int ntaps, int Ck, void* stream) {
     if (!w || !wsq || Co <= 0 || ntaps <= 0 || Ck <= 0) return EG3D_ERR_INVALID;
     hipLaunchKernelGGL(weight_sqsum_kernel, dim3(eg3d_cdiv((int64_t)Co * Ck, 256)), dim3(256), 0, (hipStream_t)stream, w, wsq, Co, ntaps, Ck);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_weight_grad_finish_batched(const eg3d_wgf_item* items, int n, void* stream) {
+    if (!items || n < 1 || n > EG3D_WGF_BATCH_MAX) return EG3D_ERR_INVALID;
+    WgfBatch b;
+    int blocks = 0;
+    size_t smem = 0;
+    for (int l = 0; l < n; ++l) {
+        const eg3d_wgf_item& q = items[l];
+        if (!q.g || !q.w || !q.dw || q.N <= 0 || q.O <= 0 || q.I <= 0 || q.T <= 0 || q.T > 64 || (q.dd && (!q.s || !q.d)) || q.nslab < 1 ||
+            (q.nslab > 1 && q.slab_stride < (int64_t)q.O * q.T * q.I)) return EG3D_ERR_INVALID;
+        b.it[l] = q;
+        b.blk0[l] = blocks;
+        blocks += q.O;
+        smem = std::max(smem, ((size_t)q.T * (q.I + 1) + q.I) * sizeof(float));
+    }
+    b.blk0[n] = blocks;
+    b.n = n;
+    if (smem > 64 * 1024) return EG3D_ERR_UNSUPPORTED;
+    static std::atomic<uint64_t> attr_done{0};
+    if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(weight_grad_finish_batched_kernel), 64 * 1024, attr_done)) return e;
+    hipLaunchKernelGGL(weight_grad_finish_batched_kernel, dim3(blocks), dim3(256), smem, (hipStream_t)stream, b);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }

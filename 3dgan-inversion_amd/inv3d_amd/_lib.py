@@ -34,6 +34,15 @@ class ActBwd(C.Structure):
                 ('dbias', C.c_void_p), ('dd', C.c_void_p), ('dnoise', C.c_void_p), ('dnoise_nstride', C.c_int64), ('dstrength', C.c_void_p)]
 
 
+class WgfItem(C.Structure):
+    """eg3d_wgf_item: one layer of eg3d_weight_grad_finish_batched."""
+    _fields_ = [('g', C.c_void_p), ('w', C.c_void_p), ('s', C.c_void_p), ('d', C.c_void_p), ('dd', C.c_void_p), ('dw', C.c_void_p),
+                ('slab_stride', C.c_int64), ('N', C.c_int32), ('O', C.c_int32), ('I', C.c_int32), ('T', C.c_int32), ('nslab', C.c_int32)]
+
+
+WGF_BATCH_MAX = 32
+
+
 class PackItem(C.Structure):
     """eg3d_pack_item: one layer of eg3d_pack_conv_weights_batched."""
     _fields_ = [('w', C.c_void_p), ('wf', C.c_void_p), ('wa', C.c_void_p), ('wsq', C.c_void_p),
@@ -285,6 +294,7 @@ _SIGS = {
     'eg3d_unit_normalize_bwd': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int64, C.c_int, C.c_void_p]),
     'eg3d_pack_conv_weight': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     'eg3d_weight_grad_finish': (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]),
+    'eg3d_weight_grad_finish_batched': (C.c_int, [C.POINTER(WgfItem), C.c_int, C.c_void_p]),
     'eg3d_pack_conv_weights_batched': (C.c_int, [C.POINTER(PackItem), C.c_int, C.c_void_p]),
     'eg3d_pack_conv_weight_padded': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
     'eg3d_pack_conv_weight_scaled': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),

@@ -1186,10 +1186,70 @@ def pack_conv_weights_batched(items):
         L.check(L.lib().eg3d_pack_conv_weights_batched(arr, len(chunk), L.stream_ptr()), 'pack_conv_weights_batched')
 
 
+DEFERRED_WGRADS = None         # a list while `deferred_weight_grads()` is active: weight_grad_finish() queues its arguments there and returns None
+
+
+@contextlib.contextmanager
+def deferred_weight_grads():
+    """Pivotal tuning: the conv layers' backward passes queue their packed weight-gradient images instead of launching one
+    eg3d_weight_grad_finish each (17 launches of 5 - 13 us); `flush_weight_grads(queue)` turns all of them into the parameters' `.grad` with one
+    launch (eg3d_weight_grad_finish_batched).  Inside the context the layers return NO gradient for their weights through autograd --
+    only a caller that flushes before its optimiser step may use it (inversion.PivotalTuner does)."""
+    global DEFERRED_WGRADS
+    prev, DEFERRED_WGRADS = DEFERRED_WGRADS, []
+    try:
+        yield DEFERRED_WGRADS
+    finally:
+        DEFERRED_WGRADS = prev
+
+
+_WGRAD_BUFS = {}               # id(weight) -> (weakref(weight), persistent gradient buffer): the same storage every step (graph replay)
+
+
+def flush_weight_grads(queue):
+    """One launch for everything `deferred_weight_grads()` queued; sets / accumulates `weight.grad`."""
+    if not queue:
+        return
+    for a in range(0, len(queue), L.WGF_BATCH_MAX):
+        chunk = queue[a:a + L.WGF_BATCH_MAX]
+        arr = (L.WgfItem * len(chunk))()
+        outs = []
+        for q, (dwp, weight, styles, d, dd) in zip(arr, chunk):
+            w = weight.detach()
+            assert w.is_contiguous() and w.dtype == torch.float32
+            o, i, kh, kw = w.shape
+            ent = _WGRAD_BUFS.get(id(weight))
+            if ent is None or ent[0]() is not weight or ent[1].shape != w.shape:
+                if len(_WGRAD_BUFS) > 512:
+                    _WGRAD_BUFS.clear()
+                ent = (weakref.ref(weight), torch.empty_like(w))
+                _WGRAD_BUFS[id(weight)] = ent
+            dw = ent[1]
+            q.g, q.w, q.s, q.d, q.dd, q.dw = dwp.data_ptr(), w.data_ptr(), L.ptr(styles), L.ptr(d), L.ptr(dd), dw.data_ptr()
+            q.N, q.O, q.I, q.T = (styles.shape[0] if styles is not None else 1), o, i, kh * kw
+            if dwp.dim() == 3:
+                assert dwp.is_contiguous() and dwp.shape[1:] == (o, kh * kw * i)
+                q.nslab, q.slab_stride = dwp.shape[0], dwp.stride(0)
+            else:
+                q.nslab, q.slab_stride = 1, 0
+            outs.append((weight, dw))
+        L.check(L.lib().eg3d_weight_grad_finish_batched(arr, len(chunk), L.stream_ptr()), 'weight_grad_finish_batched')
+        keep_for_capture(*[t for item in chunk for t in item if torch.is_tensor(t)])
+        for weight, dw in outs:
+            if weight.grad is None:
+                weight.grad = dw
+            elif weight.grad.data_ptr() != dw.data_ptr():
+                weight.grad.add_(dw)
+            # (else: the optimiser kept last step's buffer as .grad -- it now holds this step's gradient)
+
+
 def weight_grad_finish(dwp, weight, styles, d, dd):
     """[O,I,kh,kw] gradient of a demodulated modulated conv weight from the packed weight-gradient image dwp [O, taps*I] and the
     demodulation path (eg3d_weight_grad_finish); dd None: no demodulation term."""
     L.require_cuda(dwp, weight)
+    if DEFERRED_WGRADS is not None and weight.is_contiguous() and weight.dtype == torch.float32:
+        DEFERRED_WGRADS.append((dwp, weight, styles, d, dd))
+        return None
     w = weight.detach().contiguous().float()
     o, i, kh, kw = w.shape
     dw = torch.empty_like(w)

@@ -190,6 +190,7 @@ POSE_CHAIN_KERNEL = os.environ.get('EG3D_POSE_CHAIN', '1') != '0'
 # cache_backbone / use_cached_backbone, triplane.py:55-63 of the reference) instead of running the backbone a second time on the same ws:
 # identical planes (the backbone is a function of ws and the const noise alone), one backbone forward less per step
 SHARE_BACKBONE = os.environ.get('EG3D_C3_SHARE_BACKBONE', '1') != '0'
+BATCHED_WGRAD_FINISH = os.environ.get('EG3D_BATCHED_WGRAD_FINISH', '1') != '0'     # PivotalTuner: hipops.deferred_weight_grads / flush_weight_grads
 GRID_SAMPLE_KERNEL = os.environ.get('EG3D_GRID_SAMPLE', '1') != '0'     # the feature warp of the warping loss on eg3d_grid_sample_nhwc_* (0: F.grid_sample)
 
 
@@ -844,7 +845,12 @@ class PivotalTuner:
             # the same decision on the device, every step, replayable: done |= (lpips <= threshold); the update below is skipped once set
             hipops.early_stop_flag(lp.detach().reshape(()), self.thr, self.done_t)
             self.last['done_flag'] = self.done_t
-        loss.backward()
+        if BATCHED_WGRAD_FINISH:        # the 17 conv weight gradients leave their packed form in one launch, after the backward pass
+            with hipops.deferred_weight_grads() as pending:
+                loss.backward()
+            hipops.flush_weight_grads(pending)
+        else:
+            loss.backward()
         if self.hip_adam:
             self.optimizer.step(skip=self.done_t if self.device_stop else None)
         else:

@@ -530,6 +530,15 @@ int eg3d_weight_grad_finish(const float* g, const float* w, const float* s, cons
 /* ... with g = the sum, in slab order, of nslab images [O][T*I] that lie slab_stride floats apart (eg3d_wgrad_v2_params::slabs). */
 int eg3d_weight_grad_finish_slabs(const float* g, int nslab, int64_t slab_stride, const float* w, const float* s, const float* d, const float* dd, float* dw,
                                   int N, int O, int I, int T, void* stream);
+/* eg3d_weight_grad_finish_slabs of up to EG3D_WGF_BATCH_MAX layers in ONE launch (pivotal tuning: the gradients of all conv weights are
+ * wanted together, by the optimiser; same arguments per item). */
+#define EG3D_WGF_BATCH_MAX 32
+typedef struct eg3d_wgf_item {
+    const float* g; const float* w; const float* s; const float* d; const float* dd; float* dw;
+    int64_t slab_stride;
+    int32_t N, O, I, T, nslab;
+} eg3d_wgf_item;
+int eg3d_weight_grad_finish_batched(const eg3d_wgf_item* items, int n, void* stream);
 /* eg3d_pack_conv_weight (O_pad = 0) / eg3d_pack_conv_weight_padded of up to EG3D_PACK_BATCH_MAX layers in ONE launch: during pivotal tuning
  * all generator weights change together once per step.  wa / wsq may be null per item. */
 #define EG3D_PACK_BATCH_MAX 40
