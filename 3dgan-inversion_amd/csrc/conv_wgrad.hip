@@ -204,15 +204,11 @@ __device__ __forceinline__ void split4h_w(const float a, const float b, const fl
 }
 
 template <bool ONE>          // ONE: EG3D_PREC_F16X1 -- high pieces only: no low-piece arithmetic, LDS traffic or cross products
-__global__ void __launch_bounds__(256, 2) conv_wgrad_f16x3_kernel(const eg3d_wgrad_params p, int tiles_o, int tiles_i, int ntap_total) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void conv_wgrad_f16x3_body(const eg3d_wgrad_params& p, float* smem, const int tiles_i, const int bx, const int by, const int bz) {
     char* const lds = reinterpret_cast<char*>(smem);          // [2 stages][g | x][piece][octet][slot][16 B]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int nblk_xy = gridDim.x * gridDim.y;          // XCD-aware logical block id, as in conv_wgrad_kernel
-    const int lid = eg3d_xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nblk_xy * gridDim.z);
-    const int bz = lid / nblk_xy, bxy = lid - bz * nblk_xy, by = bxy / gridDim.x, bx = bxy - by * gridDim.x;
     const int to = bx / tiles_i, ti = bx % tiles_i;
     int cls_id = 0, tap = by;
     while (cls_id < p.ncls && tap >= p.cls[cls_id].ntaps) { tap -= p.cls[cls_id].ntaps; ++cls_id; }
@@ -412,18 +408,45 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_f16x3_kernel(const eg3d_wgr
     }
 }
 
+template <bool ONE>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_f16x3_kernel(const eg3d_wgrad_params p, int tiles_o, int tiles_i, int ntap_total) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nblk_xy = gridDim.x * gridDim.y;          // XCD-aware logical block id, as in conv_wgrad_kernel
+    const int lid = eg3d_xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nblk_xy * gridDim.z);
+    const int bz = lid / nblk_xy, bxy = lid - bz * nblk_xy, by = bxy / gridDim.x, bx = bxy - by * gridDim.x;
+    conv_wgrad_f16x3_body<ONE>(p, smem, tiles_i, bx, by, bz);
+}
+
+// Several layers in one launch (pivotal tuning queues the weight gradients of its backward pass: the 4^2 .. 64^2 layers and the toRGB
+// layers are 10 - 25 us launches of a few dozen workgroups each; together they fill the chip).  grid.x = all blocks, layer by prefix table.
+struct WgradBatch {
+    eg3d_wgrad_params p[EG3D_WGRAD_BATCH_MAX];
+    int blk0[EG3D_WGRAD_BATCH_MAX + 1];
+    int nx[EG3D_WGRAD_BATCH_MAX], ny[EG3D_WGRAD_BATCH_MAX], tiles_i[EG3D_WGRAD_BATCH_MAX];
+    int n;
+};
+template <bool ONE>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_f16x3_batched_kernel(const WgradBatch b) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int l = 0;
+    while (l + 1 < b.n && (int)blockIdx.x >= b.blk0[l + 1]) ++l;
+    const int nblk = b.blk0[l + 1] - b.blk0[l], nxy = b.nx[l] * b.ny[l];
+    const int lid = eg3d_xcd_remap(blockIdx.x - b.blk0[l], nblk);
+    const int bz = lid / nxy, bxy = lid - bz * nxy, by = bxy / b.nx[l], bx = bxy - by * b.nx[l];
+    conv_wgrad_f16x3_body<ONE>(b.p[l], smem, b.tiles_i[l], bx, by, bz);
+}
+
 }  // namespace
 
-extern "C" int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* pp, void* stream) {
-    if (!pp) return EG3D_ERR_INVALID;
-    eg3d_wgrad_params p = *pp;
+// argument checks + the choice of the pixel split (p.psplit is filled in); tiles_o / tiles_i / ntap_total = the launch geometry
+static int wgrad_prepare(eg3d_wgrad_params& p, int& tiles_o, int& tiles_i, int& ntap_total, bool& f16) {
     if (!p.x || !p.g || !p.dw) return EG3D_ERR_INVALID;
     if (p.N <= 0 || p.Hi <= 0 || p.Wi <= 0 || p.Ck <= 0 || p.Nc <= 0 || p.Ho <= 0 || p.Wo <= 0) return EG3D_ERR_INVALID;
     if (p.ncls < 1 || p.ncls > 4 || p.in_stride < 1 || p.out_stride < 1) return EG3D_ERR_INVALID;
     if ((int64_t)p.N * p.Hi * p.Wi * p.ldx * 4 > 0x7fffffe0ll || (int64_t)p.N * p.Ho * p.Wo * p.ldg * 4 > 0x7fffffe0ll) return EG3D_ERR_TOO_LARGE;   // 31-bit buffer offsets
     if ((p.Ck & 3) || (p.ldx & 3) || (p.ldg & 3) || p.ldg < ((p.Nc + 3) & ~3)) return EG3D_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(p.x) & 15) || (reinterpret_cast<uintptr_t>(p.g) & 15)) return EG3D_ERR_UNSUPPORTED;
-    int ntap_total = 0;
+    ntap_total = 0;
     int64_t maxM = 0;
     for (int c = 0; c < p.ncls; ++c) {
         const eg3d_conv_class& k = p.cls[c];
@@ -431,8 +454,8 @@ extern "C" int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* pp, void* stream) 
         ntap_total += k.ntaps;
         maxM = std::max<int64_t>(maxM, (int64_t)p.N * k.Ha * k.Wa);
     }
-    const int tiles_o = eg3d_cdiv(p.Nc, BO), tiles_i = eg3d_cdiv(p.Ck, BI);
-    const bool f16 = p.precision == EG3D_PREC_F16X3 || p.precision == EG3D_PREC_F16X1;
+    tiles_o = eg3d_cdiv(p.Nc, BO); tiles_i = eg3d_cdiv(p.Ck, BI);
+    f16 = p.precision == EG3D_PREC_F16X3 || p.precision == EG3D_PREC_F16X1;
     if (p.psplit <= 0 && f16) {      // ~2048 blocks like the fp32 path, but >= 16 K-steps each (the shorter main loop makes the atomic epilogue weigh more)
         int64_t base = (int64_t)tiles_o * tiles_i * ntap_total;
         int64_t steps = (maxM + BC - 1) / BC;
@@ -448,6 +471,15 @@ extern "C" int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* pp, void* stream) 
         p.psplit = (int)std::max<int64_t>(1, std::min<int64_t>(want, std::max<int64_t>(1, steps / 8)));
     }
     if (p.precision != EG3D_PREC_F32 && !f16) return EG3D_ERR_UNSUPPORTED;
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* pp, void* stream) {
+    if (!pp) return EG3D_ERR_INVALID;
+    eg3d_wgrad_params p = *pp;
+    int tiles_o, tiles_i, ntap_total;
+    bool f16;
+    if (int rc = wgrad_prepare(p, tiles_o, tiles_i, ntap_total, f16)) return rc;
     EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND(det, p.dw, (int64_t)p.Nc * p.w_row); EG3D_DET_COMMIT(det);
     if (f16) {
         static std::atomic<uint64_t> attr16{0}, attr16one{0};
@@ -466,6 +498,40 @@ extern "C" int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* pp, void* stream) 
     if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_wgrad_kernel), (int)smem, attr_done)) return e;
     dim3 grid(tiles_o * tiles_i, ntap_total, p.psplit);
     hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), smem, (hipStream_t)stream, p, tiles_o, tiles_i, ntap_total);
+    EG3D_DET_END(det);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_conv2d_wgrad_batched(const eg3d_wgrad_params* items, int n, void* stream) {
+    if (!items || n < 1) return EG3D_ERR_INVALID;
+    static std::atomic<uint64_t> attr16{0}, attr16one{0};
+    const size_t smem16 = (size_t)2 * H_STAGE;
+    EG3D_DET_SCOPE(det, stream);
+    for (int i = 0; i < n; ++i) EG3D_DET_BIND(det, items[i].dw, (int64_t)items[i].Nc * items[i].w_row);
+    EG3D_DET_COMMIT(det);
+    int i = 0;
+    while (i < n) {
+        WgradBatch b;
+        int blocks = 0, m = 0;
+        bool one = false;
+        for (; i < n && m < EG3D_WGRAD_BATCH_MAX; ++i, ++m) {
+            eg3d_wgrad_params p = items[i];
+            int tiles_o, tiles_i, ntap_total;
+            bool f16;
+            if (int rc = wgrad_prepare(p, tiles_o, tiles_i, ntap_total, f16)) return rc;
+            if (!f16) return EG3D_ERR_UNSUPPORTED;                                  // (the fp32 matrix path has no batched form)
+            const bool this_one = p.precision == EG3D_PREC_F16X1;
+            if (m > 0 && this_one != one) break;                                    // a launch is one instantiation: start a new one
+            one = this_one;
+            b.p[m] = p; b.blk0[m] = blocks; b.nx[m] = tiles_o * tiles_i; b.ny[m] = ntap_total; b.tiles_i[m] = tiles_i;
+            blocks += tiles_o * tiles_i * ntap_total * p.psplit;
+        }
+        b.blk0[m] = blocks; b.n = m;
+        auto kern = one ? conv_wgrad_f16x3_batched_kernel<true> : conv_wgrad_f16x3_batched_kernel<false>;
+        if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)smem16, one ? attr16one : attr16)) return e;
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem16, (hipStream_t)stream, b);
+    }
     EG3D_DET_END(det);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;

@@ -215,6 +215,7 @@ _SIGS = {
     'eg3d_conv2d_igemm_config': (C.c_int, [C.POINTER(ConvParams)]),
     'eg3d_conv2d_igemm_act_bwd_ok': (C.c_int, [C.POINTER(ConvParams)]),
     'eg3d_conv2d_wgrad_f32': (C.c_int, [C.POINTER(WgradParams), C.c_void_p]),
+    'eg3d_conv2d_wgrad_batched': (C.c_int, [C.POINTER(WgradParams), C.c_int, C.c_void_p]),
     'eg3d_conv2d_v2_supported': (C.c_int, [C.POINTER(ConvV2Params)]),
     'eg3d_conv2d_v2': (C.c_int, [C.POINTER(ConvV2Params), C.c_void_p]),
     'eg3d_conv2d_wgrad_v2_supported': (C.c_int, [C.POINTER(WgradV2Params)]),

@@ -950,6 +950,10 @@ def conv_wgrad(x, g, Ck, Nc, dwp, classes, in_stride=1, out_stride=1, in_scale=N
     p.precision = PRECISIONS[precision]
     p.g_amax = g_amax.data_ptr() if g_amax is not None else None
     p.g_amax_mul = float(g_amax_mul)
+    if DEFERRED_CONV_WGRADS is not None and precision in ('f16x3', 'f16x1'):
+        # queued (deferred_weight_grads): launched together with the other layers' by flush_weight_grads; the operands stay referenced until then
+        DEFERRED_CONV_WGRADS.append((p, (x, g, dwp, in_scale, g_amax)))
+        return dwp
     L.check(L.lib().eg3d_conv2d_wgrad_f32(C.byref(p), L.stream_ptr()), 'conv2d_wgrad_f32')
     return dwp
 
@@ -1187,6 +1191,8 @@ def pack_conv_weights_batched(items):
 
 
 DEFERRED_WGRADS = None         # a list while `deferred_weight_grads()` is active: weight_grad_finish() queues its arguments there and returns None
+DEFERRED_CONV_WGRADS = None    # ... and conv_wgrad() its launch parameters (eg3d_conv2d_wgrad_batched: the small layers fill the chip only together)
+BATCH_CONV_WGRADS = os.environ.get('EG3D_BATCH_CONV_WGRADS', '1') != '0'
 
 
 @contextlib.contextmanager
@@ -1195,12 +1201,14 @@ def deferred_weight_grads():
     eg3d_weight_grad_finish each (17 launches of 5 - 13 us); `flush_weight_grads(queue)` turns all of them into the parameters' `.grad` with one
     launch (eg3d_weight_grad_finish_batched).  Inside the context the layers return NO gradient for their weights through autograd --
     only a caller that flushes before its optimiser step may use it (inversion.PivotalTuner does)."""
-    global DEFERRED_WGRADS
+    global DEFERRED_WGRADS, DEFERRED_CONV_WGRADS
     prev, DEFERRED_WGRADS = DEFERRED_WGRADS, []
+    prev_c, DEFERRED_CONV_WGRADS = DEFERRED_CONV_WGRADS, ([] if BATCH_CONV_WGRADS else None)
+    DEFERRED_WGRADS.append(DEFERRED_CONV_WGRADS)          # (slot 0 of the queue: the conv launches, which the finishing pass depends on)
     try:
         yield DEFERRED_WGRADS
     finally:
-        DEFERRED_WGRADS = prev
+        DEFERRED_WGRADS, DEFERRED_CONV_WGRADS = prev, prev_c
 
 
 _WGRAD_BUFS = {}               # id(weight) -> (weakref(weight), persistent gradient buffer): the same storage every step (graph replay)
@@ -1210,6 +1218,11 @@ def flush_weight_grads(queue):
     """One launch for everything `deferred_weight_grads()` queued; sets / accumulates `weight.grad`."""
     if not queue:
         return
+    convs, queue = queue[0], queue[1:]
+    if convs:              # first the queued weight-gradient GEMMs themselves, five layers per launch
+        arr = (L.WgradParams * len(convs))(*[p for p, _ in convs])
+        L.check(L.lib().eg3d_conv2d_wgrad_batched(arr, len(convs), L.stream_ptr()), 'conv2d_wgrad_batched')
+        keep_for_capture(*[t for _, ts in convs for t in ts if t is not None])
     for a in range(0, len(queue), L.WGF_BATCH_MAX):
         chunk = queue[a:a + L.WGF_BATCH_MAX]
         arr = (L.WgfItem * len(chunk))()

@@ -335,6 +335,10 @@ typedef struct eg3d_wgrad_params {
 } eg3d_wgrad_params;
 
 int eg3d_conv2d_wgrad_f32(const eg3d_wgrad_params* p, void* stream);
+/* n launches of eg3d_conv2d_wgrad_f32 (F16X3 / F16X1 only) as ceil(n / EG3D_WGRAD_BATCH_MAX) launches: the weight gradients of a backward
+ * pass are independent of each other, and the small layers' launches (a few dozen workgroups, 10 - 25 us) fill the chip only together. */
+#define EG3D_WGRAD_BATCH_MAX 5
+int eg3d_conv2d_wgrad_batched(const eg3d_wgrad_params* items, int n, void* stream);
 
 /* The same weight gradient for stride-1 layers whose two operands already exist as split images (csrc/conv_wgrad_v2.hip): g = the image of
  * the gradient operand dz [N][2][Co/8][H][W][8] fp16 (what the data gradient of eg3d_conv2d_v2 consumes), x = the image of the layer input
