@@ -19,6 +19,8 @@
 // instead of 128 fp32 ones (64 cycles each); 24 instead of 64 for the forward one.  The gather is done in the same split layout: the
 // two lanes of a sample read the two 64-byte halves of each 128-byte texel.
 #include "render_common.h"
+#include "det.h"
+#include <atomic>
 #include <cstdlib>
 
 using namespace eg3d_render;
@@ -44,6 +46,8 @@ struct DecodeArgs {
     float4* gc_rows;            // [M] (dL/d position, depth)            (or null)
     float* dump_dpre; float* dump_h; float* dump_dout; float* dump_feat;   // decoder-weight gradient operands (or null)
     float* df_amax;             // backward: max|df_rows| over the launch (one atomic per block), or null
+    float* gram_w0; float* gram_b0; float* gram_w1; float* gram_b1;        // GRAM instantiation: decoder-weight gradients contracted in the kernel
+    float gram_s0, gram_s1, gram_sb;
     float* feat;                // FEAT instantiations: [rows, FC] interpolated features in OUTPUT row order (written by gather_rows_kernel)
 };
 
@@ -63,8 +67,8 @@ struct Frags {
     float inv0, inv1;  // 1 / (power-of-two range multiplier of W0, W1)
 };
 constexpr int FRAG_PLANES = 4 * 3 * 64;                 // f16x8 units of one GEMM's fragment image
-constexpr int FRAG_BYTES_FWD = 2 * FRAG_PLANES * 16 + (64 + 64 + 32 + 8) * 4;
-constexpr int FRAG_BYTES_BWD = 4 * FRAG_PLANES * 16 + (64 + 64 + 32 + 8) * 4;
+constexpr int FRAG_BYTES_FWD = 2 * FRAG_PLANES * 16 + (64 + 64 + 32 + 16) * 4;
+constexpr int FRAG_BYTES_BWD = 4 * FRAG_PLANES * 16 + (64 + 64 + 32 + 16) * 4;
 
 // multiplier that brings `amax` to [2^11, 2^12): an exact power of two (1 for zero / non-finite input)
 __device__ __forceinline__ float pow2_range_mul(float amax, int target_exp) {
@@ -119,8 +123,8 @@ __device__ __forceinline__ Frags setup_frags(char* lds, const DecodeArgs& a) {
     for (int o = 32; o >= 1; o >>= 1) { m0 = fmaxf(m0, __shfl_xor(m0, o)); m1 = fmaxf(m1, __shfl_xor(m1, o)); }
     if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = m0; red[(threadIdx.x >> 6) * 2 + 1] = m1; }
     __syncthreads();
-    m0 = fmaxf(fmaxf(red[0], red[2]), fmaxf(red[4], red[6]));
-    m1 = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+    m0 = m1 = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { m0 = fmaxf(m0, red[2 * w]); m1 = fmaxf(m1, red[2 * w + 1]); }          // (4 or 8 waves)
     const float s0 = pow2_range_mul(m0, 11), s1 = pow2_range_mul(m1, 11);
     F.inv0 = 1.f / s0; F.inv1 = 1.f / s1;
     // one (block/k-step, lane) fragment per thread iteration: 4 x 64 per GEMM
@@ -303,11 +307,33 @@ __global__ void __launch_bounds__(256) gather_grad_rows_kernel(const DecodeArgs 
     if (q == 0 && in_range) a.gc_rows[row] = valid ? make_float4(gx, gy, gz, ps.w) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-template <bool BWD, bool FEAT>
-__global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_rows_kernel(const DecodeArgs a) {
+// GRAM (backward only): the two Gram products of the decoder-weight gradients, dPRE^T F [64 x 32] and dOUT^T H [32 x 64] (+ the sigma row and
+// the bias sums), are accumulated here instead of dumping their four operands (1.0 GB per step) for a GEMM pass over them.  Per tile the
+// wave transposes its operands through a private 13 KB LDS area -- lane = sample writes rows, lane = (unit, sample parity) reads the A / B
+// operands of v_mfma_f32_32x32x2_f32 (K = two samples), the exact-fp32-product arithmetic rows_gram.hip uses -- 64 MFMAs per 32 samples on
+// top of the 48 of the backward itself; four 32 x 32 accumulators live in registers across all tiles of the wave, the sigma row and the
+// bias sums are per-lane partial sums reduced once at the end.  One block of eight waves per CU (the accumulators; 104 KB of transposition space).
+constexpr int GRAM_LDP = 68, GRAM_LDQ = 36;                               // row pitches (floats) of the 64- and 32-column tiles: 16-byte rows, banks staggered
+constexpr int GRAM_NACC = 161;                                            // per-wave LDS sums: sigma row [64], d b0 [64], d b1 colours [32], d b1 sigma [1]
+constexpr int GRAM_WAVE_BYTES = (32 * GRAM_LDP + 32 * GRAM_LDQ + 192) * 4;      // 14080
+
+template <bool BWD, bool FEAT, bool GRAM = false>
+__global__ void __launch_bounds__(GRAM ? 512 : 256, GRAM ? 1 : (BWD ? DEC_OCC_BWD : DEC_OCC_FWD)) decode_rows_kernel(const DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const Frags F = setup_frags<BWD>(lds, a);
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    // GRAM state (dead code otherwise)
+    float* const TP = reinterpret_cast<float*>(lds + FRAG_BYTES_BWD + (threadIdx.x >> 6) * GRAM_WAVE_BYTES);      // [32 samples][GRAM_LDP]
+    float* const TQ = TP + 32 * GRAM_LDP;                                                                       // [32 samples][GRAM_LDQ]
+    float* const TA = TQ + 32 * GRAM_LDQ;                                                                       // [GRAM_NACC] running sums of this wave
+    f32x16 gram1[2], gram2[2];
+    if constexpr (GRAM) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { gram1[u][r] = 0.f; gram2[u][r] = 0.f; }
+        for (int i = lane; i < GRAM_NACC; i += 64) TA[i] = 0.f;
+    }
     const int64_t ntiles = (a.M + 31) / 32;
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -464,6 +490,58 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
                 for (int g = 0; g < 4; ++g)
                     *reinterpret_cast<float4*>(a.dump_dpre + row * HD + 32 * ht + 8 * g + 4 * h) = make_float4(dh[ht][4 * g], dh[ht][4 * g + 1], dh[ht][4 * g + 2], dh[ht][4 * g + 3]);
         }
+        if constexpr (GRAM) {
+            // sums over the tile's samples that are not matrix products (sigma row of d W1, the bias gradients): reduced over the 16 lanes of a
+            // DPP row, then added to the wave's LDS sums by the row's first lane (wave-private memory, lanes of one instruction in lane order:
+            // the order of these additions is fixed) -- as per-lane registers they were 81 of them, and the kernel one wave per SIMD
+            auto red_add = [&](float v, int idx) {
+                v = eg3d_row_group_sum(v, 16);
+                if ((li & 15) == 0) atomicAdd(TA + idx, v);
+            };
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int unit = 32 * ht + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    red_add(dsig * hid[ht][r], unit);
+                    red_add(dh[ht][r], 64 + unit);
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red_add(dout[r], 128 + (r & 3) + 8 * (r >> 2) + 4 * h);
+            red_add(h == 0 ? dsig : 0.f, 160);
+            // phase 1: TP = dPRE [sample][64], TQ = F [sample][32]  ->  gram1[u] += dPRE[:, 32u ..]^T F
+            auto put64 = [&](const f32x16 (&v)[2]) {
+#pragma unroll
+                for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4*>(TP + li * GRAM_LDP + 32 * ht + 8 * g + 4 * h) = make_float4(v[ht][4 * g], v[ht][4 * g + 1], v[ht][4 * g + 2], v[ht][4 * g + 3]);
+            };
+            auto put32 = [&](const f32x16& v) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(TQ + li * GRAM_LDQ + 8 * g + 4 * h) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+            };
+            put64(dh);
+            put32(f);
+#pragma unroll 4
+            for (int t = 0; t < 16; ++t) {
+                const float* rp = TP + (2 * t + h) * GRAM_LDP + li;
+                const float bq = TQ[(2 * t + h) * GRAM_LDQ + li];
+                gram1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(rp[0], bq, gram1[0], 0, 0, 0);
+                gram1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(rp[32], bq, gram1[1], 0, 0, 0);
+            }
+            // phase 2: TP = H [sample][64], TQ = dOUT [sample][32]  ->  gram2[u] += dOUT^T H[:, 32u ..]
+            put64(hid);
+            put32(dout);
+#pragma unroll 4
+            for (int t = 0; t < 16; ++t) {
+                const float* rp = TP + (2 * t + h) * GRAM_LDP + li;
+                const float aq = TQ[(2 * t + h) * GRAM_LDQ + li];
+                gram2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq, rp[0], gram2[0], 0, 0, 0);
+                gram2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq, rp[32], gram2[1], 0, 0, 0);
+            }
+        }
         phase_fence();
         // ---- dF^T = W0^T dPRE^T -------------------------------------------------------------------------------------------
         f32x16 df;
@@ -535,6 +613,24 @@ __global__ void __launch_bounds__(256, BWD ? DEC_OCC_BWD : DEC_OCC_FWD) decode_r
             if (h == 0 && row < a.M) a.gc_rows[row] = valid ? make_float4(gx, gy, gz, ps.w) : make_float4(0, 0, 0, 0);
         }
     }
+    if constexpr (GRAM) {
+        // accumulator element r of lane (li, h) = (row (r&3) + 8 (r>>2) + 4 h, column li) of its 32 x 32 block
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                eg3d_acc(a.gram_w0 + (32 * u + row) * FC + li, gram1[u][r] * a.gram_s0);                   // d W0 [unit][feature]
+                eg3d_acc(a.gram_w1 + (1 + row) * HD + 32 * u + li, gram2[u][r] * a.gram_s1);               // d W1 [1 + colour][hidden]
+            }
+        for (int i = lane; i < GRAM_NACC; i += 64) {
+            const float v = TA[i];
+            if (i < 64) eg3d_acc(a.gram_w1 + i, v * a.gram_s1);                        // sigma row of d W1
+            else if (i < 128) eg3d_acc(a.gram_b0 + (i - 64), v * a.gram_sb);
+            else if (i < 160) eg3d_acc(a.gram_b1 + 1 + (i - 128), v * a.gram_sb);
+            else eg3d_acc(a.gram_b1, v * a.gram_sb);
+        }
+    }
     if constexpr (BWD) {
         if (a.df_amax != nullptr) {       // non-negative floats order like their bit patterns
 #pragma unroll
@@ -562,7 +658,13 @@ int launch_decode(const DecodeArgs& a, bool bwd, hipStream_t st) {
     }
     if (a.feat != nullptr) {
         if (!bwd) hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((a.M * 8 + 255) / 256)), dim3(256), 0, st, a);
-        if (bwd) hipLaunchKernelGGL((decode_rows_kernel<true, true>), dim3(blocks), dim3(256), FRAG_BYTES_BWD, st, a);
+        if (bwd && a.gram_w0 != nullptr) {
+            static std::atomic<uint64_t> attr_done{0};
+            auto kern = decode_rows_kernel<true, true, true>;
+            const int smem = FRAG_BYTES_BWD + 8 * GRAM_WAVE_BYTES;                                                         // 156 KB: one resident block of eight waves per CU
+            if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, attr_done)) return e;
+            hipLaunchKernelGGL(kern, dim3((int)std::min<int64_t>((ntiles + 7) / 8, 256)), dim3(512), smem, st, a);
+        } else if (bwd) hipLaunchKernelGGL((decode_rows_kernel<true, true>), dim3(blocks), dim3(256), FRAG_BYTES_BWD, st, a);
         else hipLaunchKernelGGL((decode_rows_kernel<false, true>), dim3(blocks), dim3(256), FRAG_BYTES_FWD, st, a);
     } else if (bwd) hipLaunchKernelGGL((decode_rows_kernel<true, false>), dim3(blocks), dim3(256), FRAG_BYTES_BWD, st, a);
     else hipLaunchKernelGGL((decode_rows_kernel<false, false>), dim3(blocks), dim3(256), FRAG_BYTES_FWD, st, a);
@@ -600,5 +702,10 @@ int eg3d_decode_rows_bwd(const eg3d_render_bwd_params& bp, const float* pos, int
     a.dump_feat = bp.dump_feat ? bp.dump_feat + row0 * FC : nullptr;
     a.feat = p.feat_rows ? p.feat_rows + row0 * FC : nullptr;
     a.df_amax = bp.df_amax;
+    if (bp.gram_w0 != nullptr) {
+        if (!bp.gram_b0 || !bp.gram_w1 || !bp.gram_b1 || !p.feat_rows || bp.dump_dpre || bp.dump_h || bp.dump_dout) return EG3D_ERR_INVALID;
+        a.gram_w0 = bp.gram_w0; a.gram_b0 = bp.gram_b0; a.gram_w1 = bp.gram_w1; a.gram_b1 = bp.gram_b1;
+        a.gram_s0 = bp.gram_scale0; a.gram_s1 = bp.gram_scale1; a.gram_sb = bp.gram_bias_scale;
+    }
     return launch_decode(a, true, (hipStream_t)stream);
 }

@@ -1533,7 +1533,11 @@ extern "C" int eg3d_render_bwd(const eg3d_render_bwd_params* bp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(render_kernel<1>, dim3(eg3d_cdiv(nrays, RPB)), dim3(MAXT), render_smem(p, 1), st, *bp);
     const int64_t S = nrays * 2 * D;
+    EG3D_DET_SCOPE(det, stream);
+    EG3D_DET_BIND(det, bp->gram_w0, HD * FC); EG3D_DET_BIND(det, bp->gram_b0, HD); EG3D_DET_BIND(det, bp->gram_w1, (1 + CO) * HD); EG3D_DET_BIND(det, bp->gram_b1, 1 + CO);
+    EG3D_DET_COMMIT(det);
     if (int rc2 = eg3d_decode_rows_bwd(*bp, bp->df_pos, 0, S, (int64_t)p.R * 2 * D, 2 * D, stream)) return rc2;
+    EG3D_DET_END(det);
     if (bp->d_origins || bp->d_dirs)
         hipLaunchKernelGGL(render_coord_reduce_kernel, dim3(eg3d_cdiv(nrays, 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(bp->gc_rows),
                            bp->d_origins, bp->d_dirs, nrays, 2 * D);

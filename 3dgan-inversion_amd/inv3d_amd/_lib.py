@@ -120,7 +120,9 @@ class RenderBwdParams(C.Structure):
     _fields_ = [('fwd', RenderParams), ('depth_out', C.c_void_p), ('d_rgb', C.c_void_p), ('d_depth', C.c_void_p),
                 ('d_wsum', C.c_void_p), ('df_rows', C.c_void_p), ('df_pos', C.c_void_p), ('ag_rows', C.c_void_p), ('gc_rows', C.c_void_p), ('d_origins', C.c_void_p),
                 ('d_dirs', C.c_void_p),
-                ('dump_dpre', C.c_void_p), ('dump_h', C.c_void_p), ('dump_dout', C.c_void_p), ('dump_feat', C.c_void_p), ('df_amax', C.c_void_p)]
+                ('dump_dpre', C.c_void_p), ('dump_h', C.c_void_p), ('dump_dout', C.c_void_p), ('dump_feat', C.c_void_p), ('df_amax', C.c_void_p),
+                ('gram_w0', C.c_void_p), ('gram_b0', C.c_void_p), ('gram_w1', C.c_void_p), ('gram_b1', C.c_void_p),
+                ('gram_scale0', C.c_float), ('gram_scale1', C.c_float), ('gram_bias_scale', C.c_float)]
 
 
 class RenderSizes(C.Structure):

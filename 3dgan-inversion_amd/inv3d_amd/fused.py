@@ -181,6 +181,7 @@ def _zeros_views(device, *shapes):
 
 TORGB4_ELEMENTWISE = os.environ.get('EG3D_TORGB4_ELEMENTWISE', '1') != '0'   # 4-output toRGB data gradient as an element-wise pass (hipops.torgb_dgrad_act)
 USE_PIECES = os.environ.get('EG3D_WEIGHT_PIECES', '1') != '0'      # loader-split conv kernel reads pre-split weight images (WeightCache.get_pieces)
+GRAM_FUSED = os.environ.get('EG3D_GRAM_FUSED', '1') != '0'        # decoder-weight gradients inside the renderer's backward kernel (0: operand dumps + hipops.rows_gram)
 RENDER_PIPELINE_NOGRAD = os.environ.get('EG3D_RENDER_PIPELINE_NOGRAD', '1') != '0'   # ... also for no-grad rendering (scratch rows)
 RENDER_FEAT_ROWS = os.environ.get('EG3D_RENDER_FEAT_ROWS', '1') != '0'   # gather pass + feature rows (eg3d_render_params.feat_rows) in the pipelined renderer
 RENDER_PIPELINE = os.environ.get('EG3D_RENDER_PIPELINE', '1') != '0'     # forward renderer as positions -> MFMA decode -> importance -> decode -> composite
@@ -949,8 +950,11 @@ class RenderFn(torch.autograd.Function):
         d_planes = H.zeros_cl(*planes.shape, dev) if need[0] else None
         d_o = torch.empty_like(origins) if (need[1] or need[2]) else None
         d_d = torch.empty_like(dirs) if (need[1] or need[2]) else None
-        dumps = None
-        if any(need[3:7]):
+        dumps = gram = None
+        if any(need[3:7]) and GRAM_FUSED and feat_rows is not None and torch.is_tensor(g0) is False:
+            # decoder-weight gradients contracted inside the sample-level kernel (eg3d_render_bwd_params::gram_*): no operand dumps, no GEMM passes
+            gram = (H.zeros((64, 32), dev), H.zeros((64,), dev), H.zeros((33, 64), dev), H.zeros((33,), dev), g0, g1, lr_mul)
+        elif any(need[3:7]):
             D = max(p.Dc, p.Df)
             S = N * R * 2 * D
             # with equal coarse / fine counts every row is a live sample and is written by the sample-level kernel
@@ -959,9 +963,11 @@ class RenderFn(torch.autograd.Function):
             #  absent samples hold zeros there as well)
             dumps = [mk((S, 64), device=dev), mk((S, 64), device=dev), mk((S, 33), device=dev), feat_rows if feat_rows is not None else mk((S, 32), device=dev)]
         with H._Span('render_bwd'):
-            H.render_bwd(p, g_rgb, g_depth, g_wsum, d_planes, d_o, d_d, dumps)
+            H.render_bwd(p, g_rgb, g_depth, g_wsum, d_planes, d_o, d_d, dumps, gram)
         dw0 = db0 = dw1 = db1 = None
-        if dumps is not None:
+        if gram is not None:
+            dw0, db0, dw1, db1 = gram[:4]
+        elif dumps is not None:
             dpre, hid, dout, feat = dumps
             dw0, db0 = H.rows_gram(dpre, feat, g0, lr_mul)          # [64,32] = g0 dpre^T feat and lr_mul x its column sums over 1.57 M samples
             dw1, db1 = H.rows_gram(dout, hid, g1, lr_mul)           # [33,64]  (the runtime gains applied to the partial sums: no scaling passes)

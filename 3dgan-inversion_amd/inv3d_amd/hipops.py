@@ -1375,7 +1375,7 @@ def render_finalize(depth, minmax):
     L.check(L.lib().eg3d_render_finalize(L.ptr(depth), L.ptr(minmax), depth.numel(), L.stream_ptr()), 'render_finalize')
 
 
-def render_bwd(p, d_rgb, d_depth, d_wsum, d_planes, d_origins, d_dirs, dumps=None):
+def render_bwd(p, d_rgb, d_depth, d_wsum, d_planes, d_origins, d_dirs, dumps=None, gram=None):
     """d_planes (pre-zeroed, channels_last [N,3C,Hp,Wp]) is filled by the tile-binned scatter of the dumped rows."""
     bp = L.RenderBwdParams()
     bp.fwd = p
@@ -1402,6 +1402,9 @@ def render_bwd(p, d_rgb, d_depth, d_wsum, d_planes, d_origins, d_dirs, dumps=Non
     bp.d_dirs = d_dirs.data_ptr() if d_dirs is not None else None
     if dumps is not None:
         bp.dump_dpre, bp.dump_h, bp.dump_dout, bp.dump_feat = [t.data_ptr() for t in dumps]
+    if gram is not None:        # (w0 [64,32], b0 [64], w1 [33,64], b1 [33] pre-zeroed, scale0, scale1, bias_scale): contracted inside the sample-level kernel
+        bp.gram_w0, bp.gram_b0, bp.gram_w1, bp.gram_b1 = [t.data_ptr() for t in gram[:4]]
+        bp.gram_scale0, bp.gram_scale1, bp.gram_bias_scale = float(gram[4]), float(gram[5]), float(gram[6])
         if p.feat_rows and bp.dump_feat == p.feat_rows:         # the caller uses the saved feature rows as that operand: nothing to dump
             bp.dump_feat = None
     amax = None

@@ -770,6 +770,12 @@ typedef struct eg3d_render_bwd_params {
     float* df_amax;            /* optional [1]: max|df_rows| of this call (reset by the call itself).  Hand it to eg3d_triplane_scatter and the
                                 * accumulation runs on the 16-bit matrix cores (three products of two-piece operands, the arithmetic of the
                                 * convolutions, operands scaled by this maximum); null = exact fp32 products on the fp32 matrix cores */
+    /* Decoder-weight gradients contracted INSIDE the sample-level kernel (all four or none; pre-zeroed, accumulated; excludes the dumps):
+     *   gram_w0 [64,32] += gram_scale0 * dpre^T feat      gram_b0 [64] += gram_bias_scale * colsum(dpre)
+     *   gram_w1 [33,64] += gram_scale1 * dout^T h         gram_b1 [33] += gram_bias_scale * colsum(dout)        (row / entry 0 = sigma)
+     * exact fp32 products (v_mfma_f32_32x32x2_f32), as the caller's GEMM over the dumps would do: the 1.0 GB of dump rows is never written. */
+    float* gram_w0; float* gram_b0; float* gram_w1; float* gram_b1;
+    float gram_scale0, gram_scale1, gram_bias_scale;
 } eg3d_render_bwd_params;
 
 int eg3d_render_bwd(const eg3d_render_bwd_params* p, void* stream);
