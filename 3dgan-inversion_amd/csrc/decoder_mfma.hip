@@ -53,6 +53,7 @@ struct DecodeArgs {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // LDS fragment images of the weights: per (output block, k-step) three planes (hw, lw, hw 2^-11) of 64 lanes x 8 halfs.
 // K index of slot j of lane l in k-step s: kidx(s, l >> 5, j) = split_idx(8 s + j, l >> 5).
@@ -61,9 +62,9 @@ struct Frags {
     const f16x8* a2;   // [4 ks][3][64]        W1[1 + (l&31)][32 (ks>>1) + kidx(ks&1)]          (layer 2:  i = colour, k = hidden)
     const f16x8* a3;   // [2 ht][2 s][3][64]   W1[1 + kidx][32 ht + (l&31)]                     (dH:       i = hidden, k = colour)
     const f16x8* a4;   // [4 ks][3][64]        W0[32 (ks>>1) + kidx(ks&1)][(l&31)]              (dF:       i = feature, k = hidden)
-    const float* ws;   // [2][16][2]   W1[0][32ht + idx(r,h)]                                   (sigma row, fp32)
-    const float* bi0;  // [2][16][2]   b0[32ht + idx(r,h)]
-    const float* bi1;  // [16][2]      b1[1 + idx(r,h)]
+    const float* ws;   // [2 h][2 ht][16]   W1[0][32ht + idx(r,h)]                              (sigma row, fp32; a lane reads its 16 values as float4s)
+    const float* bi0;  // [2 h][2 ht][16]   b0[32ht + idx(r,h)]
+    const float* bi1;  // [2 h][16]         b1[1 + idx(r,h)]
     float inv0, inv1;  // 1 / (power-of-two range multiplier of W0, W1)
 };
 constexpr int FRAG_PLANES = 4 * 3 * 64;                 // f16x8 units of one GEMM's fragment image
@@ -90,12 +91,26 @@ __device__ __forceinline__ void split_pieces8(const float (&v)[8], float lo_mul,
     }
 }
 
-// B-operand fragments (high piece, low piece scaled by 2^11) of k-step s of a 16-register split-layout vector, times `mul`
+// B-operand fragments (high piece, low piece scaled by 2^11) of k-step s of a 16-register split-layout vector, times `mul` (a power of two).
+// The sample-level kernels are VALU-bound (round 4: ~1650 vector instructions against 48 MFMAs per 32 samples in the backward kernel), so
+// the split is written for the packed fp32 pipe: per PAIR of elements one v_pk_mul (range), one v_cvt_pkrtz (high pieces), one v_pk_mul
+// (x 2^11) and two v_fma_mix{lo,hi}_f16 -- fma(-h, 2^11, x 2^11) with the f16 operand read in place and the result rounded ONCE to f16
+// (the product and the difference are exact) -- 2.5 instructions per element instead of 6.  RANGE = false: no multiplier (features,
+// hidden activations).  CLAMP: the input is held inside the fp16 range first (features are whatever the planes hold; an operand the
+// caller normalised needs none).
+template <bool RANGE, bool CLAMP>
 __device__ __forceinline__ void act_frag(const f32x16& v, int s, float mul, f16x8& h, f16x8& l) {
-    float t[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) t[j] = v[8 * s + j] * mul;
-    split_pieces8(t, 2048.f, h, l);
+    for (int q = 0; q < 4; ++q) {
+        f32x2 x = {v[8 * s + 2 * q], v[8 * s + 2 * q + 1]};
+        if (CLAMP) { x.x = __builtin_amdgcn_fmed3f(x.x, -65504.f, 65504.f); x.y = __builtin_amdgcn_fmed3f(x.y, -65504.f, 65504.f); }
+        const f32x2 xs = RANGE ? x * mul : x;
+        const f32x2 xk = RANGE ? x * (mul * 2048.f) : x * 2048.f;
+        const fp16x2_t hh = __builtin_amdgcn_cvt_pkrtz(xs.x, xs.y);
+        h[2 * q] = (_Float16)hh[0]; h[2 * q + 1] = (_Float16)hh[1];
+        l[2 * q] = (_Float16)fmaf((float)hh[0], -2048.f, xk.x);
+        l[2 * q + 1] = (_Float16)fmaf((float)hh[1], -2048.f, xk.y);
+    }
 }
 
 // acc += W-fragment (3 planes at `a`) x activation fragment (bh, bl): small terms first
@@ -104,6 +119,36 @@ __device__ __forceinline__ void mfma3(f32x16& acc, const f16x8* a, int lane, con
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ag, bl, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+}
+
+// ---- packed-fp32 forms of the per-element arithmetic (v_pk_mul / v_pk_add / v_pk_fma: two elements per instruction) -------------------
+#define PAIR(v, q) (f32x2{(v)[2 * (q)], (v)[2 * (q) + 1]})
+#define SET_PAIR(v, q, p) do { const f32x2 p_ = (p); (v)[2 * (q)] = p_.x; (v)[2 * (q) + 1] = p_.y; } while (0)
+__device__ __forceinline__ f32x2 lds_pair(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// softplus(x) = max(x,0) + ln2 log2(1 + 2^(-|x| log2 e)): the arithmetic of softplus_fast (render_common.h), pairwise
+__device__ __forceinline__ f32x2 softplus2(f32x2 x) {
+    const f32x2 t = x * 1.4426950408889634f;
+    const f32x2 e = {__builtin_amdgcn_exp2f(-fabsf(t.x)), __builtin_amdgcn_exp2f(-fabsf(t.y))};
+    const f32x2 a = e + 1.f;
+    const f32x2 lg = {__builtin_amdgcn_logf(a.x), __builtin_amdgcn_logf(a.y)};
+    const f32x2 mx = {fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)};
+    return fma2(lg, f32x2{0.6931471805599453f, 0.6931471805599453f}, mx);
+}
+// sigmoid(x) = 1 / (1 + 2^(-x log2 e)) with the hardware reciprocal (1 ulp; the IEEE division sequence is ten instructions per value)
+__device__ __forceinline__ f32x2 sigmoid2(f32x2 x) {
+    const f32x2 t = x * -1.4426950408889634f;
+    const f32x2 a = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.f;
+    return f32x2{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)};
+}
+// power of two that brings `amax` to [2^target, 2^(target+1)) and its exact inverse, by exponent arithmetic (1, 1 for zero / non-finite input)
+__device__ __forceinline__ void pow2_range_pair(float amax, int target_exp, float& mul, float& inv) {
+    mul = 1.f; inv = 1.f;
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return;
+    int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127;
+    e = max(-100, min(100, e));
+    mul = __uint_as_float((unsigned)(127 + target_exp - e) << 23);
+    inv = __uint_as_float((unsigned)(127 - target_exp + e) << 23);
 }
 
 template <bool BWD>
@@ -152,10 +197,10 @@ __device__ __forceinline__ Frags setup_frags(char* lds, const DecodeArgs& a) {
     }
     for (int i = threadIdx.x; i < 64; i += blockDim.x) {
         const int h = i & 1, r = (i >> 1) & 15, ht = i >> 5;
-        const int e = 32 * ht + split_idx(r, h);
-        ws[i] = a.w1t[e * (1 + CO)];
-        bi0[i] = a.b0[e];
-        if (ht == 0) bi1[i] = a.b1[1 + split_idx(r, h)];
+        const int e = 32 * ht + split_idx(r, h), j = 32 * h + 16 * ht + r;
+        ws[j] = a.w1t[e * (1 + CO)];
+        bi0[j] = a.b0[e];
+        if (ht == 0) bi1[16 * h + r] = a.b1[1 + split_idx(r, h)];
     }
     __syncthreads();
     F.a1 = a1; F.a2 = a2; F.a3 = a3; F.a4 = a4; F.ws = ws; F.bi0 = bi0; F.bi1 = bi1;
@@ -332,8 +377,12 @@ __global__ void __launch_bounds__(GRAM ? 512 : 256, GRAM ? 1 : (BWD ? DEC_OCC_BW
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { gram1[u][r] = 0.f; gram2[u][r] = 0.f; }
-        for (int i = lane; i < GRAM_NACC; i += 64) TA[i] = 0.f;
     }
+    // sums over samples that are not matrix products -- the sigma row of d W1 (sum_s dsigma_s H[s][u]), d b0 (sum_s dPRE[s][u]), d b1 -- are column
+    // sums of the tiles the wave transposes through LDS anyway: lane (li, h) owns column li + 32 h of the 64-wide tiles (column li, sample parity
+    // h, of the 32-wide one) and keeps its sum in a register across all tiles of the wave.  (As 81 DPP row reductions + LDS adds per tile
+    // they were ~400 of the kernel's ~1500 vector instructions per tile.)
+    float cs_sig = 0.f, cs_b0 = 0.f, cs_b1 = 0.f, cs_ds = 0.f;
     const int64_t ntiles = (a.M + 31) / 32;
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -374,8 +423,8 @@ __global__ void __launch_bounds__(GRAM ? 512 : 256, GRAM ? 1 : (BWD ? DEC_OCC_BW
         f32x16 hid[2];
         {
             f16x8 bh[2], bl[2];
-            act_frag(f, 0, 1.f, bh[0], bl[0]);
-            act_frag(f, 1, 1.f, bh[1], bl[1]);
+            act_frag<false, true>(f, 0, 1.f, bh[0], bl[0]);
+            act_frag<false, true>(f, 1, 1.f, bh[1], bl[1]);
 #pragma unroll
             for (int ht = 0; ht < 2; ++ht) {
 #pragma unroll
@@ -384,10 +433,13 @@ __global__ void __launch_bounds__(GRAM ? 512 : 256, GRAM ? 1 : (BWD ? DEC_OCC_BW
                 for (int s = 0; s < 2; ++s) mfma3(hid[ht], F.a1 + (2 * ht + s) * 192, lane, bh[s], bl[s]);
             }
         }
+        {
+            const f32x2 inv0 = {F.inv0, F.inv0};
 #pragma unroll
-        for (int ht = 0; ht < 2; ++ht)
+            for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hid[ht][r] = softplus_fast(fmaf(hid[ht][r], F.inv0, F.bi0[(ht * 16 + r) * 2 + h]));
+                for (int q = 0; q < 8; ++q) SET_PAIR(hid[ht], q, softplus2(fma2(PAIR(hid[ht], q), inv0, lds_pair(F.bi0 + 32 * h + 16 * ht + 2 * q))));
+        }
 
         phase_fence();
         // ---- layer 2: OUT^T = W1c H^T + b1c ; sigma = w1s . H + b1[0] ----------------------------------------------------
@@ -398,15 +450,20 @@ __global__ void __launch_bounds__(GRAM ? 512 : 256, GRAM ? 1 : (BWD ? DEC_OCC_BW
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             f16x8 bh, bl;
-            act_frag(hid[ks >> 1], ks & 1, 1.f, bh, bl);
+            act_frag<false, false>(hid[ks >> 1], ks & 1, 1.f, bh, bl);
             mfma3(out, F.a2 + ks * 192, lane, bh, bl);
         }
+        {
+            const f32x2 inv1 = {F.inv1, F.inv1};
+            f32x2 sg2 = {0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[r] = fmaf(out[r], F.inv1, F.bi1[r * 2 + h]);
+            for (int q = 0; q < 8; ++q) SET_PAIR(out, q, fma2(PAIR(out, q), inv1, lds_pair(F.bi1 + 16 * h + 2 * q)));
 #pragma unroll
-        for (int ht = 0; ht < 2; ++ht)
+            for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sig = fmaf(F.ws[(ht * 16 + r) * 2 + h], hid[ht][r], sig);
+                for (int q = 0; q < 8; ++q) sg2 = fma2(lds_pair(F.ws + 32 * h + 16 * ht + 2 * q), PAIR(hid[ht], q), sg2);
+            sig = sg2.x + sg2.y;
+        }
         sig += __shfl_xor(sig, 32);
         sig += a.b1[0];
 
@@ -414,10 +471,12 @@ __global__ void __launch_bounds__(GRAM ? 512 : 256, GRAM ? 1 : (BWD ? DEC_OCC_BW
             if (valid) {
                 if (h == 0) a.sigma[orow] = sig;
                 float* o = a.rgb + orow * CO + 4 * h;
+                const f32x2 c1 = {1.002f, 1.002f}, c0 = {-0.001f, -0.001f};
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(o + 8 * g) = make_float4(sigmoid_fast(out[4 * g]) * 1.002f - 0.001f, sigmoid_fast(out[4 * g + 1]) * 1.002f - 0.001f,
-                                                                       sigmoid_fast(out[4 * g + 2]) * 1.002f - 0.001f, sigmoid_fast(out[4 * g + 3]) * 1.002f - 0.001f);
+                for (int g = 0; g < 4; ++g) {
+                    const f32x2 lo = fma2(sigmoid2(PAIR(out, 2 * g)), c1, c0), hi = fma2(sigmoid2(PAIR(out, 2 * g + 1)), c1, c0);
+                    *reinterpret_cast<float4*>(o + 8 * g) = make_float4(lo.x, lo.y, hi.x, hi.y);
+                }
             }
             continue;
         }
@@ -430,14 +489,18 @@ __global__ void __launch_bounds__(GRAM ? 512 : 256, GRAM ? 1 : (BWD ? DEC_OCC_BW
         const float* grgb = a.d_rgb + ray * CO + 4 * h;
         // dOUT (colours): d rgb / d out = 1.002 * s (1 - s);  dL/d rgb = 2 a d_rgb
         f32x16 dout;
+        {
+            const float cw = valid ? 2.f * 1.002f * ag.x : 0.f;
+            const f32x2 cw2 = {cw, cw};
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 gv = *reinterpret_cast<const float4*>(grgb + 8 * g);
-            const float gq[4] = {gv.x, gv.y, gv.z, gv.w};
+            for (int g = 0; g < 4; ++g) {
+                const float4 gv = *reinterpret_cast<const float4*>(grgb + 8 * g);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float sg = sigmoid_fast(out[4 * g + j]);
-                dout[4 * g + j] = valid ? (2.f * ag.x * gq[j]) * 1.002f * sg * (1.f - sg) : 0.f;
+                for (int j = 0; j < 2; ++j) {
+                    const f32x2 sg = sigmoid2(PAIR(out, 2 * g + j));
+                    const f32x2 gq = j ? f32x2{gv.z, gv.w} : f32x2{gv.x, gv.y};
+                    SET_PAIR(dout, 2 * g + j, (cw2 * gq) * fma2(-sg, sg, sg));          // s (1 - s) = s - s^2
+                }
             }
         }
         const float dsig = valid ? ag.y : 0.f;
@@ -468,10 +531,12 @@ __global__ void __launch_bounds__(GRAM ? 512 : 256, GRAM ? 1 : (BWD ? DEC_OCC_BW
 #pragma unroll
             for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(dout[r]));
             m = fmaxf(m, __shfl_xor(m, 32));
-            const float sc = pow2_range_mul(m, 6), isc = F.inv1 * __frcp_rn(sc);      // exact: sc is a power of two
+            float sc, isc;
+            pow2_range_pair(m, 6, sc, isc);
+            isc *= F.inv1;
             f16x8 bh[2], bl[2];
-            act_frag(dout, 0, sc, bh[0], bl[0]);
-            act_frag(dout, 1, sc, bh[1], bl[1]);
+            act_frag<true, false>(dout, 0, sc, bh[0], bl[0]);
+            act_frag<true, false>(dout, 1, sc, bh[1], bl[1]);
 #pragma unroll
             for (int ht = 0; ht < 2; ++ht) {
 #pragma unroll
@@ -479,8 +544,12 @@ __global__ void __launch_bounds__(GRAM ? 512 : 256, GRAM ? 1 : (BWD ? DEC_OCC_BW
 #pragma unroll
                 for (int s = 0; s < 2; ++s) mfma3(dh[ht], F.a3 + (2 * ht + s) * 192, lane, bh[s], bl[s]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    dh[ht][r] = fmaf(dh[ht][r], isc, F.ws[(ht * 16 + r) * 2 + h] * dsig) * (1.f - __expf(-hid[ht][r]));
+                for (int q = 0; q < 8; ++q) {          // d softplus = 1 - exp(-H)
+                    const f32x2 t = PAIR(hid[ht], q) * -1.4426950408889634f;
+                    const f32x2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                    const f32x2 lin = fma2(PAIR(dh[ht], q), f32x2{isc, isc}, lds_pair(F.ws + 32 * h + 16 * ht + 2 * q) * dsig);
+                    SET_PAIR(dh[ht], q, lin * (1.f - e));
+                }
             }
         }
         if (a.dump_dpre && valid) {
@@ -491,24 +560,6 @@ __global__ void __launch_bounds__(GRAM ? 512 : 256, GRAM ? 1 : (BWD ? DEC_OCC_BW
                     *reinterpret_cast<float4*>(a.dump_dpre + row * HD + 32 * ht + 8 * g + 4 * h) = make_float4(dh[ht][4 * g], dh[ht][4 * g + 1], dh[ht][4 * g + 2], dh[ht][4 * g + 3]);
         }
         if constexpr (GRAM) {
-            // sums over the tile's samples that are not matrix products (sigma row of d W1, the bias gradients): reduced over the 16 lanes of a
-            // DPP row, then added to the wave's LDS sums by the row's first lane (wave-private memory, lanes of one instruction in lane order:
-            // the order of these additions is fixed) -- as per-lane registers they were 81 of them, and the kernel one wave per SIMD
-            auto red_add = [&](float v, int idx) {
-                v = eg3d_row_group_sum(v, 16);
-                if ((li & 15) == 0) atomicAdd(TA + idx, v);
-            };
-#pragma unroll
-            for (int ht = 0; ht < 2; ++ht)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int unit = 32 * ht + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    red_add(dsig * hid[ht][r], unit);
-                    red_add(dh[ht][r], 64 + unit);
-                }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red_add(dout[r], 128 + (r & 3) + 8 * (r >> 2) + 4 * h);
-            red_add(h == 0 ? dsig : 0.f, 160);
             // phase 1: TP = dPRE [sample][64], TQ = F [sample][32]  ->  gram1[u] += dPRE[:, 32u ..]^T F
             auto put64 = [&](const f32x16 (&v)[2]) {
 #pragma unroll
@@ -524,6 +575,9 @@ __global__ void __launch_bounds__(GRAM ? 512 : 256, GRAM ? 1 : (BWD ? DEC_OCC_BW
             };
             put64(dh);
             put32(f);
+            if (h == 0) cs_ds += dsig;
+#pragma unroll 8
+            for (int t = 0; t < 32; ++t) cs_b0 += TP[t * GRAM_LDP + lane];
 #pragma unroll 4
             for (int t = 0; t < 16; ++t) {
                 const float* rp = TP + (2 * t + h) * GRAM_LDP + li;
@@ -534,6 +588,10 @@ __global__ void __launch_bounds__(GRAM ? 512 : 256, GRAM ? 1 : (BWD ? DEC_OCC_BW
             // phase 2: TP = H [sample][64], TQ = dOUT [sample][32]  ->  gram2[u] += dOUT^T H[:, 32u ..]
             put64(hid);
             put32(dout);
+#pragma unroll 8
+            for (int t = 0; t < 32; ++t) cs_sig = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dsig), t)), TP[t * GRAM_LDP + lane], cs_sig);      // d sigma of sample t: lanes t and t + 32 hold it
+#pragma unroll 8
+            for (int t = 0; t < 16; ++t) cs_b1 += TQ[(2 * t + h) * GRAM_LDQ + li];
 #pragma unroll 4
             for (int t = 0; t < 16; ++t) {
                 const float* rp = TP + (2 * t + h) * GRAM_LDP + li;
@@ -552,17 +610,19 @@ __global__ void __launch_bounds__(GRAM ? 512 : 256, GRAM ? 1 : (BWD ? DEC_OCC_BW
 #pragma unroll
                 for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(dh[ht][r]));
             m = fmaxf(m, __shfl_xor(m, 32));
-            const float sc = pow2_range_mul(m, 6), isc = F.inv0 * __frcp_rn(sc) * (1.f / 3.f);     // / 3: mean over the three planes
+            float sc, isc;
+            pow2_range_pair(m, 6, sc, isc);
+            isc = F.inv0 * isc * (1.f / 3.f);                                                       // / 3: mean over the three planes
 #pragma unroll
             for (int r = 0; r < 16; ++r) df[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 f16x8 bh, bl;
-                act_frag(dh[ks >> 1], ks & 1, sc, bh, bl);
+                act_frag<true, false>(dh[ks >> 1], ks & 1, sc, bh, bl);
                 mfma3(df, F.a4 + ks * 192, lane, bh, bl);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) df[r] = df[r] * isc;
+            for (int q = 0; q < 8; ++q) SET_PAIR(df, q, PAIR(df, q) * isc);
         }
         if (a.df_rows && valid) {
 #pragma unroll
@@ -623,13 +683,13 @@ __global__ void __launch_bounds__(GRAM ? 512 : 256, GRAM ? 1 : (BWD ? DEC_OCC_BW
                 eg3d_acc(a.gram_w0 + (32 * u + row) * FC + li, gram1[u][r] * a.gram_s0);                   // d W0 [unit][feature]
                 eg3d_acc(a.gram_w1 + (1 + row) * HD + 32 * u + li, gram2[u][r] * a.gram_s1);               // d W1 [1 + colour][hidden]
             }
-        for (int i = lane; i < GRAM_NACC; i += 64) {
-            const float v = TA[i];
-            if (i < 64) eg3d_acc(a.gram_w1 + i, v * a.gram_s1);                        // sigma row of d W1
-            else if (i < 128) eg3d_acc(a.gram_b0 + (i - 64), v * a.gram_sb);
-            else if (i < 160) eg3d_acc(a.gram_b1 + 1 + (i - 128), v * a.gram_sb);
-            else eg3d_acc(a.gram_b1, v * a.gram_sb);
-        }
+        eg3d_acc(a.gram_w1 + lane, cs_sig * a.gram_s1);                               // sigma row of d W1
+        eg3d_acc(a.gram_b0 + lane, cs_b0 * a.gram_sb);
+        cs_b1 += __shfl_xor(cs_b1, 32);                                                // the two sample parities of a colour column
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) cs_ds += __shfl_xor(cs_ds, o);               // (lanes 32 .. 63 hold zeros)
+        if (h == 0) eg3d_acc(a.gram_b1 + 1 + li, cs_b1 * a.gram_sb);
+        if (lane == 0) eg3d_acc(a.gram_b1, cs_ds * a.gram_sb);
     }
     if constexpr (BWD) {
         if (a.df_amax != nullptr) {       // non-negative floats order like their bit patterns

@@ -153,6 +153,121 @@ __device__ __forceinline__ void march_alpha(const float* d, const float* sg, int
     alpha = 1.f - expf(-(sp * delta));
 }
 
+// ---- the per-ray serial scans ---------------------------------------------------------------------------------------------------------
+// Transmittance scan by ONE lane per ray: w_i = alpha_i T_i, T_{i+1} = T_i q_i, (+ sum w, sum w mid_i), in interval order -- the order of the
+// reference's cumprod / sum on its CPU path, kept so that results do not change.  The recurrence is one multiply per interval; what made the
+// loop slow was its shape: four LDS reads, their full latency, and a store PER INTERVAL (the arrays may alias, so the compiler neither batches
+// nor hoists them) while the block's other waves wait at the barrier -- SQ_WAIT_ANY was 63 % of the wave cycles of render_kernel<1>.  With
+// `vec` (16-byte aligned per-ray arrays: D even) the operands of eight intervals arrive as 16-byte reads ahead of the chain and leave as
+// 16-byte stores: ~12 LDS round trips per scan instead of ~95.  Arrays are 2 D long; a tail batch reads (and zero-fills) up to index 2 D - 1.
+__device__ __forceinline__ float4 lds_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void lds_st4(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
+
+template <bool KEEP_T, bool SUMS, int B>          // B = intervals per batch (4 or 8: the batch lives in registers of EVERY wave of the kernel)
+__device__ __forceinline__ void march_scan(const RayLds& Ls, int nI, int cap, bool vec, float& wsum_o, float& dnum_o) {
+    float T = 1.f, wsum = 0.f, dnum = 0.f;
+    if (vec) {
+        for (int i0 = 0; i0 < nI; i0 += B) {
+            const bool full = i0 + B <= cap;                     // (cap = array length: a last batch that would run past it goes one by one)
+            float tv[B], qv[B], sv[B + 1], Tv[B];
+            if (full) {
+#pragma unroll
+                for (int g = 0; g < B / 4; ++g) {
+                    const float4 ta = lds_ld4(Ls.t + i0 + 4 * g), qa = lds_ld4(Ls.q + i0 + 4 * g);
+                    tv[4 * g] = ta.x; tv[4 * g + 1] = ta.y; tv[4 * g + 2] = ta.z; tv[4 * g + 3] = ta.w;
+                    qv[4 * g] = qa.x; qv[4 * g + 1] = qa.y; qv[4 * g + 2] = qa.z; qv[4 * g + 3] = qa.w;
+                    if (SUMS) {
+                        const float4 sa = lds_ld4(Ls.sd + i0 + 4 * g);
+                        sv[4 * g] = sa.x; sv[4 * g + 1] = sa.y; sv[4 * g + 2] = sa.z; sv[4 * g + 3] = sa.w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < B; ++k) {
+                    const bool in = i0 + k < cap;
+                    tv[k] = in ? Ls.t[i0 + k] : 0.f; qv[k] = in ? Ls.q[i0 + k] : 1.f;
+                    if (SUMS) sv[k] = in ? Ls.sd[i0 + k] : 0.f;
+                }
+            }
+            if (SUMS) sv[B] = i0 + B < cap ? Ls.sd[i0 + B] : 0.f;
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+                const bool ok = i0 + k < nI;
+                const float w = tv[k] * T;
+                tv[k] = ok ? w : 0.f; Tv[k] = T;
+                if (ok) {
+                    T *= qv[k];
+                    if (SUMS) { wsum += w; dnum += w * (0.5f * (sv[k] + sv[k + 1])); }
+                }
+            }
+            if (full) {
+#pragma unroll
+                for (int g = 0; g < B / 4; ++g) {
+                    lds_st4(Ls.w + i0 + 4 * g, tv[4 * g], tv[4 * g + 1], tv[4 * g + 2], tv[4 * g + 3]);
+                    if (KEEP_T) lds_st4(Ls.t + i0 + 4 * g, Tv[4 * g], Tv[4 * g + 1], Tv[4 * g + 2], Tv[4 * g + 3]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < B; ++k)
+                    if (i0 + k < nI) { Ls.w[i0 + k] = tv[k]; if (KEEP_T) Ls.t[i0 + k] = Tv[k]; }
+            }
+        }
+    } else {
+        for (int i = 0; i < nI; ++i) {
+            const float w = Ls.t[i] * T;
+            Ls.w[i] = w;
+            if (KEEP_T) Ls.t[i] = T;                  // keep T_i for the gradient
+            T *= Ls.q[i];
+            if (SUMS) { wsum += w; dnum += w * (0.5f * (Ls.sd[i] + Ls.sd[i + 1])); }
+        }
+    }
+    wsum_o = wsum; dnum_o = dnum;
+}
+
+// Exclusive suffix sums of e[0 .. n) in place, from the far end (the order of the backward's reverse scan): e[i] <- sum_{j > i} e[j]
+__device__ __forceinline__ void suffix_scan_inplace(float* e, int n, int cap, bool vec) {
+    float S = 0.f;
+    if (vec) {
+        for (int i0 = ((n - 1) >> 3) << 3; i0 >= 0; i0 -= 8) {
+            const bool full = i0 + 8 <= cap;
+            float ev[8];
+            if (full) {
+                const float4 a = lds_ld4(e + i0), b = lds_ld4(e + i0 + 4);
+                ev[0] = a.x; ev[1] = a.y; ev[2] = a.z; ev[3] = a.w; ev[4] = b.x; ev[5] = b.y; ev[6] = b.z; ev[7] = b.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ev[k] = i0 + k < n ? e[i0 + k] : 0.f;
+            }
+#pragma unroll
+            for (int k = 7; k >= 0; --k) {
+                if (i0 + k < n) { const float t = ev[k]; ev[k] = S; S += t; }
+            }
+            if (full) { lds_st4(e + i0, ev[0], ev[1], ev[2], ev[3]); lds_st4(e + i0 + 4, ev[4], ev[5], ev[6], ev[7]); }
+            else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (i0 + k < n) e[i0 + k] = ev[k];
+            }
+        }
+    } else {
+        for (int i = n - 1; i >= 0; --i) { const float t = e[i]; e[i] = S; S += t; }
+    }
+}
+
+// rank of `x` among `n` LDS values: the number that sort before it -- v < x, or (ties == 1) v <= x, or (ties == 2) v == x with index < self
+__device__ __forceinline__ int count_before(const float* v, int n, float x, int ties, int self, bool vec) {
+    int cnt = 0, i = 0;
+    if (vec) {
+        for (; i + 4 <= n; i += 4) {
+            const float4 o = lds_ld4(v + i);
+            const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cnt += (ov[k] < x || (ov[k] == x && (ties == 1 || (ties == 2 && i + k < self)))) ? 1 : 0;
+        }
+    }
+    for (; i < n; ++i) { const float o = v[i]; cnt += (o < x || (o == x && (ties == 1 || (ties == 2 && i < self)))) ? 1 : 0; }
+    return cnt;
+}
+
 // The colour reduction of the compositing stage goes through LDS CCH channels at a time: a full [threads][33] buffer (25 KB) holds a
 // block to 3 waves per SIMD; [threads][9] leaves room for 6 (the stage streams 200 MB of saved rows and is latency-bound).
 constexpr int CCH = 8;
@@ -170,6 +285,13 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int D = p.Dc > p.Df ? p.Dc : p.Df;
     const int RPB = MAXT / D;                    // rays per block
+#ifndef RK_VEC_SCAN
+#define RK_VEC_SCAN 1          // batched transmittance scan: 1 = backward kernel only (-1.7 us; the forward kernels measured no gain, render_kernel<3> lost occupancy), 2 = everywhere
+#endif
+#ifndef RK_VEC_RANK
+#define RK_VEC_RANK 0          // 16-byte reads in the merge's rank loops: measured +5 .. +10 us on render_kernel<3> (104 registers: four waves per SIMD instead of five), off
+#endif
+    const bool vec = (D & 1) == 0;               // per-ray LDS arrays start on 16-byte boundaries (RAY_LDS_FLOATS(D) * 4 and the 2 D / 4 D offsets are multiples of 16)
     const int nthreads = RPB * D;
     const int tid = threadIdx.x;
     const int r = tid / D, s = tid - r * D;
@@ -225,7 +347,8 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
         depth_c = coarse_depth(p, rr, s, p.u1[rr * Dc + s]);
         const int64_t row = (rr * 2 + 0) * D + s;
         sig_c = p.save_sigma[row];
-        if constexpr (MODE == 3) {
+        if constexpr (MODE == 3) {          // (reading the colour rows only where they are composited frees 64 registers across the merge and the scan -- and
+            // exposes their latency: 76 -> 118 us)
             const float4* c4p = reinterpret_cast<const float4*>(p.save_rgb + row * CO);
 #pragma unroll
             for (int c4 = 0; c4 < CO / 4; ++c4) {
@@ -266,8 +389,8 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
             }
             __syncthreads();
             if (scan_lane) {
-                float T = 1.f;
-                for (int i = 0; i < Dc - 1; ++i) { Ls.w[i] = Ls.t[i] * T; T *= Ls.q[i]; }
+                float unused0, unused1;
+                march_scan<false, false, (MODE == 0 ? 4 : 8)>(Ls, Dc - 1, 2 * D, vec && RK_VEC_SCAN, unused0, unused1);
             }
             __syncthreads();
             // smoothing: max_pool1d(2,1,pad 1) -> avg_pool1d(2,1) -> + 0.01      (renderer.py:260-262)
@@ -280,17 +403,21 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
             __syncthreads();
             if (live && s < nw) L.t[s] = sm;
             __syncthreads();
+            // sample_pdf on bins = mids[0..nw-1], weights = sm[1..nw-2]   (renderer.py:264-266,281-307)
+            const int ns = nw - 2;
+            const float eps = 1e-5f;
+            float tot = 0.f;
+            if (live) for (int k = 0; k < ns; ++k) tot += L.t[1 + k] + eps;
+            // pdf_k = (sm_k + eps) / tot once per ray (thread k), not inside every thread's search: the division is ten dependent instructions
+            // per step of a loop that the 48 threads of a ray all walk (q[] is free: the coarse scan has consumed it)
+            if (live && s >= 1 && s <= ns) L.q[s] = (L.t[s] + eps) / tot;
+            __syncthreads();
             if (has_f) {
-                // sample_pdf on bins = mids[0..nw-1], weights = sm[1..nw-2]   (renderer.py:264-266,281-307)
-                const int ns = nw - 2;
-                const float eps = 1e-5f;
-                float tot = 0.f;
-                for (int k = 0; k < ns; ++k) tot += L.t[1 + k] + eps;
                 const float u = p.u2[rr * Df + s];
                 float c = 0.f, c_below = 0.f, c_above = 0.f;
                 int inds = ns + 1;
                 for (int k = 1; k <= ns; ++k) {
-                    float cn = c + (L.t[k] + eps) / tot;
+                    float cn = c + L.q[k];
                     if (cn > u) { inds = k; c_below = c; c_above = cn; c = cn; break; }
                     c = cn;
                 }
@@ -372,17 +499,11 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
     if (has_c) {
         // position in torch.sort(cat(coarse, fine), stable=True) (renderer.py:212-222).  The stratified depths t_i + u_i * delta are increasing
         // in exact arithmetic only: u = 1 - 2^-24 next to u = 0 can round the wrong way round, so the coarse list is ranked too, not assumed sorted
-        int cnt = 0;
-        for (int i = 0; i < Dc; ++i) { float o = L.dc[i]; cnt += (o < depth_c || (o == depth_c && i < s)) ? 1 : 0; }
-        for (int j = 0; j < Df; ++j) cnt += L.df[j] < depth_c ? 1 : 0;
-        rank_c = cnt;
+        rank_c = count_before(L.dc, Dc, depth_c, 2, s, vec && RK_VEC_RANK) + count_before(L.df, Df, depth_c, 0, 0, vec && RK_VEC_RANK);
         L.sd[rank_c] = depth_c; L.ss[rank_c] = sig_c;
     }
     if (has_f) {
-        int cnt = 0;
-        for (int i = 0; i < Dc; ++i) cnt += L.dc[i] <= depth_f ? 1 : 0;
-        for (int j = 0; j < Df; ++j) { float o = L.df[j]; cnt += (o < depth_f || (o == depth_f && j < s)) ? 1 : 0; }
-        rank_f = cnt;
+        rank_f = count_before(L.dc, Dc, depth_f, 1, 0, vec && RK_VEC_RANK) + count_before(L.df, Df, depth_f, 2, s, vec && RK_VEC_RANK);
         L.sd[rank_f] = depth_f; L.ss[rank_f] = sig_f;
     }
     if (p.dbg_ranks) {
@@ -402,15 +523,8 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
     }
     __syncthreads();
     if (scan_lane) {
-        float T = 1.f, wsum = 0.f, dnum = 0.f;
-        for (int i = 0; i < nI; ++i) {
-            float w = Ls.t[i] * T;
-            Ls.w[i] = w;
-            if (BWD) Ls.t[i] = T;                     // keep T_i for the gradient
-            T *= Ls.q[i];
-            wsum += w;
-            dnum += w * (0.5f * (Ls.sd[i] + Ls.sd[i + 1]));
-        }
+        float wsum, dnum;
+        march_scan<BWD, true, (BWD ? 8 : 4)>(Ls, nI, 2 * D, vec && RK_VEC_SCAN && (BWD || RK_VEC_SCAN > 1), wsum, dnum);          // (backward: T_i kept in t[] for the gradient)
         Ls.misc[0] = wsum; Ls.misc[1] = dnum; Ls.misc[2] = Ls.sd[0]; Ls.misc[3] = Ls.sd[nS - 1];
     }
     __syncthreads();
@@ -505,20 +619,17 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
         for (int i = s; i < nI; i += D, ++k) E[i] = xw[k];
     }
     __syncthreads();
-    if (scan_lane) {
-        // dL/dalpha_i = gw_i T_i - S_i / q_i with the reverse suffix sum S_i = sum_{j > i} gw_j w_j
-        const float* Es = red + tid * 2 * D;
-        float* GAs = red + RPB * 2 * D + tid * 2 * D;
-        const float* GWTs = red + 2 * RPB * 2 * D + tid * 4 * D;
-        const float* DLs = GWTs + 2 * D;
-        float S = 0.f;
-        for (int i = nI - 1; i >= 0; --i) {
-            const float q = Ls.q[i];
-            const float galpha = GWTs[i] - S / q;
-            S += Es[i];
+    // dL/dalpha_i = gw_i T_i - S_i / q_i with the reverse suffix sum S_i = sum_{j > i} gw_j w_j: only the sum itself is a recurrence (one add per
+    // interval, one lane per ray); the division and the products around it are formed by the ray's D threads again
+    if (scan_lane) suffix_scan_inplace(red + tid * 2 * D, nI, 2 * D, vec);
+    __syncthreads();
+    if (live) {
+        for (int i = s; i < nI; i += D) {
+            const float q = L.q[i];
+            const float galpha = GWT[i] - E[i] / q;
             const float one_minus_alpha = q - 1e-10f;
-            const float gsp = galpha * DLs[i] * one_minus_alpha;
-            GAs[i] = gsp * GAs[i];
+            const float gsp = galpha * DL[i] * one_minus_alpha;
+            GA[i] = gsp * GA[i];
         }
     }
     __syncthreads();
