@@ -423,7 +423,158 @@ __host__ __device__ int group_width(int C4) {
     return g;
 }
 
+
+// ---- small-channel 3 x 3 convolutions on the vector ALUs (the stand-in feature pyramid: 4 -> 16 -> 32 -> 64 channels at 256^2 .. 64^2) ---------
+// Those layers are 0.08 - 0.15 GFLOP: on the implicit-GEMM kernel each is a 17 - 23 us launch (a 128 x 32 tile walks a 36 .. 288-deep
+// contraction in barrier-separated steps) plus separate pooling / activation-backward / gradient-add passes.  Here a thread owns a 2 x 2 quad
+// of output pixels and G output channels, walks the input channels four at a time (a 4 x 4 patch of 16-byte pixels in registers per step) and
+// multiplies in exact fp32; the weights of a workgroup's channel group are wave-uniform (scalar loads, SGPR operands of v_fmac).  The
+// epilogue applies lrelu * gain and (POOL) writes the 2 x 2 average next to the full-resolution tensor the backward needs for the sign.
+// The data gradient is the same kernel on the flipped, transposed weights.
+template <int G, bool POOL, int KS>         // KS: the input-channel quads are dealt to KS waves of the block (64 output quads per block), partial sums meet in LDS
+__global__ void __launch_bounds__(64 * KS) conv3x3_direct_kernel(const eg3d_conv3x3_direct_params p) {
+    __shared__ float part[KS > 1 ? (KS - 1) * 64 * 4 * G : 1];
+    const int Hq = p.H >> 1, Wq = p.W >> 1;
+    const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + lane;
+    const bool live = q < Hq * Wq;
+    const int qy = live ? q / Wq : 0, qx = live ? q - qy * Wq : 0;
+    const int n = blockIdx.z, cog = blockIdx.y;
+    const int y0 = 2 * qy - 1, x0 = 2 * qx - 1;                      // top-left corner of the 4 x 4 input patch
+    const float* xn = p.x + (int64_t)n * p.H * p.W * p.Ci;
+    const float* wq = p.w + (int64_t)cog * (p.Ci >> 2) * 9 * 4 * G;
+    float acc[4][G];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[i][g] = 0.f;
+    // patch addresses / validity do not depend on the channel step
+    int off[16];
+    bool ok[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int yy = y0 + (i >> 2), xx = x0 + (i & 3);
+        ok[i] = live && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+        off[i] = ok[i] ? (yy * p.W + xx) * p.Ci : 0;
+    }
+    for (int cq = ks; cq < (p.Ci >> 2); cq += KS) {
+        float4 t[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = ok[i] ? *reinterpret_cast<const float4*>(xn + off[i] + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* wc = wq + (int64_t)cq * 9 * 4 * G;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float wv = wc[(tap * 4 + j) * G + g];
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        const float4 tv = t[((o >> 1) + ky) * 4 + (o & 1) + kx];
+                        const float xv = j == 0 ? tv.x : (j == 1 ? tv.y : (j == 2 ? tv.z : tv.w));
+                        acc[o][g] = fmaf(xv, wv, acc[o][g]);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (KS > 1) {             // slices 1 .. KS-1 hand their partial sums to slice 0 (lane-major: conflict-free)
+        if (ks > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < G; ++g) part[((ks - 1) * 4 * G + i * G + g) * 64 + lane] = acc[i][g];
+        }
+        __syncthreads();
+        if (ks > 0) return;
+#pragma unroll
+        for (int k = 0; k < KS - 1; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[i][g] += part[(k * 4 * G + i * G + g) * 64 + lane];
+    }
+    if (!live) return;
+    const float gpos = p.gain, gneg = p.gain * p.alpha;
+    float pool[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) pool[g] = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        float v[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            v[g] = p.act ? acc[o][g] * (acc[o][g] > 0.f ? gpos : gneg) : acc[o][g];
+            pool[g] += v[g];
+        }
+        if (p.y != nullptr) {
+            float* yo = p.y + (((int64_t)n * p.H + 2 * qy + (o >> 1)) * p.W + 2 * qx + (o & 1)) * p.Co + cog * G;
+            if constexpr (G == 4) *reinterpret_cast<float4*>(yo) = make_float4(v[0], v[1], v[2], v[3]);
+            else if constexpr (G == 2) *reinterpret_cast<float2*>(yo) = make_float2(v[0], v[1]);
+            else yo[0] = v[0];
+        }
+    }
+    if constexpr (POOL) {
+        float* po = p.pooled + (((int64_t)n * Hq + qy) * Wq + qx) * p.Co + cog * G;
+        if constexpr (G == 4) *reinterpret_cast<float4*>(po) = make_float4(pool[0] * 0.25f, pool[1] * 0.25f, pool[2] * 0.25f, pool[3] * 0.25f);
+        else if constexpr (G == 2) *reinterpret_cast<float2*>(po) = make_float2(pool[0] * 0.25f, pool[1] * 0.25f);
+        else po[0] = pool[0] * 0.25f;
+    }
+}
+
+// dz[n,y,x,c] = 0.25 (ga + gb)[n,y/2,x/2,c] * gain * (yref[n,y,x,c] > 0 ? 1 : alpha): the 2 x 2 average's backward, the sum of the pooled
+// tensor's two consumers' gradients and the lrelu backward (bias_act.cu:76,145 semantics on the saved output) in one pass
+__global__ void __launch_bounds__(NT) pool2_act_bwd_kernel(const float4* __restrict__ ga, const float4* __restrict__ gb, const float4* __restrict__ yref,
+                                                           float4* __restrict__ dz, int N, int H, int W, int C4, float alpha, float gain) {
+    const int64_t total = (int64_t)N * H * W * C4;
+    const int Hq = H >> 1, Wq = W >> 1;
+    const float gp = 0.25f * gain, gn = 0.25f * gain * alpha;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int c = (int)(i % C4);
+        int64_t r = i / C4;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const int n = (int)(r / H);
+        const int64_t j = (((int64_t)n * Hq + (y >> 1)) * Wq + (x >> 1)) * C4 + c;
+        float4 g = ga != nullptr ? ga[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gb != nullptr) { const float4 h = gb[j]; g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w; }
+        const float4 yv = yref[i];
+        dz[i] = make_float4(g.x * (yv.x > 0.f ? gp : gn), g.y * (yv.y > 0.f ? gp : gn), g.z * (yv.z > 0.f ? gp : gn), g.w * (yv.w > 0.f ? gp : gn));
+    }
+}
+
 }  // namespace
+
+extern "C" int eg3d_conv3x3_direct(const eg3d_conv3x3_direct_params* p, void* stream) {
+    if (!p || !p->x || !p->w || (!p->y && !p->pooled)) return EG3D_ERR_INVALID;
+    if (p->N < 1 || p->H < 2 || p->W < 2 || (p->H & 1) || (p->W & 1) || p->Ci < 4 || (p->Ci & 3) || p->Co < 1) return EG3D_ERR_UNSUPPORTED;
+    if ((p->G != 1 && p->G != 2 && p->G != 4) || p->Co % p->G || (int64_t)p->H * p->W * p->Ci > INT32_MAX || p->N > 65535 || p->Co / p->G > 65535) return EG3D_ERR_UNSUPPORTED;
+    if (!aligned16(p->x) || !aligned16(p->w) || (p->y && !aligned16(p->y)) || (p->pooled && !aligned16(p->pooled)) || (p->G > 1 && (p->Co * 4) % (4 * p->G))) return EG3D_ERR_INVALID;
+    const dim3 grid((unsigned)(((int64_t)(p->H / 2) * (p->W / 2) + 63) / 64), (unsigned)(p->Co / p->G), (unsigned)p->N);
+    const bool pool = p->pooled != nullptr;
+    const int ks = p->Ci >= 16 ? 4 : 1;            // four waves share a block's contraction once it is four channel quads deep
+#define EG3D_C3D2(G_, KS_) do { if (pool) hipLaunchKernelGGL((conv3x3_direct_kernel<G_, true, KS_>), grid, dim3(64 * KS_), 0, (hipStream_t)stream, *p); \
+                               else hipLaunchKernelGGL((conv3x3_direct_kernel<G_, false, KS_>), grid, dim3(64 * KS_), 0, (hipStream_t)stream, *p); } while (0)
+#define EG3D_C3D(G_) do { if (ks == 4) EG3D_C3D2(G_, 4); else EG3D_C3D2(G_, 1); } while (0)
+    if (p->G == 4) EG3D_C3D(4); else if (p->G == 2) EG3D_C3D(2); else EG3D_C3D(1);
+#undef EG3D_C3D2
+#undef EG3D_C3D
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_pool2_act_bwd(const float* ga, const float* gb, const float* yref, float* dz, int N, int H, int W, int C, float alpha, float gain, void* stream) {
+    if (!yref || !dz || (!ga && !gb) || N < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 4 || (C & 3)) return EG3D_ERR_INVALID;
+    if ((ga && !aligned16(ga)) || (gb && !aligned16(gb)) || !aligned16(yref) || !aligned16(dz)) return EG3D_ERR_INVALID;
+    hipLaunchKernelGGL(pool2_act_bwd_kernel, dim3(grid_blocks((int64_t)N * H * W * (C / 4))), dim3(NT), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(ga ? ga : gb), reinterpret_cast<const float4*>(ga ? gb : nullptr), reinterpret_cast<const float4*>(yref),
+                       reinterpret_cast<float4*>(dz), N, H, W, C / 4, alpha, gain);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
 
 extern "C" int eg3d_maxpool2d_fwd(const float* x, float* y, uint8_t* argmax, int N, int H, int W, int C, int ldx, int k, int s, void* stream) {
     int rc = pool_check(x, y, N, H, W, C, ldx, k, s);

@@ -154,6 +154,11 @@ class TorgbSmallBwdParams(C.Structure):
                 ('ldx', C.c_int32), ('wa_row', C.c_int32), ('act_on', C.c_int32), ('pad_', C.c_int32), ('act_bwd', ActBwd)]
 
 
+class Conv3x3DirectParams(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('w', C.c_void_p), ('y', C.c_void_p), ('pooled', C.c_void_p), ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('Ci', C.c_int32), ('Co', C.c_int32), ('G', C.c_int32), ('act', C.c_int32), ('alpha', C.c_float), ('gain', C.c_float)]
+
+
 ADAM_ITEMS_MAX = 32
 
 
@@ -273,6 +278,8 @@ _SIGS = {
     'eg3d_unit_normalize_fwd': (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int64, C.c_int, C.c_void_p]),
     'eg3d_image_prepare_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     'eg3d_image_prepare_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    'eg3d_conv3x3_direct': (C.c_int, [C.POINTER(Conv3x3DirectParams), C.c_void_p]),
+    'eg3d_pool2_act_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     'eg3d_sqdist_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     'eg3d_sqdist_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     'eg3d_sqdist_sum_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p]),

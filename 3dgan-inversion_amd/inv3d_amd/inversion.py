@@ -53,8 +53,11 @@ class StubFeatureNet(torch.nn.Module):
         n, c, h, w = img.shape
         x = torch.cat([img, img.new_zeros(n, 4 - c, h, w)], 1) if c < 4 else img
         x = hipops.to_cl(x.float())
+        wl = list(self.ws)[:upto]
+        if LN.stub_pyramid_ok(x, wl):        # levels this small run as direct convolutions with pooling / activation backward fused (csrc/loss_ops.hip)
+            return LN.stub_pyramid(x, wl, 0.2, math.sqrt(2.0))
         outs = []
-        for wt in list(self.ws)[:upto]:
+        for wt in wl:
             x = LN.conv_act(x, wt, None, 1, 1, 'lrelu', 0.2, math.sqrt(2.0))
             x = F.avg_pool2d(x, 2)
             outs.append(x)

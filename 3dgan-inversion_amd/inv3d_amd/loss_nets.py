@@ -269,6 +269,103 @@ def conv_act(x, weight, bias, stride=1, pad=0, act='relu', alpha=0.0, gain=1.0):
     return _ConvActFn.apply(x, weight, bias, stride, pad, act, alpha, gain)
 
 
+# ---- the stand-in feature pyramid as direct convolutions (csrc/loss_ops.hip: eg3d_conv3x3_direct, eg3d_pool2_act_bwd) ----------------------------
+DIRECT_PYRAMID = os.environ.get('EG3D_DIRECT_PYRAMID', '1') != '0'
+
+
+def _direct_group(co: int, quads: int, ci: int) -> int:
+    """Output channels per thread: the widest group that still leaves ~32 k threads (512 waves) for the chip (the kernel deals the
+    input-channel quads to four waves of a block from 16 channels on)."""
+    ks = 4 if ci >= 16 else 1
+    for g in (4, 2, 1):
+        if co % g == 0 and quads * (co // g) * ks >= 32768:
+            return g
+    return 1
+
+
+def _pack_direct(w: torch.Tensor, g: int) -> torch.Tensor:
+    """[Co,Ci,3,3] -> [Co/G][Ci/4][9][4][G] (Ci zero-padded to a multiple of 4)."""
+    co, ci = w.shape[:2]
+    cip = (ci + 3) // 4 * 4
+    if cip != ci:
+        w = torch.cat([w, w.new_zeros(co, cip - ci, 3, 3)], 1)
+    return w.float().reshape(co // g, g, cip // 4, 4, 9).permute(0, 2, 4, 3, 1).contiguous()
+
+
+def _conv3x3_direct(x, wp, co, g, *, y=None, pooled=None, act=False, alpha=0.2, gain=1.0):
+    n, ci, h, w = x.shape
+    p = L.Conv3x3DirectParams(x=x.data_ptr(), w=wp.data_ptr(), y=y.data_ptr() if y is not None else None,
+                              pooled=pooled.data_ptr() if pooled is not None else None, N=n, H=h, W=w, Ci=ci, Co=co, G=g, act=1 if act else 0,
+                              alpha=float(alpha), gain=float(gain))
+    L.check(L.lib().eg3d_conv3x3_direct(C_byref(p), L.stream_ptr()), 'conv3x3_direct')
+
+
+class _StubPyramidFn(torch.autograd.Function):
+    """p_l = avg_pool2(lrelu(conv3x3(p_{l-1}, W_l)) * gain), l = 1..L, with frozen weights: one launch per level forward, two per level
+    backward (pooling backward + sum of the level's two consumers' gradients + activation backward; then the data gradient), where the
+    generic path took conv + pool forward and add + pool backward + activation backward + conv backward.  Returns every level's output."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, gain, *weights):
+        L.require_cuda(x, *weights)
+        assert H.is_cl(x) and x.dtype == torch.float32
+        ys, outs, cur = [], [], x
+        for wt in weights:
+            n, ci, h, w = cur.shape
+            co = wt.shape[0]
+            g = _direct_group(co, (h // 2) * (w // 2), ci)
+            wp = H.memo(('direct_fwd', ci, g), [wt], lambda wt=wt, g=g: _pack_direct(wt.detach(), g))
+            y = H.empty_cl(n, co, h, w, x.device)
+            pl = H.empty_cl(n, co, h // 2, w // 2, x.device)
+            _conv3x3_direct(cur, wp, co, g, y=y, pooled=pl, act=True, alpha=alpha, gain=gain)
+            ys.append(y)
+            outs.append(pl)
+            cur = pl
+        ctx.save_for_backward(*ys, *weights)
+        ctx.cfg = (float(alpha), float(gain), len(weights), tuple(x.shape))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        alpha, gain, nl, xshape = ctx.cfg
+        ys, weights = ctx.saved_tensors[:nl], ctx.saved_tensors[nl:]
+        dx = None                                    # gradient arriving from the level above (w.r.t. this level's pooled output)
+        for l in range(nl - 1, -1, -1):
+            y, wt = ys[l], weights[l]
+            n, co, h, w = y.shape
+            ga = grads[l]
+            if ga is not None:
+                ga = H.to_cl(ga.float())
+            if ga is None and dx is None:
+                dx = None
+                continue
+            dz = H.empty_cl(n, co, h, w, y.device)
+            L.check(L.lib().eg3d_pool2_act_bwd(ga.data_ptr() if ga is not None else None, dx.data_ptr() if dx is not None else None, y.data_ptr(), dz.data_ptr(),
+                                               n, h, w, co, alpha, gain, L.stream_ptr()), 'pool2_act_bwd')
+            ci = xshape[1] if l == 0 else ys[l - 1].shape[1]
+            g = _direct_group(ci, (h // 2) * (w // 2), co)
+            wa = H.memo(('direct_adj', co, g), [wt], lambda wt=wt, g=g: _pack_direct(wt.detach().flip(2, 3).permute(1, 0, 2, 3), g))
+            dx = H.empty_cl(n, ci, h, w, y.device)
+            _conv3x3_direct(dz, wa, ci, g, y=dx)
+        return (dx, None, None) + (None,) * nl
+
+
+def stub_pyramid_ok(x: torch.Tensor, weights) -> bool:
+    if not (DIRECT_PYRAMID and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] % 4 == 0 and H.is_cl(x)):
+        return False
+    h, w, c = x.shape[2], x.shape[3], x.shape[1]
+    for wt in weights:
+        if wt.requires_grad or tuple(wt.shape[2:]) != (3, 3) or wt.shape[1] != c or wt.shape[0] % 4 or h % 2 or w % 2 or h < 2 or w < 2:
+            return False
+        h, w, c = h // 2, w // 2, wt.shape[0]
+    return True
+
+
+def stub_pyramid(x: torch.Tensor, weights, alpha: float = 0.2, gain: float = math.sqrt(2.0)):
+    """The pooled outputs of every level of the stand-in pyramid (inversion.StubFeatureNet.stages) from the direct kernels."""
+    return list(_StubPyramidFn.apply(x, float(alpha), float(gain), *weights))
+
+
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, k, s):

@@ -845,6 +845,25 @@ int eg3d_unit_normalize_levels(const eg3d_unit_levels* batch, int bwd, void* str
  * bwd: dimg[n,Y,X,c] = mul / factor^2 * dout[n,Y/factor,X/factor,c] (c < 3), 0 for c = 3. */
 int eg3d_image_prepare_fwd(const float* img, float* out, int N, int H, int W, int factor, float mul, float add, void* stream);
 int eg3d_image_prepare_bwd(const float* dout, float* dimg, int N, int H, int W, int factor, float mul, void* stream);
+/* Small-channel 3 x 3 convolution (stride 1, zero padding 1) in exact fp32 on the vector ALUs, for layers too small for the matrix-core tiles
+ * (the stand-in feature pyramid of inv3d_amd.inversion.StubFeatureNet: 4 -> 16 -> 32 -> 64 channels at 256^2 .. 64^2; the reference's feature
+ * networks are torchvision / lpips modules, w_projector.py:50-58):
+ *   y = lrelu(conv(x, W)) * gain (act != 0; plain conv otherwise), written at full resolution (y, optional) and / or as its 2 x 2 average (pooled).
+ * x: [N,H,W,Ci] NHWC, Ci % 4 == 0, H and W even.  w: packed [Co/G][Ci/4][9 taps (ky*3+kx)][4][G] (correlation taps: the data gradient passes
+ * the flipped, channel-transposed weights).  G in {1,2,4} output channels per thread. */
+typedef struct eg3d_conv3x3_direct_params {
+    const float* x;
+    const float* w;
+    float* y;
+    float* pooled;
+    int N, H, W, Ci, Co, G;
+    int act;
+    float alpha, gain;
+} eg3d_conv3x3_direct_params;
+int eg3d_conv3x3_direct(const eg3d_conv3x3_direct_params* p, void* stream);
+/* Backward of `pooled = avg_pool2(lrelu(z) * gain)` towards z, summing the gradients of the pooled tensor's (up to) two consumers:
+ *   dz[n,y,x,c] = 0.25 (ga + gb)[n,y/2,x/2,c] * gain * (yref[n,y,x,c] > 0 ? 1 : alpha)   (ga or gb may be null; NHWC, C % 4 == 0). */
+int eg3d_pool2_act_bwd(const float* ga, const float* gb, const float* yref, float* dz, int N, int H, int W, int C, float alpha, float gain, void* stream);
 /* out[n] (pre-zeroed) += sum_i (a[n,i] - b[n,i])^2 over flat feature vectors [N,F] (F % 4 == 0) -- the projector's per-image distance
  * (w_projector.py:216-219); bwd: da = 2 g[n] (a - b). */
 int eg3d_sqdist_fwd(const float* a, const float* b, float* out, int N, int64_t F, void* stream);

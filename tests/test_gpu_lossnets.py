@@ -243,3 +243,55 @@ def test_weighted_objective_and_rgb_slice_vs_aten():
     want = torch.zeros_like(feat)
     want.view(2, 16, 16, 32)[..., :3] = gy[:, :3].permute(0, 2, 3, 1)
     assert torch.equal(feat.grad, want)
+
+
+@pytest.mark.parametrize('n,res,upto', [(1, 256, 3), (2, 64, 3), (1, 32, 2), (1, 16, 1)])
+def test_stub_pyramid_direct_kernels_match_the_oracle(n, res, upto):
+    """inversion.StubFeatureNet.stages on the direct kernels (eg3d_conv3x3_direct + eg3d_pool2_act_bwd: conv, lrelu, 2 x 2 average in one
+    launch; pooling backward + the sum of a level's two consumers' gradients + activation backward in one) against the oracle's restatement
+    (oracle/inversion_oracle.py:43-59, conv2d -> bias_act(lrelu) -> avg_pool2d), with EVERY level's output consumed -- each pooled tensor
+    feeds the next level and the loss -- and against the generic path the kernels replace."""
+    import math
+    from inv3d_amd import loss_nets as LN
+    from inv3d_amd.inversion import StubFeatureNet
+    from oracle import eg3d_oracle as O
+    from oracle import inversion_oracle as IO
+    torch.manual_seed(n * res + upto)
+    net = StubFeatureNet().to(DEV)
+    ws_cpu = IO.stub_feature_weights()
+    for a, b in zip(net.ws, ws_cpu):
+        assert torch.equal(a.detach().cpu(), b)
+    img = (torch.randn(n, 3, res, res) * 60 + 128)
+    mix = [torch.randn(n, w, res >> (l + 1), res >> (l + 1)) for l, w in enumerate((16, 32, 64)[:upto])]
+
+    def run_oracle():
+        x = img.clone().requires_grad_(True)
+        cur = torch.cat([x, x.new_zeros(n, 1, res, res)], 1)
+        outs = []
+        for wt in ws_cpu[:upto]:
+            cur = F.avg_pool2d(O.bias_act(F.conv2d(cur, wt, padding=1), None, act='lrelu'), 2)
+            outs.append(cur)
+        sum((o * m).sum() for o, m in zip(outs, mix)).backward()
+        return outs, x.grad
+
+    def run_gpu():
+        x = img.to(DEV).requires_grad_(True)
+        x4 = cl(torch.cat([x, x.new_zeros(n, 1, res, res)], 1))
+        outs = net.stages(x4, upto=upto)
+        sum((o * m.to(DEV)).sum() for o, m in zip(outs, mix)).backward()
+        return outs, x.grad
+
+    assert LN.stub_pyramid_ok(cl(torch.zeros(n, 4, res, res)), list(net.ws)[:upto])
+    ref_o, ref_g = run_oracle()
+    got_o, got_g = run_gpu()
+    for l, (a, b) in enumerate(zip(got_o, ref_o)):
+        close(a, b, 2e-6, f'level {l}')
+    close(got_g, ref_g, 5e-6, 'd img')
+    LN.DIRECT_PYRAMID, keep = False, LN.DIRECT_PYRAMID
+    try:
+        gen_o, gen_g = run_gpu()
+    finally:
+        LN.DIRECT_PYRAMID = keep
+    for l, (a, b) in enumerate(zip(got_o, gen_o)):
+        close(a, b, 2e-6, f'level {l} vs generic path')
+    close(got_g, gen_g, 5e-6, 'd img vs generic path')
