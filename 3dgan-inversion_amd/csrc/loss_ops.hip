@@ -431,7 +431,7 @@ __host__ __device__ int group_width(int C4) {
 // multiplies in exact fp32; the weights of a workgroup's channel group are wave-uniform (scalar loads, SGPR operands of v_fmac).  The
 // epilogue applies lrelu * gain and (POOL) writes the 2 x 2 average next to the full-resolution tensor the backward needs for the sign.
 // The data gradient is the same kernel on the flipped, transposed weights.
-template <int G, bool POOL, int KS>         // KS: the input-channel quads are dealt to KS waves of the block (64 output quads per block), partial sums meet in LDS
+template <int G, bool POOL, int KS, bool XF = false>         // XF: the input is formed on the fly (see eg3d_conv3x3_direct_params::ga).  KS: the input-channel quads are dealt to KS waves of the block (64 output quads per block), partial sums meet in LDS
 __global__ void __launch_bounds__(64 * KS) conv3x3_direct_kernel(const eg3d_conv3x3_direct_params p) {
     __shared__ float part[KS > 1 ? (KS - 1) * 64 * 4 * G : 1];
     const int Hq = p.H >> 1, Wq = p.W >> 1;
@@ -457,10 +457,34 @@ __global__ void __launch_bounds__(64 * KS) conv3x3_direct_kernel(const eg3d_conv
         ok[i] = live && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
         off[i] = ok[i] ? (yy * p.W + xx) * p.Ci : 0;
     }
+    // XF: the 4 x 4 patch spans the 3 x 3 pooled cells (qy - 1 .. qy + 1, qx - 1 .. qx + 1); patch row / column i lies in cell (i + 1) >> 1
+    int goff[9];
+    if constexpr (XF) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            const int cy = min(max(qy - 1 + c / 3, 0), Hq - 1), cx = min(max(qx - 1 + c % 3, 0), Wq - 1);      // (cells outside the image are only met by patch pixels with ok = false)
+            goff[c] = ((n * Hq + cy) * Wq + cx) * p.Ci;
+        }
+    }
+    const float xf_pos = 0.25f * p.gain, xf_neg = 0.25f * p.gain * p.alpha;
     for (int cq = ks; cq < (p.Ci >> 2); cq += KS) {
         float4 t[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) t[i] = ok[i] ? *reinterpret_cast<const float4*>(xn + off[i] + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (XF) {             // x is the saved activation output: dz = 0.25 (ga + gb)[cell] * gain * (y > 0 ? 1 : alpha)   (eg3d_pool2_act_bwd)
+            float4 gsum[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                gsum[c] = p.ga != nullptr ? *reinterpret_cast<const float4*>(p.ga + goff[c] + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.gb != nullptr) { const float4 h = *reinterpret_cast<const float4*>(p.gb + goff[c] + 4 * cq); gsum[c].x += h.x; gsum[c].y += h.y; gsum[c].z += h.z; gsum[c].w += h.w; }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float4 g = gsum[(((i >> 2) + 1) >> 1) * 3 + (((i & 3) + 1) >> 1)], yv = t[i];
+                t[i] = ok[i] ? make_float4(g.x * (yv.x > 0.f ? xf_pos : xf_neg), g.y * (yv.y > 0.f ? xf_pos : xf_neg), g.z * (yv.z > 0.f ? xf_pos : xf_neg),
+                                           g.w * (yv.w > 0.f ? xf_pos : xf_neg)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         const float* wc = wq + (int64_t)cq * 9 * 4 * G;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -554,8 +578,11 @@ extern "C" int eg3d_conv3x3_direct(const eg3d_conv3x3_direct_params* p, void* st
     if (!aligned16(p->x) || !aligned16(p->w) || (p->y && !aligned16(p->y)) || (p->pooled && !aligned16(p->pooled)) || (p->G > 1 && (p->Co * 4) % (4 * p->G))) return EG3D_ERR_INVALID;
     const dim3 grid((unsigned)(((int64_t)(p->H / 2) * (p->W / 2) + 63) / 64), (unsigned)(p->Co / p->G), (unsigned)p->N);
     const bool pool = p->pooled != nullptr;
+    const bool xf = p->ga != nullptr || p->gb != nullptr;
+    if (xf && (p->act || pool || (p->ga && !aligned16(p->ga)) || (p->gb && !aligned16(p->gb)))) return EG3D_ERR_INVALID;      // alpha / gain belong to the input transform then
     const int ks = p->Ci >= 16 ? 4 : 1;            // four waves share a block's contraction once it is four channel quads deep
 #define EG3D_C3D2(G_, KS_) do { if (pool) hipLaunchKernelGGL((conv3x3_direct_kernel<G_, true, KS_>), grid, dim3(64 * KS_), 0, (hipStream_t)stream, *p); \
+                               else if (xf) hipLaunchKernelGGL((conv3x3_direct_kernel<G_, false, KS_, true>), grid, dim3(64 * KS_), 0, (hipStream_t)stream, *p); \
                                else hipLaunchKernelGGL((conv3x3_direct_kernel<G_, false, KS_>), grid, dim3(64 * KS_), 0, (hipStream_t)stream, *p); } while (0)
 #define EG3D_C3D(G_) do { if (ks == 4) EG3D_C3D2(G_, 4); else EG3D_C3D2(G_, 1); } while (0)
     if (p->G == 4) EG3D_C3D(4); else if (p->G == 2) EG3D_C3D(2); else EG3D_C3D(1);

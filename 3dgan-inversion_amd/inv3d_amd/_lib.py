@@ -156,7 +156,8 @@ class TorgbSmallBwdParams(C.Structure):
 
 class Conv3x3DirectParams(C.Structure):
     _fields_ = [('x', C.c_void_p), ('w', C.c_void_p), ('y', C.c_void_p), ('pooled', C.c_void_p), ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
-                ('Ci', C.c_int32), ('Co', C.c_int32), ('G', C.c_int32), ('act', C.c_int32), ('alpha', C.c_float), ('gain', C.c_float)]
+                ('Ci', C.c_int32), ('Co', C.c_int32), ('G', C.c_int32), ('act', C.c_int32), ('alpha', C.c_float), ('gain', C.c_float), ('pad_', C.c_int32),
+                ('ga', C.c_void_p), ('gb', C.c_void_p)]
 
 
 ADAM_ITEMS_MAX = 32

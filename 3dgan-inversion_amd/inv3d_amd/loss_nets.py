@@ -271,6 +271,7 @@ def conv_act(x, weight, bias, stride=1, pad=0, act='relu', alpha=0.0, gain=1.0):
 
 # ---- the stand-in feature pyramid as direct convolutions (csrc/loss_ops.hip: eg3d_conv3x3_direct, eg3d_pool2_act_bwd) ----------------------------
 DIRECT_PYRAMID = os.environ.get('EG3D_DIRECT_PYRAMID', '1') != '0'
+FUSE_POOL_BWD = os.environ.get('EG3D_FUSE_POOL_BWD', '0') != '0'     # dz formed inside the data-gradient launch (eg3d_conv3x3_direct_params::ga): measured 219.7 vs 220.1 steps/s -- every channel-group block re-forms it; off
 
 
 def _direct_group(co: int, quads: int, ci: int) -> int:
@@ -292,11 +293,11 @@ def _pack_direct(w: torch.Tensor, g: int) -> torch.Tensor:
     return w.float().reshape(co // g, g, cip // 4, 4, 9).permute(0, 2, 4, 3, 1).contiguous()
 
 
-def _conv3x3_direct(x, wp, co, g, *, y=None, pooled=None, act=False, alpha=0.2, gain=1.0):
+def _conv3x3_direct(x, wp, co, g, *, y=None, pooled=None, act=False, alpha=0.2, gain=1.0, ga=None, gb=None):
     n, ci, h, w = x.shape
     p = L.Conv3x3DirectParams(x=x.data_ptr(), w=wp.data_ptr(), y=y.data_ptr() if y is not None else None,
                               pooled=pooled.data_ptr() if pooled is not None else None, N=n, H=h, W=w, Ci=ci, Co=co, G=g, act=1 if act else 0,
-                              alpha=float(alpha), gain=float(gain))
+                              alpha=float(alpha), gain=float(gain), ga=ga.data_ptr() if ga is not None else None, gb=gb.data_ptr() if gb is not None else None)
     L.check(L.lib().eg3d_conv3x3_direct(C_byref(p), L.stream_ptr()), 'conv3x3_direct')
 
 
@@ -339,14 +340,18 @@ class _StubPyramidFn(torch.autograd.Function):
             if ga is None and dx is None:
                 dx = None
                 continue
-            dz = H.empty_cl(n, co, h, w, y.device)
-            L.check(L.lib().eg3d_pool2_act_bwd(ga.data_ptr() if ga is not None else None, dx.data_ptr() if dx is not None else None, y.data_ptr(), dz.data_ptr(),
-                                               n, h, w, co, alpha, gain, L.stream_ptr()), 'pool2_act_bwd')
             ci = xshape[1] if l == 0 else ys[l - 1].shape[1]
             g = _direct_group(ci, (h // 2) * (w // 2), co)
             wa = H.memo(('direct_adj', co, g), [wt], lambda wt=wt, g=g: _pack_direct(wt.detach().flip(2, 3).permute(1, 0, 2, 3), g))
-            dx = H.empty_cl(n, ci, h, w, y.device)
-            _conv3x3_direct(dz, wa, ci, g, y=dx)
+            nxt = H.empty_cl(n, ci, h, w, y.device)
+            if FUSE_POOL_BWD:       # the data-gradient launch forms dz from (ga, dx, y) while it loads its patch
+                _conv3x3_direct(y, wa, ci, g, y=nxt, alpha=alpha, gain=gain, ga=ga, gb=dx)
+            else:
+                dz = H.empty_cl(n, co, h, w, y.device)
+                L.check(L.lib().eg3d_pool2_act_bwd(ga.data_ptr() if ga is not None else None, dx.data_ptr() if dx is not None else None, y.data_ptr(), dz.data_ptr(),
+                                                   n, h, w, co, alpha, gain, L.stream_ptr()), 'pool2_act_bwd')
+                _conv3x3_direct(dz, wa, ci, g, y=nxt)
+            dx = nxt
         return (dx, None, None) + (None,) * nl
 
 

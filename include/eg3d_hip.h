@@ -859,6 +859,10 @@ typedef struct eg3d_conv3x3_direct_params {
     int N, H, W, Ci, Co, G;
     int act;
     float alpha, gain;
+    /* input transform (data gradient of a pooled level; act must be 0, pooled null): with ga or gb set, x is the level's saved full-resolution
+     * output and the convolved tensor is  0.25 (ga + gb)[n,y/2,x/2,c] * gain * (x > 0 ? 1 : alpha)  -- eg3d_pool2_act_bwd without its launch */
+    const float* ga;
+    const float* gb;
 } eg3d_conv3x3_direct_params;
 int eg3d_conv3x3_direct(const eg3d_conv3x3_direct_params* p, void* stream);
 /* Backward of `pooled = avg_pool2(lrelu(z) * gain)` towards z, summing the gradients of the pooled tensor's (up to) two consumers:
