@@ -48,6 +48,16 @@ __global__ void __launch_bounds__(256) torgb_small_kernel(const eg3d_torgb_small
     const float* xr = p.x + ((int64_t)n * HW + (pok ? pix : 0)) * p.ldx + 4 * h;
     const float* wr = p.w + (int64_t)(o0 + row) * p.w_row + 4 * h;           // B operand: lane = (output column, k half)
     const float* sr = p.s + (int64_t)n * p.C + 4 * h;
+    // PRE (pre_z set): the layer input does not exist yet -- the producing 3 x 3 layer left its split-K sums in pre_z and this launch runs that
+    // layer's finishing epilogue while it loads its operand, x = clamp(lrelu(z d + noise + bias) gain) (the arithmetic of epilogue_fwd_kernel, in its
+    // order), and the workgroups of output tile 0 write x for the layers that follow: the 5 - 10 us finishing launch of the 4^2 .. 64^2 blocks is gone
+    const bool pre = p.pre_z != nullptr;
+    const float* zr = pre ? p.pre_z + ((int64_t)n * HW + (pok ? pix : 0)) * p.ldx + 4 * h : nullptr;
+    const float* dr = pre && p.pre_d != nullptr ? p.pre_d + (int64_t)n * p.C + 4 * h : nullptr;
+    const float* br = pre && p.pre_bias != nullptr ? p.pre_bias + 4 * h : nullptr;
+    float* xw = (pre && blockIdx.y == 0 && pok) ? const_cast<float*>(p.x) + ((int64_t)n * HW + pix) * p.ldx + 4 * h : nullptr;
+    float pre_nz = 0.f, pre_amax = 0.f;
+    if (pre && pok && p.pre_noise != nullptr) pre_nz = p.pre_noise[(int64_t)n * p.pre_noise_nstride + pix] * *p.pre_strength;
     // the epilogue's side inputs do not depend on the products: issued here, they travel with the operand loads instead of after the matrix phase
     const int er = threadIdx.x >> 3, eq = threadIdx.x & 7;
     const int ep = p0 + er, eo = o0 + eq * 4;
@@ -71,9 +81,32 @@ __global__ void __launch_bounds__(256) torgb_small_kernel(const eg3d_torgb_small
         for (int j = 0; j < TS_BATCH; ++j) {
             const bool ok = g + j < g1;
             const int kb = (ok ? g + j : g0) * 8;
-            xa[j] = (ok && pok) ? *reinterpret_cast<const float4*>(xr + kb) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xa[j] = (ok && pok) ? *reinterpret_cast<const float4*>((pre ? zr : xr) + kb) : make_float4(0.f, 0.f, 0.f, 0.f);
             wb[j] = ok ? *reinterpret_cast<const float4*>(wr + kb) : make_float4(0.f, 0.f, 0.f, 0.f);
             sv[j] = *reinterpret_cast<const float4*>(sr + kb);
+        }
+        if (pre) {
+#pragma unroll
+            for (int j = 0; j < TS_BATCH; ++j) {
+                const bool ok = g + j < g1;
+                const int kb = (ok ? g + j : g0) * 8;
+                float4 v = xa[j];
+                if (dr != nullptr) { const float4 dv = *reinterpret_cast<const float4*>(dr + kb); v.x *= dv.x; v.y *= dv.y; v.z *= dv.z; v.w *= dv.w; }
+                if (p.pre_noise != nullptr) { v.x += pre_nz; v.y += pre_nz; v.z += pre_nz; v.w += pre_nz; }
+                if (br != nullptr) { const float4 bv = *reinterpret_cast<const float4*>(br + kb); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+                v.x = eg3d_pwl_fwd(v.x, p.pre_slope) * p.pre_gain; v.y = eg3d_pwl_fwd(v.y, p.pre_slope) * p.pre_gain;
+                v.z = eg3d_pwl_fwd(v.z, p.pre_slope) * p.pre_gain; v.w = eg3d_pwl_fwd(v.w, p.pre_slope) * p.pre_gain;
+                if (p.pre_clamp >= 0.f) {
+                    v.x = fminf(fmaxf(v.x, -p.pre_clamp), p.pre_clamp); v.y = fminf(fmaxf(v.y, -p.pre_clamp), p.pre_clamp);
+                    v.z = fminf(fmaxf(v.z, -p.pre_clamp), p.pre_clamp); v.w = fminf(fmaxf(v.w, -p.pre_clamp), p.pre_clamp);
+                }
+                if (!(ok && pok)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok && xw != nullptr) {
+                    *reinterpret_cast<float4*>(xw + kb) = v;
+                    pre_amax = fmaxf(pre_amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+                }
+                xa[j] = v;
+            }
         }
 #pragma unroll
         for (int j = 0; j < TS_BATCH; ++j) {
@@ -83,6 +116,11 @@ __global__ void __launch_bounds__(256) torgb_small_kernel(const eg3d_torgb_small
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j].z * sv[j].z, wb[j].z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j].w * sv[j].w, wb[j].w, acc, 0, 0, 0);
         }
+    }
+    if (pre && blockIdx.y == 0 && p.x_amax != nullptr) {          // max|x|: the operand range of the layers that read x.  One fire-and-forget atomic per wave:
+#pragma unroll                                                    // a look-before-update (eg3d_commit_amax_block) is a memory round trip this launch cannot hide
+        for (int o = 32; o >= 1; o >>= 1) pre_amax = fmaxf(pre_amax, __shfl_xor(pre_amax, o));
+        if (lane == 0 && pre_amax > 0.f && pre_amax < 3.0e38f) atomicMax(reinterpret_cast<unsigned*>(p.x_amax), __float_as_uint(pre_amax));
     }
     // accumulator element r of a lane: pixel row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), output column lane & 31
 #pragma unroll
@@ -218,6 +256,7 @@ extern "C" int eg3d_torgb_small_supported(const eg3d_torgb_small_params* p) {
     if (p->N < 1 || p->H < 1 || p->W < 1 || p->C < 32 || (p->C & 7) || p->Cp < TS_OUT || (p->Cp % TS_OUT)) return 0;
     if ((p->ldx & 3) || p->ldx < p->C || (p->ldo & 3) || p->ldo < p->Cp || (p->w_row & 3) || p->w_row < p->C) return 0;
     if (!al16(p->x) || !al16(p->w) || !al16(p->s) || !al16(p->out) || (p->bias && !al16(p->bias)) || (p->addend && !al16(p->addend))) return 0;
+    if (p->pre_z && (!al16(p->pre_z) || (p->pre_d && !al16(p->pre_d)) || (p->pre_bias && !al16(p->pre_bias)) || (p->pre_noise && !p->pre_strength) || !(p->pre_gain > 0.f))) return 0;
     if (p->addend && p->addend_up2 && ((p->H & 1) || (p->W & 1))) return 0;
     if ((int64_t)p->N * eg3d_cdiv((int64_t)p->H * p->W, TS_PIX) > 0x7fffffff) return 0;
     return 1;

@@ -145,7 +145,9 @@ class SplitWBatch(C.Structure):
 class TorgbSmallParams(C.Structure):
     _fields_ = [('x', C.c_void_p), ('w', C.c_void_p), ('s', C.c_void_p), ('bias', C.c_void_p), ('addend', C.c_void_p), ('out', C.c_void_p),
                 ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('C', C.c_int32), ('Cp', C.c_int32), ('ldx', C.c_int32), ('ldo', C.c_int32),
-                ('w_row', C.c_int32), ('addend_up2', C.c_int32), ('clamp', C.c_float), ('addend_taps', C.c_float * 4)]
+                ('w_row', C.c_int32), ('addend_up2', C.c_int32), ('clamp', C.c_float), ('addend_taps', C.c_float * 4),
+                ('pre_z', C.c_void_p), ('pre_d', C.c_void_p), ('pre_bias', C.c_void_p), ('pre_noise', C.c_void_p), ('pre_strength', C.c_void_p), ('x_amax', C.c_void_p),
+                ('pre_noise_nstride', C.c_int64), ('pre_slope', C.c_float), ('pre_gain', C.c_float), ('pre_clamp', C.c_float), ('pad_', C.c_int32)]
 
 
 class TorgbSmallBwdParams(C.Structure):

@@ -263,7 +263,9 @@ def _act_bwd_for(x, dev):
 class ModConvLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, styles, noise, noise_strength, bias, up, act_gain, clamp, cache, want_wgrad, d_in=None, single_consumer=False,
-                input_is_layer_output=False, precision=None, next_styles=None):
+                input_is_layer_output=False, precision=None, next_styles=None, defer_epilogue=False):
+        # defer_epilogue: the caller hands the output to a toRGB node NEXT and to nothing before it: a split-K layer then leaves its finishing pass
+        # to that node's launch (hipops.PendingEpilogue on the output tensor; ToRGBFn.forward runs or absorbs it)
         # precision: None = the process-wide arithmetic of the modulated convs; 'f16x1' = the reference's fp16 layers (one product of
         # fp16-rounded operands, fp32 accumulation; forward, data gradient and weight gradient alike)
         # x: CL [N,Ci,H,W]; weight [Co,Ci,3,3]; styles [N,Ci]; noise None | [res,res] | [N,1,res,res]; noise_strength 0-d
@@ -284,6 +286,7 @@ class ModConvLayerFn(torch.autograd.Function):
         out = H.empty_cl(N, Co, Ho, Wo, x.device)
         b = bias.contiguous().float() if bias is not None else None
         aflops = 2.0 * N * Hi * Wi * (1 if up == 2 else 1) * kh * kw * Ci * Co     # MACs of the (transposed) conv
+        pending = None
         prec = precision or H.modconv_precision()
         ig_prec = 'f16x3' if prec == 'f16x1' else prec      # the loader-split kernel has no single-product form: it keeps the three products
         # pre-split weight image for the loader-split kernel; frozen weights only (a trained weight would need the pass every step: +34 launches for ~1 %)
@@ -326,14 +329,20 @@ class ModConvLayerFn(torch.autograd.Function):
             elif ks2:
                 z = H.zeros_cl(N, Co, Ho, Wo, x.device)
                 H.conv_v2(aimg, wimg, z, cls, epi=L.EPI_ATOMIC, ksplit=ks2, algo_flops=aflops, products=nprod)
-                H.epilogue_fwd(z, out, d=d, out_amax=amax_out, **epi_kw)
+                if defer_epilogue and H.DEFER_EPILOGUE:
+                    pending = H.PendingEpilogue(z, out, d, amax_out, **epi_kw)
+                else:
+                    H.epilogue_fwd(z, out, d=d, out_amax=amax_out, **epi_kw)
             elif ks == 1:
                 H.conv_igemm(x, wf, Ci, Co, out, cls, in_scale=styles, epi=L.EPI_FWD, out_scale=d, algo_flops=aflops, precision=ig_prec, out_amax=amax_out, w_pieces=wfp,
                              **epi_kw)
             else:
                 z = H.zeros_cl(N, Co, Ho, Wo, x.device)
                 H.conv_atomic(x, wf, Ci, Co, z, cls, in_scale=styles, ksplit=ks, algo_flops=aflops, precision=ig_prec, w_pieces=wfp)
-                H.epilogue_fwd(z, out, d=d, out_amax=amax_out, **epi_kw)
+                if defer_epilogue and H.DEFER_EPILOGUE:
+                    pending = H.PendingEpilogue(z, out, d, amax_out, **epi_kw)
+                else:
+                    H.epilogue_fwd(z, out, d=d, out_amax=amax_out, **epi_kw)
         else:
             if ksu:
                 ksplit, ragged = ksu
@@ -370,6 +379,8 @@ class ModConvLayerFn(torch.autograd.Function):
             else:
                 H.epilogue_fwd(z, out, fir=fir44(x.device), pad0=1, fir_gain=float(up * up), d=d, out_amax=amax_out, **epi_kw)
         H.tag_amax(out, amax_out)
+        if pending is not None:
+            out._eg3d_pending_epi = pending
         rec = None
         if FUSE_ACT_BWD and single_consumer and any(ctx.needs_input_grad[:6]):      # see _ActProducer: the consumer may run this layer's activation backward
             ng = ctx.needs_input_grad
@@ -558,7 +569,7 @@ class ModConvLayerFn(torch.autograd.Function):
         if dnoise is not None and noise4d:
             dnoise = dnoise.view(N, 1, Ho, Wo)
         return (dx if need_x else None, dweight, ds if need_s else None, dnoise, dstrength, dbias, None, None, None, None, None,
-                dd if d_given else None, None, None, None, None)
+                dd if d_given else None, None, None, None, None, None)
 
 
 class StyleBankFn(torch.autograd.Function):
@@ -669,6 +680,10 @@ class ToRGBFn(torch.autograd.Function):
         gradient through THIS backward, where it is added inside the data-gradient epilogue instead of by a separate autograd add
         (3 x tensor bytes per block, 67 MB tensors in the SR head)."""
         L.require_cuda(x, weight, styles)
+        pend = x.__dict__.pop('_eg3d_pending_epi', None) if hasattr(x, '__dict__') else None      # the producing layer's finishing pass is still due (ModConvLayerFn defer_epilogue)
+        if pend is not None and not (H.is_cl(x) and x.dtype == torch.float32 and pend.out is x):
+            pend.run()
+            pend = None
         x = H.to_cl(x.float())
         styles = styles.contiguous().float()
         N, Ci, Hh, Ww = x.shape
@@ -695,15 +710,24 @@ class ToRGBFn(torch.autograd.Function):
         # csrc/torgb_small.hip does the same arithmetic (exact fp32 products) in one short launch
         small = (H.TORGB_SMALL and N * Hh * Ww <= H.TORGB_SMALL_MAX_PIX and Ci % 8 == 0 and Cp % 32 == 0 and wf.stride(1) == 1
                  and (skip is None or up_taps is not None or tuple(skip.shape) == (N, Cp, Hh, Ww)))
+        if pend is not None and not small:
+            pend.run()
+            pend = None
         if small and clampv < 0 and skip is not None:
             out = H.empty_cl(N, Cp, Hh, Ww, x.device)
-            small = H.torgb_small(x, wf, styles, out, bias=b, clamp=-1.0, addend=skip, addend_up2_taps=up_taps)
+            small = H.torgb_small(x, wf, styles, out, bias=b, clamp=-1.0, addend=skip, addend_up2_taps=up_taps, pre=pend)
+            if not small and pend is not None:
+                pend.run()
+            pend = None
         elif small:
             y = H.empty_cl(N, Cp, Hh, Ww, x.device)
             if up_taps is not None:          # clamped layer: its backward needs y itself, the skip image is added by a pass of its own
                 skip = H.upfirdn2d_nhwc(skip, fir44(skip.device), up=2, pad=(2, 1, 2, 1), gain=4.0)
                 up_taps = None
-            small = H.torgb_small(x, wf, styles, y, bias=b, clamp=clampv)
+            small = H.torgb_small(x, wf, styles, y, bias=b, clamp=clampv, pre=pend)
+            if not small and pend is not None:
+                pend.run()
+            pend = None
             if small:
                 out = y + skip if skip is not None else y
         if small:

@@ -1462,14 +1462,34 @@ def noise_regularizer(bufs, scale=1.0, want_grad=True, grads=None):
 
 
 
+class PendingEpilogue:
+    """A 3 x 3 layer's finishing epilogue that has not run yet: the layer's output tensor is allocated but still unwritten, `z` holds the split-K
+    sums.  The toRGB launch that consumes the output next runs it (torgb_small(pre=...)); anything else calls run() first."""
+    __slots__ = ('z', 'out', 'd', 'noise', 'noise_nstride', 'noise_strength', 'bias', 'act', 'alpha', 'gain', 'clamp', 'out_amax')
+
+    def __init__(self, z, out, d, out_amax, noise=None, noise_nstride=0, noise_strength=None, bias=None, act='linear', alpha=0.0, gain=1.0, clamp=-1.0):
+        self.z, self.out, self.d, self.out_amax = z, out, d, out_amax
+        self.noise, self.noise_nstride, self.noise_strength, self.bias = noise, noise_nstride, noise_strength, bias
+        self.act, self.alpha, self.gain, self.clamp = act, alpha, gain, clamp
+
+    def run(self):
+        epilogue_fwd(self.z, self.out, d=self.d, out_amax=self.out_amax, noise=self.noise, noise_nstride=self.noise_nstride, noise_strength=self.noise_strength,
+                     bias=self.bias, act=self.act, alpha=self.alpha, gain=self.gain, clamp=self.clamp)
+
+
+# conv1's finishing pass inside the toRGB launch of the 4^2 .. 64^2 blocks (eg3d_torgb_small_params::pre_z): parity-green, five launches fewer per step, and
+# NOT faster -- the merged launch takes 20.2 us where the two took 11.3 + 10.1 (rocprofv3, same session; 218.0 vs 218.3 steps/s): these launches are chains
+# of dependent memory round trips, and merging them does not shorten the chain.  Off by default.
+DEFER_EPILOGUE = os.environ.get('EG3D_DEFER_EPILOGUE', '0') != '0'
 TORGB_SMALL = os.environ.get('EG3D_TORGB_SMALL', '1') != '0'            # low-latency toRGB launch for small pixel counts (csrc/torgb_small.hip)
 TORGB_SMALL_MAX_PIX = int(os.environ.get('EG3D_TORGB_SMALL_MAX_PIX', '4096'))
 # (the data gradient at 64^2 takes 31 us in the trace against 27 for the implicit GEMM it replaced -- yet the step is 0.2 % faster with it: A/B 209.1 vs 208.8)
 TORGB_SMALL_BWD_MAX_PIX = int(os.environ.get('EG3D_TORGB_SMALL_BWD_MAX_PIX', '4096'))
 
 
-def torgb_small(x, wf, styles, out, bias=None, clamp=-1.0, addend=None, addend_up2_taps=None):
+def torgb_small(x, wf, styles, out, bias=None, clamp=-1.0, addend=None, addend_up2_taps=None, pre=None):
     """eg3d_torgb_small_fwd: out = clamp(conv1x1(x * styles, wf) + bias) + addend.  x / out / addend channels_last fp32; wf [Cp, C] packed rows.
+    `pre` (a PendingEpilogue): x does not exist yet -- the launch runs the producing layer's finishing epilogue on its split-K sums and WRITES x.
     Returns False (nothing launched) when the geometry is not the kernel's."""
     assert is_cl(x) and is_cl(out)
     n, c, h, w = x.shape
@@ -1478,6 +1498,14 @@ def torgb_small(x, wf, styles, out, bias=None, clamp=-1.0, addend=None, addend_u
                            ldx=c, ldo=out.shape[1], w_row=wf.stride(0), addend_up2=1 if addend_up2_taps is not None else 0, clamp=float(clamp))
     if addend_up2_taps is not None:
         p.addend_taps[:] = [float(t) for t in addend_up2_taps]
+    if pre is not None:
+        if pre.act not in ('linear', 'lrelu', 'relu') or tuple(pre.z.shape) != tuple(x.shape) or not is_cl(pre.z):
+            return False
+        p.pre_z, p.pre_d, p.pre_bias = pre.z.data_ptr(), L.ptr(pre.d), L.ptr(pre.bias)
+        p.pre_noise, p.pre_strength, p.pre_noise_nstride = L.ptr(pre.noise), L.ptr(pre.noise_strength), int(pre.noise_nstride or 0)
+        p.x_amax = L.ptr(pre.out_amax)
+        p.pre_slope = {'linear': 1.0, 'lrelu': float(pre.alpha), 'relu': 0.0}[pre.act]
+        p.pre_gain, p.pre_clamp = float(pre.gain), float(pre.clamp)
     if not L.lib().eg3d_torgb_small_supported(C.byref(p)):
         return False
     L.check(L.lib().eg3d_torgb_small_fwd(C.byref(p), L.stream_ptr()), 'torgb_small_fwd')

@@ -598,6 +598,18 @@ typedef struct eg3d_torgb_small_params {
     int32_t addend_up2;
     float clamp;
     float addend_taps[4];
+    /* optional: the producing layer's finishing epilogue inside this launch.  With pre_z set, x is an OUTPUT: pre_z [N,H*W,ldx] holds that layer's
+     * split-K sums, x = clamp(pwl(pre_z * pre_d[n,c] + pre_noise[n,p] * *pre_strength + pre_bias[c]) * pre_gain) is formed while the operand loads
+     * (eg3d_modconv_epilogue_fwd's arithmetic; pwl = x > 0 ? x : x * pre_slope) and written to x; max|x| goes to x_amax (atomic max, or null). */
+    const float* pre_z;
+    const float* pre_d;
+    const float* pre_bias;
+    const float* pre_noise;
+    const float* pre_strength;
+    float* x_amax;
+    int64_t pre_noise_nstride;
+    float pre_slope, pre_gain, pre_clamp;
+    int32_t pad_;
 } eg3d_torgb_small_params;
 int eg3d_torgb_small_supported(const eg3d_torgb_small_params* p);
 int eg3d_torgb_small_fwd(const eg3d_torgb_small_params* p, void* stream);

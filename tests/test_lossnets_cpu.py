@@ -70,3 +70,44 @@ def test_strided_tap_lists_match_conv2d_and_its_adjoint():
         acls, _ = LN._classes_strided_adjoint(h, w, k, k, s, p)
         dxe = _emulate(dy.float(), wt.float(), acls, 1, s, h, w, True)
         assert torch.allclose(dxe.double(), x.grad, atol=1e-4), (k, s, 'adjoint')
+
+
+def test_direct_conv_weight_packing_matches_conv2d_and_its_adjoint():
+    """Host side of eg3d_conv3x3_direct (inv3d_amd/loss_nets.py::_pack_direct, _direct_group): the packed image [Co/G][Ci/4][9][4][G], read the way
+    the kernel reads it (tap = ky * 3 + kx, correlation, zero padding 1), reproduces F.conv2d; the image of the flipped, channel-transposed weights
+    reproduces the data gradient -- for every group width the launcher can pick, input channels padded to a multiple of 4."""
+    from inv3d_amd import loss_nets as LN
+    g = torch.Generator().manual_seed(3)
+
+    def run_packed(x, wp, co, G):            # x [N,Cip,H,W]; the kernel's arithmetic, one tap at a time
+        n, cip, h, w = x.shape
+        xp = F.pad(x, (1, 1, 1, 1))
+        out = torch.zeros(n, co, h, w, dtype=x.dtype)
+        for cog in range(co // G):
+            for cq in range(cip // 4):
+                for tap in range(9):
+                    ky, kx = divmod(tap, 3)
+                    win = xp[:, 4 * cq:4 * cq + 4, ky:ky + h, kx:kx + w]                       # [N,4,H,W]
+                    wv = wp[cog, cq, tap]                                                     # [4][G]
+                    out[:, cog * G:(cog + 1) * G] += torch.einsum('njhw,jg->nghw', win, wv)
+        return out
+
+    for (ci, co, hw) in ((4, 16, 8), (16, 32, 6), (3, 8, 4)):
+        w = torch.randn(co, ci, 3, 3, generator=g).double()
+        cip = (ci + 3) // 4 * 4
+        x = torch.randn(2, ci, hw, hw, generator=g).double()
+        xpad = torch.cat([x, x.new_zeros(2, cip - ci, hw, hw)], 1)
+        ref = F.conv2d(x, w, padding=1)
+        for G in (1, 2, 4):
+            wp = LN._pack_direct(w, G).double()
+            assert tuple(wp.shape) == (co // G, cip // 4, 9, 4, G)
+            assert torch.allclose(run_packed(xpad, wp, co, G), ref, atol=1e-12)
+        if ci % 4 == 0:                      # data gradient: dx = conv(dy, flip(W)^T)
+            dy = torch.randn(2, co, hw, hw, generator=g).double()
+            xr = x.clone().requires_grad_(True)
+            (F.conv2d(xr, w, padding=1) * dy).sum().backward()
+            for G in (1, 2, 4):
+                wa = LN._pack_direct(w.flip(2, 3).permute(1, 0, 2, 3), G).double()
+                assert torch.allclose(run_packed(dy, wa, ci, G), xr.grad, atol=1e-12)
+    # group width: widest that leaves >= 32 k threads; the contraction is dealt to four waves from 16 input channels on
+    assert LN._direct_group(16, 128 * 128, 4) == 4 and LN._direct_group(64, 32 * 32, 32) == 4 and LN._direct_group(32, 32 * 32, 4) == 1
