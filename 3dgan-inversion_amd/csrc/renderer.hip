@@ -270,7 +270,10 @@ __device__ __forceinline__ int count_before(const float* v, int n, float x, int 
 
 // The colour reduction of the compositing stage goes through LDS CCH channels at a time: a full [threads][33] buffer (25 KB) holds a
 // block to 3 waves per SIMD; [threads][9] leaves room for 6 (the stage streams 200 MB of saved rows and is latency-bound).
-constexpr int CCH = 8;
+#ifndef RK_CCH
+#define RK_CCH 16         // 8: 75.8 us, 16: 72.2 us, 32: 84.8 us for render_kernel<3> (LDS per block vs barriers per ray)
+#endif
+constexpr int CCH = RK_CCH;
 __host__ __device__ constexpr int render_red_floats(int RPB, int D, int mode) {
     return mode == 1 ? 2 * RPB * 2 * D + RPB * D * 7 : (mode == 2 ? 0 : RPB * D * (CCH + 1));
 }
