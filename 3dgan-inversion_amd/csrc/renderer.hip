@@ -291,6 +291,9 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
 #ifndef RK_VEC_SCAN
 #define RK_VEC_SCAN 1          // batched transmittance scan: 1 = backward kernel only (-1.7 us; the forward kernels measured no gain, render_kernel<3> lost occupancy), 2 = everywhere
 #endif
+#ifndef RK_SORTED_FAST
+#define RK_SORTED_FAST 1
+#endif
 #ifndef RK_VEC_RANK
 #define RK_VEC_RANK 0          // 16-byte reads in the merge's rank loops: measured +5 .. +10 us on render_kernel<3> (104 registers: four waves per SIMD instead of five), off
 #endif
@@ -499,14 +502,29 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
     // ---------------- merge (stable: coarse precedes fine at ties) ----------------
     const int nS = Dc + Df;
     int rank_c = s, rank_f = 0;
+    // position in torch.sort(cat(coarse, fine), stable=True) (renderer.py:212-222).  The stratified depths t_i + u_i * delta are increasing
+    // in exact arithmetic only: u = 1 - 2^-24 next to u = 0 can round the wrong way round, so the coarse list is ranked too, not assumed sorted --
+    // but it is CHECKED sorted first (one compare per thread, one block-wide OR): when every ray of the block has strictly increasing coarse
+    // depths (all but a handful of blocks per million rays) a coarse sample's rank among the coarse ones is its index and a fine sample's is an
+    // upper bound found by bisection: 102 instead of 192 LDS reads per thread, the same integers (test_sampler_indices_exact)
+#if RK_SORTED_FAST
+    const int unsorted = __syncthreads_or((has_c && s + 1 < Dc && !(depth_c < L.dc[s + 1])) ? 1 : 0);
+#else
+    const int unsorted = 1;
+#endif
     if (has_c) {
-        // position in torch.sort(cat(coarse, fine), stable=True) (renderer.py:212-222).  The stratified depths t_i + u_i * delta are increasing
-        // in exact arithmetic only: u = 1 - 2^-24 next to u = 0 can round the wrong way round, so the coarse list is ranked too, not assumed sorted
-        rank_c = count_before(L.dc, Dc, depth_c, 2, s, vec && RK_VEC_RANK) + count_before(L.df, Df, depth_c, 0, 0, vec && RK_VEC_RANK);
+        rank_c = (unsorted ? count_before(L.dc, Dc, depth_c, 2, s, vec && RK_VEC_RANK) : s) + count_before(L.df, Df, depth_c, 0, 0, vec && RK_VEC_RANK);
         L.sd[rank_c] = depth_c; L.ss[rank_c] = sig_c;
     }
     if (has_f) {
-        rank_f = count_before(L.dc, Dc, depth_f, 1, 0, vec && RK_VEC_RANK) + count_before(L.df, Df, depth_f, 2, s, vec && RK_VEC_RANK);
+        int below;
+        if (unsorted) below = count_before(L.dc, Dc, depth_f, 1, 0, vec && RK_VEC_RANK);
+        else {                                      // number of coarse depths <= depth_f (NaN: 0, as the count)
+            int lo = 0, hi = Dc;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (L.dc[mid] <= depth_f) lo = mid + 1; else hi = mid; }
+            below = lo;
+        }
+        rank_f = below + count_before(L.df, Df, depth_f, 2, s, vec && RK_VEC_RANK);
         L.sd[rank_f] = depth_f; L.ss[rank_f] = sig_f;
     }
     if (p.dbg_ranks) {
