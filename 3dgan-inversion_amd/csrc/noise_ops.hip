@@ -250,13 +250,15 @@ __global__ void early_stop_flag_kernel(const float* __restrict__ value, float th
 
 __global__ void __launch_bounds__(NT) adam_step_kernel(const eg3d_adam_list A, float* __restrict__ ws) {
     __shared__ float red[32];
-    if (A.skip != nullptr && *A.skip != 0.f) return;          // (uniform over the grid: nothing is touched, the step count stays)
+    // the three device scalars are read together (one memory round trip in front of the update instead of three in sequence)
+    const float skipv = A.skip != nullptr ? *A.skip : 0.f;
     const float t = *A.step + 1.0f;
+    const float lr = *A.lr;
+    if (skipv != 0.f) return;                                  // (uniform over the grid: nothing is touched, the step count stays)
     int item;
     int64_t start;
     if (adam_locate(A, blockIdx.x, item, start)) {
         const eg3d_adam_item& it = A.items[item];
-        const float lr = *A.lr;
         const float bc1 = 1.0f - powf(A.beta1, t), bc2s = sqrtf(1.0f - powf(A.beta2, t));
         const float step_size = lr / bc1;
         float s = 0.f, q = 0.f;
