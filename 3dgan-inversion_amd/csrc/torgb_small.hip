@@ -53,8 +53,11 @@ __global__ void __launch_bounds__(256) torgb_small_kernel(const eg3d_torgb_small
     // order), and the workgroups of output tile 0 write x for the layers that follow: the 5 - 10 us finishing launch of the 4^2 .. 64^2 blocks is gone
     const bool pre = p.pre_z != nullptr;
     const float* zr = pre ? p.pre_z + ((int64_t)n * HW + (pok ? pix : 0)) * p.ldx + 4 * h : nullptr;
-    const float* dr = pre && p.pre_d != nullptr ? p.pre_d + (int64_t)n * p.C + 4 * h : nullptr;
-    const float* br = pre && p.pre_bias != nullptr ? p.pre_bias + 4 * h : nullptr;
+    // (absent d / bias: the loads still go out -- to the styles, a valid address -- and their values are replaced: a load under a branch is a
+    //  memory round trip of its own, sixteen of them in sequence per batch made the merged launch 8 us slower than the two it replaces)
+    const bool has_d = pre && p.pre_d != nullptr, has_b = pre && p.pre_bias != nullptr;
+    const float* dr = has_d ? p.pre_d + (int64_t)n * p.C + 4 * h : sr;
+    const float* br = has_b ? p.pre_bias + 4 * h : sr;
     float* xw = (pre && blockIdx.y == 0 && pok) ? const_cast<float*>(p.x) + ((int64_t)n * HW + pix) * p.ldx + 4 * h : nullptr;
     float pre_nz = 0.f, pre_amax = 0.f;
     if (pre && pok && p.pre_noise != nullptr) pre_nz = p.pre_noise[(int64_t)n * p.pre_noise_nstride + pix] * *p.pre_strength;
@@ -76,7 +79,7 @@ __global__ void __launch_bounds__(256) torgb_small_kernel(const eg3d_torgb_small
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     for (int g = g0; g < g1; g += TS_BATCH) {
-        float4 xa[TS_BATCH], wb[TS_BATCH], sv[TS_BATCH];
+        float4 xa[TS_BATCH], wb[TS_BATCH], sv[TS_BATCH], dvv[TS_BATCH], bvv[TS_BATCH];
 #pragma unroll
         for (int j = 0; j < TS_BATCH; ++j) {
             const bool ok = g + j < g1;
@@ -84,6 +87,7 @@ __global__ void __launch_bounds__(256) torgb_small_kernel(const eg3d_torgb_small
             xa[j] = (ok && pok) ? *reinterpret_cast<const float4*>((pre ? zr : xr) + kb) : make_float4(0.f, 0.f, 0.f, 0.f);
             wb[j] = ok ? *reinterpret_cast<const float4*>(wr + kb) : make_float4(0.f, 0.f, 0.f, 0.f);
             sv[j] = *reinterpret_cast<const float4*>(sr + kb);
+            if (pre) { dvv[j] = *reinterpret_cast<const float4*>(dr + kb); bvv[j] = *reinterpret_cast<const float4*>(br + kb); }
         }
         if (pre) {
 #pragma unroll
@@ -91,9 +95,9 @@ __global__ void __launch_bounds__(256) torgb_small_kernel(const eg3d_torgb_small
                 const bool ok = g + j < g1;
                 const int kb = (ok ? g + j : g0) * 8;
                 float4 v = xa[j];
-                if (dr != nullptr) { const float4 dv = *reinterpret_cast<const float4*>(dr + kb); v.x *= dv.x; v.y *= dv.y; v.z *= dv.z; v.w *= dv.w; }
+                if (has_d) { const float4 dv = dvv[j]; v.x *= dv.x; v.y *= dv.y; v.z *= dv.z; v.w *= dv.w; }
                 if (p.pre_noise != nullptr) { v.x += pre_nz; v.y += pre_nz; v.z += pre_nz; v.w += pre_nz; }
-                if (br != nullptr) { const float4 bv = *reinterpret_cast<const float4*>(br + kb); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+                if (has_b) { const float4 bv = bvv[j]; v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
                 v.x = eg3d_pwl_fwd(v.x, p.pre_slope) * p.pre_gain; v.y = eg3d_pwl_fwd(v.y, p.pre_slope) * p.pre_gain;
                 v.z = eg3d_pwl_fwd(v.z, p.pre_slope) * p.pre_gain; v.w = eg3d_pwl_fwd(v.w, p.pre_slope) * p.pre_gain;
                 if (p.pre_clamp >= 0.f) {

@@ -1477,10 +1477,11 @@ class PendingEpilogue:
                      bias=self.bias, act=self.act, alpha=self.alpha, gain=self.gain, clamp=self.clamp)
 
 
-# conv1's finishing pass inside the toRGB launch of the 4^2 .. 64^2 blocks (eg3d_torgb_small_params::pre_z): parity-green, five launches fewer per step, and
-# NOT faster -- the merged launch takes 20.2 us where the two took 11.3 + 10.1 (rocprofv3, same session; 218.0 vs 218.3 steps/s): these launches are chains
-# of dependent memory round trips, and merging them does not shorten the chain.  Off by default.
-DEFER_EPILOGUE = os.environ.get('EG3D_DEFER_EPILOGUE', '0') != '0'
+# conv1's finishing pass inside the toRGB launch of the 4^2 .. 64^2 blocks (eg3d_torgb_small_params::pre_z): five launches fewer per step.  The first
+# version was NOT faster (merged launch 17.9 - 18.9 us against 10.0 - 10.9 + 5.5 - 9.1 for the two): its d / bias loads sat under (uniform) null-pointer
+# branches inside the unrolled batch, and a load under a branch is a memory round trip of its own -- sixteen in sequence per batch.  Issued with the
+# operand loads (dummy address when absent) the merged launch is 14.2 - 15.3 us and the step +0.5 % (220.1 vs 219.0 steps/s, A/B).  EG3D_DEFER_EPILOGUE=0: separate pass.
+DEFER_EPILOGUE = os.environ.get('EG3D_DEFER_EPILOGUE', '1') != '0'
 TORGB_SMALL = os.environ.get('EG3D_TORGB_SMALL', '1') != '0'            # low-latency toRGB launch for small pixel counts (csrc/torgb_small.hip)
 TORGB_SMALL_MAX_PIX = int(os.environ.get('EG3D_TORGB_SMALL_MAX_PIX', '4096'))
 # (the data gradient at 64^2 takes 31 us in the trace against 27 for the implicit GEMM it replaced -- yet the step is 0.2 % faster with it: A/B 209.1 vs 208.8)
