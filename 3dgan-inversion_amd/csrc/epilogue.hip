@@ -211,6 +211,19 @@ __global__ void __launch_bounds__(256) upconv_epilogue_kernel(const float* __res
         sp_mul = ue_range_mul(clamp * fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
         if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *sp_scale_out = sp_mul;
     }
+    // the noise values of this thread's eight output pixels are requested here, with phase 1's loads: inside the phase-2 loop each was a load
+    // under a branch followed by its use -- eight memory round trips in sequence per block
+    constexpr int UE_ITEMS = UE_TH * UE_TW * (UE_CH / 4) / 256;
+    const float strength = noise ? *noise_strength : 0.f;
+    float nzv[UE_ITEMS];
+#pragma unroll
+    for (int k = 0; k < UE_ITEMS; ++k) {
+        const int pix = (threadIdx.x >> 4) + k * 16;
+        const int y = y0 + pix / UE_TW, x = x0 + pix % UE_TW;
+        const bool okp = noise != nullptr && y < H && x < W;
+        nzv[k] = (noise != nullptr ? noise : z)[okp ? (int64_t)n * noise_nstride + (int64_t)y * W + x : 0];        // (a valid address either way: no branch around the load)
+        if (!okp) nzv[k] = 0.f;
+    }
     // ---- phase 1
     for (int it = threadIdx.x; it < UE_COLS * (UE_CH / 4); it += 256) {
         const int col = it / (UE_CH / 4), c4 = it - col * (UE_CH / 4);
@@ -234,7 +247,6 @@ __global__ void __launch_bounds__(256) upconv_epilogue_kernel(const float* __res
     }
     __syncthreads();
     // ---- phase 2: item = (row, column, channel quad); a thread keeps its channel quad
-    const float strength = noise ? *noise_strength : 0.f;
     const int c4 = threadIdx.x & 15, c = c0 + c4 * 4;
     float4 dv = make_float4(1.f, 1.f, 1.f, 1.f), bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (d != nullptr) dv = ld4(d + (int64_t)n * C + c);
@@ -255,8 +267,7 @@ __global__ void __launch_bounds__(256) upconv_epilogue_kernel(const float* __res
         v.z = ((a0.z * kk[0] + a1.z * kk[1]) + (a2.z * kk[2] + a3.z * kk[3])) * fir_gain;
         v.w = ((a0.w * kk[0] + a1.w * kk[1]) + (a2.w * kk[2] + a3.w * kk[3])) * fir_gain;
         const bool ok = y < H && x < W;
-        float nz = 0.f;
-        if (ok && noise != nullptr) nz = noise[(int64_t)n * noise_nstride + (int64_t)y * W + x] * strength;
+        const float nz = nzv[k] * strength;
         v.x = act1<true>(v.x * dv.x + nz + bv.x, 0, slope, gain, clamp); v.y = act1<true>(v.y * dv.y + nz + bv.y, 0, slope, gain, clamp);
         v.z = act1<true>(v.z * dv.z + nz + bv.z, 0, slope, gain, clamp); v.w = act1<true>(v.w * dv.w + nz + bv.w, 0, slope, gain, clamp);
         if (ok) {
