@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256) torgb_small_kernel(const eg3d_torgb_small
 // Cp outputs (96: twelve 8-groups, three per wave).
 __global__ void __launch_bounds__(256) torgb_small_bwd_kernel(const eg3d_torgb_small_bwd_params p) {
     __shared__ float red[4][TS_PIX][TS_OUT + 1];
-    __shared__ float col[3][TS_PIX][TS_OUT + 1];          // per-cell terms of the column sums (ds, dbias, dd): summed by 96 threads, no LDS atomics
+    __shared__ float col[4][TS_PIX][TS_OUT + 1];          // per-cell terms of the column sums (ds, dbias, dd, the addend's ds): summed by 128 threads, no LDS atomics
     __shared__ float sc_lds[1];
     const int HW = p.H * p.W;
     const int tiles = (HW + TS_PIX - 1) / TS_PIX;
@@ -173,6 +173,11 @@ __global__ void __launch_bounds__(256) torgb_small_bwd_kernel(const eg3d_torgb_s
     float4 xin4 = make_float4(0.f, 0.f, 0.f, 0.f), a4 = xin4, abd4 = make_float4(1.f, 1.f, 1.f, 1.f), abb4 = xin4;
     float nz = 0.f;
     const float4 s4 = *reinterpret_cast<const float4*>(p.s + (int64_t)n * p.C + eo);
+    // add_scale: the pass-through gradient arrives UNFINISHED -- the split-K sums z of the consumer layer's data gradient -- and its finishing pass
+    // (eg3d_dgrad_finish: dx = z * add_scale[n,c]; add_ds[n,c] += sum_p z x) happens here, on values this launch loads anyway.  (The load goes
+    // out unconditionally, to the styles when absent: no load under a branch.)
+    float4 as4 = *reinterpret_cast<const float4*>((p.add_scale != nullptr ? p.add_scale : p.s) + (int64_t)n * p.C + eo);
+    if (p.add_scale == nullptr) as4 = make_float4(1.f, 1.f, 1.f, 1.f);
     if (ok && p.xin != nullptr) xin4 = *reinterpret_cast<const float4*>(p.xin + off);
     if (ok && p.addend != nullptr) a4 = *reinterpret_cast<const float4*>(p.addend + off);
     if (act_on) {
@@ -206,7 +211,7 @@ __global__ void __launch_bounds__(256) torgb_small_bwd_kernel(const eg3d_torgb_s
     eg3d_act_bwd_consts abc = {};
     if (act_on) abc = eg3d_act_bwd_setup(ab);
     float omax = 0.f;
-    float4 t_ds = make_float4(0.f, 0.f, 0.f, 0.f), t_db = t_ds, t_dq = t_ds;
+    float4 t_ds = make_float4(0.f, 0.f, 0.f, 0.f), t_db = t_ds, t_dq = t_ds, t_da = t_ds;
     if (ok) {
         float4 v;
         v.x = (red[0][er][eq * 4 + 0] + red[1][er][eq * 4 + 0]) + (red[2][er][eq * 4 + 0] + red[3][er][eq * 4 + 0]);
@@ -214,6 +219,8 @@ __global__ void __launch_bounds__(256) torgb_small_bwd_kernel(const eg3d_torgb_s
         v.z = (red[0][er][eq * 4 + 2] + red[1][er][eq * 4 + 2]) + (red[2][er][eq * 4 + 2] + red[3][er][eq * 4 + 2]);
         v.w = (red[0][er][eq * 4 + 3] + red[1][er][eq * 4 + 3]) + (red[2][er][eq * 4 + 3] + red[3][er][eq * 4 + 3]);
         if (p.ds != nullptr) t_ds = make_float4(v.x * xin4.x, v.y * xin4.y, v.z * xin4.z, v.w * xin4.w);
+        if (p.add_ds != nullptr) t_da = make_float4(a4.x * xin4.x, a4.y * xin4.y, a4.z * xin4.z, a4.w * xin4.w);
+        a4 = make_float4(a4.x * as4.x, a4.y * as4.y, a4.z * as4.z, a4.w * as4.w);
         v = make_float4(v.x * s4.x + a4.x, v.y * s4.y + a4.y, v.z * s4.z + a4.z, v.w * s4.w + a4.w);
         if (act_on) {
             float4 accb4 = make_float4(0.f, 0.f, 0.f, 0.f), accd4 = accb4;
@@ -235,15 +242,17 @@ __global__ void __launch_bounds__(256) torgb_small_bwd_kernel(const eg3d_torgb_s
     col[0][er][eq * 4 + 0] = t_ds.x; col[0][er][eq * 4 + 1] = t_ds.y; col[0][er][eq * 4 + 2] = t_ds.z; col[0][er][eq * 4 + 3] = t_ds.w;
     col[1][er][eq * 4 + 0] = t_db.x; col[1][er][eq * 4 + 1] = t_db.y; col[1][er][eq * 4 + 2] = t_db.z; col[1][er][eq * 4 + 3] = t_db.w;
     col[2][er][eq * 4 + 0] = t_dq.x; col[2][er][eq * 4 + 1] = t_dq.y; col[2][er][eq * 4 + 2] = t_dq.z; col[2][er][eq * 4 + 3] = t_dq.w;
+    col[3][er][eq * 4 + 0] = t_da.x; col[3][er][eq * 4 + 1] = t_da.y; col[3][er][eq * 4 + 2] = t_da.z; col[3][er][eq * 4 + 3] = t_da.w;
     __syncthreads();
-    if (threadIdx.x < 3 * TS_OUT) {          // thread = (which sum, column): 32 conflict-free LDS reads, then one global atomic
+    if (threadIdx.x < 4 * TS_OUT) {          // thread = (which sum, column): 32 conflict-free LDS reads, then one global atomic
         const int a = threadIdx.x / TS_OUT, cc = threadIdx.x - a * TS_OUT, c = c0 + cc;
-        const bool want = a == 0 ? p.ds != nullptr : (act_on && (a == 1 ? ab.dbias != nullptr : ab.dd != nullptr));
+        const bool want = a == 0 ? p.ds != nullptr : (a == 3 ? p.add_ds != nullptr : (act_on && (a == 1 ? ab.dbias != nullptr : ab.dd != nullptr)));
         if (want) {
             float sum = 0.f;
 #pragma unroll 8
             for (int r = 0; r < TS_PIX; ++r) sum += col[a][r][cc];
             if (a == 0) eg3d_acc(p.ds + (int64_t)n * p.C + c, sum);
+            else if (a == 3) eg3d_acc(p.add_ds + (int64_t)n * p.C + c, sum);
             else if (a == 1) eg3d_acc(ab.dbias + c, sum);
             else eg3d_acc(ab.dd + (int64_t)n * p.C + c, sum / (ab.d != nullptr ? ab.d[(int64_t)n * p.C + c] : 1.f));      // dL/dd = sum dy * z,  z = (pre - bias - noise) / d
         }
@@ -280,7 +289,8 @@ extern "C" int eg3d_torgb_small_bwd_supported(const eg3d_torgb_small_bwd_params*
     if (p->N < 1 || p->H < 1 || p->W < 1 || p->Cp < 8 || (p->Cp & 7) || p->C < TS_OUT || (p->C % TS_OUT)) return 0;
     if ((p->ldg & 3) || p->ldg < p->Cp || (p->ldx & 3) || p->ldx < p->C || (p->wa_row & 3) || p->wa_row < p->Cp) return 0;
     if (!al16(p->dy) || !al16(p->wa) || !al16(p->s) || !al16(p->dx) || (p->xin && !al16(p->xin)) || (p->addend && !al16(p->addend))) return 0;
-    if ((p->ds || p->act_on) && !p->xin) return 0;
+    if ((p->ds || p->act_on || p->add_ds) && !p->xin) return 0;
+    if ((p->add_scale || p->add_ds) && (!p->addend || !p->add_scale || !al16(p->add_scale))) return 0;
     if (p->act_on) {
         const eg3d_act_bwd& ab = p->act_bwd;
         if (ab.act != EG3D_ACT_LINEAR && ab.act != EG3D_ACT_LRELU) return 0;          // invertible piecewise-linear activations only
@@ -297,6 +307,7 @@ extern "C" int eg3d_torgb_small_bwd(const eg3d_torgb_small_bwd_params* p, void* 
     const dim3 grid(p->N * eg3d_cdiv((int64_t)p->H * p->W, TS_PIX), p->C / TS_OUT);
     EG3D_DET_SCOPE(det, stream);
     EG3D_DET_BIND(det, p->ds, (int64_t)p->N * p->C);
+    EG3D_DET_BIND(det, p->add_ds, (int64_t)p->N * p->C);
     if (p->act_on) { EG3D_DET_BIND_ACT(det, p->act_bwd, p->N, p->C, (int64_t)p->H * p->W); }
     EG3D_DET_COMMIT(det);
     hipLaunchKernelGGL(torgb_small_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p);

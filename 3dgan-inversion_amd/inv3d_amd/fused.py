@@ -260,6 +260,19 @@ def _act_bwd_for(x, dev):
     return rec, spec, acc
 
 
+# Unfinished split-K data gradients on their way to a toRGB node (hipops.DEFER_DGRAD_FINISH): key = data_ptr of the tensor both nodes know (the
+# conv's input x = the toRGB node's x), value = (z, styles, ds).  Written by ModConvLayerFn.backward, consumed by the ToRGBFn.backward that runs next in
+# the same backward pass; that node finishes the gradient inside its own launch -- or with eg3d_dgrad_finish when it cannot.
+PENDING_DGRAD = {}
+
+
+def _finish_pending(pend, x):
+    z, s0, ds0 = pend
+    fin = H.empty_cl(*x.shape, x.device)
+    H.dgrad_finish(z, x, s0, fin, ds=ds0)
+    return fin
+
+
 class ModConvLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, styles, noise, noise_strength, bias, up, act_gain, clamp, cache, want_wgrad, d_in=None, single_consumer=False,
@@ -271,6 +284,7 @@ class ModConvLayerFn(torch.autograd.Function):
         # x: CL [N,Ci,H,W]; weight [Co,Ci,3,3]; styles [N,Ci]; noise None | [res,res] | [N,1,res,res]; noise_strength 0-d
         # d_in: the demodulation coefficients [N,Co] when the style bank already computed them (their gradient is then returned)
         L.require_cuda(x, weight, styles)
+        from_torgb = bool(getattr(x, '_eg3d_from_torgb', False)) and H.is_cl(x) and x.dtype == torch.float32      # x is a toRGB node's pass-through output (SynthesisBlock.forward)
         x = H.to_cl(x.float())
         styles = styles.contiguous().float()
         N, Ci, Hi, Wi = x.shape
@@ -405,6 +419,7 @@ class ModConvLayerFn(torch.autograd.Function):
         # both ends opt in: the producer promises a single consumer, the consumer that its x is that producer's output handed over directly
         # (NOT the copy routed through a toRGB node: that gradient is summed inside the toRGB data gradient, which is the fusing launch then)
         ctx.fuse_input = bool(input_is_layer_output)
+        ctx.from_torgb = from_torgb
         return out
 
     @staticmethod
@@ -516,6 +531,9 @@ class ModConvLayerFn(torch.autograd.Function):
                 did = prod is not None and Ci % 4 == 0 and Ci <= 1024
                 if did:
                     H.dgrad_finish_act(z, x, styles, dx, spec, ds=ds, dz_amax=pacc[4])
+                elif ctx.from_torgb and H.DEFER_DGRAD_FINISH and need_x and prod is None:
+                    PENDING_DGRAD[x.data_ptr()] = (z, styles, ds)         # the toRGB node that receives this gradient next finishes it in its launch
+                    dx = z
                 else:
                     H.dgrad_finish(z, x, styles, dx, ds=ds)
             elif ks == 1:
@@ -530,6 +548,9 @@ class ModConvLayerFn(torch.autograd.Function):
                 did = prod is not None and Ci % 4 == 0 and Ci <= 1024
                 if did:
                     H.dgrad_finish_act(z, x, styles, dx, spec, ds=ds, dz_amax=pacc[4])
+                elif ctx.from_torgb and H.DEFER_DGRAD_FINISH and need_x and prod is None:
+                    PENDING_DGRAD[x.data_ptr()] = (z, styles, ds)         # the toRGB node that receives this gradient next finishes it in its launch
+                    dx = z
                 else:
                     H.dgrad_finish(z, x, styles, dx, ds=ds)
             if prod is not None and did is True:
@@ -680,6 +701,7 @@ class ToRGBFn(torch.autograd.Function):
         gradient through THIS backward, where it is added inside the data-gradient epilogue instead of by a separate autograd add
         (3 x tensor bytes per block, 67 MB tensors in the SR head)."""
         L.require_cuda(x, weight, styles)
+        PENDING_DGRAD.clear()            # (entries live inside one backward pass; anything left over belongs to a pass that was abandoned)
         pend = x.__dict__.pop('_eg3d_pending_epi', None) if hasattr(x, '__dict__') else None      # the producing layer's finishing pass is still due (ModConvLayerFn defer_epilogue)
         if pend is not None and not (H.is_cl(x) and x.dtype == torch.float32 and pend.out is x):
             pend.run()
@@ -781,13 +803,22 @@ class ToRGBFn(torch.autograd.Function):
             H.epilogue_bwd(dout, y if y is not None else dout, dy, act='linear', gain=1.0, clamp=clampv, dbias=dbias_p, dz_amax=dy_amax)
             dbias = dbias_p[:Co] if need_b else None
         dx = ds = None
+        pdg = PENDING_DGRAD.pop(x.data_ptr(), None)          # the pass-through gradient is an unfinished split-K sum (ModConvLayerFn.backward)
+        if pdg is not None and (dx_pass is None or dx_pass.data_ptr() != pdg[0].data_ptr() or tuple(dx_pass.shape) != tuple(x.shape)):
+            raise RuntimeError('ToRGBFn.backward: a deferred data-gradient finish is pending for this input but the gradient that arrived is another tensor '
+                               '(set EG3D_DEFER_DGRAD_FINISH=0 and report the configuration)')
         if need_x or need_s:
             wa_p = cache.get(weight)[1] if Cp == Co else cache.get_padded(weight, Cp)[1]    # contraction dim (output channels) padded to 4
             dx = H.empty_cl(N, Ci, Hh, Ww, dev)
             ds = H.zeros((N, Ci), dev)
+            small_ok = H.TORGB_SMALL and N * Hh * Ww <= H.TORGB_SMALL_BWD_MAX_PIX and Ci % 32 == 0 and Cp % 8 == 0 and wa_p.stride(1) == 1
+            if pdg is not None and not (small_ok and H.is_cl(dx_pass) and dx_pass.dtype == torch.float32):
+                dx_pass, pdg = _finish_pending(pdg, x), None
             add = H.to_cl(dx_pass.float()) if dx_pass is not None else None
             prod, spec, pacc = _act_bwd_for(x, dev) if (need_x and ctx.fuse_input) else (None, None, None)      # x = conv1's output: run its activation backward here
             fkw = dict(act_bwd=spec, out_amax=pacc[4]) if prod is not None else {}
+            if pdg is not None and prod is not None and Cp == 4 and Ci % 4 == 0 and Ci <= 1024 and TORGB4_ELEMENTWISE:
+                add, pdg = _finish_pending(pdg, x), None
             if prod is not None and Cp == 4 and Ci % 4 == 0 and Ci <= 1024 and TORGB4_ELEMENTWISE:
                 # four outputs (the SR head's toRGB): the data gradient is four multiply-adds per element -- one element-wise pass with the
                 # producing layer's activation backward instead of a GEMM launch with a 4-deep contraction (105 -> 60 us at 512^2 x 128)
@@ -810,14 +841,17 @@ class ToRGBFn(torch.autograd.Function):
                 did = None
                 if H.TORGB_SMALL and N * Hh * Ww <= H.TORGB_SMALL_BWD_MAX_PIX and Ci % 32 == 0 and Cp % 8 == 0 and wa_p.stride(1) == 1:
                     # small pixel counts: the low-latency launch (csrc/torgb_small.hip), same epilogue as the implicit GEMM's
-                    did = H.torgb_small_bwd(dy, wa_p, styles, x, dx, ds=ds, addend=add, **fkw)
+                    did = H.torgb_small_bwd(dy, wa_p, styles, x, dx, ds=ds, addend=add, **fkw,
+                                            **(dict(addend_scale=pdg[1], addend_ds=pdg[2]) if pdg is not None else {}))
+                if did is None and pdg is not None:
+                    add, pdg = _finish_pending(pdg, x), None
                 if did is None:
                     did = H.conv_igemm(dy, wa_p, Cp, Ci, dx, H.classes_corr_adjoint(Hh, Ww, 1, 1, 0), epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, addend=add,
                                        **fkw)
             if prod is not None and did is True:
                 prod.fused = (dx,) + tuple(pacc)
         elif dx_pass is not None:
-            dx = dx_pass
+            dx = _finish_pending(pdg, x) if pdg is not None else dx_pass
         dweight = None
         if need_w:
             dwp = H.zeros((Co, Ci), dev)

@@ -1482,6 +1482,10 @@ class PendingEpilogue:
 # branches inside the unrolled batch, and a load under a branch is a memory round trip of its own -- sixteen in sequence per batch.  Issued with the
 # operand loads (dummy address when absent) the merged launch is 14.2 - 15.3 us and the step +0.5 % (220.1 vs 219.0 steps/s, A/B).  EG3D_DEFER_EPILOGUE=0: separate pass.
 DEFER_EPILOGUE = os.environ.get('EG3D_DEFER_EPILOGUE', '1') != '0'
+# the mirror image in the backward pass: conv0's split-K data gradient goes to the previous block's toRGB node unfinished (fused.PENDING_DGRAD) and that
+# node's launch applies the styles and accumulates the style gradient (eg3d_torgb_small_bwd_params::add_scale): the dgrad_finish launch of the 8^2 .. 64^2 blocks is gone
+DEFER_DGRAD_FINISH = os.environ.get('EG3D_DEFER_DGRAD_FINISH', '1') != '0'
+
 TORGB_SMALL = os.environ.get('EG3D_TORGB_SMALL', '1') != '0'            # low-latency toRGB launch for small pixel counts (csrc/torgb_small.hip)
 TORGB_SMALL_MAX_PIX = int(os.environ.get('EG3D_TORGB_SMALL_MAX_PIX', '4096'))
 # (the data gradient at 64^2 takes 31 us in the trace against 27 for the implicit GEMM it replaced -- yet the step is 0.2 % faster with it: A/B 209.1 vs 208.8)
@@ -1513,7 +1517,7 @@ def torgb_small(x, wf, styles, out, bias=None, clamp=-1.0, addend=None, addend_u
     return True
 
 
-def torgb_small_bwd(dy, wa, styles, x, dx, ds=None, addend=None, act_bwd=None, out_amax=None):
+def torgb_small_bwd(dy, wa, styles, x, dx, ds=None, addend=None, act_bwd=None, out_amax=None, addend_scale=None, addend_ds=None):
     """eg3d_torgb_small_bwd: the toRGB data gradient for small pixel counts (+ the producing layer's activation backward when act_bwd is an
     ActBwdSpec the kernel takes).  Returns None when nothing was launched (geometry not the kernel's), else True / False = the activation
     backward was / was not fused (as conv_igemm)."""
@@ -1522,6 +1526,8 @@ def torgb_small_bwd(dy, wa, styles, x, dx, ds=None, addend=None, act_bwd=None, o
     p = L.TorgbSmallBwdParams(dy=dy.data_ptr(), wa=wa.data_ptr(), s=styles.data_ptr(), xin=x.data_ptr(), addend=addend.data_ptr() if addend is not None else None,
                               dx=dx.data_ptr(), ds=ds.data_ptr() if ds is not None else None, out_amax=out_amax.data_ptr() if out_amax is not None else None,
                               N=n, H=h, W=w, C=c, Cp=dy.shape[1], ldg=dy.shape[1], ldx=c, wa_row=wa.stride(0), act_on=0)
+    if addend_scale is not None:          # the addend is an unfinished split-K data gradient: finish it in this launch (PendingDgrad)
+        p.add_scale, p.add_ds = addend_scale.data_ptr(), addend_ds.data_ptr() if addend_ds is not None else None
     fused = False
     if act_bwd is not None:
         p.act_on = 1

@@ -261,6 +261,7 @@ class SynthesisBlock(ReferenceStateMixin, torch.nn.Module):
             img, x = self.torgb(x, next(w_iter), skip=img, styles=next(s_iter), passthrough=True, input_is_layer_output=True, skip_up=skip_up)
             if amax is not None:        # the pass-through output is the same values: keep the producer's max|x| report with it
                 H.tag_amax(x, amax)
+            x._eg3d_from_torgb = True       # (the next block's conv0 may leave the finish of its split-K data gradient to this node's backward launch)
         return x, img
 
 

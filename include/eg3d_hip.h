@@ -631,6 +631,10 @@ typedef struct eg3d_torgb_small_bwd_params {
     int32_t ldg, ldx, wa_row;
     int32_t act_on, pad_;
     eg3d_act_bwd act_bwd;
+    /* optional (both or neither; needs addend and xin): the addend is the UNFINISHED split-K data gradient z of the layer that consumes x next
+     * (eg3d_dgrad_finish not run): this launch adds z * add_scale[n,c] and accumulates add_ds[n,c] += sum_p z[n,p,c] xin[n,p,c] (pre-zeroed). */
+    const float* add_scale;
+    float* add_ds;
 } eg3d_torgb_small_bwd_params;
 int eg3d_torgb_small_bwd_supported(const eg3d_torgb_small_bwd_params* p);
 int eg3d_torgb_small_bwd(const eg3d_torgb_small_bwd_params* p, void* stream);

@@ -342,11 +342,13 @@ def test_generator_with_the_128px_head():
     close(dws, dws_r, 2e-3, '2X generator d ws')
 
 
-def test_deferred_finishing_epilogue_equals_the_separate_pass():
-    """hipops.DEFER_EPILOGUE (opt-in): conv1's split-K finishing pass run inside the toRGB launch of the 4^2 .. 64^2 blocks
-    (eg3d_torgb_small_params::pre_z; the layer output is written by that launch).  Full-size generator (the split-K layers only exist there):
-    the image equals that of the separate eg3d_modconv_epilogue_fwd launch to rounding of the atomically accumulated split-K sums, the latent
-    gradient to 1e-5 of its scale."""
+@pytest.mark.parametrize('switch', ['DEFER_EPILOGUE', 'DEFER_DGRAD_FINISH'])
+def test_deferred_finishing_passes_equal_the_separate_launches(switch):
+    """hipops.DEFER_EPILOGUE: conv1's split-K finishing pass run inside the toRGB launch of the 4^2 .. 64^2 blocks (eg3d_torgb_small_params::pre_z;
+    the layer output is written by that launch).  hipops.DEFER_DGRAD_FINISH: conv0's split-K data gradient finished (styles, style gradient) inside
+    the previous block's toRGB backward launch (eg3d_torgb_small_bwd_params::add_scale).  Full-size generator (the split-K layers only exist
+    there): image and latent gradient equal those of the separate eg3d_modconv_epilogue_fwd / eg3d_dgrad_finish launches up to the rounding of the
+    atomically accumulated sums."""
     from inv3d_amd import hipops as H, synthetic as S
     G = S.make_generator(device=DEV)
     S.load_synthetic_weights(G)
@@ -356,16 +358,16 @@ def test_deferred_finishing_epilogue_equals_the_separate_pass():
     cam = S.synth_cameras(1).to(DEV)
     u1, u2 = S.make_uniforms(1, 128 * 128, 48, 48)
     res = {}
-    keep = H.DEFER_EPILOGUE
+    keep = getattr(H, switch)
     try:
         for mode in (False, True):
-            H.DEFER_EPILOGUE = mode
+            setattr(H, switch, mode)
             ws = ws0.clone().requires_grad_(True)
             out = G.synthesis(ws, cam, noise_mode='const', force_fp32=True, render_uniforms=(u1.to(DEV), u2.to(DEV)))
             out['image'].square().sum().backward()
             res[mode] = (out['image'].detach().clone(), ws.grad.clone())
     finally:
-        H.DEFER_EPILOGUE = keep
+        setattr(H, switch, keep)
     scale = float(res[False][0].abs().max())
     assert float((res[False][0] - res[True][0]).abs().max()) <= 2e-5 * scale
     g0, g1 = res[False][1], res[True][1]
