@@ -229,6 +229,8 @@ _SIGS = {
     'eg3d_conv2d_wgrad_batched': (C.c_int, [C.POINTER(WgradParams), C.c_int, C.c_void_p]),
     'eg3d_conv2d_v2_supported': (C.c_int, [C.POINTER(ConvV2Params)]),
     'eg3d_conv2d_v2': (C.c_int, [C.POINTER(ConvV2Params), C.c_void_p]),
+    'eg3d_conv2d_v3_supported': (C.c_int, [C.POINTER(ConvV2Params)]),
+    'eg3d_conv2d_v3': (C.c_int, [C.POINTER(ConvV2Params), C.c_void_p]),
     'eg3d_conv2d_wgrad_v2_supported': (C.c_int, [C.POINTER(WgradV2Params)]),
     'eg3d_conv2d_wgrad_v2': (C.c_int, [C.POINTER(WgradV2Params), C.c_void_p]),
     'eg3d_conv2d_wgrad_v2_slabs': (C.c_int, [C.POINTER(WgradV2Params)]),

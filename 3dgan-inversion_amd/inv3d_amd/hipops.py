@@ -698,6 +698,70 @@ def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_
     return fused_act if act_bwd is not None else out
 
 
+# ------------------------------------------------------------------------------------------------- wave-split pre-split convolution (csrc/conv_v3.hip)
+V3_CONFIG = 11       # profiler id of conv_v3_kernel
+USE_V3 = os.environ.get('EG3D_CONV_V3', '1') != '0'
+V3_MAX_TILES8 = int(os.environ.get('EG3D_V3_MAX_TILES8', '256'))       # 256-cell x 128-channel tiles below which a 3x3 launch goes to the wave-split kernel
+V3_MIN_CELLS = int(os.environ.get('EG3D_V3_MIN_CELLS', '1024'))        # class grids (all images) from this many cells (32^2) -- below, launches are latency-bound
+
+
+def conv_v3_plan(Ck, Nc, classes, N=1):
+    """(patch_rows, waves) for eg3d_conv2d_v3, or None when the launch is not one for it: nine-tap stride-1 classes whose 256 x 128 tiling
+    leaves the chip under-filled.  128-cell tiles with the contraction over four waves when they give >= 192 workgroups, else 64-cell tiles
+    over eight waves (twice the workgroups, half the steps per wave)."""
+    if not USE_V3 or CONV_MODE != 'auto' or Ck % 16 or Nc % 64 or not (1 <= len(classes) <= 4):
+        return None
+    for c in classes:
+        if c.ntaps != 9:
+            return None
+        dys, dxs = [c.dy[t] for t in range(9)], [c.dx[t] for t in range(9)]
+        if max(dys) - min(dys) > 2 or max(dxs) - min(dxs) > 2:
+            return None
+    cells = sum(N * c.Ha * c.Wa for c in classes)
+    tiles8 = sum(N * -(-c.Ha // 8) * -(-c.Wa // 32) for c in classes) * -(-Nc // 128)
+    if cells < V3_MIN_CELLS or tiles8 >= V3_MAX_TILES8:
+        return None
+    wg4 = sum(N * -(-c.Ha // 4) * -(-c.Wa // 32) for c in classes) * (Nc // 64)
+    return (4, 4) if wg4 >= 192 else (2, 8)
+
+
+def conv_v3(a: SplitImage, w: SplitImage, out, classes, plan=None, out_stride=1, epi=L.EPI_STORE, out_scale=None, bias=None, noise=None, noise_nstride=0,
+            noise_strength=None, act='linear', alpha=0.0, gain=1.0, clamp=-1.0, addend=None, xin=None, ds=None, out_amax=None, algo_flops=None,
+            act_bwd=None, products=3):
+    """Launch eg3d_conv2d_v3 (operands as for conv_v2).  plan = (patch_rows, waves).  act_bwd (ActBwdSpec, with epi=EPI_BWD): EPI_BWD_ACT when the
+    kernel takes it -- returns True if the fused epilogue ran, False for a plain EPI_BWD."""
+    assert is_cl(out)
+    p = _conv_v2_params(a, w, out, classes, out_stride, epi, out_scale, bias, noise, noise_nstride, noise_strength, act, alpha, gain, clamp,
+                        addend, xin, ds, out_amax)
+    rows, waves = plan if plan is not None else (4, 4)
+    p.products, p.patch_rows, p.ksplit = int(products), int(rows), int(waves)
+    fused_act = False
+    if act_bwd is not None and epi == L.EPI_BWD and xin is not None:
+        p.epi = L.EPI_BWD_ACT
+        act_bwd.fill(p.act_bwd)
+        fused_act = bool(L.lib().eg3d_conv2d_v3_supported(C.byref(p))) and all(
+            t is None or t.data_ptr() % 16 == 0 for t in (act_bwd.d, act_bwd.bias))
+        if not fused_act:
+            p.epi = L.EPI_BWD
+            p.act_bwd = L.ActBwd()
+    prof = PROFILER
+    if prof is not None and prof.only_config is not None and prof.only_config != V3_CONFIG:
+        prof = None
+    if prof is not None:
+        if algo_flops is None:
+            algo_flops = 2.0 * p.Ck * p.Nc * sum(p.N * c.Ha * c.Wa * c.ntaps for c in classes)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    L.check(L.lib().eg3d_conv2d_v3(C.byref(p), L.stream_ptr()), 'conv2d_v3')
+    if prof is not None:
+        e1.record()
+        prof.records.append(((V3_CONFIG, PRECISIONS['f16x3']), float(algo_flops), e0, e1))
+        if prof.meta is not None:
+            prof.meta.append(dict(N=p.N, Hi=p.Hi, Wi=p.Wi, Ck=p.Ck, Nc=p.Nc, Ho=p.Ho, Wo=p.Wo, taps=[c.ntaps for c in classes], epi=epi, ksplit=int(waves),
+                                  in_stride=1, out_stride=out_stride, prec=3, v3=True, patch_rows=int(rows)))
+    return fused_act if act_bwd is not None else out
+
+
 def fir44_adjoint_split(dz, dz_amax, gain=4.0):
     """FIR adjoint of an up layer + operand split in one pass (eg3d_fir44_adjoint_split): dz [N,C,2Hi,2Wi] channels_last ->
     SplitImage of the four parity images of G = upfirdn2d(dz, [1,3,3,1]^2 / 64, pad 2, gain), shape (N, C, Hi + 1, Wi + 1) per parity."""

@@ -232,6 +232,15 @@ typedef struct eg3d_conv_v2_params {
 } eg3d_conv_v2_params;
 int eg3d_conv2d_v2_supported(const eg3d_conv_v2_params* p);
 int eg3d_conv2d_v2(const eg3d_conv_v2_params* p, void* stream);
+/* Wave-split form of that convolution (csrc/conv_v3.hip) for the nine-tap layers whose grids cannot fill the chip with 256-cell x 128-channel
+ * tiles (64^2 x 512, 32^2 x 512, and the 128^2 / 256^2 backbone layers at one image per GPU; training/networks_stylegan2.py:34-91,417-461): same
+ * operand images, contract and epilogues (STORE / FWD / BWD / BWD_ACT) as eg3d_conv2d_v2, but a workgroup tile is r x 32 cells x 64 channels
+ * (r = p->patch_rows: 0 / 4 | 2) and the contraction is split over the w waves of the workgroup (w = p->ksplit: 0 / 4 | 8; 8 only with r = 2)
+ * and summed in LDS in wave order -- no atomics, zero fill, slabs or finishing pass; run-to-run deterministic.  The waves share nothing in the
+ * main loop (private LDS halo per wave by LDS-DMA, weight fragments straight from global memory into registers): no barrier in it.
+ * Restrictions (eg3d_conv2d_v3_supported): Ck % 16 == 0, Nc % 64 == 0, in_stride 1, nine-tap classes spanning at most 3 x 3. */
+int eg3d_conv2d_v3_supported(const eg3d_conv_v2_params* p);
+int eg3d_conv2d_v3(const eg3d_conv_v2_params* p, void* stream);
 /* Low-resolution form of that convolution (csrc/conv_lr.hip) for the layers whose grids cannot fill the chip with 256-cell tiles (the
  * 4^2 .. 64^2 blocks of the backbone at one image per GPU; training/networks_stylegan2.py:417-461): same contract, epilogues
  * (STORE / FWD / BWD / BWD_ACT) and W image as eg3d_conv2d_v2, but

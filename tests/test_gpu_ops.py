@@ -1053,6 +1053,94 @@ def test_conv_v2_half_patch_full_size():
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
+# Wave-split pre-split convolution (csrc/conv_v3.hip): 128 / 64-cell x 64-channel tiles, contraction over the waves of the workgroup
+# ---------------------------------------------------------------------------------------------------------------------------
+V3_PLANS = [(4, 4), (2, 4), (2, 8)]
+
+
+@pytest.mark.parametrize('plan', V3_PLANS)
+@pytest.mark.parametrize('shape', [(1, 32, 16, 64, 128), (2, 64, 40, 72, 64), (1, 128, 33, 37, 192), (1, 16, 8, 32, 64), (1, 512, 32, 32, 128), (1, 80, 9, 33, 64)])
+def test_conv_v3_forward_epilogue_vs_torch(shape, plan):
+    """3x3 correlation with the fused forward epilogue on ragged grids, batch 2, 1 - 3 channel tiles of 64, chunk counts below / not a multiple of
+    the number of waves (16, 80 and 32 channels over 4 / 8 waves: some waves own no chunk), max|out| reported; every tile / wave configuration."""
+    from inv3d_amd import hipops as H, _lib as L
+    n, ci, h, w, co = shape
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)
+    s = 1 + 0.5 * torch.randn(n, ci, generator=g)
+    d = 0.5 + torch.rand(n, co, generator=g)
+    noise, strength = torch.randn(n, 1, h, w, generator=g), torch.tensor(0.3)
+    bias, add = 0.1 * torch.randn(co, generator=g), torch.randn(n, co, h, w, generator=g)
+    z = torch.nn.functional.conv2d(x.double() * s.double()[:, :, None, None], wt.double(), padding=1) * d.double()[:, :, None, None]
+    ref = torch.nn.functional.leaky_relu(z + noise.double() * 0.3 + bias.double()[None, :, None, None], 0.2) * 1.4 + add.double()
+    xc, aimg, wimg = _v2_operands(x, wt, s)
+    out = H.empty_cl(n, co, h, w, DEV)
+    amax = torch.zeros(1, device=DEV)
+    H.conv_v3(aimg, wimg, out, H.classes_corr(h, w, 3, 3, 1), plan=plan, epi=L.EPI_FWD, out_scale=d.to(DEV), bias=bias.to(DEV), noise=noise.to(DEV).contiguous(),
+              noise_nstride=h * w, noise_strength=strength.to(DEV), act='lrelu', alpha=0.2, gain=1.4, clamp=-1.0,
+              addend=add.to(DEV).contiguous(memory_format=torch.channels_last), out_amax=amax)
+    close(out, ref.float(), 2e-5, f'conv_v3 fwd {shape} {plan}')
+    assert abs(float(amax) - float(out.abs().max())) == 0.0
+
+
+@pytest.mark.parametrize('plan', V3_PLANS)
+@pytest.mark.parametrize('products', [3, 1])
+def test_conv_v3_data_gradient_epilogue_vs_torch(plan, products):
+    """Data gradient of a 3x3 layer: adjoint taps on the adjoint weight image, gradient-sized operand, dx = acc * styles + addend,
+    ds = sum_px acc * x; three-product and single-product (fp16-operand) arithmetic."""
+    from inv3d_amd import hipops as H, _lib as L
+    n, ci, h, w, co = 2, 128, 24, 40, 96
+    g = torch.Generator().manual_seed(42)
+    gz = torch.randn(n, co, h, w, generator=g) * 1e-4
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)
+    s, xin, add = 1 + 0.5 * torch.randn(n, ci, generator=g), torch.randn(n, ci, h, w, generator=g), torch.randn(n, ci, h, w, generator=g) * 1e-4
+    acc = torch.nn.functional.conv_transpose2d(gz.double(), wt.double(), padding=1)
+    ref_dx = acc * s.double()[:, :, None, None] + add.double()
+    ref_ds = (acc * xin.double()).sum((2, 3))
+    gc, aimg, wimg = _v2_operands(gz, wt, None, adjoint=True)
+    dx, ds = H.empty_cl(n, ci, h, w, DEV), torch.zeros(n, ci, device=DEV)
+    H.conv_v3(aimg, wimg, dx, H.classes_corr_adjoint(h, w, 3, 3, 1), plan=plan, epi=L.EPI_BWD, out_scale=s.to(DEV),
+              xin=xin.to(DEV).contiguous(memory_format=torch.channels_last), ds=ds, addend=add.to(DEV).contiguous(memory_format=torch.channels_last), products=products)
+    tol = 2e-5 if products == 3 else 2e-3
+    close(dx * 1e4, ref_dx.float() * 1e4, tol, 'conv_v3 dgrad dx')
+    close(ds * 1e4, ref_ds.float() * 1e4, tol * 2.5, 'conv_v3 dgrad ds')
+
+
+def test_conv_v3_full_size_layers_deterministic_and_equal_to_conv_v2():
+    """The backbone layers the kernel exists for (64^2 x 512 -> 512 and 128^2 x 256 -> 256 at one image) with the fused forward epilogue:
+    against fp64, against the pre-split kernel (same products, different summation order: fp32 rounding apart) and bit-identical from
+    launch to launch (the K slices of the waves are summed in wave order)."""
+    from inv3d_amd import hipops as H, _lib as L
+    for (n, ci, h, co) in ((1, 512, 64, 512), (1, 256, 128, 256)):
+        w = h
+        g = torch.Generator().manual_seed(43)
+        x = torch.randn(n, ci, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+        wt = (torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)).to(DEV)
+        s = (1 + 0.5 * torch.randn(n, ci, generator=g)).to(DEV)
+        d = (0.5 + torch.rand(n, co, generator=g)).to(DEV)
+        noise, strength = torch.randn(h, w, generator=g).to(DEV), torch.tensor(0.3, device=DEV)
+        bias = (0.1 * torch.randn(co, generator=g)).to(DEV)
+        aimg = H.split_activation(x, H.absmax(x), in_scale=s)
+        wimg = H.split_weight(H.pack_weight_fwd(wt), co, ci, 9)
+        cls = H.classes_corr(h, w, 3, 3, 1)
+        z = torch.nn.functional.conv2d(x.double() * s.double()[:, :, None, None], wt.double(), padding=1) * d.double()[:, :, None, None]
+        ref = (torch.nn.functional.leaky_relu(z + noise.double() * 0.3 + bias.double()[None, :, None, None], 0.2) * 1.4).float()
+        kw = dict(epi=L.EPI_FWD, out_scale=d, bias=bias, noise=noise, noise_nstride=0, noise_strength=strength, act='lrelu', alpha=0.2, gain=1.4, clamp=-1.0)
+        o2 = H.empty_cl(n, co, h, w, DEV)
+        H.conv_v2(aimg, wimg, o2, cls, patch_rows=4, **kw)
+        outs = []
+        for plan in ((4, 4), (4, 4), (4, 4), (2, 8), (2, 8)):
+            out = H.empty_cl(n, co, h, w, DEV)
+            H.conv_v3(aimg, wimg, out, cls, plan=plan, out_amax=torch.zeros(1, device=DEV), **kw)
+            torch.cuda.synchronize()
+            close(out, ref, 5e-5, f'conv_v3 full size {h} {plan}')
+            close(out, o2, 2e-6, f'conv_v3 vs conv_v2 {h} {plan}')
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[3], outs[4])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
 # Low-resolution convolution (csrc/conv_lr.hip): fp32 activation in, in-kernel split, deep weight ring, ordered split-K
 # ---------------------------------------------------------------------------------------------------------------------------
 def _lr_plan(H, ci, co, cls, n, ks, rpw=0):
@@ -1382,7 +1470,7 @@ def test_absmax_any_length(n):
         assert float(H.absmax(x.to(DEV))) == 9.25
 
 
-@pytest.mark.parametrize('kind', ['v2_3x3', 'igemm_3x3', 'igemm_1x1', 'igemm_clamp_shared_noise', 'torgb4_elementwise', 'torgb_small', 'torgb_small_clamp_shared_noise'])
+@pytest.mark.parametrize('kind', ['v2_3x3', 'v3_3x3', 'v3_3x3_rows2_waves8', 'igemm_3x3', 'igemm_1x1', 'igemm_clamp_shared_noise', 'torgb4_elementwise', 'torgb_small', 'torgb_small_clamp_shared_noise'])
 def test_fused_activation_backward_equals_separate_pass(kind):
     """EG3D_EPI_BWD_ACT: a data-gradient launch that also runs the activation backward of the layer that produced its `xin`
     (dz, dbias, dd, dnoise, dstrength, max|dz|) against the two-pass form it replaces (EPI_BWD, then eg3d_modconv_epilogue_bwd on
@@ -1425,6 +1513,9 @@ def test_fused_activation_backward_equals_separate_pass(kind):
         if kind == 'v2_3x3':
             _, aimg, wimg = _v2_operands(gz, wt, None, adjoint=True)
             r = H.conv_v2(aimg, wimg, dx, cls, **kw)
+        elif kind.startswith('v3_3x3'):
+            _, aimg, wimg = _v2_operands(gz, wt, None, adjoint=True)
+            r = H.conv_v3(aimg, wimg, dx, cls, plan=(2, 8) if kind.endswith('waves8') else (4, 4), **kw)
         else:
             wa = wt.permute(1, 2, 3, 0).reshape(ci, k * k * co).to(DEV).contiguous()          # adjoint pack [I][tap][O]
             if kind == 'torgb4_elementwise' and spec is not None:          # the element-wise form of the same launch (eg3d_torgb_dgrad_act)
