@@ -71,7 +71,7 @@ __device__ __forceinline__ float range_mul(float amax) {
 // ---- epilogue of a 256-cell x 128-channel tile held as acc[4][2] (wave (wm, wn): patch rows 4 wm .. 4 wm + 3, channels 64 wn .. + 63) ---
 // Output cell (ay, ax) of the class grid Ha x Wa goes to pixel (ay * out_stride + out_py, ax * out_stride + out_px).  Must be entered by
 // the whole block after the last LDS read of the main loop (it re-uses the dynamic LDS).
-// GENW (conv_lr.hip): the workgroup's cells are a (64 RPW >> logw) x (1 << logw) patch (narrow images: 16 / 8 / 4 columns) instead of rows of 32:
+// GENW (tools/proto/conv_lr.hip, not built): the workgroup's cells are a (64 RPW >> logw) x (1 << logw) patch (narrow images: 16 / 8 / 4 columns) instead of rows of 32:
 // cell c of MFMA tile mt is patch position lin = 32 mt + c -> row lin >> logw, column lin & ((1 << logw) - 1).  out_mul: 1 / (a_scale * w_scale).
 template <bool ATOMIC, int RPW = 4, bool GENW = false>   // ATOMIC at compile time: the split-K form must not cost the fused epilogues a register (together they spilled 30 VGPRs);
                                       // RPW = patch rows per wave (4: 8 x 32 patch, 2: 4 x 32)

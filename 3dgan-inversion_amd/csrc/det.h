@@ -4,7 +4,9 @@
 // before this header existed).  In the deterministic build a value is added, as an exact integer, to a small fixed-point
 // super-accumulator (four 64-bit words per target: bits 2^-90 .. 2^70 of the sum in 40-bit digits with 24 bits of carry room each), so
 // the result does not depend on the order in which blocks, waves or lanes arrive -- integer addition is associative -- and is the
-// correctly rounded sum up to one final double -> float rounding.  That is stronger than an ordered reduction: the same bits come out
+// correctly rounded sum up to one final double -> float rounding, PROVIDED no digit receives more than 2^23 same-sign additions between two
+// closes of a scope (24 bits of carry room; the largest target of the library, a 512^2 plane-gradient texel row, sees < 2^21) and every
+// |value| < 2^53 (larger ones fall back to the float atomic and count in eg3d_det_misses()).  That is stronger than an ordered reduction: the same bits come out
 // of a different grid, a different split-K factor or a different sort order of the renderer's scatter lists.
 //
 // Who owns the accumulators: the library call.  An entry point that accumulates opens a scope, binds its targets (pointer + element
@@ -122,13 +124,14 @@ struct eg3d_det_scope_t {
         if (!on) return EG3D_OK;
         if (bad) return EG3D_ERR_WORKSPACE;
         if (!t.n) return EG3D_OK;
-        // targets carved from one allocation (neighbours, or the same pointer bound twice) become one region
+        // the same pointer bound twice, overlapping or exactly adjacent targets become one region.  (Gaps are NOT bridged: a stray eg3d_acc to
+        // memory between two separate targets must count in `misses`, not be absorbed.)
         for (int i = 1; i < t.n; ++i)
             for (int j = i; j > 0 && t.r[j].base < t.r[j - 1].base; --j) { const eg3d_det_region x = t.r[j]; t.r[j] = t.r[j - 1]; t.r[j - 1] = x; }
         int m = 0;
         for (int i = 1; i < t.n; ++i) {
             float* end = t.r[m].base + t.r[m].count;
-            if (t.r[i].base <= end + 256) {
+            if (t.r[i].base <= end) {
                 float* e2 = t.r[i].base + t.r[i].count;
                 if (e2 > end) t.r[m].count = (unsigned long long)(e2 - t.r[m].base);
             } else {

@@ -76,11 +76,6 @@ class ConvV2Params(C.Structure):
                 ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p), ('out_amax', C.c_void_p), ('act_bwd', ActBwd), ('products', C.c_int32), ('ksplit', C.c_int32), ('patch_rows', C.c_int32)]
 
 
-class ConvLrParams(C.Structure):
-    _fields_ = [('v', ConvV2Params), ('in_scale', C.c_void_p), ('x_amax', C.c_void_p), ('amax_mul', C.c_float), ('ldx', C.c_int32),
-                ('logw', C.c_int32), ('slabs', C.c_void_p), ('tickets', C.c_void_p), ('rotate', C.c_int32)]
-
-
 class ConvUp2Params(C.Structure):
     _fields_ = [('a', C.c_void_p), ('w', C.c_void_p), ('a_scale', C.c_void_p), ('w_scale', C.c_void_p), ('out', C.c_void_p),
                 ('N', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32), ('Ck', C.c_int32), ('Nc', C.c_int32),
@@ -235,9 +230,6 @@ _SIGS = {
     'eg3d_conv2d_wgrad_v2': (C.c_int, [C.POINTER(WgradV2Params), C.c_void_p]),
     'eg3d_conv2d_wgrad_v2_slabs': (C.c_int, [C.POINTER(WgradV2Params)]),
     'eg3d_weight_grad_finish_slabs': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    'eg3d_conv2d_lr_supported': (C.c_int, [C.POINTER(ConvLrParams)]),
-    'eg3d_conv2d_lr_workspace': (C.c_int, [C.POINTER(ConvLrParams), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
-    'eg3d_conv2d_lr': (C.c_int, [C.POINTER(ConvLrParams), C.c_void_p]),
     'eg3d_split_activation_bytes': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'eg3d_split_activation': (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]),
     'eg3d_split_weight': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
@@ -296,8 +288,6 @@ _SIGS = {
     'eg3d_slice_rgb4_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     'eg3d_warp_project_fwd': (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]),
     'eg3d_warp_project_bwd': (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_void_p]),
-    'eg3d_conv2d_small_supported': (C.c_int, [C.POINTER(ConvParams)]),
-    'eg3d_conv2d_small_atomic': (C.c_int, [C.POINTER(ConvParams), C.c_void_p]),
     'eg3d_torgb_small_supported': (C.c_int, [C.POINTER(TorgbSmallParams)]),
     'eg3d_torgb_small_fwd': (C.c_int, [C.POINTER(TorgbSmallParams), C.c_void_p]),
     'eg3d_torgb_small_bwd_supported': (C.c_int, [C.POINTER(TorgbSmallBwdParams)]),

@@ -80,7 +80,8 @@ def numa_cpus_for_rank(local_rank: int, local_world: int, allowed: Sequence[int]
         if mine and local_rank in peers:
             k, n = peers.index(local_rank), len(peers)
             per = max(1, len(mine) // n)
-            return mine[k * per:(k + 1) * per] if k < n - 1 else mine[k * per:] or mine
+            chunk = mine[k * per:(k + 1) * per] if k < n - 1 else mine[k * per:]
+            return chunk or mine        # (fewer CPUs on the node than peer ranks: share them all rather than pin to nothing)
     per = max(1, len(allowed) // max(1, local_world))
     chunk = allowed[local_rank * per:(local_rank + 1) * per]
     return chunk or allowed

@@ -266,6 +266,18 @@ def _act_bwd_for(x, dev):
 PENDING_DGRAD = {}
 
 
+def _pend_dgrad(x, z, styles, ds):
+    """Queue an unfinished split-K data gradient for the toRGB node that receives it next IN THIS backward pass.  Entries are keyed by the
+    layer input's address, so they must not outlive the pass: the first entry of a pass registers an engine callback that clears the table
+    when the pass completes (ToRGBFn.forward clears it as well -- an abandoned pass, where callbacks do not run, is covered by that)."""
+    if not PENDING_DGRAD:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(PENDING_DGRAD.clear)
+        except Exception:          # not inside an engine-driven backward (a direct call in a test): the forward-time clear remains
+            pass
+    PENDING_DGRAD[x.data_ptr()] = (z, styles, ds)
+
+
 def _finish_pending(pend, x):
     z, s0, ds0 = pend
     fin = H.empty_cl(*x.shape, x.device)
@@ -316,18 +328,18 @@ class ModConvLayerFn(torch.autograd.Function):
         if v2:
             ks = 1
         nprod = 1 if prec == 'f16x1' else 3
-        # 3x3 layers whose grids cannot fill the chip (128^2 x 256, 64^2 x 512, 32^2 x 512): the pre-split kernel with the contraction
-        # split over workgroups (atomic partial tiles) + the finishing epilogue pass
-        ks2 = H.conv_v2_ksplit(Ci, Co, cls, N) if (up == 1 and not v2 and prec in ('f16x3', 'f16x1')) else 0
+        # 3x3 layers whose grids cannot fill the chip with 256 x 128 tiles (64^2 x 512, 32^2 x 512 at one image): the wave-split kernel
+        # (csrc/conv_v3.hip) -- 128 / 64-cell x 64-channel tiles, the contraction split over the waves of a workgroup, fused epilogue, no zero
+        # fill / atomics / finishing pass
+        v3p = H.conv_v3_plan(Ci, Co, cls, N) if (up == 1 and prec in ('f16x3', 'f16x1')) else None
+        if v3p:
+            v2, ks = False, 1
+        # ... or (opt-in) the pre-split kernel with the contraction split over workgroups (atomic partial tiles) + the finishing epilogue pass
+        ks2 = H.conv_v2_ksplit(Ci, Co, cls, N) if (up == 1 and not v2 and not v3p and prec in ('f16x3', 'f16x1')) else 0
         # up-sampling layers: the four output parities of the transposed conv from one workgroup per input patch (csrc/conv_v2_up.hip)
         ksu = H.conv_up2_plan(Ci, Co, Hi, Wi, N) if (up == 2 and not v2 and kh == 3 and kw == 3 and prec in ('f16x3', 'f16x1')) else None
         epi_kw = dict(noise=nz, noise_nstride=nstride or 0, noise_strength=noise_strength, bias=b, act='lrelu', alpha=0.2, gain=act_gain, clamp=clampv)
-        # the 4^2 .. 64^2 layers at one image per GPU: the low-resolution kernel (csrc/conv_lr.hip) -- fp32 activation in, weight pieces streamed
-        # through a deep LDS ring, split-K summed in slice order by the last workgroup, fused epilogue; no zero fill, no finishing pass
-        lrp = H.conv_lr_plan(Ci, Co, cls, N) if (up == 1 and not v2 and not ks2 and prec in ('f16x3', 'f16x1')) else None
-        if lrp:
-            wimg = cache.get_split(weight)[0]
-        if v2 or ks2 or ksu:   # pre-split operands: modulation, range normalisation and the fp16 split happen once, not per tile and tap
+        if v2 or v3p or ks2 or ksu:   # pre-split operands: modulation, range normalisation and the fp16 split happen once, not per tile and tap
             pre_img = getattr(x, '_eg3d_split', None)           # (SplitImage, styles ptr, styles version) left by the producing layer's epilogue
             if pre_img is not None and pre_img[1] == styles.data_ptr() and pre_img[2] == styles._version and pre_img[0].shape == tuple(x.shape):
                 aimg = pre_img[0]
@@ -337,9 +349,8 @@ class ModConvLayerFn(torch.autograd.Function):
         if up == 1:
             if v2:
                 H.conv_v2(aimg, wimg, out, cls, epi=L.EPI_FWD, out_scale=d, out_amax=amax_out, algo_flops=aflops, products=nprod, **epi_kw)
-            elif lrp:
-                H.conv_lr(x, H.amax_of(x), wimg, out, cls, lrp, in_scale=styles, epi=L.EPI_FWD, out_scale=d, out_amax=amax_out, algo_flops=aflops,
-                          products=nprod, **epi_kw)
+            elif v3p:
+                H.conv_v3(aimg, wimg, out, cls, plan=v3p, epi=L.EPI_FWD, out_scale=d, out_amax=amax_out, algo_flops=aflops, products=nprod, **epi_kw)
             elif ks2:
                 z = H.zeros_cl(N, Co, Ho, Wo, x.device)
                 H.conv_v2(aimg, wimg, z, cls, epi=L.EPI_ATOMIC, ksplit=ks2, algo_flops=aflops, products=nprod)
@@ -411,7 +422,7 @@ class ModConvLayerFn(torch.autograd.Function):
         if rec is not None:             # (a no-grad forward of the same layer -- the canonical view of the warping loss -- leaves a pending record alone)
             _set_producer(cache, rec)
         # pivotal tuning: the weight gradient reads the forward's operand image again (csrc/conv_wgrad_v2.hip) instead of the fp32 activation
-        ctx.aimg = aimg if (v2 and up == 1 and want_wgrad and ctx.needs_input_grad[1] and H.WGRAD_V2 and Ci % 64 == 0 and Co % 64 == 0) else None
+        ctx.aimg = aimg if ((v2 or v3p) and up == 1 and want_wgrad and ctx.needs_input_grad[1] and H.WGRAD_V2 and Ci % 64 == 0 and Co % 64 == 0) else None
         ctx.rec = rec                   # THIS forward's record: the backward below trusts only it (two live graphs of one layer cannot mix)
         ctx.save_for_backward(x, weight, styles, d, out, nz, noise_strength, b)
         ctx.cfg = (up, act_gain, clampv, nstride, cache, want_wgrad, noise is not None and noise.dim() == 4, d_in is not None)
@@ -520,10 +531,12 @@ class ModConvLayerFn(torch.autograd.Function):
                 did = H.conv_v2(gimg, cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD,
                                 out_scale=styles, xin=x, ds=ds, algo_flops=aflops, products=1 if prec == 'f16x1' else 3, **fkw)
                 dz_img = None
-            elif up == 1 and prec in ('f16x3', 'f16x1') and amax is not None and not ks2 and H.conv_lr_plan(Co, Ci, cls_adj, N):
-                # low-resolution layer: data gradient, style gradient and the producer's activation backward from one launch (csrc/conv_lr.hip)
-                did = H.conv_lr(g, amax, cache.get_split(weight)[1], dx, cls_adj, H.conv_lr_plan(Co, Ci, cls_adj, N), epi=L.EPI_BWD, out_scale=styles,
+            elif up == 1 and prec in ('f16x3', 'f16x1') and amax is not None and H.conv_v3_plan(Co, Ci, cls_adj, N):
+                # under-filled 3x3 grid: data gradient, style gradient and the producer's activation backward from one launch of the wave-split kernel
+                gimg = dz_img if dz_img is not None else H.split_activation(g, amax)
+                did = H.conv_v3(gimg, cache.get_split(weight)[1], dx, cls_adj, plan=H.conv_v3_plan(Co, Ci, cls_adj, N), epi=L.EPI_BWD, out_scale=styles,
                                 xin=x, ds=ds, algo_flops=aflops, products=1 if prec == 'f16x1' else 3, **fkw)
+                dz_img = None
             elif ks2:                              # under-filled 3x3 grid: split-K launch of the pre-split kernel, then the finishing pass
                 z = H.zeros_cl(N, Ci, Hi, Wi, dev)
                 H.conv_v2(H.split_activation(g, amax), cache.get_split(weight)[1], z, cls_adj, epi=L.EPI_ATOMIC, ksplit=ks2, algo_flops=aflops,
@@ -531,8 +544,9 @@ class ModConvLayerFn(torch.autograd.Function):
                 did = prod is not None and Ci % 4 == 0 and Ci <= 1024
                 if did:
                     H.dgrad_finish_act(z, x, styles, dx, spec, ds=ds, dz_amax=pacc[4])
-                elif ctx.from_torgb and H.DEFER_DGRAD_FINISH and need_x and prod is None:
-                    PENDING_DGRAD[x.data_ptr()] = (z, styles, ds)         # the toRGB node that receives this gradient next finishes it in its launch
+                elif ctx.from_torgb and H.DEFER_DGRAD_FINISH and need_x and prod is None and d_given:
+                    _pend_dgrad(x, z, styles, ds)                          # the toRGB node that receives this gradient next finishes it in its launch (d_given: `ds` is read by
+                                                                          # the style bank's node, which runs after every layer -- a per-layer affine would read it before the x.z term lands)
                     dx = z
                 else:
                     H.dgrad_finish(z, x, styles, dx, ds=ds)
@@ -548,8 +562,8 @@ class ModConvLayerFn(torch.autograd.Function):
                 did = prod is not None and Ci % 4 == 0 and Ci <= 1024
                 if did:
                     H.dgrad_finish_act(z, x, styles, dx, spec, ds=ds, dz_amax=pacc[4])
-                elif ctx.from_torgb and H.DEFER_DGRAD_FINISH and need_x and prod is None:
-                    PENDING_DGRAD[x.data_ptr()] = (z, styles, ds)         # the toRGB node that receives this gradient next finishes it in its launch
+                elif ctx.from_torgb and H.DEFER_DGRAD_FINISH and need_x and prod is None and d_given:
+                    _pend_dgrad(x, z, styles, ds)                          # the toRGB node that receives this gradient next finishes it in its launch
                     dx = z
                 else:
                     H.dgrad_finish(z, x, styles, dx, ds=ds)
@@ -861,7 +875,13 @@ class ToRGBFn(torch.autograd.Function):
                 H.conv_wgrad(x, dy, Ci, Co, dwp, H.classes_corr(Hh, Ww, 1, 1, 0), in_scale=styles, precision='f16x3', g_amax=dy_amax)
             else:
                 H.conv_wgrad(x, dy, Ci, Co, dwp, H.classes_corr(Hh, Ww, 1, 1, 0), in_scale=styles)
-            dweight = dwp.view(Co, Ci, 1, 1)
+            if H.DEFERRED_CONV_WGRADS is not None:
+                # inside hipops.deferred_weight_grads() the GEMM above is only QUEUED: dwp is still zero here.  Handing its view to autograd was
+                # right only while AccumulateGrad stole the tensor; with an existing .grad (zero_grad(set_to_none=False), accumulation, a hook) the
+                # toRGB weight gradient was silently zero.  Same route as the 3x3 layers: the flush sets / accumulates weight.grad.
+                dweight = H.weight_grad_finish(dwp, weight, None, None, None)
+            else:
+                dweight = dwp.view(Co, Ci, 1, 1)
         dskip = None
         if need_skip and has_skip:        # the adjoint of the up-sampling when the node took the half-resolution image
             dskip = H.upfirdn2d_nhwc(dout, fir44(dev), down=2, pad=(1, 1, 1, 1), flip=True, gain=4.0) if skip_up else dout

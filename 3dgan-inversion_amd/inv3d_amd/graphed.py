@@ -275,7 +275,7 @@ def synthesis(G, impl, ws, c, render_uniforms=None, **kw):
     pack_inside = bool(trainable)
     uni_key = None if render_uniforms is None else tuple(None if u is None else tuple(u.shape) for u in render_uniforms)
     key = (tuple(ws.shape), tuple(c.shape), ws.dtype, c.dtype, need_grad, bool(ws.requires_grad and need_grad), bool(c.requires_grad and need_grad), kk, uni_key,
-           tuple(id(t) for t in leaves), frozen_sig, trainable, H.CONV_MODE, G.neural_rendering_resolution, ws.device.index, G.training, rkey)
+           tuple(id(t) for t in leaves), frozen_sig, trainable, H.CONV_MODE, H.MODCONV_OVERRIDE, G.neural_rendering_resolution, ws.device.index, G.training, rkey)
     st = _STATE.get(G)
     if st is None:
         st = _STATE[G] = _PerG()

@@ -386,9 +386,29 @@ def set_conv_precision(name):
     CONV_PRECISION = PRECISIONS['bf16x6' if name == 'auto' else name]
 
 
+MODCONV_OVERRIDE = None      # 'f16x1' inside modconv_override(): every modulated conv on the pre-split kernels runs ONE product of fp16-rounded operands
+
+
 def modconv_precision() -> str:
     """Arithmetic of the style-modulated convolutions (the dominant kernels) under the current mode."""
+    if MODCONV_OVERRIDE is not None and CONV_MODE == 'auto':
+        return MODCONV_OVERRIDE
     return 'f16x3' if CONV_MODE == 'auto' else CONV_MODE
+
+
+@contextlib.contextmanager
+def modconv_override(name):
+    """Arithmetic class of the reference's own GPU path for the modulated convs of BOTH networks (backbone + super-resolution head): `f16x1` =
+    one v_mfma_f32_32x32x16_f16 product of range-normalised fp16-rounded operands, fp32 accumulation, fp32 results -- an 11-bit significand
+    per operand, what a TF32 convolution keeps (the reference never disables TF32 on its inversion path: only training/training_loop.py:135-136
+    and calc_metrics.py:52-53 do).  Layers still on the loader-split kernel (it has no single-product form) keep three products."""
+    global MODCONV_OVERRIDE
+    assert name in (None, 'f16x1', 'f16x3')
+    prev, MODCONV_OVERRIDE = MODCONV_OVERRIDE, name
+    try:
+        yield
+    finally:
+        MODCONV_OVERRIDE = prev
 
 
 class ActBwdSpec:
@@ -701,7 +721,7 @@ def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_
 # ------------------------------------------------------------------------------------------------- wave-split pre-split convolution (csrc/conv_v3.hip)
 V3_CONFIG = 11       # profiler id of conv_v3_kernel
 USE_V3 = os.environ.get('EG3D_CONV_V3', '1') != '0'
-V3_MAX_TILES8 = int(os.environ.get('EG3D_V3_MAX_TILES8', '256'))       # 256-cell x 128-channel tiles below which a 3x3 launch goes to the wave-split kernel
+V3_MAX_TILES8 = int(os.environ.get('EG3D_V3_MAX_TILES8', '128'))       # 256-cell x 128-channel tiles below which a 3x3 launch goes to the wave-split kernel
 V3_MIN_CELLS = int(os.environ.get('EG3D_V3_MIN_CELLS', '1024'))        # class grids (all images) from this many cells (32^2) -- below, launches are latency-bound
 
 
@@ -888,106 +908,6 @@ def conv_up2(a: SplitImage, w: SplitImage, out, Hc=None, Wc=None, epi=L.EPI_STOR
             prof.meta.append(dict(N=n, Hi=hi, Wi=wi, Ck=ck, Nc=nc, Ho=ho, Wo=wo, taps=[4, 2, 2, 1], epi=epi, ksplit=int(ksplit), in_stride=1, out_stride=2,
                                   prec=3, v2=True, up2=True))
     return out
-
-
-# ------------------------------------------------------------------------------------------------- low-resolution convolution (csrc/conv_lr.hip)
-LR_CONFIG = 10       # profiler id of conv_lr_kernel
-USE_LR = os.environ.get('EG3D_CONV_LR', '0') != '0'
-LR_MAX_CELLS = int(os.environ.get('EG3D_LR_MAX_CELLS', '4096'))        # class grids up to this many cells per image (64^2)
-LR_KS_TARGET = int(os.environ.get('EG3D_LR_KS_TARGET', '256'))         # workgroups a launch aims for
-LR_ROTATE = int(os.environ.get('EG3D_LR_ROTATE', '1'))                 # tile-dependent start of the chunk walk (eg3d_conv_lr_params::rotate)
-LR_KS_MAX = int(os.environ.get('EG3D_LR_KS_MAX', '8'))                 # K slices per tile (the last arriver reads that many 32 KB slabs)
-
-
-def conv_lr_plan(Ck, Nc, classes, N=1, in_stride=1, force=False, rpw=0):
-    """(logw, ksplit) for eg3d_conv2d_lr, or None when the launch is not one for it: stride-1 tap classes of 9 / 4 / 2 / 1 taps on grids of at
-    most LR_MAX_CELLS cells whose 256-cell tiles cannot fill the chip.  logw: tile width 32 / 16 / 8 / 4 cells, the narrowest power of two
-    that covers the widest class grid; ksplit: K slices per 64-cell x 128-channel tile so that the launch has ~LR_KS_TARGET workgroups, each
-    with at least two 16-channel chunks, at most LR_KS_MAX."""
-    if not (USE_LR or force) or CONV_MODE != 'auto' or in_stride != 1 or Ck % 16 or Nc % 128 or Ck > 1024 or not (1 <= len(classes) <= 4):
-        return None
-    wmax = max(c.Wa for c in classes)
-    if max(c.Ha * c.Wa for c in classes) > LR_MAX_CELLS:
-        return None
-    for c in classes:
-        if c.ntaps not in (9, 4, 2, 1):
-            return None
-        dys, dxs = [c.dy[t] for t in range(c.ntaps)], [c.dx[t] for t in range(c.ntaps)]
-        if max(dys) - min(dys) > 2 or max(dxs) - min(dxs) > 2:
-            return None
-    logw = 5 if wmax > 16 else (4 if wmax > 8 else (3 if wmax > 4 else 2))
-    # cells per tile: 256 (24 MFMAs per wave and step amortise the per-step latencies) when that still gives >= 64 tiles before the K split,
-    # 64 for the small images
-    cells = max(c.Ha * c.Wa for c in classes) * N
-    rpw = rpw if rpw else (4 if cells >= 4096 else (2 if cells >= 1024 else 1))
-    if rpw == 4 and logw < 3:
-        rpw = 2
-    tw, tr = 1 << logw, (64 * rpw) >> logw
-    tiles = sum(N * -(-c.Ha // tr) * -(-c.Wa // tw) for c in classes) * (Nc // 128)
-    ks = max(1, min(LR_KS_MAX if rpw == 1 else 4 * (2 if rpw == 2 else 1), -(-LR_KS_TARGET // tiles), (Ck // 16) // 2))
-    return logw, ks, rpw
-
-
-def conv_lr(x, x_amax, w: SplitImage, out, classes, plan, in_scale=None, amax_mul=1.0, out_stride=1, epi=L.EPI_STORE, out_scale=None, bias=None,
-            noise=None, noise_nstride=0, noise_strength=None, act='linear', alpha=0.0, gain=1.0, clamp=-1.0, addend=None, xin=None, ds=None,
-            out_amax=None, algo_flops=None, act_bwd=None, products=3, rotate=None):
-    """Launch eg3d_conv2d_lr: fp32 channels_last x (times in_scale[n,k]) against the split weight image `w`, epilogues of conv_v2.  plan =
-    conv_lr_plan(...).  act_bwd (ActBwdSpec, with epi=EPI_BWD): EPI_BWD_ACT when the launch takes it -- returns True if the fused epilogue
-    ran, False for a plain EPI_BWD."""
-    assert is_cl(x) and is_cl(out)
-    logw, ks = plan[:2]
-    rpw = plan[2] if len(plan) > 2 else 1
-    n, cx, hi, wi = x.shape
-    nc, ck, wtaps = w.shape
-    _, co, ho, wo = out.shape
-
-    class _A:          # what _conv_v2_params reads of an operand image
-        pass
-    a = _A()
-    a.shape, a.data, a.scale = (n, ck, hi, wi), x, x_amax
-    P = L.ConvLrParams()
-    v = _conv_v2_params(a, w, out, classes, out_stride, epi, out_scale, bias, noise, noise_nstride, noise_strength, act, alpha, gain, clamp,
-                        addend, xin, ds, out_amax)
-    v.products, v.ksplit, v.patch_rows = int(products), int(ks), int(rpw)
-    fused_act = False
-    if act_bwd is not None and epi == L.EPI_BWD and xin is not None:
-        v.epi = L.EPI_BWD_ACT
-        act_bwd.fill(v.act_bwd)
-        fused_act = all(t is None or t.data_ptr() % 16 == 0 for t in (act_bwd.d, act_bwd.bias))
-        if not fused_act:
-            v.epi = L.EPI_BWD
-            v.act_bwd = L.ActBwd()
-    P.v = v
-    P.in_scale = in_scale.data_ptr() if in_scale is not None else None
-    P.x_amax, P.amax_mul, P.ldx, P.logw = x_amax.data_ptr(), float(amax_mul), cx, int(logw)
-    P.rotate = int(LR_ROTATE if rotate is None else rotate)
-    if fused_act and not L.lib().eg3d_conv2d_lr_supported(C.byref(P)):
-        fused_act = False
-        P.v.epi = L.EPI_BWD
-        P.v.act_bwd = L.ActBwd()
-    slabs = tickets = None
-    if ks > 1:
-        sb, tw = C.c_int64(0), C.c_int64(0)
-        L.check(L.lib().eg3d_conv2d_lr_workspace(C.byref(P), C.byref(sb), C.byref(tw)), 'conv2d_lr_workspace')
-        slabs = torch.empty((sb.value // 4,), dtype=torch.float32, device=x.device)
-        tickets = zeros((tw.value,), x.device)             # zero words (the kernel leaves them zero)
-        P.slabs, P.tickets = slabs.data_ptr(), tickets.data_ptr()
-    prof = PROFILER
-    if prof is not None and prof.only_config is not None and prof.only_config != LR_CONFIG:
-        prof = None
-    if prof is not None:
-        if algo_flops is None:
-            algo_flops = 2.0 * ck * nc * sum(n * c.Ha * c.Wa * c.ntaps for c in classes)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    L.check(L.lib().eg3d_conv2d_lr(C.byref(P), L.stream_ptr()), 'conv2d_lr')
-    if prof is not None:
-        e1.record()
-        prof.records.append(((LR_CONFIG, PRECISIONS['f16x3']), float(algo_flops), e0, e1))
-        if prof.meta is not None:
-            prof.meta.append(dict(N=n, Hi=hi, Wi=wi, Ck=ck, Nc=nc, Ho=ho, Wo=wo, taps=[c.ntaps for c in classes], epi=epi, ksplit=int(ks),
-                                  in_stride=1, out_stride=out_stride, prec=3, lr=True, logw=int(logw)))
-    return fused_act if act_bwd is not None else out
 
 
 def conv_wgrad(x, g, Ck, Nc, dwp, classes, in_stride=1, out_stride=1, in_scale=None, psplit=0, precision='f32', g_amax=None, g_amax_mul=1.0):
@@ -1607,46 +1527,8 @@ def torgb_small_bwd(dy, wa, styles, x, dx, ds=None, addend=None, act_bwd=None, o
     return fused
 
 
-# The same recipe for the split 3x3 / up-sampling launches of the 4^2 .. 32^2 layers (csrc/conv_small.hip): OFF by default.  It is parity-green
-# (tests/test_gpu_ops.py::test_conv_small_equals_the_split_implicit_gemm) but slower where it matters: 4608-deep contractions are arithmetic, not
-# latency, on the fp32 matrix pipe (157 TFLOP/s: 7.7 us for a 16^2 x 512 x 512 layer before anything else) -- steps/s 206.5 -> 206.1 (<= 256 cells),
-# 197 (<= 1024), 173 (<= 4096); even at <= 100 cells -0.5 %.  toRGB (K = 512, 0.4 GFLOP at most) is where the recipe pays.
-CONV_SMALL = os.environ.get('EG3D_CONV_SMALL', '0') != '0'
-CONV_SMALL_MAX_CELLS = int(os.environ.get('EG3D_CONV_SMALL_MAX_CELLS', '256'))
-
-
-def conv_small_atomic(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=None):
-    """eg3d_conv2d_small_atomic: out (pre-zeroed) += conv(x * in_scale, wp) over the tap classes; False when the geometry is not the kernel's
-    (nothing launched)."""
-    assert is_cl(x) and is_cl(out)
-    if len(classes) > 4:
-        return False
-    p = L.ConvParams()
-    n, cx, hi, wi = x.shape
-    _, co, ho, wo = out.shape
-    p.x, p.w, p.out = x.data_ptr(), wp.data_ptr(), out.data_ptr()
-    p.N, p.Hi, p.Wi, p.Ck, p.ldx = n, hi, wi, Ck, cx
-    p.Nc, p.w_row = Nc, wp.stride(0)
-    p.Ho, p.Wo, p.ldo = ho, wo, co
-    p.in_stride, p.out_stride = in_stride, out_stride
-    p.ncls = len(classes)
-    for i, c in enumerate(classes):
-        p.cls[i] = c
-    p.in_scale = in_scale.data_ptr() if in_scale is not None else None
-    p.epi, p.ksplit = L.EPI_ATOMIC, 1
-    if not L.lib().eg3d_conv2d_small_supported(C.byref(p)):
-        return False
-    L.check(L.lib().eg3d_conv2d_small_atomic(C.byref(p), L.stream_ptr()), 'conv2d_small_atomic')
-    return True
-
-
 def conv_atomic(x, wp, Ck, Nc, out, classes, in_stride=1, out_stride=1, in_scale=None, ksplit=1, **igemm_kw):
-    """A split (EPI_ATOMIC) conv launch into the pre-zeroed `out`: the low-latency kernel when the layer has few output cells, else the implicit
-    GEMM with `ksplit` slices."""
-    cells = x.shape[0] * max(c.Ha * c.Wa for c in classes)
-    if CONV_SMALL and cells <= CONV_SMALL_MAX_CELLS and Ck % 8 == 0 and Ck >= 32 and Nc % 32 == 0 and wp.dtype == torch.float32 and wp.stride(1) == 1:
-        if conv_small_atomic(x, wp, Ck, Nc, out, classes, in_stride, out_stride, in_scale):
-            return
+    """A split (EPI_ATOMIC) launch of the implicit GEMM with `ksplit` slices into the pre-zeroed `out`."""
     conv_igemm(x, wp, Ck, Nc, out, classes, in_stride=in_stride, out_stride=out_stride, in_scale=in_scale, epi=L.EPI_ATOMIC, ksplit=ksplit, **igemm_kw)
 
 

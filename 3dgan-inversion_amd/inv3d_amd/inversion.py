@@ -370,7 +370,8 @@ class LatentProjector:
                  noise_ramp_length=0.75, lr_rampdown_length=0.25, lr_rampup_length=0.05, regularize_noise_weight=1e5,
                  initial_learning_rate=0.01, radius=2.7, wplus=False, synth_kwargs: Optional[dict] = None, seed: int = 0,
                  init_noise: Optional[Dict[str, torch.Tensor]] = None, use_graph: bool = False, graph_warmup: int = 2,
-                 pose_net: Optional[torch.nn.Module] = None, pose_mode: str = 'quat', translation_start=None, sr_fp16: bool = False):
+                 pose_net: Optional[torch.nn.Module] = None, pose_mode: str = 'quat', translation_start=None, sr_fp16: bool = False,
+                 modconv_f16x1: bool = False):
         if pose_mode not in POSE_DIMS:
             raise ValueError(f'pose_mode must be one of {sorted(POSE_DIMS)}, got {pose_mode!r}')
         self.pose_mode = pose_mode
@@ -378,6 +379,10 @@ class LatentProjector:
         # Phase A.  The reference itself passes force_fp32=True here (w_projector.py:189), so this is an OPTION for a secondary figure
         # (to be shown to keep the final-PSNR drift small), never the default.
         self.sr_fp16 = bool(sr_fp16)
+        # modconv_f16x1: EVERY modulated conv on the pre-split kernels (backbone and super-resolution head) in one product of fp16-rounded
+        # operands -- the arithmetic class of the reference's TF32 convolutions on its named GPU (hipops.modconv_override).  A labelled side
+        # figure of bench.py, never the headline.
+        self.modconv_f16x1 = bool(modconv_f16x1)
         dev = target.device
         N = self.N = int(target.shape[0])
         if N > 1 and optimize_pose:
@@ -518,6 +523,12 @@ class LatentProjector:
         return w_noise_scale, self.lr0 * lr_ramp
 
     def step(self, w_noise: Optional[torch.Tensor] = None, **step_kwargs) -> Dict[str, torch.Tensor]:
+        if self.modconv_f16x1:
+            with hipops.modconv_override('f16x1'):
+                return self._step(w_noise, **step_kwargs)
+        return self._step(w_noise, **step_kwargs)
+
+    def _step(self, w_noise: Optional[torch.Tensor] = None, **step_kwargs) -> Dict[str, torch.Tensor]:
         """One optimisation step.  `w_noise` (unit normal, shape of w_opt) and `render_uniforms=(u1,u2)` may be injected for
         deterministic runs; otherwise they are drawn on the device.
 

@@ -271,7 +271,6 @@ def conv_act(x, weight, bias, stride=1, pad=0, act='relu', alpha=0.0, gain=1.0):
 
 # ---- the stand-in feature pyramid as direct convolutions (csrc/loss_ops.hip: eg3d_conv3x3_direct, eg3d_pool2_act_bwd) ----------------------------
 DIRECT_PYRAMID = os.environ.get('EG3D_DIRECT_PYRAMID', '1') != '0'
-FUSE_POOL_BWD = os.environ.get('EG3D_FUSE_POOL_BWD', '0') != '0'     # dz formed inside the data-gradient launch (eg3d_conv3x3_direct_params::ga): measured 219.7 vs 220.1 steps/s -- every channel-group block re-forms it; off
 
 
 def _direct_group(co: int, quads: int, ci: int) -> int:
@@ -344,13 +343,12 @@ class _StubPyramidFn(torch.autograd.Function):
             g = _direct_group(ci, (h // 2) * (w // 2), co)
             wa = H.memo(('direct_adj', co, g), [wt], lambda wt=wt, g=g: _pack_direct(wt.detach().flip(2, 3).permute(1, 0, 2, 3), g))
             nxt = H.empty_cl(n, ci, h, w, y.device)
-            if FUSE_POOL_BWD:       # the data-gradient launch forms dz from (ga, dx, y) while it loads its patch
-                _conv3x3_direct(y, wa, ci, g, y=nxt, alpha=alpha, gain=gain, ga=ga, gb=dx)
-            else:
-                dz = H.empty_cl(n, co, h, w, y.device)
-                L.check(L.lib().eg3d_pool2_act_bwd(ga.data_ptr() if ga is not None else None, dx.data_ptr() if dx is not None else None, y.data_ptr(), dz.data_ptr(),
-                                                   n, h, w, co, alpha, gain, L.stream_ptr()), 'pool2_act_bwd')
-                _conv3x3_direct(dz, wa, ci, g, y=nxt)
+            # (dz formed inside the data-gradient launch -- eg3d_conv3x3_direct_params::ga -- measured 219.7 vs 220.1 steps/s twice: every
+            #  channel-group block re-forms it; the separate pass stays)
+            dz = H.empty_cl(n, co, h, w, y.device)
+            L.check(L.lib().eg3d_pool2_act_bwd(ga.data_ptr() if ga is not None else None, dx.data_ptr() if dx is not None else None, y.data_ptr(), dz.data_ptr(),
+                                               n, h, w, co, alpha, gain, L.stream_ptr()), 'pool2_act_bwd')
+            _conv3x3_direct(dz, wa, ci, g, y=nxt)
             dx = nxt
         return (dx, None, None) + (None,) * nl
 

@@ -2,8 +2,8 @@
 bias_act(x, b, dim, act, alpha, gain, clamp, impl)), executed by eg3d_bias_act on gfx950.
 
 First- and second-order gradients are provided (the reference contract: bias_act.py:128-209); derivatives are keyed on
-the output like the native kernel (bias_act.cu:76,145).  CPU tensors raise: the only CPU implementation in this
-repository is the test oracle."""
+the output like the native kernel (bias_act.cu:76,145).  impl='cuda' (default) raises on CPU tensors -- no automatic fallback; an
+explicit impl='ref' selects the plain-torch composite of _ref_impl.py (reference: bias_act.py:84-88)."""
 import math
 from types import SimpleNamespace
 
@@ -87,9 +87,6 @@ def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None, 
     """y = clamp(act(x + b) * gain); shape/dtype/layout of x are preserved."""
     assert isinstance(x, torch.Tensor)
     assert impl in ('ref', 'cuda')
-    if impl == 'ref':
-        raise NotImplementedError("impl='ref' is not part of the MI355X product path; the CPU restatement lives in oracle/ (tests only)")
-    L.require_cuda(x, b)
     spec = activation_funcs[act]
     alpha = float(spec.def_alpha if alpha is None else alpha)
     gain = float(spec.def_gain if gain is None else gain)
@@ -97,4 +94,8 @@ def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None, 
     if b is not None:
         assert b.dim() == 1 and 0 <= dim < x.dim() and b.shape[0] == x.shape[dim]
         b = b.to(x.dtype)
+    if impl == 'ref':       # explicit request only (reference: bias_act.py:84-88); there is no automatic fallback to it
+        from ._ref_impl import bias_act_ref
+        return bias_act_ref(x, b, dim, act, alpha, gain, clamp)
+    L.require_cuda(x, b)
     return _BiasAct.apply(x, b, dim, spec, alpha, gain, clamp)

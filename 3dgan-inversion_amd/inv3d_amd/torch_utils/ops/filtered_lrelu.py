@@ -149,13 +149,14 @@ def filtered_lrelu(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=np
     padding = int | [x, y] | [x_before, x_after, y_before, y_after] in the up-sampled grid, gain/slope/clamp of the leaky ReLU."""
     assert isinstance(x, torch.Tensor) and x.ndim == 4
     assert impl in ('ref', 'cuda')
-    if impl == 'ref':
-        raise NotImplementedError("impl='ref' lives in oracle/eg3d_oracle.py (test infrastructure); the product path has no CPU fallback")
     assert isinstance(up, int) and up >= 1 and isinstance(down, int) and down >= 1
     assert gain == float(gain) and gain > 0 and slope == float(slope) and slope >= 0
     assert clamp is None or (clamp == float(clamp) and clamp >= 0)
     if b is not None:
         assert isinstance(b, torch.Tensor) and b.dtype == x.dtype and tuple(b.shape) == (x.shape[1],)
+    if impl == 'ref':       # explicit request only (reference: filtered_lrelu.py:113-120); there is no automatic fallback to it
+        from ._ref_impl import filtered_lrelu_ref
+        return filtered_lrelu_ref(x, fu, fd, b, up, down, _pad4(padding), float(gain), float(slope), clamp, bool(flip_filter))
     f1, f2 = _dense(fu, x.device), _dense(fd, x.device)
     cfg = _Cfg(up, down, _pad4(padding), [0, 0, 0, 0], float(up) ** 2, 1.0, bool(flip_filter), bool(flip_filter), x.shape[2:],
                _filter_hw(f1), _filter_hw(f2))

@@ -96,8 +96,9 @@ class _Upfirdn2d(torch.autograd.Function):
 def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cuda'):
     """Pad, upsample, FIR-filter and downsample a batch of 2-D images."""
     assert isinstance(x, torch.Tensor) and impl in ('ref', 'cuda')
-    if impl == 'ref':
-        raise NotImplementedError("impl='ref' is not part of the MI355X product path; see oracle/ (tests only)")
+    if impl == 'ref':       # explicit request only (reference: upfirdn2d.py:160-164); there is no automatic fallback to it
+        from ._ref_impl import upfirdn2d_ref
+        return upfirdn2d_ref(x, f, _scaling(up), _scaling(down), _padding(padding), bool(flip_filter), float(gain))
     L.require_cuda(x, f)
     return _Upfirdn2d.apply(x, f, _scaling(up), _scaling(down), _padding(padding), bool(flip_filter), float(gain))
 

@@ -319,6 +319,49 @@ def side_configs(G, target, cam, dev, use_graph, steps=10):
         return res
     guarded('phase_a_sr_f16x1', phase_a_sr_f16x1)
 
+    def ref_arith_f16x1():
+        # the arithmetic class of the reference's own GPU path, labelled.  The reference's inversion scripts never disable
+        # TF32 (only training/training_loop.py:135-136 and calc_metrics.py:52-53 do), so on the RTX 3090 it names every cuDNN conv of
+        # G.synthesis keeps an 11-bit significand per operand -- what ONE product of range-normalised fp16-rounded operands keeps.  Here: every
+        # modulated conv that runs on the pre-split kernels (backbone AND super-resolution head) in one product, fp32 accumulation and results.
+        from inv3d_amd.inversion import psnr_01
+        from inv3d_amd import hipops as H
+        import torch.nn.functional as F
+        res = {}
+        ws1 = S.synth_ws(14, 512, 1, seed=7).to(dev)
+        imgs, grads = {}, {}
+        for key, ov in (('f16x3', None), ('f16x1', 'f16x1')):
+            w = ws1.clone().requires_grad_(True)
+            with H.modconv_override(ov):
+                o = G.synthesis(w, cam[:1], noise_mode='const', force_fp32=True)
+                (F.avg_pool2d(o['image'], 2) - F.avg_pool2d(target[:1], 2)).square().sum().backward()
+            imgs[key], grads[key] = o['image'].detach(), w.grad.detach().clone()
+        res['forward_psnr_vs_f16x3_db'] = round(float(psnr_01(imgs['f16x1'], imgs['f16x3'])), 2)
+        res['forward_max_abs_err'] = float((imgs['f16x1'] - imgs['f16x3']).abs().max())
+        res['d_ws_rel_err'] = float((grads['f16x1'] - grads['f16x3']).abs().max() / grads['f16x3'].abs().max())
+        for key, flag in (('f16x3', False), ('f16x1', True)):
+            pr = LatentProjector(G, target[:1], num_steps=400, cam=cam[:1], seed=321, use_graph=use_graph, modconv_f16x1=flag)
+            pr.preheat = 0
+            for _ in range(pr._graph_warmup + 1):
+                pr.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_timed = 400 - pr.step_idx
+            for _ in range(n_timed):
+                out = pr.step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res[key] = dict(steps_per_s=round(n_timed / dt, 2), final_psnr_db=round(float(psnr_01(out['image'], target[:1])), 4))
+        res['final_psnr_drift_db'] = round(abs(res['f16x3']['final_psnr_db'] - res['f16x1']['final_psnr_db']), 4)
+        res['headline_arithmetic'] = 'f16x3 (this entry is a side figure: the headline moves to one product only if the 400-step drift is <= 1e-3 dB)'
+        res['note'] = ('every modulated conv on the pre-split kernels (backbone + SR head; conv_v2 / conv_v3 / up2 / s2adj) in ONE v_mfma_f32_32x32x16_f16 product of '
+                       'range-normalised fp16-rounded operands, fp32 accumulation / results; layers still on the loader-split kernel keep three products.  The reference '
+                       'runs TF32 convs on its inversion path on its named GPU (TF32 is only disabled in training/training_loop.py:135-136 and calc_metrics.py:52-53): '
+                       'same 11-bit operand significand.  forward_psnr / d_ws_rel_err: one full-size forward + C2-style backward against the three-product path; '
+                       'final_psnr_drift: two 400-step latent projections from the same seed')
+        return res
+    guarded('ref_arith_f16x1', ref_arith_f16x1)
+
     def phase_b():
         import copy
         state = copy.deepcopy(G.state_dict())
@@ -532,7 +575,7 @@ def main():
                     continue
                 pk = FP32_MFMA_PEAK_TFLOPS if {vv: kk for kk, vv in H.PRECISIONS.items()}[k[1]] == 'f32' else BF16_MFMA_PEAK_TFLOPS
                 name = {H.V2_CONFIG: 'conv_v2<8 rows>', H.V2H_CONFIG: 'conv_v2<4 rows>', H.V2Q_CONFIG: 'conv_v2<2 rows>', H.UP2_CONFIG: 'conv_v2_up2',
-                        H.S2ADJ_CONFIG: 'conv_v2_s2adj', H.LR_CONFIG: 'conv_lr'}.get(k[0], 'conv_igemm<%s>' % H.TILE_NAMES.get(k[0], '?'))
+                        H.S2ADJ_CONFIG: 'conv_v2_s2adj', H.V3_CONFIG: 'conv_v3'}.get(k[0], 'conv_igemm<%s>' % H.TILE_NAMES.get(k[0], '?'))
                 fams.append(dict(kernel=name + ' / ' + {vv: kk for kk, vv in H.PRECISIONS.items()}[k[1]], launches_per_step=v['launches'] / args.steps,
                                  ms_per_step=round(v['ms'] / args.steps, 4), tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1),
                                  frac=round(v['flops'] / (v['ms'] * 1e-3) / 1e12 / pk, 4), share_of_conv_time=round(v['ms'] / all_ms, 3)))
@@ -543,6 +586,7 @@ def main():
                         peak_basis=('fp32 matrix peak (MI355X_MICROARCH.md)' if dom_prec == 'f32' else 'dense 16-bit matrix peak of v_mfma_f32_32x32x16_f16 (MI355X_MICROARCH.md); achieved = algorithmic flops'),
                         products_per_fp32_product=nprod, mfma_executed_tflops=round(ach * nprod, 1), frac_executed=round(ach * nprod / hw_peak, 4),
                         mfma_register_loop_tflops_measured=round(probe_tf, 1) if probe_tf is not None else None,
+                        frac_of_sustained=round(ach * nprod / probe_tf, 4) if probe_tf else None,       # executed TFLOP/s / what a register-only loop of the same instruction sustains on this part: the schedule headroom left
                         mfma_register_loop_note=('eg3d_probe_mfma_f16: register-only v_mfma_f32_32x32x16_f16 loop on RANDOM fp16 data, 1024 blocks x 4 waves x 8 accumulators, timed with HIP events '
                                                  'in this run right after the timed region.  The guide\'s 2495 TFLOP/s is the same instruction on its own benchmark; this probe reads 1.4-1.6 PFLOP/s on random data '
                                                  'and 2.0-2.3 on zeros on every box of this pool (tools/proto/mfma_peak.hip: the part clocks down under dense 16-bit MFMA load -- the guide\'s "DVFS give-back": '
@@ -552,7 +596,7 @@ def main():
                         avg_launch_ms=round(dom['ms'] / dom['launches'], 4), share_of_conv_time=round(dom['ms'] / all_ms, 3),
                         all_conv_tflops=round(all_fl / (all_ms * 1e-3) / 1e12, 1), all_conv_ms_per_step=round(all_ms / args.steps, 3),
                         all_conv_frac=round(all_fl / (all_ms * 1e-3) / 1e12 / hw_peak, 4),
-                        all_conv_scope=('launches of the implicit-GEMM family (conv_igemm / conv_v2 / up2 / s2adj / conv_lr); the low-latency toRGB launches of the '
+                        all_conv_scope=('launches of the implicit-GEMM family (conv_igemm / conv_v2 / conv_v3 / up2 / s2adj); the low-latency toRGB launches of the '
                                         '4^2 .. 64^2 blocks (fp32 matrix pipe, 0.5 of 579 GFLOP per step) are not in it'),
                         families=fams, furthest_from_roofline=worst,
                         step_gflop_algorithmic=round(611.6 * M, 1), step_tflops=round(611.6e9 * M / (elapsed / args.steps) / 1e12, 1),

@@ -7,6 +7,9 @@
  *   - extern "C", plain device pointers + sizes; no torch / C++ types cross the boundary.
  *   - every entry takes the hipStream_t to launch on (as void*), allocates nothing (the caller owns all
  *     buffers, including workspaces), keeps no global mutable state (re-entrant, multi-stream safe).
+ *     ONE exception, in the deterministic build only (libeg3d_hip_det.so, -DEG3D_DET=1; csrc/det.h): the exact accumulators live in a
+ *     workspace the caller lends with eg3d_det_set_workspace(), and the table of a call's accumulation targets is one process-global
+ *     device object updated in stream order -- that build is single-stream and not re-entrant ("Deterministic build").
  *   - return value: 0 = ok, <0 = invalid argument / unsupported configuration (EG3D_ERR_*),
  *     >0 = hipError_t of a failed launch.  No exceptions.
  *   - tensors are fp32 unless a `dtype` argument says otherwise (EG3D_F32 / EG3D_F16 / EG3D_F64).
@@ -241,38 +244,6 @@ int eg3d_conv2d_v2(const eg3d_conv_v2_params* p, void* stream);
  * Restrictions (eg3d_conv2d_v3_supported): Ck % 16 == 0, Nc % 64 == 0, in_stride 1, nine-tap classes spanning at most 3 x 3. */
 int eg3d_conv2d_v3_supported(const eg3d_conv_v2_params* p);
 int eg3d_conv2d_v3(const eg3d_conv_v2_params* p, void* stream);
-/* Low-resolution form of that convolution (csrc/conv_lr.hip) for the layers whose grids cannot fill the chip with 256-cell tiles (the
- * 4^2 .. 64^2 blocks of the backbone at one image per GPU; training/networks_stylegan2.py:417-461): same contract, epilogues
- * (STORE / FWD / BWD / BWD_ACT) and W image as eg3d_conv2d_v2, but
- *   - the A operand is the fp32 NHWC activation itself (v.a = x [N,Hi,Wi,ldx], v.a_scale unused): a workgroup stages the halo of its tile
- *     per 16-channel chunk by LDS-DMA, multiplies by in_scale[n,k] and by the power of two that brings x_amax * amax_mul * max|in_scale| to
- *     [2^13, 2^14), and splits it into the two fp16 pieces in LDS -- no operand image, no split pass;
- *   - a workgroup tile is 64 r cells x 128 channels (r = v.patch_rows: 1 | 2 | 4), the cells a (64 r >> logw) x (1 << logw) patch (r = 1, logw = 5: 2 x 32 ... logw = 2: 16 x 4),
- *     so narrow images do not waste matrix work on padding columns;
- *   - the weight tile of a (tap, chunk) step goes through an eight-slot LDS ring (seven steps of LDS-DMA in flight per workgroup): the
- *     4^2 .. 16^2 layers are bound by streaming 9.4 MB of weight pieces, not by arithmetic;
- *   - ksplit > 1 splits the 16-channel chunks over ksplit workgroups per tile WITHOUT atomics, zero fill or finishing pass: every workgroup
- *     stores its partial tile into `slabs`, takes a ticket, and the last one to arrive sums the ksplit partial tiles in slice order (the
- *     result does not depend on arrival order: run-to-run deterministic) and runs the fused epilogue.  `tickets` (one uint32 per tile,
- *     all classes) must be zero on entry and is zero again on exit.
- * Restrictions (eg3d_conv2d_lr_supported): Ck % 16 == 0, Nc % 128 == 0, in_stride 1, tap offsets spanning at most 3 x 3, 1 <= ksplit <= 16. */
-typedef struct eg3d_conv_lr_params {
-    eg3d_conv_v2_params v;     /* v.a = fp32 activation, v.a_scale ignored, v.ksplit = K slices, v.patch_rows = 0 / 1 | 2 | 4: tile of 64 | 128 | 256 cells */
-    const float* in_scale;     /* [N,Ck] or null                                                                             */
-    const float* x_amax;       /* device scalar max|x| (required)                                                            */
-    float amax_mul;            /* |x| <= x_amax * amax_mul                                                                   */
-    int32_t ldx;               /* row pitch of x in floats (>= Ck, multiple of 4)                                            */
-    int32_t logw;              /* tile width = 1 << logw cells (2 .. 5)                                                      */
-    float* slabs;              /* ksplit > 1: eg3d_conv2d_lr_workspace() bytes                                               */
-    uint32_t* tickets;         /* ksplit > 1: one word per tile, zero on entry / exit                                        */
-    int32_t rotate;            /* != 0: cell tile m starts its walk over the 16-channel chunks of its K slice at a tile-dependent chunk (and wraps):
-                                * the workgroups of an XCD that stream the same weight slice then read different lines at any moment instead of
-                                * queueing on the same L2 channel.  The summation order per tile stays a fixed function of the tile index.       */
-} eg3d_conv_lr_params;
-int eg3d_conv2d_lr_supported(const eg3d_conv_lr_params* p);
-/* slab bytes and ticket words a launch with ksplit > 1 needs (0, 0 for ksplit <= 1); returns EG3D_OK or an error code */
-int eg3d_conv2d_lr_workspace(const eg3d_conv_lr_params* p, int64_t* slab_bytes, int64_t* ticket_words);
-int eg3d_conv2d_lr(const eg3d_conv_lr_params* p, void* stream);
 /* Data gradient of that transposed convolution (a stride-2 3x3 correlation; csrc/conv_v2_s2adj.hip) with the contract, epilogues and
  * weight image of eg3d_conv2d_v2, for ONE class of nine taps (dy, dx) = (t / 3, t % 3):
  *     acc[n,a,b,o] = sum_t sum_k  G[n, 2a + dy[t], 2b + dx[t], k] * W[o, wtap[t], k]
@@ -579,14 +550,6 @@ int64_t eg3d_noise_reg_workspace_floats(const int32_t* res, int nbufs);
 int eg3d_noise_regularizer(float* const* x, float* const* grad, const int32_t* res, int nbufs, float* workspace,
                            float* reg_out, float scale, void* stream);
 int eg3d_noise_normalize(float* const* x, const int32_t* res, int nbufs, float* workspace, void* stream);
-
-/* The EG3D_EPI_ATOMIC launch of eg3d_conv2d_igemm_f32 for FEW output cells (the 4^2 .. 32^2 layers of the backbone: modulated 3x3 convs,
- * up-sampling transposed convs and their data gradients -- training/networks_stylegan2.py:62-90, torch_utils/ops/conv2d_resample.py:114-136):
- * out (pre-zeroed) += conv(x * in_scale, w) over the tap classes of p, exact fp32 products; all other epilogue fields of p are ignored
- * (ksplit too: the taps are the split).  Ck % 8 == 0, Ck >= 32, Nc % 32 == 0.  Where the 16-channel step loop of the implicit GEMM is all
- * latency (10 - 30 us for < 1.2 GFLOP) this one takes two memory latencies per workgroup. */
-int eg3d_conv2d_small_supported(const eg3d_conv_params* p);
-int eg3d_conv2d_small_atomic(const eg3d_conv_params* p, void* stream);
 
 /* Low-latency toRGB for small pixel counts (the 4^2 .. 64^2 blocks of the backbone) -- replaces ToRGBLayer.forward
  * (training/networks_stylegan2.py:338-359) + the skip accumulation of SynthesisBlock.forward (:433-436) where eg3d_conv2d_igemm_f32's

@@ -112,6 +112,10 @@ def test_numa_cpu_split_is_a_partition():
     even = [D.numa_cpus_for_rank(r, 8, list(range(16)), {}, {}) for r in range(8)]
     assert even == [[2 * r, 2 * r + 1] for r in range(8)]
     assert D.numa_cpus_for_rank(3, 8, [5], {}, {}) == [5]          # fewer CPUs than ranks: never an empty set
+    # fewer allowed CPUs on the NUMA node than peer ranks (a cgroup with 2 CPUs of node 0, four ranks there): every rank gets a non-empty set
+    # (`A if c else B or mine` bound the `or` to the else branch only -- non-last ranks got [] and stayed unpinned)
+    few = [D.numa_cpus_for_rank(r, 8, [0, 1, 50, 51], node_cpus, gpu_node) for r in range(8)]
+    assert all(few) and few[0] == [0] and few[1] == [1] and few[2] == [0, 1] and few[3] == [0, 1]
     assert D._parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11]
 
 

@@ -448,50 +448,6 @@ def test_conv2d_gradfix_dilation_and_output_padding(case):
     close(gw, gwr, 5e-5, f'{case} dw')
 
 
-@pytest.mark.parametrize('kind', ['corr3', 'corr3_batch', 'corr1', 'convT', 'convT_adjoint', 'corr_adjoint'])
-def test_conv_small_equals_the_split_implicit_gemm(kind):
-    """eg3d_conv2d_small_atomic (csrc/conv_small.hip: the low-latency launch for the 4^2 .. 32^2 layers) against the EPI_ATOMIC launch of the
-    implicit GEMM in exact-fp32 arithmetic and against torch in float64: stride-1 3x3 / 1x1 classes with zero padding, the four parity classes of
-    the up-sampling transposed conv (strided writes), its stride-2 adjoint (strided reads), ragged cell counts, per-image input scales."""
-    from inv3d_amd import hipops as H, _lib as L
-    g = torch.Generator().manual_seed(5)
-    n, ci, co, h, w = (2, 64, 96, 5, 7) if kind == 'corr3_batch' else (1, 96, 64, 6, 5)
-    k = 1 if kind == 'corr1' else 3
-    x = torch.randn(n, ci, h, w, generator=g)
-    wt = torch.randn(co, ci, k, k, generator=g) / math.sqrt(ci * k * k)
-    s = 1 + 0.5 * torch.randn(n, ci, generator=g)
-    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
-    if kind in ('corr3', 'corr3_batch', 'corr1'):
-        wp, cls, ho, wo, kw = H.pack_weight_fwd(wt.to(DEV)), H.classes_corr(h, w, k, k, k // 2), h, w, dict(in_scale=s.to(DEV))
-        ref = torch.nn.functional.conv2d(x.double() * s.double()[:, :, None, None], wt.double(), padding=k // 2)
-        ck, nc = ci, co
-    elif kind == 'convT':
-        cls, ho, wo = H.classes_convT(h, w, 3, 3, 2)
-        wp, kw = H.pack_weight_fwd(wt.to(DEV)), dict(in_scale=s.to(DEV), out_stride=2)
-        ref = torch.nn.functional.conv_transpose2d(x.double() * s.double()[:, :, None, None], wt.double().transpose(0, 1), stride=2)
-        ck, nc = ci, co
-    elif kind == 'convT_adjoint':         # data gradient of the transposed conv: input = gradient at (2h + 1) x (2w + 1), output at h x w
-        gz = torch.randn(n, co, 2 * h + 1, 2 * w + 1, generator=g)
-        xd = gz.to(DEV).contiguous(memory_format=torch.channels_last)
-        cls, ho, wo = H.classes_convT_adjoint(h, w, 3, 3, 2), h, w
-        wp, kw = H.pack_weight_adj(wt.to(DEV)), dict(in_stride=2)
-        ref = torch.nn.functional.conv2d(gz.double(), wt.double().transpose(0, 1), stride=2)
-        ck, nc = co, ci
-    else:                                  # data gradient of the stride-1 conv
-        gz = torch.randn(n, co, h, w, generator=g)
-        xd = gz.to(DEV).contiguous(memory_format=torch.channels_last)
-        cls, ho, wo = H.classes_corr_adjoint(h, w, 3, 3, 1), h, w
-        wp, kw = H.pack_weight_adj(wt.to(DEV)), {}
-        ref = torch.nn.functional.conv_transpose2d(gz.double(), wt.double(), padding=1)
-        ck, nc = co, ci
-    a = H.zeros_cl(n, nc, ho, wo, DEV)
-    assert H.conv_small_atomic(xd, wp, ck, nc, a, cls, **kw) is True
-    b = H.zeros_cl(n, nc, ho, wo, DEV)
-    H.conv_igemm(xd, wp, ck, nc, b, cls, epi=L.EPI_ATOMIC, ksplit=2, precision='f32', **kw)
-    close(a, ref, 2e-5, f'conv_small {kind} vs float64')
-    close(a, b, 2e-5, f'conv_small {kind} vs the implicit GEMM')
-
-
 @pytest.mark.parametrize('n,trainable', [(1, False), (3, False), (2, True)])
 def test_style_bank_matches_torch(n, trainable):
     """fused.StyleBankFn (eg3d_style_affine_fwd / _bwd: the per-layer affines `styles = affine(w) * gain` of networks_stylegan2.py:98-108,129-137 and
@@ -1138,128 +1094,6 @@ def test_conv_v3_full_size_layers_deterministic_and_equal_to_conv_v2():
             close(out, o2, 2e-6, f'conv_v3 vs conv_v2 {h} {plan}')
             outs.append(out)
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[3], outs[4])
-
-
-# ---------------------------------------------------------------------------------------------------------------------------
-# Low-resolution convolution (csrc/conv_lr.hip): fp32 activation in, in-kernel split, deep weight ring, ordered split-K
-# ---------------------------------------------------------------------------------------------------------------------------
-def _lr_plan(H, ci, co, cls, n, ks, rpw=0):
-    plan = H.conv_lr_plan(ci, co, cls, n, force=True, rpw=rpw)         # (the kernel is opt-in: EG3D_CONV_LR)
-    assert plan is not None
-    return (plan[0], ks if ks else plan[1], plan[2])
-
-
-@pytest.mark.parametrize('ks', [0, 1, 2, 8])      # 0: the planner's choice
-@pytest.mark.parametrize('shape', [(1, 512, 4, 4, 512), (1, 64, 8, 8, 128), (2, 128, 16, 16, 256), (1, 32, 32, 32, 128), (1, 64, 64, 64, 128),
-                                   (1, 48, 5, 9, 128), (2, 32, 17, 33, 128)])
-def test_conv_lr_forward_epilogue_vs_torch(shape, ks):
-    """3x3 correlation with the fused forward epilogue on the backbone's low resolutions (4^2 .. 64^2) and ragged grids, tile widths 4 / 8 /
-    16 / 32, with and without the ordered split-K; max|out| reported."""
-    from inv3d_amd import hipops as H, _lib as L
-    n, ci, h, w, co = shape
-    if ks > ci // 16:
-        pytest.skip('more K slices than 16-channel chunks')
-    g = torch.Generator().manual_seed(31)
-    x = torch.randn(n, ci, h, w, generator=g)
-    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)
-    s = 1 + 0.5 * torch.randn(n, ci, generator=g)
-    d = 0.5 + torch.rand(n, co, generator=g)
-    noise, strength = torch.randn(n, 1, h, w, generator=g), torch.tensor(0.3)
-    bias, add = 0.1 * torch.randn(co, generator=g), torch.randn(n, co, h, w, generator=g)
-    z = torch.nn.functional.conv2d(x.double() * s.double()[:, :, None, None], wt.double(), padding=1) * d.double()[:, :, None, None]
-    ref = torch.nn.functional.leaky_relu(z + noise.double() * 0.3 + bias.double()[None, :, None, None], 0.2) * 1.4 + add.double()
-    xc = x.to(DEV).contiguous(memory_format=torch.channels_last)
-    wimg = H.split_weight(H.pack_weight_fwd(wt.to(DEV)), co, ci, 9)
-    cls = H.classes_corr(h, w, 3, 3, 1)
-    out = H.empty_cl(n, co, h, w, DEV)
-    amax = torch.zeros(1, device=DEV)
-    H.conv_lr(xc, H.absmax(xc), wimg, out, cls, _lr_plan(H, ci, co, cls, n, ks), in_scale=s.to(DEV), epi=L.EPI_FWD, out_scale=d.to(DEV), bias=bias.to(DEV),
-              noise=noise.to(DEV).contiguous(), noise_nstride=h * w, noise_strength=strength.to(DEV), act='lrelu', alpha=0.2, gain=1.4, clamp=-1.0,
-              addend=add.to(DEV).contiguous(memory_format=torch.channels_last), out_amax=amax)
-    close(out, ref.float(), 2e-5, f'conv_lr fwd {shape} ks {ks}')
-    assert abs(float(amax) - float(out.abs().max())) == 0.0
-
-
-@pytest.mark.parametrize('rpw,ks', [(2, 1), (2, 3), (4, 1), (4, 2)])
-@pytest.mark.parametrize('shape', [(1, 64, 64, 64, 128), (2, 32, 17, 33, 128), (1, 128, 16, 16, 256), (1, 64, 40, 9, 128)])
-def test_conv_lr_large_tiles_vs_torch(shape, rpw, ks):
-    """The 128- and 256-cell tiles (12 / 24 MFMAs per wave and step) with the fused forward epilogue and the ordered split-K."""
-    from inv3d_amd import hipops as H, _lib as L
-    n, ci, h, w, co = shape
-    g = torch.Generator().manual_seed(34)
-    x = torch.randn(n, ci, h, w, generator=g)
-    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)
-    s = 1 + 0.5 * torch.randn(n, ci, generator=g)
-    d = 0.5 + torch.rand(n, co, generator=g)
-    noise, strength = torch.randn(h, w, generator=g), torch.tensor(0.3)
-    bias = 0.1 * torch.randn(co, generator=g)
-    z = torch.nn.functional.conv2d(x.double() * s.double()[:, :, None, None], wt.double(), padding=1) * d.double()[:, :, None, None]
-    ref = torch.nn.functional.leaky_relu(z + noise.double() * 0.3 + bias.double()[None, :, None, None], 0.2) * 1.4
-    xc = x.to(DEV).contiguous(memory_format=torch.channels_last)
-    wimg = H.split_weight(H.pack_weight_fwd(wt.to(DEV)), co, ci, 9)
-    cls = H.classes_corr(h, w, 3, 3, 1)
-    plan = _lr_plan(H, ci, co, cls, n, ks, rpw)
-    if plan[2] != rpw or ks > ci // 16:
-        pytest.skip('tile size not available for this width / more K slices than chunks')
-    out = H.empty_cl(n, co, h, w, DEV)
-    amax = torch.zeros(1, device=DEV)
-    H.conv_lr(xc, H.absmax(xc), wimg, out, cls, plan, in_scale=s.to(DEV), epi=L.EPI_FWD, out_scale=d.to(DEV), bias=bias.to(DEV), noise=noise.to(DEV),
-              noise_nstride=0, noise_strength=strength.to(DEV), act='lrelu', alpha=0.2, gain=1.4, clamp=-1.0, out_amax=amax)
-    close(out, ref.float(), 2e-5, f'conv_lr rpw {rpw} ks {ks} {shape}')
-    assert abs(float(amax) - float(out.abs().max())) == 0.0
-
-
-@pytest.mark.parametrize('ks', [1, 4])
-@pytest.mark.parametrize('shape', [(2, 128, 16, 16, 128), (1, 256, 8, 8, 128), (1, 128, 24, 40, 64)])
-def test_conv_lr_data_gradient_epilogue_vs_torch(shape, ks):
-    """Data gradient of a 3x3 layer on the low-resolution kernel: adjoint taps on the adjoint weight image, gradient-sized operand
-    (range-normalised by its max), dx = acc * styles + addend, ds = sum_px acc * x."""
-    from inv3d_amd import hipops as H, _lib as L
-    n, ci, h, w, co = shape
-    g = torch.Generator().manual_seed(32)
-    gz = torch.randn(n, co, h, w, generator=g) * 1e-4
-    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)
-    s, xin, add = 1 + 0.5 * torch.randn(n, ci, generator=g), torch.randn(n, ci, h, w, generator=g), torch.randn(n, ci, h, w, generator=g) * 1e-4
-    acc = torch.nn.functional.conv_transpose2d(gz.double(), wt.double(), padding=1)
-    ref_dx = acc * s.double()[:, :, None, None] + add.double()
-    ref_ds = (acc * xin.double()).sum((2, 3))
-    gc = gz.to(DEV).contiguous(memory_format=torch.channels_last)
-    wimg = H.split_weight(H.pack_weight_adj(wt.to(DEV)), ci, co, 9)
-    cls = H.classes_corr_adjoint(h, w, 3, 3, 1)
-    if co % 16 or ci % 128:
-        pytest.skip('geometry outside the kernel')
-    dx, ds = H.empty_cl(n, ci, h, w, DEV), torch.zeros(n, ci, device=DEV)
-    H.conv_lr(gc, H.absmax(gc), wimg, dx, cls, _lr_plan(H, co, ci, cls, n, ks), epi=L.EPI_BWD, out_scale=s.to(DEV),
-              xin=xin.to(DEV).contiguous(memory_format=torch.channels_last), ds=ds, addend=add.to(DEV).contiguous(memory_format=torch.channels_last))
-    close(dx * 1e4, ref_dx.float() * 1e4, 2e-5, 'conv_lr dgrad dx')
-    close(ds * 1e4, ref_ds.float() * 1e4, 5e-5, 'conv_lr dgrad ds')
-
-
-def test_conv_lr_split_k_is_deterministic_and_tickets_reset():
-    """The ordered split-K: repeated launches are bit-identical (the slabs are summed in slice order whatever the arrival order), equal to
-    the un-split launch up to fp32 summation order, and the ticket words are zero again after every launch."""
-    from inv3d_amd import hipops as H, _lib as L
-    n, ci, h, w, co = 1, 512, 16, 16, 512
-    g = torch.Generator().manual_seed(33)
-    x = torch.randn(n, ci, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
-    wt = (torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)).to(DEV)
-    s = (1 + 0.5 * torch.randn(n, ci, generator=g)).to(DEV)
-    wimg = H.split_weight(H.pack_weight_fwd(wt), co, ci, 9)
-    cls = H.classes_corr(h, w, 3, 3, 1)
-    ax = H.absmax(x)
-    outs = []
-    for rep in range(6):
-        out = H.empty_cl(n, co, h, w, DEV)
-        H.conv_lr(x, ax, wimg, out, cls, (4, 8), in_scale=s, epi=L.EPI_STORE)
-        outs.append(out)
-    torch.cuda.synchronize()
-    for o in outs[1:]:
-        assert torch.equal(o, outs[0])
-    one = H.empty_cl(n, co, h, w, DEV)
-    H.conv_lr(x, ax, wimg, one, cls, (4, 1), in_scale=s, epi=L.EPI_STORE)
-    ref = torch.nn.functional.conv2d(x.double() * s.double()[:, :, None, None], wt.double(), padding=1).float()
-    close(outs[0], ref, 2e-5, 'conv_lr split-K vs fp64')
-    close(one, ref, 2e-5, 'conv_lr un-split vs fp64')
 
 
 @pytest.mark.parametrize('rows', [8, 4, 2])
