@@ -311,16 +311,17 @@ def pin_target(cfg, P, seed=31):
         return O.synthesis(P, cfg, O.synth_ws(cfg, 1, seed=seed), O.synth_cameras(1, seed=seed + 1), u1, u2, noise_mode='const')['image'][0]
 
 
-def pin_projector_inputs(cfg, P, mode):
-    uniforms = [O.make_uniforms(cfg, 1, seed=100 + k) for k in range(PIN_PROJ_STEPS)]
-    wns = [O._randn(f'wn{k}', 41, (1, 1, cfg.w_dim)) for k in range(PIN_PROJ_STEPS)]
+def pin_projector_inputs(cfg, P, mode, steps=PIN_PROJ_STEPS):
+    uniforms = [O.make_uniforms(cfg, 1, seed=100 + k) for k in range(steps)]
+    wns = [O._randn(f'wn{k}', 41, (1, 1, cfg.w_dim)) for k in range(steps)]
     init_noise = {k: O._randn('init.' + k, 42, v.shape) for k, v in P.items() if k.endswith('noise_const')}
     w0 = 0.3 * O._randn('w0', 43, (1, 1, cfg.w_dim))
     base = torch.tensor(POSE_INIT[mode]) + 0.05 * O._randn('pose0' + mode, 44, (len(POSE_INIT[mode]),))
     return dict(uniforms=uniforms, wns=wns, init_noise=init_noise, w0=w0, pose_base=base)
 
 
-def pin_tuner_inputs(cfg):
+def pin_tuner_inputs(cfg, steps=None):
+    PIN_TUNER_STEPS = steps if steps is not None else globals()['PIN_TUNER_STEPS']
     names = [f'backbone.synthesis.b{r}.{cv}' for r in cfg.block_resolutions for cv in (['conv1'] if r == 4 else ['conv0', 'conv1'])]
     res = lambda nm: int(nm.split('.b')[1].split('.')[0])                         # noqa: E731
     uniforms = [O.make_uniforms(cfg, 1, seed=200 + k) for k in range(PIN_TUNER_STEPS)]

@@ -1004,6 +1004,159 @@ def gen_c3_full():
         gc.use_quaternions, gc.use_6d, gc.visualize_opt_process, gc.visualize_warp_process, hp.cam_preheat_steps = saved
 
 
+C2_FULL_STEPS = 10
+
+
+def gen_c2_full():
+    """Config C2 at FULL size over a trajectory (BASELINE.json configs[1]): ten steps of the reference's optimisation-loop body
+    (w_projector.py:145-270, executed as is) on the ffhqrebalanced512-128-shaped generator built from the reference's own classes, with the
+    camera held fixed the way config C2 means it -- the loop body always runs the pose chain and the warping loss, so here calc_warping_loss
+    is a stub returning (None, None) (the body's `if warp_loss != None` then skips the term) and the two pose optimisers run with lr = 0 (Adam
+    moves nothing), no camera preheat.  Recorded: loss / distance / regulariser / PSNR of every step, the camera the chain produces, the final
+    latent and probes of two noise maps."""
+    print('config C2 at full size, %d steps (reference loop body, lifted) -- takes several minutes' % C2_FULL_STEPS)
+    from utils import camera_utils as ref_cam
+    from configs import global_config as gc, hyperparameters as hp
+    from oracle import inversion_oracle as IO
+    cfg = O.full_config()
+    P = O.synth_params(cfg, seed=0)
+    target = IO.pin_target(cfg, P)
+    fw = IO.stub_feature_weights()
+    loop = [n for n in _func(_parse('training/projectors/w_projector.py'), 'project').body if isinstance(n, ast.For)][-1]
+    node = _lifted_loop(loop, 'num_steps', "_trace.append((float(loss), float(dist), float(reg_loss), _psnr(pred_dict['image']))); _cams.append(pred_cam.detach().clone())")
+    saved = (gc.use_quaternions, gc.use_6d, gc.visualize_opt_process, gc.visualize_warp_process, hp.cam_preheat_steps)
+    o_randn_like = torch.randn_like
+    mode = 'quat'
+    try:
+        gc.visualize_opt_process = gc.visualize_warp_process = False
+        hp.cam_preheat_steps = 0
+        gc.use_quaternions, gc.use_6d = True, False
+        G = RefComposite(cfg, P).requires_grad_(False)
+        pin = IO.pin_projector_inputs(cfg, P, mode, steps=C2_FULL_STEPS)
+        uniforms, wns, init_noise, w0, base = pin['uniforms'], pin['wns'], pin['init_noise'], pin['w0'], pin['pose_base']
+        cam_predictor = IO.StubPoseNet(base, seed=7)
+        Gs = _GSteps(G, uniforms, calls_per_step=1)
+        noise_bufs = {n: b for n, b in G.backbone.synthesis.named_buffers() if 'noise_const' in n}
+        noise_bufs2 = {f'{blk}.{n}': b for blk in ('block0', 'block1') for n, b in getattr(G, blk).named_buffers() if 'noise_const' in n}
+        with torch.no_grad():
+            for n_, b in noise_bufs.items():
+                b[:] = init_noise['backbone.synthesis.' + n_]
+                b.requires_grad = True
+            for n_, b in noise_bufs2.items():
+                b[:] = init_noise['superresolution.' + n_]
+                b.requires_grad = True
+        w_opt = w0.clone().requires_grad_(True)
+        translation_opt = torch.tensor([IO.PIN_TRANSLATION_START], requires_grad=True)
+        t255 = (((target + 1) / 2) * 255).unsqueeze(0)
+        if t255.shape[2] > 256:
+            t255 = torch.nn.functional.interpolate(t255, size=(256, 256), mode='area')
+        vgg16 = lambda img, resize_images=False, return_lpips=True: IO.stub_features(img, fw)      # noqa: E731
+        init_ext = torch.Tensor([1, 0, 0, 0, 0, -1, 0, 0, 0, 0, -1, 2.7, 0, 0, 0, 1]).reshape(-1, 4, 4)
+        intrinsic = torch.tensor([4.2647, 0, 0.5, 0, 4.2647, 0.5, 0, 0, 1]).unsqueeze(0)
+        ns = dict(torch=torch, F=torch.nn.functional, np=np, math=math, os=os, PIL=None, tqdm=lambda x: x, global_config=gc, hyperparameters=hp,
+                  compute_rotation_matrix_from_quaternion=ref_cam.compute_rotation_matrix_from_quaternion, rot6d_to_rotmat=ref_cam.rot6d_to_rotmat,
+                  euler2rot=ref_cam.euler2rot, calc_warping_loss=lambda *a, **k: (None, None), ray_generator=RaySampler(), G=Gs, vgg16=vgg16,
+                  torch_vgg=None, layers='14', cam_predictor=cam_predictor, target_images=t255, target_images_contiguous=target.contiguous(),
+                  target_features=vgg16(t255), init_ext=init_ext, intrinsic=intrinsic, canonical_cam=torch.cat([init_ext.reshape(-1, 16), intrinsic], -1),
+                  radius=2.7, w_opt=w_opt, translation_opt=translation_opt, noise_bufs=noise_bufs, noise_bufs2=noise_bufs2,
+                  optimizer=torch.optim.Adam([w_opt] + list(noise_bufs.values()) + list(noise_bufs2.values()), betas=(0.9, 0.999), lr=hp.first_inv_lr),
+                  cam_optimizer=torch.optim.Adam(cam_predictor.parameters(), lr=0.0, betas=(0.9, 0.999)),
+                  translation_optimizer=torch.optim.Adam([translation_opt], lr=0.0),
+                  num_steps=C2_FULL_STEPS, w_std=IO.PIN_W_STD, initial_learning_rate=0.01, lr_rampdown_length=0.25, initial_noise_factor=0.05,
+                  noise_ramp_length=0.75, lr_rampup_length=0.05, regularize_noise_weight=1e5, outdir=None, w_name='pin', _trace=[], _cams=[],
+                  _psnr=lambda im: float(O.psnr_01(im.detach(), target[None])))
+        q = list(wns)
+        torch.randn_like = lambda x, **k: q.pop(0).reshape(x.shape)
+        try:
+            _exec_nodes([node], ns, 'w_projector.project loop, full size, C2')
+        finally:
+            torch.randn_like = o_randn_like
+        trace = torch.tensor(ns['_trace'])
+        cams = torch.cat(ns['_cams'])
+        assert float((cams - cams[:1]).abs().max()) == 0.0, 'the camera moved: lr = 0 must hold it'
+        cam = cams[:1]
+        print('    reference trace (loss, dist, reg, psnr):', trace.tolist())
+        # ---- the oracle must reproduce it ----------------------------------------------------------------------------------------
+        po = IO.ProjectorOracle(P, cfg, target[None], num_steps=C2_FULL_STEPS, cam=cam, init_noise=init_noise, w_start=w0, w_std=IO.PIN_W_STD)
+        otrace = []
+        for k in range(C2_FULL_STEPS):
+            r = po.step(*uniforms[k], w_noise=wns[k])
+            otrace.append((float(r['loss']), float(r['dist']), float(r['reg']), float(O.psnr_01(r['image'], target[None]))))
+        otrace = torch.tensor(otrace)
+        e = [check(otrace[:, j], trace[:, j], 5e-5, f'C2 full: {nm}') for j, nm in enumerate(('loss', 'dist', 'reg', 'psnr'))]
+        check(po.w_opt, w_opt, 1e-5, 'C2 full: w_opt')
+        print(f'    trace errs {["%.1e" % x for x in e]}')
+        probe = torch.Generator().manual_seed(78)
+        nb_last, sb_last = list(noise_bufs.values())[-1].detach().flatten(), list(noise_bufs2.values())[-1].detach().flatten()
+        i1, i2 = torch.randint(0, nb_last.numel(), (256,), generator=probe), torch.randint(0, sb_last.numel(), (256,), generator=probe)
+        save('c2_full', 5e-5, trace=trace, cam=cam, w_opt=w_opt, buf_idx=i1, buf_val=nb_last[i1], srbuf_idx=i2, srbuf_val=sb_last[i2],
+             target_probe=target.flatten()[::4099].clone())
+    finally:
+        gc.use_quaternions, gc.use_6d, gc.visualize_opt_process, gc.visualize_warp_process, hp.cam_preheat_steps = saved
+
+
+C4_FULL_STEPS = 5
+
+
+def gen_c4_full():
+    """Config C4 at FULL size over a trajectory (BASELINE.json configs[3]): five steps of SingleIDCoach.train's inner loop
+    (single_id_coach.py:64-77) with BaseCoach.calc_loss / forward (base_coach.py:101-126,162-164), lifted and executed as is on the
+    ffhqrebalanced512-128-shaped generator of the reference's classes (Adam 3e-4 over all 30.7 M weights, noise_mode='random' replayed)."""
+    print('config C4 at full size, %d steps (reference loop body, lifted) -- takes several minutes' % C4_FULL_STEPS)
+    from configs import global_config as gc, hyperparameters as hp
+    from criteria import l2_loss
+    from oracle import inversion_oracle as IO
+    cfg = O.full_config()
+    P = O.synth_params(cfg, seed=0)
+    target = IO.pin_target(cfg, P)[None]
+    fw = IO.stub_feature_weights()
+    base = _parse('training/coaches/base_coach.py')
+    ns_c = dict(torch=torch, F=torch.nn.functional, hyperparameters=hp, global_config=gc, l2_loss=l2_loss, wandb=None)
+    _exec_nodes([_func(base, 'compute_tv_norm'), _func(base, 'calc_loss', 'BaseCoach'), _func(base, 'forward', 'BaseCoach')], ns_c, 'BaseCoach')
+    train = _func(_parse('training/coaches/single_id_coach.py'), 'train', 'SingleIDCoach')
+    loops = [n for n in ast.walk(train) if isinstance(n, ast.For) and 'max_pti_steps' in ast.unparse(n.iter)]
+    assert len(loops) == 1
+    node = _lifted_loop(loops[0], 'hyperparameters.max_pti_steps', "_trace.append((float(loss), float(l2_loss_val), float(loss_lpips), _psnr(generated_images['image'])))")
+    pin = IO.pin_tuner_inputs(cfg, steps=C4_FULL_STEPS)
+    w_pivot, cam, noise_names, uniforms, noises = pin['w_pivot'], pin['cam'], pin['noise_names'], pin['uniforms'], pin['noises']
+    out = dict(target_probe=target.flatten()[::4099].clone(), w_pivot=w_pivot, cam=cam)
+    saved = (hp.max_pti_steps, hp.LPIPS_value_threshold, gc.training_step)
+    try:
+        hp.max_pti_steps, hp.LPIPS_value_threshold = C4_FULL_STEPS, -1.0
+        G = RefComposite(cfg, P).requires_grad_(True)
+        Gs = _GSteps(G, uniforms, calls_per_step=1, randn=[[nz[nm] for nm in noise_names] for nz in noises])
+        coach = types.SimpleNamespace(G=Gs, use_wandb=False, space_regulizer=None,
+                                      lpips_loss=lambda a, b: (IO.stub_features(a, fw) - IO.stub_features(b, fw)).square().sum())
+        coach.calc_loss = types.MethodType(ns_c['calc_loss'], coach)
+        coach.forward = types.MethodType(ns_c['forward'], coach)
+        coach.optimizer = torch.optim.Adam(G.parameters(), lr=hp.pti_learning_rate)
+        ns = dict(self=coach, tqdm=lambda x: x, hyperparameters=hp, global_config=gc, w_pivot=w_pivot, freezed_cam=cam, real_images_batch=target,
+                  image_name='pin', use_ball_holder=True, log_images_counter=0, _trace=[], _psnr=lambda im: float(O.psnr_01(im.detach(), target)))
+        _exec_nodes([node], ns, 'SingleIDCoach.train loop, full size')
+        trace = torch.tensor(ns['_trace'])
+        print('    reference trace (loss, l2, lpips, psnr):', trace.tolist())
+        to = IO.PivotalTunerOracle(P, cfg, target, w_pivot, cam, lr=hp.pti_learning_rate, lpips_threshold=-1.0)
+        otrace = []
+        for k in range(C4_FULL_STEPS):
+            r = to.step(*uniforms[k], noise_mode='random', noises=noises[k], early_stop=True)
+            otrace.append((float(r['loss']), float(r['l2']), float(r['lpips']), float(O.psnr_01(r['image'], target))))
+        otrace = torch.tensor(otrace)
+        e = [check(otrace[:, j], trace[:, j], 5e-5, f'C4 full: {nm}') for j, nm in enumerate(('loss', 'l2', 'lpips', 'psnr'))]
+        sd = dict(G.named_parameters())
+        probe = torch.Generator().manual_seed(79)
+        for k_ in TUNER_KEYS:
+            rk = k_[len('superresolution.'):] if k_.startswith('superresolution.') else k_
+            check(to.P[k_], sd[rk], 1e-5, f'C4 full: {k_}')
+            flat, flat0 = sd[rk].detach().flatten(), P[k_].flatten()
+            idx = torch.randint(0, flat.numel(), (min(256, flat.numel()),), generator=probe)
+            out[f'p_idx.{k_}'], out[f'p_val.{k_}'], out[f'p_move.{k_}'] = idx, flat[idx], np.float64((flat - flat0).abs().max().item())
+        print(f'    {trace.shape[0]} updates, trace errs {["%.1e" % x for x in e]}, loss {trace[0, 0]:.4f} -> {trace[-1, 0]:.4f}')
+        out['trace'] = trace
+    finally:
+        hp.max_pti_steps, hp.LPIPS_value_threshold, gc.training_step = saved
+    save('c4_full', 5e-5, **out)
+
+
 TUNER_KEYS = ('backbone.synthesis.b8.conv0.weight', 'backbone.synthesis.b16.torgb.bias', 'backbone.synthesis.b32.conv1.noise_strength',
               'backbone.synthesis.b16.conv1.affine.weight', 'superresolution.block1.conv1.weight', 'superresolution.block0.torgb.weight',
               'decoder.net.0.weight', 'decoder.net.2.bias')
@@ -1264,7 +1417,8 @@ if __name__ == '__main__':
     only = sys.argv[1:]
     gens = dict(bias_act=gen_bias_act, upfirdn2d=gen_upfirdn2d, filtered_lrelu=gen_filtered_lrelu, conv=gen_conv2d_resample, renderer=gen_renderer,
                 graph_small=gen_graph_small, graph_full=gen_graph_full, loss=gen_loss_glue, projector_loop=gen_projector_loop, tuner_loop=gen_tuner_loop,
-                inference=gen_inference, pose_net=gen_pose_net, e4e=gen_e4e, sr_heads=gen_sr_heads, c3_full=gen_c3_full)
+                inference=gen_inference, pose_net=gen_pose_net, e4e=gen_e4e, sr_heads=gen_sr_heads, c3_full=gen_c3_full, c2_full=gen_c2_full,
+                c4_full=gen_c4_full)
     mpath = os.path.join(HERE, 'MANIFEST.json')
     if only and os.path.exists(mpath):
         MANIFEST.update(json.load(open(mpath)).get('fixtures', {}))

@@ -167,7 +167,10 @@ def test_sr_heads_fixture(golden, kind):
             # stable, except that one run in four lands on another branch of an lrelu kink / the +-256 clamp for a few elements (fp32 atomics
             # order moves a pre-activation by an ulp) and then shows 6e-5 (x), 2.4e-4 (ws), 1.4e-3 (noise_strength).
             tol = 2e-3 if nm.endswith('noise_strength') else (1e-3 if nm == 'ws' else (3e-4 if nm in ('x', 'rgb') else 5e-4))
-            if DET:           # deterministic build (EG3D_DETERMINISTIC=1, csrc/det.h): exact sums, no run-to-run spread -- a third of the bounds above
+            if DET and not nm.endswith('noise_strength'):
+                # deterministic build (EG3D_DETERMINISTIC=1, csrc/det.h): exact sums, no run-to-run spread -- a third of the bounds above.  (Not for
+                # noise_strength: its spread is the lrelu-kink / clamp branch of a few elements, which moves with the ROUNDING of the conv that
+                # produced the pre-activation -- another kernel (conv_v3 on the 'small' head since r5) lands on another branch: 7.7e-4.)
                 tol /= 3.0
             close(gv.flatten()[t(d[f'{kind}.{tag}.gidx.{nm}'])], d[f'{kind}.{tag}.gval.{nm}'], tol, f'{kind} {tag} d {nm}')
             stat = d[f'{kind}.{tag}.gstat.{nm}']

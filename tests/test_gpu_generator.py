@@ -192,7 +192,7 @@ def test_graph_full_weight_grads_golden(golden, arith):
     g_dep = O._randn('gf_dep', 8, o['image_depth'].shape) / (128 * 128)
     grads = torch.autograd.grad([o['image'], o['image_depth']], [ws, c] + leaves, [g_img.to(DEV), g_dep.to(DEV)])
     close(grads[0], d['dws'], 2e-3 if arith == 'f16x3' else 2e-2, 'full d ws (all weights trainable)')
-    worst = {}
+    worst, bad = {}, []
     for k, gv in zip(wkeys, grads[2:]):
         ref_norm, ref_max = [float(v) for v in d['wg_stat.' + k]]
         flat = gv.detach().flatten()
@@ -204,14 +204,19 @@ def test_graph_full_weight_grads_golden(golden, arith):
         # samples that land one texel over) and every gradient inherits that; observed 0.5e-4 .. 9e-4 of max|g|, varying from run to run
         # with the order of the atomically accumulated sums -- bound 3e-3
         tol = 3e-3 if arith == 'f16x3' else 5e-2
-        if DET and arith == 'f16x3':      # deterministic build: exact accumulation, a third of the atomics path's bound (the sr_f16x1 bound is
-            tol /= 3.0                    # operand rounding of the fp16 head, not summation order)
+        # (round 4 held a third of that under the deterministic build.  Round 5 measured the four combinations {conv_v3 on / off} x {exact /
+        #  atomic accumulation}: b128.conv1.bias sits at 2.4e-3 in three of them and at 3.7e-4 in one, b32.conv0.noise_const at 1.1e-3 / 5.5e-4 --
+        #  the worst entries are lrelu-kink branches of a few pre-activations that flip with ANY one-ulp change upstream (another kernel's summation
+        #  order as much as an atomic's), deterministic but not smaller in the exact build.  Same bound in both builds.)
         err = float((got - ref).abs().max())
         worst[k] = err / ref_max
-        assert err <= tol * ref_max, f'd {k}: probe err {err:.3e} > {tol} * max|g| {ref_max:.3e}'
         nrm = float(flat.double().norm())
-        assert abs(nrm - ref_norm) <= 2 * tol * ref_norm, f'd {k}: norm {nrm:.6e} vs {ref_norm:.6e}'
-    print({k: f'{v:.1e}' for k, v in worst.items()})
+        if err > tol * ref_max:
+            bad.append(f'd {k}: probe err {err:.3e} > {tol} * max|g| {ref_max:.3e}')
+        if abs(nrm - ref_norm) > 2 * tol * ref_norm:
+            bad.append(f'd {k}: norm {nrm:.6e} vs {ref_norm:.6e}')
+    print({k: f'{v:.1e}' for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:12]})
+    assert not bad, bad
 
 
 def test_cpu_tensors_fail_loudly():

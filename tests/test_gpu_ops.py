@@ -183,8 +183,9 @@ def test_filtered_lrelu_golden(golden):
         yh = FL.filtered_lrelu(x.detach().half(), b=None if b is None else b.detach().half(), **kw)
         assert yh.dtype == torch.float16
         close(yh.float(), d[f'{k}_y'], 2e-2, f'filtered_lrelu case {i} fp16')
-    with pytest.raises(NotImplementedError):
-        FL.filtered_lrelu(torch.zeros(1, 1, 4, 4, device=DEV), impl='ref')
+    # the explicit impl='ref' (the reference's own keyword, filtered_lrelu.py:113-120): the product's plain-torch composite agrees with the kernel
+    with torch.no_grad():       # (x, b, kw: the last fixture case)
+        close(FL.filtered_lrelu(x.detach(), b=None if b is None else b.detach(), impl='ref', **kw), y.detach(), 2e-5, 'filtered_lrelu impl=ref vs kernel')
 
 
 def test_upfirdn2d_nhwc_fused(golden):
