@@ -129,6 +129,13 @@ def test_noise_const_gradient():
         close(a, b, 5e-4, f'd {k}')
 
 
+# Full-size d ws / d c against the reference's own class, RELATIVE to the gradient's largest entry.  Measured in round 5 (normal and
+# deterministic build, two runs each): d ws 3.8e-4 .. 4.1e-4, d c 1.14e-2 .. 1.25e-2 (absolute 2.8e-5 on entries of 2.4e-3: the camera
+# gradient is a sum over 16 384 rays of per-ray terms that are piecewise constant in the sample position -- a sample one ulp across a texel
+# boundary changes its ray's term by O(1 / samples); the same in both builds, i.e. not summation order).  Bounds = worst observed x 3.
+EWS_BOUND, EC_BOUND = 1.5e-3, 4e-2
+
+
 def test_graph_full_golden(golden):
     """Full-size ffhqrebalanced512-128-shaped generator vs the reference's own TriPlaneGenerator (probe samples)."""
     from inv3d_amd import synthetic as S
@@ -156,8 +163,13 @@ def test_graph_full_golden(golden):
     g_img = O._randn('gf_img', 8, img.shape) / (3 * 512 * 512)
     g_dep = O._randn('gf_dep', 8, dep.shape) / (128 * 128)
     dws, dc = torch.autograd.grad([img, dep], [ws, c], [g_img.to(DEV), g_dep.to(DEV)])
-    close(dws, d['dws'], 2e-3, 'full d ws')
-    close(dc, d['dc'], 1e-2, 'full d c')
+    rel = lambda a, b: float((a.detach().cpu().double() - t(b).cpu().double()).abs().max() / float(t(b).abs().max()))      # noqa: E731
+    e_ws, e_c = rel(dws, d['dws']), rel(dc, d['dc'])
+    print(f'full-size gradient errors relative to max|ref|: d ws {e_ws:.2e}, d c {e_c:.2e}')
+    # rounds 1-4 held 2e-3 / 1e-2 of max(1, max|ref|) -- with gradients of size 1e-4 that bound said nothing.  Relative to the gradient's own
+    # largest entry (both builds, two runs each in round 5: see DESIGN.md section 4)
+    assert e_ws <= EWS_BOUND, e_ws
+    assert e_c <= EC_BOUND, e_c
 
 
 @pytest.mark.parametrize('arith', ['f16x3', 'sr_f16x1'])

@@ -338,8 +338,11 @@ def test_config_c3_at_full_size(golden):
         # gradients of this step (they stay in .grad until the next step clears them)
         dt, dp = hip.translation_opt.grad.detach().cpu(), net.base.grad.detach().cpu()
         rt, rp = g('d_translation')[k], g('d_pose_base')[k]
-        assert float((dt - rt).abs().max()) <= 0.03 * float(rt.abs().max()) + 1e-7, (k, dt, rt)
-        assert float((dp - rp).abs().max()) <= 0.03 * float(rp.abs().max()) + 1e-7, (k, dp, rp)
+        print(f'C3 full step {k}: d translation rel err {float((dt - rt).abs().max() / rt.abs().max()):.2e}, d pose rel err {float((dp - rp).abs().max() / rp.abs().max()):.2e}')
+        # rounds 3-4 allowed 3 % here (and 5 % on the Adam moves below); measured in round 5, both builds, two runs each: d translation
+        # 0.9e-5 .. 4.6e-5, d pose 2.9e-4 .. 3.8e-4, translation move 1.3e-4 .. 3.4e-4, pose move 0 -- bounds = worst observed x 3..4
+        assert float((dt - rt).abs().max()) <= 2e-4 * float(rt.abs().max()) + 1e-9, (k, dt, rt)
+        assert float((dp - rp).abs().max()) <= 1.2e-3 * float(rp.abs().max()) + 1e-9, (k, dp, rp)
     dw = hip.w_opt.grad.detach().cpu().flatten()
     ref_dw, stat = g('dw_val'), np.asarray(d['dw_stat'])
     assert float((dw[g('dw_idx')] - ref_dw).abs().max()) <= 5e-3 * float(stat[1]), 'd latent (probes) vs the reference'
@@ -347,10 +350,93 @@ def test_config_c3_at_full_size(golden):
     assert float((hip.w_opt.detach().cpu() - g('w_opt')).abs().max()) < 2e-4
     mv_ref = g('translation') - torch.tensor([IO.PIN_TRANSLATION_START])
     mv_hip = hip.translation_opt.detach().cpu() - torch.tensor([IO.PIN_TRANSLATION_START])
-    assert float((mv_hip - mv_ref).abs().max()) <= 0.05 * float(mv_ref.abs().max()), (mv_hip, mv_ref)
+    print(f'C3 full: translation move rel err {float((mv_hip - mv_ref).abs().max() / mv_ref.abs().max()):.2e}')
+    assert float((mv_hip - mv_ref).abs().max()) <= 1e-3 * float(mv_ref.abs().max()), (mv_hip, mv_ref)
     mv_ref = g('pose_base') - pin['pose_base'].reshape(1, -1)
     mv_hip = net.base.detach().cpu() - pin['pose_base'].reshape(1, -1)
-    assert float((mv_hip - mv_ref).abs().max()) <= 0.05 * float(mv_ref.abs().max()) + 1e-9
+    print(f'C3 full: pose move rel err {float((mv_hip - mv_ref).abs().max() / mv_ref.abs().max()):.2e}')
+    assert float((mv_hip - mv_ref).abs().max()) <= 1e-3 * float(mv_ref.abs().max()) + 1e-9
+
+
+def test_config_c2_at_full_size_trajectory(golden):
+    """BASELINE.json configs[1] at FULL size over TEN steps against the reference itself (tests/golden/make_golden.py::gen_c2_full: the loop body
+    of w_projector.project, w_projector.py:145-270, executed as is on the 512^2 / 128^2 generator built from the reference's classes, camera
+    held fixed): the north-star bar -- per-step PSNR drift <= 1e-3 dB -- and loss <= 1e-4 relative, on every step; final latent and noise maps."""
+    from inv3d_amd import synthetic as S
+    from inv3d_amd.inversion import LatentProjector
+    d = golden('c2_full')
+    cfg = O.full_config()
+    P = O.synth_params(cfg, seed=0)
+    G = S.make_generator(device=DEV)
+    S.load_synthetic_weights(G, 0)
+    steps = int(np.asarray(d['trace']).shape[0])
+    pin = IO.pin_projector_inputs(cfg, P, 'quat', steps=steps)
+    target = IO.pin_target(cfg, P)[None]
+    assert float((target[0].flatten()[::4099] - torch.from_numpy(np.asarray(d['target_probe']))).abs().max()) <= 2e-5
+    target = target.to(DEV)
+    g = lambda k: torch.from_numpy(np.asarray(d[k]))           # noqa: E731
+    hip = LatentProjector(G, target, num_steps=steps, cam=g('cam').to(DEV), init_noise=pin['init_noise'], start_w=pin['w0'], w_std=IO.PIN_W_STD)
+    ref = g('trace').double()
+    worst_db = worst_loss = 0.0
+    for k in range(steps):
+        u1, u2 = pin['uniforms'][k]
+        h = hip.step(w_noise=pin['wns'][k], render_uniforms=(u1.to(DEV), u2.to(DEV)))
+        got = [float(h['loss']), float(h['dist']), float(h['reg']) / 1e5, _psnr(h['image'], target.cpu())]
+        worst_loss = max(worst_loss, abs(got[0] - float(ref[k, 0])) / abs(float(ref[k, 0])))
+        worst_db = max(worst_db, abs(got[3] - float(ref[k, 3])))
+        assert abs(got[0] - float(ref[k, 0])) <= 1e-4 * abs(float(ref[k, 0])), (k, 'loss', got[0], float(ref[k, 0]))
+        assert abs(got[1] - float(ref[k, 1])) <= 2e-3 * max(1.0, abs(float(ref[k, 1]))), (k, 'dist', got[1], float(ref[k, 1]))
+        assert abs(got[2] - float(ref[k, 2])) <= 1e-4 * max(1.0, abs(float(ref[k, 2]))), (k, 'reg', got[2], float(ref[k, 2]))
+        assert abs(got[3] - float(ref[k, 3])) <= 1e-3, f'step {k}: PSNR drift {abs(got[3] - float(ref[k, 3])):.2e} dB vs the reference'
+    print(f'C2 full size, {steps} steps: worst PSNR drift {worst_db:.2e} dB, worst relative loss drift {worst_loss:.2e}')
+    assert float((hip.w_opt.detach().cpu() - g('w_opt')).abs().max()) < 5e-4
+    bufs = {n: b for n, b in G.named_buffers() if 'noise_const' in n}
+    nb = [b for n, b in bufs.items() if n.startswith('backbone.')][-1].detach().flatten().cpu()
+    sb = [b for n, b in bufs.items() if n.startswith('superresolution.')][-1].detach().flatten().cpu()
+    # Adam normalises every element's first moves to ~lr whatever the gradient's size: elements whose gradient is at rounding level may differ by a
+    # step -- all but 0.5 % within 1e-4, none further than the moves of the ten steps
+    for got_b, idx, val, nm in ((nb, g('buf_idx'), g('buf_val'), 'backbone noise map'), (sb, g('srbuf_idx'), g('srbuf_val'), 'SR noise map')):
+        e = (got_b[idx] - val).abs()
+        assert float((e > 1e-4).float().mean()) <= 0.005 and float(e.max()) <= steps * 0.011, (nm, float(e.max()), float((e > 1e-4).float().mean()))
+
+
+def test_config_c4_at_full_size_trajectory(golden):
+    """BASELINE.json configs[3] at FULL size over FIVE updates against the reference itself (gen_c4_full: SingleIDCoach.train's loop,
+    single_id_coach.py:64-77, with BaseCoach.calc_loss / forward lifted, on the 30.7 M-parameter generator of the reference's classes; Adam 3e-4
+    over every weight, noise_mode='random' replayed): per-step PSNR drift <= 1e-3 dB, losses <= 1e-4 relative, probes of eight tuned tensors."""
+    from inv3d_amd import synthetic as S
+    from inv3d_amd.inversion import PivotalTuner
+    d = golden('c4_full')
+    cfg = O.full_config()
+    P = O.synth_params(cfg, seed=0)
+    G = S.make_generator(device=DEV)
+    S.load_synthetic_weights(G, 0)
+    ref = torch.from_numpy(np.asarray(d['trace'])).double()
+    steps = int(ref.shape[0])
+    pin = IO.pin_tuner_inputs(cfg, steps=steps)
+    target = IO.pin_target(cfg, P)[None]
+    assert float((target[0].flatten()[::4099] - torch.from_numpy(np.asarray(d['target_probe']))).abs().max()) <= 2e-5
+    hip = PivotalTuner(G, target.to(DEV), pin['w_pivot'].to(DEV), pin['cam'].to(DEV), lr=3e-4, lpips_threshold=-1.0, sr_fp16=False)
+    worst_db = worst_loss = 0.0
+    for k in range(steps):
+        u1, u2 = pin['uniforms'][k]
+        h = hip.step(early_stop=True, noise_mode='random', noise_inject={a: b.to(DEV) for a, b in pin['noises'][k].items()},
+                     render_uniforms=(u1.to(DEV), u2.to(DEV)))
+        assert not h['done']
+        got = [float(h['loss']), float(h['l2']), float(h['lpips']), _psnr(h['image'], target)]
+        for j, nm in enumerate(('loss', 'l2', 'lpips')):
+            assert abs(got[j] - float(ref[k, j])) <= 1e-4 * max(1.0, abs(float(ref[k, j]))), (k, nm, got[j], float(ref[k, j]))
+        worst_loss = max(worst_loss, abs(got[0] - float(ref[k, 0])) / abs(float(ref[k, 0])))
+        worst_db = max(worst_db, abs(got[3] - float(ref[k, 3])))
+        assert abs(got[3] - float(ref[k, 3])) <= 1e-3, f'step {k}: PSNR drift {abs(got[3] - float(ref[k, 3])):.2e} dB vs the reference'
+    print(f'C4 full size, {steps} updates: worst PSNR drift {worst_db:.2e} dB, worst relative loss drift {worst_loss:.2e}')
+    sd = G.state_dict()
+    for key in [k[len('p_idx.'):] for k in d.files if k.startswith('p_idx.')]:
+        idx, val, move = torch.from_numpy(np.asarray(d['p_idx.' + key])), torch.from_numpy(np.asarray(d['p_val.' + key])), float(d['p_move.' + key])
+        e = (sd[key].detach().flatten().cpu()[idx] - val).abs()
+        # every weight has moved by ~ steps x lr; the tuned value must agree to a fraction of that move (Adam's sign-like first steps amplify
+        # rounding-level gradient differences of near-zero entries: all but 1 % within 2 % of the largest move)
+        assert float((e > 0.02 * move).float().mean()) <= 0.01 and float(e.max()) <= 0.5 * move, (key, float(e.max()), move)
 
 
 def test_tuner_loop_vs_reference(golden):
