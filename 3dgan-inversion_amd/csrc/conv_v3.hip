@@ -196,15 +196,92 @@ __device__ __forceinline__ void v3_epilogue(const eg3d_conv_v2_params& p, const 
     eg3d_commit_amax_block(amax, p.out_amax);
 }
 
+// ---- after the main loop: the NW partial tiles meet in LDS, the sum is staged as [cell][64] and the fused epilogue runs on it ---------------
+template <int RPW, int NW>
+__device__ __forceinline__ void v3_finish(const eg3d_conv_v2_params& p, f32x16 (&acc)[RPW][2], char* smem, const int wave, const int lane, const int Ha, const int Wa,
+                                          const int out_py, const int out_px, const int n, const int y0, const int x0, const int n0) {
+    constexpr int T = 2 * RPW;                            // 32 x 32 accumulator tiles of the workgroup tile
+    constexpr int OWN = NW < T ? NW : T;                  // waves that own tiles after the reduction
+    constexpr int TPO = T / OWN;                          // tiles per owner
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- reduction over the NW K slices: tile t = 2 i + j belongs to wave t / TPO; the others hand their partial tile over through LDS ------
+    const float out_mul = 1.f / (*p.a_scale * *p.w_scale);
+    {
+        f32x4v* part = reinterpret_cast<f32x4v*>(smem);               // block (t, s') = 16 x 64 floats as [r / 4][lane][4]
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int t = 2 * i + j, o = t / TPO;
+                if (wave != o) {
+                    const int sp = wave < o ? wave : wave - 1;
+                    f32x4v* dst = part + (t * (NW - 1) + sp) * 256 + lane;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dst[q * 64] = f32x4v{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                }
+            }
+        __syncthreads();
+        if (wave < OWN) {
+#pragma unroll
+            for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int t = 2 * i + j;
+                    if (t / TPO != wave) continue;
+                    f32x16 sum;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum[r] = 0.f;
+                    bool first = true;
+#pragma unroll
+                    for (int s = 0; s < NW; ++s) {                 // ascending slice order, whoever owns the tile
+                        f32x16 v;
+                        if (s == wave) {
+                            v = acc[i][j];
+                        } else {
+                            const int sp = s < wave ? s : s - 1;
+                            const f32x4v* src = part + (t * (NW - 1) + sp) * 256 + lane;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const f32x4v w4 = src[q * 64];
+                                v[4 * q] = w4[0]; v[4 * q + 1] = w4[1]; v[4 * q + 2] = w4[2]; v[4 * q + 3] = w4[3];
+                            }
+                        }
+                        if (first) { sum = v; first = false; }
+                        else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) sum[r] += v[r];
+                        }
+                    }
+                    acc[i][j] = sum;
+                }
+        }
+        __syncthreads();
+        float* stage = reinterpret_cast<float*>(smem);
+        if (wave < OWN) {
+#pragma unroll
+            for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if ((2 * i + j) / TPO != wave) continue;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * STG_N + j * 32 + (lane & 31)] = acc[i][j][r] * out_mul;
+                }
+        }
+        __syncthreads();
+        v3_epilogue<RPW, NW>(p, stage, Ha, Wa, out_py, out_px, n, y0, x0, n0);
+    }
+}
+
+
 // FULL: three products per fp32 product; !FULL: high pieces only (EG3D_PREC_F16X1).  RPW: rows of 32 cells per tile (4 | 2).  NW: waves = K slices.
 template <bool FULL, int RPW, int NW>
 __global__ void __launch_bounds__(NW * 64, NW / 4) conv_v3_kernel(const eg3d_conv_v2_params p, const int cls_base) {
     using G = v3g<RPW, FULL>;
     constexpr int NTAPS = 9;
     constexpr int NB = FULL ? 4 : 2;                      // B loads per step
-    constexpr int T = 2 * RPW;                            // 32 x 32 accumulator tiles of the workgroup tile
-    constexpr int OWN = NW < T ? NW : T;                  // waves that own tiles after the reduction
-    constexpr int TPO = T / OWN;                          // tiles per owner
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -360,76 +437,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) conv_v3_kernel(const eg3d_con
         for (int k = 0; k + 1 < nmine; ++k, chunk += NW, buf ^= 1) run_chunk(chunk, buf, std::false_type{});
         run_chunk(chunk, buf, std::true_type{});
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // ---- reduction over the NW K slices: tile t = 2 i + j belongs to wave t / TPO; the others hand their partial tile over through LDS ------
-    const float out_mul = 1.f / (*p.a_scale * *p.w_scale);
-    {
-        f32x4v* part = reinterpret_cast<f32x4v*>(smem);               // block (t, s') = 16 x 64 floats as [r / 4][lane][4]
-#pragma unroll
-        for (int i = 0; i < RPW; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int t = 2 * i + j, o = t / TPO;
-                if (wave != o) {
-                    const int sp = wave < o ? wave : wave - 1;
-                    f32x4v* dst = part + (t * (NW - 1) + sp) * 256 + lane;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) dst[q * 64] = f32x4v{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                }
-            }
-        __syncthreads();
-        if (wave < OWN) {
-#pragma unroll
-            for (int i = 0; i < RPW; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int t = 2 * i + j;
-                    if (t / TPO != wave) continue;
-                    f32x16 sum;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sum[r] = 0.f;
-                    bool first = true;
-#pragma unroll
-                    for (int s = 0; s < NW; ++s) {                 // ascending slice order, whoever owns the tile
-                        f32x16 v;
-                        if (s == wave) {
-                            v = acc[i][j];
-                        } else {
-                            const int sp = s < wave ? s : s - 1;
-                            const f32x4v* src = part + (t * (NW - 1) + sp) * 256 + lane;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const f32x4v w4 = src[q * 64];
-                                v[4 * q] = w4[0]; v[4 * q + 1] = w4[1]; v[4 * q + 2] = w4[2]; v[4 * q + 3] = w4[3];
-                            }
-                        }
-                        if (first) { sum = v; first = false; }
-                        else {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) sum[r] += v[r];
-                        }
-                    }
-                    acc[i][j] = sum;
-                }
-        }
-        __syncthreads();
-        float* stage = reinterpret_cast<float*>(smem);
-        if (wave < OWN) {
-#pragma unroll
-            for (int i = 0; i < RPW; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if ((2 * i + j) / TPO != wave) continue;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * STG_N + j * 32 + (lane & 31)] = acc[i][j][r] * out_mul;
-                }
-        }
-        __syncthreads();
-        v3_epilogue<RPW, NW>(p, stage, Ha, Wa, cl.out_py, cl.out_px, n, y0, x0, n0);
-    }
+    v3_finish<RPW, NW>(p, acc, smem, wave, lane, Ha, Wa, cl.out_py, cl.out_px, n, y0, x0, n0);
 }
 
 std::atomic<uint64_t> g_attr3[8];

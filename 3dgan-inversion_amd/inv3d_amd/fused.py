@@ -263,6 +263,13 @@ def _act_bwd_for(x, dev):
 # Unfinished split-K data gradients on their way to a toRGB node (hipops.DEFER_DGRAD_FINISH): key = data_ptr of the tensor both nodes know (the
 # conv's input x = the toRGB node's x), value = (z, styles, ds).  Written by ModConvLayerFn.backward, consumed by the ToRGBFn.backward that runs next in
 # the same backward pass; that node finishes the gradient inside its own launch -- or with eg3d_dgrad_finish when it cannot.
+def _igemm_precision():
+    """Arithmetic of the launches that stay on the loader-split kernel (toRGB): it has no single-product form, so under
+    hipops.modconv_override('f16x1') they keep three products."""
+    pr = H.modconv_precision()
+    return 'f16x3' if pr == 'f16x1' else pr
+
+
 PENDING_DGRAD = {}
 
 
@@ -772,18 +779,18 @@ class ToRGBFn(torch.autograd.Function):
             out = H.empty_cl(N, Cp, Hh, Ww, x.device)
             try:
                 H.conv_igemm(x, wf, Ci, Cp, out, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=-1.0, addend=skip,
-                             precision=H.modconv_precision(), addend_up2_taps=up_taps)
+                             precision=_igemm_precision(), addend_up2_taps=up_taps)
             except RuntimeError:
                 if up_taps is None:
                     raise
                 # the launch could not take the half-resolution image (tile / alignment conditions of the vector epilogue): up-sample first
                 skip = H.upfirdn2d_nhwc(skip, fir44(skip.device), up=2, pad=(2, 1, 2, 1), gain=4.0)
                 H.conv_igemm(x, wf, Ci, Cp, out, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=-1.0, addend=skip,
-                             precision=H.modconv_precision())
+                             precision=_igemm_precision())
         else:
             y = H.empty_cl(N, Cp, Hh, Ww, x.device)
             H.conv_igemm(x, wf, Ci, Cp, y, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=clampv,
-                         precision=H.modconv_precision())
+                         precision=_igemm_precision())
             out = y + skip if skip is not None else y
         ctx.save_for_backward(x, weight, styles, y if clampv >= 0 else None)
         ctx.cfg = (clampv, cache, want_wgrad, Cp, skip is not None, bool(skip_up))
@@ -811,7 +818,7 @@ class ToRGBFn(torch.autograd.Function):
         if clampv >= 0 or need_b:
             dbias_p = H.zeros((Cp,), dev) if need_b else None
             dy = H.empty_cl(N, Cp, Hh, Ww, dev)
-            if (need_w and H.modconv_precision() == 'f16x3') or (SPLIT_DZ and Cp == 4):
+            if (need_w and _igemm_precision() == 'f16x3') or (SPLIT_DZ and Cp == 4):
                 dy_amax = H.zeros((1,), dev)          # max|dy| from the same pass: the weight gradient can then run in the two-piece fp16 arithmetic
                                                       # (and the fused split of the producing layer's dz takes its range bound from it)
             H.epilogue_bwd(dout, y if y is not None else dout, dy, act='linear', gain=1.0, clamp=clampv, dbias=dbias_p, dz_amax=dy_amax)

@@ -82,3 +82,4 @@ for (ci, res, co) in ((512, 32, 512), (512, 64, 512), (256, 128, 256), (128, 256
             err = float((out - ref).abs().max() / ref.abs().max())
             print(f'      conv_v3 rows {plan[0]} waves {plan[1]} products {products}: {t:6.1f} us ({gf / t * 1e3:4.0f} TF/s, executed {gf * products / t * 1e3:4.0f})  diff {err:.1e}',
                   flush=True)
+

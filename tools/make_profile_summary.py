@@ -46,6 +46,7 @@ ncalls = sum(int(r['Calls']) for r in rows)
 tr = list(csv.DictReader(open(one(sess + '/stats/*_kernel_trace.csv'))))
 tr.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(tr) if 'adam_apply_norm_kernel' in r['Kernel_Name'] or 'noise_apply_norm_kernel' in r['Kernel_Name']]      # last launch of a step
+idx = [i for k, i in enumerate(idx) if k + 1 == len(idx) or idx[k + 1] - i > 12]         # (a batch has several of them in a row: keep the last of each step)
 a, b = idx[8], idx[9]                       # a graph-replayed step of the timed region (3 set-up + 2 warm-up steps precede it)
 seg = tr[a + 1:b + 1]
 agg = collections.defaultdict(lambda: [0, 0])
