@@ -440,7 +440,176 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) conv_v3_kernel(const eg3d_con
     v3_finish<RPW, NW>(p, acc, smem, wave, lane, Ha, Wa, cl.out_py, cl.out_px, n, y0, x0, n0);
 }
 
-std::atomic<uint64_t> g_attr3[8];
+// ---- data gradient of the up-sampling layers' transposed convolution (a stride-2 3x3 correlation; conv_v2_s2adj.hip's contract) -----------------
+//     dx[n, a, b, ci] = sum_{ky,kx} sum_co  g[n, 2a + ky, 2b + kx, co] * w[co, ci, ky, kx]
+// on the PARITY-split image of g (eg3d_fir44_adjoint_split): tap (ky, kx) reads parity (ky & 1, kx & 1) at offset (ky >> 1, kx >> 1).  The
+// contraction is the list of ITEMS (parity q, 16-channel chunk c) with 4 / 2 / 2 / 1 taps; the four waves of a workgroup take contiguous runs of
+// that list of equal cost (9 nchunk / 4 tap-steps each) and every wave accumulates the WHOLE 128-cell x 64-channel tile for its items -- the
+// decomposition of conv_v3_kernel with items in place of chunks.  An item's halo is 5 x 33 cells of ONE parity image (10.3 KB for the four
+// (piece, k-octet) planes): private, double-buffered, by LDS-DMA; its weight tiles go straight into registers (two sets).  Loads are pipelined
+// per item: wait for everything issued during the previous item, issue the next item's, multiply.  No barrier in the loop; v3_finish reduces.
+struct v3a {
+    static constexpr int RPW = 4, NW = 4;
+    static constexpr int HWA = PW + 1;                          // halo pitch: 33 cells
+    static constexpr int SLOTS = (RPW + 1) * HWA;              // 165
+    static constexpr int APL = SLOTS * 16;
+    static constexpr int NOPS = (4 * SLOTS + 63) / 64;         // 11
+    static constexpr int ABUF3 = NOPS * 1024;
+    static constexpr int WAVE_LDS = 2 * ABUF3;                 // 22528
+};
+constexpr int v3a_lds_bytes() {
+    constexpr int main_b = v3a::NW * v3a::WAVE_LDS, red_b = 2 * v3a::RPW * (v3a::NW - 1) * 4096;
+    return main_b > red_b ? main_b : red_b;
+}
+// taps of a kind (parity 2 py + px) as 3 ky + kx, and their halo offsets (ky >> 1, kx >> 1)
+constexpr int v3a_nt(int q) { return q == 0 ? 4 : (q == 3 ? 1 : 2); }
+constexpr int v3a_tap(int q, int j) { return q == 0 ? (j == 0 ? 0 : (j == 1 ? 2 : (j == 2 ? 6 : 8))) : (q == 1 ? (j == 0 ? 1 : 7) : (q == 2 ? (j == 0 ? 3 : 5) : 4)); }
+
+template <bool FULL>
+__global__ void __launch_bounds__(256, 1) conv_v3_s2adj_kernel(const eg3d_conv_v2_params p) {
+    using G = v3a;
+    constexpr int RPW = G::RPW, NW = G::NW, NB = FULL ? 4 : 2;
+    constexpr int NOPS_USED = FULL ? G::NOPS : (2 * G::SLOTS + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const eg3d_conv_class& cl = p.cls[0];
+    const int Ha = cl.Ha, Wa = cl.Wa;
+    const int tiles_x = (Wa + PW - 1) / PW, tiles_y = (Ha + RPW - 1) / RPW, ntile_n = p.Nc / BN3;
+    int bid = blockIdx.x;
+    if (bid >= p.N * tiles_y * tiles_x * ntile_n) return;
+    const int n_t = bid % ntile_n; bid /= ntile_n;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y; const int n = bid / tiles_y;
+    const int y0 = ty * RPW, x0 = tx * PW, n0 = n_t * BN3;
+    const int nchunk = p.Ck / 16;
+    const int Hp = p.Hi, Wp = p.Wi;
+    const int planeP = Hp * Wp * 16;
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    const unsigned wlds = (unsigned)(wave * G::WAVE_LDS);
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, (int)((int64_t)p.N * 2 * (p.Ck / 8) * 4 * planeP), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)((int64_t)p.wtaps * nchunk * 4 * p.Nc * 16), 0x00020000);
+    constexpr unsigned OOB = 0x7ffffff0u;
+    unsigned a_src[NOPS_USED];
+#pragma unroll
+    for (int k = 0; k < NOPS_USED; ++k) {
+        const int gs = k * 64 + lane;
+        const int plane = gs / G::SLOTS, slot = gs - plane * G::SLOTS;
+        const int hy = slot / G::HWA, hx = slot - hy * G::HWA;
+        const int y = y0 + hy, x = x0 + hx;
+        const bool ok = plane < (FULL ? 4 : 2) && y < Hp && x < Wp;            // cells a parity image does not have hold zeros (eg3d_fir44_adjoint_split)
+        a_src[k] = ok ? (unsigned)((y * Wp + x) * 16 + ((plane >> 1) * (p.Ck / 8) + (plane & 1)) * 4 * planeP) : OOB;
+    }
+    const int a_img = n * 2 * (p.Ck / 8);
+    auto issue_A = [&](int q, int chunk, int buf) {
+        const int soff = ((a_img + chunk * 2) * 4 + q) * planeP;
+#pragma unroll
+        for (int k = 0; k < NOPS_USED; ++k) glds16s(ars, lds0 + wlds + buf * G::ABUF3 + k * 1024, a_src[k], soff);
+    };
+    const unsigned b_lane = (unsigned)(((lane >> 5) * p.Nc + n0 + (lane & 31)) * 16);
+    const int b_chunk = 4 * p.Nc * 16, b_piece = 2 * p.Nc * 16, b_tap = nchunk * b_chunk;
+    const int wt0 = cl.wtap[0] * b_tap, wt1 = cl.wtap[1] * b_tap, wt2 = cl.wtap[2] * b_tap, wt3 = cl.wtap[3] * b_tap, wt4 = cl.wtap[4] * b_tap,
+              wt5 = cl.wtap[5] * b_tap, wt6 = cl.wtap[6] * b_tap, wt7 = cl.wtap[7] * b_tap, wt8 = cl.wtap[8] * b_tap;
+    u32x4 breg[2][4][NB];
+    f32x16 acc[RPW][2];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const unsigned a_lane = wlds + (unsigned)((lane & 31) * 16 + (lane >> 5) * G::APL);
+    const f16x2 k2m11 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
+    // this wave's run of the item list: items (q, c) q-major, start cost B_q + c cost_q, owner = floor(4 start / (9 nchunk)).  Smallest c with
+    // 4 (base + c cost) >= w T9 (ceil division, clamped to [0, nchunk]):
+    const int T9 = 9 * nchunk;
+    auto first_c = [&](int w, int base, int cost) { const int num = w * T9 - 4 * base, den = 4 * cost; const int cc = num <= 0 ? 0 : (num + den - 1) / den; return cc > nchunk ? nchunk : cc; };
+    // One loop per kind, each specialised at compile time (a run-time branch around an MFMA block makes the compiler shuttle the accumulators
+    // between register files at every join); loads are pipelined inside a kind, a kind starts cold (three exposed latencies per wave at most).
+    auto run_kind = [&](auto q_tag, const int lo, const int hi) {
+        constexpr int Q = decltype(q_tag)::value;
+        constexpr int NT = v3a_nt(Q);
+        auto issue_B = [&](int chunk, auto set_tag) {
+            constexpr int SET = decltype(set_tag)::value;
+            auto one = [&](auto j_tag) {
+                constexpr int J = decltype(j_tag)::value;
+                if constexpr (J < NT) {
+                    constexpr int TAP = v3a_tap(Q, J);
+                    const int wbase = (TAP == 0 ? wt0 : TAP == 1 ? wt1 : TAP == 2 ? wt2 : TAP == 3 ? wt3 : TAP == 4 ? wt4 : TAP == 5 ? wt5 : TAP == 6 ? wt6 : TAP == 7 ? wt7 : wt8) + chunk * b_chunk;
+#pragma unroll
+                    for (int e = 0; e < NB; ++e)
+                        breg[SET][J][e] = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_lane + (e & 1) * 512, wbase + (e >> 1) * b_piece, 0);
+                }
+            };
+            one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
+        };
+        auto item = [&](const int chunk, const bool has_next, auto set_tag) {
+            constexpr int SET = decltype(set_tag)::value;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this item's halo and weight tiles
+            if (has_next) {
+                issue_A(Q, chunk + 1, SET ^ 1);
+                issue_B(chunk + 1, std::integral_constant<int, SET ^ 1>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            auto one = [&](auto j_tag) {
+                constexpr int j = decltype(j_tag)::value;
+                if constexpr (j < NT) {
+                    constexpr int t = v3a_tap(Q, j);
+                    constexpr int sy = (t / 3) >> 1, sx = (t % 3) >> 1;
+                    const unsigned abase = a_lane + (unsigned)(SET * G::ABUF3 + (sy * G::HWA + sx) * 16);
+                    f16x8 bh[2], bl[2], bg[2];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        bh[jj] = as_f16x8(breg[SET][j][jj]);
+                        if constexpr (FULL) {
+                            bl[jj] = as_f16x8(breg[SET][j][2 + jj]);
+                            f16x2* s2 = reinterpret_cast<f16x2*>(&bh[jj]);
+                            f16x2* d2 = reinterpret_cast<f16x2*>(&bg[jj]);
+#pragma unroll
+                            for (int qq = 0; qq < 4; ++qq) d2[qq] = s2[qq] * k2m11;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < RPW; ++i) {
+                        const f16x8 ah = *reinterpret_cast<const f16x8*>(smem + abase + i * G::HWA * 16);
+                        if constexpr (FULL) {
+                            const f16x8 al = *reinterpret_cast<const f16x8*>(smem + abase + i * G::HWA * 16 + 2 * G::APL);
+#pragma unroll
+                            for (int jj = 0; jj < 2; ++jj) {
+                                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bg[jj], acc[i][jj], 0, 0, 0);
+                                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[jj], acc[i][jj], 0, 0, 0);
+                                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[jj], acc[i][jj], 0, 0, 0);
+                            }
+                        } else {
+#pragma unroll
+                            for (int jj = 0; jj < 2; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[jj], acc[i][jj], 0, 0, 0);
+                        }
+                    }
+                }
+            };
+            one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
+            asm volatile("" ::: "memory");
+        };
+        const int cnt = hi - lo;
+        if (cnt > 0) {
+            issue_A(Q, lo, 0);
+            issue_B(lo, std::integral_constant<int, 0>{});
+            int k = 0;
+            for (; k + 1 < cnt; k += 2) {
+                item(lo + k, true, std::integral_constant<int, 0>{});
+                item(lo + k + 1, k + 2 < cnt, std::integral_constant<int, 1>{});
+            }
+            if (k < cnt) item(lo + k, false, std::integral_constant<int, 0>{});
+        }
+    };
+    run_kind(std::integral_constant<int, 0>{}, first_c(wave, 0, 4), first_c(wave + 1, 0, 4));
+    run_kind(std::integral_constant<int, 1>{}, first_c(wave, 4 * nchunk, 2), first_c(wave + 1, 4 * nchunk, 2));
+    run_kind(std::integral_constant<int, 2>{}, first_c(wave, 6 * nchunk, 2), first_c(wave + 1, 6 * nchunk, 2));
+    run_kind(std::integral_constant<int, 3>{}, first_c(wave, 8 * nchunk, 1), first_c(wave + 1, 8 * nchunk, 1));
+    v3_finish<RPW, NW>(p, acc, smem, wave, lane, Ha, Wa, cl.out_py, cl.out_px, n, y0, x0, n0);
+}
+
+std::atomic<uint64_t> g_attr3[10];
 
 template <bool FULL, int RPW, int NW>
 int launch_v3(const eg3d_conv_v2_params& p, int cls_base, int ncls, int max_tiles, hipStream_t st, int slot) {
@@ -506,6 +675,53 @@ extern "C" int eg3d_conv2d_v3(const eg3d_conv_v2_params* pp, void* stream) {
     else if (nw == 4) rc = full ? launch_v3<true, 2, 4>(p, 0, p.ncls, max_tiles, st, 2) : launch_v3<false, 2, 4>(p, 0, p.ncls, max_tiles, st, 3);
     else rc = full ? launch_v3<true, 2, 8>(p, 0, p.ncls, max_tiles, st, 4) : launch_v3<false, 2, 8>(p, 0, p.ncls, max_tiles, st, 5);
     if (rc != EG3D_OK) return rc;
+    EG3D_DET_END(det);
+    return EG3D_OK;
+}
+
+extern "C" int eg3d_conv2d_v3_s2adj_supported(const eg3d_conv_v2_params* pp) {
+    if (!pp) return 0;
+    const eg3d_conv_v2_params& p = *pp;
+    if (p.N <= 0 || p.Hi <= 0 || p.Wi <= 0 || p.Ck < 16 || (p.Ck & 15) || p.Nc < BN3 || (p.Nc % BN3) || (p.ldo & 3)) return 0;
+    if (p.out_stride != 1 || p.ncls != 1 || p.wtaps < 9) return 0;
+    if (p.products != 0 && p.products != 1 && p.products != 3) return 0;
+    if (p.epi != EG3D_EPI_STORE && p.epi != EG3D_EPI_BWD && p.epi != EG3D_EPI_BWD_ACT) return 0;
+    if (p.epi == EG3D_EPI_BWD_ACT) {
+        const eg3d_act_bwd& ab = p.act_bwd;
+        if (ab.act != EG3D_ACT_LINEAR && ab.act != EG3D_ACT_LRELU) return 0;
+        if (!(ab.gain > 0.f) || (ab.noise != nullptr && ab.noise_strength == nullptr)) return 0;
+    }
+    const eg3d_conv_class& k = p.cls[0];
+    if (k.ntaps != 9 || k.out_py != 0 || k.out_px != 0) return 0;
+    for (int t = 0; t < 9; ++t)
+        if (k.dy[t] != t / 3 || k.dx[t] != t % 3 || k.wtap[t] < 0 || k.wtap[t] >= p.wtaps) return 0;
+    if (p.Hi < k.Ha + 1 || p.Wi < k.Wa + 1) return 0;         // parity images cover the class grid + the offset-1 taps
+    if ((int64_t)p.N * 2 * (p.Ck / 8) * 4 * p.Hi * p.Wi * 16 > 0x7fffffe0ll) return 0;
+    if ((int64_t)p.wtaps * (p.Ck / 16) * 4 * p.Nc * 16 > 0x7fffffe0ll) return 0;
+    if ((int64_t)p.N * p.Ho * p.Wo * p.ldo > INT32_MAX) return 0;
+    return 1;
+}
+
+extern "C" int eg3d_conv2d_v3_s2adj(const eg3d_conv_v2_params* pp, void* stream) {
+    if (!pp || !pp->a || !pp->w || !pp->out || !pp->a_scale || !pp->w_scale) return EG3D_ERR_INVALID;
+    if (!eg3d_conv2d_v3_s2adj_supported(pp)) return EG3D_ERR_UNSUPPORTED;
+    const eg3d_conv_v2_params& p = *pp;
+    if (p.epi == EG3D_EPI_BWD_ACT && !p.xin) return EG3D_ERR_INVALID;
+    const void* ptrs[] = {p.out, p.addend, p.xin, p.out_scale, p.act_bwd.d, p.act_bwd.bias};
+    for (const void* q : ptrs)
+        if (q != nullptr && (reinterpret_cast<uintptr_t>(q) & 15)) return EG3D_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND_V2(det, p); EG3D_DET_COMMIT(det);
+    const int tiles = p.N * eg3d_cdiv(p.cls[0].Ha, 4) * eg3d_cdiv(p.cls[0].Wa, PW) * (p.Nc / BN3);
+    constexpr int lds = v3a_lds_bytes();
+    if (p.products != 1) {
+        if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_v3_s2adj_kernel<true>), lds, g_attr3[8])) return e;
+        hipLaunchKernelGGL(conv_v3_s2adj_kernel<true>, dim3(tiles), dim3(256), lds, st, p);
+    } else {
+        if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_v3_s2adj_kernel<false>), lds, g_attr3[9])) return e;
+        hipLaunchKernelGGL(conv_v3_s2adj_kernel<false>, dim3(tiles), dim3(256), lds, st, p);
+    }
+    EG3D_LAUNCH_CHECK();
     EG3D_DET_END(det);
     return EG3D_OK;
 }

@@ -240,6 +240,8 @@ _SIGS = {
     'eg3d_filtered_lrelu_act': (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_float] * 3 + [C.c_int, C.c_void_p]),
     'eg3d_conv2d_v2_s2adj_supported': (C.c_int, [C.POINTER(ConvV2Params)]),
     'eg3d_conv2d_v2_s2adj': (C.c_int, [C.POINTER(ConvV2Params), C.c_void_p]),
+    'eg3d_conv2d_v3_s2adj_supported': (C.c_int, [C.POINTER(ConvV2Params)]),
+    'eg3d_conv2d_v3_s2adj': (C.c_int, [C.POINTER(ConvV2Params), C.c_void_p]),
     'eg3d_fir44_adjoint_split_bytes': (C.c_int64, [C.c_int] * 4),
     'eg3d_fir44_adjoint_split': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_float, C.c_void_p]),
     'eg3d_conv2d_up2_supported': (C.c_int, [C.POINTER(ConvUp2Params)]),

@@ -499,7 +499,7 @@ class ModConvLayerFn(torch.autograd.Function):
             in_stride = 1
             cls_w, out_stride_w = H.classes_corr(Ho, Wo, kh, kw, kh // 2), 1
         elif (not need_w and (need_x or need_s) and up == 2 and kh == 3 and kw == 3 and prec in ('f16x3', 'f16x1') and amax is not None
-              and H.conv_s2adj_ok(Co, Ci, Hi, Wi, N)):
+              and (H.conv_s2adj_ok(Co, Ci, Hi, Wi, N) or H.conv_v3_s2adj_ok(Co, Ci, Hi, Wi, N))):
             # frozen weights (latent projection): the FIR adjoint writes the data gradient's operand directly as parity-split fp16 images
             # (range bound up^2 max|dz|) -- no fp32 g, no strided gathers in the conv loader
             g = None
@@ -532,7 +532,7 @@ class ModConvLayerFn(torch.autograd.Function):
                     fkw = dict(out_amax=dx_amax)
                     _DX_AMAX[dx.data_ptr()] = (dx_amax, weakref.ref(dx))
                 did = H.conv_v2_s2adj(gimg, cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD, out_scale=styles, xin=x, ds=ds, algo_flops=aflops,
-                                      products=1 if prec == 'f16x1' else 3, **fkw)
+                                      products=1 if prec == 'f16x1' else 3, v3=not H.conv_s2adj_ok(Co, Ci, Hi, Wi, N), **fkw)
             elif H.USE_V2 and up == 1 and (ks == 1 or H.conv_v2_rows(Co, Ci, cls_adj, N) == 2) and prec in ('f16x3', 'f16x1') and H.conv_v2_supported(Co, Ci, cls_adj, N):
                 gimg = dz_img if dz_img is not None else H.split_activation(g, amax)           # (kept: the weight gradient below reads it too)
                 did = H.conv_v2(gimg, cache.get_split(weight)[1], dx, cls_adj, epi=L.EPI_BWD,

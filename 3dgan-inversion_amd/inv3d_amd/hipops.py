@@ -807,10 +807,25 @@ def conv_s2adj_ok(Ck, Nc, Hi, Wi, N=1):
     return N * -(-Hi // 8) * -(-Wi // 32) * (Nc // 128) >= S2ADJ_MIN_TILES
 
 
+V3_S2ADJ = os.environ.get('EG3D_V3_S2ADJ', '1') != '0'
+V3_S2ADJ_MIN_CELLS = int(os.environ.get('EG3D_V3_S2ADJ_MIN_CELLS', '4096'))
+
+
+def conv_v3_s2adj_ok(Ck, Nc, Hi, Wi, N=1):
+    """The up layers' data gradient on the wave-split form of the parity-split kernel (conv_v3_s2adj_kernel): the grids conv_s2adj_ok turns down
+    for want of 256 x 128 tiles, from 32^2 cells."""
+    if not (USE_V3 and V3_S2ADJ) or CONV_MODE != 'auto' or Ck % 16 or Nc % 64 or conv_s2adj_ok(Ck, Nc, Hi, Wi, N):
+        return False
+    return N * Hi * Wi >= V3_S2ADJ_MIN_CELLS
+
+
 def conv_v2_s2adj(a: SplitImage, w: SplitImage, out, classes, epi=L.EPI_STORE, out_scale=None, addend=None, xin=None, ds=None, out_amax=None, algo_flops=None,
-                  act_bwd=None, products=3, ksplit=1):
-    """Launch eg3d_conv2d_v2_s2adj: `a` = parity-split image of G (fir44_adjoint_split), `classes` = classes_convT_adjoint(...).  Returns like conv_v2."""
+                  act_bwd=None, products=3, ksplit=1, v3=False):
+    """Launch eg3d_conv2d_v2_s2adj (v3: eg3d_conv2d_v3_s2adj, the wave-split form): `a` = parity-split image of G (fir44_adjoint_split),
+    `classes` = classes_convT_adjoint(...).  Returns like conv_v2."""
     assert is_cl(out) and len(classes) == 1
+    fn_ok, fn, nm, cfg_id = ((L.lib().eg3d_conv2d_v3_s2adj_supported, L.lib().eg3d_conv2d_v3_s2adj, 'conv2d_v3_s2adj', V3_CONFIG) if v3 else
+                             (L.lib().eg3d_conv2d_v2_s2adj_supported, L.lib().eg3d_conv2d_v2_s2adj, 'conv2d_v2_s2adj', S2ADJ_CONFIG))
     p = _conv_v2_params(a, w, out, classes, 1, epi, out_scale, None, None, 0, None, 'linear', 0.0, 1.0, -1.0, addend, xin, ds, out_amax)
     p.in_stride = 2
     p.products, p.ksplit = int(products), int(ksplit)
@@ -818,22 +833,22 @@ def conv_v2_s2adj(a: SplitImage, w: SplitImage, out, classes, epi=L.EPI_STORE, o
     if act_bwd is not None and epi == L.EPI_BWD and xin is not None:
         p.epi = L.EPI_BWD_ACT
         act_bwd.fill(p.act_bwd)
-        fused_act = bool(L.lib().eg3d_conv2d_v2_s2adj_supported(C.byref(p))) and all(t is None or t.data_ptr() % 16 == 0 for t in (act_bwd.d, act_bwd.bias))
+        fused_act = bool(fn_ok(C.byref(p))) and all(t is None or t.data_ptr() % 16 == 0 for t in (act_bwd.d, act_bwd.bias))
         if not fused_act:
             p.epi = L.EPI_BWD
             p.act_bwd = L.ActBwd()
     prof = PROFILER
-    if prof is not None and prof.only_config is not None and prof.only_config != S2ADJ_CONFIG:
+    if prof is not None and prof.only_config is not None and prof.only_config != cfg_id:
         prof = None
     if prof is not None:
         if algo_flops is None:
             algo_flops = 2.0 * p.Ck * p.Nc * p.N * classes[0].Ha * classes[0].Wa * 9
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    L.check(L.lib().eg3d_conv2d_v2_s2adj(C.byref(p), L.stream_ptr()), 'conv2d_v2_s2adj')
+    L.check(fn(C.byref(p), L.stream_ptr()), nm)
     if prof is not None:
         e1.record()
-        prof.records.append(((S2ADJ_CONFIG, PRECISIONS['f16x3']), float(algo_flops), e0, e1))
+        prof.records.append(((cfg_id, PRECISIONS['f16x3']), float(algo_flops), e0, e1))
         if prof.meta is not None:
             prof.meta.append(dict(N=p.N, Hi=2 * p.Hi - 1, Wi=2 * p.Wi - 1, Ck=p.Ck, Nc=p.Nc, Ho=p.Ho, Wo=p.Wo, taps=[9], epi=epi, ksplit=int(ksplit), in_stride=2,
                                   out_stride=1, prec=3, v2=True))

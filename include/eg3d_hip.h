@@ -251,6 +251,12 @@ int eg3d_conv2d_v3(const eg3d_conv_v2_params* p, void* stream);
  * parity image (py, px)[a', b'] = G[2a' + py, 2b' + px] (p->Hi, p->Wi = dimensions of one parity image, >= Ha + 1, Wa + 1). */
 int eg3d_conv2d_v2_s2adj_supported(const eg3d_conv_v2_params* p);
 int eg3d_conv2d_v2_s2adj(const eg3d_conv_v2_params* p, void* stream);
+/* The same data gradient, same operands and epilogues (STORE / BWD / BWD_ACT), in the wave-split decomposition of eg3d_conv2d_v3 for the layers
+ * whose grids cannot fill the chip with 256 x 128 tiles (the backbone's up layers at one image per GPU): 128-cell x 64-channel tiles, the
+ * contraction -- the list of (parity image, 16-channel chunk) items with 4 / 2 / 2 / 1 taps -- dealt to the four waves of a workgroup in runs of
+ * equal cost and summed in LDS in wave order (csrc/conv_v3.hip).  Nc % 64 == 0, Ck % 16 == 0; taps (dy, dx) = (t / 3, t % 3) as above. */
+int eg3d_conv2d_v3_s2adj_supported(const eg3d_conv_v2_params* p);
+int eg3d_conv2d_v3_s2adj(const eg3d_conv_v2_params* p, void* stream);
 /* FIR adjoint of an up-sampling layer fused with the operand split: G = upfirdn2d(dz, outer([1,3,3,1]) / 64, padding 2, gain) of
  * dz [N, 2 Hi, 2 Wi, ldz] NHWC fp32 (C used channels, C % 8 == 0) -- the (2 Hi + 1) x (2 Wi + 1) input of the data gradient above
  * (torch_utils/ops/upfirdn2d.py:258-268 applied to conv2d_resample.py:129) -- written as the four parity images [.][Hi + 1][Wi + 1] in the

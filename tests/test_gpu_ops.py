@@ -1223,6 +1223,38 @@ def test_conv_v2_stride2_adjoint_vs_torch(shape, products):
         assert float((dx - dx2).abs().max()) <= 2e-5 * scale
 
 
+@pytest.mark.parametrize('shape', [(1, 128, 16, 32, 64), (2, 256, 9, 33, 128), (1, 64, 24, 40, 192), (1, 512, 32, 32, 64), (1, 64, 5, 7, 64)])
+@pytest.mark.parametrize('products', [3, 1])
+def test_conv_v3_stride2_adjoint_vs_torch(shape, products):
+    """The same data gradient on the wave-split form (conv_v3_s2adj_kernel: the (parity, chunk) items of the contraction dealt to the four waves
+    in runs of equal cost): vs torch fp64 on ragged grids, batch 2, 1 .. 8 channel tiles of 64, chunk counts 4, 8, 12."""
+    from inv3d_amd import hipops as H, _lib as L
+    n, ci, h, w, co = shape
+    g_ = torch.Generator().manual_seed(52)
+    dz = torch.randn(n, co, 2 * h, 2 * w, generator=g_) * 1e-3
+    wt = torch.randn(co, ci, 3, 3, generator=g_) / math.sqrt(ci * 9)
+    s, xin = 1 + 0.5 * torch.randn(n, ci, generator=g_), torch.randn(n, ci, h, w, generator=g_)
+    f1 = torch.tensor([1., 3., 3., 1.], dtype=torch.float64) / 8
+    f2 = torch.outer(f1, f1)[None, None].repeat(co, 1, 1, 1)
+    G = torch.nn.functional.conv2d(torch.nn.functional.pad(dz.double(), (2, 2, 2, 2)), f2, groups=co) * 4.0
+    acc = torch.nn.functional.conv2d(G, wt.double().transpose(0, 1), stride=2)
+    ref_dx, ref_ds = acc * s.double()[:, :, None, None], (acc * xin.double()).sum((2, 3))
+    dzc = dz.to(DEV).contiguous(memory_format=torch.channels_last)
+    gimg = H.fir44_adjoint_split(dzc, H.absmax(dzc), gain=4.0)
+    wimg = H.split_weight(H.pack_weight_adj(wt.to(DEV)), ci, co, 9)
+    outs = []
+    for rep in range(2):
+        dx, ds = H.empty_cl(n, ci, h, w, DEV), torch.zeros(n, ci, device=DEV)
+        H.conv_v2_s2adj(gimg, wimg, dx, H.classes_convT_adjoint(h, w, 3, 3, 2), epi=L.EPI_BWD, out_scale=s.to(DEV),
+                        xin=xin.to(DEV).contiguous(memory_format=torch.channels_last), ds=ds, products=products, v3=True)
+        outs.append(dx)
+    tol = 2e-5 if products == 3 else 3e-3
+    assert torch.isfinite(dx).all()
+    assert float((dx.double().cpu() - ref_dx).abs().max()) <= tol * float(ref_dx.abs().max())
+    assert float((ds.double().cpu() - ref_ds).abs().max()) <= 3 * tol * float(ref_ds.abs().max())
+    assert torch.equal(outs[0], outs[1])            # the K slices are summed in wave order: run-to-run identical
+
+
 @pytest.mark.parametrize('shape', [(1, 64, 16, 32), (2, 128, 9, 20), (1, 192, 33, 17)])
 def test_upconv_epilogue_lds_and_fused_split(shape):
     """The LDS-staged separable FIR epilogue of the up layers (eg3d_upconv_epilogue_fwd) vs the 25-load kernel it replaces, on ragged tiles;

@@ -83,3 +83,45 @@ for (ci, res, co) in ((512, 32, 512), (512, 64, 512), (256, 128, 256), (128, 256
             print(f'      conv_v3 rows {plan[0]} waves {plan[1]} products {products}: {t:6.1f} us ({gf / t * 1e3:4.0f} TF/s, executed {gf * products / t * 1e3:4.0f})  diff {err:.1e}',
                   flush=True)
 
+
+
+# ---- the up-sampling layers' data gradient (stride-2 adjoint on parity-split images): wave-split kernel vs the loader-split kernel ----------
+print('--- stride-2 adjoint (data gradient of the up layers, EPI_BWD) ---', flush=True)
+for (ci, res, co) in ((512, 32, 512), (512, 64, 256), (256, 128, 128)):
+    ws = [(torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)).to(dev) for _ in range(NWT)]
+    was = [H.pack_weight_adj(w) for w in ws]
+    wimgs = [H.split_weight(wa, ci, co, 9) for wa in was]
+    wps = [H.split_weight_pieces(wa) for wa in was]
+    s = (1 + 0.5 * torch.randn(N, ci, generator=g)).to(dev)
+    xin = torch.randn(N, ci, res, res, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    dz = (torch.randn(N, co, 2 * res, 2 * res, generator=g) * 1e-3).to(dev).contiguous(memory_format=torch.channels_last)
+    amax = H.absmax(dz)
+    cls = H.classes_convT_adjoint(res, res, 3, 3, 2)
+    dx, ds = H.empty_cl(N, ci, res, res, dev), torch.zeros(N, ci, device=dev)
+    gf = 2.0 * N * res * res * ci * co * 9 / 1e9
+    gfull = H.empty_cl(N, co, 2 * res + 1, 2 * res + 1, dev)
+    ks_old = F._auto_ksplit(cls, N, ci, co)
+    z = torch.zeros(N, ci, res, res, device=dev).contiguous(memory_format=torch.channels_last)
+
+    def old(k):
+        H.upconv_epilogue_fwd(dz, gfull, pad0=2, fir_gain=4.0)
+        if ks_old > 1:
+            z.zero_()
+            H.conv_atomic(gfull, was[k], co, ci, z, cls, in_stride=2, ksplit=ks_old, precision='f16x3', a_amax=amax, w_pieces=wps[k], a_amax_mul=4.0)
+            H.dgrad_finish(z, xin, s, dx, ds=ds)
+        else:
+            H.conv_igemm(gfull, was[k], co, ci, dx, cls, in_stride=2, epi=L.EPI_BWD, out_scale=s, xin=xin, ds=ds, precision='f16x3', a_amax=amax, a_amax_mul=4.0,
+                         w_pieces=wps[k])
+    t = timed(old)
+    old(0); ref = dx.clone()
+    print(f'{2 * res}^2 -> {res}^2 x {co}->{ci} N={N} ({gf:.1f} GF): FIR adjoint + igemm ks {ks_old} (+finish) {t:6.1f} us ({gf / t * 1e3:4.0f} TF/s)', flush=True)
+    t = timed(lambda k: H.fir44_adjoint_split(dz, amax, gain=4.0))
+    print(f'      fir44_adjoint_split {t:5.1f} us', flush=True)
+    gimg = H.fir44_adjoint_split(dz, amax, gain=4.0)
+    for products in (3, 1):
+        def v3(k):
+            H.conv_v2_s2adj(gimg, wimgs[k], dx, cls, epi=L.EPI_BWD, out_scale=s, xin=xin, ds=ds, products=products, v3=True)
+        t = timed(v3)
+        v3(0)
+        err = float((dx - ref).abs().max() / ref.abs().max())
+        print(f'      conv_v3_s2adj products {products}: {t:6.1f} us ({gf / t * 1e3:4.0f} TF/s, executed {gf * products / t * 1e3:4.0f})  diff {err:.1e}', flush=True)
