@@ -175,7 +175,14 @@ __global__ void __launch_bounds__(256) epilogue_fwd_fir44_kernel(const float* __
 //           consumer disappears.  The image needs its range before the tile exists, so this form requires clamp >= 0 (the super-resolution
 //           head, conv_clamp = 256): |out| <= clamp is the bound; scale = the power of two that brings clamp * max|styles| to [2^13, 2^14).
 // Measured on MI355X, 513^2 x 128 -> 512^2 x 128: 94 us (2.9 TB/s) for the 25-load form.
-constexpr int UE_TH = 8, UE_TW = 16, UE_CH = 64, UE_PITCH = UE_CH + 4, UE_COLS = UE_TW + 3;
+constexpr int UE_TH = 8, UE_TW = 16, UE_CH = 64, UE_COLS = UE_TW + 3;
+// LDS pitches (floats).  V (vertical sums, read in phase 2 by 16 lanes per pixel x 4 consecutive pixels = one contiguous 1 KB run per wave-instruction when
+// the pitch is exactly 64: conflict-free; with the former 68 the ds_read_b128 lane groups straddled two pixels 4 banks apart -- LdsBankConflict 0.50).
+// O (activated tile of the SPLIT form, read in phase 3 with lanes along PIXELS): 68, so that consecutive pixels are 4 banks apart.
+#ifndef UE_VPITCH
+#define UE_VPITCH 64
+#endif
+constexpr int UE_PITCH = UE_VPITCH, UE_OPITCH = UE_CH + 4;
 
 __device__ __forceinline__ float ue_range_mul(float amax) {
     if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
@@ -191,7 +198,8 @@ __global__ void __launch_bounds__(256) upconv_epilogue_kernel(const float* __res
                                                              const float* __restrict__ noise, int64_t noise_nstride, const float* __restrict__ noise_strength,
                                                              const float* __restrict__ bias, float slope, float gain, float clamp, float* out_amax,
                                                              const float* __restrict__ sp_scale_in, _Float16* __restrict__ sp_image, float* sp_scale_out) {
-    __shared__ __attribute__((aligned(16))) float V[UE_TH * UE_COLS * UE_PITCH];                       // vertical sums [row][column][channel]
+    constexpr int UE_VFLOATS = UE_TH * UE_COLS * UE_PITCH, UE_OFLOATS = UE_TH * UE_TW * UE_OPITCH;
+    __shared__ __attribute__((aligned(16))) float V[UE_VFLOATS > UE_OFLOATS ? UE_VFLOATS : UE_OFLOATS];                       // vertical sums [row][column][channel]
     float* const O = V;                  // activated tile (SPLIT): takes V's place once phase 2 has read it (41 KB of LDS: three blocks per CU, not two)
     __shared__ float red[4];
     const int tiles_x = (W + UE_TW - 1) / UE_TW, tiles_y = (H + UE_TH - 1) / UE_TH;
@@ -280,7 +288,7 @@ __global__ void __launch_bounds__(256) upconv_epilogue_kernel(const float* __res
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < UE_TH * UE_TW * (UE_CH / 4) / 256; ++k)
-            *reinterpret_cast<float4*>(O + ((threadIdx.x >> 4) + k * 16) * UE_PITCH + c4 * 4) = keep[k];
+            *reinterpret_cast<float4*>(O + ((threadIdx.x >> 4) + k * 16) * UE_OPITCH + c4 * 4) = keep[k];
         // ---- phase 3: item = (octet, pixel), lanes along the pixels of a tile row (16 x 16 bytes contiguous in a plane's row)
         __syncthreads();
         const int noct = C / 8;
@@ -293,7 +301,7 @@ __global__ void __launch_bounds__(256) upconv_epilogue_kernel(const float* __res
             const int oy = pix / UE_TW, ox = pix - oy * UE_TW;
             const int y = y0 + oy, x = x0 + ox;
             if (y >= H || x >= W) continue;
-            const float4 lo = *reinterpret_cast<const float4*>(O + pix * UE_PITCH + kl * 8), hi = *reinterpret_cast<const float4*>(O + pix * UE_PITCH + kl * 8 + 4);
+            const float4 lo = *reinterpret_cast<const float4*>(O + pix * UE_OPITCH + kl * 8), hi = *reinterpret_cast<const float4*>(O + pix * UE_OPITCH + kl * 8 + 4);
             const float* sr = sp_scale_in + (int64_t)n * C + c0 + kl * 8;
             const float v[8] = {lo.x * sr[0], lo.y * sr[1], lo.z * sr[2], lo.w * sr[3], hi.x * sr[4], hi.y * sr[5], hi.z * sr[6], hi.w * sr[7]};
             f16x8_t h, l;
