@@ -428,6 +428,41 @@ def side_configs(G, target, cam, dev, use_graph, steps=10):
     return out
 
 
+def final_psnr_run(G, target, cam, use_graph, feature_net):
+    """Second half of the metric: one image through the whole budget of configs/hyperparameters.py (400 latent + 400 pivotal-tuning steps)."""
+    from inv3d_amd.coach import InversionCoach
+    t1 = time.perf_counter()
+    try:
+        coach = InversionCoach(G, first_inv_steps=400, max_pti_steps=400, lpips_threshold=0.0, use_graph=use_graph, early_stop_interval=1, w_avg_samples=0,
+                               feature_net=feature_net)
+        res = coach.invert('bench', target[:1], cam[:1])
+        torch.cuda.synchronize()
+        modes = coach.last_launch_modes                 # how the two phases were actually issued: stated in the note (a refused capture falls back to eager launches)
+        return dict(final_psnr_db=round(res.psnr_tuned, 3), pivot_psnr_db=round(res.psnr_pivot, 3), steps=res.steps_a + res.steps_b,
+                    wall_s=round(time.perf_counter() - t1, 2), note='400 latent steps (fp32-equivalent) + 400 pivotal-tuning steps (SR head in the reference\'s fp16-operand arithmetic, as BaseCoach.forward), %s, stub feature pyramid, synthetic target' % ('both phases replayed from HIP graphs (the early-stop criterion is evaluated on the device in every step of the captured tuning step; the host polls the flag every step)' if modes == dict(phase_a='graph', phase_b='graph') else 'launch modes: %s' % modes))
+    except Exception as e:           # the side run must never cost the benchmark line
+        return dict(error='%s: %s' % (type(e).__name__, e))
+
+
+def run_child(kind, args, timeout=600):
+    """`bench.py --child side|final` with the parent's workload flags; returns the child's dictionary or an error entry."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--child', kind, '--no-cpu-baseline', '--no-roofline', '--loss-net', args.loss_net]
+    if args.no_graph:
+        cmd.append('--no-graph')
+    if args.precision is not None:
+        cmd += ['--precision', args.precision]
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return dict(error=f'child process ({kind}) exceeded {timeout} s')
+    for ln in reversed(r.stdout.strip().splitlines()):
+        if ln.startswith('{"child"'):
+            return json.loads(ln)['child']
+    return dict(error=f'child process ({kind}) ended with code {r.returncode} and no result', stderr_tail=r.stderr.strip()[-300:])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -446,6 +481,7 @@ def main():
     ap.add_argument('--loss-net', default='stub', choices=['stub', 'vgg16'],
                     help="feature network of the LPIPS term: 'stub' = the small fixed conv pyramid the C2 workload is defined with (SURVEY.md "
                          "section 8d); 'vgg16' = the full VGG16-LPIPS architecture (random weights) on the same kernels")
+    ap.add_argument('--child', default=None, choices=['side', 'final'], help=argparse.SUPPRESS)      # internal: the side figures / the final-PSNR run in a process of their own
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
@@ -485,6 +521,12 @@ def main():
     if args.loss_net == 'vgg16':
         from inv3d_amd.loss_nets import VGG16LPIPS
         feature_net = VGG16LPIPS().to(dev)
+    if args.child == 'side':             # (same generator, target and camera as the parent built: everything here is seeded)
+        print(json.dumps(dict(child=side_configs(G, target, cam, dev, use_graph))), flush=True)
+        return
+    if args.child == 'final':
+        print(json.dumps(dict(child=final_psnr_run(G, target, cam, use_graph, feature_net))), flush=True)
+        return
     proj = LatentProjector(G, target, num_steps=400, cam=cam, wplus=args.wplus, seed=100 + rank, use_graph=use_graph, feature_net=feature_net)
     proj.preheat = 0
 
@@ -642,26 +684,20 @@ def main():
     cpu_c1 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_c1 = cpu_baseline_c1()
+    # The side figures and the full-budget run each capture a dozen graphs and build optimisers over all 30.7 M weights: they run in a process
+    # of their own, AFTER this one has everything the benchmark line needs -- a fault in one of them (the runtime's graph capture has produced
+    # segmentation faults under memory pressure) costs its own entry, never the line.
     side = None
     if rank == 0 and world == 1 and not args.no_side_configs and M == 1 and args.loss_net == 'stub' and not args.wplus:
-        side = side_configs(G, target, cam, dev, use_graph)
-    final = None
-    if rank == 0 and world == 1 and not args.no_final_psnr:
-        # second half of the metric: one image through the whole budget of configs/hyperparameters.py (400 latent + 400 pivotal-tuning steps)
-        from inv3d_amd.coach import InversionCoach
         del proj
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        try:
-          coach = InversionCoach(G, first_inv_steps=400, max_pti_steps=400, lpips_threshold=0.0, use_graph=use_graph, early_stop_interval=1, w_avg_samples=0,
-                                 feature_net=feature_net)
-          res = coach.invert('bench', target[:1], cam[:1])
-          torch.cuda.synchronize()
-          modes = coach.last_launch_modes                 # how the two phases were actually issued: stated in the note (a refused capture falls back to eager launches)
-          final = dict(final_psnr_db=round(res.psnr_tuned, 3), pivot_psnr_db=round(res.psnr_pivot, 3), steps=res.steps_a + res.steps_b,
-                       wall_s=round(time.perf_counter() - t1, 2), note='400 latent steps (fp32-equivalent) + 400 pivotal-tuning steps (SR head in the reference\'s fp16-operand arithmetic, as BaseCoach.forward), %s, stub feature pyramid, synthetic target' % ('both phases replayed from HIP graphs (the early-stop criterion is evaluated on the device in every step of the captured tuning step; the host polls the flag every step)' if modes == dict(phase_a='graph', phase_b='graph') else 'launch modes: %s' % modes))
-        except Exception as e:           # the side run must never cost the benchmark line
-          final = dict(error='%s: %s' % (type(e).__name__, e))
+        torch.cuda.empty_cache()
+        side = run_child('side', args)
+    final = None
+    if rank == 0 and world == 1 and not args.no_final_psnr:
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        final = run_child('final', args)
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         wl = ('C2: FFHQ 512^2 single-image latent inversion step' if M == 1 else
