@@ -228,6 +228,8 @@ _SIGS = {
     'eg3d_conv2d_v3': (C.c_int, [C.POINTER(ConvV2Params), C.c_void_p]),
     'eg3d_conv2d_wgrad_v2_supported': (C.c_int, [C.POINTER(WgradV2Params)]),
     'eg3d_conv2d_wgrad_v2': (C.c_int, [C.POINTER(WgradV2Params), C.c_void_p]),
+    'eg3d_conv2d_wgrad_v2_up_supported': (C.c_int, [C.POINTER(WgradV2Params)]),
+    'eg3d_conv2d_wgrad_v2_up': (C.c_int, [C.POINTER(WgradV2Params), C.c_void_p]),
     'eg3d_conv2d_wgrad_v2_slabs': (C.c_int, [C.POINTER(WgradV2Params)]),
     'eg3d_weight_grad_finish_slabs': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'eg3d_split_activation_bytes': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -429,7 +429,7 @@ class ModConvLayerFn(torch.autograd.Function):
         if rec is not None:             # (a no-grad forward of the same layer -- the canonical view of the warping loss -- leaves a pending record alone)
             _set_producer(cache, rec)
         # pivotal tuning: the weight gradient reads the forward's operand image again (csrc/conv_wgrad_v2.hip) instead of the fp32 activation
-        ctx.aimg = aimg if ((v2 or v3p) and up == 1 and want_wgrad and ctx.needs_input_grad[1] and H.WGRAD_V2 and Ci % 64 == 0 and Co % 64 == 0) else None
+        ctx.aimg = aimg if ((((v2 or v3p) and up == 1) or (ksu and up == 2)) and want_wgrad and ctx.needs_input_grad[1] and H.WGRAD_V2 and Ci % 64 == 0 and Co % 64 == 0) else None
         ctx.rec = rec                   # THIS forward's record: the backward below trusts only it (two live graphs of one layer cannot mix)
         ctx.save_for_backward(x, weight, styles, d, out, nz, noise_strength, b)
         ctx.cfg = (up, act_gain, clampv, nstride, cache, want_wgrad, noise is not None and noise.dim() == 4, d_in is not None)
@@ -498,15 +498,17 @@ class ModConvLayerFn(torch.autograd.Function):
             cls_adj = H.classes_corr_adjoint(Hi, Wi, kh, kw, kh // 2)
             in_stride = 1
             cls_w, out_stride_w = H.classes_corr(Ho, Wo, kh, kw, kh // 2), 1
-        elif (not need_w and (need_x or need_s) and up == 2 and kh == 3 and kw == 3 and prec in ('f16x3', 'f16x1') and amax is not None
-              and (H.conv_s2adj_ok(Co, Ci, Hi, Wi, N) or H.conv_v3_s2adj_ok(Co, Ci, Hi, Wi, N))):
-            # frozen weights (latent projection): the FIR adjoint writes the data gradient's operand directly as parity-split fp16 images
-            # (range bound up^2 max|dz|) -- no fp32 g, no strided gathers in the conv loader
+        elif ((need_x or need_s or need_w) and up == 2 and kh == 3 and kw == 3 and prec in ('f16x3', 'f16x1') and amax is not None
+              and (not (need_x or need_s) or H.conv_s2adj_ok(Co, Ci, Hi, Wi, N) or H.conv_v3_s2adj_ok(Co, Ci, Hi, Wi, N))
+              and (not need_w or H.conv_wgrad_v2_up_ok(Ci, Co, Hi, Wi, N))):
+            # the FIR adjoint writes the gradient operand directly as parity-split fp16 images (range bound up^2 max|dz|) -- no fp32 g, no strided
+            # gathers in a conv loader: the data gradient (conv_v2_s2adj / conv_v3_s2adj) and, when the weights train, the weight gradient
+            # (conv_wgrad_v2_up) both read them
             g = None
             gimg = H.fir44_adjoint_split(dz, amax, gain=float(up * up))
             cls_adj = H.classes_convT_adjoint(Hi, Wi, kh, kw, up)
             in_stride = up
-            cls_w, out_stride_w = None, up
+            cls_w, out_stride_w = H.classes_convT(Hi, Wi, kh, kw, up)[0], up
         else:
             if FIR_ADJ_LDS and Co % 64 == 0 and dz.shape[2] * dz.shape[3] >= FIR_ADJ_LDS:
                 # the separable, LDS-tiled FIR pass of the forward (1.6 loads per output instead of 6.25): the [1,3,3,1] filter is its own flip
@@ -596,7 +598,15 @@ class ModConvLayerFn(torch.autograd.Function):
                 use_v2w = H.conv_wgrad_v2_ok(gimg, ximg, cls_w)
             else:
                 use_v2w = False
-            if use_v2w:       # both operands as the split images the forward / data gradient consumed: LDS-DMA + transposing LDS reads, no VALU loader
+            if up == 2 and g is None:       # up layer on the parity-split path: G as the four parity images, X as the forward's (or a fresh) operand image
+                if ximg is None:
+                    ximg = H.split_activation(x, H.amax_of(x), in_scale=styles)
+                wtaps = [0] * 9
+                for c_ in cls_w:
+                    for t_ in range(c_.ntaps):
+                        wtaps[3 * (c_.out_py - 2 * c_.dy[t_]) + (c_.out_px - 2 * c_.dx[t_])] = c_.wtap[t_]
+                dwp = H.conv_wgrad_v2_up(gimg, ximg, H.zeros(wf.shape, dev), wtaps, products=1 if wprec == 'f16x1' else 3)
+            elif use_v2w:       # both operands as the split images the forward / data gradient consumed: LDS-DMA + transposing LDS reads, no VALU loader
                 if H.WGRAD_SLABS:       # partial tiles stored, summed in slab order by weight_grad_finish: no atomics, no zero fill
                     dwp = H.conv_wgrad_v2_slabs(gimg, ximg, cls_w, products=1 if wprec == 'f16x1' else 3)
                 else:

@@ -995,6 +995,32 @@ def conv_wgrad_v2(gimg: SplitImage, ximg: SplitImage, dwp, classes, products=3, 
     return dwp
 
 
+WGRAD_V2_UP = os.environ.get('EG3D_WGRAD_V2_UP', '1') != '0'
+WGRAD_V2_UP_MIN_CELLS = int(os.environ.get('EG3D_WGRAD_V2_UP_MIN_CELLS', '1024'))      # input cells (32^2) from which an up layer's weight gradient takes the parity-split kernel
+
+
+def conv_wgrad_v2_up_ok(Ci, Co, Hi, Wi, N=1):
+    """An up-sampling layer's weight gradient on conv_wgrad_v2_up_kernel (parity-split G image x split X image)."""
+    return bool(WGRAD_V2 and WGRAD_V2_UP and USE_V2 and CONV_MODE == 'auto' and Ci % 64 == 0 and Co % 64 == 0 and N * Hi * Wi >= WGRAD_V2_UP_MIN_CELLS)
+
+
+def conv_wgrad_v2_up(gimg: SplitImage, ximg: SplitImage, dwp, wtaps, products=3, row_groups=0):
+    """dwp[Co, 9*Ci] += weight gradient of a stride-2 3x3 transposed conv from the parity-split image of its gradient operand (fir44_adjoint_split) and
+    the split image of its modulated input; wtaps[3 ky + kx] = weight tap (eg3d_conv2d_wgrad_v2_up)."""
+    p = L.WgradV2Params()
+    n, ci, h, w = ximg.shape
+    co = gimg.shape[1]
+    p.g, p.x, p.g_scale, p.x_scale = gimg.data.data_ptr(), ximg.data.data_ptr(), gimg.scale.data_ptr(), ximg.scale.data_ptr()
+    p.N, p.H, p.W, p.Co, p.Ci = n, h, w, co, ci
+    p.ntaps = 9
+    for t in range(9):
+        p.dy[t], p.dx[t], p.wtap[t] = 0, 0, int(wtaps[t])
+    p.products, p.row_groups, p.slabs = int(products), int(row_groups), 0
+    p.dw, p.w_row = dwp.data_ptr(), dwp.stride(0)
+    L.check(L.lib().eg3d_conv2d_wgrad_v2_up(C.byref(p), L.stream_ptr()), 'conv2d_wgrad_v2_up')
+    return dwp
+
+
 def conv_wgrad_v2_slabs(gimg: SplitImage, ximg: SplitImage, classes, products=3, row_groups=0):
     """The same without atomics: returns slabs [nslab, Co, taps*Ci] of partial gradients whose sum IN SLAB ORDER is the gradient
     (weight_grad_finish(slabs, ...) sums them; torch.sum(0) for tests)."""

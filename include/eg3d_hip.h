@@ -349,6 +349,13 @@ typedef struct eg3d_wgrad_v2_params {
 int eg3d_conv2d_wgrad_v2_supported(const eg3d_wgrad_v2_params* p);
 int eg3d_conv2d_wgrad_v2_slabs(const eg3d_wgrad_v2_params* p);      /* number of slabs (= workgroups per channel tile) the launch will write; < 0: error */
 int eg3d_conv2d_wgrad_v2(const eg3d_wgrad_v2_params* p, void* stream);
+/* The same for an UP-SAMPLING layer (stride-2 3x3 transposed conv, torch_utils/ops/conv2d_resample.py:114-136 under base_coach.py:96-99):
+ *     dw[o, wtap[3 ky + kx], k] += 1 / (g_scale x_scale) * sum_{n,a,b} G_p[n, a + (ky >> 1), b + (kx >> 1), o] * X[n, a, b, k],  p = (ky & 1, kx & 1)
+ * p->g = the PARITY-split image of the gradient operand as eg3d_fir44_adjoint_split writes it ([N][2][Co/8][4][H + 1][W + 1][8] fp16),
+ * p->x = the split image of the layer input times its styles ([N][2][Ci/8][H][W][8]), H x W = the layer's INPUT resolution; ntaps = 9, dy / dx
+ * ignored, slabs = 0 (partial tiles added with atomics: dw pre-zeroed). */
+int eg3d_conv2d_wgrad_v2_up_supported(const eg3d_wgrad_v2_params* p);
+int eg3d_conv2d_wgrad_v2_up(const eg3d_wgrad_v2_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Tall-skinny Gram product for the decoder-weight gradients of pivotal tuning (training/triplane.py:116-136 under

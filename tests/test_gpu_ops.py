@@ -1255,6 +1255,47 @@ def test_conv_v3_stride2_adjoint_vs_torch(shape, products):
     assert torch.equal(outs[0], outs[1])            # the K slices are summed in wave order: run-to-run identical
 
 
+@pytest.mark.parametrize('shape', [(1, 64, 16, 32, 64), (2, 128, 9, 33, 64), (1, 64, 40, 70, 128), (1, 256, 32, 32, 128)])
+@pytest.mark.parametrize('products', [3, 1])
+def test_conv_wgrad_v2_up_vs_torch(shape, products):
+    """Weight gradient of an up-sampling layer (stride-2 3x3 transposed conv) from the parity-split image of its gradient operand
+    (eg3d_fir44_adjoint_split) and the split image of its modulated input (conv_wgrad_v2_up_kernel), vs torch fp64 autograd of F.conv_transpose2d
+    on the same FIR-adjoint gradient: ragged strips and row groups, batch 2, several channel tiles; and vs the loader-split kernel it replaces."""
+    from inv3d_amd import hipops as H, _lib as L
+    n, ci, h, w, co = shape
+    g_ = torch.Generator().manual_seed(71)
+    dz = torch.randn(n, co, 2 * h, 2 * w, generator=g_) * 1e-3
+    x = torch.randn(n, ci, h, w, generator=g_)
+    s = 1 + 0.5 * torch.randn(n, ci, generator=g_)
+    f1 = torch.tensor([1., 3., 3., 1.], dtype=torch.float64) / 8
+    f2 = torch.outer(f1, f1)[None, None].repeat(co, 1, 1, 1)
+    G = torch.nn.functional.conv2d(torch.nn.functional.pad(dz.double(), (2, 2, 2, 2)), f2, groups=co) * 4.0              # (2h + 1) x (2w + 1)
+    wt = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    z = torch.nn.functional.conv_transpose2d(x.double() * s.double()[:, :, None, None], wt.transpose(0, 1), stride=2)
+    ref, = torch.autograd.grad(z, wt, G)                                   # [co, ci, 3, 3]
+    dzc = dz.to(DEV).contiguous(memory_format=torch.channels_last)
+    xc = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    gimg = H.fir44_adjoint_split(dzc, H.absmax(dzc), gain=4.0)
+    ximg = H.split_activation(xc, H.absmax(xc), in_scale=s.to(DEV))
+    cls_w = H.classes_convT(h, w, 3, 3, 2)[0]
+    wtaps = [0] * 9
+    for c in cls_w:
+        for t in range(c.ntaps):
+            ky, kx = c.out_py - 2 * c.dy[t], c.out_px - 2 * c.dx[t]
+            wtaps[3 * ky + kx] = c.wtap[t]
+    dwp = torch.zeros(co, 9 * ci, device=DEV)
+    H.conv_wgrad_v2_up(gimg, ximg, dwp, wtaps, products=products)
+    got = dwp.view(co, 9, ci).permute(0, 2, 1).reshape(co, ci, 3, 3)
+    tol = 2e-5 if products == 3 else 3e-3
+    scale = float(ref.abs().max())
+    assert float((got.double().cpu() - ref).abs().max()) <= tol * scale, float((got.double().cpu() - ref).abs().max()) / scale
+    if products == 3:                   # the launch it replaces: fp32 G from the stand-alone FIR adjoint through the loader-split kernel
+        Gf = H.upfirdn2d_nhwc(dzc, torch.outer(f1, f1).float().to(DEV).contiguous(), pad=(2, 2, 2, 2), flip=True, gain=4.0)
+        dw2 = torch.zeros(co, 9 * ci, device=DEV)
+        H.conv_wgrad(xc, Gf, ci, co, dw2, cls_w, in_stride=1, out_stride=2, in_scale=s.to(DEV), precision='f16x3', g_amax=H.absmax(dzc), g_amax_mul=4.0)
+        assert float((dwp - dw2).abs().max()) <= 2e-5 * scale
+
+
 @pytest.mark.parametrize('shape', [(1, 64, 16, 32), (2, 128, 9, 20), (1, 192, 33, 17)])
 def test_upconv_epilogue_lds_and_fused_split(shape):
     """The LDS-staged separable FIR epilogue of the up layers (eg3d_upconv_epilogue_fwd) vs the 25-load kernel it replaces, on ragged tiles;
