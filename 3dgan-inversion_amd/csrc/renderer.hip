@@ -25,7 +25,10 @@ namespace {
 constexpr int FC = 32;     // features per plane
 constexpr int HD = 64;     // decoder hidden width
 constexpr int CO = 32;     // decoder colour outputs
-constexpr int MAXT = 192;  // threads per block
+#ifndef RK_MAXT
+#define RK_MAXT 192
+#endif
+constexpr int MAXT = RK_MAXT;  // threads per block
 
 // Decoder non-linearities: 64 softplus + 32 sigmoid per sample.  The libm log1pf/expf expand to ~150 instructions each (more than
 // twice the MLP's FMAs); the hardware exp2/log2 forms below are ~10 instructions, absolute error < 2e-7 on the result
@@ -146,11 +149,21 @@ __device__ __forceinline__ void atomic_max_float(float* a, float v) {
 }
 
 // weights of nS sorted samples (depths d, densities sg): alpha_i -> q_i -> T_i -> w_i, serial scan by one thread per ray
+#ifndef RK_FAST_ALPHA
+#define RK_FAST_ALPHA 1
+#endif
 __device__ __forceinline__ void march_alpha(const float* d, const float* sg, int i, float& alpha, float& delta, float& dens_mid) {
     delta = d[i + 1] - d[i];
     dens_mid = (sg[i] + sg[i + 1]) * 0.5f;
+#if RK_FAST_ALPHA
+    // hardware exp2 / log2 forms (absolute error < 2e-7 on sp and on alpha -- the size of the rounding of `1 - exp(-x)` itself); the libm
+    // expf / log1pf pair is ~450 of the ~750 vector instructions a thread of render_kernel<3> spends per interval
+    const float sp = softplusf_(dens_mid - 1.f);
+    alpha = 1.f - __expf(-(sp * delta));
+#else
     float sp = softplus_acc(dens_mid - 1.f);
     alpha = 1.f - expf(-(sp * delta));
+#endif
 }
 
 // ---- the per-ray serial scans ---------------------------------------------------------------------------------------------------------
@@ -630,7 +643,7 @@ __global__ void __launch_bounds__(MAXT) render_kernel(const eg3d_render_bwd_para
             const float m = 0.5f * (L.ss[i] + L.ss[i + 1]) - 1.f;
             GWT[i] = gw * L.t[i];
             DL[i] = L.sd[i + 1] - L.sd[i];
-            GA[i] = m > 20.f ? 1.f : sigmoid_acc(m);         // replaced by the interval's gradient in the scan
+            GA[i] = m > 20.f ? 1.f : (RK_FAST_ALPHA ? sigmoidf_(m) : sigmoid_acc(m));         // replaced by the interval's gradient in the scan
             xw[k] = gw * L.w[i];
         }
     }
