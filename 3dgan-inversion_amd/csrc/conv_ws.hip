@@ -1,0 +1,277 @@
+// Weight-streaming split-K convolution for gfx950: the 3x3 stride-1 layers of the 4^2 .. 16^2 blocks (16 .. 256 cells x 512 -> 512 channels at one
+// image per GPU; training/networks_stylegan2.py:34-91,417-461 -- forward and data gradient).
+//
+// At these sizes a launch is 9.4 MB of weights for 0.08 .. 1.2 GFLOP: the only thing to get right is that every weight byte is fetched ONCE, by
+// a workgroup that has all its loads in flight before its first matrix instruction.  The loader-split implicit GEMM walks the 4608-deep
+// contraction in 36 .. 288 barrier-separated steps of 3 MFMAs per wave (10 .. 30 us per launch, MfmaUtil 2 %, 4.4 x the weight bytes from HBM).
+// Here the contraction is cut into its 16-channel chunks ACROSS workgroups and nothing is left to loop over:
+//   workgroup = (32-channel tile, group of four chunks, block of <= 256 cells): 16 x 8 x 1 = 128 workgroups for 16^2 x 512 -> 512; wave = chunk;
+//   B: the nine taps' weight fragments of the wave's chunk -- 18 KB per wave, each byte of the weight image read by exactly one wave --
+//      go straight from global memory into registers (18 x buffer_load_dwordx4 per lane, issued first);
+//   A: the chunks' halos (<= 10 x 34 pixels x 16 channels of the fp32 NHWC activation each) are loaded, modulated, range-normalised and split
+//      into the two fp16 pieces HERE (a separate operand pass would cost a launch) and parked in LDS as the (piece, k-octet) planes conv_v3.hip reads;
+//   one barrier, then 9 taps x (MT x 3) v_mfma_f32_32x32x16_f16 per wave over ALL cells of the block; the four chunk tiles are summed in LDS in
+//   wave order and the total is added to the pre-zeroed fp32 output with atomics (EG3D_EPI_ATOMIC's contract: the finishing epilogue is
+//   somebody else's launch).  The atomics are what such a launch costs beyond its ~6 us latency chain -- 230 G float adds per second device-wide
+//   (one chunk per workgroup, 32 slices of 16^2 x 512: 18 us of a 25 us launch) -- hence four chunks per workgroup, not one.
+// Same arithmetic as conv_v2 / conv_v3 (two-piece split, three products, small terms first), so results differ from theirs by summation order only.
+#include "conv_v2_common.h"
+#include <atomic>
+#include <algorithm>
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int WS_BN = 32;                       // output channels of a workgroup (one MFMA column tile)
+constexpr int WS_CPW = 4;                       // 16-channel chunks of the contraction per workgroup = waves
+constexpr int WS_MAXSLOTS = 344;                // halo pixels of a cell block: 10 x 34 (32 wide), 18 x 18 (16 wide) ...
+constexpr int WS_SPP = 256 / (2 * WS_CPW);      // halo pixels per load pass: thread = (pixel of the pass, chunk, k-octet)
+
+__device__ __forceinline__ f16x8 ws_f16x8(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
+
+// FULL: three products per fp32 product; !FULL: high pieces only.  MT: MFMA row tiles (32 cells) of the workgroup's cell block (every wave computes
+// all of them for ITS chunk).
+template <bool FULL, int MT>
+__global__ void __launch_bounds__(256) conv_ws_kernel(const eg3d_conv_ws_params p) {
+    constexpr int NB = FULL ? 2 : 1;                                  // weight pieces
+    constexpr int MB = 32 * MT;
+    // halo load passes in flight: the whole halo of the 256-cell block in one global round trip (18 x 18 or 10 x 34 pixels: 11 passes), fewer
+    // for the smaller blocks (8 x 8 + halo: 4 passes; more registers and skipped instructions measured +0.7 us there)
+    constexpr int WS_BATCH = MT == 8 ? (WS_MAXSLOTS + WS_SPP - 1) / WS_SPP : (MT == 4 ? 7 : 4);
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // WS_CPW x 4 planes x SLOTS x 16 bytes; afterwards the [MT][4][64] float4 tile image
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HW = p.H * p.W;
+    const int ntile_n = p.Nc / WS_BN, nchunk = p.Ck / 16, ngrp = (nchunk + WS_CPW - 1) / WS_CPW, nmb = (HW + MB - 1) / MB;
+    int bid = blockIdx.x;
+    const int n_t = bid % ntile_n; bid /= ntile_n;
+    const int cg = bid % ngrp; bid /= ngrp;
+    const int mb = bid % nmb; const int n = bid / nmb;
+    const int m0 = mb * MB, n0 = n_t * WS_BN;
+    const int mlast = min(m0 + MB, HW) - 1;
+    const int ylo = m0 / p.W - 1, yhi = mlast / p.W + 1;
+    const int HP = p.W + 2, SLOTS = (yhi - ylo + 1) * HP;
+    const int chunk = cg * WS_CPW + wave;
+    const bool wave_live = chunk < nchunk;                             // (a contraction of 16 .. 48 channels: the last group is short)
+
+    // ---- B: all nine taps of this wave's chunk, both pieces, issued before anything else ---------------------------------------------------------
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)((int64_t)p.wtaps * nchunk * 4 * p.Nc * 16), 0x00020000);
+    const unsigned b_lane = (unsigned)(((lane >> 5) * p.Nc + n0 + (lane & 31)) * 16);
+    const int b_chunk = 4 * p.Nc * 16, b_piece = 2 * p.Nc * 16;
+    u32x4 breg[9][NB];
+    if (wave_live) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < NB; ++e)
+                breg[t][e] = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_lane, (p.wtap[t] * nchunk + chunk) * b_chunk + e * b_piece, 0);
+    }
+    // ---- A: the halos of the group's chunks.  thread = (pixel of the pass, chunk c, k-octet): its eight channels and their modulation are fixed -----
+    const int oct = tid & 1, ac = (tid >> 1) & (WS_CPW - 1), ps = tid >> 3;
+    const int achunk = min(cg * WS_CPW + ac, nchunk - 1);
+    const bool a_live = cg * WS_CPW + ac < nchunk;
+    const float* xn = p.x + (int64_t)n * HW * p.ldx + achunk * 16 + oct * 8;
+    float sv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sv[q] = 1.f;
+    float smax = 1.f;
+    if (p.in_scale != nullptr) {
+        const float* sr = p.in_scale + (int64_t)n * p.Ck + achunk * 16 + oct * 8;
+        const float4 s0 = *reinterpret_cast<const float4*>(sr), s1 = *reinterpret_cast<const float4*>(sr + 4);
+        sv[0] = s0.x; sv[1] = s0.y; sv[2] = s0.z; sv[3] = s0.w; sv[4] = s1.x; sv[5] = s1.y; sv[6] = s1.z; sv[7] = s1.w;
+        float m = 0.f;                       // max|in_scale| over [N, Ck]: every workgroup derives the same value (split_act_kernel's recipe)
+        for (int i = tid; i < p.N * p.Ck; i += 256) m = fmaxf(m, fabsf(p.in_scale[i]));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        smax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    }
+    const float mul = range_mul(*p.x_amax * p.x_amax_mul * smax);
+    const float out_mul = 1.f / (mul * *p.w_scale);
+    const int cplane = 4 * SLOTS * 16;                                 // bytes of one chunk's four (piece, k-octet) planes
+    for (int s0 = 0; s0 < SLOTS; s0 += WS_SPP * WS_BATCH) {
+        float4 raw[WS_BATCH][2];
+#pragma unroll
+        for (int k = 0; k < WS_BATCH; ++k) {
+            const int slot = s0 + k * WS_SPP + ps;
+            const int hy = slot / HP, hx = slot - hy * HP;
+            const int y = ylo + hy, x = hx - 1;
+            raw[k][0] = make_float4(0.f, 0.f, 0.f, 0.f); raw[k][1] = raw[k][0];
+            if (a_live && slot < SLOTS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+                const float* src = xn + (int64_t)(y * p.W + x) * p.ldx;
+                raw[k][0] = *reinterpret_cast<const float4*>(src); raw[k][1] = *reinterpret_cast<const float4*>(src + 4);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < WS_BATCH; ++k) {
+            const int slot = s0 + k * WS_SPP + ps;
+            if (slot >= SLOTS) continue;
+            float v[8] = {raw[k][0].x * sv[0], raw[k][0].y * sv[1], raw[k][0].z * sv[2], raw[k][0].w * sv[3],
+                          raw[k][1].x * sv[4], raw[k][1].y * sv[5], raw[k][1].z * sv[6], raw[k][1].w * sv[7]};
+            f16x8 h, l;
+            split8(v, mul, h, l, 2048.f);
+            *reinterpret_cast<f16x8*>(smem + ac * cplane + (oct * SLOTS + slot) * 16) = h;
+            if constexpr (FULL) *reinterpret_cast<f16x8*>(smem + ac * cplane + ((2 + oct) * SLOTS + slot) * 16) = l;
+        }
+    }
+    __syncthreads();
+
+    // ---- 9 taps x MT x 3 MFMAs -----------------------------------------------------------------------------------------------------------------
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    if (wave_live) {
+        unsigned a_addr[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = min(m0 + i * 32 + (lane & 31), HW - 1);
+            const int y = m / p.W, x = m - y * p.W;
+            a_addr[i] = (unsigned)(wave * cplane + ((lane >> 5) * SLOTS + (y - ylo) * HP + x + 1) * 16);
+        }
+        const f16x2 k2m11 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
+        const int lo_plane = 2 * SLOTS * 16;
+        // A fragments one tap ahead (one wave per SIMD: nothing else covers the LDS latency)
+        f16x8 af[2][MT][NB];
+        auto load_A = [&](int par, int t) {
+            const int toff = (p.dy[t] * HP + p.dx[t]) * 16;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                af[par][i][0] = *reinterpret_cast<const f16x8*>(smem + a_addr[i] + toff);
+                if constexpr (FULL) af[par][i][1] = *reinterpret_cast<const f16x8*>(smem + a_addr[i] + toff + lo_plane);
+            }
+        };
+        load_A(0, 0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t + 1 < 9) load_A((t + 1) & 1, t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const f16x8 bh = ws_f16x8(breg[t][0]);
+            f16x8 bl, bg;
+            if constexpr (FULL) {
+                bl = ws_f16x8(breg[t][1]);
+                const f16x2* s2 = reinterpret_cast<const f16x2*>(&bh);
+                f16x2* d2 = reinterpret_cast<f16x2*>(&bg);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) d2[q] = s2[q] * k2m11;
+            }
+            if constexpr (FULL) {               // product-major: consecutive MFMAs write different accumulators
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t & 1][i][1], bg, acc[i], 0, 0, 0);       // small terms first
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t & 1][i][0], bl, acc[i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t & 1][i][0], bh, acc[i], 0, 0, 0);
+        }
+    }
+    // ---- the four chunk tiles meet in LDS in wave order (fixed order: the sum a workgroup adds to `out` is a function of the geometry only), as an
+    //      image of the accumulator registers ([tile][register quad][lane] float4: 16-byte conflict-free accesses); then every wave adds a quarter of
+    //      the total to the pre-zeroed output: 32 lanes = 32 consecutive channels of one cell per atomic instruction ----------------------------------------------
+    float4* img = reinterpret_cast<float4*>(smem);
+#pragma unroll
+    for (int w = 0; w < WS_CPW; ++w) {
+        __syncthreads();                        // (w = 0: every wave is done reading the halos)
+        if (wave != w) continue;
+        if (w == 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) img[(i * 4 + g) * 64 + lane] = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 o = img[(i * 4 + g) * 64 + lane];
+                    acc[i][4 * g] += o.x; acc[i][4 * g + 1] += o.y; acc[i][4 * g + 2] += o.z; acc[i][4 * g + 3] += o.w;
+                    img[(i * 4 + g) * 64 + lane] = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+                }
+        }
+    }
+    __syncthreads();
+    // every wave adds its share of the total (row tiles wave, wave + 4, ...; with fewer than four tiles, register quads) to `out`
+    float* on = p.out + (int64_t)n * HW * p.ldo + n0 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (((i * 4 + g) & 3) != wave) continue;            // 4 MT quads over 4 waves
+            const float4 v = img[(i * 4 + g) * 64 + lane];
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            const int mrow = m0 + i * 32 + 4 * (lane >> 5) + 8 * g;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (mrow + q < HW) eg3d_acc(on + (int64_t)(mrow + q) * p.ldo, vv[q] * out_mul);
+        }
+}
+
+int ws_lds_bytes(const eg3d_conv_ws_params& p, int MT) {
+    const int HW = p.H * p.W, MB = 32 * MT;
+    const int rows = (HW > MB ? MB / p.W : p.H) + 2;
+    const int halo = WS_CPW * 4 * rows * (p.W + 2) * 16;
+    return std::max(halo, MT * 4 * 64 * 16);
+}
+
+std::atomic<uint64_t> g_ws_attr[8];
+
+template <bool FULL, int MT>
+int launch_ws(const eg3d_conv_ws_params& p, hipStream_t st, int slot) {
+    const int nmb = (p.H * p.W + 32 * MT - 1) / (32 * MT);
+    const int blocks = p.N * nmb * ((p.Ck / 16 + WS_CPW - 1) / WS_CPW) * (p.Nc / WS_BN);
+    const int lds = ws_lds_bytes(p, MT);
+    if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_ws_kernel<FULL, MT>), lds, g_ws_attr[slot])) return e;
+    hipLaunchKernelGGL((conv_ws_kernel<FULL, MT>), dim3(blocks), dim3(256), lds, st, p);
+    return EG3D_OK;
+}
+
+// row tiles (32 cells) per workgroup: the smallest of 1 / 2 / 4 / 8 that holds the image, else 256-cell blocks of whole rows
+int ws_mt(const eg3d_conv_ws_params& p) {
+    const int HW = p.H * p.W;
+    return HW <= 32 ? 1 : (HW <= 64 ? 2 : (HW <= 128 ? 4 : 8));
+}
+
+}  // namespace
+
+extern "C" int eg3d_conv2d_ws_supported(const eg3d_conv_ws_params* pp) {
+    if (!pp) return 0;
+    const eg3d_conv_ws_params& p = *pp;
+    if (p.N <= 0 || p.H <= 0 || p.W <= 0 || p.W > 32 || p.Ck < 16 || (p.Ck & 15) || p.Nc < WS_BN || (p.Nc % WS_BN) || (p.ldx & 3) || p.ldx < p.Ck || p.ldo < p.Nc) return 0;
+    if (p.products != 0 && p.products != 1 && p.products != 3) return 0;
+    for (int t = 0; t < 9; ++t)
+        if (p.dy[t] < -1 || p.dy[t] > 1 || p.dx[t] < -1 || p.dx[t] > 1 || p.wtap[t] < 0 || p.wtap[t] >= p.wtaps) return 0;
+    const int HW = p.H * p.W, MB = 32 * ws_mt(p);
+    if (HW > MB && (MB % p.W)) return 0;                                  // blocks of whole rows
+    const int rows = (HW > MB ? MB / p.W : p.H) + 2;
+    if (rows * (p.W + 2) > WS_MAXSLOTS) return 0;
+    if ((int64_t)p.wtaps * (p.Ck / 16) * 4 * p.Nc * 16 > 0x7fffffe0ll) return 0;
+    if ((int64_t)p.N * ((HW + MB - 1) / MB) * (p.Ck / 16) * (p.Nc / WS_BN) > 0x7fffffffll) return 0;
+    if (ws_lds_bytes(p, ws_mt(p)) > 160 * 1024) return 0;
+    return 1;
+}
+
+extern "C" int eg3d_conv2d_ws(const eg3d_conv_ws_params* pp, void* stream) {
+    if (!pp || !pp->x || !pp->w || !pp->out || !pp->x_amax || !pp->w_scale) return EG3D_ERR_INVALID;
+    if (!eg3d_conv2d_ws_supported(pp)) return EG3D_ERR_UNSUPPORTED;
+    const eg3d_conv_ws_params& p = *pp;
+    const void* ptrs[] = {p.x, p.in_scale, p.w};
+    for (const void* q : ptrs)
+        if (q != nullptr && (reinterpret_cast<uintptr_t>(q) & 15)) return EG3D_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND(det, p.out, (int64_t)p.N * p.H * p.W * p.ldo); EG3D_DET_COMMIT(det);
+    const bool full = p.products != 1;
+    int rc;
+    switch (ws_mt(p)) {
+        case 1: rc = full ? launch_ws<true, 1>(p, st, 0) : launch_ws<false, 1>(p, st, 1); break;
+        case 2: rc = full ? launch_ws<true, 2>(p, st, 2) : launch_ws<false, 2>(p, st, 3); break;
+        case 4: rc = full ? launch_ws<true, 4>(p, st, 4) : launch_ws<false, 4>(p, st, 5); break;
+        default: rc = full ? launch_ws<true, 8>(p, st, 6) : launch_ws<false, 8>(p, st, 7); break;
+    }
+    if (rc != EG3D_OK) return rc;
+    EG3D_DET_END(det);
+    return EG3D_OK;
+}

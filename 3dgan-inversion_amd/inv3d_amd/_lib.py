@@ -66,6 +66,14 @@ class ConvParams(C.Structure):
                 ('addend_up2', C.c_int32), ('addend_taps', C.c_float * 4)]
 
 
+class ConvWsParams(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('in_scale', C.c_void_p), ('x_amax', C.c_void_p), ('x_amax_mul', C.c_float),
+                ('w', C.c_void_p), ('w_scale', C.c_void_p), ('out', C.c_void_p),
+                ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('Ck', C.c_int32), ('ldx', C.c_int32),
+                ('Nc', C.c_int32), ('ldo', C.c_int32), ('wtaps', C.c_int32),
+                ('dy', C.c_int32 * 9), ('dx', C.c_int32 * 9), ('wtap', C.c_int32 * 9), ('products', C.c_int32)]
+
+
 class ConvV2Params(C.Structure):
     _fields_ = [('a', C.c_void_p), ('w', C.c_void_p), ('a_scale', C.c_void_p), ('w_scale', C.c_void_p), ('out', C.c_void_p),
                 ('N', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32), ('Ck', C.c_int32), ('Nc', C.c_int32), ('wtaps', C.c_int32),
@@ -226,6 +234,8 @@ _SIGS = {
     'eg3d_conv2d_v2': (C.c_int, [C.POINTER(ConvV2Params), C.c_void_p]),
     'eg3d_conv2d_v3_supported': (C.c_int, [C.POINTER(ConvV2Params)]),
     'eg3d_conv2d_v3': (C.c_int, [C.POINTER(ConvV2Params), C.c_void_p]),
+    'eg3d_conv2d_ws_supported': (C.c_int, [C.POINTER(ConvWsParams)]),
+    'eg3d_conv2d_ws': (C.c_int, [C.POINTER(ConvWsParams), C.c_void_p]),
     'eg3d_conv2d_wgrad_v2_supported': (C.c_int, [C.POINTER(WgradV2Params)]),
     'eg3d_conv2d_wgrad_v2': (C.c_int, [C.POINTER(WgradV2Params), C.c_void_p]),
     'eg3d_conv2d_wgrad_v2_up_supported': (C.c_int, [C.POINTER(WgradV2Params)]),

@@ -370,7 +370,11 @@ class ModConvLayerFn(torch.autograd.Function):
                              **epi_kw)
             else:
                 z = H.zeros_cl(N, Co, Ho, Wo, x.device)
-                H.conv_atomic(x, wf, Ci, Co, z, cls, in_scale=styles, ksplit=ks, algo_flops=aflops, precision=ig_prec, w_pieces=wfp)
+                if prec in ('f16x3', 'f16x1') and not weight.requires_grad and H.conv_ws_ok(Ci, Co, cls, N, Hi, Wi):
+                    # 4^2 .. 16^2: one workgroup per (channel tile, 16-channel chunk), every weight byte fetched once, operand split inside (csrc/conv_ws.hip)
+                    H.conv_ws(x, cache.get_split(weight)[0], z, cls, in_scale=styles, x_amax=H.amax_of(x), products=nprod, algo_flops=aflops)
+                else:
+                    H.conv_atomic(x, wf, Ci, Co, z, cls, in_scale=styles, ksplit=ks, algo_flops=aflops, precision=ig_prec, w_pieces=wfp)
                 if defer_epilogue and H.DEFER_EPILOGUE:
                     pending = H.PendingEpilogue(z, out, d, amax_out, **epi_kw)
                 else:
@@ -566,8 +570,11 @@ class ModConvLayerFn(torch.autograd.Function):
                     ds = ds.sum(0)
             else:                                  # low resolution: split K over blocks, then scale / reduce in a finishing pass
                 z = H.zeros_cl(N, Ci, Hi, Wi, dev)
-                H.conv_atomic(g, wa, Co, Ci, z, cls_adj, in_stride=in_stride, ksplit=ks, algo_flops=aflops, precision=ig_prec, a_amax=amax, w_pieces=wap,
-                              a_amax_mul=amul)
+                if up == 1 and prec in ('f16x3', 'f16x1') and amax is not None and not weight.requires_grad and H.conv_ws_ok(Co, Ci, cls_adj, N, Hi, Wi):
+                    H.conv_ws(g, cache.get_split(weight)[1], z, cls_adj, x_amax=amax, products=1 if prec == 'f16x1' else 3, algo_flops=aflops)
+                else:
+                    H.conv_atomic(g, wa, Co, Ci, z, cls_adj, in_stride=in_stride, ksplit=ks, algo_flops=aflops, precision=ig_prec, a_amax=amax, w_pieces=wap,
+                                  a_amax_mul=amul)
                 did = prod is not None and Ci % 4 == 0 and Ci <= 1024
                 if did:
                     H.dgrad_finish_act(z, x, styles, dx, spec, ds=ds, dz_amax=pacc[4])

@@ -782,6 +782,59 @@ def conv_v3(a: SplitImage, w: SplitImage, out, classes, plan=None, out_stride=1,
     return fused_act if act_bwd is not None else out
 
 
+CONV_WS = os.environ.get('EG3D_CONV_WS', '1') != '0'
+CONV_WS_MAX_CELLS = int(os.environ.get('EG3D_CONV_WS_MAX_CELLS', '256'))
+WS_CONFIG = 12
+
+
+def _conv_ws_params(x, w: SplitImage, out, cls, in_scale, x_amax, x_amax_mul, products):
+    p = L.ConvWsParams()
+    n, cx, h, wd = x.shape
+    _, co, ho, wo = out.shape
+    assert (ho, wo) == (h, wd) and cls.ntaps == 9 and cls.Ha == h and cls.Wa == wd and cls.out_py == 0 and cls.out_px == 0
+    p.x, p.in_scale, p.x_amax, p.x_amax_mul = x.data_ptr(), (in_scale.data_ptr() if in_scale is not None else None), x_amax.data_ptr(), float(x_amax_mul)
+    p.w, p.w_scale, p.out = w.data.data_ptr(), w.scale.data_ptr(), out.data_ptr()
+    O, I, T = w.shape
+    p.N, p.H, p.W, p.Ck, p.ldx = n, h, wd, I, cx
+    p.Nc, p.ldo, p.wtaps = O, co, T
+    for t in range(9):
+        p.dy[t], p.dx[t], p.wtap[t] = cls.dy[t], cls.dx[t], cls.wtap[t]
+    p.products = int(products)
+    return p
+
+
+def conv_ws_ok(Ck, Nc, classes, N, H, W):
+    """A split (atomic) 3x3 stride-1 launch on the weight-streaming kernel (csrc/conv_ws.hip): the 4^2 .. 16^2 layers at one image per GPU."""
+    if not (USE_V2 and CONV_WS) or CONV_MODE != 'auto' or len(classes) != 1 or classes[0].ntaps != 9 or Ck % 16 or Nc % 32 or W > 32:
+        return False
+    c = classes[0]
+    if (c.Ha, c.Wa, c.out_py, c.out_px) != (H, W, 0, 0) or any(abs(c.dy[t]) > 1 or abs(c.dx[t]) > 1 for t in range(9)):
+        return False
+    return N * H * W <= CONV_WS_MAX_CELLS
+
+
+def conv_ws(x, w: SplitImage, out, classes, in_scale=None, x_amax=None, x_amax_mul=1.0, products=3, algo_flops=None):
+    """Launch eg3d_conv2d_ws: out (pre-zeroed, channels_last fp32) += conv(x * in_scale, W) over the nine taps of classes[0]; w: split_weight image."""
+    assert is_cl(x) and is_cl(out) and x.dtype == torch.float32
+    p = _conv_ws_params(x, w, out, classes[0], in_scale, x_amax if x_amax is not None else absmax(x), x_amax_mul, products)
+    prof = PROFILER
+    if prof is not None and prof.only_config is not None and prof.only_config != WS_CONFIG:
+        prof = None
+    if prof is not None:
+        if algo_flops is None:
+            algo_flops = 2.0 * p.Ck * p.Nc * p.N * p.H * p.W * 9
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    L.check(L.lib().eg3d_conv2d_ws(C.byref(p), L.stream_ptr()), 'conv2d_ws')
+    if prof is not None:
+        e1.record()
+        prof.records.append(((WS_CONFIG, PRECISIONS['f16x3']), float(algo_flops), e0, e1))
+        if prof.meta is not None:
+            prof.meta.append(dict(N=p.N, Hi=p.H, Wi=p.W, Ck=p.Ck, Nc=p.Nc, Ho=p.H, Wo=p.W, taps=[9], epi=L.EPI_ATOMIC, ksplit=p.Ck // 16,
+                                  in_stride=1, out_stride=1, prec=3, ws=True))
+    return out
+
+
 def fir44_adjoint_split(dz, dz_amax, gain=4.0):
     """FIR adjoint of an up layer + operand split in one pass (eg3d_fir44_adjoint_split): dz [N,C,2Hi,2Wi] channels_last ->
     SplitImage of the four parity images of G = upfirdn2d(dz, [1,3,3,1]^2 / 64, pad 2, gain), shape (N, C, Hi + 1, Wi + 1) per parity."""

@@ -241,7 +241,7 @@ class SynthesisBlock(ReferenceStateMixin, torch.nn.Module):
         if self.in_channels == 0:
             if self.const.is_cuda and not self.const.requires_grad:      # frozen (latent projection): the broadcast channels_last copy is made once
                 nb = int(ws.shape[0])
-                x = H.memo(('const_cl', nb), [self.const], lambda: H.to_cl(self.const.detach().float().unsqueeze(0).expand(nb, -1, -1, -1)))
+                x = H.memo(('const_cl', nb), [self.const], lambda: (lambda t: H.tag_amax(t, H.absmax(t)))(H.to_cl(self.const.detach().float().unsqueeze(0).expand(nb, -1, -1, -1))))
             else:
                 x = self.const.unsqueeze(0).expand(ws.shape[0], -1, -1, -1)
             x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), styles=next(s_iter), demod=next(d_iter), single_consumer=True,

@@ -244,6 +244,28 @@ int eg3d_conv2d_v2(const eg3d_conv_v2_params* p, void* stream);
  * Restrictions (eg3d_conv2d_v3_supported): Ck % 16 == 0, Nc % 64 == 0, in_stride 1, nine-tap classes spanning at most 3 x 3. */
 int eg3d_conv2d_v3_supported(const eg3d_conv_v2_params* p);
 int eg3d_conv2d_v3(const eg3d_conv_v2_params* p, void* stream);
+/* Weight-streaming split-K form (csrc/conv_ws.hip) for the 3x3 stride-1 layers of the 4^2 .. 16^2 blocks at one image per GPU (16 .. 256 cells x
+ * 512 -> 512: 9.4 MB of weights for <= 1.2 GFLOP; forward and data gradient of training/networks_stylegan2.py:34-91): EG3D_EPI_ATOMIC's contract --
+ *     out[n, y, x, o] += sum_t sum_k  x[n, y + dy[t], x + dx[t], k] * in_scale[n, k] * W[o, wtap[t], k]        (out pre-zeroed, fp32, NHWC)
+ * with one workgroup per (32-channel tile, four 16-channel chunks of the contraction -- one per wave, summed in LDS in wave order --, block of
+ * <= 256 cells): every byte of the weight image is fetched by exactly one wave, all of its loads are in flight before its first matrix
+ * instruction, and the fp32 activation is modulated, range-normalised (x_amax * x_amax_mul * max|in_scale|) and split into the two fp16 pieces inside the kernel (no operand pass).
+ * Arithmetic of eg3d_conv2d_v2 (w: the weight image of eg3d_split_weight, w_scale its scale).  W <= 32, |dy|, |dx| <= 1, Ck % 16 == 0,
+ * Nc % 32 == 0, ldx % 4 == 0. */
+typedef struct eg3d_conv_ws_params {
+    const float* x;            /* [N,H,W,ldx] fp32 */
+    const float* in_scale;     /* [N,Ck] or null */
+    const float* x_amax;       /* device scalar: max|x| (or a bound) */
+    float x_amax_mul;
+    const void* w;  const float* w_scale;
+    float* out;                /* [N,H,W,ldo] fp32, accumulated with atomics */
+    int32_t N, H, W, Ck, ldx;
+    int32_t Nc, ldo, wtaps;
+    int32_t dy[9], dx[9], wtap[9];
+    int32_t products;          /* 0 / 3 | 1 */
+} eg3d_conv_ws_params;
+int eg3d_conv2d_ws_supported(const eg3d_conv_ws_params* p);
+int eg3d_conv2d_ws(const eg3d_conv_ws_params* p, void* stream);
 /* Data gradient of that transposed convolution (a stride-2 3x3 correlation; csrc/conv_v2_s2adj.hip) with the contract, epilogues and
  * weight image of eg3d_conv2d_v2, for ONE class of nine taps (dy, dx) = (t / 3, t % 3):
  *     acc[n,a,b,o] = sum_t sum_k  G[n, 2a + dy[t], 2b + dx[t], k] * W[o, wtap[t], k]

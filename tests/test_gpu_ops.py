@@ -955,6 +955,44 @@ def _v2_operands(x, wt, styles, adjoint=False):
     return xc, aimg, wimg
 
 
+@pytest.mark.parametrize('shape', [(1, 512, 16, 16, 512), (1, 512, 8, 8, 512), (1, 512, 4, 4, 512), (2, 64, 8, 16, 128), (1, 96, 5, 7, 64), (1, 32, 32, 32, 64),
+                                   (3, 32, 2, 32, 192), (1, 32, 1, 1, 64)])
+@pytest.mark.parametrize('products', [3, 1])
+@pytest.mark.parametrize('adjoint', [False, True])
+def test_conv_ws_vs_torch(shape, products, adjoint):
+    """Weight-streaming split-K kernel (csrc/conv_ws.hip): 3x3 stride-1 correlation of the style-modulated fp32 activation (forward taps) and the
+    flipped-tap data gradient (adjoint weight image), accumulated into a buffer that already holds values, vs torch fp64; the backbone's 16^2 /
+    8^2 / 4^2 x 512 -> 512 layers, batch 2 / 3, ragged 5 x 7 and 1 x 1 images, a 32^2 image in four 256-cell blocks."""
+    from inv3d_amd import hipops as H
+    n, ci, h, w, co = shape
+    g = torch.Generator().manual_seed(77)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)
+    if adjoint:           # dx = conv_transpose(dz, w): contraction over co
+        x = torch.randn(n, co, h, w, generator=g)
+        s = None
+        ref = torch.nn.functional.conv_transpose2d(x.double(), wt.double(), padding=1)
+        wp = H.pack_weight_adj(wt.to(DEV)); wimg = H.split_weight(wp, ci, co, 9)
+        cls = H.classes_corr_adjoint(h, w, 3, 3, 1)
+        cout = ci
+    else:
+        x = torch.randn(n, ci, h, w, generator=g) * 3
+        s = 1 + 0.5 * torch.randn(n, ci, generator=g)
+        ref = torch.nn.functional.conv2d(x.double() * s.double()[:, :, None, None], wt.double(), padding=1)
+        wp = H.pack_weight_fwd(wt.to(DEV)); wimg = H.split_weight(wp, co, ci, 9)
+        cls = H.classes_corr(h, w, 3, 3, 1)
+        cout = co
+    xc = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    sd = s.to(DEV) if s is not None else None
+    base = torch.randn(n, cout, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    assert H.conv_ws_ok(x.shape[1], cout, cls, n, h, w) == (n * h * w <= 256)
+    outs = []
+    for rep in range(2):
+        z = base.clone(memory_format=torch.channels_last)
+        H.conv_ws(xc, wimg, z, cls, in_scale=sd, x_amax=H.absmax(xc), products=products)
+        outs.append(z)
+    close(outs[0] - base, ref.float(), 2e-5 if products == 3 else 3e-3, f'conv_ws {shape} adjoint={adjoint}')
+
+
 @pytest.mark.parametrize('rows', [8, 4])        # 4: the half-height patch (hipops.V2_HALF)
 @pytest.mark.parametrize('shape', [(1, 32, 16, 64, 128), (2, 64, 40, 72, 128), (1, 128, 33, 37, 256), (1, 16, 8, 32, 128)])
 def test_conv_v2_forward_epilogue_vs_torch(shape, rows):

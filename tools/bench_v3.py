@@ -125,3 +125,32 @@ for (ci, res, co) in ((512, 32, 512), (512, 64, 256), (256, 128, 128)):
         v3(0)
         err = float((dx - ref).abs().max() / ref.abs().max())
         print(f'      conv_v3_s2adj products {products}: {t:6.1f} us ({gf / t * 1e3:4.0f} TF/s, executed {gf * products / t * 1e3:4.0f})  diff {err:.1e}', flush=True)
+
+
+# ---- the 4^2 .. 16^2 layers (split-K, atomic accumulation into a zeroed buffer): weight-streaming kernel vs the loader-split kernel ----------
+print('--- low-resolution 3x3 layers, EPI_ATOMIC (zero fill not included) ---', flush=True)
+for (ci, res, co) in ((512, 4, 512), (512, 8, 512), (512, 16, 512), (512, 32, 512)):
+    ws_ = [(torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)).to(dev) for _ in range(NWT)]
+    wfs = [H.pack_weight_fwd(w) for w in ws_]
+    wimgs = [H.split_weight(wf, co, ci, 9) for wf in wfs]
+    wps = [H.split_weight_pieces(wf) for wf in wfs]
+    s = (1 + 0.5 * torch.randn(N, ci, generator=g)).to(dev)
+    x = torch.randn(N, ci, res, res, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    ax = H.absmax(x)
+    cls = H.classes_corr(res, res, 3, 3, 1)
+    z = torch.zeros(N, co, res, res, device=dev).contiguous(memory_format=torch.channels_last)
+    gf = 2.0 * N * res * res * ci * co * 9 / 1e9
+    ks_old = F._auto_ksplit(cls, N, co, ci)
+
+    def old(k):
+        H.conv_atomic(x, wfs[k], ci, co, z, cls, in_scale=s, ksplit=ks_old, precision='f16x3', w_pieces=wps[k])
+    t = timed(old)
+    z.zero_(); old(0); ref = z.clone()
+    print(f'{res}^2 x {ci}->{co} N={N} ({gf:.2f} GF): igemm ks {ks_old} {t:6.1f} us', flush=True)
+    for products in (3, 1):
+        def ws(k):
+            H.conv_ws(x, wimgs[k], z, cls, in_scale=s, x_amax=ax, products=products)
+        t = timed(ws)
+        z.zero_(); ws(0)
+        err = float((z - ref).abs().max() / ref.abs().max())
+        print(f'      conv_ws products {products}: {t:6.1f} us  diff {err:.1e}', flush=True)
