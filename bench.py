@@ -624,7 +624,7 @@ def main():
                     continue
                 pk = FP32_MFMA_PEAK_TFLOPS if {vv: kk for kk, vv in H.PRECISIONS.items()}[k[1]] == 'f32' else BF16_MFMA_PEAK_TFLOPS
                 name = {H.V2_CONFIG: 'conv_v2<8 rows>', H.V2H_CONFIG: 'conv_v2<4 rows>', H.V2Q_CONFIG: 'conv_v2<2 rows>', H.UP2_CONFIG: 'conv_v2_up2',
-                        H.S2ADJ_CONFIG: 'conv_v2_s2adj', H.V3_CONFIG: 'conv_v3'}.get(k[0], 'conv_igemm<%s>' % H.TILE_NAMES.get(k[0], '?'))
+                        H.S2ADJ_CONFIG: 'conv_v2_s2adj', H.V3_CONFIG: 'conv_v3', H.WS_CONFIG: 'conv_ws'}.get(k[0], 'conv_igemm<%s>' % H.TILE_NAMES.get(k[0], '?'))
                 fams.append(dict(kernel=name + ' / ' + {vv: kk for kk, vv in H.PRECISIONS.items()}[k[1]], launches_per_step=v['launches'] / args.steps,
                                  ms_per_step=round(v['ms'] / args.steps, 4), tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1),
                                  frac=round(v['flops'] / (v['ms'] * 1e-3) / 1e12 / pk, 4), share_of_conv_time=round(v['ms'] / all_ms, 3)))
