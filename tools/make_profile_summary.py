@@ -104,15 +104,25 @@ if pf and pw:
     o.append('## HBM traffic (PMC, separate passes; FETCH_SIZE / WRITE_SIZE are reported in KiB)\n')
     o.append('`FETCH_SIZE` on gfx950 counts 64 B per 128-B request for wide coalesced reads, so it is doubled below as MI355X_MICROARCH.md (HBM section) '
              'prescribes; `WRITE_SIZE` is used as reported (uncalibrated).\n')
-    o.append('| kernel | launches | FETCH_SIZE/launch (raw MB) | corrected read MB | WRITE_SIZE/launch MB | total MB/launch |\n|---|---:|---:|---:|---:|---:|')
+    o.append('| kernel | launches | FETCH_SIZE/launch (raw MB) | corrected read MB | WRITE_SIZE/launch MB | total MB/launch | avg µs (same launches, FETCH pass) | TB/s |\n|---|---:|---:|---:|---:|---:|---:|---:|')
+    # durations of the SAME launches the FETCH_SIZE counters belong to (the pass's own kernel trace; counters attached)
+    dur = collections.defaultdict(lambda: [0, 0.0])
+    tf = one(sess + '/pf/*_kernel_trace.csv')
+    if tf:
+        for r in csv.DictReader(open(tf)):
+            e = dur[short(r['Kernel_Name'])]
+            e[0] += 1
+            e[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    avg_us = {k: v[1] / v[0] for k, v in dur.items() if v[0]}
     per_launch = {}
     for k in f:
         fr = f[k][1] / f[k][0] / 1024
         wr = w[k][1] / max(w[k][0], 1) / 1024 if k in w else 0.0
         per_launch[k] = (f[k][0], fr, wr, (2 * fr + wr) * 1e6)
-    for k in sorted(per_launch, key=lambda k: -per_launch[k][0] * per_launch[k][3])[:14]:
+    for k in sorted(per_launch, key=lambda k: -per_launch[k][0] * per_launch[k][3])[:22]:
         n, fr, wr, tot = per_launch[k]
-        o.append(f'| `{k}` | {n} | {fr:.2f} | {2*fr:.2f} | {wr:.2f} | {tot/1e6:.2f} |')
+        us = avg_us.get(k)
+        o.append(f'| `{k}` | {n} | {fr:.2f} | {2*fr:.2f} | {wr:.2f} | {tot/1e6:.2f} | ' + (f'{us:.1f} | {tot / us / 1e6:.2f} |' if us else '| |'))
     src = f'{os.path.basename(prefix)}_summary.md (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)'
     for k, (n, fr, wr, tot) in per_launch.items():
         if k.startswith('conv_'):
