@@ -359,6 +359,40 @@ def test_generator_with_the_128px_head():
     close(dws, dws_r, 2e-3, '2X generator d ws')
 
 
+def test_per_layer_style_affines_equal_the_style_bank():
+    """The style affines of every layer from ONE launch (fused.style_bank) vs the per-layer path (`styles = self.affine(w)` inside each layer: what
+    runs when the bank does not apply), full-size generator, every deferral switch at its default: same image and same latent gradient.  On the
+    per-layer path an affine's backward node runs BEFORE the previous block's toRGB node, so a split-K data gradient whose finish (and x.z
+    style-gradient term) is deferred to that toRGB launch would hand the affine an incomplete `ds` -- the deferral therefore requires the bank
+    (ADVICE r4, medium); this test fails if that condition goes."""
+    from inv3d_amd import hipops as H, synthetic as S, fused
+    G = S.make_generator(device=DEV)
+    S.load_synthetic_weights(G)
+    G.requires_grad_(False)
+    G.graph_eager = False
+    ws0 = S.synth_ws(G.backbone.num_ws, 512, 1).to(DEV)
+    cam = S.synth_cameras(1).to(DEV)
+    u1, u2 = S.make_uniforms(1, 128 * 128, 48, 48)
+    res = {}
+    keep = fused.style_bank
+    calls = []
+    try:
+        for mode in ('bank', 'per_layer'):
+            if mode == 'per_layer':
+                fused.style_bank = lambda ws, entries: (calls.append(len(entries)), None)[1]
+            ws = ws0.clone().requires_grad_(True)
+            out = G.synthesis(ws, cam, noise_mode='const', force_fp32=True, render_uniforms=(u1.to(DEV), u2.to(DEV)))
+            out['image'].square().sum().backward()
+            res[mode] = (out['image'].detach().clone(), ws.grad.clone())
+    finally:
+        fused.style_bank = keep
+    assert calls, 'the per-layer pass never asked for the bank: the test did not exercise what it claims'
+    scale = float(res['bank'][0].abs().max())
+    assert float((res['bank'][0] - res['per_layer'][0]).abs().max()) <= 2e-5 * scale
+    g0, g1 = res['bank'][1], res['per_layer'][1]
+    assert float((g0 - g1).abs().max()) <= 1e-4 * float(g0.abs().max()), float((g0 - g1).abs().max()) / float(g0.abs().max())
+
+
 @pytest.mark.parametrize('switch', ['DEFER_EPILOGUE', 'DEFER_DGRAD_FINISH'])
 def test_deferred_finishing_passes_equal_the_separate_launches(switch):
     """hipops.DEFER_EPILOGUE: conv1's split-K finishing pass run inside the toRGB launch of the 4^2 .. 64^2 blocks (eg3d_torgb_small_params::pre_z;
