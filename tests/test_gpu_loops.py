@@ -139,6 +139,40 @@ def test_pivotal_tuning_c4():
     assert worst < 5e-3, worst
 
 
+def test_deferred_weight_gradients_accumulate_into_existing_grads():
+    """Weight gradients queued inside hipops.deferred_weight_grads() (PivotalTuner's backward: the conv and toRGB weight-gradient GEMMs are
+    launched batched by flush_weight_grads) vs plain autograd, when every parameter ALREADY has a `.grad` (zero_grad(set_to_none=False),
+    gradient accumulation): the flush must ADD to it.  The toRGB layers used to hand autograd a view of a buffer the queued GEMM had not
+    written yet -- right only while AccumulateGrad stole that tensor."""
+    from inv3d_amd import hipops as H
+    cfg, P, G, cam, u1, u2, target, _ = _setup()
+    G.requires_grad_(True)
+    G.graph_eager = False
+    ws = O.synth_ws(cfg, 1, seed=1).to(DEV)
+    ru = (u1.to(DEV), u2.to(DEV))
+    params = [(k, v) for k, v in G.named_parameters() if v.requires_grad]
+
+    def loss():
+        return G.synthesis(ws, cam.to(DEV), noise_mode='const', force_fp32=True, render_uniforms=ru)['image'].square().mean()
+    for _, v in params:
+        v.grad = None
+    loss().backward()                                   # plain autograd, fresh gradients
+    plain = {k: v.grad.detach().clone() for k, v in params if v.grad is not None}
+    assert any('torgb.weight' in k for k in plain) and any('conv1.weight' in k for k in plain)
+    for _, v in params:                                 # existing gradients: ones
+        v.grad = torch.ones_like(v)
+    with H.deferred_weight_grads() as pending:
+        loss().backward()
+    H.flush_weight_grads(pending)
+    torch.cuda.synchronize()
+    for k, v in params:
+        if k not in plain:
+            continue
+        want = plain[k] + 1.0
+        e = float((v.grad - want).abs().max())
+        assert e <= 2e-4 * max(1e-3, float(plain[k].abs().max())), (k, e, float(plain[k].abs().max()))
+
+
 def test_coach_phase_a_then_b_per_image():
     """InversionCoach (the image loop of single_id_coach.py): per image a pristine generator, Phase A then Phase B, metrics; the
     generator is restored between images and at the end, and tuning improves on the pivot."""
