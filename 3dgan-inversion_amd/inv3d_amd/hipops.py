@@ -914,7 +914,7 @@ V2H_CONFIG = 8       # ... of the pre-split kernel's half-height (4 x 32) patch 
 V2Q_CONFIG = 9       # ... of its quarter-height (2 x 32) patch instantiation
 V2_UP2 = os.environ.get('EG3D_V2_UP2', '1') != '0'
 UP2_MIN_TILES = int(os.environ.get('EG3D_UP2_MIN_TILES', '256'))      # workgroups (512 threads, 115 KB of LDS: one per CU) below which the layer stays on the loader-split kernel
-UP2_MIN_CK = int(os.environ.get('EG3D_UP2_MIN_CK', '64'))
+UP2_MIN_CK = int(os.environ.get('EG3D_UP2_MIN_CK', '32'))      # 32: SR block 0 conv0 (32 -> 256 channels, 128^2 -> 256^2) too: +0.2 % on the step (A/B twice)
 
 
 def conv_up2_plan(Ck, Nc, Hi, Wi, N=1):
