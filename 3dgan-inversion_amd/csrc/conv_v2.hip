@@ -399,6 +399,7 @@ extern "C" int eg3d_conv2d_v2_supported(const eg3d_conv_v2_params* pp) {
         for (int c = 0; c < p.ncls; ++c) if (p.cls[c].ntaps != 9) return 0;
     }
     if (p.epi == EG3D_EPI_FWD && !eg3d_act_is_pwl(p.act)) return 0;
+    if (p.rgb_out != nullptr && (p.epi != EG3D_EPI_FWD || p.Nc != BN || p.ncls != 1 || !p.rgb_w || !p.rgb_s || (p.rgb_ldw & 3) || p.rgb_ldw < p.Nc || (p.rgb_nout != 0 && p.rgb_nout != 3 && p.rgb_nout != 4))) return 0;
     if (p.epi == EG3D_EPI_BWD_ACT) {
         const eg3d_act_bwd& ab = p.act_bwd;
         if (ab.act != EG3D_ACT_LINEAR && ab.act != EG3D_ACT_LRELU) return 0;          // invertible piecewise-linear activations only
@@ -423,7 +424,7 @@ extern "C" int eg3d_conv2d_v2(const eg3d_conv_v2_params* pp, void* stream) {
     if (!eg3d_conv2d_v2_supported(pp)) return EG3D_ERR_UNSUPPORTED;
     const eg3d_conv_v2_params& p = *pp;
     if (p.epi == EG3D_EPI_BWD_ACT && !p.xin) return EG3D_ERR_INVALID;
-    const void* ptrs[] = {p.out, p.addend, p.xin, p.out_scale, p.bias, p.act_bwd.d, p.act_bwd.bias};
+    const void* ptrs[] = {p.out, p.addend, p.xin, p.out_scale, p.bias, p.act_bwd.d, p.act_bwd.bias, p.rgb_w, p.rgb_s, p.rgb_bias, p.rgb_out};
     for (const void* q : ptrs)
         if (q != nullptr && (reinterpret_cast<uintptr_t>(q) & 15)) return EG3D_ERR_UNSUPPORTED;
     if (p.epi == EG3D_EPI_FWD && p.noise && !p.noise_strength) return EG3D_ERR_INVALID;

@@ -124,6 +124,21 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), scl4 = make_float4(1.f, 1.f, 1.f, 1.f), dsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (epi == EG3D_EPI_FWD && p.bias != nullptr) bias4 = *reinterpret_cast<const float4*>(p.bias + col);
     if ((epi == EG3D_EPI_FWD || bwd_like) && p.out_scale != nullptr) scl4 = *reinterpret_cast<const float4*>(p.out_scale + (int64_t)n * p.Nc + col);
+    // the 1x1 head (eg3d_conv_v2_params::rgb_out): this thread's four channels of the four modulated weight rows
+    const bool rgb_on = epi == EG3D_EPI_FWD && p.rgb_out != nullptr;
+    float4 rw[4];
+    float4 rgb_b = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) rw[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rgb_on) {
+        const float4 s4 = *reinterpret_cast<const float4*>(p.rgb_s + (int64_t)n * p.Nc + col);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const float4 w4 = *reinterpret_cast<const float4*>(p.rgb_w + (int64_t)o * p.rgb_ldw + col);
+            rw[o] = make_float4(w4.x * s4.x, w4.y * s4.y, w4.z * s4.z, w4.w * s4.w);
+        }
+        if (p.rgb_bias != nullptr) rgb_b = *reinterpret_cast<const float4*>(p.rgb_bias);
+    }
     float4 abd4 = make_float4(1.f, 1.f, 1.f, 1.f), abb4 = make_float4(0.f, 0.f, 0.f, 0.f), accb4 = abb4, accd4 = abb4;
     float accs = 0.f;
     if (act_on && ab.d != nullptr) abd4 = *reinterpret_cast<const float4*>(ab.d + (int64_t)n * p.Nc + col);
@@ -185,6 +200,22 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
                         if (p.clamp >= 0.f) e[q] = fminf(fmaxf(e[q], -p.clamp), p.clamp);
                     }
                     v = make_float4(e[0] + sa[u].x, e[1] + sa[u].y, e[2] + sa[u].z, e[3] + sa[u].w);
+                    if (rgb_on) {                   // the 32 lanes of a half-wave hold the 128 channels of this pixel
+                        float r4[4];
+#pragma unroll
+                        for (int o = 0; o < 3; ++o)
+                            r4[o] = eg3d_row_group_sum(fmaf(v.w, rw[o].w, fmaf(v.z, rw[o].z, fmaf(v.y, rw[o].y, v.x * rw[o].x))), 32);
+                        r4[3] = 0.f;
+                        if (p.rgb_nout != 3) r4[3] = eg3d_row_group_sum(fmaf(v.w, rw[3].w, fmaf(v.z, rw[3].z, fmaf(v.y, rw[3].y, v.x * rw[3].x))), 32);
+                        if (c4 == 0) {
+                            float4 y = make_float4(r4[0] + rgb_b.x, r4[1] + rgb_b.y, r4[2] + rgb_b.z, r4[3] + rgb_b.w);
+                            if (p.rgb_clamp >= 0.f) {
+                                y.x = fminf(fmaxf(y.x, -p.rgb_clamp), p.rgb_clamp); y.y = fminf(fmaxf(y.y, -p.rgb_clamp), p.rgb_clamp);
+                                y.z = fminf(fmaxf(y.z, -p.rgb_clamp), p.rgb_clamp); y.w = fminf(fmaxf(y.w, -p.rgb_clamp), p.rgb_clamp);
+                            }
+                            *reinterpret_cast<float4*>(p.rgb_out + ((int64_t)n * HWo + pixl[u]) * 4) = y;
+                        }
+                    }
                 } else if (bwd_like) {
                     if (do_ds) { dsum4.x += v.x * sb[u].x; dsum4.y += v.y * sb[u].y; dsum4.z += v.z * sb[u].z; dsum4.w += v.w * sb[u].w; }
                     v = make_float4(v.x * scl4.x + sa[u].x, v.y * scl4.y + sa[u].y, v.z * scl4.z + sa[u].z, v.w * scl4.w + sa[u].w);

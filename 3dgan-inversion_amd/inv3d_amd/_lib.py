@@ -81,7 +81,8 @@ class ConvV2Params(C.Structure):
                 ('ncls', C.c_int32), ('cls', ConvClass * 4), ('epi', C.c_int32),
                 ('out_scale', C.c_void_p), ('bias', C.c_void_p), ('noise', C.c_void_p), ('noise_nstride', C.c_int64),
                 ('noise_strength', C.c_void_p), ('act', C.c_int32), ('alpha', C.c_float), ('gain', C.c_float), ('clamp', C.c_float),
-                ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p), ('out_amax', C.c_void_p), ('act_bwd', ActBwd), ('products', C.c_int32), ('ksplit', C.c_int32), ('patch_rows', C.c_int32)]
+                ('addend', C.c_void_p), ('xin', C.c_void_p), ('ds', C.c_void_p), ('out_amax', C.c_void_p), ('act_bwd', ActBwd), ('products', C.c_int32), ('ksplit', C.c_int32), ('patch_rows', C.c_int32),
+                ('rgb_w', C.c_void_p), ('rgb_s', C.c_void_p), ('rgb_bias', C.c_void_p), ('rgb_out', C.c_void_p), ('rgb_clamp', C.c_float), ('rgb_ldw', C.c_int32), ('rgb_nout', C.c_int32)]
 
 
 class ConvUp2Params(C.Structure):

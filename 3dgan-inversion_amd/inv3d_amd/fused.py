@@ -295,7 +295,10 @@ def _finish_pending(pend, x):
 class ModConvLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, styles, noise, noise_strength, bias, up, act_gain, clamp, cache, want_wgrad, d_in=None, single_consumer=False,
-                input_is_layer_output=False, precision=None, next_styles=None, defer_epilogue=False):
+                input_is_layer_output=False, precision=None, next_styles=None, defer_epilogue=False, rgb_head=None):
+        # rgb_head: (toRGB weight [O<=4, Co, 1, 1], its styles [N, Co], bias | None, clamp | None, its WeightCache) of the toRGB layer that reads this
+        # layer's output next: evaluated in this launch's epilogue where the kernel can (hipops.conv_v2 rgb_head); the result rides on the output
+        # tensor (`_eg3d_rgb_y`) for ToRGBFn.forward, which then launches nothing
         # defer_epilogue: the caller hands the output to a toRGB node NEXT and to nothing before it: a split-K layer then leaves its finishing pass
         # to that node's launch (hipops.PendingEpilogue on the output tensor; ToRGBFn.forward runs or absorbs it)
         # precision: None = the process-wide arithmetic of the modulated convs; 'f16x1' = the reference's fp16 layers (one product of
@@ -353,9 +356,20 @@ class ModConvLayerFn(torch.autograd.Function):
             else:
                 aimg = H.split_activation(x, H.amax_of(x), in_scale=styles)
             wimg = cache.get_split(weight)[0]
+        rgb_y = None
         if up == 1:
             if v2:
-                H.conv_v2(aimg, wimg, out, cls, epi=L.EPI_FWD, out_scale=d, out_amax=amax_out, algo_flops=aflops, products=nprod, **epi_kw)
+                rkw = {}
+                if rgb_head is not None and H.RGB_HEAD and Co == 128 and len(cls) == 1:
+                    tw, ts, tb, tclamp, tcache = rgb_head
+                    if tw.shape[0] <= 4 and tw.shape[1] == Co and tuple(ts.shape) == (N, Co):
+                        tw4, _, tb4 = tcache.get_padded(tw, 4, tb) if tw.shape[0] != 4 else (tcache.get(tw)[0], None, tb.contiguous().float() if tb is not None else None)
+                        y4 = H.empty_cl(N, 4, Ho, Wo, x.device)
+                        ts_c = ts.contiguous().float()
+                        rkw = dict(rgb_head=(tw4, ts_c, tb4, y4, -1.0 if tclamp is None else float(tclamp), 3 if tw.shape[0] == 3 else 4))
+                        rgb_y = (y4, tw.data_ptr(), tw._version, ts.data_ptr(), None, None if tb is None else (tb.data_ptr(), tb._version),
+                                 -1.0 if tclamp is None else float(tclamp))
+                H.conv_v2(aimg, wimg, out, cls, epi=L.EPI_FWD, out_scale=d, out_amax=amax_out, algo_flops=aflops, products=nprod, **epi_kw, **rkw)
             elif v3p:
                 H.conv_v3(aimg, wimg, out, cls, plan=v3p, epi=L.EPI_FWD, out_scale=d, out_amax=amax_out, algo_flops=aflops, products=nprod, **epi_kw)
             elif ks2:
@@ -415,6 +429,8 @@ class ModConvLayerFn(torch.autograd.Function):
             else:
                 H.epilogue_fwd(z, out, fir=fir44(x.device), pad0=1, fir_gain=float(up * up), d=d, out_amax=amax_out, **epi_kw)
         H.tag_amax(out, amax_out)
+        if rgb_y is not None:
+            out._eg3d_rgb_y = rgb_y
         if pending is not None:
             out._eg3d_pending_epi = pending
         rec = None
@@ -628,7 +644,7 @@ class ModConvLayerFn(torch.autograd.Function):
         if dnoise is not None and noise4d:
             dnoise = dnoise.view(N, 1, Ho, Wo)
         return (dx if need_x else None, dweight, ds if need_s else None, dnoise, dstrength, dbias, None, None, None, None, None,
-                dd if d_given else None, None, None, None, None, None)
+                dd if d_given else None, None, None, None, None, None, None)
 
 
 class StyleBankFn(torch.autograd.Function):
@@ -741,10 +757,12 @@ class ToRGBFn(torch.autograd.Function):
         L.require_cuda(x, weight, styles)
         PENDING_DGRAD.clear()            # (entries live inside one backward pass; anything left over belongs to a pass that was abandoned)
         pend = x.__dict__.pop('_eg3d_pending_epi', None) if hasattr(x, '__dict__') else None      # the producing layer's finishing pass is still due (ModConvLayerFn defer_epilogue)
+        pre_y = x.__dict__.pop('_eg3d_rgb_y', None) if hasattr(x, '__dict__') else None            # ... or this very layer already ran in the producing launch's epilogue
         if pend is not None and not (H.is_cl(x) and x.dtype == torch.float32 and pend.out is x):
             pend.run()
             pend = None
         x = H.to_cl(x.float())
+        styles_key = styles.data_ptr()          # (of the tensor the caller holds: what ModConvLayerFn recorded with a pre-computed y)
         styles = styles.contiguous().float()
         N, Ci, Hh, Ww = x.shape
         Co = weight.shape[0]
@@ -805,9 +823,13 @@ class ToRGBFn(torch.autograd.Function):
                 H.conv_igemm(x, wf, Ci, Cp, out, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=-1.0, addend=skip,
                              precision=_igemm_precision())
         else:
-            y = H.empty_cl(N, Cp, Hh, Ww, x.device)
-            H.conv_igemm(x, wf, Ci, Cp, y, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=clampv,
-                         precision=_igemm_precision())
+            if (pre_y is not None and Cp == 4 and tuple(pre_y[0].shape) == (N, Cp, Hh, Ww) and pre_y[1:3] == (weight.data_ptr(), weight._version)
+                    and pre_y[3] == styles_key and pre_y[5] == (None if bias is None else (bias.data_ptr(), bias._version)) and pre_y[6] == clampv):
+                y = pre_y[0]                # evaluated by conv1's epilogue from the values it was writing: no launch here
+            else:
+                y = H.empty_cl(N, Cp, Hh, Ww, x.device)
+                H.conv_igemm(x, wf, Ci, Cp, y, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=clampv,
+                             precision=_igemm_precision())
             out = y + skip if skip is not None else y
         ctx.save_for_backward(x, weight, styles, y if clampv >= 0 else None)
         ctx.cfg = (clampv, cache, want_wgrad, Cp, skip is not None, bool(skip_up))

@@ -678,9 +678,12 @@ V2_KS_MIN_CHUNKS = int(os.environ.get('EG3D_V2_KS_MIN_CHUNKS', '2'))
 
 def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_STORE, out_scale=None, bias=None, noise=None, noise_nstride=0,
             noise_strength=None, act='linear', alpha=0.0, gain=1.0, clamp=-1.0, addend=None, xin=None, ds=None, out_amax=None, algo_flops=None,
-            act_bwd=None, products=3, ksplit=1, patch_rows=None):
+            act_bwd=None, products=3, ksplit=1, patch_rows=None, rgb_head=None):
     """Launch eg3d_conv2d_v2 (operands prepared by split_activation / split_weight).  act_bwd (ActBwdSpec, with epi=EPI_BWD): EPI_BWD_ACT when
-    the kernel takes it -- returns True if the fused epilogue ran, False for a plain EPI_BWD."""
+    the kernel takes it -- returns True if the fused epilogue ran, False for a plain EPI_BWD.
+    rgb_head (EPI_FWD, 128 output channels): (w4 [4, >= Nc] packed weight rows, styles [N, Nc], bias4 [4] | None, y4 [N,4,H,W] channels_last, clamp[, 3 = the
+    fourth row is padding]) --
+    the 1x1 layer that reads `out` next, evaluated in this launch's epilogue (eg3d_conv_v2_params::rgb_out)."""
     assert is_cl(out)
     p = _conv_v2_params(a, w, out, classes, out_stride, epi, out_scale, bias, noise, noise_nstride, noise_strength, act, alpha, gain, clamp,
                         addend, xin, ds, out_amax)
@@ -690,6 +693,12 @@ def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_
     if patch_rows is None:          # the caller did not plan: 4-row patches where they fill the chip and 8-row ones do not
         patch_rows = conv_v2_rows(p.Ck, p.Nc, classes, p.N) if epi != L.EPI_ATOMIC else 8
     p.patch_rows = patch_rows if patch_rows in (4, 2) else 8
+    if rgb_head is not None:
+        w4, s4, b4, y4, rclamp = rgb_head[:5]
+        p.rgb_nout = int(rgb_head[5]) if len(rgb_head) > 5 else 4
+        assert epi == L.EPI_FWD and is_cl(y4) and y4.shape[1] == 4 and w4.shape[0] == 4 and w4.stride(1) == 1 and s4.is_contiguous()
+        p.rgb_w, p.rgb_s, p.rgb_bias, p.rgb_out = w4.data_ptr(), s4.data_ptr(), (b4.data_ptr() if b4 is not None else None), y4.data_ptr()
+        p.rgb_clamp, p.rgb_ldw = float(rclamp), w4.stride(0)
     fused_act = False
     if act_bwd is not None and epi == L.EPI_BWD and xin is not None:
         p.epi = L.EPI_BWD_ACT
@@ -782,6 +791,7 @@ def conv_v3(a: SplitImage, w: SplitImage, out, classes, plan=None, out_stride=1,
     return fused_act if act_bwd is not None else out
 
 
+RGB_HEAD = os.environ.get('EG3D_RGB_HEAD', '1') != '0'       # the SR head's last toRGB evaluated in conv1's forward epilogue (eg3d_conv_v2_params::rgb_out)
 CONV_WS = os.environ.get('EG3D_CONV_WS', '1') != '0'
 CONV_WS_MAX_CELLS = int(os.environ.get('EG3D_CONV_WS_MAX_CELLS', '256'))
 WS_CONFIG = 12

@@ -135,8 +135,9 @@ class SynthesisLayer(ReferenceStateMixin, torch.nn.Module):
         self._cache = fused.WeightCache()
 
     def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, noise_inject=None, styles=None, demod=None, single_consumer=False,
-                input_is_layer_output=False, precision=None, next_styles=None, defer_epilogue=False):
-        """`defer_epilogue`: the returned tensor goes to a toRGB node next and to nothing before it (fused.ModConvLayerFn).
+                input_is_layer_output=False, precision=None, next_styles=None, defer_epilogue=False, rgb_head=None):
+        """`rgb_head`: (toRGB layer, its styles) when that layer reads the returned tensor next (fused.ModConvLayerFn).
+        `defer_epilogue`: the returned tensor goes to a toRGB node next and to nothing before it (fused.ModConvLayerFn).
         `styles` / `demod`: this layer's affine(w) and demodulation coefficients when the enclosing network already evaluated them
         for all layers in one launch (fused.style_bank).  `single_consumer`: the caller promises that the returned tensor feeds exactly one
         fused op (conv1 / toRGB of the same block), which lets that op's backward absorb this layer's activation backward (fused.py);
@@ -154,7 +155,8 @@ class SynthesisLayer(ReferenceStateMixin, torch.nn.Module):
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return fused.ModConvLayerFn.apply(x, self.weight, styles, noise, self.noise_strength if noise is not None else None, self.bias,
                                           self.up, self.act_gain * gain, clamp, self._cache, self.weight.requires_grad, demod, single_consumer,
-                                          input_is_layer_output, precision, next_styles, defer_epilogue)
+                                          input_is_layer_output, precision, next_styles, defer_epilogue,
+                                          None if rgb_head is None else (rgb_head[0].weight, rgb_head[1], rgb_head[0].bias, rgb_head[0].conv_clamp, rgb_head[0]._cache))
 
     def extra_repr(self):
         return f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}, w_dim={self.w_dim:d}, ' \
@@ -248,10 +250,13 @@ class SynthesisBlock(ReferenceStateMixin, torch.nn.Module):
                            defer_epilogue=True, **layer_kwargs)
         else:       # conv0's output feeds conv1 only, conv1's the toRGB node only (which passes it on to the next block through itself)
             s0, s1 = next(s_iter), next(s_iter)          # conv1's styles are known before conv0 runs: its epilogue can write conv1's operand image
+            st = next(s_iter)                             # ... and the toRGB layer's before conv1 runs: a <= 4-channel toRGB can ride in conv1's epilogue
+            s_iter = iter([st])
             x = self.conv0(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv0'), styles=s0, demod=next(d_iter), single_consumer=True,
                            next_styles=s1, **layer_kwargs)
             x = self.conv1(x, next(w_iter), noise_inject=ni.get(f'{_name}.conv1'), styles=s1, demod=next(d_iter), single_consumer=True,
-                           input_is_layer_output=True, defer_epilogue=True, **layer_kwargs)
+                           input_is_layer_output=True, defer_epilogue=True,
+                           rgb_head=(self.torgb, st) if (st is not None and self.torgb.out_channels <= 4) else None, **layer_kwargs)
         # the skip image is handed over at half resolution: the toRGB node up-samples it (inside its conv's epilogue where it can)
         skip_up = img is not None and self.conv0_up == 2
         if self.is_last:

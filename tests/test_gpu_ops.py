@@ -1019,6 +1019,46 @@ def test_conv_v2_forward_epilogue_vs_torch(shape, rows):
     assert abs(float(amax) - float(out.abs().max())) == 0.0
 
 
+@pytest.mark.parametrize('rows', [8, 4])
+@pytest.mark.parametrize('products', [3, 1])
+@pytest.mark.parametrize('shape', [(1, 32, 16, 64, 128), (2, 64, 40, 72, 128), (1, 16, 9, 33, 128)])
+def test_conv_v2_rgb_head_vs_torch(shape, rows, products):
+    """The 1x1 head of the forward epilogue (eg3d_conv_v2_params::rgb_out: the toRGB layer that reads a 128-channel layer's output next,
+    networks_stylegan2.py:338-359, evaluated while the values are in registers): y = clamp(sum_c out[c] w[o,c] s[n,c] + b[o]) against torch on the
+    layer output the same launch wrote (exact fp32 arithmetic on identical inputs: 1e-6), a clamp that bites, ragged grids, batch 2, both patch
+    heights, both arithmetic classes; the layer output itself is unchanged by the head."""
+    from inv3d_amd import hipops as H, _lib as L
+    n, ci, h, w, co = shape
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)
+    s = 1 + 0.5 * torch.randn(n, ci, generator=g)
+    d = 0.5 + torch.rand(n, co, generator=g)
+    bias = 0.1 * torch.randn(co, generator=g)
+    tw = torch.zeros(4, co + 4)                         # row pitch larger than the channel count; fourth row = padding channel
+    tw[:3, :co] = torch.randn(3, co, generator=g)
+    ts = (1 + 0.5 * torch.randn(n, co, generator=g)) / math.sqrt(co)
+    tb = torch.tensor([0.2, -0.1, 0.05, 0.0])
+    xc, aimg, wimg = _v2_operands(x, wt, s)
+    cls = H.classes_corr(h, w, 3, 3, 1)
+    kw = dict(epi=L.EPI_FWD, out_scale=d.to(DEV), bias=bias.to(DEV), act='lrelu', alpha=0.2, gain=1.4, clamp=-1.0, patch_rows=rows, products=products)
+    plain = H.empty_cl(n, co, h, w, DEV)
+    H.conv_v2(aimg, wimg, plain, cls, **kw)
+    for clamp in (-1.0, 0.6):
+        out = H.empty_cl(n, co, h, w, DEV)
+        y4 = H.empty_cl(n, 4, h, w, DEV)
+        y4.fill_(float('nan'))
+        twd = tw.to(DEV)
+        H.conv_v2(aimg, wimg, out, cls, rgb_head=(twd[:, :co], ts.to(DEV), tb.to(DEV), y4, clamp) + ((3,) if clamp >= 0 else ()), **kw)       # (both forms of the padding channel)
+        assert torch.equal(out, plain)
+        ref = torch.einsum('nchw,oc,nc->nohw', out.double().cpu(), tw[:, :co].double(), ts.double()) + tb.double()[None, :, None, None]
+        if clamp >= 0:
+            assert float(ref.abs().max()) > clamp
+            ref = ref.clamp(-clamp, clamp)
+        close(y4, ref.float(), 2e-6, f'rgb head {shape} clamp {clamp}')
+        assert float(y4[:, 3].abs().max()) == 0.0
+
+
 def test_conv_v2_half_patch_full_size():
     """The 4 x 32-cell patch with the fused forward epilogue at a full-size layer (256^2 x 128 -> 128), three launches: the shapes of the test
     above never showed the fault this guards against (sporadic wrong elements from an SLP-vectorised epilogue: 3dgan-inversion_amd/Makefile)."""
