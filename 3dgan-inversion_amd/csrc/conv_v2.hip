@@ -25,7 +25,7 @@ namespace {
 // patch (256 cells), 2 = a 4 x 32 patch (128 cells x 128 channels per workgroup, 12 MFMAs per wave and step): twice the workgroups for the
 // layers whose 8-row grids leave CUs idle (128^2 x 256: 128 -> 256), with the fused epilogues intact (split-K needs a zero fill + a finishing pass);
 // 1 = a 2 x 32 patch (64 cells: 64^2 x 512 -> 256 workgroups)
-template <int NTAPS, bool FULL = true, bool ATOMIC = false, int RPW = 4>
+template <int NTAPS, bool FULL = true, bool ATOMIC = false, int RPW = 4, bool RGB = false>          // RGB: + the 1x1 head of the forward epilogue (eg3d_conv_v2_params::rgb_out)
 __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_params p, const int cls_base) {
     constexpr int PHK = 2 * RPW;                          // patch rows of this instantiation
     constexpr int NPARTS = ((PHK + 2) * (PW + 2) + 63) / 64;      // 64-slot wave-instructions per A plane: halo <= (PHK + 2) x 34 slots (6 | 4 | 3)
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    v2_epilogue<ATOMIC, RPW>(p, acc, Ha, Wa, cl.out_py, cl.out_px, n, y0, x0, n0, smem, 1.f / (*p.a_scale * *p.w_scale));
+    v2_epilogue<ATOMIC, RPW, false, RGB>(p, acc, Ha, Wa, cl.out_py, cl.out_px, n, y0, x0, n0, smem, 1.f / (*p.a_scale * *p.w_scale));
 }
 
 // ---- operand preparation (split8 / range_mul: conv_v2_common.h) ------------------------------------------------------------
@@ -368,11 +368,11 @@ __global__ void __launch_bounds__(256) split_w_batched_kernel(const eg3d_split_w
     }
 }
 
-std::atomic<uint64_t> g_attr[11];
+std::atomic<uint64_t> g_attr[15];
 
-template <int NTAPS, bool FULL = true, bool ATOMIC = false, int RPW = 4>
+template <int NTAPS, bool FULL = true, bool ATOMIC = false, int RPW = 4, bool RGB = false>
 int launch_v2(const eg3d_conv_v2_params& p, int cls_base, int ncls, int max_tiles, hipStream_t st, int slot) {
-    auto kern = conv_v2_kernel<NTAPS, FULL, ATOMIC, RPW>;
+    auto kern = conv_v2_kernel<NTAPS, FULL, ATOMIC, RPW, RGB>;
     if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, g_attr[slot])) return e;
     hipLaunchKernelGGL(kern, dim3(max_tiles, p.ksplit > 1 ? p.ksplit : 1, ncls), dim3(256), LDS_BYTES, st, p, cls_base);
     EG3D_LAUNCH_CHECK();
@@ -399,7 +399,7 @@ extern "C" int eg3d_conv2d_v2_supported(const eg3d_conv_v2_params* pp) {
         for (int c = 0; c < p.ncls; ++c) if (p.cls[c].ntaps != 9) return 0;
     }
     if (p.epi == EG3D_EPI_FWD && !eg3d_act_is_pwl(p.act)) return 0;
-    if (p.rgb_out != nullptr && (p.epi != EG3D_EPI_FWD || p.Nc != BN || p.ncls != 1 || !p.rgb_w || !p.rgb_s || (p.rgb_ldw & 3) || p.rgb_ldw < p.Nc || (p.rgb_nout != 0 && p.rgb_nout != 3 && p.rgb_nout != 4))) return 0;
+    if (p.rgb_out != nullptr && (p.epi != EG3D_EPI_FWD || p.Nc != BN || p.ncls != 1 || !p.rgb_w || !p.rgb_s || (p.rgb_ldw & 3) || p.rgb_ldw < p.Nc || (p.rgb_nout != 0 && p.rgb_nout != 3 && p.rgb_nout != 4) || p.patch_rows == 4 || p.patch_rows == 2 || p.cls[0].ntaps != 9)) return 0;
     if (p.epi == EG3D_EPI_BWD_ACT) {
         const eg3d_act_bwd& ab = p.act_bwd;
         if (ab.act != EG3D_ACT_LINEAR && ab.act != EG3D_ACT_LRELU) return 0;          // invertible piecewise-linear activations only
@@ -446,6 +446,7 @@ extern "C" int eg3d_conv2d_v2(const eg3d_conv_v2_params* pp, void* stream) {
                 if (p.patch_rows == 2) rc = p.products == 1 ? launch_v2<9, false, false, 1>(p, c, e - c, max_tiles, st, 10) : launch_v2<9, true, false, 1>(p, c, e - c, max_tiles, st, 9);
                 else if (p.patch_rows == 4) rc = p.products == 1 ? launch_v2<9, false, false, 2>(p, c, e - c, max_tiles, st, 8) : launch_v2<9, true, false, 2>(p, c, e - c, max_tiles, st, 7);
                 else if (p.epi == EG3D_EPI_ATOMIC) rc = p.products == 1 ? launch_v2<9, false, true>(p, c, e - c, max_tiles, st, 6) : launch_v2<9, true, true>(p, c, e - c, max_tiles, st, 5);
+                else if (p.rgb_out != nullptr) rc = p.products == 1 ? launch_v2<9, false, false, 4, true>(p, c, e - c, max_tiles, st, 11) : launch_v2<9, true, false, 4, true>(p, c, e - c, max_tiles, st, 12);
                 else rc = p.products == 1 ? launch_v2<9, false>(p, c, e - c, max_tiles, st, 4) : launch_v2<9>(p, c, e - c, max_tiles, st, 0);
                 break;
             case 4: rc = launch_v2<4>(p, c, e - c, max_tiles, st, 1); break;

@@ -73,7 +73,7 @@ __device__ __forceinline__ float range_mul(float amax) {
 // the whole block after the last LDS read of the main loop (it re-uses the dynamic LDS).
 // GENW (tools/proto/conv_lr.hip, not built): the workgroup's cells are a (64 RPW >> logw) x (1 << logw) patch (narrow images: 16 / 8 / 4 columns) instead of rows of 32:
 // cell c of MFMA tile mt is patch position lin = 32 mt + c -> row lin >> logw, column lin & ((1 << logw) - 1).  out_mul: 1 / (a_scale * w_scale).
-template <bool ATOMIC, int RPW = 4, bool GENW = false>   // ATOMIC at compile time: the split-K form must not cost the fused epilogues a register (together they spilled 30 VGPRs);
+template <bool ATOMIC, int RPW = 4, bool GENW = false, bool RGB = false>   // ATOMIC at compile time: the split-K form must not cost the fused epilogues a register (together they spilled 30 VGPRs);
                                       // RPW = patch rows per wave (4: 8 x 32 patch, 2: 4 x 32)
 __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16 (&acc)[RPW][2], const int Ha, const int Wa, const int out_py, const int out_px,
                                             const int n, const int y0, const int x0, const int n0, char* smem, const float out_mul, const int logw = 5) {
@@ -124,18 +124,16 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), scl4 = make_float4(1.f, 1.f, 1.f, 1.f), dsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (epi == EG3D_EPI_FWD && p.bias != nullptr) bias4 = *reinterpret_cast<const float4*>(p.bias + col);
     if ((epi == EG3D_EPI_FWD || bwd_like) && p.out_scale != nullptr) scl4 = *reinterpret_cast<const float4*>(p.out_scale + (int64_t)n * p.Nc + col);
-    // the 1x1 head (eg3d_conv_v2_params::rgb_out): this thread's four channels of the four modulated weight rows
-    const bool rgb_on = epi == EG3D_EPI_FWD && p.rgb_out != nullptr;
-    float4 rw[4];
+    // the 1x1 head (eg3d_conv_v2_params::rgb_out): the four modulated weight rows of this channel tile live in LDS behind the epilogue's staging
+    // area (as 16 registers per thread across the whole epilogue they pushed the instantiation to 256 VGPRs + scratch: +25 us on a 200 us launch)
+    const bool rgb_on = RGB && epi == EG3D_EPI_FWD && p.rgb_out != nullptr;          // (RGB: its own instantiation -- the others must not pay for it)
+    float* rwl = reinterpret_cast<float*>(smem + ((LDS_EPI + 15) & ~15));             // [4][BN]
     float4 rgb_b = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int o = 0; o < 4; ++o) rw[o] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (rgb_on) {
-        const float4 s4 = *reinterpret_cast<const float4*>(p.rgb_s + (int64_t)n * p.Nc + col);
+        if (tid < BN) {
+            const float sv = p.rgb_s[(int64_t)n * p.Nc + n0 + tid];
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const float4 w4 = *reinterpret_cast<const float4*>(p.rgb_w + (int64_t)o * p.rgb_ldw + col);
-            rw[o] = make_float4(w4.x * s4.x, w4.y * s4.y, w4.z * s4.z, w4.w * s4.w);
+            for (int o = 0; o < 4; ++o) rwl[o * BN + tid] = p.rgb_w[(int64_t)o * p.rgb_ldw + n0 + tid] * sv;
         }
         if (p.rgb_bias != nullptr) rgb_b = *reinterpret_cast<const float4*>(p.rgb_bias);
     }
@@ -143,6 +141,17 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
     float accs = 0.f;
     if (act_on && ab.d != nullptr) abd4 = *reinterpret_cast<const float4*>(ab.d + (int64_t)n * p.Nc + col);
     if (act_on && ab.bias != nullptr) abb4 = *reinterpret_cast<const float4*>(ab.bias + col);
+    float4 rw[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) rw[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rgb_on) {           // three rows in registers (straight from global memory: 12 loads per thread, once), a fourth one only in LDS
+        const float4 s4 = *reinterpret_cast<const float4*>(p.rgb_s + (int64_t)n * p.Nc + col);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float4 w4 = *reinterpret_cast<const float4*>(p.rgb_w + (int64_t)o * p.rgb_ldw + col);
+            rw[o] = make_float4(w4.x * s4.x, w4.y * s4.y, w4.z * s4.z, w4.w * s4.w);
+        }
+    }
     float amax = 0.f;
     // the patch's noise values (forward: this layer's; EPI_BWD_ACT: the producing layer's), one per cell, read from LDS by the 32 lanes that
     // hold a cell's channels
@@ -166,14 +175,16 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
             for (int r = 0; r < 16; ++r)
                 stage[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDS_N + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r] * out_mul;
         __syncthreads();
-        // 64 rows x 32 float4 units = 2048 units, 8 per thread, in two groups of 4 (loads first, then arithmetic + stores)
+        // 64 rows x 32 float4 units = 2048 units, 8 per thread, in two groups of 4 (loads first, then arithmetic + stores); the instantiation
+        // with the 1x1 head takes them in four groups of 2: the head's weight rows live in registers and the unit arrays make room for them
+        constexpr int UGN = RGB ? 2 : 4;
 #pragma unroll
-        for (int ug = 0; ug < 8; ug += 4) {
-            int offs[4], pixl[4];
-            float4 va[4], sa[4], sb[4];
-            float nz[4];
+        for (int ug = 0; ug < 8; ug += UGN) {
+            int offs[UGN], pixl[UGN];
+            float4 va[UGN], sa[UGN], sb[UGN];
+            float nz[UGN];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UGN; ++u) {
                 const int row = (tid + (ug + u) * 256) >> 5;             // 0..63: wave-row row >> 5, patch column row & 31
                 const int ay = GENW ? y0 + ((((row >> 5) * RPW + i) * 32 + (row & 31)) >> logw) : y0 + (row >> 5) * RPW + i;
                 const int ax = GENW ? x0 + (row & wmask) : x0 + (row & 31);
@@ -188,7 +199,7 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
                 if (ok && (do_ds || act_on)) sb[u] = *reinterpret_cast<const float4*>(p.xin + offs[u]);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UGN; ++u) {
                 if (offs[u] < 0) continue;
                 float4 v = va[u];
                 if (epi == EG3D_EPI_FWD) {
@@ -201,12 +212,28 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
                     }
                     v = make_float4(e[0] + sa[u].x, e[1] + sa[u].y, e[2] + sa[u].z, e[3] + sa[u].w);
                     if (rgb_on) {                   // the 32 lanes of a half-wave hold the 128 channels of this pixel
+                        // four sums over the 32 lanes in 6 exchanges instead of 20: the first two steps halve the number of values a lane
+                        // carries (lane bit 0 chooses outputs {0,1} | {2,3}, bit 1 the one of the pair), the rest are butterflies on ONE value
+                        // that keep the low two lane bits (row_ror 4 / 8, then the other 16-lane row); lane l then holds output
+                        // 2 (l & 1) + ((l >> 1) & 1) summed over all 32 lanes and lane 0 collects the four from its quad
+                        const float q0 = fmaf(v.w, rw[0].w, fmaf(v.z, rw[0].z, fmaf(v.y, rw[0].y, v.x * rw[0].x)));
+                        const float q1 = fmaf(v.w, rw[1].w, fmaf(v.z, rw[1].z, fmaf(v.y, rw[1].y, v.x * rw[1].x)));
+                        const float q2 = fmaf(v.w, rw[2].w, fmaf(v.z, rw[2].z, fmaf(v.y, rw[2].y, v.x * rw[2].x)));
+                        float q3 = 0.f;
+                        if (p.rgb_nout != 3) {          // a real fourth output: its row stays in LDS
+                            const float4 r = *reinterpret_cast<const float4*>(rwl + 3 * BN + c4 * 4);
+                            q3 = fmaf(v.w, r.w, fmaf(v.z, r.z, fmaf(v.y, r.y, v.x * r.x)));
+                        }
+                        const bool b0 = (c4 & 1) != 0, b1 = (c4 & 2) != 0;
+                        float ka = b0 ? q2 : q0, kb = b0 ? q3 : q1;                                 // what this lane keeps ...
+                        ka += eg3d_dpp<0xB1>(b0 ? q0 : q2); kb += eg3d_dpp<0xB1>(b0 ? q1 : q3);     // ... plus what lane ^ 1 gives it (quad_perm [1,0,3,2])
+                        float k = b1 ? kb : ka;
+                        k += eg3d_dpp<0x4E>(b1 ? ka : kb);                                          // lane ^ 2 (quad_perm [2,3,0,1])
+                        k += eg3d_dpp<0x124>(k);                                                    // row_ror 4
+                        k += eg3d_dpp<0x128>(k);                                                    // row_ror 8
+                        k += __shfl_xor(k, 16);
                         float r4[4];
-#pragma unroll
-                        for (int o = 0; o < 3; ++o)
-                            r4[o] = eg3d_row_group_sum(fmaf(v.w, rw[o].w, fmaf(v.z, rw[o].z, fmaf(v.y, rw[o].y, v.x * rw[o].x))), 32);
-                        r4[3] = 0.f;
-                        if (p.rgb_nout != 3) r4[3] = eg3d_row_group_sum(fmaf(v.w, rw[3].w, fmaf(v.z, rw[3].z, fmaf(v.y, rw[3].y, v.x * rw[3].x))), 32);
+                        r4[0] = k; r4[2] = eg3d_dpp<0x55>(k); r4[1] = eg3d_dpp<0xAA>(k); r4[3] = eg3d_dpp<0xFF>(k);      // quad broadcasts of lanes 1, 2, 3
                         if (c4 == 0) {
                             float4 y = make_float4(r4[0] + rgb_b.x, r4[1] + rgb_b.y, r4[2] + rgb_b.z, r4[3] + rgb_b.w);
                             if (p.rgb_clamp >= 0.f) {

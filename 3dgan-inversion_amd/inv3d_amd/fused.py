@@ -360,7 +360,7 @@ class ModConvLayerFn(torch.autograd.Function):
         if up == 1:
             if v2:
                 rkw = {}
-                if rgb_head is not None and H.RGB_HEAD and Co == 128 and len(cls) == 1:
+                if rgb_head is not None and H.RGB_HEAD and Co == 128 and len(cls) == 1 and H.conv_v2_rows(Ci, Co, cls, N) == 8:
                     tw, ts, tb, tclamp, tcache = rgb_head
                     if tw.shape[0] <= 4 and tw.shape[1] == Co and tuple(ts.shape) == (N, Co):
                         tw4, _, tb4 = tcache.get_padded(tw, 4, tb) if tw.shape[0] != 4 else (tcache.get(tw)[0], None, tb.contiguous().float() if tb is not None else None)

@@ -232,7 +232,8 @@ typedef struct eg3d_conv_v2_params {
                                 * cannot fill the chip (128^2 x 256: 128 tiles; 64^2 x 512: 64) */
     int32_t patch_rows;        /* 0 / 8: workgroup tile = 8 x 32 cells x 128 channels.  4: 4 x 32 cells -- twice the workgroups for 3x3 layers whose
                                 * 8-row grid leaves CUs idle, fused epilogues intact (nine-tap classes, not with EG3D_EPI_ATOMIC) */
-    /* Optional 1x1 head on the finished tile (eg3d_conv2d_v2 with EG3D_EPI_FWD, Nc == 128 = one channel tile per cell, one class): the toRGB layer
+    /* Optional 1x1 head on the finished tile (eg3d_conv2d_v2 with EG3D_EPI_FWD, Nc == 128 = one channel tile per cell, one nine-tap class,
+     * patch_rows 0 / 8): the toRGB layer
      * that reads this layer's output next (training/networks_stylegan2.py:338-359, the super-resolution head's last block) evaluated while the
      * output values are still in registers instead of by a launch that reads the tensor again --
      *     rgb_out[n,y,x,o] = clamp(sum_c out[n,y,x,c] * rgb_w[o * rgb_ldw + c] * rgb_s[n * Nc + c] + rgb_bias[o], +-rgb_clamp),  o = 0 .. 3
@@ -241,7 +242,7 @@ typedef struct eg3d_conv_v2_params {
     float* rgb_out;            /* [N,Ho,Wo,4] */
     float rgb_clamp;
     int32_t rgb_ldw;
-    int32_t rgb_nout;          /* 0 / 4: four outputs; 3: the fourth is a padding channel (only its bias is written) */
+    int32_t rgb_nout;          /* 0 / 4: four outputs; 3: the fourth row of rgb_w is a zero padding row (a hint: the result is the same) */
 } eg3d_conv_v2_params;
 int eg3d_conv2d_v2_supported(const eg3d_conv_v2_params* p);
 int eg3d_conv2d_v2(const eg3d_conv_v2_params* p, void* stream);

@@ -1019,14 +1019,13 @@ def test_conv_v2_forward_epilogue_vs_torch(shape, rows):
     assert abs(float(amax) - float(out.abs().max())) == 0.0
 
 
-@pytest.mark.parametrize('rows', [8, 4])
 @pytest.mark.parametrize('products', [3, 1])
 @pytest.mark.parametrize('shape', [(1, 32, 16, 64, 128), (2, 64, 40, 72, 128), (1, 16, 9, 33, 128)])
-def test_conv_v2_rgb_head_vs_torch(shape, rows, products):
+def test_conv_v2_rgb_head_vs_torch(shape, products, rows=8):
     """The 1x1 head of the forward epilogue (eg3d_conv_v2_params::rgb_out: the toRGB layer that reads a 128-channel layer's output next,
     networks_stylegan2.py:338-359, evaluated while the values are in registers): y = clamp(sum_c out[c] w[o,c] s[n,c] + b[o]) against torch on the
-    layer output the same launch wrote (exact fp32 arithmetic on identical inputs: 1e-6), a clamp that bites, ragged grids, batch 2, both patch
-    heights, both arithmetic classes; the layer output itself is unchanged by the head."""
+    layer output the same launch wrote (exact fp32 arithmetic on identical inputs: 1e-6), a clamp that bites, ragged grids, batch 2, both
+    arithmetic classes (the head is an instantiation of the 8-row patch kernel); the layer output itself is unchanged by the head."""
     from inv3d_amd import hipops as H, _lib as L
     n, ci, h, w, co = shape
     g = torch.Generator().manual_seed(23)
