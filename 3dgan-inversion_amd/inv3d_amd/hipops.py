@@ -710,6 +710,8 @@ def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_
             p.act_bwd = L.ActBwd()
     prof = PROFILER
     cfg_id = {8: V2_CONFIG, 4: V2H_CONFIG, 2: V2Q_CONFIG}[int(p.patch_rows)]   # the patch heights are different instantiations: separate profiler records
+    if rgb_head is not None:
+        cfg_id = V2RGB_CONFIG       # ... and so is the one with the 1x1 head (conv_v2_kernel<9,*,false,4,true>)
     if prof is not None and prof.only_config is not None and prof.only_config != cfg_id:
         prof = None
     if prof is not None:
@@ -922,6 +924,7 @@ V2_CONFIG = 5        # "tile configuration" id of the pre-split kernel in profil
 UP2_CONFIG = 6       # ... of the fused-parity transposed-conv kernel (csrc/conv_v2_up.hip)
 V2H_CONFIG = 8       # ... of the pre-split kernel's half-height (4 x 32) patch instantiation
 V2Q_CONFIG = 9       # ... of its quarter-height (2 x 32) patch instantiation
+V2RGB_CONFIG = 13    # ... of the 8-row instantiation that carries the 1x1 head of the forward epilogue (eg3d_conv_v2_params::rgb_out)
 V2_UP2 = os.environ.get('EG3D_V2_UP2', '1') != '0'
 UP2_MIN_TILES = int(os.environ.get('EG3D_UP2_MIN_TILES', '256'))      # workgroups (512 threads, 115 KB of LDS: one per CU) below which the layer stays on the loader-split kernel
 UP2_MIN_CK = int(os.environ.get('EG3D_UP2_MIN_CK', '32'))      # 32: SR block 0 conv0 (32 -> 256 channels, 128^2 -> 256^2) too: +0.2 % on the step (A/B twice)

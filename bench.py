@@ -601,18 +601,29 @@ def main():
             nprod = PRODUCTS[dom_prec]
             peak = FP32_MFMA_PEAK_TFLOPS if dom_prec == 'f32' else BF16_MFMA_PEAK_TFLOPS / nprod
             if is_v2:
-                tkey = 'conv_v2_kernel<9,true,false,%d>' % v2_rpw
+                tkey = 'conv_v2_kernel<9,true,false,%d,false>' % v2_rpw          # (the name rocprofv3 prints: NTAPS, FULL, ATOMIC, RPW, RGB)
                 kern = tkey + ' (pre-split fp16 pieces, LDS-DMA staged halo; fp32 in/out, 3 x v_mfma_f32_32x32x16_f16 per fp32 product)'
             else:
                 kern = 'conv_igemm_kernel<%s,%d,*> (fp32 in/out, %d x MFMA per fp32 product)' % (H.TILE_NAMES.get(dom_id[0], '?'), H.PRECISIONS[dom_prec], nprod)
                 tkey = 'conv_igemm_kernel<%s>' % H.TILE_NAMES.get(dom_id[0], '?')
-            tr = traffic.get(tkey) or traffic.get(tkey.replace(',true>', '>'), {})
+            tr = traffic.get(tkey) or traffic.get(tkey.replace(',false>', '>')) or traffic.get(tkey.replace(',true>', '>'), {})
             per_launch_ref = tr.get('gflop_per_launch')
             tbytes = tr.get('bytes_per_launch')
             if tbytes is not None and per_launch_ref:           # the PMC pass ran the same kernel: scale by the work of this run's launches
                 tbytes = tbytes * (dom['flops'] / dom['launches'] / 1e9) / per_launch_ref
             all_ms = sum(v['ms'] for v in summ.values())
             all_fl = sum(v['flops'] for v in summ.values())
+            launch_set = {}
+            rgbk = (H.V2RGB_CONFIG, dom_id[1])
+            if dom_id[0] == H.V2_CONFIG and rgbk in summ and summ[rgbk]['ms'] > 0:
+                # the fourth 77 GFLOP launch of a step (SR block 1 conv1 forward) is another instantiation since round 5 -- it carries the toRGB layer in
+                # its epilogue -- so `frac` above averages block 0 conv1 forward and the two DATA GRADIENTS (the slower direction); the four
+                # launches together, as rounds 1-4 reported them:
+                both_fl, both_ms = dom['flops'] + summ[rgbk]['flops'], dom['ms'] + summ[rgbk]['ms']
+                launch_set = dict(launch_set='SR block 0 conv1 forward + the data gradients of both 77 GFLOP layers; block 1 conv1 forward runs as '
+                                             'conv_v2_kernel<9,true,false,4,true> (same main loop + the 1x1 toRGB head in the epilogue: see `families`)',
+                                  four_launch_tflops=round(both_fl / (both_ms * 1e-3) / 1e12, 2),
+                                  four_launch_frac=round(both_fl / (both_ms * 1e-3) / 1e12 / (FP32_MFMA_PEAK_TFLOPS if dom_prec == 'f32' else BF16_MFMA_PEAK_TFLOPS), 4))
             # Every fraction below follows from a guide peak (MI355X_MICROARCH.md: dense 16-bit MFMA 2500 TFLOP/s, fp32 MFMA 157.3) and a
             # number measured in this run.  `frac` = ALGORITHMIC TFLOP/s / the peak of the instruction the kernel issues; a three-product
             # kernel executes 3 MFMA flops per algorithmic flop, so its executed fraction (`frac_executed`, what the MfmaUtil counter sees)
@@ -623,7 +634,7 @@ def main():
                 if v['ms'] <= 0:
                     continue
                 pk = FP32_MFMA_PEAK_TFLOPS if {vv: kk for kk, vv in H.PRECISIONS.items()}[k[1]] == 'f32' else BF16_MFMA_PEAK_TFLOPS
-                name = {H.V2_CONFIG: 'conv_v2<8 rows>', H.V2H_CONFIG: 'conv_v2<4 rows>', H.V2Q_CONFIG: 'conv_v2<2 rows>', H.UP2_CONFIG: 'conv_v2_up2',
+                name = {H.V2_CONFIG: 'conv_v2<8 rows>', H.V2RGB_CONFIG: 'conv_v2<8 rows, 1x1 head> (SR block 1 conv1 forward + its toRGB)', H.V2H_CONFIG: 'conv_v2<4 rows>', H.V2Q_CONFIG: 'conv_v2<2 rows>', H.UP2_CONFIG: 'conv_v2_up2',
                         H.S2ADJ_CONFIG: 'conv_v2_s2adj', H.V3_CONFIG: 'conv_v3', H.WS_CONFIG: 'conv_ws'}.get(k[0], 'conv_igemm<%s>' % H.TILE_NAMES.get(k[0], '?'))
                 fams.append(dict(kernel=name + ' / ' + {vv: kk for kk, vv in H.PRECISIONS.items()}[k[1]], launches_per_step=v['launches'] / args.steps,
                                  ms_per_step=round(v['ms'] / args.steps, 4), tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1),
@@ -647,7 +658,7 @@ def main():
                         all_conv_frac=round(all_fl / (all_ms * 1e-3) / 1e12 / hw_peak, 4),
                         all_conv_scope=('launches of the implicit-GEMM family (conv_igemm / conv_v2 / conv_v3 / up2 / s2adj); the low-latency toRGB launches of the '
                                         '4^2 .. 64^2 blocks (fp32 matrix pipe, 0.5 of 579 GFLOP per step) are not in it'),
-                        families=fams, furthest_from_roofline=worst,
+                        families=fams, furthest_from_roofline=worst, **launch_set,
                         step_gflop_algorithmic=round(611.6 * M, 1), step_tflops=round(611.6e9 * M / (elapsed / args.steps) / 1e12, 1),
                         step_frac=round(611.6e9 * M / (elapsed / args.steps) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
                         step_note='whole step: SURVEY 8d algorithmic 611.6 GFLOP per image-step (forward + data gradient, activation-scaled formulation) / ms_per_step of the timed region / 2500',
