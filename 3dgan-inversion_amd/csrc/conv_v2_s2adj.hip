@@ -167,6 +167,9 @@ __global__ void __launch_bounds__(256, 2) conv_v2_s2adj_kernel(const eg3d_conv_v
 // 2 FA + 3 input rows of its (column, channel quad) and leaves the vertical sums of both row parities in LDS.  Phase 2 (lanes along cells:
 // 16-byte stores contiguous over a plane's row): horizontal sums, split, store.  The thread-per-(cell, octet) form without LDS measured
 // ~5x slower (32-byte reads from 64 different pixel rows per instruction, 16-byte stores into 16 different planes).
+#ifndef UE_XCD_REMAP
+#define UE_XCD_REMAP 1
+#endif
 constexpr int FA = 2, FW = 32, FCH = 64, FCOLS = 2 * FW + 3;        // input columns 2 b0 - 2 .. 2 b0 + 2 FW
 __global__ void __launch_bounds__(256) fir44_adjoint_split_kernel(const float* __restrict__ dz, const float* dz_amax, f16x8* __restrict__ out, float* scale_out,
                                                                   int N, int Hi, int Wi, int C, int ldz, float gain) {
@@ -176,8 +179,9 @@ __global__ void __launch_bounds__(256) fir44_adjoint_split_kernel(const float* _
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *scale_out = mul;
     const int Hp = Hi + 1, Wp = Wi + 1, Ho = 2 * Hi, Wo = 2 * Wi;
     const int tiles_x = (Wp + FW - 1) / FW, tiles_y = (Hp + FA - 1) / FA;
-    const int n = blockIdx.x / (tiles_x * tiles_y);
-    const int t = blockIdx.x - n * tiles_x * tiles_y;
+    const int bid = UE_XCD_REMAP ? eg3d_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;       // vertical neighbours (3 shared input rows) on one XCD: see upconv_epilogue_kernel
+    const int n = bid / (tiles_x * tiles_y);
+    const int t = bid - n * tiles_x * tiles_y;
     const int a0 = (t / tiles_x) * FA, b0 = (t % tiles_x) * FW;
     const int c0 = blockIdx.y * FCH;
     const float k[4] = {0.125f, 0.375f, 0.375f, 0.125f};

@@ -192,6 +192,9 @@ __device__ __forceinline__ float ue_range_mul(float amax) {
     return ldexpf(1.f, 14 - e);
 }
 
+#ifndef UE_XCD_REMAP
+#define UE_XCD_REMAP 1
+#endif
 template <bool SPLIT>
 __global__ void __launch_bounds__(256) upconv_epilogue_kernel(const float* __restrict__ z, float* __restrict__ out, int N, int H, int W, int C, int Hz, int Wz,
                                                              float k0, float k1, float k2, float k3, int pad0, float fir_gain, const float* __restrict__ d,
@@ -203,8 +206,11 @@ __global__ void __launch_bounds__(256) upconv_epilogue_kernel(const float* __res
     float* const O = V;                  // activated tile (SPLIT): takes V's place once phase 2 has read it (41 KB of LDS: three blocks per CU, not two)
     __shared__ float red[4];
     const int tiles_x = (W + UE_TW - 1) / UE_TW, tiles_y = (H + UE_TH - 1) / UE_TH;
-    const int n = blockIdx.x / (tiles_x * tiles_y);
-    const int t = blockIdx.x - n * tiles_x * tiles_y;
+    // (the hardware places block b on XCD b % 8: with the linear order a tile's vertical neighbours -- which re-read three of its input rows --
+    //  sit on other XCDs and miss their L2s; remapped, each XCD owns a band of consecutive tile rows)
+    const int bid = UE_XCD_REMAP ? eg3d_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int n = bid / (tiles_x * tiles_y);
+    const int t = bid - n * tiles_x * tiles_y;
     const int y0 = (t / tiles_x) * UE_TH, x0 = (t % tiles_x) * UE_TW;
     const int c0 = blockIdx.y * UE_CH;
     const float kk[4] = {k3, k2, k1, k0};                    // true convolution: tap i of the window meets filter element 3 - i
