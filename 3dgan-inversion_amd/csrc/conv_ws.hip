@@ -217,7 +217,7 @@ int ws_lds_bytes(const eg3d_conv_ws_params& p, int MT) {
     return std::max(halo, MT * 4 * 64 * 16);
 }
 
-std::atomic<uint64_t> g_ws_attr[8];
+std::atomic<uint64_t> g_ws_attr[16];
 
 template <bool FULL, int MT>
 int launch_ws(const eg3d_conv_ws_params& p, hipStream_t st, int slot) {
@@ -235,6 +235,199 @@ int ws_mt(const eg3d_conv_ws_params& p) {
     return HW <= 32 ? 1 : (HW <= 64 ? 2 : (HW <= 128 ? 4 : 8));
 }
 
+
+// ---- stride-2 adjoint: the data gradient of the up layers of the 8^2 .. 32^2 blocks (4^2 .. 16^2 output cells), same recipe ----------------------
+//     out[n, a, b, o] += sum_t sum_k  g[n, 2a + dy[t], 2b + dx[t], k] * W[o, wtap[t], k]         dy, dx in {0, 1, 2}
+// g: the FIR-adjointed gradient, fp32 NHWC [N, Hx, Wx, ldx] (Hx >= 2H + 1 rows are read where they exist, zeros elsewhere).  The halo of a chunk is
+// the WHOLE image as its four parity images P[py][px][a'][b'] = g[2a' + py, 2b' + px] of (H + 1) x (W + 1) cells -- tap (dy, dx) then reads
+// parity (dy & 1, dx & 1) at cell offset (dy >> 1, dx >> 1), a constant LDS offset, and a 32-cell MFMA row reads consecutive slots.  Four times
+// the halo of the stride-1 form: CPW = 2 chunks per workgroup where four do not fit in LDS (16^2: 148 KB), and the 4 / CPW wave groups split the
+// cells instead (MT tiles each).
+template <bool FULL, int MT, int CPW>
+__global__ void __launch_bounds__(256) conv_ws_s2adj_kernel(const eg3d_conv_ws_params p) {
+    constexpr int NB = FULL ? 2 : 1;
+    constexpr int NG = 4 / CPW;                                       // wave groups along the cells
+    constexpr int SPP = 256 / (2 * CPW), BATCH = 6;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = wave % CPW, mh = wave / CPW;
+    const int HW = p.H * p.W, PW = p.W + 1, PP = (p.H + 1) * PW, SLOTS = 4 * PP;
+    const int ntile_n = p.Nc / WS_BN, nchunk = p.Ck / 16, ngrp = (nchunk + CPW - 1) / CPW;
+    int bid = blockIdx.x;
+    const int n_t = bid % ntile_n; bid /= ntile_n;
+    const int cg = bid % ngrp; const int n = bid / ngrp;
+    const int n0 = n_t * WS_BN;
+    const int chunk = cg * CPW + cl;
+    const bool wave_live = chunk < nchunk && mh * MT * 32 < HW;
+
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)((int64_t)p.wtaps * nchunk * 4 * p.Nc * 16), 0x00020000);
+    const unsigned b_lane = (unsigned)(((lane >> 5) * p.Nc + n0 + (lane & 31)) * 16);
+    const int b_chunk = 4 * p.Nc * 16, b_piece = 2 * p.Nc * 16;
+    u32x4 breg[9][NB];
+    if (wave_live) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < NB; ++e)
+                breg[t][e] = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_lane, (p.wtap[t] * nchunk + chunk) * b_chunk + e * b_piece, 0);
+    }
+    const int oct = tid & 1, ac = (tid >> 1) & (CPW - 1), ps = tid / (2 * CPW);
+    const int achunk = min(cg * CPW + ac, nchunk - 1);
+    const bool a_live = cg * CPW + ac < nchunk;
+    const float* xn = p.x + (int64_t)n * p.Hx * p.Wx * p.ldx + achunk * 16 + oct * 8;
+    float sv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sv[q] = 1.f;
+    float smax = 1.f;
+    if (p.in_scale != nullptr) {
+        const float* sr = p.in_scale + (int64_t)n * p.Ck + achunk * 16 + oct * 8;
+        const float4 s0 = *reinterpret_cast<const float4*>(sr), s1 = *reinterpret_cast<const float4*>(sr + 4);
+        sv[0] = s0.x; sv[1] = s0.y; sv[2] = s0.z; sv[3] = s0.w; sv[4] = s1.x; sv[5] = s1.y; sv[6] = s1.z; sv[7] = s1.w;
+        float m = 0.f;
+        for (int i = tid; i < p.N * p.Ck; i += 256) m = fmaxf(m, fabsf(p.in_scale[i]));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        smax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    }
+    const float mul = range_mul(*p.x_amax * p.x_amax_mul * smax);
+    const float out_mul = 1.f / (mul * *p.w_scale);
+    const int cplane = 4 * SLOTS * 16;
+    for (int s0 = 0; s0 < SLOTS; s0 += SPP * BATCH) {
+        float4 raw[BATCH][2];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int slot = s0 + k * SPP + ps;
+            const int par = slot / PP, r = slot - par * PP;
+            const int ap = r / PW, bp = r - ap * PW;
+            const int y = 2 * ap + (par >> 1), x = 2 * bp + (par & 1);
+            raw[k][0] = make_float4(0.f, 0.f, 0.f, 0.f); raw[k][1] = raw[k][0];
+            if (a_live && slot < SLOTS && y < p.Hx && x < p.Wx) {
+                const float* src = xn + (int64_t)(y * p.Wx + x) * p.ldx;
+                raw[k][0] = *reinterpret_cast<const float4*>(src); raw[k][1] = *reinterpret_cast<const float4*>(src + 4);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int slot = s0 + k * SPP + ps;
+            if (slot >= SLOTS) continue;
+            float v[8] = {raw[k][0].x * sv[0], raw[k][0].y * sv[1], raw[k][0].z * sv[2], raw[k][0].w * sv[3],
+                          raw[k][1].x * sv[4], raw[k][1].y * sv[5], raw[k][1].z * sv[6], raw[k][1].w * sv[7]};
+            f16x8 h, l;
+            split8(v, mul, h, l, 2048.f);
+            *reinterpret_cast<f16x8*>(smem + ac * cplane + (oct * SLOTS + slot) * 16) = h;
+            if constexpr (FULL) *reinterpret_cast<f16x8*>(smem + ac * cplane + ((2 + oct) * SLOTS + slot) * 16) = l;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    if (wave_live) {
+        unsigned a_addr[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = min((mh * MT + i) * 32 + (lane & 31), HW - 1);
+            const int a = m / p.W, b = m - a * p.W;
+            a_addr[i] = (unsigned)(cl * cplane + ((lane >> 5) * SLOTS + a * PW + b) * 16);
+        }
+        const f16x2 k2m11 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
+        const int lo_plane = 2 * SLOTS * 16;
+        f16x8 af[2][MT][NB];
+        auto load_A = [&](int par, int t) {
+            const int dy = p.dy[t], dx = p.dx[t];
+            const int toff = (((dy & 1) * 2 + (dx & 1)) * PP + (dy >> 1) * PW + (dx >> 1)) * 16;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                af[par][i][0] = *reinterpret_cast<const f16x8*>(smem + a_addr[i] + toff);
+                if constexpr (FULL) af[par][i][1] = *reinterpret_cast<const f16x8*>(smem + a_addr[i] + toff + lo_plane);
+            }
+        };
+        load_A(0, 0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t + 1 < 9) load_A((t + 1) & 1, t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const f16x8 bh = ws_f16x8(breg[t][0]);
+            f16x8 bl, bg;
+            if constexpr (FULL) {
+                bl = ws_f16x8(breg[t][1]);
+                const f16x2* s2 = reinterpret_cast<const f16x2*>(&bh);
+                f16x2* d2 = reinterpret_cast<f16x2*>(&bg);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) d2[q] = s2[q] * k2m11;
+            }
+            if constexpr (FULL) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t & 1][i][1], bg, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t & 1][i][0], bl, acc[i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t & 1][i][0], bh, acc[i], 0, 0, 0);
+        }
+    }
+    // the CPW chunk tiles of a wave group meet in LDS in chunk order (register images, one region per group), then every wave adds a quarter of
+    // the quads to `out`
+    float4* img = reinterpret_cast<float4*>(smem) + mh * MT * 4 * 64;
+#pragma unroll
+    for (int w = 0; w < CPW; ++w) {
+        __syncthreads();
+        if (cl != w) continue;
+        if (w == 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) img[(i * 4 + g) * 64 + lane] = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 o = img[(i * 4 + g) * 64 + lane];
+                    acc[i][4 * g] += o.x; acc[i][4 * g + 1] += o.y; acc[i][4 * g + 2] += o.z; acc[i][4 * g + 3] += o.w;
+                    img[(i * 4 + g) * 64 + lane] = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+                }
+        }
+    }
+    __syncthreads();
+    const float4* all = reinterpret_cast<const float4*>(smem);
+    float* on = p.out + (int64_t)n * HW * p.ldo + n0 + (lane & 31);
+#pragma unroll
+    for (int qd = 0; qd < NG * MT * 4; ++qd) {
+        if ((qd & 3) != wave) continue;
+        const float4 v = all[qd * 64 + lane];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        const int mrow = (qd >> 2) * 32 + 4 * (lane >> 5) + 8 * (qd & 3);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (mrow + q < HW) eg3d_acc(on + (int64_t)(mrow + q) * p.ldo, vv[q] * out_mul);
+    }
+}
+
+// (MT, CPW) of the stride-2 adjoint form for an H x W output, 0 when it does not fit
+void ws_s2_plan(const eg3d_conv_ws_params& p, int& mt, int& cpw, int& lds) {
+    const int HW = p.H * p.W;
+    mt = cpw = lds = 0;
+    if (HW <= 32) { mt = 1; cpw = 4; } else if (HW <= 64) { mt = 2; cpw = 4; } else if (HW <= 128) { mt = 2; cpw = 2; } else if (HW <= 256) { mt = 4; cpw = 2; } else return;
+    const int slots = 4 * (p.H + 1) * (p.W + 1);
+    lds = std::max(cpw * 4 * slots * 16, (4 / cpw) * mt * 4 * 64 * 16);
+}
+
+template <bool FULL, int MT, int CPW>
+int launch_ws_s2(const eg3d_conv_ws_params& p, hipStream_t st, int lds, int slot) {
+    const int blocks = p.N * ((p.Ck / 16 + CPW - 1) / CPW) * (p.Nc / WS_BN);
+    if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_ws_s2adj_kernel<FULL, MT, CPW>), lds, g_ws_attr[slot])) return e;
+    hipLaunchKernelGGL((conv_ws_s2adj_kernel<FULL, MT, CPW>), dim3(blocks), dim3(256), lds, st, p);
+    return EG3D_OK;
+}
+
 }  // namespace
 
 extern "C" int eg3d_conv2d_ws_supported(const eg3d_conv_ws_params* pp) {
@@ -242,6 +435,17 @@ extern "C" int eg3d_conv2d_ws_supported(const eg3d_conv_ws_params* pp) {
     const eg3d_conv_ws_params& p = *pp;
     if (p.N <= 0 || p.H <= 0 || p.W <= 0 || p.W > 32 || p.Ck < 16 || (p.Ck & 15) || p.Nc < WS_BN || (p.Nc % WS_BN) || (p.ldx & 3) || p.ldx < p.Ck || p.ldo < p.Nc) return 0;
     if (p.products != 0 && p.products != 1 && p.products != 3) return 0;
+    if (p.in_stride == 2) {                                               // the stride-2 adjoint form: whole image per workgroup
+        for (int t = 0; t < 9; ++t)
+            if (p.dy[t] < 0 || p.dy[t] > 2 || p.dx[t] < 0 || p.dx[t] > 2 || p.wtap[t] < 0 || p.wtap[t] >= p.wtaps) return 0;
+        if (p.Hx < 1 || p.Wx < 1 || (int64_t)p.N * p.Hx * p.Wx * p.ldx > 0x7fffffffll) return 0;
+        int mt, cpw, lds;
+        ws_s2_plan(p, mt, cpw, lds);
+        if (mt == 0 || lds > 156 * 1024) return 0;
+        if ((int64_t)p.wtaps * (p.Ck / 16) * 4 * p.Nc * 16 > 0x7fffffe0ll) return 0;
+        return 1;
+    }
+    if (p.in_stride != 0 && p.in_stride != 1) return 0;
     for (int t = 0; t < 9; ++t)
         if (p.dy[t] < -1 || p.dy[t] > 1 || p.dx[t] < -1 || p.dx[t] > 1 || p.wtap[t] < 0 || p.wtap[t] >= p.wtaps) return 0;
     const int HW = p.H * p.W, MB = 32 * ws_mt(p);
@@ -265,6 +469,17 @@ extern "C" int eg3d_conv2d_ws(const eg3d_conv_ws_params* pp, void* stream) {
     EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND(det, p.out, (int64_t)p.N * p.H * p.W * p.ldo); EG3D_DET_COMMIT(det);
     const bool full = p.products != 1;
     int rc;
+    if (p.in_stride == 2) {
+        int mt, cpw, lds;
+        ws_s2_plan(p, mt, cpw, lds);
+        if (mt == 1) rc = full ? launch_ws_s2<true, 1, 4>(p, st, lds, 8) : launch_ws_s2<false, 1, 4>(p, st, lds, 9);
+        else if (mt == 2 && cpw == 4) rc = full ? launch_ws_s2<true, 2, 4>(p, st, lds, 10) : launch_ws_s2<false, 2, 4>(p, st, lds, 11);
+        else if (mt == 2) rc = full ? launch_ws_s2<true, 2, 2>(p, st, lds, 12) : launch_ws_s2<false, 2, 2>(p, st, lds, 13);
+        else rc = full ? launch_ws_s2<true, 4, 2>(p, st, lds, 14) : launch_ws_s2<false, 4, 2>(p, st, lds, 15);
+        if (rc != EG3D_OK) return rc;
+        EG3D_DET_END(det);
+        return EG3D_OK;
+    }
     switch (ws_mt(p)) {
         case 1: rc = full ? launch_ws<true, 1>(p, st, 0) : launch_ws<false, 1>(p, st, 1); break;
         case 2: rc = full ? launch_ws<true, 2>(p, st, 2) : launch_ws<false, 2>(p, st, 3); break;

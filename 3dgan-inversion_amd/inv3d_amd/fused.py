@@ -588,6 +588,10 @@ class ModConvLayerFn(torch.autograd.Function):
                 z = H.zeros_cl(N, Ci, Hi, Wi, dev)
                 if up == 1 and prec in ('f16x3', 'f16x1') and amax is not None and not weight.requires_grad and H.conv_ws_ok(Co, Ci, cls_adj, N, Hi, Wi):
                     H.conv_ws(g, cache.get_split(weight)[1], z, cls_adj, x_amax=amax, products=1 if prec == 'f16x1' else 3, algo_flops=aflops)
+                elif (up == 2 and g is not None and kh == 3 and kw == 3 and prec in ('f16x3', 'f16x1') and amax is not None and not weight.requires_grad
+                      and H.conv_ws_ok(Co, Ci, cls_adj, N, Hi, Wi, in_stride=2)):
+                    H.conv_ws(g, cache.get_split(weight)[1], z, cls_adj, x_amax=amax, x_amax_mul=amul, products=1 if prec == 'f16x1' else 3, algo_flops=aflops,
+                              in_stride=2)
                 else:
                     H.conv_atomic(g, wa, Co, Ci, z, cls_adj, in_stride=in_stride, ksplit=ks, algo_flops=aflops, precision=ig_prec, a_amax=amax, w_pieces=wap,
                                   a_amax_mul=amul)

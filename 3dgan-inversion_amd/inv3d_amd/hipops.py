@@ -796,39 +796,50 @@ def conv_v3(a: SplitImage, w: SplitImage, out, classes, plan=None, out_stride=1,
 RGB_HEAD = os.environ.get('EG3D_RGB_HEAD', '1') != '0'       # the SR head's last toRGB evaluated in conv1's forward epilogue (eg3d_conv_v2_params::rgb_out)
 CONV_WS = os.environ.get('EG3D_CONV_WS', '1') != '0'
 CONV_WS_MAX_CELLS = int(os.environ.get('EG3D_CONV_WS_MAX_CELLS', '256'))
+CONV_WS_S2 = os.environ.get('EG3D_CONV_WS_S2', '1') != '0'      # ... and its stride-2 adjoint form for the data gradients of the 8^2 .. 32^2 up layers
 WS_CONFIG = 12
 
 
-def _conv_ws_params(x, w: SplitImage, out, cls, in_scale, x_amax, x_amax_mul, products):
+def _conv_ws_params(x, w: SplitImage, out, cls, in_scale, x_amax, x_amax_mul, products, in_stride=1):
     p = L.ConvWsParams()
-    n, cx, h, wd = x.shape
+    n, cx, hx, wx = x.shape
     _, co, ho, wo = out.shape
-    assert (ho, wo) == (h, wd) and cls.ntaps == 9 and cls.Ha == h and cls.Wa == wd and cls.out_py == 0 and cls.out_px == 0
+    assert cls.ntaps == 9 and (cls.Ha, cls.Wa, cls.out_py, cls.out_px) == (ho, wo, 0, 0) and (in_stride == 2 or (hx, wx) == (ho, wo))
     p.x, p.in_scale, p.x_amax, p.x_amax_mul = x.data_ptr(), (in_scale.data_ptr() if in_scale is not None else None), x_amax.data_ptr(), float(x_amax_mul)
     p.w, p.w_scale, p.out = w.data.data_ptr(), w.scale.data_ptr(), out.data_ptr()
     O, I, T = w.shape
-    p.N, p.H, p.W, p.Ck, p.ldx = n, h, wd, I, cx
+    p.N, p.H, p.W, p.Ck, p.ldx = n, ho, wo, I, cx
     p.Nc, p.ldo, p.wtaps = O, co, T
     for t in range(9):
         p.dy[t], p.dx[t], p.wtap[t] = cls.dy[t], cls.dx[t], cls.wtap[t]
     p.products = int(products)
+    p.in_stride, p.Hx, p.Wx = int(in_stride), hx, wx
     return p
 
 
-def conv_ws_ok(Ck, Nc, classes, N, H, W):
-    """A split (atomic) 3x3 stride-1 launch on the weight-streaming kernel (csrc/conv_ws.hip): the 4^2 .. 16^2 layers at one image per GPU."""
+def conv_ws_ok(Ck, Nc, classes, N, H, W, in_stride=1):
+    """A split (atomic) 3x3 launch on the weight-streaming kernel (csrc/conv_ws.hip): the stride-1 layers of the 4^2 .. 16^2 blocks at one image per GPU;
+    in_stride 2: the stride-2 adjoint (data gradient of an up layer) with H x W <= 256 output cells."""
     if not (USE_V2 and CONV_WS) or CONV_MODE != 'auto' or len(classes) != 1 or classes[0].ntaps != 9 or Ck % 16 or Nc % 32 or W > 32:
         return False
     c = classes[0]
-    if (c.Ha, c.Wa, c.out_py, c.out_px) != (H, W, 0, 0) or any(abs(c.dy[t]) > 1 or abs(c.dx[t]) > 1 for t in range(9)):
+    if (c.Ha, c.Wa, c.out_py, c.out_px) != (H, W, 0, 0):
+        return False
+    if in_stride == 2:
+        if not CONV_WS_S2 or any(not (0 <= c.dy[t] <= 2 and 0 <= c.dx[t] <= 2) for t in range(9)) or H * W > 256 or N != 1:
+            return False
+        mt, cpw = (1, 4) if H * W <= 32 else ((2, 4) if H * W <= 64 else ((2, 2) if H * W <= 128 else (4, 2)))
+        return cpw * 4 * 4 * (H + 1) * (W + 1) * 16 <= 156 * 1024
+    if any(abs(c.dy[t]) > 1 or abs(c.dx[t]) > 1 for t in range(9)):
         return False
     return N * H * W <= CONV_WS_MAX_CELLS
 
 
-def conv_ws(x, w: SplitImage, out, classes, in_scale=None, x_amax=None, x_amax_mul=1.0, products=3, algo_flops=None):
-    """Launch eg3d_conv2d_ws: out (pre-zeroed, channels_last fp32) += conv(x * in_scale, W) over the nine taps of classes[0]; w: split_weight image."""
+def conv_ws(x, w: SplitImage, out, classes, in_scale=None, x_amax=None, x_amax_mul=1.0, products=3, algo_flops=None, in_stride=1):
+    """Launch eg3d_conv2d_ws: out (pre-zeroed, channels_last fp32) += conv(x * in_scale, W) over the nine taps of classes[0]; w: split_weight image.
+    in_stride 2: the stride-2 adjoint form (x: the FIR-adjointed gradient of an up layer, out: its data gradient before the style scale)."""
     assert is_cl(x) and is_cl(out) and x.dtype == torch.float32
-    p = _conv_ws_params(x, w, out, classes[0], in_scale, x_amax if x_amax is not None else absmax(x), x_amax_mul, products)
+    p = _conv_ws_params(x, w, out, classes[0], in_scale, x_amax if x_amax is not None else absmax(x), x_amax_mul, products, in_stride)
     prof = PROFILER
     if prof is not None and prof.only_config is not None and prof.only_config != WS_CONFIG:
         prof = None
@@ -842,8 +853,8 @@ def conv_ws(x, w: SplitImage, out, classes, in_scale=None, x_amax=None, x_amax_m
         e1.record()
         prof.records.append(((WS_CONFIG, PRECISIONS['f16x3']), float(algo_flops), e0, e1))
         if prof.meta is not None:
-            prof.meta.append(dict(N=p.N, Hi=p.H, Wi=p.W, Ck=p.Ck, Nc=p.Nc, Ho=p.H, Wo=p.W, taps=[9], epi=L.EPI_ATOMIC, ksplit=p.Ck // 16,
-                                  in_stride=1, out_stride=1, prec=3, ws=True))
+            prof.meta.append(dict(N=p.N, Hi=p.Hx, Wi=p.Wx, Ck=p.Ck, Nc=p.Nc, Ho=p.H, Wo=p.W, taps=[9], epi=L.EPI_ATOMIC, ksplit=p.Ck // 16,
+                                  in_stride=int(in_stride), out_stride=1, prec=3, ws=True))
     return out
 
 

@@ -274,6 +274,10 @@ typedef struct eg3d_conv_ws_params {
     int32_t Nc, ldo, wtaps;
     int32_t dy[9], dx[9], wtap[9];
     int32_t products;          /* 0 / 3 | 1 */
+    int32_t in_stride;         /* 0 / 1: correlation, |dy|, |dx| <= 1, x is [N,H,W,ldx].  2: the stride-2 adjoint (data gradient of the up layers):
+                                * out[n,a,b,o] += sum x[n, 2a + dy[t], 2b + dx[t], k] ..., dy, dx in 0 .. 2, x is [N,Hx,Wx,ldx] (zeros beyond it),
+                                * H * W <= 256 output cells */
+    int32_t Hx, Wx;            /* in_stride 2 only */
 } eg3d_conv_ws_params;
 int eg3d_conv2d_ws_supported(const eg3d_conv_ws_params* p);
 int eg3d_conv2d_ws(const eg3d_conv_ws_params* p, void* stream);

@@ -993,6 +993,31 @@ def test_conv_ws_vs_torch(shape, products, adjoint):
     close(outs[0] - base, ref.float(), 2e-5 if products == 3 else 3e-3, f'conv_ws {shape} adjoint={adjoint}')
 
 
+@pytest.mark.parametrize('shape', [(512, 16, 16, 512), (512, 8, 8, 512), (512, 4, 4, 512), (64, 8, 16, 96), (48, 3, 5, 32), (32, 8, 32, 64), (16, 1, 1, 32)])
+@pytest.mark.parametrize('products', [3, 1])
+def test_conv_ws_stride2_adjoint_vs_torch(shape, products):
+    """The stride-2 adjoint form of the weight-streaming kernel (data gradient of an up layer before the style scale): with G the (2H + 1) x
+    (2W + 1) gradient of the transposed conv's output, dx = conv2d(G, w^T-taps, stride 2) -- against torch fp64 on the backbone's 32^2 -> 16^2,
+    16^2 -> 8^2, 8^2 -> 4^2 layers (512 channels), 128-cell and ragged images, a contraction whose last chunk group is short, a single cell;
+    accumulated into a buffer that holds values."""
+    from inv3d_amd import hipops as H
+    co, h, w, ci = shape                                # contraction over co (the up layer's output channels), result ci channels at h x w
+    g = torch.Generator().manual_seed(91)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(co * 9)
+    G = torch.randn(1, co, 2 * h + 1, 2 * w + 1, generator=g)
+    # forward: z = conv_transpose2d(x, w, stride 2) (w: [ci -> co] as [ci, co, 3, 3] = wt.transpose(0, 1)); its adjoint w.r.t. x:
+    ref = torch.nn.functional.conv2d(G.double(), wt.double().transpose(0, 1), stride=2)
+    assert ref.shape == (1, ci, h, w)
+    wp = H.pack_weight_adj(wt.to(DEV)); wimg = H.split_weight(wp, ci, co, 9)
+    cls = H.classes_convT_adjoint(h, w, 3, 3, 2)
+    Gc = G.to(DEV).contiguous(memory_format=torch.channels_last)
+    base = torch.randn(1, ci, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    assert H.conv_ws_ok(co, ci, cls, 1, h, w, in_stride=2)
+    z = base.clone(memory_format=torch.channels_last)
+    H.conv_ws(Gc, wimg, z, cls, x_amax=H.absmax(Gc), products=products, in_stride=2)
+    close(z - base, ref.float(), 2e-5 if products == 3 else 3e-3, f'conv_ws s2adj {shape}')
+
+
 @pytest.mark.parametrize('rows', [8, 4])        # 4: the half-height patch (hipops.V2_HALF)
 @pytest.mark.parametrize('shape', [(1, 32, 16, 64, 128), (2, 64, 40, 72, 128), (1, 128, 33, 37, 256), (1, 16, 8, 32, 128)])
 def test_conv_v2_forward_epilogue_vs_torch(shape, rows):
