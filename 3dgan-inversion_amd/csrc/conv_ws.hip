@@ -217,7 +217,7 @@ int ws_lds_bytes(const eg3d_conv_ws_params& p, int MT) {
     return std::max(halo, MT * 4 * 64 * 16);
 }
 
-std::atomic<uint64_t> g_ws_attr[16];
+std::atomic<uint64_t> g_ws_attr[22];
 
 template <bool FULL, int MT>
 int launch_ws(const eg3d_conv_ws_params& p, hipStream_t st, int slot) {
@@ -428,6 +428,196 @@ int launch_ws_s2(const eg3d_conv_ws_params& p, hipStream_t st, int lds, int slot
     return EG3D_OK;
 }
 
+
+// ---- stride-2 TRANSPOSED conv (forward of the up layers of the 8^2 / 16^2 blocks: 4^2 / 8^2 input cells), same recipe ---------------------------------
+//     out[n, 2a + ky, 2b + kx, o] += sum_k x[n, a, b, k] * in_scale[n, k] * W[o, wtap[3 ky + kx], k]          out: [N, 2H + 1, 2W + 1, ldo], pre-zeroed
+// Output-centric like conv_v2_up.hip: the output pixels of parity (py, px) are the cells (a', b') of an (H + 1) x (W + 1) grid, cell (a', b') sums
+// the taps with ky & 1 == py, kx & 1 == px at input (a' - (ky >> 1), b' - (kx >> 1)) -- four accumulator sets per wave (4 / 2 / 2 / 1 taps),
+// one halo ((H + 2) x (W + 2) pixels: the one-pixel border supplies the zeros), nine weight fragments.  MT = ceil((H + 1)(W + 1) / 32) <= 3:
+// the 16^2 -> 32^2 layer would need ten tiles per set and 4.5 M output atomics (19 us): it stays on the split-K implicit GEMM.
+template <bool FULL, int MT>
+__global__ void __launch_bounds__(256) conv_ws_up_kernel(const eg3d_conv_ws_params p) {
+    constexpr int NB = FULL ? 2 : 1;
+    constexpr int BATCH = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HW = p.H * p.W, PW = p.W + 1, PC = (p.H + 1) * PW;        // cells of a parity class
+    const int HP = p.W + 2, SLOTS = (p.H + 2) * HP;
+    const int Ho = 2 * p.H + 1, Wo = 2 * p.W + 1;
+    const int ntile_n = p.Nc / WS_BN, nchunk = p.Ck / 16, ngrp = (nchunk + WS_CPW - 1) / WS_CPW;
+    int bid = blockIdx.x;
+    const int n_t = bid % ntile_n; bid /= ntile_n;
+    const int cg = bid % ngrp; const int n = bid / ngrp;
+    const int n0 = n_t * WS_BN;
+    const int chunk = cg * WS_CPW + wave;
+    const bool wave_live = chunk < nchunk;
+
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)((int64_t)p.wtaps * nchunk * 4 * p.Nc * 16), 0x00020000);
+    const unsigned b_lane = (unsigned)(((lane >> 5) * p.Nc + n0 + (lane & 31)) * 16);
+    const int b_chunk = 4 * p.Nc * 16, b_piece = 2 * p.Nc * 16;
+    u32x4 breg[9][NB];
+    if (wave_live) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < NB; ++e)
+                breg[t][e] = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_lane, (p.wtap[t] * nchunk + chunk) * b_chunk + e * b_piece, 0);
+    }
+    const int oct = tid & 1, ac = (tid >> 1) & (WS_CPW - 1), ps = tid >> 3;
+    const int achunk = min(cg * WS_CPW + ac, nchunk - 1);
+    const bool a_live = cg * WS_CPW + ac < nchunk;
+    const float* xn = p.x + (int64_t)n * HW * p.ldx + achunk * 16 + oct * 8;
+    float sv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sv[q] = 1.f;
+    float smax = 1.f;
+    if (p.in_scale != nullptr) {
+        const float* sr = p.in_scale + (int64_t)n * p.Ck + achunk * 16 + oct * 8;
+        const float4 s0 = *reinterpret_cast<const float4*>(sr), s1 = *reinterpret_cast<const float4*>(sr + 4);
+        sv[0] = s0.x; sv[1] = s0.y; sv[2] = s0.z; sv[3] = s0.w; sv[4] = s1.x; sv[5] = s1.y; sv[6] = s1.z; sv[7] = s1.w;
+        float m = 0.f;
+        for (int i = tid; i < p.N * p.Ck; i += 256) m = fmaxf(m, fabsf(p.in_scale[i]));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        smax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    }
+    const float mul = range_mul(*p.x_amax * p.x_amax_mul * smax);
+    const float out_mul = 1.f / (mul * *p.w_scale);
+    const int cplane = 4 * SLOTS * 16;
+    for (int s0 = 0; s0 < SLOTS; s0 += WS_SPP * BATCH) {
+        float4 raw[BATCH][2];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int slot = s0 + k * WS_SPP + ps;
+            const int hy = slot / HP, hx = slot - hy * HP;
+            const int y = hy - 1, x = hx - 1;
+            raw[k][0] = make_float4(0.f, 0.f, 0.f, 0.f); raw[k][1] = raw[k][0];
+            if (a_live && slot < SLOTS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+                const float* src = xn + (int64_t)(y * p.W + x) * p.ldx;
+                raw[k][0] = *reinterpret_cast<const float4*>(src); raw[k][1] = *reinterpret_cast<const float4*>(src + 4);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int slot = s0 + k * WS_SPP + ps;
+            if (slot >= SLOTS) continue;
+            float v[8] = {raw[k][0].x * sv[0], raw[k][0].y * sv[1], raw[k][0].z * sv[2], raw[k][0].w * sv[3],
+                          raw[k][1].x * sv[4], raw[k][1].y * sv[5], raw[k][1].z * sv[6], raw[k][1].w * sv[7]};
+            f16x8 h, l;
+            split8(v, mul, h, l, 2048.f);
+            *reinterpret_cast<f16x8*>(smem + ac * cplane + (oct * SLOTS + slot) * 16) = h;
+            if constexpr (FULL) *reinterpret_cast<f16x8*>(smem + ac * cplane + ((2 + oct) * SLOTS + slot) * 16) = l;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[4][MT];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][i][r] = 0.f;
+    if (wave_live) {
+        unsigned a_addr[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = min(i * 32 + (lane & 31), PC - 1);
+            const int a = m / PW, b = m - a * PW;
+            a_addr[i] = (unsigned)(wave * cplane + ((lane >> 5) * SLOTS + (a + 1) * HP + b + 1) * 16);
+        }
+        const f16x2 k2m11 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
+        const int lo_plane = 2 * SLOTS * 16;
+        f16x8 af[2][MT][NB];
+        auto load_A = [&](int par, int t) {
+            const int toff = -(((t / 3) >> 1) * HP + ((t % 3) >> 1)) * 16;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                af[par][i][0] = *reinterpret_cast<const f16x8*>(smem + a_addr[i] + toff);
+                if constexpr (FULL) af[par][i][1] = *reinterpret_cast<const f16x8*>(smem + a_addr[i] + toff + lo_plane);
+            }
+        };
+        load_A(0, 0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            constexpr int dummy = 0; (void)dummy;
+            if (t + 1 < 9) load_A((t + 1) & 1, t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int P = ((t / 3) & 1) * 2 + ((t % 3) & 1);              // (compile-time in the unrolled loop)
+            const f16x8 bh = ws_f16x8(breg[t][0]);
+            f16x8 bl, bg;
+            if constexpr (FULL) {
+                bl = ws_f16x8(breg[t][1]);
+                const f16x2* s2 = reinterpret_cast<const f16x2*>(&bh);
+                f16x2* d2 = reinterpret_cast<f16x2*>(&bg);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) d2[q] = s2[q] * k2m11;
+            }
+            if constexpr (FULL) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[P][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t & 1][i][1], bg, acc[P][i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[P][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t & 1][i][0], bl, acc[P][i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[P][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t & 1][i][0], bh, acc[P][i], 0, 0, 0);
+        }
+    }
+    // the four chunk tiles (4 parity sets x MT tiles each) meet in LDS in wave order; then every wave adds a quarter of the quads to `out`
+    float4* img = reinterpret_cast<float4*>(smem);
+#pragma unroll
+    for (int w = 0; w < WS_CPW; ++w) {
+        __syncthreads();
+        if (wave != w) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4* q = img + ((c * MT + i) * 4 + g) * 64 + lane;
+                    if (w > 0) {
+                        const float4 o = *q;
+                        acc[c][i][4 * g] += o.x; acc[c][i][4 * g + 1] += o.y; acc[c][i][4 * g + 2] += o.z; acc[c][i][4 * g + 3] += o.w;
+                    }
+                    *q = make_float4(acc[c][i][4 * g], acc[c][i][4 * g + 1], acc[c][i][4 * g + 2], acc[c][i][4 * g + 3]);
+                }
+    }
+    __syncthreads();
+    float* on = p.out + (int64_t)n * Ho * Wo * p.ldo + n0 + (lane & 31);
+#pragma unroll
+    for (int qd = 0; qd < 4 * MT * 4; ++qd) {
+        if ((qd & 3) != wave) continue;
+        const int tq = qd >> 2, c = tq / MT, i = tq - c * MT;
+        const float4 v = img[qd * 64 + lane];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        const int m0r = i * 32 + 4 * (lane >> 5) + 8 * (qd & 3);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = m0r + q;
+            const int a = m / PW, b = m - a * PW;
+            const int y = 2 * a + (c >> 1), x = 2 * b + (c & 1);
+            if (m < PC && y < Ho && x < Wo) eg3d_acc(on + (int64_t)(y * Wo + x) * p.ldo, vv[q] * out_mul);
+        }
+    }
+}
+
+int ws_up_mt(const eg3d_conv_ws_params& p) { const int pc = (p.H + 1) * (p.W + 1); return pc <= 32 ? 1 : (pc <= 64 ? 2 : (pc <= 96 ? 3 : 0)); }
+int ws_up_lds(const eg3d_conv_ws_params& p, int mt) { return std::max(WS_CPW * 4 * (p.H + 2) * (p.W + 2) * 16, 4 * mt * 4 * 64 * 16); }
+
+template <bool FULL, int MT>
+int launch_ws_up(const eg3d_conv_ws_params& p, hipStream_t st, int slot) {
+    const int blocks = p.N * ((p.Ck / 16 + WS_CPW - 1) / WS_CPW) * (p.Nc / WS_BN);
+    const int lds = ws_up_lds(p, MT);
+    if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_ws_up_kernel<FULL, MT>), lds, g_ws_attr[slot])) return e;
+    hipLaunchKernelGGL((conv_ws_up_kernel<FULL, MT>), dim3(blocks), dim3(256), lds, st, p);
+    return EG3D_OK;
+}
+
 }  // namespace
 
 extern "C" int eg3d_conv2d_ws_supported(const eg3d_conv_ws_params* pp) {
@@ -435,6 +625,15 @@ extern "C" int eg3d_conv2d_ws_supported(const eg3d_conv_ws_params* pp) {
     const eg3d_conv_ws_params& p = *pp;
     if (p.N <= 0 || p.H <= 0 || p.W <= 0 || p.W > 32 || p.Ck < 16 || (p.Ck & 15) || p.Nc < WS_BN || (p.Nc % WS_BN) || (p.ldx & 3) || p.ldx < p.Ck || p.ldo < p.Nc) return 0;
     if (p.products != 0 && p.products != 1 && p.products != 3) return 0;
+    if (p.out_stride == 2) {                                              // the transposed form: whole image per workgroup, <= 96 cells per output parity
+        if (p.in_stride > 1) return 0;
+        for (int t = 0; t < 9; ++t) if (p.wtap[t] < 0 || p.wtap[t] >= p.wtaps) return 0;
+        const int mt = ws_up_mt(p);
+        if (mt == 0 || ws_up_lds(p, mt) > 156 * 1024) return 0;
+        if ((int64_t)p.wtaps * (p.Ck / 16) * 4 * p.Nc * 16 > 0x7fffffe0ll) return 0;
+        return 1;
+    }
+    if (p.out_stride != 0 && p.out_stride != 1) return 0;
     if (p.in_stride == 2) {                                               // the stride-2 adjoint form: whole image per workgroup
         for (int t = 0; t < 9; ++t)
             if (p.dy[t] < 0 || p.dy[t] > 2 || p.dx[t] < 0 || p.dx[t] > 2 || p.wtap[t] < 0 || p.wtap[t] >= p.wtaps) return 0;
@@ -466,9 +665,20 @@ extern "C" int eg3d_conv2d_ws(const eg3d_conv_ws_params* pp, void* stream) {
     for (const void* q : ptrs)
         if (q != nullptr && (reinterpret_cast<uintptr_t>(q) & 15)) return EG3D_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    EG3D_DET_SCOPE(det, stream); EG3D_DET_BIND(det, p.out, (int64_t)p.N * p.H * p.W * p.ldo); EG3D_DET_COMMIT(det);
+    EG3D_DET_SCOPE(det, stream);
+    EG3D_DET_BIND(det, p.out, p.out_stride == 2 ? (int64_t)p.N * (2 * p.H + 1) * (2 * p.W + 1) * p.ldo : (int64_t)p.N * p.H * p.W * p.ldo);
+    EG3D_DET_COMMIT(det);
     const bool full = p.products != 1;
     int rc;
+    if (p.out_stride == 2) {
+        const int mt = ws_up_mt(p);
+        if (mt == 1) rc = full ? launch_ws_up<true, 1>(p, st, 16) : launch_ws_up<false, 1>(p, st, 17);
+        else if (mt == 2) rc = full ? launch_ws_up<true, 2>(p, st, 18) : launch_ws_up<false, 2>(p, st, 19);
+        else rc = full ? launch_ws_up<true, 3>(p, st, 20) : launch_ws_up<false, 3>(p, st, 21);
+        if (rc != EG3D_OK) return rc;
+        EG3D_DET_END(det);
+        return EG3D_OK;
+    }
     if (p.in_stride == 2) {
         int mt, cpw, lds;
         ws_s2_plan(p, mt, cpw, lds);

@@ -72,7 +72,7 @@ class ConvWsParams(C.Structure):
                 ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('Ck', C.c_int32), ('ldx', C.c_int32),
                 ('Nc', C.c_int32), ('ldo', C.c_int32), ('wtaps', C.c_int32),
                 ('dy', C.c_int32 * 9), ('dx', C.c_int32 * 9), ('wtap', C.c_int32 * 9), ('products', C.c_int32),
-                ('in_stride', C.c_int32), ('Hx', C.c_int32), ('Wx', C.c_int32)]
+                ('in_stride', C.c_int32), ('Hx', C.c_int32), ('Wx', C.c_int32), ('out_stride', C.c_int32)]
 
 
 class ConvV2Params(C.Structure):

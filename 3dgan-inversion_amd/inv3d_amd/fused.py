@@ -415,7 +415,11 @@ class ModConvLayerFn(torch.autograd.Function):
                 H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_STORE, algo_flops=aflops, precision=ig_prec, w_pieces=wfp)
             else:
                 z = H.zeros_cl(N, Co, Hz, Wz, x.device)
-                H.conv_atomic(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, ksplit=ks, algo_flops=aflops, precision=ig_prec, w_pieces=wfp)
+                if up == 2 and kh == 3 and kw == 3 and prec in ('f16x3', 'f16x1') and not weight.requires_grad and H.conv_ws_up_ok(Ci, Co, N, Hi, Wi):
+                    # 4^2 / 8^2 input cells: the weight-streaming kernel's transposed form (four parity accumulator sets per wave, csrc/conv_ws.hip)
+                    H.conv_ws_up(x, cache.get_split(weight)[0], z, in_scale=styles, x_amax=H.amax_of(x), products=nprod, algo_flops=aflops)
+                else:
+                    H.conv_atomic(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, ksplit=ks, algo_flops=aflops, precision=ig_prec, w_pieces=wfp)
             simg = None
             if H.UPCONV_EPI and Co % 64 == 0 and up == 2:
                 # consumer = a 3x3 layer on the pre-split kernel (same channel count, output resolution): its operand image comes out of this

@@ -858,6 +858,52 @@ def conv_ws(x, w: SplitImage, out, classes, in_scale=None, x_amax=None, x_amax_m
     return out
 
 
+CONV_WS_UP = os.environ.get('EG3D_CONV_WS_UP', '1') != '0'      # ... and its transposed form for the forward of the 8^2 block's up layer
+CONV_WS_UP_MAX_CELLS = int(os.environ.get('EG3D_CONV_WS_UP_MAX_CELLS', '32'))      # cells per output parity routed there: 4^2 -> 9^2 (25 cells) 18.9 -> 12.4 us; 8^2 -> 17^2 (81 cells: three row tiles x four parity sets per wave, 1.2 M output atomics) 18.0 -> 23.1, stays on the split-K implicit GEMM
+
+
+def conv_ws_up_ok(Ck, Nc, N, H, W, max_cells=None):
+    """Forward of an up layer (stride-2 transposed 3x3 conv, split-K accumulation into a zeroed buffer) on the weight-streaming kernel: 4^2 / 8^2
+    input cells at one image per GPU.  max_cells: cells per output parity the caller accepts (default: the routing threshold; the kernel takes 96)."""
+    return bool(USE_V2 and CONV_WS and CONV_WS_UP and CONV_MODE == 'auto' and Ck % 16 == 0 and Nc % 32 == 0 and N == 1 and (H + 1) * (W + 1) <= min(96, max_cells or CONV_WS_UP_MAX_CELLS)
+                and W <= 30)
+
+
+def conv_ws_up(x, w: SplitImage, out, in_scale=None, x_amax=None, x_amax_mul=1.0, products=3, algo_flops=None):
+    """Launch eg3d_conv2d_ws with out_stride 2: out [N,Co,2H+1,2W+1] (pre-zeroed, channels_last) += conv_transpose2d(x * in_scale, W, stride 2);
+    w: the FORWARD split weight image (tap index 3 ky + kx)."""
+    assert is_cl(x) and is_cl(out) and x.dtype == torch.float32
+    p = L.ConvWsParams()
+    n, cx, hx, wx = x.shape
+    _, co, ho, wo = out.shape
+    assert (ho, wo) == (2 * hx + 1, 2 * wx + 1)
+    xa = x_amax if x_amax is not None else absmax(x)
+    p.x, p.in_scale, p.x_amax, p.x_amax_mul = x.data_ptr(), (in_scale.data_ptr() if in_scale is not None else None), xa.data_ptr(), float(x_amax_mul)
+    p.w, p.w_scale, p.out = w.data.data_ptr(), w.scale.data_ptr(), out.data_ptr()
+    O, I, T = w.shape
+    p.N, p.H, p.W, p.Ck, p.ldx = n, hx, wx, I, cx
+    p.Nc, p.ldo, p.wtaps = O, co, T
+    for t in range(9):
+        p.dy[t], p.dx[t], p.wtap[t] = 0, 0, t
+    p.products, p.in_stride, p.out_stride = int(products), 1, 2
+    prof = PROFILER
+    if prof is not None and prof.only_config is not None and prof.only_config != WS_CONFIG:
+        prof = None
+    if prof is not None:
+        if algo_flops is None:
+            algo_flops = 2.0 * p.Ck * p.Nc * p.N * p.H * p.W * 9
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    L.check(L.lib().eg3d_conv2d_ws(C.byref(p), L.stream_ptr()), 'conv2d_ws (transposed)')
+    if prof is not None:
+        e1.record()
+        prof.records.append(((WS_CONFIG, PRECISIONS['f16x3']), float(algo_flops), e0, e1))
+        if prof.meta is not None:
+            prof.meta.append(dict(N=p.N, Hi=p.H, Wi=p.W, Ck=p.Ck, Nc=p.Nc, Ho=ho, Wo=wo, taps=[4, 2, 2, 1], epi=L.EPI_ATOMIC, ksplit=p.Ck // 16,
+                                  in_stride=1, out_stride=2, prec=3, ws=True))
+    return out
+
+
 def fir44_adjoint_split(dz, dz_amax, gain=4.0):
     """FIR adjoint of an up layer + operand split in one pass (eg3d_fir44_adjoint_split): dz [N,C,2Hi,2Wi] channels_last ->
     SplitImage of the four parity images of G = upfirdn2d(dz, [1,3,3,1]^2 / 64, pad 2, gain), shape (N, C, Hi + 1, Wi + 1) per parity."""

@@ -278,6 +278,9 @@ typedef struct eg3d_conv_ws_params {
                                 * out[n,a,b,o] += sum x[n, 2a + dy[t], 2b + dx[t], k] ..., dy, dx in 0 .. 2, x is [N,Hx,Wx,ldx] (zeros beyond it),
                                 * H * W <= 256 output cells */
     int32_t Hx, Wx;            /* in_stride 2 only */
+    int32_t out_stride;        /* 0 / 1.  2: the stride-2 TRANSPOSED conv (forward of an up layer, in_stride <= 1): x is [N,H,W,ldx], out is
+                                * [N, 2H + 1, 2W + 1, ldo], out[n, 2a + ky, 2b + kx, o] += x[n,a,b,k] in_scale[n,k] W[o, wtap[3 ky + kx], k]  (dy, dx unused);
+                                * (H + 1)(W + 1) <= 96 */
 } eg3d_conv_ws_params;
 int eg3d_conv2d_ws_supported(const eg3d_conv_ws_params* p);
 int eg3d_conv2d_ws(const eg3d_conv_ws_params* p, void* stream);

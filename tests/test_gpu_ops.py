@@ -993,6 +993,28 @@ def test_conv_ws_vs_torch(shape, products, adjoint):
     close(outs[0] - base, ref.float(), 2e-5 if products == 3 else 3e-3, f'conv_ws {shape} adjoint={adjoint}')
 
 
+@pytest.mark.parametrize('shape', [(512, 8, 8, 512), (512, 4, 4, 512), (48, 3, 5, 64), (32, 6, 6, 96), (16, 1, 1, 32), (64, 2, 30, 32)])
+@pytest.mark.parametrize('products', [3, 1])
+def test_conv_ws_transposed_vs_torch(shape, products):
+    """The transposed form of the weight-streaming kernel (forward of an up layer: stride-2 3x3 transposed conv of the style-modulated activation,
+    accumulated into a (2H + 1) x (2W + 1) buffer that holds values) vs conv_transpose2d in fp64: the backbone's 8^2 -> 17^2 and 4^2 -> 9^2
+    x 512 layers, ragged images with one / two / three row tiles per parity class, a short last chunk group, a single pixel."""
+    from inv3d_amd import hipops as H
+    ci, h, w, co = shape
+    g = torch.Generator().manual_seed(93)
+    x = torch.randn(1, ci, h, w, generator=g) * 2
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)
+    s = 1 + 0.5 * torch.randn(1, ci, generator=g)
+    ref = torch.nn.functional.conv_transpose2d(x.double() * s.double()[:, :, None, None], wt.double().transpose(0, 1), stride=2)
+    wimg = H.split_weight(H.pack_weight_fwd(wt.to(DEV)), co, ci, 9)
+    xc = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    base = torch.randn(1, co, 2 * h + 1, 2 * w + 1, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    assert H.conv_ws_up_ok(ci, co, 1, h, w, max_cells=96)
+    z = base.clone(memory_format=torch.channels_last)
+    H.conv_ws_up(xc, wimg, z, in_scale=s.to(DEV), x_amax=H.absmax(xc), products=products)
+    close(z - base, ref.float(), 2e-5 if products == 3 else 3e-3, f'conv_ws transposed {shape}')
+
+
 @pytest.mark.parametrize('shape', [(512, 16, 16, 512), (512, 8, 8, 512), (512, 4, 4, 512), (64, 8, 16, 96), (48, 3, 5, 32), (32, 8, 32, 64), (16, 1, 1, 32)])
 @pytest.mark.parametrize('products', [3, 1])
 def test_conv_ws_stride2_adjoint_vs_torch(shape, products):
