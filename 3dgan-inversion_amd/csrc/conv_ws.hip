@@ -29,6 +29,14 @@ constexpr int WS_MAXSLOTS = 344;                // halo pixels of a cell block: 
 constexpr int WS_SPP = 256 / (2 * WS_CPW);      // halo pixels per load pass: thread = (pixel of the pass, chunk, k-octet)
 
 __device__ __forceinline__ f16x8 ws_f16x8(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
+// m / d for 0 <= m < 2^20, 1 <= d <= 2^10 without the ~35-instruction integer division sequence (these kernels are latency chains of a few
+// microseconds: the halo loaders and the output loops did 40 .. 200 divisions by run-time pitches per lane): float estimate + one correction each way
+__device__ __forceinline__ int ws_div(int m, int d, float rcp) {
+    int q = (int)((float)m * rcp);
+    q -= (q * d > m) ? 1 : 0;
+    q += ((q + 1) * d <= m) ? 1 : 0;
+    return q;
+}
 
 // FULL: three products per fp32 product; !FULL: high pieces only.  MT: MFMA row tiles (32 cells) of the workgroup's cell block (every wave computes
 // all of them for ITS chunk).
@@ -53,6 +61,7 @@ __global__ void __launch_bounds__(256) conv_ws_kernel(const eg3d_conv_ws_params 
     const int mlast = min(m0 + MB, HW) - 1;
     const int ylo = m0 / p.W - 1, yhi = mlast / p.W + 1;
     const int HP = p.W + 2, SLOTS = (yhi - ylo + 1) * HP;
+    const float rHP = 1.f / (float)HP, rW = 1.f / (float)p.W;
     const int chunk = cg * WS_CPW + wave;
     const bool wave_live = chunk < nchunk;                             // (a contraction of 16 .. 48 channels: the last group is short)
 
@@ -97,7 +106,7 @@ __global__ void __launch_bounds__(256) conv_ws_kernel(const eg3d_conv_ws_params 
 #pragma unroll
         for (int k = 0; k < WS_BATCH; ++k) {
             const int slot = s0 + k * WS_SPP + ps;
-            const int hy = slot / HP, hx = slot - hy * HP;
+            const int hy = ws_div(slot, HP, rHP), hx = slot - hy * HP;
             const int y = ylo + hy, x = hx - 1;
             raw[k][0] = make_float4(0.f, 0.f, 0.f, 0.f); raw[k][1] = raw[k][0];
             if (a_live && slot < SLOTS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
@@ -130,7 +139,7 @@ __global__ void __launch_bounds__(256) conv_ws_kernel(const eg3d_conv_ws_params 
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int m = min(m0 + i * 32 + (lane & 31), HW - 1);
-            const int y = m / p.W, x = m - y * p.W;
+            const int y = ws_div(m, p.W, rW), x = m - y * p.W;
             a_addr[i] = (unsigned)(wave * cplane + ((lane >> 5) * SLOTS + (y - ylo) * HP + x + 1) * 16);
         }
         const f16x2 k2m11 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
@@ -254,6 +263,7 @@ __global__ void __launch_bounds__(256) conv_ws_s2adj_kernel(const eg3d_conv_ws_p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cl = wave % CPW, mh = wave / CPW;
     const int HW = p.H * p.W, PW = p.W + 1, PP = (p.H + 1) * PW, SLOTS = 4 * PP;
+    const float rPP = 1.f / (float)PP, rPW = 1.f / (float)PW, rW = 1.f / (float)p.W;
     const int ntile_n = p.Nc / WS_BN, nchunk = p.Ck / 16, ngrp = (nchunk + CPW - 1) / CPW;
     int bid = blockIdx.x;
     const int n_t = bid % ntile_n; bid /= ntile_n;
@@ -301,8 +311,8 @@ __global__ void __launch_bounds__(256) conv_ws_s2adj_kernel(const eg3d_conv_ws_p
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
             const int slot = s0 + k * SPP + ps;
-            const int par = slot / PP, r = slot - par * PP;
-            const int ap = r / PW, bp = r - ap * PW;
+            const int par = ws_div(slot, PP, rPP), r = slot - par * PP;
+            const int ap = ws_div(r, PW, rPW), bp = r - ap * PW;
             const int y = 2 * ap + (par >> 1), x = 2 * bp + (par & 1);
             raw[k][0] = make_float4(0.f, 0.f, 0.f, 0.f); raw[k][1] = raw[k][0];
             if (a_live && slot < SLOTS && y < p.Hx && x < p.Wx) {
@@ -334,7 +344,7 @@ __global__ void __launch_bounds__(256) conv_ws_s2adj_kernel(const eg3d_conv_ws_p
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int m = min((mh * MT + i) * 32 + (lane & 31), HW - 1);
-            const int a = m / p.W, b = m - a * p.W;
+            const int a = ws_div(m, p.W, rW), b = m - a * p.W;
             a_addr[i] = (unsigned)(cl * cplane + ((lane >> 5) * SLOTS + a * PW + b) * 16);
         }
         const f16x2 k2m11 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
@@ -445,6 +455,7 @@ __global__ void __launch_bounds__(256) conv_ws_up_kernel(const eg3d_conv_ws_para
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int HW = p.H * p.W, PW = p.W + 1, PC = (p.H + 1) * PW;        // cells of a parity class
     const int HP = p.W + 2, SLOTS = (p.H + 2) * HP;
+    const float rHP = 1.f / (float)HP, rPW = 1.f / (float)PW;
     const int Ho = 2 * p.H + 1, Wo = 2 * p.W + 1;
     const int ntile_n = p.Nc / WS_BN, nchunk = p.Ck / 16, ngrp = (nchunk + WS_CPW - 1) / WS_CPW;
     int bid = blockIdx.x;
@@ -493,7 +504,7 @@ __global__ void __launch_bounds__(256) conv_ws_up_kernel(const eg3d_conv_ws_para
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
             const int slot = s0 + k * WS_SPP + ps;
-            const int hy = slot / HP, hx = slot - hy * HP;
+            const int hy = ws_div(slot, HP, rHP), hx = slot - hy * HP;
             const int y = hy - 1, x = hx - 1;
             raw[k][0] = make_float4(0.f, 0.f, 0.f, 0.f); raw[k][1] = raw[k][0];
             if (a_live && slot < SLOTS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
@@ -527,7 +538,7 @@ __global__ void __launch_bounds__(256) conv_ws_up_kernel(const eg3d_conv_ws_para
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int m = min(i * 32 + (lane & 31), PC - 1);
-            const int a = m / PW, b = m - a * PW;
+            const int a = ws_div(m, PW, rPW), b = m - a * PW;
             a_addr[i] = (unsigned)(wave * cplane + ((lane >> 5) * SLOTS + (a + 1) * HP + b + 1) * 16);
         }
         const f16x2 k2m11 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
@@ -596,12 +607,12 @@ __global__ void __launch_bounds__(256) conv_ws_up_kernel(const eg3d_conv_ws_para
         const float4 v = img[qd * 64 + lane];
         const float vv[4] = {v.x, v.y, v.z, v.w};
         const int m0r = i * 32 + 4 * (lane >> 5) + 8 * (qd & 3);
+        int a = ws_div(m0r, PW, rPW), b = m0r - a * PW;                 // four consecutive cells: one division, then steps
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int m = m0r + q;
-            const int a = m / PW, b = m - a * PW;
             const int y = 2 * a + (c >> 1), x = 2 * b + (c & 1);
-            if (m < PC && y < Ho && x < Wo) eg3d_acc(on + (int64_t)(y * Wo + x) * p.ldo, vv[q] * out_mul);
+            if (m0r + q < PC && y < Ho && x < Wo) eg3d_acc(on + (int64_t)(y * Wo + x) * p.ldo, vv[q] * out_mul);
+            if (++b == PW) { b = 0; ++a; }
         }
     }
 }
