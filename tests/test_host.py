@@ -315,3 +315,43 @@ def test_default_switch_state():
     assert sorted(now) == sorted(want), sorted(set(now) ^ set(want))
     for k in want:
         assert now[k] == want[k], (k, now[k], want[k])
+
+
+def test_ctypes_structures_match_the_header():
+    """Every parameter structure of inv3d_amd/_lib.py has the size and the field offsets of its C definition in include/eg3d_hip.h (compiled
+    here with gcc: the header is plain C, as an FFI boundary must be) -- a field appended on one side only would otherwise show up as wrong
+    numbers on the GPU, or not at all."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which('gcc') is None:
+        pytest.skip('no C compiler')
+    from inv3d_amd import _lib as L
+    pairs = [('eg3d_conv_class', L.ConvClass), ('eg3d_act_bwd', L.ActBwd), ('eg3d_conv_params', L.ConvParams), ('eg3d_conv_ws_params', L.ConvWsParams),
+             ('eg3d_conv_v2_params', L.ConvV2Params), ('eg3d_conv_up2_params', L.ConvUp2Params), ('eg3d_wgrad_params', L.WgradParams),
+             ('eg3d_wgrad_v2_params', L.WgradV2Params), ('eg3d_render_params', L.RenderParams), ('eg3d_render_bwd_params', L.RenderBwdParams),
+             ('eg3d_render_sizes', L.RenderSizes), ('eg3d_split_w_item', L.SplitWItem), ('eg3d_split_w_batch', L.SplitWBatch),
+             ('eg3d_torgb_small_params', L.TorgbSmallParams), ('eg3d_torgb_small_bwd_params', L.TorgbSmallBwdParams),
+             ('eg3d_conv3x3_direct_params', L.Conv3x3DirectParams), ('eg3d_adam_item', L.AdamItem), ('eg3d_adam_list', L.AdamList),
+             ('eg3d_unit_level', L.UnitLevel), ('eg3d_unit_levels', L.UnitLevels), ('eg3d_flrelu_params', L.FlreluParams),
+             ('eg3d_style_layer', L.StyleLayer), ('eg3d_style_bank', L.StyleBank), ('eg3d_wgf_item', L.WgfItem), ('eg3d_pack_item', L.PackItem)]
+    header = open(os.path.join(ROOT, 'include', 'eg3d_hip.h')).read()
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "eg3d_hip.h"', 'int main(void) {']
+    want = []
+    for cname, cls in pairs:
+        assert cname in header, cname
+        src.append(f' printf("%zu\\n", sizeof({cname}));')
+        want.append(C.sizeof(cls))
+        for f in cls._fields_:
+            if f[0].startswith('pad') or f[0].startswith('_'):          # explicit padding on the Python side, implicit in C
+                continue
+            src.append(f' printf("%zu\\n", offsetof({cname}, {f[0]}));')
+            want.append(getattr(cls, f[0]).offset)
+    src += [' return 0;', '}']
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, 't.c'), 'w').write('\n'.join(src) + '\n')
+        r = subprocess.run(['gcc', '-std=c99', '-I', os.path.join(ROOT, 'include'), '-o', os.path.join(d, 't'), os.path.join(d, 't.c')], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-600:]
+        got = [int(v) for v in subprocess.run([os.path.join(d, 't')], capture_output=True, text=True, check=True).stdout.split()]
+    assert got == want, [(i, a, b) for i, (a, b) in enumerate(zip(want, got)) if a != b][:5]
