@@ -11,6 +11,8 @@
 //   block = 256 threads = 4 waves; tile = 32 pixels (of ONE image) x 32 outputs; grid = (N * ceil(HW / 32), Cp / 32).
 #include "common.h"
 #include "det.h"
+#include <algorithm>
+#include <atomic>
 
 namespace {
 
@@ -260,6 +262,380 @@ __global__ void __launch_bounds__(256) torgb_small_bwd_kernel(const eg3d_torgb_s
     if (act_on && ab.dstrength != nullptr && threadIdx.x == 0 && sc_lds[0] != 0.f) eg3d_acc(ab.dstrength, sc_lds[0]);
 }
 
+
+// =====================================================================================================================================
+// The same layer for the 128^2 / 256^2 blocks of the backbone (96 outputs, 128 - 256 input channels, >= 8192 pixels): there the launch is a
+// pass over x -- 17 / 34 MB in, 6 / 25 MB out, 1.6 GFLOP -- and what the small kernel does well (one memory round trip per launch) is beside the
+// point: as 6144 independent 32 x 32 tiles it re-reads x once per output tile and 16 KB of weights per 16 KB of x, and its backward ends every
+// tile with 128 atomics onto the same few hundred addresses (measured at 256^2: forward 73 us, backward 122 us; the implicit GEMM 42 / 56).
+// The "mid" kernels are persistent streaming forms of the same arithmetic (exact fp32 products, v_mfma_f32_32x32x2_f32):
+//   forward : the whole weight matrix sits in LDS as MFMA B fragments (C x 96 floats), a wave owns 32 pixels and ALL 96 outputs -- x is read
+//             once --, its operand loads run four channel groups ahead of the matrix instructions, nothing is shared between the waves
+//             (KS = 2: the contraction of a tile is cut across a wave pair that meets in LDS -- 128^2 has only 512 tiles for 1024 SIMDs);
+//   backward: a wave owns (32 pixels, 32 input channels) with its 12 KB weight slice in registers, the result tile goes through a
+//             wave-private LDS area to the (pixel, channel quad) layout of the small kernel's epilogue -- same expressions, 16 bytes per
+//             lane --, and the column sums (ds, dbias, dd, the addend's ds) stay in registers across all tiles of the wave: one set of
+//             atomics per block.
+constexpr int TM_NT = 3;                                   // output tiles (Cp = 96)
+typedef float tm_f4 __attribute__((ext_vector_type(4)));      // (staging arrays of HIP's float4 struct next to a compiler fence ended up in scratch memory)
+constexpr int TM_DEPTH = 4;                                // channel groups in flight ahead of the matrix instructions
+
+// compiler-level fence: keeps the load batches where they are written (without it the scheduler sinks every prefetch to its first use and
+// splits it into dword loads, each followed by a full wait: no load is ever in flight under the matrix instructions)
+__device__ __forceinline__ void tm_fence() { asm volatile("" ::: "memory"); }
+
+// ADD: 0 = no addend, 1 = full-resolution addend, 2 = half-resolution addend through the 2 x 2 taps of the up-sampling FIR
+template <int KS, int ADD, int FILL>
+__global__ void __launch_bounds__(256, FILL == 12 ? 2 : 1) torgb_mid_kernel(const eg3d_torgb_small_params p) {
+    extern __shared__ __attribute__((aligned(16))) char tm_lds[];
+    float* const wrow = reinterpret_cast<float*>(tm_lds);                       // the weight matrix, [96][C + 4]
+    const int groups = p.C / 8, wpitch = p.C + 4;
+    float* const red = wrow + 96 * wpitch;                                      // KS = 2: [pair][48][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
+    constexpr int TPB = 4 / KS;                                                 // tiles a block works on at a time
+    const int sub = wave / KS, kp = wave % KS;
+    const int HW = p.H * p.W, tpi = HW / TS_PIX;
+    const int T = p.N * tpi;
+    const int ng = groups / KS, g0 = kp * ng;
+    const int stride = gridDim.x * TPB;
+    const int iters = (T + stride - 1) / stride;
+    const int Hl = p.H >> 1, Wl = p.W >> 1;
+    const float t0 = p.addend_taps[0], t1 = p.addend_taps[1], t2 = p.addend_taps[2], t3 = p.addend_taps[3];
+    // the tile of iteration `it` of this wave
+    bool valid;
+    int n, p0;
+    const float* xr;
+    const float* sr;
+    auto set_tile = [&](int it) {
+        const int tile = it * stride + blockIdx.x * TPB + sub;
+        valid = tile < T;
+        const int tl = valid ? tile : 0;
+        n = tl / tpi; p0 = (tl - n * tpi) * TS_PIX;
+        xr = p.x + ((int64_t)n * HW + p0 + col) * p.ldx + 4 * h + 8 * g0;
+        sr = p.s + (int64_t)n * p.C + 4 * h + 8 * g0;
+    };
+    auto load_batch = [&](int gb, float4 (&xx)[TM_DEPTH], float4 (&ss)[TM_DEPTH]) {
+#pragma unroll
+        for (int j = 0; j < TM_DEPTH; ++j) {
+            const int gi = min(gb + j, ng - 1);                                  // (past the end the last group is requested again: no load under a branch)
+            xx[j] = *reinterpret_cast<const float4*>(xr + 8 * gi);
+            ss[j] = *reinterpret_cast<const float4*>(sr + 8 * gi);
+        }
+    };
+    // two batches of TM_DEPTH channel groups in flight: the loads of one are requested before the matrix instructions of the other
+    float4 xa[TM_DEPTH], sa[TM_DEPTH], xb[TM_DEPTH], sb[TM_DEPTH];
+    float bias_v[TM_NT];
+    {   // Start-up: ONE memory round trip.  The bias, the first operand batch of the first tile and ALL fill loads of the thread are requested before
+        // the first wait (as two fill batches, then the bias loads under their null-pointer branches, then the first operand batch, the launch spent
+        // 7.7 - 8.8 us of 22 - 30 waiting four times).
+        // Fill: the weight matrix is copied as it lies -- rows of C floats, 16 bytes per lane, whole rows per instruction; LDS row pitch C + 4 floats, so
+        // that the B-fragment reads of the matrix instructions (lane = output row, 16 bytes at a fixed channel offset) fall on distinct banks.
+        // (tools/proto/fill_probe.hip: 256 blocks pulling the same 96 KB this way take 1.2 - 1.7 us.)
+#pragma unroll
+        for (int t = 0; t < TM_NT; ++t) bias_v[t] = (p.bias != nullptr ? p.bias : p.w)[32 * t + col];
+        set_tile(0);
+        load_batch(0, xa, sa);
+        const int q4 = p.C / 4;                                                    // float4s per weight row
+        const int nb = 96 * q4 / 256;                                              // batches of 256 float4s: 3 C / 32 (3 .. 24)
+        // (indices spelled out in the unrolled loops: with the address arithmetic in lambdas the staging arrays stayed in scratch memory)
+        float* const dummy = red + 2 * 48 * 64;                                    // 256 float4s nobody reads: where the surplus slots of a batch are stored
+        tm_f4 ta[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const int i = min(j, nb - 1) * 256 + (int)threadIdx.x, o = i / q4, k = i - o * q4;
+            ta[j] = *reinterpret_cast<const tm_f4*>(p.w + (int64_t)o * p.w_row + 4 * k);
+        }
+        if (FILL == 24) {
+            tm_f4 tb[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const int i = min(12 + j, nb - 1) * 256 + (int)threadIdx.x, o = i / q4, k = i - o * q4;
+                tb[j] = *reinterpret_cast<const tm_f4*>(p.w + (int64_t)o * p.w_row + 4 * k);
+            }
+            tm_fence();
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const int i = (12 + j) * 256 + (int)threadIdx.x, o = i / q4, k = i - o * q4;
+                float* d = 12 + j < nb ? wrow + o * wpitch + 4 * k : dummy + 4 * (int)threadIdx.x;
+                *reinterpret_cast<tm_f4*>(d) = tb[j];
+            }
+        }
+        tm_fence();
+        if (p.bias == nullptr) { bias_v[0] = 0.f; bias_v[1] = 0.f; bias_v[2] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const int i = j * 256 + (int)threadIdx.x, o = i / q4, k = i - o * q4;
+            float* d = j < nb ? wrow + o * wpitch + 4 * k : dummy + 4 * (int)threadIdx.x;
+            *reinterpret_cast<tm_f4*>(d) = ta[j];
+        }
+    }
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        if (it > 0) {
+            set_tile(it);
+            load_batch(0, xa, sa);
+        }
+        tm_fence();
+        f32x16_t acc[TM_NT];
+#pragma unroll
+        for (int t = 0; t < TM_NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        const float* const wbase = wrow + col * wpitch + 8 * g0 + 4 * h;
+        tm_f4 bn[TM_NT] = {*reinterpret_cast<const tm_f4*>(wbase), *reinterpret_cast<const tm_f4*>(wbase + 32 * wpitch), *reinterpret_cast<const tm_f4*>(wbase + 64 * wpitch)};
+        auto compute = [&](int gb, const float4 (&xx)[TM_DEPTH], const float4 (&ss)[TM_DEPTH]) {
+#pragma unroll
+            for (int j = 0; j < TM_DEPTH; ++j) {
+                const float4 a = make_float4(xx[j].x * ss[j].x, xx[j].y * ss[j].y, xx[j].z * ss[j].z, xx[j].w * ss[j].w);
+                // (B fragments one group ahead of their use: read right before the matrix instructions, the LDS latency was exposed once per group)
+                const tm_f4 b0 = bn[0], b1 = bn[1], b2 = bn[2];
+                {
+                    const float* wq = wbase + 8 * min(gb + j + 1, ng - 1);
+                    bn[0] = *reinterpret_cast<const tm_f4*>(wq); bn[1] = *reinterpret_cast<const tm_f4*>(wq + 32 * wpitch); bn[2] = *reinterpret_cast<const tm_f4*>(wq + 64 * wpitch);
+                }
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b2.x, acc[2], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b2.y, acc[2], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b2.z, acc[2], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b2.w, acc[2], 0, 0, 0);
+            }
+        };
+        for (int gb = 0; gb < ng; gb += 2 * TM_DEPTH) {
+            load_batch(gb + TM_DEPTH, xb, sb);
+            tm_fence();
+            compute(gb, xa, sa);
+            tm_fence();
+            load_batch(gb + 2 * TM_DEPTH, xa, sa);
+            tm_fence();
+            if (gb + TM_DEPTH < ng) compute(gb + TM_DEPTH, xb, sb);
+            tm_fence();
+        }
+        if (KS == 2) {
+            float* rp = red + (int64_t)sub * 48 * 64 + lane;
+            if (kp == 1) {
+#pragma unroll
+                for (int t = 0; t < TM_NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rp[(t * 16 + r) * 64] = acc[t][r];
+            }
+            __syncthreads();
+            if (kp == 0) {
+#pragma unroll
+                for (int t = 0; t < TM_NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] += rp[(t * 16 + r) * 64];
+            }
+        }
+        if (kp == 0 && valid) {
+            // accumulator element r of a lane: pixel row (r & 3) + 8 (r >> 2) + 4 h, output column 32 t + col.  Four r (= four consecutive pixels) at a time:
+            // all addend loads of the four are requested, then the arithmetic and the stores
+            const int y0 = p0 / p.W, x0 = p0 - y0 * p.W;
+            float* orow = p.out + ((int64_t)n * HW + p0) * p.ldo + col;
+            const float* arow = ADD == 2 ? p.addend + (int64_t)n * (HW >> 2) * p.ldo + col : (ADD == 1 ? p.addend + ((int64_t)n * HW + p0) * p.ldo + col : nullptr);
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                float ad[4][TM_NT];
+                if (ADD == 1) {
+#pragma unroll
+                    for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                        for (int t = 0; t < TM_NT; ++t) ad[ri][t] = arow[(int64_t)(ri + 8 * rq + 4 * h) * p.ldo + 32 * t];
+                } else if (ADD == 2) {
+                    float tv[4][4][TM_NT], wgt[4][4];
+#pragma unroll
+                    for (int ri = 0; ri < 4; ++ri) {
+                        const int pr = ri + 8 * rq + 4 * h;
+                        int xx = x0 + pr, yy = y0;
+                        if (xx >= p.W) { xx -= p.W; ++yy; }                           // (W >= 32: at most one row boundary inside a tile)
+                        const int oy = yy & 1, ox = xx & 1;
+                        const int r0 = (yy >> 1) - 1 + oy, c0 = (xx >> 1) - 1 + ox;
+                        const bool ra = r0 >= 0, rb = r0 + 1 < Hl, ca = c0 >= 0, cb = c0 + 1 < Wl;
+                        const int rr0 = ra ? r0 : 0, rr1 = rb ? r0 + 1 : 0, cc0 = ca ? c0 : 0, cc1 = cb ? c0 + 1 : 0;      // clamped addresses, masked values
+                        wgt[ri][0] = (ra && ca) ? 1.f : 0.f; wgt[ri][1] = (ra && cb) ? 1.f : 0.f; wgt[ri][2] = (rb && ca) ? 1.f : 0.f; wgt[ri][3] = (rb && cb) ? 1.f : 0.f;
+                        const float* q[4] = {arow + ((int64_t)rr0 * Wl + cc0) * p.ldo, arow + ((int64_t)rr0 * Wl + cc1) * p.ldo,
+                                             arow + ((int64_t)rr1 * Wl + cc0) * p.ldo, arow + ((int64_t)rr1 * Wl + cc1) * p.ldo};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+#pragma unroll
+                            for (int t = 0; t < TM_NT; ++t) tv[ri][c][t] = q[c][32 * t];
+                    }
+                    tm_fence();
+#pragma unroll
+                    for (int ri = 0; ri < 4; ++ri) {
+                        const int pr = ri + 8 * rq + 4 * h;
+                        int xx = x0 + pr, yy = y0;
+                        if (xx >= p.W) { xx -= p.W; ++yy; }
+                        const int oy = yy & 1, ox = xx & 1;
+                        const float wy0 = oy ? t2 : t3, wy1 = oy ? t0 : t1, wx0 = ox ? t2 : t3, wx1 = ox ? t0 : t1;
+#pragma unroll
+                        for (int t = 0; t < TM_NT; ++t) {
+                            const float A = wgt[ri][0] != 0.f ? tv[ri][0][t] : 0.f, B = wgt[ri][1] != 0.f ? tv[ri][1][t] : 0.f;
+                            const float Cc = wgt[ri][2] != 0.f ? tv[ri][2][t] : 0.f, D = wgt[ri][3] != 0.f ? tv[ri][3][t] : 0.f;
+                            ad[ri][t] = wy0 * (wx0 * A + wx1 * B) + wy1 * (wx0 * Cc + wx1 * D);          // the expression of up2_at
+                        }
+                    }
+                }
+                if (ADD == 1) tm_fence();
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri) {
+                    const int r = ri + 4 * rq, pr = ri + 8 * rq + 4 * h;
+#pragma unroll
+                    for (int t = 0; t < TM_NT; ++t) {
+                        float v = acc[t][r] + bias_v[t];
+                        if (p.clamp >= 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
+                        orow[(int64_t)pr * p.ldo + 32 * t] = ADD ? v + ad[ri][t] : v;
+                    }
+                }
+            }
+        }
+        if (KS == 2) __syncthreads();                                              // the pair's LDS area is rewritten by the next tile
+    }
+}
+
+__global__ void __launch_bounds__(256) torgb_mid_bwd_kernel(const eg3d_torgb_small_bwd_params p) {
+    __shared__ float red[4][TS_PIX][TS_OUT + 1];                                  // wave-private result tiles
+    __shared__ float colsum[4][4][TS_OUT];                                        // [wave][which sum][column]
+    __shared__ float str_lds[4];
+    const int HW = p.H * p.W, tpi = HW / TS_PIX;
+    const int n = blockIdx.z;                                                     // one image per grid plane: ds / dd / add_ds are per-image sums
+    const int c0 = blockIdx.y * TS_OUT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane & 31, h = lane >> 5;
+    const int er0 = lane >> 3, eq = lane & 7, eo = c0 + eq * 4;                     // epilogue: lane = (pixel row er0 + 8 k, channel quad)
+    const bool act_on = p.act_on != 0;
+    const eg3d_act_bwd& ab = p.act_bwd;
+    constexpr int NG = 12;                                                         // Cp = 96: twelve 8-groups
+    float4 wb[NG];
+    {
+        const float* wr = p.wa + (int64_t)(c0 + row) * p.wa_row + 4 * h;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) wb[g] = *reinterpret_cast<const float4*>(wr + 8 * g);
+    }
+    float4 abb4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act_on && ab.bias != nullptr) abb4 = *reinterpret_cast<const float4*>(ab.bias + eo);
+    float4 t_ds = make_float4(0.f, 0.f, 0.f, 0.f), t_db = t_ds, t_dq = t_ds, t_da = t_ds;
+    float omax = 0.f, dstr = 0.f;
+    float (*my)[TS_OUT + 1] = red[wave];
+    const float4 s4 = *reinterpret_cast<const float4*>(p.s + (int64_t)n * p.C + eo);
+    float4 as4 = *reinterpret_cast<const float4*>((p.add_scale != nullptr ? p.add_scale : p.s) + (int64_t)n * p.C + eo);
+    if (p.add_scale == nullptr) as4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 abd4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (act_on && ab.d != nullptr) abd4 = *reinterpret_cast<const float4*>(ab.d + (int64_t)n * p.C + eo);
+    // the operand tile of the wave's first pixel tile is requested with the weight slice (one memory round trip before the first matrix instruction);
+    // inside the loop the NEXT tile's operand loads go out as soon as the matrix instructions have consumed this one's registers, i.e. under the epilogue
+    const int tstep = gridDim.x * 4;
+    float4 ga[NG];
+    {
+        const int t0 = min((int)blockIdx.x * 4 + wave, tpi - 1);
+        const float* gr = p.dy + ((int64_t)n * HW + t0 * TS_PIX + row) * p.ldg + 4 * h;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) ga[g] = *reinterpret_cast<const float4*>(gr + 8 * g);
+    }
+    tm_fence();
+    eg3d_act_bwd_consts abc = {};
+    if (act_on) abc = eg3d_act_bwd_setup(ab);
+    for (int tile = blockIdx.x * 4 + wave; tile < tpi; tile += tstep) {
+        const int p0 = tile * TS_PIX;
+        // the epilogue's side inputs are requested before the matrix instructions
+        const int64_t off0 = ((int64_t)n * HW + p0 + er0) * p.ldx + eo;
+        float4 xin4[4], a4[4];
+        float nz[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t off = off0 + (int64_t)8 * k * p.ldx;
+            xin4[k] = p.xin != nullptr ? *reinterpret_cast<const float4*>(p.xin + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            a4[k] = p.addend != nullptr ? *reinterpret_cast<const float4*>(p.addend + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            nz[k] = (act_on && ab.noise != nullptr) ? ab.noise[(int64_t)n * ab.noise_nstride + p0 + er0 + 8 * k] : 0.f;
+        }
+        tm_fence();
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[g].x, wb[g].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[g].y, wb[g].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[g].z, wb[g].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[g].w, wb[g].w, acc, 0, 0, 0);
+        }
+        tm_fence();
+        {
+            const int tn = min(tile + tstep, tpi - 1);                               // (past the end: a tile that exists, requested again -- no load under a branch)
+            const float* gr = p.dy + ((int64_t)n * HW + tn * TS_PIX + row) * p.ldg + 4 * h;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) ga[g] = *reinterpret_cast<const float4*>(gr + 8 * g);
+        }
+        tm_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) my[(r & 3) + 8 * (r >> 2) + 4 * h][row] = acc[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                       // wave-private area: LDS operations of one wave complete in order
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int er = er0 + 8 * k;
+            float4 v = make_float4(my[er][eq * 4 + 0], my[er][eq * 4 + 1], my[er][eq * 4 + 2], my[er][eq * 4 + 3]);
+            const float4 xi = xin4[k];
+            float4 a = a4[k];
+            if (p.ds != nullptr) { t_ds.x += v.x * xi.x; t_ds.y += v.y * xi.y; t_ds.z += v.z * xi.z; t_ds.w += v.w * xi.w; }
+            if (p.add_ds != nullptr) { t_da.x += a.x * xi.x; t_da.y += a.y * xi.y; t_da.z += a.z * xi.z; t_da.w += a.w * xi.w; }
+            a = make_float4(a.x * as4.x, a.y * as4.y, a.z * as4.z, a.w * as4.w);
+            v = make_float4(v.x * s4.x + a.x, v.y * s4.y + a.y, v.z * s4.z + a.z, v.w * s4.w + a.w);
+            if (act_on) {
+                float cs;
+                v = eg3d_act_bwd_unit(abc, v, xi, abd4, abb4, nz[k] * abc.strength, t_db, t_dq, cs);
+                if (ab.dnoise != nullptr || ab.dstrength != nullptr) {
+                    cs = eg3d_row_group_sum(cs, 8);
+                    if (eq == 0) {
+                        if (ab.dnoise != nullptr) eg3d_acc(ab.dnoise + (int64_t)n * ab.dnoise_nstride + p0 + er, cs * abc.strength);
+                        dstr += cs * nz[k];
+                    }
+                }
+            }
+            omax = fmaxf(omax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            *reinterpret_cast<float4*>(p.dx + off0 + (int64_t)8 * k * p.ldx) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+    eg3d_commit_amax_block(omax, p.out_amax);
+    // column sums: lanes that share a channel quad differ in bits 3 .. 5
+    float cs16[16] = {t_ds.x, t_ds.y, t_ds.z, t_ds.w, t_db.x, t_db.y, t_db.z, t_db.w, t_dq.x, t_dq.y, t_dq.z, t_dq.w, t_da.x, t_da.y, t_da.z, t_da.w};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float v = cs16[i];
+        v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        cs16[i] = v;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) dstr += __shfl_xor(dstr, o);
+    if (lane < 8) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) colsum[wave][i >> 2][lane * 4 + (i & 3)] = cs16[i];
+    }
+    if (lane == 0) str_lds[wave] = dstr;
+    __syncthreads();
+    if (threadIdx.x < 4 * TS_OUT) {
+        const int a = threadIdx.x / TS_OUT, cc = threadIdx.x - a * TS_OUT, c = c0 + cc;
+        const bool want = a == 0 ? p.ds != nullptr : (a == 3 ? p.add_ds != nullptr : (act_on && (a == 1 ? ab.dbias != nullptr : ab.dd != nullptr)));
+        if (want) {
+            const float sum = (colsum[0][a][cc] + colsum[1][a][cc]) + (colsum[2][a][cc] + colsum[3][a][cc]);
+            if (a == 0) eg3d_acc(p.ds + (int64_t)n * p.C + c, sum);
+            else if (a == 3) eg3d_acc(p.add_ds + (int64_t)n * p.C + c, sum);
+            else if (a == 1) eg3d_acc(ab.dbias + c, sum);
+            else eg3d_acc(ab.dd + (int64_t)n * p.C + c, sum / (ab.d != nullptr ? ab.d[(int64_t)n * p.C + c] : 1.f));
+        }
+    }
+    if (act_on && ab.dstrength != nullptr && threadIdx.x == 0) {
+        const float sv = (str_lds[0] + str_lds[1]) + (str_lds[2] + str_lds[3]);
+        if (sv != 0.f) eg3d_acc(ab.dstrength, sv);
+    }
+}
+
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 }  // namespace
@@ -275,9 +651,40 @@ extern "C" int eg3d_torgb_small_supported(const eg3d_torgb_small_params* p) {
     return 1;
 }
 
+// the streaming form (torgb_mid_kernel) takes the launch when the geometry is the backbone's 128^2 / 256^2 toRGB: 96 outputs, whole 32-pixel tiles
+// inside an image, the weight matrix fits LDS, no pending epilogue, and there are enough tiles to fill the chip
+extern "C" int eg3d_torgb_mid_supported(const eg3d_torgb_small_params* p) {
+    if (!eg3d_torgb_small_supported(p) || p->pre_z != nullptr) return 0;
+    if (p->Cp != 32 * TM_NT || (p->C % 32) || p->C > 256 || p->W < TS_PIX || ((int64_t)p->H * p->W) % TS_PIX) return 0;
+    if ((int64_t)p->N * p->H * p->W < 8192) return 0;
+    return 1;
+}
+
+static int launch_torgb_mid(const eg3d_torgb_small_params* p, hipStream_t st) {
+    const int T = (int)((int64_t)p->N * p->H * p->W / TS_PIX);
+    const int wbytes = 96 * (p->C + 4) * 4;
+    // K split across wave pairs while whole tiles do not give every SIMD a wave (needs C / 16 channel groups a multiple of TM_DEPTH)
+    const bool ks2 = T < 1024 && (p->C % 64) == 0;
+    const int smem = wbytes + 2 * 48 * 64 * 4 + 4096;          // weights, the wave pairs' exchange area (KS = 2), the fill's dummy slots
+    const int per_cu = std::max(1, (160 * 1024) / (smem + 1024));
+    const int tpb = ks2 ? 2 : 4;
+    const int blocks = std::min((T + tpb - 1) / tpb, 256 * std::min(per_cu, 2));
+    static std::atomic<uint64_t> done[12];
+    const int add = p->addend == nullptr ? 0 : (p->addend_up2 ? 2 : 1);
+    void (*kerns[12])(const eg3d_torgb_small_params) = {
+        torgb_mid_kernel<1, 0, 12>, torgb_mid_kernel<1, 1, 12>, torgb_mid_kernel<1, 2, 12>, torgb_mid_kernel<2, 0, 12>, torgb_mid_kernel<2, 1, 12>, torgb_mid_kernel<2, 2, 12>,
+        torgb_mid_kernel<1, 0, 24>, torgb_mid_kernel<1, 1, 24>, torgb_mid_kernel<1, 2, 24>, torgb_mid_kernel<2, 0, 24>, torgb_mid_kernel<2, 1, 24>, torgb_mid_kernel<2, 2, 24>};
+    const int ki = (p->C > 128 ? 6 : 0) + (ks2 ? 3 : 0) + add;
+    if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kerns[ki]), 160 * 1024, done[ki])) return e;
+    hipLaunchKernelGGL(kerns[ki], dim3(blocks), dim3(256), smem, st, *p);
+    EG3D_LAUNCH_CHECK();
+    return EG3D_OK;
+}
+
 extern "C" int eg3d_torgb_small_fwd(const eg3d_torgb_small_params* p, void* stream) {
     if (!p || !p->x || !p->w || !p->s || !p->out) return EG3D_ERR_INVALID;
     if (!eg3d_torgb_small_supported(p)) return EG3D_ERR_UNSUPPORTED;
+    if (eg3d_torgb_mid_supported(p)) return launch_torgb_mid(p, (hipStream_t)stream);
     const dim3 grid(p->N * eg3d_cdiv((int64_t)p->H * p->W, TS_PIX), p->Cp / TS_OUT);
     hipLaunchKernelGGL(torgb_small_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p);
     EG3D_LAUNCH_CHECK();
@@ -301,16 +708,29 @@ extern "C" int eg3d_torgb_small_bwd_supported(const eg3d_torgb_small_bwd_params*
     return 1;
 }
 
+extern "C" int eg3d_torgb_mid_bwd_supported(const eg3d_torgb_small_bwd_params* p) {
+    if (!eg3d_torgb_small_bwd_supported(p)) return 0;
+    if (p->Cp != 96 || ((int64_t)p->H * p->W) % TS_PIX || p->N > 65535) return 0;
+    if ((int64_t)p->N * p->H * p->W < 8192) return 0;
+    return 1;
+}
+
 extern "C" int eg3d_torgb_small_bwd(const eg3d_torgb_small_bwd_params* p, void* stream) {
     if (!p || !p->dy || !p->wa || !p->s || !p->dx) return EG3D_ERR_INVALID;
     if (!eg3d_torgb_small_bwd_supported(p)) return EG3D_ERR_UNSUPPORTED;
+    const bool mid = eg3d_torgb_mid_bwd_supported(p) != 0;
     const dim3 grid(p->N * eg3d_cdiv((int64_t)p->H * p->W, TS_PIX), p->C / TS_OUT);
+    // streaming form: ~two resident blocks per CU in all (a wave walks several tiles with its column sums in registers: one set of atomics per block)
+    const int tpi = (int)((int64_t)p->H * p->W / TS_PIX);
+    const int planes = (p->C / TS_OUT) * p->N;
+    const dim3 grid_mid(std::max(1, std::min((tpi + 3) / 4, 512 / std::max(1, planes))), p->C / TS_OUT, p->N);
     EG3D_DET_SCOPE(det, stream);
     EG3D_DET_BIND(det, p->ds, (int64_t)p->N * p->C);
     EG3D_DET_BIND(det, p->add_ds, (int64_t)p->N * p->C);
     if (p->act_on) { EG3D_DET_BIND_ACT(det, p->act_bwd, p->N, p->C, (int64_t)p->H * p->W); }
     EG3D_DET_COMMIT(det);
-    hipLaunchKernelGGL(torgb_small_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p);
+    if (mid) hipLaunchKernelGGL(torgb_mid_bwd_kernel, grid_mid, dim3(256), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL(torgb_small_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p);
     EG3D_DET_END(det);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;

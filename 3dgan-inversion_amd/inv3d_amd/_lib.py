@@ -308,6 +308,8 @@ _SIGS = {
     'eg3d_torgb_small_fwd': (C.c_int, [C.POINTER(TorgbSmallParams), C.c_void_p]),
     'eg3d_torgb_small_bwd_supported': (C.c_int, [C.POINTER(TorgbSmallBwdParams)]),
     'eg3d_torgb_small_bwd': (C.c_int, [C.POINTER(TorgbSmallBwdParams), C.c_void_p]),
+    'eg3d_torgb_mid_supported': (C.c_int, [C.POINTER(TorgbSmallParams)]),
+    'eg3d_torgb_mid_bwd_supported': (C.c_int, [C.POINTER(TorgbSmallBwdParams)]),
     'eg3d_adam_step': (C.c_int, [C.POINTER(AdamList), C.c_void_p, C.c_void_p]),
     'eg3d_pose_chain_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'eg3d_pose_chain_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -794,7 +794,7 @@ class ToRGBFn(torch.autograd.Function):
                     skip = H.upfirdn2d_nhwc(skip, fir44(skip.device), up=2, pad=(2, 1, 2, 1), gain=4.0)
         # small pixel counts (the 4^2 .. 64^2 blocks): the implicit GEMM's 32-step contraction is all latency there (~21 us for 64 pixels);
         # csrc/torgb_small.hip does the same arithmetic (exact fp32 products) in one short launch
-        small = (H.TORGB_SMALL and N * Hh * Ww <= H.TORGB_SMALL_MAX_PIX and Ci % 8 == 0 and Cp % 32 == 0 and wf.stride(1) == 1
+        small = (H.TORGB_SMALL and (N * Hh * Ww <= H.TORGB_SMALL_MAX_PIX or (H.TORGB_MID and pend is None)) and Ci % 8 == 0 and Cp % 32 == 0 and wf.stride(1) == 1
                  and (skip is None or up_taps is not None or tuple(skip.shape) == (N, Cp, Hh, Ww)))
         if pend is not None and not small:
             pend.run()
@@ -879,7 +879,7 @@ class ToRGBFn(torch.autograd.Function):
             wa_p = cache.get(weight)[1] if Cp == Co else cache.get_padded(weight, Cp)[1]    # contraction dim (output channels) padded to 4
             dx = H.empty_cl(N, Ci, Hh, Ww, dev)
             ds = H.zeros((N, Ci), dev)
-            small_ok = H.TORGB_SMALL and N * Hh * Ww <= H.TORGB_SMALL_BWD_MAX_PIX and Ci % 32 == 0 and Cp % 8 == 0 and wa_p.stride(1) == 1
+            small_ok = H.TORGB_SMALL and (N * Hh * Ww <= H.TORGB_SMALL_BWD_MAX_PIX or H.TORGB_MID_BWD) and Ci % 32 == 0 and Cp % 8 == 0 and wa_p.stride(1) == 1
             if pdg is not None and not (small_ok and H.is_cl(dx_pass) and dx_pass.dtype == torch.float32):
                 dx_pass, pdg = _finish_pending(pdg, x), None
             add = H.to_cl(dx_pass.float()) if dx_pass is not None else None
@@ -907,7 +907,7 @@ class ToRGBFn(torch.autograd.Function):
                     did = True
             else:
                 did = None
-                if H.TORGB_SMALL and N * Hh * Ww <= H.TORGB_SMALL_BWD_MAX_PIX and Ci % 32 == 0 and Cp % 8 == 0 and wa_p.stride(1) == 1:
+                if small_ok:
                     # small pixel counts: the low-latency launch (csrc/torgb_small.hip), same epilogue as the implicit GEMM's
                     did = H.torgb_small_bwd(dy, wa_p, styles, x, dx, ds=ds, addend=add, **fkw,
                                             **(dict(addend_scale=pdg[1], addend_ds=pdg[2]) if pdg is not None else {}))

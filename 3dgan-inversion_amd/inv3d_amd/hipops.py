@@ -1638,6 +1638,10 @@ TORGB_SMALL = os.environ.get('EG3D_TORGB_SMALL', '1') != '0'            # low-la
 TORGB_SMALL_MAX_PIX = int(os.environ.get('EG3D_TORGB_SMALL_MAX_PIX', '4096'))
 # (the data gradient at 64^2 takes 31 us in the trace against 27 for the implicit GEMM it replaced -- yet the step is 0.2 % faster with it: A/B 209.1 vs 208.8)
 TORGB_SMALL_BWD_MAX_PIX = int(os.environ.get('EG3D_TORGB_SMALL_BWD_MAX_PIX', '4096'))
+# the streaming form of the same entry points for the 128^2 / 256^2 blocks (torgb_mid_kernel / torgb_mid_bwd_kernel, csrc/torgb_small.hip): beyond
+# TORGB_SMALL_*_MAX_PIX the launch is taken only when the library says it runs in that form (eg3d_torgb_mid_supported); EG3D_TORGB_MID=0: implicit GEMM as before
+TORGB_MID = os.environ.get('EG3D_TORGB_MID', '1') != '0'
+TORGB_MID_BWD = os.environ.get('EG3D_TORGB_MID_BWD', '1') != '0'
 
 
 def torgb_small(x, wf, styles, out, bias=None, clamp=-1.0, addend=None, addend_up2_taps=None, pre=None):
@@ -1660,6 +1664,8 @@ def torgb_small(x, wf, styles, out, bias=None, clamp=-1.0, addend=None, addend_u
         p.pre_slope = {'linear': 1.0, 'lrelu': float(pre.alpha), 'relu': 0.0}[pre.act]
         p.pre_gain, p.pre_clamp = float(pre.gain), float(pre.clamp)
     if not L.lib().eg3d_torgb_small_supported(C.byref(p)):
+        return False
+    if n * h * w > TORGB_SMALL_MAX_PIX and not (TORGB_MID and L.lib().eg3d_torgb_mid_supported(C.byref(p))):
         return False
     L.check(L.lib().eg3d_torgb_small_fwd(C.byref(p), L.stream_ptr()), 'torgb_small_fwd')
     return True
@@ -1686,6 +1692,8 @@ def torgb_small_bwd(dy, wa, styles, x, dx, ds=None, addend=None, act_bwd=None, o
             p.act_bwd = L.ActBwd()
             p.out_amax = None
     if not fused and not L.lib().eg3d_torgb_small_bwd_supported(C.byref(p)):
+        return None
+    if n * h * w > TORGB_SMALL_BWD_MAX_PIX and not (TORGB_MID_BWD and L.lib().eg3d_torgb_mid_bwd_supported(C.byref(p))):
         return None
     L.check(L.lib().eg3d_torgb_small_bwd(C.byref(p), L.stream_ptr()), 'torgb_small_bwd')
     return fused

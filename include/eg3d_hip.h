@@ -638,6 +638,10 @@ typedef struct eg3d_torgb_small_params {
 } eg3d_torgb_small_params;
 int eg3d_torgb_small_supported(const eg3d_torgb_small_params* p);
 int eg3d_torgb_small_fwd(const eg3d_torgb_small_params* p, void* stream);
+/* Large pixel counts (the 128^2 / 256^2 blocks of the backbone: Cp == 96, C % 32 == 0, C <= 256, H*W % 32 == 0, W >= 32, >= 8192 pixels, no
+ * pre_z): eg3d_torgb_small_fwd runs the same arithmetic as a persistent streaming kernel (weights resident in LDS, x read once); this
+ * reports whether a launch with these parameters takes that form -- callers use it to decide between this entry and the implicit GEMM. */
+int eg3d_torgb_mid_supported(const eg3d_torgb_small_params* p);
 
 /* Data gradient of that layer for small pixel counts: dx[n,p,c] = (sum_o dy[n,p,o] wa[c,o]) s[n,c] + addend[n,p,c]; ds[n,c] += the un-scaled
  * sum times xin[n,p,c] (pre-zeroed, optional).  act_on != 0: additionally the activation backward of the layer that produced xin, exactly as
@@ -663,6 +667,9 @@ typedef struct eg3d_torgb_small_bwd_params {
 } eg3d_torgb_small_bwd_params;
 int eg3d_torgb_small_bwd_supported(const eg3d_torgb_small_bwd_params* p);
 int eg3d_torgb_small_bwd(const eg3d_torgb_small_bwd_params* p, void* stream);
+/* The streaming form of the data gradient (Cp == 96, H*W % 32 == 0, >= 8192 pixels): waves walk several pixel tiles with the column sums in
+ * registers, one set of atomics per workgroup.  Same results up to summation order; reports whether eg3d_torgb_small_bwd takes that form. */
+int eg3d_torgb_mid_bwd_supported(const eg3d_torgb_small_bwd_params* p);
 
 /* torch.optim.Adam(betas, eps; no weight decay, no amsgrad) over up to EG3D_ADAM_ITEMS_MAX leaves in one launch (the projector's
  * optimiser, w_projector.py:107-118,256): p, m (exp_avg), v (exp_avg_sq) updated in place from the gradient g + g2 (one of them may be

@@ -346,6 +346,10 @@ def test_synthesis_layer_fwd_bwd(cfg):
 @pytest.mark.parametrize('cfg', [(2, 16, 96, 8, None, True), (1, 32, 3, 16, 256.0, True), (2, 8, 3, 4, 0.5, False),
                                  # the low-latency launch of csrc/torgb_small.hip (>= 32 input channels, outputs a multiple of 32, few pixels):
                                  (2, 64, 96, 8, None, True), (1, 512, 96, 4, None, False), (1, 64, 96, 16, 0.5, True), (3, 136, 32, 7, None, True),
+                                 # >= 8192 pixels, 96 outputs: the streaming form (torgb_mid_kernel / torgb_mid_bwd_kernel): K split over wave pairs (few tiles,
+                                 # C % 64 == 0), whole contraction per wave (C = 96; 1152 tiles), two images, clamp
+                                 (1, 128, 96, 96, None, True), (1, 96, 96, 96, None, False), (1, 32, 96, 192, None, True), (2, 64, 96, 80, None, True),
+                                 (1, 256, 96, 96, 0.5, True),
                                  # four outputs, > 4096 pixels: the stream kernel of the SR head's toRGB (eg3d_torgb4_fwd)
                                  (1, 64, 3, 72, 2.0, True), (2, 128, 3, 48, None, False), (1, 256, 3, 68, 256.0, True), (1, 32, 4, 80, 0.7, False)])
 def test_torgb_fwd_bwd(cfg):
@@ -386,6 +390,7 @@ def test_torgb_fwd_bwd(cfg):
 
 @pytest.mark.parametrize('cfg', [(1, 16, 96, 8, None), (2, 32, 96, 16, None), (1, 16, 3, 32, None), (2, 16, 96, 6, None), (1, 16, 3, 16, 256.0),
                                  (1, 512, 96, 8, None), (2, 64, 96, 6, None), (1, 64, 96, 8, 2.0), (1, 256, 96, 64, None),
+                                 (1, 128, 96, 96, None), (2, 64, 96, 128, None), (1, 96, 96, 160, None),          # the streaming form (torgb_mid_kernel)
                                  (1, 64, 3, 72, 1.5), (2, 128, 3, 66, None), (1, 256, 3, 70, 256.0)])
 def test_torgb_takes_the_skip_image_at_half_resolution(cfg):
     """skip + toRGB of a 'skip' block (networks_stylegan2.py:433-436: img = upsample2d(img); img = img.add_(y)) with the up-sampling done
@@ -1502,7 +1507,8 @@ def test_absmax_any_length(n):
         assert float(H.absmax(x.to(DEV))) == 9.25
 
 
-@pytest.mark.parametrize('kind', ['v2_3x3', 'v3_3x3', 'v3_3x3_rows2_waves8', 'igemm_3x3', 'igemm_1x1', 'igemm_clamp_shared_noise', 'torgb4_elementwise', 'torgb_small', 'torgb_small_clamp_shared_noise'])
+@pytest.mark.parametrize('kind', ['v2_3x3', 'v3_3x3', 'v3_3x3_rows2_waves8', 'igemm_3x3', 'igemm_1x1', 'igemm_clamp_shared_noise', 'torgb4_elementwise', 'torgb_small', 'torgb_small_clamp_shared_noise',
+                                  'torgb_mid', 'torgb_mid_clamp_shared_noise'])
 def test_fused_activation_backward_equals_separate_pass(kind):
     """EG3D_EPI_BWD_ACT: a data-gradient launch that also runs the activation backward of the layer that produced its `xin`
     (dz, dbias, dd, dnoise, dstrength, max|dz|) against the two-pass form it replaces (EPI_BWD, then eg3d_modconv_epilogue_bwd on
@@ -1516,9 +1522,10 @@ def test_fused_activation_backward_equals_separate_pass(kind):
         err, scale = float((a - b).abs().max()), float(b.abs().max())
         assert err <= tol * scale, f'{what}: err {err:.3e} > {tol} * {scale:.3e}'
 
-    small = kind.startswith('torgb_small')               # csrc/torgb_small.hip: 96 outputs, 63 pixels per image (a ragged last tile)
+    mid = kind.startswith('torgb_mid')                   # ... its streaming form: 2 x 4608 pixels, 144 tiles per image
+    small = kind.startswith('torgb_small') or mid        # csrc/torgb_small.hip: 96 outputs, 63 pixels per image (a ragged last tile)
     one = kind in ('igemm_1x1', 'torgb4_elementwise') or small
-    n, ci, h, w, co = (2, 128, 24, 64, 128) if not one else ((2, 128, 32, 32, 4) if not small else (2, 160, 9, 7, 96))
+    n, ci, h, w, co = (2, 128, 24, 64, 128) if not one else ((2, 128, 32, 32, 4) if not small else ((2, 160, 72, 64, 96) if mid else (2, 160, 9, 7, 96)))
     k = 1 if one else 3
     g = torch.Generator().manual_seed(31)
     gz = torch.randn(n, co, h, w, generator=g) * 1e-3

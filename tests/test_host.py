@@ -276,6 +276,16 @@ def test_round2_entry_points_reject_bad_arguments_before_touching_the_gpu():
     assert lib.eg3d_torgb_small_bwd_supported(C.byref(tb)) == 0                      # a style gradient without the layer input
     tb.xin = a
     assert lib.eg3d_torgb_small_bwd_supported(C.byref(tb)) == 1
+    # the streaming forms take the backbone's 128^2 / 256^2 geometries and nothing the small kernels are for
+    assert lib.eg3d_torgb_mid_supported(C.byref(ts)) == 0 and lib.eg3d_torgb_mid_bwd_supported(C.byref(tb)) == 0
+    for (hw, c, want) in ((128, 256, 1), (256, 128, 1), (64, 512, 0), (128, 512, 0), (120, 96, 1), (100, 128, 0)):
+        tm = L.TorgbSmallParams(x=a, w=a, s=a, out=a, N=1, H=hw, W=hw, C=c, Cp=96, ldx=c, ldo=96, w_row=c, clamp=-1.0)
+        assert lib.eg3d_torgb_mid_supported(C.byref(tm)) == want, (hw, c)
+        tmb = L.TorgbSmallBwdParams(dy=a, wa=a, s=a, dx=a, xin=a, ds=a, N=1, H=hw, W=hw, C=c, Cp=96, ldg=96, ldx=c, wa_row=96)
+        assert lib.eg3d_torgb_mid_bwd_supported(C.byref(tmb)) == (1 if hw * hw >= 8192 and (hw * hw) % 32 == 0 else 0), (hw, c)
+    tm.pre_z = a                                                                     # a pending finishing epilogue: the small kernel's business
+    tm.pre_gain = 1.0
+    assert lib.eg3d_torgb_mid_supported(C.byref(tm)) == 0
     ad = L.AdamList(n=1, bump_step=1, beta1=0.9, beta2=0.999, eps=1e-8, lr=a, step=a)
     ad.items[0] = L.AdamItem(a, None, None, a, a, 16, 0)
     assert lib.eg3d_adam_step(C.byref(ad), a, None) < 0                              # no gradient at all
