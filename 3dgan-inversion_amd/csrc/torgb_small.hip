@@ -35,8 +35,11 @@ __device__ __forceinline__ float4 up2_at(const float* __restrict__ low, int ld, 
 
 constexpr int TS_PIX = 32, TS_OUT = 32, TS_BATCH = 8;        // TS_BATCH: 8-channel groups loaded ahead per operand (8 x 16 bytes per lane)
 
-__global__ void __launch_bounds__(256) torgb_small_kernel(const eg3d_torgb_small_params p) {
-    __shared__ float red[4][TS_PIX][TS_OUT + 1];
+// NW waves per block share the contraction: 4, or 8 when a wave's share would otherwise be more than one batch of TS_BATCH channel groups (C = 512: two
+// batches = two memory round trips in sequence, 2 - 2.5 us each, in a launch whose arithmetic is 1 us)
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) torgb_small_kernel(const eg3d_torgb_small_params p) {
+    __shared__ float red[NW][TS_PIX][TS_OUT + 1];
     const int HW = p.H * p.W;
     const int tiles = (HW + TS_PIX - 1) / TS_PIX;
     const int n = blockIdx.x / tiles, p0 = (blockIdx.x - n * tiles) * TS_PIX, o0 = blockIdx.y * TS_OUT;
@@ -46,7 +49,7 @@ __global__ void __launch_bounds__(256) torgb_small_kernel(const eg3d_torgb_small
     const bool pok = pix < HW;
     // this wave's share of the contraction: channels [k0, k1), a multiple of 8 wide
     const int groups = p.C / 8;
-    const int g0 = (int)((int64_t)groups * wave / 4), g1 = (int)((int64_t)groups * (wave + 1) / 4);
+    const int g0 = (int)((int64_t)groups * wave / NW), g1 = (int)((int64_t)groups * (wave + 1) / NW);
     const float* xr = p.x + ((int64_t)n * HW + (pok ? pix : 0)) * p.ldx + 4 * h;
     const float* wr = p.w + (int64_t)(o0 + row) * p.w_row + 4 * h;           // B operand: lane = (output column, k half)
     const float* sr = p.s + (int64_t)n * p.C + 4 * h;
@@ -61,22 +64,41 @@ __global__ void __launch_bounds__(256) torgb_small_kernel(const eg3d_torgb_small
     const float* dr = has_d ? p.pre_d + (int64_t)n * p.C + 4 * h : sr;
     const float* br = has_b ? p.pre_bias + 4 * h : sr;
     float* xw = (pre && blockIdx.y == 0 && pok) ? const_cast<float*>(p.x) + ((int64_t)n * HW + pix) * p.ldx + 4 * h : nullptr;
-    float pre_nz = 0.f, pre_amax = 0.f;
-    if (pre && pok && p.pre_noise != nullptr) pre_nz = p.pre_noise[(int64_t)n * p.pre_noise_nstride + pix] * *p.pre_strength;
-    // the epilogue's side inputs do not depend on the products: issued here, they travel with the operand loads instead of after the matrix phase
-    const int er = threadIdx.x >> 3, eq = threadIdx.x & 7;
+    const int er = (threadIdx.x >> 3) & 31, eq = threadIdx.x & 7;                   // (the epilogue is the first 256 threads' business)
     const int ep = p0 + er, eo = o0 + eq * 4;
-    const bool eok = ep < HW;
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), add4 = bias4;
-    if (p.bias != nullptr) bias4 = *reinterpret_cast<const float4*>(p.bias + eo);
-    if (eok && p.addend != nullptr) {
-        if (p.addend_up2) {
-            const int yy = ep / p.W, xx = ep - yy * p.W;
-            add4 = up2_at(p.addend + (int64_t)n * (HW >> 2) * p.ldo + eo, p.ldo, p.H >> 1, p.W >> 1, yy, xx, p.addend_taps);
-        } else {
-            add4 = *reinterpret_cast<const float4*>(p.addend + ((int64_t)n * HW + ep) * p.ldo + eo);
+    const bool eok = ep < HW && threadIdx.x < 256;
+    const int epc = eok ? ep : 0;
+    const int e_yy = epc / p.W, e_xx = epc - e_yy * p.W;          // (the division sequence before the first load goes out: its temporaries made the compiler wait for pending loads)
+    // (every side input below is only REQUESTED here -- the arithmetic on it comes after the first operand batch has been requested too: as first written
+    //  -- noise times strength, the four up-sampling taps combined on the spot -- the launch waited out three memory round trips of 2 - 2.5 us each before
+    //  its operand loads went out, half of a 14 us launch)
+    float pre_nz_raw = 0.f, pre_strength = 0.f, pre_amax = 0.f;
+    if (pre && p.pre_noise != nullptr) { pre_nz_raw = p.pre_noise[pok ? (int64_t)n * p.pre_noise_nstride + pix : 0]; pre_strength = *p.pre_strength; }
+    // the epilogue's side inputs do not depend on the products: issued here, they travel with the operand loads instead of after the matrix phase
+    float4 bias4 = *reinterpret_cast<const float4*>((p.bias != nullptr ? p.bias : p.s) + (p.bias != nullptr ? eo : 0));          // (a valid address either way)
+    // addend: the pixel itself, or the four half-resolution neighbours of the up-sampling (clamped addresses; the zero padding is applied to the VALUES later)
+    // One unconditional set of four loads whatever the mode (pointer selects, no branch: behind a branch the register allocator reused a pending load's
+    // destination in the other arm and the compiler waited for everything in flight)
+    const bool add_up2 = p.addend != nullptr && p.addend_up2 != 0, add_full = p.addend != nullptr && !add_up2;
+    bool mA = false, mB = false, mC = false, mD = false;                       // A .. D inside the half-resolution image
+    const float* qA = p.s; const float* qB = p.s; const float* qC = p.s; const float* qD = p.s;          // (a valid address when there is nothing to add)
+    {
+        const int Hl = p.H >> 1, Wl = p.W >> 1;
+        const int oy = e_yy & 1, ox = e_xx & 1;
+        const int r0 = (e_yy >> 1) - 1 + oy, c0 = (e_xx >> 1) - 1 + ox;
+        const bool ra = r0 >= 0, rb = r0 + 1 < Hl, ca = c0 >= 0, cb = c0 + 1 < Wl;
+        const int rr0 = ra ? r0 : 0, rr1 = rb ? r0 + 1 : max(Hl - 1, 0), cc0 = ca ? c0 : 0, cc1 = cb ? c0 + 1 : max(Wl - 1, 0);
+        const float* low = (p.addend != nullptr ? p.addend : p.s) + (add_up2 ? (int64_t)n * (HW >> 2) * p.ldo + eo : 0);
+        if (add_up2) {
+            qA = low + ((int64_t)rr0 * Wl + cc0) * p.ldo; qB = low + ((int64_t)rr0 * Wl + cc1) * p.ldo;
+            qC = low + ((int64_t)rr1 * Wl + cc0) * p.ldo; qD = low + ((int64_t)rr1 * Wl + cc1) * p.ldo;
+            mA = ra && ca; mB = ra && cb; mC = rb && ca; mD = rb && cb;
+        } else if (add_full) {
+            qA = p.addend + ((int64_t)n * HW + epc) * p.ldo + eo;
         }
     }
+    const float4 adA = *reinterpret_cast<const float4*>(qA), adB = *reinterpret_cast<const float4*>(qB), adC = *reinterpret_cast<const float4*>(qC),
+                 adD = *reinterpret_cast<const float4*>(qD);
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -92,6 +114,7 @@ __global__ void __launch_bounds__(256) torgb_small_kernel(const eg3d_torgb_small
             if (pre) { dvv[j] = *reinterpret_cast<const float4*>(dr + kb); bvv[j] = *reinterpret_cast<const float4*>(br + kb); }
         }
         if (pre) {
+            const float pre_nz = pok ? pre_nz_raw * pre_strength : 0.f;
 #pragma unroll
             for (int j = 0; j < TS_BATCH; ++j) {
                 const bool ok = g + j < g1;
@@ -136,11 +159,25 @@ __global__ void __launch_bounds__(256) torgb_small_kernel(const eg3d_torgb_small
     if (!eok) return;
     float v[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = (red[0][er][eq * 4 + q] + red[1][er][eq * 4 + q]) + (red[2][er][eq * 4 + q] + red[3][er][eq * 4 + q]);
+    for (int q = 0; q < 4; ++q) {
+        v[q] = (red[0][er][eq * 4 + q] + red[1][er][eq * 4 + q]) + (red[2][er][eq * 4 + q] + red[3][er][eq * 4 + q]);
+        if (NW == 8) v[q] += (red[NW - 4][er][eq * 4 + q] + red[NW - 3][er][eq * 4 + q]) + (red[NW - 2][er][eq * 4 + q] + red[NW - 1][er][eq * 4 + q]);
+    }
+    if (p.bias == nullptr) bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     v[0] += bias4.x; v[1] += bias4.y; v[2] += bias4.z; v[3] += bias4.w;
     if (p.clamp >= 0.f) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = fminf(fmaxf(v[q], -p.clamp), p.clamp);
+    }
+    float4 add4 = add_full ? adA : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (add_up2) {
+        const int oy = e_yy & 1, ox = e_xx & 1;
+        const float* t = p.addend_taps;
+        const float wy0 = oy ? t[2] : t[3], wy1 = oy ? t[0] : t[1], wx0 = ox ? t[2] : t[3], wx1 = ox ? t[0] : t[1];
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 A = mA ? adA : z, B = mB ? adB : z, Cc = mC ? adC : z, D = mD ? adD : z;
+        add4 = make_float4(wy0 * (wx0 * A.x + wx1 * B.x) + wy1 * (wx0 * Cc.x + wx1 * D.x), wy0 * (wx0 * A.y + wx1 * B.y) + wy1 * (wx0 * Cc.y + wx1 * D.y),
+                           wy0 * (wx0 * A.z + wx1 * B.z) + wy1 * (wx0 * Cc.z + wx1 * D.z), wy0 * (wx0 * A.w + wx1 * B.w) + wy1 * (wx0 * Cc.w + wx1 * D.w));          // up2_at's expression
     }
     *reinterpret_cast<float4*>(p.out + ((int64_t)n * HW + ep) * p.ldo + eo) = make_float4(v[0] + add4.x, v[1] + add4.y, v[2] + add4.z, v[3] + add4.w);
 }
@@ -178,8 +215,7 @@ __global__ void __launch_bounds__(256) torgb_small_bwd_kernel(const eg3d_torgb_s
     // add_scale: the pass-through gradient arrives UNFINISHED -- the split-K sums z of the consumer layer's data gradient -- and its finishing pass
     // (eg3d_dgrad_finish: dx = z * add_scale[n,c]; add_ds[n,c] += sum_p z x) happens here, on values this launch loads anyway.  (The load goes
     // out unconditionally, to the styles when absent: no load under a branch.)
-    float4 as4 = *reinterpret_cast<const float4*>((p.add_scale != nullptr ? p.add_scale : p.s) + (int64_t)n * p.C + eo);
-    if (p.add_scale == nullptr) as4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 as4_raw = *reinterpret_cast<const float4*>((p.add_scale != nullptr ? p.add_scale : p.s) + (int64_t)n * p.C + eo);      // (replaced by ones at its use when absent: a select here makes the launch wait for the load)
     if (ok && p.xin != nullptr) xin4 = *reinterpret_cast<const float4*>(p.xin + off);
     if (ok && p.addend != nullptr) a4 = *reinterpret_cast<const float4*>(p.addend + off);
     if (act_on) {
@@ -222,6 +258,7 @@ __global__ void __launch_bounds__(256) torgb_small_bwd_kernel(const eg3d_torgb_s
         v.w = (red[0][er][eq * 4 + 3] + red[1][er][eq * 4 + 3]) + (red[2][er][eq * 4 + 3] + red[3][er][eq * 4 + 3]);
         if (p.ds != nullptr) t_ds = make_float4(v.x * xin4.x, v.y * xin4.y, v.z * xin4.z, v.w * xin4.w);
         if (p.add_ds != nullptr) t_da = make_float4(a4.x * xin4.x, a4.y * xin4.y, a4.z * xin4.z, a4.w * xin4.w);
+        const float4 as4 = p.add_scale != nullptr ? as4_raw : make_float4(1.f, 1.f, 1.f, 1.f);
         a4 = make_float4(a4.x * as4.x, a4.y * as4.y, a4.z * as4.z, a4.w * as4.w);
         v = make_float4(v.x * s4.x + a4.x, v.y * s4.y + a4.y, v.z * s4.z + a4.z, v.w * s4.w + a4.w);
         if (act_on) {
@@ -518,16 +555,14 @@ __global__ void __launch_bounds__(256) torgb_mid_bwd_kernel(const eg3d_torgb_sma
 #pragma unroll
         for (int g = 0; g < NG; ++g) wb[g] = *reinterpret_cast<const float4*>(wr + 8 * g);
     }
-    float4 abb4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (act_on && ab.bias != nullptr) abb4 = *reinterpret_cast<const float4*>(ab.bias + eo);
+    const bool has_abb = act_on && ab.bias != nullptr;
+    const float4 abb4_raw = *reinterpret_cast<const float4*>(has_abb ? ab.bias + eo : p.s);
     float4 t_ds = make_float4(0.f, 0.f, 0.f, 0.f), t_db = t_ds, t_dq = t_ds, t_da = t_ds;
     float omax = 0.f, dstr = 0.f;
     float (*my)[TS_OUT + 1] = red[wave];
     const float4 s4 = *reinterpret_cast<const float4*>(p.s + (int64_t)n * p.C + eo);
-    float4 as4 = *reinterpret_cast<const float4*>((p.add_scale != nullptr ? p.add_scale : p.s) + (int64_t)n * p.C + eo);
-    if (p.add_scale == nullptr) as4 = make_float4(1.f, 1.f, 1.f, 1.f);
-    float4 abd4 = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (act_on && ab.d != nullptr) abd4 = *reinterpret_cast<const float4*>(ab.d + (int64_t)n * p.C + eo);
+    const float4 as4_raw = *reinterpret_cast<const float4*>((p.add_scale != nullptr ? p.add_scale : p.s) + (int64_t)n * p.C + eo);
+    const float4 abd4_raw = *reinterpret_cast<const float4*>(((act_on && ab.d != nullptr) ? ab.d : p.s) + (int64_t)n * p.C + eo);
     // the operand tile of the wave's first pixel tile is requested with the weight slice (one memory round trip before the first matrix instruction);
     // inside the loop the NEXT tile's operand loads go out as soon as the matrix instructions have consumed this one's registers, i.e. under the epilogue
     const int tstep = gridDim.x * 4;
@@ -541,6 +576,9 @@ __global__ void __launch_bounds__(256) torgb_mid_bwd_kernel(const eg3d_torgb_sma
     tm_fence();
     eg3d_act_bwd_consts abc = {};
     if (act_on) abc = eg3d_act_bwd_setup(ab);
+    const float4 ones4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 abb4 = has_abb ? abb4_raw : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 as4 = p.add_scale != nullptr ? as4_raw : ones4, abd4 = (act_on && ab.d != nullptr) ? abd4_raw : ones4;
     for (int tile = blockIdx.x * 4 + wave; tile < tpi; tile += tstep) {
         const int p0 = tile * TS_PIX;
         // the epilogue's side inputs are requested before the matrix instructions
@@ -686,7 +724,9 @@ extern "C" int eg3d_torgb_small_fwd(const eg3d_torgb_small_params* p, void* stre
     if (!eg3d_torgb_small_supported(p)) return EG3D_ERR_UNSUPPORTED;
     if (eg3d_torgb_mid_supported(p)) return launch_torgb_mid(p, (hipStream_t)stream);
     const dim3 grid(p->N * eg3d_cdiv((int64_t)p->H * p->W, TS_PIX), p->Cp / TS_OUT);
-    hipLaunchKernelGGL(torgb_small_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p);
+    // (64^2 x 512 = 384 blocks: measured slower with eight waves, 14.9 -> 16.4 us)
+    if (p->C / 8 > 4 * TS_BATCH && (int64_t)grid.x * grid.y <= 128) hipLaunchKernelGGL(torgb_small_kernel<8>, grid, dim3(512), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL(torgb_small_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, *p);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }
