@@ -1170,49 +1170,88 @@ __global__ void __launch_bounds__(BIN16_THREADS) scatter_bin16_kernel(const floa
         const int nslab = rpr / SL, slab = blockIdx.x % nslab, pb = blockIdx.x / nslab, ppr = ray_w / 16;
         brick_row0 = ((pb / ppr) * 16 * ray_w + (pb % ppr) * 16) * rpr + slab * SL;
     }
+    // Memory operations in batches of BIN16_BATCH items: as one loop over the items -- load the position, use it, next item -- a thread made 18 memory
+    // round trips in sequence in each of its two loops, and pass 1's bin owners another 18 RETURNING atomics one after the other (every
+    // load / atomic of the kernel was followed by a full wait in the ISA).  Here the positions of a batch are requested before the first is used, and
+    // all of a thread's reservations are in flight together.
+    typedef float b16_f4 __attribute__((ext_vector_type(4)));
+    constexpr int BIN16_BATCH = 6;
+    static_assert(BIN16_ITEMS % BIN16_BATCH == 0, "batches");
 #pragma unroll
-    for (int k = 0; k < BIN16_ITEMS; ++k) {
-        bin[k] = -1;
-        int64_t row; int pl;
-        if (SL > 0) {
-            const int u = threadIdx.x + k * BIN16_THREADS;
-            if (u >= 256 * SL * 3) continue;
-            pl = u % 3;
-            const int v = u / 3, sidx = v % SL, r = v / SL;
-            row = brick_row0 + ((r >> 4) * ray_w + (r & 15)) * rpr + sidx;
-        } else {
-            const int64_t i = ((int64_t)blockIdx.x * BIN16_ITEMS + k) * BIN16_THREADS + threadIdx.x;
-            if (i >= S * 3) continue;
-            row = i / 3; pl = (int)(i - row * 3);
+    for (int kb = 0; kb < BIN16_ITEMS; kb += BIN16_BATCH) {
+        b16_f4 psv[BIN16_BATCH];
+        int plv[BIN16_BATCH];
+#pragma unroll
+        for (int j = 0; j < BIN16_BATCH; ++j) {
+            const int k = kb + j;
+            bin[k] = -1;
+            int64_t row = -1; int pl = 0;
+            if (SL > 0) {
+                const int u = threadIdx.x + k * BIN16_THREADS;
+                if (u < 256 * SL * 3) {
+                    pl = u % 3;
+                    const int v = u / 3, sidx = v % SL, r = v / SL;
+                    row = brick_row0 + ((r >> 4) * ray_w + (r & 15)) * rpr + sidx;
+                }
+            } else {
+                const int64_t i = ((int64_t)blockIdx.x * BIN16_ITEMS + k) * BIN16_THREADS + threadIdx.x;
+                if (i < S * 3) { row = i / 3; pl = (int)(i - row * 3); }
+            }
+            rowi[k] = (int)row;
+            plv[j] = pl;
+            psv[j] = reinterpret_cast<const b16_f4*>(pos)[row >= 0 ? row : 0];          // (a valid address either way: no load under a branch)
         }
-        const float4 ps = pos[row];
-        if (isnan(ps.x)) continue;
-        int x0, y0; float wx1, wy1;
-        if (!plane_cell(ps, pl, cs, Hp, Wp, x0, y0, wx1, wy1)) continue;
-        const int t = tile_of(x0, y0, ntx, nty);
-        bin[k] = (pl * ntile + t) * TROWS + (y0 - (t / ntx) * TS + 1);
-        rowi[k] = (int)row;
-        lrank[k] = atomicAdd(&hist[bin[k]], 1);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < BIN16_BATCH; ++j) {
+            const int k = kb + j;
+            const float4 ps = make_float4(psv[j].x, psv[j].y, psv[j].z, psv[j].w);
+            if (rowi[k] < 0 || isnan(ps.x)) continue;
+            int x0, y0; float wx1, wy1;
+            if (!plane_cell(ps, plv[j], cs, Hp, Wp, x0, y0, wx1, wy1)) continue;
+            const int t = tile_of(x0, y0, ntx, nty);
+            bin[k] = (plv[j] * ntile + t) * TROWS + (y0 - (t / ntx) * TS + 1);
+            lrank[k] = atomicAdd(&hist[bin[k]], 1);
+        }
+    }
+    __syncthreads();
+    if (PASS == 0) {
+#pragma unroll
+        for (int k = 0; k < BIN16_ITEMS; ++k)
+            if (bin[k] >= 0 && lrank[k] == 0) atomicAdd(counts + bin[k], hist[bin[k]]);
+        return;
+    }
+    {
+        int got[BIN16_ITEMS], off[BIN16_ITEMS];
+#pragma unroll
+        for (int k = 0; k < BIN16_ITEMS; ++k) {
+            got[k] = 0; off[k] = 0;
+            if (bin[k] >= 0 && lrank[k] == 0) { got[k] = atomicAdd(fill + bin[k], hist[bin[k]]); off[k] = offsets[bin[k]]; }
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < BIN16_ITEMS; ++k)
+            if (bin[k] >= 0 && lrank[k] == 0) hist[bin[k]] = off[k] + got[k];
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < BIN16_ITEMS; ++k)
-        if (bin[k] >= 0 && lrank[k] == 0) {
-            const int c = hist[bin[k]];
-            if (PASS == 0) atomicAdd(counts + bin[k], c);
-            else hist[bin[k]] = offsets[bin[k]] + atomicAdd(fill + bin[k], c);
-        }
-    if (PASS == 0) return;
-    __syncthreads();
+    for (int kb = 0; kb < BIN16_ITEMS; kb += BIN16_BATCH) {
+        b16_f4 psv[BIN16_BATCH];
 #pragma unroll
-    for (int k = 0; k < BIN16_ITEMS; ++k)
-        if (bin[k] >= 0) {
-            const int t = (bin[k] / TROWS) % ntile, pl = bin[k] / (TROWS * ntile);
-            int x0, y0; float wx1, wy1;
-            plane_cell(pos[rowi[k]], pl, cs, Hp, Wp, x0, y0, wx1, wy1);
-            const int lx = x0 - (t % ntx) * TS;                                      // in [-1, TS-1]
-            recs[hist[bin[k]] + lrank[k]] = make_float4(__int_as_float(rowi[k] | ((lx + 1) << 27)), wx1, wy1, 0.f);
+        for (int j = 0; j < BIN16_BATCH; ++j) psv[j] = reinterpret_cast<const b16_f4*>(pos)[bin[kb + j] >= 0 ? rowi[kb + j] : 0];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < BIN16_BATCH; ++j) {
+            const int k = kb + j;
+            if (bin[k] >= 0) {
+                const int t = (bin[k] / TROWS) % ntile, pl = bin[k] / (TROWS * ntile);
+                int x0, y0; float wx1, wy1;
+                plane_cell(make_float4(psv[j].x, psv[j].y, psv[j].z, psv[j].w), pl, cs, Hp, Wp, x0, y0, wx1, wy1);
+                const int lx = x0 - (t % ntx) * TS;                                      // in [-1, TS-1]
+                recs[hist[bin[k]] + lrank[k]] = make_float4(__int_as_float(rowi[k] | ((lx + 1) << 27)), wx1, wy1, 0.f);
+            }
         }
+    }
 }
 
 // single block: exclusive scan of n <= 16384 counts -> offsets[n + 1]; the counts pass through LDS so that global accesses stay coalesced
