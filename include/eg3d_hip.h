@@ -667,7 +667,7 @@ typedef struct eg3d_torgb_small_bwd_params {
 } eg3d_torgb_small_bwd_params;
 int eg3d_torgb_small_bwd_supported(const eg3d_torgb_small_bwd_params* p);
 int eg3d_torgb_small_bwd(const eg3d_torgb_small_bwd_params* p, void* stream);
-/* The streaming form of the data gradient (Cp == 96, H*W % 32 == 0, >= 8192 pixels): waves walk several pixel tiles with the column sums in
+/* The streaming form of the data gradient (Cp == 96, H*W % 32 == 0, >= 4096 pixels): waves walk several pixel tiles with the column sums in
  * registers, one set of atomics per workgroup.  Same results up to summation order; reports whether eg3d_torgb_small_bwd takes that form. */
 int eg3d_torgb_mid_bwd_supported(const eg3d_torgb_small_bwd_params* p);
 
