@@ -145,12 +145,12 @@ __device__ __forceinline__ void eg3d_commit_amax(float m, float* out) {
 // Block-level form (every thread of the block must call it): wave maxima meet in LDS, ONE conditional atomic per block.  For short
 // memory-bound kernels all waves finish within the same few microseconds, every one reads the still-stale value and the per-wave form
 // degenerates into thousands of serialised atomics on one address (a 20 us pass took 55 us).
-__device__ __forceinline__ void eg3d_commit_amax_block(float m, float* out) {
+__device__ __forceinline__ void eg3d_commit_amax_block(float m, float* out, const int nwaves = 0 /* waves taking part (0 = blockDim.x / 64) */) {
     if (out == nullptr) return;                 // uniform across the block
     __shared__ float s_wave_max[16];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    const int nw = (blockDim.x + 63) >> 6;
+    const int nw = nwaves > 0 ? nwaves : (int)((blockDim.x + 63) >> 6);
     if ((threadIdx.x & 63) == 0) s_wave_max[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -25,16 +25,23 @@ namespace {
 // patch (256 cells), 2 = a 4 x 32 patch (128 cells x 128 channels per workgroup, 12 MFMAs per wave and step): twice the workgroups for the
 // layers whose 8-row grids leave CUs idle (128^2 x 256: 128 -> 256), with the fused epilogues intact (split-K needs a zero fill + a finishing pass);
 // 1 = a 2 x 32 patch (64 cells: 64^2 x 512 -> 256 workgroups)
-template <int NTAPS, bool FULL = true, bool ATOMIC = false, int RPW = 4, bool RGB = false>          // RGB: + the 1x1 head of the forward epilogue (eg3d_conv_v2_params::rgb_out)
-__global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_params p, const int cls_base) {
+// KH = 2 (4 x 32 patches whose grid gives every CU ONE workgroup: 128^2 x 256, 256^2 x 128): the workgroup has eight waves -- two independent halves,
+// each the four-wave kernel on one half of the contraction with its own LDS image (A double buffer + weight ring) -- so that every SIMD holds two waves and
+// one half's matrix instructions issue under the other's barrier / LDS-read latencies (with one wave per SIMD nothing does: MfmaUtil 33 % against 57 % for
+// the 8-row launches that have two workgroups per CU).  The halves meet once, in LDS, after their last step; the upper half then ends (a barrier does not
+// wait for waves that have ended) and the lower one runs the fused epilogue unchanged.
+template <int NTAPS, bool FULL = true, bool ATOMIC = false, int RPW = 4, bool RGB = false, int KH = 1>          // RGB: + the 1x1 head of the forward epilogue (eg3d_conv_v2_params::rgb_out)
+__global__ void __launch_bounds__(256 * KH, KH == 1 ? 2 : 1) conv_v2_kernel(const eg3d_conv_v2_params p, const int cls_base) {
     constexpr int PHK = 2 * RPW;                          // patch rows of this instantiation
     constexpr int NPARTS = ((PHK + 2) * (PW + 2) + 63) / 64;      // 64-slot wave-instructions per A plane: halo <= (PHK + 2) x 34 slots (6 | 4 | 3)
     constexpr int APT = (NPARTS + NTAPS - 1) / NTAPS;     // A parts a wave issues per step
     constexpr int NA_TAPS = NPARTS / APT;                 // ... during the first NA_TAPS taps of a chunk (APT divides NPARTS)
     static_assert(NPARTS % APT == 0, "A parts per step");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = KH == 2 ? wave_all >> 2 : 0, wave = wave_all & 3;
+    char* const smem = smem_all + khalf * LDS_MAIN;                    // this half's LDS image
     const int wm = wave >> 1, wn = wave & 1;
     const eg3d_conv_class& cl = p.cls[cls_base + blockIdx.z];
     const int Ha = cl.Ha, Wa = cl.Wa;
@@ -49,8 +56,9 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
     const int y0 = ty * PHK, x0 = tx * PW, n0 = n_t * BN;
     const int nchunk = p.Ck / 16;
     // split-K (EG3D_EPI_ATOMIC): blockIdx.y owns the 16-channel chunks [c0, c1) of the contraction and adds its partial tile to `out`
-    const int ks = p.ksplit > 1 ? p.ksplit : 1;
-    const int c0 = (int)((int64_t)blockIdx.y * nchunk / ks), c1 = (int)((int64_t)(blockIdx.y + 1) * nchunk / ks);
+    const int ks = (KH == 1 && p.ksplit > 1) ? p.ksplit : 1;
+    const int c0 = KH == 2 ? khalf * (nchunk / 2) : (int)((int64_t)blockIdx.y * nchunk / ks);
+    const int c1 = KH == 2 ? (khalf + 1) * (nchunk / 2) : (int)((int64_t)(blockIdx.y + 1) * nchunk / ks);          // (KH = 2: nchunk even, host check -- both halves make the same number of steps, i.e. meet at the same barriers)
     const int planeA = p.Hi * p.Wi * 16;                   // bytes of one (piece, k-octet) plane of the A image
     // tap extent of this class -> halo geometry
     int dymin = cl.dy[0], dymax = cl.dy[0], dxmin = cl.dx[0], dxmax = cl.dx[0];
@@ -175,8 +183,28 @@ __global__ void __launch_bounds__(256, 2) conv_v2_kernel(const eg3d_conv_v2_para
     run_chunk(c1 - 1, std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if constexpr (KH == 2) {
+        // the upper half's partial tile goes to the lower one through the upper half's (now idle) LDS image: [i][j][r][thread], lane-contiguous
+        float* xch = reinterpret_cast<float*>(smem_all + LDS_MAIN) + (wave * 64 + lane);
+        if (khalf == 1) {
+#pragma unroll
+            for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xch[((i * 2 + j) * 16 + r) * 256] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (khalf == 1) return;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[((i * 2 + j) * 16 + r) * 256];
+    }
 
-    v2_epilogue<ATOMIC, RPW, false, RGB>(p, acc, Ha, Wa, cl.out_py, cl.out_px, n, y0, x0, n0, smem, 1.f / (*p.a_scale * *p.w_scale));
+    v2_epilogue<ATOMIC, RPW, false, RGB>(p, acc, Ha, Wa, cl.out_py, cl.out_px, n, y0, x0, n0, smem, 1.f / (*p.a_scale * *p.w_scale), 5, KH == 2 ? 4 : 0);
 }
 
 // ---- operand preparation (split8 / range_mul: conv_v2_common.h) ------------------------------------------------------------
@@ -370,11 +398,13 @@ __global__ void __launch_bounds__(256) split_w_batched_kernel(const eg3d_split_w
 
 std::atomic<uint64_t> g_attr[15];
 
-template <int NTAPS, bool FULL = true, bool ATOMIC = false, int RPW = 4, bool RGB = false>
+template <int NTAPS, bool FULL = true, bool ATOMIC = false, int RPW = 4, bool RGB = false, int KH = 1>
 int launch_v2(const eg3d_conv_v2_params& p, int cls_base, int ncls, int max_tiles, hipStream_t st, int slot) {
-    auto kern = conv_v2_kernel<NTAPS, FULL, ATOMIC, RPW, RGB>;
-    if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, g_attr[slot])) return e;
-    hipLaunchKernelGGL(kern, dim3(max_tiles, p.ksplit > 1 ? p.ksplit : 1, ncls), dim3(256), LDS_BYTES, st, p, cls_base);
+    auto kern = conv_v2_kernel<NTAPS, FULL, ATOMIC, RPW, RGB, KH>;
+    constexpr int LDS_K = KH == 2 ? 2 * LDS_MAIN : LDS_BYTES;          // (KH = 2: two main-loop images; the epilogue re-uses the lower one, the exchange the upper one: 64 KB <= LDS_MAIN)
+    static_assert(KH == 1 || (LDS_EPI <= LDS_MAIN && RPW * 2 * 16 * 256 * 4 <= LDS_MAIN), "KH = 2 LDS re-use");
+    if (int e = eg3d_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_K, g_attr[slot])) return e;
+    hipLaunchKernelGGL(kern, dim3(max_tiles, (KH == 1 && p.ksplit > 1) ? p.ksplit : 1, ncls), dim3(256 * KH), LDS_K, st, p, cls_base);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
 }
@@ -392,7 +422,10 @@ extern "C" int eg3d_conv2d_v2_supported(const eg3d_conv_v2_params* pp) {
     if (p.epi != EG3D_EPI_STORE && p.epi != EG3D_EPI_FWD && p.epi != EG3D_EPI_BWD && p.epi != EG3D_EPI_BWD_ACT && p.epi != EG3D_EPI_ATOMIC) return 0;
     if (p.epi == EG3D_EPI_ATOMIC)                         // the split-K instantiations exist for the 3x3 classes
         for (int c = 0; c < p.ncls; ++c) if (p.cls[c].ntaps != 9) return 0;
-    if (p.ksplit > 1 && (p.epi != EG3D_EPI_ATOMIC || p.ksplit > p.Ck / 16 || p.ksplit > 65535)) return 0;     // every slice owns >= 1 chunk
+    // ksplit == 2 with a fused (non-atomic) epilogue and 4-row patches: the contraction is split over the two four-wave halves of an eight-wave
+    // workgroup (KH = 2 of conv_v2_kernel) -- no partial tiles leave the workgroup
+    const bool khalves = p.ksplit == 2 && p.epi != EG3D_EPI_ATOMIC && p.patch_rows == 4 && ((p.Ck / 16) % 2) == 0 && p.Ck / 16 >= 4 && p.rgb_out == nullptr;
+    if (p.ksplit > 1 && !khalves && (p.epi != EG3D_EPI_ATOMIC || p.ksplit > p.Ck / 16 || p.ksplit > 65535)) return 0;     // every slice owns >= 1 chunk
     if (p.patch_rows != 0 && p.patch_rows != 8 && p.patch_rows != 4 && p.patch_rows != 2) return 0;
     if (p.patch_rows == 4 || p.patch_rows == 2) {         // the half / quarter-height patches are instantiated for the fused 3x3 launches
         if (p.epi == EG3D_EPI_ATOMIC) return 0;
@@ -444,6 +477,8 @@ extern "C" int eg3d_conv2d_v2(const eg3d_conv_v2_params* pp, void* stream) {
         switch (p.cls[c].ntaps) {
             case 9:
                 if (p.patch_rows == 2) rc = p.products == 1 ? launch_v2<9, false, false, 1>(p, c, e - c, max_tiles, st, 10) : launch_v2<9, true, false, 1>(p, c, e - c, max_tiles, st, 9);
+                else if (p.patch_rows == 4 && p.ksplit == 2 && p.epi != EG3D_EPI_ATOMIC)
+                    rc = p.products == 1 ? launch_v2<9, false, false, 2, false, 2>(p, c, e - c, max_tiles, st, 14) : launch_v2<9, true, false, 2, false, 2>(p, c, e - c, max_tiles, st, 13);
                 else if (p.patch_rows == 4) rc = p.products == 1 ? launch_v2<9, false, false, 2>(p, c, e - c, max_tiles, st, 8) : launch_v2<9, true, false, 2>(p, c, e - c, max_tiles, st, 7);
                 else if (p.epi == EG3D_EPI_ATOMIC) rc = p.products == 1 ? launch_v2<9, false, true>(p, c, e - c, max_tiles, st, 6) : launch_v2<9, true, true>(p, c, e - c, max_tiles, st, 5);
                 else if (p.rgb_out != nullptr) rc = p.products == 1 ? launch_v2<9, false, false, 4, true>(p, c, e - c, max_tiles, st, 11) : launch_v2<9, true, false, 4, true>(p, c, e - c, max_tiles, st, 12);

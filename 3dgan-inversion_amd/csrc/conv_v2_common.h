@@ -76,7 +76,8 @@ __device__ __forceinline__ float range_mul(float amax) {
 template <bool ATOMIC, int RPW = 4, bool GENW = false, bool RGB = false>   // ATOMIC at compile time: the split-K form must not cost the fused epilogues a register (together they spilled 30 VGPRs);
                                       // RPW = patch rows per wave (4: 8 x 32 patch, 2: 4 x 32)
 __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16 (&acc)[RPW][2], const int Ha, const int Wa, const int out_py, const int out_px,
-                                            const int n, const int y0, const int x0, const int n0, char* smem, const float out_mul, const int logw = 5) {
+                                            const int n, const int y0, const int x0, const int n0, char* smem, const float out_mul, const int logw = 5,
+                                            const int nwaves = 0 /* waves that enter (0 = the whole block) */) {
     const int wmask = (1 << logw) - 1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -291,7 +292,7 @@ __device__ __forceinline__ void v2_epilogue(const eg3d_conv_v2_params& p, f32x16
         }
         if (act_on && ab.dstrength != nullptr && tid == 0 && sc_lds[0] != 0.f) eg3d_acc(ab.dstrength, sc_lds[0]);
     }
-    eg3d_commit_amax_block(amax, p.out_amax);    // max|out|: the consumer's operand range (one atomic per block)
+    eg3d_commit_amax_block(amax, p.out_amax, nwaves);    // max|out|: the consumer's operand range (one atomic per block)
     }
 }
 

@@ -661,6 +661,10 @@ V2_CONVT = os.environ.get('EG3D_V2_CONVT', '0') == '1'
 # 4 x 32-cell patches for under-filled 3x3 grids (conv_v2_rows): 128^2 x 256: 107 -> 91 us, 256^2 x 128: 84 -> 67 us per launch.  (Off in the
 # first half of round 3: with the fused epilogues a few hundred of 8 M output elements per launch came out wrong on full-size layers --
 # a miscompile of the scalar epilogue arithmetic by the SLP vectoriser, see the Makefile; tests/test_gpu_ops.py::test_conv_v2_half_patch_full_size.)
+# 4-row launches that give every CU at most one workgroup (128^2 x 256, 256^2 x 128 at N = 1) as eight-wave workgroups whose two halves split the contraction
+# (csrc/conv_v2.hip KH = 2): two waves per SIMD instead of one
+V2_KHALVES = os.environ.get('EG3D_V2_KHALVES', '1') != '0'
+V2_KHALVES_MAX_TILES = int(os.environ.get('EG3D_V2_KHALVES_MAX_TILES', '256'))
 V2_HALF = os.environ.get('EG3D_V2_HALF', '1') != '0'             # half-height (4 x 32) patches for nine-tap launches ...
 # quarter-height (2 x 32) patches where not even the 4-row grid fills the chip (64^2 x 512: 64 -> 256 workgroups): OFF by default.  Stand-alone
 # (weights warm in L2) 74 us against 99 + 23 (4-way split-K launch of the loader-split kernel + its finishing pass); inside the step, where every
@@ -693,6 +697,10 @@ def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_
     if patch_rows is None:          # the caller did not plan: 4-row patches where they fill the chip and 8-row ones do not
         patch_rows = conv_v2_rows(p.Ck, p.Nc, classes, p.N) if epi != L.EPI_ATOMIC else 8
     p.patch_rows = patch_rows if patch_rows in (4, 2) else 8
+    if (V2_KHALVES and p.patch_rows == 4 and epi != L.EPI_ATOMIC and ksplit <= 1 and rgb_head is None and (p.Ck // 16) % 2 == 0 and p.Ck >= 64
+            and sum(p.N * -(-c.Ha // 4) * -(-c.Wa // 32) for c in classes) * (p.Nc // 128) <= V2_KHALVES_MAX_TILES):
+        # one workgroup per CU: eight waves, the contraction split over the two four-wave halves inside the workgroup (KH = 2 of conv_v2_kernel)
+        p.ksplit = 2
     if rgb_head is not None:
         w4, s4, b4, y4, rclamp = rgb_head[:5]
         p.rgb_nout = int(rgb_head[5]) if len(rgb_head) > 5 else 4

@@ -1138,6 +1138,47 @@ def test_conv_v2_half_patch_full_size():
         assert torch.equal(o, outs[0]), 'the 2-, 4- and 8-row patches accumulate in the same order: bit-identical results'
 
 
+@pytest.mark.parametrize('shape', [(1, 256, 128, 128, 256), (2, 64, 36, 40, 128), (1, 96, 20, 64, 128)])
+def test_conv_v2_k_halves_equal_the_four_wave_form(shape, monkeypatch):
+    """KH = 2 of conv_v2_kernel (hipops.V2_KHALVES: 4-row launches with at most one workgroup per CU run as eight-wave workgroups whose halves split
+    the contraction and meet in LDS): against float64 and against the four-wave form -- equal up to the one extra rounding of the cross-half sum --
+    with the fused forward epilogue and with the data-gradient epilogue (style gradient, max|out|), at the full-size 128^2 x 256 layer, a batch of
+    two on a ragged grid, and a chunk count (6) that is even but not a power of two."""
+    from inv3d_amd import hipops as H, _lib as L
+    n, ci, h, w, co = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, ci, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)).to(DEV)
+    s = (1 + 0.5 * torch.randn(n, ci, generator=g)).to(DEV)
+    d = (0.5 + torch.rand(n, co, generator=g)).to(DEV)
+    noise, strength = torch.randn(h, w, generator=g).to(DEV), torch.tensor(0.3, device=DEV)
+    bias = (0.1 * torch.randn(co, generator=g)).to(DEV)
+    aimg = H.split_activation(x, H.absmax(x), in_scale=s)
+    wimg = H.split_weight(H.pack_weight_fwd(wt), co, ci, 9)
+    z = torch.nn.functional.conv2d(x.double() * s.double()[:, :, None, None], wt.double(), padding=1)
+    ref = (torch.nn.functional.leaky_relu(z * d.double()[:, :, None, None] + noise.double() * 0.3 + bias.double()[None, :, None, None], 0.2) * 1.4).float()
+    cls = H.classes_corr(h, w, 3, 3, 1)
+    res = {}
+    for kh in (False, True):
+        monkeypatch.setattr(H, 'V2_KHALVES', kh)
+        out, amax = H.empty_cl(n, co, h, w, DEV), torch.zeros(1, device=DEV)
+        H.conv_v2(aimg, wimg, out, cls, epi=L.EPI_FWD, out_scale=d, bias=bias, noise=noise, noise_nstride=0, noise_strength=strength,
+                  act='lrelu', alpha=0.2, gain=1.4, clamp=-1.0, out_amax=amax, patch_rows=4)
+        # the data-gradient epilogue on the same products: dx = z * styles, ds += sum z * xin
+        dx, ds, amax2 = H.empty_cl(n, co, h, w, DEV), torch.zeros(n, co, device=DEV), torch.zeros(1, device=DEV)
+        xin = torch.randn(n, co, h, w, generator=torch.Generator().manual_seed(6)).to(DEV).contiguous(memory_format=torch.channels_last)
+        H.conv_v2(aimg, wimg, dx, cls, epi=L.EPI_BWD, out_scale=d, xin=xin, ds=ds, out_amax=amax2, patch_rows=4)
+        torch.cuda.synchronize()
+        close(out, ref, 5e-5, f'k halves {kh} fwd')
+        assert abs(float(amax) - float(out.abs().max())) <= 1e-6 * float(amax)
+        close(dx, (z * d.double()[:, :, None, None]).float(), 5e-5, f'k halves {kh} dx')
+        close(ds, (z * xin.double()).sum((2, 3)).float(), 2e-4 * math.sqrt(h * w), f'k halves {kh} ds')
+        assert abs(float(amax2) - float(dx.abs().max())) <= 1e-6 * float(amax2)
+        res[kh] = (out, dx)
+    for a, b in zip(res[False], res[True]):
+        assert float((a - b).abs().max()) <= 4e-6 * float(a.abs().max()), 'the two forms differ by more than the rounding of one extra sum'
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # Wave-split pre-split convolution (csrc/conv_v3.hip): 128 / 64-cell x 64-channel tiles, contraction over the waves of the workgroup
 # ---------------------------------------------------------------------------------------------------------------------------
