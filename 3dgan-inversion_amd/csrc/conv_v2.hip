@@ -37,11 +37,16 @@ __global__ void __launch_bounds__(256 * KH, KH == 1 ? 2 : 1) conv_v2_kernel(cons
     constexpr int APT = (NPARTS + NTAPS - 1) / NTAPS;     // A parts a wave issues per step
     constexpr int NA_TAPS = NPARTS / APT;                 // ... during the first NA_TAPS taps of a chunk (APT divides NPARTS)
     static_assert(NPARTS % APT == 0, "A parts per step");
-    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int khalf = KH == 2 ? wave_all >> 2 : 0, wave = wave_all & 3;
-    char* const smem = smem_all + khalf * LDS_MAIN;                    // this half's LDS image
+    // (KH = 1 must compile to the instructions it had before KH existed: written with `wave = wave_all & 3` for both forms, every instantiation of this
+    //  kernel came out 10 - 150 instructions different and the deterministic build stopped being bit-identical run to run -- sporadic 1e-7 .. 1e-5
+    //  differences, the signature of the counted-vmcnt / LDS-DMA protocol being disturbed -- see the Makefile note on this kernel's other sensitivity)
+    int wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int khalf = 0;
+    if constexpr (KH == 2) { khalf = wave_ >> 2; wave_ &= 3; }
+    const int wave = wave_;
+    char* const smem = KH == 2 ? smem_dyn + khalf * LDS_MAIN : smem_dyn;          // this half's LDS image
     const int wm = wave >> 1, wn = wave & 1;
     const eg3d_conv_class& cl = p.cls[cls_base + blockIdx.z];
     const int Ha = cl.Ha, Wa = cl.Wa;
@@ -56,9 +61,9 @@ __global__ void __launch_bounds__(256 * KH, KH == 1 ? 2 : 1) conv_v2_kernel(cons
     const int y0 = ty * PHK, x0 = tx * PW, n0 = n_t * BN;
     const int nchunk = p.Ck / 16;
     // split-K (EG3D_EPI_ATOMIC): blockIdx.y owns the 16-channel chunks [c0, c1) of the contraction and adds its partial tile to `out`
-    const int ks = (KH == 1 && p.ksplit > 1) ? p.ksplit : 1;
-    const int c0 = KH == 2 ? khalf * (nchunk / 2) : (int)((int64_t)blockIdx.y * nchunk / ks);
-    const int c1 = KH == 2 ? (khalf + 1) * (nchunk / 2) : (int)((int64_t)(blockIdx.y + 1) * nchunk / ks);          // (KH = 2: nchunk even, host check -- both halves make the same number of steps, i.e. meet at the same barriers)
+    const int ks = p.ksplit > 1 ? p.ksplit : 1;
+    int c0 = (int)((int64_t)blockIdx.y * nchunk / ks), c1 = (int)((int64_t)(blockIdx.y + 1) * nchunk / ks);
+    if constexpr (KH == 2) { c0 = khalf * (nchunk / 2); c1 = c0 + nchunk / 2; }          // (nchunk even, host check: both halves make the same number of steps, i.e. meet at the same barriers)
     const int planeA = p.Hi * p.Wi * 16;                   // bytes of one (piece, k-octet) plane of the A image
     // tap extent of this class -> halo geometry
     int dymin = cl.dy[0], dymax = cl.dy[0], dxmin = cl.dx[0], dxmax = cl.dx[0];
@@ -185,7 +190,7 @@ __global__ void __launch_bounds__(256 * KH, KH == 1 ? 2 : 1) conv_v2_kernel(cons
     __syncthreads();
     if constexpr (KH == 2) {
         // the upper half's partial tile goes to the lower one through the upper half's (now idle) LDS image: [i][j][r][thread], lane-contiguous
-        float* xch = reinterpret_cast<float*>(smem_all + LDS_MAIN) + (wave * 64 + lane);
+        float* xch = reinterpret_cast<float*>(smem_dyn + LDS_MAIN) + (wave * 64 + lane);
         if (khalf == 1) {
 #pragma unroll
             for (int i = 0; i < RPW; ++i)
@@ -204,7 +209,8 @@ __global__ void __launch_bounds__(256 * KH, KH == 1 ? 2 : 1) conv_v2_kernel(cons
                 for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[((i * 2 + j) * 16 + r) * 256];
     }
 
-    v2_epilogue<ATOMIC, RPW, false, RGB>(p, acc, Ha, Wa, cl.out_py, cl.out_px, n, y0, x0, n0, smem, 1.f / (*p.a_scale * *p.w_scale), 5, KH == 2 ? 4 : 0);
+    if constexpr (KH == 2) v2_epilogue<ATOMIC, RPW, false, RGB>(p, acc, Ha, Wa, cl.out_py, cl.out_px, n, y0, x0, n0, smem, 1.f / (*p.a_scale * *p.w_scale), 5, 4);
+    else v2_epilogue<ATOMIC, RPW, false, RGB>(p, acc, Ha, Wa, cl.out_py, cl.out_px, n, y0, x0, n0, smem, 1.f / (*p.a_scale * *p.w_scale));
 }
 
 // ---- operand preparation (split8 / range_mul: conv_v2_common.h) ------------------------------------------------------------

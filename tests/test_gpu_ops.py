@@ -1177,6 +1177,20 @@ def test_conv_v2_k_halves_equal_the_four_wave_form(shape, monkeypatch):
         res[kh] = (out, dx)
     for a, b in zip(res[False], res[True]):
         assert float((a - b).abs().max()) <= 4e-6 * float(a.abs().max()), 'the two forms differ by more than the rounding of one extra sum'
+    # run-to-run: the kernel's counted waits / LDS-DMA protocol leave no room for a hazard to hide -- a first version of the KH template parameter changed
+    # the code of EVERY instantiation slightly and the deterministic build stopped being bit-identical (sporadic 1e-7 .. 1e-5 differences).  Both forms,
+    # sixty launches each on the same operands: every result bit-identical to the first.
+    for kh in (False, True):
+        monkeypatch.setattr(H, 'V2_KHALVES', kh)
+        first = None
+        for rep in range(60):
+            out = H.empty_cl(n, co, h, w, DEV)
+            H.conv_v2(aimg, wimg, out, cls, epi=L.EPI_FWD, out_scale=d, bias=bias, noise=noise, noise_nstride=0, noise_strength=strength,
+                      act='lrelu', alpha=0.2, gain=1.4, clamp=-1.0, out_amax=torch.zeros(1, device=DEV), patch_rows=4)
+            if first is None:
+                first = out
+            else:
+                assert torch.equal(out, first), f'k halves {kh}: launch {rep} differs from the first'
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
