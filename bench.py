@@ -601,12 +601,13 @@ def main():
             nprod = PRODUCTS[dom_prec]
             peak = FP32_MFMA_PEAK_TFLOPS if dom_prec == 'f32' else BF16_MFMA_PEAK_TFLOPS / nprod
             if is_v2:
-                tkey = 'conv_v2_kernel<9,true,false,%d,false>' % v2_rpw          # (the name rocprofv3 prints: NTAPS, FULL, ATOMIC, RPW, RGB)
+                tkey = 'conv_v2_kernel<9,true,false,%d,false,1>' % v2_rpw        # (the name rocprofv3 prints: NTAPS, FULL, ATOMIC, RPW, RGB, KH)
                 kern = tkey + ' (pre-split fp16 pieces, LDS-DMA staged halo; fp32 in/out, 3 x v_mfma_f32_32x32x16_f16 per fp32 product)'
             else:
                 kern = 'conv_igemm_kernel<%s,%d,*> (fp32 in/out, %d x MFMA per fp32 product)' % (H.TILE_NAMES.get(dom_id[0], '?'), H.PRECISIONS[dom_prec], nprod)
                 tkey = 'conv_igemm_kernel<%s>' % H.TILE_NAMES.get(dom_id[0], '?')
-            tr = traffic.get(tkey) or traffic.get(tkey.replace(',false>', '>')) or traffic.get(tkey.replace(',true>', '>'), {})
+            tr = (traffic.get(tkey) or traffic.get(tkey.replace(',1>', '>'))          # (tables written before the KH template argument existed)
+                  or traffic.get(tkey.replace(',false,1>', '>')) or traffic.get(tkey.replace(',false>', '>')) or traffic.get(tkey.replace(',true>', '>'), {}))
             per_launch_ref = tr.get('gflop_per_launch')
             tbytes = tr.get('bytes_per_launch')
             if tbytes is not None and per_launch_ref:           # the PMC pass ran the same kernel: scale by the work of this run's launches
@@ -621,7 +622,7 @@ def main():
                 # launches together, as rounds 1-4 reported them:
                 both_fl, both_ms = dom['flops'] + summ[rgbk]['flops'], dom['ms'] + summ[rgbk]['ms']
                 launch_set = dict(launch_set='SR block 0 conv1 forward + the data gradients of both 77 GFLOP layers; block 1 conv1 forward runs as '
-                                             'conv_v2_kernel<9,true,false,4,true> (same main loop + the 1x1 toRGB head in the epilogue: see `families`)',
+                                             'conv_v2_kernel<9,true,false,4,true,1> (same main loop + the 1x1 toRGB head in the epilogue: see `families`)',
                                   four_launch_tflops=round(both_fl / (both_ms * 1e-3) / 1e12, 2),
                                   four_launch_frac=round(both_fl / (both_ms * 1e-3) / 1e12 / (FP32_MFMA_PEAK_TFLOPS if dom_prec == 'f32' else BF16_MFMA_PEAK_TFLOPS), 4))
             # Every fraction below follows from a guide peak (MI355X_MICROARCH.md: dense 16-bit MFMA 2500 TFLOP/s, fp32 MFMA 157.3) and a
