@@ -229,7 +229,11 @@ typedef struct eg3d_conv_v2_params {
     int32_t products;          /* 0 / 3: three products (fp32-equivalent);  1: high pieces only (EG3D_PREC_F16X1)            */
     int32_t ksplit;            /* 0 / 1: none.  > 1 (EG3D_EPI_ATOMIC only, `out` pre-zeroed): the contraction's 16-channel chunks are split over
                                 * ksplit workgroups per tile which add their partial tiles with fp32 atomics -- the layers whose grids
-                                * cannot fill the chip (128^2 x 256: 128 tiles; 64^2 x 512: 64) */
+                                * cannot fill the chip (128^2 x 256: 128 tiles; 64^2 x 512: 64).
+                                * 2 with a fused (non-atomic) epilogue and patch_rows == 4 (Ck / 16 even and >= 4, no rgb_out): the split stays INSIDE
+                                * the workgroup -- eight waves, each four-wave half takes half of the chunks and the halves meet in LDS before the
+                                * epilogue: for 4-row grids that give every CU at most one workgroup (two waves per SIMD instead of one).  Same
+                                * result as ksplit 0 up to the rounding of one extra sum per element; no zero fill, nothing leaves the workgroup */
     int32_t patch_rows;        /* 0 / 8: workgroup tile = 8 x 32 cells x 128 channels.  4: 4 x 32 cells -- twice the workgroups for 3x3 layers whose
                                 * 8-row grid leaves CUs idle, fused epilogues intact (nine-tap classes, not with EG3D_EPI_ATOMIC) */
     /* Optional 1x1 head on the finished tile (eg3d_conv2d_v2 with EG3D_EPI_FWD, Nc == 128 = one channel tile per cell, one nine-tap class,
