@@ -16,6 +16,8 @@ static inline int eg3d_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b
 
 #ifdef __cplusplus
 #include <atomic>
+#include <type_traits>
+#include <utility>
 
 // Zero-fill of a small accumulator as a KERNEL node.  hipMemsetAsync becomes a memset node when the step is captured into a HIP graph, and
 // the ROCm 7.0 runtime's packet-captured replay of a single-branch graph stops honouring such a node after the first device-wide
@@ -220,3 +222,37 @@ __device__ __forceinline__ int eg3d_xcd_remap(int bid, int nblocks) {
     int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
 }
+
+// ---- the step boundary of every LDS-DMA pipeline of this family (conv_v2 / conv_v2_s2adj / conv_v2_up / conv_wgrad_v2) -------------------------------------
+// A step reads LDS tiles that LDS-DMA operations of ALL waves of the workgroup brought in, and issues LDS-DMA operations into slots that were READ during the
+// previous step.  One boundary per step makes both directions safe:
+//     s_waitcnt vmcnt(N)     this wave's LDS-DMA operations, except the youngest N, have written LDS            (read-after-write: the tiles of this step)
+//     s_waitcnt lgkmcnt(0)   this wave's LDS reads of the previous step have RETURNED                             (write-after-read: the slots re-used from here on)
+//     s_barrier              ... and so have every other wave's
+// in ONE asm statement: nothing can be scheduled between the waits and the barrier, and the "memory" clobber keeps every LDS access and every LDS-DMA issue on
+// the side of the boundary the source puts it on.
+//
+// ROOT CAUSE of the two "schedule-dependent" faults of rounds 2 and 5 (tools/rootcause/): until round 6 the boundary was
+//     asm volatile("s_waitcnt vmcnt(N)" ::: "memory");  __builtin_amdgcn_s_barrier();
+// The builtin is IntrNoMem: it orders nothing but itself.  The scheduler sinks the last matrix instructions of a step -- and the `s_waitcnt lgkmcnt` in front of
+// them -- BELOW the barrier, so 2 .. 7 ds_read_b128 of the previous step (in the 4- and 2-row instantiations the low pieces and the second high piece of the weight
+// ring) were still IN FLIGHT when a wave arrived at the barrier.  Another wave then passes the barrier and issues the LDS-DMA of step + 2 into the ring slot
+// those reads address; weight tiles are L2 / TCP hits, the DMA can land before a read that is queued behind the other workgroup's LDS traffic: the read
+// returns the tile of the wrong tap.  Low pieces are read last, hence errors of relative size 2^-11 / steps = 1e-7 .. 1e-5, sporadic, and dependent on
+// exactly how many reads the scheduler happened to leave behind the barrier -- which any neutral change of the source re-rolls.
+// tools/rootcause/isa_protocol.py checks the compiled code of every kernel that uses this boundary (no LDS read in flight at a barrier, LDS-DMA issues per
+// step and vmcnt immediates equal to the constexpr schedule below); tests/test_isa_protocol.py runs it on every build.
+template <int N>
+__device__ __forceinline__ void step_sync() {
+    static_assert(N >= 0 && N <= 63, "vmcnt immediate (6 bits on gfx9)");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+

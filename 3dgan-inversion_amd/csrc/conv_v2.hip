@@ -21,6 +21,32 @@
 #include "conv_v2_common.h"
 
 namespace {
+// ---- issue schedule of conv_v2_kernel: what ONE wave issues at a step = (tap, is this the last chunk), in issue order ----------------------------------
+// prologue: all NPARTS A parts of the first chunk, B(step 0), B(step 1);   step (tap, last): n_a A parts of the NEXT chunk, then the two B operations of step + 2.
+// The kernel's issue loops AND its vmcnt immediates are both taken from these functions, and tools/rootcause/isa_protocol.py compares them with the compiled code.
+template <int NTAPS, int NPARTS>
+struct v2_sched {
+    static constexpr int APT = (NPARTS + NTAPS - 1) / NTAPS;          // A parts a wave issues per step ...
+    static constexpr int NA_TAPS = NPARTS / APT;                      // ... during the first NA_TAPS taps of a chunk
+    static_assert(NPARTS % APT == 0 && NA_TAPS <= NTAPS, "A parts per step");
+    static constexpr int n_a(int tap, bool last) { return (!last && tap < NA_TAPS) ? APT : 0; }
+    // B(step + 2) is issued unless it lies past the last chunk (one-tap classes decide that at run time and therefore always wait for everything)
+    static constexpr bool b_static(int tap, bool last) { return !last || tap + 2 < NTAPS; }
+    static constexpr int n_b(int tap, bool last) { return b_static(tap, last) ? 2 : 0; }
+    // LDS-DMA operations that may still be in flight at the boundary in front of step (tap, last): what the PREVIOUS step issued after B(this step) -- its A parts
+    // (they precede its B operations) and its B operations -- except at tap 0, where the A parts are this chunk's own tile and must have landed as well.
+    // (the step before tap 0 is the last tap of a chunk that is not the last one -- or the prologue, which ends with the same two B operations)
+    static constexpr int allow(int tap, bool last) {
+        if (NTAPS == 1) return 0;
+        const int ptap = tap >= 1 ? tap - 1 : NTAPS - 1;
+        const bool plast = tap >= 1 ? last : false;
+        return n_b(ptap, plast) + (tap == 0 ? 0 : n_a(ptap, plast));
+    }
+    static constexpr int total_a() { int t = 0; for (int i = 0; i < NTAPS; ++i) t += n_a(i, false); return t; }
+    static_assert(total_a() == NPARTS, "every A part of the next chunk is issued exactly once per chunk");
+    static_assert(allow(NTAPS - 1, true) == 0 || NTAPS == 1, "the last step waits for everything");
+};
+
 // FULL: three products per fp32 product; !FULL: high pieces only (EG3D_PREC_F16X1); ATOMIC: split-K; RPW: patch rows per wave -- 4 = the 8 x 32
 // patch (256 cells), 2 = a 4 x 32 patch (128 cells x 128 channels per workgroup, 12 MFMAs per wave and step): twice the workgroups for the
 // layers whose 8-row grids leave CUs idle (128^2 x 256: 128 -> 256), with the fused epilogues intact (split-K needs a zero fill + a finishing pass);
@@ -34,9 +60,7 @@ template <int NTAPS, bool FULL = true, bool ATOMIC = false, int RPW = 4, bool RG
 __global__ void __launch_bounds__(256 * KH, KH == 1 ? 2 : 1) conv_v2_kernel(const eg3d_conv_v2_params p, const int cls_base) {
     constexpr int PHK = 2 * RPW;                          // patch rows of this instantiation
     constexpr int NPARTS = ((PHK + 2) * (PW + 2) + 63) / 64;      // 64-slot wave-instructions per A plane: halo <= (PHK + 2) x 34 slots (6 | 4 | 3)
-    constexpr int APT = (NPARTS + NTAPS - 1) / NTAPS;     // A parts a wave issues per step
-    constexpr int NA_TAPS = NPARTS / APT;                 // ... during the first NA_TAPS taps of a chunk (APT divides NPARTS)
-    static_assert(NPARTS % APT == 0, "A parts per step");
+    using sched = v2_sched<NTAPS, NPARTS>;                // issue counts per step and the vmcnt immediates that follow from them
     extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
     const int tid = threadIdx.x, lane = tid & 63;
     // (KH = 1 must compile to the instructions it had before KH existed: written with `wave = wave_all & 3` for both forms, every instantiation of this
@@ -100,11 +124,11 @@ __global__ void __launch_bounds__(256 * KH, KH == 1 ? 2 : 1) conv_v2_kernel(cons
         // (!FULL: the low-piece planes are never read -- the DMA slot is kept for the wait accounting but fetches nothing)
         glds16(ars, lds0 + LDS_A + (chunk & 1) * ABUF + a_plane[i] * APLANE + a_part[i] * 1024, (a_pix[i] == OOB || (!FULL && piece == 1)) ? OOB : a_pix[i] + plane_off);
     };
-    auto issue_B = [&](int chunk, int tap, int slot) {
+    auto issue_B = [&](int chunk, int wtap, int slot) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int idx = wave * 2 + e, plane = idx >> 1, half = idx & 1;
-            const unsigned v = (unsigned)(((((cl.wtap[tap] * nchunk + chunk) * 4 + plane) * p.Nc) + n0 + half * 64 + lane) * 16);
+            const unsigned v = (unsigned)(((((wtap * nchunk + chunk) * 4 + plane) * p.Nc) + n0 + half * 64 + lane) * 16);
             glds16(wrs, lds0 + LDS_B + slot * BSLOT + plane * BPLANE + half * 1024, (!FULL && plane >= 2) ? OOB : v);
         }
     };
@@ -121,38 +145,37 @@ __global__ void __launch_bounds__(256 * KH, KH == 1 ? 2 : 1) conv_v2_kernel(cons
     const unsigned b_lane = (unsigned)((wn * 64 + (lane & 31)) * 16 + (lane >> 5) * BPLANE);
     const f16x2 k2m11 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
 
+    // the class's tap tables in scalar registers: read through `cl` inside the loop they are re-fetched from the kernel-argument segment after every boundary
+    // (the boundary clobbers memory), an s_load + s_waitcnt lgkmcnt(0) in front of every step's first matrix instruction
+    // (one register per tap: LDS byte offset of the tap inside the halo, < 2^16, | weight-tap index << 16)
+    unsigned tap_tab[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) tap_tab[t] = (unsigned)__builtin_amdgcn_readfirstlane(((cl.dy[t] * hw + cl.dx[t]) * 16) | (cl.wtap[t] << 16));
+    auto tap_w = [&](int t) { return (int)(tap_tab[t] >> 16); };
+    auto tap_off = [&](int t) { return tap_tab[t] & 0xffffu; };
+
     // ---- prologue: A(c0), B(step 0), B(step 1) -------------------------------------------------------------------------------------------
     const int S = (c1 - c0) * NTAPS;
 #pragma unroll
     for (int i = 0; i < NPARTS; ++i) issue_A(c0, i);
-    issue_B(c0, 0, 0);
-    if (S > 1) issue_B(NTAPS > 1 ? c0 : c0 + 1, NTAPS > 1 ? 1 : 0, 1);
-    else { issue_B(c0, 0, 1); }                      // keeps the wait accounting uniform (never read)
+    issue_B(c0, tap_w(0), 0);
+    if (S > 1) issue_B(NTAPS > 1 ? c0 : c0 + 1, tap_w(NTAPS > 1 ? 1 : 0), 1);
+    else { issue_B(c0, tap_w(0), 1); }               // keeps the wait accounting uniform (never read)
 
     int step = 0;
     auto run_chunk = [&](const int chunk, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
+        static_for<0, NTAPS>([&](auto tap_tag) {
+            constexpr int tap = decltype(tap_tag)::value;
+            // B(step) -- and at tap 0 all of A(chunk) -- have landed, everybody's LDS reads of the previous step have returned
+            step_sync<sched::allow(tap, LAST)>();
 #pragma unroll
-        for (int tap = 0; tap < NTAPS; ++tap, ++step) {
-            // B(step) -- and at tap 0 all of A(chunk) -- were issued before B(step+1) [2 ops] and the A parts of the previous step
-            if constexpr (NTAPS == 1) {
-                wait_vm<0>();                        // one-tap classes (1/9 of an up-sampling layer): no look-ahead bookkeeping
-            } else {
-                if (LAST && tap == NTAPS - 1) wait_vm<0>();
-                else if (!LAST && tap >= 1 && tap - 1 < NA_TAPS) wait_vm<2 + APT>();
-                else wait_vm<2>();
-            }
-            __builtin_amdgcn_s_barrier();
-            if (!LAST && tap < NA_TAPS) {
-#pragma unroll
-                for (int e = 0; e < APT; ++e) issue_A(chunk + 1, tap * APT + e);
-            }
+            for (int e = 0; e < sched::n_a(tap, LAST); ++e) issue_A(chunk + 1, tap * sched::APT + e);
             {
-                int t2 = tap + 2, c2 = chunk;
-                while (t2 >= NTAPS) { t2 -= NTAPS; c2 += 1; }
-                if (NTAPS == 1 ? c2 < c1 : (!LAST || c2 == chunk)) issue_B(c2, t2, (step + 2) % 3);
+                constexpr int t2 = (tap + 2) % NTAPS, dc = (tap + 2) / NTAPS;
+                if (NTAPS == 1 ? chunk + dc < c1 : sched::b_static(tap, LAST)) issue_B(chunk + dc, tap_w(t2), (step + 2) % 3);
             }
-            const unsigned abase = LDS_A + (chunk & 1) * ABUF + a_lane + (unsigned)((cl.dy[tap] * hw + cl.dx[tap]) * 16);
+            const unsigned abase = LDS_A + (chunk & 1) * ABUF + a_lane + tap_off(tap);
             const unsigned bbase = LDS_B + (step % 3) * BSLOT + b_lane;
             f16x8 bh[2], bl[2], bg[2];
 #pragma unroll
@@ -182,12 +205,12 @@ __global__ void __launch_bounds__(256 * KH, KH == 1 ? 2 : 1) conv_v2_kernel(cons
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[i][j], 0, 0, 0);
                 }
             }
-        }
+            ++step;
+        });
     };
     for (int chunk = c0; chunk + 1 < c1; ++chunk) run_chunk(chunk, std::false_type{});
     run_chunk(c1 - 1, std::true_type{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    step_sync<0>();                      // every LDS-DMA and LDS read of the main loop is over: the exchange / the epilogue re-use the dynamic LDS
     if constexpr (KH == 2) {
         // the upper half's partial tile goes to the lower one through the upper half's (now idle) LDS image: [i][j][r][thread], lane-contiguous
         float* xch = reinterpret_cast<float*>(smem_dyn + LDS_MAIN) + (wave * 64 + lane);

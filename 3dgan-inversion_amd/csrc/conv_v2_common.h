@@ -9,7 +9,6 @@
         EG3D_DET_BIND(name, (p).ds, (int64_t)(p).N * (p).Nc); \
         if ((p).epi == EG3D_EPI_BWD_ACT) EG3D_DET_BIND_ACT(name, (p).act_bwd, (p).N, (p).Nc, (int64_t)(p).Ho * (p).Wo); \
     } while (0)
-#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -33,17 +32,6 @@ constexpr int LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
 __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rs, unsigned lds_byte, unsigned voff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(uintptr_t)lds_byte, 16, voff, 0, 0, 0);
 }
-
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else static_assert(N == 0, "vmcnt immediate");
-}
-
 
 // ---- operand preparation -------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void split8(const float* x, float mul, f16x8& h, f16x8& l, float lo_mul) {

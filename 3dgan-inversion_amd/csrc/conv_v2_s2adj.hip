@@ -24,6 +24,24 @@ __device__ constexpr int AFIRST[9] = {0, 2, 4, 0, 0, 3, 0, 3, 0};
 // ops allowed in flight when step s starts: B(s + 1) [2 per wave] + the A parts issued during step s - 1 unless they belong to the
 // sub-chunk that starts now
 __device__ constexpr int WAITN[9] = {2, 4, 4, 3, 2, 5, 2, 5, 2};
+// ... derived from the schedule (the table above is checked against it): the previous step issued its A parts, then B(s + 1); the A parts may stay in flight
+// unless their sub-chunk starts with this step; in the last chunk step 7 issues no B (there is no step 9) and step 8 waits for everything
+constexpr int s2_allow(int s, bool last) {
+    if (last && s == 8) return 0;
+    const int ps = s >= 1 ? s - 1 : 8;
+    return 2 + (SUB[s] != SUB[ps] ? 0 : AISS[ps]);
+}
+constexpr bool s2_table_ok() {
+    for (int s = 0; s < 9; ++s)
+        if (s2_allow(s, false) != WAITN[s]) return false;
+    int parts[4] = {0, 0, 0, 0};
+    for (int s = 0; s < 9; ++s) {                       // the parts of sub-chunk q are issued during sub-chunk q - 1, in order, S_PARTS per wave
+        if (AISS[s] > 0 && AFIRST[s] != parts[(SUB[s] + 1) & 3]) return false;
+        parts[(SUB[s] + 1) & 3] += AISS[s];
+    }
+    return parts[0] == S_PARTS && parts[1] == S_PARTS && parts[2] == S_PARTS && parts[3] == S_PARTS;
+}
+static_assert(s2_table_ok(), "conv_v2_s2adj: wait table / A-part schedule");
 
 template <bool FULL, bool ATOMIC>
 __global__ void __launch_bounds__(256, 2) conv_v2_s2adj_kernel(const eg3d_conv_v2_params p) {
@@ -71,11 +89,14 @@ __global__ void __launch_bounds__(256, 2) conv_v2_s2adj_kernel(const eg3d_conv_v
         const unsigned plane_off = (unsigned)((((((n * 2 + piece) * (p.Ck / 8)) + chunk * 2 + koct) * 4 + par)) * planeP);
         glds16(ars, lds0 + LDS_A + buf * ABUF + a_plane[i] * APLANE + a_part[i] * 1024, (a_pix[i] == OOB || (!FULL && piece == 1)) ? OOB : a_pix[i] + plane_off);
     };
+    int wtap_r[9];                       // (in scalar registers: through `cl` they are re-fetched from the kernel-argument segment after every boundary)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wtap_r[t] = __builtin_amdgcn_readfirstlane(cl.wtap[t]);
     auto issue_B = [&](int chunk, int t9, int slot) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int idx = wave * 2 + e, plane = idx >> 1, half = idx & 1;
-            const unsigned v = (unsigned)(((((cl.wtap[t9] * nchunk + chunk) * 4 + plane) * p.Nc) + n0 + half * 64 + lane) * 16);
+            const unsigned v = (unsigned)(((((wtap_r[t9] * nchunk + chunk) * 4 + plane) * p.Nc) + n0 + half * 64 + lane) * 16);
             glds16(wrs, lds0 + LDS_B + slot * BSLOT + plane * BPLANE + half * 1024, (!FULL && plane >= 2) ? OOB : v);
         }
     };
@@ -101,14 +122,9 @@ __global__ void __launch_bounds__(256, 2) conv_v2_s2adj_kernel(const eg3d_conv_v
     int step = 0;                        // global step counter: weight ring slot = step % 3; sub-chunk counter = 4 (chunk - c0) + SUB -> A buffer & 1
     auto run_chunk = [&](const int chunk, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
-#pragma unroll
-        for (int s = 0; s < 9; ++s, ++step) {
-            if (LAST && s == 8) wait_vm<0>();
-            else if (WAITN[s] == 2) wait_vm<2>();
-            else if (WAITN[s] == 3) wait_vm<3>();
-            else if (WAITN[s] == 4) wait_vm<4>();
-            else wait_vm<5>();
-            __builtin_amdgcn_s_barrier();
+        static_for<0, 9>([&](auto s_tag) {
+            constexpr int s = decltype(s_tag)::value;
+            step_sync<s2_allow(s, LAST)>();          // conv_v2_common.h: this step's tiles have landed, everybody's LDS reads of the previous step have returned
             const int sub = SUB[s];
             const int abufi = sub & 1;                       // four sub-chunks per chunk: the buffer parity restarts with every chunk
             // A parts of the next sub-chunk (the next chunk's parity 0 after the last one)
@@ -116,8 +132,8 @@ __global__ void __launch_bounds__(256, 2) conv_v2_s2adj_kernel(const eg3d_conv_v
 #pragma unroll
                 for (int e = 0; e < AISS[s]; ++e) issue_A(sub == 3 ? chunk + 1 : chunk, sub == 3 ? 0 : sub + 1, abufi ^ 1, AFIRST[s] + e);
             }
-            if (s + 2 < 9) issue_B(chunk, TAP9[s + 2], (step + 2) % 3);
-            else if (!LAST) issue_B(chunk + 1, TAP9[s + 2 - 9], (step + 2) % 3);
+            if constexpr (s + 2 < 9) issue_B(chunk, TAP9[s + 2], (step + 2) % 3);
+            else if constexpr (!LAST) issue_B(chunk + 1, TAP9[s + 2 - 9], (step + 2) % 3);
             const int t9 = TAP9[s];
             const int oy = (t9 / 3) >> 1, ox = (t9 % 3) >> 1;
             const unsigned abase = LDS_A + abufi * ABUF + a_lane + (unsigned)((oy * hw + ox) * 16);
@@ -150,12 +166,12 @@ __global__ void __launch_bounds__(256, 2) conv_v2_s2adj_kernel(const eg3d_conv_v
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[i][j], 0, 0, 0);
                 }
             }
-        }
+            ++step;
+        });
     };
     for (int chunk = c0; chunk + 1 < c1; ++chunk) run_chunk(chunk, std::false_type{});
     run_chunk(c1 - 1, std::true_type{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    step_sync<0>();                      // every LDS-DMA and LDS read of the main loop is over: the epilogue re-uses the dynamic LDS
     v2_epilogue<ATOMIC, 4>(p, acc, Ha, Wa, cl.out_py, cl.out_px, n, y0, x0, n0, smem, 1.f / (*p.a_scale * *p.w_scale));
 }
 

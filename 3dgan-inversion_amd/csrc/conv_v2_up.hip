@@ -110,8 +110,7 @@ __global__ void __launch_bounds__(512, 2) conv_v2_up2_kernel(const eg3d_conv_up2
     issue_chunk(c0, 0);
     for (int chunk = c0; chunk < c1; ++chunk) {
         const int buf = (chunk - c0) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        step_sync<0>();                  // common.h: this chunk's tiles have landed; everybody's LDS reads of the previous chunk (the buffer refilled next) have returned
         if (chunk + 1 < c1) issue_chunk(chunk + 1, buf ^ 1);
         const unsigned abuf = LDS_A + buf * ABUF + a_lane, bbuf = LDS_B + buf * BBUF + b_lane;
 #pragma unroll

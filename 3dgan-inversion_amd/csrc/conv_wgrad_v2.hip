@@ -126,8 +126,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_v2_kernel(const eg3d_wgrad_
 
     for (int s = 0; s < R; ++s) {
         // bundle s must have landed; younger: bundles s+1 .. s+P-1
-        wg_wait<(WG_P - 1) * 2 * NIW>();
-        __builtin_amdgcn_s_barrier();
+        step_sync<(WG_P - 1) * 2 * NIW>();           // common.h: + everybody's LDS reads of the previous row have returned (its ring slots are refilled next)
         issue_bundle(s + WG_P);
         const unsigned gb = LDS_G + (s % WG_GR) * SLOT + g_lane;
 #pragma unroll
@@ -266,8 +265,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_v2_up_kernel(const eg3d_wgr
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     for (int s = 0; s < R; ++s) {
-        wg_wait<(WU_P - 1) * 5 * NIW>();
-        __builtin_amdgcn_s_barrier();
+        step_sync<(WU_P - 1) * 5 * NIW>();
         issue_bundle(s + WU_P);
         const unsigned xb = LDS_X + (s % WU_XR) * SLOT + x_lane;
 #pragma unroll

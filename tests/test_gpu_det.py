@@ -64,3 +64,18 @@ def test_parity_bounds_tightened_under_the_deterministic_build():
               'tests/test_gpu_generator.py::test_graph_full_weight_grads_golden', 'tests/test_gpu_loops.py::test_pose_and_warping_c3_long_horizon',
               'tests/test_gpu_loops.py::test_run_to_run_drift_of_the_atomically_accumulated_gradients', 'tests/test_gpu_ops.py'], timeout=2400)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize('det', [False, True])
+def test_lds_dma_kernels_are_bit_identical_launch_to_launch(det):
+    """Every instantiation of the LDS-DMA convolution family (conv_v2 8 / 4 / 2-row patches, K halves, 1x1 head, tap classes 4 / 2 / 1, conv_up2, the
+    stride-2 adjoint, conv_v3, conv_wgrad_v2) at full-size layer shapes: 5000 launches each on the same operands, every (atomic-free) output bit-identical
+    to the first launch's -- in both builds.  Before round 6 the step boundary of these kernels left LDS reads in flight across the s_barrier (csrc/common.h
+    `step_sync`): the stride-2 adjoint differed in 11 of 5000 launches at HEAD, the 4-row patches in 1 of 5000 under the first spelling
+    of the KH template parameter (tools/rootcause/stress_v2.py under EG3D_LIBNAME=... for other builds of the library)."""
+    r = _run(['tools/rootcause/stress_v2.py', '--launches', '5000'], det=det, timeout=1800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(rows) >= 26 and not any('error' in x for x in rows), rows
+    dirty = [x for x in rows if x['differing_launches']]
+    assert not dirty, dirty
