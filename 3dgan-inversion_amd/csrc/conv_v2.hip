@@ -141,16 +141,17 @@ __global__ void __launch_bounds__(256 * KH, KH == 1 ? 2 : 1) conv_v2_kernel(cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const unsigned a_lane = (unsigned)(((wm * RPW - dymin) * hw + (lane & 31) - dxmin) * 16 + (lane >> 5) * APLANE);
+    const unsigned a_lane = (unsigned)(((wm * RPW) * hw + (lane & 31)) * 16 + (lane >> 5) * APLANE);          // (+ the tap's offset from the halo origin: tap_off)
     const unsigned b_lane = (unsigned)((wn * 64 + (lane & 31)) * 16 + (lane >> 5) * BPLANE);
     const f16x2 k2m11 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
 
     // the class's tap tables in scalar registers: read through `cl` inside the loop they are re-fetched from the kernel-argument segment after every boundary
     // (the boundary clobbers memory), an s_load + s_waitcnt lgkmcnt(0) in front of every step's first matrix instruction
-    // (one register per tap: LDS byte offset of the tap inside the halo, < 2^16, | weight-tap index << 16)
+    // (one register per tap: LDS byte offset of the tap from the halo origin, < 2^16, | weight-tap index << 16)
     unsigned tap_tab[NTAPS];
 #pragma unroll
-    for (int t = 0; t < NTAPS; ++t) tap_tab[t] = (unsigned)__builtin_amdgcn_readfirstlane(((cl.dy[t] * hw + cl.dx[t]) * 16) | (cl.wtap[t] << 16));
+    for (int t = 0; t < NTAPS; ++t)          // offsets relative to the halo origin (dymin, dxmin): non-negative, <= (2 * 34 + 2) * 16
+        tap_tab[t] = (unsigned)__builtin_amdgcn_readfirstlane((((cl.dy[t] - dymin) * hw + (cl.dx[t] - dxmin)) * 16) | (cl.wtap[t] << 16));
     auto tap_w = [&](int t) { return (int)(tap_tab[t] >> 16); };
     auto tap_off = [&](int t) { return tap_tab[t] & 0xffffu; };
 

@@ -750,8 +750,8 @@ extern "C" int eg3d_torgb_small_bwd_supported(const eg3d_torgb_small_bwd_params*
 
 extern "C" int eg3d_torgb_mid_bwd_supported(const eg3d_torgb_small_bwd_params* p) {
     if (!eg3d_torgb_small_bwd_supported(p)) return 0;
-    if (p->Cp != 96 || ((int64_t)p->H * p->W) % TS_PIX || p->N > 65535) return 0;
-    if ((int64_t)p->N * p->H * p->W < 4096) return 0;
+    if (p->no_mid || p->Cp != 96 || ((int64_t)p->H * p->W) % TS_PIX || p->N > 65535) return 0;
+    if ((int64_t)p->N * p->H * p->W < 4096) return 0;          // (the backbone's 64^2 block at one image included: 4096 pixels)
     return 1;
 }
 

@@ -158,7 +158,7 @@ class TorgbSmallParams(C.Structure):
 class TorgbSmallBwdParams(C.Structure):
     _fields_ = [('dy', C.c_void_p), ('wa', C.c_void_p), ('s', C.c_void_p), ('xin', C.c_void_p), ('addend', C.c_void_p), ('dx', C.c_void_p), ('ds', C.c_void_p),
                 ('out_amax', C.c_void_p), ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('C', C.c_int32), ('Cp', C.c_int32), ('ldg', C.c_int32),
-                ('ldx', C.c_int32), ('wa_row', C.c_int32), ('act_on', C.c_int32), ('pad_', C.c_int32), ('act_bwd', ActBwd),
+                ('ldx', C.c_int32), ('wa_row', C.c_int32), ('act_on', C.c_int32), ('no_mid', C.c_int32), ('act_bwd', ActBwd),
                 ('add_scale', C.c_void_p), ('add_ds', C.c_void_p)]
 
 

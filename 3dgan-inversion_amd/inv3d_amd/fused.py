@@ -367,9 +367,12 @@ class ModConvLayerFn(torch.autograd.Function):
                         y4 = H.empty_cl(N, 4, Ho, Wo, x.device)
                         ts_c = ts.contiguous().float()
                         rkw = dict(rgb_head=(tw4, ts_c, tb4, y4, -1.0 if tclamp is None else float(tclamp), 3 if tw.shape[0] == 3 else 4))
-                        rgb_y = (y4, tw.data_ptr(), tw._version, ts.data_ptr(), None, None if tb is None else (tb.data_ptr(), tb._version),
+                        rgb_y = (y4, tw.data_ptr(), tw._version, ts.data_ptr(), ts._version, None if tb is None else (tb.data_ptr(), tb._version),
                                  -1.0 if tclamp is None else float(tclamp))
-                H.conv_v2(aimg, wimg, out, cls, epi=L.EPI_FWD, out_scale=d, out_amax=amax_out, algo_flops=aflops, products=nprod, **epi_kw, **rkw)
+                ran = []
+                H.conv_v2(aimg, wimg, out, cls, epi=L.EPI_FWD, out_scale=d, out_amax=amax_out, algo_flops=aflops, products=nprod, rgb_head_ran=ran, **epi_kw, **rkw)
+                if rgb_y is not None and ran != [True]:
+                    rgb_y = None                # the library refused the head's operands: ToRGBFn launches the 1x1 layer
             elif v3p:
                 H.conv_v3(aimg, wimg, out, cls, plan=v3p, epi=L.EPI_FWD, out_scale=d, out_amax=amax_out, algo_flops=aflops, products=nprod, **epi_kw)
             elif ks2:
@@ -434,7 +437,7 @@ class ModConvLayerFn(torch.autograd.Function):
                 H.epilogue_fwd(z, out, fir=fir44(x.device), pad0=1, fir_gain=float(up * up), d=d, out_amax=amax_out, **epi_kw)
         H.tag_amax(out, amax_out)
         if rgb_y is not None:
-            out._eg3d_rgb_y = rgb_y
+            out._eg3d_rgb_y = rgb_y + (out._version,)          # (ToRGBFn.forward accepts y only for THIS content of the output and the styles)
         if pending is not None:
             out._eg3d_pending_epi = pending
         rec = None
@@ -766,6 +769,8 @@ class ToRGBFn(torch.autograd.Function):
         PENDING_DGRAD.clear()            # (entries live inside one backward pass; anything left over belongs to a pass that was abandoned)
         pend = x.__dict__.pop('_eg3d_pending_epi', None) if hasattr(x, '__dict__') else None      # the producing layer's finishing pass is still due (ModConvLayerFn defer_epilogue)
         pre_y = x.__dict__.pop('_eg3d_rgb_y', None) if hasattr(x, '__dict__') else None            # ... or this very layer already ran in the producing launch's epilogue
+        if pre_y is not None and (pre_y[7] != x._version or pre_y[4] != styles._version):          # x or the styles were written in place since (a hook, a noise injection): y is stale
+            pre_y = None
         if pend is not None and not (H.is_cl(x) and x.dtype == torch.float32 and pend.out is x):
             pend.run()
             pend = None

@@ -682,12 +682,13 @@ V2_KS_MIN_CHUNKS = int(os.environ.get('EG3D_V2_KS_MIN_CHUNKS', '2'))
 
 def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_STORE, out_scale=None, bias=None, noise=None, noise_nstride=0,
             noise_strength=None, act='linear', alpha=0.0, gain=1.0, clamp=-1.0, addend=None, xin=None, ds=None, out_amax=None, algo_flops=None,
-            act_bwd=None, products=3, ksplit=1, patch_rows=None, rgb_head=None):
+            act_bwd=None, products=3, ksplit=1, patch_rows=None, rgb_head=None, rgb_head_ran=None):
     """Launch eg3d_conv2d_v2 (operands prepared by split_activation / split_weight).  act_bwd (ActBwdSpec, with epi=EPI_BWD): EPI_BWD_ACT when
     the kernel takes it -- returns True if the fused epilogue ran, False for a plain EPI_BWD.
     rgb_head (EPI_FWD, 128 output channels): (w4 [4, >= Nc] packed weight rows, styles [N, Nc], bias4 [4] | None, y4 [N,4,H,W] channels_last, clamp[, 3 = the
     fourth row is padding]) --
-    the 1x1 layer that reads `out` next, evaluated in this launch's epilogue (eg3d_conv_v2_params::rgb_out)."""
+    the 1x1 layer that reads `out` next, evaluated in this launch's epilogue (eg3d_conv_v2_params::rgb_out); rgb_head_ran (a list): receives True / False =
+    the library took / refused the head (refused: the launch runs without it)."""
     assert is_cl(out)
     p = _conv_v2_params(a, w, out, classes, out_stride, epi, out_scale, bias, noise, noise_nstride, noise_strength, act, alpha, gain, clamp,
                         addend, xin, ds, out_amax)
@@ -707,6 +708,12 @@ def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_
         assert epi == L.EPI_FWD and is_cl(y4) and y4.shape[1] == 4 and w4.shape[0] == 4 and w4.stride(1) == 1 and s4.is_contiguous()
         p.rgb_w, p.rgb_s, p.rgb_bias, p.rgb_out = w4.data_ptr(), s4.data_ptr(), (b4.data_ptr() if b4 is not None else None), y4.data_ptr()
         p.rgb_clamp, p.rgb_ldw = float(rclamp), w4.stride(0)
+        if not L.lib().eg3d_conv2d_v2_supported(C.byref(p)):        # (alignment of the head's operands, patch height ...): this launch without the head, the caller launches the 1x1 layer itself
+            p.rgb_w = p.rgb_s = p.rgb_bias = p.rgb_out = None
+            p.rgb_nout = 0
+            rgb_head = None
+        if rgb_head_ran is not None:
+            rgb_head_ran.append(rgb_head is not None)
     fused_act = False
     if act_bwd is not None and epi == L.EPI_BWD and xin is not None:
         p.epi = L.EPI_BWD_ACT
@@ -836,11 +843,22 @@ def conv_ws_ok(Ck, Nc, classes, N, H, W, in_stride=1):
     if in_stride == 2:
         if not CONV_WS_S2 or any(not (0 <= c.dy[t] <= 2 and 0 <= c.dx[t] <= 2) for t in range(9)) or H * W > 256 or N != 1:
             return False
-        mt, cpw = (1, 4) if H * W <= 32 else ((2, 4) if H * W <= 64 else ((2, 2) if H * W <= 128 else (4, 2)))
-        return cpw * 4 * 4 * (H + 1) * (W + 1) * 16 <= 156 * 1024
+        return _conv_ws_geometry_ok(Ck, Nc, N, H, W, c, 2, 2 * H + 1, 2 * W + 1, 1)
     if any(abs(c.dy[t]) > 1 or abs(c.dx[t]) > 1 for t in range(9)):
         return False
-    return N * H * W <= CONV_WS_MAX_CELLS
+    # the routing threshold, then the library's own geometry check (e.g. a 64 x 4 grid passes the cell count but not the kernel's halo-slot limit): a launch the
+    # kernel refuses must fall back to the split-K implicit GEMM here, not raise from L.check later
+    return N * H * W <= CONV_WS_MAX_CELLS and _conv_ws_geometry_ok(Ck, Nc, N, H, W, c, 1, H, W, 1)
+
+
+def _conv_ws_geometry_ok(Ck, Nc, N, H, W, c, in_stride, Hx, Wx, out_stride):
+    """eg3d_conv2d_ws_supported on the geometry alone (it reads no pointer)."""
+    p = L.ConvWsParams()
+    p.N, p.H, p.W, p.Ck, p.ldx, p.Nc, p.ldo, p.wtaps = N, H, W, Ck, Ck, Nc, Nc, 9
+    for t in range(9):
+        p.dy[t], p.dx[t], p.wtap[t] = (c.dy[t], c.dx[t], c.wtap[t]) if c is not None else (0, 0, t)
+    p.products, p.in_stride, p.Hx, p.Wx, p.out_stride = 3, in_stride, Hx, Wx, out_stride
+    return bool(L.lib().eg3d_conv2d_ws_supported(C.byref(p)))
 
 
 def conv_ws(x, w: SplitImage, out, classes, in_scale=None, x_amax=None, x_amax_mul=1.0, products=3, algo_flops=None, in_stride=1):
@@ -874,7 +892,7 @@ def conv_ws_up_ok(Ck, Nc, N, H, W, max_cells=None):
     """Forward of an up layer (stride-2 transposed 3x3 conv, split-K accumulation into a zeroed buffer) on the weight-streaming kernel: 4^2 / 8^2
     input cells at one image per GPU.  max_cells: cells per output parity the caller accepts (default: the routing threshold; the kernel takes 96)."""
     return bool(USE_V2 and CONV_WS and CONV_WS_UP and CONV_MODE == 'auto' and Ck % 16 == 0 and Nc % 32 == 0 and N == 1 and (H + 1) * (W + 1) <= min(96, max_cells or CONV_WS_UP_MAX_CELLS)
-                and W <= 30)
+                and W <= 30 and _conv_ws_geometry_ok(Ck, Nc, N, H, W, None, 1, H, W, 2))
 
 
 def conv_ws_up(x, w: SplitImage, out, in_scale=None, x_amax=None, x_amax_mul=1.0, products=3, algo_flops=None):
@@ -1687,7 +1705,8 @@ def torgb_small_bwd(dy, wa, styles, x, dx, ds=None, addend=None, act_bwd=None, o
     n, c, h, w = x.shape
     p = L.TorgbSmallBwdParams(dy=dy.data_ptr(), wa=wa.data_ptr(), s=styles.data_ptr(), xin=x.data_ptr(), addend=addend.data_ptr() if addend is not None else None,
                               dx=dx.data_ptr(), ds=ds.data_ptr() if ds is not None else None, out_amax=out_amax.data_ptr() if out_amax is not None else None,
-                              N=n, H=h, W=w, C=c, Cp=dy.shape[1], ldg=dy.shape[1], ldx=c, wa_row=wa.stride(0), act_on=0)
+                              N=n, H=h, W=w, C=c, Cp=dy.shape[1], ldg=dy.shape[1], ldx=c, wa_row=wa.stride(0), act_on=0,
+                              no_mid=0 if TORGB_MID_BWD else 1)          # (the library picks the streaming form itself from 4096 pixels: the switch must reach it)
     if addend_scale is not None:          # the addend is an unfinished split-K data gradient: finish it in this launch (PendingDgrad)
         p.add_scale, p.add_ds = addend_scale.data_ptr(), addend_ds.data_ptr() if addend_ds is not None else None
     fused = False

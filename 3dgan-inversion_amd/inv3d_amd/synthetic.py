@@ -79,6 +79,35 @@ def load_synthetic_weights(G: torch.nn.Module, seed: int = 0, bias_scale: float 
     return out
 
 
+@torch.no_grad()
+def apply_heavy_tail(G: torch.nn.Module, seed: int = 0) -> None:
+    """Trained-checkpoint statistics on top of load_synthetic_weights (no EG3D pickle exists in the image): per-input-channel log-normal gains on every
+    modulated conv weight (unit mean square), four x100 channels in b4.const, two x10 entries in every affine bias, noise_strength ~ U(0,1).  The f16x3
+    operand split normalises each tensor by ONE power of two taken from max|x| * max|style|: this is the input that stresses it (training/
+    networks_stylegan2.py:54-56 pre-normalises for the same reason).  Same numbers as oracle.eg3d_oracle.heavy_tailed_params (tests compare the two)."""
+    sd = G.state_dict()
+    out = {}
+    for name, t in sd.items():
+        body = name.startswith('backbone.synthesis.') or name.startswith('superresolution.')
+        dev = t.device
+        if body and name.endswith('.weight') and t.dim() == 4:
+            g = torch.exp(randn_named(name + '#gain', seed, (t.shape[1],)))
+            g = g / g.square().mean().sqrt()
+            out[name] = t * g.to(dev)[None, :, None, None]
+        elif name.endswith('b4.const'):
+            idx = torch.randperm(t.shape[0], generator=torch.Generator().manual_seed(_name_seed(name + '#outliers', seed)))[:4]
+            v = t.clone(); v[idx.to(dev)] *= 100.0
+            out[name] = v
+        elif body and name.endswith('affine.bias'):
+            idx = torch.randperm(t.shape[0], generator=torch.Generator().manual_seed(_name_seed(name + '#outliers', seed)))[:2]
+            v = t.clone(); v[idx.to(dev)] *= 10.0
+            out[name] = v
+        elif name.endswith('noise_strength'):
+            out[name] = rand_named(name + '#heavy', seed, tuple(t.shape)).to(dev)
+    sd.update(out)
+    G.load_state_dict(sd)
+
+
 def synth_ws(num_ws: int, w_dim: int, n: int, seed: int = 1, wplus: bool = False) -> torch.Tensor:
     if wplus:
         return 0.5 * randn_named('ws+', seed, (n, num_ws, w_dim))

@@ -180,15 +180,22 @@ def measure_backbone(G, dev, M, reps=20):
         torch.cuda.current_stream().wait_stream(side)
 
 
-def _time_steps(fn, n, warm):
+def _time_steps(fn, n, warm, repeats=1, spread=None):
+    """ms per call: `repeats` timed regions of n calls each, the MEDIAN region; spread (a dict) receives min / median / max / repeats."""
     for _ in range(warm):
         fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e3
+    ts = []
+    for _ in range(max(1, repeats)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / n * 1e3)
+    ts.sort()
+    if spread is not None:
+        spread.update(repeats=len(ts), calls_per_region=n, ms_min=round(ts[0], 3), ms_median=round(ts[len(ts) // 2], 3), ms_max=round(ts[-1], 3))
+    return ts[len(ts) // 2]
 
 
 def side_configs(G, target, cam, dev, use_graph, steps=10):
@@ -211,10 +218,11 @@ def side_configs(G, target, cam, dev, use_graph, steps=10):
             pr = LatentProjector(G, kw.pop('target', target), num_steps=400, cam=kw.pop('cam', cam), seed=100, use_graph=use_graph, **kw)
             pr.preheat = 0
             m = pr.N
-            ms = _time_steps(pr.step, steps, pr._graph_warmup + 2)
+            sp = {}
+            ms = _time_steps(pr.step, steps, pr._graph_warmup + 2, repeats=5, spread=sp)
             if use_graph and pr._graph is None:
                 raise RuntimeError(f'capture failed: {pr.graph_capture_error}')
-            return dict(ms_per_step=round(ms, 3), image_steps_per_s=round(m * 1e3 / ms, 2))
+            return dict(ms_per_step=round(ms, 3), image_steps_per_s=round(m * 1e3 / ms, 2), spread=sp)
         return run
 
     guarded('wplus', projector(wplus=True))
@@ -375,10 +383,11 @@ def side_configs(G, target, cam, dev, use_graph, steps=10):
         try:
             w_pivot = S.synth_ws(14, 512, 1, seed=5).to(dev)
             tuner = PivotalTuner(G, target[:1], w_pivot, cam[:1], use_graph=use_graph)
-            ms = _time_steps(tuner.step, steps, 4)
+            sp = {}
+            ms = _time_steps(tuner.step, steps, 4, repeats=5, spread=sp)
             if use_graph and tuner._graph is None:
                 raise RuntimeError(f'capture failed: {tuner.graph_capture_error}')
-            return dict(ms_per_step=round(ms, 3), steps_per_s=round(1e3 / ms, 2),
+            return dict(ms_per_step=round(ms, 3), steps_per_s=round(1e3 / ms, 2), spread=sp,
                         note='config C4: pivotal-tuning step, all 30.7 M weights trainable (forward + data and weight gradients + fused Adam), SR head in the reference\'s fp16-operand arithmetic')
         finally:
             G.load_state_dict(state)
@@ -452,6 +461,8 @@ def run_child(kind, args, timeout=600):
         cmd.append('--no-graph')
     if args.precision is not None:
         cmd += ['--precision', args.precision]
+    if args.wplus:
+        cmd.append('--wplus')
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
@@ -468,6 +479,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--repeats', type=int, default=5, help='timed regions of --steps steps each; the line reports the median region and the spread')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel from the host instead of replaying the captured step')
@@ -554,16 +566,21 @@ def main():
     if not args.no_roofline and not use_graph:
         prof = profiler()
         H.PROFILER = prof
-    torch.cuda.synchronize()
-    D.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    torch.cuda.synchronize()
-    D.barrier()
-    elapsed = time.perf_counter() - t0
+    # `--repeats` timed regions of EXACTLY `--steps` steps, each bracketed by a device synchronise + barrier on both sides and reduced to the maximum
+    # over ranks; the line reports the MEDIAN region (a single 0.08 .. 0.8 s sample on one box cannot tell a +3 % change from a lucky lease) and the
+    # min / max beside it.  With the launch profiler on (eager --no-graph runs) one region only: the profiler brackets every launch of it.
+    regions = []
+    for _ in range(1 if prof is not None else max(1, args.repeats)):
+        torch.cuda.synchronize()
+        D.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        torch.cuda.synchronize()
+        D.barrier()
+        regions.append(D.max_over_ranks(time.perf_counter() - t0, dev))
+    elapsed = sorted(regions)[len(regions) // 2]
     H.PROFILER = None
-    elapsed = D.max_over_ranks(elapsed, dev)
     step_stats = reducer.finish()              # [sum loss, sum dist, steps x ranks, .] over everything pushed (warm-up included)
     psnr_now = float(psnr_01(proj.last['image'], target))
     roofline_pass = 'HIP events around every launch of the kernel inside the timed region'
@@ -699,16 +716,16 @@ def main():
     # The side figures and the full-budget run each capture a dozen graphs and build optimisers over all 30.7 M weights: they run in a process
     # of their own, AFTER this one has everything the benchmark line needs -- a fault in one of them (the runtime's graph capture has produced
     # segmentation faults under memory pressure) costs its own entry, never the line.
-    side = None
-    if rank == 0 and world == 1 and not args.no_side_configs and M == 1 and args.loss_net == 'stub' and not args.wplus:
+    side = final = None
+    want_side = rank == 0 and world == 1 and not args.no_side_configs and M == 1 and args.loss_net == 'stub' and not args.wplus
+    want_final = rank == 0 and world == 1 and not args.no_final_psnr
+    if want_side or want_final:         # the children capture their own graphs: give the projector, its graphs and the optimiser state back first
         del proj
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
+    if want_side:
         side = run_child('side', args)
-    final = None
-    if rank == 0 and world == 1 and not args.no_final_psnr:
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()
+    if want_final:
         final = run_child('final', args)
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -727,6 +744,10 @@ def main():
                                     ' (one packed vector per step, asynchronous; mean loss over ranks and steps %.5g)' % float(step_stats[0] / step_stats[2].clamp(min=1)) if world > 1 else ''),
                                 launch='one HIP graph replay per step' if use_graph else 'eager (one launch per kernel)',
                                 psnr_after_timed_steps_db=round(psnr_now, 3)),
+                    spread=dict(repeats=len(regions), steps_per_region=args.steps, statistic='median region (value / ms_per_step); each region = --steps steps between two device synchronisations + barriers, max over ranks',
+                                steps_per_s_min=round(world * M * args.steps / max(regions), 3), steps_per_s_median=round(world * M * args.steps / elapsed, 3),
+                                steps_per_s_max=round(world * M * args.steps / min(regions), 3), ms_per_step_regions=[round(r / args.steps * 1e3, 4) for r in regions],
+                                rel_spread=round((max(regions) - min(regions)) / elapsed, 4)),
                     roofline=roof, roofline_renderer=roof_r, cpu_baseline=cpu, cpu_baseline_c1=cpu_c1, side_configs=side, final_psnr=final)
         print(json.dumps(line), flush=True)
     if world > 1:

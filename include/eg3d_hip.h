@@ -662,7 +662,8 @@ typedef struct eg3d_torgb_small_bwd_params {
     float* out_amax;
     int32_t N, H, W, C, Cp;
     int32_t ldg, ldx, wa_row;
-    int32_t act_on, pad_;
+    int32_t act_on;
+    int32_t no_mid;              /* != 0: never the streaming form (eg3d_torgb_mid_bwd_supported reports 0): the A/B switch EG3D_TORGB_MID_BWD=0 reaches every launch */
     eg3d_act_bwd act_bwd;
     /* optional (both or neither; needs addend and xin): the addend is the UNFINISHED split-K data gradient z of the layer that consumes x next
      * (eg3d_dgrad_finish not run): this launch adds z * add_scale[n,c] and accumulates add_ds[n,c] += sum_p z[n,p,c] xin[n,p,c] (pre-zeroed). */

@@ -194,6 +194,34 @@ def synth_params(cfg: GenConfig, seed: int = 0, bias_scale: float = 0.1) -> Dict
     return out
 
 
+def heavy_tailed_params(P: Dict[str, Tensor], seed: int = 0) -> Dict[str, Tensor]:
+    """Trained-checkpoint STATISTICS on top of synth_params (no EG3D pickle exists in the image: VERDICT r5 item 7).  Trained StyleGAN2 weights and
+    activations are heavy-tailed -- the reason modulated_conv2d pre-normalises its operands (training/networks_stylegan2.py:54-56).  In place of N(0,1):
+      * every modulated conv weight [O, I, k, k] of the backbone and the super-resolution head: per-INPUT-channel log-normal gains exp(n_i), n ~ N(0,1),
+        rescaled to unit mean square (a few input channels carry most of the contraction);
+      * b4.const: 4 channels x 100; every affine.bias: 2 entries x 10 (styles of +-10 on two input channels per layer; x1000 / x30 drive the REFERENCE's own fp32 backward to NaN);
+      * noise_strength ~ U(0, 1) instead of U(0, 0.1).
+    Pure function of (names, seed): inv3d_amd.synthetic.apply_heavy_tail is the product-side twin."""
+    out = dict(P)
+    for name, t in P.items():
+        body = name.startswith('backbone.synthesis.') or name.startswith('superresolution.')
+        if body and name.endswith('.weight') and t.dim() == 4:
+            g = torch.exp(_randn(name + '#gain', seed, (t.shape[1],)))
+            g = g / g.square().mean().sqrt()
+            out[name] = t * g[None, :, None, None]
+        elif name.endswith('b4.const'):
+            idx = torch.randperm(t.shape[0], generator=torch.Generator().manual_seed(_name_seed(name + '#outliers', seed)))[:4]
+            t = t.clone(); t[idx] *= 100.0
+            out[name] = t
+        elif body and name.endswith('affine.bias'):
+            idx = torch.randperm(t.shape[0], generator=torch.Generator().manual_seed(_name_seed(name + '#outliers', seed)))[:2]
+            t = t.clone(); t[idx] *= 10.0
+            out[name] = t
+        elif name.endswith('noise_strength'):
+            out[name] = _rand(name + '#heavy', seed, tuple(t.shape))
+    return out
+
+
 def synth_ws(cfg: GenConfig, n: int, seed: int = 1, wplus: bool = False) -> Tensor:
     if wplus:
         return 0.5 * _randn('ws+', seed, (n, cfg.num_ws, cfg.w_dim))

@@ -645,6 +645,71 @@ def gen_graph_full():
          dep_stats=stats(o['image_depth']), dws=dws, dc=dc, **wprobe)
 
 
+def cond_loss_cotangents(img, dep):
+    """d/d(image, depth) of a smooth objective -- L = mean((avg_pool2(image) - target)^2) + 0.1 mean(depth^2), target a fixed low-pass image in [-1, 1] --
+    the shape of the image term of w_projector.py:232-249 at 256^2.  Unlike the white-noise cotangents of graph_full, d c under it is well conditioned
+    (VERDICT r5 item 6).  Shared by this generator and tests/test_gpu_generator.py."""
+    import torch.nn.functional as F
+    low = O._randn('cond_target', 11, (1, 3, 16, 16))
+    target = torch.tanh(F.interpolate(low, size=(256, 256), mode='bilinear', align_corners=False)).to(img.device)
+    img = img.detach().requires_grad_(True)
+    dep = dep.detach().requires_grad_(True)
+    L = (F.avg_pool2d(img, 2) - target).square().mean() + 0.1 * dep.square().mean()
+    g_img, g_dep = torch.autograd.grad(L, [img, dep])
+    return g_img, g_dep
+
+
+def gen_graph_full_cond():
+    """Full-size generator, reference class, under (i) the N(0,1) synthetic weights and (ii) the heavy-tailed ones (O.heavy_tailed_params: log-normal
+    per-channel gains, x100 const channels, x10 affine-bias entries, noise_strength up to 1) -- image / raw / depth probes, output ranges, and
+    d ws, d c under the conditioned loss cotangent.  Pins the f16x3 range normalisation at GRAPH level on trained-checkpoint statistics."""
+    cfg = O.full_config()
+    rk = dict(cfg.rendering, superresolution_module='training.superresolution.SuperresolutionHybrid8XDC')
+    arrays = {}
+    for tag in ('plain', 'heavy'):
+        print(f'full-size generator, conditioned cotangent, weights: {tag} -- takes a minute')
+        P = O.synth_params(cfg, seed=0)
+        if tag == 'heavy':
+            P = O.heavy_tailed_params(P, seed=0)
+        G = TriPlaneGenerator(z_dim=512, c_dim=25, w_dim=512, img_resolution=512, img_channels=3, mapping_kwargs={'num_layers': 2},
+                              rendering_kwargs=rk, channel_base=32768, channel_max=512, fused_modconv_default='inference_only',
+                              num_fp16_res=0, sr_num_fp16_res=4,
+                              sr_kwargs={'channel_base': 32768, 'channel_max': 512, 'fused_modconv_default': 'inference_only'},
+                              conv_clamp=None)
+        G.neural_rendering_resolution = 128
+        missing, unexpected = G.load_state_dict(P, strict=False)
+        assert not missing and not unexpected, (missing, unexpected)
+        G.eval().float()
+        ws = O.synth_ws(cfg, 1, seed=1).requires_grad_(True)
+        c = O.synth_cameras(1, seed=2).requires_grad_(True)
+        u1, u2 = O.make_uniforms(cfg, 1, seed=4)
+        with inject(rand_like=[u1], rand=[u2]):
+            o = G.synthesis(ws, c, noise_mode='const', force_fp32=True)
+        assert all(torch.isfinite(o[k]).all() for k in ('image', 'image_raw', 'image_depth'))
+        g_img, g_dep = cond_loss_cotangents(o['image'], o['image_depth'])
+        dws, dc = torch.autograd.grad([o['image'], o['image_depth']], [ws, c], [g_img, g_dep])
+        assert torch.isfinite(dws).all() and torch.isfinite(dc).all(), 'the reference\'s own gradient is not finite under these weights'
+        probe = torch.Generator().manual_seed(98)
+        idx_img = torch.randint(0, 3 * 512 * 512, (4096,), generator=probe)
+        idx_raw = torch.randint(0, 3 * 128 * 128, (2048,), generator=probe)
+        idx_dep = torch.randint(0, 128 * 128, (2048,), generator=probe)
+        with torch.no_grad():
+            oo = O.synthesis(P, cfg, ws.detach(), c.detach(), u1, u2, noise_mode='const')
+        for k in ('image', 'image_raw', 'image_depth'):
+            rng = float(o[k].max() - o[k].min())
+            e = check(oo[k] / rng, o[k] / rng, 1e-4, f'full cond {tag} {k} (relative to the output range {rng:.3g})')
+        stats = lambda t: np.array([t.mean().item(), t.abs().mean().item(), t.min().item(), t.max().item()])
+        print(f'    image range [{o["image"].min().item():.3g}, {o["image"].max().item():.3g}], |d ws| max {dws.abs().max().item():.3e}, |d c| max {dc.abs().max().item():.3e}')
+        arrays.update({f'{tag}.idx_img': idx_img, f'{tag}.idx_raw': idx_raw, f'{tag}.idx_dep': idx_dep,
+                       f'{tag}.img_probe': o['image'].flatten()[idx_img], f'{tag}.raw_probe': o['image_raw'].flatten()[idx_raw],
+                       f'{tag}.dep_probe': o['image_depth'].flatten()[idx_dep], f'{tag}.img_stats': stats(o['image']), f'{tag}.raw_stats': stats(o['image_raw']),
+                       f'{tag}.dep_stats': stats(o['image_depth']), f'{tag}.dws': dws, f'{tag}.dc': dc})
+        if tag == 'plain':
+            arrays['ws'], arrays['c'] = ws, c
+        del G, o
+    save('graph_full_cond', 1e-4, **arrays)
+
+
 # ---------------------------------------------------------------------------------------------------
 # Loop-level pins.  training/projectors/w_projector.py, training/coaches/*.py import wandb / lpips / torchvision / mrcfile
 # (absent here), so their loop bodies are lifted out of the source by AST and executed UNMODIFIED in a namespace that holds the
@@ -1418,7 +1483,7 @@ if __name__ == '__main__':
     gens = dict(bias_act=gen_bias_act, upfirdn2d=gen_upfirdn2d, filtered_lrelu=gen_filtered_lrelu, conv=gen_conv2d_resample, renderer=gen_renderer,
                 graph_small=gen_graph_small, graph_full=gen_graph_full, loss=gen_loss_glue, projector_loop=gen_projector_loop, tuner_loop=gen_tuner_loop,
                 inference=gen_inference, pose_net=gen_pose_net, e4e=gen_e4e, sr_heads=gen_sr_heads, c3_full=gen_c3_full, c2_full=gen_c2_full,
-                c4_full=gen_c4_full)
+                c4_full=gen_c4_full, graph_full_cond=gen_graph_full_cond)
     mpath = os.path.join(HERE, 'MANIFEST.json')
     if only and os.path.exists(mpath):
         MANIFEST.update(json.load(open(mpath)).get('fixtures', {}))

@@ -172,6 +172,70 @@ def test_graph_full_golden(golden):
     assert e_c <= EC_BOUND, e_c
 
 
+def _cond_loss_cotangents(img, dep):
+    """The conditioned objective of tests/golden/make_golden.py::cond_loss_cotangents, restated (the generator does not travel):
+    L = mean((avg_pool2(image) - target)^2) + 0.1 mean(depth^2), target = tanh(bilinear(N(0,1) 16^2 -> 256^2))."""
+    import torch.nn.functional as F
+    low = O._randn('cond_target', 11, (1, 3, 16, 16))
+    target = torch.tanh(F.interpolate(low, size=(256, 256), mode='bilinear', align_corners=False)).to(img.device)
+    img = img.detach().requires_grad_(True)
+    dep = dep.detach().requires_grad_(True)
+    L = (F.avg_pool2d(img, 2) - target).square().mean() + 0.1 * dep.square().mean()
+    return torch.autograd.grad(L, [img, dep])
+
+
+# observed (round 6, both builds) x 3 -- DESIGN.md section 4
+COND_BOUNDS = dict(plain=dict(probe=2e-4, psnr=60.0, dws=1.5e-3, dc=1.5e-3), heavy=dict(probe=3e-4, psnr=60.0, dws=1.5e-3, dc=1.5e-3))
+
+
+@pytest.mark.parametrize('weights', ['plain', 'heavy'])
+def test_graph_full_conditioned_and_heavy_tailed(golden, weights):
+    """Full-size generator vs the reference's own TriPlaneGenerator under a CONDITIONED cotangent (a smooth image + depth objective: with the white-noise
+    cotangent of test_graph_full_golden a 3 % camera-gradient bug passes), (i) on the N(0,1) synthetic weights and (ii) on heavy-tailed ones -- per-channel
+    log-normal weight gains, x100 outlier channels in b4.const, x10 affine-bias entries, noise_strength up to 1: the statistics of a trained checkpoint,
+    where the f16x3 operand split (one power-of-two range per tensor from max|x| max|style|) loses precision first.  Probes relative to the reference
+    output's own range; PSNR > 60 dB on the probe set; d ws, d c relative to the gradient's largest entry."""
+    from inv3d_amd import synthetic as S
+    d = golden('graph_full_cond')
+    cfg = O.full_config()
+    G = S.make_generator(device=DEV)
+    S.load_synthetic_weights(G, 0)
+    if weights == 'heavy':
+        S.apply_heavy_tail(G, 0)
+        P = O.heavy_tailed_params(O.synth_params(cfg, seed=0), seed=0)          # the product-side transform is the oracle's, tensor for tensor
+        sd = G.state_dict()
+        for k in ('backbone.synthesis.b4.const', 'backbone.synthesis.b64.conv1.weight', 'superresolution.block1.conv1.weight', 'backbone.synthesis.b256.conv0.affine.bias',
+                  'backbone.synthesis.b128.conv1.noise_strength'):
+            assert torch.equal(sd[k].cpu(), P[k]), k
+    for p in G.parameters():
+        p.requires_grad_(False)
+    from inv3d_amd import hipops as H
+    H.weights_changed()
+    ws = t(d['ws']).requires_grad_(True)
+    c = t(d['c']).requires_grad_(True)
+    u1, u2 = O.make_uniforms(cfg, 1, seed=4)
+    o = G.synthesis(ws, c, noise_mode='const', force_fp32=True, render_uniforms=(u1.to(DEV), u2.to(DEV)))
+    img, raw, dep = o['image'], o['image_raw'], o['image_depth']
+    B = COND_BOUNDS[weights]
+    for name, x, ik, pk, sk in (('image', img, 'idx_img', 'img_probe', 'img_stats'), ('raw', raw, 'idx_raw', 'raw_probe', 'raw_stats'), ('depth', dep, 'idx_dep', 'dep_probe', 'dep_stats')):
+        ref = t(d[f'{weights}.{pk}'])
+        rng = float(d[f'{weights}.{sk}'][3] - d[f'{weights}.{sk}'][2])            # the reference output's own range (heavy tails: far beyond [-1, 1])
+        got = x.flatten()[t(d[f'{weights}.{ik}'])]
+        assert torch.isfinite(x).all(), name
+        err = float((got - ref).abs().max()) / rng
+        ps = psnr(got, ref, peak=rng)
+        print(f'{weights} {name}: range {rng:.4g}, probe err / range {err:.2e}, PSNR {ps:.1f} dB')
+        assert err <= B['probe'], (name, err)
+        assert ps > B['psnr'], (name, ps)
+    g_img, g_dep = _cond_loss_cotangents(img, dep)
+    dws, dc = torch.autograd.grad([img, dep], [ws, c], [g_img, g_dep])
+    rel = lambda a, b: float((a.detach().cpu().double() - t(b).cpu().double()).abs().max() / float(t(b).abs().max()))      # noqa: E731
+    e_ws, e_c = rel(dws, d[f'{weights}.dws']), rel(dc, d[f'{weights}.dc'])
+    print(f'{weights}: conditioned-cotangent gradient errors relative to max|ref|: d ws {e_ws:.2e}, d c {e_c:.2e}')
+    assert e_ws <= B['dws'], e_ws
+    assert e_c <= B['dc'], e_c
+
+
 @pytest.mark.parametrize('arith', ['f16x3', 'sr_f16x1'])
 def test_graph_full_weight_grads_golden(golden, arith):
     """Phase B at full size (base_coach.py:96-99: Adam over every weight): weight, bias, affine, noise-strength, decoder and noise_const
