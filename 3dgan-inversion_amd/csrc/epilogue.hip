@@ -345,11 +345,8 @@ __device__ __forceinline__ void bwd1(float dout, float o, int act, float alpha, 
 // 2*C atomics onto the same dbias / dd addresses (measured: launch time grows linearly with the block count), so the
 // parallelism comes from 16 waves per block rather than from many blocks.
 constexpr int EPI_BWD_THREADS = 1024;
-// blocks of the activation-backward / finishing passes (one block of 16 waves per CU by default; EG3D_EPI_BWD_CAP overrides, for tuning)
-static int epi_bwd_cap() {
-    static const int v = [] { const char* e = getenv("EG3D_EPI_BWD_CAP"); const int c = e ? atoi(e) : 256; return c > 0 ? c : 256; }();
-    return v;
-}
+// blocks of the activation-backward / finishing passes: one block of 16 waves per CU (tuned in round 3; was the EG3D_EPI_BWD_CAP knob)
+static int epi_bwd_cap() { return 256; }
 // FIN: the incoming gradient is not read but formed on the fly as the finish of a split-K data gradient of the CONSUMER layer,
 // dout = fz * fs[n,c] (+ fadd), and that layer's style gradient fds[n,c] += sum_px fz * out rides along (eg3d_dgrad_finish_act).
 struct FinArgs { const float* z; const float* s; const float* addend; float* ds; const float* dy4; const float* wa4;

@@ -1799,11 +1799,10 @@ extern "C" int eg3d_triplane_scatter(const float* df_rows, const float* df_pos, 
 #if EG3D_DET
             hipLaunchKernelGGL(scatter_sort16_kernel, dim3(nb16_img), dim3(256), 0, st, offsets16, recs);
 #endif
-            static const int split = [] { const char* e = getenv("EG3D_SCATTER_SPLIT"); return e ? atoi(e) : 1; }();
+            constexpr int split = 1;
             // one block of four waves per four lists: the hardware's block dispatch does the load balancing (lists differ 0 .. 990 pairs); with
             // 1024 persistent blocks taking lists w, w + 4096, ... the launch lasted as long as its unluckiest wave (fp32: 142 -> 128 us)
-            static const int accb_env = [] { const char* e = getenv("EG3D_SCATTER_BLOCKS"); return e ? atoi(e) : 0; }();
-            const int accb = accb_env > 0 ? accb_env : (nb16_img + ACCP_WAVES - 1) / ACCP_WAVES;
+            const int accb = (nb16_img + ACCP_WAVES - 1) / ACCP_WAVES;
             if (df_amax != nullptr) {
                 hipLaunchKernelGGL(scatter_accum16h_kernel, dim3(accb), dim3(ACCP_WAVES * 64), 0, st, df_rows + (int64_t)n * Si * FC, Si, offsets16, recs,
                                    d_planes + (int64_t)n * Hp * Wp * ldp, Hp, Wp, ldp, ntx, nty, df_amax);

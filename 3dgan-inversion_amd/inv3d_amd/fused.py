@@ -185,7 +185,7 @@ GRAM_FUSED = os.environ.get('EG3D_GRAM_FUSED', '1') != '0'        # decoder-weig
 RENDER_PIPELINE_NOGRAD = os.environ.get('EG3D_RENDER_PIPELINE_NOGRAD', '1') != '0'   # ... also for no-grad rendering (scratch rows)
 RENDER_FEAT_ROWS = os.environ.get('EG3D_RENDER_FEAT_ROWS', '1') != '0'   # gather pass + feature rows (eg3d_render_params.feat_rows) in the pipelined renderer
 RENDER_PIPELINE = os.environ.get('EG3D_RENDER_PIPELINE', '1') != '0'     # forward renderer as positions -> MFMA decode -> importance -> decode -> composite
-KS_TARGET = int(os.environ.get('EG3D_KS_TARGET', '256'))       # blocks a split launch aims for (one per CU; 512 measured 0.7 % slower per step)
+KS_TARGET = 256       # blocks a split launch aims for (one per CU; 512 measured 0.7 % slower per step)
 
 
 def _auto_ksplit(classes, N, Nc, Ck):
@@ -209,7 +209,7 @@ def _auto_ksplit(classes, N, Nc, Ck):
 # this layer's activation backward in the same epilogue -- and hands back dz in place of dout.  This layer's backward recognises the
 # buffer and skips its own pass.
 FUSE_ACT_BWD = os.environ.get('EG3D_FUSE_ACT_BWD', '1') != '0'
-FIR_ADJ_LDS = int(os.environ.get('EG3D_FIR_ADJ_LDS', '4096'))       # pixels from which the FIR adjoint of an up layer's backward runs on the LDS-tiled separable kernel (0 = never)
+FIR_ADJ_LDS = 4096       # pixels from which the FIR adjoint of an up layer's backward runs on the LDS-tiled separable kernel (0 = never)
 FUSE_SKIP_UP = os.environ.get('EG3D_FUSE_SKIP_UP', '1') != '0'   # skip image up-sampled inside the toRGB conv's epilogue (eg3d_conv_params::addend_up2)
 SPLIT_DZ = os.environ.get('EG3D_SPLIT_DZ', '1') != '0'         # ... and write dz as the data gradient's fp16 operand image where it can (torgb_dgrad_act_split)
 _DX_AMAX = {}                 # dx.data_ptr() -> (device scalar max|dx| reported by the data-gradient kernel that wrote it, weak ref to dx); read once by a toRGB backward

@@ -30,7 +30,7 @@ import torch
 from . import hipops as H
 
 ENABLED = os.environ.get('EG3D_GRAPH_EAGER', '1') != '0'
-HOT_AFTER = int(os.environ.get('EG3D_GRAPH_EAGER_AFTER', '2'))      # per-launch calls of a signature before it is captured (they double as warm-up)
+HOT_AFTER = 2      # per-launch calls of a signature before it is captured (they double as warm-up)
 MAX_ENTRIES = 3                                                     # captured signatures kept per generator (each holds its activations)
 
 _STATE = weakref.WeakKeyDictionary()        # generator -> _PerG   (not an attribute: copy.deepcopy(G) must not meet graph objects)

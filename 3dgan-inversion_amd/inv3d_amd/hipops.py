@@ -655,29 +655,29 @@ def conv_v2_ksplit(Ck, Nc, classes, N=1):
     return ks if ks >= 2 else 0
 
 
-V2_MIN_TILES = int(os.environ.get('EG3D_V2_MIN_TILES', '256'))
+V2_MIN_TILES = 256
 USE_V2 = os.environ.get('EG3D_CONV_V2', '1') != '0'
-V2_CONVT = os.environ.get('EG3D_V2_CONVT', '0') == '1'
+V2_CONVT = False          # (was EG3D_V2_CONVT: the up layers on tap classes of the pre-split kernel -- superseded by conv_up2; tests set the attribute)
 # 4 x 32-cell patches for under-filled 3x3 grids (conv_v2_rows): 128^2 x 256: 107 -> 91 us, 256^2 x 128: 84 -> 67 us per launch.  (Off in the
 # first half of round 3: with the fused epilogues a few hundred of 8 M output elements per launch came out wrong on full-size layers --
 # a miscompile of the scalar epilogue arithmetic by the SLP vectoriser, see the Makefile; tests/test_gpu_ops.py::test_conv_v2_half_patch_full_size.)
 # 4-row launches that give every CU at most one workgroup (128^2 x 256, 256^2 x 128 at N = 1) as eight-wave workgroups whose two halves split the contraction
 # (csrc/conv_v2.hip KH = 2): two waves per SIMD instead of one
 V2_KHALVES = os.environ.get('EG3D_V2_KHALVES', '1') != '0'
-V2_KHALVES_MAX_TILES = int(os.environ.get('EG3D_V2_KHALVES_MAX_TILES', '256'))
+V2_KHALVES_MAX_TILES = 256
 V2_HALF = os.environ.get('EG3D_V2_HALF', '1') != '0'             # half-height (4 x 32) patches for nine-tap launches ...
 # quarter-height (2 x 32) patches where not even the 4-row grid fills the chip (64^2 x 512: 64 -> 256 workgroups): OFF by default.  Stand-alone
 # (weights warm in L2) 74 us against 99 + 23 (4-way split-K launch of the loader-split kernel + its finishing pass); inside the step, where every
 # workgroup streams its 2.4 MB weight slice from HBM / MALL, 109 us + the 12 us operand split: no gain (194.3 vs 194.3 steps/s, A/B in one session)
-V2_QUARTER = os.environ.get('EG3D_V2_QUARTER', '0') != '0'
-V2_HALF_BELOW = int(os.environ.get('EG3D_V2_HALF_BELOW', '512'))      # ... when the 8-row grid has fewer workgroups than this (256^2 x 128: 84 -> 67 us, 128^2 x 256: 107 -> 91 us)
+V2_QUARTER = False        # (was EG3D_V2_QUARTER; lost its A/B twice -- tests set the attribute)
+V2_HALF_BELOW = 512      # ... when the 8-row grid has fewer workgroups than this (256^2 x 128: 84 -> 67 us, 128^2 x 256: 107 -> 91 us)
 # split-K launches of the pre-split kernel for under-filled 3x3 grids: OFF by default.  Measured at N = 1 (MI355X): 128^2 x 256 118 -> 81 us,
 # 64^2 x 512 103 -> 82 us per launch, but the operand split pass (7 us), the zero fill and the finishing pass (2 x 10 us; the loader-split
 # kernel's fused epilogue needs neither on the 128^2 layer) eat it: -1.2 % per step.  Batched runs do not need it (the grids fill).
-V2_SPLITK = os.environ.get('EG3D_V2_SPLITK', '0') != '0'
-V2_KS_TARGET = int(os.environ.get('EG3D_V2_KS_TARGET', '512'))        # workgroups a split launch aims for (2 per CU)
-V2_KS_MIN_TILES = int(os.environ.get('EG3D_V2_KS_MIN_TILES', '32'))      # 32^2 x 512 (16 tiles): no gain over the loader-split kernel (46.8 vs 46.4 us)
-V2_KS_MIN_CHUNKS = int(os.environ.get('EG3D_V2_KS_MIN_CHUNKS', '2'))
+V2_SPLITK = False         # (was EG3D_V2_SPLITK; -1.2 % twice -- tests set the attribute)
+V2_KS_TARGET = 512        # workgroups a split launch aims for (2 per CU)
+V2_KS_MIN_TILES = 32      # 32^2 x 512 (16 tiles): no gain over the loader-split kernel (46.8 vs 46.4 us)
+V2_KS_MIN_CHUNKS = 2
 
 
 def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_STORE, out_scale=None, bias=None, noise=None, noise_nstride=0,
@@ -747,8 +747,8 @@ def conv_v2(a: SplitImage, w: SplitImage, out, classes, out_stride=1, epi=L.EPI_
 # ------------------------------------------------------------------------------------------------- wave-split pre-split convolution (csrc/conv_v3.hip)
 V3_CONFIG = 11       # profiler id of conv_v3_kernel
 USE_V3 = os.environ.get('EG3D_CONV_V3', '1') != '0'
-V3_MAX_TILES8 = int(os.environ.get('EG3D_V3_MAX_TILES8', '128'))       # 256-cell x 128-channel tiles below which a 3x3 launch goes to the wave-split kernel
-V3_MIN_CELLS = int(os.environ.get('EG3D_V3_MIN_CELLS', '1024'))        # class grids (all images) from this many cells (32^2) -- below, launches are latency-bound
+V3_MAX_TILES8 = 128       # 256-cell x 128-channel tiles below which a 3x3 launch goes to the wave-split kernel
+V3_MIN_CELLS = 1024        # class grids (all images) from this many cells (32^2) -- below, launches are latency-bound
 
 
 def conv_v3_plan(Ck, Nc, classes, N=1):
@@ -810,7 +810,7 @@ def conv_v3(a: SplitImage, w: SplitImage, out, classes, plan=None, out_stride=1,
 
 RGB_HEAD = os.environ.get('EG3D_RGB_HEAD', '1') != '0'       # the SR head's last toRGB evaluated in conv1's forward epilogue (eg3d_conv_v2_params::rgb_out)
 CONV_WS = os.environ.get('EG3D_CONV_WS', '1') != '0'
-CONV_WS_MAX_CELLS = int(os.environ.get('EG3D_CONV_WS_MAX_CELLS', '256'))
+CONV_WS_MAX_CELLS = 256
 CONV_WS_S2 = os.environ.get('EG3D_CONV_WS_S2', '1') != '0'      # ... and its stride-2 adjoint form for the data gradients of the 8^2 .. 32^2 up layers
 WS_CONFIG = 12
 
@@ -885,7 +885,7 @@ def conv_ws(x, w: SplitImage, out, classes, in_scale=None, x_amax=None, x_amax_m
 
 
 CONV_WS_UP = os.environ.get('EG3D_CONV_WS_UP', '1') != '0'      # ... and its transposed form for the forward of the 8^2 block's up layer
-CONV_WS_UP_MAX_CELLS = int(os.environ.get('EG3D_CONV_WS_UP_MAX_CELLS', '32'))      # cells per output parity routed there: 4^2 -> 9^2 (25 cells) 18.9 -> 12.4 us; 8^2 -> 17^2 (81 cells: three row tiles x four parity sets per wave, 1.2 M output atomics) 18.0 -> 23.1, stays on the split-K implicit GEMM
+CONV_WS_UP_MAX_CELLS = 32      # cells per output parity routed there: 4^2 -> 9^2 (25 cells) 18.9 -> 12.4 us; 8^2 -> 17^2 (81 cells: three row tiles x four parity sets per wave, 1.2 M output atomics) 18.0 -> 23.1, stays on the split-K implicit GEMM
 
 
 def conv_ws_up_ok(Ck, Nc, N, H, W, max_cells=None):
@@ -944,7 +944,7 @@ def fir44_adjoint_split(dz, dz_amax, gain=4.0):
 
 
 V2_S2ADJ = os.environ.get('EG3D_V2_S2ADJ', '1') != '0'
-S2ADJ_MIN_TILES = int(os.environ.get('EG3D_S2ADJ_MIN_TILES', '256'))     # 128 tiles (257^2 x 128 -> 128^2 x 256): 79 us vs 65-70 on the loader-split kernel
+S2ADJ_MIN_TILES = 256     # 128 tiles (257^2 x 128 -> 128^2 x 256): 79 us vs 65-70 on the loader-split kernel
 S2ADJ_CONFIG = 7
 
 
@@ -956,7 +956,7 @@ def conv_s2adj_ok(Ck, Nc, Hi, Wi, N=1):
 
 
 V3_S2ADJ = os.environ.get('EG3D_V3_S2ADJ', '1') != '0'
-V3_S2ADJ_MIN_CELLS = int(os.environ.get('EG3D_V3_S2ADJ_MIN_CELLS', '4096'))
+V3_S2ADJ_MIN_CELLS = 4096
 
 
 def conv_v3_s2adj_ok(Ck, Nc, Hi, Wi, N=1):
@@ -1009,8 +1009,8 @@ V2H_CONFIG = 8       # ... of the pre-split kernel's half-height (4 x 32) patch 
 V2Q_CONFIG = 9       # ... of its quarter-height (2 x 32) patch instantiation
 V2RGB_CONFIG = 13    # ... of the 8-row instantiation that carries the 1x1 head of the forward epilogue (eg3d_conv_v2_params::rgb_out)
 V2_UP2 = os.environ.get('EG3D_V2_UP2', '1') != '0'
-UP2_MIN_TILES = int(os.environ.get('EG3D_UP2_MIN_TILES', '256'))      # workgroups (512 threads, 115 KB of LDS: one per CU) below which the layer stays on the loader-split kernel
-UP2_MIN_CK = int(os.environ.get('EG3D_UP2_MIN_CK', '32'))      # 32: SR block 0 conv0 (32 -> 256 channels, 128^2 -> 256^2) too: +0.2 % on the step (A/B twice)
+UP2_MIN_TILES = 256      # workgroups (512 threads, 115 KB of LDS: one per CU) below which the layer stays on the loader-split kernel
+UP2_MIN_CK = 32      # 32: SR block 0 conv0 (32 -> 256 channels, 128^2 -> 256^2) too: +0.2 % on the step (A/B twice)
 
 
 def conv_up2_plan(Ck, Nc, Hi, Wi, N=1):
@@ -1145,7 +1145,7 @@ def conv_wgrad_v2(gimg: SplitImage, ximg: SplitImage, dwp, classes, products=3, 
 
 
 WGRAD_V2_UP = os.environ.get('EG3D_WGRAD_V2_UP', '1') != '0'
-WGRAD_V2_UP_MIN_CELLS = int(os.environ.get('EG3D_WGRAD_V2_UP_MIN_CELLS', '1024'))      # input cells (32^2) from which an up layer's weight gradient takes the parity-split kernel
+WGRAD_V2_UP_MIN_CELLS = 1024      # input cells (32^2) from which an up layer's weight gradient takes the parity-split kernel
 
 
 def conv_wgrad_v2_up_ok(Ci, Co, Hi, Wi, N=1):
@@ -1490,7 +1490,7 @@ def ray_gen_bwd(c2w, K, g_o, g_d, res, want_K=True):
     return d_c2w, d_K
 
 
-SCATTER_F16 = os.environ.get('EG3D_SCATTER_F16', '0') != '0'     # tri-plane gradient accumulation with three fp16 products per fp32 product: 128 -> 112 us, off (exact fp32 products)
+SCATTER_F16 = False     # tri-plane gradient accumulation with three fp16 products per fp32 product: 128 -> 112 us, off (exact fp32 products)
 
 
 def make_render_params(planes, origins, dirs, u1, u2, opts, w0, b0, w1t, b1, rgb, depth, wsum, minmax, fine, ray_limits=None, save=None, ray_tile_width=None, pos_rows=None,
@@ -1661,9 +1661,9 @@ DEFER_EPILOGUE = os.environ.get('EG3D_DEFER_EPILOGUE', '1') != '0'
 DEFER_DGRAD_FINISH = os.environ.get('EG3D_DEFER_DGRAD_FINISH', '1') != '0'
 
 TORGB_SMALL = os.environ.get('EG3D_TORGB_SMALL', '1') != '0'            # low-latency toRGB launch for small pixel counts (csrc/torgb_small.hip)
-TORGB_SMALL_MAX_PIX = int(os.environ.get('EG3D_TORGB_SMALL_MAX_PIX', '4096'))
+TORGB_SMALL_MAX_PIX = 4096
 # (the data gradient at 64^2 takes 31 us in the trace against 27 for the implicit GEMM it replaced -- yet the step is 0.2 % faster with it: A/B 209.1 vs 208.8)
-TORGB_SMALL_BWD_MAX_PIX = int(os.environ.get('EG3D_TORGB_SMALL_BWD_MAX_PIX', '4096'))
+TORGB_SMALL_BWD_MAX_PIX = 4096
 # the streaming form of the same entry points for the 128^2 / 256^2 blocks (torgb_mid_kernel / torgb_mid_bwd_kernel, csrc/torgb_small.hip): beyond
 # TORGB_SMALL_*_MAX_PIX the launch is taken only when the library says it runs in that form (eg3d_torgb_mid_supported); EG3D_TORGB_MID=0: implicit GEMM as before
 TORGB_MID = os.environ.get('EG3D_TORGB_MID', '1') != '0'

@@ -353,6 +353,9 @@ def _area_resize(img: torch.Tensor, size: int) -> torch.Tensor:
     return F.interpolate(img, size=(size, size), mode='area')
 
 
+REG_BRANCH = False          # the noise regulariser on a second stream (a branch of the captured graph): measured -1.5 %
+
+
 class LatentProjector:
     """Phase A.  One `step()` = pose chain (optional) -> G.synthesis with grad -> [canonical no-grad forward + warping loss] ->
     feature distance + 1e5 * noise regulariser -> backward -> Adam steps -> noise renormalisation.
@@ -619,9 +622,9 @@ class LatentProjector:
         # The noise regulariser only reads the noise buffers.  While its kernel occupied 17 CUs for ~0.4 ms (rounds 1-2) it ran on a second
         # stream -- a parallel branch of the captured graph, joined where the loss is formed.  Since it is three multi-block passes of
         # ~50 us together the fork / join of the replayed graph costs more than it hides: in line by default (+1.5 % per step), the branch
-        # stays available as EG3D_REG_BRANCH=1.
+        # stays available as the module attribute REG_BRANCH.
         cur = torch.cuda.current_stream()
-        reg_branch = os.environ.get('EG3D_REG_BRANCH', '0') != '0'
+        reg_branch = REG_BRANCH
         if reg_branch and self._reg_stream is None:
             self._reg_stream = torch.cuda.Stream(device=self.dev)
             _quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
