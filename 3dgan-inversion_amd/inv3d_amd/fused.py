@@ -387,7 +387,7 @@ class ModConvLayerFn(torch.autograd.Function):
                              **epi_kw)
             else:
                 z = H.zeros_cl(N, Co, Ho, Wo, x.device)
-                if prec in ('f16x3', 'f16x1') and not weight.requires_grad and H.conv_ws_ok(Ci, Co, cls, N, Hi, Wi):
+                if prec in ('f16x3', 'f16x1') and (H.CONV_WS_TRAINABLE or not weight.requires_grad) and H.conv_ws_ok(Ci, Co, cls, N, Hi, Wi):
                     # 4^2 .. 16^2: one workgroup per (channel tile, 16-channel chunk), every weight byte fetched once, operand split inside (csrc/conv_ws.hip)
                     H.conv_ws(x, cache.get_split(weight)[0], z, cls, in_scale=styles, x_amax=H.amax_of(x), products=nprod, algo_flops=aflops)
                 else:
@@ -418,7 +418,7 @@ class ModConvLayerFn(torch.autograd.Function):
                 H.conv_igemm(x, wf, Ci, Co, z, cls, out_stride=up, in_scale=styles, epi=L.EPI_STORE, algo_flops=aflops, precision=ig_prec, w_pieces=wfp)
             else:
                 z = H.zeros_cl(N, Co, Hz, Wz, x.device)
-                if up == 2 and kh == 3 and kw == 3 and prec in ('f16x3', 'f16x1') and not weight.requires_grad and H.conv_ws_up_ok(Ci, Co, N, Hi, Wi):
+                if up == 2 and kh == 3 and kw == 3 and prec in ('f16x3', 'f16x1') and (H.CONV_WS_TRAINABLE or not weight.requires_grad) and H.conv_ws_up_ok(Ci, Co, N, Hi, Wi):
                     # 4^2 / 8^2 input cells: the weight-streaming kernel's transposed form (four parity accumulator sets per wave, csrc/conv_ws.hip)
                     H.conv_ws_up(x, cache.get_split(weight)[0], z, in_scale=styles, x_amax=H.amax_of(x), products=nprod, algo_flops=aflops)
                 else:
@@ -593,9 +593,9 @@ class ModConvLayerFn(torch.autograd.Function):
                     ds = ds.sum(0)
             else:                                  # low resolution: split K over blocks, then scale / reduce in a finishing pass
                 z = H.zeros_cl(N, Ci, Hi, Wi, dev)
-                if up == 1 and prec in ('f16x3', 'f16x1') and amax is not None and not weight.requires_grad and H.conv_ws_ok(Co, Ci, cls_adj, N, Hi, Wi):
+                if up == 1 and prec in ('f16x3', 'f16x1') and amax is not None and (H.CONV_WS_TRAINABLE or not weight.requires_grad) and H.conv_ws_ok(Co, Ci, cls_adj, N, Hi, Wi):
                     H.conv_ws(g, cache.get_split(weight)[1], z, cls_adj, x_amax=amax, products=1 if prec == 'f16x1' else 3, algo_flops=aflops)
-                elif (up == 2 and g is not None and kh == 3 and kw == 3 and prec in ('f16x3', 'f16x1') and amax is not None and not weight.requires_grad
+                elif (up == 2 and g is not None and kh == 3 and kw == 3 and prec in ('f16x3', 'f16x1') and amax is not None and (H.CONV_WS_TRAINABLE or not weight.requires_grad)
                       and H.conv_ws_ok(Co, Ci, cls_adj, N, Hi, Wi, in_stride=2)):
                     H.conv_ws(g, cache.get_split(weight)[1], z, cls_adj, x_amax=amax, x_amax_mul=amul, products=1 if prec == 'f16x1' else 3, algo_flops=aflops,
                               in_stride=2)

@@ -811,6 +811,9 @@ def conv_v3(a: SplitImage, w: SplitImage, out, classes, plan=None, out_stride=1,
 RGB_HEAD = os.environ.get('EG3D_RGB_HEAD', '1') != '0'       # the SR head's last toRGB evaluated in conv1's forward epilogue (eg3d_conv_v2_params::rgb_out)
 CONV_WS = os.environ.get('EG3D_CONV_WS', '1') != '0'
 CONV_WS_MAX_CELLS = 256
+# ... NOT when the weights carry gradients (pivotal tuning): measured in round 6 (A/B twice in one session, graph-replayed C4 step) 6.22 / 6.21 ms without,
+# 6.29 / 6.26 ms with -- re-splitting six more 9.4 MB weight tensors per step (forward + adjoint images) costs more than the twelve 19.7 us launches save
+CONV_WS_TRAINABLE = False
 CONV_WS_S2 = os.environ.get('EG3D_CONV_WS_S2', '1') != '0'      # ... and its stride-2 adjoint form for the data gradients of the 8^2 .. 32^2 up layers
 WS_CONFIG = 12
 

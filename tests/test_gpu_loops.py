@@ -411,7 +411,7 @@ def test_config_c2_at_full_size_trajectory(golden):
     g = lambda k: torch.from_numpy(np.asarray(d[k]))           # noqa: E731
     hip = LatentProjector(G, target, num_steps=steps, cam=g('cam').to(DEV), init_noise=pin['init_noise'], start_w=pin['w0'], w_std=IO.PIN_W_STD)
     ref = g('trace').double()
-    worst_db = worst_loss = 0.0
+    worst_db = worst_loss = worst_dist = 0.0
     for k in range(steps):
         u1, u2 = pin['uniforms'][k]
         h = hip.step(w_noise=pin['wns'][k], render_uniforms=(u1.to(DEV), u2.to(DEV)))
@@ -419,10 +419,11 @@ def test_config_c2_at_full_size_trajectory(golden):
         worst_loss = max(worst_loss, abs(got[0] - float(ref[k, 0])) / abs(float(ref[k, 0])))
         worst_db = max(worst_db, abs(got[3] - float(ref[k, 3])))
         assert abs(got[0] - float(ref[k, 0])) <= 1e-4 * abs(float(ref[k, 0])), (k, 'loss', got[0], float(ref[k, 0]))
-        assert abs(got[1] - float(ref[k, 1])) <= 2e-3 * max(1.0, abs(float(ref[k, 1]))), (k, 'dist', got[1], float(ref[k, 1]))
+        worst_dist = max(worst_dist, abs(got[1] - float(ref[k, 1])) / max(1.0, abs(float(ref[k, 1]))))
+        assert abs(got[1] - float(ref[k, 1])) <= 5e-4 * max(1.0, abs(float(ref[k, 1]))), (k, 'dist', got[1], float(ref[k, 1]))        # (`loss` is dominated by the 1e5-weighted regulariser: dist and PSNR are the informative bounds)
         assert abs(got[2] - float(ref[k, 2])) <= 1e-4 * max(1.0, abs(float(ref[k, 2]))), (k, 'reg', got[2], float(ref[k, 2]))
         assert abs(got[3] - float(ref[k, 3])) <= 1e-3, f'step {k}: PSNR drift {abs(got[3] - float(ref[k, 3])):.2e} dB vs the reference'
-    print(f'C2 full size, {steps} steps: worst PSNR drift {worst_db:.2e} dB, worst relative loss drift {worst_loss:.2e}')
+    print(f'C2 full size, {steps} steps: worst PSNR drift {worst_db:.2e} dB, worst relative loss drift {worst_loss:.2e}, worst dist drift {worst_dist:.2e}')
     assert float((hip.w_opt.detach().cpu() - g('w_opt')).abs().max()) < 5e-4
     bufs = {n: b for n, b in G.named_buffers() if 'noise_const' in n}
     nb = [b for n, b in bufs.items() if n.startswith('backbone.')][-1].detach().flatten().cpu()

@@ -649,6 +649,9 @@ def test_render_vs_oracle(variant):
     close(gg[0], gr[0], 1e-4, f'{variant} d planes'); close_most(gg[1], gr[1], 1e-4, f'{variant} d origins'); close_most(gg[2], gr[2], 1e-4, f'{variant} d dirs')
 
 
+ORACLE_BIN_MISMATCHES = {'random': 19, 'det': None, 'ties': None}          # observed in round 6, both builds (None: printed, not yet pinned)
+
+
 @pytest.mark.parametrize('variant', ['random', 'det', 'ties', 'no_grad_fused'])
 def test_sampler_indices_exact(variant):
     """The integer side of the sampler at 110 592 rays x (48 + 48) samples (renderer.py:281-307 sample_pdf: searchsorted(right=True), the
@@ -732,7 +735,13 @@ def test_sampler_indices_exact(variant):
     # (det=True puts its last uniform exactly ON the last edge, u = 1.0 = cdf[ns] up to rounding: which side it falls on is the rounding of a
     #  48-term sum -- a third of the rays differ there, and only there)
     at_end = (u2 >= 1.0).expand_as(bad)
-    assert int((bad & ~at_end).sum()) <= 2e-4 * bad.numel(), f'{int((bad & ~at_end).sum())} of {bad.numel()} bin indices differ from the oracle'
+    n_off = int((bad & ~at_end).sum())
+    print(f'sampler indices [{variant}]: mismatches away from u = 1: {n_off}')
+    # the kernel's scan and the oracle's cumsum are both deterministic: the count is a constant of (seed, variant), observed in round 6 in both builds
+    # (a bound of 2e-4 x 5.3 M = 1061 would let sixty times as many through)
+    assert n_off <= 2e-5 * bad.numel()
+    if ORACLE_BIN_MISMATCHES[variant] is not None:
+        assert n_off == ORACLE_BIN_MISMATCHES[variant], f'{n_off} of {bad.numel()} bin indices differ from the oracle, expected exactly {ORACLE_BIN_MISMATCHES[variant]}'
     if nbad:
         # every mismatch: u within rounding of the edge the two sides disagree about
         r_i, s_i = bad.nonzero(as_tuple=True)
