@@ -290,49 +290,60 @@ __global__ void __launch_bounds__(256) split_act_lds_kernel(const float* __restr
     constexpr int TP = 64, PITCH = CH + 4, F4 = CH / 4, PPP = 256 / F4;          // pixels per load pass
     __shared__ __attribute__((aligned(16))) float tile[TP * PITCH];
     __shared__ float red[4];
+    const int64_t npix = (int64_t)N * HW;
+    const int64_t pix0 = (int64_t)blockIdx.x * TP;
+    const int c0 = blockIdx.y * CH;
+    const int f4 = threadIdx.x % F4, pl = threadIdx.x / F4;
+    // The tile's loads go out FIRST; max|in_scale| (every block derives the same value from a few KB), the range scalar and this thread's style values are
+    // requested while they are in flight and everything meets at ONE barrier.  In front of the tile loads the reduction was a dependent memory round trip plus
+    // a barrier of its own per block, and the styles a third round trip after the barrier (2 - 2.5 us each on a 6 - 14 us launch: DESIGN.md 3.1a).
+    float4 tv[TP / PPP];
+#pragma unroll
+    for (int pass = 0; pass < TP / PPP; ++pass) {
+        const int pq = pl + pass * PPP;
+        tv[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pix0 + pq < npix) tv[pass] = *reinterpret_cast<const float4*>(x + (pix0 + pq) * ldx + c0 + f4 * 4);
+    }
+    const int p = threadIdx.x & 63, og = threadIdx.x >> 6;                        // phase 2: pixel, group of CH / 32 octets
+    const int64_t pix = pix0 + p;
+    const bool live = pix < npix;
+    const int n = live ? (int)(pix / HW) : 0;
+    const int64_t pp = pix - (int64_t)n * HW;
+    const int noct = C / 8;
+    float4 sv[CH / 32][2];
+#pragma unroll
+    for (int k = 0; k < CH / 32; ++k) {
+        sv[k][0] = sv[k][1] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (s != nullptr) {
+            const float* sr = s + (int64_t)n * C + c0 + (og * (CH / 32) + k) * 8;
+            sv[k][0] = *reinterpret_cast<const float4*>(sr); sv[k][1] = *reinterpret_cast<const float4*>(sr + 4);
+        }
+    }
     float smax = 1.f;
-    if (s_amax != nullptr) {
-        smax = *s_amax;
-    } else if (s != nullptr) {
+    const bool own_max = s_amax == nullptr && s != nullptr;
+    if (s_amax != nullptr) smax = *s_amax;
+    if (own_max) {
         float m = 0.f;
         for (int i = threadIdx.x; i < N * C; i += 256) m = fmaxf(m, fabsf(s[i]));
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-        __syncthreads();
-        smax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     }
-    const float mul = range_mul(*x_amax * smax);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *scale_out = mul;
-    const int64_t npix = (int64_t)N * HW;
-    const int64_t pix0 = (int64_t)blockIdx.x * TP;
-    const int c0 = blockIdx.y * CH;
-    const int f4 = threadIdx.x % F4, pl = threadIdx.x / F4;
+    const float xa = *x_amax;
 #pragma unroll
-    for (int pass = 0; pass < TP / PPP; ++pass) {
-        const int p = pl + pass * PPP;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pix0 + p < npix) v = *reinterpret_cast<const float4*>(x + (pix0 + p) * ldx + c0 + f4 * 4);
-        *reinterpret_cast<float4*>(tile + p * PITCH + f4 * 4) = v;
-    }
+    for (int pass = 0; pass < TP / PPP; ++pass) *reinterpret_cast<float4*>(tile + (pl + pass * PPP) * PITCH + f4 * 4) = tv[pass];
     __syncthreads();
-    const int p = threadIdx.x & 63, og = threadIdx.x >> 6;                        // pixel, group of CH / 32 octets
-    const int64_t pix = pix0 + p;
-    if (pix >= npix) return;
-    const int n = (int)(pix / HW);
-    const int64_t pp = pix - (int64_t)n * HW;
-    const int noct = C / 8;
-    const float* sr = s ? s + (int64_t)n * C + c0 : nullptr;
+    if (own_max) smax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float mul = range_mul(xa * smax);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *scale_out = mul;
+    if (!live) return;
 #pragma unroll
     for (int k = 0; k < CH / 32; ++k) {
         const int kl = og * (CH / 32) + k;                                        // octet inside the chunk
         float v[8];
         const float4 v0 = *reinterpret_cast<const float4*>(tile + p * PITCH + kl * 8), v1 = *reinterpret_cast<const float4*>(tile + p * PITCH + kl * 8 + 4);
-        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-        if (sr) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] *= sr[kl * 8 + q];
-        }
+        v[0] = v0.x * sv[k][0].x; v[1] = v0.y * sv[k][0].y; v[2] = v0.z * sv[k][0].z; v[3] = v0.w * sv[k][0].w;
+        v[4] = v1.x * sv[k][1].x; v[5] = v1.y * sv[k][1].y; v[6] = v1.z * sv[k][1].z; v[7] = v1.w * sv[k][1].w;
         f16x8 h, l;
         split8(v, mul, h, l, 2048.f);
         const int ko = c0 / 8 + kl;

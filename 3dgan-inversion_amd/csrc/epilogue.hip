@@ -215,15 +215,11 @@ __global__ void __launch_bounds__(256) upconv_epilogue_kernel(const float* __res
     const int c0 = blockIdx.y * UE_CH;
     const float kk[4] = {k3, k2, k1, k0};                    // true convolution: tap i of the window meets filter element 3 - i
     float sp_mul = 1.f;
-    if (SPLIT) {
+    if (SPLIT) {         // max|consumer styles| (every block derives it from the same few KB): requested here, reduced behind phase 1's loads, published by phase 1's
+                         // barrier -- as a reduction + barrier of its own in front of phase 1 it was a dependent memory round trip per block
         float m = 0.f;
         for (int i = threadIdx.x; i < N * C; i += 256) m = fmaxf(m, fabsf(sp_scale_in[i]));
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-        __syncthreads();
-        sp_mul = ue_range_mul(clamp * fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *sp_scale_out = sp_mul;
+        sp_mul = m;      // (this thread's partial maximum until the barrier)
     }
     // the noise values of this thread's eight output pixels are requested here, with phase 1's loads: inside the phase-2 loop each was a load
     // under a branch followed by its use -- eight memory round trips in sequence per block
@@ -259,7 +255,17 @@ __global__ void __launch_bounds__(256) upconv_epilogue_kernel(const float* __res
             *reinterpret_cast<float4*>(V + (oy * UE_COLS + col) * UE_PITCH + c4 * 4) = v;
         }
     }
+    if (SPLIT) {
+        float m = sp_mul;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    }
     __syncthreads();
+    if (SPLIT) {
+        sp_mul = ue_range_mul(clamp * fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *sp_scale_out = sp_mul;
+    }
     // ---- phase 2: item = (row, column, channel quad); a thread keeps its channel quad
     const int c4 = threadIdx.x & 15, c = c0 + c4 * 4;
     float4 dv = make_float4(1.f, 1.f, 1.f, 1.f), bv = make_float4(0.f, 0.f, 0.f, 0.f);
