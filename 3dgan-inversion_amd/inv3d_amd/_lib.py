@@ -90,7 +90,7 @@ class ConvUp2Params(C.Structure):
     _fields_ = [('a', C.c_void_p), ('w', C.c_void_p), ('a_scale', C.c_void_p), ('w_scale', C.c_void_p), ('out', C.c_void_p),
                 ('N', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32), ('Ck', C.c_int32), ('Nc', C.c_int32),
                 ('Hc', C.c_int32), ('Wc', C.c_int32), ('Ho', C.c_int32), ('Wo', C.c_int32), ('ldo', C.c_int32),
-                ('wtap', C.c_int32 * 9), ('epi', C.c_int32), ('products', C.c_int32), ('ksplit', C.c_int32)]
+                ('wtap', C.c_int32 * 9), ('epi', C.c_int32), ('products', C.c_int32), ('ksplit', C.c_int32), ('patch_rows', C.c_int32)]
 
 
 class WgradParams(C.Structure):

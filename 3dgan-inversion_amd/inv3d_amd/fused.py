@@ -398,16 +398,16 @@ class ModConvLayerFn(torch.autograd.Function):
                     H.epilogue_fwd(z, out, d=d, out_amax=amax_out, **epi_kw)
         else:
             if ksu:
-                ksplit, ragged = ksu
+                ksplit, ragged, urows = ksu
                 z = H.zeros_cl(N, Co, Hz, Wz, x.device) if ksplit > 1 else H.empty_cl(N, Co, Hz, Wz, x.device)
                 if ragged:      # the full (Hi + 1) x (Wi + 1) cell grid still fits one round of workgroups
-                    H.conv_up2(aimg, wimg, z, epi=L.EPI_ATOMIC if ksplit > 1 else L.EPI_STORE, ksplit=ksplit, products=nprod, algo_flops=aflops)
+                    H.conv_up2(aimg, wimg, z, epi=L.EPI_ATOMIC if ksplit > 1 else L.EPI_STORE, ksplit=ksplit, products=nprod, algo_flops=aflops, patch_rows=urows)
                 else:
                     # main grid (Hi x Wi cells, perfectly tiled) on the fused-parity kernel; the last output row / column (1-D problems, ~20 us
                     # of latency for 0.1 GFLOP) as four small tap classes of the loader-split kernel.  (Forking that launch onto a second
                     # stream hides it at N = 1 -- but two processes sharing one device then replayed the two-branch graph at 1.2 s per step:
                     # not worth the risk on an 8-rank node.)
-                    H.conv_up2(aimg, wimg, z, Hc=Hi, Wc=Wi, epi=L.EPI_ATOMIC if ksplit > 1 else L.EPI_STORE, ksplit=ksplit, products=nprod, algo_flops=aflops)
+                    H.conv_up2(aimg, wimg, z, Hc=Hi, Wc=Wi, epi=L.EPI_ATOMIC if ksplit > 1 else L.EPI_STORE, ksplit=ksplit, products=nprod, algo_flops=aflops, patch_rows=urows)
                     H.conv_igemm(x, wf, Ci, Co, z, H.up2_border_classes(Hi, Wi), out_stride=up, in_scale=styles, epi=L.EPI_STORE, algo_flops=0.0,
                                  precision=ig_prec, w_pieces=wfp)
             elif v2:

@@ -1025,11 +1025,25 @@ def conv_up2_plan(Ck, Nc, Hi, Wi, N=1):
     CU); otherwise the main Hi x Wi grid (perfectly tiled) + the last output row / column as border classes of the loader-split kernel."""
     if not (USE_V2 and V2_UP2) or CONV_MODE != 'auto' or Ck % 16 or Nc % 64 or Ck < UP2_MIN_CK or Hi < 8 or Wi < 32:
         return None
-    tiles = N * -(-Hi // 8) * -(-Wi // 32) * (Nc // 64)
-    if tiles < UP2_MIN_TILES:
+    # 8 x 32-cell patches (eight waves, one workgroup per CU) when they fill the chip; else 4 x 32-cell patches (conv_v2_up2r_kernel: four waves, tap-row weight
+    # ring, two workgroups per CU) when THOSE do -- the backbone's 128^2 -> 256^2 layer at one image (128 -> 256 workgroups)
+    tiles8 = N * -(-Hi // 8) * -(-Wi // 32) * (Nc // 64)
+    tiles4 = N * -(-Hi // 4) * -(-Wi // 32) * (Nc // 64)
+    if tiles8 >= UP2_MIN_TILES:
+        rows = 8
+    elif UP2_ROWS4 and tiles4 >= UP2_MIN_TILES:
+        rows = 4
+    else:
         return None
-    ragged = N * -(-(Hi + 1) // 8) * -(-(Wi + 1) // 32) * (Nc // 64) <= 256
-    return 1, ragged
+    # ragged: the full (Hi + 1) x (Wi + 1) cell grid in one launch when it still fits one round of workgroups (8 rows: one per CU; 4 rows: two per CU)
+    ragged = N * -(-(Hi + 1) // rows) * -(-(Wi + 1) // 32) * (Nc // 64) <= (512 if rows == 4 else 256)
+    return 1, ragged, rows
+
+
+# Round 6, A/B in one session (EG3D_UP2_ROWS4=0 | 1 for ALL up2 launches): the SR layers do not care (256^2 x 256 -> 128: 116.9 vs 117.0 us -- 0.99 PFLOP/s executed
+# either way, the kernel is at the matrix pipe's sustained rate, not waiting for its epilogue; 128^2 x 32 -> 256: 23.3 vs 27.4 us), the backbone's b256 conv0 leaves the
+# loader-split kernel: 64.7 -> 7.9 (operand split) + 50.3 us.  Hence: 4-row patches only where the 8-row grid does not fill the chip.
+UP2_ROWS4 = True
 
 
 def up2_border_classes(Hi, Wi, kh=3, kw=3):
@@ -1043,7 +1057,7 @@ def up2_border_classes(Hi, Wi, kh=3, kw=3):
             _mk_class(Hi, 1, 1, 2 * Wi, [(0, Wi - 1, wt(1, 2))])]
 
 
-def conv_up2(a: SplitImage, w: SplitImage, out, Hc=None, Wc=None, epi=L.EPI_STORE, ksplit=1, products=3, algo_flops=None):
+def conv_up2(a: SplitImage, w: SplitImage, out, Hc=None, Wc=None, epi=L.EPI_STORE, ksplit=1, products=3, algo_flops=None, patch_rows=8):
     """Launch eg3d_conv2d_up2: out [N,Co,2Hi+1,2Wi+1] channels_last (+)= transposed 3x3 stride-2 conv of the split image `a` with the
     forward weight image `w`, for the cells a < Hc, b < Wc (default: the full (Hi + 1) x (Wi + 1) grid)."""
     assert is_cl(out)
@@ -1058,7 +1072,7 @@ def conv_up2(a: SplitImage, w: SplitImage, out, Hc=None, Wc=None, epi=L.EPI_STOR
     p.Ho, p.Wo, p.ldo = ho, wo, co
     for t in range(9):
         p.wtap[t] = t
-    p.epi, p.products, p.ksplit = epi, int(products), int(ksplit)
+    p.epi, p.products, p.ksplit, p.patch_rows = epi, int(products), int(ksplit), int(patch_rows)
     prof = PROFILER
     if prof is not None and prof.only_config is not None and prof.only_config != UP2_CONFIG:
         prof = None

@@ -326,6 +326,7 @@ typedef struct eg3d_conv_up2_params {
     int32_t Ho, Wo, ldo;
     int32_t wtap[9];           /* weight tap index of (ky, kx) = (t / 3, t % 3)                                               */
     int32_t epi, products, ksplit;
+    int32_t patch_rows;        /* 0 | 8: 8 x 32-cell patches, eight waves, one workgroup per CU; 4: 4 x 32 cells, four waves, tap-row weight ring, two per CU */
 } eg3d_conv_up2_params;
 int eg3d_conv2d_up2_supported(const eg3d_conv_up2_params* p);
 int eg3d_conv2d_up2(const eg3d_conv_up2_params* p, void* stream);

@@ -1352,7 +1352,8 @@ def test_conv_v2_transposed_classes_vs_torch(shape):
 
 @pytest.mark.parametrize('shape,ks', [((1, 64, 16, 32, 64), 1), ((2, 32, 20, 33, 128), 1), ((1, 128, 8, 64, 64), 4), ((1, 48, 19, 40, 192), 3)])
 @pytest.mark.parametrize('products', [3, 1])
-def test_conv_up2_fused_parity_vs_torch(shape, ks, products):
+@pytest.mark.parametrize('rows', [8, 4])          # 4: conv_v2_up2r_kernel (four waves, tap-row weight ring, two workgroups per CU: round 6)
+def test_conv_up2_fused_parity_vs_torch(shape, ks, products, rows):
     """The fused-parity transposed-conv kernel (csrc/conv_v2_up.hip): all four output parities of the stride-2 3x3 transposed conv from
     one workgroup per 8 x 32 input patch, (i) on the full ragged (Hi + 1) x (Wi + 1) cell grid and (ii) as the model runs it: main grid
     Hi x Wi + the last output row / column as four tap classes of the loader-split kernel; with and without split-K, both arithmetics."""
@@ -1369,12 +1370,12 @@ def test_conv_up2_fused_parity_vs_torch(shape, ks, products):
     epi = L.EPI_ATOMIC if ks > 1 else L.EPI_STORE
     mk = (lambda: torch.zeros((n, co, hz, wz), device=DEV).contiguous(memory_format=torch.channels_last)) if ks > 1 else (lambda: H.empty_cl(n, co, hz, wz, DEV))
     z = mk()
-    H.conv_up2(aimg, wimg, z, epi=epi, ksplit=ks, products=products)
+    H.conv_up2(aimg, wimg, z, epi=epi, ksplit=ks, products=products, patch_rows=rows)
     close(z, ref.float(), tol, f'conv_up2 full grid {shape} x{ks}')
     z2 = mk()
     if ks == 1:
         z2.fill_(float('nan'))             # every output pixel must be written by exactly one of the two launches
-    H.conv_up2(aimg, wimg, z2, Hc=h, Wc=w, epi=epi, ksplit=ks, products=products)
+    H.conv_up2(aimg, wimg, z2, Hc=h, Wc=w, epi=epi, ksplit=ks, products=products, patch_rows=rows)
     H.conv_igemm(xc, H.pack_weight_fwd(wt.to(DEV)), ci, co, z2, H.up2_border_classes(h, w), out_stride=2, in_scale=s.to(DEV), epi=L.EPI_STORE, precision='f16x3')
     close(z2, ref.float(), tol, f'conv_up2 main grid + border classes {shape} x{ks}')
 

@@ -15,7 +15,7 @@ import re, sys, argparse
 def kernel_body(lines, key):
     start = None
     for i, l in enumerate(lines):
-        if l.startswith('_Z') and key in l and l.rstrip().split(':')[0].endswith('paramsi') and ':' in l:
+        if l.startswith('_Z') and key in l and re.match(r'^_Z\w+:', l):
             start = i
         elif start is not None and l.strip().startswith('.end_amdhsa_kernel'):
             return lines[start:i]

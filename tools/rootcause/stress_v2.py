@@ -82,13 +82,13 @@ def case_v2_convT(n, ci, h, co):
     return launch
 
 
-def case_up2(n, ci, h, co):
+def case_up2(n, ci, h, co, rows=8):
     o = operands(n, ci, h, h, co)
     z = H.empty_cl(n, co, 2 * h + 1, 2 * h + 1, DEV)
     z.zero_()
 
     def launch():
-        H.conv_up2(o['aimg'], o['wimg'], z, Hc=h, Wc=h, epi=L.EPI_STORE)
+        H.conv_up2(o['aimg'], o['wimg'], z, Hc=h, Wc=h, epi=L.EPI_STORE, patch_rows=rows)
         return [z]
     return launch
 
@@ -163,6 +163,9 @@ CASES = {
     # the up-sampling layers: fused-parity forward, parity-split adjoint
     'up2_256x256to128': lambda: case_up2(1, 256, 256, 128),
     'up2_128x256to256': lambda: case_up2(1, 256, 128, 256),
+    'up2r4_256x256to128': lambda: case_up2(1, 256, 256, 128, rows=4),
+    'up2r4_128x256to128': lambda: case_up2(1, 256, 128, 128, rows=4),
+    'up2r4_128x32to256': lambda: case_up2(1, 32, 128, 256, rows=4),
     's2adj_256x256from128': lambda: case_s2adj(1, 256, 256, 128),
     's2adj_128x256from256': lambda: case_s2adj(1, 256, 128, 256),
     's2adj_v3_64x512': lambda: case_s2adj(1, 512, 64, 256, v3=True),
