@@ -82,6 +82,24 @@ def _launch_groups(x, wp, Ck, Nc, out, classes, accumulate, **kw):
         H.conv_igemm(x, wp, Ck, Nc, out, classes[i:i + 4], epi=L.EPI_ATOMIC if accumulate else L.EPI_STORE, **dict(dict(precision=LOSS_NET_PRECISION), **kw))
 
 
+LOSS_NET_PRESPLIT = os.environ.get('EG3D_LOSS_NET_PRESPLIT', '1') != '0'          # 3x3 stride-1 layers of the frozen loss networks on the pre-split kernels (conv_v3 / conv_ws) instead of the loader-split one
+
+
+def _presplit_plan(Ck, Nc, classes, N, H_, W_):
+    """How a frozen 3x3 / stride-1 / pad-1 layer (Ck -> Nc channels on an H_ x W_ grid) runs on the pre-split kernels: ('v3', (rows, waves)) -- the wave-split
+    kernel with its fused bias + activation epilogue (csrc/conv_v3.hip), ('ws', None) -- the weight-streaming kernel for <= 256 cells (csrc/conv_ws.hip,
+    accumulates into a zeroed buffer), or None (loader-split implicit GEMM).  Round 6: VGG16 at 256^2 spends 1.0 of its 1.45 ms in thirteen 30 - 50 us launches
+    of the loader-split kernel at 50 - 130 TFLOP/s plus a bias pass and an absmax pass per layer."""
+    if not LOSS_NET_PRESPLIT or len(classes) != 1 or classes[0].ntaps != 9 or Ck % 16 or H.CONV_MODE != 'auto' or not H.USE_V2:
+        return None
+    if Nc % 32 == 0 and N * H_ * W_ >= 256 and H.conv_ws_ok(Ck, Nc, classes, N, H_, W_):          # (16^2: VGG16 conv5_x; smaller grids -- LPIPS-Alex at 128^2 -- stay where they were)
+        return 'ws', None
+    if Nc % 64 or not H.USE_V3 or N * H_ * W_ < 1024:
+        return None
+    wg4 = N * -(-H_ // 4) * -(-W_ // 32) * (Nc // 64)
+    return 'v3', ((4, 4) if wg4 >= 192 else (2, 8))
+
+
 class _ConvActFn(torch.autograd.Function):
     """y = act(conv2d(x, w, stride, pad) + b).  x, y: fp32 channels-last, channel counts multiples of 4.  The loss networks call it
     with frozen w, b (forward + data gradient); with trainable w / b (the pose estimator, pose_net.py) the weight gradient comes from
@@ -108,7 +126,18 @@ class _ConvActFn(torch.autograd.Function):
         if f16:             # operand range: the producer's report if the tensor carries one, else one reduction pass (hipops.amax_of)
             pk = dict(precision='f16x3', a_amax=H.amax_of(x), w_pieces=H.memo(('lossnet_fwd_pieces', Cip), [weight], lambda: H.split_weight_pieces(wf)))
         y_amax = None
-        if len(cls) == 1 and ks == 1:
+        route = _presplit_plan(Cip, Co, cls, N, Ho, Wo) if (f16 and kh == 3 and kw == 3 and stride == 1 and pad == 1) else None
+        if route is not None and route[0] == 'v3':
+            wimg = H.memo(('lossnet_fwd_split', Cip), [weight], lambda: H.split_weight(wf, Co, Cip, 9))
+            y = H.empty_cl(N, Co, Ho, Wo, x.device)
+            y_amax = H.zeros((1,), x.device)
+            H.conv_v3(H.split_activation(x, H.amax_of(x)), wimg, y, cls, plan=route[1], epi=L.EPI_FWD, bias=bias, act=act, alpha=alpha, gain=gain, out_amax=y_amax)
+        elif route is not None:
+            wimg = H.memo(('lossnet_fwd_split', Cip), [weight], lambda: H.split_weight(wf, Co, Cip, 9))
+            z = H.zeros_cl(N, Co, Ho, Wo, x.device)
+            H.conv_ws(x, wimg, z, cls, x_amax=H.amax_of(x))
+            y = H.bias_act_raw(z, bias, None, None, None, 0, 1, L.ACT_IDS[act], alpha, gain, -1.0)
+        elif len(cls) == 1 and ks == 1:
             y = H.empty_cl(N, Co, Ho, Wo, x.device)
             y_amax = H.zeros((1,), x.device) if f16 else None
             H.conv_igemm(x, wf, Cip, Co, y, cls, in_stride=stride, epi=L.EPI_FWD, bias=bias, act=act, alpha=alpha, gain=gain, out_amax=y_amax,
@@ -158,7 +187,19 @@ class _ConvActFn(torch.autograd.Function):
             pk = {}
             if ctx.f16 and amax is not None and not need_w:
                 pk = dict(precision='f16x3', a_amax=amax, w_pieces=H.memo(('lossnet_adj_pieces', Cip), [weight], lambda: H.split_weight_pieces(wa)))
-            _launch_groups(dz, wa, Co, Cip, dx, cls, overlapping, out_stride=stride, ksplit=ks, **pk)
+            route = _presplit_plan(Co, Cip, cls, N, Hi, Wi) if (pk and kh == 3 and kw == 3 and stride == 1 and pad == 1 and len(cls) == 1) else None
+            if route is not None:
+                wimg = H.memo(('lossnet_adj_split', Cip), [weight], lambda: H.split_weight(wa, Cip, Co, 9))
+                if route[0] == 'v3':
+                    if overlapping:
+                        dx = H.empty_cl(N, Cip, Hi, Wi, dy.device)        # (split-K was planned for the loader-split kernel: the wave-split one writes every pixel once)
+                    H.conv_v3(H.split_activation(dz, amax), wimg, dx, cls, plan=route[1], epi=L.EPI_STORE)
+                else:
+                    if not overlapping:
+                        dx = H.zeros_cl(N, Cip, Hi, Wi, dy.device)
+                    H.conv_ws(dz, wimg, dx, cls, x_amax=amax)
+            else:
+                _launch_groups(dz, wa, Co, Cip, dx, cls, overlapping, out_stride=stride, ksplit=ks, **pk)
         if need_w:
             dwp = H.zeros((Co, kh * kw * Cip), dy.device)
             cls = _classes_strided(Ho, Wo, kh, kw, pad)
@@ -703,10 +744,17 @@ class _LpipsBase(torch.nn.Module):
         for i, c in enumerate(chns):
             self.add_module(f'lin{i}', _Lin(c))
 
+    accepts_cl4 = True          # [N,4,H,W] channels-last images with a zero fourth channel (hipops / loss_nets.image_prepare) are taken as they are
+
     def _input(self, img):
-        if self.input_range == '255':
-            return _image_cl4(img, self.shift, self.scale, 2.0 / 255.0, -1.0)
-        return _image_cl4(img, self.shift, self.scale, 1.0, 0.0)
+        pre_mul, pre_add = (2.0 / 255.0, -1.0) if self.input_range == '255' else (1.0, 0.0)
+        if img.dim() == 4 and img.shape[1] == 4 and H.is_cl(img) and img.dtype == torch.float32:
+            # the projector's one-pass image (scale, shift, area resize, 4-float pixels): the LPIPS input normalisation is one fused multiply-add on it
+            # (fourth channel: 0 * x + 0) instead of slice / scale / shift / divide / concatenate / layout passes (13 launches + their backward)
+            a = torch.cat([pre_mul / self.scale, self.scale.new_zeros(1)]).view(1, 4, 1, 1)
+            b = torch.cat([(pre_add - self.shift) / self.scale, self.scale.new_zeros(1)]).view(1, 4, 1, 1)
+            return torch.addcmul(b, img, a)
+        return _image_cl4(img, self.shift, self.scale, pre_mul, pre_add)
 
     def _head(self, taps):
         return lpips_features(taps, [getattr(self, f'lin{i}').sqrt_weight() for i in range(len(self.chns))])

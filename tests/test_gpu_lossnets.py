@@ -295,3 +295,22 @@ def test_stub_pyramid_direct_kernels_match_the_oracle(n, res, upto):
     for l, (a, b) in enumerate(zip(got_o, gen_o)):
         close(a, b, 2e-6, f'level {l} vs generic path')
     close(got_g, gen_g, 5e-6, 'd img vs generic path')
+
+
+@pytest.mark.parametrize('input_range', ['255', 'pm1'])
+def test_lpips_nets_take_the_one_pass_four_channel_image(input_range):
+    """Round 6: VGG16LPIPS / LPIPSAlex accept the projector's [N,4,H,W] channels-last image (fourth channel zero; loss_nets.image_prepare) and apply the LPIPS
+    input normalisation as ONE fused multiply-add on it -- same features and the same image gradient as the RGB path (slice / scale / shift / divide / concatenate)."""
+    from inv3d_amd.loss_nets import VGG16LPIPS
+    net = VGG16LPIPS(input_range=input_range).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    rgb = torch.rand(2, 3, 64, 64, generator=g)
+    rgb = (rgb * 255 if input_range == '255' else rgb * 2 - 1).to(DEV)
+    a = rgb.clone().requires_grad_(True)
+    b4 = torch.cat([rgb, torch.zeros(2, 1, 64, 64, device=DEV)], 1).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    fa, fb = net(a), net(b4)
+    close(fb, fa, 2e-6, 'features from the 4-channel image')
+    ga, = torch.autograd.grad(fa.square().sum(), a)
+    gb, = torch.autograd.grad(fb.square().sum(), b4)
+    close(gb[:, :3], ga, 2e-5, 'image gradient through the 4-channel input')
+    assert float(gb[:, 3].abs().max()) == 0.0
