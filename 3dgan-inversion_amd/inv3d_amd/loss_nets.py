@@ -751,9 +751,13 @@ class _LpipsBase(torch.nn.Module):
         if img.dim() == 4 and img.shape[1] == 4 and H.is_cl(img) and img.dtype == torch.float32:
             # the projector's one-pass image (scale, shift, area resize, 4-float pixels): the LPIPS input normalisation is one fused multiply-add on it
             # (fourth channel: 0 * x + 0) instead of slice / scale / shift / divide / concatenate / layout passes (13 launches + their backward)
-            a = torch.cat([pre_mul / self.scale, self.scale.new_zeros(1)]).view(1, 4, 1, 1)
-            b = torch.cat([(pre_add - self.shift) / self.scale, self.scale.new_zeros(1)]).view(1, 4, 1, 1)
-            return torch.addcmul(b, img, a)
+            key = (self.scale.data_ptr(), self.scale._version, self.shift.data_ptr(), self.shift._version, img.device)
+            if getattr(self, '_cl4_key', None) != key:          # (constants of the network: formed once, not nine tiny launches per replayed step)
+                with torch.no_grad():
+                    self._cl4_a = torch.cat([pre_mul / self.scale, self.scale.new_zeros(1)]).view(1, 4, 1, 1).to(img.device)
+                    self._cl4_b = torch.cat([(pre_add - self.shift) / self.scale, self.scale.new_zeros(1)]).view(1, 4, 1, 1).to(img.device)
+                self._cl4_key = key
+            return torch.addcmul(self._cl4_b, img, self._cl4_a)
         return _image_cl4(img, self.shift, self.scale, pre_mul, pre_add)
 
     def _head(self, taps):
