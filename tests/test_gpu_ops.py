@@ -1380,6 +1380,26 @@ def test_conv_up2_fused_parity_vs_torch(shape, ks, products, rows):
     close(z2, ref.float(), tol, f'conv_up2 main grid + border classes {shape} x{ks}')
 
 
+def test_conv_up2_patch_heights_are_bit_identical():
+    """conv_v2_up2_kernel (8 x 32 cells, eight waves) and conv_v2_up2r_kernel (4 x 32 cells, four waves, tap-row weight ring) accumulate every output in the same
+    order -- chunk-major, taps in (ky, kx) order -- so their results must be equal bit for bit, on a ragged grid, at the backbone's b256 conv0 shape and with the
+    single-product arithmetic."""
+    from inv3d_amd import hipops as H, _lib as L
+    for (n, ci, h, w, co, products) in ((1, 256, 128, 128, 128, 3), (2, 48, 19, 40, 192, 3), (1, 64, 16, 32, 64, 1)):
+        g = torch.Generator().manual_seed(77)
+        x = torch.randn(n, ci, h, w, generator=g)
+        wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)
+        s = 1 + 0.5 * torch.randn(n, ci, generator=g)
+        xc, aimg, wimg = _v2_operands(x, wt, s)
+        outs = []
+        for rows in (8, 4):
+            z = H.empty_cl(n, co, 2 * h + 1, 2 * w + 1, DEV)
+            z.fill_(float('nan'))
+            H.conv_up2(aimg, wimg, z, epi=L.EPI_STORE, products=products, patch_rows=rows)
+            outs.append(z)
+        assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1]), (n, ci, h, w, co, products)
+
+
 @pytest.mark.parametrize('shape', [(1, 128, 16, 32, 64), (2, 256, 9, 33, 128), (1, 128, 24, 40, 192)])
 @pytest.mark.parametrize('products', [3, 1])
 def test_conv_v2_stride2_adjoint_vs_torch(shape, products):
