@@ -238,6 +238,11 @@ def test_graph_full_conditioned_and_heavy_tailed(golden, weights):
     assert e_c <= B['dc'], e_c
 
 
+# median probe error of every tensor with >= 64 probes, relative to max|g|: observed (round 6, both builds) <= 1.7e-4 (b64.torgb.bias), 7e-5 and below elsewhere;
+# single-product SR head: <= 6e-3.  Bounds = observed x 3.
+BULK_BOUND_F16X3, BULK_BOUND_F16X1 = 5e-4, 2e-2
+
+
 @pytest.mark.parametrize('arith', ['f16x3', 'sr_f16x1'])
 def test_graph_full_weight_grads_golden(golden, arith):
     """Phase B at full size (base_coach.py:96-99: Adam over every weight): weight, bias, affine, noise-strength, decoder and noise_const
@@ -270,7 +275,7 @@ def test_graph_full_weight_grads_golden(golden, arith):
     g_dep = O._randn('gf_dep', 8, o['image_depth'].shape) / (128 * 128)
     grads = torch.autograd.grad([o['image'], o['image_depth']], [ws, c] + leaves, [g_img.to(DEV), g_dep.to(DEV)])
     close(grads[0], d['dws'], 2e-3 if arith == 'f16x3' else 2e-2, 'full d ws (all weights trainable)')
-    worst, bad = {}, []
+    worst, bulk, bad = {}, {}, []
     for k, gv in zip(wkeys, grads[2:]):
         ref_norm, ref_max = [float(v) for v in d['wg_stat.' + k]]
         flat = gv.detach().flatten()
@@ -288,13 +293,17 @@ def test_graph_full_weight_grads_golden(golden, arith):
         #  order as much as an atomic's), deterministic but not smaller in the exact build.  Same bound in both builds.)
         err = float((got - ref).abs().max())
         worst[k] = err / ref_max
+        if got.numel() >= 64:           # (scalar parameters -- the noise strengths -- have one probe: their error is the maximum above)
+            bulk[k] = float((got - ref).abs().median()) / ref_max          # the probe set's MEDIAN error: what an arithmetic fault would move (the maximum sits on kink flips)
         nrm = float(flat.double().norm())
         if err > tol * ref_max:
             bad.append(f'd {k}: probe err {err:.3e} > {tol} * max|g| {ref_max:.3e}')
         if abs(nrm - ref_norm) > 2 * tol * ref_norm:
             bad.append(f'd {k}: norm {nrm:.6e} vs {ref_norm:.6e}')
     print({k: f'{v:.1e}' for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:12]})
+    print('median probe error / max|g|, worst tensors:', {k: f'{v:.1e}' for k, v in sorted(bulk.items(), key=lambda kv: -kv[1])[:6]})
     assert not bad, bad
+    assert max(bulk.values()) <= (BULK_BOUND_F16X3 if arith == 'f16x3' else BULK_BOUND_F16X1), max(bulk.values())
 
 
 def test_cpu_tensors_fail_loudly():
