@@ -224,6 +224,10 @@ __global__ void __launch_bounds__(256 * KH, KH == 1 ? 2 : 1) conv_v2_kernel(cons
                     for (int r = 0; r < 16; ++r) xch[((i * 2 + j) * 16 + r) * 256] = acc[i][j][r];
         }
         __syncthreads();
+        // The upper half ends here; the lower one goes on through the barriers of the epilogue.  That is defined behaviour of the INSTRUCTION, not of the HIP model:
+        // S_BARRIER waits for the waves of the workgroup that have not terminated ("if some waves in the threadgroup have already terminated, this waits on only the
+        // surviving waves", CDNA ISA, SOPP S_BARRIER) -- the epilogue and eg3d_commit_amax_block are told the surviving wave count (nwaves = 4) for everything that is
+        // indexed by wave.  tests/test_gpu_ops.py::test_conv_v2_k_halves_equal_the_four_wave_form holds it to the four-wave form and to launch-to-launch bit-identity.
         if (khalf == 1) return;
 #pragma unroll
         for (int i = 0; i < RPW; ++i)

@@ -110,14 +110,12 @@ def inflight_at_barriers(body):
 
 
 def all_kernels(lines):
-    """(name, body) for every .amdhsa kernel of the file."""
+    """(name, body) for every kernel of the file: from its label to its .end_amdhsa_kernel directive."""
     out, start, name = [], None, None
     for i, l in enumerate(lines):
-        m = re.match(r'^(_Z\w+):\s', l + ' ')
-        if m and start is None and (i > 0 and '.type' in lines[i - 1] or True):
-            cand = m.group(1)
-            if any(('.amdhsa_kernel ' + cand) in x for x in lines[i:i + 1]) or True:
-                start, name = i, cand
+        m = re.match(r'^(_Z\w+):', l)
+        if m and start is None:
+            start, name = i, m.group(1)
         if start is not None and l.strip().startswith('.end_amdhsa_kernel'):
             out.append((name, lines[start:i])); start = None
     return out
