@@ -253,6 +253,9 @@ __device__ __forceinline__ void gather_split(const float* __restrict__ pn, int H
 // phases above the MFMA chains of earlier ones: 256 VGPRs + 92 AGPRs for the backward kernel (one wave per SIMD, every latency exposed).
 // With it: 137 VGPRs, no spills.
 __device__ __forceinline__ void phase_fence() { asm volatile("" ::: "memory"); }
+// ... and one the instruction scheduler does not move anything across either (the GRAM steps: their operands are register-only computations
+// that the scheduler otherwise starts early, all at once)
+__device__ __forceinline__ void hard_fence() { asm volatile("" ::: "memory"); }
 
 #ifndef DEC_OCC_BWD
 #define DEC_OCC_BWD 3
@@ -356,15 +359,77 @@ __global__ void __launch_bounds__(256) gather_grad_rows_kernel(const DecodeArgs 
     if (q == 0 && in_range) a.gc_rows[row] = valid ? make_float4(gx, gy, gz, ps.w) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// GRAM (backward only): the two Gram products of the decoder-weight gradients, dPRE^T F [64 x 32] and dOUT^T H [32 x 64] (+ the sigma row and
-// the bias sums), are accumulated here instead of dumping their four operands (1.0 GB per step) for a GEMM pass over them.  Per tile the
-// wave transposes its operands through a private 13 KB LDS area -- lane = sample writes rows, lane = (unit, sample parity) reads the A / B
-// operands of v_mfma_f32_32x32x2_f32 (K = two samples), the exact-fp32-product arithmetic rows_gram.hip uses -- 64 MFMAs per 32 samples on
-// top of the 48 of the backward itself; four 32 x 32 accumulators live in registers across all tiles of the wave, the sigma row and the
-// bias sums are per-lane partial sums reduced once at the end.  One block of eight waves per CU (the accumulators; 104 KB of transposition space).
-constexpr int GRAM_LDP = 68, GRAM_LDQ = 36;                               // row pitches (floats) of the 64- and 32-column tiles: 16-byte rows, banks staggered
-constexpr int GRAM_NACC = 161;                                            // per-wave LDS sums: sigma row [64], d b0 [64], d b1 colours [32], d b1 sigma [1]
-constexpr int GRAM_WAVE_BYTES = (32 * GRAM_LDP + 32 * GRAM_LDQ + 192) * 4;      // 14080
+// GRAM (backward only): the two Gram products of the decoder-weight gradients, dPRE^T F [64 x 32] and dOUT^T H [32 x 64], the sigma row
+// sum_s dsigma_s H[s][:] and the bias sums are accumulated here instead of dumping their four operands (1.0 GB per step) for a GEMM pass
+// over them.  The contraction runs over SAMPLES, which the wave holds one per lane, so the operands are transposed through a wave-private
+// 14 KB LDS area: lane = sample writes the fp16 pieces of its k-step fragments (the pieces the decoder GEMMs consume: act_frag) one half at
+// a time to [unit][sample]; lane = (unit, sample octet) reads eight consecutive samples back as the A / B operand of
+// v_mfma_f32_16x16x32_f16 (K = the 32 samples of the tile).  Arithmetic = the three-product form of the rest of the file; the gradient-side operand (dPRE, dOUT, dsigma) is
+// brought into fp16 range by ONE power of two per 32-sample tile (samples far below the tile's largest lose nothing that the sum keeps),
+// the tile's product starts from a zero accumulator and is added, scaled back, to fp32 running sums in registers: 72 MFMAs of 16 cycles
+// per tile.  Round 5 contracted exact fp32 products with v_mfma_f32_32x32x2_f32: 64 MFMAs of 64 cycles per tile -- 4096 matrix-pipe
+// cycles against the 1536 of the backward itself, 158 -> 383 us for the launch.  The bias sums and the sigma row are MFMAs against
+// all-ones / broadcast rows (every accumulator row holds the complete sum: one register per block is kept).  One block of eight waves per
+// CU (the transposition space).
+constexpr int G_PT = 72;                                                  // bytes per [unit] row: 32 samples x 2 + 8 (the two sample octets of a read land on different banks)
+constexpr int G_PH = 0, G_PL = 64 * G_PT, G_QH = 128 * G_PT, G_QL = 160 * G_PT, G_SH = 192 * G_PT, G_SL = 193 * G_PT;
+constexpr int GRAM_WAVE_BYTES = 194 * G_PT;                               // 13968: P (64 units) and Q (32 units) as high / low pieces + the dsigma row
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+// lane (sample li, half h) -> rows unit0 + split_idx(j, h), column li, of a [unit][sample] piece image; `base` = image + 4 h G_PT + 2 li.
+// Written as instructions: from C++ the compiler unpacks every high half into a register of its own first (one shift and one register per
+// half) instead of storing it with ds_write_b16_d16_hi.  LDS operations of a wave execute in order, so the reads that follow need no wait.
+template <int OFF>
+__device__ __forceinline__ void gram_put_pair(unsigned addr, int packed) {
+    asm volatile("ds_write_b16 %0, %1 offset:%2\n\tds_write_b16_d16_hi %0, %1 offset:%3" ::"v"(addr), "v"(packed), "n"(OFF), "n"(OFF + G_PT) : "memory");
+}
+template <int IMG, int UNIT0>
+__device__ __forceinline__ void gram_put(unsigned base, const f16x8& v) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4 w = __builtin_bit_cast(i32x4, v);
+    gram_put_pair<IMG + (UNIT0 + 0) * G_PT>(base, w[0]);
+    gram_put_pair<IMG + (UNIT0 + 2) * G_PT>(base, w[1]);
+    gram_put_pair<IMG + (UNIT0 + 8) * G_PT>(base, w[2]);
+    gram_put_pair<IMG + (UNIT0 + 10) * G_PT>(base, w[3]);
+}
+// reader lane (row rl = lane & 15, sample octet kg = lane >> 4) <- samples 8 kg .. + 7 of row `row0 + rl`: the A / B operand of
+// v_mfma_f32_16x16x32_f16 (K = the 32 samples of the tile); `base` = image + rl G_PT + 16 kg
+__device__ __forceinline__ f16x8 gram_get(const char* base, int row0) {
+    const f16x4 lo = *reinterpret_cast<const f16x4*>(base + row0 * G_PT), hi = *reinterpret_cast<const f16x4*>(base + row0 * G_PT + 8);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// max over the wave of a non-negative value (four row steps + the four row leaders)
+__device__ __forceinline__ float wave_max_nonneg(float m) {
+    m = fmaxf(m, eg3d_dpp<0xB1>(m)); m = fmaxf(m, eg3d_dpp<0x4E>(m)); m = fmaxf(m, eg3d_dpp<0x141>(m)); m = fmaxf(m, eg3d_dpp<0x140>(m));
+    const int b = __float_as_int(m);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 0)), __int_as_float(__builtin_amdgcn_readlane(b, 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 32)), __int_as_float(__builtin_amdgcn_readlane(b, 48))));
+}
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// one 16 x 16 block of a tile's Gram product from a zero accumulator: Ah Bh + 2^-11 (Ah Bl + Al Bh)  (low pieces are stored x 2^11).
+// 16 x 16 blocks rather than 32 x 32: four transient registers per chain instead of sixteen -- the kernel sits at the register limit of two
+// waves per SIMD with its 64 running sums.
+__device__ __forceinline__ f32x4v gram_tile(const f16x8& Ah, const f16x8& Al, const f16x8& Bh, const f16x8& Bl) {
+    const f32x4v Z = {0.f, 0.f, 0.f, 0.f};
+    f32x4v x = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh, Z, 0, 0, 0);
+    x = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, x, 0, 0, 0);
+    const f32x4v m = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, Z, 0, 0, 0);
+    return x * 0.00048828125f + m;
+}
+// The running sums are consumed only by the NEXT tile, so the optimiser sinks their updates to the end of the loop body and keeps every tile
+// product alive (in scratch: 0.5 KB per lane) across the rest of the backward.  An empty statement that reads and writes the sum pins the
+// update where it is written.
+__device__ __forceinline__ void pin(f32x4v& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+// column sums of a block: ones^T (Bh + 2^-11 Bl) (every accumulator row holds them)
+__device__ __forceinline__ float gram_colsum(const f16x8& Bh, const f16x8& Bl) {
+    const f32x4v Z = {0.f, 0.f, 0.f, 0.f};
+    const _Float16 o1 = (_Float16)1.f, o11 = (_Float16)0.00048828125f;
+    const f16x8 one = {o1, o1, o1, o1, o1, o1, o1, o1}, eps = {o11, o11, o11, o11, o11, o11, o11, o11};
+    f32x4v m = __builtin_amdgcn_mfma_f32_16x16x32_f16(eps, Bl, Z, 0, 0, 0);
+    m = __builtin_amdgcn_mfma_f32_16x16x32_f16(one, Bh, m, 0, 0, 0);
+    return m[0];
+}
 
 template <bool BWD, bool FEAT, bool GRAM = false>
 __global__ void __launch_bounds__(GRAM ? 512 : 256, GRAM ? 1 : (BWD ? DEC_OCC_BWD : DEC_OCC_FWD)) decode_rows_kernel(const DecodeArgs a) {
@@ -372,21 +437,19 @@ __global__ void __launch_bounds__(GRAM ? 512 : 256, GRAM ? 1 : (BWD ? DEC_OCC_BW
     const Frags F = setup_frags<BWD>(lds, a);
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     // GRAM state (dead code otherwise)
-    float* const TP = reinterpret_cast<float*>(lds + FRAG_BYTES_BWD + (threadIdx.x >> 6) * GRAM_WAVE_BYTES);      // [32 samples][GRAM_LDP]
-    float* const TQ = TP + 32 * GRAM_LDP;                                                                       // [32 samples][GRAM_LDQ]
-    float* const TA = TQ + 32 * GRAM_LDQ;                                                                       // [GRAM_NACC] running sums of this wave
-    f32x16 gram1[2], gram2[2];
+    char* const GW = lds + FRAG_BYTES_BWD + (threadIdx.x >> 6) * GRAM_WAVE_BYTES;          // this wave's transposition space
+    const unsigned gput = (unsigned)(uintptr_t)(GW + 4 * h * G_PT + 2 * li);                // writer: lane = (sample li, unit half h); LDS byte address
+    const char* const gget = GW + (lane & 15) * G_PT + 16 * (lane >> 4);                   // reader: lane = (row lane & 15, sample octet lane >> 4)
+    // running sums: block (i, j) of d W0 = rows (hidden units) 16 i .., columns (features) 16 j ..; of d W1 = rows (colours) 16 i .., columns
+    // (hidden units) 16 j ..; accumulator element r of lane (c = lane & 15, g = lane >> 4) = (row 4 g + r, column c) of its block
+    f32x4v gram1[4][2], gram2[2][4];
+    float run_sig[4] = {0.f, 0.f, 0.f, 0.f}, run_b0[4] = {0.f, 0.f, 0.f, 0.f}, run_b1[2] = {0.f, 0.f}, cs_ds = 0.f;      // per column c (every g holds the same sums)
     if constexpr (GRAM) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { gram1[u][r] = 0.f; gram2[u][r] = 0.f; }
+            for (int j = 0; j < 2; ++j) { gram1[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f}; gram2[j][i] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
     }
-    // sums over samples that are not matrix products -- the sigma row of d W1 (sum_s dsigma_s H[s][u]), d b0 (sum_s dPRE[s][u]), d b1 -- are column
-    // sums of the tiles the wave transposes through LDS anyway: lane (li, h) owns column li + 32 h of the 64-wide tiles (column li, sample parity
-    // h, of the 32-wide one) and keeps its sum in a register across all tiles of the wave.  (As 81 DPP row reductions + LDS adds per tile
-    // they were ~400 of the kernel's ~1500 vector instructions per tile.)
-    float cs_sig = 0.f, cs_b0 = 0.f, cs_b1 = 0.f, cs_ds = 0.f;
     const int64_t ntiles = (a.M + 31) / 32;
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -451,12 +514,15 @@ __global__ void __launch_bounds__(GRAM ? 512 : 256, GRAM ? 1 : (BWD ? DEC_OCC_BW
         float sig = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        static_for<0, 4>([&](auto ks) {
             f16x8 bh, bl;
-            act_frag<false, false>(hid[ks >> 1], ks & 1, 1.f, bh, bl);
-            mfma3(out, F.a2 + ks * 192, lane, bh, bl);
-        }
+            act_frag<false, false>(hid[ks.value >> 1], ks.value & 1, 1.f, bh, bl);
+            if constexpr (GRAM && BWD) {          // the same pieces are the H operand of the d W1 Gram product: to [unit][sample] while they exist
+                gram_put<G_PH, 16 * ks.value>(gput, bh);
+                gram_put<G_PL, 16 * ks.value>(gput, bl);
+            }
+            mfma3(out, F.a2 + ks.value * 192, lane, bh, bl);
+        });
         {
             const f32x2 inv1 = {F.inv1, F.inv1};
             f32x2 sg2 = {0.f, 0.f};
@@ -526,6 +592,50 @@ __global__ void __launch_bounds__(GRAM ? 512 : 256, GRAM ? 1 : (BWD ? DEC_OCC_BW
                 for (int g = 0; g < 4; ++g)
                     *reinterpret_cast<float4*>(a.dump_h + row * HD + 32 * ht + 8 * g + 4 * h) = make_float4(hid[ht][4 * g], hid[ht][4 * g + 1], hid[ht][4 * g + 2], hid[ht][4 * g + 3]);
         }
+        if constexpr (GRAM) {
+            // dOUT^T H and the sigma row dsigma^T H: P = H (written by layer 2), Q = dOUT, S = dsigma, each x its tile power of two
+            float m = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(dout[r]));
+            float sc, isc, ss, iss;
+            pow2_range_pair(wave_max_nonneg(m), 6, sc, isc);
+            pow2_range_pair(wave_max_nonneg(fabsf(dsig)), 6, ss, iss);
+            if (h == 0) cs_ds += dsig;
+            static_for<0, 2>([&](auto ks) {
+                f16x8 qh, ql;
+                act_frag<true, false>(dout, ks.value, sc, qh, ql);
+                gram_put<G_QH, 16 * ks.value>(gput, qh);
+                gram_put<G_QL, 16 * ks.value>(gput, ql);
+                hard_fence();
+            });
+            {
+                const float x = dsig * ss;
+                const fp16x2_t hh = __builtin_amdgcn_cvt_pkrtz(x, x);
+                *reinterpret_cast<_Float16*>(GW + G_SH + 2 * li) = (_Float16)hh[0];       // (lanes li and li + 32 hold the same sample)
+                *reinterpret_cast<_Float16*>(GW + G_SL + 2 * li) = (_Float16)fmaf((float)hh[0], -2048.f, x * 2048.f);
+            }
+            hard_fence();
+            f16x8 Qh[2], Ql[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                Qh[i] = gram_get(gget + G_QH, 16 * i); Ql[i] = gram_get(gget + G_QL, 16 * i);
+                run_b1[i] = fmaf(gram_colsum(Qh[i], Ql[i]), isc, run_b1[i]);
+                pin(run_b1[i]);
+            }
+            const f16x8 Sh = gram_get(GW + G_SH + 16 * (lane >> 4), 0), Sl = gram_get(GW + G_SL + 16 * (lane >> 4), 0);      // every accumulator row = the dsigma row
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                hard_fence();
+                const f16x8 Ph = gram_get(gget + G_PH, 16 * j), Pl = gram_get(gget + G_PL, 16 * j);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    gram2[i][j] += gram_tile(Qh[i], Ql[i], Ph, Pl) * isc;                 // rows = colours 16 i .., columns = hidden units 16 j ..
+                    pin(gram2[i][j]);
+                }
+                run_sig[j] = fmaf(gram_tile(Sh, Sl, Ph, Pl)[0], iss, run_sig[j]);
+                pin(run_sig[j]);
+            }
+        }
         phase_fence();
         // ---- dH^T = W1c^T dOUT^T + w1s dsigma ;  dPRE = dH * sigmoid(PRE) = dH * (1 - exp(-H)) ---------------------------
         // the sample's gradient column is brought to [2^6, 2^7) by its own power of two and the result column scaled back
@@ -564,45 +674,44 @@ __global__ void __launch_bounds__(GRAM ? 512 : 256, GRAM ? 1 : (BWD ? DEC_OCC_BW
                     *reinterpret_cast<float4*>(a.dump_dpre + row * HD + 32 * ht + 8 * g + 4 * h) = make_float4(dh[ht][4 * g], dh[ht][4 * g + 1], dh[ht][4 * g + 2], dh[ht][4 * g + 3]);
         }
         if constexpr (GRAM) {
-            // phase 1: TP = dPRE [sample][64], TQ = F [sample][32]  ->  gram1[u] += dPRE[:, 32u ..]^T F
-            auto put64 = [&](const f32x16 (&v)[2]) {
+            // dPRE^T F: P = dPRE x (tile power of two), Q = F (the fragments layer 1 consumed)
+            float m = 0.f;
 #pragma unroll
-                for (int ht = 0; ht < 2; ++ht)
+            for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<float4*>(TP + li * GRAM_LDP + 32 * ht + 8 * g + 4 * h) = make_float4(v[ht][4 * g], v[ht][4 * g + 1], v[ht][4 * g + 2], v[ht][4 * g + 3]);
-            };
-            auto put32 = [&](const f32x16& v) {
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(dh[ht][r]));
+            float sc, isc;
+            pow2_range_pair(wave_max_nonneg(m), 6, sc, isc);
+            static_for<0, 4>([&](auto ks) {
+                f16x8 ph, pl;
+                act_frag<true, false>(dh[ks.value >> 1], ks.value & 1, sc, ph, pl);
+                gram_put<G_PH, 16 * ks.value>(gput, ph);
+                gram_put<G_PL, 16 * ks.value>(gput, pl);
+                hard_fence();
+            });
+            static_for<0, 2>([&](auto ks) {
+                f16x8 qh, ql;
+                act_frag<false, true>(f, ks.value, 1.f, qh, ql);
+                gram_put<G_QH, 16 * ks.value>(gput, qh);
+                gram_put<G_QL, 16 * ks.value>(gput, ql);
+            });
+            hard_fence();
+            f16x8 Qh[2], Ql[2];
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(TQ + li * GRAM_LDQ + 8 * g + 4 * h) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
-            };
-            put64(dh);
-            put32(f);
-            if (h == 0) cs_ds += dsig;
-#pragma unroll 8
-            for (int t = 0; t < 32; ++t) cs_b0 += TP[t * GRAM_LDP + lane];
-#pragma unroll 4
-            for (int t = 0; t < 16; ++t) {
-                const float* rp = TP + (2 * t + h) * GRAM_LDP + li;
-                const float bq = TQ[(2 * t + h) * GRAM_LDQ + li];
-                gram1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(rp[0], bq, gram1[0], 0, 0, 0);
-                gram1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(rp[32], bq, gram1[1], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) { Qh[j] = gram_get(gget + G_QH, 16 * j); Ql[j] = gram_get(gget + G_QL, 16 * j); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                hard_fence();
+                const f16x8 Ph = gram_get(gget + G_PH, 16 * i), Pl = gram_get(gget + G_PL, 16 * i);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    gram1[i][j] += gram_tile(Ph, Pl, Qh[j], Ql[j]) * isc;                 // rows = hidden units 16 i .., columns = features 16 j ..
+                    pin(gram1[i][j]);
+                }
+                run_b0[i] = fmaf(gram_colsum(Ph, Pl), isc, run_b0[i]);
+                pin(run_b0[i]);
             }
-            // phase 2: TP = H [sample][64], TQ = dOUT [sample][32]  ->  gram2[u] += dOUT^T H[:, 32u ..]
-            put64(hid);
-            put32(dout);
-#pragma unroll 8
-            for (int t = 0; t < 32; ++t) cs_sig = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dsig), t)), TP[t * GRAM_LDP + lane], cs_sig);      // d sigma of sample t: lanes t and t + 32 hold it
-#pragma unroll 8
-            for (int t = 0; t < 16; ++t) cs_b1 += TQ[(2 * t + h) * GRAM_LDQ + li];
-#pragma unroll 4
-            for (int t = 0; t < 16; ++t) {
-                const float* rp = TP + (2 * t + h) * GRAM_LDP + li;
-                const float aq = TQ[(2 * t + h) * GRAM_LDQ + li];
-                gram2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq, rp[0], gram2[0], 0, 0, 0);
-                gram2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq, rp[32], gram2[1], 0, 0, 0);
-            }
+            hard_fence();
         }
         phase_fence();
         // ---- dF^T = W0^T dPRE^T -------------------------------------------------------------------------------------------
@@ -678,21 +787,27 @@ __global__ void __launch_bounds__(GRAM ? 512 : 256, GRAM ? 1 : (BWD ? DEC_OCC_BW
         }
     }
     if constexpr (GRAM) {
-        // accumulator element r of lane (li, h) = (row (r&3) + 8 (r>>2) + 4 h, column li) of its 32 x 32 block
+        const int c = lane & 15, g = lane >> 4;
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                eg3d_acc(a.gram_w0 + (32 * u + row) * FC + li, gram1[u][r] * a.gram_s0);                   // d W0 [unit][feature]
-                eg3d_acc(a.gram_w1 + (1 + row) * HD + 32 * u + li, gram2[u][r] * a.gram_s1);               // d W1 [1 + colour][hidden]
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    eg3d_acc(a.gram_w0 + (16 * i + 4 * g + r) * FC + 16 * j + c, gram1[i][j][r] * a.gram_s0);                 // d W0 [unit][feature]
+                    eg3d_acc(a.gram_w1 + (1 + 16 * j + 4 * g + r) * HD + 16 * i + c, gram2[j][i][r] * a.gram_s1);           // d W1 [1 + colour][hidden]
+                }
+        if (g == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                eg3d_acc(a.gram_w1 + 16 * i + c, run_sig[i] * a.gram_s1);             // sigma row of d W1
+                eg3d_acc(a.gram_b0 + 16 * i + c, run_b0[i] * a.gram_sb);
             }
-        eg3d_acc(a.gram_w1 + lane, cs_sig * a.gram_s1);                               // sigma row of d W1
-        eg3d_acc(a.gram_b0 + lane, cs_b0 * a.gram_sb);
-        cs_b1 += __shfl_xor(cs_b1, 32);                                                // the two sample parities of a colour column
+#pragma unroll
+            for (int j = 0; j < 2; ++j) eg3d_acc(a.gram_b1 + 1 + 16 * j + c, run_b1[j] * a.gram_sb);
+        }
 #pragma unroll
         for (int o = 16; o >= 1; o >>= 1) cs_ds += __shfl_xor(cs_ds, o);               // (lanes 32 .. 63 hold zeros)
-        if (h == 0) eg3d_acc(a.gram_b1 + 1 + li, cs_b1 * a.gram_sb);
         if (lane == 0) eg3d_acc(a.gram_b1, cs_ds * a.gram_sb);
     }
     if constexpr (BWD) {

@@ -28,6 +28,14 @@ def close(a, b, tol, what=''):
     assert err <= tol * scale, f'{what}: err {err:.3e} > {tol} * {scale:.3e}'
 
 
+def close_rel(a, b, tol, what=''):
+    """max |a - b| <= tol x max |b| (no floor at 1: gradient-sized operands)."""
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape and torch.isfinite(a).all(), what
+    err, scale = float((a - b).abs().max()), float(b.abs().max())
+    assert err <= tol * scale, f'{what}: err {err:.3e} > {tol} * {scale:.3e}'
+
+
 def close_most(a, b, tol, what='', frac=0.002, loose=0.05):
     """Per-ray coordinate gradients are piecewise constant in the sample position (bilinear texel boundaries): a sample
     whose coordinate differs by one ulp between CPU and GPU can flip a floor() and change that ray's gradient by O(1/samples).
@@ -600,6 +608,64 @@ def test_render_feature_row_path_equals_gather_in_decoder(variant):
         assert torch.equal(a[k], b[k]), f'forward output {k} differs between the gather paths'
     close(b[3], a[3], 2e-6, 'd planes'); close_most(b[4], a[4], 1e-5, 'd origins'); close_most(b[5], a[5], 1e-5, 'd dirs')
     close(c[3], b[3], 2e-6, 'd planes, fp16 three-product accumulation vs fp32')
+
+
+@pytest.mark.parametrize('variant', ['ffhq48', 'wide_range', 'ragged'])
+def test_decoder_weight_gradients_in_the_backward_kernel(variant):
+    """Pivotal tuning's decoder-weight gradients (OSGDecoder, training/triplane.py:124-136; Adam over every weight, base_coach.py:96-99)
+    contracted inside the sample-level backward kernel (decode_rows_kernel<true, true, true>: per 32-sample tile the operands' fp16 pieces
+    transposed through LDS, three-product v_mfma_f32_16x16x32_f16, one power of two per tile on the gradient side) against (a) the same
+    backward with the four operands dumped and contracted by the exact-fp32 rows_gram kernel and (b) the oracle's autograd.
+    'wide_range': the per-ray cotangent spans eight decades from ray to ray (tiles whose samples differ by 1e8 in gradient size);
+    'ragged': a ray count that leaves the last 32-sample tile partly empty and uneven coarse / fine counts (absent sample rows)."""
+    from inv3d_amd.training.volumetric_rendering.renderer import ImportanceRenderer
+    from inv3d_amd import fused
+    cfg = O.full_config()
+    opts = dict(cfg.rendering)
+    res, n = (32, 2) if variant != 'ragged' else (9, 1)
+    if variant == 'ragged':
+        opts['depth_resolution'], opts['depth_resolution_importance'] = 40, 24
+    P = O.synth_params(O.small_config(), seed=7)
+    g = torch.Generator().manual_seed(17)
+    planes = (torch.randn(n, 3, 32, 64, 64, generator=g) * 0.8)
+    cam = O.synth_cameras(n, seed=11)
+    o, dr = O.ray_sampler(cam[:, :16].reshape(n, 4, 4), cam[:, 16:].reshape(n, 3, 3), res)
+    dc, df = opts['depth_resolution'], opts['depth_resolution_importance']
+    u1, u2 = torch.rand(n, res * res, dc, 1, generator=g), torch.rand(n * res * res, df, generator=g)
+    g_rgb, g_dep = torch.randn(n, res * res, 32, generator=g), torch.randn(n, res * res, 1, generator=g)
+    if variant == 'wide_range':
+        amp = 10.0 ** (torch.rand(n, res * res, 1, generator=g) * 8 - 6)
+        g_rgb, g_dep = g_rgb * amp, g_dep * amp
+    names = ['decoder.net.0.weight', 'decoder.net.0.bias', 'decoder.net.2.weight', 'decoder.net.2.bias']
+
+    Pd = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in P.items()}
+    rgb_r, dep_r, _ = O.render(Pd, planes, o, dr, opts, u1, u2)
+    ref = torch.autograd.grad([rgb_r, dep_r], [Pd[k] for k in names], [g_rgb, g_dep])
+
+    def run(in_kernel):
+        old = fused.GRAM_FUSED
+        fused.GRAM_FUSED = in_kernel
+        try:
+            dec = _decoder(P)
+            R = ImportanceRenderer()
+            R.set_uniforms(u1.to(DEV), u2.to(DEV))
+            pg = planes.to(DEV).requires_grad_(True)
+            rgb, dep, _ = R(pg, dec, o.to(DEV), dr.to(DEV), opts)
+            pd = dict(dec.named_parameters())
+            gg = torch.autograd.grad([rgb, dep], [pd[k[len('decoder.'):]] for k in names] + [pg], [g_rgb.to(DEV), g_dep.to(DEV)])
+            torch.cuda.synchronize()
+            return gg
+        finally:
+            fused.GRAM_FUSED = old
+    a, b = run(True), run(False)
+    # (the oracle is fp32 on the CPU: its importance samples differ from the kernels' in a few bins, hence the looser bound against it)
+    for k, nm in enumerate(names):
+        print(f'{variant} {nm}: in-kernel vs dumped {float((a[k] - b[k]).abs().max() / b[k].abs().max()):.2e}, in-kernel vs oracle '
+              f'{float((a[k].cpu() - ref[k]).abs().max() / ref[k].abs().max()):.2e}, dumped vs oracle {float((b[k].cpu() - ref[k]).abs().max() / ref[k].abs().max()):.2e}')
+        close_rel(a[k], b[k], 2e-5, f'{variant} {nm}: in-kernel Gram vs dumped operands')
+        close_rel(a[k], ref[k], 2e-4, f'{variant} {nm}: in-kernel Gram vs the oracle')
+        close_rel(b[k], ref[k], 2e-4, f'{variant} {nm}: dumped operands vs the oracle')
+    close_rel(a[4], b[4], 1e-6, f'{variant} d planes unchanged by the Gram path')
 
 
 @pytest.mark.parametrize('variant', ['ffhq48', 'white_back', 'disparity', 'coarse_only', 'uneven', 'negative_depths', 'no_grad_fused'])
