@@ -282,11 +282,11 @@ __global__ void __launch_bounds__(NT) slice_rgb4_fwd_kernel(const float* __restr
     y[i] = make_float4(v.x, v.y, v.z, 0.f);
 }
 
-__global__ void __launch_bounds__(NT) slice_rgb4_bwd_kernel(const float4* __restrict__ dy, float4* __restrict__ dx, int64_t P, int C4) {
+__global__ void __launch_bounds__(NT) slice_rgb4_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ addend, float4* __restrict__ dx, int64_t P, int C4) {
     const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
     if (i >= P * C4) return;
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i % C4 == 0) { const float4 g = dy[i / C4]; o = make_float4(g.x, g.y, g.z, 0.f); }
+    float4 o = addend != nullptr ? addend[i] : make_float4(0.f, 0.f, 0.f, 0.f);       // (the gradient the feature image's other consumer, the SR head, sent)
+    if (i % C4 == 0) { const float4 g = dy[i / C4]; o.x += g.x; o.y += g.y; o.z += g.z; }
     dx[i] = o;
 }
 
@@ -749,12 +749,19 @@ extern "C" int eg3d_slice_rgb4_fwd(const float* x, float* y4, int64_t P, int C, 
     return EG3D_OK;
 }
 
-extern "C" int eg3d_slice_rgb4_bwd(const float* dy4, float* dx, int64_t P, int C, void* stream) {
-    if (!dy4 || !dx || P < 1 || C < 4 || (C & 3) || !aligned16(dx) || !aligned16(dy4)) return EG3D_ERR_INVALID;
+static int slice_rgb4_bwd_impl(const float* dy4, const float* addend, float* dx, int64_t P, int C, void* stream) {
+    if (!dy4 || !dx || P < 1 || C < 4 || (C & 3) || !aligned16(dx) || !aligned16(dy4) || !aligned16(addend)) return EG3D_ERR_INVALID;
     hipLaunchKernelGGL(slice_rgb4_bwd_kernel, dim3((unsigned)((P * (C / 4) + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4*>(dy4), reinterpret_cast<float4*>(dx), P, C / 4);
+                       reinterpret_cast<const float4*>(dy4), reinterpret_cast<const float4*>(addend), reinterpret_cast<float4*>(dx), P, C / 4);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
+}
+
+extern "C" int eg3d_slice_rgb4_bwd(const float* dy4, float* dx, int64_t P, int C, void* stream) { return slice_rgb4_bwd_impl(dy4, nullptr, dx, P, C, stream); }
+
+extern "C" int eg3d_slice_rgb4_bwd_add(const float* dy4, const float* addend, float* dx, int64_t P, int C, void* stream) {
+    if (!addend) return EG3D_ERR_INVALID;
+    return slice_rgb4_bwd_impl(dy4, addend, dx, P, C, stream);
 }
 
 extern "C" int eg3d_warp_project_fwd(const float* origins, const float* dirs, const float* depth, const float* consts, float* uv, int64_t P, void* stream) {

@@ -53,9 +53,9 @@ __global__ void __launch_bounds__(256) upfirdn2d_generic(const T* __restrict__ x
 }
 
 // channels-last fp32, float4 over channels, optional accumulate (fused-path resampler)
-__global__ void __launch_bounds__(256) upfirdn2d_nhwc4(const float* __restrict__ x, const float* __restrict__ f, float* __restrict__ y,
+__global__ void __launch_bounds__(256) upfirdn2d_nhwc4(const float* __restrict__ x, const float* __restrict__ f, float* y, const float* addend,
                                                        int N, int C4, int inH, int inW, int outH, int outW, int fH, int fW, int up,
-                                                       int down, int padx0, int pady0, int flip, float gain, int accumulate) {
+                                                       int down, int padx0, int pady0, int flip, float gain) {
     __shared__ float fs[64];
     if (threadIdx.x < fH * fW) {
         int ky = threadIdx.x / fW, kx = threadIdx.x % fW;
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc4(const float* __restrict__
                 acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
             }
         }
-        if (accumulate) { float4 o = y4[i]; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+        if (addend != nullptr) { const float4 o = reinterpret_cast<const float4*>(addend)[i]; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }      // (y itself when accumulating)
         y4[i] = acc;
     }
 }
@@ -189,10 +189,11 @@ extern "C" int eg3d_upfirdn2d(const void* x, const float* f, void* y, int dtype,
     return EG3D_OK;
 }
 
-extern "C" int eg3d_upfirdn2d_nhwc(const float* x, const float* f, float* y, int N, int C, int inH, int inW, int fH, int fW, int up,
-                                   int down, int padx0, int padx1, int pady0, int pady1, int flip, float gain, int outH, int outW,
-                                   int accumulate, void* stream) {
+static int upfirdn2d_nhwc_impl(const float* x, const float* f, float* y, const float* addend, int N, int C, int inH, int inW, int fH, int fW, int up,
+                               int down, int padx0, int padx1, int pady0, int pady1, int flip, float gain, int outH, int outW,
+                               int accumulate, void* stream) {
     if (!x || !f || !y || N <= 0 || C <= 0 || up < 1 || down < 1 || fH < 1 || fW < 1) return EG3D_ERR_INVALID;
+    if (addend != nullptr && (accumulate || (up == 1 && down == 1 && fH == 4 && fW == 4) || (reinterpret_cast<uintptr_t>(addend) & 15))) return EG3D_ERR_UNSUPPORTED;
     if (C % 4 != 0 || fH * fW > 64) return EG3D_ERR_UNSUPPORTED;
     if (outW != (inW * up + padx0 + padx1 - fW + down) / down || outH != (inH * up + pady0 + pady1 - fH + down) / down)
         return EG3D_ERR_INVALID;
@@ -206,8 +207,20 @@ extern "C" int eg3d_upfirdn2d_nhwc(const float* x, const float* f, float* y, int
     }
     const int64_t total = (int64_t)N * outH * outW * (C / 4);
     int blocks = (int)std::min<int64_t>(eg3d_cdiv(total, 256), 256 * 16);
-    hipLaunchKernelGGL(upfirdn2d_nhwc4, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, f, y, N, C / 4, inH, inW, outH, outW, fH,
-                       fW, up, down, padx0, pady0, flip, gain, accumulate);
+    hipLaunchKernelGGL(upfirdn2d_nhwc4, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, f, y, accumulate ? y : addend, N, C / 4, inH, inW, outH, outW, fH,
+                       fW, up, down, padx0, pady0, flip, gain);
     EG3D_LAUNCH_CHECK();
     return EG3D_OK;
+}
+
+extern "C" int eg3d_upfirdn2d_nhwc(const float* x, const float* f, float* y, int N, int C, int inH, int inW, int fH, int fW, int up,
+                                   int down, int padx0, int padx1, int pady0, int pady1, int flip, float gain, int outH, int outW,
+                                   int accumulate, void* stream) {
+    return upfirdn2d_nhwc_impl(x, f, y, nullptr, N, C, inH, inW, fH, fW, up, down, padx0, padx1, pady0, pady1, flip, gain, outH, outW, accumulate, stream);
+}
+
+extern "C" int eg3d_upfirdn2d_nhwc_add(const float* x, const float* f, const float* addend, float* y, int N, int C, int inH, int inW, int fH, int fW, int up,
+                                       int down, int padx0, int padx1, int pady0, int pady1, int flip, float gain, int outH, int outW, void* stream) {
+    if (!addend) return EG3D_ERR_INVALID;
+    return upfirdn2d_nhwc_impl(x, f, y, addend, N, C, inH, inW, fH, fW, up, down, padx0, padx1, pady0, pady1, flip, gain, outH, outW, 0, stream);
 }

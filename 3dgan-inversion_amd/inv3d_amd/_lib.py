@@ -280,6 +280,7 @@ _SIGS = {
     'eg3d_torgb_dgrad_act_split': (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.POINTER(ActBwd)] + [C.c_void_p] * 5),
     'eg3d_upfirdn2d_nhwc': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 13 + [C.c_float, C.c_int, C.c_int,
                                                                                              C.c_int, C.c_void_p]),
+    'eg3d_upfirdn2d_nhwc_add': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 13 + [C.c_float, C.c_int, C.c_int, C.c_void_p]),
     'eg3d_weight_sqsum': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'eg3d_demod_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'eg3d_demod_bwd': (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -302,6 +303,7 @@ _SIGS = {
     'eg3d_tv_norm_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'eg3d_slice_rgb4_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     'eg3d_slice_rgb4_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    'eg3d_slice_rgb4_bwd_add': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     'eg3d_warp_project_fwd': (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]),
     'eg3d_warp_project_bwd': (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_void_p]),
     'eg3d_torgb_small_supported': (C.c_int, [C.POINTER(TorgbSmallParams)]),

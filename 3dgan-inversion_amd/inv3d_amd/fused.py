@@ -211,6 +211,7 @@ def _auto_ksplit(classes, N, Nc, Ck):
 FUSE_ACT_BWD = os.environ.get('EG3D_FUSE_ACT_BWD', '1') != '0'
 FIR_ADJ_LDS = 4096       # pixels from which the FIR adjoint of an up layer's backward runs on the LDS-tiled separable kernel (0 = never)
 FUSE_SKIP_UP = os.environ.get('EG3D_FUSE_SKIP_UP', '1') != '0'   # skip image up-sampled inside the toRGB conv's epilogue (eg3d_conv_params::addend_up2)
+FUSE_SKIP_ADD = True          # clamped toRGB layers (the SR head): img = upsample2d(img) + y in one pass (eg3d_upfirdn2d_nhwc_add) instead of an up-sampling pass and an add
 SPLIT_DZ = os.environ.get('EG3D_SPLIT_DZ', '1') != '0'         # ... and write dz as the data gradient's fp16 operand image where it can (torgb_dgrad_act_split)
 _DX_AMAX = {}                 # dx.data_ptr() -> (device scalar max|dx| reported by the data-gradient kernel that wrote it, weak ref to dx); read once by a toRGB backward
 _DZ_TOKEN = {}                # device -> 1-element tensor: expanded, it stands in for a dz that only exists as an operand image
@@ -658,6 +659,28 @@ class ModConvLayerFn(torch.autograd.Function):
                 dd if d_given else None, None, None, None, None, None, None)
 
 
+class BroadcastRowsFn(torch.autograd.Function):
+    """ws = w.repeat([1, L, 1]) of the latent projector (projectors/w_projector.py:117: one optimised row, num_ws identical style inputs) as a
+    stride-0 view: no copy forward.  Backward: the style bank, which reads such a view through its single row, delivers the whole gradient in
+    row 0 of a zero-filled [N,L,D] tensor and says so (`_eg3d_row0_total`) -- row 0 is returned; any other gradient is summed over the rows."""
+
+    @staticmethod
+    def forward(ctx, w, L_):
+        ctx.L = int(L_)
+        return w.expand(-1, ctx.L, -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        if getattr(g, '_eg3d_row0_total', False):
+            return g[:, :1, :], None
+        return g.sum(1, keepdim=True), None
+
+
+def broadcast_rows(w: torch.Tensor, L_: int) -> torch.Tensor:
+    """[N,1,D] -> [N,L,D] (see BroadcastRowsFn)."""
+    return BroadcastRowsFn.apply(w, int(L_))
+
+
 class StyleBankFn(torch.autograd.Function):
     """Styles -- and, for the conv layers, demodulation coefficients -- of all modulated layers of a network from two launches
     (eg3d_style_affine_fwd/_bwd).  apply(ws, plan, *weights_and_biases) -> tuple: the L styles [N, C_l], then one d [N, Co_l] per
@@ -668,6 +691,11 @@ class StyleBankFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ws, plan, *params):
         L.require_cuda(ws)
+        # one row broadcast over the style inputs (broadcast_rows): read in place through that row, every layer's row index 0
+        ctx.bcast = None
+        if ws.dim() == 3 and ws.shape[0] == 1 and ws.shape[1] > 1 and ws.stride(1) == 0 and ws.stride(2) == 1 and ws.dtype == torch.float32:
+            ctx.bcast = tuple(ws.shape)
+            ws = ws[:, :1, :]
         ws = ws.contiguous().float()
         N = ws.shape[0]
         layers, wsqs, pi = [], [], 0
@@ -675,7 +703,7 @@ class StyleBankFn(torch.autograd.Function):
             w = params[pi].detach().contiguous().float()
             b = params[pi + 1].detach().contiguous().float() if has_bias else None
             pi += 2 if has_bias else 1
-            layers.append((w, b, wrow, wgain, bgain, post))
+            layers.append((w, b, 0 if ctx.bcast is not None else wrow, wgain, bgain, post))
             wsqs.append(wsq)
         outs = tuple(torch.empty((N, ly[0].shape[0]), device=ws.device) for ly in layers)
         ds = [torch.empty((N, q.shape[0]), device=ws.device) if q is not None else None for q in wsqs]
@@ -702,7 +730,8 @@ class StyleBankFn(torch.autograd.Function):
         if not (ctx.needs_input_grad[0] or any_w):
             return (None, None) + (None,) * (pi - 2)
         if ctx.needs_input_grad[0]:
-            dws = H.zeros(ctx.ws.shape, dev)
+            # (a broadcast row: the whole gradient lands in row 0 of the zero-filled [1,L,D] tensor -- BroadcastRowsFn takes it from there)
+            dws = H.zeros(ctx.ws.shape if ctx.bcast is None else ctx.bcast, dev)
         douts = [g.contiguous().float() if g is not None else None for g in grads[:nl]]
         dds = [g.contiguous().float() if g is not None else None for g in grads[nl:]]
         demod, di = [], 0
@@ -723,6 +752,8 @@ class StyleBankFn(torch.autograd.Function):
             pg.append(w_)
             if ly[1] is not None:
                 pg.append(b_)
+        if dws is not None and ctx.bcast is not None:
+            dws._eg3d_row0_total = True
         return (dws, None) + tuple(pg)
 
 
@@ -789,18 +820,28 @@ class ToRGBFn(torch.autograd.Function):
         cls = H.classes_corr(Hh, Ww, 1, 1, 0)
         y = None
         up_taps = None
+        lazy_up = False          # clamped layer (its backward needs y itself): out = upsample2d(skip) + y in ONE pass once y exists (eg3d_upfirdn2d_nhwc_add)
         if skip is not None:
             skip = H.to_cl(skip.float())
             assert skip.shape[1] == Cp
             if skip_up:
                 if FUSE_SKIP_UP and clampv < 0 and Hh % 2 == 0 and Ww % 2 == 0 and tuple(skip.shape[2:]) == (Hh // 2, Ww // 2) and (N == 1 or (Hh * Ww) % 128 == 0):
                     up_taps = (0.25, 0.75, 0.75, 0.25)          # [1,3,3,1] / 8, times the per-axis gain 2
+                elif FUSE_SKIP_ADD and clampv >= 0 and tuple(skip.shape) == (N, Cp, Hh // 2, Ww // 2) and Hh % 2 == 0 and Ww % 2 == 0:
+                    lazy_up = True
                 else:
                     skip = H.upfirdn2d_nhwc(skip, fir44(skip.device), up=2, pad=(2, 1, 2, 1), gain=4.0)
+
+        def add_skip(y_):
+            if skip is None:
+                return y_
+            if lazy_up:
+                return H.upfirdn2d_nhwc(skip, fir44(skip.device), up=2, pad=(2, 1, 2, 1), gain=4.0, addend=y_)
+            return y_ + skip
         # small pixel counts (the 4^2 .. 64^2 blocks): the implicit GEMM's 32-step contraction is all latency there (~21 us for 64 pixels);
         # csrc/torgb_small.hip does the same arithmetic (exact fp32 products) in one short launch
         small = (H.TORGB_SMALL and (N * Hh * Ww <= H.TORGB_SMALL_MAX_PIX or (H.TORGB_MID and pend is None)) and Ci % 8 == 0 and Cp % 32 == 0 and wf.stride(1) == 1
-                 and (skip is None or up_taps is not None or tuple(skip.shape) == (N, Cp, Hh, Ww)))
+                 and (skip is None or up_taps is not None or lazy_up or tuple(skip.shape) == (N, Cp, Hh, Ww)))
         if pend is not None and not small:
             pend.run()
             pend = None
@@ -820,7 +861,7 @@ class ToRGBFn(torch.autograd.Function):
                 pend.run()
             pend = None
             if small:
-                out = y + skip if skip is not None else y
+                out = add_skip(y)
         if small:
             pass
         elif clampv < 0 and skip is not None:
@@ -843,7 +884,7 @@ class ToRGBFn(torch.autograd.Function):
                 y = H.empty_cl(N, Cp, Hh, Ww, x.device)
                 H.conv_igemm(x, wf, Ci, Cp, y, cls, in_scale=styles, epi=L.EPI_FWD, bias=b, act='linear', gain=1.0, clamp=clampv,
                              precision=_igemm_precision())
-            out = y + skip if skip is not None else y
+            out = add_skip(y)
         ctx.save_for_backward(x, weight, styles, y if clampv >= 0 else None)
         ctx.cfg = (clampv, cache, want_wgrad, Cp, skip is not None, bool(skip_up))
         ctx.fuse_input = bool(input_is_layer_output)         # x is conv1's output handed over directly (see ModConvLayerFn)
@@ -949,28 +990,38 @@ class ToRGBFn(torch.autograd.Function):
 
 class _SliceRgb4Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, res):
+    def forward(ctx, feat, res, share):
         L.require_cuda(feat)
         feat = feat.contiguous().float()
         n, r, c = feat.shape
         y = torch.empty((n, res, res, 4), device=feat.device)
         L.check(L.lib().eg3d_slice_rgb4_fwd(feat.data_ptr(), y.data_ptr(), n * r, c, L.stream_ptr()), 'slice_rgb4_fwd')
         ctx.shape = (n, r, c)
+        if share:           # the feature image's other consumer (the SR head) reads it through THIS node: both gradients arrive in one backward call
+            return y.permute(0, 3, 1, 2), feat.view_as(feat)
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_feat=None):
         n, r, c = ctx.shape
+        dev = (g if g is not None else g_feat).device
+        if g is None:
+            return g_feat, None, None
         g = H.to_cl(g.float())
-        dx = torch.empty((n, r, c), device=g.device)
-        L.check(L.lib().eg3d_slice_rgb4_bwd(g.data_ptr(), dx.data_ptr(), n * r, c, L.stream_ptr()), 'slice_rgb4_bwd')
-        return dx, None
+        dx = torch.empty((n, r, c), device=dev)
+        if g_feat is not None:      # dx = g_feat + (g.xyz, 0, ...) in one pass (eg3d_slice_rgb4_bwd_add) instead of a scatter pass and autograd's add
+            g_feat = g_feat.contiguous().float()
+            L.check(L.lib().eg3d_slice_rgb4_bwd_add(g.data_ptr(), g_feat.data_ptr(), dx.data_ptr(), n * r, c, L.stream_ptr()), 'slice_rgb4_bwd_add')
+        else:
+            L.check(L.lib().eg3d_slice_rgb4_bwd(g.data_ptr(), dx.data_ptr(), n * r, c, L.stream_ptr()), 'slice_rgb4_bwd')
+        return dx, None, None
 
 
-def slice_rgb4(feat: torch.Tensor, res: int) -> torch.Tensor:
+def slice_rgb4(feat: torch.Tensor, res: int, share: bool = False):
     """[N, res*res, C] rendered features -> the raw RGB image [N,4,res,res] channels_last with 4-float pixels (features[:, :3], channel 3 = 0;
-    triplane.py:84-85) in one launch per direction."""
-    return _SliceRgb4Fn.apply(feat, int(res))
+    triplane.py:84-85) in one launch per direction.  share=True: returns (image, features) where `features` is the input itself behind this
+    node -- a caller that hands it to the feature image's other consumer gets the two gradients summed inside the backward launch."""
+    return _SliceRgb4Fn.apply(feat, int(res), bool(share))
 
 
 class UpsampleImgFn(torch.autograd.Function):

@@ -236,7 +236,8 @@ def upfirdn2d_raw(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, fl
     return y
 
 
-def upfirdn2d_nhwc(x, f2d, up=1, down=1, pad=(0, 0, 0, 0), flip=False, gain=1.0, out=None, accumulate=False):
+def upfirdn2d_nhwc(x, f2d, up=1, down=1, pad=(0, 0, 0, 0), flip=False, gain=1.0, out=None, accumulate=False, addend=None):
+    """addend (fp32 channels_last, the output's shape): returns result + addend in the same pass (eg3d_upfirdn2d_nhwc_add)."""
     assert is_cl(x), 'upfirdn2d_nhwc expects an fp32 channels_last CUDA tensor'
     n, c, h, w = x.shape
     fh, fw = f2d.shape
@@ -246,6 +247,11 @@ def upfirdn2d_nhwc(x, f2d, up=1, down=1, pad=(0, 0, 0, 0), flip=False, gain=1.0,
     if out is None:
         out = empty_cl(n, c, oh, ow, x.device)
         accumulate = False
+    if addend is not None:
+        assert not accumulate and is_cl(addend) and tuple(addend.shape) == (n, c, oh, ow) and addend.dtype == torch.float32
+        L.check(L.lib().eg3d_upfirdn2d_nhwc_add(L.ptr(x), L.ptr(f2d), L.ptr(addend), L.ptr(out), n, c, h, w, fh, fw, up, down, px0, px1, py0, py1,
+                                                int(bool(flip)), float(gain), oh, ow, L.stream_ptr()), 'upfirdn2d_nhwc_add')
+        return out
     L.check(L.lib().eg3d_upfirdn2d_nhwc(L.ptr(x), L.ptr(f2d), L.ptr(out), n, c, h, w, fh, fw, up, down, px0, px1, py0, py1,
                                         int(bool(flip)), float(gain), oh, ow, int(bool(accumulate)), L.stream_ptr()), 'upfirdn2d_nhwc')
     return out

@@ -21,6 +21,7 @@ import torch
 import torch.nn.functional as F
 
 from . import hipops
+from . import fused as _fused
 from .torch_utils.ops import bias_act, conv2d_gradfix
 
 
@@ -353,6 +354,10 @@ def _area_resize(img: torch.Tensor, size: int) -> torch.Tensor:
     return F.interpolate(img, size=(size, size), mode='area')
 
 
+# w-space projection: ws as a stride-0 view of the optimised row (fused.BroadcastRowsFn) instead of w.repeat(...).  Not in the deterministic build: a
+# replayed G.synthesis (graphed.py) copies ws into a dense static buffer and sums d w per row and then over the rows, the eager call sums all layers into
+# one row -- two roundings of the same exact sums, and which steps replay depends on what ran before (two runs would differ by ~4e-7 in w)
+BROADCAST_WS = not hipops.L.DETERMINISTIC
 REG_BRANCH = False          # the noise regulariser on a second stream (a branch of the captured graph): measured -1.5 %
 
 
@@ -644,7 +649,10 @@ class LatentProjector:
         w = self.w_opt
         if wn is not None:          # w + wn * scale in one launch (scale: a device scalar under graph replay)
             w = torch.addcmul(w, wn, w_noise_scale) if torch.is_tensor(w_noise_scale) else torch.add(w, wn, alpha=float(w_noise_scale))
-        ws = w.repeat(1, self.num_ws, 1) if w.shape[1] == 1 else w
+        # (one optimised row: a stride-0 view that the style bank reads in place -- no repeat copy, no row sum in the backward: fused.BroadcastRowsFn.
+        #  Only of the step's own w + noise tensor: a view of the PARAMETER made inside a custom Function may not outlive the optimiser's in-place update.)
+        ws = ((_fused.broadcast_rows(w, self.num_ws) if (BROADCAST_WS and w.is_cuda and w.shape[0] == 1 and w is not self.w_opt) else w.repeat(1, self.num_ws, 1))
+              if w.shape[1] == 1 else w)
         if self._noise_inject is not None:
             kw = dict(kw, noise_inject=self._noise_inject)
         if self.use_graph and self._uni is not None and 'render_uniforms' not in kw:

@@ -20,6 +20,7 @@ from .volumetric_rendering.ray_sampler import RaySampler
 from .volumetric_rendering.renderer import ImportanceRenderer
 
 JOINT_STYLE_BANK = os.environ.get('EG3D_JOINT_STYLE_BANK', '1') != '0'   # SR head's style affines computed by the backbone's bank launch
+SHARE_FEATURE_NODE = True      # image_raw's 4-float copy and the SR head's input behind one autograd node (fused.slice_rgb4 share=True): their gradients summed in one launch
 
 _SR_MODULES = {'training.superresolution.SuperresolutionHybrid8XDC': SuperresolutionHybrid8XDC,
                'training.superresolution.SuperresolutionHybrid8X': SuperresolutionHybrid8X,
@@ -131,12 +132,14 @@ class TriPlaneGenerator(ReferenceStateMixin, torch.nn.Module):
             self.renderer.set_uniforms(*render_uniforms)
         feat, depth, _ = self.renderer(planes, self.decoder, origins, directions, self.rendering_kwargs)
         n = origins.shape[0]
-        features = feat.view(n, res, res, feat.shape[-1]).permute(0, 3, 1, 2)          # [N, H*W, 32] IS the channels_last image: zero-copy
         if feat.is_cuda and feat.shape[-1] % 4 == 0:      # 4-float pixels (channel 3 = 0) for the SR head's skip path and the fused loss kernels
-            raw4 = fused.slice_rgb4(feat, res)
+            raw4 = fused.slice_rgb4(feat, res, share=SHARE_FEATURE_NODE)
+            if SHARE_FEATURE_NODE:                        # the SR head reads the features behind the same node: one gradient pass for both
+                raw4, feat = raw4
             rgb = raw4[:, :3]                             # image_raw is a view of it
             rgb._eg3d_padded4 = raw4
-        else:
+        features = feat.view(n, res, res, feat.shape[-1]).permute(0, 3, 1, 2)          # [N, H*W, 32] IS the channels_last image: zero-copy
+        if not (feat.is_cuda and feat.shape[-1] % 4 == 0):
             rgb = features[:, :3].contiguous()
         image = self.superresolution(rgb, features, ws, noise_mode=self.rendering_kwargs['superresolution_noise_mode'], noise_inject=noise_inject,
                                      force_fp32=block_fp32, **({'_bank': bank_out['extra']} if 'extra' in bank_out else {}),

@@ -542,6 +542,12 @@ int eg3d_torgb_dgrad_act_split(const float* dy4, const float* wa4, const float* 
 int eg3d_upfirdn2d_nhwc(const float* x, const float* f, float* y, int N, int C, int inH, int inW, int fH, int fW,
                         int up, int down, int padx0, int padx1, int pady0, int pady1, int flip, float gain,
                         int outH, int outW, int accumulate, void* stream);
+/* ... and y = result + addend ([N, outH, outW, C] fp32, 16-byte aligned, not y itself; resampling forms only, i.e. not the plain 4x4 FIR): the skip
+ * image of a clamped toRGB layer, img = upsample2d(img) + y (training/networks_stylegan2.py:453-455), in one pass instead of an up-sampling
+ * pass and an element-wise add. */
+int eg3d_upfirdn2d_nhwc_add(const float* x, const float* f, const float* addend, float* y, int N, int C, int inH, int inW, int fH, int fW,
+                            int up, int down, int padx0, int padx1, int pady0, int pady1, int flip, float gain, int outH, int outW,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Style / demodulation helpers (training/networks_stylegan2.py:62-67,303,315,354):
@@ -940,6 +946,9 @@ int eg3d_tv_norm_bwd(const float* v, const float* g, float gscale, float* dv, in
  * x [P,C] (C % 4 == 0) -> y4 [P,4] = (x0, x1, x2, 0);  bwd: dx [P,C] = (dy4.xyz, 0, ..., 0) (overwritten). */
 int eg3d_slice_rgb4_fwd(const float* x, float* y4, int64_t P, int C, void* stream);
 int eg3d_slice_rgb4_bwd(const float* dy4, float* dx, int64_t P, int C, void* stream);
+/* ... bwd with the gradient of the feature image's OTHER consumer (the SR head's input, triplane.py:87-88) added in the same pass:
+ * dx = addend + (dy4.xyz, 0, ..., 0); addend [P,C], may be dx itself. */
+int eg3d_slice_rgb4_bwd_add(const float* dy4, const float* addend, float* dx, int64_t P, int C, void* stream);
 
 /* Depth-reprojection geometry of the warping loss (training/warping_loss.py:18-54 + LinePlaneCollision :58-72) per pixel:
  *   xyz = o + d * depth;  hit = intersection of the line (c, xyz - c) with the plane through P0 with normal -c;

@@ -306,6 +306,36 @@ def test_graph_full_weight_grads_golden(golden, arith):
     assert max(bulk.values()) <= (BULK_BOUND_F16X3 if arith == 'f16x3' else BULK_BOUND_F16X1), max(bulk.values())
 
 
+def test_broadcast_latent_row_equals_repeat():
+    """w-space projection (projectors/w_projector.py:117, ws = (w_opt + w_noise).repeat([1, num_ws, 1])): fused.broadcast_rows hands the style
+    bank a stride-0 view of the one row (no repeat copy; the bank's backward delivers d w in row 0, no row sum) -- same styles bit for bit,
+    d w equal to the repeat path's row sum up to the order of the atomically accumulated layer contributions."""
+    from inv3d_amd import fused
+    cfg, G = small_G()
+    g = torch.Generator().manual_seed(9)
+    w0 = torch.randn(1, 1, 32, generator=g).to(DEV)
+    c = t(O.synth_cameras(1, seed=11))
+    u1, u2 = O.make_uniforms(cfg, 1, seed=4)
+    uni = (u1.to(DEV), u2.to(DEV))
+    gi = None
+    res = []
+    for mode in ('repeat', 'broadcast'):
+        w = w0.clone().requires_grad_(True)
+        ws = w.repeat(1, G.backbone.num_ws, 1) if mode == 'repeat' else fused.broadcast_rows(w, G.backbone.num_ws)
+        o = G.synthesis(ws, c, noise_mode='const', render_uniforms=uni, force_fp32=True)
+        if gi is None:
+            gi = torch.randn(o['image'].shape, generator=g).to(DEV)
+        o['image'].backward(gi)
+        res.append((o['image'].detach(), o['image_raw'].detach(), w.grad.detach()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    close(res[1][2], res[0][2], 2e-5, 'd w through the broadcast row vs the repeat path')
+    # a consumer that is not the style bank gets a correct [N,L,D] gradient too (row sum fall-back)
+    w = w0.clone().requires_grad_(True)
+    ws = fused.broadcast_rows(w, 5)
+    (ws * torch.arange(5, device=DEV).view(1, 5, 1)).sum().backward()
+    close(w.grad, torch.full_like(w0, 10.0), 1e-6, 'broadcast rows: generic consumer')
+
+
 def test_cpu_tensors_fail_loudly():
     from inv3d_amd.torch_utils.ops import bias_act
     from inv3d_amd._lib import Eg3dHipError

@@ -243,6 +243,22 @@ def test_weighted_objective_and_rgb_slice_vs_aten():
     want = torch.zeros_like(feat)
     want.view(2, 16, 16, 32)[..., :3] = gy[:, :3].permute(0, 2, 3, 1)
     assert torch.equal(feat.grad, want)
+    # share=True: the feature image's other consumer (the SR head's input) reads it behind the same node -- both gradients in one backward
+    # pass (eg3d_slice_rgb4_bwd_add) instead of a scatter pass and autograd's add
+    feat2 = feat.detach().clone().requires_grad_(True)
+    y2, f2 = fused.slice_rgb4(feat2, 16, share=True)
+    assert torch.equal(y2, y) and torch.equal(f2, feat2) and f2.data_ptr() == feat2.data_ptr()
+    gf = torch.randn(feat.shape, generator=g).to(DEV)
+    torch.autograd.backward([y2, f2.view(2, 16, 16, 32).permute(0, 3, 1, 2)], [gy, gf.view(2, 16, 16, 32).permute(0, 3, 1, 2)])
+    assert torch.equal(feat2.grad, want + gf)
+    feat3 = feat.detach().clone().requires_grad_(True)        # ... and either output alone
+    y3, f3 = fused.slice_rgb4(feat3, 16, share=True)
+    y3.backward(gy)
+    assert torch.equal(feat3.grad, want)
+    feat3.grad = None
+    y3, f3 = fused.slice_rgb4(feat3, 16, share=True)
+    f3.backward(gf)
+    assert torch.equal(feat3.grad, gf)
 
 
 @pytest.mark.parametrize('n,res,upto', [(1, 256, 3), (2, 64, 3), (1, 32, 2), (1, 16, 1)])

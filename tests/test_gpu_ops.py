@@ -610,6 +610,24 @@ def test_render_feature_row_path_equals_gather_in_decoder(variant):
     close(c[3], b[3], 2e-6, 'd planes, fp16 three-product accumulation vs fp32')
 
 
+def test_upfirdn2d_nhwc_with_addend():
+    """img = upsample2d(img) + y of a clamped toRGB layer (networks_stylegan2.py:453-457) in one pass (eg3d_upfirdn2d_nhwc_add) against the
+    up-sampling pass followed by an add: the same multiply-adds in the same order, so bit-identical; refusals for the forms it does not cover."""
+    from inv3d_amd import hipops as H
+    from inv3d_amd._lib import Eg3dHipError
+    g = torch.Generator().manual_seed(3)
+    f = torch.tensor([1., 3., 3., 1.])
+    f2 = (f[:, None] * f[None, :] / 64).to(DEV)
+    for n, c, h, w in [(1, 4, 32, 32), (2, 8, 9, 7)]:
+        x = torch.randn(n, c, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+        a = torch.randn(n, c, 2 * h, 2 * w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+        sep = H.upfirdn2d_nhwc(x, f2, up=2, pad=(2, 1, 2, 1), gain=4.0) + a
+        one = H.upfirdn2d_nhwc(x, f2, up=2, pad=(2, 1, 2, 1), gain=4.0, addend=a)
+        assert torch.equal(one, sep)
+    with pytest.raises(Eg3dHipError):         # the plain 4 x 4 FIR form (2 x 2 outputs per thread) has no addend path
+        H.upfirdn2d_nhwc(x, f2, pad=(2, 1, 2, 1), addend=torch.zeros(2, 8, 9, 7, device=DEV).contiguous(memory_format=torch.channels_last))
+
+
 @pytest.mark.parametrize('variant', ['ffhq48', 'wide_range', 'ragged'])
 def test_decoder_weight_gradients_in_the_backward_kernel(variant):
     """Pivotal tuning's decoder-weight gradients (OSGDecoder, training/triplane.py:124-136; Adam over every weight, base_coach.py:96-99)
